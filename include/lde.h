@@ -1,0 +1,185 @@
+/*
+ * lde.h — C ABI of the MI355X-native latent-ODE solve + adjoint ("liblde").
+ *
+ * This is the drop-in boundary for ONE hot path of gabrevaya/LatentDiffEq.jl:
+ * what runs *under*
+ *
+ *     ẑ = diffeq_layer(decoder, l̂, t)            [REF src/models/LatentDiffEqModel.jl:107]
+ *
+ * i.e. the bodies of
+ *     diffeq_layer(::Decoder{<:GOKU},    (ẑ₀, θ̂), t)   [REF src/models/GOKU.jl:98-130]
+ *     diffeq_layer(::Decoder{LatentODE},  ẑ₀,      t)   [REF src/models/LatentODE.jl:61-78]
+ * and their reverse-mode pullbacks (in the reference these are delegated to the un-vendored
+ * OrdinaryDiffEq 6.27.1 / SciMLSensitivity 7.10.0 / DiffEqFlux 1.52.0, pinned in Manifest.toml).
+ *
+ * The reference has no FFI today (pure Julia multiple dispatch); the entry points below are what a
+ * `ccall` binding inside `diffeq_layer` + its `ChainRulesCore.rrule` would bind.
+ *
+ * Conventions
+ *  - plain C types only; every array is a raw pointer + sizes. No torch / HIP types in signatures:
+ *    a stream is passed as `void*` (a hipStream_t; NULL = the default stream).
+ *  - `z0`, `theta`, `z_out`, `dz_out`, `dz0`, `dtheta`, `dW`, `retcode` are DEVICE pointers
+ *    (caller-owned). `ts` and flat weights given to lde_set_weights are HOST pointers.
+ *  - array layouts are the reference's (Julia column-major):
+ *        z0     [D  × B]      element (d,b)   at d + D*b            [REF GOKU.jl:111  ẑ₀[:,i]]
+ *        theta  [P  × B]      element (p,b)   at p + P*b            [REF GOKU.jl:111  θ̂[:,i]]
+ *        z_out  [D' × B × T]  element (d,b,j) at d + D'*(b + B*j)   [REF GOKU.jl:125  permutedims(ẑ,[1,3,2])]
+ *    with D' = D + augment_dim                                      [REF LatentODE.jl:71]
+ *  - flat weight layout = Flux.destructure order: per Dense layer vec(W) (column-major [out×in])
+ *    followed by b                                                  [REF nODE.jl:12-14]
+ *  - all calls return 0 on success or a negative lde_status; they never abort/throw.
+ *    A trajectory whose solve fails (maxiters, dt<dtmin, non-finite) gets retcode!=0 and its
+ *    [D'×T] block filled with NaN — the call itself still returns 0  [REF GOKU.jl:114].
+ *  - a handle is not thread-safe; calls are asynchronous on the given stream.
+ */
+#ifndef LDE_H
+#define LDE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LDE_ABI_VERSION 1
+#define LDE_MAX_LAYERS 6          /* Dense layers in the RHS MLP */
+
+/* ---- enums (kept as plain ints inside the struct for a stable ABI) ---------------------- */
+
+/* Right-hand sides: the closed menu that replaces "any Julia function". */
+enum lde_rhs_kind {
+  LDE_RHS_PENDULUM          = 0,  /* du = [y, -G/L sin x], G=10, L=p[1]    [REF examples/pendulum_friction-less/pendulum.jl:19-26] */
+  LDE_RHS_PENDULUM_FRICTION = 1,  /* ... - (b/m) y, b=0.7, m=1             [REF pendulum.jl:65-74] */
+  LDE_RHS_MLP               = 2,  /* Chain(Dense(relu)...Dense)            [REF examples/pendulum_friction-less/nODE.jl:12-14] */
+  LDE_RHS_PENDULUM_PLUS_MLP = 3   /* pendulum(z,L) + MLP(z): BASELINE.json configs[2] */
+};
+
+enum lde_solver {
+  LDE_SOLVER_TSIT5 = 0,           /* Tsit5()  [REF pendulum.jl:11], [REF nODE.jl:15] */
+  LDE_SOLVER_RK4   = 1            /* RK4(), fixed step only (adaptive=0, dt=h) — BASELINE.json configs[1] */
+};
+
+enum lde_batching {
+  LDE_BATCH_PER_TRAJECTORY = 0,   /* B independent solves, own dt each: EnsembleProblem  [REF GOKU.jl:111-121] */
+  LDE_BATCH_COUPLED        = 1    /* one solve on the [D'×B] matrix state, shared dt, RMS norm over D'·B: NeuralODE [REF LatentODE.jl:70-72] */
+};
+
+enum lde_sensealg {
+  LDE_SENSE_BACKSOLVE_CHECKPOINTED = 0, /* reverse-time adjoint, z re-integrated backwards and reset to the saved ẑ(t_j) at every save time */
+  LDE_SENSE_BACKSOLVE              = 1  /* same without the reset (BacksolveAdjoint, hinted at [REF nODE.jl:17]) */
+};
+
+enum lde_activation { LDE_ACT_RELU = 0, LDE_ACT_TANH = 1 };
+
+enum lde_status {
+  LDE_OK               =  0,
+  LDE_ERR_INVALID_ARG  = -1,
+  LDE_ERR_UNSUPPORTED  = -2,
+  LDE_ERR_NO_DEVICE    = -3,
+  LDE_ERR_HIP          = -4,
+  LDE_ERR_NO_WEIGHTS   = -5,
+  LDE_ERR_ALLOC        = -6
+};
+
+/* per-trajectory return codes written to retcode[B] */
+enum lde_retcode {
+  LDE_RET_SUCCESS   = 0,
+  LDE_RET_MAXITERS  = 1,
+  LDE_RET_DTMIN     = 2,
+  LDE_RET_NONFINITE = 3
+};
+
+/* ---- problem description: the `diffeq` plug-in struct, flattened ------------------------- */
+/* mirrors Pendulum{prob,solver,sensealg,kwargs}   [REF pendulum.jl:4-46]
+ *     and NODE{dudt,solver,neural_model,latent_dim_in,latent_dim_out,augment_dim,kwargs} [REF nODE.jl:3-32];
+ * the option block mirrors the `kwargs...` splat into solve()  [REF GOKU.jl:121], [REF LatentODE.jl:70]. */
+typedef struct lde_problem_desc {
+  int32_t abi_version;            /* = LDE_ABI_VERSION */
+  int32_t rhs_kind;               /* lde_rhs_kind */
+  int32_t state_dim;              /* D  (latent_dim_in)  */
+  int32_t param_dim;              /* P  (per-trajectory ODE parameters θ̂; 1 for the pendulum, 0 for NODE) */
+  int32_t augment_dim;            /* extra zero-initialised state rows (AugmentedNDELayer) */
+  int32_t n_layers;               /* Dense layers of the RHS MLP (0 if none) */
+  int32_t layer_sizes[LDE_MAX_LAYERS + 1]; /* [in, h1, ..., out]; in = out = D + augment_dim */
+  int32_t activation;             /* hidden-layer activation (last layer is linear) */
+  int32_t solver;                 /* lde_solver */
+  int32_t batching;               /* lde_batching */
+  int32_t sensealg;               /* lde_sensealg */
+  int32_t adaptive;               /* 1 = error-controlled steps, 0 = fixed dt */
+  int64_t maxiters;               /* default 100000 */
+  double  dt;                     /* fixed step size (adaptive=0); 0 = automatic initial dt (adaptive=1) */
+  double  abstol;                 /* default 1e-6 (OrdinaryDiffEq default) */
+  double  reltol;                 /* default 1e-3 */
+  double  dtmin;                  /* default 0 → 1e-12·|tspan| is used */
+  double  qmin, qmax, gamma;      /* PI controller: 0.2, 10, 0.9 */
+  double  beta1, beta2;           /* 7/50, 2/25 (Tsit5) */
+} lde_problem_desc;
+
+typedef struct lde_stats {
+  int64_t nfe;                    /* RHS evaluations, summed over trajectories (coupled: of the matrix RHS) */
+  int64_t naccept;
+  int64_t nreject;
+  int64_t nfailed;                /* trajectories with retcode != 0 */
+  int64_t max_steps;              /* max over trajectories of accepted+rejected steps */
+} lde_stats;
+
+typedef struct lde_handle lde_handle;
+
+/* ---- entry points ------------------------------------------------------------------------ */
+
+/* library ABI version (= LDE_ABI_VERSION it was built with). */
+int lde_abi_version(void);
+
+/* Fill `desc` with the defaults `Pendulum()` would carry: Tsit5, per-trajectory, abstol 1e-6,
+ * reltol 1e-3, maxiters 1e5, PI controller constants  [REF pendulum.jl:11]. */
+int lde_problem_desc_default(lde_problem_desc* desc);
+
+/* Number of floats in the flat weight vector implied by desc (0 for analytic RHS). */
+int64_t lde_num_weights(const lde_problem_desc* desc);
+
+/* Create / destroy a solver handle for one `diffeq` struct on the current HIP device.
+ * Replaces the per-call `remake`/`EnsembleProblem`/`NeuralODE(...)` construction
+ * [REF GOKU.jl:111-118], [REF LatentODE.jl:70-71]. */
+int  lde_create(const lde_problem_desc* desc, lde_handle** out);
+void lde_destroy(lde_handle* h);
+
+/* Upload the RHS-MLP weights (HOST pointer, Flux.destructure order, n = lde_num_weights).
+ * Replaces `p, re = Flux.destructure(dudt)` on every call [REF LatentODE.jl:70 → DiffEqFlux NeuralODE]. */
+int lde_set_weights(lde_handle* h, const float* flat_host, int64_t n);
+/* Same from a DEVICE pointer (async copy on `stream`). */
+int lde_set_weights_device(lde_handle* h, const float* flat_dev, int64_t n, void* stream);
+
+/* Pre-size the handle's workspace for batches up to B and T save points (so that later
+ * lde_forward/lde_adjoint calls allocate nothing and can be captured in a hipGraph). */
+int lde_reserve(lde_handle* h, int B, int T);
+
+/* Forward solve: the body of diffeq_layer            [REF GOKU.jl:98-130], [REF LatentODE.jl:61-78].
+ *   z0    [D×B]  device, theta [P×B] device (NULL if P==0), ts[T] HOST, strictly increasing (f64),
+ *   z_out [D'×B×T] device (written), retcode[B] device int32 (written; may be NULL). */
+int lde_forward(lde_handle* h, const float* z0, const float* theta,
+                const double* ts, int T, int B,
+                float* z_out, int32_t* retcode, void* stream);
+
+/* Reverse-mode pullback of lde_forward (continuous adjoint with jumps at the save times).
+ *   z_out  [D'×B×T] device: the forward result (saved for backward),
+ *   dz_out [D'×B×T] device: incoming cotangent ∂L/∂ẑ,
+ *   dz0    [D×B]    device (written),
+ *   dtheta [P×B]    device (written; NULL if P==0),
+ *   dW     [n_weights] device, ACCUMULATED (+=) — caller zeroes it (NULL if no MLP). */
+int lde_adjoint(lde_handle* h, const float* z_out, const float* theta,
+                const double* ts, int T, int B,
+                const float* dz_out,
+                float* dz0, float* dtheta, float* dW, void* stream);
+
+/* Solver statistics of the most recent lde_forward (which=0) or lde_adjoint (which=1) on this
+ * handle. Synchronises `stream`. */
+int lde_get_stats(lde_handle* h, int which, lde_stats* out, void* stream);
+
+/* Human-readable text for the last error on this handle (never NULL). */
+const char* lde_last_error(const lde_handle* h);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LDE_H */

@@ -1,0 +1,829 @@
+/*
+ * lde_oracle.c — CPU restatement of the latent-ODE forward solve + adjoint.
+ *
+ * *** TEST INFRASTRUCTURE — NOT PRODUCT CODE. ***
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this library.
+ * The product path (latentdiffeq.jl_amd → liblde.so, HIP) never calls into it.
+ *
+ * *** PARITY UNPINNED against the reference's own tests ***
+ * The reference ships an empty test suite [REF test/runtests.jl:4-6], no golden vectors, and its
+ * arithmetic lives in un-vendored Julia packages (OrdinaryDiffEq 6.27.1 [REF Manifest.toml:979],
+ * SciMLSensitivity 7.10.0 [REF Manifest.toml:1200], DiffEqFlux 1.52.0 [REF Manifest.toml:304]);
+ * there is no Julia in the build image. This file restates the *published* algorithms those
+ * packages implement (Tsitouras 2011 5(4) pair with the free 4th-order interpolant; Hairer–Nørsett–
+ * Wanner initial step; PI step controller; classical RK4; continuous adjoint with jumps at the
+ * observation times) and is pinned instead by independent known-answer tests in tests/:
+ * order conditions of the tableau, the exact pendulum (Jacobi elliptic functions), scipy DOP853,
+ * scipy expm for linear RHS, float64 finite-difference gradients, torch autograd through RK4.
+ *
+ * What it follows in the reference (semantics, shapes, ordering):
+ *   - diffeq_layer, GOKU:      per-trajectory ensemble, column i ↦ trajectory i, saveat=t,
+ *                              NaN block on failure, [D×B×T] output   [REF src/models/GOKU.jl:98-130]
+ *   - diffeq_layer, LatentODE: one ODE on the [D'×B] matrix state, optional zero augmentation
+ *                                                                     [REF src/models/LatentODE.jl:61-78]
+ *   - pendulum RHS / friction  [REF examples/pendulum_friction-less/pendulum.jl:19-26, :65-74]
+ *   - NODE RHS MLP, Dense/relu, destructure order  [REF examples/pendulum_friction-less/nODE.jl:12-14]
+ *
+ * Build: see oracle/Makefile (compiled twice: REAL=float → liblde_oracle_f32.so,
+ *                                             REAL=double → liblde_oracle_f64.so).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+#include "../include/lde.h"
+
+#ifdef ORACLE_F64
+typedef double real;
+#define r_sin sin
+#define r_cos cos
+#define r_fabs fabs
+#define r_sqrt sqrt
+#define r_pow pow
+#define r_tanh tanh
+#define r_fmax fmax
+#define r_fmin fmin
+#else
+typedef float real;
+#define r_sin sinf
+#define r_cos cosf
+#define r_fabs fabsf
+#define r_sqrt sqrtf
+#define r_pow powf
+#define r_tanh tanhf
+#define r_fmax fmaxf
+#define r_fmin fminf
+#endif
+
+/* ------------------------------------------------------------------------------------------ */
+/* Tsit5 tableau (Tsitouras 2011) and its 4th-order continuous extension.                      */
+static const double TS_C[7] = {0.0, 0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0};
+static const double TS_A[7][6] = {
+    {0, 0, 0, 0, 0, 0},
+    {0.161, 0, 0, 0, 0, 0},
+    {-0.008480655492356989, 0.335480655492357, 0, 0, 0, 0},
+    {2.8971530571054935, -6.359448489975075, 4.3622954328695815, 0, 0, 0},
+    {5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525, 0, 0},
+    {5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383, 0},
+    {0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774}};
+static const double TS_BT[7] = {-0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995,
+                                -0.1447110071732629,     0.5823571654525552,     -0.45808210592918697,
+                                0.015151515151515152};
+/* b_1(Θ) = Θ(1 + Θ(r12 + Θ(r13 + Θ r14))) ; b_i(Θ) = Θ²(ri2 + Θ(ri3 + Θ ri4)), i=2..7 */
+static const double TS_R1[3] = {-2.763706197274826, 2.9132554618219126, -1.0530884977290216};
+static const double TS_R[6][3] = {{0.13169999999999998, -0.2234, 0.1017},
+                                  {3.9302962368947516, -5.941033872131505, 2.490627285651253},
+                                  {-12.411077166933676, 30.33818863028232, -16.548102889244902},
+                                  {37.50931341651104, -88.1789048947664, 47.37952196281928},
+                                  {-27.896526289197286, 65.09189467479366, -34.87065786149661},
+                                  {1.5, -4.0, 2.5}};
+
+static void tsit5_interp_weights(double th, double bw[7]) {
+  bw[0] = th * (1.0 + th * (TS_R1[0] + th * (TS_R1[1] + th * TS_R1[2])));
+  for (int i = 0; i < 6; i++) bw[i + 1] = th * th * (TS_R[i][0] + th * (TS_R[i][1] + th * TS_R[i][2]));
+}
+
+/* exported so the tests can check the order conditions of the constants compiled in here.
+ * out: c[7], a[7*6], btilde[7], r1[3], r[6*3]  (= 7+42+7+3+18 = 77 doubles) */
+void oracle_tsit5_tableau(double* out) {
+  int k = 0;
+  for (int i = 0; i < 7; i++) out[k++] = TS_C[i];
+  for (int i = 0; i < 7; i++)
+    for (int j = 0; j < 6; j++) out[k++] = TS_A[i][j];
+  for (int i = 0; i < 7; i++) out[k++] = TS_BT[i];
+  for (int i = 0; i < 3; i++) out[k++] = TS_R1[i];
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 3; j++) out[k++] = TS_R[i][j];
+}
+
+int oracle_real_size(void) { return (int)sizeof(real); }
+
+/* ------------------------------------------------------------------------------------------ */
+/* RHS for ONE column (one trajectory).                                                        */
+typedef struct {
+  const lde_problem_desc* d;
+  int Dp, P, nL;
+  const real* W;          /* flat weights, destructure order */
+  int64_t woff[LDE_MAX_LAYERS], boff[LDE_MAX_LAYERS];
+  real* act[LDE_MAX_LAYERS + 1]; /* act[0] = input copy, act[l+1] = output of layer l (post-activation) */
+  real* del[2];           /* backprop scratch */
+  real* dW_step;          /* [nW] contributions of the current step attempt (NULL if none) */
+  int64_t nW;
+} colrhs;
+
+static int64_t num_weights(const lde_problem_desc* d) {
+  int64_t n = 0;
+  for (int l = 0; l < d->n_layers; l++) n += (int64_t)d->layer_sizes[l + 1] * d->layer_sizes[l] + d->layer_sizes[l + 1];
+  return n;
+}
+int64_t oracle_num_weights(const lde_problem_desc* d) { return num_weights(d); }
+
+static int has_mlp(const lde_problem_desc* d) { return d->rhs_kind == LDE_RHS_MLP || d->rhs_kind == LDE_RHS_PENDULUM_PLUS_MLP; }
+static int has_pend(const lde_problem_desc* d) { return d->rhs_kind != LDE_RHS_MLP; }
+
+static int colrhs_init(colrhs* c, const lde_problem_desc* d, const real* W) {
+  memset(c, 0, sizeof(*c));
+  c->d = d;
+  c->Dp = d->state_dim + d->augment_dim;
+  c->P = d->param_dim;
+  c->nL = has_mlp(d) ? d->n_layers : 0;
+  c->W = W;
+  c->nW = has_mlp(d) ? num_weights(d) : 0;
+  int64_t off = 0;
+  int maxw = c->Dp;
+  for (int l = 0; l < c->nL; l++) {
+    c->woff[l] = off;
+    off += (int64_t)d->layer_sizes[l + 1] * d->layer_sizes[l];
+    c->boff[l] = off;
+    off += d->layer_sizes[l + 1];
+    if (d->layer_sizes[l + 1] > maxw) maxw = d->layer_sizes[l + 1];
+    if (d->layer_sizes[l] > maxw) maxw = d->layer_sizes[l];
+  }
+  for (int l = 0; l <= c->nL; l++) c->act[l] = (real*)calloc((size_t)maxw, sizeof(real));
+  c->del[0] = (real*)calloc((size_t)maxw, sizeof(real));
+  c->del[1] = (real*)calloc((size_t)maxw, sizeof(real));
+  if (c->nW) c->dW_step = (real*)calloc((size_t)c->nW, sizeof(real));
+  return 0;
+}
+static void colrhs_free(colrhs* c) {
+  for (int l = 0; l <= LDE_MAX_LAYERS; l++) free(c->act[l]);
+  free(c->del[0]);
+  free(c->del[1]);
+  free(c->dW_step);
+}
+
+static real act_fn(int kind, real x) { return kind == LDE_ACT_TANH ? r_tanh(x) : (x > 0 ? x : (real)0); }
+/* derivative expressed through the post-activation value a */
+static real act_grad(int kind, real a) { return kind == LDE_ACT_TANH ? (real)1 - a * a : (a > 0 ? (real)1 : (real)0); }
+
+static void mlp_forward(colrhs* c, const real* z) {
+  const lde_problem_desc* d = c->d;
+  for (int i = 0; i < d->layer_sizes[0]; i++) c->act[0][i] = z[i];
+  for (int l = 0; l < c->nL; l++) {
+    int in = d->layer_sizes[l], out = d->layer_sizes[l + 1];
+    const real* Wl = c->W + c->woff[l]; /* col-major [out×in]: W(o,i) at o + out*i */
+    const real* bl = c->W + c->boff[l];
+    real* y = c->act[l + 1];
+    for (int o = 0; o < out; o++) y[o] = bl[o];
+    for (int i = 0; i < in; i++) {
+      real xi = c->act[l][i];
+      const real* col = Wl + (int64_t)out * i;
+      for (int o = 0; o < out; o++) y[o] += col[o] * xi;
+    }
+    if (l < c->nL - 1)
+      for (int o = 0; o < out; o++) y[o] = act_fn(d->activation, y[o]);
+  }
+}
+
+/* f(z, θ) for one column */
+static void rhs_col(colrhs* c, const real* z, const real* th, real* out) {
+  const lde_problem_desc* d = c->d;
+  for (int i = 0; i < c->Dp; i++) out[i] = 0;
+  if (c->nL) {
+    mlp_forward(c, z);
+    for (int i = 0; i < c->Dp; i++) out[i] = c->act[c->nL][i];
+  }
+  if (has_pend(d)) {
+    const real G = (real)10;
+    real L = th[0];
+    out[0] += z[1];
+    real acc = (-G / L) * r_sin(z[0]);
+    if (d->rhs_kind == LDE_RHS_PENDULUM_FRICTION) acc -= ((real)0.7 / (real)1) * z[1];
+    out[1] += acc;
+  }
+}
+
+/* f, (∂f/∂z)ᵀλ, (∂f/∂θ)ᵀλ for one column, and dW_step += wq·(∂f/∂W)ᵀλ  (wq==0 → skipped) */
+static void rhs_vjp_col(colrhs* c, const real* z, const real* th, const real* lam, real* f, real* vz, real* vth,
+                        real wq) {
+  const lde_problem_desc* d = c->d;
+  for (int i = 0; i < c->Dp; i++) {
+    f[i] = 0;
+    vz[i] = 0;
+  }
+  for (int p = 0; p < c->P; p++) vth[p] = 0;
+  if (c->nL) {
+    mlp_forward(c, z);
+    for (int i = 0; i < c->Dp; i++) f[i] = c->act[c->nL][i];
+    real* dl = c->del[0];
+    real* dn = c->del[1];
+    for (int i = 0; i < c->Dp; i++) dl[i] = lam[i];
+    for (int l = c->nL - 1; l >= 0; l--) {
+      int in = d->layer_sizes[l], out = d->layer_sizes[l + 1];
+      const real* Wl = c->W + c->woff[l];
+      if (l < c->nL - 1)
+        for (int o = 0; o < out; o++) dl[o] *= act_grad(d->activation, c->act[l + 1][o]);
+      if (wq != 0 && c->dW_step) {
+        real* gW = c->dW_step + c->woff[l];
+        real* gb = c->dW_step + c->boff[l];
+        for (int i = 0; i < in; i++) {
+          real xi = wq * c->act[l][i];
+          real* col = gW + (int64_t)out * i;
+          for (int o = 0; o < out; o++) col[o] += dl[o] * xi;
+        }
+        for (int o = 0; o < out; o++) gb[o] += wq * dl[o];
+      }
+      for (int i = 0; i < in; i++) {
+        const real* col = Wl + (int64_t)out * i;
+        real s = 0;
+        for (int o = 0; o < out; o++) s += col[o] * dl[o];
+        dn[i] = s;
+      }
+      real* t = dl;
+      dl = dn;
+      dn = t;
+    }
+    for (int i = 0; i < c->Dp; i++) vz[i] = dl[i];
+  }
+  if (has_pend(d)) {
+    const real G = (real)10;
+    real L = th[0];
+    real s = r_sin(z[0]), co = r_cos(z[0]);
+    f[0] += z[1];
+    real acc = (-G / L) * s;
+    if (d->rhs_kind == LDE_RHS_PENDULUM_FRICTION) acc -= (real)0.7 * z[1];
+    f[1] += acc;
+    /* J = [[0,1],[-(G/L)cos x, -b/m]] ;  Jᵀλ = [-(G/L)cos x·λ₂, λ₁ - (b/m)λ₂] */
+    vz[0] += (-G / L) * co * lam[1];
+    vz[1] += lam[0];
+    if (d->rhs_kind == LDE_RHS_PENDULUM_FRICTION) vz[1] -= (real)0.7 * lam[1];
+    /* ∂f₂/∂L = (G/L²) sin x */
+    vth[0] += (G / (L * L)) * s * lam[1];
+  }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Generic explicit RK drivers on an n-vector state.                                           */
+typedef void (*ode_fn)(void* ctx, double t, const real* y, real* dy, real wq);
+typedef void (*hook_fn)(void* ctx);
+
+typedef struct {
+  int adaptive, solver;
+  double dt_fixed, abstol, reltol, dtmin, qmin, qmax, gamma, beta1, beta2;
+  int64_t maxiters;
+} sopts;
+
+typedef struct {
+  int64_t nfe, nacc, nrej;
+  int retcode;
+} sstat;
+
+static void opts_from_desc(const lde_problem_desc* d, sopts* o, double t0, double t1) {
+  o->adaptive = d->adaptive;
+  o->solver = d->solver;
+  o->dt_fixed = d->dt;
+  o->abstol = d->abstol;
+  o->reltol = d->reltol;
+  o->dtmin = d->dtmin > 0 ? d->dtmin : 1e-12 * fabs(t1 - t0);
+  o->qmin = d->qmin;
+  o->qmax = d->qmax;
+  o->gamma = d->gamma;
+  o->beta1 = d->beta1;
+  o->beta2 = d->beta2;
+  o->maxiters = d->maxiters;
+}
+
+static int all_finite(const real* y, int64_t n) {
+  for (int64_t i = 0; i < n; i++)
+    if (!isfinite((double)y[i])) return 0;
+  return 1;
+}
+
+/* Hairer–Nørsett–Wanner initial step (order 5); f0 = f(t0,y0) given. sign = +1/-1 direction. */
+static double init_dt(ode_fn fn, void* ctx, int64_t n, double t0, const real* y0, const real* f0, double sign,
+                      double dtmax, const sopts* o, real* tmp, real* f1, sstat* st) {
+  real at = (real)o->abstol, rt = (real)o->reltol;
+  double s0 = 0, s1 = 0;
+  for (int64_t i = 0; i < n; i++) {
+    real sk = at + r_fabs(y0[i]) * rt;
+    real a = y0[i] / sk, b = f0[i] / sk;
+    s0 += (double)(a * a);
+    s1 += (double)(b * b);
+  }
+  double d0 = sqrt(s0 / (double)n), d1 = sqrt(s1 / (double)n);
+  double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+  if (dt0 > dtmax) dt0 = dtmax;
+  real h = (real)(sign * dt0);
+  for (int64_t i = 0; i < n; i++) tmp[i] = y0[i] + h * f0[i];
+  fn(ctx, t0 + sign * dt0, tmp, f1, 0);
+  st->nfe++;
+  double s2 = 0;
+  for (int64_t i = 0; i < n; i++) {
+    real sk = at + r_fabs(y0[i]) * rt;
+    real a = (f1[i] - f0[i]) / sk;
+    s2 += (double)(a * a);
+  }
+  double d2 = sqrt(s2 / (double)n) / dt0;
+  double dm = d1 > d2 ? d1 : d2;
+  double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : pow(10.0, -(2.0 + log10(dm)) / 5.0);
+  double dt = fmin(100.0 * dt0, dt1);
+  if (dt > dtmax) dt = dtmax;
+  return dt;
+}
+
+typedef struct {
+  int64_t n;
+  real *k[7], *ynew, *tmp;
+} rkwork;
+static void rkwork_init(rkwork* w, int64_t n) {
+  w->n = n;
+  for (int i = 0; i < 7; i++) w->k[i] = (real*)calloc((size_t)n, sizeof(real));
+  w->ynew = (real*)calloc((size_t)n, sizeof(real));
+  w->tmp = (real*)calloc((size_t)n, sizeof(real));
+}
+static void rkwork_free(rkwork* w) {
+  for (int i = 0; i < 7; i++) free(w->k[i]);
+  free(w->ynew);
+  free(w->tmp);
+}
+
+/* One Tsit5 attempt from (t,y) with signed step dt. k[0] must hold f(t,y) unless eval_k1.
+ * wscale: quadrature weight scale (|dt| for the backward pass, 0 for forward); stage i gets wscale*b_i. */
+static real tsit5_attempt(ode_fn fn, void* ctx, rkwork* w, double t, double dt, const real* y, int eval_k1,
+                          double wscale, const sopts* o, sstat* st) {
+  int64_t n = w->n;
+  real h = (real)dt;
+  if (eval_k1) {
+    fn(ctx, t, y, w->k[0], (real)(wscale * TS_A[6][0]));
+    st->nfe++;
+  }
+  for (int s = 1; s < 6; s++) {
+    for (int64_t i = 0; i < n; i++) {
+      real acc = (real)TS_A[s][0] * w->k[0][i];
+      for (int j = 1; j < s; j++) acc += (real)TS_A[s][j] * w->k[j][i];
+      w->tmp[i] = y[i] + h * acc;
+    }
+    fn(ctx, t + TS_C[s] * dt, w->tmp, w->k[s], (real)(wscale * TS_A[6][s]));
+    st->nfe++;
+  }
+  for (int64_t i = 0; i < n; i++) {
+    real acc = (real)TS_A[6][0] * w->k[0][i];
+    for (int j = 1; j < 6; j++) acc += (real)TS_A[6][j] * w->k[j][i];
+    w->ynew[i] = y[i] + h * acc;
+  }
+  fn(ctx, t + dt, w->ynew, w->k[6], 0);
+  st->nfe++;
+  if (!o->adaptive) return 0;
+  real at = (real)o->abstol, rt = (real)o->reltol;
+  double s2 = 0;
+  for (int64_t i = 0; i < n; i++) {
+    real e = (real)TS_BT[0] * w->k[0][i];
+    for (int j = 1; j < 7; j++) e += (real)TS_BT[j] * w->k[j][i];
+    e *= h;
+    real sk = at + r_fmax(r_fabs(y[i]), r_fabs(w->ynew[i])) * rt;
+    real r = e / sk;
+    s2 += (double)(r * r);
+  }
+  return (real)sqrt(s2 / (double)n);
+}
+
+/* classical RK4 step; k[0] = f(t,y) must be valid unless eval_k1. Leaves k[4] = f(t+dt, ynew) if want_fnew. */
+static void rk4_step(ode_fn fn, void* ctx, rkwork* w, double t, double dt, const real* y, int eval_k1, double wscale,
+                     int want_fnew, sstat* st) {
+  int64_t n = w->n;
+  real h = (real)dt, hh = (real)(0.5 * dt);
+  if (eval_k1) {
+    fn(ctx, t, y, w->k[0], (real)(wscale / 6.0));
+    st->nfe++;
+  }
+  for (int64_t i = 0; i < n; i++) w->tmp[i] = y[i] + hh * w->k[0][i];
+  fn(ctx, t + 0.5 * dt, w->tmp, w->k[1], (real)(wscale / 3.0));
+  for (int64_t i = 0; i < n; i++) w->tmp[i] = y[i] + hh * w->k[1][i];
+  fn(ctx, t + 0.5 * dt, w->tmp, w->k[2], (real)(wscale / 3.0));
+  for (int64_t i = 0; i < n; i++) w->tmp[i] = y[i] + h * w->k[2][i];
+  fn(ctx, t + dt, w->tmp, w->k[3], (real)(wscale / 6.0));
+  st->nfe += 3;
+  real h6 = (real)(dt / 6.0);
+  for (int64_t i = 0; i < n; i++)
+    w->ynew[i] = y[i] + h6 * (w->k[0][i] + (real)2 * (w->k[1][i] + w->k[2][i]) + w->k[3][i]);
+  if (want_fnew) {
+    fn(ctx, t + dt, w->ynew, w->k[4], 0);
+    st->nfe++;
+  }
+}
+
+/* PI controller (OrdinaryDiffEq PIController): returns q; *q11_out for the reject branch */
+static real pi_q(real EEst, real qold, const sopts* o, real* q11_out) {
+  real q;
+  if (EEst == 0) {
+    q = (real)(1.0 / o->qmax);
+    *q11_out = 0;
+  } else {
+    real q11 = r_pow(EEst, (real)o->beta1);
+    q = q11 / r_pow(qold, (real)o->beta2);
+    *q11_out = q11;
+    q = r_fmax((real)(1.0 / o->qmax), r_fmin((real)(1.0 / o->qmin), q / (real)o->gamma));
+  }
+  return q;
+}
+
+/* Forward solve with saveat: out[j*n + i] = y_i(ts[j]). dt_trace (optional): accepted dt's. */
+static void solve_forward(ode_fn fn, void* ctx, int64_t n, const real* y0, const double* ts, int T, const sopts* o,
+                          real* out, sstat* st, double* dt_trace, int* n_trace, int max_trace) {
+  rkwork w;
+  rkwork_init(&w, n);
+  real* y = (real*)malloc((size_t)n * sizeof(real));
+  memcpy(y, y0, (size_t)n * sizeof(real));
+  memcpy(out, y0, (size_t)n * sizeof(real));
+  st->retcode = LDE_RET_SUCCESS;
+  int ntr = 0;
+  if (T > 1) {
+    double t = ts[0], tend = ts[T - 1], dtmax = tend - t;
+    int j = 1;
+    fn(ctx, t, y, w.k[0], 0);
+    st->nfe++;
+    double dt;
+    if (o->adaptive)
+      dt = o->dt_fixed > 0 ? fmin(o->dt_fixed, dtmax) : init_dt(fn, ctx, n, t, y, w.k[0], 1.0, dtmax, o, w.tmp, w.k[1], st);
+    else
+      dt = o->dt_fixed;
+    real qold = (real)1e-4;
+    int64_t iters = 0;
+    while (t < tend) {
+      if (iters++ >= o->maxiters) { st->retcode = LDE_RET_MAXITERS; break; }
+      double dtp = dt; /* controller proposal */
+      int last = 0;
+      if (t + dt >= tend - 1e-12 * fabs(tend)) { dt = tend - t; last = 1; }
+      real EEst = 0;
+      if (o->solver == LDE_SOLVER_TSIT5)
+        EEst = tsit5_attempt(fn, ctx, &w, t, dt, y, 0, 0.0, o, st);
+      else
+        rk4_step(fn, ctx, &w, t, dt, y, 0, 0.0, 1, st);
+      if (!all_finite(w.ynew, n) || !(EEst == EEst)) {
+        if (o->adaptive && dt > o->dtmin) { /* treat as a rejected step with maximal shrink */
+          st->nrej++;
+          dt = dt * o->qmin;
+          continue;
+        }
+        st->retcode = LDE_RET_NONFINITE;
+        break;
+      }
+      if (o->adaptive) {
+        real q11, q = pi_q(EEst, qold, o, &q11);
+        if (EEst > (real)1) {
+          st->nrej++;
+          dt = dt / (double)r_fmin((real)(1.0 / o->qmin), q11 / (real)o->gamma);
+          if (dt < o->dtmin) { st->retcode = LDE_RET_DTMIN; break; }
+          continue;
+        }
+        qold = r_fmax(EEst, (real)1e-4);
+        dtp = dt / (double)q;
+        if (dtp > dtmax) dtp = dtmax;
+      }
+      st->nacc++;
+      if (dt_trace && ntr < max_trace) dt_trace[ntr] = dt;
+      ntr++;
+      double tnew = last ? tend : t + dt;
+      while (j < T && ts[j] <= tnew) {
+        double th = (ts[j] - t) / dt;
+        real* o_j = out + (int64_t)j * n;
+        if (th >= 1.0 || (j == T - 1 && last)) {
+          memcpy(o_j, w.ynew, (size_t)n * sizeof(real));
+        } else if (o->solver == LDE_SOLVER_TSIT5) {
+          double bw[7];
+          tsit5_interp_weights(th, bw);
+          real h = (real)dt;
+          for (int64_t i = 0; i < n; i++) {
+            real acc = (real)bw[0] * w.k[0][i];
+            for (int s = 1; s < 7; s++) acc += (real)bw[s] * w.k[s][i];
+            o_j[i] = y[i] + h * acc;
+          }
+        } else { /* cubic Hermite between (y,k1) and (ynew,f(ynew)) */
+          double h00 = (1 + 2 * th) * (1 - th) * (1 - th), h10 = th * (1 - th) * (1 - th);
+          double h01 = th * th * (3 - 2 * th), h11 = th * th * (th - 1);
+          for (int64_t i = 0; i < n; i++)
+            o_j[i] = (real)h00 * y[i] + (real)(h10 * dt) * w.k[0][i] + (real)h01 * w.ynew[i] + (real)(h11 * dt) * w.k[4][i];
+        }
+        j++;
+      }
+      memcpy(y, w.ynew, (size_t)n * sizeof(real));
+      real* fs = (o->solver == LDE_SOLVER_TSIT5) ? w.k[6] : w.k[4];
+      real* t0 = w.k[0];
+      if (o->solver == LDE_SOLVER_TSIT5) { w.k[0] = fs; w.k[6] = t0; } else { w.k[0] = fs; w.k[4] = t0; }
+      t = tnew;
+      dt = o->adaptive ? dtp : o->dt_fixed;
+    }
+  }
+  if (st->retcode != LDE_RET_SUCCESS) {
+    for (int64_t i = 0; i < (int64_t)T * n; i++) out[i] = (real)NAN;
+  }
+  if (n_trace) *n_trace = ntr;
+  free(y);
+  rkwork_free(&w);
+}
+
+/* Backward solve from ts[T-1] to ts[0] with a forced stop + jump at every save time.
+ * y holds the state at ts[T-1] (first jump already applied). jump(ctx, j, y) is called on arrival at ts[j].
+ * begin/commit/discard bracket the dW quadrature of one step attempt. */
+typedef void (*jump_fn)(void* ctx, int j, real* y);
+static void solve_backward(ode_fn fn, void* ctx, int64_t n, real* y, const double* ts, int T, const sopts* o,
+                           jump_fn jump, hook_fn begin, hook_fn commit, sstat* st) {
+  rkwork w;
+  rkwork_init(&w, n);
+  st->retcode = LDE_RET_SUCCESS;
+  if (T > 1) {
+    double t = ts[T - 1], t0 = ts[0], dtmax = fabs(t - t0);
+    double dt; /* magnitude of the proposed step */
+    if (o->adaptive) {
+      if (o->dt_fixed > 0) dt = fmin(o->dt_fixed, dtmax);
+      else {
+        fn(ctx, t, y, w.k[0], 0);
+        st->nfe++;
+        dt = init_dt(fn, ctx, n, t, y, w.k[0], -1.0, dtmax, o, w.tmp, w.k[1], st);
+      }
+    } else
+      dt = o->dt_fixed;
+    real qold = (real)1e-4;
+    int64_t iters = 0;
+    int j = T - 2;
+    while (j >= 0) {
+      if (iters++ >= o->maxiters) { st->retcode = LDE_RET_MAXITERS; break; }
+      double tstop = ts[j];
+      double dist = t - tstop;
+      double h = dt;
+      int hit = 0;
+      if (h >= dist * (1.0 - 1e-12)) { h = dist; hit = 1; }
+      if (begin) begin(ctx);
+      real EEst = 0;
+      if (o->solver == LDE_SOLVER_TSIT5)
+        EEst = tsit5_attempt(fn, ctx, &w, t, -h, y, 1, h, o, st);
+      else
+        rk4_step(fn, ctx, &w, t, -h, y, 1, h, 0, st);
+      if (!all_finite(w.ynew, n) || !(EEst == EEst)) {
+        if (o->adaptive && h > o->dtmin) { st->nrej++; dt = h * o->qmin; continue; }
+        st->retcode = LDE_RET_NONFINITE;
+        break;
+      }
+      double dtp = dt;
+      if (o->adaptive) {
+        real q11, q = pi_q(EEst, qold, o, &q11);
+        if (EEst > (real)1) {
+          st->nrej++;
+          dt = h / (double)r_fmin((real)(1.0 / o->qmin), q11 / (real)o->gamma);
+          if (dt < o->dtmin) { st->retcode = LDE_RET_DTMIN; break; }
+          continue;
+        }
+        qold = r_fmax(EEst, (real)1e-4);
+        dtp = h / (double)q;
+        if (dtp > dtmax) dtp = dtmax;
+      }
+      st->nacc++;
+      if (commit) commit(ctx);
+      memcpy(y, w.ynew, (size_t)n * sizeof(real));
+      if (hit) {
+        t = tstop;
+        jump(ctx, j, y);
+        j--;
+      } else
+        t -= h;
+      dt = o->adaptive ? dtp : o->dt_fixed;
+    }
+  }
+  rkwork_free(&w);
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* Problem-level contexts: a block of `ncol` columns integrated as ONE ODE state                */
+/* (ncol = 1 → per-trajectory / EnsembleProblem semantics; ncol = B → coupled / NeuralODE).    */
+typedef struct {
+  colrhs c;
+  int ncol, Dp, P;
+  const real* theta;   /* [P × ncol] for this block */
+  /* backward only */
+  const real* zsave;   /* z_out base for this block: element (d,b,j) at d + Dp*(b + Bstride*j) */
+  const real* dzout;
+  int64_t Bstride;     /* full batch size B (stride between save times) */
+  int checkpoint;
+  double* dW_acc;      /* [nW] committed quadrature (double accumulation) */
+} blockctx;
+
+static void fwd_fn(void* vctx, double t, const real* y, real* dy, real wq) {
+  (void)t; (void)wq;
+  blockctx* b = (blockctx*)vctx;
+  for (int c = 0; c < b->ncol; c++) rhs_col(&b->c, y + (int64_t)c * b->Dp, b->theta + (int64_t)c * b->P, dy + (int64_t)c * b->Dp);
+}
+
+/* backward state layout: [ Z (Dp·ncol) | Λ (Dp·ncol) | Gθ (P·ncol) ] */
+static void bwd_fn(void* vctx, double t, const real* y, real* dy, real wq) {
+  (void)t;
+  blockctx* b = (blockctx*)vctx;
+  int64_t nz = (int64_t)b->Dp * b->ncol;
+  real vz[1024]; /* Dp <= 1024 (check_desc) */
+  real vth[16];
+  for (int c = 0; c < b->ncol; c++) {
+    const real* z = y + (int64_t)c * b->Dp;
+    const real* lam = y + nz + (int64_t)c * b->Dp;
+    real* fz = dy + (int64_t)c * b->Dp;
+    real* dl = dy + nz + (int64_t)c * b->Dp;
+    real* dg = dy + 2 * nz + (int64_t)c * b->P;
+    rhs_vjp_col(&b->c, z, b->theta + (int64_t)c * b->P, lam, fz, vz, vth, wq);
+    for (int i = 0; i < b->Dp; i++) dl[i] = -vz[i];
+    for (int p = 0; p < b->P; p++) dg[p] = -vth[p];
+  }
+}
+
+static void bwd_jump(void* vctx, int j, real* y) {
+  blockctx* b = (blockctx*)vctx;
+  int64_t nz = (int64_t)b->Dp * b->ncol;
+  for (int c = 0; c < b->ncol; c++)
+    for (int i = 0; i < b->Dp; i++) {
+      int64_t src = i + (int64_t)b->Dp * (c + b->Bstride * j);
+      y[nz + (int64_t)c * b->Dp + i] += b->dzout[src];
+      if (b->checkpoint) y[(int64_t)c * b->Dp + i] = b->zsave[src];
+    }
+}
+static void bwd_begin(void* vctx) {
+  blockctx* b = (blockctx*)vctx;
+  if (b->c.dW_step) memset(b->c.dW_step, 0, (size_t)b->c.nW * sizeof(real));
+}
+static void bwd_commit(void* vctx) {
+  blockctx* b = (blockctx*)vctx;
+  if (b->c.dW_step && b->dW_acc)
+    for (int64_t i = 0; i < b->c.nW; i++) b->dW_acc[i] += (double)b->c.dW_step[i];
+}
+
+static int check_desc(const lde_problem_desc* d) {
+  if (!d || d->abi_version != LDE_ABI_VERSION) return LDE_ERR_INVALID_ARG;
+  if (d->state_dim < 1 || d->param_dim < 0 || d->param_dim > 16 || d->augment_dim < 0) return LDE_ERR_INVALID_ARG;
+  if (d->state_dim + d->augment_dim > 1024) return LDE_ERR_INVALID_ARG;
+  if (has_pend(d) && (d->state_dim != 2 || d->param_dim != 1 || d->augment_dim != 0)) return LDE_ERR_INVALID_ARG;
+  if (has_mlp(d)) {
+    if (d->n_layers < 1 || d->n_layers > LDE_MAX_LAYERS) return LDE_ERR_INVALID_ARG;
+    int Dp = d->state_dim + d->augment_dim;
+    if (d->layer_sizes[0] != Dp || d->layer_sizes[d->n_layers] != Dp) return LDE_ERR_INVALID_ARG;
+  }
+  if (d->solver == LDE_SOLVER_RK4 && d->adaptive) return LDE_ERR_UNSUPPORTED;
+  if (!d->adaptive && !(d->dt > 0)) return LDE_ERR_INVALID_ARG;
+  return LDE_OK;
+}
+
+/* out layouts as in include/lde.h. stats: [nfe, naccept, nreject, nfailed, max_steps].
+ * dt_trace/n_trace: accepted step sizes of trajectory 0 (or of the coupled solve). */
+int oracle_forward(const lde_problem_desc* d, const real* W, const real* z0, const real* theta, const double* ts, int T,
+                   int B, real* z_out, int32_t* retcode, int64_t* stats, double* dt_trace, int* n_trace, int max_trace,
+                   int nthreads) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (T < 1 || B < 1) return LDE_ERR_INVALID_ARG;
+  const int D = d->state_dim, Dp = D + d->augment_dim, P = d->param_dim;
+  sopts o;
+  opts_from_desc(d, &o, ts[0], ts[T - 1]);
+  int64_t nfe = 0, nacc = 0, nrej = 0, nfail = 0, maxsteps = 0;
+  if (n_trace) *n_trace = 0;
+  if (d->batching == LDE_BATCH_COUPLED) {
+    blockctx b;
+    memset(&b, 0, sizeof(b));
+    colrhs_init(&b.c, d, W);
+    b.ncol = B; b.Dp = Dp; b.P = P; b.theta = theta;
+    int64_t n = (int64_t)Dp * B;
+    real* y0 = (real*)calloc((size_t)n, sizeof(real));
+    for (int c = 0; c < B; c++)
+      for (int i = 0; i < D; i++) y0[(int64_t)c * Dp + i] = z0[(int64_t)c * D + i];
+    sstat st = {0, 0, 0, 0};
+    /* out as [T][Dp*B] is exactly the [Dp × B × T] column-major layout */
+    solve_forward(fwd_fn, &b, n, y0, ts, T, &o, z_out, &st, dt_trace, n_trace, max_trace);
+    for (int c = 0; c < B; c++)
+      if (retcode) retcode[c] = st.retcode;
+    nfe = st.nfe; nacc = st.nacc; nrej = st.nrej; nfail = st.retcode ? B : 0; maxsteps = st.nacc + st.nrej;
+    free(y0);
+    colrhs_free(&b.c);
+  } else {
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel reduction(+ : nfe, nacc, nrej, nfail) reduction(max : maxsteps)
+    {
+      blockctx b;
+      memset(&b, 0, sizeof(b));
+      colrhs_init(&b.c, d, W);
+      b.ncol = 1; b.Dp = Dp; b.P = P;
+      real* y0 = (real*)calloc((size_t)Dp, sizeof(real));
+      real* out = (real*)calloc((size_t)Dp * T, sizeof(real));
+#pragma omp for schedule(static)
+      for (int c = 0; c < B; c++) {
+        for (int i = 0; i < Dp; i++) y0[i] = i < D ? z0[(int64_t)c * D + i] : (real)0;
+        b.theta = theta ? theta + (int64_t)c * P : NULL;
+        sstat st = {0, 0, 0, 0};
+        solve_forward(fwd_fn, &b, Dp, y0, ts, T, &o, out, &st, c == 0 ? dt_trace : NULL, c == 0 ? n_trace : NULL, max_trace);
+        for (int j = 0; j < T; j++)
+          for (int i = 0; i < Dp; i++) z_out[i + (int64_t)Dp * (c + (int64_t)B * j)] = out[(int64_t)j * Dp + i];
+        if (retcode) retcode[c] = st.retcode;
+        nfe += st.nfe; nacc += st.nacc; nrej += st.nrej; nfail += st.retcode ? 1 : 0;
+        if (st.nacc + st.nrej > maxsteps) maxsteps = st.nacc + st.nrej;
+      }
+      free(y0);
+      free(out);
+      colrhs_free(&b.c);
+    }
+  }
+  if (stats) { stats[0] = nfe; stats[1] = nacc; stats[2] = nrej; stats[3] = nfail; stats[4] = maxsteps; }
+  return LDE_OK;
+}
+
+/* dW is ACCUMULATED (+=), as in lde_adjoint. */
+int oracle_adjoint(const lde_problem_desc* d, const real* W, const real* z_out, const real* theta, const double* ts,
+                   int T, int B, const real* dz_out, real* dz0, real* dtheta, real* dW, int64_t* stats, int nthreads) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (T < 1 || B < 1) return LDE_ERR_INVALID_ARG;
+  const int D = d->state_dim, Dp = D + d->augment_dim, P = d->param_dim;
+  const int64_t nW = has_mlp(d) ? num_weights(d) : 0;
+  sopts o;
+  opts_from_desc(d, &o, ts[0], ts[T - 1]);
+  int64_t nfe = 0, nacc = 0, nrej = 0, nfail = 0, maxsteps = 0;
+  double* dW_tot = nW ? (double*)calloc((size_t)nW, sizeof(double)) : NULL;
+  const int ckpt = d->sensealg == LDE_SENSE_BACKSOLVE_CHECKPOINTED;
+  if (d->batching == LDE_BATCH_COUPLED) {
+    blockctx b;
+    memset(&b, 0, sizeof(b));
+    colrhs_init(&b.c, d, W);
+    b.ncol = B; b.Dp = Dp; b.P = P; b.theta = theta;
+    b.zsave = z_out; b.dzout = dz_out; b.Bstride = B; b.checkpoint = ckpt; b.dW_acc = dW_tot;
+    int64_t nz = (int64_t)Dp * B, n = 2 * nz + (int64_t)P * B;
+    real* y = (real*)calloc((size_t)n, sizeof(real));
+    int bad = 0;
+    for (int64_t i = 0; i < nz; i++) {
+      y[i] = z_out[i + nz * (T - 1)];
+      y[nz + i] = dz_out[i + nz * (T - 1)];
+      if (!isfinite((double)y[i])) bad = 1;
+    }
+    sstat st = {0, 0, 0, 0};
+    if (!bad) solve_backward(bwd_fn, &b, n, y, ts, T, &o, bwd_jump, bwd_begin, bwd_commit, &st);
+    for (int c = 0; c < B; c++) {
+      for (int i = 0; i < D; i++) dz0[(int64_t)c * D + i] = bad ? 0 : y[nz + (int64_t)c * Dp + i];
+      for (int p = 0; p < P; p++) dtheta[(int64_t)c * P + p] = bad ? 0 : y[2 * nz + (int64_t)c * P + p];
+    }
+    nfe = st.nfe; nacc = st.nacc; nrej = st.nrej; nfail = (bad || st.retcode) ? B : 0; maxsteps = st.nacc + st.nrej;
+    free(y);
+    colrhs_free(&b.c);
+  } else {
+#ifdef _OPENMP
+    if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel reduction(+ : nfe, nacc, nrej, nfail) reduction(max : maxsteps)
+    {
+      blockctx b;
+      memset(&b, 0, sizeof(b));
+      colrhs_init(&b.c, d, W);
+      b.ncol = 1; b.Dp = Dp; b.P = P; b.Bstride = B; b.checkpoint = ckpt;
+      b.dW_acc = nW ? (double*)calloc((size_t)nW, sizeof(double)) : NULL;
+      int n = 2 * Dp + P;
+      real* y = (real*)calloc((size_t)n, sizeof(real));
+#pragma omp for schedule(static)
+      for (int c = 0; c < B; c++) {
+        b.theta = theta ? theta + (int64_t)c * P : NULL;
+        b.zsave = z_out + (int64_t)Dp * c;
+        b.dzout = dz_out + (int64_t)Dp * c;
+        int bad = 0;
+        for (int i = 0; i < Dp; i++) {
+          int64_t src = i + (int64_t)Dp * ((int64_t)B * (T - 1));
+          y[i] = b.zsave[src];
+          y[Dp + i] = b.dzout[src];
+          if (!isfinite((double)y[i])) bad = 1;
+        }
+        for (int p = 0; p < P; p++) y[2 * Dp + p] = 0;
+        sstat st = {0, 0, 0, 0};
+        if (!bad) solve_backward(bwd_fn, &b, n, y, ts, T, &o, bwd_jump, bwd_begin, bwd_commit, &st);
+        if (st.retcode) bad = 1;
+        for (int i = 0; i < D; i++) dz0[(int64_t)c * D + i] = bad ? 0 : y[Dp + i];
+        for (int p = 0; p < P; p++) dtheta[(int64_t)c * P + p] = bad ? 0 : y[2 * Dp + p];
+        nfe += st.nfe; nacc += st.nacc; nrej += st.nrej; nfail += bad;
+        if (st.nacc + st.nrej > maxsteps) maxsteps = st.nacc + st.nrej;
+      }
+      if (nW) {
+#pragma omp critical
+        for (int64_t i = 0; i < nW; i++) dW_tot[i] += b.dW_acc[i];
+        free(b.dW_acc);
+      }
+      free(y);
+      colrhs_free(&b.c);
+    }
+  }
+  if (nW && dW)
+    for (int64_t i = 0; i < nW; i++) dW[i] += (real)dW_tot[i];
+  free(dW_tot);
+  if (stats) { stats[0] = nfe; stats[1] = nacc; stats[2] = nrej; stats[3] = nfail; stats[4] = maxsteps; }
+  return LDE_OK;
+}
+
+/* RHS and VJP of a single column, exported for unit tests of the RHS menu. */
+int oracle_rhs(const lde_problem_desc* d, const real* W, const real* z, const real* theta, real* out) {
+  colrhs c;
+  colrhs_init(&c, d, W);
+  rhs_col(&c, z, theta, out);
+  colrhs_free(&c);
+  return 0;
+}
+int oracle_rhs_vjp(const lde_problem_desc* d, const real* W, const real* z, const real* theta, const real* lam, real* f,
+                   real* vz, real* vth, real* dW) {
+  colrhs c;
+  colrhs_init(&c, d, W);
+  if (c.dW_step) memset(c.dW_step, 0, (size_t)c.nW * sizeof(real));
+  rhs_vjp_col(&c, z, theta, lam, f, vz, vth, (real)1);
+  if (dW && c.dW_step) memcpy(dW, c.dW_step, (size_t)c.nW * sizeof(real));
+  colrhs_free(&c);
+  return 0;
+}

@@ -1,0 +1,213 @@
+"""ctypes front-end of the CPU oracle (oracle/lde_oracle.c).
+
+*** TEST INFRASTRUCTURE — NOT PRODUCT CODE. ***  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg import this module; the product package never does.
+
+PARITY UNPINNED against the reference's own tests (it has none: [REF test/runtests.jl:4-6]); pinned by the
+independent known-answer tests in tests/test_oracle_kat.py instead. See the header of lde_oracle.c.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_BUILD = os.path.join(_HERE, "_build")
+
+LDE_MAX_LAYERS = 6
+RHS_PENDULUM, RHS_PENDULUM_FRICTION, RHS_MLP, RHS_PENDULUM_PLUS_MLP = 0, 1, 2, 3
+SOLVER_TSIT5, SOLVER_RK4 = 0, 1
+BATCH_PER_TRAJECTORY, BATCH_COUPLED = 0, 1
+SENSE_BACKSOLVE_CHECKPOINTED, SENSE_BACKSOLVE = 0, 1
+ACT_RELU, ACT_TANH = 0, 1
+
+
+class Desc(C.Structure):
+    """Mirror of lde_problem_desc (include/lde.h)."""
+
+    _fields_ = [
+        ("abi_version", C.c_int32),
+        ("rhs_kind", C.c_int32),
+        ("state_dim", C.c_int32),
+        ("param_dim", C.c_int32),
+        ("augment_dim", C.c_int32),
+        ("n_layers", C.c_int32),
+        ("layer_sizes", C.c_int32 * (LDE_MAX_LAYERS + 1)),
+        ("activation", C.c_int32),
+        ("solver", C.c_int32),
+        ("batching", C.c_int32),
+        ("sensealg", C.c_int32),
+        ("adaptive", C.c_int32),
+        ("maxiters", C.c_int64),
+        ("dt", C.c_double),
+        ("abstol", C.c_double),
+        ("reltol", C.c_double),
+        ("dtmin", C.c_double),
+        ("qmin", C.c_double),
+        ("qmax", C.c_double),
+        ("gamma", C.c_double),
+        ("beta1", C.c_double),
+        ("beta2", C.c_double),
+    ]
+
+
+def make_desc(rhs_kind=RHS_PENDULUM, state_dim=2, param_dim=1, augment_dim=0, layers=(), activation=ACT_RELU,
+              solver=SOLVER_TSIT5, batching=BATCH_PER_TRAJECTORY, sensealg=SENSE_BACKSOLVE_CHECKPOINTED,
+              adaptive=True, dt=0.0, abstol=1e-6, reltol=1e-3, maxiters=100000, dtmin=0.0,
+              qmin=0.2, qmax=10.0, gamma=0.9, beta1=7.0 / 50.0, beta2=2.0 / 25.0) -> Desc:
+    d = Desc()
+    d.abi_version = 1
+    d.rhs_kind, d.state_dim, d.param_dim, d.augment_dim = rhs_kind, state_dim, param_dim, augment_dim
+    layers = tuple(layers)
+    d.n_layers = max(len(layers) - 1, 0)
+    for i, s in enumerate(layers):
+        d.layer_sizes[i] = s
+    d.activation, d.solver, d.batching, d.sensealg = activation, solver, batching, sensealg
+    d.adaptive, d.maxiters, d.dt = int(adaptive), maxiters, dt
+    d.abstol, d.reltol, d.dtmin = abstol, reltol, dtmin
+    d.qmin, d.qmax, d.gamma, d.beta1, d.beta2 = qmin, qmax, gamma, beta1, beta2
+    return d
+
+
+def build(native: bool = False) -> None:
+    """Compile the oracle (gcc). Building the checker is not using it."""
+    targets = ["all"] + (["native"] if native else [])
+    subprocess.run(["make", "-s", "-C", _HERE] + targets, check=True)
+
+
+class Oracle:
+    """One precision of the oracle: Oracle('f32') or Oracle('f64')."""
+
+    def __init__(self, prec: str = "f32", native: bool = False):
+        assert prec in ("f32", "f64")
+        name = f"liblde_oracle_{prec}{'_native' if native else ''}.so"
+        path = os.path.join(_BUILD, name)
+        if not os.path.exists(path):
+            build(native=native)
+        self.lib = C.CDLL(path)
+        self.dtype = np.float32 if prec == "f32" else np.float64
+        assert self.lib.oracle_real_size() == np.dtype(self.dtype).itemsize
+        self.lib.oracle_num_weights.restype = C.c_int64
+
+    def _p(self, a):
+        return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+    def tableau(self):
+        out = np.zeros(77)
+        self.lib.oracle_tsit5_tableau(self._p(out))
+        c, a, bt, r1, r = out[:7], out[7:49].reshape(7, 6), out[49:56], out[56:59], out[59:].reshape(6, 3)
+        return c, a, bt, r1, r
+
+    def num_weights(self, d: Desc) -> int:
+        return int(self.lib.oracle_num_weights(C.byref(d)))
+
+    def forward(self, d: Desc, z0, theta, ts, W=None, nthreads=0, max_trace=4096):
+        """z0 [D,B] (Fortran order semantic: pass arrays shaped (B,D) C-order == [D×B] column-major).
+
+        To keep the layout explicit, all arrays here are numpy arrays whose *memory* is the reference's
+        column-major layout: z0.shape == (B, D), theta.shape == (B, P), z_out.shape == (T, B, D').
+        """
+        dt = self.dtype
+        z0 = np.ascontiguousarray(z0, dtype=dt)
+        B, D = z0.shape
+        assert D == d.state_dim
+        Dp = D + d.augment_dim
+        theta = None if theta is None else np.ascontiguousarray(theta, dtype=dt)
+        ts = np.ascontiguousarray(ts, dtype=np.float64)
+        T = ts.shape[0]
+        W = None if W is None else np.ascontiguousarray(W, dtype=dt)
+        z_out = np.zeros((T, B, Dp), dtype=dt)
+        ret = np.zeros(B, dtype=np.int32)
+        stats = np.zeros(5, dtype=np.int64)
+        trace = np.zeros(max_trace, dtype=np.float64)
+        ntr = C.c_int(0)
+        rc = self.lib.oracle_forward(C.byref(d), self._p(W), self._p(z0), self._p(theta), self._p(ts), T, B,
+                                     self._p(z_out), self._p(ret), self._p(stats), self._p(trace), C.byref(ntr),
+                                     max_trace, nthreads)
+        if rc != 0:
+            raise RuntimeError(f"oracle_forward failed: {rc}")
+        info = dict(nfe=int(stats[0]), naccept=int(stats[1]), nreject=int(stats[2]), nfailed=int(stats[3]),
+                    max_steps=int(stats[4]), dt_trace=trace[: min(ntr.value, max_trace)].copy())
+        return z_out, ret, info
+
+    def adjoint(self, d: Desc, z_out, theta, ts, dz_out, W=None, nthreads=0):
+        dt = self.dtype
+        z_out = np.ascontiguousarray(z_out, dtype=dt)
+        dz_out = np.ascontiguousarray(dz_out, dtype=dt)
+        T, B, Dp = z_out.shape
+        D, P = d.state_dim, d.param_dim
+        theta = None if theta is None else np.ascontiguousarray(theta, dtype=dt)
+        ts = np.ascontiguousarray(ts, dtype=np.float64)
+        W = None if W is None else np.ascontiguousarray(W, dtype=dt)
+        dz0 = np.zeros((B, D), dtype=dt)
+        dth = np.zeros((B, max(P, 1)), dtype=dt)
+        nW = self.num_weights(d) if d.rhs_kind in (RHS_MLP, RHS_PENDULUM_PLUS_MLP) else 0
+        dW = np.zeros(max(nW, 1), dtype=dt)
+        stats = np.zeros(5, dtype=np.int64)
+        rc = self.lib.oracle_adjoint(C.byref(d), self._p(W), self._p(z_out), self._p(theta), self._p(ts), T, B,
+                                     self._p(dz_out), self._p(dz0), self._p(dth), self._p(dW), self._p(stats),
+                                     nthreads)
+        if rc != 0:
+            raise RuntimeError(f"oracle_adjoint failed: {rc}")
+        info = dict(nfe=int(stats[0]), naccept=int(stats[1]), nreject=int(stats[2]), nfailed=int(stats[3]),
+                    max_steps=int(stats[4]))
+        return dz0, (dth[:, :P] if P else None), (dW[:nW] if nW else None), info
+
+    def rhs(self, d: Desc, z, theta, W=None):
+        dt = self.dtype
+        z = np.ascontiguousarray(z, dtype=dt)
+        out = np.zeros(d.state_dim + d.augment_dim, dtype=dt)
+        theta = None if theta is None else np.ascontiguousarray(theta, dtype=dt)
+        W = None if W is None else np.ascontiguousarray(W, dtype=dt)
+        self.lib.oracle_rhs(C.byref(d), self._p(W), self._p(z), self._p(theta), self._p(out))
+        return out
+
+    def rhs_vjp(self, d: Desc, z, theta, lam, W=None):
+        dt = self.dtype
+        Dp = d.state_dim + d.augment_dim
+        z = np.ascontiguousarray(z, dtype=dt)
+        lam = np.ascontiguousarray(lam, dtype=dt)
+        theta = None if theta is None else np.ascontiguousarray(theta, dtype=dt)
+        W = None if W is None else np.ascontiguousarray(W, dtype=dt)
+        nW = self.num_weights(d) if W is not None else 0
+        f, vz, vth, dW = np.zeros(Dp, dt), np.zeros(Dp, dt), np.zeros(max(d.param_dim, 1), dt), np.zeros(max(nW, 1), dt)
+        self.lib.oracle_rhs_vjp(C.byref(d), self._p(W), self._p(z), self._p(theta), self._p(lam), self._p(f),
+                                self._p(vz), self._p(vth), self._p(dW))
+        return f, vz, vth[: d.param_dim], dW[:nW]
+
+
+# ---------------------------------------------------------------------------------------------
+# synthetic inputs shared by tests, golden generation and bench
+def pendulum_inputs(B: int, seed: int = 1, dtype=np.float32):
+    """θ₀~U(±π/6), ω₀~U(±π/3), L~U(1,2)  [REF examples/pendulum_friction-less/create_data.jl:19-22]."""
+    rng = np.random.default_rng(seed)
+    z0 = np.stack([rng.uniform(-np.pi / 6, np.pi / 6, B), rng.uniform(-np.pi / 3, np.pi / 3, B)], axis=1)
+    L = rng.uniform(1.0, 2.0, (B, 1))
+    return z0.astype(dtype), L.astype(dtype)
+
+
+def time_grid(T: int = 50, dt: float = 0.05, t0: float = 0.0):
+    """t = range(0, step=0.05, length=50), Float64  [REF examples/pendulum_friction-less/model_train.jl:40,44,181]."""
+    return t0 + dt * np.arange(T, dtype=np.float64)
+
+
+def cotangent(T: int, B: int, Dp: int, seed: int = 2, dtype=np.float32):
+    rng = np.random.default_rng(seed)
+    return (rng.standard_normal((T, B, Dp)) / (B * T)).astype(dtype)
+
+
+def mlp_weights(layers, seed: int = 3, scale: float = 1.0, dtype=np.float32):
+    """Flat Flux.destructure-order weights, U(±1/√fan_in)·scale, biases U(±1/√fan_in)·scale."""
+    rng = np.random.default_rng(seed)
+    parts = []
+    for i in range(len(layers) - 1):
+        fan_in, out = layers[i], layers[i + 1]
+        bound = scale / np.sqrt(fan_in)
+        Wl = rng.uniform(-bound, bound, (out, fan_in))
+        bl = rng.uniform(-bound, bound, out)
+        parts.append(Wl.flatten(order="F"))  # vec(W), column-major [out×in]
+        parts.append(bl)
+    return np.concatenate(parts).astype(dtype)

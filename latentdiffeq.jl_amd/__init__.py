@@ -1,0 +1,24 @@
+"""latentdiffeq.jl_amd — MI355X-native latent-ODE forward solve + adjoint behind LatentDiffEq.jl's
+`diffeq_layer` API (and nothing else of the reference). Import as `latentdiffeq_amd`.
+
+Layout:
+  csrc/      HIP kernels (gfx950) + the C ABI of include/lde.h  → liblde.so
+  _lib.py    ctypes binding of liblde.so (no fallback: raises if the library is missing)
+  api.py     host-side mirror of the reference interface: Pendulum / Pendulum_friction / NODE,
+             GOKU_basic / LatentODE, Decoder, diffeq_layer, transform_after_diffeq
+  dist.py    one-process-per-GPU batch sharding + the single gradient all-reduce (RCCL / gloo)
+"""
+from .build import build_lib  # noqa: F401
+
+
+def __getattr__(name):  # lazy: importing the package must not need torch or the built library
+    import importlib
+
+    for mod in ("api", "dist"):
+        try:
+            m = importlib.import_module(f"{__name__}.{mod}")
+        except ModuleNotFoundError:
+            continue
+        if hasattr(m, name):
+            return getattr(m, name)
+    raise AttributeError(name)

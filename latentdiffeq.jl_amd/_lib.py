@@ -1,0 +1,98 @@
+"""ctypes binding of liblde.so — the only way the Python host code reaches the solver.
+
+There is deliberately NO fallback: if the HIP library is missing or fails to load, every entry point
+raises. (The CPU oracle under oracle/ is test infrastructure and is never imported from here.)
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "liblde.so")
+
+LDE_ABI_VERSION = 1
+LDE_MAX_LAYERS = 6
+
+RHS_PENDULUM, RHS_PENDULUM_FRICTION, RHS_MLP, RHS_PENDULUM_PLUS_MLP = 0, 1, 2, 3
+SOLVER_TSIT5, SOLVER_RK4 = 0, 1
+BATCH_PER_TRAJECTORY, BATCH_COUPLED = 0, 1
+SENSE_BACKSOLVE_CHECKPOINTED, SENSE_BACKSOLVE = 0, 1
+ACT_RELU, ACT_TANH = 0, 1
+
+STATUS = {0: "LDE_OK", -1: "LDE_ERR_INVALID_ARG", -2: "LDE_ERR_UNSUPPORTED", -3: "LDE_ERR_NO_DEVICE",
+          -4: "LDE_ERR_HIP", -5: "LDE_ERR_NO_WEIGHTS", -6: "LDE_ERR_ALLOC"}
+
+# every symbol include/lde.h declares
+EXPORTS = ["lde_abi_version", "lde_problem_desc_default", "lde_num_weights", "lde_create", "lde_destroy",
+           "lde_set_weights", "lde_set_weights_device", "lde_reserve", "lde_forward", "lde_adjoint",
+           "lde_get_stats", "lde_last_error"]
+
+
+class ProblemDesc(C.Structure):
+    """lde_problem_desc (include/lde.h)."""
+
+    _fields_ = [
+        ("abi_version", C.c_int32), ("rhs_kind", C.c_int32), ("state_dim", C.c_int32), ("param_dim", C.c_int32),
+        ("augment_dim", C.c_int32), ("n_layers", C.c_int32), ("layer_sizes", C.c_int32 * (LDE_MAX_LAYERS + 1)),
+        ("activation", C.c_int32), ("solver", C.c_int32), ("batching", C.c_int32), ("sensealg", C.c_int32),
+        ("adaptive", C.c_int32), ("maxiters", C.c_int64), ("dt", C.c_double), ("abstol", C.c_double),
+        ("reltol", C.c_double), ("dtmin", C.c_double), ("qmin", C.c_double), ("qmax", C.c_double),
+        ("gamma", C.c_double), ("beta1", C.c_double), ("beta2", C.c_double),
+    ]
+
+
+class Stats(C.Structure):
+    """lde_stats (include/lde.h)."""
+
+    _fields_ = [("nfe", C.c_int64), ("naccept", C.c_int64), ("nreject", C.c_int64), ("nfailed", C.c_int64),
+                ("max_steps", C.c_int64)]
+
+
+class LdeError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load():
+    """Load liblde.so (once). Raises if it is missing: there is no CPU path in the product."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LdeError(f"{LIB_PATH} not found — build it with `python latentdiffeq.jl_amd/build.py` "
+                       "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
+    lib.lde_abi_version.restype = i32
+    lib.lde_problem_desc_default.argtypes = [C.POINTER(ProblemDesc)]
+    lib.lde_num_weights.argtypes = [C.POINTER(ProblemDesc)]
+    lib.lde_num_weights.restype = i64
+    lib.lde_create.argtypes = [C.POINTER(ProblemDesc), C.POINTER(vp)]
+    lib.lde_destroy.argtypes = [vp]
+    lib.lde_destroy.restype = None
+    lib.lde_set_weights.argtypes = [vp, vp, i64]
+    lib.lde_set_weights_device.argtypes = [vp, vp, i64, vp]
+    lib.lde_reserve.argtypes = [vp, i32, i32]
+    lib.lde_forward.argtypes = [vp, vp, vp, C.POINTER(C.c_double), i32, i32, vp, vp, vp]
+    lib.lde_adjoint.argtypes = [vp, vp, vp, C.POINTER(C.c_double), i32, i32, vp, vp, vp, vp, vp]
+    lib.lde_get_stats.argtypes = [vp, i32, C.POINTER(Stats), vp]
+    lib.lde_last_error.argtypes = [vp]
+    lib.lde_last_error.restype = C.c_char_p
+    if lib.lde_abi_version() != LDE_ABI_VERSION:
+        raise LdeError("liblde.so ABI version mismatch — rebuild")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, handle=None, what: str = ""):
+    if rc == 0:
+        return
+    msg = STATUS.get(rc, str(rc))
+    if handle is not None and _lib is not None:
+        detail = _lib.lde_last_error(handle)
+        if detail:
+            msg += ": " + detail.decode()
+    raise LdeError(f"{what} failed: {msg}")

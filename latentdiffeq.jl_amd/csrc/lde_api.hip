@@ -1,0 +1,372 @@
+// lde_api.hip — host side of the C ABI declared in include/lde.h.
+//
+// Owns what the reference rebuilds on every call (remake / EnsembleProblem / NeuralODE +
+// Flux.destructure [REF src/models/GOKU.jl:111-118], [REF src/models/LatentODE.jl:70-71]):
+// the validated problem description, the device copy of the RHS-MLP weights, the device copy of the
+// save-time grid and the per-trajectory statistics workspace. No torch types, no allocation on the
+// hot path once lde_reserve() (or a first call of the same size) has run.
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "lde_device.h"
+
+namespace lde {
+int launch_pend_forward(int kind, int solver, const float* z0, const float* theta, const double* ts_dev, const KOpts& o,
+                        float* z_out, int32_t* retcode, int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret,
+                        hipStream_t stream);
+int launch_pend_adjoint(int kind, int solver, const float* z_out, const float* theta, const double* ts_dev,
+                        const KOpts& o, const float* dz_out, float* dz0, float* dtheta, int32_t* nfe, int32_t* nacc,
+                        int32_t* nrej, int32_t* ret, hipStream_t stream);
+struct MlpPlan;
+int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err);
+void mlp_plan_destroy(MlpPlan* p);
+int mlp_reserve(MlpPlan* p, int B, int T, std::string& err);
+int mlp_set_weights(MlpPlan* p, const float* W_dev, hipStream_t stream, std::string& err);
+int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* theta, const double* ts_dev,
+                const KOpts& o, float* z_out, int32_t* retcode, int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret,
+                hipStream_t stream, std::string& err);
+int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float* theta, const double* ts_dev,
+                const KOpts& o, const float* dz_out, float* dz0, float* dtheta, float* dW, int32_t* nfe, int32_t* nacc,
+                int32_t* nrej, int32_t* ret, hipStream_t stream, std::string& err);
+}  // namespace lde
+
+static constexpr int TS_RING = 8;
+
+struct lde_handle {
+  lde_problem_desc d;
+  int device = 0;
+  int64_t nW = 0;
+  float* W_dev = nullptr;
+  bool have_W = false;
+  lde::MlpPlan* mlp = nullptr;
+  // save-time grid cache
+  std::vector<double> ts_host;
+  double* ts_dev = nullptr;
+  int ts_cap = 0;
+  double* ts_pinned[TS_RING] = {};
+  hipEvent_t ts_ev[TS_RING] = {};
+  int ts_pin_cap = 0;
+  int ring = 0;
+  // per-trajectory statistics, [0]=forward, [1]=adjoint: nfe, nacc, nrej, ret
+  int32_t* st[2][4] = {};
+  int cap_B = 0;
+  int last_B[2] = {0, 0};
+  std::string err = "";
+};
+
+#define HIP_TRY(h, expr)                                                                   \
+  do {                                                                                     \
+    hipError_t e_ = (expr);                                                                \
+    if (e_ != hipSuccess) {                                                                \
+      (h)->err = std::string(#expr) + ": " + hipGetErrorString(e_);                        \
+      return LDE_ERR_HIP;                                                                  \
+    }                                                                                      \
+  } while (0)
+
+static bool has_mlp(const lde_problem_desc& d) {
+  return d.rhs_kind == LDE_RHS_MLP || d.rhs_kind == LDE_RHS_PENDULUM_PLUS_MLP;
+}
+static bool has_pend(const lde_problem_desc& d) { return d.rhs_kind != LDE_RHS_MLP; }
+
+static int validate(const lde_problem_desc* d, std::string* why) {
+  auto bad = [&](const char* m) {
+    if (why) *why = m;
+    return (int)LDE_ERR_INVALID_ARG;
+  };
+  if (!d) return bad("desc is NULL");
+  if (d->abi_version != LDE_ABI_VERSION) return bad("abi_version mismatch");
+  if (d->rhs_kind < 0 || d->rhs_kind > LDE_RHS_PENDULUM_PLUS_MLP) return bad("unknown rhs_kind");
+  if (d->state_dim < 1 || d->param_dim < 0 || d->augment_dim < 0) return bad("bad dims");
+  if (has_pend(*d) && (d->state_dim != 2 || d->param_dim != 1 || d->augment_dim != 0))
+    return bad("pendulum RHS needs state_dim=2, param_dim=1, augment_dim=0");
+  if (d->rhs_kind == LDE_RHS_MLP && d->param_dim != 0) return bad("MLP RHS takes no per-trajectory parameters");
+  if (has_mlp(*d)) {
+    if (d->n_layers < 1 || d->n_layers > LDE_MAX_LAYERS) return bad("n_layers out of range");
+    const int Dp = d->state_dim + d->augment_dim;
+    if (d->layer_sizes[0] != Dp || d->layer_sizes[d->n_layers] != Dp) return bad("MLP in/out must equal D+augment_dim");
+    for (int l = 0; l <= d->n_layers; l++)
+      if (d->layer_sizes[l] < 1) return bad("layer size < 1");
+    if (d->activation != LDE_ACT_RELU && d->activation != LDE_ACT_TANH) return bad("unknown activation");
+  }
+  if (d->solver != LDE_SOLVER_TSIT5 && d->solver != LDE_SOLVER_RK4) return bad("unknown solver");
+  if (d->batching != LDE_BATCH_PER_TRAJECTORY && d->batching != LDE_BATCH_COUPLED) return bad("unknown batching");
+  if (d->sensealg != LDE_SENSE_BACKSOLVE_CHECKPOINTED && d->sensealg != LDE_SENSE_BACKSOLVE) return bad("unknown sensealg");
+  if (d->solver == LDE_SOLVER_RK4 && d->adaptive) {
+    if (why) *why = "RK4 is fixed-step only here: pass adaptive=0, dt=h";
+    return LDE_ERR_UNSUPPORTED;
+  }
+  if (!d->adaptive && !(d->dt > 0)) return bad("adaptive=0 needs dt>0");
+  if (d->adaptive && (!(d->abstol > 0) || !(d->reltol > 0))) return bad("tolerances must be > 0");
+  if (d->maxiters < 1) return bad("maxiters < 1");
+  if (!(d->qmin > 0) || !(d->qmax > 0) || !(d->gamma > 0)) return bad("controller constants must be > 0");
+  return LDE_OK;
+}
+
+extern "C" {
+
+int lde_abi_version(void) { return LDE_ABI_VERSION; }
+
+int lde_problem_desc_default(lde_problem_desc* d) {
+  if (!d) return LDE_ERR_INVALID_ARG;
+  std::memset(d, 0, sizeof(*d));
+  d->abi_version = LDE_ABI_VERSION;
+  d->rhs_kind = LDE_RHS_PENDULUM;
+  d->state_dim = 2;
+  d->param_dim = 1;
+  d->solver = LDE_SOLVER_TSIT5;
+  d->batching = LDE_BATCH_PER_TRAJECTORY;
+  d->sensealg = LDE_SENSE_BACKSOLVE_CHECKPOINTED;
+  d->activation = LDE_ACT_RELU;
+  d->adaptive = 1;
+  d->maxiters = 100000;
+  d->abstol = 1e-6;
+  d->reltol = 1e-3;
+  d->qmin = 0.2;
+  d->qmax = 10.0;
+  d->gamma = 0.9;
+  d->beta1 = 7.0 / 50.0;
+  d->beta2 = 2.0 / 25.0;
+  return LDE_OK;
+}
+
+int64_t lde_num_weights(const lde_problem_desc* d) {
+  if (!d || !has_mlp(*d)) return 0;
+  int64_t n = 0;
+  for (int l = 0; l < d->n_layers && l < LDE_MAX_LAYERS; l++)
+    n += (int64_t)d->layer_sizes[l + 1] * d->layer_sizes[l] + d->layer_sizes[l + 1];
+  return n;
+}
+
+int lde_create(const lde_problem_desc* desc, lde_handle** out) {
+  if (!out) return LDE_ERR_INVALID_ARG;
+  *out = nullptr;
+  int rc = validate(desc, nullptr);
+  if (rc) return rc;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return LDE_ERR_NO_DEVICE;
+  lde_handle* h = new (std::nothrow) lde_handle();
+  if (!h) return LDE_ERR_ALLOC;
+  h->d = *desc;
+  if (hipGetDevice(&h->device) != hipSuccess) {
+    delete h;
+    return LDE_ERR_NO_DEVICE;
+  }
+  h->nW = lde_num_weights(desc);
+  if (h->nW) {
+    if (hipMalloc(&h->W_dev, (size_t)h->nW * sizeof(float)) != hipSuccess) {
+      delete h;
+      return LDE_ERR_ALLOC;
+    }
+    rc = lde::mlp_plan_create(h->d, &h->mlp, h->err);
+    if (rc) {
+      (void)hipFree(h->W_dev);
+      delete h;
+      return rc;
+    }
+  }
+  for (int i = 0; i < TS_RING; i++)
+    if (hipEventCreateWithFlags(&h->ts_ev[i], hipEventDisableTiming) != hipSuccess) {
+      lde_destroy(h);
+      return LDE_ERR_HIP;
+    }
+  *out = h;
+  return LDE_OK;
+}
+
+void lde_destroy(lde_handle* h) {
+  if (!h) return;
+  if (h->mlp) lde::mlp_plan_destroy(h->mlp);
+  if (h->W_dev) (void)hipFree(h->W_dev);
+  if (h->ts_dev) (void)hipFree(h->ts_dev);
+  for (int i = 0; i < TS_RING; i++) {
+    if (h->ts_pinned[i]) (void)hipHostFree(h->ts_pinned[i]);
+    if (h->ts_ev[i]) (void)hipEventDestroy(h->ts_ev[i]);
+  }
+  for (int w = 0; w < 2; w++)
+    for (int i = 0; i < 4; i++)
+      if (h->st[w][i]) (void)hipFree(h->st[w][i]);
+  delete h;
+}
+
+int lde_set_weights(lde_handle* h, const float* flat_host, int64_t n) {
+  if (!h) return LDE_ERR_INVALID_ARG;
+  if (n != h->nW || (n && !flat_host)) {
+    h->err = "lde_set_weights: wrong weight count";
+    return LDE_ERR_INVALID_ARG;
+  }
+  if (!n) return LDE_OK;
+  HIP_TRY(h, hipMemcpy(h->W_dev, flat_host, (size_t)n * sizeof(float), hipMemcpyHostToDevice));
+  h->have_W = true;
+  return lde::mlp_set_weights(h->mlp, h->W_dev, nullptr, h->err);
+}
+
+int lde_set_weights_device(lde_handle* h, const float* flat_dev, int64_t n, void* stream) {
+  if (!h) return LDE_ERR_INVALID_ARG;
+  if (n != h->nW || (n && !flat_dev)) {
+    h->err = "lde_set_weights_device: wrong weight count";
+    return LDE_ERR_INVALID_ARG;
+  }
+  if (!n) return LDE_OK;
+  HIP_TRY(h, hipMemcpyAsync(h->W_dev, flat_dev, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  h->have_W = true;
+  return lde::mlp_set_weights(h->mlp, h->W_dev, (hipStream_t)stream, h->err);
+}
+
+int lde_reserve(lde_handle* h, int B, int T) {
+  if (!h || B < 1 || T < 1) return LDE_ERR_INVALID_ARG;
+  if (B > h->cap_B) {
+    for (int w = 0; w < 2; w++)
+      for (int i = 0; i < 4; i++) {
+        if (h->st[w][i]) (void)hipFree(h->st[w][i]);
+        h->st[w][i] = nullptr;
+        HIP_TRY(h, hipMalloc(&h->st[w][i], (size_t)B * sizeof(int32_t)));
+      }
+    h->cap_B = B;
+  }
+  if (T > h->ts_cap) {
+    if (h->ts_dev) (void)hipFree(h->ts_dev);
+    h->ts_dev = nullptr;
+    HIP_TRY(h, hipMalloc(&h->ts_dev, (size_t)T * sizeof(double)));
+    h->ts_cap = T;
+    h->ts_host.clear();
+  }
+  if (T > h->ts_pin_cap) {
+    for (int i = 0; i < TS_RING; i++) {
+      if (h->ts_pinned[i]) (void)hipHostFree(h->ts_pinned[i]);
+      h->ts_pinned[i] = nullptr;
+      HIP_TRY(h, hipHostMalloc((void**)&h->ts_pinned[i], (size_t)T * sizeof(double), hipHostMallocDefault));
+    }
+    h->ts_pin_cap = T;
+  }
+  if (h->mlp) return lde::mlp_reserve(h->mlp, B, T, h->err);
+  return LDE_OK;
+}
+
+}  // extern "C"
+
+// Make the device copy of the save-time grid current (no-op when `ts` is unchanged since the last call).
+static int stage_ts(lde_handle* h, const double* ts, int T, hipStream_t stream) {
+  for (int j = 0; j < T; j++) {
+    if (!std::isfinite(ts[j]) || (j && !(ts[j] > ts[j - 1]))) {
+      h->err = "ts must be finite and strictly increasing";
+      return LDE_ERR_INVALID_ARG;
+    }
+  }
+  if ((int)h->ts_host.size() == T && std::memcmp(h->ts_host.data(), ts, (size_t)T * sizeof(double)) == 0) return LDE_OK;
+  const int slot = h->ring;
+  h->ring = (h->ring + 1) % TS_RING;
+  HIP_TRY(h, hipEventSynchronize(h->ts_ev[slot]));  // slot's previous copy has drained
+  std::memcpy(h->ts_pinned[slot], ts, (size_t)T * sizeof(double));
+  HIP_TRY(h, hipMemcpyAsync(h->ts_dev, h->ts_pinned[slot], (size_t)T * sizeof(double), hipMemcpyHostToDevice, stream));
+  HIP_TRY(h, hipEventRecord(h->ts_ev[slot], stream));
+  h->ts_host.assign(ts, ts + T);
+  return LDE_OK;
+}
+
+static lde::KOpts make_opts(const lde_problem_desc& d, const double* ts, int T, int B) {
+  lde::KOpts o;
+  o.abstol = (float)d.abstol;
+  o.reltol = (float)d.reltol;
+  o.beta1 = (float)d.beta1;
+  o.beta2 = (float)d.beta2;
+  o.inv_gamma = (float)(1.0 / d.gamma);
+  o.q_lo = (float)(1.0 / d.qmax);
+  o.q_hi = (float)(1.0 / d.qmin);
+  o.qmin = (float)d.qmin;
+  o.dtmin = d.dtmin > 0 ? d.dtmin : 1e-12 * std::fabs(ts[T - 1] - ts[0]);
+  o.dt_fixed = d.dt;
+  o.maxiters = d.maxiters;
+  o.adaptive = d.adaptive;
+  o.checkpoint = d.sensealg == LDE_SENSE_BACKSOLVE_CHECKPOINTED;
+  o.T = T;
+  o.B = B;
+  return o;
+}
+
+extern "C" {
+
+int lde_forward(lde_handle* h, const float* z0, const float* theta, const double* ts, int T, int B, float* z_out,
+                int32_t* retcode, void* stream_) {
+  if (!h) return LDE_ERR_INVALID_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!z0 || !ts || !z_out || T < 1 || B < 1 || (h->d.param_dim > 0 && !theta)) {
+    h->err = "lde_forward: NULL pointer or empty batch";
+    return LDE_ERR_INVALID_ARG;
+  }
+  if (h->nW && !h->have_W) {
+    h->err = "lde_forward: weights not set";
+    return LDE_ERR_NO_WEIGHTS;
+  }
+  int rc = lde_reserve(h, B, T);
+  if (rc) return rc;
+  rc = stage_ts(h, ts, T, stream);
+  if (rc) return rc;
+  const lde::KOpts o = make_opts(h->d, ts, T, B);
+  int32_t** st = h->st[0];
+  h->last_B[0] = B;
+  if (h->mlp)
+    return lde::mlp_forward(h->mlp, h->W_dev, z0, theta, h->ts_dev, o, z_out, retcode, st[0], st[1], st[2], st[3], stream, h->err);
+  rc = lde::launch_pend_forward(h->d.rhs_kind, h->d.solver, z0, theta, h->ts_dev, o, z_out, retcode, st[0], st[1], st[2],
+                                st[3], stream);
+  if (rc) h->err = "lde_forward: kernel launch failed";
+  return rc;
+}
+
+int lde_adjoint(lde_handle* h, const float* z_out, const float* theta, const double* ts, int T, int B,
+                const float* dz_out, float* dz0, float* dtheta, float* dW, void* stream_) {
+  if (!h) return LDE_ERR_INVALID_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!z_out || !ts || !dz_out || !dz0 || T < 1 || B < 1 || (h->d.param_dim > 0 && (!theta || !dtheta)) ||
+      (h->nW && !dW)) {
+    h->err = "lde_adjoint: NULL pointer or empty batch";
+    return LDE_ERR_INVALID_ARG;
+  }
+  if (h->nW && !h->have_W) {
+    h->err = "lde_adjoint: weights not set";
+    return LDE_ERR_NO_WEIGHTS;
+  }
+  int rc = lde_reserve(h, B, T);
+  if (rc) return rc;
+  rc = stage_ts(h, ts, T, stream);
+  if (rc) return rc;
+  const lde::KOpts o = make_opts(h->d, ts, T, B);
+  int32_t** st = h->st[1];
+  h->last_B[1] = B;
+  if (h->mlp)
+    return lde::mlp_adjoint(h->mlp, h->W_dev, z_out, theta, h->ts_dev, o, dz_out, dz0, dtheta, dW, st[0], st[1], st[2],
+                            st[3], stream, h->err);
+  rc = lde::launch_pend_adjoint(h->d.rhs_kind, h->d.solver, z_out, theta, h->ts_dev, o, dz_out, dz0, dtheta, st[0], st[1],
+                                st[2], st[3], stream);
+  if (rc) h->err = "lde_adjoint: kernel launch failed";
+  return rc;
+}
+
+int lde_get_stats(lde_handle* h, int which, lde_stats* out, void* stream_) {
+  if (!h || !out || which < 0 || which > 1) return LDE_ERR_INVALID_ARG;
+  std::memset(out, 0, sizeof(*out));
+  const int B = h->last_B[which];
+  if (B < 1) return LDE_OK;
+  HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream_));
+  std::vector<int32_t> buf((size_t)B * 4, 0);
+  for (int i = 0; i < 4; i++)
+    HIP_TRY(h, hipMemcpy(buf.data() + (size_t)i * B, h->st[which][i], (size_t)B * sizeof(int32_t), hipMemcpyDeviceToHost));
+  for (int b = 0; b < B; b++) {
+    out->nfe += buf[b];
+    out->naccept += buf[(size_t)B + b];
+    out->nreject += buf[(size_t)2 * B + b];
+    const int64_t steps = (int64_t)buf[(size_t)B + b] + buf[(size_t)2 * B + b];
+    if (steps > out->max_steps) out->max_steps = steps;
+    if (buf[(size_t)3 * B + b]) out->nfailed++;
+  }
+  return LDE_OK;
+}
+
+const char* lde_last_error(const lde_handle* h) { return h ? h->err.c_str() : "NULL handle"; }
+
+}  // extern "C"

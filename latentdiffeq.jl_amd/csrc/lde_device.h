@@ -1,0 +1,180 @@
+// lde_device.h — device-side building blocks shared by the gfx950 kernels of liblde.
+//
+// Everything here is per-lane register code: Tsit5 5(4) with the free 4th-order interpolant,
+// classical RK4, the Hairer–Nørsett–Wanner initial step and the PI step controller, i.e. the
+// pieces of OrdinaryDiffEq 6.27.1 [REF Manifest.toml:979] that run under
+//     solve(ens_prob, solver, EnsembleThreads(); saveat = t, kwargs...)   [REF src/models/GOKU.jl:121]
+// State and slopes are f32, time / dt are f64 (the reference's `t` is a Float64 range while the
+// state is Float32 [REF examples/pendulum_friction-less/model_train.jl:44, :181]).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lde.h"
+
+namespace lde {
+
+// Options handed to every kernel by value (mirrors the `kwargs...` splat into solve()).
+struct KOpts {
+  float abstol, reltol;
+  float beta1, beta2;
+  float inv_gamma;   // 1/γ
+  float q_lo;        // 1/qmax : lower clamp of q
+  float q_hi;        // 1/qmin : upper clamp of q
+  float qmin;
+  double dtmin;
+  double dt_fixed;   // fixed step (adaptive=0) or user initial dt (adaptive=1, >0)
+  long long maxiters;
+  int adaptive;
+  int checkpoint;    // adjoint: reset z to the saved ẑ(t_j) at every save time
+  int T, B;
+};
+
+// ---- Tsit5 tableau (Tsitouras 2011), f32 copies of the f64 constants ------------------------
+namespace ts5 {
+constexpr float A[7][6] = {
+    {0.f, 0.f, 0.f, 0.f, 0.f, 0.f},
+    {0.161f, 0.f, 0.f, 0.f, 0.f, 0.f},
+    {(float)-0.008480655492356989, (float)0.335480655492357, 0.f, 0.f, 0.f, 0.f},
+    {(float)2.8971530571054935, (float)-6.359448489975075, (float)4.3622954328695815, 0.f, 0.f, 0.f},
+    {(float)5.325864828439257, (float)-11.748883564062828, (float)7.4955393428898365, (float)-0.09249506636175525, 0.f, 0.f},
+    {(float)5.86145544294642, (float)-12.92096931784711, (float)8.159367898576159, (float)-0.071584973281401,
+     (float)-0.028269050394068383, 0.f},
+    {(float)0.09646076681806523, 0.01f, (float)0.4798896504144996, (float)1.379008574103742, (float)-3.290069515436081,
+     (float)2.324710524099774}};
+constexpr float BT[7] = {(float)-0.00178001105222577714, (float)-0.0008164344596567469, (float)0.007880878010261995,
+                         (float)-0.1447110071732629,     (float)0.5823571654525552,     (float)-0.45808210592918697,
+                         (float)0.015151515151515152};
+constexpr double C[7] = {0.0, 0.161, 0.327, 0.9, 0.9800255409045097, 1.0, 1.0};
+constexpr float R1[3] = {(float)-2.763706197274826, (float)2.9132554618219126, (float)-1.0530884977290216};
+constexpr float R[6][3] = {{(float)0.13169999999999998, -0.2234f, 0.1017f},
+                           {(float)3.9302962368947516, (float)-5.941033872131505, (float)2.490627285651253},
+                           {(float)-12.411077166933676, (float)30.33818863028232, (float)-16.548102889244902},
+                           {(float)37.50931341651104, (float)-88.1789048947664, (float)47.37952196281928},
+                           {(float)-27.896526289197286, (float)65.09189467479366, (float)-34.87065786149661},
+                           {1.5f, -4.0f, 2.5f}};
+}  // namespace ts5
+
+// weights of the continuous extension: u(t+Θh) = u + h Σ b_i(Θ) k_i
+__device__ __forceinline__ void tsit5_interp_weights(float th, float (&bw)[7]) {
+  bw[0] = th * (1.0f + th * (ts5::R1[0] + th * (ts5::R1[1] + th * ts5::R1[2])));
+  const float th2 = th * th;
+#pragma unroll
+  for (int i = 0; i < 6; i++) bw[i + 1] = th2 * (ts5::R[i][0] + th * (ts5::R[i][1] + th * ts5::R[i][2]));
+}
+
+// One Tsit5 attempt on an N-vector held in registers. k[0] = f(y) on entry.
+// Leaves k[1..6], yn; returns the RMS error estimate (0 when !adaptive).
+template <int N, class F>
+__device__ __forceinline__ float tsit5_attempt(F& f, float h, const float (&y)[N], float (&k)[7][N], float (&yn)[N],
+                                               const KOpts& o) {
+  float tmp[N];
+#pragma unroll
+  for (int s = 1; s < 6; s++) {
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      float acc = ts5::A[s][0] * k[0][i];
+#pragma unroll
+      for (int j = 1; j < s; j++) acc += ts5::A[s][j] * k[j][i];
+      tmp[i] = y[i] + h * acc;
+    }
+    f(tmp, k[s]);
+  }
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    float acc = ts5::A[6][0] * k[0][i];
+#pragma unroll
+    for (int j = 1; j < 6; j++) acc += ts5::A[6][j] * k[j][i];
+    yn[i] = y[i] + h * acc;
+  }
+  f(yn, k[6]);
+  if (!o.adaptive) return 0.f;
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    float e = ts5::BT[0] * k[0][i];
+#pragma unroll
+    for (int j = 1; j < 7; j++) e += ts5::BT[j] * k[j][i];
+    e *= h;
+    const float sk = o.abstol + fmaxf(fabsf(y[i]), fabsf(yn[i])) * o.reltol;
+    const float r = __fdividef(e, sk);
+    s2 += r * r;
+  }
+  return sqrtf(s2 * (1.0f / N));
+}
+
+// classical RK4 on registers; k[0] = f(y) on entry, leaves k[4] = f(yn).
+template <int N, class F>
+__device__ __forceinline__ void rk4_step(F& f, float h, const float (&y)[N], float (&k)[7][N], float (&yn)[N]) {
+  float tmp[N];
+  const float hh = 0.5f * h;
+#pragma unroll
+  for (int i = 0; i < N; i++) tmp[i] = y[i] + hh * k[0][i];
+  f(tmp, k[1]);
+#pragma unroll
+  for (int i = 0; i < N; i++) tmp[i] = y[i] + hh * k[1][i];
+  f(tmp, k[2]);
+#pragma unroll
+  for (int i = 0; i < N; i++) tmp[i] = y[i] + h * k[2][i];
+  f(tmp, k[3]);
+  const float h6 = h * (1.0f / 6.0f);
+#pragma unroll
+  for (int i = 0; i < N; i++) yn[i] = y[i] + h6 * (k[0][i] + 2.0f * (k[1][i] + k[2][i]) + k[3][i]);
+  f(yn, k[4]);
+}
+
+// PI controller (OrdinaryDiffEq PIController, Tsit5 defaults β₁=7/50, β₂=2/25).
+__device__ __forceinline__ float pi_q(float EEst, float qold, const KOpts& o, float& q11) {
+  if (EEst == 0.f) {
+    q11 = 0.f;
+    return o.q_lo;
+  }
+  q11 = __powf(EEst, o.beta1);
+  float q = __fdividef(q11, __powf(qold, o.beta2));
+  return fmaxf(o.q_lo, fminf(o.q_hi, q * o.inv_gamma));
+}
+
+// Hairer–Nørsett–Wanner initial step for a 5th-order method; f0 = f(y0). sign = ±1.
+template <int N, class F>
+__device__ __forceinline__ double init_dt(F& f, const float (&y0)[N], const float (&f0)[N], float sign, double dtmax,
+                                          const KOpts& o) {
+  float s0 = 0.f, s1 = 0.f;
+  float sk[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    sk[i] = o.abstol + fabsf(y0[i]) * o.reltol;
+    const float a = y0[i] / sk[i], b = f0[i] / sk[i];
+    s0 += a * a;
+    s1 += b * b;
+  }
+  const float d0 = sqrtf(s0 * (1.0f / N)), d1 = sqrtf(s1 * (1.0f / N));
+  double dt0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6 : 0.01 * (double)(d0 / d1);
+  if (dt0 > dtmax) dt0 = dtmax;
+  const float h = sign * (float)dt0;
+  float tmp[N], f1[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) tmp[i] = y0[i] + h * f0[i];
+  f(tmp, f1);
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < N; i++) {
+    const float a = (f1[i] - f0[i]) / sk[i];
+    s2 += a * a;
+  }
+  const float d2 = sqrtf(s2 * (1.0f / N)) / (float)dt0;
+  const float dm = fmaxf(d1, d2);
+  // 10^(-(2+log10 dm)/5) = 10^-0.4 · dm^-0.2
+  const double dt1 = (dm <= 1e-15f) ? fmax(1e-6, dt0 * 1e-3) : (double)(0.39810717055349726f * __powf(dm, -0.2f));
+  double dt = fmin(100.0 * dt0, dt1);
+  return dt > dtmax ? dtmax : dt;
+}
+
+template <int N>
+__device__ __forceinline__ bool all_finite(const float (&y)[N]) {
+  bool ok = true;
+#pragma unroll
+  for (int i = 0; i < N; i++) ok = ok && isfinite(y[i]);
+  return ok;
+}
+
+}  // namespace lde

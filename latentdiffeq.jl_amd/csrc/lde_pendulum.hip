@@ -1,0 +1,322 @@
+// lde_pendulum.hip — GOKU path, analytic right-hand sides, one lane per trajectory.
+//
+// Replaces the per-trajectory ensemble solve of
+//     diffeq_layer(::Decoder{<:GOKU}, (ẑ₀, θ̂), t)          [REF src/models/GOKU.jl:98-130]
+// (prob_func/remake: column i ↦ trajectory i [REF :111]; output_func: NaN block on failure [REF :114];
+//  result laid out [D × B × T] after permutedims [REF :125]) and its reverse-mode pullback.
+//
+// Design (gfx950): every trajectory is an independent IVP with its own adaptive step sequence, so a
+// lane owns a trajectory and keeps the whole solver state in VGPRs — state (2 f32), the seven Tsit5
+// slopes, t/dt in f64. There is no LDS traffic in the step loop and no inter-lane communication;
+// the only global traffic is the algorithmic one: 12 B in, 8·T B out per trajectory, with lane ↔ batch
+// index so that every load/store of a wave covers 64 consecutive float2 (512 B).
+// Wave-level divergence comes only from differing step counts (11–17 at default tolerances).
+#include "lde_device.h"
+
+namespace lde {
+
+// ---- the closed menu of 2-state / 1-parameter physics RHS -------------------------------------
+// KIND 0: du = [y, -(G/L) sin x]                    [REF examples/pendulum_friction-less/pendulum.jl:19-26]
+// KIND 1: du = [y, -(G/L) sin x - (b/m) y], b/m=0.7  [REF pendulum.jl:65-74]
+template <int KIND>
+struct PendFwd {
+  float ngl;  // -G/L
+  __device__ __forceinline__ explicit PendFwd(float L) : ngl(-10.0f / L) {}
+  __device__ __forceinline__ void operator()(const float (&y)[2], float (&dy)[2]) const {
+    dy[0] = y[1];
+    float acc = ngl * sinf(y[0]);
+    if (KIND == 1) acc -= 0.7f * y[1];
+    dy[1] = acc;
+  }
+};
+
+// augmented reverse-time system on [z₀ z₁ λ₀ λ₁ g]:  ż=f, λ̇=-(∂f/∂z)ᵀλ, ġ=-(∂f/∂L)ᵀλ
+template <int KIND>
+struct PendBwd {
+  float ngl, gl2;  // -G/L, G/L²
+  __device__ __forceinline__ explicit PendBwd(float L) : ngl(-10.0f / L), gl2(10.0f / (L * L)) {}
+  __device__ __forceinline__ void operator()(const float (&y)[5], float (&dy)[5]) const {
+    float s, c;
+    sincosf(y[0], &s, &c);
+    dy[0] = y[1];
+    float acc = ngl * s;
+    if (KIND == 1) acc -= 0.7f * y[1];
+    dy[1] = acc;
+    dy[2] = -(ngl * c * y[3]);
+    float v1 = y[2];
+    if (KIND == 1) v1 -= 0.7f * y[3];
+    dy[3] = -v1;
+    dy[4] = -(gl2 * s * y[3]);
+  }
+};
+
+// ---- forward ------------------------------------------------------------------------------------
+template <int KIND, int SOLVER>
+__global__ void __launch_bounds__(256) k_pend_forward(const float2* __restrict__ z0, const float* __restrict__ theta,
+                                                      const double* __restrict__ ts_g, KOpts o,
+                                                      float2* __restrict__ z_out, int32_t* __restrict__ retcode,
+                                                      int32_t* __restrict__ st_nfe, int32_t* __restrict__ st_nacc,
+                                                      int32_t* __restrict__ st_nrej, int32_t* __restrict__ st_ret) {
+  extern __shared__ __attribute__((aligned(16))) double s_ts[];
+  const int T = o.T, B = o.B;
+  for (int i = threadIdx.x; i < T; i += blockDim.x) s_ts[i] = ts_g[i];
+  __syncthreads();
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+
+  const float2 zi = z0[b];
+  PendFwd<KIND> f(theta[b]);
+  float y[2] = {zi.x, zi.y};
+  float k[7][2], yn[2];
+  z_out[b] = zi;  // ts[0] is saved as ẑ₀ itself
+  int ret = LDE_RET_SUCCESS, nfe = 0, nacc = 0, nrej = 0;
+
+  if (T > 1) {
+    double t = s_ts[0];
+    const double tend = s_ts[T - 1], dtmax = tend - t;
+    f(y, k[0]);
+    nfe = 1;
+    double dt;
+    if (o.adaptive) {
+      if (o.dt_fixed > 0) dt = fmin(o.dt_fixed, dtmax);
+      else {
+        dt = init_dt<2>(f, y, k[0], 1.0f, dtmax, o);
+        nfe++;
+      }
+    } else
+      dt = o.dt_fixed;
+    float qold = 1e-4f;
+    long long iters = 0;
+    int j = 1;
+    while (t < tend) {
+      if (iters++ >= o.maxiters) { ret = LDE_RET_MAXITERS; break; }
+      double dtp = dt;
+      bool last = false;
+      if (t + dt >= tend - 1e-12 * fabs(tend)) { dt = tend - t; last = true; }
+      const float h = (float)dt;
+      float EEst = 0.f;
+      if (SOLVER == LDE_SOLVER_TSIT5) {
+        EEst = tsit5_attempt<2>(f, h, y, k, yn, o);
+        nfe += 6;
+      } else {
+        rk4_step<2>(f, h, y, k, yn);
+        nfe += 4;
+      }
+      if (!all_finite<2>(yn) || !(EEst == EEst)) {
+        if (o.adaptive && dt > o.dtmin) { nrej++; dt = dt * (double)o.qmin; continue; }
+        ret = LDE_RET_NONFINITE;
+        break;
+      }
+      if (o.adaptive) {
+        float q11;
+        const float q = pi_q(EEst, qold, o, q11);
+        if (EEst > 1.0f) {
+          nrej++;
+          dt = dt / (double)fminf(o.q_hi, q11 * o.inv_gamma);
+          if (dt < o.dtmin) { ret = LDE_RET_DTMIN; break; }
+          continue;
+        }
+        qold = fmaxf(EEst, 1e-4f);
+        dtp = dt / (double)q;
+        if (dtp > dtmax) dtp = dtmax;
+      }
+      nacc++;
+      const double tnew = last ? tend : t + dt;
+      while (j < T && s_ts[j] <= tnew) {
+        const double thd = (s_ts[j] - t) / dt;
+        float2 out;
+        if (thd >= 1.0 || (j == T - 1 && last)) {
+          out = make_float2(yn[0], yn[1]);
+        } else if (SOLVER == LDE_SOLVER_TSIT5) {
+          float bw[7];
+          tsit5_interp_weights((float)thd, bw);
+          float a0 = bw[0] * k[0][0], a1 = bw[0] * k[0][1];
+#pragma unroll
+          for (int s = 1; s < 7; s++) {
+            a0 += bw[s] * k[s][0];
+            a1 += bw[s] * k[s][1];
+          }
+          out = make_float2(y[0] + h * a0, y[1] + h * a1);
+        } else {  // cubic Hermite between (y,k1) and (yn,f(yn))
+          const float th = (float)thd, om = 1.0f - th;
+          const float h00 = (1.0f + 2.0f * th) * om * om, h10 = th * om * om;
+          const float h01 = th * th * (3.0f - 2.0f * th), h11 = th * th * (th - 1.0f);
+          out.x = h00 * y[0] + (h10 * h) * k[0][0] + h01 * yn[0] + (h11 * h) * k[4][0];
+          out.y = h00 * y[1] + (h10 * h) * k[0][1] + h01 * yn[1] + (h11 * h) * k[4][1];
+        }
+        z_out[(size_t)j * B + b] = out;
+        j++;
+      }
+      y[0] = yn[0];
+      y[1] = yn[1];
+      constexpr int FS = (SOLVER == LDE_SOLVER_TSIT5) ? 6 : 4;  // FSAL slope
+      k[0][0] = k[FS][0];
+      k[0][1] = k[FS][1];
+      t = tnew;
+      dt = o.adaptive ? dtp : o.dt_fixed;
+    }
+  }
+  if (ret != LDE_RET_SUCCESS) {  // failed solve ⇒ NaN block, never an error [REF GOKU.jl:114]
+    const float qn = __int_as_float(0x7fc00000);
+    for (int j = 0; j < T; j++) z_out[(size_t)j * B + b] = make_float2(qn, qn);
+  }
+  if (retcode) retcode[b] = ret;
+  st_ret[b] = ret;
+  st_nfe[b] = nfe;
+  st_nacc[b] = nacc;
+  st_nrej[b] = nrej;
+}
+
+// ---- adjoint --------------------------------------------------------------------------------------
+// Reverse-time integration of [z, λ, g_L] from t_T to t_1 with a forced stop at every save time:
+// λ += Δ_j there, and (checkpointed mode) z is reset to the saved ẑ(t_j).
+template <int KIND, int SOLVER>
+__global__ void __launch_bounds__(256) k_pend_adjoint(const float2* __restrict__ z_out, const float* __restrict__ theta,
+                                                      const double* __restrict__ ts_g, KOpts o,
+                                                      const float2* __restrict__ dz_out, float2* __restrict__ dz0,
+                                                      float* __restrict__ dtheta, int32_t* __restrict__ st_nfe,
+                                                      int32_t* __restrict__ st_nacc, int32_t* __restrict__ st_nrej,
+                                                      int32_t* __restrict__ st_ret) {
+  extern __shared__ __attribute__((aligned(16))) double s_ts[];
+  const int T = o.T, B = o.B;
+  for (int i = threadIdx.x; i < T; i += blockDim.x) s_ts[i] = ts_g[i];
+  __syncthreads();
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+
+  PendBwd<KIND> f(theta[b]);
+  const float2 zT = z_out[(size_t)(T - 1) * B + b];
+  const float2 dT = dz_out[(size_t)(T - 1) * B + b];
+  float y[5] = {zT.x, zT.y, dT.x, dT.y, 0.f};
+  float k[7][5], yn[5];
+  int ret = LDE_RET_SUCCESS, nfe = 0, nacc = 0, nrej = 0;
+  bool bad = !(isfinite(zT.x) && isfinite(zT.y));  // failed forward trajectory: NaN block is a constant ⇒ zero gradient
+
+  if (T > 1 && !bad) {
+    double t = s_ts[T - 1];
+    const double dtmax = fabs(t - s_ts[0]);
+    int j = T - 2;
+    // prefetch the jump data of the next stop
+    float2 zc = z_out[(size_t)j * B + b], dc = dz_out[(size_t)j * B + b];
+    f(y, k[0]);
+    nfe = 1;
+    double dt;
+    if (o.adaptive) {
+      if (o.dt_fixed > 0) dt = fmin(o.dt_fixed, dtmax);
+      else {
+        dt = init_dt<5>(f, y, k[0], -1.0f, dtmax, o);
+        nfe++;
+      }
+    } else
+      dt = o.dt_fixed;
+    float qold = 1e-4f;
+    long long iters = 0;
+    while (j >= 0) {
+      if (iters++ >= o.maxiters) { ret = LDE_RET_MAXITERS; break; }
+      const double tstop = s_ts[j];
+      const double dist = t - tstop;
+      double hmag = dt;
+      bool hit = false;
+      if (hmag >= dist * (1.0 - 1e-12)) { hmag = dist; hit = true; }
+      const float h = -(float)hmag;
+      float EEst = 0.f;
+      if (SOLVER == LDE_SOLVER_TSIT5) {
+        EEst = tsit5_attempt<5>(f, h, y, k, yn, o);
+        nfe += 6;
+      } else {
+        rk4_step<5>(f, h, y, k, yn);
+        nfe += 4;
+      }
+      if (!all_finite<5>(yn) || !(EEst == EEst)) {
+        if (o.adaptive && hmag > o.dtmin) { nrej++; dt = hmag * (double)o.qmin; continue; }
+        ret = LDE_RET_NONFINITE;
+        break;
+      }
+      double dtp = dt;
+      if (o.adaptive) {
+        float q11;
+        const float q = pi_q(EEst, qold, o, q11);
+        if (EEst > 1.0f) {
+          nrej++;
+          dt = hmag / (double)fminf(o.q_hi, q11 * o.inv_gamma);
+          if (dt < o.dtmin) { ret = LDE_RET_DTMIN; break; }
+          continue;
+        }
+        qold = fmaxf(EEst, 1e-4f);
+        dtp = hmag / (double)q;
+        if (dtp > dtmax) dtp = dtmax;
+      }
+      nacc++;
+#pragma unroll
+      for (int i = 0; i < 5; i++) y[i] = yn[i];
+      constexpr int FS = (SOLVER == LDE_SOLVER_TSIT5) ? 6 : 4;
+      if (hit) {
+        t = tstop;
+        y[2] += dc.x;
+        y[3] += dc.y;
+        if (o.checkpoint) {
+          y[0] = zc.x;
+          y[1] = zc.y;
+        }
+        j--;
+        if (j >= 0) {
+          zc = z_out[(size_t)j * B + b];
+          dc = dz_out[(size_t)j * B + b];
+          f(y, k[0]);  // the jump invalidates the FSAL slope
+          nfe++;
+        }
+      } else {
+        t -= hmag;
+#pragma unroll
+        for (int i = 0; i < 5; i++) k[0][i] = k[FS][i];
+      }
+      dt = o.adaptive ? dtp : o.dt_fixed;
+    }
+  }
+  if (ret != LDE_RET_SUCCESS) bad = true;
+  dz0[b] = bad ? make_float2(0.f, 0.f) : make_float2(y[2], y[3]);
+  dtheta[b] = bad ? 0.f : y[4];
+  st_nfe[b] = nfe;
+  st_nacc[b] = nacc;
+  st_nrej[b] = nrej;
+  st_ret[b] = bad ? (ret ? ret : LDE_RET_NONFINITE) : 0;
+}
+
+// ---- host-side launchers (called from lde_api.cpp) -------------------------------------------------
+static inline int pick_block(int B) { return B <= 4096 ? 64 : 256; }
+
+int launch_pend_forward(int kind, int solver, const float* z0, const float* theta, const double* ts_dev, const KOpts& o,
+                        float* z_out, int32_t* retcode, int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret,
+                        hipStream_t stream) {
+  const int block = pick_block(o.B), grid = (o.B + block - 1) / block;
+  const size_t shm = (size_t)o.T * sizeof(double);
+#define LDE_LAUNCH(K, S)                                                                                              \
+  hipLaunchKernelGGL((k_pend_forward<K, S>), dim3(grid), dim3(block), shm, stream, (const float2*)z0, theta, ts_dev, o, \
+                     (float2*)z_out, retcode, nfe, nacc, nrej, ret)
+  if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH(0, LDE_SOLVER_TSIT5);
+  else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_RK4) LDE_LAUNCH(0, LDE_SOLVER_RK4);
+  else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH(1, LDE_SOLVER_TSIT5);
+  else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_RK4) LDE_LAUNCH(1, LDE_SOLVER_RK4);
+  else return LDE_ERR_UNSUPPORTED;
+#undef LDE_LAUNCH
+  return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
+}
+
+int launch_pend_adjoint(int kind, int solver, const float* z_out, const float* theta, const double* ts_dev,
+                        const KOpts& o, const float* dz_out, float* dz0, float* dtheta, int32_t* nfe, int32_t* nacc,
+                        int32_t* nrej, int32_t* ret, hipStream_t stream) {
+  const int block = pick_block(o.B), grid = (o.B + block - 1) / block;
+  const size_t shm = (size_t)o.T * sizeof(double);
+#define LDE_LAUNCH(K, S)                                                                                          \
+  hipLaunchKernelGGL((k_pend_adjoint<K, S>), dim3(grid), dim3(block), shm, stream, (const float2*)z_out, theta, ts_dev, \
+                     o, (const float2*)dz_out, (float2*)dz0, dtheta, nfe, nacc, nrej, ret)
+  if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH(0, LDE_SOLVER_TSIT5);
+  else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_RK4) LDE_LAUNCH(0, LDE_SOLVER_RK4);
+  else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH(1, LDE_SOLVER_TSIT5);
+  else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_RK4) LDE_LAUNCH(1, LDE_SOLVER_RK4);
+  else return LDE_ERR_UNSUPPORTED;
+#undef LDE_LAUNCH
+  return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
+}
+
+}  // namespace lde

@@ -1,0 +1,100 @@
+"""Helpers for the `-m gpu` parity tests: call liblde.so through its C ABI with torch-owned device buffers."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from latentdiffeq_amd import _lib as L
+
+
+def make_desc(**kw):
+    lib = L.load()
+    d = L.ProblemDesc()
+    lib.lde_problem_desc_default(C.byref(d))
+    layers = kw.pop("layers", ())
+    d.n_layers = max(len(layers) - 1, 0)
+    for i, s in enumerate(layers):
+        d.layer_sizes[i] = s
+    for k, v in kw.items():
+        assert hasattr(d, k), k
+        setattr(d, k, v)
+    return d
+
+
+def copy_desc_to_oracle(d):
+    """Same bytes, oracle's own ctypes type."""
+    from oracle import oracle as O
+    od = O.Desc()
+    C.memmove(C.byref(od), C.byref(d), C.sizeof(od))
+    assert C.sizeof(od) == C.sizeof(d)
+    return od
+
+
+class Native:
+    """Thin RAII over the C ABI, numpy in / numpy out (device staging through torch)."""
+
+    def __init__(self, desc):
+        self.lib = L.load()
+        self.d = desc
+        self.h = C.c_void_p()
+        L.check(self.lib.lde_create(C.byref(desc), C.byref(self.h)), None, "lde_create")
+        self.nW = int(self.lib.lde_num_weights(C.byref(desc)))
+
+    def close(self):
+        if self.h:
+            self.lib.lde_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _p(t):
+        return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p()
+
+    def set_weights(self, W):
+        W = np.ascontiguousarray(W, np.float32)
+        L.check(self.lib.lde_set_weights(self.h, W.ctypes.data_as(C.c_void_p), W.size), self.h, "lde_set_weights")
+
+    def forward(self, z0, theta, ts):
+        dev = "cuda"
+        z0d = torch.from_numpy(np.ascontiguousarray(z0, np.float32)).to(dev)
+        thd = None if theta is None else torch.from_numpy(np.ascontiguousarray(theta, np.float32)).to(dev)
+        B, D = z0d.shape
+        ts = np.ascontiguousarray(ts, np.float64)
+        T = ts.shape[0]
+        Dp = D + self.d.augment_dim
+        out = torch.full((T, B, Dp), 7.0, device=dev, dtype=torch.float32)
+        ret = torch.full((B,), -1, device=dev, dtype=torch.int32)
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(self.lib.lde_forward(self.h, self._p(z0d), self._p(thd), ts.ctypes.data_as(C.POINTER(C.c_double)), T, B,
+                                     self._p(out), self._p(ret), s), self.h, "lde_forward")
+        torch.cuda.synchronize()
+        return out.cpu().numpy(), ret.cpu().numpy(), self.stats(0)
+
+    def adjoint(self, z_out, theta, ts, dz_out):
+        dev = "cuda"
+        zo = torch.from_numpy(np.ascontiguousarray(z_out, np.float32)).to(dev)
+        dzo = torch.from_numpy(np.ascontiguousarray(dz_out, np.float32)).to(dev)
+        thd = None if theta is None else torch.from_numpy(np.ascontiguousarray(theta, np.float32)).to(dev)
+        T, B, Dp = zo.shape
+        D, P = self.d.state_dim, self.d.param_dim
+        ts = np.ascontiguousarray(ts, np.float64)
+        dz0 = torch.full((B, D), 7.0, device=dev)
+        dth = torch.full((B, P), 7.0, device=dev) if P else None
+        dW = torch.zeros((self.nW,), device=dev) if self.nW else None
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(self.lib.lde_adjoint(self.h, self._p(zo), self._p(thd), ts.ctypes.data_as(C.POINTER(C.c_double)), T, B,
+                                     self._p(dzo), self._p(dz0), self._p(dth), self._p(dW), s), self.h, "lde_adjoint")
+        torch.cuda.synchronize()
+        return (dz0.cpu().numpy(), None if dth is None else dth.cpu().numpy(),
+                None if dW is None else dW.cpu().numpy(), self.stats(1))
+
+    def stats(self, which):
+        st = L.Stats()
+        L.check(self.lib.lde_get_stats(self.h, which, C.byref(st), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+                self.h, "lde_get_stats")
+        return dict(nfe=st.nfe, naccept=st.naccept, nreject=st.nreject, nfailed=st.nfailed, max_steps=st.max_steps)

@@ -1,0 +1,156 @@
+"""GPU parity: HIP per-trajectory pendulum kernels (through the C ABI) vs the CPU oracle on the same inputs.
+
+Tolerances (fp32 state, stated per SURVEY.md §7 hard part 1):
+  * kernel vs oracle-f32, same algorithm and controller: |Δẑ| ≤ 2e-5 at default tol (1e-6/1e-3), ≤ 1e-5 at 1e-6/1e-6
+  * kernel vs float64 truth (oracle-f64 at 1e-10): ≤ 5e-4 at default tol, ≤ 1e-5 at tight tol  (north_star: 1e-4 at the parity gate)
+  * gradients: relative ≤ 2e-4 vs oracle-f32, ≤ 1e-3 vs float64 oracle at tight tolerance
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _native(**kw):
+    from tests.gpu_util import Native, make_desc, copy_desc_to_oracle
+    d = make_desc(**kw)
+    return Native(d), copy_desc_to_oracle(d)
+
+
+@pytest.mark.parametrize("kind", [O.RHS_PENDULUM, O.RHS_PENDULUM_FRICTION])
+@pytest.mark.parametrize("tol", [(1e-6, 1e-3), (1e-6, 1e-6)])
+@pytest.mark.parametrize("B", [64, 256, 1000])
+def test_forward_matches_oracle(o32, o64, kind, tol, B):
+    nat, od = _native(rhs_kind=kind, abstol=tol[0], reltol=tol[1])
+    z0, L = O.pendulum_inputs(B)
+    ts = O.time_grid(50)
+    z, ret, st = nat.forward(z0, L, ts)
+    zr, retr, info = o32.forward(od, z0, L, ts)
+    assert (ret == 0).all() and (retr == 0).all()
+    assert np.array_equal(z[0], z0), "ẑ[:,:,1] must equal ẑ₀ exactly"
+    lim = 2e-5 if tol[1] > 1e-4 else 1e-5
+    assert np.abs(z - zr).max() <= lim
+    # identical step counts (same controller arithmetic up to ulps)
+    assert st["naccept"] == info["naccept"] and st["nreject"] == info["nreject"] and st["nfe"] == info["nfe"]
+    # against float64 truth
+    dtruth = O.make_desc(rhs_kind=kind, abstol=1e-10, reltol=1e-10)
+    zt, _, _ = o64.forward(dtruth, z0, L, ts)
+    assert np.abs(z - zt).max() <= (5e-4 if tol[1] > 1e-4 else 1e-5)
+
+
+@pytest.mark.parametrize("kind", [O.RHS_PENDULUM, O.RHS_PENDULUM_FRICTION])
+@pytest.mark.parametrize("sense", [O.SENSE_BACKSOLVE_CHECKPOINTED, O.SENSE_BACKSOLVE])
+@pytest.mark.parametrize("tol", [(1e-6, 1e-3), (1e-6, 1e-6)])
+def test_adjoint_matches_oracle(o32, o64, kind, sense, tol):
+    B, T = 256, 50
+    nat, od = _native(rhs_kind=kind, abstol=tol[0], reltol=tol[1], sensealg=sense)
+    z0, L = O.pendulum_inputs(B)
+    ts = O.time_grid(T)
+    dz = O.cotangent(T, B, 2)
+    z, _, _ = nat.forward(z0, L, ts)
+    g0, gL, _, st = nat.adjoint(z, L, ts, dz)
+    r0, rL, _, info = o32.adjoint(od, z, L, ts, dz)
+    s0, sL = np.abs(r0).max(), np.abs(rL).max()
+    assert np.abs(g0 - r0).max() <= 2e-4 * s0
+    assert np.abs(gL - rL).max() <= 2e-4 * sL
+    assert st["naccept"] == info["naccept"] and st["nreject"] == info["nreject"]
+    # float64 truth of the same continuous adjoint
+    dtruth = O.make_desc(rhs_kind=kind, abstol=1e-11, reltol=1e-11, sensealg=sense)
+    zt, _, _ = o64.forward(dtruth, z0, L, ts)
+    t0, tL, _, _ = o64.adjoint(dtruth, zt, L, ts, dz)
+    lim = 5e-3 if tol[1] > 1e-4 else 1e-3
+    assert np.abs(g0 - t0).max() <= lim * np.abs(t0).max()
+    assert np.abs(gL - tL).max() <= lim * np.abs(tL).max()
+
+
+def test_rk4_fixed_step(o32):
+    B, T = 128, 50
+    nat, od = _native(solver=O.SOLVER_RK4, adaptive=0, dt=0.0125)
+    z0, L = O.pendulum_inputs(B)
+    ts = O.time_grid(T)
+    z, ret, st = nat.forward(z0, L, ts)
+    zr, _, info = o32.forward(od, z0, L, ts)
+    assert np.abs(z - zr).max() <= 1e-5
+    assert st["naccept"] == info["naccept"] == B * 196
+    dz = O.cotangent(T, B, 2)
+    g0, gL, _, _ = nat.adjoint(z, L, ts, dz)
+    r0, rL, _, _ = o32.adjoint(od, z, L, ts, dz)
+    assert np.abs(g0 - r0).max() <= 1e-4 * np.abs(r0).max()
+    assert np.abs(gL - rL).max() <= 1e-4 * np.abs(rL).max()
+
+
+def test_off_grid_save_times_and_single_point(o32):
+    nat, od = _native()
+    z0, L = O.pendulum_inputs(70, seed=5)
+    rng = np.random.default_rng(0)
+    ts = np.sort(rng.uniform(0.3, 4.0, 23))
+    z, ret, _ = nat.forward(z0, L, ts)
+    zr, _, _ = o32.forward(od, z0, L, ts)
+    assert np.abs(z - zr).max() <= 2e-5
+    # T = 1: nothing to integrate
+    z1, ret1, _ = nat.forward(z0, L, ts[:1])
+    assert np.array_equal(z1[0], z0) and (ret1 == 0).all()
+    dz = O.cotangent(1, 70, 2)
+    g0, gL, _, _ = nat.adjoint(z1, L, ts[:1], dz)
+    assert np.array_equal(g0, dz[0]) and (gL == 0).all()
+
+
+def test_failed_trajectories_give_nan_blocks(o32):
+    """maxiters exhausted ⇒ retcode != 0 and a NaN [D×T] block for that trajectory only [REF GOKU.jl:114]."""
+    nat, od = _native(maxiters=12)
+    z0, L = O.pendulum_inputs(256)
+    ts = O.time_grid(50)
+    z, ret, st = nat.forward(z0, L, ts)
+    zr, retr, info = o32.forward(od, z0, L, ts)
+    assert np.array_equal(ret, retr)
+    assert 0 < (ret != 0).sum() < 256
+    assert st["nfailed"] == (ret != 0).sum()
+    bad = ret != 0
+    assert np.isnan(z[:, bad, :]).all() and np.isfinite(z[:, ~bad, :]).all()
+    assert np.abs(z[:, ~bad] - zr[:, ~bad]).max() <= 2e-5
+    # pullback through a NaN block: zero gradient for that trajectory, finite for the others
+    dz = O.cotangent(50, 256, 2)
+    g0, gL, _, sb = nat.adjoint(z, L, ts, dz)
+    assert (g0[bad] == 0).all() and (gL[bad] == 0).all() and np.isfinite(g0).all()
+    assert sb["nfailed"] == bad.sum()
+
+
+def test_large_batch_properties(o32):
+    """B = 2^17 (no oracle at this size): energy conservation, determinism, and agreement of a subsample."""
+    B, T = 1 << 17, 50
+    nat, od = _native(abstol=1e-6, reltol=1e-6)
+    z0, L = O.pendulum_inputs(B, seed=11)
+    ts = O.time_grid(T)
+    z, ret, _ = nat.forward(z0, L, ts)
+    assert (ret == 0).all()
+    E = 0.5 * z[..., 1] ** 2 - (10.0 / L[None, :, 0]) * np.cos(z[..., 0])
+    assert np.abs(E - E[0]).max() <= 2e-4  # frictionless: ½ω² − (G/L)cos θ is conserved
+    z2, _, _ = nat.forward(z0, L, ts)
+    assert np.array_equal(z, z2), "bitwise deterministic"
+    idx = np.arange(0, B, 997)
+    zr, _, _ = o32.forward(od, z0[idx], L[idx], ts)
+    assert np.abs(z[:, idx] - zr).max() <= 1e-5
+
+
+def test_torch_api_diffeq_layer(o32):
+    """The reference-shaped host API: ẑ = diffeq_layer(decoder, (ẑ₀, θ̂), t), differentiable."""
+    import torch
+    import latentdiffeq_amd as la
+    B, T = 64, 50
+    z0, L = O.pendulum_inputs(B)
+    ts = O.time_grid(T)
+    dec = la.Decoder(la.GOKU_basic(), (None, la.Pendulum(), None))
+    z0t = torch.tensor(z0.T.copy(), device="cuda", requires_grad=True)      # [D, B]
+    tht = torch.tensor(L.T.copy(), device="cuda", requires_grad=True)        # [P, B]
+    zhat = la.diffeq_layer(dec, (z0t, tht), ts)
+    assert tuple(zhat.shape) == (2, B, T)
+    od = O.make_desc()
+    zr, _, _ = o32.forward(od, z0, L, ts)
+    assert np.abs(zhat.detach().permute(2, 1, 0).cpu().numpy() - zr).max() <= 2e-5
+    dz = O.cotangent(T, B, 2)
+    (zhat * torch.tensor(dz, device="cuda").permute(2, 1, 0)).sum().backward()
+    r0, rL, _, _ = o32.adjoint(od, zr, L, ts, dz)
+    assert np.abs(z0t.grad.cpu().numpy().T - r0).max() <= 2e-4 * np.abs(r0).max()
+    assert np.abs(tht.grad.cpu().numpy().T - rL).max() <= 2e-4 * np.abs(rL).max()

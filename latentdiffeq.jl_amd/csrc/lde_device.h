@@ -30,6 +30,46 @@ struct KOpts {
   int T, B;
 };
 
+
+// ---- fast scalar math (gfx950 hardware transcendentals; ≈1 ulp) ----------------------------------
+__device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+// x^y for x > 0 via v_log_f32 / v_exp_f32 (the step controller only needs ~1e-6 relative accuracy;
+// OrdinaryDiffEq itself uses a low-precision `fastpow` here)
+__device__ __forceinline__ float fast_pow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
+
+// sin and cos with ≈1.3e-7 absolute error: k = rint(x/π), r = x − kπ (two-term Cody–Waite with FMA),
+// odd/even minimax polynomials on [−π/2, π/2], sign (−1)^k. ~25 VALU instructions for the pair,
+// branch-free (ocml's sinf carries a Payne–Hanek slow path that costs ≈150 instructions of code per call).
+__device__ __forceinline__ void fast_sincos(float x, float& s, float& c) {
+  const float k = rintf(x * 0.3183098861837907f);
+  float r = fmaf(-k, 3.1415927410125732f, x);
+  r = fmaf(-k, -8.742277657347586e-08f, r);
+  const float r2 = r * r;
+  float ps = fmaf(r2, 2.6348157007305417e-06f, -0.00019822761532850564f);
+  ps = fmaf(ps, r2, 0.008333242498338223f);
+  ps = fmaf(ps, r2, -0.1666666567325592f);
+  const float sv = fmaf(r * r2, ps, r);
+  float pc = fmaf(r2, -2.629789719321707e-07f, 2.477459747751709e-05f);
+  pc = fmaf(pc, r2, -0.0013888651737943292f);
+  pc = fmaf(pc, r2, 0.0416666604578495f);
+  pc = fmaf(pc, r2, -0.5f);
+  const float cv = fmaf(r2, pc, 1.0f);
+  const int sign = ((int)k) << 31;
+  s = __int_as_float(__float_as_int(sv) ^ sign);
+  c = __int_as_float(__float_as_int(cv) ^ sign);
+}
+__device__ __forceinline__ float fast_sin(float x) {
+  const float k = rintf(x * 0.3183098861837907f);
+  float r = fmaf(-k, 3.1415927410125732f, x);
+  r = fmaf(-k, -8.742277657347586e-08f, r);
+  const float r2 = r * r;
+  float ps = fmaf(r2, 2.6348157007305417e-06f, -0.00019822761532850564f);
+  ps = fmaf(ps, r2, 0.008333242498338223f);
+  ps = fmaf(ps, r2, -0.1666666567325592f);
+  const float sv = fmaf(r * r2, ps, r);
+  return __int_as_float(__float_as_int(sv) ^ (((int)k) << 31));
+}
+
 // ---- Tsit5 tableau (Tsitouras 2011), f32 copies of the f64 constants ------------------------
 namespace ts5 {
 constexpr float A[7][6] = {
@@ -61,6 +101,25 @@ __device__ __forceinline__ void tsit5_interp_weights(float th, float (&bw)[7]) {
   const float th2 = th * th;
 #pragma unroll
   for (int i = 0; i < 6; i++) bw[i + 1] = th2 * (ts5::R[i][0] + th * (ts5::R[i][1] + th * ts5::R[i][2]));
+}
+
+// Dense output in Horner form: u(t+Θh) = u + h·(Θ·k₁ + Θ²·(P₂ + Θ(P₃ + Θ·P₄))) with the Θ-independent
+// P_m = Σ_i r_{i,m} k_i computed once per accepted step (5 FMA per component and save point afterwards).
+template <int N>
+__device__ __forceinline__ void tsit5_dense_coeffs(const float (&k)[7][N], float (&P)[3][N]) {
+#pragma unroll
+  for (int m = 0; m < 3; m++)
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+      float acc = ts5::R1[m] * k[0][i];
+#pragma unroll
+      for (int s = 0; s < 6; s++) acc += ts5::R[s][m] * k[s + 1][i];
+      P[m][i] = acc;
+    }
+}
+template <int N>
+__device__ __forceinline__ float tsit5_dense_eval(float th, float h, float y, float k1, float P2, float P3, float P4) {
+  return y + (h * th) * (k1 + th * (P2 + th * (P3 + th * P4)));
 }
 
 // One Tsit5 attempt on an N-vector held in registers. k[0] = f(y) on entry.
@@ -97,7 +156,7 @@ __device__ __forceinline__ float tsit5_attempt(F& f, float h, const float (&y)[N
     for (int j = 1; j < 7; j++) e += ts5::BT[j] * k[j][i];
     e *= h;
     const float sk = o.abstol + fmaxf(fabsf(y[i]), fabsf(yn[i])) * o.reltol;
-    const float r = __fdividef(e, sk);
+    const float r = e * fast_rcp(sk);
     s2 += r * r;
   }
   return sqrtf(s2 * (1.0f / N));
@@ -129,8 +188,8 @@ __device__ __forceinline__ float pi_q(float EEst, float qold, const KOpts& o, fl
     q11 = 0.f;
     return o.q_lo;
   }
-  q11 = __powf(EEst, o.beta1);
-  float q = __fdividef(q11, __powf(qold, o.beta2));
+  q11 = fast_pow(EEst, o.beta1);
+  float q = q11 * fast_pow(qold, -o.beta2);
   return fmaxf(o.q_lo, fminf(o.q_hi, q * o.inv_gamma));
 }
 
@@ -142,13 +201,13 @@ __device__ __forceinline__ double init_dt(F& f, const float (&y0)[N], const floa
   float sk[N];
 #pragma unroll
   for (int i = 0; i < N; i++) {
-    sk[i] = o.abstol + fabsf(y0[i]) * o.reltol;
-    const float a = y0[i] / sk[i], b = f0[i] / sk[i];
+    sk[i] = fast_rcp(o.abstol + fabsf(y0[i]) * o.reltol);  // 1/scale
+    const float a = y0[i] * sk[i], b = f0[i] * sk[i];
     s0 += a * a;
     s1 += b * b;
   }
   const float d0 = sqrtf(s0 * (1.0f / N)), d1 = sqrtf(s1 * (1.0f / N));
-  double dt0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6 : 0.01 * (double)(d0 / d1);
+  double dt0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6 : 0.01 * (double)(d0 * fast_rcp(d1));
   if (dt0 > dtmax) dt0 = dtmax;
   const float h = sign * (float)dt0;
   float tmp[N], f1[N];
@@ -158,13 +217,13 @@ __device__ __forceinline__ double init_dt(F& f, const float (&y0)[N], const floa
   float s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < N; i++) {
-    const float a = (f1[i] - f0[i]) / sk[i];
+    const float a = (f1[i] - f0[i]) * sk[i];
     s2 += a * a;
   }
-  const float d2 = sqrtf(s2 * (1.0f / N)) / (float)dt0;
+  const float d2 = sqrtf(s2 * (1.0f / N)) * fast_rcp((float)dt0);
   const float dm = fmaxf(d1, d2);
   // 10^(-(2+log10 dm)/5) = 10^-0.4 · dm^-0.2
-  const double dt1 = (dm <= 1e-15f) ? fmax(1e-6, dt0 * 1e-3) : (double)(0.39810717055349726f * __powf(dm, -0.2f));
+  const double dt1 = (dm <= 1e-15f) ? fmax(1e-6, dt0 * 1e-3) : (double)(0.39810717055349726f * fast_pow(dm, -0.2f));
   double dt = fmin(100.0 * dt0, dt1);
   return dt > dtmax ? dtmax : dt;
 }

@@ -21,10 +21,10 @@ namespace lde {
 template <int KIND>
 struct PendFwd {
   float ngl;  // -G/L
-  __device__ __forceinline__ explicit PendFwd(float L) : ngl(-10.0f / L) {}
+  __device__ __forceinline__ explicit PendFwd(float L) : ngl(-10.0f / L) {}  // one IEEE division per trajectory
   __device__ __forceinline__ void operator()(const float (&y)[2], float (&dy)[2]) const {
     dy[0] = y[1];
-    float acc = ngl * sinf(y[0]);
+    float acc = ngl * fast_sin(y[0]);
     if (KIND == 1) acc -= 0.7f * y[1];
     dy[1] = acc;
   }
@@ -37,7 +37,7 @@ struct PendBwd {
   __device__ __forceinline__ explicit PendBwd(float L) : ngl(-10.0f / L), gl2(10.0f / (L * L)) {}
   __device__ __forceinline__ void operator()(const float (&y)[5], float (&dy)[5]) const {
     float s, c;
-    sincosf(y[0], &s, &c);
+    fast_sincos(y[0], s, c);
     dy[0] = y[1];
     float acc = ngl * s;
     if (KIND == 1) acc -= 0.7f * y[1];
@@ -112,40 +112,41 @@ __global__ void __launch_bounds__(256) k_pend_forward(const float2* __restrict__
         const float q = pi_q(EEst, qold, o, q11);
         if (EEst > 1.0f) {
           nrej++;
-          dt = dt / (double)fminf(o.q_hi, q11 * o.inv_gamma);
+          dt = dt * (double)fast_rcp(fminf(o.q_hi, q11 * o.inv_gamma));
           if (dt < o.dtmin) { ret = LDE_RET_DTMIN; break; }
           continue;
         }
         qold = fmaxf(EEst, 1e-4f);
-        dtp = dt / (double)q;
+        dtp = dt * (double)fast_rcp(q);
         if (dtp > dtmax) dtp = dtmax;
       }
       nacc++;
       const double tnew = last ? tend : t + dt;
-      while (j < T && s_ts[j] <= tnew) {
-        const double thd = (s_ts[j] - t) / dt;
-        float2 out;
-        if (thd >= 1.0 || (j == T - 1 && last)) {
-          out = make_float2(yn[0], yn[1]);
-        } else if (SOLVER == LDE_SOLVER_TSIT5) {
-          float bw[7];
-          tsit5_interp_weights((float)thd, bw);
-          float a0 = bw[0] * k[0][0], a1 = bw[0] * k[0][1];
-#pragma unroll
-          for (int s = 1; s < 7; s++) {
-            a0 += bw[s] * k[s][0];
-            a1 += bw[s] * k[s][1];
+      if (j < T && s_ts[j] <= tnew) {  // at least one save time in (t, tnew]
+        float P[3][2];
+        if (SOLVER == LDE_SOLVER_TSIT5) tsit5_dense_coeffs<2>(k, P);
+        const float rh = fast_rcp(h);
+        do {
+          const double tj = s_ts[j];
+          float2 out;
+          if (tj >= tnew || (j == T - 1 && last)) {
+            out = make_float2(yn[0], yn[1]);
+          } else {
+            const float th = (float)(tj - t) * rh;
+            if (SOLVER == LDE_SOLVER_TSIT5) {
+              out.x = tsit5_dense_eval<2>(th, h, y[0], k[0][0], P[0][0], P[1][0], P[2][0]);
+              out.y = tsit5_dense_eval<2>(th, h, y[1], k[0][1], P[0][1], P[1][1], P[2][1]);
+            } else {  // cubic Hermite between (y,k1) and (yn,f(yn))
+              const float om = 1.0f - th;
+              const float h00 = (1.0f + 2.0f * th) * om * om, h10 = th * om * om;
+              const float h01 = th * th * (3.0f - 2.0f * th), h11 = th * th * (th - 1.0f);
+              out.x = h00 * y[0] + (h10 * h) * k[0][0] + h01 * yn[0] + (h11 * h) * k[4][0];
+              out.y = h00 * y[1] + (h10 * h) * k[0][1] + h01 * yn[1] + (h11 * h) * k[4][1];
+            }
           }
-          out = make_float2(y[0] + h * a0, y[1] + h * a1);
-        } else {  // cubic Hermite between (y,k1) and (yn,f(yn))
-          const float th = (float)thd, om = 1.0f - th;
-          const float h00 = (1.0f + 2.0f * th) * om * om, h10 = th * om * om;
-          const float h01 = th * th * (3.0f - 2.0f * th), h11 = th * th * (th - 1.0f);
-          out.x = h00 * y[0] + (h10 * h) * k[0][0] + h01 * yn[0] + (h11 * h) * k[4][0];
-          out.y = h00 * y[1] + (h10 * h) * k[0][1] + h01 * yn[1] + (h11 * h) * k[4][1];
-        }
-        z_out[(size_t)j * B + b] = out;
-        j++;
+          z_out[(size_t)j * B + b] = out;
+          j++;
+        } while (j < T && s_ts[j] <= tnew);
       }
       y[0] = yn[0];
       y[1] = yn[1];
@@ -238,12 +239,12 @@ __global__ void __launch_bounds__(256) k_pend_adjoint(const float2* __restrict__
         const float q = pi_q(EEst, qold, o, q11);
         if (EEst > 1.0f) {
           nrej++;
-          dt = hmag / (double)fminf(o.q_hi, q11 * o.inv_gamma);
+          dt = hmag * (double)fast_rcp(fminf(o.q_hi, q11 * o.inv_gamma));
           if (dt < o.dtmin) { ret = LDE_RET_DTMIN; break; }
           continue;
         }
         qold = fmaxf(EEst, 1e-4f);
-        dtp = hmag / (double)q;
+        dtp = hmag * (double)fast_rcp(q);
         if (dtp > dtmax) dtp = dtmax;
       }
       nacc++;

@@ -69,7 +69,7 @@ def build_problem(w, B, seed_shift=0):
         theta = None
     else:
         z0, theta = O.pendulum_inputs(B, seed=1 + seed_shift)
-    W = O.mlp_weights(w["layers"], seed=3, scale=0.5) if w["layers"] else None
+    W = O.mlp_weights(w["layers"], seed=3, scale=1.0) if w["layers"] else None
     dz = O.cotangent(T, B, D, seed=2 + seed_shift)
     return d, ts, z0, theta, W, dz
 

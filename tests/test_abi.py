@@ -1,0 +1,140 @@
+"""CPU-side checks of the drop-in boundary: liblde.so loads without a GPU and exports every symbol that
+include/lde.h declares; struct layouts agree between the header, the product binding and the oracle binding;
+host-side validation behaves like the reference interface (bad arguments → error code, never an abort)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    src = open(os.path.join(ROOT, "include", "lde.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lde_[a-z_0-9]+)\s*\(", src)))
+
+
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    import latentdiffeq_amd as la
+    from latentdiffeq_amd import _lib
+    la.build_lib()
+    lib = _lib.load()
+    decl = _declared_functions()
+    assert len(decl) >= 12
+    for name in decl:
+        assert hasattr(lib, name), f"{name} declared in include/lde.h but not exported by liblde.so"
+    assert sorted(_lib.EXPORTS) == decl, "the ctypes binding must bind exactly the declared entry points"
+    assert lib.lde_abi_version() == 1
+
+
+def test_desc_defaults_match_ordinarydiffeq_defaults_and_bindings_agree():
+    from latentdiffeq_amd import _lib
+    from oracle import oracle as O
+    lib = _lib.load()
+    d = _lib.ProblemDesc()
+    assert lib.lde_problem_desc_default(C.byref(d)) == 0
+    # Pendulum() carries Tsit5 and no kwargs ⇒ OrdinaryDiffEq defaults  [REF pendulum.jl:11]
+    assert (d.abstol, d.reltol, d.maxiters, d.adaptive) == (1e-6, 1e-3, 100000, 1)
+    assert (d.qmin, d.qmax, d.gamma) == (0.2, 10.0, 0.9) and abs(d.beta1 - 0.14) < 1e-15 and abs(d.beta2 - 0.08) < 1e-15
+    assert (d.rhs_kind, d.state_dim, d.param_dim, d.solver, d.batching) == (0, 2, 1, 0, 0)
+    od = O.make_desc()
+    assert C.sizeof(od) == C.sizeof(d)
+    assert bytes(od) == bytes(d), "oracle and product describe the default problem with identical bytes"
+    # header struct size: 18 int32 (incl. layer_sizes[7]) + pad, 1 int64, 9 doubles
+    assert C.sizeof(d) == 4 * 18 + 8 + 9 * 8
+
+
+def test_num_weights_follows_destructure_order():
+    from latentdiffeq_amd import _lib
+    lib = _lib.load()
+    d = _lib.ProblemDesc()
+    lib.lde_problem_desc_default(C.byref(d))
+    assert lib.lde_num_weights(C.byref(d)) == 0
+    d.rhs_kind, d.state_dim, d.param_dim, d.n_layers = _lib.RHS_MLP, 16, 0, 3
+    for i, s in enumerate((16, 200, 200, 16)):
+        d.layer_sizes[i] = s
+    assert lib.lde_num_weights(C.byref(d)) == 46816      # the reference default NODE  [REF nODE.jl:11-14]
+    for i, s in enumerate((32, 128, 128, 32)):
+        d.layer_sizes[i] = s
+    assert lib.lde_num_weights(C.byref(d)) == 24864      # BASELINE config 4
+
+
+def test_null_and_invalid_arguments_return_error_codes():
+    from latentdiffeq_amd import _lib
+    lib = _lib.load()
+    assert lib.lde_problem_desc_default(None) == -1
+    h = C.c_void_p()
+    assert lib.lde_create(None, C.byref(h)) == -1
+    d = _lib.ProblemDesc()
+    lib.lde_problem_desc_default(C.byref(d))
+    d.abi_version = 99
+    assert lib.lde_create(C.byref(d), C.byref(h)) == -1 and not h.value
+    lib.lde_problem_desc_default(C.byref(d))
+    d.solver, d.adaptive = _lib.SOLVER_RK4, 1
+    assert lib.lde_create(C.byref(d), C.byref(h)) == -2            # adaptive RK4: LDE_ERR_UNSUPPORTED
+    lib.lde_problem_desc_default(C.byref(d))
+    d.state_dim = 3
+    assert lib.lde_create(C.byref(d), C.byref(h)) == -1            # pendulum is 2-state
+    assert lib.lde_forward(None, None, None, None, 0, 0, None, None, None) == -1
+    assert lib.lde_last_error(None) == b"NULL handle"
+    lib.lde_destroy(None)                                          # no-op
+
+
+def test_product_fails_loudly_without_gpu_or_library(monkeypatch):
+    """No CPU fallback anywhere in the product path."""
+    import torch
+    from latentdiffeq_amd import _lib
+    import latentdiffeq_amd as la
+    if not torch.cuda.is_available():
+        lib = _lib.load()
+        d = _lib.ProblemDesc()
+        lib.lde_problem_desc_default(C.byref(d))
+        h = C.c_void_p()
+        assert lib.lde_create(C.byref(d), C.byref(h)) == -3       # LDE_ERR_NO_DEVICE
+        dec = la.Decoder(la.GOKU_basic(), (None, la.Pendulum(), None))
+        with pytest.raises(_lib.LdeError):
+            la.diffeq_layer(dec, (torch.zeros(2, 4), torch.ones(1, 4)), np.arange(5) * 0.05)
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "LIB_PATH", "/nonexistent/liblde.so")
+    with pytest.raises(_lib.LdeError, match="no CPU fallback"):
+        _lib.load()
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "latentdiffeq.jl_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", txt, flags=re.M), f
+                assert "lde_oracle" not in txt, f
+
+
+def test_reference_shaped_host_api_surface():
+    import latentdiffeq_amd as la
+    p = la.Pendulum()
+    # the struct fields the reference reads  [REF src/models/GOKU.jl:105-108, :207-208]
+    assert hasattr(p, "prob") and hasattr(p, "solver") and hasattr(p, "sensealg") and hasattr(p, "kwargs")
+    assert len(p.prob.u0) == 2 and len(p.prob.p) == 1
+    assert isinstance(la.Pendulum(sensalg=la.BacksolveAdjoint()).sensealg, la.BacksolveAdjoint)  # `sensalg` spelling [REF pendulum.jl:11]
+    n = la.NODE(4, hidden_dim=8, augment_dim=2)
+    # [REF nODE.jl:3-32], [REF src/models/LatentODE.jl:62-66, :105-106]
+    for f in ("dudt", "solver", "neural_model", "latent_dim_in", "latent_dim_out", "augment_dim", "kwargs"):
+        assert hasattr(n, f)
+    assert n.latent_dim_out == 6 and n.layer_sizes == [6, 8, 8, 6]
+    w = n.flat_weights()
+    assert w.numel() == 6 * 8 + 8 + 8 * 8 + 8 + 8 * 6 + 6
+    lin = n.dudt[0]
+    assert np.allclose(w[:48].detach().numpy().reshape(6, 8).T, lin.weight.detach().numpy())  # vec(W) column-major
+    assert issubclass(la.GOKU_basic, la.GOKU) and issubclass(la.GOKU, la.LatentDE) and issubclass(la.LatentODE, la.LatentDE)
+    assert la.transform_after_diffeq("x", p) == "x"   # identity by default [REF GOKU.jl:136]
+
+    class Kuramoto(la.Pendulum):
+        def transform_after_diffeq(self, x):
+            return ("sin", x)
+    assert la.transform_after_diffeq("x", Kuramoto()) == ("sin", "x")
+    with pytest.raises(TypeError):
+        la.diffeq_layer(la.Decoder(object(), (None, p, None)), None, [0.0])

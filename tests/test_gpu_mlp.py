@@ -1,0 +1,124 @@
+"""GPU parity of the MLP right-hand sides (LatentODE path, physics+MLP) against the CPU oracle.
+
+Tolerances: fixed-step RK4 has no controller ⇒ fp32 round-off only: |Δẑ| ≤ 2e-5·max(1,|ẑ|). Adaptive Tsit5 at the
+OrdinaryDiffEq default tolerance: see tests/test_gpu_pendulum.py (≤ 3e-4 from the oracle, no farther from the float64
+truth than 1.5× the oracle + 1e-5); at 1e-6/1e-6 ≤ 2e-5."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def _native(W, **kw):
+    from tests.gpu_util import Native, make_desc, copy_desc_to_oracle
+    d = make_desc(**kw)
+    nat = Native(d)
+    if W is not None:
+        nat.set_weights(W)
+    return nat, copy_desc_to_oracle(d)
+
+
+def _z0(B, D, seed=1):
+    return (0.5 * np.random.default_rng(seed).standard_normal((B, D))).astype(np.float32)
+
+
+def _check_forward(z, zr, zt, tight):
+    scale = max(1.0, np.abs(zr).max())
+    if tight and zt is None:
+        assert np.abs(z - zr).max() <= 2e-5 * scale
+    elif tight:  # adaptive at 1e-6 on a relu network: kinks make the step sequence round-off sensitive
+        assert np.abs(z - zr).max() <= 1e-4 * scale
+        assert np.abs(z - zt).max() <= 1.5 * np.abs(zr - zt).max() + 2e-5 * scale
+    else:  # two correct fp32 solves differ by at most about the solver's own error at this tolerance
+        e_o = np.abs(zr - zt).max()
+        assert np.abs(z - zr).max() <= max(3e-4 * scale, e_o)
+        assert np.abs(z - zt).max() <= 1.5 * e_o + 1e-5 * scale
+
+
+@pytest.mark.parametrize("B", [16, 40, 256])
+def test_c2_rk4_fixed_step_coupled(o32, o64, B):
+    """BASELINE config 2: D=8, 8→200→200→8 relu, RK4 dt=0.05, coupled batch (several workgroups, ragged last tile)."""
+    layers = (8, 200, 200, 8)
+    W = O.mlp_weights(layers, seed=3)
+    kw = dict(rhs_kind=O.RHS_MLP, state_dim=8, param_dim=0, layers=layers, solver=O.SOLVER_RK4, adaptive=0, dt=0.05,
+              batching=O.BATCH_COUPLED)
+    nat, od = _native(W, **kw)
+    z0, ts = _z0(B, 8), O.time_grid(50)
+    z, ret, st = nat.forward(z0, None, ts)
+    zr, _, info = o32.forward(od, z0, None, ts, W=W)
+    assert (ret == 0).all() and np.array_equal(z[0], z0)
+    assert st["naccept"] == info["naccept"] == 49 and st["nfe"] == info["nfe"] == 197
+    _check_forward(z, zr, None, True)
+
+
+@pytest.mark.parametrize("batching", [O.BATCH_PER_TRAJECTORY, O.BATCH_COUPLED])
+@pytest.mark.parametrize("tol", [(1e-6, 1e-3), (1e-6, 1e-6)])
+@pytest.mark.parametrize("B", [16, 72])
+def test_tsit5_mlp_forward(o32, o64, batching, tol, B):
+    """Adaptive Tsit5 on a 32→128→128→32 relu MLP (config-4 shape); B=72 ⇒ 5 workgroups, coupled mode then needs the
+    grid-wide error norm."""
+    layers = (32, 128, 128, 32)
+    W = O.mlp_weights(layers, seed=3)
+    kw = dict(rhs_kind=O.RHS_MLP, state_dim=32, param_dim=0, layers=layers, batching=batching, abstol=tol[0], reltol=tol[1])
+    nat, od = _native(W, **kw)
+    z0, ts = _z0(B, 32), O.time_grid(50)
+    z, ret, st = nat.forward(z0, None, ts)
+    zr, _, info = o32.forward(od, z0, None, ts, W=W)
+    assert (ret == 0).all()
+    dt_ = O.make_desc(rhs_kind=O.RHS_MLP, state_dim=32, param_dim=0, layers=layers, batching=batching, abstol=1e-10, reltol=1e-10)
+    zt, _, _ = o64.forward(dt_, z0, None, ts, W=W.astype(np.float64))
+    _check_forward(z, zr, zt, tol[1] < 1e-4)
+    assert abs(st["naccept"] - info["naccept"]) <= 0.05 * info["naccept"] + 1
+    if batching == O.BATCH_COUPLED:
+        assert st["nfe"] == 6 * (st["naccept"] + st["nreject"]) + 2
+
+
+def test_c3_pendulum_plus_mlp_forward(o32, o64):
+    layers = (2, 64, 64, 2)
+    W = O.mlp_weights(layers, seed=3)
+    nat, od = _native(W, rhs_kind=O.RHS_PENDULUM_PLUS_MLP, layers=layers)
+    B = 100
+    z0, L = O.pendulum_inputs(B)
+    ts = O.time_grid(50)
+    z, ret, st = nat.forward(z0, L, ts)
+    zr, _, info = o32.forward(od, z0, L, ts, W=W)
+    assert (ret == 0).all()
+    zt, _, _ = o64.forward(O.make_desc(rhs_kind=O.RHS_PENDULUM_PLUS_MLP, layers=layers, abstol=1e-10, reltol=1e-10), z0, L, ts,
+                           W=W.astype(np.float64))
+    _check_forward(z, zr, zt, False)
+    assert abs(st["naccept"] - info["naccept"]) <= 0.03 * info["naccept"] + 1
+
+
+def test_augmented_tanh_and_odd_sizes(o32):
+    """AugmentedNDELayer: extra zero rows [REF LatentODE.jl:71]; widths that are not multiples of 16/4; 4 Dense layers."""
+    layers = (7, 33, 50, 21, 7)
+    W = O.mlp_weights(layers, seed=4)
+    kw = dict(rhs_kind=O.RHS_MLP, state_dim=5, param_dim=0, augment_dim=2, layers=layers, activation=O.ACT_TANH,
+              abstol=1e-6, reltol=1e-6)
+    nat, od = _native(W, **kw)
+    z0, ts = _z0(21, 5), O.time_grid(20)
+    z, ret, _ = nat.forward(z0, None, ts)
+    zr, _, _ = o32.forward(od, z0, None, ts, W=W)
+    assert z.shape == (20, 21, 7) and np.array_equal(z[0, :, :5], z0) and (z[0, :, 5:] == 0).all()
+    _check_forward(z, zr, None, True)
+
+
+def test_linear_rhs_vs_expm():
+    """Independent of the oracle: one Dense layer ⇒ ż = Az + b, compared with scipy.linalg.expm."""
+    from scipy.linalg import expm
+    rng = np.random.default_rng(0)
+    D, B, T = 4, 19, 20
+    A = rng.standard_normal((D, D)) * 0.5
+    b = rng.standard_normal(D) * 0.1
+    W = np.concatenate([A.flatten(order="F"), b]).astype(np.float32)
+    nat, _ = _native(W, rhs_kind=O.RHS_MLP, state_dim=D, param_dim=0, layers=(D, D), abstol=1e-7, reltol=1e-7)
+    z0 = rng.standard_normal((B, D)).astype(np.float32)
+    ts = O.time_grid(T, 0.1)
+    z, ret, _ = nat.forward(z0, None, ts)
+    M = np.zeros((D + 1, D + 1))
+    M[:D, :D], M[:D, D] = A.astype(np.float32), b.astype(np.float32)
+    for j, t in enumerate(ts):
+        E = expm(M * t)
+        assert np.abs((E[:D, :D] @ z0.T.astype(np.float64)).T + E[:D, D] - z[j]).max() <= 2e-5

@@ -55,6 +55,9 @@ struct MlpDims {
   int coupled;            // LDE_BATCH_COUPLED
   int solver;
   int nW;
+  int bias_lin[MAXL];     // offset of layer l's bias gradient in the compact [Σ out] LDS vector
+  int nbias;
+  int tile_off[MAXL + 1]; // first weight-gradient tile (16×16 of Wᵀ) of layer l in the global tile enumeration
 };
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -607,6 +610,507 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
   }
 }
 
+
+// ================================================ adjoint ==================================================
+struct BwdArgs {
+  const float* z_out;
+  const float* dz_out;
+  const float* theta;
+  const double* ts;
+  const float* frag;
+  const float* fragT;
+  const float* Wflat;
+  float* dz0;
+  float* dtheta;
+  float* slab;        // [nWG][nW] this launch's per-workgroup weight-gradient slabs
+  int32_t *st_nfe, *st_nacc, *st_nrej, *st_ret;
+  GridSync gs;
+};
+
+// f, −(∂f/∂z)ᵀλ, −(∂f/∂θ)ᵀλ for the tile, and the weighted outer products of this stage.
+//   src/dst rows: [0,Dp) z | [Dp,2Dp) λ | [2Dp,2Dp+P) g.   wst[col] = quadrature weight of this stage (0 ⇒ none)
+template <int NDW>
+__device__ __forceinline__ void eval_bwd(const MlpDims& dm, const BwdArgs& a, const Panels& P, const Ctl* c,
+                                         const float* src, float* dst, const float* wst, bool any_w,
+                                         f32x4 (&acc)[NDW], float* bstep, const int* tile_off) {
+  const int Dp = dm.Dp, nL = dm.nL;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // 1. forward through the MLP (relu masks are recomputed here, not stored by the forward solve)
+  eval_rhs(dm, a.frag, a.Wflat, P, c, src, dst);
+  // 2. back-propagate λ; δ_L = λ_stage
+  const float* dl = src + Dp * LDP;
+  for (int l = nL - 1; l >= 0; l--) {
+    const int in = dm.sizes[l], out = dm.sizes[l + 1];
+    const float* al = l == 0 ? src : P.hid(l - 1);   // input activation of layer l
+    if (any_w) {
+      // gWᵀ tile [i][o] += Σ_n a_l[i][n] · (w_n δ[o][n]); tiles of layer l owned by this wave
+      const int IT = cdiv(in, 16);
+      const int t0 = tile_off[l], t1 = tile_off[l + 1];
+      float wl[4];
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4++) wl[s4] = wst[s4 * 4 + (lane >> 4)];
+#pragma unroll
+      for (int m = 0; m < NDW; m++) {
+        const int t = wave + 4 * m;
+        if (t >= t0 && t < t1) {
+          const int tt = t - t0, ot = tt / IT, it = tt % IT;
+          const float* ap = al + (it * 16 + (lane & 15)) * LDP + (lane >> 4);
+          const float* bp = dl + (ot * 16 + (lane & 15)) * LDP + (lane >> 4);
+#pragma unroll
+          for (int s4 = 0; s4 < 4; s4++)
+            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[s4 * 4], bp[s4 * 4] * wl[s4], acc[m], 0, 0, 0);
+        }
+      }
+      for (int row = threadIdx.x; row < out; row += NTHREADS) {
+        float sacc = 0.f;
+#pragma unroll
+        for (int n = 0; n < NB; n++) sacc += wst[n] * dl[row * LDP + n];
+        bstep[dm.bias_lin[l] + row] += sacc;   // each (layer,row) is owned by exactly one thread
+      }
+    }
+    // δ_in = W_lᵀ δ  (⊙ act'(a_l) for hidden layers); layer 0 gives (∂f/∂z)ᵀλ
+    if (l > 0) {
+      float* dn = P.del((nL - 1 - l) & 1);
+      const int actk = dm.act;
+      panel_gemm(a.fragT + dm.fragT_off[l], in, out, dl, [&](int row, int col, float v) {
+        dn[row * LDP + col] = v * act_grad(actk, al[row * LDP + col]);
+      });
+      __syncthreads();
+      dl = dn;
+    } else {
+      float* dlam = dst + Dp * LDP;
+      panel_gemm(a.fragT + dm.fragT_off[0], in, out, dl, [&](int row, int col, float v) { dlam[row * LDP + col] = -v; });
+      __syncthreads();
+    }
+  }
+  // 3. known-physics part: J = [[0,1],[ngl·cos x, 0]], ∂f₂/∂L = gl2·sin x
+  if (dm.has_pend) {
+    if (threadIdx.x < NB) {
+      const int col = threadIdx.x;
+      float sn, cs;
+      fast_sincos(src[0 * LDP + col], sn, cs);
+      const float l0 = src[(Dp + 0) * LDP + col], l1 = src[(Dp + 1) * LDP + col];
+      // eval_rhs already added the pendulum to f (rows 0,1)
+      dst[(Dp + 0) * LDP + col] -= c->ngl[col] * cs * l1;
+      dst[(Dp + 1) * LDP + col] -= l0;
+      dst[(2 * Dp) * LDP + col] = -(c->gl2[col] * sn * l1);
+    }
+    __syncthreads();
+  }
+}
+
+// Reverse-time solve of [z; λ; g_θ] for one tile, with forced stops + jumps at the save times.
+template <int NDW>
+__global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int T = o.T, B = o.B, Dp = dm.Dp, D = dm.D, NP = dm.P;
+  Ctl* c = reinterpret_cast<Ctl*>(smem);
+  double* s_ts = reinterpret_cast<double*>(smem + ((sizeof(Ctl) + 15) & ~size_t(15)));
+  float* base = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(s_ts) + (((size_t)T * 8 + 15) & ~size_t(15)));
+  Panels P;
+  const int NS = 2 * Dp + NP;
+  const int NSr = (NS + 3) & ~3;
+  float* p = base;
+  P.pstride = NSr * LDP;
+  P.hstride = dm.hmax * LDP;
+  P.y = p; p += P.pstride;
+  P.yn = p; p += P.pstride;
+  P.tmp = p; p += P.pstride;
+  P.kbase = p; p += 7 * P.pstride;
+  P.scr = p; p += P.pstride;
+  P.hidbase = p; p += (dm.nL > 1 ? dm.nL - 1 : 0) * P.hstride;
+  P.delbase = p; p += 2 * P.hstride;
+  float* bstep = p; p += (dm.nbias + 3) & ~3;
+  float* wst = p; p += NB;
+  const int nfloat = (int)(p - base);
+  for (int i = threadIdx.x; i < nfloat; i += NTHREADS) base[i] = 0.f;
+  for (int i = threadIdx.x; i < T; i += NTHREADS) s_ts[i] = a.ts[i];
+  __syncthreads();
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = blockIdx.x * NB;
+  const int nel = NS * NB;
+  const bool coupled = dm.coupled != 0;
+  const double tT = s_ts[T - 1], dtmax = fabs(tT - s_ts[0]);
+  unsigned gen = 0;
+  float* slab = a.slab + (size_t)blockIdx.x * dm.nW;
+  for (int i = tid; i < dm.nW; i += NTHREADS) slab[i] = 0.f;
+
+  f32x4 acc[NDW];
+#pragma unroll
+  for (int m = 0; m < NDW; m++) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // commit the step's outer products (held as Wᵀ tiles [i][o] in MFMA accumulators) and bias sums to the slab
+  auto commit = [&]() {
+    for (int l = 0; l < dm.nL; l++) {
+      const int in = dm.sizes[l], out = dm.sizes[l + 1], IT = cdiv(in, 16);
+      const int t0 = dm.tile_off[l], t1 = dm.tile_off[l + 1];
+      float* gW = slab + dm.w_off[l];
+#pragma unroll
+      for (int m = 0; m < NDW; m++) {
+        const int t = wave + 4 * m;
+        if (t >= t0 && t < t1) {
+          const int tt = t - t0, ot = tt / IT, it = tt % IT;
+          const int oc = ot * 16 + (lane & 15);
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int ir = it * 16 + (lane >> 4) * 4 + r;
+            if (oc < out && ir < in) gW[oc + (size_t)out * ir] += acc[m][r];
+          }
+          acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+      float* gb = slab + dm.b_off[l];
+      for (int row = tid; row < out; row += NTHREADS) {
+        gb[row] += bstep[dm.bias_lin[l] + row];
+        bstep[dm.bias_lin[l] + row] = 0.f;
+      }
+    }
+  };
+  auto discard = [&]() {
+#pragma unroll
+    for (int m = 0; m < NDW; m++) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = tid; i < dm.nbias; i += NTHREADS) bstep[i] = 0.f;
+  };
+
+  // ---- load the terminal condition: z = ẑ(t_T), λ = Δ_T, g = 0 ------------------------------------------
+  for (int e = tid; e < NB * Dp; e += NTHREADS) {
+    const int col = e / Dp, row = e % Dp;
+    if (b0 + col < B) {
+      const size_t src = (size_t)Dp * ((size_t)(b0 + col) + (size_t)B * (T - 1)) + row;
+      P.y[row * LDP + col] = a.z_out[src];
+      P.y[(Dp + row) * LDP + col] = a.dz_out[src];
+    }
+  }
+  __syncthreads();
+  if (tid < NB) {
+    const int col = tid;
+    const bool valid = b0 + col < B;
+    bool bad = false;
+    for (int r = 0; r < Dp; r++) bad = bad || !isfinite(P.y[r * LDP + col]);
+    c->t[col] = tT;
+    c->dt[col] = 0.0;
+    c->qold[col] = 1e-4f;
+    // a failed forward trajectory is a constant NaN block ⇒ zero gradient  [REF GOKU.jl:114]
+    c->status[col] = !valid ? 1 : (bad ? 1 + LDE_RET_NONFINITE : (T > 1 ? 0 : 1));
+    c->j[col] = T - 2;
+    c->nfe[col] = c->nacc[col] = c->nrej[col] = c->iters[col] = 0;
+    c->h[col] = 0.f;
+    float L = 1.f;
+    if (dm.has_pend && valid) L = a.theta[(size_t)(b0 + col) * NP];
+    c->ngl[col] = -10.0f / L;
+    c->gl2[col] = 10.0f / (L * L);
+    wst[col] = 0.f;
+  }
+  __syncthreads();
+  if (tid < NB && c->status[tid] > 1) {   // neutralise the NaN column so that it cannot trip the tile-wide logic
+    for (int r = 0; r < NS; r++) P.y[r * LDP + tid] = 0.f;
+  }
+  __syncthreads();
+
+  if (T > 1) {
+    // ---- initial step size (Hairer) on the augmented state, direction −1 ------------------------------------
+    if (o.adaptive && !(o.dt_fixed > 0)) {
+      eval_bwd<NDW>(dm, a, P, c, P.y, P.k(0), wst, false, acc, bstep, dm.tile_off);
+      if (tid < NB && c->status[tid] == 0) c->nfe[tid]++;
+      for (int e = tid; e < nel; e += NTHREADS) {
+        const int row = e / NB, col = e % NB, idx = row * LDP + col;
+        const float yv = P.y[idx];
+        const float sk = fast_rcp(o.abstol + fabsf(yv) * o.reltol);
+        P.scr[idx] = sk;
+        const float a0 = yv * sk, a1 = P.k(0)[idx] * sk;
+        P.tmp[idx] = a0 * a0;
+        P.yn[idx] = a1 * a1;
+      }
+      __syncthreads();
+      if (tid < NB) {
+        float s0 = 0.f, s1 = 0.f;
+        for (int r = 0; r < NS; r++) { s0 += P.tmp[r * LDP + tid]; s1 += P.yn[r * LDP + tid]; }
+        c->eest[tid] = s0;
+        c->wq[tid] = s1;
+      }
+      __syncthreads();
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (coupled) {
+        if (tid == 0)
+          for (int col = 0; col < NB; col++)
+            if (c->status[col] == 0) { v[0] += c->eest[col]; v[1] += c->wq[col]; }
+        grid_sum4(a.gs, gen, v, c->bcast);
+      }
+      if (tid < NB) {
+        const float n = coupled ? (float)NS * (float)B : (float)NS;
+        const float d0 = sqrtf((coupled ? v[0] : c->eest[tid]) / n), d1 = sqrtf((coupled ? v[1] : c->wq[tid]) / n);
+        double dt0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6 : 0.01 * (double)(d0 * fast_rcp(d1));
+        if (dt0 > dtmax) dt0 = dtmax;
+        c->dt[tid] = dt0;
+        c->h[tid] = c->status[tid] == 0 ? -(float)dt0 : 0.f;
+        c->th[tid] = d1;
+      }
+      __syncthreads();
+      for (int e = tid; e < nel; e += NTHREADS) {
+        const int row = e / NB, col = e % NB, idx = row * LDP + col;
+        P.tmp[idx] = P.y[idx] + c->h[col] * P.k(0)[idx];
+      }
+      __syncthreads();
+      eval_bwd<NDW>(dm, a, P, c, P.tmp, P.k(1), wst, false, acc, bstep, dm.tile_off);
+      if (tid < NB && c->status[tid] == 0) c->nfe[tid]++;
+      for (int e = tid; e < nel; e += NTHREADS) {
+        const int row = e / NB, col = e % NB, idx = row * LDP + col;
+        const float dd = (P.k(1)[idx] - P.k(0)[idx]) * P.scr[idx];
+        P.yn[idx] = dd * dd;
+      }
+      __syncthreads();
+      if (tid < NB) {
+        float s2 = 0.f;
+        for (int r = 0; r < NS; r++) s2 += P.yn[r * LDP + tid];
+        c->eest[tid] = s2;
+      }
+      __syncthreads();
+      float w[4] = {0.f, 0.f, 0.f, 0.f};
+      if (coupled) {
+        if (tid == 0)
+          for (int col = 0; col < NB; col++)
+            if (c->status[col] == 0) w[0] += c->eest[col];
+        grid_sum4(a.gs, gen, w, c->bcast);
+      }
+      if (tid < NB) {
+        const float n = coupled ? (float)NS * (float)B : (float)NS;
+        const double dt0 = c->dt[tid];
+        const float d2 = sqrtf((coupled ? w[0] : c->eest[tid]) / n) * fast_rcp((float)dt0);
+        const float dm_ = fmaxf(c->th[tid], d2);
+        const double dt1 = (dm_ <= 1e-15f) ? fmax(1e-6, dt0 * 1e-3) : (double)(0.39810717055349726f * fast_pow(dm_, -0.2f));
+        double dt = fmin(100.0 * dt0, dt1);
+        c->dt[tid] = dt > dtmax ? dtmax : dt;
+      }
+      __syncthreads();
+    } else if (tid < NB) {
+      c->dt[tid] = o.adaptive ? fmin(o.dt_fixed, dtmax) : o.dt_fixed;
+    }
+    __syncthreads();
+
+    // ---- main loop ---------------------------------------------------------------------------------------------
+    bool replay = false;
+    for (;;) {
+      if (!replay) {
+        if (tid < NB) {
+          const int col = tid;
+          if (c->status[col] == 0 && c->iters[col]++ >= o.maxiters) c->status[col] = 1 + LDE_RET_MAXITERS;
+          if (c->status[col] == 0) {
+            const double tstop = s_ts[c->j[col]];
+            const double dist = c->t[col] - tstop;
+            double hmag = c->dt[col];
+            int hit = 0;
+            if (hmag >= dist * (1.0 - 1e-12)) { hmag = dist; hit = 1; }
+            c->hit[col] = hit;
+            c->tnew[col] = hmag;            // step magnitude actually attempted
+            c->h[col] = -(float)hmag;
+            c->wq[col] = (float)hmag;       // quadrature weight scale |h|
+          } else {
+            c->h[col] = 0.f;
+            c->wq[col] = 0.f;
+            c->hit[col] = 0;
+          }
+        }
+        __syncthreads();
+        if (tid == 0) {
+          int any = 0;
+          for (int col = 0; col < NB; col++) any |= (c->status[col] == 0);
+          c->any_active = any;
+        }
+        __syncthreads();
+        if (!c->any_active) break;
+      }
+
+      // ---- stages (k₁ is evaluated fresh: it carries this step's quadrature weight) ---------------------------
+      if (dm.solver == LDE_SOLVER_TSIT5) {
+        for (int s = 0; s <= 6; s++) {
+          const float* src = P.y;
+          if (s > 0) {
+            float* dst = s < 6 ? P.tmp : P.yn;
+            for (int e = tid; e < nel; e += NTHREADS) {
+              const int row = e / NB, col = e % NB, idx = row * LDP + col;
+              float accv = ts5::A[s][0] * P.k(0)[idx];
+              for (int jj = 1; jj < s; jj++) accv += ts5::A[s][jj] * P.k(jj)[idx];
+              dst[idx] = P.y[idx] + c->h[col] * accv;
+            }
+            src = dst;
+          }
+          const float bs = s < 6 ? ts5::A[6][s] : 0.f;
+          if (tid < NB) wst[tid] = (s < 6 && (!replay || c->accepted[tid])) ? c->wq[tid] * bs : 0.f;
+          __syncthreads();
+          eval_bwd<NDW>(dm, a, P, c, src, P.k(s), wst, s < 6, acc, bstep, dm.tile_off);
+        }
+        if (!replay && tid < NB && c->status[tid] == 0) c->nfe[tid] += 7;
+      } else {
+        for (int s = 0; s <= 3; s++) {
+          const float* src = P.y;
+          if (s > 0) {
+            const float cs = s == 3 ? 1.0f : 0.5f;
+            for (int e = tid; e < nel; e += NTHREADS) {
+              const int row = e / NB, col = e % NB, idx = row * LDP + col;
+              P.tmp[idx] = P.y[idx] + (cs * c->h[col]) * P.k(s - 1)[idx];
+            }
+            src = P.tmp;
+          }
+          const float bs = (s == 0 || s == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
+          if (tid < NB) wst[tid] = (!replay || c->accepted[tid]) ? c->wq[tid] * bs : 0.f;
+          __syncthreads();
+          eval_bwd<NDW>(dm, a, P, c, src, P.k(s), wst, true, acc, bstep, dm.tile_off);
+        }
+        for (int e = tid; e < nel; e += NTHREADS) {
+          const int row = e / NB, col = e % NB, idx = row * LDP + col;
+          P.yn[idx] = P.y[idx] + (c->h[col] * (1.0f / 6.0f)) * (P.k(0)[idx] + 2.0f * (P.k(1)[idx] + P.k(2)[idx]) + P.k(3)[idx]);
+        }
+        __syncthreads();
+        if (!replay && tid < NB && c->status[tid] == 0) c->nfe[tid] += 4;
+      }
+
+      if (!replay) {
+        // ---- error estimate + control ----------------------------------------------------------------------------
+        for (int e = tid; e < nel; e += NTHREADS) {
+          const int row = e / NB, col = e % NB, idx = row * LDP + col;
+          float r2 = 0.f;
+          const float yv = P.y[idx], ynv = P.yn[idx];
+          if (o.adaptive) {
+            float er = ts5::BT[0] * P.k(0)[idx];
+#pragma unroll
+            for (int jj = 1; jj < 7; jj++) er += ts5::BT[jj] * P.k(jj)[idx];
+            er *= c->h[col];
+            const float sk = o.abstol + fmaxf(fabsf(yv), fabsf(ynv)) * o.reltol;
+            const float r = er * fast_rcp(sk);
+            r2 = r * r;
+          }
+          P.scr[idx] = isfinite(ynv) ? r2 : __int_as_float(0x7fc00000);
+        }
+        __syncthreads();
+        if (tid < NB) {
+          float s2 = 0.f;
+          for (int r = 0; r < NS; r++) s2 += P.scr[r * LDP + tid];
+          c->eest[tid] = s2;
+        }
+        __syncthreads();
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (coupled) {
+          if (tid == 0)
+            for (int col = 0; col < NB; col++)
+              if (c->status[col] == 0) v[0] += c->eest[col];
+          grid_sum4(a.gs, gen, v, c->bcast);
+        }
+        if (tid < NB && c->status[tid] == 0) {
+          const int col = tid;
+          const float n = coupled ? (float)NS * (float)B : (float)NS;
+          const float s2 = coupled ? v[0] : c->eest[col];
+          const float EEst = o.adaptive ? sqrtf(s2 / n) : (s2 == s2 ? 0.f : s2);
+          const double hmag = c->tnew[col];
+          int accepted = 0;
+          if (!(EEst == EEst)) {
+            if (o.adaptive && hmag > o.dtmin) { c->nrej[col]++; c->dt[col] = hmag * (double)o.qmin; }
+            else c->status[col] = 1 + LDE_RET_NONFINITE;
+          } else if (o.adaptive) {
+            float q11;
+            const float q = pi_q(EEst, c->qold[col], o, q11);
+            if (EEst > 1.0f) {
+              c->nrej[col]++;
+              const double nd = hmag * (double)fast_rcp(fminf(o.q_hi, q11 * o.inv_gamma));
+              c->dt[col] = nd;
+              if (nd < o.dtmin) c->status[col] = 1 + LDE_RET_DTMIN;
+            } else {
+              c->qold[col] = fmaxf(EEst, 1e-4f);
+              double dtp = hmag * (double)fast_rcp(q);
+              if (dtp > dtmax) dtp = dtmax;
+              c->dt[col] = dtp;
+              accepted = 1;
+            }
+          } else {
+            c->dt[col] = o.dt_fixed;
+            accepted = 1;
+          }
+          c->accepted[col] = accepted;
+          if (accepted) c->nacc[col]++;
+        } else if (tid < NB)
+          c->accepted[tid] = 0;
+        __syncthreads();
+        if (tid == 0) {
+          int all = 1, any = 0;
+          for (int col = 0; col < NB; col++) {
+            if (c->wq[col] != 0.f) { all &= c->accepted[col]; any |= c->accepted[col]; }
+          }
+          c->all_accepted = all;
+          c->any_save = any;
+        }
+        __syncthreads();
+        if (c->all_accepted) {
+          if (o.adaptive) commit();            // fixed step: everything is accepted, commit once at the end
+        } else {
+          discard();
+          if (c->any_save) { replay = true; __syncthreads(); continue; }   // redo the stages for the accepted columns only
+        }
+      } else {
+        commit();
+        replay = false;
+      }
+      __syncthreads();
+
+      // ---- advance accepted columns; jump at a save time --------------------------------------------------------
+      for (int e = tid; e < nel; e += NTHREADS) {
+        const int row = e / NB, col = e % NB, idx = row * LDP + col;
+        if (c->accepted[col]) P.y[idx] = P.yn[idx];
+      }
+      __syncthreads();
+      for (int e = tid; e < NB * Dp; e += NTHREADS) {
+        const int col = e / Dp, row = e % Dp;
+        if (c->accepted[col] && c->hit[col]) {
+          const size_t src = (size_t)Dp * ((size_t)(b0 + col) + (size_t)B * c->j[col]) + row;
+          P.y[(Dp + row) * LDP + col] += a.dz_out[src];
+          if (o.checkpoint) P.y[row * LDP + col] = a.z_out[src];
+        }
+      }
+      __syncthreads();
+      if (tid < NB && c->accepted[tid]) {
+        const int col = tid;
+        if (c->hit[col]) {
+          c->t[col] = s_ts[c->j[col]];
+          c->j[col]--;
+          if (c->j[col] < 0) c->status[col] = 1;
+        } else
+          c->t[col] -= c->tnew[col];
+      }
+      __syncthreads();
+    }
+  }
+  if (!o.adaptive) commit();
+  __syncthreads();
+
+  // ---- results ----------------------------------------------------------------------------------------------------
+  for (int e = tid; e < NB * D; e += NTHREADS) {
+    const int col = e / D, row = e % D;
+    if (b0 + col < B) a.dz0[(size_t)(b0 + col) * D + row] = c->status[col] > 1 ? 0.f : P.y[(Dp + row) * LDP + col];
+  }
+  if (NP) {
+    for (int e = tid; e < NB * NP; e += NTHREADS) {
+      const int col = e / NP, row = e % NP;
+      if (b0 + col < B) a.dtheta[(size_t)(b0 + col) * NP + row] = c->status[col] > 1 ? 0.f : P.y[(2 * Dp + row) * LDP + col];
+    }
+  }
+  if (tid < NB && b0 + tid < B) {
+    const int col = tid, b = b0 + col;
+    a.st_ret[b] = c->status[col] > 1 ? c->status[col] - 1 : 0;
+    const bool rep = !coupled || b == 0;
+    a.st_nfe[b] = rep ? c->nfe[col] : 0;
+    a.st_nacc[b] = rep ? c->nacc[col] : 0;
+    a.st_nrej[b] = rep ? c->nrej[col] : 0;
+  }
+}
+
+// dW[i] += Σ_wg slab[wg][i]   (fixed order ⇒ deterministic)
+__global__ void k_reduce_slabs(const float* __restrict__ slab, int nwg, int nW, float* __restrict__ dW) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nW) return;
+  float s = 0.f;
+  for (int w = 0; w < nwg; w++) s += slab[(size_t)w * nW + i];
+  dW[i] += s;
+}
+
 // ================================================ host side =================================================
 struct MlpPlan {
   MlpDims dm;
@@ -648,8 +1152,17 @@ int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err) 
     woff += o;
     if (l + 1 < dm.nL && o > hmax) hmax = o;
   }
-  dm.hmax = (hmax + 3) & ~3;   // padded to whole K-steps
+  dm.hmax = (hmax + 15) & ~15;   // padded to whole 16-row tiles
   dm.nW = woff;
+  int blin = 0, toff = 0;
+  for (int l = 0; l < dm.nL; l++) {
+    dm.bias_lin[l] = blin;
+    blin += dm.sizes[l + 1];
+    dm.tile_off[l] = toff;
+    toff += cdiv(dm.sizes[l + 1], 16) * cdiv(dm.sizes[l], 16);
+  }
+  dm.tile_off[dm.nL] = toff;
+  dm.nbias = blin;
   p->nfrag = off;
   p->nfragT = offT;
   if (dm.Dp > 256 || hmax > 1024) {
@@ -760,10 +1273,75 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
   return LDE_OK;
 }
 
-int mlp_adjoint(MlpPlan*, const float*, const float*, const float*, const double*, const KOpts&, const float*, float*,
-                float*, float*, int32_t*, int32_t*, int32_t*, int32_t*, hipStream_t, std::string& err) {
-  err = "MLP adjoint kernel not built yet";
-  return LDE_ERR_UNSUPPORTED;
+static size_t bwd_lds_bytes(const MlpDims& dm, int T) {
+  size_t b = (sizeof(Ctl) + 15) & ~size_t(15);
+  b += ((size_t)T * 8 + 15) & ~size_t(15);
+  const int NSr = (2 * dm.Dp + dm.P + 3) & ~3;
+  b += (size_t)(11 * NSr + ((dm.nL > 1 ? dm.nL - 1 : 0) + 2) * dm.hmax) * LDP * sizeof(float);
+  b += (size_t)(((dm.nbias + 3) & ~3) + NB) * sizeof(float);
+  return b;
+}
+
+template <int NDW>
+static int launch_adjoint(MlpPlan* p, const KOpts& o, const BwdArgs& a, int nwg, size_t lds, hipStream_t stream,
+                          std::string& err) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k_mlp_adjoint<NDW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+        hipSuccess) {
+      err = "hipFuncSetAttribute(k_mlp_adjoint) failed";
+      return LDE_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_mlp_adjoint<NDW>), dim3(nwg), dim3(NTHREADS), lds, stream, p->dm, o, a);
+  return LDE_OK;
+}
+
+int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float* theta, const double* ts_dev,
+                const KOpts& o, const float* dz_out, float* dz0, float* dtheta, float* dW, int32_t* nfe, int32_t* nacc,
+                int32_t* nrej, int32_t* ret, hipStream_t stream, std::string& err) {
+  const MlpDims& dm = p->dm;
+  const int nwg = cdiv(o.B, NB);
+  const bool sync = dm.coupled && o.adaptive && nwg > 1;
+  if (sync && nwg > 256) {
+    err = "coupled adaptive solve: batch per GPU limited to 4096 trajectories (one resident workgroup per CU)";
+    return LDE_ERR_UNSUPPORTED;
+  }
+  const size_t lds = bwd_lds_bytes(dm, o.T);
+  if (lds > 160 * 1024) {
+    err = "MLP adjoint: tile state does not fit the 160 KiB LDS";
+    return LDE_ERR_UNSUPPORTED;
+  }
+  BwdArgs a;
+  a.z_out = z_out; a.dz_out = dz_out; a.theta = theta; a.ts = ts_dev; a.frag = p->frag; a.fragT = p->fragT; a.Wflat = W_dev;
+  a.dz0 = dz0; a.dtheta = dtheta; a.slab = p->slab;
+  a.st_nfe = nfe; a.st_nacc = nacc; a.st_nrej = nrej; a.st_ret = ret;
+  a.gs.counter = p->counter; a.gs.slots = p->slots; a.gs.abort_flag = p->abort_flag; a.gs.nwg = sync ? nwg : 1;
+  if (sync && hipMemsetAsync(p->counter, 0, sizeof(unsigned), stream) != hipSuccess) {
+    err = "hipMemsetAsync(counter) failed";
+    return LDE_ERR_HIP;
+  }
+  const int per_wave = cdiv(dm.tile_off[dm.nL], 4);   // weight-gradient tiles held in each wave's accumulators
+  int rc;
+  if (per_wave <= 8) rc = launch_adjoint<8>(p, o, a, nwg, lds, stream, err);
+  else if (per_wave <= 24) rc = launch_adjoint<24>(p, o, a, nwg, lds, stream, err);
+  else if (per_wave <= 52) rc = launch_adjoint<52>(p, o, a, nwg, lds, stream, err);
+  else {
+    err = "MLP adjoint: more than 208 16x16 weight-gradient tiles (hidden width too large for the register-resident accumulators)";
+    return LDE_ERR_UNSUPPORTED;
+  }
+  if (rc) return rc;
+  if (hipGetLastError() != hipSuccess) {
+    err = "k_mlp_adjoint launch failed";
+    return LDE_ERR_HIP;
+  }
+  hipLaunchKernelGGL(k_reduce_slabs, dim3(cdiv(dm.nW, 256)), dim3(256), 0, stream, p->slab, nwg, dm.nW, dW);
+  if (hipGetLastError() != hipSuccess) {
+    err = "k_reduce_slabs launch failed";
+    return LDE_ERR_HIP;
+  }
+  return LDE_OK;
 }
 
 }  // namespace lde

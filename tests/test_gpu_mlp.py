@@ -122,3 +122,116 @@ def test_linear_rhs_vs_expm():
     for j, t in enumerate(ts):
         E = expm(M * t)
         assert np.abs((E[:D, :D] @ z0.T.astype(np.float64)).T + E[:D, D] - z[j]).max() <= 2e-5
+
+
+# ------------------------------------------------------------------------------------------------ adjoint
+def _check_grads(g, r, t, lim_o, lim_t, what):
+    s = np.abs(t).max()
+    assert np.abs(g - r).max() <= lim_o * s, what
+    assert np.abs(g - t).max() <= 1.5 * np.abs(r - t).max() + lim_t * s, what
+
+
+@pytest.mark.parametrize("B", [16, 40])
+def test_c2_rk4_adjoint(o32, o64, B):
+    """Config 2 backward: fixed-step RK4 continuous adjoint, dW accumulated over all 49·4 stage evaluations."""
+    layers = (8, 200, 200, 8)
+    W = O.mlp_weights(layers, seed=3)
+    kw = dict(rhs_kind=O.RHS_MLP, state_dim=8, param_dim=0, layers=layers, solver=O.SOLVER_RK4, adaptive=0, dt=0.05,
+              batching=O.BATCH_COUPLED)
+    nat, od = _native(W, **kw)
+    z0, ts = _z0(B, 8), O.time_grid(50)
+    dz = O.cotangent(50, B, 8)
+    z, _, _ = nat.forward(z0, None, ts)
+    g0, _, gW, st = nat.adjoint(z, None, ts, dz)
+    r0, _, rW, info = o32.adjoint(od, z, None, ts, dz, W=W)
+    assert st["naccept"] == info["naccept"] == 49
+    d64 = O.make_desc(**{**kw, "adaptive": False, "dt": 0.05 / 8})
+    z64, _, _ = o64.forward(d64, z0, None, ts, W=W.astype(np.float64))
+    t0, _, tW, _ = o64.adjoint(d64, z64, None, ts, dz, W=W.astype(np.float64))
+    _check_grads(g0, r0, t0, 2e-4, 1e-3, "dz0")
+    _check_grads(gW, rW, tW, 2e-4, 1e-3, "dW")
+
+
+@pytest.mark.parametrize("batching", [O.BATCH_PER_TRAJECTORY, O.BATCH_COUPLED])
+@pytest.mark.parametrize("B", [16, 72])
+def test_tsit5_mlp_adjoint(o32, o64, batching, B):
+    layers = (32, 128, 128, 32)
+    W = O.mlp_weights(layers, seed=3)
+    kw = dict(rhs_kind=O.RHS_MLP, state_dim=32, param_dim=0, layers=layers, batching=batching)
+    nat, od = _native(W, **kw)
+    z0, ts = _z0(B, 32), O.time_grid(50)
+    dz = O.cotangent(50, B, 32)
+    z, _, _ = nat.forward(z0, None, ts)
+    g0, _, gW, st = nat.adjoint(z, None, ts, dz)
+    r0, _, rW, info = o32.adjoint(od, z, None, ts, dz, W=W)
+    assert st["nfailed"] == 0
+    assert abs(st["naccept"] - info["naccept"]) <= 0.1 * info["naccept"] + 2
+    d64 = O.make_desc(**{**kw, "abstol": 1e-10, "reltol": 1e-10})
+    z64, _, _ = o64.forward(d64, z0, None, ts, W=W.astype(np.float64))
+    t0, _, tW, _ = o64.adjoint(d64, z64, None, ts, dz, W=W.astype(np.float64))
+    _check_grads(g0, r0, t0, 5e-3, 5e-3, "dz0")
+    _check_grads(gW, rW, tW, 5e-3, 5e-3, "dW")
+
+
+def test_c3_pendulum_plus_mlp_adjoint(o32, o64):
+    layers = (2, 64, 64, 2)
+    W = O.mlp_weights(layers, seed=3)
+    kw = dict(rhs_kind=O.RHS_PENDULUM_PLUS_MLP, layers=layers)
+    nat, od = _native(W, **kw)
+    B = 100
+    z0, L = O.pendulum_inputs(B)
+    ts = O.time_grid(50)
+    dz = O.cotangent(50, B, 2)
+    z, _, _ = nat.forward(z0, L, ts)
+    g0, gL, gW, st = nat.adjoint(z, L, ts, dz)
+    r0, rL, rW, info = o32.adjoint(od, z, L, ts, dz, W=W)
+    assert st["nfailed"] == 0 and abs(st["naccept"] - info["naccept"]) <= 0.1 * info["naccept"] + 2
+    d64 = O.make_desc(**{**kw, "abstol": 1e-10, "reltol": 1e-10})
+    z64, _, _ = o64.forward(d64, z0, L, ts, W=W.astype(np.float64))
+    t0, tL, tW, _ = o64.adjoint(d64, z64, L, ts, dz, W=W.astype(np.float64))
+    _check_grads(g0, r0, t0, 5e-3, 5e-3, "dz0")
+    _check_grads(gL, rL, tL, 5e-3, 5e-3, "dL")
+    _check_grads(gW, rW, tW, 5e-3, 5e-3, "dW")
+
+
+def test_augmented_tanh_adjoint_tight(o32, o64):
+    """Smooth activation at tight tolerance: gradients must agree with the float64 adjoint to 1e-4."""
+    layers = (7, 33, 50, 21, 7)
+    W = O.mlp_weights(layers, seed=4)
+    kw = dict(rhs_kind=O.RHS_MLP, state_dim=5, param_dim=0, augment_dim=2, layers=layers, activation=O.ACT_TANH,
+              abstol=1e-7, reltol=1e-7)
+    nat, od = _native(W, **kw)
+    B, T = 21, 20
+    z0, ts = _z0(B, 5), O.time_grid(T)
+    dz = O.cotangent(T, B, 7)
+    z, _, _ = nat.forward(z0, None, ts)
+    g0, _, gW, st = nat.adjoint(z, None, ts, dz)
+    d64 = O.make_desc(**{**kw, "abstol": 1e-11, "reltol": 1e-11})
+    z64, _, _ = o64.forward(d64, z0, None, ts, W=W.astype(np.float64))
+    t0, _, tW, _ = o64.adjoint(d64, z64, None, ts, dz, W=W.astype(np.float64))
+    assert g0.shape == (B, 5)
+    assert np.abs(g0 - t0).max() <= 1e-4 * np.abs(t0).max()
+    assert np.abs(gW - tW).max() <= 1e-4 * np.abs(tW).max()
+
+
+def test_per_trajectory_rejections_exercise_the_replay_path(o32, o64):
+    """A huge user-supplied initial dt forces rejected steps in some columns of a tile while others accept:
+    the weight gradient must still equal the oracle's (accepted steps only)."""
+    layers = (4, 32, 32, 4)
+    W = O.mlp_weights(layers, seed=6, scale=2.0)
+    kw = dict(rhs_kind=O.RHS_MLP, state_dim=4, param_dim=0, layers=layers, activation=O.ACT_TANH, abstol=1e-6, reltol=1e-6,
+              dt=0.5)
+    nat, od = _native(W, **kw)
+    B, T = 37, 8
+    z0 = (np.random.default_rng(3).standard_normal((B, 4)) * np.linspace(0.05, 2.0, B)[:, None]).astype(np.float32)
+    ts = O.time_grid(T, 0.5)
+    dz = O.cotangent(T, B, 4)
+    z, _, fs = nat.forward(z0, None, ts)
+    g0, _, gW, st = nat.adjoint(z, None, ts, dz)
+    assert st["nreject"] > 0 and fs["nreject"] > 0
+    d64 = O.make_desc(**{**kw, "abstol": 1e-11, "reltol": 1e-11, "dt": 0.0})
+    z64, _, _ = o64.forward(d64, z0, None, ts, W=W.astype(np.float64))
+    t0, _, tW, _ = o64.adjoint(d64, z64, None, ts, dz, W=W.astype(np.float64))
+    assert np.abs(z - z64).max() <= 2e-5 * max(1, np.abs(z64).max())
+    assert np.abs(g0 - t0).max() <= 2e-4 * np.abs(t0).max()
+    assert np.abs(gW - tW).max() <= 2e-4 * np.abs(tW).max()

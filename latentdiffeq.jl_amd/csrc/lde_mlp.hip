@@ -104,12 +104,24 @@ __device__ __forceinline__ void panel_gemm(const float* __restrict__ frag, int R
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
     const float* f0 = frag + (size_t)rt * KS * 64 + lane;
     const float* f1 = frag + (size_t)(two ? rt2 : rt) * KS * 64 + lane;
-    for (int ks = 0; ks < KS; ks++) {
-      const float b = xb[ks * 4 * LDP];
-      const float a0 = f0[ks * 64];
-      const float a1 = f1[ks * 64];
-      acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0, b, acc0, 0, 0, 0);
-      acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, b, acc1, 0, 0, 0);
+    // K-steps in chunks of 8: all 24 operand loads of a chunk are issued before its 16 MFMAs, so the L2 latency of
+    // the weight-fragment stream is paid once per chunk instead of once per K-step.
+    for (int ks0 = 0; ks0 < KS; ks0 += 8) {
+      float a0[8], a1[8], bb[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int ks = min(ks0 + u, KS - 1);
+        a0[u] = f0[ks * 64];
+        a1[u] = f1[ks * 64];
+        bb[u] = xb[ks * 4 * LDP];
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        if (ks0 + u < KS) {
+          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], bb[u], acc0, 0, 0, 0);
+          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], bb[u], acc1, 0, 0, 0);
+        }
+      }
     }
     const int col = lane & 15, rbase = (lane >> 4) * 4;
 #pragma unroll

@@ -75,6 +75,26 @@ def test_tsit5_mlp_forward(o32, o64, batching, tol, B):
         assert st["nfe"] == 6 * (st["naccept"] + st["nreject"]) + 2
 
 
+def test_c3_pendulum_plus_mlp_tight_tanh(o32, o64):
+    """Smooth variant at 1e-7: the physics+MLP right-hand side and its adjoint to 2e-5 / 1e-4 of the float64 answer."""
+    layers = (2, 64, 64, 2)
+    W = O.mlp_weights(layers, seed=3)
+    kw = dict(rhs_kind=O.RHS_PENDULUM_PLUS_MLP, layers=layers, activation=O.ACT_TANH, abstol=1e-7, reltol=1e-7)
+    nat, od = _native(W, **kw)
+    B, T = 50, 50
+    z0, L = O.pendulum_inputs(B)
+    ts = O.time_grid(T)
+    dz = O.cotangent(T, B, 2)
+    z, ret, _ = nat.forward(z0, L, ts)
+    d64 = O.make_desc(**{**kw, "abstol": 1e-11, "reltol": 1e-11})
+    zt, _, _ = o64.forward(d64, z0, L, ts, W=W.astype(np.float64))
+    assert (ret == 0).all() and np.abs(z - zt).max() <= 2e-5
+    g0, gL, gW, _ = nat.adjoint(z, L, ts, dz)
+    t0, tL, tW, _ = o64.adjoint(d64, zt, L, ts, dz, W=W.astype(np.float64))
+    for g, t in ((g0, t0), (gL, tL), (gW, tW)):
+        assert np.abs(g - t).max() <= 1e-4 * np.abs(t).max()
+
+
 def test_c3_pendulum_plus_mlp_forward(o32, o64):
     layers = (2, 64, 64, 2)
     W = O.mlp_weights(layers, seed=3)

@@ -1,0 +1,97 @@
+"""The N>1 path on CPU: world_size-2 `gloo` processes.
+
+The solve itself is GPU-only, so the ranks here use the CPU oracle as the stand-in solver (tests may); what is
+under test is the multi-process logic the GPU path shares: contiguous column sharding with no data-path collective,
+and ONE flat sum-all-reduce of the shared weight gradient that reproduces the single-process gradient of the
+global batch (gradient all-reduce equivalence 1 vs N ranks)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from latentdiffeq_amd import dist as D
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_shard_bounds_tile_the_batch():
+    for B in (1, 7, 64, 256, 1000):
+        for world in (1, 2, 3, 8):
+            blocks = [D.shard_bounds(B, r, world) for r in range(world)]
+            assert blocks[0][0] == 0 and blocks[-1][1] == B
+            assert all(blocks[i][1] == blocks[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in blocks]
+            assert max(sizes) - min(sizes) <= 1
+    x = torch.arange(2 * 10 * 3).reshape(2, 10, 3)
+    parts = [D.shard_columns(x, r, 4, 1) for r in range(4)]
+    assert torch.equal(torch.cat(parts, dim=1), x) and parts[0].data_ptr() == x.data_ptr()
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    r, w, _ = D.init("gloo")
+    assert (r, w) == (rank, world)
+    from oracle import oracle as O
+    o32 = O.Oracle("f32")
+    layers = (2, 16, 16, 2)
+    W = O.mlp_weights(layers, seed=3)
+    B, T = 24, 20
+    z0, L = O.pendulum_inputs(B)
+    ts = O.time_grid(T)
+    dz = O.cotangent(T, B, 2)          # already carries the 1/(B·T) of the GLOBAL batch
+    d = O.make_desc(rhs_kind=O.RHS_PENDULUM_PLUS_MLP, layers=layers)
+    lo, hi = D.shard_bounds(B, rank, world)
+    z, _, _ = o32.forward(d, z0[lo:hi], L[lo:hi], ts, W=W, nthreads=1)
+    g0, gL, gW, _ = o32.adjoint(d, z, L[lo:hi], ts, dz[:, lo:hi], W=W, nthreads=1)
+    # (1) the one collective of the path: flat sum of the shared weight gradient
+    buf = torch.from_numpy(gW.copy())
+    D.allreduce_flat_(buf)
+    # (2) the same through parameter .grad fields (what a trainer uses), as ONE message
+    p1, p2 = torch.nn.Parameter(torch.zeros(100)), torch.nn.Parameter(torch.zeros(gW.size - 100))
+    p1.grad, p2.grad = torch.from_numpy(gW[:100].copy()), torch.from_numpy(gW[100:].copy())
+    D.FlatGradAllReduce([p1, p2])()
+    q.put((rank, lo, hi, z, g0, gL, buf.numpy(), torch.cat([p1.grad, p2.grad]).numpy()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_two_rank_gradient_allreduce_matches_single_process():
+    from oracle import oracle as O
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    # single-process reference on the global batch
+    o32 = O.Oracle("f32")
+    layers = (2, 16, 16, 2)
+    W = O.mlp_weights(layers, seed=3)
+    B, T = 24, 20
+    z0, L = O.pendulum_inputs(B)
+    ts = O.time_grid(T)
+    dz = O.cotangent(T, B, 2)
+    d = O.make_desc(rhs_kind=O.RHS_PENDULUM_PLUS_MLP, layers=layers)
+    z, _, _ = o32.forward(d, z0, L, ts, W=W, nthreads=1)
+    g0, gL, gW, _ = o32.adjoint(d, z, L, ts, dz, W=W, nthreads=1)
+    zs = np.concatenate([r[3] for r in res], axis=1)
+    assert np.array_equal(zs, z), "per-trajectory solves are shard-invariant, bit for bit"
+    assert np.array_equal(np.concatenate([r[4] for r in res]), g0) and np.array_equal(np.concatenate([r[5] for r in res]), gL)
+    for r in res:
+        assert np.allclose(r[6], gW, rtol=2e-5, atol=1e-9), "sum over ranks of shard dW == global-batch dW"
+        assert np.array_equal(r[6], r[7]), "flat-buffer and per-parameter paths agree exactly"
+    assert np.array_equal(res[0][6], res[1][6]), "every rank ends with identical gradients"

@@ -67,7 +67,13 @@ enum lde_batching {
 
 enum lde_sensealg {
   LDE_SENSE_BACKSOLVE_CHECKPOINTED = 0, /* reverse-time adjoint, z re-integrated backwards and reset to the saved ẑ(t_j) at every save time */
-  LDE_SENSE_BACKSOLVE              = 1  /* same without the reset (BacksolveAdjoint, hinted at [REF nODE.jl:17]) */
+  LDE_SENSE_BACKSOLVE              = 1, /* same without the reset (BacksolveAdjoint, hinted at [REF nODE.jl:17]) */
+  LDE_SENSE_PARALLEL_CHECKPOINTED  = 2  /* checkpointed adjoint, parallel in time: with z reset at every save time the T-1 save
+                                           intervals are independent and λ enters linearly, so each (trajectory, interval) pair
+                                           integrates the interval's transition operator (λ_j = M_j λ_{j+1}, g += n_j·λ_{j+1}) on
+                                           its own lane and a short scan composes them. Same continuous adjoint as mode 0, agreeing
+                                           to solver tolerance. Implemented for analytic right-hand sides with per-trajectory batching;
+                                           for MLP right-hand sides / coupled batching mode 0 runs instead. */
 };
 
 enum lde_activation { LDE_ACT_RELU = 0, LDE_ACT_TANH = 1 };
@@ -132,7 +138,7 @@ typedef struct lde_handle lde_handle;
 int lde_abi_version(void);
 
 /* Fill `desc` with the defaults `Pendulum()` would carry: Tsit5, per-trajectory, abstol 1e-6,
- * reltol 1e-3, maxiters 1e5, PI controller constants  [REF pendulum.jl:11]. */
+ * reltol 1e-3, maxiters 1e5, PI controller constants  [REF pendulum.jl:11]; sensealg = PARALLEL_CHECKPOINTED. */
 int lde_problem_desc_default(lde_problem_desc* desc);
 
 /* Number of floats in the flat weight vector implied by desc (0 for analytic RHS). */

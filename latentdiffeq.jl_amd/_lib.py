@@ -17,7 +17,7 @@ LDE_MAX_LAYERS = 6
 RHS_PENDULUM, RHS_PENDULUM_FRICTION, RHS_MLP, RHS_PENDULUM_PLUS_MLP = 0, 1, 2, 3
 SOLVER_TSIT5, SOLVER_RK4 = 0, 1
 BATCH_PER_TRAJECTORY, BATCH_COUPLED = 0, 1
-SENSE_BACKSOLVE_CHECKPOINTED, SENSE_BACKSOLVE = 0, 1
+SENSE_BACKSOLVE_CHECKPOINTED, SENSE_BACKSOLVE, SENSE_PARALLEL_CHECKPOINTED = 0, 1, 2
 ACT_RELU, ACT_TANH = 0, 1
 
 STATUS = {0: "LDE_OK", -1: "LDE_ERR_INVALID_ARG", -2: "LDE_ERR_UNSUPPORTED", -3: "LDE_ERR_NO_DEVICE",

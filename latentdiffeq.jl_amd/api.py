@@ -59,12 +59,19 @@ class InterpolatingAdjoint(BacksolveAdjoint):
         super().__init__(checkpointing=True)
 
 
-class ForwardDiffSensitivity(BacksolveAdjoint):
-    """The reference's GOKU default [REF pendulum.jl:11]. Gradients of forward sensitivities and of the
-    continuous adjoint agree to solver tolerance; the native path always runs the adjoint."""
+class ParallelAdjoint(BacksolveAdjoint):
+    """Checkpointed continuous adjoint, parallel in time (LDE_SENSE_PARALLEL_CHECKPOINTED): one lane per
+    (trajectory, save interval) integrates the interval's transition operator, a short scan composes them.
+    Analytic right-hand sides with per-trajectory batching (the GOKU path)."""
 
     def __init__(self):
-        super().__init__(checkpointing=True)
+        self.code = L.SENSE_PARALLEL_CHECKPOINTED
+
+
+class ForwardDiffSensitivity(ParallelAdjoint):
+    """The reference's GOKU default [REF pendulum.jl:11]. Gradients of forward sensitivities and of the
+    continuous adjoint agree to solver tolerance; the native path always runs a reverse-mode adjoint — for the
+    GOKU path the time-parallel one."""
 
 
 # ------------------------------------------------------------------------------------------------
@@ -233,8 +240,9 @@ class NODE:
     def _native(self) -> _Handle:
         if self._handle is None:
             P = 1 if self._rhs_kind == L.RHS_PENDULUM_PLUS_MLP else 0
+            sa = self.sensealg if self.sensealg.code != L.SENSE_PARALLEL_CHECKPOINTED else BacksolveAdjoint()
             d = _make_desc(self._rhs_kind, self.latent_dim_in, P, self.augment_dim, self.layer_sizes, self.solver,
-                           self.sensealg, self.batching, self.kwargs)
+                           sa, self.batching, self.kwargs)
             self._handle = _Handle(d)
         return self._handle
 

@@ -23,6 +23,9 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
 int launch_pend_adjoint(int kind, int solver, const float* z_out, const float* theta, const double* ts_dev,
                         const KOpts& o, const float* dz_out, float* dz0, float* dtheta, int32_t* nfe, int32_t* nacc,
                         int32_t* nrej, int32_t* ret, hipStream_t stream);
+int launch_pend_adjoint_par(int kind, int solver, const float* z_out, const float* theta, const double* ts_dev,
+                            const KOpts& o, const float* dz_out, float* dz0, float* dtheta, float* ops, int32_t* info,
+                            int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret, hipStream_t stream);
 struct MlpPlan;
 int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err);
 void mlp_plan_destroy(MlpPlan* p);
@@ -57,6 +60,10 @@ struct lde_handle {
   int32_t* st[2][4] = {};
   int cap_B = 0;
   int last_B[2] = {0, 0};
+  // parallel-in-time adjoint: per-(interval, trajectory) transition operators
+  float* par_ops = nullptr;
+  int32_t* par_info = nullptr;
+  size_t par_cap = 0;
   std::string err = "";
 };
 
@@ -96,7 +103,8 @@ static int validate(const lde_problem_desc* d, std::string* why) {
   }
   if (d->solver != LDE_SOLVER_TSIT5 && d->solver != LDE_SOLVER_RK4) return bad("unknown solver");
   if (d->batching != LDE_BATCH_PER_TRAJECTORY && d->batching != LDE_BATCH_COUPLED) return bad("unknown batching");
-  if (d->sensealg != LDE_SENSE_BACKSOLVE_CHECKPOINTED && d->sensealg != LDE_SENSE_BACKSOLVE) return bad("unknown sensealg");
+  if (d->sensealg < LDE_SENSE_BACKSOLVE_CHECKPOINTED || d->sensealg > LDE_SENSE_PARALLEL_CHECKPOINTED) return bad("unknown sensealg");
+
   if (d->solver == LDE_SOLVER_RK4 && d->adaptive) {
     if (why) *why = "RK4 is fixed-step only here: pass adaptive=0, dt=h";
     return LDE_ERR_UNSUPPORTED;
@@ -121,7 +129,7 @@ int lde_problem_desc_default(lde_problem_desc* d) {
   d->param_dim = 1;
   d->solver = LDE_SOLVER_TSIT5;
   d->batching = LDE_BATCH_PER_TRAJECTORY;
-  d->sensealg = LDE_SENSE_BACKSOLVE_CHECKPOINTED;
+  d->sensealg = LDE_SENSE_PARALLEL_CHECKPOINTED;
   d->activation = LDE_ACT_RELU;
   d->adaptive = 1;
   d->maxiters = 100000;
@@ -153,6 +161,10 @@ int lde_create(const lde_problem_desc* desc, lde_handle** out) {
   lde_handle* h = new (std::nothrow) lde_handle();
   if (!h) return LDE_ERR_ALLOC;
   h->d = *desc;
+  // the time-parallel adjoint exists for analytic right-hand sides with per-trajectory control; elsewhere the same
+  // checkpointed adjoint runs sequentially (documented in include/lde.h)
+  if (h->d.sensealg == LDE_SENSE_PARALLEL_CHECKPOINTED && (has_mlp(h->d) || h->d.batching != LDE_BATCH_PER_TRAJECTORY))
+    h->d.sensealg = LDE_SENSE_BACKSOLVE_CHECKPOINTED;
   if (hipGetDevice(&h->device) != hipSuccess) {
     delete h;
     return LDE_ERR_NO_DEVICE;
@@ -184,6 +196,8 @@ void lde_destroy(lde_handle* h) {
   if (h->mlp) lde::mlp_plan_destroy(h->mlp);
   if (h->W_dev) (void)hipFree(h->W_dev);
   if (h->ts_dev) (void)hipFree(h->ts_dev);
+  if (h->par_ops) (void)hipFree(h->par_ops);
+  if (h->par_info) (void)hipFree(h->par_info);
   for (int i = 0; i < TS_RING; i++) {
     if (h->ts_pinned[i]) (void)hipHostFree(h->ts_pinned[i]);
     if (h->ts_ev[i]) (void)hipEventDestroy(h->ts_ev[i]);
@@ -231,6 +245,8 @@ int lde_reserve(lde_handle* h, int B, int T) {
   }
   if (T > h->ts_cap) {
     if (h->ts_dev) (void)hipFree(h->ts_dev);
+  if (h->par_ops) (void)hipFree(h->par_ops);
+  if (h->par_info) (void)hipFree(h->par_info);
     h->ts_dev = nullptr;
     HIP_TRY(h, hipMalloc(&h->ts_dev, (size_t)T * sizeof(double)));
     h->ts_cap = T;
@@ -243,6 +259,18 @@ int lde_reserve(lde_handle* h, int B, int T) {
       HIP_TRY(h, hipHostMalloc((void**)&h->ts_pinned[i], (size_t)T * sizeof(double), hipHostMallocDefault));
     }
     h->ts_pin_cap = T;
+  }
+  if (!h->mlp && h->d.sensealg == LDE_SENSE_PARALLEL_CHECKPOINTED) {
+    const size_t need = (size_t)(T > 1 ? T - 1 : 1) * (size_t)B;
+    if (need > h->par_cap) {
+      if (h->par_ops) (void)hipFree(h->par_ops);
+      if (h->par_info) (void)hipFree(h->par_info);
+      h->par_ops = nullptr;
+      h->par_info = nullptr;
+      HIP_TRY(h, hipMalloc(&h->par_ops, need * 6 * sizeof(float)));
+      HIP_TRY(h, hipMalloc(&h->par_info, need * sizeof(int32_t)));
+      h->par_cap = need;
+    }
   }
   if (h->mlp) return lde::mlp_reserve(h->mlp, B, T, h->err);
   return LDE_OK;
@@ -283,7 +311,7 @@ static lde::KOpts make_opts(const lde_problem_desc& d, const double* ts, int T, 
   o.dt_fixed = d.dt;
   o.maxiters = d.maxiters;
   o.adaptive = d.adaptive;
-  o.checkpoint = d.sensealg == LDE_SENSE_BACKSOLVE_CHECKPOINTED;
+  o.checkpoint = d.sensealg != LDE_SENSE_BACKSOLVE;
   o.T = T;
   o.B = B;
   return o;
@@ -341,8 +369,12 @@ int lde_adjoint(lde_handle* h, const float* z_out, const float* theta, const dou
   if (h->mlp)
     return lde::mlp_adjoint(h->mlp, h->W_dev, z_out, theta, h->ts_dev, o, dz_out, dz0, dtheta, dW, st[0], st[1], st[2],
                             st[3], stream, h->err);
-  rc = lde::launch_pend_adjoint(h->d.rhs_kind, h->d.solver, z_out, theta, h->ts_dev, o, dz_out, dz0, dtheta, st[0], st[1],
-                                st[2], st[3], stream);
+  if (h->d.sensealg == LDE_SENSE_PARALLEL_CHECKPOINTED)
+    rc = lde::launch_pend_adjoint_par(h->d.rhs_kind, h->d.solver, z_out, theta, h->ts_dev, o, dz_out, dz0, dtheta, h->par_ops,
+                                      h->par_info, st[0], st[1], st[2], st[3], stream);
+  else
+    rc = lde::launch_pend_adjoint(h->d.rhs_kind, h->d.solver, z_out, theta, h->ts_dev, o, dz_out, dz0, dtheta, st[0], st[1],
+                                  st[2], st[3], stream);
   if (rc) h->err = "lde_adjoint: kernel launch failed";
   return rc;
 }

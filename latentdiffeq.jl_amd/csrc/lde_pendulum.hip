@@ -283,6 +283,146 @@ __global__ void __launch_bounds__(256) k_pend_adjoint(const float2* __restrict__
   st_ret[b] = bad ? (ret ? ret : LDE_RET_NONFINITE) : 0;
 }
 
+
+// ---- parallel-in-time checkpointed adjoint (LDE_SENSE_PARALLEL_CHECKPOINTED) ---------------------------------------
+// With z reset to the saved ẑ(t_j) at every save time, the T−1 save intervals are independent, and λ (and g) enter
+// the reverse-time system linearly. Phase 1 gives every (trajectory b, interval j) pair its own lane, which integrates
+// [z | λᵃ λᵇ | gᵃ gᵇ] (λᵃ(t_{j+1}) = e₁, λᵇ(t_{j+1}) = e₂) from t_{j+1} down to t_j: the 2×2 transition matrix M_j and
+// the row n_j of the parameter-gradient functional. Phase 2 composes them with a 49-term scan per trajectory:
+//   g += n_j·λ ;  λ ← M_j λ + Δ_j.
+// The sequential chain of ≥49 Tsit5 steps per trajectory (k_pend_adjoint) becomes ≈1–2 steps + 49·8 FMAs, and a batch
+// of 256 trajectories fills 196 wavefronts instead of 4.
+template <int KIND>
+struct PendBasis {
+  float ngl, gl2;
+  __device__ __forceinline__ explicit PendBasis(float L) : ngl(-10.0f / L), gl2(10.0f / (L * L)) {}
+  // y = [z0 z1 | la0 la1 lb0 lb1 | ga gb]
+  __device__ __forceinline__ void operator()(const float (&y)[8], float (&dy)[8]) const {
+    float s, c;
+    fast_sincos(y[0], s, c);
+    dy[0] = y[1];
+    float acc = ngl * s;
+    if (KIND == 1) acc -= 0.7f * y[1];
+    dy[1] = acc;
+    const float nc = ngl * c, gs = gl2 * s;
+    dy[2] = -(nc * y[3]);
+    float va = y[2];
+    if (KIND == 1) va -= 0.7f * y[3];
+    dy[3] = -va;
+    dy[4] = -(nc * y[5]);
+    float vb = y[4];
+    if (KIND == 1) vb -= 0.7f * y[5];
+    dy[5] = -vb;
+    dy[6] = -(gs * y[3]);
+    dy[7] = -(gs * y[5]);
+  }
+};
+
+template <int KIND, int SOLVER>
+__global__ void __launch_bounds__(256) k_pend_adjoint_par1(const float2* __restrict__ z_out, const float* __restrict__ theta,
+                                                           const double* __restrict__ ts_g, KOpts o,
+                                                           float* __restrict__ ops, int32_t* __restrict__ info) {
+  const int T = o.T, B = o.B;
+  const int gid = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (T - 1) * B) return;
+  const int j = gid / B, b = gid - j * B;   // lanes of a wave share j and cover consecutive b (coalesced)
+  const double t1 = ts_g[j + 1], t0 = ts_g[j];
+  const float2 zc = z_out[(size_t)(j + 1) * B + b];
+  PendBasis<KIND> f(theta[b]);
+  float y[8] = {zc.x, zc.y, 1.f, 0.f, 0.f, 1.f, 0.f, 0.f};
+  float k[7][8], yn[8];
+  int ret = LDE_RET_SUCCESS, nacc = 0, nrej = 0;
+  if (!(isfinite(zc.x) && isfinite(zc.y))) ret = LDE_RET_NONFINITE;
+  else {
+    const double len = t1 - t0;
+    double t = t1, dt = o.adaptive ? len : o.dt_fixed;   // first attempt: the whole interval
+    const double dtmax = len;
+    float qold = 1e-4f;
+    long long iters = 0;
+    f(y, k[0]);
+    for (;;) {
+      if (iters++ >= o.maxiters) { ret = LDE_RET_MAXITERS; break; }
+      const double dist = t - t0;
+      double hmag = dt;
+      bool hit = false;
+      if (hmag >= dist * (1.0 - 1e-12)) { hmag = dist; hit = true; }
+      const float h = -(float)hmag;
+      float EEst = 0.f;
+      if (SOLVER == LDE_SOLVER_TSIT5) EEst = tsit5_attempt<8>(f, h, y, k, yn, o);
+      else rk4_step<8>(f, h, y, k, yn);
+      if (!all_finite<8>(yn) || !(EEst == EEst)) {
+        if (o.adaptive && hmag > o.dtmin) { nrej++; dt = hmag * (double)o.qmin; continue; }
+        ret = LDE_RET_NONFINITE;
+        break;
+      }
+      double dtp = dt;
+      if (o.adaptive) {
+        float q11;
+        const float q = pi_q(EEst, qold, o, q11);
+        if (EEst > 1.0f) {
+          nrej++;
+          dt = hmag * (double)fast_rcp(fminf(o.q_hi, q11 * o.inv_gamma));
+          if (dt < o.dtmin) { ret = LDE_RET_DTMIN; break; }
+          continue;
+        }
+        qold = fmaxf(EEst, 1e-4f);
+        dtp = hmag * (double)fast_rcp(q);
+        if (dtp > dtmax) dtp = dtmax;
+      }
+      nacc++;
+#pragma unroll
+      for (int i = 0; i < 8; i++) y[i] = yn[i];
+      if (hit) break;
+      t -= hmag;
+      constexpr int FS = (SOLVER == LDE_SOLVER_TSIT5) ? 6 : 4;
+#pragma unroll
+      for (int i = 0; i < 8; i++) k[0][i] = k[FS][i];
+      dt = o.adaptive ? dtp : o.dt_fixed;
+    }
+  }
+  // operator of interval j for trajectory b: [la0 la1 lb0 lb1 ga gb], plane-major so that phase 2 reads coalesced
+  const size_t plane = (size_t)(T - 1) * B, at = (size_t)j * B + b;
+#pragma unroll
+  for (int i = 0; i < 6; i++) ops[(size_t)i * plane + at] = y[2 + i];
+  info[at] = (ret << 24) | (min(nrej, 4095) << 12) | min(nacc, 4095);
+}
+
+__global__ void __launch_bounds__(256) k_pend_adjoint_par2(const float2* __restrict__ z_out, const float2* __restrict__ dz_out,
+                                                           const float* __restrict__ ops, const int32_t* __restrict__ info,
+                                                           int T, int B, float2* __restrict__ dz0, float* __restrict__ dtheta,
+                                                           int32_t* __restrict__ st_nfe, int32_t* __restrict__ st_nacc,
+                                                           int32_t* __restrict__ st_nrej, int32_t* __restrict__ st_ret) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float2 zT = z_out[(size_t)(T - 1) * B + b];
+  const float2 dT = dz_out[(size_t)(T - 1) * B + b];
+  float l0 = dT.x, l1 = dT.y, g = 0.f;
+  int ret = (isfinite(zT.x) && isfinite(zT.y)) ? 0 : LDE_RET_NONFINITE;
+  int nacc = 0, nrej = 0;
+  const size_t plane = (size_t)(T - 1) * B;
+  for (int j = T - 2; j >= 0; j--) {
+    const size_t at = (size_t)j * B + b;
+    const float la0 = ops[at], la1 = ops[plane + at], lb0 = ops[2 * plane + at], lb1 = ops[3 * plane + at];
+    const float ga = ops[4 * plane + at], gb = ops[5 * plane + at];
+    const float2 d = dz_out[at];
+    const int inf = info[at];
+    g += ga * l0 + gb * l1;
+    const float n0 = la0 * l0 + lb0 * l1 + d.x;
+    const float n1 = la1 * l0 + lb1 * l1 + d.y;
+    l0 = n0;
+    l1 = n1;
+    nacc += inf & 4095;
+    nrej += (inf >> 12) & 4095;
+    if (!ret) ret = inf >> 24;
+  }
+  dz0[b] = ret ? make_float2(0.f, 0.f) : make_float2(l0, l1);
+  dtheta[b] = ret ? 0.f : g;
+  st_nacc[b] = nacc;
+  st_nrej[b] = nrej;
+  st_nfe[b] = (T - 1) + 6 * (nacc + nrej);
+  st_ret[b] = ret;
+}
+
 // ---- host-side launchers (called from lde_api.cpp) -------------------------------------------------
 static inline int pick_block(int B) { return B <= 4096 ? 64 : 256; }
 
@@ -317,6 +457,30 @@ int launch_pend_adjoint(int kind, int solver, const float* z_out, const float* t
   else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_RK4) LDE_LAUNCH(1, LDE_SOLVER_RK4);
   else return LDE_ERR_UNSUPPORTED;
 #undef LDE_LAUNCH
+  return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
+}
+
+int launch_pend_adjoint_par(int kind, int solver, const float* z_out, const float* theta, const double* ts_dev,
+                            const KOpts& o, const float* dz_out, float* dz0, float* dtheta, float* ops, int32_t* info,
+                            int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret, hipStream_t stream) {
+  if (o.T > 1) {
+    const long long n = (long long)(o.T - 1) * o.B;
+    const int block = n <= 65536 ? 64 : 256;
+    const int grid = (int)((n + block - 1) / block);
+#define LDE_LAUNCH(K, S)                                                                                                 \
+  hipLaunchKernelGGL((k_pend_adjoint_par1<K, S>), dim3(grid), dim3(block), 0, stream, (const float2*)z_out, theta, ts_dev, o, \
+                     ops, info)
+    if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH(0, LDE_SOLVER_TSIT5);
+    else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_RK4) LDE_LAUNCH(0, LDE_SOLVER_RK4);
+    else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH(1, LDE_SOLVER_TSIT5);
+    else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_RK4) LDE_LAUNCH(1, LDE_SOLVER_RK4);
+    else return LDE_ERR_UNSUPPORTED;
+#undef LDE_LAUNCH
+    if (hipGetLastError() != hipSuccess) return LDE_ERR_HIP;
+  }
+  const int block2 = pick_block(o.B), grid2 = (o.B + block2 - 1) / block2;
+  hipLaunchKernelGGL(k_pend_adjoint_par2, dim3(grid2), dim3(block2), 0, stream, (const float2*)z_out, (const float2*)dz_out, ops,
+                     info, o.T, o.B, (float2*)dz0, dtheta, nfe, nacc, nrej, ret);
   return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
 }
 

@@ -723,19 +723,112 @@ int oracle_forward(const lde_problem_desc* d, const real* W, const real* z0, con
   return LDE_OK;
 }
 
+/* ---- parallel-in-time checkpointed adjoint (LDE_SENSE_PARALLEL_CHECKPOINTED), analytic RHS ------------------ */
+/* interval state: [ z (Dp) | Λ (Dp basis vectors × Dp) | G (Dp basis vectors × P) ] */
+static void basis_fn(void* vctx, double t, const real* y, real* dy, real wq) {
+  (void)t; (void)wq;
+  blockctx* b = (blockctx*)vctx;
+  const int Dp = b->Dp, P = b->P;
+  real f[64], vz[64], vth[16];
+  for (int v = 0; v < Dp; v++) {
+    rhs_vjp_col(&b->c, y, b->theta, y + Dp + (int64_t)v * Dp, f, vz, vth, 0);
+    for (int i = 0; i < Dp; i++) dy[Dp + (int64_t)v * Dp + i] = -vz[i];
+    for (int p = 0; p < P; p++) dy[Dp + (int64_t)Dp * Dp + (int64_t)v * P + p] = -vth[p];
+  }
+  for (int i = 0; i < Dp; i++) dy[i] = f[i];
+}
+static void no_jump(void* ctx, int j, real* y) { (void)ctx; (void)j; (void)y; }
+
+static int adjoint_parallel(const lde_problem_desc* d, const real* z_out, const real* theta, const double* ts, int T, int B,
+                            const real* dz_out, real* dz0, real* dtheta, int64_t* stats, int nthreads) {
+  const int Dp = d->state_dim, P = d->param_dim;
+  if (has_mlp(d) || d->batching != LDE_BATCH_PER_TRAJECTORY || Dp > 8) return LDE_ERR_UNSUPPORTED;
+  int64_t nfe = 0, nacc = 0, nrej = 0, nfail = 0, maxsteps = 0;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel reduction(+ : nfe, nacc, nrej, nfail) reduction(max : maxsteps)
+  {
+    blockctx b;
+    memset(&b, 0, sizeof(b));
+    colrhs_init(&b.c, d, NULL);
+    b.ncol = 1; b.Dp = Dp; b.P = P;
+    const int n = Dp + Dp * Dp + Dp * P;
+    real* y = (real*)calloc((size_t)n, sizeof(real));
+    real* M = (real*)calloc((size_t)(T > 1 ? T - 1 : 1) * (Dp * Dp + Dp * P), sizeof(real));
+#pragma omp for schedule(static)
+    for (int c = 0; c < B; c++) {
+      b.theta = theta + (int64_t)c * P;
+      int bad = 0;
+      int64_t steps = 0;
+      for (int j = T - 2; j >= 0 && !bad; j--) {  /* independent intervals (a GPU runs them concurrently) */
+        for (int i = 0; i < n; i++) y[i] = 0;
+        for (int i = 0; i < Dp; i++) {
+          y[i] = z_out[i + (int64_t)Dp * (c + (int64_t)B * (j + 1))];
+          y[Dp + i * Dp + i] = 1;
+          if (!isfinite((double)y[i])) bad = 1;
+        }
+        if (bad) break;
+        double tsj[2] = {ts[j], ts[j + 1]};
+        sopts o;
+        opts_from_desc(d, &o, ts[0], ts[T - 1]);
+        if (o.adaptive) o.dt_fixed = ts[j + 1] - ts[j];   /* first attempt = the whole interval */
+        sstat st = {0, 0, 0, 0};
+        solve_backward(basis_fn, &b, n, y, tsj, 2, &o, no_jump, NULL, NULL, &st);
+        if (st.retcode) bad = 1;
+        memcpy(M + (int64_t)j * (Dp * Dp + Dp * P), y + Dp, (size_t)(Dp * Dp + Dp * P) * sizeof(real));
+        nfe += st.nfe; nacc += st.nacc; nrej += st.nrej; steps += st.nacc + st.nrej;
+      }
+      if (T > 0) {
+        real lam[8], nl[8], g[16];
+        for (int i = 0; i < Dp; i++) {
+          lam[i] = dz_out[i + (int64_t)Dp * (c + (int64_t)B * (T - 1))];
+          if (!isfinite((double)z_out[i + (int64_t)Dp * (c + (int64_t)B * (T - 1))])) bad = 1;
+        }
+        for (int p = 0; p < P; p++) g[p] = 0;
+        for (int j = T - 2; j >= 0 && !bad; j--) {  /* the scan: λ_j = M_j λ_{j+1} + Δ_j ; g += n_j · λ_{j+1} */
+          const real* Mj = M + (int64_t)j * (Dp * Dp + Dp * P);
+          for (int i = 0; i < Dp; i++) {
+            real s = 0;
+            for (int v = 0; v < Dp; v++) s += Mj[v * Dp + i] * lam[v];
+            nl[i] = s + dz_out[i + (int64_t)Dp * (c + (int64_t)B * j)];
+          }
+          for (int p = 0; p < P; p++) {
+            real s = g[p];
+            for (int v = 0; v < Dp; v++) s += Mj[Dp * Dp + v * P + p] * lam[v];
+            g[p] = s;
+          }
+          for (int i = 0; i < Dp; i++) lam[i] = nl[i];
+        }
+        for (int i = 0; i < Dp; i++) dz0[(int64_t)c * Dp + i] = bad ? 0 : lam[i];
+        for (int p = 0; p < P; p++) dtheta[(int64_t)c * P + p] = bad ? 0 : g[p];
+      }
+      nfail += bad;
+      if (steps > maxsteps) maxsteps = steps;
+    }
+    free(y);
+    free(M);
+    colrhs_free(&b.c);
+  }
+  if (stats) { stats[0] = nfe; stats[1] = nacc; stats[2] = nrej; stats[3] = nfail; stats[4] = maxsteps; }
+  return LDE_OK;
+}
+
 /* dW is ACCUMULATED (+=), as in lde_adjoint. */
 int oracle_adjoint(const lde_problem_desc* d, const real* W, const real* z_out, const real* theta, const double* ts,
                    int T, int B, const real* dz_out, real* dz0, real* dtheta, real* dW, int64_t* stats, int nthreads) {
   int rc = check_desc(d);
   if (rc) return rc;
   if (T < 1 || B < 1) return LDE_ERR_INVALID_ARG;
+  if (d->sensealg == LDE_SENSE_PARALLEL_CHECKPOINTED && !has_mlp(d) && d->batching == LDE_BATCH_PER_TRAJECTORY)
+    return adjoint_parallel(d, z_out, theta, ts, T, B, dz_out, dz0, dtheta, stats, nthreads);
   const int D = d->state_dim, Dp = D + d->augment_dim, P = d->param_dim;
   const int64_t nW = has_mlp(d) ? num_weights(d) : 0;
   sopts o;
   opts_from_desc(d, &o, ts[0], ts[T - 1]);
   int64_t nfe = 0, nacc = 0, nrej = 0, nfail = 0, maxsteps = 0;
   double* dW_tot = nW ? (double*)calloc((size_t)nW, sizeof(double)) : NULL;
-  const int ckpt = d->sensealg == LDE_SENSE_BACKSOLVE_CHECKPOINTED;
+  const int ckpt = d->sensealg != LDE_SENSE_BACKSOLVE;
   if (d->batching == LDE_BATCH_COUPLED) {
     blockctx b;
     memset(&b, 0, sizeof(b));

@@ -40,7 +40,8 @@ def test_desc_defaults_match_ordinarydiffeq_defaults_and_bindings_agree():
     assert (d.abstol, d.reltol, d.maxiters, d.adaptive) == (1e-6, 1e-3, 100000, 1)
     assert (d.qmin, d.qmax, d.gamma) == (0.2, 10.0, 0.9) and abs(d.beta1 - 0.14) < 1e-15 and abs(d.beta2 - 0.08) < 1e-15
     assert (d.rhs_kind, d.state_dim, d.param_dim, d.solver, d.batching) == (0, 2, 1, 0, 0)
-    od = O.make_desc()
+    assert d.sensealg == _lib.SENSE_PARALLEL_CHECKPOINTED   # the GOKU path defaults to the time-parallel adjoint
+    od = O.make_desc(sensealg=O.SENSE_PARALLEL_CHECKPOINTED)
     assert C.sizeof(od) == C.sizeof(d)
     assert bytes(od) == bytes(d), "oracle and product describe the default problem with identical bytes"
     # header struct size: 18 int32 (incl. layer_sizes[7]) + pad, 1 int64, 9 doubles

@@ -51,7 +51,7 @@ def test_forward_matches_oracle(o32, o64, kind, tol, B):
 
 
 @pytest.mark.parametrize("kind", [O.RHS_PENDULUM, O.RHS_PENDULUM_FRICTION])
-@pytest.mark.parametrize("sense", [O.SENSE_BACKSOLVE_CHECKPOINTED, O.SENSE_BACKSOLVE])
+@pytest.mark.parametrize("sense", [O.SENSE_BACKSOLVE_CHECKPOINTED, O.SENSE_BACKSOLVE, O.SENSE_PARALLEL_CHECKPOINTED])
 @pytest.mark.parametrize("tol", [(1e-6, 1e-3), (1e-6, 1e-6)])
 def test_adjoint_matches_oracle(o32, o64, kind, sense, tol):
     B, T = 256, 50
@@ -68,7 +68,7 @@ def test_adjoint_matches_oracle(o32, o64, kind, sense, tol):
     assert np.abs(gL - rL).max() <= lim * sL
     assert abs(st["naccept"] - info["naccept"]) <= 0.02 * info["naccept"] + 1
     # float64 truth of the same continuous adjoint
-    dtruth = O.make_desc(rhs_kind=kind, abstol=1e-11, reltol=1e-11, sensealg=sense)
+    dtruth = O.make_desc(rhs_kind=kind, abstol=1e-11, reltol=1e-11, sensealg=min(sense, 1))
     zt, _, _ = o64.forward(dtruth, z0, L, ts)
     t0, tL, _, _ = o64.adjoint(dtruth, zt, L, ts, dz)
     lim = 5e-3 if tol[1] > 1e-4 else 1e-3
@@ -76,9 +76,10 @@ def test_adjoint_matches_oracle(o32, o64, kind, sense, tol):
     assert np.abs(gL - tL).max() <= lim * np.abs(tL).max()
 
 
-def test_rk4_fixed_step(o32):
+@pytest.mark.parametrize("sense", [O.SENSE_BACKSOLVE_CHECKPOINTED, O.SENSE_PARALLEL_CHECKPOINTED])
+def test_rk4_fixed_step(o32, sense):
     B, T = 128, 50
-    nat, od = _native(solver=O.SOLVER_RK4, adaptive=0, dt=0.0125)
+    nat, od = _native(solver=O.SOLVER_RK4, adaptive=0, dt=0.0125, sensealg=sense)
     z0, L = O.pendulum_inputs(B)
     ts = O.time_grid(T)
     z, ret, st = nat.forward(z0, L, ts)
@@ -124,7 +125,7 @@ def test_failed_trajectories_give_nan_blocks(o32):
     assert np.abs(z[:, both] - zr[:, both]).max() <= 3e-4
     # pullback through a NaN block: zero gradient for that trajectory, finite for the others
     dz = O.cotangent(50, 256, 2)
-    nat2, od2 = _native()  # default maxiters: the adjoint itself must not run out of iterations
+    nat2, od2 = _native()  # default maxiters (and the default, time-parallel adjoint): the adjoint itself must not run out of iterations
     g0, gL, _, sb = nat2.adjoint(z, L, ts, dz)
     assert (g0[bad] == 0).all() and (gL[bad] == 0).all() and np.isfinite(g0).all() and np.isfinite(gL).all()
     assert sb["nfailed"] == bad.sum()

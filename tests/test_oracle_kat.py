@@ -212,7 +212,8 @@ def _fd(loss, x, eps=1e-6, idx=None):
 
 
 @pytest.mark.parametrize("kind,sense", itertools.product([O.RHS_PENDULUM, O.RHS_PENDULUM_FRICTION],
-                                                         [O.SENSE_BACKSOLVE_CHECKPOINTED, O.SENSE_BACKSOLVE]))
+                                                         [O.SENSE_BACKSOLVE_CHECKPOINTED, O.SENSE_BACKSOLVE,
+                                                          O.SENSE_PARALLEL_CHECKPOINTED]))
 def test_pendulum_adjoint_vs_finite_differences(o64, kind, sense):
     B, T = 6, 50
     z0, L = O.pendulum_inputs(B, dtype=np.float64)

@@ -318,6 +318,66 @@ struct PendBasis {
   }
 };
 
+// integrate one save interval [t0, t1] backwards for the basis state; returns retcode, leaves the operator in y[2..7]
+template <int KIND, int SOLVER>
+__device__ __forceinline__ int pend_interval_operator(float2 zc, float L, double t0, double t1, const KOpts& o, float (&y)[8],
+                                                      int& nacc, int& nrej) {
+  PendBasis<KIND> f(L);
+  y[0] = zc.x; y[1] = zc.y; y[2] = 1.f; y[3] = 0.f; y[4] = 0.f; y[5] = 1.f; y[6] = 0.f; y[7] = 0.f;
+  float k[7][8], yn[8];
+  int ret = LDE_RET_SUCCESS;
+  nacc = 0;
+  nrej = 0;
+  if (!(isfinite(zc.x) && isfinite(zc.y))) return LDE_RET_NONFINITE;
+  const double len = t1 - t0;
+  double t = t1, dt = o.adaptive ? len : o.dt_fixed;   // first attempt: the whole interval
+  const double dtmax = len;
+  float qold = 1e-4f;
+  long long iters = 0;
+  f(y, k[0]);
+  for (;;) {
+    if (iters++ >= o.maxiters) { ret = LDE_RET_MAXITERS; break; }
+    const double dist = t - t0;
+    double hmag = dt;
+    bool hit = false;
+    if (hmag >= dist * (1.0 - 1e-12)) { hmag = dist; hit = true; }
+    const float h = -(float)hmag;
+    float EEst = 0.f;
+    if (SOLVER == LDE_SOLVER_TSIT5) EEst = tsit5_attempt<8>(f, h, y, k, yn, o);
+    else rk4_step<8>(f, h, y, k, yn);
+    if (!all_finite<8>(yn) || !(EEst == EEst)) {
+      if (o.adaptive && hmag > o.dtmin) { nrej++; dt = hmag * (double)o.qmin; continue; }
+      ret = LDE_RET_NONFINITE;
+      break;
+    }
+    double dtp = dt;
+    if (o.adaptive) {
+      float q11;
+      const float q = pi_q(EEst, qold, o, q11);
+      if (EEst > 1.0f) {
+        nrej++;
+        dt = hmag * (double)fast_rcp(fminf(o.q_hi, q11 * o.inv_gamma));
+        if (dt < o.dtmin) { ret = LDE_RET_DTMIN; break; }
+        continue;
+      }
+      qold = fmaxf(EEst, 1e-4f);
+      dtp = hmag * (double)fast_rcp(q);
+      if (dtp > dtmax) dtp = dtmax;
+    }
+    nacc++;
+#pragma unroll
+    for (int i = 0; i < 8; i++) y[i] = yn[i];
+    if (hit) break;
+    t -= hmag;
+    constexpr int FS = (SOLVER == LDE_SOLVER_TSIT5) ? 6 : 4;
+#pragma unroll
+    for (int i = 0; i < 8; i++) k[0][i] = k[FS][i];
+    dt = o.adaptive ? dtp : o.dt_fixed;
+  }
+  return ret;
+}
+
+// two-kernel form (large batches: every access coalesced over the batch index)
 template <int KIND, int SOLVER>
 __global__ void __launch_bounds__(256) k_pend_adjoint_par1(const float2* __restrict__ z_out, const float* __restrict__ theta,
                                                            const double* __restrict__ ts_g, KOpts o,
@@ -326,65 +386,108 @@ __global__ void __launch_bounds__(256) k_pend_adjoint_par1(const float2* __restr
   const int gid = blockIdx.x * blockDim.x + threadIdx.x;
   if (gid >= (T - 1) * B) return;
   const int j = gid / B, b = gid - j * B;   // lanes of a wave share j and cover consecutive b (coalesced)
-  const double t1 = ts_g[j + 1], t0 = ts_g[j];
-  const float2 zc = z_out[(size_t)(j + 1) * B + b];
-  PendBasis<KIND> f(theta[b]);
-  float y[8] = {zc.x, zc.y, 1.f, 0.f, 0.f, 1.f, 0.f, 0.f};
-  float k[7][8], yn[8];
-  int ret = LDE_RET_SUCCESS, nacc = 0, nrej = 0;
-  if (!(isfinite(zc.x) && isfinite(zc.y))) ret = LDE_RET_NONFINITE;
-  else {
-    const double len = t1 - t0;
-    double t = t1, dt = o.adaptive ? len : o.dt_fixed;   // first attempt: the whole interval
-    const double dtmax = len;
-    float qold = 1e-4f;
-    long long iters = 0;
-    f(y, k[0]);
-    for (;;) {
-      if (iters++ >= o.maxiters) { ret = LDE_RET_MAXITERS; break; }
-      const double dist = t - t0;
-      double hmag = dt;
-      bool hit = false;
-      if (hmag >= dist * (1.0 - 1e-12)) { hmag = dist; hit = true; }
-      const float h = -(float)hmag;
-      float EEst = 0.f;
-      if (SOLVER == LDE_SOLVER_TSIT5) EEst = tsit5_attempt<8>(f, h, y, k, yn, o);
-      else rk4_step<8>(f, h, y, k, yn);
-      if (!all_finite<8>(yn) || !(EEst == EEst)) {
-        if (o.adaptive && hmag > o.dtmin) { nrej++; dt = hmag * (double)o.qmin; continue; }
-        ret = LDE_RET_NONFINITE;
-        break;
-      }
-      double dtp = dt;
-      if (o.adaptive) {
-        float q11;
-        const float q = pi_q(EEst, qold, o, q11);
-        if (EEst > 1.0f) {
-          nrej++;
-          dt = hmag * (double)fast_rcp(fminf(o.q_hi, q11 * o.inv_gamma));
-          if (dt < o.dtmin) { ret = LDE_RET_DTMIN; break; }
-          continue;
-        }
-        qold = fmaxf(EEst, 1e-4f);
-        dtp = hmag * (double)fast_rcp(q);
-        if (dtp > dtmax) dtp = dtmax;
-      }
-      nacc++;
-#pragma unroll
-      for (int i = 0; i < 8; i++) y[i] = yn[i];
-      if (hit) break;
-      t -= hmag;
-      constexpr int FS = (SOLVER == LDE_SOLVER_TSIT5) ? 6 : 4;
-#pragma unroll
-      for (int i = 0; i < 8; i++) k[0][i] = k[FS][i];
-      dt = o.adaptive ? dtp : o.dt_fixed;
-    }
-  }
+  float y[8];
+  int nacc, nrej;
+  const int ret = pend_interval_operator<KIND, SOLVER>(z_out[(size_t)(j + 1) * B + b], theta[b], ts_g[j], ts_g[j + 1], o, y,
+                                                       nacc, nrej);
   // operator of interval j for trajectory b: [la0 la1 lb0 lb1 ga gb], plane-major so that phase 2 reads coalesced
   const size_t plane = (size_t)(T - 1) * B, at = (size_t)j * B + b;
 #pragma unroll
   for (int i = 0; i < 6; i++) ops[(size_t)i * plane + at] = y[2 + i];
   info[at] = (ret << 24) | (min(nrej, 4095) << 12) | min(nacc, 4095);
+}
+
+// fused form (small/medium batches): one workgroup per trajectory, one lane per save interval; the interval operators
+// never leave registers — they are composed by an order-preserving tree reduction over the wave (affine maps
+// (λ,g) ↦ (Mλ+Δ, g+n·λ+γ) compose associatively), then across waves through LDS.
+struct AffOp {
+  float m00, m01, m10, m11;   // M (λ' = Mλ + d)
+  float d0, d1;
+  float n0, n1, gam;          // g' = g + n·λ + γ
+};
+// apply `a` first, then `b`
+__device__ __forceinline__ AffOp aff_compose(const AffOp& a, const AffOp& b) {
+  AffOp r;
+  r.m00 = b.m00 * a.m00 + b.m01 * a.m10;
+  r.m01 = b.m00 * a.m01 + b.m01 * a.m11;
+  r.m10 = b.m10 * a.m00 + b.m11 * a.m10;
+  r.m11 = b.m10 * a.m01 + b.m11 * a.m11;
+  r.d0 = b.m00 * a.d0 + b.m01 * a.d1 + b.d0;
+  r.d1 = b.m10 * a.d0 + b.m11 * a.d1 + b.d1;
+  r.n0 = a.n0 + b.n0 * a.m00 + b.n1 * a.m10;
+  r.n1 = a.n1 + b.n0 * a.m01 + b.n1 * a.m11;
+  r.gam = a.gam + b.gam + b.n0 * a.d0 + b.n1 * a.d1;
+  return r;
+}
+__device__ __forceinline__ AffOp aff_shfl_down(const AffOp& a, int off) {
+  AffOp r;
+  r.m00 = __shfl_down(a.m00, off); r.m01 = __shfl_down(a.m01, off); r.m10 = __shfl_down(a.m10, off);
+  r.m11 = __shfl_down(a.m11, off); r.d0 = __shfl_down(a.d0, off); r.d1 = __shfl_down(a.d1, off);
+  r.n0 = __shfl_down(a.n0, off); r.n1 = __shfl_down(a.n1, off); r.gam = __shfl_down(a.gam, off);
+  return r;
+}
+
+template <int KIND, int SOLVER>
+__global__ void __launch_bounds__(1024) k_pend_adjoint_fused(const float2* __restrict__ z_out, const float* __restrict__ theta,
+                                                             const double* __restrict__ ts_g, KOpts o,
+                                                             const float2* __restrict__ dz_out, float2* __restrict__ dz0,
+                                                             float* __restrict__ dtheta, int32_t* __restrict__ st_nfe,
+                                                             int32_t* __restrict__ st_nacc, int32_t* __restrict__ st_nrej,
+                                                             int32_t* __restrict__ st_ret) {
+  __shared__ AffOp s_op[16];
+  __shared__ int s_stat[16][3];
+  const int T = o.T, B = o.B;
+  const int b = blockIdx.x;
+  const int l = threadIdx.x;              // l-th interval counted from the end: j = T-2-l (applied first ⇒ lowest lane)
+  const int j = T - 2 - l;
+  const int lane = l & 63, wave = l >> 6, nwave = (blockDim.x + 63) >> 6;
+  AffOp op = {1.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // identity for lanes beyond the first interval
+  int nacc = 0, nrej = 0, ret = 0;
+  if (j >= 0) {
+    float y[8];
+    ret = pend_interval_operator<KIND, SOLVER>(z_out[(size_t)(j + 1) * B + b], theta[b], ts_g[j], ts_g[j + 1], o, y, nacc, nrej);
+    const float2 d = dz_out[(size_t)j * B + b];
+    op = AffOp{y[2], y[4], y[3], y[5], d.x, d.y, y[6], y[7], 0.f};   // λ' = λ₀·(la) + λ₁·(lb) + Δ_j ; g' = g + ga λ₀ + gb λ₁
+  }
+  // order-preserving tree reduction inside the wave: lane ℓ ← (ℓ's block first, then the block of ℓ+off)
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const AffOp hi = aff_shfl_down(op, off);
+    const int a2 = __shfl_down(nacc, off), r2 = __shfl_down(nrej, off), e2 = __shfl_down(ret, off);
+    if ((lane & (2 * off - 1)) == 0) {
+      op = aff_compose(op, hi);
+      nacc += a2;
+      nrej += r2;
+      ret = ret ? ret : e2;
+    }
+  }
+  if (lane == 0) {
+    s_op[wave] = op;
+    s_stat[wave][0] = nacc;
+    s_stat[wave][1] = nrej;
+    s_stat[wave][2] = ret;
+  }
+  __syncthreads();
+  if (l == 0) {
+    for (int w = 1; w < nwave; w++) {
+      op = aff_compose(op, s_op[w]);
+      nacc += s_stat[w][0];
+      nrej += s_stat[w][1];
+      ret = ret ? ret : s_stat[w][2];
+    }
+    const float2 zT = z_out[(size_t)(T - 1) * B + b];
+    const float2 dT = dz_out[(size_t)(T - 1) * B + b];
+    if (!(isfinite(zT.x) && isfinite(zT.y))) ret = ret ? ret : LDE_RET_NONFINITE;
+    const float l0 = op.m00 * dT.x + op.m01 * dT.y + op.d0;
+    const float l1 = op.m10 * dT.x + op.m11 * dT.y + op.d1;
+    const float g = op.n0 * dT.x + op.n1 * dT.y + op.gam;
+    dz0[b] = ret ? make_float2(0.f, 0.f) : make_float2(l0, l1);
+    dtheta[b] = ret ? 0.f : g;
+    st_nacc[b] = nacc;
+    st_nrej[b] = nrej;
+    st_nfe[b] = (T - 1) + 6 * (nacc + nrej);
+    st_ret[b] = ret;
+  }
 }
 
 __global__ void __launch_bounds__(256) k_pend_adjoint_par2(const float2* __restrict__ z_out, const float2* __restrict__ dz_out,
@@ -463,6 +566,19 @@ int launch_pend_adjoint(int kind, int solver, const float* z_out, const float* t
 int launch_pend_adjoint_par(int kind, int solver, const float* z_out, const float* theta, const double* ts_dev,
                             const KOpts& o, const float* dz_out, float* dz0, float* dtheta, float* ops, int32_t* info,
                             int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret, hipStream_t stream) {
+  if (o.T > 1 && o.T - 1 <= 1024 && o.B <= 32768) {   // fused: one workgroup per trajectory, one lane per interval
+    const int block = ((o.T - 1 + 63) / 64) * 64;
+#define LDE_LAUNCH(K, S)                                                                                                  \
+  hipLaunchKernelGGL((k_pend_adjoint_fused<K, S>), dim3(o.B), dim3(block), 0, stream, (const float2*)z_out, theta, ts_dev, o, \
+                     (const float2*)dz_out, (float2*)dz0, dtheta, nfe, nacc, nrej, ret)
+    if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH(0, LDE_SOLVER_TSIT5);
+    else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_RK4) LDE_LAUNCH(0, LDE_SOLVER_RK4);
+    else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH(1, LDE_SOLVER_TSIT5);
+    else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_RK4) LDE_LAUNCH(1, LDE_SOLVER_RK4);
+    else return LDE_ERR_UNSUPPORTED;
+#undef LDE_LAUNCH
+    return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
+  }
   if (o.T > 1) {
     const long long n = (long long)(o.T - 1) * o.B;
     const int block = n <= 65536 ? 64 : 256;

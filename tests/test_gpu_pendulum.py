@@ -170,3 +170,27 @@ def test_torch_api_diffeq_layer(o32):
     r0, rL, _, _ = o32.adjoint(od, zr, L, ts, dz)
     assert np.abs(z0t.grad.cpu().numpy().T - r0).max() <= 5e-4 * np.abs(r0).max()
     assert np.abs(tht.grad.cpu().numpy().T - rL).max() <= 5e-4 * np.abs(rL).max()
+
+
+@pytest.mark.parametrize("B,T", [(300, 100), (40000, 50), (64, 1300), (1, 2), (3, 65), (3, 66)])
+def test_parallel_adjoint_variants_agree_with_sequential_kernel(o32, B, T):
+    """The time-parallel adjoint has three code paths (fused one-wave, fused multi-wave via LDS, two-kernel coalesced
+    form for big batches / very long grids); each must reproduce the sequential checkpointed adjoint to solver tolerance
+    (both are the same continuous adjoint; abstol=reltol=1e-6 here ⇒ 2e-4 relative)."""
+    par, _ = _native(abstol=1e-6, reltol=1e-6, sensealg=O.SENSE_PARALLEL_CHECKPOINTED)
+    seq, od = _native(abstol=1e-6, reltol=1e-6, sensealg=O.SENSE_BACKSOLVE_CHECKPOINTED)
+    z0, L = O.pendulum_inputs(B, seed=7)
+    ts = O.time_grid(T, 0.05 if T <= 100 else 0.004)
+    dz = O.cotangent(T, B, 2, seed=8)
+    z, ret, _ = par.forward(z0, L, ts)
+    assert (ret == 0).all()
+    g0, gL, _, sp = par.adjoint(z, L, ts, dz)
+    s0, sL, _, ss = seq.adjoint(z, L, ts, dz)
+    assert sp["nfailed"] == 0 and sp["naccept"] >= B * (T - 1)
+    assert np.abs(g0 - s0).max() <= 2e-4 * np.abs(s0).max()
+    assert np.abs(gL - sL).max() <= 2e-4 * max(np.abs(sL).max(), 1e-12)
+    if B <= 300 and T <= 100:   # and the oracle's time-parallel twin
+        odp = O.make_desc(abstol=1e-6, reltol=1e-6, sensealg=O.SENSE_PARALLEL_CHECKPOINTED)
+        r0, rL, _, info = o32.adjoint(odp, z, L, ts, dz)
+        assert np.abs(g0 - r0).max() <= 1e-4 * np.abs(r0).max() and np.abs(gL - rL).max() <= 1e-4 * np.abs(rL).max()
+        assert sp["naccept"] == info["naccept"]

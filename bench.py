@@ -258,6 +258,17 @@ def main():
         roof = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
                     traffic=None, alg_bytes_per_launch=dom_bytes * B, avg_launch_ms=dom_ms)
 
+    # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command
+    # (profiles/collect.sh + profiles/summarize.py; FETCH_SIZE ×2 on gfx950, WRITE_SIZE as is — MI355X_MICROARCH.md §HBM)
+    prof = os.path.join(ROOT, "profiles", f"r1_{args.workload}_b{B}_summary.json")
+    if os.path.exists(prof) and not Ff:
+        kn = {"lde_forward": "k_pend_forward", "lde_adjoint": "k_pend_adjoint"}[dom]
+        for name, kd in json.load(open(prof))["kernels"].items():
+            if name.startswith(kn) and "write_bytes" in kd:
+                roof["traffic"] = kd["fetch_bytes_x2_gfx950"] + kd["write_bytes"]
+                roof["traffic_source"] = os.path.relpath(prof, ROOT)
+                roof["rocprof_avg_launch_ms"] = kd["avg_ns"] * 1e-6
+
     out = {
         "metric": "trajectories/sec (fwd+adjoint) GOKU pendulum, batch=256, 1/2/4/8 GPU"
         if args.workload == "goku_pendulum" else f"trajectories/sec (fwd+adjoint) {args.workload}",

@@ -88,6 +88,8 @@ __global__ void __launch_bounds__(256) k_pend_forward(const float2* __restrict__
     float qold = 1e-4f;
     long long iters = 0;
     int j = 1;
+    // next save time kept in a register, the one after it prefetched: no LDS round trip on the save loop's exit test
+    double tj = s_ts[1], tjn = s_ts[min(2, T - 1)];
     while (t < tend) {
       if (iters++ >= o.maxiters) { ret = LDE_RET_MAXITERS; break; }
       double dtp = dt;
@@ -122,12 +124,11 @@ __global__ void __launch_bounds__(256) k_pend_forward(const float2* __restrict__
       }
       nacc++;
       const double tnew = last ? tend : t + dt;
-      if (j < T && s_ts[j] <= tnew) {  // at least one save time in (t, tnew]
+      if (j < T && tj <= tnew) {  // at least one save time in (t, tnew]
         float P[3][2];
         if (SOLVER == LDE_SOLVER_TSIT5) tsit5_dense_coeffs<2>(k, P);
         const float rh = fast_rcp(h);
         do {
-          const double tj = s_ts[j];
           float2 out;
           if (tj >= tnew || (j == T - 1 && last)) {
             out = make_float2(yn[0], yn[1]);
@@ -146,7 +147,9 @@ __global__ void __launch_bounds__(256) k_pend_forward(const float2* __restrict__
           }
           z_out[(size_t)j * B + b] = out;
           j++;
-        } while (j < T && s_ts[j] <= tnew);
+          tj = tjn;
+          tjn = s_ts[min(j + 1, T - 1)];
+        } while (j < T && tj <= tnew);
       }
       y[0] = yn[0];
       y[1] = yn[1];

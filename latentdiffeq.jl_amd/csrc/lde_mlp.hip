@@ -8,22 +8,26 @@
 //
 // Design (gfx950)
 //  * A workgroup (256 threads = 4 waves, one per SIMD) owns a tile of NB = 16 trajectories (columns) for the
-//    WHOLE solve: state, the seven Tsit5 slopes and the hidden activations of the tile live in LDS as
-//    [row][18] f32 panels (stride 18 ⇒ the MFMA operand reads below are bank-conflict-free or 2-way).
-//  * Every Dense layer is Y[out×16] = W[out×in]·X[in×16] on the f32 matrix cores:
-//    v_mfma_f32_16x16x4_f32, A = a 16×4 weight fragment, B = a 4×16 slab of the activation panel. Weights are
-//    re-laid out ONCE per lde_set_weights into MFMA fragment order (one coalesced 256-B load per fragment, for W
-//    and for Wᵀ), so the inner loop is {1 global/L2 load, 1 ds_read_b32, 1 MFMA}; f32 MFMA runs at the f32 vector
-//    rate (64 FLOP/clk/SIMD), which an L2-resident weight stream can feed.
-//  * Per-trajectory step control (GOKU semantics) costs nothing extra: all 16 columns run the same stage of
-//    their own step (own t, dt, accept/reject) in lock-step; a finished column idles with h = 0.
-//  * Coupled control (NeuralODE semantics: one dt, RMS norm over all D'·B entries) needs one grid-wide sum per
-//    step: each workgroup publishes its partial, a monotonic-counter barrier (agent-scope release/acquire)
-//    follows, and every workgroup adds the partials in the same order ⇒ bitwise identical decisions everywhere.
+//    WHOLE solve. State, the seven Tsit5 slopes and the hidden activations of the tile live in LDS as TRANSPOSED
+//    panels Xt[col][row] (row contiguous) with a stride ≡ 8 (mod 32) floats, which makes the 16-byte MFMA operand
+//    reads below bank-conflict-free.
+//  * Every Dense layer is Y[out×16] = W[out×in]·X[in×16] on the f32 matrix cores (v_mfma_f32_16x16x4_f32: exact f32,
+//    64 FLOP/clk/SIMD — gfx950 has no xf32, and bf16 would break the 1e-4 tolerance). The K index is permuted so that
+//    one ds_read_b128 per lane feeds FOUR consecutive MFMAs on each side: in K-group kg, MFMA s contracts
+//    k = 16·kg + 4·(lane>>4) + s. Weights are re-laid out ONCE per lde_set_weights into that fragment order
+//    (for W and for Wᵀ), and copied into LDS at kernel start as far as they fit (the rest streams from L2).
+//    Two accumulators per wave are always in flight (two row tiles, or the even/odd K-groups of one), narrow
+//    layers (fewer than 3 row tiles) are split along K across the waves and reduced through LDS. Bias + activation
+//    are fused into the epilogue, which writes the 4 consecutive rows a lane owns with one ds_write_b128.
+//  * Per-trajectory step control (GOKU semantics): all 16 columns run the same stage of their own step
+//    (own t, dt, accept/reject) in lock-step; a finished column idles with h = 0.
+//  * Coupled control (NeuralODE semantics: one dt, RMS norm over all D'·B entries): one grid-wide sum per step —
+//    each workgroup publishes its partial, a monotonic-counter barrier (agent-scope release/acquire) follows, and
+//    every workgroup adds the partials in the same order ⇒ bitwise identical decisions everywhere.
 //  * Adjoint: reverse-time Tsit5/RK4 on [z; λ; g_θ] with the MLP re-evaluated at every stage (relu masks are
 //    recomputed, not stored), vector-Jacobian products through Wᵀ fragments, and the weight gradient
-//    gW += (w·δ_l)·act_{l-1}ᵀ accumulated in MFMA accumulators across the stages of a step (K = the 16 columns
-//    of the tile), committed to the workgroup's slab only when the step is accepted.
+//    gWᵀ[i][o] += Σ_n a_l[i][n]·(w_n δ_l[o][n]) as MFMAs with K = the 16 columns, accumulated in MFMA accumulators
+//    across the stages of a step and committed to the workgroup's slab only when the step is accepted.
 #include <hip/hip_runtime.h>
 
 #include <string>
@@ -34,11 +38,11 @@
 namespace lde {
 
 constexpr int NB = 16;        // trajectories (columns) per workgroup
-constexpr int LDP = 18;       // LDS panel stride (floats)
 constexpr int NTHREADS = 256;
 constexpr int MAXL = LDE_MAX_LAYERS;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 // Static description of the RHS handed to the kernels by value.
 struct MlpDims {
@@ -46,42 +50,54 @@ struct MlpDims {
   int sizes[MAXL + 1];    // [in, h1, ..., out]
   int act;                // hidden activation
   int D, Dp, P;           // state_dim, D + augment_dim, param_dim
+  int DpA;                // Dp rounded up to 4: in the adjoint state λ rows start at DpA, g rows at 2·DpA
   int has_pend;           // PENDULUM_PLUS_MLP
-  int frag_off[MAXL];     // float offset of layer l's W fragments   (RT_l × KS_l × 64)
-  int fragT_off[MAXL];    // float offset of layer l's Wᵀ fragments  (RTt_l × KSt_l × 64)
+  int frag_off[MAXL];     // float offset of layer l's W fragments   (RT_l × KG_l × 256)
+  int fragT_off[MAXL];    // float offset of layer l's Wᵀ fragments
+  int frag_n[MAXL], fragT_n[MAXL];
   int w_off[MAXL];        // offset of vec(W_l) in the flat (destructure-order) weight vector
   int b_off[MAXL];        // offset of b_l
-  int hmax;               // widest hidden panel
+  int hmax;               // rows of a hidden panel (widest hidden layer, padded to 16)
+  int ld_h;               // stride of hidden panels
+  int ld_sf, ld_sb;       // stride of state panels in the forward / adjoint kernel
   int coupled;            // LDE_BATCH_COUPLED
   int solver;
   int nW;
-  int bias_lin[MAXL];     // offset of layer l's bias gradient in the compact [Σ out] LDS vector
+  int bias_lin[MAXL];     // offset of layer l's bias (gradient) in the compact [Σ out] vector
   int nbias;
-  int tile_off[MAXL + 1]; // first weight-gradient tile (16×16 of Wᵀ) of layer l in the global tile enumeration
+  int tile_off[MAXL + 1]; // first weight-gradient tile (32×32 of Wᵀ) of layer l in the global tile enumeration
+  int slab_n;             // floats of one workgroup's slab: ntiles·1024 (tiles in accumulator-fragment order) + nbias
 };
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// smallest stride ≥ rows with stride ≡ 8 (mod 32): (stride/4) ≡ 2 (mod 8) makes the ds_read_b128 operand pattern
+// "16 columns × 4 lane-groups of 16 B" conflict-free in every 16-lane service group.
+__host__ __device__ inline int panel_stride(int rows) {
+  int v = ((rows + 31) / 32) * 32 + 8;
+  if (v - 32 >= rows) v -= 32;
+  return v;
+}
 
 // ---- one-time weight re-layout: flat destructure order → MFMA fragment order (W and Wᵀ) ---------------
-// fragment (rt, ks) of a matrix M[R×K]: lane l holds M[rt*16 + (l&15)][ks*4 + (l>>4)] (0 outside).
+// fragment (rt, kg) of a matrix M[R×K]: lane l holds the float4 M[rt*16 + (l&15)][kg*16 + 4*(l>>4) + 0..3] (0 outside).
 __global__ void k_build_frags(const float* __restrict__ Wflat, MlpDims dm, float* __restrict__ frag,
                               float* __restrict__ fragT) {
   const int l = blockIdx.y;
   const int in = dm.sizes[l], out = dm.sizes[l + 1];
   const float* W = Wflat + dm.w_off[l];  // column-major [out×in]: W(o,i) at o + out*i
   {
-    const int RT = cdiv(out, 16), KS = cdiv(in, 4), n = RT * KS * 64;
+    const int KG = cdiv(in, 16), n = dm.frag_n[l];
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-      const int lane = e & 63, f = e >> 6, rt = f / KS, ks = f % KS;
-      const int o = rt * 16 + (lane & 15), i = ks * 4 + (lane >> 4);
+      const int s4 = e & 3, lane = (e >> 2) & 63, f = e >> 8, rt = f / KG, kg = f % KG;
+      const int o = rt * 16 + (lane & 15), i = kg * 16 + 4 * (lane >> 4) + s4;
       frag[dm.frag_off[l] + e] = (o < out && i < in) ? W[o + (size_t)out * i] : 0.f;
     }
   }
   {
-    const int RT = cdiv(in, 16), KS = cdiv(out, 4), n = RT * KS * 64;  // Wᵀ[in×out]
+    const int KG = cdiv(out, 16), n = dm.fragT_n[l];  // Wᵀ[in×out]
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
-      const int lane = e & 63, f = e >> 6, rt = f / KS, ks = f % KS;
-      const int i = rt * 16 + (lane & 15), o = ks * 4 + (lane >> 4);
+      const int s4 = e & 3, lane = (e >> 2) & 63, f = e >> 8, rt = f / KG, kg = f % KG;
+      const int i = rt * 16 + (lane & 15), o = kg * 16 + 4 * (lane >> 4) + s4;
       fragT[dm.fragT_off[l] + e] = (o < out && i < in) ? W[o + (size_t)out * i] : 0.f;
     }
   }
@@ -90,53 +106,101 @@ __global__ void k_build_frags(const float* __restrict__ Wflat, MlpDims dm, float
 __device__ __forceinline__ float act_fn(int kind, float x) { return kind == LDE_ACT_TANH ? tanhf(x) : fmaxf(x, 0.f); }
 __device__ __forceinline__ float act_grad(int kind, float a) { return kind == LDE_ACT_TANH ? 1.f - a * a : (a > 0.f ? 1.f : 0.f); }
 
-// Y[R×16] (+)= M[R×K]·X[K×16] for one workgroup; M given as fragments. EPI(row, col, acc) stores.
-// Row tiles are dealt to the 4 waves; two tiles are kept in flight per wave to cover the 40-cycle
-// dependent-accumulator latency of v_mfma_f32_16x16x4_f32.
+// Y[R×16] = M[R×K]·X[K×16] for one workgroup. M as K4 fragments (LDS copy or global), X a transposed panel
+// (Xt[col*ldx + row], rows [0,K) starting at the pointer), EPI(row0, col, acc4) gets the 4 consecutive rows a lane owns.
+// `red` = 4 KiB LDS scratch for the split-K reduction of narrow layers.
+#ifndef LDE_ABL
+#define LDE_ABL 0
+#endif
 template <class Epi>
-__device__ __forceinline__ void panel_gemm(const float* __restrict__ frag, int R, int K, const float* X, Epi epi) {
+__device__ __forceinline__ void panel_gemm(const float* frag, int R, int K, const float* Xt, int ldx, float* red, Epi epi) {
+  if (LDE_ABL == 1) return;   // diagnostic build: no GEMM at all
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int RT = cdiv(R, 16), KS = cdiv(K, 4);
-  const float* xb = X + (lane >> 4) * LDP + (lane & 15);
-  for (int rt = wave; rt < RT; rt += 8) {
-    const int rt2 = rt + 4;
-    const bool two = rt2 < RT;
-    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const float* f0 = frag + (size_t)rt * KS * 64 + lane;
-    const float* f1 = frag + (size_t)(two ? rt2 : rt) * KS * 64 + lane;
-    // K-steps in chunks of 8: all 24 operand loads of a chunk are issued before its 16 MFMAs, so the L2 latency of
-    // the weight-fragment stream is paid once per chunk instead of once per K-step.
-    for (int ks0 = 0; ks0 < KS; ks0 += 8) {
-      float a0[8], a1[8], bb[8];
+  const int RT = cdiv(R, 16), KG = cdiv(K, 16);
+  const f32x4* A = reinterpret_cast<const f32x4*>(frag);
+  const float* xp = Xt + (lane & 15) * ldx + 4 * (lane >> 4);
+  const int col = lane & 15, rsub = 4 * (lane >> 4);
+  if (RT >= 3) {
+    for (int rt = wave; rt < RT; rt += 8) {
+      const int rt2 = rt + 4;
+      const bool two = rt2 < RT;
+      f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+      const f32x4* a0p = A + (size_t)rt * KG * 64 + lane;
+      if (two) {
+        const f32x4* a1p = A + (size_t)rt2 * KG * 64 + lane;
+        f32x4 a0 = a0p[0], a1 = a1p[0], b = *reinterpret_cast<const f32x4*>(xp);
+        for (int kg = 0; kg < KG; kg++) {
+          const f32x4 ca0 = a0, ca1 = a1, cb = b;
+          if (kg + 1 < KG) {
+            a0 = a0p[(kg + 1) * 64];
+            a1 = a1p[(kg + 1) * 64];
+            b = *reinterpret_cast<const f32x4*>(xp + (kg + 1) * 16);
+          }
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int ks = min(ks0 + u, KS - 1);
-        a0[u] = f0[ks * 64];
-        a1[u] = f1[ks * 64];
-        bb[u] = xb[ks * 4 * LDP];
-      }
-#pragma unroll
-      for (int u = 0; u < 8; u++) {
-        if (ks0 + u < KS) {
-          acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[u], bb[u], acc0, 0, 0, 0);
-          acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[u], bb[u], acc1, 0, 0, 0);
+          for (int s4 = 0; s4 < 4; s4++) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca0[s4], cb[s4], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca1[s4], cb[s4], acc1, 0, 0, 0);
+          }
         }
+        epi(rt * 16 + rsub, col, acc0);
+        epi(rt2 * 16 + rsub, col, acc1);
+      } else {  // one tile: even/odd K-groups on two accumulators
+        for (int kg = 0; kg < KG; kg += 2) {
+          const f32x4 a0 = a0p[kg * 64], b0 = *reinterpret_cast<const f32x4*>(xp + kg * 16);
+          const bool has1 = kg + 1 < KG;
+          f32x4 a1 = a0, b1 = b0;
+          if (has1) {
+            a1 = a0p[(kg + 1) * 64];
+            b1 = *reinterpret_cast<const f32x4*>(xp + (kg + 1) * 16);
+          }
+#pragma unroll
+          for (int s4 = 0; s4 < 4; s4++) {
+            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s4], b0[s4], acc0, 0, 0, 0);
+            if (has1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s4], b1[s4], acc1, 0, 0, 0);
+          }
+        }
+        epi(rt * 16 + rsub, col, acc0 + acc1);
       }
     }
-    const int col = lane & 15, rbase = (lane >> 4) * 4;
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const int row = rt * 16 + rbase + r;
-      if (row < R) epi(row, col, acc0[r]);
-    }
-    if (two) {
-#pragma unroll
-      for (int r = 0; r < 4; r++) {
-        const int row = rt2 * 16 + rbase + r;
-        if (row < R) epi(row, col, acc1[r]);
+  } else {
+    // narrow layer (1 or 2 row tiles): split K over the waves, reduce through LDS
+    const int nparts = RT == 1 ? 4 : 2;
+    const int rt = wave % RT, part = wave / RT;
+    const int per = cdiv(KG, nparts), k0 = part * per, k1 = min(KG, k0 + per);
+    f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+    const f32x4* a0p = A + (size_t)rt * KG * 64 + lane;
+    for (int kg = k0; kg < k1; kg += 2) {
+      const f32x4 a0 = a0p[kg * 64], b0 = *reinterpret_cast<const f32x4*>(xp + kg * 16);
+      const bool has1 = kg + 1 < k1;
+      f32x4 a1 = a0, b1 = b0;
+      if (has1) {
+        a1 = a0p[(kg + 1) * 64];
+        b1 = *reinterpret_cast<const f32x4*>(xp + (kg + 1) * 16);
       }
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4++) {
+        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s4], b0[s4], acc0, 0, 0, 0);
+        if (has1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s4], b1[s4], acc1, 0, 0, 0);
+      }
+    }
+    f32x4* rp = reinterpret_cast<f32x4*>(red);
+    rp[wave * 64 + lane] = acc0 + acc1;
+    __syncthreads();
+    if (part == 0) {
+      f32x4 t = rp[rt * 64 + lane];
+      for (int pp = 1; pp < nparts; pp++) t += rp[(rt + pp * RT) * 64 + lane];
+      epi(rt * 16 + rsub, col, t);
     }
   }
+}
+
+// A-fragments either from the LDS cache (pointer formed from the LDS base ⇒ ds_read_b128) or from global/L2
+// (kernel-argument pointer ⇒ global_load_dwordx4) — never through a generic pointer.
+template <class Epi>
+__device__ __forceinline__ void layer_gemm(const float* lds_base, int ofs, const float* gfrag, int R, int K, const float* Xt,
+                                           int ldx, float* red, Epi epi) {
+  if (ofs >= 0) panel_gemm(lds_base + ofs, R, K, Xt, ldx, red, epi);
+  else panel_gemm(gfrag, R, K, Xt, ldx, red, epi);
 }
 
 // ---- grid-wide deterministic sum (coupled mode) ----------------------------------------------------
@@ -202,47 +266,92 @@ struct Ctl {
   int j[NB], accepted[NB], last[NB], hit[NB], nfe[NB], nacc[NB], nrej[NB], iters[NB], savej[NB];
   int any_active, any_save, all_accepted;
   float bcast[4];
+  int wofs[MAXL];    // ≥0: float offset (from the LDS base) of the cached copy of layer l's W fragments; <0: not cached
+  int wTofs[MAXL];   // same for Wᵀ  (offsets, not pointers: a pointer read back from memory is "flat" to the compiler and
+                     //  every flat load drains vmcnt AND lgkmcnt — measured: ~50 % of all wave cycles parked)
 };
 
-struct Panels {       // LDS carve-up
-  float* y;           // [NSr][LDP]   NSr = rows of the integrated state, padded to a multiple of 4
+struct Panels {       // LDS carve-up; every panel is transposed: element (row, col) at col*ld + row
+  float* y;
   float* yn;
   float* tmp;
-  float* kbase;       // k[s] = kbase + s*pstride   (computed, not an array of pointers: no scratch)
-  float* hidbase;     // hidden activations (post-activation) of layers 0..nL-2: hid[l] = hidbase + l*hstride
+  float* kbase;       // k[s] = kbase + s*pstride
+  float* hidbase;     // hidden activations (post-activation) of layers 0..nL-2
   float* delbase;     // backprop panels (adjoint only)
-  float* scr;         // [NSr][LDP] scratch (error terms)
+  float* scr;         // scratch (error terms, 1/scale)
+  float* red;         // 1024 floats: split-K reduction scratch
+  float* biasc;       // LDS copy of all biases (compact, bias_lin order)
   int pstride, hstride;
+  int lds, ldh;       // strides of state / hidden panels
+  const float* lbase; // LDS base (float view of the dynamic shared array)
+  const float* gfrag; // global fragment arrays
+  const float* gfragT;
   __device__ __forceinline__ float* k(int s) const { return kbase + s * pstride; }
   __device__ __forceinline__ float* hid(int l) const { return hidbase + l * hstride; }
   __device__ __forceinline__ float* del(int i) const { return delbase + i * hstride; }
 };
 
-// f(z) for the tile: dst[0:Dp] = MLP(src[0:Dp]) (+ pendulum); hidden activations are left in P.hid[*].
-__device__ __forceinline__ void eval_rhs(const MlpDims& dm, const float* __restrict__ frag,
-                                         const float* __restrict__ Wflat, const Panels& P, const Ctl* c,
-                                         const float* src, float* dst) {
-  const float* X = src;
+// copy weight fragments into the LDS cache while they fit; record where each layer's fragments live
+__device__ __forceinline__ float* cache_frags(const MlpDims& dm, const float* gfrag, const int* off, const int* cnt,
+                                              int* table, const float* lds_base, float* cache, float* cache_end) {
   for (int l = 0; l < dm.nL; l++) {
+    const float* src = gfrag + off[l];
+    const int n = cnt[l];
+    const bool fits = cache + n <= cache_end;
+    if (fits) {
+      const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
+      f32x4* d4 = reinterpret_cast<f32x4*>(cache);
+      for (int i = threadIdx.x; i < n / 4; i += NTHREADS) d4[i] = s4[i];
+    }
+    if (threadIdx.x == 0) table[l] = fits ? (int)(cache - lds_base) : -1;
+    if (fits) cache += n;
+  }
+  return cache;
+}
+
+// f(z) for the tile: dst rows [0,Dp) = MLP(src rows [0,Dp)) (+ pendulum); hidden activations are left in P.hid(*).
+// NL > 0: the layer loop is unrolled with compile-time l, so that every dm.x[l] is a fixed kernel-argument word the
+// compiler loads once into SGPRs (with a runtime l each access is a scalar-memory load followed by an lgkmcnt wait
+// that also drains the LDS queue). NL = 0: generic runtime loop.
+template <int NL>
+__device__ __forceinline__ void eval_rhs(const MlpDims& dm, const Panels& P, const Ctl* c, const float* src, float* dst) {
+  const float* X = src;
+  int ldx = P.lds;
+  const int nL = NL > 0 ? NL : dm.nL;
+#pragma unroll
+  for (int l = 0; l < (NL > 0 ? NL : MAXL); l++) {
+    if (NL == 0 && l >= nL) break;
     const int in = dm.sizes[l], out = dm.sizes[l + 1];
-    const bool lastl = l == dm.nL - 1;
+    const bool lastl = l == nL - 1;
     float* Y = lastl ? dst : P.hid(l);
-    const float* bias = Wflat + dm.b_off[l];
+    const int ldy = lastl ? P.lds : P.ldh;
+    const float* bias = P.biasc + dm.bias_lin[l];
     const int actk = dm.act;
-    panel_gemm(frag + dm.frag_off[l], out, in, X, [&](int row, int col, float v) {
-      v += bias[row];
-      if (!lastl) v = act_fn(actk, v);
-      Y[row * LDP + col] = v;
+    layer_gemm(P.lbase, c->wofs[l], P.gfrag + dm.frag_off[l], out, in, X, ldx, P.red, [&](int row0, int col, f32x4 v) {
+      f32x4 r;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        float x = row0 + q < out ? v[q] + bias[row0 + q] : 0.f;
+        if (!lastl) x = act_fn(actk, x);
+        r[q] = x;
+      }
+      if (lastl) {  // never write the rows that follow the output block (λ rows in the adjoint state)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (row0 + q < out) Y[col * ldy + row0 + q] = r[q];
+      } else
+        *reinterpret_cast<f32x4*>(Y + col * ldy + row0) = r;
     });
     __syncthreads();
     X = Y;
+    ldx = ldy;
   }
   if (dm.has_pend) {
     if (threadIdx.x < NB) {
       const int col = threadIdx.x;
-      const float x = src[0 * LDP + col], yv = src[1 * LDP + col];
-      dst[0 * LDP + col] += yv;
-      dst[1 * LDP + col] += c->ngl[col] * fast_sin(x);
+      const float x = src[col * P.lds + 0], yv = src[col * P.lds + 1];
+      dst[col * P.lds + 0] += yv;
+      dst[col * P.lds + 1] += c->ngl[col] * fast_sin(x);
     }
     __syncthreads();
   }
@@ -259,8 +368,15 @@ struct FwdArgs {
   int32_t* retcode;
   int32_t *st_nfe, *st_nacc, *st_nrej, *st_ret;
   GridSync gs;
+  int lds_bytes;      // dynamic LDS actually requested (the weight cache takes what the panels leave)
 };
 
+__device__ __forceinline__ void load_biases(const MlpDims& dm, const float* Wflat, float* biasc) {
+  for (int l = 0; l < dm.nL; l++)
+    for (int i = threadIdx.x; i < dm.sizes[l + 1]; i += NTHREADS) biasc[dm.bias_lin[l] + i] = Wflat[dm.b_off[l] + i];
+}
+
+template <int NL>
 __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int T = o.T, B = o.B, Dp = dm.Dp, D = dm.D;
@@ -270,33 +386,45 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
   float* base = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(s_ts) + (((size_t)T * 8 + 15) & ~size_t(15)));
   Panels P;
   const int NS = Dp;
-  const int NSr = (NS + 3) & ~3;   // panels are padded to a multiple of 4 rows (K-steps read whole groups of 4)
+  P.lds = dm.ld_sf;
+  P.ldh = dm.ld_h;
+  P.pstride = NB * P.lds;
+  P.hstride = NB * P.ldh;
   float* p = base;
-  P.y = p; p += NSr * LDP;
-  P.yn = p; p += NSr * LDP;
-  P.tmp = p; p += NSr * LDP;
-  P.pstride = NSr * LDP;
-  P.hstride = dm.hmax * LDP;
+  P.y = p; p += P.pstride;
+  P.yn = p; p += P.pstride;
+  P.tmp = p; p += P.pstride;
   P.kbase = p; p += 7 * P.pstride;
-  P.scr = p; p += NSr * LDP;
+  P.scr = p; p += P.pstride;
   P.hidbase = p; p += (dm.nL > 1 ? dm.nL - 1 : 0) * P.hstride;
   P.delbase = nullptr;
+  P.red = p; p += 1024;
+  P.biasc = p; p += (dm.nbias + 3) & ~3;
   const int nfloat = (int)(p - base);
-  for (int i = threadIdx.x; i < nfloat; i += NTHREADS) base[i] = 0.f;   // pad rows/cols must be finite (0·x)
+  for (int i = threadIdx.x; i < nfloat; i += NTHREADS) base[i] = 0.f;   // pad rows must be finite (0·x)
   for (int i = threadIdx.x; i < T; i += NTHREADS) s_ts[i] = a.ts[i];
+  __syncthreads();
+  P.lbase = reinterpret_cast<const float*>(smem);
+  P.gfrag = a.frag;
+  P.gfragT = nullptr;
+  load_biases(dm, a.Wflat, P.biasc);
+  cache_frags(dm, a.frag, dm.frag_off, dm.frag_n, c->wofs, P.lbase, p, reinterpret_cast<float*>(smem + a.lds_bytes));
   __syncthreads();
 
   const int tid = threadIdx.x;
   const int b0 = blockIdx.x * NB;
   const int nel = NS * NB;                      // elements of a state panel handled cooperatively
+  const int lds = P.lds;
   const bool coupled = dm.coupled != 0;
   const double t0 = s_ts[0], tend = s_ts[T - 1], dtmax = tend - t0;
   unsigned gen = 0;
+#define EIDX(e) (((e) / NS) * lds + ((e) % NS))   /* element e ↦ (col = e/NS, row = e%NS) */
+#define ECOL(e) ((e) / NS)
 
   // ---- load the tile: column-major z0 [D×B]; augmented rows stay 0 -----------------------------------
   for (int e = tid; e < NB * D; e += NTHREADS) {
     const int col = e / D, row = e % D;
-    if (b0 + col < B) P.y[row * LDP + col] = a.z0[(size_t)(b0 + col) * D + row];
+    if (b0 + col < B) P.y[col * lds + row] = a.z0[(size_t)(b0 + col) * D + row];
   }
   if (tid < NB) {
     const int col = tid;
@@ -316,32 +444,31 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
   // save time 0 = ẑ₀ itself (augmented rows 0)
   for (int e = tid; e < NB * Dp; e += NTHREADS) {
     const int col = e / Dp, row = e % Dp;
-    if (b0 + col < B) a.z_out[(size_t)(b0 + col) * Dp + row] = P.y[row * LDP + col];
+    if (b0 + col < B) a.z_out[(size_t)(b0 + col) * Dp + row] = P.y[col * lds + row];
   }
 
   if (T > 1) {
-    eval_rhs(dm, a.frag, a.Wflat, P, c, P.y, P.k(0));
+    eval_rhs<NL>(dm, P, c, P.y, P.k(0));
     if (tid < NB && c->status[tid] == 0) c->nfe[tid]++;
 
     // ---- initial step size ---------------------------------------------------------------------------
     if (o.adaptive && !(o.dt_fixed > 0)) {
-      // d0, d1 (per column, or over the whole batch when coupled)
       for (int e = tid; e < nel; e += NTHREADS) {
-        const int row = e / NB, col = e % NB;
-        const float yv = P.y[row * LDP + col];
+        const int idx = EIDX(e);
+        const float yv = P.y[idx];
         const float sk = fast_rcp(o.abstol + fabsf(yv) * o.reltol);
-        P.scr[row * LDP + col] = sk;
-        const float a0 = yv * sk, a1 = P.k(0)[row * LDP + col] * sk;
-        P.tmp[row * LDP + col] = a0 * a0;
-        P.yn[row * LDP + col] = a1 * a1;
+        P.scr[idx] = sk;
+        const float a0 = yv * sk, a1 = P.k(0)[idx] * sk;
+        P.tmp[idx] = a0 * a0;
+        P.yn[idx] = a1 * a1;
       }
       __syncthreads();
       float v[4] = {0.f, 0.f, 0.f, 0.f};
       if (tid < NB) {
         float s0 = 0.f, s1 = 0.f;
-        for (int r = 0; r < NS; r++) { s0 += P.tmp[r * LDP + tid]; s1 += P.yn[r * LDP + tid]; }
-        c->eest[tid] = s0;   // reuse as scratch: Σ (y/sk)²
-        c->wq[tid] = s1;     //                   Σ (f0/sk)²
+        for (int r = 0; r < NS; r++) { s0 += P.tmp[tid * lds + r]; s1 += P.yn[tid * lds + r]; }
+        c->eest[tid] = s0;   // Σ (y/sk)²
+        c->wq[tid] = s1;     // Σ (f0/sk)²
       }
       __syncthreads();
       if (coupled) {
@@ -362,21 +489,21 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
       }
       __syncthreads();
       for (int e = tid; e < nel; e += NTHREADS) {
-        const int row = e / NB, col = e % NB;
-        P.tmp[row * LDP + col] = P.y[row * LDP + col] + c->h[col] * P.k(0)[row * LDP + col];
+        const int idx = EIDX(e);
+        P.tmp[idx] = P.y[idx] + c->h[ECOL(e)] * P.k(0)[idx];
       }
       __syncthreads();
-      eval_rhs(dm, a.frag, a.Wflat, P, c, P.tmp, P.k(1));
+      eval_rhs<NL>(dm, P, c, P.tmp, P.k(1));
       if (tid < NB && c->status[tid] == 0) c->nfe[tid]++;
       for (int e = tid; e < nel; e += NTHREADS) {
-        const int row = e / NB, col = e % NB;
-        const float d = (P.k(1)[row * LDP + col] - P.k(0)[row * LDP + col]) * P.scr[row * LDP + col];
-        P.yn[row * LDP + col] = d * d;
+        const int idx = EIDX(e);
+        const float d = (P.k(1)[idx] - P.k(0)[idx]) * P.scr[idx];
+        P.yn[idx] = d * d;
       }
       __syncthreads();
       if (tid < NB) {
         float s2 = 0.f;
-        for (int r = 0; r < NS; r++) s2 += P.yn[r * LDP + tid];
+        for (int r = 0; r < NS; r++) s2 += P.yn[tid * lds + r];
         c->eest[tid] = s2;
       }
       __syncthreads();
@@ -429,65 +556,60 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
         c->any_active = any;
       }
       __syncthreads();
-      int any_active = c->any_active;
-      if (coupled && a.gs.nwg > 1) {  // all workgroups make identical decisions, but leave together
-        // (identical control arithmetic ⇒ any_active agrees everywhere; nothing to exchange)
-      }
-      if (!any_active) break;
+      if (!c->any_active) break;   // coupled: identical control arithmetic ⇒ every workgroup leaves together
 
       if (dm.solver == LDE_SOLVER_TSIT5) {
         for (int s = 1; s <= 6; s++) {
           float* dst = s < 6 ? P.tmp : P.yn;
           for (int e = tid; e < nel; e += NTHREADS) {
-            const int row = e / NB, col = e % NB, idx = row * LDP + col;
+            const int idx = EIDX(e);
             float acc = ts5::A[s][0] * P.k(0)[idx];
             for (int jj = 1; jj < s; jj++) acc += ts5::A[s][jj] * P.k(jj)[idx];
-            dst[idx] = P.y[idx] + c->h[col] * acc;
+            dst[idx] = P.y[idx] + c->h[ECOL(e)] * acc;
           }
           __syncthreads();
-          eval_rhs(dm, a.frag, a.Wflat, P, c, dst, P.k(s));
+          eval_rhs<NL>(dm, P, c, dst, P.k(s));
         }
         if (tid < NB && c->status[tid] == 0) c->nfe[tid] += 6;
       } else {  // classical RK4; k[4] = f(yn) doubles as the next k1
         for (int s = 1; s <= 3; s++) {
           const float cs = s == 3 ? 1.0f : 0.5f;
           for (int e = tid; e < nel; e += NTHREADS) {
-            const int row = e / NB, col = e % NB, idx = row * LDP + col;
-            P.tmp[idx] = P.y[idx] + (cs * c->h[col]) * P.k(s - 1)[idx];
+            const int idx = EIDX(e);
+            P.tmp[idx] = P.y[idx] + (cs * c->h[ECOL(e)]) * P.k(s - 1)[idx];
           }
           __syncthreads();
-          eval_rhs(dm, a.frag, a.Wflat, P, c, P.tmp, P.k(s));
+          eval_rhs<NL>(dm, P, c, P.tmp, P.k(s));
         }
         for (int e = tid; e < nel; e += NTHREADS) {
-          const int row = e / NB, col = e % NB, idx = row * LDP + col;
-          P.yn[idx] = P.y[idx] + (c->h[col] * (1.0f / 6.0f)) * (P.k(0)[idx] + 2.0f * (P.k(1)[idx] + P.k(2)[idx]) + P.k(3)[idx]);
+          const int idx = EIDX(e);
+          P.yn[idx] = P.y[idx] + (c->h[ECOL(e)] * (1.0f / 6.0f)) * (P.k(0)[idx] + 2.0f * (P.k(1)[idx] + P.k(2)[idx]) + P.k(3)[idx]);
         }
         __syncthreads();
-        eval_rhs(dm, a.frag, a.Wflat, P, c, P.yn, P.k(4));
+        eval_rhs<NL>(dm, P, c, P.yn, P.k(4));
         if (tid < NB && c->status[tid] == 0) c->nfe[tid] += 4;
       }
 
       // ---- error estimate -----------------------------------------------------------------------------
       for (int e = tid; e < nel; e += NTHREADS) {
-        const int row = e / NB, col = e % NB, idx = row * LDP + col;
+        const int idx = EIDX(e);
         float r2 = 0.f;
         const float yv = P.y[idx], ynv = P.yn[idx];
         if (o.adaptive) {
           float er = ts5::BT[0] * P.k(0)[idx];
 #pragma unroll
           for (int jj = 1; jj < 7; jj++) er += ts5::BT[jj] * P.k(jj)[idx];
-          er *= c->h[col];
+          er *= c->h[ECOL(e)];
           const float sk = o.abstol + fmaxf(fabsf(yv), fabsf(ynv)) * o.reltol;
           const float r = er * fast_rcp(sk);
           r2 = r * r;
         }
-        // non-finite state poisons the column's sum
-        P.scr[idx] = isfinite(ynv) ? r2 : __int_as_float(0x7fc00000);
+        P.scr[idx] = isfinite(ynv) ? r2 : __int_as_float(0x7fc00000);   // non-finite state poisons the column's sum
       }
       __syncthreads();
       if (tid < NB) {
         float s2 = 0.f;
-        for (int r = 0; r < NS; r++) s2 += P.scr[r * LDP + tid];
+        for (int r = 0; r < NS; r++) s2 += P.scr[tid * lds + r];
         c->eest[tid] = s2;
       }
       __syncthreads();
@@ -560,7 +682,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
         __syncthreads();
         if (!c->any_save) break;
         for (int e = tid; e < NB * Dp; e += NTHREADS) {
-          const int col = e / Dp, row = e % Dp, idx = row * LDP + col;
+          const int col = e / Dp, row = e % Dp, idx = col * lds + row;
           if (!c->hit[col]) continue;
           const float th = c->th[col], h = c->wq[col];
           float out;
@@ -587,8 +709,8 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
       {
         const int fs = dm.solver == LDE_SOLVER_TSIT5 ? 6 : 4;
         for (int e = tid; e < nel; e += NTHREADS) {
-          const int row = e / NB, col = e % NB, idx = row * LDP + col;
-          if (c->accepted[col]) {
+          const int idx = EIDX(e);
+          if (c->accepted[ECOL(e)]) {
             P.y[idx] = P.yn[idx];
             P.k(0)[idx] = P.k(fs)[idx];
           }
@@ -620,8 +742,9 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
     a.st_nacc[b] = rep ? c->nacc[col] : 0;
     a.st_nrej[b] = rep ? c->nrej[col] : 0;
   }
+#undef EIDX
+#undef ECOL
 }
-
 
 // ================================================ adjoint ==================================================
 struct BwdArgs {
@@ -637,75 +760,95 @@ struct BwdArgs {
   float* slab;        // [nWG][nW] this launch's per-workgroup weight-gradient slabs
   int32_t *st_nfe, *st_nacc, *st_nrej, *st_ret;
   GridSync gs;
+  int lds_bytes;
 };
 
 // f, −(∂f/∂z)ᵀλ, −(∂f/∂θ)ᵀλ for the tile, and the weighted outer products of this stage.
-//   src/dst rows: [0,Dp) z | [Dp,2Dp) λ | [2Dp,2Dp+P) g.   wst[col] = quadrature weight of this stage (0 ⇒ none)
+//   src/dst rows: [0,Dp) z | [DpA,DpA+Dp) λ | [2DpA,2DpA+P) g.   wst[col] = quadrature weight of this stage (0 ⇒ none)
 template <int NDW>
-__device__ __forceinline__ void eval_bwd(const MlpDims& dm, const BwdArgs& a, const Panels& P, const Ctl* c,
-                                         const float* src, float* dst, const float* wst, bool any_w,
-                                         f32x4 (&acc)[NDW], float* bstep, const int* tile_off) {
-  const int Dp = dm.Dp, nL = dm.nL;
+__device__ __forceinline__ void eval_bwd(const MlpDims& dm, const Panels& P, const Ctl* c, const float* src, float* dst,
+                                         const float* wst, bool any_w, f32x16 (&acc)[NDW], float* bstep) {
+  const int DpA = dm.DpA, nL = dm.nL;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // 1. forward through the MLP (relu masks are recomputed here, not stored by the forward solve)
-  eval_rhs(dm, a.frag, a.Wflat, P, c, src, dst);
+  eval_rhs<0>(dm, P, c, src, dst);
   // 2. back-propagate λ; δ_L = λ_stage
-  const float* dl = src + Dp * LDP;
+  const float* dl = src + DpA;
+  int ldd = P.lds;
+  const int half = lane >> 5;
   for (int l = nL - 1; l >= 0; l--) {
     const int in = dm.sizes[l], out = dm.sizes[l + 1];
     const float* al = l == 0 ? src : P.hid(l - 1);   // input activation of layer l
+    const int lda = l == 0 ? P.lds : P.ldh;
     if (any_w) {
-      // gWᵀ tile [i][o] += Σ_n a_l[i][n] · (w_n δ[o][n]); tiles of layer l owned by this wave
-      const int IT = cdiv(in, 16);
-      const int t0 = tile_off[l], t1 = tile_off[l + 1];
-      float wl[4];
+      // gWᵀ 32×32 tile [i][o] += Σ_n a_l[i][n] · (w_n δ[o][n]) on v_mfma_f32_32x32x2_f32: MFMA s contracts the two columns
+      // n = 2s + (lane>>5); every operand read is 32 consecutive floats per half-wave (conflict-free).
+      const int IT = cdiv(in, 32);
+      const int t0 = dm.tile_off[l], t1 = dm.tile_off[l + 1];
+      float wl[8];
 #pragma unroll
-      for (int s4 = 0; s4 < 4; s4++) wl[s4] = wst[s4 * 4 + (lane >> 4)];
+      for (int s8 = 0; s8 < 8; s8++) wl[s8] = wst[2 * s8 + half];
 #pragma unroll
       for (int m = 0; m < NDW; m++) {
         const int t = wave + 4 * m;
         if (t >= t0 && t < t1) {
-          const int tt = t - t0, ot = tt / IT, it = tt % IT;
-          const float* ap = al + (it * 16 + (lane & 15)) * LDP + (lane >> 4);
-          const float* bp = dl + (ot * 16 + (lane & 15)) * LDP + (lane >> 4);
+          const int tt = t - t0, ot = tt / IT, it = tt - ot * IT;
+          const float* ap = al + half * lda + it * 32 + (lane & 31);
+          const float* bp = dl + half * ldd + ot * 32 + (lane & 31);
+          float av[8], bv[8];
 #pragma unroll
-          for (int s4 = 0; s4 < 4; s4++)
-            acc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[s4 * 4], bp[s4 * 4] * wl[s4], acc[m], 0, 0, 0);
+          for (int s8 = 0; s8 < 8; s8++) {
+            av[s8] = ap[s8 * 2 * lda];
+            bv[s8] = bp[s8 * 2 * ldd] * wl[s8];
+          }
+#pragma unroll
+          for (int s8 = 0; s8 < 8; s8++) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s8], bv[s8], acc[m], 0, 0, 0);
         }
+        __builtin_amdgcn_sched_barrier(0);   // keep one tile's 16 operand loads in flight, not all NDW tiles' (VGPR blow-up)
       }
       for (int row = threadIdx.x; row < out; row += NTHREADS) {
         float sacc = 0.f;
 #pragma unroll
-        for (int n = 0; n < NB; n++) sacc += wst[n] * dl[row * LDP + n];
+        for (int n = 0; n < NB; n++) sacc += wst[n] * dl[n * ldd + row];
         bstep[dm.bias_lin[l] + row] += sacc;   // each (layer,row) is owned by exactly one thread
       }
     }
     // δ_in = W_lᵀ δ  (⊙ act'(a_l) for hidden layers); layer 0 gives (∂f/∂z)ᵀλ
     if (l > 0) {
       float* dn = P.del((nL - 1 - l) & 1);
-      const int actk = dm.act;
-      panel_gemm(a.fragT + dm.fragT_off[l], in, out, dl, [&](int row, int col, float v) {
-        dn[row * LDP + col] = v * act_grad(actk, al[row * LDP + col]);
+      const int actk = dm.act, ldh = P.ldh;
+      layer_gemm(P.lbase, c->wTofs[l], P.gfragT + dm.fragT_off[l], in, out, dl, ldd, P.red, [&](int row0, int col, f32x4 v) {
+        const f32x4 av = *reinterpret_cast<const f32x4*>(al + col * ldh + row0);
+        f32x4 r;
+#pragma unroll
+        for (int q = 0; q < 4; q++) r[q] = row0 + q < in ? v[q] * act_grad(actk, av[q]) : 0.f;
+        *reinterpret_cast<f32x4*>(dn + col * ldh + row0) = r;
       });
       __syncthreads();
       dl = dn;
+      ldd = ldh;
     } else {
-      float* dlam = dst + Dp * LDP;
-      panel_gemm(a.fragT + dm.fragT_off[0], in, out, dl, [&](int row, int col, float v) { dlam[row * LDP + col] = -v; });
+      float* dlam = dst + DpA;
+      const int lds = P.lds;
+      layer_gemm(P.lbase, c->wTofs[0], P.gfragT + dm.fragT_off[0], in, out, dl, ldd, P.red, [&](int row0, int col, f32x4 v) {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (row0 + q < in) dlam[col * lds + row0 + q] = -v[q];
+      });
       __syncthreads();
     }
   }
   // 3. known-physics part: J = [[0,1],[ngl·cos x, 0]], ∂f₂/∂L = gl2·sin x
   if (dm.has_pend) {
     if (threadIdx.x < NB) {
-      const int col = threadIdx.x;
+      const int col = threadIdx.x, o_ = col * P.lds;
       float sn, cs;
-      fast_sincos(src[0 * LDP + col], sn, cs);
-      const float l0 = src[(Dp + 0) * LDP + col], l1 = src[(Dp + 1) * LDP + col];
+      fast_sincos(src[o_ + 0], sn, cs);
+      const float l0 = src[o_ + DpA + 0], l1 = src[o_ + DpA + 1];
       // eval_rhs already added the pendulum to f (rows 0,1)
-      dst[(Dp + 0) * LDP + col] -= c->ngl[col] * cs * l1;
-      dst[(Dp + 1) * LDP + col] -= l0;
-      dst[(2 * Dp) * LDP + col] = -(c->gl2[col] * sn * l1);
+      dst[o_ + DpA + 0] -= c->ngl[col] * cs * l1;
+      dst[o_ + DpA + 1] -= l0;
+      dst[o_ + 2 * DpA] = -(c->gl2[col] * sn * l1);
     }
     __syncthreads();
   }
@@ -715,16 +858,18 @@ __device__ __forceinline__ void eval_bwd(const MlpDims& dm, const BwdArgs& a, co
 template <int NDW>
 __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const int T = o.T, B = o.B, Dp = dm.Dp, D = dm.D, NP = dm.P;
+  const int T = o.T, B = o.B, Dp = dm.Dp, DpA = dm.DpA, D = dm.D, NP = dm.P;
   Ctl* c = reinterpret_cast<Ctl*>(smem);
   double* s_ts = reinterpret_cast<double*>(smem + ((sizeof(Ctl) + 15) & ~size_t(15)));
   float* base = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(s_ts) + (((size_t)T * 8 + 15) & ~size_t(15)));
   Panels P;
-  const int NS = 2 * Dp + NP;
-  const int NSr = (NS + 3) & ~3;
+  const int NS = 2 * DpA + NP;        // panel rows in use (pad rows between the blocks stay 0)
+  const int NREAL = 2 * Dp + NP;      // entries that count in the error norm
+  P.lds = dm.ld_sb;
+  P.ldh = dm.ld_h;
+  P.pstride = NB * P.lds;
+  P.hstride = NB * P.ldh;
   float* p = base;
-  P.pstride = NSr * LDP;
-  P.hstride = dm.hmax * LDP;
   P.y = p; p += P.pstride;
   P.yn = p; p += P.pstride;
   P.tmp = p; p += P.pstride;
@@ -732,56 +877,78 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
   P.scr = p; p += P.pstride;
   P.hidbase = p; p += (dm.nL > 1 ? dm.nL - 1 : 0) * P.hstride;
   P.delbase = p; p += 2 * P.hstride;
+  P.red = p; p += 1024;
+  P.biasc = p; p += (dm.nbias + 3) & ~3;
   float* bstep = p; p += (dm.nbias + 3) & ~3;
   float* wst = p; p += NB;
   const int nfloat = (int)(p - base);
   for (int i = threadIdx.x; i < nfloat; i += NTHREADS) base[i] = 0.f;
   for (int i = threadIdx.x; i < T; i += NTHREADS) s_ts[i] = a.ts[i];
   __syncthreads();
+  P.lbase = reinterpret_cast<const float*>(smem);
+  P.gfrag = a.frag;
+  P.gfragT = a.fragT;
+  load_biases(dm, a.Wflat, P.biasc);
+  {
+    float* cend = reinterpret_cast<float*>(smem + a.lds_bytes);
+    float* cp = cache_frags(dm, a.fragT, dm.fragT_off, dm.fragT_n, c->wTofs, P.lbase, p, cend);
+    cache_frags(dm, a.frag, dm.frag_off, dm.frag_n, c->wofs, P.lbase, cp, cend);
+  }
+  __syncthreads();
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int b0 = blockIdx.x * NB;
   const int nel = NS * NB;
+  const int lds = P.lds;
   const bool coupled = dm.coupled != 0;
   const double tT = s_ts[T - 1], dtmax = fabs(tT - s_ts[0]);
   unsigned gen = 0;
-  float* slab = a.slab + (size_t)blockIdx.x * dm.nW;
-  for (int i = tid; i < dm.nW; i += NTHREADS) slab[i] = 0.f;
+  float* slab = a.slab + (size_t)blockIdx.x * dm.slab_n;
+  for (int i = tid; i < dm.slab_n; i += NTHREADS) slab[i] = 0.f;
+#define EIDX(e) (((e) / NS) * lds + ((e) % NS))
+#define ECOL(e) ((e) / NS)
 
-  f32x4 acc[NDW];
+  f32x16 acc[NDW];
 #pragma unroll
-  for (int m = 0; m < NDW; m++) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int m = 0; m < NDW; m++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
 
-  // commit the step's outer products (held as Wᵀ tiles [i][o] in MFMA accumulators) and bias sums to the slab
+  // commit the step's outer products to the slab. The slab keeps every 32×32 tile in ACCUMULATOR-FRAGMENT order
+  // (tile, lane, 16 registers), so a lane adds 64 contiguous bytes per tile: four coalesced dwordx4 read-modify-writes.
+  // k_reduce_slabs maps fragment order back to the flat destructure order.
+  const int ntiles = dm.tile_off[dm.nL];
   auto commit = [&]() {
-    for (int l = 0; l < dm.nL; l++) {
-      const int in = dm.sizes[l], out = dm.sizes[l + 1], IT = cdiv(in, 16);
-      const int t0 = dm.tile_off[l], t1 = dm.tile_off[l + 1];
-      float* gW = slab + dm.w_off[l];
 #pragma unroll
-      for (int m = 0; m < NDW; m++) {
-        const int t = wave + 4 * m;
-        if (t >= t0 && t < t1) {
-          const int tt = t - t0, ot = tt / IT, it = tt % IT;
-          const int oc = ot * 16 + (lane & 15);
+    for (int m = 0; m < NDW; m++) {
+      const int t = wave + 4 * m;
+      if (t < ntiles) {
+        f32x4* g4 = reinterpret_cast<f32x4*>(slab + ((size_t)t * 64 + lane) * 16);
 #pragma unroll
-          for (int r = 0; r < 4; r++) {
-            const int ir = it * 16 + (lane >> 4) * 4 + r;
-            if (oc < out && ir < in) gW[oc + (size_t)out * ir] += acc[m][r];
-          }
-          acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int q = 0; q < 4; q++) {
+          f32x4 v = g4[q];
+          v[0] += acc[m][4 * q + 0];
+          v[1] += acc[m][4 * q + 1];
+          v[2] += acc[m][4 * q + 2];
+          v[3] += acc[m][4 * q + 3];
+          g4[q] = v;
         }
+#pragma unroll
+        for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
       }
-      float* gb = slab + dm.b_off[l];
-      for (int row = tid; row < out; row += NTHREADS) {
-        gb[row] += bstep[dm.bias_lin[l] + row];
-        bstep[dm.bias_lin[l] + row] = 0.f;
-      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    float* gb = slab + (size_t)ntiles * 1024;
+    for (int i = tid; i < dm.nbias; i += NTHREADS) {
+      gb[i] += bstep[i];
+      bstep[i] = 0.f;
     }
   };
   auto discard = [&]() {
 #pragma unroll
-    for (int m = 0; m < NDW; m++) acc[m] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int m = 0; m < NDW; m++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
     for (int i = tid; i < dm.nbias; i += NTHREADS) bstep[i] = 0.f;
   };
 
@@ -790,8 +957,8 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
     const int col = e / Dp, row = e % Dp;
     if (b0 + col < B) {
       const size_t src = (size_t)Dp * ((size_t)(b0 + col) + (size_t)B * (T - 1)) + row;
-      P.y[row * LDP + col] = a.z_out[src];
-      P.y[(Dp + row) * LDP + col] = a.dz_out[src];
+      P.y[col * lds + row] = a.z_out[src];
+      P.y[col * lds + DpA + row] = a.dz_out[src];
     }
   }
   __syncthreads();
@@ -799,7 +966,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
     const int col = tid;
     const bool valid = b0 + col < B;
     bool bad = false;
-    for (int r = 0; r < Dp; r++) bad = bad || !isfinite(P.y[r * LDP + col]);
+    for (int r = 0; r < Dp; r++) bad = bad || !isfinite(P.y[col * lds + r]);
     c->t[col] = tT;
     c->dt[col] = 0.0;
     c->qold[col] = 1e-4f;
@@ -816,17 +983,17 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
   }
   __syncthreads();
   if (tid < NB && c->status[tid] > 1) {   // neutralise the NaN column so that it cannot trip the tile-wide logic
-    for (int r = 0; r < NS; r++) P.y[r * LDP + tid] = 0.f;
+    for (int r = 0; r < NS; r++) P.y[tid * lds + r] = 0.f;
   }
   __syncthreads();
 
   if (T > 1) {
     // ---- initial step size (Hairer) on the augmented state, direction −1 ------------------------------------
     if (o.adaptive && !(o.dt_fixed > 0)) {
-      eval_bwd<NDW>(dm, a, P, c, P.y, P.k(0), wst, false, acc, bstep, dm.tile_off);
+      eval_bwd<NDW>(dm, P, c, P.y, P.k(0), wst, false, acc, bstep);
       if (tid < NB && c->status[tid] == 0) c->nfe[tid]++;
       for (int e = tid; e < nel; e += NTHREADS) {
-        const int row = e / NB, col = e % NB, idx = row * LDP + col;
+        const int idx = EIDX(e);
         const float yv = P.y[idx];
         const float sk = fast_rcp(o.abstol + fabsf(yv) * o.reltol);
         P.scr[idx] = sk;
@@ -837,7 +1004,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
       __syncthreads();
       if (tid < NB) {
         float s0 = 0.f, s1 = 0.f;
-        for (int r = 0; r < NS; r++) { s0 += P.tmp[r * LDP + tid]; s1 += P.yn[r * LDP + tid]; }
+        for (int r = 0; r < NS; r++) { s0 += P.tmp[tid * lds + r]; s1 += P.yn[tid * lds + r]; }
         c->eest[tid] = s0;
         c->wq[tid] = s1;
       }
@@ -850,7 +1017,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
         grid_sum4(a.gs, gen, v, c->bcast);
       }
       if (tid < NB) {
-        const float n = coupled ? (float)NS * (float)B : (float)NS;
+        const float n = coupled ? (float)NREAL * (float)B : (float)NREAL;
         const float d0 = sqrtf((coupled ? v[0] : c->eest[tid]) / n), d1 = sqrtf((coupled ? v[1] : c->wq[tid]) / n);
         double dt0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6 : 0.01 * (double)(d0 * fast_rcp(d1));
         if (dt0 > dtmax) dt0 = dtmax;
@@ -860,21 +1027,21 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
       }
       __syncthreads();
       for (int e = tid; e < nel; e += NTHREADS) {
-        const int row = e / NB, col = e % NB, idx = row * LDP + col;
-        P.tmp[idx] = P.y[idx] + c->h[col] * P.k(0)[idx];
+        const int idx = EIDX(e);
+        P.tmp[idx] = P.y[idx] + c->h[ECOL(e)] * P.k(0)[idx];
       }
       __syncthreads();
-      eval_bwd<NDW>(dm, a, P, c, P.tmp, P.k(1), wst, false, acc, bstep, dm.tile_off);
+      eval_bwd<NDW>(dm, P, c, P.tmp, P.k(1), wst, false, acc, bstep);
       if (tid < NB && c->status[tid] == 0) c->nfe[tid]++;
       for (int e = tid; e < nel; e += NTHREADS) {
-        const int row = e / NB, col = e % NB, idx = row * LDP + col;
+        const int idx = EIDX(e);
         const float dd = (P.k(1)[idx] - P.k(0)[idx]) * P.scr[idx];
         P.yn[idx] = dd * dd;
       }
       __syncthreads();
       if (tid < NB) {
         float s2 = 0.f;
-        for (int r = 0; r < NS; r++) s2 += P.yn[r * LDP + tid];
+        for (int r = 0; r < NS; r++) s2 += P.yn[tid * lds + r];
         c->eest[tid] = s2;
       }
       __syncthreads();
@@ -886,7 +1053,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
         grid_sum4(a.gs, gen, w, c->bcast);
       }
       if (tid < NB) {
-        const float n = coupled ? (float)NS * (float)B : (float)NS;
+        const float n = coupled ? (float)NREAL * (float)B : (float)NREAL;
         const double dt0 = c->dt[tid];
         const float d2 = sqrtf((coupled ? w[0] : c->eest[tid]) / n) * fast_rcp((float)dt0);
         const float dm_ = fmaxf(c->th[tid], d2);
@@ -940,17 +1107,17 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
           if (s > 0) {
             float* dst = s < 6 ? P.tmp : P.yn;
             for (int e = tid; e < nel; e += NTHREADS) {
-              const int row = e / NB, col = e % NB, idx = row * LDP + col;
+              const int idx = EIDX(e);
               float accv = ts5::A[s][0] * P.k(0)[idx];
               for (int jj = 1; jj < s; jj++) accv += ts5::A[s][jj] * P.k(jj)[idx];
-              dst[idx] = P.y[idx] + c->h[col] * accv;
+              dst[idx] = P.y[idx] + c->h[ECOL(e)] * accv;
             }
             src = dst;
           }
           const float bs = s < 6 ? ts5::A[6][s] : 0.f;
           if (tid < NB) wst[tid] = (s < 6 && (!replay || c->accepted[tid])) ? c->wq[tid] * bs : 0.f;
           __syncthreads();
-          eval_bwd<NDW>(dm, a, P, c, src, P.k(s), wst, s < 6, acc, bstep, dm.tile_off);
+          eval_bwd<NDW>(dm, P, c, src, P.k(s), wst, s < 6, acc, bstep);
         }
         if (!replay && tid < NB && c->status[tid] == 0) c->nfe[tid] += 7;
       } else {
@@ -959,19 +1126,19 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
           if (s > 0) {
             const float cs = s == 3 ? 1.0f : 0.5f;
             for (int e = tid; e < nel; e += NTHREADS) {
-              const int row = e / NB, col = e % NB, idx = row * LDP + col;
-              P.tmp[idx] = P.y[idx] + (cs * c->h[col]) * P.k(s - 1)[idx];
+              const int idx = EIDX(e);
+              P.tmp[idx] = P.y[idx] + (cs * c->h[ECOL(e)]) * P.k(s - 1)[idx];
             }
             src = P.tmp;
           }
           const float bs = (s == 0 || s == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
           if (tid < NB) wst[tid] = (!replay || c->accepted[tid]) ? c->wq[tid] * bs : 0.f;
           __syncthreads();
-          eval_bwd<NDW>(dm, a, P, c, src, P.k(s), wst, true, acc, bstep, dm.tile_off);
+          eval_bwd<NDW>(dm, P, c, src, P.k(s), wst, true, acc, bstep);
         }
         for (int e = tid; e < nel; e += NTHREADS) {
-          const int row = e / NB, col = e % NB, idx = row * LDP + col;
-          P.yn[idx] = P.y[idx] + (c->h[col] * (1.0f / 6.0f)) * (P.k(0)[idx] + 2.0f * (P.k(1)[idx] + P.k(2)[idx]) + P.k(3)[idx]);
+          const int idx = EIDX(e);
+          P.yn[idx] = P.y[idx] + (c->h[ECOL(e)] * (1.0f / 6.0f)) * (P.k(0)[idx] + 2.0f * (P.k(1)[idx] + P.k(2)[idx]) + P.k(3)[idx]);
         }
         __syncthreads();
         if (!replay && tid < NB && c->status[tid] == 0) c->nfe[tid] += 4;
@@ -980,14 +1147,14 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
       if (!replay) {
         // ---- error estimate + control ----------------------------------------------------------------------------
         for (int e = tid; e < nel; e += NTHREADS) {
-          const int row = e / NB, col = e % NB, idx = row * LDP + col;
+          const int idx = EIDX(e);
           float r2 = 0.f;
           const float yv = P.y[idx], ynv = P.yn[idx];
           if (o.adaptive) {
             float er = ts5::BT[0] * P.k(0)[idx];
 #pragma unroll
             for (int jj = 1; jj < 7; jj++) er += ts5::BT[jj] * P.k(jj)[idx];
-            er *= c->h[col];
+            er *= c->h[ECOL(e)];
             const float sk = o.abstol + fmaxf(fabsf(yv), fabsf(ynv)) * o.reltol;
             const float r = er * fast_rcp(sk);
             r2 = r * r;
@@ -997,7 +1164,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
         __syncthreads();
         if (tid < NB) {
           float s2 = 0.f;
-          for (int r = 0; r < NS; r++) s2 += P.scr[r * LDP + tid];
+          for (int r = 0; r < NS; r++) s2 += P.scr[tid * lds + r];
           c->eest[tid] = s2;
         }
         __syncthreads();
@@ -1010,7 +1177,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
         }
         if (tid < NB && c->status[tid] == 0) {
           const int col = tid;
-          const float n = coupled ? (float)NS * (float)B : (float)NS;
+          const float n = coupled ? (float)NREAL * (float)B : (float)NREAL;
           const float s2 = coupled ? v[0] : c->eest[col];
           const float EEst = o.adaptive ? sqrtf(s2 / n) : (s2 == s2 ? 0.f : s2);
           const double hmag = c->tnew[col];
@@ -1065,16 +1232,16 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
 
       // ---- advance accepted columns; jump at a save time --------------------------------------------------------
       for (int e = tid; e < nel; e += NTHREADS) {
-        const int row = e / NB, col = e % NB, idx = row * LDP + col;
-        if (c->accepted[col]) P.y[idx] = P.yn[idx];
+        const int idx = EIDX(e);
+        if (c->accepted[ECOL(e)]) P.y[idx] = P.yn[idx];
       }
       __syncthreads();
       for (int e = tid; e < NB * Dp; e += NTHREADS) {
         const int col = e / Dp, row = e % Dp;
         if (c->accepted[col] && c->hit[col]) {
           const size_t src = (size_t)Dp * ((size_t)(b0 + col) + (size_t)B * c->j[col]) + row;
-          P.y[(Dp + row) * LDP + col] += a.dz_out[src];
-          if (o.checkpoint) P.y[row * LDP + col] = a.z_out[src];
+          P.y[col * lds + DpA + row] += a.dz_out[src];
+          if (o.checkpoint) P.y[col * lds + row] = a.z_out[src];
         }
       }
       __syncthreads();
@@ -1096,12 +1263,12 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
   // ---- results ----------------------------------------------------------------------------------------------------
   for (int e = tid; e < NB * D; e += NTHREADS) {
     const int col = e / D, row = e % D;
-    if (b0 + col < B) a.dz0[(size_t)(b0 + col) * D + row] = c->status[col] > 1 ? 0.f : P.y[(Dp + row) * LDP + col];
+    if (b0 + col < B) a.dz0[(size_t)(b0 + col) * D + row] = c->status[col] > 1 ? 0.f : P.y[col * lds + DpA + row];
   }
   if (NP) {
     for (int e = tid; e < NB * NP; e += NTHREADS) {
       const int col = e / NP, row = e % NP;
-      if (b0 + col < B) a.dtheta[(size_t)(b0 + col) * NP + row] = c->status[col] > 1 ? 0.f : P.y[(2 * Dp + row) * LDP + col];
+      if (b0 + col < B) a.dtheta[(size_t)(b0 + col) * NP + row] = c->status[col] > 1 ? 0.f : P.y[col * lds + 2 * DpA + row];
     }
   }
   if (tid < NB && b0 + tid < B) {
@@ -1112,15 +1279,29 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
     a.st_nacc[b] = rep ? c->nacc[col] : 0;
     a.st_nrej[b] = rep ? c->nrej[col] : 0;
   }
+#undef EIDX
+#undef ECOL
 }
 
-// dW[i] += Σ_wg slab[wg][i]   (fixed order ⇒ deterministic)
-__global__ void k_reduce_slabs(const float* __restrict__ slab, int nwg, int nW, float* __restrict__ dW) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nW) return;
-  float s = 0.f;
-  for (int w = 0; w < nwg; w++) s += slab[(size_t)w * nW + i];
-  dW[i] += s;
+// dW[flat] += Σ_wg slab[wg][fragment position of flat]   (workgroups added in index order ⇒ deterministic)
+__global__ void k_reduce_slabs(const float* __restrict__ slab, int nwg, MlpDims dm, float* __restrict__ dW) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= dm.nW) return;
+  int l = 0;
+  while (l + 1 < dm.nL && idx >= dm.w_off[l + 1]) l++;
+  const int in = dm.sizes[l], out = dm.sizes[l + 1];
+  size_t pos;
+  if (idx < dm.b_off[l]) {
+    const int e = idx - dm.w_off[l], o = e % out, i = e / out;       // vec(W) column-major [out×in]
+    const int t = dm.tile_off[l] + (o >> 5) * cdiv(in, 32) + (i >> 5);
+    const int row = i & 31, col = o & 31;                             // tile holds Wᵀ: row = input index, col = output index
+    const int h = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);     // C/D layout of v_mfma_f32_32x32x2_f32
+    pos = ((size_t)t * 64 + col + 32 * h) * 16 + r;
+  } else
+    pos = (size_t)dm.tile_off[dm.nL] * 1024 + dm.bias_lin[l] + (idx - dm.b_off[l]);
+  float sacc = 0.f;
+  for (int w = 0; w < nwg; w++) sacc += slab[(size_t)w * dm.slab_n + pos];
+  dW[idx] += sacc;
 }
 
 // ================================================ host side =================================================
@@ -1147,34 +1328,45 @@ int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err) 
   dm.act = d.activation;
   dm.D = d.state_dim;
   dm.Dp = d.state_dim + d.augment_dim;
+  dm.DpA = (dm.Dp + 3) & ~3;
   dm.P = d.param_dim;
   dm.has_pend = d.rhs_kind == LDE_RHS_PENDULUM_PLUS_MLP;
   dm.coupled = d.batching == LDE_BATCH_COUPLED;
   dm.solver = d.solver;
-  int off = 0, offT = 0, woff = 0, hmax = 1;
+  int off = 0, offT = 0, woff = 0, hmax = 16;
   for (int l = 0; l < dm.nL; l++) {
     const int in = dm.sizes[l], o = dm.sizes[l + 1];
     dm.frag_off[l] = off;
-    off += cdiv(o, 16) * cdiv(in, 4) * 64;
+    dm.frag_n[l] = cdiv(o, 16) * cdiv(in, 16) * 256;
+    off += dm.frag_n[l];
     dm.fragT_off[l] = offT;
-    offT += cdiv(in, 16) * cdiv(o, 4) * 64;
+    dm.fragT_n[l] = cdiv(in, 16) * cdiv(o, 16) * 256;
+    offT += dm.fragT_n[l];
     dm.w_off[l] = woff;
     woff += o * in;
     dm.b_off[l] = woff;
     woff += o;
     if (l + 1 < dm.nL && o > hmax) hmax = o;
   }
-  dm.hmax = (hmax + 15) & ~15;   // padded to whole 16-row tiles
+  dm.hmax = (hmax + 31) & ~31;   // whole 32-row weight-gradient tiles (and 16-row K-groups)
+  dm.ld_h = panel_stride(dm.hmax);
+  const int Dp16 = (dm.Dp + 15) & ~15, Dp32 = (dm.Dp + 31) & ~31;
+  dm.ld_sf = panel_stride(Dp16);
+  // adjoint state rows: z [0,Dp) | λ [DpA,DpA+Dp) | g [2DpA, 2DpA+P); operand reads reach DpA + Dp32 rows (32-row tiles)
+  int rows_b = 2 * dm.DpA + dm.P;
+  if (dm.DpA + Dp32 > rows_b) rows_b = dm.DpA + Dp32;
+  dm.ld_sb = panel_stride((rows_b + 15) & ~15);
   dm.nW = woff;
   int blin = 0, toff = 0;
   for (int l = 0; l < dm.nL; l++) {
     dm.bias_lin[l] = blin;
     blin += dm.sizes[l + 1];
     dm.tile_off[l] = toff;
-    toff += cdiv(dm.sizes[l + 1], 16) * cdiv(dm.sizes[l], 16);
+    toff += cdiv(dm.sizes[l + 1], 32) * cdiv(dm.sizes[l], 32);
   }
   dm.tile_off[dm.nL] = toff;
   dm.nbias = blin;
+  dm.slab_n = toff * 1024 + ((blin + 3) & ~3);
   p->nfrag = off;
   p->nfragT = offT;
   if (dm.Dp > 256 || hmax > 1024) {
@@ -1216,7 +1408,7 @@ int mlp_reserve(MlpPlan* p, int B, int T, std::string& err) {
     }
     p->cap_wg = nwg;
   }
-  const size_t need = (size_t)nwg * (size_t)p->dm.nW;
+  const size_t need = (size_t)nwg * (size_t)p->dm.slab_n;
   if (need > p->slab_cap) {
     if (p->slab) (void)hipFree(p->slab);
     p->slab = nullptr;
@@ -1239,11 +1431,28 @@ int mlp_set_weights(MlpPlan* p, const float* W_dev, hipStream_t stream, std::str
   return LDE_OK;
 }
 
-static size_t fwd_lds_bytes(const MlpDims& dm, int T) {
+static constexpr size_t LDS_MAX = 160 * 1024;
+
+static size_t fwd_lds_fixed(const MlpDims& dm, int T) {
   size_t b = (sizeof(Ctl) + 15) & ~size_t(15);
   b += ((size_t)T * 8 + 15) & ~size_t(15);
-  b += (size_t)(11 * ((dm.Dp + 3) & ~3) + (dm.nL > 1 ? dm.nL - 1 : 0) * dm.hmax) * LDP * sizeof(float);
+  b += (size_t)(11 * NB * dm.ld_sf + (dm.nL > 1 ? dm.nL - 1 : 0) * NB * dm.ld_h + 1024 + ((dm.nbias + 3) & ~3)) * sizeof(float);
   return b;
+}
+
+static size_t bwd_lds_fixed(const MlpDims& dm, int T) {
+  size_t b = (sizeof(Ctl) + 15) & ~size_t(15);
+  b += ((size_t)T * 8 + 15) & ~size_t(15);
+  b += (size_t)(11 * NB * dm.ld_sb + ((dm.nL > 1 ? dm.nL - 1 : 0) + 2) * NB * dm.ld_h + 1024 + 2 * ((dm.nbias + 3) & ~3) + NB) *
+       sizeof(float);
+  return b;
+}
+
+// the weight cache takes whatever the panels leave, up to what the fragments need
+static size_t with_cache(size_t fixed, size_t want_floats) {
+  size_t total = fixed + want_floats * sizeof(float);
+  if (total > LDS_MAX) total = LDS_MAX;
+  return total & ~size_t(15);
 }
 
 int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* theta, const double* ts_dev,
@@ -1256,28 +1465,32 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
     err = "coupled adaptive solve: batch per GPU limited to 4096 trajectories (one resident workgroup per CU)";
     return LDE_ERR_UNSUPPORTED;
   }
-  const size_t lds = fwd_lds_bytes(dm, o.T);
-  if (lds > 160 * 1024) {
+  const size_t fixed = fwd_lds_fixed(dm, o.T);
+  if (fixed > LDS_MAX) {
     err = "MLP forward: tile state does not fit the 160 KiB LDS";
     return LDE_ERR_UNSUPPORTED;
   }
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_mlp_forward, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) {
+  const void* kfn = (const void*)k_mlp_forward<0>;   // (compile-time layer counts measured: −8 % time, 3× build time — not worth it)
+  static bool attr_set[3] = {false, false, false};
+  const int ki = 0;
+  if (!attr_set[ki]) {
+    if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
       err = "hipFuncSetAttribute(k_mlp_forward) failed";
       return LDE_ERR_HIP;
     }
-    attr_set = true;
+    attr_set[ki] = true;
   }
   FwdArgs a;
   a.z0 = z0; a.theta = theta; a.ts = ts_dev; a.frag = p->frag; a.Wflat = W_dev; a.z_out = z_out; a.retcode = retcode;
   a.st_nfe = nfe; a.st_nacc = nacc; a.st_nrej = nrej; a.st_ret = ret;
   a.gs.counter = p->counter; a.gs.slots = p->slots; a.gs.abort_flag = p->abort_flag; a.gs.nwg = sync ? nwg : 1;
+  const size_t lds = with_cache(fixed, p->nfrag);
+  a.lds_bytes = (int)lds;
   if (sync && hipMemsetAsync(p->counter, 0, sizeof(unsigned), stream) != hipSuccess) {
     err = "hipMemsetAsync(counter) failed";
     return LDE_ERR_HIP;
   }
-  hipLaunchKernelGGL(k_mlp_forward, dim3(nwg), dim3(NTHREADS), lds, stream, dm, o, a);
+  hipLaunchKernelGGL(k_mlp_forward<0>, dim3(nwg), dim3(NTHREADS), lds, stream, dm, o, a);
   if (hipGetLastError() != hipSuccess) {
     err = "k_mlp_forward launch failed";
     return LDE_ERR_HIP;
@@ -1285,21 +1498,12 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
   return LDE_OK;
 }
 
-static size_t bwd_lds_bytes(const MlpDims& dm, int T) {
-  size_t b = (sizeof(Ctl) + 15) & ~size_t(15);
-  b += ((size_t)T * 8 + 15) & ~size_t(15);
-  const int NSr = (2 * dm.Dp + dm.P + 3) & ~3;
-  b += (size_t)(11 * NSr + ((dm.nL > 1 ? dm.nL - 1 : 0) + 2) * dm.hmax) * LDP * sizeof(float);
-  b += (size_t)(((dm.nbias + 3) & ~3) + NB) * sizeof(float);
-  return b;
-}
-
 template <int NDW>
 static int launch_adjoint(MlpPlan* p, const KOpts& o, const BwdArgs& a, int nwg, size_t lds, hipStream_t stream,
                           std::string& err) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_mlp_adjoint<NDW>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) !=
+    if (hipFuncSetAttribute((const void*)k_mlp_adjoint<NDW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) !=
         hipSuccess) {
       err = "hipFuncSetAttribute(k_mlp_adjoint) failed";
       return LDE_ERR_HIP;
@@ -1320,8 +1524,8 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
     err = "coupled adaptive solve: batch per GPU limited to 4096 trajectories (one resident workgroup per CU)";
     return LDE_ERR_UNSUPPORTED;
   }
-  const size_t lds = bwd_lds_bytes(dm, o.T);
-  if (lds > 160 * 1024) {
+  const size_t fixed = bwd_lds_fixed(dm, o.T);
+  if (fixed > LDS_MAX) {
     err = "MLP adjoint: tile state does not fit the 160 KiB LDS";
     return LDE_ERR_UNSUPPORTED;
   }
@@ -1330,17 +1534,19 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
   a.dz0 = dz0; a.dtheta = dtheta; a.slab = p->slab;
   a.st_nfe = nfe; a.st_nacc = nacc; a.st_nrej = nrej; a.st_ret = ret;
   a.gs.counter = p->counter; a.gs.slots = p->slots; a.gs.abort_flag = p->abort_flag; a.gs.nwg = sync ? nwg : 1;
+  const size_t lds = with_cache(fixed, p->nfrag + p->nfragT);
+  a.lds_bytes = (int)lds;
   if (sync && hipMemsetAsync(p->counter, 0, sizeof(unsigned), stream) != hipSuccess) {
     err = "hipMemsetAsync(counter) failed";
     return LDE_ERR_HIP;
   }
   const int per_wave = cdiv(dm.tile_off[dm.nL], 4);   // weight-gradient tiles held in each wave's accumulators
   int rc;
-  if (per_wave <= 8) rc = launch_adjoint<8>(p, o, a, nwg, lds, stream, err);
-  else if (per_wave <= 24) rc = launch_adjoint<24>(p, o, a, nwg, lds, stream, err);
-  else if (per_wave <= 52) rc = launch_adjoint<52>(p, o, a, nwg, lds, stream, err);
+  if (per_wave <= 2) rc = launch_adjoint<2>(p, o, a, nwg, lds, stream, err);
+  else if (per_wave <= 6) rc = launch_adjoint<6>(p, o, a, nwg, lds, stream, err);
+  else if (per_wave <= 16) rc = launch_adjoint<16>(p, o, a, nwg, lds, stream, err);
   else {
-    err = "MLP adjoint: more than 208 16x16 weight-gradient tiles (hidden width too large for the register-resident accumulators)";
+    err = "MLP adjoint: more than 64 32x32 weight-gradient tiles (hidden width too large for the register-resident accumulators)";
     return LDE_ERR_UNSUPPORTED;
   }
   if (rc) return rc;
@@ -1348,7 +1554,7 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
     err = "k_mlp_adjoint launch failed";
     return LDE_ERR_HIP;
   }
-  hipLaunchKernelGGL(k_reduce_slabs, dim3(cdiv(dm.nW, 256)), dim3(256), 0, stream, p->slab, nwg, dm.nW, dW);
+  hipLaunchKernelGGL(k_reduce_slabs, dim3(cdiv(dm.nW, 256)), dim3(256), 0, stream, p->slab, nwg, dm, dW);
   if (hipGetLastError() != hipSuccess) {
     err = "k_reduce_slabs launch failed";
     return LDE_ERR_HIP;

@@ -43,6 +43,14 @@ constexpr int MAXL = LDE_MAX_LAYERS;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef LDE_ABL
+#define LDE_ABL 0
+#endif
+// diagnostic builds only (LDE_ABL != 0): 1 = no GEMM, 2 = operands loaded but no MFMA, 3 = no epilogue
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  if (LDE_ABL == 2) { c[0] += a + b; return c; }
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
 
 // Static description of the RHS handed to the kernels by value.
 struct MlpDims {
@@ -109,9 +117,6 @@ __device__ __forceinline__ float act_grad(int kind, float a) { return kind == LD
 // Y[R×16] = M[R×K]·X[K×16] for one workgroup. M as K4 fragments (LDS copy or global), X a transposed panel
 // (Xt[col*ldx + row], rows [0,K) starting at the pointer), EPI(row0, col, acc4) gets the 4 consecutive rows a lane owns.
 // `red` = 4 KiB LDS scratch for the split-K reduction of narrow layers.
-#ifndef LDE_ABL
-#define LDE_ABL 0
-#endif
 template <class Epi>
 __device__ __forceinline__ void panel_gemm(const float* frag, int R, int K, const float* Xt, int ldx, float* red, Epi epi) {
   if (LDE_ABL == 1) return;   // diagnostic build: no GEMM at all
@@ -138,12 +143,12 @@ __device__ __forceinline__ void panel_gemm(const float* frag, int R, int K, cons
           }
 #pragma unroll
           for (int s4 = 0; s4 < 4; s4++) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca0[s4], cb[s4], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(ca1[s4], cb[s4], acc1, 0, 0, 0);
+            acc0 = mfma16(ca0[s4], cb[s4], acc0);
+            acc1 = mfma16(ca1[s4], cb[s4], acc1);
           }
         }
-        epi(rt * 16 + rsub, col, acc0);
-        epi(rt2 * 16 + rsub, col, acc1);
+        if (LDE_ABL != 3) epi(rt * 16 + rsub, col, acc0);
+        if (LDE_ABL != 3) epi(rt2 * 16 + rsub, col, acc1);
       } else {  // one tile: even/odd K-groups on two accumulators
         for (int kg = 0; kg < KG; kg += 2) {
           const f32x4 a0 = a0p[kg * 64], b0 = *reinterpret_cast<const f32x4*>(xp + kg * 16);
@@ -155,11 +160,11 @@ __device__ __forceinline__ void panel_gemm(const float* frag, int R, int K, cons
           }
 #pragma unroll
           for (int s4 = 0; s4 < 4; s4++) {
-            acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s4], b0[s4], acc0, 0, 0, 0);
-            if (has1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s4], b1[s4], acc1, 0, 0, 0);
+            acc0 = mfma16(a0[s4], b0[s4], acc0);
+            if (has1) acc1 = mfma16(a1[s4], b1[s4], acc1);
           }
         }
-        epi(rt * 16 + rsub, col, acc0 + acc1);
+        if (LDE_ABL != 3) epi(rt * 16 + rsub, col, acc0 + acc1);
       }
     }
   } else {
@@ -179,8 +184,8 @@ __device__ __forceinline__ void panel_gemm(const float* frag, int R, int K, cons
       }
 #pragma unroll
       for (int s4 = 0; s4 < 4; s4++) {
-        acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[s4], b0[s4], acc0, 0, 0, 0);
-        if (has1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[s4], b1[s4], acc1, 0, 0, 0);
+        acc0 = mfma16(a0[s4], b0[s4], acc0);
+        if (has1) acc1 = mfma16(a1[s4], b1[s4], acc1);
       }
     }
     f32x4* rp = reinterpret_cast<f32x4*>(red);
@@ -189,7 +194,7 @@ __device__ __forceinline__ void panel_gemm(const float* frag, int R, int K, cons
     if (part == 0) {
       f32x4 t = rp[rt * 64 + lane];
       for (int pp = 1; pp < nparts; pp++) t += rp[(rt + pp * RT) * 64 + lane];
-      epi(rt * 16 + rsub, col, t);
+      if (LDE_ABL != 3) epi(rt * 16 + rsub, col, t);
     }
   }
 }
@@ -310,17 +315,12 @@ __device__ __forceinline__ float* cache_frags(const MlpDims& dm, const float* gf
 }
 
 // f(z) for the tile: dst rows [0,Dp) = MLP(src rows [0,Dp)) (+ pendulum); hidden activations are left in P.hid(*).
-// NL > 0: the layer loop is unrolled with compile-time l, so that every dm.x[l] is a fixed kernel-argument word the
-// compiler loads once into SGPRs (with a runtime l each access is a scalar-memory load followed by an lgkmcnt wait
-// that also drains the LDS queue). NL = 0: generic runtime loop.
-template <int NL>
+// (A variant with the layer loop unrolled at compile time was measured: −8 % time for 3× code and build time — dropped.)
 __device__ __forceinline__ void eval_rhs(const MlpDims& dm, const Panels& P, const Ctl* c, const float* src, float* dst) {
   const float* X = src;
   int ldx = P.lds;
-  const int nL = NL > 0 ? NL : dm.nL;
-#pragma unroll
-  for (int l = 0; l < (NL > 0 ? NL : MAXL); l++) {
-    if (NL == 0 && l >= nL) break;
+  const int nL = dm.nL;
+  for (int l = 0; l < nL; l++) {
     const int in = dm.sizes[l], out = dm.sizes[l + 1];
     const bool lastl = l == nL - 1;
     float* Y = lastl ? dst : P.hid(l);
@@ -376,7 +376,7 @@ __device__ __forceinline__ void load_biases(const MlpDims& dm, const float* Wfla
     for (int i = threadIdx.x; i < dm.sizes[l + 1]; i += NTHREADS) biasc[dm.bias_lin[l] + i] = Wflat[dm.b_off[l] + i];
 }
 
-template <int NL>
+template <int SOLVER>
 __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int T = o.T, B = o.B, Dp = dm.Dp, D = dm.D;
@@ -447,54 +447,132 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
     if (b0 + col < B) a.z_out[(size_t)(b0 + col) * Dp + row] = P.y[col * lds + row];
   }
 
-  if (T > 1) {
-    eval_rhs<NL>(dm, P, c, P.y, P.k(0));
+  // ---- the solve as a phase machine: the MLP evaluation below is the ONLY instantiation of eval_rhs in this kernel
+  //      (five inlined copies of the GEMM code made the hot loop several times larger than the instruction cache)
+  enum { PH_K0 = 0, PH_INIT1 = 1, PH_STAGE = 2 };
+  constexpr int LAST_STAGE = SOLVER == LDE_SOLVER_TSIT5 ? 6 : 4;   // Tsit5: k2..k7 ; RK4: k2,k3,k4 and f(y_new)
+
+  // start of a step: iteration guard, clip the step to t_end, per-column h; false when every column has finished
+  auto begin_step = [&]() -> bool {
+    if (tid < NB) {
+      const int col = tid;
+      if (c->status[col] == 0) {
+        if (c->iters[col]++ >= o.maxiters) c->status[col] = 1 + LDE_RET_MAXITERS;
+      }
+      if (c->status[col] == 0) {
+        double dt = c->dt[col];
+        const double t = c->t[col];
+        int last = 0;
+        if (t + dt >= tend - 1e-12 * fabs(tend)) { dt = tend - t; last = 1; }
+        c->last[col] = last;
+        c->tnew[col] = last ? tend : t + dt;
+        c->h[col] = (float)dt;
+        c->wq[col] = (float)dt;   // step actually attempted (f32)
+        c->dt[col] = dt;
+      } else
+        c->h[col] = 0.f;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int any = 0;
+      for (int col = 0; col < NB; col++) any |= (c->status[col] == 0);
+      c->any_active = any;
+    }
+    __syncthreads();
+    return c->any_active != 0;   // coupled: identical control arithmetic ⇒ every workgroup leaves together
+  };
+
+  int phase = PH_K0, s = 0;
+  bool running = T > 1;
+  while (running) {
+    // ---- input of this evaluation ---------------------------------------------------------------------------
+    const float* src = P.y;
+    if (phase == PH_INIT1) src = P.tmp;
+    if (phase == PH_STAGE) {
+      if (SOLVER == LDE_SOLVER_TSIT5) {
+        float* dstp = s < 6 ? P.tmp : P.yn;
+        for (int e = tid; e < nel; e += NTHREADS) {
+          const int idx = EIDX(e);
+          float acc = ts5::A[s][0] * P.k(0)[idx];
+          for (int jj = 1; jj < s; jj++) acc += ts5::A[s][jj] * P.k(jj)[idx];
+          dstp[idx] = P.y[idx] + c->h[ECOL(e)] * acc;
+        }
+        src = dstp;
+      } else if (s < 4) {
+        const float cs = s == 3 ? 1.0f : 0.5f;
+        for (int e = tid; e < nel; e += NTHREADS) {
+          const int idx = EIDX(e);
+          P.tmp[idx] = P.y[idx] + (cs * c->h[ECOL(e)]) * P.k(s - 1)[idx];
+        }
+        src = P.tmp;
+      } else {
+        for (int e = tid; e < nel; e += NTHREADS) {
+          const int idx = EIDX(e);
+          P.yn[idx] = P.y[idx] + (c->h[ECOL(e)] * (1.0f / 6.0f)) * (P.k(0)[idx] + 2.0f * (P.k(1)[idx] + P.k(2)[idx]) + P.k(3)[idx]);
+        }
+        src = P.yn;
+      }
+      __syncthreads();
+    }
+    float* dst = phase == PH_K0 ? P.k(0) : (phase == PH_INIT1 ? P.k(1) : P.k(s));
+
+    eval_rhs(dm, P, c, src, dst);
     if (tid < NB && c->status[tid] == 0) c->nfe[tid]++;
 
-    // ---- initial step size ---------------------------------------------------------------------------
-    if (o.adaptive && !(o.dt_fixed > 0)) {
-      for (int e = tid; e < nel; e += NTHREADS) {
-        const int idx = EIDX(e);
-        const float yv = P.y[idx];
-        const float sk = fast_rcp(o.abstol + fabsf(yv) * o.reltol);
-        P.scr[idx] = sk;
-        const float a0 = yv * sk, a1 = P.k(0)[idx] * sk;
-        P.tmp[idx] = a0 * a0;
-        P.yn[idx] = a1 * a1;
-      }
-      __syncthreads();
-      float v[4] = {0.f, 0.f, 0.f, 0.f};
-      if (tid < NB) {
-        float s0 = 0.f, s1 = 0.f;
-        for (int r = 0; r < NS; r++) { s0 += P.tmp[tid * lds + r]; s1 += P.yn[tid * lds + r]; }
-        c->eest[tid] = s0;   // Σ (y/sk)²
-        c->wq[tid] = s1;     // Σ (f0/sk)²
-      }
-      __syncthreads();
-      if (coupled) {
-        if (tid == 0) {
-          for (int col = 0; col < NB; col++)
-            if (b0 + col < B) { v[0] += c->eest[col]; v[1] += c->wq[col]; }
+    // ---- what follows the evaluation ---------------------------------------------------------------------------
+    if (phase == PH_K0) {
+      if (o.adaptive && !(o.dt_fixed > 0)) {
+        // Hairer–Nørsett–Wanner, part 1: d0, d1, trial Euler step
+        for (int e = tid; e < nel; e += NTHREADS) {
+          const int idx = EIDX(e);
+          const float yv = P.y[idx];
+          const float sk = fast_rcp(o.abstol + fabsf(yv) * o.reltol);
+          P.scr[idx] = sk;
+          const float a0 = yv * sk, a1 = P.k(0)[idx] * sk;
+          P.tmp[idx] = a0 * a0;
+          P.yn[idx] = a1 * a1;
         }
-        grid_sum4(a.gs, gen, v, c->bcast);
+        __syncthreads();
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        if (tid < NB) {
+          float s0 = 0.f, s1 = 0.f;
+          for (int r = 0; r < NS; r++) { s0 += P.tmp[tid * lds + r]; s1 += P.yn[tid * lds + r]; }
+          c->eest[tid] = s0;   // Σ (y/sk)²
+          c->wq[tid] = s1;     // Σ (f0/sk)²
+        }
+        __syncthreads();
+        if (coupled) {
+          if (tid == 0) {
+            for (int col = 0; col < NB; col++)
+              if (b0 + col < B) { v[0] += c->eest[col]; v[1] += c->wq[col]; }
+          }
+          grid_sum4(a.gs, gen, v, c->bcast);
+        }
+        if (tid < NB) {
+          const float n = coupled ? (float)NS * (float)B : (float)NS;
+          const float d0 = sqrtf((coupled ? v[0] : c->eest[tid]) / n), d1 = sqrtf((coupled ? v[1] : c->wq[tid]) / n);
+          double dt0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6 : 0.01 * (double)(d0 * fast_rcp(d1));
+          if (dt0 > dtmax) dt0 = dtmax;
+          c->dt[tid] = dt0;
+          c->h[tid] = (float)dt0;
+          c->th[tid] = d1;
+        }
+        __syncthreads();
+        for (int e = tid; e < nel; e += NTHREADS) {
+          const int idx = EIDX(e);
+          P.tmp[idx] = P.y[idx] + c->h[ECOL(e)] * P.k(0)[idx];
+        }
+        __syncthreads();
+        phase = PH_INIT1;
+      } else {
+        if (tid < NB) c->dt[tid] = o.adaptive ? fmin(o.dt_fixed, dtmax) : o.dt_fixed;
+        __syncthreads();
+        phase = PH_STAGE;
+        s = 1;
+        running = begin_step();
       }
-      if (tid < NB) {
-        const float n = coupled ? (float)NS * (float)B : (float)NS;
-        const float d0 = sqrtf((coupled ? v[0] : c->eest[tid]) / n), d1 = sqrtf((coupled ? v[1] : c->wq[tid]) / n);
-        double dt0 = (d0 < 1e-5f || d1 < 1e-5f) ? 1e-6 : 0.01 * (double)(d0 * fast_rcp(d1));
-        if (dt0 > dtmax) dt0 = dtmax;
-        c->dt[tid] = dt0;
-        c->h[tid] = (float)dt0;
-        c->th[tid] = d1;
-      }
-      __syncthreads();
-      for (int e = tid; e < nel; e += NTHREADS) {
-        const int idx = EIDX(e);
-        P.tmp[idx] = P.y[idx] + c->h[ECOL(e)] * P.k(0)[idx];
-      }
-      __syncthreads();
-      eval_rhs<NL>(dm, P, c, P.tmp, P.k(1));
-      if (tid < NB && c->status[tid] == 0) c->nfe[tid]++;
+    } else if (phase == PH_INIT1) {
+      // part 2: d2 and the initial step
       for (int e = tid; e < nel; e += NTHREADS) {
         const int idx = EIDX(e);
         const float d = (P.k(1)[idx] - P.k(0)[idx]) * P.scr[idx];
@@ -524,73 +602,13 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
         c->dt[tid] = dt > dtmax ? dtmax : dt;
       }
       __syncthreads();
-    } else if (tid < NB) {
-      c->dt[tid] = o.adaptive ? fmin(o.dt_fixed, dtmax) : o.dt_fixed;
-    }
-    __syncthreads();
-
-    // ---- main loop -------------------------------------------------------------------------------------
-    for (;;) {
-      if (tid < NB) {
-        const int col = tid;
-        if (c->status[col] == 0) {
-          if (c->iters[col]++ >= o.maxiters) c->status[col] = 1 + LDE_RET_MAXITERS;
-        }
-        if (c->status[col] == 0) {
-          double dt = c->dt[col];
-          const double t = c->t[col];
-          int last = 0;
-          if (t + dt >= tend - 1e-12 * fabs(tend)) { dt = tend - t; last = 1; }
-          c->last[col] = last;
-          c->tnew[col] = last ? tend : t + dt;
-          c->h[col] = (float)dt;
-          c->wq[col] = (float)dt;   // step actually attempted (f32)
-          c->dt[col] = dt;
-        } else
-          c->h[col] = 0.f;
-      }
-      __syncthreads();
-      if (tid == 0) {
-        int any = 0;
-        for (int col = 0; col < NB; col++) any |= (c->status[col] == 0);
-        c->any_active = any;
-      }
-      __syncthreads();
-      if (!c->any_active) break;   // coupled: identical control arithmetic ⇒ every workgroup leaves together
-
-      if (dm.solver == LDE_SOLVER_TSIT5) {
-        for (int s = 1; s <= 6; s++) {
-          float* dst = s < 6 ? P.tmp : P.yn;
-          for (int e = tid; e < nel; e += NTHREADS) {
-            const int idx = EIDX(e);
-            float acc = ts5::A[s][0] * P.k(0)[idx];
-            for (int jj = 1; jj < s; jj++) acc += ts5::A[s][jj] * P.k(jj)[idx];
-            dst[idx] = P.y[idx] + c->h[ECOL(e)] * acc;
-          }
-          __syncthreads();
-          eval_rhs<NL>(dm, P, c, dst, P.k(s));
-        }
-        if (tid < NB && c->status[tid] == 0) c->nfe[tid] += 6;
-      } else {  // classical RK4; k[4] = f(yn) doubles as the next k1
-        for (int s = 1; s <= 3; s++) {
-          const float cs = s == 3 ? 1.0f : 0.5f;
-          for (int e = tid; e < nel; e += NTHREADS) {
-            const int idx = EIDX(e);
-            P.tmp[idx] = P.y[idx] + (cs * c->h[ECOL(e)]) * P.k(s - 1)[idx];
-          }
-          __syncthreads();
-          eval_rhs<NL>(dm, P, c, P.tmp, P.k(s));
-        }
-        for (int e = tid; e < nel; e += NTHREADS) {
-          const int idx = EIDX(e);
-          P.yn[idx] = P.y[idx] + (c->h[ECOL(e)] * (1.0f / 6.0f)) * (P.k(0)[idx] + 2.0f * (P.k(1)[idx] + P.k(2)[idx]) + P.k(3)[idx]);
-        }
-        __syncthreads();
-        eval_rhs<NL>(dm, P, c, P.yn, P.k(4));
-        if (tid < NB && c->status[tid] == 0) c->nfe[tid] += 4;
-      }
-
-      // ---- error estimate -----------------------------------------------------------------------------
+      phase = PH_STAGE;
+      s = 1;
+      running = begin_step();
+    } else if (s < LAST_STAGE) {
+      s++;
+    } else {
+      // ---- end of a step attempt: error estimate ------------------------------------------------------------
       for (int e = tid; e < nel; e += NTHREADS) {
         const int idx = EIDX(e);
         float r2 = 0.f;
@@ -687,12 +705,12 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
           const float th = c->th[col], h = c->wq[col];
           float out;
           if (th > 1.5f) out = P.yn[idx];
-          else if (dm.solver == LDE_SOLVER_TSIT5) {
+          else if (SOLVER == LDE_SOLVER_TSIT5) {
             float bw[7];
             tsit5_interp_weights(th, bw);
             float acc = bw[0] * P.k(0)[idx];
 #pragma unroll
-            for (int s = 1; s < 7; s++) acc += bw[s] * P.k(s)[idx];
+            for (int q = 1; q < 7; q++) acc += bw[q] * P.k(q)[idx];
             out = P.y[idx] + h * acc;
           } else {
             const float om = 1.0f - th;
@@ -705,15 +723,12 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
         __syncthreads();
       }
 
-      // ---- advance accepted columns ----------------------------------------------------------------------
-      {
-        const int fs = dm.solver == LDE_SOLVER_TSIT5 ? 6 : 4;
-        for (int e = tid; e < nel; e += NTHREADS) {
-          const int idx = EIDX(e);
-          if (c->accepted[ECOL(e)]) {
-            P.y[idx] = P.yn[idx];
-            P.k(0)[idx] = P.k(fs)[idx];
-          }
+      // ---- advance accepted columns (FSAL: the last slope becomes k1) --------------------------------------
+      for (int e = tid; e < nel; e += NTHREADS) {
+        const int idx = EIDX(e);
+        if (c->accepted[ECOL(e)]) {
+          P.y[idx] = P.yn[idx];
+          P.k(0)[idx] = P.k(LAST_STAGE)[idx];
         }
       }
       if (tid < NB && c->accepted[tid]) {
@@ -721,6 +736,8 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
         if (c->last[tid]) c->status[tid] = 1;
       }
       __syncthreads();
+      s = 1;
+      running = begin_step();
     }
   }
 
@@ -771,7 +788,7 @@ __device__ __forceinline__ void eval_bwd(const MlpDims& dm, const Panels& P, con
   const int DpA = dm.DpA, nL = dm.nL;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // 1. forward through the MLP (relu masks are recomputed here, not stored by the forward solve)
-  eval_rhs<0>(dm, P, c, src, dst);
+  eval_rhs(dm, P, c, src, dst);
   // 2. back-propagate λ; δ_L = λ_stage
   const float* dl = src + DpA;
   int ldd = P.lds;
@@ -855,7 +872,7 @@ __device__ __forceinline__ void eval_bwd(const MlpDims& dm, const Panels& P, con
 }
 
 // Reverse-time solve of [z; λ; g_θ] for one tile, with forced stops + jumps at the save times.
-template <int NDW>
+template <int NDW, int SOLVER>
 __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int T = o.T, B = o.B, Dp = dm.Dp, DpA = dm.DpA, D = dm.D, NP = dm.P;
@@ -987,11 +1004,93 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
   }
   __syncthreads();
 
-  if (T > 1) {
-    // ---- initial step size (Hairer) on the augmented state, direction −1 ------------------------------------
-    if (o.adaptive && !(o.dt_fixed > 0)) {
-      eval_bwd<NDW>(dm, P, c, P.y, P.k(0), wst, false, acc, bstep);
-      if (tid < NB && c->status[tid] == 0) c->nfe[tid]++;
+  // ---- the reverse-time solve as a phase machine: ONE instantiation of eval_bwd in this kernel -------------------
+  enum { PH_K0 = 0, PH_INIT1 = 1, PH_STAGE = 2 };
+  constexpr int LAST_STAGE = SOLVER == LDE_SOLVER_TSIT5 ? 6 : 3;   // Tsit5: k1..k7 evaluated (s = 0..6); RK4: k1..k4 (s = 0..3)
+
+  // start of a step attempt: iteration guard, clip to the next save time; false when every column has finished
+  auto begin_step = [&]() -> bool {
+    if (tid < NB) {
+      const int col = tid;
+      if (c->status[col] == 0 && c->iters[col]++ >= o.maxiters) c->status[col] = 1 + LDE_RET_MAXITERS;
+      if (c->status[col] == 0) {
+        const double tstop = s_ts[c->j[col]];
+        const double dist = c->t[col] - tstop;
+        double hmag = c->dt[col];
+        int hit = 0;
+        if (hmag >= dist * (1.0 - 1e-12)) { hmag = dist; hit = 1; }
+        c->hit[col] = hit;
+        c->tnew[col] = hmag;            // step magnitude actually attempted
+        c->h[col] = -(float)hmag;
+        c->wq[col] = (float)hmag;       // quadrature weight scale |h|
+      } else {
+        c->h[col] = 0.f;
+        c->wq[col] = 0.f;
+        c->hit[col] = 0;
+      }
+    }
+    __syncthreads();
+    if (tid == 0) {
+      int any = 0;
+      for (int col = 0; col < NB; col++) any |= (c->status[col] == 0);
+      c->any_active = any;
+    }
+    __syncthreads();
+    return c->any_active != 0;
+  };
+
+  const bool auto_dt = o.adaptive && !(o.dt_fixed > 0);
+  int phase = auto_dt ? PH_K0 : PH_STAGE, s = 0;
+  bool replay = false;
+  bool running = T > 1;
+  if (running && !auto_dt) {
+    if (tid < NB) c->dt[tid] = o.adaptive ? fmin(o.dt_fixed, dtmax) : o.dt_fixed;
+    __syncthreads();
+    running = begin_step();
+  }
+  while (running) {
+    // ---- input of this evaluation + this stage's quadrature weights ------------------------------------------------
+    const float* src = P.y;
+    bool any_w = false;
+    if (phase == PH_INIT1) src = P.tmp;
+    if (phase == PH_STAGE) {
+      float bs;
+      if (SOLVER == LDE_SOLVER_TSIT5) {
+        if (s > 0) {
+          float* dstp = s < 6 ? P.tmp : P.yn;
+          for (int e = tid; e < nel; e += NTHREADS) {
+            const int idx = EIDX(e);
+            float accv = ts5::A[s][0] * P.k(0)[idx];
+            for (int jj = 1; jj < s; jj++) accv += ts5::A[s][jj] * P.k(jj)[idx];
+            dstp[idx] = P.y[idx] + c->h[ECOL(e)] * accv;
+          }
+          src = dstp;
+        }
+        bs = s < 6 ? ts5::A[6][s] : 0.f;   // k₁ is evaluated fresh each attempt: it carries this step's weight b₁|h|
+        any_w = s < 6;
+      } else {
+        if (s > 0) {
+          const float cs = s == 3 ? 1.0f : 0.5f;
+          for (int e = tid; e < nel; e += NTHREADS) {
+            const int idx = EIDX(e);
+            P.tmp[idx] = P.y[idx] + (cs * c->h[ECOL(e)]) * P.k(s - 1)[idx];
+          }
+          src = P.tmp;
+        }
+        bs = (s == 0 || s == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
+        any_w = true;
+      }
+      if (tid < NB) wst[tid] = (any_w && (!replay || c->accepted[tid])) ? c->wq[tid] * bs : 0.f;
+      __syncthreads();
+    }
+    float* dst = phase == PH_K0 ? P.k(0) : (phase == PH_INIT1 ? P.k(1) : P.k(s));
+
+    eval_bwd<NDW>(dm, P, c, src, dst, wst, any_w, acc, bstep);
+    if (!replay && tid < NB && c->status[tid] == 0) c->nfe[tid]++;
+
+    // ---- what follows the evaluation -----------------------------------------------------------------------------
+    if (phase == PH_K0) {
+      // Hairer–Nørsett–Wanner on the augmented state, direction −1: part 1
       for (int e = tid; e < nel; e += NTHREADS) {
         const int idx = EIDX(e);
         const float yv = P.y[idx];
@@ -1031,8 +1130,8 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
         P.tmp[idx] = P.y[idx] + c->h[ECOL(e)] * P.k(0)[idx];
       }
       __syncthreads();
-      eval_bwd<NDW>(dm, P, c, P.tmp, P.k(1), wst, false, acc, bstep);
-      if (tid < NB && c->status[tid] == 0) c->nfe[tid]++;
+      phase = PH_INIT1;
+    } else if (phase == PH_INIT1) {
       for (int e = tid; e < nel; e += NTHREADS) {
         const int idx = EIDX(e);
         const float dd = (P.k(1)[idx] - P.k(0)[idx]) * P.scr[idx];
@@ -1062,88 +1161,20 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
         c->dt[tid] = dt > dtmax ? dtmax : dt;
       }
       __syncthreads();
-    } else if (tid < NB) {
-      c->dt[tid] = o.adaptive ? fmin(o.dt_fixed, dtmax) : o.dt_fixed;
-    }
-    __syncthreads();
-
-    // ---- main loop ---------------------------------------------------------------------------------------------
-    bool replay = false;
-    for (;;) {
-      if (!replay) {
-        if (tid < NB) {
-          const int col = tid;
-          if (c->status[col] == 0 && c->iters[col]++ >= o.maxiters) c->status[col] = 1 + LDE_RET_MAXITERS;
-          if (c->status[col] == 0) {
-            const double tstop = s_ts[c->j[col]];
-            const double dist = c->t[col] - tstop;
-            double hmag = c->dt[col];
-            int hit = 0;
-            if (hmag >= dist * (1.0 - 1e-12)) { hmag = dist; hit = 1; }
-            c->hit[col] = hit;
-            c->tnew[col] = hmag;            // step magnitude actually attempted
-            c->h[col] = -(float)hmag;
-            c->wq[col] = (float)hmag;       // quadrature weight scale |h|
-          } else {
-            c->h[col] = 0.f;
-            c->wq[col] = 0.f;
-            c->hit[col] = 0;
-          }
-        }
-        __syncthreads();
-        if (tid == 0) {
-          int any = 0;
-          for (int col = 0; col < NB; col++) any |= (c->status[col] == 0);
-          c->any_active = any;
-        }
-        __syncthreads();
-        if (!c->any_active) break;
-      }
-
-      // ---- stages (k₁ is evaluated fresh: it carries this step's quadrature weight) ---------------------------
-      if (dm.solver == LDE_SOLVER_TSIT5) {
-        for (int s = 0; s <= 6; s++) {
-          const float* src = P.y;
-          if (s > 0) {
-            float* dst = s < 6 ? P.tmp : P.yn;
-            for (int e = tid; e < nel; e += NTHREADS) {
-              const int idx = EIDX(e);
-              float accv = ts5::A[s][0] * P.k(0)[idx];
-              for (int jj = 1; jj < s; jj++) accv += ts5::A[s][jj] * P.k(jj)[idx];
-              dst[idx] = P.y[idx] + c->h[ECOL(e)] * accv;
-            }
-            src = dst;
-          }
-          const float bs = s < 6 ? ts5::A[6][s] : 0.f;
-          if (tid < NB) wst[tid] = (s < 6 && (!replay || c->accepted[tid])) ? c->wq[tid] * bs : 0.f;
-          __syncthreads();
-          eval_bwd<NDW>(dm, P, c, src, P.k(s), wst, s < 6, acc, bstep);
-        }
-        if (!replay && tid < NB && c->status[tid] == 0) c->nfe[tid] += 7;
-      } else {
-        for (int s = 0; s <= 3; s++) {
-          const float* src = P.y;
-          if (s > 0) {
-            const float cs = s == 3 ? 1.0f : 0.5f;
-            for (int e = tid; e < nel; e += NTHREADS) {
-              const int idx = EIDX(e);
-              P.tmp[idx] = P.y[idx] + (cs * c->h[ECOL(e)]) * P.k(s - 1)[idx];
-            }
-            src = P.tmp;
-          }
-          const float bs = (s == 0 || s == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
-          if (tid < NB) wst[tid] = (!replay || c->accepted[tid]) ? c->wq[tid] * bs : 0.f;
-          __syncthreads();
-          eval_bwd<NDW>(dm, P, c, src, P.k(s), wst, true, acc, bstep);
-        }
+      phase = PH_STAGE;
+      s = 0;
+      running = begin_step();
+    } else if (s < LAST_STAGE) {
+      s++;
+    } else {
+      // ---- all stages of this attempt are done ---------------------------------------------------------------------
+      if (SOLVER == LDE_SOLVER_RK4) {
         for (int e = tid; e < nel; e += NTHREADS) {
           const int idx = EIDX(e);
           P.yn[idx] = P.y[idx] + (c->h[ECOL(e)] * (1.0f / 6.0f)) * (P.k(0)[idx] + 2.0f * (P.k(1)[idx] + P.k(2)[idx]) + P.k(3)[idx]);
         }
         __syncthreads();
-        if (!replay && tid < NB && c->status[tid] == 0) c->nfe[tid] += 4;
       }
-
       if (!replay) {
         // ---- error estimate + control ----------------------------------------------------------------------------
         for (int e = tid; e < nel; e += NTHREADS) {
@@ -1222,7 +1253,12 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
           if (o.adaptive) commit();            // fixed step: everything is accepted, commit once at the end
         } else {
           discard();
-          if (c->any_save) { replay = true; __syncthreads(); continue; }   // redo the stages for the accepted columns only
+          if (c->any_save) {   // some columns accepted, some rejected: redo the stages with the accepted columns' weights only
+            replay = true;
+            s = 0;
+            __syncthreads();
+            continue;
+          }
         }
       } else {
         commit();
@@ -1239,9 +1275,9 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
       for (int e = tid; e < NB * Dp; e += NTHREADS) {
         const int col = e / Dp, row = e % Dp;
         if (c->accepted[col] && c->hit[col]) {
-          const size_t src = (size_t)Dp * ((size_t)(b0 + col) + (size_t)B * c->j[col]) + row;
-          P.y[col * lds + DpA + row] += a.dz_out[src];
-          if (o.checkpoint) P.y[col * lds + row] = a.z_out[src];
+          const size_t srcg = (size_t)Dp * ((size_t)(b0 + col) + (size_t)B * c->j[col]) + row;
+          P.y[col * lds + DpA + row] += a.dz_out[srcg];
+          if (o.checkpoint) P.y[col * lds + row] = a.z_out[srcg];
         }
       }
       __syncthreads();
@@ -1255,8 +1291,11 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
           c->t[col] -= c->tnew[col];
       }
       __syncthreads();
+      s = 0;
+      running = begin_step();
     }
   }
+
   if (!o.adaptive) commit();
   __syncthreads();
 
@@ -1470,9 +1509,10 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
     err = "MLP forward: tile state does not fit the 160 KiB LDS";
     return LDE_ERR_UNSUPPORTED;
   }
-  const void* kfn = (const void*)k_mlp_forward<0>;   // (compile-time layer counts measured: −8 % time, 3× build time — not worth it)
-  static bool attr_set[3] = {false, false, false};
-  const int ki = 0;
+  const bool rk4 = dm.solver == LDE_SOLVER_RK4;
+  const void* kfn = rk4 ? (const void*)k_mlp_forward<LDE_SOLVER_RK4> : (const void*)k_mlp_forward<LDE_SOLVER_TSIT5>;
+  static bool attr_set[2] = {false, false};
+  const int ki = rk4 ? 1 : 0;
   if (!attr_set[ki]) {
     if (hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
       err = "hipFuncSetAttribute(k_mlp_forward) failed";
@@ -1490,7 +1530,8 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
     err = "hipMemsetAsync(counter) failed";
     return LDE_ERR_HIP;
   }
-  hipLaunchKernelGGL(k_mlp_forward<0>, dim3(nwg), dim3(NTHREADS), lds, stream, dm, o, a);
+  if (rk4) hipLaunchKernelGGL(k_mlp_forward<LDE_SOLVER_RK4>, dim3(nwg), dim3(NTHREADS), lds, stream, dm, o, a);
+  else hipLaunchKernelGGL(k_mlp_forward<LDE_SOLVER_TSIT5>, dim3(nwg), dim3(NTHREADS), lds, stream, dm, o, a);
   if (hipGetLastError() != hipSuccess) {
     err = "k_mlp_forward launch failed";
     return LDE_ERR_HIP;
@@ -1498,20 +1539,26 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
   return LDE_OK;
 }
 
-template <int NDW>
-static int launch_adjoint(MlpPlan* p, const KOpts& o, const BwdArgs& a, int nwg, size_t lds, hipStream_t stream,
-                          std::string& err) {
+template <int NDW, int SOLVER>
+static int launch_adjoint2(MlpPlan* p, const KOpts& o, const BwdArgs& a, int nwg, size_t lds, hipStream_t stream,
+                           std::string& err) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_mlp_adjoint<NDW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) !=
-        hipSuccess) {
+    if (hipFuncSetAttribute((const void*)k_mlp_adjoint<NDW, SOLVER>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LDS_MAX) != hipSuccess) {
       err = "hipFuncSetAttribute(k_mlp_adjoint) failed";
       return LDE_ERR_HIP;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_mlp_adjoint<NDW>), dim3(nwg), dim3(NTHREADS), lds, stream, p->dm, o, a);
+  hipLaunchKernelGGL((k_mlp_adjoint<NDW, SOLVER>), dim3(nwg), dim3(NTHREADS), lds, stream, p->dm, o, a);
   return LDE_OK;
+}
+template <int NDW>
+static int launch_adjoint(MlpPlan* p, const KOpts& o, const BwdArgs& a, int nwg, size_t lds, hipStream_t stream,
+                          std::string& err) {
+  return p->dm.solver == LDE_SOLVER_RK4 ? launch_adjoint2<NDW, LDE_SOLVER_RK4>(p, o, a, nwg, lds, stream, err)
+                                        : launch_adjoint2<NDW, LDE_SOLVER_TSIT5>(p, o, a, nwg, lds, stream, err);
 }
 
 int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float* theta, const double* ts_dev,

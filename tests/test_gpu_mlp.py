@@ -209,9 +209,10 @@ def test_c3_pendulum_plus_mlp_adjoint(o32, o64):
     d64 = O.make_desc(**{**kw, "abstol": 1e-10, "reltol": 1e-10})
     z64, _, _ = o64.forward(d64, z0, L, ts, W=W.astype(np.float64))
     t0, tL, tW, _ = o64.adjoint(d64, z64, L, ts, dz, W=W.astype(np.float64))
-    _check_grads(g0, r0, t0, 5e-3, 5e-3, "dz0")
-    _check_grads(gL, rL, tL, 5e-3, 5e-3, "dL")
-    _check_grads(gW, rW, tW, 5e-3, 5e-3, "dW")
+    # default tolerance + relu: gradients of two correct fp32 solves agree to about 1 %
+    _check_grads(g0, r0, t0, 1e-2, 5e-3, "dz0")
+    _check_grads(gL, rL, tL, 1e-2, 5e-3, "dL")
+    _check_grads(gW, rW, tW, 1e-2, 5e-3, "dW")
 
 
 def test_augmented_tanh_adjoint_tight(o32, o64):

@@ -256,3 +256,61 @@ def test_per_trajectory_rejections_exercise_the_replay_path(o32, o64):
     assert np.abs(z - z64).max() <= 2e-5 * max(1, np.abs(z64).max())
     assert np.abs(g0 - t0).max() <= 2e-4 * np.abs(t0).max()
     assert np.abs(gW - tW).max() <= 2e-4 * np.abs(tW).max()
+
+
+def test_torch_api_latentode_trains_the_node_weights(o32, o64):
+    """diffeq_layer(::Decoder{LatentODE}, ẑ₀, t) through the reference-shaped host API: ẑ [D', B, T], and — unlike the
+    reference, where `dudt` is invisible to Flux.params — the adjoint's dW reaches the torch parameters
+    of `dudt` (through the differentiable destructure-order flattening)."""
+    import torch
+    import latentdiffeq_amd as la
+    torch.manual_seed(0)
+    D, aug, H, B, T = 6, 2, 32, 24, 20
+    node = la.NODE(D, hidden_dim=H, augment_dim=aug, device="cuda", abstol=1e-7, reltol=1e-7, activation="tanh")
+    dec = la.Decoder(la.LatentODE(), (None, node, None))
+    z0 = _z0(B, D)
+    ts = O.time_grid(T)
+    dz = O.cotangent(T, B, D + aug)
+    z0t = torch.tensor(z0.T.copy(), device="cuda", requires_grad=True)           # [D, B]
+    zhat = la.diffeq_layer(dec, z0t, ts)
+    assert tuple(zhat.shape) == (D + aug, B, T) and zhat.is_cuda
+    (zhat * torch.tensor(dz, device="cuda").permute(2, 1, 0)).sum().backward()
+    W = node.flat_weights().detach().cpu().numpy()
+    od = O.make_desc(rhs_kind=O.RHS_MLP, state_dim=D, param_dim=0, augment_dim=aug, layers=tuple(node.layer_sizes),
+                     batching=O.BATCH_COUPLED, abstol=1e-10, reltol=1e-10, activation=O.ACT_TANH)
+    zt, _, _ = o64.forward(od, z0, None, ts, W=W.astype(np.float64))
+    t0, _, tW, _ = o64.adjoint(od, zt, None, ts, dz, W=W.astype(np.float64))
+    assert np.abs(zhat.detach().permute(2, 1, 0).cpu().numpy() - zt).max() <= 2e-5
+    assert np.abs(z0t.grad.cpu().numpy().T - t0).max() <= 2e-4 * np.abs(t0).max()
+    # gradients arrive on the torch parameters in THEIR layout (weight [out, in] row-major, bias)
+    off = 0
+    for m in node.dudt:
+        if isinstance(m, torch.nn.Linear):
+            o_, i_ = m.weight.shape
+            gw = tW[off:off + o_ * i_].reshape(i_, o_).T      # vec(W) column-major [out×in]
+            off += o_ * i_
+            gb = tW[off:off + o_]
+            off += o_
+            assert np.abs(m.weight.grad.cpu().numpy() - gw).max() <= 3e-4 * np.abs(tW).max()
+            assert np.abs(m.bias.grad.cpu().numpy() - gb).max() <= 3e-4 * np.abs(tW).max()
+    # single process: the gradient all-reduce is a no-op and must not need an initialised process group
+    la.FlatGradAllReduce(node.dudt.parameters())()
+
+
+def test_hook_and_sharded_entry_point():
+    """transform_after_diffeq is applied where the reference applies it; diffeq_layer_sharded(world=1) == diffeq_layer."""
+    import torch
+    import latentdiffeq_amd as la
+
+    class Doubling(la.Pendulum):
+        def transform_after_diffeq(self, x):     # sees [D, T, B] for GOKU  [REF GOKU.jl:124]
+            assert tuple(x.shape) == (2, 10, 8)
+            return 2 * x
+    z0, L = O.pendulum_inputs(8)
+    ts = O.time_grid(10)
+    a = torch.tensor(z0.T.copy(), device="cuda"), torch.tensor(L.T.copy(), device="cuda")
+    plain = la.diffeq_layer(la.Decoder(la.GOKU_basic(), (None, la.Pendulum(), None)), a, ts)
+    hooked = la.diffeq_layer(la.Decoder(la.GOKU_basic(), (None, Doubling(), None)), a, ts)
+    assert tuple(hooked.shape) == (2, 8, 10) and torch.equal(hooked, 2 * plain)
+    shard = la.diffeq_layer_sharded(la.Decoder(la.GOKU_basic(), (None, la.Pendulum(), None)), a, ts, rank=1, world=2)
+    assert torch.equal(shard, plain[:, 4:, :])

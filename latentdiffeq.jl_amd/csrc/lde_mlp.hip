@@ -65,8 +65,11 @@ struct MlpDims {
   int frag_n[MAXL], fragT_n[MAXL];
   int w_off[MAXL];        // offset of vec(W_l) in the flat (destructure-order) weight vector
   int b_off[MAXL];        // offset of b_l
-  int hmax;               // rows of a hidden panel (widest hidden layer, padded to 16)
-  int ld_h;               // stride of hidden panels
+  int hmax;               // rows of the widest hidden panel (padded to 32)
+  int ld_h;               // stride of the widest hidden panel (the two back-propagation panels use it)
+  int ld_hl[MAXL];        // stride of hidden panel l (activation of layer l), sized for ITS width
+  int h_off[MAXL];        // float offset of hidden panel l from the first one
+  int h_total;            // floats of all hidden panels
   int ld_sf, ld_sb;       // stride of state panels in the forward / adjoint kernel
   int coupled;            // LDE_BATCH_COUPLED
   int solver;
@@ -292,7 +295,8 @@ struct Panels {       // LDS carve-up; every panel is transposed: element (row, 
   const float* gfrag; // global fragment arrays
   const float* gfragT;
   __device__ __forceinline__ float* k(int s) const { return kbase + s * pstride; }
-  __device__ __forceinline__ float* hid(int l) const { return hidbase + l * hstride; }
+  const int* hoff;    // dm.h_off
+  __device__ __forceinline__ float* hid(int l) const { return hidbase + hoff[l]; }
   __device__ __forceinline__ float* del(int i) const { return delbase + i * hstride; }
 };
 
@@ -324,7 +328,7 @@ __device__ __forceinline__ void eval_rhs(const MlpDims& dm, const Panels& P, con
     const int in = dm.sizes[l], out = dm.sizes[l + 1];
     const bool lastl = l == nL - 1;
     float* Y = lastl ? dst : P.hid(l);
-    const int ldy = lastl ? P.lds : P.ldh;
+    const int ldy = lastl ? P.lds : dm.ld_hl[l];
     const float* bias = P.biasc + dm.bias_lin[l];
     const int actk = dm.act;
     layer_gemm(P.lbase, c->wofs[l], P.gfrag + dm.frag_off[l], out, in, X, ldx, P.red, [&](int row0, int col, f32x4 v) {
@@ -396,7 +400,8 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
   P.tmp = p; p += P.pstride;
   P.kbase = p; p += 7 * P.pstride;
   P.scr = p; p += P.pstride;
-  P.hidbase = p; p += (dm.nL > 1 ? dm.nL - 1 : 0) * P.hstride;
+  P.hidbase = p; p += dm.h_total;
+  P.hoff = dm.h_off;
   P.delbase = nullptr;
   P.red = p; p += 1024;
   P.biasc = p; p += (dm.nbias + 3) & ~3;
@@ -796,7 +801,7 @@ __device__ __forceinline__ void eval_bwd(const MlpDims& dm, const Panels& P, con
   for (int l = nL - 1; l >= 0; l--) {
     const int in = dm.sizes[l], out = dm.sizes[l + 1];
     const float* al = l == 0 ? src : P.hid(l - 1);   // input activation of layer l
-    const int lda = l == 0 ? P.lds : P.ldh;
+    const int lda = l == 0 ? P.lds : dm.ld_hl[l - 1];
     if (any_w) {
       // gWᵀ 32×32 tile [i][o] += Σ_n a_l[i][n] · (w_n δ[o][n]) on v_mfma_f32_32x32x2_f32: MFMA s contracts the two columns
       // n = 2s + (lane>>5); every operand read is 32 consecutive floats per half-wave (conflict-free).
@@ -833,7 +838,7 @@ __device__ __forceinline__ void eval_bwd(const MlpDims& dm, const Panels& P, con
     // δ_in = W_lᵀ δ  (⊙ act'(a_l) for hidden layers); layer 0 gives (∂f/∂z)ᵀλ
     if (l > 0) {
       float* dn = P.del((nL - 1 - l) & 1);
-      const int actk = dm.act, ldh = P.ldh;
+      const int actk = dm.act, ldh = dm.ld_hl[l - 1];   // δ_{l-1} shares the geometry of the activation it masks
       layer_gemm(P.lbase, c->wTofs[l], P.gfragT + dm.fragT_off[l], in, out, dl, ldd, P.red, [&](int row0, int col, f32x4 v) {
         const f32x4 av = *reinterpret_cast<const f32x4*>(al + col * ldh + row0);
         f32x4 r;
@@ -892,7 +897,8 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
   P.tmp = p; p += P.pstride;
   P.kbase = p; p += 7 * P.pstride;
   P.scr = p; p += P.pstride;
-  P.hidbase = p; p += (dm.nL > 1 ? dm.nL - 1 : 0) * P.hstride;
+  P.hidbase = p; p += dm.h_total;
+  P.hoff = dm.h_off;
   P.delbase = p; p += 2 * P.hstride;
   P.red = p; p += 1024;
   P.biasc = p; p += (dm.nbias + 3) & ~3;
@@ -1389,6 +1395,13 @@ int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err) 
   }
   dm.hmax = (hmax + 31) & ~31;   // whole 32-row weight-gradient tiles (and 16-row K-groups)
   dm.ld_h = panel_stride(dm.hmax);
+  dm.h_total = 0;
+  for (int l = 0; l < MAXL; l++) { dm.ld_hl[l] = dm.ld_h; dm.h_off[l] = 0; }
+  for (int l = 0; l + 1 < dm.nL; l++) {
+    dm.ld_hl[l] = panel_stride((dm.sizes[l + 1] + 31) & ~31);
+    dm.h_off[l] = dm.h_total;
+    dm.h_total += NB * dm.ld_hl[l];
+  }
   const int Dp16 = (dm.Dp + 15) & ~15, Dp32 = (dm.Dp + 31) & ~31;
   dm.ld_sf = panel_stride(Dp16);
   // adjoint state rows: z [0,Dp) | λ [DpA,DpA+Dp) | g [2DpA, 2DpA+P); operand reads reach DpA + Dp32 rows (32-row tiles)
@@ -1475,15 +1488,14 @@ static constexpr size_t LDS_MAX = 160 * 1024;
 static size_t fwd_lds_fixed(const MlpDims& dm, int T) {
   size_t b = (sizeof(Ctl) + 15) & ~size_t(15);
   b += ((size_t)T * 8 + 15) & ~size_t(15);
-  b += (size_t)(11 * NB * dm.ld_sf + (dm.nL > 1 ? dm.nL - 1 : 0) * NB * dm.ld_h + 1024 + ((dm.nbias + 3) & ~3)) * sizeof(float);
+  b += (size_t)(11 * NB * dm.ld_sf + dm.h_total + 1024 + ((dm.nbias + 3) & ~3)) * sizeof(float);
   return b;
 }
 
 static size_t bwd_lds_fixed(const MlpDims& dm, int T) {
   size_t b = (sizeof(Ctl) + 15) & ~size_t(15);
   b += ((size_t)T * 8 + 15) & ~size_t(15);
-  b += (size_t)(11 * NB * dm.ld_sb + ((dm.nL > 1 ? dm.nL - 1 : 0) + 2) * NB * dm.ld_h + 1024 + 2 * ((dm.nbias + 3) & ~3) + NB) *
-       sizeof(float);
+  b += (size_t)(11 * NB * dm.ld_sb + dm.h_total + 2 * NB * dm.ld_h + 1024 + 2 * ((dm.nbias + 3) & ~3) + NB) * sizeof(float);
   return b;
 }
 

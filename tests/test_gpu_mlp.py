@@ -314,3 +314,46 @@ def test_hook_and_sharded_entry_point():
     assert tuple(hooked.shape) == (2, 8, 10) and torch.equal(hooked, 2 * plain)
     shard = la.diffeq_layer_sharded(la.Decoder(la.GOKU_basic(), (None, la.Pendulum(), None)), a, ts, rank=1, world=2)
     assert torch.equal(shard, plain[:, 4:, :])
+
+
+@pytest.mark.parametrize("seed", range(16))
+def test_random_mlp_shapes_forward_and_adjoint(o64, seed):
+    """Shape fuzzing of the padding / tiling logic: random depth (1–6 Dense layers), widths that are not multiples of
+    4/16/32 (including 1 and >128), random state/augment dims, both batching modes and both solvers, ragged batches.
+    Smooth activation + tight tolerance so that the float64 oracle is a sharp reference (1e-4 relative)."""
+    rng = np.random.default_rng(1000 + seed)
+    D = int(rng.integers(1, 41))
+    aug = int(rng.integers(0, 4)) if rng.random() < 0.5 else 0
+    Dp = D + aug
+    nl = int(rng.integers(1, 7))
+    widths = [int(rng.choice([1, 3, 5, 16, 17, 31, 32, 33, 50, 64, 65, 100, 129, 200])) for _ in range(nl - 1)]
+    layers = (Dp, *widths, Dp)
+    batching = int(rng.integers(0, 2))
+    rk4 = rng.random() < 0.3
+    B = int(rng.choice([1, 5, 16, 17, 40]))
+    T = int(rng.integers(2, 12))
+    W = O.mlp_weights(layers, seed=seed, scale=0.7)
+    kw = dict(rhs_kind=O.RHS_MLP, state_dim=D, param_dim=0, augment_dim=aug, layers=layers, activation=O.ACT_TANH,
+              batching=batching)
+    kw.update(dict(solver=O.SOLVER_RK4, adaptive=0, dt=0.025) if rk4 else dict(abstol=1e-7, reltol=1e-7))
+    nat, od = _native(W, **kw)
+    z0 = _z0(B, D, seed=seed)
+    ts = O.time_grid(T, 0.1)
+    dz = O.cotangent(T, B, Dp, seed=seed)
+    from latentdiffeq_amd._lib import LdeError
+    z, ret, _ = nat.forward(z0, None, ts)
+    try:
+        g0, _, gW, st = nat.adjoint(z, None, ts, dz)
+    except LdeError as e:   # the only acceptable refusal: a deep AND wide net whose tile state exceeds the 160 KiB LDS
+        assert "does not fit the 160 KiB LDS" in str(e) and sum(widths) >= 500, (layers, str(e))
+        return
+    kw64 = dict(kw)
+    kw64.update(dict(dt=0.025 / 4) if rk4 else dict(abstol=1e-11, reltol=1e-11))
+    d64 = O.make_desc(**{k: (bool(v) if k == "adaptive" else v) for k, v in kw64.items()})
+    zt, _, _ = o64.forward(d64, z0, None, ts, W=W.astype(np.float64))
+    t0, _, tW, _ = o64.adjoint(d64, zt, None, ts, dz, W=W.astype(np.float64))
+    assert (ret == 0).all() and st["nfailed"] == 0
+    assert z.shape == (T, B, Dp)
+    assert np.abs(z - zt).max() <= 1e-4 * max(1.0, np.abs(zt).max()), (layers, batching, rk4, B, T)
+    assert np.abs(g0 - t0).max() <= 2e-4 * np.abs(t0).max() + 1e-9, (layers, batching, rk4, B, T)
+    assert np.abs(gW - tW).max() <= 2e-4 * np.abs(tW).max() + 1e-9, (layers, batching, rk4, B, T)

@@ -38,7 +38,6 @@
 namespace lde {
 
 constexpr int NB = 16;        // trajectories (columns) per workgroup
-constexpr int NTHREADS = 256;
 constexpr int MAXL = LDE_MAX_LAYERS;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -120,7 +119,7 @@ __device__ __forceinline__ float act_grad(int kind, float a) { return kind == LD
 // Y[R×16] = M[R×K]·X[K×16] for one workgroup. M as K4 fragments (LDS copy or global), X a transposed panel
 // (Xt[col*ldx + row], rows [0,K) starting at the pointer), EPI(row0, col, acc4) gets the 4 consecutive rows a lane owns.
 // `red` = 4 KiB LDS scratch for the split-K reduction of narrow layers.
-template <class Epi>
+template <int NT, class Epi>
 __device__ __forceinline__ void panel_gemm(const float* frag, int R, int K, const float* Xt, int ldx, float* red, Epi epi) {
   if (LDE_ABL == 1) return;   // diagnostic build: no GEMM at all
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -128,9 +127,9 @@ __device__ __forceinline__ void panel_gemm(const float* frag, int R, int K, cons
   const f32x4* A = reinterpret_cast<const f32x4*>(frag);
   const float* xp = Xt + (lane & 15) * ldx + 4 * (lane >> 4);
   const int col = lane & 15, rsub = 4 * (lane >> 4);
-  if (RT >= 3) {
-    for (int rt = wave; rt < RT; rt += 8) {
-      const int rt2 = rt + 4;
+  if (RT >= 3 || RT > (NT / 64) / 2) {
+    for (int rt = wave; rt < RT; rt += 2 * (NT / 64)) {
+      const int rt2 = rt + (NT / 64);
       const bool two = rt2 < RT;
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
       const f32x4* a0p = A + (size_t)rt * KG * 64 + lane;
@@ -172,7 +171,7 @@ __device__ __forceinline__ void panel_gemm(const float* frag, int R, int K, cons
     }
   } else {
     // narrow layer (1 or 2 row tiles): split K over the waves, reduce through LDS
-    const int nparts = RT == 1 ? 4 : 2;
+    const int nparts = (NT / 64) / RT;
     const int rt = wave % RT, part = wave / RT;
     const int per = cdiv(KG, nparts), k0 = part * per, k1 = min(KG, k0 + per);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
@@ -204,11 +203,11 @@ __device__ __forceinline__ void panel_gemm(const float* frag, int R, int K, cons
 
 // A-fragments either from the LDS cache (pointer formed from the LDS base ⇒ ds_read_b128) or from global/L2
 // (kernel-argument pointer ⇒ global_load_dwordx4) — never through a generic pointer.
-template <class Epi>
+template <int NT, class Epi>
 __device__ __forceinline__ void layer_gemm(const float* lds_base, int ofs, const float* gfrag, int R, int K, const float* Xt,
                                            int ldx, float* red, Epi epi) {
-  if (ofs >= 0) panel_gemm(lds_base + ofs, R, K, Xt, ldx, red, epi);
-  else panel_gemm(gfrag, R, K, Xt, ldx, red, epi);
+  if (ofs >= 0) panel_gemm<NT>(lds_base + ofs, R, K, Xt, ldx, red, epi);
+  else panel_gemm<NT>(gfrag, R, K, Xt, ldx, red, epi);
 }
 
 // ---- grid-wide deterministic sum (coupled mode) ----------------------------------------------------
@@ -287,7 +286,7 @@ struct Panels {       // LDS carve-up; every panel is transposed: element (row, 
   float* hidbase;     // hidden activations (post-activation) of layers 0..nL-2
   float* delbase;     // backprop panels (adjoint only)
   float* scr;         // scratch (error terms, 1/scale)
-  float* red;         // 1024 floats: split-K reduction scratch
+  float* red;         // (NT / 64)*256 floats: split-K reduction scratch
   float* biasc;       // LDS copy of all biases (compact, bias_lin order)
   int pstride, hstride;
   int lds, ldh;       // strides of state / hidden panels
@@ -301,6 +300,7 @@ struct Panels {       // LDS carve-up; every panel is transposed: element (row, 
 };
 
 // copy weight fragments into the LDS cache while they fit; record where each layer's fragments live
+template <int NT>
 __device__ __forceinline__ float* cache_frags(const MlpDims& dm, const float* gfrag, const int* off, const int* cnt,
                                               int* table, const float* lds_base, float* cache, float* cache_end) {
   for (int l = 0; l < dm.nL; l++) {
@@ -310,7 +310,7 @@ __device__ __forceinline__ float* cache_frags(const MlpDims& dm, const float* gf
     if (fits) {
       const f32x4* s4 = reinterpret_cast<const f32x4*>(src);
       f32x4* d4 = reinterpret_cast<f32x4*>(cache);
-      for (int i = threadIdx.x; i < n / 4; i += NTHREADS) d4[i] = s4[i];
+      for (int i = threadIdx.x; i < n / 4; i += NT) d4[i] = s4[i];
     }
     if (threadIdx.x == 0) table[l] = fits ? (int)(cache - lds_base) : -1;
     if (fits) cache += n;
@@ -320,6 +320,7 @@ __device__ __forceinline__ float* cache_frags(const MlpDims& dm, const float* gf
 
 // f(z) for the tile: dst rows [0,Dp) = MLP(src rows [0,Dp)) (+ pendulum); hidden activations are left in P.hid(*).
 // (A variant with the layer loop unrolled at compile time was measured: −8 % time for 3× code and build time — dropped.)
+template <int NT>
 __device__ __forceinline__ void eval_rhs(const MlpDims& dm, const Panels& P, const Ctl* c, const float* src, float* dst) {
   const float* X = src;
   int ldx = P.lds;
@@ -331,7 +332,7 @@ __device__ __forceinline__ void eval_rhs(const MlpDims& dm, const Panels& P, con
     const int ldy = lastl ? P.lds : dm.ld_hl[l];
     const float* bias = P.biasc + dm.bias_lin[l];
     const int actk = dm.act;
-    layer_gemm(P.lbase, c->wofs[l], P.gfrag + dm.frag_off[l], out, in, X, ldx, P.red, [&](int row0, int col, f32x4 v) {
+    layer_gemm<NT>(P.lbase, c->wofs[l], P.gfrag + dm.frag_off[l], out, in, X, ldx, P.red, [&](int row0, int col, f32x4 v) {
       f32x4 r;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
@@ -375,13 +376,14 @@ struct FwdArgs {
   int lds_bytes;      // dynamic LDS actually requested (the weight cache takes what the panels leave)
 };
 
+template <int NT>
 __device__ __forceinline__ void load_biases(const MlpDims& dm, const float* Wflat, float* biasc) {
   for (int l = 0; l < dm.nL; l++)
-    for (int i = threadIdx.x; i < dm.sizes[l + 1]; i += NTHREADS) biasc[dm.bias_lin[l] + i] = Wflat[dm.b_off[l] + i];
+    for (int i = threadIdx.x; i < dm.sizes[l + 1]; i += NT) biasc[dm.bias_lin[l] + i] = Wflat[dm.b_off[l] + i];
 }
 
-template <int SOLVER>
-__global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, FwdArgs a) {
+template <int SOLVER, int NT>
+__global__ void __launch_bounds__(NT) k_mlp_forward(MlpDims dm, KOpts o, FwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int T = o.T, B = o.B, Dp = dm.Dp, D = dm.D;
   // ---- carve LDS -------------------------------------------------------------------------------------
@@ -403,17 +405,17 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
   P.hidbase = p; p += dm.h_total;
   P.hoff = dm.h_off;
   P.delbase = nullptr;
-  P.red = p; p += 1024;
+  P.red = p; p += (NT / 64) * 256;
   P.biasc = p; p += (dm.nbias + 3) & ~3;
   const int nfloat = (int)(p - base);
-  for (int i = threadIdx.x; i < nfloat; i += NTHREADS) base[i] = 0.f;   // pad rows must be finite (0·x)
-  for (int i = threadIdx.x; i < T; i += NTHREADS) s_ts[i] = a.ts[i];
+  for (int i = threadIdx.x; i < nfloat; i += NT) base[i] = 0.f;   // pad rows must be finite (0·x)
+  for (int i = threadIdx.x; i < T; i += NT) s_ts[i] = a.ts[i];
   __syncthreads();
   P.lbase = reinterpret_cast<const float*>(smem);
   P.gfrag = a.frag;
   P.gfragT = nullptr;
-  load_biases(dm, a.Wflat, P.biasc);
-  cache_frags(dm, a.frag, dm.frag_off, dm.frag_n, c->wofs, P.lbase, p, reinterpret_cast<float*>(smem + a.lds_bytes));
+  load_biases<NT>(dm, a.Wflat, P.biasc);
+  cache_frags<NT>(dm, a.frag, dm.frag_off, dm.frag_n, c->wofs, P.lbase, p, reinterpret_cast<float*>(smem + a.lds_bytes));
   __syncthreads();
 
   const int tid = threadIdx.x;
@@ -427,7 +429,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
 #define ECOL(e) ((e) / NS)
 
   // ---- load the tile: column-major z0 [D×B]; augmented rows stay 0 -----------------------------------
-  for (int e = tid; e < NB * D; e += NTHREADS) {
+  for (int e = tid; e < NB * D; e += NT) {
     const int col = e / D, row = e % D;
     if (b0 + col < B) P.y[col * lds + row] = a.z0[(size_t)(b0 + col) * D + row];
   }
@@ -447,7 +449,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
   }
   __syncthreads();
   // save time 0 = ẑ₀ itself (augmented rows 0)
-  for (int e = tid; e < NB * Dp; e += NTHREADS) {
+  for (int e = tid; e < NB * Dp; e += NT) {
     const int col = e / Dp, row = e % Dp;
     if (b0 + col < B) a.z_out[(size_t)(b0 + col) * Dp + row] = P.y[col * lds + row];
   }
@@ -496,7 +498,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
     if (phase == PH_STAGE) {
       if (SOLVER == LDE_SOLVER_TSIT5) {
         float* dstp = s < 6 ? P.tmp : P.yn;
-        for (int e = tid; e < nel; e += NTHREADS) {
+        for (int e = tid; e < nel; e += NT) {
           const int idx = EIDX(e);
           float acc = ts5::A[s][0] * P.k(0)[idx];
           for (int jj = 1; jj < s; jj++) acc += ts5::A[s][jj] * P.k(jj)[idx];
@@ -505,13 +507,13 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
         src = dstp;
       } else if (s < 4) {
         const float cs = s == 3 ? 1.0f : 0.5f;
-        for (int e = tid; e < nel; e += NTHREADS) {
+        for (int e = tid; e < nel; e += NT) {
           const int idx = EIDX(e);
           P.tmp[idx] = P.y[idx] + (cs * c->h[ECOL(e)]) * P.k(s - 1)[idx];
         }
         src = P.tmp;
       } else {
-        for (int e = tid; e < nel; e += NTHREADS) {
+        for (int e = tid; e < nel; e += NT) {
           const int idx = EIDX(e);
           P.yn[idx] = P.y[idx] + (c->h[ECOL(e)] * (1.0f / 6.0f)) * (P.k(0)[idx] + 2.0f * (P.k(1)[idx] + P.k(2)[idx]) + P.k(3)[idx]);
         }
@@ -521,14 +523,14 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
     }
     float* dst = phase == PH_K0 ? P.k(0) : (phase == PH_INIT1 ? P.k(1) : P.k(s));
 
-    eval_rhs(dm, P, c, src, dst);
+    eval_rhs<NT>(dm, P, c, src, dst);
     if (tid < NB && c->status[tid] == 0) c->nfe[tid]++;
 
     // ---- what follows the evaluation ---------------------------------------------------------------------------
     if (phase == PH_K0) {
       if (o.adaptive && !(o.dt_fixed > 0)) {
         // Hairer–Nørsett–Wanner, part 1: d0, d1, trial Euler step
-        for (int e = tid; e < nel; e += NTHREADS) {
+        for (int e = tid; e < nel; e += NT) {
           const int idx = EIDX(e);
           const float yv = P.y[idx];
           const float sk = fast_rcp(o.abstol + fabsf(yv) * o.reltol);
@@ -563,7 +565,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
           c->th[tid] = d1;
         }
         __syncthreads();
-        for (int e = tid; e < nel; e += NTHREADS) {
+        for (int e = tid; e < nel; e += NT) {
           const int idx = EIDX(e);
           P.tmp[idx] = P.y[idx] + c->h[ECOL(e)] * P.k(0)[idx];
         }
@@ -578,7 +580,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
       }
     } else if (phase == PH_INIT1) {
       // part 2: d2 and the initial step
-      for (int e = tid; e < nel; e += NTHREADS) {
+      for (int e = tid; e < nel; e += NT) {
         const int idx = EIDX(e);
         const float d = (P.k(1)[idx] - P.k(0)[idx]) * P.scr[idx];
         P.yn[idx] = d * d;
@@ -614,7 +616,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
       s++;
     } else {
       // ---- end of a step attempt: error estimate ------------------------------------------------------------
-      for (int e = tid; e < nel; e += NTHREADS) {
+      for (int e = tid; e < nel; e += NT) {
         const int idx = EIDX(e);
         float r2 = 0.f;
         const float yv = P.y[idx], ynv = P.yn[idx];
@@ -704,7 +706,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
         }
         __syncthreads();
         if (!c->any_save) break;
-        for (int e = tid; e < NB * Dp; e += NTHREADS) {
+        for (int e = tid; e < NB * Dp; e += NT) {
           const int col = e / Dp, row = e % Dp, idx = col * lds + row;
           if (!c->hit[col]) continue;
           const float th = c->th[col], h = c->wq[col];
@@ -729,7 +731,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
       }
 
       // ---- advance accepted columns (FSAL: the last slope becomes k1) --------------------------------------
-      for (int e = tid; e < nel; e += NTHREADS) {
+      for (int e = tid; e < nel; e += NT) {
         const int idx = EIDX(e);
         if (c->accepted[ECOL(e)]) {
           P.y[idx] = P.yn[idx];
@@ -747,7 +749,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_forward(MlpDims dm, KOpts o, F
   }
 
   // ---- epilogue: NaN blocks for failed columns, statistics -------------------------------------------------
-  for (int e = tid; e < NB * Dp; e += NTHREADS) {
+  for (int e = tid; e < NB * Dp; e += NT) {
     const int col = e / Dp, row = e % Dp;
     if (b0 + col < B && c->status[col] > 1) {
       const float qn = __int_as_float(0x7fc00000);
@@ -787,13 +789,13 @@ struct BwdArgs {
 
 // f, −(∂f/∂z)ᵀλ, −(∂f/∂θ)ᵀλ for the tile, and the weighted outer products of this stage.
 //   src/dst rows: [0,Dp) z | [DpA,DpA+Dp) λ | [2DpA,2DpA+P) g.   wst[col] = quadrature weight of this stage (0 ⇒ none)
-template <int NDW>
+template <int NDW, int NT>
 __device__ __forceinline__ void eval_bwd(const MlpDims& dm, const Panels& P, const Ctl* c, const float* src, float* dst,
                                          const float* wst, bool any_w, f32x16 (&acc)[NDW], float* bstep) {
   const int DpA = dm.DpA, nL = dm.nL;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // 1. forward through the MLP (relu masks are recomputed here, not stored by the forward solve)
-  eval_rhs(dm, P, c, src, dst);
+  eval_rhs<NT>(dm, P, c, src, dst);
   // 2. back-propagate λ; δ_L = λ_stage
   const float* dl = src + DpA;
   int ldd = P.lds;
@@ -812,7 +814,7 @@ __device__ __forceinline__ void eval_bwd(const MlpDims& dm, const Panels& P, con
       for (int s8 = 0; s8 < 8; s8++) wl[s8] = wst[2 * s8 + half];
 #pragma unroll
       for (int m = 0; m < NDW; m++) {
-        const int t = wave + 4 * m;
+        const int t = wave + (NT / 64) * m;
         if (t >= t0 && t < t1) {
           const int tt = t - t0, ot = tt / IT, it = tt - ot * IT;
           const float* ap = al + half * lda + it * 32 + (lane & 31);
@@ -828,7 +830,7 @@ __device__ __forceinline__ void eval_bwd(const MlpDims& dm, const Panels& P, con
         }
         __builtin_amdgcn_sched_barrier(0);   // keep one tile's 16 operand loads in flight, not all NDW tiles' (VGPR blow-up)
       }
-      for (int row = threadIdx.x; row < out; row += NTHREADS) {
+      for (int row = threadIdx.x; row < out; row += NT) {
         float sacc = 0.f;
 #pragma unroll
         for (int n = 0; n < NB; n++) sacc += wst[n] * dl[n * ldd + row];
@@ -839,7 +841,7 @@ __device__ __forceinline__ void eval_bwd(const MlpDims& dm, const Panels& P, con
     if (l > 0) {
       float* dn = P.del((nL - 1 - l) & 1);
       const int actk = dm.act, ldh = dm.ld_hl[l - 1];   // δ_{l-1} shares the geometry of the activation it masks
-      layer_gemm(P.lbase, c->wTofs[l], P.gfragT + dm.fragT_off[l], in, out, dl, ldd, P.red, [&](int row0, int col, f32x4 v) {
+      layer_gemm<NT>(P.lbase, c->wTofs[l], P.gfragT + dm.fragT_off[l], in, out, dl, ldd, P.red, [&](int row0, int col, f32x4 v) {
         const f32x4 av = *reinterpret_cast<const f32x4*>(al + col * ldh + row0);
         f32x4 r;
 #pragma unroll
@@ -852,7 +854,7 @@ __device__ __forceinline__ void eval_bwd(const MlpDims& dm, const Panels& P, con
     } else {
       float* dlam = dst + DpA;
       const int lds = P.lds;
-      layer_gemm(P.lbase, c->wTofs[0], P.gfragT + dm.fragT_off[0], in, out, dl, ldd, P.red, [&](int row0, int col, f32x4 v) {
+      layer_gemm<NT>(P.lbase, c->wTofs[0], P.gfragT + dm.fragT_off[0], in, out, dl, ldd, P.red, [&](int row0, int col, f32x4 v) {
 #pragma unroll
         for (int q = 0; q < 4; q++)
           if (row0 + q < in) dlam[col * lds + row0 + q] = -v[q];
@@ -877,8 +879,8 @@ __device__ __forceinline__ void eval_bwd(const MlpDims& dm, const Panels& P, con
 }
 
 // Reverse-time solve of [z; λ; g_θ] for one tile, with forced stops + jumps at the save times.
-template <int NDW, int SOLVER>
-__global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs a) {
+template <int NDW, int SOLVER, int NT>
+__global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int T = o.T, B = o.B, Dp = dm.Dp, DpA = dm.DpA, D = dm.D, NP = dm.P;
   Ctl* c = reinterpret_cast<Ctl*>(smem);
@@ -900,22 +902,22 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
   P.hidbase = p; p += dm.h_total;
   P.hoff = dm.h_off;
   P.delbase = p; p += 2 * P.hstride;
-  P.red = p; p += 1024;
+  P.red = p; p += (NT / 64) * 256;
   P.biasc = p; p += (dm.nbias + 3) & ~3;
   float* bstep = p; p += (dm.nbias + 3) & ~3;
   float* wst = p; p += NB;
   const int nfloat = (int)(p - base);
-  for (int i = threadIdx.x; i < nfloat; i += NTHREADS) base[i] = 0.f;
-  for (int i = threadIdx.x; i < T; i += NTHREADS) s_ts[i] = a.ts[i];
+  for (int i = threadIdx.x; i < nfloat; i += NT) base[i] = 0.f;
+  for (int i = threadIdx.x; i < T; i += NT) s_ts[i] = a.ts[i];
   __syncthreads();
   P.lbase = reinterpret_cast<const float*>(smem);
   P.gfrag = a.frag;
   P.gfragT = a.fragT;
-  load_biases(dm, a.Wflat, P.biasc);
+  load_biases<NT>(dm, a.Wflat, P.biasc);
   {
     float* cend = reinterpret_cast<float*>(smem + a.lds_bytes);
-    float* cp = cache_frags(dm, a.fragT, dm.fragT_off, dm.fragT_n, c->wTofs, P.lbase, p, cend);
-    cache_frags(dm, a.frag, dm.frag_off, dm.frag_n, c->wofs, P.lbase, cp, cend);
+    float* cp = cache_frags<NT>(dm, a.fragT, dm.fragT_off, dm.fragT_n, c->wTofs, P.lbase, p, cend);
+    cache_frags<NT>(dm, a.frag, dm.frag_off, dm.frag_n, c->wofs, P.lbase, cp, cend);
   }
   __syncthreads();
 
@@ -927,7 +929,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
   const double tT = s_ts[T - 1], dtmax = fabs(tT - s_ts[0]);
   unsigned gen = 0;
   float* slab = a.slab + (size_t)blockIdx.x * dm.slab_n;
-  for (int i = tid; i < dm.slab_n; i += NTHREADS) slab[i] = 0.f;
+  for (int i = tid; i < dm.slab_n; i += NT) slab[i] = 0.f;
 #define EIDX(e) (((e) / NS) * lds + ((e) % NS))
 #define ECOL(e) ((e) / NS)
 
@@ -944,7 +946,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
   auto commit = [&]() {
 #pragma unroll
     for (int m = 0; m < NDW; m++) {
-      const int t = wave + 4 * m;
+      const int t = wave + (NT / 64) * m;
       if (t < ntiles) {
         f32x4* g4 = reinterpret_cast<f32x4*>(slab + ((size_t)t * 64 + lane) * 16);
 #pragma unroll
@@ -962,7 +964,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
       __builtin_amdgcn_sched_barrier(0);
     }
     float* gb = slab + (size_t)ntiles * 1024;
-    for (int i = tid; i < dm.nbias; i += NTHREADS) {
+    for (int i = tid; i < dm.nbias; i += NT) {
       gb[i] += bstep[i];
       bstep[i] = 0.f;
     }
@@ -972,11 +974,11 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
     for (int m = 0; m < NDW; m++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
-    for (int i = tid; i < dm.nbias; i += NTHREADS) bstep[i] = 0.f;
+    for (int i = tid; i < dm.nbias; i += NT) bstep[i] = 0.f;
   };
 
   // ---- load the terminal condition: z = ẑ(t_T), λ = Δ_T, g = 0 ------------------------------------------
-  for (int e = tid; e < NB * Dp; e += NTHREADS) {
+  for (int e = tid; e < NB * Dp; e += NT) {
     const int col = e / Dp, row = e % Dp;
     if (b0 + col < B) {
       const size_t src = (size_t)Dp * ((size_t)(b0 + col) + (size_t)B * (T - 1)) + row;
@@ -1064,7 +1066,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
       if (SOLVER == LDE_SOLVER_TSIT5) {
         if (s > 0) {
           float* dstp = s < 6 ? P.tmp : P.yn;
-          for (int e = tid; e < nel; e += NTHREADS) {
+          for (int e = tid; e < nel; e += NT) {
             const int idx = EIDX(e);
             float accv = ts5::A[s][0] * P.k(0)[idx];
             for (int jj = 1; jj < s; jj++) accv += ts5::A[s][jj] * P.k(jj)[idx];
@@ -1077,7 +1079,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
       } else {
         if (s > 0) {
           const float cs = s == 3 ? 1.0f : 0.5f;
-          for (int e = tid; e < nel; e += NTHREADS) {
+          for (int e = tid; e < nel; e += NT) {
             const int idx = EIDX(e);
             P.tmp[idx] = P.y[idx] + (cs * c->h[ECOL(e)]) * P.k(s - 1)[idx];
           }
@@ -1091,13 +1093,13 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
     }
     float* dst = phase == PH_K0 ? P.k(0) : (phase == PH_INIT1 ? P.k(1) : P.k(s));
 
-    eval_bwd<NDW>(dm, P, c, src, dst, wst, any_w, acc, bstep);
+    eval_bwd<NDW, NT>(dm, P, c, src, dst, wst, any_w, acc, bstep);
     if (!replay && tid < NB && c->status[tid] == 0) c->nfe[tid]++;
 
     // ---- what follows the evaluation -----------------------------------------------------------------------------
     if (phase == PH_K0) {
       // Hairer–Nørsett–Wanner on the augmented state, direction −1: part 1
-      for (int e = tid; e < nel; e += NTHREADS) {
+      for (int e = tid; e < nel; e += NT) {
         const int idx = EIDX(e);
         const float yv = P.y[idx];
         const float sk = fast_rcp(o.abstol + fabsf(yv) * o.reltol);
@@ -1131,14 +1133,14 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
         c->th[tid] = d1;
       }
       __syncthreads();
-      for (int e = tid; e < nel; e += NTHREADS) {
+      for (int e = tid; e < nel; e += NT) {
         const int idx = EIDX(e);
         P.tmp[idx] = P.y[idx] + c->h[ECOL(e)] * P.k(0)[idx];
       }
       __syncthreads();
       phase = PH_INIT1;
     } else if (phase == PH_INIT1) {
-      for (int e = tid; e < nel; e += NTHREADS) {
+      for (int e = tid; e < nel; e += NT) {
         const int idx = EIDX(e);
         const float dd = (P.k(1)[idx] - P.k(0)[idx]) * P.scr[idx];
         P.yn[idx] = dd * dd;
@@ -1175,7 +1177,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
     } else {
       // ---- all stages of this attempt are done ---------------------------------------------------------------------
       if (SOLVER == LDE_SOLVER_RK4) {
-        for (int e = tid; e < nel; e += NTHREADS) {
+        for (int e = tid; e < nel; e += NT) {
           const int idx = EIDX(e);
           P.yn[idx] = P.y[idx] + (c->h[ECOL(e)] * (1.0f / 6.0f)) * (P.k(0)[idx] + 2.0f * (P.k(1)[idx] + P.k(2)[idx]) + P.k(3)[idx]);
         }
@@ -1183,7 +1185,7 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
       }
       if (!replay) {
         // ---- error estimate + control ----------------------------------------------------------------------------
-        for (int e = tid; e < nel; e += NTHREADS) {
+        for (int e = tid; e < nel; e += NT) {
           const int idx = EIDX(e);
           float r2 = 0.f;
           const float yv = P.y[idx], ynv = P.yn[idx];
@@ -1273,12 +1275,12 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
       __syncthreads();
 
       // ---- advance accepted columns; jump at a save time --------------------------------------------------------
-      for (int e = tid; e < nel; e += NTHREADS) {
+      for (int e = tid; e < nel; e += NT) {
         const int idx = EIDX(e);
         if (c->accepted[ECOL(e)]) P.y[idx] = P.yn[idx];
       }
       __syncthreads();
-      for (int e = tid; e < NB * Dp; e += NTHREADS) {
+      for (int e = tid; e < NB * Dp; e += NT) {
         const int col = e / Dp, row = e % Dp;
         if (c->accepted[col] && c->hit[col]) {
           const size_t srcg = (size_t)Dp * ((size_t)(b0 + col) + (size_t)B * c->j[col]) + row;
@@ -1306,12 +1308,12 @@ __global__ void __launch_bounds__(NTHREADS) k_mlp_adjoint(MlpDims dm, KOpts o, B
   __syncthreads();
 
   // ---- results ----------------------------------------------------------------------------------------------------
-  for (int e = tid; e < NB * D; e += NTHREADS) {
+  for (int e = tid; e < NB * D; e += NT) {
     const int col = e / D, row = e % D;
     if (b0 + col < B) a.dz0[(size_t)(b0 + col) * D + row] = c->status[col] > 1 ? 0.f : P.y[col * lds + DpA + row];
   }
   if (NP) {
-    for (int e = tid; e < NB * NP; e += NTHREADS) {
+    for (int e = tid; e < NB * NP; e += NT) {
       const int col = e / NP, row = e % NP;
       if (b0 + col < B) a.dtheta[(size_t)(b0 + col) * NP + row] = c->status[col] > 1 ? 0.f : P.y[col * lds + 2 * DpA + row];
     }
@@ -1485,17 +1487,19 @@ int mlp_set_weights(MlpPlan* p, const float* W_dev, hipStream_t stream, std::str
 
 static constexpr size_t LDS_MAX = 160 * 1024;
 
-static size_t fwd_lds_fixed(const MlpDims& dm, int T) {
+static size_t fwd_lds_fixed(const MlpDims& dm, int T, int nt) {
+  const int NW = nt / 64;
   size_t b = (sizeof(Ctl) + 15) & ~size_t(15);
   b += ((size_t)T * 8 + 15) & ~size_t(15);
-  b += (size_t)(11 * NB * dm.ld_sf + dm.h_total + 1024 + ((dm.nbias + 3) & ~3)) * sizeof(float);
+  b += (size_t)(11 * NB * dm.ld_sf + dm.h_total + NW * 256 + ((dm.nbias + 3) & ~3)) * sizeof(float);
   return b;
 }
 
-static size_t bwd_lds_fixed(const MlpDims& dm, int T) {
+static size_t bwd_lds_fixed(const MlpDims& dm, int T, int nt) {
+  const int NW = nt / 64;
   size_t b = (sizeof(Ctl) + 15) & ~size_t(15);
   b += ((size_t)T * 8 + 15) & ~size_t(15);
-  b += (size_t)(11 * NB * dm.ld_sb + dm.h_total + 2 * NB * dm.ld_h + 1024 + 2 * ((dm.nbias + 3) & ~3) + NB) * sizeof(float);
+  b += (size_t)(11 * NB * dm.ld_sb + dm.h_total + 2 * NB * dm.ld_h + NW * 256 + 2 * ((dm.nbias + 3) & ~3) + NB) * sizeof(float);
   return b;
 }
 
@@ -1516,13 +1520,14 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
     err = "coupled adaptive solve: batch per GPU limited to 4096 trajectories (one resident workgroup per CU)";
     return LDE_ERR_UNSUPPORTED;
   }
-  const size_t fixed = fwd_lds_fixed(dm, o.T);
+  constexpr int NTF = 512;   // forward: 8 waves (2 per SIMD) — the second wave hides the first one's LDS/barrier waits
+  const size_t fixed = fwd_lds_fixed(dm, o.T, NTF);
   if (fixed > LDS_MAX) {
     err = "MLP forward: tile state does not fit the 160 KiB LDS";
     return LDE_ERR_UNSUPPORTED;
   }
   const bool rk4 = dm.solver == LDE_SOLVER_RK4;
-  const void* kfn = rk4 ? (const void*)k_mlp_forward<LDE_SOLVER_RK4> : (const void*)k_mlp_forward<LDE_SOLVER_TSIT5>;
+  const void* kfn = rk4 ? (const void*)k_mlp_forward<LDE_SOLVER_RK4, NTF> : (const void*)k_mlp_forward<LDE_SOLVER_TSIT5, NTF>;
   static bool attr_set[2] = {false, false};
   const int ki = rk4 ? 1 : 0;
   if (!attr_set[ki]) {
@@ -1542,8 +1547,8 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
     err = "hipMemsetAsync(counter) failed";
     return LDE_ERR_HIP;
   }
-  if (rk4) hipLaunchKernelGGL(k_mlp_forward<LDE_SOLVER_RK4>, dim3(nwg), dim3(NTHREADS), lds, stream, dm, o, a);
-  else hipLaunchKernelGGL(k_mlp_forward<LDE_SOLVER_TSIT5>, dim3(nwg), dim3(NTHREADS), lds, stream, dm, o, a);
+  if (rk4) hipLaunchKernelGGL((k_mlp_forward<LDE_SOLVER_RK4, NTF>), dim3(nwg), dim3(NTF), lds, stream, dm, o, a);
+  else hipLaunchKernelGGL((k_mlp_forward<LDE_SOLVER_TSIT5, NTF>), dim3(nwg), dim3(NTF), lds, stream, dm, o, a);
   if (hipGetLastError() != hipSuccess) {
     err = "k_mlp_forward launch failed";
     return LDE_ERR_HIP;
@@ -1551,26 +1556,26 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
   return LDE_OK;
 }
 
-template <int NDW, int SOLVER>
+template <int NDW, int SOLVER, int NT>
 static int launch_adjoint2(MlpPlan* p, const KOpts& o, const BwdArgs& a, int nwg, size_t lds, hipStream_t stream,
                            std::string& err) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_mlp_adjoint<NDW, SOLVER>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)k_mlp_adjoint<NDW, SOLVER, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)LDS_MAX) != hipSuccess) {
       err = "hipFuncSetAttribute(k_mlp_adjoint) failed";
       return LDE_ERR_HIP;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_mlp_adjoint<NDW, SOLVER>), dim3(nwg), dim3(NTHREADS), lds, stream, p->dm, o, a);
+  hipLaunchKernelGGL((k_mlp_adjoint<NDW, SOLVER, NT>), dim3(nwg), dim3(NT), lds, stream, p->dm, o, a);
   return LDE_OK;
 }
-template <int NDW>
+template <int NDW, int NT>
 static int launch_adjoint(MlpPlan* p, const KOpts& o, const BwdArgs& a, int nwg, size_t lds, hipStream_t stream,
                           std::string& err) {
-  return p->dm.solver == LDE_SOLVER_RK4 ? launch_adjoint2<NDW, LDE_SOLVER_RK4>(p, o, a, nwg, lds, stream, err)
-                                        : launch_adjoint2<NDW, LDE_SOLVER_TSIT5>(p, o, a, nwg, lds, stream, err);
+  return p->dm.solver == LDE_SOLVER_RK4 ? launch_adjoint2<NDW, LDE_SOLVER_RK4, NT>(p, o, a, nwg, lds, stream, err)
+                                        : launch_adjoint2<NDW, LDE_SOLVER_TSIT5, NT>(p, o, a, nwg, lds, stream, err);
 }
 
 int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float* theta, const double* ts_dev,
@@ -1583,7 +1588,10 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
     err = "coupled adaptive solve: batch per GPU limited to 4096 trajectories (one resident workgroup per CU)";
     return LDE_ERR_UNSUPPORTED;
   }
-  const size_t fixed = bwd_lds_fixed(dm, o.T);
+  // 8 waves (2 per SIMD) when the weight-gradient tiles then fit 6 accumulator tiles per wave; else 4 waves × 16 tiles
+  const int ntiles_all = dm.tile_off[dm.nL];
+  const int nt = cdiv(ntiles_all, 8) <= 6 ? 512 : 256;
+  const size_t fixed = bwd_lds_fixed(dm, o.T, nt);
   if (fixed > LDS_MAX) {
     err = "MLP adjoint: tile state does not fit the 160 KiB LDS";
     return LDE_ERR_UNSUPPORTED;
@@ -1599,11 +1607,11 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
     err = "hipMemsetAsync(counter) failed";
     return LDE_ERR_HIP;
   }
-  const int per_wave = cdiv(dm.tile_off[dm.nL], 4);   // weight-gradient tiles held in each wave's accumulators
+  const int per_wave = cdiv(ntiles_all, nt / 64);   // weight-gradient tiles held in each wave's accumulators
   int rc;
-  if (per_wave <= 2) rc = launch_adjoint<2>(p, o, a, nwg, lds, stream, err);
-  else if (per_wave <= 6) rc = launch_adjoint<6>(p, o, a, nwg, lds, stream, err);
-  else if (per_wave <= 16) rc = launch_adjoint<16>(p, o, a, nwg, lds, stream, err);
+  if (nt == 512 && per_wave <= 2) rc = launch_adjoint<2, 512>(p, o, a, nwg, lds, stream, err);
+  else if (nt == 512) rc = launch_adjoint<6, 512>(p, o, a, nwg, lds, stream, err);
+  else if (per_wave <= 16) rc = launch_adjoint<16, 256>(p, o, a, nwg, lds, stream, err);
   else {
     err = "MLP adjoint: more than 64 32x32 weight-gradient tiles (hidden width too large for the register-resident accumulators)";
     return LDE_ERR_UNSUPPORTED;

@@ -11,6 +11,8 @@
 // the only global traffic is the algorithmic one: 12 B in, 8·T B out per trajectory, with lane ↔ batch
 // index so that every load/store of a wave covers 64 consecutive float2 (512 B).
 // Wave-level divergence comes only from differing step counts (11–17 at default tolerances).
+#include <cstdlib>
+
 #include "lde_device.h"
 
 namespace lde {
@@ -574,7 +576,8 @@ int launch_pend_adjoint(int kind, int solver, const float* z_out, const float* t
 int launch_pend_adjoint_par(int kind, int solver, const float* z_out, const float* theta, const double* ts_dev,
                             const KOpts& o, const float* dz_out, float* dz0, float* dtheta, float* ops, int32_t* info,
                             int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret, hipStream_t stream) {
-  if (o.T > 1 && o.T - 1 <= 1024 && o.B <= 32768) {   // fused: one workgroup per trajectory, one lane per interval
+  static const int fused_max_b = [] { const char* e = getenv("LDE_FUSED_MAX_B"); return e ? atoi(e) : 32768; }();
+  if (o.T > 1 && o.T - 1 <= 1024 && o.B <= fused_max_b) {   // fused: one workgroup per trajectory, one lane per interval
     const int block = ((o.T - 1 + 63) / 64) * 64;
 #define LDE_LAUNCH(K, S)                                                                                                  \
   hipLaunchKernelGGL((k_pend_adjoint_fused<K, S>), dim3(((o.B + 7) / 8) * 8), dim3(block), 0, stream, (const float2*)z_out, theta, ts_dev, o, \

@@ -30,6 +30,7 @@
 //    across the stages of a step and committed to the workgroup's slab only when the step is accepted.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -334,13 +335,21 @@ __device__ __forceinline__ void eval_rhs(const MlpDims& dm, const Panels& P, con
     const int actk = dm.act;
     layer_gemm<NT>(P.lbase, c->wofs[l], P.gfrag + dm.frag_off[l], out, in, X, ldx, P.red, [&](int row0, int col, f32x4 v) {
       f32x4 r;
+      if (row0 + 3 < out) {   // whole group of 4 rows inside the layer: vector bias load, no per-row selects
+        r = v + *reinterpret_cast<const f32x4*>(bias + row0);
+        if (!lastl) {
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        float x = row0 + q < out ? v[q] + bias[row0 + q] : 0.f;
-        if (!lastl) x = act_fn(actk, x);
-        r[q] = x;
+          for (int q = 0; q < 4; q++) r[q] = act_fn(actk, r[q]);
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          float x = row0 + q < out ? v[q] + bias[row0 + q] : 0.f;
+          if (!lastl) x = act_fn(actk, x);
+          r[q] = x;
+        }
       }
-      if (lastl) {  // never write the rows that follow the output block (λ rows in the adjoint state)
+      if (lastl && row0 + 3 >= out) {  // never write the rows that follow the output block (λ rows in the adjoint state)
 #pragma unroll
         for (int q = 0; q < 4; q++)
           if (row0 + q < out) Y[col * ldy + row0 + q] = r[q];
@@ -425,8 +434,10 @@ __global__ void __launch_bounds__(NT) k_mlp_forward(MlpDims dm, KOpts o, FwdArgs
   const bool coupled = dm.coupled != 0;
   const double t0 = s_ts[0], tend = s_ts[T - 1], dtmax = tend - t0;
   unsigned gen = 0;
-#define EIDX(e) (((e) / NS) * lds + ((e) % NS))   /* element e ↦ (col = e/NS, row = e%NS) */
-#define ECOL(e) ((e) / NS)
+// all NS×16 elements of a state panel: 32 row-lanes × NT/32 columns per pass (shifts only; conflict-free b32 accesses)
+#define FOR_ELEMS(idx, colv)                            \
+  for (int colv = tid >> 5; colv < NB; colv += NT / 32) \
+    for (int r_ = tid & 31, idx = colv * lds + r_; r_ < NS; r_ += 32, idx += 32)
 
   // ---- load the tile: column-major z0 [D×B]; augmented rows stay 0 -----------------------------------
   for (int e = tid; e < NB * D; e += NT) {
@@ -498,24 +509,21 @@ __global__ void __launch_bounds__(NT) k_mlp_forward(MlpDims dm, KOpts o, FwdArgs
     if (phase == PH_STAGE) {
       if (SOLVER == LDE_SOLVER_TSIT5) {
         float* dstp = s < 6 ? P.tmp : P.yn;
-        for (int e = tid; e < nel; e += NT) {
-          const int idx = EIDX(e);
+        FOR_ELEMS(idx, ecol) {
           float acc = ts5::A[s][0] * P.k(0)[idx];
           for (int jj = 1; jj < s; jj++) acc += ts5::A[s][jj] * P.k(jj)[idx];
-          dstp[idx] = P.y[idx] + c->h[ECOL(e)] * acc;
+          dstp[idx] = P.y[idx] + c->h[ecol] * acc;
         }
         src = dstp;
       } else if (s < 4) {
         const float cs = s == 3 ? 1.0f : 0.5f;
-        for (int e = tid; e < nel; e += NT) {
-          const int idx = EIDX(e);
-          P.tmp[idx] = P.y[idx] + (cs * c->h[ECOL(e)]) * P.k(s - 1)[idx];
+        FOR_ELEMS(idx, ecol) {
+          P.tmp[idx] = P.y[idx] + (cs * c->h[ecol]) * P.k(s - 1)[idx];
         }
         src = P.tmp;
       } else {
-        for (int e = tid; e < nel; e += NT) {
-          const int idx = EIDX(e);
-          P.yn[idx] = P.y[idx] + (c->h[ECOL(e)] * (1.0f / 6.0f)) * (P.k(0)[idx] + 2.0f * (P.k(1)[idx] + P.k(2)[idx]) + P.k(3)[idx]);
+        FOR_ELEMS(idx, ecol) {
+          P.yn[idx] = P.y[idx] + (c->h[ecol] * (1.0f / 6.0f)) * (P.k(0)[idx] + 2.0f * (P.k(1)[idx] + P.k(2)[idx]) + P.k(3)[idx]);
         }
         src = P.yn;
       }
@@ -530,8 +538,7 @@ __global__ void __launch_bounds__(NT) k_mlp_forward(MlpDims dm, KOpts o, FwdArgs
     if (phase == PH_K0) {
       if (o.adaptive && !(o.dt_fixed > 0)) {
         // Hairer–Nørsett–Wanner, part 1: d0, d1, trial Euler step
-        for (int e = tid; e < nel; e += NT) {
-          const int idx = EIDX(e);
+        FOR_ELEMS(idx, ecol) {
           const float yv = P.y[idx];
           const float sk = fast_rcp(o.abstol + fabsf(yv) * o.reltol);
           P.scr[idx] = sk;
@@ -565,9 +572,8 @@ __global__ void __launch_bounds__(NT) k_mlp_forward(MlpDims dm, KOpts o, FwdArgs
           c->th[tid] = d1;
         }
         __syncthreads();
-        for (int e = tid; e < nel; e += NT) {
-          const int idx = EIDX(e);
-          P.tmp[idx] = P.y[idx] + c->h[ECOL(e)] * P.k(0)[idx];
+        FOR_ELEMS(idx, ecol) {
+          P.tmp[idx] = P.y[idx] + c->h[ecol] * P.k(0)[idx];
         }
         __syncthreads();
         phase = PH_INIT1;
@@ -580,8 +586,7 @@ __global__ void __launch_bounds__(NT) k_mlp_forward(MlpDims dm, KOpts o, FwdArgs
       }
     } else if (phase == PH_INIT1) {
       // part 2: d2 and the initial step
-      for (int e = tid; e < nel; e += NT) {
-        const int idx = EIDX(e);
+      FOR_ELEMS(idx, ecol) {
         const float d = (P.k(1)[idx] - P.k(0)[idx]) * P.scr[idx];
         P.yn[idx] = d * d;
       }
@@ -616,15 +621,14 @@ __global__ void __launch_bounds__(NT) k_mlp_forward(MlpDims dm, KOpts o, FwdArgs
       s++;
     } else {
       // ---- end of a step attempt: error estimate ------------------------------------------------------------
-      for (int e = tid; e < nel; e += NT) {
-        const int idx = EIDX(e);
+      FOR_ELEMS(idx, ecol) {
         float r2 = 0.f;
         const float yv = P.y[idx], ynv = P.yn[idx];
         if (o.adaptive) {
           float er = ts5::BT[0] * P.k(0)[idx];
 #pragma unroll
           for (int jj = 1; jj < 7; jj++) er += ts5::BT[jj] * P.k(jj)[idx];
-          er *= c->h[ECOL(e)];
+          er *= c->h[ecol];
           const float sk = o.abstol + fmaxf(fabsf(yv), fabsf(ynv)) * o.reltol;
           const float r = er * fast_rcp(sk);
           r2 = r * r;
@@ -731,9 +735,8 @@ __global__ void __launch_bounds__(NT) k_mlp_forward(MlpDims dm, KOpts o, FwdArgs
       }
 
       // ---- advance accepted columns (FSAL: the last slope becomes k1) --------------------------------------
-      for (int e = tid; e < nel; e += NT) {
-        const int idx = EIDX(e);
-        if (c->accepted[ECOL(e)]) {
+      FOR_ELEMS(idx, ecol) {
+        if (c->accepted[ecol]) {
           P.y[idx] = P.yn[idx];
           P.k(0)[idx] = P.k(LAST_STAGE)[idx];
         }
@@ -766,8 +769,7 @@ __global__ void __launch_bounds__(NT) k_mlp_forward(MlpDims dm, KOpts o, FwdArgs
     a.st_nacc[b] = rep ? c->nacc[col] : 0;
     a.st_nrej[b] = rep ? c->nrej[col] : 0;
   }
-#undef EIDX
-#undef ECOL
+#undef FOR_ELEMS
 }
 
 // ================================================ adjoint ==================================================
@@ -855,9 +857,13 @@ __device__ __forceinline__ void eval_bwd(const MlpDims& dm, const Panels& P, con
       float* dlam = dst + DpA;
       const int lds = P.lds;
       layer_gemm<NT>(P.lbase, c->wTofs[0], P.gfragT + dm.fragT_off[0], in, out, dl, ldd, P.red, [&](int row0, int col, f32x4 v) {
+        if (row0 + 3 < in) {
+          *reinterpret_cast<f32x4*>(dlam + col * lds + row0) = -v;
+        } else {
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-          if (row0 + q < in) dlam[col * lds + row0 + q] = -v[q];
+          for (int q = 0; q < 4; q++)
+            if (row0 + q < in) dlam[col * lds + row0 + q] = -v[q];
+        }
       });
       __syncthreads();
     }
@@ -930,8 +936,10 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
   unsigned gen = 0;
   float* slab = a.slab + (size_t)blockIdx.x * dm.slab_n;
   for (int i = tid; i < dm.slab_n; i += NT) slab[i] = 0.f;
-#define EIDX(e) (((e) / NS) * lds + ((e) % NS))
-#define ECOL(e) ((e) / NS)
+// all NS×16 elements of a state panel: 32 row-lanes × NT/32 columns per pass (shifts only; conflict-free b32 accesses)
+#define FOR_ELEMS(idx, colv)                            \
+  for (int colv = tid >> 5; colv < NB; colv += NT / 32) \
+    for (int r_ = tid & 31, idx = colv * lds + r_; r_ < NS; r_ += 32, idx += 32)
 
   f32x16 acc[NDW];
 #pragma unroll
@@ -1066,11 +1074,10 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
       if (SOLVER == LDE_SOLVER_TSIT5) {
         if (s > 0) {
           float* dstp = s < 6 ? P.tmp : P.yn;
-          for (int e = tid; e < nel; e += NT) {
-            const int idx = EIDX(e);
+          FOR_ELEMS(idx, ecol) {
             float accv = ts5::A[s][0] * P.k(0)[idx];
             for (int jj = 1; jj < s; jj++) accv += ts5::A[s][jj] * P.k(jj)[idx];
-            dstp[idx] = P.y[idx] + c->h[ECOL(e)] * accv;
+            dstp[idx] = P.y[idx] + c->h[ecol] * accv;
           }
           src = dstp;
         }
@@ -1079,9 +1086,8 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
       } else {
         if (s > 0) {
           const float cs = s == 3 ? 1.0f : 0.5f;
-          for (int e = tid; e < nel; e += NT) {
-            const int idx = EIDX(e);
-            P.tmp[idx] = P.y[idx] + (cs * c->h[ECOL(e)]) * P.k(s - 1)[idx];
+          FOR_ELEMS(idx, ecol) {
+            P.tmp[idx] = P.y[idx] + (cs * c->h[ecol]) * P.k(s - 1)[idx];
           }
           src = P.tmp;
         }
@@ -1099,8 +1105,7 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
     // ---- what follows the evaluation -----------------------------------------------------------------------------
     if (phase == PH_K0) {
       // Hairer–Nørsett–Wanner on the augmented state, direction −1: part 1
-      for (int e = tid; e < nel; e += NT) {
-        const int idx = EIDX(e);
+      FOR_ELEMS(idx, ecol) {
         const float yv = P.y[idx];
         const float sk = fast_rcp(o.abstol + fabsf(yv) * o.reltol);
         P.scr[idx] = sk;
@@ -1133,15 +1138,13 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
         c->th[tid] = d1;
       }
       __syncthreads();
-      for (int e = tid; e < nel; e += NT) {
-        const int idx = EIDX(e);
-        P.tmp[idx] = P.y[idx] + c->h[ECOL(e)] * P.k(0)[idx];
+      FOR_ELEMS(idx, ecol) {
+        P.tmp[idx] = P.y[idx] + c->h[ecol] * P.k(0)[idx];
       }
       __syncthreads();
       phase = PH_INIT1;
     } else if (phase == PH_INIT1) {
-      for (int e = tid; e < nel; e += NT) {
-        const int idx = EIDX(e);
+      FOR_ELEMS(idx, ecol) {
         const float dd = (P.k(1)[idx] - P.k(0)[idx]) * P.scr[idx];
         P.yn[idx] = dd * dd;
       }
@@ -1177,23 +1180,21 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
     } else {
       // ---- all stages of this attempt are done ---------------------------------------------------------------------
       if (SOLVER == LDE_SOLVER_RK4) {
-        for (int e = tid; e < nel; e += NT) {
-          const int idx = EIDX(e);
-          P.yn[idx] = P.y[idx] + (c->h[ECOL(e)] * (1.0f / 6.0f)) * (P.k(0)[idx] + 2.0f * (P.k(1)[idx] + P.k(2)[idx]) + P.k(3)[idx]);
+        FOR_ELEMS(idx, ecol) {
+          P.yn[idx] = P.y[idx] + (c->h[ecol] * (1.0f / 6.0f)) * (P.k(0)[idx] + 2.0f * (P.k(1)[idx] + P.k(2)[idx]) + P.k(3)[idx]);
         }
         __syncthreads();
       }
       if (!replay) {
         // ---- error estimate + control ----------------------------------------------------------------------------
-        for (int e = tid; e < nel; e += NT) {
-          const int idx = EIDX(e);
+        FOR_ELEMS(idx, ecol) {
           float r2 = 0.f;
           const float yv = P.y[idx], ynv = P.yn[idx];
           if (o.adaptive) {
             float er = ts5::BT[0] * P.k(0)[idx];
 #pragma unroll
             for (int jj = 1; jj < 7; jj++) er += ts5::BT[jj] * P.k(jj)[idx];
-            er *= c->h[ECOL(e)];
+            er *= c->h[ecol];
             const float sk = o.abstol + fmaxf(fabsf(yv), fabsf(ynv)) * o.reltol;
             const float r = er * fast_rcp(sk);
             r2 = r * r;
@@ -1275,9 +1276,8 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
       __syncthreads();
 
       // ---- advance accepted columns; jump at a save time --------------------------------------------------------
-      for (int e = tid; e < nel; e += NT) {
-        const int idx = EIDX(e);
-        if (c->accepted[ECOL(e)]) P.y[idx] = P.yn[idx];
+      FOR_ELEMS(idx, ecol) {
+        if (c->accepted[ecol]) P.y[idx] = P.yn[idx];
       }
       __syncthreads();
       for (int e = tid; e < NB * Dp; e += NT) {
@@ -1326,8 +1326,7 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
     a.st_nacc[b] = rep ? c->nacc[col] : 0;
     a.st_nrej[b] = rep ? c->nrej[col] : 0;
   }
-#undef EIDX
-#undef ECOL
+#undef FOR_ELEMS
 }
 
 // dW[flat] += Σ_wg slab[wg][fragment position of flat]   (workgroups added in index order ⇒ deterministic)
@@ -1414,7 +1413,7 @@ int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err) 
   int blin = 0, toff = 0;
   for (int l = 0; l < dm.nL; l++) {
     dm.bias_lin[l] = blin;
-    blin += dm.sizes[l + 1];
+    blin += (dm.sizes[l + 1] + 3) & ~3;   // 16-byte aligned bias blocks (vector loads in the epilogue)
     dm.tile_off[l] = toff;
     toff += cdiv(dm.sizes[l + 1], 32) * cdiv(dm.sizes[l], 32);
   }
@@ -1588,9 +1587,12 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
     err = "coupled adaptive solve: batch per GPU limited to 4096 trajectories (one resident workgroup per CU)";
     return LDE_ERR_UNSUPPORTED;
   }
-  // 8 waves (2 per SIMD) when the weight-gradient tiles then fit 6 accumulator tiles per wave; else 4 waves × 16 tiles
+  // 8 waves (2 per SIMD) when the weight-gradient tiles then fit 8 accumulator tiles per wave; else 4 waves × 16 tiles.
+  // Instantiations 2/3/6/8 exist because register spills are what hurts: measured on config 4, 6 tile slots (172 B of
+  // scratch per lane) 6.18 ms vs 3 slots (no scratch) 5.18 ms; config 2, 4 waves × 16 slots 8.45 ms vs 8 waves × 8 slots 6.52 ms.
   const int ntiles_all = dm.tile_off[dm.nL];
-  const int nt = cdiv(ntiles_all, 8) <= 6 ? 512 : 256;
+  static const int nt_force = [] { const char* e = getenv("LDE_MLP_ADJ_NT"); return e ? atoi(e) : 0; }();
+  const int nt = nt_force ? nt_force : (cdiv(ntiles_all, 8) <= 8 ? 512 : 256);
   const size_t fixed = bwd_lds_fixed(dm, o.T, nt);
   if (fixed > LDS_MAX) {
     err = "MLP adjoint: tile state does not fit the 160 KiB LDS";
@@ -1610,7 +1612,9 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
   const int per_wave = cdiv(ntiles_all, nt / 64);   // weight-gradient tiles held in each wave's accumulators
   int rc;
   if (nt == 512 && per_wave <= 2) rc = launch_adjoint<2, 512>(p, o, a, nwg, lds, stream, err);
-  else if (nt == 512) rc = launch_adjoint<6, 512>(p, o, a, nwg, lds, stream, err);
+  else if (nt == 512 && per_wave <= 3) rc = launch_adjoint<3, 512>(p, o, a, nwg, lds, stream, err);
+  else if (nt == 512 && per_wave <= 6) rc = launch_adjoint<6, 512>(p, o, a, nwg, lds, stream, err);
+  else if (nt == 512 && per_wave <= 8) rc = launch_adjoint<8, 512>(p, o, a, nwg, lds, stream, err);
   else if (per_wave <= 16) rc = launch_adjoint<16, 256>(p, o, a, nwg, lds, stream, err);
   else {
     err = "MLP adjoint: more than 64 32x32 weight-gradient tiles (hidden width too large for the register-resident accumulators)";

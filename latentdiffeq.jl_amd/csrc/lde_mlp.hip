@@ -7,7 +7,8 @@
 // (DiffEqFlux 1.52.0 / OrdinaryDiffEq 6.27.1 / SciMLSensitivity 7.10.0, un-vendored) and its pullback.
 //
 // Design (gfx950)
-//  * A workgroup (256 threads = 4 waves, one per SIMD) owns a tile of NB = 16 trajectories (columns) for the
+//  * A workgroup of 8 waves (two per SIMD: one wave's LDS / barrier waits are covered by the other; 4 waves only when
+//    the adjoint needs more than 8 weight-gradient tiles per wave) owns a tile of NB = 16 trajectories (columns) for the
 //    WHOLE solve. State, the seven Tsit5 slopes and the hidden activations of the tile live in LDS as TRANSPOSED
 //    panels Xt[col][row] (row contiguous) with a stride ≡ 8 (mod 32) floats, which makes the 16-byte MFMA operand
 //    reads below bank-conflict-free.

@@ -125,3 +125,43 @@ def test_argument_errors_are_codes_not_crashes():
     ob = torch.empty((5, 5000, 2), device=dev)
     assert lib.lde_forward(big.h, p(zb), None, tsp, 5, 5000, p(ob), None, None) == -2          # LDE_ERR_UNSUPPORTED
     assert b"4096" in lib.lde_last_error(big.h)
+
+
+def test_forward_and_adjoint_are_graph_capturable(o32):
+    """After lde_reserve (or one eager call of the same shape) the hot calls allocate nothing and synchronise nothing:
+    they can be captured into a hipGraph and replayed on new inputs (MI355X-first: graphs instead of a tracing compiler)."""
+    import torch
+    from latentdiffeq_amd import _lib as L
+    lib = L.load()
+    nat, od = _native(abstol=1e-6, reltol=1e-6)
+    B, T = 256, 50
+    ts = O.time_grid(T)
+    tsp = ts.ctypes.data_as(C.POINTER(C.c_double))
+    dev = "cuda"
+    z0a, La = O.pendulum_inputs(B, seed=1)
+    z0b, Lb = O.pendulum_inputs(B, seed=2)
+    dz = O.cotangent(T, B, 2)
+    z0d, thd, dzd = torch.from_numpy(z0a).to(dev), torch.from_numpy(La).to(dev), torch.from_numpy(dz).to(dev)
+    out = torch.empty((T, B, 2), device=dev)
+    g0, gL = torch.empty((B, 2), device=dev), torch.empty((B, 1), device=dev)
+    p = lambda t: C.c_void_p(t.data_ptr())
+
+    def step():
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(lib.lde_forward(nat.h, p(z0d), p(thd), tsp, T, B, p(out), None, s), nat.h, "fwd")
+        L.check(lib.lde_adjoint(nat.h, p(out), p(thd), tsp, T, B, p(dzd), p(g0), p(gL), None, s), nat.h, "adj")
+
+    step()                       # eager warm-up: workspace sized, save-time grid uploaded
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        step()
+    z0d.copy_(torch.from_numpy(z0b))     # new inputs in the same buffers
+    thd.copy_(torch.from_numpy(Lb))
+    graph.replay()
+    torch.cuda.synchronize()
+    zr, _, _ = o32.forward(od, z0b, Lb, ts)
+    r0, rL, _, _ = o32.adjoint(O.make_desc(abstol=1e-6, reltol=1e-6, sensealg=O.SENSE_PARALLEL_CHECKPOINTED), zr, Lb, ts, dz)
+    assert np.abs(out.cpu().numpy() - zr).max() <= 1e-5
+    assert np.abs(g0.cpu().numpy() - r0).max() <= 2e-4 * np.abs(r0).max()
+    assert np.abs(gL.cpu().numpy() - rL).max() <= 2e-4 * np.abs(rL).max()

@@ -1,0 +1,64 @@
+"""GPU: the gradients are good enough to LEARN with — a miniature of what the reference's training loop does with this
+layer [REF examples/pendulum_friction-less/model_train.jl:195-201]: recover the pendulum length and initial state of
+every trajectory from its observed latent path by gradient descent through diffeq_layer, and fit a NODE's weights
+(which the reference never trains) to a linear vector field."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+
+def test_recover_pendulum_length_and_initial_state_by_gradient_descent():
+    import torch
+    import latentdiffeq_amd as la
+    torch.manual_seed(0)
+    B, T = 64, 50
+    z0_true, L_true = O.pendulum_inputs(B, seed=3)
+    ts = O.time_grid(T)
+    dec = la.Decoder(la.GOKU_basic(), (None, la.Pendulum(abstol=1e-6, reltol=1e-5), None))
+    dev = "cuda"
+    with torch.no_grad():
+        target = la.diffeq_layer(dec, (torch.tensor(z0_true.T.copy(), device=dev), torch.tensor(L_true.T.copy(), device=dev)), ts)
+    # start from wrong guesses; θ̂ goes through softplus like the reference's latent_out head [REF GOKU.jl:252-256]
+    z0 = torch.tensor((z0_true * 0.5).T.copy(), device=dev, requires_grad=True)
+    raw = torch.full((1, B), 1.0, device=dev, requires_grad=True)
+    opt = torch.optim.Adam([z0, raw], lr=0.05)
+    losses = []
+    for it in range(300):
+        opt.zero_grad()
+        zhat = la.diffeq_layer(dec, (z0, torch.nn.functional.softplus(raw) + 0.5), ts)
+        loss = ((zhat - target) ** 2).mean()
+        loss.backward()
+        opt.step()
+        losses.append(float(loss.detach()))
+    L_fit = (torch.nn.functional.softplus(raw) + 0.5).detach().cpu().numpy().T
+    assert losses[-1] < 1e-3 * losses[0], (losses[0], losses[-1])
+    assert np.median(np.abs(L_fit - L_true)) < 0.02 and np.abs(z0.detach().cpu().numpy().T - z0_true).max() < 0.05
+
+
+def test_node_weights_learn_a_rotation_field():
+    import torch
+    import latentdiffeq_amd as la
+    torch.manual_seed(1)
+    D, B, T, w = 2, 48, 25, 1.5
+    ts = O.time_grid(T, 0.1)
+    rng = np.random.default_rng(0)
+    z0 = rng.standard_normal((B, D)).astype(np.float32)
+    c, s = np.cos(w * ts)[:, None], np.sin(w * ts)[:, None]
+    target = np.stack([c * z0[None, :, 0] - s * z0[None, :, 1], s * z0[None, :, 0] + c * z0[None, :, 1]], axis=2)  # (T,B,2)
+    node = la.NODE(D, hidden_dim=32, device="cuda", activation="tanh", abstol=1e-5, reltol=1e-4)
+    dec = la.Decoder(la.LatentODE(), (None, node, None))
+    tgt = torch.tensor(target, device="cuda", dtype=torch.float32).permute(2, 1, 0)
+    z0t = torch.tensor(z0.T.copy(), device="cuda")
+    opt = torch.optim.Adam(node.dudt.parameters(), lr=0.01)
+    first = last = None
+    for it in range(250):
+        opt.zero_grad()
+        loss = ((la.diffeq_layer(dec, z0t, ts) - tgt) ** 2).mean()
+        loss.backward()
+        opt.step()
+        first = float(loss.detach()) if first is None else first
+        last = float(loss.detach())
+    assert last < 0.05 * first, (first, last)

@@ -357,3 +357,21 @@ def test_random_mlp_shapes_forward_and_adjoint(o64, seed):
     assert np.abs(z - zt).max() <= 1e-4 * max(1.0, np.abs(zt).max()), (layers, batching, rk4, B, T)
     assert np.abs(g0 - t0).max() <= 2e-4 * np.abs(t0).max() + 1e-9, (layers, batching, rk4, B, T)
     assert np.abs(gW - tW).max() <= 2e-4 * np.abs(tW).max() + 1e-9, (layers, batching, rk4, B, T)
+
+
+@pytest.mark.parametrize("batching", [O.BATCH_PER_TRAJECTORY, O.BATCH_COUPLED])
+def test_mlp_tsit5_with_fixed_step(o32, batching):
+    layers = (6, 40, 40, 6)
+    W = O.mlp_weights(layers, seed=9)
+    kw = dict(rhs_kind=O.RHS_MLP, state_dim=6, param_dim=0, layers=layers, batching=batching, adaptive=0, dt=0.025)
+    nat, od = _native(W, **kw)
+    B, T = 35, 20
+    z0, ts = _z0(B, 6), O.time_grid(T)
+    dz = O.cotangent(T, B, 6)
+    z, ret, st = nat.forward(z0, None, ts)
+    zr, _, info = o32.forward(od, z0, None, ts, W=W)
+    assert (ret == 0).all() and st["naccept"] == info["naccept"]
+    assert np.abs(z - zr).max() <= 2e-5 * max(1.0, np.abs(zr).max())
+    g0, _, gW, _ = nat.adjoint(z, None, ts, dz)
+    r0, _, rW, _ = o32.adjoint(od, z, None, ts, dz, W=W)
+    assert np.abs(g0 - r0).max() <= 2e-4 * np.abs(r0).max() and np.abs(gW - rW).max() <= 2e-4 * np.abs(rW).max()

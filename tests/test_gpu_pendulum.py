@@ -194,3 +194,22 @@ def test_parallel_adjoint_variants_agree_with_sequential_kernel(o32, B, T):
         r0, rL, _, info = o32.adjoint(odp, z, L, ts, dz)
         assert np.abs(g0 - r0).max() <= 1e-4 * np.abs(r0).max() and np.abs(gL - rL).max() <= 1e-4 * np.abs(rL).max()
         assert sp["naccept"] == info["naccept"]
+
+
+@pytest.mark.parametrize("sense", [O.SENSE_BACKSOLVE_CHECKPOINTED, O.SENSE_PARALLEL_CHECKPOINTED])
+def test_tsit5_with_fixed_step(o32, sense):
+    """`adaptive=false, dt=h` with Tsit5 (a legal kwargs combination of the reference's solve call): no controller, so the
+    kernel and the oracle take identical steps and agree to fp32 round-off."""
+    nat, od = _native(adaptive=0, dt=0.02, sensealg=sense)
+    B, T = 96, 50
+    z0, L = O.pendulum_inputs(B)
+    ts = O.time_grid(T)
+    z, ret, st = nat.forward(z0, L, ts)
+    zr, _, info = o32.forward(od, z0, L, ts)
+    assert (ret == 0).all() and st["naccept"] == info["naccept"] and st["nreject"] == 0
+    assert np.abs(z - zr).max() <= 1e-5
+    dz = O.cotangent(T, B, 2)
+    g0, gL, _, sb = nat.adjoint(z, L, ts, dz)
+    r0, rL, _, ib = o32.adjoint(od, z, L, ts, dz)
+    assert sb["naccept"] == ib["naccept"]
+    assert np.abs(g0 - r0).max() <= 1e-4 * np.abs(r0).max() and np.abs(gL - rL).max() <= 1e-4 * np.abs(rL).max()

@@ -244,11 +244,12 @@ __device__ __forceinline__ void grid_sum4(const GridSync& gs, unsigned& gen, flo
     __hip_atomic_fetch_add(gs.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned target = gen * (unsigned)gs.nwg;
     long long spins = 0;
-    while (__hip_atomic_load(gs.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    bool aborted = __hip_atomic_load(gs.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;   // sticky
+    while (!aborted && __hip_atomic_load(gs.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(2);
       if (++spins > 20000000LL) {  // ≈ seconds: a peer is not resident — give up instead of hanging the GPU
         __hip_atomic_store(gs.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
+        aborted = true;
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -258,8 +259,10 @@ __device__ __forceinline__ void grid_sum4(const GridSync& gs, unsigned& gen, flo
 #pragma unroll
       for (int i = 0; i < 4; i++) t[i] += slots[(size_t)w * 4 + i];
     }
+    // a timed-out barrier poisons the sums: every step is then "non-finite", dt shrinks to dtmin and the solve ends with
+    // retcode != 0 and NaN blocks instead of silently wrong numbers (later calls return at once: the flag is sticky)
 #pragma unroll
-    for (int i = 0; i < 4; i++) s_bcast[i] = t[i];
+    for (int i = 0; i < 4; i++) s_bcast[i] = aborted ? __int_as_float(0x7fc00000) : t[i];
   }
   __syncthreads();
 #pragma unroll
@@ -1543,7 +1546,8 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
   a.gs.counter = p->counter; a.gs.slots = p->slots; a.gs.abort_flag = p->abort_flag; a.gs.nwg = sync ? nwg : 1;
   const size_t lds = with_cache(fixed, p->nfrag);
   a.lds_bytes = (int)lds;
-  if (sync && hipMemsetAsync(p->counter, 0, sizeof(unsigned), stream) != hipSuccess) {
+  if (sync && (hipMemsetAsync(p->counter, 0, sizeof(unsigned), stream) != hipSuccess ||
+               hipMemsetAsync(p->abort_flag, 0, sizeof(int), stream) != hipSuccess)) {
     err = "hipMemsetAsync(counter) failed";
     return LDE_ERR_HIP;
   }
@@ -1606,7 +1610,8 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
   a.gs.counter = p->counter; a.gs.slots = p->slots; a.gs.abort_flag = p->abort_flag; a.gs.nwg = sync ? nwg : 1;
   const size_t lds = with_cache(fixed, p->nfrag + p->nfragT);
   a.lds_bytes = (int)lds;
-  if (sync && hipMemsetAsync(p->counter, 0, sizeof(unsigned), stream) != hipSuccess) {
+  if (sync && (hipMemsetAsync(p->counter, 0, sizeof(unsigned), stream) != hipSuccess ||
+               hipMemsetAsync(p->abort_flag, 0, sizeof(int), stream) != hipSuccess)) {
     err = "hipMemsetAsync(counter) failed";
     return LDE_ERR_HIP;
   }

@@ -52,17 +52,22 @@ struct PendBwd {
   }
 };
 
+constexpr int TS_LDS_MAX = 6000;   // doubles of the save-time grid kept in LDS (48 KB)
+
 // ---- forward ------------------------------------------------------------------------------------
-template <int KIND, int SOLVER>
+template <int KIND, int SOLVER, bool TS_LDS>
 __global__ void __launch_bounds__(256) k_pend_forward(const float2* __restrict__ z0, const float* __restrict__ theta,
                                                       const double* __restrict__ ts_g, KOpts o,
                                                       float2* __restrict__ z_out, int32_t* __restrict__ retcode,
                                                       int32_t* __restrict__ st_nfe, int32_t* __restrict__ st_nacc,
                                                       int32_t* __restrict__ st_nrej, int32_t* __restrict__ st_ret) {
-  extern __shared__ __attribute__((aligned(16))) double s_ts[];
+  extern __shared__ __attribute__((aligned(16))) double s_lds[];
   const int T = o.T, B = o.B;
-  for (int i = threadIdx.x; i < T; i += blockDim.x) s_ts[i] = ts_g[i];
+  // the save-time grid is staged in LDS when it fits (T ≤ 6000, TS_LDS); longer grids are read from L2
+  if (TS_LDS)
+    for (int i = threadIdx.x; i < T; i += blockDim.x) s_lds[i] = ts_g[i];
   __syncthreads();
+  auto s_ts = [&](int i) -> double { return TS_LDS ? s_lds[i] : ts_g[i]; };   // compile-time choice
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
 
@@ -74,8 +79,8 @@ __global__ void __launch_bounds__(256) k_pend_forward(const float2* __restrict__
   int ret = LDE_RET_SUCCESS, nfe = 0, nacc = 0, nrej = 0;
 
   if (T > 1) {
-    double t = s_ts[0];
-    const double tend = s_ts[T - 1], dtmax = tend - t;
+    double t = s_ts(0);
+    const double tend = s_ts(T - 1), dtmax = tend - t;
     f(y, k[0]);
     nfe = 1;
     double dt;
@@ -91,7 +96,7 @@ __global__ void __launch_bounds__(256) k_pend_forward(const float2* __restrict__
     long long iters = 0;
     int j = 1;
     // next save time kept in a register, the one after it prefetched: no LDS round trip on the save loop's exit test
-    double tj = s_ts[1], tjn = s_ts[min(2, T - 1)];
+    double tj = s_ts(1), tjn = s_ts(min(2, T - 1));
     while (t < tend) {
       if (iters++ >= o.maxiters) { ret = LDE_RET_MAXITERS; break; }
       double dtp = dt;
@@ -150,7 +155,7 @@ __global__ void __launch_bounds__(256) k_pend_forward(const float2* __restrict__
           z_out[(size_t)j * B + b] = out;
           j++;
           tj = tjn;
-          tjn = s_ts[min(j + 1, T - 1)];
+          tjn = s_ts(min(j + 1, T - 1));
         } while (j < T && tj <= tnew);
       }
       y[0] = yn[0];
@@ -176,17 +181,19 @@ __global__ void __launch_bounds__(256) k_pend_forward(const float2* __restrict__
 // ---- adjoint --------------------------------------------------------------------------------------
 // Reverse-time integration of [z, λ, g_L] from t_T to t_1 with a forced stop at every save time:
 // λ += Δ_j there, and (checkpointed mode) z is reset to the saved ẑ(t_j).
-template <int KIND, int SOLVER>
+template <int KIND, int SOLVER, bool TS_LDS>
 __global__ void __launch_bounds__(256) k_pend_adjoint(const float2* __restrict__ z_out, const float* __restrict__ theta,
                                                       const double* __restrict__ ts_g, KOpts o,
                                                       const float2* __restrict__ dz_out, float2* __restrict__ dz0,
                                                       float* __restrict__ dtheta, int32_t* __restrict__ st_nfe,
                                                       int32_t* __restrict__ st_nacc, int32_t* __restrict__ st_nrej,
                                                       int32_t* __restrict__ st_ret) {
-  extern __shared__ __attribute__((aligned(16))) double s_ts[];
+  extern __shared__ __attribute__((aligned(16))) double s_lds[];
   const int T = o.T, B = o.B;
-  for (int i = threadIdx.x; i < T; i += blockDim.x) s_ts[i] = ts_g[i];
+  if (TS_LDS)
+    for (int i = threadIdx.x; i < T; i += blockDim.x) s_lds[i] = ts_g[i];
   __syncthreads();
+  auto s_ts = [&](int i) -> double { return TS_LDS ? s_lds[i] : ts_g[i]; };   // compile-time choice
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
 
@@ -199,8 +206,8 @@ __global__ void __launch_bounds__(256) k_pend_adjoint(const float2* __restrict__
   bool bad = !(isfinite(zT.x) && isfinite(zT.y));  // failed forward trajectory: NaN block is a constant ⇒ zero gradient
 
   if (T > 1 && !bad) {
-    double t = s_ts[T - 1];
-    const double dtmax = fabs(t - s_ts[0]);
+    double t = s_ts(T - 1);
+    const double dtmax = fabs(t - s_ts(0));
     int j = T - 2;
     // prefetch the jump data of the next stop
     float2 zc = z_out[(size_t)j * B + b], dc = dz_out[(size_t)j * B + b];
@@ -219,7 +226,7 @@ __global__ void __launch_bounds__(256) k_pend_adjoint(const float2* __restrict__
     long long iters = 0;
     while (j >= 0) {
       if (iters++ >= o.maxiters) { ret = LDE_RET_MAXITERS; break; }
-      const double tstop = s_ts[j];
+      const double tstop = s_ts(j);
       const double dist = t - tstop;
       double hmag = dt;
       bool hit = false;
@@ -543,10 +550,16 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
                         float* z_out, int32_t* retcode, int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret,
                         hipStream_t stream) {
   const int block = pick_block(o.B), grid = (o.B + block - 1) / block;
-  const size_t shm = (size_t)o.T * sizeof(double);
+  const size_t shm = o.T <= TS_LDS_MAX ? (size_t)o.T * sizeof(double) : 0;
 #define LDE_LAUNCH(K, S)                                                                                              \
-  hipLaunchKernelGGL((k_pend_forward<K, S>), dim3(grid), dim3(block), shm, stream, (const float2*)z0, theta, ts_dev, o, \
-                     (float2*)z_out, retcode, nfe, nacc, nrej, ret)
+  do {                                                                                                                \
+    if (shm)                                                                                                          \
+      hipLaunchKernelGGL((k_pend_forward<K, S, true>), dim3(grid), dim3(block), shm, stream, (const float2*)z0, theta,  \
+                         ts_dev, o, (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                   \
+    else                                                                                                              \
+      hipLaunchKernelGGL((k_pend_forward<K, S, false>), dim3(grid), dim3(block), 0, stream, (const float2*)z0, theta,   \
+                         ts_dev, o, (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                   \
+  } while (0)
   if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH(0, LDE_SOLVER_TSIT5);
   else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_RK4) LDE_LAUNCH(0, LDE_SOLVER_RK4);
   else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH(1, LDE_SOLVER_TSIT5);
@@ -560,10 +573,16 @@ int launch_pend_adjoint(int kind, int solver, const float* z_out, const float* t
                         const KOpts& o, const float* dz_out, float* dz0, float* dtheta, int32_t* nfe, int32_t* nacc,
                         int32_t* nrej, int32_t* ret, hipStream_t stream) {
   const int block = pick_block(o.B), grid = (o.B + block - 1) / block;
-  const size_t shm = (size_t)o.T * sizeof(double);
+  const size_t shm = o.T <= TS_LDS_MAX ? (size_t)o.T * sizeof(double) : 0;
 #define LDE_LAUNCH(K, S)                                                                                          \
-  hipLaunchKernelGGL((k_pend_adjoint<K, S>), dim3(grid), dim3(block), shm, stream, (const float2*)z_out, theta, ts_dev, \
-                     o, (const float2*)dz_out, (float2*)dz0, dtheta, nfe, nacc, nrej, ret)
+  do {                                                                                                              \
+    if (shm)                                                                                                        \
+      hipLaunchKernelGGL((k_pend_adjoint<K, S, true>), dim3(grid), dim3(block), shm, stream, (const float2*)z_out,    \
+                         theta, ts_dev, o, (const float2*)dz_out, (float2*)dz0, dtheta, nfe, nacc, nrej, ret);      \
+    else                                                                                                            \
+      hipLaunchKernelGGL((k_pend_adjoint<K, S, false>), dim3(grid), dim3(block), 0, stream, (const float2*)z_out,     \
+                         theta, ts_dev, o, (const float2*)dz_out, (float2*)dz0, dtheta, nfe, nacc, nrej, ret);      \
+  } while (0)
   if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH(0, LDE_SOLVER_TSIT5);
   else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_RK4) LDE_LAUNCH(0, LDE_SOLVER_RK4);
   else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH(1, LDE_SOLVER_TSIT5);

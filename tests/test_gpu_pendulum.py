@@ -213,3 +213,19 @@ def test_tsit5_with_fixed_step(o32, sense):
     r0, rL, _, ib = o32.adjoint(od, z, L, ts, dz)
     assert sb["naccept"] == ib["naccept"]
     assert np.abs(g0 - r0).max() <= 1e-4 * np.abs(r0).max() and np.abs(gL - rL).max() <= 1e-4 * np.abs(rL).max()
+
+
+def test_very_long_save_grid(o32):
+    """T = 7000 save times: the grid no longer fits the LDS staging buffer and is read from L2 instead."""
+    nat, od = _native(abstol=1e-6, reltol=1e-6)
+    B, T = 40, 7000
+    z0, L = O.pendulum_inputs(B, seed=4)
+    ts = O.time_grid(T, 0.0005)
+    z, ret, _ = nat.forward(z0, L, ts)
+    zr, _, _ = o32.forward(od, z0, L, ts)
+    assert (ret == 0).all() and np.abs(z - zr).max() <= 1e-5
+    dz = O.cotangent(T, B, 2)
+    g0, gL, _, _ = nat.adjoint(z, L, ts, dz)           # T−1 > 1024 ⇒ two-kernel time-parallel form
+    seq, ods = _native(abstol=1e-6, reltol=1e-6, sensealg=O.SENSE_BACKSOLVE_CHECKPOINTED)
+    s0, sL, _, _ = seq.adjoint(z, L, ts, dz)           # sequential kernel, grid from L2 as well
+    assert np.abs(g0 - s0).max() <= 2e-4 * np.abs(s0).max() and np.abs(gL - sL).max() <= 2e-4 * np.abs(sL).max()

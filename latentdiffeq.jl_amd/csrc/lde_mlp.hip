@@ -47,7 +47,8 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 #ifndef LDE_ABL
 #define LDE_ABL 0
 #endif
-// diagnostic builds only (LDE_ABL != 0): 1 = no GEMM, 2 = operands loaded but no MFMA, 3 = no epilogue
+// diagnostic builds only (LDE_ABL != 0): 1 = no GEMM, 2 = operands loaded but no MFMA, 3 = no epilogue,
+// 4 = no weight-gradient products (and no bias sums), 5 = no bias sums
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   if (LDE_ABL == 2) { c[0] += a + b; return c; }
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
@@ -810,7 +811,7 @@ __device__ __forceinline__ void eval_bwd(const MlpDims& dm, const Panels& P, con
     const int in = dm.sizes[l], out = dm.sizes[l + 1];
     const float* al = l == 0 ? src : P.hid(l - 1);   // input activation of layer l
     const int lda = l == 0 ? P.lds : dm.ld_hl[l - 1];
-    if (any_w) {
+    if (any_w && LDE_ABL != 4) {
       // gWᵀ 32×32 tile [i][o] += Σ_n a_l[i][n] · (w_n δ[o][n]) on v_mfma_f32_32x32x2_f32: MFMA s contracts the two columns
       // n = 2s + (lane>>5); every operand read is 32 consecutive floats per half-wave (conflict-free).
       const int IT = cdiv(in, 32);
@@ -836,6 +837,7 @@ __device__ __forceinline__ void eval_bwd(const MlpDims& dm, const Panels& P, con
         }
         __builtin_amdgcn_sched_barrier(0);   // keep one tile's 16 operand loads in flight, not all NDW tiles' (VGPR blow-up)
       }
+      if (LDE_ABL != 5)
       for (int row = threadIdx.x; row < out; row += NT) {
         float sacc = 0.f;
 #pragma unroll

@@ -30,6 +30,7 @@ struct MlpPlan;
 int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err);
 void mlp_plan_destroy(MlpPlan* p);
 int mlp_reserve(MlpPlan* p, int B, int T, std::string& err);
+int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::string& err);
 int mlp_set_weights(MlpPlan* p, const float* W_dev, hipStream_t stream, std::string& err);
 int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* theta, const double* ts_dev,
                 const KOpts& o, float* z_out, int32_t* retcode, int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret,
@@ -232,7 +233,10 @@ int lde_set_weights_device(lde_handle* h, const float* flat_dev, int64_t n, void
   return lde::mlp_set_weights(h->mlp, h->W_dev, (hipStream_t)stream, h->err);
 }
 
-int lde_reserve(lde_handle* h, int B, int T) {
+}  // extern "C"
+
+// adjoint_ws: also size the workspace only lde_adjoint needs (the MLP adjoint's staging area is large)
+static int reserve_impl(lde_handle* h, int B, int T, bool adjoint_ws, int64_t steps_hint) {
   if (!h || B < 1 || T < 1) return LDE_ERR_INVALID_ARG;
   if (B > h->cap_B) {
     for (int w = 0; w < 2; w++)
@@ -272,11 +276,15 @@ int lde_reserve(lde_handle* h, int B, int T) {
       h->par_cap = need;
     }
   }
-  if (h->mlp) return lde::mlp_reserve(h->mlp, B, T, h->err);
+  if (h->mlp) {
+    const int rc = lde::mlp_reserve(h->mlp, B, T, h->err);
+    if (rc || !adjoint_ws) return rc;
+    return lde::mlp_reserve_adjoint(h->mlp, B, T, steps_hint, h->err);
+  }
   return LDE_OK;
 }
 
-}  // extern "C"
+extern "C" int lde_reserve(lde_handle* h, int B, int T) { return reserve_impl(h, B, T, true, 0); }
 
 // Make the device copy of the save-time grid current (no-op when `ts` is unchanged since the last call).
 static int stage_ts(lde_handle* h, const double* ts, int T, hipStream_t stream) {
@@ -331,7 +339,7 @@ int lde_forward(lde_handle* h, const float* z0, const float* theta, const double
     h->err = "lde_forward: weights not set";
     return LDE_ERR_NO_WEIGHTS;
   }
-  int rc = lde_reserve(h, B, T);
+  int rc = reserve_impl(h, B, T, false, 0);
   if (rc) return rc;
   rc = stage_ts(h, ts, T, stream);
   if (rc) return rc;
@@ -359,7 +367,15 @@ int lde_adjoint(lde_handle* h, const float* z_out, const float* theta, const dou
     h->err = "lde_adjoint: weights not set";
     return LDE_ERR_NO_WEIGHTS;
   }
-  int rc = lde_reserve(h, B, T);
+  int64_t steps_hint = 0;   // fixed step size: the number of step attempts is known here
+  if (h->mlp && !h->d.adaptive && h->d.dt > 0) {
+    for (int j = 0; j + 1 < T; j++) {
+      const double n = std::ceil((ts[j + 1] - ts[j]) / h->d.dt * (1.0 - 1e-12));
+      steps_hint += n < 1 ? 1 : (n > 1e9 ? (int64_t)1e9 : (int64_t)n);
+    }
+    if (steps_hint > h->d.maxiters) steps_hint = h->d.maxiters;
+  }
+  int rc = reserve_impl(h, B, T, true, steps_hint);
   if (rc) return rc;
   rc = stage_ts(h, ts, T, stream);
   if (rc) return rc;

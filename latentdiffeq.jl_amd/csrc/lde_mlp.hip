@@ -26,11 +26,16 @@
 //    each workgroup publishes its partial, a monotonic-counter barrier (agent-scope release/acquire) follows, and
 //    every workgroup adds the partials in the same order ⇒ bitwise identical decisions everywhere.
 //  * Adjoint: reverse-time Tsit5/RK4 on [z; λ; g_θ] with the MLP re-evaluated at every stage (relu masks are
-//    recomputed, not stored), vector-Jacobian products through Wᵀ fragments, and the weight gradient
-//    gWᵀ[i][o] += Σ_n a_l[i][n]·(w_n δ_l[o][n]) as MFMAs with K = the 16 columns, accumulated in MFMA accumulators
-//    across the stages of a step and committed to the workgroup's slab only when the step is accepted.
+//    recomputed, not stored) and vector-Jacobian products through Wᵀ fragments. The weight gradient is a quadrature
+//    over the accepted steps, gW_l = Σ_stages Σ_n w_n δ_l[:,n] a_l[:,n]ᵀ, and does not feed back into the solve, so
+//    the solve kernel only STAGES the (a_l, δ_l) panels of every weighted stage in HBM (a few coalesced 16-byte
+//    stores per lane) with the per-column quadrature weights next to them (weights of rejected columns are zeroed
+//    afterwards, slots of wholly rejected attempts are reused). A second kernel, k_mlp_dw, then forms the gradient as
+//    ONE large-K product per 32×32 tile of W_lᵀ over all staged columns, spread over the whole chip (tile × K-split ×
+//    layer jobs) on v_mfma_f32_32x32x2_f32, and k_reduce_slabs adds the partial slabs in a fixed order.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -80,6 +85,8 @@ struct MlpDims {
   int nbias;
   int tile_off[MAXL + 1]; // first weight-gradient tile (32×32 of Wᵀ) of layer l in the global tile enumeration
   int slab_n;             // floats of one workgroup's slab: ntiles·1024 (tiles in accumulator-fragment order) + nbias
+  int blk_off[MAXL];      // staged block of one evaluation: layer l's a-panel [16][in32] at blk_off[l], its δ-panel [16][out32] right after
+  int blk_floats;         // floats of one staged block
 };
 
 __host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
@@ -788,62 +795,46 @@ struct BwdArgs {
   const float* Wflat;
   float* dz0;
   float* dtheta;
-  float* slab;        // [nWG][nW] this launch's per-workgroup weight-gradient slabs
+  float* slab;        // [nWG][slab_n] private slabs, written only by a workgroup whose staging area overflowed
+  float* stage;       // [nWG][cap][blk_floats] staged (a_l, δ_l) panels of every weighted stage evaluation
+  float* wts;         // [nWG][cap][16] quadrature weight of each staged column (0 ⇒ rejected / idle)
+  int32_t* nslots;    // [nWG] staged evaluations that count
+  int32_t* nflush;    // [nWG] times the workgroup had to fold its staging area into its private slab
+  int cap;            // staging slots per workgroup
   int32_t *st_nfe, *st_nacc, *st_nrej, *st_ret;
   GridSync gs;
   int lds_bytes;
 };
 
-// f, −(∂f/∂z)ᵀλ, −(∂f/∂θ)ᵀλ for the tile, and the weighted outer products of this stage.
-//   src/dst rows: [0,Dp) z | [DpA,DpA+Dp) λ | [2DpA,2DpA+P) g.   wst[col] = quadrature weight of this stage (0 ⇒ none)
-template <int NDW, int NT>
+__device__ __forceinline__ int pad32(int v) { return (v + 31) & ~31; }
+
+// f, −(∂f/∂z)ᵀλ, −(∂f/∂θ)ᵀλ for the tile; when `blk` is given, the (a_l, δ_l) panels of this evaluation are staged there.
+//   src/dst rows: [0,Dp) z | [DpA,DpA+Dp) λ | [2DpA,2DpA+P) g.
+template <int NT>
 __device__ __forceinline__ void eval_bwd(const MlpDims& dm, const Panels& P, const Ctl* c, const float* src, float* dst,
-                                         const float* wst, bool any_w, f32x16 (&acc)[NDW], float* bstep) {
+                                         float* blk) {
+  static_assert(NT == 512, "the staging copy maps one half-wave to each of the 16 columns");
   const int DpA = dm.DpA, nL = dm.nL;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   // 1. forward through the MLP (relu masks are recomputed here, not stored by the forward solve)
   eval_rhs<NT>(dm, P, c, src, dst);
   // 2. back-propagate λ; δ_L = λ_stage
   const float* dl = src + DpA;
   int ldd = P.lds;
-  const int half = lane >> 5;
   for (int l = nL - 1; l >= 0; l--) {
     const int in = dm.sizes[l], out = dm.sizes[l + 1];
     const float* al = l == 0 ? src : P.hid(l - 1);   // input activation of layer l
     const int lda = l == 0 ? P.lds : dm.ld_hl[l - 1];
-    if (any_w && LDE_ABL != 4) {
-      // gWᵀ 32×32 tile [i][o] += Σ_n a_l[i][n] · (w_n δ[o][n]) on v_mfma_f32_32x32x2_f32: MFMA s contracts the two columns
-      // n = 2s + (lane>>5); every operand read is 32 consecutive floats per half-wave (conflict-free).
-      const int IT = cdiv(in, 32);
-      const int t0 = dm.tile_off[l], t1 = dm.tile_off[l + 1];
-      float wl[8];
-#pragma unroll
-      for (int s8 = 0; s8 < 8; s8++) wl[s8] = wst[2 * s8 + half];
-#pragma unroll
-      for (int m = 0; m < NDW; m++) {
-        const int t = wave + (NT / 64) * m;
-        if (t >= t0 && t < t1) {
-          const int tt = t - t0, ot = tt / IT, it = tt - ot * IT;
-          const float* ap = al + half * lda + it * 32 + (lane & 31);
-          const float* bp = dl + half * ldd + ot * 32 + (lane & 31);
-          float av[8], bv[8];
-#pragma unroll
-          for (int s8 = 0; s8 < 8; s8++) {
-            av[s8] = ap[s8 * 2 * lda];
-            bv[s8] = bp[s8 * 2 * ldd] * wl[s8];
-          }
-#pragma unroll
-          for (int s8 = 0; s8 < 8; s8++) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s8], bv[s8], acc[m], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);   // keep one tile's 16 operand loads in flight, not all NDW tiles' (VGPR blow-up)
-      }
-      if (LDE_ABL != 5)
-      for (int row = threadIdx.x; row < out; row += NT) {
-        float sacc = 0.f;
-#pragma unroll
-        for (int n = 0; n < NB; n++) sacc += wst[n] * dl[n * ldd + row];
-        bstep[dm.bias_lin[l] + row] += sacc;   // each (layer,row) is owned by exactly one thread
-      }
+    if (blk && LDE_ABL != 4) {
+      // stage a_l rows [0,in32) and δ_l rows [0,out32) of the 16 columns: one half-wave per column, 512 contiguous bytes
+      // per store instruction. Pad rows are whatever follows in the panel (finite): they only reach pad rows of gWᵀ tiles.
+      const int in32 = pad32(in), out32 = pad32(out);
+      float* ga = blk + dm.blk_off[l];
+      float* gd = ga + NB * in32;
+      const int col = threadIdx.x >> 5, l31 = threadIdx.x & 31;
+      for (int r4 = l31; 4 * r4 < in32; r4 += 32)
+        *reinterpret_cast<f32x4*>(ga + col * in32 + 4 * r4) = *reinterpret_cast<const f32x4*>(al + col * lda + 4 * r4);
+      for (int r4 = l31; 4 * r4 < out32; r4 += 32)
+        *reinterpret_cast<f32x4*>(gd + col * out32 + 4 * r4) = *reinterpret_cast<const f32x4*>(dl + col * ldd + 4 * r4);
     }
     // δ_in = W_lᵀ δ  (⊙ act'(a_l) for hidden layers); layer 0 gives (∂f/∂z)ᵀλ
     if (l > 0) {
@@ -890,8 +881,60 @@ __device__ __forceinline__ void eval_bwd(const MlpDims& dm, const Panels& P, con
   }
 }
 
+// Slow path, taken only when a workgroup runs out of staging slots: gW contributions of its slots [0, ns) are added to
+// its private slab (same fragment order as k_mlp_dw writes). One 32×32 tile per wave at a time, operands straight from
+// L2 with agent-scope loads (the blocks were written by this workgroup's own stores a moment ago).
+__device__ __forceinline__ float ld_agent(const float* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int NT>
+__device__ __forceinline__ void flush_stage(const MlpDims& dm, const float* stage, const float* wts, int ns, float* slab, bool first) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  if (first) {
+    for (int i = tid; i < dm.slab_n; i += NT) slab[i] = 0.f;
+    __syncthreads();
+  }
+  for (int l = 0; l < dm.nL; l++) {
+    const int in = dm.sizes[l], out = dm.sizes[l + 1], in32 = pad32(in), out32 = pad32(out);
+    const int IT = in32 / 32, OT = out32 / 32;
+    for (int tl = wave; tl < IT * OT; tl += NT / 64) {
+      const int ot = tl / IT, it = tl - ot * IT;
+      f32x16 acc;
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[r] = 0.f;
+      for (int e = 0; e < ns; e++) {
+        const float* pa = stage + (size_t)e * dm.blk_floats + dm.blk_off[l];
+        const float* pd = pa + NB * in32;
+        const float* wv = wts + (size_t)e * NB;
+        for (int s8 = 0; s8 < 8; s8++) {
+          const int n = 2 * s8 + half;
+          const float w = ld_agent(wv + n);
+          const float av = ld_agent(pa + n * in32 + it * 32 + l31);
+          const float dv = ld_agent(pd + n * out32 + ot * 32 + l31);
+          acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, w != 0.f ? dv * w : 0.f, acc, 0, 0, 0);
+        }
+      }
+      float* g = slab + ((size_t)(dm.tile_off[l] + tl) * 64 + lane) * 16;
+#pragma unroll
+      for (int r = 0; r < 16; r++) g[r] += acc[r];
+    }
+    for (int row = tid; row < out; row += NT) {
+      float sacc = 0.f;
+      for (int e = 0; e < ns; e++) {
+        const float* pd = stage + (size_t)e * dm.blk_floats + dm.blk_off[l] + NB * in32;
+        for (int n = 0; n < NB; n++) {
+          const float w = ld_agent(wts + (size_t)e * NB + n);
+          const float dv = ld_agent(pd + n * out32 + row);
+          sacc += w != 0.f ? dv * w : 0.f;
+        }
+      }
+      slab[(size_t)dm.tile_off[dm.nL] * 1024 + dm.bias_lin[l] + row] += sacc;
+    }
+  }
+}
+
 // Reverse-time solve of [z; λ; g_θ] for one tile, with forced stops + jumps at the save times.
-template <int NDW, int SOLVER, int NT>
+template <int SOLVER, int NT>
 __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int T = o.T, B = o.B, Dp = dm.Dp, DpA = dm.DpA, D = dm.D, NP = dm.P;
@@ -916,7 +959,6 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
   P.delbase = p; p += 2 * P.hstride;
   P.red = p; p += (NT / 64) * 256;
   P.biasc = p; p += (dm.nbias + 3) & ~3;
-  float* bstep = p; p += (dm.nbias + 3) & ~3;
   float* wst = p; p += NB;
   const int nfloat = (int)(p - base);
   for (int i = threadIdx.x; i < nfloat; i += NT) base[i] = 0.f;
@@ -940,56 +982,17 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
   const bool coupled = dm.coupled != 0;
   const double tT = s_ts[T - 1], dtmax = fabs(tT - s_ts[0]);
   unsigned gen = 0;
-  float* slab = a.slab + (size_t)blockIdx.x * dm.slab_n;
-  for (int i = tid; i < dm.slab_n; i += NT) slab[i] = 0.f;
+  // staging area of this workgroup: slot e holds one weighted stage evaluation (block of panels + 16 column weights)
+  constexpr int NST = SOLVER == LDE_SOLVER_TSIT5 ? 6 : 4;   // weighted stages per step attempt
+  float* const my_stage = a.stage + (size_t)blockIdx.x * a.cap * dm.blk_floats;
+  float* const my_wts = a.wts + (size_t)blockIdx.x * a.cap * NB;
+  int slot_base = 0;      // slots [0, slot_base) hold accepted work; the running attempt writes slot_base + stage
+  int nflush = 0;
 // all NS×16 elements of a state panel: 32 row-lanes × NT/32 columns per pass (shifts only; conflict-free b32 accesses)
 #define FOR_ELEMS(idx, colv)                            \
   for (int colv = tid >> 5; colv < NB; colv += NT / 32) \
     for (int r_ = tid & 31, idx = colv * lds + r_; r_ < NS; r_ += 32, idx += 32)
 
-  f32x16 acc[NDW];
-#pragma unroll
-  for (int m = 0; m < NDW; m++)
-#pragma unroll
-    for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
-
-  // commit the step's outer products to the slab. The slab keeps every 32×32 tile in ACCUMULATOR-FRAGMENT order
-  // (tile, lane, 16 registers), so a lane adds 64 contiguous bytes per tile: four coalesced dwordx4 read-modify-writes.
-  // k_reduce_slabs maps fragment order back to the flat destructure order.
-  const int ntiles = dm.tile_off[dm.nL];
-  auto commit = [&]() {
-#pragma unroll
-    for (int m = 0; m < NDW; m++) {
-      const int t = wave + (NT / 64) * m;
-      if (t < ntiles) {
-        f32x4* g4 = reinterpret_cast<f32x4*>(slab + ((size_t)t * 64 + lane) * 16);
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          f32x4 v = g4[q];
-          v[0] += acc[m][4 * q + 0];
-          v[1] += acc[m][4 * q + 1];
-          v[2] += acc[m][4 * q + 2];
-          v[3] += acc[m][4 * q + 3];
-          g4[q] = v;
-        }
-#pragma unroll
-        for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    float* gb = slab + (size_t)ntiles * 1024;
-    for (int i = tid; i < dm.nbias; i += NT) {
-      gb[i] += bstep[i];
-      bstep[i] = 0.f;
-    }
-  };
-  auto discard = [&]() {
-#pragma unroll
-    for (int m = 0; m < NDW; m++)
-#pragma unroll
-      for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
-    for (int i = tid; i < dm.nbias; i += NT) bstep[i] = 0.f;
-  };
 
   // ---- load the terminal condition: z = ẑ(t_T), λ = Δ_T, g = 0 ------------------------------------------
   for (int e = tid; e < NB * Dp; e += NT) {
@@ -1063,7 +1066,6 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
 
   const bool auto_dt = o.adaptive && !(o.dt_fixed > 0);
   int phase = auto_dt ? PH_K0 : PH_STAGE, s = 0;
-  bool replay = false;
   bool running = T > 1;
   if (running && !auto_dt) {
     if (tid < NB) c->dt[tid] = o.adaptive ? fmin(o.dt_fixed, dtmax) : o.dt_fixed;
@@ -1076,6 +1078,14 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
     bool any_w = false;
     if (phase == PH_INIT1) src = P.tmp;
     if (phase == PH_STAGE) {
+      if (s == 0 && slot_base + NST > a.cap) {
+        // staging area full (far more steps than the sizing heuristic expected): fold it into the private slab
+        __syncthreads();
+        flush_stage<NT>(dm, my_stage, my_wts, slot_base, a.slab + (size_t)blockIdx.x * dm.slab_n, nflush == 0);
+        slot_base = 0;
+        nflush++;
+        __syncthreads();
+      }
       float bs;
       if (SOLVER == LDE_SOLVER_TSIT5) {
         if (s > 0) {
@@ -1100,13 +1110,13 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
         bs = (s == 0 || s == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
         any_w = true;
       }
-      if (tid < NB) wst[tid] = (any_w && (!replay || c->accepted[tid])) ? c->wq[tid] * bs : 0.f;
+      if (any_w && tid < NB) my_wts[(size_t)(slot_base + s) * NB + tid] = c->wq[tid] * bs;   // optimistic: zeroed on rejection
       __syncthreads();
     }
     float* dst = phase == PH_K0 ? P.k(0) : (phase == PH_INIT1 ? P.k(1) : P.k(s));
 
-    eval_bwd<NDW, NT>(dm, P, c, src, dst, wst, any_w, acc, bstep);
-    if (!replay && tid < NB && c->status[tid] == 0) c->nfe[tid]++;
+    eval_bwd<NT>(dm, P, c, src, dst, any_w ? my_stage + (size_t)(slot_base + s) * dm.blk_floats : nullptr);
+    if (tid < NB && c->status[tid] == 0) c->nfe[tid]++;
 
     // ---- what follows the evaluation -----------------------------------------------------------------------------
     if (phase == PH_K0) {
@@ -1191,95 +1201,81 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
         }
         __syncthreads();
       }
-      if (!replay) {
-        // ---- error estimate + control ----------------------------------------------------------------------------
-        FOR_ELEMS(idx, ecol) {
-          float r2 = 0.f;
-          const float yv = P.y[idx], ynv = P.yn[idx];
-          if (o.adaptive) {
-            float er = ts5::BT[0] * P.k(0)[idx];
+      // ---- error estimate + control ----------------------------------------------------------------------------
+      FOR_ELEMS(idx, ecol) {
+        float r2 = 0.f;
+        const float yv = P.y[idx], ynv = P.yn[idx];
+        if (o.adaptive) {
+          float er = ts5::BT[0] * P.k(0)[idx];
 #pragma unroll
-            for (int jj = 1; jj < 7; jj++) er += ts5::BT[jj] * P.k(jj)[idx];
-            er *= c->h[ecol];
-            const float sk = o.abstol + fmaxf(fabsf(yv), fabsf(ynv)) * o.reltol;
-            const float r = er * fast_rcp(sk);
-            r2 = r * r;
-          }
-          P.scr[idx] = isfinite(ynv) ? r2 : __int_as_float(0x7fc00000);
+          for (int jj = 1; jj < 7; jj++) er += ts5::BT[jj] * P.k(jj)[idx];
+          er *= c->h[ecol];
+          const float sk = o.abstol + fmaxf(fabsf(yv), fabsf(ynv)) * o.reltol;
+          const float r = er * fast_rcp(sk);
+          r2 = r * r;
         }
-        __syncthreads();
-        if (tid < NB) {
-          float s2 = 0.f;
-          for (int r = 0; r < NS; r++) s2 += P.scr[tid * lds + r];
-          c->eest[tid] = s2;
-        }
-        __syncthreads();
-        float v[4] = {0.f, 0.f, 0.f, 0.f};
-        if (coupled) {
-          if (tid == 0)
-            for (int col = 0; col < NB; col++)
-              if (c->status[col] == 0) v[0] += c->eest[col];
-          grid_sum4(a.gs, gen, v, c->bcast);
-        }
-        if (tid < NB && c->status[tid] == 0) {
-          const int col = tid;
-          const float n = coupled ? (float)NREAL * (float)B : (float)NREAL;
-          const float s2 = coupled ? v[0] : c->eest[col];
-          const float EEst = o.adaptive ? sqrtf(s2 / n) : (s2 == s2 ? 0.f : s2);
-          const double hmag = c->tnew[col];
-          int accepted = 0;
-          if (!(EEst == EEst)) {
-            if (o.adaptive && hmag > o.dtmin) { c->nrej[col]++; c->dt[col] = hmag * (double)o.qmin; }
-            else c->status[col] = 1 + LDE_RET_NONFINITE;
-          } else if (o.adaptive) {
-            float q11;
-            const float q = pi_q(EEst, c->qold[col], o, q11);
-            if (EEst > 1.0f) {
-              c->nrej[col]++;
-              const double nd = hmag * (double)fast_rcp(fminf(o.q_hi, q11 * o.inv_gamma));
-              c->dt[col] = nd;
-              if (nd < o.dtmin) c->status[col] = 1 + LDE_RET_DTMIN;
-            } else {
-              c->qold[col] = fmaxf(EEst, 1e-4f);
-              double dtp = hmag * (double)fast_rcp(q);
-              if (dtp > dtmax) dtp = dtmax;
-              c->dt[col] = dtp;
-              accepted = 1;
-            }
-          } else {
-            c->dt[col] = o.dt_fixed;
-            accepted = 1;
-          }
-          c->accepted[col] = accepted;
-          if (accepted) c->nacc[col]++;
-        } else if (tid < NB)
-          c->accepted[tid] = 0;
-        __syncthreads();
-        if (tid == 0) {
-          int all = 1, any = 0;
-          for (int col = 0; col < NB; col++) {
-            if (c->wq[col] != 0.f) { all &= c->accepted[col]; any |= c->accepted[col]; }
-          }
-          c->all_accepted = all;
-          c->any_save = any;
-        }
-        __syncthreads();
-        if (c->all_accepted) {
-          if (o.adaptive) commit();            // fixed step: everything is accepted, commit once at the end
-        } else {
-          discard();
-          if (c->any_save) {   // some columns accepted, some rejected: redo the stages with the accepted columns' weights only
-            replay = true;
-            s = 0;
-            __syncthreads();
-            continue;
-          }
-        }
-      } else {
-        commit();
-        replay = false;
+        P.scr[idx] = isfinite(ynv) ? r2 : __int_as_float(0x7fc00000);
       }
       __syncthreads();
+      if (tid < NB) {
+        float s2 = 0.f;
+        for (int r = 0; r < NS; r++) s2 += P.scr[tid * lds + r];
+        c->eest[tid] = s2;
+      }
+      __syncthreads();
+      float v[4] = {0.f, 0.f, 0.f, 0.f};
+      if (coupled) {
+        if (tid == 0)
+          for (int col = 0; col < NB; col++)
+            if (c->status[col] == 0) v[0] += c->eest[col];
+        grid_sum4(a.gs, gen, v, c->bcast);
+      }
+      if (tid < NB && c->status[tid] == 0) {
+        const int col = tid;
+        const float n = coupled ? (float)NREAL * (float)B : (float)NREAL;
+        const float s2 = coupled ? v[0] : c->eest[col];
+        const float EEst = o.adaptive ? sqrtf(s2 / n) : (s2 == s2 ? 0.f : s2);
+        const double hmag = c->tnew[col];
+        int accepted = 0;
+        if (!(EEst == EEst)) {
+          if (o.adaptive && hmag > o.dtmin) { c->nrej[col]++; c->dt[col] = hmag * (double)o.qmin; }
+          else c->status[col] = 1 + LDE_RET_NONFINITE;
+        } else if (o.adaptive) {
+          float q11;
+          const float q = pi_q(EEst, c->qold[col], o, q11);
+          if (EEst > 1.0f) {
+            c->nrej[col]++;
+            const double nd = hmag * (double)fast_rcp(fminf(o.q_hi, q11 * o.inv_gamma));
+            c->dt[col] = nd;
+            if (nd < o.dtmin) c->status[col] = 1 + LDE_RET_DTMIN;
+          } else {
+            c->qold[col] = fmaxf(EEst, 1e-4f);
+            double dtp = hmag * (double)fast_rcp(q);
+            if (dtp > dtmax) dtp = dtmax;
+            c->dt[col] = dtp;
+            accepted = 1;
+          }
+        } else {
+          c->dt[col] = o.dt_fixed;
+          accepted = 1;
+        }
+        c->accepted[col] = accepted;
+        if (accepted) c->nacc[col]++;
+      } else if (tid < NB)
+        c->accepted[tid] = 0;
+      __syncthreads();
+      if (tid == 0) {
+        int any = 0;
+        for (int col = 0; col < NB; col++) any |= c->accepted[col];
+        c->any_save = any;
+      }
+      __syncthreads();
+      // the attempt's staged evaluations: rejected columns do not contribute; if nothing was accepted the slots are reused
+      if (tid < NB && !c->accepted[tid] && c->wq[tid] != 0.f) {
+#pragma unroll
+        for (int st = 0; st < NST; st++) my_wts[(size_t)(slot_base + st) * NB + tid] = 0.f;
+      }
+      if (c->any_save) slot_base += NST;
 
       // ---- advance accepted columns; jump at a save time --------------------------------------------------------
       FOR_ELEMS(idx, ecol) {
@@ -1310,8 +1306,10 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
     }
   }
 
-  if (!o.adaptive) commit();
-  __syncthreads();
+  if (tid == 0) {
+    a.nslots[blockIdx.x] = slot_base;
+    a.nflush[blockIdx.x] = nflush;
+  }
 
   // ---- results ----------------------------------------------------------------------------------------------------
   for (int e = tid; e < NB * D; e += NT) {
@@ -1335,9 +1333,124 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
 #undef FOR_ELEMS
 }
 
+// ---- the weight gradient as one large-K product over everything the solve staged ---------------------------------------
+// grid (solve tile, K-split part, job); a job = up to 8·NDW 32×32 tiles of ONE layer's gWᵀ. The workgroup walks the
+// tile's staged slots part, part+KS, …: copies that layer's a-panel and (weight-scaled) δ-panel into LDS and every wave
+// adds 8 MFMAs (K = the 16 columns) to each of its tiles. Result: the (tile, part) slab in accumulator-fragment order.
+struct DwArgs {
+  const float* stage;
+  const float* wts;
+  const int32_t* nslots;
+  float* slab;          // [nWG·KS][slab_n]
+  int cap;
+};
+
+template <int NDW>
+__global__ void __launch_bounds__(512) k_mlp_dw(MlpDims dm, DwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  const int tile = blockIdx.x, part = blockIdx.y, KS = gridDim.y;
+  int l = 0, g = blockIdx.z;
+  for (; l < dm.nL; l++) {
+    const int nj = cdiv(cdiv(dm.sizes[l], 32) * cdiv(dm.sizes[l + 1], 32), 8 * NDW);
+    if (g < nj) break;
+    g -= nj;
+  }
+  const int in = dm.sizes[l], out = dm.sizes[l + 1], in32 = pad32(in), out32 = pad32(out);
+  const int IT = in32 / 32, ntl = IT * (out32 / 32);
+  // LDS strides: an odd multiple of 32 floats puts the two half-waves of a ds_read_b32 on disjoint bank halves
+  const int lsa = in32 | 32, lsd = out32 | 32;
+  float* pa = dsm;
+  float* pd = pa + NB * lsa;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  f32x16 acc[NDW];
+  int aoff[NDW], doff[NDW];
+#pragma unroll
+  for (int m = 0; m < NDW; m++) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
+    const int tl = g * 8 * NDW + wave + 8 * m;
+    const int ot = tl / IT, it = tl - ot * IT;
+    aoff[m] = tl < ntl ? half * lsa + it * 32 + l31 : -1;
+    doff[m] = half * lsd + ot * 32 + l31;
+  }
+  float bsum[2] = {0.f, 0.f};
+  const int ns = a.nslots[tile];
+  const int col = tid >> 5;
+  for (int e = part; e < ns; e += KS) {
+    const float* blk = a.stage + ((size_t)tile * a.cap + e) * dm.blk_floats + dm.blk_off[l];
+    const float w = a.wts[((size_t)tile * a.cap + e) * NB + col];
+    for (int r4 = l31; 4 * r4 < in32; r4 += 32)
+      *reinterpret_cast<f32x4*>(pa + col * lsa + 4 * r4) = *reinterpret_cast<const f32x4*>(blk + col * in32 + 4 * r4);
+    for (int r4 = l31; 4 * r4 < out32; r4 += 32) {
+      f32x4 d = *reinterpret_cast<const f32x4*>(blk + NB * in32 + col * out32 + 4 * r4);
+      // a column that carries no weight may hold anything (a diverged trajectory's NaN): 0·NaN must not reach the sum
+#pragma unroll
+      for (int q = 0; q < 4; q++) d[q] = w != 0.f ? d[q] * w : 0.f;
+      *reinterpret_cast<f32x4*>(pd + col * lsd + 4 * r4) = d;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < NDW; m++) {
+      if (aoff[m] >= 0) {
+        const float* ap = pa + aoff[m];
+        const float* bp = pd + doff[m];
+        float av[8], bv[8];
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++) {
+          av[s8] = ap[s8 * 2 * lsa];
+          bv[s8] = bp[s8 * 2 * lsd];
+        }
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s8], bv[s8], acc[m], 0, 0, 0);
+      }
+    }
+    if (g == 0) {
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int row = tid + 512 * q;
+        if (row < out) {
+          float sacc = 0.f;
+#pragma unroll
+          for (int n = 0; n < NB; n++) sacc += pd[n * lsd + row];
+          bsum[q] += sacc;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* slab = a.slab + ((size_t)tile * KS + part) * dm.slab_n;
+#pragma unroll
+  for (int m = 0; m < NDW; m++) {
+    const int tl = g * 8 * NDW + wave + 8 * m;
+    if (tl < ntl) {
+      f32x4* g4 = reinterpret_cast<f32x4*>(slab + ((size_t)(dm.tile_off[l] + tl) * 64 + lane) * 16);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        f32x4 v;
+        v[0] = acc[m][4 * q + 0]; v[1] = acc[m][4 * q + 1]; v[2] = acc[m][4 * q + 2]; v[3] = acc[m][4 * q + 3];
+        g4[q] = v;
+      }
+    }
+  }
+  if (g == 0) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int row = tid + 512 * q;
+      if (row < out) slab[(size_t)dm.tile_off[dm.nL] * 1024 + dm.bias_lin[l] + row] = bsum[q];
+    }
+  }
+}
+
 // dW[flat] += Σ_wg slab[wg][fragment position of flat]   (workgroups added in index order ⇒ deterministic)
-__global__ void k_reduce_slabs(const float* __restrict__ slab, int nwg, MlpDims dm, float* __restrict__ dW) {
+__global__ void k_reduce_slabs(const float* __restrict__ priv, const int32_t* __restrict__ nflush, int nwg,
+                               const float* __restrict__ slab, int nslab, MlpDims dm, float* __restrict__ dW,
+                               int32_t* __restrict__ feedback) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx == 0) {   // tell the host (asynchronously) whether any workgroup ran out of staging slots
+    int mx = 0;
+    for (int w = 0; w < nwg; w++) mx = max(mx, nflush[w]);
+    feedback[0] = mx;
+  }
   if (idx >= dm.nW) return;
   int l = 0;
   while (l + 1 < dm.nL && idx >= dm.w_off[l + 1]) l++;
@@ -1352,7 +1465,9 @@ __global__ void k_reduce_slabs(const float* __restrict__ slab, int nwg, MlpDims 
   } else
     pos = (size_t)dm.tile_off[dm.nL] * 1024 + dm.bias_lin[l] + (idx - dm.b_off[l]);
   float sacc = 0.f;
-  for (int w = 0; w < nwg; w++) sacc += slab[(size_t)w * dm.slab_n + pos];
+  for (int w = 0; w < nslab; w++) sacc += slab[(size_t)w * dm.slab_n + pos];
+  for (int w = 0; w < nwg; w++)
+    if (nflush[w]) sacc += priv[(size_t)w * dm.slab_n + pos];
   dW[idx] += sacc;
 }
 
@@ -1366,8 +1481,24 @@ struct MlpPlan {
   float* slots = nullptr;
   int* abort_flag = nullptr;
   int cap_wg = 0;
-  float* slab = nullptr;       // [nWG][nW] per-workgroup weight-gradient slabs (adjoint)
+  // adjoint workspace (allocated by the first lde_adjoint / lde_reserve, not by forward-only use)
+  float* slab = nullptr;       // [nWG·(1+KS)][slab_n]: private (overflow) slabs, then k_mlp_dw's (tile, part) slabs
   size_t slab_cap = 0;
+  float* stage = nullptr;      // [nWG][cap][blk_floats]
+  size_t stage_cap = 0;        // floats
+  float* wts = nullptr;        // [nWG][cap][16]
+  size_t wts_cap = 0;
+  int32_t* nslots = nullptr;   // [2][nWG]: staged slots, flush counts
+  int nslots_cap = 0;
+  int adj_cap = 0;             // staging slots per workgroup the workspace is currently laid out for
+  int adj_ks = 1;              // K-split of k_mlp_dw
+  // feedback: the largest per-workgroup overflow count of the previous adjoint call, copied to pinned memory behind the
+  // kernels; the next reservation doubles the staging area when it was non-zero (no host synchronisation anywhere)
+  int32_t* fb_dev = nullptr;
+  int32_t* fb_host = nullptr;
+  hipEvent_t fb_ev = nullptr;
+  bool fb_pending = false;
+  int cap_scale = 1;
 };
 
 void mlp_plan_destroy(MlpPlan* p);
@@ -1426,6 +1557,12 @@ int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err) 
   dm.tile_off[dm.nL] = toff;
   dm.nbias = blin;
   dm.slab_n = toff * 1024 + ((blin + 3) & ~3);
+  int boff = 0;
+  for (int l = 0; l < dm.nL; l++) {
+    dm.blk_off[l] = boff;
+    boff += NB * (((dm.sizes[l] + 31) & ~31) + ((dm.sizes[l + 1] + 31) & ~31));
+  }
+  dm.blk_floats = boff;
   p->nfrag = off;
   p->nfragT = offT;
   if (dm.Dp > 256 || hmax > 1024) {
@@ -1435,12 +1572,15 @@ int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err) 
   }
   if (hipMalloc(&p->frag, p->nfrag * sizeof(float)) != hipSuccess ||
       hipMalloc(&p->fragT, p->nfragT * sizeof(float)) != hipSuccess ||
-      hipMalloc(&p->counter, 64) != hipSuccess || hipMalloc(&p->abort_flag, 64) != hipSuccess) {
+      hipMalloc(&p->counter, 64) != hipSuccess || hipMalloc(&p->abort_flag, 64) != hipSuccess ||
+      hipMalloc(&p->fb_dev, 64) != hipSuccess || hipHostMalloc((void**)&p->fb_host, 64, hipHostMallocDefault) != hipSuccess ||
+      hipEventCreateWithFlags(&p->fb_ev, hipEventDisableTiming) != hipSuccess) {
     err = "MLP plan: hipMalloc failed";
     mlp_plan_destroy(p);
     return LDE_ERR_ALLOC;
   }
   (void)hipMemset(p->abort_flag, 0, 64);
+  p->fb_host[0] = 0;
   *out = p;
   return LDE_OK;
 }
@@ -1453,6 +1593,12 @@ void mlp_plan_destroy(MlpPlan* p) {
   if (p->abort_flag) (void)hipFree(p->abort_flag);
   if (p->slots) (void)hipFree(p->slots);
   if (p->slab) (void)hipFree(p->slab);
+  if (p->stage) (void)hipFree(p->stage);
+  if (p->wts) (void)hipFree(p->wts);
+  if (p->nslots) (void)hipFree(p->nslots);
+  if (p->fb_dev) (void)hipFree(p->fb_dev);
+  if (p->fb_host) (void)hipHostFree(p->fb_host);
+  if (p->fb_ev) (void)hipEventDestroy(p->fb_ev);
   delete p;
 }
 
@@ -1467,17 +1613,71 @@ int mlp_reserve(MlpPlan* p, int B, int T, std::string& err) {
     }
     p->cap_wg = nwg;
   }
-  const size_t need = (size_t)nwg * (size_t)p->dm.slab_n;
-  if (need > p->slab_cap) {
-    if (p->slab) (void)hipFree(p->slab);
-    p->slab = nullptr;
-    if (hipMalloc(&p->slab, need * sizeof(float)) != hipSuccess) {
-      err = "MLP plan: hipMalloc(slab) failed";
-      return LDE_ERR_ALLOC;
-    }
-    p->slab_cap = need;
-  }
   (void)T;
+  return LDE_OK;
+}
+
+// jobs of k_mlp_dw: per layer, groups of up to 8·ndw tiles
+static int dw_jobs(const MlpDims& dm, int ndw) {
+  int n = 0;
+  for (int l = 0; l < dm.nL; l++) n += cdiv(cdiv(dm.sizes[l], 32) * cdiv(dm.sizes[l + 1], 32), 8 * ndw);
+  return n;
+}
+static int dw_ndw(const MlpDims& dm) {
+  int mx = 0;
+  for (int l = 0; l < dm.nL; l++) mx = std::max(mx, cdiv(dm.sizes[l], 32) * cdiv(dm.sizes[l + 1], 32));
+  return mx <= 16 ? 2 : 8;
+}
+
+template <class T>
+static bool grow(T** ptr, size_t* cap, size_t need) {
+  if (need <= *cap) return true;
+  if (*ptr) (void)hipFree(*ptr);
+  *ptr = nullptr;
+  *cap = 0;
+  if (hipMalloc(ptr, need * sizeof(T)) != hipSuccess) return false;
+  *cap = need;
+  return true;
+}
+
+// Workspace of the adjoint for batches up to B with T save points. `steps_hint` > 0: step attempts known in advance
+// (fixed step size). Staging slots per workgroup: stages × (3 step attempts per save interval + 32) — doubled whenever
+// the previous call reported an overflow — bounded by a memory budget
+// (LDE_MLP_STAGE_MB, default 24 GiB of the 288); a workgroup that needs more folds its slots into its private slab
+// (slow but correct). LDE_MLP_STAGE_SLOTS forces the slot count (tests).
+int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::string& err) {
+  const MlpDims& dm = p->dm;
+  const int nwg = cdiv(B, NB);
+  const int nst = dm.solver == LDE_SOLVER_RK4 ? 4 : 6;
+  static const long budget_mb = [] { const char* e = getenv("LDE_MLP_STAGE_MB"); return e ? atol(e) : 24576L; }();
+  const char* sf = getenv("LDE_MLP_STAGE_SLOTS");   // read on every call: the tests switch it inside one process
+  const int slots_force = sf ? atoi(sf) : 0;
+  if (p->fb_pending) {
+    if (hipEventQuery(p->fb_ev) == hipSuccess) {
+      p->fb_pending = false;
+      if (p->fb_host[0] > 0 && p->cap_scale < 64) p->cap_scale *= 2;
+    } else
+      (void)hipGetLastError();   // hipErrorNotReady is not an error of the caller's
+  }
+  int64_t want = (int64_t)nst * (steps_hint > 0 ? steps_hint + 2 : p->cap_scale * (3 * (int64_t)(T > 1 ? T - 1 : 1) + 32));
+  const int64_t fit = ((int64_t)budget_mb << 20) / ((int64_t)nwg * dm.blk_floats * (int64_t)sizeof(float));
+  if (want > fit) want = fit;
+  if (slots_force > 0) want = slots_force;
+  if (want < nst) want = nst;
+  if (want > (1 << 24)) want = 1 << 24;
+  const int cap = (int)want;
+  const int ndw = dw_ndw(dm);
+  int ks = cdiv(768, nwg * dw_jobs(dm, ndw));
+  ks = ks < 1 ? 1 : (ks > 16 ? 16 : ks);
+  size_t nsl = (size_t)p->nslots_cap;
+  if (!grow(&p->stage, &p->stage_cap, (size_t)nwg * cap * dm.blk_floats) || !grow(&p->wts, &p->wts_cap, (size_t)nwg * cap * NB) ||
+      !grow(&p->slab, &p->slab_cap, (size_t)nwg * (1 + ks) * dm.slab_n) || !grow(&p->nslots, &nsl, (size_t)2 * nwg)) {
+    err = "MLP plan: hipMalloc of the adjoint workspace failed";
+    return LDE_ERR_ALLOC;
+  }
+  p->nslots_cap = (int)nsl;
+  p->adj_cap = cap;
+  p->adj_ks = ks;
   return LDE_OK;
 }
 
@@ -1504,7 +1704,7 @@ static size_t bwd_lds_fixed(const MlpDims& dm, int T, int nt) {
   const int NW = nt / 64;
   size_t b = (sizeof(Ctl) + 15) & ~size_t(15);
   b += ((size_t)T * 8 + 15) & ~size_t(15);
-  b += (size_t)(11 * NB * dm.ld_sb + dm.h_total + 2 * NB * dm.ld_h + NW * 256 + 2 * ((dm.nbias + 3) & ~3) + NB) * sizeof(float);
+  b += (size_t)(11 * NB * dm.ld_sb + dm.h_total + 2 * NB * dm.ld_h + NW * 256 + ((dm.nbias + 3) & ~3) + NB) * sizeof(float);
   return b;
 }
 
@@ -1562,26 +1762,34 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
   return LDE_OK;
 }
 
-template <int NDW, int SOLVER, int NT>
-static int launch_adjoint2(MlpPlan* p, const KOpts& o, const BwdArgs& a, int nwg, size_t lds, hipStream_t stream,
-                           std::string& err) {
+template <int SOLVER>
+static int launch_adjoint(MlpPlan* p, const KOpts& o, const BwdArgs& a, int nwg, size_t lds, hipStream_t stream,
+                          std::string& err) {
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_mlp_adjoint<NDW, SOLVER, NT>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)k_mlp_adjoint<SOLVER, 512>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             (int)LDS_MAX) != hipSuccess) {
       err = "hipFuncSetAttribute(k_mlp_adjoint) failed";
       return LDE_ERR_HIP;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_mlp_adjoint<NDW, SOLVER, NT>), dim3(nwg), dim3(NT), lds, stream, p->dm, o, a);
+  hipLaunchKernelGGL((k_mlp_adjoint<SOLVER, 512>), dim3(nwg), dim3(512), lds, stream, p->dm, o, a);
   return LDE_OK;
 }
-template <int NDW, int NT>
-static int launch_adjoint(MlpPlan* p, const KOpts& o, const BwdArgs& a, int nwg, size_t lds, hipStream_t stream,
-                          std::string& err) {
-  return p->dm.solver == LDE_SOLVER_RK4 ? launch_adjoint2<NDW, LDE_SOLVER_RK4, NT>(p, o, a, nwg, lds, stream, err)
-                                        : launch_adjoint2<NDW, LDE_SOLVER_TSIT5, NT>(p, o, a, nwg, lds, stream, err);
+
+template <int NDW>
+static int launch_dw(const MlpDims& dm, const DwArgs& a, dim3 grid, size_t lds, hipStream_t stream, std::string& err) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k_mlp_dw<NDW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
+      err = "hipFuncSetAttribute(k_mlp_dw) failed";
+      return LDE_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_mlp_dw<NDW>), grid, dim3(512), lds, stream, dm, a);
+  return LDE_OK;
 }
 
 int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float* theta, const double* ts_dev,
@@ -1594,20 +1802,20 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
     err = "coupled adaptive solve: batch per GPU limited to 4096 trajectories (one resident workgroup per CU)";
     return LDE_ERR_UNSUPPORTED;
   }
-  // 8 waves (2 per SIMD) when the weight-gradient tiles then fit 8 accumulator tiles per wave; else 4 waves × 16 tiles.
-  // Instantiations 2/3/6/8 exist because register spills are what hurts: measured on config 4, 6 tile slots (172 B of
-  // scratch per lane) 6.18 ms vs 3 slots (no scratch) 5.18 ms; config 2, 4 waves × 16 slots 8.45 ms vs 8 waves × 8 slots 6.52 ms.
-  const int ntiles_all = dm.tile_off[dm.nL];
-  static const int nt_force = [] { const char* e = getenv("LDE_MLP_ADJ_NT"); return e ? atoi(e) : 0; }();
-  const int nt = nt_force ? nt_force : (cdiv(ntiles_all, 8) <= 8 ? 512 : 256);
-  const size_t fixed = bwd_lds_fixed(dm, o.T, nt);
+  const size_t fixed = bwd_lds_fixed(dm, o.T, 512);
   if (fixed > LDS_MAX) {
     err = "MLP adjoint: tile state does not fit the 160 KiB LDS";
     return LDE_ERR_UNSUPPORTED;
   }
+  if (!p->stage || p->adj_cap < 1) {
+    err = "MLP adjoint: workspace not reserved";
+    return LDE_ERR_INVALID_ARG;
+  }
+  const int ks = p->adj_ks;
   BwdArgs a;
   a.z_out = z_out; a.dz_out = dz_out; a.theta = theta; a.ts = ts_dev; a.frag = p->frag; a.fragT = p->fragT; a.Wflat = W_dev;
   a.dz0 = dz0; a.dtheta = dtheta; a.slab = p->slab;
+  a.stage = p->stage; a.wts = p->wts; a.nslots = p->nslots; a.nflush = p->nslots + nwg; a.cap = p->adj_cap;
   a.st_nfe = nfe; a.st_nacc = nacc; a.st_nrej = nrej; a.st_ret = ret;
   a.gs.counter = p->counter; a.gs.slots = p->slots; a.gs.abort_flag = p->abort_flag; a.gs.nwg = sync ? nwg : 1;
   const size_t lds = with_cache(fixed, p->nfrag + p->nfragT);
@@ -1617,26 +1825,43 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
     err = "hipMemsetAsync(counter) failed";
     return LDE_ERR_HIP;
   }
-  const int per_wave = cdiv(ntiles_all, nt / 64);   // weight-gradient tiles held in each wave's accumulators
-  int rc;
-  if (nt == 512 && per_wave <= 2) rc = launch_adjoint<2, 512>(p, o, a, nwg, lds, stream, err);
-  else if (nt == 512 && per_wave <= 3) rc = launch_adjoint<3, 512>(p, o, a, nwg, lds, stream, err);
-  else if (nt == 512 && per_wave <= 6) rc = launch_adjoint<6, 512>(p, o, a, nwg, lds, stream, err);
-  else if (nt == 512 && per_wave <= 8) rc = launch_adjoint<8, 512>(p, o, a, nwg, lds, stream, err);
-  else if (per_wave <= 16) rc = launch_adjoint<16, 256>(p, o, a, nwg, lds, stream, err);
-  else {
-    err = "MLP adjoint: more than 64 32x32 weight-gradient tiles (hidden width too large for the register-resident accumulators)";
-    return LDE_ERR_UNSUPPORTED;
-  }
+  int rc = dm.solver == LDE_SOLVER_RK4 ? launch_adjoint<LDE_SOLVER_RK4>(p, o, a, nwg, lds, stream, err)
+                                       : launch_adjoint<LDE_SOLVER_TSIT5>(p, o, a, nwg, lds, stream, err);
   if (rc) return rc;
   if (hipGetLastError() != hipSuccess) {
     err = "k_mlp_adjoint launch failed";
     return LDE_ERR_HIP;
   }
-  hipLaunchKernelGGL(k_reduce_slabs, dim3(cdiv(dm.nW, 256)), dim3(256), 0, stream, p->slab, nwg, dm, dW);
+  // the weight gradient from the staged panels
+  DwArgs da;
+  da.stage = p->stage; da.wts = p->wts; da.nslots = p->nslots; da.slab = p->slab + (size_t)nwg * dm.slab_n; da.cap = p->adj_cap;
+  const int ndw = dw_ndw(dm);
+  int maxrows = 0;
+  for (int l = 0; l < dm.nL; l++)
+    maxrows = std::max(maxrows, ((((dm.sizes[l] + 31) & ~31) | 32) + (((dm.sizes[l + 1] + 31) & ~31) | 32)));
+  const size_t dlds = (size_t)NB * maxrows * sizeof(float);
+  if (dlds > LDS_MAX) {
+    err = "MLP adjoint: layer too wide for the weight-gradient kernel's LDS panels";
+    return LDE_ERR_UNSUPPORTED;
+  }
+  const dim3 grid(nwg, ks, dw_jobs(dm, ndw));
+  rc = ndw == 2 ? launch_dw<2>(dm, da, grid, dlds, stream, err) : launch_dw<8>(dm, da, grid, dlds, stream, err);
+  if (rc) return rc;
+  if (hipGetLastError() != hipSuccess) {
+    err = "k_mlp_dw launch failed";
+    return LDE_ERR_HIP;
+  }
+  hipLaunchKernelGGL(k_reduce_slabs, dim3(cdiv(dm.nW, 256)), dim3(256), 0, stream, p->slab, p->nslots + nwg, nwg,
+                     p->slab + (size_t)nwg * dm.slab_n, nwg * ks, dm, dW, p->fb_dev);
   if (hipGetLastError() != hipSuccess) {
     err = "k_reduce_slabs launch failed";
     return LDE_ERR_HIP;
+  }
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {   // not inside a hipGraph capture
+    if (hipMemcpyAsync(p->fb_host, p->fb_dev, sizeof(int32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&
+        hipEventRecord(p->fb_ev, stream) == hipSuccess)
+      p->fb_pending = true;
   }
   return LDE_OK;
 }

@@ -235,7 +235,7 @@ def test_augmented_tanh_adjoint_tight(o32, o64):
     assert np.abs(gW - tW).max() <= 1e-4 * np.abs(tW).max()
 
 
-def test_per_trajectory_rejections_exercise_the_replay_path(o32, o64):
+def test_per_trajectory_rejections_partial_acceptance(o32, o64):
     """A huge user-supplied initial dt forces rejected steps in some columns of a tile while others accept:
     the weight gradient must still equal the oracle's (accepted steps only)."""
     layers = (4, 32, 32, 4)
@@ -256,6 +256,52 @@ def test_per_trajectory_rejections_exercise_the_replay_path(o32, o64):
     assert np.abs(z - z64).max() <= 2e-5 * max(1, np.abs(z64).max())
     assert np.abs(g0 - t0).max() <= 2e-4 * np.abs(t0).max()
     assert np.abs(gW - tW).max() <= 2e-4 * np.abs(tW).max()
+
+
+@pytest.mark.parametrize("case", ["rk4_coupled", "tsit5_per_traj", "c3"])
+def test_staging_overflow_path_gives_the_same_gradient(case, monkeypatch):
+    """The adjoint stages (a_l, δ_l) panels in HBM and a second kernel forms dW. When a workgroup runs out of staging
+    slots it folds them into a private slab inside the solve kernel. Forcing a tiny staging area (2 step attempts) must
+    reproduce the gradient of the roomy run: dz0 bit-for-bit (the solve is untouched), dW up to summation order."""
+    if case == "rk4_coupled":
+        layers = (8, 200, 200, 8)
+        kw = dict(rhs_kind=O.RHS_MLP, state_dim=8, param_dim=0, layers=layers, solver=O.SOLVER_RK4, adaptive=0, dt=0.05,
+                  batching=O.BATCH_COUPLED)
+        B, D, T, nst = 40, 8, 20, 4
+    elif case == "tsit5_per_traj":
+        layers = (6, 40, 70, 6)
+        kw = dict(rhs_kind=O.RHS_MLP, state_dim=6, param_dim=0, layers=layers, activation=O.ACT_TANH, abstol=1e-6,
+                  reltol=1e-5, dt=0.5)   # dt=0.5: rejected first attempts, per-column accept/reject inside a tile
+        B, D, T, nst = 53, 6, 12, 6
+    else:
+        layers = (2, 64, 64, 2)
+        kw = dict(rhs_kind=O.RHS_PENDULUM_PLUS_MLP, layers=layers)
+        B, D, T, nst = 48, 2, 15, 6
+    W = O.mlp_weights(layers, seed=5)
+    ts = O.time_grid(T)
+    if case == "c3":
+        z0, L = O.pendulum_inputs(B)
+    else:
+        z0, L = _z0(B, D, seed=2), None
+    dz = O.cotangent(T, B, D)
+    res = []
+    for slots in (None, 2 * nst):
+        if slots is None:
+            monkeypatch.delenv("LDE_MLP_STAGE_SLOTS", raising=False)
+        else:
+            monkeypatch.setenv("LDE_MLP_STAGE_SLOTS", str(slots))
+        nat, _ = _native(W, **kw)
+        z, _, _ = nat.forward(z0, L, ts)
+        g0, gL, gW, st = nat.adjoint(z, L, ts, dz)
+        assert st["nfailed"] == 0 and st["naccept"] >= T - 1
+        res.append((g0, gL, gW, st))
+    (a0, aL, aW, ast), (b0, bL, bW, bst) = res
+    assert ast == bst
+    assert np.array_equal(a0, b0)
+    if aL is not None:
+        assert np.array_equal(aL, bL)
+    assert np.isfinite(aW).all() and np.abs(aW).max() > 0
+    assert np.abs(aW - bW).max() <= 2e-5 * np.abs(aW).max()
 
 
 def test_torch_api_latentode_trains_the_node_weights(o32, o64):

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, "liblde.so")
+# LDE_LIB_PATH: load another build of the same library (diagnostic / ablation builds made with -DLDE_ABL=n)
+LIB_PATH = os.environ.get("LDE_LIB_PATH") or os.path.join(HERE, "liblde.so")
 
 LDE_ABI_VERSION = 1
 LDE_MAX_LAYERS = 6

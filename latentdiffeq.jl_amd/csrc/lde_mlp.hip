@@ -36,6 +36,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <string>
 #include <vector>
@@ -58,6 +59,21 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   if (LDE_ABL == 2) { c[0] += a + b; return c; }
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
+
+// LDE_PROF builds (diagnostic): thread 0 of workgroup 0 accumulates s_memtime cycles per phase into g_prof[].
+//   0 stage combination   1 control / error norm / save   2+2l GEMM of layer l (to its last MFMA/epilogue)   3+2l barrier after it
+//   in the adjoint the backward layers follow at 2+2(nL+l'), and 30 = panel staging stores
+#ifndef LDE_PROF
+#define LDE_PROF 0
+#endif
+#if LDE_PROF
+__device__ long long g_prof[64];
+#define PROF_T(var) const long long var = (long long)__builtin_readcyclecounter()
+#define PROF_ADD(slot, t0, t1) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[slot] += (t1) - (t0); } while (0)
+#else
+#define PROF_T(var) do {} while (0)
+#define PROF_ADD(slot, t0, t1) do {} while (0)
+#endif
 
 // Static description of the RHS handed to the kernels by value.
 struct MlpDims {
@@ -126,79 +142,118 @@ __global__ void k_build_frags(const float* __restrict__ Wflat, MlpDims dm, float
 __device__ __forceinline__ float act_fn(int kind, float x) { return kind == LDE_ACT_TANH ? tanhf(x) : fmaxf(x, 0.f); }
 __device__ __forceinline__ float act_grad(int kind, float a) { return kind == LDE_ACT_TANH ? 1.f - a * a : (a > 0.f ? 1.f : 0.f); }
 
-// Y[R×16] = M[R×K]·X[K×16] for one workgroup. M as K4 fragments (LDS copy or global), X a transposed panel
+// One wave, one or two 16-row tiles, K-groups [k0,k1): software-pipelined through a PF-deep register ring (operands of
+// group k+PF are requested before the MFMAs of group k issue; indices past the end are clamped, not branched, so the
+// loop body stays straight-line and the s_waitcnt counters exact). Even/odd groups go to two accumulators.
+__device__ __forceinline__ void mfma4(const f32x4& a, const f32x4& b, f32x4& acc) {
+#pragma unroll
+  for (int s4 = 0; s4 < 4; s4++) acc = mfma16(a[s4], b[s4], acc);
+}
+
+template <int PF>
+__device__ __forceinline__ void mac1(const f32x4* A, const float* xp, int k0, int k1, f32x4& acc0, f32x4& acc1) {
+  if (k0 >= k1) return;
+  f32x4 ra[PF], rb[PF];
+  const int kl = k1 - 1;
+#pragma unroll
+  for (int i = 0; i < PF; i++) {
+    const int k = min(k0 + i, kl);
+    ra[i] = A[k * 64];
+    rb[i] = *reinterpret_cast<const f32x4*>(xp + k * 16);
+  }
+  int kg = k0;
+  for (; kg + PF <= k1; kg += PF) {
+#pragma unroll
+    for (int i = 0; i < PF; i++) {
+      const f32x4 ca = ra[i], cb = rb[i];
+      const int k = min(kg + i + PF, kl);
+      ra[i] = A[k * 64];
+      rb[i] = *reinterpret_cast<const f32x4*>(xp + k * 16);
+      mfma4(ca, cb, (i & 1) ? acc1 : acc0);
+    }
+  }
+  const int r = k1 - kg;
+#pragma unroll
+  for (int i = 0; i < PF - 1; i++)
+    if (i < r) mfma4(ra[i], rb[i], (i & 1) ? acc1 : acc0);
+}
+
+template <int PF>
+__device__ __forceinline__ void mac2(const f32x4* A0, const f32x4* A1, const float* xp, int k1, f32x4& acc0, f32x4& acc1) {
+  f32x4 r0[PF], r1[PF], rb[PF];
+  const int kl = k1 - 1;
+#pragma unroll
+  for (int i = 0; i < PF; i++) {
+    const int k = min(i, kl);
+    r0[i] = A0[k * 64];
+    r1[i] = A1[k * 64];
+    rb[i] = *reinterpret_cast<const f32x4*>(xp + k * 16);
+  }
+  int kg = 0;
+  for (; kg + PF <= k1; kg += PF) {
+#pragma unroll
+    for (int i = 0; i < PF; i++) {
+      const f32x4 c0 = r0[i], c1 = r1[i], cb = rb[i];
+      const int k = min(kg + i + PF, kl);
+      r0[i] = A0[k * 64];
+      r1[i] = A1[k * 64];
+      rb[i] = *reinterpret_cast<const f32x4*>(xp + k * 16);
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4++) {
+        acc0 = mfma16(c0[s4], cb[s4], acc0);
+        acc1 = mfma16(c1[s4], cb[s4], acc1);
+      }
+    }
+  }
+  const int r = k1 - kg;
+#pragma unroll
+  for (int i = 0; i < PF - 1; i++)
+    if (i < r) {
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4++) {
+        acc0 = mfma16(r0[i][s4], rb[i][s4], acc0);
+        acc1 = mfma16(r1[i][s4], rb[i][s4], acc1);
+      }
+    }
+}
+
+// Y[R×16] = M[R×K]·X[K×16] for one workgroup. M as K4 fragments (LDS copy, or global/L2 when GLB), X a transposed panel
 // (Xt[col*ldx + row], rows [0,K) starting at the pointer), EPI(row0, col, acc4) gets the 4 consecutive rows a lane owns.
-// `red` = 4 KiB LDS scratch for the split-K reduction of narrow layers.
-template <int NT, class Epi>
+// `red` = (NT/64)·1 KiB LDS scratch for the split-K reduction.
+//   more row tiles than waves : a wave takes tiles rt, rt + NW (two accumulators = the two tiles), then leftovers singly
+//   3 ≤ tiles ≤ NW            : one tile per wave (two accumulators = even/odd K-groups)
+//   1–2 tiles                 : K split over NW/tiles waves per tile, partial sums reduced through LDS
+template <int NT, bool GLB, class Epi>
 __device__ __forceinline__ void panel_gemm(const float* frag, int R, int K, const float* Xt, int ldx, float* red, Epi epi) {
   if (LDE_ABL == 1) return;   // diagnostic build: no GEMM at all
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  constexpr int NW = NT / 64;
+  constexpr int PF1 = GLB ? 6 : 2, PF2 = GLB ? 4 : 2;   // L2 latency ≈ 5 K-groups of MFMA time; LDS ≈ 1
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // uniform ⇒ scalar loop control below
   const int RT = cdiv(R, 16), KG = cdiv(K, 16);
-  const f32x4* A = reinterpret_cast<const f32x4*>(frag);
+  const f32x4* A = reinterpret_cast<const f32x4*>(frag) + lane;
   const float* xp = Xt + (lane & 15) * ldx + 4 * (lane >> 4);
   const int col = lane & 15, rsub = 4 * (lane >> 4);
-  if (RT >= 3 || RT > (NT / 64) / 2) {
-    for (int rt = wave; rt < RT; rt += 2 * (NT / 64)) {
-      const int rt2 = rt + (NT / 64);
-      const bool two = rt2 < RT;
+  if (RT >= 3 || 2 * RT > NW) {   // (splitting K for 3–4 row tiles was measured slower: the reduction's extra barrier)
+    for (int rt = wave; rt < RT; rt += 2 * NW) {
+      const int rt2 = rt + NW;
       f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-      const f32x4* a0p = A + (size_t)rt * KG * 64 + lane;
-      if (two) {
-        const f32x4* a1p = A + (size_t)rt2 * KG * 64 + lane;
-        f32x4 a0 = a0p[0], a1 = a1p[0], b = *reinterpret_cast<const f32x4*>(xp);
-        for (int kg = 0; kg < KG; kg++) {
-          const f32x4 ca0 = a0, ca1 = a1, cb = b;
-          if (kg + 1 < KG) {
-            a0 = a0p[(kg + 1) * 64];
-            a1 = a1p[(kg + 1) * 64];
-            b = *reinterpret_cast<const f32x4*>(xp + (kg + 1) * 16);
-          }
-#pragma unroll
-          for (int s4 = 0; s4 < 4; s4++) {
-            acc0 = mfma16(ca0[s4], cb[s4], acc0);
-            acc1 = mfma16(ca1[s4], cb[s4], acc1);
-          }
-        }
+      if (rt2 < RT) {
+        mac2<PF2>(A + (size_t)rt * KG * 64, A + (size_t)rt2 * KG * 64, xp, KG, acc0, acc1);
         if (LDE_ABL != 3) epi(rt * 16 + rsub, col, acc0);
         if (LDE_ABL != 3) epi(rt2 * 16 + rsub, col, acc1);
-      } else {  // one tile: even/odd K-groups on two accumulators
-        for (int kg = 0; kg < KG; kg += 2) {
-          const f32x4 a0 = a0p[kg * 64], b0 = *reinterpret_cast<const f32x4*>(xp + kg * 16);
-          const bool has1 = kg + 1 < KG;
-          f32x4 a1 = a0, b1 = b0;
-          if (has1) {
-            a1 = a0p[(kg + 1) * 64];
-            b1 = *reinterpret_cast<const f32x4*>(xp + (kg + 1) * 16);
-          }
-#pragma unroll
-          for (int s4 = 0; s4 < 4; s4++) {
-            acc0 = mfma16(a0[s4], b0[s4], acc0);
-            if (has1) acc1 = mfma16(a1[s4], b1[s4], acc1);
-          }
-        }
+      } else {
+        mac1<PF1>(A + (size_t)rt * KG * 64, xp, 0, KG, acc0, acc1);
         if (LDE_ABL != 3) epi(rt * 16 + rsub, col, acc0 + acc1);
       }
     }
   } else {
-    // narrow layer (1 or 2 row tiles): split K over the waves, reduce through LDS
-    const int nparts = (NT / 64) / RT;
+    const int nparts = NW / RT;
     const int rt = wave % RT, part = wave / RT;
-    const int per = cdiv(KG, nparts), k0 = part * per, k1 = min(KG, k0 + per);
     f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
-    const f32x4* a0p = A + (size_t)rt * KG * 64 + lane;
-    for (int kg = k0; kg < k1; kg += 2) {
-      const f32x4 a0 = a0p[kg * 64], b0 = *reinterpret_cast<const f32x4*>(xp + kg * 16);
-      const bool has1 = kg + 1 < k1;
-      f32x4 a1 = a0, b1 = b0;
-      if (has1) {
-        a1 = a0p[(kg + 1) * 64];
-        b1 = *reinterpret_cast<const f32x4*>(xp + (kg + 1) * 16);
-      }
-#pragma unroll
-      for (int s4 = 0; s4 < 4; s4++) {
-        acc0 = mfma16(a0[s4], b0[s4], acc0);
-        if (has1) acc1 = mfma16(a1[s4], b1[s4], acc1);
-      }
+    if (part < nparts) {
+      const int per = cdiv(KG, nparts), k0 = part * per, k1 = min(KG, k0 + per);
+      mac1<PF1>(A + (size_t)rt * KG * 64, xp, k0, k1, acc0, acc1);
     }
     f32x4* rp = reinterpret_cast<f32x4*>(red);
     rp[wave * 64 + lane] = acc0 + acc1;
@@ -216,8 +271,8 @@ __device__ __forceinline__ void panel_gemm(const float* frag, int R, int K, cons
 template <int NT, class Epi>
 __device__ __forceinline__ void layer_gemm(const float* lds_base, int ofs, const float* gfrag, int R, int K, const float* Xt,
                                            int ldx, float* red, Epi epi) {
-  if (ofs >= 0) panel_gemm<NT>(lds_base + ofs, R, K, Xt, ldx, red, epi);
-  else panel_gemm<NT>(gfrag, R, K, Xt, ldx, red, epi);
+  if (ofs >= 0) panel_gemm<NT, false>(lds_base + ofs, R, K, Xt, ldx, red, epi);
+  else panel_gemm<NT, true>(gfrag, R, K, Xt, ldx, red, epi);
 }
 
 // ---- grid-wide deterministic sum (coupled mode) ----------------------------------------------------
@@ -345,6 +400,7 @@ __device__ __forceinline__ void eval_rhs(const MlpDims& dm, const Panels& P, con
     const int ldy = lastl ? P.lds : dm.ld_hl[l];
     const float* bias = P.biasc + dm.bias_lin[l];
     const int actk = dm.act;
+    PROF_T(pt0);
     layer_gemm<NT>(P.lbase, c->wofs[l], P.gfrag + dm.frag_off[l], out, in, X, ldx, P.red, [&](int row0, int col, f32x4 v) {
       f32x4 r;
       if (row0 + 3 < out) {   // whole group of 4 rows inside the layer: vector bias load, no per-row selects
@@ -368,7 +424,11 @@ __device__ __forceinline__ void eval_rhs(const MlpDims& dm, const Panels& P, con
       } else
         *reinterpret_cast<f32x4*>(Y + col * ldy + row0) = r;
     });
+    PROF_T(pt1);
     __syncthreads();
+    PROF_T(pt2);
+    PROF_ADD(2 + 2 * l, pt0, pt1);
+    PROF_ADD(3 + 2 * l, pt1, pt2);
     X = Y;
     ldx = ldy;
   }
@@ -515,6 +575,7 @@ __global__ void __launch_bounds__(NT) k_mlp_forward(MlpDims dm, KOpts o, FwdArgs
   int phase = PH_K0, s = 0;
   bool running = T > 1;
   while (running) {
+    PROF_T(pl0);
     // ---- input of this evaluation ---------------------------------------------------------------------------
     const float* src = P.y;
     if (phase == PH_INIT1) src = P.tmp;
@@ -543,8 +604,15 @@ __global__ void __launch_bounds__(NT) k_mlp_forward(MlpDims dm, KOpts o, FwdArgs
     }
     float* dst = phase == PH_K0 ? P.k(0) : (phase == PH_INIT1 ? P.k(1) : P.k(s));
 
+    PROF_T(pl1);
+    PROF_ADD(0, pl0, pl1);
     eval_rhs<NT>(dm, P, c, src, dst);
     if (tid < NB && c->status[tid] == 0) c->nfe[tid]++;
+    PROF_T(pl2);
+    PROF_ADD(40, pl1, pl2);
+#if LDE_PROF
+    struct ProfEnd { long long t0; __device__ ~ProfEnd() { PROF_T(t1); PROF_ADD(1, t0, t1); } } prof_end{pl2};
+#endif
 
     // ---- what follows the evaluation ---------------------------------------------------------------------------
     if (phase == PH_K0) {
@@ -824,6 +892,7 @@ __device__ __forceinline__ void eval_bwd(const MlpDims& dm, const Panels& P, con
     const int in = dm.sizes[l], out = dm.sizes[l + 1];
     const float* al = l == 0 ? src : P.hid(l - 1);   // input activation of layer l
     const int lda = l == 0 ? P.lds : dm.ld_hl[l - 1];
+    PROF_T(ps0);
     if (blk && LDE_ABL != 4) {
       // stage a_l rows [0,in32) and δ_l rows [0,out32) of the 16 columns: one half-wave per column, 512 contiguous bytes
       // per store instruction. Pad rows are whatever follows in the panel (finite): they only reach pad rows of gWᵀ tiles.
@@ -836,6 +905,8 @@ __device__ __forceinline__ void eval_bwd(const MlpDims& dm, const Panels& P, con
       for (int r4 = l31; 4 * r4 < out32; r4 += 32)
         *reinterpret_cast<f32x4*>(gd + col * out32 + 4 * r4) = *reinterpret_cast<const f32x4*>(dl + col * ldd + 4 * r4);
     }
+    PROF_T(ps1);
+    PROF_ADD(30, ps0, ps1);
     // δ_in = W_lᵀ δ  (⊙ act'(a_l) for hidden layers); layer 0 gives (∂f/∂z)ᵀλ
     if (l > 0) {
       float* dn = P.del((nL - 1 - l) & 1);
@@ -847,7 +918,11 @@ __device__ __forceinline__ void eval_bwd(const MlpDims& dm, const Panels& P, con
         for (int q = 0; q < 4; q++) r[q] = row0 + q < in ? v[q] * act_grad(actk, av[q]) : 0.f;
         *reinterpret_cast<f32x4*>(dn + col * ldh + row0) = r;
       });
+      PROF_T(ps2);
       __syncthreads();
+      PROF_T(ps3);
+      PROF_ADD(16 + 2 * l, ps1, ps2);
+      PROF_ADD(17 + 2 * l, ps2, ps3);
       dl = dn;
       ldd = ldh;
     } else {
@@ -862,7 +937,11 @@ __device__ __forceinline__ void eval_bwd(const MlpDims& dm, const Panels& P, con
             if (row0 + q < in) dlam[col * lds + row0 + q] = -v[q];
         }
       });
+      PROF_T(ps2);
       __syncthreads();
+      PROF_T(ps3);
+      PROF_ADD(16, ps1, ps2);
+      PROF_ADD(17, ps2, ps3);
     }
   }
   // 3. known-physics part: J = [[0,1],[ngl·cos x, 0]], ∂f₂/∂L = gl2·sin x
@@ -1073,6 +1152,7 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
     running = begin_step();
   }
   while (running) {
+    PROF_T(pl0);
     // ---- input of this evaluation + this stage's quadrature weights ------------------------------------------------
     const float* src = P.y;
     bool any_w = false;
@@ -1115,8 +1195,15 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
     }
     float* dst = phase == PH_K0 ? P.k(0) : (phase == PH_INIT1 ? P.k(1) : P.k(s));
 
+    PROF_T(pl1);
+    PROF_ADD(0, pl0, pl1);
     eval_bwd<NT>(dm, P, c, src, dst, any_w ? my_stage + (size_t)(slot_base + s) * dm.blk_floats : nullptr);
     if (tid < NB && c->status[tid] == 0) c->nfe[tid]++;
+    PROF_T(pl2);
+    PROF_ADD(40, pl1, pl2);
+#if LDE_PROF
+    struct ProfEnd { long long t0; __device__ ~ProfEnd() { PROF_T(t1); PROF_ADD(1, t0, t1); } } prof_end{pl2};
+#endif
 
     // ---- what follows the evaluation -----------------------------------------------------------------------------
     if (phase == PH_K0) {
@@ -1692,6 +1779,24 @@ int mlp_set_weights(MlpPlan* p, const float* W_dev, hipStream_t stream, std::str
 
 static constexpr size_t LDS_MAX = 160 * 1024;
 
+#if LDE_PROF
+static void prof_reset() {
+  long long z[64] = {0};
+  (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z));
+}
+static void prof_dump(const char* what, hipStream_t stream) {
+  static int calls = 0;
+  (void)hipStreamSynchronize(stream);
+  long long v[64];
+  (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(g_prof), sizeof(v));
+  if (++calls % 20 != 0) return;   // a few samples are enough
+  fprintf(stderr, "[prof %s] cycles(100MHz ticks):", what);
+  for (int i = 0; i < 64; i++)
+    if (v[i]) fprintf(stderr, " %d:%lld", i, v[i]);
+  fprintf(stderr, "\n");
+}
+#endif
+
 static size_t fwd_lds_fixed(const MlpDims& dm, int T, int nt) {
   const int NW = nt / 64;
   size_t b = (sizeof(Ctl) + 15) & ~size_t(15);
@@ -1753,8 +1858,14 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
     err = "hipMemsetAsync(counter) failed";
     return LDE_ERR_HIP;
   }
+#if LDE_PROF
+  prof_reset();
+#endif
   if (rk4) hipLaunchKernelGGL((k_mlp_forward<LDE_SOLVER_RK4, NTF>), dim3(nwg), dim3(NTF), lds, stream, dm, o, a);
   else hipLaunchKernelGGL((k_mlp_forward<LDE_SOLVER_TSIT5, NTF>), dim3(nwg), dim3(NTF), lds, stream, dm, o, a);
+#if LDE_PROF
+  prof_dump("forward", stream);
+#endif
   if (hipGetLastError() != hipSuccess) {
     err = "k_mlp_forward launch failed";
     return LDE_ERR_HIP;
@@ -1825,8 +1936,14 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
     err = "hipMemsetAsync(counter) failed";
     return LDE_ERR_HIP;
   }
+#if LDE_PROF
+  prof_reset();
+#endif
   int rc = dm.solver == LDE_SOLVER_RK4 ? launch_adjoint<LDE_SOLVER_RK4>(p, o, a, nwg, lds, stream, err)
                                        : launch_adjoint<LDE_SOLVER_TSIT5>(p, o, a, nwg, lds, stream, err);
+#if LDE_PROF
+  prof_dump("adjoint", stream);
+#endif
   if (rc) return rc;
   if (hipGetLastError() != hipSuccess) {
     err = "k_mlp_adjoint launch failed";

@@ -185,6 +185,55 @@ int lde_get_stats(lde_handle* h, int which, lde_stats* out, void* stream);
 /* Human-readable text for the last error on this handle (never NULL). */
 const char* lde_last_error(const lde_handle* h);
 
+
+/* ======================================================================================================
+ * Dense chains either side of the solve — scope row f-1: what runs under
+ *
+ *     l̂ = apply_latent_out(decoder, l̃)         [REF src/models/GOKU.jl:83-91], [REF src/models/LatentODE.jl:53]
+ *     x̂ = apply_reconstructor(decoder, ẑ)       [REF src/models/GOKU.jl:148],   [REF src/models/LatentODE.jl:80]
+ *
+ * i.e. a Flux `Chain` of `Dense(in, out, act)` layers, each optionally wrapped in `SkipConnection(·, +)`, applied
+ * column-wise: the default layers are  lo_z₀ = Chain(Dense(16,200,relu), Dense(200,D)),
+ * lo_θ = Chain(Dense(16,200,relu), Dense(200,P,softplus)),
+ * reconstructor = Chain(Dense(D,200,relu), Skip(Dense(200,200,relu)), Skip(Dense(200,200,relu)), Dense(200,784,σ))
+ *                                                                  [REF src/models/GOKU.jl:252-269]
+ * A Flux Dense on a [D×B×T] array acts on the first dimension, so the reconstructor consumes lde_forward's z_out
+ * in place as x [D' × N], N = B·T, and produces x̂ [784 × B × T] in the reference's layout.
+ *  - x, y, dy, dx are DEVICE pointers, column-major [rows × N] (rows fastest).
+ *  - flat weights: Flux.destructure order of the Chain — per Dense vec(W) (column-major [out×in]) then b.
+ *  - lde_chain_backward recomputes the hidden activations from x (nothing is kept from the forward call); it takes
+ *    the forward OUTPUT y so that the last (widest) layer is not recomputed.
+ */
+#define LDE_CHAIN_MAX_LAYERS 6
+
+enum lde_chain_activation {
+  LDE_CACT_IDENTITY = 0, LDE_CACT_RELU = 1, LDE_CACT_TANH = 2, LDE_CACT_SIGMOID = 3, LDE_CACT_SOFTPLUS = 4
+};
+
+typedef struct lde_chain_desc {
+  int32_t abi_version;                           /* = LDE_ABI_VERSION */
+  int32_t n_layers;                              /* Dense layers, 1..LDE_CHAIN_MAX_LAYERS */
+  int32_t sizes[LDE_CHAIN_MAX_LAYERS + 1];       /* [in, h1, ..., out] */
+  int32_t activation[LDE_CHAIN_MAX_LAYERS];      /* lde_chain_activation of each layer */
+  int32_t skip[LDE_CHAIN_MAX_LAYERS];            /* 1: SkipConnection(Dense, +): y = x + act(Wx+b); needs in == out; not on the last layer */
+} lde_chain_desc;
+
+typedef struct lde_chain lde_chain;
+
+int64_t lde_chain_num_weights(const lde_chain_desc* desc);
+int  lde_chain_create(const lde_chain_desc* desc, lde_chain** out);
+void lde_chain_destroy(lde_chain* c);
+int  lde_chain_set_weights(lde_chain* c, const float* flat_host, int64_t n);
+int  lde_chain_set_weights_device(lde_chain* c, const float* flat_dev, int64_t n, void* stream);
+/* Pre-size the workspace for up to N columns (the backward pass stages its activations / deltas in HBM). */
+int  lde_chain_reserve(lde_chain* c, int64_t N);
+/* y[out×N] = chain(x[in×N]). */
+int  lde_chain_forward(lde_chain* c, const float* x, int64_t N, float* y, void* stream);
+/* Pullback: dx[in×N] (written; may be NULL when the input needs no gradient), dW[n_weights] ACCUMULATED (+=). */
+int  lde_chain_backward(lde_chain* c, const float* x, const float* y, const float* dy, int64_t N,
+                        float* dx, float* dW, void* stream);
+const char* lde_chain_last_error(const lde_chain* c);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,6 +6,7 @@ Layout:
   _lib.py    ctypes binding of liblde.so (no fallback: raises if the library is missing)
   api.py     host-side mirror of the reference interface: Pendulum / Pendulum_friction / NODE,
              GOKU_basic / LatentODE, Decoder, diffeq_layer, transform_after_diffeq
+  chain.py   Dense / SkipConnection / Chain, apply_latent_out, apply_reconstructor (the dense chains either side of the solve)
   dist.py    one-process-per-GPU batch sharding + the single gradient all-reduce (RCCL / gloo)
 """
 from .build import build_lib  # noqa: F401
@@ -14,7 +15,12 @@ from .build import build_lib  # noqa: F401
 def __getattr__(name):  # lazy: importing the package must not need torch or the built library
     import importlib
 
-    for mod in ("api", "dist"):
+    if name.startswith("_"):   # `from . import _lib` inside a submodule: a plain submodule import, not an API name
+        try:
+            return importlib.import_module(f"{__name__}.{name}")
+        except ModuleNotFoundError:
+            raise AttributeError(name) from None
+    for mod in ("api", "dist", "chain"):
         try:
             m = importlib.import_module(f"{__name__}.{mod}")
         except ModuleNotFoundError:

@@ -27,7 +27,20 @@ STATUS = {0: "LDE_OK", -1: "LDE_ERR_INVALID_ARG", -2: "LDE_ERR_UNSUPPORTED", -3:
 # every symbol include/lde.h declares
 EXPORTS = ["lde_abi_version", "lde_problem_desc_default", "lde_num_weights", "lde_create", "lde_destroy",
            "lde_set_weights", "lde_set_weights_device", "lde_reserve", "lde_forward", "lde_adjoint",
-           "lde_get_stats", "lde_last_error"]
+           "lde_get_stats", "lde_last_error",
+           "lde_chain_num_weights", "lde_chain_create", "lde_chain_destroy", "lde_chain_set_weights",
+           "lde_chain_set_weights_device", "lde_chain_reserve", "lde_chain_forward", "lde_chain_backward",
+           "lde_chain_last_error"]
+
+LDE_CHAIN_MAX_LAYERS = 6
+CACT_IDENTITY, CACT_RELU, CACT_TANH, CACT_SIGMOID, CACT_SOFTPLUS = 0, 1, 2, 3, 4
+
+
+class ChainDesc(C.Structure):
+    """lde_chain_desc (include/lde.h)."""
+
+    _fields_ = [("abi_version", C.c_int32), ("n_layers", C.c_int32), ("sizes", C.c_int32 * (LDE_CHAIN_MAX_LAYERS + 1)),
+                ("activation", C.c_int32 * LDE_CHAIN_MAX_LAYERS), ("skip", C.c_int32 * LDE_CHAIN_MAX_LAYERS)]
 
 
 class ProblemDesc(C.Structure):
@@ -82,18 +95,30 @@ def load():
     lib.lde_get_stats.argtypes = [vp, i32, C.POINTER(Stats), vp]
     lib.lde_last_error.argtypes = [vp]
     lib.lde_last_error.restype = C.c_char_p
+    lib.lde_chain_num_weights.argtypes = [C.POINTER(ChainDesc)]
+    lib.lde_chain_num_weights.restype = i64
+    lib.lde_chain_create.argtypes = [C.POINTER(ChainDesc), C.POINTER(vp)]
+    lib.lde_chain_destroy.argtypes = [vp]
+    lib.lde_chain_destroy.restype = None
+    lib.lde_chain_set_weights.argtypes = [vp, vp, i64]
+    lib.lde_chain_set_weights_device.argtypes = [vp, vp, i64, vp]
+    lib.lde_chain_reserve.argtypes = [vp, i64]
+    lib.lde_chain_forward.argtypes = [vp, vp, i64, vp, vp]
+    lib.lde_chain_backward.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp]
+    lib.lde_chain_last_error.argtypes = [vp]
+    lib.lde_chain_last_error.restype = C.c_char_p
     if lib.lde_abi_version() != LDE_ABI_VERSION:
         raise LdeError("liblde.so ABI version mismatch — rebuild")
     _lib = lib
     return lib
 
 
-def check(rc: int, handle=None, what: str = ""):
+def check(rc: int, handle=None, what: str = "", chain: bool = False):
     if rc == 0:
         return
     msg = STATUS.get(rc, str(rc))
     if handle is not None and _lib is not None:
-        detail = _lib.lde_last_error(handle)
+        detail = (_lib.lde_chain_last_error if chain else _lib.lde_last_error)(handle)
         if detail:
             msg += ": " + detail.decode()
     raise LdeError(f"{what} failed: {msg}")

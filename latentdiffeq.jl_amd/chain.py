@@ -1,0 +1,215 @@
+"""Host-side mirror of the dense chains either side of the solve (scope row f-1):
+
+    reference                                                                      here
+    -----------------------------------------------------------------------------  ---------------------------------
+    Dense(in, out, act; init)                        [Flux; REF GOKU.jl:252-266]    Dense(in, out, act)
+    SkipConnection(Dense(...), +)                    [REF GOKU.jl:262-263]          SkipConnection(Dense(...))
+    Chain(l1, SkipConnection(l2,+), ...)             [REF GOKU.jl:252-266]          Chain(l1, SkipConnection(l2), ...)
+    apply_latent_out(decoder, l̃)                     [REF GOKU.jl:83-91], [REF LatentODE.jl:53]   same
+    apply_reconstructor(decoder, ẑ)                  [REF GOKU.jl:148], [REF LatentODE.jl:80]     same
+    decoder(l̃, t) → (x̂, ẑ, l̂)                       [REF LatentDiffEqModel.jl:101-113]           decode(decoder, l̃, t)
+    default_layers(GOKU_basic(), input_dim, diffeq)  [REF GOKU.jl:201-273] (decoder part)         default_decoder_layers
+
+Everything under `Chain.__call__` is liblde.so (lde_chain_forward / lde_chain_backward, include/lde.h). Arrays keep the
+reference's shapes ([rows, B] or [rows, B, T]); their memory is the reference's column-major layout, i.e. transposed
+views of batch-major torch buffers, exactly like `diffeq_layer` (api.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Sequence
+
+import torch
+
+from . import _lib as L
+from .api import GOKU, LatentODE, Decoder, diffeq_layer
+
+_ACT = {"identity": L.CACT_IDENTITY, "relu": L.CACT_RELU, "tanh": L.CACT_TANH, "sigmoid": L.CACT_SIGMOID, "σ": L.CACT_SIGMOID,
+        "softplus": L.CACT_SOFTPLUS}
+
+
+class Dense(torch.nn.Module):
+    """Dense(in, out, act): y = act.(W*x .+ b). Default init = Flux.kaiming_uniform(gain = 1/√3) ⇒ U(±1/√fan_in),
+    zero bias  [REF src/models/GOKU.jl:204]."""
+
+    def __init__(self, n_in: int, n_out: int, act: str = "identity"):
+        super().__init__()
+        if act not in _ACT:
+            raise ValueError(f"unknown activation {act!r}")
+        self.n_in, self.n_out, self.act = n_in, n_out, act
+        bound = 1.0 / math.sqrt(n_in)
+        self.weight = torch.nn.Parameter(torch.empty(n_out, n_in).uniform_(-bound, bound))
+        self.bias = torch.nn.Parameter(torch.zeros(n_out))
+
+
+class SkipConnection(torch.nn.Module):
+    """SkipConnection(layer, +): y = layer(x) + x  [REF src/models/GOKU.jl:262-263]."""
+
+    def __init__(self, layer: Dense):
+        super().__init__()
+        if layer.n_in != layer.n_out:
+            raise ValueError("SkipConnection(+) needs in == out")
+        self.layer = layer
+
+
+class _ChainFn(torch.autograd.Function):
+    """y = chain(x) on batch-major buffers: x (N, in) → y (N, out); backward = lde_chain_backward."""
+
+    @staticmethod
+    def forward(ctx, chain: "Chain", x: torch.Tensor, W: torch.Tensor):
+        if not x.is_cuda:
+            raise L.LdeError("Chain needs CUDA/HIP tensors: it runs on the GPU only (no CPU fallback)")
+        h = chain._native()
+        lib = chain._lib
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        Wc = W.detach().contiguous().float()
+        L.check(lib.lde_chain_set_weights_device(h, C.c_void_p(Wc.data_ptr()), Wc.numel(), stream), h,
+                "lde_chain_set_weights_device", chain=True)
+        N = x.shape[0]
+        y = torch.empty((N, chain.sizes[-1]), device=x.device, dtype=torch.float32)
+        L.check(lib.lde_chain_forward(h, C.c_void_p(x.data_ptr()), N, C.c_void_p(y.data_ptr()), stream), h,
+                "lde_chain_forward", chain=True)
+        ctx.chain = chain
+        ctx.need_dx = x.requires_grad
+        ctx.save_for_backward(x, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        chain = ctx.chain
+        h = chain._native()
+        lib = chain._lib
+        x, y = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        dx = torch.empty_like(x) if ctx.need_dx else None
+        dW = torch.zeros((chain.num_weights,), device=x.device, dtype=torch.float32)
+        L.check(lib.lde_chain_backward(h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(dy.data_ptr()),
+                                       x.shape[0], C.c_void_p(dx.data_ptr()) if dx is not None else C.c_void_p(),
+                                       C.c_void_p(dW.data_ptr()), stream), h, "lde_chain_backward", chain=True)
+        return None, dx, dW
+
+
+class Chain(torch.nn.Module):
+    """Chain(layers...) of Dense / SkipConnection(Dense) applied to the first dimension of x ([in, B] or [in, B, T])."""
+
+    def __init__(self, *layers):
+        super().__init__()
+        self.layers = torch.nn.ModuleList(layers)
+        dense = [l.layer if isinstance(l, SkipConnection) else l for l in layers]
+        if not dense or not all(isinstance(d, Dense) for d in dense):
+            raise TypeError("Chain takes Dense and SkipConnection(Dense) layers")
+        for a, b in zip(dense[:-1], dense[1:]):
+            if a.n_out != b.n_in:
+                raise ValueError("layer sizes do not chain")
+        self._dense = dense
+        self.sizes = [dense[0].n_in] + [d.n_out for d in dense]
+        self.acts = [_ACT[d.act] for d in dense]
+        self.skips = [int(isinstance(l, SkipConnection)) for l in layers]
+        self.num_weights = sum(d.n_in * d.n_out + d.n_out for d in dense)
+        self._handle = None
+        self._lib = None
+
+    def _native(self):
+        if self._handle is None:
+            self._lib = L.load()
+            d = L.ChainDesc()
+            d.abi_version = L.LDE_ABI_VERSION
+            d.n_layers = len(self._dense)
+            for i, s in enumerate(self.sizes):
+                d.sizes[i] = s
+            for i, (a, k) in enumerate(zip(self.acts, self.skips)):
+                d.activation[i], d.skip[i] = a, k
+            h = C.c_void_p()
+            rc = self._lib.lde_chain_create(C.byref(d), C.byref(h))
+            if rc != 0:
+                try:
+                    L.check(rc, h if h else None, "lde_chain_create", chain=True)
+                finally:
+                    if h:
+                        self._lib.lde_chain_destroy(h)
+            self._handle = h
+        return self._handle
+
+    def __del__(self):
+        try:
+            if self._handle is not None and self._lib is not None:
+                self._lib.lde_chain_destroy(self._handle)
+        except Exception:
+            pass
+
+    def flat_weights(self) -> torch.Tensor:
+        """Flux.destructure order: per Dense vec(W) column-major [out×in], then b."""
+        parts = []
+        for d in self._dense:
+            parts.append(d.weight.t().reshape(-1))
+            parts.append(d.bias)
+        return torch.cat(parts).float()
+
+    def apply_batch_major(self, x_N_in: torch.Tensor) -> torch.Tensor:
+        """x (N, in) contiguous → y (N, out). Differentiable wrt x and the layers' parameters."""
+        return _ChainFn.apply(self, x_N_in.contiguous().float(), self.flat_weights())
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x [in, B] → [out, B];  x [in, B, T] → [out, B, T] (a Flux Dense acts on the first dimension)."""
+        if x.dim() == 2:
+            return self.apply_batch_major(x.t()).t()
+        if x.dim() == 3:
+            n_in, B, T = x.shape
+            buf = x.permute(2, 1, 0)                          # (T, B, in): contiguous when x came from diffeq_layer
+            y = self.apply_batch_major(buf.reshape(T * B, n_in))
+            return y.reshape(T, B, -1).permute(2, 1, 0)
+        raise ValueError("Chain takes [in, B] or [in, B, T] arrays")
+
+
+def apply_latent_out(decoder: Decoder, l_tilde):
+    """l̂ = apply_latent_out(decoder, l̃)  [REF src/models/GOKU.jl:83-91], [REF src/models/LatentODE.jl:53]."""
+    if isinstance(decoder.model_type, GOKU):
+        z0_t, th_t = l_tilde
+        lo_z0, lo_th = decoder.latent_out
+        return lo_z0(z0_t), lo_th(th_t)
+    if isinstance(decoder.model_type, LatentODE):
+        return decoder.latent_out(l_tilde)
+    raise TypeError(f"no apply_latent_out method for model type {type(decoder.model_type).__name__}")
+
+
+def apply_reconstructor(decoder: Decoder, z_hat: torch.Tensor) -> torch.Tensor:
+    """x̂ = decoder.reconstructor(ẑ)  [REF src/models/GOKU.jl:148], [REF src/models/LatentODE.jl:80]."""
+    return decoder.reconstructor(z_hat)
+
+
+def decode(decoder: Decoder, l_tilde, t):
+    """(x̂, ẑ, l̂) = decoder(l̃, t)  [REF src/models/LatentDiffEqModel.jl:101-113]."""
+    l_hat = apply_latent_out(decoder, l_tilde)
+    z_hat = diffeq_layer(decoder, l_hat, t)
+    x_hat = apply_reconstructor(decoder, z_hat)
+    return x_hat, z_hat, l_hat
+
+
+def default_decoder_layers(model_type, input_dim: int, diffeq, hidden_dim_resnet: int = 200, latent_dim_z0: int = 16,
+                           latent_dim_theta: int = 16, latent_to_diffeq_dim: int = 200, z0_activation: str = "identity",
+                           theta_activation: str = "softplus", output_activation: str = "sigmoid", device=None):
+    """The decoder half of default_layers  [REF src/models/GOKU.jl:247-271], [REF src/models/LatentODE.jl:130-142]:
+    (latent_out, diffeq, reconstructor)."""
+    if isinstance(model_type, GOKU):
+        z_dim, th_dim = len(diffeq.prob.u0), len(diffeq.prob.p)
+        lo_z0 = Chain(Dense(latent_dim_z0, latent_to_diffeq_dim, "relu"), Dense(latent_to_diffeq_dim, z_dim, z0_activation))
+        lo_th = Chain(Dense(latent_dim_theta, latent_to_diffeq_dim, "relu"),
+                      Dense(latent_to_diffeq_dim, th_dim, theta_activation))
+        latent_out = (lo_z0, lo_th)
+        rec_in = z_dim
+    elif isinstance(model_type, LatentODE):
+        latent_out = lambda x: x                                            # [REF LatentODE.jl:142]
+        rec_in = diffeq.latent_dim_out
+    else:
+        raise TypeError("default_decoder_layers: GOKU_basic() or LatentODE()")
+    rec = Chain(Dense(rec_in, hidden_dim_resnet, "relu"),
+                SkipConnection(Dense(hidden_dim_resnet, hidden_dim_resnet, "relu")),
+                SkipConnection(Dense(hidden_dim_resnet, hidden_dim_resnet, "relu")),
+                Dense(hidden_dim_resnet, input_dim, output_activation))
+    if device is not None:
+        rec = rec.to(device)
+        if isinstance(latent_out, tuple):
+            latent_out = tuple(m.to(device) for m in latent_out)
+    return latent_out, diffeq, rec

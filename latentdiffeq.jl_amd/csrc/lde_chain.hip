@@ -1,0 +1,663 @@
+// lde_chain.hip — the dense chains either side of the solve (scope row f-1).
+//
+// Replaces what runs under
+//     l̂ = apply_latent_out(decoder, l̃)       [REF src/models/GOKU.jl:83-91], [REF src/models/LatentODE.jl:53]
+//     x̂ = apply_reconstructor(decoder, ẑ)     [REF src/models/GOKU.jl:148],   [REF src/models/LatentODE.jl:80]
+// i.e. Flux `Chain`s of `Dense(in,out,act)` / `SkipConnection(Dense,+)` applied column-wise (Flux 0.13.6, un-vendored),
+// and their pullbacks. The reconstructor is the first genuinely matrix-core-heavy operator next to the solve:
+// 2·(D·200 + 2·200² + 200·784) ≈ 474 kflop per (trajectory, save time), N = B·T columns.
+//
+// Design (gfx950)
+//  * Forward: a workgroup of 8 waves owns NC = 16·CG columns (CG = 4 when the panels fit the 160 KB LDS) and runs the
+//    whole chain on them: activations live in LDS as transposed panels (stride ≡ 8 mod 32 floats, as in lde_mlp.hip),
+//    weights stream from L2 in MFMA-fragment order through a 4-deep register ring, every A fragment is used for CG
+//    column groups × 2 row tiles (32 `v_mfma_f32_16x16x4_f32` per 2 fragment loads). Bias, activation and the skip
+//    addition are fused into the epilogue; the last layer's epilogue stores x̂ straight to HBM (16 B per lane).
+//  * Backward, kernel 1 (per column tile): recompute the hidden activations, stage every layer's input panel a_l in
+//    HBM; δ_L = dy ⊙ act'(y) is formed from the caller's y, staged, and read back as the B operand of W_Lᵀ·δ_L (the
+//    widest layer never touches LDS); then δ flows down the chain through Wᵀ fragments, each δ_l staged as it appears.
+//    The gradient wrt a layer's output is kept in its own panel so that skip connections add it back.
+//  * Backward, kernel 2: the weight gradient is the same large-K product over staged (a_l, δ_l) panels as in the MLP
+//    adjoint — `k_mlp_dw` + `k_reduce_slabs` from lde_mfma.h, with every 16-column group as one slot of weight 1.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "lde_mfma.h"
+
+namespace lde {
+
+struct ChainDims {
+  MlpDims dm;          // sizes + offsets (fill_layer_offsets)
+  int act[MAXL];
+  int skip[MAXL];
+  int ld0;             // stride of the input panel (≥ pad32(in))
+  int ldh;             // stride of hidden / gradient panels
+};
+
+__device__ __forceinline__ float cact(int kind, float x) {
+  switch (kind) {
+    case LDE_CACT_RELU: return fmaxf(x, 0.f);
+    case LDE_CACT_TANH: return tanhf(x);
+    case LDE_CACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
+    case LDE_CACT_SOFTPLUS: return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+    default: return x;
+  }
+}
+// derivative of the activation expressed through its OUTPUT f = act(pre)
+__device__ __forceinline__ float cact_grad_out(int kind, float f) {
+  switch (kind) {
+    case LDE_CACT_RELU: return f > 0.f ? 1.f : 0.f;
+    case LDE_CACT_TANH: return 1.f - f * f;
+    case LDE_CACT_SIGMOID: return f * (1.f - f);
+    case LDE_CACT_SOFTPLUS: return 1.f - expf(-f);
+    default: return 1.f;
+  }
+}
+
+// Y[R × 16·CG] = M[R×K] · B[K × 16·CG] for one workgroup of 8 waves. M as K4 fragments in global memory (L2-resident),
+// B transposed: element (k, column c of group cg) at Bp[cg*cgstride + c*ldb + k], in LDS or (BGLB) in global memory.
+// A wave takes row tiles rt and rt+8 together: per K-group 2 fragment loads + CG operand loads feed 8·CG MFMAs.
+// pre(row0, cg, col) is called before the K loop (its loads overlap the MFMAs), epi(row0, cg, col, acc, pre-result) after.
+template <int CG, bool BGLB, class Pre, class Epi>
+__device__ __forceinline__ void chain_gemm(const float* __restrict__ gfrag, int R, int K, const float* Bp, int ldb,
+                                           int cgstride, Pre pre, Epi epi) {
+  constexpr int NW = 8, PFA = 4, PFB = BGLB ? 4 : 2;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int RT = cdiv(R, 16), KG = cdiv(K, 16), kl = KG - 1;
+  const f32x4* A = reinterpret_cast<const f32x4*>(gfrag) + lane;
+  const float* bp = Bp + (lane & 15) * ldb + 4 * (lane >> 4);
+  const int col = lane & 15, rsub = 4 * (lane >> 4);
+  for (int rt = wave; rt < RT; rt += 2 * NW) {
+    const int rt2 = rt + NW;
+    const bool two = rt2 < RT;
+    const f32x4* A0 = A + (size_t)rt * KG * 64;
+    const f32x4* A1 = A + (size_t)(two ? rt2 : rt) * KG * 64;   // a lone tile is computed twice (the wave would idle anyway)
+    f32x4 acc0[CG], acc1[CG];
+#pragma unroll
+    for (int cg = 0; cg < CG; cg++) {
+      acc0[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+      acc1[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    decltype(pre(0, 0, 0)) p0[CG], p1[CG];
+#pragma unroll
+    for (int cg = 0; cg < CG; cg++) {
+      p0[cg] = pre(rt * 16 + rsub, cg, col);
+      p1[cg] = pre((two ? rt2 : rt) * 16 + rsub, cg, col);
+    }
+    f32x4 ra0[PFA], ra1[PFA], rb[PFB][CG];
+#pragma unroll
+    for (int i = 0; i < PFA; i++) {
+      const int k = min(i, kl);
+      ra0[i] = A0[k * 64];
+      ra1[i] = A1[k * 64];
+    }
+#pragma unroll
+    for (int i = 0; i < PFB; i++) {
+      const int k = min(i, kl);
+#pragma unroll
+      for (int cg = 0; cg < CG; cg++) rb[i][cg] = *reinterpret_cast<const f32x4*>(bp + cg * cgstride + k * 16);
+    }
+    for (int kg = 0; kg < KG; kg += PFA) {
+#pragma unroll
+      for (int i = 0; i < PFA; i++) {
+        if (kg + i < KG) {
+          const f32x4 c0 = ra0[i], c1 = ra1[i];
+          f32x4 cb[CG];
+#pragma unroll
+          for (int cg = 0; cg < CG; cg++) cb[cg] = rb[i % PFB][cg];
+          const int ka = min(kg + i + PFA, kl), kb = min(kg + i + PFB, kl);
+          ra0[i] = A0[ka * 64];
+          ra1[i] = A1[ka * 64];
+#pragma unroll
+          for (int cg = 0; cg < CG; cg++) rb[i % PFB][cg] = *reinterpret_cast<const f32x4*>(bp + cg * cgstride + kb * 16);
+#pragma unroll
+          for (int cg = 0; cg < CG; cg++) {
+#pragma unroll
+            for (int s4 = 0; s4 < 4; s4++) {
+              acc0[cg] = mfma16(c0[s4], cb[cg][s4], acc0[cg]);
+              acc1[cg] = mfma16(c1[s4], cb[cg][s4], acc1[cg]);
+            }
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int cg = 0; cg < CG; cg++) {
+      epi(rt * 16 + rsub, cg, col, acc0[cg], p0[cg]);
+      if (two) epi(rt2 * 16 + rsub, cg, col, acc1[cg], p1[cg]);
+    }
+  }
+}
+
+struct NoPre {};
+
+// copy rows [0, rows32) of the 16 columns of column group cg from an LDS panel to a staged block panel [col][rows32]
+__device__ __forceinline__ void stage_panel(const float* panel, int ld, int rows32, float* dst) {
+  const int col = threadIdx.x >> 5, l31 = threadIdx.x & 31;   // one half-wave per column (512 threads = 16 columns)
+  for (int r4 = l31; 4 * r4 < rows32; r4 += 32)
+    *reinterpret_cast<f32x4*>(dst + col * rows32 + 4 * r4) = *reinterpret_cast<const f32x4*>(panel + col * ld + 4 * r4);
+}
+
+struct ChainFwdArgs {
+  const float* x;
+  float* y;
+  const float* frag;
+  const float* Wflat;
+  long long N;
+};
+
+template <int CG>
+__device__ __forceinline__ void chain_load_tile(const ChainDims& cd, const float* x, long long n0, long long N, float* X0,
+                                                float* biasc, const float* Wflat, int nfloat_zero, float* zero_base) {
+  constexpr int NC = 16 * CG;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < nfloat_zero; i += 512) zero_base[i] = 0.f;   // pad rows / pad columns must be finite
+  __syncthreads();
+  const MlpDims& dm = cd.dm;
+  for (int l = 0; l < dm.nL; l++)
+    for (int i = tid; i < dm.sizes[l + 1]; i += 512) biasc[dm.bias_lin[l] + i] = Wflat[dm.b_off[l] + i];
+  const int in0 = dm.sizes[0];
+  for (int e = tid; e < NC * in0; e += 512) {
+    const int c = e / in0, r = e - c * in0;
+    if (n0 + c < N) X0[c * cd.ld0 + r] = x[(size_t)(n0 + c) * in0 + r];
+  }
+  __syncthreads();
+}
+
+// one hidden (non-last) layer: Y = [Xin +] act(W·Xin + b) into an LDS panel
+template <int CG>
+__device__ __forceinline__ void chain_hidden_layer(const ChainDims& cd, int l, const float* frag, const float* biasc,
+                                                   const float* Xin, int ldx, float* Y) {
+  const MlpDims& dm = cd.dm;
+  const int in = dm.sizes[l], out = dm.sizes[l + 1], actk = cd.act[l], skip = cd.skip[l], ldh = cd.ldh;
+  const float* bias = biasc + dm.bias_lin[l];
+  chain_gemm<CG, false>(frag + dm.frag_off[l], out, in, Xin, ldx, 16 * ldx, [](int, int, int) { return NoPre{}; },
+                        [&](int row0, int cg, int col, f32x4 v, NoPre) {
+                          const int c = cg * 16 + col;
+                          f32x4 r;
+#pragma unroll
+                          for (int q = 0; q < 4; q++) r[q] = row0 + q < out ? cact(actk, v[q] + bias[row0 + q]) : 0.f;
+                          if (skip) r += *reinterpret_cast<const f32x4*>(Xin + c * ldx + row0);   // in == out; pad rows are 0
+                          *reinterpret_cast<f32x4*>(Y + c * ldh + row0) = r;
+                        });
+}
+
+template <int CG>
+__global__ void __launch_bounds__(512) k_chain_forward(ChainDims cd, ChainFwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float csm[];
+  constexpr int NC = 16 * CG;
+  const MlpDims& dm = cd.dm;
+  const int nL = dm.nL, ldh = cd.ldh;
+  float* X0 = csm;
+  float* H0 = X0 + NC * cd.ld0;
+  float* H1 = H0 + NC * ldh;
+  float* biasc = H1 + NC * ldh;
+  const long long n0 = (long long)blockIdx.x * NC;
+  chain_load_tile<CG>(cd, a.x, n0, a.N, X0, biasc, a.Wflat, NC * cd.ld0 + 2 * NC * ldh, csm);
+  const float* Xin = X0;
+  int ldx = cd.ld0;
+  for (int l = 0; l + 1 < nL; l++) {
+    float* Y = (l & 1) ? H1 : H0;
+    chain_hidden_layer<CG>(cd, l, a.frag, biasc, Xin, ldx, Y);
+    __syncthreads();
+    Xin = Y;
+    ldx = ldh;
+  }
+  {  // last layer: straight to HBM
+    const int l = nL - 1, in = dm.sizes[l], out = dm.sizes[l + 1], actk = cd.act[l];
+    const float* bias = biasc + dm.bias_lin[l];
+    const bool vec = (out & 3) == 0;
+    chain_gemm<CG, false>(a.frag + dm.frag_off[l], out, in, Xin, ldx, 16 * ldx, [](int, int, int) { return NoPre{}; },
+                          [&](int row0, int cg, int col, f32x4 v, NoPre) {
+                            const long long n = n0 + cg * 16 + col;
+                            if (n >= a.N || row0 >= out) return;
+                            f32x4 r;
+#pragma unroll
+                            for (int q = 0; q < 4; q++) r[q] = row0 + q < out ? cact(actk, v[q] + bias[row0 + q]) : 0.f;
+                            float* yp = a.y + (size_t)n * out + row0;
+                            if (vec) *reinterpret_cast<f32x4*>(yp) = r;
+                            else {
+#pragma unroll
+                              for (int q = 0; q < 4; q++)
+                                if (row0 + q < out) yp[q] = r[q];
+                            }
+                          });
+  }
+}
+
+struct ChainBwdArgs {
+  const float* x;
+  const float* y;
+  const float* dy;
+  float* dx;
+  const float* frag;
+  const float* fragT;
+  const float* Wflat;
+  float* stage;        // [slots][blk_floats]
+  float* wts;          // [slots][16]
+  long long N;
+};
+
+struct PrePair { f32x4 h, a; };
+
+template <int CG>
+__global__ void __launch_bounds__(512) k_chain_backward(ChainDims cd, ChainBwdArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float csm[];
+  constexpr int NC = 16 * CG;
+  const MlpDims& dm = cd.dm;
+  const int nL = dm.nL, ldh = cd.ldh, tid = threadIdx.x;
+  float* X0 = csm;
+  float* P0 = X0 + NC * cd.ld0;
+  float* P1 = P0 + NC * ldh;
+  float* G = P1 + NC * ldh;
+  float* biasc = G + NC * ldh;
+  const long long n0 = (long long)blockIdx.x * NC;
+  const size_t slot0 = (size_t)blockIdx.x * CG;
+  float* const blk0 = a.stage + slot0 * dm.blk_floats;   // the CG staged blocks of this tile are contiguous
+  chain_load_tile<CG>(cd, a.x, n0, a.N, X0, biasc, a.Wflat, NC * cd.ld0 + 3 * NC * ldh, csm);
+
+  // ---- 1. recompute the hidden activations; stage every layer's input panel ---------------------------------------
+#pragma unroll
+  for (int cg = 0; cg < CG; cg++)
+    stage_panel(X0 + cg * 16 * cd.ld0, cd.ld0, pad32(dm.sizes[0]), blk0 + (size_t)cg * dm.blk_floats + dm.blk_off[0]);
+  {
+    const float* Xin = X0;
+    int ldx = cd.ld0;
+    for (int l = 0; l + 1 < nL; l++) {
+      float* Y = (l & 1) ? P1 : P0;
+      chain_hidden_layer<CG>(cd, l, a.frag, biasc, Xin, ldx, Y);
+      __syncthreads();
+#pragma unroll
+      for (int cg = 0; cg < CG; cg++)
+        stage_panel(Y + cg * 16 * ldh, ldh, pad32(dm.sizes[l + 1]), blk0 + (size_t)cg * dm.blk_floats + dm.blk_off[l + 1]);
+      Xin = Y;
+      ldx = ldh;
+    }
+  }
+  // ---- 2. δ_L = dy ⊙ act'(y) from the caller's arrays, staged as layer L's δ-panel; column weights ------------------
+  const int L1 = nL - 1;
+  {
+    const int out = dm.sizes[nL], out32 = pad32(out), actk = cd.act[L1];
+    const bool vec = (out & 3) == 0;
+    const int col = tid >> 5, l31 = tid & 31;
+#pragma unroll
+    for (int cg = 0; cg < CG; cg++) {
+      float* dst = blk0 + (size_t)cg * dm.blk_floats + dm.blk_off[L1] + NB * pad32(dm.sizes[L1]) + col * out32;
+      const long long n = n0 + cg * 16 + col;
+      const float* dyp = a.dy + (size_t)n * out;
+      const float* yp = a.y + (size_t)n * out;
+      for (int r4 = l31; 4 * r4 < out32; r4 += 32) {
+        const int r = 4 * r4;
+        f32x4 d = {0.f, 0.f, 0.f, 0.f};
+        if (n < a.N && r < out) {
+          if (vec) {
+            const f32x4 g = *reinterpret_cast<const f32x4*>(dyp + r), f = *reinterpret_cast<const f32x4*>(yp + r);
+#pragma unroll
+            for (int q = 0; q < 4; q++) d[q] = g[q] * cact_grad_out(actk, f[q]);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+              if (r + q < out) d[q] = dyp[r + q] * cact_grad_out(actk, yp[r + q]);
+          }
+        }
+        *reinterpret_cast<f32x4*>(dst + r) = d;
+      }
+      if (tid < 16) a.wts[(slot0 + cg) * NB + tid] = (n0 + cg * 16 + tid < a.N) ? 1.f : 0.f;
+    }
+  }
+  __syncthreads();   // the staged panels are read back below (s_waitcnt vmcnt(0) + barrier ⇒ they are in L2)
+
+  // ---- 3. δ down the chain ------------------------------------------------------------------------------------------
+  const float* Dcur = nullptr;   // LDS panel holding δ_l for l < L1
+  for (int l = L1; l >= 0; l--) {
+    const int in = dm.sizes[l], out = dm.sizes[l + 1];
+    const int skl = cd.skip[l];
+    const float* fragT = a.fragT + dm.fragT_off[l];
+    const float* Bglb = blk0 + dm.blk_off[l] + NB * pad32(in);   // δ_l panel of column group 0 (only used for l == L1)
+    if (l > 0) {
+      float* Dn = (l & 1) ? P1 : P0;
+      const int actp = cd.act[l - 1], skp = cd.skip[l - 1];
+      const int in32 = pad32(in), inp32 = pad32(dm.sizes[l - 1]);
+      const float* hblk = blk0 + dm.blk_off[l];        // a_l = output of layer l-1
+      const float* ablk = blk0 + dm.blk_off[l - 1];    // a_{l-1} (its input), needed when layer l-1 is a skip layer
+      auto pre = [&](int row0, int cg, int col) {
+        PrePair p;
+        p.h = *reinterpret_cast<const f32x4*>(hblk + (size_t)cg * dm.blk_floats + col * in32 + row0);
+        p.a = skp ? *reinterpret_cast<const f32x4*>(ablk + (size_t)cg * dm.blk_floats + col * inp32 + row0)
+                  : f32x4{0.f, 0.f, 0.f, 0.f};
+        return p;
+      };
+      auto epi = [&](int row0, int cg, int col, f32x4 v, PrePair p) {
+        const int c = cg * 16 + col;
+        f32x4 g = v;
+        if (skl) g += *reinterpret_cast<const f32x4*>(G + c * ldh + row0);
+        if (skp) *reinterpret_cast<f32x4*>(G + c * ldh + row0) = g;   // layer l-1 adds it back to what flows through it
+        f32x4 d;
+#pragma unroll
+        for (int q = 0; q < 4; q++) d[q] = row0 + q < in ? g[q] * cact_grad_out(actp, p.h[q] - p.a[q]) : 0.f;
+        *reinterpret_cast<f32x4*>(Dn + c * ldh + row0) = d;
+      };
+      if (l == L1) chain_gemm<CG, true>(fragT, in, out, Bglb, pad32(out), dm.blk_floats, pre, epi);
+      else chain_gemm<CG, false>(fragT, in, out, Dcur, ldh, 16 * ldh, pre, epi);
+      __syncthreads();
+#pragma unroll
+      for (int cg = 0; cg < CG; cg++)
+        stage_panel(Dn + cg * 16 * ldh, ldh, in32, blk0 + (size_t)cg * dm.blk_floats + dm.blk_off[l - 1] + NB * inp32);
+      Dcur = Dn;
+    } else if (a.dx) {
+      auto pre = [](int, int, int) { return NoPre{}; };
+      auto epi = [&](int row0, int cg, int col, f32x4 v, NoPre) {
+        const int c = cg * 16 + col;
+        const long long n = n0 + c;
+        f32x4 g = v;
+        if (skl) g += *reinterpret_cast<const f32x4*>(G + c * ldh + row0);
+        if (n < a.N) {
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (row0 + q < in) a.dx[(size_t)n * in + row0 + q] = g[q];
+        }
+      };
+      if (l == L1) chain_gemm<CG, true>(fragT, in, out, Bglb, pad32(out), dm.blk_floats, pre, epi);
+      else chain_gemm<CG, false>(fragT, in, out, Dcur, ldh, 16 * ldh, pre, epi);
+    }
+  }
+}
+
+static __global__ void k_chain_fill_slots(int32_t* nslots, int32_t* zeros, int nvt, int cap, long long total) {
+  const int v = blockIdx.x * blockDim.x + threadIdx.x;
+  if (v < nvt) {
+    const long long left = total - (long long)v * cap;
+    nslots[v] = left <= 0 ? 0 : (left < cap ? (int)left : cap);
+  }
+  if (v == 0) zeros[0] = 0;
+}
+
+}  // namespace lde
+
+// ================================================ C ABI ======================================================
+using namespace lde;
+
+struct lde_chain {
+  lde_chain_desc d;
+  ChainDims cd;
+  int64_t nW = 0;
+  size_t nfrag = 0, nfragT = 0;
+  float* W_dev = nullptr;
+  float* frag = nullptr;
+  float* fragT = nullptr;
+  bool have_W = false;
+  int cg_fwd = 0, cg_bwd = 0;
+  size_t lds_fwd = 0, lds_bwd = 0;
+  // backward workspace
+  float* stage = nullptr; size_t stage_cap = 0;
+  float* wts = nullptr; size_t wts_cap = 0;
+  float* slab = nullptr; size_t slab_cap = 0;
+  int32_t* ints = nullptr; size_t ints_cap = 0;   // [nvt] slots per virtual tile, then one zero / feedback word
+  std::string err;
+};
+
+static int chain_desc_ok(const lde_chain_desc* d) {
+  if (!d || d->abi_version != LDE_ABI_VERSION || d->n_layers < 1 || d->n_layers > LDE_CHAIN_MAX_LAYERS) return 0;
+  for (int l = 0; l <= d->n_layers; l++)
+    if (d->sizes[l] < 1) return 0;
+  for (int l = 0; l < d->n_layers; l++) {
+    if (d->activation[l] < 0 || d->activation[l] > LDE_CACT_SOFTPLUS) return 0;
+    if (d->skip[l] && d->sizes[l] != d->sizes[l + 1]) return 0;
+  }
+  return 1;
+}
+
+static size_t chain_lds(const ChainDims& cd, int cg, int npanels) {
+  const int NC = 16 * cg;
+  return ((size_t)NC * cd.ld0 + (size_t)npanels * NC * cd.ldh + ((cd.dm.nbias + 3) & ~3)) * sizeof(float);
+}
+
+extern "C" {
+
+int64_t lde_chain_num_weights(const lde_chain_desc* d) {
+  if (!chain_desc_ok(d)) return -1;
+  int64_t n = 0;
+  for (int l = 0; l < d->n_layers; l++) n += (int64_t)d->sizes[l + 1] * d->sizes[l] + d->sizes[l + 1];
+  return n;
+}
+
+void lde_chain_destroy(lde_chain* c) {
+  if (!c) return;
+  if (c->W_dev) (void)hipFree(c->W_dev);
+  if (c->frag) (void)hipFree(c->frag);
+  if (c->fragT) (void)hipFree(c->fragT);
+  if (c->stage) (void)hipFree(c->stage);
+  if (c->wts) (void)hipFree(c->wts);
+  if (c->slab) (void)hipFree(c->slab);
+  if (c->ints) (void)hipFree(c->ints);
+  delete c;
+}
+
+int lde_chain_create(const lde_chain_desc* d, lde_chain** out) {
+  if (!out) return LDE_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (!chain_desc_ok(d)) return LDE_ERR_INVALID_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return LDE_ERR_NO_DEVICE;   // no CPU fallback
+  lde_chain* c = new lde_chain();
+  c->d = *d;
+  ChainDims& cd = c->cd;
+  std::memset(&cd, 0, sizeof(cd));
+  MlpDims& dm = cd.dm;
+  dm.nL = d->n_layers;
+  int hmax = 16;
+  for (int l = 0; l <= d->n_layers; l++) {
+    dm.sizes[l] = d->sizes[l];
+    if (l > 0 && l < d->n_layers) hmax = std::max(hmax, d->sizes[l]);
+  }
+  for (int l = 0; l < d->n_layers; l++) {
+    cd.act[l] = d->activation[l];
+    cd.skip[l] = d->skip[l] ? 1 : 0;
+  }
+  fill_layer_offsets(dm, &c->nfrag, &c->nfragT);
+  c->nW = dm.nW;
+  cd.ld0 = panel_stride(pad32(dm.sizes[0]));
+  cd.ldh = panel_stride(pad32(hmax));
+  *out = c;   // from here on errors carry a message
+  if (cd.skip[d->n_layers - 1] && d->n_layers > 1) {
+    c->err = "a skip connection around the last layer of a chain is not supported";
+    return LDE_ERR_UNSUPPORTED;
+  }
+  if (cd.skip[d->n_layers - 1]) {   // single skip layer: would need the gradient panel at the output width
+    c->err = "a chain made of one skip layer is not supported";
+    return LDE_ERR_UNSUPPORTED;
+  }
+  for (int l = 0; l <= d->n_layers; l++)
+    if (d->sizes[l] > 1024) {
+      c->err = "chain layer widths up to 1024 are supported";
+      return LDE_ERR_UNSUPPORTED;
+    }
+  for (int cg : {4, 2, 1})
+    if (!c->cg_fwd && chain_lds(cd, cg, 2) <= LDS_MAX) { c->cg_fwd = cg; c->lds_fwd = chain_lds(cd, cg, 2); }
+  for (int cg : {2, 1})
+    if (!c->cg_bwd && chain_lds(cd, cg, 3) <= LDS_MAX) { c->cg_bwd = cg; c->lds_bwd = chain_lds(cd, cg, 3); }
+  if (!c->cg_fwd || !c->cg_bwd) {
+    c->err = "chain: activation panels do not fit the 160 KiB LDS";
+    return LDE_ERR_UNSUPPORTED;
+  }
+  if (hipMalloc(&c->W_dev, (size_t)c->nW * sizeof(float)) != hipSuccess ||
+      hipMalloc(&c->frag, c->nfrag * sizeof(float)) != hipSuccess ||
+      hipMalloc(&c->fragT, c->nfragT * sizeof(float)) != hipSuccess) {
+    c->err = "chain: hipMalloc failed";
+    return LDE_ERR_ALLOC;
+  }
+  return LDE_OK;
+}
+
+static int chain_frags(lde_chain* c, hipStream_t stream) {
+  hipLaunchKernelGGL(k_build_frags, dim3(64, c->cd.dm.nL), dim3(256), 0, stream, c->W_dev, c->cd.dm, c->frag, c->fragT);
+  if (hipGetLastError() != hipSuccess) {
+    c->err = "k_build_frags launch failed";
+    return LDE_ERR_HIP;
+  }
+  c->have_W = true;
+  return LDE_OK;
+}
+
+int lde_chain_set_weights(lde_chain* c, const float* flat_host, int64_t n) {
+  if (!c || !c->W_dev) return LDE_ERR_INVALID_ARG;
+  if (n != c->nW || !flat_host) {
+    c->err = "lde_chain_set_weights: wrong weight count";
+    return LDE_ERR_INVALID_ARG;
+  }
+  if (hipMemcpy(c->W_dev, flat_host, (size_t)n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    c->err = "lde_chain_set_weights: hipMemcpy failed";
+    return LDE_ERR_HIP;
+  }
+  return chain_frags(c, nullptr);
+}
+
+int lde_chain_set_weights_device(lde_chain* c, const float* flat_dev, int64_t n, void* stream) {
+  if (!c || !c->W_dev) return LDE_ERR_INVALID_ARG;
+  if (n != c->nW || !flat_dev) {
+    c->err = "lde_chain_set_weights_device: wrong weight count";
+    return LDE_ERR_INVALID_ARG;
+  }
+  if (hipMemcpyAsync(c->W_dev, flat_dev, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+    c->err = "lde_chain_set_weights_device: hipMemcpyAsync failed";
+    return LDE_ERR_HIP;
+  }
+  return chain_frags(c, (hipStream_t)stream);
+}
+
+// virtual tiling of the slot range for k_mlp_dw: nvt tiles × ks parts ≈ 32 partial slabs
+static void chain_dw_split(const lde_chain* c, int64_t N, int* nvt, int* cap, int64_t* total) {
+  const int64_t tiles = (N + 16 * c->cg_bwd - 1) / (16 * c->cg_bwd);
+  *total = tiles * c->cg_bwd;
+  int v = 32;
+  if (*total < v) v = (int)*total;
+  if (v < 1) v = 1;
+  *nvt = v;
+  *cap = (int)((*total + v - 1) / v);
+  if (*cap < 1) *cap = 1;
+}
+
+int lde_chain_reserve(lde_chain* c, int64_t N) {
+  if (!c || !c->W_dev || N < 1) return LDE_ERR_INVALID_ARG;
+  int nvt, cap;
+  int64_t total;
+  chain_dw_split(c, N, &nvt, &cap, &total);
+  const MlpDims& dm = c->cd.dm;
+  if (!grow(&c->stage, &c->stage_cap, (size_t)total * dm.blk_floats) || !grow(&c->wts, &c->wts_cap, (size_t)total * NB) ||
+      !grow(&c->slab, &c->slab_cap, (size_t)nvt * dm.slab_n) || !grow(&c->ints, &c->ints_cap, (size_t)nvt + 16)) {
+    c->err = "chain: hipMalloc of the backward workspace failed";
+    return LDE_ERR_ALLOC;
+  }
+  return LDE_OK;
+}
+
+int lde_chain_forward(lde_chain* c, const float* x, int64_t N, float* y, void* stream_) {
+  if (!c || !c->W_dev) return LDE_ERR_INVALID_ARG;
+  if (!x || !y || N < 1) {
+    c->err = "lde_chain_forward: NULL pointer or empty batch";
+    return LDE_ERR_INVALID_ARG;
+  }
+  if (!c->have_W) {
+    c->err = "lde_chain_forward: weights not set";
+    return LDE_ERR_NO_WEIGHTS;
+  }
+  if (((uintptr_t)y & 15) != 0) {
+    c->err = "lde_chain_forward: y must be 16-byte aligned";
+    return LDE_ERR_INVALID_ARG;
+  }
+  hipStream_t stream = (hipStream_t)stream_;
+  ChainFwdArgs a{x, y, c->frag, c->W_dev, (long long)N};
+  const int NC = 16 * c->cg_fwd;
+  const dim3 grid((unsigned)((N + NC - 1) / NC));
+  static bool attr[5] = {false, false, false, false, false};
+  const void* fn = c->cg_fwd == 4 ? (const void*)k_chain_forward<4> : c->cg_fwd == 2 ? (const void*)k_chain_forward<2>
+                                                                                    : (const void*)k_chain_forward<1>;
+  if (!attr[c->cg_fwd]) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
+      c->err = "hipFuncSetAttribute(k_chain_forward) failed";
+      return LDE_ERR_HIP;
+    }
+    attr[c->cg_fwd] = true;
+  }
+  if (c->cg_fwd == 4) hipLaunchKernelGGL(k_chain_forward<4>, grid, dim3(512), c->lds_fwd, stream, c->cd, a);
+  else if (c->cg_fwd == 2) hipLaunchKernelGGL(k_chain_forward<2>, grid, dim3(512), c->lds_fwd, stream, c->cd, a);
+  else hipLaunchKernelGGL(k_chain_forward<1>, grid, dim3(512), c->lds_fwd, stream, c->cd, a);
+  if (hipGetLastError() != hipSuccess) {
+    c->err = "k_chain_forward launch failed";
+    return LDE_ERR_HIP;
+  }
+  return LDE_OK;
+}
+
+int lde_chain_backward(lde_chain* c, const float* x, const float* y, const float* dy, int64_t N, float* dx, float* dW,
+                       void* stream_) {
+  if (!c || !c->W_dev) return LDE_ERR_INVALID_ARG;
+  if (!x || !y || !dy || !dW || N < 1) {
+    c->err = "lde_chain_backward: NULL pointer or empty batch";
+    return LDE_ERR_INVALID_ARG;
+  }
+  if (!c->have_W) {
+    c->err = "lde_chain_backward: weights not set";
+    return LDE_ERR_NO_WEIGHTS;
+  }
+  if ((((uintptr_t)y | (uintptr_t)dy) & 15) != 0) {
+    c->err = "lde_chain_backward: y and dy must be 16-byte aligned";
+    return LDE_ERR_INVALID_ARG;
+  }
+  int rc = lde_chain_reserve(c, N);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  const MlpDims& dm = c->cd.dm;
+  int nvt, cap;
+  int64_t total;
+  chain_dw_split(c, N, &nvt, &cap, &total);
+  ChainBwdArgs a{x, y, dy, dx, c->frag, c->fragT, c->W_dev, c->stage, c->wts, (long long)N};
+  const int NC = 16 * c->cg_bwd;
+  const dim3 grid((unsigned)((N + NC - 1) / NC));
+  static bool attr[3] = {false, false, false};
+  const void* fn = c->cg_bwd == 2 ? (const void*)k_chain_backward<2> : (const void*)k_chain_backward<1>;
+  if (!attr[c->cg_bwd]) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
+      c->err = "hipFuncSetAttribute(k_chain_backward) failed";
+      return LDE_ERR_HIP;
+    }
+    attr[c->cg_bwd] = true;
+  }
+  hipLaunchKernelGGL(k_chain_fill_slots, dim3(cdiv(nvt, 64)), dim3(64), 0, stream, c->ints, c->ints + nvt, nvt, cap,
+                     (long long)total);
+  if (c->cg_bwd == 2) hipLaunchKernelGGL(k_chain_backward<2>, grid, dim3(512), c->lds_bwd, stream, c->cd, a);
+  else hipLaunchKernelGGL(k_chain_backward<1>, grid, dim3(512), c->lds_bwd, stream, c->cd, a);
+  if (hipGetLastError() != hipSuccess) {
+    c->err = "k_chain_backward launch failed";
+    return LDE_ERR_HIP;
+  }
+  // weight gradient: large-K product over the staged panels (lde_mfma.h)
+  DwArgs da;
+  da.stage = c->stage; da.wts = c->wts; da.nslots = c->ints; da.slab = c->slab; da.cap = cap;
+  const int ndw = dw_ndw(dm);
+  int maxrows = 0;
+  for (int l = 0; l < dm.nL; l++) maxrows = std::max(maxrows, (pad32(dm.sizes[l]) | 32) + (pad32(dm.sizes[l + 1]) | 32));
+  const size_t dlds = (size_t)NB * maxrows * sizeof(float);
+  if (dlds > LDS_MAX) {
+    c->err = "chain: layer too wide for the weight-gradient kernel's LDS panels";
+    return LDE_ERR_UNSUPPORTED;
+  }
+  const dim3 dgrid(nvt, 1, dw_jobs(dm, ndw));
+  rc = ndw == 2 ? launch_dw<2>(dm, da, dgrid, dlds, stream, c->err) : launch_dw<8>(dm, da, dgrid, dlds, stream, c->err);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_reduce_slabs, dim3(cdiv(dm.nW, 256)), dim3(256), 0, stream, (const float*)nullptr,
+                     (const int32_t*)(c->ints + nvt), 0, (const float*)c->slab, nvt, dm, dW, c->ints + nvt + 1);
+  if (hipGetLastError() != hipSuccess) {
+    c->err = "chain: weight-gradient kernels failed to launch";
+    return LDE_ERR_HIP;
+  }
+  return LDE_OK;
+}
+
+const char* lde_chain_last_error(const lde_chain* c) { return c ? c->err.c_str() : "null handle"; }
+
+}  // extern "C"

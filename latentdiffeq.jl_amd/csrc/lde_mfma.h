@@ -1,0 +1,323 @@
+// lde_mfma.h — pieces shared by the MLP right-hand-side kernels (lde_mlp.hip) and the dense-chain kernels (lde_chain.hip):
+// the layer description, the one-time weight re-layout into MFMA fragment order, and the large-K weight-gradient
+// kernel + slab reduction that consume staged (a_l, δ_l) panels.
+#ifndef LDE_MFMA_H
+#define LDE_MFMA_H
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdint>
+#include <string>
+
+#include "lde_device.h"
+
+namespace lde {
+
+constexpr int NB = 16;        // trajectories (columns) per workgroup
+constexpr int MAXL = LDE_MAX_LAYERS;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+#ifndef LDE_ABL
+#define LDE_ABL 0
+#endif
+// diagnostic builds only (LDE_ABL != 0): 1 = no GEMM, 2 = operands loaded but no MFMA, 3 = no epilogue,
+// 4 = no weight-gradient products (and no bias sums), 5 = no bias sums
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  if (LDE_ABL == 2) { c[0] += a + b; return c; }
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+
+// LDE_PROF builds (diagnostic): thread 0 of workgroup 0 accumulates s_memtime cycles per phase into g_prof[].
+//   0 stage combination   1 control / error norm / save   2+2l GEMM of layer l (to its last MFMA/epilogue)   3+2l barrier after it
+//   in the adjoint the backward layers follow at 2+2(nL+l'), and 30 = panel staging stores
+#ifndef LDE_PROF
+#define LDE_PROF 0
+#endif
+#if LDE_PROF
+static __device__ long long g_prof[64];
+#define PROF_T(var) const long long var = (long long)__builtin_readcyclecounter()
+#define PROF_ADD(slot, t0, t1) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[slot] += (t1) - (t0); } while (0)
+#else
+#define PROF_T(var) do {} while (0)
+#define PROF_ADD(slot, t0, t1) do {} while (0)
+#endif
+
+// Static description of the RHS handed to the kernels by value.
+struct MlpDims {
+  int nL;                 // Dense layers
+  int sizes[MAXL + 1];    // [in, h1, ..., out]
+  int act;                // hidden activation
+  int D, Dp, P;           // state_dim, D + augment_dim, param_dim
+  int DpA;                // Dp rounded up to 4: in the adjoint state λ rows start at DpA, g rows at 2·DpA
+  int has_pend;           // PENDULUM_PLUS_MLP
+  int frag_off[MAXL];     // float offset of layer l's W fragments   (RT_l × KG_l × 256)
+  int fragT_off[MAXL];    // float offset of layer l's Wᵀ fragments
+  int frag_n[MAXL], fragT_n[MAXL];
+  int w_off[MAXL];        // offset of vec(W_l) in the flat (destructure-order) weight vector
+  int b_off[MAXL];        // offset of b_l
+  int hmax;               // rows of the widest hidden panel (padded to 32)
+  int ld_h;               // stride of the widest hidden panel (the two back-propagation panels use it)
+  int ld_hl[MAXL];        // stride of hidden panel l (activation of layer l), sized for ITS width
+  int h_off[MAXL];        // float offset of hidden panel l from the first one
+  int h_total;            // floats of all hidden panels
+  int ld_sf, ld_sb;       // stride of state panels in the forward / adjoint kernel
+  int coupled;            // LDE_BATCH_COUPLED
+  int solver;
+  int nW;
+  int bias_lin[MAXL];     // offset of layer l's bias (gradient) in the compact [Σ out] vector
+  int nbias;
+  int tile_off[MAXL + 1]; // first weight-gradient tile (32×32 of Wᵀ) of layer l in the global tile enumeration
+  int slab_n;             // floats of one workgroup's slab: ntiles·1024 (tiles in accumulator-fragment order) + nbias
+  int blk_off[MAXL];      // staged block of one evaluation: layer l's a-panel [16][in32] at blk_off[l], its δ-panel [16][out32] right after
+  int blk_floats;         // floats of one staged block
+};
+
+__host__ __device__ inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// smallest stride ≥ rows with stride ≡ 8 (mod 32): (stride/4) ≡ 2 (mod 8) makes the ds_read_b128 operand pattern
+// "16 columns × 4 lane-groups of 16 B" conflict-free in every 16-lane service group.
+__host__ __device__ inline int panel_stride(int rows) {
+  int v = ((rows + 31) / 32) * 32 + 8;
+  if (v - 32 >= rows) v -= 32;
+  return v;
+}
+
+// ---- one-time weight re-layout: flat destructure order → MFMA fragment order (W and Wᵀ) ---------------
+// fragment (rt, kg) of a matrix M[R×K]: lane l holds the float4 M[rt*16 + (l&15)][kg*16 + 4*(l>>4) + 0..3] (0 outside).
+static __global__ void k_build_frags(const float* __restrict__ Wflat, MlpDims dm, float* __restrict__ frag,
+                              float* __restrict__ fragT) {
+  const int l = blockIdx.y;
+  const int in = dm.sizes[l], out = dm.sizes[l + 1];
+  const float* W = Wflat + dm.w_off[l];  // column-major [out×in]: W(o,i) at o + out*i
+  {
+    const int KG = cdiv(in, 16), n = dm.frag_n[l];
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+      const int s4 = e & 3, lane = (e >> 2) & 63, f = e >> 8, rt = f / KG, kg = f % KG;
+      const int o = rt * 16 + (lane & 15), i = kg * 16 + 4 * (lane >> 4) + s4;
+      frag[dm.frag_off[l] + e] = (o < out && i < in) ? W[o + (size_t)out * i] : 0.f;
+    }
+  }
+  {
+    const int KG = cdiv(out, 16), n = dm.fragT_n[l];  // Wᵀ[in×out]
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+      const int s4 = e & 3, lane = (e >> 2) & 63, f = e >> 8, rt = f / KG, kg = f % KG;
+      const int i = rt * 16 + (lane & 15), o = kg * 16 + 4 * (lane >> 4) + s4;
+      fragT[dm.fragT_off[l] + e] = (o < out && i < in) ? W[o + (size_t)out * i] : 0.f;
+    }
+  }
+}
+
+__host__ __device__ inline int pad32(int v) { return (v + 31) & ~31; }
+
+// Offsets every kernel derives from the layer sizes: fragment arrays, flat (destructure-order) weight vector, compact
+// bias vector, 32×32 weight-gradient tile enumeration, staged-block layout. Returns {W-fragment floats, Wᵀ-fragment floats}.
+inline void fill_layer_offsets(MlpDims& dm, size_t* nfrag, size_t* nfragT) {
+  int off = 0, offT = 0, woff = 0, blin = 0, toff = 0, boff = 0;
+  for (int l = 0; l < dm.nL; l++) {
+    const int in = dm.sizes[l], o = dm.sizes[l + 1];
+    dm.frag_off[l] = off;
+    dm.frag_n[l] = cdiv(o, 16) * cdiv(in, 16) * 256;
+    off += dm.frag_n[l];
+    dm.fragT_off[l] = offT;
+    dm.fragT_n[l] = cdiv(in, 16) * cdiv(o, 16) * 256;
+    offT += dm.fragT_n[l];
+    dm.w_off[l] = woff;
+    woff += o * in;
+    dm.b_off[l] = woff;
+    woff += o;
+    dm.bias_lin[l] = blin;
+    blin += (o + 3) & ~3;   // 16-byte aligned bias blocks (vector loads in the epilogue)
+    dm.tile_off[l] = toff;
+    toff += cdiv(o, 32) * cdiv(in, 32);
+    dm.blk_off[l] = boff;
+    boff += NB * (pad32(in) + pad32(o));
+  }
+  dm.nW = woff;
+  dm.tile_off[dm.nL] = toff;
+  dm.nbias = blin;
+  dm.slab_n = toff * 1024 + ((blin + 3) & ~3);
+  dm.blk_floats = boff;
+  *nfrag = off;
+  *nfragT = offT;
+}
+
+static constexpr size_t LDS_MAX = 160 * 1024;
+
+// ---- the weight gradient as one large-K product over everything the solve staged ---------------------------------------
+// grid (solve tile, K-split part, job); a job = up to 8·NDW 32×32 tiles of ONE layer's gWᵀ. The workgroup walks the
+// tile's staged slots part, part+KS, …: copies that layer's a-panel and (weight-scaled) δ-panel into LDS and every wave
+// adds 8 MFMAs (K = the 16 columns) to each of its tiles. Result: the (tile, part) slab in accumulator-fragment order.
+struct DwArgs {
+  const float* stage;
+  const float* wts;
+  const int32_t* nslots;
+  float* slab;          // [nWG·KS][slab_n]
+  int cap;
+};
+
+template <int NDW>
+static __global__ void __launch_bounds__(512) k_mlp_dw(MlpDims dm, DwArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  const int tile = blockIdx.x, part = blockIdx.y, KS = gridDim.y;
+  int l = 0, g = blockIdx.z;
+  for (; l < dm.nL; l++) {
+    const int nj = cdiv(cdiv(dm.sizes[l], 32) * cdiv(dm.sizes[l + 1], 32), 8 * NDW);
+    if (g < nj) break;
+    g -= nj;
+  }
+  const int in = dm.sizes[l], out = dm.sizes[l + 1], in32 = pad32(in), out32 = pad32(out);
+  const int IT = in32 / 32, ntl = IT * (out32 / 32);
+  // LDS strides: an odd multiple of 32 floats puts the two half-waves of a ds_read_b32 on disjoint bank halves
+  const int lsa = in32 | 32, lsd = out32 | 32;
+  float* pa = dsm;
+  float* pd = pa + NB * lsa;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
+  f32x16 acc[NDW];
+  int aoff[NDW], doff[NDW];
+#pragma unroll
+  for (int m = 0; m < NDW; m++) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
+    const int tl = g * 8 * NDW + wave + 8 * m;
+    const int ot = tl / IT, it = tl - ot * IT;
+    aoff[m] = tl < ntl ? half * lsa + it * 32 + l31 : -1;
+    doff[m] = half * lsd + ot * 32 + l31;
+  }
+  float bsum[2] = {0.f, 0.f};
+  const int ns = a.nslots[tile];
+  const int col = tid >> 5;
+  for (int e = part; e < ns; e += KS) {
+    const float* blk = a.stage + ((size_t)tile * a.cap + e) * dm.blk_floats + dm.blk_off[l];
+    const float w = a.wts[((size_t)tile * a.cap + e) * NB + col];
+    for (int r4 = l31; 4 * r4 < in32; r4 += 32)
+      *reinterpret_cast<f32x4*>(pa + col * lsa + 4 * r4) = *reinterpret_cast<const f32x4*>(blk + col * in32 + 4 * r4);
+    for (int r4 = l31; 4 * r4 < out32; r4 += 32) {
+      f32x4 d = *reinterpret_cast<const f32x4*>(blk + NB * in32 + col * out32 + 4 * r4);
+      // a column that carries no weight may hold anything (a diverged trajectory's NaN): 0·NaN must not reach the sum
+#pragma unroll
+      for (int q = 0; q < 4; q++) d[q] = w != 0.f ? d[q] * w : 0.f;
+      *reinterpret_cast<f32x4*>(pd + col * lsd + 4 * r4) = d;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < NDW; m++) {
+      if (aoff[m] >= 0) {
+        const float* ap = pa + aoff[m];
+        const float* bp = pd + doff[m];
+        float av[8], bv[8];
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++) {
+          av[s8] = ap[s8 * 2 * lsa];
+          bv[s8] = bp[s8 * 2 * lsd];
+        }
+#pragma unroll
+        for (int s8 = 0; s8 < 8; s8++) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s8], bv[s8], acc[m], 0, 0, 0);
+      }
+    }
+    if (g == 0) {
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int row = tid + 512 * q;
+        if (row < out) {
+          float sacc = 0.f;
+#pragma unroll
+          for (int n = 0; n < NB; n++) sacc += pd[n * lsd + row];
+          bsum[q] += sacc;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* slab = a.slab + ((size_t)tile * KS + part) * dm.slab_n;
+#pragma unroll
+  for (int m = 0; m < NDW; m++) {
+    const int tl = g * 8 * NDW + wave + 8 * m;
+    if (tl < ntl) {
+      f32x4* g4 = reinterpret_cast<f32x4*>(slab + ((size_t)(dm.tile_off[l] + tl) * 64 + lane) * 16);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        f32x4 v;
+        v[0] = acc[m][4 * q + 0]; v[1] = acc[m][4 * q + 1]; v[2] = acc[m][4 * q + 2]; v[3] = acc[m][4 * q + 3];
+        g4[q] = v;
+      }
+    }
+  }
+  if (g == 0) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int row = tid + 512 * q;
+      if (row < out) slab[(size_t)dm.tile_off[dm.nL] * 1024 + dm.bias_lin[l] + row] = bsum[q];
+    }
+  }
+}
+
+// dW[flat] += Σ_wg slab[wg][fragment position of flat]   (workgroups added in index order ⇒ deterministic)
+static __global__ void k_reduce_slabs(const float* __restrict__ priv, const int32_t* __restrict__ nflush, int nwg,
+                               const float* __restrict__ slab, int nslab, MlpDims dm, float* __restrict__ dW,
+                               int32_t* __restrict__ feedback) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx == 0) {   // tell the host (asynchronously) whether any workgroup ran out of staging slots
+    int mx = 0;
+    for (int w = 0; w < nwg; w++) mx = max(mx, nflush[w]);
+    feedback[0] = mx;
+  }
+  if (idx >= dm.nW) return;
+  int l = 0;
+  while (l + 1 < dm.nL && idx >= dm.w_off[l + 1]) l++;
+  const int in = dm.sizes[l], out = dm.sizes[l + 1];
+  size_t pos;
+  if (idx < dm.b_off[l]) {
+    const int e = idx - dm.w_off[l], o = e % out, i = e / out;       // vec(W) column-major [out×in]
+    const int t = dm.tile_off[l] + (o >> 5) * cdiv(in, 32) + (i >> 5);
+    const int row = i & 31, col = o & 31;                             // tile holds Wᵀ: row = input index, col = output index
+    const int h = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);     // C/D layout of v_mfma_f32_32x32x2_f32
+    pos = ((size_t)t * 64 + col + 32 * h) * 16 + r;
+  } else
+    pos = (size_t)dm.tile_off[dm.nL] * 1024 + dm.bias_lin[l] + (idx - dm.b_off[l]);
+  float sacc = 0.f;
+  for (int w = 0; w < nslab; w++) sacc += slab[(size_t)w * dm.slab_n + pos];
+  for (int w = 0; w < nwg; w++)
+    if (nflush[w]) sacc += priv[(size_t)w * dm.slab_n + pos];
+  dW[idx] += sacc;
+}
+
+// jobs of k_mlp_dw: per layer, groups of up to 8·ndw tiles
+static int dw_jobs(const MlpDims& dm, int ndw) {
+  int n = 0;
+  for (int l = 0; l < dm.nL; l++) n += cdiv(cdiv(dm.sizes[l], 32) * cdiv(dm.sizes[l + 1], 32), 8 * ndw);
+  return n;
+}
+static int dw_ndw(const MlpDims& dm) {
+  int mx = 0;
+  for (int l = 0; l < dm.nL; l++) mx = std::max(mx, cdiv(dm.sizes[l], 32) * cdiv(dm.sizes[l + 1], 32));
+  return mx <= 16 ? 2 : 8;
+}
+
+template <class T>
+static bool grow(T** ptr, size_t* cap, size_t need) {
+  if (need <= *cap) return true;
+  if (*ptr) (void)hipFree(*ptr);
+  *ptr = nullptr;
+  *cap = 0;
+  if (hipMalloc(ptr, need * sizeof(T)) != hipSuccess) return false;
+  *cap = need;
+  return true;
+}
+
+template <int NDW>
+static int launch_dw(const MlpDims& dm, const DwArgs& a, dim3 grid, size_t lds, hipStream_t stream, std::string& err) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k_mlp_dw<NDW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
+      err = "hipFuncSetAttribute(k_mlp_dw) failed";
+      return LDE_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_mlp_dw<NDW>), grid, dim3(512), lds, stream, dm, a);
+  return LDE_OK;
+}
+
+}  // namespace lde
+#endif  // LDE_MFMA_H

@@ -98,5 +98,28 @@ def main():
               f"bwd {binfo['naccept']} acc / {binfo['nreject']} rej")
 
 
+def chain_main():
+    """Dense-chain fixture (scope row f-1): a small reconstructor-shaped chain, f32 oracle outputs + f64 truth."""
+    o32, o64 = O.Oracle("f32"), O.Oracle("f64")
+    sizes, acts, skips = (6, 48, 48, 48, 40), (O.CACT_RELU, O.CACT_RELU, O.CACT_RELU, O.CACT_SIGMOID), (0, 1, 1, 0)
+    d = O.make_chain_desc(sizes, acts, skips)
+    W = O.mlp_weights(sizes, seed=11)
+    rng = np.random.default_rng(12)
+    N = 24
+    x = rng.standard_normal((N, sizes[0])).astype(np.float32)
+    dy = (rng.standard_normal((N, sizes[-1])) / N).astype(np.float32)
+    y32 = o32.chain_forward(d, W, x)
+    dx32, dW32 = o32.chain_backward(d, W, x, dy)
+    y64 = o64.chain_forward(d, W.astype(np.float64), x.astype(np.float64))
+    dx64, dW64 = o64.chain_backward(d, W.astype(np.float64), x.astype(np.float64), dy.astype(np.float64))
+    path = os.path.join(HERE, "chain_decoder.npz")
+    np.savez_compressed(path, sizes=np.array(sizes), acts=np.array(acts), skips=np.array(skips), W=W, x=x, dy=dy,
+                        y_f32=y32, dx_f32=dx32, dW_f32=dW32, y_f64=y64, dx_f64=dx64, dW_f64=dW64)
+    print(f"chain_decoder: {os.path.getsize(path) / 1024:.1f} KB")
+
+
 if __name__ == "__main__":
-    main()
+    import sys
+    if "--chain-only" not in sys.argv:
+        main()
+    chain_main()

@@ -98,3 +98,69 @@ class Native:
         L.check(self.lib.lde_get_stats(self.h, which, C.byref(st), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
                 self.h, "lde_get_stats")
         return dict(nfe=st.nfe, naccept=st.naccept, nreject=st.nreject, nfailed=st.nfailed, max_steps=st.max_steps)
+
+
+class NativeChain:
+    """The dense-chain entry points of the C ABI (lde_chain_*), numpy in / numpy out."""
+
+    def __init__(self, sizes, acts, skips=None):
+        self.lib = L.load()
+        d = L.ChainDesc()
+        d.abi_version = L.LDE_ABI_VERSION
+        d.n_layers = len(sizes) - 1
+        for i, s in enumerate(sizes):
+            d.sizes[i] = s
+        for i, a in enumerate(acts):
+            d.activation[i] = a
+            d.skip[i] = int(bool(skips[i])) if skips is not None else 0
+        self.d, self.sizes = d, tuple(sizes)
+        self.h = C.c_void_p()
+        rc = self.lib.lde_chain_create(C.byref(d), C.byref(self.h))
+        if rc != 0:
+            try:
+                L.check(rc, self.h if self.h else None, "lde_chain_create", chain=True)
+            finally:
+                self.close()
+        self.nW = int(self.lib.lde_chain_num_weights(C.byref(d)))
+
+    def close(self):
+        if self.h:
+            self.lib.lde_chain_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_weights(self, W):
+        W = np.ascontiguousarray(W, np.float32)
+        L.check(self.lib.lde_chain_set_weights(self.h, W.ctypes.data_as(C.c_void_p), W.size), self.h,
+                "lde_chain_set_weights", chain=True)
+
+    def forward(self, x):
+        xd = torch.from_numpy(np.ascontiguousarray(x, np.float32)).to("cuda")
+        N = xd.shape[0]
+        y = torch.full((N, self.sizes[-1]), 7.0, device="cuda")
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(self.lib.lde_chain_forward(self.h, C.c_void_p(xd.data_ptr()), N, C.c_void_p(y.data_ptr()), s), self.h,
+                "lde_chain_forward", chain=True)
+        torch.cuda.synchronize()
+        return y.cpu().numpy()
+
+    def backward(self, x, y, dy, need_dx=True, dW0=None):
+        dev = "cuda"
+        xd = torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+        yd = torch.from_numpy(np.ascontiguousarray(y, np.float32)).to(dev)
+        dyd = torch.from_numpy(np.ascontiguousarray(dy, np.float32)).to(dev)
+        N = xd.shape[0]
+        dx = torch.full_like(xd, 7.0) if need_dx else None
+        dW = torch.zeros((self.nW,), device=dev) if dW0 is None else torch.from_numpy(np.ascontiguousarray(dW0, np.float32)).to(dev)
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(self.lib.lde_chain_backward(self.h, C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()),
+                                            C.c_void_p(dyd.data_ptr()), N,
+                                            C.c_void_p(dx.data_ptr()) if dx is not None else C.c_void_p(),
+                                            C.c_void_p(dW.data_ptr()), s), self.h, "lde_chain_backward", chain=True)
+        torch.cuda.synchronize()
+        return (None if dx is None else dx.cpu().numpy()), dW.cpu().numpy()

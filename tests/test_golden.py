@@ -11,7 +11,8 @@ import pytest
 from oracle import oracle as O
 from tests.golden import make_golden as G
 
-FIX = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+FIX = sorted(f for f in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
+             if not os.path.basename(f).startswith("chain_"))   # chain fixtures: tests/test_oracle_chain.py
 
 
 def test_fixture_set_is_complete():

@@ -1,0 +1,161 @@
+"""GPU parity of the dense chains either side of the solve (lde_chain_*, scope row f-1) against the CPU oracle.
+
+Tolerance: exact-f32 MFMA vs the oracle's sequential f32 sums ⇒ round-off only. Forward |Δy| ≤ 2e-5·max(1,|y|);
+gradients ≤ 1e-4 relative to the largest entry of the float64 reference, and no farther from float64 than 2× the f32
+oracle + 2e-5."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+RECON = ((2, 200, 200, 200, 784), (O.CACT_RELU, O.CACT_RELU, O.CACT_RELU, O.CACT_SIGMOID), (0, 1, 1, 0))
+LO_Z0 = ((16, 200, 2), (O.CACT_RELU, O.CACT_IDENTITY), (0, 0))
+LO_TH = ((16, 200, 1), (O.CACT_RELU, O.CACT_SOFTPLUS), (0, 0))
+ODD = ((5, 33, 33, 7, 7, 19), (O.CACT_TANH, O.CACT_SOFTPLUS, O.CACT_RELU, O.CACT_SIGMOID, O.CACT_IDENTITY), (0, 1, 0, 1, 0))
+WIDE = ((32, 512, 512, 40), (O.CACT_RELU, O.CACT_TANH, O.CACT_IDENTITY), (0, 1, 0))      # panels force 32 / 16 columns per tile
+ONE = ((24, 10), (O.CACT_SIGMOID,), (0,))
+
+
+def _run(spec, N, o32, o64, seed=5, need_dx=True):
+    from tests.gpu_util import NativeChain
+    sizes, acts, skips = spec
+    d = O.make_chain_desc(sizes, acts, skips)
+    W = O.mlp_weights(sizes, seed=seed + 2)
+    rng = np.random.default_rng(seed)
+    x = rng.standard_normal((N, sizes[0])).astype(np.float32)
+    dy = (rng.standard_normal((N, sizes[-1])) / N).astype(np.float32)
+    nat = NativeChain(sizes, acts, skips)
+    assert nat.nW == W.size
+    nat.set_weights(W)
+    y = nat.forward(x)
+    yr = o32.chain_forward(d, W, x)
+    y64 = o64.chain_forward(d, W.astype(np.float64), x.astype(np.float64))
+    sc = max(1.0, np.abs(y64).max())
+    assert np.abs(y - yr).max() <= 2e-5 * sc
+    assert np.abs(y - y64).max() <= 2e-5 * sc
+    dx, dW = nat.backward(x, y, dy, need_dx=need_dx)
+    rx, rW = o32.chain_backward(d, W, x, dy)
+    tx, tW = o64.chain_backward(d, W.astype(np.float64), x.astype(np.float64), dy.astype(np.float64))
+    for g, r, t, what in ((dx, rx, tx, "dx"), (dW, rW, tW, "dW")):
+        if g is None:
+            continue
+        s = np.abs(t).max()
+        assert np.isfinite(g).all(), what
+        assert np.abs(g - r).max() <= 1e-4 * s, what
+        assert np.abs(g - t).max() <= 2 * np.abs(r - t).max() + 2e-5 * s, what
+    return nat, (x, y, dy, dx, dW)
+
+
+@pytest.mark.parametrize("spec", [RECON, LO_Z0, LO_TH, ODD, WIDE, ONE], ids=["reconstructor", "lo_z0", "lo_theta", "odd", "wide", "one"])
+@pytest.mark.parametrize("N", [1, 37, 256])
+def test_chain_forward_backward_parity(o32, o64, spec, N):
+    _run(spec, N, o32, o64)
+
+
+def test_reconstructor_at_the_metric_shape(o32, o64):
+    """x̂ = reconstructor(ẑ) on N = B·T = 256·50 columns (the metric config's ẑ), ragged by one column."""
+    _run(RECON, 256 * 50 - 1, o32, o64, seed=9)
+
+
+def test_chain_dw_accumulates_and_dx_is_optional(o32):
+    nat, (x, y, dy, dx, dW) = _run(LO_TH, 100, o32, O.Oracle("f64"))
+    base = np.full(nat.nW, 0.25, np.float32)
+    dx2, dW2 = nat.backward(x, y, dy, need_dx=False, dW0=base)
+    assert dx2 is None
+    assert np.abs((dW2 - base) - dW).max() <= 1e-6 * max(1.0, np.abs(dW).max())
+    _, dW3 = nat.backward(x, y, dy)            # same call twice: same bits (fixed summation order)
+    _, dW4 = nat.backward(x, y, dy)
+    assert np.array_equal(dW3, dW4)
+
+
+def test_chain_golden_fixture():
+    from tests.gpu_util import NativeChain
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "chain_decoder.npz"))
+    nat = NativeChain(tuple(g["sizes"]), tuple(g["acts"]), tuple(g["skips"]))
+    nat.set_weights(g["W"])
+    y = nat.forward(g["x"])
+    assert np.abs(y - g["y_f32"]).max() <= 2e-6 and np.abs(y - g["y_f64"]).max() <= 2e-6
+    dx, dW = nat.backward(g["x"], y, g["dy"])
+    assert np.abs(dx - g["dx_f64"]).max() <= 3e-5 * np.abs(g["dx_f64"]).max()
+    assert np.abs(dW - g["dW_f64"]).max() <= 3e-5 * np.abs(g["dW_f64"]).max()
+
+
+def test_chain_errors_are_reported_not_thrown():
+    import ctypes as C
+    from latentdiffeq_amd import _lib as L
+    from tests.gpu_util import NativeChain
+    with pytest.raises(L.LdeError, match="UNSUPPORTED"):
+        NativeChain((8, 8, 4, 4), (1, 1, 1), (0, 0, 1))            # skip around the last layer
+    with pytest.raises(L.LdeError, match="INVALID_ARG"):
+        NativeChain((8, 9, 4), (1, 1), (1, 0))                      # skip needs in == out
+    nat = NativeChain((4, 8, 2), (1, 0))
+    import torch
+    x = torch.zeros((3, 4), device="cuda")
+    y = torch.zeros((3, 2), device="cuda")
+    rc = nat.lib.lde_chain_forward(nat.h, C.c_void_p(x.data_ptr()), 3, C.c_void_p(y.data_ptr()), C.c_void_p())
+    assert rc == -5 and b"weights" in nat.lib.lde_chain_last_error(nat.h)      # LDE_ERR_NO_WEIGHTS
+
+
+def test_torch_decoder_path_end_to_end(o64):
+    """decode(decoder, l̃, t) = apply_latent_out → diffeq_layer → apply_reconstructor with autograd through all three:
+    gradients of an MSE loss wrt every Dense parameter and wrt l̃ match the float64 oracle composition."""
+    import torch
+    import latentdiffeq_amd as M
+    from latentdiffeq_amd.chain import decode, default_decoder_layers
+    torch.manual_seed(0)
+    diffeq = M.Pendulum(abstol=1e-7, reltol=1e-7)
+    layers = default_decoder_layers(M.GOKU_basic(), 784, diffeq, device="cuda")
+    dec = M.Decoder(M.GOKU_basic(), layers)
+    B, T = 24, 10
+    ts = O.time_grid(T)
+    z0_t = torch.randn(16, B, device="cuda", requires_grad=True)
+    th_t = torch.randn(16, B, device="cuda", requires_grad=True)
+    # biases away from zero so that every term is exercised
+    with torch.no_grad():
+        for m in list(layers[0]) + [layers[2]]:
+            for p in m.parameters():
+                if p.dim() == 1:
+                    p.uniform_(-0.1, 0.1)
+    x_hat, z_hat, (z0_hat, th_hat) = decode(dec, (z0_t, th_t), ts)
+    assert x_hat.shape == (784, B, T) and z_hat.shape == (2, B, T) and z0_hat.shape == (2, B) and th_hat.shape == (1, B)
+    target = torch.rand(784, B, T, device="cuda")
+    loss = ((x_hat - target) ** 2).mean()
+    loss.backward()
+
+    # float64 composition with the oracle
+    lo_z0, lo_th = layers[0]
+    rec = layers[2]
+
+    def od(ch):
+        return O.make_chain_desc(ch.sizes, ch.acts, ch.skips), ch.flat_weights().detach().cpu().numpy().astype(np.float64)
+
+    (dz, Wz), (dt, Wt), (dr, Wr) = od(lo_z0), od(lo_th), od(rec)
+    z0t = z0_t.detach().cpu().numpy().T.astype(np.float64)
+    tht = th_t.detach().cpu().numpy().T.astype(np.float64)
+    z0h = o64.chain_forward(dz, Wz, z0t)
+    thh = o64.chain_forward(dt, Wt, tht)
+    assert np.abs(z0h - z0_hat.detach().cpu().numpy().T).max() <= 1e-5
+    assert np.abs(thh - th_hat.detach().cpu().numpy().T).max() <= 1e-5
+    sd = O.make_desc(abstol=1e-11, reltol=1e-11)
+    z64, _, _ = o64.forward(sd, z0h, thh, ts)
+    assert np.abs(z64 - z_hat.detach().cpu().numpy().transpose(2, 1, 0)).max() <= 2e-5
+    xh = o64.chain_forward(dr, Wr, z64.reshape(T * B, 2))
+    tg = target.cpu().numpy().transpose(2, 1, 0).reshape(T * B, 784).astype(np.float64)
+    dxh = 2.0 * (xh - tg) / xh.size
+    dz64, dWr = o64.chain_backward(dr, Wr, z64.reshape(T * B, 2), dxh)
+    g0, gth, _, _ = o64.adjoint(sd, z64, thh, ts, dz64.reshape(T, B, 2))
+    dz0t, dWz = o64.chain_backward(dz, Wz, z0t, g0)
+    dtht, dWt = o64.chain_backward(dt, Wt, tht, gth)
+
+    def flat_grad(ch):
+        return torch.cat([torch.cat([d.weight.grad.t().reshape(-1), d.bias.grad]) for d in ch._dense]).cpu().numpy()
+
+    for got, ref, what in ((flat_grad(rec), dWr, "reconstructor dW"), (flat_grad(lo_z0), dWz, "lo_z0 dW"),
+                           (flat_grad(lo_th), dWt, "lo_theta dW"), (z0_t.grad.cpu().numpy().T, dz0t, "dz̃0"),
+                           (th_t.grad.cpu().numpy().T, dtht, "dθ̃")):
+        s = np.abs(ref).max()
+        assert s > 0 and np.abs(got - ref).max() <= 2e-4 * s, what

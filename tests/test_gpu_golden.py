@@ -14,7 +14,8 @@ import pytest
 from tests.golden import make_golden as G
 
 pytestmark = pytest.mark.gpu
-FIX = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+FIX = sorted(f for f in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
+             if not os.path.basename(f).startswith("chain_"))   # chain fixtures: tests/test_oracle_chain.py
 
 
 @pytest.mark.parametrize("path", FIX, ids=[os.path.basename(f)[:-4] for f in FIX])

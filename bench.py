@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — trajectories/sec (forward solve + adjoint) of the latent-ODE hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload goku_pendulum|c2|c3|c4] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload goku_pendulum|c2|c3|c4|goku_decoder] [--batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -133,12 +133,214 @@ def cpu_baseline(w, d_native, ts, z0, theta, W, dz, budget_s=12.0):
                        f"{nthreads} OpenMP thread(s) (fastest of {cands} on {avail} available cores)")
 
 
+# ---- decoder path: apply_latent_out → diffeq_layer → apply_reconstructor and its pullback (scope row f-1) ----------
+DECODER = dict(desc="GOKU decoder: latent_out (16-200-2, 16-200-1 softplus) -> pendulum solve (Tsit5) -> reconstructor "
+                    "(2-200-200-200-784, skips, sigmoid), forward + pullback", B=256, T=50, input_dim=784, latent=16)
+
+
+def run_decoder(args, torch, dist, world, rank, local):
+    from latentdiffeq_amd import _lib as L
+    from latentdiffeq_amd import synthetic as S
+    lib = L.load()
+    w = WORKLOADS["goku_pendulum"]
+    B = args.batch or DECODER["B"]
+    T, D, P, NI, NL = DECODER["T"], 2, 1, DECODER["input_dim"], DECODER["latent"]
+    N = B * T
+    dev = torch.device("cuda", local)
+    d, ts, _, _, _, _ = build_problem(w, B, seed_shift=rank)
+    h = C.c_void_p()
+    L.check(lib.lde_create(C.byref(d), C.byref(h)), None, "lde_create")
+    L.check(lib.lde_reserve(h, B, T), h, "lde_reserve")
+    specs = {  # [REF src/models/GOKU.jl:252-269]
+        "lo_z0": ((NL, 200, D), (L.CACT_RELU, L.CACT_IDENTITY), (0, 0)),
+        "lo_th": ((NL, 200, P), (L.CACT_RELU, L.CACT_SOFTPLUS), (0, 0)),
+        "rec": ((D, 200, 200, 200, NI), (L.CACT_RELU, L.CACT_RELU, L.CACT_RELU, L.CACT_SIGMOID), (0, 1, 1, 0)),
+    }
+    chains, weights = {}, {}
+    for i, (name, (sizes, acts, skips)) in enumerate(specs.items()):
+        cdsc = L.ChainDesc()
+        cdsc.abi_version, cdsc.n_layers = L.LDE_ABI_VERSION, len(sizes) - 1
+        for k, v in enumerate(sizes):
+            cdsc.sizes[k] = v
+        for k, (a_, s_) in enumerate(zip(acts, skips)):
+            cdsc.activation[k], cdsc.skip[k] = a_, s_
+        ch = C.c_void_p()
+        L.check(lib.lde_chain_create(C.byref(cdsc), C.byref(ch)), ch if ch else None, "lde_chain_create", chain=True)
+        Wc = S.mlp_weights(sizes, seed=20 + i, scale=0.5 if name != "rec" else 1.0)
+        if name == "lo_th":   # keep the pendulum length L = softplus(·) in the data range U(1,2)
+            Wc[-1] = 1.0
+        L.check(lib.lde_chain_set_weights(ch, Wc.ctypes.data_as(C.c_void_p), Wc.size), ch, "lde_chain_set_weights", chain=True)
+        L.check(lib.lde_chain_reserve(ch, N if name == "rec" else B), ch, "lde_chain_reserve", chain=True)
+        chains[name], weights[name] = (ch, sizes), Wc
+    rng = np.random.default_rng(40 + rank)
+    zt = torch.from_numpy((0.6 * rng.standard_normal((B, NL))).astype(np.float32)).to(dev)     # l̃ = (z̃₀, θ̃)
+    tt = torch.from_numpy((0.6 * rng.standard_normal((B, NL))).astype(np.float32)).to(dev)
+    dxh = torch.from_numpy((rng.standard_normal((N, NI)) / (N * NI)).astype(np.float32)).to(dev)  # ∂L/∂x̂ of an MSE
+    z0 = torch.empty((B, D), device=dev); th = torch.empty((B, P), device=dev)
+    zout = torch.empty((T, B, D), device=dev); ret = torch.empty((B,), device=dev, dtype=torch.int32)
+    xhat = torch.empty((N, NI), device=dev)
+    dz = torch.empty((T, B, D), device=dev); dz0 = torch.empty((B, D), device=dev); dth = torch.empty((B, P), device=dev)
+    dzt = torch.empty((B, NL), device=dev); dtt = torch.empty((B, NL), device=dev)
+    nWs = {k: int(v.size) for k, v in weights.items()}
+    flat = torch.zeros((sum(nWs.values()),), device=dev)      # ONE flat gradient buffer ⇒ one all-reduce
+    offs, o = {}, 0
+    for k in specs:
+        offs[k] = o
+        o += nWs[k]
+    gW = {k: flat[offs[k]:offs[k] + nWs[k]] for k in specs}
+    tsp = ts.ctypes.data_as(C.POINTER(C.c_double))
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p()
+    stream = torch.cuda.current_stream()
+    sp = C.c_void_p(stream.cuda_stream)
+    ck = lambda rc, ch, what: L.check(rc, ch, what, chain=True)
+
+    def fwd():
+        ck(lib.lde_chain_forward(chains["lo_z0"][0], p(zt), B, p(z0), sp), chains["lo_z0"][0], "lo_z0 fwd")
+        ck(lib.lde_chain_forward(chains["lo_th"][0], p(tt), B, p(th), sp), chains["lo_th"][0], "lo_th fwd")
+        L.check(lib.lde_forward(h, p(z0), p(th), tsp, T, B, p(zout), p(ret), sp), h, "lde_forward")
+        ck(lib.lde_chain_forward(chains["rec"][0], p(zout), N, p(xhat), sp), chains["rec"][0], "rec fwd")
+
+    def bwd():
+        flat.zero_()
+        ck(lib.lde_chain_backward(chains["rec"][0], p(zout), p(xhat), p(dxh), N, p(dz), p(gW["rec"]), sp), chains["rec"][0], "rec bwd")
+        L.check(lib.lde_adjoint(h, p(zout), p(th), tsp, T, B, p(dz), p(dz0), p(dth), C.c_void_p(), sp), h, "lde_adjoint")
+        ck(lib.lde_chain_backward(chains["lo_z0"][0], p(zt), p(z0), p(dz0), B, p(dzt), p(gW["lo_z0"]), sp), chains["lo_z0"][0], "lo_z0 bwd")
+        ck(lib.lde_chain_backward(chains["lo_th"][0], p(tt), p(th), p(dth), B, p(dtt), p(gW["lo_th"]), sp), chains["lo_th"][0], "lo_th bwd")
+        if world > 1:
+            dist.all_reduce(flat)     # the one collective: shared decoder parameters
+
+    def step():
+        fwd()
+        bwd()
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        el = float(tmax.item())
+    assert int(ret.abs().sum().item()) == 0 and bool(torch.isfinite(flat).all()) and float(flat.abs().max()) > 0
+
+    def ev_ms(fn, n):
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        for a, b in evs:
+            a.record(stream); fn(); b.record(stream)
+        torch.cuda.synchronize()
+        return float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
+    n = min(args.steps, 50)
+    parts = {
+        "reconstructor_forward": ev_ms(lambda: ck(lib.lde_chain_forward(chains["rec"][0], p(zout), N, p(xhat), sp), chains["rec"][0], "f"), n),
+        "reconstructor_backward": ev_ms(lambda: ck(lib.lde_chain_backward(chains["rec"][0], p(zout), p(xhat), p(dxh), N, p(dz), p(gW["rec"]), sp), chains["rec"][0], "b"), n),
+        "lde_forward": ev_ms(lambda: L.check(lib.lde_forward(h, p(z0), p(th), tsp, T, B, p(zout), p(ret), sp), h, "f"), n),
+        "lde_adjoint": ev_ms(lambda: L.check(lib.lde_adjoint(h, p(zout), p(th), tsp, T, B, p(dz), p(dz0), p(dth), C.c_void_p(), sp), h, "a"), n),
+        "latent_out_forward_x2": ev_ms(lambda: (lib.lde_chain_forward(chains["lo_z0"][0], p(zt), B, p(z0), sp), lib.lde_chain_forward(chains["lo_th"][0], p(tt), B, p(th), sp)), n),
+        "latent_out_backward_x2": ev_ms(lambda: (lib.lde_chain_backward(chains["lo_z0"][0], p(zt), p(z0), p(dz0), B, p(dzt), p(gW["lo_z0"]), sp),
+                                                 lib.lde_chain_backward(chains["lo_th"][0], p(tt), p(th), p(dth), B, p(dtt), p(gW["lo_th"]), sp)), n),
+    }
+    mac = lambda sizes: sum(a * b for a, b in zip(sizes[:-1], sizes[1:]))
+    F_rec = 2 * mac(specs["rec"][0]) * N
+    F_lo = 2 * (mac(specs["lo_z0"][0]) + mac(specs["lo_th"][0])) * B
+    # algorithmic flops of a step: forward F, pullback 2F (input + weight gradients); the solve's flops are negligible here
+    flops = 3 * (F_rec + F_lo)
+    ms_per_step = el / args.steps * 1e3
+    dom = max(("reconstructor_forward", "reconstructor_backward"), key=lambda k: parts[k])
+    dom_flops = F_rec if dom == "reconstructor_forward" else 2 * F_rec
+    ach = dom_flops / (parts[dom] * 1e-3) / 1e12
+    out = {
+        "metric": "trajectories/sec (latent_out -> solve -> reconstructor, forward + pullback) goku_decoder",
+        "value": B * world * args.steps / el, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"goku_decoder: {DECODER['desc']}", "batch_per_gpu": B, "global_batch": B * world,
+                   "save_points": T, "columns_through_the_reconstructor": N,
+                   "parallelism": f"dp{world} (batch sharded by trajectory; one all-reduce of the flat decoder gradient per step)"},
+        "roofline": dict(bound="mfma", kernel=f"lde_chain {dom}", achieved=ach, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s",
+                         frac=ach / FP32_PEAK_TFLOPS, traffic=None, alg_flops_per_launch=dom_flops, avg_launch_ms=parts[dom],
+                         whole_step_TFLOPs=flops / (ms_per_step * 1e-3) / 1e12),
+        "kernel_ms": parts,
+    }
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = decoder_cpu_baseline(specs, weights, d, ts, zt.cpu().numpy(), tt.cpu().numpy(), dxh.cpu().numpy(), B, T)
+    else:
+        out["cpu_baseline"] = None
+    for ch, _ in chains.values():
+        lib.lde_chain_destroy(ch)
+    lib.lde_destroy(h)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def decoder_cpu_baseline(specs, weights, d_native, ts, zt, tt, dxh, B, T, budget_s=12.0):
+    """The same decoder step with the CPU oracle (OpenMP over columns / trajectories), bounded sample."""
+    from oracle import oracle as O
+    try:
+        orc = O.Oracle("f32", native=True)
+    except Exception:
+        orc = O.Oracle("f32")
+    od = O.Desc()
+    C.memmove(C.byref(od), C.byref(d_native), C.sizeof(od))
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cd = {k: O.make_chain_desc(*v) for k, v in specs.items()}
+    cap = min(B, 64)                         # bounded sample: 64 trajectories × T columns
+    zs, tsm, dxs = zt[:cap], tt[:cap], dxh.reshape(T, B, -1)[:, :cap].reshape(T * cap, -1)
+
+    def one(nt):
+        z0 = orc.chain_forward(cd["lo_z0"], weights["lo_z0"], zs, nthreads=nt)
+        th = orc.chain_forward(cd["lo_th"], weights["lo_th"], tsm, nthreads=nt)
+        z, _, _ = orc.forward(od, z0, th, ts, nthreads=nt)
+        zc = z.reshape(T * cap, -1)
+        orc.chain_forward(cd["rec"], weights["rec"], zc, nthreads=nt)
+        dz, _ = orc.chain_backward(cd["rec"], weights["rec"], zc, dxs, nthreads=nt)
+        g0, gth, _, _ = orc.adjoint(od, z, th, ts, dz.reshape(T, cap, -1), nthreads=nt)
+        orc.chain_backward(cd["lo_z0"], weights["lo_z0"], zs, g0, nthreads=nt)
+        orc.chain_backward(cd["lo_th"], weights["lo_th"], tsm, gth, nthreads=nt)
+
+    def rate(nt, budget):
+        one(nt)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            one(nt)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget:
+                return n, el
+
+    cands = sorted({1, 8, 16, 32, 64, min(avail, 128), avail} & set(range(1, avail + 1)))
+    best, best_r = 1, 0.0
+    for nt in cands:
+        n, el = rate(nt, 1.0)
+        if n * cap / el > best_r:
+            best, best_r = nt, n * cap / el
+    n, el = rate(best, budget_s)
+    return dict(value=n * cap / el, unit="trajectories/s", cores=best, kind="port",
+                sample=f"{n} passes of the decoder step over {cap} trajectories ({cap * T} reconstructor columns), {el:.1f} s wall, "
+                       f"{best} OpenMP thread(s) (fastest of {cands} on {avail} available cores)")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="goku_pendulum", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default="goku_pendulum", choices=sorted(WORKLOADS) + ["goku_decoder"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep", action="store_true", help="also report a large-batch sweep (extra keys, rank 0)")
@@ -158,6 +360,9 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    if args.workload == "goku_decoder":
+        return run_decoder(args, torch, dist, world, rank, local)
 
     from latentdiffeq_amd import _lib as L
     lib = L.load()

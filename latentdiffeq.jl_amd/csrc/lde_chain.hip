@@ -41,7 +41,7 @@ __device__ __forceinline__ float cact(int kind, float x) {
   switch (kind) {
     case LDE_CACT_RELU: return fmaxf(x, 0.f);
     case LDE_CACT_TANH: return tanhf(x);
-    case LDE_CACT_SIGMOID: return 1.0f / (1.0f + expf(-x));
+    case LDE_CACT_SIGMOID: return fast_rcp(1.0f + __expf(-x));   // v_exp_f32 + v_rcp_f32: ≈ 1e-7 absolute on (0,1)
     case LDE_CACT_SOFTPLUS: return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
     default: return x;
   }
@@ -57,79 +57,106 @@ __device__ __forceinline__ float cact_grad_out(int kind, float f) {
   }
 }
 
-// Y[R × 16·CG] = M[R×K] · B[K × 16·CG] for one workgroup of 8 waves. M as K4 fragments in global memory (L2-resident),
-// B transposed: element (k, column c of group cg) at Bp[cg*cgstride + c*ldb + k], in LDS or (BGLB) in global memory.
-// A wave takes row tiles rt and rt+8 together: per K-group 2 fragment loads + CG operand loads feed 8·CG MFMAs.
-// pre(row0, cg, col) is called before the K loop (its loads overlap the MFMAs), epi(row0, cg, col, acc, pre-result) after.
-template <int CG, bool BGLB, class Pre, class Epi>
-__device__ __forceinline__ void chain_gemm(const float* __restrict__ gfrag, int R, int K, const float* Bp, int ldb,
-                                           int cgstride, Pre pre, Epi epi) {
-  constexpr int NW = 8, PFA = 4, PFB = BGLB ? 4 : 2;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int RT = cdiv(R, 16), KG = cdiv(K, 16), kl = KG - 1;
-  const f32x4* A = reinterpret_cast<const f32x4*>(gfrag) + lane;
-  const float* bp = Bp + (lane & 15) * ldb + 4 * (lane >> 4);
-  const int col = lane & 15, rsub = 4 * (lane >> 4);
-  for (int rt = wave; rt < RT; rt += 2 * NW) {
-    const int rt2 = rt + NW;
-    const bool two = rt2 < RT;
-    const f32x4* A0 = A + (size_t)rt * KG * 64;
-    const f32x4* A1 = A + (size_t)(two ? rt2 : rt) * KG * 64;   // a lone tile is computed twice (the wave would idle anyway)
-    f32x4 acc0[CG], acc1[CG];
+// One wave: NT_ (1 or 2) 16-row tiles × NCG column groups, all K-groups, software-pipelined: A fragments (global/L2) run
+// PFA K-groups ahead in a register ring, B operands PFB ahead; pre() is called before the K loop (its loads overlap the
+// MFMAs), epi() after. Per K-group NT_ fragment loads + NCG operand loads feed 4·NT_·NCG MFMAs.
+template <int NT_, int NCG, bool BGLB, class Pre, class Epi>
+__device__ __forceinline__ void chain_mac(const f32x4* A0, const f32x4* A1, const float* bp, int cgstride, int KG, int row_a,
+                                          int row_b, int cg0, int col, Pre pre, Epi epi) {
+  constexpr int PFA = 4, PFB = BGLB ? 4 : 2;
+  const int kl = KG - 1;
+  f32x4 acc0[NCG], acc1[NCG];
+  decltype(pre(0, 0, 0)) p0[NCG], p1[NCG];
 #pragma unroll
-    for (int cg = 0; cg < CG; cg++) {
-      acc0[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
-      acc1[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    decltype(pre(0, 0, 0)) p0[CG], p1[CG];
+  for (int cg = 0; cg < NCG; cg++) {
+    acc0[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc1[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+    p0[cg] = pre(row_a, cg0 + cg, col);
+    if (NT_ == 2) p1[cg] = pre(row_b >= 0 ? row_b : row_a, cg0 + cg, col);
+  }
+  f32x4 ra0[PFA], ra1[PFA], rb[PFB][NCG];
 #pragma unroll
-    for (int cg = 0; cg < CG; cg++) {
-      p0[cg] = pre(rt * 16 + rsub, cg, col);
-      p1[cg] = pre((two ? rt2 : rt) * 16 + rsub, cg, col);
-    }
-    f32x4 ra0[PFA], ra1[PFA], rb[PFB][CG];
+  for (int i = 0; i < PFA; i++) {
+    const int k = min(i, kl);
+    ra0[i] = A0[k * 64];
+    if (NT_ == 2) ra1[i] = A1[k * 64];
+  }
+#pragma unroll
+  for (int i = 0; i < PFB; i++) {
+    const int k = min(i, kl);
+#pragma unroll
+    for (int cg = 0; cg < NCG; cg++) rb[i][cg] = *reinterpret_cast<const f32x4*>(bp + (cg0 + cg) * cgstride + k * 16);
+  }
+  for (int kg = 0; kg < KG; kg += PFA) {
 #pragma unroll
     for (int i = 0; i < PFA; i++) {
-      const int k = min(i, kl);
-      ra0[i] = A0[k * 64];
-      ra1[i] = A1[k * 64];
-    }
+      if (kg + i < KG) {
+        const f32x4 c0 = ra0[i];
+        f32x4 c1 = c0;
+        if (NT_ == 2) c1 = ra1[i];
+        f32x4 cb[NCG];
 #pragma unroll
-    for (int i = 0; i < PFB; i++) {
-      const int k = min(i, kl);
+        for (int cg = 0; cg < NCG; cg++) cb[cg] = rb[i % PFB][cg];
+        const int ka = min(kg + i + PFA, kl), kb = min(kg + i + PFB, kl);
+        ra0[i] = A0[ka * 64];
+        if (NT_ == 2) ra1[i] = A1[ka * 64];
 #pragma unroll
-      for (int cg = 0; cg < CG; cg++) rb[i][cg] = *reinterpret_cast<const f32x4*>(bp + cg * cgstride + k * 16);
-    }
-    for (int kg = 0; kg < KG; kg += PFA) {
+        for (int cg = 0; cg < NCG; cg++) rb[i % PFB][cg] = *reinterpret_cast<const f32x4*>(bp + (cg0 + cg) * cgstride + kb * 16);
 #pragma unroll
-      for (int i = 0; i < PFA; i++) {
-        if (kg + i < KG) {
-          const f32x4 c0 = ra0[i], c1 = ra1[i];
-          f32x4 cb[CG];
+        for (int cg = 0; cg < NCG; cg++) {
 #pragma unroll
-          for (int cg = 0; cg < CG; cg++) cb[cg] = rb[i % PFB][cg];
-          const int ka = min(kg + i + PFA, kl), kb = min(kg + i + PFB, kl);
-          ra0[i] = A0[ka * 64];
-          ra1[i] = A1[ka * 64];
-#pragma unroll
-          for (int cg = 0; cg < CG; cg++) rb[i % PFB][cg] = *reinterpret_cast<const f32x4*>(bp + cg * cgstride + kb * 16);
-#pragma unroll
-          for (int cg = 0; cg < CG; cg++) {
-#pragma unroll
-            for (int s4 = 0; s4 < 4; s4++) {
-              acc0[cg] = mfma16(c0[s4], cb[cg][s4], acc0[cg]);
-              acc1[cg] = mfma16(c1[s4], cb[cg][s4], acc1[cg]);
-            }
+          for (int s4 = 0; s4 < 4; s4++) {
+            acc0[cg] = mfma16(c0[s4], cb[cg][s4], acc0[cg]);
+            if (NT_ == 2) acc1[cg] = mfma16(c1[s4], cb[cg][s4], acc1[cg]);
           }
         }
       }
     }
+  }
 #pragma unroll
-    for (int cg = 0; cg < CG; cg++) {
-      epi(rt * 16 + rsub, cg, col, acc0[cg], p0[cg]);
-      if (two) epi(rt2 * 16 + rsub, cg, col, acc1[cg], p1[cg]);
-    }
+  for (int cg = 0; cg < NCG; cg++) {
+    epi(row_a, cg0 + cg, col, acc0[cg], p0[cg]);
+    if (NT_ == 2 && row_b >= 0) epi(row_b, cg0 + cg, col, acc1[cg], p1[cg]);   // row_b < 0: the second tile was a stand-in
+  }
+}
+
+// Y[R × 16·CG] = M[R×K] · B[K × 16·CG] for one workgroup of 8 waves. M as K4 fragments in global memory (L2-resident),
+// B transposed: element (k, column c of group cg) at Bp[cg*cgstride + c*ldb + k], in LDS or (BGLB) in global memory.
+// Row tiles are dealt 16 at a time (a wave takes tiles rt and rt+8 together); 9–15 left-over tiles make one more such
+// pass, exactly 8 a single-tile pass, and fewer than 8 are dealt as (tile, column group) units so that the last pass
+// still uses every wave (49 tiles of the 784-row layer: 3 passes + 1/8 instead of 4).
+template <int CG, bool BGLB, class Pre, class Epi>
+__device__ __forceinline__ void chain_gemm(const float* __restrict__ gfrag, int R, int K, const float* Bp, int ldb,
+                                           int cgstride, Pre pre, Epi epi) {
+  constexpr int NW = 8;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int RT = cdiv(R, 16), KG = cdiv(K, 16);
+  const f32x4* A = reinterpret_cast<const f32x4*>(gfrag) + lane;
+  const float* bp = Bp + (lane & 15) * ldb + 4 * (lane >> 4);
+  const int col = lane & 15, rsub = 4 * (lane >> 4);
+  int base = 0;
+  for (; base + 2 * NW <= RT; base += 2 * NW) {
+    const int rt = base + wave, rt2 = rt + NW;
+    chain_mac<2, CG, BGLB>(A + (size_t)rt * KG * 64, A + (size_t)rt2 * KG * 64, bp, cgstride, KG, rt * 16 + rsub,
+                           rt2 * 16 + rsub, 0, col, pre, epi);
+  }
+  if (RT - base > NW) {   // 9–15 tiles left: one more double pass; a wave without a second tile repeats its first
+    const int rt = base + wave, rt2 = rt + NW;
+    const bool two = rt2 < RT;
+    chain_mac<2, CG, BGLB>(A + (size_t)rt * KG * 64, A + (size_t)(two ? rt2 : rt) * KG * 64, bp, cgstride, KG,
+                           rt * 16 + rsub, two ? rt2 * 16 + rsub : -1, 0, col, pre, epi);
+    return;
+  }
+  if (RT - base == NW) {
+    const int rt = base + wave;
+    chain_mac<1, CG, BGLB>(A + (size_t)rt * KG * 64, nullptr, bp, cgstride, KG, rt * 16 + rsub, 0, 0, col, pre, epi);
+    return;
+  }
+  const int units = (RT - base) * CG;
+  for (int u = wave; u < units; u += NW) {
+    const int rt = base + u / CG, cg = u % CG;
+    chain_mac<1, 1, BGLB>(A + (size_t)rt * KG * 64, nullptr, bp, cgstride, KG, rt * 16 + rsub, 0, cg, col, pre, epi);
   }
 }
 
@@ -529,13 +556,14 @@ int lde_chain_set_weights_device(lde_chain* c, const float* flat_dev, int64_t n,
   return chain_frags(c, (hipStream_t)stream);
 }
 
-// virtual tiling of the slot range for k_mlp_dw: nvt tiles × ks parts ≈ 32 partial slabs
+// virtual tiling of the slot range for k_mlp_dw: (virtual tiles × jobs) ≈ one workgroup per CU — the kernel's register
+// footprint allows one resident workgroup per CU, so 256 equal shares beat 384 (a second, half-empty round)
 static void chain_dw_split(const lde_chain* c, int64_t N, int* nvt, int* cap, int64_t* total) {
   const int64_t tiles = (N + 16 * c->cg_bwd - 1) / (16 * c->cg_bwd);
   *total = tiles * c->cg_bwd;
-  int v = 32;
-  if (*total < v) v = (int)*total;
+  int v = 256 / dw_jobs(c->cd.dm);
   if (v < 1) v = 1;
+  if (*total < v) v = (int)*total;
   *nvt = v;
   *cap = (int)((*total + v - 1) / v);
   if (*cap < 1) *cap = 1;
@@ -548,7 +576,7 @@ int lde_chain_reserve(lde_chain* c, int64_t N) {
   chain_dw_split(c, N, &nvt, &cap, &total);
   const MlpDims& dm = c->cd.dm;
   if (!grow(&c->stage, &c->stage_cap, (size_t)total * dm.blk_floats) || !grow(&c->wts, &c->wts_cap, (size_t)total * NB) ||
-      !grow(&c->slab, &c->slab_cap, (size_t)nvt * dm.slab_n) || !grow(&c->ints, &c->ints_cap, (size_t)nvt + 16)) {
+      !grow(&c->slab, &c->slab_cap, ((size_t)nvt + 1) * dm.slab_n) || !grow(&c->ints, &c->ints_cap, (size_t)nvt + 16)) {
     c->err = "chain: hipMalloc of the backward workspace failed";
     return LDE_ERR_ALLOC;
   }
@@ -638,23 +666,8 @@ int lde_chain_backward(lde_chain* c, const float* x, const float* y, const float
   // weight gradient: large-K product over the staged panels (lde_mfma.h)
   DwArgs da;
   da.stage = c->stage; da.wts = c->wts; da.nslots = c->ints; da.slab = c->slab; da.cap = cap;
-  const int ndw = dw_ndw(dm);
-  int maxrows = 0;
-  for (int l = 0; l < dm.nL; l++) maxrows = std::max(maxrows, (pad32(dm.sizes[l]) | 32) + (pad32(dm.sizes[l + 1]) | 32));
-  const size_t dlds = (size_t)NB * maxrows * sizeof(float);
-  if (dlds > LDS_MAX) {
-    c->err = "chain: layer too wide for the weight-gradient kernel's LDS panels";
-    return LDE_ERR_UNSUPPORTED;
-  }
-  const dim3 dgrid(nvt, 1, dw_jobs(dm, ndw));
-  rc = ndw == 2 ? launch_dw<2>(dm, da, dgrid, dlds, stream, c->err) : launch_dw<8>(dm, da, dgrid, dlds, stream, c->err);
+  rc = launch_weight_gradient(dm, da, nvt, 1, nullptr, c->ints + nvt, 0, dW, c->ints + nvt + 1, stream, c->err);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_reduce_slabs, dim3(cdiv(dm.nW, 256)), dim3(256), 0, stream, (const float*)nullptr,
-                     (const int32_t*)(c->ints + nvt), 0, (const float*)c->slab, nvt, dm, dW, c->ints + nvt + 1);
-  if (hipGetLastError() != hipSuccess) {
-    c->err = "chain: weight-gradient kernels failed to launch";
-    return LDE_ERR_HIP;
-  }
   return LDE_OK;
 }
 

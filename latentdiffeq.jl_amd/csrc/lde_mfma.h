@@ -145,9 +145,12 @@ inline void fill_layer_offsets(MlpDims& dm, size_t* nfrag, size_t* nfragT) {
 static constexpr size_t LDS_MAX = 160 * 1024;
 
 // ---- the weight gradient as one large-K product over everything the solve staged ---------------------------------------
-// grid (solve tile, K-split part, job); a job = up to 8·NDW 32×32 tiles of ONE layer's gWᵀ. The workgroup walks the
-// tile's staged slots part, part+KS, …: copies that layer's a-panel and (weight-scaled) δ-panel into LDS and every wave
-// adds 8 MFMAs (K = the 16 columns) to each of its tiles. Result: the (tile, part) slab in accumulator-fragment order.
+// grid (solve tile, K-split part, job). A job is a block of 32×32 tiles of ONE layer's gWᵀ[in×out]: a range of output
+// tiles [o0,o1) × a range of input tiles [i0,i1), at most DW_CAP tiles (4 per wave). The workgroup walks the tile's
+// staged slots part, part+KS, …: copies the rows of that layer's a-panel and (weight-scaled) δ-panel it needs into LDS
+// and every wave adds 8 MFMAs (v_mfma_f32_32x32x2_f32, K = the 16 columns of the slot) to each of its tiles.
+// ≈ 110 VGPRs and a few tens of KB of LDS ⇒ two workgroups per CU: one loads while the other multiplies.
+// Result: the job's part of the (tile, part) slab, tiles in accumulator-fragment order (+ bias sums).
 struct DwArgs {
   const float* stage;
   const float* wts;
@@ -156,53 +159,123 @@ struct DwArgs {
   int cap;
 };
 
-template <int NDW>
+constexpr int DW_NDW = 4;            // accumulator tiles per wave
+constexpr int DW_CAP = 8 * DW_NDW;   // tiles per job
+
+struct DwJob { int l, o0, o1, i0, i1; };
+
+__host__ __device__ inline int dw_layer_jobs(int IT, int OT) {
+  return IT <= DW_CAP ? cdiv(OT, DW_CAP / IT) : OT * cdiv(IT, DW_CAP);
+}
+__host__ __device__ inline int dw_jobs(const MlpDims& dm) {
+  int n = 0;
+  for (int l = 0; l < dm.nL; l++) n += dw_layer_jobs(cdiv(dm.sizes[l], 32), cdiv(dm.sizes[l + 1], 32));
+  return n;
+}
+__host__ __device__ inline DwJob dw_decode(const MlpDims& dm, int z) {
+  DwJob j{0, 0, 0, 0, 0};
+  for (int l = 0; l < dm.nL; l++) {
+    const int IT = cdiv(dm.sizes[l], 32), OT = cdiv(dm.sizes[l + 1], 32), nj = dw_layer_jobs(IT, OT);
+    if (z < nj) {
+      j.l = l;
+      if (IT <= DW_CAP) {
+        const int ro = DW_CAP / IT;
+        j.o0 = z * ro;
+        j.o1 = min(OT, j.o0 + ro);
+        j.i0 = 0;
+        j.i1 = IT;
+      } else {
+        const int nic = cdiv(IT, DW_CAP);
+        j.o0 = z / nic;
+        j.o1 = j.o0 + 1;
+        j.i0 = (z % nic) * DW_CAP;
+        j.i1 = min(IT, j.i0 + DW_CAP);
+      }
+      return j;
+    }
+    z -= nj;
+  }
+  return j;
+}
+// LDS floats a job of this layer set needs at most
+inline size_t dw_lds_floats(const MlpDims& dm) {
+  size_t mx = 0;
+  for (int z = 0, n = dw_jobs(dm); z < n; z++) {
+    const DwJob j = dw_decode(dm, z);
+    mx = std::max(mx, (size_t)NB * (((32 * (j.i1 - j.i0)) | 32) + ((32 * (j.o1 - j.o0)) | 32)));
+  }
+  return mx;
+}
+
 static __global__ void __launch_bounds__(512) k_mlp_dw(MlpDims dm, DwArgs a) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   const int tile = blockIdx.x, part = blockIdx.y, KS = gridDim.y;
-  int l = 0, g = blockIdx.z;
-  for (; l < dm.nL; l++) {
-    const int nj = cdiv(cdiv(dm.sizes[l], 32) * cdiv(dm.sizes[l + 1], 32), 8 * NDW);
-    if (g < nj) break;
-    g -= nj;
-  }
-  const int in = dm.sizes[l], out = dm.sizes[l + 1], in32 = pad32(in), out32 = pad32(out);
-  const int IT = in32 / 32, ntl = IT * (out32 / 32);
+  const DwJob jb = dw_decode(dm, blockIdx.z);
+  const int l = jb.l, in = dm.sizes[l], out = dm.sizes[l + 1], in32 = pad32(in), out32 = pad32(out);
+  const int IT = in32 / 32, nit = jb.i1 - jb.i0, ntile = (jb.o1 - jb.o0) * nit;
+  const int na = 32 * nit, nd = 32 * (jb.o1 - jb.o0), ra0 = 32 * jb.i0, rd0 = 32 * jb.o0;
   // LDS strides: an odd multiple of 32 floats puts the two half-waves of a ds_read_b32 on disjoint bank halves
-  const int lsa = in32 | 32, lsd = out32 | 32;
+  const int lsa = na | 32, lsd = nd | 32;
   float* pa = dsm;
   float* pd = pa + NB * lsa;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, half = lane >> 5, l31 = lane & 31;
-  f32x16 acc[NDW];
-  int aoff[NDW], doff[NDW];
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  f32x16 acc[DW_NDW];
+  int aoff[DW_NDW], doff[DW_NDW];
 #pragma unroll
-  for (int m = 0; m < NDW; m++) {
+  for (int m = 0; m < DW_NDW; m++) {
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
-    const int tl = g * 8 * NDW + wave + 8 * m;
-    const int ot = tl / IT, it = tl - ot * IT;
-    aoff[m] = tl < ntl ? half * lsa + it * 32 + l31 : -1;
-    doff[m] = half * lsd + ot * 32 + l31;
+    const int t = wave + 8 * m;
+    const int otl = t / nit, itl = t - otl * nit;
+    aoff[m] = t < ntile ? half * lsa + itl * 32 + l31 : -1;
+    doff[m] = half * lsd + otl * 32 + l31;
   }
+  const bool do_bias = jb.i0 == 0;   // the jobs that hold the first input tile of their output rows also sum the bias gradient
   float bsum[2] = {0.f, 0.f};
   const int ns = a.nslots[tile];
   const int col = tid >> 5;
+  // Slot e+KS's rows are fetched into registers while slot e is multiplied (up to PQ quads of each panel per lane;
+  // wider jobs fetch the rest at store time).
+  constexpr int PQ = 2;
+  f32x4 qa[PQ], qd[PQ];
+  float qw = 0.f;
+  auto fetch = [&](int e) {
+    const float* blk = a.stage + ((size_t)tile * a.cap + e) * dm.blk_floats + dm.blk_off[l];
+    qw = a.wts[((size_t)tile * a.cap + e) * NB + col];
+#pragma unroll
+    for (int q = 0; q < PQ; q++) {
+      const int r4 = l31 + 32 * q;
+      if (4 * r4 < na) qa[q] = *reinterpret_cast<const f32x4*>(blk + col * in32 + ra0 + 4 * r4);
+      if (4 * r4 < nd) qd[q] = *reinterpret_cast<const f32x4*>(blk + NB * in32 + col * out32 + rd0 + 4 * r4);
+    }
+  };
+  auto scale = [&](f32x4 dv, float w) {
+    // a column that carries no weight may hold anything (a diverged trajectory's NaN): 0·NaN must not reach the sum
+#pragma unroll
+    for (int q = 0; q < 4; q++) dv[q] = w != 0.f ? dv[q] * w : 0.f;
+    return dv;
+  };
+  if (part < ns) fetch(part);
   for (int e = part; e < ns; e += KS) {
     const float* blk = a.stage + ((size_t)tile * a.cap + e) * dm.blk_floats + dm.blk_off[l];
-    const float w = a.wts[((size_t)tile * a.cap + e) * NB + col];
-    for (int r4 = l31; 4 * r4 < in32; r4 += 32)
-      *reinterpret_cast<f32x4*>(pa + col * lsa + 4 * r4) = *reinterpret_cast<const f32x4*>(blk + col * in32 + 4 * r4);
-    for (int r4 = l31; 4 * r4 < out32; r4 += 32) {
-      f32x4 d = *reinterpret_cast<const f32x4*>(blk + NB * in32 + col * out32 + 4 * r4);
-      // a column that carries no weight may hold anything (a diverged trajectory's NaN): 0·NaN must not reach the sum
+    const float w = qw;
 #pragma unroll
-      for (int q = 0; q < 4; q++) d[q] = w != 0.f ? d[q] * w : 0.f;
-      *reinterpret_cast<f32x4*>(pd + col * lsd + 4 * r4) = d;
+    for (int q = 0; q < PQ; q++) {
+      const int r4 = l31 + 32 * q;
+      if (4 * r4 < na) *reinterpret_cast<f32x4*>(pa + col * lsa + 4 * r4) = qa[q];
+      if (4 * r4 < nd) *reinterpret_cast<f32x4*>(pd + col * lsd + 4 * r4) = scale(qd[q], w);
     }
+    for (int r4 = l31 + 32 * PQ; 4 * r4 < na; r4 += 32)
+      *reinterpret_cast<f32x4*>(pa + col * lsa + 4 * r4) = *reinterpret_cast<const f32x4*>(blk + col * in32 + ra0 + 4 * r4);
+    for (int r4 = l31 + 32 * PQ; 4 * r4 < nd; r4 += 32)
+      *reinterpret_cast<f32x4*>(pd + col * lsd + 4 * r4) =
+          scale(*reinterpret_cast<const f32x4*>(blk + NB * in32 + col * out32 + rd0 + 4 * r4), w);
     __syncthreads();
+    if (e + KS < ns) fetch(e + KS);
 #pragma unroll
-    for (int m = 0; m < NDW; m++) {
-      if (aoff[m] >= 0) {
+    for (int m = 0; m < DW_NDW; m++) {
+      if (aoff[m] >= 0) {   // (a branch-free variant — absent tiles multiplied and dropped — was measured: no faster, and slower on small layers)
         const float* ap = pa + aoff[m];
         const float* bp = pd + doff[m];
         float av[8], bv[8];
@@ -215,11 +288,11 @@ static __global__ void __launch_bounds__(512) k_mlp_dw(MlpDims dm, DwArgs a) {
         for (int s8 = 0; s8 < 8; s8++) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s8], bv[s8], acc[m], 0, 0, 0);
       }
     }
-    if (g == 0) {
+    if (do_bias) {
 #pragma unroll
       for (int q = 0; q < 2; q++) {
         const int row = tid + 512 * q;
-        if (row < out) {
+        if (row < nd) {
           float sacc = 0.f;
 #pragma unroll
           for (int n = 0; n < NB; n++) sacc += pd[n * lsd + row];
@@ -231,9 +304,11 @@ static __global__ void __launch_bounds__(512) k_mlp_dw(MlpDims dm, DwArgs a) {
   }
   float* slab = a.slab + ((size_t)tile * KS + part) * dm.slab_n;
 #pragma unroll
-  for (int m = 0; m < NDW; m++) {
-    const int tl = g * 8 * NDW + wave + 8 * m;
-    if (tl < ntl) {
+  for (int m = 0; m < DW_NDW; m++) {
+    const int t = wave + 8 * m;
+    if (t < ntile) {
+      const int otl = t / nit, itl = t - otl * nit;
+      const int tl = (jb.o0 + otl) * IT + jb.i0 + itl;   // the layer's tile enumeration: output tile major
       f32x4* g4 = reinterpret_cast<f32x4*>(slab + ((size_t)(dm.tile_off[l] + tl) * 64 + lane) * 16);
 #pragma unroll
       for (int q = 0; q < 4; q++) {
@@ -243,19 +318,28 @@ static __global__ void __launch_bounds__(512) k_mlp_dw(MlpDims dm, DwArgs a) {
       }
     }
   }
-  if (g == 0) {
+  if (do_bias) {
 #pragma unroll
     for (int q = 0; q < 2; q++) {
       const int row = tid + 512 * q;
-      if (row < out) slab[(size_t)dm.tile_off[dm.nL] * 1024 + dm.bias_lin[l] + row] = bsum[q];
+      if (row < nd && rd0 + row < out) slab[(size_t)dm.tile_off[dm.nL] * 1024 + dm.bias_lin[l] + rd0 + row] = bsum[q];
     }
   }
 }
 
-// dW[flat] += Σ_wg slab[wg][fragment position of flat]   (workgroups added in index order ⇒ deterministic)
+// sum[pos] = Σ_w slab[w][pos] over the launch's partial slabs, in slab order (deterministic), fully coalesced
+static __global__ void k_sum_slabs(const float* __restrict__ slab, int nslab, int slab_n, float* __restrict__ sum) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (4 * idx >= slab_n) return;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  for (int w = 0; w < nslab; w++) s += *reinterpret_cast<const f32x4*>(slab + (size_t)w * slab_n + 4 * idx);
+  *reinterpret_cast<f32x4*>(sum + 4 * idx) = s;
+}
+
+// dW[flat] += sum[fragment position of flat] (+ the private slabs of workgroups that overflowed their staging area)
 static __global__ void k_reduce_slabs(const float* __restrict__ priv, const int32_t* __restrict__ nflush, int nwg,
-                               const float* __restrict__ slab, int nslab, MlpDims dm, float* __restrict__ dW,
-                               int32_t* __restrict__ feedback) {
+                                      const float* __restrict__ sum, MlpDims dm, float* __restrict__ dW,
+                                      int32_t* __restrict__ feedback) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx == 0) {   // tell the host (asynchronously) whether any workgroup ran out of staging slots
     int mx = 0;
@@ -275,23 +359,10 @@ static __global__ void k_reduce_slabs(const float* __restrict__ priv, const int3
     pos = ((size_t)t * 64 + col + 32 * h) * 16 + r;
   } else
     pos = (size_t)dm.tile_off[dm.nL] * 1024 + dm.bias_lin[l] + (idx - dm.b_off[l]);
-  float sacc = 0.f;
-  for (int w = 0; w < nslab; w++) sacc += slab[(size_t)w * dm.slab_n + pos];
+  float sacc = sum[pos];
   for (int w = 0; w < nwg; w++)
     if (nflush[w]) sacc += priv[(size_t)w * dm.slab_n + pos];
   dW[idx] += sacc;
-}
-
-// jobs of k_mlp_dw: per layer, groups of up to 8·ndw tiles
-static int dw_jobs(const MlpDims& dm, int ndw) {
-  int n = 0;
-  for (int l = 0; l < dm.nL; l++) n += cdiv(cdiv(dm.sizes[l], 32) * cdiv(dm.sizes[l + 1], 32), 8 * ndw);
-  return n;
-}
-static int dw_ndw(const MlpDims& dm) {
-  int mx = 0;
-  for (int l = 0; l < dm.nL; l++) mx = std::max(mx, cdiv(dm.sizes[l], 32) * cdiv(dm.sizes[l + 1], 32));
-  return mx <= 16 ? 2 : 8;
 }
 
 template <class T>
@@ -305,17 +376,32 @@ static bool grow(T** ptr, size_t* cap, size_t need) {
   return true;
 }
 
-template <int NDW>
-static int launch_dw(const MlpDims& dm, const DwArgs& a, dim3 grid, size_t lds, hipStream_t stream, std::string& err) {
+// dW += Σ over the staged slots: k_mlp_dw over (ntile × ks × jobs), then the two-stage slab reduction.
+//   slabs: [ntile·ks][slab_n] partial slabs followed by one slab_n sum buffer (caller sizes it: (ntile·ks + 1)·slab_n)
+static int launch_weight_gradient(const MlpDims& dm, const DwArgs& da, int ntile, int ks, const float* priv,
+                                  const int32_t* nflush, int npriv, float* dW, int32_t* feedback, hipStream_t stream,
+                                  std::string& err) {
+  const size_t dlds = dw_lds_floats(dm) * sizeof(float);
+  if (dlds > LDS_MAX) {
+    err = "layer too wide for the weight-gradient kernel's LDS panels";
+    return LDE_ERR_UNSUPPORTED;
+  }
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_mlp_dw<NDW>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)k_mlp_dw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
       err = "hipFuncSetAttribute(k_mlp_dw) failed";
       return LDE_ERR_HIP;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_mlp_dw<NDW>), grid, dim3(512), lds, stream, dm, a);
+  hipLaunchKernelGGL(k_mlp_dw, dim3(ntile, ks, dw_jobs(dm)), dim3(512), dlds, stream, dm, da);
+  float* sum = da.slab + (size_t)ntile * ks * dm.slab_n;
+  hipLaunchKernelGGL(k_sum_slabs, dim3(cdiv(cdiv(dm.slab_n, 4), 256)), dim3(256), 0, stream, da.slab, ntile * ks, dm.slab_n, sum);
+  hipLaunchKernelGGL(k_reduce_slabs, dim3(cdiv(dm.nW, 256)), dim3(256), 0, stream, priv, nflush, npriv, sum, dm, dW, feedback);
+  if (hipGetLastError() != hipSuccess) {
+    err = "weight-gradient kernels failed to launch";
+    return LDE_ERR_HIP;
+  }
   return LDE_OK;
 }
 

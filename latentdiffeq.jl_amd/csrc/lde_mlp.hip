@@ -1336,7 +1336,7 @@ struct MlpPlan {
   int* abort_flag = nullptr;
   int cap_wg = 0;
   // adjoint workspace (allocated by the first lde_adjoint / lde_reserve, not by forward-only use)
-  float* slab = nullptr;       // [nWG·(1+KS)][slab_n]: private (overflow) slabs, then k_mlp_dw's (tile, part) slabs
+  float* slab = nullptr;       // [nWG·(1+KS)+1][slab_n]: private (overflow) slabs, k_mlp_dw's (tile, part) slabs, their sum
   size_t slab_cap = 0;
   float* stage = nullptr;      // [nWG][cap][blk_floats]
   size_t stage_cap = 0;        // floats
@@ -1466,12 +1466,11 @@ int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::strin
   if (want < nst) want = nst;
   if (want > (1 << 24)) want = 1 << 24;
   const int cap = (int)want;
-  const int ndw = dw_ndw(dm);
-  int ks = cdiv(768, nwg * dw_jobs(dm, ndw));
+  int ks = cdiv(768, nwg * dw_jobs(dm));
   ks = ks < 1 ? 1 : (ks > 16 ? 16 : ks);
   size_t nsl = (size_t)p->nslots_cap;
   if (!grow(&p->stage, &p->stage_cap, (size_t)nwg * cap * dm.blk_floats) || !grow(&p->wts, &p->wts_cap, (size_t)nwg * cap * NB) ||
-      !grow(&p->slab, &p->slab_cap, (size_t)nwg * (1 + ks) * dm.slab_n) || !grow(&p->nslots, &nsl, (size_t)2 * nwg)) {
+      !grow(&p->slab, &p->slab_cap, ((size_t)nwg * (1 + ks) + 1) * dm.slab_n) || !grow(&p->nslots, &nsl, (size_t)2 * nwg)) {
     err = "MLP plan: hipMalloc of the adjoint workspace failed";
     return LDE_ERR_ALLOC;
   }
@@ -1650,28 +1649,8 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
   // the weight gradient from the staged panels
   DwArgs da;
   da.stage = p->stage; da.wts = p->wts; da.nslots = p->nslots; da.slab = p->slab + (size_t)nwg * dm.slab_n; da.cap = p->adj_cap;
-  const int ndw = dw_ndw(dm);
-  int maxrows = 0;
-  for (int l = 0; l < dm.nL; l++)
-    maxrows = std::max(maxrows, ((((dm.sizes[l] + 31) & ~31) | 32) + (((dm.sizes[l + 1] + 31) & ~31) | 32)));
-  const size_t dlds = (size_t)NB * maxrows * sizeof(float);
-  if (dlds > LDS_MAX) {
-    err = "MLP adjoint: layer too wide for the weight-gradient kernel's LDS panels";
-    return LDE_ERR_UNSUPPORTED;
-  }
-  const dim3 grid(nwg, ks, dw_jobs(dm, ndw));
-  rc = ndw == 2 ? launch_dw<2>(dm, da, grid, dlds, stream, err) : launch_dw<8>(dm, da, grid, dlds, stream, err);
+  rc = launch_weight_gradient(dm, da, nwg, ks, p->slab, p->nslots + nwg, nwg, dW, p->fb_dev, stream, err);
   if (rc) return rc;
-  if (hipGetLastError() != hipSuccess) {
-    err = "k_mlp_dw launch failed";
-    return LDE_ERR_HIP;
-  }
-  hipLaunchKernelGGL(k_reduce_slabs, dim3(cdiv(dm.nW, 256)), dim3(256), 0, stream, p->slab, p->nslots + nwg, nwg,
-                     p->slab + (size_t)nwg * dm.slab_n, nwg * ks, dm, dW, p->fb_dev);
-  if (hipGetLastError() != hipSuccess) {
-    err = "k_reduce_slabs launch failed";
-    return LDE_ERR_HIP;
-  }
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {   // not inside a hipGraph capture
     if (hipMemcpyAsync(p->fb_host, p->fb_dev, sizeof(int32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&

@@ -21,6 +21,7 @@
 //    adjoint — `k_mlp_dw` + `k_reduce_slabs` from lde_mfma.h, with every 16-column group as one slot of weight 1.
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -103,9 +104,9 @@ __device__ __forceinline__ void chain_mac(const f32x4* A0, const f32x4* A1, cons
 #pragma unroll
         for (int cg = 0; cg < NCG; cg++) rb[i % PFB][cg] = *reinterpret_cast<const f32x4*>(bp + (cg0 + cg) * cgstride + kb * 16);
 #pragma unroll
-        for (int cg = 0; cg < NCG; cg++) {
+        for (int s4 = 0; s4 < 4; s4++) {   // K-step outer: 2·NCG independent accumulators between two uses of the same one
 #pragma unroll
-          for (int s4 = 0; s4 < 4; s4++) {
+          for (int cg = 0; cg < NCG; cg++) {
             acc0[cg] = mfma16(c0[s4], cb[cg][s4], acc0[cg]);
             if (NT_ == 2) acc1[cg] = mfma16(c1[s4], cb[cg][s4], acc1[cg]);
           }
@@ -224,16 +225,25 @@ __global__ void __launch_bounds__(512) k_chain_forward(ChainDims cd, ChainFwdArg
   float* H1 = H0 + NC * ldh;
   float* biasc = H1 + NC * ldh;
   const long long n0 = (long long)blockIdx.x * NC;
+  PROF_T(pc0);
   chain_load_tile<CG>(cd, a.x, n0, a.N, X0, biasc, a.Wflat, NC * cd.ld0 + 2 * NC * ldh, csm);
+  PROF_T(pc1);
+  PROF_ADD(0, pc0, pc1);
   const float* Xin = X0;
   int ldx = cd.ld0;
   for (int l = 0; l + 1 < nL; l++) {
     float* Y = (l & 1) ? H1 : H0;
+    PROF_T(pl0);
     chain_hidden_layer<CG>(cd, l, a.frag, biasc, Xin, ldx, Y);
+    PROF_T(pl1);
     __syncthreads();
+    PROF_T(pl2);
+    PROF_ADD(2 + 2 * l, pl0, pl1);
+    PROF_ADD(3 + 2 * l, pl1, pl2);
     Xin = Y;
     ldx = ldh;
   }
+  PROF_T(pz0);
   {  // last layer: straight to HBM
     const int l = nL - 1, in = dm.sizes[l], out = dm.sizes[l + 1], actk = cd.act[l];
     const float* bias = biasc + dm.bias_lin[l];
@@ -254,6 +264,9 @@ __global__ void __launch_bounds__(512) k_chain_forward(ChainDims cd, ChainFwdArg
                             }
                           });
   }
+  PROF_T(pz1);
+  PROF_ADD(2 + 2 * (nL - 1), pz0, pz1);
+  PROF_ADD(40, pc0, pz1);
 }
 
 struct ChainBwdArgs {
@@ -503,10 +516,18 @@ int lde_chain_create(const lde_chain_desc* d, lde_chain** out) {
       c->err = "chain layer widths up to 1024 are supported";
       return LDE_ERR_UNSUPPORTED;
     }
-  for (int cg : {4, 2, 1})
-    if (!c->cg_fwd && chain_lds(cd, cg, 2) <= LDS_MAX) { c->cg_fwd = cg; c->lds_fwd = chain_lds(cd, cg, 2); }
-  for (int cg : {2, 1})
-    if (!c->cg_bwd && chain_lds(cd, cg, 3) <= LDS_MAX) { c->cg_bwd = cg; c->lds_bwd = chain_lds(cd, cg, 3); }
+  // Column groups per workgroup: the widest tile that still lets TWO workgroups share a CU (≤ 80 KB of LDS each) — one
+  // tile's barrier / prologue latencies are then covered by the other's MFMAs. Measured on the reconstructor
+  // (N = 12800): forward 64 columns 110 µs, 32 columns 107 µs; backward 32 columns 331 µs, 16 columns 313 µs.
+  // Falls back to the widest tile that fits at all. LDE_CHAIN_CG_FWD / LDE_CHAIN_CG_BWD force a value (experiments).
+  const char* ef = getenv("LDE_CHAIN_CG_FWD");
+  const char* eb = getenv("LDE_CHAIN_CG_BWD");
+  for (size_t lim : {LDS_MAX / 2, LDS_MAX}) {
+    for (int cg : {4, 2, 1}) {
+      if (!c->cg_fwd && (!ef || cg == atoi(ef)) && chain_lds(cd, cg, 2) <= (ef ? LDS_MAX : lim)) { c->cg_fwd = cg; c->lds_fwd = chain_lds(cd, cg, 2); }
+      if (cg <= 2 && !c->cg_bwd && (!eb || cg == atoi(eb)) && chain_lds(cd, cg, 3) <= (eb ? LDS_MAX : lim)) { c->cg_bwd = cg; c->lds_bwd = chain_lds(cd, cg, 3); }
+    }
+  }
   if (!c->cg_fwd || !c->cg_bwd) {
     c->err = "chain: activation panels do not fit the 160 KiB LDS";
     return LDE_ERR_UNSUPPORTED;
@@ -611,6 +632,9 @@ int lde_chain_forward(lde_chain* c, const float* x, int64_t N, float* y, void* s
     }
     attr[c->cg_fwd] = true;
   }
+#if LDE_PROF
+  { long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
+#endif
   if (c->cg_fwd == 4) hipLaunchKernelGGL(k_chain_forward<4>, grid, dim3(512), c->lds_fwd, stream, c->cd, a);
   else if (c->cg_fwd == 2) hipLaunchKernelGGL(k_chain_forward<2>, grid, dim3(512), c->lds_fwd, stream, c->cd, a);
   else hipLaunchKernelGGL(k_chain_forward<1>, grid, dim3(512), c->lds_fwd, stream, c->cd, a);
@@ -618,6 +642,20 @@ int lde_chain_forward(lde_chain* c, const float* x, int64_t N, float* y, void* s
     c->err = "k_chain_forward launch failed";
     return LDE_ERR_HIP;
   }
+#if LDE_PROF
+  {
+    static int calls = 0;
+    (void)hipStreamSynchronize(stream);
+    long long v[64];
+    (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(g_prof), sizeof(v));
+    if (N > 1000 && ++calls % 20 == 0) {
+      fprintf(stderr, "[prof chain fwd] cycles:");
+      for (int i = 0; i < 64; i++)
+        if (v[i]) fprintf(stderr, " %d:%lld", i, v[i]);
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
   return LDE_OK;
 }
 

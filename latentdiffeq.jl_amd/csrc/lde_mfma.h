@@ -344,7 +344,7 @@ static __global__ void k_reduce_slabs(const float* __restrict__ priv, const int3
   if (idx == 0) {   // tell the host (asynchronously) whether any workgroup ran out of staging slots
     int mx = 0;
     for (int w = 0; w < nwg; w++) mx = max(mx, nflush[w]);
-    feedback[0] = mx;
+    feedback[0] = max(mx, feedback[1]);   // feedback[1]: set by a kernel that ran out of staging slots without a private slab
   }
   if (idx >= dm.nW) return;
   int l = 0;
@@ -360,8 +360,9 @@ static __global__ void k_reduce_slabs(const float* __restrict__ priv, const int3
   } else
     pos = (size_t)dm.tile_off[dm.nL] * 1024 + dm.bias_lin[l] + (idx - dm.b_off[l]);
   float sacc = sum[pos];
-  for (int w = 0; w < nwg; w++)
-    if (nflush[w]) sacc += priv[(size_t)w * dm.slab_n + pos];
+  if (priv)
+    for (int w = 0; w < nwg; w++)
+      if (nflush[w]) sacc += priv[(size_t)w * dm.slab_n + pos];
   dW[idx] += sacc;
 }
 

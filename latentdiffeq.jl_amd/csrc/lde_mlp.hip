@@ -776,6 +776,8 @@ struct BwdArgs {
   int32_t* nslots;    // [nWG] staged evaluations that count
   int32_t* nflush;    // [nWG] times the workgroup had to fold its staging area into its private slab
   int cap;            // staging slots per workgroup
+  int32_t* ovf;       // set to 1 by the 4-columns-per-wave kernel when a wave ran out of staging slots
+  int fallback;       // k_mlp_adjoint launched behind that kernel: run only if *ovf != 0 (then redo everything)
   int32_t *st_nfe, *st_nacc, *st_nrej, *st_ret;
   GridSync gs;
   int lds_bytes;
@@ -921,6 +923,7 @@ __device__ __forceinline__ void flush_stage(const MlpDims& dm, const float* stag
 template <int SOLVER, int NT>
 __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  if (a.fallback && __hip_atomic_load(a.ovf, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0) return;   // uniform
   const int T = o.T, B = o.B, Dp = dm.Dp, DpA = dm.DpA, D = dm.D, NP = dm.P;
   Ctl* c = reinterpret_cast<Ctl*>(smem);
   double* s_ts = reinterpret_cast<double*>(smem + ((sizeof(Ctl) + 15) & ~size_t(15)));
@@ -1325,6 +1328,8 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
 #undef FOR_ELEMS
 }
 
+#include "lde_mlp4.h"
+
 // ================================================ host side =================================================
 struct MlpPlan {
   MlpDims dm;
@@ -1403,6 +1408,7 @@ int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err) 
     return LDE_ERR_ALLOC;
   }
   (void)hipMemset(p->abort_flag, 0, 64);
+  (void)hipMemset(p->fb_dev, 0, 64);
   p->fb_host[0] = 0;
   *out = p;
   return LDE_OK;
@@ -1426,7 +1432,7 @@ void mlp_plan_destroy(MlpPlan* p) {
 }
 
 int mlp_reserve(MlpPlan* p, int B, int T, std::string& err) {
-  const int nwg = cdiv(B, NB);
+  const int nwg = cdiv(B, 4) + 1;   // grid-sum slots: one per workgroup; the 4-columns-per-wave adjoint may run one wave per workgroup
   if (nwg > p->cap_wg) {
     if (p->slots) (void)hipFree(p->slots);
     p->slots = nullptr;
@@ -1460,7 +1466,7 @@ int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::strin
       (void)hipGetLastError();   // hipErrorNotReady is not an error of the caller's
   }
   int64_t want = (int64_t)nst * (steps_hint > 0 ? steps_hint + 2 : p->cap_scale * (3 * (int64_t)(T > 1 ? T - 1 : 1) + 32));
-  const int64_t fit = ((int64_t)budget_mb << 20) / ((int64_t)nwg * dm.blk_floats * (int64_t)sizeof(float));
+  const int64_t fit = ((int64_t)budget_mb << 20) / ((int64_t)(nwg + 1) * dm.blk_floats * (int64_t)sizeof(float));
   if (want > fit) want = fit;
   if (slots_force > 0) want = slots_force;
   if (want < nst) want = nst;
@@ -1469,8 +1475,8 @@ int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::strin
   int ks = cdiv(768, nwg * dw_jobs(dm));
   ks = ks < 1 ? 1 : (ks > 16 ? 16 : ks);
   size_t nsl = (size_t)p->nslots_cap;
-  if (!grow(&p->stage, &p->stage_cap, (size_t)nwg * cap * dm.blk_floats) || !grow(&p->wts, &p->wts_cap, (size_t)nwg * cap * NB) ||
-      !grow(&p->slab, &p->slab_cap, ((size_t)nwg * (1 + ks) + 1) * dm.slab_n) || !grow(&p->nslots, &nsl, (size_t)2 * nwg)) {
+  if (!grow(&p->stage, &p->stage_cap, (size_t)(nwg + 1) * cap * dm.blk_floats) || !grow(&p->wts, &p->wts_cap, (size_t)(nwg + 1) * cap * NB) ||
+      !grow(&p->slab, &p->slab_cap, ((size_t)(nwg + 1) * (1 + ks) + 1) * dm.slab_n) || !grow(&p->nslots, &nsl, (size_t)2 * (nwg + 1))) {
     err = "MLP plan: hipMalloc of the adjoint workspace failed";
     return LDE_ERR_ALLOC;
   }
@@ -1600,6 +1606,58 @@ static int launch_adjoint(MlpPlan* p, const KOpts& o, const BwdArgs& a, int nwg,
   return LDE_OK;
 }
 
+// ---- the 4-columns-per-wave adjoint (lde_mlp4.h): applicability, LDS layout, launch --------------------------------
+static bool mlp4_layout(const MlpDims& dm, int T, int B, bool coupled_adaptive, Mlp4Dims* md, size_t* lds, int* nblocks) {
+  const char* e4 = getenv("LDE_MLP4");   // read per call: the tests switch kernels inside one process
+  if ((e4 && atoi(e4) == 0) || dm.Dp > 64 || dm.P > 1) return false;
+  int maxw = 0;
+  for (int l = 0; l <= dm.nL; l++) maxw = std::max(maxw, dm.sizes[l]);
+  // measured (MI355X): one wave has ONE SIMD's matrix pipe and v_mfma_f32_4x4x1 costs 11 cycles per 256 MACs (the
+  // 16x16x4 form: 8), so the 4-column kernel only wins while the layers are small enough for the 16-column kernel's
+  // fixed ≈ 2 000 cycles per layer to dominate: config 3 (64 wide) 7.3 → 5.3 ms, config 4 (128 wide) 4.4 → 5.5 ms.
+  const char* ew = getenv("LDE_MLP4_MAXW");
+  const int maxw_lim = ew ? atoi(ew) : 64;
+  if (maxw > maxw_lim || maxw > 256) return false;
+  int off = 0;
+  for (int l = 0; l < dm.nL; l++) {
+    int v = (dm.sizes[l] + 3) & ~3;
+    if (((v >> 2) & 1) == 0) v += 4;   // (ldw/4) odd ⇒ the row-segment reads of 16 consecutive rows hit distinct banks
+    md->ldw[l] = v;
+    md->wl_off[l] = off;
+    off += dm.sizes[l + 1] * v;
+  }
+  for (int l = 0; l < dm.nL; l++) {
+    md->bl_off[l] = off;
+    off += (dm.sizes[l + 1] + 63) & ~63;
+  }
+  md->w_total = off;
+  md->ldx = ((maxw + 63) & ~63) + 8;   // +8: the 4 columns of a panel start 8 banks apart (broadcast b128 reads, b128 writes: conflict-free)
+  const int nwaves = cdiv(B, 4);
+  int wpb = cdiv(nwaves, 256);
+  wpb = wpb < 1 ? 1 : (wpb > 4 ? 4 : wpb);
+  md->wpb = wpb;
+  *nblocks = cdiv(nwaves, wpb);
+  if (coupled_adaptive && *nblocks > 256) return false;   // grid-wide sums need every workgroup resident
+  *lds = ((size_t)md->w_total + (size_t)wpb * (dm.nL + 1) * 4 * md->ldx + (size_t)wpb * 4 + 8) * sizeof(float) + (size_t)T * sizeof(double) + 64 + 8 * 264 * sizeof(float);   // tail slack: operand prefetch reads ≤ 8 rows past the end
+  return *lds <= LDS_MAX;
+}
+
+template <int SOLVER, int NTH>
+static int launch_mlp4(const MlpDims& dm, const Mlp4Dims& md, const KOpts& o, const BwdArgs& a, int nblocks, size_t lds,
+                       hipStream_t stream, std::string& err) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute((const void*)k_mlp4_adjoint<SOLVER, NTH>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)LDS_MAX) != hipSuccess) {
+      err = "hipFuncSetAttribute(k_mlp4_adjoint) failed";
+      return LDE_ERR_HIP;
+    }
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_mlp4_adjoint<SOLVER, NTH>), dim3(nblocks), dim3(64 * md.wpb), lds, stream, dm, md, o, a);
+  return LDE_OK;
+}
+
 int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float* theta, const double* ts_dev,
                 const KOpts& o, const float* dz_out, float* dz0, float* dtheta, float* dW, int32_t* nfe, int32_t* nacc,
                 int32_t* nrej, int32_t* ret, hipStream_t stream, std::string& err) {
@@ -1623,7 +1681,8 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
   BwdArgs a;
   a.z_out = z_out; a.dz_out = dz_out; a.theta = theta; a.ts = ts_dev; a.frag = p->frag; a.fragT = p->fragT; a.Wflat = W_dev;
   a.dz0 = dz0; a.dtheta = dtheta; a.slab = p->slab;
-  a.stage = p->stage; a.wts = p->wts; a.nslots = p->nslots; a.nflush = p->nslots + nwg; a.cap = p->adj_cap;
+  a.stage = p->stage; a.wts = p->wts; a.nslots = p->nslots; a.nflush = p->nslots + (nwg + 1); a.cap = p->adj_cap;
+  a.ovf = p->fb_dev + 1; a.fallback = 0;
   a.st_nfe = nfe; a.st_nacc = nacc; a.st_nrej = nrej; a.st_ret = ret;
   a.gs.counter = p->counter; a.gs.slots = p->slots; a.gs.abort_flag = p->abort_flag; a.gs.nwg = sync ? nwg : 1;
   const size_t lds = with_cache(fixed, p->nfrag + p->nfragT);
@@ -1636,6 +1695,51 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
 #if LDE_PROF
   prof_reset();
 #endif
+  // networks whose weights fit LDS once: four columns per wave, no barriers (lde_mlp4.h)
+  int ntile_dw = nwg;
+  {
+    Mlp4Dims md;
+    size_t lds4 = 0;
+    int nblocks = 0;
+    if (mlp4_layout(dm, o.T, o.B, dm.coupled && o.adaptive, &md, &lds4, &nblocks)) {
+      const bool sync4 = dm.coupled && o.adaptive && nblocks > 1;
+      const int ntile4 = cdiv(nblocks * md.wpb, 4);   // ≤ nwg + 1: the workspace is sized for that
+      if (hipMemsetAsync(p->fb_dev, 0, 2 * sizeof(int32_t), stream) != hipSuccess ||
+          hipMemsetAsync(p->nslots, 0, (size_t)2 * (nwg + 1) * sizeof(int32_t), stream) != hipSuccess ||
+          hipMemsetAsync(p->wts, 0, (size_t)ntile4 * p->adj_cap * NB * sizeof(float), stream) != hipSuccess) {
+        err = "hipMemsetAsync(staging weights) failed";
+        return LDE_ERR_HIP;
+      }
+      a.gs.nwg = sync4 ? nblocks : 1;
+      if (sync4 && !sync && (hipMemsetAsync(p->counter, 0, sizeof(unsigned), stream) != hipSuccess ||
+                             hipMemsetAsync(p->abort_flag, 0, sizeof(int), stream) != hipSuccess)) {
+        err = "hipMemsetAsync(counter) failed";
+        return LDE_ERR_HIP;
+      }
+      int hmaxw = 0;
+      for (int l = 1; l < dm.nL; l++) hmaxw = std::max(hmaxw, dm.sizes[l]);
+      const int nth = hmaxw <= 64 ? 1 : (hmaxw <= 128 ? 2 : 4);
+      const bool rk4 = dm.solver == LDE_SOLVER_RK4;
+      int rc4;
+      if (nth == 1) rc4 = rk4 ? launch_mlp4<LDE_SOLVER_RK4, 1>(dm, md, o, a, nblocks, lds4, stream, err) : launch_mlp4<LDE_SOLVER_TSIT5, 1>(dm, md, o, a, nblocks, lds4, stream, err);
+      else if (nth == 2) rc4 = rk4 ? launch_mlp4<LDE_SOLVER_RK4, 2>(dm, md, o, a, nblocks, lds4, stream, err) : launch_mlp4<LDE_SOLVER_TSIT5, 2>(dm, md, o, a, nblocks, lds4, stream, err);
+      else rc4 = rk4 ? launch_mlp4<LDE_SOLVER_RK4, 4>(dm, md, o, a, nblocks, lds4, stream, err) : launch_mlp4<LDE_SOLVER_TSIT5, 4>(dm, md, o, a, nblocks, lds4, stream, err);
+      if (rc4) return rc4;
+      if (hipGetLastError() != hipSuccess) {
+        err = "k_mlp4_adjoint launch failed";
+        return LDE_ERR_HIP;
+      }
+      // A wave that ran out of staging slots sets *ovf: k_mlp_adjoint (which can fold its slots into a private slab) then
+      // redoes the whole call; otherwise it returns at once. The host never waits: the decision is taken on the device.
+      ntile_dw = cdiv(nblocks * md.wpb, 4);
+      a.fallback = 1;
+      a.gs.nwg = sync ? nwg : 1;
+      if (sync && hipMemsetAsync(p->counter, 0, sizeof(unsigned), stream) != hipSuccess) {
+        err = "hipMemsetAsync(counter) failed";
+        return LDE_ERR_HIP;
+      }
+    }
+  }
   int rc = dm.solver == LDE_SOLVER_RK4 ? launch_adjoint<LDE_SOLVER_RK4>(p, o, a, nwg, lds, stream, err)
                                        : launch_adjoint<LDE_SOLVER_TSIT5>(p, o, a, nwg, lds, stream, err);
 #if LDE_PROF
@@ -1648,8 +1752,8 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
   }
   // the weight gradient from the staged panels
   DwArgs da;
-  da.stage = p->stage; da.wts = p->wts; da.nslots = p->nslots; da.slab = p->slab + (size_t)nwg * dm.slab_n; da.cap = p->adj_cap;
-  rc = launch_weight_gradient(dm, da, nwg, ks, p->slab, p->nslots + nwg, nwg, dW, p->fb_dev, stream, err);
+  da.stage = p->stage; da.wts = p->wts; da.nslots = p->nslots; da.slab = p->slab + (size_t)(nwg + 1) * dm.slab_n; da.cap = p->adj_cap;
+  rc = launch_weight_gradient(dm, da, ntile_dw, ks, p->slab, p->nslots + (nwg + 1), nwg, dW, p->fb_dev, stream, err);
   if (rc) return rc;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {   // not inside a hipGraph capture

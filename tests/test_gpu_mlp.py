@@ -296,12 +296,68 @@ def test_staging_overflow_path_gives_the_same_gradient(case, monkeypatch):
         assert st["nfailed"] == 0 and st["naccept"] >= T - 1
         res.append((g0, gL, gW, st))
     (a0, aL, aW, ast), (b0, bL, bW, bst) = res
-    assert ast == bst
-    assert np.array_equal(a0, b0)
+    # The roomy run may use the 4-columns-per-wave kernel and the tiny one its 16-column fallback: the same solve in another
+    # summation order. Smooth right-hand side at 1e-6: agreement to round-off; relu at the default tolerance: two correct
+    # fp32 solves agree to about 1 % (see test_c3_pendulum_plus_mlp_adjoint); same kernel both times: same bits in dz0.
+    lim = {"rk4_coupled": 0.0, "tsit5_per_traj": 2e-5, "c3": 1e-2}[case]
+    assert abs(ast["naccept"] - bst["naccept"]) <= (0.1 if case == "c3" else 0.02) * ast["naccept"] + 1
+    assert np.abs(a0 - b0).max() <= lim * np.abs(a0).max()
     if aL is not None:
-        assert np.array_equal(aL, bL)
+        assert np.abs(aL - bL).max() <= lim * np.abs(aL).max()
     assert np.isfinite(aW).all() and np.abs(aW).max() > 0
-    assert np.abs(aW - bW).max() <= 2e-5 * np.abs(aW).max()
+    assert np.abs(aW - bW).max() <= max(lim, 5e-5) * np.abs(aW).max()
+
+
+@pytest.mark.parametrize("case", ["c3", "tanh_per_traj", "tanh_coupled", "rk4_fixed", "wide_128", "aug_odd"])
+def test_four_column_kernel_matches_sixteen_column_kernel(case, monkeypatch, o64):
+    """Networks ≤ 64 wide run the adjoint with four trajectories per wave (lde_mlp4.h); LDE_MLP4=0 forces the 16-column
+    workgroup kernel. Same algorithm, other summation order: at tight tolerance both must sit within 1e-4 of the float64
+    adjoint and within 5e-5 of each other (LDE_MLP4_MAXW=256 lets the 128-wide case through the four-column kernel)."""
+    tight = dict(abstol=1e-7, reltol=1e-7)
+    if case == "c3":
+        layers, kw, B, D, T = (2, 64, 64, 2), dict(rhs_kind=O.RHS_PENDULUM_PLUS_MLP, activation=O.ACT_TANH, **tight), 70, 2, 12
+    elif case == "tanh_per_traj":
+        layers, kw, B, D, T = (6, 40, 33, 6), dict(rhs_kind=O.RHS_MLP, state_dim=6, param_dim=0, activation=O.ACT_TANH, **tight), 37, 6, 10
+    elif case == "tanh_coupled":
+        layers, kw, B, D, T = (6, 40, 33, 6), dict(rhs_kind=O.RHS_MLP, state_dim=6, param_dim=0, activation=O.ACT_TANH,
+                                                   batching=O.BATCH_COUPLED, **tight), 37, 6, 10
+    elif case == "rk4_fixed":
+        layers, kw, B, D, T = (8, 64, 64, 8), dict(rhs_kind=O.RHS_MLP, state_dim=8, param_dim=0, solver=O.SOLVER_RK4, adaptive=0,
+                                                   dt=0.0125, batching=O.BATCH_COUPLED), 19, 8, 12
+    elif case == "wide_128":
+        layers, kw, B, D, T = (32, 128, 128, 32), dict(rhs_kind=O.RHS_MLP, state_dim=32, param_dim=0, activation=O.ACT_TANH,
+                                                       batching=O.BATCH_COUPLED, **tight), 24, 32, 8
+        monkeypatch.setenv("LDE_MLP4_MAXW", "256")
+    else:
+        layers, kw, B, D, T = (7, 33, 50, 21, 7), dict(rhs_kind=O.RHS_MLP, state_dim=5, param_dim=0, augment_dim=2,
+                                                       activation=O.ACT_TANH, **tight), 21, 5, 9
+    kw["layers"] = layers
+    W = O.mlp_weights(layers, seed=4)
+    ts = O.time_grid(T)
+    if case == "c3":
+        z0, L = O.pendulum_inputs(B)
+    else:
+        z0, L = _z0(B, D, seed=3), None
+    Dp = D + kw.get("augment_dim", 0)
+    dz = O.cotangent(T, B, Dp)
+    out = {}
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LDE_MLP4", flag)
+        nat, od = _native(W, **kw)
+        z, _, _ = nat.forward(z0, L, ts)
+        out[flag] = nat.adjoint(z, L, ts, dz)
+    d64 = O.make_desc(**{**kw, **({"abstol": 1e-11, "reltol": 1e-11} if kw.get("adaptive", 1) else {"dt": kw["dt"] / 8, "adaptive": False})})
+    z64, _, _ = o64.forward(d64, z0, L, ts, W=W.astype(np.float64))
+    t0, tL, tW, _ = o64.adjoint(d64, z64, L, ts, dz, W=W.astype(np.float64))
+    (a0, aL, aW, ast), (b0, bL, bW, bst) = out["1"], out["0"]
+    assert ast["nfailed"] == 0 and bst["nfailed"] == 0
+    assert abs(ast["naccept"] - bst["naccept"]) <= 0.15 * bst["naccept"] + 1   # fp32 noise in the error estimates of the first tiny steps
+    for g4, g16, t, what in ((a0, b0, t0, "dz0"), (aL, bL, tL, "dL"), (aW, bW, tW, "dW")):
+        if g4 is None:
+            continue
+        s = np.abs(t).max()
+        assert np.abs(g4 - g16).max() <= 5e-5 * s, what
+        assert np.abs(g4 - t).max() <= (1e-3 if case == "rk4_fixed" else 1e-4) * s, what   # rk4: the h⁴ error of dt = 0.0125 itself
 
 
 def test_torch_api_latentode_trains_the_node_weights(o32, o64):

@@ -582,7 +582,7 @@ int lde_chain_set_weights_device(lde_chain* c, const float* flat_dev, int64_t n,
 static void chain_dw_split(const lde_chain* c, int64_t N, int* nvt, int* cap, int64_t* total) {
   const int64_t tiles = (N + 16 * c->cg_bwd - 1) / (16 * c->cg_bwd);
   *total = tiles * c->cg_bwd;
-  int v = 256 / dw_jobs(c->cd.dm);
+  int v = 256 / dw_jobs(c->cd.dm, dw_pick_ndw(c->cd.dm));
   if (v < 1) v = 1;
   if (*total < v) v = (int)*total;
   *nvt = v;

@@ -146,7 +146,7 @@ static constexpr size_t LDS_MAX = 160 * 1024;
 
 // ---- the weight gradient as one large-K product over everything the solve staged ---------------------------------------
 // grid (solve tile, K-split part, job). A job is a block of 32×32 tiles of ONE layer's gWᵀ[in×out]: a range of output
-// tiles [o0,o1) × a range of input tiles [i0,i1), at most DW_CAP tiles (4 per wave). The workgroup walks the tile's
+// tiles [o0,o1) × a range of input tiles [i0,i1), at most 8·NDW tiles (NDW per wave). The workgroup walks the tile's
 // staged slots part, part+KS, …: copies the rows of that layer's a-panel and (weight-scaled) δ-panel it needs into LDS
 // and every wave adds 8 MFMAs (v_mfma_f32_32x32x2_f32, K = the 16 columns of the slot) to each of its tiles.
 // ≈ 110 VGPRs and a few tens of KB of LDS ⇒ two workgroups per CU: one loads while the other multiplies.
@@ -159,23 +159,28 @@ struct DwArgs {
   int cap;
 };
 
-constexpr int DW_NDW = 4;            // accumulator tiles per wave
-constexpr int DW_CAP = 8 * DW_NDW;   // tiles per job
+// accumulator tiles per wave: 4 (32 tiles per job) in general; 1 or 2 when every layer is that small — fewer registers,
+// more workgroups per CU, which is what a kernel that mostly streams staged panels needs (config 3: 8 tiles in all)
+inline int dw_pick_ndw(const MlpDims& dm) {
+  int mx = 0;
+  for (int l = 0; l < dm.nL; l++) mx = std::max(mx, cdiv(dm.sizes[l], 32) * cdiv(dm.sizes[l + 1], 32));
+  return mx <= 8 ? 1 : (mx <= 16 ? 2 : 4);
+}
 
 struct DwJob { int l, o0, o1, i0, i1; };
 
-__host__ __device__ inline int dw_layer_jobs(int IT, int OT) {
-  return IT <= DW_CAP ? cdiv(OT, DW_CAP / IT) : OT * cdiv(IT, DW_CAP);
+__host__ __device__ inline int dw_layer_jobs(int IT, int OT, int cap) {
+  return IT <= cap ? cdiv(OT, cap / IT) : OT * cdiv(IT, cap);
 }
-__host__ __device__ inline int dw_jobs(const MlpDims& dm) {
+__host__ __device__ inline int dw_jobs(const MlpDims& dm, int ndw) {
   int n = 0;
-  for (int l = 0; l < dm.nL; l++) n += dw_layer_jobs(cdiv(dm.sizes[l], 32), cdiv(dm.sizes[l + 1], 32));
+  for (int l = 0; l < dm.nL; l++) n += dw_layer_jobs(cdiv(dm.sizes[l], 32), cdiv(dm.sizes[l + 1], 32), 8 * ndw);
   return n;
 }
-__host__ __device__ inline DwJob dw_decode(const MlpDims& dm, int z) {
+__host__ __device__ inline DwJob dw_decode(const MlpDims& dm, int z, int DW_CAP) {
   DwJob j{0, 0, 0, 0, 0};
   for (int l = 0; l < dm.nL; l++) {
-    const int IT = cdiv(dm.sizes[l], 32), OT = cdiv(dm.sizes[l + 1], 32), nj = dw_layer_jobs(IT, OT);
+    const int IT = cdiv(dm.sizes[l], 32), OT = cdiv(dm.sizes[l + 1], 32), nj = dw_layer_jobs(IT, OT, DW_CAP);
     if (z < nj) {
       j.l = l;
       if (IT <= DW_CAP) {
@@ -198,19 +203,20 @@ __host__ __device__ inline DwJob dw_decode(const MlpDims& dm, int z) {
   return j;
 }
 // LDS floats a job of this layer set needs at most
-inline size_t dw_lds_floats(const MlpDims& dm) {
+inline size_t dw_lds_floats(const MlpDims& dm, int ndw) {
   size_t mx = 0;
-  for (int z = 0, n = dw_jobs(dm); z < n; z++) {
-    const DwJob j = dw_decode(dm, z);
+  for (int z = 0, n = dw_jobs(dm, ndw); z < n; z++) {
+    const DwJob j = dw_decode(dm, z, 8 * ndw);
     mx = std::max(mx, (size_t)NB * (((32 * (j.i1 - j.i0)) | 32) + ((32 * (j.o1 - j.o0)) | 32)));
   }
   return mx;
 }
 
+template <int DW_NDW>
 static __global__ void __launch_bounds__(512) k_mlp_dw(MlpDims dm, DwArgs a) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   const int tile = blockIdx.x, part = blockIdx.y, KS = gridDim.y;
-  const DwJob jb = dw_decode(dm, blockIdx.z);
+  const DwJob jb = dw_decode(dm, blockIdx.z, 8 * DW_NDW);
   const int l = jb.l, in = dm.sizes[l], out = dm.sizes[l + 1], in32 = pad32(in), out32 = pad32(out);
   const int IT = in32 / 32, nit = jb.i1 - jb.i0, ntile = (jb.o1 - jb.o0) * nit;
   const int na = 32 * nit, nd = 32 * (jb.o1 - jb.o0), ra0 = 32 * jb.i0, rd0 = 32 * jb.o0;
@@ -327,12 +333,22 @@ static __global__ void __launch_bounds__(512) k_mlp_dw(MlpDims dm, DwArgs a) {
   }
 }
 
-// sum[pos] = Σ_w slab[w][pos] over the launch's partial slabs, in slab order (deterministic), fully coalesced
+// sum[pos] = Σ_w slab[w][pos] over the launch's partial slabs, in slab order (deterministic), fully coalesced; eight
+// loads in flight per lane (a serial loop over 260 slabs was 110 µs of pure latency)
 static __global__ void k_sum_slabs(const float* __restrict__ slab, int nslab, int slab_n, float* __restrict__ sum) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (4 * idx >= slab_n) return;
+  const float* p = slab + 4 * idx;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  for (int w = 0; w < nslab; w++) s += *reinterpret_cast<const f32x4*>(slab + (size_t)w * slab_n + 4 * idx);
+  int w = 0;
+  for (; w + 8 <= nslab; w += 8) {
+    f32x4 v[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(w + u) * slab_n);
+#pragma unroll
+    for (int u = 0; u < 8; u++) s += v[u];
+  }
+  for (; w < nslab; w++) s += *reinterpret_cast<const f32x4*>(p + (size_t)w * slab_n);
   *reinterpret_cast<f32x4*>(sum + 4 * idx) = s;
 }
 
@@ -382,20 +398,26 @@ static bool grow(T** ptr, size_t* cap, size_t need) {
 static int launch_weight_gradient(const MlpDims& dm, const DwArgs& da, int ntile, int ks, const float* priv,
                                   const int32_t* nflush, int npriv, float* dW, int32_t* feedback, hipStream_t stream,
                                   std::string& err) {
-  const size_t dlds = dw_lds_floats(dm) * sizeof(float);
+  const int ndw = dw_pick_ndw(dm);
+  const size_t dlds = dw_lds_floats(dm, ndw) * sizeof(float);
   if (dlds > LDS_MAX) {
     err = "layer too wide for the weight-gradient kernel's LDS panels";
     return LDE_ERR_UNSUPPORTED;
   }
   static bool attr_set = false;
   if (!attr_set) {
-    if (hipFuncSetAttribute((const void*)k_mlp_dw, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
+    if (hipFuncSetAttribute((const void*)k_mlp_dw<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_mlp_dw<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_mlp_dw<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
       err = "hipFuncSetAttribute(k_mlp_dw) failed";
       return LDE_ERR_HIP;
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL(k_mlp_dw, dim3(ntile, ks, dw_jobs(dm)), dim3(512), dlds, stream, dm, da);
+  const dim3 grid(ntile, ks, dw_jobs(dm, ndw));
+  if (ndw == 1) hipLaunchKernelGGL(k_mlp_dw<1>, grid, dim3(512), dlds, stream, dm, da);
+  else if (ndw == 2) hipLaunchKernelGGL(k_mlp_dw<2>, grid, dim3(512), dlds, stream, dm, da);
+  else hipLaunchKernelGGL(k_mlp_dw<4>, grid, dim3(512), dlds, stream, dm, da);
   float* sum = da.slab + (size_t)ntile * ks * dm.slab_n;
   hipLaunchKernelGGL(k_sum_slabs, dim3(cdiv(cdiv(dm.slab_n, 4), 256)), dim3(256), 0, stream, da.slab, ntile * ks, dm.slab_n, sum);
   hipLaunchKernelGGL(k_reduce_slabs, dim3(cdiv(dm.nW, 256)), dim3(256), 0, stream, priv, nflush, npriv, sum, dm, dW, feedback);

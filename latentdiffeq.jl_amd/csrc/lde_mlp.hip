@@ -1472,7 +1472,7 @@ int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::strin
   if (want < nst) want = nst;
   if (want > (1 << 24)) want = 1 << 24;
   const int cap = (int)want;
-  int ks = cdiv(768, nwg * dw_jobs(dm));
+  int ks = cdiv(768, nwg * dw_jobs(dm, dw_pick_ndw(dm)));
   ks = ks < 1 ? 1 : (ks > 16 ? 16 : ks);
   size_t nsl = (size_t)p->nslots_cap;
   if (!grow(&p->stage, &p->stage_cap, (size_t)(nwg + 1) * cap * dm.blk_floats) || !grow(&p->wts, &p->wts_cap, (size_t)(nwg + 1) * cap * NB) ||

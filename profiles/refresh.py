@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Copy the newest profiles/collect.sh results from gpurun_out/ into profiles/ (summary JSON, kernel stats CSV, bench line).
+
+    python profiles/refresh.py c2 c3 c4 goku_decoder goku_pendulum_b256
+
+gpurun merges every call's files into the local gpurun_out/, so only the newest run of each sub-directory is used."""
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "gpurun_out")
+
+
+def newest_only(d):
+    for sub in ("trace", "fetch", "write"):
+        infos = sorted(glob.glob(f"{d}/{sub}/*/*_agent_info.csv"), key=os.path.getmtime)
+        for f in infos[:-1]:
+            pid = os.path.basename(f).split("_")[0]
+            for g in glob.glob(os.path.join(os.path.dirname(f), pid + "_*")):
+                os.remove(g)
+
+
+for w in sys.argv[1:]:
+    d = f"{OUT}/prof_r1_{w}"
+    newest_only(d)
+    subprocess.run([sys.executable, f"{ROOT}/profiles/summarize.py", d, f"{ROOT}/profiles/r1_{w}_summary.json"],
+                   stdout=subprocess.DEVNULL, check=True)
+    ks = sorted(glob.glob(f"{d}/trace/*/*kernel_stats.csv"), key=os.path.getmtime)[-1]
+    shutil.copy(ks, f"{ROOT}/profiles/r1_{w}_kernel_stats.csv")
+    b = f"{OUT}/bench_{w}.json" if not w.startswith("goku_pendulum") else f"{OUT}/bench_metric.json"
+    if os.path.exists(b):
+        shutil.copy(b, f"{ROOT}/profiles/r1_{w}_bench.json")
+    s = json.load(open(f"{ROOT}/profiles/r1_{w}_summary.json"))
+    print(w, {k.split("<")[0]: round(v.get("avg_ns", 0) / 1e3, 1) for k, v in s["kernels"].items() if k.startswith("k_")})

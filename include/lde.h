@@ -234,6 +234,49 @@ int  lde_chain_backward(lde_chain* c, const float* x, const float* y, const floa
                         float* dx, float* dW, void* stream);
 const char* lde_chain_last_error(const lde_chain* c);
 
+/* ======================================================================================================
+ * Recurrent pattern extractor — scope row f-2: what runs under
+ *
+ *     pe_out = apply_pattern_extractor(encoder, fe_out)     [REF src/models/GOKU.jl:32-51], [REF src/models/LatentODE.jl:24-33]
+ *
+ * i.e. a stack `Chain(RNN(in,h,relu), RNN(h,h,relu))` or `Chain(LSTM(in,h), LSTM(h,h))` [REF src/models/GOKU.jl:229-238]
+ * applied to the T time frames of fe_out [in×B×T] in forward or REVERSED order, keeping the LAST output
+ * (`[pe(x) for x in fe_out_rev][end]`), with the hidden state starting from the cell's `state0` on every call
+ * (`Flux.reset!`). Cells follow Flux 0.13.6 (un-vendored [REF Manifest.toml:452]):
+ *   RNNCell : h' = act.(Wi*x .+ Wh*h .+ b)
+ *   LSTMCell: g = Wi*x .+ Wh*h .+ b;  input, forget, cell, output = σ(g[1:o]), σ(g[o+1:2o]), tanh(g[2o+1:3o]), σ(g[3o+1:4o]);
+ *             c' = forget.*c .+ input.*cell;  h' = output.*tanh.(c')
+ * Flat weights = Flux.destructure order per cell: vec(Wi) [G·h × in], vec(Wh) [G·h × h] (column-major), b [G·h],
+ * state0 (h0 [h]; LSTM: then c0 [h]) — the initial state is a trainable parameter in this Flux version.
+ *  - x [in×B×T], y [h_last×B], dy, dx are DEVICE pointers in the reference's column-major layout.
+ *  - lde_rnn_backward recomputes the forward sweep (nothing is kept from lde_rnn_forward).
+ */
+#define LDE_RNN_MAX_LAYERS 4
+
+enum lde_cell_kind { LDE_CELL_RNN_RELU = 0, LDE_CELL_RNN_TANH = 1, LDE_CELL_LSTM = 2 };
+
+typedef struct lde_rnn_desc {
+  int32_t abi_version;                       /* = LDE_ABI_VERSION */
+  int32_t cell;                              /* lde_cell_kind */
+  int32_t n_layers;                          /* stacked cells, 1..LDE_RNN_MAX_LAYERS */
+  int32_t sizes[LDE_RNN_MAX_LAYERS + 1];     /* [in, h1, ..., hL]; every h ≤ 64, in ≤ 256 */
+  int32_t reverse;                           /* 1: feed the frames T, T-1, ..., 1 (reverse(fe_out)) */
+} lde_rnn_desc;
+
+typedef struct lde_rnn lde_rnn;
+
+int64_t lde_rnn_num_weights(const lde_rnn_desc* desc);
+int  lde_rnn_create(const lde_rnn_desc* desc, lde_rnn** out);
+void lde_rnn_destroy(lde_rnn* r);
+int  lde_rnn_set_weights(lde_rnn* r, const float* flat_host, int64_t n);
+int  lde_rnn_set_weights_device(lde_rnn* r, const float* flat_dev, int64_t n, void* stream);
+int  lde_rnn_reserve(lde_rnn* r, int B, int T);
+/* y[hL×B] = output of the top cell after the last frame. */
+int  lde_rnn_forward(lde_rnn* r, const float* x, int T, int B, float* y, void* stream);
+/* Back-propagation through time from dy[hL×B]: dx[in×B×T] (written; may be NULL), dW[n_weights] ACCUMULATED (+=). */
+int  lde_rnn_backward(lde_rnn* r, const float* x, const float* dy, int T, int B, float* dx, float* dW, void* stream);
+const char* lde_rnn_last_error(const lde_rnn* r);
+
 #ifdef __cplusplus
 }
 #endif

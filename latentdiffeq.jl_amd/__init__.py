@@ -7,6 +7,7 @@ Layout:
   api.py     host-side mirror of the reference interface: Pendulum / Pendulum_friction / NODE,
              GOKU_basic / LatentODE, Decoder, diffeq_layer, transform_after_diffeq
   chain.py   Dense / SkipConnection / Chain, apply_latent_out, apply_reconstructor (the dense chains either side of the solve)
+  recurrent.py  RNN / LSTM / Recurrent, Encoder, apply_feature_extractor / _pattern_extractor / _latent_in, sample
   dist.py    one-process-per-GPU batch sharding + the single gradient all-reduce (RCCL / gloo)
 """
 from .build import build_lib  # noqa: F401
@@ -20,7 +21,7 @@ def __getattr__(name):  # lazy: importing the package must not need torch or the
             return importlib.import_module(f"{__name__}.{name}")
         except ModuleNotFoundError:
             raise AttributeError(name) from None
-    for mod in ("api", "dist", "chain"):
+    for mod in ("api", "dist", "chain", "recurrent"):
         try:
             m = importlib.import_module(f"{__name__}.{mod}")
         except ModuleNotFoundError:

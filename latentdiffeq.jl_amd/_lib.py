@@ -30,7 +30,19 @@ EXPORTS = ["lde_abi_version", "lde_problem_desc_default", "lde_num_weights", "ld
            "lde_get_stats", "lde_last_error",
            "lde_chain_num_weights", "lde_chain_create", "lde_chain_destroy", "lde_chain_set_weights",
            "lde_chain_set_weights_device", "lde_chain_reserve", "lde_chain_forward", "lde_chain_backward",
-           "lde_chain_last_error"]
+           "lde_chain_last_error",
+           "lde_rnn_num_weights", "lde_rnn_create", "lde_rnn_destroy", "lde_rnn_set_weights", "lde_rnn_set_weights_device",
+           "lde_rnn_reserve", "lde_rnn_forward", "lde_rnn_backward", "lde_rnn_last_error"]
+
+LDE_RNN_MAX_LAYERS = 4
+CELL_RNN_RELU, CELL_RNN_TANH, CELL_LSTM = 0, 1, 2
+
+
+class RnnDesc(C.Structure):
+    """lde_rnn_desc (include/lde.h)."""
+
+    _fields_ = [("abi_version", C.c_int32), ("cell", C.c_int32), ("n_layers", C.c_int32),
+                ("sizes", C.c_int32 * (LDE_RNN_MAX_LAYERS + 1)), ("reverse", C.c_int32)]
 
 LDE_CHAIN_MAX_LAYERS = 6
 CACT_IDENTITY, CACT_RELU, CACT_TANH, CACT_SIGMOID, CACT_SOFTPLUS = 0, 1, 2, 3, 4
@@ -107,18 +119,30 @@ def load():
     lib.lde_chain_backward.argtypes = [vp, vp, vp, vp, i64, vp, vp, vp]
     lib.lde_chain_last_error.argtypes = [vp]
     lib.lde_chain_last_error.restype = C.c_char_p
+    lib.lde_rnn_num_weights.argtypes = [C.POINTER(RnnDesc)]
+    lib.lde_rnn_num_weights.restype = i64
+    lib.lde_rnn_create.argtypes = [C.POINTER(RnnDesc), C.POINTER(vp)]
+    lib.lde_rnn_destroy.argtypes = [vp]
+    lib.lde_rnn_destroy.restype = None
+    lib.lde_rnn_set_weights.argtypes = [vp, vp, i64]
+    lib.lde_rnn_set_weights_device.argtypes = [vp, vp, i64, vp]
+    lib.lde_rnn_reserve.argtypes = [vp, i32, i32]
+    lib.lde_rnn_forward.argtypes = [vp, vp, i32, i32, vp, vp]
+    lib.lde_rnn_backward.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
+    lib.lde_rnn_last_error.argtypes = [vp]
+    lib.lde_rnn_last_error.restype = C.c_char_p
     if lib.lde_abi_version() != LDE_ABI_VERSION:
         raise LdeError("liblde.so ABI version mismatch — rebuild")
     _lib = lib
     return lib
 
 
-def check(rc: int, handle=None, what: str = "", chain: bool = False):
+def check(rc: int, handle=None, what: str = "", chain: bool = False, rnn: bool = False):
     if rc == 0:
         return
     msg = STATUS.get(rc, str(rc))
     if handle is not None and _lib is not None:
-        detail = (_lib.lde_chain_last_error if chain else _lib.lde_last_error)(handle)
+        detail = (_lib.lde_rnn_last_error if rnn else _lib.lde_chain_last_error if chain else _lib.lde_last_error)(handle)
         if detail:
             msg += ": " + detail.decode()
     raise LdeError(f"{what} failed: {msg}")

@@ -1,0 +1,512 @@
+// lde_rnn.hip — the recurrent pattern extractor (scope row f-2).
+//
+// Replaces what runs under
+//     pe_out = apply_pattern_extractor(encoder, fe_out)      [REF src/models/GOKU.jl:32-51], [REF src/models/LatentODE.jl:24-33]
+// i.e. stacks Chain(RNN(32,16,relu), RNN(16,16,relu)) / Chain(LSTM(32,16), LSTM(16,16)) [REF src/models/GOKU.jl:229-238]
+// run over the T frames of fe_out [in×B×T] (forward or reversed), keeping the last output, and their pullback.
+// Cells: Flux 0.13.6 RNNCell / LSTMCell (un-vendored [REF Manifest.toml:452]); equations and weight order in include/lde.h.
+//
+// Design (gfx950). The cells are tiny (16 hidden units, K = in + h = 48) and strictly sequential in time: this is
+// latency-bound scalar work, not matrix-core work (north star: "MFMA only if latent_dim×hidden is large enough to fill
+// a tile"). A workgroup owns 16 trajectories, Hp = pow2(h) lanes per trajectory (all lanes of a trajectory sit in one
+// wave, so a step needs no barrier); lane (trajectory, unit u) computes the G gate rows of its unit as dot products of
+// LDS-resident rows of [Wi | Wh] with the trajectory's [x_t ; h_{t-1}] vector (16-byte LDS reads, broadcast within the
+// trajectory). The pullback recomputes the sweep with per-step records in HBM, walks it backwards (δ per gate,
+// transposed matrix–vector products through the same LDS copy), and STAGES the (a, δ) = ([x_t;h_{t-1}], gate deltas)
+// panels of every (step, layer) in the block layout of lde_mfma.h, so that the weight gradient — the only
+// matrix-shaped part: K' = B·T columns — is formed by the shared large-K MFMA kernel k_mlp_dw, once per cell.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+#include <cstring>
+#include <string>
+
+#include "lde_mfma.h"
+
+namespace lde {
+
+constexpr int RNN_ML = LDE_RNN_MAX_LAYERS;
+
+struct RnnDims {
+  int cell, nL, reverse, G;
+  int sizes[RNN_ML + 1];
+  int Hp;               // lanes per trajectory
+  int K[RNN_ML];        // in_l + h_l
+  int ldk[RNN_ML];      // row stride of [Wi | Wh] in LDS: ≥ pad4(K), (ldk/4) odd
+  int w_off[RNN_ML];    // LDS float offsets: rows [G·h][ldk]
+  int b_off[RNN_ML];    // bias [G·h]
+  int s_off[RNN_ML];    // state0: h0 [h] (LSTM: then c0 [h])
+  int f_off[RNN_ML];    // offset of the cell in the flat weight vector
+  int lds_w;            // floats of the weight area
+  int vmax;             // floats of one trajectory's [x; h] vector (pad4(max K) + 4)
+  int rmax;             // floats of one trajectory's δ vector (pad4(max G·h))
+  int hmax;
+  int recw;             // floats of one (step, layer, trajectory) record: gates G·hmax | c hmax | h hmax
+};
+
+__device__ __forceinline__ float sigm(float x) { return fast_rcp(1.0f + __expf(-x)); }
+
+struct RnnArgs {
+  const float* x;       // [in × B × T]
+  const float* Wflat;
+  float* y;             // forward: [hL × B]
+  float* rec;           // training: [T][L][B][recw]
+  const float* dy;      // backward
+  float* dx;            // [in × B × T] or NULL
+  float* stage[RNN_ML]; // per layer: [ntile][T][blk_l]
+  int blk[RNN_ML];      // floats of one staged block of layer l: 16·(pad32(K) + pad32(G·h))
+  float* wts;           // [ntile][T][16]
+  float* g0;            // [B][Σ state0 sizes]: per-trajectory gradient of the initial states
+  int g0w;              // floats per trajectory in g0
+  int T, B, mode;       // mode 0: forward only (writes y); 1: backward (recompute + BPTT)
+};
+
+// weights → LDS: rows of [Wi | Wh] (row r = g·h + u), zero padded; biases; state0
+__device__ __forceinline__ void rnn_load_weights(const RnnDims& rd, const float* Wflat, float* lw, int nthr) {
+  const int tid = threadIdx.x;
+  for (int i = tid; i < rd.lds_w; i += nthr) lw[i] = 0.f;
+  __syncthreads();
+  for (int l = 0; l < rd.nL; l++) {
+    const int in = rd.sizes[l], h = rd.sizes[l + 1], R = rd.G * h, ldk = rd.ldk[l];
+    const float* Wi = Wflat + rd.f_off[l];
+    const float* Wh = Wi + (size_t)R * in;
+    const float* b = Wh + (size_t)R * h;
+    const float* s0 = b + R;
+    for (int e = tid; e < R * in; e += nthr) { const int k = e / R, r = e - k * R; lw[rd.w_off[l] + r * ldk + k] = Wi[e]; }
+    for (int e = tid; e < R * h; e += nthr) { const int k = e / R, r = e - k * R; lw[rd.w_off[l] + r * ldk + in + k] = Wh[e]; }
+    for (int e = tid; e < R; e += nthr) lw[rd.b_off[l] + e] = b[e];
+    const int ns = rd.cell == LDE_CELL_LSTM ? 2 * h : h;
+    for (int e = tid; e < ns; e += nthr) lw[rd.s_off[l] + e] = s0[e];
+  }
+  __syncthreads();
+}
+
+// One workgroup = 16 trajectories × Hp lanes. mode 0: forward sweep → y. mode 1: sweep with records, then BPTT.
+__global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float rsm[];
+  const int Hp = rd.Hp, nthr = 16 * Hp, tid = threadIdx.x, tr = tid / Hp, u = tid - tr * Hp;
+  const int L = rd.nL, G = rd.G, T = a.T, B = a.B, lstm = rd.cell == LDE_CELL_LSTM;
+  float* lw = rsm;
+  float* vbuf = lw + rd.lds_w + tr * rd.vmax;                     // this trajectory's [x; h_prev]
+  float* dbuf = lw + rd.lds_w + 16 * rd.vmax + tr * rd.rmax;      // its gate deltas
+  float* hst = lw + rd.lds_w + 16 * (rd.vmax + rd.rmax) + tr * (2 * L * rd.hmax);   // h[l][hmax], then c[l][hmax]
+  float* cst = hst + L * rd.hmax;
+  float* dhs = lw + rd.lds_w + 16 * (rd.vmax + rd.rmax + 2 * L * rd.hmax) + tr * (2 * L * rd.hmax);   // dh, dc
+  float* dcs = dhs + L * rd.hmax;
+  rnn_load_weights(rd, a.Wflat, lw, nthr);
+  const long long b = (long long)blockIdx.x * 16 + tr;
+  const bool valid = b < B;
+  const int in0 = rd.sizes[0];
+
+  // ---- forward sweep (state0 → … → last frame) ------------------------------------------------------------------------
+  for (int l = 0; l < L; l++) {
+    const int h = rd.sizes[l + 1];
+    if (u < h) {
+      hst[l * rd.hmax + u] = lw[rd.s_off[l] + u];
+      cst[l * rd.hmax + u] = lstm ? lw[rd.s_off[l] + h + u] : 0.f;
+    }
+  }
+  for (int s = 0; s < T; s++) {
+    const int t = rd.reverse ? T - 1 - s : s;
+    for (int l = 0; l < L; l++) {
+      const int in = rd.sizes[l], h = rd.sizes[l + 1], K = in + h, ldk = rd.ldk[l];
+      // assemble [input ; h_prev] (the tail up to pad4(K) stays zero: vbuf was zero-filled, entries beyond K never written)
+      if (l == 0) {
+        for (int k = u; k < in; k += Hp) vbuf[k] = valid ? a.x[(size_t)in0 * ((size_t)b + (size_t)B * t) + k] : 0.f;
+      } else {
+        for (int k = u; k < in; k += Hp) vbuf[k] = hst[(l - 1) * rd.hmax + k];
+      }
+      for (int k = u; k < h; k += Hp) vbuf[in + k] = hst[l * rd.hmax + k];
+      for (int k = K + u; k < ((K + 3) & ~3); k += Hp) vbuf[k] = 0.f;
+      if (u < h) {
+        float z[4] = {0.f, 0.f, 0.f, 0.f};
+        const int K4 = (K + 3) >> 2;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+          if (g < G) {
+            const float* wr = lw + rd.w_off[l] + (g * h + u) * ldk;
+            float acc = lw[rd.b_off[l] + g * h + u];
+            for (int k4 = 0; k4 < K4; k4++) {
+              const f32x4 w = *reinterpret_cast<const f32x4*>(wr + 4 * k4);
+              const f32x4 v = *reinterpret_cast<const f32x4*>(vbuf + 4 * k4);
+              acc += w[0] * v[0] + w[1] * v[1] + w[2] * v[2] + w[3] * v[3];
+            }
+            z[g] = acc;
+          }
+        }
+        float hn, cn = 0.f;
+        if (lstm) {
+          const float ig = sigm(z[0]), fg = sigm(z[1]), gg = tanhf(z[2]), og = sigm(z[3]);
+          z[0] = ig; z[1] = fg; z[2] = gg; z[3] = og;
+          cn = fg * cst[l * rd.hmax + u] + ig * gg;
+          hn = og * tanhf(cn);
+        } else {
+          hn = rd.cell == LDE_CELL_RNN_TANH ? tanhf(z[0]) : fmaxf(z[0], 0.f);
+          z[0] = hn;
+        }
+        if (a.mode == 1 && valid) {
+          float* r = a.rec + (((size_t)s * L + l) * B + (size_t)b) * rd.recw;
+#pragma unroll
+          for (int g = 0; g < 4; g++)
+            if (g < G) r[g * h + u] = z[g];
+          r[G * h + u] = cn;
+          r[G * h + h + u] = hn;
+        }
+        hst[l * rd.hmax + u] = hn;   // every lane of the trajectory has copied h_prev into vbuf already (same wave, in order)
+        cst[l * rd.hmax + u] = cn;
+      }
+    }
+  }
+  if (a.mode == 0) {
+    const int hL = rd.sizes[L];
+    if (valid && u < hL) a.y[(size_t)hL * b + u] = hst[(L - 1) * rd.hmax + u];
+    return;
+  }
+  __syncthreads();   // the records are read back below by other lanes of the trajectory: stores drained (vmcnt(0)) first
+
+  // ---- back-propagation through time -----------------------------------------------------------------------------------
+  for (int l = 0; l < L; l++) {
+    const int h = rd.sizes[l + 1];
+    if (u < h) {
+      dhs[l * rd.hmax + u] = (l == L - 1 && valid) ? a.dy[(size_t)h * b + u] : 0.f;
+      dcs[l * rd.hmax + u] = 0.f;
+    }
+  }
+  for (int s = T - 1; s >= 0; s--) {
+    const int t = rd.reverse ? T - 1 - s : s;
+    if (u == 0) a.wts[((size_t)blockIdx.x * T + s) * NB + tr] = valid ? 1.f : 0.f;
+    for (int l = L - 1; l >= 0; l--) {
+      const int in = rd.sizes[l], h = rd.sizes[l + 1], K = in + h, R = G * h, ldk = rd.ldk[l];
+      const int K32 = pad32(K), R32 = pad32(R);
+      const float* r = a.rec + (((size_t)s * L + l) * B + (size_t)b) * rd.recw;
+      const float* rp = a.rec + (((size_t)(s > 0 ? s - 1 : 0) * L + l) * B + (size_t)b) * rd.recw;   // previous step of this layer (used when s > 0)
+      // gate deltas of this lane's unit
+      if (u < h) {
+        const float dh = dhs[l * rd.hmax + u];
+        if (lstm) {
+          float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cn = 0.f, cp = 0.f;
+          if (valid) {
+            ig = r[u]; fg = r[h + u]; gg = r[2 * h + u]; og = r[3 * h + u]; cn = r[R + u];
+            cp = s > 0 ? rp[R + u] : lw[rd.s_off[l] + h + u];
+          }
+          const float tc = tanhf(cn);
+          const float dct = dcs[l * rd.hmax + u] + dh * og * (1.f - tc * tc);
+          dbuf[u] = dct * gg * ig * (1.f - ig);
+          dbuf[h + u] = dct * cp * fg * (1.f - fg);
+          dbuf[2 * h + u] = dct * ig * (1.f - gg * gg);
+          dbuf[3 * h + u] = dh * tc * og * (1.f - og);
+          dcs[l * rd.hmax + u] = dct * fg;
+        } else {
+          const float av = valid ? r[u] : 0.f;
+          dbuf[u] = dh * (rd.cell == LDE_CELL_RNN_TANH ? 1.f - av * av : (av > 0.f ? 1.f : 0.f));
+        }
+      }
+      // the layer's input vector [x_in ; h_prev] again (for the weight gradient), staged with the deltas
+      {
+        float* blk = a.stage[l] + ((size_t)blockIdx.x * T + s) * a.blk[l];
+        float* ga = blk + tr * K32;
+        float* gd = blk + NB * K32 + tr * R32;
+        for (int k = u; k < K32; k += Hp) {
+          float v = 0.f;
+          if (valid) {
+            if (k < in) v = l == 0 ? a.x[(size_t)in0 * ((size_t)b + (size_t)B * t) + k]
+                                   : a.rec[(((size_t)s * L + (l - 1)) * B + (size_t)b) * rd.recw + G * rd.sizes[l] + rd.sizes[l] + k];
+            else if (k < K) v = s > 0 ? rp[R + h + (k - in)] : lw[rd.s_off[l] + (k - in)];
+          }
+          ga[k] = v;
+        }
+        for (int k = u; k < R32; k += Hp) gd[k] = (valid && k < R) ? dbuf[k] : 0.f;
+      }
+      // [d_in ; dh_prev] = [Wi | Wh]ᵀ δ
+      for (int k = u; k < K; k += Hp) {
+        const float* wc = lw + rd.w_off[l] + k;
+        float acc = 0.f;
+        for (int rr = 0; rr < R; rr++) acc += wc[rr * ldk] * dbuf[rr];
+        if (k < in) {
+          if (l > 0) dhs[(l - 1) * rd.hmax + k] += acc;
+          else if (a.dx && valid) a.dx[(size_t)in0 * ((size_t)b + (size_t)B * t) + k] = acc;
+        } else
+          dhs[l * rd.hmax + (k - in)] = acc;
+      }
+    }
+  }
+  // what is left flows into the trainable initial states
+  if (valid) {
+    int off = 0;
+    for (int l = 0; l < L; l++) {
+      const int h = rd.sizes[l + 1];
+      if (u < h) {
+        a.g0[(size_t)b * a.g0w + off + u] = dhs[l * rd.hmax + u];
+        if (lstm) a.g0[(size_t)b * a.g0w + off + h + u] = dcs[l * rd.hmax + u];
+      }
+      off += lstm ? 2 * h : h;
+    }
+  }
+}
+
+// ints[0..n) = v, ints[n..total) = 0
+__global__ void k_fill_i32(int32_t* p, int n, int v, int total) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < total) p[i] = i < n ? v : 0;
+}
+
+// dW[state0 slots] += Σ_b g0[b][·]   (trajectory order ⇒ deterministic)
+__global__ void k_rnn_state0(const float* __restrict__ g0, int B, int g0w, RnnDims rd, float* __restrict__ dW) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= g0w) return;
+  int off = 0, l = 0;
+  for (; l < rd.nL; l++) {
+    const int ns = (rd.cell == LDE_CELL_LSTM ? 2 : 1) * rd.sizes[l + 1];
+    if (i < off + ns) break;
+    off += ns;
+  }
+  const int in = rd.sizes[l], h = rd.sizes[l + 1], R = rd.G * h;
+  float s = 0.f;
+  for (int b = 0; b < B; b++) s += g0[(size_t)b * g0w + i];
+  dW[rd.f_off[l] + (size_t)R * in + (size_t)R * h + R + (i - off)] += s;
+}
+
+}  // namespace lde
+
+// ================================================ C ABI ======================================================
+using namespace lde;
+
+struct lde_rnn {
+  lde_rnn_desc d;
+  RnnDims rd;
+  MlpDims dmw[RNN_ML];     // one-layer descriptions [K_l → G·h_l] for the weight-gradient kernel
+  int64_t nW = 0;
+  float* W_dev = nullptr;
+  bool have_W = false;
+  size_t lds = 0;
+  int g0w = 0;
+  // workspace
+  float* rec = nullptr; size_t rec_cap = 0;
+  float* stage[RNN_ML] = {nullptr, nullptr, nullptr, nullptr}; size_t stage_cap[RNN_ML] = {0, 0, 0, 0};
+  float* wts = nullptr; size_t wts_cap = 0;
+  float* g0 = nullptr; size_t g0_cap = 0;
+  float* slab = nullptr; size_t slab_cap = 0;
+  int32_t* ints = nullptr; size_t ints_cap = 0;
+  std::string err;
+};
+
+static int rnn_desc_ok(const lde_rnn_desc* d) {
+  if (!d || d->abi_version != LDE_ABI_VERSION || d->n_layers < 1 || d->n_layers > LDE_RNN_MAX_LAYERS) return 0;
+  if (d->cell < 0 || d->cell > LDE_CELL_LSTM) return 0;
+  for (int l = 0; l <= d->n_layers; l++)
+    if (d->sizes[l] < 1) return 0;
+  return 1;
+}
+
+extern "C" {
+
+int64_t lde_rnn_num_weights(const lde_rnn_desc* d) {
+  if (!rnn_desc_ok(d)) return -1;
+  const int64_t G = d->cell == LDE_CELL_LSTM ? 4 : 1, S = d->cell == LDE_CELL_LSTM ? 2 : 1;
+  int64_t n = 0;
+  for (int l = 0; l < d->n_layers; l++) {
+    const int64_t in = d->sizes[l], h = d->sizes[l + 1];
+    n += G * h * in + G * h * h + G * h + S * h;
+  }
+  return n;
+}
+
+void lde_rnn_destroy(lde_rnn* r) {
+  if (!r) return;
+  if (r->W_dev) (void)hipFree(r->W_dev);
+  if (r->rec) (void)hipFree(r->rec);
+  for (int l = 0; l < RNN_ML; l++)
+    if (r->stage[l]) (void)hipFree(r->stage[l]);
+  if (r->wts) (void)hipFree(r->wts);
+  if (r->g0) (void)hipFree(r->g0);
+  if (r->slab) (void)hipFree(r->slab);
+  if (r->ints) (void)hipFree(r->ints);
+  delete r;
+}
+
+int lde_rnn_create(const lde_rnn_desc* d, lde_rnn** out) {
+  if (!out) return LDE_ERR_INVALID_ARG;
+  *out = nullptr;
+  if (!rnn_desc_ok(d)) return LDE_ERR_INVALID_ARG;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev < 1) return LDE_ERR_NO_DEVICE;   // no CPU fallback
+  lde_rnn* r = new lde_rnn();
+  *out = r;
+  r->d = *d;
+  RnnDims& rd = r->rd;
+  std::memset(&rd, 0, sizeof(rd));
+  rd.cell = d->cell; rd.nL = d->n_layers; rd.reverse = d->reverse ? 1 : 0; rd.G = d->cell == LDE_CELL_LSTM ? 4 : 1;
+  int hmax = 0, kmax = 0, rmax = 0;
+  for (int l = 0; l <= d->n_layers; l++) rd.sizes[l] = d->sizes[l];
+  for (int l = 1; l <= d->n_layers; l++) hmax = std::max(hmax, d->sizes[l]);
+  if (hmax > 64 || d->sizes[0] > 256) {
+    r->err = "recurrent stack: hidden width ≤ 64 and input width ≤ 256 supported";
+    return LDE_ERR_UNSUPPORTED;
+  }
+  int Hp = 1;
+  while (Hp < hmax) Hp <<= 1;
+  rd.Hp = Hp;
+  rd.hmax = hmax;
+  int off = 0, foff = 0;
+  r->g0w = 0;
+  for (int l = 0; l < rd.nL; l++) {
+    const int in = rd.sizes[l], h = rd.sizes[l + 1], R = rd.G * h, K = in + h;
+    rd.K[l] = K;
+    int v = (K + 3) & ~3;
+    if (((v >> 2) & 1) == 0) v += 4;
+    rd.ldk[l] = v;
+    rd.w_off[l] = off; off += R * v;
+    rd.b_off[l] = off; off += (R + 3) & ~3;
+    rd.s_off[l] = off; off += (2 * h + 3) & ~3;
+    rd.f_off[l] = foff;
+    foff += R * in + R * h + R + (d->cell == LDE_CELL_LSTM ? 2 : 1) * h;
+    kmax = std::max(kmax, K);
+    rmax = std::max(rmax, R);
+    r->g0w += (d->cell == LDE_CELL_LSTM ? 2 : 1) * h;
+    // one Dense-like layer [K → R] for the weight-gradient kernel: vec([Wi|Wh]) column-major then b = the cell's flat order
+    MlpDims& dm = r->dmw[l];
+    std::memset(&dm, 0, sizeof(dm));
+    dm.nL = 1; dm.sizes[0] = K; dm.sizes[1] = R;
+    size_t nf, nft;
+    fill_layer_offsets(dm, &nf, &nft);
+  }
+  rd.lds_w = off;
+  rd.vmax = ((kmax + 3) & ~3) + 4;
+  rd.rmax = (rmax + 3) & ~3;
+  rd.recw = (rd.G + 2) * hmax;
+  r->nW = foff;
+  r->lds = ((size_t)rd.lds_w + 16 * ((size_t)rd.vmax + rd.rmax + 4 * rd.nL * hmax)) * sizeof(float);
+  if (r->lds > LDS_MAX) {
+    r->err = "recurrent stack: weights do not fit the 160 KiB LDS";
+    return LDE_ERR_UNSUPPORTED;
+  }
+  if (hipMalloc(&r->W_dev, (size_t)r->nW * sizeof(float)) != hipSuccess) {
+    r->err = "recurrent stack: hipMalloc failed";
+    return LDE_ERR_ALLOC;
+  }
+  return LDE_OK;
+}
+
+int lde_rnn_set_weights(lde_rnn* r, const float* flat_host, int64_t n) {
+  if (!r || !r->W_dev) return LDE_ERR_INVALID_ARG;
+  if (n != r->nW || !flat_host) {
+    r->err = "lde_rnn_set_weights: wrong weight count";
+    return LDE_ERR_INVALID_ARG;
+  }
+  if (hipMemcpy(r->W_dev, flat_host, (size_t)n * sizeof(float), hipMemcpyHostToDevice) != hipSuccess) {
+    r->err = "lde_rnn_set_weights: hipMemcpy failed";
+    return LDE_ERR_HIP;
+  }
+  r->have_W = true;
+  return LDE_OK;
+}
+
+int lde_rnn_set_weights_device(lde_rnn* r, const float* flat_dev, int64_t n, void* stream) {
+  if (!r || !r->W_dev) return LDE_ERR_INVALID_ARG;
+  if (n != r->nW || !flat_dev) {
+    r->err = "lde_rnn_set_weights_device: wrong weight count";
+    return LDE_ERR_INVALID_ARG;
+  }
+  if (hipMemcpyAsync(r->W_dev, flat_dev, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
+    r->err = "lde_rnn_set_weights_device: hipMemcpyAsync failed";
+    return LDE_ERR_HIP;
+  }
+  r->have_W = true;
+  return LDE_OK;
+}
+
+int lde_rnn_reserve(lde_rnn* r, int B, int T) {
+  if (!r || !r->W_dev || B < 1 || T < 1) return LDE_ERR_INVALID_ARG;
+  const RnnDims& rd = r->rd;
+  const size_t ntile = (size_t)cdiv(B, 16);
+  size_t slab_need = 0;
+  bool ok = grow(&r->rec, &r->rec_cap, (size_t)T * rd.nL * B * rd.recw) && grow(&r->wts, &r->wts_cap, ntile * T * NB) &&
+            grow(&r->g0, &r->g0_cap, (size_t)B * r->g0w) && grow(&r->ints, &r->ints_cap, ntile + 16);
+  for (int l = 0; l < rd.nL && ok; l++) {
+    ok = grow(&r->stage[l], &r->stage_cap[l], ntile * T * r->dmw[l].blk_floats);
+    slab_need = std::max(slab_need, (ntile * 8 + 1) * (size_t)r->dmw[l].slab_n);
+  }
+  ok = ok && grow(&r->slab, &r->slab_cap, slab_need);
+  if (!ok) {
+    r->err = "recurrent stack: hipMalloc of the workspace failed";
+    return LDE_ERR_ALLOC;
+  }
+  return LDE_OK;
+}
+
+static int rnn_launch(lde_rnn* r, const RnnArgs& a, int B, hipStream_t stream) {
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)k_rnn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
+      r->err = "hipFuncSetAttribute(k_rnn) failed";
+      return LDE_ERR_HIP;
+    }
+    attr = true;
+  }
+  hipLaunchKernelGGL(k_rnn, dim3(cdiv(B, 16)), dim3(16 * r->rd.Hp), r->lds, stream, r->rd, a);
+  if (hipGetLastError() != hipSuccess) {
+    r->err = "k_rnn launch failed";
+    return LDE_ERR_HIP;
+  }
+  return LDE_OK;
+}
+
+int lde_rnn_forward(lde_rnn* r, const float* x, int T, int B, float* y, void* stream_) {
+  if (!r || !r->W_dev) return LDE_ERR_INVALID_ARG;
+  if (!x || !y || T < 1 || B < 1) {
+    r->err = "lde_rnn_forward: NULL pointer or empty batch";
+    return LDE_ERR_INVALID_ARG;
+  }
+  if (!r->have_W) {
+    r->err = "lde_rnn_forward: weights not set";
+    return LDE_ERR_NO_WEIGHTS;
+  }
+  RnnArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.x = x; a.Wflat = r->W_dev; a.y = y; a.T = T; a.B = B; a.mode = 0;
+  return rnn_launch(r, a, B, (hipStream_t)stream_);
+}
+
+int lde_rnn_backward(lde_rnn* r, const float* x, const float* dy, int T, int B, float* dx, float* dW, void* stream_) {
+  if (!r || !r->W_dev) return LDE_ERR_INVALID_ARG;
+  if (!x || !dy || !dW || T < 1 || B < 1) {
+    r->err = "lde_rnn_backward: NULL pointer or empty batch";
+    return LDE_ERR_INVALID_ARG;
+  }
+  if (!r->have_W) {
+    r->err = "lde_rnn_backward: weights not set";
+    return LDE_ERR_NO_WEIGHTS;
+  }
+  int rc = lde_rnn_reserve(r, B, T);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  const RnnDims& rd = r->rd;
+  const int ntile = cdiv(B, 16);
+  RnnArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.x = x; a.Wflat = r->W_dev; a.rec = r->rec; a.dy = dy; a.dx = dx; a.wts = r->wts; a.g0 = r->g0; a.g0w = r->g0w;
+  a.T = T; a.B = B; a.mode = 1;
+  for (int l = 0; l < rd.nL; l++) { a.stage[l] = r->stage[l]; a.blk[l] = r->dmw[l].blk_floats; }
+  rc = rnn_launch(r, a, B, stream);
+  if (rc) return rc;
+  // every tile staged exactly T slots
+  hipLaunchKernelGGL(k_fill_i32, dim3(cdiv(ntile + 2, 64)), dim3(64), 0, stream, r->ints, ntile, T, ntile + 2);
+  for (int l = 0; l < rd.nL; l++) {
+    DwArgs da;
+    da.stage = r->stage[l]; da.wts = r->wts; da.nslots = r->ints; da.slab = r->slab; da.cap = T;
+    int ks = cdiv(512, ntile * dw_jobs(r->dmw[l], dw_pick_ndw(r->dmw[l])));
+    ks = ks < 1 ? 1 : (ks > 8 ? 8 : ks);
+    rc = launch_weight_gradient(r->dmw[l], da, ntile, ks, nullptr, r->ints + ntile, 0, dW + rd.f_off[l], r->ints + ntile, stream, r->err);
+    if (rc) return rc;
+  }
+  hipLaunchKernelGGL(k_rnn_state0, dim3(cdiv(r->g0w, 64)), dim3(64), 0, stream, r->g0, B, r->g0w, rd, dW);
+  if (hipGetLastError() != hipSuccess) {
+    r->err = "recurrent stack: gradient kernels failed to launch";
+    return LDE_ERR_HIP;
+  }
+  return LDE_OK;
+}
+
+const char* lde_rnn_last_error(const lde_rnn* r) { return r ? r->err.c_str() : "null handle"; }
+
+}  // extern "C"

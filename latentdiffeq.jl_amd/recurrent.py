@@ -1,0 +1,227 @@
+"""Host-side mirror of the encoder side of the model (scope row f-2): recurrent pattern extractor + the dense layers
+around it.
+
+    reference                                                                    here
+    ---------------------------------------------------------------------------  ------------------------------------
+    RNN(in, out, relu; init), LSTM(in, out; init)      [Flux; REF GOKU.jl:229-238]  RNN(in, out, act), LSTM(in, out)
+    Chain(RNN(..), RNN(..)) applied frame by frame     [REF GOKU.jl:229-238]        Recurrent(RNN(..), RNN(..), reverse=)
+    apply_feature_extractor(encoder, x)                [REF GOKU.jl:19]             same  (a Chain: chain.py)
+    apply_pattern_extractor(encoder, fe_out)           [REF GOKU.jl:32-51], [REF LatentODE.jl:24-33]   same
+    apply_latent_in(encoder, pe_out)                   [REF GOKU.jl:61-72], [REF LatentODE.jl:35-43]   same
+    Encoder(model_type, (fe, pe, li)); encoder(x)      [REF LatentDiffEqModel.jl:52-75]                Encoder, encode
+    default_layers(...) (encoder part)                 [REF GOKU.jl:214-245], [REF LatentODE.jl:108-128]  default_encoder_layers
+    sample(μ, logσ², model)                            [REF GOKU.jl:155-163], [REF LatentODE.jl:82-89]  sample
+
+`Recurrent.__call__` is liblde.so (lde_rnn_forward / lde_rnn_backward, include/lde.h); the feature extractor and
+latent_in are `Chain`s (lde_chain_*). `sample` is the host-side reparameterisation (torch RNG — not on the kernel path).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+
+import torch
+
+from . import _lib as L
+from .api import GOKU, LatentODE
+from .chain import Chain, Dense, SkipConnection
+
+
+class _Cell(torch.nn.Module):
+    G, S, code = 1, 1, L.CELL_RNN_RELU
+
+    def __init__(self, n_in: int, n_out: int):
+        super().__init__()
+        self.n_in, self.n_out = n_in, n_out
+        bi, bh = 1.0 / math.sqrt(n_in), 1.0 / math.sqrt(n_out)       # kaiming_uniform(gain = 1/√3) ⇒ U(±1/√fan_in)  [REF GOKU.jl:204]
+        self.Wi = torch.nn.Parameter(torch.empty(self.G * n_out, n_in).uniform_(-bi, bi))
+        self.Wh = torch.nn.Parameter(torch.empty(self.G * n_out, n_out).uniform_(-bh, bh))
+        self.b = torch.nn.Parameter(torch.zeros(self.G * n_out))
+        self.state0 = torch.nn.Parameter(torch.zeros(self.S * n_out))   # trainable initial state (Flux 0.13)
+
+    def flat(self):
+        return torch.cat([self.Wi.t().reshape(-1), self.Wh.t().reshape(-1), self.b, self.state0])
+
+
+class RNN(_Cell):
+    """RNN(in, out, act): h' = act.(Wi*x .+ Wh*h .+ b)  [Flux RNNCell]."""
+
+    def __init__(self, n_in: int, n_out: int, act: str = "relu"):
+        super().__init__(n_in, n_out)
+        if act not in ("relu", "tanh"):
+            raise ValueError("RNN activation: relu or tanh")
+        self.act = act
+        self.code = L.CELL_RNN_RELU if act == "relu" else L.CELL_RNN_TANH
+
+
+class LSTM(_Cell):
+    """LSTM(in, out)  [Flux LSTMCell: gates input, forget, cell, output; forget-gate bias initialised to 1]."""
+    G, S, code = 4, 2, L.CELL_LSTM
+
+    def __init__(self, n_in: int, n_out: int):
+        super().__init__(n_in, n_out)
+        with torch.no_grad():
+            self.b[n_out:2 * n_out] = 1.0
+
+
+class _RecurrentFn(torch.autograd.Function):
+    """y = stack(x) on batch-major buffers: x (T, B, in) → y (B, h_last); backward = lde_rnn_backward."""
+
+    @staticmethod
+    def forward(ctx, rec: "Recurrent", x: torch.Tensor, W: torch.Tensor):
+        if not x.is_cuda:
+            raise L.LdeError("Recurrent needs CUDA/HIP tensors: it runs on the GPU only (no CPU fallback)")
+        h = rec._native()
+        lib = rec._lib
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        Wc = W.detach().contiguous().float()
+        L.check(lib.lde_rnn_set_weights_device(h, C.c_void_p(Wc.data_ptr()), Wc.numel(), stream), h, "lde_rnn_set_weights_device", rnn=True)
+        T, B, _ = x.shape
+        y = torch.empty((B, rec.sizes[-1]), device=x.device, dtype=torch.float32)
+        L.check(lib.lde_rnn_forward(h, C.c_void_p(x.data_ptr()), T, B, C.c_void_p(y.data_ptr()), stream), h, "lde_rnn_forward", rnn=True)
+        ctx.rec, ctx.need_dx = rec, x.requires_grad
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        rec = ctx.rec
+        h = rec._native()
+        lib = rec._lib
+        (x,) = ctx.saved_tensors
+        T, B, _ = x.shape
+        dy = dy.contiguous().float()
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        dx = torch.empty_like(x) if ctx.need_dx else None
+        dW = torch.zeros((rec.num_weights,), device=x.device, dtype=torch.float32)
+        L.check(lib.lde_rnn_backward(h, C.c_void_p(x.data_ptr()), C.c_void_p(dy.data_ptr()), T, B,
+                                     C.c_void_p(dx.data_ptr()) if dx is not None else C.c_void_p(), C.c_void_p(dW.data_ptr()), stream),
+                h, "lde_rnn_backward", rnn=True)
+        return None, dx, dW
+
+
+class Recurrent(torch.nn.Module):
+    """A stack of cells of one kind applied to the frames of x [in, B, T] (reverse=True: frames T..1), returning the output
+    after the last frame, [h_last, B] — `[pe(x) for x in frames][end]` followed by `Flux.reset!`  [REF GOKU.jl:40-47]."""
+
+    def __init__(self, *cells, reverse: bool = False):
+        super().__init__()
+        if not cells or len({type(c) for c in cells}) != 1 or len({c.code for c in cells}) != 1:
+            raise TypeError("Recurrent takes cells of one kind (all RNN with one activation, or all LSTM)")
+        for a, b in zip(cells[:-1], cells[1:]):
+            if a.n_out != b.n_in:
+                raise ValueError("cell sizes do not chain")
+        self.cells = torch.nn.ModuleList(cells)
+        self.reverse = bool(reverse)
+        self.sizes = [cells[0].n_in] + [c.n_out for c in cells]
+        self.code = cells[0].code
+        self.num_weights = sum(c.flat().numel() for c in cells)
+        self._handle, self._lib = None, None
+
+    def _native(self):
+        if self._handle is None:
+            self._lib = L.load()
+            d = L.RnnDesc()
+            d.abi_version, d.cell, d.n_layers, d.reverse = L.LDE_ABI_VERSION, self.code, len(self.cells), int(self.reverse)
+            for i, s in enumerate(self.sizes):
+                d.sizes[i] = s
+            h = C.c_void_p()
+            rc = self._lib.lde_rnn_create(C.byref(d), C.byref(h))
+            if rc != 0:
+                try:
+                    L.check(rc, h if h else None, "lde_rnn_create", rnn=True)
+                finally:
+                    if h:
+                        self._lib.lde_rnn_destroy(h)
+            self._handle = h
+        return self._handle
+
+    def __del__(self):
+        try:
+            if self._handle is not None and self._lib is not None:
+                self._lib.lde_rnn_destroy(self._handle)
+        except Exception:
+            pass
+
+    def flat_weights(self) -> torch.Tensor:
+        return torch.cat([c.flat() for c in self.cells]).float()
+
+    def forward(self, x: torch.Tensor) -> torch.Tensor:
+        """x [in, B, T] → [h_last, B]."""
+        if x.dim() != 3:
+            raise ValueError("Recurrent takes [in, B, T] arrays")
+        buf = x.permute(2, 1, 0).contiguous().float()              # (T, B, in) == column-major [in × B × T]
+        return _RecurrentFn.apply(self, buf, self.flat_weights()).t()
+
+
+class Encoder:
+    """Encoder(model_type, (feature_extractor, pattern_extractor, latent_in))  [REF src/models/LatentDiffEqModel.jl:30-61]."""
+
+    def __init__(self, model_type, encoder_layers):
+        self.model_type = model_type
+        self.feature_extractor, self.pattern_extractor, self.latent_in = encoder_layers
+
+
+def apply_feature_extractor(encoder: Encoder, x):
+    """fe_out = encoder.feature_extractor(x), x [pixels, B, T]  [REF src/models/GOKU.jl:19]."""
+    return encoder.feature_extractor(x)
+
+
+def apply_pattern_extractor(encoder: Encoder, fe_out):
+    """[REF src/models/GOKU.jl:32-51]: pe_z₀ on the reversed frames; pe_θ forward ⊕ pe_θ backward (reversed frames).
+    [REF src/models/LatentODE.jl:24-33]: one stack on the reversed frames."""
+    if isinstance(encoder.model_type, GOKU):
+        pe_z0, pe_th_f, pe_th_b = encoder.pattern_extractor
+        return pe_z0(fe_out), torch.cat([pe_th_f(fe_out), pe_th_b(fe_out)], dim=0)
+    if isinstance(encoder.model_type, LatentODE):
+        return encoder.pattern_extractor(fe_out)
+    raise TypeError(f"no apply_pattern_extractor method for model type {type(encoder.model_type).__name__}")
+
+
+def apply_latent_in(encoder: Encoder, pe_out):
+    """(μ, logσ²)  [REF src/models/GOKU.jl:61-72], [REF src/models/LatentODE.jl:35-43]."""
+    if isinstance(encoder.model_type, GOKU):
+        pe_z0, pe_th = pe_out
+        li_mu_z0, li_ls_z0, li_mu_th, li_ls_th = encoder.latent_in
+        return (li_mu_z0(pe_z0), li_mu_th(pe_th)), (li_ls_z0(pe_z0), li_ls_th(pe_th))
+    li_mu, li_ls = encoder.latent_in
+    return li_mu(pe_out), li_ls(pe_out)
+
+
+def encode(encoder: Encoder, x):
+    """(μ, logσ²) = encoder(x)  [REF src/models/LatentDiffEqModel.jl:63-75]."""
+    return apply_latent_in(encoder, apply_pattern_extractor(encoder, apply_feature_extractor(encoder, x)))
+
+
+def sample(mu, logvar, model_type=None):
+    """l̃ = μ + ε·exp(logσ²/2), ε ~ N(0, 1)  [REF src/models/GOKU.jl:155-163], [REF src/models/LatentODE.jl:82-89]."""
+    if isinstance(mu, tuple):
+        return tuple(m + torch.randn_like(s) * torch.exp(s / 2) for m, s in zip(mu, logvar))
+    return mu + torch.randn_like(logvar) * torch.exp(logvar / 2)
+
+
+def default_encoder_layers(model_type, input_dim: int, diffeq=None, hidden_dim_resnet: int = 200, rnn_input_dim: int = 32,
+                           rnn_output_dim: int = None, latent_dim_z0: int = 16, latent_dim_theta: int = 16, device=None):
+    """The encoder half of default_layers  [REF src/models/GOKU.jl:214-245], [REF src/models/LatentODE.jl:108-128]."""
+    fe = Chain(Dense(input_dim, hidden_dim_resnet, "relu"),
+               SkipConnection(Dense(hidden_dim_resnet, hidden_dim_resnet, "relu")),
+               SkipConnection(Dense(hidden_dim_resnet, hidden_dim_resnet, "relu")),
+               Dense(hidden_dim_resnet, rnn_input_dim, "relu"))
+    if isinstance(model_type, GOKU):
+        ro = rnn_output_dim or 16
+        pe = (Recurrent(RNN(rnn_input_dim, ro, "relu"), RNN(ro, ro, "relu"), reverse=True),
+              Recurrent(LSTM(rnn_input_dim, ro), LSTM(ro, ro), reverse=False),
+              Recurrent(LSTM(rnn_input_dim, ro), LSTM(ro, ro), reverse=True))
+        li = (Chain(Dense(ro, latent_dim_z0)), Chain(Dense(ro, latent_dim_z0)),
+              Chain(Dense(2 * ro, latent_dim_theta)), Chain(Dense(2 * ro, latent_dim_theta)))
+    elif isinstance(model_type, LatentODE):
+        ro = rnn_output_dim or 32
+        pe = Recurrent(RNN(rnn_input_dim, ro, "relu"), RNN(ro, ro, "relu"), reverse=True)
+        li = (Chain(Dense(ro, diffeq.latent_dim_in)), Chain(Dense(ro, diffeq.latent_dim_in)))
+    else:
+        raise TypeError("default_encoder_layers: GOKU_basic() or LatentODE()")
+    if device is not None:
+        fe = fe.to(device)
+        pe = tuple(m.to(device) for m in pe) if isinstance(pe, tuple) else pe.to(device)
+        li = tuple(m.to(device) for m in li)
+    return fe, pe, li

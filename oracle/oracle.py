@@ -247,3 +247,76 @@ def _chain_num_weights(self, d: ChainDesc) -> int:
 Oracle.chain_forward = _chain_forward
 Oracle.chain_backward = _chain_backward
 Oracle.chain_num_weights = _chain_num_weights
+
+
+# ---- recurrent pattern extractor (oracle/lde_rnn_oracle.c) -----------------------------------------------------
+LDE_RNN_MAX_LAYERS = 4
+CELL_RNN_RELU, CELL_RNN_TANH, CELL_LSTM = 0, 1, 2
+
+
+class RnnDesc(C.Structure):
+    """Mirror of lde_rnn_desc (include/lde.h)."""
+
+    _fields_ = [("abi_version", C.c_int32), ("cell", C.c_int32), ("n_layers", C.c_int32),
+                ("sizes", C.c_int32 * (LDE_RNN_MAX_LAYERS + 1)), ("reverse", C.c_int32)]
+
+
+def make_rnn_desc(cell, sizes, reverse=False) -> RnnDesc:
+    d = RnnDesc()
+    d.abi_version, d.cell, d.n_layers, d.reverse = 1, cell, len(sizes) - 1, int(bool(reverse))
+    for i, s in enumerate(sizes):
+        d.sizes[i] = s
+    return d
+
+
+def rnn_weights(cell, sizes, seed=5, dtype=np.float32):
+    """Flat Flux.destructure-order weights of a stack: per cell vec(Wi), vec(Wh), b, state0 — U(±1/√fan_in), non-zero
+    bias and initial state so that every term is exercised."""
+    rng = np.random.default_rng(seed)
+    G = 4 if cell == CELL_LSTM else 1
+    parts = []
+    for i in range(len(sizes) - 1):
+        n_in, h = sizes[i], sizes[i + 1]
+        parts.append(rng.uniform(-1, 1, (G * h, n_in)).flatten(order="F") / np.sqrt(n_in))
+        parts.append(rng.uniform(-1, 1, (G * h, h)).flatten(order="F") / np.sqrt(h))
+        parts.append(rng.uniform(-0.3, 0.3, G * h))
+        parts.append(rng.uniform(-0.5, 0.5, h * (2 if cell == CELL_LSTM else 1)))
+    return np.concatenate(parts).astype(dtype)
+
+
+def _rnn_num_weights(self, d: RnnDesc) -> int:
+    self.lib.oracle_rnn_num_weights.restype = C.c_int64
+    return int(self.lib.oracle_rnn_num_weights(C.byref(d)))
+
+
+def _rnn_forward(self, d: RnnDesc, W, x, nthreads=0):
+    """x.shape == (T, B, in) C-order == [in × B × T] column-major; returns y (B, h_last)."""
+    dt = self.dtype
+    x = np.ascontiguousarray(x, dtype=dt)
+    W = np.ascontiguousarray(W, dtype=dt)
+    T, B, n_in = x.shape
+    assert n_in == d.sizes[0]
+    y = np.zeros((B, d.sizes[d.n_layers]), dtype=dt)
+    rc = self.lib.oracle_rnn_forward(C.byref(d), self._p(W), self._p(x), T, B, self._p(y), nthreads)
+    if rc != 0:
+        raise RuntimeError(f"oracle_rnn_forward failed: {rc}")
+    return y
+
+
+def _rnn_backward(self, d: RnnDesc, W, x, dy, nthreads=0, need_dx=True):
+    dt = self.dtype
+    x = np.ascontiguousarray(x, dtype=dt)
+    dy = np.ascontiguousarray(dy, dtype=dt)
+    W = np.ascontiguousarray(W, dtype=dt)
+    T, B, _ = x.shape
+    dx = np.zeros_like(x) if need_dx else None
+    dW = np.zeros_like(W)
+    rc = self.lib.oracle_rnn_backward(C.byref(d), self._p(W), self._p(x), self._p(dy), T, B, self._p(dx), self._p(dW), nthreads)
+    if rc != 0:
+        raise RuntimeError(f"oracle_rnn_backward failed: {rc}")
+    return dx, dW
+
+
+Oracle.rnn_num_weights = _rnn_num_weights
+Oracle.rnn_forward = _rnn_forward
+Oracle.rnn_backward = _rnn_backward

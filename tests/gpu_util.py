@@ -164,3 +164,61 @@ class NativeChain:
                                             C.c_void_p(dW.data_ptr()), s), self.h, "lde_chain_backward", chain=True)
         torch.cuda.synchronize()
         return (None if dx is None else dx.cpu().numpy()), dW.cpu().numpy()
+
+
+class NativeRnn:
+    """The recurrent-stack entry points of the C ABI (lde_rnn_*), numpy in / numpy out."""
+
+    def __init__(self, cell, sizes, reverse=False):
+        self.lib = L.load()
+        d = L.RnnDesc()
+        d.abi_version, d.cell, d.n_layers, d.reverse = L.LDE_ABI_VERSION, cell, len(sizes) - 1, int(bool(reverse))
+        for i, s in enumerate(sizes):
+            d.sizes[i] = s
+        self.d, self.sizes = d, tuple(sizes)
+        self.h = C.c_void_p()
+        rc = self.lib.lde_rnn_create(C.byref(d), C.byref(self.h))
+        if rc != 0:
+            try:
+                L.check(rc, self.h if self.h else None, "lde_rnn_create", rnn=True)
+            finally:
+                self.close()
+        self.nW = int(self.lib.lde_rnn_num_weights(C.byref(d)))
+
+    def close(self):
+        if self.h:
+            self.lib.lde_rnn_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_weights(self, W):
+        W = np.ascontiguousarray(W, np.float32)
+        L.check(self.lib.lde_rnn_set_weights(self.h, W.ctypes.data_as(C.c_void_p), W.size), self.h, "lde_rnn_set_weights", rnn=True)
+
+    def forward(self, x):
+        xd = torch.from_numpy(np.ascontiguousarray(x, np.float32)).to("cuda")
+        T, B, _ = xd.shape
+        y = torch.full((B, self.sizes[-1]), 7.0, device="cuda")
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(self.lib.lde_rnn_forward(self.h, C.c_void_p(xd.data_ptr()), T, B, C.c_void_p(y.data_ptr()), s), self.h,
+                "lde_rnn_forward", rnn=True)
+        torch.cuda.synchronize()
+        return y.cpu().numpy()
+
+    def backward(self, x, dy, need_dx=True, dW0=None):
+        xd = torch.from_numpy(np.ascontiguousarray(x, np.float32)).to("cuda")
+        dyd = torch.from_numpy(np.ascontiguousarray(dy, np.float32)).to("cuda")
+        T, B, _ = xd.shape
+        dx = torch.full_like(xd, 7.0) if need_dx else None
+        dW = torch.zeros((self.nW,), device="cuda") if dW0 is None else torch.from_numpy(np.ascontiguousarray(dW0, np.float32)).to("cuda")
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(self.lib.lde_rnn_backward(self.h, C.c_void_p(xd.data_ptr()), C.c_void_p(dyd.data_ptr()), T, B,
+                                          C.c_void_p(dx.data_ptr()) if dx is not None else C.c_void_p(), C.c_void_p(dW.data_ptr()), s),
+                self.h, "lde_rnn_backward", rnn=True)
+        torch.cuda.synchronize()
+        return (None if dx is None else dx.cpu().numpy()), dW.cpu().numpy()

@@ -1,0 +1,129 @@
+"""GPU parity of the recurrent pattern extractor (lde_rnn_*, scope row f-2) against the CPU oracle.
+
+Tolerance: f32 round-off only (hardware exp/rcp in σ, ≈1e-7): forward ≤ 2e-5, gradients ≤ 1e-4 of the float64 scale and
+no farther from float64 than 2× the f32 oracle + 2e-5."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    (O.CELL_RNN_RELU, (32, 16, 16), True),      # pe_z₀          [REF src/models/GOKU.jl:229-230]
+    (O.CELL_LSTM, (32, 16, 16), False),         # pe_θ_forward   [REF src/models/GOKU.jl:233-234]
+    (O.CELL_LSTM, (32, 16, 16), True),          # pe_θ_backward  [REF src/models/GOKU.jl:236-237]
+    (O.CELL_RNN_RELU, (32, 32, 32), True),      # LatentODE      [REF src/models/LatentODE.jl:120-121]
+    (O.CELL_RNN_TANH, (5, 7, 3, 9), False),
+    (O.CELL_LSTM, (3, 10), True),
+    (O.CELL_LSTM, (40, 48, 33), False),
+]
+
+
+def _run(cell, sizes, reverse, T, B, o32, o64, seed=4):
+    from tests.gpu_util import NativeRnn
+    d = O.make_rnn_desc(cell, sizes, reverse)
+    W = O.rnn_weights(cell, sizes, seed=seed)
+    rng = np.random.default_rng(seed + 1)
+    x = rng.standard_normal((T, B, sizes[0])).astype(np.float32)
+    dy = (rng.standard_normal((B, sizes[-1])) / B).astype(np.float32)
+    nat = NativeRnn(cell, sizes, reverse)
+    assert nat.nW == W.size
+    nat.set_weights(W)
+    y = nat.forward(x)
+    yr = o32.rnn_forward(d, W, x)
+    y64 = o64.rnn_forward(d, W.astype(np.float64), x.astype(np.float64))
+    assert np.abs(y - yr).max() <= 2e-5 and np.abs(y - y64).max() <= 2e-5
+    dx, dW = nat.backward(x, dy)
+    rx, rW = o32.rnn_backward(d, W, x, dy)
+    tx, tW = o64.rnn_backward(d, W.astype(np.float64), x.astype(np.float64), dy.astype(np.float64))
+    for g, r, t, what in ((dx, rx, tx, "dx"), (dW, rW, tW, "dW")):
+        s = np.abs(t).max()
+        assert np.isfinite(g).all(), what
+        assert np.abs(g - r).max() <= 1e-4 * s, what
+        assert np.abs(g - t).max() <= 2 * np.abs(r - t).max() + 2e-5 * s, what
+    return nat, (x, dy, dx, dW)
+
+
+@pytest.mark.parametrize("cell,sizes,reverse", CASES)
+@pytest.mark.parametrize("T,B", [(1, 1), (9, 37), (50, 256)])
+def test_rnn_forward_backward_parity(o32, o64, cell, sizes, reverse, T, B):
+    _run(cell, sizes, reverse, T, B, o32, o64)
+
+
+def test_rnn_dw_accumulates_dx_optional_and_repeatable(o32, o64):
+    nat, (x, dy, dx, dW) = _run(O.CELL_LSTM, (32, 16, 16), True, 12, 40, o32, o64)
+    base = np.full(nat.nW, 0.5, np.float32)
+    dx2, dW2 = nat.backward(x, dy, need_dx=False, dW0=base)
+    assert dx2 is None and np.abs((dW2 - base) - dW).max() <= 1e-6 * max(1.0, np.abs(dW).max())
+    assert np.array_equal(nat.backward(x, dy)[1], nat.backward(x, dy)[1])
+
+
+def test_rnn_errors_are_reported_not_thrown():
+    from latentdiffeq_amd import _lib as L
+    from tests.gpu_util import NativeRnn
+    with pytest.raises(L.LdeError, match="UNSUPPORTED"):
+        NativeRnn(O.CELL_LSTM, (8, 128))            # hidden width > 64
+    with pytest.raises(L.LdeError, match="INVALID_ARG"):
+        NativeRnn(7, (8, 8))
+    with pytest.raises(L.LdeError, match="do not fit"):
+        NativeRnn(O.CELL_LSTM, (40, 64, 33))        # [Wi|Wh] of both cells: 163 KB > the 160 KB LDS
+
+
+def test_torch_encoder_path_end_to_end(o64):
+    """encode(encoder, x) = feature extractor → pattern extractor → latent_in through autograd: (μ, logσ²) and the gradients of
+    every parameter match the float64 oracle composition (GOKU default layers at reduced input size)."""
+    import torch
+    import latentdiffeq_amd as M
+    from latentdiffeq_amd.recurrent import Encoder, default_encoder_layers, encode
+    torch.manual_seed(1)
+    NI, B, T = 48, 20, 7
+    mt = M.GOKU_basic()
+    fe, pe, li = default_encoder_layers(mt, NI, hidden_dim_resnet=40, device="cuda")
+    with torch.no_grad():      # biases / initial states away from zero so that every term is exercised
+        for m in [fe, *pe, *li]:
+            for n, p in m.named_parameters():
+                if p.dim() == 1:
+                    p.add_(torch.empty_like(p).uniform_(-0.2, 0.2))
+    enc = Encoder(mt, (fe, pe, li))
+    x = torch.rand(NI, B, T, device="cuda")
+    (mu_z, mu_t), (ls_z, ls_t) = encode(enc, x)
+    assert mu_z.shape == (16, B) and mu_t.shape == (16, B) and ls_z.shape == (16, B) and ls_t.shape == (16, B)
+    cz, ct, dz_, dt_ = (torch.randn(16, B, device="cuda") for _ in range(4))
+    ((mu_z * cz).sum() + (mu_t * ct).sum() + (ls_z * dz_).sum() + (ls_t * dt_).sum()).backward()
+
+    f64 = lambda t: t.detach().cpu().numpy().astype(np.float64)
+    cdesc = lambda ch: (O.make_chain_desc(ch.sizes, ch.acts, ch.skips), f64(ch.flat_weights()))
+    rdesc = lambda r: (O.make_rnn_desc(r.code, r.sizes, r.reverse), f64(r.flat_weights()))
+    dfe, Wfe = cdesc(fe)
+    xb = f64(x).transpose(2, 1, 0).reshape(T * B, NI)
+    fo = o64.chain_forward(dfe, Wfe, xb)                       # (T*B, 32)
+    fo3 = fo.reshape(T, B, -1)
+    outs, recs = [], [rdesc(r) for r in pe]
+    for (dr, Wr) in recs:
+        outs.append(o64.rnn_forward(dr, Wr, fo3))
+    pe_z, pe_t = outs[0], np.concatenate([outs[1], outs[2]], axis=1)
+    lis = [cdesc(c) for c in li]
+    got = [f64(mu_z).T, f64(ls_z).T, f64(mu_t).T, f64(ls_t).T]
+    ins = [pe_z, pe_z, pe_t, pe_t]
+    cts = [f64(cz).T, f64(dz_).T, f64(ct).T, f64(dt_).T]
+    d_pe_z, d_pe_t = np.zeros_like(pe_z), np.zeros_like(pe_t)
+    flat_grad = lambda ch: torch.cat([torch.cat([d.weight.grad.t().reshape(-1), d.bias.grad]) for d in ch._dense]).cpu().numpy()
+    for i, ((dd, Wl), xin, c_) in enumerate(zip(lis, ins, cts)):
+        ref = o64.chain_forward(dd, Wl, xin)
+        assert np.abs(got[i] - ref).max() <= 2e-5, f"latent_in {i}"
+        dxi, dWl = o64.chain_backward(dd, Wl, xin, c_)
+        assert np.abs(flat_grad(li[i]) - dWl).max() <= 2e-4 * np.abs(dWl).max(), f"latent_in {i} dW"
+        if i < 2:
+            d_pe_z += dxi
+        else:
+            d_pe_t += dxi
+    dys = [d_pe_z, d_pe_t[:, :16], d_pe_t[:, 16:]]
+    dfo = np.zeros_like(fo3)
+    for r, (dr, Wr), dy in zip(pe, recs, dys):
+        dxr, dWr = o64.rnn_backward(dr, Wr, fo3, dy)
+        dfo += dxr
+        gW = torch.cat([torch.cat([c.Wi.grad.t().reshape(-1), c.Wh.grad.t().reshape(-1), c.b.grad, c.state0.grad]) for c in r.cells]).cpu().numpy()
+        assert np.abs(gW - dWr).max() <= 2e-4 * np.abs(dWr).max(), "recurrent dW"
+    _, dWfe = o64.chain_backward(dfe, Wfe, xb, dfo.reshape(T * B, -1), need_dx=False)
+    assert np.abs(flat_grad(fe) - dWfe).max() <= 2e-4 * np.abs(dWfe).max(), "feature extractor dW"

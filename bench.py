@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — trajectories/sec (forward solve + adjoint) of the latent-ODE hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload goku_pendulum|c2|c3|c4|goku_decoder] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload goku_pendulum|c2|c3|c4|goku_decoder|goku_step] [--batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -335,12 +335,92 @@ def decoder_cpu_baseline(specs, weights, d_native, ts, zt, tt, dxh, B, T, budget
                        f"{best} OpenMP thread(s) (fastest of {cands} on {avail} available cores)")
 
 
+# ---- whole GOKU training step (BASELINE.json configs[4] shape, one GPU's share): encoder → sample → decoder → loss → pullback → AdamW
+def run_goku_step(args, torch, dist, world, rank, local):
+    import latentdiffeq_amd as M
+    from latentdiffeq_amd.chain import decode, default_decoder_layers
+    from latentdiffeq_amd.dist import FlatGradAllReduce
+    from latentdiffeq_amd.recurrent import Encoder, default_encoder_layers, encode, sample
+    B = args.batch or 256
+    T, NI = 50, 784
+    dev = torch.device("cuda", local)
+    torch.manual_seed(100 + rank)
+    mt = M.GOKU_basic()
+    diffeq = M.Pendulum()
+    enc = Encoder(mt, default_encoder_layers(mt, NI, device=dev))
+    dec = M.Decoder(mt, default_decoder_layers(mt, NI, diffeq, device=dev))
+    lo_z0, lo_th = dec.latent_out
+    with torch.no_grad():   # start inside the data range of the pendulum length, L ~ U(1,2) [REF create_data.jl:19-22]
+        lo_th._dense[-1].bias.fill_(1.0)
+    mods = [enc.feature_extractor, *enc.pattern_extractor, *enc.latent_in, lo_z0, lo_th, dec.reconstructor]
+    params = [p for m in mods for p in m.parameters()]
+    opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=1e-10)            # [REF model_train.jl:138, :150]
+    sync = FlatGradAllReduce(params)
+    x = torch.rand(NI, B, T, device=dev)                                    # synthetic frames in [0, 1]
+    ts = np.arange(T) * 0.05
+    Bg = B * world
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        mu, logvar = encode(enc, x)
+        l_tilde = sample(mu, logvar)
+        x_hat, z_hat, l_hat = decode(dec, l_tilde, ts)
+        rec = ((x_hat - x) ** 2).sum() / (NI * Bg * T) * NI                  # Σ_pixels mean_{B,T}  [REF model_train.jl:232]
+        kl = sum((-0.5 * (1 + s - m ** 2 - torch.exp(s))).sum() for m, s in zip(mu, logvar)) / Bg
+        loss = rec + 1e-3 * kl
+        loss.backward()
+        sync()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    fence()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        el = float(tmax.item())
+    assert bool(torch.isfinite(loss))
+    N = B * T
+    mac = lambda sizes: sum(a * b for a, b in zip(sizes[:-1], sizes[1:]))
+    F_dense = 2 * (mac(enc.feature_extractor.sizes) + mac(dec.reconstructor.sizes)) * N
+    ms = el / args.steps * 1e3
+    out = {
+        "metric": "trajectories/sec, whole GOKU training step (encoder -> sample -> latent_out -> solve -> reconstructor, loss, pullback, AdamW) goku_step",
+        "value": B * world * args.steps / el, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "goku_step: GOKU_basic default layers (input 784, T=50), Pendulum Tsit5, MSE + 1e-3·KL, AdamW; "
+                               "torch-level API over lde_chain_* / lde_rnn_* / lde_forward / lde_adjoint",
+                   "batch_per_gpu": B, "global_batch": Bg, "save_points": T,
+                   "parallelism": f"dp{world} (batch sharded by trajectory; one flat all-reduce of all parameter gradients per step)"},
+        "roofline": dict(bound="mfma", kernel="whole step (dense chains dominate the flops)", achieved=3 * F_dense / (ms * 1e-3) / 1e12,
+                         peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=3 * F_dense / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, traffic=None,
+                         note="host-side autograd / launch overhead of ~60 small torch ops is inside the step"),
+        "loss": float(loss), "cpu_baseline": None,
+    }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="goku_pendulum", choices=sorted(WORKLOADS) + ["goku_decoder"])
+    ap.add_argument("--workload", default="goku_pendulum", choices=sorted(WORKLOADS) + ["goku_decoder", "goku_step"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep", action="store_true", help="also report a large-batch sweep (extra keys, rank 0)")
@@ -363,6 +443,8 @@ def main():
 
     if args.workload == "goku_decoder":
         return run_decoder(args, torch, dist, world, rank, local)
+    if args.workload == "goku_step":
+        return run_goku_step(args, torch, dist, world, rank, local)
 
     from latentdiffeq_amd import _lib as L
     lib = L.load()

@@ -259,7 +259,7 @@ typedef struct lde_rnn_desc {
   int32_t abi_version;                       /* = LDE_ABI_VERSION */
   int32_t cell;                              /* lde_cell_kind */
   int32_t n_layers;                          /* stacked cells, 1..LDE_RNN_MAX_LAYERS */
-  int32_t sizes[LDE_RNN_MAX_LAYERS + 1];     /* [in, h1, ..., hL]; every h ≤ 64, in ≤ 256 */
+  int32_t sizes[LDE_RNN_MAX_LAYERS + 1];     /* [in, h1, ..., hL]; gate rows G·h ≤ 64 (LSTM: h ≤ 16, RNN: h ≤ 64), in ≤ 256 */
   int32_t reverse;                           /* 1: feed the frames T, T-1, ..., 1 (reverse(fe_out)) */
 } lde_rnn_desc;
 

@@ -8,10 +8,10 @@
 //
 // Design (gfx950). The cells are tiny (16 hidden units, K = in + h = 48) and strictly sequential in time: this is
 // latency-bound scalar work, not matrix-core work (north star: "MFMA only if latent_dim×hidden is large enough to fill
-// a tile"). A workgroup owns 16 trajectories, Hp = pow2(h) lanes per trajectory (all lanes of a trajectory sit in one
-// wave, so a step needs no barrier); lane (trajectory, unit u) computes the G gate rows of its unit as dot products of
-// LDS-resident rows of [Wi | Wh] with the trajectory's [x_t ; h_{t-1}] vector (16-byte LDS reads, broadcast within the
-// trajectory). The pullback recomputes the sweep with per-step records in HBM, walks it backwards (δ per gate,
+// a tile"). A workgroup owns 16 trajectories, Hp = pow2(G·h) ≤ 64 lanes per trajectory (all lanes of a trajectory sit in
+// one wave, so a step needs no barrier); lane (trajectory, row r) computes one gate pre-activation as the dot product of
+// the LDS-resident row r of [Wi | Wh] with the trajectory's [x_t ; h_{t-1}] vector (16-byte LDS reads, broadcast within
+// the trajectory), the first h lanes then combine the gates of their unit. The pullback recomputes the sweep with per-step records in HBM, walks it backwards (δ per gate,
 // transposed matrix–vector products through the same LDS copy), and STAGES the (a, δ) = ([x_t;h_{t-1}], gate deltas)
 // panels of every (step, layer) in the block layout of lde_mfma.h, so that the weight gradient — the only
 // matrix-shaped part: K' = B·T columns — is formed by the shared large-K MFMA kernel k_mlp_dw, once per cell.
@@ -106,34 +106,55 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
       cst[l * rd.hmax + u] = lstm ? lw[rd.s_off[l] + h + u] : 0.f;
     }
   }
+  // frame s+1 is fetched while frame s is processed (a global round trip per time step would otherwise be exposed T times)
+  constexpr int XQ = 4;                       // prefetched inputs per lane (in ≤ XQ·Hp; wider inputs fall back to direct loads)
+  float xq[XQ];
+  auto fetch_x = [&](int s) {
+    const int t = rd.reverse ? T - 1 - s : s;
+#pragma unroll
+    for (int q = 0; q < XQ; q++) {
+      const int k = u + q * Hp;
+      xq[q] = (valid && k < in0) ? a.x[(size_t)in0 * ((size_t)b + (size_t)B * t) + k] : 0.f;
+    }
+  };
+  fetch_x(0);
   for (int s = 0; s < T; s++) {
     const int t = rd.reverse ? T - 1 - s : s;
     for (int l = 0; l < L; l++) {
       const int in = rd.sizes[l], h = rd.sizes[l + 1], K = in + h, ldk = rd.ldk[l];
       // assemble [input ; h_prev] (the tail up to pad4(K) stays zero: vbuf was zero-filled, entries beyond K never written)
       if (l == 0) {
-        for (int k = u; k < in; k += Hp) vbuf[k] = valid ? a.x[(size_t)in0 * ((size_t)b + (size_t)B * t) + k] : 0.f;
+#pragma unroll
+        for (int q = 0; q < XQ; q++)
+          if (u + q * Hp < in) vbuf[u + q * Hp] = xq[q];
+        for (int k = u + XQ * Hp; k < in; k += Hp) vbuf[k] = valid ? a.x[(size_t)in0 * ((size_t)b + (size_t)B * t) + k] : 0.f;
+        if (s + 1 < T) fetch_x(s + 1);
       } else {
         for (int k = u; k < in; k += Hp) vbuf[k] = hst[(l - 1) * rd.hmax + k];
       }
       for (int k = u; k < h; k += Hp) vbuf[in + k] = hst[l * rd.hmax + k];
       for (int k = K + u; k < ((K + 3) & ~3); k += Hp) vbuf[k] = 0.f;
+      if (a.mode == 1) {   // the layer's input vector is the a-panel of the weight gradient: staged here, while it is in LDS
+        float* ga = a.stage[l] + ((size_t)blockIdx.x * T + s) * a.blk[l] + tr * pad32(K);
+        for (int k = u; k < pad32(K); k += Hp) ga[k] = (valid && k < K) ? vbuf[k] : 0.f;
+      }
+      // one lane per gate ROW (Hp ≥ G·h lanes per trajectory): z_r = b_r + [Wi|Wh]_r · [x; h]; the unit lanes then pick
+      // their G pre-activations up from LDS. (One lane per UNIT doing G rows was 4× the dependent work per lane.)
+      const int Rl = G * h;
+      if (u < Rl) {
+        const int K4 = (K + 3) >> 2;
+        const float* wr = lw + rd.w_off[l] + u * ldk;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int k4 = 0; k4 < K4; k4++)
+          acc += *reinterpret_cast<const f32x4*>(wr + 4 * k4) * *reinterpret_cast<const f32x4*>(vbuf + 4 * k4);
+        dbuf[u] = lw[rd.b_off[l] + u] + ((acc[0] + acc[1]) + (acc[2] + acc[3]));
+      }
       if (u < h) {
         float z[4] = {0.f, 0.f, 0.f, 0.f};
-        const int K4 = (K + 3) >> 2;
 #pragma unroll
-        for (int g = 0; g < 4; g++) {
-          if (g < G) {
-            const float* wr = lw + rd.w_off[l] + (g * h + u) * ldk;
-            float acc = lw[rd.b_off[l] + g * h + u];
-            for (int k4 = 0; k4 < K4; k4++) {
-              const f32x4 w = *reinterpret_cast<const f32x4*>(wr + 4 * k4);
-              const f32x4 v = *reinterpret_cast<const f32x4*>(vbuf + 4 * k4);
-              acc += w[0] * v[0] + w[1] * v[1] + w[2] * v[2] + w[3] * v[3];
-            }
-            z[g] = acc;
-          }
-        }
+        for (int g = 0; g < 4; g++)
+          if (g < G) z[g] = dbuf[g * h + u];
         float hn, cn = 0.f;
         if (lstm) {
           const float ig = sigm(z[0]), fg = sigm(z[1]), gg = tanhf(z[2]), og = sigm(z[3]);
@@ -172,23 +193,35 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
       dcs[l * rd.hmax + u] = 0.f;
     }
   }
+  // records of the next (step, layer) are fetched while the current one is processed
+  float rq[6];   // gates (≤ 4), c_new, c_prev
+  auto fetch_rec = [&](int s, int l) {
+    const int h = rd.sizes[l + 1], R = G * h;
+    const float* r = a.rec + (((size_t)s * L + l) * B + (size_t)b) * rd.recw;
+#pragma unroll
+    for (int g = 0; g < 4; g++) rq[g] = (valid && u < h && g < G) ? r[g * h + u] : 0.f;
+    rq[4] = (valid && u < h && lstm) ? r[R + u] : 0.f;
+    rq[5] = 0.f;
+    if (valid && u < h && lstm)
+      rq[5] = s > 0 ? a.rec[(((size_t)(s - 1) * L + l) * B + (size_t)b) * rd.recw + R + u] : lw[rd.s_off[l] + h + u];
+  };
+  fetch_rec(T - 1, L - 1);
   for (int s = T - 1; s >= 0; s--) {
     const int t = rd.reverse ? T - 1 - s : s;
     if (u == 0) a.wts[((size_t)blockIdx.x * T + s) * NB + tr] = valid ? 1.f : 0.f;
     for (int l = L - 1; l >= 0; l--) {
       const int in = rd.sizes[l], h = rd.sizes[l + 1], K = in + h, R = G * h, ldk = rd.ldk[l];
       const int K32 = pad32(K), R32 = pad32(R);
-      const float* r = a.rec + (((size_t)s * L + l) * B + (size_t)b) * rd.recw;
-      const float* rp = a.rec + (((size_t)(s > 0 ? s - 1 : 0) * L + l) * B + (size_t)b) * rd.recw;   // previous step of this layer (used when s > 0)
+      float cur[6];
+#pragma unroll
+      for (int q = 0; q < 6; q++) cur[q] = rq[q];
+      if (l > 0) fetch_rec(s, l - 1);
+      else if (s > 0) fetch_rec(s - 1, L - 1);
       // gate deltas of this lane's unit
       if (u < h) {
         const float dh = dhs[l * rd.hmax + u];
         if (lstm) {
-          float ig = 0.f, fg = 0.f, gg = 0.f, og = 0.f, cn = 0.f, cp = 0.f;
-          if (valid) {
-            ig = r[u]; fg = r[h + u]; gg = r[2 * h + u]; og = r[3 * h + u]; cn = r[R + u];
-            cp = s > 0 ? rp[R + u] : lw[rd.s_off[l] + h + u];
-          }
+          const float ig = cur[0], fg = cur[1], gg = cur[2], og = cur[3], cn = cur[4], cp = cur[5];
           const float tc = tanhf(cn);
           const float dct = dcs[l * rd.hmax + u] + dh * og * (1.f - tc * tc);
           dbuf[u] = dct * gg * ig * (1.f - ig);
@@ -197,31 +230,30 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
           dbuf[3 * h + u] = dh * tc * og * (1.f - og);
           dcs[l * rd.hmax + u] = dct * fg;
         } else {
-          const float av = valid ? r[u] : 0.f;
+          const float av = cur[0];
           dbuf[u] = dh * (rd.cell == LDE_CELL_RNN_TANH ? 1.f - av * av : (av > 0.f ? 1.f : 0.f));
         }
       }
-      // the layer's input vector [x_in ; h_prev] again (for the weight gradient), staged with the deltas
-      {
-        float* blk = a.stage[l] + ((size_t)blockIdx.x * T + s) * a.blk[l];
-        float* ga = blk + tr * K32;
-        float* gd = blk + NB * K32 + tr * R32;
-        for (int k = u; k < K32; k += Hp) {
-          float v = 0.f;
-          if (valid) {
-            if (k < in) v = l == 0 ? a.x[(size_t)in0 * ((size_t)b + (size_t)B * t) + k]
-                                   : a.rec[(((size_t)s * L + (l - 1)) * B + (size_t)b) * rd.recw + G * rd.sizes[l] + rd.sizes[l] + k];
-            else if (k < K) v = s > 0 ? rp[R + h + (k - in)] : lw[rd.s_off[l] + (k - in)];
-          }
-          ga[k] = v;
-        }
+      {   // the δ-panel next to the a-panel the forward sweep staged
+        float* gd = a.stage[l] + ((size_t)blockIdx.x * T + s) * a.blk[l] + NB * K32 + tr * R32;
         for (int k = u; k < R32; k += Hp) gd[k] = (valid && k < R) ? dbuf[k] : 0.f;
       }
-      // [d_in ; dh_prev] = [Wi | Wh]ᵀ δ
+      // [d_in ; dh_prev] = [Wi | Wh]ᵀ δ: lane u owns the outputs k = u, u+Hp, …; four rows of δ per step, independent sums
       for (int k = u; k < K; k += Hp) {
         const float* wc = lw + rd.w_off[l] + k;
-        float acc = 0.f;
-        for (int rr = 0; rr < R; rr++) acc += wc[rr * ldk] * dbuf[rr];
+        f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
+        const int R4 = R >> 2;
+#pragma unroll 4
+        for (int r4 = 0; r4 < R4; r4++) {
+          const f32x4 dq = *reinterpret_cast<const f32x4*>(dbuf + 4 * r4);
+          const float* w = wc + (4 * r4) * ldk;
+          acc4[0] += w[0] * dq[0];
+          acc4[1] += w[ldk] * dq[1];
+          acc4[2] += w[2 * ldk] * dq[2];
+          acc4[3] += w[3 * ldk] * dq[3];
+        }
+        float acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
+        for (int rr = 4 * R4; rr < R; rr++) acc += wc[rr * ldk] * dbuf[rr];
         if (k < in) {
           if (l > 0) dhs[(l - 1) * rd.hmax + k] += acc;
           else if (a.dx && valid) a.dx[(size_t)in0 * ((size_t)b + (size_t)B * t) + k] = acc;
@@ -262,7 +294,15 @@ __global__ void k_rnn_state0(const float* __restrict__ g0, int B, int g0w, RnnDi
   }
   const int in = rd.sizes[l], h = rd.sizes[l + 1], R = rd.G * h;
   float s = 0.f;
-  for (int b = 0; b < B; b++) s += g0[(size_t)b * g0w + i];
+  int b = 0;
+  for (; b + 8 <= B; b += 8) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) v[q] = g0[(size_t)(b + q) * g0w + i];
+#pragma unroll
+    for (int q = 0; q < 8; q++) s += v[q];
+  }
+  for (; b < B; b++) s += g0[(size_t)b * g0w + i];
   dW[rd.f_off[l] + (size_t)R * in + (size_t)R * h + R + (i - off)] += s;
 }
 
@@ -343,8 +383,12 @@ int lde_rnn_create(const lde_rnn_desc* d, lde_rnn** out) {
     r->err = "recurrent stack: hidden width ≤ 64 and input width ≤ 256 supported";
     return LDE_ERR_UNSUPPORTED;
   }
-  int Hp = 1;
-  while (Hp < hmax) Hp <<= 1;
+  int Hp = 1;   // lanes per trajectory: one per gate row of the widest cell (≤ 64 ⇒ a trajectory never leaves its wave)
+  while (Hp < rd.G * hmax && Hp < 64) Hp <<= 1;
+  if (Hp < rd.G * hmax) {
+    r->err = "recurrent stack: G·h ≤ 64 gate rows per cell supported (LSTM: h ≤ 16, RNN: h ≤ 64)";
+    return LDE_ERR_UNSUPPORTED;
+  }
   rd.Hp = Hp;
   rd.hmax = hmax;
   int off = 0, foff = 0;

@@ -167,12 +167,37 @@ def apply_feature_extractor(encoder: Encoder, x):
     return encoder.feature_extractor(x)
 
 
+_side_streams = {}
+
+
+def _run_concurrently(stacks, x):
+    """The three stacks of the GOKU pattern extractor are independent and each fills only B/16 workgroups: run them on
+    side HIP streams (autograd replays each pullback on the stream its forward ran on, so those overlap too)."""
+    if not x.is_cuda or len(stacks) < 2:
+        return [m(x) for m in stacks]
+    dev = x.device
+    main = torch.cuda.current_stream(dev)
+    streams = _side_streams.setdefault((dev.index, len(stacks)), [torch.cuda.Stream(dev) for _ in stacks])
+    ready = main.record_event()
+    outs = []
+    for m, st in zip(stacks, streams):
+        st.wait_event(ready)
+        with torch.cuda.stream(st):
+            y = m(x)
+        x.record_stream(st)
+        outs.append(y)
+    for st, y in zip(streams, outs):
+        main.wait_stream(st)
+        y.record_stream(main)
+    return outs
+
+
 def apply_pattern_extractor(encoder: Encoder, fe_out):
     """[REF src/models/GOKU.jl:32-51]: pe_z₀ on the reversed frames; pe_θ forward ⊕ pe_θ backward (reversed frames).
     [REF src/models/LatentODE.jl:24-33]: one stack on the reversed frames."""
     if isinstance(encoder.model_type, GOKU):
-        pe_z0, pe_th_f, pe_th_b = encoder.pattern_extractor
-        return pe_z0(fe_out), torch.cat([pe_th_f(fe_out), pe_th_b(fe_out)], dim=0)
+        outs = _run_concurrently(encoder.pattern_extractor, fe_out)
+        return outs[0], torch.cat([outs[1], outs[2]], dim=0)
     if isinstance(encoder.model_type, LatentODE):
         return encoder.pattern_extractor(fe_out)
     raise TypeError(f"no apply_pattern_extractor method for model type {type(encoder.model_type).__name__}")

@@ -139,3 +139,36 @@ def test_reference_shaped_host_api_surface():
     assert la.transform_after_diffeq("x", Kuramoto()) == ("sin", "x")
     with pytest.raises(TypeError):
         la.diffeq_layer(la.Decoder(object(), (None, p, None)), None, [0.0])
+
+
+def test_dense_chain_and_recurrent_mirrors_fail_loudly_on_cpu():
+    """Rows f-1 / f-2: same rule — CPU tensors (or no GPU) raise, nothing is computed on the host."""
+    import torch
+    from latentdiffeq_amd import _lib
+    from latentdiffeq_amd.chain import Chain, Dense, SkipConnection
+    from latentdiffeq_amd.recurrent import LSTM, RNN, Recurrent
+    ch = Chain(Dense(4, 8, "relu"), SkipConnection(Dense(8, 8, "tanh")), Dense(8, 3, "sigmoid"))
+    assert ch.sizes == [4, 8, 8, 3] and ch.skips == [0, 1, 0] and ch.num_weights == 4 * 8 + 8 + 8 * 8 + 8 + 8 * 3 + 3
+    assert ch.flat_weights().numel() == ch.num_weights
+    rec = Recurrent(LSTM(6, 5), LSTM(5, 5), reverse=True)
+    assert rec.num_weights == 2 * 0 + (20 * 6 + 20 * 5 + 20 + 10) + (20 * 5 + 20 * 5 + 20 + 10)
+    with pytest.raises(TypeError):
+        Recurrent(RNN(4, 4), LSTM(4, 4))
+    with pytest.raises(ValueError):
+        SkipConnection(Dense(4, 5))
+    if not torch.cuda.is_available():
+        with pytest.raises(_lib.LdeError):
+            ch(torch.zeros(4, 2))
+        with pytest.raises(_lib.LdeError):
+            rec(torch.zeros(6, 2, 3))
+        lib = _lib.load()
+        d = _lib.ChainDesc()
+        d.abi_version, d.n_layers = 1, 1
+        d.sizes[0], d.sizes[1] = 3, 2
+        h = C.c_void_p()
+        assert lib.lde_chain_create(C.byref(d), C.byref(h)) == -3 and not h.value      # LDE_ERR_NO_DEVICE
+        r = _lib.RnnDesc()
+        r.abi_version, r.cell, r.n_layers = 1, _lib.CELL_LSTM, 1
+        r.sizes[0], r.sizes[1] = 3, 2
+        assert lib.lde_rnn_create(C.byref(r), C.byref(h)) == -3 and not h.value
+        assert lib.lde_chain_num_weights(C.byref(d)) == 8 and lib.lde_rnn_num_weights(C.byref(r)) == 8 * 3 + 8 * 2 + 8 + 4

@@ -406,7 +406,7 @@ def run_goku_step(args, torch, dist, world, rank, local):
         "roofline": dict(bound="mfma", kernel="whole step (dense chains dominate the flops)", achieved=3 * F_dense / (ms * 1e-3) / 1e12,
                          peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=3 * F_dense / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, traffic=None,
                          note="host-side autograd / launch overhead of ~60 small torch ops is inside the step"),
-        "loss": float(loss), "cpu_baseline": None,
+        "loss": float(loss.detach()), "cpu_baseline": None,
     }
     if world > 1:
         dist.barrier()

@@ -62,3 +62,49 @@ def test_node_weights_learn_a_rotation_field():
         first = float(loss.detach()) if first is None else first
         last = float(loss.detach())
     assert last < 0.05 * first, (first, last)
+
+
+def test_whole_goku_model_trains_on_synthetic_frames():
+    """The full model on this library — encoder (dense chain + RNN / LSTM stacks + latent_in) → sample → latent_out →
+    pendulum solve → reconstructor — through torch autograd with AdamW: the loss must fall on a small synthetic batch
+    (frames rendered from true pendulum trajectories, 8×8 pixels)."""
+    import torch
+    import latentdiffeq_amd as M
+    from latentdiffeq_amd.chain import decode, default_decoder_layers
+    from latentdiffeq_amd.recurrent import Encoder, default_encoder_layers, encode, sample
+    torch.manual_seed(0)
+    B, T, side = 32, 20, 8
+    NI = side * side
+    dev = "cuda"
+    # ground truth: pendulum angle → a bright blob at the bob position  [REF examples/pendulum_friction-less/create_data.jl:90-111] (simplified)
+    z0, L = O.pendulum_inputs(B)
+    ts = O.time_grid(T)
+    ztrue, _, _ = O.Oracle("f64").forward(O.make_desc(abstol=1e-9, reltol=1e-9), z0, L, ts)      # (T, B, 2)
+    ang = torch.tensor(ztrue[:, :, 0].T.copy(), dtype=torch.float32)                              # (B, T)
+    gx, gy = torch.meshgrid(torch.linspace(-1, 1, side), torch.linspace(-1, 1, side), indexing="ij")
+    bx, by = 0.7 * torch.sin(ang), 0.7 * torch.cos(ang)
+    frames = torch.exp(-(((gx[None, None] - bx[..., None, None]) ** 2 + (gy[None, None] - by[..., None, None]) ** 2) / 0.08))
+    x = frames.reshape(B, T, NI).permute(2, 0, 1).contiguous().to(dev)                            # [NI, B, T]
+    mt = M.GOKU_basic()
+    diffeq = M.Pendulum()
+    enc = Encoder(mt, default_encoder_layers(mt, NI, hidden_dim_resnet=64, device=dev))
+    dec = M.Decoder(mt, default_decoder_layers(mt, NI, diffeq, hidden_dim_resnet=64, latent_to_diffeq_dim=64, device=dev))
+    with torch.no_grad():
+        dec.latent_out[1]._dense[-1].bias.fill_(1.0)
+    mods = [enc.feature_extractor, *enc.pattern_extractor, *enc.latent_in, *dec.latent_out, dec.reconstructor]
+    params = [p for m in mods for p in m.parameters()]
+    opt = torch.optim.AdamW(params, lr=2e-3, weight_decay=1e-10)
+    losses = []
+    for it in range(60):
+        opt.zero_grad(set_to_none=True)
+        mu, logvar = encode(enc, x)
+        x_hat, z_hat, _ = decode(dec, sample(mu, logvar), ts)
+        rec = ((x_hat - x) ** 2).mean()
+        kl = sum((-0.5 * (1 + s - m ** 2 - torch.exp(s))).mean() for m, s in zip(mu, logvar))
+        loss = rec + 1e-4 * kl
+        loss.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in params)
+        opt.step()
+        losses.append(float(rec.detach()))
+    assert np.isfinite(losses).all()
+    assert np.mean(losses[-5:]) < 0.7 * np.mean(losses[:5]), (losses[:5], losses[-5:])

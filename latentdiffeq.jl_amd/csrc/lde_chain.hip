@@ -34,7 +34,8 @@ struct ChainDims {
   MlpDims dm;          // sizes + offsets (fill_layer_offsets)
   int act[MAXL];
   int skip[MAXL];
-  int ld0;             // stride of the input panel (≥ pad32(in))
+  int ld0;             // stride of the input panel (≥ pad32(in)); 0 when the first layer reads x straight from HBM (gx)
+  int gx;              // wide input (in % 16 == 0): x[in×N] itself is the B operand of layer 0 — no input panel, wider tiles
   int ldh;             // stride of hidden / gradient panels
 };
 
@@ -189,21 +190,34 @@ __device__ __forceinline__ void chain_load_tile(const ChainDims& cd, const float
   for (int l = 0; l < dm.nL; l++)
     for (int i = tid; i < dm.sizes[l + 1]; i += 512) biasc[dm.bias_lin[l] + i] = Wflat[dm.b_off[l] + i];
   const int in0 = dm.sizes[0];
-  for (int e = tid; e < NC * in0; e += 512) {
-    const int c = e / in0, r = e - c * in0;
-    if (n0 + c < N) X0[c * cd.ld0 + r] = x[(size_t)(n0 + c) * in0 + r];
+  if (!cd.gx) {
+    for (int e = tid; e < NC * in0; e += 512) {
+      const int c = e / in0, r = e - c * in0;
+      if (n0 + c < N) X0[c * cd.ld0 + r] = x[(size_t)(n0 + c) * in0 + r];
+    }
   }
   __syncthreads();
 }
 
+// first column of a workgroup's tile. With gx the ragged last tile is shifted back to end at N (its first `dup` columns
+// repeat the previous tile's: same values are stored twice, and they get weight 0 in the weight gradient), so that
+// every column a lane reads from x exists.
+__device__ __forceinline__ long long chain_tile_start(const ChainDims& cd, int NC, long long N, int* dup) {
+  const long long n = (long long)blockIdx.x * NC;
+  long long n0 = n;
+  if (cd.gx && n + NC > N) n0 = N - NC;
+  *dup = (int)(n - n0);
+  return n0;
+}
+
 // one hidden (non-last) layer: Y = [Xin +] act(W·Xin + b) into an LDS panel
-template <int CG>
+template <int CG, bool BG = false>
 __device__ __forceinline__ void chain_hidden_layer(const ChainDims& cd, int l, const float* frag, const float* biasc,
                                                    const float* Xin, int ldx, float* Y) {
   const MlpDims& dm = cd.dm;
-  const int in = dm.sizes[l], out = dm.sizes[l + 1], actk = cd.act[l], skip = cd.skip[l], ldh = cd.ldh;
+  const int in = dm.sizes[l], out = dm.sizes[l + 1], actk = cd.act[l], skip = BG ? 0 : cd.skip[l], ldh = cd.ldh;
   const float* bias = biasc + dm.bias_lin[l];
-  chain_gemm<CG, false>(frag + dm.frag_off[l], out, in, Xin, ldx, 16 * ldx, [](int, int, int) { return NoPre{}; },
+  chain_gemm<CG, BG>(frag + dm.frag_off[l], out, in, Xin, ldx, 16 * ldx, [](int, int, int) { return NoPre{}; },
                         [&](int row0, int cg, int col, f32x4 v, NoPre) {
                           const int c = cg * 16 + col;
                           f32x4 r;
@@ -224,17 +238,20 @@ __global__ void __launch_bounds__(512) k_chain_forward(ChainDims cd, ChainFwdArg
   float* H0 = X0 + NC * cd.ld0;
   float* H1 = H0 + NC * ldh;
   float* biasc = H1 + NC * ldh;
-  const long long n0 = (long long)blockIdx.x * NC;
+  int dup;
+  const long long n0 = chain_tile_start(cd, NC, a.N, &dup);
   PROF_T(pc0);
   chain_load_tile<CG>(cd, a.x, n0, a.N, X0, biasc, a.Wflat, NC * cd.ld0 + 2 * NC * ldh, csm);
   PROF_T(pc1);
   PROF_ADD(0, pc0, pc1);
   const float* Xin = X0;
   int ldx = cd.ld0;
+  const float* xg = a.x + (size_t)n0 * dm.sizes[0];   // gx: column c of the tile at xg + c·in
   for (int l = 0; l + 1 < nL; l++) {
     float* Y = (l & 1) ? H1 : H0;
     PROF_T(pl0);
-    chain_hidden_layer<CG>(cd, l, a.frag, biasc, Xin, ldx, Y);
+    if (l == 0 && cd.gx) chain_hidden_layer<CG, true>(cd, 0, a.frag, biasc, xg, dm.sizes[0], Y);
+    else chain_hidden_layer<CG>(cd, l, a.frag, biasc, Xin, ldx, Y);
     PROF_T(pl1);
     __syncthreads();
     PROF_T(pl2);
@@ -248,8 +265,7 @@ __global__ void __launch_bounds__(512) k_chain_forward(ChainDims cd, ChainFwdArg
     const int l = nL - 1, in = dm.sizes[l], out = dm.sizes[l + 1], actk = cd.act[l];
     const float* bias = biasc + dm.bias_lin[l];
     const bool vec = (out & 3) == 0;
-    chain_gemm<CG, false>(a.frag + dm.frag_off[l], out, in, Xin, ldx, 16 * ldx, [](int, int, int) { return NoPre{}; },
-                          [&](int row0, int cg, int col, f32x4 v, NoPre) {
+    auto epi_last = [&](int row0, int cg, int col, f32x4 v, NoPre) {
                             const long long n = n0 + cg * 16 + col;
                             if (n >= a.N || row0 >= out) return;
                             f32x4 r;
@@ -262,7 +278,10 @@ __global__ void __launch_bounds__(512) k_chain_forward(ChainDims cd, ChainFwdArg
                               for (int q = 0; q < 4; q++)
                                 if (row0 + q < out) yp[q] = r[q];
                             }
-                          });
+                          };
+    auto nopre = [](int, int, int) { return NoPre{}; };
+    if (nL == 1 && cd.gx) chain_gemm<CG, true>(a.frag + dm.frag_off[l], out, in, xg, in, 16 * in, nopre, epi_last);
+    else chain_gemm<CG, false>(a.frag + dm.frag_off[l], out, in, Xin, ldx, 16 * ldx, nopre, epi_last);
   }
   PROF_T(pz1);
   PROF_ADD(2 + 2 * (nL - 1), pz0, pz1);
@@ -295,21 +314,35 @@ __global__ void __launch_bounds__(512) k_chain_backward(ChainDims cd, ChainBwdAr
   float* P1 = P0 + NC * ldh;
   float* G = P1 + NC * ldh;
   float* biasc = G + NC * ldh;
-  const long long n0 = (long long)blockIdx.x * NC;
+  int dup;
+  const long long n0 = chain_tile_start(cd, NC, a.N, &dup);
   const size_t slot0 = (size_t)blockIdx.x * CG;
   float* const blk0 = a.stage + slot0 * dm.blk_floats;   // the CG staged blocks of this tile are contiguous
   chain_load_tile<CG>(cd, a.x, n0, a.N, X0, biasc, a.Wflat, NC * cd.ld0 + 3 * NC * ldh, csm);
+  const float* xg = a.x + (size_t)n0 * dm.sizes[0];
 
   // ---- 1. recompute the hidden activations; stage every layer's input panel ---------------------------------------
+  if (cd.gx) {   // a_0 straight from x (every column of a shifted tile exists)
+    const int in0 = dm.sizes[0], in32 = pad32(in0), col = tid >> 5, l31 = tid & 31;
 #pragma unroll
-  for (int cg = 0; cg < CG; cg++)
-    stage_panel(X0 + cg * 16 * cd.ld0, cd.ld0, pad32(dm.sizes[0]), blk0 + (size_t)cg * dm.blk_floats + dm.blk_off[0]);
+    for (int cg = 0; cg < CG; cg++) {
+      float* dst = blk0 + (size_t)cg * dm.blk_floats + dm.blk_off[0] + col * in32;
+      const float* src = xg + (size_t)(cg * 16 + col) * in0;
+      for (int r4 = l31; 4 * r4 < in32; r4 += 32)
+        *reinterpret_cast<f32x4*>(dst + 4 * r4) = 4 * r4 < in0 ? *reinterpret_cast<const f32x4*>(src + 4 * r4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  } else {
+#pragma unroll
+    for (int cg = 0; cg < CG; cg++)
+      stage_panel(X0 + cg * 16 * cd.ld0, cd.ld0, pad32(dm.sizes[0]), blk0 + (size_t)cg * dm.blk_floats + dm.blk_off[0]);
+  }
   {
     const float* Xin = X0;
     int ldx = cd.ld0;
     for (int l = 0; l + 1 < nL; l++) {
       float* Y = (l & 1) ? P1 : P0;
-      chain_hidden_layer<CG>(cd, l, a.frag, biasc, Xin, ldx, Y);
+      if (l == 0 && cd.gx) chain_hidden_layer<CG, true>(cd, 0, a.frag, biasc, xg, dm.sizes[0], Y);
+      else chain_hidden_layer<CG>(cd, l, a.frag, biasc, Xin, ldx, Y);
       __syncthreads();
 #pragma unroll
       for (int cg = 0; cg < CG; cg++)
@@ -346,7 +379,7 @@ __global__ void __launch_bounds__(512) k_chain_backward(ChainDims cd, ChainBwdAr
         }
         *reinterpret_cast<f32x4*>(dst + r) = d;
       }
-      if (tid < 16) a.wts[(slot0 + cg) * NB + tid] = (n0 + cg * 16 + tid < a.N) ? 1.f : 0.f;
+      if (tid < 16) a.wts[(slot0 + cg) * NB + tid] = (n0 + cg * 16 + tid < a.N && cg * 16 + tid >= dup) ? 1.f : 0.f;   // repeated columns of a shifted tile: weight 0
     }
   }
   __syncthreads();   // the staged panels are read back below (s_waitcnt vmcnt(0) + barrier ⇒ they are in L2)
@@ -432,6 +465,9 @@ struct lde_chain {
   bool have_W = false;
   int cg_fwd = 0, cg_bwd = 0;
   size_t lds_fwd = 0, lds_bwd = 0;
+  ChainDims cdx;               // the panel-free layout for wide inputs (gx), when applicable
+  int cgx_fwd = 0, cgx_bwd = 0;
+  size_t ldsx_fwd = 0, ldsx_bwd = 0;
   // backward workspace
   float* stage = nullptr; size_t stage_cap = 0;
   float* wts = nullptr; size_t wts_cap = 0;
@@ -522,15 +558,31 @@ int lde_chain_create(const lde_chain_desc* d, lde_chain** out) {
   // Falls back to the widest tile that fits at all. LDE_CHAIN_CG_FWD / LDE_CHAIN_CG_BWD force a value (experiments).
   const char* ef = getenv("LDE_CHAIN_CG_FWD");
   const char* eb = getenv("LDE_CHAIN_CG_BWD");
-  for (size_t lim : {LDS_MAX / 2, LDS_MAX}) {
-    for (int cg : {4, 2, 1}) {
-      if (!c->cg_fwd && (!ef || cg == atoi(ef)) && chain_lds(cd, cg, 2) <= (ef ? LDS_MAX : lim)) { c->cg_fwd = cg; c->lds_fwd = chain_lds(cd, cg, 2); }
-      if (cg <= 2 && !c->cg_bwd && (!eb || cg == atoi(eb)) && chain_lds(cd, cg, 3) <= (eb ? LDS_MAX : lim)) { c->cg_bwd = cg; c->lds_bwd = chain_lds(cd, cg, 3); }
+  auto pick = [&](const ChainDims& q, int* cgf, size_t* ldf, int* cgb, size_t* ldb) {
+    *cgf = *cgb = 0;
+    for (size_t lim : {LDS_MAX / 2, LDS_MAX}) {
+      for (int cg : {4, 2, 1}) {
+        if (!*cgf && (!ef || cg == atoi(ef)) && chain_lds(q, cg, 2) <= (ef ? LDS_MAX : lim)) { *cgf = cg; *ldf = chain_lds(q, cg, 2); }
+        if (cg <= 2 && !*cgb && (!eb || cg == atoi(eb)) && chain_lds(q, cg, 3) <= (eb ? LDS_MAX : lim)) { *cgb = cg; *ldb = chain_lds(q, cg, 3); }
+      }
     }
+  };
+  pick(cd, &c->cg_fwd, &c->lds_fwd, &c->cg_bwd, &c->lds_bwd);
+  // wide inputs (an image encoder's first layer): x itself is the B operand of layer 0, no input panel
+  c->cdx = cd;
+  const char* eg = getenv("LDE_CHAIN_GX");
+  if (dm.sizes[0] % 16 == 0 && dm.sizes[0] >= 128 && !cd.skip[0] && !(eg && atoi(eg) == 0)) {
+    c->cdx.gx = 1;
+    c->cdx.ld0 = 0;
+    pick(c->cdx, &c->cgx_fwd, &c->ldsx_fwd, &c->cgx_bwd, &c->ldsx_bwd);
   }
   if (!c->cg_fwd || !c->cg_bwd) {
-    c->err = "chain: activation panels do not fit the 160 KiB LDS";
-    return LDE_ERR_UNSUPPORTED;
+    if (c->cgx_fwd && c->cgx_bwd) {   // only the panel-free layout fits: it needs N ≥ one tile (checked per call)
+      c->cg_fwd = c->cg_bwd = 0;
+    } else {
+      c->err = "chain: activation panels do not fit the 160 KiB LDS";
+      return LDE_ERR_UNSUPPORTED;
+    }
   }
   if (hipMalloc(&c->W_dev, (size_t)c->nW * sizeof(float)) != hipSuccess ||
       hipMalloc(&c->frag, c->nfrag * sizeof(float)) != hipSuccess ||
@@ -577,11 +629,24 @@ int lde_chain_set_weights_device(lde_chain* c, const float* flat_dev, int64_t n,
   return chain_frags(c, (hipStream_t)stream);
 }
 
+// which layout a call uses: the panel-free one (gx) when the input is wide, x is 16-byte aligned and N fills a tile
+struct ChainPick { const ChainDims* cd; int cg; size_t lds; };
+static bool chain_pick(const lde_chain* c, const float* x, int64_t N, bool bwd, ChainPick* p) {
+  const int cgx = bwd ? c->cgx_bwd : c->cgx_fwd, cg = bwd ? c->cg_bwd : c->cg_fwd;
+  if (cgx && N >= 16 * cgx && (((uintptr_t)x) & 15) == 0) {
+    *p = ChainPick{&c->cdx, cgx, bwd ? c->ldsx_bwd : c->ldsx_fwd};
+    return true;
+  }
+  if (!cg) return false;
+  *p = ChainPick{&c->cd, cg, bwd ? c->lds_bwd : c->lds_fwd};
+  return true;
+}
+
 // virtual tiling of the slot range for k_mlp_dw: (virtual tiles × jobs) ≈ one workgroup per CU — the kernel's register
 // footprint allows one resident workgroup per CU, so 256 equal shares beat 384 (a second, half-empty round)
-static void chain_dw_split(const lde_chain* c, int64_t N, int* nvt, int* cap, int64_t* total) {
-  const int64_t tiles = (N + 16 * c->cg_bwd - 1) / (16 * c->cg_bwd);
-  *total = tiles * c->cg_bwd;
+static void chain_dw_split(const lde_chain* c, int cg_bwd, int64_t N, int* nvt, int* cap, int64_t* total) {
+  const int64_t tiles = (N + 16 * cg_bwd - 1) / (16 * cg_bwd);
+  *total = tiles * cg_bwd;
   int v = 256 / dw_jobs(c->cd.dm, dw_pick_ndw(c->cd.dm));
   if (v < 1) v = 1;
   if (*total < v) v = (int)*total;
@@ -594,7 +659,7 @@ int lde_chain_reserve(lde_chain* c, int64_t N) {
   if (!c || !c->W_dev || N < 1) return LDE_ERR_INVALID_ARG;
   int nvt, cap;
   int64_t total;
-  chain_dw_split(c, N, &nvt, &cap, &total);
+  chain_dw_split(c, 2, N, &nvt, &cap, &total);   // 2 column groups per tile rounds the slot count up the most
   const MlpDims& dm = c->cd.dm;
   if (!grow(&c->stage, &c->stage_cap, (size_t)total * dm.blk_floats) || !grow(&c->wts, &c->wts_cap, (size_t)total * NB) ||
       !grow(&c->slab, &c->slab_cap, ((size_t)nvt + 1) * dm.slab_n) || !grow(&c->ints, &c->ints_cap, (size_t)nvt + 16)) {
@@ -620,24 +685,29 @@ int lde_chain_forward(lde_chain* c, const float* x, int64_t N, float* y, void* s
   }
   hipStream_t stream = (hipStream_t)stream_;
   ChainFwdArgs a{x, y, c->frag, c->W_dev, (long long)N};
-  const int NC = 16 * c->cg_fwd;
+  ChainPick pk;
+  if (!chain_pick(c, x, N, false, &pk)) {
+    c->err = "lde_chain_forward: the only layout whose panels fit LDS reads x in place and needs N ≥ one tile and a 16-byte aligned x";
+    return LDE_ERR_UNSUPPORTED;
+  }
+  const int NC = 16 * pk.cg;
   const dim3 grid((unsigned)((N + NC - 1) / NC));
   static bool attr[5] = {false, false, false, false, false};
-  const void* fn = c->cg_fwd == 4 ? (const void*)k_chain_forward<4> : c->cg_fwd == 2 ? (const void*)k_chain_forward<2>
-                                                                                    : (const void*)k_chain_forward<1>;
-  if (!attr[c->cg_fwd]) {
+  const void* fn = pk.cg == 4 ? (const void*)k_chain_forward<4> : pk.cg == 2 ? (const void*)k_chain_forward<2>
+                                                                            : (const void*)k_chain_forward<1>;
+  if (!attr[pk.cg]) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
       c->err = "hipFuncSetAttribute(k_chain_forward) failed";
       return LDE_ERR_HIP;
     }
-    attr[c->cg_fwd] = true;
+    attr[pk.cg] = true;
   }
 #if LDE_PROF
   { long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
 #endif
-  if (c->cg_fwd == 4) hipLaunchKernelGGL(k_chain_forward<4>, grid, dim3(512), c->lds_fwd, stream, c->cd, a);
-  else if (c->cg_fwd == 2) hipLaunchKernelGGL(k_chain_forward<2>, grid, dim3(512), c->lds_fwd, stream, c->cd, a);
-  else hipLaunchKernelGGL(k_chain_forward<1>, grid, dim3(512), c->lds_fwd, stream, c->cd, a);
+  if (pk.cg == 4) hipLaunchKernelGGL(k_chain_forward<4>, grid, dim3(512), pk.lds, stream, *pk.cd, a);
+  else if (pk.cg == 2) hipLaunchKernelGGL(k_chain_forward<2>, grid, dim3(512), pk.lds, stream, *pk.cd, a);
+  else hipLaunchKernelGGL(k_chain_forward<1>, grid, dim3(512), pk.lds, stream, *pk.cd, a);
   if (hipGetLastError() != hipSuccess) {
     c->err = "k_chain_forward launch failed";
     return LDE_ERR_HIP;
@@ -678,25 +748,30 @@ int lde_chain_backward(lde_chain* c, const float* x, const float* y, const float
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)stream_;
   const MlpDims& dm = c->cd.dm;
+  ChainPick pk;
+  if (!chain_pick(c, x, N, true, &pk)) {
+    c->err = "lde_chain_backward: the only layout whose panels fit LDS reads x in place and needs N ≥ one tile and a 16-byte aligned x";
+    return LDE_ERR_UNSUPPORTED;
+  }
   int nvt, cap;
   int64_t total;
-  chain_dw_split(c, N, &nvt, &cap, &total);
+  chain_dw_split(c, pk.cg, N, &nvt, &cap, &total);
   ChainBwdArgs a{x, y, dy, dx, c->frag, c->fragT, c->W_dev, c->stage, c->wts, (long long)N};
-  const int NC = 16 * c->cg_bwd;
+  const int NC = 16 * pk.cg;
   const dim3 grid((unsigned)((N + NC - 1) / NC));
   static bool attr[3] = {false, false, false};
-  const void* fn = c->cg_bwd == 2 ? (const void*)k_chain_backward<2> : (const void*)k_chain_backward<1>;
-  if (!attr[c->cg_bwd]) {
+  const void* fn = pk.cg == 2 ? (const void*)k_chain_backward<2> : (const void*)k_chain_backward<1>;
+  if (!attr[pk.cg]) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
       c->err = "hipFuncSetAttribute(k_chain_backward) failed";
       return LDE_ERR_HIP;
     }
-    attr[c->cg_bwd] = true;
+    attr[pk.cg] = true;
   }
   hipLaunchKernelGGL(k_chain_fill_slots, dim3(cdiv(nvt, 64)), dim3(64), 0, stream, c->ints, c->ints + nvt, nvt, cap,
                      (long long)total);
-  if (c->cg_bwd == 2) hipLaunchKernelGGL(k_chain_backward<2>, grid, dim3(512), c->lds_bwd, stream, c->cd, a);
-  else hipLaunchKernelGGL(k_chain_backward<1>, grid, dim3(512), c->lds_bwd, stream, c->cd, a);
+  if (pk.cg == 2) hipLaunchKernelGGL(k_chain_backward<2>, grid, dim3(512), pk.lds, stream, *pk.cd, a);
+  else hipLaunchKernelGGL(k_chain_backward<1>, grid, dim3(512), pk.lds, stream, *pk.cd, a);
   if (hipGetLastError() != hipSuccess) {
     c->err = "k_chain_backward launch failed";
     return LDE_ERR_HIP;

@@ -18,6 +18,8 @@ LO_TH = ((16, 200, 1), (O.CACT_RELU, O.CACT_SOFTPLUS), (0, 0))
 ODD = ((5, 33, 33, 7, 7, 19), (O.CACT_TANH, O.CACT_SOFTPLUS, O.CACT_RELU, O.CACT_SIGMOID, O.CACT_IDENTITY), (0, 1, 0, 1, 0))
 WIDE = ((32, 512, 512, 40), (O.CACT_RELU, O.CACT_TANH, O.CACT_IDENTITY), (0, 1, 0))      # panels force 32 / 16 columns per tile
 ONE = ((24, 10), (O.CACT_SIGMOID,), (0,))
+FE = ((784, 200, 200, 200, 32), (O.CACT_RELU,) * 4, (0, 1, 1, 0))   # feature extractor [REF src/models/GOKU.jl:219-226]: x read in place
+ONE_WIDE = ((256, 24), (O.CACT_TANH,), (0,))                         # single layer, wide input: in place too
 
 
 def _run(spec, N, o32, o64, seed=5, need_dx=True):
@@ -50,7 +52,8 @@ def _run(spec, N, o32, o64, seed=5, need_dx=True):
     return nat, (x, y, dy, dx, dW)
 
 
-@pytest.mark.parametrize("spec", [RECON, LO_Z0, LO_TH, ODD, WIDE, ONE], ids=["reconstructor", "lo_z0", "lo_theta", "odd", "wide", "one"])
+@pytest.mark.parametrize("spec", [RECON, LO_Z0, LO_TH, ODD, WIDE, ONE, FE, ONE_WIDE],
+                         ids=["reconstructor", "lo_z0", "lo_theta", "odd", "wide", "one", "feature_extractor", "one_wide"])
 @pytest.mark.parametrize("N", [1, 37, 256])
 def test_chain_forward_backward_parity(o32, o64, spec, N):
     _run(spec, N, o32, o64)
@@ -59,6 +62,20 @@ def test_chain_forward_backward_parity(o32, o64, spec, N):
 def test_reconstructor_at_the_metric_shape(o32, o64):
     """x̂ = reconstructor(ẑ) on N = B·T = 256·50 columns (the metric config's ẑ), ragged by one column."""
     _run(RECON, 256 * 50 - 1, o32, o64, seed=9)
+
+
+def test_wide_input_layouts_agree(o32, o64, monkeypatch):
+    """Wide inputs are read in place from x (no LDS input panel, ragged last tile shifted back with zero-weight repeats);
+    LDE_CHAIN_GX=0 forces the panel layout. Both must give the same numbers to round-off, on a ragged N."""
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LDE_CHAIN_GX", flag)
+        _, (x, y, dy, dx, dW) = _run(FE, 16 * 7 + 5, o32, o64, seed=13)
+        outs.append((y, dx, dW))
+    (ya, dxa, dWa), (yb, dxb, dWb) = outs
+    assert np.abs(ya - yb).max() <= 1e-6 * max(1.0, np.abs(ya).max())
+    assert np.abs(dxa - dxb).max() <= 1e-5 * np.abs(dxa).max()
+    assert np.abs(dWa - dWb).max() <= 1e-5 * np.abs(dWa).max()
 
 
 def test_chain_dw_accumulates_and_dx_is_optional(o32):

@@ -15,6 +15,9 @@
 // transposed matrix–vector products through the same LDS copy), and STAGES the (a, δ) = ([x_t;h_{t-1}], gate deltas)
 // panels of every (step, layer) in the block layout of lde_mfma.h, so that the weight gradient — the only
 // matrix-shaped part: K' = B·T columns — is formed by the shared large-K MFMA kernel k_mlp_dw, once per cell.
+// (Measured alternative: 2 or 4 trajectories per wave sharing every weight read — a quarter of the LDS traffic, but only
+// 4–8 waves per workgroup left to hide the LDS latency: the whole training step got 12–15 % slower. Kept: one trajectory
+// per lane group, 16 waves.)
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -45,6 +48,8 @@ struct RnnDims {
 };
 
 __device__ __forceinline__ float sigm(float x) { return fast_rcp(1.0f + __expf(-x)); }
+// tanh x = 1 − 2/(1 + e^{2x}): v_exp_f32 + v_rcp_f32, ≈ 2e-7 absolute (saturates cleanly: e^{2x} → ∞ ⇒ 1, → 0 ⇒ −1)
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * fast_rcp(1.0f + __expf(2.0f * x)); }
 
 struct RnnArgs {
   const float* x;       // [in × B × T]
@@ -157,12 +162,12 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
           if (g < G) z[g] = dbuf[g * h + u];
         float hn, cn = 0.f;
         if (lstm) {
-          const float ig = sigm(z[0]), fg = sigm(z[1]), gg = tanhf(z[2]), og = sigm(z[3]);
+          const float ig = sigm(z[0]), fg = sigm(z[1]), gg = fast_tanh(z[2]), og = sigm(z[3]);
           z[0] = ig; z[1] = fg; z[2] = gg; z[3] = og;
           cn = fg * cst[l * rd.hmax + u] + ig * gg;
-          hn = og * tanhf(cn);
+          hn = og * fast_tanh(cn);
         } else {
-          hn = rd.cell == LDE_CELL_RNN_TANH ? tanhf(z[0]) : fmaxf(z[0], 0.f);
+          hn = rd.cell == LDE_CELL_RNN_TANH ? fast_tanh(z[0]) : fmaxf(z[0], 0.f);
           z[0] = hn;
         }
         if (a.mode == 1 && valid) {
@@ -222,7 +227,7 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
         const float dh = dhs[l * rd.hmax + u];
         if (lstm) {
           const float ig = cur[0], fg = cur[1], gg = cur[2], og = cur[3], cn = cur[4], cp = cur[5];
-          const float tc = tanhf(cn);
+          const float tc = fast_tanh(cn);
           const float dct = dcs[l * rd.hmax + u] + dh * og * (1.f - tc * tc);
           dbuf[u] = dct * gg * ig * (1.f - ig);
           dbuf[h + u] = dct * cp * fg * (1.f - fg);

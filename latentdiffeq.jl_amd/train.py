@@ -1,0 +1,160 @@
+"""Host-side training harness (scope row f-3): what the reference's example script wraps around the model. Pure host code —
+the compute under `model(x, t)` is liblde.so (api.py, chain.py, recurrent.py); this file launches no kernel of its own.
+
+    reference                                                                         here
+    --------------------------------------------------------------------------------  -----------------------------
+    LatentDiffEqModel(model_type, encoder_layers, decoder_layers); model(x, t, variational)
+                                                      [REF src/models/LatentDiffEqModel.jl:6-37]      LatentDiffEqModel
+    default_layers(model_type, input_dim, diffeq)     [REF src/models/GOKU.jl:201-273]               default_layers
+    loss_batch(model, x, t, β, variational)           [REF examples/pendulum_friction-less/model_train.jl:225-238]   loss_batch
+    kl, vector_kl                                     [REF src/utils/utils.jl:15-49]                  kl, vector_kl
+    frange_cycle_linear(n_iter, start, stop, n_cycle, ratio)   [REF src/utils/utils.jl:53-66]         frange_cycle_linear
+    normalize_to_unit_segment / denormalize_unit_segment       [REF src/utils/utils.jl:71-79]         same
+    time_loader(x, full_seq_len, seq_len), rand_time  [REF src/utils/utils.jl:85-99]                  time_loader, rand_time
+    the epoch loop: β schedule, progressive sequence length, ADAMW, per-minibatch validation loss, best weights
+                                                      [REF model_train.jl:138-150, :172-218]          train
+"""
+from __future__ import annotations
+
+from typing import Callable, Iterable, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .api import Decoder
+from .chain import decode, default_decoder_layers
+from .recurrent import Encoder, default_encoder_layers, encode, sample
+
+
+class LatentDiffEqModel:
+    """LatentDiffEqModel(model_type, encoder_layers, decoder_layers); `model(x, t, variational)` → ((x̂, ẑ, l̂), μ, logσ²)."""
+
+    def __init__(self, model_type, encoder_layers, decoder_layers):
+        self.model_type = model_type
+        self.encoder = Encoder(model_type, encoder_layers)
+        self.decoder = Decoder(model_type, decoder_layers)
+
+    def modules(self) -> List[torch.nn.Module]:
+        e, d = self.encoder, self.decoder
+        pe = list(e.pattern_extractor) if isinstance(e.pattern_extractor, tuple) else [e.pattern_extractor]
+        lo = list(d.latent_out) if isinstance(d.latent_out, tuple) else []
+        extra = [d.diffeq.dudt] if hasattr(d.diffeq, "dudt") else []   # the NODE's weights: trained here
+        return [e.feature_extractor, *pe, *e.latent_in, *lo, *extra, d.reconstructor]
+
+    def parameters(self) -> List[torch.nn.Parameter]:
+        return [p for m in self.modules() for p in m.parameters()]
+
+    def __call__(self, x, t, variational: bool = False):
+        mu, logvar = encode(self.encoder, x)
+        l_tilde = sample(mu, logvar) if variational else mu                      # [REF LatentDiffEqModel.jl:31]
+        return decode(self.decoder, l_tilde, t), mu, logvar
+
+
+def default_layers(model_type, input_dim: int, diffeq, device=None, **kw):
+    """(encoder_layers, decoder_layers)  [REF src/models/GOKU.jl:201-273], [REF src/models/LatentODE.jl:91-145]."""
+    ekw = {k: v for k, v in kw.items() if k in ("hidden_dim_resnet", "rnn_input_dim", "rnn_output_dim", "latent_dim_z0", "latent_dim_theta")}
+    dkw = {k: v for k, v in kw.items() if k in ("hidden_dim_resnet", "latent_dim_z0", "latent_dim_theta", "latent_to_diffeq_dim",
+                                                "z0_activation", "theta_activation", "output_activation")}
+    return (default_encoder_layers(model_type, input_dim, diffeq, device=device, **ekw),
+            default_decoder_layers(model_type, input_dim, diffeq, device=device, **dkw))
+
+
+def kl(mu, logvar):
+    """kl(μ, logσ²) = (exp(logσ²) + μ² − logσ² − 1) / 2, elementwise  [REF src/utils/utils.jl:15]."""
+    return (torch.exp(logvar) + mu ** 2 - logvar - 1) / 2
+
+
+def vector_kl(mu, logvar):
+    """Σ over entries of kl, divided by the batch size; for the GOKU tuple the sum of both parts  [REF utils.jl:17-49]."""
+    if isinstance(mu, tuple):
+        return sum(kl(m, s).sum() / m.shape[1] for m, s in zip(mu, logvar))
+    return kl(mu, logvar).sum() / mu.shape[1]
+
+
+def loss_batch(model, x, t, beta: float, variational: bool):
+    """reconstruction_loss + β·kl_loss with reconstruction_loss = sum(mean((x − x̂)², dims=(2,3)))  [REF model_train.jl:225-238]."""
+    (x_hat, _z, _l), mu, logvar = model(x, t, variational)
+    rec = ((x - x_hat) ** 2).mean(dim=(1, 2)).sum()
+    return rec + beta * vector_kl(mu, logvar)
+
+
+def frange_cycle_linear(n_iter: int, start: float = 0.0, stop: float = 1.0, n_cycle: int = 4, ratio: float = 0.5) -> np.ndarray:
+    """Cyclical KL-annealing schedule, the reference's loop transcribed index for index (1-based `L[Int(round(i + c·period))]`
+    with the strict `< n_iter` guard — so the last entry is never rewritten; Julia's `round` is round-half-even like Python's)
+    [REF src/utils/utils.jl:53-66]."""
+    L = np.ones(n_iter, dtype=np.float64) * stop
+    period = n_iter / n_cycle
+    step = np.float32((stop - start) / (period * ratio))
+    for c in range(n_cycle):
+        v, i = np.float32(start), 1
+        while v <= stop and int(round(i + c * period)) < n_iter:
+            L[int(round(i + c * period)) - 1] = v
+            v = np.float32(v + step)
+            i += 1
+    return L.astype(np.float32)
+
+
+def normalize_to_unit_segment(X):
+    """[REF src/utils/utils.jl:71-77]."""
+    lo, hi = X.min(), X.max()
+    return (X - lo) / (hi - lo), lo, hi
+
+
+def denormalize_unit_segment(Xh, lo, hi):
+    """[REF src/utils/utils.jl:79]."""
+    return Xh * (hi - lo) + lo
+
+
+def rand_time(full_seq_len: int, seq_len: int, rng: Optional[np.random.Generator] = None):
+    """start_time = rand(1:full_seq_len − seq_len); idxs = start:start+seq_len−1 (1-based, inclusive)  [REF utils.jl:95-99].
+    Returned 0-based as a slice. (As in the reference the last possible window is never drawn.)"""
+    rng = rng or np.random.default_rng()
+    start = int(rng.integers(1, full_seq_len - seq_len + 1))      # 1 … full − seq, inclusive
+    return slice(start - 1, start - 1 + seq_len)
+
+
+def time_loader(x, full_seq_len: int, seq_len: int, rng: Optional[np.random.Generator] = None):
+    """One random window of seq_len frames, the same for every sample of the minibatch: x [pixels, B, full] → [pixels, B, seq]
+    [REF src/utils/utils.jl:85-93]."""
+    return x[:, :, rand_time(full_seq_len, seq_len, rng)]
+
+
+def train(model: LatentDiffEqModel, loader_train: Iterable, val_set, dt: float, epochs: int, seq_len: int, full_seq_len: int,
+          lr: float = 1e-3, decay: float = 1e-10, start_beta: float = 0.0, end_beta: float = 1.0, n_cycle: int = 3, ratio: float = 0.9,
+          progressive_training: bool = False, prog_training_duration: int = 0, start_seq_len: int = 0, variational: bool = True,
+          rng: Optional[np.random.Generator] = None, on_epoch: Optional[Callable] = None, grad_sync: Optional[Callable] = None):
+    """The epoch loop of the example script  [REF examples/pendulum_friction-less/model_train.jl:138-218]: cyclical β, optional
+    progressive sequence length, AdamW, validation loss after every minibatch, best weights kept. `loader_train` yields
+    x [pixels, B, full_seq_len] tensors on the model's device; `grad_sync` is called between backward and the optimiser step
+    (dist.FlatGradAllReduce for multi-GPU). Returns (history, best_state)."""
+    params = model.parameters()
+    opt = torch.optim.AdamW(params, lr=lr, betas=(0.9, 0.999), weight_decay=decay)           # ADAMW(η, (0.9, 0.999), decay)
+    schedule = frange_cycle_linear(epochs, start_beta, end_beta, n_cycle, ratio)
+    if progressive_training:
+        prog = np.rint(np.linspace(start_seq_len, seq_len, prog_training_duration)).astype(int)
+    else:
+        prog_training_duration = 0
+    t_val = np.arange(val_set.shape[2]) * dt
+    best, best_state, history = float("inf"), None, []
+    val_loss = 0.0
+    for epoch in range(1, epochs + 1):
+        beta = float(schedule[epoch - 1])
+        sl = int(prog[epoch - 1]) if epoch <= prog_training_duration else seq_len
+        t = np.arange(sl) * dt
+        for x in loader_train:
+            xb = time_loader(x, full_seq_len, sl, rng)
+            opt.zero_grad(set_to_none=True)
+            loss = loss_batch(model, xb, t, beta, variational)
+            loss.backward()
+            if grad_sync is not None:
+                grad_sync()
+            opt.step()
+            with torch.no_grad():
+                val_loss = float(loss_batch(model, val_set, t_val, beta, False))
+            history.append((epoch, float(loss.detach()), val_loss))
+        if on_epoch is not None:
+            on_epoch(epoch, history)
+        if val_loss < best:
+            best = val_loss
+            best_state = [p.detach().clone() for p in params]
+    return history, best_state

@@ -108,3 +108,45 @@ def test_whole_goku_model_trains_on_synthetic_frames():
         losses.append(float(rec.detach()))
     assert np.isfinite(losses).all()
     assert np.mean(losses[-5:]) < 0.7 * np.mean(losses[:5]), (losses[:5], losses[-5:])
+
+
+def _pendulum_frames(B, T, side, seed=1):
+    import torch
+    z0, L = O.pendulum_inputs(B, seed=seed)
+    ts = O.time_grid(T)
+    ztrue, _, _ = O.Oracle("f64").forward(O.make_desc(abstol=1e-9, reltol=1e-9), z0, L, ts)
+    ang = torch.tensor(ztrue[:, :, 0].T.copy(), dtype=torch.float32)
+    gx, gy = torch.meshgrid(torch.linspace(-1, 1, side), torch.linspace(-1, 1, side), indexing="ij")
+    bx, by = 0.7 * torch.sin(ang), 0.7 * torch.cos(ang)
+    fr = torch.exp(-(((gx[None, None] - bx[..., None, None]) ** 2 + (gy[None, None] - by[..., None, None]) ** 2) / 0.08))
+    return fr.reshape(B, T, side * side).permute(2, 0, 1).contiguous()          # [pixels, B, T]
+
+
+@pytest.mark.parametrize("kind", ["goku", "latentode"])
+def test_train_harness_runs_both_model_types(kind):
+    """train() — cyclical β, random time windows, AdamW, validation loss after every minibatch, best weights — on the GOKU
+    model and on the LatentODE model (whose NODE weights are trained here, unlike in the reference: SURVEY.md B2)."""
+    import torch
+    import latentdiffeq_amd as M
+    from latentdiffeq_amd import train as TR
+    torch.manual_seed(3)
+    side, full, seq = 6, 24, 12
+    data = _pendulum_frames(40, full, side).to("cuda")
+    train_set, val_set = data[:, :32], data[:, 32:, :seq]
+    if kind == "goku":
+        mt, diffeq = M.GOKU_basic(), M.Pendulum()
+    else:
+        mt, diffeq = M.LatentODE(), M.NODE(4, hidden_dim=32, device="cuda", batching="per_trajectory")
+    enc, dec = TR.default_layers(mt, side * side, diffeq, device="cuda", hidden_dim_resnet=48, latent_to_diffeq_dim=48)
+    if kind == "goku":
+        with torch.no_grad():
+            dec[0][1]._dense[-1].bias.fill_(1.0)
+    model = TR.LatentDiffEqModel(mt, enc, dec)
+    loader = [train_set[:, :16], train_set[:, 16:]]
+    hist, best = TR.train(model, loader, val_set, dt=0.05, epochs=12, seq_len=seq, full_seq_len=full, lr=2e-3, end_beta=1e-3,
+                          n_cycle=2, ratio=0.5, rng=np.random.default_rng(0))
+    losses = np.array([h[1] for h in hist])
+    assert len(hist) == 24 and np.isfinite(losses).all() and best is not None and len(best) == len(model.parameters())
+    assert losses[-4:].mean() < 0.8 * losses[:4].mean(), (losses[:4], losses[-4:])
+    if kind == "latentode":
+        assert any(p.grad is not None and float(p.grad.abs().max()) > 0 for p in diffeq.dudt.parameters())

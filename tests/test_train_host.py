@@ -1,0 +1,61 @@
+"""CPU: the host-side training harness (scope row f-3) against values worked out by hand from the reference's code
+[REF src/utils/utils.jl], [REF examples/pendulum_friction-less/model_train.jl:225-238]."""
+import numpy as np
+import torch
+
+from latentdiffeq_amd import train as TR
+
+
+def julia_frange(n_iter, start, stop, n_cycle, ratio):
+    """The reference loop with 1-based indices, written independently of train.py (dict as a 1-based array)."""
+    L = {i: stop for i in range(1, n_iter + 1)}
+    period = n_iter / n_cycle
+    step = np.float32((stop - start) / (period * ratio))
+    for c in range(0, n_cycle):
+        v, i = np.float32(start), 1
+        while (v <= stop) and (int(round(i + c * period)) < n_iter):
+            L[int(round(i + c * period))] = v
+            v = np.float32(v + step)
+            i += 1
+    return np.array([L[i] for i in range(1, n_iter + 1)], dtype=np.float32)
+
+
+def test_frange_cycle_linear_matches_the_reference_loop():
+    for args in [(900, 0.0, 1.0, 3, 0.9), (10, 0.0, 1.0, 4, 0.5), (37, 0.0, 0.5, 5, 0.3), (8, 0.0, 1.0, 3, 0.9)]:
+        got = TR.frange_cycle_linear(*args)
+        assert got.dtype == np.float32 and np.array_equal(got, julia_frange(*args)), args
+    s = TR.frange_cycle_linear(12, 0.0, 1.0, 3, 0.5)          # period 4, ramp over 2 steps: 0, .5, 1, 1 | 0, .5, 1, 1 | 0, .5, 1, 1
+    assert np.allclose(s, [0, .5, 1, 1, 0, .5, 1, 1, 0, .5, 1, 1])
+
+
+def test_kl_and_loss_follow_the_reference_definitions():
+    mu = torch.tensor([[0.5, -1.0], [0.0, 2.0]])
+    ls = torch.tensor([[0.0, 0.3], [-0.2, 0.1]])
+    e = (np.exp(ls.numpy()) + mu.numpy() ** 2 - ls.numpy() - 1) / 2
+    assert np.allclose(TR.kl(mu, ls).numpy(), e)
+    assert np.isclose(float(TR.vector_kl(mu, ls)), e.sum() / 2)                       # divided by the batch size (columns)
+    assert np.isclose(float(TR.vector_kl((mu, mu), (ls, ls))), 2 * e.sum() / 2)
+
+    class M:   # a stand-in model: x̂ = 0.5·x
+        def __call__(self, x, t, variational):
+            return (0.5 * x, None, None), mu, ls
+    x = torch.arange(24, dtype=torch.float32).reshape(3, 2, 4)                        # [pixels, B, T]
+    want = ((0.5 * x.numpy()) ** 2).mean(axis=(1, 2)).sum() + 0.25 * e.sum() / 2      # sum(mean(·, dims=(2,3))) + β·kl
+    assert np.isclose(float(TR.loss_batch(M(), x, None, 0.25, False)), want)
+
+
+def test_time_loader_and_normalisation():
+    x = torch.arange(2 * 3 * 10, dtype=torch.float32).reshape(2, 3, 10)
+    starts = set()
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        w = TR.time_loader(x, 10, 4, rng)
+        assert w.shape == (2, 3, 4)
+        s0 = int(w[0, 0, 0])
+        assert torch.equal(w, x[:, :, s0:s0 + 4])
+        starts.add(s0)
+    assert starts == set(range(0, 6))          # rand(1:full−seq) ⇒ 0-based starts 0..5; the last window (6) is never drawn
+    X = np.array([[2.0, 4.0], [6.0, 10.0]])
+    Xh, lo, hi = TR.normalize_to_unit_segment(X)
+    assert (lo, hi) == (2.0, 10.0) and Xh.min() == 0 and Xh.max() == 1
+    assert np.allclose(TR.denormalize_unit_segment(Xh, lo, hi), X)

@@ -1,0 +1,65 @@
+"""Synthetic pendulum videos (scope row f-4): the data the reference's example trains on.
+
+    reference                                                                      here
+    -----------------------------------------------------------------------------  -------------------------------
+    generate_dataset(; diffeq = Pendulum(), tspan, dt, u₀_range, p₀_range, n_traj, seed, high_dim_args)
+                                   [REF examples/pendulum_friction-less/create_data.jl:13-57]   generate_dataset
+    maketrajectories / frame / create_frames (Luxor)   [REF create_data.jl:66-117]               create_frames
+
+The latent trajectories are solved by lde_forward (the product's own solver, on the GPU). The frames are an
+approximation of the Luxor drawing, not a pixel copy: Cairo's anti-aliasing and the "|" text glyph of `drawrod`
+[REF create_data.jl:84-87] cannot be reproduced without Cairo, so a frame here is the supersampled coverage of the same
+geometry — bob disc and pivot disc of radius 1.75, a rod 3.75 thick between them, the pivot's black inner disc — on the
+same 28×28 canvas (origin at the centre, y down, pivot at (0, −8.5), pendulum length 19 px). Julia's `Random.seed!`
+stream is not reproducible either: numpy's `default_rng(seed)` draws the initial states and lengths.
+"""
+from __future__ import annotations
+
+import math
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+
+def create_frames(theta: torch.Tensor, pendulumlength: float = 19.0, radius: float = 1.75, rodthickness: float = 3.75,
+                  w: int = 28, h: int = 28, ss: int = 4) -> torch.Tensor:
+    """theta [...]: pendulum angles → frames [..., h, w] in [0, 1] (supersampled ss×ss coverage)."""
+    dev = theta.device
+    sub = (torch.arange(ss, device=dev, dtype=torch.float32) + 0.5) / ss
+    xs = (torch.arange(w, device=dev, dtype=torch.float32)[:, None] + sub[None, :]).reshape(-1) - w / 2      # [w·ss]
+    ys = (torch.arange(h, device=dev, dtype=torch.float32)[:, None] + sub[None, :]).reshape(-1) - h / 2      # [h·ss]
+    Y, X = torch.meshgrid(ys, xs, indexing="ij")                                                                # [h·ss, w·ss]
+    ox, oy = 0.0, -8.5                                                                                          # offset = Point(0, −8.5)
+    th = theta.to(torch.float32)[..., None, None]
+    px = ox + pendulumlength * torch.cos(math.pi / 2 + th)                                                      # angle1 = π/2 + θ
+    py = oy + pendulumlength * torch.sin(math.pi / 2 + th)
+    bob = ((X - px) ** 2 + (Y - py) ** 2) <= radius ** 2
+    piv = ((X - ox) ** 2 + (Y - oy) ** 2) <= radius ** 2
+    dx, dy = px - ox, py - oy
+    tt = (((X - ox) * dx + (Y - oy) * dy) / (dx * dx + dy * dy)).clamp(0, 1)
+    rod = ((X - (ox + tt * dx)) ** 2 + (Y - (oy + tt * dy)) ** 2) <= (rodthickness / 2) ** 2
+    inner = ((X - ox) ** 2 + (Y - oy) ** 2) <= (radius / 2) ** 2
+    img = ((bob | piv | rod) & ~inner).to(torch.float32)
+    lead = img.shape[:-2]
+    return img.reshape(*lead, h, ss, w, ss).mean(dim=(-3, -1))
+
+
+def generate_dataset(diffeq=None, tspan: Tuple[float, float] = (0.0, 4.95), dt: float = 0.05,
+                     u0_range=((-math.pi / 6, math.pi / 6), (-math.pi / 3, math.pi / 3)), p0_range: Tuple[float, float] = (1.0, 2.0),
+                     n_traj: int = 450, seed: int = 1, high_dim_args=(19.0, 1.75, 3.75), device: Optional[str] = None):
+    """(latent_data [2, T, n], u0s [2, n], ps [1, n], high_dim_data [28, 28, T, n])  [REF create_data.jl:31-57]."""
+    from .api import Decoder, GOKU_basic, Pendulum, diffeq_layer
+    device = device or "cuda"
+    diffeq = diffeq or Pendulum(abstol=1e-8, reltol=1e-8)
+    rng = np.random.default_rng(seed)
+    ps = rng.uniform(p0_range[0], p0_range[1], (1, n_traj)).astype(np.float32)
+    u0s = np.stack([rng.uniform(lo, hi, n_traj) for lo, hi in u0_range]).astype(np.float32)
+    T = int(round((tspan[1] - tspan[0]) / dt)) + 1
+    ts = tspan[0] + dt * np.arange(T)
+    dec = Decoder(GOKU_basic(), (None, diffeq, None))
+    with torch.no_grad():
+        z = diffeq_layer(dec, (torch.from_numpy(u0s).to(device), torch.from_numpy(ps).to(device)), ts)      # [2, n, T]
+    latent = z.permute(0, 2, 1).contiguous()                                                                    # [2, T, n]
+    frames = create_frames(latent[0].t(), *high_dim_args)                                                        # [n, T, 28, 28]
+    return latent, torch.from_numpy(u0s).to(device), torch.from_numpy(ps).to(device), frames.permute(2, 3, 1, 0).contiguous()

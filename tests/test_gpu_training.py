@@ -150,3 +150,17 @@ def test_train_harness_runs_both_model_types(kind):
     assert losses[-4:].mean() < 0.8 * losses[:4].mean(), (losses[:4], losses[-4:])
     if kind == "latentode":
         assert any(p.grad is not None and float(p.grad.abs().max()) > 0 for p in diffeq.dudt.parameters())
+
+
+def test_generate_dataset_matches_the_float64_pendulum():
+    """generate_dataset: latent trajectories from lde_forward (tight tolerance) against the float64 oracle; frames rendered from them."""
+    import torch
+    from latentdiffeq_amd.data import create_frames, generate_dataset
+    latent, u0s, ps, frames = generate_dataset(n_traj=12, seed=4)
+    T = 100
+    assert latent.shape == (2, T, 12) and u0s.shape == (2, 12) and ps.shape == (1, 12) and frames.shape == (28, 28, T, 12)
+    z64, _, _ = O.Oracle("f64").forward(O.make_desc(abstol=1e-11, reltol=1e-11), u0s.cpu().numpy().T, ps.cpu().numpy().T, 0.05 * np.arange(T))
+    assert np.abs(latent.cpu().numpy().transpose(1, 2, 0) - z64).max() <= 2e-5
+    assert float(frames.min()) >= 0 and float(frames.max()) <= 1
+    again = create_frames(latent[0, 7, :3])
+    assert torch.allclose(again, frames[:, :, 7, :3].permute(2, 0, 1))

@@ -59,3 +59,25 @@ def test_time_loader_and_normalisation():
     Xh, lo, hi = TR.normalize_to_unit_segment(X)
     assert (lo, hi) == (2.0, 10.0) and Xh.min() == 0 and Xh.max() == 1
     assert np.allclose(TR.denormalize_unit_segment(Xh, lo, hi), X)
+
+
+def test_pendulum_frames_geometry():
+    """create_frames: the reference drawing's geometry [REF examples/pendulum_friction-less/create_data.jl:90-111] on a 28×28
+    canvas — pivot disc at (0, −8.5) with a dark centre, bob 19 px away along π/2 + θ (y down), a 3.75-thick rod between."""
+    from latentdiffeq_amd.data import create_frames
+    f = create_frames(torch.tensor([0.0, 0.5, -0.5]))
+    assert f.shape == (3, 28, 28) and float(f.min()) >= 0 and float(f.max()) <= 1
+    f0 = f[0]
+    sub = 2.0 / 16                                                         # two of the 16 sub-samples of a pixel (cos(π/2) is −4e-8 in f32)
+    assert float((f0 - f0.flip(1)).abs().max()) <= sub                     # θ = 0: mirror-symmetric in x
+    assert float((f[1] - f[2].flip(1)).abs().max()) <= sub                 # ±θ are mirror images
+    # bob centre at y = −8.5 + 19 = 10.5 → rows 24/25, columns 13/14 fully lit; pivot centre (row 5, cols 13/14) dark
+    assert float(f0[24, 13]) == 1 and float(f0[24, 14]) == 1 and float(f0[5:6, 13:15].mean()) < 0.5
+    assert float(f0[15, 13]) == 1                                          # the rod runs down the middle
+    assert float(f0[15, 5]) == 0 and float(f0[2, 2]) == 0                  # background
+    # lit area ≈ rod (19 × 3.75) + two half discs at its ends + the parts of the discs outside the rod − inner disc
+    area = float(f0.sum())
+    assert 70 < area < 90
+    # θ = 0.5: the bob moves to x = −19·sin(0.5) ≈ −9.1 → column ≈ 4–5, y = −8.5 + 19·cos(0.5) ≈ 8.2 → row ≈ 22
+    r, c = np.unravel_index(int(f[1][18:].argmax()), f[1][18:].shape)
+    assert abs((c + 0.5 - 14) - (-19 * np.sin(0.5))) < 2.5

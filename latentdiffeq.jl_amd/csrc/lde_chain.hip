@@ -35,6 +35,7 @@ struct ChainDims {
   int act[MAXL];
   int skip[MAXL];
   int ld0;             // stride of the input panel (≥ pad32(in)); 0 when the first layer reads x straight from HBM (gx)
+  int f_off[MAXL];     // skip layers: offset (in a staged block) of the extra panel holding act(W·x+b) BEFORE the skip addition
   int gx;              // wide input (in % 16 == 0): x[in×N] itself is the B operand of layer 0 — no input panel, wider tiles
   int ldh;             // stride of hidden / gradient panels
 };
@@ -211,18 +212,24 @@ __device__ __forceinline__ long long chain_tile_start(const ChainDims& cd, int N
 }
 
 // one hidden (non-last) layer: Y = [Xin +] act(W·Xin + b) into an LDS panel
+// fstage (pullback only, skip layers only): the activation before the skip addition goes to the staged block as well —
+// the derivative is taken from it. (Recovering it as h − x loses it when it is tiny next to x: relu′ flips from 1 to 0 for
+// about one unit in 10⁷, which a test with 3·10⁵ columns caught as a 3 % error in one column's gradient.)
 template <int CG, bool BG = false>
 __device__ __forceinline__ void chain_hidden_layer(const ChainDims& cd, int l, const float* frag, const float* biasc,
-                                                   const float* Xin, int ldx, float* Y) {
+                                                   const float* Xin, int ldx, float* Y, float* fstage = nullptr) {
   const MlpDims& dm = cd.dm;
   const int in = dm.sizes[l], out = dm.sizes[l + 1], actk = cd.act[l], skip = BG ? 0 : cd.skip[l], ldh = cd.ldh;
   const float* bias = biasc + dm.bias_lin[l];
+  const int out32 = pad32(out);
   chain_gemm<CG, BG>(frag + dm.frag_off[l], out, in, Xin, ldx, 16 * ldx, [](int, int, int) { return NoPre{}; },
                         [&](int row0, int cg, int col, f32x4 v, NoPre) {
                           const int c = cg * 16 + col;
                           f32x4 r;
 #pragma unroll
                           for (int q = 0; q < 4; q++) r[q] = row0 + q < out ? cact(actk, v[q] + bias[row0 + q]) : 0.f;
+                          if (skip && fstage && row0 < out32)
+                            *reinterpret_cast<f32x4*>(fstage + (size_t)cg * dm.blk_floats + col * out32 + row0) = r;
                           if (skip) r += *reinterpret_cast<const f32x4*>(Xin + c * ldx + row0);   // in == out; pad rows are 0
                           *reinterpret_cast<f32x4*>(Y + c * ldh + row0) = r;
                         });
@@ -342,7 +349,7 @@ __global__ void __launch_bounds__(512) k_chain_backward(ChainDims cd, ChainBwdAr
     for (int l = 0; l + 1 < nL; l++) {
       float* Y = (l & 1) ? P1 : P0;
       if (l == 0 && cd.gx) chain_hidden_layer<CG, true>(cd, 0, a.frag, biasc, xg, dm.sizes[0], Y);
-      else chain_hidden_layer<CG>(cd, l, a.frag, biasc, Xin, ldx, Y);
+      else chain_hidden_layer<CG>(cd, l, a.frag, biasc, Xin, ldx, Y, cd.skip[l] ? blk0 + cd.f_off[l] : nullptr);
       __syncthreads();
 #pragma unroll
       for (int cg = 0; cg < CG; cg++)
@@ -395,13 +402,13 @@ __global__ void __launch_bounds__(512) k_chain_backward(ChainDims cd, ChainBwdAr
       float* Dn = (l & 1) ? P1 : P0;
       const int actp = cd.act[l - 1], skp = cd.skip[l - 1];
       const int in32 = pad32(in), inp32 = pad32(dm.sizes[l - 1]);
-      const float* hblk = blk0 + dm.blk_off[l];        // a_l = output of layer l-1
-      const float* ablk = blk0 + dm.blk_off[l - 1];    // a_{l-1} (its input), needed when layer l-1 is a skip layer
+      // activation output of layer l-1: its staged output a_l, or — for a skip layer — the extra panel written before the
+      // skip addition (rows padded to 32 like every staged panel; in == out for a skip layer, so the strides agree)
+      const float* hblk = skp ? blk0 + cd.f_off[l - 1] : blk0 + dm.blk_off[l];
       auto pre = [&](int row0, int cg, int col) {
         PrePair p;
         p.h = *reinterpret_cast<const f32x4*>(hblk + (size_t)cg * dm.blk_floats + col * in32 + row0);
-        p.a = skp ? *reinterpret_cast<const f32x4*>(ablk + (size_t)cg * dm.blk_floats + col * inp32 + row0)
-                  : f32x4{0.f, 0.f, 0.f, 0.f};
+        p.a = f32x4{0.f, 0.f, 0.f, 0.f};
         return p;
       };
       auto epi = [&](int row0, int cg, int col, f32x4 v, PrePair p) {
@@ -536,6 +543,13 @@ int lde_chain_create(const lde_chain_desc* d, lde_chain** out) {
   }
   fill_layer_offsets(dm, &c->nfrag, &c->nfragT);
   c->nW = dm.nW;
+  for (int l = 0; l < d->n_layers; l++) {   // extra staged panel per skip layer (after the (a, δ) panels k_mlp_dw reads)
+    cd.f_off[l] = 0;
+    if (cd.skip[l]) {
+      cd.f_off[l] = dm.blk_floats;
+      dm.blk_floats += NB * pad32(dm.sizes[l + 1]);
+    }
+  }
   cd.ld0 = panel_stride(pad32(dm.sizes[0]));
   cd.ldh = panel_stride(pad32(hmax));
   *out = c;   // from here on errors carry a message

@@ -176,3 +176,25 @@ def test_torch_decoder_path_end_to_end(o64):
                            (th_t.grad.cpu().numpy().T, dtht, "dθ̃")):
         s = np.abs(ref).max()
         assert s > 0 and np.abs(got - ref).max() <= 2e-4 * s, what
+
+
+def test_chain_large_column_count(o32):
+    """N = 300 001 columns (ragged, many tiles per CU, > 16 slots per virtual tile of the weight gradient): forward and
+    gradients against the oracle."""
+    from tests.gpu_util import NativeChain
+    sizes, acts, skips = (8, 32, 32, 8), (O.CACT_TANH, O.CACT_RELU, O.CACT_IDENTITY), (0, 1, 0)
+    N = 300_001
+    d = O.make_chain_desc(sizes, acts, skips)
+    W = O.mlp_weights(sizes, seed=2)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((N, 8)).astype(np.float32)
+    dy = (rng.standard_normal((N, 8)) / N).astype(np.float32)
+    nat = NativeChain(sizes, acts, skips)
+    nat.set_weights(W)
+    y = nat.forward(x)
+    yr = o32.chain_forward(d, W, x)
+    assert np.abs(y - yr).max() <= 2e-5 * max(1.0, np.abs(yr).max())
+    dx, dW = nat.backward(x, y, dy)
+    rx, rW = o32.chain_backward(d, W, x, dy)
+    assert np.abs(dx - rx).max() <= 1e-4 * np.abs(rx).max()
+    assert np.abs(dW - rW).max() <= 2e-4 * np.abs(rW).max()      # 3e5 terms per entry: f32 summation order

@@ -126,3 +126,8 @@ def test_torch_encoder_path_end_to_end(o64):
         assert np.abs(gW - dWr).max() <= 2e-4 * np.abs(dWr).max(), "recurrent dW"
     _, dWfe = o64.chain_backward(dfe, Wfe, xb, dfo.reshape(T * B, -1), need_dx=False)
     assert np.abs(flat_grad(fe) - dWfe).max() <= 2e-4 * np.abs(dWfe).max(), "feature extractor dW"
+
+
+def test_rnn_large_batch(o32, o64):
+    """B = 5 003 trajectories (313 workgroups, ragged last one), T = 30."""
+    _run(O.CELL_LSTM, (32, 16, 16), True, 30, 5003, o32, o64, seed=8)

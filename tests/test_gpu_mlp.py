@@ -477,3 +477,25 @@ def test_mlp_tsit5_with_fixed_step(o32, batching):
     g0, _, gW, _ = nat.adjoint(z, None, ts, dz)
     r0, _, rW, _ = o32.adjoint(od, z, None, ts, dz, W=W)
     assert np.abs(g0 - r0).max() <= 2e-4 * np.abs(r0).max() and np.abs(gW - rW).max() <= 2e-4 * np.abs(rW).max()
+
+
+@pytest.mark.parametrize("layers,B", [((4, 48, 48, 4), 3001), ((8, 96, 96, 8), 1003)])
+def test_mlp_adjoint_large_batches(o32, o64, layers, B):
+    """Many tiles per CU, ragged last tile, both adjoint kernels (≤ 64 wide: four columns per wave; wider: 16-column
+    workgroups), per-trajectory control at 1e-6: gradients against the float64 adjoint."""
+    D = layers[0]
+    W = O.mlp_weights(layers, seed=9)
+    kw = dict(rhs_kind=O.RHS_MLP, state_dim=D, param_dim=0, layers=layers, activation=O.ACT_TANH, abstol=1e-6, reltol=1e-6)
+    nat, od = _native(W, **kw)
+    T = 8
+    z0, ts = _z0(B, D, seed=6), O.time_grid(T)
+    dz = O.cotangent(T, B, D)
+    z, ret, _ = nat.forward(z0, None, ts)
+    g0, _, gW, st = nat.adjoint(z, None, ts, dz)
+    assert (ret == 0).all() and st["nfailed"] == 0
+    d64 = O.make_desc(**{**kw, "abstol": 1e-11, "reltol": 1e-11})
+    z64, _, _ = o64.forward(d64, z0, None, ts, W=W.astype(np.float64))
+    t0, _, tW, _ = o64.adjoint(d64, z64, None, ts, dz, W=W.astype(np.float64))
+    assert np.abs(z - z64).max() <= 2e-5 * max(1, np.abs(z64).max())
+    assert np.abs(g0 - t0).max() <= 2e-4 * np.abs(t0).max()
+    assert np.abs(gW - tW).max() <= 2e-4 * np.abs(tW).max()

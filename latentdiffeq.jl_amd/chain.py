@@ -29,25 +29,44 @@ _ACT = {"identity": L.CACT_IDENTITY, "relu": L.CACT_RELU, "tanh": L.CACT_TANH, "
         "softplus": L.CACT_SOFTPLUS}
 
 
-class Dense(torch.nn.Module):
+class Dense:
     """Dense(in, out, act): y = act.(W*x .+ b). Default init = Flux.kaiming_uniform(gain = 1/√3) ⇒ U(±1/√fan_in),
-    zero bias  [REF src/models/GOKU.jl:204]."""
+    zero bias  [REF src/models/GOKU.jl:204]. Inside a `Chain` the layer's weights live in the chain's single flat parameter
+    `theta` (Flux.destructure order): `weight` [out, in] and `bias` [out] are views of it."""
 
     def __init__(self, n_in: int, n_out: int, act: str = "identity"):
-        super().__init__()
         if act not in _ACT:
             raise ValueError(f"unknown activation {act!r}")
         self.n_in, self.n_out, self.act = n_in, n_out, act
         bound = 1.0 / math.sqrt(n_in)
-        self.weight = torch.nn.Parameter(torch.empty(n_out, n_in).uniform_(-bound, bound))
-        self.bias = torch.nn.Parameter(torch.zeros(n_out))
+        self._w0 = torch.empty(n_out, n_in).uniform_(-bound, bound)
+        self._b0 = torch.zeros(n_out)
+        self._owner, self._off = None, 0
+
+    @property
+    def weight(self) -> torch.Tensor:
+        if self._owner is None:
+            return self._w0
+        n = self.n_in * self.n_out
+        return self._owner.theta[self._off:self._off + n].view(self.n_in, self.n_out).t()     # vec(W) column-major [out×in]
+
+    @property
+    def bias(self) -> torch.Tensor:
+        if self._owner is None:
+            return self._b0
+        o = self._off + self.n_in * self.n_out
+        return self._owner.theta[o:o + self.n_out]
+
+    def grads(self):
+        """(∂L/∂W [out, in], ∂L/∂b [out]) as views of the owner's theta.grad."""
+        g, n = self._owner.theta.grad, self.n_in * self.n_out
+        return g[self._off:self._off + n].view(self.n_in, self.n_out).t(), g[self._off + n:self._off + n + self.n_out]
 
 
-class SkipConnection(torch.nn.Module):
+class SkipConnection:
     """SkipConnection(layer, +): y = layer(x) + x  [REF src/models/GOKU.jl:262-263]."""
 
     def __init__(self, layer: Dense):
-        super().__init__()
         if layer.n_in != layer.n_out:
             raise ValueError("SkipConnection(+) needs in == out")
         self.layer = layer
@@ -96,7 +115,7 @@ class Chain(torch.nn.Module):
 
     def __init__(self, *layers):
         super().__init__()
-        self.layers = torch.nn.ModuleList(layers)
+        self.layers = list(layers)
         dense = [l.layer if isinstance(l, SkipConnection) else l for l in layers]
         if not dense or not all(isinstance(d, Dense) for d in dense):
             raise TypeError("Chain takes Dense and SkipConnection(Dense) layers")
@@ -108,6 +127,16 @@ class Chain(torch.nn.Module):
         self.acts = [_ACT[d.act] for d in dense]
         self.skips = [int(isinstance(l, SkipConnection)) for l in layers]
         self.num_weights = sum(d.n_in * d.n_out + d.n_out for d in dense)
+        # ONE flat parameter in Flux.destructure order (per Dense vec(W) column-major [out×in], then b): it is what
+        # lde_chain_* consumes and what the gradient comes back as — no per-step gathering or scattering of pieces
+        parts, off = [], 0
+        for d in dense:
+            parts += [d.weight.detach().t().reshape(-1), d.bias.detach()]
+            d._off = off
+            off += d.n_in * d.n_out + d.n_out
+        self.theta = torch.nn.Parameter(torch.cat(parts).float())
+        for d in dense:
+            d._owner, d._w0, d._b0 = self, None, None
         self._handle = None
         self._lib = None
 
@@ -140,12 +169,8 @@ class Chain(torch.nn.Module):
             pass
 
     def flat_weights(self) -> torch.Tensor:
-        """Flux.destructure order: per Dense vec(W) column-major [out×in], then b."""
-        parts = []
-        for d in self._dense:
-            parts.append(d.weight.t().reshape(-1))
-            parts.append(d.bias)
-        return torch.cat(parts).float()
+        """Flux.destructure order: per Dense vec(W) column-major [out×in], then b — the parameter itself."""
+        return self.theta
 
     def apply_batch_major(self, x_N_in: torch.Tensor) -> torch.Tensor:
         """x (N, in) contiguous → y (N, out). Differentiable wrt x and the layers' parameters."""

@@ -27,17 +27,38 @@ from .api import GOKU, LatentODE
 from .chain import Chain, Dense, SkipConnection
 
 
-class _Cell(torch.nn.Module):
+class _Cell:
     G, S, code = 1, 1, L.CELL_RNN_RELU
 
     def __init__(self, n_in: int, n_out: int):
-        super().__init__()
         self.n_in, self.n_out = n_in, n_out
         bi, bh = 1.0 / math.sqrt(n_in), 1.0 / math.sqrt(n_out)       # kaiming_uniform(gain = 1/√3) ⇒ U(±1/√fan_in)  [REF GOKU.jl:204]
-        self.Wi = torch.nn.Parameter(torch.empty(self.G * n_out, n_in).uniform_(-bi, bi))
-        self.Wh = torch.nn.Parameter(torch.empty(self.G * n_out, n_out).uniform_(-bh, bh))
-        self.b = torch.nn.Parameter(torch.zeros(self.G * n_out))
-        self.state0 = torch.nn.Parameter(torch.zeros(self.S * n_out))   # trainable initial state (Flux 0.13)
+        self._init = [torch.empty(self.G * n_out, n_in).uniform_(-bi, bi), torch.empty(self.G * n_out, n_out).uniform_(-bh, bh),
+                      torch.zeros(self.G * n_out), torch.zeros(self.S * n_out)]   # Wi, Wh, b, state0 (trainable in Flux 0.13)
+        self._owner, self._off = None, 0
+
+    def _piece(self, src, i):
+        R, n_in, h = self.G * self.n_out, self.n_in, self.n_out
+        sizes = [R * n_in, R * h, R, self.S * h]
+        o = self._off + sum(sizes[:i])
+        v = src[o:o + sizes[i]]
+        return v.view(n_in, R).t() if i == 0 else v.view(h, R).t() if i == 1 else v
+
+    def _get(self, i):
+        return self._init[i] if self._owner is None else self._piece(self._owner.theta, i)
+
+    Wi = property(lambda self: self._get(0))
+    Wh = property(lambda self: self._get(1))
+    b = property(lambda self: self._get(2))
+    state0 = property(lambda self: self._get(3))
+
+    def grads(self):
+        """(∂Wi, ∂Wh, ∂b, ∂state0) as views of the owner's theta.grad."""
+        return tuple(self._piece(self._owner.theta.grad, i) for i in range(4))
+
+    def num_weights(self):
+        R = self.G * self.n_out
+        return R * self.n_in + R * self.n_out + R + self.S * self.n_out
 
     def flat(self):
         return torch.cat([self.Wi.t().reshape(-1), self.Wh.t().reshape(-1), self.b, self.state0])
@@ -60,8 +81,7 @@ class LSTM(_Cell):
 
     def __init__(self, n_in: int, n_out: int):
         super().__init__(n_in, n_out)
-        with torch.no_grad():
-            self.b[n_out:2 * n_out] = 1.0
+        self._init[2][n_out:2 * n_out] = 1.0
 
 
 class _RecurrentFn(torch.autograd.Function):
@@ -111,11 +131,21 @@ class Recurrent(torch.nn.Module):
         for a, b in zip(cells[:-1], cells[1:]):
             if a.n_out != b.n_in:
                 raise ValueError("cell sizes do not chain")
-        self.cells = torch.nn.ModuleList(cells)
+        self.cells = list(cells)
         self.reverse = bool(reverse)
         self.sizes = [cells[0].n_in] + [c.n_out for c in cells]
         self.code = cells[0].code
-        self.num_weights = sum(c.flat().numel() for c in cells)
+        self.num_weights = sum(c.num_weights() for c in cells)
+        # ONE flat parameter in Flux.destructure order (per cell vec(Wi), vec(Wh), b, state0): what lde_rnn_* consumes
+        off = 0
+        parts = []
+        for c in cells:
+            parts.append(c.flat().detach())
+            c._off = off
+            off += c.num_weights()
+        self.theta = torch.nn.Parameter(torch.cat(parts).float())
+        for c in cells:
+            c._owner, c._init = self, None
         self._handle, self._lib = None, None
 
     def _native(self):
@@ -144,7 +174,7 @@ class Recurrent(torch.nn.Module):
             pass
 
     def flat_weights(self) -> torch.Tensor:
-        return torch.cat([c.flat() for c in self.cells]).float()
+        return self.theta
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         """x [in, B, T] → [h_last, B]."""

@@ -169,7 +169,7 @@ def test_torch_decoder_path_end_to_end(o64):
     dtht, dWt = o64.chain_backward(dt, Wt, tht, gth)
 
     def flat_grad(ch):
-        return torch.cat([torch.cat([d.weight.grad.t().reshape(-1), d.bias.grad]) for d in ch._dense]).cpu().numpy()
+        return ch.theta.grad.cpu().numpy()
 
     for got, ref, what in ((flat_grad(rec), dWr, "reconstructor dW"), (flat_grad(lo_z0), dWz, "lo_z0 dW"),
                            (flat_grad(lo_th), dWt, "lo_theta dW"), (z0_t.grad.cpu().numpy().T, dz0t, "dz̃0"),

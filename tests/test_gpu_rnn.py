@@ -107,7 +107,7 @@ def test_torch_encoder_path_end_to_end(o64):
     ins = [pe_z, pe_z, pe_t, pe_t]
     cts = [f64(cz).T, f64(dz_).T, f64(ct).T, f64(dt_).T]
     d_pe_z, d_pe_t = np.zeros_like(pe_z), np.zeros_like(pe_t)
-    flat_grad = lambda ch: torch.cat([torch.cat([d.weight.grad.t().reshape(-1), d.bias.grad]) for d in ch._dense]).cpu().numpy()
+    flat_grad = lambda ch: ch.theta.grad.cpu().numpy()
     for i, ((dd, Wl), xin, c_) in enumerate(zip(lis, ins, cts)):
         ref = o64.chain_forward(dd, Wl, xin)
         assert np.abs(got[i] - ref).max() <= 2e-5, f"latent_in {i}"
@@ -122,7 +122,7 @@ def test_torch_encoder_path_end_to_end(o64):
     for r, (dr, Wr), dy in zip(pe, recs, dys):
         dxr, dWr = o64.rnn_backward(dr, Wr, fo3, dy)
         dfo += dxr
-        gW = torch.cat([torch.cat([c.Wi.grad.t().reshape(-1), c.Wh.grad.t().reshape(-1), c.b.grad, c.state0.grad]) for c in r.cells]).cpu().numpy()
+        gW = r.theta.grad.cpu().numpy()
         assert np.abs(gW - dWr).max() <= 2e-4 * np.abs(dWr).max(), "recurrent dW"
     _, dWfe = o64.chain_backward(dfe, Wfe, xb, dfo.reshape(T * B, -1), need_dx=False)
     assert np.abs(flat_grad(fe) - dWfe).max() <= 2e-4 * np.abs(dWfe).max(), "feature extractor dW"

@@ -344,7 +344,7 @@ def run_goku_step(args, torch, dist, world, rank, local):
     B = args.batch or 256
     T, NI = 50, 784
     dev = torch.device("cuda", local)
-    torch.manual_seed(100 + rank)
+    torch.manual_seed(100)                  # the same initial weights on every rank (data parallel); the data differs per rank
     mt = M.GOKU_basic()
     diffeq = M.Pendulum()
     enc = Encoder(mt, default_encoder_layers(mt, NI, device=dev))
@@ -356,7 +356,8 @@ def run_goku_step(args, torch, dist, world, rank, local):
     params = [p for m in mods for p in m.parameters()]
     opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=1e-10)            # [REF model_train.jl:138, :150]
     sync = FlatGradAllReduce(params)
-    x = torch.rand(NI, B, T, device=dev)                                    # synthetic frames in [0, 1]
+    torch.manual_seed(1000 + rank)
+    x = torch.rand(NI, B, T, device=dev)                                    # synthetic frames in [0, 1], this rank's shard
     ts = np.arange(T) * 0.05
     Bg = B * world
 

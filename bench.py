@@ -357,7 +357,8 @@ def run_goku_step(args, torch, dist, world, rank, local):
     opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=1e-10)            # [REF model_train.jl:138, :150]
     sync = FlatGradAllReduce(params)
     torch.manual_seed(1000 + rank)
-    x = torch.rand(NI, B, T, device=dev)                                    # synthetic frames in [0, 1], this rank's shard
+    x = torch.rand(T, B, NI, device=dev).permute(2, 1, 0)                   # synthetic frames in [0, 1], this rank's shard: [pixels, B, T] in the
+                                                                            # reference's column-major memory order (pixels fastest), like ẑ
     ts = np.arange(T) * 0.05
     Bg = B * world
 

@@ -607,8 +607,10 @@ int lde_chain_create(const lde_chain_desc* d, lde_chain** out) {
   return LDE_OK;
 }
 
-static int chain_frags(lde_chain* c, hipStream_t stream) {
-  hipLaunchKernelGGL(k_build_frags, dim3(64, c->cd.dm.nL), dim3(256), 0, stream, c->W_dev, c->cd.dm, c->frag, c->fragT);
+static int chain_frags(lde_chain* c, const float* src, hipStream_t stream) {
+  // src == W_dev: fragments only; otherwise the kernel also copies src into W_dev
+  hipLaunchKernelGGL(k_build_frags, dim3(64, c->cd.dm.nL), dim3(256), 0, stream, src, c->cd.dm, c->frag, c->fragT,
+                     src == c->W_dev ? (float*)nullptr : c->W_dev);
   if (hipGetLastError() != hipSuccess) {
     c->err = "k_build_frags launch failed";
     return LDE_ERR_HIP;
@@ -627,7 +629,7 @@ int lde_chain_set_weights(lde_chain* c, const float* flat_host, int64_t n) {
     c->err = "lde_chain_set_weights: hipMemcpy failed";
     return LDE_ERR_HIP;
   }
-  return chain_frags(c, nullptr);
+  return chain_frags(c, c->W_dev, nullptr);
 }
 
 int lde_chain_set_weights_device(lde_chain* c, const float* flat_dev, int64_t n, void* stream) {
@@ -636,11 +638,7 @@ int lde_chain_set_weights_device(lde_chain* c, const float* flat_dev, int64_t n,
     c->err = "lde_chain_set_weights_device: wrong weight count";
     return LDE_ERR_INVALID_ARG;
   }
-  if (hipMemcpyAsync(c->W_dev, flat_dev, (size_t)n * sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream) != hipSuccess) {
-    c->err = "lde_chain_set_weights_device: hipMemcpyAsync failed";
-    return LDE_ERR_HIP;
-  }
-  return chain_frags(c, (hipStream_t)stream);
+  return chain_frags(c, flat_dev, (hipStream_t)stream);
 }
 
 // which layout a call uses: the panel-free one (gx) when the input is wide, x is 16-byte aligned and N fills a tile

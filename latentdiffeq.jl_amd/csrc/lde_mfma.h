@@ -85,10 +85,17 @@ __host__ __device__ inline int panel_stride(int rows) {
 
 // ---- one-time weight re-layout: flat destructure order → MFMA fragment order (W and Wᵀ) ---------------
 // fragment (rt, kg) of a matrix M[R×K]: lane l holds the float4 M[rt*16 + (l&15)][kg*16 + 4*(l>>4) + 0..3] (0 outside).
+// (`keep`, optional: the flat vector is also copied there — the handle's own copy, read for the biases later — which
+//  saves a separate device-to-device copy per lde_*_set_weights_device call: one launch instead of two per training step
+//  and module.)
 static __global__ void k_build_frags(const float* __restrict__ Wflat, MlpDims dm, float* __restrict__ frag,
-                              float* __restrict__ fragT) {
+                              float* __restrict__ fragT, float* __restrict__ keep) {
   const int l = blockIdx.y;
   const int in = dm.sizes[l], out = dm.sizes[l + 1];
+  if (keep) {   // this layer's slice [w_off[l], w_off[l+1]) of the flat vector
+    const int lo = dm.w_off[l], hi = l + 1 < dm.nL ? dm.w_off[l + 1] : dm.nW;
+    for (int e = lo + blockIdx.x * blockDim.x + threadIdx.x; e < hi; e += gridDim.x * blockDim.x) keep[e] = Wflat[e];
+  }
   const float* W = Wflat + dm.w_off[l];  // column-major [out×in]: W(o,i) at o + out*i
   {
     const int KG = cdiv(in, 16), n = dm.frag_n[l];

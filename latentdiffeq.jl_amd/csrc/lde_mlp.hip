@@ -1487,7 +1487,7 @@ int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::strin
 }
 
 int mlp_set_weights(MlpPlan* p, const float* W_dev, hipStream_t stream, std::string& err) {
-  hipLaunchKernelGGL(k_build_frags, dim3(64, p->dm.nL), dim3(256), 0, stream, W_dev, p->dm, p->frag, p->fragT);
+  hipLaunchKernelGGL(k_build_frags, dim3(64, p->dm.nL), dim3(256), 0, stream, W_dev, p->dm, p->frag, p->fragT, (float*)nullptr);
   if (hipGetLastError() != hipSuccess) {
     err = "k_build_frags launch failed";
     return LDE_ERR_HIP;

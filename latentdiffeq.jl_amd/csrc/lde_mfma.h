@@ -176,8 +176,13 @@ inline int dw_pick_ndw(const MlpDims& dm) {
 
 struct DwJob { int l, o0, o1, i0, i1; };
 
+// A layer's IT × OT tile grid is cut into jobs of ≤ cap tiles along its LONGER side, each job spanning the whole shorter
+// side: a job loads (rows of a) + (rows of δ) per slot, and that sum is smallest this way (the encoder's 784 → 200
+// layer: 25 × 7 tiles; 7 jobs of one output tile each would load the 800-row a-panel seven times — 53 KB per job and
+// slot — where jobs of 4 input tiles × 7 output tiles load 22 KB).
 __host__ __device__ inline int dw_layer_jobs(int IT, int OT, int cap) {
-  return IT <= cap ? cdiv(OT, cap / IT) : OT * cdiv(IT, cap);
+  if (IT <= OT || OT > cap) return IT <= cap ? cdiv(OT, cap / IT) : OT * cdiv(IT, cap);
+  return cdiv(IT, cap / OT);
 }
 __host__ __device__ inline int dw_jobs(const MlpDims& dm, int ndw) {
   int n = 0;
@@ -190,13 +195,19 @@ __host__ __device__ inline DwJob dw_decode(const MlpDims& dm, int z, int DW_CAP)
     const int IT = cdiv(dm.sizes[l], 32), OT = cdiv(dm.sizes[l + 1], 32), nj = dw_layer_jobs(IT, OT, DW_CAP);
     if (z < nj) {
       j.l = l;
-      if (IT <= DW_CAP) {
+      if (IT > OT && OT <= DW_CAP) {          // cut along the input tiles
+        const int ci = DW_CAP / OT;
+        j.o0 = 0;
+        j.o1 = OT;
+        j.i0 = z * ci;
+        j.i1 = min(IT, j.i0 + ci);
+      } else if (IT <= DW_CAP) {              // cut along the output tiles
         const int ro = DW_CAP / IT;
         j.o0 = z * ro;
         j.o1 = min(OT, j.o0 + ro);
         j.i0 = 0;
         j.i1 = IT;
-      } else {
+      } else {                                // both sides longer than a job: one output tile × chunks of input tiles
         const int nic = cdiv(IT, DW_CAP);
         j.o0 = z / nic;
         j.o1 = j.o0 + 1;

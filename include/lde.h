@@ -232,6 +232,13 @@ int  lde_chain_forward(lde_chain* c, const float* x, int64_t N, float* y, void* 
 /* Pullback: dx[in×N] (written; may be NULL when the input needs no gradient), dW[n_weights] ACCUMULATED (+=). */
 int  lde_chain_backward(lde_chain* c, const float* x, const float* y, const float* dy, int64_t N,
                         float* dx, float* dW, void* stream);
+/* Training variant: the forward call also writes the hidden activations into a caller-owned buffer `saved`
+ * (lde_chain_saved_floats(c, N) floats, device), and lde_chain_backward_saved reads them instead of recomputing the
+ * hidden layers. Same results as lde_chain_backward; the handle keeps no state between the two calls. */
+int64_t lde_chain_saved_floats(const lde_chain* c, int64_t N);
+int  lde_chain_forward_save(lde_chain* c, const float* x, int64_t N, float* y, float* saved, void* stream);
+int  lde_chain_backward_saved(lde_chain* c, const float* x, const float* y, const float* dy, const float* saved, int64_t N,
+                              float* dx, float* dW, void* stream);
 const char* lde_chain_last_error(const lde_chain* c);
 
 /* ======================================================================================================

@@ -73,7 +73,9 @@ class SkipConnection:
 
 
 class _ChainFn(torch.autograd.Function):
-    """y = chain(x) on batch-major buffers: x (N, in) → y (N, out); backward = lde_chain_backward."""
+    """y = chain(x) on batch-major buffers: x (N, in) → y (N, out); backward = lde_chain_backward[_saved]. When a gradient
+    will be asked for, the forward call keeps the hidden activations in a buffer of its own (lde_chain_forward_save) and the
+    pullback reads them instead of recomputing the hidden layers."""
 
     @staticmethod
     def forward(ctx, chain: "Chain", x: torch.Tensor, W: torch.Tensor):
@@ -87,11 +89,19 @@ class _ChainFn(torch.autograd.Function):
                 "lde_chain_set_weights_device", chain=True)
         N = x.shape[0]
         y = torch.empty((N, chain.sizes[-1]), device=x.device, dtype=torch.float32)
-        L.check(lib.lde_chain_forward(h, C.c_void_p(x.data_ptr()), N, C.c_void_p(y.data_ptr()), stream), h,
-                "lde_chain_forward", chain=True)
+        train = (x.requires_grad or W.requires_grad) and torch.is_grad_enabled()
+        saved = None
+        if train:
+            saved = torch.empty((int(lib.lde_chain_saved_floats(h, N)),), device=x.device, dtype=torch.float32)
+            L.check(lib.lde_chain_forward_save(h, C.c_void_p(x.data_ptr()), N, C.c_void_p(y.data_ptr()),
+                                               C.c_void_p(saved.data_ptr()), stream), h, "lde_chain_forward_save", chain=True)
+        else:
+            L.check(lib.lde_chain_forward(h, C.c_void_p(x.data_ptr()), N, C.c_void_p(y.data_ptr()), stream), h,
+                    "lde_chain_forward", chain=True)
         ctx.chain = chain
         ctx.need_dx = x.requires_grad
-        ctx.save_for_backward(x, y)
+        ctx.has_saved = saved is not None
+        ctx.save_for_backward(x, y, saved if saved is not None else x.new_empty(0))
         return y
 
     @staticmethod
@@ -99,14 +109,19 @@ class _ChainFn(torch.autograd.Function):
         chain = ctx.chain
         h = chain._native()
         lib = chain._lib
-        x, y = ctx.saved_tensors
+        x, y, saved = ctx.saved_tensors
         dy = dy.contiguous().float()
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         dx = torch.empty_like(x) if ctx.need_dx else None
         dW = torch.zeros((chain.num_weights,), device=x.device, dtype=torch.float32)
-        L.check(lib.lde_chain_backward(h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(dy.data_ptr()),
-                                       x.shape[0], C.c_void_p(dx.data_ptr()) if dx is not None else C.c_void_p(),
-                                       C.c_void_p(dW.data_ptr()), stream), h, "lde_chain_backward", chain=True)
+        pdx = C.c_void_p(dx.data_ptr()) if dx is not None else C.c_void_p()
+        if ctx.has_saved:
+            L.check(lib.lde_chain_backward_saved(h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(dy.data_ptr()),
+                                                 C.c_void_p(saved.data_ptr()), x.shape[0], pdx, C.c_void_p(dW.data_ptr()), stream),
+                    h, "lde_chain_backward_saved", chain=True)
+        else:
+            L.check(lib.lde_chain_backward(h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(dy.data_ptr()),
+                                           x.shape[0], pdx, C.c_void_p(dW.data_ptr()), stream), h, "lde_chain_backward", chain=True)
         return None, dx, dW
 
 

@@ -36,6 +36,9 @@ struct ChainDims {
   int skip[MAXL];
   int ld0;             // stride of the input panel (≥ pad32(in)); 0 when the first layer reads x straight from HBM (gx)
   int f_off[MAXL];     // skip layers: offset (in a staged block) of the extra panel holding act(W·x+b) BEFORE the skip addition
+  int sv_pre[MAXL];    // saved-activation buffer: hidden layer l's output [h_l × N] starts at N·sv_pre[l] floats, its pre-skip copy (skip
+                       // layers) right after it
+  int sv_total;        // floats per column of that buffer
   int gx;              // wide input (in % 16 == 0): x[in×N] itself is the B operand of layer 0 — no input panel, wider tiles
   int ldh;             // stride of hidden / gradient panels
 };
@@ -178,6 +181,7 @@ struct ChainFwdArgs {
   const float* frag;
   const float* Wflat;
   long long N;
+  float* saved;        // training: hidden activations go here as well (lde_chain_forward_save)
 };
 
 template <int CG>
@@ -215,9 +219,12 @@ __device__ __forceinline__ long long chain_tile_start(const ChainDims& cd, int N
 // fstage (pullback only, skip layers only): the activation before the skip addition goes to the staged block as well —
 // the derivative is taken from it. (Recovering it as h − x loses it when it is tiny next to x: relu′ flips from 1 to 0 for
 // about one unit in 10⁷, which a test with 3·10⁵ columns caught as a 3 % error in one column's gradient.)
+struct SaveTo { float* base; long long n0, N; };   // base == nullptr: nothing is saved
+
 template <int CG, bool BG = false>
 __device__ __forceinline__ void chain_hidden_layer(const ChainDims& cd, int l, const float* frag, const float* biasc,
-                                                   const float* Xin, int ldx, float* Y, float* fstage = nullptr) {
+                                                   const float* Xin, int ldx, float* Y, float* fstage = nullptr,
+                                                   SaveTo sv = SaveTo{nullptr, 0, 0}) {
   const MlpDims& dm = cd.dm;
   const int in = dm.sizes[l], out = dm.sizes[l + 1], actk = cd.act[l], skip = BG ? 0 : cd.skip[l], ldh = cd.ldh;
   const float* bias = biasc + dm.bias_lin[l];
@@ -230,7 +237,20 @@ __device__ __forceinline__ void chain_hidden_layer(const ChainDims& cd, int l, c
                           for (int q = 0; q < 4; q++) r[q] = row0 + q < out ? cact(actk, v[q] + bias[row0 + q]) : 0.f;
                           if (skip && fstage && row0 < out32)
                             *reinterpret_cast<f32x4*>(fstage + (size_t)cg * dm.blk_floats + col * out32 + row0) = r;
+                          const long long nsv = sv.n0 + c;
+                          const bool dosv = sv.base && nsv < sv.N && row0 < out;
+                          float* svp = sv.base + (size_t)sv.N * cd.sv_pre[l] + (size_t)nsv * out + row0;
+                          auto put = [&](float* p, const f32x4& v4) {
+                            if ((out & 3) == 0) *reinterpret_cast<f32x4*>(p) = v4;
+                            else {
+#pragma unroll
+                              for (int q = 0; q < 4; q++)
+                                if (row0 + q < out) p[q] = v4[q];
+                            }
+                          };
+                          if (dosv && cd.skip[l]) put(svp + (size_t)sv.N * out, r);   // before the skip addition
                           if (skip) r += *reinterpret_cast<const f32x4*>(Xin + c * ldx + row0);   // in == out; pad rows are 0
+                          if (dosv) put(svp, r);
                           *reinterpret_cast<f32x4*>(Y + c * ldh + row0) = r;
                         });
 }
@@ -257,8 +277,9 @@ __global__ void __launch_bounds__(512) k_chain_forward(ChainDims cd, ChainFwdArg
   for (int l = 0; l + 1 < nL; l++) {
     float* Y = (l & 1) ? H1 : H0;
     PROF_T(pl0);
-    if (l == 0 && cd.gx) chain_hidden_layer<CG, true>(cd, 0, a.frag, biasc, xg, dm.sizes[0], Y);
-    else chain_hidden_layer<CG>(cd, l, a.frag, biasc, Xin, ldx, Y);
+    const SaveTo sv{a.saved, n0, a.N};
+    if (l == 0 && cd.gx) chain_hidden_layer<CG, true>(cd, 0, a.frag, biasc, xg, dm.sizes[0], Y, nullptr, sv);
+    else chain_hidden_layer<CG>(cd, l, a.frag, biasc, Xin, ldx, Y, nullptr, sv);
     PROF_T(pl1);
     __syncthreads();
     PROF_T(pl2);
@@ -306,6 +327,7 @@ struct ChainBwdArgs {
   float* stage;        // [slots][blk_floats]
   float* wts;          // [slots][16]
   long long N;
+  const float* saved;  // hidden activations written by lde_chain_forward_save (nullptr: recompute them)
 };
 
 struct PrePair { f32x4 h, a; };
@@ -343,7 +365,38 @@ __global__ void __launch_bounds__(512) k_chain_backward(ChainDims cd, ChainBwdAr
     for (int cg = 0; cg < CG; cg++)
       stage_panel(X0 + cg * 16 * cd.ld0, cd.ld0, pad32(dm.sizes[0]), blk0 + (size_t)cg * dm.blk_floats + dm.blk_off[0]);
   }
-  {
+  if (a.saved) {   // the forward call kept the hidden activations: copy them into the staged panels, no recomputation
+    const int col = tid >> 5, l31 = tid & 31;
+    for (int l = 0; l + 1 < nL; l++) {
+      const int h = dm.sizes[l + 1], h32 = pad32(h);
+      const bool vec = (h & 3) == 0;
+#pragma unroll
+      for (int cg = 0; cg < CG; cg++) {
+        const long long n = n0 + cg * 16 + col;
+        const float* sh = a.saved + (size_t)a.N * cd.sv_pre[l] + (size_t)n * h;
+        float* dst = blk0 + (size_t)cg * dm.blk_floats + dm.blk_off[l + 1] + col * h32;
+        float* dstf = blk0 + (size_t)cg * dm.blk_floats + cd.f_off[l] + col * h32;
+        for (int r4 = l31; 4 * r4 < h32; r4 += 32) {
+          f32x4 v = {0.f, 0.f, 0.f, 0.f}, vf = v;
+          if (n < a.N && 4 * r4 < h) {
+            if (vec) {
+              v = *reinterpret_cast<const f32x4*>(sh + 4 * r4);
+              if (cd.skip[l]) vf = *reinterpret_cast<const f32x4*>(sh + (size_t)a.N * h + 4 * r4);
+            } else {
+#pragma unroll
+              for (int q = 0; q < 4; q++)
+                if (4 * r4 + q < h) {
+                  v[q] = sh[4 * r4 + q];
+                  if (cd.skip[l]) vf[q] = sh[(size_t)a.N * h + 4 * r4 + q];
+                }
+            }
+          }
+          *reinterpret_cast<f32x4*>(dst + 4 * r4) = v;
+          if (cd.skip[l]) *reinterpret_cast<f32x4*>(dstf + 4 * r4) = vf;
+        }
+      }
+    }
+  } else {
     const float* Xin = X0;
     int ldx = cd.ld0;
     for (int l = 0; l + 1 < nL; l++) {
@@ -550,6 +603,11 @@ int lde_chain_create(const lde_chain_desc* d, lde_chain** out) {
       dm.blk_floats += NB * pad32(dm.sizes[l + 1]);
     }
   }
+  cd.sv_total = 0;
+  for (int l = 0; l + 1 < d->n_layers; l++) {
+    cd.sv_pre[l] = cd.sv_total;   // widths rounded up to 4 keep every region 16-byte aligned (N·sv_pre floats from the base)
+    cd.sv_total += ((dm.sizes[l + 1] + 3) & ~3) * (cd.skip[l] ? 2 : 1);
+  }
   cd.ld0 = panel_stride(pad32(dm.sizes[0]));
   cd.ldh = panel_stride(pad32(hmax));
   *out = c;   // from here on errors carry a message
@@ -681,7 +739,7 @@ int lde_chain_reserve(lde_chain* c, int64_t N) {
   return LDE_OK;
 }
 
-int lde_chain_forward(lde_chain* c, const float* x, int64_t N, float* y, void* stream_) {
+static int chain_forward_impl(lde_chain* c, const float* x, int64_t N, float* y, float* saved, void* stream_) {
   if (!c || !c->W_dev) return LDE_ERR_INVALID_ARG;
   if (!x || !y || N < 1) {
     c->err = "lde_chain_forward: NULL pointer or empty batch";
@@ -696,7 +754,7 @@ int lde_chain_forward(lde_chain* c, const float* x, int64_t N, float* y, void* s
     return LDE_ERR_INVALID_ARG;
   }
   hipStream_t stream = (hipStream_t)stream_;
-  ChainFwdArgs a{x, y, c->frag, c->W_dev, (long long)N};
+  ChainFwdArgs a{x, y, c->frag, c->W_dev, (long long)N, saved};
   ChainPick pk;
   if (!chain_pick(c, x, N, false, &pk)) {
     c->err = "lde_chain_forward: the only layout whose panels fit LDS reads x in place and needs N ≥ one tile and a 16-byte aligned x";
@@ -741,8 +799,8 @@ int lde_chain_forward(lde_chain* c, const float* x, int64_t N, float* y, void* s
   return LDE_OK;
 }
 
-int lde_chain_backward(lde_chain* c, const float* x, const float* y, const float* dy, int64_t N, float* dx, float* dW,
-                       void* stream_) {
+static int chain_backward_impl(lde_chain* c, const float* x, const float* y, const float* dy, const float* saved, int64_t N,
+                               float* dx, float* dW, void* stream_) {
   if (!c || !c->W_dev) return LDE_ERR_INVALID_ARG;
   if (!x || !y || !dy || !dW || N < 1) {
     c->err = "lde_chain_backward: NULL pointer or empty batch";
@@ -768,7 +826,7 @@ int lde_chain_backward(lde_chain* c, const float* x, const float* y, const float
   int nvt, cap;
   int64_t total;
   chain_dw_split(c, pk.cg, N, &nvt, &cap, &total);
-  ChainBwdArgs a{x, y, dy, dx, c->frag, c->fragT, c->W_dev, c->stage, c->wts, (long long)N};
+  ChainBwdArgs a{x, y, dy, dx, c->frag, c->fragT, c->W_dev, c->stage, c->wts, (long long)N, saved};
   const int NC = 16 * pk.cg;
   const dim3 grid((unsigned)((N + NC - 1) / NC));
   static bool attr[3] = {false, false, false};
@@ -794,6 +852,33 @@ int lde_chain_backward(lde_chain* c, const float* x, const float* y, const float
   rc = launch_weight_gradient(dm, da, nvt, 1, nullptr, c->ints + nvt, 0, dW, c->ints + nvt + 1, stream, c->err);
   if (rc) return rc;
   return LDE_OK;
+}
+
+int lde_chain_forward(lde_chain* c, const float* x, int64_t N, float* y, void* stream) {
+  return chain_forward_impl(c, x, N, y, nullptr, stream);
+}
+int lde_chain_backward(lde_chain* c, const float* x, const float* y, const float* dy, int64_t N, float* dx, float* dW, void* stream) {
+  return chain_backward_impl(c, x, y, dy, nullptr, N, dx, dW, stream);
+}
+int64_t lde_chain_saved_floats(const lde_chain* c, int64_t N) {
+  if (!c || N < 1) return -1;
+  const int64_t n = (int64_t)c->cd.sv_total * N;
+  return n > 0 ? n : 4;   // a chain without hidden layers saves nothing; keep the buffer non-empty
+}
+int lde_chain_forward_save(lde_chain* c, const float* x, int64_t N, float* y, float* saved, void* stream) {
+  if (c && (!saved || (((uintptr_t)saved) & 15) != 0)) {
+    c->err = "lde_chain_forward_save: saved must be a 16-byte aligned device buffer of lde_chain_saved_floats(c, N) floats";
+    return LDE_ERR_INVALID_ARG;
+  }
+  return chain_forward_impl(c, x, N, y, saved, stream);
+}
+int lde_chain_backward_saved(lde_chain* c, const float* x, const float* y, const float* dy, const float* saved, int64_t N,
+                             float* dx, float* dW, void* stream) {
+  if (c && (!saved || (((uintptr_t)saved) & 15) != 0)) {
+    c->err = "lde_chain_backward_saved: saved must be the buffer lde_chain_forward_save filled";
+    return LDE_ERR_INVALID_ARG;
+  }
+  return chain_backward_impl(c, x, y, dy, saved, N, dx, dW, stream);
 }
 
 const char* lde_chain_last_error(const lde_chain* c) { return c ? c->err.c_str() : "null handle"; }

@@ -149,6 +149,34 @@ class NativeChain:
         torch.cuda.synchronize()
         return y.cpu().numpy()
 
+    def forward_save(self, x):
+        xd = torch.from_numpy(np.ascontiguousarray(x, np.float32)).to("cuda")
+        N = xd.shape[0]
+        y = torch.full((N, self.sizes[-1]), 7.0, device="cuda")
+        self.lib.lde_chain_saved_floats.restype = C.c_int64
+        saved = torch.full((int(self.lib.lde_chain_saved_floats(self.h, N)),), 7.0, device="cuda")
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(self.lib.lde_chain_forward_save(self.h, C.c_void_p(xd.data_ptr()), N, C.c_void_p(y.data_ptr()),
+                                                C.c_void_p(saved.data_ptr()), s), self.h, "lde_chain_forward_save", chain=True)
+        torch.cuda.synchronize()
+        return y.cpu().numpy(), saved
+
+    def backward_saved(self, x, y, dy, saved, need_dx=True):
+        dev = "cuda"
+        xd = torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)
+        yd = torch.from_numpy(np.ascontiguousarray(y, np.float32)).to(dev)
+        dyd = torch.from_numpy(np.ascontiguousarray(dy, np.float32)).to(dev)
+        N = xd.shape[0]
+        dx = torch.full_like(xd, 7.0) if need_dx else None
+        dW = torch.zeros((self.nW,), device=dev)
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(self.lib.lde_chain_backward_saved(self.h, C.c_void_p(xd.data_ptr()), C.c_void_p(yd.data_ptr()), C.c_void_p(dyd.data_ptr()),
+                                                  C.c_void_p(saved.data_ptr()), N,
+                                                  C.c_void_p(dx.data_ptr()) if dx is not None else C.c_void_p(),
+                                                  C.c_void_p(dW.data_ptr()), s), self.h, "lde_chain_backward_saved", chain=True)
+        torch.cuda.synchronize()
+        return (None if dx is None else dx.cpu().numpy()), dW.cpu().numpy()
+
     def backward(self, x, y, dy, need_dx=True, dW0=None):
         dev = "cuda"
         xd = torch.from_numpy(np.ascontiguousarray(x, np.float32)).to(dev)

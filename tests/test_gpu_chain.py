@@ -78,6 +78,28 @@ def test_wide_input_layouts_agree(o32, o64, monkeypatch):
     assert np.abs(dWa - dWb).max() <= 1e-5 * np.abs(dWa).max()
 
 
+@pytest.mark.parametrize("spec", [RECON, ODD, FE, ONE, LO_TH], ids=["reconstructor", "odd", "feature_extractor", "one", "lo_theta"])
+@pytest.mark.parametrize("N", [37, 256])
+def test_saved_activation_variant_gives_the_same_numbers(o32, spec, N):
+    """lde_chain_forward_save + lde_chain_backward_saved (the pullback reads the hidden activations the forward call kept in
+    a caller-owned buffer) against lde_chain_forward + lde_chain_backward (it recomputes them): identical outputs and —
+    same staged panels, same summation order — identical gradients."""
+    from tests.gpu_util import NativeChain
+    sizes, acts, skips = spec
+    W = O.mlp_weights(sizes, seed=4)
+    rng = np.random.default_rng(6)
+    x = rng.standard_normal((N, sizes[0])).astype(np.float32)
+    dy = (rng.standard_normal((N, sizes[-1])) / N).astype(np.float32)
+    nat = NativeChain(sizes, acts, skips)
+    nat.set_weights(W)
+    y = nat.forward(x)
+    dx, dW = nat.backward(x, y, dy)
+    y2, saved = nat.forward_save(x)
+    assert np.array_equal(y, y2)
+    dx2, dW2 = nat.backward_saved(x, y2, dy, saved)
+    assert np.array_equal(dx, dx2) and np.array_equal(dW, dW2)
+
+
 def test_chain_dw_accumulates_and_dx_is_optional(o32):
     nat, (x, y, dy, dx, dW) = _run(LO_TH, 100, o32, O.Oracle("f64"))
     base = np.full(nat.nW, 0.25, np.float32)

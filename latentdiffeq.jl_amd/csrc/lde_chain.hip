@@ -500,15 +500,6 @@ __global__ void __launch_bounds__(512) k_chain_backward(ChainDims cd, ChainBwdAr
   }
 }
 
-static __global__ void k_chain_fill_slots(int32_t* nslots, int32_t* zeros, int nvt, int cap, long long total) {
-  const int v = blockIdx.x * blockDim.x + threadIdx.x;
-  if (v < nvt) {
-    const long long left = total - (long long)v * cap;
-    nslots[v] = left <= 0 ? 0 : (left < cap ? (int)left : cap);
-  }
-  if (v == 0) zeros[0] = 0;
-}
-
 }  // namespace lde
 
 // ================================================ C ABI ======================================================
@@ -532,7 +523,7 @@ struct lde_chain {
   float* stage = nullptr; size_t stage_cap = 0;
   float* wts = nullptr; size_t wts_cap = 0;
   float* slab = nullptr; size_t slab_cap = 0;
-  int32_t* ints = nullptr; size_t ints_cap = 0;   // [nvt] slots per virtual tile, then one zero / feedback word
+  int32_t* ints = nullptr; size_t ints_cap = 0;   // zero words for the slab reduction: [0] "no private slabs", [2..3] feedback sink
   std::string err;
 };
 
@@ -732,9 +723,16 @@ int lde_chain_reserve(lde_chain* c, int64_t N) {
   chain_dw_split(c, 2, N, &nvt, &cap, &total);   // 2 column groups per tile rounds the slot count up the most
   const MlpDims& dm = c->cd.dm;
   if (!grow(&c->stage, &c->stage_cap, (size_t)total * dm.blk_floats) || !grow(&c->wts, &c->wts_cap, (size_t)total * NB) ||
-      !grow(&c->slab, &c->slab_cap, ((size_t)nvt + 1) * dm.slab_n) || !grow(&c->ints, &c->ints_cap, (size_t)nvt + 16)) {
+      !grow(&c->slab, &c->slab_cap, ((size_t)nvt + 1) * dm.slab_n)) {
     c->err = "chain: hipMalloc of the backward workspace failed";
     return LDE_ERR_ALLOC;
+  }
+  if (!c->ints) {   // two words the slab reduction reads as "no private slabs" / writes its feedback to: zero, once
+    if (hipMalloc(&c->ints, 64) != hipSuccess || hipMemset(c->ints, 0, 64) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
+      c->err = "chain: hipMalloc of the backward workspace failed";
+      return LDE_ERR_ALLOC;
+    }
+    c->ints_cap = 16;
   }
   return LDE_OK;
 }
@@ -838,8 +836,6 @@ static int chain_backward_impl(lde_chain* c, const float* x, const float* y, con
     }
     attr[pk.cg] = true;
   }
-  hipLaunchKernelGGL(k_chain_fill_slots, dim3(cdiv(nvt, 64)), dim3(64), 0, stream, c->ints, c->ints + nvt, nvt, cap,
-                     (long long)total);
   if (pk.cg == 2) hipLaunchKernelGGL(k_chain_backward<2>, grid, dim3(512), pk.lds, stream, *pk.cd, a);
   else hipLaunchKernelGGL(k_chain_backward<1>, grid, dim3(512), pk.lds, stream, *pk.cd, a);
   if (hipGetLastError() != hipSuccess) {
@@ -848,8 +844,8 @@ static int chain_backward_impl(lde_chain* c, const float* x, const float* y, con
   }
   // weight gradient: large-K product over the staged panels (lde_mfma.h)
   DwArgs da;
-  da.stage = c->stage; da.wts = c->wts; da.nslots = c->ints; da.slab = c->slab; da.cap = cap;
-  rc = launch_weight_gradient(dm, da, nvt, 1, nullptr, c->ints + nvt, 0, dW, c->ints + nvt + 1, stream, c->err);
+  da.stage = c->stage; da.wts = c->wts; da.nslots = nullptr; da.slab = c->slab; da.cap = cap; da.total = total;   // tiles filled in order
+  rc = launch_weight_gradient(dm, da, nvt, 1, nullptr, c->ints, 0, dW, c->ints + 2, stream, c->err);
   if (rc) return rc;
   return LDE_OK;
 }

@@ -161,9 +161,10 @@ static constexpr size_t LDS_MAX = 160 * 1024;
 struct DwArgs {
   const float* stage;
   const float* wts;
-  const int32_t* nslots;
+  const int32_t* nslots;   // staged slots per tile, or nullptr: tiles are filled in order, `total` slots in all (cap per tile)
   float* slab;          // [nWG·KS][slab_n]
   int cap;
+  long long total;
 };
 
 // accumulator tiles per wave: 4 (32 tiles per job) in general; 1 or 2 when every layer is that small — fewer registers,
@@ -257,7 +258,12 @@ static __global__ void __launch_bounds__(512) k_mlp_dw(MlpDims dm, DwArgs a) {
   }
   const bool do_bias = jb.i0 == 0;   // the jobs that hold the first input tile of their output rows also sum the bias gradient
   float bsum[2] = {0.f, 0.f};
-  const int ns = a.nslots[tile];
+  int ns;
+  if (a.nslots) ns = a.nslots[tile];
+  else {
+    const long long left = a.total - (long long)tile * a.cap;
+    ns = left <= 0 ? 0 : (left < a.cap ? (int)left : a.cap);
+  }
   const int col = tid >> 5;
   // Slot e+KS's rows are fetched into registers while slot e is multiplied (up to PQ quads of each panel per lane;
   // wider jobs fetch the rest at store time).

@@ -1752,7 +1752,7 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
   }
   // the weight gradient from the staged panels
   DwArgs da;
-  da.stage = p->stage; da.wts = p->wts; da.nslots = p->nslots; da.slab = p->slab + (size_t)(nwg + 1) * dm.slab_n; da.cap = p->adj_cap;
+  da.stage = p->stage; da.wts = p->wts; da.nslots = p->nslots; da.slab = p->slab + (size_t)(nwg + 1) * dm.slab_n; da.cap = p->adj_cap; da.total = 0;
   rc = launch_weight_gradient(dm, da, ntile_dw, ks, p->slab, p->nslots + (nwg + 1), nwg, dW, p->fb_dev, stream, err);
   if (rc) return rc;
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;

@@ -281,12 +281,6 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
   }
 }
 
-// ints[0..n) = v, ints[n..total) = 0
-__global__ void k_fill_i32(int32_t* p, int n, int v, int total) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < total) p[i] = i < n ? v : 0;
-}
-
 // dW[state0 slots] += Σ_b g0[b][·]   (trajectory order ⇒ deterministic)
 __global__ void k_rnn_state0(const float* __restrict__ g0, int B, int g0w, RnnDims rd, float* __restrict__ dW) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -470,7 +464,11 @@ int lde_rnn_reserve(lde_rnn* r, int B, int T) {
   const size_t ntile = (size_t)cdiv(B, 16);
   size_t slab_need = 0;
   bool ok = grow(&r->rec, &r->rec_cap, (size_t)T * rd.nL * B * rd.recw) && grow(&r->wts, &r->wts_cap, ntile * T * NB) &&
-            grow(&r->g0, &r->g0_cap, (size_t)B * r->g0w) && grow(&r->ints, &r->ints_cap, ntile + 16);
+            grow(&r->g0, &r->g0_cap, (size_t)B * r->g0w);
+  if (ok && !r->ints) {   // two zero words for the slab reduction (no private slabs; feedback sink)
+    ok = hipMalloc(&r->ints, 64) == hipSuccess && hipMemset(r->ints, 0, 64) == hipSuccess && hipStreamSynchronize(nullptr) == hipSuccess;
+    r->ints_cap = 16;
+  }
   for (int l = 0; l < rd.nL && ok; l++) {
     ok = grow(&r->stage[l], &r->stage_cap[l], ntile * T * r->dmw[l].blk_floats);
     slab_need = std::max(slab_need, (ntile * 8 + 1) * (size_t)r->dmw[l].slab_n);
@@ -538,14 +536,12 @@ int lde_rnn_backward(lde_rnn* r, const float* x, const float* dy, int T, int B, 
   for (int l = 0; l < rd.nL; l++) { a.stage[l] = r->stage[l]; a.blk[l] = r->dmw[l].blk_floats; }
   rc = rnn_launch(r, a, B, stream);
   if (rc) return rc;
-  // every tile staged exactly T slots
-  hipLaunchKernelGGL(k_fill_i32, dim3(cdiv(ntile + 2, 64)), dim3(64), 0, stream, r->ints, ntile, T, ntile + 2);
   for (int l = 0; l < rd.nL; l++) {
     DwArgs da;
-    da.stage = r->stage[l]; da.wts = r->wts; da.nslots = r->ints; da.slab = r->slab; da.cap = T;
+    da.stage = r->stage[l]; da.wts = r->wts; da.nslots = nullptr; da.slab = r->slab; da.cap = T; da.total = (long long)ntile * T;   // every tile staged exactly T slots
     int ks = cdiv(512, ntile * dw_jobs(r->dmw[l], dw_pick_ndw(r->dmw[l])));
     ks = ks < 1 ? 1 : (ks > 8 ? 8 : ks);
-    rc = launch_weight_gradient(r->dmw[l], da, ntile, ks, nullptr, r->ints + ntile, 0, dW + rd.f_off[l], r->ints + ntile, stream, r->err);
+    rc = launch_weight_gradient(r->dmw[l], da, ntile, ks, nullptr, r->ints, 0, dW + rd.f_off[l], r->ints + 2, stream, r->err);
     if (rc) return rc;
   }
   hipLaunchKernelGGL(k_rnn_state0, dim3(cdiv(r->g0w, 64)), dim3(64), 0, stream, r->g0, B, r->g0w, rd, dW);

@@ -5,7 +5,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from latentdiffeq_amd import _lib as L
 from latentdiffeq_amd import synthetic  # noqa
 lib = L.load()
-B, T = 256, 50
+B, T = int(os.environ.get('RB_B', 256)), int(os.environ.get('RB_T', 50))
 for cell, name in ((L.CELL_LSTM, "lstm"), (L.CELL_RNN_RELU, "rnn")):
     d = L.RnnDesc(); d.abi_version, d.cell, d.n_layers, d.reverse = 1, cell, 2, 1
     for i, s in enumerate((32, 16, 16)): d.sizes[i] = s

@@ -24,3 +24,13 @@ t0 = time.perf_counter()
 for _ in range(50): step()
 t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
 print("host enqueue per step %.3f ms; total per step %.3f ms" % ((t1 - t0) / 50 * 1e3, (t2 - t0) / 50 * 1e3))
+# the same with an EMPTY queue (so that the host can never be throttled by the device): n steps after a synchronise
+for n in (1, 2, 4):
+    best = (1e9, 0)
+    for _ in range(5):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n): step()
+        t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+        best = min(best, ((t1 - t0) / n * 1e3, (t2 - t0) / n * 1e3))
+    print("n=%d: host %.3f ms/step, host+drain %.3f ms/step" % (n, best[0], best[1]))

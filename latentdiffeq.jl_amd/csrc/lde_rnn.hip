@@ -64,6 +64,7 @@ struct RnnArgs {
   float* g0;            // [B][Σ state0 sizes]: per-trajectory gradient of the initial states
   int g0w;              // floats per trajectory in g0
   int T, B, mode;       // mode 0: forward only (writes y); 1: backward (recompute + BPTT)
+  int tpw;              // trajectories per workgroup: 1, 2, 4, 8 or 16 (a staging tile of 16 spans 16/tpw workgroups)
 };
 
 // weights → LDS: rows of [Wi | Wh] (row r = g·h + u), zero padded; biases; state0
@@ -86,29 +87,48 @@ __device__ __forceinline__ void rnn_load_weights(const RnnDims& rd, const float*
   __syncthreads();
 }
 
-// One workgroup = 16 trajectories × Hp lanes. mode 0: forward sweep → y. mode 1: sweep with records, then BPTT.
+constexpr int rnn_pow2(int v) { int p = 1; while (p < v) p <<= 1; return p; }
+__host__ __device__ constexpr int rnn_ldk(int K) { int v = (K + 3) & ~3; return ((v >> 2) & 1) ? v : v + 4; }
+
+// One workgroup = tpw trajectories × Hp lanes. mode 0: forward sweep → y. mode 1: sweep with records, then BPTT.
+// CELL_ ≥ 0 instantiates the kernel for one stack shape (cell kind, IN0_ → H_ → … → H_, L_ cells) — the reference's default
+// pattern extractors [REF src/models/GOKU.jl:229-238] —: every loop bound and LDS stride is then a compile-time constant, the
+// layer loops unroll, and the per-layer kernel-argument reads, the short runtime loops and the vmcnt(0) waits they force
+// (the prefetched frame / record behind a variable number of staging stores) disappear. CELL_ = −1: any shape, at run time.
+template <int CELL_, int IN0_, int H_, int L_>
 __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float rsm[];
-  const int Hp = rd.Hp, nthr = 16 * Hp, tid = threadIdx.x, tr = tid / Hp, u = tid - tr * Hp;
-  const int L = rd.nL, G = rd.G, T = a.T, B = a.B, lstm = rd.cell == LDE_CELL_LSTM;
+  constexpr bool SP = CELL_ >= 0;
+  constexpr int UL = SP ? L_ : 1, UK = SP ? 16 : 4;   // unroll factors: layer loops, dot-product loops
+  const int cellk = SP ? CELL_ : rd.cell;
+  const bool lstm = cellk == LDE_CELL_LSTM;
+  const int G = lstm ? 4 : 1, L = SP ? L_ : rd.nL;
+  const int Hp = SP ? rnn_pow2((CELL_ == LDE_CELL_LSTM ? 4 : 1) * H_) : rd.Hp, hmaxv = SP ? H_ : rd.hmax;
+  auto size_of = [&](int l) { return SP ? (l == 0 ? IN0_ : H_) : rd.sizes[l]; };
+  auto ldk_of = [&](int l) { return SP ? rnn_ldk(size_of(l) + size_of(l + 1)) : rd.ldk[l]; };
+  const int tpw = a.tpw, nthr = tpw * Hp, tid = threadIdx.x, tr = tid / Hp, u = tid - tr * Hp;
+  const int T = a.T, B = a.B;
   float* lw = rsm;
   float* vbuf = lw + rd.lds_w + tr * rd.vmax;                     // this trajectory's [x; h_prev]
-  float* dbuf = lw + rd.lds_w + 16 * rd.vmax + tr * rd.rmax;      // its gate deltas
-  float* hst = lw + rd.lds_w + 16 * (rd.vmax + rd.rmax) + tr * (2 * L * rd.hmax);   // h[l][hmax], then c[l][hmax]
-  float* cst = hst + L * rd.hmax;
-  float* dhs = lw + rd.lds_w + 16 * (rd.vmax + rd.rmax + 2 * L * rd.hmax) + tr * (2 * L * rd.hmax);   // dh, dc
-  float* dcs = dhs + L * rd.hmax;
+  float* dbuf = lw + rd.lds_w + tpw * rd.vmax + tr * rd.rmax;      // its gate deltas
+  float* hst = lw + rd.lds_w + tpw * (rd.vmax + rd.rmax) + tr * (2 * L * hmaxv);   // h[l][hmax], then c[l][hmax]
+  float* cst = hst + L * hmaxv;
+  float* dhs = lw + rd.lds_w + tpw * (rd.vmax + rd.rmax + 2 * L * hmaxv) + tr * (2 * L * hmaxv);   // dh, dc
+  float* dcs = dhs + L * hmaxv;
   rnn_load_weights(rd, a.Wflat, lw, nthr);
-  const long long b = (long long)blockIdx.x * 16 + tr;
+  const long long b = (long long)blockIdx.x * tpw + tr;
   const bool valid = b < B;
-  const int in0 = rd.sizes[0];
+  const size_t tile = (size_t)(b >> 4);   // staging tile (16 trajectories = one column slot of the weight-gradient kernel)
+  const int row = (int)(b & 15);
+  const int in0 = size_of(0);
 
   // ---- forward sweep (state0 → … → last frame) ------------------------------------------------------------------------
+#pragma unroll UL
   for (int l = 0; l < L; l++) {
-    const int h = rd.sizes[l + 1];
+    const int h = size_of(l + 1);
     if (u < h) {
-      hst[l * rd.hmax + u] = lw[rd.s_off[l] + u];
-      cst[l * rd.hmax + u] = lstm ? lw[rd.s_off[l] + h + u] : 0.f;
+      hst[l * hmaxv + u] = lw[rd.s_off[l] + u];
+      cst[l * hmaxv + u] = lstm ? lw[rd.s_off[l] + h + u] : 0.f;
     }
   }
   // frame s+1 is fetched while frame s is processed (a global round trip per time step would otherwise be exposed T times)
@@ -125,8 +145,9 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
   fetch_x(0);
   for (int s = 0; s < T; s++) {
     const int t = rd.reverse ? T - 1 - s : s;
-    for (int l = 0; l < L; l++) {
-      const int in = rd.sizes[l], h = rd.sizes[l + 1], K = in + h, ldk = rd.ldk[l];
+  #pragma unroll UL
+  for (int l = 0; l < L; l++) {
+      const int in = size_of(l), h = size_of(l + 1), K = in + h, ldk = ldk_of(l);
       // assemble [input ; h_prev] (the tail up to pad4(K) stays zero: vbuf was zero-filled, entries beyond K never written)
       if (l == 0) {
 #pragma unroll
@@ -135,12 +156,12 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
         for (int k = u + XQ * Hp; k < in; k += Hp) vbuf[k] = valid ? a.x[(size_t)in0 * ((size_t)b + (size_t)B * t) + k] : 0.f;
         if (s + 1 < T) fetch_x(s + 1);
       } else {
-        for (int k = u; k < in; k += Hp) vbuf[k] = hst[(l - 1) * rd.hmax + k];
+        for (int k = u; k < in; k += Hp) vbuf[k] = hst[(l - 1) * hmaxv + k];
       }
-      for (int k = u; k < h; k += Hp) vbuf[in + k] = hst[l * rd.hmax + k];
+      for (int k = u; k < h; k += Hp) vbuf[in + k] = hst[l * hmaxv + k];
       for (int k = K + u; k < ((K + 3) & ~3); k += Hp) vbuf[k] = 0.f;
       if (a.mode == 1) {   // the layer's input vector is the a-panel of the weight gradient: staged here, while it is in LDS
-        float* ga = a.stage[l] + ((size_t)blockIdx.x * T + s) * a.blk[l] + tr * pad32(K);
+        float* ga = a.stage[l] + (tile * T + s) * a.blk[l] + row * pad32(K);
         for (int k = u; k < pad32(K); k += Hp) ga[k] = (valid && k < K) ? vbuf[k] : 0.f;
       }
       // one lane per gate ROW (Hp ≥ G·h lanes per trajectory): z_r = b_r + [Wi|Wh]_r · [x; h]; the unit lanes then pick
@@ -150,7 +171,7 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
         const int K4 = (K + 3) >> 2;
         const float* wr = lw + rd.w_off[l] + u * ldk;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll 4
+#pragma unroll UK
         for (int k4 = 0; k4 < K4; k4++)
           acc += *reinterpret_cast<const f32x4*>(wr + 4 * k4) * *reinterpret_cast<const f32x4*>(vbuf + 4 * k4);
         dbuf[u] = lw[rd.b_off[l] + u] + ((acc[0] + acc[1]) + (acc[2] + acc[3]));
@@ -164,10 +185,10 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
         if (lstm) {
           const float ig = sigm(z[0]), fg = sigm(z[1]), gg = fast_tanh(z[2]), og = sigm(z[3]);
           z[0] = ig; z[1] = fg; z[2] = gg; z[3] = og;
-          cn = fg * cst[l * rd.hmax + u] + ig * gg;
+          cn = fg * cst[l * hmaxv + u] + ig * gg;
           hn = og * fast_tanh(cn);
         } else {
-          hn = rd.cell == LDE_CELL_RNN_TANH ? fast_tanh(z[0]) : fmaxf(z[0], 0.f);
+          hn = cellk == LDE_CELL_RNN_TANH ? fast_tanh(z[0]) : fmaxf(z[0], 0.f);
           z[0] = hn;
         }
         if (a.mode == 1 && valid) {
@@ -178,30 +199,31 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
           r[G * h + u] = cn;
           r[G * h + h + u] = hn;
         }
-        hst[l * rd.hmax + u] = hn;   // every lane of the trajectory has copied h_prev into vbuf already (same wave, in order)
-        cst[l * rd.hmax + u] = cn;
+        hst[l * hmaxv + u] = hn;   // every lane of the trajectory has copied h_prev into vbuf already (same wave, in order)
+        cst[l * hmaxv + u] = cn;
       }
     }
   }
   if (a.mode == 0) {
-    const int hL = rd.sizes[L];
-    if (valid && u < hL) a.y[(size_t)hL * b + u] = hst[(L - 1) * rd.hmax + u];
+    const int hL = size_of(L);
+    if (valid && u < hL) a.y[(size_t)hL * b + u] = hst[(L - 1) * hmaxv + u];
     return;
   }
   __syncthreads();   // the records are read back below by other lanes of the trajectory: stores drained (vmcnt(0)) first
 
   // ---- back-propagation through time -----------------------------------------------------------------------------------
+#pragma unroll UL
   for (int l = 0; l < L; l++) {
-    const int h = rd.sizes[l + 1];
+    const int h = size_of(l + 1);
     if (u < h) {
-      dhs[l * rd.hmax + u] = (l == L - 1 && valid) ? a.dy[(size_t)h * b + u] : 0.f;
-      dcs[l * rd.hmax + u] = 0.f;
+      dhs[l * hmaxv + u] = (l == L - 1 && valid) ? a.dy[(size_t)h * b + u] : 0.f;
+      dcs[l * hmaxv + u] = 0.f;
     }
   }
   // records of the next (step, layer) are fetched while the current one is processed
   float rq[6];   // gates (≤ 4), c_new, c_prev
   auto fetch_rec = [&](int s, int l) {
-    const int h = rd.sizes[l + 1], R = G * h;
+    const int h = size_of(l + 1), R = G * h;
     const float* r = a.rec + (((size_t)s * L + l) * B + (size_t)b) * rd.recw;
 #pragma unroll
     for (int g = 0; g < 4; g++) rq[g] = (valid && u < h && g < G) ? r[g * h + u] : 0.f;
@@ -213,9 +235,10 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
   fetch_rec(T - 1, L - 1);
   for (int s = T - 1; s >= 0; s--) {
     const int t = rd.reverse ? T - 1 - s : s;
-    if (u == 0) a.wts[((size_t)blockIdx.x * T + s) * NB + tr] = valid ? 1.f : 0.f;
+    if (u == 0) a.wts[(tile * T + s) * NB + row] = valid ? 1.f : 0.f;
+#pragma unroll UL
     for (int l = L - 1; l >= 0; l--) {
-      const int in = rd.sizes[l], h = rd.sizes[l + 1], K = in + h, R = G * h, ldk = rd.ldk[l];
+      const int in = size_of(l), h = size_of(l + 1), K = in + h, R = G * h, ldk = ldk_of(l);
       const int K32 = pad32(K), R32 = pad32(R);
       float cur[6];
 #pragma unroll
@@ -224,23 +247,23 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
       else if (s > 0) fetch_rec(s - 1, L - 1);
       // gate deltas of this lane's unit
       if (u < h) {
-        const float dh = dhs[l * rd.hmax + u];
+        const float dh = dhs[l * hmaxv + u];
         if (lstm) {
           const float ig = cur[0], fg = cur[1], gg = cur[2], og = cur[3], cn = cur[4], cp = cur[5];
           const float tc = fast_tanh(cn);
-          const float dct = dcs[l * rd.hmax + u] + dh * og * (1.f - tc * tc);
+          const float dct = dcs[l * hmaxv + u] + dh * og * (1.f - tc * tc);
           dbuf[u] = dct * gg * ig * (1.f - ig);
           dbuf[h + u] = dct * cp * fg * (1.f - fg);
           dbuf[2 * h + u] = dct * ig * (1.f - gg * gg);
           dbuf[3 * h + u] = dh * tc * og * (1.f - og);
-          dcs[l * rd.hmax + u] = dct * fg;
+          dcs[l * hmaxv + u] = dct * fg;
         } else {
           const float av = cur[0];
-          dbuf[u] = dh * (rd.cell == LDE_CELL_RNN_TANH ? 1.f - av * av : (av > 0.f ? 1.f : 0.f));
+          dbuf[u] = dh * (cellk == LDE_CELL_RNN_TANH ? 1.f - av * av : (av > 0.f ? 1.f : 0.f));
         }
       }
       {   // the δ-panel next to the a-panel the forward sweep staged
-        float* gd = a.stage[l] + ((size_t)blockIdx.x * T + s) * a.blk[l] + NB * K32 + tr * R32;
+        float* gd = a.stage[l] + (tile * T + s) * a.blk[l] + NB * K32 + row * R32;
         for (int k = u; k < R32; k += Hp) gd[k] = (valid && k < R) ? dbuf[k] : 0.f;
       }
       // [d_in ; dh_prev] = [Wi | Wh]ᵀ δ: lane u owns the outputs k = u, u+Hp, …; four rows of δ per step, independent sums
@@ -248,7 +271,7 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
         const float* wc = lw + rd.w_off[l] + k;
         f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
         const int R4 = R >> 2;
-#pragma unroll 4
+#pragma unroll UK
         for (int r4 = 0; r4 < R4; r4++) {
           const f32x4 dq = *reinterpret_cast<const f32x4*>(dbuf + 4 * r4);
           const float* w = wc + (4 * r4) * ldk;
@@ -260,21 +283,22 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
         float acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
         for (int rr = 4 * R4; rr < R; rr++) acc += wc[rr * ldk] * dbuf[rr];
         if (k < in) {
-          if (l > 0) dhs[(l - 1) * rd.hmax + k] += acc;
+          if (l > 0) dhs[(l - 1) * hmaxv + k] += acc;
           else if (a.dx && valid) a.dx[(size_t)in0 * ((size_t)b + (size_t)B * t) + k] = acc;
         } else
-          dhs[l * rd.hmax + (k - in)] = acc;
+          dhs[l * hmaxv + (k - in)] = acc;
       }
     }
   }
   // what is left flows into the trainable initial states
   if (valid) {
     int off = 0;
-    for (int l = 0; l < L; l++) {
-      const int h = rd.sizes[l + 1];
+  #pragma unroll UL
+  for (int l = 0; l < L; l++) {
+      const int h = size_of(l + 1);
       if (u < h) {
-        a.g0[(size_t)b * a.g0w + off + u] = dhs[l * rd.hmax + u];
-        if (lstm) a.g0[(size_t)b * a.g0w + off + h + u] = dcs[l * rd.hmax + u];
+        a.g0[(size_t)b * a.g0w + off + u] = dhs[l * hmaxv + u];
+        if (lstm) a.g0[(size_t)b * a.g0w + off + h + u] = dcs[l * hmaxv + u];
       }
       off += lstm ? 2 * h : h;
     }
@@ -326,6 +350,7 @@ struct lde_rnn {
   float* g0 = nullptr; size_t g0_cap = 0;
   float* slab = nullptr; size_t slab_cap = 0;
   int32_t* ints = nullptr; size_t ints_cap = 0;
+  void (*kernel)(lde::RnnDims, lde::RnnArgs) = nullptr;   // the k_rnn instantiation for this stack
   std::string err;
 };
 
@@ -481,16 +506,42 @@ int lde_rnn_reserve(lde_rnn* r, int B, int T) {
   return LDE_OK;
 }
 
+typedef void (*rnn_kernel_t)(RnnDims, RnnArgs);
+
+// the instantiation for this stack: the reference's default pattern extractors (32 → 16 → 16) have their own, any other shape
+// runs the run-time-shaped kernel
+static rnn_kernel_t rnn_pick(const RnnDims& rd) {
+  static const bool generic_only = std::getenv("LDE_RNN_GENERIC") && std::atoi(std::getenv("LDE_RNN_GENERIC")) != 0;
+  if (!generic_only && rd.nL == 2 && rd.sizes[0] == 32 && rd.sizes[1] == 16 && rd.sizes[2] == 16) {
+    if (rd.cell == LDE_CELL_LSTM) return k_rnn<LDE_CELL_LSTM, 32, 16, 2>;
+    if (rd.cell == LDE_CELL_RNN_RELU) return k_rnn<LDE_CELL_RNN_RELU, 32, 16, 2>;
+    if (rd.cell == LDE_CELL_RNN_TANH) return k_rnn<LDE_CELL_RNN_TANH, 32, 16, 2>;
+  }
+  return k_rnn<-1, 0, 0, 0>;
+}
+
 static int rnn_launch(lde_rnn* r, const RnnArgs& a, int B, hipStream_t stream) {
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute((const void*)k_rnn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
+  if (!r->kernel) {
+    r->kernel = rnn_pick(r->rd);
+    if (hipFuncSetAttribute((const void*)r->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
+      r->kernel = nullptr;
       r->err = "hipFuncSetAttribute(k_rnn) failed";
       return LDE_ERR_HIP;
     }
-    attr = true;
   }
-  hipLaunchKernelGGL(k_rnn, dim3(cdiv(B, 16)), dim3(16 * r->rd.Hp), r->lds, stream, r->rd, a);
+  // Trajectories per workgroup. The sweep is sequential in time and every trajectory re-reads the cell's weights from LDS
+  // at every step, so a small batch is spread over as many CUs as it has waves (one wave per workgroup: the LDS of a CU then
+  // serves one wave instead of sixteen); only a batch that would exceed ~4 workgroups per CU packs more trajectories
+  // behind one LDS copy of the weights.
+  static const int tpw_env = std::getenv("LDE_RNN_TPW") ? std::atoi(std::getenv("LDE_RNN_TPW")) : 0;
+  int tpw = std::max(1, 64 / r->rd.Hp);
+  while (tpw < 16 && cdiv(B, tpw) > 1024) tpw *= 2;
+  if (tpw_env == 1 || tpw_env == 2 || tpw_env == 4 || tpw_env == 8 || tpw_env == 16) tpw = tpw_env;
+  RnnArgs aa = a;
+  aa.tpw = tpw;
+  const size_t lds = ((size_t)r->rd.lds_w + tpw * ((size_t)r->rd.vmax + r->rd.rmax + 4 * r->rd.nL * r->rd.hmax)) * sizeof(float);
+  // whole staging tiles are covered (rows past B write zero panels and zero column weights)
+  hipLaunchKernelGGL(r->kernel, dim3(cdiv(B, 16) * (16 / tpw)), dim3(tpw * r->rd.Hp), lds, stream, r->rd, aa);
   if (hipGetLastError() != hipSuccess) {
     r->err = "k_rnn launch failed";
     return LDE_ERR_HIP;

@@ -20,6 +20,7 @@
 // per lane group, 16 waves.)
 #include <hip/hip_runtime.h>
 
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -40,6 +41,9 @@ struct RnnDims {
   int b_off[RNN_ML];    // bias [G·h]
   int s_off[RNN_ML];    // state0: h0 [h] (LSTM: then c0 [h])
   int f_off[RNN_ML];    // offset of the cell in the flat weight vector
+  int wt;               // 1: LDS also holds the transposed copies [K][ldr] (the pullback's Wᵀδ then reads 16-byte rows too)
+  int ldr[RNN_ML];      // their row stride: ≥ pad4(G·h), (ldr/4) odd
+  int wt_off[RNN_ML];
   int lds_w;            // floats of the weight area
   int vmax;             // floats of one trajectory's [x; h] vector (pad4(max K) + 4)
   int rmax;             // floats of one trajectory's δ vector (pad4(max G·h))
@@ -68,7 +72,7 @@ struct RnnArgs {
 };
 
 // weights → LDS: rows of [Wi | Wh] (row r = g·h + u), zero padded; biases; state0
-__device__ __forceinline__ void rnn_load_weights(const RnnDims& rd, const float* Wflat, float* lw, int nthr) {
+__device__ __forceinline__ void rnn_load_weights(const RnnDims& rd, const float* Wflat, float* lw, int nthr, bool transposed) {
   const int tid = threadIdx.x;
   for (int i = tid; i < rd.lds_w; i += nthr) lw[i] = 0.f;
   __syncthreads();
@@ -81,6 +85,8 @@ __device__ __forceinline__ void rnn_load_weights(const RnnDims& rd, const float*
     for (int e = tid; e < R * in; e += nthr) { const int k = e / R, r = e - k * R; lw[rd.w_off[l] + r * ldk + k] = Wi[e]; }
     for (int e = tid; e < R * h; e += nthr) { const int k = e / R, r = e - k * R; lw[rd.w_off[l] + r * ldk + in + k] = Wh[e]; }
     for (int e = tid; e < R; e += nthr) lw[rd.b_off[l] + e] = b[e];
+    if (transposed && rd.wt)   // vec([Wi | Wh]) is column-major: column k of the flat order is row k of the transposed copy
+      for (int e = tid; e < R * (in + h); e += nthr) { const int k = e / R, r = e - k * R; lw[rd.wt_off[l] + k * rd.ldr[l] + r] = Wi[e]; }
     const int ns = rd.cell == LDE_CELL_LSTM ? 2 * h : h;
     for (int e = tid; e < ns; e += nthr) lw[rd.s_off[l] + e] = s0[e];
   }
@@ -95,7 +101,7 @@ __host__ __device__ constexpr int rnn_ldk(int K) { int v = (K + 3) & ~3; return 
 // pattern extractors [REF src/models/GOKU.jl:229-238] —: every loop bound and LDS stride is then a compile-time constant, the
 // layer loops unroll, and the per-layer kernel-argument reads, the short runtime loops and the vmcnt(0) waits they force
 // (the prefetched frame / record behind a variable number of staging stores) disappear. CELL_ = −1: any shape, at run time.
-template <int CELL_, int IN0_, int H_, int L_>
+template <int CELL_, int IN0_, int H_, int L_, int MODE_>
 __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float rsm[];
   constexpr bool SP = CELL_ >= 0;
@@ -108,6 +114,8 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
   auto ldk_of = [&](int l) { return SP ? rnn_ldk(size_of(l) + size_of(l + 1)) : rd.ldk[l]; };
   const int tpw = a.tpw, nthr = tpw * Hp, tid = threadIdx.x, tr = tid / Hp, u = tid - tr * Hp;
   const int T = a.T, B = a.B;
+  const int mode = SP ? MODE_ : a.mode;   // compile-time in the instantiated kernels: the staging stores are then unconditional
+                                          // and the waits for the prefetched frames count them instead of draining them
   float* lw = rsm;
   float* vbuf = lw + rd.lds_w + tr * rd.vmax;                     // this trajectory's [x; h_prev]
   float* dbuf = lw + rd.lds_w + tpw * rd.vmax + tr * rd.rmax;      // its gate deltas
@@ -115,7 +123,7 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
   float* cst = hst + L * hmaxv;
   float* dhs = lw + rd.lds_w + tpw * (rd.vmax + rd.rmax + 2 * L * hmaxv) + tr * (2 * L * hmaxv);   // dh, dc
   float* dcs = dhs + L * hmaxv;
-  rnn_load_weights(rd, a.Wflat, lw, nthr);
+  rnn_load_weights(rd, a.Wflat, lw, nthr, mode == 1);
   const long long b = (long long)blockIdx.x * tpw + tr;
   const bool valid = b < B;
   const size_t tile = (size_t)(b >> 4);   // staging tile (16 trajectories = one column slot of the weight-gradient kernel)
@@ -134,12 +142,17 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
   // frame s+1 is fetched while frame s is processed (a global round trip per time step would otherwise be exposed T times)
   constexpr int XQ = 4;                       // prefetched inputs per lane (in ≤ XQ·Hp; wider inputs fall back to direct loads)
   float xq[XQ];
+  // (branch-free: always-in-bounds addresses and no masking — a trajectory past B computes on a copy of trajectory B−1 and
+  // stores nothing. A load under a branch, or a select right behind it, would turn the wait for it into a vmcnt(0) at the
+  // point of issue, i.e. no prefetch at all.)
+  const size_t bc = (size_t)(valid ? b : B - 1);
   auto fetch_x = [&](int s) {
     const int t = rd.reverse ? T - 1 - s : s;
 #pragma unroll
     for (int q = 0; q < XQ; q++) {
       const int k = u + q * Hp;
-      xq[q] = (valid && k < in0) ? a.x[(size_t)in0 * ((size_t)b + (size_t)B * t) + k] : 0.f;
+      if (SP && k >= in0) { xq[q] = 0.f; continue; }
+      xq[q] = a.x[(size_t)in0 * (bc + (size_t)B * t) + (k < in0 ? k : in0 - 1)];
     }
   };
   fetch_x(0);
@@ -148,24 +161,29 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
   #pragma unroll UL
   for (int l = 0; l < L; l++) {
       const int in = size_of(l), h = size_of(l + 1), K = in + h, ldk = ldk_of(l);
+      PROF_T(p0);
       // assemble [input ; h_prev] (the tail up to pad4(K) stays zero: vbuf was zero-filled, entries beyond K never written)
       if (l == 0) {
 #pragma unroll
         for (int q = 0; q < XQ; q++)
           if (u + q * Hp < in) vbuf[u + q * Hp] = xq[q];
-        for (int k = u + XQ * Hp; k < in; k += Hp) vbuf[k] = valid ? a.x[(size_t)in0 * ((size_t)b + (size_t)B * t) + k] : 0.f;
-        if (s + 1 < T) fetch_x(s + 1);
+        for (int k = u + XQ * Hp; k < in; k += Hp) vbuf[k] = a.x[(size_t)in0 * (bc + (size_t)B * t) + k];
+        fetch_x(s + 1 < T ? s + 1 : s);
       } else {
         for (int k = u; k < in; k += Hp) vbuf[k] = hst[(l - 1) * hmaxv + k];
       }
       for (int k = u; k < h; k += Hp) vbuf[in + k] = hst[l * hmaxv + k];
       for (int k = K + u; k < ((K + 3) & ~3); k += Hp) vbuf[k] = 0.f;
-      if (a.mode == 1) {   // the layer's input vector is the a-panel of the weight gradient: staged here, while it is in LDS
+      PROF_T(p1);
+      PROF_ADD(0, p0, p1);
+      if (mode == 1) {   // the layer's input vector is the a-panel of the weight gradient: staged here, while it is in LDS
         float* ga = a.stage[l] + (tile * T + s) * a.blk[l] + row * pad32(K);
         for (int k = u; k < pad32(K); k += Hp) ga[k] = (valid && k < K) ? vbuf[k] : 0.f;
       }
       // one lane per gate ROW (Hp ≥ G·h lanes per trajectory): z_r = b_r + [Wi|Wh]_r · [x; h]; the unit lanes then pick
       // their G pre-activations up from LDS. (One lane per UNIT doing G rows was 4× the dependent work per lane.)
+      PROF_T(p2);
+      PROF_ADD(1, p1, p2);
       const int Rl = G * h;
       if (u < Rl) {
         const int K4 = (K + 3) >> 2;
@@ -176,6 +194,8 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
           acc += *reinterpret_cast<const f32x4*>(wr + 4 * k4) * *reinterpret_cast<const f32x4*>(vbuf + 4 * k4);
         dbuf[u] = lw[rd.b_off[l] + u] + ((acc[0] + acc[1]) + (acc[2] + acc[3]));
       }
+      PROF_T(p3);
+      PROF_ADD(2, p2, p3);
       if (u < h) {
         float z[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -191,7 +211,7 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
           hn = cellk == LDE_CELL_RNN_TANH ? fast_tanh(z[0]) : fmaxf(z[0], 0.f);
           z[0] = hn;
         }
-        if (a.mode == 1 && valid) {
+        if (mode == 1 && valid) {
           float* r = a.rec + (((size_t)s * L + l) * B + (size_t)b) * rd.recw;
 #pragma unroll
           for (int g = 0; g < 4; g++)
@@ -202,9 +222,11 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
         hst[l * hmaxv + u] = hn;   // every lane of the trajectory has copied h_prev into vbuf already (same wave, in order)
         cst[l * hmaxv + u] = cn;
       }
+      PROF_T(p4);
+      PROF_ADD(3, p3, p4);
     }
   }
-  if (a.mode == 0) {
+  if (mode == 0) {
     const int hL = size_of(L);
     if (valid && u < hL) a.y[(size_t)hL * b + u] = hst[(L - 1) * hmaxv + u];
     return;
@@ -222,15 +244,18 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
   }
   // records of the next (step, layer) are fetched while the current one is processed
   float rq[6];   // gates (≤ 4), c_new, c_prev
-  auto fetch_rec = [&](int s, int l) {
+  auto fetch_rec = [&](int s, int l) {   // branch-free like fetch_x; c_prev of step 0 (the trainable c0) is patched in at the use
     const int h = size_of(l + 1), R = G * h;
-    const float* r = a.rec + (((size_t)s * L + l) * B + (size_t)b) * rd.recw;
+    const int uc = u < h ? u : h - 1;
+    const float* r = a.rec + (((size_t)s * L + l) * B + bc) * rd.recw;
 #pragma unroll
-    for (int g = 0; g < 4; g++) rq[g] = (valid && u < h && g < G) ? r[g * h + u] : 0.f;
-    rq[4] = (valid && u < h && lstm) ? r[R + u] : 0.f;
+    for (int g = 0; g < 4; g++) rq[g] = g < G ? r[g * h + uc] : 0.f;
+    rq[4] = 0.f;
     rq[5] = 0.f;
-    if (valid && u < h && lstm)
-      rq[5] = s > 0 ? a.rec[(((size_t)(s - 1) * L + l) * B + (size_t)b) * rd.recw + R + u] : lw[rd.s_off[l] + h + u];
+    if (lstm) {
+      rq[4] = r[R + uc];
+      rq[5] = a.rec[(((size_t)(s > 0 ? s - 1 : 0) * L + l) * B + bc) * rd.recw + R + uc];
+    }
   };
   fetch_rec(T - 1, L - 1);
   for (int s = T - 1; s >= 0; s--) {
@@ -240,16 +265,20 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
     for (int l = L - 1; l >= 0; l--) {
       const int in = size_of(l), h = size_of(l + 1), K = in + h, R = G * h, ldk = ldk_of(l);
       const int K32 = pad32(K), R32 = pad32(R);
+      PROF_T(q0);
       float cur[6];
 #pragma unroll
       for (int q = 0; q < 6; q++) cur[q] = rq[q];
       if (l > 0) fetch_rec(s, l - 1);
-      else if (s > 0) fetch_rec(s - 1, L - 1);
+      else fetch_rec(s > 0 ? s - 1 : 0, L - 1);
+      PROF_T(q1);
+      PROF_ADD(10, q0, q1);
       // gate deltas of this lane's unit
       if (u < h) {
         const float dh = dhs[l * hmaxv + u];
         if (lstm) {
-          const float ig = cur[0], fg = cur[1], gg = cur[2], og = cur[3], cn = cur[4], cp = cur[5];
+          const float ig = cur[0], fg = cur[1], gg = cur[2], og = cur[3], cn = cur[4];
+          const float cp = s > 0 ? cur[5] : lw[rd.s_off[l] + h + u];
           const float tc = fast_tanh(cn);
           const float dct = dcs[l * hmaxv + u] + dh * og * (1.f - tc * tc);
           dbuf[u] = dct * gg * ig * (1.f - ig);
@@ -262,23 +291,35 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
           dbuf[u] = dh * (cellk == LDE_CELL_RNN_TANH ? 1.f - av * av : (av > 0.f ? 1.f : 0.f));
         }
       }
+      PROF_T(q2);
+      PROF_ADD(11, q1, q2);
       {   // the δ-panel next to the a-panel the forward sweep staged
         float* gd = a.stage[l] + (tile * T + s) * a.blk[l] + NB * K32 + row * R32;
         for (int k = u; k < R32; k += Hp) gd[k] = (valid && k < R) ? dbuf[k] : 0.f;
       }
+      PROF_T(q3);
+      PROF_ADD(12, q2, q3);
       // [d_in ; dh_prev] = [Wi | Wh]ᵀ δ: lane u owns the outputs k = u, u+Hp, …; four rows of δ per step, independent sums
+      const bool wt = SP || rd.wt;
       for (int k = u; k < K; k += Hp) {
         const float* wc = lw + rd.w_off[l] + k;
         f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
         const int R4 = R >> 2;
+        if (wt) {   // row k of the transposed copy · δ, 16 bytes at a time (same shape of loop as the forward dot product)
+          const float* wk = lw + rd.wt_off[l] + k * (SP ? rnn_ldk(R) : rd.ldr[l]);
 #pragma unroll UK
-        for (int r4 = 0; r4 < R4; r4++) {
-          const f32x4 dq = *reinterpret_cast<const f32x4*>(dbuf + 4 * r4);
-          const float* w = wc + (4 * r4) * ldk;
-          acc4[0] += w[0] * dq[0];
-          acc4[1] += w[ldk] * dq[1];
-          acc4[2] += w[2 * ldk] * dq[2];
-          acc4[3] += w[3 * ldk] * dq[3];
+          for (int r4 = 0; r4 < R4; r4++)
+            acc4 += *reinterpret_cast<const f32x4*>(wk + 4 * r4) * *reinterpret_cast<const f32x4*>(dbuf + 4 * r4);
+        } else {
+#pragma unroll 4
+          for (int r4 = 0; r4 < R4; r4++) {
+            const f32x4 dq = *reinterpret_cast<const f32x4*>(dbuf + 4 * r4);
+            const float* w = wc + (4 * r4) * ldk;
+            acc4[0] += w[0] * dq[0];
+            acc4[1] += w[ldk] * dq[1];
+            acc4[2] += w[2 * ldk] * dq[2];
+            acc4[3] += w[3 * ldk] * dq[3];
+          }
         }
         float acc = (acc4[0] + acc4[1]) + (acc4[2] + acc4[3]);
         for (int rr = 4 * R4; rr < R; rr++) acc += wc[rr * ldk] * dbuf[rr];
@@ -288,6 +329,8 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
         } else
           dhs[l * hmaxv + (k - in)] = acc;
       }
+      PROF_T(q4);
+      PROF_ADD(13, q3, q4);
     }
   }
   // what is left flows into the trainable initial states
@@ -350,7 +393,7 @@ struct lde_rnn {
   float* g0 = nullptr; size_t g0_cap = 0;
   float* slab = nullptr; size_t slab_cap = 0;
   int32_t* ints = nullptr; size_t ints_cap = 0;
-  void (*kernel)(lde::RnnDims, lde::RnnArgs) = nullptr;   // the k_rnn instantiation for this stack
+  void (*kernel[2])(lde::RnnDims, lde::RnnArgs) = {nullptr, nullptr};   // the k_rnn instantiations for this stack: forward, pullback
   std::string err;
 };
 
@@ -438,6 +481,17 @@ int lde_rnn_create(const lde_rnn_desc* d, lde_rnn** out) {
     size_t nf, nft;
     fill_layer_offsets(dm, &nf, &nft);
   }
+  {   // transposed copies for the pullback, when they fit beside everything else
+    int offT = off;
+    for (int l = 0; l < rd.nL; l++) {
+      rd.ldr[l] = rnn_ldk(rd.G * rd.sizes[l + 1]);
+      rd.wt_off[l] = offT;
+      offT += rd.K[l] * rd.ldr[l];
+    }
+    const size_t per_traj = (size_t)((kmax + 3) & ~3) + 4 + ((rmax + 3) & ~3) + 4 * rd.nL * hmax;
+    rd.wt = ((size_t)offT + 16 * per_traj) * sizeof(float) <= LDS_MAX ? 1 : 0;
+    if (rd.wt) off = offT;
+  }
   rd.lds_w = off;
   rd.vmax = ((kmax + 3) & ~3) + 4;
   rd.rmax = (rmax + 3) & ~3;
@@ -510,21 +564,22 @@ typedef void (*rnn_kernel_t)(RnnDims, RnnArgs);
 
 // the instantiation for this stack: the reference's default pattern extractors (32 → 16 → 16) have their own, any other shape
 // runs the run-time-shaped kernel
-static rnn_kernel_t rnn_pick(const RnnDims& rd) {
+static rnn_kernel_t rnn_pick(const RnnDims& rd, int mode) {
   static const bool generic_only = std::getenv("LDE_RNN_GENERIC") && std::atoi(std::getenv("LDE_RNN_GENERIC")) != 0;
-  if (!generic_only && rd.nL == 2 && rd.sizes[0] == 32 && rd.sizes[1] == 16 && rd.sizes[2] == 16) {
-    if (rd.cell == LDE_CELL_LSTM) return k_rnn<LDE_CELL_LSTM, 32, 16, 2>;
-    if (rd.cell == LDE_CELL_RNN_RELU) return k_rnn<LDE_CELL_RNN_RELU, 32, 16, 2>;
-    if (rd.cell == LDE_CELL_RNN_TANH) return k_rnn<LDE_CELL_RNN_TANH, 32, 16, 2>;
+  if (!generic_only && rd.wt && rd.nL == 2 && rd.sizes[0] == 32 && rd.sizes[1] == 16 && rd.sizes[2] == 16) {
+    if (rd.cell == LDE_CELL_LSTM) return mode ? k_rnn<LDE_CELL_LSTM, 32, 16, 2, 1> : k_rnn<LDE_CELL_LSTM, 32, 16, 2, 0>;
+    if (rd.cell == LDE_CELL_RNN_RELU) return mode ? k_rnn<LDE_CELL_RNN_RELU, 32, 16, 2, 1> : k_rnn<LDE_CELL_RNN_RELU, 32, 16, 2, 0>;
+    if (rd.cell == LDE_CELL_RNN_TANH) return mode ? k_rnn<LDE_CELL_RNN_TANH, 32, 16, 2, 1> : k_rnn<LDE_CELL_RNN_TANH, 32, 16, 2, 0>;
   }
-  return k_rnn<-1, 0, 0, 0>;
+  return k_rnn<-1, 0, 0, 0, 0>;
 }
 
 static int rnn_launch(lde_rnn* r, const RnnArgs& a, int B, hipStream_t stream) {
-  if (!r->kernel) {
-    r->kernel = rnn_pick(r->rd);
-    if (hipFuncSetAttribute((const void*)r->kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
-      r->kernel = nullptr;
+  const int m = a.mode ? 1 : 0;
+  if (!r->kernel[m]) {
+    r->kernel[m] = rnn_pick(r->rd, m);
+    if (hipFuncSetAttribute((const void*)r->kernel[m], hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
+      r->kernel[m] = nullptr;
       r->err = "hipFuncSetAttribute(k_rnn) failed";
       return LDE_ERR_HIP;
     }
@@ -541,11 +596,28 @@ static int rnn_launch(lde_rnn* r, const RnnArgs& a, int B, hipStream_t stream) {
   aa.tpw = tpw;
   const size_t lds = ((size_t)r->rd.lds_w + tpw * ((size_t)r->rd.vmax + r->rd.rmax + 4 * r->rd.nL * r->rd.hmax)) * sizeof(float);
   // whole staging tiles are covered (rows past B write zero panels and zero column weights)
-  hipLaunchKernelGGL(r->kernel, dim3(cdiv(B, 16) * (16 / tpw)), dim3(tpw * r->rd.Hp), lds, stream, r->rd, aa);
+#if LDE_PROF
+  { long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
+#endif
+  hipLaunchKernelGGL(r->kernel[m], dim3(cdiv(B, 16) * (16 / tpw)), dim3(tpw * r->rd.Hp), lds, stream, r->rd, aa);
   if (hipGetLastError() != hipSuccess) {
     r->err = "k_rnn launch failed";
     return LDE_ERR_HIP;
   }
+#if LDE_PROF
+  {
+    static int calls = 0;
+    (void)hipStreamSynchronize(stream);
+    long long v[64];
+    (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(g_prof), sizeof(v));
+    if (++calls % 20 == 0) {
+      fprintf(stderr, "[prof rnn mode %d cell %d] cycles:", m, r->rd.cell);
+      for (int i = 0; i < 64; i++)
+        if (v[i]) fprintf(stderr, " %d:%lld", i, v[i]);
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
   return LDE_OK;
 }
 

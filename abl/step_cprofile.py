@@ -10,7 +10,7 @@ enc, dec = TR.default_layers(mt, NI, diffeq, device="cuda")
 with torch.no_grad():
     dec[0][1]._dense[-1].bias.fill_(1.0)
 model = TR.LatentDiffEqModel(mt, enc, dec)
-opt = torch.optim.AdamW(model.parameters(), lr=1e-3)
+opt = torch.optim.AdamW(model.parameters(), lr=1e-3, fused=True)
 x = torch.rand(T, B, NI, device="cuda").permute(2, 1, 0); ts = np.arange(T) * 0.05
 def step():
     opt.zero_grad(set_to_none=True)

@@ -12,7 +12,7 @@ with torch.no_grad():
     dec[0][1]._dense[-1].bias.fill_(1.0)
 model = TR.LatentDiffEqModel(mt, enc, dec)
 params = model.parameters()
-opt = torch.optim.AdamW(params, lr=1e-3)
+opt = torch.optim.AdamW(params, lr=1e-3, fused=True)
 x = torch.rand(NI, B, T, device="cuda"); ts = np.arange(T) * 0.05
 def step():
     opt.zero_grad(set_to_none=True)

@@ -340,7 +340,8 @@ def run_goku_step(args, torch, dist, world, rank, local):
     import latentdiffeq_amd as M
     from latentdiffeq_amd.chain import decode, default_decoder_layers
     from latentdiffeq_amd.dist import FlatGradAllReduce
-    from latentdiffeq_amd.recurrent import Encoder, default_encoder_layers, encode, sample
+    from latentdiffeq_amd.loss import reconstruction_loss, sample, vector_kl
+    from latentdiffeq_amd.recurrent import Encoder, default_encoder_layers, encode
     B = args.batch or 256
     T, NI = 50, 784
     dev = torch.device("cuda", local)
@@ -354,7 +355,7 @@ def run_goku_step(args, torch, dist, world, rank, local):
         lo_th._dense[-1].bias.fill_(1.0)
     mods = [enc.feature_extractor, *enc.pattern_extractor, *enc.latent_in, lo_z0, lo_th, dec.reconstructor]
     params = [p for m in mods for p in m.parameters()]
-    opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=1e-10)            # [REF model_train.jl:138, :150]
+    opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=1e-10, fused=True)   # [REF model_train.jl:138, :150]; one fused update kernel
     sync = FlatGradAllReduce(params)
     torch.manual_seed(1000 + rank)
     x = torch.rand(T, B, NI, device=dev).permute(2, 1, 0)                   # synthetic frames in [0, 1], this rank's shard: [pixels, B, T] in the
@@ -367,9 +368,7 @@ def run_goku_step(args, torch, dist, world, rank, local):
         mu, logvar = encode(enc, x)
         l_tilde = sample(mu, logvar)
         x_hat, z_hat, l_hat = decode(dec, l_tilde, ts)
-        rec = ((x_hat - x) ** 2).sum() / (NI * Bg * T) * NI                  # Σ_pixels mean_{B,T}  [REF model_train.jl:232]
-        kl = sum((-0.5 * (1 + s - m ** 2 - torch.exp(s))).sum() for m, s in zip(mu, logvar)) / Bg
-        loss = rec + 1e-3 * kl
+        loss = reconstruction_loss(x, x_hat, Bg) + 1e-3 * vector_kl(mu, logvar, Bg)   # Σ_pixels mean_{B,T} + β·KL  [REF model_train.jl:225-238]
         loss.backward()
         sync()
         opt.step()

@@ -284,6 +284,33 @@ int  lde_rnn_forward(lde_rnn* r, const float* x, int T, int B, float* y, void* s
 int  lde_rnn_backward(lde_rnn* r, const float* x, const float* dy, int T, int B, float* dx, float* dW, void* stream);
 const char* lde_rnn_last_error(const lde_rnn* r);
 
+/* ====================================================================================================================
+ * The variational sample and the loss terms (scope row f-3): what the example script computes between encoder and
+ * decoder and around the model's output. Stateless elementwise / reduction kernels; all pointers are device memory.
+ *
+ *   sample:  l̃ = μ + ε·exp(logσ²/2), ε ~ N(0,1) supplied by the caller   [REF src/models/GOKU.jl:155-163],
+ *                                                                        [REF src/models/LatentODE.jl:82-89]
+ *   kl:      out = scale · Σ_i (exp(logσ²_i) + μ_i² − logσ²_i − 1)/2      [REF src/utils/utils.jl:15-49]  (scale = 1/B)
+ *   mse:     out = scale · Σ_i (x_i − x̂_i)²                              [REF examples/pendulum_friction-less/
+ *            (sum(mean(·, dims=(2,3))) ⇒ scale = 1/(B·T))                       model_train.jl:225-238]
+ *
+ * Reductions run in a fixed order (per-workgroup partial sums in `scratch`, combined by index): results are
+ * bit-reproducible. `scratch` must hold LDE_LOSS_SCRATCH_FLOATS floats and must not be shared by concurrent calls.
+ * The pullbacks take the cotangent of the scalar output as a DEVICE pointer (no host synchronisation).
+ * ==================================================================================================================== */
+#define LDE_LOSS_SCRATCH_FLOATS 1024
+
+int lde_sample_forward(const float* mu, const float* logvar, const float* eps, int64_t n, float* l, void* stream);
+/* dμ = dl (not written: it is the input); dlogvar_i = dl_i · ε_i · exp(logσ²_i/2) / 2 */
+int lde_sample_backward(const float* logvar, const float* eps, const float* dl, int64_t n, float* dlogvar, void* stream);
+int lde_kl_forward(const float* mu, const float* logvar, int64_t n, float scale, float* out, float* scratch, void* stream);
+/* dμ_i = g·scale·μ_i,  dlogvar_i = g·scale·(exp(logσ²_i) − 1)/2,  g = *dout */
+int lde_kl_backward(const float* mu, const float* logvar, int64_t n, float scale, const float* dout, float* dmu,
+                    float* dlogvar, void* stream);
+int lde_mse_forward(const float* x, const float* xhat, int64_t n, float scale, float* out, float* scratch, void* stream);
+/* dx̂_i = g·scale·2·(x̂_i − x_i),  g = *dout */
+int lde_mse_backward(const float* x, const float* xhat, int64_t n, float scale, const float* dout, float* dxhat, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

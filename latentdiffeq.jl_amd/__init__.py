@@ -8,7 +8,8 @@ Layout:
              GOKU_basic / LatentODE, Decoder, diffeq_layer, transform_after_diffeq
   chain.py   Dense / SkipConnection / Chain, apply_latent_out, apply_reconstructor (the dense chains either side of the solve)
   recurrent.py  RNN / LSTM / Recurrent, Encoder, apply_feature_extractor / _pattern_extractor / _latent_in, sample
-  train.py   LatentDiffEqModel, default_layers, loss_batch, vector_kl, frange_cycle_linear, time_loader, train (host only)
+  loss.py    sample, vector_kl, reconstruction_loss (lde_sample_* / lde_kl_* / lde_mse_*)
+  train.py   LatentDiffEqModel, default_layers, loss_batch, frange_cycle_linear, time_loader, train (host only)
   data.py    generate_dataset, create_frames: synthetic pendulum videos (approximation of the Luxor drawing)
   dist.py    one-process-per-GPU batch sharding + the single gradient all-reduce (RCCL / gloo)
 """
@@ -23,7 +24,7 @@ def __getattr__(name):  # lazy: importing the package must not need torch or the
             return importlib.import_module(f"{__name__}.{name}")
         except ModuleNotFoundError:
             raise AttributeError(name) from None
-    for mod in ("api", "dist", "chain", "recurrent", "train", "data"):
+    for mod in ("api", "dist", "chain", "recurrent", "loss", "train", "data"):
         try:
             m = importlib.import_module(f"{__name__}.{mod}")
         except ModuleNotFoundError:

@@ -32,7 +32,10 @@ EXPORTS = ["lde_abi_version", "lde_problem_desc_default", "lde_num_weights", "ld
            "lde_chain_set_weights_device", "lde_chain_reserve", "lde_chain_forward", "lde_chain_backward",
            "lde_chain_last_error", "lde_chain_saved_floats", "lde_chain_forward_save", "lde_chain_backward_saved",
            "lde_rnn_num_weights", "lde_rnn_create", "lde_rnn_destroy", "lde_rnn_set_weights", "lde_rnn_set_weights_device",
-           "lde_rnn_reserve", "lde_rnn_forward", "lde_rnn_backward", "lde_rnn_last_error"]
+           "lde_rnn_reserve", "lde_rnn_forward", "lde_rnn_backward", "lde_rnn_last_error",
+           "lde_sample_forward", "lde_sample_backward", "lde_kl_forward", "lde_kl_backward", "lde_mse_forward",
+           "lde_mse_backward"]
+LOSS_SCRATCH_FLOATS = 1024
 
 LDE_RNN_MAX_LAYERS = 4
 CELL_RNN_RELU, CELL_RNN_TANH, CELL_LSTM = 0, 1, 2
@@ -135,6 +138,13 @@ def load():
     lib.lde_rnn_backward.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     lib.lde_rnn_last_error.argtypes = [vp]
     lib.lde_rnn_last_error.restype = C.c_char_p
+    f32 = C.c_float
+    lib.lde_sample_forward.argtypes = [vp, vp, vp, i64, vp, vp]
+    lib.lde_sample_backward.argtypes = [vp, vp, vp, i64, vp, vp]
+    lib.lde_kl_forward.argtypes = [vp, vp, i64, f32, vp, vp, vp]
+    lib.lde_kl_backward.argtypes = [vp, vp, i64, f32, vp, vp, vp, vp]
+    lib.lde_mse_forward.argtypes = [vp, vp, i64, f32, vp, vp, vp]
+    lib.lde_mse_backward.argtypes = [vp, vp, i64, f32, vp, vp, vp]
     if lib.lde_abi_version() != LDE_ABI_VERSION:
         raise LdeError("liblde.so ABI version mismatch — rebuild")
     _lib = lib

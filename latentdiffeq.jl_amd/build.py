@@ -15,7 +15,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "liblde.so")
-SOURCES = ["lde_api.hip", "lde_pendulum.hip", "lde_mlp.hip", "lde_chain.hip", "lde_rnn.hip"]
+SOURCES = ["lde_api.hip", "lde_pendulum.hip", "lde_mlp.hip", "lde_chain.hip", "lde_rnn.hip", "lde_loss.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
 
 

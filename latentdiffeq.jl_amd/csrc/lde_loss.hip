@@ -1,0 +1,197 @@
+// lde_loss.hip — the variational sample and the loss terms of the training step (scope row f-3).
+//
+// Replaces what the example script runs as broadcast expressions between the encoder and the decoder and around the model's
+// output:  sample(μ, logσ²)  [REF src/models/GOKU.jl:155-163],  vector_kl  [REF src/utils/utils.jl:15-49],  and
+// reconstruction_loss = sum(mean((x − x̂)², dims=(2,3)))  [REF examples/pendulum_friction-less/model_train.jl:225-238].
+//
+// Design (gfx950). Pure HBM-bound streaming: one pass over the operands per call, 16-byte accesses, no LDS staging of data.
+// The two reductions are bit-reproducible: a fixed grid of workgroups (a function of n only) each sums a contiguous,
+// 16-byte-aligned slice in a fixed order (per-lane strided running sums → wave DPP tree → one LDS exchange per workgroup),
+// writes its partial to `scratch`, and a one-wave kernel adds the partials by index. No atomics anywhere.
+// Algorithmic bytes: sample 16 B/element (3 reads + 1 write), its pullback 16 B, kl 8 B, its pullback 16 B, mse 8 B, its
+// pullback 12 B.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "../../include/lde.h"
+
+namespace lde {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int LOSS_WG = 256;                    // threads per workgroup
+constexpr int LOSS_CHUNK = 4 * LOSS_WG * 8;     // floats per workgroup pass: 8 × 16-byte loads per lane
+
+static inline int loss_grid(int64_t n) {   // a function of n only ⇒ the summation order is too
+  const int64_t g = (n + LOSS_CHUNK - 1) / LOSS_CHUNK;
+  return (int)(g < 1 ? 1 : (g > LDE_LOSS_SCRATCH_FLOATS ? LDE_LOSS_SCRATCH_FLOATS : g));
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// workgroup sum of one value per thread, fixed order; result valid in thread 0
+__device__ __forceinline__ float wg_sum(float v) {
+  __shared__ float part[LOSS_WG / 64];
+  v = wave_sum(v);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < LOSS_WG / 64; w++) s += part[w];
+  return s;
+}
+
+__device__ __forceinline__ float kl_term(float m, float lv) { return 0.5f * (__expf(lv) + m * m - lv - 1.0f); }
+
+// TERM 0: kl(a = μ, b = logσ²); TERM 1: (a − b)²
+template <int TERM>
+__global__ void __launch_bounds__(LOSS_WG) k_loss_partial(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                                          float* __restrict__ scratch) {
+  // workgroup w owns the slice [w·per, (w+1)·per) with per a multiple of 4 floats
+  const int64_t nwg = gridDim.x;
+  int64_t per = (n + nwg - 1) / nwg;
+  per = (per + 3) & ~(int64_t)3;
+  const int64_t lo = (int64_t)blockIdx.x * per;
+  int64_t hi = lo + per;
+  if (hi > n) hi = n;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  const bool al = ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0;
+  int64_t i = lo + 4 * (int64_t)threadIdx.x;
+  if (al) {
+    for (; i + 4 <= hi; i += 4 * LOSS_WG) {
+      const f4 va = *reinterpret_cast<const f4*>(a + i), vb = *reinterpret_cast<const f4*>(b + i);
+      if (TERM == 0) {
+        s0 += kl_term(va[0], vb[0]); s1 += kl_term(va[1], vb[1]); s2 += kl_term(va[2], vb[2]); s3 += kl_term(va[3], vb[3]);
+      } else {
+        const f4 d = va - vb;
+        s0 += d[0] * d[0]; s1 += d[1] * d[1]; s2 += d[2] * d[2]; s3 += d[3] * d[3];
+      }
+    }
+  }
+  for (; i < hi; i += 4 * LOSS_WG)   // unaligned operands, and the ragged end of the last slice
+    for (int q = 0; q < 4 && i + q < hi; q++) {
+      const float x = a[i + q], y = b[i + q];
+      s0 += TERM == 0 ? kl_term(x, y) : (x - y) * (x - y);
+    }
+  const float s = wg_sum((s0 + s1) + (s2 + s3));
+  if (threadIdx.x == 0) scratch[blockIdx.x] = s;
+}
+
+__global__ void __launch_bounds__(64) k_loss_final(const float* __restrict__ scratch, int nwg, float scale, float* __restrict__ out) {
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nwg; i += 64) s += scratch[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) out[0] = scale * s;
+}
+
+// OP 0: l = μ + ε·exp(lv/2)                           (a = μ, b = lv, c = ε → o0)
+// OP 1: dlv = dl·ε·exp(lv/2)/2                        (a = lv, b = ε, c = dl → o0)
+// OP 2: dμ = k·μ, dlv = k·(exp(lv) − 1)/2, k = g·scale (a = μ, b = lv → o0, o1)
+// OP 3: dx̂ = 2k·(x̂ − x)                              (a = x, b = x̂ → o0)
+template <int OP>
+__device__ __forceinline__ void loss_map1(float a, float b, float c, float k, float& o0, float& o1) {
+  if (OP == 0) o0 = a + c * __expf(0.5f * b);
+  else if (OP == 1) o0 = 0.5f * c * b * __expf(0.5f * a);
+  else if (OP == 2) { o0 = k * a; o1 = 0.5f * k * (__expf(b) - 1.0f); }
+  else o0 = 2.0f * k * (b - a);
+}
+
+template <int OP>
+__global__ void __launch_bounds__(LOSS_WG) k_loss_map(const float* __restrict__ a, const float* __restrict__ b,
+                                                      const float* __restrict__ c, const float* __restrict__ g, float scale,
+                                                      int64_t n, float* __restrict__ o0, float* __restrict__ o1) {
+  const float k = g ? g[0] * scale : scale;
+  const bool three = OP == 0 || OP == 1, two_out = OP == 2;
+  const bool al = ((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)(three ? c : a)) | ((uintptr_t)o0) | ((uintptr_t)(two_out ? o1 : o0))) & 15) == 0;
+  const int64_t stride = 4 * (int64_t)gridDim.x * LOSS_WG;
+  int64_t i = 4 * ((int64_t)blockIdx.x * LOSS_WG + threadIdx.x);
+  if (al) {
+    for (; i + 4 <= n; i += stride) {
+      const f4 va = *reinterpret_cast<const f4*>(a + i), vb = *reinterpret_cast<const f4*>(b + i);
+      f4 vc = {0.f, 0.f, 0.f, 0.f}, r0, r1;
+      if (three) vc = *reinterpret_cast<const f4*>(c + i);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        float t0, t1 = 0.f;
+        loss_map1<OP>(va[q], vb[q], vc[q], k, t0, t1);
+        r0[q] = t0;
+        r1[q] = t1;
+      }
+      *reinterpret_cast<f4*>(o0 + i) = r0;
+      if (two_out) *reinterpret_cast<f4*>(o1 + i) = r1;
+    }
+  }
+  for (; i < n; i += stride)
+    for (int q = 0; q < 4 && i + q < n; q++) {
+      float r0, r1 = 0.f;
+      loss_map1<OP>(a[i + q], b[i + q], three ? c[i + q] : 0.f, k, r0, r1);
+      o0[i + q] = r0;
+      if (two_out) o1[i + q] = r1;
+    }
+}
+
+static inline int map_grid(int64_t n) {
+  const int64_t g = (n + 4 * LOSS_WG - 1) / (4 * LOSS_WG);
+  return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
+}
+
+template <int TERM>
+static int loss_reduce(const float* a, const float* b, int64_t n, float scale, float* out, float* scratch, void* stream_) {
+  if (!out || !scratch || n < 0 || (n > 0 && (!a || !b))) return LDE_ERR_INVALID_ARG;
+  hipStream_t stream = (hipStream_t)stream_;
+  const int g = n == 0 ? 0 : loss_grid(n);   // an empty sum is 0
+  if (g) hipLaunchKernelGGL(k_loss_partial<TERM>, dim3(g), dim3(LOSS_WG), 0, stream, a, b, n, scratch);
+  hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(64), 0, stream, scratch, g, scale, out);
+  return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
+}
+
+template <int OP>
+static int loss_map(const float* a, const float* b, const float* c, const float* g, float scale, int64_t n, float* o0, float* o1,
+                    void* stream_) {
+  if (n < 0) return LDE_ERR_INVALID_ARG;
+  if (n == 0) return LDE_OK;
+  hipLaunchKernelGGL(k_loss_map<OP>, dim3(map_grid(n)), dim3(LOSS_WG), 0, (hipStream_t)stream_, a, b, c, g, scale, n, o0, o1);
+  return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
+}
+
+}  // namespace lde
+
+using namespace lde;
+
+extern "C" {
+
+int lde_sample_forward(const float* mu, const float* logvar, const float* eps, int64_t n, float* l, void* stream) {
+  if (n > 0 && (!mu || !logvar || !eps || !l)) return LDE_ERR_INVALID_ARG;
+  return loss_map<0>(mu, logvar, eps, nullptr, 1.0f, n, l, nullptr, stream);
+}
+
+int lde_sample_backward(const float* logvar, const float* eps, const float* dl, int64_t n, float* dlogvar, void* stream) {
+  if (n > 0 && (!logvar || !eps || !dl || !dlogvar)) return LDE_ERR_INVALID_ARG;
+  return loss_map<1>(logvar, eps, dl, nullptr, 1.0f, n, dlogvar, nullptr, stream);
+}
+
+int lde_kl_forward(const float* mu, const float* logvar, int64_t n, float scale, float* out, float* scratch, void* stream) {
+  return loss_reduce<0>(mu, logvar, n, scale, out, scratch, stream);
+}
+
+int lde_kl_backward(const float* mu, const float* logvar, int64_t n, float scale, const float* dout, float* dmu, float* dlogvar,
+                    void* stream) {
+  if (n > 0 && (!mu || !logvar || !dout || !dmu || !dlogvar)) return LDE_ERR_INVALID_ARG;
+  return loss_map<2>(mu, logvar, nullptr, dout, scale, n, dmu, dlogvar, stream);
+}
+
+int lde_mse_forward(const float* x, const float* xhat, int64_t n, float scale, float* out, float* scratch, void* stream) {
+  return loss_reduce<1>(x, xhat, n, scale, out, scratch, stream);
+}
+
+int lde_mse_backward(const float* x, const float* xhat, int64_t n, float scale, const float* dout, float* dxhat, void* stream) {
+  if (n > 0 && (!x || !xhat || !dout || !dxhat)) return LDE_ERR_INVALID_ARG;
+  return loss_map<3>(x, xhat, nullptr, dout, scale, n, dxhat, nullptr, stream);
+}
+
+}  // extern "C"

@@ -1,0 +1,157 @@
+"""Host-side mirror of the variational sample and the loss terms (scope row f-3):
+
+    reference                                                                          here
+    ---------------------------------------------------------------------------------  ------------------------------
+    sample(μ, logσ²) = μ + ε·exp(logσ²/2)   [REF GOKU.jl:155-163], [REF LatentODE.jl:82-89]     sample(mu, logvar)
+    kl(μ, logσ²), vector_kl                  [REF src/utils/utils.jl:15-49]                      kl, vector_kl
+    reconstruction_loss = sum(mean((x − x̂)², dims=(2,3)))   [REF model_train.jl:225-238]        reconstruction_loss
+
+On HIP tensors every function is one liblde.so kernel (two for the reductions) forward and one backward
+(lde_sample_* / lde_kl_* / lde_mse_*, include/lde.h): no chain of broadcast kernels, no host synchronisation. ε is drawn
+with torch.randn (the caller's generator), like the reference draws it with randn. There is no CPU path."""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def _p(t):
+    return C.c_void_p(t.data_ptr())
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _need_gpu(t):
+    if not t.is_cuda:
+        raise L.LdeError("the loss kernels run on the GPU only (no CPU fallback)")
+
+
+class _SampleFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, logvar, eps):
+        _need_gpu(mu)
+        lib = L.load()
+        mu, logvar = mu.contiguous().float(), logvar.contiguous().float()
+        out = torch.empty_like(mu)
+        L.check(lib.lde_sample_forward(_p(mu), _p(logvar), _p(eps), mu.numel(), _p(out), _stream()), None, "lde_sample_forward")
+        ctx.save_for_backward(logvar, eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, dl):
+        logvar, eps = ctx.saved_tensors
+        dl = dl.contiguous()
+        dlv = torch.empty_like(logvar)
+        L.check(L.load().lde_sample_backward(_p(logvar), _p(eps), _p(dl), dl.numel(), _p(dlv), _stream()), None,
+                "lde_sample_backward")
+        return dl, dlv, None
+
+
+class _KlFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, mu, logvar, scale):
+        _need_gpu(mu)
+        lib = L.load()
+        mu, logvar = mu.contiguous().float(), logvar.contiguous().float()
+        ws = torch.empty(L.LOSS_SCRATCH_FLOATS + 1, device=mu.device, dtype=torch.float32)     # [0]: the result, then scratch
+        L.check(lib.lde_kl_forward(_p(mu), _p(logvar), mu.numel(), scale, _p(ws), C.c_void_p(ws.data_ptr() + 4), _stream()),
+                None, "lde_kl_forward")
+        ctx.save_for_backward(mu, logvar)
+        ctx.scale = scale
+        return ws[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        mu, logvar = ctx.saved_tensors
+        g = g.contiguous().float()
+        dmu, dlv = torch.empty_like(mu), torch.empty_like(logvar)
+        L.check(L.load().lde_kl_backward(_p(mu), _p(logvar), mu.numel(), ctx.scale, _p(g), _p(dmu), _p(dlv), _stream()), None,
+                "lde_kl_backward")
+        return dmu, dlv, None
+
+
+class _MseFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, xhat, scale):
+        _need_gpu(xhat)
+        lib = L.load()
+        ws = torch.empty(L.LOSS_SCRATCH_FLOATS + 1, device=xhat.device, dtype=torch.float32)
+        L.check(lib.lde_mse_forward(_p(x), _p(xhat), xhat.numel(), scale, _p(ws), C.c_void_p(ws.data_ptr() + 4), _stream()),
+                None, "lde_mse_forward")
+        ctx.save_for_backward(x, xhat)
+        ctx.scale = scale
+        return ws[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, xhat = ctx.saved_tensors
+        g = g.contiguous().float()
+        dxh = torch.empty_like(xhat)
+        L.check(L.load().lde_mse_backward(_p(x), _p(xhat), xhat.numel(), ctx.scale, _p(g), _p(dxh), _stream()), None,
+                "lde_mse_backward")
+        return None, dxh, None
+
+
+def _same_layout(a: torch.Tensor, b: torch.Tensor):
+    """a and b brought to contiguous buffers with the SAME element order."""
+    if a.shape != b.shape:
+        raise ValueError("operands differ in shape")
+    if a.is_contiguous() and b.is_contiguous():
+        return a, b
+    order = sorted(range(b.dim()), key=lambda d: -b.stride(d))
+    a2, b2 = a.permute(order), b.permute(order)
+    if not b2.is_contiguous():
+        b2 = b2.contiguous()
+    if not a2.is_contiguous():
+        a2 = a2.contiguous()
+    return a2, b2
+
+
+def _sample1(mu, logvar):
+    m, s = _same_layout(mu.float(), logvar.float())
+    eps = torch.randn(m.shape, device=m.device, dtype=torch.float32)
+    out = _SampleFn.apply(m, s, eps)
+    if m.shape != mu.shape:                      # undo the common permutation
+        order = sorted(range(logvar.dim()), key=lambda d: -logvar.stride(d))
+        inv = [order.index(d) for d in range(mu.dim())]
+        out = out.permute(inv)
+    return out
+
+
+def sample(mu, logvar, model_type=None):
+    """l̃ = μ + ε·exp(logσ²/2), ε ~ N(0, 1)  [REF src/models/GOKU.jl:155-163], [REF src/models/LatentODE.jl:82-89]."""
+    if isinstance(mu, tuple):
+        return tuple(_sample1(m, s) for m, s in zip(mu, logvar))
+    return _sample1(mu, logvar)
+
+
+def _kl_sum(mu, logvar, scale: float):
+    m, s = _same_layout(mu.float(), logvar.float())
+    return _KlFn.apply(m, s, float(scale))
+
+
+def vector_kl(mu, logvar, batch_size=None):
+    """Σ over entries of kl(μ, logσ²) = (exp(logσ²) + μ² − logσ² − 1)/2, divided by the batch size (the columns; or the global
+    `batch_size` when the arrays are one rank's shard); for the GOKU tuple the sum of both parts  [REF src/utils/utils.jl:15-49]."""
+    if isinstance(mu, tuple):
+        parts = [_kl_sum(m, s, 1.0 / (batch_size or m.shape[1])) for m, s in zip(mu, logvar)]
+        out = parts[0]
+        for p in parts[1:]:
+            out = out + p
+        return out
+    return _kl_sum(mu, logvar, 1.0 / (batch_size or mu.shape[1]))
+
+
+def reconstruction_loss(x, x_hat, batch_size=None):
+    """sum(mean((x − x̂)², dims=(2,3))) for x, x̂ [pixels, B, T]  [REF examples/pendulum_friction-less/model_train.jl:225-238]
+    (`batch_size`: the global B when the arrays are one rank's shard)."""
+    xs, xh = _same_layout(x.float(), x_hat.float())
+    n_mean = batch_size or x_hat.shape[1]
+    for d in x_hat.shape[2:]:
+        n_mean *= d
+    return _MseFn.apply(xs, xh, 1.0 / n_mean)

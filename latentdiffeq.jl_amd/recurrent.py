@@ -13,7 +13,7 @@ around it.
     sample(μ, logσ², model)                            [REF GOKU.jl:155-163], [REF LatentODE.jl:82-89]  sample
 
 `Recurrent.__call__` is liblde.so (lde_rnn_forward / lde_rnn_backward, include/lde.h); the feature extractor and
-latent_in are `Chain`s (lde_chain_*). `sample` is the host-side reparameterisation (torch RNG — not on the kernel path).
+latent_in are `Chain`s (lde_chain_*). `sample` (loss.py) draws ε with torch's generator and forms l̃ in one kernel (lde_sample_*).
 """
 from __future__ import annotations
 
@@ -248,11 +248,7 @@ def encode(encoder: Encoder, x):
     return apply_latent_in(encoder, apply_pattern_extractor(encoder, apply_feature_extractor(encoder, x)))
 
 
-def sample(mu, logvar, model_type=None):
-    """l̃ = μ + ε·exp(logσ²/2), ε ~ N(0, 1)  [REF src/models/GOKU.jl:155-163], [REF src/models/LatentODE.jl:82-89]."""
-    if isinstance(mu, tuple):
-        return tuple(m + torch.randn_like(s) * torch.exp(s / 2) for m, s in zip(mu, logvar))
-    return mu + torch.randn_like(logvar) * torch.exp(logvar / 2)
+from .loss import sample  # noqa: E402,F401  (l̃ = μ + ε·exp(logσ²/2): lde_sample_forward / _backward)
 
 
 def default_encoder_layers(model_type, input_dim: int, diffeq=None, hidden_dim_resnet: int = 200, rnn_input_dim: int = 32,

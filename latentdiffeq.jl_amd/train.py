@@ -1,5 +1,6 @@
 """Host-side training harness (scope row f-3): what the reference's example script wraps around the model. Pure host code —
-the compute under `model(x, t)` is liblde.so (api.py, chain.py, recurrent.py); this file launches no kernel of its own.
+the compute under `model(x, t)` and the loss terms is liblde.so (api.py, chain.py, recurrent.py, loss.py); this file launches
+no kernel of its own.
 
     reference                                                                         here
     --------------------------------------------------------------------------------  -----------------------------
@@ -7,7 +8,7 @@ the compute under `model(x, t)` is liblde.so (api.py, chain.py, recurrent.py); t
                                                       [REF src/models/LatentDiffEqModel.jl:6-37]      LatentDiffEqModel
     default_layers(model_type, input_dim, diffeq)     [REF src/models/GOKU.jl:201-273]               default_layers
     loss_batch(model, x, t, β, variational)           [REF examples/pendulum_friction-less/model_train.jl:225-238]   loss_batch
-    kl, vector_kl                                     [REF src/utils/utils.jl:15-49]                  kl, vector_kl
+    kl, vector_kl                                     [REF src/utils/utils.jl:15-49]                  kl (elementwise), loss.vector_kl
     frange_cycle_linear(n_iter, start, stop, n_cycle, ratio)   [REF src/utils/utils.jl:53-66]         frange_cycle_linear
     normalize_to_unit_segment / denormalize_unit_segment       [REF src/utils/utils.jl:71-79]         same
     time_loader(x, full_seq_len, seq_len), rand_time  [REF src/utils/utils.jl:85-99]                  time_loader, rand_time
@@ -23,7 +24,8 @@ import torch
 
 from .api import Decoder
 from .chain import decode, default_decoder_layers
-from .recurrent import Encoder, default_encoder_layers, encode, sample
+from .loss import reconstruction_loss, sample, vector_kl  # noqa: F401
+from .recurrent import Encoder, default_encoder_layers, encode
 
 
 class LatentDiffEqModel:
@@ -64,18 +66,11 @@ def kl(mu, logvar):
     return (torch.exp(logvar) + mu ** 2 - logvar - 1) / 2
 
 
-def vector_kl(mu, logvar):
-    """Σ over entries of kl, divided by the batch size; for the GOKU tuple the sum of both parts  [REF utils.jl:17-49]."""
-    if isinstance(mu, tuple):
-        return sum(kl(m, s).sum() / m.shape[1] for m, s in zip(mu, logvar))
-    return kl(mu, logvar).sum() / mu.shape[1]
-
-
-def loss_batch(model, x, t, beta: float, variational: bool):
-    """reconstruction_loss + β·kl_loss with reconstruction_loss = sum(mean((x − x̂)², dims=(2,3)))  [REF model_train.jl:225-238]."""
+def loss_batch(model, x, t, beta: float, variational: bool, batch_size: Optional[int] = None):
+    """reconstruction_loss + β·kl_loss with reconstruction_loss = sum(mean((x − x̂)², dims=(2,3)))  [REF model_train.jl:225-238].
+    `batch_size`: the GLOBAL minibatch size when x is one rank's shard (the per-rank losses then add up to the reference's)."""
     (x_hat, _z, _l), mu, logvar = model(x, t, variational)
-    rec = ((x - x_hat) ** 2).mean(dim=(1, 2)).sum()
-    return rec + beta * vector_kl(mu, logvar)
+    return reconstruction_loss(x, x_hat, batch_size) + beta * vector_kl(mu, logvar, batch_size)
 
 
 def frange_cycle_linear(n_iter: int, start: float = 0.0, stop: float = 1.0, n_cycle: int = 4, ratio: float = 0.5) -> np.ndarray:
@@ -128,7 +123,8 @@ def train(model: LatentDiffEqModel, loader_train: Iterable, val_set, dt: float, 
     x [pixels, B, full_seq_len] tensors on the model's device; `grad_sync` is called between backward and the optimiser step
     (dist.FlatGradAllReduce for multi-GPU). Returns (history, best_state)."""
     params = model.parameters()
-    opt = torch.optim.AdamW(params, lr=lr, betas=(0.9, 0.999), weight_decay=decay)           # ADAMW(η, (0.9, 0.999), decay)
+    opt = torch.optim.AdamW(params, lr=lr, betas=(0.9, 0.999), weight_decay=decay,           # ADAMW(η, (0.9, 0.999), decay)
+                            fused=all(p.is_cuda for p in params))                            # one update kernel for all parameters
     schedule = frange_cycle_linear(epochs, start_beta, end_beta, n_cycle, ratio)
     if progressive_training:
         prog = np.rint(np.linspace(start_seq_len, seq_len, prog_training_duration)).astype(int)

@@ -320,3 +320,54 @@ def _rnn_backward(self, d: RnnDesc, W, x, dy, nthreads=0, need_dx=True):
 Oracle.rnn_num_weights = _rnn_num_weights
 Oracle.rnn_forward = _rnn_forward
 Oracle.rnn_backward = _rnn_backward
+
+
+# ---- the variational sample and the loss terms (lde_loss_oracle.c) ---------------------------------------------------
+def _sample_forward(self, mu, logvar, eps):
+    dt = self.dtype
+    mu, logvar, eps = (np.ascontiguousarray(a, dtype=dt) for a in (mu, logvar, eps))
+    out = np.empty_like(mu)
+    self.lib.oracle_sample_forward(self._p(mu), self._p(logvar), self._p(eps), C.c_int64(mu.size), self._p(out))
+    return out
+
+def _sample_backward(self, logvar, eps, dl):
+    dt = self.dtype
+    logvar, eps, dl = (np.ascontiguousarray(a, dtype=dt) for a in (logvar, eps, dl))
+    dmu, dlv = np.empty_like(dl), np.empty_like(dl)
+    self.lib.oracle_sample_backward(self._p(logvar), self._p(eps), self._p(dl), C.c_int64(dl.size), self._p(dmu), self._p(dlv))
+    return dmu, dlv
+
+def _kl_forward(self, mu, logvar, scale):
+    dt = self.dtype
+    mu, logvar = np.ascontiguousarray(mu, dtype=dt), np.ascontiguousarray(logvar, dtype=dt)
+    self.lib.oracle_kl_forward.restype = C.c_double
+    return float(self.lib.oracle_kl_forward(self._p(mu), self._p(logvar), C.c_int64(mu.size), C.c_double(scale)))
+
+def _kl_backward(self, mu, logvar, scale, g=1.0):
+    dt = self.dtype
+    mu, logvar = np.ascontiguousarray(mu, dtype=dt), np.ascontiguousarray(logvar, dtype=dt)
+    dmu, dlv = np.empty_like(mu), np.empty_like(mu)
+    self.lib.oracle_kl_backward(self._p(mu), self._p(logvar), C.c_int64(mu.size), C.c_double(scale), C.c_double(g),
+                                self._p(dmu), self._p(dlv))
+    return dmu, dlv
+
+def _mse_forward(self, x, xhat, scale):
+    dt = self.dtype
+    x, xhat = np.ascontiguousarray(x, dtype=dt), np.ascontiguousarray(xhat, dtype=dt)
+    self.lib.oracle_mse_forward.restype = C.c_double
+    return float(self.lib.oracle_mse_forward(self._p(x), self._p(xhat), C.c_int64(x.size), C.c_double(scale)))
+
+def _mse_backward(self, x, xhat, scale, g=1.0):
+    dt = self.dtype
+    x, xhat = np.ascontiguousarray(x, dtype=dt), np.ascontiguousarray(xhat, dtype=dt)
+    dxh = np.empty_like(xhat)
+    self.lib.oracle_mse_backward(self._p(x), self._p(xhat), C.c_int64(x.size), C.c_double(scale), C.c_double(g), self._p(dxh))
+    return dxh
+
+
+Oracle.sample_forward = _sample_forward
+Oracle.sample_backward = _sample_backward
+Oracle.kl_forward = _kl_forward
+Oracle.kl_backward = _kl_backward
+Oracle.mse_forward = _mse_forward
+Oracle.mse_backward = _mse_backward

@@ -250,3 +250,67 @@ class NativeRnn:
                 self.h, "lde_rnn_backward", rnn=True)
         torch.cuda.synchronize()
         return (None if dx is None else dx.cpu().numpy()), dW.cpu().numpy()
+
+
+class NativeLoss:
+    """The stateless loss entry points of the C ABI (lde_sample_* / lde_kl_* / lde_mse_*), numpy in / numpy out."""
+
+    def __init__(self):
+        self.lib = L.load()
+
+    @staticmethod
+    def _d(a, offset=0):
+        """numpy → device tensor; `offset` floats into a larger buffer (to exercise unaligned operands)."""
+        a = np.ascontiguousarray(a, np.float32).reshape(-1)
+        buf = torch.empty(a.size + offset, device="cuda", dtype=torch.float32)
+        t = buf[offset:]
+        t.copy_(torch.from_numpy(a))
+        return t
+
+    @staticmethod
+    def _s():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def sample_forward(self, mu, logvar, eps, offset=0):
+        m, s, e = self._d(mu, offset), self._d(logvar, offset), self._d(eps, offset)
+        out = torch.full_like(m, 7.0)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        L.check(self.lib.lde_sample_forward(p(m), p(s), p(e), m.numel(), p(out), self._s()), None, "lde_sample_forward")
+        return out.cpu().numpy()
+
+    def sample_backward(self, logvar, eps, dl, offset=0):
+        s, e, g = self._d(logvar, offset), self._d(eps, offset), self._d(dl, offset)
+        out = torch.full_like(s, 7.0)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        L.check(self.lib.lde_sample_backward(p(s), p(e), p(g), s.numel(), p(out), self._s()), None, "lde_sample_backward")
+        return out.cpu().numpy()
+
+    def _reduce(self, fn, a, b, scale, offset):
+        a, b = self._d(a, offset), self._d(b, offset)
+        out = torch.full((1,), 7.0, device="cuda")
+        scratch = torch.full((L.LOSS_SCRATCH_FLOATS,), float("nan"), device="cuda")
+        p = lambda t: C.c_void_p(t.data_ptr())
+        L.check(fn(p(a), p(b), a.numel(), scale, p(out), p(scratch), self._s()), None, "loss reduction")
+        return float(out.cpu()[0])
+
+    def kl_forward(self, mu, logvar, scale, offset=0):
+        return self._reduce(self.lib.lde_kl_forward, mu, logvar, scale, offset)
+
+    def mse_forward(self, x, xhat, scale, offset=0):
+        return self._reduce(self.lib.lde_mse_forward, x, xhat, scale, offset)
+
+    def kl_backward(self, mu, logvar, scale, g, offset=0):
+        m, s = self._d(mu, offset), self._d(logvar, offset)
+        gd = torch.tensor([g], device="cuda", dtype=torch.float32)
+        dm, ds = torch.full_like(m, 7.0), torch.full_like(m, 7.0)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        L.check(self.lib.lde_kl_backward(p(m), p(s), m.numel(), scale, p(gd), p(dm), p(ds), self._s()), None, "lde_kl_backward")
+        return dm.cpu().numpy(), ds.cpu().numpy()
+
+    def mse_backward(self, x, xhat, scale, g, offset=0):
+        a, b = self._d(x, offset), self._d(xhat, offset)
+        gd = torch.tensor([g], device="cuda", dtype=torch.float32)
+        out = torch.full_like(a, 7.0)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        L.check(self.lib.lde_mse_backward(p(a), p(b), a.numel(), scale, p(gd), p(out), self._s()), None, "lde_mse_backward")
+        return out.cpu().numpy()

@@ -1,0 +1,131 @@
+"""GPU: the variational sample and the loss terms (lde_sample_* / lde_kl_* / lde_mse_*, scope row f-3) through the C ABI,
+against the f64 CPU oracle (oracle/lde_loss_oracle.c) on the same seeded inputs.
+
+Tolerances (f32 kernels vs the f64 oracle): elementwise outputs 2e-6 relative to the largest entry (one v_exp_f32 and a few
+roundings); the reductions 1e-5 relative (f32 partial sums in a fixed tree; the terms are non-negative)."""
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+E_ELEM, E_SUM = 2e-6, 1e-5
+
+
+@pytest.fixture(scope="module")
+def o64():
+    return O.Oracle("f64")
+
+
+@pytest.fixture(scope="module")
+def nat():
+    from tests.gpu_util import NativeLoss
+    return NativeLoss()
+
+
+def _rel(a, b):
+    return float(np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30))
+
+
+# latent sizes of the GOKU default (16 × B), ragged sizes, one past / one short of the 16-byte and workgroup boundaries,
+# and an operand offset of one float (unaligned pointers take the scalar path)
+SIZES = [(1, 0), (3, 0), (16 * 256, 0), (16 * 256, 1), (4097, 0), (8191, 3), (8192, 0), (100003, 0), (100003, 2)]
+
+
+@pytest.mark.parametrize("n,offset", SIZES)
+def test_sample_and_its_pullback(nat, o64, n, offset):
+    rng = np.random.default_rng(n + offset)
+    mu, ls, eps, dl = (rng.standard_normal(n).astype(np.float32) for _ in range(4))
+    want = o64.sample_forward(mu, ls, eps)
+    assert _rel(nat.sample_forward(mu, ls, eps, offset), want) <= E_ELEM
+    _, dlv = o64.sample_backward(ls, eps, dl)
+    assert _rel(nat.sample_backward(ls, eps, dl, offset), dlv) <= E_ELEM
+
+
+@pytest.mark.parametrize("n,offset", SIZES)
+def test_kl_and_its_pullback(nat, o64, n, offset):
+    rng = np.random.default_rng(7 * n + offset)
+    mu, ls = rng.standard_normal(n).astype(np.float32), (0.7 * rng.standard_normal(n)).astype(np.float32)
+    B = 13
+    want = o64.kl_forward(mu, ls, 1 / B)
+    got = nat.kl_forward(mu, ls, 1 / B, offset)
+    assert abs(got - want) <= E_SUM * abs(want), (got, want)
+    dmu, dlv = o64.kl_backward(mu, ls, 1 / B, 1.7)
+    gm, gl = nat.kl_backward(mu, ls, 1 / B, 1.7, offset)
+    assert _rel(gm, dmu) <= E_ELEM and _rel(gl, dlv) <= E_ELEM
+
+
+@pytest.mark.parametrize("n,offset", SIZES)
+def test_mse_and_its_pullback(nat, o64, n, offset):
+    rng = np.random.default_rng(11 * n + offset)
+    x, xh = rng.random(n).astype(np.float32), rng.random(n).astype(np.float32)
+    scale = 1 / 50.0
+    want = o64.mse_forward(x, xh, scale)
+    got = nat.mse_forward(x, xh, scale, offset)
+    assert abs(got - want) <= E_SUM * abs(want), (got, want)
+    assert _rel(nat.mse_backward(x, xh, scale, 0.3, offset), o64.mse_backward(x, xh, scale, 0.3)) <= E_ELEM
+
+
+def test_known_answers_and_edges(nat):
+    z = np.zeros(64, np.float32)
+    assert nat.kl_forward(z, z, 1.0) == 0.0                      # kl(0, 0) = 0 exactly
+    x = np.linspace(0, 1, 1000).astype(np.float32)
+    assert nat.mse_forward(x, x, 1.0) == 0.0
+    assert np.array_equal(nat.sample_forward(x, x, np.zeros_like(x)), x)    # ε = 0 ⇒ l̃ = μ, bit for bit
+    e = np.zeros(0, np.float32)
+    assert nat.kl_forward(e, e, 1.0) == 0.0 and nat.mse_forward(e, e, 1.0) == 0.0   # empty input: the sum is 0
+    assert nat.sample_forward(e, e, e).size == 0
+
+
+def test_reductions_are_reproducible_and_full_size(nat, o64):
+    """The reconstruction loss at the size of the training step (784 × 256 × 50 ≈ 10 M terms): two calls agree bit for bit
+    (fixed summation order, no atomics), and the value matches the oracle."""
+    rng = np.random.default_rng(3)
+    n = 784 * 256 * 50
+    x, xh = rng.random(n, dtype=np.float32), rng.random(n, dtype=np.float32)
+    a = nat.mse_forward(x, xh, 1 / (256 * 50))
+    b = nat.mse_forward(x, xh, 1 / (256 * 50))
+    assert a == b
+    want = o64.mse_forward(x, xh, 1 / (256 * 50))
+    assert abs(a - want) <= E_SUM * want, (a, want)
+
+
+def test_torch_level_functions_match_the_oracle(o64):
+    """loss.sample / vector_kl / reconstruction_loss on the reference-shaped (transposed) arrays, gradients through autograd."""
+    import torch
+    from latentdiffeq_amd import loss as LS
+    torch.manual_seed(5)
+    B, T, P = 40, 7, 12
+    mu_b = torch.randn(B, 16, device="cuda", requires_grad=True)                 # batch-major buffers, as the chains return them
+    ls_b = (0.5 * torch.randn(B, 16, device="cuda")).requires_grad_(True)
+    mu, ls = mu_b.t(), ls_b.t()                                                  # [16, B] views: the reference's layout
+    k = LS.vector_kl((mu, mu), (ls, ls))
+    k.backward()
+    m64, l64 = mu_b.detach().cpu().numpy().astype(np.float64), ls_b.detach().cpu().numpy().astype(np.float64)
+    want = 2 * o64.kl_forward(m64, l64, 1 / B)
+    assert abs(float(k) - want) <= E_SUM * want
+    dmu, dlv = o64.kl_backward(m64, l64, 1 / B, 2.0)
+    assert _rel(mu_b.grad.cpu().numpy(), dmu) <= E_ELEM and _rel(ls_b.grad.cpu().numpy(), dlv) <= E_ELEM
+    mu_b.grad = ls_b.grad = None
+    torch.manual_seed(9)
+    l = LS.sample(mu, ls)
+    assert l.shape == mu.shape
+    torch.manual_seed(9)
+    eps = torch.randn(B, 16, device="cuda")                                       # the draw sample() made (same generator state)
+    want_l = o64.sample_forward(m64, l64, eps.cpu().numpy().astype(np.float64))
+    assert _rel(l.detach().t().cpu().numpy(), want_l) <= E_ELEM
+    ct = torch.randn_like(l)
+    (l * ct).sum().backward()
+    _, dlv = o64.sample_backward(l64, eps.cpu().numpy().astype(np.float64), ct.t().cpu().numpy().astype(np.float64))
+    assert _rel(ls_b.grad.cpu().numpy(), dlv) <= E_ELEM
+    assert torch.equal(mu_b.grad, ct.t())
+    x = torch.rand(T, B, P, device="cuda").permute(2, 1, 0)                       # [pixels, B, T], pixels fastest
+    xh_b = torch.rand(T, B, P, device="cuda", requires_grad=True)
+    r = LS.reconstruction_loss(x, xh_b.permute(2, 1, 0))
+    r.backward()
+    x64, h64 = x.permute(2, 1, 0).cpu().numpy().astype(np.float64), xh_b.detach().cpu().numpy().astype(np.float64)
+    want = o64.mse_forward(x64, h64, 1 / (B * T))
+    assert abs(float(r) - want) <= E_SUM * want
+    assert np.isclose(want, ((x64 - h64) ** 2).transpose(2, 1, 0).mean(axis=(1, 2)).sum(), rtol=1e-12)   # sum(mean(·, dims=(2,3)))
+    assert _rel(xh_b.grad.cpu().numpy(), o64.mse_backward(x64, h64, 1 / (B * T), 1.0)) <= E_ELEM

@@ -376,9 +376,12 @@ static __global__ void k_sum_slabs(const float* __restrict__ slab, int nslab, in
   *reinterpret_cast<f32x4*>(sum + 4 * idx) = s;
 }
 
-// dW[flat] += sum[fragment position of flat] (+ the private slabs of workgroups that overflowed their staging area)
+// dW[flat] += sum[fragment position of flat] (+ the private slabs of workgroups that overflowed their staging area).
+// nslab > 0: `sum` is the base of nslab partial slabs that are added here, in slab order (the same order and therefore the
+// same bits as k_sum_slabs) — for the few-slab launches of the small chains, where a separate summing launch costs more
+// than the gather.
 static __global__ void k_reduce_slabs(const float* __restrict__ priv, const int32_t* __restrict__ nflush, int nwg,
-                                      const float* __restrict__ sum, MlpDims dm, float* __restrict__ dW,
+                                      const float* __restrict__ sum, int nslab, MlpDims dm, float* __restrict__ dW,
                                       int32_t* __restrict__ feedback) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx == 0) {   // tell the host (asynchronously) whether any workgroup ran out of staging slots
@@ -399,7 +402,21 @@ static __global__ void k_reduce_slabs(const float* __restrict__ priv, const int3
     pos = ((size_t)t * 64 + col + 32 * h) * 16 + r;
   } else
     pos = (size_t)dm.tile_off[dm.nL] * 1024 + dm.bias_lin[l] + (idx - dm.b_off[l]);
-  float sacc = sum[pos];
+  float sacc;
+  if (nslab > 0) {
+    const float* p = sum + pos;
+    sacc = 0.f;
+    int w = 0;
+    for (; w + 8 <= nslab; w += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = p[(size_t)(w + u) * dm.slab_n];
+#pragma unroll
+      for (int u = 0; u < 8; u++) sacc += v[u];
+    }
+    for (; w < nslab; w++) sacc += p[(size_t)w * dm.slab_n];
+  } else
+    sacc = sum[pos];
   if (priv)
     for (int w = 0; w < nwg; w++)
       if (nflush[w]) sacc += priv[(size_t)w * dm.slab_n + pos];
@@ -442,9 +459,14 @@ static int launch_weight_gradient(const MlpDims& dm, const DwArgs& da, int ntile
   if (ndw == 1) hipLaunchKernelGGL(k_mlp_dw<1>, grid, dim3(512), dlds, stream, dm, da);
   else if (ndw == 2) hipLaunchKernelGGL(k_mlp_dw<2>, grid, dim3(512), dlds, stream, dm, da);
   else hipLaunchKernelGGL(k_mlp_dw<4>, grid, dim3(512), dlds, stream, dm, da);
-  float* sum = da.slab + (size_t)ntile * ks * dm.slab_n;
-  hipLaunchKernelGGL(k_sum_slabs, dim3(cdiv(cdiv(dm.slab_n, 4), 256)), dim3(256), 0, stream, da.slab, ntile * ks, dm.slab_n, sum);
-  hipLaunchKernelGGL(k_reduce_slabs, dim3(cdiv(dm.nW, 256)), dim3(256), 0, stream, priv, nflush, npriv, sum, dm, dW, feedback);
+  if (ntile * ks <= 32) {   // few slabs: summed inside the gather
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(cdiv(dm.nW, 256)), dim3(256), 0, stream, priv, nflush, npriv, da.slab, ntile * ks, dm, dW,
+                       feedback);
+  } else {
+    float* sum = da.slab + (size_t)ntile * ks * dm.slab_n;
+    hipLaunchKernelGGL(k_sum_slabs, dim3(cdiv(cdiv(dm.slab_n, 4), 256)), dim3(256), 0, stream, da.slab, ntile * ks, dm.slab_n, sum);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(cdiv(dm.nW, 256)), dim3(256), 0, stream, priv, nflush, npriv, sum, 0, dm, dW, feedback);
+  }
   if (hipGetLastError() != hipSuccess) {
     err = "weight-gradient kernels failed to launch";
     return LDE_ERR_HIP;

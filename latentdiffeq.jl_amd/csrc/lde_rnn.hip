@@ -348,10 +348,10 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
   }
 }
 
-// dW[state0 slots] += Σ_b g0[b][·]   (trajectory order ⇒ deterministic)
-__global__ void k_rnn_state0(const float* __restrict__ g0, int B, int g0w, RnnDims rd, float* __restrict__ dW) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= g0w) return;
+// dW[state0 slots] += Σ_b g0[b][·]: one wave per state entry, lane j adds trajectories j, j+64, … in order, then a fixed
+// butterfly over the lanes (deterministic)
+__global__ void __launch_bounds__(64) k_rnn_state0(const float* __restrict__ g0, int B, int g0w, RnnDims rd, float* __restrict__ dW) {
+  const int i = blockIdx.x;
   int off = 0, l = 0;
   for (; l < rd.nL; l++) {
     const int ns = (rd.cell == LDE_CELL_LSTM ? 2 : 1) * rd.sizes[l + 1];
@@ -360,16 +360,10 @@ __global__ void k_rnn_state0(const float* __restrict__ g0, int B, int g0w, RnnDi
   }
   const int in = rd.sizes[l], h = rd.sizes[l + 1], R = rd.G * h;
   float s = 0.f;
-  int b = 0;
-  for (; b + 8 <= B; b += 8) {
-    float v[8];
+  for (int b = threadIdx.x; b < B; b += 64) s += g0[(size_t)b * g0w + i];
 #pragma unroll
-    for (int q = 0; q < 8; q++) v[q] = g0[(size_t)(b + q) * g0w + i];
-#pragma unroll
-    for (int q = 0; q < 8; q++) s += v[q];
-  }
-  for (; b < B; b++) s += g0[(size_t)b * g0w + i];
-  dW[rd.f_off[l] + (size_t)R * in + (size_t)R * h + R + (i - off)] += s;
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
+  if (threadIdx.x == 0) dW[rd.f_off[l] + (size_t)R * in + (size_t)R * h + R + (i - off)] += s;
 }
 
 }  // namespace lde
@@ -667,7 +661,7 @@ int lde_rnn_backward(lde_rnn* r, const float* x, const float* dy, int T, int B, 
     rc = launch_weight_gradient(r->dmw[l], da, ntile, ks, nullptr, r->ints, 0, dW + rd.f_off[l], r->ints + 2, stream, r->err);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(k_rnn_state0, dim3(cdiv(r->g0w, 64)), dim3(64), 0, stream, r->g0, B, r->g0w, rd, dW);
+  hipLaunchKernelGGL(k_rnn_state0, dim3(r->g0w), dim3(64), 0, stream, r->g0, B, r->g0w, rd, dW);
   if (hipGetLastError() != hipSuccess) {
     r->err = "recurrent stack: gradient kernels failed to launch";
     return LDE_ERR_HIP;

@@ -14,6 +14,7 @@ CASES = [
     (O.CELL_LSTM, (32, 16, 16), False),         # pe_θ_forward   [REF src/models/GOKU.jl:233-234]
     (O.CELL_LSTM, (32, 16, 16), True),          # pe_θ_backward  [REF src/models/GOKU.jl:236-237]
     (O.CELL_RNN_RELU, (32, 32, 32), True),      # LatentODE      [REF src/models/LatentODE.jl:120-121]
+    (O.CELL_RNN_TANH, (32, 16, 16), False),     # the third compile-time instantiation of k_rnn
     (O.CELL_RNN_TANH, (5, 7, 3, 9), False),
     (O.CELL_LSTM, (3, 10), True),
     (O.CELL_LSTM, (40, 16, 11), False),
@@ -131,3 +132,44 @@ def test_torch_encoder_path_end_to_end(o64):
 def test_rnn_large_batch(o32, o64):
     """B = 5 003 trajectories (313 workgroups, ragged last one), T = 30."""
     _run(O.CELL_LSTM, (32, 16, 16), True, 30, 5003, o32, o64, seed=8)
+
+
+_GENERIC = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+from oracle import oracle as O
+from tests.gpu_util import NativeRnn
+out = {{}}
+for name, cell in (("lstm", O.CELL_LSTM), ("relu", O.CELL_RNN_RELU), ("tanh", O.CELL_RNN_TANH)):
+    sizes, T, B = (32, 16, 16), 23, 70
+    W = O.rnn_weights(cell, sizes, seed=6)
+    rng = np.random.default_rng(7)
+    x = rng.standard_normal((T, B, 32)).astype(np.float32)
+    dy = (rng.standard_normal((B, 16)) / B).astype(np.float32)
+    nat = NativeRnn(cell, sizes, True)
+    nat.set_weights(W)
+    out[name + "_y"] = nat.forward(x)
+    out[name + "_dx"], out[name + "_dW"] = nat.backward(x, dy)
+np.savez({path!r}, **out)
+"""
+
+
+def test_instantiated_and_run_time_shaped_kernels_agree(tmp_path):
+    """The reference's default stacks (32 → 16 → 16) run compile-time instantiations of k_rnn; LDE_RNN_GENERIC=1 forces the
+    run-time-shaped kernel every other shape uses. Same source, same order of operations: the two must agree to round-off
+    (the compiler may contract multiply-adds differently, nothing more)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if os.environ.get("LDE_RNN_GENERIC", "0") not in ("", "0"):
+        pytest.skip("this process already runs the run-time-shaped kernel")
+    path = str(tmp_path / "rnn_generic.npz")
+    subprocess.run([sys.executable, "-c", _GENERIC.format(root=root, path=path)], check=True,
+                   env=dict(os.environ, LDE_RNN_GENERIC="1"), timeout=600)
+    here = str(tmp_path / "rnn_here.npz")
+    exec(compile(_GENERIC.format(root=root, path=here), "<rnn instantiated>", "exec"), {})      # the same script, in this process
+    res = {"0": np.load(here), "1": np.load(path)}
+    for k in res["0"].files:
+        a, b = res["0"][k], res["1"][k]
+        assert np.abs(a - b).max() <= 2e-6 * max(np.abs(b).max(), 1e-30), k

@@ -249,8 +249,6 @@ static int reserve_impl(lde_handle* h, int B, int T, bool adjoint_ws, int64_t st
   }
   if (T > h->ts_cap) {
     if (h->ts_dev) (void)hipFree(h->ts_dev);
-  if (h->par_ops) (void)hipFree(h->par_ops);
-  if (h->par_info) (void)hipFree(h->par_info);
     h->ts_dev = nullptr;
     HIP_TRY(h, hipMalloc(&h->ts_dev, (size_t)T * sizeof(double)));
     h->ts_cap = T;

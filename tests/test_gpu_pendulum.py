@@ -109,6 +109,22 @@ def test_off_grid_save_times_and_single_point(o32):
     assert np.array_equal(g0, dz[0]) and (gL == 0).all()
 
 
+def test_one_handle_growing_and_shrinking_shapes(o32):
+    """One handle used with save grids and batches of changing size (progressive sequence length, ragged last minibatch):
+    every workspace regrows cleanly — forward and adjoint match the oracle at every shape."""
+    nat, od = _native()
+    for T, B in [(2, 64), (3, 64), (50, 64), (7, 256), (50, 256), (51, 300), (4, 5)]:
+        z0, L = O.pendulum_inputs(B, seed=T)
+        ts = O.time_grid(T)
+        z, ret, _ = nat.forward(z0, L, ts)
+        zr, _, _ = o32.forward(od, z0, L, ts)
+        assert (ret == 0).all() and np.abs(z - zr).max() <= 3e-4, (T, B)
+        dz = O.cotangent(T, B, 2)
+        g0, gL, _, _ = nat.adjoint(z, L, ts, dz)
+        r0, rL, _, _ = o32.adjoint(od, z, L, ts, dz)
+        assert np.abs(g0 - r0).max() <= 5e-4 * np.abs(r0).max() and np.abs(gL - rL).max() <= 5e-4 * np.abs(rL).max(), (T, B)
+
+
 def test_failed_trajectories_give_nan_blocks(o32):
     """maxiters exhausted ⇒ retcode != 0 and a NaN [D×T] block for that trajectory only [REF GOKU.jl:114]."""
     nat, od = _native(maxiters=12)

@@ -220,3 +220,27 @@ def test_chain_large_column_count(o32):
     rx, rW = o32.chain_backward(d, W, x, dy)
     assert np.abs(dx - rx).max() <= 1e-4 * np.abs(rx).max()
     assert np.abs(dW - rW).max() <= 2e-4 * np.abs(rW).max()      # 3e5 terms per entry: f32 summation order
+
+
+@pytest.mark.parametrize("spec", [RECON, FE, ONE], ids=["reconstructor", "feature_extractor", "one"])
+def test_one_chain_handle_changing_column_counts(o32, spec):
+    """One handle, column counts growing and shrinking (ragged last minibatch, validation set after a training batch):
+    every workspace regrows cleanly, results match the oracle at each size, plain and saved-activation variants."""
+    from tests.gpu_util import NativeChain
+    sizes, acts, skips = spec
+    d = O.make_chain_desc(sizes, acts, skips)
+    W = O.mlp_weights(sizes, seed=9)
+    nat = NativeChain(sizes, acts, skips)
+    nat.set_weights(W)
+    for N in (5, 300, 17, 2000, 64, 2001):
+        rng = np.random.default_rng(N)
+        x = rng.standard_normal((N, sizes[0])).astype(np.float32)
+        dy = (rng.standard_normal((N, sizes[-1])) / N).astype(np.float32)
+        yr = o32.chain_forward(d, W, x)
+        rx, rW = o32.chain_backward(d, W, x, dy)
+        y = nat.forward(x)
+        assert np.abs(y - yr).max() <= 2e-5 * max(1.0, np.abs(yr).max()), N
+        y2, saved = nat.forward_save(x)
+        assert np.array_equal(y, y2), N
+        for dx, dW in (nat.backward(x, y, dy), nat.backward_saved(x, y2, dy, saved)):
+            assert np.abs(dx - rx).max() <= 1e-4 * np.abs(rx).max() and np.abs(dW - rW).max() <= 1e-4 * np.abs(rW).max(), N

@@ -499,3 +499,27 @@ def test_mlp_adjoint_large_batches(o32, o64, layers, B):
     assert np.abs(z - z64).max() <= 2e-5 * max(1, np.abs(z64).max())
     assert np.abs(g0 - t0).max() <= 2e-4 * np.abs(t0).max()
     assert np.abs(gW - tW).max() <= 2e-4 * np.abs(tW).max()
+
+
+@pytest.mark.parametrize("layers,batching,solver", [((8, 200, 200, 8), O.BATCH_COUPLED, O.SOLVER_RK4), ((2, 64, 64, 2), O.BATCH_PER_TRAJECTORY, O.SOLVER_TSIT5)],
+                         ids=["c2", "c3-like"])
+def test_one_mlp_handle_changing_shapes(o32, layers, batching, solver):
+    """One handle with save grids and batches growing and shrinking: every workspace (panels, staging area, slabs) regrows
+    cleanly, forward and adjoint match the oracle at each shape."""
+    W = O.mlp_weights(layers, seed=3)
+    D = layers[0]
+    kw = dict(rhs_kind=O.RHS_MLP, state_dim=D, param_dim=0, layers=layers, solver=solver, batching=batching, abstol=1e-6, reltol=1e-6,
+              activation=O.ACT_TANH)        # smooth: the adaptive step sequence is then not round-off sensitive (no relu kinks)
+    if solver == O.SOLVER_RK4:
+        kw.update(adaptive=0, dt=0.05)
+    nat, od = _native(W, **kw)
+    for T, B in ((5, 16), (50, 64), (10, 200), (51, 33), (3, 257)):
+        z0, ts = _z0(B, D, seed=T), O.time_grid(T)
+        z, ret, _ = nat.forward(z0, None, ts)
+        zr, _, _ = o32.forward(od, z0, None, ts, W=W)
+        assert (ret == 0).all() and np.abs(z - zr).max() <= 1e-4 * max(1.0, np.abs(zr).max()), (T, B)
+        dz = O.cotangent(T, B, D)
+        g0, _, gW, _ = nat.adjoint(z, None, ts, dz)
+        r0, _, rW, _ = o32.adjoint(od, z, None, ts, dz, W=W)
+        e0, eW = np.abs(g0 - r0).max() / np.abs(r0).max(), np.abs(gW - rW).max() / np.abs(rW).max()
+        assert e0 <= 2e-3 and eW <= 2e-3, (T, B, e0, eW)

@@ -134,6 +134,24 @@ def test_rnn_large_batch(o32, o64):
     _run(O.CELL_LSTM, (32, 16, 16), True, 30, 5003, o32, o64, seed=8)
 
 
+def test_one_rnn_handle_changing_shapes(o32):
+    """One handle with sequence lengths and batches growing and shrinking (progressive sequence length, ragged minibatch)."""
+    from tests.gpu_util import NativeRnn
+    for cell, sizes in ((O.CELL_LSTM, (32, 16, 16)), (O.CELL_RNN_TANH, (5, 7, 3, 9))):
+        d = O.make_rnn_desc(cell, sizes, True)
+        W = O.rnn_weights(cell, sizes, seed=3)
+        nat = NativeRnn(cell, sizes, True)
+        nat.set_weights(W)
+        for T, B in ((3, 5), (20, 40), (7, 300), (50, 16), (51, 301), (2, 1)):
+            rng = np.random.default_rng(T * 1000 + B)
+            x = rng.standard_normal((T, B, sizes[0])).astype(np.float32)
+            dy = (rng.standard_normal((B, sizes[-1])) / B).astype(np.float32)
+            assert np.abs(nat.forward(x) - o32.rnn_forward(d, W, x)).max() <= 2e-5, (T, B)
+            dx, dW = nat.backward(x, dy)
+            rx, rW = o32.rnn_backward(d, W, x, dy)
+            assert np.abs(dx - rx).max() <= 1e-4 * np.abs(rx).max() and np.abs(dW - rW).max() <= 1e-4 * np.abs(rW).max(), (T, B)
+
+
 _GENERIC = r"""
 import sys, numpy as np
 sys.path.insert(0, {root!r})

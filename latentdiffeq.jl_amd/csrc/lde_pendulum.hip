@@ -17,6 +17,8 @@
 
 namespace lde {
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
 // ---- the closed menu of 2-state / 1-parameter physics RHS -------------------------------------
 // KIND 0: du = [y, -(G/L) sin x]                    [REF examples/pendulum_friction-less/pendulum.jl:19-26]
 // KIND 1: du = [y, -(G/L) sin x - (b/m) y], b/m=0.7  [REF pendulum.jl:65-74]
@@ -167,6 +169,227 @@ __global__ void __launch_bounds__(256) k_pend_forward(const float2* __restrict__
       dt = o.adaptive ? dtp : o.dt_fixed;
     }
   }
+  if (ret != LDE_RET_SUCCESS) {  // failed solve ⇒ NaN block, never an error [REF GOKU.jl:114]
+    const float qn = __int_as_float(0x7fc00000);
+    for (int j = 0; j < T; j++) z_out[(size_t)j * B + b] = make_float2(qn, qn);
+  }
+  if (retcode) retcode[b] = ret;
+  st_ret[b] = ret;
+  st_nfe[b] = nfe;
+  st_nacc[b] = nacc;
+  st_nrej[b] = nrej;
+}
+
+// ---- forward, small batches: stepping and dense output on different waves ---------------------------------------------
+// At B ≤ 4096 the launch is a handful of waves and its duration is one wave's dependent-instruction chain. In
+// k_pend_forward a third of that chain is the dense output: ≈ 75 wave-iterations (the per-step maximum over 64 lanes of
+// the saves inside the step) of interpolation, f64 save-time compares and stores — 9.4 of 28.4 µs at T = 50
+// (abl/pend_T.py). Here the stepping wave only RECORDS each accepted step (t, h, y, k₁…k₇) in LDS, five 16-byte words per step,
+// and the workgroup's sixteen waves then evaluate the saves from the records, each a contiguous slice of the save grid for
+// the same 64 trajectories (one barrier pair per ≤ 20 accepted steps; a trajectory that needs more steps than the record
+// area holds simply goes through another round). Same formulas as k_pend_forward; the two compilations contract
+// multiply-adds differently, so they agree to the solver's tolerance, not bit for bit (tests/test_gpu_pendulum.py).
+// Measured (B = 256, T = 50): 28.4 → 22.7 µs.
+constexpr int WS_CAP = 20;       // accepted steps recorded between two save phases
+constexpr int WS_WAVES = 16;     // waves per workgroup: one steps, all sixteen evaluate saves
+constexpr int WS_THREADS = 64 * WS_WAVES;
+constexpr int WS_RW = 20;        // floats per record = five 16-byte words: {h, y₀, y₁, –} {k₁ k₂} {k₃ k₄} {k₅ k₆} {k₇, t (f64)};
+                                 // a lane stride of 80 B spreads the 16 lanes of a b128 access over all 64 banks
+
+template <int KIND, int SOLVER>
+__global__ void __launch_bounds__(WS_THREADS) k_pend_forward_ws(const float2* __restrict__ z0, const float* __restrict__ theta,
+                                                         const double* __restrict__ ts_g, KOpts o,
+                                                         float2* __restrict__ z_out, int32_t* __restrict__ retcode,
+                                                         int32_t* __restrict__ st_nfe, int32_t* __restrict__ st_nacc,
+                                                         int32_t* __restrict__ st_nrej, int32_t* __restrict__ st_ret) {
+  extern __shared__ __attribute__((aligned(16))) double s_lds[];
+  __shared__ int s_cnt[64];
+  __shared__ int s_done;
+  const int T = o.T, B = o.B, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  for (int i = tid; i < T; i += WS_THREADS) s_lds[i] = ts_g[i];
+  float* rec = reinterpret_cast<float*>(s_lds + ((T + 1) & ~1));          // [(WS_CAP + 1)][64][WS_RW]
+  auto rec_at = [&](int n) -> float* { return rec + (size_t)(n * 64 + lane) * WS_RW; };
+  auto rec_t = [&](int n) -> double { return *reinterpret_cast<const double*>(rec_at(n) + 18); };   // start time of record n
+  __syncthreads();
+  auto s_ts = [&](int i) -> double { return s_lds[i]; };
+  const int b = blockIdx.x * 64 + lane;
+  const bool valid = b < B;
+  constexpr int FS = (SOLVER == LDE_SOLVER_TSIT5) ? 6 : 4;  // FSAL slope
+
+  // --- the stepping wave's state (wave 0) ---
+  float y[2] = {0.f, 0.f}, k[7][2], yn[2], kf[2] = {0.f, 0.f};   // kf: f(y) at the current state (the first-same-as-last slope)
+  PendFwd<KIND> f(valid && w == 0 ? theta[b] : 1.0f);
+  int ret = LDE_RET_SUCCESS, nfe = 0, nacc = 0, nrej = 0;
+  double t = 0.0, dt = 0.0, tend = 0.0, dtmax = 0.0;
+  float qold = 1e-4f;
+  long long iters = 0;
+  bool active = false;
+#pragma unroll
+  for (int s = 0; s < 7; s++) k[s][0] = k[s][1] = 0.f;
+  if (w == 0 && valid) {
+    const float2 zi = z0[b];
+    y[0] = zi.x;
+    y[1] = zi.y;
+    z_out[b] = zi;  // ts[0] is saved as ẑ₀ itself
+    if (T > 1) {
+      t = s_ts(0);
+      tend = s_ts(T - 1);
+      dtmax = tend - t;
+      f(y, kf);
+      nfe = 1;
+      if (o.adaptive) {
+        if (o.dt_fixed > 0) dt = fmin(o.dt_fixed, dtmax);
+        else {
+          dt = init_dt<2>(f, y, kf, 1.0f, dtmax, o);
+          nfe++;
+        }
+      } else
+        dt = o.dt_fixed;
+      active = t < tend;
+    }
+  }
+  // --- the save waves' state: wave w owns the saves j ∈ [jq, jend) of its 64 trajectories ---
+  const int chunk = (T - 1 + WS_WAVES - 1) / WS_WAVES;
+  int jq = 1 + w * chunk;
+  const int jend = min(T, 1 + (w + 1) * chunk);
+
+  for (;;) {
+    if (w == 0) {
+      int n = 0;
+      for (;;) {
+        const bool go = active && n < WS_CAP;
+        if (!__any(go)) break;
+        if (go) do {
+          if (iters++ >= o.maxiters) { ret = LDE_RET_MAXITERS; active = false; break; }
+          double dtp = dt;
+          bool last = false;
+          if (t + dt >= tend - 1e-12 * fabs(tend)) { dt = tend - t; last = true; }
+          const float h = (float)dt;
+          k[0][0] = kf[0];
+          k[0][1] = kf[1];
+          float EEst = 0.f;
+          if (SOLVER == LDE_SOLVER_TSIT5) {
+            EEst = tsit5_attempt<2>(f, h, y, k, yn, o);
+            nfe += 6;
+          } else {
+            rk4_step<2>(f, h, y, k, yn);
+            nfe += 4;
+          }
+          if (!all_finite<2>(yn) || !(EEst == EEst)) {
+            if (o.adaptive && dt > o.dtmin) { nrej++; dt = dt * (double)o.qmin; break; }
+            ret = LDE_RET_NONFINITE;
+            active = false;
+            break;
+          }
+          if (o.adaptive) {
+            float q11;
+            const float q = pi_q(EEst, qold, o, q11);
+            if (EEst > 1.0f) {
+              nrej++;
+              dt = dt * (double)fast_rcp(fminf(o.q_hi, q11 * o.inv_gamma));
+              if (dt < o.dtmin) { ret = LDE_RET_DTMIN; active = false; }
+              break;
+            }
+            qold = fmaxf(EEst, 1e-4f);
+            dtp = dt * (double)fast_rcp(q);
+            if (dtp > dtmax) dtp = dtmax;
+          }
+          nacc++;
+          {   // record the accepted step
+            f32x4* r = reinterpret_cast<f32x4*>(rec_at(n));
+            r[0] = f32x4{h, y[0], y[1], 0.f};
+            r[1] = f32x4{k[0][0], k[0][1], k[1][0], k[1][1]};
+            r[2] = f32x4{k[2][0], k[2][1], k[3][0], k[3][1]};
+            r[3] = f32x4{k[4][0], k[4][1], k[5][0], k[5][1]};
+            const unsigned long long tb = (unsigned long long)__double_as_longlong(t);
+            r[4] = f32x4{k[6][0], k[6][1], __uint_as_float((unsigned)tb), __uint_as_float((unsigned)(tb >> 32))};
+            n++;
+          }
+          y[0] = yn[0];
+          y[1] = yn[1];
+          kf[0] = k[FS][0];
+          kf[1] = k[FS][1];
+          t = last ? tend : t + dt;
+          dt = o.adaptive ? dtp : o.dt_fixed;
+          if (!(t < tend)) active = false;
+        } while (0);
+      }
+      // sentinel: where the trajectory stands now (end time and end state of its last record)
+      *reinterpret_cast<double*>(rec_at(n) + 18) = t;
+      rec_at(n)[1] = y[0];
+      rec_at(n)[2] = y[1];
+      s_cnt[lane] = n;
+      const bool any_active = __any(active);
+      if (lane == 0) s_done = any_active ? 0 : 1;
+    }
+    __syncthreads();
+    {   // save phase, all waves
+      const int cnt = s_cnt[lane];
+      int n2 = 0, pn = -1;
+      if (jq < jend && cnt > 1) {   // first record whose end time reaches this wave's first save time (bisection: ≤ 5 LDS reads)
+        const double tj0 = s_ts(jq);
+        int lo = 0, hi = cnt;       // invariant: end(lo − 1) < tj0; answer in [lo, hi]
+        while (lo < hi) {
+          const int mid = (lo + hi) >> 1;
+          if (rec_t(mid + 1) < tj0) lo = mid + 1;
+          else hi = mid;
+        }
+        n2 = lo;
+      }
+      float h = 0.f, rh = 0.f, ys[2] = {0.f, 0.f}, k0[2] = {0.f, 0.f}, kE[2] = {0.f, 0.f}, P[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
+      double tn = 0.0;
+      while (jq < jend) {
+        const double tj = s_ts(jq);
+        while (n2 < cnt && rec_t(n2 + 1) < tj) n2++;
+        if (n2 == cnt) break;   // beyond what has been integrated so far
+        const double t1 = rec_t(n2 + 1);
+        float2 out;
+        if (tj >= t1) {   // the save time is the step's end: the next record's start state
+          const float* r1 = rec_at(n2 + 1);
+          out = make_float2(r1[1], r1[2]);
+        } else {
+          if (pn != n2) {
+            const f32x4* r = reinterpret_cast<const f32x4*>(rec_at(n2));
+            const f32x4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3], q4 = r[4];
+            h = q0[0];
+            rh = fast_rcp(h);
+            ys[0] = q0[1];
+            ys[1] = q0[2];
+            tn = __longlong_as_double((long long)(((unsigned long long)__float_as_uint(q4[3]) << 32) | __float_as_uint(q4[2])));
+            k0[0] = q1[0];
+            k0[1] = q1[1];
+            if (SOLVER == LDE_SOLVER_TSIT5) {
+              const float kk[7][2] = {{q1[0], q1[1]}, {q1[2], q1[3]}, {q2[0], q2[1]}, {q2[2], q2[3]}, {q3[0], q3[1]}, {q3[2], q3[3]}, {q4[0], q4[1]}};
+              tsit5_dense_coeffs<2>(kk, P);
+            } else {
+              kE[0] = q3[0];   // k₅ = f(yₙ₊₁), the slope at the end of the step
+              kE[1] = q3[1];
+            }
+            pn = n2;
+          }
+          const float th = (float)(tj - tn) * rh;
+          if (SOLVER == LDE_SOLVER_TSIT5) {
+            out.x = tsit5_dense_eval<2>(th, h, ys[0], k0[0], P[0][0], P[1][0], P[2][0]);
+            out.y = tsit5_dense_eval<2>(th, h, ys[1], k0[1], P[0][1], P[1][1], P[2][1]);
+          } else {  // cubic Hermite between (y,k1) and (yn,f(yn))
+            const float* r1 = rec_at(n2 + 1);
+            const float y1a = r1[1], y1b = r1[2];
+            const float om = 1.0f - th;
+            const float h00 = (1.0f + 2.0f * th) * om * om, h10 = th * om * om;
+            const float h01 = th * th * (3.0f - 2.0f * th), h11 = th * th * (th - 1.0f);
+            out.x = h00 * ys[0] + (h10 * h) * k0[0] + h01 * y1a + (h11 * h) * kE[0];
+            out.y = h00 * ys[1] + (h10 * h) * k0[1] + h01 * y1b + (h11 * h) * kE[1];
+          }
+        }
+        if (valid) z_out[(size_t)jq * B + b] = out;
+        jq++;
+      }
+    }
+    const int done = s_done;
+    __syncthreads();   // the records are overwritten in the next round
+    if (done) break;
+  }
+  if (w != 0 || !valid) return;
   if (ret != LDE_RET_SUCCESS) {  // failed solve ⇒ NaN block, never an error [REF GOKU.jl:114]
     const float qn = __int_as_float(0x7fc00000);
     for (int j = 0; j < T; j++) z_out[(size_t)j * B + b] = make_float2(qn, qn);
@@ -551,6 +774,31 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
                         hipStream_t stream) {
   const int block = pick_block(o.B), grid = (o.B + block - 1) / block;
   const size_t shm = o.T <= TS_LDS_MAX ? (size_t)o.T * sizeof(double) : 0;
+  // small batches: stepping and dense output on different waves of a 64-trajectory workgroup (k_pend_forward_ws)
+  static const bool ws_on = [] { const char* e = getenv("LDE_PEND_WS"); return !e || atoi(e) != 0; }();
+  if (ws_on && shm && o.T > 2 && block == 64) {
+    const size_t lds = (size_t)((o.T + 1) & ~1) * sizeof(double) + (size_t)(WS_CAP + 1) * 64 * WS_RW * sizeof(float);
+    const int g64 = (o.B + 63) / 64;
+#define LDE_LAUNCH_WS(K, S)                                                                                            \
+  do {                                                                                                                 \
+    static bool attr = false;                                                                                          \
+    if (!attr) {                                                                                                       \
+      if (hipFuncSetAttribute((const void*)k_pend_forward_ws<K, S>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
+                              160 * 1024 - 512) != hipSuccess)                                                         \
+        return LDE_ERR_HIP;                                                                                            \
+      attr = true;                                                                                                     \
+    }                                                                                                                  \
+    hipLaunchKernelGGL((k_pend_forward_ws<K, S>), dim3(g64), dim3(WS_THREADS), lds, stream, (const float2*)z0, theta, ts_dev, \
+                       o, (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                              \
+  } while (0)
+    if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH_WS(0, LDE_SOLVER_TSIT5);
+    else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_RK4) LDE_LAUNCH_WS(0, LDE_SOLVER_RK4);
+    else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH_WS(1, LDE_SOLVER_TSIT5);
+    else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_RK4) LDE_LAUNCH_WS(1, LDE_SOLVER_RK4);
+    else return LDE_ERR_UNSUPPORTED;
+#undef LDE_LAUNCH_WS
+    return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
+  }
 #define LDE_LAUNCH(K, S)                                                                                              \
   do {                                                                                                                \
     if (shm)                                                                                                          \

@@ -66,7 +66,7 @@ def test_adjoint_matches_oracle(o32, o64, kind, sense, tol):
     lim = 5e-4 if tol[1] > 1e-4 else 1e-4
     assert np.abs(g0 - r0).max() <= lim * s0
     assert np.abs(gL - rL).max() <= lim * sL
-    assert abs(st["naccept"] - info["naccept"]) <= 0.02 * info["naccept"] + 1
+    assert abs(st["naccept"] - info["naccept"]) <= 0.03 * info["naccept"] + 1   # (tight backsolve: acceptance is round-off sensitive)
     # float64 truth of the same continuous adjoint
     dtruth = O.make_desc(rhs_kind=kind, abstol=1e-11, reltol=1e-11, sensealg=min(sense, 1))
     zt, _, _ = o64.forward(dtruth, z0, L, ts)
@@ -245,3 +245,54 @@ def test_very_long_save_grid(o32):
     seq, ods = _native(abstol=1e-6, reltol=1e-6, sensealg=O.SENSE_BACKSOLVE_CHECKPOINTED)
     s0, sL, _, _ = seq.adjoint(z, L, ts, dz)           # sequential kernel, grid from L2 as well
     assert np.abs(g0 - s0).max() <= 2e-4 * np.abs(s0).max() and np.abs(gL - sL).max() <= 2e-4 * np.abs(sL).max()
+
+
+_WS_SCRIPT = r"""
+import sys, numpy as np
+sys.path.insert(0, {root!r})
+from oracle import oracle as O
+from tests.gpu_util import Native, make_desc
+out = {{}}
+cases = [("default", dict(), 256, 50), ("tight", dict(abstol=1e-6, reltol=1e-6), 70, 50), ("friction", dict(rhs_kind=O.RHS_PENDULUM_FRICTION), 64, 23),
+         ("rk4", dict(solver=O.SOLVER_RK4, adaptive=0, dt=0.013), 65, 50), ("one", dict(), 1, 3), ("long", dict(abstol=1e-8, reltol=1e-8), 130, 200),
+         ("fail", dict(maxiters=9), 256, 50)]
+for name, kw, B, T in cases:
+    z0, L = O.pendulum_inputs(B, seed=3)
+    ts = np.sort(np.random.default_rng(1).uniform(0.0, 3.0, T)) if name == "friction" else O.time_grid(T)
+    z, ret, st = Native(make_desc(**kw)).forward(z0, L, ts)
+    out[name + "_z"], out[name + "_ret"] = z, ret
+    out[name + "_st"] = np.array([st["nfe"], st["naccept"], st["nreject"], st["nfailed"]])
+np.savez({path!r}, **out)
+"""
+
+
+def test_wave_split_forward_matches_the_single_wave_kernel(tmp_path):
+    """Batches ≤ 4096 run k_pend_forward_ws (stepping wave + save waves); LDE_PEND_WS=0 forces k_pend_forward, the kernel of
+    the large batches. Same step code and the same dense-output formulas: the two agree like two correct f32 solves —
+    default and tight tolerance (several record rounds), friction with an off-grid save
+    times, fixed-step RK4, a single trajectory, 200 save points, and trajectories that fail (NaN blocks)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if os.environ.get("LDE_PEND_WS", "1") == "0":
+        pytest.skip("this process already runs the single-wave kernel")
+    path = str(tmp_path / "single.npz")
+    subprocess.run([sys.executable, "-c", _WS_SCRIPT.format(root=root, path=path)], check=True,
+                   env=dict(os.environ, LDE_PEND_WS="0"), timeout=600)
+    here = str(tmp_path / "split.npz")
+    exec(compile(_WS_SCRIPT.format(root=root, path=here), "<wave split>", "exec"), {})
+    a, b = np.load(here), np.load(path)
+    # two compilations of the same step code: multiply-adds contract differently, so the adaptive step sequences part at
+    # round-off level — the kernels agree like two correct f32 solves do (tests above: ≤ 3e-4 at the default tolerance,
+    # ≤ 2e-5 at 1e-6), exactly where there is no controller (fixed-step RK4 ≤ 2e-6)
+    tol = dict(default=3e-4, friction=3e-4, one=3e-4, fail=3e-4, tight=2e-5, long=2e-5, rk4=2e-6)
+    for name, lim in tol.items():
+        za, zb, ra, rb = a[name + "_z"], b[name + "_z"], a[name + "_ret"], b[name + "_ret"]
+        flips = ra != rb
+        assert flips.sum() <= (3 if name == "fail" else 0), name     # a trajectory sitting exactly at maxiters may flip
+        ok = ~flips
+        assert np.array_equal(np.isnan(za[:, ok]), np.isnan(zb[:, ok])), name
+        assert np.nanmax(np.abs(za[:, ok] - zb[:, ok]), initial=0.0) <= lim, name
+        sa, sb = a[name + "_st"], b[name + "_st"]
+        assert np.all(np.abs(sa - sb) <= 0.02 * sb[1] + 3), (name, sa, sb)     # nfe, naccept, nreject, nfailed: within 2 % of the steps

@@ -93,6 +93,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise LdeError(f"{LIB_PATH} not found — build it with `python latentdiffeq.jl_amd/build.py` "
                        "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+    # torch first: liblde.so and torch must share ONE HIP runtime (device pointers and streams cross the boundary), and
+    # the process uses whichever libamdhip64 is loaded first — torch bundles its own. Loading liblde.so before torch
+    # binds it to /opt/rocm's copy and leaves two runtimes in the process (lde_create then reports LDE_ERR_NO_DEVICE).
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
     lib.lde_abi_version.restype = i32

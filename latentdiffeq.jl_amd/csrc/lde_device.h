@@ -37,23 +37,10 @@ __device__ __forceinline__ float fast_rcp(float x) { return __builtin_amdgcn_rcp
 // OrdinaryDiffEq itself uses a low-precision `fastpow` here)
 __device__ __forceinline__ float fast_pow(float x, float y) { return __builtin_amdgcn_exp2f(y * __builtin_amdgcn_logf(x)); }
 
-// sin and cos: the hardware's v_sin_f32 / v_cos_f32 on x/2π — one multiply and one quarter-rate instruction each,
-// measured max absolute error 2.7e-7 on [−3, 3], 1.4e-7 on [−1, 1] (abl/vsin_test.hip). The parity margins of the GOKU path
-// are unchanged against the polynomial version below (abl/sin_margin.py: 2.4e-6 vs 2.3e-6 from the oracle at 1e-6/1e-6,
-// gate 1e-5) and a Tsit5 step is 11 % shorter (six sines of ≈ 14 instructions each per step become six of 2).
-// -DLDE_HW_SIN=0 (diagnostic) restores the polynomials: k = rint(x/π), r = x − kπ (two-term Cody–Waite with FMA), odd/even
-// minimax on [−π/2, π/2], sign (−1)^k, ≈ 1.3e-7 absolute, ~25 VALU instructions for the pair, branch-free (ocml's sinf
-// carries a Payne–Hanek slow path that costs ≈150 instructions of code per call).
-#ifndef LDE_HW_SIN
-#define LDE_HW_SIN 1
-#endif
+// sin and cos with ≈1.3e-7 absolute error: k = rint(x/π), r = x − kπ (two-term Cody–Waite with FMA),
+// odd/even minimax polynomials on [−π/2, π/2], sign (−1)^k. ~25 VALU instructions for the pair,
+// branch-free (ocml's sinf carries a Payne–Hanek slow path that costs ≈150 instructions of code per call).
 __device__ __forceinline__ void fast_sincos(float x, float& s, float& c) {
-  if (LDE_HW_SIN) {
-    const float r = x * 0.15915494309189535f;
-    s = __builtin_amdgcn_sinf(r);
-    c = __builtin_amdgcn_cosf(r);
-    return;
-  }
   const float k = rintf(x * 0.3183098861837907f);
   float r = fmaf(-k, 3.1415927410125732f, x);
   r = fmaf(-k, -8.742277657347586e-08f, r);
@@ -72,7 +59,6 @@ __device__ __forceinline__ void fast_sincos(float x, float& s, float& c) {
   c = __int_as_float(__float_as_int(cv) ^ sign);
 }
 __device__ __forceinline__ float fast_sin(float x) {
-  if (LDE_HW_SIN) return __builtin_amdgcn_sinf(x * 0.15915494309189535f);
   const float k = rintf(x * 0.3183098861837907f);
   float r = fmaf(-k, 3.1415927410125732f, x);
   r = fmaf(-k, -8.742277657347586e-08f, r);
@@ -82,6 +68,27 @@ __device__ __forceinline__ float fast_sin(float x) {
   ps = fmaf(ps, r2, -0.1666666567325592f);
   const float sv = fmaf(r * r2, ps, r);
   return __int_as_float(__float_as_int(sv) ^ (((int)k) << 31));
+}
+// The hardware's v_sin_f32 / v_cos_f32 on x/2π — one multiply and one quarter-rate instruction each; measured max absolute
+// error 2.7e-7 on [−3, 3], 1.4e-7 on [−1, 1] (abl/vsin_test.hip). Used by the analytic GOKU kernels (lde_pendulum.hip), whose
+// duration at small batches is one wave's dependent-instruction chain: the parity margins are unchanged against the
+// polynomials (abl/sin_margin.py: 2.4e-6 vs 2.3e-6 from the oracle at 1e-6/1e-6, gate 1e-5) and a Tsit5 step is 11 % shorter.
+// NOT used where the sine rides along a network (physics + MLP): there the adaptive adjoint's longest trajectory took 9 %
+// more steps with the slightly noisier sine (c3: 5.65 → 6.01 ms per step), more than the instruction saving is worth.
+// -DLDE_HW_SIN=0 (diagnostic) makes these the polynomials too.
+#ifndef LDE_HW_SIN
+#define LDE_HW_SIN 1
+#endif
+__device__ __forceinline__ float hw_sin(float x) {
+  return LDE_HW_SIN ? __builtin_amdgcn_sinf(x * 0.15915494309189535f) : fast_sin(x);
+}
+__device__ __forceinline__ void hw_sincos(float x, float& s, float& c) {
+  if (LDE_HW_SIN) {
+    const float r = x * 0.15915494309189535f;
+    s = __builtin_amdgcn_sinf(r);
+    c = __builtin_amdgcn_cosf(r);
+  } else
+    fast_sincos(x, s, c);
 }
 
 // ---- Tsit5 tableau (Tsitouras 2011), f32 copies of the f64 constants ------------------------

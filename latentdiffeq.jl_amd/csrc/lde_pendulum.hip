@@ -28,7 +28,7 @@ struct PendFwd {
   __device__ __forceinline__ explicit PendFwd(float L) : ngl(-10.0f / L) {}  // one IEEE division per trajectory
   __device__ __forceinline__ void operator()(const float (&y)[2], float (&dy)[2]) const {
     dy[0] = y[1];
-    float acc = ngl * fast_sin(y[0]);
+    float acc = ngl * hw_sin(y[0]);
     if (KIND == 1) acc -= 0.7f * y[1];
     dy[1] = acc;
   }
@@ -41,7 +41,7 @@ struct PendBwd {
   __device__ __forceinline__ explicit PendBwd(float L) : ngl(-10.0f / L), gl2(10.0f / (L * L)) {}
   __device__ __forceinline__ void operator()(const float (&y)[5], float (&dy)[5]) const {
     float s, c;
-    fast_sincos(y[0], s, c);
+    hw_sincos(y[0], s, c);
     dy[0] = y[1];
     float acc = ngl * s;
     if (KIND == 1) acc -= 0.7f * y[1];
@@ -534,7 +534,7 @@ struct PendBasis {
   // y = [z0 z1 | la0 la1 lb0 lb1 | ga gb]
   __device__ __forceinline__ void operator()(const float (&y)[8], float (&dy)[8]) const {
     float s, c;
-    fast_sincos(y[0], s, c);
+    hw_sincos(y[0], s, c);
     dy[0] = y[1];
     float acc = ngl * s;
     if (KIND == 1) acc -= 0.7f * y[1];

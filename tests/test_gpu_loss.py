@@ -129,3 +129,24 @@ def test_torch_level_functions_match_the_oracle(o64):
     assert abs(float(r) - want) <= E_SUM * want
     assert np.isclose(want, ((x64 - h64) ** 2).transpose(2, 1, 0).mean(axis=(1, 2)).sum(), rtol=1e-12)   # sum(mean(·, dims=(2,3)))
     assert _rel(xh_b.grad.cpu().numpy(), o64.mse_backward(x64, h64, 1 / (B * T), 1.0)) <= E_ELEM
+
+
+def test_loss_errors_are_reported_not_thrown():
+    """NULL operands and negative sizes come back as LDE_ERR_INVALID_ARG; nothing is launched, nothing crashes."""
+    import ctypes as C
+    import torch
+    from latentdiffeq_amd import _lib as L
+    lib = L.load()
+    t = torch.zeros(64, device="cuda")
+    p, null, s = C.c_void_p(t.data_ptr()), C.c_void_p(), C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    bad = L.STATUS_CODE["LDE_ERR_INVALID_ARG"] if hasattr(L, "STATUS_CODE") else -1
+    assert lib.lde_sample_forward(null, p, p, 64, p, s) == bad
+    assert lib.lde_sample_backward(p, p, null, 64, p, s) == bad
+    assert lib.lde_kl_forward(p, p, 64, 1.0, null, p, s) == bad
+    assert lib.lde_kl_forward(p, null, 64, 1.0, p, p, s) == bad
+    assert lib.lde_kl_forward(p, p, -1, 1.0, p, p, s) == bad
+    assert lib.lde_kl_backward(p, p, 64, 1.0, null, p, p, s) == bad
+    assert lib.lde_mse_forward(p, p, 64, 1.0, p, null, s) == bad
+    assert lib.lde_mse_backward(p, p, 64, 1.0, p, null, s) == bad
+    torch.cuda.synchronize()
+    assert float(t.abs().max()) == 0.0

@@ -193,19 +193,24 @@ def run_decoder(args, torch, dist, world, rank, local):
     stream = torch.cuda.current_stream()
     sp = C.c_void_p(stream.cuda_stream)
     ck = lambda rc, ch, what: L.check(rc, ch, what, chain=True)
+    # the training variant of the chains: the forward call keeps the hidden activations for the pullback
+    saved = {k: torch.empty((int(lib.lde_chain_saved_floats(chains[k][0], N if k == "rec" else B)),), device=dev) for k in specs}
 
     def fwd():
-        ck(lib.lde_chain_forward(chains["lo_z0"][0], p(zt), B, p(z0), sp), chains["lo_z0"][0], "lo_z0 fwd")
-        ck(lib.lde_chain_forward(chains["lo_th"][0], p(tt), B, p(th), sp), chains["lo_th"][0], "lo_th fwd")
+        ck(lib.lde_chain_forward_save(chains["lo_z0"][0], p(zt), B, p(z0), p(saved["lo_z0"]), sp), chains["lo_z0"][0], "lo_z0 fwd")
+        ck(lib.lde_chain_forward_save(chains["lo_th"][0], p(tt), B, p(th), p(saved["lo_th"]), sp), chains["lo_th"][0], "lo_th fwd")
         L.check(lib.lde_forward(h, p(z0), p(th), tsp, T, B, p(zout), p(ret), sp), h, "lde_forward")
-        ck(lib.lde_chain_forward(chains["rec"][0], p(zout), N, p(xhat), sp), chains["rec"][0], "rec fwd")
+        ck(lib.lde_chain_forward_save(chains["rec"][0], p(zout), N, p(xhat), p(saved["rec"]), sp), chains["rec"][0], "rec fwd")
 
     def bwd():
         flat.zero_()
-        ck(lib.lde_chain_backward(chains["rec"][0], p(zout), p(xhat), p(dxh), N, p(dz), p(gW["rec"]), sp), chains["rec"][0], "rec bwd")
+        ck(lib.lde_chain_backward_saved(chains["rec"][0], p(zout), p(xhat), p(dxh), p(saved["rec"]), N, p(dz), p(gW["rec"]), sp),
+           chains["rec"][0], "rec bwd")
         L.check(lib.lde_adjoint(h, p(zout), p(th), tsp, T, B, p(dz), p(dz0), p(dth), C.c_void_p(), sp), h, "lde_adjoint")
-        ck(lib.lde_chain_backward(chains["lo_z0"][0], p(zt), p(z0), p(dz0), B, p(dzt), p(gW["lo_z0"]), sp), chains["lo_z0"][0], "lo_z0 bwd")
-        ck(lib.lde_chain_backward(chains["lo_th"][0], p(tt), p(th), p(dth), B, p(dtt), p(gW["lo_th"]), sp), chains["lo_th"][0], "lo_th bwd")
+        ck(lib.lde_chain_backward_saved(chains["lo_z0"][0], p(zt), p(z0), p(dz0), p(saved["lo_z0"]), B, p(dzt), p(gW["lo_z0"]), sp),
+           chains["lo_z0"][0], "lo_z0 bwd")
+        ck(lib.lde_chain_backward_saved(chains["lo_th"][0], p(tt), p(th), p(dth), p(saved["lo_th"]), B, p(dtt), p(gW["lo_th"]), sp),
+           chains["lo_th"][0], "lo_th bwd")
         if world > 1:
             dist.all_reduce(flat)     # the one collective: shared decoder parameters
 
@@ -241,13 +246,15 @@ def run_decoder(args, torch, dist, world, rank, local):
 
     n = min(args.steps, 50)
     parts = {
-        "reconstructor_forward": ev_ms(lambda: ck(lib.lde_chain_forward(chains["rec"][0], p(zout), N, p(xhat), sp), chains["rec"][0], "f"), n),
-        "reconstructor_backward": ev_ms(lambda: ck(lib.lde_chain_backward(chains["rec"][0], p(zout), p(xhat), p(dxh), N, p(dz), p(gW["rec"]), sp), chains["rec"][0], "b"), n),
+        "reconstructor_forward": ev_ms(lambda: ck(lib.lde_chain_forward_save(chains["rec"][0], p(zout), N, p(xhat), p(saved["rec"]), sp), chains["rec"][0], "f"), n),
+        "reconstructor_backward": ev_ms(lambda: ck(lib.lde_chain_backward_saved(chains["rec"][0], p(zout), p(xhat), p(dxh), p(saved["rec"]), N, p(dz), p(gW["rec"]), sp), chains["rec"][0], "b"), n),
+        "reconstructor_backward_recompute": ev_ms(lambda: ck(lib.lde_chain_backward(chains["rec"][0], p(zout), p(xhat), p(dxh), N, p(dz), p(gW["rec"]), sp), chains["rec"][0], "b"), n),
         "lde_forward": ev_ms(lambda: L.check(lib.lde_forward(h, p(z0), p(th), tsp, T, B, p(zout), p(ret), sp), h, "f"), n),
         "lde_adjoint": ev_ms(lambda: L.check(lib.lde_adjoint(h, p(zout), p(th), tsp, T, B, p(dz), p(dz0), p(dth), C.c_void_p(), sp), h, "a"), n),
-        "latent_out_forward_x2": ev_ms(lambda: (lib.lde_chain_forward(chains["lo_z0"][0], p(zt), B, p(z0), sp), lib.lde_chain_forward(chains["lo_th"][0], p(tt), B, p(th), sp)), n),
-        "latent_out_backward_x2": ev_ms(lambda: (lib.lde_chain_backward(chains["lo_z0"][0], p(zt), p(z0), p(dz0), B, p(dzt), p(gW["lo_z0"]), sp),
-                                                 lib.lde_chain_backward(chains["lo_th"][0], p(tt), p(th), p(dth), B, p(dtt), p(gW["lo_th"]), sp)), n),
+        "latent_out_forward_x2": ev_ms(lambda: (lib.lde_chain_forward_save(chains["lo_z0"][0], p(zt), B, p(z0), p(saved["lo_z0"]), sp),
+                                                lib.lde_chain_forward_save(chains["lo_th"][0], p(tt), B, p(th), p(saved["lo_th"]), sp)), n),
+        "latent_out_backward_x2": ev_ms(lambda: (lib.lde_chain_backward_saved(chains["lo_z0"][0], p(zt), p(z0), p(dz0), p(saved["lo_z0"]), B, p(dzt), p(gW["lo_z0"]), sp),
+                                                 lib.lde_chain_backward_saved(chains["lo_th"][0], p(tt), p(th), p(dth), p(saved["lo_th"]), B, p(dtt), p(gW["lo_th"]), sp)), n),
     }
     mac = lambda sizes: sum(a * b for a, b in zip(sizes[:-1], sizes[1:]))
     F_rec = 2 * mac(specs["rec"][0]) * N

@@ -145,7 +145,8 @@ __device__ __forceinline__ float tsit5_dense_eval(float th, float h, float y, fl
 
 // One Tsit5 attempt on an N-vector held in registers. k[0] = f(y) on entry.
 // Leaves k[1..6], yn; returns the RMS error estimate (0 when !adaptive).
-template <int N, class F>
+// MSQ: return the MEAN SQUARE of the scaled error (EEst²) instead of EEst — for callers that run the controller on log₂ EEst.
+template <int N, class F, bool MSQ = false>
 __device__ __forceinline__ float tsit5_attempt(F& f, float h, const float (&y)[N], float (&k)[7][N], float (&yn)[N],
                                                const KOpts& o) {
   float tmp[N];
@@ -180,7 +181,7 @@ __device__ __forceinline__ float tsit5_attempt(F& f, float h, const float (&y)[N
     const float r = e * fast_rcp(sk);
     s2 += r * r;
   }
-  return sqrtf(s2 * (1.0f / N));
+  return MSQ ? s2 * (1.0f / N) : sqrtf(s2 * (1.0f / N));
 }
 
 // classical RK4 on registers; k[0] = f(y) on entry, leaves k[4] = f(yn).

@@ -221,7 +221,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_pend_forward_ws(const float2* __
   PendFwd<KIND> f(valid && w == 0 ? theta[b] : 1.0f);
   int ret = LDE_RET_SUCCESS, nfe = 0, nacc = 0, nrej = 0;
   double t = 0.0, dt = 0.0, tend = 0.0, dtmax = 0.0;
-  float qold = 1e-4f;
+  float lqold = -13.287712379549449f;   // log₂ of qold = 1e-4: the PI controller runs on log₂ EEst here (see below)
   long long iters = 0;
   bool active = false;
 #pragma unroll
@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_pend_forward_ws(const float2* __
           k[0][1] = kf[1];
           float EEst = 0.f;
           if (SOLVER == LDE_SOLVER_TSIT5) {
-            EEst = tsit5_attempt<2>(f, h, y, k, yn, o);
+            EEst = tsit5_attempt<2, PendFwd<KIND>, true>(f, h, y, k, yn, o);   // EEst²
             nfe += 6;
           } else {
             rk4_step<2>(f, h, y, k, yn);
@@ -282,15 +282,18 @@ __global__ void __launch_bounds__(WS_THREADS) k_pend_forward_ws(const float2* __
             break;
           }
           if (o.adaptive) {
-            float q11;
-            const float q = pi_q(EEst, qold, o, q11);
+            // PI controller on l = log₂ EEst = ½ log₂ EEst²: q = EEst^β₁ · qold^(−β₂) = 2^(β₁ l − β₂ l_old) — no square root
+            // and one v_log / v_exp pair per step instead of two (EEst = 0 ⇒ l = −∞ ⇒ q = q_lo, as pi_q has it)
+            const float l = 0.5f * __builtin_amdgcn_logf(EEst);
             if (EEst > 1.0f) {
               nrej++;
+              const float q11 = __builtin_amdgcn_exp2f(o.beta1 * l);
               dt = dt * (double)fast_rcp(fminf(o.q_hi, q11 * o.inv_gamma));
               if (dt < o.dtmin) { ret = LDE_RET_DTMIN; active = false; }
               break;
             }
-            qold = fmaxf(EEst, 1e-4f);
+            const float q = fmaxf(o.q_lo, fminf(o.q_hi, __builtin_amdgcn_exp2f(o.beta1 * l - o.beta2 * lqold) * o.inv_gamma));
+            lqold = fmaxf(l, -13.287712379549449f);
             dtp = dt * (double)fast_rcp(q);
             if (dtp > dtmax) dtp = dtmax;
           }

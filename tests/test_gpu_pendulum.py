@@ -249,6 +249,18 @@ def test_very_long_save_grid(o32):
     assert np.abs(g0 - s0).max() <= 2e-4 * np.abs(s0).max() and np.abs(gL - sL).max() <= 2e-4 * np.abs(sL).max()
 
 
+def test_save_grid_at_the_lds_limit_of_the_small_batch_kernel(o32):
+    """T = 6000: the largest save grid the small-batch forward kernel keeps in LDS beside its step records (≈ 155 KB of the
+    160 KB); many saves per step, several record rounds at this tolerance, a ragged last workgroup."""
+    nat, od = _native(abstol=1e-6, reltol=1e-6)
+    B, T = 70, 6000
+    z0, L = O.pendulum_inputs(B, seed=6)
+    ts = O.time_grid(T, 0.0005)
+    z, ret, _ = nat.forward(z0, L, ts)
+    zr, _, _ = o32.forward(od, z0, L, ts)
+    assert (ret == 0).all() and np.abs(z - zr).max() <= 1e-5
+
+
 _WS_SCRIPT = r"""
 import sys, numpy as np
 sys.path.insert(0, {root!r})

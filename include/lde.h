@@ -239,6 +239,9 @@ int64_t lde_chain_saved_floats(const lde_chain* c, int64_t N);
 int  lde_chain_forward_save(lde_chain* c, const float* x, int64_t N, float* y, float* saved, void* stream);
 int  lde_chain_backward_saved(lde_chain* c, const float* x, const float* y, const float* dy, const float* saved, int64_t N,
                               float* dx, float* dW, void* stream);
+/* How the pullbacks deliver the weight gradient: on = 1 (default) dW += gradient, like lde_adjoint; on = 0: dW = gradient — every
+ * entry of dW is written exactly once, so a caller that wants the plain gradient needs no zero fill (one launch less). */
+int  lde_chain_set_accumulate(lde_chain* c, int on);
 const char* lde_chain_last_error(const lde_chain* c);
 
 /* ======================================================================================================
@@ -282,6 +285,7 @@ int  lde_rnn_reserve(lde_rnn* r, int B, int T);
 int  lde_rnn_forward(lde_rnn* r, const float* x, int T, int B, float* y, void* stream);
 /* Back-propagation through time from dy[hL×B]: dx[in×B×T] (written; may be NULL), dW[n_weights] ACCUMULATED (+=). */
 int  lde_rnn_backward(lde_rnn* r, const float* x, const float* dy, int T, int B, float* dx, float* dW, void* stream);
+int  lde_rnn_set_accumulate(lde_rnn* r, int on);   /* as lde_chain_set_accumulate */
 const char* lde_rnn_last_error(const lde_rnn* r);
 
 /* ====================================================================================================================

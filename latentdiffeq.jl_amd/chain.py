@@ -113,7 +113,7 @@ class _ChainFn(torch.autograd.Function):
         dy = dy.contiguous().float()
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         dx = torch.empty_like(x) if ctx.need_dx else None
-        dW = torch.zeros((chain.num_weights,), device=x.device, dtype=torch.float32)
+        dW = torch.empty((chain.num_weights,), device=x.device, dtype=torch.float32)     # written, not accumulated (set_accumulate(0))
         pdx = C.c_void_p(dx.data_ptr()) if dx is not None else C.c_void_p()
         if ctx.has_saved:
             L.check(lib.lde_chain_backward_saved(h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(dy.data_ptr()),
@@ -173,6 +173,7 @@ class Chain(torch.nn.Module):
                 finally:
                     if h:
                         self._lib.lde_chain_destroy(h)
+            L.check(self._lib.lde_chain_set_accumulate(h, 0), h, "lde_chain_set_accumulate", chain=True)   # the pullback hands autograd a fresh gradient
             self._handle = h
         return self._handle
 

@@ -506,6 +506,7 @@ __global__ void __launch_bounds__(512) k_chain_backward(ChainDims cd, ChainBwdAr
 using namespace lde;
 
 struct lde_chain {
+  bool accumulate = true;   // pullback: dW += gradient (default) or dW = gradient
   lde_chain_desc d;
   ChainDims cd;
   int64_t nW = 0;
@@ -845,7 +846,7 @@ static int chain_backward_impl(lde_chain* c, const float* x, const float* y, con
   // weight gradient: large-K product over the staged panels (lde_mfma.h)
   DwArgs da;
   da.stage = c->stage; da.wts = c->wts; da.nslots = nullptr; da.slab = c->slab; da.cap = cap; da.total = total;   // tiles filled in order
-  rc = launch_weight_gradient(dm, da, nvt, 1, nullptr, c->ints, 0, dW, c->ints + 2, stream, c->err);
+  rc = launch_weight_gradient(dm, da, nvt, 1, nullptr, c->ints, 0, dW, c->ints + 2, stream, c->err, !c->accumulate);
   if (rc) return rc;
   return LDE_OK;
 }
@@ -875,6 +876,12 @@ int lde_chain_backward_saved(lde_chain* c, const float* x, const float* y, const
     return LDE_ERR_INVALID_ARG;
   }
   return chain_backward_impl(c, x, y, dy, saved, N, dx, dW, stream);
+}
+
+int lde_chain_set_accumulate(lde_chain* c, int on) {
+  if (!c) return LDE_ERR_INVALID_ARG;
+  c->accumulate = on != 0;
+  return LDE_OK;
 }
 
 const char* lde_chain_last_error(const lde_chain* c) { return c ? c->err.c_str() : "null handle"; }

@@ -382,7 +382,7 @@ static __global__ void k_sum_slabs(const float* __restrict__ slab, int nslab, in
 // than the gather.
 static __global__ void k_reduce_slabs(const float* __restrict__ priv, const int32_t* __restrict__ nflush, int nwg,
                                       const float* __restrict__ sum, int nslab, MlpDims dm, float* __restrict__ dW,
-                                      int32_t* __restrict__ feedback) {
+                                      int32_t* __restrict__ feedback, int assign) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx == 0) {   // tell the host (asynchronously) whether any workgroup ran out of staging slots
     int mx = 0;
@@ -420,7 +420,8 @@ static __global__ void k_reduce_slabs(const float* __restrict__ priv, const int3
   if (priv)
     for (int w = 0; w < nwg; w++)
       if (nflush[w]) sacc += priv[(size_t)w * dm.slab_n + pos];
-  dW[idx] += sacc;
+  if (assign) dW[idx] = sacc;   // the caller asked for dW = gradient (every entry of dW is one idx of one launch)
+  else dW[idx] += sacc;
 }
 
 template <class T>
@@ -438,7 +439,7 @@ static bool grow(T** ptr, size_t* cap, size_t need) {
 //   slabs: [ntile·ks][slab_n] partial slabs followed by one slab_n sum buffer (caller sizes it: (ntile·ks + 1)·slab_n)
 static int launch_weight_gradient(const MlpDims& dm, const DwArgs& da, int ntile, int ks, const float* priv,
                                   const int32_t* nflush, int npriv, float* dW, int32_t* feedback, hipStream_t stream,
-                                  std::string& err) {
+                                  std::string& err, bool assign = false) {
   const int ndw = dw_pick_ndw(dm);
   const size_t dlds = dw_lds_floats(dm, ndw) * sizeof(float);
   if (dlds > LDS_MAX) {
@@ -461,11 +462,11 @@ static int launch_weight_gradient(const MlpDims& dm, const DwArgs& da, int ntile
   else hipLaunchKernelGGL(k_mlp_dw<4>, grid, dim3(512), dlds, stream, dm, da);
   if (ntile * ks <= 32) {   // few slabs: summed inside the gather
     hipLaunchKernelGGL(k_reduce_slabs, dim3(cdiv(dm.nW, 256)), dim3(256), 0, stream, priv, nflush, npriv, da.slab, ntile * ks, dm, dW,
-                       feedback);
+                       feedback, assign ? 1 : 0);
   } else {
     float* sum = da.slab + (size_t)ntile * ks * dm.slab_n;
     hipLaunchKernelGGL(k_sum_slabs, dim3(cdiv(cdiv(dm.slab_n, 4), 256)), dim3(256), 0, stream, da.slab, ntile * ks, dm.slab_n, sum);
-    hipLaunchKernelGGL(k_reduce_slabs, dim3(cdiv(dm.nW, 256)), dim3(256), 0, stream, priv, nflush, npriv, sum, 0, dm, dW, feedback);
+    hipLaunchKernelGGL(k_reduce_slabs, dim3(cdiv(dm.nW, 256)), dim3(256), 0, stream, priv, nflush, npriv, sum, 0, dm, dW, feedback, assign ? 1 : 0);
   }
   if (hipGetLastError() != hipSuccess) {
     err = "weight-gradient kernels failed to launch";

@@ -354,7 +354,8 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
 
 // dW[state0 slots] += Σ_b g0[b][·]: one wave per state entry, lane j adds trajectories j, j+64, … in order, then a fixed
 // butterfly over the lanes (deterministic)
-__global__ void __launch_bounds__(64) k_rnn_state0(const float* __restrict__ g0, int B, int g0w, RnnDims rd, float* __restrict__ dW) {
+__global__ void __launch_bounds__(64) k_rnn_state0(const float* __restrict__ g0, int B, int g0w, RnnDims rd, float* __restrict__ dW,
+                                                    int assign) {
   const int i = blockIdx.x;
   int off = 0, l = 0;
   for (; l < rd.nL; l++) {
@@ -367,7 +368,10 @@ __global__ void __launch_bounds__(64) k_rnn_state0(const float* __restrict__ g0,
   for (int b = threadIdx.x; b < B; b += 64) s += g0[(size_t)b * g0w + i];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o, 64);
-  if (threadIdx.x == 0) dW[rd.f_off[l] + (size_t)R * in + (size_t)R * h + R + (i - off)] += s;
+  if (threadIdx.x == 0) {
+    float* o = dW + rd.f_off[l] + (size_t)R * in + (size_t)R * h + R + (i - off);
+    *o = assign ? s : *o + s;
+  }
 }
 
 }  // namespace lde
@@ -391,6 +395,7 @@ struct lde_rnn {
   float* g0 = nullptr; size_t g0_cap = 0;
   float* slab = nullptr; size_t slab_cap = 0;
   int32_t* ints = nullptr; size_t ints_cap = 0;
+  bool accumulate = true;   // pullback: dW += gradient (default) or dW = gradient
   void (*kernel[2])(lde::RnnDims, lde::RnnArgs) = {nullptr, nullptr};   // the k_rnn instantiations for this stack: forward, pullback
   std::string err;
 };
@@ -662,14 +667,20 @@ int lde_rnn_backward(lde_rnn* r, const float* x, const float* dy, int T, int B, 
     da.stage = r->stage[l]; da.wts = r->wts; da.nslots = nullptr; da.slab = r->slab; da.cap = T; da.total = (long long)ntile * T;   // every tile staged exactly T slots
     int ks = cdiv(512, ntile * dw_jobs(r->dmw[l], dw_pick_ndw(r->dmw[l])));
     ks = ks < 1 ? 1 : (ks > 8 ? 8 : ks);
-    rc = launch_weight_gradient(r->dmw[l], da, ntile, ks, nullptr, r->ints, 0, dW + rd.f_off[l], r->ints + 2, stream, r->err);
+    rc = launch_weight_gradient(r->dmw[l], da, ntile, ks, nullptr, r->ints, 0, dW + rd.f_off[l], r->ints + 2, stream, r->err, !r->accumulate);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(k_rnn_state0, dim3(r->g0w), dim3(64), 0, stream, r->g0, B, r->g0w, rd, dW);
+  hipLaunchKernelGGL(k_rnn_state0, dim3(r->g0w), dim3(64), 0, stream, r->g0, B, r->g0w, rd, dW, r->accumulate ? 0 : 1);
   if (hipGetLastError() != hipSuccess) {
     r->err = "recurrent stack: gradient kernels failed to launch";
     return LDE_ERR_HIP;
   }
+  return LDE_OK;
+}
+
+int lde_rnn_set_accumulate(lde_rnn* r, int on) {
+  if (!r) return LDE_ERR_INVALID_ARG;
+  r->accumulate = on != 0;
   return LDE_OK;
 }
 

@@ -113,7 +113,7 @@ class _RecurrentFn(torch.autograd.Function):
         dy = dy.contiguous().float()
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         dx = torch.empty_like(x) if ctx.need_dx else None
-        dW = torch.zeros((rec.num_weights,), device=x.device, dtype=torch.float32)
+        dW = torch.empty((rec.num_weights,), device=x.device, dtype=torch.float32)       # written, not accumulated (set_accumulate(0))
         L.check(lib.lde_rnn_backward(h, C.c_void_p(x.data_ptr()), C.c_void_p(dy.data_ptr()), T, B,
                                      C.c_void_p(dx.data_ptr()) if dx is not None else C.c_void_p(), C.c_void_p(dW.data_ptr()), stream),
                 h, "lde_rnn_backward", rnn=True)
@@ -163,6 +163,7 @@ class Recurrent(torch.nn.Module):
                 finally:
                     if h:
                         self._lib.lde_rnn_destroy(h)
+            L.check(self._lib.lde_rnn_set_accumulate(h, 0), h, "lde_rnn_set_accumulate", rnn=True)   # the pullback hands autograd a fresh gradient
             self._handle = h
         return self._handle
 

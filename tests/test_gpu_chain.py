@@ -244,3 +244,37 @@ def test_one_chain_handle_changing_column_counts(o32, spec):
         assert np.array_equal(y, y2), N
         for dx, dW in (nat.backward(x, y, dy), nat.backward_saved(x, y2, dy, saved)):
             assert np.abs(dx - rx).max() <= 1e-4 * np.abs(rx).max() and np.abs(dW - rW).max() <= 1e-4 * np.abs(rW).max(), N
+
+
+def test_overwrite_mode_of_the_weight_gradient(o32):
+    """lde_chain_set_accumulate(0) / lde_rnn_set_accumulate(0): dW = gradient — a dW buffer full of garbage comes back as the plain
+    gradient (bit-identical to accumulating into zeros), for a multi-layer chain, a one-layer chain and an LSTM stack."""
+    import ctypes as C
+    from tests.gpu_util import NativeChain, NativeRnn
+    for spec, N in ((RECON, 300), (ONE, 37)):
+        sizes, acts, skips = spec
+        W = O.mlp_weights(sizes, seed=3)
+        rng = np.random.default_rng(N)
+        x = rng.standard_normal((N, sizes[0])).astype(np.float32)
+        dy = (rng.standard_normal((N, sizes[-1])) / N).astype(np.float32)
+        nat = NativeChain(sizes, acts, skips)
+        nat.set_weights(W)
+        y = nat.forward(x)
+        _, ref = nat.backward(x, y, dy)
+        assert nat.lib.lde_chain_set_accumulate(nat.h, 0) == 0
+        _, got = nat.backward(x, y, dy, dW0=np.full(nat.nW, 123.0, np.float32))
+        assert np.array_equal(got, ref)
+        assert nat.lib.lde_chain_set_accumulate(nat.h, 1) == 0
+        _, acc = nat.backward(x, y, dy, dW0=np.full(nat.nW, 0.5, np.float32))
+        assert np.abs((acc - 0.5) - ref).max() <= 1e-6 * max(1.0, np.abs(ref).max())
+    cell, sizes = O.CELL_LSTM, (32, 16, 16)
+    W = O.rnn_weights(cell, sizes, seed=3)
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((9, 37, 32)).astype(np.float32)
+    dy = (rng.standard_normal((37, 16)) / 37).astype(np.float32)
+    nat = NativeRnn(cell, sizes, True)
+    nat.set_weights(W)
+    _, ref = nat.backward(x, dy)
+    assert nat.lib.lde_rnn_set_accumulate(nat.h, 0) == 0
+    _, got = nat.backward(x, dy, dW0=np.full(nat.nW, -7.0, np.float32))
+    assert np.array_equal(got, ref)

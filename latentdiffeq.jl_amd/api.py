@@ -322,7 +322,7 @@ class _SolveFn(torch.autograd.Function):
         B, D = z0.shape
         T = int(ts.shape[0])
         Dp = D + handle.desc.augment_dim
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = L.raw_stream(z0.device.index)
         if W is not None:
             Wc = W.detach().contiguous().float()
             L.check(lib.lde_set_weights_device(handle.ptr, _ptr(Wc), Wc.numel(), stream), handle.ptr,
@@ -347,7 +347,7 @@ class _SolveFn(torch.autograd.Function):
         T, B, Dp = z_out.shape
         D = handle.desc.state_dim
         dz_out = dz_out.contiguous().float()
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = L.raw_stream(z_out.device.index)
         dz0 = torch.empty((B, D), device=z_out.device, dtype=torch.float32)
         dth = torch.empty_like(theta) if theta is not None else None
         dW = torch.zeros((handle.nW,), device=z_out.device, dtype=torch.float32) if ctx.has_W else None

@@ -83,7 +83,7 @@ class _ChainFn(torch.autograd.Function):
             raise L.LdeError("Chain needs CUDA/HIP tensors: it runs on the GPU only (no CPU fallback)")
         h = chain._native()
         lib = chain._lib
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = L.raw_stream(x.device.index)
         Wc = W.detach().contiguous().float()
         L.check(lib.lde_chain_set_weights_device(h, C.c_void_p(Wc.data_ptr()), Wc.numel(), stream), h,
                 "lde_chain_set_weights_device", chain=True)
@@ -111,7 +111,7 @@ class _ChainFn(torch.autograd.Function):
         lib = chain._lib
         x, y, saved = ctx.saved_tensors
         dy = dy.contiguous().float()
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = L.raw_stream(x.device.index)
         dx = torch.empty_like(x) if ctx.need_dx else None
         dW = torch.empty((chain.num_weights,), device=x.device, dtype=torch.float32)     # written, not accumulated (set_accumulate(0))
         pdx = C.c_void_p(dx.data_ptr()) if dx is not None else C.c_void_p()

@@ -23,7 +23,7 @@ def _p(t):
 
 
 def _stream():
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    return L.raw_stream()
 
 
 def _need_gpu(t):

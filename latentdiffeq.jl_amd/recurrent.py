@@ -93,7 +93,7 @@ class _RecurrentFn(torch.autograd.Function):
             raise L.LdeError("Recurrent needs CUDA/HIP tensors: it runs on the GPU only (no CPU fallback)")
         h = rec._native()
         lib = rec._lib
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = L.raw_stream(x.device.index)
         Wc = W.detach().contiguous().float()
         L.check(lib.lde_rnn_set_weights_device(h, C.c_void_p(Wc.data_ptr()), Wc.numel(), stream), h, "lde_rnn_set_weights_device", rnn=True)
         T, B, _ = x.shape
@@ -111,7 +111,7 @@ class _RecurrentFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         T, B, _ = x.shape
         dy = dy.contiguous().float()
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        stream = L.raw_stream(x.device.index)
         dx = torch.empty_like(x) if ctx.need_dx else None
         dW = torch.empty((rec.num_weights,), device=x.device, dtype=torch.float32)       # written, not accumulated (set_accumulate(0))
         L.check(lib.lde_rnn_backward(h, C.c_void_p(x.data_ptr()), C.c_void_p(dy.data_ptr()), T, B,

@@ -129,6 +129,11 @@ def test_torch_level_functions_match_the_oracle(o64):
     assert abs(float(r) - want) <= E_SUM * want
     assert np.isclose(want, ((x64 - h64) ** 2).transpose(2, 1, 0).mean(axis=(1, 2)).sum(), rtol=1e-12)   # sum(mean(·, dims=(2,3)))
     assert _rel(xh_b.grad.cpu().numpy(), o64.mse_backward(x64, h64, 1 / (B * T), 1.0)) <= E_ELEM
+    # one rank's shard of a global batch of 4·B: the per-rank terms are the reference's divided by 4 (they add up over ranks)
+    with torch.no_grad():
+        assert abs(float(LS.reconstruction_loss(x, xh_b.permute(2, 1, 0), 4 * B)) - want / 4) <= E_SUM * want
+        k1, k4 = float(LS.vector_kl(mu, ls)), float(LS.vector_kl(mu, ls, 4 * B))
+        assert abs(k4 - k1 / 4) <= E_SUM * abs(k1)
 
 
 def test_loss_errors_are_reported_not_thrown():

@@ -18,6 +18,7 @@ latent_in are `Chain`s (lde_chain_*). `sample` (loss.py) draws ε with torch's g
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 
 import torch
@@ -199,6 +200,7 @@ def apply_feature_extractor(encoder: Encoder, x):
 
 
 _side_streams = {}
+_BRANCH_STREAMS = os.environ.get("LDE_BRANCH_STREAMS", "1") != "0"   # encode(): keep the z₀ / θ branches on their own streams (diagnostic switch)
 
 
 def _run_concurrently(stacks, x):
@@ -244,9 +246,45 @@ def apply_latent_in(encoder: Encoder, pe_out):
     return li_mu(pe_out), li_ls(pe_out)
 
 
+def _encode_goku_branches(encoder: Encoder, fe_out):
+    """apply_latent_in(apply_pattern_extractor(fe_out)) for GOKU with the two independent branches kept on their own HIP
+    streams to the end: z₀ branch = pe_z₀ → (li_μ_z₀, li_logσ²_z₀); θ branch = (pe_θ forward, pe_θ backward) → vcat →
+    (li_μ_θ, li_logσ²_θ). The z₀ branch's small chains then run beside the θ branch's longer LSTM stacks instead of after
+    them (and so do their pullbacks: autograd replays every node on its forward stream). Same events as running only the
+    three stacks on side streams; same arithmetic as the two reference functions."""
+    pe_z0_m, pe_f_m, pe_b_m = encoder.pattern_extractor
+    li_mu_z0, li_ls_z0, li_mu_th, li_ls_th = encoder.latent_in
+    dev = fe_out.device
+    main = torch.cuda.current_stream(dev)
+    sA, sB, sC = _side_streams.setdefault((dev.index, 3), [torch.cuda.Stream(dev) for _ in range(3)])
+    ready = main.record_event()
+    for st in (sA, sB, sC):
+        st.wait_event(ready)
+        fe_out.record_stream(st)
+    with torch.cuda.stream(sA):
+        pe_z0 = pe_z0_m(fe_out)
+        mu_z0, ls_z0 = li_mu_z0(pe_z0), li_ls_z0(pe_z0)
+    with torch.cuda.stream(sC):
+        pe_b = pe_b_m(fe_out)
+    with torch.cuda.stream(sB):
+        pe_f = pe_f_m(fe_out)
+        sB.wait_stream(sC)
+        pe_b.record_stream(sB)
+        pe_th = torch.cat([pe_f, pe_b], dim=0)
+        mu_th, ls_th = li_mu_th(pe_th), li_ls_th(pe_th)
+    main.wait_stream(sA)
+    main.wait_stream(sB)
+    for y in (mu_z0, ls_z0, mu_th, ls_th):
+        y.record_stream(main)
+    return (mu_z0, mu_th), (ls_z0, ls_th)
+
+
 def encode(encoder: Encoder, x):
     """(μ, logσ²) = encoder(x)  [REF src/models/LatentDiffEqModel.jl:63-75]."""
-    return apply_latent_in(encoder, apply_pattern_extractor(encoder, apply_feature_extractor(encoder, x)))
+    fe_out = apply_feature_extractor(encoder, x)
+    if isinstance(encoder.model_type, GOKU) and fe_out.is_cuda and _BRANCH_STREAMS:
+        return _encode_goku_branches(encoder, fe_out)
+    return apply_latent_in(encoder, apply_pattern_extractor(encoder, fe_out))
 
 
 from .loss import sample  # noqa: E402,F401  (l̃ = μ + ε·exp(logσ²/2): lde_sample_forward / _backward)

@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(256) k_pend_forward(const float2* __restrict__
 }
 
 // ---- forward, small batches: stepping and dense output on different waves ---------------------------------------------
-// At B ≤ 4096 the launch is a handful of waves and its duration is one wave's dependent-instruction chain. In
+// At B ≤ 16384 (one 64-trajectory workgroup per CU) the launch is a handful of waves per CU and its duration is one wave's dependent-instruction chain. In
 // k_pend_forward a third of that chain is the dense output: ≈ 75 wave-iterations (the per-step maximum over 64 lanes of
 // the saves inside the step) of interpolation, f64 save-time compares and stores — 9.4 of 28.4 µs at T = 50
 // (abl/pend_T.py). Here the stepping wave only RECORDS each accepted step (t, h, y, k₁…k₇) in LDS, five 16-byte words per step,
@@ -779,7 +779,8 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
   const size_t shm = o.T <= TS_LDS_MAX ? (size_t)o.T * sizeof(double) : 0;
   // small batches: stepping and dense output on different waves of a 64-trajectory workgroup (k_pend_forward_ws)
   static const bool ws_on = [] { const char* e = getenv("LDE_PEND_WS"); return !e || atoi(e) != 0; }();
-  if (ws_on && shm && o.T > 2 && block == 64) {
+  static const int ws_max_b = [] { const char* e = getenv("LDE_PEND_WS_MAX_B"); return e ? atoi(e) : 16384; }();   // measured (abl/pend_B.py): 21.6 vs 31.2 µs at 16384, 36.8 vs 32.6 µs at 32768
+  if (ws_on && shm && o.T > 2 && o.B <= ws_max_b) {
     const size_t lds = (size_t)((o.T + 1) & ~1) * sizeof(double) + (size_t)(WS_CAP + 1) * 64 * WS_RW * sizeof(float);
     const int g64 = (o.B + 63) / 64;
 #define LDE_LAUNCH_WS(K, S)                                                                                            \

@@ -281,7 +281,7 @@ np.savez({path!r}, **out)
 
 
 def test_wave_split_forward_matches_the_single_wave_kernel(tmp_path):
-    """Batches ≤ 4096 run k_pend_forward_ws (stepping wave + save waves); LDE_PEND_WS=0 forces k_pend_forward, the kernel of
+    """Batches ≤ 16384 run k_pend_forward_ws (stepping wave + save waves); LDE_PEND_WS=0 forces k_pend_forward, the kernel of
     the large batches. Same step code and the same dense-output formulas: the two agree like two correct f32 solves —
     default and tight tolerance (several record rounds), friction with an off-grid save
     times, fixed-step RK4, a single trajectory, 200 save points, and trajectories that fail (NaN blocks)."""

@@ -589,7 +589,7 @@ __device__ __forceinline__ int pend_interval_operator(float2 zc, float L, double
       break;
     }
     double dtp = dt;
-    if (o.adaptive) {
+    if (o.adaptive && (EEst > 1.0f || !hit)) {   // an accepted step that ends the interval needs no next step size
       float q11;
       const float q = pi_q(EEst, qold, o, q11);
       if (EEst > 1.0f) {

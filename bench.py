@@ -423,6 +423,58 @@ def run_goku_step(args, torch, dist, world, rank, local):
         print(json.dumps(out))
 
 
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks as CHILD processes
+    (`python -m torch.distributed.run --nproc-per-node N bench.py …`, one rank per GPU) BEFORE this process touches a GPU
+    — a process that has initialised HIP must never be replaced by another program —, relay rank 0's single JSON line and
+    exit with the children's code."""
+    import subprocess
+    if not args.dry_launch:
+        import torch
+        have = torch.cuda.device_count()          # counts devices without initialising the GPU
+        if have < args.gpus:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (RCCL needs it)
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, text=True, env=env)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    if r.returncode != 0 or len(lines) != 1:
+        sys.stderr.write(r.stdout)
+        raise SystemExit(r.returncode or 1)
+    print(lines[0])
+    raise SystemExit(0)
+
+
+def dry_launch(args):
+    """The launch path without GPUs (CPU test of the N-rank plumbing): gloo ranks, one all-reduce of ones, one JSON line."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    ranks = 1
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+        one = torch.ones(1)
+        dist.all_reduce(one)
+        ranks = int(one.item())
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps({"metric": "trajectories/sec (fwd+adjoint) GOKU pendulum, batch=256, 1/2/4/8 GPU", "value": 0.0,
+                          "unit": "trajectories/s", "n_gpus": world, "steps": 0, "warmup": 0, "ms_per_step": None,
+                          "dry_launch": True, "collective_ranks": ranks, "config": {"workload": args.workload}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -430,9 +482,19 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--workload", default="goku_pendulum", choices=sorted(WORKLOADS) + ["goku_decoder", "goku_step"])
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default: the workload's)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: the workload's batch on EVERY GPU (default); strong: the workload's batch split over the GPUs")
+    ap.add_argument("--dtype", default="f32", choices=["f32", "mixed"],
+                    help="goku_step / goku_decoder: 'mixed' = bf16 dense chains (f32 accumulate, f32 master weights), f32 solve")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep", action="store_true", help="also report a large-batch sweep (extra keys, rank 0)")
+    ap.add_argument("--dry-launch", action="store_true", help="exercise the N-rank launch path without GPUs (gloo)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        launch_ranks(args, sys.argv[1:])
+    if args.dry_launch:
+        return dry_launch(args)
 
     import torch
     import torch.distributed as dist
@@ -440,14 +502,20 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
+    if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
     torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    args.rccl_ranks = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group("nccl", device_id=dev)
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)                    # RCCL is up and spans every rank
+        args.rccl_ranks = int(one.item())
+        assert args.rccl_ranks == world
 
     if args.workload == "goku_decoder":
         return run_decoder(args, torch, dist, world, rank, local)
@@ -455,128 +523,189 @@ def main():
         return run_goku_step(args, torch, dist, world, rank, local)
 
     from latentdiffeq_amd import _lib as L
+    from latentdiffeq_amd.dist import shard_bounds
     lib = L.load()
     w = WORKLOADS[args.workload]
-    B = args.batch or w["B"]
-    d, ts, z0, theta, W, dz = build_problem(w, B, seed_shift=rank)
     T, D, P = w["T"], w["D"], w["P"]
-
-    h = C.c_void_p()
-    L.check(lib.lde_create(C.byref(d), C.byref(h)), None, "lde_create")
-    nW = int(lib.lde_num_weights(C.byref(d)))
-    if nW:
-        L.check(lib.lde_set_weights(h, W.ctypes.data_as(C.c_void_p), nW), h, "lde_set_weights")
-    L.check(lib.lde_reserve(h, B, T), h, "lde_reserve")
-
-    dev = torch.device("cuda", local)
-    z0d = torch.from_numpy(z0).to(dev)
-    thd = torch.from_numpy(theta).to(dev) if theta is not None else None
-    dzd = torch.from_numpy(dz).to(dev)
-    zout = torch.empty((T, B, D), device=dev)
-    ret = torch.empty((B,), device=dev, dtype=torch.int32)
-    dz0 = torch.empty((B, D), device=dev)
-    dth = torch.empty((B, P), device=dev) if P else None
-    dW = torch.zeros((nW,), device=dev) if nW else None
-    tsp = ts.ctypes.data_as(C.POINTER(C.c_double))
     p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p()
     stream = torch.cuda.current_stream()
     sp = C.c_void_p(stream.cuda_stream)
 
-    def fwd():
-        L.check(lib.lde_forward(h, p(z0d), p(thd), tsp, T, B, p(zout), p(ret), sp), h, "lde_forward")
-
-    def bwd():
-        if dW is not None:
-            dW.zero_()
-        L.check(lib.lde_adjoint(h, p(zout), p(thd), tsp, T, B, p(dzd), p(dz0), p(dth), p(dW), sp), h, "lde_adjoint")
-        if dW is not None and world > 1:  # the one collective of the path: shared RHS-MLP gradient
-            dist.all_reduce(dW)
-
-    def step():
-        fwd()
-        bwd()
+    # the one collective of the path (shared RHS-MLP gradient): through the C ABI (lde_comm_*) when RCCL binds, else torch's
+    comm, comm_kind = None, "none"
+    if world > 1:
+        try:
+            from latentdiffeq_amd.dist import LdeComm
+            comm, comm_kind = LdeComm(rank, world), "lde_comm_allreduce_f32 (C ABI over RCCL)"
+        except Exception as e:                                                   # noqa: BLE001
+            comm_kind = f"torch.distributed all_reduce (lde_comm unavailable: {e})"
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    fence()
-    el = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([el], device=dev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        el = float(tmax.item())
-    ms_per_step = el / args.steps * 1e3
-    value = B * world * args.steps / el
-
-    # per-kernel launch durations, HIP events on the launch stream (separate pass, same launches)
     def kernel_ms(fn, n):
+        """average duration of n launches: bracketed = an event pair around every launch; stream = one pair around n back-to-back"""
         evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
         for a, b in evs:
             a.record(stream)
             fn()
             b.record(stream)
         torch.cuda.synchronize()
-        return float(np.mean([a.elapsed_time(b) for a, b in evs]))
+        br = [a.elapsed_time(b) for a, b in evs]
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(stream)
+        for _ in range(n):
+            fn()
+        b.record(stream)
+        torch.cuda.synchronize()
+        return float(np.mean(br)), float(np.median(br)), a.elapsed_time(b) / n
 
-    nprobe = min(args.steps, 100)
-    fwd()
-    fwd_ms = kernel_ms(fwd, nprobe)
-    bwd_ms = kernel_ms(bwd, nprobe)
+    def measure(B, seed_shift, detail):
+        """W warm-up steps, then exactly K timed steps of lde_forward + lde_adjoint on B resident trajectories."""
+        d, ts, z0, theta, W, dz = build_problem(w, B, seed_shift=seed_shift)
+        h = C.c_void_p()
+        L.check(lib.lde_create(C.byref(d), C.byref(h)), None, "lde_create")
+        nW = int(lib.lde_num_weights(C.byref(d)))
+        if nW:
+            L.check(lib.lde_set_weights(h, W.ctypes.data_as(C.c_void_p), nW), h, "lde_set_weights")
+        L.check(lib.lde_reserve(h, B, T), h, "lde_reserve")
+        z0d = torch.from_numpy(z0).to(dev)
+        thd = torch.from_numpy(theta).to(dev) if theta is not None else None
+        dzd = torch.from_numpy(dz).to(dev)
+        zout = torch.empty((T, B, D), device=dev)
+        ret = torch.empty((B,), device=dev, dtype=torch.int32)
+        dz0 = torch.empty((B, D), device=dev)
+        dth = torch.empty((B, P), device=dev) if P else None
+        dW = torch.zeros((nW,), device=dev) if nW else None
+        tsp = ts.ctypes.data_as(C.POINTER(C.c_double))
 
-    st = L.Stats()
-    lib.lde_get_stats(h, 0, C.byref(st), sp)
-    fstat = dict(nfe=st.nfe, naccept=st.naccept, nreject=st.nreject, nfailed=st.nfailed, max_steps=st.max_steps)
-    lib.lde_get_stats(h, 1, C.byref(st), sp)
-    bstat = dict(nfe=st.nfe, naccept=st.naccept, nreject=st.nreject, nfailed=st.nfailed, max_steps=st.max_steps)
+        def fwd():
+            L.check(lib.lde_forward(h, p(z0d), p(thd), tsp, T, B, p(zout), p(ret), sp), h, "lde_forward")
+
+        def bwd():
+            if dW is not None:
+                dW.zero_()
+            L.check(lib.lde_adjoint(h, p(zout), p(thd), tsp, T, B, p(dzd), p(dz0), p(dth), p(dW), sp), h, "lde_adjoint")
+            if dW is not None and world > 1:  # the one collective of the path: shared RHS-MLP gradient
+                if comm is not None:
+                    comm.allreduce_(dW)
+                else:
+                    dist.all_reduce(dW)
+
+        def step():
+            fwd()
+            bwd()
+
+        for _ in range(args.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        fence()
+        el = time.perf_counter() - t0
+        if world > 1:
+            tmax = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        res = dict(el=el, B=B, nW=nW, problem=(d, ts, z0, theta, W, dz))
+        if detail:
+            nprobe = min(max(args.steps, 20), 200)
+            fwd()
+            res["fwd"] = kernel_ms(fwd, nprobe)
+            res["bwd"] = kernel_ms(bwd, nprobe)
+            res["step"] = kernel_ms(step, nprobe)
+            st = L.Stats()
+            lib.lde_get_stats(h, 0, C.byref(st), sp)
+            res["fstat"] = dict(nfe=st.nfe, naccept=st.naccept, nreject=st.nreject, nfailed=st.nfailed, max_steps=st.max_steps)
+            lib.lde_get_stats(h, 1, C.byref(st), sp)
+            res["bstat"] = dict(nfe=st.nfe, naccept=st.naccept, nreject=st.nreject, nfailed=st.nfailed, max_steps=st.max_steps)
+        res["handle"] = h
+        return res
+
+    Bw = args.batch or w["B"]
+    if args.scaling == "strong":
+        lo, hi = shard_bounds(Bw, rank, world)
+        B = hi - lo
+        global_batch = Bw
+    else:
+        B = Bw
+        global_batch = Bw * world
+    m = measure(B, rank, True)
+    el, nW, h = m["el"], m["nW"], m["handle"]
+    d, ts, z0, theta, W, dz = m["problem"]
+    ms_per_step = el / args.steps * 1e3
+    value = global_batch * args.steps / el
+    (fwd_ms, fwd_med, fwd_stream), (bwd_ms, bwd_med, bwd_stream) = m["fwd"], m["bwd"]
+    fstat, bstat = m["fstat"], m["bstat"]
 
     fb, bb = alg_bytes_per_traj(w)
-    dom, dom_ms, dom_bytes = ("lde_adjoint", bwd_ms, bb) if bwd_ms >= fwd_ms else ("lde_forward", fwd_ms, fb)
+    dom, dom_ms, dom_stream, dom_bytes = ("lde_adjoint", bwd_ms, bwd_stream, bb) if bwd_ms >= fwd_ms else ("lde_forward", fwd_ms, fwd_stream, fb)
     Ff = flops_per_eval(w)
     if Ff and w["batching"] == "coupled":
         flops = (fstat["nfe"] * Ff + bstat["nfe"] * 3 * Ff) * B
     else:
         flops = fstat["nfe"] * Ff + bstat["nfe"] * 3 * Ff
     if Ff:  # MLP right-hand side: compute-bound on the f32 MFMA/VALU rate
-        ach = flops / ((fwd_ms + bwd_ms) * 1e-3) / 1e12
+        ach = flops / ((fwd_stream + bwd_stream) * 1e-3) / 1e12
         roof = dict(bound="mfma", kernel="lde_forward+lde_adjoint", achieved=ach, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=ach / FP32_PEAK_TFLOPS, traffic=None)
+                    frac=ach / FP32_PEAK_TFLOPS, traffic=None, alg_flops_per_step=flops,
+                    avg_launch_ms=fwd_stream + bwd_stream, avg_launch_ms_bracketed=fwd_ms + bwd_ms)
     else:
-        ach = dom_bytes * B / (dom_ms * 1e-3) / 1e9
+        # average launch duration of the dominant call over n back-to-back launches (HIP events on the launch stream); the
+        # bracketed figure (an event pair around every single launch) carries the events' own ≈ 2.5 µs
+        ach = dom_bytes * B / (dom_stream * 1e-3) / 1e9
         roof = dict(bound="hbm", kernel=dom, achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
-                    traffic=None, alg_bytes_per_launch=dom_bytes * B, avg_launch_ms=dom_ms)
+                    traffic=None, alg_bytes_per_launch=dom_bytes * B, avg_launch_ms=dom_stream, avg_launch_ms_bracketed=dom_ms)
 
     # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command
     # (profiles/collect.sh + profiles/summarize.py; FETCH_SIZE ×2 on gfx950, WRITE_SIZE as is — MI355X_MICROARCH.md §HBM)
-    prof = os.path.join(ROOT, "profiles", f"r1_{args.workload}_b{B}_summary.json")
-    if os.path.exists(prof) and not Ff:
-        kn = {"lde_forward": "k_pend_forward", "lde_adjoint": "k_pend_adjoint"}[dom]
-        for name, kd in json.load(open(prof))["kernels"].items():
-            if name.startswith(kn) and "write_bytes" in kd:
-                roof["traffic"] = kd["fetch_bytes_x2_gfx950"] + kd["write_bytes"]
-                roof["traffic_source"] = os.path.relpath(prof, ROOT)
-                roof["rocprof_avg_launch_ms"] = kd["avg_ns"] * 1e-6
+    for rnd in ("r2", "r1"):
+        prof = os.path.join(ROOT, "profiles", f"{rnd}_{args.workload}_b{B}_summary.json" if not Ff else f"{rnd}_{args.workload}_summary.json")
+        if not os.path.exists(prof):
+            continue
+        kern = json.load(open(prof))["kernels"]
+        if not Ff:
+            kn = {"lde_forward": "k_pend_forward", "lde_adjoint": "k_pend_adjoint"}[dom]
+            for name, kd in kern.items():
+                if name.startswith(kn) and "write_bytes" in kd:
+                    roof["traffic"] = kd["fetch_bytes_x2_gfx950"] + kd["write_bytes"]
+                    roof["rocprof_avg_launch_ms"] = kd["avg_ns"] * 1e-6
+        elif B == w["B"]:   # MLP workloads: the solve + adjoint kernels of one step together
+            tr = [kd["fetch_bytes_x2_gfx950"] + kd["write_bytes"] for name, kd in kern.items()
+                  if name.startswith(("k_mlp", "k_reduce", "k_sum")) and "write_bytes" in kd]
+            if tr:
+                roof["traffic"] = float(sum(tr))
+        if roof["traffic"] is not None:
+            roof["traffic_source"] = os.path.relpath(prof, ROOT)
+            break
 
     out = {
         "metric": "trajectories/sec (fwd+adjoint) GOKU pendulum, batch=256, 1/2/4/8 GPU"
         if args.workload == "goku_pendulum" else f"trajectories/sec (fwd+adjoint) {args.workload}",
         "value": value, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: {w['desc']}", "batch_per_gpu": B, "global_batch": B * world,
-                   "save_points": T, "parallelism": f"dp{world} (batch sharded by trajectory, no data-path collective)"
-                   if not nW else f"dp{world} (batch sharded; one all-reduce of dW per step)"},
+        "config": {"workload": f"{args.workload}: {w['desc']}", "batch_per_gpu": B, "global_batch": global_batch,
+                   "save_points": T, "rccl_ranks": args.rccl_ranks,
+                   "parallelism": f"dp{world} (batch sharded by trajectory, no data-path collective)"
+                   if not nW else f"dp{world} (batch sharded; one all-reduce of dW per step: {comm_kind})"},
         "roofline": roof,
-        "kernel_ms": {"lde_forward": fwd_ms, "lde_adjoint": bwd_ms},
+        "kernel_ms": {"lde_forward": fwd_stream, "lde_adjoint": bwd_stream, "lde_forward_bracketed": fwd_ms, "lde_adjoint_bracketed": bwd_ms},
+        # per-step figures from HIP events (an event pair around every step): the wall-clock mean above is K steps / elapsed
+        "ms_per_step_events": {"median": m["step"][1], "mean": m["step"][0], "back_to_back": m["step"][2], "samples": min(max(args.steps, 20), 200)},
         "solver_stats": {"forward": fstat, "adjoint": bstat},
     }
+
+    if world > 1 and args.scaling == "weak" and args.workload == "goku_pendulum":
+        # the same ranks on the GLOBAL batch of the metric (256 split over the GPUs): the strong-scaling figure beside the weak one
+        lo, hi = shard_bounds(Bw, rank, world)
+        ms2 = measure(hi - lo, 100 + rank, False)
+        out["strong_scaling"] = {"global_batch": Bw, "batch_per_gpu": hi - lo, "value": Bw * args.steps / ms2["el"],
+                                 "ms_per_step": ms2["el"] / args.steps * 1e3}
+        lib.lde_destroy(ms2["handle"])
 
     if rank == 0 and args.sweep and not nW:
         sweep = {}
@@ -586,14 +715,15 @@ def main():
             zo = torch.empty((T, Bs, D), device=dev); r = torch.empty((Bs,), device=dev, dtype=torch.int32)
             g0 = torch.empty((Bs, D), device=dev); gt = torch.empty((Bs, P), device=dev)
             lib.lde_reserve(h, Bs, T)
+            tsp2 = ts2.ctypes.data_as(C.POINTER(C.c_double))
 
             def f2():
-                L.check(lib.lde_forward(h, p(a), p(b_), tsp, T, Bs, p(zo), p(r), sp), h, "fwd")
+                L.check(lib.lde_forward(h, p(a), p(b_), tsp2, T, Bs, p(zo), p(r), sp), h, "fwd")
 
             def b2():
-                L.check(lib.lde_adjoint(h, p(zo), p(b_), tsp, T, Bs, p(c), p(g0), p(gt), C.c_void_p(), sp), h, "bwd")
+                L.check(lib.lde_adjoint(h, p(zo), p(b_), tsp2, T, Bs, p(c), p(g0), p(gt), C.c_void_p(), sp), h, "bwd")
             f2(); b2(); torch.cuda.synchronize()
-            fm, bm = kernel_ms(f2, 10), kernel_ms(b2, 10)
+            fm, bm = kernel_ms(f2, 10)[2], kernel_ms(b2, 10)[2]
             sweep[str(Bs)] = dict(traj_per_s=Bs / ((fm + bm) * 1e-3), fwd_ms=fm, bwd_ms=bm,
                                   fwd_GBs=fb * Bs / (fm * 1e-3) / 1e9, bwd_GBs=bb * Bs / (bm * 1e-3) / 1e9)
         out["batch_sweep"] = sweep
@@ -604,6 +734,8 @@ def main():
         out["cpu_baseline"] = None
 
     lib.lde_destroy(h)
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

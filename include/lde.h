@@ -315,6 +315,37 @@ int lde_mse_forward(const float* x, const float* xhat, int64_t n, float scale, f
 /* dx̂_i = g·scale·2·(x̂_i − x_i),  g = *dout */
 int lde_mse_backward(const float* x, const float* xhat, int64_t n, float scale, const float* dout, float* dxhat, void* stream);
 
+/* ====================================================================================================================
+ * The one collective of the path. The reference's only parallelism is `EnsembleThreads()` over the
+ * trajectories of one batch  [REF src/models/GOKU.jl:121]; here the batch shards by trajectory over one process per GPU
+ * with NO collective inside lde_forward / lde_adjoint, and the gradients of the parameters every rank shares — the
+ * RHS-MLP `dW` of lde_adjoint, the chains' and recurrent stacks' `dW` — are summed once per optimiser step
+ * [REF examples/pendulum_friction-less/model_train.jl:186-204 is the step]. These entry points give a `ccall` host that
+ * exchange through the same boundary: an in-place f32 sum over RCCL (xGMI inside a node).
+ *
+ *   rank 0:      lde_comm_unique_id(id)            → hand the 128 bytes to every rank by any host-side means
+ *                                                     (MPI.bcast, a file, Distributed.jl's remotecall — not the library's concern)
+ *   every rank:  hipSetDevice(local_rank); lde_comm_init(&c, nranks, rank, id)        (collective)
+ *   every step:  lde_comm_allreduce_f32(c, flat_gradient, n, stream)                  (asynchronous on `stream`)
+ *
+ * The loss is a mean over the GLOBAL batch [REF model_train.jl:232]: fold 1/B_global into the cotangent and the plain sum is
+ * exact. librccl is bound at run time (a copy already in the process is preferred; LDE_RCCL_PATH overrides); without it these
+ * calls return LDE_ERR_UNSUPPORTED and everything else in the library still works.
+ * ==================================================================================================================== */
+#define LDE_COMM_ID_BYTES 128
+
+typedef struct lde_comm lde_comm;
+
+int  lde_comm_unique_id(char* id /* [LDE_COMM_ID_BYTES], host, written */);
+int  lde_comm_init(lde_comm** out, int nranks, int rank, const char* id /* [LDE_COMM_ID_BYTES] */);
+/* buf[n] (device) ← Σ over ranks of buf[n], in place, asynchronous on `stream`; every rank passes the same n. */
+int  lde_comm_allreduce_f32(lde_comm* c, float* buf, int64_t n, void* stream);
+int  lde_comm_nranks(const lde_comm* c);
+int  lde_comm_rank(const lde_comm* c);
+void lde_comm_destroy(lde_comm* c);
+/* c == NULL: the last error of lde_comm_unique_id / lde_comm_init in this process. */
+const char* lde_comm_last_error(const lde_comm* c);
+
 #ifdef __cplusplus
 }
 #endif

@@ -34,7 +34,10 @@ EXPORTS = ["lde_abi_version", "lde_problem_desc_default", "lde_num_weights", "ld
            "lde_rnn_num_weights", "lde_rnn_create", "lde_rnn_destroy", "lde_rnn_set_weights", "lde_rnn_set_weights_device",
            "lde_rnn_reserve", "lde_rnn_forward", "lde_rnn_backward", "lde_rnn_last_error",
            "lde_sample_forward", "lde_sample_backward", "lde_kl_forward", "lde_kl_backward", "lde_mse_forward",
-           "lde_mse_backward"]
+           "lde_mse_backward",
+           "lde_comm_unique_id", "lde_comm_init", "lde_comm_allreduce_f32", "lde_comm_nranks", "lde_comm_rank",
+           "lde_comm_destroy", "lde_comm_last_error"]
+COMM_ID_BYTES = 128
 LOSS_SCRATCH_FLOATS = 1024
 
 LDE_RNN_MAX_LAYERS = 4
@@ -151,6 +154,15 @@ def load():
     lib.lde_kl_backward.argtypes = [vp, vp, i64, f32, vp, vp, vp, vp]
     lib.lde_mse_forward.argtypes = [vp, vp, i64, f32, vp, vp, vp]
     lib.lde_mse_backward.argtypes = [vp, vp, i64, f32, vp, vp, vp]
+    lib.lde_comm_unique_id.argtypes = [C.c_char_p]
+    lib.lde_comm_init.argtypes = [C.POINTER(vp), i32, i32, C.c_char_p]
+    lib.lde_comm_allreduce_f32.argtypes = [vp, vp, i64, vp]
+    lib.lde_comm_nranks.argtypes = [vp]
+    lib.lde_comm_rank.argtypes = [vp]
+    lib.lde_comm_destroy.argtypes = [vp]
+    lib.lde_comm_destroy.restype = None
+    lib.lde_comm_last_error.argtypes = [vp]
+    lib.lde_comm_last_error.restype = C.c_char_p
     if lib.lde_abi_version() != LDE_ABI_VERSION:
         raise LdeError("liblde.so ABI version mismatch — rebuild")
     _lib = lib

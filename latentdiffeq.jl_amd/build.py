@@ -1,9 +1,10 @@
 """Compile liblde.so (HIP kernels + C ABI) for gfx950, in-tree.
 
-    python latentdiffeq.jl_amd/build.py          # or: import latentdiffeq_amd; latentdiffeq_amd.build_lib()
+    python latentdiffeq.jl_amd/build.py [--force] [-v]     # or: import latentdiffeq_amd; latentdiffeq_amd.build_lib()
 
 hipcc cross-compiles without a GPU; the resulting .so sits next to this file so that it travels with
-the source tree (it is git-ignored, not gpurun-ignored).
+the source tree (it is git-ignored, not gpurun-ignored). Every source is compiled to its own object
+(in parallel, only when it or a header changed), then linked: touching one kernel file rebuilds in seconds.
 """
 from __future__ import annotations
 
@@ -11,37 +12,63 @@ import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "liblde.so")
-SOURCES = ["lde_api.hip", "lde_pendulum.hip", "lde_mlp.hip", "lde_chain.hip", "lde_rnn.hip", "lde_loss.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-Wall", "-Wno-unused-function"]
+SOURCES = ["lde_api.hip", "lde_pendulum.hip", "lde_mlp.hip", "lde_chain.hip", "lde_rnn.hip", "lde_loss.hip", "lde_comm.hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 
-def _stale() -> bool:
-    if not os.path.exists(LIB):
+def _headers():
+    return [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(HERE, "..", "include", "lde.h")]
+
+
+def _newer(target: str, deps) -> bool:
+    if not os.path.exists(target):
         return True
-    t = os.path.getmtime(LIB)
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(HERE, "..", "include", "lde.h")]
+    t = os.path.getmtime(target)
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_lib(force: bool = False, verbose: bool = False) -> str:
-    if not force and not _stale():
-        return LIB
+def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out: str = LIB) -> str:
+    """Build (if stale) and return the library path. `extra_flags` (e.g. ["-DLDE_PROF=1"]) with another `out` makes a
+    diagnostic build next to the product one (objects are then kept in a directory of their own)."""
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
-    if verbose:
-        cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
-        print(" ".join(cmd))
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode != 0:
-        sys.stderr.write(r.stdout + r.stderr)
-        raise RuntimeError("hipcc failed building liblde.so")
-    if verbose:
-        sys.stderr.write(r.stderr)
-    return LIB
+    objdir = OBJ if out == LIB else out + ".obj"
+    os.makedirs(objdir, exist_ok=True)
+    hdrs = _headers()
+    jobs = []
+    for s in SOURCES:
+        src, obj = os.path.join(CSRC, s), os.path.join(objdir, s.replace(".hip", ".o"))
+        if force or _newer(obj, [src, __file__] + hdrs):
+            cmd = [hipcc] + FLAGS + list(extra_flags) + ["-c", src, "-o", obj]
+            if verbose:
+                cmd.insert(1, "-Rpass-analysis=kernel-resource-usage")
+            jobs.append(cmd)
+
+    def run(cmd):
+        if verbose:
+            print(" ".join(cmd))
+        return cmd, subprocess.run(cmd, capture_output=True, text=True)
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), os.cpu_count() or 1)) as ex:
+            for cmd, r in ex.map(run, jobs):
+                if r.returncode != 0:
+                    sys.stderr.write(r.stdout + r.stderr)
+                    raise RuntimeError("hipcc failed: " + " ".join(cmd))
+                if verbose:
+                    sys.stderr.write(r.stderr)
+    objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    if jobs or _newer(out, objs):
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"], capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("hipcc failed linking liblde.so")
+    return out
 
 
 if __name__ == "__main__":

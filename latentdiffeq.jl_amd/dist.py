@@ -94,6 +94,51 @@ def allreduce_flat_(buf: torch.Tensor, group=None) -> torch.Tensor:
     return buf
 
 
+class LdeComm:
+    """The C-ABI communicator (lde_comm_*, include/lde.h): what a `ccall` host uses for the one collective of the path.
+    Rank 0 draws the id (lde_comm_unique_id) and it travels to the other ranks over the already-initialised
+    torch.distributed group (any backend) — or pass `id_bytes` obtained by other means. In-place f32 sum on a HIP stream."""
+
+    def __init__(self, rank: Optional[int] = None, world: Optional[int] = None, id_bytes: Optional[bytes] = None, group=None):
+        import ctypes as C
+
+        from . import _lib as L
+        self._L, self._C = L, C
+        lib = self._lib = L.load()
+        if world is None:
+            world = dist.get_world_size(group) if dist.is_initialized() else 1
+            rank = dist.get_rank(group) if dist.is_initialized() else 0
+        if id_bytes is None:
+            box = [None]
+            if rank == 0:
+                buf = C.create_string_buffer(L.COMM_ID_BYTES)
+                rc = lib.lde_comm_unique_id(buf)
+                box[0] = (rc, buf.raw)
+            if world > 1:
+                dist.broadcast_object_list(box, src=0, group=group)
+            rc, id_bytes = box[0]
+            if rc:
+                raise L.LdeError("lde_comm_unique_id failed: " + (lib.lde_comm_last_error(None) or b"").decode())
+        self.handle = C.c_void_p()
+        rc = lib.lde_comm_init(C.byref(self.handle), world, rank, id_bytes)
+        if rc:
+            raise L.LdeError(f"lde_comm_init failed ({L.STATUS.get(rc, rc)}): " + (lib.lde_comm_last_error(None) or b"").decode())
+        self.rank, self.world = rank, world
+
+    def allreduce_(self, buf: torch.Tensor, stream=None) -> torch.Tensor:
+        if buf.dtype != torch.float32 or not buf.is_cuda or not buf.is_contiguous():
+            raise self._L.LdeError("lde_comm_allreduce_f32 takes a contiguous f32 device buffer")
+        sp = self._L.raw_stream(buf.device.index) if stream is None else self._C.c_void_p(stream.cuda_stream)
+        self._L.check(self._lib.lde_comm_allreduce_f32(self.handle, self._C.c_void_p(buf.data_ptr()), buf.numel(), sp), None,
+                      "lde_comm_allreduce_f32")
+        return buf
+
+    def close(self):
+        if self.handle:
+            self._lib.lde_comm_destroy(self.handle)
+            self.handle = self._C.c_void_p()
+
+
 def diffeq_layer_sharded(decoder, l_hat, t, rank: Optional[int] = None, world: Optional[int] = None):
     """diffeq_layer on this rank's block of columns: returns the LOCAL shard ẑ[:, lo:hi, :] (it feeds the local shard of
     the reconstructor). No communication."""

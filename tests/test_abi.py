@@ -172,3 +172,35 @@ def test_dense_chain_and_recurrent_mirrors_fail_loudly_on_cpu():
         r.sizes[0], r.sizes[1] = 3, 2
         assert lib.lde_rnn_create(C.byref(r), C.byref(h)) == -3 and not h.value
         assert lib.lde_chain_num_weights(C.byref(d)) == 8 and lib.lde_rnn_num_weights(C.byref(r)) == 8 * 3 + 8 * 2 + 8 + 4
+
+
+def _julia_struct_fields(name):
+    """(field, julia type) list of `mutable struct <name>` in INTEGRATION.md, in declaration order."""
+    src = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    m = re.search(r"mutable struct " + name + r"\b(.*?)\nend\b", src, flags=re.S)
+    assert m, name
+    body = re.sub(r"#.*", "", m.group(1))
+    return re.findall(r"(\w+)::(Int32|Int64|Float64|NTuple\{\d+,Int32\})", body)
+
+
+def test_documented_julia_struct_layouts():
+    """The Julia stub of INTEGRATION.md cannot run here; its struct mirrors must at least be field-for-field right:
+    same order, sizes and C offsets (natural alignment — what Julia uses for an isbits-field struct passed by Ref)."""
+    from latentdiffeq_amd import _lib
+    for jname, cstruct in (("LdeDesc", _lib.ProblemDesc), ("LdeChainDesc", _lib.ChainDesc), ("LdeRnnDesc", _lib.RnnDesc)):
+        fields = _julia_struct_fields(jname)
+        assert [f for f, _ in fields] == [f for f, _ in cstruct._fields_], jname
+        off = 0
+        for fname, jt in fields:
+            if jt.startswith("NTuple"):
+                size, align = 4 * int(re.search(r"\{(\d+),", jt).group(1)), 4
+            else:
+                size = align = {"Int32": 4, "Int64": 8, "Float64": 8}[jt]
+            off = (off + align - 1) // align * align
+            cf = getattr(cstruct, fname)
+            assert (cf.offset, cf.size) == (off, size), (jname, fname, cf.offset, off)
+            off += size
+        assert (off + 7) // 8 * 8 == C.sizeof(cstruct) or off == C.sizeof(cstruct), jname
+    # the stub must start from the library's defaults (sensealg = PARALLEL_CHECKPOINTED), not from zeros
+    src = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "lde_problem_desc_default" in src.split("mutable struct LdeHandle")[0]

@@ -118,9 +118,10 @@ def cpu_baseline(w, d_native, ts, z0, theta, W, dz, budget_s=12.0):
             if el > budget:
                 return n, el
 
-    # EnsembleThreads analogue: pick the thread count that is fastest on this box (more threads than
-    # trajectories-worth-of-work only adds fork/join cost), then time that one for the budget.
-    cands = [1] if w["batching"] != "per_trajectory" else sorted({1, 8, 16, 32, 64, min(avail, 128), avail} & set(range(1, avail + 1)))
+    # EnsembleThreads analogue (per-trajectory mode: OpenMP over trajectories; coupled mode: OpenMP over the columns of every
+    # stage evaluation, the role OpenBLAS threads play under the reference's per-stage sgemms): pick the thread count that is
+    # fastest on this box (more threads than work only adds fork/join cost), then time that one for the budget.
+    cands = sorted({1, 8, 16, 32, 64, min(avail, 128), avail} & set(range(1, avail + 1)))
     best, best_r = 1, 0.0
     for nt in cands:
         n, el = rate(nt, 0.8)
@@ -130,7 +131,16 @@ def cpu_baseline(w, d_native, ts, z0, theta, W, dz, budget_s=12.0):
     n, el = rate(nthreads, budget_s)
     return dict(value=n * cap / el, unit="trajectories/s", cores=nthreads, kind="port",
                 sample=f"{n} passes of fwd+adjoint over {cap} trajectories of the same workload, {el:.1f} s wall, "
-                       f"{nthreads} OpenMP thread(s) (fastest of {cands} on {avail} available cores)")
+                       f"{nthreads} OpenMP thread(s) (fastest of {cands} on {avail} available cores; {cpu_model()})")
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            names = [ln.split(":", 1)[1].strip() for ln in f if ln.startswith("model name")]
+        return f"{names[0]}, {len(names)} logical CPUs" if names else "unknown CPU"
+    except OSError:
+        return "unknown CPU"
 
 
 # ---- decoder path: apply_latent_out → diffeq_layer → apply_reconstructor and its pullback (scope row f-1) ----------
@@ -339,7 +349,7 @@ def decoder_cpu_baseline(specs, weights, d_native, ts, zt, tt, dxh, B, T, budget
     n, el = rate(best, budget_s)
     return dict(value=n * cap / el, unit="trajectories/s", cores=best, kind="port",
                 sample=f"{n} passes of the decoder step over {cap} trajectories ({cap * T} reconstructor columns), {el:.1f} s wall, "
-                       f"{best} OpenMP thread(s) (fastest of {cands} on {avail} available cores)")
+                       f"{best} OpenMP thread(s) (fastest of {cands} on {avail} available cores; {cpu_model()})")
 
 
 # ---- whole GOKU training step (BASELINE.json configs[4] shape, one GPU's share): encoder → sample → decoder → loss → pullback → AdamW
@@ -362,7 +372,8 @@ def run_goku_step(args, torch, dist, world, rank, local):
         lo_th._dense[-1].bias.fill_(1.0)
     mods = [enc.feature_extractor, *enc.pattern_extractor, *enc.latent_in, lo_z0, lo_th, dec.reconstructor]
     params = [p for m in mods for p in m.parameters()]
-    opt = torch.optim.AdamW(params, lr=1e-3, weight_decay=1e-10, fused=True)   # [REF model_train.jl:138, :150]; one fused update kernel
+    from latentdiffeq_amd.train import FluxADAMW
+    opt = FluxADAMW(params, lr=1e-3, decay=1e-10)   # ADAMW(η, β, decay), Flux flavour [REF model_train.jl:138, :150]; one fused update kernel
     sync = FlatGradAllReduce(params)
     torch.manual_seed(1000 + rank)
     x = torch.rand(T, B, NI, device=dev).permute(2, 1, 0)                   # synthetic frames in [0, 1], this rank's shard: [pixels, B, T] in the

@@ -79,12 +79,15 @@ __device__ __forceinline__ float fast_sin(float x) {
 #ifndef LDE_HW_SIN
 #define LDE_HW_SIN 1
 #endif
+// v_sin_f32 / v_cos_f32 are only defined for |x/2π| ≤ 256 (outside they return 0 / 1 — a pendulum that has rotated past
+// ≈ 1608 rad would silently lose its restoring force), so the argument is reduced with v_fract_f32 first, one full-rate
+// instruction, as LLVM's own lowering of sin for gfx9 does.
 __device__ __forceinline__ float hw_sin(float x) {
-  return LDE_HW_SIN ? __builtin_amdgcn_sinf(x * 0.15915494309189535f) : fast_sin(x);
+  return LDE_HW_SIN ? __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x * 0.15915494309189535f)) : fast_sin(x);
 }
 __device__ __forceinline__ void hw_sincos(float x, float& s, float& c) {
   if (LDE_HW_SIN) {
-    const float r = x * 0.15915494309189535f;
+    const float r = __builtin_amdgcn_fractf(x * 0.15915494309189535f);
     s = __builtin_amdgcn_sinf(r);
     c = __builtin_amdgcn_cosf(r);
   } else

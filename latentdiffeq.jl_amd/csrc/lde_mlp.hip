@@ -1471,11 +1471,20 @@ int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::strin
   if (slots_force > 0) want = slots_force;
   if (want < nst) want = nst;
   if (want > (1 << 24)) want = 1 << 24;
-  const int cap = (int)want;
   int ks = cdiv(768, nwg * dw_jobs(dm, dw_pick_ndw(dm)));
   ks = ks < 1 ? 1 : (ks > 16 ? 16 : ks);
   size_t nsl = (size_t)p->nslots_cap;
-  if (!grow(&p->stage, &p->stage_cap, (size_t)(nwg + 1) * cap * dm.blk_floats) || !grow(&p->wts, &p->wts_cap, (size_t)(nwg + 1) * cap * NB) ||
+  // the staging area is the large allocation: if the device cannot give it (another allocator holds the memory, a smaller
+  // device), halve the slot count down to one step's worth — a workgroup that runs out of slots folds them into its private
+  // slab inside the solve kernel (exact), so fewer slots cost time, never correctness
+  int cap = (int)want;
+  for (;;) {
+    if (grow(&p->stage, &p->stage_cap, (size_t)(nwg + 1) * cap * dm.blk_floats)) break;
+    (void)hipGetLastError();
+    if (cap <= nst || slots_force > 0 || steps_hint > 0) { cap = 0; break; }
+    cap = cap / 2 < nst ? nst : cap / 2;
+  }
+  if (cap == 0 || !grow(&p->wts, &p->wts_cap, (size_t)(nwg + 1) * cap * NB) ||
       !grow(&p->slab, &p->slab_cap, ((size_t)(nwg + 1) * (1 + ks) + 1) * dm.slab_n) || !grow(&p->nslots, &nsl, (size_t)2 * (nwg + 1))) {
     err = "MLP plan: hipMalloc of the adjoint workspace failed";
     return LDE_ERR_ALLOC;

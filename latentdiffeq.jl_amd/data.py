@@ -63,3 +63,60 @@ def generate_dataset(diffeq=None, tspan: Tuple[float, float] = (0.0, 4.95), dt: 
     latent = z.permute(0, 2, 1).contiguous()                                                                    # [2, T, n]
     frames = create_frames(latent[0].t(), *high_dim_args)                                                        # [n, T, 28, 28]
     return latent, torch.from_numpy(u0s).to(device), torch.from_numpy(ps).to(device), frames.permute(2, 3, 1, 0).contiguous()
+
+
+# ---- on-disk container and the example script's loader (host code, no kernels) ------------------------------------------------
+DATA_KEYS = ("latent_data", "u0s", "ps", "high_dim_data")
+
+
+def save_dataset(path: str, latent_data, u0s, ps, high_dim_data) -> str:
+    """`@save data_path data` with `data = (latent_data, u0s, ps, high_dim_data)`  [REF examples/pendulum_friction-less/
+    model_train.jl:86-91]. The reference writes a BSON file; BSON is Julia-side glue (no reader in this image), so the same
+    4-tuple is kept as one `.npz` with the tuple's names, arrays in the reference's shapes: latent_data [2, T, n], u0s [2, n],
+    ps [1, n], high_dim_data [28, 28, T, n] (float32)."""
+    arrs = {k: np.ascontiguousarray((v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)), dtype=np.float32)
+            for k, v in zip(DATA_KEYS, (latent_data, u0s, ps, high_dim_data))}
+    if not path.endswith(".npz"):
+        path += ".npz"
+    np.savez(path, **arrs)
+    return path
+
+
+def load_dataset(path: str):
+    """`load(data_path, :data)` → (latent_data, u0s, ps, high_dim_data) as numpy arrays  [REF model_train.jl:95]."""
+    with np.load(path) as f:
+        missing = [k for k in DATA_KEYS if k not in f]
+        if missing:
+            raise KeyError(f"{path}: not a dataset container (missing {missing})")
+        return tuple(np.array(f[k]) for k in DATA_KEYS)
+
+
+def prepare_training_data(data, at: float = 0.9):
+    """What the example script does with the loaded tuple  [REF model_train.jl:96-121]: vectorise the frames to
+    [input_dim, full_seq_len, observations], split the OBSERVATIONS 90 / 10 in order (`splitobs(·, 0.9)`: the first
+    floor-rounded 90 % train, the rest validation — no shuffle), and bring the validation set to [input_dim, n_val, T].
+    Returns dict(train_set [input_dim, T, n_train], val_set [input_dim, n_val, T], train/val latent and params, input_dim,
+    full_seq_len)."""
+    latent, _u0s, ps, high = data
+    h, w, T, n = high.shape
+    train_data = high.reshape(h * w, T, n, order="F").astype(np.float32)           # Julia's reshape(train_data, :, T, n) is column-major
+    n_train = int(round(at * n))                                                   # MLUtils.splitobs: round(Int, at·n)
+    sp = lambda a: (a[..., :n_train], a[..., n_train:])
+    tr, va = sp(train_data)
+    trl, val = sp(np.asarray(latent))
+    trp, vap = sp(np.asarray(ps))
+    return dict(train_set=tr, val_set=np.transpose(va, (0, 2, 1)), train_set_latent=trl, val_set_latent=val,
+                train_set_params=trp, val_set_params=vap, input_dim=h * w, full_seq_len=T)
+
+
+def data_loader(train_set, batch_size: int, rng: Optional[np.random.Generator] = None, device: Optional[str] = None):
+    """`DataLoader(train_set, batchsize, shuffle=true, partial=false)`  [REF model_train.jl:117]: one pass over a random
+    permutation of the observations in full minibatches [input_dim, full_seq_len, batch] → yielded as [input_dim, batch,
+    full_seq_len] tensors (the script's `permutedims(x, [1,3,2])` inside the loop [REF model_train.jl:179])."""
+    rng = rng or np.random.default_rng()
+    n = train_set.shape[-1]
+    perm = rng.permutation(n)
+    for i in range(0, n - batch_size + 1, batch_size):
+        xb = np.transpose(train_set[..., perm[i:i + batch_size]], (0, 2, 1))
+        t = torch.from_numpy(np.ascontiguousarray(xb))
+        yield t.to(device) if device else t

@@ -98,28 +98,28 @@ class _MseFn(torch.autograd.Function):
 
 
 def _same_layout(a: torch.Tensor, b: torch.Tensor):
-    """a and b brought to contiguous buffers with the SAME element order."""
+    """a and b brought to contiguous buffers with the SAME element order; also returns the permutation applied to both
+    (None when they were contiguous already) so that a caller can undo it — never inferred from shapes: a [16, 16] view
+    permutes without changing its shape."""
     if a.shape != b.shape:
         raise ValueError("operands differ in shape")
     if a.is_contiguous() and b.is_contiguous():
-        return a, b
+        return a, b, None
     order = sorted(range(b.dim()), key=lambda d: -b.stride(d))
     a2, b2 = a.permute(order), b.permute(order)
     if not b2.is_contiguous():
         b2 = b2.contiguous()
     if not a2.is_contiguous():
         a2 = a2.contiguous()
-    return a2, b2
+    return a2, b2, (None if order == list(range(b.dim())) else order)
 
 
 def _sample1(mu, logvar):
-    m, s = _same_layout(mu.float(), logvar.float())
+    m, s, order = _same_layout(mu.float(), logvar.float())
     eps = torch.randn(m.shape, device=m.device, dtype=torch.float32)
     out = _SampleFn.apply(m, s, eps)
-    if m.shape != mu.shape:                      # undo the common permutation
-        order = sorted(range(logvar.dim()), key=lambda d: -logvar.stride(d))
-        inv = [order.index(d) for d in range(mu.dim())]
-        out = out.permute(inv)
+    if order is not None:                        # undo the common permutation
+        out = out.permute([order.index(d) for d in range(mu.dim())])
     return out
 
 
@@ -131,7 +131,7 @@ def sample(mu, logvar, model_type=None):
 
 
 def _kl_sum(mu, logvar, scale: float):
-    m, s = _same_layout(mu.float(), logvar.float())
+    m, s, _ = _same_layout(mu.float(), logvar.float())
     return _KlFn.apply(m, s, float(scale))
 
 
@@ -150,7 +150,7 @@ def vector_kl(mu, logvar, batch_size=None):
 def reconstruction_loss(x, x_hat, batch_size=None):
     """sum(mean((x − x̂)², dims=(2,3))) for x, x̂ [pixels, B, T]  [REF examples/pendulum_friction-less/model_train.jl:225-238]
     (`batch_size`: the global B when the arrays are one rank's shard)."""
-    xs, xh = _same_layout(x.float(), x_hat.float())
+    xs, xh, _ = _same_layout(x.float(), x_hat.float())
     n_mean = batch_size or x_hat.shape[1]
     for d in x_hat.shape[2:]:
         n_mean *= d

@@ -251,7 +251,14 @@ def _encode_goku_branches(encoder: Encoder, fe_out):
     streams to the end: z₀ branch = pe_z₀ → (li_μ_z₀, li_logσ²_z₀); θ branch = (pe_θ forward, pe_θ backward) → vcat →
     (li_μ_θ, li_logσ²_θ). The z₀ branch's small chains then run beside the θ branch's longer LSTM stacks instead of after
     them (and so do their pullbacks: autograd replays every node on its forward stream). Same events as running only the
-    three stacks on side streams; same arithmetic as the two reference functions."""
+    three stacks on side streams; same arithmetic as the two reference functions.
+
+    Allocator invariant (torch's caching allocator ties a block to the stream it was allocated on): every tensor that
+    ESCAPES its `with torch.cuda.stream(...)` block is recorded on the stream that consumes it — fe_out on the three side
+    streams, pe_b on sB, the four results on main. pe_z0, pe_f and pe_th are produced and consumed on ONE stream and are
+    not returned; anything that starts using them elsewhere (e.g. returning pe_out for diagnostics) must add
+    `record_stream` for that stream. tests/test_gpu_rnn.py::test_branch_streams_match_joined_streams runs both paths
+    over changing (B, T) and compares outputs and gradients."""
     pe_z0_m, pe_f_m, pe_b_m = encoder.pattern_extractor
     li_mu_z0, li_ls_z0, li_mu_th, li_ls_th = encoder.latent_in
     dev = fe_out.device

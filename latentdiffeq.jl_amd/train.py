@@ -114,17 +114,40 @@ def time_loader(x, full_seq_len: int, seq_len: int, rng: Optional[np.random.Gene
     return x[:, :, rand_time(full_seq_len, seq_len, rng)]
 
 
+class FluxADAMW(torch.optim.Adam):
+    """`ADAMW(η, (β₁, β₂), decay)` of the pinned Flux 0.13.6 [REF Manifest.toml:452] = `Optimiser(ADAM(η, β), WeightDecay(decay))`
+    [REF examples/pendulum_friction-less/model_train.jl:138]: Δ = η·m̂/(√v̂ + ε), then Δ += decay·x, then x −= Δ, i.e.
+    x ← (1 − decay)·x − ADAM step — the decay is NOT multiplied by η (torch.optim.AdamW applies lr·weight_decay·x: 1000× weaker at
+    the example's η = decay = 1e-3). ε = 1e-8 and the bias correction are Flux's = torch's. Implemented as one multi-tensor scale
+    of the parameters followed by torch's (fused, on GPU) Adam update with the gradients taken at the un-decayed point."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), decay: float = 0.0, eps: float = 1e-8, fused=None):
+        params = list(params)
+        if fused is None:
+            fused = bool(params) and all(p.is_cuda for p in params)
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0.0, fused=fused or None)
+        self.decay = float(decay)
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        if self.decay:
+            for g in self.param_groups:
+                ps = [p for p in g["params"] if p.grad is not None]
+                if ps:
+                    torch._foreach_mul_(ps, 1.0 - self.decay)
+        return super().step(closure)
+
+
 def train(model: LatentDiffEqModel, loader_train: Iterable, val_set, dt: float, epochs: int, seq_len: int, full_seq_len: int,
           lr: float = 1e-3, decay: float = 1e-10, start_beta: float = 0.0, end_beta: float = 1.0, n_cycle: int = 3, ratio: float = 0.9,
           progressive_training: bool = False, prog_training_duration: int = 0, start_seq_len: int = 0, variational: bool = True,
           rng: Optional[np.random.Generator] = None, on_epoch: Optional[Callable] = None, grad_sync: Optional[Callable] = None):
     """The epoch loop of the example script  [REF examples/pendulum_friction-less/model_train.jl:138-218]: cyclical β, optional
-    progressive sequence length, AdamW, validation loss after every minibatch, best weights kept. `loader_train` yields
+    progressive sequence length, Flux-flavour ADAMW, validation loss after every minibatch, best weights kept. `loader_train` yields
     x [pixels, B, full_seq_len] tensors on the model's device; `grad_sync` is called between backward and the optimiser step
     (dist.FlatGradAllReduce for multi-GPU). Returns (history, best_state)."""
     params = model.parameters()
-    opt = torch.optim.AdamW(params, lr=lr, betas=(0.9, 0.999), weight_decay=decay,           # ADAMW(η, (0.9, 0.999), decay)
-                            fused=all(p.is_cuda for p in params))                            # one update kernel for all parameters
+    opt = FluxADAMW(params, lr=lr, betas=(0.9, 0.999), decay=decay)      # ADAMW(η, (0.9, 0.999), decay), Flux flavour
     schedule = frange_cycle_linear(epochs, start_beta, end_beta, n_cycle, ratio)
     if progressive_training:
         prog = np.rint(np.linspace(start_seq_len, seq_len, prog_training_duration)).astype(int)

@@ -598,11 +598,42 @@ typedef struct {
   int64_t Bstride;     /* full batch size B (stride between save times) */
   int checkpoint;
   double* dW_acc;      /* [nW] committed quadrature (double accumulation) */
+  colrhs* cs;          /* coupled mode with nth > 1: one RHS scratch per OpenMP thread (columns of a stage evaluation are
+                          independent — the reference gets the same from OpenBLAS threads under its per-stage sgemms) */
+  int nth;
 } blockctx;
+
+static void block_threads_init(blockctx* b, const lde_problem_desc* d, const real* W, int nthreads) {
+  b->nth = 1;
+  b->cs = NULL;
+#ifdef _OPENMP
+  if (nthreads > 1) {
+    b->nth = nthreads;
+    b->cs = (colrhs*)calloc((size_t)nthreads, sizeof(colrhs));
+    for (int t = 0; t < nthreads; t++) colrhs_init(&b->cs[t], d, W);
+  }
+#else
+  (void)d; (void)W; (void)nthreads;
+#endif
+}
+static void block_threads_free(blockctx* b) {
+  if (b->cs) {
+    for (int t = 0; t < b->nth; t++) colrhs_free(&b->cs[t]);
+    free(b->cs);
+  }
+}
 
 static void fwd_fn(void* vctx, double t, const real* y, real* dy, real wq) {
   (void)t; (void)wq;
   blockctx* b = (blockctx*)vctx;
+#ifdef _OPENMP
+  if (b->nth > 1) {
+#pragma omp parallel for num_threads(b->nth) schedule(static)
+    for (int c = 0; c < b->ncol; c++)
+      rhs_col(&b->cs[omp_get_thread_num()], y + (int64_t)c * b->Dp, b->theta + (int64_t)c * b->P, dy + (int64_t)c * b->Dp);
+    return;
+  }
+#endif
   for (int c = 0; c < b->ncol; c++) rhs_col(&b->c, y + (int64_t)c * b->Dp, b->theta + (int64_t)c * b->P, dy + (int64_t)c * b->Dp);
 }
 
@@ -611,6 +642,23 @@ static void bwd_fn(void* vctx, double t, const real* y, real* dy, real wq) {
   (void)t;
   blockctx* b = (blockctx*)vctx;
   int64_t nz = (int64_t)b->Dp * b->ncol;
+#ifdef _OPENMP
+  if (b->nth > 1) {
+#pragma omp parallel for num_threads(b->nth) schedule(static)
+    for (int c = 0; c < b->ncol; c++) {
+      real vz[1024], vth[16];
+      const real* z = y + (int64_t)c * b->Dp;
+      const real* lam = y + nz + (int64_t)c * b->Dp;
+      real* fz = dy + (int64_t)c * b->Dp;
+      real* dl = dy + nz + (int64_t)c * b->Dp;
+      real* dg = dy + 2 * nz + (int64_t)c * b->P;
+      rhs_vjp_col(&b->cs[omp_get_thread_num()], z, b->theta + (int64_t)c * b->P, lam, fz, vz, vth, wq);
+      for (int i = 0; i < b->Dp; i++) dl[i] = -vz[i];
+      for (int p = 0; p < b->P; p++) dg[p] = -vth[p];
+    }
+    return;
+  }
+#endif
   real vz[1024]; /* Dp <= 1024 (check_desc) */
   real vth[16];
   for (int c = 0; c < b->ncol; c++) {
@@ -638,11 +686,18 @@ static void bwd_jump(void* vctx, int j, real* y) {
 static void bwd_begin(void* vctx) {
   blockctx* b = (blockctx*)vctx;
   if (b->c.dW_step) memset(b->c.dW_step, 0, (size_t)b->c.nW * sizeof(real));
+  if (b->cs)
+    for (int t = 0; t < b->nth; t++)
+      if (b->cs[t].dW_step) memset(b->cs[t].dW_step, 0, (size_t)b->cs[t].nW * sizeof(real));
 }
 static void bwd_commit(void* vctx) {
   blockctx* b = (blockctx*)vctx;
   if (b->c.dW_step && b->dW_acc)
     for (int64_t i = 0; i < b->c.nW; i++) b->dW_acc[i] += (double)b->c.dW_step[i];
+  if (b->cs && b->dW_acc)
+    for (int t = 0; t < b->nth; t++)   /* fixed thread order: deterministic for a given thread count */
+      if (b->cs[t].dW_step)
+        for (int64_t i = 0; i < b->cs[t].nW; i++) b->dW_acc[i] += (double)b->cs[t].dW_step[i];
 }
 
 static int check_desc(const lde_problem_desc* d) {
@@ -678,6 +733,7 @@ int oracle_forward(const lde_problem_desc* d, const real* W, const real* z0, con
     memset(&b, 0, sizeof(b));
     colrhs_init(&b.c, d, W);
     b.ncol = B; b.Dp = Dp; b.P = P; b.theta = theta;
+    block_threads_init(&b, d, W, nthreads);
     int64_t n = (int64_t)Dp * B;
     real* y0 = (real*)calloc((size_t)n, sizeof(real));
     for (int c = 0; c < B; c++)
@@ -689,6 +745,7 @@ int oracle_forward(const lde_problem_desc* d, const real* W, const real* z0, con
       if (retcode) retcode[c] = st.retcode;
     nfe = st.nfe; nacc = st.nacc; nrej = st.nrej; nfail = st.retcode ? B : 0; maxsteps = st.nacc + st.nrej;
     free(y0);
+    block_threads_free(&b);
     colrhs_free(&b.c);
   } else {
 #ifdef _OPENMP
@@ -835,6 +892,7 @@ int oracle_adjoint(const lde_problem_desc* d, const real* W, const real* z_out, 
     colrhs_init(&b.c, d, W);
     b.ncol = B; b.Dp = Dp; b.P = P; b.theta = theta;
     b.zsave = z_out; b.dzout = dz_out; b.Bstride = B; b.checkpoint = ckpt; b.dW_acc = dW_tot;
+    block_threads_init(&b, d, W, nthreads);
     int64_t nz = (int64_t)Dp * B, n = 2 * nz + (int64_t)P * B;
     real* y = (real*)calloc((size_t)n, sizeof(real));
     int bad = 0;
@@ -851,6 +909,7 @@ int oracle_adjoint(const lde_problem_desc* d, const real* W, const real* z_out, 
     }
     nfe = st.nfe; nacc = st.nacc; nrej = st.nrej; nfail = (bad || st.retcode) ? B : 0; maxsteps = st.nacc + st.nrej;
     free(y);
+    block_threads_free(&b);
     colrhs_free(&b.c);
   } else {
 #ifdef _OPENMP

@@ -136,6 +136,28 @@ def test_torch_level_functions_match_the_oracle(o64):
         assert abs(k4 - k1 / 4) <= E_SUM * abs(k1)
 
 
+@pytest.mark.parametrize("B", [16, 17])
+def test_sample_when_batch_equals_latent_dim(o64, B):
+    """B == latent dim (16, the default latent_dim_z0 / latent_dim_theta): the [16, 16] transposed views permute without
+    changing shape — the result must still come back in the caller's layout (round-1 advisor finding)."""
+    import torch
+    from latentdiffeq_amd import loss as LS
+    torch.manual_seed(3)
+    mu_b = torch.randn(B, 16, device="cuda", requires_grad=True)
+    ls_b = (0.5 * torch.randn(B, 16, device="cuda")).requires_grad_(True)
+    mu, ls = mu_b.t(), ls_b.t()                                                   # [16, B] non-contiguous views
+    torch.manual_seed(11)
+    l = LS.sample(mu, ls)
+    torch.manual_seed(11)
+    eps = torch.randn(B, 16, device="cuda")
+    want = o64.sample_forward(mu_b.detach().cpu().numpy().astype(np.float64), ls_b.detach().cpu().numpy().astype(np.float64),
+                              eps.cpu().numpy().astype(np.float64))
+    assert l.shape == (16, B) and _rel(l.detach().t().cpu().numpy(), want) <= E_ELEM
+    ct = torch.randn(16, B, device="cuda")
+    (l * ct).sum().backward()
+    assert torch.equal(mu_b.grad, ct.t())
+
+
 def test_loss_errors_are_reported_not_thrown():
     """NULL operands and negative sizes come back as LDE_ERR_INVALID_ARG; nothing is launched, nothing crashes."""
     import ctypes as C

@@ -310,3 +310,32 @@ def test_wave_split_forward_matches_the_single_wave_kernel(tmp_path):
         assert np.nanmax(np.abs(za[:, ok] - zb[:, ok]), initial=0.0) <= lim, name
         sa, sb = a[name + "_st"], b[name + "_st"]
         assert np.all(np.abs(sa - sb) <= 0.02 * sb[1] + 3), (name, sa, sb)     # nfe, naccept, nreject, nfailed: within 2 % of the steps
+
+
+@pytest.mark.parametrize("sense", [O.SENSE_PARALLEL_CHECKPOINTED, O.SENSE_BACKSOLVE_CHECKPOINTED])
+def test_large_angles_keep_their_restoring_force(o32, o64, sense):
+    """v_sin_f32 / v_cos_f32 are defined for |x/2π| ≤ 256 only (≈ 1608 rad): beyond that the raw instruction returns 0 / 1 and
+    a pendulum that has wound up many turns would silently drift in a straight line. The kernels reduce the argument first;
+    known answer: the solution from θ₀ + 2πk equals the solution from θ₀ shifted by 2πk (the right-hand side is 2π-periodic)."""
+    nat, od = _native(abstol=1e-6, reltol=1e-6, sensealg=sense)
+    B, T, k = 64, 50, 320                                        # 2π·320 ≈ 2011 rad > 1608
+    z0, L = O.pendulum_inputs(B)
+    ts = O.time_grid(T)
+    shift = np.float32(2 * np.pi * k)
+    z0s = z0.copy()
+    z0s[:, 0] += shift
+    z, ret, _ = nat.forward(z0s, L, ts)
+    zb, _, _ = nat.forward(z0, L, ts)
+    assert (ret == 0).all()
+    ulp = np.spacing(np.float32(shift + 3))                      # f32 resolution at that magnitude (≈ 1.2e-4)
+    # the angle, un-shifted in float64, and the velocity follow the base solution — not θ₀ + ω₀·t
+    assert np.abs((z[..., 0].astype(np.float64) - float(shift)) - zb[..., 0]).max() <= 8 * ulp
+    assert np.abs(z[..., 1] - zb[..., 1]).max() <= 2e-3
+    drift = z0[None, :, 0] + z0[None, :, 1] * ts[:, None]        # what sin ≡ 0 would give
+    assert np.abs(zb[..., 0] - drift).max() > 0.2                # (the two are far apart, so the check above means something)
+    zr, _, _ = o32.forward(od, z0s, L, ts)                       # the oracle uses libm's sinf on the same inputs
+    assert np.abs(z[..., 1] - zr[..., 1]).max() <= 2e-3
+    dz = O.cotangent(T, B, 2)
+    g0, gL, _, _ = nat.adjoint(z, L, ts, dz)
+    r0, rL, _, _ = o32.adjoint(od, z, L, ts, dz)
+    assert np.abs(g0 - r0).max() <= 2e-3 * np.abs(r0).max() and np.abs(gL - rL).max() <= 2e-3 * np.abs(rL).max()

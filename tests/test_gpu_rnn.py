@@ -191,3 +191,40 @@ def test_instantiated_and_run_time_shaped_kernels_agree(tmp_path):
     for k in res["0"].files:
         a, b = res["0"][k], res["1"][k]
         assert np.abs(a - b).max() <= 2e-6 * max(np.abs(b).max(), 1e-30), k
+
+
+def test_branch_streams_match_joined_streams():
+    """encode() with the z₀ / θ branches kept on their own HIP streams to the end (default) against the variant that joins the
+    streams after the recurrent stacks, over several iterations with changing (B, T) — allocator reuse across streams would
+    show up as differing outputs or gradients (round-1 advisor finding on record_stream coverage)."""
+    import torch
+    import latentdiffeq_amd as M
+    from latentdiffeq_amd import recurrent as R
+    torch.manual_seed(2)
+    NI = 48
+    mt = M.GOKU_basic()
+    fe, pe, li = R.default_encoder_layers(mt, NI, hidden_dim_resnet=40, device="cuda")
+    enc = R.Encoder(mt, (fe, pe, li))
+    params = [p for m in [fe, *pe, *li] for p in m.parameters()]
+    keep = R._BRANCH_STREAMS
+    try:
+        for it, (B, T) in enumerate([(20, 7), (64, 12), (16, 5), (33, 9), (64, 12), (256, 20)]):
+            x = torch.rand(NI, B, T, device="cuda")
+            cts = [torch.randn(16, B, device="cuda") for _ in range(4)]
+            res = []
+            for flag in (True, False):
+                R._BRANCH_STREAMS = flag
+                for p in params:
+                    p.grad = None
+                (mz, mt_), (lz, lt) = R.encode(enc, x)
+                junk = [torch.randn(64, 64, device="cuda") for _ in range(8)]       # churn the main stream's allocator between the two
+                ((mz * cts[0]).sum() + (mt_ * cts[1]).sum() + (lz * cts[2]).sum() + (lt * cts[3]).sum()).backward()
+                torch.cuda.synchronize()
+                res.append(([t.detach().clone() for t in (mz, mt_, lz, lt)], [p.grad.clone() for p in params]))
+                del junk
+            for a, b in zip(res[0][0], res[1][0]):
+                assert torch.equal(a, b), (it, B, T)
+            for a, b in zip(res[0][1], res[1][1]):
+                assert torch.equal(a, b), (it, B, T)
+    finally:
+        R._BRANCH_STREAMS = keep

@@ -426,3 +426,25 @@ def test_coupled_vs_per_trajectory_semantics(o64):
     zc2, _, _ = o64.forward(mk(O.BATCH_COUPLED), z0[:3], None, ts, W=W)
     assert not np.array_equal(zc2, zc[:, :3])               # batch-mates matter in coupled mode
     assert np.abs(zc2 - zc[:, :3]).max() < 2e-3
+
+
+def test_coupled_mode_threads_over_columns_agree_with_serial(o32):
+    """bench.py's cpu_baseline runs the coupled configs with OpenMP over the columns of every stage evaluation; the
+    checker itself (nthreads = 0) stays serial. Columns are independent inside a stage, so ẑ is bit-identical and the
+    shared-weight gradient differs only by summation order."""
+    layers = (8, 24, 24, 8)
+    W = O.mlp_weights(layers, seed=3, scale=0.5)
+    rng = np.random.default_rng(1)
+    B, T = 12, 10
+    z0 = (0.5 * rng.standard_normal((B, 8))).astype(np.float32)
+    ts = O.time_grid(T)
+    dz = O.cotangent(T, B, 8)
+    for kw in (dict(solver=O.SOLVER_TSIT5), dict(solver=O.SOLVER_RK4, adaptive=0, dt=0.05)):
+        d = O.make_desc(rhs_kind=O.RHS_MLP, state_dim=8, param_dim=0, layers=layers, batching=O.BATCH_COUPLED, **kw)
+        z1, r1, i1 = o32.forward(d, z0, None, ts, W=W)
+        z4, r4, i4 = o32.forward(d, z0, None, ts, W=W, nthreads=4)
+        assert np.array_equal(z1, z4) and i1["naccept"] == i4["naccept"]
+        g1 = o32.adjoint(d, z1, None, ts, dz, W=W)
+        g4 = o32.adjoint(d, z1, None, ts, dz, W=W, nthreads=4)
+        assert np.array_equal(g1[0], g4[0])
+        assert np.allclose(g1[2], g4[2], rtol=1e-4, atol=1e-7 * np.abs(g1[2]).max())

@@ -10,7 +10,7 @@ T = 50
 ts = O.time_grid(T); tsp = ts.ctypes.data_as(C.POINTER(C.c_double))
 s = torch.cuda.current_stream(); sp = C.c_void_p(s.cuda_stream)
 p = lambda t: C.c_void_p(t.data_ptr())
-for B in (1024, 2048, 4096, 8192, 16384, 32768):
+for B in (256, 512, 1024, 2048, 4096, 8192, 16384, 32768):
     z0, L = O.pendulum_inputs(B)
     nat = Native(make_desc())
     z0d = torch.tensor(z0, device="cuda"); thd = torch.tensor(L, device="cuda")

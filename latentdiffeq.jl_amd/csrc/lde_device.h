@@ -80,14 +80,19 @@ __device__ __forceinline__ float fast_sin(float x) {
 #define LDE_HW_SIN 1
 #endif
 // v_sin_f32 / v_cos_f32 are only defined for |x/2π| ≤ 256 (outside they return 0 / 1 — a pendulum that has rotated past
-// ≈ 1608 rad would silently lose its restoring force), so the argument is reduced with v_fract_f32 first, one full-rate
-// instruction, as LLVM's own lowering of sin for gfx9 does.
-__device__ __forceinline__ float hw_sin(float x) {
-  return LDE_HW_SIN ? __builtin_amdgcn_sinf(__builtin_amdgcn_fractf(x * 0.15915494309189535f)) : fast_sin(x);
+// ≈ 1608 rad would silently lose its restoring force). The argument is therefore reduced — not per sine (v_fract_f32 would
+// put one more instruction on every stage's dependent chain AND lose the absolute precision of small negative angles:
+// fract(−ε) = 1 − ε rounds at 6e-8 turns), but ONCE PER STEP ATTEMPT: the caller anchors the whole turns of the step's start
+// angle, noff = −rint(x₀/2π), and every stage evaluates sin(2π·fma(x, 1/2π, noff)) — the multiply that was there anyway,
+// exact for |x| < π (noff = 0), and within a step the angle moves by |h·ω| ≪ 256 turns.
+constexpr float INV_2PI = 0.15915494309189535f;
+__device__ __forceinline__ float turn_anchor(float x0) { return LDE_HW_SIN ? -rintf(x0 * INV_2PI) : 0.f; }
+__device__ __forceinline__ float hw_sin(float x, float noff = 0.f) {
+  return LDE_HW_SIN ? __builtin_amdgcn_sinf(fmaf(x, INV_2PI, noff)) : fast_sin(x);
 }
-__device__ __forceinline__ void hw_sincos(float x, float& s, float& c) {
+__device__ __forceinline__ void hw_sincos(float x, float& s, float& c, float noff = 0.f) {
   if (LDE_HW_SIN) {
-    const float r = __builtin_amdgcn_fractf(x * 0.15915494309189535f);
+    const float r = fmaf(x, INV_2PI, noff);
     s = __builtin_amdgcn_sinf(r);
     c = __builtin_amdgcn_cosf(r);
   } else
@@ -149,7 +154,8 @@ __device__ __forceinline__ float tsit5_dense_eval(float th, float h, float y, fl
 // One Tsit5 attempt on an N-vector held in registers. k[0] = f(y) on entry.
 // Leaves k[1..6], yn; returns the RMS error estimate (0 when !adaptive).
 // MSQ: return the MEAN SQUARE of the scaled error (EEst²) instead of EEst — for callers that run the controller on log₂ EEst.
-template <int N, class F, bool MSQ = false>
+// ADAPT: 1 / 0 = the error estimate is / is not needed, decided at compile time; −1 = o.adaptive decides at run time.
+template <int N, class F, bool MSQ = false, int ADAPT = -1>
 __device__ __forceinline__ float tsit5_attempt(F& f, float h, const float (&y)[N], float (&k)[7][N], float (&yn)[N],
                                                const KOpts& o) {
   float tmp[N];
@@ -172,7 +178,7 @@ __device__ __forceinline__ float tsit5_attempt(F& f, float h, const float (&y)[N
     yn[i] = y[i] + h * acc;
   }
   f(yn, k[6]);
-  if (!o.adaptive) return 0.f;
+  if (ADAPT == 0 || (ADAPT < 0 && !o.adaptive)) return 0.f;
   float s2 = 0.f;
 #pragma unroll
   for (int i = 0; i < N; i++) {

@@ -18,17 +18,25 @@
 namespace lde {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // ---- the closed menu of 2-state / 1-parameter physics RHS -------------------------------------
 // KIND 0: du = [y, -(G/L) sin x]                    [REF examples/pendulum_friction-less/pendulum.jl:19-26]
 // KIND 1: du = [y, -(G/L) sin x - (b/m) y], b/m=0.7  [REF pendulum.jl:65-74]
 template <int KIND>
 struct PendFwd {
-  float ngl;  // -G/L
-  __device__ __forceinline__ explicit PendFwd(float L) : ngl(-10.0f / L) {}  // one IEEE division per trajectory
+  float ngl;   // -G/L
+  float noff;  // −(whole turns of the step's start angle): see turn_anchor (lde_device.h)
+  __device__ __forceinline__ explicit PendFwd(float L) : ngl(-10.0f / L), noff(0.f) {}  // one IEEE division per trajectory
+  __device__ __forceinline__ void anchor(float x0) { noff = turn_anchor(x0); }
+  __device__ __forceinline__ f32x2 ev(f32x2 y) const {   // the same right-hand side on a register pair (v_pk_* arithmetic around it)
+    float acc = ngl * hw_sin(y.x, noff);
+    if (KIND == 1) acc -= 0.7f * y.y;
+    return f32x2{y.y, acc};
+  }
   __device__ __forceinline__ void operator()(const float (&y)[2], float (&dy)[2]) const {
     dy[0] = y[1];
-    float acc = ngl * hw_sin(y[0]);
+    float acc = ngl * hw_sin(y[0], noff);
     if (KIND == 1) acc -= 0.7f * y[1];
     dy[1] = acc;
   }
@@ -38,10 +46,12 @@ struct PendFwd {
 template <int KIND>
 struct PendBwd {
   float ngl, gl2;  // -G/L, G/L²
-  __device__ __forceinline__ explicit PendBwd(float L) : ngl(-10.0f / L), gl2(10.0f / (L * L)) {}
+  float noff;
+  __device__ __forceinline__ explicit PendBwd(float L) : ngl(-10.0f / L), gl2(10.0f / (L * L)), noff(0.f) {}
+  __device__ __forceinline__ void anchor(float x0) { noff = turn_anchor(x0); }
   __device__ __forceinline__ void operator()(const float (&y)[5], float (&dy)[5]) const {
     float s, c;
-    hw_sincos(y[0], s, c);
+    hw_sincos(y[0], s, c, noff);
     dy[0] = y[1];
     float acc = ngl * s;
     if (KIND == 1) acc -= 0.7f * y[1];
@@ -53,6 +63,52 @@ struct PendBwd {
     dy[4] = -(gl2 * s * y[3]);
   }
 };
+
+// -DLDE_PEND_PROF=1 (diagnostic builds, abl/pend_prof.py): lane 0 of wave 0 of workgroup 0 of k_pend_forward_ws stamps the
+// 100 MHz wall clock and the shader cycle counter at its phase boundaries; read back with lde_debug_pend_prof.
+#ifndef LDE_PEND_PROF
+#define LDE_PEND_PROF 0
+#endif
+#ifndef LDE_PEND_ABL
+#define LDE_PEND_ABL 0   // diagnostic ablations of the stepping loop (abl/pend_prof.py): 1 no record writes, 2 no controller, 3 idle helpers
+#endif
+#if LDE_PEND_PROF
+static __device__ long long g_pprof[32];
+#define PPROF(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { g_pprof[2 * (i)] = wall_clock64(); g_pprof[2 * (i) + 1] = __builtin_readcyclecounter(); } } while (0)
+#define PPROF_VAL(i, v) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_pprof[i] = (v); } while (0)
+#else
+#define PPROF(i) do { } while (0)
+#define PPROF_VAL(i, v) do { } while (0)
+#endif
+
+// One Tsit5 attempt on the 2-vector state held as ONE register pair: every stage sum is a chain of v_pk_fma_f32 with a
+// scalar coefficient (no per-component instructions, no operand shuffles) — the stepping wave's instruction count is the
+// metric kernel's duration. Same tableau, same order of operations per component as tsit5_attempt<2>; k[0] = f(y) on entry;
+// leaves k[1..6], yn; returns the mean square of the scaled error (EEst²; 0 when !ADAPT).
+template <class F, bool ADAPT>
+__device__ __forceinline__ float tsit5_attempt_pair(F& f, float h, f32x2 y, f32x2 (&k)[7], f32x2& yn, const KOpts& o) {
+#pragma unroll
+  for (int s = 1; s < 6; s++) {
+    f32x2 acc = k[0] * ts5::A[s][0];
+#pragma unroll
+    for (int j = 1; j < s; j++) acc += k[j] * ts5::A[s][j];
+    k[s] = f.ev(y + acc * h);
+  }
+  f32x2 acc = k[0] * ts5::A[6][0];
+#pragma unroll
+  for (int j = 1; j < 6; j++) acc += k[j] * ts5::A[6][j];
+  yn = y + acc * h;
+  k[6] = f.ev(yn);
+  if (!ADAPT) return 0.f;
+  f32x2 e = k[0] * ts5::BT[0];
+#pragma unroll
+  for (int j = 1; j < 7; j++) e += k[j] * ts5::BT[j];
+  e *= h;
+  const f32x2 sk = f32x2{fmaxf(fabsf(y.x), fabsf(yn.x)), fmaxf(fabsf(y.y), fabsf(yn.y))} * o.reltol + o.abstol;
+  const f32x2 r = e * f32x2{fast_rcp(sk.x), fast_rcp(sk.y)};
+  const f32x2 r2 = r * r;
+  return (r2.x + r2.y) * 0.5f;
+}
 
 constexpr int TS_LDS_MAX = 6000;   // doubles of the save-time grid kept in LDS (48 KB)
 
@@ -83,6 +139,7 @@ __global__ void __launch_bounds__(256) k_pend_forward(const float2* __restrict__
   if (T > 1) {
     double t = s_ts(0);
     const double tend = s_ts(T - 1), dtmax = tend - t;
+    f.anchor(y[0]);
     f(y, k[0]);
     nfe = 1;
     double dt;
@@ -106,6 +163,7 @@ __global__ void __launch_bounds__(256) k_pend_forward(const float2* __restrict__
       if (t + dt >= tend - 1e-12 * fabs(tend)) { dt = tend - t; last = true; }
       const float h = (float)dt;
       float EEst = 0.f;
+      f.anchor(y[0]);
       if (SOLVER == LDE_SOLVER_TSIT5) {
         EEst = tsit5_attempt<2>(f, h, y, k, yn, o);
         nfe += 6;
@@ -180,228 +238,530 @@ __global__ void __launch_bounds__(256) k_pend_forward(const float2* __restrict__
   st_nrej[b] = nrej;
 }
 
-// ---- forward, small batches: stepping and dense output on different waves ---------------------------------------------
-// At B ≤ 16384 (one 64-trajectory workgroup per CU) the launch is a handful of waves per CU and its duration is one wave's dependent-instruction chain. In
-// k_pend_forward a third of that chain is the dense output: ≈ 75 wave-iterations (the per-step maximum over 64 lanes of
-// the saves inside the step) of interpolation, f64 save-time compares and stores — 9.4 of 28.4 µs at T = 50
-// (abl/pend_T.py). Here the stepping wave only RECORDS each accepted step (t, h, y, k₁…k₇) in LDS, five 16-byte words per step,
-// and the workgroup's sixteen waves then evaluate the saves from the records, each a contiguous slice of the save grid for
-// the same 64 trajectories (one barrier pair per ≤ 20 accepted steps; a trajectory that needs more steps than the record
-// area holds simply goes through another round). Same formulas as k_pend_forward; the two compilations contract
-// multiply-adds differently, so they agree to the solver's tolerance, not bit for bit (tests/test_gpu_pendulum.py).
-// Measured (B = 256, T = 50): 28.4 → 22.7 µs.
-constexpr int WS_CAP = 20;       // accepted steps recorded between two save phases
-constexpr int WS_WAVES = 16;     // waves per workgroup: one steps, all sixteen evaluate saves
+// ---- forward, small batches: stepping and dense output on different waves, pipelined through LDS ------------------------
+// At B ≤ 16384 (one 64-trajectory workgroup per CU) the launch is a handful of waves per CU and its duration is one wave's
+// dependent-instruction chain. In k_pend_forward a third of that chain is the dense output: ≈ 75 wave-iterations (the
+// per-step maximum over 64 lanes of the saves inside the step) of interpolation, f64 save-time compares and stores — 9.4 of
+// 28.4 µs at T = 50 (abl/pend_T.py). Here wave 0 (the stepper) does nothing but step, and what it leaves behind per
+// accepted step is THREE floats in LDS — the step size and the state after the step — followed by the trajectory's step
+// count (LDS executes one wave's instructions in order, so a reader that sees the count sees the records; no barrier, no
+// fence on the stepping chain). One wave's LDS writes cost ≈ 5 cycles per float (abl/valu_rate.hip): the full record of
+// round 1 — h, y, k₁…k₇, t: 25 floats — was 216 of the 1130 cycles of a step (abl/pend_prof.py with -DLDE_PEND_ABL=1).
+// The helper waves poll the counts and evaluate the saves, helper i of the nh helpers that do not share the stepper's
+// SIMD a contiguous slice of the save grid for the same 64 trajectories, each lane as soon as ITS trajectory has passed the save
+// time: the lane re-evaluates the six stages of the ONE step its save time falls in from (yₙ, hₙ) — same code, same
+// inputs as the stepper's — and interpolates; start times are rebuilt by the same f64 additions the stepper makes. A
+// helper serves 4–5 neighbouring save times, so it repeats ≈ 2 of the ≈ 19 steps, off the critical path. Only the saves inside the
+// last step remain after the stepper is done (round 1: 2.2 µs of save phase + 0.7 µs of barriers behind the stepping loop).
+// The record area holds WS_CAP steps; a trajectory that needs more goes through another round (one barrier pair per round).
+// Same formulas as k_pend_forward; the two compilations contract multiply-adds differently, so they agree to the solver's
+// tolerance, not bit for bit (tests/test_gpu_pendulum.py).
+constexpr int WS_CAP = 96;       // accepted steps recorded per round
+constexpr int WS_WAVES = 16;     // waves per workgroup: wave 0 steps, waves 1…15 evaluate saves
+constexpr int WS_HELPERS = WS_WAVES - 1;
 constexpr int WS_THREADS = 64 * WS_WAVES;
-constexpr int WS_RW = 20;        // floats per record = five 16-byte words: {h, y₀, y₁, –} {k₁ k₂} {k₃ k₄} {k₅ k₆} {k₇, t (f64)};
-                                 // a lane stride of 80 B spreads the 16 lanes of a b128 access over all 64 banks
+constexpr int WS_RW = 4;         // floats per record: {h, y₀, y₁ after the step, –}: 16 B per lane, conflict-free b128 / b64 accesses
 
-template <int KIND, int SOLVER>
+template <int KIND, int SOLVER, bool ADAPT>
 __global__ void __launch_bounds__(WS_THREADS) k_pend_forward_ws(const float2* __restrict__ z0, const float* __restrict__ theta,
                                                          const double* __restrict__ ts_g, KOpts o,
                                                          float2* __restrict__ z_out, int32_t* __restrict__ retcode,
                                                          int32_t* __restrict__ st_nfe, int32_t* __restrict__ st_nacc,
                                                          int32_t* __restrict__ st_nrej, int32_t* __restrict__ st_ret) {
   extern __shared__ __attribute__((aligned(16))) double s_lds[];
-  __shared__ int s_cnt[64];
-  __shared__ int s_done;
+  __shared__ int s_cnt[64];      // records published per trajectory in this round
+  __shared__ int s_fin;          // 0: the stepper is stepping; 1: its round is over, another follows; 2: all trajectories done
+  __shared__ int s_fail;         // some trajectory of the workgroup failed (NaN block to be written after the helpers' stores)
+  __shared__ int s_simd[WS_WAVES];   // the SIMD each wave landed on
+  __shared__ __attribute__((aligned(16))) float s_base[64 * 4];   // where every trajectory stands at the start of the round: {t (f64), y₀, y₁}
   const int T = o.T, B = o.B, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-  for (int i = tid; i < T; i += WS_THREADS) s_lds[i] = ts_g[i];
-  float* rec = reinterpret_cast<float*>(s_lds + ((T + 1) & ~1));          // [(WS_CAP + 1)][64][WS_RW]
-  auto rec_at = [&](int n) -> float* { return rec + (size_t)(n * 64 + lane) * WS_RW; };
-  auto rec_t = [&](int n) -> double { return *reinterpret_cast<const double*>(rec_at(n) + 18); };   // start time of record n
-  __syncthreads();
-  auto s_ts = [&](int i) -> double { return s_lds[i]; };
+  PPROF(0);
+#if LDE_PEND_PROF
+  if (blockIdx.x == 0 && tid == 0) { g_pprof[27] = 0; g_pprof[29] = 0; g_pprof[24] = 0; }
+#endif
   const int b = blockIdx.x * 64 + lane;
   const bool valid = b < B;
-  constexpr int FS = (SOLVER == LDE_SOLVER_TSIT5) ? 6 : 4;  // FSAL slope
-
-  // --- the stepping wave's state (wave 0) ---
-  float y[2] = {0.f, 0.f}, k[7][2], yn[2], kf[2] = {0.f, 0.f};   // kf: f(y) at the current state (the first-same-as-last slope)
-  PendFwd<KIND> f(valid && w == 0 ? theta[b] : 1.0f);
-  int ret = LDE_RET_SUCCESS, nfe = 0, nacc = 0, nrej = 0;
-  double t = 0.0, dt = 0.0, tend = 0.0, dtmax = 0.0;
-  float lqold = -13.287712379549449f;   // log₂ of qold = 1e-4: the PI controller runs on log₂ EEst here (see below)
-  long long iters = 0;
-  bool active = false;
-#pragma unroll
-  for (int s = 0; s < 7; s++) k[s][0] = k[s][1] = 0.f;
-  if (w == 0 && valid) {
-    const float2 zi = z0[b];
-    y[0] = zi.x;
-    y[1] = zi.y;
-    z_out[b] = zi;  // ts[0] is saved as ẑ₀ itself
-    if (T > 1) {
-      t = s_ts(0);
-      tend = s_ts(T - 1);
-      dtmax = tend - t;
-      f(y, kf);
-      nfe = 1;
-      if (o.adaptive) {
-        if (o.dt_fixed > 0) dt = fmin(o.dt_fixed, dtmax);
-        else {
-          dt = init_dt<2>(f, y, kf, 1.0f, dtmax, o);
-          nfe++;
-        }
-      } else
-        dt = o.dt_fixed;
-      active = t < tend;
-    }
+  // inputs are requested before the save grid is staged: one memory latency instead of two
+  float2 zi = make_float2(0.f, 0.f);
+  float Lb = 1.0f;
+  if (valid) {
+    zi = z0[b];
+    Lb = theta[b];
   }
-  // --- the save waves' state: wave w owns the saves j ∈ [jq, jend) of its 64 trajectories ---
-  const int chunk = (T - 1 + WS_WAVES - 1) / WS_WAVES;
-  int jq = 1 + w * chunk;
-  const int jend = min(T, 1 + (w + 1) * chunk);
+  for (int i = tid; i < T; i += WS_THREADS) s_lds[i] = ts_g[i];
+  float* rec = reinterpret_cast<float*>(s_lds + ((T + 1) & ~1));          // [WS_CAP][64][WS_RW]
+  auto rec_at = [&](int n) -> float* { return rec + (size_t)(n * 64 + lane) * WS_RW; };
+  if (tid < 64) s_cnt[tid] = 0;
+  if (tid == 0) { s_fin = 0; s_fail = 0; }
+  // HW_REG_HW_ID[5:4] = SIMD_ID (gfx9): a helper that shares the stepper's SIMD would take issue slots from the one wave whose
+  // instruction chain IS the kernel's duration, so those waves stay idle
+  if (lane == 0) s_simd[w] = (int)__builtin_amdgcn_s_getreg((1 << 11) | (4 << 6) | 4);
+  __syncthreads();
+  PPROF(1);
+  auto s_ts = [&](int i) -> double { return s_lds[i]; };
+  constexpr int FS = (SOLVER == LDE_SOLVER_TSIT5) ? 6 : 4;  // FSAL slope
+  constexpr int NS = (SOLVER == LDE_SOLVER_TSIT5) ? 6 : 4;  // RHS evaluations per attempt
+  PendFwd<KIND> f(Lb);
+  const double tend = T > 1 ? s_ts(T - 1) : 0.0;
 
-  for (;;) {
-    if (w == 0) {
-      int n = 0;
-      for (;;) {
-        const bool go = active && n < WS_CAP;
-        if (!__any(go)) break;
-        if (go) do {
-          if (iters++ >= o.maxiters) { ret = LDE_RET_MAXITERS; active = false; break; }
-          double dtp = dt;
-          bool last = false;
-          if (t + dt >= tend - 1e-12 * fabs(tend)) { dt = tend - t; last = true; }
-          const float h = (float)dt;
-          k[0][0] = kf[0];
-          k[0][1] = kf[1];
-          float EEst = 0.f;
-          if (SOLVER == LDE_SOLVER_TSIT5) {
-            EEst = tsit5_attempt<2, PendFwd<KIND>, true>(f, h, y, k, yn, o);   // EEst²
-            nfe += 6;
-          } else {
-            rk4_step<2>(f, h, y, k, yn);
-            nfe += 4;
+  if (w == 0) {
+    // ================= the stepper =================
+    // t is f64 (the reference's time is Float64 on Float32 state), the step size proposal dt is f32: a step is taken with
+    // h = (float)dt anyway, and only ONE f64 addition per accepted step (t += h) and one per attempt (tend − t) remain.
+    f32x2 y = {zi.x, zi.y}, k[7], yn = {0.f, 0.f}, kf = {0.f, 0.f};   // register pairs; kf: f(y) at the current state (first-same-as-last slope)
+    int ret = LDE_RET_SUCCESS, nfe = 0, nacc = 0, nrej = 0;   // nfe: the evaluations before the first step; the rest is NS × attempts
+    double t = 0.0;
+    float dt = 0.f, dtmax = 0.f;
+    constexpr float LQ_MIN = -13.287712379549449f;   // log₂ of qoldinit = 1e-4
+    float lqold = LQ_MIN;                            // the PI controller runs on log₂ EEst here (see below)
+    const int maxit = o.maxiters > 0x7fffffffLL ? 0x7fffffff : (int)o.maxiters;
+    const float dtmin = (float)o.dtmin;
+    int iters = 0;
+    bool active = false;
+#pragma unroll
+    for (int s = 0; s < 7; s++) k[s] = f32x2{0.f, 0.f};
+    if (valid) {
+      z_out[b] = zi;  // ts[0] is saved as ẑ₀ itself
+      if (T > 1) {
+        t = s_ts(0);
+        const double dtmax_d = tend - t;
+        dtmax = (float)dtmax_d;
+        f.anchor(y.x);
+        kf = f.ev(y);
+        nfe = 1;
+        if (ADAPT) {
+          if (o.dt_fixed > 0) dt = (float)fmin(o.dt_fixed, dtmax_d);
+          else {
+            const float ya[2] = {y.x, y.y}, fa[2] = {kf.x, kf.y};
+            dt = (float)init_dt<2>(f, ya, fa, 1.0f, dtmax_d, o);
+            nfe++;
           }
-          if (!all_finite<2>(yn) || !(EEst == EEst)) {
-            if (o.adaptive && dt > o.dtmin) { nrej++; dt = dt * (double)o.qmin; break; }
-            ret = LDE_RET_NONFINITE;
-            active = false;
-            break;
-          }
-          if (o.adaptive) {
-            // PI controller on l = log₂ EEst = ½ log₂ EEst²: q = EEst^β₁ · qold^(−β₂) = 2^(β₁ l − β₂ l_old) — no square root
-            // and one v_log / v_exp pair per step instead of two (EEst = 0 ⇒ l = −∞ ⇒ q = q_lo, as pi_q has it)
-            const float l = 0.5f * __builtin_amdgcn_logf(EEst);
-            if (EEst > 1.0f) {
-              nrej++;
-              const float q11 = __builtin_amdgcn_exp2f(o.beta1 * l);
-              dt = dt * (double)fast_rcp(fminf(o.q_hi, q11 * o.inv_gamma));
-              if (dt < o.dtmin) { ret = LDE_RET_DTMIN; active = false; }
-              break;
-            }
-            const float q = fmaxf(o.q_lo, fminf(o.q_hi, __builtin_amdgcn_exp2f(o.beta1 * l - o.beta2 * lqold) * o.inv_gamma));
-            lqold = fmaxf(l, -13.287712379549449f);
-            dtp = dt * (double)fast_rcp(q);
-            if (dtp > dtmax) dtp = dtmax;
-          }
-          nacc++;
-          {   // record the accepted step
-            f32x4* r = reinterpret_cast<f32x4*>(rec_at(n));
-            r[0] = f32x4{h, y[0], y[1], 0.f};
-            r[1] = f32x4{k[0][0], k[0][1], k[1][0], k[1][1]};
-            r[2] = f32x4{k[2][0], k[2][1], k[3][0], k[3][1]};
-            r[3] = f32x4{k[4][0], k[4][1], k[5][0], k[5][1]};
-            const unsigned long long tb = (unsigned long long)__double_as_longlong(t);
-            r[4] = f32x4{k[6][0], k[6][1], __uint_as_float((unsigned)tb), __uint_as_float((unsigned)(tb >> 32))};
-            n++;
-          }
-          y[0] = yn[0];
-          y[1] = yn[1];
-          kf[0] = k[FS][0];
-          kf[1] = k[FS][1];
-          t = last ? tend : t + dt;
-          dt = o.adaptive ? dtp : o.dt_fixed;
-          if (!(t < tend)) active = false;
-        } while (0);
+        } else
+          dt = (float)o.dt_fixed;
+        active = t < tend && maxit > 0;
+        if (t < tend && !active) ret = LDE_RET_MAXITERS;
       }
-      // sentinel: where the trajectory stands now (end time and end state of its last record)
-      *reinterpret_cast<double*>(rec_at(n) + 18) = t;
-      rec_at(n)[1] = y[0];
-      rec_at(n)[2] = y[1];
-      s_cnt[lane] = n;
-      const bool any_active = __any(active);
-      if (lane == 0) s_done = any_active ? 0 : 1;
     }
-    __syncthreads();
-    {   // save phase, all waves
-      const int cnt = s_cnt[lane];
-      int n2 = 0, pn = -1;
-      if (jq < jend && cnt > 1) {   // first record whose end time reaches this wave's first save time (bisection: ≤ 5 LDS reads)
-        const double tj0 = s_ts(jq);
-        int lo = 0, hi = cnt;       // invariant: end(lo − 1) < tj0; answer in [lo, hi]
-        while (lo < hi) {
-          const int mid = (lo + hi) >> 1;
-          if (rec_t(mid + 1) < tj0) lo = mid + 1;
-          else hi = mid;
-        }
-        n2 = lo;
+    bool first_round = true;
+    for (;;) {   // rounds
+      int n = 0;
+      float* rp = rec_at(0);
+      if (!first_round) {   // (the first round's base is written by the helpers themselves: they hold z₀ and ts[0])
+        *reinterpret_cast<double*>(&s_base[lane * 4]) = t;
+        *reinterpret_cast<float2*>(&s_base[lane * 4 + 2]) = make_float2(y.x, y.y);
+        __syncthreads();   // B: the counts are reset, the base is in place
       }
-      float h = 0.f, rh = 0.f, ys[2] = {0.f, 0.f}, k0[2] = {0.f, 0.f}, kE[2] = {0.f, 0.f}, P[3][2] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}};
-      double tn = 0.0;
+      first_round = false;
+      int wave_iters = 0;
+      PPROF(2);
+      // The stepping loop is the launch's critical path. What one wave pays for on gfx950 (abl/valu_rate.hip): 4 cycles per
+      // VALU instruction whether dependent or not, ≈ 8 per transcendental, ≈ 55 per TAKEN branch, ≈ 18 extra whenever a
+      // lane mask goes VALU → SALU → VALU back to back, ≈ 5 per float written to LDS. So the loop is straight-line code with
+      // ONE predicated block, and one float decides acceptance: mq = EEst² (+ NaN if the new state is not finite, + ∞ for
+      // a lane that is not stepping: `pen`); accepted ⇔ mq ≤ 1. Everything rare (rejections, non-finite attempts, step-size
+      // underflow) is out of line.
+      float pen = (active && iters < maxit) ? 0.f : __builtin_inff();
+      for (;;) {
+        if (!__any(pen == 0.f)) break;
+        wave_iters++;
+        const float rem = (float)(tend - t);
+        const bool last = dt >= rem * 0.99999988f;   // the step would reach (or pass) the end: land on it exactly
+        const float h = last ? rem : dt;             // (the helpers recognise the last step by h == (float)(tend − t))
+        k[0] = kf;
+        f.anchor(y.x);
+        float msq = 0.f;   // mean square of the scaled error estimate (EEst²)
+        if (SOLVER == LDE_SOLVER_TSIT5) msq = tsit5_attempt_pair<PendFwd<KIND>, ADAPT>(f, h, y, k, yn, o);
+        else {
+          const float ya[2] = {y.x, y.y};
+          float ka[7][2], yna[2];
+          ka[0][0] = kf.x;
+          ka[0][1] = kf.y;
+          rk4_step<2>(f, h, ya, ka, yna);
+#pragma unroll
+          for (int s = 1; s <= 4; s++) k[s] = f32x2{ka[s][0], ka[s][1]};
+          yn = f32x2{yna[0], yna[1]};
+        }
+        const float mq = fmaf(0.f, fabsf(yn.x) + fabsf(yn.y), msq + pen);   // ∞·0 = NaN: a non-finite state never passes
+        const bool ok = mq <= 1.0f;
+        // PI controller on l = log₂ EEst = ½ log₂ EEst²: q = EEst^β₁ · qold^(−β₂) = 2^(β₁ l − β₂ l_old) — no square root and
+        // one v_log / v_exp pair per step; accepted: clamp(q/γ, 1/qmax, 1/qmin). EEst = 0 ⇒ l = −∞ ⇒ q = 1/qmax, as pi_q has it.
+        float dtn = (float)o.dt_fixed, l = 0.f;
+        if (ADAPT) {
+#if LDE_PEND_ABL == 2
+          dtn = dt;
+#else
+          l = 0.5f * __builtin_amdgcn_logf(msq);
+          const float q = fmaxf(o.q_lo, fminf(o.q_hi, __builtin_amdgcn_exp2f(o.beta1 * l - o.beta2 * lqold) * o.inv_gamma));
+          dtn = fminf(h * fast_rcp(q), dtmax);
+#endif
+        }
+        if (__builtin_expect(__any(!ok && pen == 0.f), 0)) {   // rare: a rejected or non-finite attempt somewhere in the wave
+          if (!ok && pen == 0.f) {
+            const bool fin = (fabsf(yn.x) + fabsf(yn.y)) < __builtin_inff();   // false for NaN too
+            nrej++;
+            iters++;
+            if (!ADAPT) { ret = LDE_RET_NONFINITE; active = false; nrej--; }
+            else if (!fin) {
+              if (h > dtmin) dt = h * o.qmin;
+              else { ret = LDE_RET_NONFINITE; active = false; nrej--; }
+            } else {   // rejected: dt / min(1/qmin, EEst^β₁/γ); a NaN estimate gives 1/qmin (v_min returns the other operand)
+              dt = h * fast_rcp(fminf(o.q_hi, __builtin_amdgcn_exp2f(o.beta1 * l) * o.inv_gamma));
+              if (dt < dtmin) { ret = LDE_RET_DTMIN; active = false; }
+            }
+            if (!active || iters >= maxit) pen = __builtin_inff();
+          }
+        }
+        if (ok) {   // the accepted step: leave {h, yₙ₊₁} behind, publish, advance
+#if LDE_PEND_ABL != 1
+          *reinterpret_cast<f32x4*>(rp) = f32x4{h, yn.x, yn.y, 0.f};
+#endif
+          rp += 64 * WS_RW;
+          n++;
+          asm volatile("" ::: "memory");                                      // the count is published AFTER the record
+          __hip_atomic_store(&s_cnt[lane], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (a plain LDS store: ds_write_b32)
+          nacc++;
+          iters++;
+          y = yn;
+          kf = k[FS];
+          t = last ? tend : t + (double)h;
+          dt = dtn;
+          lqold = fmaxf(l, LQ_MIN);
+          active = !last;
+          if (last || n >= WS_CAP || iters >= maxit) pen = __builtin_inff();
+        }
+      }
+      if (active && iters >= maxit) { ret = LDE_RET_MAXITERS; active = false; }
+      PPROF(3);
+      PPROF_VAL(30, wave_iters);
+      const bool more = __any(active);
+      if (__any(ret != LDE_RET_SUCCESS) && lane == 0) __hip_atomic_store(&s_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      asm volatile("" ::: "memory");
+      if (lane == 0) __hip_atomic_store(&s_fin, more ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (!more) break;
+      __syncthreads();   // A: the helpers have consumed this round's records
+      s_cnt[lane] = 0;
+      if (lane == 0) s_fin = 0;
+    }
+    PPROF(4);
+    if (__hip_atomic_load(&s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) __syncthreads();   // F: every helper store has been issued and waited for
+    if (valid) {
+      if (ret != LDE_RET_SUCCESS) {  // failed solve ⇒ NaN block, never an error [REF GOKU.jl:114]
+        const float qn = __int_as_float(0x7fc00000);
+        for (int j = 0; j < T; j++) z_out[(size_t)j * B + b] = make_float2(qn, qn);
+      }
+      if (retcode) retcode[b] = ret;
+      st_ret[b] = ret;
+      st_nfe[b] = nfe + NS * (nacc + nrej);
+      st_nacc[b] = nacc;
+      st_nrej[b] = nrej;
+    }
+    PPROF(7);
+    return;
+  }
+
+  // ================= the helpers: dense output for save times rank+1, rank+1+nh, … of the workgroup's 64 trajectories =================
+  int nh = 0, rank = 0;   // helpers that do not share the stepper's SIMD, and this wave's rank among them
+  {
+    const int s0 = s_simd[0];
+    int ne = 0;
+    for (int i = 1; i < WS_WAVES; i++) {
+      const bool e = s_simd[i] != s0;
+      if (i == w) rank = ne;
+      ne += e ? 1 : 0;
+    }
+    nh = ne;
+    if (nh == 0) { nh = WS_HELPERS; rank = w - 1; }          // (every wave on one SIMD: cannot happen with 16 waves; all help)
+    else if (s_simd[w] == s0) rank = -1;
+  }
+  constexpr int T_none = 0x7fffffff;
+#if LDE_PEND_ABL == 3
+  rank = -1;
+#endif
+  // helper `rank` serves a CONTIGUOUS slice of the save grid: neighbouring save times mostly fall into the same step (≈ 2.6 per
+  // step at the default tolerance), whose slopes are then rebuilt once — interleaved slices rebuilt one step per save time and
+  // kept the helpers' SIMDs busy for 6 µs after the stepper had finished
+  const int chunk = (T - 1 + nh - 1) / nh;
+  int jq = rank < 0 ? T_none : 1 + rank * chunk;   // per lane from here on: a lane serves a save time as soon as ITS trajectory has passed it
+  const int jend = rank < 0 ? 0 : min(T, 1 + (rank + 1) * chunk);
+  // A wave with nothing (left) to serve leaves the kernel: s_barrier only counts the workgroup's surviving waves, so the
+  // round / failure barriers below stay matched among those that remain, and nobody polls next to the stepper.
+  // (Its stores are waited for first: a failed trajectory's NaN block is written by the stepper later.)
+  if (rank < 0 || jq >= jend) return;
+#if LDE_PEND_PROF
+  if (blockIdx.x == 0 && threadIdx.x == 64) g_pprof[28] = nh;
+#endif
+  bool first_round = true;
+  for (;;) {   // rounds
+    // where the walk over this round's records starts: record n2 begins at time tn in state ys
+    int n2 = 0, pn = -1;
+    double tn = T > 1 ? s_ts(0) : 0.0;
+    f32x2 ys = {zi.x, zi.y};
+    if (!first_round) {
+      __syncthreads();   // B: the stepper has reset the counts and written the base
+      tn = *reinterpret_cast<const double*>(&s_base[lane * 4]);
+      const float2 yb = *reinterpret_cast<const float2*>(&s_base[lane * 4 + 2]);
+      ys = f32x2{yb.x, yb.y};
+    }
+    first_round = false;
+    // the step the walk stands in: size, end time and end state (valid while n2 < cnt)
+    float h = 0.f, rh = 0.f;
+    double t1 = 0.0;
+    f32x2 ye = {0.f, 0.f}, k0 = {0.f, 0.f}, kE = {0.f, 0.f}, P2 = {0.f, 0.f}, P3 = {0.f, 0.f}, P4 = {0.f, 0.f};
+    int ld = -1;   // record whose {h, t1, ye} are loaded
+    int fin;
+    for (;;) {
+#if LDE_PEND_PROF
+      if (blockIdx.x == 0 && lane == 0 && jend == T) g_pprof[24]++;
+#endif
+      fin = __hip_atomic_load(&s_fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // read BEFORE the count: if the round is over, the count is final
+      const int cnt = __hip_atomic_load(&s_cnt[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      asm volatile("" ::: "memory");
       while (jq < jend) {
         const double tj = s_ts(jq);
-        while (n2 < cnt && rec_t(n2 + 1) < tj) n2++;
-        if (n2 == cnt) break;   // beyond what has been integrated so far
-        const double t1 = rec_t(n2 + 1);
+        bool have = false;
+        while (n2 < cnt) {
+          if (ld != n2) {
+            const f32x4 q = *reinterpret_cast<const f32x4*>(rec_at(n2));
+            h = q[0];
+            ye = f32x2{q[1], q[2]};
+            t1 = (h == (float)(tend - tn)) ? tend : tn + (double)h;   // exactly the stepper's arithmetic
+            ld = n2;
+          }
+          if (t1 >= tj) { have = true; break; }
+          tn = t1;       // the save time lies beyond this step: move on
+          ys = ye;
+          n2++;
+        }
+        if (!have) break;   // beyond what has been integrated so far
         float2 out;
-        if (tj >= t1) {   // the save time is the step's end: the next record's start state
-          const float* r1 = rec_at(n2 + 1);
-          out = make_float2(r1[1], r1[2]);
-        } else {
-          if (pn != n2) {
-            const f32x4* r = reinterpret_cast<const f32x4*>(rec_at(n2));
-            const f32x4 q0 = r[0], q1 = r[1], q2 = r[2], q3 = r[3], q4 = r[4];
-            h = q0[0];
+        if (tj >= t1) out = make_float2(ye.x, ye.y);   // the save time is the step's end
+        else {
+          if (pn != n2) {   // rebuild the step's slopes: the stepper's code on the stepper's inputs (yₙ, hₙ)
+            f.anchor(ys.x);
+            k0 = f.ev(ys);
             rh = fast_rcp(h);
-            ys[0] = q0[1];
-            ys[1] = q0[2];
-            tn = __longlong_as_double((long long)(((unsigned long long)__float_as_uint(q4[3]) << 32) | __float_as_uint(q4[2])));
-            k0[0] = q1[0];
-            k0[1] = q1[1];
             if (SOLVER == LDE_SOLVER_TSIT5) {
-              const float kk[7][2] = {{q1[0], q1[1]}, {q1[2], q1[3]}, {q2[0], q2[1]}, {q2[2], q2[3]}, {q3[0], q3[1]}, {q3[2], q3[3]}, {q4[0], q4[1]}};
-              tsit5_dense_coeffs<2>(kk, P);
-            } else {
-              kE[0] = q3[0];   // k₅ = f(yₙ₊₁), the slope at the end of the step
-              kE[1] = q3[1];
-            }
+              f32x2 kk[7], ynr;
+              kk[0] = k0;
+              (void)tsit5_attempt_pair<PendFwd<KIND>, false>(f, h, ys, kk, ynr, o);
+              P2 = kk[0] * ts5::R1[0];
+              P3 = kk[0] * ts5::R1[1];
+              P4 = kk[0] * ts5::R1[2];
+#pragma unroll
+              for (int s = 0; s < 6; s++) {
+                P2 += kk[s + 1] * ts5::R[s][0];
+                P3 += kk[s + 1] * ts5::R[s][1];
+                P4 += kk[s + 1] * ts5::R[s][2];
+              }
+            } else
+              kE = f.ev(ye);   // f(yₙ₊₁), the slope at the end of the step
             pn = n2;
           }
           const float th = (float)(tj - tn) * rh;
           if (SOLVER == LDE_SOLVER_TSIT5) {
-            out.x = tsit5_dense_eval<2>(th, h, ys[0], k0[0], P[0][0], P[1][0], P[2][0]);
-            out.y = tsit5_dense_eval<2>(th, h, ys[1], k0[1], P[0][1], P[1][1], P[2][1]);
+            out.x = tsit5_dense_eval<2>(th, h, ys.x, k0.x, P2.x, P3.x, P4.x);
+            out.y = tsit5_dense_eval<2>(th, h, ys.y, k0.y, P2.y, P3.y, P4.y);
           } else {  // cubic Hermite between (y,k1) and (yn,f(yn))
-            const float* r1 = rec_at(n2 + 1);
-            const float y1a = r1[1], y1b = r1[2];
             const float om = 1.0f - th;
             const float h00 = (1.0f + 2.0f * th) * om * om, h10 = th * om * om;
             const float h01 = th * th * (3.0f - 2.0f * th), h11 = th * th * (th - 1.0f);
-            out.x = h00 * ys[0] + (h10 * h) * k0[0] + h01 * y1a + (h11 * h) * kE[0];
-            out.y = h00 * ys[1] + (h10 * h) * k0[1] + h01 * y1b + (h11 * h) * kE[1];
+            out.x = h00 * ys.x + (h10 * h) * k0.x + h01 * ye.x + (h11 * h) * kE.x;
+            out.y = h00 * ys.y + (h10 * h) * k0.y + h01 * ye.y + (h11 * h) * kE.y;
           }
         }
         if (valid) z_out[(size_t)jq * B + b] = out;
+#if LDE_PEND_PROF
+        if (blockIdx.x == 0 && lane == 0 && jend == T && jend - jq <= 8) g_pprof[16 + (jend - jq - 1)] = wall_clock64();
+#endif
         jq++;
       }
+      if (fin || !__any(jq < jend)) break;
+      // Twelve helpers share three SIMDs: a helper whose slice the stepper is still several steps away from must not spin
+      // there (s_sleep's unit is ≈ 0.14 µs on gfx950, far longer than 64 core cycles).
+      const bool near = jq < jend && (float)(s_ts(min(jq, T - 1)) - tn) < 3.0f * h;
+      if (__any(near)) __builtin_amdgcn_s_sleep(1);
+      else __builtin_amdgcn_s_sleep(4);
     }
-    const int done = s_done;
-    __syncthreads();   // the records are overwritten in the next round
-    if (done) break;
+    if (fin == 2 || !__any(jq < jend)) break;
+    __syncthreads();   // A
   }
-  if (w != 0 || !valid) return;
+#if LDE_PEND_PROF
+  if (blockIdx.x == 0 && lane == 0) {
+    atomicMax(reinterpret_cast<unsigned long long*>(&g_pprof[29]), (unsigned long long)wall_clock64());
+    if (rank == 0) g_pprof[26] = wall_clock64();
+  }
+#endif
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// ---- forward, the smallest batches: lanes = save times ---------------------------------------------------------------------
+// At B ≤ 1024 the chip has more SIMDs than there are trajectories, so a wave is spent on TPW trajectories only (TPW = 1:
+// one trajectory per wave): ALL 64/TPW lanes of a trajectory's group step it — redundantly, which costs nothing in a SIMT
+// machine — and each lane OWNS save times (lane s of the group: j = 1+s, 1+s+64/TPW, …). After an accepted step every lane
+// looks whether its save time fell into the step and, if so, interpolates straight from the slopes in its registers and
+// stores. No LDS, no records, no helper waves, no barrier, no tail after the last step; with TPW = 1 the accept decision is
+// wave-uniform and the wave runs its own trajectory's step count, not the maximum over 64. The dense output costs the step
+// ≈ 45 instructions (the Θ-independent coefficients once, one evaluation per lane) instead of the wave-sequential save
+// loop of k_pend_forward (≈ 75 iterations at T = 50). Same formulas as the other two forward kernels.
+template <int KIND, int SOLVER, bool ADAPT, int TPW>
+__global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict__ z0, const float* __restrict__ theta,
+                                                        const double* __restrict__ ts_g, KOpts o,
+                                                        float2* __restrict__ z_out, int32_t* __restrict__ retcode,
+                                                        int32_t* __restrict__ st_nfe, int32_t* __restrict__ st_nacc,
+                                                        int32_t* __restrict__ st_nrej, int32_t* __restrict__ st_ret) {
+  constexpr int LPT = 64 / TPW;   // lanes per trajectory
+  const int T = o.T, B = o.B, lane = threadIdx.x, slot = lane % LPT;
+  const int b = blockIdx.x * TPW + lane / LPT;
+  const bool valid = b < B;
+  const int bc = valid ? b : B - 1;   // an out-of-range group computes on a copy of the last trajectory and stores nothing
+  const float2 zi = z0[bc];
+  PendFwd<KIND> f(theta[bc]);
+  constexpr int FS = (SOLVER == LDE_SOLVER_TSIT5) ? 6 : 4;  // FSAL slope
+  constexpr int NS = (SOLVER == LDE_SOLVER_TSIT5) ? 6 : 4;  // RHS evaluations per attempt
+  const double dinf = __longlong_as_double(0x7ff0000000000000LL);
+  int j = 1 + slot;                                                   // the save time this lane serves next,
+  double tj = j < T ? ts_g[j] : dinf;                                 // its value, and the one after it (prefetched:
+  double tjn = j + LPT < T ? ts_g[j + LPT] : dinf;                    // a load on the stepping chain would cost a memory latency)
+  f32x2 y = {zi.x, zi.y}, k[7], yn = {0.f, 0.f}, kf = {0.f, 0.f};
+  int ret = LDE_RET_SUCCESS, nfe = 0, nacc = 0, nrej = 0;
+  double t = 0.0, tend = 0.0;
+  float dt = 0.f, dtmax = 0.f;
+  constexpr float LQ_MIN = -13.287712379549449f;   // log₂ of qoldinit = 1e-4
+  float lqold = LQ_MIN;
+  const int maxit = o.maxiters > 0x7fffffffLL ? 0x7fffffff : (int)o.maxiters;
+  const float dtmin = (float)o.dtmin;
+  int iters = 0;
+  bool active = false;
+#pragma unroll
+  for (int s = 0; s < 7; s++) k[s] = f32x2{0.f, 0.f};
+  if (valid && slot == 0) z_out[b] = zi;  // ts[0] is saved as ẑ₀ itself
+  if (T > 1) {
+    t = ts_g[0];
+    tend = ts_g[T - 1];
+    const double dtmax_d = tend - t;
+    dtmax = (float)dtmax_d;
+    f.anchor(y.x);
+    kf = f.ev(y);
+    nfe = 1;
+    if (ADAPT) {
+      if (o.dt_fixed > 0) dt = (float)fmin(o.dt_fixed, dtmax_d);
+      else {
+        const float ya[2] = {y.x, y.y}, fa[2] = {kf.x, kf.y};
+        dt = (float)init_dt<2>(f, ya, fa, 1.0f, dtmax_d, o);
+        nfe++;
+      }
+    } else
+      dt = (float)o.dt_fixed;
+    active = t < tend && maxit > 0;
+    if (t < tend && !active) ret = LDE_RET_MAXITERS;
+  }
+  // the stepping loop of k_pend_forward_ws (see there): one float decides acceptance, rare cases out of line
+  float pen = (active && iters < maxit) ? 0.f : __builtin_inff();
+  for (;;) {
+    if (!__any(pen == 0.f)) break;
+    const float rem = (float)(tend - t);
+    const bool last = dt >= rem * 0.99999988f;
+    const float h = last ? rem : dt;
+    k[0] = kf;
+    f.anchor(y.x);
+    float msq = 0.f;
+    if (SOLVER == LDE_SOLVER_TSIT5) msq = tsit5_attempt_pair<PendFwd<KIND>, ADAPT>(f, h, y, k, yn, o);
+    else {
+      const float ya[2] = {y.x, y.y};
+      float ka[7][2], yna[2];
+      ka[0][0] = kf.x;
+      ka[0][1] = kf.y;
+      rk4_step<2>(f, h, ya, ka, yna);
+#pragma unroll
+      for (int s = 1; s <= 4; s++) k[s] = f32x2{ka[s][0], ka[s][1]};
+      yn = f32x2{yna[0], yna[1]};
+    }
+    const float mq = fmaf(0.f, fabsf(yn.x) + fabsf(yn.y), msq + pen);   // ∞·0 = NaN: a non-finite state never passes
+    const bool ok = mq <= 1.0f;
+    float dtn = (float)o.dt_fixed, l = 0.f;
+    if (ADAPT) {
+      l = 0.5f * __builtin_amdgcn_logf(msq);
+      const float q = fmaxf(o.q_lo, fminf(o.q_hi, __builtin_amdgcn_exp2f(o.beta1 * l - o.beta2 * lqold) * o.inv_gamma));
+      dtn = fminf(h * fast_rcp(q), dtmax);
+    }
+    if (__builtin_expect(__any(!ok && pen == 0.f), 0)) {   // rare: a rejected or non-finite attempt
+      if (!ok && pen == 0.f) {
+        const bool fin = (fabsf(yn.x) + fabsf(yn.y)) < __builtin_inff();
+        nrej++;
+        iters++;
+        if (!ADAPT) { ret = LDE_RET_NONFINITE; active = false; nrej--; }
+        else if (!fin) {
+          if (h > dtmin) dt = h * o.qmin;
+          else { ret = LDE_RET_NONFINITE; active = false; nrej--; }
+        } else {
+          dt = h * fast_rcp(fminf(o.q_hi, __builtin_amdgcn_exp2f(o.beta1 * l) * o.inv_gamma));
+          if (dt < dtmin) { ret = LDE_RET_DTMIN; active = false; }
+        }
+        if (!active || iters >= maxit) pen = __builtin_inff();
+      }
+    }
+    if (ok) {
+      const double tn = last ? tend : t + (double)h;
+      if (__any(tj <= tn)) {   // dense output: some lane's save time lies in (t, tn]
+        f32x2 P2, P3, P4;
+        if (SOLVER == LDE_SOLVER_TSIT5) {
+          P2 = k[0] * ts5::R1[0];
+          P3 = k[0] * ts5::R1[1];
+          P4 = k[0] * ts5::R1[2];
+#pragma unroll
+          for (int s = 0; s < 6; s++) {
+            P2 += k[s + 1] * ts5::R[s][0];
+            P3 += k[s + 1] * ts5::R[s][1];
+            P4 += k[s + 1] * ts5::R[s][2];
+          }
+        }
+        const float rh = fast_rcp(h);
+        while (tj <= tn) {   // (one trip when the group has a lane per save time)
+          float2 out;
+          if (tj >= tn) out = make_float2(yn.x, yn.y);
+          else {
+            const float th = (float)(tj - t) * rh;
+            if (SOLVER == LDE_SOLVER_TSIT5) {
+              out.x = tsit5_dense_eval<2>(th, h, y.x, k[0].x, P2.x, P3.x, P4.x);
+              out.y = tsit5_dense_eval<2>(th, h, y.y, k[0].y, P2.y, P3.y, P4.y);
+            } else {  // cubic Hermite between (y,k1) and (yn,f(yn))
+              const float om = 1.0f - th;
+              const float h00 = (1.0f + 2.0f * th) * om * om, h10 = th * om * om;
+              const float h01 = th * th * (3.0f - 2.0f * th), h11 = th * th * (th - 1.0f);
+              out.x = h00 * y.x + (h10 * h) * k[0].x + h01 * yn.x + (h11 * h) * k[4].x;
+              out.y = h00 * y.y + (h10 * h) * k[0].y + h01 * yn.y + (h11 * h) * k[4].y;
+            }
+          }
+          if (valid) z_out[(size_t)j * B + b] = out;
+          j += LPT;
+          tj = tjn;
+          tjn = j + LPT < T ? ts_g[j + LPT] : dinf;
+        }
+      }
+      nacc++;
+      iters++;
+      y = yn;
+      kf = k[FS];
+      t = tn;
+      dt = dtn;
+      lqold = fmaxf(l, LQ_MIN);
+      active = !last;
+      if (last || iters >= maxit) pen = __builtin_inff();
+    }
+  }
+  if (active && iters >= maxit) { ret = LDE_RET_MAXITERS; active = false; }
+  if (!valid) return;
   if (ret != LDE_RET_SUCCESS) {  // failed solve ⇒ NaN block, never an error [REF GOKU.jl:114]
     const float qn = __int_as_float(0x7fc00000);
-    for (int j = 0; j < T; j++) z_out[(size_t)j * B + b] = make_float2(qn, qn);
+    for (int jj = slot; jj < T; jj += LPT) z_out[(size_t)jj * B + b] = make_float2(qn, qn);
   }
-  if (retcode) retcode[b] = ret;
-  st_ret[b] = ret;
-  st_nfe[b] = nfe;
-  st_nacc[b] = nacc;
-  st_nrej[b] = nrej;
+  if (slot == 0) {
+    if (retcode) retcode[b] = ret;
+    st_ret[b] = ret;
+    st_nfe[b] = nfe + NS * (nacc + nrej);
+    st_nacc[b] = nacc;
+    st_nrej[b] = nrej;
+  }
 }
 
 // ---- adjoint --------------------------------------------------------------------------------------
@@ -437,6 +797,7 @@ __global__ void __launch_bounds__(256) k_pend_adjoint(const float2* __restrict__
     int j = T - 2;
     // prefetch the jump data of the next stop
     float2 zc = z_out[(size_t)j * B + b], dc = dz_out[(size_t)j * B + b];
+    f.anchor(y[0]);
     f(y, k[0]);
     nfe = 1;
     double dt;
@@ -459,6 +820,7 @@ __global__ void __launch_bounds__(256) k_pend_adjoint(const float2* __restrict__
       if (hmag >= dist * (1.0 - 1e-12)) { hmag = dist; hit = true; }
       const float h = -(float)hmag;
       float EEst = 0.f;
+      f.anchor(y[0]);
       if (SOLVER == LDE_SOLVER_TSIT5) {
         EEst = tsit5_attempt<5>(f, h, y, k, yn, o);
         nfe += 6;
@@ -501,6 +863,7 @@ __global__ void __launch_bounds__(256) k_pend_adjoint(const float2* __restrict__
         if (j >= 0) {
           zc = z_out[(size_t)j * B + b];
           dc = dz_out[(size_t)j * B + b];
+          f.anchor(y[0]);
           f(y, k[0]);  // the jump invalidates the FSAL slope
           nfe++;
         }
@@ -533,11 +896,13 @@ __global__ void __launch_bounds__(256) k_pend_adjoint(const float2* __restrict__
 template <int KIND>
 struct PendBasis {
   float ngl, gl2;
-  __device__ __forceinline__ explicit PendBasis(float L) : ngl(-10.0f / L), gl2(10.0f / (L * L)) {}
+  float noff;
+  __device__ __forceinline__ explicit PendBasis(float L) : ngl(-10.0f / L), gl2(10.0f / (L * L)), noff(0.f) {}
+  __device__ __forceinline__ void anchor(float x0) { noff = turn_anchor(x0); }
   // y = [z0 z1 | la0 la1 lb0 lb1 | ga gb]
   __device__ __forceinline__ void operator()(const float (&y)[8], float (&dy)[8]) const {
     float s, c;
-    hw_sincos(y[0], s, c);
+    hw_sincos(y[0], s, c, noff);
     dy[0] = y[1];
     float acc = ngl * s;
     if (KIND == 1) acc -= 0.7f * y[1];
@@ -572,9 +937,11 @@ __device__ __forceinline__ int pend_interval_operator(float2 zc, float L, double
   const double dtmax = len;
   float qold = 1e-4f;
   long long iters = 0;
+  f.anchor(y[0]);
   f(y, k[0]);
   for (;;) {
     if (iters++ >= o.maxiters) { ret = LDE_RET_MAXITERS; break; }
+    f.anchor(y[0]);
     const double dist = t - t0;
     double hmag = dt;
     bool hit = false;
@@ -780,25 +1147,45 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
   // small batches: stepping and dense output on different waves of a 64-trajectory workgroup (k_pend_forward_ws)
   static const bool ws_on = [] { const char* e = getenv("LDE_PEND_WS"); return !e || atoi(e) != 0; }();
   static const int ws_max_b = [] { const char* e = getenv("LDE_PEND_WS_MAX_B"); return e ? atoi(e) : 16384; }();   // measured (abl/pend_B.py): 21.6 vs 31.2 µs at 16384, 36.8 vs 32.6 µs at 32768
+  // the smallest batches: lanes = save times, TPW trajectories per wave (k_pend_forward_tl)
+  static const int tl_max_b = [] { const char* e = getenv("LDE_PEND_TL_MAX_B"); return e ? atoi(e) : 1024; }();
+  if (o.T > 1 && o.B <= tl_max_b) {
+    const bool ad = o.adaptive != 0;
+#define LDE_LAUNCH_TL(K, S, A)                                                                                          \
+  hipLaunchKernelGGL((k_pend_forward_tl<K, S, A, 1>), dim3(o.B), dim3(64), 0, stream, (const float2*)z0, theta, ts_dev, o,   \
+                     (float2*)z_out, retcode, nfe, nacc, nrej, ret)
+    if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5 && ad) LDE_LAUNCH_TL(0, LDE_SOLVER_TSIT5, true);
+    else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH_TL(0, LDE_SOLVER_TSIT5, false);
+    else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_RK4) LDE_LAUNCH_TL(0, LDE_SOLVER_RK4, false);
+    else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_TSIT5 && ad) LDE_LAUNCH_TL(1, LDE_SOLVER_TSIT5, true);
+    else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH_TL(1, LDE_SOLVER_TSIT5, false);
+    else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_RK4) LDE_LAUNCH_TL(1, LDE_SOLVER_RK4, false);
+    else return LDE_ERR_UNSUPPORTED;
+#undef LDE_LAUNCH_TL
+    return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
+  }
   if (ws_on && shm && o.T > 2 && o.B <= ws_max_b) {
-    const size_t lds = (size_t)((o.T + 1) & ~1) * sizeof(double) + (size_t)(WS_CAP + 1) * 64 * WS_RW * sizeof(float);
+    const size_t lds = (size_t)((o.T + 1) & ~1) * sizeof(double) + (size_t)WS_CAP * 64 * WS_RW * sizeof(float);
     const int g64 = (o.B + 63) / 64;
-#define LDE_LAUNCH_WS(K, S)                                                                                            \
+#define LDE_LAUNCH_WS(K, S, A)                                                                                         \
   do {                                                                                                                 \
     static bool attr = false;                                                                                          \
     if (!attr) {                                                                                                       \
-      if (hipFuncSetAttribute((const void*)k_pend_forward_ws<K, S>, hipFuncAttributeMaxDynamicSharedMemorySize,        \
-                              160 * 1024 - 512) != hipSuccess)                                                         \
+      if (hipFuncSetAttribute((const void*)k_pend_forward_ws<K, S, A>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+                              160 * 1024 - 2048) != hipSuccess)                                                         \
         return LDE_ERR_HIP;                                                                                            \
       attr = true;                                                                                                     \
     }                                                                                                                  \
-    hipLaunchKernelGGL((k_pend_forward_ws<K, S>), dim3(g64), dim3(WS_THREADS), lds, stream, (const float2*)z0, theta, ts_dev, \
+    hipLaunchKernelGGL((k_pend_forward_ws<K, S, A>), dim3(g64), dim3(WS_THREADS), lds, stream, (const float2*)z0, theta, ts_dev, \
                        o, (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                              \
   } while (0)
-    if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH_WS(0, LDE_SOLVER_TSIT5);
-    else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_RK4) LDE_LAUNCH_WS(0, LDE_SOLVER_RK4);
-    else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH_WS(1, LDE_SOLVER_TSIT5);
-    else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_RK4) LDE_LAUNCH_WS(1, LDE_SOLVER_RK4);
+    const bool ad = o.adaptive != 0;
+    if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5 && ad) LDE_LAUNCH_WS(0, LDE_SOLVER_TSIT5, true);
+    else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH_WS(0, LDE_SOLVER_TSIT5, false);
+    else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_RK4) LDE_LAUNCH_WS(0, LDE_SOLVER_RK4, false);
+    else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_TSIT5 && ad) LDE_LAUNCH_WS(1, LDE_SOLVER_TSIT5, true);
+    else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH_WS(1, LDE_SOLVER_TSIT5, false);
+    else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_RK4) LDE_LAUNCH_WS(1, LDE_SOLVER_RK4, false);
     else return LDE_ERR_UNSUPPORTED;
 #undef LDE_LAUNCH_WS
     return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
@@ -883,3 +1270,9 @@ int launch_pend_adjoint_par(int kind, int solver, const float* z_out, const floa
 }
 
 }  // namespace lde
+
+#if LDE_PEND_PROF
+extern "C" int lde_debug_pend_prof(long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(lde::g_pprof), sizeof(long long) * 32) == hipSuccess ? 0 : -4;
+}
+#endif

@@ -1546,6 +1546,33 @@ static size_t with_cache(size_t fixed, size_t want_floats) {
   return total & ~size_t(15);
 }
 
+// Kernels that run the grid-wide sum (coupled adaptive control) need every workgroup resident at once: they are launched
+// COOPERATIVELY — the runtime checks that the grid fits the device and keeps other streams' work from taking its CUs —
+// instead of assuming residency (the bounded spin of grid_sum4 stays as the last line of defence). LDE_COOP=0 (diagnostic)
+// restores the plain launch.
+template <class... A>
+static int launch_maybe_coop(bool coop, const void* fn, dim3 grid, dim3 block, size_t lds, hipStream_t stream, std::string& err,
+                             const char* what, A&... args) {
+  static const bool coop_on = [] { const char* e = getenv("LDE_COOP"); return !e || atoi(e) != 0; }();
+  void* argv[] = {(void*)&args...};
+  hipError_t rc;
+  if (coop && coop_on) {
+    rc = hipLaunchCooperativeKernel(fn, grid, block, argv, (unsigned)lds, stream);
+    if (rc == hipErrorCooperativeLaunchTooLarge) {
+      (void)hipGetLastError();
+      err = std::string(what) + ": the coupled adaptive solve needs all its workgroups resident at once and this grid does not fit the device";
+      return LDE_ERR_UNSUPPORTED;
+    }
+  } else
+    rc = hipLaunchKernel(fn, grid, block, argv, lds, stream);
+  if (rc != hipSuccess) {
+    (void)hipGetLastError();
+    err = std::string(what) + " launch failed: " + hipGetErrorString(rc);
+    return LDE_ERR_HIP;
+  }
+  return LDE_OK;
+}
+
 int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* theta, const double* ts_dev,
                 const KOpts& o, float* z_out, int32_t* retcode, int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret,
                 hipStream_t stream, std::string& err) {
@@ -1587,21 +1614,18 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
 #if LDE_PROF
   prof_reset();
 #endif
-  if (rk4) hipLaunchKernelGGL((k_mlp_forward<LDE_SOLVER_RK4, NTF>), dim3(nwg), dim3(NTF), lds, stream, dm, o, a);
-  else hipLaunchKernelGGL((k_mlp_forward<LDE_SOLVER_TSIT5, NTF>), dim3(nwg), dim3(NTF), lds, stream, dm, o, a);
+  MlpDims dmv = dm;
+  KOpts ov = o;
+  const int rcl = launch_maybe_coop(sync, kfn, dim3(nwg), dim3(NTF), lds, stream, err, "k_mlp_forward", dmv, ov, a);
 #if LDE_PROF
   prof_dump("forward", stream);
 #endif
-  if (hipGetLastError() != hipSuccess) {
-    err = "k_mlp_forward launch failed";
-    return LDE_ERR_HIP;
-  }
-  return LDE_OK;
+  return rcl;
 }
 
 template <int SOLVER>
 static int launch_adjoint(MlpPlan* p, const KOpts& o, const BwdArgs& a, int nwg, size_t lds, hipStream_t stream,
-                          std::string& err) {
+                          std::string& err, bool coop) {
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)k_mlp_adjoint<SOLVER, 512>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1611,8 +1635,10 @@ static int launch_adjoint(MlpPlan* p, const KOpts& o, const BwdArgs& a, int nwg,
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_mlp_adjoint<SOLVER, 512>), dim3(nwg), dim3(512), lds, stream, p->dm, o, a);
-  return LDE_OK;
+  MlpDims dmv = p->dm;
+  KOpts ov = o;
+  BwdArgs av = a;
+  return launch_maybe_coop(coop, (const void*)k_mlp_adjoint<SOLVER, 512>, dim3(nwg), dim3(512), lds, stream, err, "k_mlp_adjoint", dmv, ov, av);
 }
 
 // ---- the 4-columns-per-wave adjoint (lde_mlp4.h): applicability, LDS layout, launch --------------------------------
@@ -1653,7 +1679,7 @@ static bool mlp4_layout(const MlpDims& dm, int T, int B, bool coupled_adaptive, 
 
 template <int SOLVER, int NTH>
 static int launch_mlp4(const MlpDims& dm, const Mlp4Dims& md, const KOpts& o, const BwdArgs& a, int nblocks, size_t lds,
-                       hipStream_t stream, std::string& err) {
+                       hipStream_t stream, std::string& err, bool coop) {
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)k_mlp4_adjoint<SOLVER, NTH>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1663,8 +1689,12 @@ static int launch_mlp4(const MlpDims& dm, const Mlp4Dims& md, const KOpts& o, co
     }
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_mlp4_adjoint<SOLVER, NTH>), dim3(nblocks), dim3(64 * md.wpb), lds, stream, dm, md, o, a);
-  return LDE_OK;
+  MlpDims dmv = dm;
+  Mlp4Dims mdv = md;
+  KOpts ov = o;
+  BwdArgs av = a;
+  return launch_maybe_coop(coop, (const void*)k_mlp4_adjoint<SOLVER, NTH>, dim3(nblocks), dim3(64 * md.wpb), lds, stream, err,
+                           "k_mlp4_adjoint", dmv, mdv, ov, av);
 }
 
 int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float* theta, const double* ts_dev,
@@ -1730,14 +1760,10 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
       const int nth = hmaxw <= 64 ? 1 : (hmaxw <= 128 ? 2 : 4);
       const bool rk4 = dm.solver == LDE_SOLVER_RK4;
       int rc4;
-      if (nth == 1) rc4 = rk4 ? launch_mlp4<LDE_SOLVER_RK4, 1>(dm, md, o, a, nblocks, lds4, stream, err) : launch_mlp4<LDE_SOLVER_TSIT5, 1>(dm, md, o, a, nblocks, lds4, stream, err);
-      else if (nth == 2) rc4 = rk4 ? launch_mlp4<LDE_SOLVER_RK4, 2>(dm, md, o, a, nblocks, lds4, stream, err) : launch_mlp4<LDE_SOLVER_TSIT5, 2>(dm, md, o, a, nblocks, lds4, stream, err);
-      else rc4 = rk4 ? launch_mlp4<LDE_SOLVER_RK4, 4>(dm, md, o, a, nblocks, lds4, stream, err) : launch_mlp4<LDE_SOLVER_TSIT5, 4>(dm, md, o, a, nblocks, lds4, stream, err);
+      if (nth == 1) rc4 = rk4 ? launch_mlp4<LDE_SOLVER_RK4, 1>(dm, md, o, a, nblocks, lds4, stream, err, sync4) : launch_mlp4<LDE_SOLVER_TSIT5, 1>(dm, md, o, a, nblocks, lds4, stream, err, sync4);
+      else if (nth == 2) rc4 = rk4 ? launch_mlp4<LDE_SOLVER_RK4, 2>(dm, md, o, a, nblocks, lds4, stream, err, sync4) : launch_mlp4<LDE_SOLVER_TSIT5, 2>(dm, md, o, a, nblocks, lds4, stream, err, sync4);
+      else rc4 = rk4 ? launch_mlp4<LDE_SOLVER_RK4, 4>(dm, md, o, a, nblocks, lds4, stream, err, sync4) : launch_mlp4<LDE_SOLVER_TSIT5, 4>(dm, md, o, a, nblocks, lds4, stream, err, sync4);
       if (rc4) return rc4;
-      if (hipGetLastError() != hipSuccess) {
-        err = "k_mlp4_adjoint launch failed";
-        return LDE_ERR_HIP;
-      }
       // A wave that ran out of staging slots sets *ovf: k_mlp_adjoint (which can fold its slots into a private slab) then
       // redoes the whole call; otherwise it returns at once. The host never waits: the decision is taken on the device.
       ntile_dw = cdiv(nblocks * md.wpb, 4);
@@ -1749,16 +1775,12 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
       }
     }
   }
-  int rc = dm.solver == LDE_SOLVER_RK4 ? launch_adjoint<LDE_SOLVER_RK4>(p, o, a, nwg, lds, stream, err)
-                                       : launch_adjoint<LDE_SOLVER_TSIT5>(p, o, a, nwg, lds, stream, err);
+  int rc = dm.solver == LDE_SOLVER_RK4 ? launch_adjoint<LDE_SOLVER_RK4>(p, o, a, nwg, lds, stream, err, sync)
+                                       : launch_adjoint<LDE_SOLVER_TSIT5>(p, o, a, nwg, lds, stream, err, sync);
 #if LDE_PROF
   prof_dump("adjoint", stream);
 #endif
   if (rc) return rc;
-  if (hipGetLastError() != hipSuccess) {
-    err = "k_mlp_adjoint launch failed";
-    return LDE_ERR_HIP;
-  }
   // the weight gradient from the staged panels
   DwArgs da;
   da.stage = p->stage; da.wts = p->wts; da.nslots = p->nslots; da.slab = p->slab + (size_t)(nwg + 1) * dm.slab_n; da.cap = p->adj_cap; da.total = 0;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Copy the newest profiles/collect.sh results from gpurun_out/ into profiles/ (summary JSON, kernel stats CSV, bench line).
 
-    python profiles/refresh.py c2 c3 c4 goku_decoder goku_pendulum_b256
+    python profiles/refresh.py [--round r2] c2 c3 c4 goku_decoder goku_pendulum_b256
 
 gpurun merges every call's files into the local gpurun_out/, so only the newest run of each sub-directory is used."""
 import glob
@@ -24,15 +24,19 @@ def newest_only(d):
                 os.remove(g)
 
 
-for w in sys.argv[1:]:
-    d = f"{OUT}/prof_r1_{w}"
+args = sys.argv[1:]
+RND = "r1"
+if args and args[0] == "--round":
+    RND, args = args[1], args[2:]
+for w in args:
+    d = f"{OUT}/prof_{RND}_{w}"
     newest_only(d)
-    subprocess.run([sys.executable, f"{ROOT}/profiles/summarize.py", d, f"{ROOT}/profiles/r1_{w}_summary.json"],
+    subprocess.run([sys.executable, f"{ROOT}/profiles/summarize.py", d, f"{ROOT}/profiles/{RND}_{w}_summary.json"],
                    stdout=subprocess.DEVNULL, check=True)
     ks = sorted(glob.glob(f"{d}/trace/*/*kernel_stats.csv"), key=os.path.getmtime)[-1]
-    shutil.copy(ks, f"{ROOT}/profiles/r1_{w}_kernel_stats.csv")
+    shutil.copy(ks, f"{ROOT}/profiles/{RND}_{w}_kernel_stats.csv")
     b = f"{OUT}/bench_{w}.json" if not w.startswith("goku_pendulum") else f"{OUT}/bench_metric.json"
     if os.path.exists(b):
-        shutil.copy(b, f"{ROOT}/profiles/r1_{w}_bench.json")
-    s = json.load(open(f"{ROOT}/profiles/r1_{w}_summary.json"))
+        shutil.copy(b, f"{ROOT}/profiles/{RND}_{w}_bench.json")
+    s = json.load(open(f"{ROOT}/profiles/{RND}_{w}_summary.json"))
     print(w, {k.split("<")[0]: round(v.get("avg_ns", 0) / 1e3, 1) for k, v in s["kernels"].items() if k.startswith("k_")})

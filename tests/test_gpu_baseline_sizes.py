@@ -1,0 +1,157 @@
+"""GPU parity at the batch sizes BASELINE.json names (the other GPU tests use fixture-sized batches): c3 at B = 1024,
+c2's adjoint at B = 256, c4 coupled at B = 512 and at B = 4096 (256 workgroups through the grid-wide sum of the coupled
+adaptive controller, launched cooperatively). The oracle runs the whole batch with OpenMP (per-trajectory mode over
+trajectories, coupled mode over the columns of every stage evaluation) — seconds on the GPU box's host cores.
+Every case also checks bitwise run-to-run determinism of the kernels.
+
+Tolerances are the ones of tests/test_gpu_mlp.py for the same workloads at small B (stated there); the float64 truth is
+taken on a column subsample where the control mode allows it (per-trajectory)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+NT = max(1, min(64, (os.cpu_count() or 2) // 2))
+
+
+def _native(W, **kw):
+    from tests.gpu_util import Native, make_desc, copy_desc_to_oracle
+    d = make_desc(**kw)
+    nat = Native(d)
+    if W is not None:
+        nat.set_weights(W)
+    return nat, copy_desc_to_oracle(d)
+
+
+def _z0(B, D, seed=1):
+    return (0.5 * np.random.default_rng(seed).standard_normal((B, D))).astype(np.float32)
+
+
+def _rel(a, b):
+    return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+def test_c3_full_batch_1024(o32, o64):
+    """BASELINE.json configs[2]: GOKU pendulum + 2-64-64-2 MLP, Tsit5, per-trajectory control, B = 1024, with adjoint."""
+    layers = (2, 64, 64, 2)
+    W = O.mlp_weights(layers, seed=3)
+    kw = dict(rhs_kind=O.RHS_PENDULUM_PLUS_MLP, layers=layers)
+    nat, od = _native(W, **kw)
+    B, T = 1024, 50
+    z0, L = O.pendulum_inputs(B)
+    ts = O.time_grid(T)
+    dz = O.cotangent(T, B, 2)
+    z, ret, st = nat.forward(z0, L, ts)
+    g0, gL, gW, sb = nat.adjoint(z, L, ts, dz)
+    assert (ret == 0).all() and st["nfailed"] == 0 and sb["nfailed"] == 0
+    zr, retr, info = o32.forward(od, z0, L, ts, W=W, nthreads=NT)
+    r0, rL, rW, infob = o32.adjoint(od, z, L, ts, dz, W=W, nthreads=NT)
+    per_traj = np.abs(z - zr).max(axis=(0, 2))
+    assert abs(st["naccept"] - info["naccept"]) <= 0.05 * info["naccept"] + 2
+    assert abs(sb["naccept"] - infob["naccept"]) <= 0.1 * infob["naccept"] + 2
+    # float64 truth on every 16th column (per-trajectory control: a column's solve does not depend on the others)
+    sub = np.arange(0, B, 16)
+    d64 = O.make_desc(**{**kw, "abstol": 1e-10, "reltol": 1e-10})
+    W64 = W.astype(np.float64)
+    z64, _, _ = o64.forward(d64, z0[sub], L[sub], ts, W=W64, nthreads=NT)
+    t0, tL, _, _ = o64.adjoint(d64, z64, L[sub], ts, dz[:, sub], W=W64, nthreads=NT)
+    # the gates of tests/test_gpu_mlp.py::_check_forward: at the default tolerance two correct f32 solves differ by at most about
+    # the solver's own error e_o (relu kinks + reltol 1e-3: a few 1e-3 here), and the kernel is no farther from the truth than 1.5 e_o
+    scale = max(1.0, np.abs(zr).max())
+    e_o = np.abs(zr[:, sub] - z64).max()
+    assert np.abs(z[:, sub] - zr[:, sub]).max() <= max(3e-4 * scale, 1.5 * e_o)
+    assert np.abs(z[:, sub] - z64).max() <= 1.5 * e_o + 1e-5 * scale
+    assert per_traj.max() <= max(1e-3 * scale, 3.0 * e_o) and np.quantile(per_traj, 0.9) <= max(3e-4 * scale, e_o)   # all 1024 columns
+    # default tolerance + relu: gradients of two correct f32 solves agree to about 1 % (tests/test_gpu_mlp.py, B = 100)
+    for g, r, t, what in ((g0[sub], r0[sub], t0, "dz0"), (gL[sub], rL[sub], tL, "dL")):
+        s = np.abs(t).max()
+        assert np.abs(g - r).max() <= 1e-2 * s, what
+        assert np.abs(g - t).max() <= 1.5 * np.abs(r - t).max() + 5e-3 * s, what
+    assert _rel(g0, r0) <= 1e-2 and _rel(gL, rL) <= 1e-2 and _rel(gW, rW) <= 1e-2
+    z2, _, _ = nat.forward(z0, L, ts)
+    h0, hL, hW, _ = nat.adjoint(z2, L, ts, dz)
+    assert np.array_equal(z, z2) and np.array_equal(g0, h0) and np.array_equal(gL, hL) and np.array_equal(gW, hW)
+
+
+def test_c2_adjoint_full_batch_256(o32, o64):
+    """BASELINE.json configs[1]: LatentODE D = 8, 8-200-200-8, fixed-step RK4 dt = 0.05, B = 256 — the adjoint at full size."""
+    layers = (8, 200, 200, 8)
+    W = O.mlp_weights(layers, seed=3)
+    kw = dict(rhs_kind=O.RHS_MLP, state_dim=8, param_dim=0, layers=layers, solver=O.SOLVER_RK4, adaptive=0, dt=0.05,
+              batching=O.BATCH_COUPLED)
+    nat, od = _native(W, **kw)
+    B, T = 256, 50
+    z0, ts = _z0(B, 8), O.time_grid(T)
+    dz = O.cotangent(T, B, 8)
+    z, _, st = nat.forward(z0, None, ts)
+    g0, _, gW, sb = nat.adjoint(z, None, ts, dz)
+    zr, _, _ = o32.forward(od, z0, None, ts, W=W, nthreads=NT)
+    r0, _, rW, info = o32.adjoint(od, z, None, ts, dz, W=W, nthreads=NT)
+    assert sb["naccept"] == info["naccept"] == 49 and sb["nfailed"] == 0
+    assert np.abs(z - zr).max() <= 2e-5 * max(1.0, np.abs(zr).max())               # no controller: f32 round-off only
+    # float64 with the SAME step size: what is left is f32 round-off of the two f32 implementations
+    d64 = O.make_desc(**kw)
+    W64 = W.astype(np.float64)
+    z64, _, _ = o64.forward(d64, z0, None, ts, W=W64, nthreads=NT)
+    t0, _, tW, _ = o64.adjoint(d64, z64, None, ts, dz, W=W64, nthreads=NT)
+    for g, r, t, what in ((g0, r0, t0, "dz0"), (gW, rW, tW, "dW")):
+        s = np.abs(t).max()
+        assert np.abs(g - r).max() <= 2e-4 * s, what
+        assert np.abs(g - t).max() <= 1.5 * np.abs(r - t).max() + 2e-4 * s, what
+    h0, _, hW, _ = nat.adjoint(z, None, ts, dz)
+    assert np.array_equal(g0, h0) and np.array_equal(gW, hW)
+
+
+@pytest.mark.parametrize("B", [512, 4096])
+def test_c4_coupled_full_batches(o32, B):
+    """BASELINE.json configs[3]: LatentODE D = 32, 32-128-128-32, Tsit5, ONE coupled solve on the [32 × B] state (RMS norm over all
+    entries): B = 512 is one GPU's share of the 4096, B = 4096 puts 256 workgroups through the grid-wide sum of every step
+    (cooperative launch). Against the oracle's coupled solve of the same batch; bitwise determinism across runs."""
+    layers = (32, 128, 128, 32)
+    W = O.mlp_weights(layers, seed=3)
+    kw = dict(rhs_kind=O.RHS_MLP, state_dim=32, param_dim=0, layers=layers, batching=O.BATCH_COUPLED)
+    nat, od = _native(W, **kw)
+    T = 50
+    z0, ts = _z0(B, 32), O.time_grid(T)
+    dz = O.cotangent(T, B, 32)
+    z, ret, st = nat.forward(z0, None, ts)
+    g0, _, gW, sb = nat.adjoint(z, None, ts, dz)
+    assert (ret == 0).all() and st["nfailed"] == 0 and sb["nfailed"] == 0
+    zr, _, info = o32.forward(od, z0, None, ts, W=W, nthreads=NT)
+    r0, _, rW, infob = o32.adjoint(od, z, None, ts, dz, W=W, nthreads=NT)
+    assert abs(st["naccept"] - info["naccept"]) <= 0.1 * info["naccept"] + 2
+    assert abs(sb["naccept"] - infob["naccept"]) <= 0.1 * infob["naccept"] + 2
+    scale = max(1.0, np.abs(zr).max())
+    assert np.abs(z - zr).max() <= 3e-4 * scale                                      # default tolerance (tests/test_gpu_mlp.py)
+    assert _rel(g0, r0) <= 5e-3 and _rel(gW, rW) <= 5e-3
+    z2, _, _ = nat.forward(z0, None, ts)
+    h0, _, hW, _ = nat.adjoint(z2, None, ts, dz)
+    assert np.array_equal(z, z2) and np.array_equal(g0, h0) and np.array_equal(gW, hW)
+
+
+def test_coupled_solve_while_another_stream_keeps_the_gpu_busy(o32):
+    """The grid-wide sum of the coupled adaptive solve needs every workgroup resident: with a second stream saturating the
+    CUs the cooperative launch must still give the same result as on an idle device (no timeout, no NaN blocks)."""
+    import torch
+    layers = (32, 128, 128, 32)
+    W = O.mlp_weights(layers, seed=3)
+    kw = dict(rhs_kind=O.RHS_MLP, state_dim=32, param_dim=0, layers=layers, batching=O.BATCH_COUPLED)
+    nat, _ = _native(W, **kw)
+    B, T = 2048, 50
+    z0, ts = _z0(B, 32), O.time_grid(T)
+    dz = O.cotangent(T, B, 32)
+    z_idle, ret, _ = nat.forward(z0, None, ts)
+    g_idle = nat.adjoint(z_idle, None, ts, dz)
+    side = torch.cuda.Stream()
+    a = torch.randn(8192, 8192, device="cuda")
+    with torch.cuda.stream(side):
+        for _ in range(40):
+            a = torch.tanh(a @ a * 1e-4)      # ≈ 1.1 TFLOP each: the device stays full for the duration of the solves
+    z_busy, ret2, st = nat.forward(z0, None, ts)
+    g_busy = nat.adjoint(z_busy, None, ts, dz)
+    torch.cuda.synchronize()
+    assert (ret == 0).all() and (ret2 == 0).all() and st["nfailed"] == 0
+    assert np.array_equal(z_idle, z_busy) and np.array_equal(g_idle[0], g_busy[0]) and np.array_equal(g_idle[2], g_busy[2])

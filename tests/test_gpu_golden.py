@@ -3,8 +3,24 @@ guaranteed identical on the build container and on the GPU box.
 
 Tolerances: tight-tolerance / fixed-step fixtures ≤ 2e-5 on ẑ (fp32 round-off through ≤ 200 RHS evaluations);
 default-tolerance fixtures: worst column within 3× max(3e-4, the fixture's own float64 error), median within
-max(1e-4, half of it), and no farther from the stored float64 truth than 2.5× the fixture's own error + 1e-5. Gradients: ≤ 1e-3 relative (default tol 1e-2)
-against the fixture, ≤ the fixture's own distance ×3.5 + 1e-3 against the float64 adjoint."""
+max(1e-4, half of it), and no farther from the stored float64 truth than 2.5× the fixture's own error + 1e-5.
+Gradients: a per-fixture relative gate against the fixture (GRAD_LIM), set at ≈ 3–10× the margin measured on MI355X
+(abl/golden_margins.py, round 2; "own" = the fixture's own distance from its float64 adjoint):
+
+    fixture                              |Δẑ|      dẑ₀       dθ̂        dW        own dẑ₀ / dθ̂ / dW
+    c1_goku_pendulum_b64                 5.3e-5    4.7e-7    1.0e-6    –         2.4e-6 / 2.7e-5 / –
+    metric_goku_pendulum_b256            2.6e-5    6.7e-7    1.8e-6    –         3.9e-6 / 1.5e-5 / –
+    metric_goku_pendulum_b256_tight      1.2e-6    2.5e-7    3.2e-7    –         3.0e-7 / 4.8e-7 / –
+    goku_pendulum_friction_b32           2.3e-5    2.8e-7    6.0e-7    –         4.6e-7 / 1.8e-5 / –
+    c2_latentode_rk4_d8_h200_b16         1.2e-7    1.4e-7    –         1.2e-7    3.4e-4 / – / 4.0e-4   (own: RK4 dt=0.05 truncation)
+    latentode_aug_tanh_d6a2_b16          3.8e-7    2.3e-7    –         2.2e-7    2.5e-7 / – / 1.4e-7
+    c4_latentode_tsit5_d32_h128_b16      3.2e-5    8.3e-4    –         4.2e-3    5.9e-4 / – / 3.5e-3   (relu + reltol 1e-3)
+    c3_pendulum_plus_mlp_b32             1.3e-3    2.6e-3    3.9e-3    8.4e-3    2.4e-3 / 2.0e-3 / 1.0e-2 (relu + reltol 1e-3)
+
+The analytic right-hand sides and the smooth / fixed-step networks reproduce the fixture's gradients to ~1e-6 (the
+time-parallel adjoint takes the same single step per save interval as the oracle); where a relu network meets the adaptive
+controller at reltol = 1e-3, two correct f32 solves differ by about the solver's own error — those two fixtures keep a
+gate of the size of their own float64 distance. Against the float64 adjoint: ≤ 3.5× the fixture's own distance + 1e-3."""
 import glob
 import os
 
@@ -14,6 +30,12 @@ import pytest
 from tests.golden import make_golden as G
 
 pytestmark = pytest.mark.gpu
+# relative gradient gates against the fixture: (dẑ₀ and dθ̂, dW)
+GRAD_LIM = {
+    "c1_goku_pendulum_b64": (1e-5, None), "metric_goku_pendulum_b256": (1e-5, None), "metric_goku_pendulum_b256_tight": (5e-6, None),
+    "goku_pendulum_friction_b32": (1e-5, None), "c2_latentode_rk4_d8_h200_b16": (5e-6, 5e-6), "latentode_aug_tanh_d6a2_b16": (5e-6, 5e-6),
+    "c4_latentode_tsit5_d32_h128_b16": (3e-3, 1e-2), "c3_pendulum_plus_mlp_b32": (1e-2, 2.5e-2),
+}
 FIX = sorted(f for f in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
              if not os.path.basename(f).startswith("chain_"))   # chain fixtures: tests/test_oracle_chain.py
 
@@ -49,17 +71,17 @@ def test_hip_matches_golden_fixture(path):
         assert e_k <= 2.5 * e_o + 1e-5
     assert abs(st["naccept"] - fx["fwd_stats"][1]) <= 0.10 * fx["fwd_stats"][1] + 2
     g0, gth, gW, sb = nat.adjoint(z, theta, ts, dz)
-    lim = 1e-3 if tight else 1e-2   # default tolerance (esp. relu right-hand sides): ~1 % between two correct fp32 solves
+    lim, limW = GRAD_LIM.get(name, (1e-3 if tight else 1e-2, 1e-3 if tight else 1e-2))   # (a new fixture starts at the round-1 gates)
     s0 = np.abs(fx["dz0"]).max()
 
-    def close(g, ref, ref64):   # within lim of the fixture, or within 3× the fixture's own float64 error (≈1 % for relu at reltol=1e-3)
-        return np.abs(g - ref).max() <= max(lim * np.abs(ref).max(), 3 * np.abs(ref - ref64).max())
+    def close(g, ref, ref64, lim=lim):   # within the fixture's measured-margin gate (module docstring)
+        return np.abs(g - ref).max() <= lim * np.abs(ref).max()
     assert close(g0[:k], fx["dz0"], fx["dz0_64"])
     assert np.abs(g0[:k] - fx["dz0_64"]).max() <= 3.5 * np.abs(fx["dz0"] - fx["dz0_64"]).max() + 1e-3 * s0
     if theta is not None:
         assert close(gth[:k], fx["dtheta"], fx["dtheta_64"])
     if W is not None:
         sw = np.abs(fx["dW"]).max()
-        assert close(gW[fx["dW_idx"]], fx["dW"], fx["dW_64"])
-        assert abs(np.linalg.norm(gW.astype(np.float64)) - fx["dW_norm"][0]) <= 4 * lim * fx["dW_norm"][0]
+        assert close(gW[fx["dW_idx"]], fx["dW"], fx["dW_64"], limW)
+        assert abs(np.linalg.norm(gW.astype(np.float64)) - fx["dW_norm"][0]) <= 4 * limW * fx["dW_norm"][0]
         assert np.abs(gW[fx["dW_idx"]] - fx["dW_64"]).max() <= 3.5 * np.abs(fx["dW"] - fx["dW_64"]).max() + 1e-3 * sw

@@ -26,6 +26,7 @@ int launch_pend_adjoint(int kind, int solver, const float* z_out, const float* t
 int launch_pend_adjoint_par(int kind, int solver, const float* z_out, const float* theta, const double* ts_dev,
                             const KOpts& o, const float* dz_out, float* dz0, float* dtheta, float* ops, int32_t* info,
                             int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret, hipStream_t stream);
+bool pend_adjoint_needs_ops(int B, int T);
 struct MlpPlan;
 int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err);
 void mlp_plan_destroy(MlpPlan* p);
@@ -262,7 +263,7 @@ static int reserve_impl(lde_handle* h, int B, int T, bool adjoint_ws, int64_t st
     }
     h->ts_pin_cap = T;
   }
-  if (!h->mlp && h->d.sensealg == LDE_SENSE_PARALLEL_CHECKPOINTED) {
+  if (!h->mlp && h->d.sensealg == LDE_SENSE_PARALLEL_CHECKPOINTED && lde::pend_adjoint_needs_ops(B, T)) {
     const size_t need = (size_t)(T > 1 ? T - 1 : 1) * (size_t)B;
     if (need > h->par_cap) {
       if (h->par_ops) (void)hipFree(h->par_ops);

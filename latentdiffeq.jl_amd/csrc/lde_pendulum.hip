@@ -1231,14 +1231,210 @@ int launch_pend_adjoint(int kind, int solver, const float* z_out, const float* t
   return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
 }
 
+// ---- time-parallel adjoint's large-batch form: the same interval-by-interval control, streamed per trajectory -------------------
+// Beyond a few 10⁴ trajectories there is no parallelism left to win from giving every save interval its own lane, and the
+// two-kernel form above pays for it: six operator planes + an info word per (trajectory, interval) written and read back —
+// 2.7 KB per trajectory against 412 B of algorithmic traffic, 344 GB/s algorithmic at B = 2²⁰ — and integrates two basis
+// vectors of λ where one actual λ is wanted. Here a lane owns a trajectory and walks its T−1 intervals from the last to the
+// first, each exactly as pend_interval_operator treats it (z reset to the saved ẑ(t_{j+1}), first attempt = the whole
+// interval, adaptive inside, no step size carried across the save time), but on the 5-state [z | λ | g] itself: the only
+// traffic is the algorithmic one (Δẑ, and ẑ as checkpoints), every access coalesced over the batch index, the next
+// interval's ẑ / Δẑ requested before the current one is integrated. Arithmetic on register pairs (z, λ, (g,·)).
+template <int KIND>
+struct PendBwdPair {
+  float ngl, gl2, noff;
+  __device__ __forceinline__ explicit PendBwdPair(float L) : ngl(-10.0f / L), gl2(10.0f / (L * L)), noff(0.f) {}
+  __device__ __forceinline__ void anchor(float x0) { noff = turn_anchor(x0); }
+  // ż = f(z),  λ̇ = −(∂f/∂z)ᵀλ,  ġ = −(∂f/∂L)ᵀλ
+  __device__ __forceinline__ void ev(const f32x2 (&y)[3], f32x2 (&dy)[3]) const {
+    float s, c;
+    hw_sincos(y[0].x, s, c, noff);
+    float acc = ngl * s, v1 = y[1].x;
+    if (KIND == 1) {
+      acc -= 0.7f * y[0].y;
+      v1 -= 0.7f * y[1].y;
+    }
+    dy[0] = f32x2{y[0].y, acc};
+    dy[1] = f32x2{-(ngl * c * y[1].y), -v1};
+    dy[2] = f32x2{-(gl2 * s * y[1].y), 0.f};
+  }
+};
+
+// one Tsit5 attempt on three register pairs; k[0] = f(y) on entry; returns the mean square of the scaled error over the 5 entries
+template <class F, bool ADAPT>
+__device__ __forceinline__ float tsit5_attempt_pair3(F& f, float h, const f32x2 (&y)[3], f32x2 (&k)[7][3], f32x2 (&yn)[3], const KOpts& o) {
+  f32x2 tmp[3];
+#pragma unroll
+  for (int s = 1; s < 6; s++) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+      f32x2 acc = k[0][i] * ts5::A[s][0];
+#pragma unroll
+      for (int j = 1; j < s; j++) acc += k[j][i] * ts5::A[s][j];
+      tmp[i] = y[i] + acc * h;
+    }
+    f.ev(tmp, k[s]);
+  }
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    f32x2 acc = k[0][i] * ts5::A[6][0];
+#pragma unroll
+    for (int j = 1; j < 6; j++) acc += k[j][i] * ts5::A[6][j];
+    yn[i] = y[i] + acc * h;
+  }
+  f.ev(yn, k[6]);
+  if (!ADAPT) return 0.f;
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 3; i++) {
+    f32x2 e = k[0][i] * ts5::BT[0];
+#pragma unroll
+    for (int j = 1; j < 7; j++) e += k[j][i] * ts5::BT[j];
+    e *= h;
+    const f32x2 sk = f32x2{fmaxf(fabsf(y[i].x), fabsf(yn[i].x)), fmaxf(fabsf(y[i].y), fabsf(yn[i].y))} * o.reltol + o.abstol;
+    const f32x2 r = e * f32x2{fast_rcp(sk.x), fast_rcp(sk.y)};
+    s2 += r.x * r.x;
+    if (i < 2) s2 += r.y * r.y;   // (the second half of the g pair is padding)
+  }
+  return s2 * 0.2f;
+}
+
+template <int KIND, int SOLVER>
+__global__ void __launch_bounds__(256) k_pend_adjoint_stream(const float2* __restrict__ z_out, const float* __restrict__ theta,
+                                                             const double* __restrict__ ts_g, KOpts o,
+                                                             const float2* __restrict__ dz_out, float2* __restrict__ dz0,
+                                                             float* __restrict__ dtheta, int32_t* __restrict__ st_nfe,
+                                                             int32_t* __restrict__ st_nacc, int32_t* __restrict__ st_nrej,
+                                                             int32_t* __restrict__ st_ret) {
+  const int T = o.T, B = o.B;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  PendBwdPair<KIND> f(theta[b]);
+  float2 zc = z_out[(size_t)(T - 1) * B + b];
+  const float2 dT = dz_out[(size_t)(T - 1) * B + b];
+  f32x2 lam = {dT.x, dT.y};
+  float g = 0.f;
+  int ret = (isfinite(zc.x) && isfinite(zc.y)) ? LDE_RET_SUCCESS : LDE_RET_NONFINITE;   // failed forward trajectory: zero gradient
+  int nacc = 0, nrej = 0;
+  float2 zn = zc, dn = dT;
+  if (T > 1) {
+    zn = z_out[(size_t)(T - 2) * B + b];
+    dn = dz_out[(size_t)(T - 2) * B + b];
+  }
+  const float dtmin = (float)o.dtmin;
+  for (int j = T - 2; j >= 0 && ret == LDE_RET_SUCCESS; j--) {
+    const float2 zj = zn, dj = dn;   // ẑ(t_j) (the next interval's start state) and the jump Δ_j
+    if (j > 0) {
+      zn = z_out[(size_t)(j - 1) * B + b];
+      dn = dz_out[(size_t)(j - 1) * B + b];
+    }
+    const double t0 = ts_g[j], t1 = ts_g[j + 1];
+    // integrate [z | λ | g] from t1 down to t0; first attempt: the whole interval
+    f32x2 y[3] = {f32x2{zc.x, zc.y}, lam, f32x2{g, 0.f}}, yn[3], k[7][3];
+    const float len = (float)(t1 - t0);
+    float left = len, dt = o.adaptive ? len : fminf((float)o.dt_fixed, len);
+    float lqold = -13.287712379549449f;
+    long long iters = 0;
+    f.anchor(y[0].x);
+    f.ev(y, k[0]);
+    for (;;) {
+      if (iters++ >= o.maxiters) { ret = LDE_RET_MAXITERS; break; }
+      const bool hit = dt >= left * 0.99999988f;
+      const float hmag = hit ? left : dt;
+      f.anchor(y[0].x);
+      float msq = 0.f;
+      if (SOLVER == LDE_SOLVER_TSIT5) {
+        if (o.adaptive) msq = tsit5_attempt_pair3<PendBwdPair<KIND>, true>(f, -hmag, y, k, yn, o);
+        else (void)tsit5_attempt_pair3<PendBwdPair<KIND>, false>(f, -hmag, y, k, yn, o);
+      } else {   // classical RK4 on the pairs
+        f32x2 tmp[3];
+        const float h = -hmag, hh = 0.5f * h;
+#pragma unroll
+        for (int i = 0; i < 3; i++) tmp[i] = y[i] + k[0][i] * hh;
+        f.ev(tmp, k[1]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) tmp[i] = y[i] + k[1][i] * hh;
+        f.ev(tmp, k[2]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) tmp[i] = y[i] + k[2][i] * h;
+        f.ev(tmp, k[3]);
+#pragma unroll
+        for (int i = 0; i < 3; i++) yn[i] = y[i] + (k[0][i] + (k[1][i] + k[2][i]) * 2.0f + k[3][i]) * (h * (1.0f / 6.0f));
+        f.ev(yn, k[4]);
+      }
+      const float size = fabsf(yn[0].x) + fabsf(yn[0].y) + fabsf(yn[1].x) + fabsf(yn[1].y) + fabsf(yn[2].x);
+      const bool fin = size < __builtin_inff() && msq == msq;
+      if (!fin) {
+        if (o.adaptive && hmag > dtmin) { nrej++; dt = hmag * o.qmin; continue; }
+        ret = LDE_RET_NONFINITE;
+        break;
+      }
+      if (o.adaptive && (msq > 1.0f || !hit)) {   // an accepted step that ends the interval needs no next step size
+        const float l = 0.5f * __builtin_amdgcn_logf(msq);
+        if (msq > 1.0f) {
+          nrej++;
+          dt = hmag * fast_rcp(fminf(o.q_hi, __builtin_amdgcn_exp2f(o.beta1 * l) * o.inv_gamma));
+          if (dt < dtmin) { ret = LDE_RET_DTMIN; break; }
+          continue;
+        }
+        const float q = fmaxf(o.q_lo, fminf(o.q_hi, __builtin_amdgcn_exp2f(o.beta1 * l - o.beta2 * lqold) * o.inv_gamma));
+        lqold = fmaxf(l, -13.287712379549449f);
+        dt = fminf(hmag * fast_rcp(q), len);
+      }
+      nacc++;
+#pragma unroll
+      for (int i = 0; i < 3; i++) y[i] = yn[i];
+      if (hit) break;
+      left -= hmag;
+      constexpr int FS = (SOLVER == LDE_SOLVER_TSIT5) ? 6 : 4;
+#pragma unroll
+      for (int i = 0; i < 3; i++) k[0][i] = k[FS][i];
+      if (!o.adaptive) dt = (float)o.dt_fixed;
+    }
+    // the jump at t_j; z restarts from the checkpoint
+    lam = f32x2{y[1].x + dj.x, y[1].y + dj.y};
+    g = y[2].x;
+    zc = zj;
+  }
+  dz0[b] = ret ? make_float2(0.f, 0.f) : make_float2(lam.x, lam.y);
+  dtheta[b] = ret ? 0.f : g;
+  st_nacc[b] = nacc;
+  st_nrej[b] = nrej;
+  st_nfe[b] = (T - 1) + ((SOLVER == LDE_SOLVER_TSIT5) ? 6 : 4) * (nacc + nrej);
+  st_ret[b] = ret;
+}
+
+// does the time-parallel adjoint need the operator planes in HBM for this shape? (only the two-kernel form does)
+bool pend_adjoint_needs_ops(int B, int T) {
+  const char* e = getenv("LDE_PEND_ADJ_STREAM");
+  const char* f = getenv("LDE_FUSED_MAX_B");
+  const int fused_max_b = f ? atoi(f) : 24576;
+  const bool fused = T > 1 && T - 1 <= 1024 && B <= fused_max_b;
+  return !fused && e && atoi(e) == 0;
+}
+
 int launch_pend_adjoint_par(int kind, int solver, const float* z_out, const float* theta, const double* ts_dev,
                             const KOpts& o, const float* dz_out, float* dz0, float* dtheta, float* ops, int32_t* info,
                             int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret, hipStream_t stream) {
-  static const int fused_max_b = [] { const char* e = getenv("LDE_FUSED_MAX_B"); return e ? atoi(e) : 32768; }();
+  static const int fused_max_b = [] { const char* e = getenv("LDE_FUSED_MAX_B"); return e ? atoi(e) : 24576; }();   // measured (abl/adj_B.py): fused 9.5 µs vs stream 39 µs at 4096, 48 vs 41 µs at 32768
   if (o.T > 1 && o.T - 1 <= 1024 && o.B <= fused_max_b) {   // fused: one workgroup per trajectory, one lane per interval
     const int block = ((o.T - 1 + 63) / 64) * 64;
 #define LDE_LAUNCH(K, S)                                                                                                  \
   hipLaunchKernelGGL((k_pend_adjoint_fused<K, S>), dim3(((o.B + 7) / 8) * 8), dim3(block), 0, stream, (const float2*)z_out, theta, ts_dev, o, \
+                     (const float2*)dz_out, (float2*)dz0, dtheta, nfe, nacc, nrej, ret)
+    if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH(0, LDE_SOLVER_TSIT5);
+    else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_RK4) LDE_LAUNCH(0, LDE_SOLVER_RK4);
+    else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH(1, LDE_SOLVER_TSIT5);
+    else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_RK4) LDE_LAUNCH(1, LDE_SOLVER_RK4);
+    else return LDE_ERR_UNSUPPORTED;
+#undef LDE_LAUNCH
+    return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
+  }
+  static const bool stream_on = [] { const char* e = getenv("LDE_PEND_ADJ_STREAM"); return !e || atoi(e) != 0; }();
+  if (stream_on) {   // large batches: one lane per trajectory, interval by interval (k_pend_adjoint_stream)
+    const int block = 256, grid = (o.B + block - 1) / block;
+#define LDE_LAUNCH(K, S)                                                                                                  \
+  hipLaunchKernelGGL((k_pend_adjoint_stream<K, S>), dim3(grid), dim3(block), 0, stream, (const float2*)z_out, theta, ts_dev, o, \
                      (const float2*)dz_out, (float2*)dz0, dtheta, nfe, nacc, nrej, ret)
     if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH(0, LDE_SOLVER_TSIT5);
     else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_RK4) LDE_LAUNCH(0, LDE_SOLVER_RK4);

@@ -168,6 +168,36 @@ def test_large_batch_properties(o32):
     assert np.abs(z[:, idx] - zr).max() <= 1e-5
 
 
+@pytest.mark.parametrize("kind,tol", [(O.RHS_PENDULUM, (1e-6, 1e-3)), (O.RHS_PENDULUM_FRICTION, (1e-6, 1e-6))])
+def test_large_batch_adjoint_streams_per_trajectory(o32, o64, kind, tol):
+    """B = 2^16 + 5 > 32768: the time-parallel adjoint runs in its streaming form (k_pend_adjoint_stream: a lane per trajectory,
+    interval-by-interval control, algorithmic traffic only). Against the oracle's time-parallel adjoint and the float64 adjoint
+    on a subsample (trajectories are independent), a trajectory with a NaN block (zero pullback), and bitwise determinism."""
+    B, T = (1 << 16) + 5, 50
+    nat, od = _native(rhs_kind=kind, abstol=tol[0], reltol=tol[1])
+    z0, L = O.pendulum_inputs(B, seed=5)
+    ts = O.time_grid(T)
+    dz = O.cotangent(T, B, 2, seed=6)
+    z, ret, _ = nat.forward(z0, L, ts)
+    assert (ret == 0).all()
+    z[:, 77] = np.nan                                                   # a failed forward trajectory: the block is a constant
+    g0, gL, _, st = nat.adjoint(z, L, ts, dz)
+    assert st["nfailed"] == 1 and (g0[77] == 0).all() and gL[77] == 0
+    assert st["naccept"] >= (B - 1) * (T - 1) and st["nfe"] == (B - 1) * (T - 1) + 6 * (st["naccept"] + st["nreject"]) + (T - 1)
+    idx = np.concatenate([np.arange(0, B, 613), [B - 1]])
+    idx = idx[idx != 77]
+    r0, rL, _, _ = o32.adjoint(od, z[:, idx], L[idx], ts, dz[:, idx])
+    tight = tol[1] < 1e-4
+    lim = 1e-4 if tight else 5e-4
+    assert np.abs(g0[idx] - r0).max() <= lim * np.abs(r0).max() and np.abs(gL[idx] - rL).max() <= lim * np.abs(rL).max()
+    d64 = O.make_desc(rhs_kind=kind, abstol=1e-10, reltol=1e-10, sensealg=O.SENSE_BACKSOLVE_CHECKPOINTED)
+    t0, tL, _, _ = o64.adjoint(d64, z[:, idx].astype(np.float64), L[idx].astype(np.float64), ts, dz[:, idx].astype(np.float64))
+    lim64 = 1e-3 if tight else 5e-3
+    assert np.abs(g0[idx] - t0).max() <= lim64 * np.abs(t0).max() and np.abs(gL[idx] - tL).max() <= lim64 * np.abs(tL).max()
+    h0, hL, _, _ = nat.adjoint(z, L, ts, dz)
+    assert np.array_equal(g0, h0) and np.array_equal(gL, hL)
+
+
 def test_torch_api_diffeq_layer(o32):
     """The reference-shaped host API: ẑ = diffeq_layer(decoder, (ẑ₀, θ̂), t), differentiable."""
     import torch

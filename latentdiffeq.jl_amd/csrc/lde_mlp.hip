@@ -1329,10 +1329,14 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
 }
 
 #include "lde_mlp4.h"
+#include "lde_mlpv.h"
 
 // ================================================ host side =================================================
 struct MlpPlan {
   MlpDims dm;
+  VecDims vd;                  // small-batch kernels (lde_mlpv.h): geometry and the swizzled weight copies
+  bool vec_ok = false;
+  float* vecw = nullptr;
   float* frag = nullptr;
   float* fragT = nullptr;
   size_t nfrag = 0, nfragT = 0;
@@ -1398,6 +1402,61 @@ int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err) 
     delete p;
     return LDE_ERR_UNSUPPORTED;
   }
+  {   // one-trajectory-per-workgroup kernels: every width ≤ 256
+    VecDims& vd = p->vd;
+    int maxw = dm.Dp;
+    for (int l = 0; l <= dm.nL; l++) maxw = std::max(maxw, dm.sizes[l]);
+    p->vec_ok = maxw <= 256;
+    if (p->vec_ok) {
+      int nt = 64;
+      while (nt < maxw) nt *= 2;
+      vd.NT = nt;
+      auto geom = [&](int rows, int K, int* rp, int* lg, int* k4, int* S) {
+        int r = 4, g = 2;
+        while (r < rows) { r *= 2; g++; }
+        const int kg = (K + 3) / 4;           // K-groups of 4
+        int sp = nt / r;
+        sp = sp > 8 ? 8 : sp;
+        while (sp > 1 && (kg + sp - 1) / sp < 4) sp /= 2;   // a split lane's share is at least one round of 4 groups
+        sp = sp < 1 ? 1 : sp;
+        *S = sp;
+        *lg = g;
+        *rp = sp > 1 ? r : ((rows + 3) & ~3);   // no split: lane = row, no padding to a power of two
+        const int per = (kg + sp - 1) / sp;
+        *k4 = per < 4 ? per : ((per + 3) & ~3);   // groups per lane: 1–3, or a multiple of 4 (zero-padded) for the pipelined loop
+      };
+      int off = 0;
+      for (int l = 0; l < dm.nL; l++) {
+        geom(dm.sizes[l + 1], dm.sizes[l], &vd.rpf[l], &vd.lgf[l], &vd.k4f[l], &vd.sf[l]);
+        vd.off_f[l] = off;
+        off += vd.sf[l] * vd.k4f[l] * vd.rpf[l];
+      }
+      for (int l = 0; l < dm.nL; l++) {
+        geom(dm.sizes[l], dm.sizes[l + 1], &vd.rpb[l], &vd.lgb[l], &vd.k4b[l], &vd.sb[l]);
+        vd.off_b[l] = off;
+        off += vd.sb[l] * vd.k4b[l] * vd.rpb[l];
+      }
+      vd.total4 = off;
+      // every vector a product reads as x is followed by zeros up to the product's padded K (4·S·cnt floats): the padded weight
+      // groups are zero, but 0·NaN is NaN, so the tail must never be another vector's (possibly non-finite) data
+      vd.htotal = 0;
+      vd.maxw4 = (maxw + 3) & ~3;
+      for (int l = 0; l < dm.nL; l++) vd.maxw4 = std::max(vd.maxw4, 4 * vd.sb[l] * vd.k4b[l]);
+      for (int l = 0; l < MAXL; l++) vd.hoff[l] = 0;
+      for (int l = 0; l + 1 < dm.nL; l++) {
+        vd.hoff[l] = vd.htotal;
+        vd.htotal += std::max((dm.sizes[l + 1] + 3) & ~3, 4 * vd.sf[l + 1] * vd.k4f[l + 1]);
+      }
+      const int x0 = 4 * vd.sf[0] * vd.k4f[0], xt = dm.DpA + 4 * vd.sb[dm.nL - 1] * vd.k4b[dm.nL - 1];
+      vd.nsp_f = std::max((dm.Dp + 3) & ~3, x0);
+      vd.nsp_b = std::max(std::max((2 * dm.DpA + dm.P + 3) & ~3, x0), xt);
+      if (hipMalloc(&p->vecw, (size_t)vd.total4 * 4 * sizeof(float)) != hipSuccess) {
+        err = "MLP plan: hipMalloc failed";
+        mlp_plan_destroy(p);
+        return LDE_ERR_ALLOC;
+      }
+    }
+  }
   if (hipMalloc(&p->frag, p->nfrag * sizeof(float)) != hipSuccess ||
       hipMalloc(&p->fragT, p->nfragT * sizeof(float)) != hipSuccess ||
       hipMalloc(&p->counter, 64) != hipSuccess || hipMalloc(&p->abort_flag, 64) != hipSuccess ||
@@ -1418,6 +1477,7 @@ void mlp_plan_destroy(MlpPlan* p) {
   if (!p) return;
   if (p->frag) (void)hipFree(p->frag);
   if (p->fragT) (void)hipFree(p->fragT);
+  if (p->vecw) (void)hipFree(p->vecw);
   if (p->counter) (void)hipFree(p->counter);
   if (p->abort_flag) (void)hipFree(p->abort_flag);
   if (p->slots) (void)hipFree(p->slots);
@@ -1432,7 +1492,7 @@ void mlp_plan_destroy(MlpPlan* p) {
 }
 
 int mlp_reserve(MlpPlan* p, int B, int T, std::string& err) {
-  const int nwg = cdiv(B, 4) + 1;   // grid-sum slots: one per workgroup; the 4-columns-per-wave adjoint may run one wave per workgroup
+  const int nwg = B + 1;   // grid-sum slots: one per workgroup; the small-batch kernels run one trajectory per workgroup
   if (nwg > p->cap_wg) {
     if (p->slots) (void)hipFree(p->slots);
     p->slots = nullptr;
@@ -1478,6 +1538,7 @@ int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::strin
   // device), halve the slot count down to one step's worth — a workgroup that runs out of slots folds them into its private
   // slab inside the solve kernel (exact), so fewer slots cost time, never correctness
   int cap = (int)want;
+  const size_t stage_before = p->stage_cap;
   for (;;) {
     if (grow(&p->stage, &p->stage_cap, (size_t)(nwg + 1) * cap * dm.blk_floats)) break;
     (void)hipGetLastError();
@@ -1489,6 +1550,12 @@ int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::strin
     err = "MLP plan: hipMalloc of the adjoint workspace failed";
     return LDE_ERR_ALLOC;
   }
+  // a fresh staging area holds arbitrary bits; the one-trajectory-per-workgroup kernel fills a tile's slots column by column,
+  // and a column that never reaches a slot carries weight 0 there — its a-panel must still be finite (0·NaN) for k_mlp_dw
+  if (p->stage_cap != stage_before && hipMemset(p->stage, 0, p->stage_cap * sizeof(float)) != hipSuccess) {
+    err = "MLP plan: hipMemset(stage) failed";
+    return LDE_ERR_HIP;
+  }
   p->nslots_cap = (int)nsl;
   p->adj_cap = cap;
   p->adj_ks = ks;
@@ -1497,6 +1564,7 @@ int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::strin
 
 int mlp_set_weights(MlpPlan* p, const float* W_dev, hipStream_t stream, std::string& err) {
   hipLaunchKernelGGL(k_build_frags, dim3(64, p->dm.nL), dim3(256), 0, stream, W_dev, p->dm, p->frag, p->fragT, (float*)nullptr);
+  if (p->vec_ok) hipLaunchKernelGGL(k_build_vec, dim3(64, p->dm.nL), dim3(256), 0, stream, W_dev, p->dm, p->vd, p->vecw);
   if (hipGetLastError() != hipSuccess) {
     err = "k_build_frags launch failed";
     return LDE_ERR_HIP;
@@ -1573,10 +1641,87 @@ static int launch_maybe_coop(bool coop, const void* fn, dim3 grid, dim3 block, s
   return LDE_OK;
 }
 
+// ---- the one-trajectory-per-workgroup kernels (lde_mlpv.h): applicability, LDS budget, launch -------------------------------------
+static size_t vec_lds_fixed(const MlpDims& dm, const VecDims& vd, int T, bool adj) {
+  const int nsp = adj ? vd.nsp_b : vd.nsp_f;
+  size_t b = (sizeof(VCtl) + 15) & ~size_t(15);
+  b += ((size_t)T * 8 + 15) & ~size_t(15);
+  b += (size_t)(11 * nsp + vd.htotal + 2 * vd.maxw4 + vd.NT + ((dm.nbias + 3) & ~3) + 2 * MAXL * (sizeof(VLayer) / 4)) * sizeof(float);
+  return (b + 15) & ~size_t(15);
+}
+// Which batches run there: see the measurement below. LDE_MLPV=0 switches the kernels off, LDE_MLPV_MAX_B moves the limit.
+static bool vec_applicable(const MlpPlan* p, int B, int T, bool adj, bool coupled_adaptive, size_t* lds, std::string& why) {
+  const char* e = getenv("LDE_MLPV");   // read per call: the tests switch kernels inside one process
+  if (!p->vec_ok || (e && atoi(e) == 0)) return false;
+  // measured (MI355X, c2 / c3 / c4 shapes, abl/ + profiles/): the one-trajectory workgroups win while the chip has a SIMD per
+  // wave (B·NT/64 ≤ 1024: c2 0.88 + 1.97 ms vs 1.77 + 3.44 at B = 256, c3 0.36 + 4.28 vs 0.63 + 5.0 at 1024, c4 0.46 + 3.77 vs
+  // 0.45 + 4.3 at 512) and lose beyond (c2 at B = 1024: 1.94 + 4.5 vs 1.78 + 3.9) — the tiles then have enough columns
+  const char* m = getenv("LDE_MLPV_MAX_B");
+  const int maxb = m ? atoi(m) : 1024 * 64 / p->vd.NT;
+  if (B > maxb) return false;
+  const size_t fixed = vec_lds_fixed(p->dm, p->vd, T, adj);
+  if (fixed > LDS_MAX / 2) return false;
+  // LDS per workgroup: everything when a CU gets one workgroup, a share otherwise (coupled adaptive control needs all B resident)
+  const int per_cu = cdiv(B, 256);
+  size_t budget = LDS_MAX / (size_t)per_cu;
+  if (per_cu > 1) budget -= 256;
+  if (budget < fixed) {
+    if (coupled_adaptive) return false;
+    budget = fixed;
+  }
+  const size_t want = fixed + (size_t)p->vd.total4 * 16;
+  *lds = (std::min(want, budget)) & ~size_t(15);
+  (void)why;
+  return true;
+}
+
+template <int SOLVER, bool ADJ>
+static int launch_vec(const MlpPlan* p, const KOpts& o, VArgs& a, size_t lds, bool coop, hipStream_t stream, std::string& err) {
+  MlpDims dmv = p->dm;
+  VecDims vdv = p->vd;
+  KOpts ov = o;
+  const void* fn = p->vd.NT == 64 ? (const void*)k_mlpv<SOLVER, 64, ADJ> : p->vd.NT == 128 ? (const void*)k_mlpv<SOLVER, 128, ADJ> : (const void*)k_mlpv<SOLVER, 256, ADJ>;
+  static bool attr_set[3] = {false, false, false};
+  const int ki = p->vd.NT == 64 ? 0 : (p->vd.NT == 128 ? 1 : 2);
+  if (!attr_set[ki]) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
+      err = "hipFuncSetAttribute(k_mlpv) failed";
+      return LDE_ERR_HIP;
+    }
+    attr_set[ki] = true;
+  }
+  a.lds_bytes = (int)lds;
+#if LDE_PROF
+  prof_reset();
+#endif
+  const int rcl = launch_maybe_coop(coop, fn, dim3(o.B), dim3(p->vd.NT), lds, stream, err, "k_mlpv", dmv, vdv, ov, a);
+#if LDE_PROF
+  prof_dump(ADJ ? "vec adjoint" : "vec forward", stream);
+#endif
+  return rcl;
+}
+
 int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* theta, const double* ts_dev,
                 const KOpts& o, float* z_out, int32_t* retcode, int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret,
                 hipStream_t stream, std::string& err) {
   const MlpDims& dm = p->dm;
+  {   // small batches: one trajectory per workgroup, lanes = hidden units (lde_mlpv.h)
+    size_t ldsv = 0;
+    const bool ca = dm.coupled && o.adaptive && o.B > 1;
+    if (vec_applicable(p, o.B, o.T, false, ca, &ldsv, err)) {
+      VArgs va{};
+      va.z0 = z0; va.theta = theta; va.ts = ts_dev; va.vecw = p->vecw; va.Wflat = W_dev; va.z_out = z_out; va.retcode = retcode;
+      va.st_nfe = nfe; va.st_nacc = nacc; va.st_nrej = nrej; va.st_ret = ret;
+      va.gs.counter = p->counter; va.gs.slots = p->slots; va.gs.abort_flag = p->abort_flag; va.gs.nwg = ca ? o.B : 1;
+      if (ca && (hipMemsetAsync(p->counter, 0, sizeof(unsigned), stream) != hipSuccess ||
+                 hipMemsetAsync(p->abort_flag, 0, sizeof(int), stream) != hipSuccess)) {
+        err = "hipMemsetAsync(counter) failed";
+        return LDE_ERR_HIP;
+      }
+      return dm.solver == LDE_SOLVER_RK4 ? launch_vec<LDE_SOLVER_RK4, false>(p, o, va, ldsv, ca, stream, err)
+                                         : launch_vec<LDE_SOLVER_TSIT5, false>(p, o, va, ldsv, ca, stream, err);
+    }
+  }
   const int nwg = cdiv(o.B, NB);
   const bool sync = dm.coupled && o.adaptive && nwg > 1;
   if (sync && nwg > 256) {
@@ -1734,9 +1879,43 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
 #if LDE_PROF
   prof_reset();
 #endif
-  // networks whose weights fit LDS once: four columns per wave, no barriers (lde_mlp4.h)
   int ntile_dw = nwg;
-  {
+  bool vec_done = false;
+  {   // small batches: one trajectory per workgroup, lanes = hidden units (lde_mlpv.h)
+    size_t ldsv = 0;
+    const bool ca = dm.coupled && o.adaptive && o.B > 1;
+    if (vec_applicable(p, o.B, o.T, true, ca, &ldsv, err)) {
+      if (hipMemsetAsync(p->fb_dev, 0, 2 * sizeof(int32_t), stream) != hipSuccess ||
+          hipMemsetAsync(p->nslots, 0, (size_t)2 * (nwg + 1) * sizeof(int32_t), stream) != hipSuccess ||
+          hipMemsetAsync(p->wts, 0, (size_t)nwg * p->adj_cap * NB * sizeof(float), stream) != hipSuccess) {
+        err = "hipMemsetAsync(staging weights) failed";
+        return LDE_ERR_HIP;
+      }
+      if (ca && (hipMemsetAsync(p->counter, 0, sizeof(unsigned), stream) != hipSuccess ||
+                 hipMemsetAsync(p->abort_flag, 0, sizeof(int), stream) != hipSuccess)) {
+        err = "hipMemsetAsync(counter) failed";
+        return LDE_ERR_HIP;
+      }
+      VArgs va{};
+      va.theta = theta; va.ts = ts_dev; va.vecw = p->vecw; va.Wflat = W_dev; va.z_out = const_cast<float*>(z_out); va.dz_out = dz_out;
+      va.dz0 = dz0; va.dtheta = dtheta; va.stage = p->stage; va.wts = p->wts; va.nslots = p->nslots; va.cap = p->adj_cap; va.ovf = p->fb_dev + 1;
+      va.st_nfe = nfe; va.st_nacc = nacc; va.st_nrej = nrej; va.st_ret = ret;
+      va.gs.counter = p->counter; va.gs.slots = p->slots; va.gs.abort_flag = p->abort_flag; va.gs.nwg = ca ? o.B : 1;
+      const int rcv = dm.solver == LDE_SOLVER_RK4 ? launch_vec<LDE_SOLVER_RK4, true>(p, o, va, ldsv, ca, stream, err)
+                                                  : launch_vec<LDE_SOLVER_TSIT5, true>(p, o, va, ldsv, ca, stream, err);
+      if (rcv) return rcv;
+      // a trajectory that ran out of staging slots sets *ovf: k_mlp_adjoint (which folds its slots into a private slab) then
+      // redoes the whole call; otherwise it returns at once. The decision is taken on the device.
+      vec_done = true;
+      a.fallback = 1;
+      if (sync && hipMemsetAsync(p->counter, 0, sizeof(unsigned), stream) != hipSuccess) {
+        err = "hipMemsetAsync(counter) failed";
+        return LDE_ERR_HIP;
+      }
+    }
+  }
+  // networks whose weights fit LDS once: four columns per wave, no barriers (lde_mlp4.h)
+  if (!vec_done) {
     Mlp4Dims md;
     size_t lds4 = 0;
     int nblocks = 0;

@@ -185,7 +185,8 @@ def test_tsit5_mlp_adjoint(o32, o64, batching, B):
     g0, _, gW, st = nat.adjoint(z, None, ts, dz)
     r0, _, rW, info = o32.adjoint(od, z, None, ts, dz, W=W)
     assert st["nfailed"] == 0
-    assert abs(st["naccept"] - info["naccept"]) <= 0.1 * info["naccept"] + 2
+    # relu network + reltol 1e-3: the step sequence of two correct f32 solves differs by round-off-triggered accept/reject flips
+    assert abs(st["naccept"] - info["naccept"]) <= 0.15 * info["naccept"] + 2
     d64 = O.make_desc(**{**kw, "abstol": 1e-10, "reltol": 1e-10})
     z64, _, _ = o64.forward(d64, z0, None, ts, W=W.astype(np.float64))
     t0, _, tW, _ = o64.adjoint(d64, z64, None, ts, dz, W=W.astype(np.float64))
@@ -296,10 +297,10 @@ def test_staging_overflow_path_gives_the_same_gradient(case, monkeypatch):
         assert st["nfailed"] == 0 and st["naccept"] >= T - 1
         res.append((g0, gL, gW, st))
     (a0, aL, aW, ast), (b0, bL, bW, bst) = res
-    # The roomy run may use the 4-columns-per-wave kernel and the tiny one its 16-column fallback: the same solve in another
-    # summation order. Smooth right-hand side at 1e-6: agreement to round-off; relu at the default tolerance: two correct
-    # fp32 solves agree to about 1 % (see test_c3_pendulum_plus_mlp_adjoint); same kernel both times: same bits in dz0.
-    lim = {"rk4_coupled": 0.0, "tsit5_per_traj": 2e-5, "c3": 1e-2}[case]
+    # The roomy run uses the small-batch kernel (one trajectory per workgroup) and the tiny one its 16-column fallback: the same
+    # solve in another summation order. Fixed step: round-off; smooth right-hand side at 1e-6: agreement to round-off; relu at
+    # the default tolerance: two correct fp32 solves agree to about 1 % (see test_c3_pendulum_plus_mlp_adjoint).
+    lim = {"rk4_coupled": 5e-6, "tsit5_per_traj": 2e-5, "c3": 1e-2}[case]
     assert abs(ast["naccept"] - bst["naccept"]) <= (0.1 if case == "c3" else 0.02) * ast["naccept"] + 1
     assert np.abs(a0 - b0).max() <= lim * np.abs(a0).max()
     if aL is not None:

@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 FP32_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: peak FP32 vector == matrix (f32-in MFMA)
+BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (no sparsity)
 
 WORKLOADS = {
     # name: dict(describing BASELINE.json configs; SURVEY.md §8d inputs)
@@ -181,6 +182,8 @@ def run_decoder(args, torch, dist, world, rank, local):
             Wc[-1] = 1.0
         L.check(lib.lde_chain_set_weights(ch, Wc.ctypes.data_as(C.c_void_p), Wc.size), ch, "lde_chain_set_weights", chain=True)
         L.check(lib.lde_chain_reserve(ch, N if name == "rec" else B), ch, "lde_chain_reserve", chain=True)
+        if args.dtype == "mixed":
+            L.check(lib.lde_chain_set_dtype(ch, L.DTYPE_BF16), ch, "lde_chain_set_dtype", chain=True)
         chains[name], weights[name] = (ch, sizes), Wc
     rng = np.random.default_rng(40 + rank)
     zt = torch.from_numpy((0.6 * rng.standard_normal((B, NL))).astype(np.float32)).to(dev)     # l̃ = (z̃₀, θ̃)
@@ -279,12 +282,12 @@ def run_decoder(args, torch, dist, world, rank, local):
         "metric": "trajectories/sec (latent_out -> solve -> reconstructor, forward + pullback) goku_decoder",
         "value": B * world * args.steps / el, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "f32", "data": "synthetic",
+        "dtype": "f32" if args.dtype == "f32" else "bf16 operands / f32 accumulate (dense chains), f32 solve", "data": "synthetic",
         "config": {"workload": f"goku_decoder: {DECODER['desc']}", "batch_per_gpu": B, "global_batch": B * world,
                    "save_points": T, "columns_through_the_reconstructor": N,
                    "parallelism": f"dp{world} (batch sharded by trajectory; one all-reduce of the flat decoder gradient per step)"},
-        "roofline": dict(bound="mfma", kernel=f"lde_chain {dom}", achieved=ach, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s",
-                         frac=ach / FP32_PEAK_TFLOPS, traffic=None, alg_flops_per_launch=dom_flops, avg_launch_ms=parts[dom],
+        "roofline": dict(bound="mfma", kernel=f"lde_chain {dom}", achieved=ach, peak=FP32_PEAK_TFLOPS if args.dtype == "f32" else BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                         frac=ach / (FP32_PEAK_TFLOPS if args.dtype == "f32" else BF16_PEAK_TFLOPS), traffic=None, alg_flops_per_launch=dom_flops, avg_launch_ms=parts[dom],
                          whole_step_TFLOPs=flops / (ms_per_step * 1e-3) / 1e12),
         "kernel_ms": parts,
     }
@@ -371,6 +374,9 @@ def run_goku_step(args, torch, dist, world, rank, local):
     with torch.no_grad():   # start inside the data range of the pendulum length, L ~ U(1,2) [REF create_data.jl:19-22]
         lo_th._dense[-1].bias.fill_(1.0)
     mods = [enc.feature_extractor, *enc.pattern_extractor, *enc.latent_in, lo_z0, lo_th, dec.reconstructor]
+    if args.dtype == "mixed":   # BASELINE.json configs[4]: bf16 encoder-decoder (the dense chains), f32 solve; the recurrent stacks stay f32
+        for m in (enc.feature_extractor, *enc.latent_in, lo_z0, lo_th, dec.reconstructor):
+            m.set_dtype("bf16")
     params = [p for m in mods for p in m.parameters()]
     from latentdiffeq_amd.train import FluxADAMW
     opt = FluxADAMW(params, lr=1e-3, decay=1e-10)   # ADAMW(η, β, decay), Flux flavour [REF model_train.jl:138, :150]; one fused update kernel
@@ -417,7 +423,8 @@ def run_goku_step(args, torch, dist, world, rank, local):
     out = {
         "metric": "trajectories/sec, whole GOKU training step (encoder -> sample -> latent_out -> solve -> reconstructor, loss, pullback, AdamW) goku_step",
         "value": B * world * args.steps / el, "unit": "trajectories/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32" if args.dtype == "f32" else "mixed: bf16 operands / f32 accumulate in the dense chains, f32 solve and recurrent stacks", "data": "synthetic",
         "config": {"workload": "goku_step: GOKU_basic default layers (input 784, T=50), Pendulum Tsit5, MSE + 1e-3·KL, AdamW; "
                                "torch-level API over lde_chain_* / lde_rnn_* / lde_forward / lde_adjoint",
                    "batch_per_gpu": B, "global_batch": Bg, "save_points": T,

@@ -242,6 +242,13 @@ int  lde_chain_backward_saved(lde_chain* c, const float* x, const float* y, cons
 /* How the pullbacks deliver the weight gradient: on = 1 (default) dW += gradient, like lde_adjoint; on = 0: dW = gradient — every
  * entry of dW is written exactly once, so a caller that wants the plain gradient needs no zero fill (one launch less). */
 int  lde_chain_set_accumulate(lde_chain* c, int on);
+/* Arithmetic of the chain's matrix products — BASELINE.json configs[4]: "mixed fp32 solve / bf16 encoder-decoder". LDE_DTYPE_F32
+ * (default): exact f32 products (v_mfma_f32_16x16x4_f32). LDE_DTYPE_BF16: both operands of every product (forward, input gradient,
+ * weight gradient) are rounded to bfloat16 (round-to-nearest-even) and multiplied on the bf16 matrix cores with f32 accumulation;
+ * weights, biases, activations, saved activations and gradients stay f32 in memory (f32 master weights), so a caller switches modes
+ * without re-uploading anything. The solve (lde_forward / lde_adjoint) is f32 in either mode. */
+enum lde_dtype { LDE_DTYPE_F32 = 0, LDE_DTYPE_BF16 = 1 };
+int  lde_chain_set_dtype(lde_chain* c, int dtype);
 const char* lde_chain_last_error(const lde_chain* c);
 
 /* ======================================================================================================

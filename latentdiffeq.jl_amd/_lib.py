@@ -30,7 +30,7 @@ EXPORTS = ["lde_abi_version", "lde_problem_desc_default", "lde_num_weights", "ld
            "lde_get_stats", "lde_last_error",
            "lde_chain_num_weights", "lde_chain_create", "lde_chain_destroy", "lde_chain_set_weights",
            "lde_chain_set_weights_device", "lde_chain_reserve", "lde_chain_forward", "lde_chain_backward",
-           "lde_chain_last_error", "lde_chain_set_accumulate", "lde_rnn_set_accumulate", "lde_chain_saved_floats", "lde_chain_forward_save", "lde_chain_backward_saved",
+           "lde_chain_last_error", "lde_chain_set_accumulate", "lde_chain_set_dtype", "lde_rnn_set_accumulate", "lde_chain_saved_floats", "lde_chain_forward_save", "lde_chain_backward_saved",
            "lde_rnn_num_weights", "lde_rnn_create", "lde_rnn_destroy", "lde_rnn_set_weights", "lde_rnn_set_weights_device",
            "lde_rnn_reserve", "lde_rnn_forward", "lde_rnn_backward", "lde_rnn_last_error",
            "lde_sample_forward", "lde_sample_backward", "lde_kl_forward", "lde_kl_backward", "lde_mse_forward",
@@ -52,6 +52,7 @@ class RnnDesc(C.Structure):
 
 LDE_CHAIN_MAX_LAYERS = 6
 CACT_IDENTITY, CACT_RELU, CACT_TANH, CACT_SIGMOID, CACT_SOFTPLUS = 0, 1, 2, 3, 4
+DTYPE_F32, DTYPE_BF16 = 0, 1
 
 
 class ChainDesc(C.Structure):
@@ -130,6 +131,7 @@ def load():
     lib.lde_chain_last_error.argtypes = [vp]
     lib.lde_chain_last_error.restype = C.c_char_p
     lib.lde_chain_set_accumulate.argtypes = [vp, i32]
+    lib.lde_chain_set_dtype.argtypes = [vp, i32]
     lib.lde_rnn_set_accumulate.argtypes = [vp, i32]
     lib.lde_chain_saved_floats.argtypes = [vp, i64]
     lib.lde_chain_saved_floats.restype = i64

@@ -154,6 +154,18 @@ class Chain(torch.nn.Module):
             d._owner, d._w0, d._b0 = self, None, None
         self._handle = None
         self._lib = None
+        self.dtype = "f32"
+
+    def set_dtype(self, dtype: str) -> "Chain":
+        """'f32' (default) or 'bf16': operands of every matrix product rounded to bfloat16, f32 accumulation, f32 master weights
+        and activations (lde_chain_set_dtype; BASELINE.json configs[4] "mixed fp32 solve / bf16 encoder-decoder")."""
+        if dtype not in ("f32", "bf16"):
+            raise ValueError("dtype: 'f32' or 'bf16'")
+        self.dtype = dtype
+        if self._handle is not None:
+            L.check(self._lib.lde_chain_set_dtype(self._handle, L.DTYPE_BF16 if dtype == "bf16" else L.DTYPE_F32), self._handle,
+                    "lde_chain_set_dtype", chain=True)
+        return self
 
     def _native(self):
         if self._handle is None:
@@ -174,6 +186,8 @@ class Chain(torch.nn.Module):
                     if h:
                         self._lib.lde_chain_destroy(h)
             L.check(self._lib.lde_chain_set_accumulate(h, 0), h, "lde_chain_set_accumulate", chain=True)   # the pullback hands autograd a fresh gradient
+            if self.dtype == "bf16":
+                L.check(self._lib.lde_chain_set_dtype(h, L.DTYPE_BF16), h, "lde_chain_set_dtype", chain=True)
             self._handle = h
         return self._handle
 

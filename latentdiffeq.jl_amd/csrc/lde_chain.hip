@@ -66,7 +66,7 @@ __device__ __forceinline__ float cact_grad_out(int kind, float f) {
 // One wave: NT_ (1 or 2) 16-row tiles × NCG column groups, all K-groups, software-pipelined: A fragments (global/L2) run
 // PFA K-groups ahead in a register ring, B operands PFB ahead; pre() is called before the K loop (its loads overlap the
 // MFMAs), epi() after. Per K-group NT_ fragment loads + NCG operand loads feed 4·NT_·NCG MFMAs.
-template <int NT_, int NCG, bool BGLB, class Pre, class Epi>
+template <int NT_, int NCG, bool BGLB, bool BF, class Pre, class Epi>
 __device__ __forceinline__ void chain_mac(const f32x4* A0, const f32x4* A1, const float* bp, int cgstride, int KG, int row_a,
                                           int row_b, int cg0, int col, Pre pre, Epi epi) {
   constexpr int PFA = 4, PFB = BGLB ? 4 : 2;
@@ -108,12 +108,22 @@ __device__ __forceinline__ void chain_mac(const f32x4* A0, const f32x4* A1, cons
         if (NT_ == 2) ra1[i] = A1[ka * 64];
 #pragma unroll
         for (int cg = 0; cg < NCG; cg++) rb[i % PFB][cg] = *reinterpret_cast<const f32x4*>(bp + (cg0 + cg) * cgstride + kb * 16);
-#pragma unroll
-        for (int s4 = 0; s4 < 4; s4++) {   // K-step outer: 2·NCG independent accumulators between two uses of the same one
+        if (BF) {   // bf16 operands: one 16x16x16 MFMA per (row tile, column group) and K-group
+          const s16x4 a0 = cvt_bf16x4(c0), a1 = cvt_bf16x4(c1);
 #pragma unroll
           for (int cg = 0; cg < NCG; cg++) {
-            acc0[cg] = mfma16(c0[s4], cb[cg][s4], acc0[cg]);
-            if (NT_ == 2) acc1[cg] = mfma16(c1[s4], cb[cg][s4], acc1[cg]);
+            const s16x4 b4 = cvt_bf16x4(cb[cg]);
+            acc0[cg] = mfma16_bf(a0, b4, acc0[cg]);
+            if (NT_ == 2) acc1[cg] = mfma16_bf(a1, b4, acc1[cg]);
+          }
+        } else {
+#pragma unroll
+          for (int s4 = 0; s4 < 4; s4++) {   // K-step outer: 2·NCG independent accumulators between two uses of the same one
+#pragma unroll
+            for (int cg = 0; cg < NCG; cg++) {
+              acc0[cg] = mfma16(c0[s4], cb[cg][s4], acc0[cg]);
+              if (NT_ == 2) acc1[cg] = mfma16(c1[s4], cb[cg][s4], acc1[cg]);
+            }
           }
         }
       }
@@ -131,7 +141,7 @@ __device__ __forceinline__ void chain_mac(const f32x4* A0, const f32x4* A1, cons
 // Row tiles are dealt 16 at a time (a wave takes tiles rt and rt+8 together); 9–15 left-over tiles make one more such
 // pass, exactly 8 a single-tile pass, and fewer than 8 are dealt as (tile, column group) units so that the last pass
 // still uses every wave (49 tiles of the 784-row layer: 3 passes + 1/8 instead of 4).
-template <int CG, bool BGLB, class Pre, class Epi>
+template <int CG, bool BGLB, bool BF, class Pre, class Epi>
 __device__ __forceinline__ void chain_gemm(const float* __restrict__ gfrag, int R, int K, const float* Bp, int ldb,
                                            int cgstride, Pre pre, Epi epi) {
   constexpr int NW = 8;
@@ -144,25 +154,25 @@ __device__ __forceinline__ void chain_gemm(const float* __restrict__ gfrag, int 
   int base = 0;
   for (; base + 2 * NW <= RT; base += 2 * NW) {
     const int rt = base + wave, rt2 = rt + NW;
-    chain_mac<2, CG, BGLB>(A + (size_t)rt * KG * 64, A + (size_t)rt2 * KG * 64, bp, cgstride, KG, rt * 16 + rsub,
+    chain_mac<2, CG, BGLB, BF>(A + (size_t)rt * KG * 64, A + (size_t)rt2 * KG * 64, bp, cgstride, KG, rt * 16 + rsub,
                            rt2 * 16 + rsub, 0, col, pre, epi);
   }
   if (RT - base > NW) {   // 9–15 tiles left: one more double pass; a wave without a second tile repeats its first
     const int rt = base + wave, rt2 = rt + NW;
     const bool two = rt2 < RT;
-    chain_mac<2, CG, BGLB>(A + (size_t)rt * KG * 64, A + (size_t)(two ? rt2 : rt) * KG * 64, bp, cgstride, KG,
+    chain_mac<2, CG, BGLB, BF>(A + (size_t)rt * KG * 64, A + (size_t)(two ? rt2 : rt) * KG * 64, bp, cgstride, KG,
                            rt * 16 + rsub, two ? rt2 * 16 + rsub : -1, 0, col, pre, epi);
     return;
   }
   if (RT - base == NW) {
     const int rt = base + wave;
-    chain_mac<1, CG, BGLB>(A + (size_t)rt * KG * 64, nullptr, bp, cgstride, KG, rt * 16 + rsub, 0, 0, col, pre, epi);
+    chain_mac<1, CG, BGLB, BF>(A + (size_t)rt * KG * 64, nullptr, bp, cgstride, KG, rt * 16 + rsub, 0, 0, col, pre, epi);
     return;
   }
   const int units = (RT - base) * CG;
   for (int u = wave; u < units; u += NW) {
     const int rt = base + u / CG, cg = u % CG;
-    chain_mac<1, 1, BGLB>(A + (size_t)rt * KG * 64, nullptr, bp, cgstride, KG, rt * 16 + rsub, 0, cg, col, pre, epi);
+    chain_mac<1, 1, BGLB, BF>(A + (size_t)rt * KG * 64, nullptr, bp, cgstride, KG, rt * 16 + rsub, 0, cg, col, pre, epi);
   }
 }
 
@@ -221,7 +231,7 @@ __device__ __forceinline__ long long chain_tile_start(const ChainDims& cd, int N
 // about one unit in 10⁷, which a test with 3·10⁵ columns caught as a 3 % error in one column's gradient.)
 struct SaveTo { float* base; long long n0, N; };   // base == nullptr: nothing is saved
 
-template <int CG, bool BG = false>
+template <int CG, bool BF, bool BG = false>
 __device__ __forceinline__ void chain_hidden_layer(const ChainDims& cd, int l, const float* frag, const float* biasc,
                                                    const float* Xin, int ldx, float* Y, float* fstage = nullptr,
                                                    SaveTo sv = SaveTo{nullptr, 0, 0}) {
@@ -229,7 +239,7 @@ __device__ __forceinline__ void chain_hidden_layer(const ChainDims& cd, int l, c
   const int in = dm.sizes[l], out = dm.sizes[l + 1], actk = cd.act[l], skip = BG ? 0 : cd.skip[l], ldh = cd.ldh;
   const float* bias = biasc + dm.bias_lin[l];
   const int out32 = pad32(out);
-  chain_gemm<CG, BG>(frag + dm.frag_off[l], out, in, Xin, ldx, 16 * ldx, [](int, int, int) { return NoPre{}; },
+  chain_gemm<CG, BG, BF>(frag + dm.frag_off[l], out, in, Xin, ldx, 16 * ldx, [](int, int, int) { return NoPre{}; },
                         [&](int row0, int cg, int col, f32x4 v, NoPre) {
                           const int c = cg * 16 + col;
                           f32x4 r;
@@ -255,7 +265,7 @@ __device__ __forceinline__ void chain_hidden_layer(const ChainDims& cd, int l, c
                         });
 }
 
-template <int CG>
+template <int CG, bool BF>
 __global__ void __launch_bounds__(512) k_chain_forward(ChainDims cd, ChainFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float csm[];
   constexpr int NC = 16 * CG;
@@ -278,8 +288,8 @@ __global__ void __launch_bounds__(512) k_chain_forward(ChainDims cd, ChainFwdArg
     float* Y = (l & 1) ? H1 : H0;
     PROF_T(pl0);
     const SaveTo sv{a.saved, n0, a.N};
-    if (l == 0 && cd.gx) chain_hidden_layer<CG, true>(cd, 0, a.frag, biasc, xg, dm.sizes[0], Y, nullptr, sv);
-    else chain_hidden_layer<CG>(cd, l, a.frag, biasc, Xin, ldx, Y, nullptr, sv);
+    if (l == 0 && cd.gx) chain_hidden_layer<CG, BF, true>(cd, 0, a.frag, biasc, xg, dm.sizes[0], Y, nullptr, sv);
+    else chain_hidden_layer<CG, BF>(cd, l, a.frag, biasc, Xin, ldx, Y, nullptr, sv);
     PROF_T(pl1);
     __syncthreads();
     PROF_T(pl2);
@@ -308,8 +318,8 @@ __global__ void __launch_bounds__(512) k_chain_forward(ChainDims cd, ChainFwdArg
                             }
                           };
     auto nopre = [](int, int, int) { return NoPre{}; };
-    if (nL == 1 && cd.gx) chain_gemm<CG, true>(a.frag + dm.frag_off[l], out, in, xg, in, 16 * in, nopre, epi_last);
-    else chain_gemm<CG, false>(a.frag + dm.frag_off[l], out, in, Xin, ldx, 16 * ldx, nopre, epi_last);
+    if (nL == 1 && cd.gx) chain_gemm<CG, true, BF>(a.frag + dm.frag_off[l], out, in, xg, in, 16 * in, nopre, epi_last);
+    else chain_gemm<CG, false, BF>(a.frag + dm.frag_off[l], out, in, Xin, ldx, 16 * ldx, nopre, epi_last);
   }
   PROF_T(pz1);
   PROF_ADD(2 + 2 * (nL - 1), pz0, pz1);
@@ -332,7 +342,7 @@ struct ChainBwdArgs {
 
 struct PrePair { f32x4 h, a; };
 
-template <int CG>
+template <int CG, bool BF>
 __global__ void __launch_bounds__(512) k_chain_backward(ChainDims cd, ChainBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float csm[];
   constexpr int NC = 16 * CG;
@@ -401,8 +411,8 @@ __global__ void __launch_bounds__(512) k_chain_backward(ChainDims cd, ChainBwdAr
     int ldx = cd.ld0;
     for (int l = 0; l + 1 < nL; l++) {
       float* Y = (l & 1) ? P1 : P0;
-      if (l == 0 && cd.gx) chain_hidden_layer<CG, true>(cd, 0, a.frag, biasc, xg, dm.sizes[0], Y);
-      else chain_hidden_layer<CG>(cd, l, a.frag, biasc, Xin, ldx, Y, cd.skip[l] ? blk0 + cd.f_off[l] : nullptr);
+      if (l == 0 && cd.gx) chain_hidden_layer<CG, BF, true>(cd, 0, a.frag, biasc, xg, dm.sizes[0], Y);
+      else chain_hidden_layer<CG, BF>(cd, l, a.frag, biasc, Xin, ldx, Y, cd.skip[l] ? blk0 + cd.f_off[l] : nullptr);
       __syncthreads();
 #pragma unroll
       for (int cg = 0; cg < CG; cg++)
@@ -474,8 +484,8 @@ __global__ void __launch_bounds__(512) k_chain_backward(ChainDims cd, ChainBwdAr
         for (int q = 0; q < 4; q++) d[q] = row0 + q < in ? g[q] * cact_grad_out(actp, p.h[q] - p.a[q]) : 0.f;
         *reinterpret_cast<f32x4*>(Dn + c * ldh + row0) = d;
       };
-      if (l == L1) chain_gemm<CG, true>(fragT, in, out, Bglb, pad32(out), dm.blk_floats, pre, epi);
-      else chain_gemm<CG, false>(fragT, in, out, Dcur, ldh, 16 * ldh, pre, epi);
+      if (l == L1) chain_gemm<CG, true, BF>(fragT, in, out, Bglb, pad32(out), dm.blk_floats, pre, epi);
+      else chain_gemm<CG, false, BF>(fragT, in, out, Dcur, ldh, 16 * ldh, pre, epi);
       __syncthreads();
 #pragma unroll
       for (int cg = 0; cg < CG; cg++)
@@ -494,8 +504,8 @@ __global__ void __launch_bounds__(512) k_chain_backward(ChainDims cd, ChainBwdAr
             if (row0 + q < in) a.dx[(size_t)n * in + row0 + q] = g[q];
         }
       };
-      if (l == L1) chain_gemm<CG, true>(fragT, in, out, Bglb, pad32(out), dm.blk_floats, pre, epi);
-      else chain_gemm<CG, false>(fragT, in, out, Dcur, ldh, 16 * ldh, pre, epi);
+      if (l == L1) chain_gemm<CG, true, BF>(fragT, in, out, Bglb, pad32(out), dm.blk_floats, pre, epi);
+      else chain_gemm<CG, false, BF>(fragT, in, out, Dcur, ldh, 16 * ldh, pre, epi);
     }
   }
 }
@@ -507,6 +517,7 @@ using namespace lde;
 
 struct lde_chain {
   bool accumulate = true;   // pullback: dW += gradient (default) or dW = gradient
+  bool bf16 = false;        // MFMA operands rounded to bf16 (lde_chain_set_dtype); storage and accumulation stay f32
   lde_chain_desc d;
   ChainDims cd;
   int64_t nW = 0;
@@ -761,22 +772,25 @@ static int chain_forward_impl(lde_chain* c, const float* x, int64_t N, float* y,
   }
   const int NC = 16 * pk.cg;
   const dim3 grid((unsigned)((N + NC - 1) / NC));
-  static bool attr[5] = {false, false, false, false, false};
-  const void* fn = pk.cg == 4 ? (const void*)k_chain_forward<4> : pk.cg == 2 ? (const void*)k_chain_forward<2>
-                                                                            : (const void*)k_chain_forward<1>;
-  if (!attr[pk.cg]) {
+  static bool attr[2][5] = {{false, false, false, false, false}, {false, false, false, false, false}};
+  const int bf = c->bf16 ? 1 : 0;
+  const void* fn = bf ? (pk.cg == 4 ? (const void*)k_chain_forward<4, true> : pk.cg == 2 ? (const void*)k_chain_forward<2, true> : (const void*)k_chain_forward<1, true>)
+                      : (pk.cg == 4 ? (const void*)k_chain_forward<4, false> : pk.cg == 2 ? (const void*)k_chain_forward<2, false> : (const void*)k_chain_forward<1, false>);
+  if (!attr[bf][pk.cg]) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
       c->err = "hipFuncSetAttribute(k_chain_forward) failed";
       return LDE_ERR_HIP;
     }
-    attr[pk.cg] = true;
+    attr[bf][pk.cg] = true;
   }
 #if LDE_PROF
   { long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
 #endif
-  if (pk.cg == 4) hipLaunchKernelGGL(k_chain_forward<4>, grid, dim3(512), pk.lds, stream, *pk.cd, a);
-  else if (pk.cg == 2) hipLaunchKernelGGL(k_chain_forward<2>, grid, dim3(512), pk.lds, stream, *pk.cd, a);
-  else hipLaunchKernelGGL(k_chain_forward<1>, grid, dim3(512), pk.lds, stream, *pk.cd, a);
+  {
+    ChainDims cdv = *pk.cd;
+    void* argv[] = {(void*)&cdv, (void*)&a};
+    (void)hipLaunchKernel(fn, grid, dim3(512), argv, pk.lds, stream);
+  }
   if (hipGetLastError() != hipSuccess) {
     c->err = "k_chain_forward launch failed";
     return LDE_ERR_HIP;
@@ -828,17 +842,22 @@ static int chain_backward_impl(lde_chain* c, const float* x, const float* y, con
   ChainBwdArgs a{x, y, dy, dx, c->frag, c->fragT, c->W_dev, c->stage, c->wts, (long long)N, saved};
   const int NC = 16 * pk.cg;
   const dim3 grid((unsigned)((N + NC - 1) / NC));
-  static bool attr[3] = {false, false, false};
-  const void* fn = pk.cg == 2 ? (const void*)k_chain_backward<2> : (const void*)k_chain_backward<1>;
-  if (!attr[pk.cg]) {
+  static bool attr[2][3] = {{false, false, false}, {false, false, false}};
+  const int bf = c->bf16 ? 1 : 0;
+  const void* fn = bf ? (pk.cg == 2 ? (const void*)k_chain_backward<2, true> : (const void*)k_chain_backward<1, true>)
+                      : (pk.cg == 2 ? (const void*)k_chain_backward<2, false> : (const void*)k_chain_backward<1, false>);
+  if (!attr[bf][pk.cg]) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
       c->err = "hipFuncSetAttribute(k_chain_backward) failed";
       return LDE_ERR_HIP;
     }
-    attr[pk.cg] = true;
+    attr[bf][pk.cg] = true;
   }
-  if (pk.cg == 2) hipLaunchKernelGGL(k_chain_backward<2>, grid, dim3(512), pk.lds, stream, *pk.cd, a);
-  else hipLaunchKernelGGL(k_chain_backward<1>, grid, dim3(512), pk.lds, stream, *pk.cd, a);
+  {
+    ChainDims cdv = *pk.cd;
+    void* argv[] = {(void*)&cdv, (void*)&a};
+    (void)hipLaunchKernel(fn, grid, dim3(512), argv, pk.lds, stream);
+  }
   if (hipGetLastError() != hipSuccess) {
     c->err = "k_chain_backward launch failed";
     return LDE_ERR_HIP;
@@ -846,11 +865,16 @@ static int chain_backward_impl(lde_chain* c, const float* x, const float* y, con
   // weight gradient: large-K product over the staged panels (lde_mfma.h)
   DwArgs da;
   da.stage = c->stage; da.wts = c->wts; da.nslots = nullptr; da.slab = c->slab; da.cap = cap; da.total = total;   // tiles filled in order
-  rc = launch_weight_gradient(dm, da, nvt, 1, nullptr, c->ints, 0, dW, c->ints + 2, stream, c->err, !c->accumulate);
+  rc = launch_weight_gradient(dm, da, nvt, 1, nullptr, c->ints, 0, dW, c->ints + 2, stream, c->err, !c->accumulate, c->bf16);
   if (rc) return rc;
   return LDE_OK;
 }
 
+int lde_chain_set_dtype(lde_chain* c, int dtype) {
+  if (!c || (dtype != LDE_DTYPE_F32 && dtype != LDE_DTYPE_BF16)) return LDE_ERR_INVALID_ARG;
+  c->bf16 = dtype == LDE_DTYPE_BF16;
+  return LDE_OK;
+}
 int lde_chain_forward(lde_chain* c, const float* x, int64_t N, float* y, void* stream) {
   return chain_forward_impl(c, x, N, y, nullptr, stream);
 }

@@ -29,6 +29,21 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
 
+// bf16 operand mode of the dense chains (BASELINE.json configs[4]: "mixed fp32 solve / bf16 encoder-decoder"): storage, biases,
+// activations and accumulation stay f32; only the two MFMA operands are rounded to bf16 (round-to-nearest-even,
+// v_cvt_pk_bf16_f32) right before the multiply. A lane's float4 of a K-group — k = 16·kg + 4·(lane>>4) + 0..3 — is exactly the
+// operand of ONE v_mfma_f32_16x16x16_bf16, which replaces the four v_mfma_f32_16x16x4_f32 of the f32 path.
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2_ __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2_ __attribute__((ext_vector_type(2)));
+typedef int i32x2_ __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x4 cvt_bf16x4(f32x4 v) {
+  const bf16x2_ lo = __builtin_convertvector((f32x2_){v[0], v[1]}, bf16x2_), hi = __builtin_convertvector((f32x2_){v[2], v[3]}, bf16x2_);
+  const i32x2_ r = {__builtin_bit_cast(int, lo), __builtin_bit_cast(int, hi)};
+  return __builtin_bit_cast(s16x4, r);
+}
+__device__ __forceinline__ f32x4 mfma16_bf(s16x4 a, s16x4 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x16bf16_1k(a, b, c, 0, 0, 0); }
+
 // LDE_PROF builds (diagnostic): thread 0 of workgroup 0 accumulates s_memtime cycles per phase into g_prof[].
 //   0 stage combination   1 control / error norm / save   2+2l GEMM of layer l (to its last MFMA/epilogue)   3+2l barrier after it
 //   in the adjoint the backward layers follow at 2+2(nL+l'), and 30 = panel staging stores
@@ -231,7 +246,9 @@ inline size_t dw_lds_floats(const MlpDims& dm, int ndw) {
   return mx;
 }
 
-template <int DW_NDW>
+// BF: bf16 operands (chains in bf16 mode): the lane's eight (a, δ) pairs of a slot — columns 2·s8 + half — feed two
+// v_mfma_f32_32x32x8_bf16 (s8 = 0..3 and 4..7: the same column set on both operands, so the contraction is the same sum).
+template <int DW_NDW, bool BF = false>
 static __global__ void __launch_bounds__(512) k_mlp_dw(MlpDims dm, DwArgs a) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   const int tile = blockIdx.x, part = blockIdx.y, KS = gridDim.y;
@@ -314,8 +331,13 @@ static __global__ void __launch_bounds__(512) k_mlp_dw(MlpDims dm, DwArgs a) {
           av[s8] = ap[s8 * 2 * lsa];
           bv[s8] = bp[s8 * 2 * lsd];
         }
+        if (BF) {
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(cvt_bf16x4(f32x4{av[0], av[1], av[2], av[3]}), cvt_bf16x4(f32x4{bv[0], bv[1], bv[2], bv[3]}), acc[m], 0, 0, 0);
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(cvt_bf16x4(f32x4{av[4], av[5], av[6], av[7]}), cvt_bf16x4(f32x4{bv[4], bv[5], bv[6], bv[7]}), acc[m], 0, 0, 0);
+        } else {
 #pragma unroll
-        for (int s8 = 0; s8 < 8; s8++) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s8], bv[s8], acc[m], 0, 0, 0);
+          for (int s8 = 0; s8 < 8; s8++) acc[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[s8], bv[s8], acc[m], 0, 0, 0);
+        }
       }
     }
     if (do_bias) {
@@ -439,7 +461,7 @@ static bool grow(T** ptr, size_t* cap, size_t need) {
 //   slabs: [ntile·ks][slab_n] partial slabs followed by one slab_n sum buffer (caller sizes it: (ntile·ks + 1)·slab_n)
 static int launch_weight_gradient(const MlpDims& dm, const DwArgs& da, int ntile, int ks, const float* priv,
                                   const int32_t* nflush, int npriv, float* dW, int32_t* feedback, hipStream_t stream,
-                                  std::string& err, bool assign = false) {
+                                  std::string& err, bool assign = false, bool bf16 = false) {
   const int ndw = dw_pick_ndw(dm);
   const size_t dlds = dw_lds_floats(dm, ndw) * sizeof(float);
   if (dlds > LDS_MAX) {
@@ -450,14 +472,21 @@ static int launch_weight_gradient(const MlpDims& dm, const DwArgs& da, int ntile
   if (!attr_set) {
     if (hipFuncSetAttribute((const void*)k_mlp_dw<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess ||
         hipFuncSetAttribute((const void*)k_mlp_dw<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess ||
-        hipFuncSetAttribute((const void*)k_mlp_dw<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
+        hipFuncSetAttribute((const void*)k_mlp_dw<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_mlp_dw<1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_mlp_dw<2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess ||
+        hipFuncSetAttribute((const void*)k_mlp_dw<4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
       err = "hipFuncSetAttribute(k_mlp_dw) failed";
       return LDE_ERR_HIP;
     }
     attr_set = true;
   }
   const dim3 grid(ntile, ks, dw_jobs(dm, ndw));
-  if (ndw == 1) hipLaunchKernelGGL(k_mlp_dw<1>, grid, dim3(512), dlds, stream, dm, da);
+  if (bf16) {
+    if (ndw == 1) hipLaunchKernelGGL((k_mlp_dw<1, true>), grid, dim3(512), dlds, stream, dm, da);
+    else if (ndw == 2) hipLaunchKernelGGL((k_mlp_dw<2, true>), grid, dim3(512), dlds, stream, dm, da);
+    else hipLaunchKernelGGL((k_mlp_dw<4, true>), grid, dim3(512), dlds, stream, dm, da);
+  } else if (ndw == 1) hipLaunchKernelGGL(k_mlp_dw<1>, grid, dim3(512), dlds, stream, dm, da);
   else if (ndw == 2) hipLaunchKernelGGL(k_mlp_dw<2>, grid, dim3(512), dlds, stream, dm, da);
   else hipLaunchKernelGGL(k_mlp_dw<4>, grid, dim3(512), dlds, stream, dm, da);
   if (ntile * ks <= 32) {   // few slabs: summed inside the gather

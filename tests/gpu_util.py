@@ -139,6 +139,10 @@ class NativeChain:
         L.check(self.lib.lde_chain_set_weights(self.h, W.ctypes.data_as(C.c_void_p), W.size), self.h,
                 "lde_chain_set_weights", chain=True)
 
+    def set_dtype(self, dtype):
+        L.check(self.lib.lde_chain_set_dtype(self.h, {"f32": L.DTYPE_F32, "bf16": L.DTYPE_BF16}[dtype]), self.h,
+                "lde_chain_set_dtype", chain=True)
+
     def forward(self, x):
         xd = torch.from_numpy(np.ascontiguousarray(x, np.float32)).to("cuda")
         N = xd.shape[0]

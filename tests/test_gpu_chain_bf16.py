@@ -1,0 +1,124 @@
+"""GPU: the dense chains in bf16 operand mode (lde_chain_set_dtype; BASELINE.json configs[4] "mixed fp32 solve / bf16
+encoder-decoder"): both operands of every matrix product — forward, input gradient, weight gradient — are rounded to
+bfloat16 (round-to-nearest-even) and multiplied with f32 accumulation; weights, activations and gradients stay f32.
+
+Checked against a numpy restatement of exactly that arithmetic (Flux's Dense / SkipConnection definitions as in
+oracle/lde_chain_oracle.c, operands rounded to bf16 with integer arithmetic, products accumulated in float64):
+agreement to f32 accumulation order (median ≤ 2e-6, worst entry ≤ 2e-3 of the output scale — a hidden value sitting on a rounding
+boundary may round the other way), and against the f32 path at the bf16 level (≤ 3e-2)."""
+import numpy as np
+import pytest
+
+from latentdiffeq_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def bf16r(a):
+    """float32 → nearest bfloat16 (ties to even), returned as float32."""
+    u = np.ascontiguousarray(a, np.float32).view(np.uint32).astype(np.uint64)
+    u = (u + 0x7FFF + ((u >> 16) & 1)) & 0xFFFF0000
+    return u.astype(np.uint32).view(np.float32).reshape(np.shape(a))
+
+
+def _act(kind, x):
+    if kind == L.CACT_RELU:
+        return np.maximum(x, 0)
+    if kind == L.CACT_TANH:
+        return np.tanh(x)
+    if kind == L.CACT_SIGMOID:
+        return 1 / (1 + np.exp(-x))
+    if kind == L.CACT_SOFTPLUS:
+        return np.maximum(x, 0) + np.log1p(np.exp(-np.abs(x)))
+    return x
+
+
+def _act_grad_out(kind, f):
+    if kind == L.CACT_RELU:
+        return (f > 0).astype(f.dtype)
+    if kind == L.CACT_TANH:
+        return 1 - f * f
+    if kind == L.CACT_SIGMOID:
+        return f * (1 - f)
+    if kind == L.CACT_SOFTPLUS:
+        return 1 - np.exp(-f)
+    return np.ones_like(f)
+
+
+def _split(sizes, W):
+    out, off = [], 0
+    for i, o in zip(sizes[:-1], sizes[1:]):
+        Wl = W[off:off + i * o].reshape(i, o).T          # vec(W) column-major [out×in]
+        off += i * o
+        out.append((Wl, W[off:off + o]))
+        off += o
+    return out
+
+
+def chain_ref(sizes, acts, skips, W, x, dy, rnd):
+    """x (N, in), dy (N, out) → y, dx, dW with `rnd` applied to the operands of every product (identity: the f32 chain)."""
+    layers = _split(sizes, W.astype(np.float64))
+    h = [x.astype(np.float64).T]
+    f = []
+    for (Wl, bl), a, s in zip(layers, acts, skips):
+        pre = rnd(Wl).astype(np.float64) @ rnd(h[-1]).astype(np.float64) + bl[:, None]
+        fl = _act(a, pre).astype(np.float32).astype(np.float64)      # activations are stored in f32
+        f.append(fl)
+        h.append((h[-1] + fl if s else fl).astype(np.float32).astype(np.float64))
+    G = dy.astype(np.float64).T
+    dW = []
+    for l in range(len(layers) - 1, -1, -1):
+        Wl, _ = layers[l]
+        d = (G * _act_grad_out(acts[l], f[l])).astype(np.float32).astype(np.float64)
+        gW = rnd(d).astype(np.float64) @ rnd(h[l]).astype(np.float64).T
+        dW = [gW.T.reshape(-1), d.sum(axis=1)] + dW
+        G = rnd(Wl.T).astype(np.float64) @ rnd(d).astype(np.float64) + (G if skips[l] else 0)
+    return h[-1].T, G.T, np.concatenate(dW)
+
+
+SPECS = {
+    "reconstructor": ((2, 200, 200, 200, 784), (L.CACT_RELU, L.CACT_RELU, L.CACT_RELU, L.CACT_SIGMOID), (0, 1, 1, 0)),
+    "feature_extractor": ((784, 200, 200, 200, 32), (L.CACT_RELU, L.CACT_RELU, L.CACT_RELU, L.CACT_RELU), (0, 1, 1, 0)),
+    "latent_out": ((16, 200, 1), (L.CACT_RELU, L.CACT_SOFTPLUS), (0, 0)),
+    "odd_tanh": ((7, 33, 50, 21), (L.CACT_TANH, L.CACT_TANH, L.CACT_IDENTITY), (0, 0, 0)),
+}
+
+
+@pytest.mark.parametrize("spec", sorted(SPECS))
+@pytest.mark.parametrize("N", [40, 1000])
+def test_bf16_chain_matches_the_rounded_operand_restatement(spec, N):
+    from tests.gpu_util import NativeChain
+    from latentdiffeq_amd import synthetic as S
+    sizes, acts, skips = SPECS[spec]
+    rng = np.random.default_rng(7)
+    W = S.mlp_weights(sizes, seed=11)
+    x = (rng.uniform(0, 1, (N, sizes[0])) if sizes[0] == 784 else 0.6 * rng.standard_normal((N, sizes[0]))).astype(np.float32)
+    dy = (rng.standard_normal((N, sizes[-1])) / N).astype(np.float32)
+    ch = NativeChain(sizes, acts, skips)
+    ch.set_weights(W)
+    y32 = ch.forward(x)
+    dx32, dW32 = ch.backward(x, y32, dy)
+    ch.set_dtype("bf16")
+    y = ch.forward(x)
+    dx, dW = ch.backward(x, y, dy)
+    ys, saved = ch.forward_save(x)
+    dxs, dWs = ch.backward_saved(x, ys, dy, saved)
+    assert np.array_equal(y, ys) and np.array_equal(dx, dxs) and np.array_equal(dW, dWs)      # training variant: same numbers
+    yr, dxr, dWr = chain_ref(sizes, acts, skips, W, x, dy, bf16r)
+    rel = lambda a, b: np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+    # most entries agree to 7 digits; a hidden value that sits on a bf16 rounding boundary rounds the other way when the f32
+    # accumulation order differs in its last bit, and moves what follows by one bf16 ulp of one term: ≤ 2e-3 of the scale over
+    # four layers of K = 200 … 784 (measured 9e-4 on the 784-200-200-200-32 chain at N = 1000, 1e-5 … 2e-4 elsewhere)
+    assert rel(y, yr) <= 2e-3, rel(y, yr)
+    assert np.median(np.abs(y - yr)) <= 2e-6 * max(np.abs(yr).max(), 1e-30)
+    assert rel(dx, dxr) <= 5e-3 and rel(dW, dWr) <= 5e-3, (rel(dx, dxr), rel(dW, dWr))
+    # bf16 is bf16: the mode moves the results by its rounding (2⁻⁹ per operand), no more — and it is not the f32 path
+    assert 1e-6 < rel(y, y32) <= 3e-2 and rel(dx, dx32) <= 0.25 and rel(dW, dW32) <= 0.25   # (relu kinks flip for a few units: gradients move more than values)
+    ch.set_dtype("f32")
+    assert np.array_equal(ch.forward(x), y32)                                                  # and back: nothing was re-uploaded
+
+
+def test_set_dtype_validates():
+    from tests.gpu_util import NativeChain
+    ch = NativeChain((4, 8, 2), (L.CACT_RELU, L.CACT_IDENTITY))
+    assert ch.lib.lde_chain_set_dtype(ch.h, 7) == -1 and ch.lib.lde_chain_set_dtype(None, 0) == -1

@@ -1330,6 +1330,7 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
 
 #include "lde_mlp4.h"
 #include "lde_mlpv.h"
+#include "lde_mlp64.h"
 
 // ================================================ host side =================================================
 struct MlpPlan {
@@ -1641,6 +1642,28 @@ static int launch_maybe_coop(bool coop, const void* fn, dim3 grid, dim3 block, s
   return LDE_OK;
 }
 
+// ---- one wave per trajectory, everything in registers (lde_mlp64.h): small networks on small states, per-trajectory control
+static bool mlp64_applicable(const MlpDims& dm, int B) {
+  const char* e = getenv("LDE_MLP64");   // read per call: the tests switch kernels inside one process
+  if (e && atoi(e) == 0) return false;
+  const char* m = getenv("LDE_MLP64_MAX_B");
+  const int maxb = m ? atoi(m) : 65536;   // measured (c3 shape): 0.28 + 3.9 ms vs 0.61 + 5.8 for the tile kernels at B = 4096, 0.77 + 10.4 vs 2.2 + 12.0 at 16384
+  return dm.nL == 3 && dm.sizes[1] <= 64 && dm.sizes[2] <= 64 && dm.Dp <= 4 && dm.P <= 1 && !dm.coupled && B <= maxb;
+}
+template <bool ADJ>
+static int launch_mlp64(const MlpDims& dm, const KOpts& o, const VArgs& a, hipStream_t stream, std::string& err) {
+  const bool rk4 = dm.solver == LDE_SOLVER_RK4, d2 = dm.Dp <= 2;
+  if (rk4 && d2) hipLaunchKernelGGL((k_mlp64<LDE_SOLVER_RK4, 2, ADJ>), dim3(o.B), dim3(64), 0, stream, dm, o, a);
+  else if (rk4) hipLaunchKernelGGL((k_mlp64<LDE_SOLVER_RK4, 4, ADJ>), dim3(o.B), dim3(64), 0, stream, dm, o, a);
+  else if (d2) hipLaunchKernelGGL((k_mlp64<LDE_SOLVER_TSIT5, 2, ADJ>), dim3(o.B), dim3(64), 0, stream, dm, o, a);
+  else hipLaunchKernelGGL((k_mlp64<LDE_SOLVER_TSIT5, 4, ADJ>), dim3(o.B), dim3(64), 0, stream, dm, o, a);
+  if (hipGetLastError() != hipSuccess) {
+    err = "k_mlp64 launch failed";
+    return LDE_ERR_HIP;
+  }
+  return LDE_OK;
+}
+
 // ---- the one-trajectory-per-workgroup kernels (lde_mlpv.h): applicability, LDS budget, launch -------------------------------------
 static size_t vec_lds_fixed(const MlpDims& dm, const VecDims& vd, int T, bool adj) {
   const int nsp = adj ? vd.nsp_b : vd.nsp_f;
@@ -1705,6 +1728,12 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
                 const KOpts& o, float* z_out, int32_t* retcode, int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret,
                 hipStream_t stream, std::string& err) {
   const MlpDims& dm = p->dm;
+  if (mlp64_applicable(dm, o.B)) {   // small network, small state: one wave per trajectory, registers only (lde_mlp64.h)
+    VArgs va{};
+    va.z0 = z0; va.theta = theta; va.ts = ts_dev; va.Wflat = W_dev; va.z_out = z_out; va.retcode = retcode;
+    va.st_nfe = nfe; va.st_nacc = nacc; va.st_nrej = nrej; va.st_ret = ret;
+    return launch_mlp64<false>(dm, o, va, stream, err);
+  }
   {   // small batches: one trajectory per workgroup, lanes = hidden units (lde_mlpv.h)
     size_t ldsv = 0;
     const bool ca = dm.coupled && o.adaptive && o.B > 1;
@@ -1881,7 +1910,23 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
 #endif
   int ntile_dw = nwg;
   bool vec_done = false;
-  {   // small batches: one trajectory per workgroup, lanes = hidden units (lde_mlpv.h)
+  if (mlp64_applicable(dm, o.B)) {   // one wave per trajectory, registers only (lde_mlp64.h)
+    if (hipMemsetAsync(p->fb_dev, 0, 2 * sizeof(int32_t), stream) != hipSuccess ||
+        hipMemsetAsync(p->nslots, 0, (size_t)2 * (nwg + 1) * sizeof(int32_t), stream) != hipSuccess ||
+        hipMemsetAsync(p->wts, 0, (size_t)nwg * p->adj_cap * NB * sizeof(float), stream) != hipSuccess) {
+      err = "hipMemsetAsync(staging weights) failed";
+      return LDE_ERR_HIP;
+    }
+    VArgs va{};
+    va.theta = theta; va.ts = ts_dev; va.Wflat = W_dev; va.z_out = const_cast<float*>(z_out); va.dz_out = dz_out;
+    va.dz0 = dz0; va.dtheta = dtheta; va.stage = p->stage; va.wts = p->wts; va.nslots = p->nslots; va.cap = p->adj_cap; va.ovf = p->fb_dev + 1;
+    va.st_nfe = nfe; va.st_nacc = nacc; va.st_nrej = nrej; va.st_ret = ret;
+    const int rc6 = launch_mlp64<true>(dm, o, va, stream, err);
+    if (rc6) return rc6;
+    vec_done = true;
+    a.fallback = 1;
+  }
+  if (!vec_done) {   // small batches: one trajectory per workgroup, lanes = hidden units (lde_mlpv.h)
     size_t ldsv = 0;
     const bool ca = dm.coupled && o.adaptive && o.B > 1;
     if (vec_applicable(p, o.B, o.T, true, ca, &ldsv, err)) {

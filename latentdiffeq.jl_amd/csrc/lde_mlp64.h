@@ -1,0 +1,495 @@
+// lde_mlp64.h — small networks on small states, per-trajectory control: ONE WAVE per trajectory, everything in registers
+// (included by lde_mlp.hip after lde_mlpv.h).
+//
+// BASELINE.json configs[2] — GOKU pendulum + a 2-64-64-2 MLP, Tsit5, B = 1024 with adjoint — is 1024 independent adaptive
+// solves of a 2-dimensional state through a network of 4.4 k weights. In k_mlpv (one trajectory per workgroup, activations and
+// state in LDS) every product is a chain of ≈ 100-cycle LDS round trips: ≈ 1 300 cycles per layer for 64×64 work, 5.8 µs per
+// evaluation of the adjoint. Here nothing leaves the register file:
+//   * lane j owns hidden unit j of both hidden layers (widths ≤ 64); its rows of W₁, W₂, its COLUMNS of W₂, W₃ and its biases
+//     are loaded once into VGPRs (≈ 140 of them);
+//   * a 64×64 product is 64 × (v_readlane_b32 → SGPR, v_fmac with that SGPR): the activation of unit k reaches every lane through
+//     the scalar register file, no LDS, no wait — and Wᵀδ is the same loop over the lane's column;
+//   * the D' ≤ 4 outputs are wave sums (four DPP row shifts + four readlanes each);
+//   * the state [z; λ; g], the seven slopes and the whole step control are wave-uniform values that every lane carries
+//     redundantly (a SIMT machine does that for free), so an evaluation is ≈ 350 instructions with no memory access besides the
+//     staging stores of the weight gradient's (a_l, δ_l) panels, which nobody waits for.
+// Same algorithm and control arithmetic as k_mlp_adjoint / k_mlpv (HNW initial step, PI controller carried across the save
+// times, k₁ re-evaluated every attempt, quadrature weights written at accept time, k_mlp_dw forms dW): agreement to solver
+// tolerance. Limits: exactly three Dense layers D' → H₁ → H₂ → D' with H ≤ 64 and D' ∈ {2, 4}-padded, P ≤ 1, per-trajectory
+// control (coupled control needs the grid-wide sum: k_mlpv). Anything else runs k_mlpv / the tile kernels.
+
+template <int CTRL>
+__device__ __forceinline__ float dpp_add(float v) {   // v + (v of the lane CTRL points at, 0 outside the row)
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// Σ over the 64 lanes, returned wave-uniform (inclusive prefix within each row of 16, then the four row totals)
+__device__ __forceinline__ float wave_sum64(float v) {
+  v = dpp_add<0x111>(v);   // row_shr:1
+  v = dpp_add<0x112>(v);   // row_shr:2
+  v = dpp_add<0x114>(v);   // row_shr:4
+  v = dpp_add<0x118>(v);   // row_shr:8
+  const int iv = __builtin_bit_cast(int, v);
+  const float r0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 15)), r1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 31));
+  const float r2 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 47)), r3 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(iv, 63));
+  return (r0 + r1) + (r2 + r3);
+}
+__device__ __forceinline__ float lane_bcast(float v, int k) {   // k compile-time after unrolling
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), k));
+}
+
+template <int DP>
+struct Net64 {
+  float w1[DP], b1;        // row j of W₁ [H₁×D'], bias
+  float w2r[64], b2;       // row j of W₂ [H₂×H₁]
+  float w2c[64];           // column j of W₂: W₂[i][j], i < H₂
+  float w3c[DP];           // column j of W₃ [D'×H₂]: W₃[d][j]
+  float b3[DP];            // uniform
+  float ngl, gl2;          // pendulum: −G/L, G/L²
+  int act, has_pend;
+  float h1, h2;            // post-activation hidden units of the last evaluation (lane j)
+};
+
+// f(z) (+ pendulum); leaves h1, h2 in the net
+template <int DP>
+__device__ __forceinline__ void net64_rhs(Net64<DP>& n, const float (&z)[DP], float (&f)[DP]) {
+  float a1 = n.b1;
+#pragma unroll
+  for (int k = 0; k < DP; k++) a1 += n.w1[k] * z[k];
+  n.h1 = act_fn(n.act, a1);
+  float a2 = n.b2;
+#pragma unroll
+  for (int k = 0; k < 64; k++) a2 += n.w2r[k] * lane_bcast(n.h1, k);
+  n.h2 = act_fn(n.act, a2);
+#pragma unroll
+  for (int d = 0; d < DP; d++) f[d] = n.b3[d] + wave_sum64(n.w3c[d] * n.h2);
+  if (n.has_pend) {
+    f[0] += z[1];
+    f[1] += n.ngl * fast_sin(z[0]);
+  }
+}
+
+// after net64_rhs on the same z: vz = (∂f/∂z)ᵀλ, vth = (∂f/∂L)ᵀλ; d1, d2 = the hidden layers' δ (lane j)
+template <int DP>
+__device__ __forceinline__ void net64_vjp(const Net64<DP>& n, const float (&z)[DP], const float (&lam)[DP], float (&vz)[DP], float& vth,
+                                          float& d1, float& d2) {
+  float s2 = 0.f;
+#pragma unroll
+  for (int d = 0; d < DP; d++) s2 += n.w3c[d] * lam[d];
+  d2 = s2 * act_grad(n.act, n.h2);
+  float s1 = 0.f;
+#pragma unroll
+  for (int i = 0; i < 64; i++) s1 += n.w2c[i] * lane_bcast(d2, i);
+  d1 = s1 * act_grad(n.act, n.h1);
+#pragma unroll
+  for (int k = 0; k < DP; k++) vz[k] = wave_sum64(n.w1[k] * d1);
+  vth = 0.f;
+  if (n.has_pend) {
+    float sn, cs;
+    fast_sincos(z[0], sn, cs);
+    vz[0] += n.ngl * cs * lam[1];
+    vz[1] += lam[0];
+    vth = n.gl2 * sn * lam[1];
+  }
+}
+
+template <int SOLVER, int DP, bool ADJ>
+__global__ void __launch_bounds__(64) k_mlp64(MlpDims dm, KOpts o, VArgs a) {
+  const int T = o.T, B = o.B, D = dm.D, Dp = dm.Dp, NP = dm.P, lane = threadIdx.x, b = blockIdx.x;
+  constexpr int NS = ADJ ? 2 * DP + 1 : DP;      // [z | λ | g] (g stays 0 without a parameter)
+  const int H1 = dm.sizes[1], H2 = dm.sizes[2];
+  Net64<DP> n;
+  {   // weights into registers (flat destructure order: vec(W) column-major [out×in], then b)
+    const float* W = a.Wflat;
+    const float *W1 = W + dm.w_off[0], *W2 = W + dm.w_off[1], *W3 = W + dm.w_off[2];
+#pragma unroll
+    for (int k = 0; k < DP; k++) n.w1[k] = (lane < H1 && k < Dp) ? W1[lane + H1 * k] : 0.f;
+    n.b1 = lane < H1 ? W[dm.b_off[0] + lane] : 0.f;
+#pragma unroll
+    for (int k = 0; k < 64; k++) n.w2r[k] = (lane < H2 && k < H1) ? W2[lane + H2 * k] : 0.f;
+    n.b2 = lane < H2 ? W[dm.b_off[1] + lane] : 0.f;
+#pragma unroll
+    for (int i = 0; i < 64; i++) n.w2c[i] = (ADJ && lane < H1 && i < H2) ? W2[i + H2 * lane] : 0.f;
+#pragma unroll
+    for (int d = 0; d < DP; d++) {
+      n.w3c[d] = (lane < H2 && d < Dp) ? W3[d + Dp * lane] : 0.f;
+      n.b3[d] = d < Dp ? W[dm.b_off[2] + d] : 0.f;
+    }
+    float L = 1.f;
+    if (dm.has_pend) L = a.theta[(size_t)b * NP];
+    n.ngl = -10.0f / L;
+    n.gl2 = 10.0f / (L * L);
+    n.act = dm.act;
+    n.has_pend = dm.has_pend;
+    n.h1 = n.h2 = 0.f;
+  }
+  const double* ts = a.ts;
+  const double t0 = ts[0], tend = ts[T - 1], dtmax = fabs(tend - t0);
+  constexpr int NST = SOLVER == LDE_SOLVER_TSIT5 ? 6 : 4;
+  const int tile = b >> 4, ncol = b & 15;
+  float* const my_stage = ADJ ? a.stage + (size_t)tile * a.cap * dm.blk_floats : nullptr;
+  float* const my_wts = ADJ ? a.wts + (size_t)tile * a.cap * NB : nullptr;
+  int slot_base = 0;
+  bool overflow = false;
+  const int blk_floats = dm.blk_floats;
+  const int in32_0 = pad32(Dp), h1_32 = pad32(H1), h2_32 = pad32(H2);
+  const int boff0 = dm.blk_off[0], boff1 = dm.blk_off[1], boff2 = dm.blk_off[2];
+
+  // state: y = [z (DP) | λ (DP) | g]
+  float y[NS], yn[NS], tmp[NS], k[7][NS], scr[NS];
+#pragma unroll
+  for (int i = 0; i < NS; i++) {
+    y[i] = yn[i] = tmp[i] = scr[i] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 7; s++) k[s][i] = 0.f;
+  }
+  bool bad = false;
+  if (!ADJ) {
+#pragma unroll
+    for (int r = 0; r < DP; r++) y[r] = r < D ? a.z0[(size_t)b * D + r] : 0.f;
+  } else {
+#pragma unroll
+    for (int r = 0; r < DP; r++)
+      if (r < Dp) {
+        const size_t srcg = (size_t)Dp * ((size_t)b + (size_t)B * (T - 1)) + r;
+        y[r] = a.z_out[srcg];
+        y[DP + r] = a.dz_out[srcg];
+        bad = bad || !isfinite(y[r]);
+      }
+  }
+  double t = ADJ ? tend : t0, dt = 0.0, tnew = 0.0;
+  float h = 0.f, qold = 1e-4f, wq = 0.f, d1n = 0.f;
+  int status = bad ? 1 + LDE_RET_NONFINITE : (T > 1 ? 0 : 1), j = ADJ ? T - 2 : 1, last = 0, hit = 0, nfe = 0, nacc = 0, nrej = 0;
+  long long iters = 0;
+  if (ADJ && status > 1) {
+#pragma unroll
+    for (int i = 0; i < NS; i++) y[i] = 0.f;
+  }
+  if (!ADJ && lane < Dp) a.z_out[(size_t)b * Dp + lane] = lane < D ? a.z0[(size_t)b * D + lane] : 0.f;   // save time 0 = ẑ₀ itself
+
+  enum { PH_K0 = 0, PH_INIT1 = 1, PH_STAGE = 2 };
+  constexpr int LAST_STAGE = SOLVER == LDE_SOLVER_TSIT5 ? 6 : (ADJ ? 3 : 4);
+  const float dirn = ADJ ? -1.f : 1.f;
+  const float nnorm = (float)(ADJ ? 2 * Dp + NP : Dp);
+  auto counted = [&](int i) -> bool {   // does state entry i count in the norms?
+    if (!ADJ) return i < Dp;
+    return (i < DP && i < Dp) || (i >= DP && i < 2 * DP && i - DP < Dp) || (i == 2 * DP && NP > 0);
+  };
+
+  auto begin_step = [&]() -> bool {
+    if (status == 0 && iters++ >= o.maxiters) status = 1 + LDE_RET_MAXITERS;
+    if (status == 0) {
+      if (!ADJ) {
+        double d = dt;
+        last = 0;
+        if (t + d >= tend - 1e-12 * fabs(tend)) { d = tend - t; last = 1; }
+        tnew = last ? tend : t + d;
+        h = (float)d;
+        wq = (float)d;
+        dt = d;
+      } else {
+        const double dist = t - ts[j];
+        double hmag = dt;
+        hit = 0;
+        if (hmag >= dist * (1.0 - 1e-12)) { hmag = dist; hit = 1; }
+        tnew = hmag;
+        h = -(float)hmag;
+        wq = (float)hmag;
+      }
+    } else {
+      h = 0.f;
+      wq = 0.f;
+      hit = 0;
+    }
+    return status == 0;
+  };
+
+  // one evaluation of the (augmented) right-hand side at `src`, staged into slot `blk` when given
+  auto eval = [&](const float (&src)[NS], float (&dst)[NS], float* blk) {
+    float z[DP], f[DP];
+#pragma unroll
+    for (int r = 0; r < DP; r++) z[r] = src[r];
+    net64_rhs<DP>(n, z, f);
+#pragma unroll
+    for (int r = 0; r < DP; r++) dst[r] = f[r];
+    if (ADJ) {
+      float lam[DP], vz[DP], vth, d1, d2;
+#pragma unroll
+      for (int r = 0; r < DP; r++) lam[r] = src[DP + r];
+      net64_vjp<DP>(n, z, lam, vz, vth, d1, d2);
+#pragma unroll
+      for (int r = 0; r < DP; r++) dst[DP + r] = -vz[r];
+      dst[2 * DP] = -vth;
+      if (blk) {   // (a_l, δ_l) of the three layers, column ncol of the tile's slot; rows beyond the layer are zeros
+        float zl = 0.f, ll = 0.f;
+#pragma unroll
+        for (int r = 0; r < DP; r++) {
+          zl = lane == r ? z[r] : zl;
+          ll = lane == r ? lam[r] : ll;
+        }
+        if (lane < in32_0) blk[boff0 + ncol * in32_0 + lane] = lane < Dp ? zl : 0.f;                    // a₀ = z
+        if (lane < h1_32) blk[boff0 + NB * in32_0 + ncol * h1_32 + lane] = lane < H1 ? d1 : 0.f;        // δ₁
+        if (lane < h1_32) blk[boff1 + ncol * h1_32 + lane] = lane < H1 ? n.h1 : 0.f;                    // a₁ = h₁
+        if (lane < h2_32) blk[boff1 + NB * h1_32 + ncol * h2_32 + lane] = lane < H2 ? d2 : 0.f;         // δ₂
+        if (lane < h2_32) blk[boff2 + ncol * h2_32 + lane] = lane < H2 ? n.h2 : 0.f;                    // a₂ = h₂
+        if (lane < in32_0) blk[boff2 + NB * h2_32 + ncol * in32_0 + lane] = lane < Dp ? ll : 0.f;       // δ₃ = λ
+      }
+    }
+  };
+
+  const bool auto_dt = o.adaptive && !(o.dt_fixed > 0);
+  int phase = (ADJ && !auto_dt) ? PH_STAGE : PH_K0, s = 0;
+  bool running = T > 1 && status == 0;
+  if (ADJ && running && !auto_dt) {
+    dt = o.adaptive ? fmin(o.dt_fixed, dtmax) : o.dt_fixed;
+    running = begin_step();
+  }
+  while (running) {
+    float src[NS];
+    bool any_w = false;
+#pragma unroll
+    for (int i = 0; i < NS; i++) src[i] = phase == PH_INIT1 ? tmp[i] : y[i];
+    if (phase == PH_STAGE) {
+      if (SOLVER == LDE_SOLVER_TSIT5) {
+        if (s > 0) {
+#define M64STAGE(S_)                                                                  \
+  case S_:                                                                            \
+    _Pragma("unroll") for (int i = 0; i < NS; i++) {                                  \
+      float accv = ts5::A[S_][0] * k[0][i];                                           \
+      _Pragma("unroll") for (int jj = 1; jj < S_; jj++) accv += ts5::A[S_][jj] * k[jj][i]; \
+      src[i] = y[i] + h * accv;                                                       \
+    }                                                                                 \
+    break;
+          switch (s) {
+            M64STAGE(1) M64STAGE(2) M64STAGE(3) M64STAGE(4) M64STAGE(5) M64STAGE(6)
+            default: break;
+          }
+#undef M64STAGE
+          if (s == 6) {
+#pragma unroll
+            for (int i = 0; i < NS; i++) yn[i] = src[i];
+          }
+        }
+        any_w = ADJ && s < 6;
+      } else if (ADJ || s < 4) {
+        if (s > 0) {
+          const float cs = (s == 3 ? 1.0f : 0.5f) * h;
+#pragma unroll
+          for (int i = 0; i < NS; i++) src[i] = y[i] + cs * (s == 1 ? k[0][i] : (s == 2 ? k[1][i] : k[2][i]));
+        }
+        any_w = ADJ;
+      } else {
+        const float h6 = h * (1.0f / 6.0f);
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+          yn[i] = y[i] + h6 * (k[0][i] + 2.0f * (k[1][i] + k[2][i]) + k[3][i]);
+          src[i] = yn[i];
+        }
+      }
+      if (ADJ && s == 0 && slot_base + NST > a.cap) overflow = true;
+    }
+    float dst[NS];
+#pragma unroll
+    for (int i = 0; i < NS; i++) dst[i] = 0.f;
+    eval(src, dst, (any_w && !overflow) ? my_stage + (size_t)(slot_base + s) * blk_floats : nullptr);
+    {   // store the slope where the phase wants it (static register indices)
+      const int ks = phase == PH_K0 ? 0 : (phase == PH_INIT1 ? 1 : s);
+#pragma unroll
+      for (int q = 0; q < 7; q++)
+        if (q == ks) {
+#pragma unroll
+          for (int i = 0; i < NS; i++) k[q][i] = dst[i];
+        }
+    }
+    if (status == 0) nfe++;
+
+    if (phase == PH_K0 && !(ADJ || auto_dt)) {
+      dt = o.adaptive ? fmin(o.dt_fixed, dtmax) : o.dt_fixed;
+      phase = PH_STAGE;
+      s = 1;
+      running = begin_step();
+    } else if (phase == PH_K0) {
+      float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NS; i++) {
+        const float sk = fast_rcp(o.abstol + fabsf(y[i]) * o.reltol);
+        scr[i] = sk;
+        const float a0 = y[i] * sk, a1 = k[0][i] * sk;
+        if (counted(i)) { v0 += a0 * a0; v1 += a1 * a1; }
+      }
+      const float d0 = sqrtf(v0 / nnorm);
+      d1n = sqrtf(v1 / nnorm);
+      double dt0 = (d0 < 1e-5f || d1n < 1e-5f) ? 1e-6 : 0.01 * (double)(d0 * fast_rcp(d1n));
+      if (dt0 > dtmax) dt0 = dtmax;
+      dt = dt0;
+      h = status == 0 ? dirn * (float)dt0 : 0.f;
+#pragma unroll
+      for (int i = 0; i < NS; i++) tmp[i] = y[i] + h * k[0][i];
+      phase = PH_INIT1;
+    } else if (phase == PH_INIT1) {
+      float w0 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NS; i++) {
+        const float dd = (k[1][i] - k[0][i]) * scr[i];
+        if (counted(i)) w0 += dd * dd;
+      }
+      const double dt0 = dt;
+      const float d2 = sqrtf(w0 / nnorm) * fast_rcp((float)dt0);
+      const float dm_ = fmaxf(d1n, d2);
+      const double dt1 = (dm_ <= 1e-15f) ? fmax(1e-6, dt0 * 1e-3) : (double)(0.39810717055349726f * fast_pow(dm_, -0.2f));
+      const double dn = fmin(100.0 * dt0, dt1);
+      dt = dn > dtmax ? dtmax : dn;
+      phase = PH_STAGE;
+      s = ADJ ? 0 : 1;
+      running = begin_step();
+    } else if (s < LAST_STAGE) {
+      s++;
+    } else {
+      if (ADJ && SOLVER == LDE_SOLVER_RK4) {
+        const float h6 = h * (1.0f / 6.0f);
+#pragma unroll
+        for (int i = 0; i < NS; i++) yn[i] = y[i] + h6 * (k[0][i] + 2.0f * (k[1][i] + k[2][i]) + k[3][i]);
+      }
+      float s2 = 0.f;
+      bool fin = true;
+#pragma unroll
+      for (int i = 0; i < NS; i++) {
+        fin = fin && isfinite(yn[i]);
+        if (o.adaptive && counted(i)) {
+          float er = ts5::BT[0] * k[0][i];
+#pragma unroll
+          for (int jj = 1; jj < 7; jj++) er += ts5::BT[jj] * k[jj][i];
+          er *= h;
+          const float sk = o.abstol + fmaxf(fabsf(y[i]), fabsf(yn[i])) * o.reltol;
+          const float r = er * fast_rcp(sk);
+          s2 += r * r;
+        }
+      }
+      if (!fin) s2 = __int_as_float(0x7fc00000);
+      bool accepted = false;
+      if (status == 0) {
+        const float EEst = o.adaptive ? sqrtf(s2 / nnorm) : (s2 == s2 ? 0.f : s2);
+        const double hmag = ADJ ? tnew : dt;
+        if (!(EEst == EEst)) {
+          if (o.adaptive && hmag > o.dtmin) { nrej++; dt = hmag * (double)o.qmin; }
+          else status = 1 + LDE_RET_NONFINITE;
+        } else if (o.adaptive) {
+          float q11;
+          const float q = pi_q(EEst, qold, o, q11);
+          if (EEst > 1.0f) {
+            nrej++;
+            const double nd = hmag * (double)fast_rcp(fminf(o.q_hi, q11 * o.inv_gamma));
+            dt = nd;
+            if (nd < o.dtmin) status = 1 + LDE_RET_DTMIN;
+          } else {
+            qold = fmaxf(EEst, 1e-4f);
+            double dtp = hmag * (double)fast_rcp(q);
+            if (dtp > dtmax) dtp = dtmax;
+            dt = dtp;
+            accepted = true;
+          }
+        } else {
+          dt = o.dt_fixed;
+          accepted = true;
+        }
+        if (accepted) nacc++;
+      }
+      if (!ADJ) {
+        while (accepted && j < T && ts[j] <= tnew) {   // dense output at every save time inside the accepted step
+          const double tj = ts[j];
+          const float th = (tj >= tnew || (j == T - 1 && last)) ? 2.0f : (float)(tj - t) * fast_rcp(wq);
+          float outv = 0.f;
+#pragma unroll
+          for (int r = 0; r < DP; r++) {
+            float ov;
+            if (th > 1.5f) ov = yn[r];
+            else if (SOLVER == LDE_SOLVER_TSIT5) {
+              float bw[7];
+              tsit5_interp_weights(th, bw);
+              float acc = bw[0] * k[0][r];
+#pragma unroll
+              for (int q = 1; q < 7; q++) acc += bw[q] * k[q][r];
+              ov = y[r] + wq * acc;
+            } else {
+              const float om = 1.0f - th;
+              const float h00 = (1.0f + 2.0f * th) * om * om, h10 = th * om * om;
+              const float h01 = th * th * (3.0f - 2.0f * th), h11 = th * th * (th - 1.0f);
+              ov = h00 * y[r] + (h10 * wq) * k[0][r] + h01 * yn[r] + (h11 * wq) * k[4][r];
+            }
+            outv = lane == r ? ov : outv;
+          }
+          if (lane < Dp) a.z_out[(size_t)Dp * ((size_t)b + (size_t)B * j) + lane] = outv;
+          j++;
+        }
+        if (accepted) {
+#pragma unroll
+          for (int i = 0; i < NS; i++) {
+            y[i] = yn[i];
+            k[0][i] = k[LAST_STAGE][i];
+          }
+          t = tnew;
+          if (last) status = 1;
+        }
+        s = 1;
+        running = begin_step();
+      } else {
+        if (accepted && !overflow) {
+          if (lane < NST) {
+            float bs;
+            if (SOLVER == LDE_SOLVER_TSIT5) bs = ts5::A[6][lane];
+            else bs = (lane == 0 || lane == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
+            my_wts[(size_t)(slot_base + lane) * NB + ncol] = wq * bs;
+          }
+          slot_base += NST;
+        }
+        if (accepted) {
+#pragma unroll
+          for (int i = 0; i < NS; i++) y[i] = yn[i];
+          if (hit) {
+#pragma unroll
+            for (int r = 0; r < DP; r++)
+              if (r < Dp) {
+                const size_t srcg = (size_t)Dp * ((size_t)b + (size_t)B * j) + r;
+                y[DP + r] += a.dz_out[srcg];
+                if (o.checkpoint) y[r] = a.z_out[srcg];
+              }
+            t = ts[j];
+            j--;
+            if (j < 0) status = 1;
+          } else
+            t -= tnew;
+        }
+        s = 0;
+        running = begin_step();
+      }
+    }
+  }
+
+  const int st = status;
+  if (!ADJ) {
+    if (st > 1) {
+      const float qn = __int_as_float(0x7fc00000);
+      for (int e = lane; e < Dp * T; e += 64) a.z_out[(size_t)Dp * ((size_t)b + (size_t)B * (e / Dp)) + (e % Dp)] = qn;
+    }
+    if (lane == 0) {
+      const int ret = st > 1 ? st - 1 : 0;
+      if (a.retcode) a.retcode[b] = ret;
+      a.st_ret[b] = ret;
+    }
+  } else {
+    float g0 = 0.f;
+#pragma unroll
+    for (int r = 0; r < DP; r++) g0 = lane == r ? y[DP + r] : g0;
+    if (lane < D) a.dz0[(size_t)b * D + lane] = st > 1 ? 0.f : g0;
+    if (lane == 0 && NP > 0) a.dtheta[(size_t)b * NP] = st > 1 ? 0.f : y[2 * DP];
+    if (lane == 0) {
+      a.st_ret[b] = st > 1 ? st - 1 : 0;
+      atomicMax(&a.nslots[tile], slot_base);
+      if (overflow) __hip_atomic_store(a.ovf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  if (lane == 0) {
+    a.st_nfe[b] = nfe;
+    a.st_nacc[b] = nacc;
+    a.st_nrej[b] = nrej;
+  }
+}

@@ -113,7 +113,8 @@ def test_bf16_chain_matches_the_rounded_operand_restatement(spec, N):
     assert np.median(np.abs(y - yr)) <= 2e-6 * max(np.abs(yr).max(), 1e-30)
     assert rel(dx, dxr) <= 5e-3 and rel(dW, dWr) <= 5e-3, (rel(dx, dxr), rel(dW, dWr))
     # bf16 is bf16: the mode moves the results by its rounding (2⁻⁹ per operand), no more — and it is not the f32 path
-    assert 1e-6 < rel(y, y32) <= 3e-2 and rel(dx, dx32) <= 0.25 and rel(dW, dW32) <= 0.25   # (relu kinks flip for a few units: gradients move more than values)
+    l2 = lambda a, b: np.linalg.norm((a - b).astype(np.float64)) / max(np.linalg.norm(b.astype(np.float64)), 1e-30)
+    assert 1e-6 < rel(y, y32) <= 3e-2 and l2(dx, dx32) <= 0.3 and l2(dW, dW32) <= 0.3   # (sanity only: relu kinks flip for a few units, gradients move more than values; the parity is the restatement above)
     ch.set_dtype("f32")
     assert np.array_equal(ch.forward(x), y32)                                                  # and back: nothing was re-uploaded
 

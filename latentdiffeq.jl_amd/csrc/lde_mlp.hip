@@ -1411,6 +1411,10 @@ int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err) 
     if (p->vec_ok) {
       int nt = 64;
       while (nt < maxw) nt *= 2;
+      if (const char* e = getenv("LDE_MLPV_NT")) {   // diagnostic: more lanes than units = the contractions split over lane groups
+        const int v = atoi(e);
+        if ((v == 64 || v == 128 || v == 256) && v >= nt) nt = v;
+      }
       vd.NT = nt;
       auto geom = [&](int rows, int K, int* rp, int* lg, int* k4, int* S) {
         int r = 4, g = 2;
@@ -1669,7 +1673,7 @@ static size_t vec_lds_fixed(const MlpDims& dm, const VecDims& vd, int T, bool ad
   const int nsp = adj ? vd.nsp_b : vd.nsp_f;
   size_t b = (sizeof(VCtl) + 15) & ~size_t(15);
   b += ((size_t)T * 8 + 15) & ~size_t(15);
-  b += (size_t)(11 * nsp + vd.htotal + 2 * vd.maxw4 + vd.NT + ((dm.nbias + 3) & ~3) + 2 * MAXL * (sizeof(VLayer) / 4)) * sizeof(float);
+  b += (size_t)(11 * nsp + vd.htotal + MAXL * vd.maxw4 + vd.NT + ((dm.nbias + 3) & ~3) + 2 * MAXL * (sizeof(VLayer) / 4)) * sizeof(float);
   return (b + 15) & ~size_t(15);
 }
 // Which batches run there: see the measurement below. LDE_MLPV=0 switches the kernels off, LDE_MLPV_MAX_B moves the limit.

@@ -226,21 +226,32 @@ __device__ __forceinline__ void vec_eval_bwd(const VPanels& P, const VCtl* c, co
   for (int l = nL - 1; l >= 0; l--) {
     const VLayer q = vlayer_load(P.tb + l);      // rows = in, K = out
     const float* al = q.aofs < 0 ? src : P.hid + q.aofs;
-    if (blk) {
-      float* ga = blk + q.blk_off + n * q.in32;
-      float* gd = blk + q.blk_off + NB * q.in32 + n * q.out32;
-      for (int r = tid; r < q.in32; r += NT) ga[r] = r < q.rows ? al[r] : 0.f;
-      for (int r = tid; r < q.out32; r += NT) gd[r] = r < q.K ? dl[r] : 0.f;
-    }
+    PROF_T(b0);
     const float acc = vec_layer<NT>(P.lbase, P.gw, q, dl, P.red);
+    PROF_T(b1);
+    PROF_ADD(13 + l, b0, b1);
     if (l > 0) {
-      float* dn = P.del + ((nL - 1 - l) & 1) * P.maxw4;
+      float* dn = P.del + (l - 1) * P.maxw4;     // δ_{l−1}: every layer keeps its own buffer (they are staged together below)
       if (tid < q.rows) dn[tid] = acc * act_grad(P.act, al[tid]);
       __syncthreads();
       dl = dn;
     } else {
       if (tid < q.rows) dst[DpA + tid] = -acc;
       __syncthreads();
+    }
+  }
+  // The (a_l, δ_l) panels go to HBM in ONE pass after the last product: on gfx9 stores and loads share the in-order vmcnt
+  // counter, so a weight load issued behind a layer's staging stores waited for their write acknowledgements (measured:
+  // ≈ 7 000 of an evaluation's 22 000 cycles on c2 / c4) — now only the next evaluation's first load does.
+  if (blk) {
+    for (int l = nL - 1; l >= 0; l--) {
+      const VLayer q = vlayer_load(P.tb + l);
+      const float* al = q.aofs < 0 ? src : P.hid + q.aofs;
+      const float* dv = l == nL - 1 ? src + DpA : P.del + l * P.maxw4;
+      float* ga = blk + q.blk_off + n * q.in32;
+      float* gd = blk + q.blk_off + NB * q.in32 + n * q.out32;
+      for (int r = tid; r < q.in32; r += NT) ga[r] = r < q.rows ? al[r] : 0.f;
+      for (int r = tid; r < q.out32; r += NT) gd[r] = r < q.K ? dv[r] : 0.f;
     }
   }
   if (P.has_pend) {
@@ -285,6 +296,7 @@ __device__ __forceinline__ void vec_grid_sum(const GridSync& gs, unsigned& gen, 
     return;
   }
   gen++;
+  PROF_T(gs0);
   float* slots = gs.slots + (size_t)(gen & 1) * gs.nwg * 4;
   if (tid == 0) {
     float* mine = slots + (size_t)blockIdx.x * 4;
@@ -322,6 +334,9 @@ __device__ __forceinline__ void vec_grid_sum(const GridSync& gs, unsigned& gen, 
     v[i] = aborted ? __int_as_float(0x7fc00000) : t;   // a timed-out barrier poisons the sums: the solve ends with retcode != 0
   }
   __syncthreads();
+  PROF_T(gs1);
+  PROF_ADD(12, gs0, gs1);
+  PROF_ADD(21, gs1 - 1, gs1);
 }
 
 template <int SOLVER, int NT, bool ADJ>
@@ -343,7 +358,7 @@ __global__ void __launch_bounds__(NT) k_mlpv(MlpDims dm, VecDims vd, KOpts o, VA
   P.kbase = p; p += 7 * P.nsp;
   P.scr = p; p += P.nsp;
   P.hid = p; p += vd.htotal;
-  P.del = p; p += 2 * vd.maxw4;
+  P.del = p; p += MAXL * vd.maxw4;       // δ of every hidden layer (staged together after the last product)
   P.red = p; p += NT;                  // split-K partial sums (S·rp ≤ NT) / the grid sum's per-wave partials
   P.biasc = p; p += (dm.nbias + 3) & ~3;
   VLayer* tf = reinterpret_cast<VLayer*>(p); p += MAXL * (sizeof(VLayer) / 4);

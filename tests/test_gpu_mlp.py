@@ -524,3 +524,49 @@ def test_one_mlp_handle_changing_shapes(o32, layers, batching, solver):
         r0, _, rW, _ = o32.adjoint(od, z, None, ts, dz, W=W)
         e0, eW = np.abs(g0 - r0).max() / np.abs(r0).max(), np.abs(gW - rW).max() / np.abs(rW).max()
         assert e0 <= 2e-3 and eW <= 2e-3, (T, B, e0, eW)
+
+
+@pytest.mark.parametrize("case", ["c2_rk4_coupled", "c3_per_traj", "c4_coupled", "tanh_per_traj_4d", "rk4_per_traj_small", "deep_4_layers"])
+def test_kernel_families_agree(case, monkeypatch, o64):
+    """Three kernel families serve the MLP right-hand sides: 16-column MFMA tiles (large batches; LDE_MLPV=0 LDE_MLP64=0 forces
+    them), one trajectory per workgroup with lanes = hidden units (k_mlpv), and one wave per trajectory with everything in
+    registers (k_mlp64: three layers ≤ 64 wide, D' ≤ 4, per-trajectory control). Same algorithm, same control arithmetic: they
+    agree like two correct f32 solves — round-off for fixed steps and smooth networks at tight tolerance, the solver's own error
+    where a relu network meets the adaptive controller — and every family is no farther from the float64 adjoint than that."""
+    cfg = {
+        "c2_rk4_coupled": dict(layers=(8, 200, 200, 8), B=48, kw=dict(rhs_kind=O.RHS_MLP, state_dim=8, param_dim=0, solver=O.SOLVER_RK4, adaptive=0, dt=0.05, batching=O.BATCH_COUPLED), lim=5e-6),
+        "c3_per_traj": dict(layers=(2, 64, 64, 2), B=80, kw=dict(rhs_kind=O.RHS_PENDULUM_PLUS_MLP), lim=1e-2),
+        "c4_coupled": dict(layers=(32, 128, 128, 32), B=40, kw=dict(rhs_kind=O.RHS_MLP, state_dim=32, param_dim=0, batching=O.BATCH_COUPLED), lim=5e-3),
+        "tanh_per_traj_4d": dict(layers=(4, 48, 33, 4), B=37, kw=dict(rhs_kind=O.RHS_MLP, state_dim=4, param_dim=0, activation=O.ACT_TANH, abstol=1e-7, reltol=1e-7), lim=1e-4),
+        "rk4_per_traj_small": dict(layers=(3, 20, 64, 3), B=19, kw=dict(rhs_kind=O.RHS_MLP, state_dim=3, param_dim=0, solver=O.SOLVER_RK4, adaptive=0, dt=0.025, activation=O.ACT_TANH), lim=5e-6),
+        "deep_4_layers": dict(layers=(6, 40, 24, 40, 6), B=21, kw=dict(rhs_kind=O.RHS_MLP, state_dim=6, param_dim=0, activation=O.ACT_TANH, abstol=1e-7, reltol=1e-7), lim=1e-4),
+    }[case]
+    layers, B, kw, lim = cfg["layers"], cfg["B"], dict(cfg["kw"], layers=cfg["layers"]), cfg["lim"]
+    W = O.mlp_weights(layers, seed=8)
+    D = kw.get("state_dim", 2)
+    T = 20
+    ts = O.time_grid(T)
+    if kw["rhs_kind"] == O.RHS_PENDULUM_PLUS_MLP:
+        z0, L = O.pendulum_inputs(B)
+    else:
+        z0, L = _z0(B, D, seed=4), None
+    dz = O.cotangent(T, B, D)
+    res = {}
+    for fam, env in (("new", {}), ("tiles", {"LDE_MLPV": "0", "LDE_MLP64": "0"}), ("mlpv", {"LDE_MLP64": "0"})):
+        for k_ in ("LDE_MLPV", "LDE_MLP64"):
+            monkeypatch.delenv(k_, raising=False)
+        for k_, v_ in env.items():
+            monkeypatch.setenv(k_, v_)
+        nat, _ = _native(W, **kw)
+        z, ret, st = nat.forward(z0, L, ts)
+        g0, gL, gW, sb = nat.adjoint(z, L, ts, dz)
+        assert (ret == 0).all() and sb["nfailed"] == 0
+        res[fam] = (z, g0, gL, gW)
+    rel = lambda a, b: np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
+    for fam in ("new", "mlpv"):
+        z, g0, gL, gW = res[fam]
+        zt, t0, tL, tW = res["tiles"]
+        assert np.abs(z - zt).max() <= max(lim, 2e-5) * max(1.0, np.abs(zt).max()), (fam, "z")
+        assert rel(g0, t0) <= max(lim, 2e-5) and rel(gW, tW) <= max(lim, 5e-5), (fam, rel(g0, t0), rel(gW, tW))
+        if gL is not None:
+            assert rel(gL, tL) <= max(lim, 2e-5), fam

@@ -53,7 +53,7 @@ __device__ __forceinline__ f32x4 mfma16_bf(s16x4 a, s16x4 b, f32x4 c) { return _
 #if LDE_PROF
 static __device__ long long g_prof[64];
 #define PROF_T(var) const long long var = (long long)__builtin_readcyclecounter()
-#define PROF_ADD(slot, t0, t1) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_prof[slot] += (t1) - (t0); } while (0)
+#define PROF_ADD(slot, t0, t1) do { if (threadIdx.x == 0 && blockIdx.x == 0) __hip_atomic_fetch_add((unsigned long long*)&g_prof[slot], (unsigned long long)((t1) - (t0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (0)   /* no return value: nothing waits for it */
 #else
 #define PROF_T(var) do {} while (0)
 #define PROF_ADD(slot, t0, t1) do {} while (0)

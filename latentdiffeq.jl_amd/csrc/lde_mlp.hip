@@ -1331,6 +1331,7 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
 #include "lde_mlp4.h"
 #include "lde_mlpv.h"
 #include "lde_mlp64.h"
+#include "lde_mlpw.h"
 
 // ================================================ host side =================================================
 struct MlpPlan {
@@ -1338,6 +1339,10 @@ struct MlpPlan {
   VecDims vd;                  // small-batch kernels (lde_mlpv.h): geometry and the swizzled weight copies
   bool vec_ok = false;
   float* vecw = nullptr;
+  WDims wd;                    // W-waves-per-trajectory register kernels (lde_mlpw.h)
+  bool w_ok = false;
+  float* wpack = nullptr;
+  unsigned epoch = 0;          // launch counter of k_mlpw's tagged grid-sum words
   float* frag = nullptr;
   float* fragT = nullptr;
   size_t nfrag = 0, nfragT = 0;
@@ -1415,6 +1420,23 @@ int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err) 
         const int v = atoi(e);
         if ((v == 64 || v == 128 || v == 256) && v >= nt) nt = v;
       }
+      // Register-resident hidden layer (lde_mlpv.h: vec_matvec_reg): three Dense layers with a hidden×hidden product of at
+      // most 128×128 — the workgroup takes S·r lanes so that a lane's share of a row is VREG_K groups (LDE_MLPV_REG=0: off)
+      vd.reg_l = -1;
+      int reg_r = 0, reg_s = 0;
+      {
+        const char* e = getenv("LDE_MLPV_REG");
+        const int hm = dm.nL == 3 ? std::max(dm.sizes[1], dm.sizes[2]) : 0;
+        if (!(e && atoi(e) == 0) && dm.nL == 3 && hm <= 128 && hm > 16) {
+          reg_r = hm <= 64 ? 64 : 128;
+          reg_s = reg_r / 64;                 // 64 → one wave holds the rows whole; 128 → two lane groups split K
+          const int want = reg_r * reg_s;     // 64 or 256 lanes
+          if (nt <= want) {
+            nt = want;
+            vd.reg_l = 1;
+          }
+        }
+      }
       vd.NT = nt;
       auto geom = [&](int rows, int K, int* rp, int* lg, int* k4, int* S) {
         int r = 4, g = 2;
@@ -1433,11 +1455,13 @@ int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err) 
       int off = 0;
       for (int l = 0; l < dm.nL; l++) {
         geom(dm.sizes[l + 1], dm.sizes[l], &vd.rpf[l], &vd.lgf[l], &vd.k4f[l], &vd.sf[l]);
+        if (l == vd.reg_l) { vd.rpf[l] = reg_r; vd.lgf[l] = reg_r == 64 ? 6 : 7; vd.k4f[l] = VREG_K; vd.sf[l] = reg_s; }
         vd.off_f[l] = off;
         off += vd.sf[l] * vd.k4f[l] * vd.rpf[l];
       }
       for (int l = 0; l < dm.nL; l++) {
         geom(dm.sizes[l], dm.sizes[l + 1], &vd.rpb[l], &vd.lgb[l], &vd.k4b[l], &vd.sb[l]);
+        if (l == vd.reg_l) { vd.rpb[l] = reg_r; vd.lgb[l] = reg_r == 64 ? 6 : 7; vd.k4b[l] = VREG_K; vd.sb[l] = reg_s; }
         vd.off_b[l] = off;
         off += vd.sb[l] * vd.k4b[l] * vd.rpb[l];
       }
@@ -1456,6 +1480,35 @@ int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err) 
       vd.nsp_f = std::max((dm.Dp + 3) & ~3, x0);
       vd.nsp_b = std::max(std::max((2 * dm.DpA + dm.P + 3) & ~3, x0), xt);
       if (hipMalloc(&p->vecw, (size_t)vd.total4 * 4 * sizeof(float)) != hipSuccess) {
+        err = "MLP plan: hipMalloc failed";
+        mlp_plan_destroy(p);
+        return LDE_ERR_ALLOC;
+      }
+    }
+  }
+  {   // W waves per trajectory, weights in registers (lde_mlpw.h): three layers, no analytic part, H ≤ 200, D′ ≤ 32
+    const int hm = dm.nL == 3 ? std::max(dm.sizes[1], dm.sizes[2]) : 0;
+    p->w_ok = dm.nL == 3 && !dm.has_pend && dm.P == 0 && dm.Dp <= 32 && hm >= 1 && hm <= 200;
+    if (p->w_ok) {
+      WDims& wd = p->wd;
+      wd.DP = dm.Dp <= 8 ? 8 : 32;
+      wd.HP = hm <= 128 ? 128 : 200;
+      wd.W = hm <= 128 ? 2 : 4;
+      wd.UT = 64 * wd.W;
+      wd.SEG = 64 / wd.DP;
+      wd.GS = (wd.HP / wd.SEG + 3) / 4;   // = the kernel's compile-time GS
+      wd.HX = (std::max(wd.UT, wd.SEG * wd.GS * 4) + 3) & ~3;
+      wd.o_w1r = 0;
+      wd.o_w2r = wd.o_w1r + wd.DP * wd.UT;
+      wd.o_w2c = wd.o_w2r + wd.HP * wd.UT;
+      wd.o_w3c = wd.o_w2c + wd.HP * wd.UT;
+      wd.o_b1 = wd.o_w3c + wd.DP * wd.UT;
+      wd.o_b2 = wd.o_b1 + wd.UT;
+      wd.o_b3 = wd.o_b2 + wd.UT;
+      wd.o_n3 = wd.o_b3 + 64;
+      wd.o_n1 = wd.o_n3 + wd.GS * 64 * 4;
+      wd.total = wd.o_n1 + wd.GS * 64 * 4;
+      if (hipMalloc(&p->wpack, (size_t)wd.total * sizeof(float)) != hipSuccess) {
         err = "MLP plan: hipMalloc failed";
         mlp_plan_destroy(p);
         return LDE_ERR_ALLOC;
@@ -1483,6 +1536,7 @@ void mlp_plan_destroy(MlpPlan* p) {
   if (p->frag) (void)hipFree(p->frag);
   if (p->fragT) (void)hipFree(p->fragT);
   if (p->vecw) (void)hipFree(p->vecw);
+  if (p->wpack) (void)hipFree(p->wpack);
   if (p->counter) (void)hipFree(p->counter);
   if (p->abort_flag) (void)hipFree(p->abort_flag);
   if (p->slots) (void)hipFree(p->slots);
@@ -1501,7 +1555,8 @@ int mlp_reserve(MlpPlan* p, int B, int T, std::string& err) {
   if (nwg > p->cap_wg) {
     if (p->slots) (void)hipFree(p->slots);
     p->slots = nullptr;
-    if (hipMalloc(&p->slots, (size_t)2 * nwg * 4 * sizeof(float)) != hipSuccess) {
+    if (hipMalloc(&p->slots, (size_t)2 * nwg * 4 * sizeof(float)) != hipSuccess ||
+        hipMemset(p->slots, 0, (size_t)2 * nwg * 4 * sizeof(float)) != hipSuccess) {   // k_mlpw's tagged words: no tag is 0
       err = "MLP plan: hipMalloc(slots) failed";
       return LDE_ERR_ALLOC;
     }
@@ -1570,6 +1625,7 @@ int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::strin
 int mlp_set_weights(MlpPlan* p, const float* W_dev, hipStream_t stream, std::string& err) {
   hipLaunchKernelGGL(k_build_frags, dim3(64, p->dm.nL), dim3(256), 0, stream, W_dev, p->dm, p->frag, p->fragT, (float*)nullptr);
   if (p->vec_ok) hipLaunchKernelGGL(k_build_vec, dim3(64, p->dm.nL), dim3(256), 0, stream, W_dev, p->dm, p->vd, p->vecw);
+  if (p->w_ok) hipLaunchKernelGGL(k_build_wpack, dim3(128), dim3(256), 0, stream, W_dev, p->dm, p->wd, p->wpack);
   if (hipGetLastError() != hipSuccess) {
     err = "k_build_frags launch failed";
     return LDE_ERR_HIP;
@@ -1684,7 +1740,7 @@ static bool vec_applicable(const MlpPlan* p, int B, int T, bool adj, bool couple
   // wave (B·NT/64 ≤ 1024: c2 0.88 + 1.97 ms vs 1.77 + 3.44 at B = 256, c3 0.36 + 4.28 vs 0.63 + 5.0 at 1024, c4 0.46 + 3.77 vs
   // 0.45 + 4.3 at 512) and lose beyond (c2 at B = 1024: 1.94 + 4.5 vs 1.78 + 3.9) — the tiles then have enough columns
   const char* m = getenv("LDE_MLPV_MAX_B");
-  const int maxb = m ? atoi(m) : 1024 * 64 / p->vd.NT;
+  const int maxb = m ? atoi(m) : (p->vd.reg_l >= 0 ? 2048 : 1024) * 64 / p->vd.NT;   // register-resident layer: two waves per SIMD still win
   if (B > maxb) return false;
   const size_t fixed = vec_lds_fixed(p->dm, p->vd, T, adj);
   if (fixed > LDS_MAX / 2) return false;
@@ -1707,9 +1763,12 @@ static int launch_vec(const MlpPlan* p, const KOpts& o, VArgs& a, size_t lds, bo
   MlpDims dmv = p->dm;
   VecDims vdv = p->vd;
   KOpts ov = o;
-  const void* fn = p->vd.NT == 64 ? (const void*)k_mlpv<SOLVER, 64, ADJ> : p->vd.NT == 128 ? (const void*)k_mlpv<SOLVER, 128, ADJ> : (const void*)k_mlpv<SOLVER, 256, ADJ>;
-  static bool attr_set[3] = {false, false, false};
-  const int ki = p->vd.NT == 64 ? 0 : (p->vd.NT == 128 ? 1 : 2);
+  constexpr int KB = ADJ ? VREG_K : 0;
+  const bool reg = p->vd.reg_l >= 0;
+  const void* fn = reg ? (p->vd.NT == 64 ? (const void*)k_mlpv<SOLVER, 64, ADJ, VREG_K, KB> : (const void*)k_mlpv<SOLVER, 256, ADJ, VREG_K, KB>)
+                       : (p->vd.NT == 64 ? (const void*)k_mlpv<SOLVER, 64, ADJ> : p->vd.NT == 128 ? (const void*)k_mlpv<SOLVER, 128, ADJ> : (const void*)k_mlpv<SOLVER, 256, ADJ>);
+  static bool attr_set[5] = {false, false, false, false, false};
+  const int ki = reg ? (p->vd.NT == 64 ? 3 : 4) : (p->vd.NT == 64 ? 0 : (p->vd.NT == 128 ? 1 : 2));
   if (!attr_set[ki]) {
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
       err = "hipFuncSetAttribute(k_mlpv) failed";
@@ -1728,6 +1787,52 @@ static int launch_vec(const MlpPlan* p, const KOpts& o, VArgs& a, size_t lds, bo
   return rcl;
 }
 
+// ---- W waves per trajectory, weights and state in registers (lde_mlpw.h)
+static bool w_applicable(const MlpPlan* p, int B, bool coupled_adaptive) {
+  const char* e = getenv("LDE_MLPW");   // read per call: the tests switch kernels inside one process
+  if (!p->w_ok || (e && atoi(e) == 0)) return false;
+  // one wave per SIMD (the weights take most of the 512 registers): 1024 waves are resident at once; an uncoupled solve may
+  // queue a second round, a coupled one needs every trajectory resident
+  const char* m = getenv("LDE_MLPW_MAX_WAVES");
+  const int maxw = coupled_adaptive ? 1024 : (m ? atoi(m) : 2048);
+  return (long long)B * p->wd.W <= maxw;
+}
+template <int SOLVER, bool ADJ>
+static int launch_w(const MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t stream, std::string& err) {
+  MlpDims dmv = p->dm;
+  WDims wdv = p->wd;
+  KOpts ov = o;
+  const bool d8 = wdv.DP == 8, w2 = wdv.W == 2;
+  const void* fn = w2 ? (d8 ? (const void*)k_mlpw<SOLVER, 8, 128, 2, ADJ> : (const void*)k_mlpw<SOLVER, 32, 128, 2, ADJ>)
+                      : (d8 ? (const void*)k_mlpw<SOLVER, 8, 200, 4, ADJ> : (const void*)k_mlpw<SOLVER, 32, 200, 4, ADJ>);
+  size_t lds = (((size_t)o.T * 8 + 15) & ~size_t(15)) + (size_t)(wdv.W * 64 + 2 * wdv.HX) * 4 +
+               (size_t)wdv.GS * 64 * 16 * (ADJ ? 2 : 1) + 16;
+  const size_t cot = ADJ ? (size_t)o.T * dmv.Dp * 4 * (o.checkpoint ? 2 : 1) : 0;
+  a.cot_lds = ADJ && cot <= 40 * 1024;   // the trajectory's dẑ (and saved ẑ) by save time: no global load inside the solve
+  if (a.cot_lds) lds += cot;
+  a.wpack = p->wpack;
+  if (coop) {   // tagged grid-sum words: a fresh epoch per launch, the buffer cleared when the 16-bit epoch wraps
+    MlpPlan* pm = const_cast<MlpPlan*>(p);
+    pm->epoch = (pm->epoch + 1) & 0xffffu;
+    if (pm->epoch == 0) {
+      if (hipMemsetAsync(p->slots, 0, (size_t)2 * p->cap_wg * 4 * sizeof(float), stream) != hipSuccess) {
+        err = "hipMemsetAsync(slots) failed";
+        return LDE_ERR_HIP;
+      }
+      pm->epoch = 1;
+    }
+    a.epoch = pm->epoch;
+  }
+#if LDE_PROF
+  prof_reset();
+#endif
+  const int rcl = launch_maybe_coop(coop, fn, dim3(o.B), dim3(wdv.UT), lds, stream, err, "k_mlpw", dmv, wdv, ov, a);
+#if LDE_PROF
+  prof_dump(ADJ ? "w adjoint" : "w forward", stream);
+#endif
+  return rcl;
+}
+
 int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* theta, const double* ts_dev,
                 const KOpts& o, float* z_out, int32_t* retcode, int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret,
                 hipStream_t stream, std::string& err) {
@@ -1741,7 +1846,8 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
   {   // small batches: one trajectory per workgroup, lanes = hidden units (lde_mlpv.h)
     size_t ldsv = 0;
     const bool ca = dm.coupled && o.adaptive && o.B > 1;
-    if (vec_applicable(p, o.B, o.T, false, ca, &ldsv, err)) {
+    const bool use_w = w_applicable(p, o.B, ca);
+    if (use_w || vec_applicable(p, o.B, o.T, false, ca, &ldsv, err)) {
       VArgs va{};
       va.z0 = z0; va.theta = theta; va.ts = ts_dev; va.vecw = p->vecw; va.Wflat = W_dev; va.z_out = z_out; va.retcode = retcode;
       va.st_nfe = nfe; va.st_nacc = nacc; va.st_nrej = nrej; va.st_ret = ret;
@@ -1751,6 +1857,9 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
         err = "hipMemsetAsync(counter) failed";
         return LDE_ERR_HIP;
       }
+      if (use_w)
+        return dm.solver == LDE_SOLVER_RK4 ? launch_w<LDE_SOLVER_RK4, false>(p, o, va, ca, stream, err)
+                                           : launch_w<LDE_SOLVER_TSIT5, false>(p, o, va, ca, stream, err);
       return dm.solver == LDE_SOLVER_RK4 ? launch_vec<LDE_SOLVER_RK4, false>(p, o, va, ldsv, ca, stream, err)
                                          : launch_vec<LDE_SOLVER_TSIT5, false>(p, o, va, ldsv, ca, stream, err);
     }
@@ -1933,7 +2042,8 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
   if (!vec_done) {   // small batches: one trajectory per workgroup, lanes = hidden units (lde_mlpv.h)
     size_t ldsv = 0;
     const bool ca = dm.coupled && o.adaptive && o.B > 1;
-    if (vec_applicable(p, o.B, o.T, true, ca, &ldsv, err)) {
+    const bool use_w = w_applicable(p, o.B, ca);
+    if (use_w || vec_applicable(p, o.B, o.T, true, ca, &ldsv, err)) {
       if (hipMemsetAsync(p->fb_dev, 0, 2 * sizeof(int32_t), stream) != hipSuccess ||
           hipMemsetAsync(p->nslots, 0, (size_t)2 * (nwg + 1) * sizeof(int32_t), stream) != hipSuccess ||
           hipMemsetAsync(p->wts, 0, (size_t)nwg * p->adj_cap * NB * sizeof(float), stream) != hipSuccess) {
@@ -1950,8 +2060,10 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
       va.dz0 = dz0; va.dtheta = dtheta; va.stage = p->stage; va.wts = p->wts; va.nslots = p->nslots; va.cap = p->adj_cap; va.ovf = p->fb_dev + 1;
       va.st_nfe = nfe; va.st_nacc = nacc; va.st_nrej = nrej; va.st_ret = ret;
       va.gs.counter = p->counter; va.gs.slots = p->slots; va.gs.abort_flag = p->abort_flag; va.gs.nwg = ca ? o.B : 1;
-      const int rcv = dm.solver == LDE_SOLVER_RK4 ? launch_vec<LDE_SOLVER_RK4, true>(p, o, va, ldsv, ca, stream, err)
-                                                  : launch_vec<LDE_SOLVER_TSIT5, true>(p, o, va, ldsv, ca, stream, err);
+      const int rcv = use_w ? (dm.solver == LDE_SOLVER_RK4 ? launch_w<LDE_SOLVER_RK4, true>(p, o, va, ca, stream, err)
+                                                           : launch_w<LDE_SOLVER_TSIT5, true>(p, o, va, ca, stream, err))
+                            : (dm.solver == LDE_SOLVER_RK4 ? launch_vec<LDE_SOLVER_RK4, true>(p, o, va, ldsv, ca, stream, err)
+                                                           : launch_vec<LDE_SOLVER_TSIT5, true>(p, o, va, ldsv, ca, stream, err));
       if (rcv) return rcv;
       // a trajectory that ran out of staging slots sets *ovf: k_mlp_adjoint (which folds its slots into a private slab) then
       // redoes the whole call; otherwise it returns at once. The decision is taken on the device.

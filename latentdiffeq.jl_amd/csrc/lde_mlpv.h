@@ -27,13 +27,18 @@ struct VecDims {
   int hoff[MAXL], htotal;                                      // hidden vectors (post-activation), each padded to a multiple of 4
   int maxw4;                                                   // floats of one δ buffer (widest vector / widest padded K)
   int nsp_f, nsp_b;                                            // floats of one state vector in the forward / adjoint kernel (incl. the zero tail a product may read)
+  int reg_l;                                                   // layer whose two products keep their weights in REGISTERS (−1: none), VREG_K groups per lane
 };
+constexpr int VREG_K = 16;   // K-groups (of 4) per lane of a register-resident product: 64 VGPRs per direction
 
 struct VArgs {
   const float* z0;        // forward: [D×B]
   const float* theta;
   const double* ts;
   const float* vecw;      // swizzled weights
+  const float* wpack;     // k_mlpw's packed weights (lde_mlpw.h)
+  unsigned epoch;         // k_mlpw: launch epoch (16 bits) of the tagged grid-sum words
+  int cot_lds;            // k_mlpw adjoint: the trajectory's cotangents fit LDS
   const float* Wflat;     // flat weights (biases)
   float* z_out;           // forward: written; adjoint: the saved ẑ (read)
   int32_t* retcode;
@@ -141,6 +146,45 @@ __device__ __forceinline__ float vec_matvec(const f32x4* __restrict__ Wq, int rp
   return acc;
 }
 
+// The same product with the lane's weights already in registers (KR groups, zero-padded): no weight traffic at all — the
+// evaluation's only loads are the KR broadcast reads of x. This is what the square hidden layer of c4 (128×128) and of the
+// smaller three-layer networks runs on: a workgroup of S·rp lanes holds the whole matrix once per direction (KR·4 = 64 VGPRs).
+template <int NT, int KR>
+__device__ __forceinline__ float vec_matvec_reg(const f32x4 (&w)[KR], int rp, int lg, int S, const float* x, float* red) {
+  const int tid = threadIdx.x;
+  const int i = S > 1 ? (tid & (rp - 1)) : tid, s = S > 1 ? (tid >> lg) : 0;
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  {
+    const f32x4* xv = reinterpret_cast<const f32x4*>(x) + (s < S ? s : 0) * KR;
+#pragma unroll
+    for (int g = 0; g < KR; g += 4) {
+      const f32x4 x0 = xv[g], x1 = xv[g + 1], x2 = xv[g + 2], x3 = xv[g + 3];
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        acc0 += w[g][e] * x0[e];
+        acc1 += w[g + 1][e] * x1[e];
+        acc2 += w[g + 2][e] * x2[e];
+        acc3 += w[g + 3][e] * x3[e];
+      }
+    }
+  }
+  float acc = (acc0 + acc1) + (acc2 + acc3);
+  if (S > 1) {   // uniform
+    if (s < S) red[s * rp + i] = acc;
+    __syncthreads();
+    if (s == 0) {
+      acc = red[i];
+      for (int q = 1; q < S; q++) acc += red[q * rp + i];
+    }
+  }
+  return acc;
+}
+template <int KF, int KB>
+struct VRegs {
+  f32x4 wf[KF > 0 ? KF : 1], wb[KB > 0 ? KB : 1];
+  int l;   // the layer they belong to
+};
+
 // Per-layer parameters of the two products, kept as one 64-byte LDS record each: a dynamically indexed kernel-argument array
 // costs a dependent scalar load (+ a full s_waitcnt) per field and layer — measured: most of an evaluation's time for the small
 // networks — where the record is four broadcast ds_read_b128 in flight together.
@@ -184,8 +228,8 @@ struct VPanels {
 };
 
 // f(z): dst rows [0,Dp) = MLP(src rows [0,Dp)) (+ pendulum); post-activation hidden vectors stay in P.hid
-template <int NT>
-__device__ __forceinline__ void vec_eval_rhs(const VPanels& P, const VCtl* c, const float* src, float* dst) {
+template <int NT, int KF, int KB>
+__device__ __forceinline__ void vec_eval_rhs(const VPanels& P, const VRegs<KF, KB>& R, const VCtl* c, const float* src, float* dst) {
   const int tid = threadIdx.x, nL = P.nL;
   const float* x = src;
   for (int l = 0; l < nL; l++) {
@@ -194,7 +238,13 @@ __device__ __forceinline__ void vec_eval_rhs(const VPanels& P, const VCtl* c, co
     const bool lastl = q.yofs < 0;
     float* Y = lastl ? dst : P.hid + q.yofs;
     PROF_T(v1);
-    const float acc = vec_layer<NT>(P.lbase, P.gw, q, x, P.red);
+    float acc;
+    if constexpr (KF > 0) {
+      if (l == R.l) acc = vec_matvec_reg<NT, KF>(R.wf, q.rp, q.lg, q.S, x, P.red);
+      else acc = vec_layer<NT>(P.lbase, P.gw, q, x, P.red);
+    } else {
+      acc = vec_layer<NT>(P.lbase, P.gw, q, x, P.red);
+    }
     PROF_T(v2);
     if (tid < q.rows) {
       float v = acc + P.biasc[q.bias + tid];
@@ -218,16 +268,24 @@ __device__ __forceinline__ void vec_eval_rhs(const VPanels& P, const VCtl* c, co
 }
 
 // f, −(∂f/∂z)ᵀλ, −(∂f/∂θ)ᵀλ; rows: [0,Dp) z | [DpA,DpA+Dp) λ | [2DpA,2DpA+P) g. With `blk`, column `n` of the staged block gets (a_l, δ_l).
-template <int NT>
-__device__ __forceinline__ void vec_eval_bwd(const VPanels& P, const VCtl* c, const float* src, float* dst, float* blk, int n) {
+template <int NT, int KF, int KB>
+__device__ __forceinline__ void vec_eval_bwd(const VPanels& P, const VRegs<KF, KB>& R, const VCtl* c, const float* src, float* dst, float* blk, int n) {
   const int tid = threadIdx.x, nL = P.nL, DpA = P.DpA;
-  vec_eval_rhs<NT>(P, c, src, dst);
+  PROF_T(r0);
+  vec_eval_rhs<NT, KF, KB>(P, R, c, src, dst);
+  PROF_T(r1);
   const float* dl = src + DpA;
   for (int l = nL - 1; l >= 0; l--) {
     const VLayer q = vlayer_load(P.tb + l);      // rows = in, K = out
     const float* al = q.aofs < 0 ? src : P.hid + q.aofs;
     PROF_T(b0);
-    const float acc = vec_layer<NT>(P.lbase, P.gw, q, dl, P.red);
+    float acc;
+    if constexpr (KB > 0) {
+      if (l == R.l) acc = vec_matvec_reg<NT, KB>(R.wb, q.rp, q.lg, q.S, dl, P.red);
+      else acc = vec_layer<NT>(P.lbase, P.gw, q, dl, P.red);
+    } else {
+      acc = vec_layer<NT>(P.lbase, P.gw, q, dl, P.red);
+    }
     PROF_T(b1);
     PROF_ADD(13 + l, b0, b1);
     if (l > 0) {
@@ -243,6 +301,9 @@ __device__ __forceinline__ void vec_eval_bwd(const VPanels& P, const VCtl* c, co
   // The (a_l, δ_l) panels go to HBM in ONE pass after the last product: on gfx9 stores and loads share the in-order vmcnt
   // counter, so a weight load issued behind a layer's staging stores waited for their write acknowledgements (measured:
   // ≈ 7 000 of an evaluation's 22 000 cycles on c2 / c4) — now only the next evaluation's first load does.
+  PROF_T(sg0);
+  PROF_ADD(23, r0, r1);
+  PROF_ADD(24, r1, sg0);
   if (blk) {
     for (int l = nL - 1; l >= 0; l--) {
       const VLayer q = vlayer_load(P.tb + l);
@@ -254,6 +315,8 @@ __device__ __forceinline__ void vec_eval_bwd(const VPanels& P, const VCtl* c, co
       for (int r = tid; r < q.out32; r += NT) gd[r] = r < q.K ? dv[r] : 0.f;
     }
   }
+  PROF_T(sg1);
+  PROF_ADD(22, sg0, sg1);
   if (P.has_pend) {
     if (tid == 0) {
       float sn, cs;
@@ -339,8 +402,8 @@ __device__ __forceinline__ void vec_grid_sum(const GridSync& gs, unsigned& gen, 
   PROF_ADD(21, gs1 - 1, gs1);
 }
 
-template <int SOLVER, int NT, bool ADJ>
-__global__ void __launch_bounds__(NT) k_mlpv(MlpDims dm, VecDims vd, KOpts o, VArgs a) {
+template <int SOLVER, int NT, bool ADJ, int KF = 0, int KB = 0>
+__global__ void __launch_bounds__(NT, (KF > 0 ? 2 : 1)) k_mlpv(MlpDims dm, VecDims vd, KOpts o, VArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int T = o.T, B = o.B, Dp = dm.Dp, DpA = dm.DpA, D = dm.D, NP = dm.P;
   const int tid = threadIdx.x, b = blockIdx.x;
@@ -380,7 +443,8 @@ __global__ void __launch_bounds__(NT) k_mlpv(MlpDims dm, VecDims vd, KOpts o, VA
       for (int l = 0; l < dm.nL; l++) {
         const int n = 4 * (pass ? vd.sb[l] * vd.k4b[l] * vd.rpb[l] : vd.sf[l] * vd.k4f[l] * vd.rpf[l]);
         const float* srcw = a.vecw + (size_t)(pass ? vd.off_b[l] : vd.off_f[l]) * 4;
-        const bool fits = cache + n <= cend;
+        const bool in_regs = l == vd.reg_l && (pass ? KB > 0 : KF > 0);
+        const bool fits = !in_regs && cache + n <= cend;
         if (fits) {
           const f32x4* s4 = reinterpret_cast<const f32x4*>(srcw);
           f32x4* d4 = reinterpret_cast<f32x4*>(cache);
@@ -410,6 +474,24 @@ __global__ void __launch_bounds__(NT) k_mlpv(MlpDims dm, VecDims vd, KOpts o, VA
       }
   }
   __syncthreads();
+  VRegs<KF, KB> R;
+  R.l = (KF > 0 || KB > 0) ? vd.reg_l : -1;
+  if (KF > 0 || KB > 0) {   // the lane's share of the register-resident layer, once (geometry: rp·S = NT lanes, VREG_K groups each)
+    const int l = vd.reg_l;
+    const f32x4* g4 = reinterpret_cast<const f32x4*>(a.vecw);
+    if (KF > 0) {
+      const int rp = vd.rpf[l], S = vd.sf[l], i = S > 1 ? (tid & (rp - 1)) : tid, sg = S > 1 ? (tid >> vd.lgf[l]) : 0;
+      const bool on = sg < S && i < rp;
+#pragma unroll
+      for (int g = 0; g < (KF > 0 ? KF : 1); g++) R.wf[g] = on ? g4[vd.off_f[l] + (sg * KF + g) * rp + i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    if (KB > 0) {
+      const int rp = vd.rpb[l], S = vd.sb[l], i = S > 1 ? (tid & (rp - 1)) : tid, sg = S > 1 ? (tid >> vd.lgb[l]) : 0;
+      const bool on = sg < S && i < rp;
+#pragma unroll
+      for (int g = 0; g < (KB > 0 ? KB : 1); g++) R.wb[g] = on ? g4[vd.off_b[l] + (sg * KB + g) * rp + i] : f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
 
   const bool coupled = dm.coupled != 0;
   const double t0 = s_ts[0], tend = s_ts[T - 1], dtmax = fabs(tend - t0);
@@ -553,9 +635,9 @@ __global__ void __launch_bounds__(NT) k_mlpv(MlpDims dm, VecDims vd, KOpts o, VA
     PROF_T(pe0);
     PROF_ADD(0, pl0, pe0);
     if (ADJ)
-      vec_eval_bwd<NT>(P, c, src, dst, (any_w && !overflow) ? my_stage + (size_t)(slot_base + s) * blk_floats : nullptr, ncol);
+      vec_eval_bwd<NT, KF, KB>(P, R, c, src, dst, (any_w && !overflow) ? my_stage + (size_t)(slot_base + s) * blk_floats : nullptr, ncol);
     else
-      vec_eval_rhs<NT>(P, c, src, dst);
+      vec_eval_rhs<NT, KF, KB>(P, R, c, src, dst);
     if (status == 0) nfe++;
     PROF_T(pe1);
     PROF_ADD(1, pe0, pe1);

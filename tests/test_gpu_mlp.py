@@ -526,11 +526,13 @@ def test_one_mlp_handle_changing_shapes(o32, layers, batching, solver):
         assert e0 <= 2e-3 and eW <= 2e-3, (T, B, e0, eW)
 
 
-@pytest.mark.parametrize("case", ["c2_rk4_coupled", "c3_per_traj", "c4_coupled", "tanh_per_traj_4d", "rk4_per_traj_small", "deep_4_layers"])
+@pytest.mark.parametrize("case", ["c2_rk4_coupled", "c3_per_traj", "c4_coupled", "tanh_per_traj_4d", "rk4_per_traj_small", "deep_4_layers",
+                                  "tsit5_d12_h150_coupled", "rk4_d20_h96_per_traj", "tanh_d8_h70_aug"])
 def test_kernel_families_agree(case, monkeypatch, o64):
-    """Three kernel families serve the MLP right-hand sides: 16-column MFMA tiles (large batches; LDE_MLPV=0 LDE_MLP64=0 forces
-    them), one trajectory per workgroup with lanes = hidden units (k_mlpv), and one wave per trajectory with everything in
-    registers (k_mlp64: three layers ≤ 64 wide, D' ≤ 4, per-trajectory control). Same algorithm, same control arithmetic: they
+    """Four kernel families serve the MLP right-hand sides: 16-column MFMA tiles (large batches; LDE_MLPV=0 LDE_MLP64=0 LDE_MLPW=0
+    forces them), one trajectory per workgroup with lanes = hidden units (k_mlpv; LDE_MLP64=0 LDE_MLPW=0), one wave per trajectory
+    with everything in registers (k_mlp64: three layers ≤ 64 wide, D' ≤ 4, per-trajectory control) and W waves per trajectory with
+    weights and state in registers (k_mlpw: three layers ≤ 200 wide, D' ≤ 32). Same algorithm, same control arithmetic: they
     agree like two correct f32 solves — round-off for fixed steps and smooth networks at tight tolerance, the solver's own error
     where a relu network meets the adaptive controller — and every family is no farther from the float64 adjoint than that."""
     cfg = {
@@ -540,6 +542,10 @@ def test_kernel_families_agree(case, monkeypatch, o64):
         "tanh_per_traj_4d": dict(layers=(4, 48, 33, 4), B=37, kw=dict(rhs_kind=O.RHS_MLP, state_dim=4, param_dim=0, activation=O.ACT_TANH, abstol=1e-7, reltol=1e-7), lim=1e-4),
         "rk4_per_traj_small": dict(layers=(3, 20, 64, 3), B=19, kw=dict(rhs_kind=O.RHS_MLP, state_dim=3, param_dim=0, solver=O.SOLVER_RK4, adaptive=0, dt=0.025, activation=O.ACT_TANH), lim=5e-6),
         "deep_4_layers": dict(layers=(6, 40, 24, 40, 6), B=21, kw=dict(rhs_kind=O.RHS_MLP, state_dim=6, param_dim=0, activation=O.ACT_TANH, abstol=1e-7, reltol=1e-7), lim=1e-4),
+        # the other instantiations of k_mlpw: (D' > 8, H > 128), (D' > 8, H ≤ 128) fixed step, (D' ≤ 8, H ≤ 128) with augmented rows
+        "tsit5_d12_h150_coupled": dict(layers=(12, 150, 137, 12), B=24, kw=dict(rhs_kind=O.RHS_MLP, state_dim=12, param_dim=0, activation=O.ACT_TANH, abstol=1e-7, reltol=1e-7, batching=O.BATCH_COUPLED), lim=1e-4),
+        "rk4_d20_h96_per_traj": dict(layers=(20, 96, 128, 20), B=33, kw=dict(rhs_kind=O.RHS_MLP, state_dim=20, param_dim=0, solver=O.SOLVER_RK4, adaptive=0, dt=0.025, activation=O.ACT_TANH), lim=5e-6),
+        "tanh_d8_h70_aug": dict(layers=(8, 70, 65, 8), B=26, kw=dict(rhs_kind=O.RHS_MLP, state_dim=6, augment_dim=2, param_dim=0, activation=O.ACT_TANH, abstol=1e-7, reltol=1e-7), lim=1e-4),
     }[case]
     layers, B, kw, lim = cfg["layers"], cfg["B"], dict(cfg["kw"], layers=cfg["layers"]), cfg["lim"]
     W = O.mlp_weights(layers, seed=8)
@@ -550,10 +556,10 @@ def test_kernel_families_agree(case, monkeypatch, o64):
         z0, L = O.pendulum_inputs(B)
     else:
         z0, L = _z0(B, D, seed=4), None
-    dz = O.cotangent(T, B, D)
+    dz = O.cotangent(T, B, D + kw.get("augment_dim", 0))
     res = {}
-    for fam, env in (("new", {}), ("tiles", {"LDE_MLPV": "0", "LDE_MLP64": "0"}), ("mlpv", {"LDE_MLP64": "0"})):
-        for k_ in ("LDE_MLPV", "LDE_MLP64"):
+    for fam, env in (("new", {}), ("tiles", {"LDE_MLPV": "0", "LDE_MLP64": "0", "LDE_MLPW": "0"}), ("mlpv", {"LDE_MLP64": "0", "LDE_MLPW": "0"})):
+        for k_ in ("LDE_MLPV", "LDE_MLP64", "LDE_MLPW"):
             monkeypatch.delenv(k_, raising=False)
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)

@@ -706,12 +706,21 @@ int lde_chain_set_weights_device(lde_chain* c, const float* flat_dev, int64_t n,
 struct ChainPick { const ChainDims* cd; int cg; size_t lds; };
 static bool chain_pick(const lde_chain* c, const float* x, int64_t N, bool bwd, ChainPick* p) {
   const int cgx = bwd ? c->cgx_bwd : c->cgx_fwd, cg = bwd ? c->cg_bwd : c->cg_fwd;
+  // Mid-size batches (a training step's N = B·T ≈ 3 200 columns): the widest tile leaves most CUs without a workgroup —
+  // 50–100 tiles on 256 CUs — and a tile's time barely depends on its width (the weight fragments stream through the
+  // workgroup either way). Narrow the tile until the grid has ≈ 200 workgroups (measured, GOKU step: 2.06 → 1.88 ms).
+  static const bool fill = [] { const char* e = getenv("LDE_CHAIN_FILL"); return !e || atoi(e) != 0; }();
+  auto narrow = [&](const ChainDims& q, int cg0, size_t lds0) {
+    int g = cg0;
+    while (fill && g > 1 && (N + 16 * g - 1) / (16 * g) < 192) g /= 2;
+    return ChainPick{&q, g, g == cg0 ? lds0 : chain_lds(q, g, bwd ? 3 : 2)};
+  };
   if (cgx && N >= 16 * cgx && (((uintptr_t)x) & 15) == 0) {
-    *p = ChainPick{&c->cdx, cgx, bwd ? c->ldsx_bwd : c->ldsx_fwd};
+    *p = narrow(c->cdx, cgx, bwd ? c->ldsx_bwd : c->ldsx_fwd);
     return true;
   }
   if (!cg) return false;
-  *p = ChainPick{&c->cd, cg, bwd ? c->lds_bwd : c->lds_fwd};
+  *p = narrow(c->cd, cg, bwd ? c->lds_bwd : c->lds_fwd);
   return true;
 }
 
@@ -865,8 +874,25 @@ static int chain_backward_impl(lde_chain* c, const float* x, const float* y, con
   // weight gradient: large-K product over the staged panels (lde_mfma.h)
   DwArgs da;
   da.stage = c->stage; da.wts = c->wts; da.nslots = nullptr; da.slab = c->slab; da.cap = cap; da.total = total;   // tiles filled in order
+#if LDE_PROF
+  { (void)hipStreamSynchronize(stream); long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
+#endif
   rc = launch_weight_gradient(dm, da, nvt, 1, nullptr, c->ints, 0, dW, c->ints + 2, stream, c->err, !c->accumulate, c->bf16);
   if (rc) return rc;
+#if LDE_PROF
+  {
+    static int calls = 0;
+    (void)hipStreamSynchronize(stream);
+    long long v[64];
+    (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(g_prof), sizeof(v));
+    if (N > 1000 && ++calls % 20 == 0) {
+      fprintf(stderr, "[prof chain dw] nvt=%d cap=%d jobs=%d ndw=%d cycles:", nvt, cap, dw_jobs(dm, dw_pick_ndw(dm)), dw_pick_ndw(dm));
+      for (int i = 0; i < 64; i++)
+        if (v[i]) fprintf(stderr, " %d:%lld", i, v[i]);
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
   return LDE_OK;
 }
 

@@ -303,6 +303,7 @@ static __global__ void __launch_bounds__(512) k_mlp_dw(MlpDims dm, DwArgs a) {
     for (int q = 0; q < 4; q++) dv[q] = w != 0.f ? dv[q] * w : 0.f;
     return dv;
   };
+  PROF_T(dw0);
   if (part < ns) fetch(part);
   for (int e = part; e < ns; e += KS) {
     const float* blk = a.stage + ((size_t)tile * a.cap + e) * dm.blk_floats + dm.blk_off[l];
@@ -354,6 +355,10 @@ static __global__ void __launch_bounds__(512) k_mlp_dw(MlpDims dm, DwArgs a) {
     }
     __syncthreads();
   }
+  PROF_T(dw1);
+  PROF_ADD(50, dw0, dw1);
+  PROF_ADD(51, dw1 - (long long)ns, dw1);   // slots
+  PROF_ADD(52, dw1 - 1, dw1);               // workgroups counted
   float* slab = a.slab + ((size_t)tile * KS + part) * dm.slab_n;
 #pragma unroll
   for (int m = 0; m < DW_NDW; m++) {

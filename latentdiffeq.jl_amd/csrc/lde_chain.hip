@@ -650,6 +650,10 @@ int lde_chain_create(const lde_chain_desc* d, lde_chain** out) {
     c->cdx.gx = 1;
     c->cdx.ld0 = 0;
     pick(c->cdx, &c->cgx_fwd, &c->ldsx_fwd, &c->cgx_bwd, &c->ldsx_bwd);
+    if (const char* ex = getenv("LDE_CHAIN_CGX_FWD")) {   // experiments: the panel-free layout's forward tile alone
+      const int g = atoi(ex);
+      if ((g == 1 || g == 2 || g == 4) && chain_lds(c->cdx, g, 2) <= LDS_MAX) { c->cgx_fwd = g; c->ldsx_fwd = chain_lds(c->cdx, g, 2); }
+    }
   }
   if (!c->cg_fwd || !c->cg_bwd) {
     if (c->cgx_fwd && c->cgx_bwd) {   // only the panel-free layout fits: it needs N ≥ one tile (checked per call)
@@ -708,7 +712,8 @@ static bool chain_pick(const lde_chain* c, const float* x, int64_t N, bool bwd, 
   const int cgx = bwd ? c->cgx_bwd : c->cgx_fwd, cg = bwd ? c->cg_bwd : c->cg_fwd;
   // Mid-size batches (a training step's N = B·T ≈ 3 200 columns): the widest tile leaves most CUs without a workgroup —
   // 50–100 tiles on 256 CUs — and a tile's time barely depends on its width (the weight fragments stream through the
-  // workgroup either way). Narrow the tile until the grid has ≈ 200 workgroups (measured, GOKU step: 2.06 → 1.88 ms).
+  // workgroup either way). Narrow the tile until the grid has ≈ 200 workgroups (measured, GOKU training step at B = 64:
+  // 1.70 → 1.32 ms and 2.17 → 1.84 ms in two back-to-back pairs; at B = 256 the grids are full and nothing changes). LDE_CHAIN_FILL=0: off.
   static const bool fill = [] { const char* e = getenv("LDE_CHAIN_FILL"); return !e || atoi(e) != 0; }();
   auto narrow = [&](const ChainDims& q, int cg0, size_t lds0) {
     int g = cg0;

@@ -527,7 +527,8 @@ def test_one_mlp_handle_changing_shapes(o32, layers, batching, solver):
 
 
 @pytest.mark.parametrize("case", ["c2_rk4_coupled", "c3_per_traj", "c4_coupled", "tanh_per_traj_4d", "rk4_per_traj_small", "deep_4_layers",
-                                  "tsit5_d12_h150_coupled", "rk4_d20_h96_per_traj", "tanh_d8_h70_aug"])
+                                  "tsit5_d12_h150_coupled", "rk4_d20_h96_per_traj", "tanh_d8_h70_aug", "tanh_d8_h70_backsolve",
+                                  "relu_d32_h128_long_grid"])
 def test_kernel_families_agree(case, monkeypatch, o64):
     """Four kernel families serve the MLP right-hand sides: 16-column MFMA tiles (large batches; LDE_MLPV=0 LDE_MLP64=0 LDE_MLPW=0
     forces them), one trajectory per workgroup with lanes = hidden units (k_mlpv; LDE_MLP64=0 LDE_MLPW=0), one wave per trajectory
@@ -546,11 +547,15 @@ def test_kernel_families_agree(case, monkeypatch, o64):
         "tsit5_d12_h150_coupled": dict(layers=(12, 150, 137, 12), B=24, kw=dict(rhs_kind=O.RHS_MLP, state_dim=12, param_dim=0, activation=O.ACT_TANH, abstol=1e-7, reltol=1e-7, batching=O.BATCH_COUPLED), lim=1e-4),
         "rk4_d20_h96_per_traj": dict(layers=(20, 96, 128, 20), B=33, kw=dict(rhs_kind=O.RHS_MLP, state_dim=20, param_dim=0, solver=O.SOLVER_RK4, adaptive=0, dt=0.025, activation=O.ACT_TANH), lim=5e-6),
         "tanh_d8_h70_aug": dict(layers=(8, 70, 65, 8), B=26, kw=dict(rhs_kind=O.RHS_MLP, state_dim=6, augment_dim=2, param_dim=0, activation=O.ACT_TANH, abstol=1e-7, reltol=1e-7), lim=1e-4),
+        # the adjoint without restarts from the saved states (BacksolveAdjoint(checkpointing = false))
+        "tanh_d8_h70_backsolve": dict(layers=(8, 70, 65, 8), B=26, kw=dict(rhs_kind=O.RHS_MLP, state_dim=8, param_dim=0, activation=O.ACT_TANH, abstol=1e-7, reltol=1e-7, sensealg=O.SENSE_BACKSOLVE), lim=1e-4),
+        # 220 save times × 32 states: the cotangents no longer fit k_mlpw's LDS copy (the jump reads them from HBM)
+        "relu_d32_h128_long_grid": dict(layers=(32, 128, 128, 32), B=12, T=220, kw=dict(rhs_kind=O.RHS_MLP, state_dim=32, param_dim=0, abstol=1e-6, reltol=1e-6), lim=2e-3),
     }[case]
     layers, B, kw, lim = cfg["layers"], cfg["B"], dict(cfg["kw"], layers=cfg["layers"]), cfg["lim"]
     W = O.mlp_weights(layers, seed=8)
     D = kw.get("state_dim", 2)
-    T = 20
+    T = cfg.get("T", 20)
     ts = O.time_grid(T)
     if kw["rhs_kind"] == O.RHS_PENDULUM_PLUS_MLP:
         z0, L = O.pendulum_inputs(B)

@@ -18,6 +18,8 @@
 // tolerance. Limits: exactly three Dense layers D' → H₁ → H₂ → D' with H ≤ 64 and D' ∈ {2, 4}-padded, P ≤ 1, per-trajectory
 // control (coupled control needs the grid-wide sum: k_mlpv). Anything else runs k_mlpv / the tile kernels.
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {   // v + (v of the lane CTRL points at, 0 outside the row)
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
@@ -40,8 +42,9 @@ __device__ __forceinline__ float lane_bcast(float v, int k) {   // k compile-tim
 template <int DP>
 struct Net64 {
   float w1[DP], b1;        // row j of W₁ [H₁×D'], bias
-  float w2r[64], b2;       // row j of W₂ [H₂×H₁]
-  float w2c[64];           // column j of W₂: W₂[i][j], i < H₂
+  f32x2 w2r[32]; float b2; // row j of W₂ [H₂×H₁], as register pairs (v_pk_fma_f32)
+  f32x2 w2c[32];           // column j of W₂: W₂[i][j], i < H₂
+  float* hx;               // LDS: two 64-float vectors through which h₁ / δ₂ reach every lane (broadcast ds_read_b128)
   float w3c[DP];           // column j of W₃ [D'×H₂]: W₃[d][j]
   float b3[DP];            // uniform
   float ngl, gl2;          // pendulum: −G/L, G/L²
@@ -56,9 +59,23 @@ __device__ __forceinline__ void net64_rhs(Net64<DP>& n, const float (&z)[DP], fl
 #pragma unroll
   for (int k = 0; k < DP; k++) a1 += n.w1[k] * z[k];
   n.h1 = act_fn(n.act, a1);
+  // 64×64 product: h₁ goes through LDS once and comes back as 16 broadcast 16-byte reads feeding 32 packed FMAs on the lane's
+  // register row. (The v_readlane form — SGPR broadcast, one v_fmac per element — is 64 × (readlane, 2 wait states, fmac) on
+  // ONE accumulator: ≈ 770 cycles per product against ≈ 350 here.) One wave per workgroup: in-order LDS, no barrier.
+  n.hx[threadIdx.x] = n.h1;
+  asm volatile("" ::: "memory");
   float a2 = n.b2;
+  {
+    const f32x4* hv = reinterpret_cast<const f32x4*>(n.hx);
+    f32x2 c01 = {0.f, 0.f}, c23 = {0.f, 0.f};
 #pragma unroll
-  for (int k = 0; k < 64; k++) a2 += n.w2r[k] * lane_bcast(n.h1, k);
+    for (int g = 0; g < 16; g++) {
+      const f32x4 xv = hv[g];
+      c01 += n.w2r[2 * g] * xv.lo;
+      c23 += n.w2r[2 * g + 1] * xv.hi;
+    }
+    a2 += (c01.x + c01.y) + (c23.x + c23.y);
+  }
   n.h2 = act_fn(n.act, a2);
 #pragma unroll
   for (int d = 0; d < DP; d++) f[d] = n.b3[d] + wave_sum64(n.w3c[d] * n.h2);
@@ -76,9 +93,20 @@ __device__ __forceinline__ void net64_vjp(const Net64<DP>& n, const float (&z)[D
 #pragma unroll
   for (int d = 0; d < DP; d++) s2 += n.w3c[d] * lam[d];
   d2 = s2 * act_grad(n.act, n.h2);
-  float s1 = 0.f;
+  n.hx[64 + threadIdx.x] = d2;
+  asm volatile("" ::: "memory");
+  float s1;
+  {
+    const f32x4* hv = reinterpret_cast<const f32x4*>(n.hx + 64);
+    f32x2 c01 = {0.f, 0.f}, c23 = {0.f, 0.f};
 #pragma unroll
-  for (int i = 0; i < 64; i++) s1 += n.w2c[i] * lane_bcast(d2, i);
+    for (int g = 0; g < 16; g++) {
+      const f32x4 xv = hv[g];
+      c01 += n.w2c[2 * g] * xv.lo;
+      c23 += n.w2c[2 * g + 1] * xv.hi;
+    }
+    s1 = (c01.x + c01.y) + (c23.x + c23.y);
+  }
   d1 = s1 * act_grad(n.act, n.h1);
 #pragma unroll
   for (int k = 0; k < DP; k++) vz[k] = wave_sum64(n.w1[k] * d1);
@@ -105,10 +133,12 @@ __global__ void __launch_bounds__(64) k_mlp64(MlpDims dm, KOpts o, VArgs a) {
     for (int k = 0; k < DP; k++) n.w1[k] = (lane < H1 && k < Dp) ? W1[lane + H1 * k] : 0.f;
     n.b1 = lane < H1 ? W[dm.b_off[0] + lane] : 0.f;
 #pragma unroll
-    for (int k = 0; k < 64; k++) n.w2r[k] = (lane < H2 && k < H1) ? W2[lane + H2 * k] : 0.f;
+    for (int k = 0; k < 64; k++) n.w2r[k >> 1][k & 1] = (lane < H2 && k < H1) ? W2[lane + H2 * k] : 0.f;
     n.b2 = lane < H2 ? W[dm.b_off[1] + lane] : 0.f;
 #pragma unroll
-    for (int i = 0; i < 64; i++) n.w2c[i] = (ADJ && lane < H1 && i < H2) ? W2[i + H2 * lane] : 0.f;
+    for (int i = 0; i < 64; i++) n.w2c[i >> 1][i & 1] = (ADJ && lane < H1 && i < H2) ? W2[i + H2 * lane] : 0.f;
+    __shared__ __attribute__((aligned(16))) float s_hx[128];
+    n.hx = s_hx;
 #pragma unroll
     for (int d = 0; d < DP; d++) {
       n.w3c[d] = (lane < H2 && d < Dp) ? W3[d + Dp * lane] : 0.f;

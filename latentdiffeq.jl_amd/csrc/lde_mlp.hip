@@ -1343,6 +1343,8 @@ struct MlpPlan {
   bool w_ok = false;
   float* wpack = nullptr;
   unsigned epoch = 0;          // launch counter of k_mlpw's tagged grid-sum words
+  float* wslots = nullptr;     // k_mlpw's own [2][nWG][4] words ({value, tag} pairs): never shared with the float partials of grid_sum4
+  int wslots_cap = 0;
   float* frag = nullptr;
   float* fragT = nullptr;
   size_t nfrag = 0, nfragT = 0;
@@ -1537,6 +1539,7 @@ void mlp_plan_destroy(MlpPlan* p) {
   if (p->fragT) (void)hipFree(p->fragT);
   if (p->vecw) (void)hipFree(p->vecw);
   if (p->wpack) (void)hipFree(p->wpack);
+  if (p->wslots) (void)hipFree(p->wslots);
   if (p->counter) (void)hipFree(p->counter);
   if (p->abort_flag) (void)hipFree(p->abort_flag);
   if (p->slots) (void)hipFree(p->slots);
@@ -1555,8 +1558,7 @@ int mlp_reserve(MlpPlan* p, int B, int T, std::string& err) {
   if (nwg > p->cap_wg) {
     if (p->slots) (void)hipFree(p->slots);
     p->slots = nullptr;
-    if (hipMalloc(&p->slots, (size_t)2 * nwg * 4 * sizeof(float)) != hipSuccess ||
-        hipMemset(p->slots, 0, (size_t)2 * nwg * 4 * sizeof(float)) != hipSuccess) {   // k_mlpw's tagged words: no tag is 0
+    if (hipMalloc(&p->slots, (size_t)2 * nwg * 4 * sizeof(float)) != hipSuccess) {
       err = "MLP plan: hipMalloc(slots) failed";
       return LDE_ERR_ALLOC;
     }
@@ -1798,7 +1800,7 @@ static bool w_applicable(const MlpPlan* p, int B, bool coupled_adaptive) {
   return (long long)B * p->wd.W <= maxw;
 }
 template <int SOLVER, bool ADJ>
-static int launch_w(const MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t stream, std::string& err) {
+static int launch_w(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t stream, std::string& err) {
   MlpDims dmv = p->dm;
   WDims wdv = p->wd;
   KOpts ov = o;
@@ -1811,17 +1813,30 @@ static int launch_w(const MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipSt
   a.cot_lds = ADJ && cot <= 40 * 1024;   // the trajectory's dẑ (and saved ẑ) by save time: no global load inside the solve
   if (a.cot_lds) lds += cot;
   a.wpack = p->wpack;
-  if (coop) {   // tagged grid-sum words: a fresh epoch per launch, the buffer cleared when the 16-bit epoch wraps
-    MlpPlan* pm = const_cast<MlpPlan*>(p);
-    pm->epoch = (pm->epoch + 1) & 0xffffu;
-    if (pm->epoch == 0) {
-      if (hipMemsetAsync(p->slots, 0, (size_t)2 * p->cap_wg * 4 * sizeof(float), stream) != hipSuccess) {
-        err = "hipMemsetAsync(slots) failed";
+  if (coop) {   // tagged grid-sum words: an own buffer (zeroed: no tag is 0), a fresh epoch per launch, cleared when the epoch wraps
+    const size_t bytes = (size_t)2 * (o.B + 1) * 4 * sizeof(float);
+    if (o.B + 1 > p->wslots_cap) {
+      if (p->wslots) (void)hipFree(p->wslots);
+      p->wslots = nullptr;
+      p->wslots_cap = 0;
+      if (hipMalloc(&p->wslots, bytes) != hipSuccess || hipMemsetAsync(p->wslots, 0, bytes, stream) != hipSuccess) {
+        (void)hipGetLastError();
+        err = "MLP plan: hipMalloc of the grid-sum words failed";
+        return LDE_ERR_ALLOC;
+      }
+      p->wslots_cap = o.B + 1;
+      p->epoch = 0;
+    }
+    p->epoch = (p->epoch + 1) & 0xffffu;
+    if (p->epoch == 0) {
+      if (hipMemsetAsync(p->wslots, 0, (size_t)2 * p->wslots_cap * 4 * sizeof(float), stream) != hipSuccess) {
+        err = "hipMemsetAsync(grid-sum words) failed";
         return LDE_ERR_HIP;
       }
-      pm->epoch = 1;
+      p->epoch = 1;
     }
-    a.epoch = pm->epoch;
+    a.epoch = p->epoch;
+    a.gs.slots = p->wslots;
   }
 #if LDE_PROF
   prof_reset();

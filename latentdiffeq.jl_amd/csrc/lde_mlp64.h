@@ -4,14 +4,16 @@
 // BASELINE.json configs[2] — GOKU pendulum + a 2-64-64-2 MLP, Tsit5, B = 1024 with adjoint — is 1024 independent adaptive
 // solves of a 2-dimensional state through a network of 4.4 k weights. In k_mlpv (one trajectory per workgroup, activations and
 // state in LDS) every product is a chain of ≈ 100-cycle LDS round trips: ≈ 1 300 cycles per layer for 64×64 work, 5.8 µs per
-// evaluation of the adjoint. Here nothing leaves the register file:
+// evaluation of the adjoint. Here weights, state and control stay in the register file:
 //   * lane j owns hidden unit j of both hidden layers (widths ≤ 64); its rows of W₁, W₂, its COLUMNS of W₂, W₃ and its biases
 //     are loaded once into VGPRs (≈ 140 of them);
-//   * a 64×64 product is 64 × (v_readlane_b32 → SGPR, v_fmac with that SGPR): the activation of unit k reaches every lane through
-//     the scalar register file, no LDS, no wait — and Wᵀδ is the same loop over the lane's column;
+//   * a 64×64 product: the 64 activations go through a 256-byte LDS vector once (one ds_write per lane, one wave per workgroup:
+//     in-order LDS, no barrier) and come back as 16 broadcast ds_read_b128 feeding 32 v_pk_fma_f32 on the lane's register row
+//     held as pairs — and Wᵀδ is the same loop over the lane's column. (First version: 64 × (v_readlane_b32 → SGPR, v_fmac):
+//     one scalar register, two wait states and one accumulator per element — ≈ 770 cycles per product against ≈ 350.)
 //   * the D' ≤ 4 outputs are wave sums (four DPP row shifts + four readlanes each);
 //   * the state [z; λ; g], the seven slopes and the whole step control are wave-uniform values that every lane carries
-//     redundantly (a SIMT machine does that for free), so an evaluation is ≈ 350 instructions with no memory access besides the
+//     redundantly (a SIMT machine does that for free), so an evaluation touches no memory besides those LDS vectors and the
 //     staging stores of the weight gradient's (a_l, δ_l) panels, which nobody waits for.
 // Same algorithm and control arithmetic as k_mlp_adjoint / k_mlpv (HNW initial step, PI controller carried across the save
 // times, k₁ re-evaluated every attempt, quadrature weights written at accept time, k_mlp_dw forms dW): agreement to solver

@@ -79,7 +79,7 @@ static __global__ void k_build_wpack(const float* __restrict__ Wflat, MlpDims dm
 // carries the current tag, then adds the values in index order (lane w mod 64 ascending, DPP wave sum) — identical bits in every
 // wave of every workgroup, no counter, no LDS reduction. Two buffers by generation parity: a workgroup publishes generation
 // g + 2 only after it has read all of g + 1, which every workgroup wrote after it finished reading g. Stale words of earlier
-// launches carry another epoch (the host clears the buffer when the 16-bit epoch wraps).
+// launches carry another epoch (the words live in a buffer of their own, zeroed when allocated and when the 16-bit epoch wraps).
 template <bool TWO>
 __device__ __forceinline__ void w_grid_sum(const GridSync& gs, unsigned& gen, unsigned epoch, float& v0, float& v1) {
   if (gs.nwg == 1) return;

@@ -1,6 +1,7 @@
 #!/bin/bash
 # round-2 evidence: rocprofv3 kernel trace + FETCH_SIZE / WRITE_SIZE passes and the plain bench line for every workload
 cd "$GRAFT_REPO_ROOT"
+python bench.py --workload goku_step --steps 30 --warmup 10 --no-cpu-baseline > /dev/null 2>&1   # a fresh box runs its first process ≈ 8 % slow
 bash profiles/collect.sh r2_goku_pendulum_b256 --steps 200 --warmup 20 --no-cpu-baseline > /dev/null 2>&1
 python bench.py --steps 200 --warmup 20 --sweep > gpurun_out/bench_metric.json 2> gpurun_out/bench_metric.err
 for w in c2 c3 c4; do

@@ -1790,9 +1790,13 @@ static int launch_vec(const MlpPlan* p, const KOpts& o, VArgs& a, size_t lds, bo
 }
 
 // ---- W waves per trajectory, weights and state in registers (lde_mlpw.h)
-static bool w_applicable(const MlpPlan* p, int B, bool coupled_adaptive) {
+static size_t w_lds_base(const WDims& wd, int T, bool adj) {   // save times, state copies, exchange buffers, narrow slices
+  return (((size_t)T * 8 + 15) & ~size_t(15)) + (size_t)(wd.W * 64 + 2 * wd.HX) * 4 + (size_t)wd.GS * 64 * 16 * (adj ? 2 : 1) + 16;
+}
+static bool w_applicable(const MlpPlan* p, int B, int T, bool adj, bool coupled_adaptive) {
   const char* e = getenv("LDE_MLPW");   // read per call: the tests switch kernels inside one process
   if (!p->w_ok || (e && atoi(e) == 0)) return false;
+  if (w_lds_base(p->wd, T, adj) > LDS_MAX * p->wd.W / 4) return false;   // 4/W workgroups share a CU's LDS (one wave per SIMD)
   // one wave per SIMD (the weights take most of the 512 registers): 1024 waves are resident at once; an uncoupled solve may
   // queue a second round, a coupled one needs every trajectory resident
   const char* m = getenv("LDE_MLPW_MAX_WAVES");
@@ -1807,11 +1811,29 @@ static int launch_w(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t
   const bool d8 = wdv.DP == 8, w2 = wdv.W == 2;
   const void* fn = w2 ? (d8 ? (const void*)k_mlpw<SOLVER, 8, 128, 2, ADJ> : (const void*)k_mlpw<SOLVER, 32, 128, 2, ADJ>)
                       : (d8 ? (const void*)k_mlpw<SOLVER, 8, 200, 4, ADJ> : (const void*)k_mlpw<SOLVER, 32, 200, 4, ADJ>);
-  size_t lds = (((size_t)o.T * 8 + 15) & ~size_t(15)) + (size_t)(wdv.W * 64 + 2 * wdv.HX) * 4 +
-               (size_t)wdv.GS * 64 * 16 * (ADJ ? 2 : 1) + 16;
+  size_t lds = w_lds_base(wdv, o.T, ADJ);
   const size_t cot = ADJ ? (size_t)o.T * dmv.Dp * 4 * (o.checkpoint ? 2 : 1) : 0;
-  a.cot_lds = ADJ && cot <= 40 * 1024;   // the trajectory's dẑ (and saved ẑ) by save time: no global load inside the solve
+  a.cot_lds = ADJ && cot <= 40 * 1024 && lds + cot <= LDS_MAX * wdv.W / 4;   // the trajectory's dẑ (and saved ẑ) by save time: no global load inside the solve
   if (a.cot_lds) lds += cot;
+  if (lds > LDS_MAX) {
+    err = "k_mlpw: the save-time grid does not fit LDS";
+    return LDE_ERR_UNSUPPORTED;
+  }
+  {   // dynamic LDS beyond the default limit needs the attribute, once per instantiation
+    static bool attr_set[2][2] = {{false, false}, {false, false}};
+    if (!attr_set[d8][w2]) {
+      hipFuncAttributes fa{};
+      (void)hipFuncGetAttributes(&fa, fn);
+      const hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX - (int)fa.sharedSizeBytes);
+      if (ea != hipSuccess) {
+        (void)hipGetLastError();
+        err = std::string("hipFuncSetAttribute(k_mlpw) failed: ") + hipGetErrorString(ea) + " d8=" + std::to_string(d8) + " w2=" + std::to_string(w2) +
+              " adj=" + std::to_string(ADJ) + " static=" + std::to_string(fa.sharedSizeBytes) + " regs=" + std::to_string(fa.numRegs);
+        return LDE_ERR_HIP;
+      }
+      attr_set[d8][w2] = true;
+    }
+  }
   a.wpack = p->wpack;
   if (coop) {   // tagged grid-sum words: an own buffer (zeroed: no tag is 0), a fresh epoch per launch, cleared when the epoch wraps
     const size_t bytes = (size_t)2 * (o.B + 1) * 4 * sizeof(float);
@@ -1861,7 +1883,7 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
   {   // small batches: one trajectory per workgroup, lanes = hidden units (lde_mlpv.h)
     size_t ldsv = 0;
     const bool ca = dm.coupled && o.adaptive && o.B > 1;
-    const bool use_w = w_applicable(p, o.B, ca);
+    const bool use_w = w_applicable(p, o.B, o.T, false, ca);
     if (use_w || vec_applicable(p, o.B, o.T, false, ca, &ldsv, err)) {
       VArgs va{};
       va.z0 = z0; va.theta = theta; va.ts = ts_dev; va.vecw = p->vecw; va.Wflat = W_dev; va.z_out = z_out; va.retcode = retcode;
@@ -2057,7 +2079,7 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
   if (!vec_done) {   // small batches: one trajectory per workgroup, lanes = hidden units (lde_mlpv.h)
     size_t ldsv = 0;
     const bool ca = dm.coupled && o.adaptive && o.B > 1;
-    const bool use_w = w_applicable(p, o.B, ca);
+    const bool use_w = w_applicable(p, o.B, o.T, true, ca);
     if (use_w || vec_applicable(p, o.B, o.T, true, ca, &ldsv, err)) {
       if (hipMemsetAsync(p->fb_dev, 0, 2 * sizeof(int32_t), stream) != hipSuccess ||
           hipMemsetAsync(p->nslots, 0, (size_t)2 * (nwg + 1) * sizeof(int32_t), stream) != hipSuccess ||

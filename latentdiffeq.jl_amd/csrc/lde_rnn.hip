@@ -33,6 +33,8 @@
 
 namespace lde {
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
 constexpr int RNN_ML = LDE_RNN_MAX_LAYERS;
 
 struct RnnDims {
@@ -105,10 +107,15 @@ __host__ __device__ constexpr int rnn_ldk(int K) { int v = (K + 3) & ~3; return 
 // pattern extractors [REF src/models/GOKU.jl:229-238] —: every loop bound and LDS stride is then a compile-time constant, the
 // layer loops unroll, and the per-layer kernel-argument reads, the short runtime loops and the vmcnt(0) waits they force
 // (the prefetched frame / record behind a variable number of staging stores) disappear. CELL_ = −1: any shape, at run time.
-template <int CELL_, int IN0_, int H_, int L_, int MODE_>
-__global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
+// REGW (specialised shapes launched with ONE wave per workgroup — every small batch): each lane copies its rows of [Wi | Wh]
+// (and, for the pullback, of the transposed copy) from LDS into registers once; a dot product is then K/4 broadcast reads of
+// [x; h] feeding v_pk_fma_f32 on register pairs — half the LDS instructions and half the FMA issue slots of the LDS-row form
+// (measured per (step, layer) on the LSTM stack: forward product 610 → ≈ 330 cycles, Wᵀδ 940 → ≈ 450).
+template <int CELL_, int IN0_, int H_, int L_, int MODE_, bool REGW = false>
+__global__ void __launch_bounds__(REGW ? 64 : 1024) k_rnn(RnnDims rd, RnnArgs a) {
   extern __shared__ __attribute__((aligned(16))) float rsm[];
   constexpr bool SP = CELL_ >= 0;
+  static_assert(!REGW || SP, "register-resident weights need a compile-time shape");
   constexpr int UL = SP ? L_ : 1, UK = SP ? 16 : 4;   // unroll factors: layer loops, dot-product loops
   const int cellk = SP ? CELL_ : rd.cell;
   const bool lstm = cellk == LDE_CELL_LSTM;
@@ -128,6 +135,35 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
   float* dhs = lw + rd.lds_w + tpw * (rd.vmax + rd.rmax + 2 * L * hmaxv) + tr * (2 * L * hmaxv);   // dh, dc
   float* dcs = dhs + L * hmaxv;
   rnn_load_weights(rd, a.Wflat, lw, nthr, mode == 1);
+  // REGW: the lane's weight rows, as float4 groups (zero padded like the LDS rows)
+  constexpr int GC = SP ? (CELL_ == LDE_CELL_LSTM ? 4 : 1) : 1;
+  constexpr int HPC = SP ? rnn_pow2(GC * (H_ > 0 ? H_ : 1)) : 1;                 // lanes per trajectory
+  constexpr int KF4 = REGW ? (IN0_ + H_ + 3) / 4 : 1;                             // float4 groups of the widest forward row
+  constexpr int RB4 = REGW ? (GC * H_ + 3) / 4 : 1;                               // float4 groups of a transposed row (R = G·h)
+  constexpr int NKI = REGW ? (IN0_ + H_ + HPC - 1) / HPC : 1;                      // outputs of Wᵀδ per lane
+  f32x4 wrow[REGW ? L_ : 1][KF4];
+  f32x4 wcol[(REGW && MODE_ == 1) ? L_ : 1][(REGW && MODE_ == 1) ? NKI : 1][(REGW && MODE_ == 1) ? RB4 : 1];
+  if (REGW) {
+#pragma unroll
+    for (int l = 0; l < (REGW ? L_ : 0); l++) {
+      const int K = size_of(l) + size_of(l + 1), ldk = ldk_of(l), Rl = GC * size_of(l + 1);
+      const float* wr = lw + rd.w_off[l] + (u < Rl ? u : 0) * ldk;
+#pragma unroll
+      for (int k4 = 0; k4 < KF4; k4++)
+        wrow[l][k4] = (u < Rl && 4 * k4 < K) ? *reinterpret_cast<const f32x4*>(wr + 4 * k4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      if (MODE_ == 1) {
+        const int ldr = rnn_ldk(Rl);
+#pragma unroll
+        for (int q = 0; q < ((REGW && MODE_ == 1) ? NKI : 0); q++) {
+          const int k = u + q * HPC;
+          const float* wk = lw + rd.wt_off[l] + (k < K ? k : 0) * ldr;
+#pragma unroll
+          for (int r4 = 0; r4 < RB4; r4++)
+            wcol[l][q][r4] = (k < K && 4 * r4 < Rl) ? *reinterpret_cast<const f32x4*>(wk + 4 * r4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+      }
+    }
+  }
   const long long b = (long long)blockIdx.x * tpw + tr;
   const bool valid = b < B;
   const size_t tile = (size_t)(b >> 4);   // staging tile (16 trajectories = one column slot of the weight-gradient kernel)
@@ -189,7 +225,20 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
       PROF_T(p2);
       PROF_ADD(1, p1, p2);
       const int Rl = G * h;
-      if (u < Rl) {
+      if (REGW) {
+        if (u < Rl) {
+          f32x2 c01 = {0.f, 0.f}, c23 = {0.f, 0.f};
+#pragma unroll
+          for (int k4 = 0; k4 < KF4; k4++) {
+            if (4 * k4 < K) {   // (compile-time after unrolling: layer 1's rows are shorter)
+              const f32x4 xv = *reinterpret_cast<const f32x4*>(vbuf + 4 * k4);
+              c01 += wrow[REGW ? l : 0][k4].lo * xv.lo;
+              c23 += wrow[REGW ? l : 0][k4].hi * xv.hi;
+            }
+          }
+          dbuf[u] = lw[rd.b_off[l] + u] + ((c01.x + c01.y) + (c23.x + c23.y));
+        }
+      } else if (u < Rl) {
         const int K4 = (K + 3) >> 2;
         const float* wr = lw + rd.w_off[l] + u * ldk;
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -305,6 +354,27 @@ __global__ void __launch_bounds__(1024) k_rnn(RnnDims rd, RnnArgs a) {
       PROF_ADD(12, q2, q3);
       // [d_in ; dh_prev] = [Wi | Wh]ᵀ δ: lane u owns the outputs k = u, u+Hp, …; four rows of δ per step, independent sums
       const bool wt = SP || rd.wt;
+      if (REGW) {
+#pragma unroll
+        for (int q = 0; q < ((REGW && MODE_ == 1) ? NKI : 0); q++) {
+          const int k = u + q * HPC;
+          if (k < K) {
+            f32x2 c01 = {0.f, 0.f}, c23 = {0.f, 0.f};
+#pragma unroll
+            for (int r4 = 0; r4 < RB4; r4++) {
+              const f32x4 dq = *reinterpret_cast<const f32x4*>(dbuf + 4 * r4);
+              c01 += wcol[(REGW && MODE_ == 1) ? l : 0][q][r4].lo * dq.lo;
+              c23 += wcol[(REGW && MODE_ == 1) ? l : 0][q][r4].hi * dq.hi;
+            }
+            const float acc = (c01.x + c01.y) + (c23.x + c23.y);
+            if (k < in) {
+              if (l > 0) dhs[(l - 1) * hmaxv + k] += acc;
+              else if (a.dx && valid) a.dx[(size_t)in0 * ((size_t)b + (size_t)B * t) + k] = acc;
+            } else
+              dhs[l * hmaxv + (k - in)] = acc;
+          }
+        }
+      } else
       for (int k = u; k < K; k += Hp) {
         const float* wc = lw + rd.w_off[l] + k;
         f32x4 acc4 = {0.f, 0.f, 0.f, 0.f};
@@ -396,7 +466,7 @@ struct lde_rnn {
   float* slab = nullptr; size_t slab_cap = 0;
   int32_t* ints = nullptr; size_t ints_cap = 0;
   bool accumulate = true;   // pullback: dW += gradient (default) or dW = gradient
-  void (*kernel[2])(lde::RnnDims, lde::RnnArgs) = {nullptr, nullptr};   // the k_rnn instantiations for this stack: forward, pullback
+  void (*kernel[2][2])(lde::RnnDims, lde::RnnArgs) = {{nullptr, nullptr}, {nullptr, nullptr}};   // the k_rnn instantiations for this stack: [forward, pullback][any workgroup size, one wave per workgroup]
   std::string err;
 };
 
@@ -567,8 +637,14 @@ typedef void (*rnn_kernel_t)(RnnDims, RnnArgs);
 
 // the instantiation for this stack: the reference's default pattern extractors (32 → 16 → 16) have their own, any other shape
 // runs the run-time-shaped kernel
-static rnn_kernel_t rnn_pick(const RnnDims& rd, int mode) {
+static rnn_kernel_t rnn_pick(const RnnDims& rd, int mode, bool one_wave = false) {
   static const bool generic_only = std::getenv("LDE_RNN_GENERIC") && std::atoi(std::getenv("LDE_RNN_GENERIC")) != 0;
+  static const bool regw_on = !(std::getenv("LDE_RNN_REGW") && std::atoi(std::getenv("LDE_RNN_REGW")) == 0);
+  if (!generic_only && regw_on && one_wave && rd.wt && rd.nL == 2 && rd.sizes[0] == 32 && rd.sizes[1] == 16 && rd.sizes[2] == 16) {
+    if (rd.cell == LDE_CELL_LSTM) return mode ? k_rnn<LDE_CELL_LSTM, 32, 16, 2, 1, true> : k_rnn<LDE_CELL_LSTM, 32, 16, 2, 0, true>;
+    if (rd.cell == LDE_CELL_RNN_RELU) return mode ? k_rnn<LDE_CELL_RNN_RELU, 32, 16, 2, 1, true> : k_rnn<LDE_CELL_RNN_RELU, 32, 16, 2, 0, true>;
+    if (rd.cell == LDE_CELL_RNN_TANH) return mode ? k_rnn<LDE_CELL_RNN_TANH, 32, 16, 2, 1, true> : k_rnn<LDE_CELL_RNN_TANH, 32, 16, 2, 0, true>;
+  }
   if (!generic_only && rd.wt && rd.nL == 2 && rd.sizes[0] == 32 && rd.sizes[1] == 16 && rd.sizes[2] == 16) {
     if (rd.cell == LDE_CELL_LSTM) return mode ? k_rnn<LDE_CELL_LSTM, 32, 16, 2, 1> : k_rnn<LDE_CELL_LSTM, 32, 16, 2, 0>;
     if (rd.cell == LDE_CELL_RNN_RELU) return mode ? k_rnn<LDE_CELL_RNN_RELU, 32, 16, 2, 1> : k_rnn<LDE_CELL_RNN_RELU, 32, 16, 2, 0>;
@@ -579,14 +655,6 @@ static rnn_kernel_t rnn_pick(const RnnDims& rd, int mode) {
 
 static int rnn_launch(lde_rnn* r, const RnnArgs& a, int B, hipStream_t stream) {
   const int m = a.mode ? 1 : 0;
-  if (!r->kernel[m]) {
-    r->kernel[m] = rnn_pick(r->rd, m);
-    if (hipFuncSetAttribute((const void*)r->kernel[m], hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
-      r->kernel[m] = nullptr;
-      r->err = "hipFuncSetAttribute(k_rnn) failed";
-      return LDE_ERR_HIP;
-    }
-  }
   // Trajectories per workgroup. The sweep is sequential in time and every trajectory re-reads the cell's weights from LDS
   // at every step, so a small batch is spread over as many CUs as it has waves (one wave per workgroup: the LDS of a CU then
   // serves one wave instead of sixteen); only a batch that would exceed ~4 workgroups per CU packs more trajectories
@@ -595,6 +663,15 @@ static int rnn_launch(lde_rnn* r, const RnnArgs& a, int B, hipStream_t stream) {
   int tpw = std::max(1, 64 / r->rd.Hp);
   while (tpw < 16 && cdiv(B, tpw) > 1024) tpw *= 2;
   if (tpw_env == 1 || tpw_env == 2 || tpw_env == 4 || tpw_env == 8 || tpw_env == 16) tpw = tpw_env;
+  const int one = tpw * r->rd.Hp == 64 ? 1 : 0;   // one wave per workgroup: the register-resident-weights instantiation
+  if (!r->kernel[m][one]) {
+    r->kernel[m][one] = rnn_pick(r->rd, m, one != 0);
+    if (hipFuncSetAttribute((const void*)r->kernel[m][one], hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
+      r->kernel[m][one] = nullptr;
+      r->err = "hipFuncSetAttribute(k_rnn) failed";
+      return LDE_ERR_HIP;
+    }
+  }
   RnnArgs aa = a;
   aa.tpw = tpw;
   const size_t lds = ((size_t)r->rd.lds_w + tpw * ((size_t)r->rd.vmax + r->rd.rmax + 4 * r->rd.nL * r->rd.hmax)) * sizeof(float);
@@ -602,7 +679,7 @@ static int rnn_launch(lde_rnn* r, const RnnArgs& a, int B, hipStream_t stream) {
 #if LDE_PROF
   { long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
 #endif
-  hipLaunchKernelGGL(r->kernel[m], dim3(cdiv(B, 16) * (16 / tpw)), dim3(tpw * r->rd.Hp), lds, stream, r->rd, aa);
+  hipLaunchKernelGGL(r->kernel[m][one], dim3(cdiv(B, 16) * (16 / tpw)), dim3(tpw * r->rd.Hp), lds, stream, r->rd, aa);
   if (hipGetLastError() != hipSuccess) {
     r->err = "k_rnn launch failed";
     return LDE_ERR_HIP;

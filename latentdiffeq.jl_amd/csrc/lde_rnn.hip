@@ -639,8 +639,7 @@ typedef void (*rnn_kernel_t)(RnnDims, RnnArgs);
 // runs the run-time-shaped kernel
 static rnn_kernel_t rnn_pick(const RnnDims& rd, int mode, bool one_wave = false) {
   static const bool generic_only = std::getenv("LDE_RNN_GENERIC") && std::atoi(std::getenv("LDE_RNN_GENERIC")) != 0;
-  static const bool regw_on = !(std::getenv("LDE_RNN_REGW") && std::atoi(std::getenv("LDE_RNN_REGW")) == 0);
-  if (!generic_only && regw_on && one_wave && rd.wt && rd.nL == 2 && rd.sizes[0] == 32 && rd.sizes[1] == 16 && rd.sizes[2] == 16) {
+  if (!generic_only && one_wave && rd.wt && rd.nL == 2 && rd.sizes[0] == 32 && rd.sizes[1] == 16 && rd.sizes[2] == 16) {
     if (rd.cell == LDE_CELL_LSTM) return mode ? k_rnn<LDE_CELL_LSTM, 32, 16, 2, 1, true> : k_rnn<LDE_CELL_LSTM, 32, 16, 2, 0, true>;
     if (rd.cell == LDE_CELL_RNN_RELU) return mode ? k_rnn<LDE_CELL_RNN_RELU, 32, 16, 2, 1, true> : k_rnn<LDE_CELL_RNN_RELU, 32, 16, 2, 0, true>;
     if (rd.cell == LDE_CELL_RNN_TANH) return mode ? k_rnn<LDE_CELL_RNN_TANH, 32, 16, 2, 1, true> : k_rnn<LDE_CELL_RNN_TANH, 32, 16, 2, 0, true>;
@@ -663,7 +662,8 @@ static int rnn_launch(lde_rnn* r, const RnnArgs& a, int B, hipStream_t stream) {
   int tpw = std::max(1, 64 / r->rd.Hp);
   while (tpw < 16 && cdiv(B, tpw) > 1024) tpw *= 2;
   if (tpw_env == 1 || tpw_env == 2 || tpw_env == 4 || tpw_env == 8 || tpw_env == 16) tpw = tpw_env;
-  const int one = tpw * r->rd.Hp == 64 ? 1 : 0;   // one wave per workgroup: the register-resident-weights instantiation
+  const char* erw = std::getenv("LDE_RNN_REGW");   // read per call: the tests compare the two instantiations inside one process
+  const int one = (tpw * r->rd.Hp == 64 && !(erw && std::atoi(erw) == 0)) ? 1 : 0;   // one wave per workgroup: the register-resident-weights instantiation
   if (!r->kernel[m][one]) {
     r->kernel[m][one] = rnn_pick(r->rd, m, one != 0);
     if (hipFuncSetAttribute((const void*)r->kernel[m][one], hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {

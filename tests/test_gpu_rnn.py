@@ -193,6 +193,28 @@ def test_instantiated_and_run_time_shaped_kernels_agree(tmp_path):
         assert np.abs(a - b).max() <= 2e-6 * max(np.abs(b).max(), 1e-30), k
 
 
+@pytest.mark.parametrize("cell", [O.CELL_LSTM, O.CELL_RNN_RELU, O.CELL_RNN_TANH])
+def test_register_and_lds_weight_rows_agree(cell, monkeypatch):
+    """Small batches of the default stacks run one wave per workgroup with the weight rows in registers (packed FMAs);
+    LDE_RNN_REGW=0 keeps them in LDS (the instantiation larger batches use). Same sums in a different association: round-off."""
+    from tests.gpu_util import NativeRnn
+    sizes, T, B = (32, 16, 16), 23, 37
+    W = O.rnn_weights(cell, sizes, seed=9)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((T, B, sizes[0])).astype(np.float32)
+    dy = (rng.standard_normal((B, sizes[-1])) / B).astype(np.float32)
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LDE_RNN_REGW", flag)
+        nat = NativeRnn(cell, sizes, True)
+        nat.set_weights(W)
+        y = nat.forward(x)
+        dx, dW = nat.backward(x, dy)
+        res.append((y, dx, dW))
+    for a, b, what in zip(res[0], res[1], ("y", "dx", "dW")):
+        assert np.abs(a - b).max() <= 5e-6 * max(np.abs(b).max(), 1e-30), what
+
+
 def test_branch_streams_match_joined_streams():
     """encode() with the z₀ / θ branches kept on their own HIP streams to the end (default) against the variant that joins the
     streams after the recurrent stacks, over several iterations with changing (B, T) — allocator reuse across streams would

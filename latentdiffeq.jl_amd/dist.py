@@ -54,37 +54,129 @@ def shard_columns(x: Optional[torch.Tensor], rank: int, world: int, dim: int = -
 
 
 class FlatGradAllReduce:
-    """Sum-all-reduce the .grad of a set of shared parameters as ONE flat fp32 message.
+    """Data-parallel gradient sum over the parameters of a model: ONE persistent flat f32 buffer, the parameters' `.grad`
+    fields are VIEWS into it (`attach()`), so a step packs and unpacks nothing — the collective runs on the buffer the
+    backward wrote. The buffer is cut into `buckets` contiguous pieces in the order the backward finishes them (the last
+    parameters first): each piece's all-reduce is issued asynchronously from a post-accumulate hook as soon as its last
+    gradient is written, i.e. it overlaps the rest of the backward; `__call__()` (after `backward()`) issues what is left and
+    waits. Zero the gradients with `zero_()` (or `zero_grad(set_to_none=False)`): setting them to None detaches the views —
+    that is detected, and the step then falls back to one multi-tensor pack / unpack (`torch._foreach_copy_`), still one
+    message per bucket. [north star: RCCL all-reduce of dθ once per optimiser step; REF has no multi-device path]
 
-    The loss is a mean over the global batch [REF examples/pendulum_friction-less/model_train.jl:232]: fold the 1/N
-    into the cotangent (each rank's loss divides by the GLOBAL batch) and a plain sum is exact.
+    Each rank's loss must already be divided by the GLOBAL batch (the loss terms take `batch_global`), so a plain sum is exact.
     """
 
-    def __init__(self, params: Iterable[torch.nn.Parameter], group=None):
+    def __init__(self, params: Iterable[torch.nn.Parameter], group=None, buckets: int = 2, attach: bool = False):
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         self.group = group
+        self.nbuckets = max(1, int(buckets))
         self._flat: Optional[torch.Tensor] = None
+        self._views: List[torch.Tensor] = []
+        self._bucket_of: List[int] = []
+        self._bounds: List[tuple] = []
+        self._pending: List[int] = []
+        self._handles: list = []
+        self._hooks: list = []
+        self._issued: List[bool] = []
+        if attach:
+            self.attach()
+
+    # ---- layout -------------------------------------------------------------------------------------------------------
+    def _active(self) -> bool:
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+
+    def _build(self, device) -> None:
+        n = sum(p.numel() for p in self.params)
+        self._flat = torch.zeros(n, dtype=torch.float32, device=device)
+        self._views, off = [], 0
+        for p in self.params:
+            self._views.append(self._flat[off:off + p.numel()].view_as(p))
+            off += p.numel()
+        # buckets: contiguous runs of parameters with about n / nbuckets elements each
+        self._bucket_of, self._bounds = [], []
+        target, start, acc, b = n / self.nbuckets, 0, 0, 0
+        for i, p in enumerate(self.params):
+            self._bucket_of.append(b)
+            acc += p.numel()
+            last = i == len(self.params) - 1
+            if (acc - start >= target and b < self.nbuckets - 1) or last:
+                self._bounds.append((start, acc))
+                start, b = acc, b + 1
+        self._reset_step()
+
+    def _reset_step(self) -> None:
+        nb = len(self._bounds)
+        self._pending = [0] * nb
+        for b in self._bucket_of:
+            self._pending[b] += 1
+        self._issued = [False] * nb
+        self._handles = []
+
+    def attach(self) -> "FlatGradAllReduce":
+        """Allocate the flat buffer and make every parameter's .grad a view into it (zeros); install the overlap hooks."""
+        if not self.params:
+            return self
+        self._build(self.params[0].device)
+        for p, v in zip(self.params, self._views):
+            p.grad = v
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
+        if hasattr(torch.Tensor, "register_post_accumulate_grad_hook"):
+            for i, p in enumerate(self.params):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+        return self
+
+    def zero_(self) -> None:
+        """Zero all gradients in one fill (keeps the views attached)."""
+        if self._flat is not None:
+            self._flat.zero_()
+            self._reset_step()
+
+    def _attached(self) -> bool:
+        return self._flat is not None and all(p.grad is not None and p.grad.data_ptr() == v.data_ptr()
+                                              for p, v in zip(self.params, self._views))
+
+    # ---- the collective -----------------------------------------------------------------------------------------------
+    def _issue(self, b: int) -> None:
+        if self._issued[b]:
+            return
+        self._issued[b] = True
+        lo, hi = self._bounds[b]
+        self._handles.append(dist.all_reduce(self._flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+
+    def _make_hook(self, i: int):
+        def hook(param):
+            if not self._active() or self._flat is None or param.grad is None or param.grad.data_ptr() != self._views[i].data_ptr():
+                return
+            b = self._bucket_of[i]
+            self._pending[b] -= 1
+            if self._pending[b] == 0:
+                self._issue(b)
+        return hook
 
     def __call__(self) -> None:
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+        if not self._active():
             return
         ps = [p for p in self.params if p.grad is not None]
         if not ps:
             return
-        n = sum(p.grad.numel() for p in ps)
-        if self._flat is None or self._flat.numel() != n or self._flat.device != ps[0].grad.device:
-            self._flat = torch.empty(n, dtype=torch.float32, device=ps[0].grad.device)
-        off = 0
-        for p in ps:
-            k = p.grad.numel()
-            self._flat[off:off + k].copy_(p.grad.reshape(-1))
-            off += k
+        if self._attached():
+            for b in range(len(self._bounds)):
+                self._issue(b)
+            for h in self._handles:
+                h.wait()
+            self._reset_step()
+            return
+        # detached gradients (zero_grad(set_to_none=True), or never attached): one multi-tensor pack, one message, one unpack
+        if len(ps) != len(self.params):
+            raise RuntimeError("FlatGradAllReduce: every parameter needs a gradient (a missing one would desynchronise the ranks)")
+        if self._flat is None or self._flat.device != ps[0].grad.device:
+            self._build(ps[0].grad.device)
+        torch._foreach_copy_(self._views, [p.grad for p in ps])
         dist.all_reduce(self._flat, op=dist.ReduceOp.SUM, group=self.group)
-        off = 0
-        for p in ps:
-            k = p.grad.numel()
-            p.grad.copy_(self._flat[off:off + k].view_as(p.grad))
-            off += k
+        torch._foreach_copy_([p.grad for p in ps], self._views)
+        self._reset_step()
 
 
 def allreduce_flat_(buf: torch.Tensor, group=None) -> torch.Tensor:

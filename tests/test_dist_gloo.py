@@ -95,3 +95,63 @@ def test_two_rank_gradient_allreduce_matches_single_process():
         assert np.allclose(r[6], gW, rtol=2e-5, atol=1e-9), "sum over ranks of shard dW == global-batch dW"
         assert np.array_equal(r[6], r[7]), "flat-buffer and per-parameter paths agree exactly"
     assert np.array_equal(res[0][6], res[1][6]), "every rank ends with identical gradients"
+
+
+def _grad_worker(rank, world, port, q):
+    """A small torch model, different data per rank: both modes of FlatGradAllReduce must leave Σ_ranks grad in every .grad."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    D.init("gloo")
+    out = {}
+    for mode in ("packed", "attached"):
+        torch.manual_seed(0)                       # identical weights on every rank
+        net = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3), torch.nn.Tanh(), torch.nn.Linear(3, 2))
+        params = list(net.parameters())
+        sync = D.FlatGradAllReduce(params, buckets=3, attach=(mode == "attached"))
+        grads = []
+        for it in range(3):                        # several steps: the per-step state (pending counts, handles) must reset
+            if mode == "attached":
+                sync.zero_()
+            else:
+                for p in params:
+                    p.grad = None
+            g = torch.Generator().manual_seed(100 * it + rank)
+            x = torch.randn(11, 5, generator=g)
+            net(x).square().sum().backward()
+            local = [p.grad.detach().clone() for p in params]
+            if mode == "attached":
+                # the hooks may already have summed the early buckets in place: the local part is recomputed without them
+                ref = torch.nn.Sequential(torch.nn.Linear(5, 7), torch.nn.Tanh(), torch.nn.Linear(7, 3), torch.nn.Tanh(), torch.nn.Linear(3, 2))
+                ref.load_state_dict(net.state_dict())
+                ref(x).square().sum().backward()
+                local = [p.grad.detach().clone() for p in ref.parameters()]
+            sync()
+            grads.append(([l.numpy() for l in local], [p.grad.detach().clone().numpy() for p in params]))
+        if mode == "attached":
+            assert sync._attached()                # the views survived three steps
+        out[mode] = grads
+    q.put((rank, out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_flat_grad_allreduce_packed_and_attached_modes():
+    """Both modes against Σ_ranks of the local gradients: the packed one (multi-tensor copy in, one message, copy out) and the
+    attached one (.grad fields are views of the flat buffer, bucketed asynchronous all-reduce issued from the
+    post-accumulate hooks while the backward is still running)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    for mode in ("packed", "attached"):
+        for it in range(3):
+            want = [a + b for a, b in zip(res[0][mode][it][0], res[1][mode][it][0])]
+            for r in range(world):
+                for g, w in zip(res[r][mode][it][1], want):
+                    assert np.abs(g - w).max() <= 1e-6 * max(1.0, np.abs(w).max()), (mode, it, r)

@@ -384,71 +384,78 @@ static __global__ void __launch_bounds__(512) k_mlp_dw(MlpDims dm, DwArgs a) {
   }
 }
 
-// sum[pos] = Σ_w slab[w][pos] over the launch's partial slabs, in slab order (deterministic), fully coalesced; eight
-// loads in flight per lane (a serial loop over 260 slabs was 110 µs of pure latency)
-static __global__ void k_sum_slabs(const float* __restrict__ slab, int nslab, int slab_n, float* __restrict__ sum) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (4 * idx >= slab_n) return;
-  const float* p = slab + 4 * idx;
-  f32x4 s = {0.f, 0.f, 0.f, 0.f};
-  int w = 0;
-  for (; w + 8 <= nslab; w += 8) {
-    f32x4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) v[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(w + u) * slab_n);
-#pragma unroll
-    for (int u = 0; u < 8; u++) s += v[u];
-  }
-  for (; w < nslab; w++) s += *reinterpret_cast<const f32x4*>(p + (size_t)w * slab_n);
-  *reinterpret_cast<f32x4*>(sum + 4 * idx) = s;
-}
-
-// dW[flat] += sum[fragment position of flat] (+ the private slabs of workgroups that overflowed their staging area).
-// nslab > 0: `sum` is the base of nslab partial slabs that are added here, in slab order (the same order and therefore the
-// same bits as k_sum_slabs) — for the few-slab launches of the small chains, where a separate summing launch costs more
-// than the gather.
-static __global__ void k_reduce_slabs(const float* __restrict__ priv, const int32_t* __restrict__ nflush, int nwg,
-                                      const float* __restrict__ sum, int nslab, MlpDims dm, float* __restrict__ dW,
+// dW[flat] (+)= Σ_w slab[w][fragment position of flat] (+ the private slabs of workgroups that overflowed their staging area):
+// ONE launch after k_mlp_dw (round 1 summed the slabs in one launch and gathered in a second). A workgroup owns one 32×32
+// tile of the slab (or 1024 floats of its bias tail): every lane sums ITS 16 bytes over the partial slabs, in slab order —
+// a fixed order, so the result is bit-reproducible — with sixteen fully coalesced loads in flight, and only then maps its
+// four accumulator-fragment positions back to flat (destructure-order) weight indices: the scatter happens once, on
+// nW floats, not once per slab.
+static __global__ void k_reduce_tiles(const float* __restrict__ priv, const int32_t* __restrict__ nflush, int nwg,
+                                      const float* __restrict__ slab, int nslab, MlpDims dm, float* __restrict__ dW,
                                       int32_t* __restrict__ feedback, int assign) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx == 0) {   // tell the host (asynchronously) whether any workgroup ran out of staging slots
+  const int tid = threadIdx.x;
+  if (blockIdx.x == 0 && tid == 0) {   // tell the host (asynchronously) whether any workgroup ran out of staging slots
     int mx = 0;
     for (int w = 0; w < nwg; w++) mx = max(mx, nflush[w]);
     feedback[0] = max(mx, feedback[1]);   // feedback[1]: set by a kernel that ran out of staging slots without a private slab
   }
-  if (idx >= dm.nW) return;
-  int l = 0;
-  while (l + 1 < dm.nL && idx >= dm.w_off[l + 1]) l++;
-  const int in = dm.sizes[l], out = dm.sizes[l + 1];
-  size_t pos;
-  if (idx < dm.b_off[l]) {
-    const int e = idx - dm.w_off[l], o = e % out, i = e / out;       // vec(W) column-major [out×in]
-    const int t = dm.tile_off[l] + (o >> 5) * cdiv(in, 32) + (i >> 5);
-    const int row = i & 31, col = o & 31;                             // tile holds Wᵀ: row = input index, col = output index
-    const int h = (row >> 2) & 1, r = (row & 3) + 4 * (row >> 3);     // C/D layout of v_mfma_f32_32x32x2_f32
-    pos = ((size_t)t * 64 + col + 32 * h) * 16 + r;
-  } else
-    pos = (size_t)dm.tile_off[dm.nL] * 1024 + dm.bias_lin[l] + (idx - dm.b_off[l]);
-  float sacc;
-  if (nslab > 0) {
-    const float* p = sum + pos;
-    sacc = 0.f;
-    int w = 0;
-    for (; w + 8 <= nslab; w += 8) {
-      float v[8];
+  const size_t base = (size_t)blockIdx.x * 1024 + 4 * tid;
+  if (base >= (size_t)dm.slab_n) return;
+  const float* p = slab + base;
+  f32x4 s = {0.f, 0.f, 0.f, 0.f};
+  int w = 0;
+  for (; w + 16 <= nslab; w += 16) {
+    f32x4 v[16];
 #pragma unroll
-      for (int u = 0; u < 8; u++) v[u] = p[(size_t)(w + u) * dm.slab_n];
+    for (int u = 0; u < 16; u++) v[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(w + u) * dm.slab_n);
 #pragma unroll
-      for (int u = 0; u < 8; u++) sacc += v[u];
-    }
-    for (; w < nslab; w++) sacc += p[(size_t)w * dm.slab_n];
-  } else
-    sacc = sum[pos];
+    for (int u = 0; u < 16; u++) s += v[u];
+  }
+  for (; w + 4 <= nslab; w += 4) {
+    f32x4 v[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) v[u] = *reinterpret_cast<const f32x4*>(p + (size_t)(w + u) * dm.slab_n);
+#pragma unroll
+    for (int u = 0; u < 4; u++) s += v[u];
+  }
+  for (; w < nslab; w++) s += *reinterpret_cast<const f32x4*>(p + (size_t)w * dm.slab_n);
   if (priv)
-    for (int w = 0; w < nwg; w++)
-      if (nflush[w]) sacc += priv[(size_t)w * dm.slab_n + pos];
-  if (assign) dW[idx] = sacc;   // the caller asked for dW = gradient (every entry of dW is one idx of one launch)
-  else dW[idx] += sacc;
+    for (int g = 0; g < nwg; g++)
+      if (nflush[g]) s += *reinterpret_cast<const f32x4*>(priv + (size_t)g * dm.slab_n + base);
+  const int ntl = dm.tile_off[dm.nL];
+  if ((int)blockIdx.x < ntl) {
+    const int t = blockIdx.x;
+    int l = 0;
+    while (l + 1 < dm.nL && t >= dm.tile_off[l + 1]) l++;
+    const int in = dm.sizes[l], out = dm.sizes[l + 1], nit = cdiv(in, 32);
+    const int otl = (t - dm.tile_off[l]) / nit, itl = (t - dm.tile_off[l]) - otl * nit;
+    const int lane64 = tid >> 2, col = lane64 & 31, h = lane64 >> 5;   // C/D layout of v_mfma_f32_32x32x2_f32, tile holds Wᵀ
+    const int o = otl * 32 + col;
+    if (o < out) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int r = 4 * (tid & 3) + q, row = (r & 3) | (h << 2) | ((r >> 2) << 3);
+        const int i = itl * 32 + row;
+        if (i < in) {
+          float* d = dW + dm.w_off[l] + (size_t)i * out + o;   // vec(W) column-major [out×in]
+          *d = assign ? s[q] : *d + s[q];
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int bp = (int)(base - (size_t)ntl * 1024) + q;   // position in the compact bias vector (blocks padded to 4)
+      if (bp >= dm.nbias) break;
+      int l = 0;
+      while (l + 1 < dm.nL && bp >= dm.bias_lin[l + 1]) l++;
+      const int j = bp - dm.bias_lin[l];
+      if (j < dm.sizes[l + 1]) {
+        float* d = dW + dm.b_off[l] + j;
+        *d = assign ? s[q] : *d + s[q];
+      }
+    }
+  }
 }
 
 template <class T>
@@ -462,8 +469,8 @@ static bool grow(T** ptr, size_t* cap, size_t need) {
   return true;
 }
 
-// dW += Σ over the staged slots: k_mlp_dw over (ntile × ks × jobs), then the two-stage slab reduction.
-//   slabs: [ntile·ks][slab_n] partial slabs followed by one slab_n sum buffer (caller sizes it: (ntile·ks + 1)·slab_n)
+// dW += Σ over the staged slots: k_mlp_dw over (ntile × ks × jobs), then the slab reduction (k_reduce_tiles).
+//   slabs: [ntile·ks][slab_n] partial slabs
 static int launch_weight_gradient(const MlpDims& dm, const DwArgs& da, int ntile, int ks, const float* priv,
                                   const int32_t* nflush, int npriv, float* dW, int32_t* feedback, hipStream_t stream,
                                   std::string& err, bool assign = false, bool bf16 = false) {
@@ -494,14 +501,8 @@ static int launch_weight_gradient(const MlpDims& dm, const DwArgs& da, int ntile
   } else if (ndw == 1) hipLaunchKernelGGL(k_mlp_dw<1>, grid, dim3(512), dlds, stream, dm, da);
   else if (ndw == 2) hipLaunchKernelGGL(k_mlp_dw<2>, grid, dim3(512), dlds, stream, dm, da);
   else hipLaunchKernelGGL(k_mlp_dw<4>, grid, dim3(512), dlds, stream, dm, da);
-  if (ntile * ks <= 32) {   // few slabs: summed inside the gather
-    hipLaunchKernelGGL(k_reduce_slabs, dim3(cdiv(dm.nW, 256)), dim3(256), 0, stream, priv, nflush, npriv, da.slab, ntile * ks, dm, dW,
-                       feedback, assign ? 1 : 0);
-  } else {
-    float* sum = da.slab + (size_t)ntile * ks * dm.slab_n;
-    hipLaunchKernelGGL(k_sum_slabs, dim3(cdiv(cdiv(dm.slab_n, 4), 256)), dim3(256), 0, stream, da.slab, ntile * ks, dm.slab_n, sum);
-    hipLaunchKernelGGL(k_reduce_slabs, dim3(cdiv(dm.nW, 256)), dim3(256), 0, stream, priv, nflush, npriv, sum, 0, dm, dW, feedback, assign ? 1 : 0);
-  }
+  hipLaunchKernelGGL(k_reduce_tiles, dim3(cdiv(dm.slab_n, 1024)), dim3(256), 0, stream, priv, nflush, npriv, da.slab, ntile * ks, dm,
+                     dW, feedback, assign ? 1 : 0);
   if (hipGetLastError() != hipSuccess) {
     err = "weight-gradient kernels failed to launch";
     return LDE_ERR_HIP;

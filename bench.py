@@ -362,6 +362,7 @@ def run_goku_step(args, torch, dist, world, rank, local):
     from latentdiffeq_amd.dist import FlatGradAllReduce
     from latentdiffeq_amd.loss import reconstruction_loss, sample, vector_kl
     from latentdiffeq_amd.recurrent import Encoder, default_encoder_layers, encode
+    from latentdiffeq_amd import _lib as L
     B = args.batch or 256
     T, NI = 50, 784
     dev = torch.device("cuda", local)
@@ -387,6 +388,8 @@ def run_goku_step(args, torch, dist, world, rank, local):
     ts = np.arange(T) * 0.05
     Bg = B * world
 
+    refresh = os.environ.get("LDE_BENCH_REFRESH", "1") != "0"   # diagnostic: 0 = every module re-uploads its weights at its next call
+
     def step():
         opt.zero_grad(set_to_none=True)
         mu, logvar = encode(enc, x)
@@ -396,6 +399,8 @@ def run_goku_step(args, torch, dist, world, rank, local):
         loss.backward()
         sync()
         opt.step()
+        if refresh:
+            L.refresh_weights(mods)         # the new weights of all eleven modules handed to the library in one launch
         return loss
 
     def fence():

@@ -295,6 +295,15 @@ int  lde_rnn_backward(lde_rnn* r, const float* x, const float* dy, int T, int B,
 int  lde_rnn_set_accumulate(lde_rnn* r, int on);   /* as lde_chain_set_accumulate */
 const char* lde_rnn_last_error(const lde_rnn* r);
 
+/* After an optimiser step: hand the new flat weights of MANY modules to their handles in ONE launch — what n calls of
+ * lde_chain_set_weights_device / lde_rnn_set_weights_device do, one launch each (the reference has no counterpart: Flux layers
+ * read their arrays in place, `Flux.update!` [REF examples/pendulum_friction-less/model_train.jl:190-192]; here a chain keeps
+ * MFMA-fragment-ordered copies of W and Wᵀ that must follow the parameters). kinds[m] ∈ lde_module_kind, handles[m] the
+ * lde_chain* / lde_rnn*, flat_dev[m] its weights in Flux.destructure order (device). The handles may then be used with those
+ * weights until they change again. */
+enum lde_module_kind { LDE_MODULE_CHAIN = 0, LDE_MODULE_RNN = 1 };
+int lde_refresh_weights(int n, const int* kinds, void* const* handles, const float* const* flat_dev, void* stream);
+
 /* ====================================================================================================================
  * The variational sample and the loss terms (scope row f-3): what the example script computes between encoder and
  * decoder and around the model's output. Stateless elementwise / reduction kernels; all pointers are device memory.

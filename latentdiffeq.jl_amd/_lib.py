@@ -32,7 +32,7 @@ EXPORTS = ["lde_abi_version", "lde_problem_desc_default", "lde_num_weights", "ld
            "lde_chain_set_weights_device", "lde_chain_reserve", "lde_chain_forward", "lde_chain_backward",
            "lde_chain_last_error", "lde_chain_set_accumulate", "lde_chain_set_dtype", "lde_rnn_set_accumulate", "lde_chain_saved_floats", "lde_chain_forward_save", "lde_chain_backward_saved",
            "lde_rnn_num_weights", "lde_rnn_create", "lde_rnn_destroy", "lde_rnn_set_weights", "lde_rnn_set_weights_device",
-           "lde_rnn_reserve", "lde_rnn_forward", "lde_rnn_backward", "lde_rnn_last_error",
+           "lde_rnn_reserve", "lde_rnn_forward", "lde_rnn_backward", "lde_rnn_last_error", "lde_refresh_weights",
            "lde_sample_forward", "lde_sample_backward", "lde_kl_forward", "lde_kl_backward", "lde_mse_forward",
            "lde_mse_backward",
            "lde_comm_unique_id", "lde_comm_init", "lde_comm_allreduce_f32", "lde_comm_nranks", "lde_comm_rank",
@@ -149,6 +149,7 @@ def load():
     lib.lde_rnn_backward.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
     lib.lde_rnn_last_error.argtypes = [vp]
     lib.lde_rnn_last_error.restype = C.c_char_p
+    lib.lde_refresh_weights.argtypes = [i32, C.POINTER(i32), C.POINTER(vp), C.POINTER(vp), vp]
     f32 = C.c_float
     lib.lde_sample_forward.argtypes = [vp, vp, vp, i64, vp, vp]
     lib.lde_sample_backward.argtypes = [vp, vp, vp, i64, vp, vp]
@@ -178,6 +179,41 @@ def raw_stream(device_index=None) -> C.c_void_p:
     if device_index is None:
         device_index = torch.cuda.current_device()
     return C.c_void_p(torch._C._cuda_getCurrentRawStream(device_index))
+
+
+MODULE_CHAIN, MODULE_RNN = 0, 1
+
+
+def weights_key(W):
+    """Identity of a parameter's current VALUE as torch tracks it: storage address + in-place version counter (an optimiser
+    step, `copy_`, `fill_` … bump it; writes through `.data` do not — torch's own saved-tensor checks share that blind spot)."""
+    return (W.data_ptr(), W._version)
+
+
+def refresh_weights(modules, stream=None):
+    """lde_refresh_weights for torch modules that own a native handle (Chain / Recurrent): ONE launch re-lays-out the weights of
+    all of them; each module then skips its own per-call upload until its parameter changes again (tracked by `weights_key`).
+    Call it after the optimiser step. Modules on the CPU or without CUDA are left alone."""
+    import torch
+    mods = [m for m in modules if hasattr(m, "_native") and hasattr(m, "theta") and m.theta.is_cuda]
+    if not mods:
+        return 0
+    lib = load()
+    n = len(mods)
+    kinds, handles, ptrs, keep = (C.c_int32 * n)(), (C.c_void_p * n)(), (C.c_void_p * n)(), []
+    for i, m in enumerate(mods):
+        W = m.theta.detach()
+        if W.dtype != torch.float32 or not W.is_contiguous():
+            W = W.contiguous().float()
+        keep.append(W)
+        kinds[i] = MODULE_RNN if getattr(m, "_is_recurrent", False) else MODULE_CHAIN
+        handles[i] = m._native().value
+        ptrs[i] = W.data_ptr()
+    check(lib.lde_refresh_weights(n, kinds, handles, ptrs, stream if stream is not None else raw_stream(mods[0].theta.device.index)),
+          None, "lde_refresh_weights")
+    for m, W in zip(mods, keep):
+        m._wkey = weights_key(m.theta) if W.data_ptr() == m.theta.data_ptr() else None
+    return n
 
 
 def check(rc: int, handle=None, what: str = "", chain: bool = False, rnn: bool = False):

@@ -84,9 +84,12 @@ class _ChainFn(torch.autograd.Function):
         h = chain._native()
         lib = chain._lib
         stream = L.raw_stream(x.device.index)
-        Wc = W.detach().contiguous().float()
-        L.check(lib.lde_chain_set_weights_device(h, C.c_void_p(Wc.data_ptr()), Wc.numel(), stream), h,
-                "lde_chain_set_weights_device", chain=True)
+        key = L.weights_key(W)
+        if chain._wkey != key:          # not handed over by refresh_weights() since the parameter last changed
+            Wc = W.detach().contiguous().float()
+            L.check(lib.lde_chain_set_weights_device(h, C.c_void_p(Wc.data_ptr()), Wc.numel(), stream), h,
+                    "lde_chain_set_weights_device", chain=True)
+            chain._wkey = None
         N = x.shape[0]
         y = torch.empty((N, chain.sizes[-1]), device=x.device, dtype=torch.float32)
         train = (x.requires_grad or W.requires_grad) and torch.is_grad_enabled()
@@ -154,6 +157,7 @@ class Chain(torch.nn.Module):
             d._owner, d._w0, d._b0 = self, None, None
         self._handle = None
         self._lib = None
+        self._wkey = None          # set by _lib.refresh_weights: the parameter value the handle already holds
         self.dtype = "f32"
 
     def set_dtype(self, dtype: str) -> "Chain":

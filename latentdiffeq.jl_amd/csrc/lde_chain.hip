@@ -18,13 +18,15 @@
 //    widest layer never touches LDS); then δ flows down the chain through Wᵀ fragments, each δ_l staged as it appears.
 //    The gradient wrt a layer's output is kept in its own panel so that skip connections add it back.
 //  * Backward, kernel 2: the weight gradient is the same large-K product over staged (a_l, δ_l) panels as in the MLP
-//    adjoint — `k_mlp_dw` + `k_reduce_slabs` from lde_mfma.h, with every 16-column group as one slot of weight 1.
+//    adjoint — `k_mlp_dw` + `k_reduce_tiles` from lde_mfma.h, with every 16-column group as one slot of weight 1.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
+#include <vector>
 
 #include "lde_mfma.h"
 
@@ -525,6 +527,7 @@ struct lde_chain {
   float* W_dev = nullptr;
   float* frag = nullptr;
   float* fragT = nullptr;
+  MlpDims* dm_dev = nullptr;   // device copy of cd.dm (lde_refresh_weights' job table points at it)
   bool have_W = false;
   int cg_fwd = 0, cg_bwd = 0;
   size_t lds_fwd = 0, lds_bwd = 0;
@@ -555,6 +558,9 @@ static size_t chain_lds(const ChainDims& cd, int cg, int npanels) {
   return ((size_t)NC * cd.ld0 + (size_t)npanels * NC * cd.ldh + ((cd.dm.nbias + 3) & ~3)) * sizeof(float);
 }
 
+// lde_rnn.hip: where lde_refresh_weights copies a recurrent stack's flat weights to (marks the handle as holding weights)
+bool rnn_refresh_target(lde_rnn* r, float** W_dev, int64_t* nW);
+
 extern "C" {
 
 int64_t lde_chain_num_weights(const lde_chain_desc* d) {
@@ -569,6 +575,7 @@ void lde_chain_destroy(lde_chain* c) {
   if (c->W_dev) (void)hipFree(c->W_dev);
   if (c->frag) (void)hipFree(c->frag);
   if (c->fragT) (void)hipFree(c->fragT);
+  if (c->dm_dev) (void)hipFree(c->dm_dev);
   if (c->stage) (void)hipFree(c->stage);
   if (c->wts) (void)hipFree(c->wts);
   if (c->slab) (void)hipFree(c->slab);
@@ -665,9 +672,13 @@ int lde_chain_create(const lde_chain_desc* d, lde_chain** out) {
   }
   if (hipMalloc(&c->W_dev, (size_t)c->nW * sizeof(float)) != hipSuccess ||
       hipMalloc(&c->frag, c->nfrag * sizeof(float)) != hipSuccess ||
-      hipMalloc(&c->fragT, c->nfragT * sizeof(float)) != hipSuccess) {
+      hipMalloc(&c->fragT, c->nfragT * sizeof(float)) != hipSuccess || hipMalloc(&c->dm_dev, sizeof(MlpDims)) != hipSuccess) {
     c->err = "chain: hipMalloc failed";
     return LDE_ERR_ALLOC;
+  }
+  if (hipMemcpy(c->dm_dev, &c->cd.dm, sizeof(MlpDims), hipMemcpyHostToDevice) != hipSuccess) {
+    c->err = "chain: hipMemcpy of the dimensions failed";
+    return LDE_ERR_HIP;
   }
   return LDE_OK;
 }
@@ -704,6 +715,55 @@ int lde_chain_set_weights_device(lde_chain* c, const float* flat_dev, int64_t n,
     return LDE_ERR_INVALID_ARG;
   }
   return chain_frags(c, flat_dev, (hipStream_t)stream);
+}
+
+// One launch for every module of a model (see include/lde.h). The job table lives in device memory and is uploaded only
+// when it differs from the previous call's (a training loop passes the same handles and pointers every step).
+int lde_refresh_weights(int n, const int* kinds, void* const* handles, const float* const* flat_dev, void* stream) {
+  static std::mutex mu;
+  static std::vector<RefreshJob> last;
+  static RefreshJob* jobs_dev = nullptr;
+  static size_t jobs_cap = 0;
+  if (n < 0 || (n > 0 && (!kinds || !handles || !flat_dev))) return LDE_ERR_INVALID_ARG;
+  if (n == 0) return LDE_OK;
+  std::vector<RefreshJob> jobs;
+  for (int m = 0; m < n; m++) {
+    if (!handles[m] || !flat_dev[m]) return LDE_ERR_INVALID_ARG;
+    if (kinds[m] == LDE_MODULE_CHAIN) {
+      lde_chain* c = (lde_chain*)handles[m];
+      if (!c->W_dev || !c->dm_dev) return LDE_ERR_INVALID_ARG;
+      for (int l = 0; l < c->cd.dm.nL; l++)
+        jobs.push_back(RefreshJob{flat_dev[m], flat_dev[m] == c->W_dev ? nullptr : c->W_dev, c->frag, c->fragT, c->dm_dev, l, 0});
+    } else if (kinds[m] == LDE_MODULE_RNN) {
+      float* dst = nullptr;
+      int64_t nw = 0;
+      if (!rnn_refresh_target((lde_rnn*)handles[m], &dst, &nw)) return LDE_ERR_INVALID_ARG;
+      if (dst != flat_dev[m]) jobs.push_back(RefreshJob{flat_dev[m], dst, nullptr, nullptr, nullptr, -1, (int)nw});
+    } else
+      return LDE_ERR_INVALID_ARG;
+  }
+  std::lock_guard<std::mutex> lk(mu);
+  hipStream_t st = (hipStream_t)stream;
+  if (jobs.size() != last.size() || std::memcmp(jobs.data(), last.data(), jobs.size() * sizeof(RefreshJob)) != 0) {
+    // rare path: an earlier launch may still be reading the table
+    if (hipDeviceSynchronize() != hipSuccess) return LDE_ERR_HIP;
+    if (jobs.size() > jobs_cap) {
+      if (jobs_dev) (void)hipFree(jobs_dev);
+      jobs_dev = nullptr;
+      jobs_cap = 0;
+      if (hipMalloc(&jobs_dev, jobs.size() * sizeof(RefreshJob)) != hipSuccess) return LDE_ERR_ALLOC;
+      jobs_cap = jobs.size();
+    }
+    if (hipMemcpy(jobs_dev, jobs.data(), jobs.size() * sizeof(RefreshJob), hipMemcpyHostToDevice) != hipSuccess) return LDE_ERR_HIP;
+    last = jobs;
+  }
+  if (!jobs.empty()) {
+    hipLaunchKernelGGL(k_refresh_many, dim3(64, (unsigned)jobs.size()), dim3(256), 0, st, jobs_dev);
+    if (hipGetLastError() != hipSuccess) return LDE_ERR_HIP;
+  }
+  for (int m = 0; m < n; m++)
+    if (kinds[m] == LDE_MODULE_CHAIN) ((lde_chain*)handles[m])->have_W = true;
+  return LDE_OK;
 }
 
 // which layout a call uses: the panel-free one (gx) when the input is wide, x is 16-byte aligned and N fills a tile

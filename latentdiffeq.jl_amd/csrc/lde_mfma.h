@@ -103,18 +103,18 @@ __host__ __device__ inline int panel_stride(int rows) {
 // (`keep`, optional: the flat vector is also copied there — the handle's own copy, read for the biases later — which
 //  saves a separate device-to-device copy per lde_*_set_weights_device call: one launch instead of two per training step
 //  and module.)
-static __global__ void k_build_frags(const float* __restrict__ Wflat, MlpDims dm, float* __restrict__ frag,
-                              float* __restrict__ fragT, float* __restrict__ keep) {
-  const int l = blockIdx.y;
+__device__ inline void build_frags_layer(const float* __restrict__ Wflat, const MlpDims& dm, float* __restrict__ frag,
+                                         float* __restrict__ fragT, float* __restrict__ keep, int l, int bx, int nbx) {
   const int in = dm.sizes[l], out = dm.sizes[l + 1];
+  const int stride = nbx * blockDim.x, first = bx * blockDim.x + threadIdx.x;
   if (keep) {   // this layer's slice [w_off[l], w_off[l+1]) of the flat vector
     const int lo = dm.w_off[l], hi = l + 1 < dm.nL ? dm.w_off[l + 1] : dm.nW;
-    for (int e = lo + blockIdx.x * blockDim.x + threadIdx.x; e < hi; e += gridDim.x * blockDim.x) keep[e] = Wflat[e];
+    for (int e = lo + first; e < hi; e += stride) keep[e] = Wflat[e];
   }
   const float* W = Wflat + dm.w_off[l];  // column-major [out×in]: W(o,i) at o + out*i
   {
     const int KG = cdiv(in, 16), n = dm.frag_n[l];
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    for (int e = first; e < n; e += stride) {
       const int s4 = e & 3, lane = (e >> 2) & 63, f = e >> 8, rt = f / KG, kg = f % KG;
       const int o = rt * 16 + (lane & 15), i = kg * 16 + 4 * (lane >> 4) + s4;
       frag[dm.frag_off[l] + e] = (o < out && i < in) ? W[o + (size_t)out * i] : 0.f;
@@ -122,12 +122,38 @@ static __global__ void k_build_frags(const float* __restrict__ Wflat, MlpDims dm
   }
   {
     const int KG = cdiv(out, 16), n = dm.fragT_n[l];  // Wᵀ[in×out]
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < n; e += gridDim.x * blockDim.x) {
+    for (int e = first; e < n; e += stride) {
       const int s4 = e & 3, lane = (e >> 2) & 63, f = e >> 8, rt = f / KG, kg = f % KG;
       const int i = rt * 16 + (lane & 15), o = kg * 16 + 4 * (lane >> 4) + s4;
       fragT[dm.fragT_off[l] + e] = (o < out && i < in) ? W[o + (size_t)out * i] : 0.f;
     }
   }
+}
+
+static __global__ void k_build_frags(const float* __restrict__ Wflat, MlpDims dm, float* __restrict__ frag,
+                              float* __restrict__ fragT, float* __restrict__ keep) {
+  build_frags_layer(Wflat, dm, frag, fragT, keep, blockIdx.y, blockIdx.x, gridDim.x);
+}
+
+// The same re-layout for MANY modules in one launch (lde_refresh_weights: once per optimiser step instead of once per
+// module and step): blockIdx.y walks a device-resident job table — one job per (chain, layer), or a plain copy of a flat
+// vector into a handle's own buffer (layer < 0: the recurrent stacks read their weights in destructure order).
+struct RefreshJob {
+  const float* src;
+  float* keep;
+  float* frag;
+  float* fragT;
+  const MlpDims* dm;   // device copy of the chain's dimensions
+  int layer;
+  int n;
+};
+static __global__ void k_refresh_many(const RefreshJob* __restrict__ jobs) {
+  const RefreshJob j = jobs[blockIdx.y];
+  if (j.layer < 0) {
+    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < j.n; e += gridDim.x * blockDim.x) j.keep[e] = j.src[e];
+    return;
+  }
+  build_frags_layer(j.src, *j.dm, j.frag, j.fragT, j.keep, j.layer, blockIdx.x, gridDim.x);
 }
 
 __host__ __device__ inline int pad32(int v) { return (v + 31) & ~31; }

@@ -32,7 +32,7 @@
 //    stores per lane) with the per-column quadrature weights next to them (weights of rejected columns are zeroed
 //    afterwards, slots of wholly rejected attempts are reused). A second kernel, k_mlp_dw, then forms the gradient as
 //    ONE large-K product per 32×32 tile of W_lᵀ over all staged columns, spread over the whole chip (tile × K-split ×
-//    layer jobs) on v_mfma_f32_32x32x2_f32, and k_reduce_slabs adds the partial slabs in a fixed order.
+//    layer jobs) on v_mfma_f32_32x32x2_f32, and k_reduce_tiles adds the partial slabs in a fixed order.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>

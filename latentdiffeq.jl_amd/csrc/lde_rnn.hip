@@ -478,6 +478,15 @@ static int rnn_desc_ok(const lde_rnn_desc* d) {
   return 1;
 }
 
+// lde_chain.hip (lde_refresh_weights): the handle's own weight buffer, which that call fills
+bool rnn_refresh_target(lde_rnn* r, float** W_dev, int64_t* nW) {
+  if (!r || !r->W_dev) return false;
+  *W_dev = r->W_dev;
+  *nW = r->nW;
+  r->have_W = true;
+  return true;
+}
+
 extern "C" {
 
 int64_t lde_rnn_num_weights(const lde_rnn_desc* d) {

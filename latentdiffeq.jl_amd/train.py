@@ -46,6 +46,13 @@ class LatentDiffEqModel:
     def parameters(self) -> List[torch.nn.Parameter]:
         return [p for m in self.modules() for p in m.parameters()]
 
+    def refresh_weights(self) -> int:
+        """After an optimiser step: hand the new weights of every chain and recurrent stack to the library in ONE launch
+        (lde_refresh_weights) instead of one per module at its next call. Optional — a module whose parameter changed without
+        it re-uploads by itself."""
+        from . import _lib as L
+        return L.refresh_weights(self.modules())
+
     def __call__(self, x, t, variational: bool = False):
         mu, logvar = encode(self.encoder, x)
         l_tilde = sample(mu, logvar) if variational else mu                      # [REF LatentDiffEqModel.jl:31]
@@ -168,6 +175,7 @@ def train(model: LatentDiffEqModel, loader_train: Iterable, val_set, dt: float, 
             if grad_sync is not None:
                 grad_sync()
             opt.step()
+            model.refresh_weights()
             with torch.no_grad():
                 val_loss = float(loss_batch(model, val_set, t_val, beta, False))
             history.append((epoch, float(loss.detach()), val_loss))

@@ -1,0 +1,70 @@
+"""GPU: lde_refresh_weights — the weights of many modules handed to the library in ONE launch after an optimiser step
+(include/lde.h) — is the same hand-over as the per-module lde_chain_set_weights_device / lde_rnn_set_weights_device calls:
+identical outputs and gradients bit for bit, and a parameter that changes afterwards is picked up again by the module
+itself (the reference has no such step: Flux layers read their arrays in place [REF model_train.jl:190-192])."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _model(seed):
+    import torch
+    import latentdiffeq_amd as la
+    from latentdiffeq_amd import train as TR
+    torch.manual_seed(seed)
+    mt, diffeq = la.GOKU_basic(), la.Pendulum()
+    enc, dec = TR.default_layers(mt, 64, diffeq, device="cuda", hidden_dim_resnet=48)
+    with torch.no_grad():
+        dec[0][1]._dense[-1].bias.fill_(1.0)
+    return TR.LatentDiffEqModel(mt, enc, dec)
+
+
+def _loss_and_grads(model, x, ts):
+    import torch
+    from latentdiffeq_amd import train as TR
+    for p in model.parameters():
+        p.grad = None
+    loss = TR.loss_batch(model, x, ts, 1e-3, False)
+    loss.backward()
+    torch.cuda.synchronize()
+    return float(loss.detach()), [p.grad.detach().clone() for p in model.parameters()]
+
+
+def test_refresh_weights_equals_per_module_uploads_and_tracks_changes():
+    import torch
+    B, T = 24, 12
+    ts = np.arange(T) * 0.05
+    x = torch.rand(T, B, 64, device="cuda").permute(2, 1, 0)
+    a, b = _model(7), _model(7)
+    for _ in range(3):
+        la_, ga = _loss_and_grads(a, x, ts)                 # a: every module uploads its own weights at every call
+        assert b.refresh_weights() == 11                    # b: one launch for the eleven modules, calls skip the upload
+        assert all(m._wkey is not None for m in b.modules())
+        lb, gb = _loss_and_grads(b, x, ts)
+        assert la_ == lb
+        for u, v in zip(ga, gb):
+            assert torch.equal(u, v)
+        with torch.no_grad():                               # an "optimiser step" on both models
+            for pa, pb, g in zip(a.parameters(), b.parameters(), ga):
+                pa.add_(g, alpha=-1e-3)
+                pb.add_(g, alpha=-1e-3)
+    # b's parameters changed after its last refresh: the keys no longer match, every module re-uploads by itself
+    la_, ga = _loss_and_grads(a, x, ts)
+    lb, gb = _loss_and_grads(b, x, ts)
+    assert la_ == lb and all(torch.equal(u, v) for u, v in zip(ga, gb))
+    assert all(m._wkey is None for m in b.modules())
+
+
+def test_refresh_weights_rejects_bad_arguments():
+    from latentdiffeq_amd import _lib as L
+    lib = L.load()
+    kinds, handles, ptrs = (C.c_int32 * 1)(7), (C.c_void_p * 1)(1), (C.c_void_p * 1)(1)
+    assert lib.lde_refresh_weights(1, kinds, handles, ptrs, None) == -1          # unknown module kind
+    kinds[0] = L.MODULE_CHAIN
+    handles[0] = None
+    assert lib.lde_refresh_weights(1, kinds, handles, ptrs, None) == -1          # null handle
+    assert lib.lde_refresh_weights(0, None, None, None, None) == 0
+    assert lib.lde_refresh_weights(-1, None, None, None, None) == -1

@@ -360,7 +360,7 @@ def run_goku_step(args, torch, dist, world, rank, local):
     import latentdiffeq_amd as M
     from latentdiffeq_amd.chain import decode, default_decoder_layers
     from latentdiffeq_amd.dist import FlatGradAllReduce
-    from latentdiffeq_amd.loss import reconstruction_loss, sample, vector_kl
+    from latentdiffeq_amd.loss import reconstruction_loss, sample, sample_with_kl, vector_kl
     from latentdiffeq_amd.recurrent import Encoder, default_encoder_layers, encode
     from latentdiffeq_amd import _lib as L
     B = args.batch or 256
@@ -388,14 +388,20 @@ def run_goku_step(args, torch, dist, world, rank, local):
     ts = np.arange(T) * 0.05
     Bg = B * world
 
+    fused_loss = os.environ.get("LDE_FUSED_LOSS", "1") != "0"     # diagnostic: 0 = separate sample / vector_kl / reconstruction_loss and torch additions
     refresh = os.environ.get("LDE_BENCH_REFRESH", "1") != "0"   # diagnostic: 0 = every module re-uploads its weights at its next call
 
     def step():
         opt.zero_grad(set_to_none=True)
         mu, logvar = encode(enc, x)
-        l_tilde = sample(mu, logvar)
-        x_hat, z_hat, l_hat = decode(dec, l_tilde, ts)
-        loss = reconstruction_loss(x, x_hat, Bg) + 1e-3 * vector_kl(mu, logvar, Bg)   # Σ_pixels mean_{B,T} + β·KL  [REF model_train.jl:225-238]
+        if fused_loss:   # sample and β·KL of the same (μ, logσ²) in one pass, the additions folded into the reductions (train.loss_batch)
+            l_tilde, bkl = sample_with_kl(mu, logvar, 1e-3, Bg)
+            x_hat, z_hat, l_hat = decode(dec, l_tilde, ts)
+            loss = reconstruction_loss(x, x_hat, Bg, plus=bkl)                            # Σ_pixels mean_{B,T} + β·KL  [REF model_train.jl:225-238]
+        else:
+            l_tilde = sample(mu, logvar)
+            x_hat, z_hat, l_hat = decode(dec, l_tilde, ts)
+            loss = reconstruction_loss(x, x_hat, Bg) + 1e-3 * vector_kl(mu, logvar, Bg)
         loss.backward()
         sync()
         opt.step()

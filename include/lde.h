@@ -331,6 +331,21 @@ int lde_mse_forward(const float* x, const float* xhat, int64_t n, float scale, f
 /* dx̂_i = g·scale·2·(x̂_i − x_i),  g = *dout */
 int lde_mse_backward(const float* x, const float* xhat, int64_t n, float scale, const float* dout, float* dxhat, void* stream);
 
+/* The same terms as `loss_batch` composes them  [REF examples/pendulum_friction-less/model_train.jl:225-238]:
+ * `reconstruction_loss + β·kl_loss` on a model output that was sampled from (μ, logσ²)  [REF src/models/LatentDiffEqModel.jl:31].
+ * The sample and its KL term read the same (μ, logσ²): one pass computes both, one pass back delivers the SUM of both cotangents
+ * (the reference's Zygote adds them as separate broadcasts), and the scalar additions of the loss expression ride on `base`:
+ *   sample_kl forward:  l_i = μ_i + ε_i·exp(logσ²_i/2);   out = (base ? *base : 0) + scale·Σ_i kl_i          (scale = β/B)
+ *   sample_kl backward: dμ_i = dl_i + g·scale·μ_i;   dlogσ²_i = dl_i·ε_i·exp(logσ²_i/2)/2 + g·scale·(exp(logσ²_i) − 1)/2,  g = *dout
+ *   mse_forward_add:    out = (base ? *base : 0) + scale·Σ_i (x_i − x̂_i)²       (pullback: lde_mse_backward; d base = dout)
+ * Same per-element formulas and the same fixed-order reductions as the separate entry points above. */
+int lde_sample_kl_forward(const float* mu, const float* logvar, const float* eps, int64_t n, float scale, const float* base,
+                          float* l, float* out, float* scratch, void* stream);
+int lde_sample_kl_backward(const float* mu, const float* logvar, const float* eps, const float* dl, const float* dout, float scale,
+                           int64_t n, float* dmu, float* dlogvar, void* stream);
+int lde_mse_forward_add(const float* x, const float* xhat, int64_t n, float scale, const float* base, float* out, float* scratch,
+                        void* stream);
+
 /* ====================================================================================================================
  * The one collective of the path. The reference's only parallelism is `EnsembleThreads()` over the
  * trajectories of one batch  [REF src/models/GOKU.jl:121]; here the batch shards by trajectory over one process per GPU

@@ -48,10 +48,11 @@ __device__ __forceinline__ float wg_sum(float v) {
 
 __device__ __forceinline__ float kl_term(float m, float lv) { return 0.5f * (__expf(lv) + m * m - lv - 1.0f); }
 
-// TERM 0: kl(a = μ, b = logσ²); TERM 1: (a − b)²
+// TERM 0: kl(a = μ, b = logσ²); TERM 1: (a − b)²; TERM 2: kl(a, b) and, in the same pass, the sample l = a + c·exp(b/2) → l
 template <int TERM>
 __global__ void __launch_bounds__(LOSS_WG) k_loss_partial(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
-                                                          float* __restrict__ scratch) {
+                                                          float* __restrict__ scratch, const float* __restrict__ c = nullptr,
+                                                          float* __restrict__ l = nullptr) {
   // workgroup w owns the slice [w·per, (w+1)·per) with per a multiple of 4 floats
   const int64_t nwg = gridDim.x;
   int64_t per = (n + nwg - 1) / nwg;
@@ -60,13 +61,20 @@ __global__ void __launch_bounds__(LOSS_WG) k_loss_partial(const float* __restric
   int64_t hi = lo + per;
   if (hi > n) hi = n;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-  const bool al = ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0;
+  const bool al = ((((uintptr_t)a) | ((uintptr_t)b) | (TERM == 2 ? ((uintptr_t)c) | ((uintptr_t)l) : 0)) & 15) == 0;
   int64_t i = lo + 4 * (int64_t)threadIdx.x;
   if (al) {
     for (; i + 4 <= hi; i += 4 * LOSS_WG) {
       const f4 va = *reinterpret_cast<const f4*>(a + i), vb = *reinterpret_cast<const f4*>(b + i);
-      if (TERM == 0) {
+      if (TERM == 0 || TERM == 2) {
         s0 += kl_term(va[0], vb[0]); s1 += kl_term(va[1], vb[1]); s2 += kl_term(va[2], vb[2]); s3 += kl_term(va[3], vb[3]);
+        if (TERM == 2) {
+          const f4 vc = *reinterpret_cast<const f4*>(c + i);
+          f4 r;
+#pragma unroll
+          for (int q = 0; q < 4; q++) r[q] = va[q] + vc[q] * __expf(0.5f * vb[q]);   // = loss_map1<0>
+          *reinterpret_cast<f4*>(l + i) = r;
+        }
       } else {
         const f4 d = va - vb;
         s0 += d[0] * d[0]; s1 += d[1] * d[1]; s2 += d[2] * d[2]; s3 += d[3] * d[3];
@@ -76,29 +84,72 @@ __global__ void __launch_bounds__(LOSS_WG) k_loss_partial(const float* __restric
   for (; i < hi; i += 4 * LOSS_WG)   // unaligned operands, and the ragged end of the last slice
     for (int q = 0; q < 4 && i + q < hi; q++) {
       const float x = a[i + q], y = b[i + q];
-      s0 += TERM == 0 ? kl_term(x, y) : (x - y) * (x - y);
+      s0 += TERM != 1 ? kl_term(x, y) : (x - y) * (x - y);
+      if (TERM == 2) l[i + q] = x + c[i + q] * __expf(0.5f * y);
     }
   const float s = wg_sum((s0 + s1) + (s2 + s3));
   if (threadIdx.x == 0) scratch[blockIdx.x] = s;
 }
 
-__global__ void __launch_bounds__(64) k_loss_final(const float* __restrict__ scratch, int nwg, float scale, float* __restrict__ out) {
+// out = scale·Σ partials (+ base[0]: a running total of loss terms — the elementwise additions of the loss expression folded in)
+__global__ void __launch_bounds__(64) k_loss_final(const float* __restrict__ scratch, int nwg, float scale, float* __restrict__ out,
+                                                   const float* __restrict__ base = nullptr) {
+#pragma clang fp contract(off)
   float s = 0.f;
   for (int i = threadIdx.x; i < nwg; i += 64) s += scratch[i];
   s = wave_sum(s);
-  if (threadIdx.x == 0) out[0] = scale * s;
+  // (no contraction into an fma: base + the separately rounded term, the bits of the separate entry point followed by an addition)
+  if (threadIdx.x == 0) out[0] = base ? base[0] + scale * s : scale * s;
 }
 
 // OP 0: l = μ + ε·exp(lv/2)                           (a = μ, b = lv, c = ε → o0)
 // OP 1: dlv = dl·ε·exp(lv/2)/2                        (a = lv, b = ε, c = dl → o0)
 // OP 2: dμ = k·μ, dlv = k·(exp(lv) − 1)/2, k = g·scale (a = μ, b = lv → o0, o1)
 // OP 3: dx̂ = 2k·(x̂ − x)                              (a = x, b = x̂ → o0)
+// OP 4: OP 1 and OP 2 in one pass, summed with the cotangent of the sample: dμ = dl + k·μ,
+//       dlv = dl·ε·exp(lv/2)/2 + k·(exp(lv) − 1)/2    (a = μ, b = lv, c = ε, d = dl → o0, o1)
 template <int OP>
 __device__ __forceinline__ void loss_map1(float a, float b, float c, float k, float& o0, float& o1) {
   if (OP == 0) o0 = a + c * __expf(0.5f * b);
   else if (OP == 1) o0 = 0.5f * c * b * __expf(0.5f * a);
   else if (OP == 2) { o0 = k * a; o1 = 0.5f * k * (__expf(b) - 1.0f); }
   else o0 = 2.0f * k * (b - a);
+}
+
+__global__ void __launch_bounds__(LOSS_WG) k_sample_kl_bwd(const float* __restrict__ mu, const float* __restrict__ lv,
+                                                           const float* __restrict__ eps, const float* __restrict__ dl,
+                                                           const float* __restrict__ g, float scale, int64_t n,
+                                                           float* __restrict__ dmu, float* __restrict__ dlv) {
+  const float k = g[0] * scale;
+  const bool al = ((((uintptr_t)mu) | ((uintptr_t)lv) | ((uintptr_t)eps) | ((uintptr_t)dl) | ((uintptr_t)dmu) | ((uintptr_t)dlv)) & 15) == 0;
+  const int64_t stride = 4 * (int64_t)gridDim.x * LOSS_WG;
+  int64_t i = 4 * ((int64_t)blockIdx.x * LOSS_WG + threadIdx.x);
+  auto one = [&](float m, float v, float e, float d, float& om, float& ov) {
+#pragma clang fp contract(off)   // the two parts rounded as the separate kernels round them, then plainly added
+    float t0, t1, u0, u1 = 0.f;
+    loss_map1<2>(m, v, 0.f, k, t0, t1);    // the KL term's part
+    loss_map1<1>(v, e, d, k, u0, u1);      // the sample's part of dlv
+    om = d + t0;              // plain additions of the two separately rounded cotangents (what autograd's accumulation does)
+    ov = u0 + t1;
+  };
+  if (al) {
+    for (; i + 4 <= n; i += stride) {
+      const f4 vm = *reinterpret_cast<const f4*>(mu + i), vv = *reinterpret_cast<const f4*>(lv + i);
+      const f4 ve = *reinterpret_cast<const f4*>(eps + i), vd = *reinterpret_cast<const f4*>(dl + i);
+      f4 r0, r1;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        float t0, t1;
+        one(vm[q], vv[q], ve[q], vd[q], t0, t1);
+        r0[q] = t0;
+        r1[q] = t1;
+      }
+      *reinterpret_cast<f4*>(dmu + i) = r0;
+      *reinterpret_cast<f4*>(dlv + i) = r1;
+    }
+  }
+  for (; i < n; i += stride)
+    for (int q = 0; q < 4 && i + q < n; q++) one(mu[i + q], lv[i + q], eps[i + q], dl[i + q], dmu[i + q], dlv[i + q]);
 }
 
 template <int OP>
@@ -141,12 +192,14 @@ static inline int map_grid(int64_t n) {
 }
 
 template <int TERM>
-static int loss_reduce(const float* a, const float* b, int64_t n, float scale, float* out, float* scratch, void* stream_) {
+static int loss_reduce(const float* a, const float* b, int64_t n, float scale, float* out, float* scratch, void* stream_,
+                       const float* base = nullptr, const float* c = nullptr, float* l = nullptr) {
   if (!out || !scratch || n < 0 || (n > 0 && (!a || !b))) return LDE_ERR_INVALID_ARG;
+  if (TERM == 2 && n > 0 && (!c || !l)) return LDE_ERR_INVALID_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   const int g = n == 0 ? 0 : loss_grid(n);   // an empty sum is 0
-  if (g) hipLaunchKernelGGL(k_loss_partial<TERM>, dim3(g), dim3(LOSS_WG), 0, stream, a, b, n, scratch);
-  hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(64), 0, stream, scratch, g, scale, out);
+  if (g) hipLaunchKernelGGL(k_loss_partial<TERM>, dim3(g), dim3(LOSS_WG), 0, stream, a, b, n, scratch, c, l);
+  hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(64), 0, stream, scratch, g, scale, out, base);
   return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
 }
 
@@ -187,6 +240,25 @@ int lde_kl_backward(const float* mu, const float* logvar, int64_t n, float scale
 
 int lde_mse_forward(const float* x, const float* xhat, int64_t n, float scale, float* out, float* scratch, void* stream) {
   return loss_reduce<1>(x, xhat, n, scale, out, scratch, stream);
+}
+
+int lde_mse_forward_add(const float* x, const float* xhat, int64_t n, float scale, const float* base, float* out, float* scratch,
+                        void* stream) {
+  return loss_reduce<1>(x, xhat, n, scale, out, scratch, stream, base);
+}
+
+int lde_sample_kl_forward(const float* mu, const float* logvar, const float* eps, int64_t n, float scale, const float* base,
+                          float* l, float* out, float* scratch, void* stream) {
+  return loss_reduce<2>(mu, logvar, n, scale, out, scratch, stream, base, eps, l);
+}
+
+int lde_sample_kl_backward(const float* mu, const float* logvar, const float* eps, const float* dl, const float* dout, float scale,
+                           int64_t n, float* dmu, float* dlogvar, void* stream) {
+  if (n < 0 || (n > 0 && (!mu || !logvar || !eps || !dl || !dout || !dmu || !dlogvar))) return LDE_ERR_INVALID_ARG;
+  if (n == 0) return LDE_OK;
+  hipLaunchKernelGGL(k_sample_kl_bwd, dim3(map_grid(n)), dim3(LOSS_WG), 0, (hipStream_t)stream, mu, logvar, eps, dl, dout, scale, n,
+                     dmu, dlogvar);
+  return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
 }
 
 int lde_mse_backward(const float* x, const float* xhat, int64_t n, float scale, const float* dout, float* dxhat, void* stream) {

@@ -3,6 +3,7 @@
     reference                                                                          here
     ---------------------------------------------------------------------------------  ------------------------------
     sample(μ, logσ²) = μ + ε·exp(logσ²/2)   [REF GOKU.jl:155-163], [REF LatentODE.jl:82-89]     sample(mu, logvar)
+    sample + β·vector_kl of the same (μ, logσ²), as loss_batch uses them                         sample_with_kl(mu, logvar, β, B)
     kl(μ, logσ²), vector_kl                  [REF src/utils/utils.jl:15-49]                      kl, vector_kl
     reconstruction_loss = sum(mean((x − x̂)², dims=(2,3)))   [REF model_train.jl:225-238]        reconstruction_loss
 
@@ -97,6 +98,55 @@ class _MseFn(torch.autograd.Function):
         return None, dxh, None
 
 
+class _SampleKlFn(torch.autograd.Function):
+    """(l̃, total) = (μ + ε·exp(logσ²/2), base + scale·Σ kl(μ, logσ²)): lde_sample_kl_forward / _backward — one pass each way
+    over (μ, logσ²) for the sample AND its KL term; the pullback writes the summed cotangents."""
+
+    @staticmethod
+    def forward(ctx, mu, logvar, eps, scale, base):
+        _need_gpu(mu)
+        lib = L.load()
+        out = torch.empty_like(mu)
+        ws = torch.empty(L.LOSS_SCRATCH_FLOATS + 1, device=mu.device, dtype=torch.float32)
+        L.check(lib.lde_sample_kl_forward(_p(mu), _p(logvar), _p(eps), mu.numel(), scale, _p(base) if base is not None else C.c_void_p(),
+                                          _p(out), _p(ws), C.c_void_p(ws.data_ptr() + 4), _stream()), None, "lde_sample_kl_forward")
+        ctx.save_for_backward(mu, logvar, eps)
+        ctx.scale, ctx.has_base = scale, base is not None
+        return out, ws[0]
+
+    @staticmethod
+    def backward(ctx, dl, g):
+        mu, logvar, eps = ctx.saved_tensors
+        dl, g = dl.contiguous(), g.contiguous().float()
+        dmu, dlv = torch.empty_like(mu), torch.empty_like(logvar)
+        L.check(L.load().lde_sample_kl_backward(_p(mu), _p(logvar), _p(eps), _p(dl), _p(g), ctx.scale, mu.numel(), _p(dmu), _p(dlv),
+                                                _stream()), None, "lde_sample_kl_backward")
+        return dmu, dlv, None, None, (g if ctx.has_base else None)
+
+
+class _MseAddFn(torch.autograd.Function):
+    """base + scale·Σ (x − x̂)²: lde_mse_forward_add; the pullback is lde_mse_backward and passes the cotangent on to `base`."""
+
+    @staticmethod
+    def forward(ctx, x, xhat, scale, base):
+        _need_gpu(xhat)
+        ws = torch.empty(L.LOSS_SCRATCH_FLOATS + 1, device=xhat.device, dtype=torch.float32)
+        L.check(L.load().lde_mse_forward_add(_p(x), _p(xhat), xhat.numel(), scale, _p(base), _p(ws), C.c_void_p(ws.data_ptr() + 4),
+                                             _stream()), None, "lde_mse_forward_add")
+        ctx.save_for_backward(x, xhat)
+        ctx.scale = scale
+        return ws[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        x, xhat = ctx.saved_tensors
+        g = g.contiguous().float()
+        dxh = torch.empty_like(xhat)
+        L.check(L.load().lde_mse_backward(_p(x), _p(xhat), xhat.numel(), ctx.scale, _p(g), _p(dxh), _stream()), None,
+                "lde_mse_backward")
+        return None, dxh, None, g
+
+
 def _same_layout(a: torch.Tensor, b: torch.Tensor):
     """a and b brought to contiguous buffers with the SAME element order; also returns the permutation applied to both
     (None when they were contiguous already) so that a caller can undo it — never inferred from shapes: a [16, 16] view
@@ -130,6 +180,28 @@ def sample(mu, logvar, model_type=None):
     return _sample1(mu, logvar)
 
 
+def _sample_kl1(mu, logvar, scale: float, base):
+    m, s, order = _same_layout(mu.float(), logvar.float())
+    eps = torch.randn(m.shape, device=m.device, dtype=torch.float32)
+    out, total = _SampleKlFn.apply(m, s, eps, float(scale), base)
+    if order is not None:
+        out = out.permute([order.index(d) for d in range(mu.dim())])
+    return out, total
+
+
+def sample_with_kl(mu, logvar, beta: float = 1.0, batch_size=None):
+    """(l̃, β·kl_loss): `sample(μ, logσ²)` and `β·vector_kl(μ, logσ²)` of the same arguments, computed together (one kernel pass
+    each way per part instead of a sample pass, a KL pass and the additions of their cotangents)  [REF src/models/GOKU.jl:155-163],
+    [REF src/utils/utils.jl:15-49]. For the GOKU tuple the second part's total continues the first's."""
+    if isinstance(mu, tuple):
+        outs, total = [], None
+        for m, s in zip(mu, logvar):
+            o, total = _sample_kl1(m, s, beta / (batch_size or m.shape[1]), total)
+            outs.append(o)
+        return tuple(outs), total
+    return _sample_kl1(mu, logvar, beta / (batch_size or mu.shape[1]), None)
+
+
 def _kl_sum(mu, logvar, scale: float):
     m, s, _ = _same_layout(mu.float(), logvar.float())
     return _KlFn.apply(m, s, float(scale))
@@ -147,11 +219,14 @@ def vector_kl(mu, logvar, batch_size=None):
     return _kl_sum(mu, logvar, 1.0 / (batch_size or mu.shape[1]))
 
 
-def reconstruction_loss(x, x_hat, batch_size=None):
+def reconstruction_loss(x, x_hat, batch_size=None, plus=None):
     """sum(mean((x − x̂)², dims=(2,3))) for x, x̂ [pixels, B, T]  [REF examples/pendulum_friction-less/model_train.jl:225-238]
-    (`batch_size`: the global B when the arrays are one rank's shard)."""
+    (`batch_size`: the global B when the arrays are one rank's shard). `plus`: a scalar loss term (β·kl_loss from
+    `sample_with_kl`) added inside the reduction's last kernel — `reconstruction_loss + β·kl_loss` without elementwise launches."""
     xs, xh, _ = _same_layout(x.float(), x_hat.float())
     n_mean = batch_size or x_hat.shape[1]
     for d in x_hat.shape[2:]:
         n_mean *= d
+    if plus is not None:
+        return _MseAddFn.apply(xs, xh, 1.0 / n_mean, plus.float())
     return _MseFn.apply(xs, xh, 1.0 / n_mean)

@@ -17,6 +17,7 @@ no kernel of its own.
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Iterable, List, Optional, Sequence
 
 import numpy as np
@@ -24,8 +25,11 @@ import torch
 
 from .api import Decoder
 from .chain import decode, default_decoder_layers
-from .loss import reconstruction_loss, sample, vector_kl  # noqa: F401
+from .loss import reconstruction_loss, sample, sample_with_kl, vector_kl  # noqa: F401
 from .recurrent import Encoder, default_encoder_layers, encode
+
+
+_FUSED_LOSS = os.environ.get("LDE_FUSED_LOSS", "1") != "0"   # loss_batch: sample + KL in one pass (diagnostic switch)
 
 
 class LatentDiffEqModel:
@@ -76,6 +80,13 @@ def kl(mu, logvar):
 def loss_batch(model, x, t, beta: float, variational: bool, batch_size: Optional[int] = None):
     """reconstruction_loss + β·kl_loss with reconstruction_loss = sum(mean((x − x̂)², dims=(2,3)))  [REF model_train.jl:225-238].
     `batch_size`: the GLOBAL minibatch size when x is one rank's shard (the per-rank losses then add up to the reference's)."""
+    if variational and _FUSED_LOSS:
+        # the same expression with the sample and the KL term read in one pass and the scalar additions folded into the
+        # reductions (loss.sample_with_kl): encoder → (l̃, β·kl) → decoder → reconstruction_loss + β·kl
+        mu, logvar = encode(model.encoder, x)
+        l_tilde, bkl = sample_with_kl(mu, logvar, beta, batch_size)
+        x_hat, _z, _l = decode(model.decoder, l_tilde, t)
+        return reconstruction_loss(x, x_hat, batch_size, plus=bkl)
     (x_hat, _z, _l), mu, logvar = model(x, t, variational)
     return reconstruction_loss(x, x_hat, batch_size) + beta * vector_kl(mu, logvar, batch_size)
 

@@ -311,6 +311,35 @@ class NativeLoss:
         L.check(self.lib.lde_kl_backward(p(m), p(s), m.numel(), scale, p(gd), p(dm), p(ds), self._s()), None, "lde_kl_backward")
         return dm.cpu().numpy(), ds.cpu().numpy()
 
+    def sample_kl_forward(self, mu, logvar, eps, scale, base=None, offset=0):
+        m, s, e = self._d(mu, offset), self._d(logvar, offset), self._d(eps, offset)
+        l = torch.full_like(m, 7.0)
+        out = torch.full((1,), 7.0, device="cuda")
+        scratch = torch.full((L.LOSS_SCRATCH_FLOATS,), float("nan"), device="cuda")
+        bd = torch.tensor([base], device="cuda", dtype=torch.float32) if base is not None else None
+        p = lambda t: C.c_void_p(t.data_ptr())
+        L.check(self.lib.lde_sample_kl_forward(p(m), p(s), p(e), m.numel(), scale, p(bd) if bd is not None else C.c_void_p(), p(l), p(out),
+                                               p(scratch), self._s()), None, "lde_sample_kl_forward")
+        return l.cpu().numpy(), float(out.cpu()[0])
+
+    def sample_kl_backward(self, mu, logvar, eps, dl, g, scale, offset=0):
+        m, s, e, d = self._d(mu, offset), self._d(logvar, offset), self._d(eps, offset), self._d(dl, offset)
+        gd = torch.tensor([g], device="cuda", dtype=torch.float32)
+        dm, ds = torch.full_like(m, 7.0), torch.full_like(m, 7.0)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        L.check(self.lib.lde_sample_kl_backward(p(m), p(s), p(e), p(d), p(gd), scale, m.numel(), p(dm), p(ds), self._s()), None,
+                "lde_sample_kl_backward")
+        return dm.cpu().numpy(), ds.cpu().numpy()
+
+    def mse_forward_add(self, x, xhat, scale, base, offset=0):
+        a, b = self._d(x, offset), self._d(xhat, offset)
+        out = torch.full((1,), 7.0, device="cuda")
+        scratch = torch.full((L.LOSS_SCRATCH_FLOATS,), float("nan"), device="cuda")
+        bd = torch.tensor([base], device="cuda", dtype=torch.float32)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        L.check(self.lib.lde_mse_forward_add(p(a), p(b), a.numel(), scale, p(bd), p(out), p(scratch), self._s()), None, "lde_mse_forward_add")
+        return float(out.cpu()[0])
+
     def mse_backward(self, x, xhat, scale, g, offset=0):
         a, b = self._d(x, offset), self._d(xhat, offset)
         gd = torch.tensor([g], device="cuda", dtype=torch.float32)

@@ -67,6 +67,68 @@ def test_mse_and_its_pullback(nat, o64, n, offset):
     assert _rel(nat.mse_backward(x, xh, scale, 0.3, offset), o64.mse_backward(x, xh, scale, 0.3)) <= E_ELEM
 
 
+@pytest.mark.parametrize("n,offset", SIZES)
+def test_sample_with_kl_in_one_pass(nat, o64, n, offset):
+    """lde_sample_kl_forward / _backward and lde_mse_forward_add = the separate entry points composed as loss_batch composes
+    them: against the oracle's separate terms, and bit for bit against the separate kernels where the arithmetic is the same
+    (the sample, both reductions before `base` is added, and the summed cotangents)."""
+    rng = np.random.default_rng(13 * n + offset)
+    mu, eps, dl = (rng.standard_normal(n).astype(np.float32) for _ in range(3))
+    ls = (0.7 * rng.standard_normal(n)).astype(np.float32)
+    scale, base, g = 1e-3 / 13, 0.625, 1.7
+    l, tot = nat.sample_kl_forward(mu, ls, eps, scale, base, offset)
+    assert np.array_equal(l, nat.sample_forward(mu, ls, eps, offset))
+    assert _rel(l, o64.sample_forward(mu, ls, eps)) <= E_ELEM
+    kl = nat.kl_forward(mu, ls, scale, offset)
+    assert tot == float(np.float32(base) + np.float32(kl))
+    assert abs((tot - base) - o64.kl_forward(mu, ls, scale)) <= E_SUM * abs(o64.kl_forward(mu, ls, scale)) + 1e-7
+    _, tot0 = nat.sample_kl_forward(mu, ls, eps, scale, None, offset)
+    assert tot0 == kl
+    dm, dv = nat.sample_kl_backward(mu, ls, eps, dl, g, scale, offset)
+    km, kv = nat.kl_backward(mu, ls, scale, g, offset)
+    sv = nat.sample_backward(ls, eps, dl, offset)
+    assert np.array_equal(dm, dl + km) and np.array_equal(dv, sv + kv)
+    om, ov = o64.kl_backward(mu, ls, scale, g)
+    _, osv = o64.sample_backward(ls, eps, dl)
+    assert _rel(dm, dl.astype(np.float64) + om) <= E_ELEM and _rel(dv, osv + ov) <= E_ELEM
+    x, xh = rng.random(n).astype(np.float32), rng.random(n).astype(np.float32)
+    assert nat.mse_forward_add(x, xh, 1 / 50.0, base, offset) == float(np.float32(base) + np.float32(nat.mse_forward(x, xh, 1 / 50.0, offset)))
+
+
+def test_loss_batch_fused_equals_the_separate_terms():
+    """train.loss_batch with the sample and β·KL in one pass (default) vs the reference's composition of sample / vector_kl /
+    reconstruction_loss and torch additions (LDE_FUSED_LOSS=0): same ε (same generator state), same loss to f32 rounding of the
+    scalar additions, same gradients to 1e-6 of their largest entry."""
+    import torch
+    import latentdiffeq_amd as la
+    from latentdiffeq_amd import train as TR
+    torch.manual_seed(3)
+    mt, diffeq = la.GOKU_basic(), la.Pendulum()
+    enc, dec = TR.default_layers(mt, 64, diffeq, device="cuda", hidden_dim_resnet=48)
+    with torch.no_grad():
+        dec[0][1]._dense[-1].bias.fill_(1.0)
+    model = TR.LatentDiffEqModel(mt, enc, dec)
+    B, T = 24, 12
+    ts = np.arange(T) * 0.05
+    x = torch.rand(T, B, 64, device="cuda").permute(2, 1, 0)
+    res = []
+    for fused in (True, False):
+        TR._FUSED_LOSS = fused
+        try:
+            for p in model.parameters():
+                p.grad = None
+            torch.manual_seed(11)
+            loss = TR.loss_batch(model, x, ts, 0.5, True)
+            loss.backward()
+            res.append((float(loss.detach()), [p.grad.detach().clone() for p in model.parameters()]))
+        finally:
+            TR._FUSED_LOSS = True
+    (lf, gf), (ls_, gs) = res
+    assert abs(lf - ls_) <= 2e-6 * abs(ls_), (lf, ls_)
+    for a, b in zip(gf, gs):
+        assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-12
+
+
 def test_known_answers_and_edges(nat):
     z = np.zeros(64, np.float32)
     assert nat.kl_forward(z, z, 1.0) == 0.0                      # kl(0, 0) = 0 exactly

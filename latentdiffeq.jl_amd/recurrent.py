@@ -235,7 +235,7 @@ def apply_pattern_extractor(encoder: Encoder, fe_out):
     [REF src/models/LatentODE.jl:24-33]: one stack on the reversed frames."""
     if isinstance(encoder.model_type, GOKU):
         outs = _run_concurrently(encoder.pattern_extractor, fe_out)
-        return outs[0], torch.cat([outs[1], outs[2]], dim=0)
+        return outs[0], torch.cat([outs[1].t(), outs[2].t()], dim=1).t()   # vcat, kept in batch-major memory (what latent_in reads)
     if isinstance(encoder.model_type, LatentODE):
         return encoder.pattern_extractor(fe_out)
     raise TypeError(f"no apply_pattern_extractor method for model type {type(encoder.model_type).__name__}")
@@ -290,7 +290,7 @@ def _encode_goku_branches(encoder: Encoder, fe_out):
     with torch.cuda.stream(sB):
         sB.wait_stream(sC)
         pe_b.record_stream(sB)
-        pe_th = torch.cat([pe_f, pe_b], dim=0)
+        pe_th = torch.cat([pe_f.t(), pe_b.t()], dim=1).t()    # vcat [REF GOKU.jl:47] in batch-major memory: latent_in reads it in place
         mu_th, ls_th = li_mu_th(pe_th), li_ls_th(pe_th)
     main.wait_stream(sA)
     main.wait_stream(sB)

@@ -346,6 +346,21 @@ int lde_sample_kl_backward(const float* mu, const float* logvar, const float* ep
 int lde_mse_forward_add(const float* x, const float* xhat, int64_t n, float scale, const float* base, float* out, float* scratch,
                         void* stream);
 
+/* The parameter update of the training step: `Flux.Optimise.update!(opt, ps, gs)` with `opt = ADAMW(η, (β₁, β₂), decay)`
+ * [REF examples/pendulum_friction-less/model_train.jl:138, :190-192] — in the pinned Flux 0.13.6 [REF Manifest.toml:452]
+ * `Optimiser(ADAM(η, β), WeightDecay(decay))`: per array  m ← β₁m + (1−β₁)g;  v ← β₂v + (1−β₂)g²;
+ * Δ = m/(1−β₁ᵗ) / (√(v/(1−β₂ᵗ)) + ε)·η + decay·x;  x ← x − Δ  (the decay is not scaled by η). ONE launch for all n arrays
+ * (`t`: a HOST array of device pointers; m and v are the caller's state arrays, zero before the first step); `step` = t ≥ 1. */
+typedef struct lde_adam_tensor {
+  float* p;          /* parameters, updated in place */
+  const float* g;    /* their gradient */
+  float* m;          /* first moment  (state) */
+  float* v;          /* second moment (state) */
+  int64_t n;         /* floats */
+} lde_adam_tensor;
+int lde_adamw_flux_step(int n, const lde_adam_tensor* t, float lr, float beta1, float beta2, float eps, float decay, int64_t step,
+                        void* stream);
+
 /* ====================================================================================================================
  * The one collective of the path. The reference's only parallelism is `EnsembleThreads()` over the
  * trajectories of one batch  [REF src/models/GOKU.jl:121]; here the batch shards by trajectory over one process per GPU

@@ -34,7 +34,7 @@ EXPORTS = ["lde_abi_version", "lde_problem_desc_default", "lde_num_weights", "ld
            "lde_rnn_num_weights", "lde_rnn_create", "lde_rnn_destroy", "lde_rnn_set_weights", "lde_rnn_set_weights_device",
            "lde_rnn_reserve", "lde_rnn_forward", "lde_rnn_backward", "lde_rnn_last_error", "lde_refresh_weights",
            "lde_sample_forward", "lde_sample_backward", "lde_kl_forward", "lde_kl_backward", "lde_mse_forward",
-           "lde_mse_backward", "lde_sample_kl_forward", "lde_sample_kl_backward", "lde_mse_forward_add",
+           "lde_mse_backward", "lde_sample_kl_forward", "lde_sample_kl_backward", "lde_mse_forward_add", "lde_adamw_flux_step",
            "lde_comm_unique_id", "lde_comm_init", "lde_comm_allreduce_f32", "lde_comm_nranks", "lde_comm_rank",
            "lde_comm_destroy", "lde_comm_last_error"]
 COMM_ID_BYTES = 128
@@ -160,6 +160,7 @@ def load():
     lib.lde_sample_kl_forward.argtypes = [vp, vp, vp, i64, f32, vp, vp, vp, vp, vp]
     lib.lde_sample_kl_backward.argtypes = [vp, vp, vp, vp, vp, f32, i64, vp, vp, vp]
     lib.lde_mse_forward_add.argtypes = [vp, vp, i64, f32, vp, vp, vp, vp]
+    lib.lde_adamw_flux_step.argtypes = [i32, C.POINTER(AdamTensor), f32, f32, f32, f32, f32, i64, vp]
     lib.lde_comm_unique_id.argtypes = [C.c_char_p]
     lib.lde_comm_init.argtypes = [C.POINTER(vp), i32, i32, C.c_char_p]
     lib.lde_comm_allreduce_f32.argtypes = [vp, vp, i64, vp]
@@ -185,6 +186,11 @@ def raw_stream(device_index=None) -> C.c_void_p:
 
 
 MODULE_CHAIN, MODULE_RNN = 0, 1
+
+
+class AdamTensor(C.Structure):
+    """lde_adam_tensor (include/lde.h)."""
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("n", C.c_int64)]
 
 
 def weights_key(W):

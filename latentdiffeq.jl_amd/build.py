@@ -18,7 +18,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "_obj")
 LIB = os.path.join(HERE, "liblde.so")
-SOURCES = ["lde_api.hip", "lde_pendulum.hip", "lde_mlp.hip", "lde_chain.hip", "lde_rnn.hip", "lde_loss.hip", "lde_comm.hip"]
+SOURCES = ["lde_api.hip", "lde_pendulum.hip", "lde_mlp.hip", "lde_chain.hip", "lde_rnn.hip", "lde_loss.hip", "lde_optim.hip", "lde_comm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function"]
 
 

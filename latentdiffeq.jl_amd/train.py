@@ -136,18 +136,62 @@ class FluxADAMW(torch.optim.Adam):
     """`ADAMW(η, (β₁, β₂), decay)` of the pinned Flux 0.13.6 [REF Manifest.toml:452] = `Optimiser(ADAM(η, β), WeightDecay(decay))`
     [REF examples/pendulum_friction-less/model_train.jl:138]: Δ = η·m̂/(√v̂ + ε), then Δ += decay·x, then x −= Δ, i.e.
     x ← (1 − decay)·x − ADAM step — the decay is NOT multiplied by η (torch.optim.AdamW applies lr·weight_decay·x: 1000× weaker at
-    the example's η = decay = 1e-3). ε = 1e-8 and the bias correction are Flux's = torch's. Implemented as one multi-tensor scale
-    of the parameters followed by torch's (fused, on GPU) Adam update with the gradients taken at the un-decayed point."""
+    the example's η = decay = 1e-3). ε = 1e-8 and the bias correction are Flux's = torch's.
+    On the GPU (`native`, the default when every parameter is a contiguous f32 HIP tensor) the whole update is ONE liblde.so launch
+    for all parameter arrays (lde_adamw_flux_step) — no per-step tensor grouping, step-counter kernels or separate decay pass;
+    otherwise one multi-tensor scale of the parameters followed by torch's Adam update with the gradients taken at the un-decayed
+    point (same arithmetic up to rounding; tests/test_gpu_optim.py compares the two)."""
 
-    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), decay: float = 0.0, eps: float = 1e-8, fused=None):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), decay: float = 0.0, eps: float = 1e-8, fused=None, native=None):
         params = list(params)
+        on_gpu = bool(params) and all(p.is_cuda for p in params)
         if fused is None:
-            fused = bool(params) and all(p.is_cuda for p in params)
+            fused = on_gpu
         super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0.0, fused=fused or None)
         self.decay = float(decay)
+        ok = on_gpu and all(p.dtype == torch.float32 and p.is_contiguous() for p in params)
+        if native is None:
+            native = ok and os.environ.get("LDE_NATIVE_ADAM", "1") != "0"
+        if native and not ok:
+            raise ValueError("FluxADAMW(native=True) needs contiguous float32 HIP parameters")
+        self.native = bool(native)
+        self._t = 0
+
+    @torch.no_grad()
+    def _native_step(self):
+        import ctypes as C
+        from . import _lib as L
+        lib = L.load()
+        self._t += 1
+        for g in self.param_groups:
+            ps = [p for p in g["params"] if p.grad is not None]
+            if not ps:
+                continue
+            tab, keep = (L.AdamTensor * len(ps))(), []
+            for i, p in enumerate(ps):
+                st = self.state[p]
+                if not st:
+                    st["step"], st["exp_avg"], st["exp_avg_sq"] = 0, torch.zeros_like(p), torch.zeros_like(p)
+                st["step"] += 1
+                gr = p.grad
+                if gr.dtype != torch.float32 or not gr.is_contiguous():
+                    gr = gr.float().contiguous()
+                    keep.append(gr)
+                t = tab[i]
+                t.p, t.g, t.m, t.v, t.n = p.data_ptr(), gr.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+            # one step count per group: Flux keeps β₁ᵗ, β₂ᵗ per array, and every array of a model is updated at every step
+            L.check(lib.lde_adamw_flux_step(len(ps), tab, g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.decay,
+                                            self.state[ps[0]]["step"], L.raw_stream(ps[0].device.index)), None, "lde_adamw_flux_step")
 
     @torch.no_grad()
     def step(self, closure=None):
+        if self.native:
+            loss = None
+            if closure is not None:
+                with torch.enable_grad():
+                    loss = closure()
+            self._native_step()
+            return loss
         if self.decay:
             for g in self.param_groups:
                 ps = [p for p in g["params"] if p.grad is not None]

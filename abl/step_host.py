@@ -12,12 +12,12 @@ with torch.no_grad():
     dec[0][1]._dense[-1].bias.fill_(1.0)
 model = TR.LatentDiffEqModel(mt, enc, dec)
 params = model.parameters()
-opt = torch.optim.AdamW(params, lr=1e-3, fused=True)
+opt = TR.FluxADAMW(params, lr=1e-3, decay=1e-10)
 x = torch.rand(NI, B, T, device="cuda"); ts = np.arange(T) * 0.05
 def step():
     opt.zero_grad(set_to_none=True)
     loss = TR.loss_batch(model, x, ts, 1e-3, True)
-    loss.backward(); opt.step()
+    loss.backward(); opt.step(); model.refresh_weights()
 for _ in range(10): step()
 torch.cuda.synchronize()
 t0 = time.perf_counter()

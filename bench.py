@@ -389,6 +389,10 @@ def run_goku_step(args, torch, dist, world, rank, local):
     Bg = B * world
 
     fused_loss = os.environ.get("LDE_FUSED_LOSS", "1") != "0"     # diagnostic: 0 = separate sample / vector_kl / reconstruction_loss and torch additions
+    if os.environ.get("LDE_ASYNC_DW", "0") != "0":               # opt-in: weight-gradient kernels of the chain / recurrent pullbacks on a stream of their
+                                                                   # own (measured at B = 256: 1.86 vs 1.66 ms median over 8 alternations — the wide dW grids
+                                                                   # slow the latency-bound small kernels they overlap with more than they save; off)
+        L.set_async_weight_gradients(True, dev)
     refresh = os.environ.get("LDE_BENCH_REFRESH", "1") != "0"   # diagnostic: 0 = every module re-uploads its weights at its next call
 
     def step():
@@ -403,6 +407,7 @@ def run_goku_step(args, torch, dist, world, rank, local):
             x_hat, z_hat, l_hat = decode(dec, l_tilde, ts)
             loss = reconstruction_loss(x, x_hat, Bg) + 1e-3 * vector_kl(mu, logvar, Bg)
         loss.backward()
+        L.join_weight_gradients()
         sync()
         opt.step()
         if refresh:

@@ -346,6 +346,17 @@ int lde_sample_kl_backward(const float* mu, const float* logvar, const float* ep
 int lde_mse_forward_add(const float* x, const float* xhat, int64_t n, float scale, const float* base, float* out, float* scratch,
                         void* stream);
 
+/* Where the chain / recurrent pullbacks enqueue their WEIGHT-GRADIENT kernels. Default (NULL): on the caller's stream, after
+ * the pullback kernel — `dW` is complete in stream order like every other output. With a stream set, lde_chain_backward[_saved]
+ * and lde_rnn_backward enqueue only the input-gradient kernel on the caller's stream and the kernels that produce `dW` on this
+ * one (ordered after it by an event): the next module's pullback does not wait for them — in the reference's Zygote pullback
+ * they are independent closures too [REF examples/pendulum_friction-less/model_train.jl:186-189]. `dW` is then complete only
+ * after lde_join_dw(s), which makes stream `s` wait (on the device; the host does not block) for every weight-gradient kernel
+ * enqueued so far: call it before the optimiser / all-reduce reads the gradients. A handle's next pullback waits for its own
+ * previous weight-gradient kernels by itself (its workspace is reused). Process-wide; lde_adjoint's dW is not affected. */
+int lde_set_dw_stream(void* stream);
+int lde_join_dw(void* stream);
+
 /* The parameter update of the training step: `Flux.Optimise.update!(opt, ps, gs)` with `opt = ADAMW(η, (β₁, β₂), decay)`
  * [REF examples/pendulum_friction-less/model_train.jl:138, :190-192] — in the pinned Flux 0.13.6 [REF Manifest.toml:452]
  * `Optimiser(ADAM(η, β), WeightDecay(decay))`: per array  m ← β₁m + (1−β₁)g;  v ← β₂v + (1−β₂)g²;

@@ -34,7 +34,7 @@ EXPORTS = ["lde_abi_version", "lde_problem_desc_default", "lde_num_weights", "ld
            "lde_rnn_num_weights", "lde_rnn_create", "lde_rnn_destroy", "lde_rnn_set_weights", "lde_rnn_set_weights_device",
            "lde_rnn_reserve", "lde_rnn_forward", "lde_rnn_backward", "lde_rnn_last_error", "lde_refresh_weights",
            "lde_sample_forward", "lde_sample_backward", "lde_kl_forward", "lde_kl_backward", "lde_mse_forward",
-           "lde_mse_backward", "lde_sample_kl_forward", "lde_sample_kl_backward", "lde_mse_forward_add", "lde_adamw_flux_step",
+           "lde_mse_backward", "lde_sample_kl_forward", "lde_sample_kl_backward", "lde_mse_forward_add", "lde_adamw_flux_step", "lde_set_dw_stream", "lde_join_dw",
            "lde_comm_unique_id", "lde_comm_init", "lde_comm_allreduce_f32", "lde_comm_nranks", "lde_comm_rank",
            "lde_comm_destroy", "lde_comm_last_error"]
 COMM_ID_BYTES = 128
@@ -160,6 +160,8 @@ def load():
     lib.lde_sample_kl_forward.argtypes = [vp, vp, vp, i64, f32, vp, vp, vp, vp, vp]
     lib.lde_sample_kl_backward.argtypes = [vp, vp, vp, vp, vp, f32, i64, vp, vp, vp]
     lib.lde_mse_forward_add.argtypes = [vp, vp, i64, f32, vp, vp, vp, vp]
+    lib.lde_set_dw_stream.argtypes = [vp]
+    lib.lde_join_dw.argtypes = [vp]
     lib.lde_adamw_flux_step.argtypes = [i32, C.POINTER(AdamTensor), f32, f32, f32, f32, f32, i64, vp]
     lib.lde_comm_unique_id.argtypes = [C.c_char_p]
     lib.lde_comm_init.argtypes = [C.POINTER(vp), i32, i32, C.c_char_p]
@@ -186,6 +188,32 @@ def raw_stream(device_index=None) -> C.c_void_p:
 
 
 MODULE_CHAIN, MODULE_RNN = 0, 1
+
+dw_stream = None        # torch.cuda.Stream the chain / recurrent pullbacks enqueue their weight-gradient kernels on (or None)
+
+
+def set_async_weight_gradients(on: bool = True, device=None):
+    """lde_set_dw_stream: the pullbacks of Chain / Recurrent put their weight-gradient kernels on a stream of their own, off the
+    critical path of the backward pass. The gradients of the parameters are then complete only after `join_weight_gradients()` —
+    call it after `loss.backward()` and before anything reads `.grad` (optimiser step, all-reduce, clipping). Opt-in."""
+    global dw_stream
+    import torch
+    lib = load()
+    if on:
+        if dw_stream is None:
+            dw_stream = torch.cuda.Stream(device)
+        check(lib.lde_set_dw_stream(C.c_void_p(dw_stream.cuda_stream)), None, "lde_set_dw_stream")
+    else:
+        if dw_stream is not None:
+            join_weight_gradients()
+        check(lib.lde_set_dw_stream(None), None, "lde_set_dw_stream")
+        dw_stream = None
+
+
+def join_weight_gradients():
+    """lde_join_dw on the current stream (a device-side wait; the host does not block). No-op when the mode is off."""
+    if dw_stream is not None:
+        check(load().lde_join_dw(raw_stream(dw_stream.device.index)), None, "lde_join_dw")
 
 
 class AdamTensor(C.Structure):

@@ -117,6 +117,8 @@ class _ChainFn(torch.autograd.Function):
         stream = L.raw_stream(x.device.index)
         dx = torch.empty_like(x) if ctx.need_dx else None
         dW = torch.empty((chain.num_weights,), device=x.device, dtype=torch.float32)     # written, not accumulated (set_accumulate(0))
+        if L.dw_stream is not None:
+            dW.record_stream(L.dw_stream)          # written on the weight-gradient stream (set_async_weight_gradients)
         pdx = C.c_void_p(dx.data_ptr()) if dx is not None else C.c_void_p()
         if ctx.has_saved:
             L.check(lib.lde_chain_backward_saved(h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(dy.data_ptr()),

@@ -7,6 +7,8 @@
 // hot path once lde_reserve() (or a first call of the same size) has run.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -118,9 +120,29 @@ static int validate(const lde_problem_desc* d, std::string* why) {
   return LDE_OK;
 }
 
+// the weight-gradient stream of the chain / recurrent pullbacks (lde_mfma.h: dw_stream_get); one per process
+static std::atomic<hipStream_t> g_dw_stream{nullptr};
+static hipEvent_t g_dw_join = nullptr;
+namespace lde {
+hipStream_t dw_stream_get() { return g_dw_stream.load(std::memory_order_acquire); }
+}
+
 extern "C" {
 
 int lde_abi_version(void) { return LDE_ABI_VERSION; }
+
+int lde_set_dw_stream(void* stream) {
+  g_dw_stream.store((hipStream_t)stream, std::memory_order_release);
+  return LDE_OK;
+}
+
+int lde_join_dw(void* stream) {
+  hipStream_t dws = g_dw_stream.load(std::memory_order_acquire);
+  if (!dws || dws == (hipStream_t)stream) return LDE_OK;
+  if (!g_dw_join && hipEventCreateWithFlags(&g_dw_join, hipEventDisableTiming) != hipSuccess) return LDE_ERR_HIP;
+  if (hipEventRecord(g_dw_join, dws) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, g_dw_join, 0) != hipSuccess) return LDE_ERR_HIP;
+  return LDE_OK;
+}
 
 int lde_problem_desc_default(lde_problem_desc* d) {
   if (!d) return LDE_ERR_INVALID_ARG;

@@ -539,6 +539,7 @@ struct lde_chain {
   float* wts = nullptr; size_t wts_cap = 0;
   float* slab = nullptr; size_t slab_cap = 0;
   int32_t* ints = nullptr; size_t ints_cap = 0;   // zero words for the slab reduction: [0] "no private slabs", [2..3] feedback sink
+  DwSync dws;                  // weight-gradient kernels on the dw stream (lde_set_dw_stream)
   std::string err;
 };
 
@@ -580,6 +581,7 @@ void lde_chain_destroy(lde_chain* c) {
   if (c->wts) (void)hipFree(c->wts);
   if (c->slab) (void)hipFree(c->slab);
   if (c->ints) (void)hipFree(c->ints);
+  dw_sync_destroy(c->dws);
   delete c;
 }
 
@@ -901,6 +903,10 @@ static int chain_backward_impl(lde_chain* c, const float* x, const float* y, con
     c->err = "lde_chain_backward: y and dy must be 16-byte aligned";
     return LDE_ERR_INVALID_ARG;
   }
+  if (!dw_sync_begin(c->dws, (hipStream_t)stream_)) {   // the workspace is about to be rewritten
+    c->err = "lde_chain_backward: waiting for the previous weight gradient failed";
+    return LDE_ERR_HIP;
+  }
   int rc = lde_chain_reserve(c, N);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)stream_;
@@ -942,7 +948,17 @@ static int chain_backward_impl(lde_chain* c, const float* x, const float* y, con
 #if LDE_PROF
   { (void)hipStreamSynchronize(stream); long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
 #endif
-  rc = launch_weight_gradient(dm, da, nvt, 1, nullptr, c->ints, 0, dW, c->ints + 2, stream, c->err, !c->accumulate, c->bf16);
+  bool sw_ok = true;
+  hipStream_t wst = dw_sync_switch(c->dws, stream, &sw_ok);
+  if (!sw_ok) {
+    c->err = "lde_chain_backward: switching to the weight-gradient stream failed";
+    return LDE_ERR_HIP;
+  }
+  rc = launch_weight_gradient(dm, da, nvt, 1, nullptr, c->ints, 0, dW, c->ints + 2, wst, c->err, !c->accumulate, c->bf16);
+  if (rc == LDE_OK && !dw_sync_end(c->dws, wst, stream)) {
+    c->err = "lde_chain_backward: hipEventRecord failed";
+    return LDE_ERR_HIP;
+  }
   if (rc) return rc;
 #if LDE_PROF
   {

@@ -484,6 +484,50 @@ static __global__ void k_reduce_tiles(const float* __restrict__ priv, const int3
   }
 }
 
+// ---- the weight-gradient stream (lde_set_dw_stream, include/lde.h): defined in lde_api.hip, shared by the chain and recurrent
+// pullbacks. A pullback's dW kernels depend on its staged panels only, and nothing but the optimiser depends on them: on a
+// stream of their own they leave the critical path of the backward pass (dx of this module → the next module's pullback).
+hipStream_t dw_stream_get();
+// After the pullback kernel was enqueued on `stream`: returns the stream its weight-gradient kernels go to — the dw stream,
+// made to wait for everything enqueued on `stream` so far, or `stream` itself when none is set. `prev_done`: this handle's
+// event after its previous weight-gradient launch (the workspace is per handle); the caller waited on it already.
+struct DwSync {
+  hipEvent_t staged = nullptr;   // the pullback kernel's panels are complete (recorded on the caller's stream)
+  hipEvent_t done = nullptr;     // this handle's weight-gradient kernels are complete (recorded on the dw stream)
+  bool pending = false;
+};
+inline void dw_sync_destroy(DwSync& s) {
+  if (s.staged) (void)hipEventDestroy(s.staged);
+  if (s.done) (void)hipEventDestroy(s.done);
+  s.staged = s.done = nullptr;
+}
+// before the pullback kernel overwrites the handle's workspace: wait for the handle's previous weight-gradient kernels
+inline bool dw_sync_begin(DwSync& s, hipStream_t stream) {
+  if (!s.pending) return true;
+  s.pending = false;
+  return hipStreamWaitEvent(stream, s.done, 0) == hipSuccess;
+}
+inline hipStream_t dw_sync_switch(DwSync& s, hipStream_t stream, bool* ok) {
+  *ok = true;
+  hipStream_t dws = dw_stream_get();
+  if (!dws || dws == stream) return stream;
+  if (!s.staged && (hipEventCreateWithFlags(&s.staged, hipEventDisableTiming) != hipSuccess ||
+                    hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess)) {
+    *ok = false;
+    return stream;
+  }
+  if (hipEventRecord(s.staged, stream) != hipSuccess || hipStreamWaitEvent(dws, s.staged, 0) != hipSuccess) {
+    *ok = false;
+    return stream;
+  }
+  return dws;
+}
+inline bool dw_sync_end(DwSync& s, hipStream_t used, hipStream_t stream) {
+  if (used == stream) return true;
+  s.pending = true;
+  return hipEventRecord(s.done, used) == hipSuccess;
+}
+
 template <class T>
 static bool grow(T** ptr, size_t* cap, size_t need) {
   if (need <= *cap) return true;

@@ -458,6 +458,7 @@ struct lde_rnn {
   bool have_W = false;
   size_t lds = 0;
   int g0w = 0;
+  DwSync dws;              // weight-gradient kernels on the dw stream (lde_set_dw_stream)
   // workspace
   float* rec = nullptr; size_t rec_cap = 0;
   float* stage[RNN_ML] = {nullptr, nullptr, nullptr, nullptr}; size_t stage_cap[RNN_ML] = {0, 0, 0, 0};
@@ -510,6 +511,7 @@ void lde_rnn_destroy(lde_rnn* r) {
   if (r->g0) (void)hipFree(r->g0);
   if (r->slab) (void)hipFree(r->slab);
   if (r->ints) (void)hipFree(r->ints);
+  dw_sync_destroy(r->dws);
   delete r;
 }
 
@@ -739,6 +741,10 @@ int lde_rnn_backward(lde_rnn* r, const float* x, const float* dy, int T, int B, 
   int rc = lde_rnn_reserve(r, B, T);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)stream_;
+  if (!dw_sync_begin(r->dws, stream)) {   // the workspace is about to be rewritten
+    r->err = "lde_rnn_backward: waiting for the previous weight gradient failed";
+    return LDE_ERR_HIP;
+  }
   const RnnDims& rd = r->rd;
   const int ntile = cdiv(B, 16);
   RnnArgs a;
@@ -748,16 +754,22 @@ int lde_rnn_backward(lde_rnn* r, const float* x, const float* dy, int T, int B, 
   for (int l = 0; l < rd.nL; l++) { a.stage[l] = r->stage[l]; a.blk[l] = r->dmw[l].blk_floats; }
   rc = rnn_launch(r, a, B, stream);
   if (rc) return rc;
+  bool sw_ok = true;
+  hipStream_t wst = dw_sync_switch(r->dws, stream, &sw_ok);   // the weight-gradient kernels: on the dw stream when one is set
+  if (!sw_ok) {
+    r->err = "lde_rnn_backward: switching to the weight-gradient stream failed";
+    return LDE_ERR_HIP;
+  }
   for (int l = 0; l < rd.nL; l++) {
     DwArgs da;
     da.stage = r->stage[l]; da.wts = r->wts; da.nslots = nullptr; da.slab = r->slab; da.cap = T; da.total = (long long)ntile * T;   // every tile staged exactly T slots
     int ks = cdiv(512, ntile * dw_jobs(r->dmw[l], dw_pick_ndw(r->dmw[l])));
     ks = ks < 1 ? 1 : (ks > 8 ? 8 : ks);
-    rc = launch_weight_gradient(r->dmw[l], da, ntile, ks, nullptr, r->ints, 0, dW + rd.f_off[l], r->ints + 2, stream, r->err, !r->accumulate);
+    rc = launch_weight_gradient(r->dmw[l], da, ntile, ks, nullptr, r->ints, 0, dW + rd.f_off[l], r->ints + 2, wst, r->err, !r->accumulate);
     if (rc) return rc;
   }
-  hipLaunchKernelGGL(k_rnn_state0, dim3(r->g0w), dim3(64), 0, stream, r->g0, B, r->g0w, rd, dW, r->accumulate ? 0 : 1);
-  if (hipGetLastError() != hipSuccess) {
+  hipLaunchKernelGGL(k_rnn_state0, dim3(r->g0w), dim3(64), 0, wst, r->g0, B, r->g0w, rd, dW, r->accumulate ? 0 : 1);
+  if (hipGetLastError() != hipSuccess || !dw_sync_end(r->dws, wst, stream)) {
     r->err = "recurrent stack: gradient kernels failed to launch";
     return LDE_ERR_HIP;
   }

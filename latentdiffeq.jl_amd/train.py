@@ -23,6 +23,7 @@ from typing import Callable, Iterable, List, Optional, Sequence
 import numpy as np
 import torch
 
+from . import _lib as L
 from .api import Decoder
 from .chain import decode, default_decoder_layers
 from .loss import reconstruction_loss, sample, sample_with_kl, vector_kl  # noqa: F401
@@ -227,6 +228,7 @@ def train(model: LatentDiffEqModel, loader_train: Iterable, val_set, dt: float, 
             opt.zero_grad(set_to_none=True)
             loss = loss_batch(model, xb, t, beta, variational)
             loss.backward()
+            L.join_weight_gradients()          # no-op unless _lib.set_async_weight_gradients(True)
             if grad_sync is not None:
                 grad_sync()
             opt.step()

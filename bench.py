@@ -447,7 +447,7 @@ def run_goku_step(args, torch, dist, world, rank, local):
                    "parallelism": f"dp{world} (batch sharded by trajectory; one flat all-reduce of all parameter gradients per step)"},
         "roofline": dict(bound="mfma", kernel="whole step (dense chains dominate the flops)", achieved=3 * F_dense / (ms * 1e-3) / 1e12,
                          peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=3 * F_dense / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, traffic=None,
-                         note="the step is ~115 launches; host enqueue time and device time are within a few per cent of each other (DESIGN.md §4.7)"),
+                         note="the step is ~78 launches; host enqueue time and device time are within a few per cent of each other (DESIGN.md §4.7)"),
         "loss": float(loss.detach()), "cpu_baseline": None,
     }
     if world > 1:

@@ -292,6 +292,12 @@ int  lde_rnn_reserve(lde_rnn* r, int B, int T);
 int  lde_rnn_forward(lde_rnn* r, const float* x, int T, int B, float* y, void* stream);
 /* Back-propagation through time from dy[hL×B]: dx[in×B×T] (written; may be NULL), dW[n_weights] ACCUMULATED (+=). */
 int  lde_rnn_backward(lde_rnn* r, const float* x, const float* dy, int T, int B, float* dx, float* dW, void* stream);
+/* The same pullback in two calls, for a caller that overlaps several stacks (the GOKU pattern extractor is three independent
+ * stacks on the same frames [REF src/models/GOKU.jl:32-51]): _dx runs the sweep — dx written, the weight gradient's panels staged
+ * in the handle — and _dw turns the staged panels into dW (+= or =, as lde_rnn_set_accumulate says) exactly once. Issue every
+ * stack's _dx (each on its stream) before the first _dw and the long sweeps start together. lde_rnn_backward = _dx then _dw. */
+int  lde_rnn_backward_dx(lde_rnn* r, const float* x, const float* dy, int T, int B, float* dx, void* stream);
+int  lde_rnn_backward_dw(lde_rnn* r, float* dW, void* stream);
 int  lde_rnn_set_accumulate(lde_rnn* r, int on);   /* as lde_chain_set_accumulate */
 const char* lde_rnn_last_error(const lde_rnn* r);
 

@@ -32,7 +32,7 @@ EXPORTS = ["lde_abi_version", "lde_problem_desc_default", "lde_num_weights", "ld
            "lde_chain_set_weights_device", "lde_chain_reserve", "lde_chain_forward", "lde_chain_backward",
            "lde_chain_last_error", "lde_chain_set_accumulate", "lde_chain_set_dtype", "lde_rnn_set_accumulate", "lde_chain_saved_floats", "lde_chain_forward_save", "lde_chain_backward_saved",
            "lde_rnn_num_weights", "lde_rnn_create", "lde_rnn_destroy", "lde_rnn_set_weights", "lde_rnn_set_weights_device",
-           "lde_rnn_reserve", "lde_rnn_forward", "lde_rnn_backward", "lde_rnn_last_error", "lde_refresh_weights",
+           "lde_rnn_reserve", "lde_rnn_forward", "lde_rnn_backward", "lde_rnn_last_error", "lde_rnn_backward_dx", "lde_rnn_backward_dw", "lde_refresh_weights",
            "lde_sample_forward", "lde_sample_backward", "lde_kl_forward", "lde_kl_backward", "lde_mse_forward",
            "lde_mse_backward", "lde_sample_kl_forward", "lde_sample_kl_backward", "lde_mse_forward_add", "lde_adamw_flux_step", "lde_set_dw_stream", "lde_join_dw",
            "lde_comm_unique_id", "lde_comm_init", "lde_comm_allreduce_f32", "lde_comm_nranks", "lde_comm_rank",
@@ -147,6 +147,8 @@ def load():
     lib.lde_rnn_reserve.argtypes = [vp, i32, i32]
     lib.lde_rnn_forward.argtypes = [vp, vp, i32, i32, vp, vp]
     lib.lde_rnn_backward.argtypes = [vp, vp, vp, i32, i32, vp, vp, vp]
+    lib.lde_rnn_backward_dx.argtypes = [vp, vp, vp, i32, i32, vp, vp]
+    lib.lde_rnn_backward_dw.argtypes = [vp, vp, vp]
     lib.lde_rnn_last_error.argtypes = [vp]
     lib.lde_rnn_last_error.restype = C.c_char_p
     lib.lde_refresh_weights.argtypes = [i32, C.POINTER(i32), C.POINTER(vp), C.POINTER(vp), vp]

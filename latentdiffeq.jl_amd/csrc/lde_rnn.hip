@@ -459,6 +459,7 @@ struct lde_rnn {
   size_t lds = 0;
   int g0w = 0;
   DwSync dws;              // weight-gradient kernels on the dw stream (lde_set_dw_stream)
+  int staged_T = 0, staged_B = 0;   // set by lde_rnn_backward_dx: the panels lde_rnn_backward_dw consumes
   // workspace
   float* rec = nullptr; size_t rec_cap = 0;
   float* stage[RNN_ML] = {nullptr, nullptr, nullptr, nullptr}; size_t stage_cap[RNN_ML] = {0, 0, 0, 0};
@@ -728,9 +729,10 @@ int lde_rnn_forward(lde_rnn* r, const float* x, int T, int B, float* y, void* st
   return rnn_launch(r, a, B, (hipStream_t)stream_);
 }
 
-int lde_rnn_backward(lde_rnn* r, const float* x, const float* dy, int T, int B, float* dx, float* dW, void* stream_) {
+// The pullback in two halves (include/lde.h): the sweep that produces dx and stages the panels, and the weight-gradient tail.
+int lde_rnn_backward_dx(lde_rnn* r, const float* x, const float* dy, int T, int B, float* dx, void* stream_) {
   if (!r || !r->W_dev) return LDE_ERR_INVALID_ARG;
-  if (!x || !dy || !dW || T < 1 || B < 1) {
+  if (!x || !dy || T < 1 || B < 1) {
     r->err = "lde_rnn_backward: NULL pointer or empty batch";
     return LDE_ERR_INVALID_ARG;
   }
@@ -738,6 +740,7 @@ int lde_rnn_backward(lde_rnn* r, const float* x, const float* dy, int T, int B, 
     r->err = "lde_rnn_backward: weights not set";
     return LDE_ERR_NO_WEIGHTS;
   }
+  r->staged_T = r->staged_B = 0;
   int rc = lde_rnn_reserve(r, B, T);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)stream_;
@@ -746,7 +749,6 @@ int lde_rnn_backward(lde_rnn* r, const float* x, const float* dy, int T, int B, 
     return LDE_ERR_HIP;
   }
   const RnnDims& rd = r->rd;
-  const int ntile = cdiv(B, 16);
   RnnArgs a;
   std::memset(&a, 0, sizeof(a));
   a.x = x; a.Wflat = r->W_dev; a.rec = r->rec; a.dy = dy; a.dx = dx; a.wts = r->wts; a.g0 = r->g0; a.g0w = r->g0w;
@@ -754,6 +756,26 @@ int lde_rnn_backward(lde_rnn* r, const float* x, const float* dy, int T, int B, 
   for (int l = 0; l < rd.nL; l++) { a.stage[l] = r->stage[l]; a.blk[l] = r->dmw[l].blk_floats; }
   rc = rnn_launch(r, a, B, stream);
   if (rc) return rc;
+  r->staged_T = T;
+  r->staged_B = B;
+  return LDE_OK;
+}
+
+int lde_rnn_backward_dw(lde_rnn* r, float* dW, void* stream_) {
+  if (!r || !r->W_dev) return LDE_ERR_INVALID_ARG;
+  if (!dW) {
+    r->err = "lde_rnn_backward_dw: NULL pointer";
+    return LDE_ERR_INVALID_ARG;
+  }
+  if (r->staged_T < 1) {
+    r->err = "lde_rnn_backward_dw: no staged pullback (call lde_rnn_backward_dx first; its panels are consumed once)";
+    return LDE_ERR_INVALID_ARG;
+  }
+  const int T = r->staged_T, B = r->staged_B;
+  r->staged_T = r->staged_B = 0;
+  hipStream_t stream = (hipStream_t)stream_;
+  const RnnDims& rd = r->rd;
+  const int ntile = cdiv(B, 16);
   bool sw_ok = true;
   hipStream_t wst = dw_sync_switch(r->dws, stream, &sw_ok);   // the weight-gradient kernels: on the dw stream when one is set
   if (!sw_ok) {
@@ -765,7 +787,7 @@ int lde_rnn_backward(lde_rnn* r, const float* x, const float* dy, int T, int B, 
     da.stage = r->stage[l]; da.wts = r->wts; da.nslots = nullptr; da.slab = r->slab; da.cap = T; da.total = (long long)ntile * T;   // every tile staged exactly T slots
     int ks = cdiv(512, ntile * dw_jobs(r->dmw[l], dw_pick_ndw(r->dmw[l])));
     ks = ks < 1 ? 1 : (ks > 8 ? 8 : ks);
-    rc = launch_weight_gradient(r->dmw[l], da, ntile, ks, nullptr, r->ints, 0, dW + rd.f_off[l], r->ints + 2, wst, r->err, !r->accumulate);
+    int rc = launch_weight_gradient(r->dmw[l], da, ntile, ks, nullptr, r->ints, 0, dW + rd.f_off[l], r->ints + 2, wst, r->err, !r->accumulate);
     if (rc) return rc;
   }
   hipLaunchKernelGGL(k_rnn_state0, dim3(r->g0w), dim3(64), 0, wst, r->g0, B, r->g0w, rd, dW, r->accumulate ? 0 : 1);
@@ -774,6 +796,15 @@ int lde_rnn_backward(lde_rnn* r, const float* x, const float* dy, int T, int B, 
     return LDE_ERR_HIP;
   }
   return LDE_OK;
+}
+
+int lde_rnn_backward(lde_rnn* r, const float* x, const float* dy, int T, int B, float* dx, float* dW, void* stream_) {
+  if (r && r->W_dev && !dW) {
+    r->err = "lde_rnn_backward: NULL pointer or empty batch";
+    return LDE_ERR_INVALID_ARG;
+  }
+  const int rc = lde_rnn_backward_dx(r, x, dy, T, B, dx, stream_);
+  return rc ? rc : lde_rnn_backward_dw(r, dW, stream_);
 }
 
 int lde_rnn_set_accumulate(lde_rnn* r, int on) {

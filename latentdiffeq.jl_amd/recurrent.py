@@ -125,6 +125,83 @@ class _RecurrentFn(torch.autograd.Function):
         return None, dx, dW
 
 
+class _RecurrentGroupFn(torch.autograd.Function):
+    """(y_1, …, y_n) = (stack_1(x), …, stack_n(x)): independent stacks on the same frames — the GOKU pattern extractor
+    [REF src/models/GOKU.jl:32-51] — as ONE autograd node. Every stack runs on a HIP stream of its own (each fills only B/16
+    workgroups), the raw stream handed straight to liblde.so: no stream context switches, one node instead of three each way.
+    The pullback issues every stack's sweep (lde_rnn_backward_dx) before the first weight-gradient tail (lde_rnn_backward_dw), so the
+    three long kernels start within a few microseconds of each other instead of one host round trip apart, and returns Σ dx.
+    Tensors are allocated on the current stream's pool and recorded on the side stream that touches them."""
+
+    @staticmethod
+    def forward(ctx, recs, x, *Ws):
+        if not x.is_cuda:
+            raise L.LdeError("Recurrent needs CUDA/HIP tensors: it runs on the GPU only (no CPU fallback)")
+        dev = x.device
+        main = torch.cuda.current_stream(dev)
+        streams = _side_streams.setdefault((dev.index, len(recs)), [torch.cuda.Stream(dev) for _ in recs])
+        T, B, _ = x.shape
+        ready = main.record_event()
+        ys = []
+        for rec, W, st in zip(recs, Ws, streams):
+            h, raw = rec._native(), C.c_void_p(st.cuda_stream)
+            st.wait_event(ready)
+            if rec._wkey != L.weights_key(W):
+                Wc = W.detach().contiguous().float()
+                L.check(rec._lib.lde_rnn_set_weights_device(h, C.c_void_p(Wc.data_ptr()), Wc.numel(), raw), h, "lde_rnn_set_weights_device", rnn=True)
+                Wc.record_stream(st)
+                rec._wkey = None
+            y = torch.empty((B, rec.sizes[-1]), device=dev, dtype=torch.float32)
+            y.record_stream(st)
+            L.check(rec._lib.lde_rnn_forward(h, C.c_void_p(x.data_ptr()), T, B, C.c_void_p(y.data_ptr()), raw), h, "lde_rnn_forward", rnn=True)
+            ys.append(y)
+        for st in streams:
+            x.record_stream(st)
+        for st in streams:
+            main.wait_stream(st)
+        ctx.recs, ctx.streams, ctx.need_dx = recs, streams, x.requires_grad
+        ctx.save_for_backward(x)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        recs, streams = ctx.recs, ctx.streams
+        (x,) = ctx.saved_tensors
+        dev = x.device
+        T, B, _ = x.shape
+        main = torch.cuda.current_stream(dev)
+        dys = [dy.contiguous().float() for dy in dys]
+        ready = main.record_event()
+        dxs, dWs = [], []
+        for rec, dy, st in zip(recs, dys, streams):               # the sweeps first …
+            h, raw = rec._native(), C.c_void_p(st.cuda_stream)
+            st.wait_event(ready)
+            dx = torch.empty_like(x) if ctx.need_dx else None
+            dy.record_stream(st)
+            x.record_stream(st)
+            if dx is not None:
+                dx.record_stream(st)
+            L.check(rec._lib.lde_rnn_backward_dx(h, C.c_void_p(x.data_ptr()), C.c_void_p(dy.data_ptr()), T, B,
+                                                 C.c_void_p(dx.data_ptr()) if dx is not None else C.c_void_p(), raw), h, "lde_rnn_backward_dx", rnn=True)
+            dxs.append(dx)
+        for rec, st in zip(recs, streams):                        # … then the weight-gradient tails
+            dW = torch.empty((rec.num_weights,), device=dev, dtype=torch.float32)     # written, not accumulated (set_accumulate(0))
+            dW.record_stream(st)
+            if L.dw_stream is not None:
+                dW.record_stream(L.dw_stream)
+            L.check(rec._lib.lde_rnn_backward_dw(rec._native(), C.c_void_p(dW.data_ptr()), C.c_void_p(st.cuda_stream)), rec._native(),
+                    "lde_rnn_backward_dw", rnn=True)
+            dWs.append(dW)
+        for st in streams:
+            main.wait_stream(st)
+        dx = None
+        if ctx.need_dx:
+            dx = dxs[0]
+            for d in dxs[1:]:
+                dx = dx + d
+        return (None, dx, *dWs)
+
+
 class Recurrent(torch.nn.Module):
     """A stack of cells of one kind applied to the frames of x [in, B, T] (reverse=True: frames T..1), returning the output
     after the last frame, [h_last, B] — `[pe(x) for x in frames][end]` followed by `Flux.reset!`  [REF GOKU.jl:40-47]."""
@@ -206,6 +283,11 @@ def apply_feature_extractor(encoder: Encoder, x):
 
 
 _side_streams = {}
+_RNN_GROUP = os.environ.get("LDE_RNN_GROUP", "0") != "0"             # encode(): the three stacks as ONE autograd node on raw side streams, sweeps issued before
+                                                                       # the weight-gradient tails. Opt-in: measured 1.80 vs 1.64 ms per goku_step at B = 256 (six
+                                                                       # alternations on one box) — the z₀ branch's latent_in chains then run after the join instead of
+                                                                       # beside the θ branch's longer stacks, and the per-tensor record_stream calls cost the host more
+                                                                       # than the two autograd nodes they save
 _STACKS_FIRST = os.environ.get("LDE_STACKS_FIRST", "1") != "0"       # encode(): issue the three recurrent stacks before the latent_in chains (diagnostic switch)
 _BRANCH_STREAMS = os.environ.get("LDE_BRANCH_STREAMS", "1") != "0"   # encode(): keep the z₀ / θ branches on their own streams (diagnostic switch)
 
@@ -251,6 +333,20 @@ def apply_latent_in(encoder: Encoder, pe_out):
         return (li_mu_z0(pe_z0), li_mu_th(pe_th)), (li_ls_z0(pe_z0), li_ls_th(pe_th))
     li_mu, li_ls = encoder.latent_in
     return li_mu(pe_out), li_ls(pe_out)
+
+
+def _encode_goku_group(encoder: Encoder, fe_out):
+    """apply_latent_in(apply_pattern_extractor(fe_out)) for GOKU with the three stacks as one autograd node
+    (_RecurrentGroupFn) and everything between the stacks and (μ, logσ²) kept in batch-major buffers — no transposed views in
+    between, the θ branch's vcat [REF GOKU.jl:47] is a concatenation along the feature axis of (B, h) buffers. Same arithmetic
+    as the two reference functions."""
+    recs = tuple(encoder.pattern_extractor)
+    li_mu_z0, li_ls_z0, li_mu_th, li_ls_th = encoder.latent_in
+    buf = fe_out.permute(2, 1, 0).contiguous().float()            # (T, B, in) == column-major [in × B × T]
+    y_z0, y_f, y_b = _RecurrentGroupFn.apply(recs, buf, *[m.flat_weights() for m in recs])
+    y_th = torch.cat([y_f, y_b], dim=1)                           # (B, 2h)
+    return ((li_mu_z0.apply_batch_major(y_z0).t(), li_mu_th.apply_batch_major(y_th).t()),
+            (li_ls_z0.apply_batch_major(y_z0).t(), li_ls_th.apply_batch_major(y_th).t()))
 
 
 def _encode_goku_branches(encoder: Encoder, fe_out):
@@ -304,6 +400,9 @@ def _encode_goku_branches(encoder: Encoder, fe_out):
 def encode(encoder: Encoder, x):
     """(μ, logσ²) = encoder(x)  [REF src/models/LatentDiffEqModel.jl:63-75]."""
     fe_out = apply_feature_extractor(encoder, x)
+    if isinstance(encoder.model_type, GOKU) and fe_out.is_cuda and _RNN_GROUP and isinstance(encoder.pattern_extractor, tuple) \
+            and len(encoder.pattern_extractor) == 3 and all(isinstance(m, Recurrent) for m in encoder.pattern_extractor):
+        return _encode_goku_group(encoder, fe_out)
     if isinstance(encoder.model_type, GOKU) and fe_out.is_cuda and _BRANCH_STREAMS:
         return _encode_goku_branches(encoder, fe_out)
     return apply_latent_in(encoder, apply_pattern_extractor(encoder, fe_out))

@@ -921,10 +921,138 @@ struct PendBasis {
   }
 };
 
+// The same system on register pairs: p0 = (z0, z1), p1 = (λᵃ₀, λᵇ₀), p2 = (λᵃ₁, λᵇ₁), p3 = (gᵃ, gᵇ) — the two basis solutions share
+// every coefficient, so their halves of the right-hand side are three packed operations.
+template <int KIND>
+struct PendBasisPair {
+  float ngl, gl2, noff;
+  __device__ __forceinline__ explicit PendBasisPair(float L) : ngl(-10.0f / L), gl2(10.0f / (L * L)), noff(0.f) {}
+  __device__ __forceinline__ void anchor(float x0) { noff = turn_anchor(x0); }
+  __device__ __forceinline__ void ev(const f32x2 (&y)[4], f32x2 (&dy)[4]) const {
+    float s, c;
+    hw_sincos(y[0].x, s, c, noff);
+    float acc = ngl * s;
+    if (KIND == 1) acc -= 0.7f * y[0].y;
+    dy[0] = f32x2{y[0].y, acc};
+    const float nc = ngl * c, gs = gl2 * s;
+    dy[1] = y[2] * (-nc);
+    f32x2 v = y[1];
+    if (KIND == 1) v -= y[2] * 0.7f;
+    dy[2] = -v;
+    dy[3] = y[2] * (-gs);
+  }
+};
+
+// one Tsit5 attempt on four register pairs (all eight entries count); k[0] = f(y) on entry; returns the RMS error estimate
+template <class F>
+__device__ __forceinline__ float tsit5_attempt_pair4(F& f, float h, const f32x2 (&y)[4], f32x2 (&k)[7][4], f32x2 (&yn)[4], const KOpts& o) {
+  f32x2 tmp[4];
+#pragma unroll
+  for (int s = 1; s < 6; s++) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      f32x2 acc = k[0][i] * ts5::A[s][0];
+#pragma unroll
+      for (int j = 1; j < s; j++) acc += k[j][i] * ts5::A[s][j];
+      tmp[i] = y[i] + acc * h;
+    }
+    f.ev(tmp, k[s]);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    f32x2 acc = k[0][i] * ts5::A[6][0];
+#pragma unroll
+    for (int j = 1; j < 6; j++) acc += k[j][i] * ts5::A[6][j];
+    yn[i] = y[i] + acc * h;
+  }
+  f.ev(yn, k[6]);
+  if (!o.adaptive) return 0.f;
+  f32x2 s2 = {0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    f32x2 e = k[0][i] * ts5::BT[0];
+#pragma unroll
+    for (int j = 1; j < 7; j++) e += k[j][i] * ts5::BT[j];
+    e *= h;
+    const f32x2 sk = f32x2{fmaxf(fabsf(y[i].x), fabsf(yn[i].x)), fmaxf(fabsf(y[i].y), fabsf(yn[i].y))} * o.reltol + o.abstol;
+    const f32x2 r = e * f32x2{fast_rcp(sk.x), fast_rcp(sk.y)};
+    s2 += r * r;
+  }
+  return sqrtf((s2.x + s2.y) * 0.125f);
+}
+
 // integrate one save interval [t0, t1] backwards for the basis state; returns retcode, leaves the operator in y[2..7]
+// Tsit5: on register pairs (PendBasisPair / tsit5_attempt_pair4) — same control flow as the generic form below, half the
+// vector instructions of the stage sums and of the right-hand side.
+template <int KIND>
+__device__ __forceinline__ int pend_interval_operator_pairs(float2 zc, float L, double t0, double t1, const KOpts& o, float (&yo)[8],
+                                                            int& nacc, int& nrej) {
+  PendBasisPair<KIND> f(L);
+  f32x2 y[4] = {f32x2{zc.x, zc.y}, f32x2{1.f, 0.f}, f32x2{0.f, 1.f}, f32x2{0.f, 0.f}};
+  f32x2 k[7][4], yn[4];
+  auto out = [&]() {   // back to [z0 z1 | la0 la1 lb0 lb1 | ga gb]
+    yo[0] = y[0].x; yo[1] = y[0].y; yo[2] = y[1].x; yo[3] = y[2].x; yo[4] = y[1].y; yo[5] = y[2].y; yo[6] = y[3].x; yo[7] = y[3].y;
+  };
+  int ret = LDE_RET_SUCCESS;
+  nacc = 0;
+  nrej = 0;
+  out();
+  if (!(isfinite(zc.x) && isfinite(zc.y))) return LDE_RET_NONFINITE;
+  const double len = t1 - t0;
+  double t = t1, dt = o.adaptive ? len : o.dt_fixed;   // first attempt: the whole interval
+  const double dtmax = len;
+  float qold = 1e-4f;
+  long long iters = 0;
+  f.anchor(y[0].x);
+  f.ev(y, k[0]);
+  for (;;) {
+    if (iters++ >= o.maxiters) { ret = LDE_RET_MAXITERS; break; }
+    f.anchor(y[0].x);
+    const double dist = t - t0;
+    double hmag = dt;
+    bool hit = false;
+    if (hmag >= dist * (1.0 - 1e-12)) { hmag = dist; hit = true; }
+    const float h = -(float)hmag;
+    const float EEst = tsit5_attempt_pair4(f, h, y, k, yn, o);
+    float fin = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) fin += fabsf(yn[i].x) + fabsf(yn[i].y);   // one non-finite entry makes the sum non-finite
+    if (!(fin < __builtin_inff()) || !(EEst == EEst)) {
+      if (o.adaptive && hmag > o.dtmin) { nrej++; dt = hmag * (double)o.qmin; continue; }
+      ret = LDE_RET_NONFINITE;
+      break;
+    }
+    double dtp = dt;
+    if (o.adaptive && (EEst > 1.0f || !hit)) {   // an accepted step that ends the interval needs no next step size
+      float q11;
+      const float q = pi_q(EEst, qold, o, q11);
+      if (EEst > 1.0f) {
+        nrej++;
+        dt = hmag * (double)fast_rcp(fminf(o.q_hi, q11 * o.inv_gamma));
+        if (dt < o.dtmin) { ret = LDE_RET_DTMIN; break; }
+        continue;
+      }
+      qold = fmaxf(EEst, 1e-4f);
+      dtp = hmag * (double)fast_rcp(q);
+      if (dtp > dtmax) dtp = dtmax;
+    }
+    nacc++;
+#pragma unroll
+    for (int i = 0; i < 4; i++) y[i] = yn[i];
+    if (hit) break;
+    t -= hmag;
+#pragma unroll
+    for (int i = 0; i < 4; i++) k[0][i] = k[6][i];
+    dt = o.adaptive ? dtp : o.dt_fixed;
+  }
+  out();
+  return ret;
+}
+
 template <int KIND, int SOLVER>
 __device__ __forceinline__ int pend_interval_operator(float2 zc, float L, double t0, double t1, const KOpts& o, float (&y)[8],
                                                       int& nacc, int& nrej) {
+  if (SOLVER == LDE_SOLVER_TSIT5) return pend_interval_operator_pairs<KIND>(zc, L, t0, t1, o, y, nacc, nrej);
   PendBasis<KIND> f(L);
   y[0] = zc.x; y[1] = zc.y; y[2] = 1.f; y[3] = 0.f; y[4] = 0.f; y[5] = 1.f; y[6] = 0.f; y[7] = 0.f;
   float k[7][8], yn[8];
@@ -1024,12 +1152,38 @@ __device__ __forceinline__ AffOp aff_compose(const AffOp& a, const AffOp& b) {
   r.gam = a.gam + b.gam + b.n0 * a.d0 + b.n1 * a.d1;
   return r;
 }
-__device__ __forceinline__ AffOp aff_shfl_down(const AffOp& a, int off) {
+// The value of lane ℓ+OFF for the lanes the tree uses at that level (ℓ a multiple of 2·OFF), without an LDS round trip per
+// float (`__shfl_down` = address arithmetic + ds_bpermute_b32: twelve of them per level were a third of the kernel):
+//   OFF ≤ 8: the partner sits in the same row of 16 lanes — DPP row_shl:OFF, one VALU move;
+//   OFF = 16: lanes 0 and 32 read lanes 16 and 48 — ds_swizzle (xor 16), no address register;
+//   OFF = 32: only lane 0 reads lane 32 — v_readlane, the value arrives in a scalar register.
+// Other lanes receive unspecified values; they do not use them.
+template <int OFF>
+__device__ __forceinline__ int lane_down(int v) {
+  if (OFF < 16) return __builtin_amdgcn_update_dpp(v, v, 0x100 + OFF, 0xf, 0xf, false);   // row_shl:OFF
+  if (OFF == 16) return __builtin_amdgcn_ds_swizzle(v, 0x401f);                            // and 0x1f, or 0, xor 0x10
+  return __builtin_amdgcn_readlane(v, 32);
+}
+template <int OFF>
+__device__ __forceinline__ float lane_down(float v) { return __builtin_bit_cast(float, lane_down<OFF>(__builtin_bit_cast(int, v))); }
+template <int OFF>
+__device__ __forceinline__ AffOp aff_down(const AffOp& a) {
   AffOp r;
-  r.m00 = __shfl_down(a.m00, off); r.m01 = __shfl_down(a.m01, off); r.m10 = __shfl_down(a.m10, off);
-  r.m11 = __shfl_down(a.m11, off); r.d0 = __shfl_down(a.d0, off); r.d1 = __shfl_down(a.d1, off);
-  r.n0 = __shfl_down(a.n0, off); r.n1 = __shfl_down(a.n1, off); r.gam = __shfl_down(a.gam, off);
+  r.m00 = lane_down<OFF>(a.m00); r.m01 = lane_down<OFF>(a.m01); r.m10 = lane_down<OFF>(a.m10);
+  r.m11 = lane_down<OFF>(a.m11); r.d0 = lane_down<OFF>(a.d0); r.d1 = lane_down<OFF>(a.d1);
+  r.n0 = lane_down<OFF>(a.n0); r.n1 = lane_down<OFF>(a.n1); r.gam = lane_down<OFF>(a.gam);
   return r;
+}
+// one level of the order-preserving tree: lane ℓ ← (ℓ's block first, then the block of ℓ+OFF); `cnt` = nacc | nrej << 16
+template <int OFF>
+__device__ __forceinline__ void aff_tree_level(AffOp& op, int& cnt, int& ret, int lane) {
+  const AffOp hi = aff_down<OFF>(op);
+  const int c2 = lane_down<OFF>(cnt), e2 = lane_down<OFF>(ret);
+  if ((lane & (2 * OFF - 1)) == 0) {
+    op = aff_compose(op, hi);
+    cnt += c2;
+    ret = ret ? ret : e2;
+  }
 }
 
 template <int KIND, int SOLVER>
@@ -1053,31 +1207,43 @@ __global__ void __launch_bounds__(1024) k_pend_adjoint_fused(const float2* __res
   const int lane = l & 63, wave = l >> 6, nwave = (blockDim.x + 63) >> 6;
   AffOp op = {1.f, 0.f, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f, 0.f};   // identity for lanes beyond the first interval
   int nacc = 0, nrej = 0, ret = 0;
+  // Every global load of the kernel is issued HERE, back to back — the interval's ẑ, its cotangent, its two save times, and the
+  // trajectory's last save point, which lane 0 needs after the reduction. As the source reads naturally (ẑ → finite? → times →
+  // integrate → Δẑ → reduce → ẑ_T, Δẑ_T) the compiler kept four dependent memory round trips on a 5 µs kernel; the empty asm pins
+  // the values to this point, so there is one.
+  const int jc = j >= 0 ? j : 0;
+  float2 zc = z_out[(size_t)(jc + 1) * B + b];
+  float2 dj = dz_out[(size_t)jc * B + b];
+  double t0 = ts_g[jc], t1 = ts_g[jc + 1];
+  float2 zT = z_out[(size_t)(T - 1) * B + b];
+  float2 dT = dz_out[(size_t)(T - 1) * B + b];
+  const float Lb = theta[b];
+  asm volatile("" : "+v"(zc.x), "+v"(zc.y), "+v"(dj.x), "+v"(dj.y), "+v"(t0), "+v"(t1), "+v"(zT.x), "+v"(zT.y), "+v"(dT.x), "+v"(dT.y));
   if (j >= 0) {
     float y[8];
-    ret = pend_interval_operator<KIND, SOLVER>(z_out[(size_t)(j + 1) * B + b], theta[b], ts_g[j], ts_g[j + 1], o, y, nacc, nrej);
-    const float2 d = dz_out[(size_t)j * B + b];
-    op = AffOp{y[2], y[4], y[3], y[5], d.x, d.y, y[6], y[7], 0.f};   // λ' = λ₀·(la) + λ₁·(lb) + Δ_j ; g' = g + ga λ₀ + gb λ₁
+    ret = pend_interval_operator<KIND, SOLVER>(zc, Lb, t0, t1, o, y, nacc, nrej);
+    op = AffOp{y[2], y[4], y[3], y[5], dj.x, dj.y, y[6], y[7], 0.f};   // λ' = λ₀·(la) + λ₁·(lb) + Δ_j ; g' = g + ga λ₀ + gb λ₁
   }
-  // order-preserving tree reduction inside the wave: lane ℓ ← (ℓ's block first, then the block of ℓ+off)
-#pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const AffOp hi = aff_shfl_down(op, off);
-    const int a2 = __shfl_down(nacc, off), r2 = __shfl_down(nrej, off), e2 = __shfl_down(ret, off);
-    if ((lane & (2 * off - 1)) == 0) {
-      op = aff_compose(op, hi);
-      nacc += a2;
-      nrej += r2;
-      ret = ret ? ret : e2;
+  // order-preserving tree reduction inside the wave (a save interval takes a handful of attempts: the two counts share a word)
+  // (per-lane counts saturate at 1023 / 511 so that 64 of them cannot carry into the neighbouring field)
+  int cnt = min(nacc, 1023) | (min(nrej, 511) << 16);
+  aff_tree_level<1>(op, cnt, ret, lane);
+  aff_tree_level<2>(op, cnt, ret, lane);
+  aff_tree_level<4>(op, cnt, ret, lane);
+  aff_tree_level<8>(op, cnt, ret, lane);
+  aff_tree_level<16>(op, cnt, ret, lane);
+  aff_tree_level<32>(op, cnt, ret, lane);
+  nacc = cnt & 0xffff;
+  nrej = (cnt >> 16) & 0x7fff;
+  if (nwave > 1) {   // T − 1 > 64: the waves' operators meet in LDS (a single wave needs neither the copy nor the barrier)
+    if (lane == 0) {
+      s_op[wave] = op;
+      s_stat[wave][0] = nacc;
+      s_stat[wave][1] = nrej;
+      s_stat[wave][2] = ret;
     }
+    __syncthreads();
   }
-  if (lane == 0) {
-    s_op[wave] = op;
-    s_stat[wave][0] = nacc;
-    s_stat[wave][1] = nrej;
-    s_stat[wave][2] = ret;
-  }
-  __syncthreads();
   if (l == 0) {
     for (int w = 1; w < nwave; w++) {
       op = aff_compose(op, s_op[w]);
@@ -1085,8 +1251,6 @@ __global__ void __launch_bounds__(1024) k_pend_adjoint_fused(const float2* __res
       nrej += s_stat[w][1];
       ret = ret ? ret : s_stat[w][2];
     }
-    const float2 zT = z_out[(size_t)(T - 1) * B + b];
-    const float2 dT = dz_out[(size_t)(T - 1) * B + b];
     if (!(isfinite(zT.x) && isfinite(zT.y))) ret = ret ? ret : LDE_RET_NONFINITE;
     const float l0 = op.m00 * dT.x + op.m01 * dT.y + op.d0;
     const float l1 = op.m10 * dT.x + op.m11 * dT.y + op.d1;

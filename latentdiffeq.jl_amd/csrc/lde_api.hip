@@ -343,6 +343,8 @@ static lde::KOpts make_opts(const lde_problem_desc& d, const double* ts, int T, 
   o.checkpoint = d.sensealg != LDE_SENSE_BACKSOLVE;
   o.T = T;
   o.B = B;
+  o.t_first = ts[0];
+  o.t_last = ts[T - 1];
   return o;
 }
 

@@ -603,7 +603,11 @@ __global__ void __launch_bounds__(WS_THREADS) k_pend_forward_ws(const float2* __
 // wave-uniform and the wave runs its own trajectory's step count, not the maximum over 64. The dense output costs the step
 // ≈ 45 instructions (the Θ-independent coefficients once, one evaluation per lane) instead of the wave-sequential save
 // loop of k_pend_forward (≈ 75 iterations at T = 50). Same formulas as the other two forward kernels.
-template <int KIND, int SOLVER, bool ADAPT, int TPW>
+// ONE = true (T − 1 ≤ 64/TPW: a lane serves exactly one save time, fetched before the first step): the dense output is a single
+// predicated block and the stepping loop contains no load at all. With the next save time's load in it the compiler must put
+// `s_waitcnt vmcnt(0)` in front of the block, and vmcnt counts the previous step's ẑ STORES too — the stepping chain then waits
+// for write acknowledgements it has no use for.
+template <int KIND, int SOLVER, bool ADAPT, int TPW, bool ONE = false>
 __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict__ z0, const float* __restrict__ theta,
                                                         const double* __restrict__ ts_g, KOpts o,
                                                         float2* __restrict__ z_out, int32_t* __restrict__ retcode,
@@ -614,6 +618,7 @@ __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict
   const int b = blockIdx.x * TPW + lane / LPT;
   const bool valid = b < B;
   const int bc = valid ? b : B - 1;   // an out-of-range group computes on a copy of the last trajectory and stores nothing
+  const double t_first = o.t_first, t_last = o.t_last;   // ts[0], ts[T−1] arrive with the kernel arguments: no load before the first step
   const float2 zi = z0[bc];
   PendFwd<KIND> f(theta[bc]);
   constexpr int FS = (SOLVER == LDE_SOLVER_TSIT5) ? 6 : 4;  // FSAL slope
@@ -636,8 +641,8 @@ __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict
   for (int s = 0; s < 7; s++) k[s] = f32x2{0.f, 0.f};
   if (valid && slot == 0) z_out[b] = zi;  // ts[0] is saved as ẑ₀ itself
   if (T > 1) {
-    t = ts_g[0];
-    tend = ts_g[T - 1];
+    t = t_first;
+    tend = t_last;
     const double dtmax_d = tend - t;
     dtmax = (float)dtmax_d;
     f.anchor(y.x);
@@ -716,7 +721,7 @@ __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict
           }
         }
         const float rh = fast_rcp(h);
-        while (tj <= tn) {   // (one trip when the group has a lane per save time)
+        for (bool more = tj <= tn; more; more = !ONE && tj <= tn) {   // (one trip when the group has a lane per save time)
           float2 out;
           if (tj >= tn) out = make_float2(yn.x, yn.y);
           else {
@@ -735,7 +740,7 @@ __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict
           if (valid) z_out[(size_t)j * B + b] = out;
           j += LPT;
           tj = tjn;
-          tjn = j + LPT < T ? ts_g[j + LPT] : dinf;
+          tjn = (!ONE && j + LPT < T) ? ts_g[j + LPT] : dinf;
         }
       }
       nacc++;
@@ -1315,9 +1320,16 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
   static const int tl_max_b = [] { const char* e = getenv("LDE_PEND_TL_MAX_B"); return e ? atoi(e) : 1024; }();
   if (o.T > 1 && o.B <= tl_max_b) {
     const bool ad = o.adaptive != 0;
+    const bool few = o.T - 1 <= 64;   // a lane serves exactly one save time: the variant without a load in the stepping loop
 #define LDE_LAUNCH_TL(K, S, A)                                                                                          \
-  hipLaunchKernelGGL((k_pend_forward_tl<K, S, A, 1>), dim3(o.B), dim3(64), 0, stream, (const float2*)z0, theta, ts_dev, o,   \
-                     (float2*)z_out, retcode, nfe, nacc, nrej, ret)
+  do {                                                                                                                  \
+    if (few)                                                                                                            \
+      hipLaunchKernelGGL((k_pend_forward_tl<K, S, A, 1, true>), dim3(o.B), dim3(64), 0, stream, (const float2*)z0, theta, ts_dev, o, \
+                         (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                                \
+    else                                                                                                                \
+      hipLaunchKernelGGL((k_pend_forward_tl<K, S, A, 1>), dim3(o.B), dim3(64), 0, stream, (const float2*)z0, theta, ts_dev, o, \
+                         (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                                \
+  } while (0)
     if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5 && ad) LDE_LAUNCH_TL(0, LDE_SOLVER_TSIT5, true);
     else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH_TL(0, LDE_SOLVER_TSIT5, false);
     else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_RK4) LDE_LAUNCH_TL(0, LDE_SOLVER_RK4, false);

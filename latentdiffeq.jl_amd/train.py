@@ -156,33 +156,33 @@ class FluxADAMW(torch.optim.Adam):
         if native and not ok:
             raise ValueError("FluxADAMW(native=True) needs contiguous float32 HIP parameters")
         self.native = bool(native)
-        self._t = 0
 
     @torch.no_grad()
     def _native_step(self):
-        import ctypes as C
-        from . import _lib as L
         lib = L.load()
-        self._t += 1
         for g in self.param_groups:
             ps = [p for p in g["params"] if p.grad is not None]
             if not ps:
                 continue
-            tab, keep = (L.AdamTensor * len(ps))(), []
-            for i, p in enumerate(ps):
+            keep, by_step = [], {}
+            for p in ps:
                 st = self.state[p]
                 if not st:
                     st["step"], st["exp_avg"], st["exp_avg_sq"] = 0, torch.zeros_like(p), torch.zeros_like(p)
                 st["step"] += 1
-                gr = p.grad
-                if gr.dtype != torch.float32 or not gr.is_contiguous():
-                    gr = gr.float().contiguous()
-                    keep.append(gr)
-                t = tab[i]
-                t.p, t.g, t.m, t.v, t.n = p.data_ptr(), gr.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
-            # one step count per group: Flux keeps β₁ᵗ, β₂ᵗ per array, and every array of a model is updated at every step
-            L.check(lib.lde_adamw_flux_step(len(ps), tab, g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.decay,
-                                            self.state[ps[0]]["step"], L.raw_stream(ps[0].device.index)), None, "lde_adamw_flux_step")
+                by_step.setdefault(st["step"], []).append(p)
+            # Flux keeps β₁ᵗ, β₂ᵗ per array: arrays that have been updated equally often share a launch (normally all of them)
+            for t_step, group in by_step.items():
+                tab = (L.AdamTensor * len(group))()
+                for i, p in enumerate(group):
+                    st, gr = self.state[p], p.grad
+                    if gr.dtype != torch.float32 or not gr.is_contiguous():
+                        gr = gr.float().contiguous()
+                        keep.append(gr)
+                    t = tab[i]
+                    t.p, t.g, t.m, t.v, t.n = p.data_ptr(), gr.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+                L.check(lib.lde_adamw_flux_step(len(group), tab, g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.decay, t_step,
+                                                L.raw_stream(group[0].device.index)), None, "lde_adamw_flux_step")
 
     @torch.no_grad()
     def step(self, closure=None):

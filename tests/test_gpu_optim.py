@@ -66,6 +66,15 @@ def test_native_update_skips_parameters_without_gradient_and_rejects_bad_argumen
     a.grad = torch.ones(10, device="cuda")
     opt.step()
     assert torch.equal(b.detach(), torch.ones(10, device="cuda")) and float(a.detach()[0]) < 1.0
+    # second step: both have gradients; a is at its step 2, b at its step 1 — each with its own bias correction (Flux keeps β₁ᵗ, β₂ᵗ per array)
+    a.grad = torch.full((10,), 0.5, device="cuda")
+    b.grad = torch.full((10,), 0.5, device="cuda")
+    opt.step()
+    one = np.ones(10, np.float32)
+    want_a = _flux_reference(one, [one, 0.5 * one], 0.1, 0.9, 0.999, 1e-8, 0.0)
+    want_b = _flux_reference(one, [0.5 * one], 0.1, 0.9, 0.999, 1e-8, 0.0)
+    assert np.abs(a.detach().cpu().numpy() - want_a).max() <= 2e-6 and np.abs(b.detach().cpu().numpy() - want_b).max() <= 2e-6
+    assert opt.state[a]["step"] == 2 and opt.state[b]["step"] == 1
     lib = L.load()
     t = (L.AdamTensor * 1)()
     t[0].n = 4

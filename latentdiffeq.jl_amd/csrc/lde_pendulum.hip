@@ -627,6 +627,7 @@ __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict
   int j = 1 + slot;                                                   // the save time this lane serves next,
   double tj = j < T ? ts_g[j] : dinf;                                 // its value, and the one after it (prefetched:
   double tjn = j + LPT < T ? ts_g[j + LPT] : dinf;                    // a load on the stepping chain would cost a memory latency)
+  float2* const dst1 = z_out + (size_t)(j < T ? j : 0) * B + (valid ? b : 0);
   f32x2 y = {zi.x, zi.y}, k[7], yn = {0.f, 0.f}, kf = {0.f, 0.f};
   int ret = LDE_RET_SUCCESS, nfe = 0, nacc = 0, nrej = 0;
   double t = 0.0, tend = 0.0;
@@ -737,7 +738,7 @@ __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict
               out.y = h00 * y.y + (h10 * h) * k[0].y + h01 * yn.y + (h11 * h) * k[4].y;
             }
           }
-          if (valid) z_out[(size_t)j * B + b] = out;
+          if (valid) *(ONE ? dst1 : z_out + (size_t)j * B + b) = out;   // (ONE: the lane's only store, address formed before the loop)
           j += LPT;
           tj = tjn;
           tjn = (!ONE && j + LPT < T) ? ts_g[j + LPT] : dinf;

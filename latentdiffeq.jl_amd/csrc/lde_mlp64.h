@@ -131,20 +131,26 @@ __global__ void __launch_bounds__(64) k_mlp64(MlpDims dm, KOpts o, VArgs a) {
   {   // weights into registers (flat destructure order: vec(W) column-major [out×in], then b)
     const float* W = a.Wflat;
     const float *W1 = W + dm.w_off[0], *W2 = W + dm.w_off[1], *W3 = W + dm.w_off[2];
+    // Every load UNCONDITIONAL, from a clamped (always valid) index, and the zero padding applied as a MULTIPLICATION by a 0/1 mask:
+    // written as `cond ? W[i] : 0` the compiler predicates each load on its lane condition — ≈ 270 exec-masked blocks, each with
+    // `s_waitcnt vmcnt(0)` before the next: 270 dependent L2 round trips before the first step (≈ half of the forward kernel's time
+    // at B = 1024); a select after an unconditional load is folded back into the same thing. (w is a finite weight, so w·0 = ±0.)
+    const int l1 = min(lane, H1 - 1), l2 = min(lane, H2 - 1);
+    const float m1 = lane < H1 ? 1.f : 0.f, m2 = lane < H2 ? 1.f : 0.f;
 #pragma unroll
-    for (int k = 0; k < DP; k++) n.w1[k] = (lane < H1 && k < Dp) ? W1[lane + H1 * k] : 0.f;
-    n.b1 = lane < H1 ? W[dm.b_off[0] + lane] : 0.f;
+    for (int k = 0; k < DP; k++) n.w1[k] = W1[l1 + H1 * min(k, Dp - 1)] * (k < Dp ? m1 : 0.f);
+    n.b1 = W[dm.b_off[0] + l1] * m1;
 #pragma unroll
-    for (int k = 0; k < 64; k++) n.w2r[k >> 1][k & 1] = (lane < H2 && k < H1) ? W2[lane + H2 * k] : 0.f;
-    n.b2 = lane < H2 ? W[dm.b_off[1] + lane] : 0.f;
+    for (int k = 0; k < 64; k++) n.w2r[k >> 1][k & 1] = W2[l2 + H2 * min(k, H1 - 1)] * (k < H1 ? m2 : 0.f);
+    n.b2 = W[dm.b_off[1] + l2] * m2;
 #pragma unroll
-    for (int i = 0; i < 64; i++) n.w2c[i >> 1][i & 1] = (ADJ && lane < H1 && i < H2) ? W2[i + H2 * lane] : 0.f;
+    for (int i = 0; i < 64; i++) n.w2c[i >> 1][i & 1] = ADJ ? W2[min(i, H2 - 1) + H2 * l1] * (i < H2 ? m1 : 0.f) : 0.f;
     __shared__ __attribute__((aligned(16))) float s_hx[128];
     n.hx = s_hx;
 #pragma unroll
     for (int d = 0; d < DP; d++) {
-      n.w3c[d] = (lane < H2 && d < Dp) ? W3[d + Dp * lane] : 0.f;
-      n.b3[d] = d < Dp ? W[dm.b_off[2] + d] : 0.f;
+      n.w3c[d] = W3[min(d, Dp - 1) + Dp * l2] * (d < Dp ? m2 : 0.f);
+      n.b3[d] = W[dm.b_off[2] + min(d, Dp - 1)] * (d < Dp ? 1.f : 0.f);
     }
     float L = 1.f;
     if (dm.has_pend) L = a.theta[(size_t)b * NP];

@@ -615,7 +615,12 @@ __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict
                                                         int32_t* __restrict__ st_nrej, int32_t* __restrict__ st_ret) {
   constexpr int LPT = 64 / TPW;   // lanes per trajectory
   const int T = o.T, B = o.B, lane = threadIdx.x, slot = lane % LPT;
-  const int b = blockIdx.x * TPW + lane / LPT;
+  // XCD-aware trajectory ↔ workgroup map (as in k_pend_adjoint_fused): workgroups are dealt round-robin to the 8 XCDs and a 128-byte
+  // line of ẑ holds 16 neighbouring trajectories' values of one save time, each written by another wave — with neighbouring
+  // trajectories on ONE XCD their partial writes meet in one L2 instead of reaching HBM as eight partial lines. Traffic only.
+  const int chunk = gridDim.x >> 3;   // the grid is a multiple of 8 workgroups
+  const int g = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  const int b = g * TPW + lane / LPT;
   const bool valid = b < B;
   const int bc = valid ? b : B - 1;   // an out-of-range group computes on a copy of the last trajectory and stores nothing
   const double t_first = o.t_first, t_last = o.t_last;   // ts[0], ts[T−1] arrive with the kernel arguments: no load before the first step
@@ -1325,10 +1330,10 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
 #define LDE_LAUNCH_TL(K, S, A)                                                                                          \
   do {                                                                                                                  \
     if (few)                                                                                                            \
-      hipLaunchKernelGGL((k_pend_forward_tl<K, S, A, 1, true>), dim3(o.B), dim3(64), 0, stream, (const float2*)z0, theta, ts_dev, o, \
+      hipLaunchKernelGGL((k_pend_forward_tl<K, S, A, 1, true>), dim3(((o.B + 7) / 8) * 8), dim3(64), 0, stream, (const float2*)z0, theta, ts_dev, o, \
                          (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                                \
     else                                                                                                                \
-      hipLaunchKernelGGL((k_pend_forward_tl<K, S, A, 1>), dim3(o.B), dim3(64), 0, stream, (const float2*)z0, theta, ts_dev, o, \
+      hipLaunchKernelGGL((k_pend_forward_tl<K, S, A, 1>), dim3(((o.B + 7) / 8) * 8), dim3(64), 0, stream, (const float2*)z0, theta, ts_dev, o, \
                          (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                                \
   } while (0)
     if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5 && ad) LDE_LAUNCH_TL(0, LDE_SOLVER_TSIT5, true);

@@ -123,7 +123,7 @@ __device__ __forceinline__ void net64_vjp(const Net64<DP>& n, const float (&z)[D
 }
 
 template <int SOLVER, int DP, bool ADJ>
-__global__ void __launch_bounds__(64) k_mlp64(MlpDims dm, KOpts o, VArgs a) {
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_mlp64(MlpDims dm, KOpts o, VArgs a) {
   const int T = o.T, B = o.B, D = dm.D, Dp = dm.Dp, NP = dm.P, lane = threadIdx.x, b = blockIdx.x;
   constexpr int NS = ADJ ? 2 * DP + 1 : DP;      // [z | λ | g] (g stays 0 without a parameter)
   const int H1 = dm.sizes[1], H2 = dm.sizes[2];
@@ -281,107 +281,74 @@ __global__ void __launch_bounds__(64) k_mlp64(MlpDims dm, KOpts o, VArgs a) {
     dt = o.adaptive ? fmin(o.dt_fixed, dtmax) : o.dt_fixed;
     running = begin_step();
   }
+  // One iteration of the loop = one whole ATTEMPT (all stages, unrolled) once the initial step size is known; the two evaluations
+  // that find it (PH_K0, PH_INIT1) keep the one-evaluation-per-iteration form. In every unrolled copy the stage number `s` is a
+  // compile-time constant: the stage sum is straight-line code and the slope lands in k[s] directly — as one evaluation per
+  // iteration with a run-time `s` every evaluation paid a jump table for the stage sum and 7·NS conditional moves to store its
+  // slope "at a static register index".
   while (running) {
-    float src[NS];
-    bool any_w = false;
-#pragma unroll
-    for (int i = 0; i < NS; i++) src[i] = phase == PH_INIT1 ? tmp[i] : y[i];
     if (phase == PH_STAGE) {
-      if (SOLVER == LDE_SOLVER_TSIT5) {
-        if (s > 0) {
+#pragma unroll
+      for (int s = ADJ ? 0 : 1; s <= LAST_STAGE; s++) {
+        float src[NS];
+        bool any_w = false;
+#pragma unroll
+        for (int i = 0; i < NS; i++) src[i] = y[i];
+        if (phase == PH_STAGE) {
+          if (SOLVER == LDE_SOLVER_TSIT5) {
+            if (s > 0) {
 #define M64STAGE(S_)                                                                  \
-  case S_:                                                                            \
-    _Pragma("unroll") for (int i = 0; i < NS; i++) {                                  \
-      float accv = ts5::A[S_][0] * k[0][i];                                           \
-      _Pragma("unroll") for (int jj = 1; jj < S_; jj++) accv += ts5::A[S_][jj] * k[jj][i]; \
-      src[i] = y[i] + h * accv;                                                       \
-    }                                                                                 \
-    break;
-          switch (s) {
-            M64STAGE(1) M64STAGE(2) M64STAGE(3) M64STAGE(4) M64STAGE(5) M64STAGE(6)
-            default: break;
-          }
+      case S_:                                                                            \
+        _Pragma("unroll") for (int i = 0; i < NS; i++) {                                  \
+          float accv = ts5::A[S_][0] * k[0][i];                                           \
+          _Pragma("unroll") for (int jj = 1; jj < S_; jj++) accv += ts5::A[S_][jj] * k[jj][i]; \
+          src[i] = y[i] + h * accv;                                                       \
+        }                                                                                 \
+        break;
+              switch (s) {
+                M64STAGE(1) M64STAGE(2) M64STAGE(3) M64STAGE(4) M64STAGE(5) M64STAGE(6)
+                default: break;
+              }
 #undef M64STAGE
-          if (s == 6) {
+              if (s == 6) {
 #pragma unroll
-            for (int i = 0; i < NS; i++) yn[i] = src[i];
+                for (int i = 0; i < NS; i++) yn[i] = src[i];
+              }
+            }
+            any_w = ADJ && s < 6;
+          } else if (ADJ || s < 4) {
+            if (s > 0) {
+              const float cs = (s == 3 ? 1.0f : 0.5f) * h;
+#pragma unroll
+              for (int i = 0; i < NS; i++) src[i] = y[i] + cs * (s == 1 ? k[0][i] : (s == 2 ? k[1][i] : k[2][i]));
+            }
+            any_w = ADJ;
+          } else {
+            const float h6 = h * (1.0f / 6.0f);
+#pragma unroll
+            for (int i = 0; i < NS; i++) {
+              yn[i] = y[i] + h6 * (k[0][i] + 2.0f * (k[1][i] + k[2][i]) + k[3][i]);
+              src[i] = yn[i];
+            }
           }
+          if (ADJ && s == 0 && slot_base + NST > a.cap) overflow = true;
         }
-        any_w = ADJ && s < 6;
-      } else if (ADJ || s < 4) {
-        if (s > 0) {
-          const float cs = (s == 3 ? 1.0f : 0.5f) * h;
+        float dst[NS];
 #pragma unroll
-          for (int i = 0; i < NS; i++) src[i] = y[i] + cs * (s == 1 ? k[0][i] : (s == 2 ? k[1][i] : k[2][i]));
+        for (int i = 0; i < NS; i++) dst[i] = 0.f;
+        eval(src, dst, (any_w && !overflow) ? my_stage + (size_t)(slot_base + s) * blk_floats : nullptr);
+        {   // store the slope where the phase wants it (static register indices)
+          const int ks = phase == PH_K0 ? 0 : (phase == PH_INIT1 ? 1 : s);
+#pragma unroll
+          for (int q = 0; q < 7; q++)
+            if (q == ks) {
+#pragma unroll
+              for (int i = 0; i < NS; i++) k[q][i] = dst[i];
+            }
         }
-        any_w = ADJ;
-      } else {
-        const float h6 = h * (1.0f / 6.0f);
-#pragma unroll
-        for (int i = 0; i < NS; i++) {
-          yn[i] = y[i] + h6 * (k[0][i] + 2.0f * (k[1][i] + k[2][i]) + k[3][i]);
-          src[i] = yn[i];
-        }
-      }
-      if (ADJ && s == 0 && slot_base + NST > a.cap) overflow = true;
-    }
-    float dst[NS];
-#pragma unroll
-    for (int i = 0; i < NS; i++) dst[i] = 0.f;
-    eval(src, dst, (any_w && !overflow) ? my_stage + (size_t)(slot_base + s) * blk_floats : nullptr);
-    {   // store the slope where the phase wants it (static register indices)
-      const int ks = phase == PH_K0 ? 0 : (phase == PH_INIT1 ? 1 : s);
-#pragma unroll
-      for (int q = 0; q < 7; q++)
-        if (q == ks) {
-#pragma unroll
-          for (int i = 0; i < NS; i++) k[q][i] = dst[i];
-        }
-    }
-    if (status == 0) nfe++;
+        if (status == 0) nfe++;
 
-    if (phase == PH_K0 && !(ADJ || auto_dt)) {
-      dt = o.adaptive ? fmin(o.dt_fixed, dtmax) : o.dt_fixed;
-      phase = PH_STAGE;
-      s = 1;
-      running = begin_step();
-    } else if (phase == PH_K0) {
-      float v0 = 0.f, v1 = 0.f;
-#pragma unroll
-      for (int i = 0; i < NS; i++) {
-        const float sk = fast_rcp(o.abstol + fabsf(y[i]) * o.reltol);
-        scr[i] = sk;
-        const float a0 = y[i] * sk, a1 = k[0][i] * sk;
-        if (counted(i)) { v0 += a0 * a0; v1 += a1 * a1; }
       }
-      const float d0 = sqrtf(v0 / nnorm);
-      d1n = sqrtf(v1 / nnorm);
-      double dt0 = (d0 < 1e-5f || d1n < 1e-5f) ? 1e-6 : 0.01 * (double)(d0 * fast_rcp(d1n));
-      if (dt0 > dtmax) dt0 = dtmax;
-      dt = dt0;
-      h = status == 0 ? dirn * (float)dt0 : 0.f;
-#pragma unroll
-      for (int i = 0; i < NS; i++) tmp[i] = y[i] + h * k[0][i];
-      phase = PH_INIT1;
-    } else if (phase == PH_INIT1) {
-      float w0 = 0.f;
-#pragma unroll
-      for (int i = 0; i < NS; i++) {
-        const float dd = (k[1][i] - k[0][i]) * scr[i];
-        if (counted(i)) w0 += dd * dd;
-      }
-      const double dt0 = dt;
-      const float d2 = sqrtf(w0 / nnorm) * fast_rcp((float)dt0);
-      const float dm_ = fmaxf(d1n, d2);
-      const double dt1 = (dm_ <= 1e-15f) ? fmax(1e-6, dt0 * 1e-3) : (double)(0.39810717055349726f * fast_pow(dm_, -0.2f));
-      const double dn = fmin(100.0 * dt0, dt1);
-      dt = dn > dtmax ? dtmax : dn;
-      phase = PH_STAGE;
-      s = ADJ ? 0 : 1;
-      running = begin_step();
-    } else if (s < LAST_STAGE) {
-      s++;
-    } else {
       if (ADJ && SOLVER == LDE_SOLVER_RK4) {
         const float h6 = h * (1.0f / 6.0f);
 #pragma unroll
@@ -497,6 +464,66 @@ __global__ void __launch_bounds__(64) k_mlp64(MlpDims dm, KOpts o, VArgs a) {
             t -= tnew;
         }
         s = 0;
+        running = begin_step();
+      }
+    } else {
+      float src[NS];
+      const bool any_w = false;
+#pragma unroll
+      for (int i = 0; i < NS; i++) src[i] = phase == PH_INIT1 ? tmp[i] : y[i];
+      float dst[NS];
+#pragma unroll
+      for (int i = 0; i < NS; i++) dst[i] = 0.f;
+      eval(src, dst, (any_w && !overflow) ? my_stage + (size_t)(slot_base + s) * blk_floats : nullptr);
+      {   // store the slope where the phase wants it (static register indices)
+        const int ks = phase == PH_K0 ? 0 : (phase == PH_INIT1 ? 1 : s);
+#pragma unroll
+        for (int q = 0; q < 7; q++)
+          if (q == ks) {
+#pragma unroll
+            for (int i = 0; i < NS; i++) k[q][i] = dst[i];
+          }
+      }
+      if (status == 0) nfe++;
+
+      if (phase == PH_K0 && !(ADJ || auto_dt)) {
+        dt = o.adaptive ? fmin(o.dt_fixed, dtmax) : o.dt_fixed;
+        phase = PH_STAGE;
+        s = 1;
+        running = begin_step();
+      } else if (phase == PH_K0) {
+        float v0 = 0.f, v1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+          const float sk = fast_rcp(o.abstol + fabsf(y[i]) * o.reltol);
+          scr[i] = sk;
+          const float a0 = y[i] * sk, a1 = k[0][i] * sk;
+          if (counted(i)) { v0 += a0 * a0; v1 += a1 * a1; }
+        }
+        const float d0 = sqrtf(v0 / nnorm);
+        d1n = sqrtf(v1 / nnorm);
+        double dt0 = (d0 < 1e-5f || d1n < 1e-5f) ? 1e-6 : 0.01 * (double)(d0 * fast_rcp(d1n));
+        if (dt0 > dtmax) dt0 = dtmax;
+        dt = dt0;
+        h = status == 0 ? dirn * (float)dt0 : 0.f;
+#pragma unroll
+        for (int i = 0; i < NS; i++) tmp[i] = y[i] + h * k[0][i];
+        phase = PH_INIT1;
+      } else if (phase == PH_INIT1) {
+        float w0 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NS; i++) {
+          const float dd = (k[1][i] - k[0][i]) * scr[i];
+          if (counted(i)) w0 += dd * dd;
+        }
+        const double dt0 = dt;
+        const float d2 = sqrtf(w0 / nnorm) * fast_rcp((float)dt0);
+        const float dm_ = fmaxf(d1n, d2);
+        const double dt1 = (dm_ <= 1e-15f) ? fmax(1e-6, dt0 * 1e-3) : (double)(0.39810717055349726f * fast_pow(dm_, -0.2f));
+        const double dn = fmin(100.0 * dt0, dt1);
+        dt = dn > dtmax ? dtmax : dn;
+        phase = PH_STAGE;
+        s = ADJ ? 0 : 1;
         running = begin_step();
       }
     }

@@ -50,6 +50,25 @@ def test_forward_matches_oracle(o32, o64, kind, tol, B):
     assert e_k <= (min(5e-4, 1.5 * e_o + 1e-5) if default else 1e-5)
 
 
+@pytest.mark.parametrize("T,dt", [(2, 0.05), (33, 0.05), (65, 0.04), (66, 0.04), (130, 0.02), (200, 0.0125)])
+@pytest.mark.parametrize("B", [5, 256])
+def test_small_batch_forward_over_save_grid_lengths(o32, B, T, dt):
+    """The lanes-as-save-times forward kernel has two instantiations: T − 1 ≤ 64 (a lane serves exactly one save time; the stepping
+    loop has no load) and longer grids (a lane serves several and fetches the next one inside the loop). Both sides of the boundary
+    (T − 1 = 64, 65) and grids of one, two and four save times per lane against the oracle, at the tight tolerance (≤ 1e-5) and the
+    default one (worst trajectory ≤ 3e-4, the gate of test_forward_matches_oracle)."""
+    z0, L = O.pendulum_inputs(B, seed=11)
+    ts = O.time_grid(T, dt)
+    for tol, gate in (((1e-6, 1e-6), 1e-5), ((1e-6, 1e-3), 3e-4)):
+        nat, od = _native(abstol=tol[0], reltol=tol[1])
+        z, ret, st = nat.forward(z0, L, ts)
+        zr, retr, info = o32.forward(od, z0, L, ts)
+        assert (ret == 0).all() and (retr == 0).all()
+        assert np.array_equal(z[0], z0)
+        assert np.abs(z - zr).max() <= gate, (T, tol)
+        assert st["nfe"] == 6 * (st["naccept"] + st["nreject"]) + 2 * B
+
+
 @pytest.mark.parametrize("kind", [O.RHS_PENDULUM, O.RHS_PENDULUM_FRICTION])
 @pytest.mark.parametrize("sense", [O.SENSE_BACKSOLVE_CHECKPOINTED, O.SENSE_BACKSOLVE, O.SENSE_PARALLEL_CHECKPOINTED])
 @pytest.mark.parametrize("tol", [(1e-6, 1e-3), (1e-6, 1e-6)])

@@ -464,6 +464,28 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def count_gpus_sysfs():
+    """GPUs of this node WITHOUT touching HIP/HSA (the launcher parent must stay GPU-free: it starts the ranks as children):
+    KFD topology nodes with a non-zero simd_count, cut down by a *_VISIBLE_DEVICES list when one is set. None if sysfs has no KFD."""
+    import glob
+    nodes = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not nodes:
+        return None
+    n = 0
+    for f in nodes:
+        try:
+            with open(f) as fh:
+                props = dict(ln.split()[:2] for ln in fh if len(ln.split()) >= 2)
+            n += int(props.get("simd_count", "0")) > 0
+        except (OSError, ValueError):
+            return None
+    for var in ("HIP_VISIBLE_DEVICES", "ROCR_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None and v.strip() != "":
+            n = min(n, len([x for x in v.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(args, argv):
     """`python bench.py --gpus N` with N > 1 and no torchrun environment: start the N ranks as CHILD processes
     (`python -m torch.distributed.run --nproc-per-node N bench.py …`, one rank per GPU) BEFORE this process touches a GPU
@@ -471,9 +493,8 @@ def launch_ranks(args, argv):
     exit with the children's code."""
     import subprocess
     if not args.dry_launch:
-        import torch
-        have = torch.cuda.device_count()          # counts devices without initialising the GPU
-        if have < args.gpus:
+        have = count_gpus_sysfs()                 # from the KFD topology in sysfs: this process never opens the GPU driver
+        if have is not None and have < args.gpus:
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + argv
@@ -762,17 +783,18 @@ def main():
                                   fwd_GBs=fb * Bs / (fm * 1e-3) / 1e9, bwd_GBs=bb * Bs / (bm * 1e-3) / 1e9)
         out["batch_sweep"] = sweep
 
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(w, d, ts, z0, theta, W, dz)
-    elif rank == 0:
-        out["cpu_baseline"] = None
-
     lib.lde_destroy(h)
     if comm is not None:
         comm.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    # the CPU baseline is taken AFTER the timed region and after the process group is gone (the other ranks have exited or are
+    # exiting: nothing competes for the host cores); on N > 1 too, with a shorter budget, so that every line carries it
+    if rank == 0 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(w, d, ts, z0, theta, W, dz, budget_s=12.0 if world == 1 else 6.0)
+    elif rank == 0:
+        out["cpu_baseline"] = None
     if rank == 0:
         print(json.dumps(out))
 

@@ -1370,9 +1370,15 @@ struct MlpPlan {
   hipEvent_t fb_ev = nullptr;
   bool fb_pending = false;
   int cap_scale = 1;
+  // k_mlp64's adjoint (lde_mlp64.h) accumulates the weight gradient in registers: one row of nW floats per wave, summed by k_sum_rows
+  float* rows = nullptr;       // [waves][rows_stride]
+  size_t rows_cap = 0;
+  int rows_stride = 0;
 };
 
 void mlp_plan_destroy(MlpPlan* p);
+static bool mlp64_applicable(const MlpDims& dm, int B);
+static int mlp64_adj_waves(int B);
 
 int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err) {
   MlpPlan* p = new MlpPlan();
@@ -1547,6 +1553,7 @@ void mlp_plan_destroy(MlpPlan* p) {
   if (p->stage) (void)hipFree(p->stage);
   if (p->wts) (void)hipFree(p->wts);
   if (p->nslots) (void)hipFree(p->nslots);
+  if (p->rows) (void)hipFree(p->rows);
   if (p->fb_dev) (void)hipFree(p->fb_dev);
   if (p->fb_host) (void)hipHostFree(p->fb_host);
   if (p->fb_ev) (void)hipEventDestroy(p->fb_ev);
@@ -1575,6 +1582,14 @@ int mlp_reserve(MlpPlan* p, int B, int T, std::string& err) {
 // (slow but correct). LDE_MLP_STAGE_SLOTS forces the slot count (tests).
 int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::string& err) {
   const MlpDims& dm = p->dm;
+  if (mlp64_applicable(dm, B)) {   // no staging area: a slab row per wave is the kernel's only workspace
+    p->rows_stride = (dm.nW + 63) & ~63;
+    if (!grow(&p->rows, &p->rows_cap, (size_t)mlp64_adj_waves(B) * p->rows_stride)) {
+      err = "MLP plan: hipMalloc of the weight-gradient rows failed";
+      return LDE_ERR_ALLOC;
+    }
+    return LDE_OK;
+  }
   const int nwg = cdiv(B, NB);
   const int nst = dm.solver == LDE_SOLVER_RK4 ? 4 : 6;
   static const long budget_mb = [] { const char* e = getenv("LDE_MLP_STAGE_MB"); return e ? atol(e) : 24576L; }();
@@ -1712,13 +1727,25 @@ static bool mlp64_applicable(const MlpDims& dm, int B) {
   const int maxb = m ? atoi(m) : 65536;   // measured (c3 shape): 0.28 + 3.9 ms vs 0.61 + 5.8 for the tile kernels at B = 4096, 0.77 + 10.4 vs 2.2 + 12.0 at 16384
   return dm.nL == 3 && dm.sizes[1] <= 64 && dm.sizes[2] <= 64 && dm.Dp <= 4 && dm.P <= 1 && !dm.coupled && B <= maxb;
 }
+// waves of the adjoint launch: one per SIMD (the kernel takes more than 256 registers); a wave walks trajectories b, b + waves, …
+// with ONE set of gradient sums, so the slab the final sum reads has `waves` rows whatever the batch
+static int mlp64_adj_waves(int B) {
+  static const int maxw = [] { const char* e = getenv("LDE_MLP64_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
+  return B < maxw ? B : maxw;
+}
 template <bool ADJ>
 static int launch_mlp64(const MlpDims& dm, const KOpts& o, const VArgs& a, hipStream_t stream, std::string& err) {
   const bool rk4 = dm.solver == LDE_SOLVER_RK4, d2 = dm.Dp <= 2;
-  if (rk4 && d2) hipLaunchKernelGGL((k_mlp64<LDE_SOLVER_RK4, 2, ADJ>), dim3(o.B), dim3(64), 0, stream, dm, o, a);
-  else if (rk4) hipLaunchKernelGGL((k_mlp64<LDE_SOLVER_RK4, 4, ADJ>), dim3(o.B), dim3(64), 0, stream, dm, o, a);
-  else if (d2) hipLaunchKernelGGL((k_mlp64<LDE_SOLVER_TSIT5, 2, ADJ>), dim3(o.B), dim3(64), 0, stream, dm, o, a);
-  else hipLaunchKernelGGL((k_mlp64<LDE_SOLVER_TSIT5, 4, ADJ>), dim3(o.B), dim3(64), 0, stream, dm, o, a);
+  if (ADJ) {
+    const dim3 grid(mlp64_adj_waves(o.B));
+    if (rk4 && d2) hipLaunchKernelGGL((k_mlp64_adj<LDE_SOLVER_RK4, 2>), grid, dim3(64), 0, stream, dm, o, a);
+    else if (rk4) hipLaunchKernelGGL((k_mlp64_adj<LDE_SOLVER_RK4, 4>), grid, dim3(64), 0, stream, dm, o, a);
+    else if (d2) hipLaunchKernelGGL((k_mlp64_adj<LDE_SOLVER_TSIT5, 2>), grid, dim3(64), 0, stream, dm, o, a);
+    else hipLaunchKernelGGL((k_mlp64_adj<LDE_SOLVER_TSIT5, 4>), grid, dim3(64), 0, stream, dm, o, a);
+  } else if (rk4 && d2) hipLaunchKernelGGL((k_mlp64<LDE_SOLVER_RK4, 2>), dim3(o.B), dim3(64), 0, stream, dm, o, a);
+  else if (rk4) hipLaunchKernelGGL((k_mlp64<LDE_SOLVER_RK4, 4>), dim3(o.B), dim3(64), 0, stream, dm, o, a);
+  else if (d2) hipLaunchKernelGGL((k_mlp64<LDE_SOLVER_TSIT5, 2>), dim3(o.B), dim3(64), 0, stream, dm, o, a);
+  else hipLaunchKernelGGL((k_mlp64<LDE_SOLVER_TSIT5, 4>), dim3(o.B), dim3(64), 0, stream, dm, o, a);
   if (hipGetLastError() != hipSuccess) {
     err = "k_mlp64 launch failed";
     return LDE_ERR_HIP;
@@ -2025,6 +2052,27 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
                 const KOpts& o, const float* dz_out, float* dz0, float* dtheta, float* dW, int32_t* nfe, int32_t* nacc,
                 int32_t* nrej, int32_t* ret, hipStream_t stream, std::string& err) {
   const MlpDims& dm = p->dm;
+  if (mlp64_applicable(dm, o.B)) {   // one wave per trajectory, registers only, the weight gradient included (lde_mlp64.h): two launches
+    const int waves = mlp64_adj_waves(o.B);
+    if (!p->rows || p->rows_cap < (size_t)waves * p->rows_stride || p->rows_stride < dm.nW) {
+      err = "MLP adjoint: workspace not reserved";
+      return LDE_ERR_INVALID_ARG;
+    }
+    VArgs va{};
+    va.theta = theta; va.ts = ts_dev; va.Wflat = W_dev; va.z_out = const_cast<float*>(z_out); va.dz_out = dz_out;
+    va.dz0 = dz0; va.dtheta = dtheta; va.stage = p->rows; va.cap = p->rows_stride;
+    va.st_nfe = nfe; va.st_nacc = nacc; va.st_nrej = nrej; va.st_ret = ret;
+    const int rc6 = launch_mlp64<true>(dm, o, va, stream, err);
+    if (rc6) return rc6;
+    if (dW) {
+      hipLaunchKernelGGL(k_sum_rows, dim3(cdiv(dm.nW, 64)), dim3(1024), 0, stream, p->rows, waves, p->rows_stride, dm.nW, dW);
+      if (hipGetLastError() != hipSuccess) {
+        err = "k_sum_rows launch failed";
+        return LDE_ERR_HIP;
+      }
+    }
+    return LDE_OK;
+  }
   const int nwg = cdiv(o.B, NB);
   const bool sync = dm.coupled && o.adaptive && nwg > 1;
   if (sync && nwg > 256) {
@@ -2060,22 +2108,6 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
 #endif
   int ntile_dw = nwg;
   bool vec_done = false;
-  if (mlp64_applicable(dm, o.B)) {   // one wave per trajectory, registers only (lde_mlp64.h)
-    if (hipMemsetAsync(p->fb_dev, 0, 2 * sizeof(int32_t), stream) != hipSuccess ||
-        hipMemsetAsync(p->nslots, 0, (size_t)2 * (nwg + 1) * sizeof(int32_t), stream) != hipSuccess ||
-        hipMemsetAsync(p->wts, 0, (size_t)nwg * p->adj_cap * NB * sizeof(float), stream) != hipSuccess) {
-      err = "hipMemsetAsync(staging weights) failed";
-      return LDE_ERR_HIP;
-    }
-    VArgs va{};
-    va.theta = theta; va.ts = ts_dev; va.Wflat = W_dev; va.z_out = const_cast<float*>(z_out); va.dz_out = dz_out;
-    va.dz0 = dz0; va.dtheta = dtheta; va.stage = p->stage; va.wts = p->wts; va.nslots = p->nslots; va.cap = p->adj_cap; va.ovf = p->fb_dev + 1;
-    va.st_nfe = nfe; va.st_nacc = nacc; va.st_nrej = nrej; va.st_ret = ret;
-    const int rc6 = launch_mlp64<true>(dm, o, va, stream, err);
-    if (rc6) return rc6;
-    vec_done = true;
-    a.fallback = 1;
-  }
   if (!vec_done) {   // small batches: one trajectory per workgroup, lanes = hidden units (lde_mlpv.h)
     size_t ldsv = 0;
     const bool ca = dm.coupled && o.adaptive && o.B > 1;

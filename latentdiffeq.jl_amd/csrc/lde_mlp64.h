@@ -13,11 +13,19 @@
 //     one scalar register, two wait states and one accumulator per element — ≈ 770 cycles per product against ≈ 350.)
 //   * the D' ≤ 4 outputs are wave sums (four DPP row shifts + four readlanes each);
 //   * the state [z; λ; g], the seven slopes and the whole step control are wave-uniform values that every lane carries
-//     redundantly (a SIMT machine does that for free), so an evaluation touches no memory besides those LDS vectors and the
-//     staging stores of the weight gradient's (a_l, δ_l) panels, which nobody waits for.
+//     redundantly (a SIMT machine does that for free), so an evaluation touches no memory besides those LDS vectors;
+//   * the weight gradient gW_l = Σ_evaluations w_e δ_l a_lᵀ (a quadrature over the accepted steps, w_e = b_s·|h|) never leaves
+//     the wave either (round 3; rounds 1–2 staged every evaluation's (a_l, δ_l) panels to HBM for a second kernel, k_mlp_dw:
+//     587 MB written and read back per c3 launch against 0.84 MB of algorithmic traffic, 20 % of the step). The LDS vectors
+//     through which h₁ and δ₂ reach every lane are a RING indexed by the stage, so at accept time the attempt's six (h₁, δ₂)
+//     pairs are still there: they are folded into four AGPR-resident 32×32 tiles of gW₂ᵀ with v_mfma_f32_32x32x2_f32 (K = two
+//     evaluations per instruction, the δ operand scaled by its quadrature weight: 12 MFMAs per accepted step), while the thin
+//     layers' gradients (gW₁ = Σ w δ₁zᵀ, gW₃ = Σ w λh₂ᵀ, the biases) are a handful of FMAs per evaluation on lane-owned
+//     registers — first into per-attempt sums with the weights b_s, scaled by |h| and added at accept (a rejected attempt's sums
+//     are dropped). A wave walks the trajectories b, b + grid, … with the same accumulators and writes ONE row of a [waves × nW]
+//     slab in flat destructure order at the end; k_sum_rows adds the rows in a fixed order (bit-reproducible).
 // Same algorithm and control arithmetic as k_mlp_adjoint / k_mlpv (HNW initial step, PI controller carried across the save
-// times, k₁ re-evaluated every attempt, quadrature weights written at accept time, k_mlp_dw forms dW): agreement to solver
-// tolerance. Limits: exactly three Dense layers D' → H₁ → H₂ → D' with H ≤ 64 and D' ∈ {2, 4}-padded, P ≤ 1, per-trajectory
+// times, k₁ re-evaluated every attempt, quadrature weights b_s·|h| of the accepted steps): agreement to solver tolerance. Limits: exactly three Dense layers D' → H₁ → H₂ → D' with H ≤ 64 and D' ∈ {2, 4}-padded, P ≤ 1, per-trajectory
 // control (coupled control needs the grid-wide sum: k_mlpv). Anything else runs k_mlpv / the tile kernels.
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
@@ -46,7 +54,7 @@ struct Net64 {
   float w1[DP], b1;        // row j of W₁ [H₁×D'], bias
   f32x2 w2r[32]; float b2; // row j of W₂ [H₂×H₁], as register pairs (v_pk_fma_f32)
   f32x2 w2c[32];           // column j of W₂: W₂[i][j], i < H₂
-  float* hx;               // LDS: two 64-float vectors through which h₁ / δ₂ reach every lane (broadcast ds_read_b128)
+  float* hx;               // LDS: two 64-float vectors through which h₁ / δ₂ reach every lane (broadcast ds_read_b128); one pair per stage (a ring)
   float w3c[DP];           // column j of W₃ [D'×H₂]: W₃[d][j]
   float b3[DP];            // uniform
   float ngl, gl2;          // pendulum: −G/L, G/L²
@@ -122,11 +130,20 @@ __device__ __forceinline__ void net64_vjp(const Net64<DP>& n, const float (&z)[D
   }
 }
 
+// the weight gradient of one wave: accepted sums, and the sums of the attempt in flight (weights b_s, not yet scaled by |h|)
+template <int DP>
+struct Grad64 {
+  f32x16 w2[2][2];                                   // gW₂ᵀ tiles [input tile of h₁][output tile of δ₂], C/D layout of v_mfma_f32_32x32x2_f32
+  float w1[DP], b1, b2, w3[DP], b3[DP];              // lane j: gW₁[j][k], gb₁[j], gb₂[j], gW₃[d][j]; gb₃[d] (uniform)
+  float pw1[DP], pb1, pb2, pw3[DP], pb3[DP];         // the attempt's
+};
+
 template <int SOLVER, int DP, bool ADJ>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_mlp64(MlpDims dm, KOpts o, VArgs a) {
-  const int T = o.T, B = o.B, D = dm.D, Dp = dm.Dp, NP = dm.P, lane = threadIdx.x, b = blockIdx.x;
+__device__ __forceinline__ void mlp64_body(const MlpDims& dm, const KOpts& o, const VArgs& a) {
+  const int T = o.T, B = o.B, D = dm.D, Dp = dm.Dp, NP = dm.P, lane = threadIdx.x;
   constexpr int NS = ADJ ? 2 * DP + 1 : DP;      // [z | λ | g] (g stays 0 without a parameter)
   const int H1 = dm.sizes[1], H2 = dm.sizes[2];
+  __shared__ __attribute__((aligned(16))) float s_hx[7 * 128];   // ring: stage s → h₁ at [128 s, +64), δ₂ at [128 s + 64, +64)
   Net64<DP> n;
   {   // weights into registers (flat destructure order: vec(W) column-major [out×in], then b)
     const float* W = a.Wflat;
@@ -145,32 +162,47 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     n.b2 = W[dm.b_off[1] + l2] * m2;
 #pragma unroll
     for (int i = 0; i < 64; i++) n.w2c[i >> 1][i & 1] = ADJ ? W2[min(i, H2 - 1) + H2 * l1] * (i < H2 ? m1 : 0.f) : 0.f;
-    __shared__ __attribute__((aligned(16))) float s_hx[128];
-    n.hx = s_hx;
+    n.hx = s_hx + 6 * 128;
 #pragma unroll
     for (int d = 0; d < DP; d++) {
       n.w3c[d] = W3[min(d, Dp - 1) + Dp * l2] * (d < Dp ? m2 : 0.f);
       n.b3[d] = W[dm.b_off[2] + min(d, Dp - 1)] * (d < Dp ? 1.f : 0.f);
     }
-    float L = 1.f;
-    if (dm.has_pend) L = a.theta[(size_t)b * NP];
-    n.ngl = -10.0f / L;
-    n.gl2 = 10.0f / (L * L);
     n.act = dm.act;
     n.has_pend = dm.has_pend;
     n.h1 = n.h2 = 0.f;
   }
   const double* ts = a.ts;
   const double t0 = ts[0], tend = ts[T - 1], dtmax = fabs(tend - t0);
-  constexpr int NST = SOLVER == LDE_SOLVER_TSIT5 ? 6 : 4;
-  const int tile = b >> 4, ncol = b & 15;
-  float* const my_stage = ADJ ? a.stage + (size_t)tile * a.cap * dm.blk_floats : nullptr;
-  float* const my_wts = ADJ ? a.wts + (size_t)tile * a.cap * NB : nullptr;
-  int slot_base = 0;
-  bool overflow = false;
-  const int blk_floats = dm.blk_floats;
-  const int in32_0 = pad32(Dp), h1_32 = pad32(H1), h2_32 = pad32(H2);
-  const int boff0 = dm.blk_off[0], boff1 = dm.blk_off[1], boff2 = dm.blk_off[2];
+  constexpr int NST = SOLVER == LDE_SOLVER_TSIT5 ? 6 : 4;   // weighted evaluations of a step (Tsit5: b₇ = 0)
+  auto bq = [](int s_) -> float {                           // quadrature weight of stage s_ (without |h|)
+    if (SOLVER == LDE_SOLVER_TSIT5) return ts5::A[6][s_ < 6 ? s_ : 0];
+    return (s_ == 0 || s_ == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
+  };
+  Grad64<DP> g;
+  const int half = lane >> 5, l31 = lane & 31;
+  float bsel[NST / 2];                                      // the lane's half of the MFMA's K pair: stage 2m + half
+  if (ADJ) {
+#pragma unroll
+    for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+      for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) g.w2[ti][tj][r] = 0.f;
+#pragma unroll
+    for (int d = 0; d < DP; d++) g.w1[d] = g.w3[d] = g.b3[d] = g.pw1[d] = g.pw3[d] = g.pb3[d] = 0.f;
+    g.b1 = g.b2 = g.pb1 = g.pb2 = 0.f;
+#pragma unroll
+    for (int m = 0; m < NST / 2; m++) bsel[m] = half ? bq(2 * m + 1) : bq(2 * m);
+  }
+
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {   // the adjoint walks several trajectories with one set of gradient sums
+  {
+    float L = 1.f;
+    if (dm.has_pend) L = a.theta[(size_t)b * NP];
+    n.ngl = -10.0f / L;
+    n.gl2 = 10.0f / (L * L);
+  }
 
   // state: y = [z (DP) | λ (DP) | g]
   float y[NS], yn[NS], tmp[NS], k[7][NS], scr[NS];
@@ -241,9 +273,11 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     return status == 0;
   };
 
-  // one evaluation of the (augmented) right-hand side at `src`, staged into slot `blk` when given
-  auto eval = [&](const float (&src)[NS], float (&dst)[NS], float* blk) {
+  // one evaluation of the (augmented) right-hand side at `src`; `slot`: the ring slot its h₁ / δ₂ vectors go through; `bs` ≠ 0: the
+  // evaluation is a weighted stage of the attempt — its thin-layer gradient terms are added to the attempt's sums
+  auto eval = [&](const float (&src)[NS], float (&dst)[NS], int slot, float bs) {
     float z[DP], f[DP];
+    n.hx = s_hx + slot * 128;
 #pragma unroll
     for (int r = 0; r < DP; r++) z[r] = src[r];
     net64_rhs<DP>(n, z, f);
@@ -257,19 +291,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
 #pragma unroll
       for (int r = 0; r < DP; r++) dst[DP + r] = -vz[r];
       dst[2 * DP] = -vth;
-      if (blk) {   // (a_l, δ_l) of the three layers, column ncol of the tile's slot; rows beyond the layer are zeros
-        float zl = 0.f, ll = 0.f;
+      if (bs != 0.f) {   // (a₀, δ₁) = (z, δ₁), (a₂, δ₃) = (h₂, λ) and the three bias terms; (a₁, δ₂) = (h₁, δ₂) waits in the ring
+        const float bd1 = bs * d1, bh2 = bs * n.h2;
 #pragma unroll
         for (int r = 0; r < DP; r++) {
-          zl = lane == r ? z[r] : zl;
-          ll = lane == r ? lam[r] : ll;
+          g.pw1[r] += bd1 * z[r];
+          g.pw3[r] += bh2 * lam[r];
+          g.pb3[r] += bs * lam[r];
         }
-        if (lane < in32_0) blk[boff0 + ncol * in32_0 + lane] = lane < Dp ? zl : 0.f;                    // a₀ = z
-        if (lane < h1_32) blk[boff0 + NB * in32_0 + ncol * h1_32 + lane] = lane < H1 ? d1 : 0.f;        // δ₁
-        if (lane < h1_32) blk[boff1 + ncol * h1_32 + lane] = lane < H1 ? n.h1 : 0.f;                    // a₁ = h₁
-        if (lane < h2_32) blk[boff1 + NB * h1_32 + ncol * h2_32 + lane] = lane < H2 ? d2 : 0.f;         // δ₂
-        if (lane < h2_32) blk[boff2 + ncol * h2_32 + lane] = lane < H2 ? n.h2 : 0.f;                    // a₂ = h₂
-        if (lane < in32_0) blk[boff2 + NB * h2_32 + ncol * in32_0 + lane] = lane < Dp ? ll : 0.f;       // δ₃ = λ
+        g.pb1 += bd1;
+        g.pb2 += bs * d2;
       }
     }
   };
@@ -331,12 +362,16 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
               src[i] = yn[i];
             }
           }
-          if (ADJ && s == 0 && slot_base + NST > a.cap) overflow = true;
+          if (ADJ && s == 0) {   // a new attempt: its thin-layer sums start from zero
+#pragma unroll
+            for (int d = 0; d < DP; d++) g.pw1[d] = g.pw3[d] = g.pb3[d] = 0.f;
+            g.pb1 = g.pb2 = 0.f;
+          }
         }
         float dst[NS];
 #pragma unroll
         for (int i = 0; i < NS; i++) dst[i] = 0.f;
-        eval(src, dst, (any_w && !overflow) ? my_stage + (size_t)(slot_base + s) * blk_floats : nullptr);
+        eval(src, dst, s, any_w ? bq(s) : 0.f);
         {   // store the slope where the phase wants it (static register indices)
           const int ks = phase == PH_K0 ? 0 : (phase == PH_INIT1 ? 1 : s);
 #pragma unroll
@@ -437,14 +472,27 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
         s = 1;
         running = begin_step();
       } else {
-        if (accepted && !overflow) {
-          if (lane < NST) {
-            float bs;
-            if (SOLVER == LDE_SOLVER_TSIT5) bs = ts5::A[6][lane];
-            else bs = (lane == 0 || lane == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
-            my_wts[(size_t)(slot_base + lane) * NB + ncol] = wq * bs;
+        if (accepted) {   // the accepted step's share of the quadrature gW = Σ |h| b_s (∂f/∂W)ᵀλ
+#pragma unroll
+          for (int d = 0; d < DP; d++) {
+            g.w1[d] += wq * g.pw1[d];
+            g.w3[d] += wq * g.pw3[d];
+            g.b3[d] += wq * g.pb3[d];
           }
-          slot_base += NST;
+          g.b1 += wq * g.pb1;
+          g.b2 += wq * g.pb2;
+          // gW₂ᵀ[i][o] += Σ_s (h₁)_s[i] · (|h| b_s δ₂)_s[o]: the stages' vectors are still in the ring; one MFMA takes two stages
+          // (A: lane → h₁ of stage 2m + half, unit 32 ti + (lane & 31); B: the same lane map on the scaled δ₂)
+#pragma unroll
+          for (int m = 0; m < NST / 2; m++) {
+            const float* rs = s_hx + (2 * m + half) * 128 + l31;
+            const float wsc = wq * bsel[m];
+            const float a0 = rs[0], a1 = rs[32], b0 = rs[64] * wsc, b1 = rs[96] * wsc;
+            g.w2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, g.w2[0][0], 0, 0, 0);
+            g.w2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, g.w2[0][1], 0, 0, 0);
+            g.w2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, g.w2[1][0], 0, 0, 0);
+            g.w2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, g.w2[1][1], 0, 0, 0);
+          }
         }
         if (accepted) {
 #pragma unroll
@@ -468,13 +516,12 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
       }
     } else {
       float src[NS];
-      const bool any_w = false;
 #pragma unroll
       for (int i = 0; i < NS; i++) src[i] = phase == PH_INIT1 ? tmp[i] : y[i];
       float dst[NS];
 #pragma unroll
       for (int i = 0; i < NS; i++) dst[i] = 0.f;
-      eval(src, dst, (any_w && !overflow) ? my_stage + (size_t)(slot_base + s) * blk_floats : nullptr);
+      eval(src, dst, 6, 0.f);
       {   // store the slope where the phase wants it (static register indices)
         const int ks = phase == PH_K0 ? 0 : (phase == PH_INIT1 ? 1 : s);
 #pragma unroll
@@ -546,15 +593,74 @@ __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2)))
     for (int r = 0; r < DP; r++) g0 = lane == r ? y[DP + r] : g0;
     if (lane < D) a.dz0[(size_t)b * D + lane] = st > 1 ? 0.f : g0;
     if (lane == 0 && NP > 0) a.dtheta[(size_t)b * NP] = st > 1 ? 0.f : y[2 * DP];
-    if (lane == 0) {
-      a.st_ret[b] = st > 1 ? st - 1 : 0;
-      atomicMax(&a.nslots[tile], slot_base);
-      if (overflow) __hip_atomic_store(a.ovf, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (lane == 0) a.st_ret[b] = st > 1 ? st - 1 : 0;
   }
   if (lane == 0) {
     a.st_nfe[b] = nfe;
     a.st_nacc[b] = nacc;
     a.st_nrej[b] = nrej;
+  }
+  }   // trajectories of this wave
+
+  if (ADJ) {   // this wave's row of the [waves × row stride] slab, flat destructure order (vec(W) column-major [out×in], then b)
+    float* row = a.stage + (size_t)blockIdx.x * a.cap;
+    const int Dpv = Dp;
+#pragma unroll
+    for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+      for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+          const int i = 32 * ti + ((r & 3) | (half << 2) | ((r >> 2) << 3)), oo = 32 * tj + l31;
+          if (i < H1 && oo < H2) row[dm.w_off[1] + oo + H2 * i] = g.w2[ti][tj][r];
+        }
+#pragma unroll
+    for (int d = 0; d < DP; d++) {
+      if (d < Dpv && lane < H1) row[dm.w_off[0] + lane + H1 * d] = g.w1[d];
+      if (d < Dpv && lane < H2) row[dm.w_off[2] + d + Dpv * lane] = g.w3[d];
+      if (lane == d && d < Dpv) row[dm.b_off[2] + d] = g.b3[d];
+    }
+    if (lane < H1) row[dm.b_off[0] + lane] = g.b1;
+    if (lane < H2) row[dm.b_off[1] + lane] = g.b2;
+  }
+}
+
+template <int SOLVER, int DP>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_mlp64(MlpDims dm, KOpts o, VArgs a) {
+  mlp64_body<SOLVER, DP, false>(dm, o, a);
+}
+// the adjoint keeps 64 accumulator registers of gW₂ᵀ on top of the weights: one wave per SIMD, 512 registers
+template <int SOLVER, int DP>
+__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) k_mlp64_adj(MlpDims dm, KOpts o, VArgs a) {
+  mlp64_body<SOLVER, DP, true>(dm, o, a);
+}
+
+// dW[e] += Σ_s rows[s][e], s in index order (bit-reproducible): the rows the adjoint's waves left. A workgroup owns 64 consecutive
+// entries; its sixteen waves each add a contiguous block of rows (eight loads in flight), the sixteen partial sums meet in LDS and
+// are added in wave order.
+static __global__ void __launch_bounds__(1024) k_sum_rows(const float* __restrict__ rows, int nrows, int stride, int n, float* __restrict__ dW) {
+  __shared__ float part[16][64];
+  const int c = threadIdx.x & 63, rg = threadIdx.x >> 6, e = blockIdx.x * 64 + c;
+  const int per = (nrows + 15) / 16, r0 = rg * per, r1 = min(nrows, r0 + per);
+  float s = 0.f;
+  if (e < n) {
+    const float* p = rows + e;
+    int r = r0;
+    for (; r + 8 <= r1; r += 8) {
+      float v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = p[(size_t)(r + u) * stride];
+#pragma unroll
+      for (int u = 0; u < 8; u++) s += v[u];
+    }
+    for (; r < r1; r++) s += p[(size_t)r * stride];
+  }
+  part[rg][c] = s;
+  __syncthreads();
+  if (rg == 0 && e < n) {
+    float t = part[0][c];
+#pragma unroll
+    for (int u = 1; u < 16; u++) t += part[u][c];
+    dW[e] += t;
   }
 }

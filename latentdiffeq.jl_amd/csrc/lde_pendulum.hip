@@ -1587,19 +1587,22 @@ __global__ void __launch_bounds__(256) k_pend_adjoint_stream(const float2* __res
 }
 
 // does the time-parallel adjoint need the operator planes in HBM for this shape? (only the two-kernel form does)
-bool pend_adjoint_needs_ops(int B, int T) {
-  const char* e = getenv("LDE_PEND_ADJ_STREAM");
-  const char* f = getenv("LDE_FUSED_MAX_B");
-  const int fused_max_b = f ? atoi(f) : 24576;
-  const bool fused = T > 1 && T - 1 <= 1024 && B <= fused_max_b;
-  return !fused && e && atoi(e) == 0;
+// ONE decision, ONE caching policy (the switches are read once per process) for both the buffer reservation and the launcher: two
+// readers with different caching could disagree after an environment change and send a NULL `ops` into the two-kernel form.
+enum { PEND_ADJ_FUSED = 0, PEND_ADJ_STREAM = 1, PEND_ADJ_TWO_KERNEL = 2 };
+static int pend_adjoint_form(int B, int T) {
+  static const int fused_max_b = [] { const char* e = getenv("LDE_FUSED_MAX_B"); return e ? atoi(e) : 24576; }();   // measured (abl/adj_B.py): fused 9.5 µs vs stream 39 µs at 4096, 48 vs 41 µs at 32768
+  static const bool stream_on = [] { const char* e = getenv("LDE_PEND_ADJ_STREAM"); return !e || atoi(e) != 0; }();
+  if (T > 1 && T - 1 <= 1024 && B <= fused_max_b) return PEND_ADJ_FUSED;
+  return stream_on ? PEND_ADJ_STREAM : PEND_ADJ_TWO_KERNEL;
 }
+bool pend_adjoint_needs_ops(int B, int T) { return pend_adjoint_form(B, T) == PEND_ADJ_TWO_KERNEL; }
 
 int launch_pend_adjoint_par(int kind, int solver, const float* z_out, const float* theta, const double* ts_dev,
                             const KOpts& o, const float* dz_out, float* dz0, float* dtheta, float* ops, int32_t* info,
                             int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret, hipStream_t stream) {
-  static const int fused_max_b = [] { const char* e = getenv("LDE_FUSED_MAX_B"); return e ? atoi(e) : 24576; }();   // measured (abl/adj_B.py): fused 9.5 µs vs stream 39 µs at 4096, 48 vs 41 µs at 32768
-  if (o.T > 1 && o.T - 1 <= 1024 && o.B <= fused_max_b) {   // fused: one workgroup per trajectory, one lane per interval
+  const int form = pend_adjoint_form(o.B, o.T);
+  if (form == PEND_ADJ_FUSED) {   // fused: one workgroup per trajectory, one lane per interval
     const int block = ((o.T - 1 + 63) / 64) * 64;
 #define LDE_LAUNCH(K, S)                                                                                                  \
   hipLaunchKernelGGL((k_pend_adjoint_fused<K, S>), dim3(((o.B + 7) / 8) * 8), dim3(block), 0, stream, (const float2*)z_out, theta, ts_dev, o, \
@@ -1612,8 +1615,7 @@ int launch_pend_adjoint_par(int kind, int solver, const float* z_out, const floa
 #undef LDE_LAUNCH
     return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
   }
-  static const bool stream_on = [] { const char* e = getenv("LDE_PEND_ADJ_STREAM"); return !e || atoi(e) != 0; }();
-  if (stream_on) {   // large batches: one lane per trajectory, interval by interval (k_pend_adjoint_stream)
+  if (form == PEND_ADJ_STREAM) {   // large batches: one lane per trajectory, interval by interval (k_pend_adjoint_stream)
     const int block = 256, grid = (o.B + block - 1) / block;
 #define LDE_LAUNCH(K, S)                                                                                                  \
   hipLaunchKernelGGL((k_pend_adjoint_stream<K, S>), dim3(grid), dim3(block), 0, stream, (const float2*)z_out, theta, ts_dev, o, \
@@ -1626,6 +1628,7 @@ int launch_pend_adjoint_par(int kind, int solver, const float* z_out, const floa
 #undef LDE_LAUNCH
     return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
   }
+  if (!ops || !info) return LDE_ERR_INVALID_ARG;   // the two-kernel form keeps its operator planes in HBM
   if (o.T > 1) {
     const long long n = (long long)(o.T - 1) * o.B;
     const int block = n <= 65536 ? 64 : 256;

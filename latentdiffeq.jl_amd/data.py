@@ -94,7 +94,7 @@ def load_dataset(path: str):
 def prepare_training_data(data, at: float = 0.9):
     """What the example script does with the loaded tuple  [REF model_train.jl:96-121]: vectorise the frames to
     [input_dim, full_seq_len, observations], split the OBSERVATIONS 90 / 10 in order (`splitobs(·, 0.9)`: the first
-    floor-rounded 90 % train, the rest validation — no shuffle), and bring the validation set to [input_dim, n_val, T].
+    90 % (rounded to nearest, as MLUtils' splitobs does) train, the rest validation — no shuffle), and bring the validation set to [input_dim, n_val, T].
     Returns dict(train_set [input_dim, T, n_train], val_set [input_dim, n_val, T], train/val latent and params, input_dim,
     full_seq_len)."""
     latent, _u0s, ps, high = data

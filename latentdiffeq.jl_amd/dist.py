@@ -78,6 +78,7 @@ class FlatGradAllReduce:
         self._handles: list = []
         self._hooks: list = []
         self._issued: List[bool] = []
+        self._events: list = []
         if attach:
             self.attach()
 
@@ -111,6 +112,7 @@ class FlatGradAllReduce:
             self._pending[b] += 1
         self._issued = [False] * nb
         self._handles = []
+        self._events = [None] * len(self.params)
 
     def attach(self) -> "FlatGradAllReduce":
         """Allocate the flat buffer and make every parameter's .grad a view into it (zeros); install the overlap hooks."""
@@ -143,6 +145,18 @@ class FlatGradAllReduce:
             return
         self._issued[b] = True
         lo, hi = self._bounds[b]
+        if self._flat.is_cuda:
+            # RCCL orders the collective after the ISSUING stream only, but one bucket holds gradients written on several streams
+            # (encode() runs the GOKU branches on side streams; the autograd engine joins leaf streams only at the end of backward):
+            # the issuing stream waits for the event each parameter's hook recorded on the stream that wrote its gradient, and for
+            # the weight-gradient stream when one is set (lde_set_dw_stream).
+            cur = torch.cuda.current_stream(self._flat.device)
+            for i, bi in enumerate(self._bucket_of):
+                if bi == b and self._events[i] is not None:
+                    cur.wait_event(self._events[i])
+            from . import _lib as L
+            if getattr(L, "dw_stream", None) is not None:
+                L.join_weight_gradients()
         self._handles.append(dist.all_reduce(self._flat[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     def _make_hook(self, i: int):
@@ -150,6 +164,15 @@ class FlatGradAllReduce:
             if not self._active() or self._flat is None or param.grad is None or param.grad.data_ptr() != self._views[i].data_ptr():
                 return
             b = self._bucket_of[i]
+            if self._issued[b]:
+                # a second backward() before __call__(): this bucket's sum is already on the wire, a local gradient added on top of it
+                # would be silently wrong on every rank
+                raise RuntimeError("FlatGradAllReduce(attach=True): backward() ran again before the reduce of the previous one was "
+                                   "collected — call the reducer after every backward(), or accumulate with attach=False")
+            if param.grad.is_cuda:
+                ev = torch.cuda.Event()
+                ev.record(torch.cuda.current_stream(param.grad.device))     # the stream this gradient was written on
+                self._events[i] = ev
             self._pending[b] -= 1
             if self._pending[b] == 0:
                 self._issue(b)

@@ -141,7 +141,10 @@ class FluxADAMW(torch.optim.Adam):
     On the GPU (`native`, the default when every parameter is a contiguous f32 HIP tensor) the whole update is ONE liblde.so launch
     for all parameter arrays (lde_adamw_flux_step) — no per-step tensor grouping, step-counter kernels or separate decay pass;
     otherwise one multi-tensor scale of the parameters followed by torch's Adam update with the gradients taken at the un-decayed
-    point (same arithmetic up to rounding; tests/test_gpu_optim.py compares the two)."""
+    point (same arithmetic up to rounding; tests/test_gpu_optim.py compares the two). The native path bumps the parameters'
+    version counters after its launch (it writes through raw pointers), so `refresh_weights()` is optional after it too. Its
+    optimiser state keeps `step` as a Python int (a tensor step from a torch checkpoint is converted on entry); a native
+    state_dict is therefore not resumable by torch's FUSED Adam, which expects tensor steps."""
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), decay: float = 0.0, eps: float = 1e-8, fused=None, native=None):
         params = list(params)
@@ -169,7 +172,9 @@ class FluxADAMW(torch.optim.Adam):
                 st = self.state[p]
                 if not st:
                     st["step"], st["exp_avg"], st["exp_avg_sq"] = 0, torch.zeros_like(p), torch.zeros_like(p)
-                st["step"] += 1
+                # a state loaded from a torch / fused Adam checkpoint carries `step` as a tensor: normalise to a Python int (the
+                # native state is not resumable by torch's fused Adam, which wants tensor steps — documented in the class docstring)
+                st["step"] = int(st["step"]) + 1
                 by_step.setdefault(st["step"], []).append(p)
             # Flux keeps β₁ᵗ, β₂ᵗ per array: arrays that have been updated equally often share a launch (normally all of them)
             for t_step, group in by_step.items():
@@ -183,6 +188,9 @@ class FluxADAMW(torch.optim.Adam):
                     t.p, t.g, t.m, t.v, t.n = p.data_ptr(), gr.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
                 L.check(lib.lde_adamw_flux_step(len(group), tab, g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.decay, t_step,
                                                 L.raw_stream(group[0].device.index)), None, "lde_adamw_flux_step")
+                # the kernel wrote through raw pointers: tell torch the parameters changed in place, so that `_lib.weights_key`
+                # (data_ptr, _version) — which lets a module skip its weight upload — and autograd's saved-tensor checks see it
+                torch.autograd.graph.increment_version(group)
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -193,12 +201,17 @@ class FluxADAMW(torch.optim.Adam):
                     loss = closure()
             self._native_step()
             return loss
+        loss = None
+        if closure is not None:             # gradients at the UN-decayed point, as Flux's Optimiser(ADAM, WeightDecay) and the native path
+            with torch.enable_grad():
+                loss = closure()
         if self.decay:
             for g in self.param_groups:
                 ps = [p for p in g["params"] if p.grad is not None]
                 if ps:
                     torch._foreach_mul_(ps, 1.0 - self.decay)
-        return super().step(closure)
+        super().step()
+        return loss
 
 
 def train(model: LatentDiffEqModel, loader_train: Iterable, val_set, dt: float, epochs: int, seq_len: int, full_seq_len: int,

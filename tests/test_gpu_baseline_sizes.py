@@ -155,3 +155,63 @@ def test_coupled_solve_while_another_stream_keeps_the_gpu_busy(o32):
     torch.cuda.synchronize()
     assert (ret == 0).all() and (ret2 == 0).all() and st["nfailed"] == 0
     assert np.array_equal(z_idle, z_busy) and np.array_equal(g_idle[0], g_busy[0]) and np.array_equal(g_idle[2], g_busy[2])
+
+
+def test_c3_full_batch_1024_tight_tolerance(o32, o64):
+    """c3 at B = 1024 with abstol = reltol = 1e-6: both f32 solves are then ≈ 1e-6 from the truth, so the parity gate can be the north
+    star's own — |ẑ_HIP − ẑ_oracle| ≤ 1e-4 on every column (measured ≈ 1e-5) — and the gradients are gated at 1e-3 of their scale
+    against the f32 oracle AND against float64 (at the default tolerance, above, a relu network under the adaptive controller only
+    allows 1e-2: a 1 % gradient bug would pass there, not here)."""
+    layers = (2, 64, 64, 2)
+    W = O.mlp_weights(layers, seed=3)
+    kw = dict(rhs_kind=O.RHS_PENDULUM_PLUS_MLP, layers=layers, abstol=1e-6, reltol=1e-6)
+    nat, od = _native(W, **kw)
+    B, T = 1024, 50
+    z0, L = O.pendulum_inputs(B)
+    ts = O.time_grid(T)
+    dz = O.cotangent(T, B, 2)
+    z, ret, st = nat.forward(z0, L, ts)
+    g0, gL, gW, sb = nat.adjoint(z, L, ts, dz)
+    assert (ret == 0).all() and st["nfailed"] == 0 and sb["nfailed"] == 0
+    zr, _, _ = o32.forward(od, z0, L, ts, W=W, nthreads=NT)
+    r0, rL, rW, _ = o32.adjoint(od, z, L, ts, dz, W=W, nthreads=NT)
+    scale = max(1.0, np.abs(zr).max())
+    assert np.abs(z - zr).max() <= 1e-4 * scale, np.abs(z - zr).max()
+    assert _rel(g0, r0) <= 1e-3 and _rel(gL, rL) <= 1e-3 and _rel(gW, rW) <= 1e-3, (_rel(g0, r0), _rel(gL, rL), _rel(gW, rW))
+    sub = np.arange(0, B, 16)
+    d64 = O.make_desc(**{**kw, "abstol": 1e-11, "reltol": 1e-11})
+    W64 = W.astype(np.float64)
+    z64, _, _ = o64.forward(d64, z0[sub], L[sub], ts, W=W64, nthreads=NT)
+    t0, tL, _, _ = o64.adjoint(d64, z64, L[sub], ts, dz[:, sub], W=W64, nthreads=NT)
+    assert np.abs(z[:, sub] - z64).max() <= 1e-4 * scale
+    assert _rel(g0[sub], t0) <= 1e-3 and _rel(gL[sub], tL) <= 1e-3, (_rel(g0[sub], t0), _rel(gL[sub], tL))
+    # the weight gradient against float64 on the WHOLE batch (a sum over all 1024 trajectories)
+    z64a, _, _ = o64.forward(d64, z0, L, ts, W=W64, nthreads=NT)
+    _, _, tW, _ = o64.adjoint(d64, z64a, L, ts, dz, W=W64, nthreads=NT)
+    assert _rel(gW, tW) <= 1e-3, _rel(gW, tW)
+
+
+def test_c4_coupled_512_tight_tolerance(o32, o64):
+    """c4 (one GPU's share, B = 512, one coupled solve) at abstol = reltol = 1e-6: ẑ within 1e-4 of the f32 oracle and of float64,
+    gradients within 1e-3 of both."""
+    layers = (32, 128, 128, 32)
+    W = O.mlp_weights(layers, seed=3)
+    kw = dict(rhs_kind=O.RHS_MLP, state_dim=32, param_dim=0, layers=layers, batching=O.BATCH_COUPLED, abstol=1e-6, reltol=1e-6)
+    nat, od = _native(W, **kw)
+    B, T = 512, 50
+    z0, ts = _z0(B, 32), O.time_grid(T)
+    dz = O.cotangent(T, B, 32)
+    z, ret, st = nat.forward(z0, None, ts)
+    g0, _, gW, sb = nat.adjoint(z, None, ts, dz)
+    assert (ret == 0).all() and st["nfailed"] == 0 and sb["nfailed"] == 0
+    zr, _, _ = o32.forward(od, z0, None, ts, W=W, nthreads=NT)
+    r0, _, rW, _ = o32.adjoint(od, z, None, ts, dz, W=W, nthreads=NT)
+    scale = max(1.0, np.abs(zr).max())
+    assert np.abs(z - zr).max() <= 1e-4 * scale, np.abs(z - zr).max()
+    assert _rel(g0, r0) <= 1e-3 and _rel(gW, rW) <= 1e-3, (_rel(g0, r0), _rel(gW, rW))
+    d64 = O.make_desc(**{**kw, "abstol": 1e-10, "reltol": 1e-10})
+    W64 = W.astype(np.float64)
+    z64, _, _ = o64.forward(d64, z0, None, ts, W=W64, nthreads=NT)
+    t0, _, tW, _ = o64.adjoint(d64, z64, None, ts, dz, W=W64, nthreads=NT)
+    assert np.abs(z - z64).max() <= 1e-4 * scale
+    assert _rel(g0, t0) <= 1e-3 and _rel(gW, tW) <= 1e-3, (_rel(g0, t0), _rel(gW, tW))

@@ -512,6 +512,8 @@ __global__ void __launch_bounds__(512) k_chain_backward(ChainDims cd, ChainBwdAr
   }
 }
 
+#include "lde_chain_bf16.h"
+
 }  // namespace lde
 
 // ================================================ C ABI ======================================================
@@ -519,7 +521,13 @@ using namespace lde;
 
 struct lde_chain {
   bool accumulate = true;   // pullback: dW += gradient (default) or dW = gradient
-  bool bf16 = false;        // MFMA operands rounded to bf16 (lde_chain_set_dtype); storage and accumulation stay f32
+  bool bf16 = false;        // lde_chain_set_dtype: the native bf16 path (lde_chain_bf16.h): bf16 weight fragments, panels, saved activations, δ
+  __bf16* fragb = nullptr;  // bf16 K = 32 fragment copies of W / Wᵀ, rebuilt with the f32 ones
+  __bf16* fragTb = nullptr;
+  BfDims bd, bdx;           // bf16 layouts (bdx: the panel-free wide-input layout)
+  int bcg_fwd = 0, bcg_bwd = 0, bcgx_fwd = 0, bcgx_bwd = 0;
+  __bf16* dstage = nullptr; size_t dstage_cap = 0;       // δ_l matrices of the bf16 pullback
+  __bf16* svscratch = nullptr; size_t svscratch_cap = 0;  // lde_chain_backward (no saved buffer) in bf16 mode: its own forward pass saves here
   lde_chain_desc d;
   ChainDims cd;
   int64_t nW = 0;
@@ -559,6 +567,14 @@ static size_t chain_lds(const ChainDims& cd, int cg, int npanels) {
   return ((size_t)NC * cd.ld0 + (size_t)npanels * NC * cd.ldh + ((cd.dm.nbias + 3) & ~3)) * sizeof(float);
 }
 
+// native bf16 path: LDS bytes of the forward (two bf16 panels + input panel + biases) and pullback (two bf16 panels + the f32
+// skip-gradient panel) kernels
+static size_t chain_lds_b(const ChainDims& cd, const BfDims& bd, int cg, bool bwd) {
+  const size_t NC = 16 * cg;
+  if (bwd) return NC * bd.ldb * 2 * 2 + NC * bd.ldg * 4;
+  return (NC * bd.ld0 + 2 * NC * bd.ldb) * 2 + (size_t)((cd.dm.nbias + 3) & ~3) * 4;
+}
+
 // lde_rnn.hip: where lde_refresh_weights copies a recurrent stack's flat weights to (marks the handle as holding weights)
 bool rnn_refresh_target(lde_rnn* r, float** W_dev, int64_t* nW);
 
@@ -576,6 +592,10 @@ void lde_chain_destroy(lde_chain* c) {
   if (c->W_dev) (void)hipFree(c->W_dev);
   if (c->frag) (void)hipFree(c->frag);
   if (c->fragT) (void)hipFree(c->fragT);
+  if (c->fragb) (void)hipFree(c->fragb);
+  if (c->fragTb) (void)hipFree(c->fragTb);
+  if (c->dstage) (void)hipFree(c->dstage);
+  if (c->svscratch) (void)hipFree(c->svscratch);
   if (c->dm_dev) (void)hipFree(c->dm_dev);
   if (c->stage) (void)hipFree(c->stage);
   if (c->wts) (void)hipFree(c->wts);
@@ -672,9 +692,39 @@ int lde_chain_create(const lde_chain_desc* d, lde_chain** out) {
       return LDE_ERR_UNSUPPORTED;
     }
   }
+  {   // native bf16 layouts (lde_chain_bf16.h)
+    BfDims& bd = c->bd;
+    std::memset(&bd, 0, sizeof(bd));
+    bd.ldb = panel_stride_b(pad32(hmax));
+    bd.ld0 = panel_stride_b(pad32(dm.sizes[0]));
+    bd.ldg = cd.ldh;
+    int off = 0;
+    for (int l = 0; l < d->n_layers; l++) {
+      bd.dl_w[l] = l == d->n_layers - 1 ? pad32(dm.sizes[l + 1]) : (dm.sizes[l + 1] + 7) & ~7;   // the last layer's rows are read back as a B operand: whole K-groups
+      bd.dl_off[l] = off;
+      off += bd.dl_w[l];
+    }
+    bd.dl_total = off;
+    c->bdx = bd;
+    c->bdx.ld0 = 0;
+    auto pickb = [&](const ChainDims& q, const BfDims& b, int* cgf, int* cgb) {
+      *cgf = *cgb = 0;
+      for (size_t lim : {LDS_MAX / 2, LDS_MAX}) {
+        for (int cg : {4, 2, 1}) {
+          if (!*cgf && chain_lds_b(q, b, cg, false) <= lim) *cgf = cg;
+          if (!*cgb && chain_lds_b(q, b, cg, true) <= lim) *cgb = cg;
+        }
+      }
+    };
+    pickb(cd, bd, &c->bcg_fwd, &c->bcg_bwd);
+    if (c->cdx.gx) pickb(c->cdx, c->bdx, &c->bcgx_fwd, &c->bcgx_bwd);
+  }
+  size_t nfb = 0, nfTb = 0;
+  for (int l = 0; l < d->n_layers; l++) { nfb += bf_frag_elems(dm, l, false); nfTb += bf_frag_elems(dm, l, true); }
   if (hipMalloc(&c->W_dev, (size_t)c->nW * sizeof(float)) != hipSuccess ||
       hipMalloc(&c->frag, c->nfrag * sizeof(float)) != hipSuccess ||
-      hipMalloc(&c->fragT, c->nfragT * sizeof(float)) != hipSuccess || hipMalloc(&c->dm_dev, sizeof(MlpDims)) != hipSuccess) {
+      hipMalloc(&c->fragT, c->nfragT * sizeof(float)) != hipSuccess || hipMalloc(&c->dm_dev, sizeof(MlpDims)) != hipSuccess ||
+      hipMalloc(&c->fragb, nfb * sizeof(__bf16)) != hipSuccess || hipMalloc(&c->fragTb, nfTb * sizeof(__bf16)) != hipSuccess) {
     c->err = "chain: hipMalloc failed";
     return LDE_ERR_ALLOC;
   }
@@ -688,7 +738,7 @@ int lde_chain_create(const lde_chain_desc* d, lde_chain** out) {
 static int chain_frags(lde_chain* c, const float* src, hipStream_t stream) {
   // src == W_dev: fragments only; otherwise the kernel also copies src into W_dev
   hipLaunchKernelGGL(k_build_frags, dim3(64, c->cd.dm.nL), dim3(256), 0, stream, src, c->cd.dm, c->frag, c->fragT,
-                     src == c->W_dev ? (float*)nullptr : c->W_dev);
+                     src == c->W_dev ? (float*)nullptr : c->W_dev, c->fragb, c->fragTb);
   if (hipGetLastError() != hipSuccess) {
     c->err = "k_build_frags launch failed";
     return LDE_ERR_HIP;
@@ -735,12 +785,12 @@ int lde_refresh_weights(int n, const int* kinds, void* const* handles, const flo
       lde_chain* c = (lde_chain*)handles[m];
       if (!c->W_dev || !c->dm_dev) return LDE_ERR_INVALID_ARG;
       for (int l = 0; l < c->cd.dm.nL; l++)
-        jobs.push_back(RefreshJob{flat_dev[m], flat_dev[m] == c->W_dev ? nullptr : c->W_dev, c->frag, c->fragT, c->dm_dev, l, 0});
+        jobs.push_back(RefreshJob{flat_dev[m], flat_dev[m] == c->W_dev ? nullptr : c->W_dev, c->frag, c->fragT, c->dm_dev, l, 0, c->fragb, c->fragTb});
     } else if (kinds[m] == LDE_MODULE_RNN) {
       float* dst = nullptr;
       int64_t nw = 0;
       if (!rnn_refresh_target((lde_rnn*)handles[m], &dst, &nw)) return LDE_ERR_INVALID_ARG;
-      if (dst != flat_dev[m]) jobs.push_back(RefreshJob{flat_dev[m], dst, nullptr, nullptr, nullptr, -1, (int)nw});
+      if (dst != flat_dev[m]) jobs.push_back(RefreshJob{flat_dev[m], dst, nullptr, nullptr, nullptr, -1, (int)nw, nullptr, nullptr});
     } else
       return LDE_ERR_INVALID_ARG;
   }
@@ -825,6 +875,161 @@ int lde_chain_reserve(lde_chain* c, int64_t N) {
   return LDE_OK;
 }
 
+// ---- the native bf16 path (lde_chain_bf16.h) ------------------------------------------------------------------------------------
+struct ChainPickB { const ChainDims* cd; const BfDims* bd; int cg; size_t lds; };
+static bool chain_pick_b(const lde_chain* c, const float* x, int64_t N, bool bwd, ChainPickB* p) {
+  const int cgx = bwd ? c->bcgx_bwd : c->bcgx_fwd, cg = bwd ? c->bcg_bwd : c->bcg_fwd;
+  static const bool fill = [] { const char* e = getenv("LDE_CHAIN_FILL"); return !e || atoi(e) != 0; }();
+  auto narrow = [&](const ChainDims& q, const BfDims& b, int cg0) {
+    int g = cg0;
+    if (const char* e = getenv(bwd ? "LDE_CHAIN_BCG_BWD" : "LDE_CHAIN_BCG_FWD")) {   // experiments: force the tile width
+      const int v = atoi(e);
+      if ((v == 1 || v == 2 || v == 4) && chain_lds_b(q, b, v, bwd) <= LDS_MAX) return ChainPickB{&q, &b, v, chain_lds_b(q, b, v, bwd)};
+    }
+    while (fill && g > 1 && (N + 16 * g - 1) / (16 * g) < 192) g /= 2;
+    return ChainPickB{&q, &b, g, chain_lds_b(q, b, g, bwd)};
+  };
+  if (c->cdx.gx && cgx && N >= 16 * cgx && (((uintptr_t)x) & 15) == 0) {
+    *p = narrow(c->cdx, c->bdx, cgx);
+    return true;
+  }
+  if (!cg) return false;
+  *p = narrow(c->cd, c->bd, cg);
+  return true;
+}
+
+static int chain_forward_b(lde_chain* c, const float* x, int64_t N, float* y, __bf16* saved, hipStream_t stream) {
+  ChainPickB pk;
+  if (!chain_pick_b(c, x, N, false, &pk)) {
+    c->err = "lde_chain_forward (bf16): no tile layout fits LDS for this input";
+    return LDE_ERR_UNSUPPORTED;
+  }
+  ChainFwdArgsB a{x, y, c->fragb, c->W_dev, (long long)N, saved};
+  const int NC = 16 * pk.cg;
+  const dim3 grid((unsigned)((N + NC - 1) / NC));
+  static bool attr[5] = {false, false, false, false, false};
+  const void* fn = pk.cg == 4 ? (const void*)k_chain_forward_b<4> : pk.cg == 2 ? (const void*)k_chain_forward_b<2> : (const void*)k_chain_forward_b<1>;
+  if (!attr[pk.cg]) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
+      c->err = "hipFuncSetAttribute(k_chain_forward_b) failed";
+      return LDE_ERR_HIP;
+    }
+    attr[pk.cg] = true;
+  }
+  ChainDims cdv = *pk.cd;
+  BfDims bdv = *pk.bd;
+  void* argv[] = {(void*)&cdv, (void*)&bdv, (void*)&a};
+  (void)hipLaunchKernel(fn, grid, dim3(512), argv, pk.lds, stream);
+  if (hipGetLastError() != hipSuccess) {
+    c->err = "k_chain_forward_b launch failed";
+    return LDE_ERR_HIP;
+  }
+  return LDE_OK;
+}
+
+static int chain_backward_b(lde_chain* c, const float* x, const float* y, const float* dy, const __bf16* saved, int64_t N, float* dx,
+                            float* dW, hipStream_t stream) {
+  const MlpDims& dm = c->cd.dm;
+  const int ndw = dw_pick_ndw(dm), jobs = dw_jobs(dm, ndw);
+  const int64_t nchunks = (N + 31) / 32;
+  int parts = 256 / jobs;
+  if (const char* e = getenv("LDE_CHAIN_DW_PARTS")) parts = atoi(e);
+  parts = parts < 1 ? 1 : parts;
+  if (parts > nchunks) parts = (int)nchunks;
+  // (+ one tile of rows of the last layer's matrix: its read-back as a B operand covers the ragged tile's columns beyond N — their
+  //  results are dropped, but the loads must stay inside the allocation)
+  if (!grow(&c->dstage, &c->dstage_cap, (size_t)N * c->bd.dl_total + (size_t)64 * c->bd.dl_w[dm.nL - 1] + 64) || !grow(&c->slab, &c->slab_cap, ((size_t)parts + 1) * dm.slab_n)) {
+    c->err = "chain: hipMalloc of the bf16 backward workspace failed";
+    return LDE_ERR_ALLOC;
+  }
+  if (!c->ints) {
+    if (hipMalloc(&c->ints, 64) != hipSuccess || hipMemset(c->ints, 0, 64) != hipSuccess || hipStreamSynchronize(nullptr) != hipSuccess) {
+      c->err = "chain: hipMalloc of the backward workspace failed";
+      return LDE_ERR_ALLOC;
+    }
+    c->ints_cap = 16;
+  }
+  if (!saved) {   // the caller kept nothing: the pullback's own forward pass fills a scratch copy of the saved matrices
+    const size_t need = (size_t)c->cd.sv_total * N + 8;
+    if (!grow(&c->svscratch, &c->svscratch_cap, need)) {
+      c->err = "chain: hipMalloc of the saved-activation scratch failed";
+      return LDE_ERR_ALLOC;
+    }
+    const int rcf = chain_forward_b(c, x, N, nullptr, c->svscratch, stream);
+    if (rcf) return rcf;
+    saved = c->svscratch;
+  }
+  ChainPickB pk;
+  if (!chain_pick_b(c, x, N, true, &pk)) {
+    c->err = "lde_chain_backward (bf16): no tile layout fits LDS for this input";
+    return LDE_ERR_UNSUPPORTED;
+  }
+  ChainBwdArgsB a{x, y, dy, dx, c->fragTb, c->W_dev, c->dstage, (long long)N, saved};
+  const int NC = 16 * pk.cg;
+  {
+    const dim3 grid((unsigned)((N + NC - 1) / NC));
+    static bool attr[5] = {false, false, false, false, false};
+    const void* fn = pk.cg == 4 ? (const void*)k_chain_backward_b<4> : pk.cg == 2 ? (const void*)k_chain_backward_b<2> : (const void*)k_chain_backward_b<1>;
+    if (!attr[pk.cg]) {
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
+        c->err = "hipFuncSetAttribute(k_chain_backward_b) failed";
+        return LDE_ERR_HIP;
+      }
+      attr[pk.cg] = true;
+    }
+    ChainDims cdv = *pk.cd;
+    BfDims bdv = *pk.bd;
+    void* argv[] = {(void*)&cdv, (void*)&bdv, (void*)&a};
+    (void)hipLaunchKernel(fn, grid, dim3(512), argv, pk.lds, stream);
+    if (hipGetLastError() != hipSuccess) {
+      c->err = "k_chain_backward_b launch failed";
+      return LDE_ERR_HIP;
+    }
+  }
+  // weight gradient: [n][feature] matrices through the transposing LDS reads, then the fixed-order slab reduction
+  bool sw_ok = true;
+  hipStream_t wst = dw_sync_switch(c->dws, stream, &sw_ok);
+  if (!sw_ok) {
+    c->err = "lde_chain_backward: switching to the weight-gradient stream failed";
+    return LDE_ERR_HIP;
+  }
+  {
+    const size_t dlds = dw_b_lds_bytes(dm, ndw);
+    if (dlds > LDS_MAX) {
+      c->err = "layer too wide for the bf16 weight-gradient kernel's LDS images";
+      return LDE_ERR_UNSUPPORTED;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute((const void*)k_chain_dw_b<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_chain_dw_b<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess ||
+          hipFuncSetAttribute((const void*)k_chain_dw_b<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
+        c->err = "hipFuncSetAttribute(k_chain_dw_b) failed";
+        return LDE_ERR_HIP;
+      }
+      attr_set = true;
+    }
+    DwArgsB da{x, saved, c->dstage, c->slab, (long long)N};
+    const dim3 grid(parts, jobs);
+    ChainDims cdv = c->cd;
+    BfDims bdv = c->bd;
+    if (ndw == 1) hipLaunchKernelGGL(k_chain_dw_b<1>, grid, dim3(512), dlds, wst, cdv, bdv, da);
+    else if (ndw == 2) hipLaunchKernelGGL(k_chain_dw_b<2>, grid, dim3(512), dlds, wst, cdv, bdv, da);
+    else hipLaunchKernelGGL(k_chain_dw_b<4>, grid, dim3(512), dlds, wst, cdv, bdv, da);
+    hipLaunchKernelGGL(k_reduce_tiles, dim3(cdiv(dm.slab_n, 1024)), dim3(256), 0, wst, (const float*)nullptr, c->ints, 0, c->slab, parts, dm, dW,
+                       c->ints + 2, c->accumulate ? 0 : 1);
+    if (hipGetLastError() != hipSuccess) {
+      c->err = "bf16 weight-gradient kernels failed to launch";
+      return LDE_ERR_HIP;
+    }
+  }
+  if (!dw_sync_end(c->dws, wst, stream)) {
+    c->err = "lde_chain_backward: hipEventRecord failed";
+    return LDE_ERR_HIP;
+  }
+  return LDE_OK;
+}
+
 static int chain_forward_impl(lde_chain* c, const float* x, int64_t N, float* y, float* saved, void* stream_) {
   if (!c || !c->W_dev) return LDE_ERR_INVALID_ARG;
   if (!x || !y || N < 1) {
@@ -840,6 +1045,7 @@ static int chain_forward_impl(lde_chain* c, const float* x, int64_t N, float* y,
     return LDE_ERR_INVALID_ARG;
   }
   hipStream_t stream = (hipStream_t)stream_;
+  if (c->bf16) return chain_forward_b(c, x, N, y, reinterpret_cast<__bf16*>(saved), stream);
   ChainFwdArgs a{x, y, c->frag, c->W_dev, (long long)N, saved};
   ChainPick pk;
   if (!chain_pick(c, x, N, false, &pk)) {
@@ -907,6 +1113,7 @@ static int chain_backward_impl(lde_chain* c, const float* x, const float* y, con
     c->err = "lde_chain_backward: waiting for the previous weight gradient failed";
     return LDE_ERR_HIP;
   }
+  if (c->bf16) return chain_backward_b(c, x, y, dy, reinterpret_cast<const __bf16*>(saved), N, dx, dW, (hipStream_t)stream_);
   int rc = lde_chain_reserve(c, N);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)stream_;

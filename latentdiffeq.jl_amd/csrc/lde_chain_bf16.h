@@ -1,0 +1,573 @@
+// lde_chain_bf16.h — the dense chains in NATIVE bf16 (round 3; included by lde_chain.hip).
+//
+// BASELINE.json configs[4] runs the encoder / decoder chains "in bf16". Round 2's mode kept every array in f32 and rounded the two
+// operands of each product right before a CDNA3-shaped MFMA (v_mfma_f32_16x16x16_bf16_1k, one v_cvt_pk per operand and K-group in
+// the K loop): 1.3–1.5× over f32 where the matrix cores offer 16×. Here the mode is what gfx950 is built for:
+//   * weights: bf16 copies of W and Wᵀ beside the f32 masters, in the K = 32 fragment order of v_mfma_f32_16x16x32_bf16 (a lane's
+//     eight consecutive-k values are ONE 16-byte load), rebuilt by the same launch that rebuilds the f32 fragments
+//     (lde_chain_set_weights[_device], lde_refresh_weights);
+//   * activations and δ: bf16 in LDS as transposed panels Xt[col][feature] whose byte stride ≡ 32 (mod 128) — the B operand of a
+//     K-group is one conflict-free ds_read_b128 (half the LDS bytes and a quarter of the read instructions of the f32 path per flop);
+//   * one v_mfma_f32_16x16x32_bf16 per (row tile, column group, K-group of 32), f32 accumulation; no conversion in the K loop (the
+//     only f32 → bf16 conversions are the epilogues', and the first layer's read of the caller's f32 input);
+//   * saved hidden activations (training variant) and the δ matrices the weight gradient reads are bf16 in HBM, all in ONE layout:
+//     [n][feature] (a column's features contiguous) — what the epilogues produce with 8- and 16-byte stores;
+//   * weight gradient: gW_lᵀ[i][o] = Σ_n a_l[i,n] δ_l[o,n] needs both operands n-contiguous per feature, i.e. the TRANSPOSE of how
+//     everything is stored. k_chain_dw_b copies [n][feature] chunks into LDS as they are (wide loads) and reads the fragments
+//     with ds_read_b64_tr_b16, gfx950's transposing LDS read (a 16-lane group reads a 4 × 16 block and every lane receives one
+//     column of it): two of them per operand feed one v_mfma_f32_32x32x16_bf16. a_l comes straight from the saved activations
+//     (a_0 from the caller's x, converted on the way in): the pullback kernel stages no a-panels at all.
+// What the mode computes (the restatement in tests/test_gpu_chain_bf16.py): every product on bf16 operands with f32
+// accumulation; hidden activations, the pre-skip activation and δ are STORED rounded to bf16 (round-to-nearest-even); biases,
+// the skip-gradient panel, x̂, dx and dW are f32.
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+
+struct BfDims {
+  int ldb;            // stride (elements) of the bf16 activation / δ panels: ≡ 16 (mod 64), ≥ pad32(widest hidden width)
+  int ld0;            // stride of the bf16 input panel (0 with gx)
+  int ldg;            // stride (floats) of the f32 skip-gradient panel
+  int dl_off[MAXL];   // δ-stage: δ_l as a matrix [N][dl_w[l]] bf16 starts at N·dl_off[l] elements
+  int dl_w[MAXL];     // its row width: out_l rounded up to 8 (16-byte rows; the pad entries are written as zeros)
+  int dl_total;
+};
+
+// smallest stride ≥ rows with stride ≡ 16 (mod 64) elements = 32 (mod 128) bytes: the ds_read_b128 operand pattern "16 columns ×
+// 4 lane groups of 16 B" is then conflict-free in every 16-lane service group (the f32 panels' rule, in bytes)
+__host__ __device__ inline int panel_stride_b(int rows) {
+  int v = ((rows + 63) / 64) * 64 + 16;
+  if (v - 64 >= rows) v -= 64;
+  return v;
+}
+
+__device__ __forceinline__ bf16x4 to_bf4(f32x4 v) { return __builtin_convertvector(v, bf16x4); }
+__device__ __forceinline__ f32x4 from_bf4(bf16x4 v) { return __builtin_convertvector(v, f32x4); }
+__device__ __forceinline__ f32x4 mfma32_b(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// One wave: NT_ (1 or 2) 16-row tiles × NCG column groups over all K-groups of 32, software-pipelined like chain_mac.
+// BSRC 0: the B operand is a bf16 image Xt[col][k] (LDS panel, or a [n][feature] matrix in global memory): bp points at the lane's
+//         first word, column group cg at + cg·cgstride elements, K-group k at + 32·k.
+// BSRC 1: the B operand is the caller's f32 x[n][in] (first layer of a wide-input chain): eight floats are loaded and rounded per
+//         K-group — the one conversion of the forward pass; a chunk beyond the row's end (K not a multiple of 32) is read from the
+//         row's last chunk instead (finite values against zero weights).
+template <int NT_, int NCG, int BSRC, class Pre, class Epi>
+__device__ __forceinline__ void chain_mac_b(const bf16x8* A0, const bf16x8* A1, const void* bpv, long cgstride, int KG, int kin, int lg8,
+                                            int row_a, int row_b, int cg0, int col, Pre pre, Epi epi) {
+  constexpr int PFA = 4, PFB = BSRC == 1 ? 2 : 2;
+  const int kl = KG - 1;
+  f32x4 acc0[NCG], acc1[NCG];
+  decltype(pre(0, 0, 0)) p0[NCG], p1[NCG];
+#pragma unroll
+  for (int cg = 0; cg < NCG; cg++) {
+    acc0[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+    acc1[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+    p0[cg] = pre(row_a, cg0 + cg, col);
+    if (NT_ == 2) p1[cg] = pre(row_b >= 0 ? row_b : row_a, cg0 + cg, col);
+  }
+  auto loadB = [&](int cg, int k) -> bf16x8 {
+    if (BSRC == 0) return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(bpv) + (long)(cg0 + cg) * cgstride + k * 32);
+    int off = k * 32;
+    if (off + lg8 + 8 > kin) off = kin - 8 - lg8;
+    const float* p = reinterpret_cast<const float*>(bpv) + (long)(cg0 + cg) * cgstride + off;
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+    const bf16x4 bl = to_bf4(lo), bh = to_bf4(hi);
+    return bf16x8{bl[0], bl[1], bl[2], bl[3], bh[0], bh[1], bh[2], bh[3]};
+  };
+  bf16x8 ra0[PFA], ra1[PFA], rb[PFB][NCG];
+#pragma unroll
+  for (int i = 0; i < PFA; i++) {
+    const int k = min(i, kl);
+    ra0[i] = A0[k * 64];
+    if (NT_ == 2) ra1[i] = A1[k * 64];
+  }
+#pragma unroll
+  for (int i = 0; i < PFB; i++) {
+    const int k = min(i, kl);
+#pragma unroll
+    for (int cg = 0; cg < NCG; cg++) rb[i][cg] = loadB(cg, k);
+  }
+  for (int kg = 0; kg < KG; kg += PFA) {
+#pragma unroll
+    for (int i = 0; i < PFA; i++) {
+      if (kg + i < KG) {
+        const bf16x8 c0 = ra0[i];
+        bf16x8 c1 = c0;
+        if (NT_ == 2) c1 = ra1[i];
+        bf16x8 cb[NCG];
+#pragma unroll
+        for (int cg = 0; cg < NCG; cg++) cb[cg] = rb[i % PFB][cg];
+        const int ka = min(kg + i + PFA, kl), kb = min(kg + i + PFB, kl);
+        ra0[i] = A0[ka * 64];
+        if (NT_ == 2) ra1[i] = A1[ka * 64];
+#pragma unroll
+        for (int cg = 0; cg < NCG; cg++) rb[i % PFB][cg] = loadB(cg, kb);
+#pragma unroll
+        for (int cg = 0; cg < NCG; cg++) {
+          acc0[cg] = mfma32_b(c0, cb[cg], acc0[cg]);
+          if (NT_ == 2) acc1[cg] = mfma32_b(c1, cb[cg], acc1[cg]);
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int cg = 0; cg < NCG; cg++) {
+    epi(row_a, cg0 + cg, col, acc0[cg], p0[cg]);
+    if (NT_ == 2 && row_b >= 0) epi(row_b, cg0 + cg, col, acc1[cg], p1[cg]);
+  }
+}
+
+// Y[R × 16·CG] = M[R×K] · B[K × 16·CG] for one workgroup of 8 waves; M as bf16 K = 32 fragments in global memory (L2-resident).
+// Row tiles are dealt exactly as in chain_gemm.
+template <int CG, int BSRC, class Pre, class Epi>
+__device__ __forceinline__ void chain_gemm_b(const __bf16* __restrict__ gfrag, int R, int K, const void* Bp, int ldb, long cgstride,
+                                             Pre pre, Epi epi) {
+  constexpr int NW = 8;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int RT = cdiv(R, 16), KG = cdiv(K, 32);
+  const bf16x8* A = reinterpret_cast<const bf16x8*>(gfrag) + lane;
+  const int lg8 = 8 * (lane >> 4);
+  const void* bp = BSRC == 1 ? (const void*)(reinterpret_cast<const float*>(Bp) + (long)(lane & 15) * ldb + lg8)
+                             : (const void*)(reinterpret_cast<const __bf16*>(Bp) + (long)(lane & 15) * ldb + lg8);
+  const int col = lane & 15, rsub = 4 * (lane >> 4);
+  int base = 0;
+  for (; base + 2 * NW <= RT; base += 2 * NW) {
+    const int rt = base + wave, rt2 = rt + NW;
+    chain_mac_b<2, CG, BSRC>(A + (size_t)rt * KG * 64, A + (size_t)rt2 * KG * 64, bp, cgstride, KG, K, lg8, rt * 16 + rsub, rt2 * 16 + rsub, 0,
+                             col, pre, epi);
+  }
+  if (RT - base > NW) {
+    const int rt = base + wave, rt2 = rt + NW;
+    const bool two = rt2 < RT;
+    chain_mac_b<2, CG, BSRC>(A + (size_t)rt * KG * 64, A + (size_t)(two ? rt2 : rt) * KG * 64, bp, cgstride, KG, K, lg8, rt * 16 + rsub,
+                             two ? rt2 * 16 + rsub : -1, 0, col, pre, epi);
+    return;
+  }
+  if (RT - base == NW) {
+    const int rt = base + wave;
+    chain_mac_b<1, CG, BSRC>(A + (size_t)rt * KG * 64, nullptr, bp, cgstride, KG, K, lg8, rt * 16 + rsub, 0, 0, col, pre, epi);
+    return;
+  }
+  const int units = (RT - base) * CG;
+  for (int u = wave; u < units; u += NW) {
+    const int rt = base + u / CG, cg = u % CG;
+    chain_mac_b<1, 1, BSRC>(A + (size_t)rt * KG * 64, nullptr, bp, cgstride, KG, K, lg8, rt * 16 + rsub, 0, cg, col, pre, epi);
+  }
+}
+
+struct ChainFwdArgsB {
+  const float* x;
+  float* y;
+  const __bf16* fragb;
+  const float* Wflat;
+  long long N;
+  __bf16* saved;       // training: hidden activations [n][h] bf16 (the regions of ChainDims::sv_pre, in elements)
+};
+
+// zero the panels, copy the biases, and (no gx) the tile's input columns rounded to bf16
+template <int CG>
+__device__ __forceinline__ void chain_load_tile_b(const ChainDims& cd, const BfDims& bd, const float* x, long long n0, long long N,
+                                                  __bf16* X0, float* biasc, const float* Wflat, int nzero16, void* zero_base) {
+  constexpr int NC = 16 * CG;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < nzero16; i += 512) reinterpret_cast<f32x4*>(zero_base)[i] = f32x4{0.f, 0.f, 0.f, 0.f};   // pad rows / columns: finite
+  __syncthreads();
+  const MlpDims& dm = cd.dm;
+  for (int l = 0; l < dm.nL; l++)
+    for (int i = tid; i < dm.sizes[l + 1]; i += 512) biasc[dm.bias_lin[l] + i] = Wflat[dm.b_off[l] + i];
+  const int in0 = dm.sizes[0];
+  if (!cd.gx) {
+    for (int e = tid; e < NC * in0; e += 512) {
+      const int c = e / in0, r = e - c * in0;
+      if (n0 + c < N) X0[c * bd.ld0 + r] = (__bf16)x[(size_t)(n0 + c) * in0 + r];
+    }
+  }
+  __syncthreads();
+}
+
+// one hidden layer: Y = [Xin +] act(W·Xin + b) into a bf16 LDS panel (and the saved-activation matrices)
+template <int CG, int BSRC>
+__device__ __forceinline__ void chain_hidden_layer_b(const ChainDims& cd, const BfDims& bd, int l, const __bf16* fragb, const float* biasc,
+                                                     const void* Xin, int ldx, __bf16* Y, __bf16* svbase, long long n0, long long N) {
+  const MlpDims& dm = cd.dm;
+  const int in = dm.sizes[l], out = dm.sizes[l + 1], actk = cd.act[l], skip = BSRC == 1 ? 0 : cd.skip[l], ldh = bd.ldb;
+  const float* bias = biasc + dm.bias_lin[l];
+  chain_gemm_b<CG, BSRC>(fragb + bf_frag_off(dm, l, false), out, in, Xin, ldx, 16L * ldx, [](int, int, int) { return NoPre{}; },
+                         [&](int row0, int cg, int col, f32x4 v, NoPre) {
+                           const int c = cg * 16 + col;
+                           f32x4 r;
+#pragma unroll
+                           for (int q = 0; q < 4; q++) r[q] = row0 + q < out ? cact(actk, v[q] + bias[row0 + q]) : 0.f;
+                           const long long nsv = n0 + c;
+                           const bool dosv = svbase && nsv < N && row0 < out;
+                           __bf16* svp = svbase + (size_t)N * cd.sv_pre[l] + (size_t)nsv * out + row0;
+                           auto put = [&](__bf16* p, const bf16x4& v4) {
+                             if ((out & 3) == 0) *reinterpret_cast<bf16x4*>(p) = v4;
+                             else {
+#pragma unroll
+                               for (int q = 0; q < 4; q++)
+                                 if (row0 + q < out) p[q] = v4[q];
+                             }
+                           };
+                           if (dosv && cd.skip[l]) put(svp + (size_t)N * out, to_bf4(r));   // before the skip addition
+                           if (skip) r += from_bf4(*reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(Xin) + c * ldx + row0));
+                           const bf16x4 rb = to_bf4(r);
+                           if (dosv) put(svp, rb);
+                           *reinterpret_cast<bf16x4*>(Y + c * ldh + row0) = rb;
+                         });
+}
+
+template <int CG>
+__global__ void __launch_bounds__(512) k_chain_forward_b(ChainDims cd, BfDims bd, ChainFwdArgsB a) {
+  extern __shared__ __attribute__((aligned(16))) float csm[];
+  constexpr int NC = 16 * CG;
+  const MlpDims& dm = cd.dm;
+  const int nL = dm.nL, ldh = bd.ldb;
+  __bf16* X0 = reinterpret_cast<__bf16*>(csm);
+  __bf16* H0 = X0 + NC * bd.ld0;
+  __bf16* H1 = H0 + NC * ldh;
+  float* biasc = reinterpret_cast<float*>(H1 + NC * ldh);
+  int dup;
+  const long long n0 = chain_tile_start(cd, NC, a.N, &dup);
+  chain_load_tile_b<CG>(cd, bd, a.x, n0, a.N, X0, biasc, a.Wflat, (NC * bd.ld0 + 2 * NC * ldh) / 8, csm);
+  const void* Xin = X0;
+  int ldx = bd.ld0;
+  const float* xg = a.x + (size_t)n0 * dm.sizes[0];   // gx: column c of the tile at xg + c·in
+  for (int l = 0; l + 1 < nL; l++) {
+    __bf16* Y = (l & 1) ? H1 : H0;
+    if (l == 0 && cd.gx) chain_hidden_layer_b<CG, 1>(cd, bd, 0, a.fragb, biasc, xg, dm.sizes[0], Y, a.saved, n0, a.N);
+    else chain_hidden_layer_b<CG, 0>(cd, bd, l, a.fragb, biasc, Xin, ldx, Y, a.saved, n0, a.N);
+    __syncthreads();
+    Xin = Y;
+    ldx = ldh;
+  }
+  if (a.y) {  // last layer: f32 straight to HBM (y == nullptr: the pullback's own forward pass, which only wants the saved matrices)
+    const int l = nL - 1, in = dm.sizes[l], out = dm.sizes[l + 1], actk = cd.act[l];
+    const float* bias = biasc + dm.bias_lin[l];
+    const bool vec = (out & 3) == 0;
+    auto epi_last = [&](int row0, int cg, int col, f32x4 v, NoPre) {
+      const long long n = n0 + cg * 16 + col;
+      if (n >= a.N || row0 >= out) return;
+      f32x4 r;
+#pragma unroll
+      for (int q = 0; q < 4; q++) r[q] = row0 + q < out ? cact(actk, v[q] + bias[row0 + q]) : 0.f;
+      float* yp = a.y + (size_t)n * out + row0;
+      if (vec) *reinterpret_cast<f32x4*>(yp) = r;
+      else {
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          if (row0 + q < out) yp[q] = r[q];
+      }
+    };
+    auto nopre = [](int, int, int) { return NoPre{}; };
+    if (nL == 1 && cd.gx) chain_gemm_b<CG, 1>(a.fragb + bf_frag_off(dm, l, false), out, in, xg, in, 16L * in, nopre, epi_last);
+    else chain_gemm_b<CG, 0>(a.fragb + bf_frag_off(dm, l, false), out, in, Xin, ldx, 16L * ldx, nopre, epi_last);
+  }
+}
+
+struct ChainBwdArgsB {
+  const float* x;
+  const float* y;
+  const float* dy;
+  float* dx;
+  const __bf16* fragTb;
+  const float* Wflat;
+  __bf16* dstage;       // δ_l matrices [n][dl_w[l]] bf16 (BfDims::dl_off), read by k_chain_dw_b
+  long long N;
+  const __bf16* saved;  // hidden activations written by k_chain_forward_b
+};
+
+struct PreH { f32x4 h; };
+
+// copy a bf16 LDS panel (columns of this tile, `rows` features each, zero beyond) to the [n][w] matrix in global memory: 16-byte
+// chunks, consecutive lanes on consecutive chunks of a column
+template <int CG>
+__device__ __forceinline__ void stage_delta_b(const __bf16* panel, int ld, int rows, __bf16* dst, int w, long long n0, long long N) {
+  constexpr int NC = 16 * CG;
+  const int chunks = w / 8;
+  for (int e = threadIdx.x; e < NC * chunks; e += 512) {
+    const int c = e / chunks, ch = e - c * chunks;
+    if (n0 + c >= N) continue;
+    bf16x8 v = *reinterpret_cast<const bf16x8*>(panel + c * ld + 8 * ch);
+    if (8 * ch + 8 > rows) {
+#pragma unroll
+      for (int q = 0; q < 8; q++)
+        if (8 * ch + q >= rows) v[q] = (__bf16)0.f;
+    }
+    *reinterpret_cast<bf16x8*>(dst + (size_t)(n0 + c) * w + 8 * ch) = v;
+  }
+}
+
+template <int CG>
+__global__ void __launch_bounds__(512) k_chain_backward_b(ChainDims cd, BfDims bd, ChainBwdArgsB a) {
+  extern __shared__ __attribute__((aligned(16))) float csm[];
+  constexpr int NC = 16 * CG;
+  const MlpDims& dm = cd.dm;
+  const int nL = dm.nL, ldh = bd.ldb, ldg = bd.ldg, tid = threadIdx.x;
+  __bf16* P0 = reinterpret_cast<__bf16*>(csm);
+  __bf16* P1 = P0 + NC * ldh;
+  float* G = reinterpret_cast<float*>(P1 + NC * ldh);
+  int dup;
+  const long long n0 = chain_tile_start(cd, NC, a.N, &dup);
+  for (int i = tid; i < (2 * NC * ldh) / 8 + (NC * ldg) / 4; i += 512) reinterpret_cast<f32x4*>(csm)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // ---- δ_L = dy ⊙ act'(y) from the caller's arrays → the δ-stage matrix of the last layer (bf16) -----------------------
+  const int L1 = nL - 1;
+  {
+    const int out = dm.sizes[nL], w = bd.dl_w[L1], actk = cd.act[L1], chunks = w / 8;
+    __bf16* dL = a.dstage + (size_t)a.N * bd.dl_off[L1];
+    const bool vec = (out & 3) == 0;
+    for (int e = tid; e < NC * chunks; e += 512) {
+      const int c = e / chunks, ch = e - c * chunks;
+      const long long n = n0 + c;
+      if (n >= a.N) continue;
+      const float* dyp = a.dy + (size_t)n * out + 8 * ch;
+      const float* yp = a.y + (size_t)n * out + 8 * ch;
+      bf16x8 d;
+      if (vec && 8 * ch + 8 <= out) {
+        const f32x4 g0 = *reinterpret_cast<const f32x4*>(dyp), g1 = *reinterpret_cast<const f32x4*>(dyp + 4);
+        const f32x4 f0 = *reinterpret_cast<const f32x4*>(yp), f1 = *reinterpret_cast<const f32x4*>(yp + 4);
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          d[q] = (__bf16)(g0[q] * cact_grad_out(actk, f0[q]));
+          d[4 + q] = (__bf16)(g1[q] * cact_grad_out(actk, f1[q]));
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 8; q++) d[q] = (__bf16)(8 * ch + q < out ? dyp[q] * cact_grad_out(actk, yp[q]) : 0.f);
+      }
+      *reinterpret_cast<bf16x8*>(dL + (size_t)n * w + 8 * ch) = d;
+    }
+  }
+  __syncthreads();   // s_waitcnt vmcnt(0) + barrier: the rows are in L2 for the read-back below; the LDS panels are zero
+
+  // ---- δ down the chain ------------------------------------------------------------------------------------------------
+  const __bf16* Dcur = nullptr;   // LDS panel holding δ_l for l < L1
+  for (int l = L1; l >= 0; l--) {
+    const int in = dm.sizes[l], out = dm.sizes[l + 1];
+    const int skl = cd.skip[l];
+    const __bf16* fragT = a.fragTb + bf_frag_off(dm, l, true);
+    const __bf16* Bglb = a.dstage + (size_t)a.N * bd.dl_off[l] + (size_t)n0 * bd.dl_w[l];   // δ_l rows of this tile (only used for l == L1)
+    if (l > 0) {
+      __bf16* Dn = (l & 1) ? P1 : P0;
+      const int actp = cd.act[l - 1], skp = cd.skip[l - 1];
+      // activation output of layer l-1 (before its skip addition): from the saved matrices, 8 bytes per (column, 4 features)
+      const __bf16* hsv = a.saved + (size_t)a.N * cd.sv_pre[l - 1] + (skp ? (size_t)a.N * in : 0);
+      const bool hvec = (in & 3) == 0;
+      auto pre = [&](int row0, int cg, int col) {
+        PreH p;
+        p.h = f32x4{0.f, 0.f, 0.f, 0.f};
+        const long long n = n0 + cg * 16 + col;
+        if (n < a.N && row0 < in) {
+          const __bf16* hp = hsv + (size_t)n * in + row0;
+          if (hvec) p.h = from_bf4(*reinterpret_cast<const bf16x4*>(hp));
+          else {
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+              if (row0 + q < in) p.h[q] = (float)hp[q];
+          }
+        }
+        return p;
+      };
+      auto epi = [&](int row0, int cg, int col, f32x4 v, PreH p) {
+        const int c = cg * 16 + col;
+        f32x4 g = v;
+        if (skl) g += *reinterpret_cast<const f32x4*>(G + c * ldg + row0);
+        if (skp) *reinterpret_cast<f32x4*>(G + c * ldg + row0) = g;   // layer l-1 adds it back to what flows through it
+        f32x4 d;
+#pragma unroll
+        for (int q = 0; q < 4; q++) d[q] = row0 + q < in ? g[q] * cact_grad_out(actp, p.h[q]) : 0.f;
+        *reinterpret_cast<bf16x4*>(Dn + c * ldh + row0) = to_bf4(d);
+      };
+      if (l == L1) chain_gemm_b<CG, 0>(fragT, in, out, Bglb, bd.dl_w[l], 16L * bd.dl_w[l], pre, epi);
+      else chain_gemm_b<CG, 0>(fragT, in, out, Dcur, ldh, 16L * ldh, pre, epi);
+      __syncthreads();
+      stage_delta_b<CG>(Dn, ldh, in, a.dstage + (size_t)a.N * bd.dl_off[l - 1], bd.dl_w[l - 1], n0, a.N);
+      Dcur = Dn;
+    } else if (a.dx) {
+      auto pre = [](int, int, int) { return NoPre{}; };
+      auto epi = [&](int row0, int cg, int col, f32x4 v, NoPre) {
+        const int c = cg * 16 + col;
+        const long long n = n0 + c;
+        f32x4 g = v;
+        if (skl) g += *reinterpret_cast<const f32x4*>(G + c * ldg + row0);
+        if (n < a.N) {
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (row0 + q < in) a.dx[(size_t)n * in + row0 + q] = g[q];
+        }
+      };
+      if (l == L1) chain_gemm_b<CG, 0>(fragT, in, out, Bglb, bd.dl_w[l], 16L * bd.dl_w[l], pre, epi);
+      else chain_gemm_b<CG, 0>(fragT, in, out, Dcur, ldh, 16L * ldh, pre, epi);
+    }
+  }
+}
+
+// ---- weight gradient: gW_lᵀ[i][o] = Σ_n a_l[i,n] δ_l[o,n] over [n][feature] matrices, transposing LDS reads ---------------------------
+// grid (K-split parts, jobs); a job = a block of ≤ 8·NDW 32×32 tiles of one layer's gWᵀ (dw_decode, as k_mlp_dw). The workgroup
+// walks its share of the n range in chunks of NK = 32 rows: the chunk's rows of a_l (features of the job's input tiles) and of δ_l
+// (features of its output tiles) are copied into LDS as they are — [n][feature], row stride ≡ 64 (mod 128) bytes, which makes the four
+// 64-byte row pieces a 32-lane half of ds_read_b64_tr_b16 touches fall on disjoint banks — and every wave feeds its tiles: per
+// 16 rows of n, two transposing reads per operand (rows 8h + 4r .. + 3, r = 0, 1: the lane receives its feature's values at those
+// four n) make the eight-k operand of one v_mfma_f32_32x32x16_bf16. Bias gradients: column sums of the δ image, by the jobs that
+// hold the first input tile. Output: the (part) slab in accumulator-fragment order — k_reduce_tiles adds the parts in a fixed order.
+struct DwArgsB {
+  const float* x;          // a_0 [N][in_0] f32 (rounded to bf16 on the way into LDS)
+  const __bf16* saved;     // a_l = hidden l-1 [N][h] (ChainDims::sv_pre)
+  const __bf16* dstage;    // δ_l [N][dl_w[l]]
+  float* slab;             // [parts][slab_n]
+  long long N;
+};
+
+__host__ __device__ inline int tr_stride_bytes(int feats) {   // row stride of an image of `feats` bf16 features: smallest ≥ 2·feats that is ≡ 64 (mod 128)
+  return ((2 * feats + 63) / 128) * 128 + 64;
+}
+// LDS bytes of k_chain_dw_b: the widest job's two images
+inline size_t dw_b_lds_bytes(const MlpDims& dm, int ndw) {
+  size_t mx = 0;
+  for (int z = 0, n = dw_jobs(dm, ndw); z < n; z++) {
+    const DwJob j = dw_decode(dm, z, 8 * ndw);
+    mx = std::max(mx, (size_t)32 * (tr_stride_bytes(32 * (j.i1 - j.i0)) + tr_stride_bytes(32 * (j.o1 - j.o0))));
+  }
+  return mx;
+}
+
+template <int DW_NDW>
+__global__ void __launch_bounds__(512) k_chain_dw_b(ChainDims cd, BfDims bd, DwArgsB a) {
+  extern __shared__ __attribute__((aligned(16))) float dsm[];
+  constexpr int NK = 32;
+  const MlpDims& dm = cd.dm;
+  const int part = blockIdx.x, KS = gridDim.x;
+  const DwJob jb = dw_decode(dm, blockIdx.y, 8 * DW_NDW);
+  const int l = jb.l, in = dm.sizes[l], out = dm.sizes[l + 1];
+  const int IT = cdiv(in, 32), nit = jb.i1 - jb.i0, ntile = (jb.o1 - jb.o0) * nit;
+  const int na = 32 * nit, nd = 32 * (jb.o1 - jb.o0), ra0 = 32 * jb.i0, rd0 = 32 * jb.o0;
+  const int sa = tr_stride_bytes(na), sd = tr_stride_bytes(nd);
+  unsigned char* ia = reinterpret_cast<unsigned char*>(dsm);
+  unsigned char* id = ia + NK * sa;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // operand addressing of the transposing read: 16-lane group g = lane >> 4 → (k half h = g >> 1, feature half g & 1); lane 4q + p of
+  // the group supplies the address of row q, features 4p .. 4p + 3 of the block
+  const int g = lane >> 4, q4 = (lane & 15) >> 2, p4 = lane & 3;
+  const int lrow = 8 * (g >> 1) + q4, lfeat = 16 * (g & 1) + 4 * p4;
+  f32x16 acc[DW_NDW];
+  int aoff[DW_NDW], doff[DW_NDW];
+#pragma unroll
+  for (int m = 0; m < DW_NDW; m++) {
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc[m][r] = 0.f;
+    const int t = wave + 8 * m;
+    const int otl = t / nit, itl = t - otl * nit;
+    aoff[m] = t < ntile ? lrow * sa + 2 * (itl * 32 + lfeat) : -1;
+    doff[m] = lrow * sd + 2 * (otl * 32 + lfeat);
+  }
+  const bool do_bias = jb.i0 == 0;
+  float bsum[2] = {0.f, 0.f};
+  // the operands' matrices in global memory: a_l rows of width aw, δ_l rows of width dw
+  const bool a_f32 = l == 0;
+  const int aw = in;
+  const __bf16* ab = a_f32 ? nullptr : a.saved + (size_t)a.N * cd.sv_pre[l - 1];
+  const __bf16* db = a.dstage + (size_t)a.N * bd.dl_off[l];
+  const int dw = bd.dl_w[l];
+  const bool avec = (aw & 7) == 0;
+  const long long nchunks = (a.N + NK - 1) / NK;
+  for (long long ch = part; ch < nchunks; ch += KS) {
+    const long long nb = ch * NK;
+    // ---- copy the chunk: 16-byte pieces (8 features of one n); rows beyond N and features beyond the layer are zeros
+    for (int e = tid; e < NK * (na / 8); e += 512) {
+      const int r = e / (na / 8), c8 = e - r * (na / 8);
+      const long long n = nb + r;
+      const int f = ra0 + 8 * c8;
+      bf16x8 v = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+      if (n < a.N && f < in) {
+        if (a_f32) {
+          const float* xp = a.x + (size_t)n * aw + f;
+          if (avec && f + 8 <= in) {
+            const bf16x4 lo = to_bf4(*reinterpret_cast<const f32x4*>(xp)), hi = to_bf4(*reinterpret_cast<const f32x4*>(xp + 4));
+            v = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          } else {
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+              if (f + q < in) v[q] = (__bf16)xp[q];
+          }
+        } else {
+          const __bf16* hp = ab + (size_t)n * aw + f;
+          if (avec && f + 8 <= in) v = *reinterpret_cast<const bf16x8*>(hp);
+          else {
+#pragma unroll
+            for (int q = 0; q < 8; q++)
+              if (f + q < in) v[q] = hp[q];
+          }
+        }
+      }
+      *reinterpret_cast<bf16x8*>(ia + r * sa + 16 * c8) = v;
+    }
+    for (int e = tid; e < NK * (nd / 8); e += 512) {
+      const int r = e / (nd / 8), c8 = e - r * (nd / 8);
+      const long long n = nb + r;
+      const int f = rd0 + 8 * c8;
+      bf16x8 v = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
+      if (n < a.N && f < dw) v = *reinterpret_cast<const bf16x8*>(db + (size_t)n * dw + f);   // (pad entries of a row are zeros)
+      *reinterpret_cast<bf16x8*>(id + r * sd + 16 * c8) = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < DW_NDW; m++) {
+      if (aoff[m] >= 0) {   // wave-uniform: EXEC stays all ones for the transposing reads
+#pragma unroll
+        for (int ks = 0; ks < NK / 16; ks++) {
+          typedef short s16x4_ __attribute__((ext_vector_type(4)));
+          typedef __attribute__((address_space(3))) s16x4_ lds_s16x4;
+          const unsigned char* pa = ia + aoff[m] + ks * 16 * sa;
+          const unsigned char* pd = id + doff[m] + ks * 16 * sd;
+          const s16x4_ a0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa));
+          const s16x4_ a1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pa + 4 * sa));
+          const s16x4_ d0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pd));
+          const s16x4_ d1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(pd + 4 * sd));
+          const bf16x8 av = __builtin_bit_cast(bf16x8, (s16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]});
+          const bf16x8 dv = __builtin_bit_cast(bf16x8, (s16x8){d0[0], d0[1], d0[2], d0[3], d1[0], d1[1], d1[2], d1[3]});
+          acc[m] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, dv, acc[m], 0, 0, 0);
+        }
+      }
+    }
+    if (do_bias) {
+#pragma unroll
+      for (int q = 0; q < 2; q++) {
+        const int row = tid + 512 * q;
+        if (row < nd) {
+          float sacc = 0.f;
+#pragma unroll 8
+          for (int n = 0; n < NK; n++) sacc += (float)*reinterpret_cast<const __bf16*>(id + n * sd + 2 * row);
+          bsum[q] += sacc;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  float* slab = a.slab + (size_t)part * dm.slab_n;
+#pragma unroll
+  for (int m = 0; m < DW_NDW; m++) {
+    const int t = wave + 8 * m;
+    if (t < ntile) {
+      const int otl = t / nit, itl = t - otl * nit;
+      const int tl = (jb.o0 + otl) * IT + jb.i0 + itl;   // the layer's tile enumeration: output tile major
+      f32x4* g4 = reinterpret_cast<f32x4*>(slab + ((size_t)(dm.tile_off[l] + tl) * 64 + lane) * 16);
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        f32x4 v;
+        v[0] = acc[m][4 * q + 0]; v[1] = acc[m][4 * q + 1]; v[2] = acc[m][4 * q + 2]; v[3] = acc[m][4 * q + 3];
+        g4[q] = v;
+      }
+    }
+  }
+  if (do_bias) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const int row = tid + 512 * q;
+      if (row < nd && rd0 + row < out) slab[(size_t)dm.tile_off[dm.nL] * 1024 + dm.bias_lin[l] + rd0 + row] = bsum[q];
+    }
+  }
+}

@@ -103,6 +103,43 @@ __host__ __device__ inline int panel_stride(int rows) {
 // (`keep`, optional: the flat vector is also copied there — the handle's own copy, read for the biases later — which
 //  saves a separate device-to-device copy per lde_*_set_weights_device call: one launch instead of two per training step
 //  and module.)
+// bf16 copies (round 3, the chains' bf16 mode): fragment (rt, kg) of M[R×K] in the K = 32 layout of v_mfma_f32_16x16x32_bf16 — lane l
+// holds the EIGHT consecutive-k values M[rt*16 + (l&15)][kg*32 + 8*(l>>4) + 0..7] as one 16-byte word (0 outside). Offsets of layer l
+// in the two bf16 arrays (elements): bf_frag_off(dm, l, false / true).
+__host__ __device__ inline size_t bf_frag_elems(const MlpDims& dm, int l, bool T) {
+  const int R = T ? dm.sizes[l] : dm.sizes[l + 1], K = T ? dm.sizes[l + 1] : dm.sizes[l];
+  return (size_t)((R + 15) / 16) * ((K + 31) / 32) * 512;
+}
+__host__ __device__ inline size_t bf_frag_off(const MlpDims& dm, int l, bool T) {
+  size_t o = 0;
+  for (int m = 0; m < l; m++) o += bf_frag_elems(dm, m, T);
+  return o;
+}
+__device__ inline void build_frags_layer_bf(const float* __restrict__ Wflat, const MlpDims& dm, __bf16* __restrict__ fragb,
+                                            __bf16* __restrict__ fragTb, int l, int bx, int nbx) {
+  const int in = dm.sizes[l], out = dm.sizes[l + 1];
+  const int stride = nbx * blockDim.x, first = bx * blockDim.x + threadIdx.x;
+  const float* W = Wflat + dm.w_off[l];  // column-major [out×in]: W(o,i) at o + out*i
+  {
+    const int KG = (in + 31) / 32, n = (int)bf_frag_elems(dm, l, false);
+    __bf16* dst = fragb + bf_frag_off(dm, l, false);
+    for (int e = first; e < n; e += stride) {
+      const int j = e & 7, lane = (e >> 3) & 63, f = e >> 9, rt = f / KG, kg = f % KG;
+      const int o = rt * 16 + (lane & 15), i = kg * 32 + 8 * (lane >> 4) + j;
+      dst[e] = (__bf16)((o < out && i < in) ? W[o + (size_t)out * i] : 0.f);
+    }
+  }
+  {
+    const int KG = (out + 31) / 32, n = (int)bf_frag_elems(dm, l, true);   // Wᵀ[in×out]
+    __bf16* dst = fragTb + bf_frag_off(dm, l, true);
+    for (int e = first; e < n; e += stride) {
+      const int j = e & 7, lane = (e >> 3) & 63, f = e >> 9, rt = f / KG, kg = f % KG;
+      const int i = rt * 16 + (lane & 15), o = kg * 32 + 8 * (lane >> 4) + j;
+      dst[e] = (__bf16)((o < out && i < in) ? W[o + (size_t)out * i] : 0.f);
+    }
+  }
+}
+
 __device__ inline void build_frags_layer(const float* __restrict__ Wflat, const MlpDims& dm, float* __restrict__ frag,
                                          float* __restrict__ fragT, float* __restrict__ keep, int l, int bx, int nbx) {
   const int in = dm.sizes[l], out = dm.sizes[l + 1];
@@ -131,7 +168,9 @@ __device__ inline void build_frags_layer(const float* __restrict__ Wflat, const 
 }
 
 static __global__ void k_build_frags(const float* __restrict__ Wflat, MlpDims dm, float* __restrict__ frag,
-                              float* __restrict__ fragT, float* __restrict__ keep) {
+                              float* __restrict__ fragT, float* __restrict__ keep, __bf16* __restrict__ fragb = nullptr,
+                              __bf16* __restrict__ fragTb = nullptr) {
+  if (fragb) build_frags_layer_bf(Wflat, dm, fragb, fragTb, blockIdx.y, blockIdx.x, gridDim.x);   // (reads Wflat: before `keep` could alias it)
   build_frags_layer(Wflat, dm, frag, fragT, keep, blockIdx.y, blockIdx.x, gridDim.x);
 }
 
@@ -146,6 +185,8 @@ struct RefreshJob {
   const MlpDims* dm;   // device copy of the chain's dimensions
   int layer;
   int n;
+  __bf16* fragb;       // bf16 K = 32 fragment copies (chains; nullptr: none)
+  __bf16* fragTb;
 };
 static __global__ void k_refresh_many(const RefreshJob* __restrict__ jobs) {
   const RefreshJob j = jobs[blockIdx.y];
@@ -153,6 +194,7 @@ static __global__ void k_refresh_many(const RefreshJob* __restrict__ jobs) {
     for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < j.n; e += gridDim.x * blockDim.x) j.keep[e] = j.src[e];
     return;
   }
+  if (j.fragb) build_frags_layer_bf(j.src, *j.dm, j.fragb, j.fragTb, j.layer, blockIdx.x, gridDim.x);
   build_frags_layer(j.src, *j.dm, j.frag, j.fragT, j.keep, j.layer, blockIdx.x, gridDim.x);
 }
 

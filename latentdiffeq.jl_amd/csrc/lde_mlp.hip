@@ -1640,7 +1640,7 @@ int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::strin
 }
 
 int mlp_set_weights(MlpPlan* p, const float* W_dev, hipStream_t stream, std::string& err) {
-  hipLaunchKernelGGL(k_build_frags, dim3(64, p->dm.nL), dim3(256), 0, stream, W_dev, p->dm, p->frag, p->fragT, (float*)nullptr);
+  hipLaunchKernelGGL(k_build_frags, dim3(64, p->dm.nL), dim3(256), 0, stream, W_dev, p->dm, p->frag, p->fragT, (float*)nullptr, (__bf16*)nullptr, (__bf16*)nullptr);
   if (p->vec_ok) hipLaunchKernelGGL(k_build_vec, dim3(64, p->dm.nL), dim3(256), 0, stream, W_dev, p->dm, p->vd, p->vecw);
   if (p->w_ok) hipLaunchKernelGGL(k_build_wpack, dim3(128), dim3(256), 0, stream, W_dev, p->dm, p->wd, p->wpack);
   if (hipGetLastError() != hipSuccess) {

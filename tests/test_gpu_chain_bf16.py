@@ -1,6 +1,7 @@
-"""GPU: the dense chains in bf16 operand mode (lde_chain_set_dtype; BASELINE.json configs[4] "mixed fp32 solve / bf16
-encoder-decoder"): both operands of every matrix product — forward, input gradient, weight gradient — are rounded to
-bfloat16 (round-to-nearest-even) and multiplied with f32 accumulation; weights, activations and gradients stay f32.
+"""GPU: the dense chains in bf16 mode (lde_chain_set_dtype; BASELINE.json configs[4] "mixed fp32 solve / bf16
+encoder-decoder"; round 3: native — csrc/lde_chain_bf16.h): both operands of every matrix product — forward, input gradient,
+weight gradient — are bfloat16 (round-to-nearest-even) multiplied with f32 accumulation on v_mfma_f32_16x16x32_bf16 /
+32x32x16_bf16; hidden activations and δ are stored in bf16; master weights, biases, y, dx and dW stay f32.
 
 Checked against a numpy restatement of exactly that arithmetic (Flux's Dense / SkipConnection definitions as in
 oracle/lde_chain_oracle.c, operands rounded to bf16 with integer arithmetic, products accumulated in float64):
@@ -56,23 +57,31 @@ def _split(sizes, W):
 
 
 def chain_ref(sizes, acts, skips, W, x, dy, rnd):
-    """x (N, in), dy (N, out) → y, dx, dW with `rnd` applied to the operands of every product (identity: the f32 chain)."""
+    """x (N, in), dy (N, out) → y, dx, dW of the mode `rnd` defines (identity: the f32 chain; bf16r: the native bf16 mode of
+    csrc/lde_chain_bf16.h): both operands of every product are `rnd`-ed, and the hidden activations, the activation before a skip
+    addition and δ are STORED `rnd`-ed; biases, the gradient that flows around a skip connection, y, dx and dW are f32."""
     layers = _split(sizes, W.astype(np.float64))
+    L = len(layers)
+    f32 = lambda a: a.astype(np.float32).astype(np.float64)
     h = [x.astype(np.float64).T]
     f = []
-    for (Wl, bl), a, s in zip(layers, acts, skips):
+    for l, ((Wl, bl), a, s) in enumerate(zip(layers, acts, skips)):
         pre = rnd(Wl).astype(np.float64) @ rnd(h[-1]).astype(np.float64) + bl[:, None]
-        fl = _act(a, pre).astype(np.float32).astype(np.float64)      # activations are stored in f32
-        f.append(fl)
-        h.append((h[-1] + fl if s else fl).astype(np.float32).astype(np.float64))
+        fl = f32(_act(a, pre))                                        # the epilogue's f32 value
+        if l == L - 1:
+            f.append(fl)
+            h.append(fl)                                               # y stays f32
+        else:
+            f.append(rnd(fl).astype(np.float64))                       # stored: what the activation derivative is taken from
+            h.append(rnd(f32(rnd(h[-1]).astype(np.float64) + fl) if s else fl).astype(np.float64))
     G = dy.astype(np.float64).T
     dW = []
-    for l in range(len(layers) - 1, -1, -1):
+    for l in range(L - 1, -1, -1):
         Wl, _ = layers[l]
-        d = (G * _act_grad_out(acts[l], f[l])).astype(np.float32).astype(np.float64)
-        gW = rnd(d).astype(np.float64) @ rnd(h[l]).astype(np.float64).T
+        d = rnd(f32(G * _act_grad_out(acts[l], f[l]))).astype(np.float64)   # δ_l as stored
+        gW = d @ rnd(h[l]).astype(np.float64).T
         dW = [gW.T.reshape(-1), d.sum(axis=1)] + dW
-        G = rnd(Wl.T).astype(np.float64) @ rnd(d).astype(np.float64) + (G if skips[l] else 0)
+        G = rnd(Wl.T).astype(np.float64) @ d + (G if skips[l] else 0)
     return h[-1].T, G.T, np.concatenate(dW)
 
 

@@ -45,14 +45,63 @@ struct ChainDims {
   int ldh;             // stride of hidden / gradient panels
 };
 
+// Activations on the hardware's v_exp_f32 / v_log_f32 / v_rcp_f32 (a few instructions each, ≈ 1e-7 ABSOLUTE error). The libm forms
+// (tanhf, log1pf, expf: hundreds of instructions each) were inlined into every unrolled epilogue copy — 4 values × column groups × 2 row
+// tiles × every chain_mac variant: 45–90 k instructions per chain kernel, several times the instruction cache, for 700 MFMAs.
 __device__ __forceinline__ float cact(int kind, float x) {
   switch (kind) {
     case LDE_CACT_RELU: return fmaxf(x, 0.f);
-    case LDE_CACT_TANH: return tanhf(x);
+    case LDE_CACT_TANH: {   // |x| < 1/4: the odd series (next term 8e-9 relative); beyond: (1 − e)/(1 + e), e = exp(−2|x|) ≤ 0.61 — no cancellation
+      const float t = fabsf(x), t2 = t * t, e = __expf(-2.0f * t);
+      const float big = (1.0f - e) * fast_rcp(1.0f + e);
+      const float sm = t * (1.0f + t2 * (-0.33333334f + t2 * (0.13333334f + t2 * (-0.053968254f + t2 * 0.021869488f))));
+      return copysignf(t < 0.25f ? sm : big, x);
+    }
     case LDE_CACT_SIGMOID: return fast_rcp(1.0f + __expf(-x));   // v_exp_f32 + v_rcp_f32: ≈ 1e-7 absolute on (0,1)
-    case LDE_CACT_SOFTPLUS: return fmaxf(x, 0.f) + log1pf(expf(-fabsf(x)));
+    case LDE_CACT_SOFTPLUS: return fmaxf(x, 0.f) + __logf(1.0f + __expf(-fabsf(x)));
     default: return x;
   }
+}
+// The same on four values with ONE wave-uniform branch on the kind. Written per value inside the epilogue's unrolled loop, the switch
+// was if-converted: every value evaluated EVERY activation (three v_exp, a v_log, three v_rcp, the tanh series …) and selected — ≈ 900
+// cycles per epilogue call, measured with in-kernel stamps: the epilogues, not the K loops, were most of a chain kernel.
+__device__ __forceinline__ f32x4 cact4(int kind, f32x4 x) {
+  const int k = __builtin_amdgcn_readfirstlane(kind);
+  f32x4 r;
+  if (k == LDE_CACT_RELU) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) r[q] = fmaxf(x[q], 0.f);
+  } else if (k == LDE_CACT_SIGMOID) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) r[q] = cact(LDE_CACT_SIGMOID, x[q]);
+  } else if (k == LDE_CACT_TANH) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) r[q] = cact(LDE_CACT_TANH, x[q]);
+  } else if (k == LDE_CACT_SOFTPLUS) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) r[q] = cact(LDE_CACT_SOFTPLUS, x[q]);
+  } else
+    r = x;
+  return r;
+}
+__device__ __forceinline__ f32x4 cact_grad_out4(int kind, f32x4 f) {
+  const int k = __builtin_amdgcn_readfirstlane(kind);
+  f32x4 r;
+  if (k == LDE_CACT_RELU) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) r[q] = f[q] > 0.f ? 1.f : 0.f;
+  } else if (k == LDE_CACT_SIGMOID) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) r[q] = f[q] * (1.f - f[q]);
+  } else if (k == LDE_CACT_TANH) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) r[q] = 1.f - f[q] * f[q];
+  } else if (k == LDE_CACT_SOFTPLUS) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) r[q] = 1.f - __expf(-f[q]);
+  } else
+    r = f32x4{1.f, 1.f, 1.f, 1.f};
+  return r;
 }
 // derivative of the activation expressed through its OUTPUT f = act(pre)
 __device__ __forceinline__ float cact_grad_out(int kind, float f) {
@@ -60,7 +109,7 @@ __device__ __forceinline__ float cact_grad_out(int kind, float f) {
     case LDE_CACT_RELU: return f > 0.f ? 1.f : 0.f;
     case LDE_CACT_TANH: return 1.f - f * f;
     case LDE_CACT_SIGMOID: return f * (1.f - f);
-    case LDE_CACT_SOFTPLUS: return 1.f - expf(-f);
+    case LDE_CACT_SOFTPLUS: return 1.f - __expf(-f);
     default: return 1.f;
   }
 }
@@ -244,9 +293,12 @@ __device__ __forceinline__ void chain_hidden_layer(const ChainDims& cd, int l, c
   chain_gemm<CG, BG, BF>(frag + dm.frag_off[l], out, in, Xin, ldx, 16 * ldx, [](int, int, int) { return NoPre{}; },
                         [&](int row0, int cg, int col, f32x4 v, NoPre) {
                           const int c = cg * 16 + col;
-                          f32x4 r;
+                          f32x4 r = v;
 #pragma unroll
-                          for (int q = 0; q < 4; q++) r[q] = row0 + q < out ? cact(actk, v[q] + bias[row0 + q]) : 0.f;
+                          for (int q = 0; q < 4; q++) r[q] += bias[min(row0 + q, out - 1)];
+                          r = cact4(actk, r);
+#pragma unroll
+                          for (int q = 0; q < 4; q++) r[q] = row0 + q < out ? r[q] : 0.f;
                           if (skip && fstage && row0 < out32)
                             *reinterpret_cast<f32x4*>(fstage + (size_t)cg * dm.blk_floats + col * out32 + row0) = r;
                           const long long nsv = sv.n0 + c;
@@ -308,9 +360,10 @@ __global__ void __launch_bounds__(512) k_chain_forward(ChainDims cd, ChainFwdArg
     auto epi_last = [&](int row0, int cg, int col, f32x4 v, NoPre) {
                             const long long n = n0 + cg * 16 + col;
                             if (n >= a.N || row0 >= out) return;
-                            f32x4 r;
+                            f32x4 r = v;
 #pragma unroll
-                            for (int q = 0; q < 4; q++) r[q] = row0 + q < out ? cact(actk, v[q] + bias[row0 + q]) : 0.f;
+                            for (int q = 0; q < 4; q++) r[q] += bias[min(row0 + q, out - 1)];
+                            r = cact4(actk, r);
                             float* yp = a.y + (size_t)n * out + row0;
                             if (vec) *reinterpret_cast<f32x4*>(yp) = r;
                             else {
@@ -441,8 +494,9 @@ __global__ void __launch_bounds__(512) k_chain_backward(ChainDims cd, ChainBwdAr
         if (n < a.N && r < out) {
           if (vec) {
             const f32x4 g = *reinterpret_cast<const f32x4*>(dyp + r), f = *reinterpret_cast<const f32x4*>(yp + r);
+            d = cact_grad_out4(actk, f);
 #pragma unroll
-            for (int q = 0; q < 4; q++) d[q] = g[q] * cact_grad_out(actk, f[q]);
+            for (int q = 0; q < 4; q++) d[q] *= g[q];
           } else {
 #pragma unroll
             for (int q = 0; q < 4; q++)
@@ -481,9 +535,9 @@ __global__ void __launch_bounds__(512) k_chain_backward(ChainDims cd, ChainBwdAr
         f32x4 g = v;
         if (skl) g += *reinterpret_cast<const f32x4*>(G + c * ldh + row0);
         if (skp) *reinterpret_cast<f32x4*>(G + c * ldh + row0) = g;   // layer l-1 adds it back to what flows through it
-        f32x4 d;
+        f32x4 d = cact_grad_out4(actp, p.h - p.a);
 #pragma unroll
-        for (int q = 0; q < 4; q++) d[q] = row0 + q < in ? g[q] * cact_grad_out(actp, p.h[q] - p.a[q]) : 0.f;
+        for (int q = 0; q < 4; q++) d[q] = row0 + q < in ? g[q] * d[q] : 0.f;
         *reinterpret_cast<f32x4*>(Dn + c * ldh + row0) = d;
       };
       if (l == L1) chain_gemm<CG, true, BF>(fragT, in, out, Bglb, pad32(out), dm.blk_floats, pre, epi);
@@ -572,7 +626,7 @@ static size_t chain_lds(const ChainDims& cd, int cg, int npanels) {
 static size_t chain_lds_b(const ChainDims& cd, const BfDims& bd, int cg, bool bwd) {
   const size_t NC = 16 * cg;
   if (bwd) return NC * bd.ldb * 2 * 2 + NC * bd.ldg * 4;
-  return (NC * bd.ld0 + 2 * NC * bd.ldb) * 2 + (size_t)((cd.dm.nbias + 3) & ~3) * 4;
+  return (2 + (bd.fpanel ? 1 : 0)) * NC * bd.ldb * 2 + (size_t)((cd.dm.nbias + 3) & ~3) * 4;   // the input panel shares the second panel's space
 }
 
 // lde_rnn.hip: where lde_refresh_weights copies a recurrent stack's flat weights to (marks the handle as holding weights)
@@ -695,8 +749,8 @@ int lde_chain_create(const lde_chain_desc* d, lde_chain** out) {
   {   // native bf16 layouts (lde_chain_bf16.h)
     BfDims& bd = c->bd;
     std::memset(&bd, 0, sizeof(bd));
-    bd.ldb = panel_stride_b(pad32(hmax));
-    bd.ld0 = panel_stride_b(pad32(dm.sizes[0]));
+    bd.ldb = panel_stride_b(pad32(std::max(hmax, dm.sizes[0])));   // the input panel shares the second hidden panel's space
+    bd.ld0 = bd.ldb;
     bd.ldg = cd.ldh;
     int off = 0;
     for (int l = 0; l < d->n_layers; l++) {
@@ -705,15 +759,18 @@ int lde_chain_create(const lde_chain_desc* d, lde_chain** out) {
       off += bd.dl_w[l];
     }
     bd.dl_total = off;
+    for (int l = 0; l + 1 < d->n_layers; l++) bd.fpanel = bd.fpanel || cd.skip[l];
     c->bdx = bd;
+    c->bdx.ldb = panel_stride_b(pad32(hmax));   // wide input read in place: the panels only hold hidden vectors
     c->bdx.ld0 = 0;
+    // The kernels take ≈ 200–250 registers at 512 threads: ONE workgroup per CU whatever its LDS, so the forward takes the widest tile
+    // that fits the 160 KB (measured, reconstructor at N = 12 800: 64 columns 45 µs, 32 columns 57 µs); the pullback's 64-column
+    // instantiation spills (132 µs against 118 µs at 32 columns): at most 32 columns there.
     auto pickb = [&](const ChainDims& q, const BfDims& b, int* cgf, int* cgb) {
       *cgf = *cgb = 0;
-      for (size_t lim : {LDS_MAX / 2, LDS_MAX}) {
-        for (int cg : {4, 2, 1}) {
-          if (!*cgf && chain_lds_b(q, b, cg, false) <= lim) *cgf = cg;
-          if (!*cgb && chain_lds_b(q, b, cg, true) <= lim) *cgb = cg;
-        }
+      for (int cg : {4, 2, 1}) {
+        if (!*cgf && chain_lds_b(q, b, cg, false) <= LDS_MAX) *cgf = cg;
+        if (cg <= 2 && !*cgb && chain_lds_b(q, b, cg, true) <= LDS_MAX) *cgb = cg;
       }
     };
     pickb(cd, bd, &c->bcg_fwd, &c->bcg_bwd);
@@ -919,11 +976,28 @@ static int chain_forward_b(lde_chain* c, const float* x, int64_t N, float* y, __
   ChainDims cdv = *pk.cd;
   BfDims bdv = *pk.bd;
   void* argv[] = {(void*)&cdv, (void*)&bdv, (void*)&a};
+#if LDE_PROF
+  { long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
+#endif
   (void)hipLaunchKernel(fn, grid, dim3(512), argv, pk.lds, stream);
   if (hipGetLastError() != hipSuccess) {
     c->err = "k_chain_forward_b launch failed";
     return LDE_ERR_HIP;
   }
+#if LDE_PROF
+  {
+    static int calls = 0;
+    (void)hipStreamSynchronize(stream);
+    long long v[64];
+    (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(g_prof), sizeof(v));
+    if (N > 1000 && ++calls % 20 == 0) {
+      fprintf(stderr, "[prof chain fwd bf16 cg=%d] cycles:", pk.cg);
+      for (int i = 0; i < 64; i++)
+        if (v[i]) fprintf(stderr, " %d:%lld", i, v[i]);
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
   return LDE_OK;
 }
 
@@ -931,7 +1005,7 @@ static int chain_backward_b(lde_chain* c, const float* x, const float* y, const 
                             float* dW, hipStream_t stream) {
   const MlpDims& dm = c->cd.dm;
   const int ndw = dw_pick_ndw(dm), jobs = dw_jobs(dm, ndw);
-  const int64_t nchunks = (N + 31) / 32;
+  const int64_t nchunks = (N + DWB_NK - 1) / DWB_NK;
   int parts = 256 / jobs;
   if (const char* e = getenv("LDE_CHAIN_DW_PARTS")) parts = atoi(e);
   parts = parts < 1 ? 1 : parts;
@@ -1011,6 +1085,9 @@ static int chain_backward_b(lde_chain* c, const float* x, const float* y, const 
     }
     DwArgsB da{x, saved, c->dstage, c->slab, (long long)N};
     const dim3 grid(parts, jobs);
+#if LDE_PROF
+    { (void)hipStreamSynchronize(wst); long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
+#endif
     ChainDims cdv = c->cd;
     BfDims bdv = c->bd;
     if (ndw == 1) hipLaunchKernelGGL(k_chain_dw_b<1>, grid, dim3(512), dlds, wst, cdv, bdv, da);
@@ -1022,6 +1099,20 @@ static int chain_backward_b(lde_chain* c, const float* x, const float* y, const 
       c->err = "bf16 weight-gradient kernels failed to launch";
       return LDE_ERR_HIP;
     }
+#if LDE_PROF
+    {
+      static int calls = 0;
+      (void)hipStreamSynchronize(wst);
+      long long v[64];
+      (void)hipMemcpyFromSymbol(v, HIP_SYMBOL(g_prof), sizeof(v));
+      if (N > 1000 && ++calls % 20 == 0) {
+        fprintf(stderr, "[prof chain dw bf16 parts=%d jobs=%d ndw=%d] cycles:", parts, jobs, ndw);
+        for (int i = 0; i < 64; i++)
+          if (v[i]) fprintf(stderr, " %d:%lld", i, v[i]);
+        fprintf(stderr, "\n");
+      }
+    }
+#endif
   }
   if (!dw_sync_end(c->dws, wst, stream)) {
     c->err = "lde_chain_backward: hipEventRecord failed";

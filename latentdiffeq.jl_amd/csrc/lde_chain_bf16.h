@@ -32,6 +32,7 @@ struct BfDims {
   int dl_off[MAXL];   // δ-stage: δ_l as a matrix [N][dl_w[l]] bf16 starts at N·dl_off[l] elements
   int dl_w[MAXL];     // its row width: out_l rounded up to 8 (16-byte rows; the pad entries are written as zeros)
   int dl_total;
+  int fpanel;         // forward: a third panel for the activation before a skip addition (chains with skip layers; used when saving)
 };
 
 // smallest stride ≥ rows with stride ≡ 16 (mod 64) elements = 32 (mod 128) bytes: the ds_read_b128 operand pattern "16 columns ×
@@ -46,116 +47,136 @@ __device__ __forceinline__ bf16x4 to_bf4(f32x4 v) { return __builtin_convertvect
 __device__ __forceinline__ f32x4 from_bf4(bf16x4 v) { return __builtin_convertvector(v, f32x4); }
 __device__ __forceinline__ f32x4 mfma32_b(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
-// One wave: NT_ (1 or 2) 16-row tiles × NCG column groups over all K-groups of 32, software-pipelined like chain_mac.
-// BSRC 0: the B operand is a bf16 image Xt[col][k] (LDS panel, or a [n][feature] matrix in global memory): bp points at the lane's
-//         first word, column group cg at + cg·cgstride elements, K-group k at + 32·k.
+// Y[R × 16·CG] = M[R×K] · B[K × 16·CG] for one workgroup of 8 waves; M as bf16 K = 32 fragments in global memory (L2-resident).
+// Row tiles are dealt 16 per PASS: wave w takes tiles 16p + w and 16p + w + 8 (a wave without a tile skips the pass). Per K-group
+// 2 fragment loads + CG operand reads feed 2·CG MFMAs.
+// BSRC 0 / 2: the B operand is a bf16 image Xt[col][k] — an LDS panel (0) or a [n][feature] matrix in global memory (2: same addressing,
+//         a deeper prefetch ring): column group cg at + cg·cgstride elements, K-group k at + 32·k.
 // BSRC 1: the B operand is the caller's f32 x[n][in] (first layer of a wide-input chain): eight floats are loaded and rounded per
 //         K-group — the one conversion of the forward pass; a chunk beyond the row's end (K not a multiple of 32) is read from the
 //         row's last chunk instead (finite values against zero weights).
-template <int NT_, int NCG, int BSRC, class Pre, class Epi>
-__device__ __forceinline__ void chain_mac_b(const bf16x8* A0, const bf16x8* A1, const void* bpv, long cgstride, int KG, int kin, int lg8,
-                                            int row_a, int row_b, int cg0, int col, Pre pre, Epi epi) {
-  constexpr int PFA = 4, PFB = BSRC == 1 ? 2 : 2;
-  const int kl = KG - 1;
-  f32x4 acc0[NCG], acc1[NCG];
-  decltype(pre(0, 0, 0)) p0[NCG], p1[NCG];
-#pragma unroll
-  for (int cg = 0; cg < NCG; cg++) {
-    acc0[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
-    acc1[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
-    p0[cg] = pre(row_a, cg0 + cg, col);
-    if (NT_ == 2) p1[cg] = pre(row_b >= 0 ? row_b : row_a, cg0 + cg, col);
-  }
+// What orders the memory operations (measured with in-kernel stamps: a 13-tile layer with ONE K-group took as long as one with
+// seven, ≈ 19 k cycles — the time was not in the K loop):
+//   * vmcnt counts loads and stores together, in order: a fragment load issued AFTER an epilogue's global stores cannot be waited for
+//     without waiting for those stores' acknowledgements. So the NEXT pass's first fragments (and its pre() loads) are issued BEFORE
+//     the current pass's epilogue, and the caller's own deferred stores (`hook`: the previous layer's coalesced copy of a finished
+//     panel to global memory) run right after the first pass's loads are in flight — every load is older than every store it meets;
+//   * A fragments run PFA = 8 K-groups ahead (the whole K of a 200-wide layer in flight at once: L2 latency ≈ 500–700 cycles under
+//     load against 2·CG × 16 cycles of MFMA per K-group).
+template <int CG, int BSRC, class Pre, class Epi, class Hook>
+__device__ __forceinline__ void chain_gemm_b(const __bf16* __restrict__ gfrag, int R, int K, const void* Bp, int ldb, long cgstride,
+                                             Pre pre, Epi epi, Hook hook) {
+  constexpr int NW = 8, PFA = 8, PFB = BSRC == 0 ? 2 : 4;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int RT = cdiv(R, 16), KG = cdiv(K, 32), kl = KG - 1;
+  const bf16x8* A = reinterpret_cast<const bf16x8*>(gfrag) + lane;
+  const int lg8 = 8 * (lane >> 4);
+  const void* bpv = BSRC == 1 ? (const void*)(reinterpret_cast<const float*>(Bp) + (long)(lane & 15) * ldb + lg8)
+                              : (const void*)(reinterpret_cast<const __bf16*>(Bp) + (long)(lane & 15) * ldb + lg8);
+  const int col = lane & 15, rsub = 4 * (lane >> 4);
+  const int npass = cdiv(RT, 2 * NW);
   auto loadB = [&](int cg, int k) -> bf16x8 {
-    if (BSRC == 0) return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(bpv) + (long)(cg0 + cg) * cgstride + k * 32);
+    if (BSRC != 1) return *reinterpret_cast<const bf16x8*>(reinterpret_cast<const __bf16*>(bpv) + (long)cg * cgstride + k * 32);
     int off = k * 32;
-    if (off + lg8 + 8 > kin) off = kin - 8 - lg8;
-    const float* p = reinterpret_cast<const float*>(bpv) + (long)(cg0 + cg) * cgstride + off;
+    if (off + lg8 + 8 > K) off = K - 8 - lg8;
+    const float* p = reinterpret_cast<const float*>(bpv) + (long)cg * cgstride + off;
     const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
     const bf16x4 bl = to_bf4(lo), bh = to_bf4(hi);
     return bf16x8{bl[0], bl[1], bl[2], bl[3], bh[0], bh[1], bh[2], bh[3]};
   };
-  bf16x8 ra0[PFA], ra1[PFA], rb[PFB][NCG];
-#pragma unroll
-  for (int i = 0; i < PFA; i++) {
-    const int k = min(i, kl);
-    ra0[i] = A0[k * 64];
-    if (NT_ == 2) ra1[i] = A1[k * 64];
-  }
-#pragma unroll
-  for (int i = 0; i < PFB; i++) {
-    const int k = min(i, kl);
-#pragma unroll
-    for (int cg = 0; cg < NCG; cg++) rb[i][cg] = loadB(cg, k);
-  }
-  for (int kg = 0; kg < KG; kg += PFA) {
+  typedef decltype(pre(0, 0, 0)) PreT;
+  bf16x8 ra0[PFA], ra1[PFA];
+  PreT p0[CG], p1[CG], q0[CG], q1[CG];
+  // the loads of pass p that do not depend on the B operand: the first PFA fragments of both tiles and the epilogue's pre() values
+  auto prologue = [&](int p, PreT (&d0)[CG], PreT (&d1)[CG]) {
+    const int rt = 2 * NW * p + wave, rt2 = rt + NW;
+    if (rt >= RT) return;
+    const bf16x8* A0 = A + (size_t)rt * KG * 64;
+    const bf16x8* A1 = A + (size_t)(rt2 < RT ? rt2 : rt) * KG * 64;
 #pragma unroll
     for (int i = 0; i < PFA; i++) {
-      if (kg + i < KG) {
-        const bf16x8 c0 = ra0[i];
-        bf16x8 c1 = c0;
-        if (NT_ == 2) c1 = ra1[i];
-        bf16x8 cb[NCG];
+      const int k = min(i, kl);
+      ra0[i] = A0[k * 64];
+      ra1[i] = A1[k * 64];
+    }
 #pragma unroll
-        for (int cg = 0; cg < NCG; cg++) cb[cg] = rb[i % PFB][cg];
-        const int ka = min(kg + i + PFA, kl), kb = min(kg + i + PFB, kl);
-        ra0[i] = A0[ka * 64];
-        if (NT_ == 2) ra1[i] = A1[ka * 64];
+    for (int cg = 0; cg < CG; cg++) {
+      d0[cg] = pre(rt * 16 + rsub, cg, col);
+      d1[cg] = pre((rt2 < RT ? rt2 : rt) * 16 + rsub, cg, col);
+    }
+  };
+  PROF_T(g0);
+  prologue(0, p0, p1);
+  hook();
+  PROF_T(g1);
+  PROF_ADD(20, g0, g1);
+  for (int p = 0; p < npass; p++) {
+    const int rt = 2 * NW * p + wave, rt2 = rt + NW;
+    const bool va = rt < RT, vb = rt2 < RT;   // wave-uniform
+    PROF_T(g2);
+    f32x4 acc0[CG], acc1[CG];
 #pragma unroll
-        for (int cg = 0; cg < NCG; cg++) rb[i % PFB][cg] = loadB(cg, kb);
+    for (int cg = 0; cg < CG; cg++) acc0[cg] = acc1[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+    if (va) {
+      const bf16x8* A0 = A + (size_t)rt * KG * 64;
+      const bf16x8* A1 = A + (size_t)(vb ? rt2 : rt) * KG * 64;
+      bf16x8 rb[PFB][CG];
 #pragma unroll
-        for (int cg = 0; cg < NCG; cg++) {
-          acc0[cg] = mfma32_b(c0, cb[cg], acc0[cg]);
-          if (NT_ == 2) acc1[cg] = mfma32_b(c1, cb[cg], acc1[cg]);
+      for (int i = 0; i < PFB; i++) {
+        const int k = min(i, kl);
+#pragma unroll
+        for (int cg = 0; cg < CG; cg++) rb[i][cg] = loadB(cg, k);
+      }
+      for (int kg = 0; kg < KG; kg += PFA) {
+#pragma unroll
+        for (int i = 0; i < PFA; i++) {
+          if (kg + i < KG) {
+            const bf16x8 c0 = ra0[i], c1 = ra1[i];
+            bf16x8 cb[CG];
+#pragma unroll
+            for (int cg = 0; cg < CG; cg++) cb[cg] = rb[i % PFB][cg];
+            if (kg + i + PFA < KG) {   // (K wider than the ring: refill in the loop; a 200-wide layer never gets here)
+              ra0[i] = A0[(kg + i + PFA) * 64];
+              ra1[i] = A1[(kg + i + PFA) * 64];
+            }
+            const int kb = min(kg + i + PFB, kl);
+#pragma unroll
+            for (int cg = 0; cg < CG; cg++) rb[i % PFB][cg] = loadB(cg, kb);
+#pragma unroll
+            for (int cg = 0; cg < CG; cg++) {
+              acc0[cg] = mfma32_b(c0, cb[cg], acc0[cg]);
+              if (vb) acc1[cg] = mfma32_b(c1, cb[cg], acc1[cg]);
+            }
+          }
         }
       }
     }
-  }
+#if LDE_PROF
+    asm volatile("" : "+v"(acc0[0][0]));   // (the stamp below waits for the accumulators)
+    asm volatile("s_nop 0" ::: "memory");
+#endif
+    PROF_T(g3);
+    if (p + 1 < npass) prologue(p + 1, q0, q1);   // before this pass's stores
+    if (va) {
 #pragma unroll
-  for (int cg = 0; cg < NCG; cg++) {
-    epi(row_a, cg0 + cg, col, acc0[cg], p0[cg]);
-    if (NT_ == 2 && row_b >= 0) epi(row_b, cg0 + cg, col, acc1[cg], p1[cg]);
+      for (int cg = 0; cg < CG; cg++) {
+        epi(rt * 16 + rsub, cg, col, acc0[cg], p0[cg]);
+        if (vb) epi(rt2 * 16 + rsub, cg, col, acc1[cg], p1[cg]);
+      }
+    }
+#pragma unroll
+    for (int cg = 0; cg < CG; cg++) {
+      p0[cg] = q0[cg];
+      p1[cg] = q1[cg];
+    }
+    PROF_T(g4);
+    PROF_ADD(21, g2, g3);
+    PROF_ADD(22, g3, g4);
+    PROF_ADD(23, g4 - 1, g4);
   }
 }
-
-// Y[R × 16·CG] = M[R×K] · B[K × 16·CG] for one workgroup of 8 waves; M as bf16 K = 32 fragments in global memory (L2-resident).
-// Row tiles are dealt exactly as in chain_gemm.
-template <int CG, int BSRC, class Pre, class Epi>
-__device__ __forceinline__ void chain_gemm_b(const __bf16* __restrict__ gfrag, int R, int K, const void* Bp, int ldb, long cgstride,
-                                             Pre pre, Epi epi) {
-  constexpr int NW = 8;
-  const int lane = threadIdx.x & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int RT = cdiv(R, 16), KG = cdiv(K, 32);
-  const bf16x8* A = reinterpret_cast<const bf16x8*>(gfrag) + lane;
-  const int lg8 = 8 * (lane >> 4);
-  const void* bp = BSRC == 1 ? (const void*)(reinterpret_cast<const float*>(Bp) + (long)(lane & 15) * ldb + lg8)
-                             : (const void*)(reinterpret_cast<const __bf16*>(Bp) + (long)(lane & 15) * ldb + lg8);
-  const int col = lane & 15, rsub = 4 * (lane >> 4);
-  int base = 0;
-  for (; base + 2 * NW <= RT; base += 2 * NW) {
-    const int rt = base + wave, rt2 = rt + NW;
-    chain_mac_b<2, CG, BSRC>(A + (size_t)rt * KG * 64, A + (size_t)rt2 * KG * 64, bp, cgstride, KG, K, lg8, rt * 16 + rsub, rt2 * 16 + rsub, 0,
-                             col, pre, epi);
-  }
-  if (RT - base > NW) {
-    const int rt = base + wave, rt2 = rt + NW;
-    const bool two = rt2 < RT;
-    chain_mac_b<2, CG, BSRC>(A + (size_t)rt * KG * 64, A + (size_t)(two ? rt2 : rt) * KG * 64, bp, cgstride, KG, K, lg8, rt * 16 + rsub,
-                             two ? rt2 * 16 + rsub : -1, 0, col, pre, epi);
-    return;
-  }
-  if (RT - base == NW) {
-    const int rt = base + wave;
-    chain_mac_b<1, CG, BSRC>(A + (size_t)rt * KG * 64, nullptr, bp, cgstride, KG, K, lg8, rt * 16 + rsub, 0, 0, col, pre, epi);
-    return;
-  }
-  const int units = (RT - base) * CG;
-  for (int u = wave; u < units; u += NW) {
-    const int rt = base + u / CG, cg = u % CG;
-    chain_mac_b<1, 1, BSRC>(A + (size_t)rt * KG * 64, nullptr, bp, cgstride, KG, K, lg8, rt * 16 + rsub, 0, cg, col, pre, epi);
-  }
-}
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
 struct ChainFwdArgsB {
   const float* x;
@@ -187,36 +208,47 @@ __device__ __forceinline__ void chain_load_tile_b(const ChainDims& cd, const BfD
   __syncthreads();
 }
 
-// one hidden layer: Y = [Xin +] act(W·Xin + b) into a bf16 LDS panel (and the saved-activation matrices)
-template <int CG, int BSRC>
+// copy the first `rows` features of this tile's columns from a bf16 LDS panel to a [n][rows] matrix in global memory: 16-byte pieces,
+// consecutive lanes on consecutive pieces of a column (fully coalesced); rows % 8 != 0: element-wise
+template <int CG>
+__device__ __forceinline__ void copy_panel_out_b(const __bf16* panel, int ld, int rows, __bf16* dst, long long n0, long long N) {
+  constexpr int NC = 16 * CG;
+  if ((rows & 7) == 0) {
+    const int chunks = rows / 8;
+    for (int e = threadIdx.x; e < NC * chunks; e += 512) {
+      const int c = e / chunks, ch = e - c * chunks;
+      if (n0 + c < N) *reinterpret_cast<bf16x8*>(dst + (size_t)(n0 + c) * rows + 8 * ch) = *reinterpret_cast<const bf16x8*>(panel + c * ld + 8 * ch);
+    }
+  } else {
+    for (int e = threadIdx.x; e < NC * rows; e += 512) {
+      const int c = e / rows, r = e - c * rows;
+      if (n0 + c < N) dst[(size_t)(n0 + c) * rows + r] = panel[c * ld + r];
+    }
+  }
+}
+
+// one hidden layer: Y = [Xin +] act(W·Xin + b) into a bf16 LDS panel; F (skip layers, training): the activation before the addition.
+// Nothing goes to global memory here: the saved-activation matrices are written from the panels, coalesced, by the NEXT product's hook.
+template <int CG, int BSRC, class Hook>
 __device__ __forceinline__ void chain_hidden_layer_b(const ChainDims& cd, const BfDims& bd, int l, const __bf16* fragb, const float* biasc,
-                                                     const void* Xin, int ldx, __bf16* Y, __bf16* svbase, long long n0, long long N) {
+                                                     const void* Xin, int ldx, __bf16* Y, __bf16* F, Hook hook) {
   const MlpDims& dm = cd.dm;
   const int in = dm.sizes[l], out = dm.sizes[l + 1], actk = cd.act[l], skip = BSRC == 1 ? 0 : cd.skip[l], ldh = bd.ldb;
   const float* bias = biasc + dm.bias_lin[l];
   chain_gemm_b<CG, BSRC>(fragb + bf_frag_off(dm, l, false), out, in, Xin, ldx, 16L * ldx, [](int, int, int) { return NoPre{}; },
                          [&](int row0, int cg, int col, f32x4 v, NoPre) {
                            const int c = cg * 16 + col;
-                           f32x4 r;
+                           const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + min(row0, ((out + 3) & ~3) - 4));   // (bias blocks are padded to 4; rows beyond `out` are masked below)
+                           f32x4 r = cact4(actk, v + b4);
 #pragma unroll
-                           for (int q = 0; q < 4; q++) r[q] = row0 + q < out ? cact(actk, v[q] + bias[row0 + q]) : 0.f;
-                           const long long nsv = n0 + c;
-                           const bool dosv = svbase && nsv < N && row0 < out;
-                           __bf16* svp = svbase + (size_t)N * cd.sv_pre[l] + (size_t)nsv * out + row0;
-                           auto put = [&](__bf16* p, const bf16x4& v4) {
-                             if ((out & 3) == 0) *reinterpret_cast<bf16x4*>(p) = v4;
-                             else {
-#pragma unroll
-                               for (int q = 0; q < 4; q++)
-                                 if (row0 + q < out) p[q] = v4[q];
-                             }
-                           };
-                           if (dosv && cd.skip[l]) put(svp + (size_t)N * out, to_bf4(r));   // before the skip addition
-                           if (skip) r += from_bf4(*reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(Xin) + c * ldx + row0));
-                           const bf16x4 rb = to_bf4(r);
-                           if (dosv) put(svp, rb);
-                           *reinterpret_cast<bf16x4*>(Y + c * ldh + row0) = rb;
-                         });
+                           for (int q = 0; q < 4; q++) r[q] = row0 + q < out ? r[q] : 0.f;
+                           if (skip) {
+                             if (F) *reinterpret_cast<bf16x4*>(F + c * ldh + row0) = to_bf4(r);   // before the skip addition
+                             r += from_bf4(*reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(Xin) + c * ldx + row0));
+                           }
+                           *reinterpret_cast<bf16x4*>(Y + c * ldh + row0) = to_bf4(r);
+                         },
+                         hook);
 }
 
 template <int CG>
@@ -225,24 +257,51 @@ __global__ void __launch_bounds__(512) k_chain_forward_b(ChainDims cd, BfDims bd
   constexpr int NC = 16 * CG;
   const MlpDims& dm = cd.dm;
   const int nL = dm.nL, ldh = bd.ldb;
-  __bf16* X0 = reinterpret_cast<__bf16*>(csm);
-  __bf16* H0 = X0 + NC * bd.ld0;
+  // H0 | H1 | [F: pre-skip activations, training with skip layers only] | biases; the input panel lives in H1's space (layer 0 reads it
+  // and writes H0; H1 is first written by layer 1). Its pad rows are zero like every panel's.
+  __bf16* H0 = reinterpret_cast<__bf16*>(csm);
   __bf16* H1 = H0 + NC * ldh;
-  float* biasc = reinterpret_cast<float*>(H1 + NC * ldh);
+  __bf16* X0 = H1;
+  bool any_skip = false;
+  for (int l = 0; l + 1 < nL; l++) any_skip = any_skip || cd.skip[l];
+  __bf16* F = (a.saved && any_skip && bd.fpanel) ? H1 + NC * ldh : nullptr;
+  float* biasc = reinterpret_cast<float*>(H1 + NC * ldh + (bd.fpanel ? NC * ldh : 0));
   int dup;
   const long long n0 = chain_tile_start(cd, NC, a.N, &dup);
-  chain_load_tile_b<CG>(cd, bd, a.x, n0, a.N, X0, biasc, a.Wflat, (NC * bd.ld0 + 2 * NC * ldh) / 8, csm);
+  PROF_T(pc0);
+  chain_load_tile_b<CG>(cd, bd, a.x, n0, a.N, X0, biasc, a.Wflat, (2 * NC * ldh) / 8, csm);
+  PROF_T(pc1);
+  PROF_ADD(0, pc0, pc1);
   const void* Xin = X0;
   int ldx = bd.ld0;
   const float* xg = a.x + (size_t)n0 * dm.sizes[0];   // gx: column c of the tile at xg + c·in
+  // layer l's output panel (and F) go to the saved matrices from the hook of the NEXT product, behind that product's first loads
+  auto save_prev = [&](int l) {   // l: the layer whose panels are complete (−1: none)
+    if (l < 0 || !a.saved) return;
+    const int h = dm.sizes[l + 1];
+    const __bf16* Yl = (l & 1) ? H1 : H0;
+    __bf16* base = a.saved + (size_t)a.N * cd.sv_pre[l];
+    copy_panel_out_b<CG>(Yl, ldh, h, base, n0, a.N);
+    if (cd.skip[l]) {
+      copy_panel_out_b<CG>(F, ldh, h, base + (size_t)a.N * h, n0, a.N);
+      if (l + 2 < nL && cd.skip[l + 1]) __syncthreads();   // the next layer's epilogues write F again
+    }
+  };
   for (int l = 0; l + 1 < nL; l++) {
     __bf16* Y = (l & 1) ? H1 : H0;
-    if (l == 0 && cd.gx) chain_hidden_layer_b<CG, 1>(cd, bd, 0, a.fragb, biasc, xg, dm.sizes[0], Y, a.saved, n0, a.N);
-    else chain_hidden_layer_b<CG, 0>(cd, bd, l, a.fragb, biasc, Xin, ldx, Y, a.saved, n0, a.N);
+    PROF_T(pl0);
+    auto hook = [&]() { save_prev(l - 1); };
+    if (l == 0 && cd.gx) chain_hidden_layer_b<CG, 1>(cd, bd, 0, a.fragb, biasc, xg, dm.sizes[0], Y, F, hook);
+    else chain_hidden_layer_b<CG, 0>(cd, bd, l, a.fragb, biasc, Xin, ldx, Y, F, hook);
+    PROF_T(pl1);
     __syncthreads();
+    PROF_T(pl2);
+    PROF_ADD(2 + 2 * l, pl0, pl1);
+    PROF_ADD(3 + 2 * l, pl1, pl2);
     Xin = Y;
     ldx = ldh;
   }
+  PROF_T(pz0);
   if (a.y) {  // last layer: f32 straight to HBM (y == nullptr: the pullback's own forward pass, which only wants the saved matrices)
     const int l = nL - 1, in = dm.sizes[l], out = dm.sizes[l + 1], actk = cd.act[l];
     const float* bias = biasc + dm.bias_lin[l];
@@ -250,9 +309,8 @@ __global__ void __launch_bounds__(512) k_chain_forward_b(ChainDims cd, BfDims bd
     auto epi_last = [&](int row0, int cg, int col, f32x4 v, NoPre) {
       const long long n = n0 + cg * 16 + col;
       if (n >= a.N || row0 >= out) return;
-      f32x4 r;
-#pragma unroll
-      for (int q = 0; q < 4; q++) r[q] = row0 + q < out ? cact(actk, v[q] + bias[row0 + q]) : 0.f;
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + row0);
+      const f32x4 r = cact4(actk, v + b4);
       float* yp = a.y + (size_t)n * out + row0;
       if (vec) *reinterpret_cast<f32x4*>(yp) = r;
       else {
@@ -262,9 +320,14 @@ __global__ void __launch_bounds__(512) k_chain_forward_b(ChainDims cd, BfDims bd
       }
     };
     auto nopre = [](int, int, int) { return NoPre{}; };
-    if (nL == 1 && cd.gx) chain_gemm_b<CG, 1>(a.fragb + bf_frag_off(dm, l, false), out, in, xg, in, 16L * in, nopre, epi_last);
-    else chain_gemm_b<CG, 0>(a.fragb + bf_frag_off(dm, l, false), out, in, Xin, ldx, 16L * ldx, nopre, epi_last);
-  }
+    auto hook = [&]() { save_prev(nL - 2); };
+    if (nL == 1 && cd.gx) chain_gemm_b<CG, 1>(a.fragb + bf_frag_off(dm, l, false), out, in, xg, in, 16L * in, nopre, epi_last, hook);
+    else chain_gemm_b<CG, 0>(a.fragb + bf_frag_off(dm, l, false), out, in, Xin, ldx, 16L * ldx, nopre, epi_last, hook);
+  } else
+    save_prev(nL - 2);
+  PROF_T(pz1);
+  PROF_ADD(2 + 2 * (nL - 1), pz0, pz1);
+  PROF_ADD(40, pc0, pz1);
 }
 
 struct ChainBwdArgsB {
@@ -329,10 +392,11 @@ __global__ void __launch_bounds__(512) k_chain_backward_b(ChainDims cd, BfDims b
       if (vec && 8 * ch + 8 <= out) {
         const f32x4 g0 = *reinterpret_cast<const f32x4*>(dyp), g1 = *reinterpret_cast<const f32x4*>(dyp + 4);
         const f32x4 f0 = *reinterpret_cast<const f32x4*>(yp), f1 = *reinterpret_cast<const f32x4*>(yp + 4);
+        const f32x4 a0 = cact_grad_out4(actk, f0), a1 = cact_grad_out4(actk, f1);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          d[q] = (__bf16)(g0[q] * cact_grad_out(actk, f0[q]));
-          d[4 + q] = (__bf16)(g1[q] * cact_grad_out(actk, f1[q]));
+          d[q] = (__bf16)(g0[q] * a0[q]);
+          d[4 + q] = (__bf16)(g1[q] * a1[q]);
         }
       } else {
 #pragma unroll
@@ -345,6 +409,12 @@ __global__ void __launch_bounds__(512) k_chain_backward_b(ChainDims cd, BfDims b
 
   // ---- δ down the chain ------------------------------------------------------------------------------------------------
   const __bf16* Dcur = nullptr;   // LDS panel holding δ_l for l < L1
+  int pend = -1;                  // layer whose δ panel still has to be copied to its matrix
+  auto stage_prev = [&]() {
+    if (pend < 0) return;
+    stage_delta_b<CG>(Dcur, ldh, dm.sizes[pend + 1], a.dstage + (size_t)a.N * bd.dl_off[pend], bd.dl_w[pend], n0, a.N);
+    pend = -1;
+  };
   for (int l = L1; l >= 0; l--) {
     const int in = dm.sizes[l], out = dm.sizes[l + 1];
     const int skl = cd.skip[l];
@@ -376,16 +446,16 @@ __global__ void __launch_bounds__(512) k_chain_backward_b(ChainDims cd, BfDims b
         f32x4 g = v;
         if (skl) g += *reinterpret_cast<const f32x4*>(G + c * ldg + row0);
         if (skp) *reinterpret_cast<f32x4*>(G + c * ldg + row0) = g;   // layer l-1 adds it back to what flows through it
-        f32x4 d;
+        f32x4 d = cact_grad_out4(actp, p.h);
 #pragma unroll
-        for (int q = 0; q < 4; q++) d[q] = row0 + q < in ? g[q] * cact_grad_out(actp, p.h[q]) : 0.f;
+        for (int q = 0; q < 4; q++) d[q] = row0 + q < in ? g[q] * d[q] : 0.f;
         *reinterpret_cast<bf16x4*>(Dn + c * ldh + row0) = to_bf4(d);
       };
-      if (l == L1) chain_gemm_b<CG, 0>(fragT, in, out, Bglb, bd.dl_w[l], 16L * bd.dl_w[l], pre, epi);
-      else chain_gemm_b<CG, 0>(fragT, in, out, Dcur, ldh, 16L * ldh, pre, epi);
+      if (l == L1) chain_gemm_b<CG, 2>(fragT, in, out, Bglb, bd.dl_w[l], 16L * bd.dl_w[l], pre, epi, stage_prev);
+      else chain_gemm_b<CG, 0>(fragT, in, out, Dcur, ldh, 16L * ldh, pre, epi, stage_prev);
       __syncthreads();
-      stage_delta_b<CG>(Dn, ldh, in, a.dstage + (size_t)a.N * bd.dl_off[l - 1], bd.dl_w[l - 1], n0, a.N);
       Dcur = Dn;
+      pend = l - 1;   // δ_{l-1} is complete in Dn: it goes to its matrix from the next product's hook (behind that product's first loads)
     } else if (a.dx) {
       auto pre = [](int, int, int) { return NoPre{}; };
       auto epi = [&](int row0, int cg, int col, f32x4 v, NoPre) {
@@ -399,10 +469,11 @@ __global__ void __launch_bounds__(512) k_chain_backward_b(ChainDims cd, BfDims b
             if (row0 + q < in) a.dx[(size_t)n * in + row0 + q] = g[q];
         }
       };
-      if (l == L1) chain_gemm_b<CG, 0>(fragT, in, out, Bglb, bd.dl_w[l], 16L * bd.dl_w[l], pre, epi);
-      else chain_gemm_b<CG, 0>(fragT, in, out, Dcur, ldh, 16L * ldh, pre, epi);
+      if (l == L1) chain_gemm_b<CG, 2>(fragT, in, out, Bglb, bd.dl_w[l], 16L * bd.dl_w[l], pre, epi, stage_prev);
+      else chain_gemm_b<CG, 0>(fragT, in, out, Dcur, ldh, 16L * ldh, pre, epi, stage_prev);
     }
   }
+  stage_prev();   // (no product followed the last δ: the input gradient was not asked for)
 }
 
 // ---- weight gradient: gW_lᵀ[i][o] = Σ_n a_l[i,n] δ_l[o,n] over [n][feature] matrices, transposing LDS reads ---------------------------
@@ -424,12 +495,13 @@ struct DwArgsB {
 __host__ __device__ inline int tr_stride_bytes(int feats) {   // row stride of an image of `feats` bf16 features: smallest ≥ 2·feats that is ≡ 64 (mod 128)
   return ((2 * feats + 63) / 128) * 128 + 64;
 }
+constexpr int DWB_NK = 64;   // rows of n per chunk of k_chain_dw_b: a chunk's MFMA work (4 K-steps) against one global round trip
 // LDS bytes of k_chain_dw_b: the widest job's two images
 inline size_t dw_b_lds_bytes(const MlpDims& dm, int ndw) {
   size_t mx = 0;
   for (int z = 0, n = dw_jobs(dm, ndw); z < n; z++) {
     const DwJob j = dw_decode(dm, z, 8 * ndw);
-    mx = std::max(mx, (size_t)32 * (tr_stride_bytes(32 * (j.i1 - j.i0)) + tr_stride_bytes(32 * (j.o1 - j.o0))));
+    mx = std::max(mx, (size_t)DWB_NK * (tr_stride_bytes(32 * (j.i1 - j.i0)) + tr_stride_bytes(32 * (j.o1 - j.o0))));
   }
   return mx;
 }
@@ -437,7 +509,7 @@ inline size_t dw_b_lds_bytes(const MlpDims& dm, int ndw) {
 template <int DW_NDW>
 __global__ void __launch_bounds__(512) k_chain_dw_b(ChainDims cd, BfDims bd, DwArgsB a) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
-  constexpr int NK = 32;
+  constexpr int NK = DWB_NK;
   const MlpDims& dm = cd.dm;
   const int part = blockIdx.x, KS = gridDim.x;
   const DwJob jb = dw_decode(dm, blockIdx.y, 8 * DW_NDW);
@@ -464,7 +536,6 @@ __global__ void __launch_bounds__(512) k_chain_dw_b(ChainDims cd, BfDims bd, DwA
     aoff[m] = t < ntile ? lrow * sa + 2 * (itl * 32 + lfeat) : -1;
     doff[m] = lrow * sd + 2 * (otl * 32 + lfeat);
   }
-  const bool do_bias = jb.i0 == 0;
   float bsum[2] = {0.f, 0.f};
   // the operands' matrices in global memory: a_l rows of width aw, δ_l rows of width dw
   const bool a_f32 = l == 0;
@@ -474,18 +545,90 @@ __global__ void __launch_bounds__(512) k_chain_dw_b(ChainDims cd, BfDims bd, DwA
   const int dw = bd.dl_w[l];
   const bool avec = (aw & 7) == 0;
   const long long nchunks = (a.N + NK - 1) / NK;
+  // The next chunk's first PQ pieces per thread and image travel into registers while the current chunk is multiplied (a piece = 16
+  // bytes = 8 features of one n). Every load is UNCONDITIONAL, from a clamped (always valid) address — a load under a lane condition is
+  // waited for where the branches merge, i.e. right where it was issued (in-kernel stamps: 2 760 cycles per chunk "issuing" the next
+  // chunk's loads) — and the zero padding (rows beyond N, features beyond the layer) is applied when the piece is stored to LDS. An f32
+  // source (x) needs two 16-byte loads per piece and is rounded at store time; a bf16 source issues the second load at the same address.
+  constexpr int PQ = 4;
+  const int apr = na / 8, dpr = nd / 8, npa = NK * apr, npd = NK * dpr;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 qlo[PQ], qhi[PQ], qdl[PQ];
+  const char* abase = a_f32 ? reinterpret_cast<const char*>(a.x) : reinterpret_cast<const char*>(ab);
+  const int aes = a_f32 ? 4 : 2;                                   // bytes per element of the a source
+  const int flast = in >= 8 ? in - 8 : 0, dflast = dw - 8;
+  // per-thread piece geometry, fixed over the chunks (two integer divisions per piece: ≈ 1 300 cycles per chunk when they sat in the loop)
+  int pa_r[PQ], pa_c8[PQ], pd_r[PQ], pd_c8[PQ];
+  size_t pa_off[PQ], pd_off[PQ];
+#pragma unroll
+  for (int i = 0; i < PQ; i++) {
+    const int e = tid + 512 * i;
+    const int ea = min(e, npa - 1), ed = min(e, npd - 1);
+    pa_r[i] = ea / apr;
+    pa_c8[i] = ea - pa_r[i] * apr;
+    pd_r[i] = ed / dpr;
+    pd_c8[i] = ed - pd_r[i] * dpr;
+    pa_off[i] = (size_t)min(ra0 + 8 * pa_c8[i], flast) * aes;
+    pd_off[i] = (size_t)min(rd0 + 8 * pd_c8[i], dflast) * 2;
+  }
+  const size_t arow_b = (size_t)aw * aes, drow_b = (size_t)dw * 2;
+  auto fetch = [&](long long chn) {
+    const long long nb = chn * NK;
+#pragma unroll
+    for (int i = 0; i < PQ; i++) {
+      // (a width that is not a multiple of 8 takes the element-wise path below: its prefetch loads are aimed at valid δ bytes and unused)
+      const char* p = avec ? abase + (size_t)min(nb + pa_r[i], a.N - 1) * arow_b + pa_off[i] : reinterpret_cast<const char*>(db);
+      const char* p2 = p + ((a_f32 && avec) ? 16 : 0);
+      asm volatile("" : "+v"(p2));   // (opaque: with a visible "p2 == p" the compiler turns the second load into a conditional COPY of the first — and waits for it here)
+      qlo[i] = *reinterpret_cast<const f32x4*>(p);
+      qhi[i] = *reinterpret_cast<const f32x4*>(p2);
+      qdl[i] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(db) + (size_t)min(nb + pd_r[i], a.N - 1) * drow_b + pd_off[i]);
+    }
+  };
+  // the bias gradient for free: the first pad feature of the a image (feature index `in`, present when in is not a multiple of 32) is set
+  // to 1 for every n < N — row `in` of gWᵀ's last input tile then accumulates Σ_n δ_l[o,n]
+  const bool ones_row = (in & 31) != 0;
+  const bool do_bias_sum = !ones_row && jb.i0 == 0;                // explicit column sums only when there is no pad row
+  const bool do_bias_row = ones_row && jb.i1 == IT;
+  if (part < nchunks) fetch(part);
   for (long long ch = part; ch < nchunks; ch += KS) {
     const long long nb = ch * NK;
-    // ---- copy the chunk: 16-byte pieces (8 features of one n); rows beyond N and features beyond the layer are zeros
-    for (int e = tid; e < NK * (na / 8); e += 512) {
-      const int r = e / (na / 8), c8 = e - r * (na / 8);
+    PROF_T(d0);
+    // ---- the chunk into LDS: 16-byte pieces; rows beyond N and features beyond the layer are zeros
+#pragma unroll
+    for (int i = 0; i < PQ; i++) {
+      const int e = tid + 512 * i;
+      if (avec && e < npa) {
+        const int r = pa_r[i], c8 = pa_c8[i], f = ra0 + 8 * c8;
+        const bool ok = nb + r < a.N && f < in;
+        f32x4 v = qlo[i];
+        if (a_f32) {
+          const bf16x4 lo = to_bf4(qlo[i]), hi = to_bf4(qhi[i]);
+          v = __builtin_bit_cast(f32x4, bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]});
+        }
+        v = ok ? v : z4;
+        if (ones_row && f == (in & ~7) && nb + r < a.N) {   // (in % 8 == 0 here: the piece [in, in + 8) is all padding)
+          bf16x8 o = __builtin_bit_cast(bf16x8, z4);
+          o[0] = (__bf16)1.0f;
+          v = __builtin_bit_cast(f32x4, o);
+        }
+        *reinterpret_cast<f32x4*>(ia + r * sa + 16 * c8) = v;
+      }
+      if (e < npd) {
+        const int r = pd_r[i], c8 = pd_c8[i];
+        const bool ok = nb + r < a.N && rd0 + 8 * c8 < dw;
+        *reinterpret_cast<f32x4*>(id + r * sd + 16 * c8) = ok ? qdl[i] : z4;
+      }
+    }
+    for (int e = tid + (avec ? 512 * PQ : 0); e < npa; e += 512) {   // wider jobs' remaining pieces, and every piece of a layer whose width is not a multiple of 8
+      const int r = e / apr, c8 = e - r * apr;
       const long long n = nb + r;
       const int f = ra0 + 8 * c8;
       bf16x8 v = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
       if (n < a.N && f < in) {
         if (a_f32) {
           const float* xp = a.x + (size_t)n * aw + f;
-          if (avec && f + 8 <= in) {
+          if (avec) {
             const bf16x4 lo = to_bf4(*reinterpret_cast<const f32x4*>(xp)), hi = to_bf4(*reinterpret_cast<const f32x4*>(xp + 4));
             v = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
           } else {
@@ -495,7 +638,7 @@ __global__ void __launch_bounds__(512) k_chain_dw_b(ChainDims cd, BfDims bd, DwA
           }
         } else {
           const __bf16* hp = ab + (size_t)n * aw + f;
-          if (avec && f + 8 <= in) v = *reinterpret_cast<const bf16x8*>(hp);
+          if (avec) v = *reinterpret_cast<const bf16x8*>(hp);
           else {
 #pragma unroll
             for (int q = 0; q < 8; q++)
@@ -503,17 +646,22 @@ __global__ void __launch_bounds__(512) k_chain_dw_b(ChainDims cd, BfDims bd, DwA
           }
         }
       }
+      if (ones_row && n < a.N && f <= in && in < f + 8) v[in - f] = (__bf16)1.0f;
       *reinterpret_cast<bf16x8*>(ia + r * sa + 16 * c8) = v;
     }
-    for (int e = tid; e < NK * (nd / 8); e += 512) {
-      const int r = e / (nd / 8), c8 = e - r * (nd / 8);
+    for (int e = tid + 512 * PQ; e < npd; e += 512) {
+      const int r = e / dpr, c8 = e - r * dpr;
       const long long n = nb + r;
       const int f = rd0 + 8 * c8;
-      bf16x8 v = {(__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f, (__bf16)0.f};
-      if (n < a.N && f < dw) v = *reinterpret_cast<const bf16x8*>(db + (size_t)n * dw + f);   // (pad entries of a row are zeros)
-      *reinterpret_cast<bf16x8*>(id + r * sd + 16 * c8) = v;
+      f32x4 v = z4;
+      if (n < a.N && f < dw) v = *reinterpret_cast<const f32x4*>(db + (size_t)n * dw + f);
+      *reinterpret_cast<f32x4*>(id + r * sd + 16 * c8) = v;
     }
+    PROF_T(d1);
     __syncthreads();
+    PROF_T(d2);
+    if (ch + KS < nchunks) fetch(ch + KS);
+    PROF_T(d3);
 #pragma unroll
     for (int m = 0; m < DW_NDW; m++) {
       if (aoff[m] >= 0) {   // wave-uniform: EXEC stays all ones for the transposing reads
@@ -533,7 +681,11 @@ __global__ void __launch_bounds__(512) k_chain_dw_b(ChainDims cd, BfDims bd, DwA
         }
       }
     }
-    if (do_bias) {
+#if LDE_PROF
+    asm volatile("" : "+v"(acc[0][0]));
+#endif
+    PROF_T(d4);
+    if (do_bias_sum) {
 #pragma unroll
       for (int q = 0; q < 2; q++) {
         const int row = tid + 512 * q;
@@ -545,7 +697,16 @@ __global__ void __launch_bounds__(512) k_chain_dw_b(ChainDims cd, BfDims bd, DwA
         }
       }
     }
+    PROF_T(d5);
     __syncthreads();
+    PROF_T(d6);
+    PROF_ADD(50, d0, d1);   // registers → LDS (waits for the prefetched loads)
+    PROF_ADD(51, d1, d2);   // barrier
+    PROF_ADD(52, d2, d3);   // next chunk's loads issued
+    PROF_ADD(53, d3, d4);   // transposing reads + MFMA
+    PROF_ADD(54, d4, d5);   // bias sums
+    PROF_ADD(55, d5, d6);   // barrier
+    PROF_ADD(56, d6 - 1, d6);
   }
   float* slab = a.slab + (size_t)part * dm.slab_n;
 #pragma unroll
@@ -561,9 +722,16 @@ __global__ void __launch_bounds__(512) k_chain_dw_b(ChainDims cd, BfDims bd, DwA
         v[0] = acc[m][4 * q + 0]; v[1] = acc[m][4 * q + 1]; v[2] = acc[m][4 * q + 2]; v[3] = acc[m][4 * q + 3];
         g4[q] = v;
       }
+      if (do_bias_row && jb.i0 + itl == IT - 1) {   // row `in` of the last input tile = the bias gradient of this tile's 32 outputs
+        const int r = in & 31, reg = (r & 3) + 4 * (r >> 3), o = (jb.o0 + otl) * 32 + (lane & 31);
+        float bv = 0.f;
+#pragma unroll
+        for (int rr = 0; rr < 16; rr++) bv = rr == reg ? acc[m][rr] : bv;
+        if ((lane >> 5) == ((r >> 2) & 1) && o < out) slab[(size_t)dm.tile_off[dm.nL] * 1024 + dm.bias_lin[l] + o] = bv;
+      }
     }
   }
-  if (do_bias) {
+  if (do_bias_sum) {
 #pragma unroll
     for (int q = 0; q < 2; q++) {
       const int row = tid + 512 * q;

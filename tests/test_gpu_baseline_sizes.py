@@ -157,61 +157,51 @@ def test_coupled_solve_while_another_stream_keeps_the_gpu_busy(o32):
     assert np.array_equal(z_idle, z_busy) and np.array_equal(g_idle[0], g_busy[0]) and np.array_equal(g_idle[2], g_busy[2])
 
 
-def test_c3_full_batch_1024_tight_tolerance(o32, o64):
-    """c3 at B = 1024 with abstol = reltol = 1e-6: both f32 solves are then ≈ 1e-6 from the truth, so the parity gate can be the north
-    star's own — |ẑ_HIP − ẑ_oracle| ≤ 1e-4 on every column (measured ≈ 1e-5) — and the gradients are gated at 1e-3 of their scale
-    against the f32 oracle AND against float64 (at the default tolerance, above, a relu network under the adaptive controller only
-    allows 1e-2: a 1 % gradient bug would pass there, not here)."""
-    layers = (2, 64, 64, 2)
-    W = O.mlp_weights(layers, seed=3)
-    kw = dict(rhs_kind=O.RHS_PENDULUM_PLUS_MLP, layers=layers, abstol=1e-6, reltol=1e-6)
+TIGHT = {
+    # name: (desc kwargs, B, D, pendulum inputs?, gates (z vs oracle, z vs f64, grads vs oracle, grads vs f64) in units of the scale)
+    # Measured (abl/c3_tight.py, MI355X): the tanh networks — smooth right-hand sides, the solver's order holds — agree to 3e-6 in ẑ and
+    # 5e-7 in every gradient between kernel, f32 oracle and float64: the gates below are 1e-5, so a 1 % gradient bug cannot pass. The relu
+    # networks of the configs do not converge with the tolerance: every kink crossing costs O(h) locally whatever reltol says, and BOTH f32
+    # solves sit 1.5e-4 (c3) / 1.6e-5 (c4) from float64 with gradients 2–4e-3 / 1.2e-3 off; the gates are those levels, plus "no farther
+    # from float64 than 1.5× the oracle".
+    "c3_relu": (dict(rhs_kind=O.RHS_PENDULUM_PLUS_MLP, layers=(2, 64, 64, 2)), 1024, 2, True, (5e-4, 5e-4, 1e-2, 1e-2)),
+    "c3_tanh": (dict(rhs_kind=O.RHS_PENDULUM_PLUS_MLP, layers=(2, 64, 64, 2), activation=O.ACT_TANH), 1024, 2, True, (2e-5, 2e-5, 1e-5, 1e-5)),
+    "c4_relu": (dict(rhs_kind=O.RHS_MLP, state_dim=32, param_dim=0, layers=(32, 128, 128, 32), batching=O.BATCH_COUPLED), 512, 32, False,
+                (1e-5, 1e-4, 5e-3, 5e-3)),
+    "c4_tanh": (dict(rhs_kind=O.RHS_MLP, state_dim=32, param_dim=0, layers=(32, 128, 128, 32), batching=O.BATCH_COUPLED,
+                     activation=O.ACT_TANH), 512, 32, False, (1e-5, 1e-5, 1e-5, 1e-5)),
+}
+
+
+@pytest.mark.parametrize("case", sorted(TIGHT))
+def test_full_batch_tight_tolerance(case, o32, o64):
+    """c3 (B = 1024, per-trajectory control) and c4 (B = 512, one coupled solve) at abstol = reltol = 1e-6, every column, forward and
+    adjoint, against the f32 oracle and against float64 — with the configs' relu networks and with the same shapes on tanh."""
+    kw, B, D, pend, (gz, gz64, gg, gg64) = TIGHT[case]
+    kw = {**kw, "abstol": 1e-6, "reltol": 1e-6}
+    W = O.mlp_weights(kw["layers"], seed=3)
     nat, od = _native(W, **kw)
-    B, T = 1024, 50
-    z0, L = O.pendulum_inputs(B)
+    T = 50
+    if pend:
+        z0, L = O.pendulum_inputs(B)
+    else:
+        z0, L = _z0(B, D), None
     ts = O.time_grid(T)
-    dz = O.cotangent(T, B, 2)
+    dz = O.cotangent(T, B, D)
     z, ret, st = nat.forward(z0, L, ts)
     g0, gL, gW, sb = nat.adjoint(z, L, ts, dz)
     assert (ret == 0).all() and st["nfailed"] == 0 and sb["nfailed"] == 0
     zr, _, _ = o32.forward(od, z0, L, ts, W=W, nthreads=NT)
     r0, rL, rW, _ = o32.adjoint(od, z, L, ts, dz, W=W, nthreads=NT)
-    scale = max(1.0, np.abs(zr).max())
-    assert np.abs(z - zr).max() <= 1e-4 * scale, np.abs(z - zr).max()
-    assert _rel(g0, r0) <= 1e-3 and _rel(gL, rL) <= 1e-3 and _rel(gW, rW) <= 1e-3, (_rel(g0, r0), _rel(gL, rL), _rel(gW, rW))
-    sub = np.arange(0, B, 16)
     d64 = O.make_desc(**{**kw, "abstol": 1e-11, "reltol": 1e-11})
     W64 = W.astype(np.float64)
-    z64, _, _ = o64.forward(d64, z0[sub], L[sub], ts, W=W64, nthreads=NT)
-    t0, tL, _, _ = o64.adjoint(d64, z64, L[sub], ts, dz[:, sub], W=W64, nthreads=NT)
-    assert np.abs(z[:, sub] - z64).max() <= 1e-4 * scale
-    assert _rel(g0[sub], t0) <= 1e-3 and _rel(gL[sub], tL) <= 1e-3, (_rel(g0[sub], t0), _rel(gL[sub], tL))
-    # the weight gradient against float64 on the WHOLE batch (a sum over all 1024 trajectories)
-    z64a, _, _ = o64.forward(d64, z0, L, ts, W=W64, nthreads=NT)
-    _, _, tW, _ = o64.adjoint(d64, z64a, L, ts, dz, W=W64, nthreads=NT)
-    assert _rel(gW, tW) <= 1e-3, _rel(gW, tW)
-
-
-def test_c4_coupled_512_tight_tolerance(o32, o64):
-    """c4 (one GPU's share, B = 512, one coupled solve) at abstol = reltol = 1e-6: ẑ within 1e-4 of the f32 oracle and of float64,
-    gradients within 1e-3 of both."""
-    layers = (32, 128, 128, 32)
-    W = O.mlp_weights(layers, seed=3)
-    kw = dict(rhs_kind=O.RHS_MLP, state_dim=32, param_dim=0, layers=layers, batching=O.BATCH_COUPLED, abstol=1e-6, reltol=1e-6)
-    nat, od = _native(W, **kw)
-    B, T = 512, 50
-    z0, ts = _z0(B, 32), O.time_grid(T)
-    dz = O.cotangent(T, B, 32)
-    z, ret, st = nat.forward(z0, None, ts)
-    g0, _, gW, sb = nat.adjoint(z, None, ts, dz)
-    assert (ret == 0).all() and st["nfailed"] == 0 and sb["nfailed"] == 0
-    zr, _, _ = o32.forward(od, z0, None, ts, W=W, nthreads=NT)
-    r0, _, rW, _ = o32.adjoint(od, z, None, ts, dz, W=W, nthreads=NT)
+    z64, _, _ = o64.forward(d64, z0, L, ts, W=W64, nthreads=NT)
+    t0, tL, tW, _ = o64.adjoint(d64, z64, L, ts, dz, W=W64, nthreads=NT)
     scale = max(1.0, np.abs(zr).max())
-    assert np.abs(z - zr).max() <= 1e-4 * scale, np.abs(z - zr).max()
-    assert _rel(g0, r0) <= 1e-3 and _rel(gW, rW) <= 1e-3, (_rel(g0, r0), _rel(gW, rW))
-    d64 = O.make_desc(**{**kw, "abstol": 1e-10, "reltol": 1e-10})
-    W64 = W.astype(np.float64)
-    z64, _, _ = o64.forward(d64, z0, None, ts, W=W64, nthreads=NT)
-    t0, _, tW, _ = o64.adjoint(d64, z64, None, ts, dz, W=W64, nthreads=NT)
-    assert np.abs(z - z64).max() <= 1e-4 * scale
-    assert _rel(g0, t0) <= 1e-3 and _rel(gW, tW) <= 1e-3, (_rel(g0, t0), _rel(gW, tW))
+    e_k, e_o = np.abs(z - z64).max(), np.abs(zr - z64).max()
+    assert np.abs(z - zr).max() <= gz * scale, np.abs(z - zr).max()
+    assert e_k <= gz64 * scale and e_k <= 1.5 * e_o + 1e-5 * scale, (e_k, e_o)
+    pairs = [(g0, r0, t0, "dz0"), (gW, rW, tW, "dW")] + ([(gL, rL, tL, "dL")] if pend else [])
+    for g, r, t, what in pairs:
+        assert _rel(g, r) <= gg, (what, _rel(g, r))
+        assert _rel(g, t) <= gg64 and _rel(g, t) <= 1.5 * _rel(r, t) + 0.2 * gg64, (what, _rel(g, t), _rel(r, t))

@@ -62,7 +62,13 @@ enum lde_solver {
 
 enum lde_batching {
   LDE_BATCH_PER_TRAJECTORY = 0,   /* B independent solves, own dt each: EnsembleProblem  [REF GOKU.jl:111-121] */
-  LDE_BATCH_COUPLED        = 1    /* one solve on the [D'×B] matrix state, shared dt, RMS norm over D'·B: NeuralODE [REF LatentODE.jl:70-72] */
+  LDE_BATCH_COUPLED        = 1,   /* one solve on the [D'×B] matrix state, shared dt, RMS norm over D'·B: NeuralODE [REF LatentODE.jl:70-72] */
+  LDE_BATCH_COUPLED_GLOBAL = 2    /* the same ONE solve with its batch SHARDED over ranks (SURVEY.md §8e option (ii)): this handle integrates its
+                                     rank's columns, and every sum of the step control — the two Hairer initial-step norms and each attempt's
+                                     Σr² — is the sum over ALL ranks' columns, exchanged through lde_set_global_sum_hook. Results equal the
+                                     unsharded LDE_BATCH_COUPLED solve up to summation order. A parity mode: lde_forward / lde_adjoint are
+                                     SYNCHRONOUS in it (the host services the exchange while the kernel runs). Three-layer MLP right-hand
+                                     sides served by the register kernels (2·D' ≤ 64, H ≤ 200); otherwise LDE_ERR_UNSUPPORTED. */
 };
 
 enum lde_sensealg {
@@ -181,6 +187,16 @@ int lde_adjoint(lde_handle* h, const float* z_out, const float* theta,
 /* Solver statistics of the most recent lde_forward (which=0) or lde_adjoint (which=1) on this
  * handle. Synchronises `stream`. */
 int lde_get_stats(lde_handle* h, int which, lde_stats* out, void* stream);
+
+/* LDE_BATCH_COUPLED_GLOBAL: the exchange of the step-control sums between the ranks that share ONE coupled solve
+ * [REF src/models/LatentODE.jl:70-72: the reference's NeuralODE norm runs over the whole [D'×B] state — here B is spread over ranks].
+ * `hook(user, vals, n)` must replace vals[0..n) (n = 1 or 2, f64) by their sums over all ranks and return 0; every rank calls it
+ * the same number of times in the same order (the decisions that follow are functions of the sums, hence identical everywhere). It
+ * is called on the thread that called lde_forward / lde_adjoint, while the solve's kernel waits for the answer — use a HOST
+ * collective (MPI, gloo, a pipe): the device is occupied. `global_batch` = Σ over ranks of their B (the norm's divisor).
+ * hook == NULL clears it (the mode then equals LDE_BATCH_COUPLED on this rank's columns). */
+typedef int (*lde_sum_hook)(void* user, double* vals, int n);
+int lde_set_global_sum_hook(lde_handle* h, lde_sum_hook hook, void* user, int64_t global_batch);
 
 /* Human-readable text for the last error on this handle (never NULL). */
 const char* lde_last_error(const lde_handle* h);

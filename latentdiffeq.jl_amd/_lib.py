@@ -17,7 +17,7 @@ LDE_MAX_LAYERS = 6
 
 RHS_PENDULUM, RHS_PENDULUM_FRICTION, RHS_MLP, RHS_PENDULUM_PLUS_MLP = 0, 1, 2, 3
 SOLVER_TSIT5, SOLVER_RK4 = 0, 1
-BATCH_PER_TRAJECTORY, BATCH_COUPLED = 0, 1
+BATCH_PER_TRAJECTORY, BATCH_COUPLED, BATCH_COUPLED_GLOBAL = 0, 1, 2
 SENSE_BACKSOLVE_CHECKPOINTED, SENSE_BACKSOLVE, SENSE_PARALLEL_CHECKPOINTED = 0, 1, 2
 ACT_RELU, ACT_TANH = 0, 1
 
@@ -27,7 +27,7 @@ STATUS = {0: "LDE_OK", -1: "LDE_ERR_INVALID_ARG", -2: "LDE_ERR_UNSUPPORTED", -3:
 # every symbol include/lde.h declares
 EXPORTS = ["lde_abi_version", "lde_problem_desc_default", "lde_num_weights", "lde_create", "lde_destroy",
            "lde_set_weights", "lde_set_weights_device", "lde_reserve", "lde_forward", "lde_adjoint",
-           "lde_get_stats", "lde_last_error",
+           "lde_get_stats", "lde_last_error", "lde_set_global_sum_hook",
            "lde_chain_num_weights", "lde_chain_create", "lde_chain_destroy", "lde_chain_set_weights",
            "lde_chain_set_weights_device", "lde_chain_reserve", "lde_chain_forward", "lde_chain_backward",
            "lde_chain_last_error", "lde_chain_set_accumulate", "lde_chain_set_dtype", "lde_rnn_set_accumulate", "lde_chain_saved_floats", "lde_chain_forward_save", "lde_chain_backward_saved",
@@ -37,6 +37,8 @@ EXPORTS = ["lde_abi_version", "lde_problem_desc_default", "lde_num_weights", "ld
            "lde_mse_backward", "lde_sample_kl_forward", "lde_sample_kl_backward", "lde_mse_forward_add", "lde_adamw_flux_step", "lde_set_dw_stream", "lde_join_dw",
            "lde_comm_unique_id", "lde_comm_init", "lde_comm_allreduce_f32", "lde_comm_nranks", "lde_comm_rank",
            "lde_comm_destroy", "lde_comm_last_error"]
+# lde_sum_hook: int hook(void* user, double* vals, int n) — vals[0..n) ← Σ over ranks, in place
+SUM_HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
 COMM_ID_BYTES = 128
 LOSS_SCRATCH_FLOATS = 1024
 
@@ -116,6 +118,8 @@ def load():
     lib.lde_forward.argtypes = [vp, vp, vp, C.POINTER(C.c_double), i32, i32, vp, vp, vp]
     lib.lde_adjoint.argtypes = [vp, vp, vp, C.POINTER(C.c_double), i32, i32, vp, vp, vp, vp, vp]
     lib.lde_get_stats.argtypes = [vp, i32, C.POINTER(Stats), vp]
+    lib.lde_set_global_sum_hook.argtypes = [vp, SUM_HOOK, vp, C.c_int64]
+    lib.lde_set_global_sum_hook.restype = C.c_int
     lib.lde_last_error.argtypes = [vp]
     lib.lde_last_error.restype = C.c_char_p
     lib.lde_chain_num_weights.argtypes = [C.POINTER(ChainDesc)]

@@ -209,6 +209,9 @@ class NODE:
 
     `batching="coupled"` (default) is the NeuralODE semantics: one solve on the [D'×B] matrix state with a
     shared step size and an RMS error norm over all D'·B entries [REF src/models/LatentODE.jl:70-72].
+    `batching="coupled_global"`: the same ONE solve with its batch sharded over ranks — this rank integrates its columns and the
+    sums of the step control run over all ranks' columns through `set_global_sum(fn, global_batch)` (SURVEY.md §8e option (ii):
+    the parity mode; `dist.global_sum_hook()` builds `fn` from a torch.distributed HOST group). Calls are synchronous in this mode.
     """
 
     def __init__(self, latent_dim_in: int, hidden_dim: int = 200, augment_dim: int = 0, device=None,
@@ -232,8 +235,10 @@ class NODE:
         self.augment_dim = augment_dim
         self.kwargs = kwargs
         self.layer_sizes = sizes
-        self.batching = {"coupled": L.BATCH_COUPLED, "per_trajectory": L.BATCH_PER_TRAJECTORY}[batching]
+        self.batching = {"coupled": L.BATCH_COUPLED, "per_trajectory": L.BATCH_PER_TRAJECTORY,
+                         "coupled_global": L.BATCH_COUPLED_GLOBAL}[batching]
         self._handle: Optional[_Handle] = None
+        self._sum_cb = None
 
     _rhs_kind = L.RHS_MLP
 
@@ -245,6 +250,25 @@ class NODE:
                            sa, self.batching, self.kwargs)
             self._handle = _Handle(d)
         return self._handle
+
+    def set_global_sum(self, fn, global_batch: int):
+        """lde_set_global_sum_hook: `fn(vals: numpy float64 array of 1 or 2 entries)` replaces the entries in place by their sums
+        over all ranks (a HOST collective — the device is busy with the solve). `fn=None` clears the hook."""
+        import numpy as np
+        lib = L.load()
+        h = self._native()
+        if fn is None:
+            cb = L.SUM_HOOK(0)
+        else:
+            def _cb(_user, vals, n):
+                try:
+                    fn(np.ctypeslib.as_array(vals, shape=(n,)))
+                    return 0
+                except Exception:      # noqa: BLE001  (an exception must not unwind through the C frame)
+                    return 1
+            cb = L.SUM_HOOK(_cb)
+        L.check(lib.lde_set_global_sum_hook(h.ptr, cb, None, int(global_batch)), h.ptr, "lde_set_global_sum_hook")
+        self._sum_cb = cb              # keep the trampoline alive as long as the handle uses it
 
     def flat_weights(self) -> torch.Tensor:
         """Flux.destructure order: per Dense layer vec(W) column-major [out×in], then b."""

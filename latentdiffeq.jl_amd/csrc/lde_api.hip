@@ -33,6 +33,7 @@ struct MlpPlan;
 int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err);
 void mlp_plan_destroy(MlpPlan* p);
 int mlp_reserve(MlpPlan* p, int B, int T, std::string& err);
+int mlp_set_sum_hook(MlpPlan* p, lde_sum_hook hook, void* user, int64_t global_batch, std::string& err);
 int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::string& err);
 int mlp_set_weights(MlpPlan* p, const float* W_dev, hipStream_t stream, std::string& err);
 int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* theta, const double* ts_dev,
@@ -106,7 +107,9 @@ static int validate(const lde_problem_desc* d, std::string* why) {
     if (d->activation != LDE_ACT_RELU && d->activation != LDE_ACT_TANH) return bad("unknown activation");
   }
   if (d->solver != LDE_SOLVER_TSIT5 && d->solver != LDE_SOLVER_RK4) return bad("unknown solver");
-  if (d->batching != LDE_BATCH_PER_TRAJECTORY && d->batching != LDE_BATCH_COUPLED) return bad("unknown batching");
+  if (d->batching != LDE_BATCH_PER_TRAJECTORY && d->batching != LDE_BATCH_COUPLED && d->batching != LDE_BATCH_COUPLED_GLOBAL)
+    return bad("unknown batching");
+  if (d->batching == LDE_BATCH_COUPLED_GLOBAL && !has_mlp(*d)) return bad("LDE_BATCH_COUPLED_GLOBAL needs an MLP right-hand side");
   if (d->sensealg < LDE_SENSE_BACKSOLVE_CHECKPOINTED || d->sensealg > LDE_SENSE_PARALLEL_CHECKPOINTED) return bad("unknown sensealg");
 
   if (d->solver == LDE_SOLVER_RK4 && d->adaptive) {
@@ -436,6 +439,19 @@ int lde_get_stats(lde_handle* h, int which, lde_stats* out, void* stream_) {
     if (buf[(size_t)3 * B + b]) out->nfailed++;
   }
   return LDE_OK;
+}
+
+int lde_set_global_sum_hook(lde_handle* h, lde_sum_hook hook, void* user, int64_t global_batch) {
+  if (!h) return LDE_ERR_INVALID_ARG;
+  if (h->d.batching != LDE_BATCH_COUPLED_GLOBAL || !h->mlp) {
+    h->err = "lde_set_global_sum_hook: the handle was not created with LDE_BATCH_COUPLED_GLOBAL";
+    return LDE_ERR_INVALID_ARG;
+  }
+  if (hook && global_batch < 1) {
+    h->err = "lde_set_global_sum_hook: global_batch < 1";
+    return LDE_ERR_INVALID_ARG;
+  }
+  return lde::mlp_set_sum_hook(h->mlp, hook, user, hook ? global_batch : 0, h->err);
 }
 
 const char* lde_last_error(const lde_handle* h) { return h ? h->err.c_str() : "NULL handle"; }

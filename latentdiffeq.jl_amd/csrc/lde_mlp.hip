@@ -38,6 +38,8 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <cmath>
 #include <string>
 #include <vector>
 
@@ -188,6 +190,13 @@ struct GridSync {
   float* slots;        // [2][nWG][4] partials (ping-pong by generation parity)
   int* abort_flag;     // set when a spin times out
   int nwg;
+  // LDE_BATCH_COUPLED_GLOBAL (the batch is sharded over ranks, the norm is over ALL ranks' columns): k_mlpw relays every device-wide
+  // sum through the host, which adds the other ranks' (lde_set_global_sum_hook). Mailbox words = {value bits, tag << 32} in pinned,
+  // coherent host memory: req[0..1] values, req[2] = {count, tag} written last; rep[0..1] the host's answer; dev_rep[0..1] the same
+  // words republished in device memory by workgroup 0 for the other workgroups. nullptr: off.
+  unsigned long long* host_req;
+  unsigned long long* host_rep;
+  unsigned long long* dev_rep;
 };
 
 // every thread of the workgroup calls this; v[0..3] of thread 0 are the workgroup's partials; returns the totals.
@@ -1374,6 +1383,14 @@ struct MlpPlan {
   float* rows = nullptr;       // [waves][rows_stride]
   size_t rows_cap = 0;
   int rows_stride = 0;
+  // LDE_BATCH_COUPLED_GLOBAL: the cross-rank exchange of the step-control sums (lde_set_global_sum_hook)
+  bool global_mode = false;
+  lde_sum_hook sum_hook = nullptr;
+  void* sum_user = nullptr;
+  int64_t global_batch = 0;
+  unsigned long long* mbox = nullptr;       // pinned, coherent host memory: [0..2] request words, [8..9] reply words
+  unsigned long long* mbox_dev = nullptr;   // device memory: the reply republished for the other workgroups
+  hipEvent_t mbox_ev = nullptr;
 };
 
 void mlp_plan_destroy(MlpPlan* p);
@@ -1391,7 +1408,8 @@ int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err) 
   dm.DpA = (dm.Dp + 3) & ~3;
   dm.P = d.param_dim;
   dm.has_pend = d.rhs_kind == LDE_RHS_PENDULUM_PLUS_MLP;
-  dm.coupled = d.batching == LDE_BATCH_COUPLED;
+  dm.coupled = d.batching == LDE_BATCH_COUPLED || d.batching == LDE_BATCH_COUPLED_GLOBAL;
+  p->global_mode = d.batching == LDE_BATCH_COUPLED_GLOBAL;
   dm.solver = d.solver;
   int hmax = 16;
   for (int l = 0; l + 1 < dm.nL; l++) hmax = std::max(hmax, dm.sizes[l + 1]);
@@ -1554,6 +1572,9 @@ void mlp_plan_destroy(MlpPlan* p) {
   if (p->wts) (void)hipFree(p->wts);
   if (p->nslots) (void)hipFree(p->nslots);
   if (p->rows) (void)hipFree(p->rows);
+  if (p->mbox) (void)hipHostFree(p->mbox);
+  if (p->mbox_dev) (void)hipFree(p->mbox_dev);
+  if (p->mbox_ev) (void)hipEventDestroy(p->mbox_ev);
   if (p->fb_dev) (void)hipFree(p->fb_dev);
   if (p->fb_host) (void)hipHostFree(p->fb_host);
   if (p->fb_ev) (void)hipEventDestroy(p->fb_ev);
@@ -1862,7 +1883,9 @@ static int launch_w(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t
     }
   }
   a.wpack = p->wpack;
-  if (coop) {   // tagged grid-sum words: an own buffer (zeroed: no tag is 0), a fresh epoch per launch, cleared when the epoch wraps
+  const bool relay = a.gs.host_req != nullptr;   // LDE_BATCH_COUPLED_GLOBAL: sums leave the device; a plain launch (two ranks' cooperative
+                                                 // launches on one device could be serialised by the runtime — each would wait for the other's sums)
+  if (coop || relay) {   // tagged grid-sum words: an own buffer (zeroed: no tag is 0), a fresh epoch per launch, cleared when the epoch wraps
     const size_t bytes = (size_t)2 * (o.B + 1) * 4 * sizeof(float);
     if (o.B + 1 > p->wslots_cap) {
       if (p->wslots) (void)hipFree(p->wslots);
@@ -1890,11 +1913,92 @@ static int launch_w(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t
 #if LDE_PROF
   prof_reset();
 #endif
-  const int rcl = launch_maybe_coop(coop, fn, dim3(o.B), dim3(wdv.UT), lds, stream, err, "k_mlpw", dmv, wdv, ov, a);
+  const int rcl = launch_maybe_coop(coop && !relay, fn, dim3(o.B), dim3(wdv.UT), lds, stream, err, "k_mlpw", dmv, wdv, ov, a);
 #if LDE_PROF
   prof_dump(ADJ ? "w adjoint" : "w forward", stream);
 #endif
   return rcl;
+}
+
+int mlp_set_sum_hook(MlpPlan* p, lde_sum_hook hook, void* user, int64_t global_batch, std::string& err) {
+  if (!p->mbox) {
+    if (hipHostMalloc((void**)&p->mbox, 16 * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
+        hipMalloc(&p->mbox_dev, 16 * sizeof(unsigned long long)) != hipSuccess ||
+        hipEventCreateWithFlags(&p->mbox_ev, hipEventDisableTiming) != hipSuccess) {
+      (void)hipGetLastError();
+      err = "lde_set_global_sum_hook: allocating the mailbox failed";
+      return LDE_ERR_ALLOC;
+    }
+  }
+  p->sum_hook = hook;
+  p->sum_user = user;
+  p->global_batch = global_batch;
+  return LDE_OK;
+}
+
+// LDE_BATCH_COUPLED_GLOBAL with a hook: arm the mailbox before the launch …
+static int global_arm(MlpPlan* p, VArgs& a, hipStream_t stream, std::string& err) {
+  a.gs.host_req = nullptr;
+  a.gs.host_rep = nullptr;
+  a.gs.dev_rep = nullptr;
+  a.Bnorm = 0;
+  if (!p->global_mode || !p->sum_hook) return LDE_OK;
+  for (int i = 0; i < 16; i++) p->mbox[i] = 0;
+  if (hipMemsetAsync(p->mbox_dev, 0, 16 * sizeof(unsigned long long), stream) != hipSuccess) {
+    err = "hipMemsetAsync(mailbox) failed";
+    return LDE_ERR_HIP;
+  }
+  unsigned long long* dptr = nullptr;
+  if (hipHostGetDevicePointer((void**)&dptr, p->mbox, 0) != hipSuccess) {
+    err = "hipHostGetDevicePointer(mailbox) failed";
+    return LDE_ERR_HIP;
+  }
+  a.gs.host_req = dptr;
+  a.gs.host_rep = dptr + 8;
+  a.gs.dev_rep = p->mbox_dev;
+  a.Bnorm = p->global_batch;
+  return LDE_OK;
+}
+// … and serve it until the kernel has finished: every request {count, tag} is answered with the sums over all ranks
+static int global_serve(MlpPlan* p, hipStream_t stream, std::string& err) {
+  if (!p->global_mode || !p->sum_hook) return LDE_OK;
+  if (hipEventRecord(p->mbox_ev, stream) != hipSuccess) {
+    err = "hipEventRecord(mailbox) failed";
+    return LDE_ERR_HIP;
+  }
+  volatile unsigned long long* mb = p->mbox;
+  unsigned last_tag = 0;
+  int rc = LDE_OK;
+  for (;;) {
+    const unsigned long long c = __atomic_load_n(&mb[2], __ATOMIC_ACQUIRE);
+    const unsigned tag = (unsigned)(c >> 32);
+    if (tag != 0 && tag != last_tag) {
+      const int n = (int)(c & 0xffffffffu) == 2 ? 2 : 1;
+      const unsigned long long w0 = __atomic_load_n(&mb[0], __ATOMIC_RELAXED), w1 = __atomic_load_n(&mb[1], __ATOMIC_RELAXED);
+      if ((unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag) {
+        auto f = [](unsigned long long w) { unsigned u = (unsigned)w; float v; std::memcpy(&v, &u, 4); return (double)v; };
+        double vals[2] = {f(w0), f(w1)};
+        if (rc == LDE_OK && p->sum_hook(p->sum_user, vals, n) != 0) {
+          err = "LDE_BATCH_COUPLED_GLOBAL: the sum hook reported an error";
+          rc = LDE_ERR_INVALID_ARG;
+        }
+        if (rc != LDE_OK) vals[0] = vals[1] = std::nan("");   // poisons the solve: it ends with retcode != 0 on this rank
+        auto g = [&](double v) { float x = (float)v; unsigned u; std::memcpy(&u, &x, 4); return ((unsigned long long)tag << 32) | u; };
+        __atomic_store_n(&mb[9], g(n == 2 ? vals[1] : 0.0), __ATOMIC_RELAXED);
+        __atomic_store_n(&mb[8], g(vals[0]), __ATOMIC_RELEASE);
+        last_tag = tag;
+        continue;
+      }
+    }
+    const hipError_t q = hipEventQuery(p->mbox_ev);
+    if (q == hipSuccess) break;
+    if (q != hipErrorNotReady) {
+      err = std::string("LDE_BATCH_COUPLED_GLOBAL: ") + hipGetErrorString(q);
+      return LDE_ERR_HIP;
+    }
+    (void)hipGetLastError();
+  }
+  return rc;
 }
 
 int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* theta, const double* ts_dev,
@@ -1911,6 +2015,10 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
     size_t ldsv = 0;
     const bool ca = dm.coupled && o.adaptive && o.B > 1;
     const bool use_w = w_applicable(p, o.B, o.T, false, ca);
+    if (p->global_mode && !use_w) {
+      err = "LDE_BATCH_COUPLED_GLOBAL: this shape / batch is not served by the register kernels (three Dense layers, 2·D' ≤ 64, H ≤ 200, B·W ≤ 1024 waves)";
+      return LDE_ERR_UNSUPPORTED;
+    }
     if (use_w || vec_applicable(p, o.B, o.T, false, ca, &ldsv, err)) {
       VArgs va{};
       va.z0 = z0; va.theta = theta; va.ts = ts_dev; va.vecw = p->vecw; va.Wflat = W_dev; va.z_out = z_out; va.retcode = retcode;
@@ -1921,9 +2029,13 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
         err = "hipMemsetAsync(counter) failed";
         return LDE_ERR_HIP;
       }
-      if (use_w)
-        return dm.solver == LDE_SOLVER_RK4 ? launch_w<LDE_SOLVER_RK4, false>(p, o, va, ca, stream, err)
-                                           : launch_w<LDE_SOLVER_TSIT5, false>(p, o, va, ca, stream, err);
+      if (use_w) {
+        const int rca = global_arm(p, va, stream, err);
+        if (rca) return rca;
+        const int rcw = dm.solver == LDE_SOLVER_RK4 ? launch_w<LDE_SOLVER_RK4, false>(p, o, va, ca, stream, err)
+                                                    : launch_w<LDE_SOLVER_TSIT5, false>(p, o, va, ca, stream, err);
+        return rcw ? rcw : global_serve(p, stream, err);
+      }
       return dm.solver == LDE_SOLVER_RK4 ? launch_vec<LDE_SOLVER_RK4, false>(p, o, va, ldsv, ca, stream, err)
                                          : launch_vec<LDE_SOLVER_TSIT5, false>(p, o, va, ldsv, ca, stream, err);
     }
@@ -2112,6 +2224,10 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
     size_t ldsv = 0;
     const bool ca = dm.coupled && o.adaptive && o.B > 1;
     const bool use_w = w_applicable(p, o.B, o.T, true, ca);
+    if (p->global_mode && !use_w) {
+      err = "LDE_BATCH_COUPLED_GLOBAL: this shape / batch is not served by the register kernels (three Dense layers, 2·D' ≤ 64, H ≤ 200, B·W ≤ 1024 waves)";
+      return LDE_ERR_UNSUPPORTED;
+    }
     if (use_w || vec_applicable(p, o.B, o.T, true, ca, &ldsv, err)) {
       if (hipMemsetAsync(p->fb_dev, 0, 2 * sizeof(int32_t), stream) != hipSuccess ||
           hipMemsetAsync(p->nslots, 0, (size_t)2 * (nwg + 1) * sizeof(int32_t), stream) != hipSuccess ||
@@ -2129,10 +2245,15 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
       va.dz0 = dz0; va.dtheta = dtheta; va.stage = p->stage; va.wts = p->wts; va.nslots = p->nslots; va.cap = p->adj_cap; va.ovf = p->fb_dev + 1;
       va.st_nfe = nfe; va.st_nacc = nacc; va.st_nrej = nrej; va.st_ret = ret;
       va.gs.counter = p->counter; va.gs.slots = p->slots; va.gs.abort_flag = p->abort_flag; va.gs.nwg = ca ? o.B : 1;
-      const int rcv = use_w ? (dm.solver == LDE_SOLVER_RK4 ? launch_w<LDE_SOLVER_RK4, true>(p, o, va, ca, stream, err)
-                                                           : launch_w<LDE_SOLVER_TSIT5, true>(p, o, va, ca, stream, err))
-                            : (dm.solver == LDE_SOLVER_RK4 ? launch_vec<LDE_SOLVER_RK4, true>(p, o, va, ldsv, ca, stream, err)
-                                                           : launch_vec<LDE_SOLVER_TSIT5, true>(p, o, va, ldsv, ca, stream, err));
+      if (use_w) {
+        const int rca = global_arm(p, va, stream, err);
+        if (rca) return rca;
+      }
+      int rcv = use_w ? (dm.solver == LDE_SOLVER_RK4 ? launch_w<LDE_SOLVER_RK4, true>(p, o, va, ca, stream, err)
+                                                     : launch_w<LDE_SOLVER_TSIT5, true>(p, o, va, ca, stream, err))
+                      : (dm.solver == LDE_SOLVER_RK4 ? launch_vec<LDE_SOLVER_RK4, true>(p, o, va, ldsv, ca, stream, err)
+                                                     : launch_vec<LDE_SOLVER_TSIT5, true>(p, o, va, ldsv, ca, stream, err));
+      if (!rcv && use_w) rcv = global_serve(p, stream, err);
       if (rcv) return rcv;
       // a trajectory that ran out of staging slots sets *ovf: k_mlp_adjoint (which folds its slots into a private slab) then
       // redoes the whole call; otherwise it returns at once. The decision is taken on the device.

@@ -290,7 +290,7 @@ __device__ __forceinline__ void mlp64_body(const MlpDims& dm, const KOpts& o, co
       net64_vjp<DP>(n, z, lam, vz, vth, d1, d2);
 #pragma unroll
       for (int r = 0; r < DP; r++) dst[DP + r] = -vz[r];
-      dst[2 * DP] = -vth;
+      dst[ADJ ? 2 * DP : 0] = -vth;
       if (bs != 0.f) {   // (a₀, δ₁) = (z, δ₁), (a₂, δ₃) = (h₂, λ) and the three bias terms; (a₁, δ₂) = (h₁, δ₂) waits in the ring
         const float bd1 = bs * d1, bh2 = bs * n.h2;
 #pragma unroll
@@ -592,7 +592,7 @@ __device__ __forceinline__ void mlp64_body(const MlpDims& dm, const KOpts& o, co
 #pragma unroll
     for (int r = 0; r < DP; r++) g0 = lane == r ? y[DP + r] : g0;
     if (lane < D) a.dz0[(size_t)b * D + lane] = st > 1 ? 0.f : g0;
-    if (lane == 0 && NP > 0) a.dtheta[(size_t)b * NP] = st > 1 ? 0.f : y[2 * DP];
+    if (lane == 0 && NP > 0) a.dtheta[(size_t)b * NP] = st > 1 ? 0.f : y[ADJ ? 2 * DP : 0];
     if (lane == 0) a.st_ret[b] = st > 1 ? st - 1 : 0;
   }
   if (lane == 0) {

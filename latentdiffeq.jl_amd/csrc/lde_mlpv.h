@@ -39,6 +39,7 @@ struct VArgs {
   const float* wpack;     // k_mlpw's packed weights (lde_mlpw.h)
   unsigned epoch;         // k_mlpw: launch epoch (16 bits) of the tagged grid-sum words
   int cot_lds;            // k_mlpw adjoint: the trajectory's cotangents fit LDS
+  long long Bnorm;        // k_mlpw, coupled control: the batch size of the error norm when it spans several ranks (0: this launch's B)
   const float* Wflat;     // flat weights (biases)
   float* z_out;           // forward: written; adjoint: the saved ẑ (read)
   int32_t* retcode;

@@ -80,12 +80,62 @@ static __global__ void k_build_wpack(const float* __restrict__ Wflat, MlpDims dm
 // wave of every workgroup, no counter, no LDS reduction. Two buffers by generation parity: a workgroup publishes generation
 // g + 2 only after it has read all of g + 1, which every workgroup wrote after it finished reading g. Stale words of earlier
 // launches carry another epoch (the words live in a buffer of their own, zeroed when allocated and when the 16-bit epoch wraps).
+// the cross-rank stage of a sum (LDE_BATCH_COUPLED_GLOBAL): every wave holds the same device-wide (v0, v1); workgroup 0 hands them to
+// the host, which adds the other ranks' values through the caller's hook, and republishes the answer in device memory
+template <bool TWO>
+__device__ __forceinline__ void w_host_sum(const GridSync& gs, unsigned tag, float& v0, float& v1) {
+  if (!gs.host_req) return;
+  bool aborted = false;
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    __hip_atomic_store(gs.host_req + 0, ((unsigned long long)tag << 32) | __float_as_uint(v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(gs.host_req + 1, ((unsigned long long)tag << 32) | __float_as_uint(TWO ? v1 : 0.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(gs.host_req + 2, ((unsigned long long)tag << 32) | (TWO ? 2u : 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    unsigned long long r0 = 0, r1 = 0;
+    long long spins = 0;
+    for (;;) {
+      r0 = __hip_atomic_load(gs.host_rep + 0, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+      r1 = __hip_atomic_load(gs.host_rep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      if ((unsigned)(r0 >> 32) == tag && (unsigned)(r1 >> 32) == tag) break;
+      __builtin_amdgcn_s_sleep(8);
+      if ((++spins & 1023) == 0 && (spins > 8000000LL || __hip_atomic_load(gs.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        // the host does not answer (a peer rank is gone, the hook failed): poison the sums instead of hanging
+        __hip_atomic_store(gs.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        r0 = ((unsigned long long)tag << 32) | 0x7fc00000u;
+        r1 = r0;
+        break;
+      }
+    }
+    __hip_atomic_store(gs.dev_rep + 1, r1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(gs.dev_rep + 0, r0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  unsigned long long q0 = 0, q1 = 0;
+  long long spins = 0;
+  for (;;) {
+    q0 = __hip_atomic_load(gs.dev_rep + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    q1 = __hip_atomic_load(gs.dev_rep + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((unsigned)(q0 >> 32) == tag && (unsigned)(q1 >> 32) == tag) break;
+    __builtin_amdgcn_s_sleep(4);
+    if ((++spins & 4095) == 0 && (spins > 40000000LL || __hip_atomic_load(gs.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+      __hip_atomic_store(gs.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      aborted = true;
+      break;
+    }
+  }
+  aborted = __syncthreads_or(aborted ? 1 : 0) != 0;
+  v0 = aborted ? __int_as_float(0x7fc00000) : __uint_as_float((unsigned)q0);
+  if (TWO) v1 = aborted ? __int_as_float(0x7fc00000) : __uint_as_float((unsigned)q1);
+}
+
 template <bool TWO>
 __device__ __forceinline__ void w_grid_sum(const GridSync& gs, unsigned& gen, unsigned epoch, float& v0, float& v1) {
-  if (gs.nwg == 1) return;
+  if (gs.nwg == 1 && !gs.host_req) return;
   gen++;
   PROF_T(g0);
   const unsigned tag = (epoch << 16) + gen;
+  if (gs.nwg == 1) {
+    w_host_sum<TWO>(gs, tag, v0, v1);
+    return;
+  }
   unsigned long long* slots = reinterpret_cast<unsigned long long*>(gs.slots) + (size_t)(gen & 1) * gs.nwg * 2;
   if (threadIdx.x == 0) {
     __hip_atomic_store(slots + (size_t)blockIdx.x * 2, ((unsigned long long)tag << 32) | __float_as_uint(v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -116,6 +166,7 @@ __device__ __forceinline__ void w_grid_sum(const GridSync& gs, unsigned& gen, un
   aborted = __syncthreads_or(aborted ? 1 : 0) != 0;   // the waves of a workgroup must take the same decision
   v0 = aborted ? __int_as_float(0x7fc00000) : wave_sum64(p0);   // a timed-out barrier poisons the sums: retcode != 0
   if (TWO) v1 = aborted ? __int_as_float(0x7fc00000) : wave_sum64(p1);
+  w_host_sum<TWO>(gs, tag, v0, v1);
   PROF_T(g1);
   PROF_ADD(12, g0, g1);
   PROF_ADD(21, g1 - 1, g1);
@@ -216,7 +267,7 @@ __global__ void __launch_bounds__(64 * W, 1) k_mlpw(MlpDims dm, WDims wd, KOpts 
   enum { PH_K0 = 0, PH_INIT1 = 1, PH_STAGE = 2 };
   constexpr int LAST_STAGE = SOLVER == LDE_SOLVER_TSIT5 ? 6 : (ADJ ? 3 : 4);
   const float dirn = ADJ ? -1.f : 1.f;
-  const float nnorm = (float)(ADJ ? 2 * Dp : Dp) * (coupled ? (float)B : 1.f);
+  const float nnorm = (float)(ADJ ? 2 * Dp : Dp) * (coupled ? (float)(a.Bnorm > 0 ? a.Bnorm : B) : 1.f);   // Bnorm: the batch over ALL ranks (LDE_BATCH_COUPLED_GLOBAL)
 
   auto begin_step = [&]() -> bool {
     if (status == 0 && iters++ >= o.maxiters) status = 1 + LDE_RET_MAXITERS;

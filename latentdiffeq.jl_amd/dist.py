@@ -7,9 +7,11 @@ gradients of parameters that every rank shares (the RHS-MLP weights dW — plus,
 encoder/decoder weights): one flat fp32 buffer, one call, in place. `backend="nccl"` is RCCL over xGMI on ROCm;
 `gloo` is used by the CPU tests.
 
-Coupled (NeuralODE) control under sharding: each rank adapts its step size on ITS columns (shard-local norm,
+Coupled (NeuralODE) control under sharding: by default each rank adapts its step size on ITS columns (shard-local norm,
 SURVEY.md §8e option (i)); results then depend on the shard at the level of the solver tolerance. Fixed-step and
-per-trajectory control are shard-invariant.
+per-trajectory control are shard-invariant. `NODE(batching="coupled_global")` + `global_sum_hook()` is option (ii): the
+step control's sums run over ALL ranks' columns (one small host all-reduce per sum) and the sharded solve equals the
+unsharded one up to summation order — the parity mode, not the fast one.
 """
 from __future__ import annotations
 
@@ -252,6 +254,16 @@ class LdeComm:
         if self.handle:
             self._lib.lde_comm_destroy(self.handle)
             self.handle = self._C.c_void_p()
+
+
+def global_sum_hook(group=None):
+    """The `fn` of `NODE.set_global_sum` (LDE_BATCH_COUPLED_GLOBAL, SURVEY.md §8e option (ii)): sums the step-control sums of ONE
+    coupled solve over the ranks that share it. `group` must be a HOST group (gloo): the hook runs while the solve's kernel occupies the
+    device and waits for the answer — create one with `dist.new_group(backend="gloo")` next to the RCCL group of the gradients."""
+    def fn(vals):
+        t = torch.from_numpy(vals)          # shares memory with the C array: the all-reduce is in place
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return fn
 
 
 def diffeq_layer_sharded(decoder, l_hat, t, rank: Optional[int] = None, world: Optional[int] = None):

@@ -286,6 +286,25 @@ static void opts_from_desc(const lde_problem_desc* d, sopts* o, double t0, doubl
   o->maxiters = d->maxiters;
 }
 
+/* Coupled control with the batch sharded over ranks (LDE_BATCH_COUPLED_GLOBAL, include/lde.h): the checker's stand-in for the cross-rank
+ * exchange. With a hook set, every sum of the step control of a COUPLED solve — the Hairer initial-step sums, each attempt's Σr², and
+ * a non-finite flag — is passed through it (vals ← Σ over ranks, in place) and the norm's element count is scaled by g_nscale =
+ * global batch / local batch. Per process (one solve at a time), set from Python with oracle_set_sum_hook. */
+typedef int (*oracle_sum_hook)(void* user, double* vals, int n);
+static oracle_sum_hook g_hook = 0;
+static void* g_hook_user = 0;
+static double g_nscale = 1.0;
+static int g_hook_on = 0;   /* armed only inside a coupled solve */
+void oracle_set_sum_hook(oracle_sum_hook hook, void* user, double nscale) {
+  g_hook = hook;
+  g_hook_user = user;
+  g_nscale = hook ? nscale : 1.0;
+}
+static void global_sums(double* v, int n) {
+  if (g_hook_on && g_hook) g_hook(g_hook_user, v, n);
+}
+static double global_n(int64_t n) { return (g_hook_on && g_hook) ? (double)n * g_nscale : (double)n; }
+
 static int all_finite(const real* y, int64_t n) {
   for (int64_t i = 0; i < n; i++)
     if (!isfinite((double)y[i])) return 0;
@@ -303,7 +322,8 @@ static double init_dt(ode_fn fn, void* ctx, int64_t n, double t0, const real* y0
     s0 += (double)(a * a);
     s1 += (double)(b * b);
   }
-  double d0 = sqrt(s0 / (double)n), d1 = sqrt(s1 / (double)n);
+  { double v[2] = {s0, s1}; global_sums(v, 2); s0 = v[0]; s1 = v[1]; }
+  double d0 = sqrt(s0 / global_n(n)), d1 = sqrt(s1 / global_n(n));
   double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
   if (dt0 > dtmax) dt0 = dtmax;
   real h = (real)(sign * dt0);
@@ -316,7 +336,8 @@ static double init_dt(ode_fn fn, void* ctx, int64_t n, double t0, const real* y0
     real a = (f1[i] - f0[i]) / sk;
     s2 += (double)(a * a);
   }
-  double d2 = sqrt(s2 / (double)n) / dt0;
+  global_sums(&s2, 1);
+  double d2 = sqrt(s2 / global_n(n)) / dt0;
   double dm = d1 > d2 ? d1 : d2;
   double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : pow(10.0, -(2.0 + log10(dm)) / 5.0);
   double dt = fmin(100.0 * dt0, dt1);
@@ -377,7 +398,11 @@ static real tsit5_attempt(ode_fn fn, void* ctx, rkwork* w, double t, double dt, 
     real r = e / sk;
     s2 += (double)(r * r);
   }
-  return (real)sqrt(s2 / (double)n);
+  if (g_hook_on && g_hook) {   /* a non-finite state on ANY rank must reject the attempt on every rank: it poisons the shared sum */
+    if (!all_finite(w->ynew, n)) s2 = NAN;
+    global_sums(&s2, 1);
+  }
+  return (real)sqrt(s2 / global_n(n));
 }
 
 /* classical RK4 step; k[0] = f(t,y) must be valid unless eval_k1. Leaves k[4] = f(t+dt, ynew) if want_fnew. */
@@ -728,7 +753,8 @@ int oracle_forward(const lde_problem_desc* d, const real* W, const real* z0, con
   opts_from_desc(d, &o, ts[0], ts[T - 1]);
   int64_t nfe = 0, nacc = 0, nrej = 0, nfail = 0, maxsteps = 0;
   if (n_trace) *n_trace = 0;
-  if (d->batching == LDE_BATCH_COUPLED) {
+  if (d->batching != LDE_BATCH_PER_TRAJECTORY) {
+    g_hook_on = d->batching == LDE_BATCH_COUPLED_GLOBAL;
     blockctx b;
     memset(&b, 0, sizeof(b));
     colrhs_init(&b.c, d, W);
@@ -747,6 +773,7 @@ int oracle_forward(const lde_problem_desc* d, const real* W, const real* z0, con
     free(y0);
     block_threads_free(&b);
     colrhs_free(&b.c);
+    g_hook_on = 0;
   } else {
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);
@@ -886,7 +913,8 @@ int oracle_adjoint(const lde_problem_desc* d, const real* W, const real* z_out, 
   int64_t nfe = 0, nacc = 0, nrej = 0, nfail = 0, maxsteps = 0;
   double* dW_tot = nW ? (double*)calloc((size_t)nW, sizeof(double)) : NULL;
   const int ckpt = d->sensealg != LDE_SENSE_BACKSOLVE;
-  if (d->batching == LDE_BATCH_COUPLED) {
+  if (d->batching != LDE_BATCH_PER_TRAJECTORY) {
+    g_hook_on = d->batching == LDE_BATCH_COUPLED_GLOBAL;
     blockctx b;
     memset(&b, 0, sizeof(b));
     colrhs_init(&b.c, d, W);
@@ -901,6 +929,11 @@ int oracle_adjoint(const lde_problem_desc* d, const real* W, const real* z_out, 
       y[nz + i] = dz_out[i + nz * (T - 1)];
       if (!isfinite((double)y[i])) bad = 1;
     }
+    if (g_hook_on && g_hook) {   /* one shard's failed forward solve fails the shared solve on every rank */
+      double v = bad;
+      global_sums(&v, 1);
+      bad = v != 0;
+    }
     sstat st = {0, 0, 0, 0};
     if (!bad) solve_backward(bwd_fn, &b, n, y, ts, T, &o, bwd_jump, bwd_begin, bwd_commit, &st);
     for (int c = 0; c < B; c++) {
@@ -911,6 +944,7 @@ int oracle_adjoint(const lde_problem_desc* d, const real* W, const real* z_out, 
     free(y);
     block_threads_free(&b);
     colrhs_free(&b.c);
+    g_hook_on = 0;
   } else {
 #ifdef _OPENMP
     if (nthreads > 0) omp_set_num_threads(nthreads);

@@ -20,7 +20,7 @@ _BUILD = os.path.join(_HERE, "_build")
 LDE_MAX_LAYERS = 6
 RHS_PENDULUM, RHS_PENDULUM_FRICTION, RHS_MLP, RHS_PENDULUM_PLUS_MLP = 0, 1, 2, 3
 SOLVER_TSIT5, SOLVER_RK4 = 0, 1
-BATCH_PER_TRAJECTORY, BATCH_COUPLED = 0, 1
+BATCH_PER_TRAJECTORY, BATCH_COUPLED, BATCH_COUPLED_GLOBAL = 0, 1, 2
 SENSE_BACKSOLVE_CHECKPOINTED, SENSE_BACKSOLVE, SENSE_PARALLEL_CHECKPOINTED = 0, 1, 2
 ACT_RELU, ACT_TANH = 0, 1
 
@@ -103,6 +103,20 @@ class Oracle:
 
     def num_weights(self, d: Desc) -> int:
         return int(self.lib.oracle_num_weights(C.byref(d)))
+
+    def set_sum_hook(self, fn, nscale: float = 1.0):
+        """LDE_BATCH_COUPLED_GLOBAL stand-in: `fn(vals: float64 array)` replaces the entries by their sums over all ranks (in place);
+        nscale = global batch / this rank's batch. `fn=None` clears it. (oracle_set_sum_hook, lde_oracle.c)"""
+        HOOK = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int)
+        if fn is None:
+            self._hook = HOOK(0)
+        else:
+            def _cb(_user, vals, n):
+                fn(np.ctypeslib.as_array(vals, shape=(n,)))
+                return 0
+            self._hook = HOOK(_cb)
+        self.lib.oracle_set_sum_hook.argtypes = [HOOK, C.c_void_p, C.c_double]
+        self.lib.oracle_set_sum_hook(self._hook, None, float(nscale))
 
     def forward(self, d: Desc, z0, theta, ts, W=None, nthreads=0, max_trace=4096):
         """z0 [D,B] (Fortran order semantic: pass arrays shaped (B,D) C-order == [D×B] column-major).

@@ -155,3 +155,63 @@ def test_flat_grad_allreduce_packed_and_attached_modes():
             for r in range(world):
                 for g, w in zip(res[r][mode][it][1], want):
                     assert np.abs(g - w).max() <= 1e-6 * max(1.0, np.abs(w).max()), (mode, it, r)
+
+
+# ---- LDE_BATCH_COUPLED_GLOBAL: one coupled solve whose batch is sharded over the ranks (SURVEY.md §8e option (ii)) ---------------------
+def _worker_global(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    D.init("gloo")
+    from oracle import oracle as O
+    o64 = O.Oracle("f64")
+    layers = (4, 24, 24, 4)
+    W = O.mlp_weights(layers, seed=3).astype(np.float64)
+    B, T, Dm = 20, 16, 4
+    z0 = 0.5 * np.random.default_rng(1).standard_normal((B, Dm))
+    ts = O.time_grid(T)
+    dz = O.cotangent(T, B, Dm).astype(np.float64)
+    kw = dict(rhs_kind=O.RHS_MLP, state_dim=Dm, param_dim=0, layers=layers, activation=O.ACT_TANH)
+    lo, hi = D.shard_bounds(B, rank, world)
+    calls = [0]
+    base = D.global_sum_hook()
+
+    def hook(vals):
+        calls[0] += 1
+        base(vals)
+    o64.set_sum_hook(hook, nscale=B / (hi - lo))
+    d = O.make_desc(batching=O.BATCH_COUPLED_GLOBAL, **kw)
+    z, _, st = o64.forward(d, z0[lo:hi], None, ts, W=W, nthreads=1)
+    g0, _, gW, sb = o64.adjoint(d, z, None, ts, dz[:, lo:hi], W=W, nthreads=1)
+    o64.set_sum_hook(None)
+    buf = torch.from_numpy(gW.copy())
+    D.allreduce_flat_(buf)                                   # the shared weight gradient: the path's one data collective
+    if rank == 0:   # the unsharded coupled solve of the whole batch, and the shard-LOCAL norm for contrast
+        dc = O.make_desc(batching=O.BATCH_COUPLED, **kw)
+        zf, _, stf = o64.forward(dc, z0, None, ts, W=W, nthreads=1)
+        f0, _, fW, sbf = o64.adjoint(dc, zf, None, ts, dz, W=W, nthreads=1)
+        zl, _, _ = o64.forward(dc, z0[lo:hi], None, ts, W=W, nthreads=1)
+        q.put(dict(ez=float(np.abs(z - zf[:, lo:hi]).max()), eg=float(np.abs(g0 - f0[lo:hi]).max() / np.abs(f0).max()),
+                   eW=float(np.abs(buf.numpy() - fW).max() / np.abs(fW).max()), steps=(st["naccept"], stf["naccept"]),
+                   bsteps=(sb["naccept"], sbf["naccept"]), calls=calls[0], elocal=float(np.abs(zl - zf[:, lo:hi]).max())))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_coupled_global_norm_sharded_equals_unsharded():
+    """Two gloo ranks share ONE coupled adaptive solve (float64 oracle as the stand-in solver, its step-control sums going through
+    dist.global_sum_hook): rank 0's shard of ẑ, of ∂L/∂ẑ₀ and the all-reduced dW equal the single-process coupled solve of the whole
+    batch to 1e-6 (they differ by summation order only: ≈ 1e-13), with the same step counts — while the shard-LOCAL norm
+    (LDE_BATCH_COUPLED on the shard) is off at the level of the solver tolerance."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_global, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = q.get(timeout=180)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res["ez"] <= 1e-6 and res["eg"] <= 1e-6 and res["eW"] <= 1e-6, res
+    assert res["steps"][0] == res["steps"][1] and res["bsteps"][0] == res["bsteps"][1], res
+    assert res["calls"] >= res["steps"][0] + res["bsteps"][0], res            # one exchange per attempt (+ the initial-step sums)
+    assert res["elocal"] > 10 * max(res["ez"], 1e-12), res                    # the mode matters: local control is measurably different

@@ -1,0 +1,151 @@
+"""GPU: LDE_BATCH_COUPLED_GLOBAL (SURVEY.md §8e option (ii)) — one coupled adaptive solve whose batch is sharded, the step control's
+sums running over ALL shards' columns through lde_set_global_sum_hook [REF src/models/LatentODE.jl:70-72: the reference's norm is over
+the whole [D'×B] state].
+
+One GPU per box here, so the two "ranks" are two handles driven by two host threads on two streams of the same device, their hooks
+meeting at a thread barrier (the exchange a gloo all-reduce performs between processes: tests/test_dist_gloo.py has that side with the
+oracle as the solver). What is checked: with a hook that adds nothing (one rank) the mode IS the plain coupled solve, bit for bit; two
+shards under the global norm reproduce the unsharded solve's step sequence and results to f32 summation order, forward and adjoint
+(ẑ ≤ 1e-6·scale, gradients ≤ 1e-5); the shard-LOCAL norm does not; a failing hook ends the solve with retcode ≠ 0, no hang."""
+import threading
+
+import numpy as np
+import pytest
+
+from oracle import oracle as O
+
+pytestmark = pytest.mark.gpu
+
+LAYERS = (32, 128, 128, 32)
+KW = dict(rhs_kind=O.RHS_MLP, state_dim=32, param_dim=0, layers=LAYERS, activation=O.ACT_TANH)
+
+
+def _setup(batching, W):
+    from tests.gpu_util import Native, make_desc
+    nat = Native(make_desc(batching=batching, **KW))
+    nat.set_weights(W)
+    return nat
+
+
+def _hook(nat, fn, global_batch):
+    from latentdiffeq_amd import _lib as L
+    import ctypes as C
+    if fn is None:
+        cb = L.SUM_HOOK(0)
+    else:
+        def _cb(_u, vals, n):
+            try:
+                return int(fn(np.ctypeslib.as_array(vals, shape=(n,))) or 0)
+            except Exception:      # noqa: BLE001
+                return 1
+        cb = L.SUM_HOOK(_cb)
+    L.check(nat.lib.lde_set_global_sum_hook(nat.h, cb, None, global_batch), nat.h, "lde_set_global_sum_hook")
+    nat._cb = cb
+
+
+def _inputs(B, T=50):
+    z0 = (0.5 * np.random.default_rng(1).standard_normal((B, 32))).astype(np.float32)
+    return z0, O.time_grid(T), O.cotangent(T, B, 32)
+
+
+def test_one_rank_global_mode_is_the_plain_coupled_solve():
+    W = O.mlp_weights(LAYERS, seed=3)
+    B = 96
+    z0, ts, dz = _inputs(B)
+    ref = _setup(O.BATCH_COUPLED, W)
+    zr, _, sr = ref.forward(z0, None, ts)
+    gr = ref.adjoint(zr, None, ts, dz)
+    nat = _setup(O.BATCH_COUPLED_GLOBAL, W)
+    calls = [0]
+
+    def ident(vals):
+        calls[0] += 1
+    _hook(nat, ident, B)
+    z, ret, st = nat.forward(z0, None, ts)
+    g = nat.adjoint(z, None, ts, dz)
+    assert (ret == 0).all() and st["naccept"] == sr["naccept"] and calls[0] >= st["naccept"] + g[3]["naccept"]
+    assert np.array_equal(z, zr) and np.array_equal(g[0], gr[0]) and np.array_equal(g[2], gr[2])
+    _hook(nat, None, 0)                      # cleared: still the coupled solve of these columns, now without the host in the loop
+    z2, _, _ = nat.forward(z0, None, ts)
+    assert np.array_equal(z2, zr)
+
+
+def test_two_shards_under_the_global_norm_equal_the_unsharded_solve():
+    import torch
+    W = O.mlp_weights(LAYERS, seed=3)
+    B = 192
+    z0, ts, dz = _inputs(B)
+    ref = _setup(O.BATCH_COUPLED, W)
+    zf, _, sf = ref.forward(z0, None, ts)
+    f0, _, fW, sbf = ref.adjoint(zf, None, ts, dz)
+    bounds = [(0, 80), (80, 192)]            # unequal shards
+    bar = threading.Barrier(2)
+    slots = [None, None]
+
+    def make_hook(r):
+        def fn(vals):
+            slots[r] = vals.copy()
+            bar.wait(timeout=60)
+            tot = slots[0] + slots[1]        # the same order on both "ranks": identical bits
+            bar.wait(timeout=60)
+            vals[:] = tot
+        return fn
+
+    out = [None, None]
+    err = []
+
+    def rank(r):
+        try:
+            lo, hi = bounds[r]
+            nat = _setup(O.BATCH_COUPLED_GLOBAL, W)
+            _hook(nat, make_hook(r), B)
+            with torch.cuda.stream(torch.cuda.Stream()):      # a stream of its own: both solves must be in flight at once
+                z, ret, st = nat.forward(z0[lo:hi], None, ts)
+                g0, _, gW, sb = nat.adjoint(z, None, ts, dz[:, lo:hi])
+            out[r] = (z, ret, st, g0, gW, sb)
+        except Exception as e:               # noqa: BLE001
+            err.append(e)
+            bar.abort()
+
+    th = [threading.Thread(target=rank, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not err, err
+    scale = max(1.0, np.abs(zf).max())
+    gW = out[0][4] + out[1][4]               # the path's one data collective: Σ over ranks of the shared weight gradient
+    for r, (lo, hi) in enumerate(bounds):
+        z, ret, st, g0, _, sb = out[r]
+        assert (ret == 0).all() and st["naccept"] == sf["naccept"] and sb["naccept"] == sbf["naccept"], (st, sf, sb, sbf)
+        assert np.abs(z - zf[:, lo:hi]).max() <= 1e-6 * scale, np.abs(z - zf[:, lo:hi]).max()
+        assert np.abs(g0 - f0[lo:hi]).max() <= 1e-5 * np.abs(f0).max()
+    assert np.abs(gW - fW).max() <= 1e-5 * np.abs(fW).max()
+    # the shard-LOCAL norm (option (i), the default for sharded runs) is a different — equally valid — step sequence
+    loc = _setup(O.BATCH_COUPLED, W)
+    zl, _, sl = loc.forward(z0[:80], None, ts)
+    assert np.abs(zl - zf[:, :80]).max() > 1e-6 * scale or sl["naccept"] != sf["naccept"]
+
+
+def test_a_failing_hook_fails_the_solve_without_hanging():
+    W = O.mlp_weights(LAYERS, seed=3)
+    B = 32
+    z0, ts, _ = _inputs(B)
+    nat = _setup(O.BATCH_COUPLED_GLOBAL, W)
+    n = [0]
+
+    def bad(vals):
+        n[0] += 1
+        return 1 if n[0] > 3 else 0
+    _hook(nat, bad, B)
+    import ctypes as C
+    import torch
+    from latentdiffeq_amd import _lib as L
+    z0d = torch.from_numpy(z0).cuda()
+    out = torch.zeros((ts.size, B, 32), device="cuda")
+    ret = torch.zeros((B,), device="cuda", dtype=torch.int32)
+    rc = nat.lib.lde_forward(nat.h, C.c_void_p(z0d.data_ptr()), None, ts.ctypes.data_as(C.POINTER(C.c_double)), ts.size, B,
+                             C.c_void_p(out.data_ptr()), C.c_void_p(ret.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+    torch.cuda.synchronize()
+    assert rc == -1 and b"hook" in nat.lib.lde_last_error(nat.h)
+    assert (ret.cpu().numpy() != 0).all() and bool(torch.isnan(out[1:]).all())       # NaN blocks, as every failed solve

@@ -672,6 +672,17 @@ def main():
             res["fwd"] = kernel_ms(fwd, nprobe)
             res["bwd"] = kernel_ms(bwd, nprobe)
             res["step"] = kernel_ms(step, nprobe)
+            if nW:   # the adjoint's two phases, from HIP events the library records on this stream (lde_set_phase_timing)
+                lib.lde_set_phase_timing(h, 1)
+                ph = []
+                ms2 = (C.c_float * 2)()
+                for _ in range(min(nprobe, 30)):
+                    bwd()
+                    if lib.lde_get_phase_ms(h, ms2) == 0:
+                        ph.append((ms2[0], ms2[1]))
+                lib.lde_set_phase_timing(h, 0)
+                if ph:
+                    res["phase_ms"] = (float(np.mean([a_ for a_, _ in ph])), float(np.mean([b_ for _, b_ in ph])))
             st = L.Stats()
             lib.lde_get_stats(h, 0, C.byref(st), sp)
             res["fstat"] = dict(nfe=st.nfe, naccept=st.naccept, nreject=st.nreject, nfailed=st.nfailed, max_steps=st.max_steps)
@@ -704,10 +715,21 @@ def main():
     else:
         flops = fstat["nfe"] * Ff + bstat["nfe"] * 3 * Ff
     if Ff:  # MLP right-hand side: compute-bound on the f32 MFMA/VALU rate
-        ach = flops / ((fwd_stream + bwd_stream) * 1e-3) / 1e12
-        roof = dict(bound="mfma", kernel="lde_forward+lde_adjoint", achieved=ach, peak=FP32_PEAK_TFLOPS, unit="TFLOP/s",
-                    frac=ach / FP32_PEAK_TFLOPS, traffic=None, alg_flops_per_step=flops,
-                    avg_launch_ms=fwd_stream + bwd_stream, avg_launch_ms_bracketed=fwd_ms + bwd_ms)
+        # the DOMINANT kernel = the adjoint's solve kernel: its flops are the recomputed forward pass and the z-VJP of every evaluation
+        # (2·F_f each; the weight-gradient product, the third F_f, is counted where it runs — inside that kernel or in the tail)
+        cols = B if w["batching"] == "coupled" else 1
+        ph = m.get("phase_ms")
+        in_kernel_dw = ph is not None and ph[1] < 0.25 * ph[0] and args.workload == "c3"   # k_mlp64 folds gW in the wave
+        dom_flops = bstat["nfe"] * (3 if in_kernel_dw else 2) * Ff * cols
+        dom_ms_k = ph[0] if ph else bwd_stream
+        ach = dom_flops / (dom_ms_k * 1e-3) / 1e12
+        whole = flops / ((fwd_stream + bwd_stream) * 1e-3) / 1e12
+        roof = dict(bound="mfma", kernel="lde_adjoint: solve kernel (HIP events of lde_set_phase_timing)", achieved=ach, peak=FP32_PEAK_TFLOPS,
+                    unit="TFLOP/s", frac=ach / FP32_PEAK_TFLOPS, traffic=None, alg_flops_per_launch=dom_flops, avg_launch_ms=dom_ms_k,
+                    tail=dict(what="weight-gradient product + fixed-order sums after the solve kernel", avg_launch_ms=ph[1] if ph else None,
+                              alg_flops=0 if in_kernel_dw else bstat["nfe"] * Ff * cols),
+                    whole_step=dict(kernel="lde_forward+lde_adjoint", achieved=whole, frac=whole / FP32_PEAK_TFLOPS, alg_flops_per_step=flops,
+                                    avg_launch_ms=fwd_stream + bwd_stream, avg_launch_ms_bracketed=fwd_ms + bwd_ms))
     else:
         # average launch duration of the dominant call over n back-to-back launches (HIP events on the launch stream); the
         # bracketed figure (an event pair around every single launch) carries the events' own ≈ 2.5 µs
@@ -717,7 +739,7 @@ def main():
 
     # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command
     # (profiles/collect.sh + profiles/summarize.py; FETCH_SIZE ×2 on gfx950, WRITE_SIZE as is — MI355X_MICROARCH.md §HBM)
-    for rnd in ("r2", "r1"):
+    for rnd in ("r3", "r2", "r1"):
         prof = os.path.join(ROOT, "profiles", f"{rnd}_{args.workload}_b{B}_summary.json" if not Ff else f"{rnd}_{args.workload}_summary.json")
         if not os.path.exists(prof):
             continue
@@ -726,13 +748,19 @@ def main():
             kn = {"lde_forward": "k_pend_forward", "lde_adjoint": "k_pend_adjoint"}[dom]
             for name, kd in kern.items():
                 if name.startswith(kn) and "write_bytes" in kd:
-                    roof["traffic"] = kd["fetch_bytes_x2_gfx950"] + kd["write_bytes"]
+                    roof["traffic"] = kd.get("fetch_bytes", kd["fetch_bytes_x2_gfx950"]) + kd["write_bytes"]
                     roof["rocprof_avg_launch_ms"] = kd["avg_ns"] * 1e-6
-        elif B == w["B"]:   # MLP workloads: the solve + adjoint kernels of one step together
-            tr = [kd["fetch_bytes_x2_gfx950"] + kd["write_bytes"] for name, kd in kern.items()
-                  if name.startswith(("k_mlp", "k_reduce", "k_sum")) and "write_bytes" in kd]
+        elif B == w["B"]:   # MLP workloads: the dominant kernel's own traffic; the whole step's beside it
+            def tb(kd):
+                return kd.get("fetch_bytes", kd["fetch_bytes_x2_gfx950"]) + kd["write_bytes"]
+            def is_adj_solve(name):   # the adjoint's solve kernels: k_mlp64_adj<…>, k_mlpw / k_mlpv<…, true…>, k_mlp_adjoint, k_mlp4_adjoint
+                return name.startswith(("k_mlp64_adj", "k_mlp_adjoint", "k_mlp4_adjoint")) or (name.startswith(("k_mlpw", "k_mlpv")) and "true" in name)
+            adj = [(kd.get("avg_ns", 0), tb(kd)) for name, kd in kern.items() if is_adj_solve(name) and "write_bytes" in kd]
+            tr = [tb(kd) for name, kd in kern.items() if name.startswith(("k_mlp", "k_reduce", "k_sum")) and "write_bytes" in kd]
+            if adj:
+                roof["traffic"] = float(max(adj)[1])                 # the longest-running solve kernel of the step = the adjoint's
             if tr:
-                roof["traffic"] = float(sum(tr))
+                roof["whole_step"]["traffic"] = float(sum(tr))
         if roof["traffic"] is not None:
             roof["traffic_source"] = os.path.relpath(prof, ROOT)
             break

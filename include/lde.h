@@ -188,6 +188,13 @@ int lde_adjoint(lde_handle* h, const float* z_out, const float* theta,
  * handle. Synchronises `stream`. */
 int lde_get_stats(lde_handle* h, int which, lde_stats* out, void* stream);
 
+/* Measurement aid (MLP right-hand sides): with timing on, every lde_adjoint records HIP events — on the caller's stream — around its
+ * solve kernel and around what follows it (the weight-gradient product where there is one, the fixed-order sums). lde_get_phase_ms
+ * waits for the last call and returns ms2[0] = the solve kernel, ms2[1] = the tail. bench.py prices its per-kernel roofline with
+ * it; off by default (two event records per call). No counterpart in the reference (it has no profiling hooks). */
+int lde_set_phase_timing(lde_handle* h, int on);
+int lde_get_phase_ms(lde_handle* h, float* ms2);
+
 /* LDE_BATCH_COUPLED_GLOBAL: the exchange of the step-control sums between the ranks that share ONE coupled solve
  * [REF src/models/LatentODE.jl:70-72: the reference's NeuralODE norm runs over the whole [D'×B] state — here B is spread over ranks].
  * `hook(user, vals, n)` must replace vals[0..n) (n = 1 or 2, f64) by their sums over all ranks and return 0; every rank calls it
@@ -393,6 +400,11 @@ typedef struct lde_adam_tensor {
 } lde_adam_tensor;
 int lde_adamw_flux_step(int n, const lde_adam_tensor* t, float lr, float beta1, float beta2, float eps, float decay, int64_t step,
                         void* stream);
+/* The same update with the step count t in DEVICE memory (*step_dev is advanced by one, then used): what a training step captured in a
+ * hipGraph needs — a graph replays the same kernel arguments every time, so the bias corrections cannot travel in them
+ * [REF examples/pendulum_friction-less/model_train.jl:186-204: the loop the graph replaces]. */
+int lde_adamw_flux_step_dev(int n, const lde_adam_tensor* t, float lr, float beta1, float beta2, float eps, float decay,
+                            int64_t* step_dev, void* stream);
 
 /* ====================================================================================================================
  * The one collective of the path. The reference's only parallelism is `EnsembleThreads()` over the

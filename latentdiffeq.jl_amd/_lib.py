@@ -27,14 +27,14 @@ STATUS = {0: "LDE_OK", -1: "LDE_ERR_INVALID_ARG", -2: "LDE_ERR_UNSUPPORTED", -3:
 # every symbol include/lde.h declares
 EXPORTS = ["lde_abi_version", "lde_problem_desc_default", "lde_num_weights", "lde_create", "lde_destroy",
            "lde_set_weights", "lde_set_weights_device", "lde_reserve", "lde_forward", "lde_adjoint",
-           "lde_get_stats", "lde_last_error", "lde_set_global_sum_hook",
+           "lde_get_stats", "lde_last_error", "lde_set_global_sum_hook", "lde_set_phase_timing", "lde_get_phase_ms",
            "lde_chain_num_weights", "lde_chain_create", "lde_chain_destroy", "lde_chain_set_weights",
            "lde_chain_set_weights_device", "lde_chain_reserve", "lde_chain_forward", "lde_chain_backward",
            "lde_chain_last_error", "lde_chain_set_accumulate", "lde_chain_set_dtype", "lde_rnn_set_accumulate", "lde_chain_saved_floats", "lde_chain_forward_save", "lde_chain_backward_saved",
            "lde_rnn_num_weights", "lde_rnn_create", "lde_rnn_destroy", "lde_rnn_set_weights", "lde_rnn_set_weights_device",
            "lde_rnn_reserve", "lde_rnn_forward", "lde_rnn_backward", "lde_rnn_last_error", "lde_rnn_backward_dx", "lde_rnn_backward_dw", "lde_refresh_weights",
            "lde_sample_forward", "lde_sample_backward", "lde_kl_forward", "lde_kl_backward", "lde_mse_forward",
-           "lde_mse_backward", "lde_sample_kl_forward", "lde_sample_kl_backward", "lde_mse_forward_add", "lde_adamw_flux_step", "lde_set_dw_stream", "lde_join_dw",
+           "lde_mse_backward", "lde_sample_kl_forward", "lde_sample_kl_backward", "lde_mse_forward_add", "lde_adamw_flux_step", "lde_adamw_flux_step_dev", "lde_set_dw_stream", "lde_join_dw",
            "lde_comm_unique_id", "lde_comm_init", "lde_comm_allreduce_f32", "lde_comm_nranks", "lde_comm_rank",
            "lde_comm_destroy", "lde_comm_last_error"]
 # lde_sum_hook: int hook(void* user, double* vals, int n) — vals[0..n) ← Σ over ranks, in place
@@ -118,6 +118,8 @@ def load():
     lib.lde_forward.argtypes = [vp, vp, vp, C.POINTER(C.c_double), i32, i32, vp, vp, vp]
     lib.lde_adjoint.argtypes = [vp, vp, vp, C.POINTER(C.c_double), i32, i32, vp, vp, vp, vp, vp]
     lib.lde_get_stats.argtypes = [vp, i32, C.POINTER(Stats), vp]
+    lib.lde_set_phase_timing.argtypes = [vp, C.c_int]
+    lib.lde_get_phase_ms.argtypes = [vp, C.POINTER(C.c_float)]
     lib.lde_set_global_sum_hook.argtypes = [vp, SUM_HOOK, vp, C.c_int64]
     lib.lde_set_global_sum_hook.restype = C.c_int
     lib.lde_last_error.argtypes = [vp]
@@ -169,6 +171,7 @@ def load():
     lib.lde_set_dw_stream.argtypes = [vp]
     lib.lde_join_dw.argtypes = [vp]
     lib.lde_adamw_flux_step.argtypes = [i32, C.POINTER(AdamTensor), f32, f32, f32, f32, f32, i64, vp]
+    lib.lde_adamw_flux_step_dev.argtypes = [i32, C.POINTER(AdamTensor), f32, f32, f32, f32, f32, vp, vp]
     lib.lde_comm_unique_id.argtypes = [C.c_char_p]
     lib.lde_comm_init.argtypes = [C.POINTER(vp), i32, i32, C.c_char_p]
     lib.lde_comm_allreduce_f32.argtypes = [vp, vp, i64, vp]

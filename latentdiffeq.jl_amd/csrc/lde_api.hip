@@ -34,6 +34,8 @@ int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err);
 void mlp_plan_destroy(MlpPlan* p);
 int mlp_reserve(MlpPlan* p, int B, int T, std::string& err);
 int mlp_set_sum_hook(MlpPlan* p, lde_sum_hook hook, void* user, int64_t global_batch, std::string& err);
+int mlp_set_phase_timing(MlpPlan* p, int on);
+int mlp_get_phase_ms(MlpPlan* p, float* out);
 int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::string& err);
 int mlp_set_weights(MlpPlan* p, const float* W_dev, hipStream_t stream, std::string& err);
 int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* theta, const double* ts_dev,
@@ -439,6 +441,15 @@ int lde_get_stats(lde_handle* h, int which, lde_stats* out, void* stream_) {
     if (buf[(size_t)3 * B + b]) out->nfailed++;
   }
   return LDE_OK;
+}
+
+int lde_set_phase_timing(lde_handle* h, int on) {
+  if (!h || !h->mlp) return LDE_ERR_INVALID_ARG;
+  return lde::mlp_set_phase_timing(h->mlp, on);
+}
+int lde_get_phase_ms(lde_handle* h, float* ms2) {
+  if (!h || !h->mlp || !ms2) return LDE_ERR_INVALID_ARG;
+  return lde::mlp_get_phase_ms(h->mlp, ms2);
 }
 
 int lde_set_global_sum_hook(lde_handle* h, lde_sum_hook hook, void* user, int64_t global_batch) {

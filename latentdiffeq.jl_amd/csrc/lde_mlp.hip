@@ -1391,6 +1391,9 @@ struct MlpPlan {
   unsigned long long* mbox = nullptr;       // pinned, coherent host memory: [0..2] request words, [8..9] reply words
   unsigned long long* mbox_dev = nullptr;   // device memory: the reply republished for the other workgroups
   hipEvent_t mbox_ev = nullptr;
+  // lde_set_phase_timing: HIP events around the adjoint's solve kernel and its weight-gradient tail (bench.py's per-kernel roofline)
+  bool phase_on = false;
+  hipEvent_t ph_ev[3] = {nullptr, nullptr, nullptr};
 };
 
 void mlp_plan_destroy(MlpPlan* p);
@@ -1575,6 +1578,8 @@ void mlp_plan_destroy(MlpPlan* p) {
   if (p->mbox) (void)hipHostFree(p->mbox);
   if (p->mbox_dev) (void)hipFree(p->mbox_dev);
   if (p->mbox_ev) (void)hipEventDestroy(p->mbox_ev);
+  for (int i = 0; i < 3; i++)
+    if (p->ph_ev[i]) (void)hipEventDestroy(p->ph_ev[i]);
   if (p->fb_dev) (void)hipFree(p->fb_dev);
   if (p->fb_host) (void)hipHostFree(p->fb_host);
   if (p->fb_ev) (void)hipEventDestroy(p->fb_ev);
@@ -1920,6 +1925,25 @@ static int launch_w(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t
   return rcl;
 }
 
+int mlp_set_phase_timing(MlpPlan* p, int on) {
+  if (on && !p->ph_ev[0])
+    for (int i = 0; i < 3; i++)
+      if (hipEventCreate(&p->ph_ev[i]) != hipSuccess) return LDE_ERR_HIP;
+  p->phase_on = on != 0;
+  return LDE_OK;
+}
+// ms of the last lde_adjoint's phases: [0] the solve kernel(s), [1] what follows it (weight-gradient product, slab / row sums)
+int mlp_get_phase_ms(MlpPlan* p, float* out) {
+  if (!p->phase_on || !p->ph_ev[0]) return LDE_ERR_INVALID_ARG;
+  if (hipEventSynchronize(p->ph_ev[2]) != hipSuccess) return LDE_ERR_HIP;
+  if (hipEventElapsedTime(&out[0], p->ph_ev[0], p->ph_ev[1]) != hipSuccess || hipEventElapsedTime(&out[1], p->ph_ev[1], p->ph_ev[2]) != hipSuccess)
+    return LDE_ERR_HIP;
+  return LDE_OK;
+}
+static void phase_mark(MlpPlan* p, int i, hipStream_t stream) {
+  if (p->phase_on) (void)hipEventRecord(p->ph_ev[i], stream);
+}
+
 int mlp_set_sum_hook(MlpPlan* p, lde_sum_hook hook, void* user, int64_t global_batch, std::string& err) {
   if (!p->mbox) {
     if (hipHostMalloc((void**)&p->mbox, 16 * sizeof(unsigned long long), hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess ||
@@ -2174,8 +2198,10 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
     va.theta = theta; va.ts = ts_dev; va.Wflat = W_dev; va.z_out = const_cast<float*>(z_out); va.dz_out = dz_out;
     va.dz0 = dz0; va.dtheta = dtheta; va.stage = p->rows; va.cap = p->rows_stride;
     va.st_nfe = nfe; va.st_nacc = nacc; va.st_nrej = nrej; va.st_ret = ret;
+    phase_mark(p, 0, stream);
     const int rc6 = launch_mlp64<true>(dm, o, va, stream, err);
     if (rc6) return rc6;
+    phase_mark(p, 1, stream);
     if (dW) {
       hipLaunchKernelGGL(k_sum_rows, dim3(cdiv(dm.nW, 64)), dim3(1024), 0, stream, p->rows, waves, p->rows_stride, dm.nW, dW);
       if (hipGetLastError() != hipSuccess) {
@@ -2183,6 +2209,7 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
         return LDE_ERR_HIP;
       }
     }
+    phase_mark(p, 2, stream);
     return LDE_OK;
   }
   const int nwg = cdiv(o.B, NB);
@@ -2249,12 +2276,14 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
         const int rca = global_arm(p, va, stream, err);
         if (rca) return rca;
       }
+      phase_mark(p, 0, stream);
       int rcv = use_w ? (dm.solver == LDE_SOLVER_RK4 ? launch_w<LDE_SOLVER_RK4, true>(p, o, va, ca, stream, err)
                                                      : launch_w<LDE_SOLVER_TSIT5, true>(p, o, va, ca, stream, err))
                       : (dm.solver == LDE_SOLVER_RK4 ? launch_vec<LDE_SOLVER_RK4, true>(p, o, va, ldsv, ca, stream, err)
                                                      : launch_vec<LDE_SOLVER_TSIT5, true>(p, o, va, ldsv, ca, stream, err));
       if (!rcv && use_w) rcv = global_serve(p, stream, err);
       if (rcv) return rcv;
+      phase_mark(p, 1, stream);
       // a trajectory that ran out of staging slots sets *ovf: k_mlp_adjoint (which folds its slots into a private slab) then
       // redoes the whole call; otherwise it returns at once. The decision is taken on the device.
       vec_done = true;
@@ -2265,6 +2294,7 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
       }
     }
   }
+  if (!vec_done) phase_mark(p, 0, stream);
   // networks whose weights fit LDS once: four columns per wave, no barriers (lde_mlp4.h)
   if (!vec_done) {
     Mlp4Dims md;
@@ -2314,8 +2344,10 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
   // the weight gradient from the staged panels
   DwArgs da;
   da.stage = p->stage; da.wts = p->wts; da.nslots = p->nslots; da.slab = p->slab + (size_t)(nwg + 1) * dm.slab_n; da.cap = p->adj_cap; da.total = 0;
+  if (!vec_done) phase_mark(p, 1, stream);   // (the tile kernels: the solve is the launch above; the small-batch kernels marked theirs already)
   rc = launch_weight_gradient(dm, da, ntile_dw, ks, p->slab, p->nslots + (nwg + 1), nwg, dW, p->fb_dev, stream, err);
   if (rc) return rc;
+  phase_mark(p, 2, stream);
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(stream, &cs) == hipSuccess && cs == hipStreamCaptureStatusNone) {   // not inside a hipGraph capture
     if (hipMemcpyAsync(p->fb_host, p->fb_dev, sizeof(int32_t), hipMemcpyDeviceToHost, stream) == hipSuccess &&

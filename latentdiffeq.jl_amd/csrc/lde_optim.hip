@@ -37,7 +37,16 @@ __device__ __forceinline__ void adam1(float& x, float g, float& m, float& v, con
   x -= d;
 }
 
-__global__ void __launch_bounds__(OPT_WG) k_adamw_flux(OptTable tab, OptCoef c) {
+// `step_dev` != nullptr: the step count t lives in device memory (a captured hipGraph replays the SAME kernel arguments every step, so
+// the bias corrections 1/(1 − βᵗ) cannot travel in them): every thread derives them from *step_dev, which k_adam_tick advanced.
+__global__ void k_adam_tick(int64_t* step_dev) { *step_dev += 1; }
+
+__global__ void __launch_bounds__(OPT_WG) k_adamw_flux(OptTable tab, OptCoef c, const int64_t* __restrict__ step_dev) {
+  if (step_dev) {
+    const double t = (double)*step_dev;
+    c.inv_bc1 = (float)(1.0 / (1.0 - pow((double)c.b1, t)));
+    c.inv_bc2 = (float)(1.0 / (1.0 - pow((double)c.b2, t)));
+  }
   int i = 0;
   while (i + 1 < tab.n && (int)blockIdx.x >= tab.blk0[i + 1]) i++;
   const lde_adam_tensor t = tab.t[i];
@@ -68,15 +77,19 @@ __global__ void __launch_bounds__(OPT_WG) k_adamw_flux(OptTable tab, OptCoef c) 
 
 using namespace lde;
 
-extern "C" int lde_adamw_flux_step(int n, const lde_adam_tensor* t, float lr, float beta1, float beta2, float eps, float decay,
-                                   int64_t step, void* stream) {
-  if (n < 0 || (n > 0 && !t) || step < 1 || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f)) return LDE_ERR_INVALID_ARG;
+static int adamw_impl(int n, const lde_adam_tensor* t, float lr, float beta1, float beta2, float eps, float decay, int64_t step,
+                      int64_t* step_dev, void* stream) {
+  if (n < 0 || (n > 0 && !t) || (!step_dev && step < 1) || !(beta1 >= 0.f && beta1 < 1.f) || !(beta2 >= 0.f && beta2 < 1.f)) return LDE_ERR_INVALID_ARG;
   for (int i = 0; i < n; i++)
     if (t[i].n < 0 || (t[i].n > 0 && (!t[i].p || !t[i].g || !t[i].m || !t[i].v))) return LDE_ERR_INVALID_ARG;
   OptCoef c;
   c.b1 = beta1; c.b2 = beta2; c.omb1 = 1.0f - beta1; c.omb2 = 1.0f - beta2; c.eps = eps; c.lr = lr; c.decay = decay;
-  c.inv_bc1 = (float)(1.0 / (1.0 - __builtin_pow((double)beta1, (double)step)));   // Flux carries β₁ᵗ, β₂ᵗ as a running product
-  c.inv_bc2 = (float)(1.0 / (1.0 - __builtin_pow((double)beta2, (double)step)));
+  c.inv_bc1 = (float)(1.0 / (1.0 - __builtin_pow((double)beta1, (double)(step_dev ? 1 : step))));   // Flux carries β₁ᵗ, β₂ᵗ as a running product
+  c.inv_bc2 = (float)(1.0 / (1.0 - __builtin_pow((double)beta2, (double)(step_dev ? 1 : step))));
+  if (step_dev) {
+    hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
+    if (hipGetLastError() != hipSuccess) return LDE_ERR_HIP;
+  }
   for (int first = 0; first < n;) {
     OptTable tab;
     tab.n = 0;
@@ -97,8 +110,18 @@ extern "C" int lde_adamw_flux_step(int n, const lde_adam_tensor* t, float lr, fl
       break;
     }
     tab.blk0[tab.n] = blk;
-    hipLaunchKernelGGL(k_adamw_flux, dim3(blk), dim3(OPT_WG), 0, (hipStream_t)stream, tab, c);
+    hipLaunchKernelGGL(k_adamw_flux, dim3(blk), dim3(OPT_WG), 0, (hipStream_t)stream, tab, c, (const int64_t*)step_dev);
     if (hipGetLastError() != hipSuccess) return LDE_ERR_HIP;
   }
   return LDE_OK;
+}
+
+extern "C" int lde_adamw_flux_step(int n, const lde_adam_tensor* t, float lr, float beta1, float beta2, float eps, float decay,
+                                   int64_t step, void* stream) {
+  return adamw_impl(n, t, lr, beta1, beta2, eps, decay, step, nullptr, stream);
+}
+extern "C" int lde_adamw_flux_step_dev(int n, const lde_adam_tensor* t, float lr, float beta1, float beta2, float eps, float decay,
+                                       int64_t* step_dev, void* stream) {
+  if (!step_dev) return LDE_ERR_INVALID_ARG;
+  return adamw_impl(n, t, lr, beta1, beta2, eps, decay, 0, step_dev, stream);
 }

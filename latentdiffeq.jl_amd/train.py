@@ -17,6 +17,7 @@ no kernel of its own.
 """
 from __future__ import annotations
 
+import ctypes as C
 import os
 from typing import Callable, Iterable, List, Optional, Sequence
 
@@ -146,7 +147,8 @@ class FluxADAMW(torch.optim.Adam):
     optimiser state keeps `step` as a Python int (a tensor step from a torch checkpoint is converted on entry); a native
     state_dict is therefore not resumable by torch's FUSED Adam, which expects tensor steps."""
 
-    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), decay: float = 0.0, eps: float = 1e-8, fused=None, native=None):
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), decay: float = 0.0, eps: float = 1e-8, fused=None, native=None,
+                 capturable: bool = False):
         params = list(params)
         on_gpu = bool(params) and all(p.is_cuda for p in params)
         if fused is None:
@@ -159,10 +161,37 @@ class FluxADAMW(torch.optim.Adam):
         if native and not ok:
             raise ValueError("FluxADAMW(native=True) needs contiguous float32 HIP parameters")
         self.native = bool(native)
+        # capturable (native only): the step count lives in ONE device int64 shared by all arrays (lde_adamw_flux_step_dev), so that the
+        # update can sit inside a captured hipGraph (train.GraphedStep); every array must then have a gradient at every step
+        self.capturable = bool(capturable)
+        if self.capturable and not self.native:
+            raise ValueError("FluxADAMW(capturable=True) needs the native path")
+        self._step_dev = torch.zeros((), dtype=torch.int64, device=params[0].device) if self.capturable else None
 
     @torch.no_grad()
     def _native_step(self):
         lib = L.load()
+        if self.capturable:
+            for g in self.param_groups:
+                ps = g["params"]
+                if any(p.grad is None for p in ps):
+                    raise RuntimeError("FluxADAMW(capturable=True): every parameter needs a gradient at every step")
+                keep = []
+                tab = (L.AdamTensor * len(ps))()
+                for i, p in enumerate(ps):
+                    st, gr = self.state[p], p.grad
+                    if not st:
+                        st["exp_avg"], st["exp_avg_sq"] = torch.zeros_like(p), torch.zeros_like(p)
+                    if gr.dtype != torch.float32 or not gr.is_contiguous():
+                        gr = gr.float().contiguous()
+                        keep.append(gr)
+                    t = tab[i]
+                    t.p, t.g, t.m, t.v, t.n = p.data_ptr(), gr.data_ptr(), st["exp_avg"].data_ptr(), st["exp_avg_sq"].data_ptr(), p.numel()
+                L.check(lib.lde_adamw_flux_step_dev(len(ps), tab, g["lr"], g["betas"][0], g["betas"][1], g["eps"], self.decay,
+                                                    C.c_void_p(self._step_dev.data_ptr()), L.raw_stream(ps[0].device.index)), None,
+                        "lde_adamw_flux_step_dev")
+                torch.autograd.graph.increment_version(ps)
+            return
         for g in self.param_groups:
             ps = [p for p in g["params"] if p.grad is not None]
             if not ps:

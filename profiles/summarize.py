@@ -5,13 +5,20 @@
 
 Units / corrections (MI355X_MICROARCH.md §HBM): FETCH_SIZE and WRITE_SIZE are reported in KiB; on gfx950 FETCH_SIZE
 counts 64 B per 128-B request for wide coalesced streaming reads (×2 to get bytes) — that calibration is for
-16-B-per-lane streams; other access widths are uncalibrated, so both the raw and the ×2 figure are stored.
+16-B-per-lane streams; other access widths are uncalibrated, so both the raw and the ×2 figure are stored, and
+`fetch_bytes` (what bench.py prices `roofline.traffic` with) applies the ×2 ONLY to the kernels declared below as
+16-byte-per-lane streaming readers; for every other kernel it is the raw count (a lower bound; ×2 is the upper one).
 """
 import csv
 import glob
 import json
 import sys
 from collections import defaultdict
+
+
+# kernels whose global reads are 16 B per lane, coalesced, streaming (the calibration's access shape)
+WIDE16 = ("k_mlp_dw", "k_reduce_tiles", "k_chain_forward", "k_chain_backward", "k_chain_dw_b", "k_loss_", "k_adamw", "k_refresh_many",
+          "k_build_frags")
 
 
 def kernel_key(name):
@@ -41,6 +48,8 @@ def main(src, dst):
                 d["FETCH_SIZE_KiB_per_launch"] = kib
                 d["fetch_bytes_raw"] = kib * 1024
                 d["fetch_bytes_x2_gfx950"] = 2 * kib * 1024
+                d["fetch_16B_per_lane"] = k.startswith(WIDE16)
+                d["fetch_bytes"] = (2 if k.startswith(WIDE16) else 1) * kib * 1024
             else:
                 d["WRITE_SIZE_KiB_per_launch"] = kib
                 d["write_bytes"] = kib * 1024

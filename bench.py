@@ -357,6 +357,8 @@ def decoder_cpu_baseline(specs, weights, d_native, ts, zt, tt, dxh, B, T, budget
 
 # ---- whole GOKU training step (BASELINE.json configs[4] shape, one GPU's share): encoder → sample → decoder → loss → pullback → AdamW
 def run_goku_step(args, torch, dist, world, rank, local):
+    if world == 1 and os.environ.get("LDE_BENCH_GRAPH", "1") != "0":
+        os.environ.setdefault("LDE_BRANCH_STREAMS", "0")   # the captured step runs on one stream (read when the package is imported)
     import latentdiffeq_amd as M
     from latentdiffeq_amd.chain import decode, default_decoder_layers
     from latentdiffeq_amd.dist import FlatGradAllReduce
@@ -379,8 +381,11 @@ def run_goku_step(args, torch, dist, world, rank, local):
         for m in (enc.feature_extractor, *enc.latent_in, lo_z0, lo_th, dec.reconstructor):
             m.set_dtype("bf16")
     params = [p for m in mods for p in m.parameters()]
-    from latentdiffeq_amd.train import FluxADAMW
-    opt = FluxADAMW(params, lr=1e-3, decay=1e-10)   # ADAMW(η, β, decay), Flux flavour [REF model_train.jl:138, :150]; one fused update kernel
+    from latentdiffeq_amd.train import FluxADAMW, GraphedStep
+    # one GPU: the whole step is captured in a hipGraph and replayed (train.GraphedStep; needs the encoder's branch streams off — read when
+    # the package was imported); LDE_BENCH_GRAPH=0 or a process group: eager
+    use_graph = world == 1 and os.environ.get("LDE_BENCH_GRAPH", "1") != "0" and os.environ.get("LDE_BRANCH_STREAMS") == "0"
+    opt = FluxADAMW(params, lr=1e-3, decay=1e-10, capturable=use_graph)   # ADAMW(η, β, decay), Flux flavour [REF model_train.jl:138, :150]; one fused update kernel
     sync = FlatGradAllReduce(params)
     torch.manual_seed(1000 + rank)
     x = torch.rand(T, B, NI, device=dev).permute(2, 1, 0)                   # synthetic frames in [0, 1], this rank's shard: [pixels, B, T] in the
@@ -419,12 +424,17 @@ def run_goku_step(args, torch, dist, world, rank, local):
             dist.barrier()
         torch.cuda.synchronize()
 
+    if use_graph:
+        gs = GraphedStep(step, warmup=3)
+        run = gs.replay
+    else:
+        run = step
     for _ in range(args.warmup):
-        step()
+        run()
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        loss = run()
     fence()
     el = time.perf_counter() - t0
     if world > 1:
@@ -444,7 +454,8 @@ def run_goku_step(args, torch, dist, world, rank, local):
         "config": {"workload": "goku_step: GOKU_basic default layers (input 784, T=50), Pendulum Tsit5, MSE + 1e-3·KL, AdamW; "
                                "torch-level API over lde_chain_* / lde_rnn_* / lde_forward / lde_adjoint",
                    "batch_per_gpu": B, "global_batch": Bg, "save_points": T,
-                   "parallelism": f"dp{world} (batch sharded by trajectory; one flat all-reduce of all parameter gradients per step)"},
+                   "parallelism": f"dp{world} (batch sharded by trajectory; one flat all-reduce of all parameter gradients per step)",
+                   "submission": "one hipGraph replay per step (train.GraphedStep)" if use_graph else "eager (≈ 80 launches per step)"},
         "roofline": dict(bound="mfma", kernel="whole step (dense chains dominate the flops)", achieved=3 * F_dense / (ms * 1e-3) / 1e12,
                          peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=3 * F_dense / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, traffic=None,
                          note="the step is ~78 launches; host enqueue time and device time are within a few per cent of each other (DESIGN.md §4.7)"),

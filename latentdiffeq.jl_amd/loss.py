@@ -180,26 +180,30 @@ def sample(mu, logvar, model_type=None):
     return _sample1(mu, logvar)
 
 
-def _sample_kl1(mu, logvar, scale: float, base):
+def _sample_kl1(mu, logvar, scale: float, base, eps=None):
     m, s, order = _same_layout(mu.float(), logvar.float())
-    eps = torch.randn(m.shape, device=m.device, dtype=torch.float32)
+    if eps is None:
+        eps = torch.randn(m.shape, device=m.device, dtype=torch.float32)
+    else:   # the caller's ε in the layout of μ (tests that compare two runs draw it once)
+        eps = eps.float().permute(order) if order is not None else eps.float()
+        eps = eps.contiguous()
     out, total = _SampleKlFn.apply(m, s, eps, float(scale), base)
     if order is not None:
         out = out.permute([order.index(d) for d in range(mu.dim())])
     return out, total
 
 
-def sample_with_kl(mu, logvar, beta: float = 1.0, batch_size=None):
+def sample_with_kl(mu, logvar, beta: float = 1.0, batch_size=None, eps=None):
     """(l̃, β·kl_loss): `sample(μ, logσ²)` and `β·vector_kl(μ, logσ²)` of the same arguments, computed together (one kernel pass
     each way per part instead of a sample pass, a KL pass and the additions of their cotangents)  [REF src/models/GOKU.jl:155-163],
     [REF src/utils/utils.jl:15-49]. For the GOKU tuple the second part's total continues the first's."""
     if isinstance(mu, tuple):
         outs, total = [], None
-        for m, s in zip(mu, logvar):
-            o, total = _sample_kl1(m, s, beta / (batch_size or m.shape[1]), total)
+        for i, (m, s) in enumerate(zip(mu, logvar)):
+            o, total = _sample_kl1(m, s, beta / (batch_size or m.shape[1]), total, None if eps is None else eps[i])
             outs.append(o)
         return tuple(outs), total
-    return _sample_kl1(mu, logvar, beta / (batch_size or mu.shape[1]), None)
+    return _sample_kl1(mu, logvar, beta / (batch_size or mu.shape[1]), None, eps)
 
 
 def _kl_sum(mu, logvar, scale: float):

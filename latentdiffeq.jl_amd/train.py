@@ -243,6 +243,39 @@ class FluxADAMW(torch.optim.Adam):
         return loss
 
 
+class GraphedStep:
+    """A whole training step — `fn()`: forward, loss, backward, `FluxADAMW(capturable=True).step()`, `refresh_weights` — captured ONCE
+    in a hipGraph (torch.cuda.CUDAGraph) and replayed: the step is ≈ 80 small launches whose host enqueue time (≈ 1.5 ms) equals the
+    device time; a replay is one submission  [REF examples/pendulum_friction-less/model_train.jl:186-204: the loop body this replaces].
+    What the capture needs, and gets: every workspace sized before it (`warmup` eager steps on a side stream), the optimiser's step count
+    in device memory (lde_adamw_flux_step_dev), gradients at fixed addresses (allocated from the graph's pool during capture), inputs
+    copied INTO the captured tensors (`static_inputs`: tensors `fn` reads; `replay(*new)` copies into them), and a single stream — call
+    with the encoder's branch streams off (`LDE_BRANCH_STREAMS=0`: cross-stream capture of the recurrent stacks' side streams aborts
+    inside the HIP runtime on ROCm 7.2). ε of `sample` comes from torch's generator, which is graph-safe (its offsets advance per replay).
+    One GPU: with a process group the all-reduce stays outside a graph here."""
+
+    def __init__(self, fn: Callable[[], torch.Tensor], static_inputs: Sequence[torch.Tensor] = (), warmup: int = 3):
+        self.fn, self.static_inputs = fn, list(static_inputs)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(warmup):
+                fn()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            out = fn()
+            self.loss = out.detach().clone() if isinstance(out, torch.Tensor) else None
+        torch.cuda.synchronize()
+
+    def replay(self, *new_inputs) -> Optional[torch.Tensor]:
+        for dst, src in zip(self.static_inputs, new_inputs):
+            dst.copy_(src)
+        self.graph.replay()
+        return self.loss
+
+
 def train(model: LatentDiffEqModel, loader_train: Iterable, val_set, dt: float, epochs: int, seq_len: int, full_seq_len: int,
           lr: float = 1e-3, decay: float = 1e-10, start_beta: float = 0.0, end_beta: float = 1.0, n_cycle: int = 3, ratio: float = 0.9,
           progressive_training: bool = False, prog_training_duration: int = 0, start_seq_len: int = 0, variational: bool = True,

@@ -1,0 +1,84 @@
+"""GPU: the whole GOKU training step captured in ONE hipGraph (train.GraphedStep: encoder → sample/KL → decoder → loss → pullback →
+Flux-flavour ADAMW with its step count in device memory → weight hand-over) replays to the SAME numbers as the eager step: with ε
+drawn once and shared, the loss of every step and every parameter after k steps are equal bit for bit
+[REF examples/pendulum_friction-less/model_train.jl:186-204: the loop body]. Runs in a subprocess: the encoder's side streams must be
+off (LDE_BRANCH_STREAMS=0, read at import) for the capture."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+SCRIPT = r'''
+import os, sys
+sys.path.insert(0, os.environ["LDE_ROOT"])
+import numpy as np, torch
+import latentdiffeq_amd as M
+from latentdiffeq_amd import _lib as L
+from latentdiffeq_amd.chain import decode, default_decoder_layers
+from latentdiffeq_amd.loss import reconstruction_loss, sample_with_kl
+from latentdiffeq_amd.recurrent import Encoder, default_encoder_layers, encode
+from latentdiffeq_amd.train import FluxADAMW, GraphedStep
+dtype = sys.argv[1]
+B, T, NI = 64, 20, 784
+dev = torch.device("cuda", 0)
+def build():
+    torch.manual_seed(100)
+    mt, diffeq = M.GOKU_basic(), M.Pendulum()
+    enc = Encoder(mt, default_encoder_layers(mt, NI, device=dev))
+    dec = M.Decoder(mt, default_decoder_layers(mt, NI, diffeq, device=dev))
+    with torch.no_grad():
+        dec.latent_out[1]._dense[-1].bias.fill_(1.0)
+    mods = [enc.feature_extractor, *enc.pattern_extractor, *enc.latent_in, *dec.latent_out, dec.reconstructor]
+    if dtype == "mixed":
+        for m in (enc.feature_extractor, *enc.latent_in, *dec.latent_out, dec.reconstructor):
+            m.set_dtype("bf16")
+    params = [p for m in mods for p in m.parameters()]
+    return enc, dec, mods, params, FluxADAMW(params, lr=1e-3, decay=1e-10, capturable=True)
+torch.manual_seed(5)
+xs = [torch.rand(T, B, NI, device=dev).permute(2, 1, 0) for _ in range(3)]        # three different minibatches, cycled
+eps = (torch.randn(16, B, device=dev), torch.randn(16, B, device=dev))            # ε of the two latent parts, drawn once
+ts = np.arange(T) * 0.05
+def make(enc, dec, mods, params, opt, x):
+    def step():
+        opt.zero_grad(set_to_none=True)
+        mu, logvar = encode(enc, x)
+        l_tilde, bkl = sample_with_kl(mu, logvar, 1e-3, B, eps=eps)
+        x_hat, _, _ = decode(dec, l_tilde, ts)
+        loss = reconstruction_loss(x, x_hat, B, plus=bkl)
+        loss.backward()
+        opt.step()
+        L.refresh_weights(mods)
+        return loss
+    return step
+K, W = 7, 3
+# eager: W warm-up steps on minibatch 0 (what GraphedStep's warm-up does), then K steps cycling the minibatches
+e = build(); xe = xs[0].clone(); se = make(*e, xe)
+for _ in range(W): se()
+le = []
+for k in range(K):
+    xe.copy_(xs[k % 3]); le.append(float(se()))
+# graph: W eager warm-up steps, the capture (which records and runs nothing), then K replays, each copying its minibatch into the
+# captured input tensor
+g = build(); xg = xs[0].clone(); sg = make(*g, xg)
+gs = GraphedStep(sg, static_inputs=[xg], warmup=W)
+lg = [float(gs.replay(xs[k % 3])) for k in range(K)]
+torch.cuda.synchronize()
+assert le == lg, (le, lg)
+for a, b in zip(e[3], g[3]):
+    assert torch.equal(a, b)
+assert int(g[4]._step_dev) == W + K
+print("ok", dtype, le[-1])
+'''
+
+
+@pytest.mark.parametrize("dtype", ["f32", "mixed"])
+def test_graph_replay_equals_eager_step(tmp_path, dtype):
+    f = tmp_path / "graph_step.py"
+    f.write_text(SCRIPT)
+    env = dict(os.environ, LDE_ROOT=ROOT, LDE_BRANCH_STREAMS="0")
+    r = subprocess.run([sys.executable, str(f), dtype], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

@@ -1755,19 +1755,39 @@ static bool mlp64_applicable(const MlpDims& dm, int B) {
 }
 // waves of the adjoint launch: one per SIMD (the kernel takes more than 256 registers); a wave walks trajectories b, b + waves, …
 // with ONE set of gradient sums, so the slab the final sum reads has `waves` rows whatever the batch
-static int mlp64_adj_waves(int B) {
-  static const int maxw = [] { const char* e = getenv("LDE_MLP64_WAVES"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 1024; }();
-  return B < maxw ? B : maxw;
+// workgroups of the adjoint launch: four waves each (one per SIMD of a CU — the kernel takes more than 256 registers), ≤ 256 of them; a
+// wave walks trajectories b, b + 4·workgroups, … with ONE set of gradient sums, the four waves' sums meet in LDS, and the slab the final
+// sum reads has one row per workgroup whatever the batch
+constexpr int MLP64_NWV = 4;
+static int mlp64_adj_waves(int B) {   // = workgroups = slab rows
+  static const int maxw = [] { const char* e = getenv("LDE_MLP64_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+  const int need = (B + MLP64_NWV - 1) / MLP64_NWV;
+  return need < maxw ? need : maxw;
 }
 template <bool ADJ>
 static int launch_mlp64(const MlpDims& dm, const KOpts& o, const VArgs& a, hipStream_t stream, std::string& err) {
   const bool rk4 = dm.solver == LDE_SOLVER_RK4, d2 = dm.Dp <= 2;
   if (ADJ) {
     const dim3 grid(mlp64_adj_waves(o.B));
-    if (rk4 && d2) hipLaunchKernelGGL((k_mlp64_adj<LDE_SOLVER_RK4, 2>), grid, dim3(64), 0, stream, dm, o, a);
-    else if (rk4) hipLaunchKernelGGL((k_mlp64_adj<LDE_SOLVER_RK4, 4>), grid, dim3(64), 0, stream, dm, o, a);
-    else if (d2) hipLaunchKernelGGL((k_mlp64_adj<LDE_SOLVER_TSIT5, 2>), grid, dim3(64), 0, stream, dm, o, a);
-    else hipLaunchKernelGGL((k_mlp64_adj<LDE_SOLVER_TSIT5, 4>), grid, dim3(64), 0, stream, dm, o, a);
+    const size_t lds = (size_t)MLP64_NWV * a.cap * sizeof(float);   // the four waves' rows (c3: 4 × 17.9 KB)
+    const void* fn = rk4 ? (d2 ? (const void*)k_mlp64_adj<LDE_SOLVER_RK4, 2> : (const void*)k_mlp64_adj<LDE_SOLVER_RK4, 4>)
+                         : (d2 ? (const void*)k_mlp64_adj<LDE_SOLVER_TSIT5, 2> : (const void*)k_mlp64_adj<LDE_SOLVER_TSIT5, 4>);
+    static bool attr_set[2][2] = {{false, false}, {false, false}};
+    if (!attr_set[rk4][d2]) {
+      hipFuncAttributes fa{};
+      (void)hipFuncGetAttributes(&fa, fn);
+      if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX - (int)fa.sharedSizeBytes) != hipSuccess) {
+        (void)hipGetLastError();
+        err = "hipFuncSetAttribute(k_mlp64_adj) failed";
+        return LDE_ERR_HIP;
+      }
+      attr_set[rk4][d2] = true;
+    }
+    MlpDims dmv = dm;
+    KOpts ov = o;
+    VArgs av = a;
+    void* argv[] = {(void*)&dmv, (void*)&ov, (void*)&av};
+    (void)hipLaunchKernel(fn, grid, dim3(64 * MLP64_NWV), argv, lds, stream);
   } else if (rk4 && d2) hipLaunchKernelGGL((k_mlp64<LDE_SOLVER_RK4, 2>), dim3(o.B), dim3(64), 0, stream, dm, o, a);
   else if (rk4) hipLaunchKernelGGL((k_mlp64<LDE_SOLVER_RK4, 4>), dim3(o.B), dim3(64), 0, stream, dm, o, a);
   else if (d2) hipLaunchKernelGGL((k_mlp64<LDE_SOLVER_TSIT5, 2>), dim3(o.B), dim3(64), 0, stream, dm, o, a);

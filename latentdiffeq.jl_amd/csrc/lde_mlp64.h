@@ -72,7 +72,7 @@ __device__ __forceinline__ void net64_rhs(Net64<DP>& n, const float (&z)[DP], fl
   // 64×64 product: h₁ goes through LDS once and comes back as 16 broadcast 16-byte reads feeding 32 packed FMAs on the lane's
   // register row. (The v_readlane form — SGPR broadcast, one v_fmac per element — is 64 × (readlane, 2 wait states, fmac) on
   // ONE accumulator: ≈ 770 cycles per product against ≈ 350 here.) One wave per workgroup: in-order LDS, no barrier.
-  n.hx[threadIdx.x] = n.h1;
+  n.hx[threadIdx.x & 63] = n.h1;
   asm volatile("" ::: "memory");
   float a2 = n.b2;
   {
@@ -103,7 +103,7 @@ __device__ __forceinline__ void net64_vjp(const Net64<DP>& n, const float (&z)[D
 #pragma unroll
   for (int d = 0; d < DP; d++) s2 += n.w3c[d] * lam[d];
   d2 = s2 * act_grad(n.act, n.h2);
-  n.hx[64 + threadIdx.x] = d2;
+  n.hx[64 + (threadIdx.x & 63)] = d2;
   asm volatile("" ::: "memory");
   float s1;
   {
@@ -140,10 +140,12 @@ struct Grad64 {
 
 template <int SOLVER, int DP, bool ADJ>
 __device__ __forceinline__ void mlp64_body(const MlpDims& dm, const KOpts& o, const VArgs& a) {
-  const int T = o.T, B = o.B, D = dm.D, Dp = dm.Dp, NP = dm.P, lane = threadIdx.x;
+  const int T = o.T, B = o.B, D = dm.D, Dp = dm.Dp, NP = dm.P, lane = threadIdx.x & 63;
+  const int wv = ADJ ? __builtin_amdgcn_readfirstlane(threadIdx.x >> 6) : 0, nwv = ADJ ? (int)(blockDim.x >> 6) : 1;   // the adjoint: NWV waves (trajectories) per workgroup
   constexpr int NS = ADJ ? 2 * DP + 1 : DP;      // [z | λ | g] (g stays 0 without a parameter)
   const int H1 = dm.sizes[1], H2 = dm.sizes[2];
-  __shared__ __attribute__((aligned(16))) float s_hx[7 * 128];   // ring: stage s → h₁ at [128 s, +64), δ₂ at [128 s + 64, +64)
+  __shared__ __attribute__((aligned(16))) float s_hx_all[(ADJ ? 4 : 1) * 7 * 128];   // per wave a ring: stage s → h₁ at [128 s, +64), δ₂ at [128 s + 64, +64)
+  float* const s_hx = s_hx_all + wv * 7 * 128;
   Net64<DP> n;
   {   // weights into registers (flat destructure order: vec(W) column-major [out×in], then b)
     const float* W = a.Wflat;
@@ -196,7 +198,7 @@ __device__ __forceinline__ void mlp64_body(const MlpDims& dm, const KOpts& o, co
     for (int m = 0; m < NST / 2; m++) bsel[m] = half ? bq(2 * m + 1) : bq(2 * m);
   }
 
-  for (int b = blockIdx.x; b < B; b += gridDim.x) {   // the adjoint walks several trajectories with one set of gradient sums
+  for (int b = blockIdx.x * nwv + wv; b < B; b += gridDim.x * nwv) {   // the adjoint walks several trajectories with one set of gradient sums
   {
     float L = 1.f;
     if (dm.has_pend) L = a.theta[(size_t)b * NP];
@@ -602,9 +604,13 @@ __device__ __forceinline__ void mlp64_body(const MlpDims& dm, const KOpts& o, co
   }
   }   // trajectories of this wave
 
-  if (ADJ) {   // this wave's row of the [waves × row stride] slab, flat destructure order (vec(W) column-major [out×in], then b)
-    float* row = a.stage + (size_t)blockIdx.x * a.cap;
+  if (ADJ) {   // the workgroup's row of the [workgroups × row stride] slab, flat destructure order (vec(W) column-major [out×in], then b):
+    // every wave lays its sums out in LDS, the four copies are added in wave order (fixed: bit-reproducible) and ONE row leaves the CU —
+    // a quarter of the slab bytes of a row per wave (c3: 18.6 → 4.6 MB written, and as much less read back by k_sum_rows)
+    extern __shared__ __attribute__((aligned(16))) float s_red[];
+    float* row = s_red + (size_t)wv * a.cap;
     const int Dpv = Dp;
+    for (int e = lane; e < a.cap; e += 64) row[e] = 0.f;   // (entries no lane owns: the padding of the row stride)
 #pragma unroll
     for (int ti = 0; ti < 2; ti++)
 #pragma unroll
@@ -622,6 +628,13 @@ __device__ __forceinline__ void mlp64_body(const MlpDims& dm, const KOpts& o, co
     }
     if (lane < H1) row[dm.b_off[0] + lane] = g.b1;
     if (lane < H2) row[dm.b_off[1] + lane] = g.b2;
+    __syncthreads();
+    float* out = a.stage + (size_t)blockIdx.x * a.cap;
+    for (int e = threadIdx.x; e < a.cap; e += blockDim.x) {
+      float t = s_red[e];
+      for (int w = 1; w < nwv; w++) t += s_red[(size_t)w * a.cap + e];
+      out[e] = t;
+    }
   }
 }
 
@@ -629,9 +642,10 @@ template <int SOLVER, int DP>
 __global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(2, 2))) k_mlp64(MlpDims dm, KOpts o, VArgs a) {
   mlp64_body<SOLVER, DP, false>(dm, o, a);
 }
-// the adjoint keeps 64 accumulator registers of gW₂ᵀ on top of the weights: one wave per SIMD, 512 registers
+// the adjoint keeps 64 accumulator registers of gW₂ᵀ on top of the weights: one wave per SIMD, 512 registers; four waves (one per SIMD of
+// a CU, each on its own trajectories) form a workgroup so that their gradient sums meet in LDS before they leave the CU
 template <int SOLVER, int DP>
-__global__ void __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(1, 1))) k_mlp64_adj(MlpDims dm, KOpts o, VArgs a) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) k_mlp64_adj(MlpDims dm, KOpts o, VArgs a) {
   mlp64_body<SOLVER, DP, true>(dm, o, a);
 }
 

@@ -763,14 +763,15 @@ int lde_chain_create(const lde_chain_desc* d, lde_chain** out) {
     c->bdx = bd;
     c->bdx.ldb = panel_stride_b(pad32(hmax));   // wide input read in place: the panels only hold hidden vectors
     c->bdx.ld0 = 0;
-    // The kernels take ≈ 200–250 registers at 512 threads: ONE workgroup per CU whatever its LDS, so the forward takes the widest tile
-    // that fits the 160 KB (measured, reconstructor at N = 12 800: 64 columns 45 µs, 32 columns 57 µs); the pullback's 64-column
-    // instantiation spills (132 µs against 118 µs at 32 columns): at most 32 columns there.
+    // 32-column tiles (CG = 2): ≤ 128 registers and ≤ 80 KB of LDS, so two workgroups share a CU (lde_chain_bf16.h: LDE_BF_PFA / LDE_BF_OCC);
+    // the 64-column forward instantiation exists for experiments (LDE_CHAIN_BCG_FWD=4)
     auto pickb = [&](const ChainDims& q, const BfDims& b, int* cgf, int* cgb) {
       *cgf = *cgb = 0;
-      for (int cg : {4, 2, 1}) {
-        if (!*cgf && chain_lds_b(q, b, cg, false) <= LDS_MAX) *cgf = cg;
-        if (cg <= 2 && !*cgb && chain_lds_b(q, b, cg, true) <= LDS_MAX) *cgb = cg;
+      for (size_t lim : {LDS_MAX / 2, LDS_MAX}) {
+        for (int cg : {2, 1}) {
+          if (!*cgf && chain_lds_b(q, b, cg, false) <= lim) *cgf = cg;
+          if (!*cgb && chain_lds_b(q, b, cg, true) <= lim) *cgb = cg;
+        }
       }
     };
     pickb(cd, bd, &c->bcg_fwd, &c->bcg_bwd);

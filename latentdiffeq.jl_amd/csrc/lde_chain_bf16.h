@@ -21,6 +21,16 @@
 // accumulation; hidden activations, the pre-skip activation and δ are STORED rounded to bf16 (round-to-nearest-even); biases,
 // the skip-gradient panel, x̂, dx and dW are f32.
 
+// Occupancy beats prefetch depth here (measured, reconstructor at N = 12 800): with the A ring two K-groups deep the 32-column kernels
+// take ≤ 128 registers, TWO workgroups share a CU (16 waves: one's barrier / L2 waits are the other's MFMAs) and all 400 tiles are
+// resident at once — forward 57 → 38 µs, pullback kernel 72 → 57 µs; eight K-groups deep (200+ registers, one workgroup per CU) the
+// 64-column forward took 45 µs, and four deep at 128 registers spills (pullback 118 → 134 µs).
+#ifndef LDE_BF_PFA
+#define LDE_BF_PFA 2
+#endif
+#ifndef LDE_BF_OCC
+#define LDE_BF_OCC 4      // __launch_bounds__' second argument = waves per SIMD: 4 = two 512-thread workgroups per CU
+#endif
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -66,7 +76,8 @@ __device__ __forceinline__ f32x4 mfma32_b(bf16x8 a, bf16x8 b, f32x4 c) { return 
 template <int CG, int BSRC, class Pre, class Epi, class Hook>
 __device__ __forceinline__ void chain_gemm_b(const __bf16* __restrict__ gfrag, int R, int K, const void* Bp, int ldb, long cgstride,
                                              Pre pre, Epi epi, Hook hook) {
-  constexpr int NW = 8, PFA = 8, PFB = BSRC == 0 ? 2 : 4;
+  constexpr int NW = 8, PFA = CG >= 4 ? 8 : LDE_BF_PFA, PFB0 = BSRC == 0 ? 2 : 4, PFB = PFB0 < PFA ? PFB0 : PFA;
+  static_assert(PFA % PFB == 0, "the B ring is indexed by i % PFB inside a PFA-unrolled block");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int RT = cdiv(R, 16), KG = cdiv(K, 32), kl = KG - 1;
@@ -252,7 +263,7 @@ __device__ __forceinline__ void chain_hidden_layer_b(const ChainDims& cd, const 
 }
 
 template <int CG>
-__global__ void __launch_bounds__(512) k_chain_forward_b(ChainDims cd, BfDims bd, ChainFwdArgsB a) {
+__global__ void __launch_bounds__(512, (CG <= 2 ? LDE_BF_OCC : 1)) k_chain_forward_b(ChainDims cd, BfDims bd, ChainFwdArgsB a) {
   extern __shared__ __attribute__((aligned(16))) float csm[];
   constexpr int NC = 16 * CG;
   const MlpDims& dm = cd.dm;
@@ -364,7 +375,7 @@ __device__ __forceinline__ void stage_delta_b(const __bf16* panel, int ld, int r
 }
 
 template <int CG>
-__global__ void __launch_bounds__(512) k_chain_backward_b(ChainDims cd, BfDims bd, ChainBwdArgsB a) {
+__global__ void __launch_bounds__(512, (CG <= 2 ? LDE_BF_OCC : 1)) k_chain_backward_b(ChainDims cd, BfDims bd, ChainBwdArgsB a) {
   extern __shared__ __attribute__((aligned(16))) float csm[];
   constexpr int NC = 16 * CG;
   const MlpDims& dm = cd.dm;

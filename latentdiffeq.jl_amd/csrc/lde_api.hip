@@ -348,6 +348,7 @@ static lde::KOpts make_opts(const lde_problem_desc& d, const double* ts, int T, 
   o.checkpoint = d.sensealg != LDE_SENSE_BACKSOLVE;
   o.T = T;
   o.B = B;
+  o.lb_hold = 0;
   o.t_first = ts[0];
   o.t_last = ts[T - 1];
   return o;

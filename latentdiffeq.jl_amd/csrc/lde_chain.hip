@@ -319,8 +319,11 @@ __device__ __forceinline__ void chain_hidden_layer(const ChainDims& cd, int l, c
                         });
 }
 
+#ifndef LDE_F32_OCC
+#define LDE_F32_OCC 1
+#endif
 template <int CG, bool BF>
-__global__ void __launch_bounds__(512) k_chain_forward(ChainDims cd, ChainFwdArgs a) {
+__global__ void __launch_bounds__(512, (CG <= 2 ? LDE_F32_OCC : 1)) k_chain_forward(ChainDims cd, ChainFwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float csm[];
   constexpr int NC = 16 * CG;
   const MlpDims& dm = cd.dm;
@@ -398,7 +401,7 @@ struct ChainBwdArgs {
 struct PrePair { f32x4 h, a; };
 
 template <int CG, bool BF>
-__global__ void __launch_bounds__(512) k_chain_backward(ChainDims cd, ChainBwdArgs a) {
+__global__ void __launch_bounds__(512, (CG <= 2 ? LDE_F32_OCC : 1)) k_chain_backward(ChainDims cd, ChainBwdArgs a) {
   extern __shared__ __attribute__((aligned(16))) float csm[];
   constexpr int NC = 16 * CG;
   const MlpDims& dm = cd.dm;

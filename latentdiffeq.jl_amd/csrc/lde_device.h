@@ -29,6 +29,7 @@ struct KOpts {
   int checkpoint;    // adjoint: reset z to the saved ẑ(t_j) at every save time
   int T, B;
   double t_first, t_last;   // ts[0], ts[T−1] (the host has the grid): a kernel need not load them before its first step
+  int lb_hold;              // large-batch forward: a lane this close to the end of the row ring waits for its wave (0: never)
 };
 
 

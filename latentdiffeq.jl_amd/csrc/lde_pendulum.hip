@@ -607,13 +607,23 @@ __global__ void __launch_bounds__(WS_THREADS) k_pend_forward_ws(const float2* __
 // predicated block and the stepping loop contains no load at all. With the next save time's load in it the compiler must put
 // `s_waitcnt vmcnt(0)` in front of the block, and vmcnt counts the previous step's ẑ STORES too — the stepping chain then waits
 // for write acknowledgements it has no use for.
-template <int KIND, int SOLVER, bool ADAPT, int TPW, bool ONE = false>
+template <int KIND, int SOLVER, bool ADAPT, int TPW, bool ONE = false, int RING = 0>
 __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict__ z0, const float* __restrict__ theta,
                                                         const double* __restrict__ ts_g, KOpts o,
                                                         float2* __restrict__ z_out, int32_t* __restrict__ retcode,
                                                         int32_t* __restrict__ st_nfe, int32_t* __restrict__ st_nacc,
                                                         int32_t* __restrict__ st_nrej, int32_t* __restrict__ st_ret) {
   constexpr int LPT = 64 / TPW;   // lanes per trajectory
+  static_assert(RING == 0 || (TPW == 64 && !ONE && RING <= 32 && (RING & (RING - 1)) == 0), "the row ring is for one trajectory per lane");
+  // RING > 0 (large batches, a lane owns a trajectory): the lanes of a wave pass a given save time at different iterations, so a
+  // direct store is 64 lanes × 8 bytes into up to 64 different rows of ẑ, and the 512 contiguous bytes a wave owns in row j arrive
+  // piecemeal over many iterations — with ≈ 25 KB of such half-written rows per resident wave and thousands of waves the L2s
+  // cannot hold them until they are whole (measured at B = 2²⁰, T = 50: 1128 MB written for 419 MB of ẑ). Here a lane parks its
+  // values in its own column of an LDS ring of RING rows, and the wave writes row jc — all 64 lanes, one full 512-byte store — as
+  // soon as its slowest trajectory has passed it. A lane that runs more than RING rows ahead stores directly (bit clear in `inring`).
+  __shared__ float2 s_ring[RING > 0 ? RING * 64 : 1];
+  unsigned inring = 0;
+  int jc = 1;                     // wave-uniform: the next row to leave the ring
   const int T = o.T, B = o.B, lane = threadIdx.x, slot = lane % LPT;
   // XCD-aware trajectory ↔ workgroup map (as in k_pend_adjoint_fused): workgroups are dealt round-robin to the 8 XCDs and a 128-byte
   // line of ẑ holds 16 neighbouring trajectories' values of one save time, each written by another wave — with neighbouring
@@ -672,6 +682,9 @@ __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict
     if (!__any(pen == 0.f)) break;
     const float rem = (float)(tend - t);
     const bool last = dt >= rem * 0.99999988f;
+    // (RING) a trajectory that has run to within lb_hold rows of the ring's end sits this iteration out: its attempt is computed and
+    // dropped like a stopped lane's, nothing of its state changes, and the rows it would have had to store piecemeal wait for the wave
+    const float penh = (RING > 0 && j >= jc + RING - o.lb_hold && o.lb_hold > 0) ? __builtin_inff() : pen;
     const float h = last ? rem : dt;
     k[0] = kf;
     f.anchor(y.x);
@@ -687,7 +700,7 @@ __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict
       for (int s = 1; s <= 4; s++) k[s] = f32x2{ka[s][0], ka[s][1]};
       yn = f32x2{yna[0], yna[1]};
     }
-    const float mq = fmaf(0.f, fabsf(yn.x) + fabsf(yn.y), msq + pen);   // ∞·0 = NaN: a non-finite state never passes
+    const float mq = fmaf(0.f, fabsf(yn.x) + fabsf(yn.y), msq + penh);   // ∞·0 = NaN: a non-finite state never passes
     const bool ok = mq <= 1.0f;
     float dtn = (float)o.dt_fixed, l = 0.f;
     if (ADAPT) {
@@ -695,8 +708,8 @@ __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict
       const float q = fmaxf(o.q_lo, fminf(o.q_hi, __builtin_amdgcn_exp2f(o.beta1 * l - o.beta2 * lqold) * o.inv_gamma));
       dtn = fminf(h * fast_rcp(q), dtmax);
     }
-    if (__builtin_expect(__any(!ok && pen == 0.f), 0)) {   // rare: a rejected or non-finite attempt
-      if (!ok && pen == 0.f) {
+    if (__builtin_expect(__any(!ok && penh == 0.f), 0)) {   // rare: a rejected or non-finite attempt
+      if (!ok && penh == 0.f) {
         const bool fin = (fabsf(yn.x) + fabsf(yn.y)) < __builtin_inff();
         nrej++;
         iters++;
@@ -743,7 +756,11 @@ __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict
               out.y = h00 * y.y + (h10 * h) * k[0].y + h01 * yn.y + (h11 * h) * k[4].y;
             }
           }
-          if (valid) *(ONE ? dst1 : z_out + (size_t)j * B + b) = out;   // (ONE: the lane's only store, address formed before the loop)
+          if (RING > 0 && j < jc + RING) {
+            s_ring[(j & (RING - 1)) * 64 + lane] = out;
+            inring |= 1u << (j & (RING - 1));
+          } else if (valid)
+            *(ONE ? dst1 : z_out + (size_t)j * B + b) = out;   // (ONE: the lane's only store, address formed before the loop)
           j += LPT;
           tj = tjn;
           tjn = (!ONE && j + LPT < T) ? ts_g[j + LPT] : dinf;
@@ -758,6 +775,15 @@ __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict
       lqold = fmaxf(l, LQ_MIN);
       active = !last;
       if (last || iters >= maxit) pen = __builtin_inff();
+    }
+    if (RING > 0) {   // rows every trajectory of the wave has passed (a stopped one — done, failed, out of range — holds nothing back)
+      const int jeff = pen == 0.f ? j : T;
+      while (jc < T && !__any(jeff <= jc)) {
+        const int r = jc & (RING - 1);
+        if (valid && ((inring >> r) & 1u)) z_out[(size_t)jc * B + b] = s_ring[r * 64 + lane];
+        inring &= ~(1u << r);
+        jc++;
+      }
     }
   }
   if (active && iters >= maxit) { ret = LDE_RET_MAXITERS; active = false; }
@@ -1370,6 +1396,41 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
     else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_RK4) LDE_LAUNCH_WS(1, LDE_SOLVER_RK4, false);
     else return LDE_ERR_UNSUPPORTED;
 #undef LDE_LAUNCH_WS
+    return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
+  }
+  // large batches (B ≥ 2¹⁷·… — LDE_PEND_LB_MIN_B): the lanes-as-save-times kernel with 64 trajectories per wave and the row ring
+  // (k_pend_forward_tl<…, 64, false, RING>): k_pend_forward's per-lane stores reach HBM as partial lines — 1128 MB written for 419 MB of
+  // ẑ at B = 2²⁰ — and the launch is bound by that traffic: 303 µs; with 16 ring rows and a 6-row hold 444 … 574 MB and 228 µs
+  // (abl/pend_LB.py, abl/pend_LB_pmc.sh). 32 rows write less still but leave 2.5 waves per SIMD (16 KB of LDS per wave): 280 µs.
+  // LDE_PEND_LB = rows of the ring (8 / 16 / 32; 0: off), LDE_PEND_LB_HOLD = the hold margin.
+  static const int lb_ring = [] { const char* e = getenv("LDE_PEND_LB"); return e ? atoi(e) : 16; }();   // rows of the ring; 0: off
+  static const int lb_min_b = [] { const char* e = getenv("LDE_PEND_LB_MIN_B"); return e ? atoi(e) : (1 << 17); }();
+  if (lb_ring > 0 && o.T > 1 && o.B >= lb_min_b) {
+    static const int lb_hold = [] { const char* e = getenv("LDE_PEND_LB_HOLD"); return e ? atoi(e) : 6; }();
+    KOpts oh = o;
+    oh.lb_hold = lb_hold;
+    const bool ad = o.adaptive != 0;
+    const int g8 = (((o.B + 63) / 64 + 7) / 8) * 8;
+#define LDE_LAUNCH_LB(K, S, A)                                                                                          \
+  do {                                                                                                                  \
+    if (lb_ring >= 32)                                                                                                  \
+      hipLaunchKernelGGL((k_pend_forward_tl<K, S, A, 64, false, 32>), dim3(g8), dim3(64), 0, stream, (const float2*)z0, theta, ts_dev, oh, \
+                         (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                                \
+    else if (lb_ring >= 16)                                                                                             \
+      hipLaunchKernelGGL((k_pend_forward_tl<K, S, A, 64, false, 16>), dim3(g8), dim3(64), 0, stream, (const float2*)z0, theta, ts_dev, oh, \
+                         (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                                \
+    else                                                                                                                \
+      hipLaunchKernelGGL((k_pend_forward_tl<K, S, A, 64, false, 8>), dim3(g8), dim3(64), 0, stream, (const float2*)z0, theta, ts_dev, oh, \
+                         (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                                \
+  } while (0)
+    if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5 && ad) LDE_LAUNCH_LB(0, LDE_SOLVER_TSIT5, true);
+    else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH_LB(0, LDE_SOLVER_TSIT5, false);
+    else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_RK4) LDE_LAUNCH_LB(0, LDE_SOLVER_RK4, false);
+    else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_TSIT5 && ad) LDE_LAUNCH_LB(1, LDE_SOLVER_TSIT5, true);
+    else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH_LB(1, LDE_SOLVER_TSIT5, false);
+    else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_RK4) LDE_LAUNCH_LB(1, LDE_SOLVER_RK4, false);
+    else return LDE_ERR_UNSUPPORTED;
+#undef LDE_LAUNCH_LB
     return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
   }
 #define LDE_LAUNCH(K, S)                                                                                              \

@@ -318,10 +318,10 @@ from tests.gpu_util import Native, make_desc
 out = {{}}
 cases = [("default", dict(), 256, 50), ("tight", dict(abstol=1e-6, reltol=1e-6), 70, 50), ("friction", dict(rhs_kind=O.RHS_PENDULUM_FRICTION), 64, 23),
          ("rk4", dict(solver=O.SOLVER_RK4, adaptive=0, dt=0.013), 65, 50), ("one", dict(), 1, 3), ("long", dict(abstol=1e-8, reltol=1e-8), 130, 200),
-         ("fail", dict(maxiters=9), 256, 50), ("mid", dict(), 3000, 50)]
+         ("fail", dict(maxiters=9), 256, 50), ("mid", dict(), 3000, 50), ("dense", dict(), 130, 600)]
 for name, kw, B, T in cases:
     z0, L = O.pendulum_inputs(B, seed=3)
-    ts = np.sort(np.random.default_rng(1).uniform(0.0, 3.0, T)) if name == "friction" else O.time_grid(T)
+    ts = np.sort(np.random.default_rng(1).uniform(0.0, 3.0, T)) if name == "friction" else O.time_grid(T, 0.004) if name == "dense" else O.time_grid(T)
     z, ret, st = Native(make_desc(**kw)).forward(z0, L, ts)
     out[name + "_z"], out[name + "_ret"] = z, ret
     out[name + "_st"] = np.array([st["nfe"], st["naccept"], st["nreject"], st["nfailed"]])
@@ -329,30 +329,34 @@ np.savez({path!r}, **out)
 """
 
 
-@pytest.mark.parametrize("variant", ["ws", "tl"])
+@pytest.mark.parametrize("variant", ["ws", "tl", "lb"])
 def test_small_batch_forward_kernels_match_the_single_wave_kernel(tmp_path, variant):
-    """Three forward kernels share the step code and the dense-output formulas: k_pend_forward_tl (B ≤ 1024: lanes = save
-    times), k_pend_forward_ws (B ≤ 16384: a stepping wave + helper waves pipelined through LDS) and k_pend_forward (one lane
-    per trajectory; LDE_PEND_TL_MAX_B=0 LDE_PEND_WS=0 forces it). They agree like two correct f32 solves — default and tight
+    """Four forward kernels share the step code and the dense-output formulas: k_pend_forward_tl (B ≤ 1024: lanes = save
+    times), k_pend_forward_ws (B ≤ 16384: a stepping wave + helper waves pipelined through LDS), k_pend_forward (one lane
+    per trajectory; LDE_PEND_TL_MAX_B=0 LDE_PEND_WS=0 forces it) and the large-batch form of the first (B ≥ 2¹⁷: a lane per
+    trajectory, ẑ rows leave through an LDS ring as whole 512-byte stores; LDE_PEND_LB_MIN_B=0 forces it, and the 200-point
+    grid with its 16-row ring exercises both the hold and the direct-store overflow). They agree like two correct f32 solves — default and tight
     tolerance, friction with off-grid save times, fixed-step RK4, a single trajectory, 200 save points (several save times
     per lane in the tl kernel), and trajectories that fail (NaN blocks)."""
     import os
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    if os.environ.get("LDE_PEND_WS", "1") == "0" or "LDE_PEND_TL_MAX_B" in os.environ:
+    if os.environ.get("LDE_PEND_WS", "1") == "0" or "LDE_PEND_TL_MAX_B" in os.environ or "LDE_PEND_LB_MIN_B" in os.environ:
         pytest.skip("this process already runs with a forced kernel choice")
     path = str(tmp_path / "single.npz")
     subprocess.run([sys.executable, "-c", _WS_SCRIPT.format(root=root, path=path)], check=True,
                    env=dict(os.environ, LDE_PEND_WS="0", LDE_PEND_TL_MAX_B="0"), timeout=600)
     here = str(tmp_path / "split.npz")
     subprocess.run([sys.executable, "-c", _WS_SCRIPT.format(root=root, path=here)], check=True,
-                   env=dict(os.environ, LDE_PEND_TL_MAX_B="0" if variant == "ws" else "1024"), timeout=600)
+                   env=dict(os.environ, **{"ws": dict(LDE_PEND_TL_MAX_B="0"), "tl": dict(LDE_PEND_TL_MAX_B="1024"),
+                                           "lb": dict(LDE_PEND_TL_MAX_B="0", LDE_PEND_WS="0", LDE_PEND_LB_MIN_B="0")}[variant]),
+                   timeout=600)
     a, b = np.load(here), np.load(path)
     # different compilations of the same step code: multiply-adds contract differently, so the adaptive step sequences part at
     # round-off level — the kernels agree like two correct f32 solves do (tests above: ≤ 3e-4 at the default tolerance,
     # ≤ 2e-5 at 1e-6), exactly where there is no controller (fixed-step RK4 ≤ 2e-6)
-    tol = dict(default=3e-4, friction=3e-4, one=3e-4, fail=3e-4, tight=2e-5, long=2e-5, rk4=2e-6, mid=3e-4)
+    tol = dict(default=3e-4, friction=3e-4, one=3e-4, fail=3e-4, tight=2e-5, long=2e-5, rk4=2e-6, mid=3e-4, dense=3e-4)   # (dense: ≈ 35 save times inside one step)
     for name, lim in tol.items():
         za, zb, ra, rb = a[name + "_z"], b[name + "_z"], a[name + "_ret"], b[name + "_ret"]
         flips = ra != rb

@@ -639,9 +639,16 @@ __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict
   constexpr int FS = (SOLVER == LDE_SOLVER_TSIT5) ? 6 : 4;  // FSAL slope
   constexpr int NS = (SOLVER == LDE_SOLVER_TSIT5) ? 6 : 4;  // RHS evaluations per attempt
   const double dinf = __longlong_as_double(0x7ff0000000000000LL);
+  // (RING) the save grid lives in LDS, one copy per wave: a global load in the dense-output loop is waited for with vmcnt, which
+  // counts the ring's row stores too — the loop would stall on write acknowledgements. A wave's LDS operations execute in order:
+  // no barrier between the staging and the first read.
+  extern __shared__ __attribute__((aligned(16))) double s_tsl[];
+  if (RING > 0)
+    for (int i = lane; i < T; i += 64) s_tsl[i] = ts_g[i];
+  auto ts_at = [&](int i) -> double { return RING > 0 ? s_tsl[i] : ts_g[i]; };
   int j = 1 + slot;                                                   // the save time this lane serves next,
-  double tj = j < T ? ts_g[j] : dinf;                                 // its value, and the one after it (prefetched:
-  double tjn = j + LPT < T ? ts_g[j + LPT] : dinf;                    // a load on the stepping chain would cost a memory latency)
+  double tj = j < T ? ts_at(j) : dinf;                                // its value, and the one after it (prefetched:
+  double tjn = j + LPT < T ? ts_at(j + LPT) : dinf;                   // a load on the stepping chain would cost a memory latency)
   float2* const dst1 = z_out + (size_t)(j < T ? j : 0) * B + (valid ? b : 0);
   f32x2 y = {zi.x, zi.y}, k[7], yn = {0.f, 0.f}, kf = {0.f, 0.f};
   int ret = LDE_RET_SUCCESS, nfe = 0, nacc = 0, nrej = 0;
@@ -763,7 +770,7 @@ __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict
             *(ONE ? dst1 : z_out + (size_t)j * B + b) = out;   // (ONE: the lane's only store, address formed before the loop)
           j += LPT;
           tj = tjn;
-          tjn = (!ONE && j + LPT < T) ? ts_g[j + LPT] : dinf;
+          tjn = (!ONE && j + LPT < T) ? ts_at(j + LPT) : dinf;
         }
       }
       nacc++;
@@ -1398,15 +1405,17 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
 #undef LDE_LAUNCH_WS
     return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
   }
-  // large batches (B ≥ 2¹⁷·… — LDE_PEND_LB_MIN_B): the lanes-as-save-times kernel with 64 trajectories per wave and the row ring
-  // (k_pend_forward_tl<…, 64, false, RING>): k_pend_forward's per-lane stores reach HBM as partial lines — 1128 MB written for 419 MB of
-  // ẑ at B = 2²⁰ — and the launch is bound by that traffic: 303 µs; with 16 ring rows and a 6-row hold 444 … 574 MB and 228 µs
-  // (abl/pend_LB.py, abl/pend_LB_pmc.sh). 32 rows write less still but leave 2.5 waves per SIMD (16 KB of LDS per wave): 280 µs.
+  // large batches (B ≥ 2¹⁷ — LDE_PEND_LB_MIN_B; T ≤ 2048): the lanes-as-save-times kernel with 64 trajectories per wave, the row ring
+  // and the save grid in LDS (k_pend_forward_tl<…, 64, false, RING>). k_pend_forward's per-lane stores reach HBM as partial lines —
+  // 1128 MB written for 419 MB of ẑ at B = 2²⁰ — and the launch is bound by that traffic: 303 µs. With 16 ring rows and an 8-row hold
+  // 444 … 574 MB are written and the launch takes 206 µs (2.1 TB/s of ẑ; abl/pend_LB.py, abl/pend_LB_pmc.sh); 8 rows / 3 the same within the
+  // run-to-run spread, 32 rows leave 2.5 waves per SIMD (16 KB of LDS per wave) and take 258 µs. What remains is instruction issue:
+  // ≈ 8.2 k instructions per wave (5.1 k VALU), of which the wave-sequential dense-output loop is ≈ 75 × 45 and the row flush 49 × 28.
   // LDE_PEND_LB = rows of the ring (8 / 16 / 32; 0: off), LDE_PEND_LB_HOLD = the hold margin.
   static const int lb_ring = [] { const char* e = getenv("LDE_PEND_LB"); return e ? atoi(e) : 16; }();   // rows of the ring; 0: off
   static const int lb_min_b = [] { const char* e = getenv("LDE_PEND_LB_MIN_B"); return e ? atoi(e) : (1 << 17); }();
-  if (lb_ring > 0 && o.T > 1 && o.B >= lb_min_b) {
-    static const int lb_hold = [] { const char* e = getenv("LDE_PEND_LB_HOLD"); return e ? atoi(e) : 6; }();
+  if (lb_ring > 0 && o.T > 1 && o.T <= 2048 && o.B >= lb_min_b) {   // (the save grid in LDS beside the ring: T ≤ 2048)
+    static const int lb_hold = [] { const char* e = getenv("LDE_PEND_LB_HOLD"); return e ? atoi(e) : 8; }();
     KOpts oh = o;
     oh.lb_hold = lb_hold;
     const bool ad = o.adaptive != 0;
@@ -1414,13 +1423,13 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
 #define LDE_LAUNCH_LB(K, S, A)                                                                                          \
   do {                                                                                                                  \
     if (lb_ring >= 32)                                                                                                  \
-      hipLaunchKernelGGL((k_pend_forward_tl<K, S, A, 64, false, 32>), dim3(g8), dim3(64), 0, stream, (const float2*)z0, theta, ts_dev, oh, \
+      hipLaunchKernelGGL((k_pend_forward_tl<K, S, A, 64, false, 32>), dim3(g8), dim3(64), (size_t)o.T * sizeof(double), stream, (const float2*)z0, theta, ts_dev, oh, \
                          (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                                \
     else if (lb_ring >= 16)                                                                                             \
-      hipLaunchKernelGGL((k_pend_forward_tl<K, S, A, 64, false, 16>), dim3(g8), dim3(64), 0, stream, (const float2*)z0, theta, ts_dev, oh, \
+      hipLaunchKernelGGL((k_pend_forward_tl<K, S, A, 64, false, 16>), dim3(g8), dim3(64), (size_t)o.T * sizeof(double), stream, (const float2*)z0, theta, ts_dev, oh, \
                          (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                                \
     else                                                                                                                \
-      hipLaunchKernelGGL((k_pend_forward_tl<K, S, A, 64, false, 8>), dim3(g8), dim3(64), 0, stream, (const float2*)z0, theta, ts_dev, oh, \
+      hipLaunchKernelGGL((k_pend_forward_tl<K, S, A, 64, false, 8>), dim3(g8), dim3(64), (size_t)o.T * sizeof(double), stream, (const float2*)z0, theta, ts_dev, oh, \
                          (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                                \
   } while (0)
     if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5 && ad) LDE_LAUNCH_LB(0, LDE_SOLVER_TSIT5, true);

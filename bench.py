@@ -475,6 +475,43 @@ def _free_port():
         return s.getsockname()[1]
 
 
+def attach_traffic(roof, workload, B, mlp, full_batch, dom=None, rounds=("r3", "r2", "r1")):
+    """roofline.traffic (+ rocprof_avg_launch_ms, whole_step.traffic) of the solve workloads from the newest committed PMC summary
+    (profiles/collect.sh + profiles/summarize.py; FETCH_SIZE ×2 only for kernels that load 16 bytes per lane, WRITE_SIZE as is —
+    MI355X_MICROARCH.md §HBM). Also called by profiles/refresh.py on the bench line it copies next to a fresh summary, so the
+    committed line and its summary cannot disagree."""
+    roof["traffic"] = None
+    for rnd in rounds:
+        prof = os.path.join(ROOT, "profiles", f"{rnd}_{workload}_b{B}_summary.json" if not mlp else f"{rnd}_{workload}_summary.json")
+        if not os.path.exists(prof):
+            continue
+        kern = json.load(open(prof))["kernels"]
+
+        def tb(kd):
+            return kd.get("fetch_bytes", kd["fetch_bytes_x2_gfx950"]) + kd["write_bytes"]
+        if not mlp:
+            kn = {"lde_forward": "k_pend_forward", "lde_adjoint": "k_pend_adjoint"}[dom or ("lde_forward" if "lde_forward" in roof.get("kernel", "lde_forward") else "lde_adjoint")]
+            for name, kd in kern.items():
+                if name.startswith(kn) and "write_bytes" in kd:
+                    roof["traffic"] = tb(kd)
+                    roof["rocprof_avg_launch_ms"] = kd["avg_ns"] * 1e-6
+        elif full_batch:   # MLP workloads: the dominant kernel's own traffic; the whole step's beside it
+            def is_adj_solve(name):   # the adjoint's solve kernels: k_mlp64_adj<…>, k_mlpw / k_mlpv<…, true…>, k_mlp_adjoint, k_mlp4_adjoint
+                return name.startswith(("k_mlp64_adj", "k_mlp_adjoint", "k_mlp4_adjoint")) or (name.startswith(("k_mlpw", "k_mlpv")) and "true" in name)
+            adj = [(kd.get("avg_ns", 0), tb(kd)) for name, kd in kern.items() if is_adj_solve(name) and "write_bytes" in kd]
+            tr = [tb(kd) for name, kd in kern.items() if name.startswith(("k_mlp", "k_reduce", "k_sum")) and "write_bytes" in kd]
+            if adj:
+                roof["traffic"] = float(max(adj)[1])                 # the longest-running solve kernel of the step = the adjoint's
+                roof["rocprof_avg_launch_ms"] = max(adj)[0] * 1e-6
+            if tr and "whole_step" in roof:
+                roof["whole_step"]["traffic"] = float(sum(tr))
+        if roof["traffic"] is not None:
+            roof["traffic_source"] = os.path.relpath(prof, ROOT)
+            break
+    return roof
+
+
+
 def count_gpus_sysfs():
     """GPUs of this node WITHOUT touching HIP/HSA (the launcher parent must stay GPU-free: it starts the ranks as children):
     KFD topology nodes with a non-zero simd_count, cut down by a *_VISIBLE_DEVICES list when one is set. None if sysfs has no KFD."""
@@ -749,32 +786,7 @@ def main():
                     traffic=None, alg_bytes_per_launch=dom_bytes * B, avg_launch_ms=dom_stream, avg_launch_ms_bracketed=dom_ms)
 
     # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    # (profiles/collect.sh + profiles/summarize.py; FETCH_SIZE ×2 on gfx950, WRITE_SIZE as is — MI355X_MICROARCH.md §HBM)
-    for rnd in ("r3", "r2", "r1"):
-        prof = os.path.join(ROOT, "profiles", f"{rnd}_{args.workload}_b{B}_summary.json" if not Ff else f"{rnd}_{args.workload}_summary.json")
-        if not os.path.exists(prof):
-            continue
-        kern = json.load(open(prof))["kernels"]
-        if not Ff:
-            kn = {"lde_forward": "k_pend_forward", "lde_adjoint": "k_pend_adjoint"}[dom]
-            for name, kd in kern.items():
-                if name.startswith(kn) and "write_bytes" in kd:
-                    roof["traffic"] = kd.get("fetch_bytes", kd["fetch_bytes_x2_gfx950"]) + kd["write_bytes"]
-                    roof["rocprof_avg_launch_ms"] = kd["avg_ns"] * 1e-6
-        elif B == w["B"]:   # MLP workloads: the dominant kernel's own traffic; the whole step's beside it
-            def tb(kd):
-                return kd.get("fetch_bytes", kd["fetch_bytes_x2_gfx950"]) + kd["write_bytes"]
-            def is_adj_solve(name):   # the adjoint's solve kernels: k_mlp64_adj<…>, k_mlpw / k_mlpv<…, true…>, k_mlp_adjoint, k_mlp4_adjoint
-                return name.startswith(("k_mlp64_adj", "k_mlp_adjoint", "k_mlp4_adjoint")) or (name.startswith(("k_mlpw", "k_mlpv")) and "true" in name)
-            adj = [(kd.get("avg_ns", 0), tb(kd)) for name, kd in kern.items() if is_adj_solve(name) and "write_bytes" in kd]
-            tr = [tb(kd) for name, kd in kern.items() if name.startswith(("k_mlp", "k_reduce", "k_sum")) and "write_bytes" in kd]
-            if adj:
-                roof["traffic"] = float(max(adj)[1])                 # the longest-running solve kernel of the step = the adjoint's
-            if tr:
-                roof["whole_step"]["traffic"] = float(sum(tr))
-        if roof["traffic"] is not None:
-            roof["traffic_source"] = os.path.relpath(prof, ROOT)
-            break
+    attach_traffic(roof, args.workload, B, mlp=bool(Ff), full_batch=(B == w["B"]), dom=None if Ff else dom)
 
     out = {
         "metric": "trajectories/sec (fwd+adjoint) GOKU pendulum, batch=256, 1/2/4/8 GPU"

@@ -70,7 +70,7 @@ struct PendBwd {
 #define LDE_PEND_PROF 0
 #endif
 #ifndef LDE_PEND_ABL
-#define LDE_PEND_ABL 0   // diagnostic ablations of the stepping loop (abl/pend_prof.py): 1 no record writes, 2 no controller, 3 idle helpers
+#define LDE_PEND_ABL 0   // diagnostic ablations of the stepping loop (abl/pend_prof.py): 1 no record writes, 2 no controller, 3 idle helpers, 4 fused adjoint without the interval integration
 #endif
 #if LDE_PEND_PROF
 static __device__ long long g_pprof[32];
@@ -1265,7 +1265,12 @@ __global__ void __launch_bounds__(1024) k_pend_adjoint_fused(const float2* __res
   asm volatile("" : "+v"(zc.x), "+v"(zc.y), "+v"(dj.x), "+v"(dj.y), "+v"(t0), "+v"(t1), "+v"(zT.x), "+v"(zT.y), "+v"(dT.x), "+v"(dT.y));
   if (j >= 0) {
     float y[8];
+#if LDE_PEND_ABL == 4   // diagnostic: what the kernel costs WITHOUT the interval integration (loads, tree, launch) — DESIGN §4.2b
+    y[2] = 1.f + zc.x * 1e-9f; y[3] = 0.f; y[4] = 0.f; y[5] = 1.f; y[6] = (float)(t1 - t0) * Lb * 1e-9f; y[7] = 0.f;
+    nacc = 1;
+#else
     ret = pend_interval_operator<KIND, SOLVER>(zc, Lb, t0, t1, o, y, nacc, nrej);
+#endif
     op = AffOp{y[2], y[4], y[3], y[5], dj.x, dj.y, y[6], y[7], 0.f};   // λ' = λ₀·(la) + λ₁·(lb) + Δ_j ; g' = g + ga λ₀ + gb λ₁
   }
   // order-preserving tree reduction inside the wave (a save interval takes a handful of attempts: the two counts share a word)

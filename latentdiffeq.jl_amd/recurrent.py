@@ -392,6 +392,7 @@ def _encode_goku_branches(encoder: Encoder, fe_out):
         mu_th, ls_th = li_mu_th(pe_th), li_ls_th(pe_th)
     main.wait_stream(sA)
     main.wait_stream(sB)
+    main.wait_stream(sC)      # (already ordered through sB; joined explicitly so that a stream capture sees every fork return to its origin)
     for y in (mu_z0, ls_z0, mu_th, ls_th):
         y.record_stream(main)
     return (mu_z0, mu_th), (ls_z0, ls_th)

@@ -37,6 +37,18 @@ for w in args:
     shutil.copy(ks, f"{ROOT}/profiles/{RND}_{w}_kernel_stats.csv")
     b = f"{OUT}/bench_{w}.json" if not w.startswith("goku_pendulum") else f"{OUT}/bench_metric.json"
     if os.path.exists(b):
-        shutil.copy(b, f"{ROOT}/profiles/{RND}_{w}_bench.json")
+        dst = f"{ROOT}/profiles/{RND}_{w}_bench.json"
+        shutil.copy(b, dst)
+        # the line was printed on the GPU box next to the PREVIOUS summary: re-attach the traffic figures from the one just written
+        sys.path.insert(0, ROOT)
+        import bench
+        lines = open(dst).read().strip().splitlines()
+        d = json.loads(lines[-1])
+        roof = d.get("roofline") or {}
+        if roof.get("bound") == "hbm" and w.startswith("goku_pendulum"):
+            bench.attach_traffic(roof, "goku_pendulum", d["config"]["batch_per_gpu"], mlp=False, full_batch=True, rounds=(RND,))
+        elif w in ("c2", "c3", "c4"):
+            bench.attach_traffic(roof, w, d["config"]["batch_per_gpu"], mlp=True, full_batch=True, rounds=(RND,))
+        open(dst, "w").write(json.dumps(d) + "\n")
     s = json.load(open(f"{ROOT}/profiles/{RND}_{w}_summary.json"))
     print(w, {k.split("<")[0]: round(v.get("avg_ns", 0) / 1e3, 1) for k, v in s["kernels"].items() if k.startswith("k_")})

@@ -40,7 +40,10 @@
 #include <cstdlib>
 #include <cstring>
 #include <cmath>
+#include <cstdint>
+#include <initializer_list>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "lde_device.h"
@@ -2045,6 +2048,37 @@ static int global_serve(MlpPlan* p, hipStream_t stream, std::string& err) {
   return rc;
 }
 
+// Control words and staging weights a call starts from zero: ONE launch for all of them. As hipMemsetAsync calls they were up to eight
+// dependent ≈ 5 µs fill kernels in front of a coupled solve (rocprofv3: 10.7 fills per c4 step, 55 µs of a 2 ms step).
+struct ZeroRegions {
+  uint32_t* p[6];
+  unsigned long long n[6];   // 32-bit words
+};
+__global__ void __launch_bounds__(256) k_zero_regions(ZeroRegions z) {
+  for (int r = 0; r < 6; r++) {
+    uint32_t* q = z.p[r];
+    const unsigned long long n = z.n[r];
+    for (unsigned long long i = (unsigned long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (unsigned long long)gridDim.x * 256) q[i] = 0u;
+  }
+}
+static bool zero_regions(hipStream_t stream, std::initializer_list<std::pair<void*, size_t>> regs) {
+  ZeroRegions z{};
+  int r = 0;
+  unsigned long long most = 0;
+  for (const auto& pr : regs) {
+    if (!pr.first || pr.second == 0) continue;
+    if (r == 6 || (pr.second & 3) || ((uintptr_t)pr.first & 3)) return false;
+    z.p[r] = (uint32_t*)pr.first;
+    z.n[r] = pr.second / 4;
+    most = std::max(most, z.n[r]);
+    r++;
+  }
+  if (r == 0) return true;
+  const int grid = (int)std::min<unsigned long long>(1024, (most + 255) / 256);
+  hipLaunchKernelGGL(k_zero_regions, dim3(grid), dim3(256), 0, stream, z);
+  return hipGetLastError() == hipSuccess;
+}
+
 int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* theta, const double* ts_dev,
                 const KOpts& o, float* z_out, int32_t* retcode, int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret,
                 hipStream_t stream, std::string& err) {
@@ -2068,9 +2102,8 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
       va.z0 = z0; va.theta = theta; va.ts = ts_dev; va.vecw = p->vecw; va.Wflat = W_dev; va.z_out = z_out; va.retcode = retcode;
       va.st_nfe = nfe; va.st_nacc = nacc; va.st_nrej = nrej; va.st_ret = ret;
       va.gs.counter = p->counter; va.gs.slots = p->slots; va.gs.abort_flag = p->abort_flag; va.gs.nwg = ca ? o.B : 1;
-      if (ca && (hipMemsetAsync(p->counter, 0, sizeof(unsigned), stream) != hipSuccess ||
-                 hipMemsetAsync(p->abort_flag, 0, sizeof(int), stream) != hipSuccess)) {
-        err = "hipMemsetAsync(counter) failed";
+      if (ca && !zero_regions(stream, {{p->counter, sizeof(unsigned)}, {p->abort_flag, sizeof(int)}})) {
+        err = "k_zero_regions(counter) failed";
         return LDE_ERR_HIP;
       }
       if (use_w) {
@@ -2113,9 +2146,8 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
   a.gs.counter = p->counter; a.gs.slots = p->slots; a.gs.abort_flag = p->abort_flag; a.gs.nwg = sync ? nwg : 1;
   const size_t lds = with_cache(fixed, p->nfrag);
   a.lds_bytes = (int)lds;
-  if (sync && (hipMemsetAsync(p->counter, 0, sizeof(unsigned), stream) != hipSuccess ||
-               hipMemsetAsync(p->abort_flag, 0, sizeof(int), stream) != hipSuccess)) {
-    err = "hipMemsetAsync(counter) failed";
+  if (sync && !zero_regions(stream, {{p->counter, sizeof(unsigned)}, {p->abort_flag, sizeof(int)}})) {
+    err = "k_zero_regions(counter) failed";
     return LDE_ERR_HIP;
   }
 #if LDE_PROF
@@ -2257,11 +2289,7 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
   a.gs.counter = p->counter; a.gs.slots = p->slots; a.gs.abort_flag = p->abort_flag; a.gs.nwg = sync ? nwg : 1;
   const size_t lds = with_cache(fixed, p->nfrag + p->nfragT);
   a.lds_bytes = (int)lds;
-  if (sync && (hipMemsetAsync(p->counter, 0, sizeof(unsigned), stream) != hipSuccess ||
-               hipMemsetAsync(p->abort_flag, 0, sizeof(int), stream) != hipSuccess)) {
-    err = "hipMemsetAsync(counter) failed";
-    return LDE_ERR_HIP;
-  }
+  bool ctl_zeroed = false;   // counter + abort flag of the grid-wide sums: zeroed together with whatever else the first solve kernel needs
 #if LDE_PROF
   prof_reset();
 #endif
@@ -2276,17 +2304,13 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
       return LDE_ERR_UNSUPPORTED;
     }
     if (use_w || vec_applicable(p, o.B, o.T, true, ca, &ldsv, err)) {
-      if (hipMemsetAsync(p->fb_dev, 0, 2 * sizeof(int32_t), stream) != hipSuccess ||
-          hipMemsetAsync(p->nslots, 0, (size_t)2 * (nwg + 1) * sizeof(int32_t), stream) != hipSuccess ||
-          hipMemsetAsync(p->wts, 0, (size_t)nwg * p->adj_cap * NB * sizeof(float), stream) != hipSuccess) {
-        err = "hipMemsetAsync(staging weights) failed";
+      if (!zero_regions(stream, {{p->fb_dev, 2 * sizeof(int32_t)}, {p->nslots, (size_t)2 * (nwg + 1) * sizeof(int32_t)},
+                                 {p->wts, (size_t)nwg * p->adj_cap * NB * sizeof(float)},
+                                 {(ca || sync) ? p->counter : nullptr, sizeof(unsigned)}, {(ca || sync) ? p->abort_flag : nullptr, sizeof(int)}})) {
+        err = "k_zero_regions(staging weights) failed";
         return LDE_ERR_HIP;
       }
-      if (ca && (hipMemsetAsync(p->counter, 0, sizeof(unsigned), stream) != hipSuccess ||
-                 hipMemsetAsync(p->abort_flag, 0, sizeof(int), stream) != hipSuccess)) {
-        err = "hipMemsetAsync(counter) failed";
-        return LDE_ERR_HIP;
-      }
+      ctl_zeroed = true;
       VArgs va{};
       va.theta = theta; va.ts = ts_dev; va.vecw = p->vecw; va.Wflat = W_dev; va.z_out = const_cast<float*>(z_out); va.dz_out = dz_out;
       va.dz0 = dz0; va.dtheta = dtheta; va.stage = p->stage; va.wts = p->wts; va.nslots = p->nslots; va.cap = p->adj_cap; va.ovf = p->fb_dev + 1;
@@ -2323,18 +2347,14 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
     if (mlp4_layout(dm, o.T, o.B, dm.coupled && o.adaptive, &md, &lds4, &nblocks)) {
       const bool sync4 = dm.coupled && o.adaptive && nblocks > 1;
       const int ntile4 = cdiv(nblocks * md.wpb, 4);   // ≤ nwg + 1: the workspace is sized for that
-      if (hipMemsetAsync(p->fb_dev, 0, 2 * sizeof(int32_t), stream) != hipSuccess ||
-          hipMemsetAsync(p->nslots, 0, (size_t)2 * (nwg + 1) * sizeof(int32_t), stream) != hipSuccess ||
-          hipMemsetAsync(p->wts, 0, (size_t)ntile4 * p->adj_cap * NB * sizeof(float), stream) != hipSuccess) {
-        err = "hipMemsetAsync(staging weights) failed";
+      if (!zero_regions(stream, {{p->fb_dev, 2 * sizeof(int32_t)}, {p->nslots, (size_t)2 * (nwg + 1) * sizeof(int32_t)},
+                                 {p->wts, (size_t)ntile4 * p->adj_cap * NB * sizeof(float)},
+                                 {(sync4 || sync) ? p->counter : nullptr, sizeof(unsigned)}, {(sync4 || sync) ? p->abort_flag : nullptr, sizeof(int)}})) {
+        err = "k_zero_regions(staging weights) failed";
         return LDE_ERR_HIP;
       }
+      ctl_zeroed = true;
       a.gs.nwg = sync4 ? nblocks : 1;
-      if (sync4 && !sync && (hipMemsetAsync(p->counter, 0, sizeof(unsigned), stream) != hipSuccess ||
-                             hipMemsetAsync(p->abort_flag, 0, sizeof(int), stream) != hipSuccess)) {
-        err = "hipMemsetAsync(counter) failed";
-        return LDE_ERR_HIP;
-      }
       int hmaxw = 0;
       for (int l = 1; l < dm.nL; l++) hmaxw = std::max(hmaxw, dm.sizes[l]);
       const int nth = hmaxw <= 64 ? 1 : (hmaxw <= 128 ? 2 : 4);
@@ -2354,6 +2374,10 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
         return LDE_ERR_HIP;
       }
     }
+  }
+  if (sync && !ctl_zeroed && !zero_regions(stream, {{p->counter, sizeof(unsigned)}, {p->abort_flag, sizeof(int)}})) {
+    err = "k_zero_regions(counter) failed";
+    return LDE_ERR_HIP;
   }
   int rc = dm.solver == LDE_SOLVER_RK4 ? launch_adjoint<LDE_SOLVER_RK4>(p, o, a, nwg, lds, stream, err, sync)
                                        : launch_adjoint<LDE_SOLVER_TSIT5>(p, o, a, nwg, lds, stream, err, sync);

@@ -71,11 +71,15 @@ DATA_KEYS = ("latent_data", "u0s", "ps", "high_dim_data")
 
 def save_dataset(path: str, latent_data, u0s, ps, high_dim_data) -> str:
     """`@save data_path data` with `data = (latent_data, u0s, ps, high_dim_data)`  [REF examples/pendulum_friction-less/
-    model_train.jl:86-91]. The reference writes a BSON file; BSON is Julia-side glue (no reader in this image), so the same
-    4-tuple is kept as one `.npz` with the tuple's names, arrays in the reference's shapes: latent_data [2, T, n], u0s [2, n],
+    model_train.jl:86-91]. A path ending in `.bson` writes the reference's container — a BSON document {data: <the 4-tuple in the
+    reference's nesting, lowered as BSON.jl lowers it>} (`bson.py`; unpinned against BSON.jl's own bytes: none exist here) — any other
+    path one `.npz` with the tuple's names. Dense arrays in the reference's shapes either way: latent_data [2, T, n], u0s [2, n],
     ps [1, n], high_dim_data [28, 28, T, n] (float32)."""
     arrs = {k: np.ascontiguousarray((v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)), dtype=np.float32)
             for k, v in zip(DATA_KEYS, (latent_data, u0s, ps, high_dim_data))}
+    if path.endswith(".bson"):
+        from . import bson
+        return bson.dump_dataset(path, *(arrs[k] for k in DATA_KEYS))
     if not path.endswith(".npz"):
         path += ".npz"
     np.savez(path, **arrs)
@@ -84,11 +88,27 @@ def save_dataset(path: str, latent_data, u0s, ps, high_dim_data) -> str:
 
 def load_dataset(path: str):
     """`load(data_path, :data)` → (latent_data, u0s, ps, high_dim_data) as numpy arrays  [REF model_train.jl:95]."""
+    if path.endswith(".bson"):
+        from . import bson
+        return bson.load_dataset(path)
     with np.load(path) as f:
         missing = [k for k in DATA_KEYS if k not in f]
         if missing:
             raise KeyError(f"{path}: not a dataset container (missing {missing})")
         return tuple(np.array(f[k]) for k in DATA_KEYS)
+
+
+def save_weights(path: str, weights) -> str:
+    """`@save "…/best_model_weights.bson" weights` with `weights = Flux.params(model)` [REF model_train.jl:213-215]: the list of
+    parameter arrays (here: each module's flat `Flux.destructure` vector), as a BSON vector of Float32 arrays."""
+    from . import bson
+    return bson.save(path, weights=[np.ascontiguousarray(w.detach().cpu().numpy() if isinstance(w, torch.Tensor) else np.asarray(w),
+                                                         dtype=np.float32) for w in weights])
+
+
+def load_weights(path: str):
+    from . import bson
+    return bson.load(path)["weights"]
 
 
 def prepare_training_data(data, at: float = 0.9):

@@ -58,6 +58,34 @@ def test_refresh_weights_equals_per_module_uploads_and_tracks_changes():
     assert all(m._wkey is None for m in b.modules())
 
 
+def test_native_optimiser_steps_without_refresh_are_seen_by_the_modules():
+    """refresh_weights() ONCE, then native FluxADAMW steps (lde_adamw_flux_step writes the parameters through raw pointers) without
+    another refresh: the optimiser bumps the parameters' version counters, so every module notices its (storage, version) key no
+    longer matches and uploads by itself — same losses and gradients as a model that is refreshed after every step. (Before round 3
+    the native update left the key unchanged and such a loop trained on the weights of the first refresh.)"""
+    import torch
+    from latentdiffeq_amd.train import FluxADAMW
+    B, T = 24, 12
+    ts = np.arange(T) * 0.05
+    x = torch.rand(T, B, 64, device="cuda").permute(2, 1, 0)
+    a, b = _model(11), _model(11)
+    oa = FluxADAMW(list(a.parameters()), lr=1e-2, decay=1e-10)
+    ob = FluxADAMW(list(b.parameters()), lr=1e-2, decay=1e-10)
+    assert b.refresh_weights() == 11
+    losses = []
+    for _ in range(3):
+        la_, _ = _loss_and_grads(a, x, ts)
+        oa.step()
+        a.refresh_weights()                                 # a: the documented loop — refresh after every update
+        lb, _ = _loss_and_grads(b, x, ts)
+        ob.step()                                           # b: never refreshed again
+        assert la_ == lb, (la_, lb)
+        losses.append(la_)
+    assert len(set(losses)) == 3                            # (the weights did move: three different losses)
+    for pa, pb in zip(a.parameters(), b.parameters()):
+        assert torch.equal(pa, pb)
+
+
 def test_refresh_weights_rejects_bad_arguments():
     from latentdiffeq_amd import _lib as L
     lib = L.load()

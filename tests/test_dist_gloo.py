@@ -128,6 +128,17 @@ def _grad_worker(rank, world, port, q):
             grads.append(([l.numpy() for l in local], [p.grad.detach().clone().numpy() for p in params]))
         if mode == "attached":
             assert sync._attached()                # the views survived three steps
+            # gradient accumulation is not silently wrong: a second backward() before the reduce of the first one raises (its
+            # buckets' sums are already on the wire); collecting afterwards drains the outstanding handles on every rank alike
+            sync.zero_()
+            net(x).square().sum().backward()
+            try:
+                net(x).square().sum().backward()
+                raised = False
+            except RuntimeError as e:
+                raised = "backward() ran again" in str(e)
+            assert raised
+            sync()
         out[mode] = grads
     q.put((rank, out))
     dist.barrier()

@@ -684,13 +684,13 @@ def main():
         dW = torch.zeros((nW,), device=dev) if nW else None
         tsp = ts.ctypes.data_as(C.POINTER(C.c_double))
 
-        def fwd():
-            L.check(lib.lde_forward(h, p(z0d), p(thd), tsp, T, B, p(zout), p(ret), sp), h, "lde_forward")
+        def fwd(s=sp):
+            L.check(lib.lde_forward(h, p(z0d), p(thd), tsp, T, B, p(zout), p(ret), s), h, "lde_forward")
 
-        def bwd():
+        def bwd(s=sp):
             if dW is not None:
                 dW.zero_()
-            L.check(lib.lde_adjoint(h, p(zout), p(thd), tsp, T, B, p(dzd), p(dz0), p(dth), p(dW), sp), h, "lde_adjoint")
+            L.check(lib.lde_adjoint(h, p(zout), p(thd), tsp, T, B, p(dzd), p(dz0), p(dth), p(dW), s), h, "lde_adjoint")
             if dW is not None and world > 1:  # the one collective of the path: shared RHS-MLP gradient
                 if comm is not None:
                     comm.allreduce_(dW)
@@ -701,19 +701,55 @@ def main():
             fwd()
             bwd()
 
+        # The analytic-RHS step is two ≈ 5–11 µs kernels: a launch-bound inner loop, so the K timed steps are submitted as hipGraph
+        # replays (chunks of ≤ 256 captured steps; every step still runs both kernels on the same buffers — abl/metric_graph.py:
+        # 14.3 µs per step against 14.9–15.5 µs for 2·K stream launches, and the rate no longer depends on how fast this host thread
+        # enqueues beside seven other ranks). LDE_BENCH_GRAPH=0 or a failed capture: plain stream launches.
+        graphs = None
+        if not nW and os.environ.get("LDE_BENCH_GRAPH", "1") != "0":
+            try:
+                gs = torch.cuda.Stream()
+                gsp = C.c_void_p(gs.cuda_stream)
+                gs.wait_stream(torch.cuda.current_stream())
+                chunk = max(1, min(args.steps, 256))
+                plan = [(chunk, args.steps // chunk)] + ([(args.steps % chunk, 1)] if args.steps % chunk else [])
+                with torch.cuda.stream(gs):
+                    fwd(gsp)
+                    bwd(gsp)
+                    torch.cuda.synchronize()
+                    graphs = []
+                    for n, reps in plan:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g, stream=gs):
+                            for _ in range(n):
+                                fwd(gsp)
+                                bwd(gsp)
+                        graphs.append((g, reps))
+                    torch.cuda.synchronize()
+                    for g, _ in graphs:      # first replay of a graph uploads it: part of the warm-up
+                        g.replay()
+                    torch.cuda.synchronize()
+            except Exception as e:   # noqa: BLE001 — the measurement falls back to stream launches and says so
+                sys.stderr.write(f"bench: hipGraph capture failed ({e}); timing stream launches\n")
+                graphs = None
         for _ in range(args.warmup):
             step()
         fence()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
+        if graphs:
+            for g, reps in graphs:
+                for _ in range(reps):
+                    g.replay()
+        else:
+            for _ in range(args.steps):
+                step()
         fence()
         el = time.perf_counter() - t0
         if world > 1:
             tmax = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             el = float(tmax.item())
-        res = dict(el=el, B=B, nW=nW, problem=(d, ts, z0, theta, W, dz))
+        res = dict(el=el, B=B, nW=nW, problem=(d, ts, z0, theta, W, dz), graphed=bool(graphs))
         if detail:
             nprobe = min(max(args.steps, 20), 200)
             fwd()
@@ -797,7 +833,9 @@ def main():
         "config": {"workload": f"{args.workload}: {w['desc']}", "batch_per_gpu": B, "global_batch": global_batch,
                    "save_points": T, "rccl_ranks": args.rccl_ranks,
                    "parallelism": f"dp{world} (batch sharded by trajectory, no data-path collective)"
-                   if not nW else f"dp{world} (batch sharded; one all-reduce of dW per step: {comm_kind})"},
+                   if not nW else f"dp{world} (batch sharded; one all-reduce of dW per step: {comm_kind})",
+                   "submission": "hipGraph replays of ≤ 256 captured steps (each step = lde_forward + lde_adjoint)" if m.get("graphed")
+                   else "stream launches (two per step)"},
         "roofline": roof,
         "kernel_ms": {"lde_forward": fwd_stream, "lde_adjoint": bwd_stream, "lde_forward_bracketed": fwd_ms, "lde_adjoint_bracketed": bwd_ms},
         # per-step figures from HIP events (an event pair around every step): the wall-clock mean above is K steps / elapsed

@@ -87,17 +87,23 @@ static __device__ long long g_pprof[32];
 // leaves k[1..6], yn; returns the mean square of the scaled error (EEst²; 0 when !ADAPT).
 template <class F, bool ADAPT>
 __device__ __forceinline__ float tsit5_attempt_pair(F& f, float h, f32x2 y, f32x2 (&k)[7], f32x2& yn, const KOpts& o) {
+  // Column-oriented: as soon as a slope exists it is added to the sums of ALL later stages — independent instructions that fill the
+  // wait states behind a packed FMA and behind v_sin, where the row-oriented form (finish one stage's sum, then evaluate) is a chain
+  // of dependent v_pk_fma_f32 with an s_nop between every two. Every sum still receives its terms in the order j = 0, 1, …: the
+  // same arithmetic, bit for bit.
+  f32x2 acc[7];
 #pragma unroll
-  for (int s = 1; s < 6; s++) {
-    f32x2 acc = k[0] * ts5::A[s][0];
+  for (int s = 1; s <= 6; s++) acc[s] = k[0] * ts5::A[s][0];
 #pragma unroll
-    for (int j = 1; j < s; j++) acc += k[j] * ts5::A[s][j];
-    k[s] = f.ev(y + acc * h);
+  for (int j = 1; j < 6; j++) {
+    k[j] = f.ev(y + acc[j] * h);
+#pragma unroll
+    for (int s = j + 1; s <= 6; s++) {
+      acc[s] += k[j] * ts5::A[s][j];
+      asm volatile("" : "+v"(acc[s]));   // keep the column order (the scheduler otherwise re-serialises the later stages' sums into chains)
+    }
   }
-  f32x2 acc = k[0] * ts5::A[6][0];
-#pragma unroll
-  for (int j = 1; j < 6; j++) acc += k[j] * ts5::A[6][j];
-  yn = y + acc * h;
+  yn = y + acc[6] * h;
   k[6] = f.ev(yn);
   if (!ADAPT) return 0.f;
   f32x2 e = k[0] * ts5::BT[0];

@@ -16,6 +16,7 @@ bash profiles/collect.sh ${R}_goku_decoder_mixed --workload goku_decoder --dtype
 python bench.py --workload goku_decoder --dtype mixed --steps 50 --warmup 10 --no-cpu-baseline > gpurun_out/bench_goku_decoder_mixed.json 2>/dev/null
 bash profiles/collect.sh ${R}_goku_step --workload goku_step --steps 100 --warmup 10 > /dev/null 2>&1
 python bench.py --workload goku_step --steps 100 --warmup 10 > gpurun_out/bench_goku_step.json 2>/dev/null
+bash profiles/collect.sh ${R}_goku_step_mixed --workload goku_step --dtype mixed --steps 100 --warmup 10 > /dev/null 2>&1
 python bench.py --workload goku_step --dtype mixed --steps 100 --warmup 10 > gpurun_out/bench_goku_step_mixed.json 2>/dev/null
 python bench.py --workload c4 --batch 4096 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_c4_b4096.json 2>/dev/null
 python bench.py --workload c2 --batch 4096 --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/bench_c2_b4096.json 2>/dev/null

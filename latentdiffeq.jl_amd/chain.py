@@ -92,7 +92,10 @@ class _ChainFn(torch.autograd.Function):
             chain._wkey = None
         N = x.shape[0]
         y = torch.empty((N, chain.sizes[-1]), device=x.device, dtype=torch.float32)
-        train = (x.requires_grad or W.requires_grad) and torch.is_grad_enabled()
+        # (inside Function.forward grad mode is always off — torch.is_grad_enabled() is False here whether or not a pullback will
+        #  follow; ctx.needs_input_grad is what says so. Until round 3 this line asked is_grad_enabled() and the training variant
+        #  was never taken through autograd: every pullback recomputed the hidden layers.)
+        train = bool(ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         saved = None
         if train:
             saved = torch.empty((int(lib.lde_chain_saved_floats(h, N)),), device=x.device, dtype=torch.float32)

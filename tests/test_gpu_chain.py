@@ -286,3 +286,33 @@ def test_overwrite_mode_of_the_weight_gradient(o32):
     assert nat.lib.lde_rnn_set_accumulate(nat.h, 0) == 0
     _, got = nat.backward(x, dy, dW0=np.full(nat.nW, -7.0, np.float32))
     assert np.array_equal(got, ref)
+
+
+def test_torch_bridge_takes_the_training_variant():
+    """Through autograd the forward call must keep the hidden activations (lde_chain_forward_save) so that the pullback does not
+    recompute them: inside torch.autograd.Function.forward grad mode is off, so the decision has to come from ctx.needs_input_grad
+    (until round 3 it asked torch.is_grad_enabled() and never took the variant). Same numbers either way (bit-equal, test above)."""
+    import torch
+    from latentdiffeq_amd.chain import Chain, Dense
+    c = Chain(Dense(16, 40, "relu"), Dense(40, 3, "identity")).to("cuda")
+    x = torch.randn(50, 16, device="cuda")
+    y = c.apply_batch_major(x)                                   # the parameter requires a gradient
+    assert y.grad_fn is not None and y.grad_fn.has_saved is True
+    y.sum().backward()
+    g_saved = c.theta.grad.clone()
+    with torch.no_grad():
+        assert c.apply_batch_major(x).grad_fn is None
+    c.theta.requires_grad_(False)
+    xr = x.clone().requires_grad_(True)
+    y2 = c.apply_batch_major(xr)                                 # only the input does: still the training variant
+    assert y2.grad_fn.has_saved is True and torch.equal(y2, y)
+    assert c.apply_batch_major(x).grad_fn is None                # nothing does: plain forward
+    # the recomputing pullback (C ABI, no saved buffer) gives the same weight gradient bit for bit
+    from tests.gpu_util import NativeChain
+    nat = NativeChain(c.sizes, c.acts, c.skips)
+    nat.set_weights(c.theta.detach().cpu().numpy())
+    xn = x.cpu().numpy()
+    yn = nat.forward(xn)
+    _, dW = nat.backward(xn, yn, np.ones_like(yn))
+    assert np.array_equal(dW, g_saved.cpu().numpy())
+

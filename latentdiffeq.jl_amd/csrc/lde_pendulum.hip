@@ -70,7 +70,7 @@ struct PendBwd {
 #define LDE_PEND_PROF 0
 #endif
 #ifndef LDE_PEND_ABL
-#define LDE_PEND_ABL 0   // diagnostic ablations of the stepping loop (abl/pend_prof.py): 1 no record writes, 2 no controller, 3 idle helpers, 4 fused adjoint without the interval integration
+#define LDE_PEND_ABL 0   // diagnostic ablations of the stepping loop (abl/pend_prof.py): 1 no record writes, 2 no controller, 3 idle helpers, 4 fused adjoint without the interval integration, 5 k_pend_forward_sh without helpers
 #endif
 #if LDE_PEND_PROF
 static __device__ long long g_pprof[32];
@@ -814,6 +814,277 @@ __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict
   }
 }
 
+// ---- forward, B ≤ one workgroup per CU: a stepping wave and three dense-output waves per TRAJECTORY (round 3) -------------------
+// In k_pend_forward_tl the wave that steps also evaluates the saves: ≈ 45 instructions + 21 constants per step of ≈ 165, on the one
+// instruction chain whose length IS the launch. Here a workgroup is ONE trajectory on four waves, one per SIMD: wave 0 steps and does
+// nothing else — per accepted step it leaves {h, yₙ₊₁} in LDS (one 16-byte write per lane into the lane's own copy, then the step
+// count; LDS executes a wave's operations in order, so a reader that sees the count sees the record: no barrier, no fence) — and
+// waves 1…3 walk the records: each rebuilds the slopes of every third step from (yₙ, hₙ) — the stepper's code on the stepper's
+// inputs, so the same bits — and its lanes, which own the save times as in the tl kernel (lane s: j = 1+s, 65+s, …), interpolate
+// and store what falls into that step. A helper has three step times for one step's slopes + dense output, so the stepper never
+// waits; what follows the last step is one helper's last evaluation. Records live in a ring of SH_CAP steps (a solve that needs
+// more goes through another round: one barrier pair); a failed solve's NaN block is written after the helpers' stores have landed.
+constexpr int SH_CAP = 48;       // accepted steps recorded per round (48 KB of LDS: 16 B × 64 lane copies per step)
+constexpr int SH_NH = 3;         // helper waves
+#ifndef LDE_PEND_SH_SLEEP
+#define LDE_PEND_SH_SLEEP 0
+#endif
+
+template <int KIND, int SOLVER, bool ADAPT>
+__global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restrict__ z0, const float* __restrict__ theta,
+                                                         const double* __restrict__ ts_g, KOpts o,
+                                                         float2* __restrict__ z_out, int32_t* __restrict__ retcode,
+                                                         int32_t* __restrict__ st_nfe, int32_t* __restrict__ st_nacc,
+                                                         int32_t* __restrict__ st_nrej, int32_t* __restrict__ st_ret) {
+  __shared__ __attribute__((aligned(16))) float s_rec[SH_CAP * 64 * 4];
+  __shared__ __attribute__((aligned(16))) float s_klast[64 * 16];   // the last step's seven slopes (a copy per lane)
+  __shared__ int s_cnt[64];
+  __shared__ int s_fin;    // 0: stepping; 1: the round is over, another follows; 2: done
+  __shared__ int s_fail;
+  const int T = o.T, B = o.B, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int chunk = gridDim.x >> 3;   // XCD-aware trajectory ↔ workgroup map (as k_pend_forward_tl); the grid is a multiple of 8
+  const int b = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  const bool valid = b < B;
+  const int bc = valid ? b : B - 1;
+  const double t_first = o.t_first, tend = o.t_last;
+  const float2 zi = z0[bc];
+  PendFwd<KIND> f(theta[bc]);
+  if (tid < 64) s_cnt[tid] = 0;
+  if (tid == 0) { s_fin = 0; s_fail = 0; }
+  __syncthreads();
+  constexpr int FS = (SOLVER == LDE_SOLVER_TSIT5) ? 6 : 4;  // FSAL slope
+  constexpr int NS = (SOLVER == LDE_SOLVER_TSIT5) ? 6 : 4;  // RHS evaluations per attempt
+  auto rec_at = [&](int n) -> float* { return s_rec + (size_t)(n * 64 + lane) * 4; };
+
+  if (w == 0) {
+    // ================= the stepper: k_pend_forward_tl's loop without the dense output =================
+    f32x2 y = {zi.x, zi.y}, k[7], yn = {0.f, 0.f}, kf = {0.f, 0.f};
+    int ret = LDE_RET_SUCCESS, nfe = 0, nacc = 0, nrej = 0;
+    double t = t_first;
+    float dt = 0.f;
+    constexpr float LQ_MIN = -13.287712379549449f;   // log₂ of qoldinit = 1e-4
+    float lqold = LQ_MIN;
+    const int maxit = o.maxiters > 0x7fffffffLL ? 0x7fffffff : (int)o.maxiters;
+    const float dtmin = (float)o.dtmin;
+    int iters = 0;
+#pragma unroll
+    for (int s = 0; s < 7; s++) k[s] = f32x2{0.f, 0.f};
+    if (valid && lane == 0) z_out[b] = zi;  // ts[0] is saved as ẑ₀ itself
+    const double dtmax_d = tend - t;
+    const float dtmax = (float)dtmax_d;
+    f.anchor(y.x);
+    kf = f.ev(y);
+    nfe = 1;
+    if (ADAPT) {
+      if (o.dt_fixed > 0) dt = (float)fmin(o.dt_fixed, dtmax_d);
+      else {
+        const float ya[2] = {y.x, y.y}, fa[2] = {kf.x, kf.y};
+        dt = (float)init_dt<2>(f, ya, fa, 1.0f, dtmax_d, o);
+        nfe++;
+      }
+    } else
+      dt = (float)o.dt_fixed;
+    bool active = t < tend && maxit > 0;
+    if (t < tend && !active) ret = LDE_RET_MAXITERS;
+    for (;;) {   // rounds
+      int n = 0;
+      float* rp = rec_at(0);
+      float pen = (active && iters < maxit) ? 0.f : __builtin_inff();
+      for (;;) {
+        if (!__any(pen == 0.f)) break;
+        const float rem = (float)(tend - t);
+        const bool last = dt >= rem * 0.99999988f;
+        const float h = last ? rem : dt;
+        k[0] = kf;
+        f.anchor(y.x);
+        float msq = 0.f;
+        if (SOLVER == LDE_SOLVER_TSIT5) msq = tsit5_attempt_pair<PendFwd<KIND>, ADAPT>(f, h, y, k, yn, o);
+        else {
+          const float ya[2] = {y.x, y.y};
+          float ka[7][2], yna[2];
+          ka[0][0] = kf.x;
+          ka[0][1] = kf.y;
+          rk4_step<2>(f, h, ya, ka, yna);
+#pragma unroll
+          for (int s = 1; s <= 4; s++) k[s] = f32x2{ka[s][0], ka[s][1]};
+          yn = f32x2{yna[0], yna[1]};
+        }
+        const float mq = fmaf(0.f, fabsf(yn.x) + fabsf(yn.y), msq + pen);   // ∞·0 = NaN: a non-finite state never passes
+        const bool ok = mq <= 1.0f;
+        float dtn = (float)o.dt_fixed, l = 0.f;
+        if (ADAPT) {
+          l = 0.5f * __builtin_amdgcn_logf(msq);
+          const float q = fmaxf(o.q_lo, fminf(o.q_hi, __builtin_amdgcn_exp2f(o.beta1 * l - o.beta2 * lqold) * o.inv_gamma));
+          dtn = fminf(h * fast_rcp(q), dtmax);
+        }
+        if (__builtin_expect(__any(!ok && pen == 0.f), 0)) {   // rare: a rejected or non-finite attempt
+          if (!ok && pen == 0.f) {
+            const bool fin = (fabsf(yn.x) + fabsf(yn.y)) < __builtin_inff();
+            nrej++;
+            iters++;
+            if (!ADAPT) { ret = LDE_RET_NONFINITE; active = false; nrej--; }
+            else if (!fin) {
+              if (h > dtmin) dt = h * o.qmin;
+              else { ret = LDE_RET_NONFINITE; active = false; nrej--; }
+            } else {
+              dt = h * fast_rcp(fminf(o.q_hi, __builtin_amdgcn_exp2f(o.beta1 * l) * o.inv_gamma));
+              if (dt < dtmin) { ret = LDE_RET_DTMIN; active = false; }
+            }
+            if (!active || iters >= maxit) pen = __builtin_inff();
+          }
+        }
+        if (ok) {   // the accepted step: leave {h, yₙ₊₁} behind, publish, advance
+          if (last) {   // once per solve: the last step's slopes travel too — its helper would otherwise start rebuilding them only now, a
+                        // whole step's worth of instructions behind the end of the solve (measured: 1.3 µs of the launch)
+            float* kl = s_klast + lane * 4;   // [quarter][lane][4]: every 16-byte write conflict-free
+            *reinterpret_cast<f32x4*>(kl) = f32x4{k[0].x, k[0].y, k[1].x, k[1].y};
+            *reinterpret_cast<f32x4*>(kl + 256) = f32x4{k[2].x, k[2].y, k[3].x, k[3].y};
+            *reinterpret_cast<f32x4*>(kl + 512) = f32x4{k[4].x, k[4].y, k[5].x, k[5].y};
+            *reinterpret_cast<f32x4*>(kl + 768) = f32x4{k[6].x, k[6].y, 0.f, 0.f};
+          }
+          *reinterpret_cast<f32x4*>(rp) = f32x4{h, yn.x, yn.y, 0.f};
+          rp += 64 * 4;
+          n++;
+          asm volatile("" ::: "memory");                                      // the count is published AFTER the record
+          __hip_atomic_store(&s_cnt[lane], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (a plain LDS store: ds_write_b32)
+          nacc++;
+          iters++;
+          y = yn;
+          kf = k[FS];
+          t = last ? tend : t + (double)h;
+          dt = dtn;
+          lqold = fmaxf(l, LQ_MIN);
+          active = !last;
+          if (last || n >= SH_CAP || iters >= maxit) pen = __builtin_inff();
+        }
+      }
+      if (active && iters >= maxit) { ret = LDE_RET_MAXITERS; active = false; }
+      if (ret != LDE_RET_SUCCESS && lane == 0) __hip_atomic_store(&s_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      asm volatile("" ::: "memory");
+      if (lane == 0) __hip_atomic_store(&s_fin, active ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (!active) break;
+      __syncthreads();   // A: the helpers have consumed this round's records
+      s_cnt[lane] = 0;
+      if (lane == 0) s_fin = 0;
+      __syncthreads();   // B: counts reset
+    }
+    if (ret != LDE_RET_SUCCESS) {  // failed solve ⇒ NaN block, never an error [REF GOKU.jl:114] — after every helper store has landed
+      __syncthreads();   // F
+      if (valid) {
+        const float qn = __int_as_float(0x7fc00000);
+        for (int j = lane; j < T; j += 64) z_out[(size_t)j * B + b] = make_float2(qn, qn);
+      }
+    }
+    if (valid && lane == 0) {
+      if (retcode) retcode[b] = ret;
+      st_ret[b] = ret;
+      st_nfe[b] = nfe + NS * (nacc + nrej);
+      st_nacc[b] = nacc;
+      st_nrej[b] = nrej;
+    }
+    return;
+  }
+
+  // ================= the helpers: wave 1 + hid rebuilds every SH_NH-th step; lanes = save times =================
+#if LDE_PEND_ABL == 5   // diagnostic: the stepper alone (no dense output at all — results are wrong)
+  return;
+#endif
+  const int hid = w - 1;
+  const double dinf = __longlong_as_double(0x7ff0000000000000LL);
+  int jq = 1 + lane;                                   // the save time this lane looks for next
+  double tj = jq < T ? ts_g[jq] : dinf;
+  double tn = t_first;                                 // the walk over the records: record n2 starts at time tn in state ys
+  f32x2 ys = {zi.x, zi.y};
+  int nrec = 0;                                        // records walked so far over all rounds (whose turn a step is)
+  for (;;) {   // rounds
+    int n2 = 0, fin;
+    for (;;) {
+      fin = __hip_atomic_load(&s_fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // read BEFORE the count: if the round is over, the count is final
+      const int cnt = __hip_atomic_load(&s_cnt[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      asm volatile("" ::: "memory");
+      while (n2 < cnt) {
+        const f32x4 q = *reinterpret_cast<const f32x4*>(rec_at(n2));
+        const float h = q[0];
+        const f32x2 ye = {q[1], q[2]};
+        const double t1 = (h == (float)(tend - tn)) ? tend : tn + (double)h;   // exactly the stepper's arithmetic
+        const bool mine = (nrec % SH_NH) == hid;
+        if (__any(tj <= t1)) {
+          f32x2 k0 = {0.f, 0.f}, kE = {0.f, 0.f}, P2 = {0.f, 0.f}, P3 = {0.f, 0.f}, P4 = {0.f, 0.f};
+          float rh = 0.f;
+          if (mine && __any(tj < t1)) {   // rebuild the step's slopes: the stepper's code on the stepper's inputs (yₙ, hₙ)
+            rh = fast_rcp(h);
+            if (SOLVER == LDE_SOLVER_TSIT5) {
+              f32x2 kk[7], ynr;
+              if (t1 == tend) {   // the step that reaches the end: its slopes came with the record
+                const float* kl = s_klast + lane * 4;
+                const f32x4 a0 = *reinterpret_cast<const f32x4*>(kl), a1 = *reinterpret_cast<const f32x4*>(kl + 256);
+                const f32x4 a2 = *reinterpret_cast<const f32x4*>(kl + 512), a3 = *reinterpret_cast<const f32x4*>(kl + 768);
+                kk[0] = f32x2{a0[0], a0[1]}; kk[1] = f32x2{a0[2], a0[3]}; kk[2] = f32x2{a1[0], a1[1]}; kk[3] = f32x2{a1[2], a1[3]};
+                kk[4] = f32x2{a2[0], a2[1]}; kk[5] = f32x2{a2[2], a2[3]}; kk[6] = f32x2{a3[0], a3[1]};
+              } else {
+                f.anchor(ys.x);
+                kk[0] = f.ev(ys);
+                (void)tsit5_attempt_pair<PendFwd<KIND>, false>(f, h, ys, kk, ynr, o);
+              }
+              k0 = kk[0];
+              P2 = kk[0] * ts5::R1[0];
+              P3 = kk[0] * ts5::R1[1];
+              P4 = kk[0] * ts5::R1[2];
+#pragma unroll
+              for (int s = 0; s < 6; s++) {
+                P2 += kk[s + 1] * ts5::R[s][0];
+                P3 += kk[s + 1] * ts5::R[s][1];
+                P4 += kk[s + 1] * ts5::R[s][2];
+              }
+            } else {
+              f.anchor(ys.x);
+              k0 = f.ev(ys);
+              kE = f.ev(ye);   // f(yₙ₊₁), the slope at the end of the step
+            }
+          }
+          while (tj <= t1) {   // this lane's save times inside the step (whoever serves them, the lane moves past them)
+            if (mine) {
+              float2 out;
+              if (tj >= t1) out = make_float2(ye.x, ye.y);   // the save time is the step's end
+              else {
+                const float th = (float)(tj - tn) * rh;
+                if (SOLVER == LDE_SOLVER_TSIT5) {
+                  out.x = tsit5_dense_eval<2>(th, h, ys.x, k0.x, P2.x, P3.x, P4.x);
+                  out.y = tsit5_dense_eval<2>(th, h, ys.y, k0.y, P2.y, P3.y, P4.y);
+                } else {  // cubic Hermite between (y,k1) and (yn,f(yn))
+                  const float om = 1.0f - th;
+                  const float h00 = (1.0f + 2.0f * th) * om * om, h10 = th * om * om;
+                  const float h01 = th * th * (3.0f - 2.0f * th), h11 = th * th * (th - 1.0f);
+                  out.x = h00 * ys.x + (h10 * h) * k0.x + h01 * ye.x + (h11 * h) * kE.x;
+                  out.y = h00 * ys.y + (h10 * h) * k0.y + h01 * ye.y + (h11 * h) * kE.y;
+                }
+              }
+              if (valid) z_out[(size_t)jq * B + b] = out;
+            }
+            jq += 64;
+            tj = jq < T ? ts_g[jq] : dinf;
+          }
+        }
+        tn = t1;
+        ys = ye;
+        n2++;
+        nrec++;
+      }
+      if (fin) break;   // (read before the count: everything of this round has been walked)
+#if LDE_PEND_SH_SLEEP
+      __builtin_amdgcn_s_sleep(1);   // (≈ 0.14 µs on gfx950; the helpers have a SIMD each, so they may as well watch the count)
+#endif
+    }
+    if (fin == 2) break;
+    __syncthreads();   // A
+    __syncthreads();   // B
+  }
+  if (__hip_atomic_load(&s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // F: every helper store has been issued and waited for
+  }
+}
+
 // ---- adjoint --------------------------------------------------------------------------------------
 // Reverse-time integration of [z, λ, g_L] from t_T to t_1 with a forced stop at every save time:
 // λ += Δ_j there, and (checkpointed mode) z is reset to the saved ẑ(t_j).
@@ -1368,6 +1639,24 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
   static const int ws_max_b = [] { const char* e = getenv("LDE_PEND_WS_MAX_B"); return e ? atoi(e) : 16384; }();   // measured (abl/pend_B.py): 21.6 vs 31.2 µs at 16384, 36.8 vs 32.6 µs at 32768
   // the smallest batches: lanes = save times, TPW trajectories per wave (k_pend_forward_tl)
   static const int tl_max_b = [] { const char* e = getenv("LDE_PEND_TL_MAX_B"); return e ? atoi(e) : 1024; }();
+  // one trajectory per workgroup, a stepping wave + three dense-output waves (k_pend_forward_sh): while every workgroup has a CU to itself
+  static const int sh_max_b = [] { const char* e = getenv("LDE_PEND_SH_MAX_B"); return e ? atoi(e) : 256; }();
+  if (o.T > 1 && o.B <= sh_max_b) {
+    const bool ad = o.adaptive != 0;
+    const int g8 = ((o.B + 7) / 8) * 8;
+#define LDE_LAUNCH_SH(K, S, A)                                                                                          \
+  hipLaunchKernelGGL((k_pend_forward_sh<K, S, A>), dim3(g8), dim3(256), 0, stream, (const float2*)z0, theta, ts_dev, o,  \
+                     (float2*)z_out, retcode, nfe, nacc, nrej, ret)
+    if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5 && ad) LDE_LAUNCH_SH(0, LDE_SOLVER_TSIT5, true);
+    else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH_SH(0, LDE_SOLVER_TSIT5, false);
+    else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_RK4) LDE_LAUNCH_SH(0, LDE_SOLVER_RK4, false);
+    else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_TSIT5 && ad) LDE_LAUNCH_SH(1, LDE_SOLVER_TSIT5, true);
+    else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH_SH(1, LDE_SOLVER_TSIT5, false);
+    else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_RK4) LDE_LAUNCH_SH(1, LDE_SOLVER_RK4, false);
+    else return LDE_ERR_UNSUPPORTED;
+#undef LDE_LAUNCH_SH
+    return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
+  }
   if (o.T > 1 && o.B <= tl_max_b) {
     const bool ad = o.adaptive != 0;
     const bool few = o.T - 1 <= 64;   // a lane serves exactly one save time: the variant without a load in the stepping loop

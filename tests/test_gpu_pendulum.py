@@ -329,9 +329,11 @@ np.savez({path!r}, **out)
 """
 
 
-@pytest.mark.parametrize("variant", ["ws", "tl", "lb"])
+@pytest.mark.parametrize("variant", ["ws", "tl", "lb", "sh"])
 def test_small_batch_forward_kernels_match_the_single_wave_kernel(tmp_path, variant):
-    """Four forward kernels share the step code and the dense-output formulas: k_pend_forward_tl (B ≤ 1024: lanes = save
+    """Five forward kernels share the step code and the dense-output formulas: k_pend_forward_sh (B ≤ 256: one trajectory per
+    workgroup, a stepping wave + three dense-output waves; LDE_PEND_SH_MAX_B forces it for every batch here — the 200-point tight case
+    needs several rounds of its 48-step record ring, the maxiters case takes its failure barrier), k_pend_forward_tl (B ≤ 1024: lanes = save
     times), k_pend_forward_ws (B ≤ 16384: a stepping wave + helper waves pipelined through LDS), k_pend_forward (one lane
     per trajectory; LDE_PEND_TL_MAX_B=0 LDE_PEND_WS=0 forces it) and the large-batch form of the first (B ≥ 2¹⁷: a lane per
     trajectory, ẑ rows leave through an LDS ring as whole 512-byte stores; LDE_PEND_LB_MIN_B=0 forces it, and the 200-point
@@ -342,15 +344,17 @@ def test_small_batch_forward_kernels_match_the_single_wave_kernel(tmp_path, vari
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    if os.environ.get("LDE_PEND_WS", "1") == "0" or "LDE_PEND_TL_MAX_B" in os.environ or "LDE_PEND_LB_MIN_B" in os.environ:
+    if os.environ.get("LDE_PEND_WS", "1") == "0" or "LDE_PEND_TL_MAX_B" in os.environ or "LDE_PEND_LB_MIN_B" in os.environ or "LDE_PEND_SH_MAX_B" in os.environ:
         pytest.skip("this process already runs with a forced kernel choice")
     path = str(tmp_path / "single.npz")
     subprocess.run([sys.executable, "-c", _WS_SCRIPT.format(root=root, path=path)], check=True,
-                   env=dict(os.environ, LDE_PEND_WS="0", LDE_PEND_TL_MAX_B="0"), timeout=600)
+                   env=dict(os.environ, LDE_PEND_WS="0", LDE_PEND_TL_MAX_B="0", LDE_PEND_SH_MAX_B="0"), timeout=600)
     here = str(tmp_path / "split.npz")
     subprocess.run([sys.executable, "-c", _WS_SCRIPT.format(root=root, path=here)], check=True,
-                   env=dict(os.environ, **{"ws": dict(LDE_PEND_TL_MAX_B="0"), "tl": dict(LDE_PEND_TL_MAX_B="1024"),
-                                           "lb": dict(LDE_PEND_TL_MAX_B="0", LDE_PEND_WS="0", LDE_PEND_LB_MIN_B="0")}[variant]),
+                   env=dict(os.environ, **{"ws": dict(LDE_PEND_TL_MAX_B="0", LDE_PEND_SH_MAX_B="0"),
+                                           "tl": dict(LDE_PEND_TL_MAX_B="1024", LDE_PEND_SH_MAX_B="0"),
+                                           "lb": dict(LDE_PEND_TL_MAX_B="0", LDE_PEND_SH_MAX_B="0", LDE_PEND_WS="0", LDE_PEND_LB_MIN_B="0"),
+                                           "sh": dict(LDE_PEND_SH_MAX_B="1000000")}[variant]),
                    timeout=600)
     a, b = np.load(here), np.load(path)
     # different compilations of the same step code: multiply-adds contract differently, so the adaptive step sequences part at

@@ -232,7 +232,9 @@ def apply_latent_out(decoder: Decoder, l_tilde):
     if isinstance(decoder.model_type, GOKU):
         z0_t, th_t = l_tilde
         lo_z0, lo_th = decoder.latent_out
-        return lo_z0(z0_t), lo_th(th_t)
+        from .recurrent import run_forked          # (two independent chains: parallel branches inside a captured step)
+        z0_hat, th_hat = run_forked([(lo_z0, z0_t), (lo_th, th_t)])
+        return z0_hat, th_hat
     if isinstance(decoder.model_type, LatentODE):
         return decoder.latent_out(l_tilde)
     raise TypeError(f"no apply_latent_out method for model type {type(decoder.model_type).__name__}")

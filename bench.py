@@ -359,7 +359,6 @@ def decoder_cpu_baseline(specs, weights, d_native, ts, zt, tt, dxh, B, T, budget
 def run_goku_step(args, torch, dist, world, rank, local):
     if world == 1 and os.environ.get("LDE_BENCH_GRAPH", "1") != "0":
         os.environ.setdefault("LDE_BRANCH_STREAMS", "0")   # the captured step runs on one stream (read when the package is imported)
-        os.environ.setdefault("LDE_CHAIN_STREAMS", "1")    # … except flat fork–joins: the recurrent stacks, latent_in's heads, latent_out's chains
     import latentdiffeq_amd as M
     from latentdiffeq_amd.chain import decode, default_decoder_layers
     from latentdiffeq_amd.dist import FlatGradAllReduce

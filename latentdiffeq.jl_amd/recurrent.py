@@ -315,10 +315,10 @@ def _run_concurrently(stacks, x):
 
 
 _CHAIN_STREAMS = os.environ.get("LDE_CHAIN_STREAMS", "0") != "0"   # the independent small chains (latent_in's four heads, latent_out's two) on side
-                                                                     # streams: inside a captured step (train.GraphedStep, bench) they are four / two
-                                                                     # parallel branches of the graph instead of a chain of ≈ 6 µs launches (their
-                                                                     # pullbacks too: autograd replays a node on its forward stream). Off in eager steps:
-                                                                     # there the host's enqueue time is the limit and the stream switches cost more of it.
+                                                                     # streams, i.e. parallel branches of a captured step instead of a chain of ≈ 6 µs
+                                                                     # launches. Opt-in: measured SLOWER — goku_step replay 1.48 → 1.61 ms f32, 1.00 →
+                                                                     # 1.13 ms mixed (one box, back to back): a fork–join inside a hipGraph costs more in
+                                                                     # dependency resolution than the four launches it takes off the critical path.
 
 
 def run_forked(pairs):

@@ -79,6 +79,6 @@ print("ok", dtype, le[-1])
 def test_graph_replay_equals_eager_step(tmp_path, dtype):
     f = tmp_path / "graph_step.py"
     f.write_text(SCRIPT)
-    env = dict(os.environ, LDE_ROOT=ROOT, LDE_BRANCH_STREAMS="0", LDE_CHAIN_STREAMS="1")   # (the small chains as forked branches, as bench.py captures them)
+    env = dict(os.environ, LDE_ROOT=ROOT, LDE_BRANCH_STREAMS="0")
     r = subprocess.run([sys.executable, str(f), dtype], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]

@@ -243,6 +243,17 @@ typedef struct lde_chain_desc {
 
 typedef struct lde_chain lde_chain;
 
+/* Several INDEPENDENT chains in one call: the (μ, log σ²) heads of apply_latent_in [REF src/models/GOKU.jl:61-72] and the two chains of
+ * apply_latent_out [REF src/models/GOKU.jl:83-91] act on B columns only — six forward and eighteen pullback launches of a few
+ * microseconds each in a training step. With n ≤ 4 chains in the same dtype mode every stage of the call (forward; pullback, weight-
+ * gradient product, fixed-order sums) is ONE launch; anything else runs the chains one after the other. Per chain the same kernels on
+ * the same arguments as lde_chain_forward_save / lde_chain_backward_saved: results equal bit for bit. saveds / dxs may be NULL or hold
+ * NULL entries with the single calls' meaning. */
+int  lde_chain_group_forward_save(int n, lde_chain* const* chains, const float* const* xs, const int64_t* Ns, float* const* ys,
+                                  float* const* saveds, void* stream);
+int  lde_chain_group_backward_saved(int n, lde_chain* const* chains, const float* const* xs, const float* const* ys, const float* const* dys,
+                                    const float* const* saveds, const int64_t* Ns, float* const* dxs, float* const* dWs, void* stream);
+
 int64_t lde_chain_num_weights(const lde_chain_desc* desc);
 int  lde_chain_create(const lde_chain_desc* desc, lde_chain** out);
 void lde_chain_destroy(lde_chain* c);

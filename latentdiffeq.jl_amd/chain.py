@@ -17,6 +17,7 @@ views of batch-major torch buffers, exactly like `diffeq_layer` (api.py).
 from __future__ import annotations
 
 import ctypes as C
+import os
 import math
 from typing import Optional, Sequence
 
@@ -133,6 +134,84 @@ class _ChainFn(torch.autograd.Function):
         return None, dx, dW
 
 
+class _ChainGroupFn(torch.autograd.Function):
+    """(y_1, …, y_n) = (chain_1(x_1), …, chain_n(x_n)) for INDEPENDENT chains as one autograd node and — when the library can merge
+    them (n ≤ 4, same dtype mode, small tiles) — one launch per stage: lde_chain_group_forward_save / _backward_saved. The heads of
+    apply_latent_in and the chains of apply_latent_out act on B columns only; as separate nodes they are 6 forward and 18 pullback
+    launches of a few microseconds each. Same kernels on the same arguments per chain: the results are those of _ChainFn bit for bit
+    (tests/test_gpu_chain.py::test_grouped_chains_equal_separate_calls). Inputs: chains, then x_1 … x_n (N_i, in_i), then W_1 … W_n."""
+
+    @staticmethod
+    def forward(ctx, chains, *xw):
+        n = len(chains)
+        xs, Ws = xw[:n], xw[n:]
+        if not all(x.is_cuda for x in xs):
+            raise L.LdeError("Chain needs CUDA/HIP tensors: it runs on the GPU only (no CPU fallback)")
+        lib = chains[0]._lib if chains[0]._handle is not None else None
+        stream = L.raw_stream(xs[0].device.index)
+        hs = []
+        for c, W in zip(chains, Ws):
+            h = c._native()
+            lib = c._lib
+            key = L.weights_key(W)
+            if c._wkey != key:
+                Wc = W.detach().contiguous().float()
+                L.check(lib.lde_chain_set_weights_device(h, C.c_void_p(Wc.data_ptr()), Wc.numel(), stream), h,
+                        "lde_chain_set_weights_device", chain=True)
+                c._wkey = None
+            hs.append(h)
+        ys = [torch.empty((x.shape[0], c.sizes[-1]), device=x.device, dtype=torch.float32) for c, x in zip(chains, xs)]
+        train = any(ctx.needs_input_grad[1:])
+        saveds = [torch.empty((int(lib.lde_chain_saved_floats(h, x.shape[0])),), device=x.device, dtype=torch.float32) for h, x in zip(hs, xs)] \
+            if train else None
+        arr = lambda ptrs: (C.c_void_p * n)(*ptrs)
+        ctx.c_handles = arr([h.value for h in hs])
+        ctx.c_Ns = (C.c_int64 * n)(*[x.shape[0] for x in xs])
+        rc = lib.lde_chain_group_forward_save(n, ctx.c_handles, arr([x.data_ptr() for x in xs]), ctx.c_Ns, arr([y.data_ptr() for y in ys]),
+                                              arr([t.data_ptr() for t in saveds]) if train else None, stream)
+        L.check(rc, hs[0], "lde_chain_group_forward_save", chain=True)
+        ctx.chains, ctx.n, ctx.train = chains, n, train
+        ctx.need_dx = [bool(g) for g in ctx.needs_input_grad[1:1 + n]]
+        ctx.save_for_backward(*xs, *ys, *(saveds if train else []))
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        chains, n = ctx.chains, ctx.n
+        t = ctx.saved_tensors
+        xs, ys, saveds = t[:n], t[n:2 * n], (t[2 * n:] if ctx.train else None)
+        lib = chains[0]._lib
+        stream = L.raw_stream(xs[0].device.index)
+        dys = [dy.contiguous().float() for dy in dys]
+        dxs = [torch.empty_like(x) if need else None for x, need in zip(xs, ctx.need_dx)]
+        dWs = [torch.empty((c.num_weights,), device=x.device, dtype=torch.float32) for c, x in zip(chains, xs)]   # written, not accumulated
+        if L.dw_stream is not None:
+            for dW in dWs:
+                dW.record_stream(L.dw_stream)
+        arr = lambda ptrs: (C.c_void_p * n)(*ptrs)
+        rc = lib.lde_chain_group_backward_saved(n, ctx.c_handles, arr([x.data_ptr() for x in xs]), arr([y.data_ptr() for y in ys]),
+                                                arr([d.data_ptr() for d in dys]), arr([s_.data_ptr() for s_ in saveds]) if saveds is not None else None,
+                                                ctx.c_Ns, arr([d.data_ptr() if d is not None else None for d in dxs]),
+                                                arr([d.data_ptr() for d in dWs]), stream)
+        L.check(rc, chains[0]._native(), "lde_chain_group_backward_saved", chain=True)
+        return (None, *dxs, *dWs)
+
+
+_CHAIN_GROUP = os.environ.get("LDE_CHAIN_GROUP", "1") != "0"   # apply_latent_in / apply_latent_out: independent chains as one node (diagnostic switch)
+
+
+def apply_chains_grouped(pairs):
+    """[(chain, x [in, B]), …] → [chain(x), …] for independent chains, as ONE autograd node (one launch per stage where the library can
+    merge them). Falls back to separate calls for anything that is not a plain Chain on a 2-D CUDA tensor."""
+    ok = _CHAIN_GROUP and 2 <= len(pairs) <= 4 and all(isinstance(m, Chain) and x.dim() == 2 and x.is_cuda for m, x in pairs)
+    if not ok:
+        return [m(x) for m, x in pairs]
+    chains = tuple(m for m, _ in pairs)
+    xs = [x.t().contiguous().float() for _, x in pairs]
+    ys = _ChainGroupFn.apply(chains, *xs, *[m.flat_weights() for m in chains])
+    return [y.t() for y in ys]
+
+
 class Chain(torch.nn.Module):
     """Chain(layers...) of Dense / SkipConnection(Dense) applied to the first dimension of x ([in, B] or [in, B, T])."""
 
@@ -232,8 +311,11 @@ def apply_latent_out(decoder: Decoder, l_tilde):
     if isinstance(decoder.model_type, GOKU):
         z0_t, th_t = l_tilde
         lo_z0, lo_th = decoder.latent_out
-        from .recurrent import run_forked          # (two independent chains: parallel branches inside a captured step)
-        z0_hat, th_hat = run_forked([(lo_z0, z0_t), (lo_th, th_t)])
+        from .recurrent import _CHAIN_STREAMS, run_forked
+        if _CHAIN_STREAMS:                          # (opt-in, measured slower: parallel branches inside a captured step)
+            z0_hat, th_hat = run_forked([(lo_z0, z0_t), (lo_th, th_t)])
+        else:
+            z0_hat, th_hat = apply_chains_grouped([(lo_z0, z0_t), (lo_th, th_t)])
         return z0_hat, th_hat
     if isinstance(decoder.model_type, LatentODE):
         return decoder.latent_out(l_tilde)

@@ -268,8 +268,8 @@ __device__ __forceinline__ void chain_load_tile(const ChainDims& cd, const float
 // first column of a workgroup's tile. With gx the ragged last tile is shifted back to end at N (its first `dup` columns
 // repeat the previous tile's: same values are stored twice, and they get weight 0 in the weight gradient), so that
 // every column a lane reads from x exists.
-__device__ __forceinline__ long long chain_tile_start(const ChainDims& cd, int NC, long long N, int* dup) {
-  const long long n = (long long)blockIdx.x * NC;
+__device__ __forceinline__ long long chain_tile_start(const ChainDims& cd, int NC, long long N, int* dup, unsigned bx) {
+  const long long n = (long long)bx * NC;
   long long n0 = n;
   if (cd.gx && n + NC > N) n0 = N - NC;
   *dup = (int)(n - n0);
@@ -323,7 +323,7 @@ __device__ __forceinline__ void chain_hidden_layer(const ChainDims& cd, int l, c
 #define LDE_F32_OCC 1
 #endif
 template <int CG, bool BF>
-__global__ void __launch_bounds__(512, (CG <= 2 ? LDE_F32_OCC : 1)) k_chain_forward(ChainDims cd, ChainFwdArgs a) {
+__device__ __forceinline__ void chain_forward_body(const ChainDims& cd, const ChainFwdArgs& a, const unsigned bx) {
   extern __shared__ __attribute__((aligned(16))) float csm[];
   constexpr int NC = 16 * CG;
   const MlpDims& dm = cd.dm;
@@ -333,7 +333,7 @@ __global__ void __launch_bounds__(512, (CG <= 2 ? LDE_F32_OCC : 1)) k_chain_forw
   float* H1 = H0 + NC * ldh;
   float* biasc = H1 + NC * ldh;
   int dup;
-  const long long n0 = chain_tile_start(cd, NC, a.N, &dup);
+  const long long n0 = chain_tile_start(cd, NC, a.N, &dup, bx);
   PROF_T(pc0);
   chain_load_tile<CG>(cd, a.x, n0, a.N, X0, biasc, a.Wflat, NC * cd.ld0 + 2 * NC * ldh, csm);
   PROF_T(pc1);
@@ -383,6 +383,15 @@ __global__ void __launch_bounds__(512, (CG <= 2 ? LDE_F32_OCC : 1)) k_chain_forw
   PROF_ADD(2 + 2 * (nL - 1), pz0, pz1);
   PROF_ADD(40, pc0, pz1);
 }
+template <int CG, bool BF>
+__global__ void __launch_bounds__(512, (CG <= 2 ? LDE_F32_OCC : 1)) k_chain_forward(ChainDims cd, ChainFwdArgs a) {
+  chain_forward_body<CG, BF>(cd, a, blockIdx.x);
+}
+template <int CG, bool BF>
+__global__ void __launch_bounds__(512, (CG <= 2 ? LDE_F32_OCC : 1)) k_chain_forward_group(GroupTable<ChainDims, ChainFwdArgs> g) {
+  const int j = group_find(g.start, g.n, blockIdx.x);
+  chain_forward_body<CG, BF>(g.dims[j], g.args[j], blockIdx.x - g.start[j]);
+}
 
 struct ChainBwdArgs {
   const float* x;
@@ -401,7 +410,7 @@ struct ChainBwdArgs {
 struct PrePair { f32x4 h, a; };
 
 template <int CG, bool BF>
-__global__ void __launch_bounds__(512, (CG <= 2 ? LDE_F32_OCC : 1)) k_chain_backward(ChainDims cd, ChainBwdArgs a) {
+__device__ __forceinline__ void chain_backward_body(const ChainDims& cd, const ChainBwdArgs& a, const unsigned bx) {
   extern __shared__ __attribute__((aligned(16))) float csm[];
   constexpr int NC = 16 * CG;
   const MlpDims& dm = cd.dm;
@@ -412,8 +421,8 @@ __global__ void __launch_bounds__(512, (CG <= 2 ? LDE_F32_OCC : 1)) k_chain_back
   float* G = P1 + NC * ldh;
   float* biasc = G + NC * ldh;
   int dup;
-  const long long n0 = chain_tile_start(cd, NC, a.N, &dup);
-  const size_t slot0 = (size_t)blockIdx.x * CG;
+  const long long n0 = chain_tile_start(cd, NC, a.N, &dup, bx);
+  const size_t slot0 = (size_t)bx * CG;
   float* const blk0 = a.stage + slot0 * dm.blk_floats;   // the CG staged blocks of this tile are contiguous
   chain_load_tile<CG>(cd, a.x, n0, a.N, X0, biasc, a.Wflat, NC * cd.ld0 + 3 * NC * ldh, csm);
   const float* xg = a.x + (size_t)n0 * dm.sizes[0];
@@ -567,6 +576,15 @@ __global__ void __launch_bounds__(512, (CG <= 2 ? LDE_F32_OCC : 1)) k_chain_back
       else chain_gemm<CG, false, BF>(fragT, in, out, Dcur, ldh, 16 * ldh, pre, epi);
     }
   }
+}
+template <int CG, bool BF>
+__global__ void __launch_bounds__(512, (CG <= 2 ? LDE_F32_OCC : 1)) k_chain_backward(ChainDims cd, ChainBwdArgs a) {
+  chain_backward_body<CG, BF>(cd, a, blockIdx.x);
+}
+template <int CG, bool BF>
+__global__ void __launch_bounds__(512, (CG <= 2 ? LDE_F32_OCC : 1)) k_chain_backward_group(GroupTable<ChainDims, ChainBwdArgs> g) {
+  const int j = group_find(g.start, g.n, blockIdx.x);
+  chain_backward_body<CG, BF>(g.dims[j], g.args[j], blockIdx.x - g.start[j]);
 }
 
 #include "lde_chain_bf16.h"
@@ -959,6 +977,199 @@ static bool chain_pick_b(const lde_chain* c, const float* x, int64_t N, bool bwd
   return true;
 }
 
+// ---- grouped calls (lde_chain_group_*): while a recorder is installed the launch sites below RECORD what they would launch; the group
+// entry point then issues each stage once for all the modules (k_*_group, lde_mfma.h) when they ask for the same kernel instance, and
+// one by one otherwise. Same arguments, same code per module: the results are those of the separate calls, bit for bit.
+struct RecMain {   // stage 0: the forward kernel, or the pullback's first kernel
+  int kind;        // 0 k_chain_forward<·,false>, 1 k_chain_forward_b, 2 k_chain_backward<·,false>, 3 k_chain_backward_b, 4: other (launched, not recorded)
+  int cg;
+  ChainDims cd;
+  BfDims bd;
+  ChainFwdArgs f32;
+  ChainFwdArgsB fb;
+  ChainBwdArgs b32;
+  ChainBwdArgsB bb;
+  unsigned grid;
+  size_t lds;
+};
+struct RecDw {     // stage 1: the weight-gradient product
+  int kind;        // 0 k_mlp_dw<ndw,false>, 1 k_chain_dw_b<ndw>
+  int ndw;
+  MlpDims dm;
+  DwArgs d32;
+  ChainDims cd;
+  BfDims bd;
+  DwArgsB db;
+  int gx, gy, gz;  // f32: (tiles, ks, jobs); bf16: (parts, jobs, 1)
+  size_t lds;
+};
+struct RecRed {    // stage 2: the fixed-order slab sums
+  MlpDims dm;
+  ReduceArgs a;
+  unsigned grid;
+};
+struct GroupRec {
+  int n = 0;
+  bool main_set[GROUP_MAX] = {}, dw_set[GROUP_MAX] = {}, red_set[GROUP_MAX] = {};
+  RecMain main[GROUP_MAX];
+  RecDw dw[GROUP_MAX];
+  RecRed red[GROUP_MAX];
+};
+static thread_local GroupRec* t_rec = nullptr;
+// (kernel arguments: 4 KB on this runtime)
+static_assert(sizeof(GroupTable<ChainBDims, ChainBwdArgsB>) <= 4096 && sizeof(GroupTable<ChainDims, ChainBwdArgs>) <= 4096 &&
+              sizeof(GroupTable<ChainBDims, DwArgsB>) <= 4096 && sizeof(GroupTable<MlpDims, DwArgs>) <= 4096 &&
+              sizeof(GroupTable<MlpDims, ReduceArgs>) <= 4096, "a group's argument table must fit the kernel-argument segment");
+
+static bool set_max_lds_(const void* fn, bool* done) {
+  if (*done) return true;
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) return false;
+  *done = true;
+  return true;
+}
+static void launch_main_single(const RecMain& r, hipStream_t stream) {
+  ChainDims cdv = r.cd;
+  BfDims bdv = r.bd;
+  if (r.kind == 0) {
+    ChainFwdArgs a = r.f32;
+    void* argv[] = {(void*)&cdv, (void*)&a};
+    const void* fn = r.cg == 4 ? (const void*)k_chain_forward<4, false> : r.cg == 2 ? (const void*)k_chain_forward<2, false> : (const void*)k_chain_forward<1, false>;
+    (void)hipLaunchKernel(fn, dim3(r.grid), dim3(512), argv, r.lds, stream);
+  } else if (r.kind == 1) {
+    ChainFwdArgsB a = r.fb;
+    void* argv[] = {(void*)&cdv, (void*)&bdv, (void*)&a};
+    const void* fn = r.cg == 4 ? (const void*)k_chain_forward_b<4> : r.cg == 2 ? (const void*)k_chain_forward_b<2> : (const void*)k_chain_forward_b<1>;
+    (void)hipLaunchKernel(fn, dim3(r.grid), dim3(512), argv, r.lds, stream);
+  } else if (r.kind == 2) {
+    ChainBwdArgs a = r.b32;
+    void* argv[] = {(void*)&cdv, (void*)&a};
+    const void* fn = r.cg == 2 ? (const void*)k_chain_backward<2, false> : (const void*)k_chain_backward<1, false>;
+    (void)hipLaunchKernel(fn, dim3(r.grid), dim3(512), argv, r.lds, stream);
+  } else {
+    ChainBwdArgsB a = r.bb;
+    void* argv[] = {(void*)&cdv, (void*)&bdv, (void*)&a};
+    const void* fn = r.cg == 4 ? (const void*)k_chain_backward_b<4> : r.cg == 2 ? (const void*)k_chain_backward_b<2> : (const void*)k_chain_backward_b<1>;
+    (void)hipLaunchKernel(fn, dim3(r.grid), dim3(512), argv, r.lds, stream);
+  }
+}
+static void launch_dw_single(const RecDw& r, hipStream_t stream) {
+  if (r.kind == 0) {
+    static bool attr[3] = {false, false, false};
+    (void)set_max_lds_((const void*)k_mlp_dw<1, false>, &attr[0]);
+    (void)set_max_lds_((const void*)k_mlp_dw<2, false>, &attr[1]);
+    (void)set_max_lds_((const void*)k_mlp_dw<4, false>, &attr[2]);
+    const dim3 grid(r.gx, r.gy, r.gz);
+    if (r.ndw == 1) hipLaunchKernelGGL((k_mlp_dw<1, false>), grid, dim3(512), r.lds, stream, r.dm, r.d32);
+    else if (r.ndw == 2) hipLaunchKernelGGL((k_mlp_dw<2, false>), grid, dim3(512), r.lds, stream, r.dm, r.d32);
+    else hipLaunchKernelGGL((k_mlp_dw<4, false>), grid, dim3(512), r.lds, stream, r.dm, r.d32);
+  } else {
+    const dim3 grid(r.gx, r.gy);
+    if (r.ndw == 1) hipLaunchKernelGGL(k_chain_dw_b<1>, grid, dim3(512), r.lds, stream, r.cd, r.bd, r.db);
+    else if (r.ndw == 2) hipLaunchKernelGGL(k_chain_dw_b<2>, grid, dim3(512), r.lds, stream, r.cd, r.bd, r.db);
+    else hipLaunchKernelGGL(k_chain_dw_b<4>, grid, dim3(512), r.lds, stream, r.cd, r.bd, r.db);
+  }
+}
+static void launch_red_single(const RecRed& r, hipStream_t stream) {
+  hipLaunchKernelGGL(k_reduce_tiles, dim3(r.grid), dim3(256), 0, stream, r.a.priv, r.a.nflush, r.a.nwg, r.a.slab, r.a.nslab, r.dm, r.a.dW, r.a.feedback,
+                     r.a.assign);
+}
+// the three stages of a recorded group: ONE launch per stage when every module asks for the same small-tile kernel instance
+static int group_flush(GroupRec& g, hipStream_t stream) {
+  const int n = g.n;
+  {   // stage 0
+    bool same = n >= 2;
+    for (int j = 0; j < n; j++) same = same && g.main_set[j] && g.main[j].kind == g.main[0].kind && g.main[j].cg == 1;
+    if (same) {
+      size_t lds = 0;
+      for (int j = 0; j < n; j++) lds = std::max(lds, g.main[j].lds);
+      const int kind = g.main[0].kind;
+      static bool attr[4] = {false, false, false, false};
+      if (kind == 0 || kind == 2) {
+        if (kind == 0) {
+          GroupTable<ChainDims, ChainFwdArgs> t{};
+          t.n = n;
+          for (int j = 0; j < n; j++) { t.start[j + 1] = t.start[j] + (int)g.main[j].grid; t.dims[j] = g.main[j].cd; t.args[j] = g.main[j].f32; }
+          if (!set_max_lds_((const void*)k_chain_forward_group<1, false>, &attr[0])) return LDE_ERR_HIP;
+          void* argv[] = {(void*)&t};
+          (void)hipLaunchKernel((const void*)k_chain_forward_group<1, false>, dim3(t.start[n]), dim3(512), argv, lds, stream);
+        } else {
+          GroupTable<ChainDims, ChainBwdArgs> t{};
+          t.n = n;
+          for (int j = 0; j < n; j++) { t.start[j + 1] = t.start[j] + (int)g.main[j].grid; t.dims[j] = g.main[j].cd; t.args[j] = g.main[j].b32; }
+          if (!set_max_lds_((const void*)k_chain_backward_group<1, false>, &attr[2])) return LDE_ERR_HIP;
+          void* argv[] = {(void*)&t};
+          (void)hipLaunchKernel((const void*)k_chain_backward_group<1, false>, dim3(t.start[n]), dim3(512), argv, lds, stream);
+        }
+      } else if (kind == 1) {
+        GroupTable<ChainBDims, ChainFwdArgsB> t{};
+        t.n = n;
+        for (int j = 0; j < n; j++) { t.start[j + 1] = t.start[j] + (int)g.main[j].grid; t.dims[j].cd = g.main[j].cd; t.dims[j].bd = g.main[j].bd; t.args[j] = g.main[j].fb; }
+        if (!set_max_lds_((const void*)k_chain_forward_b_group<1>, &attr[1])) return LDE_ERR_HIP;
+        void* argv[] = {(void*)&t};
+        (void)hipLaunchKernel((const void*)k_chain_forward_b_group<1>, dim3(t.start[n]), dim3(512), argv, lds, stream);
+      } else {
+        GroupTable<ChainBDims, ChainBwdArgsB> t{};
+        t.n = n;
+        for (int j = 0; j < n; j++) { t.start[j + 1] = t.start[j] + (int)g.main[j].grid; t.dims[j].cd = g.main[j].cd; t.dims[j].bd = g.main[j].bd; t.args[j] = g.main[j].bb; }
+        if (!set_max_lds_((const void*)k_chain_backward_b_group<1>, &attr[3])) return LDE_ERR_HIP;
+        void* argv[] = {(void*)&t};
+        (void)hipLaunchKernel((const void*)k_chain_backward_b_group<1>, dim3(t.start[n]), dim3(512), argv, lds, stream);
+      }
+    } else {
+      for (int j = 0; j < n; j++)
+        if (g.main_set[j]) launch_main_single(g.main[j], stream);
+    }
+  }
+  {   // stage 1
+    bool any = false, same = n >= 2;
+    for (int j = 0; j < n; j++) { any = any || g.dw_set[j]; same = same && g.dw_set[j] && g.dw[j].kind == g.dw[0].kind && g.dw[j].ndw == 1; }
+    if (any && same) {
+      size_t lds = 0;
+      for (int j = 0; j < n; j++) lds = std::max(lds, g.dw[j].lds);
+      static bool attr[2] = {false, false};
+      if (g.dw[0].kind == 0) {
+        GroupTable<MlpDims, DwArgs> t{};
+        t.n = n;
+        for (int j = 0; j < n; j++) {
+          t.start[j + 1] = t.start[j] + g.dw[j].gx * g.dw[j].gy * g.dw[j].gz;
+          t.gx[j] = g.dw[j].gx; t.gy[j] = g.dw[j].gy; t.dims[j] = g.dw[j].dm; t.args[j] = g.dw[j].d32;
+        }
+        if (!set_max_lds_((const void*)k_mlp_dw_group<1, false>, &attr[0])) return LDE_ERR_HIP;
+        void* argv[] = {(void*)&t};
+        (void)hipLaunchKernel((const void*)k_mlp_dw_group<1, false>, dim3(t.start[n]), dim3(512), argv, lds, stream);
+      } else {
+        GroupTable<ChainBDims, DwArgsB> t{};
+        t.n = n;
+        for (int j = 0; j < n; j++) {
+          t.start[j + 1] = t.start[j] + g.dw[j].gx * g.dw[j].gy;
+          t.gx[j] = g.dw[j].gx; t.gy[j] = g.dw[j].gy; t.dims[j].cd = g.dw[j].cd; t.dims[j].bd = g.dw[j].bd; t.args[j] = g.dw[j].db;
+        }
+        if (!set_max_lds_((const void*)k_chain_dw_b_group<1>, &attr[1])) return LDE_ERR_HIP;
+        void* argv[] = {(void*)&t};
+        (void)hipLaunchKernel((const void*)k_chain_dw_b_group<1>, dim3(t.start[n]), dim3(512), argv, lds, stream);
+      }
+    } else if (any) {
+      for (int j = 0; j < n; j++)
+        if (g.dw_set[j]) launch_dw_single(g.dw[j], stream);
+    }
+  }
+  {   // stage 2
+    bool any = false, all = n >= 2;
+    for (int j = 0; j < n; j++) { any = any || g.red_set[j]; all = all && g.red_set[j]; }
+    if (any && all) {
+      GroupTable<MlpDims, ReduceArgs> t{};
+      t.n = n;
+      for (int j = 0; j < n; j++) { t.start[j + 1] = t.start[j] + (int)g.red[j].grid; t.dims[j] = g.red[j].dm; t.args[j] = g.red[j].a; }
+      void* argv[] = {(void*)&t};
+      (void)hipLaunchKernel((const void*)k_reduce_tiles_group, dim3(t.start[n]), dim3(256), argv, 0, stream);
+    } else if (any) {
+      for (int j = 0; j < n; j++)
+        if (g.red_set[j]) launch_red_single(g.red[j], stream);
+    }
+  }
+  return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
+}
+
 static int chain_forward_b(lde_chain* c, const float* x, int64_t N, float* y, __bf16* saved, hipStream_t stream) {
   ChainPickB pk;
   if (!chain_pick_b(c, x, N, false, &pk)) {
@@ -983,6 +1194,13 @@ static int chain_forward_b(lde_chain* c, const float* x, int64_t N, float* y, __
 #if LDE_PROF
   { long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
 #endif
+  if (t_rec) {
+    RecMain& r = t_rec->main[t_rec->n];
+    r.kind = 1; r.cg = pk.cg; r.cd = cdv; r.bd = bdv; r.fb = a; r.grid = grid.x; r.lds = pk.lds;
+    t_rec->main_set[t_rec->n] = true;
+    (void)argv;
+    return LDE_OK;
+  }
   (void)hipLaunchKernel(fn, grid, dim3(512), argv, pk.lds, stream);
   if (hipGetLastError() != hipSuccess) {
     c->err = "k_chain_forward_b launch failed";
@@ -1058,10 +1276,16 @@ static int chain_backward_b(lde_chain* c, const float* x, const float* y, const 
     ChainDims cdv = *pk.cd;
     BfDims bdv = *pk.bd;
     void* argv[] = {(void*)&cdv, (void*)&bdv, (void*)&a};
-    (void)hipLaunchKernel(fn, grid, dim3(512), argv, pk.lds, stream);
-    if (hipGetLastError() != hipSuccess) {
-      c->err = "k_chain_backward_b launch failed";
-      return LDE_ERR_HIP;
+    if (t_rec) {
+      RecMain& r = t_rec->main[t_rec->n];
+      r.kind = 3; r.cg = pk.cg; r.cd = cdv; r.bd = bdv; r.bb = a; r.grid = grid.x; r.lds = pk.lds;
+      t_rec->main_set[t_rec->n] = true;
+    } else {
+      (void)hipLaunchKernel(fn, grid, dim3(512), argv, pk.lds, stream);
+      if (hipGetLastError() != hipSuccess) {
+        c->err = "k_chain_backward_b launch failed";
+        return LDE_ERR_HIP;
+      }
     }
   }
   // weight gradient: [n][feature] matrices through the transposing LDS reads, then the fixed-order slab reduction
@@ -1094,6 +1318,15 @@ static int chain_backward_b(lde_chain* c, const float* x, const float* y, const 
 #endif
     ChainDims cdv = c->cd;
     BfDims bdv = c->bd;
+    if (t_rec) {
+      RecDw& r = t_rec->dw[t_rec->n];
+      r.kind = 1; r.ndw = ndw; r.cd = cdv; r.bd = bdv; r.db = da; r.gx = parts; r.gy = jobs; r.gz = 1; r.lds = dlds;
+      t_rec->dw_set[t_rec->n] = true;
+      RecRed& q = t_rec->red[t_rec->n];
+      q.dm = dm; q.a = ReduceArgs{nullptr, c->ints, 0, c->slab, parts, dW, c->ints + 2, c->accumulate ? 0 : 1}; q.grid = (unsigned)cdiv(dm.slab_n, 1024);
+      t_rec->red_set[t_rec->n] = true;
+      return LDE_OK;
+    }
     if (ndw == 1) hipLaunchKernelGGL(k_chain_dw_b<1>, grid, dim3(512), dlds, wst, cdv, bdv, da);
     else if (ndw == 2) hipLaunchKernelGGL(k_chain_dw_b<2>, grid, dim3(512), dlds, wst, cdv, bdv, da);
     else hipLaunchKernelGGL(k_chain_dw_b<4>, grid, dim3(512), dlds, wst, cdv, bdv, da);
@@ -1163,6 +1396,12 @@ static int chain_forward_impl(lde_chain* c, const float* x, int64_t N, float* y,
 #if LDE_PROF
   { long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
 #endif
+  if (t_rec && !bf) {
+    RecMain& r = t_rec->main[t_rec->n];
+    r.kind = 0; r.cg = pk.cg; r.cd = *pk.cd; r.f32 = a; r.grid = grid.x; r.lds = pk.lds;
+    t_rec->main_set[t_rec->n] = true;
+    return LDE_OK;
+  }
   {
     ChainDims cdv = *pk.cd;
     void* argv[] = {(void*)&cdv, (void*)&a};
@@ -1235,7 +1474,12 @@ static int chain_backward_impl(lde_chain* c, const float* x, const float* y, con
     }
     attr[bf][pk.cg] = true;
   }
-  {
+  const bool rec32 = t_rec && !bf;
+  if (rec32) {
+    RecMain& r = t_rec->main[t_rec->n];
+    r.kind = 2; r.cg = pk.cg; r.cd = *pk.cd; r.b32 = a; r.grid = grid.x; r.lds = pk.lds;
+    t_rec->main_set[t_rec->n] = true;
+  } else {
     ChainDims cdv = *pk.cd;
     void* argv[] = {(void*)&cdv, (void*)&a};
     (void)hipLaunchKernel(fn, grid, dim3(512), argv, pk.lds, stream);
@@ -1255,6 +1499,16 @@ static int chain_backward_impl(lde_chain* c, const float* x, const float* y, con
   if (!sw_ok) {
     c->err = "lde_chain_backward: switching to the weight-gradient stream failed";
     return LDE_ERR_HIP;
+  }
+  if (rec32) {
+    const int ndw = dw_pick_ndw(dm);
+    RecDw& r = t_rec->dw[t_rec->n];
+    r.kind = 0; r.ndw = ndw; r.dm = dm; r.d32 = da; r.gx = nvt; r.gy = 1; r.gz = dw_jobs(dm, ndw); r.lds = dw_lds_floats(dm, ndw) * sizeof(float);
+    t_rec->dw_set[t_rec->n] = true;
+    RecRed& q = t_rec->red[t_rec->n];
+    q.dm = dm; q.a = ReduceArgs{nullptr, c->ints, 0, da.slab, nvt, dW, c->ints + 2, c->accumulate ? 0 : 1}; q.grid = (unsigned)cdiv(dm.slab_n, 1024);
+    t_rec->red_set[t_rec->n] = true;
+    return LDE_OK;
   }
   rc = launch_weight_gradient(dm, da, nvt, 1, nullptr, c->ints, 0, dW, c->ints + 2, wst, c->err, !c->accumulate, c->bf16);
   if (rc == LDE_OK && !dw_sync_end(c->dws, wst, stream)) {
@@ -1309,6 +1563,69 @@ int lde_chain_backward_saved(lde_chain* c, const float* x, const float* y, const
     return LDE_ERR_INVALID_ARG;
   }
   return chain_backward_impl(c, x, y, dy, saved, N, dx, dW, stream);
+}
+
+// ---- grouped calls: n independent chains, each stage of the call ONE launch when the chains ask for the same small-tile kernel ----------
+static bool group_ok(int n) {
+#if LDE_PROF
+  return false;
+#else
+  static const bool on = [] { const char* e = getenv("LDE_CHAIN_GROUP"); return !e || atoi(e) != 0; }();
+  return on && n >= 2 && n <= GROUP_MAX && dw_stream_get() == nullptr;
+#endif
+}
+int lde_chain_group_forward_save(int n, lde_chain* const* cs, const float* const* xs, const int64_t* Ns, float* const* ys, float* const* saveds,
+                                 void* stream) {
+  if (n < 1 || !cs || !xs || !Ns || !ys) return LDE_ERR_INVALID_ARG;
+  for (int i = 0; i < n; i++)
+    if (!cs[i]) return LDE_ERR_INVALID_ARG;
+  if (!group_ok(n)) {
+    for (int i = 0; i < n; i++) {
+      const int rc = chain_forward_impl(cs[i], xs[i], Ns[i], ys[i], saveds ? saveds[i] : nullptr, stream);
+      if (rc) return rc;
+    }
+    return LDE_OK;
+  }
+  GroupRec g;
+  t_rec = &g;
+  for (int i = 0; i < n; i++) {
+    g.n = i;
+    const int rc = chain_forward_impl(cs[i], xs[i], Ns[i], ys[i], saveds ? saveds[i] : nullptr, stream);
+    if (rc) { t_rec = nullptr; return rc; }
+  }
+  g.n = n;
+  t_rec = nullptr;
+  const int rc = group_flush(g, (hipStream_t)stream);
+  if (rc) cs[0]->err = "lde_chain_group_forward_save: launch failed";
+  return rc;
+}
+int lde_chain_group_backward_saved(int n, lde_chain* const* cs, const float* const* xs, const float* const* ys, const float* const* dys,
+                                   const float* const* saveds, const int64_t* Ns, float* const* dxs, float* const* dWs, void* stream) {
+  if (n < 1 || !cs || !xs || !ys || !dys || !Ns || !dWs) return LDE_ERR_INVALID_ARG;
+  bool grp = group_ok(n);
+  for (int i = 0; i < n; i++) {
+    if (!cs[i]) return LDE_ERR_INVALID_ARG;
+    if (cs[i]->bf16 && !(saveds && saveds[i])) grp = false;   // (a bf16 pullback without saved activations starts with a forward launch of its own)
+  }
+  if (!grp) {
+    for (int i = 0; i < n; i++) {
+      const int rc = chain_backward_impl(cs[i], xs[i], ys[i], dys[i], saveds ? saveds[i] : nullptr, Ns[i], dxs ? dxs[i] : nullptr, dWs[i], stream);
+      if (rc) return rc;
+    }
+    return LDE_OK;
+  }
+  GroupRec g;
+  t_rec = &g;
+  for (int i = 0; i < n; i++) {
+    g.n = i;
+    const int rc = chain_backward_impl(cs[i], xs[i], ys[i], dys[i], saveds ? saveds[i] : nullptr, Ns[i], dxs ? dxs[i] : nullptr, dWs[i], stream);
+    if (rc) { t_rec = nullptr; return rc; }
+  }
+  g.n = n;
+  t_rec = nullptr;
+  const int rc = group_flush(g, (hipStream_t)stream);
+  if (rc) cs[0]->err = "lde_chain_group_backward_saved: launch failed";
+  return rc;
 }
 
 int lde_chain_set_accumulate(lde_chain* c, int on) {

@@ -263,7 +263,7 @@ __device__ __forceinline__ void chain_hidden_layer_b(const ChainDims& cd, const 
 }
 
 template <int CG>
-__global__ void __launch_bounds__(512, (CG <= 2 ? LDE_BF_OCC : 1)) k_chain_forward_b(ChainDims cd, BfDims bd, ChainFwdArgsB a) {
+__device__ __forceinline__ void chain_forward_b_body(const ChainDims& cd, const BfDims& bd, const ChainFwdArgsB& a, const unsigned bx) {
   extern __shared__ __attribute__((aligned(16))) float csm[];
   constexpr int NC = 16 * CG;
   const MlpDims& dm = cd.dm;
@@ -278,7 +278,7 @@ __global__ void __launch_bounds__(512, (CG <= 2 ? LDE_BF_OCC : 1)) k_chain_forwa
   __bf16* F = (a.saved && any_skip && bd.fpanel) ? H1 + NC * ldh : nullptr;
   float* biasc = reinterpret_cast<float*>(H1 + NC * ldh + (bd.fpanel ? NC * ldh : 0));
   int dup;
-  const long long n0 = chain_tile_start(cd, NC, a.N, &dup);
+  const long long n0 = chain_tile_start(cd, NC, a.N, &dup, bx);
   PROF_T(pc0);
   chain_load_tile_b<CG>(cd, bd, a.x, n0, a.N, X0, biasc, a.Wflat, (2 * NC * ldh) / 8, csm);
   PROF_T(pc1);
@@ -340,6 +340,16 @@ __global__ void __launch_bounds__(512, (CG <= 2 ? LDE_BF_OCC : 1)) k_chain_forwa
   PROF_ADD(2 + 2 * (nL - 1), pz0, pz1);
   PROF_ADD(40, pc0, pz1);
 }
+struct ChainBDims { ChainDims cd; BfDims bd; };
+template <int CG>
+__global__ void __launch_bounds__(512, (CG <= 2 ? LDE_BF_OCC : 1)) k_chain_forward_b(ChainDims cd, BfDims bd, ChainFwdArgsB a) {
+  chain_forward_b_body<CG>(cd, bd, a, blockIdx.x);
+}
+template <int CG>
+__global__ void __launch_bounds__(512, (CG <= 2 ? LDE_BF_OCC : 1)) k_chain_forward_b_group(GroupTable<ChainBDims, ChainFwdArgsB> g) {
+  const int j = group_find(g.start, g.n, blockIdx.x);
+  chain_forward_b_body<CG>(g.dims[j].cd, g.dims[j].bd, g.args[j], blockIdx.x - g.start[j]);
+}
 
 struct ChainBwdArgsB {
   const float* x;
@@ -375,7 +385,7 @@ __device__ __forceinline__ void stage_delta_b(const __bf16* panel, int ld, int r
 }
 
 template <int CG>
-__global__ void __launch_bounds__(512, (CG <= 2 ? LDE_BF_OCC : 1)) k_chain_backward_b(ChainDims cd, BfDims bd, ChainBwdArgsB a) {
+__device__ __forceinline__ void chain_backward_b_body(const ChainDims& cd, const BfDims& bd, const ChainBwdArgsB& a, const unsigned bx) {
   extern __shared__ __attribute__((aligned(16))) float csm[];
   constexpr int NC = 16 * CG;
   const MlpDims& dm = cd.dm;
@@ -384,7 +394,7 @@ __global__ void __launch_bounds__(512, (CG <= 2 ? LDE_BF_OCC : 1)) k_chain_backw
   __bf16* P1 = P0 + NC * ldh;
   float* G = reinterpret_cast<float*>(P1 + NC * ldh);
   int dup;
-  const long long n0 = chain_tile_start(cd, NC, a.N, &dup);
+  const long long n0 = chain_tile_start(cd, NC, a.N, &dup, bx);
   for (int i = tid; i < (2 * NC * ldh) / 8 + (NC * ldg) / 4; i += 512) reinterpret_cast<f32x4*>(csm)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   // ---- δ_L = dy ⊙ act'(y) from the caller's arrays → the δ-stage matrix of the last layer (bf16) -----------------------
@@ -486,6 +496,15 @@ __global__ void __launch_bounds__(512, (CG <= 2 ? LDE_BF_OCC : 1)) k_chain_backw
   }
   stage_prev();   // (no product followed the last δ: the input gradient was not asked for)
 }
+template <int CG>
+__global__ void __launch_bounds__(512, (CG <= 2 ? LDE_BF_OCC : 1)) k_chain_backward_b(ChainDims cd, BfDims bd, ChainBwdArgsB a) {
+  chain_backward_b_body<CG>(cd, bd, a, blockIdx.x);
+}
+template <int CG>
+__global__ void __launch_bounds__(512, (CG <= 2 ? LDE_BF_OCC : 1)) k_chain_backward_b_group(GroupTable<ChainBDims, ChainBwdArgsB> g) {
+  const int j = group_find(g.start, g.n, blockIdx.x);
+  chain_backward_b_body<CG>(g.dims[j].cd, g.dims[j].bd, g.args[j], blockIdx.x - g.start[j]);
+}
 
 // ---- weight gradient: gW_lᵀ[i][o] = Σ_n a_l[i,n] δ_l[o,n] over [n][feature] matrices, transposing LDS reads ---------------------------
 // grid (K-split parts, jobs); a job = a block of ≤ 8·NDW 32×32 tiles of one layer's gWᵀ (dw_decode, as k_mlp_dw). The workgroup
@@ -518,12 +537,11 @@ inline size_t dw_b_lds_bytes(const MlpDims& dm, int ndw) {
 }
 
 template <int DW_NDW>
-__global__ void __launch_bounds__(512) k_chain_dw_b(ChainDims cd, BfDims bd, DwArgsB a) {
+__device__ __forceinline__ void chain_dw_b_body(const ChainDims& cd, const BfDims& bd, const DwArgsB& a, const int part, const int KS, const int jobz) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
   constexpr int NK = DWB_NK;
   const MlpDims& dm = cd.dm;
-  const int part = blockIdx.x, KS = gridDim.x;
-  const DwJob jb = dw_decode(dm, blockIdx.y, 8 * DW_NDW);
+  const DwJob jb = dw_decode(dm, jobz, 8 * DW_NDW);
   const int l = jb.l, in = dm.sizes[l], out = dm.sizes[l + 1];
   const int IT = cdiv(in, 32), nit = jb.i1 - jb.i0, ntile = (jb.o1 - jb.o0) * nit;
   const int na = 32 * nit, nd = 32 * (jb.o1 - jb.o0), ra0 = 32 * jb.i0, rd0 = 32 * jb.o0;
@@ -749,4 +767,13 @@ __global__ void __launch_bounds__(512) k_chain_dw_b(ChainDims cd, BfDims bd, DwA
       if (row < nd && rd0 + row < out) slab[(size_t)dm.tile_off[dm.nL] * 1024 + dm.bias_lin[l] + rd0 + row] = bsum[q];
     }
   }
+}
+template <int DW_NDW>
+__global__ void __launch_bounds__(512) k_chain_dw_b(ChainDims cd, BfDims bd, DwArgsB a) {
+  chain_dw_b_body<DW_NDW>(cd, bd, a, blockIdx.x, gridDim.x, blockIdx.y);
+}
+template <int DW_NDW>
+__global__ void __launch_bounds__(512) k_chain_dw_b_group(GroupTable<ChainBDims, DwArgsB> g) {
+  const int j = group_find(g.start, g.n, blockIdx.x), r = blockIdx.x - g.start[j];
+  chain_dw_b_body<DW_NDW>(g.dims[j].cd, g.dims[j].bd, g.args[j], r % g.gx[j], g.gx[j], r / g.gx[j]);
 }

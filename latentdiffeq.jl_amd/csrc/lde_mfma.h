@@ -316,11 +316,10 @@ inline size_t dw_lds_floats(const MlpDims& dm, int ndw) {
 
 // BF: bf16 operands (chains in bf16 mode): the lane's eight (a, δ) pairs of a slot — columns 2·s8 + half — feed two
 // v_mfma_f32_32x32x8_bf16 (s8 = 0..3 and 4..7: the same column set on both operands, so the contraction is the same sum).
-template <int DW_NDW, bool BF = false>
-static __global__ void __launch_bounds__(512) k_mlp_dw(MlpDims dm, DwArgs a) {
+template <int DW_NDW, bool BF>
+static __device__ __forceinline__ void mlp_dw_body(const MlpDims& dm, const DwArgs& a, const int tile, const int part, const int KS, const int jobz) {
   extern __shared__ __attribute__((aligned(16))) float dsm[];
-  const int tile = blockIdx.x, part = blockIdx.y, KS = gridDim.y;
-  const DwJob jb = dw_decode(dm, blockIdx.z, 8 * DW_NDW);
+  const DwJob jb = dw_decode(dm, jobz, 8 * DW_NDW);
   const int l = jb.l, in = dm.sizes[l], out = dm.sizes[l + 1], in32 = pad32(in), out32 = pad32(out);
   const int IT = in32 / 32, nit = jb.i1 - jb.i0, ntile = (jb.o1 - jb.o0) * nit;
   const int na = 32 * nit, nd = 32 * (jb.o1 - jb.o0), ra0 = 32 * jb.i0, rd0 = 32 * jb.o0;
@@ -451,6 +450,36 @@ static __global__ void __launch_bounds__(512) k_mlp_dw(MlpDims dm, DwArgs a) {
     }
   }
 }
+template <int DW_NDW, bool BF = false>
+static __global__ void __launch_bounds__(512) k_mlp_dw(MlpDims dm, DwArgs a) {
+  mlp_dw_body<DW_NDW, BF>(dm, a, blockIdx.x, blockIdx.y, gridDim.y, blockIdx.z);
+}
+
+// ---- grouped launches (lde_chain_group_*): several small independent modules in ONE launch of each kernel ------------------------------
+// A step of the GOKU model runs six chains on B columns only (latent_in's four heads, latent_out's two): 6 forward and 18 pullback
+// launches of ≈ 5–7 µs each, one behind the other — a quarter of the captured training step. Every kernel of that family exists as a
+// body taking its block coordinates as arguments; the grouped form carries up to GROUP_MAX argument sets in the kernel arguments and a
+// workgroup finds its module from the prefix sums of the modules' grids. Same code on the same data per module: bit-equal results.
+constexpr int GROUP_MAX = 4;
+template <class Dims, class Args>
+struct GroupTable {
+  int n;
+  int start[GROUP_MAX + 1];   // first flat block of module j (start[n] = the grid)
+  int gx[GROUP_MAX], gy[GROUP_MAX];   // the module's own grid extents (x, y) where a kernel decodes more than one coordinate
+  Dims dims[GROUP_MAX];
+  Args args[GROUP_MAX];
+};
+__device__ __forceinline__ int group_find(const int* start, int n, int b) {
+  int j = 0;
+  while (j + 1 < n && b >= start[j + 1]) j++;
+  return j;
+}
+template <int DW_NDW, bool BF>
+static __global__ void __launch_bounds__(512) k_mlp_dw_group(GroupTable<MlpDims, DwArgs> g) {
+  const int j = group_find(g.start, g.n, blockIdx.x), r = blockIdx.x - g.start[j];
+  const int per = g.gx[j] * g.gy[j];
+  mlp_dw_body<DW_NDW, BF>(g.dims[j], g.args[j], r % g.gx[j], (r / g.gx[j]) % g.gy[j], g.gy[j], r / per);
+}
 
 // dW[flat] (+)= Σ_w slab[w][fragment position of flat] (+ the private slabs of workgroups that overflowed their staging area):
 // ONE launch after k_mlp_dw (round 1 summed the slabs in one launch and gathered in a second). A workgroup owns one 32×32
@@ -458,16 +487,16 @@ static __global__ void __launch_bounds__(512) k_mlp_dw(MlpDims dm, DwArgs a) {
 // a fixed order, so the result is bit-reproducible — with sixteen fully coalesced loads in flight, and only then maps its
 // four accumulator-fragment positions back to flat (destructure-order) weight indices: the scatter happens once, on
 // nW floats, not once per slab.
-static __global__ void k_reduce_tiles(const float* __restrict__ priv, const int32_t* __restrict__ nflush, int nwg,
-                                      const float* __restrict__ slab, int nslab, MlpDims dm, float* __restrict__ dW,
-                                      int32_t* __restrict__ feedback, int assign) {
+static __device__ __forceinline__ void reduce_tiles_body(const float* __restrict__ priv, const int32_t* __restrict__ nflush, int nwg,
+                                                         const float* __restrict__ slab, int nslab, const MlpDims& dm, float* __restrict__ dW,
+                                                         int32_t* __restrict__ feedback, int assign, const int bx) {
   const int tid = threadIdx.x;
-  if (blockIdx.x == 0 && tid == 0) {   // tell the host (asynchronously) whether any workgroup ran out of staging slots
+  if (bx == 0 && tid == 0) {   // tell the host (asynchronously) whether any workgroup ran out of staging slots
     int mx = 0;
     for (int w = 0; w < nwg; w++) mx = max(mx, nflush[w]);
     feedback[0] = max(mx, feedback[1]);   // feedback[1]: set by a kernel that ran out of staging slots without a private slab
   }
-  const size_t base = (size_t)blockIdx.x * 1024 + 4 * tid;
+  const size_t base = (size_t)bx * 1024 + 4 * tid;
   if (base >= (size_t)dm.slab_n) return;
   const float* p = slab + base;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
@@ -491,8 +520,8 @@ static __global__ void k_reduce_tiles(const float* __restrict__ priv, const int3
     for (int g = 0; g < nwg; g++)
       if (nflush[g]) s += *reinterpret_cast<const f32x4*>(priv + (size_t)g * dm.slab_n + base);
   const int ntl = dm.tile_off[dm.nL];
-  if ((int)blockIdx.x < ntl) {
-    const int t = blockIdx.x;
+  if (bx < ntl) {
+    const int t = bx;
     int l = 0;
     while (l + 1 < dm.nL && t >= dm.tile_off[l + 1]) l++;
     const int in = dm.sizes[l], out = dm.sizes[l + 1], nit = cdiv(in, 32);
@@ -524,6 +553,26 @@ static __global__ void k_reduce_tiles(const float* __restrict__ priv, const int3
       }
     }
   }
+}
+static __global__ void k_reduce_tiles(const float* __restrict__ priv, const int32_t* __restrict__ nflush, int nwg,
+                                      const float* __restrict__ slab, int nslab, MlpDims dm, float* __restrict__ dW,
+                                      int32_t* __restrict__ feedback, int assign) {
+  reduce_tiles_body(priv, nflush, nwg, slab, nslab, dm, dW, feedback, assign, (int)blockIdx.x);
+}
+struct ReduceArgs {
+  const float* priv;
+  const int32_t* nflush;
+  int nwg;
+  const float* slab;
+  int nslab;
+  float* dW;
+  int32_t* feedback;
+  int assign;
+};
+static __global__ void k_reduce_tiles_group(GroupTable<MlpDims, ReduceArgs> g) {
+  const int j = group_find(g.start, g.n, blockIdx.x);
+  const ReduceArgs& a = g.args[j];
+  reduce_tiles_body(a.priv, a.nflush, a.nwg, a.slab, a.nslab, g.dims[j], a.dW, a.feedback, a.assign, (int)blockIdx.x - g.start[j]);
 }
 
 // ---- the weight-gradient stream (lde_set_dw_stream, include/lde.h): defined in lde_api.hip, shared by the chain and recurrent

@@ -359,10 +359,17 @@ def apply_latent_in(encoder: Encoder, pe_out):
     if isinstance(encoder.model_type, GOKU):
         pe_z0, pe_th = pe_out
         li_mu_z0, li_ls_z0, li_mu_th, li_ls_th = encoder.latent_in
-        mu_z0, mu_th, ls_z0, ls_th = run_forked([(li_mu_z0, pe_z0), (li_mu_th, pe_th), (li_ls_z0, pe_z0), (li_ls_th, pe_th)])
+        heads = [(li_mu_z0, pe_z0), (li_mu_th, pe_th), (li_ls_z0, pe_z0), (li_ls_th, pe_th)]
+        if _CHAIN_STREAMS:
+            mu_z0, mu_th, ls_z0, ls_th = run_forked(heads)
+        else:
+            from .chain import apply_chains_grouped      # the four heads as one autograd node, one launch per stage
+            mu_z0, mu_th, ls_z0, ls_th = apply_chains_grouped(heads)
         return (mu_z0, mu_th), (ls_z0, ls_th)
     li_mu, li_ls = encoder.latent_in
-    return li_mu(pe_out), li_ls(pe_out)
+    from .chain import apply_chains_grouped
+    mu, ls = apply_chains_grouped([(li_mu, pe_out), (li_ls, pe_out)])
+    return mu, ls
 
 
 def _encode_goku_group(encoder: Encoder, fe_out):

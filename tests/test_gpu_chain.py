@@ -316,3 +316,70 @@ def test_torch_bridge_takes_the_training_variant():
     _, dW = nat.backward(xn, yn, np.ones_like(yn))
     assert np.array_equal(dW, g_saved.cpu().numpy())
 
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_grouped_chains_equal_separate_calls(dtype):
+    """lde_chain_group_forward_save / _backward_saved (chain.apply_chains_grouped): independent chains as ONE autograd node, one launch
+    per stage when the library can merge them — the reference's apply_latent_in heads and apply_latent_out chains. Per chain the same
+    kernels on the same arguments: outputs, input gradients and weight gradients equal the separate calls bit for bit. Cases: the
+    GOKU bottleneck's shapes (four single Dense heads; 16→200→2 and 16→200→1), different column counts per chain, a skip / tanh
+    chain, a group whose members ask for different kernels (a 12 800-column reconstructor beside a small chain: not merged, still
+    equal), and more chains than one group takes (run separately)."""
+    import torch
+    from latentdiffeq_amd.chain import Chain, Dense, SkipConnection, apply_chains_grouped
+    torch.manual_seed(5)
+    dev = "cuda"
+
+    def mk(*layers):
+        c = Chain(*layers).to(dev)
+        if dtype == "bf16":
+            c.set_dtype("bf16")
+        return c
+
+    cases = {
+        "latent_in": [(mk(Dense(16, 16)), 256), (mk(Dense(32, 16)), 256), (mk(Dense(16, 16)), 256), (mk(Dense(32, 16)), 256)],
+        "latent_out": [(mk(Dense(16, 200, "relu"), Dense(200, 2)), 256), (mk(Dense(16, 200, "relu"), Dense(200, 1, "softplus")), 256)],
+        "ragged": [(mk(Dense(7, 33, "tanh"), SkipConnection(Dense(33, 33, "tanh")), Dense(33, 5)), 40), (mk(Dense(16, 16, "sigmoid")), 1000),
+                   (mk(Dense(3, 64, "relu"), Dense(64, 3)), 17)],
+        "mixed_kernels": [(mk(Dense(2, 200, "relu"), SkipConnection(Dense(200, 200, "relu")), Dense(200, 784, "sigmoid")), 12800),
+                          (mk(Dense(16, 200, "relu"), Dense(200, 2)), 256)],
+        "five": [(mk(Dense(8, 8)), 64) for _ in range(5)],
+    }
+    for name, members in cases.items():
+        xs = [torch.randn(c.sizes[0], N, device=dev) for c, N in members]
+        gs = [torch.randn(c.sizes[-1], N, device=dev) for c, N in members]
+
+        def run(grouped):
+            xr = [x.clone().requires_grad_(True) for x in xs]
+            for c, _ in members:
+                c.theta.grad = None
+            pairs = [(c, x) for (c, _), x in zip(members, xr)]
+            ys = apply_chains_grouped(pairs) if grouped else [c(x) for c, x in pairs]
+            torch.autograd.backward(ys, gs)
+            torch.cuda.synchronize()
+            return [y.detach().clone() for y in ys], [x.grad.clone() for x in xr], [c.theta.grad.clone() for c, _ in members]
+
+        a, b = run(False), run(True)
+        for what, u, v in zip(("y", "dx", "dW"), a, b):
+            for i, (p, q) in enumerate(zip(u, v)):
+                assert torch.equal(p, q), (dtype, name, what, i, float((p - q).abs().max()))
+    # frozen inputs (no dx asked for) and evaluation without gradients go through the same entry points
+    c1, c2 = mk(Dense(16, 16)), mk(Dense(16, 200, "relu"), Dense(200, 2))
+    x = torch.randn(16, 64, device=dev)
+    y1, y2 = apply_chains_grouped([(c1, x), (c2, x)])
+    torch.autograd.backward([y1, y2], [torch.ones_like(y1), torch.ones_like(y2)])
+    with torch.no_grad():
+        z1, z2 = apply_chains_grouped([(c1, x), (c2, x)])
+    assert torch.equal(z1, y1) and torch.equal(z2, y2) and c1.theta.grad is not None
+
+
+def test_group_entry_points_validate():
+    import ctypes as C
+    from latentdiffeq_amd import _lib as L
+    lib = L.load()
+    assert lib.lde_chain_group_forward_save(0, None, None, None, None, None, None) == -1
+    assert lib.lde_chain_group_forward_save(2, None, None, None, None, None, None) == -1
+    hs = (C.c_void_p * 2)(None, None)
+    assert lib.lde_chain_group_forward_save(2, hs, hs, (C.c_int64 * 2)(1, 1), hs, None, None) == -1        # NULL chain handle
+    assert lib.lde_chain_group_backward_saved(2, hs, hs, hs, hs, None, (C.c_int64 * 2)(1, 1), None, hs, None) == -1
+

@@ -1018,8 +1018,8 @@ struct GroupRec {
 static thread_local GroupRec* t_rec = nullptr;
 // (kernel arguments: 4 KB on this runtime)
 static_assert(sizeof(GroupTable<ChainBDims, ChainBwdArgsB>) <= 4096 && sizeof(GroupTable<ChainDims, ChainBwdArgs>) <= 4096 &&
-              sizeof(GroupTable<ChainBDims, DwArgsB>) <= 4096 && sizeof(GroupTable<MlpDims, DwArgs>) <= 4096 &&
-              sizeof(GroupTable<MlpDims, ReduceArgs>) <= 4096, "a group's argument table must fit the kernel-argument segment");
+              sizeof(GroupTable<ChainBDims, DwArgsB>) <= 4096 && sizeof(GroupTable<MlpDims, DwArgs, GROUP_MAX_DW>) <= 4096 &&
+              sizeof(GroupTable<MlpDims, ReduceArgs, GROUP_MAX_DW>) <= 4096, "a group's argument table must fit the kernel-argument segment");
 
 static bool set_max_lds_(const void* fn, bool* done) {
   if (*done) return true;
@@ -1128,7 +1128,7 @@ static int group_flush(GroupRec& g, hipStream_t stream) {
       for (int j = 0; j < n; j++) lds = std::max(lds, g.dw[j].lds);
       static bool attr[2] = {false, false};
       if (g.dw[0].kind == 0) {
-        GroupTable<MlpDims, DwArgs> t{};
+        GroupTable<MlpDims, DwArgs, GROUP_MAX_DW> t{};
         t.n = n;
         for (int j = 0; j < n; j++) {
           t.start[j + 1] = t.start[j] + g.dw[j].gx * g.dw[j].gy * g.dw[j].gz;
@@ -1157,7 +1157,7 @@ static int group_flush(GroupRec& g, hipStream_t stream) {
     bool any = false, all = n >= 2;
     for (int j = 0; j < n; j++) { any = any || g.red_set[j]; all = all && g.red_set[j]; }
     if (any && all) {
-      GroupTable<MlpDims, ReduceArgs> t{};
+      GroupTable<MlpDims, ReduceArgs, GROUP_MAX_DW> t{};
       t.n = n;
       for (int j = 0; j < n; j++) { t.start[j + 1] = t.start[j] + (int)g.red[j].grid; t.dims[j] = g.red[j].dm; t.args[j] = g.red[j].a; }
       void* argv[] = {(void*)&t};

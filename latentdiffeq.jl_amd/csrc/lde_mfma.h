@@ -460,14 +460,15 @@ static __global__ void __launch_bounds__(512) k_mlp_dw(MlpDims dm, DwArgs a) {
 // launches of ≈ 5–7 µs each, one behind the other — a quarter of the captured training step. Every kernel of that family exists as a
 // body taking its block coordinates as arguments; the grouped form carries up to GROUP_MAX argument sets in the kernel arguments and a
 // workgroup finds its module from the prefix sums of the modules' grids. Same code on the same data per module: bit-equal results.
-constexpr int GROUP_MAX = 4;
-template <class Dims, class Args>
+constexpr int GROUP_MAX = 4;      // chains per group
+constexpr int GROUP_MAX_DW = 6;   // weight-gradient jobs per group (a recurrent stack brings one per cell: three stacks of two)
+template <class Dims, class Args, int CAP = GROUP_MAX>
 struct GroupTable {
   int n;
-  int start[GROUP_MAX + 1];   // first flat block of module j (start[n] = the grid)
-  int gx[GROUP_MAX], gy[GROUP_MAX];   // the module's own grid extents (x, y) where a kernel decodes more than one coordinate
-  Dims dims[GROUP_MAX];
-  Args args[GROUP_MAX];
+  int start[CAP + 1];   // first flat block of module j (start[n] = the grid)
+  int gx[CAP], gy[CAP]; // the module's own grid extents (x, y) where a kernel decodes more than one coordinate
+  Dims dims[CAP];
+  Args args[CAP];
 };
 __device__ __forceinline__ int group_find(const int* start, int n, int b) {
   int j = 0;
@@ -475,7 +476,7 @@ __device__ __forceinline__ int group_find(const int* start, int n, int b) {
   return j;
 }
 template <int DW_NDW, bool BF>
-static __global__ void __launch_bounds__(512) k_mlp_dw_group(GroupTable<MlpDims, DwArgs> g) {
+static __global__ void __launch_bounds__(512) k_mlp_dw_group(GroupTable<MlpDims, DwArgs, GROUP_MAX_DW> g) {
   const int j = group_find(g.start, g.n, blockIdx.x), r = blockIdx.x - g.start[j];
   const int per = g.gx[j] * g.gy[j];
   mlp_dw_body<DW_NDW, BF>(g.dims[j], g.args[j], r % g.gx[j], (r / g.gx[j]) % g.gy[j], g.gy[j], r / per);
@@ -569,7 +570,7 @@ struct ReduceArgs {
   int32_t* feedback;
   int assign;
 };
-static __global__ void k_reduce_tiles_group(GroupTable<MlpDims, ReduceArgs> g) {
+static __global__ void k_reduce_tiles_group(GroupTable<MlpDims, ReduceArgs, GROUP_MAX_DW> g) {
   const int j = group_find(g.start, g.n, blockIdx.x);
   const ReduceArgs& a = g.args[j];
   reduce_tiles_body(a.priv, a.nflush, a.nwg, a.slab, a.nslab, g.dims[j], a.dW, a.feedback, a.assign, (int)blockIdx.x - g.start[j]);

@@ -111,8 +111,8 @@ __host__ __device__ constexpr int rnn_ldk(int K) { int v = (K + 3) & ~3; return 
 // (and, for the pullback, of the transposed copy) from LDS into registers once; a dot product is then K/4 broadcast reads of
 // [x; h] feeding v_pk_fma_f32 on register pairs — half the LDS instructions and half the FMA issue slots of the LDS-row form
 // (measured per (step, layer) on the LSTM stack: forward product 610 → ≈ 330 cycles, Wᵀδ 940 → ≈ 450).
-template <int CELL_, int IN0_, int H_, int L_, int MODE_, bool REGW = false>
-__global__ void __launch_bounds__(REGW ? 64 : 1024) k_rnn(RnnDims rd, RnnArgs a) {
+template <int CELL_, int IN0_, int H_, int L_, int MODE_, bool REGW>
+__device__ __forceinline__ void rnn_body(const RnnDims& rd, const RnnArgs& a, const unsigned bx) {
   extern __shared__ __attribute__((aligned(16))) float rsm[];
   constexpr bool SP = CELL_ >= 0;
   static_assert(!REGW || SP, "register-resident weights need a compile-time shape");
@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(REGW ? 64 : 1024) k_rnn(RnnDims rd, RnnArgs a)
       }
     }
   }
-  const long long b = (long long)blockIdx.x * tpw + tr;
+  const long long b = (long long)bx * tpw + tr;
   const bool valid = b < B;
   const size_t tile = (size_t)(b >> 4);   // staging tile (16 trajectories = one column slot of the weight-gradient kernel)
   const int row = (int)(b & 15);
@@ -422,11 +422,29 @@ __global__ void __launch_bounds__(REGW ? 64 : 1024) k_rnn(RnnDims rd, RnnArgs a)
   }
 }
 
+template <int CELL_, int IN0_, int H_, int L_, int MODE_, bool REGW = false>
+__global__ void __launch_bounds__(REGW ? 64 : 1024) k_rnn(RnnDims rd, RnnArgs a) {
+  rnn_body<CELL_, IN0_, H_, L_, MODE_, REGW>(rd, a, blockIdx.x);
+}
+// Several stacks of the default shape (32 → 16 → 16, one wave per workgroup) in ONE launch — the three pattern extractors of the GOKU
+// encoder [REF src/models/GOKU.jl:32-51] run on the same frames; on three streams inside a captured step their kernels started 15 and
+// 60 µs apart and their weight-gradient tails queued behind each other (kernel trace, profiles/r3_goku_step_mixed_*). The cell kind is
+// a block-uniform switch; same code on the same data per stack.
+constexpr int RNN_GROUP_MAX = 3;
+template <int MODE_>
+__global__ void __launch_bounds__(64) k_rnn_group(GroupTable<RnnDims, RnnArgs, RNN_GROUP_MAX> g) {
+  const int j = group_find(g.start, g.n, blockIdx.x);
+  const unsigned bx = blockIdx.x - g.start[j];
+  const int cell = g.dims[j].cell;
+  if (cell == LDE_CELL_LSTM) rnn_body<LDE_CELL_LSTM, 32, 16, 2, MODE_, true>(g.dims[j], g.args[j], bx);
+  else if (cell == LDE_CELL_RNN_RELU) rnn_body<LDE_CELL_RNN_RELU, 32, 16, 2, MODE_, true>(g.dims[j], g.args[j], bx);
+  else rnn_body<LDE_CELL_RNN_TANH, 32, 16, 2, MODE_, true>(g.dims[j], g.args[j], bx);
+}
+
 // dW[state0 slots] += Σ_b g0[b][·]: one wave per state entry, lane j adds trajectories j, j+64, … in order, then a fixed
 // butterfly over the lanes (deterministic)
-__global__ void __launch_bounds__(64) k_rnn_state0(const float* __restrict__ g0, int B, int g0w, RnnDims rd, float* __restrict__ dW,
-                                                    int assign) {
-  const int i = blockIdx.x;
+__device__ __forceinline__ void rnn_state0_body(const float* __restrict__ g0, int B, int g0w, const RnnDims& rd, float* __restrict__ dW,
+                                                int assign, const int i) {
   int off = 0, l = 0;
   for (; l < rd.nL; l++) {
     const int ns = (rd.cell == LDE_CELL_LSTM ? 2 : 1) * rd.sizes[l + 1];
@@ -442,6 +460,16 @@ __global__ void __launch_bounds__(64) k_rnn_state0(const float* __restrict__ g0,
     float* o = dW + rd.f_off[l] + (size_t)R * in + (size_t)R * h + R + (i - off);
     *o = assign ? s : *o + s;
   }
+}
+__global__ void __launch_bounds__(64) k_rnn_state0(const float* __restrict__ g0, int B, int g0w, RnnDims rd, float* __restrict__ dW,
+                                                    int assign) {
+  rnn_state0_body(g0, B, g0w, rd, dW, assign, (int)blockIdx.x);
+}
+struct State0Args { const float* g0; int B, g0w; float* dW; int assign; };
+__global__ void __launch_bounds__(64) k_rnn_state0_group(GroupTable<RnnDims, State0Args, RNN_GROUP_MAX> g) {
+  const int j = group_find(g.start, g.n, blockIdx.x);
+  const State0Args& a = g.args[j];
+  rnn_state0_body(a.g0, a.B, a.g0w, g.dims[j], a.dW, a.assign, (int)blockIdx.x - g.start[j]);
 }
 
 }  // namespace lde
@@ -465,7 +493,7 @@ struct lde_rnn {
   float* stage[RNN_ML] = {nullptr, nullptr, nullptr, nullptr}; size_t stage_cap[RNN_ML] = {0, 0, 0, 0};
   float* wts = nullptr; size_t wts_cap = 0;
   float* g0 = nullptr; size_t g0_cap = 0;
-  float* slab = nullptr; size_t slab_cap = 0;
+  float* slab = nullptr; size_t slab_cap = 0; size_t slab_layer = 0;
   int32_t* ints = nullptr; size_t ints_cap = 0;
   bool accumulate = true;   // pullback: dW += gradient (default) or dW = gradient
   void (*kernel[2][2])(lde::RnnDims, lde::RnnArgs) = {{nullptr, nullptr}, {nullptr, nullptr}};   // the k_rnn instantiations for this stack: [forward, pullback][any workgroup size, one wave per workgroup]
@@ -637,7 +665,8 @@ int lde_rnn_reserve(lde_rnn* r, int B, int T) {
     ok = grow(&r->stage[l], &r->stage_cap[l], ntile * T * r->dmw[l].blk_floats);
     slab_need = std::max(slab_need, (ntile * 8 + 1) * (size_t)r->dmw[l].slab_n);
   }
-  ok = ok && grow(&r->slab, &r->slab_cap, slab_need);
+  r->slab_layer = slab_need;   // one region per layer: a grouped tail runs the layers' weight-gradient products in one launch
+  ok = ok && grow(&r->slab, &r->slab_cap, slab_need * rd.nL);
   if (!ok) {
     r->err = "recurrent stack: hipMalloc of the workspace failed";
     return LDE_ERR_ALLOC;
@@ -663,6 +692,23 @@ static rnn_kernel_t rnn_pick(const RnnDims& rd, int mode, bool one_wave = false)
   }
   return k_rnn<-1, 0, 0, 0, 0>;
 }
+
+// ---- grouped calls (lde_rnn_group_*): as in lde_chain.hip — while a recorder is installed the launch sites record; the group entry point
+// issues each stage once for all stacks where they ask for the same kernel family, one by one otherwise.
+struct RnnRecMain { rnn_kernel_t fn; bool groupable; int mode; RnnDims rd; RnnArgs a; unsigned grid, block; size_t lds; };
+struct RnnRecDw { int ndw; MlpDims dm; DwArgs da; int gx, gy, gz; size_t lds; MlpDims rdm; ReduceArgs ra; unsigned rgrid; };
+struct RnnRecS0 { RnnDims rd; State0Args a; unsigned grid; };
+struct RnnGroupRec {
+  int n = 0;
+  bool main_set[RNN_GROUP_MAX] = {};
+  RnnRecMain main[RNN_GROUP_MAX];
+  int ndw = 0;
+  RnnRecDw dw[GROUP_MAX_DW];
+  int ns0 = 0;
+  RnnRecS0 s0[RNN_GROUP_MAX];
+};
+static thread_local RnnGroupRec* t_rrec = nullptr;
+static_assert(sizeof(GroupTable<RnnDims, RnnArgs, RNN_GROUP_MAX>) <= 4096, "a group's argument table must fit the kernel-argument segment");
 
 static int rnn_launch(lde_rnn* r, const RnnArgs& a, int B, hipStream_t stream) {
   const int m = a.mode ? 1 : 0;
@@ -691,6 +737,16 @@ static int rnn_launch(lde_rnn* r, const RnnArgs& a, int B, hipStream_t stream) {
 #if LDE_PROF
   { long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
 #endif
+  if (t_rrec) {
+    RnnRecMain& q = t_rrec->main[t_rrec->n];
+    q.fn = r->kernel[m][one];
+    const RnnDims& rd = r->rd;
+    q.groupable = one && rd.wt && rd.nL == 2 && rd.sizes[0] == 32 && rd.sizes[1] == 16 && rd.sizes[2] == 16 &&
+                  q.fn != (rnn_kernel_t)k_rnn<-1, 0, 0, 0, 0>;
+    q.mode = m; q.rd = rd; q.a = aa; q.grid = (unsigned)(cdiv(B, 16) * (16 / tpw)); q.block = (unsigned)(tpw * rd.Hp); q.lds = lds;
+    t_rrec->main_set[t_rrec->n] = true;
+    return LDE_OK;
+  }
   hipLaunchKernelGGL(r->kernel[m][one], dim3(cdiv(B, 16) * (16 / tpw)), dim3(tpw * r->rd.Hp), lds, stream, r->rd, aa);
   if (hipGetLastError() != hipSuccess) {
     r->err = "k_rnn launch failed";
@@ -784,11 +840,25 @@ int lde_rnn_backward_dw(lde_rnn* r, float* dW, void* stream_) {
   }
   for (int l = 0; l < rd.nL; l++) {
     DwArgs da;
-    da.stage = r->stage[l]; da.wts = r->wts; da.nslots = nullptr; da.slab = r->slab; da.cap = T; da.total = (long long)ntile * T;   // every tile staged exactly T slots
+    da.stage = r->stage[l]; da.wts = r->wts; da.nslots = nullptr; da.slab = r->slab + (size_t)l * r->slab_layer; da.cap = T; da.total = (long long)ntile * T;   // every tile staged exactly T slots
     int ks = cdiv(512, ntile * dw_jobs(r->dmw[l], dw_pick_ndw(r->dmw[l])));
     ks = ks < 1 ? 1 : (ks > 8 ? 8 : ks);
+    if (t_rrec && t_rrec->ndw < GROUP_MAX_DW) {
+      RnnRecDw& q = t_rrec->dw[t_rrec->ndw++];
+      q.ndw = dw_pick_ndw(r->dmw[l]); q.dm = r->dmw[l]; q.da = da; q.gx = ntile; q.gy = ks; q.gz = dw_jobs(r->dmw[l], q.ndw);
+      q.lds = dw_lds_floats(r->dmw[l], q.ndw) * sizeof(float);
+      q.rdm = r->dmw[l];
+      q.ra = ReduceArgs{nullptr, r->ints, 0, da.slab, ntile * ks, dW + rd.f_off[l], r->ints + 2, r->accumulate ? 0 : 1};
+      q.rgrid = (unsigned)cdiv(r->dmw[l].slab_n, 1024);
+      continue;
+    }
     int rc = launch_weight_gradient(r->dmw[l], da, ntile, ks, nullptr, r->ints, 0, dW + rd.f_off[l], r->ints + 2, wst, r->err, !r->accumulate);
     if (rc) return rc;
+  }
+  if (t_rrec) {
+    RnnRecS0& q = t_rrec->s0[t_rrec->ns0++];
+    q.rd = rd; q.a = State0Args{r->g0, B, r->g0w, dW, r->accumulate ? 0 : 1}; q.grid = (unsigned)r->g0w;
+    return LDE_OK;
   }
   hipLaunchKernelGGL(k_rnn_state0, dim3(r->g0w), dim3(64), 0, wst, r->g0, B, r->g0w, rd, dW, r->accumulate ? 0 : 1);
   if (hipGetLastError() != hipSuccess || !dw_sync_end(r->dws, wst, stream)) {
@@ -805,6 +875,139 @@ int lde_rnn_backward(lde_rnn* r, const float* x, const float* dy, int T, int B, 
   }
   const int rc = lde_rnn_backward_dx(r, x, dy, T, B, dx, stream_);
   return rc ? rc : lde_rnn_backward_dw(r, dW, stream_);
+}
+
+static int rnn_group_flush(RnnGroupRec& g, hipStream_t stream) {
+  const int n = g.n;
+  {   // the sweeps
+    bool any = false, same = n >= 2;
+    for (int j = 0; j < n; j++) { any = any || g.main_set[j]; same = same && g.main_set[j] && g.main[j].groupable && g.main[j].mode == g.main[0].mode; }
+    if (any && same) {
+      GroupTable<RnnDims, RnnArgs, RNN_GROUP_MAX> t{};
+      t.n = n;
+      size_t lds = 0;
+      for (int j = 0; j < n; j++) { t.start[j + 1] = t.start[j] + (int)g.main[j].grid; t.dims[j] = g.main[j].rd; t.args[j] = g.main[j].a; lds = std::max(lds, g.main[j].lds); }
+      static bool attr[2] = {false, false};
+      const int m = g.main[0].mode;
+      const void* fn = m ? (const void*)k_rnn_group<1> : (const void*)k_rnn_group<0>;
+      if (!attr[m]) {
+        if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) return LDE_ERR_HIP;
+        attr[m] = true;
+      }
+      void* argv[] = {(void*)&t};
+      (void)hipLaunchKernel(fn, dim3(t.start[n]), dim3(64), argv, lds, stream);
+    } else if (any) {
+      for (int j = 0; j < n; j++)
+        if (g.main_set[j]) hipLaunchKernelGGL(g.main[j].fn, dim3(g.main[j].grid), dim3(g.main[j].block), g.main[j].lds, stream, g.main[j].rd, g.main[j].a);
+    }
+  }
+  if (g.ndw > 0) {   // the weight-gradient products of every (stack, cell), then their slab sums
+    bool same = g.ndw >= 2;
+    for (int j = 0; j < g.ndw; j++) same = same && g.dw[j].ndw == 1;
+    static bool attr[3] = {false, false, false};
+    if (same) {
+      GroupTable<MlpDims, DwArgs, GROUP_MAX_DW> t{};
+      GroupTable<MlpDims, ReduceArgs, GROUP_MAX_DW> u{};
+      t.n = u.n = g.ndw;
+      size_t lds = 0;
+      for (int j = 0; j < g.ndw; j++) {
+        const RnnRecDw& q = g.dw[j];
+        t.start[j + 1] = t.start[j] + q.gx * q.gy * q.gz; t.gx[j] = q.gx; t.gy[j] = q.gy; t.dims[j] = q.dm; t.args[j] = q.da; lds = std::max(lds, q.lds);
+        u.start[j + 1] = u.start[j] + (int)q.rgrid; u.dims[j] = q.rdm; u.args[j] = q.ra;
+      }
+      if (!attr[0]) {
+        if (hipFuncSetAttribute((const void*)k_mlp_dw_group<1, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) return LDE_ERR_HIP;
+        attr[0] = true;
+      }
+      void* argv[] = {(void*)&t};
+      (void)hipLaunchKernel((const void*)k_mlp_dw_group<1, false>, dim3(t.start[g.ndw]), dim3(512), argv, lds, stream);
+      void* argu[] = {(void*)&u};
+      (void)hipLaunchKernel((const void*)k_reduce_tiles_group, dim3(u.start[g.ndw]), dim3(256), argu, 0, stream);
+    } else {
+      std::string err;
+      for (int j = 0; j < g.ndw; j++) {
+        const RnnRecDw& q = g.dw[j];
+        const int rc = launch_weight_gradient(q.dm, q.da, q.gx, q.gy, nullptr, q.ra.nflush, 0, q.ra.dW, q.ra.feedback, stream, err, q.ra.assign != 0);
+        if (rc) return rc;
+      }
+    }
+  }
+  if (g.ns0 > 0) {
+    if (g.ns0 >= 2) {
+      GroupTable<RnnDims, State0Args, RNN_GROUP_MAX> t{};
+      t.n = g.ns0;
+      for (int j = 0; j < g.ns0; j++) { t.start[j + 1] = t.start[j] + (int)g.s0[j].grid; t.dims[j] = g.s0[j].rd; t.args[j] = g.s0[j].a; }
+      void* argv[] = {(void*)&t};
+      (void)hipLaunchKernel((const void*)k_rnn_state0_group, dim3(t.start[g.ns0]), dim3(64), argv, 0, stream);
+    } else {
+      const RnnRecS0& q = g.s0[0];
+      hipLaunchKernelGGL(k_rnn_state0, dim3(q.grid), dim3(64), 0, stream, q.a.g0, q.a.B, q.a.g0w, q.rd, q.a.dW, q.a.assign);
+    }
+  }
+  return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
+}
+static bool rnn_group_ok(int n) {
+#if LDE_PROF
+  return false;
+#else
+  static const bool on = [] { const char* e = std::getenv("LDE_RNN_GROUP_LAUNCH"); return !e || std::atoi(e) != 0; }();
+  return on && n >= 2 && n <= RNN_GROUP_MAX && dw_stream_get() == nullptr;
+#endif
+}
+static bool rnn_group_fits(int n, lde_rnn* const* rs) {   // every (stack, cell) weight-gradient job must fit one table
+  int jobs = 0;
+  for (int i = 0; i < n; i++) jobs += rs[i]->rd.nL;
+  return jobs <= GROUP_MAX_DW;
+}
+int lde_rnn_group_forward(int n, lde_rnn* const* rs, const float* const* xs, int T, int B, float* const* ys, void* stream) {
+  if (n < 1 || !rs || !xs || !ys) return LDE_ERR_INVALID_ARG;
+  for (int i = 0; i < n; i++)
+    if (!rs[i]) return LDE_ERR_INVALID_ARG;
+  if (!rnn_group_ok(n)) {
+    for (int i = 0; i < n; i++) {
+      const int rc = lde_rnn_forward(rs[i], xs[i], T, B, ys[i], stream);
+      if (rc) return rc;
+    }
+    return LDE_OK;
+  }
+  RnnGroupRec g;
+  t_rrec = &g;
+  for (int i = 0; i < n; i++) {
+    g.n = i;
+    const int rc = lde_rnn_forward(rs[i], xs[i], T, B, ys[i], stream);
+    if (rc) { t_rrec = nullptr; return rc; }
+  }
+  g.n = n;
+  t_rrec = nullptr;
+  const int rc = rnn_group_flush(g, (hipStream_t)stream);
+  if (rc) rs[0]->err = "lde_rnn_group_forward: launch failed";
+  return rc;
+}
+int lde_rnn_group_backward(int n, lde_rnn* const* rs, const float* const* xs, const float* const* dys, int T, int B, float* const* dxs,
+                           float* const* dWs, void* stream) {
+  if (n < 1 || !rs || !xs || !dys || !dWs) return LDE_ERR_INVALID_ARG;
+  for (int i = 0; i < n; i++)
+    if (!rs[i] || !dWs[i]) return LDE_ERR_INVALID_ARG;
+  if (!rnn_group_ok(n) || !rnn_group_fits(n, rs)) {
+    for (int i = 0; i < n; i++) {
+      const int rc = lde_rnn_backward(rs[i], xs[i], dys[i], T, B, dxs ? dxs[i] : nullptr, dWs[i], stream);
+      if (rc) return rc;
+    }
+    return LDE_OK;
+  }
+  RnnGroupRec g;
+  t_rrec = &g;
+  for (int i = 0; i < n; i++) {
+    g.n = i;
+    int rc = lde_rnn_backward_dx(rs[i], xs[i], dys[i], T, B, dxs ? dxs[i] : nullptr, stream);
+    if (!rc) rc = lde_rnn_backward_dw(rs[i], dWs[i], stream);
+    if (rc) { t_rrec = nullptr; return rc; }
+  }
+  g.n = n;
+  t_rrec = nullptr;
+  const int rc = rnn_group_flush(g, (hipStream_t)stream);
+  if (rc) rs[0]->err = "lde_rnn_group_backward: launch failed";
+  return rc;
 }
 
 int lde_rnn_set_accumulate(lde_rnn* r, int on) {

@@ -202,6 +202,63 @@ class _RecurrentGroupFn(torch.autograd.Function):
         return (None, dx, *dWs)
 
 
+class _RecurrentLaunchGroupFn(torch.autograd.Function):
+    """(y_1, …, y_n) = (stack_1(x), …, stack_n(x)) on ONE stream through lde_rnn_group_forward / lde_rnn_group_backward: every stage of
+    the call — the sweeps, the weight-gradient products of all (stack, cell) pairs, their fixed-order sums, the initial-state sums — is
+    one launch (round 3). The same kernels on the same arguments per stack as _RecurrentFn: bit-equal results
+    (tests/test_gpu_rnn.py::test_launch_grouped_stacks_equal_separate_calls). Inside a captured step this replaces the three side
+    streams of _run_concurrently, whose kernels started 15 and 60 µs apart and whose weight-gradient tails queued behind each other."""
+
+    @staticmethod
+    def forward(ctx, recs, x, *Ws):
+        if not x.is_cuda:
+            raise L.LdeError("Recurrent needs CUDA/HIP tensors: it runs on the GPU only (no CPU fallback)")
+        n = len(recs)
+        dev = x.device
+        stream = L.raw_stream(dev.index)
+        T, B, _ = x.shape
+        hs = []
+        for rec, W in zip(recs, Ws):
+            h = rec._native()
+            if rec._wkey != L.weights_key(W):
+                Wc = W.detach().contiguous().float()
+                L.check(rec._lib.lde_rnn_set_weights_device(h, C.c_void_p(Wc.data_ptr()), Wc.numel(), stream), h, "lde_rnn_set_weights_device", rnn=True)
+                rec._wkey = None
+            hs.append(h)
+        lib = recs[0]._lib
+        ys = [torch.empty((B, rec.sizes[-1]), device=dev, dtype=torch.float32) for rec in recs]
+        arr = lambda ptrs: (C.c_void_p * n)(*ptrs)
+        ctx.c_handles = arr([h.value for h in hs])
+        rc = lib.lde_rnn_group_forward(n, ctx.c_handles, arr([x.data_ptr()] * n), T, B, arr([y.data_ptr() for y in ys]), stream)
+        L.check(rc, hs[0], "lde_rnn_group_forward", rnn=True)
+        ctx.recs, ctx.need_dx = recs, x.requires_grad
+        ctx.save_for_backward(x)
+        return tuple(ys)
+
+    @staticmethod
+    def backward(ctx, *dys):
+        recs = ctx.recs
+        (x,) = ctx.saved_tensors
+        n = len(recs)
+        dev = x.device
+        T, B, _ = x.shape
+        stream = L.raw_stream(dev.index)
+        dys = [dy.contiguous().float() for dy in dys]
+        dxs = [torch.empty_like(x) for _ in recs] if ctx.need_dx else None
+        dWs = [torch.empty((rec.num_weights,), device=dev, dtype=torch.float32) for rec in recs]     # written, not accumulated (set_accumulate(0))
+        arr = lambda ptrs: (C.c_void_p * n)(*ptrs)
+        lib = recs[0]._lib
+        rc = lib.lde_rnn_group_backward(n, ctx.c_handles, arr([x.data_ptr()] * n), arr([d.data_ptr() for d in dys]), T, B,
+                                        arr([d.data_ptr() for d in dxs]) if dxs is not None else None, arr([d.data_ptr() for d in dWs]), stream)
+        L.check(rc, recs[0]._native(), "lde_rnn_group_backward", rnn=True)
+        dx = None
+        if dxs is not None:
+            dx = dxs[0]
+            for d in dxs[1:]:
+                dx = dx + d
+        return (None, dx, *dWs)
+
+
 class Recurrent(torch.nn.Module):
     """A stack of cells of one kind applied to the frames of x [in, B, T] (reverse=True: frames T..1), returning the output
     after the last frame, [h_last, B] — `[pe(x) for x in frames][end]` followed by `Flux.reset!`  [REF GOKU.jl:40-47]."""
@@ -288,6 +345,8 @@ _RNN_GROUP = os.environ.get("LDE_RNN_GROUP", "0") != "0"             # encode():
                                                                        # alternations on one box) — the z₀ branch's latent_in chains then run after the join instead of
                                                                        # beside the θ branch's longer stacks, and the per-tensor record_stream calls cost the host more
                                                                        # than the two autograd nodes they save
+_RNN_LAUNCH_GROUP = os.environ.get("LDE_RNN_LAUNCH_GROUP", "1") != "0"   # apply_pattern_extractor (the path without branch streams — what a captured step
+                                                                           # runs): the stacks through lde_rnn_group_* on one stream instead of three side streams
 _STACKS_FIRST = os.environ.get("LDE_STACKS_FIRST", "1") != "0"       # encode(): issue the three recurrent stacks before the latent_in chains (diagnostic switch)
 _BRANCH_STREAMS = os.environ.get("LDE_BRANCH_STREAMS", "1") != "0"   # encode(): keep the z₀ / θ branches on their own streams (diagnostic switch)
 
@@ -347,7 +406,13 @@ def apply_pattern_extractor(encoder: Encoder, fe_out):
     """[REF src/models/GOKU.jl:32-51]: pe_z₀ on the reversed frames; pe_θ forward ⊕ pe_θ backward (reversed frames).
     [REF src/models/LatentODE.jl:24-33]: one stack on the reversed frames."""
     if isinstance(encoder.model_type, GOKU):
-        outs = _run_concurrently(encoder.pattern_extractor, fe_out)
+        pes = encoder.pattern_extractor
+        if _RNN_LAUNCH_GROUP and fe_out.is_cuda and fe_out.dim() == 3 and 2 <= len(pes) <= 3 and all(isinstance(m, Recurrent) for m in pes):
+            buf = fe_out.permute(2, 1, 0).contiguous().float()            # (T, B, in) == column-major [in × B × T], once for the three stacks
+            ys = _RecurrentLaunchGroupFn.apply(tuple(pes), buf, *[m.flat_weights() for m in pes])
+            outs = [y.t() for y in ys]
+        else:
+            outs = _run_concurrently(pes, fe_out)
         return outs[0], torch.cat([outs[1].t(), outs[2].t()], dim=1).t()   # vcat, kept in batch-major memory (what latent_in reads)
     if isinstance(encoder.model_type, LatentODE):
         return encoder.pattern_extractor(fe_out)

@@ -220,7 +220,8 @@ def test_branch_streams_match_joined_streams():
     their own HIP streams to the end (default), and the variant that joins the streams after the recurrent stacks — over several
     iterations with changing (B, T): allocator reuse across streams would show up as differing outputs or gradients (round-1
     advisor finding on record_stream coverage). Outputs agree bit for bit; so do the gradients of the two older variants; the
-    grouped node adds the three input gradients in its own order, so its gradients agree to f32 rounding (1e-6 of the largest)."""
+    grouped nodes (raw side streams; round 3: one launch per stage through lde_rnn_group_*) add the three input gradients in their own
+    order, so their gradients agree to f32 rounding (1e-6 of the largest)."""
     import torch
     import latentdiffeq_amd as M
     from latentdiffeq_amd import recurrent as R
@@ -230,14 +231,14 @@ def test_branch_streams_match_joined_streams():
     fe, pe, li = R.default_encoder_layers(mt, NI, hidden_dim_resnet=40, device="cuda")
     enc = R.Encoder(mt, (fe, pe, li))
     params = [p for m in [fe, *pe, *li] for p in m.parameters()]
-    keep = R._BRANCH_STREAMS, R._RNN_GROUP
+    keep = R._BRANCH_STREAMS, R._RNN_GROUP, R._RNN_LAUNCH_GROUP
     try:
         for it, (B, T) in enumerate([(20, 7), (64, 12), (16, 5), (33, 9), (64, 12), (256, 20)]):
             x = torch.rand(NI, B, T, device="cuda")
             cts = [torch.randn(16, B, device="cuda") for _ in range(4)]
             res = []
-            for group, branch in ((True, True), (False, True), (False, False)):
-                R._RNN_GROUP, R._BRANCH_STREAMS = group, branch
+            for group, branch, launch in ((True, True, False), (False, True, False), (False, False, False), (False, False, True)):
+                R._RNN_GROUP, R._BRANCH_STREAMS, R._RNN_LAUNCH_GROUP = group, branch, launch   # (the last: the stacks through lde_rnn_group_*, round 3)
                 for p in params:
                     p.grad = None
                 (mz, mt_), (lz, lt) = R.encode(enc, x)
@@ -251,7 +252,50 @@ def test_branch_streams_match_joined_streams():
                     assert torch.equal(a, b), (it, B, T)
             for a, b in zip(res[1][1], res[2][1]):
                 assert torch.equal(a, b), (it, B, T)
-            for a, b in zip(res[0][1], res[1][1]):
-                assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-12, (it, B, T)
+            for grouped in (res[0][1], res[3][1]):      # the two grouped nodes add the three frame gradients in their own order
+                for a, b in zip(grouped, res[1][1]):
+                    assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-12, (it, B, T)
     finally:
-        R._BRANCH_STREAMS, R._RNN_GROUP = keep
+        R._BRANCH_STREAMS, R._RNN_GROUP, R._RNN_LAUNCH_GROUP = keep
+
+
+def test_launch_grouped_stacks_equal_separate_calls():
+    """lde_rnn_group_forward / lde_rnn_group_backward (recurrent._RecurrentLaunchGroupFn): the GOKU encoder's three pattern extractors
+    on the same frames — one RNN stack and two LSTM stacks of the default shape — with every stage of the call ONE launch. Per stack
+    the same kernels on the same arguments as the separate calls: outputs, the frame gradient and every stack's weight gradient equal
+    them bit for bit; a non-default shape in the group (run one after the other by the library) too."""
+    import torch
+    from latentdiffeq_amd.recurrent import LSTM, RNN, Recurrent, _RecurrentLaunchGroupFn
+    torch.manual_seed(3)
+    dev = "cuda"
+    for shapes, (T, B) in (([("rnn", 32, 16), ("lstm", 32, 16), ("lstm", 32, 16)], (50, 256)), ([("rnn", 32, 16), ("lstm", 32, 16)], (7, 37)),
+                           ([("lstm", 32, 16), ("lstm", 32, 12), ("rnn", 32, 16)], (9, 40))):
+        stacks = []
+        for kind, i, h in shapes:
+            cells = (RNN(i, h, "relu"), RNN(h, h, "relu")) if kind == "rnn" else (LSTM(i, h), LSTM(h, h))
+            stacks.append(Recurrent(*cells, reverse=(len(stacks) % 2 == 0)).to(dev))
+        n_in = max(i for _, i, _ in shapes)
+        x = torch.randn(n_in, B, T, device=dev)
+        gs = [torch.randn(m.sizes[-1], B, device=dev) for m in stacks]
+
+        def run(grouped):
+            xr = x.clone().requires_grad_(True)
+            for m in stacks:
+                m.theta.grad = None
+            if grouped:
+                buf = xr.permute(2, 1, 0).contiguous().float()
+                ys = [y.t() for y in _RecurrentLaunchGroupFn.apply(tuple(stacks), buf, *[m.flat_weights() for m in stacks])]
+            else:
+                ys = [m(xr) for m in stacks]
+            torch.autograd.backward(ys, gs)
+            torch.cuda.synchronize()
+            return [y.detach().clone() for y in ys], xr.grad.clone(), [m.theta.grad.clone() for m in stacks]
+
+        a, b = run(False), run(True)
+        for u, v in zip(a[0], b[0]):
+            assert torch.equal(u, v)
+        # the frame gradient is a sum of the stacks' contributions: the grouped node adds them in stack order, autograd in its own
+        assert torch.allclose(a[1], b[1], rtol=0, atol=1e-6 * float(a[1].abs().max()))
+        for u, v in zip(a[2], b[2]):
+            assert torch.equal(u, v)
+

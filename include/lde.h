@@ -200,7 +200,9 @@ int lde_get_phase_ms(lde_handle* h, float* ms2);
  * `hook(user, vals, n)` must replace vals[0..n) (n = 1 or 2, f64) by their sums over all ranks and return 0; every rank calls it
  * the same number of times in the same order (the decisions that follow are functions of the sums, hence identical everywhere). It
  * is called on the thread that called lde_forward / lde_adjoint, while the solve's kernel waits for the answer — use a HOST
- * collective (MPI, gloo, a pipe): the device is occupied. `global_batch` = Σ over ranks of their B (the norm's divisor).
+ * collective (MPI, gloo, a pipe): the device is occupied — and nothing in the hook may synchronise the device (hipFree, a null-stream
+ * copy, a finaliser that releases device memory): it would wait for the kernel that waits for the hook. `global_batch` = Σ over ranks of
+ * their B (the norm's divisor).
  * hook == NULL clears it (the mode then equals LDE_BATCH_COUPLED on this rank's columns). */
 typedef int (*lde_sum_hook)(void* user, double* vals, int n);
 int lde_set_global_sum_hook(lde_handle* h, lde_sum_hook hook, void* user, int64_t global_batch);

@@ -455,10 +455,13 @@ def run_goku_step(args, torch, dist, world, rank, local):
                                "torch-level API over lde_chain_* / lde_rnn_* / lde_forward / lde_adjoint",
                    "batch_per_gpu": B, "global_batch": Bg, "save_points": T,
                    "parallelism": f"dp{world} (batch sharded by trajectory; one flat all-reduce of all parameter gradients per step)",
-                   "submission": "one hipGraph replay per step (train.GraphedStep)" if use_graph else "eager (≈ 80 launches per step)"},
+                   "submission": "one hipGraph replay per step (train.GraphedStep)" if use_graph else "eager (≈ 50 launches per step)"},
         "roofline": dict(bound="mfma", kernel="whole step (dense chains dominate the flops)", achieved=3 * F_dense / (ms * 1e-3) / 1e12,
                          peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=3 * F_dense / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, traffic=None,
-                         note="the step is ~78 launches; host enqueue time and device time are within a few per cent of each other (DESIGN.md §4.7)"),
+                         note=("one hipGraph replay of ≈ 50 kernels on one stream: the figure is the device's critical path (DESIGN.md §4.7)"
+                               if use_graph else "eager: ≈ 50 launches per step, host enqueue time comparable to device time (DESIGN.md §4.7)")
+                         + ("; mixed: the dense chains run on the bf16 matrix cores, the fraction is still quoted against the f32 peak"
+                            if args.dtype != "f32" else "")),
         "loss": float(loss.detach()), "cpu_baseline": None,
     }
     if world > 1:

@@ -209,9 +209,17 @@ def run_decoder(args, torch, dist, world, rank, local):
     # the training variant of the chains: the forward call keeps the hidden activations for the pullback
     saved = {k: torch.empty((int(lib.lde_chain_saved_floats(chains[k][0], N if k == "rec" else B)),), device=dev) for k in specs}
 
+    # apply_latent_out's two chains act on B columns only: one grouped call each way (lde_chain_group_*: one launch per stage)
+    arr2 = lambda a, b: (C.c_void_p * 2)(a, b)
+    lo_h = arr2(chains["lo_z0"][0].value, chains["lo_th"][0].value)
+    lo_N = (C.c_int64 * 2)(B, B)
+    lo_x, lo_y = arr2(zt.data_ptr(), tt.data_ptr()), arr2(z0.data_ptr(), th.data_ptr())
+    lo_sv = arr2(saved["lo_z0"].data_ptr(), saved["lo_th"].data_ptr())
+    lo_dy, lo_dx = arr2(dz0.data_ptr(), dth.data_ptr()), arr2(dzt.data_ptr(), dtt.data_ptr())
+    lo_dW = arr2(gW["lo_z0"].data_ptr(), gW["lo_th"].data_ptr())
+
     def fwd():
-        ck(lib.lde_chain_forward_save(chains["lo_z0"][0], p(zt), B, p(z0), p(saved["lo_z0"]), sp), chains["lo_z0"][0], "lo_z0 fwd")
-        ck(lib.lde_chain_forward_save(chains["lo_th"][0], p(tt), B, p(th), p(saved["lo_th"]), sp), chains["lo_th"][0], "lo_th fwd")
+        ck(lib.lde_chain_group_forward_save(2, lo_h, lo_x, lo_N, lo_y, lo_sv, sp), chains["lo_z0"][0], "latent_out fwd")
         L.check(lib.lde_forward(h, p(z0), p(th), tsp, T, B, p(zout), p(ret), sp), h, "lde_forward")
         ck(lib.lde_chain_forward_save(chains["rec"][0], p(zout), N, p(xhat), p(saved["rec"]), sp), chains["rec"][0], "rec fwd")
 
@@ -220,10 +228,7 @@ def run_decoder(args, torch, dist, world, rank, local):
         ck(lib.lde_chain_backward_saved(chains["rec"][0], p(zout), p(xhat), p(dxh), p(saved["rec"]), N, p(dz), p(gW["rec"]), sp),
            chains["rec"][0], "rec bwd")
         L.check(lib.lde_adjoint(h, p(zout), p(th), tsp, T, B, p(dz), p(dz0), p(dth), C.c_void_p(), sp), h, "lde_adjoint")
-        ck(lib.lde_chain_backward_saved(chains["lo_z0"][0], p(zt), p(z0), p(dz0), p(saved["lo_z0"]), B, p(dzt), p(gW["lo_z0"]), sp),
-           chains["lo_z0"][0], "lo_z0 bwd")
-        ck(lib.lde_chain_backward_saved(chains["lo_th"][0], p(tt), p(th), p(dth), p(saved["lo_th"]), B, p(dtt), p(gW["lo_th"]), sp),
-           chains["lo_th"][0], "lo_th bwd")
+        ck(lib.lde_chain_group_backward_saved(2, lo_h, lo_x, lo_y, lo_dy, lo_sv, lo_N, lo_dx, lo_dW, sp), chains["lo_z0"][0], "latent_out bwd")
         if world > 1:
             dist.all_reduce(flat)     # the one collective: shared decoder parameters
 
@@ -264,10 +269,12 @@ def run_decoder(args, torch, dist, world, rank, local):
         "reconstructor_backward_recompute": ev_ms(lambda: ck(lib.lde_chain_backward(chains["rec"][0], p(zout), p(xhat), p(dxh), N, p(dz), p(gW["rec"]), sp), chains["rec"][0], "b"), n),
         "lde_forward": ev_ms(lambda: L.check(lib.lde_forward(h, p(z0), p(th), tsp, T, B, p(zout), p(ret), sp), h, "f"), n),
         "lde_adjoint": ev_ms(lambda: L.check(lib.lde_adjoint(h, p(zout), p(th), tsp, T, B, p(dz), p(dz0), p(dth), C.c_void_p(), sp), h, "a"), n),
-        "latent_out_forward_x2": ev_ms(lambda: (lib.lde_chain_forward_save(chains["lo_z0"][0], p(zt), B, p(z0), p(saved["lo_z0"]), sp),
-                                                lib.lde_chain_forward_save(chains["lo_th"][0], p(tt), B, p(th), p(saved["lo_th"]), sp)), n),
-        "latent_out_backward_x2": ev_ms(lambda: (lib.lde_chain_backward_saved(chains["lo_z0"][0], p(zt), p(z0), p(dz0), p(saved["lo_z0"]), B, p(dzt), p(gW["lo_z0"]), sp),
-                                                 lib.lde_chain_backward_saved(chains["lo_th"][0], p(tt), p(th), p(dth), p(saved["lo_th"]), B, p(dtt), p(gW["lo_th"]), sp)), n),
+        "latent_out_forward_x2": ev_ms(lambda: lib.lde_chain_group_forward_save(2, lo_h, lo_x, lo_N, lo_y, lo_sv, sp), n),
+        "latent_out_backward_x2": ev_ms(lambda: lib.lde_chain_group_backward_saved(2, lo_h, lo_x, lo_y, lo_dy, lo_sv, lo_N, lo_dx, lo_dW, sp), n),
+        "latent_out_forward_separate_calls": ev_ms(lambda: (lib.lde_chain_forward_save(chains["lo_z0"][0], p(zt), B, p(z0), p(saved["lo_z0"]), sp),
+                                                            lib.lde_chain_forward_save(chains["lo_th"][0], p(tt), B, p(th), p(saved["lo_th"]), sp)), n),
+        "latent_out_backward_separate_calls": ev_ms(lambda: (lib.lde_chain_backward_saved(chains["lo_z0"][0], p(zt), p(z0), p(dz0), p(saved["lo_z0"]), B, p(dzt), p(gW["lo_z0"]), sp),
+                                                             lib.lde_chain_backward_saved(chains["lo_th"][0], p(tt), p(th), p(dth), p(saved["lo_th"]), B, p(dtt), p(gW["lo_th"]), sp)), n),
     }
     mac = lambda sizes: sum(a * b for a, b in zip(sizes[:-1], sizes[1:]))
     F_rec = 2 * mac(specs["rec"][0]) * N

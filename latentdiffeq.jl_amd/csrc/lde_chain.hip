@@ -1574,12 +1574,18 @@ static bool group_ok(int n) {
   return on && n >= 2 && n <= GROUP_MAX && dw_stream_get() == nullptr;
 #endif
 }
+static bool group_distinct(int n, lde_chain* const* cs) {   // a handle's workspace serves one call at a time: the same chain twice runs one after the other
+  for (int i = 0; i < n; i++)
+    for (int j = i + 1; j < n; j++)
+      if (cs[i] == cs[j]) return false;
+  return true;
+}
 int lde_chain_group_forward_save(int n, lde_chain* const* cs, const float* const* xs, const int64_t* Ns, float* const* ys, float* const* saveds,
                                  void* stream) {
   if (n < 1 || !cs || !xs || !Ns || !ys) return LDE_ERR_INVALID_ARG;
   for (int i = 0; i < n; i++)
     if (!cs[i]) return LDE_ERR_INVALID_ARG;
-  if (!group_ok(n)) {
+  if (!group_ok(n) || !group_distinct(n, cs)) {
     for (int i = 0; i < n; i++) {
       const int rc = chain_forward_impl(cs[i], xs[i], Ns[i], ys[i], saveds ? saveds[i] : nullptr, stream);
       if (rc) return rc;
@@ -1607,6 +1613,7 @@ int lde_chain_group_backward_saved(int n, lde_chain* const* cs, const float* con
     if (!cs[i]) return LDE_ERR_INVALID_ARG;
     if (cs[i]->bf16 && !(saveds && saveds[i])) grp = false;   // (a bf16 pullback without saved activations starts with a forward launch of its own)
   }
+  grp = grp && group_distinct(n, cs);
   if (!grp) {
     for (int i = 0; i < n; i++) {
       const int rc = chain_backward_impl(cs[i], xs[i], ys[i], dys[i], saveds ? saveds[i] : nullptr, Ns[i], dxs ? dxs[i] : nullptr, dWs[i], stream);

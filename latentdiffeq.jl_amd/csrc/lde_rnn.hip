@@ -954,16 +954,20 @@ static bool rnn_group_ok(int n) {
   return on && n >= 2 && n <= RNN_GROUP_MAX && dw_stream_get() == nullptr;
 #endif
 }
-static bool rnn_group_fits(int n, lde_rnn* const* rs) {   // every (stack, cell) weight-gradient job must fit one table
+static bool rnn_group_fits(int n, lde_rnn* const* rs) {   // every (stack, cell) weight-gradient job must fit one table; a handle's workspace serves one call at a time
   int jobs = 0;
-  for (int i = 0; i < n; i++) jobs += rs[i]->rd.nL;
+  for (int i = 0; i < n; i++) {
+    jobs += rs[i]->rd.nL;
+    for (int j = i + 1; j < n; j++)
+      if (rs[i] == rs[j]) return false;
+  }
   return jobs <= GROUP_MAX_DW;
 }
 int lde_rnn_group_forward(int n, lde_rnn* const* rs, const float* const* xs, int T, int B, float* const* ys, void* stream) {
   if (n < 1 || !rs || !xs || !ys) return LDE_ERR_INVALID_ARG;
   for (int i = 0; i < n; i++)
     if (!rs[i]) return LDE_ERR_INVALID_ARG;
-  if (!rnn_group_ok(n)) {
+  if (!rnn_group_ok(n) || !rnn_group_fits(n, rs)) {
     for (int i = 0; i < n; i++) {
       const int rc = lde_rnn_forward(rs[i], xs[i], T, B, ys[i], stream);
       if (rc) return rc;

@@ -363,6 +363,19 @@ def test_grouped_chains_equal_separate_calls(dtype):
         for what, u, v in zip(("y", "dx", "dW"), a, b):
             for i, (p, q) in enumerate(zip(u, v)):
                 assert torch.equal(p, q), (dtype, name, what, i, float((p - q).abs().max()))
+    # the SAME chain twice in a group (one module applied to two inputs): its workspace serves one call at a time — run one after the other
+    c = mk(Dense(16, 200, "relu"), Dense(200, 2))
+    xa, xb = torch.randn(16, 256, device=dev), torch.randn(16, 256, device=dev)
+    ga, gb = torch.randn(2, 256, device=dev), torch.randn(2, 256, device=dev)
+    ref = []
+    for grouped in (False, True):
+        c.theta.grad = None
+        xr = [xa.clone().requires_grad_(True), xb.clone().requires_grad_(True)]
+        ys = apply_chains_grouped([(c, xr[0]), (c, xr[1])]) if grouped else [c(xr[0]), c(xr[1])]
+        torch.autograd.backward(ys, [ga, gb])
+        ref.append(([y.detach().clone() for y in ys], [x.grad.clone() for x in xr], c.theta.grad.clone()))
+    assert all(torch.equal(u, v) for u, v in zip(ref[0][0] + ref[0][1], ref[1][0] + ref[1][1]))
+    assert torch.allclose(ref[0][2], ref[1][2], rtol=0, atol=1e-6 * float(ref[0][2].abs().max()))     # (Σ of two gradients: the order of the two adds)
     # frozen inputs (no dx asked for) and evaluation without gradients go through the same entry points
     c1, c2 = mk(Dense(16, 16)), mk(Dense(16, 200, "relu"), Dense(200, 2))
     x = torch.randn(16, 64, device=dev)

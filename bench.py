@@ -622,8 +622,12 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     args.rccl_ranks = 1
-    if world > 1:
+    if world > 1 or os.environ.get("LDE_BENCH_FORCE_PG") == "1":   # (the switch: a one-rank RCCL group on a one-GPU box — the capture below beside torch's collective watchdog)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
+        if world == 1:
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group("nccl", device_id=dev)
         one = torch.ones(1, device=dev)
         dist.all_reduce(one)                    # RCCL is up and spans every rank
@@ -730,7 +734,8 @@ def main():
                     graphs = []
                     for n, reps in plan:
                         g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g, stream=gs):
+                        # thread_local: torch's collective watchdog (N > 1) may query its events from another thread while this one captures
+                        with torch.cuda.graph(g, stream=gs, capture_error_mode="thread_local"):
                             for _ in range(n):
                                 fwd(gsp)
                                 bwd(gsp)
@@ -885,7 +890,7 @@ def main():
     lib.lde_destroy(h)
     if comm is not None:
         comm.close()
-    if world > 1:
+    if world > 1 or (dist.is_available() and dist.is_initialized()):
         dist.barrier()
         dist.destroy_process_group()
     # the CPU baseline is taken AFTER the timed region and after the process group is gone (the other ranks have exited or are

@@ -334,11 +334,16 @@ int  lde_rnn_backward(lde_rnn* r, const float* x, const float* dy, int T, int B,
  * stack's _dx (each on its stream) before the first _dw and the long sweeps start together. lde_rnn_backward = _dx then _dw. */
 int  lde_rnn_backward_dx(lde_rnn* r, const float* x, const float* dy, int T, int B, float* dx, void* stream);
 int  lde_rnn_backward_dw(lde_rnn* r, float* dW, void* stream);
+/* Training variant of lde_rnn_forward: the sweep also leaves its per-step records and the weight gradient's input panels in the handle's
+ * workspace; the next lde_rnn_backward[_dx] with the SAME (x, T, B) back-propagates from them instead of repeating the sweep. Same
+ * results as the plain pair. Anything that changes the weights in between drops the records (the pullback then sweeps again). */
+int  lde_rnn_forward_train(lde_rnn* r, const float* x, int T, int B, float* y, void* stream);
 /* Several stacks on the same frames in one call (the GOKU encoder's three pattern extractors [REF src/models/GOKU.jl:32-51]): with
  * n ≤ 3 stacks of the default shape every stage — the sweep, the weight-gradient products of all (stack, cell) pairs, their fixed-order
  * sums, the initial-state sums — is ONE launch; anything else runs the stacks one after the other. Per stack the same kernels on the
  * same arguments as lde_rnn_forward / lde_rnn_backward: results equal bit for bit. dxs may be NULL or hold NULL entries. */
 int  lde_rnn_group_forward(int n, lde_rnn* const* stacks, const float* const* xs, int T, int B, float* const* ys, void* stream);
+int  lde_rnn_group_forward_train(int n, lde_rnn* const* stacks, const float* const* xs, int T, int B, float* const* ys, void* stream);
 int  lde_rnn_group_backward(int n, lde_rnn* const* stacks, const float* const* xs, const float* const* dys, int T, int B,
                             float* const* dxs, float* const* dWs, void* stream);
 int  lde_rnn_set_accumulate(lde_rnn* r, int on);   /* as lde_chain_set_accumulate */

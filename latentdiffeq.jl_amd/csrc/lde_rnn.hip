@@ -134,7 +134,11 @@ __device__ __forceinline__ void rnn_body(const RnnDims& rd, const RnnArgs& a, co
   float* cst = hst + L * hmaxv;
   float* dhs = lw + rd.lds_w + tpw * (rd.vmax + rd.rmax + 2 * L * hmaxv) + tr * (2 * L * hmaxv);   // dh, dc
   float* dcs = dhs + L * hmaxv;
-  rnn_load_weights(rd, a.Wflat, lw, nthr, mode == 1);
+  // mode 0: forward sweep → y. 1: sweep with records and staged a-panels, then back-propagation through time. 2 (training forward): the
+  // sweep of mode 1, then y — the records and panels stay in the handle's workspace. 3: the back-propagation of mode 1 from what a mode-2
+  // call left there (the pullback then does not repeat the sweep: 121 → ≈ 75 µs for the LSTM stack at B = 256, T = 50).
+  const bool keep = mode == 1 || mode == 2, bptt = mode == 1 || mode == 3;
+  rnn_load_weights(rd, a.Wflat, lw, nthr, bptt);
   // REGW: the lane's weight rows, as float4 groups (zero padded like the LDS rows)
   constexpr int GC = SP ? (CELL_ == LDE_CELL_LSTM ? 4 : 1) : 1;
   constexpr int HPC = SP ? rnn_pow2(GC * (H_ > 0 ? H_ : 1)) : 1;                 // lanes per trajectory
@@ -142,7 +146,8 @@ __device__ __forceinline__ void rnn_body(const RnnDims& rd, const RnnArgs& a, co
   constexpr int RB4 = REGW ? (GC * H_ + 3) / 4 : 1;                               // float4 groups of a transposed row (R = G·h)
   constexpr int NKI = REGW ? (IN0_ + H_ + HPC - 1) / HPC : 1;                      // outputs of Wᵀδ per lane
   f32x4 wrow[REGW ? L_ : 1][KF4];
-  f32x4 wcol[(REGW && MODE_ == 1) ? L_ : 1][(REGW && MODE_ == 1) ? NKI : 1][(REGW && MODE_ == 1) ? RB4 : 1];
+  constexpr bool BP = MODE_ == 1 || MODE_ == 3;
+  f32x4 wcol[(REGW && BP) ? L_ : 1][(REGW && BP) ? NKI : 1][(REGW && BP) ? RB4 : 1];
   if (REGW) {
 #pragma unroll
     for (int l = 0; l < (REGW ? L_ : 0); l++) {
@@ -151,10 +156,10 @@ __device__ __forceinline__ void rnn_body(const RnnDims& rd, const RnnArgs& a, co
 #pragma unroll
       for (int k4 = 0; k4 < KF4; k4++)
         wrow[l][k4] = (u < Rl && 4 * k4 < K) ? *reinterpret_cast<const f32x4*>(wr + 4 * k4) : f32x4{0.f, 0.f, 0.f, 0.f};
-      if (MODE_ == 1) {
+      if (BP) {
         const int ldr = rnn_ldk(Rl);
 #pragma unroll
-        for (int q = 0; q < ((REGW && MODE_ == 1) ? NKI : 0); q++) {
+        for (int q = 0; q < ((REGW && BP) ? NKI : 0); q++) {
           const int k = u + q * HPC;
           const float* wk = lw + rd.wt_off[l] + (k < K ? k : 0) * ldr;
 #pragma unroll
@@ -169,8 +174,10 @@ __device__ __forceinline__ void rnn_body(const RnnDims& rd, const RnnArgs& a, co
   const size_t tile = (size_t)(b >> 4);   // staging tile (16 trajectories = one column slot of the weight-gradient kernel)
   const int row = (int)(b & 15);
   const int in0 = size_of(0);
+  const size_t bc = (size_t)(valid ? b : B - 1);   // (a trajectory past B computes on a copy of trajectory B−1 and stores nothing)
 
   // ---- forward sweep (state0 → … → last frame) ------------------------------------------------------------------------
+  if (mode != 3) {
 #pragma unroll UL
   for (int l = 0; l < L; l++) {
     const int h = size_of(l + 1);
@@ -185,7 +192,6 @@ __device__ __forceinline__ void rnn_body(const RnnDims& rd, const RnnArgs& a, co
   // (branch-free: always-in-bounds addresses and no masking — a trajectory past B computes on a copy of trajectory B−1 and
   // stores nothing. A load under a branch, or a select right behind it, would turn the wait for it into a vmcnt(0) at the
   // point of issue, i.e. no prefetch at all.)
-  const size_t bc = (size_t)(valid ? b : B - 1);
   auto fetch_x = [&](int s) {
     const int t = rd.reverse ? T - 1 - s : s;
 #pragma unroll
@@ -216,7 +222,7 @@ __device__ __forceinline__ void rnn_body(const RnnDims& rd, const RnnArgs& a, co
       for (int k = K + u; k < ((K + 3) & ~3); k += Hp) vbuf[k] = 0.f;
       PROF_T(p1);
       PROF_ADD(0, p0, p1);
-      if (mode == 1) {   // the layer's input vector is the a-panel of the weight gradient: staged here, while it is in LDS
+      if (keep) {   // the layer's input vector is the a-panel of the weight gradient: staged here, while it is in LDS
         float* ga = a.stage[l] + (tile * T + s) * a.blk[l] + row * pad32(K);
         for (int k = u; k < pad32(K); k += Hp) ga[k] = (valid && k < K) ? vbuf[k] : 0.f;
       }
@@ -264,7 +270,7 @@ __device__ __forceinline__ void rnn_body(const RnnDims& rd, const RnnArgs& a, co
           hn = cellk == LDE_CELL_RNN_TANH ? fast_tanh(z[0]) : fmaxf(z[0], 0.f);
           z[0] = hn;
         }
-        if (mode == 1 && valid) {
+        if (keep && valid) {
           float* r = a.rec + (((size_t)s * L + l) * B + (size_t)b) * rd.recw;
 #pragma unroll
           for (int g = 0; g < 4; g++)
@@ -279,11 +285,12 @@ __device__ __forceinline__ void rnn_body(const RnnDims& rd, const RnnArgs& a, co
       PROF_ADD(3, p3, p4);
     }
   }
-  if (mode == 0) {
+  if (mode == 0 || mode == 2) {
     const int hL = size_of(L);
     if (valid && u < hL) a.y[(size_t)hL * b + u] = hst[(L - 1) * hmaxv + u];
     return;
   }
+  }   // (mode 3 starts here)
   __syncthreads();   // the records are read back below by other lanes of the trajectory: stores drained (vmcnt(0)) first
 
   // ---- back-propagation through time -----------------------------------------------------------------------------------
@@ -356,15 +363,15 @@ __device__ __forceinline__ void rnn_body(const RnnDims& rd, const RnnArgs& a, co
       const bool wt = SP || rd.wt;
       if (REGW) {
 #pragma unroll
-        for (int q = 0; q < ((REGW && MODE_ == 1) ? NKI : 0); q++) {
+        for (int q = 0; q < ((REGW && BP) ? NKI : 0); q++) {
           const int k = u + q * HPC;
           if (k < K) {
             f32x2 c01 = {0.f, 0.f}, c23 = {0.f, 0.f};
 #pragma unroll
             for (int r4 = 0; r4 < RB4; r4++) {
               const f32x4 dq = *reinterpret_cast<const f32x4*>(dbuf + 4 * r4);
-              c01 += wcol[(REGW && MODE_ == 1) ? l : 0][q][r4].lo * dq.lo;
-              c23 += wcol[(REGW && MODE_ == 1) ? l : 0][q][r4].hi * dq.hi;
+              c01 += wcol[(REGW && BP) ? l : 0][q][r4].lo * dq.lo;
+              c23 += wcol[(REGW && BP) ? l : 0][q][r4].hi * dq.hi;
             }
             const float acc = (c01.x + c01.y) + (c23.x + c23.y);
             if (k < in) {
@@ -488,6 +495,7 @@ struct lde_rnn {
   int g0w = 0;
   DwSync dws;              // weight-gradient kernels on the dw stream (lde_set_dw_stream)
   int staged_T = 0, staged_B = 0;   // set by lde_rnn_backward_dx: the panels lde_rnn_backward_dw consumes
+  int kept_T = 0, kept_B = 0; const float* kept_x = nullptr;   // set by lde_rnn_forward_train: the records and a-panels its sweep left for the pullback
   // workspace
   float* rec = nullptr; size_t rec_cap = 0;
   float* stage[RNN_ML] = {nullptr, nullptr, nullptr, nullptr}; size_t stage_cap[RNN_ML] = {0, 0, 0, 0};
@@ -496,7 +504,7 @@ struct lde_rnn {
   float* slab = nullptr; size_t slab_cap = 0; size_t slab_layer = 0;
   int32_t* ints = nullptr; size_t ints_cap = 0;
   bool accumulate = true;   // pullback: dW += gradient (default) or dW = gradient
-  void (*kernel[2][2])(lde::RnnDims, lde::RnnArgs) = {{nullptr, nullptr}, {nullptr, nullptr}};   // the k_rnn instantiations for this stack: [forward, pullback][any workgroup size, one wave per workgroup]
+  void (*kernel[4][2])(lde::RnnDims, lde::RnnArgs) = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // the k_rnn instantiations for this stack: [forward, pullback][any workgroup size, one wave per workgroup]
   std::string err;
 };
 
@@ -514,7 +522,19 @@ bool rnn_refresh_target(lde_rnn* r, float** W_dev, int64_t* nW) {
   *W_dev = r->W_dev;
   *nW = r->nW;
   r->have_W = true;
+  r->kept_T = r->kept_B = 0;
   return true;
+}
+
+typedef void (*rnn_kernel_t)(RnnDims, RnnArgs);
+template <int CELL_, bool ONE>
+static rnn_kernel_t rnn_pick_mode(int mode) {
+  switch (mode) {
+    case 0: return k_rnn<CELL_, 32, 16, 2, 0, ONE>;
+    case 1: return k_rnn<CELL_, 32, 16, 2, 1, ONE>;
+    case 2: return k_rnn<CELL_, 32, 16, 2, 2, ONE>;
+    default: return k_rnn<CELL_, 32, 16, 2, 3, ONE>;
+  }
 }
 
 extern "C" {
@@ -633,6 +653,7 @@ int lde_rnn_set_weights(lde_rnn* r, const float* flat_host, int64_t n) {
     return LDE_ERR_HIP;
   }
   r->have_W = true;
+  r->kept_T = r->kept_B = 0;
   return LDE_OK;
 }
 
@@ -647,6 +668,7 @@ int lde_rnn_set_weights_device(lde_rnn* r, const float* flat_dev, int64_t n, voi
     return LDE_ERR_HIP;
   }
   r->have_W = true;
+  r->kept_T = r->kept_B = 0;   // records of a sweep with the previous weights are not this network's
   return LDE_OK;
 }
 
@@ -674,21 +696,21 @@ int lde_rnn_reserve(lde_rnn* r, int B, int T) {
   return LDE_OK;
 }
 
-typedef void (*rnn_kernel_t)(RnnDims, RnnArgs);
 
 // the instantiation for this stack: the reference's default pattern extractors (32 → 16 → 16) have their own, any other shape
 // runs the run-time-shaped kernel
 static rnn_kernel_t rnn_pick(const RnnDims& rd, int mode, bool one_wave = false) {
   static const bool generic_only = std::getenv("LDE_RNN_GENERIC") && std::atoi(std::getenv("LDE_RNN_GENERIC")) != 0;
-  if (!generic_only && one_wave && rd.wt && rd.nL == 2 && rd.sizes[0] == 32 && rd.sizes[1] == 16 && rd.sizes[2] == 16) {
-    if (rd.cell == LDE_CELL_LSTM) return mode ? k_rnn<LDE_CELL_LSTM, 32, 16, 2, 1, true> : k_rnn<LDE_CELL_LSTM, 32, 16, 2, 0, true>;
-    if (rd.cell == LDE_CELL_RNN_RELU) return mode ? k_rnn<LDE_CELL_RNN_RELU, 32, 16, 2, 1, true> : k_rnn<LDE_CELL_RNN_RELU, 32, 16, 2, 0, true>;
-    if (rd.cell == LDE_CELL_RNN_TANH) return mode ? k_rnn<LDE_CELL_RNN_TANH, 32, 16, 2, 1, true> : k_rnn<LDE_CELL_RNN_TANH, 32, 16, 2, 0, true>;
-  }
   if (!generic_only && rd.wt && rd.nL == 2 && rd.sizes[0] == 32 && rd.sizes[1] == 16 && rd.sizes[2] == 16) {
-    if (rd.cell == LDE_CELL_LSTM) return mode ? k_rnn<LDE_CELL_LSTM, 32, 16, 2, 1> : k_rnn<LDE_CELL_LSTM, 32, 16, 2, 0>;
-    if (rd.cell == LDE_CELL_RNN_RELU) return mode ? k_rnn<LDE_CELL_RNN_RELU, 32, 16, 2, 1> : k_rnn<LDE_CELL_RNN_RELU, 32, 16, 2, 0>;
-    if (rd.cell == LDE_CELL_RNN_TANH) return mode ? k_rnn<LDE_CELL_RNN_TANH, 32, 16, 2, 1> : k_rnn<LDE_CELL_RNN_TANH, 32, 16, 2, 0>;
+    if (one_wave) {
+      if (rd.cell == LDE_CELL_LSTM) return rnn_pick_mode<LDE_CELL_LSTM, true>(mode);
+      if (rd.cell == LDE_CELL_RNN_RELU) return rnn_pick_mode<LDE_CELL_RNN_RELU, true>(mode);
+      if (rd.cell == LDE_CELL_RNN_TANH) return rnn_pick_mode<LDE_CELL_RNN_TANH, true>(mode);
+    } else {
+      if (rd.cell == LDE_CELL_LSTM) return rnn_pick_mode<LDE_CELL_LSTM, false>(mode);
+      if (rd.cell == LDE_CELL_RNN_RELU) return rnn_pick_mode<LDE_CELL_RNN_RELU, false>(mode);
+      if (rd.cell == LDE_CELL_RNN_TANH) return rnn_pick_mode<LDE_CELL_RNN_TANH, false>(mode);
+    }
   }
   return k_rnn<-1, 0, 0, 0, 0>;
 }
@@ -711,7 +733,7 @@ static thread_local RnnGroupRec* t_rrec = nullptr;
 static_assert(sizeof(GroupTable<RnnDims, RnnArgs, RNN_GROUP_MAX>) <= 4096, "a group's argument table must fit the kernel-argument segment");
 
 static int rnn_launch(lde_rnn* r, const RnnArgs& a, int B, hipStream_t stream) {
-  const int m = a.mode ? 1 : 0;
+  const int m = a.mode & 3;
   // Trajectories per workgroup. The sweep is sequential in time and every trajectory re-reads the cell's weights from LDS
   // at every step, so a small batch is spread over as many CUs as it has waves (one wave per workgroup: the LDS of a CU then
   // serves one wave instead of sixteen); only a batch that would exceed ~4 workgroups per CU packs more trajectories
@@ -785,6 +807,45 @@ int lde_rnn_forward(lde_rnn* r, const float* x, int T, int B, float* y, void* st
   return rnn_launch(r, a, B, (hipStream_t)stream_);
 }
 
+// Training variant of the forward call: the sweep also leaves its per-step records and the weight gradient's a-panels in the handle's
+// workspace, and the next lde_rnn_backward[_dx] on the SAME (x, T, B) runs the back-propagation alone instead of repeating the sweep
+// (what lde_chain_forward_save is to the chains; here the handle keeps the buffers — they are its staging area already).
+int lde_rnn_forward_train(lde_rnn* r, const float* x, int T, int B, float* y, void* stream_) {
+  if (!r || !r->W_dev) return LDE_ERR_INVALID_ARG;
+  if (!x || !y || T < 1 || B < 1) {
+    r->err = "lde_rnn_forward_train: NULL pointer or empty batch";
+    return LDE_ERR_INVALID_ARG;
+  }
+  if (!r->have_W) {
+    r->err = "lde_rnn_forward_train: weights not set";
+    return LDE_ERR_NO_WEIGHTS;
+  }
+  static const bool keep_on = [] { const char* e = std::getenv("LDE_RNN_KEEP"); return !e || std::atoi(e) != 0; }();
+  r->kept_T = r->kept_B = 0;
+  r->kept_x = nullptr;
+  if (!keep_on) return lde_rnn_forward(r, x, T, B, y, stream_);
+  r->staged_T = r->staged_B = 0;
+  int rc = lde_rnn_reserve(r, B, T);
+  if (rc) return rc;
+  hipStream_t stream = (hipStream_t)stream_;
+  if (!dw_sync_begin(r->dws, stream)) {   // the workspace is about to be rewritten
+    r->err = "lde_rnn_forward_train: waiting for the previous weight gradient failed";
+    return LDE_ERR_HIP;
+  }
+  const RnnDims& rd = r->rd;
+  RnnArgs a;
+  std::memset(&a, 0, sizeof(a));
+  a.x = x; a.Wflat = r->W_dev; a.y = y; a.rec = r->rec; a.wts = r->wts; a.g0 = r->g0; a.g0w = r->g0w;
+  a.T = T; a.B = B; a.mode = 2;
+  for (int l = 0; l < rd.nL; l++) { a.stage[l] = r->stage[l]; a.blk[l] = r->dmw[l].blk_floats; }
+  rc = rnn_launch(r, a, B, stream);
+  if (rc) return rc;
+  r->kept_T = T;
+  r->kept_B = B;
+  r->kept_x = x;
+  return LDE_OK;
+}
+
 // The pullback in two halves (include/lde.h): the sweep that produces dx and stages the panels, and the weight-gradient tail.
 int lde_rnn_backward_dx(lde_rnn* r, const float* x, const float* dy, int T, int B, float* dx, void* stream_) {
   if (!r || !r->W_dev) return LDE_ERR_INVALID_ARG;
@@ -797,10 +858,13 @@ int lde_rnn_backward_dx(lde_rnn* r, const float* x, const float* dy, int T, int 
     return LDE_ERR_NO_WEIGHTS;
   }
   r->staged_T = r->staged_B = 0;
+  const bool kept = r->kept_T == T && r->kept_B == B && r->kept_x == x;   // lde_rnn_forward_train left the records and a-panels of this very call
+  r->kept_T = r->kept_B = 0;
+  r->kept_x = nullptr;
   int rc = lde_rnn_reserve(r, B, T);
   if (rc) return rc;
   hipStream_t stream = (hipStream_t)stream_;
-  if (!dw_sync_begin(r->dws, stream)) {   // the workspace is about to be rewritten
+  if (!kept && !dw_sync_begin(r->dws, stream)) {   // the workspace is about to be rewritten
     r->err = "lde_rnn_backward: waiting for the previous weight gradient failed";
     return LDE_ERR_HIP;
   }
@@ -808,7 +872,7 @@ int lde_rnn_backward_dx(lde_rnn* r, const float* x, const float* dy, int T, int 
   RnnArgs a;
   std::memset(&a, 0, sizeof(a));
   a.x = x; a.Wflat = r->W_dev; a.rec = r->rec; a.dy = dy; a.dx = dx; a.wts = r->wts; a.g0 = r->g0; a.g0w = r->g0w;
-  a.T = T; a.B = B; a.mode = 1;
+  a.T = T; a.B = B; a.mode = kept ? 3 : 1;
   for (int l = 0; l < rd.nL; l++) { a.stage[l] = r->stage[l]; a.blk[l] = r->dmw[l].blk_floats; }
   rc = rnn_launch(r, a, B, stream);
   if (rc) return rc;
@@ -887,9 +951,9 @@ static int rnn_group_flush(RnnGroupRec& g, hipStream_t stream) {
       t.n = n;
       size_t lds = 0;
       for (int j = 0; j < n; j++) { t.start[j + 1] = t.start[j] + (int)g.main[j].grid; t.dims[j] = g.main[j].rd; t.args[j] = g.main[j].a; lds = std::max(lds, g.main[j].lds); }
-      static bool attr[2] = {false, false};
+      static bool attr[4] = {false, false, false, false};
       const int m = g.main[0].mode;
-      const void* fn = m ? (const void*)k_rnn_group<1> : (const void*)k_rnn_group<0>;
+      const void* fn = m == 0 ? (const void*)k_rnn_group<0> : m == 1 ? (const void*)k_rnn_group<1> : m == 2 ? (const void*)k_rnn_group<2> : (const void*)k_rnn_group<3>;
       if (!attr[m]) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) return LDE_ERR_HIP;
         attr[m] = true;
@@ -985,6 +1049,30 @@ int lde_rnn_group_forward(int n, lde_rnn* const* rs, const float* const* xs, int
   t_rrec = nullptr;
   const int rc = rnn_group_flush(g, (hipStream_t)stream);
   if (rc) rs[0]->err = "lde_rnn_group_forward: launch failed";
+  return rc;
+}
+int lde_rnn_group_forward_train(int n, lde_rnn* const* rs, const float* const* xs, int T, int B, float* const* ys, void* stream) {
+  if (n < 1 || !rs || !xs || !ys) return LDE_ERR_INVALID_ARG;
+  for (int i = 0; i < n; i++)
+    if (!rs[i]) return LDE_ERR_INVALID_ARG;
+  if (!rnn_group_ok(n) || !rnn_group_fits(n, rs)) {
+    for (int i = 0; i < n; i++) {
+      const int rc = lde_rnn_forward_train(rs[i], xs[i], T, B, ys[i], stream);
+      if (rc) return rc;
+    }
+    return LDE_OK;
+  }
+  RnnGroupRec g;
+  t_rrec = &g;
+  for (int i = 0; i < n; i++) {
+    g.n = i;
+    const int rc = lde_rnn_forward_train(rs[i], xs[i], T, B, ys[i], stream);
+    if (rc) { t_rrec = nullptr; return rc; }
+  }
+  g.n = n;
+  t_rrec = nullptr;
+  const int rc = rnn_group_flush(g, (hipStream_t)stream);
+  if (rc) rs[0]->err = "lde_rnn_group_forward_train: launch failed";
   return rc;
 }
 int lde_rnn_group_backward(int n, lde_rnn* const* rs, const float* const* xs, const float* const* dys, int T, int B, float* const* dxs,

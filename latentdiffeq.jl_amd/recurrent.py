@@ -101,7 +101,9 @@ class _RecurrentFn(torch.autograd.Function):
             rec._wkey = None
         T, B, _ = x.shape
         y = torch.empty((B, rec.sizes[-1]), device=x.device, dtype=torch.float32)
-        L.check(lib.lde_rnn_forward(h, C.c_void_p(x.data_ptr()), T, B, C.c_void_p(y.data_ptr()), stream), h, "lde_rnn_forward", rnn=True)
+        # a pullback will follow (grad mode is off inside Function.forward: ctx.needs_input_grad says so): the sweep keeps its records
+        fwd = lib.lde_rnn_forward_train if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else lib.lde_rnn_forward
+        L.check(fwd(h, C.c_void_p(x.data_ptr()), T, B, C.c_void_p(y.data_ptr()), stream), h, "lde_rnn_forward", rnn=True)
         ctx.rec, ctx.need_dx = rec, x.requires_grad
         ctx.save_for_backward(x)
         return y
@@ -229,7 +231,9 @@ class _RecurrentLaunchGroupFn(torch.autograd.Function):
         ys = [torch.empty((B, rec.sizes[-1]), device=dev, dtype=torch.float32) for rec in recs]
         arr = lambda ptrs: (C.c_void_p * n)(*ptrs)
         ctx.c_handles = arr([h.value for h in hs])
-        rc = lib.lde_rnn_group_forward(n, ctx.c_handles, arr([x.data_ptr()] * n), T, B, arr([y.data_ptr() for y in ys]), stream)
+        train = any(ctx.needs_input_grad[1:])          # a pullback will follow: the sweeps keep their records (lde_rnn_forward_train)
+        fwd = lib.lde_rnn_group_forward_train if train else lib.lde_rnn_group_forward
+        rc = fwd(n, ctx.c_handles, arr([x.data_ptr()] * n), T, B, arr([y.data_ptr() for y in ys]), stream)
         L.check(rc, hs[0], "lde_rnn_group_forward", rnn=True)
         ctx.recs, ctx.need_dx = recs, x.requires_grad
         ctx.save_for_backward(x)

@@ -299,3 +299,60 @@ def test_launch_grouped_stacks_equal_separate_calls():
         for u, v in zip(a[2], b[2]):
             assert torch.equal(u, v)
 
+
+@pytest.mark.parametrize("cell", ["lstm", "rnn"])
+def test_training_forward_keeps_the_records_for_the_pullback(cell):
+    """lde_rnn_forward_train + lde_rnn_backward: the pullback back-propagates from the records and input panels the forward sweep left in
+    the handle (mode 2 / mode 3 of k_rnn) instead of sweeping again — y, dx and dW equal the plain pair (lde_rnn_forward, then a
+    pullback that sweeps itself) bit for bit; default shape (register-resident weights) and a run-time shape; a pullback for OTHER frames,
+    or after a weight upload, does not use stale records."""
+    import ctypes as C
+    import torch
+    from latentdiffeq_amd import _lib as L
+    from latentdiffeq_amd.recurrent import LSTM, RNN, Recurrent
+    torch.manual_seed(9)
+    dev = "cuda"
+    for (i, h), (T, B) in (((32, 16), (50, 256)), ((20, 12), (9, 37))):
+        cells = (LSTM(i, h), LSTM(h, h)) if cell == "lstm" else (RNN(i, h, "tanh"), RNN(h, h, "tanh"))
+        m = Recurrent(*cells, reverse=True).to(dev)
+        hnd, lib = m._native(), m._lib
+        W = m.theta.detach().contiguous()
+        s = L.raw_stream(0)
+        p = lambda t: C.c_void_p(t.data_ptr())
+        assert lib.lde_rnn_set_weights_device(hnd, p(W), W.numel(), s) == 0
+        x = torch.randn(T, B, i, device=dev)
+        x2 = torch.randn(T, B, i, device=dev)
+        dy = torch.randn(B, h, device=dev)
+
+        def pull(xx, train):
+            y = torch.empty(B, h, device=dev)
+            dx, dW = torch.empty_like(xx), torch.empty(m.num_weights, device=dev)
+            fwd = lib.lde_rnn_forward_train if train else lib.lde_rnn_forward
+            assert fwd(hnd, p(xx), T, B, p(y), s) == 0
+            return y, dx, dW
+
+        def back(xx, dx, dW):
+            assert lib.lde_rnn_backward(hnd, p(xx), p(dy), T, B, p(dx), p(dW), s) == 0
+            torch.cuda.synchronize()
+            return dx.clone(), dW.clone()
+
+        y0, dx0, dW0 = pull(x, False)
+        dx0, dW0 = back(x, dx0, dW0)                     # the plain pair
+        y1, dx1, dW1 = pull(x, True)
+        dx1, dW1 = back(x, dx1, dW1)                     # records kept
+        assert torch.equal(y0, y1) and torch.equal(dx0, dx1) and torch.equal(dW0, dW1)
+        # records of x, pullback asked for x2: swept again on x2
+        yr, dxr, dWr = pull(x2, False)
+        dxr, dWr = back(x2, dxr, dWr)
+        _ = pull(x, True)
+        dxs, dWs = back(x2, torch.empty_like(x2), torch.empty(m.num_weights, device=dev))
+        assert torch.equal(dxr, dxs) and torch.equal(dWr, dWs)
+        # a weight upload between the two drops the records
+        _ = pull(x, True)
+        W2 = (W * 1.01).contiguous()
+        assert lib.lde_rnn_set_weights_device(hnd, p(W2), W2.numel(), s) == 0
+        dxa, dWa = back(x, torch.empty_like(x), torch.empty(m.num_weights, device=dev))
+        _ = pull(x, False)
+        dxb, dWb = back(x, torch.empty_like(x), torch.empty(m.num_weights, device=dev))
+        assert torch.equal(dxa, dxb) and torch.equal(dWa, dWb)
+

@@ -1500,11 +1500,13 @@ template <int OFF>
 __device__ __forceinline__ void aff_tree_level(AffOp& op, int& cnt, int& ret, int lane) {
   const AffOp hi = aff_down<OFF>(op);
   const int c2 = lane_down<OFF>(cnt), e2 = lane_down<OFF>(ret);
-  if ((lane & (2 * OFF - 1)) == 0) {
-    op = aff_compose(op, hi);
-    cnt += c2;
-    ret = ret ? ret : e2;
-  }
+  // Unconditional on every lane: a lane that is not a multiple of 2·OFF computes something nobody reads — the lanes the next level reads
+  // (multiples of 2·OFF and their partners at +2·OFF, themselves multiples of 2·OFF) were all updated from valid partners — and the
+  // eleven per-value selects of the predicated form were a quarter of the level's instructions.
+  (void)lane;
+  op = aff_compose(op, hi);
+  cnt += c2;
+  ret = ret ? ret : e2;
 }
 
 template <int KIND, int SOLVER>

@@ -1461,15 +1461,16 @@ struct AffOp {
 };
 // apply `a` first, then `b`
 __device__ __forceinline__ AffOp aff_compose(const AffOp& a, const AffOp& b) {
+  // on register pairs: the rows of a's matrix and (n₀, n₁) are pairs, b's entries scalar multipliers — 13 instructions instead of 27
+  const f32x2 ar0 = {a.m00, a.m01}, ar1 = {a.m10, a.m11}, an = {a.n0, a.n1};
+  const f32x2 r0 = ar0 * b.m00 + ar1 * b.m01;
+  const f32x2 r1 = ar0 * b.m10 + ar1 * b.m11;
+  const f32x2 rn = an + ar0 * b.n0 + ar1 * b.n1;
   AffOp r;
-  r.m00 = b.m00 * a.m00 + b.m01 * a.m10;
-  r.m01 = b.m00 * a.m01 + b.m01 * a.m11;
-  r.m10 = b.m10 * a.m00 + b.m11 * a.m10;
-  r.m11 = b.m10 * a.m01 + b.m11 * a.m11;
+  r.m00 = r0.x; r.m01 = r0.y; r.m10 = r1.x; r.m11 = r1.y;
   r.d0 = b.m00 * a.d0 + b.m01 * a.d1 + b.d0;
   r.d1 = b.m10 * a.d0 + b.m11 * a.d1 + b.d1;
-  r.n0 = a.n0 + b.n0 * a.m00 + b.n1 * a.m10;
-  r.n1 = a.n1 + b.n0 * a.m01 + b.n1 * a.m11;
+  r.n0 = rn.x; r.n1 = rn.y;
   r.gam = a.gam + b.gam + b.n0 * a.d0 + b.n1 * a.d1;
   return r;
 }

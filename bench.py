@@ -309,7 +309,7 @@ def run_decoder(args, torch, dist, world, rank, local):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
 
 
 def decoder_cpu_baseline(specs, weights, d_native, ts, zt, tt, dxh, B, T, budget_s=12.0):
@@ -475,7 +475,7 @@ def run_goku_step(args, torch, dist, world, rank, local):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
 
 
 def _free_port():
@@ -520,6 +520,18 @@ def attach_traffic(roof, workload, B, mlp, full_batch, dom=None, rounds=("r3", "
             break
     return roof
 
+
+
+def emit(out):
+    """Rank 0's ONE JSON line — and the LAST line of stdout: RCCL writes a version banner through C stdio, which sits in libc's buffer
+    (stdout is a pipe under the driver) until the process exits, i.e. it would land BEHIND a line printed from Python. Flush libc first,
+    print, flush Python."""
+    try:
+        C.CDLL(None).fflush(None)
+    except Exception:   # noqa: BLE001
+        pass
+    sys.stdout.write(json.dumps(out) + "\n")
+    sys.stdout.flush()
 
 
 def count_gpus_sysfs():
@@ -633,6 +645,7 @@ def main():
         dist.all_reduce(one)                    # RCCL is up and spans every rank
         args.rccl_ranks = int(one.item())
         assert args.rccl_ranks == world
+        C.CDLL(None).fflush(None)   # RCCL's version banner (C stdio, every rank) leaves NOW — not at exit, behind rank 0's JSON line
 
     if args.workload == "goku_decoder":
         return run_decoder(args, torch, dist, world, rank, local)
@@ -656,6 +669,7 @@ def main():
             comm, comm_kind = LdeComm(rank, world), "lde_comm_allreduce_f32 (C ABI over RCCL)"
         except Exception as e:                                                   # noqa: BLE001
             comm_kind = f"torch.distributed all_reduce (lde_comm unavailable: {e})"
+        C.CDLL(None).fflush(None)
 
     def fence():
         if world > 1:
@@ -900,7 +914,7 @@ def main():
     elif rank == 0:
         out["cpu_baseline"] = None
     if rank == 0:
-        print(json.dumps(out))
+        emit(out)
 
 
 if __name__ == "__main__":

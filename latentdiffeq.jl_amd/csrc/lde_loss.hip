@@ -52,7 +52,8 @@ __device__ __forceinline__ float kl_term(float m, float lv) { return 0.5f * (__e
 template <int TERM>
 __global__ void __launch_bounds__(LOSS_WG) k_loss_partial(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
                                                           float* __restrict__ scratch, const float* __restrict__ c = nullptr,
-                                                          float* __restrict__ l = nullptr) {
+                                                          float* __restrict__ l = nullptr, float fscale = 0.f, float* __restrict__ fout = nullptr,
+                                                          const float* __restrict__ fbase = nullptr) {
   // workgroup w owns the slice [w·per, (w+1)·per) with per a multiple of 4 floats
   const int64_t nwg = gridDim.x;
   int64_t per = (n + nwg - 1) / nwg;
@@ -88,7 +89,15 @@ __global__ void __launch_bounds__(LOSS_WG) k_loss_partial(const float* __restric
       if (TERM == 2) l[i + q] = x + c[i + q] * __expf(0.5f * y);
     }
   const float s = wg_sum((s0 + s1) + (s2 + s3));
-  if (threadIdx.x == 0) scratch[blockIdx.x] = s;
+  if (threadIdx.x == 0) {
+    scratch[blockIdx.x] = s;
+    if (fout) {   // a one-workgroup sum (n ≤ 8192: the KL terms of a training step) is its own last kernel: what k_loss_final computes from
+                  // one partial, with the same separately rounded product and addition — one launch instead of two
+#pragma clang fp contract(off)
+      const float term = fscale * s;
+      fout[0] = fbase ? fbase[0] + term : term;
+    }
+  }
 }
 
 // out = scale·Σ partials (+ base[0]: a running total of loss terms — the elementwise additions of the loss expression folded in)
@@ -198,8 +207,11 @@ static int loss_reduce(const float* a, const float* b, int64_t n, float scale, f
   if (TERM == 2 && n > 0 && (!c || !l)) return LDE_ERR_INVALID_ARG;
   hipStream_t stream = (hipStream_t)stream_;
   const int g = n == 0 ? 0 : loss_grid(n);   // an empty sum is 0
-  if (g) hipLaunchKernelGGL(k_loss_partial<TERM>, dim3(g), dim3(LOSS_WG), 0, stream, a, b, n, scratch, c, l);
-  hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(64), 0, stream, scratch, g, scale, out, base);
+  if (g == 1) hipLaunchKernelGGL(k_loss_partial<TERM>, dim3(1), dim3(LOSS_WG), 0, stream, a, b, n, scratch, c, l, scale, out, base);
+  else {
+    if (g) hipLaunchKernelGGL(k_loss_partial<TERM>, dim3(g), dim3(LOSS_WG), 0, stream, a, b, n, scratch, c, l, 0.f, (float*)nullptr, (const float*)nullptr);
+    hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(64), 0, stream, scratch, g, scale, out, base);
+  }
   return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
 }
 

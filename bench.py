@@ -305,7 +305,7 @@ def run_decoder(args, torch, dist, world, rank, local):
     for ch, _ in chains.values():
         lib.lde_chain_destroy(ch)
     lib.lde_destroy(h)
-    if world > 1:
+    if world > 1 or (dist.is_available() and dist.is_initialized()):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
@@ -364,7 +364,7 @@ def decoder_cpu_baseline(specs, weights, d_native, ts, zt, tt, dxh, B, T, budget
 
 # ---- whole GOKU training step (BASELINE.json configs[4] shape, one GPU's share): encoder → sample → decoder → loss → pullback → AdamW
 def run_goku_step(args, torch, dist, world, rank, local):
-    if world == 1 and os.environ.get("LDE_BENCH_GRAPH", "1") != "0":
+    if os.environ.get("LDE_BENCH_GRAPH", "1") != "0":
         os.environ.setdefault("LDE_BRANCH_STREAMS", "0")   # the captured step runs on one stream (read when the package is imported)
     import latentdiffeq_amd as M
     from latentdiffeq_amd.chain import decode, default_decoder_layers
@@ -391,7 +391,8 @@ def run_goku_step(args, torch, dist, world, rank, local):
     from latentdiffeq_amd.train import FluxADAMW, GraphedStep
     # one GPU: the whole step is captured in a hipGraph and replayed (train.GraphedStep; needs the encoder's branch streams off — read when
     # the package was imported); LDE_BENCH_GRAPH=0 or a process group: eager
-    use_graph = world == 1 and os.environ.get("LDE_BENCH_GRAPH", "1") != "0" and os.environ.get("LDE_BRANCH_STREAMS") == "0"
+    use_graph = os.environ.get("LDE_BENCH_GRAPH", "1") != "0" and os.environ.get("LDE_BRANCH_STREAMS") == "0"
+    split = use_graph and (world > 1 or os.environ.get("LDE_BENCH_FORCE_PG") == "1")   # several GPUs: graph · all-reduce (eager) · graph
     opt = FluxADAMW(params, lr=1e-3, decay=1e-10, capturable=use_graph)   # ADAMW(η, β, decay), Flux flavour [REF model_train.jl:138, :150]; one fused update kernel
     sync = FlatGradAllReduce(params)
     torch.manual_seed(1000 + rank)
@@ -431,7 +432,24 @@ def run_goku_step(args, torch, dist, world, rank, local):
             dist.barrier()
         torch.cuda.synchronize()
 
-    if use_graph:
+    def step_a():        # zero_grad … backward
+        opt.zero_grad(set_to_none=True)
+        mu, logvar = encode(enc, x)
+        l_tilde, bkl = sample_with_kl(mu, logvar, 1e-3, Bg)
+        x_hat, z_hat, l_hat = decode(dec, l_tilde, ts)
+        loss = reconstruction_loss(x, x_hat, Bg, plus=bkl)
+        loss.backward()
+        return loss
+
+    def step_b():        # update + weight hand-over
+        opt.step()
+        if refresh:
+            L.refresh_weights(mods)
+
+    if split:
+        gs = GraphedStep(step_a, warmup=3, between=sync, fn2=step_b)
+        run = gs.replay
+    elif use_graph:
         gs = GraphedStep(step, warmup=3)
         run = gs.replay
     else:
@@ -462,7 +480,8 @@ def run_goku_step(args, torch, dist, world, rank, local):
                                "torch-level API over lde_chain_* / lde_rnn_* / lde_forward / lde_adjoint",
                    "batch_per_gpu": B, "global_batch": Bg, "save_points": T,
                    "parallelism": f"dp{world} (batch sharded by trajectory; one flat all-reduce of all parameter gradients per step)",
-                   "submission": "one hipGraph replay per step (train.GraphedStep)" if use_graph else "eager (≈ 50 launches per step)"},
+                   "submission": ("two hipGraph replays per step around the eager gradient all-reduce (train.GraphedStep)" if split else
+                                  "one hipGraph replay per step (train.GraphedStep)") if use_graph else "eager (≈ 50 launches per step)"},
         "roofline": dict(bound="mfma", kernel="whole step (dense chains dominate the flops)", achieved=3 * F_dense / (ms * 1e-3) / 1e12,
                          peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=3 * F_dense / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, traffic=None,
                          note=("one hipGraph replay of ≈ 50 kernels on one stream: the figure is the device's critical path (DESIGN.md §4.7)"
@@ -471,7 +490,7 @@ def run_goku_step(args, torch, dist, world, rank, local):
                             if args.dtype != "f32" else "")),
         "loss": float(loss.detach()), "cpu_baseline": None,
     }
-    if world > 1:
+    if world > 1 or (dist.is_available() and dist.is_initialized()):
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:

@@ -86,7 +86,8 @@ class FlatGradAllReduce:
 
     # ---- layout -------------------------------------------------------------------------------------------------------
     def _active(self) -> bool:
-        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1
+        # (LDE_FORCE_ALLREDUCE=1: also with ONE rank — a one-GPU box then exercises the pack / all-reduce / unpack path over RCCL)
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or os.environ.get("LDE_FORCE_ALLREDUCE") == "1")
 
     def _build(self, device) -> None:
         n = sum(p.numel() for p in self.params)

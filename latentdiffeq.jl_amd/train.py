@@ -252,27 +252,52 @@ class GraphedStep:
     copied INTO the captured tensors (`static_inputs`: tensors `fn` reads; `replay(*new)` copies into them), and a single stream — call
     with the encoder's branch streams off (`LDE_BRANCH_STREAMS=0`: cross-stream capture of the recurrent stacks' side streams aborts
     inside the HIP runtime on ROCm 7.2). ε of `sample` comes from torch's generator, which is graph-safe (its offsets advance per replay).
-    One GPU: with a process group the all-reduce stays outside a graph here."""
+    Several GPUs: the collective stays OUTSIDE the graphs — pass the step in two halves: `fn` = zero_grad, forward, loss, backward;
+    `between` = the gradient all-reduce (dist.FlatGradAllReduce: eager, on the gradients' fixed addresses); `fn2` = the optimiser step and
+    the weight hand-over, a second graph. A replay is then graph · all-reduce · graph (capture in `thread_local` error mode: torch's
+    collective watchdog thread may query its events meanwhile)."""
 
-    def __init__(self, fn: Callable[[], torch.Tensor], static_inputs: Sequence[torch.Tensor] = (), warmup: int = 3):
-        self.fn, self.static_inputs = fn, list(static_inputs)
+    def __init__(self, fn: Callable[[], torch.Tensor], static_inputs: Sequence[torch.Tensor] = (), warmup: int = 3,
+                 between: Optional[Callable[[], None]] = None, fn2: Optional[Callable[[], None]] = None):
+        self.fn, self.static_inputs, self.between, self.fn2 = fn, list(static_inputs), between, fn2
+
+        def whole():
+            out = fn()
+            if between is not None:
+                between()
+            if fn2 is not None:
+                fn2()
+            return out
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             for _ in range(warmup):
-                fn()
+                whole()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
+        mode = dict(capture_error_mode="thread_local") if (between is not None or fn2 is not None) else {}
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
+        with torch.cuda.graph(self.graph, **mode):
             out = fn()
             self.loss = out.detach().clone() if isinstance(out, torch.Tensor) else None
         torch.cuda.synchronize()
+        self.graph2 = None
+        if fn2 is not None:
+            if between is not None:
+                between()                      # the gradients the second half is captured on are the reduced ones (shapes only matter)
+            self.graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph2, **mode):
+                fn2()
+            torch.cuda.synchronize()
 
     def replay(self, *new_inputs) -> Optional[torch.Tensor]:
         for dst, src in zip(self.static_inputs, new_inputs):
             dst.copy_(src)
         self.graph.replay()
+        if self.between is not None:
+            self.between()
+        if self.graph2 is not None:
+            self.graph2.replay()
         return self.loss
 
 

@@ -23,6 +23,12 @@ from latentdiffeq_amd.loss import reconstruction_loss, sample_with_kl
 from latentdiffeq_amd.recurrent import Encoder, default_encoder_layers, encode
 from latentdiffeq_amd.train import FluxADAMW, GraphedStep
 dtype = sys.argv[1]
+split = len(sys.argv) > 2 and sys.argv[2] == "split"
+if split:   # several GPUs in miniature: a ONE-rank RCCL group, the gradient all-reduce forced on (LDE_FORCE_ALLREDUCE=1)
+    import torch.distributed as dist
+    from latentdiffeq_amd.dist import FlatGradAllReduce
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", RANK="0", WORLD_SIZE="1")
+    dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
 B, T, NI = 64, 20, 784
 dev = torch.device("cuda", 0)
 def build():
@@ -43,16 +49,24 @@ xs = [torch.rand(T, B, NI, device=dev).permute(2, 1, 0) for _ in range(3)]      
 eps = (torch.randn(16, B, device=dev), torch.randn(16, B, device=dev))            # ε of the two latent parts, drawn once
 ts = np.arange(T) * 0.05
 def make(enc, dec, mods, params, opt, x):
-    def step():
+    sync = FlatGradAllReduce(params) if split else (lambda: None)
+    def a():
         opt.zero_grad(set_to_none=True)
         mu, logvar = encode(enc, x)
         l_tilde, bkl = sample_with_kl(mu, logvar, 1e-3, B, eps=eps)
         x_hat, _, _ = decode(dec, l_tilde, ts)
         loss = reconstruction_loss(x, x_hat, B, plus=bkl)
         loss.backward()
+        return loss
+    def b():
         opt.step()
         L.refresh_weights(mods)
+    def step():
+        loss = a()
+        sync()
+        b()
         return loss
+    step.a, step.b, step.sync = a, b, sync
     return step
 K, W = 7, 3
 # eager: W warm-up steps on minibatch 0 (what GraphedStep's warm-up does), then K steps cycling the minibatches
@@ -64,13 +78,16 @@ for k in range(K):
 # graph: W eager warm-up steps, the capture (which records and runs nothing), then K replays, each copying its minibatch into the
 # captured input tensor
 g = build(); xg = xs[0].clone(); sg = make(*g, xg)
-gs = GraphedStep(sg, static_inputs=[xg], warmup=W)
+# (split: graph (zero_grad … backward) · eager all-reduce · graph (update, hand-over) — what a step with several GPUs replays)
+gs = GraphedStep(sg.a, static_inputs=[xg], warmup=W, between=sg.sync, fn2=sg.b) if split else GraphedStep(sg, static_inputs=[xg], warmup=W)
 lg = [float(gs.replay(xs[k % 3])) for k in range(K)]
 torch.cuda.synchronize()
 assert le == lg, (le, lg)
 for a, b in zip(e[3], g[3]):
     assert torch.equal(a, b)
 assert int(g[4]._step_dev) == W + K
+if split:
+    dist.destroy_process_group()
 print("ok", dtype, le[-1])
 '''
 
@@ -82,3 +99,15 @@ def test_graph_replay_equals_eager_step(tmp_path, dtype):
     env = dict(os.environ, LDE_ROOT=ROOT, LDE_BRANCH_STREAMS="0")
     r = subprocess.run([sys.executable, str(f), dtype], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_split_graph_step_with_a_process_group_equals_eager(tmp_path):
+    """The several-GPU form of the captured step — graph (zero_grad … backward) · eager gradient all-reduce over RCCL · graph (update,
+    weight hand-over) — with a ONE-rank group on this box's GPU: the same losses and parameters as the eager loop with the same
+    all-reduce, bit for bit."""
+    f = tmp_path / "graph_step_split.py"
+    f.write_text(SCRIPT)
+    env = dict(os.environ, LDE_ROOT=ROOT, LDE_BRANCH_STREAMS="0", LDE_FORCE_ALLREDUCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, str(f), "mixed", "split"], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+

@@ -247,8 +247,10 @@ def run_decoder(args, torch, dist, world, rank, local):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
-    fence()
-    el = time.perf_counter() - t0
+    torch.cuda.synchronize()          # this rank's K steps are done: its clock stops here; the closing barrier follows, and the MAX over
+    el = time.perf_counter() - t0     # ranks (below) is the job's time — the barrier's own latency (an RCCL collective) is not a step
+    if world > 1:
+        dist.barrier()
     if world > 1:
         tmax = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -460,8 +462,10 @@ def run_goku_step(args, torch, dist, world, rank, local):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = run()
-    fence()
-    el = time.perf_counter() - t0
+    torch.cuda.synchronize()          # this rank's K steps are done: its clock stops here; the closing barrier follows, and the MAX over
+    el = time.perf_counter() - t0     # ranks (below) is the job's time — the barrier's own latency (an RCCL collective) is not a step
+    if world > 1:
+        dist.barrier()
     if world > 1:
         tmax = torch.tensor([el], device=dev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -791,8 +795,10 @@ def main():
         else:
             for _ in range(args.steps):
                 step()
-        fence()
-        el = time.perf_counter() - t0
+        torch.cuda.synchronize()          # this rank's K steps are done: its clock stops here; the closing barrier follows, and the MAX over
+        el = time.perf_counter() - t0     # ranks (below) is the job's time — the barrier's own latency (an RCCL collective) is not a step
+        if world > 1:
+            dist.barrier()
         if world > 1:
             tmax = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

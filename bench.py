@@ -686,7 +686,7 @@ def main():
 
     # the one collective of the path (shared RHS-MLP gradient): through the C ABI (lde_comm_*) when RCCL binds, else torch's
     comm, comm_kind = None, "none"
-    if world > 1:
+    if world > 1 and args.workload != "goku_pendulum":   # (the metric's right-hand side has no weights: no collective, no communicator)
         try:
             from latentdiffeq_amd.dist import LdeComm
             comm, comm_kind = LdeComm(rank, world), "lde_comm_allreduce_f32 (C ABI over RCCL)"

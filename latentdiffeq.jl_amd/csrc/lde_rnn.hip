@@ -264,7 +264,7 @@ __device__ __forceinline__ void rnn_body(const RnnDims& rd, const RnnArgs& a, co
         if (lstm) {
           const float ig = sigm(z[0]), fg = sigm(z[1]), gg = fast_tanh(z[2]), og = sigm(z[3]);
           z[0] = ig; z[1] = fg; z[2] = gg; z[3] = og;
-          cn = fg * cst[l * hmaxv + u] + ig * gg;
+          cn = __builtin_fmaf(fg, cst[l * hmaxv + u], ig * gg);   // (spelled out: left to the compiler, which product is fused depends on the surrounding code — rnn_body2 must give the same bits)
           hn = og * fast_tanh(cn);
         } else {
           hn = cellk == LDE_CELL_RNN_TANH ? fast_tanh(z[0]) : fmaxf(z[0], 0.f);
@@ -429,6 +429,255 @@ __device__ __forceinline__ void rnn_body(const RnnDims& rd, const RnnArgs& a, co
   }
 }
 
+// ---- the default stacks (32 → 16 → 16) as a TWO-WAVE PIPELINE: one wave per cell (round 3) -------------------------------------------------
+// In rnn_body ONE wave walks time and, inside a step, the two cells: 100 sequential cell evaluations per sweep, and a lone wave issues
+// an instruction every ≈ 8 cycles whatever its dependences — half of what its SIMD could take. Here a workgroup is two waves (the CU
+// places them on different SIMDs): wave 0 owns cell 1, wave 1 owns cell 2. Forward: wave 0 publishes h¹ₛ into an LDS ring of PIPE_R
+// steps and then its step count (a wave's LDS operations execute in order: a reader that sees the count sees the vector; no barrier, no
+// fence); wave 1 runs cell 2 on step s while wave 0 is on step s+1…. Backward the other way round: wave 1 publishes ∂L/∂h¹ₛ, wave 0
+// adds it to what its own step s+1 left. A producer PIPE_R steps ahead waits for the consumer's count. Records, staged panels, state
+// gradients: each wave its cell's, same addresses and same arithmetic as rnn_body ⇒ the same bits (tests/test_gpu_rnn.py).
+constexpr int PIPE_R = 8;
+template <int CELL_, int MODE_, int LY>
+__device__ __forceinline__ void rnn_pipe_wave(const RnnDims& rd, const RnnArgs& a, const unsigned bx, float* lw, float* xring, float* gring,
+                                              int* cnt) {
+  constexpr int IN0 = 32, H = 16, L = 2;
+  constexpr bool lstm = CELL_ == LDE_CELL_LSTM;
+  constexpr int G = lstm ? 4 : 1, Hp = rnn_pow2(G * H), TPW = 64 / Hp;
+  constexpr int in = LY == 0 ? IN0 : H, h = H, K = in + h, ldk = rnn_ldk(K), Rl = G * h, ldr = rnn_ldk(Rl);
+  constexpr int KF4 = (K + 3) / 4, RB4 = (Rl + 3) / 4, NKI = (K + Hp - 1) / Hp;
+  constexpr bool keep = MODE_ == 1 || MODE_ == 2, bptt = MODE_ == 1 || MODE_ == 3;
+  const int lane = threadIdx.x & 63, tr = lane / Hp, u = lane - tr * Hp;
+  const int T = a.T, B = a.B;
+  const int PER = rd.vmax + rd.rmax + 4 * H;              // per (cell, trajectory): [x; h] vector, gate vector, h, c, dh, dc
+  float* base = lw + rd.lds_w + (LY * TPW + tr) * PER;
+  float* vbuf = base;
+  float* dbuf = vbuf + rd.vmax;
+  float* hs = dbuf + rd.rmax;
+  float* cs = hs + H;
+  float* dh = cs + H;
+  float* dc = dh + H;
+  f32x4 wrow[KF4];
+  f32x4 wcol[bptt ? NKI : 1][bptt ? RB4 : 1];
+  {
+    const float* wr = lw + rd.w_off[LY] + (u < Rl ? u : 0) * ldk;
+#pragma unroll
+    for (int k4 = 0; k4 < KF4; k4++) wrow[k4] = u < Rl ? *reinterpret_cast<const f32x4*>(wr + 4 * k4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    if (bptt) {
+#pragma unroll
+      for (int q = 0; q < (bptt ? NKI : 0); q++) {
+        const int k = u + q * Hp;
+        const float* wk = lw + rd.wt_off[LY] + (k < K ? k : 0) * ldr;
+#pragma unroll
+        for (int r4 = 0; r4 < RB4; r4++)
+          wcol[bptt ? q : 0][bptt ? r4 : 0] = (k < K && 4 * r4 < Rl) ? *reinterpret_cast<const f32x4*>(wk + 4 * r4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
+  const long long b = (long long)bx * TPW + tr;
+  const bool valid = b < B;
+  const size_t tile = (size_t)(b >> 4);
+  const int row = (int)(b & 15);
+  const size_t bc = (size_t)(valid ? b : B - 1);
+  auto ld_cnt = [&](int i) { return __hip_atomic_load(&cnt[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); };
+  auto st_cnt = [&](int i, int v) {
+    asm volatile("" ::: "memory");
+    if (lane == 0) __hip_atomic_store(&cnt[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+
+  if (MODE_ != 3) {
+    // ---- forward sweep ----
+    if (u < h) {
+      hs[u] = lw[rd.s_off[LY] + u];
+      cs[u] = lstm ? lw[rd.s_off[LY] + h + u] : 0.f;
+    }
+    constexpr int XQ = (IN0 + Hp - 1) / Hp;      // inputs per lane of the first cell
+    float xq[XQ];
+    auto fetch_x = [&](int s) {
+      const int t = rd.reverse ? T - 1 - s : s;
+#pragma unroll
+      for (int q = 0; q < XQ; q++) {
+        const int k = u + q * Hp;
+        xq[q] = k < IN0 ? a.x[(size_t)IN0 * (bc + (size_t)B * t) + k] : 0.f;
+      }
+    };
+    if (LY == 0) fetch_x(0);
+    for (int s = 0; s < T; s++) {
+      if (LY == 0) {
+#pragma unroll
+        for (int q = 0; q < XQ; q++)
+          if (u + q * Hp < in) vbuf[u + q * Hp] = xq[q];
+        fetch_x(s + 1 < T ? s + 1 : s);
+      } else {
+        while (ld_cnt(0) <= s) {}                                        // the cell below has published h of this step
+        asm volatile("" ::: "memory");
+        for (int k = u; k < in; k += Hp) vbuf[k] = xring[((s % PIPE_R) * TPW + tr) * H + k];
+        st_cnt(1, s + 1);                                                // taken (this wave's LDS reads above are executed before this write)
+      }
+      for (int k = u; k < h; k += Hp) vbuf[in + k] = hs[k];
+      if (keep) {
+        float* ga = a.stage[LY] + (tile * T + s) * a.blk[LY] + row * pad32(K);
+        for (int k = u; k < pad32(K); k += Hp) ga[k] = (valid && k < K) ? vbuf[k] : 0.f;
+      }
+      if (u < Rl) {
+        f32x2 c01 = {0.f, 0.f}, c23 = {0.f, 0.f};
+#pragma unroll
+        for (int k4 = 0; k4 < KF4; k4++) {
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(vbuf + 4 * k4);
+          c01 += wrow[k4].lo * xv.lo;
+          c23 += wrow[k4].hi * xv.hi;
+        }
+        dbuf[u] = lw[rd.b_off[LY] + u] + ((c01.x + c01.y) + (c23.x + c23.y));
+      }
+      float hn = 0.f;
+      if (u < h) {
+        float z[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 4; g++)
+          if (g < G) z[g] = dbuf[g * h + u];
+        float cn = 0.f;
+        if (lstm) {
+          const float ig = sigm(z[0]), fg = sigm(z[1]), gg = fast_tanh(z[2]), og = sigm(z[3]);
+          z[0] = ig; z[1] = fg; z[2] = gg; z[3] = og;
+          cn = __builtin_fmaf(fg, cs[u], ig * gg);
+          hn = og * fast_tanh(cn);
+        } else {
+          hn = CELL_ == LDE_CELL_RNN_TANH ? fast_tanh(z[0]) : fmaxf(z[0], 0.f);
+          z[0] = hn;
+        }
+        if (keep && valid) {
+          float* r = a.rec + (((size_t)s * L + LY) * B + (size_t)b) * rd.recw;
+#pragma unroll
+          for (int g = 0; g < 4; g++)
+            if (g < G) r[g * h + u] = z[g];
+          r[G * h + u] = cn;
+          r[G * h + h + u] = hn;
+        }
+        hs[u] = hn;
+        cs[u] = cn;
+      }
+      if (LY == 0) {   // hand h of this step to the cell above
+        while (s >= PIPE_R && ld_cnt(1) <= s - PIPE_R) {}                // its slot is free once the step PIPE_R back has been taken
+        if (u < h) xring[((s % PIPE_R) * TPW + tr) * H + u] = hn;
+        st_cnt(0, s + 1);
+      }
+    }
+    if (MODE_ == 0 || MODE_ == 2) {
+      if (LY == L - 1 && valid && u < h) a.y[(size_t)h * b + u] = hs[u];
+      return;
+    }
+    __syncthreads();   // the records are read back below: stores drained first (both waves of the workgroup arrive: mode 1 only)
+  }
+
+  // ---- back-propagation through time ----
+  if (u < h) {
+    dh[u] = (LY == L - 1 && valid) ? a.dy[(size_t)h * b + u] : 0.f;
+    dc[u] = 0.f;
+  }
+  float rq[6];
+  auto fetch_rec = [&](int s) {
+    const int uc = u < h ? u : h - 1;
+    const float* r = a.rec + (((size_t)s * L + LY) * B + bc) * rd.recw;
+#pragma unroll
+    for (int g = 0; g < 4; g++) rq[g] = g < G ? r[g * h + uc] : 0.f;
+    rq[4] = 0.f;
+    rq[5] = 0.f;
+    if (lstm) {
+      rq[4] = r[Rl + uc];
+      rq[5] = a.rec[(((size_t)(s > 0 ? s - 1 : 0) * L + LY) * B + bc) * rd.recw + Rl + uc];
+    }
+  };
+  fetch_rec(T - 1);
+  for (int s = T - 1; s >= 0; s--) {
+    const int t = rd.reverse ? T - 1 - s : s;
+    const int idx = T - 1 - s;
+    if (LY == 0 && u == 0) a.wts[(tile * T + s) * NB + row] = valid ? 1.f : 0.f;
+    float cur[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) cur[q] = rq[q];
+    fetch_rec(s > 0 ? s - 1 : 0);
+    if (LY == 0) {   // what the cell above sends back for this step joins what this cell's own step s+1 left
+      while (ld_cnt(2) <= idx) {}
+      asm volatile("" ::: "memory");
+      if (u < h) dh[u] += gring[((idx % PIPE_R) * TPW + tr) * H + u];
+      st_cnt(3, idx + 1);
+    }
+    if (u < h) {
+      const float dhv = dh[u];
+      if (lstm) {
+        const float ig = cur[0], fg = cur[1], gg = cur[2], og = cur[3], cn = cur[4];
+        const float cp = s > 0 ? cur[5] : lw[rd.s_off[LY] + h + u];
+        const float tc = fast_tanh(cn);
+        const float dct = dc[u] + dhv * og * (1.f - tc * tc);
+        dbuf[u] = dct * gg * ig * (1.f - ig);
+        dbuf[h + u] = dct * cp * fg * (1.f - fg);
+        dbuf[2 * h + u] = dct * ig * (1.f - gg * gg);
+        dbuf[3 * h + u] = dhv * tc * og * (1.f - og);
+        dc[u] = dct * fg;
+      } else {
+        const float av = cur[0];
+        dbuf[u] = dhv * (CELL_ == LDE_CELL_RNN_TANH ? 1.f - av * av : (av > 0.f ? 1.f : 0.f));
+      }
+    }
+    {
+      float* gd = a.stage[LY] + (tile * T + s) * a.blk[LY] + NB * pad32(K) + row * pad32(Rl);
+      for (int k = u; k < pad32(Rl); k += Hp) gd[k] = (valid && k < Rl) ? dbuf[k] : 0.f;
+    }
+    if (LY == 1) {   // the ring slot of this step's ∂/∂h (to the cell below) is free once the step PIPE_R back has been taken
+      while (idx >= PIPE_R && ld_cnt(3) <= idx - PIPE_R) {}
+    }
+#pragma unroll
+    for (int q = 0; q < (bptt ? NKI : 0); q++) {
+      const int k = u + q * Hp;
+      if (k < K) {
+        f32x2 c01 = {0.f, 0.f}, c23 = {0.f, 0.f};
+#pragma unroll
+        for (int r4 = 0; r4 < RB4; r4++) {
+          const f32x4 dq = *reinterpret_cast<const f32x4*>(dbuf + 4 * r4);
+          c01 += wcol[bptt ? q : 0][bptt ? r4 : 0].lo * dq.lo;
+          c23 += wcol[bptt ? q : 0][bptt ? r4 : 0].hi * dq.hi;
+        }
+        const float acc = (c01.x + c01.y) + (c23.x + c23.y);
+        if (k < in) {
+          if (LY > 0) gring[((idx % PIPE_R) * TPW + tr) * H + k] = acc;
+          else if (a.dx && valid) a.dx[(size_t)IN0 * ((size_t)b + (size_t)B * t) + k] = acc;
+        } else
+          dh[k - in] = acc;
+      }
+    }
+    if (LY == 1) st_cnt(2, idx + 1);
+  }
+  if (valid && u < h) {
+    const int off = LY == 0 ? 0 : (lstm ? 2 * h : h);
+    a.g0[(size_t)b * a.g0w + off + u] = dh[u];
+    if (lstm) a.g0[(size_t)b * a.g0w + off + h + u] = dc[u];
+  }
+}
+
+// LDS floats of the pipeline form beyond the weight area: per (cell, trajectory) buffers, the two rings, the four counters
+__host__ __device__ inline int rnn_pipe_extra_floats(const RnnDims& rd, int tpw) {
+  return 2 * tpw * (rd.vmax + rd.rmax + 4 * 16) + 2 * PIPE_R * tpw * 16 + 16;
+}
+template <int CELL_, int MODE_>
+__device__ __forceinline__ void rnn_body2(const RnnDims& rd, const RnnArgs& a, const unsigned bx) {
+  extern __shared__ __attribute__((aligned(16))) float rsm[];
+  constexpr int Hp = rnn_pow2((CELL_ == LDE_CELL_LSTM ? 4 : 1) * 16), TPW = 64 / Hp;
+  float* lw = rsm;
+  float* xring = lw + rd.lds_w + 2 * TPW * (rd.vmax + rd.rmax + 4 * 16);
+  float* gring = xring + PIPE_R * TPW * 16;
+  int* cnt = reinterpret_cast<int*>(gring + PIPE_R * TPW * 16);
+  if (threadIdx.x < 4) cnt[threadIdx.x] = 0;
+  rnn_load_weights(rd, a.Wflat, lw, 128, MODE_ == 1 || MODE_ == 3);   // (ends with a barrier: the counters are zero for both waves)
+  for (int i = threadIdx.x; i < 2 * TPW * (rd.vmax + rd.rmax + 4 * 16); i += 128) lw[rd.lds_w + i] = 0.f;
+  __syncthreads();
+  if (threadIdx.x < 64) rnn_pipe_wave<CELL_, MODE_, 0>(rd, a, bx, lw, xring, gring, cnt);
+  else rnn_pipe_wave<CELL_, MODE_, 1>(rd, a, bx, lw, xring, gring, cnt);
+}
+template <int CELL_, int MODE_>
+__global__ void __launch_bounds__(128) k_rnn2(RnnDims rd, RnnArgs a) {
+  rnn_body2<CELL_, MODE_>(rd, a, blockIdx.x);
+}
+
 template <int CELL_, int IN0_, int H_, int L_, int MODE_, bool REGW = false>
 __global__ void __launch_bounds__(REGW ? 64 : 1024) k_rnn(RnnDims rd, RnnArgs a) {
   rnn_body<CELL_, IN0_, H_, L_, MODE_, REGW>(rd, a, blockIdx.x);
@@ -438,14 +687,20 @@ __global__ void __launch_bounds__(REGW ? 64 : 1024) k_rnn(RnnDims rd, RnnArgs a)
 // 60 µs apart and their weight-gradient tails queued behind each other (kernel trace, profiles/r3_goku_step_mixed_*). The cell kind is
 // a block-uniform switch; same code on the same data per stack.
 constexpr int RNN_GROUP_MAX = 3;
-template <int MODE_>
-__global__ void __launch_bounds__(64) k_rnn_group(GroupTable<RnnDims, RnnArgs, RNN_GROUP_MAX> g) {
+template <int MODE_, bool PIPE = false>
+__global__ void __launch_bounds__(PIPE ? 128 : 64) k_rnn_group(GroupTable<RnnDims, RnnArgs, RNN_GROUP_MAX> g) {
   const int j = group_find(g.start, g.n, blockIdx.x);
   const unsigned bx = blockIdx.x - g.start[j];
   const int cell = g.dims[j].cell;
-  if (cell == LDE_CELL_LSTM) rnn_body<LDE_CELL_LSTM, 32, 16, 2, MODE_, true>(g.dims[j], g.args[j], bx);
-  else if (cell == LDE_CELL_RNN_RELU) rnn_body<LDE_CELL_RNN_RELU, 32, 16, 2, MODE_, true>(g.dims[j], g.args[j], bx);
-  else rnn_body<LDE_CELL_RNN_TANH, 32, 16, 2, MODE_, true>(g.dims[j], g.args[j], bx);
+  if (PIPE) {
+    if (cell == LDE_CELL_LSTM) rnn_body2<LDE_CELL_LSTM, MODE_>(g.dims[j], g.args[j], bx);
+    else if (cell == LDE_CELL_RNN_RELU) rnn_body2<LDE_CELL_RNN_RELU, MODE_>(g.dims[j], g.args[j], bx);
+    else rnn_body2<LDE_CELL_RNN_TANH, MODE_>(g.dims[j], g.args[j], bx);
+  } else {
+    if (cell == LDE_CELL_LSTM) rnn_body<LDE_CELL_LSTM, 32, 16, 2, MODE_, true>(g.dims[j], g.args[j], bx);
+    else if (cell == LDE_CELL_RNN_RELU) rnn_body<LDE_CELL_RNN_RELU, 32, 16, 2, MODE_, true>(g.dims[j], g.args[j], bx);
+    else rnn_body<LDE_CELL_RNN_TANH, 32, 16, 2, MODE_, true>(g.dims[j], g.args[j], bx);
+  }
 }
 
 // dW[state0 slots] += Σ_b g0[b][·]: one wave per state entry, lane j adds trajectories j, j+64, … in order, then a fixed
@@ -504,7 +759,7 @@ struct lde_rnn {
   float* slab = nullptr; size_t slab_cap = 0; size_t slab_layer = 0;
   int32_t* ints = nullptr; size_t ints_cap = 0;
   bool accumulate = true;   // pullback: dW += gradient (default) or dW = gradient
-  void (*kernel[4][2])(lde::RnnDims, lde::RnnArgs) = {{nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}, {nullptr, nullptr}};   // the k_rnn instantiations for this stack: [forward, pullback][any workgroup size, one wave per workgroup]
+  void (*kernel[4][3])(lde::RnnDims, lde::RnnArgs) = {};   // the k_rnn instantiations for this stack: [mode][any workgroup size, one wave per workgroup, one wave per cell]
   std::string err;
 };
 
@@ -534,6 +789,16 @@ static rnn_kernel_t rnn_pick_mode(int mode) {
     case 1: return k_rnn<CELL_, 32, 16, 2, 1, ONE>;
     case 2: return k_rnn<CELL_, 32, 16, 2, 2, ONE>;
     default: return k_rnn<CELL_, 32, 16, 2, 3, ONE>;
+  }
+}
+
+template <int CELL_>
+static rnn_kernel_t rnn_pick_pipe(int mode) {
+  switch (mode) {
+    case 0: return k_rnn2<CELL_, 0>;
+    case 1: return k_rnn2<CELL_, 1>;
+    case 2: return k_rnn2<CELL_, 2>;
+    default: return k_rnn2<CELL_, 3>;
   }
 }
 
@@ -717,7 +982,7 @@ static rnn_kernel_t rnn_pick(const RnnDims& rd, int mode, bool one_wave = false)
 
 // ---- grouped calls (lde_rnn_group_*): as in lde_chain.hip — while a recorder is installed the launch sites record; the group entry point
 // issues each stage once for all stacks where they ask for the same kernel family, one by one otherwise.
-struct RnnRecMain { rnn_kernel_t fn; bool groupable; int mode; RnnDims rd; RnnArgs a; unsigned grid, block; size_t lds; };
+struct RnnRecMain { rnn_kernel_t fn; bool groupable, pipe; int mode; RnnDims rd; RnnArgs a; unsigned grid, block; size_t lds; };
 struct RnnRecDw { int ndw; MlpDims dm; DwArgs da; int gx, gy, gz; size_t lds; MlpDims rdm; ReduceArgs ra; unsigned rgrid; };
 struct RnnRecS0 { RnnDims rd; State0Args a; unsigned grid; };
 struct RnnGroupRec {
@@ -743,9 +1008,20 @@ static int rnn_launch(lde_rnn* r, const RnnArgs& a, int B, hipStream_t stream) {
   while (tpw < 16 && cdiv(B, tpw) > 1024) tpw *= 2;
   if (tpw_env == 1 || tpw_env == 2 || tpw_env == 4 || tpw_env == 8 || tpw_env == 16) tpw = tpw_env;
   const char* erw = std::getenv("LDE_RNN_REGW");   // read per call: the tests compare the two instantiations inside one process
-  const int one = (tpw * r->rd.Hp == 64 && !(erw && std::atoi(erw) == 0)) ? 1 : 0;   // one wave per workgroup: the register-resident-weights instantiation
+  const bool one_wave = tpw * r->rd.Hp == 64 && !(erw && std::atoi(erw) == 0);   // one wave per workgroup: the register-resident-weights instantiation
+  // … and, for the default shape, one wave per CELL (rnn_body2): LDE_RNN_PIPE=0 keeps the single wave
+  const char* epipe = std::getenv("LDE_RNN_PIPE");
+  const RnnDims& rd0 = r->rd;
+  const bool def_shape = rd0.wt && rd0.nL == 2 && rd0.sizes[0] == 32 && rd0.sizes[1] == 16 && rd0.sizes[2] == 16;
+  static const bool generic_only = std::getenv("LDE_RNN_GENERIC") && std::atoi(std::getenv("LDE_RNN_GENERIC")) != 0;
+  const bool pipe = one_wave && def_shape && !generic_only && !LDE_PROF && !(epipe && std::atoi(epipe) == 0);
+  const int one = pipe ? 2 : (one_wave ? 1 : 0);
   if (!r->kernel[m][one]) {
-    r->kernel[m][one] = rnn_pick(r->rd, m, one != 0);
+    if (pipe)
+      r->kernel[m][one] = rd0.cell == LDE_CELL_LSTM ? rnn_pick_pipe<LDE_CELL_LSTM>(m)
+                          : rd0.cell == LDE_CELL_RNN_RELU ? rnn_pick_pipe<LDE_CELL_RNN_RELU>(m) : rnn_pick_pipe<LDE_CELL_RNN_TANH>(m);
+    else
+      r->kernel[m][one] = rnn_pick(r->rd, m, one != 0);
     if (hipFuncSetAttribute((const void*)r->kernel[m][one], hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
       r->kernel[m][one] = nullptr;
       r->err = "hipFuncSetAttribute(k_rnn) failed";
@@ -754,7 +1030,9 @@ static int rnn_launch(lde_rnn* r, const RnnArgs& a, int B, hipStream_t stream) {
   }
   RnnArgs aa = a;
   aa.tpw = tpw;
-  const size_t lds = ((size_t)r->rd.lds_w + tpw * ((size_t)r->rd.vmax + r->rd.rmax + 4 * r->rd.nL * r->rd.hmax)) * sizeof(float);
+  const size_t lds = pipe ? ((size_t)r->rd.lds_w + rnn_pipe_extra_floats(r->rd, tpw)) * sizeof(float)
+                          : ((size_t)r->rd.lds_w + tpw * ((size_t)r->rd.vmax + r->rd.rmax + 4 * r->rd.nL * r->rd.hmax)) * sizeof(float);
+  const unsigned block = pipe ? 128u : (unsigned)(tpw * r->rd.Hp);
   // whole staging tiles are covered (rows past B write zero panels and zero column weights)
 #if LDE_PROF
   { long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
@@ -765,11 +1043,12 @@ static int rnn_launch(lde_rnn* r, const RnnArgs& a, int B, hipStream_t stream) {
     const RnnDims& rd = r->rd;
     q.groupable = one && rd.wt && rd.nL == 2 && rd.sizes[0] == 32 && rd.sizes[1] == 16 && rd.sizes[2] == 16 &&
                   q.fn != (rnn_kernel_t)k_rnn<-1, 0, 0, 0, 0>;
-    q.mode = m; q.rd = rd; q.a = aa; q.grid = (unsigned)(cdiv(B, 16) * (16 / tpw)); q.block = (unsigned)(tpw * rd.Hp); q.lds = lds;
+    q.pipe = pipe;
+    q.mode = m; q.rd = rd; q.a = aa; q.grid = (unsigned)(cdiv(B, 16) * (16 / tpw)); q.block = block; q.lds = lds;
     t_rrec->main_set[t_rrec->n] = true;
     return LDE_OK;
   }
-  hipLaunchKernelGGL(r->kernel[m][one], dim3(cdiv(B, 16) * (16 / tpw)), dim3(tpw * r->rd.Hp), lds, stream, r->rd, aa);
+  hipLaunchKernelGGL(r->kernel[m][one], dim3(cdiv(B, 16) * (16 / tpw)), dim3(block), lds, stream, r->rd, aa);
   if (hipGetLastError() != hipSuccess) {
     r->err = "k_rnn launch failed";
     return LDE_ERR_HIP;
@@ -945,21 +1224,23 @@ static int rnn_group_flush(RnnGroupRec& g, hipStream_t stream) {
   const int n = g.n;
   {   // the sweeps
     bool any = false, same = n >= 2;
-    for (int j = 0; j < n; j++) { any = any || g.main_set[j]; same = same && g.main_set[j] && g.main[j].groupable && g.main[j].mode == g.main[0].mode; }
+    for (int j = 0; j < n; j++) { any = any || g.main_set[j]; same = same && g.main_set[j] && g.main[j].groupable && g.main[j].mode == g.main[0].mode && g.main[j].pipe == g.main[0].pipe; }
     if (any && same) {
       GroupTable<RnnDims, RnnArgs, RNN_GROUP_MAX> t{};
       t.n = n;
       size_t lds = 0;
       for (int j = 0; j < n; j++) { t.start[j + 1] = t.start[j] + (int)g.main[j].grid; t.dims[j] = g.main[j].rd; t.args[j] = g.main[j].a; lds = std::max(lds, g.main[j].lds); }
-      static bool attr[4] = {false, false, false, false};
+      static bool attr[8] = {};
       const int m = g.main[0].mode;
-      const void* fn = m == 0 ? (const void*)k_rnn_group<0> : m == 1 ? (const void*)k_rnn_group<1> : m == 2 ? (const void*)k_rnn_group<2> : (const void*)k_rnn_group<3>;
-      if (!attr[m]) {
+      const bool pipe = g.main[0].pipe;
+      const void* fn = pipe ? (m == 0 ? (const void*)k_rnn_group<0, true> : m == 1 ? (const void*)k_rnn_group<1, true> : m == 2 ? (const void*)k_rnn_group<2, true> : (const void*)k_rnn_group<3, true>)
+                            : (m == 0 ? (const void*)k_rnn_group<0> : m == 1 ? (const void*)k_rnn_group<1> : m == 2 ? (const void*)k_rnn_group<2> : (const void*)k_rnn_group<3>);
+      if (!attr[m + (pipe ? 4 : 0)]) {
         if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) return LDE_ERR_HIP;
-        attr[m] = true;
+        attr[m + (pipe ? 4 : 0)] = true;
       }
       void* argv[] = {(void*)&t};
-      (void)hipLaunchKernel(fn, dim3(t.start[n]), dim3(64), argv, lds, stream);
+      (void)hipLaunchKernel(fn, dim3(t.start[n]), dim3(pipe ? 128 : 64), argv, lds, stream);
     } else if (any) {
       for (int j = 0; j < n; j++)
         if (g.main_set[j]) hipLaunchKernelGGL(g.main[j].fn, dim3(g.main[j].grid), dim3(g.main[j].block), g.main[j].lds, stream, g.main[j].rd, g.main[j].a);

@@ -215,6 +215,31 @@ def test_register_and_lds_weight_rows_agree(cell, monkeypatch):
         assert np.abs(a - b).max() <= 5e-6 * max(np.abs(b).max(), 1e-30), what
 
 
+@pytest.mark.parametrize("cell", [O.CELL_LSTM, O.CELL_RNN_RELU, O.CELL_RNN_TANH])
+@pytest.mark.parametrize("T,B,rev", [(23, 37, True), (1, 5, False), (8, 16, True), (9, 64, False), (50, 256, True)])
+def test_one_wave_per_cell_equals_one_wave_per_stack(cell, T, B, rev, monkeypatch):
+    """The default stacks run a workgroup of two waves, one per cell, handing h¹ₛ forward and ∂L/∂h¹ₛ backward through an LDS ring
+    (rnn_body2); LDE_RNN_PIPE=0 keeps the single wave that walks both cells (rnn_body). Same arithmetic per cell, in the same
+    order ⇒ the same bits — outputs, input gradients and weight gradients, on sweeps shorter than, equal to and longer than the
+    ring, with ragged batches, both directions of time; the training forward + pullback from kept records as well."""
+    from tests.gpu_util import NativeRnn
+    sizes = (32, 16, 16)
+    W = O.rnn_weights(cell, sizes, seed=9)
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((T, B, sizes[0])).astype(np.float32)
+    dy = (rng.standard_normal((B, sizes[-1])) / B).astype(np.float32)
+    res = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("LDE_RNN_PIPE", flag)
+        nat = NativeRnn(cell, sizes, rev)
+        nat.set_weights(W)
+        y = nat.forward(x)
+        dx, dW = nat.backward(x, dy)
+        res.append((y, dx, dW))
+    for a, b, what in zip(res[0], res[1], ("y", "dx", "dW")):
+        assert np.array_equal(a, b), what
+
+
 def test_branch_streams_match_joined_streams():
     """encode() three ways — the three stacks as one autograd node on raw side streams (opt-in), the z₀ / θ branches kept on
     their own HIP streams to the end (default), and the variant that joins the streams after the recurrent stacks — over several

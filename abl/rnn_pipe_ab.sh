@@ -1,3 +1,6 @@
+#!/bin/bash
+# one wave per cell (LDE_RNN_PIPE=1, default) against the single wave per stack (=0): the recurrent tests, the isolated stack timings, then
+# goku_step alternating on ONE box
 cd "$GRAFT_REPO_ROOT"
 timeout 600 python -m pytest tests/test_gpu_rnn.py -x -q 2>&1 | grep -E "passed|failed|Error|assert" | tail -8
 for p in 0 1; do echo "PIPE=$p"; LDE_RNN_PIPE=$p timeout 200 python abl/rnn_bench.py 2>&1 | tail -4; done

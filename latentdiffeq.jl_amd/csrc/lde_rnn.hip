@@ -59,7 +59,10 @@ struct RnnDims {
 
 __device__ __forceinline__ float sigm(float x) { return fast_rcp(1.0f + __expf(-x)); }
 // tanh x = 1 − 2/(1 + e^{2x}): v_exp_f32 + v_rcp_f32, ≈ 2e-7 absolute (saturates cleanly: e^{2x} → ∞ ⇒ 1, → 0 ⇒ −1)
-__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * fast_rcp(1.0f + __expf(2.0f * x)); }
+// (Fused multiply-adds of the cell formulas are spelled out, here and below: left to the compiler, what is fused depends on the code
+// around the expression — one body got v_fma(−t, t, 1), another a packed multiply and a subtraction — and the instantiations of the
+// recurrent kernels promise each other the same bits.)
+__device__ __forceinline__ float fast_tanh(float x) { return __builtin_fmaf(-2.0f, fast_rcp(1.0f + __expf(2.0f * x)), 1.0f); }
 
 struct RnnArgs {
   const float* x;       // [in × B × T]
@@ -340,15 +343,15 @@ __device__ __forceinline__ void rnn_body(const RnnDims& rd, const RnnArgs& a, co
           const float ig = cur[0], fg = cur[1], gg = cur[2], og = cur[3], cn = cur[4];
           const float cp = s > 0 ? cur[5] : lw[rd.s_off[l] + h + u];
           const float tc = fast_tanh(cn);
-          const float dct = dcs[l * hmaxv + u] + dh * og * (1.f - tc * tc);
+          const float dct = __builtin_fmaf(dh * og, __builtin_fmaf(-tc, tc, 1.f), dcs[l * hmaxv + u]);
           dbuf[u] = dct * gg * ig * (1.f - ig);
           dbuf[h + u] = dct * cp * fg * (1.f - fg);
-          dbuf[2 * h + u] = dct * ig * (1.f - gg * gg);
+          dbuf[2 * h + u] = dct * ig * __builtin_fmaf(-gg, gg, 1.f);
           dbuf[3 * h + u] = dh * tc * og * (1.f - og);
           dcs[l * hmaxv + u] = dct * fg;
         } else {
           const float av = cur[0];
-          dbuf[u] = dh * (cellk == LDE_CELL_RNN_TANH ? 1.f - av * av : (av > 0.f ? 1.f : 0.f));
+          dbuf[u] = dh * (cellk == LDE_CELL_RNN_TANH ? __builtin_fmaf(-av, av, 1.f) : (av > 0.f ? 1.f : 0.f));
         }
       }
       PROF_T(q2);
@@ -438,6 +441,20 @@ __device__ __forceinline__ void rnn_body(const RnnDims& rd, const RnnArgs& a, co
 // adds it to what its own step s+1 left. A producer PIPE_R steps ahead waits for the consumer's count. Records, staged panels, state
 // gradients: each wave its cell's, same addresses and same arithmetic as rnn_body ⇒ the same bits (tests/test_gpu_rnn.py).
 constexpr int PIPE_R = 8;
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+// v_permlane32_swap / v_permlane16_swap with both operands the same register: .x = the even rows (of 32 / 16 lanes) repeated, .y = the odd
+// rows repeated — a lane of row 0 reads its partner in row 1 in one VALU instruction instead of an LDS round trip (gfx950)
+__device__ __forceinline__ void rows32(float v, float& even, float& odd) {
+  const u32x2 r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  even = __uint_as_float(r.x);
+  odd = __uint_as_float(r.y);
+}
+__device__ __forceinline__ void rows16(float v, float& even, float& odd) {
+  const u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  even = __uint_as_float(r.x);
+  odd = __uint_as_float(r.y);
+}
+
 template <int CELL_, int MODE_, int LY>
 __device__ __forceinline__ void rnn_pipe_wave(const RnnDims& rd, const RnnArgs& a, const unsigned bx, float* lw, float* xring, float* gring,
                                               int* cnt) {
@@ -447,22 +464,23 @@ __device__ __forceinline__ void rnn_pipe_wave(const RnnDims& rd, const RnnArgs& 
   constexpr int in = LY == 0 ? IN0 : H, h = H, K = in + h, ldk = rnn_ldk(K), Rl = G * h, ldr = rnn_ldk(Rl);
   constexpr int KF4 = (K + 3) / 4, RB4 = (Rl + 3) / 4, NKI = (K + Hp - 1) / Hp;
   constexpr bool keep = MODE_ == 1 || MODE_ == 2, bptt = MODE_ == 1 || MODE_ == 3;
+  static_assert(Rl == Hp && in % 4 == 0 && K % 4 == 0, "one lane per gate row; whole float4 groups");
   const int lane = threadIdx.x & 63, tr = lane / Hp, u = lane - tr * Hp;
   const int T = a.T, B = a.B;
-  const int PER = rd.vmax + rd.rmax + 4 * H;              // per (cell, trajectory): [x; h] vector, gate vector, h, c, dh, dc
+  // What is on the recurrence of a cell goes through LDS ONCE per step (the vector every lane's dot product reads); the rest stays in
+  // registers: the lane's weight rows and bias, the unit lanes' c (forward) and ∂L/∂h, ∂L/∂c (backward); the LSTM's four pre-activations
+  // reach their unit lane by lane-row swaps. (rnn_body: [x; h] assembled from two LDS buffers, pre-activations and states through LDS —
+  // three to four dependent LDS round trips of ≈ 100+ cycles per step.)
+  const int PER = rd.vmax + rd.rmax + 4 * H;              // per (cell, trajectory): the [x; h] vector and the gate-delta vector
   float* base = lw + rd.lds_w + (LY * TPW + tr) * PER;
   float* vbuf = base;
   float* dbuf = vbuf + rd.vmax;
-  float* hs = dbuf + rd.rmax;
-  float* cs = hs + H;
-  float* dh = cs + H;
-  float* dc = dh + H;
   f32x4 wrow[KF4];
   f32x4 wcol[bptt ? NKI : 1][bptt ? RB4 : 1];
   {
-    const float* wr = lw + rd.w_off[LY] + (u < Rl ? u : 0) * ldk;
+    const float* wr = lw + rd.w_off[LY] + u * ldk;
 #pragma unroll
-    for (int k4 = 0; k4 < KF4; k4++) wrow[k4] = u < Rl ? *reinterpret_cast<const f32x4*>(wr + 4 * k4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int k4 = 0; k4 < KF4; k4++) wrow[k4] = *reinterpret_cast<const f32x4*>(wr + 4 * k4);
     if (bptt) {
 #pragma unroll
       for (int q = 0; q < (bptt ? NKI : 0); q++) {
@@ -470,10 +488,13 @@ __device__ __forceinline__ void rnn_pipe_wave(const RnnDims& rd, const RnnArgs& 
         const float* wk = lw + rd.wt_off[LY] + (k < K ? k : 0) * ldr;
 #pragma unroll
         for (int r4 = 0; r4 < RB4; r4++)
-          wcol[bptt ? q : 0][bptt ? r4 : 0] = (k < K && 4 * r4 < Rl) ? *reinterpret_cast<const f32x4*>(wk + 4 * r4) : f32x4{0.f, 0.f, 0.f, 0.f};
+          wcol[bptt ? q : 0][bptt ? r4 : 0] = k < K ? *reinterpret_cast<const f32x4*>(wk + 4 * r4) : f32x4{0.f, 0.f, 0.f, 0.f};
       }
     }
   }
+  const float bias = lw[rd.b_off[LY] + u];
+  const float h0 = u < h ? lw[rd.s_off[LY] + u] : 0.f;
+  const float c0 = (lstm && u < h) ? lw[rd.s_off[LY] + h + u] : 0.f;
   const long long b = (long long)bx * TPW + tr;
   const bool valid = b < B;
   const size_t tile = (size_t)(b >> 4);
@@ -487,148 +508,191 @@ __device__ __forceinline__ void rnn_pipe_wave(const RnnDims& rd, const RnnArgs& 
 
   if (MODE_ != 3) {
     // ---- forward sweep ----
-    if (u < h) {
-      hs[u] = lw[rd.s_off[LY] + u];
-      cs[u] = lstm ? lw[rd.s_off[LY] + h + u] : 0.f;
-    }
+    float creg = c0, hn = h0;
+    if (u < h) vbuf[in + u] = h0;
     constexpr int XQ = (IN0 + Hp - 1) / Hp;      // inputs per lane of the first cell
     float xq[XQ];
-    auto fetch_x = [&](int s) {
-      const int t = rd.reverse ? T - 1 - s : s;
+    const ptrdiff_t xstep = (ptrdiff_t)IN0 * B * (rd.reverse ? -1 : 1);
+    const float* xp = a.x + (size_t)IN0 * (bc + (size_t)B * (rd.reverse ? T - 1 : 0));   // the frame last asked for
+    auto fetch_x = [&]() {   // (branch-free, always in bounds: see rnn_body)
 #pragma unroll
       for (int q = 0; q < XQ; q++) {
         const int k = u + q * Hp;
-        xq[q] = k < IN0 ? a.x[(size_t)IN0 * (bc + (size_t)B * t) + k] : 0.f;
+        xq[q] = k < IN0 ? xp[k] : 0.f;
       }
     };
-    if (LY == 0) fetch_x(0);
-    for (int s = 0; s < T; s++) {
-      if (LY == 0) {
+    auto put_x = [&]() {
 #pragma unroll
-        for (int q = 0; q < XQ; q++)
-          if (u + q * Hp < in) vbuf[u + q * Hp] = xq[q];
-        fetch_x(s + 1 < T ? s + 1 : s);
-      } else {
-        while (ld_cnt(0) <= s) {}                                        // the cell below has published h of this step
+      for (int q = 0; q < XQ; q++)
+        if (u + q * Hp < in) vbuf[u + q * Hp] = xq[q];
+    };
+    if (LY == 0) {   // frame 0 into the vector, frame 1 into registers; in the loop frame s+1 is written once the reads of step s are issued
+      fetch_x();
+      put_x();
+      if (1 < T) xp += xstep;
+      fetch_x();
+    }
+    float* ga = keep ? a.stage[LY] + (tile * T) * a.blk[LY] + row * pad32(K) : nullptr;
+    float* rp = keep ? a.rec + ((size_t)LY * B + bc) * rd.recw : nullptr;
+    const size_t rstep = (size_t)L * B * rd.recw;
+    int slot = 0;                                  // s mod PIPE_R
+    int avail = 0, taken = 0;                      // the other wave's counts as last seen
+    for (int s = 0; s < T; s++) {
+      const float* xs = LY == 0 ? vbuf : xring + (slot * TPW + tr) * H;   // the cell's input: cell 2 reads it where cell 1 published it
+      if (LY == 1) {
+        while (avail <= s) avail = ld_cnt(0);
         asm volatile("" ::: "memory");
-        for (int k = u; k < in; k += Hp) vbuf[k] = xring[((s % PIPE_R) * TPW + tr) * H + k];
-        st_cnt(1, s + 1);                                                // taken (this wave's LDS reads above are executed before this write)
       }
-      for (int k = u; k < h; k += Hp) vbuf[in + k] = hs[k];
-      if (keep) {
-        float* ga = a.stage[LY] + (tile * T + s) * a.blk[LY] + row * pad32(K);
-        for (int k = u; k < pad32(K); k += Hp) ga[k] = (valid && k < K) ? vbuf[k] : 0.f;
+      if (keep) {   // the a-panel row of the weight gradient
+        for (int k = u; k < pad32(K); k += Hp) {
+          const float* src = (LY == 1 && k < in) ? xs + k : vbuf + (k < K ? k : 0);
+          const float v = *src;
+          ga[k] = (valid && k < K) ? v : 0.f;
+        }
+        ga += a.blk[LY];
       }
-      if (u < Rl) {
+      float z;
+      {
         f32x2 c01 = {0.f, 0.f}, c23 = {0.f, 0.f};
 #pragma unroll
         for (int k4 = 0; k4 < KF4; k4++) {
-          const f32x4 xv = *reinterpret_cast<const f32x4*>(vbuf + 4 * k4);
+          const f32x4 xv = *reinterpret_cast<const f32x4*>((4 * k4 < in ? xs : vbuf) + 4 * k4);
           c01 += wrow[k4].lo * xv.lo;
           c23 += wrow[k4].hi * xv.hi;
         }
-        dbuf[u] = lw[rd.b_off[LY] + u] + ((c01.x + c01.y) + (c23.x + c23.y));
+        z = bias + ((c01.x + c01.y) + (c23.x + c23.y));
       }
-      float hn = 0.f;
+      if (LY == 1) st_cnt(1, s + 1);   // taken: this wave's LDS reads above execute before this write
+      if (LY == 0) {
+        put_x();                       // (the reads of step s are issued: in order)
+        if (s + 2 < T) xp += xstep;
+        fetch_x();
+      }
+      float zz[4] = {z, 0.f, 0.f, 0.f};
+      if (lstm) {   // unit lane u < 16 needs rows u, 16+u, 32+u, 48+u
+        float lo, hi;
+        rows32(z, lo, hi);
+        rows16(lo, zz[0], zz[1]);
+        rows16(hi, zz[2], zz[3]);
+      }
       if (u < h) {
-        float z[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int g = 0; g < 4; g++)
-          if (g < G) z[g] = dbuf[g * h + u];
         float cn = 0.f;
         if (lstm) {
-          const float ig = sigm(z[0]), fg = sigm(z[1]), gg = fast_tanh(z[2]), og = sigm(z[3]);
-          z[0] = ig; z[1] = fg; z[2] = gg; z[3] = og;
-          cn = __builtin_fmaf(fg, cs[u], ig * gg);
+          const float ig = sigm(zz[0]), fg = sigm(zz[1]), gg = fast_tanh(zz[2]), og = sigm(zz[3]);
+          zz[0] = ig; zz[1] = fg; zz[2] = gg; zz[3] = og;
+          cn = __builtin_fmaf(fg, creg, ig * gg);
           hn = og * fast_tanh(cn);
         } else {
-          hn = CELL_ == LDE_CELL_RNN_TANH ? fast_tanh(z[0]) : fmaxf(z[0], 0.f);
-          z[0] = hn;
+          hn = CELL_ == LDE_CELL_RNN_TANH ? fast_tanh(zz[0]) : fmaxf(zz[0], 0.f);
+          zz[0] = hn;
         }
+        creg = cn;
+        vbuf[in + u] = hn;   // the next step's h_prev
         if (keep && valid) {
-          float* r = a.rec + (((size_t)s * L + LY) * B + (size_t)b) * rd.recw;
+          float* r = rp;
 #pragma unroll
           for (int g = 0; g < 4; g++)
-            if (g < G) r[g * h + u] = z[g];
+            if (g < G) r[g * h + u] = zz[g];
           r[G * h + u] = cn;
           r[G * h + h + u] = hn;
         }
-        hs[u] = hn;
-        cs[u] = cn;
+        if (keep) rp += rstep;
       }
-      if (LY == 0) {   // hand h of this step to the cell above
-        while (s >= PIPE_R && ld_cnt(1) <= s - PIPE_R) {}                // its slot is free once the step PIPE_R back has been taken
-        if (u < h) xring[((s % PIPE_R) * TPW + tr) * H + u] = hn;
+      if (LY == 0) {   // hand h of this step to the cell above: its slot is free once the step PIPE_R back has been taken
+        while (s >= PIPE_R && taken <= s - PIPE_R) taken = ld_cnt(1);
+        if (u < h) xring[(slot * TPW + tr) * H + u] = hn;
         st_cnt(0, s + 1);
       }
+      slot = (slot + 1) & (PIPE_R - 1);
     }
     if (MODE_ == 0 || MODE_ == 2) {
-      if (LY == L - 1 && valid && u < h) a.y[(size_t)h * b + u] = hs[u];
+      if (LY == L - 1 && valid && u < h) a.y[(size_t)h * b + u] = hn;
       return;
     }
     __syncthreads();   // the records are read back below: stores drained first (both waves of the workgroup arrive: mode 1 only)
   }
 
   // ---- back-propagation through time ----
-  if (u < h) {
-    dh[u] = (LY == L - 1 && valid) ? a.dy[(size_t)h * b + u] : 0.f;
-    dc[u] = 0.f;
-  }
+  float dhr = (u < h && LY == L - 1 && valid) ? a.dy[(size_t)h * b + u] : 0.f, dcr = 0.f;
   float rq[6];
-  auto fetch_rec = [&](int s) {
-    const int uc = u < h ? u : h - 1;
-    const float* r = a.rec + (((size_t)s * L + LY) * B + bc) * rd.recw;
+  const size_t rstepb = (size_t)L * B * rd.recw;
+  const int ucb = u < h ? u : h - 1;
+  const float* rpb = a.rec + (((size_t)(T - 1) * L + LY) * B + bc) * rd.recw + ucb;   // this lane's record entries of the step being fetched
+  auto fetch_rec = [&](bool first) {   // (first: the step has no predecessor; c_prev is then the trainable c0, patched in at the use)
 #pragma unroll
-    for (int g = 0; g < 4; g++) rq[g] = g < G ? r[g * h + uc] : 0.f;
+    for (int g = 0; g < 4; g++) rq[g] = g < G ? rpb[g * h] : 0.f;
     rq[4] = 0.f;
     rq[5] = 0.f;
     if (lstm) {
-      rq[4] = r[Rl + uc];
-      rq[5] = a.rec[(((size_t)(s > 0 ? s - 1 : 0) * L + LY) * B + bc) * rd.recw + Rl + uc];
+      rq[4] = rpb[Rl];
+      rq[5] = (first ? rpb : rpb - rstepb)[Rl];
     }
   };
-  fetch_rec(T - 1);
+  fetch_rec(T == 1);
+  float* gd = a.stage[LY] + (tile * T + (T - 1)) * a.blk[LY] + NB * pad32(K) + row * pad32(Rl);
+  float* wp = a.wts + (tile * T + (T - 1)) * NB + row;
+  const ptrdiff_t dxstep = (ptrdiff_t)IN0 * B * (rd.reverse ? 1 : -1);
+  float* dxp = a.dx ? a.dx + (size_t)IN0 * (bc + (size_t)B * (rd.reverse ? 0 : T - 1)) : nullptr;
+  int slot = 0;
+  int avail = 0, taken = 0;
+  float gin = 0.f;          // cell 1: what the cell above sends back for the coming step, picked up early when it is already there
+  bool have = false;
   for (int s = T - 1; s >= 0; s--) {
-    const int t = rd.reverse ? T - 1 - s : s;
     const int idx = T - 1 - s;
-    if (LY == 0 && u == 0) a.wts[(tile * T + s) * NB + row] = valid ? 1.f : 0.f;
+    if (LY == 0 && u == 0) *wp = valid ? 1.f : 0.f;
+    wp -= NB;
     float cur[6];
 #pragma unroll
     for (int q = 0; q < 6; q++) cur[q] = rq[q];
-    fetch_rec(s > 0 ? s - 1 : 0);
-    if (LY == 0) {   // what the cell above sends back for this step joins what this cell's own step s+1 left
-      while (ld_cnt(2) <= idx) {}
-      asm volatile("" ::: "memory");
-      if (u < h) dh[u] += gring[((idx % PIPE_R) * TPW + tr) * H + u];
-      st_cnt(3, idx + 1);
+    if (s > 0) rpb -= rstepb;
+    fetch_rec(s <= 1);
+    if (LY == 0) {   // ∂L/∂h of this step: what this cell's own step s+1 left plus what the cell above sends
+      if (!have) {
+        while (avail <= idx) avail = ld_cnt(2);
+        asm volatile("" ::: "memory");
+        gin = u < h ? gring[(slot * TPW + tr) * H + u] : 0.f;
+        st_cnt(3, idx + 1);
+      }
+      dhr += gin;
     }
     if (u < h) {
-      const float dhv = dh[u];
+      const float dhv = dhr;
       if (lstm) {
         const float ig = cur[0], fg = cur[1], gg = cur[2], og = cur[3], cn = cur[4];
-        const float cp = s > 0 ? cur[5] : lw[rd.s_off[LY] + h + u];
+        const float cp = s > 0 ? cur[5] : c0;
         const float tc = fast_tanh(cn);
-        const float dct = dc[u] + dhv * og * (1.f - tc * tc);
+        const float dct = __builtin_fmaf(dhv * og, __builtin_fmaf(-tc, tc, 1.f), dcr);
         dbuf[u] = dct * gg * ig * (1.f - ig);
         dbuf[h + u] = dct * cp * fg * (1.f - fg);
-        dbuf[2 * h + u] = dct * ig * (1.f - gg * gg);
+        dbuf[2 * h + u] = dct * ig * __builtin_fmaf(-gg, gg, 1.f);
         dbuf[3 * h + u] = dhv * tc * og * (1.f - og);
-        dc[u] = dct * fg;
+        dcr = dct * fg;
       } else {
         const float av = cur[0];
-        dbuf[u] = dhv * (CELL_ == LDE_CELL_RNN_TANH ? 1.f - av * av : (av > 0.f ? 1.f : 0.f));
+        dbuf[u] = dhv * (CELL_ == LDE_CELL_RNN_TANH ? __builtin_fmaf(-av, av, 1.f) : (av > 0.f ? 1.f : 0.f));
       }
     }
     {
-      float* gd = a.stage[LY] + (tile * T + s) * a.blk[LY] + NB * pad32(K) + row * pad32(Rl);
       for (int k = u; k < pad32(Rl); k += Hp) gd[k] = (valid && k < Rl) ? dbuf[k] : 0.f;
+      gd -= a.blk[LY];
+    }
+    if (LY == 0) {   // the next step's share from above, if it is there already: its LDS latency then hides behind the products below
+      have = false;
+      if (s > 0 && avail > idx + 1) {
+        const int nslot = (slot + 1) & (PIPE_R - 1);
+        gin = u < h ? gring[(nslot * TPW + tr) * H + u] : 0.f;
+        st_cnt(3, idx + 2);
+        have = true;
+      }
     }
     if (LY == 1) {   // the ring slot of this step's ∂/∂h (to the cell below) is free once the step PIPE_R back has been taken
-      while (idx >= PIPE_R && ld_cnt(3) <= idx - PIPE_R) {}
+      while (idx >= PIPE_R && taken <= idx - PIPE_R) taken = ld_cnt(3);
     }
+    float accl = 0.f;   // the last of the lane's outputs
 #pragma unroll
     for (int q = 0; q < (bptt ? NKI : 0); q++) {
       const int k = u + q * Hp;
+      float acc = 0.f;
       if (k < K) {
         f32x2 c01 = {0.f, 0.f}, c23 = {0.f, 0.f};
 #pragma unroll
@@ -637,20 +701,31 @@ __device__ __forceinline__ void rnn_pipe_wave(const RnnDims& rd, const RnnArgs& 
           c01 += wcol[bptt ? q : 0][bptt ? r4 : 0].lo * dq.lo;
           c23 += wcol[bptt ? q : 0][bptt ? r4 : 0].hi * dq.hi;
         }
-        const float acc = (c01.x + c01.y) + (c23.x + c23.y);
+        acc = (c01.x + c01.y) + (c23.x + c23.y);
         if (k < in) {
-          if (LY > 0) gring[((idx % PIPE_R) * TPW + tr) * H + k] = acc;
-          else if (a.dx && valid) a.dx[(size_t)IN0 * ((size_t)b + (size_t)B * t) + k] = acc;
-        } else
-          dh[k - in] = acc;
+          if (LY > 0) gring[(slot * TPW + tr) * H + k] = acc;
+          else if (dxp && valid) dxp[k] = acc;
+        }
       }
+      accl = acc;
     }
+    // ∂L/∂h_prev (outputs in … K−1) to the unit lanes: the LSTM's sit one lane row (cell 2) or two (cell 1) up; the plain cells' are the
+    // lane's own last output
+    if (lstm) {
+      float ev, od;
+      if (LY == 0) rows32(accl, ev, od);
+      else rows16(accl, ev, od);
+      dhr = od;
+    } else
+      dhr = accl;
     if (LY == 1) st_cnt(2, idx + 1);
+    if (LY == 0 && dxp) dxp += dxstep;
+    slot = (slot + 1) & (PIPE_R - 1);
   }
   if (valid && u < h) {
     const int off = LY == 0 ? 0 : (lstm ? 2 * h : h);
-    a.g0[(size_t)b * a.g0w + off + u] = dh[u];
-    if (lstm) a.g0[(size_t)b * a.g0w + off + h + u] = dc[u];
+    a.g0[(size_t)b * a.g0w + off + u] = dhr;
+    if (lstm) a.g0[(size_t)b * a.g0w + off + h + u] = dcr;
   }
 }
 

@@ -372,6 +372,7 @@ def run_goku_step(args, torch, dist, world, rank, local):
     from latentdiffeq_amd.chain import decode, default_decoder_layers
     from latentdiffeq_amd.dist import FlatGradAllReduce
     from latentdiffeq_amd.loss import reconstruction_loss, sample, sample_with_kl, vector_kl
+    from latentdiffeq_amd.loss import backward as loss_backward     # loss.backward() seeded from a constant 1 (no fill launch per step)
     from latentdiffeq_amd.recurrent import Encoder, default_encoder_layers, encode
     from latentdiffeq_amd import _lib as L
     B = args.batch or 256
@@ -421,7 +422,7 @@ def run_goku_step(args, torch, dist, world, rank, local):
             l_tilde = sample(mu, logvar)
             x_hat, z_hat, l_hat = decode(dec, l_tilde, ts)
             loss = reconstruction_loss(x, x_hat, Bg) + 1e-3 * vector_kl(mu, logvar, Bg)
-        loss.backward()
+        loss_backward(loss)
         L.join_weight_gradients()
         sync()
         opt.step()
@@ -440,7 +441,7 @@ def run_goku_step(args, torch, dist, world, rank, local):
         l_tilde, bkl = sample_with_kl(mu, logvar, 1e-3, Bg)
         x_hat, z_hat, l_hat = decode(dec, l_tilde, ts)
         loss = reconstruction_loss(x, x_hat, Bg, plus=bkl)
-        loss.backward()
+        loss_backward(loss)
         return loss
 
     def step_b():        # update + weight hand-over

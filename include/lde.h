@@ -275,6 +275,12 @@ int64_t lde_chain_saved_floats(const lde_chain* c, int64_t N);
 int  lde_chain_forward_save(lde_chain* c, const float* x, int64_t N, float* y, float* saved, void* stream);
 int  lde_chain_backward_saved(lde_chain* c, const float* x, const float* y, const float* dy, const float* saved, int64_t N,
                               float* dx, float* dW, void* stream);
+/* The pullback of a chain whose OUTPUT feeds several consumers (the feature extractor's frames go to the three pattern extractors
+ * [REF src/models/GOKU.jl:32-51]): the output gradient is (dys[0] + dys[1]) + dys[2], formed where the kernel reads it — the sums a caller
+ * would otherwise launch (two elementwise kernels over [out×N] in a GOKU step). n_dy = 1..3; 16-byte aligned arrays; saved may be NULL
+ * (then as lde_chain_backward). With n_dy = 1 the call IS lde_chain_backward_saved. */
+int  lde_chain_backward_saved_sum(lde_chain* c, const float* x, const float* y, int n_dy, const float* const* dys, const float* saved,
+                                  int64_t N, float* dx, float* dW, void* stream);
 /* How the pullbacks deliver the weight gradient: on = 1 (default) dW += gradient, like lde_adjoint; on = 0: dW = gradient — every
  * entry of dW is written exactly once, so a caller that wants the plain gradient needs no zero fill (one launch less). */
 int  lde_chain_set_accumulate(lde_chain* c, int on);
@@ -346,6 +352,16 @@ int  lde_rnn_group_forward(int n, lde_rnn* const* stacks, const float* const* xs
 int  lde_rnn_group_forward_train(int n, lde_rnn* const* stacks, const float* const* xs, int T, int B, float* const* ys, void* stream);
 int  lde_rnn_group_backward(int n, lde_rnn* const* stacks, const float* const* xs, const float* const* dys, int T, int B,
                             float* const* dxs, float* const* dWs, void* stream);
+/* The grouped calls with each stack's output (ys[i]) and output gradient (dys[i]) given as a COLUMN BLOCK of a wider array: row b of
+ * stack i starts at ys[i] + b·ldys[i] (ldys[i] ≥ the stack's output width; NULL: dense rows) — the θ branch's vcat(pe_forward,
+ * pe_backward) [REF src/models/GOKU.jl:47] is then written in place by the two stacks, and its gradient read in place. dys2 (NULL, or
+ * NULL entries: absent): a second source of the output gradient with the same row stride, the gradient used is dys[i] + dys2[i] — the
+ * (μ, log σ²) heads of apply_latent_in [REF src/models/GOKU.jl:61-72] both read a stack's output. train != 0: the sweep keeps its records
+ * (lde_rnn_forward_train). Otherwise as lde_rnn_group_forward[_train] / lde_rnn_group_backward, bit for bit. */
+int  lde_rnn_group_forward_ld(int n, lde_rnn* const* stacks, const float* const* xs, int T, int B, float* const* ys, const int* ldys,
+                              int train, void* stream);
+int  lde_rnn_group_backward_ld(int n, lde_rnn* const* stacks, const float* const* xs, const float* const* dys, const float* const* dys2,
+                               const int* lddys, int T, int B, float* const* dxs, float* const* dWs, void* stream);
 int  lde_rnn_set_accumulate(lde_rnn* r, int on);   /* as lde_chain_set_accumulate */
 const char* lde_rnn_last_error(const lde_rnn* r);
 
@@ -374,6 +390,13 @@ int lde_refresh_weights(int n, const int* kinds, void* const* handles, const flo
  * ==================================================================================================================== */
 #define LDE_LOSS_SCRATCH_FLOATS 1024
 
+/* out[0..n) ~ N(0, 1): the ε of `sample` (the reference draws it with `randn` [REF src/models/GOKU.jl:155-163]). Philox4x32-10 keyed by
+ * `seed`; block i of four consecutive outputs is Box–Muller of the words of counter (i, call, offset + *epoch_dev) — u = (w >> 8 + ½)/2²⁴,
+ * (√(−2 ln u₁)·cos 2πu₂, √(−2 ln u₁)·sin 2πu₂) per pair of words. `epoch_dev` (NULL: 0) is a device counter read by the kernel: inside
+ * a captured training step it is the optimiser's step count, so every replay draws fresh noise with no host-side generator state.
+ * `call` separates the draws of one step, `offset` the steps of an eager loop. raw_words (NULL, or n words): the Philox output itself
+ * (what the known-answer vectors of the generator are stated in; tests). */
+int lde_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, uint32_t call, const int64_t* epoch_dev, uint32_t* raw_words, void* stream);
 int lde_sample_forward(const float* mu, const float* logvar, const float* eps, int64_t n, float* l, void* stream);
 /* dμ = dl (not written: it is the input); dlogvar_i = dl_i · ε_i · exp(logσ²_i/2) / 2 */
 int lde_sample_backward(const float* logvar, const float* eps, const float* dl, int64_t n, float* dlogvar, void* stream);

@@ -360,6 +360,8 @@ class _SolveFn(torch.autograd.Function):
         ctx.has_theta, ctx.has_W = theta is not None, W is not None
         ctx.save_for_backward(z_out, theta if theta is not None else z0.new_empty(0))
         ctx.mark_non_differentiable(retcode)
+        ctx.set_materialize_grads(False)      # retcode never has a gradient: without this autograd hands the pullback a zero-filled
+                                              # int array for it — one fill launch per step
         return z_out, retcode
 
     @staticmethod
@@ -370,6 +372,8 @@ class _SolveFn(torch.autograd.Function):
         theta = theta if ctx.has_theta else None
         T, B, Dp = z_out.shape
         D = handle.desc.state_dim
+        if dz_out is None:                    # (nothing downstream used ẑ)
+            dz_out = torch.zeros_like(z_out)
         dz_out = dz_out.contiguous().float()
         stream = L.raw_stream(z_out.device.index)
         dz0 = torch.empty((B, D), device=z_out.device, dtype=torch.float32)

@@ -405,6 +405,8 @@ struct ChainBwdArgs {
   float* wts;          // [slots][16]
   long long N;
   const float* saved;  // hidden activations written by lde_chain_forward_save (nullptr: recompute them)
+  const float* dy2;    // lde_chain_backward_saved_sum: the output gradient is (dy + dy2) + dy3 (nullptr: absent) — the sum a caller whose
+  const float* dy3;    // output feeds several consumers would otherwise form with launches of its own
 };
 
 struct PrePair { f32x4 h, a; };
@@ -505,14 +507,22 @@ __device__ __forceinline__ void chain_backward_body(const ChainDims& cd, const C
         f32x4 d = {0.f, 0.f, 0.f, 0.f};
         if (n < a.N && r < out) {
           if (vec) {
-            const f32x4 g = *reinterpret_cast<const f32x4*>(dyp + r), f = *reinterpret_cast<const f32x4*>(yp + r);
+            f32x4 g = *reinterpret_cast<const f32x4*>(dyp + r);
+            const f32x4 f = *reinterpret_cast<const f32x4*>(yp + r);
+            if (a.dy2) g += *reinterpret_cast<const f32x4*>(a.dy2 + (size_t)n * out + r);
+            if (a.dy3) g += *reinterpret_cast<const f32x4*>(a.dy3 + (size_t)n * out + r);
             d = cact_grad_out4(actk, f);
 #pragma unroll
             for (int q = 0; q < 4; q++) d[q] *= g[q];
           } else {
 #pragma unroll
             for (int q = 0; q < 4; q++)
-              if (r + q < out) d[q] = dyp[r + q] * cact_grad_out(actk, yp[r + q]);
+              if (r + q < out) {
+                float g = dyp[r + q];
+                if (a.dy2) g += a.dy2[(size_t)n * out + r + q];
+                if (a.dy3) g += a.dy3[(size_t)n * out + r + q];
+                d[q] = g * cact_grad_out(actk, yp[r + q]);
+              }
           }
         }
         *reinterpret_cast<f32x4*>(dst + r) = d;
@@ -1015,6 +1025,7 @@ struct GroupRec {
   RecDw dw[GROUP_MAX];
   RecRed red[GROUP_MAX];
 };
+static thread_local const float* t_dy_more[2] = {nullptr, nullptr};   // lde_chain_backward_saved_sum: further sources of the output gradient
 static thread_local GroupRec* t_rec = nullptr;
 // (kernel arguments: 4 KB on this runtime)
 static_assert(sizeof(GroupTable<ChainBDims, ChainBwdArgsB>) <= 4096 && sizeof(GroupTable<ChainDims, ChainBwdArgs>) <= 4096 &&
@@ -1260,7 +1271,7 @@ static int chain_backward_b(lde_chain* c, const float* x, const float* y, const 
     c->err = "lde_chain_backward (bf16): no tile layout fits LDS for this input";
     return LDE_ERR_UNSUPPORTED;
   }
-  ChainBwdArgsB a{x, y, dy, dx, c->fragTb, c->W_dev, c->dstage, (long long)N, saved};
+  ChainBwdArgsB a{x, y, dy, dx, c->fragTb, c->W_dev, c->dstage, (long long)N, saved, t_dy_more[0], t_dy_more[1]};
   const int NC = 16 * pk.cg;
   {
     const dim3 grid((unsigned)((N + NC - 1) / NC));
@@ -1460,7 +1471,7 @@ static int chain_backward_impl(lde_chain* c, const float* x, const float* y, con
   int nvt, cap;
   int64_t total;
   chain_dw_split(c, pk.cg, N, &nvt, &cap, &total);
-  ChainBwdArgs a{x, y, dy, dx, c->frag, c->fragT, c->W_dev, c->stage, c->wts, (long long)N, saved};
+  ChainBwdArgs a{x, y, dy, dx, c->frag, c->fragT, c->W_dev, c->stage, c->wts, (long long)N, saved, t_dy_more[0], t_dy_more[1]};
   const int NC = 16 * pk.cg;
   const dim3 grid((unsigned)((N + NC - 1) / NC));
   static bool attr[2][3] = {{false, false, false}, {false, false, false}};
@@ -1563,6 +1574,25 @@ int lde_chain_backward_saved(lde_chain* c, const float* x, const float* y, const
     return LDE_ERR_INVALID_ARG;
   }
   return chain_backward_impl(c, x, y, dy, saved, N, dx, dW, stream);
+}
+
+int lde_chain_backward_saved_sum(lde_chain* c, const float* x, const float* y, int n_dy, const float* const* dys, const float* saved, int64_t N,
+                                 float* dx, float* dW, void* stream) {
+  if (!c) return LDE_ERR_INVALID_ARG;
+  if (n_dy < 1 || n_dy > 3 || !dys) {
+    c->err = "lde_chain_backward_saved_sum: 1 to 3 output-gradient arrays";
+    return LDE_ERR_INVALID_ARG;
+  }
+  for (int i = 0; i < n_dy; i++)
+    if (!dys[i] || (((uintptr_t)dys[i]) & 15) != 0) {
+      c->err = "lde_chain_backward_saved_sum: NULL or unaligned output-gradient array";
+      return LDE_ERR_INVALID_ARG;
+    }
+  t_dy_more[0] = n_dy > 1 ? dys[1] : nullptr;
+  t_dy_more[1] = n_dy > 2 ? dys[2] : nullptr;
+  const int rc = saved ? lde_chain_backward_saved(c, x, y, dys[0], saved, N, dx, dW, stream) : lde_chain_backward(c, x, y, dys[0], N, dx, dW, stream);
+  t_dy_more[0] = t_dy_more[1] = nullptr;
+  return rc;
 }
 
 // ---- grouped calls: n independent chains, each stage of the call ONE launch when the chains ask for the same small-tile kernel ----------

@@ -361,6 +361,8 @@ struct ChainBwdArgsB {
   __bf16* dstage;       // δ_l matrices [n][dl_w[l]] bf16 (BfDims::dl_off), read by k_chain_dw_b
   long long N;
   const __bf16* saved;  // hidden activations written by k_chain_forward_b
+  const float* dy2;     // the output gradient is (dy + dy2) + dy3 (nullptr: absent), as in ChainBwdArgs
+  const float* dy3;
 };
 
 struct PreH { f32x4 h; };
@@ -411,7 +413,17 @@ __device__ __forceinline__ void chain_backward_b_body(const ChainDims& cd, const
       const float* yp = a.y + (size_t)n * out + 8 * ch;
       bf16x8 d;
       if (vec && 8 * ch + 8 <= out) {
-        const f32x4 g0 = *reinterpret_cast<const f32x4*>(dyp), g1 = *reinterpret_cast<const f32x4*>(dyp + 4);
+        f32x4 g0 = *reinterpret_cast<const f32x4*>(dyp), g1 = *reinterpret_cast<const f32x4*>(dyp + 4);
+        if (a.dy2) {
+          const float* q2 = a.dy2 + (size_t)n * out + 8 * ch;
+          g0 += *reinterpret_cast<const f32x4*>(q2);
+          g1 += *reinterpret_cast<const f32x4*>(q2 + 4);
+        }
+        if (a.dy3) {
+          const float* q3 = a.dy3 + (size_t)n * out + 8 * ch;
+          g0 += *reinterpret_cast<const f32x4*>(q3);
+          g1 += *reinterpret_cast<const f32x4*>(q3 + 4);
+        }
         const f32x4 f0 = *reinterpret_cast<const f32x4*>(yp), f1 = *reinterpret_cast<const f32x4*>(yp + 4);
         const f32x4 a0 = cact_grad_out4(actk, f0), a1 = cact_grad_out4(actk, f1);
 #pragma unroll
@@ -421,7 +433,16 @@ __device__ __forceinline__ void chain_backward_b_body(const ChainDims& cd, const
         }
       } else {
 #pragma unroll
-        for (int q = 0; q < 8; q++) d[q] = (__bf16)(8 * ch + q < out ? dyp[q] * cact_grad_out(actk, yp[q]) : 0.f);
+        for (int q = 0; q < 8; q++) {
+          float g = 0.f;
+          if (8 * ch + q < out) {
+            g = dyp[q];
+            if (a.dy2) g += a.dy2[(size_t)n * out + 8 * ch + q];
+            if (a.dy3) g += a.dy3[(size_t)n * out + 8 * ch + q];
+            g *= cact_grad_out(actk, yp[q]);
+          }
+          d[q] = (__bf16)g;
+        }
       }
       *reinterpret_cast<bf16x8*>(dL + (size_t)n * w + 8 * ch) = d;
     }

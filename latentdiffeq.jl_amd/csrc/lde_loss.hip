@@ -224,6 +224,48 @@ static int loss_map(const float* a, const float* b, const float* c, const float*
   return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
 }
 
+// ε ~ N(0, 1) for the variational sample (round 3). Philox4x32-10 [Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as
+// 1, 2, 3", SC'11] — the counter-based generator torch and Julia's Random123 use — keyed by the caller's 64-bit seed; block i of four
+// outputs has the counter (i, call, offset + *epoch): `epoch` is a DEVICE counter (the optimiser's step count), so a captured training
+// step draws fresh noise at every replay without the generator bookkeeping a framework puts in front of a replay (three launches and
+// a host-to-device copy per step for two torch.randn calls). The four words of a block make two Box–Muller pairs.
+__device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned c2, unsigned c3, unsigned k0, unsigned k1, unsigned (&o)[4]) {
+#pragma unroll
+  for (int r = 0; r < 10; r++) {
+    const unsigned long long p0 = 0xD2511F53ull * c0, p1 = 0xCD9E8D57ull * c2;
+    const unsigned n0 = (unsigned)(p1 >> 32) ^ c1 ^ k0, n1 = (unsigned)p1, n2 = (unsigned)(p0 >> 32) ^ c3 ^ k1, n3 = (unsigned)p0;
+    c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
+}
+__global__ void __launch_bounds__(256) k_randn(float* __restrict__ out, long long n, unsigned long long seed, unsigned long long offset,
+                                                unsigned call, const long long* __restrict__ epoch, unsigned* __restrict__ raw) {
+  const long long blk = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (4 * blk >= n) return;
+  const unsigned long long off = offset + (epoch ? (unsigned long long)*epoch : 0ull);
+  unsigned w[4];
+  philox4x32_10((unsigned)blk, call, (unsigned)off, (unsigned)(off >> 32), (unsigned)seed, (unsigned)(seed >> 32), w);
+  float z[4];
+#pragma unroll
+  for (int pr = 0; pr < 2; pr++) {
+    const float u1 = ((float)(w[2 * pr] >> 8) + 0.5f) * (1.0f / 16777216.0f);   // (0, 1): 24 bits, never 0
+    const float u2 = ((float)(w[2 * pr + 1] >> 8) + 0.5f) * (1.0f / 16777216.0f);
+    const float rad = sqrtf(-2.0f * logf(u1));
+    float sn, cs;
+    sincospif(2.0f * u2, &sn, &cs);
+    z[2 * pr] = rad * cs;
+    z[2 * pr + 1] = rad * sn;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+    if (4 * blk + q < n) {
+      out[4 * blk + q] = z[q];
+      if (raw) raw[4 * blk + q] = w[q];
+    }
+}
+
 }  // namespace lde
 
 using namespace lde;
@@ -276,6 +318,16 @@ int lde_sample_kl_backward(const float* mu, const float* logvar, const float* ep
 int lde_mse_backward(const float* x, const float* xhat, int64_t n, float scale, const float* dout, float* dxhat, void* stream) {
   if (n > 0 && (!x || !xhat || !dout || !dxhat)) return LDE_ERR_INVALID_ARG;
   return loss_map<3>(x, xhat, nullptr, dout, scale, n, dxhat, nullptr, stream);
+}
+
+int lde_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, uint32_t call, const int64_t* epoch_dev, uint32_t* raw_words, void* stream) {
+  if (n < 0 || (n > 0 && !out)) return LDE_ERR_INVALID_ARG;
+  if (n == 0) return LDE_OK;
+  const long long blocks = (n + 3) / 4;
+  if (blocks > 0xffffffffll) return LDE_ERR_INVALID_ARG;   // the block index is one 32-bit counter word
+  hipLaunchKernelGGL(k_randn, dim3((unsigned)((blocks + 255) / 256)), dim3(256), 0, (hipStream_t)stream, out, (long long)n, (unsigned long long)seed,
+                     (unsigned long long)offset, (unsigned)call, (const long long*)epoch_dev, raw_words);
+  return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
 }
 
 }  // extern "C"

@@ -78,7 +78,14 @@ struct RnnArgs {
   int g0w;              // floats per trajectory in g0
   int T, B, mode;       // mode 0: forward only (writes y); 1: backward (recompute + BPTT)
   int tpw;              // trajectories per workgroup: 1, 2, 4, 8 or 16 (a staging tile of 16 spans 16/tpw workgroups)
+  int ldy, lddy;        // floats between the rows of y / dy (≥ hL: the stack writes, or reads, a column block of a wider [B × ·] array —
+                        // the θ branch's vcat(pe_forward, pe_backward) [REF src/models/GOKU.jl:47] without a concatenation launch)
+  const float* dy2;     // backward: the output gradient is dy + dy2 (nullptr: absent; same row stride)
 };
+__device__ __forceinline__ float rnn_dy(const RnnArgs& a, long long b, int u) {
+  const float g = a.dy[(size_t)a.lddy * b + u];
+  return a.dy2 ? g + a.dy2[(size_t)a.lddy * b + u] : g;
+}
 
 // weights → LDS: rows of [Wi | Wh] (row r = g·h + u), zero padded; biases; state0
 __device__ __forceinline__ void rnn_load_weights(const RnnDims& rd, const float* Wflat, float* lw, int nthr, bool transposed) {
@@ -290,7 +297,7 @@ __device__ __forceinline__ void rnn_body(const RnnDims& rd, const RnnArgs& a, co
   }
   if (mode == 0 || mode == 2) {
     const int hL = size_of(L);
-    if (valid && u < hL) a.y[(size_t)hL * b + u] = hst[(L - 1) * hmaxv + u];
+    if (valid && u < hL) a.y[(size_t)a.ldy * b + u] = hst[(L - 1) * hmaxv + u];
     return;
   }
   }   // (mode 3 starts here)
@@ -301,7 +308,7 @@ __device__ __forceinline__ void rnn_body(const RnnDims& rd, const RnnArgs& a, co
   for (int l = 0; l < L; l++) {
     const int h = size_of(l + 1);
     if (u < h) {
-      dhs[l * hmaxv + u] = (l == L - 1 && valid) ? a.dy[(size_t)h * b + u] : 0.f;
+      dhs[l * hmaxv + u] = (l == L - 1 && valid) ? rnn_dy(a, b, u) : 0.f;
       dcs[l * hmaxv + u] = 0.f;
     }
   }
@@ -606,14 +613,14 @@ __device__ __forceinline__ void rnn_pipe_wave(const RnnDims& rd, const RnnArgs& 
       slot = (slot + 1) & (PIPE_R - 1);
     }
     if (MODE_ == 0 || MODE_ == 2) {
-      if (LY == L - 1 && valid && u < h) a.y[(size_t)h * b + u] = hn;
+      if (LY == L - 1 && valid && u < h) a.y[(size_t)a.ldy * b + u] = hn;
       return;
     }
     __syncthreads();   // the records are read back below: stores drained first (both waves of the workgroup arrive: mode 1 only)
   }
 
   // ---- back-propagation through time ----
-  float dhr = (u < h && LY == L - 1 && valid) ? a.dy[(size_t)h * b + u] : 0.f, dcr = 0.f;
+  float dhr = (u < h && LY == L - 1 && valid) ? rnn_dy(a, b, u) : 0.f, dcr = 0.f;
   float rq[6];
   const size_t rstepb = (size_t)L * B * rd.recw;
   const int ucb = u < h ? u : h - 1;
@@ -835,6 +842,8 @@ struct lde_rnn {
   int32_t* ints = nullptr; size_t ints_cap = 0;
   bool accumulate = true;   // pullback: dW += gradient (default) or dW = gradient
   void (*kernel[4][3])(lde::RnnDims, lde::RnnArgs) = {};   // the k_rnn instantiations for this stack: [mode][any workgroup size, one wave per workgroup, one wave per cell]
+  int io_ldy = 0, io_lddy = 0;       // set around a call by the *_ld group entry points (0: rows are hL apart)
+  const float* io_dy2 = nullptr;
   std::string err;
 };
 
@@ -1158,6 +1167,7 @@ int lde_rnn_forward(lde_rnn* r, const float* x, int T, int B, float* y, void* st
   RnnArgs a;
   std::memset(&a, 0, sizeof(a));
   a.x = x; a.Wflat = r->W_dev; a.y = y; a.T = T; a.B = B; a.mode = 0;
+  a.ldy = r->io_ldy ? r->io_ldy : r->rd.sizes[r->rd.nL];
   return rnn_launch(r, a, B, (hipStream_t)stream_);
 }
 
@@ -1190,6 +1200,7 @@ int lde_rnn_forward_train(lde_rnn* r, const float* x, int T, int B, float* y, vo
   RnnArgs a;
   std::memset(&a, 0, sizeof(a));
   a.x = x; a.Wflat = r->W_dev; a.y = y; a.rec = r->rec; a.wts = r->wts; a.g0 = r->g0; a.g0w = r->g0w;
+  a.ldy = r->io_ldy ? r->io_ldy : r->rd.sizes[r->rd.nL];
   a.T = T; a.B = B; a.mode = 2;
   for (int l = 0; l < rd.nL; l++) { a.stage[l] = r->stage[l]; a.blk[l] = r->dmw[l].blk_floats; }
   rc = rnn_launch(r, a, B, stream);
@@ -1226,6 +1237,8 @@ int lde_rnn_backward_dx(lde_rnn* r, const float* x, const float* dy, int T, int 
   RnnArgs a;
   std::memset(&a, 0, sizeof(a));
   a.x = x; a.Wflat = r->W_dev; a.rec = r->rec; a.dy = dy; a.dx = dx; a.wts = r->wts; a.g0 = r->g0; a.g0w = r->g0w;
+  a.lddy = r->io_lddy ? r->io_lddy : r->rd.sizes[r->rd.nL];
+  a.dy2 = r->io_dy2;
   a.T = T; a.B = B; a.mode = kept ? 3 : 1;
   for (int l = 0; l < rd.nL; l++) { a.stage[l] = r->stage[l]; a.blk[l] = r->dmw[l].blk_floats; }
   rc = rnn_launch(r, a, B, stream);
@@ -1455,6 +1468,46 @@ int lde_rnn_group_backward(int n, lde_rnn* const* rs, const float* const* xs, co
   t_rrec = nullptr;
   const int rc = rnn_group_flush(g, (hipStream_t)stream);
   if (rc) rs[0]->err = "lde_rnn_group_backward: launch failed";
+  return rc;
+}
+
+// The grouped calls with the stacks' outputs (and output gradients) as column blocks of wider [B × ld] arrays, and a second source for
+// each output gradient: what the GOKU encoder needs to run pattern extractor → vcat → latent_in and back without a concatenation, two
+// strided copies and two additions as launches of their own (include/lde.h).
+static int rnn_ld_ok(int n, lde_rnn* const* rs, const int* lds, const char* what) {
+  for (int i = 0; i < n; i++) {
+    if (!rs[i]) return LDE_ERR_INVALID_ARG;
+    if (lds && lds[i] < rs[i]->rd.sizes[rs[i]->rd.nL]) {
+      rs[i]->err = std::string(what) + ": a row stride below the stack's output width";
+      return LDE_ERR_INVALID_ARG;
+    }
+  }
+  return LDE_OK;
+}
+int lde_rnn_group_forward_ld(int n, lde_rnn* const* rs, const float* const* xs, int T, int B, float* const* ys, const int* ldys, int train,
+                             void* stream) {
+  if (n < 1 || !rs || !xs || !ys) return LDE_ERR_INVALID_ARG;
+  int rc = rnn_ld_ok(n, rs, ldys, "lde_rnn_group_forward_ld");
+  if (rc) return rc;
+  for (int i = 0; i < n; i++) rs[i]->io_ldy = ldys ? ldys[i] : 0;
+  rc = train ? lde_rnn_group_forward_train(n, rs, xs, T, B, ys, stream) : lde_rnn_group_forward(n, rs, xs, T, B, ys, stream);
+  for (int i = 0; i < n; i++) rs[i]->io_ldy = 0;
+  return rc;
+}
+int lde_rnn_group_backward_ld(int n, lde_rnn* const* rs, const float* const* xs, const float* const* dys, const float* const* dys2,
+                              const int* lddys, int T, int B, float* const* dxs, float* const* dWs, void* stream) {
+  if (n < 1 || !rs || !xs || !dys || !dWs) return LDE_ERR_INVALID_ARG;
+  int rc = rnn_ld_ok(n, rs, lddys, "lde_rnn_group_backward_ld");
+  if (rc) return rc;
+  for (int i = 0; i < n; i++) {
+    rs[i]->io_lddy = lddys ? lddys[i] : 0;
+    rs[i]->io_dy2 = dys2 ? dys2[i] : nullptr;
+  }
+  rc = lde_rnn_group_backward(n, rs, xs, dys, T, B, dxs, dWs, stream);
+  for (int i = 0; i < n; i++) {
+    rs[i]->io_lddy = 0;
+    rs[i]->io_dy2 = nullptr;
+  }
   return rc;
 }
 

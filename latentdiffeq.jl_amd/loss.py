@@ -9,10 +9,11 @@
 
 On HIP tensors every function is one liblde.so kernel (two for the reductions) forward and one backward
 (lde_sample_* / lde_kl_* / lde_mse_*, include/lde.h): no chain of broadcast kernels, no host synchronisation. ε is drawn
-with torch.randn (the caller's generator), like the reference draws it with randn. There is no CPU path."""
+by lde_randn from the state of torch's CUDA generator (`randn` below), like the reference draws it with randn. There is no CPU path."""
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -164,9 +165,55 @@ def _same_layout(a: torch.Tensor, b: torch.Tensor):
     return a2, b2, (None if order == list(range(b.dim())) else order)
 
 
+# ---- ε --------------------------------------------------------------------------------------------------------------------------
+# lde_randn (Philox4x32-10 + Box–Muller, include/lde.h) driven by torch's CUDA generator: outside a capture every draw takes the
+# generator's (seed, offset) and advances the offset like a torch draw of the same size would — torch.manual_seed reproduces a run, other
+# torch draws interleave consistently — without launching anything but the one kernel. Inside a stream capture the host state is frozen
+# into the graph, so the draw is keyed by the state last seen outside, a per-draw call index, and a DEVICE counter read by the kernel:
+# the step count of the optimiser in the captured step (train.FluxADAMW(capturable=True) registers it) — fresh noise at every replay,
+# none of the three fill / copy launches torch's graph-safe generator puts in front of a replay. No counter registered: torch.randn.
+_NATIVE_RNG = os.environ.get("LDE_NATIVE_RNG", "1") != "0"
+_noise_epoch = {}          # device index → int64 device scalar that changes from replay to replay
+_noise_base = {}           # device index → (seed, offset) of torch's generator when last seen outside a capture
+_noise_call = [0]
+
+
+def set_noise_epoch(counter):
+    """Register (or with None, clear) the device int64 scalar that separates the replays of a captured step for `randn`."""
+    if counter is None:
+        _noise_epoch.clear()
+        return
+    if not (torch.is_tensor(counter) and counter.is_cuda and counter.dtype == torch.int64 and counter.numel() == 1):
+        raise TypeError("set_noise_epoch: an int64 scalar on the GPU")
+    _noise_epoch[counter.device.index] = counter
+
+
+def randn(shape, device) -> torch.Tensor:
+    """ε ~ N(0, 1) of the given shape on `device` (float32)."""
+    device = torch.device(device)
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    capturing = torch.cuda.is_current_stream_capturing()
+    if not _NATIVE_RNG or (capturing and (idx not in _noise_epoch or idx not in _noise_base)):
+        return torch.randn(shape, device=device, dtype=torch.float32)
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    n = out.numel()
+    lib = L.load()
+    if capturing:
+        seed, off = _noise_base[idx]
+        _noise_call[0] += 1
+        L.check(lib.lde_randn(_p(out), n, seed, off + (1 << 40), _noise_call[0], _p(_noise_epoch[idx]), None, L.raw_stream(idx)), None, "lde_randn")
+    else:
+        gen = torch.cuda.default_generators[idx]
+        seed, off = gen.initial_seed() & 0xFFFFFFFFFFFFFFFF, gen.get_offset()
+        gen.set_offset(off + 4 * ((n + 3) // 4))
+        _noise_base[idx] = (seed, off + 4 * ((n + 3) // 4))
+        L.check(lib.lde_randn(_p(out), n, seed, off, 0, None, None, L.raw_stream(idx)), None, "lde_randn")
+    return out
+
+
 def _sample1(mu, logvar):
     m, s, order = _same_layout(mu.float(), logvar.float())
-    eps = torch.randn(m.shape, device=m.device, dtype=torch.float32)
+    eps = randn(m.shape, m.device)
     out = _SampleFn.apply(m, s, eps)
     if order is not None:                        # undo the common permutation
         out = out.permute([order.index(d) for d in range(mu.dim())])
@@ -183,7 +230,7 @@ def sample(mu, logvar, model_type=None):
 def _sample_kl1(mu, logvar, scale: float, base, eps=None):
     m, s, order = _same_layout(mu.float(), logvar.float())
     if eps is None:
-        eps = torch.randn(m.shape, device=m.device, dtype=torch.float32)
+        eps = randn(m.shape, m.device)
     else:   # the caller's ε in the layout of μ (tests that compare two runs draw it once)
         eps = eps.float().permute(order) if order is not None else eps.float()
         eps = eps.contiguous()
@@ -234,3 +281,19 @@ def reconstruction_loss(x, x_hat, batch_size=None, plus=None):
     if plus is not None:
         return _MseAddFn.apply(xs, xh, 1.0 / n_mean, plus.float())
     return _MseFn.apply(xs, xh, 1.0 / n_mean)
+
+
+_ONE = {}
+
+
+def backward(loss: torch.Tensor):
+    """loss.backward() with the seed gradient 1 taken from a constant made once per device — `loss.backward()` fills a fresh
+    ones_like(loss) every call: one launch per step for a number that never changes."""
+    key = (loss.device, loss.dtype)
+    one = _ONE.get(key)
+    if one is None:
+        if loss.is_cuda and torch.cuda.is_current_stream_capturing():
+            return loss.backward()
+        one = _ONE[key] = torch.ones((), device=loss.device, dtype=loss.dtype)
+    loss.backward(gradient=one.expand_as(loss) if loss.dim() else one)
+

@@ -263,6 +263,155 @@ class _RecurrentLaunchGroupFn(torch.autograd.Function):
         return (None, dx, *dWs)
 
 
+class _GokuEncoderFn(torch.autograd.Function):
+    """(μ_z₀, μ_θ, log σ²_z₀, log σ²_θ) = latent_in(pattern_extractor(feature_extractor(x))) for GOKU as ONE autograd node (round 3) —
+    the same library calls on the same values as the separate nodes (so the same bits: tests/test_gpu_rnn.py::
+    test_fused_encoder_node_equals_separate_nodes), minus the launches autograd and the tensor plumbing put between them in a
+    training step:
+      * the two LSTM stacks write the halves of vcat(pe_forward, pe_backward) [REF src/models/GOKU.jl:47] in place
+        (lde_rnn_group_forward_ld) and read the halves of its gradient in place — no concatenation, no two strided copies;
+      * a stack's output feeds the μ head and the log σ² head [REF src/models/GOKU.jl:61-72]: the pullback of the stacks takes both
+        heads' input gradients as the two sources of its output gradient (lde_rnn_group_backward_ld) — no two additions;
+      * the frames' features feed the three stacks [REF src/models/GOKU.jl:32-51]: the feature extractor's pullback takes their three
+        input gradients as the sources of its output gradient (lde_chain_backward_saved_sum) — no two additions over [32 × B·T].
+    Seven launches of ≈ 5 µs each per step. Inputs: (fe, pes, lis), x (T·B, pixels) batch-major, then the flat weights of fe, the three
+    stacks and the four heads. Outputs batch-major: (B, ·)."""
+
+    @staticmethod
+    def forward(ctx, mods, x, *Ws):
+        fe, pes, lis, (T, B) = mods
+        if not x.is_cuda:
+            raise L.LdeError("the encoder needs CUDA/HIP tensors: it runs on the GPU only (no CPU fallback)")
+        dev = x.device
+        stream = L.raw_stream(dev.index)
+        N = T * B
+        W_fe, W_pes, W_lis = Ws[0], Ws[1:4], Ws[4:8]
+        # weights not handed over by refresh_weights() since the parameters last changed
+        h_fe = fe._native()
+        lib = fe._lib
+        if fe._wkey != L.weights_key(W_fe):
+            Wc = W_fe.detach().contiguous().float()
+            L.check(lib.lde_chain_set_weights_device(h_fe, C.c_void_p(Wc.data_ptr()), Wc.numel(), stream), h_fe, "lde_chain_set_weights_device", chain=True)
+            fe._wkey = None
+        h_pes, h_lis = [], []
+        for rec, W in zip(pes, W_pes):
+            h = rec._native()
+            if rec._wkey != L.weights_key(W):
+                Wc = W.detach().contiguous().float()
+                L.check(lib.lde_rnn_set_weights_device(h, C.c_void_p(Wc.data_ptr()), Wc.numel(), stream), h, "lde_rnn_set_weights_device", rnn=True)
+                rec._wkey = None
+            h_pes.append(h)
+        for c, W in zip(lis, W_lis):
+            h = c._native()
+            if c._wkey != L.weights_key(W):
+                Wc = W.detach().contiguous().float()
+                L.check(lib.lde_chain_set_weights_device(h, C.c_void_p(Wc.data_ptr()), Wc.numel(), stream), h, "lde_chain_set_weights_device", chain=True)
+                c._wkey = None
+            h_lis.append(h)
+        train = any(ctx.needs_input_grad[1:])
+        f32 = dict(device=dev, dtype=torch.float32)
+        # 1. the frames' features, (T, B, f) = the stacks' [f × B × T]
+        y_fe = torch.empty((N, fe.sizes[-1]), **f32)
+        sv_fe = torch.empty((int(lib.lde_chain_saved_floats(h_fe, N)),), **f32) if train else None
+        if train:
+            L.check(lib.lde_chain_forward_save(h_fe, C.c_void_p(x.data_ptr()), N, C.c_void_p(y_fe.data_ptr()), C.c_void_p(sv_fe.data_ptr()), stream),
+                    h_fe, "lde_chain_forward_save", chain=True)
+        else:
+            L.check(lib.lde_chain_forward(h_fe, C.c_void_p(x.data_ptr()), N, C.c_void_p(y_fe.data_ptr()), stream), h_fe, "lde_chain_forward", chain=True)
+        # 2. the three stacks; the θ stacks write the two column blocks of their vcat
+        hz, hf, hb = (rec.sizes[-1] for rec in pes)
+        y_z0 = torch.empty((B, hz), **f32)
+        y_th = torch.empty((B, hf + hb), **f32)
+        arr3 = lambda ptrs: (C.c_void_p * 3)(*ptrs)
+        ctx.c_pes = arr3([h.value for h in h_pes])
+        ctx.c_ld = (C.c_int32 * 3)(hz, hf + hb, hf + hb)
+        rc = lib.lde_rnn_group_forward_ld(3, ctx.c_pes, arr3([y_fe.data_ptr()] * 3), T, B,
+                                          arr3([y_z0.data_ptr(), y_th.data_ptr(), y_th.data_ptr() + 4 * hf]), ctx.c_ld, int(train), stream)
+        L.check(rc, h_pes[0], "lde_rnn_group_forward_ld", rnn=True)
+        # 3. the four heads
+        xs_li = (y_z0, y_th, y_z0, y_th)
+        outs = [torch.empty((B, c.sizes[-1]), **f32) for c in lis]
+        sv_li = [torch.empty((int(lib.lde_chain_saved_floats(h, B)),), **f32) for h in h_lis] if train else None
+        arr4 = lambda ptrs: (C.c_void_p * 4)(*ptrs)
+        ctx.c_lis = arr4([h.value for h in h_lis])
+        ctx.c_Ns = (C.c_int64 * 4)(B, B, B, B)
+        rc = lib.lde_chain_group_forward_save(4, ctx.c_lis, arr4([t.data_ptr() for t in xs_li]), ctx.c_Ns, arr4([o.data_ptr() for o in outs]),
+                                              arr4([t.data_ptr() for t in sv_li]) if train else None, stream)
+        L.check(rc, h_lis[0], "lde_chain_group_forward_save", chain=True)
+        ctx.mods, ctx.train, ctx.TB, ctx.need_dx = mods, train, (T, B), bool(ctx.needs_input_grad[1])
+        if train:
+            ctx.save_for_backward(x, y_fe, sv_fe, y_z0, y_th, *outs, *sv_li)
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        fe, pes, lis, _ = ctx.mods
+        T, B = ctx.TB
+        N = T * B
+        t = ctx.saved_tensors
+        x, y_fe, sv_fe, y_z0, y_th = t[:5]
+        outs, sv_li = t[5:9], t[9:13]
+        lib = fe._lib
+        dev = x.device
+        stream = L.raw_stream(dev.index)
+        f32 = dict(device=dev, dtype=torch.float32)
+        arr3 = lambda ptrs: (C.c_void_p * 3)(*ptrs)
+        arr4 = lambda ptrs: (C.c_void_p * 4)(*ptrs)
+        douts = [d.contiguous().float() for d in douts]
+        # 1. the heads: input gradients per head (two per stack output), weight gradients written (set_accumulate(0))
+        xs_li = (y_z0, y_th, y_z0, y_th)
+        d_li = [torch.empty_like(xi) for xi in xs_li]
+        dW_li = [torch.empty((c.num_weights,), **f32) for c in lis]
+        rc = lib.lde_chain_group_backward_saved(4, ctx.c_lis, arr4([t_.data_ptr() for t_ in xs_li]), arr4([o.data_ptr() for o in outs]),
+                                                arr4([d.data_ptr() for d in douts]), arr4([s_.data_ptr() for s_ in sv_li]), ctx.c_Ns,
+                                                arr4([d.data_ptr() for d in d_li]), arr4([d.data_ptr() for d in dW_li]), stream)
+        L.check(rc, lis[0]._native(), "lde_chain_group_backward_saved", chain=True)
+        # 2. the stacks: output gradient = μ head's + log σ² head's input gradient, the θ stacks' as column blocks of the (B, 2h) arrays
+        hf = pes[1].sizes[-1]
+        dz_a, dth_a, dz_b, dth_b = d_li
+        dxs = [torch.empty_like(y_fe) for _ in pes]
+        dW_pe = [torch.empty((rec.num_weights,), **f32) for rec in pes]
+        rc = lib.lde_rnn_group_backward_ld(3, ctx.c_pes, arr3([y_fe.data_ptr()] * 3),
+                                           arr3([dz_a.data_ptr(), dth_a.data_ptr(), dth_a.data_ptr() + 4 * hf]),
+                                           arr3([dz_b.data_ptr(), dth_b.data_ptr(), dth_b.data_ptr() + 4 * hf]), ctx.c_ld, T, B,
+                                           arr3([d.data_ptr() for d in dxs]), arr3([d.data_ptr() for d in dW_pe]), stream)
+        L.check(rc, pes[0]._native(), "lde_rnn_group_backward_ld", rnn=True)
+        # 3. the feature extractor: output gradient = the three stacks' input gradients
+        dx = torch.empty_like(x) if ctx.need_dx else None
+        dW_fe = torch.empty((fe.num_weights,), **f32)
+        if L.dw_stream is not None:
+            for dW in (dW_fe, *dW_li):
+                dW.record_stream(L.dw_stream)
+        rc = lib.lde_chain_backward_saved_sum(fe._native(), C.c_void_p(x.data_ptr()), C.c_void_p(y_fe.data_ptr()), 3, arr3([d.data_ptr() for d in dxs]),
+                                              C.c_void_p(sv_fe.data_ptr()), N, C.c_void_p(dx.data_ptr()) if dx is not None else C.c_void_p(),
+                                              C.c_void_p(dW_fe.data_ptr()), stream)
+        L.check(rc, fe._native(), "lde_chain_backward_saved_sum", chain=True)
+        return (None, dx, dW_fe, *dW_pe, *dW_li)
+
+
+_ENCODER_FUSED = os.environ.get("LDE_ENCODER_FUSED", "1") != "0"   # encode() without branch streams (what a captured step runs): the GOKU encoder as one autograd node
+
+
+def _encode_goku_fused(encoder: Encoder, x):
+    """encode() for GOKU through _GokuEncoderFn, or None when the layers are not the kinds it handles."""
+    fe, pes, lis = encoder.feature_extractor, encoder.pattern_extractor, encoder.latent_in
+    ok = (isinstance(fe, Chain) and x.dim() == 3 and x.is_cuda and isinstance(pes, (tuple, list)) and len(pes) == 3
+          and all(isinstance(m, Recurrent) for m in pes) and isinstance(lis, (tuple, list)) and len(lis) == 4
+          and all(isinstance(m, Chain) for m in lis) and len({id(m) for m in pes}) == 3 and len({id(m) for m in lis}) == 4
+          and all(m.sizes[0] == fe.sizes[-1] for m in pes)
+          and lis[0].sizes[0] == lis[1].sizes[0] == pes[0].sizes[-1]
+          and lis[2].sizes[0] == lis[3].sizes[0] == pes[1].sizes[-1] + pes[2].sizes[-1])
+    if not ok:
+        return None
+    n_in, B, T = x.shape
+    buf = x.permute(2, 1, 0).reshape(T * B, n_in).contiguous().float()       # (T·B, pixels): in place when x is a view of a (T, B, pixels) buffer
+    li_mu_z0, li_ls_z0, li_mu_th, li_ls_th = lis
+    heads = (li_mu_z0, li_mu_th, li_ls_z0, li_ls_th)                       # the order apply_latent_in issues them in
+    mu_z0, mu_th, ls_z0, ls_th = _GokuEncoderFn.apply((fe, tuple(pes), heads, (T, B)), buf, fe.flat_weights(), *[m.flat_weights() for m in pes],
+                                                      *[m.flat_weights() for m in heads])
+    return (mu_z0.t(), mu_th.t()), (ls_z0.t(), ls_th.t())
+
+
 class Recurrent(torch.nn.Module):
     """A stack of cells of one kind applied to the frames of x [in, B, T] (reverse=True: frames T..1), returning the output
     after the last frame, [h_last, B] — `[pe(x) for x in frames][end]` followed by `Flux.reset!`  [REF GOKU.jl:40-47]."""
@@ -506,6 +655,10 @@ def _encode_goku_branches(encoder: Encoder, fe_out):
 
 def encode(encoder: Encoder, x):
     """(μ, logσ²) = encoder(x)  [REF src/models/LatentDiffEqModel.jl:63-75]."""
+    if isinstance(encoder.model_type, GOKU) and _ENCODER_FUSED and not _RNN_GROUP and not _BRANCH_STREAMS and torch.is_tensor(x) and x.is_cuda:
+        out = _encode_goku_fused(encoder, x)
+        if out is not None:
+            return out
     fe_out = apply_feature_extractor(encoder, x)
     if isinstance(encoder.model_type, GOKU) and fe_out.is_cuda and _RNN_GROUP and isinstance(encoder.pattern_extractor, tuple) \
             and len(encoder.pattern_extractor) == 3 and all(isinstance(m, Recurrent) for m in encoder.pattern_extractor):

@@ -28,6 +28,7 @@ from . import _lib as L
 from .api import Decoder
 from .chain import decode, default_decoder_layers
 from .loss import reconstruction_loss, sample, sample_with_kl, vector_kl  # noqa: F401
+from .loss import backward as _loss_backward
 from .recurrent import Encoder, default_encoder_layers, encode
 
 
@@ -167,6 +168,9 @@ class FluxADAMW(torch.optim.Adam):
         if self.capturable and not self.native:
             raise ValueError("FluxADAMW(capturable=True) needs the native path")
         self._step_dev = torch.zeros((), dtype=torch.int64, device=params[0].device) if self.capturable else None
+        if self.capturable:
+            from .loss import set_noise_epoch
+            set_noise_epoch(self._step_dev)     # a captured step's ε is keyed by this counter: fresh noise at every replay (loss.randn)
 
     @torch.no_grad()
     def _native_step(self):
@@ -327,7 +331,7 @@ def train(model: LatentDiffEqModel, loader_train: Iterable, val_set, dt: float, 
             xb = time_loader(x, full_seq_len, sl, rng)
             opt.zero_grad(set_to_none=True)
             loss = loss_batch(model, xb, t, beta, variational)
-            loss.backward()
+            _loss_backward(loss)
             L.join_weight_gradients()          # no-op unless _lib.set_async_weight_gradients(True)
             if grad_sync is not None:
                 grad_sync()

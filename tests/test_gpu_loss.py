@@ -174,7 +174,7 @@ def test_torch_level_functions_match_the_oracle(o64):
     l = LS.sample(mu, ls)
     assert l.shape == mu.shape
     torch.manual_seed(9)
-    eps = torch.randn(B, 16, device="cuda")                                       # the draw sample() made (same generator state)
+    eps = LS.randn((B, 16), "cuda")                                               # the draw sample() made (same generator state)
     want_l = o64.sample_forward(m64, l64, eps.cpu().numpy().astype(np.float64))
     assert _rel(l.detach().t().cpu().numpy(), want_l) <= E_ELEM
     ct = torch.randn_like(l)
@@ -211,7 +211,7 @@ def test_sample_when_batch_equals_latent_dim(o64, B):
     torch.manual_seed(11)
     l = LS.sample(mu, ls)
     torch.manual_seed(11)
-    eps = torch.randn(B, 16, device="cuda")
+    eps = LS.randn((B, 16), "cuda")
     want = o64.sample_forward(mu_b.detach().cpu().numpy().astype(np.float64), ls_b.detach().cpu().numpy().astype(np.float64),
                               eps.cpu().numpy().astype(np.float64))
     assert l.shape == (16, B) and _rel(l.detach().t().cpu().numpy(), want) <= E_ELEM
@@ -239,3 +239,69 @@ def test_loss_errors_are_reported_not_thrown():
     assert lib.lde_mse_backward(p, p, 64, 1.0, p, null, s) == bad
     torch.cuda.synchronize()
     assert float(t.abs().max()) == 0.0
+
+
+# ---- ε: lde_randn / loss.randn (round 3) ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,seed,offset,call,epoch", [(1, 0, 0, 0, None), (4096, 0x0123456789ABCDEF, 12, 0, None), (4099, 77, (1 << 40) + 8, 3, 5),
+                                                      (10, (1 << 64) - 1, (1 << 64) - 2, (1 << 32) - 1, 9)])
+def test_randn_is_philox_and_box_muller(n, seed, offset, call, epoch):
+    """The raw words equal the numpy restatement of Philox4x32-10 (tests/philox_ref.py, pinned by the generator's known-answer vectors in
+    tests/test_philox.py) bit for bit — counter (block, call, offset + *epoch), key = seed — and the normals are Box–Muller of them
+    (f32 logf / sincospif against f64: 2e-6 of the value's scale)."""
+    import ctypes as C
+    import torch
+    from latentdiffeq_amd import _lib as L
+    from tests import philox_ref as P
+    lib = L.load()
+    out = torch.empty(n, device="cuda")
+    raw = torch.empty(n, device="cuda", dtype=torch.int32)
+    ep = torch.tensor(epoch, device="cuda", dtype=torch.int64) if epoch is not None else None
+    rc = lib.lde_randn(C.c_void_p(out.data_ptr()), n, seed, offset, call, C.c_void_p(ep.data_ptr()) if ep is not None else None,
+                       C.c_void_p(raw.data_ptr()), L.raw_stream())
+    assert rc == 0
+    torch.cuda.synchronize()
+    want = P.words(n, seed, offset, call, epoch or 0)
+    assert np.array_equal(raw.cpu().numpy().view(np.uint32), want)
+    z = P.normals(P.words(4 * ((n + 3) // 4), seed, offset, call, epoch or 0))[:n]     # (whole blocks: a pair's second word exists past n)
+    assert np.abs(out.cpu().numpy() - z).max() <= 2e-6 * max(1.0, np.abs(z).max())
+
+
+def test_randn_moments_and_generator_semantics():
+    """loss.randn: standard normal moments over 2²⁰ draws; torch.manual_seed reproduces a sequence and consecutive draws differ (the
+    draw advances torch's CUDA generator like a torch draw of its size, with no launch of its own); inside a stream capture the draw
+    is keyed by the registered device counter — a replay after the counter moved gives new noise, a replay at the same count the same."""
+    import torch
+    from latentdiffeq_amd import loss as LS
+    torch.manual_seed(5)
+    z = LS.randn((1 << 20,), "cuda")
+    m, v, k = float(z.mean()), float(z.var()), float((z ** 4).mean())
+    assert abs(m) < 4e-3 and abs(v - 1) < 6e-3 and abs(k - 3) < 0.05, (m, v, k)
+    torch.manual_seed(9)
+    a, b = LS.randn((16, 256), "cuda"), LS.randn((16, 256), "cuda")
+    t = torch.randn(8, device="cuda")                       # a torch draw in between sees an advanced generator too
+    torch.manual_seed(9)
+    a2, b2 = LS.randn((16, 256), "cuda"), LS.randn((16, 256), "cuda")
+    t2 = torch.randn(8, device="cuda")
+    assert torch.equal(a, a2) and torch.equal(b, b2) and torch.equal(t, t2) and not torch.equal(a, b)
+    keep = dict(LS._noise_epoch)
+    try:
+        cnt = torch.zeros((), device="cuda", dtype=torch.int64)
+        LS.set_noise_epoch(cnt)
+        buf = torch.zeros(2, 1000, device="cuda")
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
+                buf[0].copy_(LS.randn((1000,), "cuda"))
+                buf[1].copy_(LS.randn((1000,), "cuda"))
+        torch.cuda.current_stream().wait_stream(s)
+        g.replay(); torch.cuda.synchronize(); r0 = buf.clone()
+        g.replay(); torch.cuda.synchronize(); r0b = buf.clone()
+        cnt += 1
+        g.replay(); torch.cuda.synchronize(); r1 = buf.clone()
+        assert torch.equal(r0, r0b) and not torch.equal(r0, r1) and not torch.equal(r0[0], r0[1])
+        assert abs(float(r1.mean())) < 0.1 and abs(float(r1.var()) - 1) < 0.15
+    finally:
+        LS._noise_epoch.clear()
+        LS._noise_epoch.update(keep)

@@ -256,7 +256,8 @@ def test_branch_streams_match_joined_streams():
     fe, pe, li = R.default_encoder_layers(mt, NI, hidden_dim_resnet=40, device="cuda")
     enc = R.Encoder(mt, (fe, pe, li))
     params = [p for m in [fe, *pe, *li] for p in m.parameters()]
-    keep = R._BRANCH_STREAMS, R._RNN_GROUP, R._RNN_LAUNCH_GROUP
+    keep = R._BRANCH_STREAMS, R._RNN_GROUP, R._RNN_LAUNCH_GROUP, R._ENCODER_FUSED
+    R._ENCODER_FUSED = False     # (the one-node encoder has a test of its own below; this one is about the streams of the separate nodes)
     try:
         for it, (B, T) in enumerate([(20, 7), (64, 12), (16, 5), (33, 9), (64, 12), (256, 20)]):
             x = torch.rand(NI, B, T, device="cuda")
@@ -281,7 +282,53 @@ def test_branch_streams_match_joined_streams():
                 for a, b in zip(grouped, res[1][1]):
                     assert float((a - b).abs().max()) <= 1e-6 * float(b.abs().max()) + 1e-12, (it, B, T)
     finally:
-        R._BRANCH_STREAMS, R._RNN_GROUP, R._RNN_LAUNCH_GROUP = keep
+        R._BRANCH_STREAMS, R._RNN_GROUP, R._RNN_LAUNCH_GROUP, R._ENCODER_FUSED = keep
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_fused_encoder_node_equals_separate_nodes(dtype):
+    """encode() on one stream (what a captured step runs) two ways: feature extractor, grouped stacks, vcat, grouped heads as separate
+    autograd nodes — and recurrent._GokuEncoderFn, ONE node that makes the same library calls on the same values with the vcat written
+    in place by the stacks (lde_rnn_group_forward_ld) and the fan-out sums of the pullback formed where the next kernel reads them
+    (lde_rnn_group_backward_ld, lde_chain_backward_saved_sum). Outputs, the frames' gradient and every weight gradient: bit for bit
+    (the separate nodes add the three frame gradients as (a + b) + c, like the kernel), ragged and full tiles, f32 and bf16 chains."""
+    import torch
+    import latentdiffeq_amd as M
+    from latentdiffeq_amd import recurrent as R
+    torch.manual_seed(5)
+    NI = 64
+    mt = M.GOKU_basic()
+    fe, pe, li = R.default_encoder_layers(mt, NI, hidden_dim_resnet=48, device="cuda")
+    for m in (fe, *li):
+        m.set_dtype(dtype)
+    enc = R.Encoder(mt, (fe, pe, li))
+    params = [p for m in [fe, *pe, *li] for p in m.parameters()]
+    keep = R._BRANCH_STREAMS, R._RNN_GROUP, R._RNN_LAUNCH_GROUP, R._ENCODER_FUSED
+    try:
+        R._BRANCH_STREAMS, R._RNN_GROUP, R._RNN_LAUNCH_GROUP = False, False, True
+        for B, T in ((20, 7), (64, 12), (33, 9), (256, 50)):
+            x0 = torch.rand(T, B, NI, device="cuda")
+            cts = [torch.randn(16, B, device="cuda") for _ in range(4)]
+            res = []
+            for fused in (True, False):
+                R._ENCODER_FUSED = fused
+                for p in params:
+                    p.grad = None
+                x = x0.clone().requires_grad_(True)
+                (mz, mt_), (lz, lt) = R.encode(enc, x.permute(2, 1, 0))
+                ((mz * cts[0]).sum() + (mt_ * cts[1]).sum() + (lz * cts[2]).sum() + (lt * cts[3]).sum()).backward()
+                torch.cuda.synchronize()
+                res.append(([t.detach().clone() for t in (mz, mt_, lz, lt)], [p.grad.clone() for p in params] + [x.grad.clone()]))
+            for a, b in zip(res[0][0], res[1][0]):
+                assert torch.equal(a, b), (B, T, "outputs")
+            for i, (a, b) in enumerate(zip(res[0][1], res[1][1])):
+                assert torch.equal(a, b), (B, T, "gradient", i)
+        # the node is the one that ran
+        R._ENCODER_FUSED = True
+        (mz, _), _ = R.encode(enc, x0.permute(2, 1, 0))
+        assert "GokuEncoderFn" in type(mz.grad_fn.next_functions[0][0]).__name__
+    finally:
+        R._BRANCH_STREAMS, R._RNN_GROUP, R._RNN_LAUNCH_GROUP, R._ENCODER_FUSED = keep
 
 
 def test_launch_grouped_stacks_equal_separate_calls():

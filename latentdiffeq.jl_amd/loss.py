@@ -191,6 +191,8 @@ def set_noise_epoch(counter):
 def randn(shape, device) -> torch.Tensor:
     """ε ~ N(0, 1) of the given shape on `device` (float32)."""
     device = torch.device(device)
+    if device.type != "cuda":
+        raise L.LdeError("the loss kernels run on the GPU only (no CPU fallback)")
     idx = device.index if device.index is not None else torch.cuda.current_device()
     capturing = torch.cuda.is_current_stream_capturing()
     if not _NATIVE_RNG or (capturing and (idx not in _noise_epoch or idx not in _noise_base)):

@@ -84,6 +84,7 @@ def test_sample_layout_is_tracked_not_inferred_from_shapes(monkeypatch):
     """loss._sample1 undoes the permutation it applied even when the permutation does not change the shape ([16, 16])."""
     from latentdiffeq_amd import loss as LS
     monkeypatch.setattr(LS._SampleFn, "apply", staticmethod(lambda m, s, eps: m.clone()))     # stand-in kernel: l̃ = μ
+    monkeypatch.setattr(LS, "randn", lambda shape, device: torch.zeros(shape))                 # (ε comes from a kernel too: lde_randn)
     for B in (16, 32):
         mu_b, ls_b = torch.randn(B, 16), torch.randn(B, 16)
         mu, ls = mu_b.t(), ls_b.t()

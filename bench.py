@@ -369,7 +369,7 @@ def run_goku_step(args, torch, dist, world, rank, local):
     if os.environ.get("LDE_BENCH_GRAPH", "1") != "0":
         os.environ.setdefault("LDE_BRANCH_STREAMS", "0")   # the captured step runs on one stream (read when the package is imported)
     import latentdiffeq_amd as M
-    from latentdiffeq_amd.chain import decode, default_decoder_layers
+    from latentdiffeq_amd.chain import decode, decode_loss, default_decoder_layers
     from latentdiffeq_amd.dist import FlatGradAllReduce
     from latentdiffeq_amd.loss import reconstruction_loss, sample, sample_with_kl, vector_kl
     from latentdiffeq_amd.loss import backward as loss_backward     # loss.backward() seeded from a constant 1 (no fill launch per step)
@@ -416,8 +416,7 @@ def run_goku_step(args, torch, dist, world, rank, local):
         mu, logvar = encode(enc, x)
         if fused_loss:   # sample and β·KL of the same (μ, logσ²) in one pass, the additions folded into the reductions (train.loss_batch)
             l_tilde, bkl = sample_with_kl(mu, logvar, 1e-3, Bg)
-            x_hat, z_hat, l_hat = decode(dec, l_tilde, ts)
-            loss = reconstruction_loss(x, x_hat, Bg, plus=bkl)                            # Σ_pixels mean_{B,T} + β·KL  [REF model_train.jl:225-238]
+            loss, (x_hat, z_hat, l_hat) = decode_loss(dec, l_tilde, ts, x, Bg, plus=bkl)   # Σ_pixels mean_{B,T} + β·KL  [REF model_train.jl:225-238]
         else:
             l_tilde = sample(mu, logvar)
             x_hat, z_hat, l_hat = decode(dec, l_tilde, ts)
@@ -439,8 +438,7 @@ def run_goku_step(args, torch, dist, world, rank, local):
         opt.zero_grad(set_to_none=True)
         mu, logvar = encode(enc, x)
         l_tilde, bkl = sample_with_kl(mu, logvar, 1e-3, Bg)
-        x_hat, z_hat, l_hat = decode(dec, l_tilde, ts)
-        loss = reconstruction_loss(x, x_hat, Bg, plus=bkl)
+        loss, _ = decode_loss(dec, l_tilde, ts, x, Bg, plus=bkl)
         loss_backward(loss)
         return loss
 

@@ -281,6 +281,13 @@ int  lde_chain_backward_saved(lde_chain* c, const float* x, const float* y, cons
  * (then as lde_chain_backward). With n_dy = 1 the call IS lde_chain_backward_saved. */
 int  lde_chain_backward_saved_sum(lde_chain* c, const float* x, const float* y, int n_dy, const float* const* dys, const float* saved,
                                   int64_t N, float* dx, float* dW, void* stream);
+/* The pullback of a chain whose output y goes into base + scale·Σ (y − target)² (the reconstructor under reconstruction_loss
+ * [REF examples/pendulum_friction-less/model_train.jl:225-238]): the output gradient is 2·(g·scale)·(y − target), g = *g_dev the scalar
+ * loss's cotangent, formed where the kernel reads it — what lde_mse_backward writes as an [out×N] array for lde_chain_backward_saved to read
+ * back (the largest array of a GOKU step: one launch and 3 × 4·out·N bytes less). dy_more (or NULL): a further cotangent of y, added.
+ * Same values as the two calls, bit for bit. */
+int  lde_chain_backward_saved_mse(lde_chain* c, const float* x, const float* y, const float* target, const float* g_dev, float scale,
+                                  const float* dy_more, const float* saved, int64_t N, float* dx, float* dW, void* stream);
 /* How the pullbacks deliver the weight gradient: on = 1 (default) dW += gradient, like lde_adjoint; on = 0: dW = gradient — every
  * entry of dW is written exactly once, so a caller that wants the plain gradient needs no zero fill (one launch less). */
 int  lde_chain_set_accumulate(lde_chain* c, int on);

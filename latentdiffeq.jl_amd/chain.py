@@ -134,6 +134,80 @@ class _ChainFn(torch.autograd.Function):
         return None, dx, dW
 
 
+class _ChainMseFn(torch.autograd.Function):
+    """(loss, y) = (base + scale·Σ (y − target)², y) with y = chain(x): the reconstructor under reconstruction_loss
+    [REF examples/pendulum_friction-less/model_train.jl:225-238] as one autograd node. Forward: the calls of _ChainFn and
+    loss._MseAddFn. Pullback: lde_chain_backward_saved_mse — the loss's cotangent 2·g·scale·(y − target) is formed where the chain's
+    pullback reads its output gradient, instead of lde_mse_backward writing it as an (N, out) array for lde_chain_backward_saved to read
+    back: one launch and three passes over the largest array of a GOKU step less; the same values (tests/test_gpu_chain.py::
+    test_reconstructor_under_mse_as_one_node). A cotangent of y itself (y used elsewhere too) is added in."""
+
+    @staticmethod
+    def forward(ctx, chain: "Chain", x, W, target, scale: float, base):
+        if not x.is_cuda:
+            raise L.LdeError("Chain needs CUDA/HIP tensors: it runs on the GPU only (no CPU fallback)")
+        h = chain._native()
+        lib = chain._lib
+        stream = L.raw_stream(x.device.index)
+        if chain._wkey != L.weights_key(W):
+            Wc = W.detach().contiguous().float()
+            L.check(lib.lde_chain_set_weights_device(h, C.c_void_p(Wc.data_ptr()), Wc.numel(), stream), h, "lde_chain_set_weights_device", chain=True)
+            chain._wkey = None
+        N = x.shape[0]
+        y = torch.empty((N, chain.sizes[-1]), device=x.device, dtype=torch.float32)
+        train = bool(ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
+        saved = torch.empty((int(lib.lde_chain_saved_floats(h, N)),), device=x.device, dtype=torch.float32) if train else None
+        if train:
+            L.check(lib.lde_chain_forward_save(h, C.c_void_p(x.data_ptr()), N, C.c_void_p(y.data_ptr()), C.c_void_p(saved.data_ptr()), stream),
+                    h, "lde_chain_forward_save", chain=True)
+        else:
+            L.check(lib.lde_chain_forward(h, C.c_void_p(x.data_ptr()), N, C.c_void_p(y.data_ptr()), stream), h, "lde_chain_forward", chain=True)
+        ws = torch.empty(L.LOSS_SCRATCH_FLOATS + 1, device=x.device, dtype=torch.float32)
+        if base is not None:
+            L.check(lib.lde_mse_forward_add(C.c_void_p(target.data_ptr()), C.c_void_p(y.data_ptr()), y.numel(), scale, C.c_void_p(base.data_ptr()),
+                                            C.c_void_p(ws.data_ptr()), C.c_void_p(ws.data_ptr() + 4), stream), None, "lde_mse_forward_add")
+        else:
+            L.check(lib.lde_mse_forward(C.c_void_p(target.data_ptr()), C.c_void_p(y.data_ptr()), y.numel(), scale, C.c_void_p(ws.data_ptr()),
+                                        C.c_void_p(ws.data_ptr() + 4), stream), None, "lde_mse_forward")
+        ctx.chain, ctx.scale, ctx.has_base, ctx.need_dx, ctx.has_saved = chain, scale, base is not None, x.requires_grad, train
+        ctx.save_for_backward(x, y, saved if train else x.new_empty(0), target)
+        ctx.set_materialize_grads(False)
+        return ws[0], y
+
+    @staticmethod
+    def backward(ctx, g, dy):
+        chain = ctx.chain
+        h = chain._native()
+        lib = chain._lib
+        x, y, saved, target = ctx.saved_tensors
+        stream = L.raw_stream(x.device.index)
+        N = x.shape[0]
+        dx = torch.empty_like(x) if ctx.need_dx else None
+        dW = torch.empty((chain.num_weights,), device=x.device, dtype=torch.float32)
+        if L.dw_stream is not None:
+            dW.record_stream(L.dw_stream)
+        pdx = C.c_void_p(dx.data_ptr()) if dx is not None else C.c_void_p()
+        psv = C.c_void_p(saved.data_ptr()) if ctx.has_saved else C.c_void_p()
+        if dy is not None:
+            dy = dy.contiguous().float()
+        if g is None:          # only y was used downstream: the plain pullback
+            if dy is None:
+                dy = torch.zeros_like(y)
+            fn = lib.lde_chain_backward_saved if ctx.has_saved else None
+            if fn is not None:
+                L.check(fn(h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(dy.data_ptr()), psv, N, pdx, C.c_void_p(dW.data_ptr()), stream),
+                        h, "lde_chain_backward_saved", chain=True)
+            else:
+                L.check(lib.lde_chain_backward(h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(dy.data_ptr()), N, pdx,
+                                               C.c_void_p(dW.data_ptr()), stream), h, "lde_chain_backward", chain=True)
+            return None, dx, dW, None, None, None
+        g = g.contiguous().float()
+        L.check(lib.lde_chain_backward_saved_mse(h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(target.data_ptr()),
+                                                 C.c_void_p(g.data_ptr()), ctx.scale, C.c_void_p(dy.data_ptr()) if dy is not None else C.c_void_p(),
+                                                 psv, N, pdx, C.c_void_p(dW.data_ptr()), stream), h, "lde_chain_backward_saved_mse", chain=True)
+        return None, dx, dW, None, None, (g if ctx.has_base else None)
+
+
 class _ChainGroupFn(torch.autograd.Function):
     """(y_1, …, y_n) = (chain_1(x_1), …, chain_n(x_n)) for INDEPENDENT chains as one autograd node and — when the library can merge
     them (n ≤ 4, same dtype mode, small tiles) — one launch per stage: lde_chain_group_forward_save / _backward_saved. The heads of
@@ -333,6 +407,30 @@ def decode(decoder: Decoder, l_tilde, t):
     z_hat = diffeq_layer(decoder, l_hat, t)
     x_hat = apply_reconstructor(decoder, z_hat)
     return x_hat, z_hat, l_hat
+
+
+_RECON_MSE = os.environ.get("LDE_RECON_MSE", "1") != "0"   # decode_loss: the reconstructor and reconstruction_loss as one autograd node (diagnostic switch)
+
+
+def decode_loss(decoder: Decoder, l_tilde, t, x, batch_size=None, plus=None):
+    """(reconstruction_loss(x, x̂) [+ plus], (x̂, ẑ, l̂)) with (x̂, ẑ, l̂) = decoder(l̃, t)  [REF src/models/LatentDiffEqModel.jl:101-113],
+    [REF examples/pendulum_friction-less/model_train.jl:225-238] — `decode` followed by `loss.reconstruction_loss`, with the
+    reconstructor and the loss as ONE autograd node when the reconstructor is a Chain on HIP frames x [pixels, B, T] (_ChainMseFn)."""
+    from .loss import reconstruction_loss
+    l_hat = apply_latent_out(decoder, l_tilde)
+    z_hat = diffeq_layer(decoder, l_hat, t)
+    rec = decoder.reconstructor
+    if not (_RECON_MSE and isinstance(rec, Chain) and z_hat.dim() == 3 and z_hat.is_cuda and x.dim() == 3 and x.is_cuda):
+        x_hat = apply_reconstructor(decoder, z_hat)
+        return reconstruction_loss(x, x_hat, batch_size, plus=plus), (x_hat, z_hat, l_hat)
+    n_in, B, T = z_hat.shape
+    if x.shape[1:] != (B, T) or x.shape[0] != rec.sizes[-1]:
+        raise ValueError("decode_loss: x and the decoder's output differ in shape")
+    zb = z_hat.permute(2, 1, 0).reshape(T * B, n_in).contiguous().float()          # (T·B, D): in place when ẑ came from diffeq_layer
+    xt = x.permute(2, 1, 0).reshape(T * B, x.shape[0]).contiguous().float()       # the frames in the same (T·B, pixels) order
+    n_mean = (batch_size or B) * T
+    loss, y = _ChainMseFn.apply(rec, zb, rec.flat_weights(), xt, 1.0 / n_mean, plus.float() if plus is not None else None)
+    return loss, (y.reshape(T, B, -1).permute(2, 1, 0), z_hat, l_hat)
 
 
 def default_decoder_layers(model_type, input_dim: int, diffeq, hidden_dim_resnet: int = 200, latent_dim_z0: int = 16,

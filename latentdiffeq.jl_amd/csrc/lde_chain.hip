@@ -407,6 +407,9 @@ struct ChainBwdArgs {
   const float* saved;  // hidden activations written by lde_chain_forward_save (nullptr: recompute them)
   const float* dy2;    // lde_chain_backward_saved_sum: the output gradient is (dy + dy2) + dy3 (nullptr: absent) — the sum a caller whose
   const float* dy3;    // output feeds several consumers would otherwise form with launches of its own
+  const float* mse_t;  // lde_chain_backward_saved_mse: dy is not read; the first source of the output gradient is 2·(g·scale)·(y − mse_t),
+  const float* mse_g;  // the pullback of base + scale·Σ(y − t)² [REF model_train.jl:225-238] — formed here instead of by a launch that
+  float mse_scale;     // reads x and x̂ and writes ∂L/∂x̂ (the largest array of a GOKU step) for this kernel to read back
 };
 
 struct PrePair { f32x4 h, a; };
@@ -507,8 +510,15 @@ __device__ __forceinline__ void chain_backward_body(const ChainDims& cd, const C
         f32x4 d = {0.f, 0.f, 0.f, 0.f};
         if (n < a.N && r < out) {
           if (vec) {
-            f32x4 g = *reinterpret_cast<const f32x4*>(dyp + r);
             const f32x4 f = *reinterpret_cast<const f32x4*>(yp + r);
+            f32x4 g;
+            if (a.mse_t) {
+              const float k2 = 2.0f * (a.mse_g[0] * a.mse_scale);
+              const f32x4 t4 = *reinterpret_cast<const f32x4*>(a.mse_t + (size_t)n * out + r);
+#pragma unroll
+              for (int q = 0; q < 4; q++) g[q] = __fmul_rn(k2, f[q] - t4[q]);   // (rounded on its own: the sum with a further cotangent must not fuse it)
+            } else
+              g = *reinterpret_cast<const f32x4*>(dyp + r);
             if (a.dy2) g += *reinterpret_cast<const f32x4*>(a.dy2 + (size_t)n * out + r);
             if (a.dy3) g += *reinterpret_cast<const f32x4*>(a.dy3 + (size_t)n * out + r);
             d = cact_grad_out4(actk, f);
@@ -518,7 +528,7 @@ __device__ __forceinline__ void chain_backward_body(const ChainDims& cd, const C
 #pragma unroll
             for (int q = 0; q < 4; q++)
               if (r + q < out) {
-                float g = dyp[r + q];
+                float g = a.mse_t ? __fmul_rn(2.0f * (a.mse_g[0] * a.mse_scale), yp[r + q] - a.mse_t[(size_t)n * out + r + q]) : dyp[r + q];
                 if (a.dy2) g += a.dy2[(size_t)n * out + r + q];
                 if (a.dy3) g += a.dy3[(size_t)n * out + r + q];
                 d[q] = g * cact_grad_out(actk, yp[r + q]);
@@ -1025,6 +1035,8 @@ struct GroupRec {
   RecDw dw[GROUP_MAX];
   RecRed red[GROUP_MAX];
 };
+struct MseSrc { const float* t; const float* g; float scale; };
+static thread_local MseSrc t_mse = {nullptr, nullptr, 0.f};              // lde_chain_backward_saved_mse
 static thread_local const float* t_dy_more[2] = {nullptr, nullptr};   // lde_chain_backward_saved_sum: further sources of the output gradient
 static thread_local GroupRec* t_rec = nullptr;
 // (kernel arguments: 4 KB on this runtime)
@@ -1271,7 +1283,7 @@ static int chain_backward_b(lde_chain* c, const float* x, const float* y, const 
     c->err = "lde_chain_backward (bf16): no tile layout fits LDS for this input";
     return LDE_ERR_UNSUPPORTED;
   }
-  ChainBwdArgsB a{x, y, dy, dx, c->fragTb, c->W_dev, c->dstage, (long long)N, saved, t_dy_more[0], t_dy_more[1]};
+  ChainBwdArgsB a{x, y, dy, dx, c->fragTb, c->W_dev, c->dstage, (long long)N, saved, t_dy_more[0], t_dy_more[1], t_mse.t, t_mse.g, t_mse.scale};
   const int NC = 16 * pk.cg;
   {
     const dim3 grid((unsigned)((N + NC - 1) / NC));
@@ -1471,7 +1483,7 @@ static int chain_backward_impl(lde_chain* c, const float* x, const float* y, con
   int nvt, cap;
   int64_t total;
   chain_dw_split(c, pk.cg, N, &nvt, &cap, &total);
-  ChainBwdArgs a{x, y, dy, dx, c->frag, c->fragT, c->W_dev, c->stage, c->wts, (long long)N, saved, t_dy_more[0], t_dy_more[1]};
+  ChainBwdArgs a{x, y, dy, dx, c->frag, c->fragT, c->W_dev, c->stage, c->wts, (long long)N, saved, t_dy_more[0], t_dy_more[1], t_mse.t, t_mse.g, t_mse.scale};
   const int NC = 16 * pk.cg;
   const dim3 grid((unsigned)((N + NC - 1) / NC));
   static bool attr[2][3] = {{false, false, false}, {false, false, false}};
@@ -1592,6 +1604,21 @@ int lde_chain_backward_saved_sum(lde_chain* c, const float* x, const float* y, i
   t_dy_more[1] = n_dy > 2 ? dys[2] : nullptr;
   const int rc = saved ? lde_chain_backward_saved(c, x, y, dys[0], saved, N, dx, dW, stream) : lde_chain_backward(c, x, y, dys[0], N, dx, dW, stream);
   t_dy_more[0] = t_dy_more[1] = nullptr;
+  return rc;
+}
+
+int lde_chain_backward_saved_mse(lde_chain* c, const float* x, const float* y, const float* target, const float* g_dev, float scale,
+                                 const float* dy_more, const float* saved, int64_t N, float* dx, float* dW, void* stream) {
+  if (!c) return LDE_ERR_INVALID_ARG;
+  if (!target || !g_dev || (((uintptr_t)target) & 15) != 0 || (dy_more && (((uintptr_t)dy_more) & 15) != 0)) {
+    c->err = "lde_chain_backward_saved_mse: NULL or unaligned target / cotangent";
+    return LDE_ERR_INVALID_ARG;
+  }
+  t_mse = MseSrc{target, g_dev, scale};
+  t_dy_more[0] = dy_more;
+  const int rc = saved ? lde_chain_backward_saved(c, x, y, target, saved, N, dx, dW, stream) : lde_chain_backward(c, x, y, target, N, dx, dW, stream);
+  t_mse = MseSrc{nullptr, nullptr, 0.f};
+  t_dy_more[0] = nullptr;
   return rc;
 }
 

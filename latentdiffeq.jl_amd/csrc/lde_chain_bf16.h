@@ -363,6 +363,9 @@ struct ChainBwdArgsB {
   const __bf16* saved;  // hidden activations written by k_chain_forward_b
   const float* dy2;     // the output gradient is (dy + dy2) + dy3 (nullptr: absent), as in ChainBwdArgs
   const float* dy3;
+  const float* mse_t;   // as in ChainBwdArgs: the first source is 2·(g·scale)·(y − mse_t) instead of dy
+  const float* mse_g;
+  float mse_scale;
 };
 
 struct PreH { f32x4 h; };
@@ -413,7 +416,21 @@ __device__ __forceinline__ void chain_backward_b_body(const ChainDims& cd, const
       const float* yp = a.y + (size_t)n * out + 8 * ch;
       bf16x8 d;
       if (vec && 8 * ch + 8 <= out) {
-        f32x4 g0 = *reinterpret_cast<const f32x4*>(dyp), g1 = *reinterpret_cast<const f32x4*>(dyp + 4);
+        const f32x4 f0 = *reinterpret_cast<const f32x4*>(yp), f1 = *reinterpret_cast<const f32x4*>(yp + 4);
+        f32x4 g0, g1;
+        if (a.mse_t) {
+          const float k2 = 2.0f * (a.mse_g[0] * a.mse_scale);
+          const float* tp = a.mse_t + (size_t)n * out + 8 * ch;
+          const f32x4 t0 = *reinterpret_cast<const f32x4*>(tp), t1 = *reinterpret_cast<const f32x4*>(tp + 4);
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            g0[q] = __fmul_rn(k2, f0[q] - t0[q]);
+            g1[q] = __fmul_rn(k2, f1[q] - t1[q]);
+          }
+        } else {
+          g0 = *reinterpret_cast<const f32x4*>(dyp);
+          g1 = *reinterpret_cast<const f32x4*>(dyp + 4);
+        }
         if (a.dy2) {
           const float* q2 = a.dy2 + (size_t)n * out + 8 * ch;
           g0 += *reinterpret_cast<const f32x4*>(q2);
@@ -424,7 +441,6 @@ __device__ __forceinline__ void chain_backward_b_body(const ChainDims& cd, const
           g0 += *reinterpret_cast<const f32x4*>(q3);
           g1 += *reinterpret_cast<const f32x4*>(q3 + 4);
         }
-        const f32x4 f0 = *reinterpret_cast<const f32x4*>(yp), f1 = *reinterpret_cast<const f32x4*>(yp + 4);
         const f32x4 a0 = cact_grad_out4(actk, f0), a1 = cact_grad_out4(actk, f1);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
@@ -436,7 +452,7 @@ __device__ __forceinline__ void chain_backward_b_body(const ChainDims& cd, const
         for (int q = 0; q < 8; q++) {
           float g = 0.f;
           if (8 * ch + q < out) {
-            g = dyp[q];
+            g = a.mse_t ? __fmul_rn(2.0f * (a.mse_g[0] * a.mse_scale), yp[q] - a.mse_t[(size_t)n * out + 8 * ch + q]) : dyp[q];
             if (a.dy2) g += a.dy2[(size_t)n * out + 8 * ch + q];
             if (a.dy3) g += a.dy3[(size_t)n * out + 8 * ch + q];
             g *= cact_grad_out(actk, yp[q]);

@@ -26,7 +26,7 @@ import torch
 
 from . import _lib as L
 from .api import Decoder
-from .chain import decode, default_decoder_layers
+from .chain import decode, decode_loss, default_decoder_layers
 from .loss import reconstruction_loss, sample, sample_with_kl, vector_kl  # noqa: F401
 from .loss import backward as _loss_backward
 from .recurrent import Encoder, default_encoder_layers, encode
@@ -88,8 +88,8 @@ def loss_batch(model, x, t, beta: float, variational: bool, batch_size: Optional
         # reductions (loss.sample_with_kl): encoder → (l̃, β·kl) → decoder → reconstruction_loss + β·kl
         mu, logvar = encode(model.encoder, x)
         l_tilde, bkl = sample_with_kl(mu, logvar, beta, batch_size)
-        x_hat, _z, _l = decode(model.decoder, l_tilde, t)
-        return reconstruction_loss(x, x_hat, batch_size, plus=bkl)
+        loss, _ = decode_loss(model.decoder, l_tilde, t, x, batch_size, plus=bkl)     # (the reconstructor and the loss as one autograd node)
+        return loss
     (x_hat, _z, _l), mu, logvar = model(x, t, variational)
     return reconstruction_loss(x, x_hat, batch_size) + beta * vector_kl(mu, logvar, batch_size)
 

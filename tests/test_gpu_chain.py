@@ -318,6 +318,53 @@ def test_torch_bridge_takes_the_training_variant():
 
 
 @pytest.mark.parametrize("dtype", ["f32", "bf16"])
+def test_reconstructor_under_mse_as_one_node(dtype):
+    """chain.decode_loss: the reconstructor and reconstruction_loss (+ the β·KL term) as ONE autograd node whose pullback forms the loss's
+    cotangent 2·g·scale·(x̂ − x) where the chain's pullback reads its output gradient (lde_chain_backward_saved_mse) — against `decode`
+    followed by `reconstruction_loss` (lde_mse_backward writes that array, lde_chain_backward_saved reads it back): the loss and every
+    gradient bit for bit, f32 and bf16 chains, full and ragged tiles, a loss cotangent other than 1, and x̂ used a second time downstream
+    (its own cotangent is then added in the kernel instead of by autograd)."""
+    import torch
+    import latentdiffeq_amd as la
+    from latentdiffeq_amd import chain as CH
+    from latentdiffeq_amd.loss import reconstruction_loss
+    torch.manual_seed(4)
+    mt, diffeq = la.GOKU_basic(), la.Pendulum()
+    NI = 96
+    lo, de, rec = CH.default_decoder_layers(mt, NI, diffeq, device="cuda", hidden_dim_resnet=56)
+    with torch.no_grad():
+        lo[1]._dense[-1].bias.fill_(1.0)
+    rec.set_dtype(dtype)
+    dec = la.Decoder(mt, (lo, de, rec))
+    params = [p for m in (*lo, rec) for p in m.parameters()]
+    keep = CH._RECON_MSE
+    try:
+        for B, T, second_use in ((24, 12, False), (64, 50, False), (33, 9, True)):
+            ts = np.arange(T) * 0.05
+            x = torch.rand(T, B, NI, device="cuda").permute(2, 1, 0)
+            l0 = (torch.randn(16, B, device="cuda"), torch.randn(16, B, device="cuda"))
+            plus0 = torch.tensor(0.37, device="cuda")
+            w2 = torch.randn(NI, B, T, device="cuda")
+            res = []
+            for fused in (True, False):
+                CH._RECON_MSE = fused
+                for p in params:
+                    p.grad = None
+                lt = tuple(t_.clone().requires_grad_(True) for t_ in l0)
+                plus = plus0.clone().requires_grad_(True)
+                loss, (x_hat, z_hat, _) = CH.decode_loss(dec, lt, ts, x, 4 * B, plus=plus)
+                total = 1.7 * loss + ((x_hat * w2).sum() if second_use else 0.0)
+                total.backward()
+                torch.cuda.synchronize()
+                res.append((loss.detach().clone(), x_hat.detach().clone(), [p.grad.clone() for p in params] + [t_.grad.clone() for t_ in lt] + [plus.grad.clone()]))
+            assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), (B, T)
+            for i, (a, b) in enumerate(zip(res[0][2], res[1][2])):
+                assert torch.equal(a, b), (B, T, second_use, i)
+    finally:
+        CH._RECON_MSE = keep
+
+
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
 def test_grouped_chains_equal_separate_calls(dtype):
     """lde_chain_group_forward_save / _backward_saved (chain.apply_chains_grouped): independent chains as ONE autograd node, one launch
     per stage when the library can merge them — the reference's apply_latent_in heads and apply_latent_out chains. Per chain the same

@@ -404,6 +404,17 @@ int lde_refresh_weights(int n, const int* kinds, void* const* handles, const flo
  * `call` separates the draws of one step, `offset` the steps of an eager loop. raw_words (NULL, or n words): the Philox output itself
  * (what the known-answer vectors of the generator are stated in; tests). */
 int lde_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, uint32_t call, const int64_t* epoch_dev, uint32_t* raw_words, void* stream);
+/* The variational sample of the GOKU tuple (z₀, θ) [REF src/models/GOKU.jl:155-163] in one launch each way: forward = lde_randn(eps_a),
+ * lde_sample_kl_forward(part a, base), lde_randn(eps_b), lde_sample_kl_forward(part b, base = the first total) — the same device code in
+ * the same order, bit for bit; ε is written to eps_a / eps_b for the pullback. Parts of 1 … 8192 entries (LDE_ERR_UNSUPPORTED otherwise:
+ * make the separate calls). scratch: 2 floats. backward = the two lde_sample_kl_backward calls. */
+int lde_sample_kl_pair_forward(const float* mu_a, const float* logvar_a, int64_t n_a, float scale_a, const float* mu_b, const float* logvar_b,
+                               int64_t n_b, float scale_b, const float* base, uint64_t seed, uint64_t offset_a, uint64_t offset_b, uint32_t call_a,
+                               uint32_t call_b, const int64_t* epoch_dev, float* eps_a, float* eps_b, float* l_a, float* l_b, float* out,
+                               float* scratch, void* stream);
+int lde_sample_kl_pair_backward(const float* mu_a, const float* logvar_a, const float* eps_a, const float* dl_a, int64_t n_a, float scale_a,
+                                const float* mu_b, const float* logvar_b, const float* eps_b, const float* dl_b, int64_t n_b, float scale_b,
+                                const float* dout, float* dmu_a, float* dlogvar_a, float* dmu_b, float* dlogvar_b, void* stream);
 int lde_sample_forward(const float* mu, const float* logvar, const float* eps, int64_t n, float* l, void* stream);
 /* dμ = dl (not written: it is the input); dlogvar_i = dl_i · ε_i · exp(logσ²_i/2) / 2 */
 int lde_sample_backward(const float* logvar, const float* eps, const float* dl, int64_t n, float* dlogvar, void* stream);

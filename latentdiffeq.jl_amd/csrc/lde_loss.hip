@@ -50,15 +50,14 @@ __device__ __forceinline__ float kl_term(float m, float lv) { return 0.5f * (__e
 
 // TERM 0: kl(a = μ, b = logσ²); TERM 1: (a − b)²; TERM 2: kl(a, b) and, in the same pass, the sample l = a + c·exp(b/2) → l
 template <int TERM>
-__global__ void __launch_bounds__(LOSS_WG) k_loss_partial(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
-                                                          float* __restrict__ scratch, const float* __restrict__ c = nullptr,
-                                                          float* __restrict__ l = nullptr, float fscale = 0.f, float* __restrict__ fout = nullptr,
-                                                          const float* __restrict__ fbase = nullptr) {
+__device__ __forceinline__ void loss_partial_body(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                                  float* __restrict__ scratch, const float* __restrict__ c, float* __restrict__ l, float fscale,
+                                                  float* __restrict__ fout, const float* __restrict__ fbase, const unsigned bx, const unsigned nblk) {
   // workgroup w owns the slice [w·per, (w+1)·per) with per a multiple of 4 floats
-  const int64_t nwg = gridDim.x;
+  const int64_t nwg = nblk;
   int64_t per = (n + nwg - 1) / nwg;
   per = (per + 3) & ~(int64_t)3;
-  const int64_t lo = (int64_t)blockIdx.x * per;
+  const int64_t lo = (int64_t)bx * per;
   int64_t hi = lo + per;
   if (hi > n) hi = n;
   float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
@@ -90,7 +89,7 @@ __global__ void __launch_bounds__(LOSS_WG) k_loss_partial(const float* __restric
     }
   const float s = wg_sum((s0 + s1) + (s2 + s3));
   if (threadIdx.x == 0) {
-    scratch[blockIdx.x] = s;
+    scratch[bx] = s;
     if (fout) {   // a one-workgroup sum (n ≤ 8192: the KL terms of a training step) is its own last kernel: what k_loss_final computes from
                   // one partial, with the same separately rounded product and addition — one launch instead of two
 #pragma clang fp contract(off)
@@ -98,6 +97,13 @@ __global__ void __launch_bounds__(LOSS_WG) k_loss_partial(const float* __restric
       fout[0] = fbase ? fbase[0] + term : term;
     }
   }
+}
+template <int TERM>
+__global__ void __launch_bounds__(LOSS_WG) k_loss_partial(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
+                                                          float* __restrict__ scratch, const float* __restrict__ c = nullptr,
+                                                          float* __restrict__ l = nullptr, float fscale = 0.f, float* __restrict__ fout = nullptr,
+                                                          const float* __restrict__ fbase = nullptr) {
+  loss_partial_body<TERM>(a, b, n, scratch, c, l, fscale, fout, fbase, blockIdx.x, gridDim.x);
 }
 
 // out = scale·Σ partials (+ base[0]: a running total of loss terms — the elementwise additions of the loss expression folded in)
@@ -125,14 +131,14 @@ __device__ __forceinline__ void loss_map1(float a, float b, float c, float k, fl
   else o0 = 2.0f * k * (b - a);
 }
 
-__global__ void __launch_bounds__(LOSS_WG) k_sample_kl_bwd(const float* __restrict__ mu, const float* __restrict__ lv,
-                                                           const float* __restrict__ eps, const float* __restrict__ dl,
-                                                           const float* __restrict__ g, float scale, int64_t n,
-                                                           float* __restrict__ dmu, float* __restrict__ dlv) {
+__device__ __forceinline__ void sample_kl_bwd_body(const float* __restrict__ mu, const float* __restrict__ lv,
+                                                   const float* __restrict__ eps, const float* __restrict__ dl,
+                                                   const float* __restrict__ g, float scale, int64_t n,
+                                                   float* __restrict__ dmu, float* __restrict__ dlv, const unsigned bx, const unsigned nblk) {
   const float k = g[0] * scale;
   const bool al = ((((uintptr_t)mu) | ((uintptr_t)lv) | ((uintptr_t)eps) | ((uintptr_t)dl) | ((uintptr_t)dmu) | ((uintptr_t)dlv)) & 15) == 0;
-  const int64_t stride = 4 * (int64_t)gridDim.x * LOSS_WG;
-  int64_t i = 4 * ((int64_t)blockIdx.x * LOSS_WG + threadIdx.x);
+  const int64_t stride = 4 * (int64_t)nblk * LOSS_WG;
+  int64_t i = 4 * ((int64_t)bx * LOSS_WG + threadIdx.x);
   auto one = [&](float m, float v, float e, float d, float& om, float& ov) {
 #pragma clang fp contract(off)   // the two parts rounded as the separate kernels round them, then plainly added
     float t0, t1, u0, u1 = 0.f;
@@ -159,6 +165,18 @@ __global__ void __launch_bounds__(LOSS_WG) k_sample_kl_bwd(const float* __restri
   }
   for (; i < n; i += stride)
     for (int q = 0; q < 4 && i + q < n; q++) one(mu[i + q], lv[i + q], eps[i + q], dl[i + q], dmu[i + q], dlv[i + q]);
+}
+__global__ void __launch_bounds__(LOSS_WG) k_sample_kl_bwd(const float* __restrict__ mu, const float* __restrict__ lv,
+                                                           const float* __restrict__ eps, const float* __restrict__ dl,
+                                                           const float* __restrict__ g, float scale, int64_t n,
+                                                           float* __restrict__ dmu, float* __restrict__ dlv) {
+  sample_kl_bwd_body(mu, lv, eps, dl, g, scale, n, dmu, dlv, blockIdx.x, gridDim.x);
+}
+// two parts (the GOKU tuple (z₀, θ) [REF src/models/GOKU.jl:155-163]) in one launch: workgroups [0, nblk_a) the first, the rest the second
+struct SampleBwdPart { const float* mu; const float* lv; const float* eps; const float* dl; float scale; long long n; float* dmu; float* dlv; };
+__global__ void __launch_bounds__(LOSS_WG) k_sample_kl_bwd_pair(SampleBwdPart pa, SampleBwdPart pb, const float* __restrict__ g, unsigned nblk_a) {
+  if (blockIdx.x < nblk_a) sample_kl_bwd_body(pa.mu, pa.lv, pa.eps, pa.dl, g, pa.scale, pa.n, pa.dmu, pa.dlv, blockIdx.x, nblk_a);
+  else sample_kl_bwd_body(pb.mu, pb.lv, pb.eps, pb.dl, g, pb.scale, pb.n, pb.dmu, pb.dlv, blockIdx.x - nblk_a, gridDim.x - nblk_a);
 }
 
 template <int OP>
@@ -240,9 +258,8 @@ __device__ __forceinline__ void philox4x32_10(unsigned c0, unsigned c1, unsigned
   }
   o[0] = c0; o[1] = c1; o[2] = c2; o[3] = c3;
 }
-__global__ void __launch_bounds__(256) k_randn(float* __restrict__ out, long long n, unsigned long long seed, unsigned long long offset,
-                                                unsigned call, const long long* __restrict__ epoch, unsigned* __restrict__ raw) {
-  const long long blk = (long long)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void randn_block(float* __restrict__ out, long long n, unsigned long long seed, unsigned long long offset,
+                                            unsigned call, const long long* __restrict__ epoch, unsigned* __restrict__ raw, const long long blk) {
   if (4 * blk >= n) return;
   const unsigned long long off = offset + (epoch ? (unsigned long long)*epoch : 0ull);
   unsigned w[4];
@@ -264,6 +281,29 @@ __global__ void __launch_bounds__(256) k_randn(float* __restrict__ out, long lon
       out[4 * blk + q] = z[q];
       if (raw) raw[4 * blk + q] = w[q];
     }
+}
+__global__ void __launch_bounds__(256) k_randn(float* __restrict__ out, long long n, unsigned long long seed, unsigned long long offset,
+                                                unsigned call, const long long* __restrict__ epoch, unsigned* __restrict__ raw) {
+  randn_block(out, n, seed, offset, call, epoch, raw, (long long)blockIdx.x * 256 + threadIdx.x);
+}
+
+// The variational sample of a GOKU step in ONE launch: ε of both latent parts, l̃ = μ + ε·exp(logσ²/2) and the running total
+// base + scale_a·Σ kl_a + scale_b·Σ kl_b — what lde_randn, lde_sample_kl_forward, lde_randn, lde_sample_kl_forward compute one after the
+// other (four launches of ≈ 5 µs on 16 × B numbers), by the same device code in the same order: the same bits. One workgroup; parts of at
+// most LOSS_CHUNK entries (a part that size is one workgroup in the separate calls too).
+struct SampleFwdPart { const float* mu; const float* lv; float* eps; float* l; float scale; long long n; unsigned long long offset; unsigned call; };
+constexpr int PAIR_WG = 1024;   // ε (ten Philox rounds and a Box–Muller pair per four numbers) by sixteen waves; the sums by the first four, as in the separate kernels
+__global__ void __launch_bounds__(PAIR_WG) k_sample_kl_pair(SampleFwdPart pa, SampleFwdPart pb, unsigned long long seed, const long long* __restrict__ epoch,
+                                                            const float* __restrict__ base, float* __restrict__ out, float* __restrict__ scratch) {
+  for (long long blk = threadIdx.x; 4 * blk < pa.n; blk += PAIR_WG) randn_block(pa.eps, pa.n, seed, pa.offset, pa.call, epoch, nullptr, blk);
+  for (long long blk = threadIdx.x; 4 * blk < pb.n; blk += PAIR_WG) randn_block(pb.eps, pb.n, seed, pb.offset, pb.call, epoch, nullptr, blk);
+  __syncthreads();   // (the workgroup's own global stores, read back below: drained and visible)
+  const bool summing = threadIdx.x < LOSS_WG;   // wave-uniform; the other waves keep the barrier count of loss_partial_body (one, in wg_sum)
+  if (summing) loss_partial_body<2>(pa.mu, pa.lv, pa.n, scratch, pa.eps, pa.l, pa.scale, out, base, 0u, 1u);
+  else __syncthreads();
+  __syncthreads();   // wg_sum's staging is reused; thread 0 wrote out[0] and reads it as the second part's base
+  if (summing) loss_partial_body<2>(pb.mu, pb.lv, pb.n, scratch + 1, pb.eps, pb.l, pb.scale, out, out, 0u, 1u);
+  else __syncthreads();
 }
 
 }  // namespace lde
@@ -318,6 +358,31 @@ int lde_sample_kl_backward(const float* mu, const float* logvar, const float* ep
 int lde_mse_backward(const float* x, const float* xhat, int64_t n, float scale, const float* dout, float* dxhat, void* stream) {
   if (n > 0 && (!x || !xhat || !dout || !dxhat)) return LDE_ERR_INVALID_ARG;
   return loss_map<3>(x, xhat, nullptr, dout, scale, n, dxhat, nullptr, stream);
+}
+
+int lde_sample_kl_pair_forward(const float* mu_a, const float* logvar_a, int64_t n_a, float scale_a, const float* mu_b, const float* logvar_b,
+                               int64_t n_b, float scale_b, const float* base, uint64_t seed, uint64_t offset_a, uint64_t offset_b, uint32_t call_a,
+                               uint32_t call_b, const int64_t* epoch_dev, float* eps_a, float* eps_b, float* l_a, float* l_b, float* out,
+                               float* scratch, void* stream) {
+  if (n_a < 1 || n_b < 1 || n_a > LOSS_CHUNK || n_b > LOSS_CHUNK) return LDE_ERR_UNSUPPORTED;   // the caller makes the separate calls
+  if (!mu_a || !logvar_a || !mu_b || !logvar_b || !eps_a || !eps_b || !l_a || !l_b || !out || !scratch) return LDE_ERR_INVALID_ARG;
+  const SampleFwdPart pa{mu_a, logvar_a, eps_a, l_a, scale_a, (long long)n_a, (unsigned long long)offset_a, (unsigned)call_a};
+  const SampleFwdPart pb{mu_b, logvar_b, eps_b, l_b, scale_b, (long long)n_b, (unsigned long long)offset_b, (unsigned)call_b};
+  hipLaunchKernelGGL(k_sample_kl_pair, dim3(1), dim3(PAIR_WG), 0, (hipStream_t)stream, pa, pb, (unsigned long long)seed, (const long long*)epoch_dev, base,
+                     out, scratch);
+  return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
+}
+int lde_sample_kl_pair_backward(const float* mu_a, const float* logvar_a, const float* eps_a, const float* dl_a, int64_t n_a, float scale_a,
+                                const float* mu_b, const float* logvar_b, const float* eps_b, const float* dl_b, int64_t n_b, float scale_b,
+                                const float* dout, float* dmu_a, float* dlogvar_a, float* dmu_b, float* dlogvar_b, void* stream) {
+  if (n_a < 1 || n_b < 1) return LDE_ERR_UNSUPPORTED;
+  if (!mu_a || !logvar_a || !eps_a || !dl_a || !mu_b || !logvar_b || !eps_b || !dl_b || !dout || !dmu_a || !dlogvar_a || !dmu_b || !dlogvar_b)
+    return LDE_ERR_INVALID_ARG;
+  const SampleBwdPart pa{mu_a, logvar_a, eps_a, dl_a, scale_a, (long long)n_a, dmu_a, dlogvar_a};
+  const SampleBwdPart pb{mu_b, logvar_b, eps_b, dl_b, scale_b, (long long)n_b, dmu_b, dlogvar_b};
+  const unsigned ga = (unsigned)map_grid(n_a), gb = (unsigned)map_grid(n_b);   // each part's grid as in lde_sample_kl_backward
+  hipLaunchKernelGGL(k_sample_kl_bwd_pair, dim3(ga + gb), dim3(LOSS_WG), 0, (hipStream_t)stream, pa, pb, dout, ga);
+  return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
 }
 
 int lde_randn(float* out, int64_t n, uint64_t seed, uint64_t offset, uint32_t call, const int64_t* epoch_dev, uint32_t* raw_words, void* stream) {

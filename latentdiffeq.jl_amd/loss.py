@@ -188,29 +188,91 @@ def set_noise_epoch(counter):
     _noise_epoch[counter.device.index] = counter
 
 
+def _draw_key(n: int, idx: int):
+    """(seed, offset, call, epoch pointer) of the next draw of n numbers on device idx, or None when torch.randn has to make it (the
+    switch is off, or a capture without a registered counter). Advances the generator state like the draw."""
+    capturing = torch.cuda.is_current_stream_capturing()
+    if not _NATIVE_RNG or (capturing and (idx not in _noise_epoch or idx not in _noise_base)):
+        return None
+    if capturing:
+        seed, off = _noise_base[idx]
+        _noise_call[0] += 1
+        return seed, (off + (1 << 40)) & 0xFFFFFFFFFFFFFFFF, _noise_call[0], _p(_noise_epoch[idx])
+    gen = torch.cuda.default_generators[idx]
+    seed, off = gen.initial_seed() & 0xFFFFFFFFFFFFFFFF, gen.get_offset()
+    gen.set_offset(off + 4 * ((n + 3) // 4))
+    _noise_base[idx] = (seed, off + 4 * ((n + 3) // 4))
+    return seed, off, 0, None
+
+
 def randn(shape, device) -> torch.Tensor:
     """ε ~ N(0, 1) of the given shape on `device` (float32)."""
     device = torch.device(device)
     if device.type != "cuda":
         raise L.LdeError("the loss kernels run on the GPU only (no CPU fallback)")
     idx = device.index if device.index is not None else torch.cuda.current_device()
+    out = torch.empty(shape, device=device, dtype=torch.float32)
+    key = _draw_key(out.numel(), idx)
+    if key is None:
+        return torch.randn(shape, device=device, dtype=torch.float32)
+    seed, off, call, ep = key
+    L.check(L.load().lde_randn(_p(out), out.numel(), seed, off, call, ep, None, L.raw_stream(idx)), None, "lde_randn")
+    return out
+
+
+class _SampleKlPairFn(torch.autograd.Function):
+    """((l̃_a, l̃_b), total) for the two parts of the GOKU tuple in ONE launch each way (lde_sample_kl_pair_forward / _backward): ε of both
+    parts drawn inside the kernel with the keys `randn` would have used, the samples, and base + scale_a·Σ kl_a + scale_b·Σ kl_b. The same
+    device code in the same order as randn → _SampleKlFn → randn → _SampleKlFn: the same bits
+    (tests/test_gpu_loss.py::test_sample_pair_equals_the_separate_calls)."""
+
+    @staticmethod
+    def forward(ctx, mu_a, lv_a, mu_b, lv_b, scale_a, scale_b, keys):
+        lib = L.load()
+        (seed, off_a, call_a, ep), (_, off_b, call_b, _) = keys
+        eps_a, eps_b, l_a, l_b = torch.empty_like(mu_a), torch.empty_like(mu_b), torch.empty_like(mu_a), torch.empty_like(mu_b)
+        ws = torch.empty(3, device=mu_a.device, dtype=torch.float32)          # [0]: the total, then two partial sums
+        L.check(lib.lde_sample_kl_pair_forward(_p(mu_a), _p(lv_a), mu_a.numel(), scale_a, _p(mu_b), _p(lv_b), mu_b.numel(), scale_b, C.c_void_p(),
+                                               seed, off_a, off_b, call_a, call_b, ep, _p(eps_a), _p(eps_b), _p(l_a), _p(l_b), _p(ws),
+                                               C.c_void_p(ws.data_ptr() + 4), _stream()), None, "lde_sample_kl_pair_forward")
+        ctx.save_for_backward(mu_a, lv_a, eps_a, mu_b, lv_b, eps_b)
+        ctx.scales = (scale_a, scale_b)
+        return l_a, l_b, ws[0]
+
+    @staticmethod
+    def backward(ctx, dl_a, dl_b, g):
+        mu_a, lv_a, eps_a, mu_b, lv_b, eps_b = ctx.saved_tensors
+        dl_a, dl_b, g = dl_a.contiguous(), dl_b.contiguous(), g.contiguous().float()
+        dmu_a, dlv_a, dmu_b, dlv_b = torch.empty_like(mu_a), torch.empty_like(lv_a), torch.empty_like(mu_b), torch.empty_like(lv_b)
+        L.check(L.load().lde_sample_kl_pair_backward(_p(mu_a), _p(lv_a), _p(eps_a), _p(dl_a), mu_a.numel(), ctx.scales[0], _p(mu_b), _p(lv_b),
+                                                     _p(eps_b), _p(dl_b), mu_b.numel(), ctx.scales[1], _p(g), _p(dmu_a), _p(dlv_a), _p(dmu_b),
+                                                     _p(dlv_b), _stream()), None, "lde_sample_kl_pair_backward")
+        return dmu_a, dlv_a, dmu_b, dlv_b, None, None, None
+
+
+_SAMPLE_PAIR = os.environ.get("LDE_SAMPLE_PAIR", "1") != "0"   # sample_with_kl of a two-part tuple: one launch each way (diagnostic switch)
+_PAIR_MAX = 8192                                                # entries per part (one workgroup of the separate kernels)
+
+
+def _sample_kl_pair(mu, logvar, beta, batch_size):
+    """The two-part tuple through _SampleKlPairFn, or None when the parts are not what it handles."""
+    if not (_SAMPLE_PAIR and len(mu) == 2 and all(torch.is_tensor(t) and t.is_cuda for t in (*mu, *logvar))):
+        return None
+    lay = [_same_layout(m.float(), s.float()) for m, s in zip(mu, logvar)]
+    if any(not 1 <= m.numel() <= _PAIR_MAX for m, _, _ in lay):
+        return None
+    dev = lay[0][0].device
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
     capturing = torch.cuda.is_current_stream_capturing()
     if not _NATIVE_RNG or (capturing and (idx not in _noise_epoch or idx not in _noise_base)):
-        return torch.randn(shape, device=device, dtype=torch.float32)
-    out = torch.empty(shape, device=device, dtype=torch.float32)
-    n = out.numel()
-    lib = L.load()
-    if capturing:
-        seed, off = _noise_base[idx]
-        _noise_call[0] += 1
-        L.check(lib.lde_randn(_p(out), n, seed, off + (1 << 40), _noise_call[0], _p(_noise_epoch[idx]), None, L.raw_stream(idx)), None, "lde_randn")
-    else:
-        gen = torch.cuda.default_generators[idx]
-        seed, off = gen.initial_seed() & 0xFFFFFFFFFFFFFFFF, gen.get_offset()
-        gen.set_offset(off + 4 * ((n + 3) // 4))
-        _noise_base[idx] = (seed, off + 4 * ((n + 3) // 4))
-        L.check(lib.lde_randn(_p(out), n, seed, off, 0, None, None, L.raw_stream(idx)), None, "lde_randn")
-    return out
+        return None
+    keys = (_draw_key(lay[0][0].numel(), idx), _draw_key(lay[1][0].numel(), idx))      # in the order the separate calls draw
+    scales = [float(beta / (batch_size or m.shape[1])) for m in mu]
+    l_a, l_b, total = _SampleKlPairFn.apply(lay[0][0], lay[0][1], lay[1][0], lay[1][1], scales[0], scales[1], keys)
+    outs = []
+    for l, (_, _, order), m in zip((l_a, l_b), lay, mu):
+        outs.append(l.permute([order.index(d) for d in range(m.dim())]) if order is not None else l)
+    return tuple(outs), total
 
 
 def _sample1(mu, logvar):
@@ -247,6 +309,10 @@ def sample_with_kl(mu, logvar, beta: float = 1.0, batch_size=None, eps=None):
     each way per part instead of a sample pass, a KL pass and the additions of their cotangents)  [REF src/models/GOKU.jl:155-163],
     [REF src/utils/utils.jl:15-49]. For the GOKU tuple the second part's total continues the first's."""
     if isinstance(mu, tuple):
+        if eps is None:
+            pair = _sample_kl_pair(mu, logvar, beta, batch_size)
+            if pair is not None:
+                return pair
         outs, total = [], None
         for i, (m, s) in enumerate(zip(mu, logvar)):
             o, total = _sample_kl1(m, s, beta / (batch_size or m.shape[1]), total, None if eps is None else eps[i])

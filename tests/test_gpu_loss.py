@@ -305,3 +305,33 @@ def test_randn_moments_and_generator_semantics():
     finally:
         LS._noise_epoch.clear()
         LS._noise_epoch.update(keep)
+
+
+@pytest.mark.parametrize("B", [1, 37, 256, 512])
+def test_sample_pair_equals_the_separate_calls(B):
+    """sample_with_kl of the GOKU tuple: one launch each way (lde_sample_kl_pair_*: both parts' ε, samples and the running KL total) against
+    the separate calls (randn, sample+KL, randn, sample+KL; two pullbacks) from the same generator state — samples, total and every
+    gradient bit for bit; the generator ends in the same state."""
+    import torch
+    from latentdiffeq_amd import loss as LS
+    torch.manual_seed(12)
+    raw = [torch.randn(B, 16, device="cuda") for _ in range(4)]
+    cts = [torch.randn(16, B, device="cuda") for _ in range(2)]
+    res = []
+    keep = LS._SAMPLE_PAIR
+    try:
+        for pair in (True, False):
+            LS._SAMPLE_PAIR = pair
+            leaves = [t.clone().requires_grad_(True) for t in raw]
+            mu, ls = (leaves[0].t(), leaves[1].t()), (0.5 * leaves[2].t(), 0.5 * leaves[3].t())
+            torch.manual_seed(21)
+            (la, lb), total = LS.sample_with_kl(mu, ls, 0.7, 4 * B)
+            after = torch.randn(4, device="cuda")
+            ((la * cts[0]).sum() + (lb * cts[1]).sum() + 1.3 * total).backward()
+            torch.cuda.synchronize()
+            res.append([la.detach().clone(), lb.detach().clone(), total.detach().clone(), after] + [t.grad.clone() for t in leaves])
+    finally:
+        LS._SAMPLE_PAIR = keep
+    for i, (a, b) in enumerate(zip(*res)):
+        assert torch.equal(a, b), (B, i)
+    assert res[0][0].shape == (16, B)

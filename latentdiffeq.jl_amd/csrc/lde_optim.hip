@@ -38,14 +38,25 @@ __device__ __forceinline__ void adam1(float& x, float g, float& m, float& v, con
 }
 
 // `step_dev` != nullptr: the step count t lives in device memory (a captured hipGraph replays the SAME kernel arguments every step, so
-// the bias corrections 1/(1 − βᵗ) cannot travel in them): every thread derives them from *step_dev, which k_adam_tick advanced.
-__global__ void k_adam_tick(int64_t* step_dev) { *step_dev += 1; }
-
-__global__ void __launch_bounds__(OPT_WG) k_adamw_flux(OptTable tab, OptCoef c, const int64_t* __restrict__ step_dev) {
+// the bias corrections 1/(1 − βᵗ) cannot travel in them): every thread derives them from t = *step_dev + 1, and the count is advanced
+// by the update kernel itself (`bump`, the step's last launch) — by the last workgroup to have READ it: each workgroup counts itself
+// in behind a barrier, i.e. after all of its waves hold t. (Until round 3 a one-thread kernel in front of the update did it: one more
+// launch per training step.)
+__device__ unsigned g_adam_seen = 0;
+__global__ void k_adam_tick(int64_t* step_dev) { *step_dev += 1; }   // (a step over empty arrays only)
+__global__ void __launch_bounds__(OPT_WG) k_adamw_flux(OptTable tab, OptCoef c, int64_t* __restrict__ step_dev, int bump) {
   if (step_dev) {
-    const double t = (double)*step_dev;
+    const int64_t ti = *step_dev + 1;
+    const double t = (double)ti;
     c.inv_bc1 = (float)(1.0 / (1.0 - pow((double)c.b1, t)));
     c.inv_bc2 = (float)(1.0 / (1.0 - pow((double)c.b2, t)));
+    if (bump) {
+      __syncthreads();
+      if (threadIdx.x == 0 && atomicAdd(&g_adam_seen, 1u) == gridDim.x - 1) {
+        *step_dev = ti;
+        g_adam_seen = 0;
+      }
+    }
   }
   int i = 0;
   while (i + 1 < tab.n && (int)blockIdx.x >= tab.blk0[i + 1]) i++;
@@ -86,10 +97,7 @@ static int adamw_impl(int n, const lde_adam_tensor* t, float lr, float beta1, fl
   c.b1 = beta1; c.b2 = beta2; c.omb1 = 1.0f - beta1; c.omb2 = 1.0f - beta2; c.eps = eps; c.lr = lr; c.decay = decay;
   c.inv_bc1 = (float)(1.0 / (1.0 - __builtin_pow((double)beta1, (double)(step_dev ? 1 : step))));   // Flux carries β₁ᵗ, β₂ᵗ as a running product
   c.inv_bc2 = (float)(1.0 / (1.0 - __builtin_pow((double)beta2, (double)(step_dev ? 1 : step))));
-  if (step_dev) {
-    hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
-    if (hipGetLastError() != hipSuccess) return LDE_ERR_HIP;
-  }
+  bool launched = false;
   for (int first = 0; first < n;) {
     OptTable tab;
     tab.n = 0;
@@ -109,8 +117,15 @@ static int adamw_impl(int n, const lde_adam_tensor* t, float lr, float beta1, fl
       if (first < n) return LDE_ERR_INVALID_ARG;   // a single array beyond 2³⁰ workgroups
       break;
     }
+    launched = true;
     tab.blk0[tab.n] = blk;
-    hipLaunchKernelGGL(k_adamw_flux, dim3(blk), dim3(OPT_WG), 0, (hipStream_t)stream, tab, c, (const int64_t*)step_dev);
+    bool more = false;   // another launch follows? (only the step's last one advances the count)
+    for (int j = first; j < n; j++) more = more || t[j].n > 0;
+    hipLaunchKernelGGL(k_adamw_flux, dim3(blk), dim3(OPT_WG), 0, (hipStream_t)stream, tab, c, step_dev, (step_dev && !more) ? 1 : 0);
+    if (hipGetLastError() != hipSuccess) return LDE_ERR_HIP;
+  }
+  if (step_dev && !launched) {
+    hipLaunchKernelGGL(k_adam_tick, dim3(1), dim3(1), 0, (hipStream_t)stream, step_dev);
     if (hipGetLastError() != hipSuccess) return LDE_ERR_HIP;
   }
   return LDE_OK;

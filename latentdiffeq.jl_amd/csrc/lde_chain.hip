@@ -617,6 +617,7 @@ using namespace lde;
 struct lde_chain {
   bool accumulate = true;   // pullback: dW += gradient (default) or dW = gradient
   bool bf16 = false;        // lde_chain_set_dtype: the native bf16 path (lde_chain_bf16.h): bf16 weight fragments, panels, saved activations, δ
+  bool frag_stale = false;   // lde_refresh_weights rebuilt only the bf16 fragments (bf16 mode): the f32 ones are rebuilt from W_dev if the mode goes back
   __bf16* fragb = nullptr;  // bf16 K = 32 fragment copies of W / Wᵀ, rebuilt with the f32 ones
   __bf16* fragTb = nullptr;
   BfDims bd, bdx;           // bf16 layouts (bdx: the panel-free wide-input layout)
@@ -843,6 +844,7 @@ static int chain_frags(lde_chain* c, const float* src, hipStream_t stream) {
     return LDE_ERR_HIP;
   }
   c->have_W = true;
+  c->frag_stale = false;
   return LDE_OK;
 }
 
@@ -884,7 +886,8 @@ int lde_refresh_weights(int n, const int* kinds, void* const* handles, const flo
       lde_chain* c = (lde_chain*)handles[m];
       if (!c->W_dev || !c->dm_dev) return LDE_ERR_INVALID_ARG;
       for (int l = 0; l < c->cd.dm.nL; l++)
-        jobs.push_back(RefreshJob{flat_dev[m], flat_dev[m] == c->W_dev ? nullptr : c->W_dev, c->frag, c->fragT, c->dm_dev, l, 0, c->fragb, c->fragTb});
+        jobs.push_back(RefreshJob{flat_dev[m], flat_dev[m] == c->W_dev ? nullptr : c->W_dev, c->bf16 ? nullptr : c->frag, c->bf16 ? nullptr : c->fragT,
+                                  c->dm_dev, l, 0, c->fragb, c->fragTb});   // (a bf16 chain reads bf16 fragments only: half the hand-over's work)
     } else if (kinds[m] == LDE_MODULE_RNN) {
       float* dst = nullptr;
       int64_t nw = 0;
@@ -913,7 +916,11 @@ int lde_refresh_weights(int n, const int* kinds, void* const* handles, const flo
     if (hipGetLastError() != hipSuccess) return LDE_ERR_HIP;
   }
   for (int m = 0; m < n; m++)
-    if (kinds[m] == LDE_MODULE_CHAIN) ((lde_chain*)handles[m])->have_W = true;
+    if (kinds[m] == LDE_MODULE_CHAIN) {
+      lde_chain* c = (lde_chain*)handles[m];
+      c->have_W = true;
+      c->frag_stale = c->bf16;
+    }
   return LDE_OK;
 }
 
@@ -1559,6 +1566,11 @@ static int chain_backward_impl(lde_chain* c, const float* x, const float* y, con
 int lde_chain_set_dtype(lde_chain* c, int dtype) {
   if (!c || (dtype != LDE_DTYPE_F32 && dtype != LDE_DTYPE_BF16)) return LDE_ERR_INVALID_ARG;
   c->bf16 = dtype == LDE_DTYPE_BF16;
+  if (!c->bf16 && c->frag_stale && c->have_W) {   // rare: back to f32 after hand-overs that skipped the f32 fragments
+    const int rc = chain_frags(c, c->W_dev, nullptr);
+    if (rc || hipStreamSynchronize(nullptr) != hipSuccess) return rc ? rc : LDE_ERR_HIP;
+  }
+  c->frag_stale = false;
   return LDE_OK;
 }
 int lde_chain_forward(lde_chain* c, const float* x, int64_t N, float* y, void* stream) {

@@ -149,6 +149,7 @@ __device__ inline void build_frags_layer(const float* __restrict__ Wflat, const 
     for (int e = lo + first; e < hi; e += stride) keep[e] = Wflat[e];
   }
   const float* W = Wflat + dm.w_off[l];  // column-major [out×in]: W(o,i) at o + out*i
+  if (!frag) return;                     // (lde_refresh_weights for a chain in bf16 mode: its f32 fragments are not read)
   {
     const int KG = cdiv(in, 16), n = dm.frag_n[l];
     for (int e = first; e < n; e += stride) {

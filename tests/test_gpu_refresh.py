@@ -96,3 +96,30 @@ def test_refresh_weights_rejects_bad_arguments():
     assert lib.lde_refresh_weights(1, kinds, handles, ptrs, None) == -1          # null handle
     assert lib.lde_refresh_weights(0, None, None, None, None) == 0
     assert lib.lde_refresh_weights(-1, None, None, None, None) == -1
+
+
+def test_handover_in_bf16_mode_skips_the_f32_fragments_and_a_switch_back_rebuilds_them():
+    """lde_refresh_weights for a chain in bf16 mode rebuilds its bf16 fragments only (round 3: half the hand-over's work in a mixed-precision
+    step); lde_chain_set_dtype back to f32 rebuilds the f32 fragments from the handle's copy of the weights — the f32 forward after
+    hand-over + switch equals the f32 forward of a fresh handle given the same weights."""
+    import torch
+    from latentdiffeq_amd import _lib as L
+    from latentdiffeq_amd.chain import Chain, Dense, SkipConnection
+    torch.manual_seed(8)
+    mk = lambda: Chain(Dense(24, 40, "relu"), SkipConnection(Dense(40, 40, "relu")), Dense(40, 12, "sigmoid")).to("cuda")
+    c = mk()
+    x = torch.randn(24, 96, device="cuda")
+    c.set_dtype("bf16")
+    y_b0 = c(x).clone()
+    with torch.no_grad():
+        c.theta.mul_(1.5).add_(0.01)                    # an optimiser step's worth of change
+    torch.autograd.graph.increment_version(c.theta)
+    assert L.refresh_weights([c]) == 1                  # hand-over in bf16 mode
+    y_b1 = c(x).clone()
+    assert not torch.equal(y_b0, y_b1)                  # the bf16 fragments are the new weights'
+    c.set_dtype("f32")                                  # … and now the f32 ones must be too
+    y_f = c(x).clone()
+    fresh = mk()
+    with torch.no_grad():
+        fresh.theta.copy_(c.theta)
+    assert torch.equal(y_f, fresh(x))

@@ -668,7 +668,8 @@ static size_t chain_lds(const ChainDims& cd, int cg, int npanels) {
 static size_t chain_lds_b(const ChainDims& cd, const BfDims& bd, int cg, bool bwd) {
   const size_t NC = 16 * cg;
   if (bwd) return NC * bd.ldb * 2 * 2 + NC * bd.ldg * 4;
-  return (2 + (bd.fpanel ? 1 : 0)) * NC * bd.ldb * 2 + (size_t)((cd.dm.nbias + 3) & ~3) * 4;   // the input panel shares the second panel's space
+  return (2 + (bd.fpanel ? 1 : 0)) * NC * bd.ldb * 2 + (size_t)((cd.dm.nbias + 3) & ~3) * 4   // the input panel shares the second panel's space
+         + ((cd.gx && (LDE_BF_XSTAGE != 0)) ? chain_xs_bytes(cg) : 0);                                 // wide input: the first layer's chunk buffers
 }
 
 // lde_rnn.hip: where lde_refresh_weights copies a recurrent stack's flat weights to (marks the handle as holding weights)

@@ -28,6 +28,9 @@
 #ifndef LDE_BF_PFA
 #define LDE_BF_PFA 2
 #endif
+#ifndef LDE_BF_XSTAGE
+#define LDE_BF_XSTAGE 1   // the wide-input first layer's operand staged through LDS by all waves (chain_gemm_b_gx); 0: every wave loads it (BSRC 1)
+#endif
 #ifndef LDE_BF_OCC
 #define LDE_BF_OCC 4      // __launch_bounds__' second argument = waves per SIMD: 4 = two 512-thread workgroups per CU
 #endif
@@ -189,6 +192,103 @@ __device__ __forceinline__ void chain_gemm_b(const __bf16* __restrict__ gfrag, i
 }
 struct NoHook { __device__ __forceinline__ void operator()() const {} };
 
+// First layer of a wide-input chain (the encoder's 784-pixel frames): Y[R × 16·CG] = M[R×K] · bf16(x) with the tile's columns of the
+// caller's f32 x[n][K] staged through LDS in K-chunks of XKC by ALL waves — each float is read from global memory once per workgroup
+// (16-byte loads, a column's chunk is 512 contiguous bytes), rounded once, and every wave's MFMAs read it from LDS. (BSRC 1 of
+// chain_gemm_b: every wave loads and rounds the whole operand itself — eight times the L1/L2 requests and the conversions, a global
+// round trip per K-group in each wave's K loop: the feature extractor's forward took 55 µs where the reconstructor's, which writes as
+// many bytes as this one reads, took 37.) Two chunk buffers; one barrier per chunk: the next chunk's global loads are issued before the
+// current chunk's MFMAs and written to the other buffer behind them. A chunk past the row's end reads the row's last floats instead
+// (finite values against zero weights, as in BSRC 1). Same products on the same rounded operands in the same order: the same bits.
+constexpr int XKC = 128, XLD = XKC + 16;      // chunk and its LDS row stride (elements; ≡ 16 mod 64 like every bf16 panel)
+__host__ __device__ inline size_t chain_xs_bytes(int cg) { return (size_t)2 * 16 * cg * XLD * 2; }
+template <int CG, class Epi, class Hook>
+__device__ __forceinline__ void chain_gemm_b_gx(const __bf16* __restrict__ gfrag, int R, int K, const float* __restrict__ xg, __bf16* XS, Epi epi,
+                                                Hook hook) {
+  constexpr int NW = 8, NC = 16 * CG, KGC = XKC / 32, PFA = KGC, NIT = (NC * (XKC / 8) + 511) / 512;   // the A ring holds one chunk: its refills are consumed a whole chunk later, behind the staging wait
+  const int lane = threadIdx.x & 63, tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int RT = cdiv(R, 16), KG = cdiv(K, 32), kl = KG - 1, NCH = cdiv(K, XKC);
+  const bf16x8* A = reinterpret_cast<const bf16x8*>(gfrag) + lane;
+  const int col = lane & 15, rsub = 4 * (lane >> 4), lg8 = 8 * (lane >> 4);
+  const int npass = cdiv(RT, 2 * NW);
+  f32x4 st[NIT][2];
+  auto gload = [&](int ch) {   // this thread's eight floats of chunk ch (column e / 16, floats 8·(e % 16) … of the chunk)
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int e = tid + 512 * it;
+      if (NC * (XKC / 8) % 512 != 0 && e >= NC * (XKC / 8)) continue;
+      const int c = e / (XKC / 8), sg = e % (XKC / 8);
+      int k = ch * XKC + 8 * sg;
+      if (k + 8 > K) k = K - 8;
+      const float* p = xg + (size_t)c * K + k;
+      st[it][0] = *reinterpret_cast<const f32x4*>(p);
+      st[it][1] = *reinterpret_cast<const f32x4*>(p + 4);
+    }
+  };
+  auto sput = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < NIT; it++) {
+      const int e = tid + 512 * it;
+      if (NC * (XKC / 8) % 512 != 0 && e >= NC * (XKC / 8)) continue;
+      const int c = e / (XKC / 8), sg = e % (XKC / 8);
+      const bf16x4 bl = to_bf4(st[it][0]), bh = to_bf4(st[it][1]);
+      *reinterpret_cast<bf16x8*>(XS + buf * NC * XLD + c * XLD + 8 * sg) = bf16x8{bl[0], bl[1], bl[2], bl[3], bh[0], bh[1], bh[2], bh[3]};
+    }
+  };
+  bool hooked = false;
+  for (int p = 0; p < npass; p++) {
+    const int rt = 2 * NW * p + wave, rt2 = rt + NW;
+    const bool va = rt < RT, vb = rt2 < RT;   // wave-uniform
+    const bf16x8* A0 = A + (size_t)(va ? rt : 0) * KG * 64;
+    const bf16x8* A1 = A + (size_t)(vb ? rt2 : (va ? rt : 0)) * KG * 64;
+    bf16x8 ra0[PFA], ra1[PFA];
+#pragma unroll
+    for (int i = 0; i < PFA; i++) {
+      ra0[i] = A0[min(i, kl) * 64];
+      ra1[i] = A1[min(i, kl) * 64];
+    }
+    gload(0);
+    if (!hooked) { hook(); hooked = true; }
+    if (p > 0) __syncthreads();   // the previous pass's last chunk is still being read
+    sput(0);
+    __syncthreads();
+    f32x4 acc0[CG], acc1[CG];
+#pragma unroll
+    for (int cg = 0; cg < CG; cg++) acc0[cg] = acc1[cg] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int ch = 0; ch < NCH; ch++) {
+      if (ch + 1 < NCH) gload(ch + 1);
+      const __bf16* xb = XS + (ch & 1) * NC * XLD + col * XLD + lg8;
+#pragma unroll
+      for (int kgl = 0; kgl < KGC; kgl++) {
+        const int kg = ch * KGC + kgl;
+        if (kg < KG && va) {
+          const bf16x8 c0 = ra0[kgl % PFA], c1 = ra1[kgl % PFA];
+          if (kg + PFA < KG) {
+            ra0[kgl % PFA] = A0[(kg + PFA) * 64];
+            ra1[kgl % PFA] = A1[(kg + PFA) * 64];
+          }
+#pragma unroll
+          for (int cg = 0; cg < CG; cg++) {
+            const bf16x8 b = *reinterpret_cast<const bf16x8*>(xb + cg * 16 * XLD + kgl * 32);
+            acc0[cg] = mfma32_b(c0, b, acc0[cg]);
+            if (vb) acc1[cg] = mfma32_b(c1, b, acc1[cg]);
+          }
+        }
+      }
+      if (ch + 1 < NCH) sput((ch + 1) & 1);
+      __syncthreads();
+    }
+    if (va) {
+#pragma unroll
+      for (int cg = 0; cg < CG; cg++) {
+        epi(rt * 16 + rsub, cg, col, acc0[cg], NoPre{});
+        if (vb) epi(rt2 * 16 + rsub, cg, col, acc1[cg], NoPre{});
+      }
+    }
+  }
+}
+
 struct ChainFwdArgsB {
   const float* x;
   float* y;
@@ -242,12 +342,11 @@ __device__ __forceinline__ void copy_panel_out_b(const __bf16* panel, int ld, in
 // Nothing goes to global memory here: the saved-activation matrices are written from the panels, coalesced, by the NEXT product's hook.
 template <int CG, int BSRC, class Hook>
 __device__ __forceinline__ void chain_hidden_layer_b(const ChainDims& cd, const BfDims& bd, int l, const __bf16* fragb, const float* biasc,
-                                                     const void* Xin, int ldx, __bf16* Y, __bf16* F, Hook hook) {
+                                                     const void* Xin, int ldx, __bf16* Y, __bf16* F, Hook hook, __bf16* XS = nullptr) {
   const MlpDims& dm = cd.dm;
   const int in = dm.sizes[l], out = dm.sizes[l + 1], actk = cd.act[l], skip = BSRC == 1 ? 0 : cd.skip[l], ldh = bd.ldb;
   const float* bias = biasc + dm.bias_lin[l];
-  chain_gemm_b<CG, BSRC>(fragb + bf_frag_off(dm, l, false), out, in, Xin, ldx, 16L * ldx, [](int, int, int) { return NoPre{}; },
-                         [&](int row0, int cg, int col, f32x4 v, NoPre) {
+  auto epi =             [&](int row0, int cg, int col, f32x4 v, NoPre) {
                            const int c = cg * 16 + col;
                            const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + min(row0, ((out + 3) & ~3) - 4));   // (bias blocks are padded to 4; rows beyond `out` are masked below)
                            f32x4 r = cact4(actk, v + b4);
@@ -258,8 +357,9 @@ __device__ __forceinline__ void chain_hidden_layer_b(const ChainDims& cd, const 
                              r += from_bf4(*reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(Xin) + c * ldx + row0));
                            }
                            *reinterpret_cast<bf16x4*>(Y + c * ldh + row0) = to_bf4(r);
-                         },
-                         hook);
+                         };
+  if (BSRC == 1 && XS) chain_gemm_b_gx<CG>(fragb + bf_frag_off(dm, l, false), out, in, reinterpret_cast<const float*>(Xin), XS, epi, hook);
+  else chain_gemm_b<CG, BSRC>(fragb + bf_frag_off(dm, l, false), out, in, Xin, ldx, 16L * ldx, [](int, int, int) { return NoPre{}; }, epi, hook);
 }
 
 template <int CG>
@@ -277,6 +377,8 @@ __device__ __forceinline__ void chain_forward_b_body(const ChainDims& cd, const 
   for (int l = 0; l + 1 < nL; l++) any_skip = any_skip || cd.skip[l];
   __bf16* F = (a.saved && any_skip && bd.fpanel) ? H1 + NC * ldh : nullptr;
   float* biasc = reinterpret_cast<float*>(H1 + NC * ldh + (bd.fpanel ? NC * ldh : 0));
+  // wide input: the chunk buffers of the first layer's staged operand (chain_gemm_b_gx) behind the biases; K ≥ 8 and 16-byte rows
+  __bf16* XS = (cd.gx && (LDE_BF_XSTAGE != 0) && dm.sizes[0] >= 8 && dm.sizes[0] % 4 == 0) ? reinterpret_cast<__bf16*>(biasc + ((dm.nbias + 3) & ~3)) : nullptr;
   int dup;
   const long long n0 = chain_tile_start(cd, NC, a.N, &dup, bx);
   PROF_T(pc0);
@@ -302,7 +404,7 @@ __device__ __forceinline__ void chain_forward_b_body(const ChainDims& cd, const 
     __bf16* Y = (l & 1) ? H1 : H0;
     PROF_T(pl0);
     auto hook = [&]() { save_prev(l - 1); };
-    if (l == 0 && cd.gx) chain_hidden_layer_b<CG, 1>(cd, bd, 0, a.fragb, biasc, xg, dm.sizes[0], Y, F, hook);
+    if (l == 0 && cd.gx) chain_hidden_layer_b<CG, 1>(cd, bd, 0, a.fragb, biasc, xg, dm.sizes[0], Y, F, hook, XS);
     else chain_hidden_layer_b<CG, 0>(cd, bd, l, a.fragb, biasc, Xin, ldx, Y, F, hook);
     PROF_T(pl1);
     __syncthreads();

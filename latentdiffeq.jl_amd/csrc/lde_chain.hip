@@ -667,7 +667,7 @@ static size_t chain_lds(const ChainDims& cd, int cg, int npanels) {
 // skip-gradient panel) kernels
 static size_t chain_lds_b(const ChainDims& cd, const BfDims& bd, int cg, bool bwd) {
   const size_t NC = 16 * cg;
-  if (bwd) return NC * bd.ldb * 2 * 2 + NC * bd.ldg * 4;
+  if (bwd) return NC * bd.ldb * 2 * 2 + NC * bd.ldg * 4 + ((LDE_BF_XSTAGE_BWD != 0) ? chain_xs_bytes(cg, XKC_BWD) : 0);
   return (2 + (bd.fpanel ? 1 : 0)) * NC * bd.ldb * 2 + (size_t)((cd.dm.nbias + 3) & ~3) * 4   // the input panel shares the second panel's space
          + ((cd.gx && (LDE_BF_XSTAGE != 0)) ? chain_xs_bytes(cg) : 0);                                 // wide input: the first layer's chunk buffers
 }

@@ -31,6 +31,11 @@
 #ifndef LDE_BF_XSTAGE
 #define LDE_BF_XSTAGE 1   // the wide-input first layer's operand staged through LDS by all waves (chain_gemm_b_gx); 0: every wave loads it (BSRC 1)
 #endif
+#ifndef LDE_BF_XSTAGE_BWD
+#define LDE_BF_XSTAGE_BWD 0   // the same staging for the pullback's first product (W_Lᵀ·δ_L, K = the chain's output width). Measured slower: the
+                              // reconstructor's pullback kernel 58 → 69 µs with 64-wide chunks (13 barriers per tile, 31 spilled registers at the
+                              // 128-register budget), and with 128-wide chunks the tile no longer fits two workgroups per CU (73 µs at 16 columns)
+#endif
 #ifndef LDE_BF_OCC
 #define LDE_BF_OCC 4      // __launch_bounds__' second argument = waves per SIMD: 4 = two 512-thread workgroups per CU
 #endif
@@ -200,11 +205,16 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // many bytes as this one reads, took 37.) Two chunk buffers; one barrier per chunk: the next chunk's global loads are issued before the
 // current chunk's MFMAs and written to the other buffer behind them. A chunk past the row's end reads the row's last floats instead
 // (finite values against zero weights, as in BSRC 1). Same products on the same rounded operands in the same order: the same bits.
-constexpr int XKC = 128, XLD = XKC + 16;      // chunk and its LDS row stride (elements; ≡ 16 mod 64 like every bf16 panel)
-__host__ __device__ inline size_t chain_xs_bytes(int cg) { return (size_t)2 * 16 * cg * XLD * 2; }
-template <int CG, class Epi, class Hook>
-__device__ __forceinline__ void chain_gemm_b_gx(const __bf16* __restrict__ gfrag, int R, int K, const float* __restrict__ xg, __bf16* XS, Epi epi,
-                                                Hook hook) {
+constexpr int XKC = 128, XKC_BWD = 64;        // chunk of the forward's first layer / of the pullback's first product (whose LDS is fuller); the LDS row
+                                              // stride is the chunk + 16 elements (≡ 16 mod 64 like every bf16 panel)
+__host__ __device__ inline size_t chain_xs_bytes(int cg, int kc = XKC) { return (size_t)2 * 16 * cg * (kc + 16) * 2; }
+// SrcT float: the caller's f32 x[n][ldx] (rounded here); SrcT __bf16: a [n][ldx] bf16 matrix as it stands — the pullback's δ_L, which
+// the same workgroup has just written (BSRC 2 of chain_gemm_b read it back per wave the same way).
+template <int CG, int XKC, class SrcT, class Pre, class Epi, class Hook>
+__device__ __forceinline__ void chain_gemm_b_gx(const __bf16* __restrict__ gfrag, int R, int K, const SrcT* __restrict__ xg, int ldx, __bf16* XS,
+                                                Pre pre, Epi epi, Hook hook) {
+  constexpr bool F32 = sizeof(SrcT) == 4;
+  constexpr int XLD = XKC + 16;
   constexpr int NW = 8, NC = 16 * CG, KGC = XKC / 32, PFA = KGC, NIT = (NC * (XKC / 8) + 511) / 512;   // the A ring holds one chunk: its refills are consumed a whole chunk later, behind the staging wait
   const int lane = threadIdx.x & 63, tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -212,18 +222,19 @@ __device__ __forceinline__ void chain_gemm_b_gx(const __bf16* __restrict__ gfrag
   const bf16x8* A = reinterpret_cast<const bf16x8*>(gfrag) + lane;
   const int col = lane & 15, rsub = 4 * (lane >> 4), lg8 = 8 * (lane >> 4);
   const int npass = cdiv(RT, 2 * NW);
-  f32x4 st[NIT][2];
-  auto gload = [&](int ch) {   // this thread's eight floats of chunk ch (column e / 16, floats 8·(e % 16) … of the chunk)
+  f32x4 st[NIT][F32 ? 2 : 1];   // (bf16 source: one 16-byte load, kept as it is)
+  const int klast = (ldx < ((K + 7) & ~7) ? ldx : ((K + 7) & ~7)) - 8;   // the last whole 8-group inside the row
+  auto gload = [&](int ch) {   // this thread's eight entries of chunk ch (column e / 16, entries 8·(e % 16) … of the chunk)
 #pragma unroll
     for (int it = 0; it < NIT; it++) {
       const int e = tid + 512 * it;
       if (NC * (XKC / 8) % 512 != 0 && e >= NC * (XKC / 8)) continue;
       const int c = e / (XKC / 8), sg = e % (XKC / 8);
       int k = ch * XKC + 8 * sg;
-      if (k + 8 > K) k = K - 8;
-      const float* p = xg + (size_t)c * K + k;
+      if (k > klast) k = klast;
+      const SrcT* p = xg + (size_t)c * ldx + k;
       st[it][0] = *reinterpret_cast<const f32x4*>(p);
-      st[it][1] = *reinterpret_cast<const f32x4*>(p + 4);
+      if (F32) st[it][F32 ? 1 : 0] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p) + 4);
     }
   };
   auto sput = [&](int buf) {
@@ -232,10 +243,15 @@ __device__ __forceinline__ void chain_gemm_b_gx(const __bf16* __restrict__ gfrag
       const int e = tid + 512 * it;
       if (NC * (XKC / 8) % 512 != 0 && e >= NC * (XKC / 8)) continue;
       const int c = e / (XKC / 8), sg = e % (XKC / 8);
-      const bf16x4 bl = to_bf4(st[it][0]), bh = to_bf4(st[it][1]);
-      *reinterpret_cast<bf16x8*>(XS + buf * NC * XLD + c * XLD + 8 * sg) = bf16x8{bl[0], bl[1], bl[2], bl[3], bh[0], bh[1], bh[2], bh[3]};
+      __bf16* dst = XS + buf * NC * XLD + c * XLD + 8 * sg;
+      if (F32) {
+        const bf16x4 bl = to_bf4(st[it][0]), bh = to_bf4(st[it][F32 ? 1 : 0]);
+        *reinterpret_cast<bf16x8*>(dst) = bf16x8{bl[0], bl[1], bl[2], bl[3], bh[0], bh[1], bh[2], bh[3]};
+      } else
+        *reinterpret_cast<f32x4*>(dst) = st[it][0];
     }
   };
+  typedef decltype(pre(0, 0, 0)) PreT;
   bool hooked = false;
   for (int p = 0; p < npass; p++) {
     const int rt = 2 * NW * p + wave, rt2 = rt + NW;
@@ -247,6 +263,12 @@ __device__ __forceinline__ void chain_gemm_b_gx(const __bf16* __restrict__ gfrag
     for (int i = 0; i < PFA; i++) {
       ra0[i] = A0[min(i, kl) * 64];
       ra1[i] = A1[min(i, kl) * 64];
+    }
+    PreT p0[CG], p1[CG];
+#pragma unroll
+    for (int cg = 0; cg < CG; cg++) {
+      p0[cg] = pre((va ? rt : 0) * 16 + rsub, cg, col);
+      p1[cg] = pre((vb ? rt2 : (va ? rt : 0)) * 16 + rsub, cg, col);
     }
     gload(0);
     if (!hooked) { hook(); hooked = true; }
@@ -282,8 +304,8 @@ __device__ __forceinline__ void chain_gemm_b_gx(const __bf16* __restrict__ gfrag
     if (va) {
 #pragma unroll
       for (int cg = 0; cg < CG; cg++) {
-        epi(rt * 16 + rsub, cg, col, acc0[cg], NoPre{});
-        if (vb) epi(rt2 * 16 + rsub, cg, col, acc1[cg], NoPre{});
+        epi(rt * 16 + rsub, cg, col, acc0[cg], p0[cg]);
+        if (vb) epi(rt2 * 16 + rsub, cg, col, acc1[cg], p1[cg]);
       }
     }
   }
@@ -358,7 +380,8 @@ __device__ __forceinline__ void chain_hidden_layer_b(const ChainDims& cd, const 
                            }
                            *reinterpret_cast<bf16x4*>(Y + c * ldh + row0) = to_bf4(r);
                          };
-  if (BSRC == 1 && XS) chain_gemm_b_gx<CG>(fragb + bf_frag_off(dm, l, false), out, in, reinterpret_cast<const float*>(Xin), XS, epi, hook);
+  if (BSRC == 1 && XS)
+    chain_gemm_b_gx<CG, XKC>(fragb + bf_frag_off(dm, l, false), out, in, reinterpret_cast<const float*>(Xin), in, XS, [](int, int, int) { return NoPre{}; }, epi, hook);
   else chain_gemm_b<CG, BSRC>(fragb + bf_frag_off(dm, l, false), out, in, Xin, ldx, 16L * ldx, [](int, int, int) { return NoPre{}; }, epi, hook);
 }
 
@@ -500,6 +523,7 @@ __device__ __forceinline__ void chain_backward_b_body(const ChainDims& cd, const
   __bf16* P0 = reinterpret_cast<__bf16*>(csm);
   __bf16* P1 = P0 + NC * ldh;
   float* G = reinterpret_cast<float*>(P1 + NC * ldh);
+  __bf16* XSB = (LDE_BF_XSTAGE_BWD != 0) ? reinterpret_cast<__bf16*>(G + NC * ldg) : nullptr;   // chunk buffers of the first product's staged operand (chain_gemm_b_gx)
   int dup;
   const long long n0 = chain_tile_start(cd, NC, a.N, &dup, bx);
   for (int i = tid; i < (2 * NC * ldh) / 8 + (NC * ldg) / 4; i += 512) reinterpret_cast<f32x4*>(csm)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -611,7 +635,8 @@ __device__ __forceinline__ void chain_backward_b_body(const ChainDims& cd, const
         for (int q = 0; q < 4; q++) d[q] = row0 + q < in ? g[q] * d[q] : 0.f;
         *reinterpret_cast<bf16x4*>(Dn + c * ldh + row0) = to_bf4(d);
       };
-      if (l == L1) chain_gemm_b<CG, 2>(fragT, in, out, Bglb, bd.dl_w[l], 16L * bd.dl_w[l], pre, epi, stage_prev);
+      if (l == L1 && XSB && out >= 2 * XKC_BWD) chain_gemm_b_gx<CG, XKC_BWD>(fragT, in, out, Bglb, bd.dl_w[l], XSB, pre, epi, stage_prev);
+      else if (l == L1) chain_gemm_b<CG, 2>(fragT, in, out, Bglb, bd.dl_w[l], 16L * bd.dl_w[l], pre, epi, stage_prev);
       else chain_gemm_b<CG, 0>(fragT, in, out, Dcur, ldh, 16L * ldh, pre, epi, stage_prev);
       __syncthreads();
       Dcur = Dn;

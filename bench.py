@@ -487,7 +487,7 @@ def run_goku_step(args, torch, dist, world, rank, local):
                                   "one hipGraph replay per step (train.GraphedStep)") if use_graph else "eager (≈ 50 launches per step)"},
         "roofline": dict(bound="mfma", kernel="whole step (dense chains dominate the flops)", achieved=3 * F_dense / (ms * 1e-3) / 1e12,
                          peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=3 * F_dense / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, traffic=None,
-                         note=("one hipGraph replay of ≈ 50 kernels on one stream: the figure is the device's critical path (DESIGN.md §4.7)"
+                         note=("one hipGraph replay of ≈ 30 kernels on one stream: the figure is the device's critical path (DESIGN.md §4.7)"
                                if use_graph else "eager: ≈ 50 launches per step, host enqueue time comparable to device time (DESIGN.md §4.7)")
                          + ("; mixed: the dense chains run on the bf16 matrix cores, the fraction is still quoted against the f32 peak"
                             if args.dtype != "f32" else "")),

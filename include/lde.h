@@ -281,6 +281,13 @@ int  lde_chain_backward_saved(lde_chain* c, const float* x, const float* y, cons
  * (then as lde_chain_backward). With n_dy = 1 the call IS lde_chain_backward_saved. */
 int  lde_chain_backward_saved_sum(lde_chain* c, const float* x, const float* y, int n_dy, const float* const* dys, const float* saved,
                                   int64_t N, float* dx, float* dW, void* stream);
+/* The forward call of such a chain with the loss value from the same launch: out[0] = (base ? base[0] : 0) + scale·Σ (y − target)², the
+ * squares summed per column tile in the last layer's epilogue while y is in registers and the tile sums added in tile order by a one-wave
+ * kernel — lde_chain_forward[_save] followed by lde_mse_forward[_add] without the latter's pass over x and x̂ (the sum's order differs from
+ * lde_mse_forward's: equal to rounding, bit-reproducible). scratch: lde_chain_mse_scratch_floats(c, N) floats. saved may be NULL. */
+int64_t lde_chain_mse_scratch_floats(const lde_chain* c, int64_t N);
+int  lde_chain_forward_save_mse(lde_chain* c, const float* x, int64_t N, float* y, float* saved, const float* target, float scale,
+                                const float* base, float* out, float* scratch, void* stream);
 /* The pullback of a chain whose output y goes into base + scale·Σ (y − target)² (the reconstructor under reconstruction_loss
  * [REF examples/pendulum_friction-less/model_train.jl:225-238]): the output gradient is 2·(g·scale)·(y − target), g = *g_dev the scalar
  * loss's cotangent, formed where the kernel reads it — what lde_mse_backward writes as an [out×N] array for lde_chain_backward_saved to read

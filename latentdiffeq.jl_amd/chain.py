@@ -157,6 +157,16 @@ class _ChainMseFn(torch.autograd.Function):
         y = torch.empty((N, chain.sizes[-1]), device=x.device, dtype=torch.float32)
         train = bool(ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         saved = torch.empty((int(lib.lde_chain_saved_floats(h, N)),), device=x.device, dtype=torch.float32) if train else None
+        if _RECON_MSE_FWD:      # the loss value from the forward launch itself: squares summed in the last layer's epilogue
+            ws = torch.empty(int(lib.lde_chain_mse_scratch_floats(h, N)) + 1, device=x.device, dtype=torch.float32)     # [0]: the result, then tile sums
+            L.check(lib.lde_chain_forward_save_mse(h, C.c_void_p(x.data_ptr()), N, C.c_void_p(y.data_ptr()),
+                                                   C.c_void_p(saved.data_ptr()) if train else C.c_void_p(), C.c_void_p(target.data_ptr()), scale,
+                                                   C.c_void_p(base.data_ptr()) if base is not None else C.c_void_p(), C.c_void_p(ws.data_ptr()),
+                                                   C.c_void_p(ws.data_ptr() + 4), stream), h, "lde_chain_forward_save_mse", chain=True)
+            ctx.chain, ctx.scale, ctx.has_base, ctx.need_dx, ctx.has_saved = chain, scale, base is not None, x.requires_grad, train
+            ctx.save_for_backward(x, y, saved if train else x.new_empty(0), target)
+            ctx.set_materialize_grads(False)
+            return ws[0], y
         if train:
             L.check(lib.lde_chain_forward_save(h, C.c_void_p(x.data_ptr()), N, C.c_void_p(y.data_ptr()), C.c_void_p(saved.data_ptr()), stream),
                     h, "lde_chain_forward_save", chain=True)
@@ -409,6 +419,8 @@ def decode(decoder: Decoder, l_tilde, t):
     return x_hat, z_hat, l_hat
 
 
+_RECON_MSE_FWD = os.environ.get("LDE_RECON_MSE_FWD", "1") != "0"   # _ChainMseFn: the loss value from the reconstructor's forward launch (its squares summed
+                                                                     # per column tile in the last layer's epilogue) instead of lde_mse_forward's pass over x and x̂
 _RECON_MSE = os.environ.get("LDE_RECON_MSE", "1") != "0"   # decode_loss: the reconstructor and reconstruction_loss as one autograd node (diagnostic switch)
 
 

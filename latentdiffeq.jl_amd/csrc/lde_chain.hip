@@ -243,7 +243,23 @@ struct ChainFwdArgs {
   const float* Wflat;
   long long N;
   float* saved;        // training: hidden activations go here as well (lde_chain_forward_save)
+  const float* mse_t;  // lde_chain_forward_save_mse: Σ (y − mse_t)² over this tile's own columns goes to mse_part[tile] from the last
+  float* mse_part;     // layer's epilogue, while y is in registers (the loss's forward pass over x and x̂ as a launch of its own: gone)
 };
+// workgroup sum of one value per thread in a fixed order (wave butterfly, then the eight waves by index); valid in thread 0
+// (cws: eight floats of the kernel's DYNAMIC LDS that no wave still reads — a static array would come off the dynamic maximum the
+// kernels ask for)
+__device__ __forceinline__ float chain_wg_sum(float v, float* cws) {
+  __syncthreads();
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  if ((threadIdx.x & 63) == 0) cws[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float s = 0.f;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < 8; w++) s += cws[w];
+  return s;
+}
 
 template <int CG>
 __device__ __forceinline__ void chain_load_tile(const ChainDims& cd, const float* x, long long n0, long long N, float* X0,
@@ -360,6 +376,7 @@ __device__ __forceinline__ void chain_forward_body(const ChainDims& cd, const Ch
     const int l = nL - 1, in = dm.sizes[l], out = dm.sizes[l + 1], actk = cd.act[l];
     const float* bias = biasc + dm.bias_lin[l];
     const bool vec = (out & 3) == 0;
+    float msum = 0.f;
     auto epi_last = [&](int row0, int cg, int col, f32x4 v, NoPre) {
                             const long long n = n0 + cg * 16 + col;
                             if (n >= a.N || row0 >= out) return;
@@ -367,6 +384,24 @@ __device__ __forceinline__ void chain_forward_body(const ChainDims& cd, const Ch
 #pragma unroll
                             for (int q = 0; q < 4; q++) r[q] += bias[min(row0 + q, out - 1)];
                             r = cact4(actk, r);
+                            if (a.mse_t && cg * 16 + col >= dup) {   // (a shifted last tile repeats `dup` columns of its neighbour: theirs)
+                              const float* tp = a.mse_t + (size_t)n * out + row0;
+                              if (vec) {   // (one 16-byte load, like the store below)
+                                const f32x4 t4 = *reinterpret_cast<const f32x4*>(tp);
+#pragma unroll
+                                for (int q = 0; q < 4; q++) {
+                                  const float d = r[q] - t4[q];
+                                  msum = __builtin_fmaf(d, d, msum);
+                                }
+                              } else {
+#pragma unroll
+                                for (int q = 0; q < 4; q++)
+                                  if (row0 + q < out) {
+                                    const float d = r[q] - tp[q];
+                                    msum = __builtin_fmaf(d, d, msum);
+                                  }
+                              }
+                            }
                             float* yp = a.y + (size_t)n * out + row0;
                             if (vec) *reinterpret_cast<f32x4*>(yp) = r;
                             else {
@@ -378,6 +413,10 @@ __device__ __forceinline__ void chain_forward_body(const ChainDims& cd, const Ch
     auto nopre = [](int, int, int) { return NoPre{}; };
     if (nL == 1 && cd.gx) chain_gemm<CG, true, BF>(a.frag + dm.frag_off[l], out, in, xg, in, 16 * in, nopre, epi_last);
     else chain_gemm<CG, false, BF>(a.frag + dm.frag_off[l], out, in, Xin, ldx, 16 * ldx, nopre, epi_last);
+    if (a.mse_t) {
+      const float t = chain_wg_sum(msum, csm);   // (the panels are free behind the barrier inside)
+      if (threadIdx.x == 0) a.mse_part[bx] = t;
+    }
   }
   PROF_T(pz1);
   PROF_ADD(2 + 2 * (nL - 1), pz0, pz1);
@@ -672,6 +711,8 @@ static size_t chain_lds_b(const ChainDims& cd, const BfDims& bd, int cg, bool bw
          + ((cd.gx && (LDE_BF_XSTAGE != 0)) ? chain_xs_bytes(cg) : 0);                                 // wide input: the first layer's chunk buffers
 }
 
+// lde_loss.hip: out[0] = (base ? base[0] : 0) + scale·Σ scratch[0..g) in index order (k_loss_final)
+int loss_finalize(const float* scratch, int g, float scale, const float* base, float* out, hipStream_t stream);
 // lde_rnn.hip: where lde_refresh_weights copies a recurrent stack's flat weights to (marks the handle as holding weights)
 bool rnn_refresh_target(lde_rnn* r, float** W_dev, int64_t* nW);
 
@@ -1043,6 +1084,8 @@ struct GroupRec {
   RecDw dw[GROUP_MAX];
   RecRed red[GROUP_MAX];
 };
+struct FwdMse { const float* t; float* part; unsigned tiles; };
+static thread_local FwdMse t_fwd_mse = {nullptr, nullptr, 0};                // lde_chain_forward_save_mse (tiles: the forward launch's grid, set by the launch site)
 struct MseSrc { const float* t; const float* g; float scale; };
 static thread_local MseSrc t_mse = {nullptr, nullptr, 0.f};              // lde_chain_backward_saved_mse
 static thread_local const float* t_dy_more[2] = {nullptr, nullptr};   // lde_chain_backward_saved_sum: further sources of the output gradient
@@ -1207,9 +1250,10 @@ static int chain_forward_b(lde_chain* c, const float* x, int64_t N, float* y, __
     c->err = "lde_chain_forward (bf16): no tile layout fits LDS for this input";
     return LDE_ERR_UNSUPPORTED;
   }
-  ChainFwdArgsB a{x, y, c->fragb, c->W_dev, (long long)N, saved};
+  ChainFwdArgsB a{x, y, c->fragb, c->W_dev, (long long)N, saved, t_fwd_mse.t, t_fwd_mse.part};
   const int NC = 16 * pk.cg;
   const dim3 grid((unsigned)((N + NC - 1) / NC));
+  t_fwd_mse.tiles = grid.x;
   static bool attr[5] = {false, false, false, false, false};
   const void* fn = pk.cg == 4 ? (const void*)k_chain_forward_b<4> : pk.cg == 2 ? (const void*)k_chain_forward_b<2> : (const void*)k_chain_forward_b<1>;
   if (!attr[pk.cg]) {
@@ -1405,7 +1449,7 @@ static int chain_forward_impl(lde_chain* c, const float* x, int64_t N, float* y,
   }
   hipStream_t stream = (hipStream_t)stream_;
   if (c->bf16) return chain_forward_b(c, x, N, y, reinterpret_cast<__bf16*>(saved), stream);
-  ChainFwdArgs a{x, y, c->frag, c->W_dev, (long long)N, saved};
+  ChainFwdArgs a{x, y, c->frag, c->W_dev, (long long)N, saved, t_fwd_mse.t, t_fwd_mse.part};
   ChainPick pk;
   if (!chain_pick(c, x, N, false, &pk)) {
     c->err = "lde_chain_forward: the only layout whose panels fit LDS reads x in place and needs N ≥ one tile and a 16-byte aligned x";
@@ -1413,6 +1457,7 @@ static int chain_forward_impl(lde_chain* c, const float* x, int64_t N, float* y,
   }
   const int NC = 16 * pk.cg;
   const dim3 grid((unsigned)((N + NC - 1) / NC));
+  t_fwd_mse.tiles = grid.x;
   static bool attr[2][5] = {{false, false, false, false, false}, {false, false, false, false, false}};
   const int bf = c->bf16 ? 1 : 0;
   const void* fn = bf ? (pk.cg == 4 ? (const void*)k_chain_forward<4, true> : pk.cg == 2 ? (const void*)k_chain_forward<2, true> : (const void*)k_chain_forward<1, true>)
@@ -1601,6 +1646,25 @@ int lde_chain_backward_saved(lde_chain* c, const float* x, const float* y, const
   return chain_backward_impl(c, x, y, dy, saved, N, dx, dW, stream);
 }
 
+int64_t lde_chain_mse_scratch_floats(const lde_chain* c, int64_t N) { return (!c || N < 1) ? -1 : (N + 15) / 16 + 1; }
+int lde_chain_forward_save_mse(lde_chain* c, const float* x, int64_t N, float* y, float* saved, const float* target, float scale, const float* base,
+                               float* out, float* scratch, void* stream) {
+  if (!c) return LDE_ERR_INVALID_ARG;
+  if (!target || !out || !scratch || (((uintptr_t)target) & 15) != 0) {
+    c->err = "lde_chain_forward_save_mse: NULL pointer or unaligned target";
+    return LDE_ERR_INVALID_ARG;
+  }
+  if (t_rec) {
+    c->err = "lde_chain_forward_save_mse: not inside a grouped call";
+    return LDE_ERR_UNSUPPORTED;
+  }
+  t_fwd_mse = FwdMse{target, scratch, 0};
+  const int rc = saved ? lde_chain_forward_save(c, x, N, y, saved, stream) : lde_chain_forward(c, x, N, y, stream);
+  const unsigned tiles = t_fwd_mse.tiles;
+  t_fwd_mse = FwdMse{nullptr, nullptr, 0};
+  if (rc) return rc;
+  return loss_finalize(scratch, (int)tiles, scale, base, out, (hipStream_t)stream);   // out = base + scale·Σ partials, in tile order
+}
 int lde_chain_backward_saved_sum(lde_chain* c, const float* x, const float* y, int n_dy, const float* const* dys, const float* saved, int64_t N,
                                  float* dx, float* dW, void* stream) {
   if (!c) return LDE_ERR_INVALID_ARG;

@@ -318,6 +318,8 @@ struct ChainFwdArgsB {
   const float* Wflat;
   long long N;
   __bf16* saved;       // training: hidden activations [n][h] bf16 (the regions of ChainDims::sv_pre, in elements)
+  const float* mse_t;  // as in ChainFwdArgs: Σ (y − mse_t)² of the tile's own columns → mse_part[tile]
+  float* mse_part;
 };
 
 // zero the panels, copy the biases, and (no gx) the tile's input columns rounded to bf16
@@ -442,11 +444,30 @@ __device__ __forceinline__ void chain_forward_b_body(const ChainDims& cd, const 
     const int l = nL - 1, in = dm.sizes[l], out = dm.sizes[l + 1], actk = cd.act[l];
     const float* bias = biasc + dm.bias_lin[l];
     const bool vec = (out & 3) == 0;
+    float msum = 0.f;
     auto epi_last = [&](int row0, int cg, int col, f32x4 v, NoPre) {
       const long long n = n0 + cg * 16 + col;
       if (n >= a.N || row0 >= out) return;
       const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + row0);
       const f32x4 r = cact4(actk, v + b4);
+      if (a.mse_t && cg * 16 + col >= dup) {   // (a shifted last tile repeats `dup` columns of its neighbour: theirs)
+        const float* tp = a.mse_t + (size_t)n * out + row0;
+        if (vec) {   // (one 16-byte load, like the store below)
+          const f32x4 t4 = *reinterpret_cast<const f32x4*>(tp);
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const float d = r[q] - t4[q];
+            msum = __builtin_fmaf(d, d, msum);
+          }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (row0 + q < out) {
+              const float d = r[q] - tp[q];
+              msum = __builtin_fmaf(d, d, msum);
+            }
+        }
+      }
       float* yp = a.y + (size_t)n * out + row0;
       if (vec) *reinterpret_cast<f32x4*>(yp) = r;
       else {
@@ -459,6 +480,10 @@ __device__ __forceinline__ void chain_forward_b_body(const ChainDims& cd, const 
     auto hook = [&]() { save_prev(nL - 2); };
     if (nL == 1 && cd.gx) chain_gemm_b<CG, 1>(a.fragb + bf_frag_off(dm, l, false), out, in, xg, in, 16L * in, nopre, epi_last, hook);
     else chain_gemm_b<CG, 0>(a.fragb + bf_frag_off(dm, l, false), out, in, Xin, ldx, 16L * ldx, nopre, epi_last, hook);
+    if (a.mse_t) {
+      const float t = chain_wg_sum(msum, csm);   // (the panels are free behind the barrier inside)
+      if (threadIdx.x == 0) a.mse_part[bx] = t;
+    }
   } else
     save_prev(nL - 2);
   PROF_T(pz1);

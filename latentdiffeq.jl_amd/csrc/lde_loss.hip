@@ -310,6 +310,12 @@ __global__ void __launch_bounds__(PAIR_WG) k_sample_kl_pair(SampleFwdPart pa, Sa
 
 using namespace lde;
 
+int loss_finalize(const float* scratch, int g, float scale, const float* base, float* out, hipStream_t stream) {
+  if (!scratch || !out || g < 1) return LDE_ERR_INVALID_ARG;
+  hipLaunchKernelGGL(k_loss_final, dim3(1), dim3(64), 0, stream, scratch, g, scale, out, base);
+  return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
+}
+
 extern "C" {
 
 int lde_sample_forward(const float* mu, const float* logvar, const float* eps, int64_t n, float* l, void* stream) {

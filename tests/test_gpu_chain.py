@@ -357,7 +357,9 @@ def test_reconstructor_under_mse_as_one_node(dtype):
                 total.backward()
                 torch.cuda.synchronize()
                 res.append((loss.detach().clone(), x_hat.detach().clone(), [p.grad.clone() for p in params] + [t_.grad.clone() for t_ in lt] + [plus.grad.clone()]))
-            assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]), (B, T)
+            # (the one node sums the squares per column tile in the reconstructor's last epilogue, lde_mse_forward per slice of the flat array:
+            #  the loss value agrees to rounding — 2e-6 —, and bit for bit with LDE_RECON_MSE_FWD=0; x̂ and every gradient are the same bits)
+            assert abs(float(res[0][0]) - float(res[1][0])) <= 2e-6 * abs(float(res[1][0])) and torch.equal(res[0][1], res[1][1]), (B, T)
             for i, (a, b) in enumerate(zip(res[0][2], res[1][2])):
                 assert torch.equal(a, b), (B, T, second_use, i)
     finally:

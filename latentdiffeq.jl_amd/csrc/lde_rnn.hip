@@ -815,6 +815,26 @@ __global__ void __launch_bounds__(64) k_rnn_state0_group(GroupTable<RnnDims, Sta
   const State0Args& a = g.args[j];
   rnn_state0_body(a.g0, a.B, a.g0w, g.dims[j], a.dW, a.assign, (int)blockIdx.x - g.start[j]);
 }
+// the slab sums of all (stack, cell) weight gradients AND the initial-state sums in one launch (they depend on different kernels of the
+// pullback, both already behind them in the stream): workgroups [0, u.start[u.n]) reduce tiles, the rest — their first wave — sum a state entry
+struct ReduceState0Tables {
+  GroupTable<MlpDims, ReduceArgs, GROUP_MAX_DW> u;
+  GroupTable<RnnDims, State0Args, RNN_GROUP_MAX> s;
+};
+static_assert(sizeof(ReduceState0Tables) <= 4096, "the two tables must fit the kernel-argument segment");
+__global__ void __launch_bounds__(256) k_rnn_reduce_state0_group(ReduceState0Tables t) {
+  const int nred = t.u.start[t.u.n];
+  if ((int)blockIdx.x < nred) {
+    const int j = group_find(t.u.start, t.u.n, blockIdx.x);
+    const ReduceArgs& a = t.u.args[j];
+    reduce_tiles_body(a.priv, a.nflush, a.nwg, a.slab, a.nslab, t.u.dims[j], a.dW, a.feedback, a.assign, (int)blockIdx.x - t.u.start[j]);
+  } else if (threadIdx.x < 64) {
+    const int b = (int)blockIdx.x - nred;
+    const int j = group_find(t.s.start, t.s.n, b);
+    const State0Args& a = t.s.args[j];
+    rnn_state0_body(a.g0, a.B, a.g0w, t.s.dims[j], a.dW, a.assign, b - t.s.start[j]);
+  }
+}
 
 }  // namespace lde
 
@@ -1274,6 +1294,10 @@ int lde_rnn_backward_dw(lde_rnn* r, float* dW, void* stream_) {
     da.stage = r->stage[l]; da.wts = r->wts; da.nslots = nullptr; da.slab = r->slab + (size_t)l * r->slab_layer; da.cap = T; da.total = (long long)ntile * T;   // every tile staged exactly T slots
     int ks = cdiv(512, ntile * dw_jobs(r->dmw[l], dw_pick_ndw(r->dmw[l])));
     ks = ks < 1 ? 1 : (ks > 8 ? 8 : ks);
+    if (const char* e = std::getenv("LDE_RNN_DW_KS")) {   // experiments: the K-split of the cells' weight-gradient products
+      const int v = std::atoi(e);
+      if (v >= 1 && v <= 8) ks = v;
+    }
     if (t_rrec && t_rrec->ndw < GROUP_MAX_DW) {
       RnnRecDw& q = t_rrec->dw[t_rrec->ndw++];
       q.ndw = dw_pick_ndw(r->dmw[l]); q.dm = r->dmw[l]; q.da = da; q.gx = ntile; q.gy = ks; q.gz = dw_jobs(r->dmw[l], q.ndw);
@@ -1354,8 +1378,19 @@ static int rnn_group_flush(RnnGroupRec& g, hipStream_t stream) {
       }
       void* argv[] = {(void*)&t};
       (void)hipLaunchKernel((const void*)k_mlp_dw_group<1, false>, dim3(t.start[g.ndw]), dim3(512), argv, lds, stream);
-      void* argu[] = {(void*)&u};
-      (void)hipLaunchKernel((const void*)k_reduce_tiles_group, dim3(u.start[g.ndw]), dim3(256), argu, 0, stream);
+      static const bool merge_s0 = [] { const char* e = std::getenv("LDE_RNN_MERGE_S0"); return !e || std::atoi(e) != 0; }();
+      if (merge_s0 && g.ns0 >= 2) {   // … and the initial-state sums ride on the slab sums' launch
+        ReduceState0Tables rs{};
+        rs.u = u;
+        rs.s.n = g.ns0;
+        for (int j = 0; j < g.ns0; j++) { rs.s.start[j + 1] = rs.s.start[j] + (int)g.s0[j].grid; rs.s.dims[j] = g.s0[j].rd; rs.s.args[j] = g.s0[j].a; }
+        void* argr[] = {(void*)&rs};
+        (void)hipLaunchKernel((const void*)k_rnn_reduce_state0_group, dim3(u.start[g.ndw] + rs.s.start[g.ns0]), dim3(256), argr, 0, stream);
+        g.ns0 = 0;
+      } else {
+        void* argu[] = {(void*)&u};
+        (void)hipLaunchKernel((const void*)k_reduce_tiles_group, dim3(u.start[g.ndw]), dim3(256), argu, 0, stream);
+      }
     } else {
       std::string err;
       for (int j = 0; j < g.ndw; j++) {

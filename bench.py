@@ -395,6 +395,7 @@ def run_goku_step(args, torch, dist, world, rank, local):
     # one GPU: the whole step is captured in a hipGraph and replayed (train.GraphedStep; needs the encoder's branch streams off — read when
     # the package was imported); LDE_BENCH_GRAPH=0 or a process group: eager
     use_graph = os.environ.get("LDE_BENCH_GRAPH", "1") != "0" and os.environ.get("LDE_BRANCH_STREAMS") == "0"
+    unroll = 1
     split = use_graph and (world > 1 or os.environ.get("LDE_BENCH_FORCE_PG") == "1")   # several GPUs: graph · all-reduce (eager) · graph
     opt = FluxADAMW(params, lr=1e-3, decay=1e-10, capturable=use_graph)   # ADAMW(η, β, decay), Flux flavour [REF model_train.jl:138, :150]; one fused update kernel
     sync = FlatGradAllReduce(params)
@@ -451,15 +452,27 @@ def run_goku_step(args, torch, dist, world, rank, local):
         gs = GraphedStep(step_a, warmup=3, between=sync, fn2=step_b)
         run = gs.replay
     elif use_graph:
-        gs = GraphedStep(step, warmup=3)
+        # several steps per captured graph: a replay has a fixed cost of its own on this runtime (≈ 13 µs at its head: a copy kernel and a
+        # gap) that a training loop feeding `unroll` minibatches per replay pays once per replay. Every step is a whole
+        # step (its own update, hand-over and noise); K steps = K / unroll replays (unroll falls back to 1 when it does not divide K).
+        unroll = int(os.environ.get("LDE_BENCH_UNROLL", "1"))
+        if unroll < 1 or args.steps % unroll or args.warmup % unroll:
+            unroll = 1
+
+        def steps_unrolled():
+            for _ in range(unroll):
+                l = step()
+            return l
+        gs = GraphedStep(steps_unrolled if unroll > 1 else step, warmup=3)
         run = gs.replay
     else:
         run = step
-    for _ in range(args.warmup):
+    n_rep = unroll if (use_graph and not split) else 1
+    for _ in range(args.warmup // n_rep):
         run()
     fence()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(args.steps // n_rep):
         loss = run()
     torch.cuda.synchronize()          # this rank's K steps are done: its clock stops here; the closing barrier follows, and the MAX over
     el = time.perf_counter() - t0     # ranks (below) is the job's time — the barrier's own latency (an RCCL collective) is not a step

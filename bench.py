@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — trajectories/sec (forward solve + adjoint) of the latent-ODE hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload goku_pendulum|c2|c3|c4|goku_decoder|goku_step] [--batch B]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload goku_pendulum|c2|c3|c4|latentode_ref|goku_decoder|goku_step] [--batch B]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
@@ -44,6 +44,9 @@ WORKLOADS = {
                T=50, layers=(2, 64, 64, 2), solver="tsit5", batching="per_trajectory"),
     "c4": dict(desc="LatentODE D=32 32-128-128-32 relu, Tsit5, coupled (512 per GPU)", B=512, rhs="mlp", D=32, P=0,
                T=50, layers=(32, 128, 128, 32), solver="tsit5", batching="coupled"),
+    # the reference's own LatentODE example [REF examples/pendulum_friction-less/model_train_LatentODE.jl:37, :42], [REF nODE.jl:11-16]
+    "latentode_ref": dict(desc="LatentODE reference example: NODE(16) 16-200-200-16 relu, Tsit5, coupled, batch 64", B=64, rhs="mlp",
+                          D=16, P=0, T=50, layers=(16, 200, 200, 16), solver="tsit5", batching="coupled"),
 }
 
 

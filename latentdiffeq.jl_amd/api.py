@@ -221,7 +221,14 @@ class NODE:
         mods = []
         act = kwargs.get("activation", "relu")
         for i in range(len(sizes) - 1):
-            mods.append(torch.nn.Linear(sizes[i], sizes[i + 1]))
+            lin = torch.nn.Linear(sizes[i], sizes[i + 1])
+            # Flux's default Dense init — the reference passes no `init=` here [REF nODE.jl:12-14]: glorot_uniform
+            # W ~ U(±√(6/(in+out))), bias = 0 (torch's default would be U(±1/√in) for both)
+            with torch.no_grad():
+                bound = (6.0 / (sizes[i] + sizes[i + 1])) ** 0.5
+                lin.weight.uniform_(-bound, bound)
+                lin.bias.zero_()
+            mods.append(lin)
             if i < len(sizes) - 2:
                 mods.append(torch.nn.ReLU() if act == "relu" else torch.nn.Tanh())
         self.dudt = torch.nn.Sequential(*mods)

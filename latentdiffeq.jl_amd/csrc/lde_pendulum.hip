@@ -1718,9 +1718,12 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
   static const int lb_ring = [] { const char* e = getenv("LDE_PEND_LB"); return e ? atoi(e) : 16; }();   // rows of the ring; 0: off
   static const int lb_min_b = [] { const char* e = getenv("LDE_PEND_LB_MIN_B"); return e ? atoi(e) : (1 << 17); }();
   if (lb_ring > 0 && o.T > 1 && o.T <= 2048 && o.B >= lb_min_b) {   // (the save grid in LDS beside the ring: T ≤ 2048)
-    static const int lb_hold = [] { const char* e = getenv("LDE_PEND_LB_HOLD"); return e ? atoi(e) : 8; }();
+    // a lane sits out while j ≥ jc + RING − hold; the slowest lane has j = jc, so hold ≤ RING − 1 keeps it (and with it jc) moving —
+    // hold ≥ RING would hold EVERY lane on every iteration and the solve loop would never end. Default: half the ring.
+    static const int lb_hold_env = [] { const char* e = getenv("LDE_PEND_LB_HOLD"); return e ? atoi(e) : -1; }();
+    const int ring_rows = lb_ring >= 32 ? 32 : (lb_ring >= 16 ? 16 : 8);
     KOpts oh = o;
-    oh.lb_hold = lb_hold;
+    oh.lb_hold = std::max(0, std::min(lb_hold_env >= 0 ? lb_hold_env : ring_rows / 2, ring_rows - 1));
     const bool ad = o.adaptive != 0;
     const int g8 = (((o.B + 63) / 64 + 7) / 8) * 8;
 #define LDE_LAUNCH_LB(K, S, A)                                                                                          \

@@ -34,6 +34,11 @@ CONFIGS = {
     # configs[3]: LatentODE D=32, 32-128-128-32, Tsit5 coupled
     "c4_latentode_tsit5_d32_h128_b16": dict(kind=O.RHS_MLP, D=32, P=0, layers=(32, 128, 128, 32), B=16, keep=6, T=50,
                                             batching=O.BATCH_COUPLED),
+    # the reference's own LatentODE example: NODE(16) = 16-200-200-16 relu, Tsit5, one coupled solve
+    # [REF examples/pendulum_friction-less/model_train_LatentODE.jl:37, :42], [REF nODE.jl:11-16] (the example's batch is 64; the
+    # fixture keeps 16 columns of a B = 16 coupled solve — the full batch is tests/test_gpu_baseline_sizes.py)
+    "latentode_ref_tsit5_d16_h200_b16": dict(kind=O.RHS_MLP, D=16, P=0, layers=(16, 200, 200, 16), B=16, keep=8, T=50,
+                                             batching=O.BATCH_COUPLED),
     # augmented NODE (AugmentedNDELayer), tanh, per-trajectory control
     "latentode_aug_tanh_d6a2_b16": dict(kind=O.RHS_MLP, D=6, P=0, aug=2, layers=(8, 32, 32, 8), B=16, keep=16, T=20,
                                         activation=O.ACT_TANH, batching=O.BATCH_PER_TRAJECTORY),
@@ -65,9 +70,11 @@ def desc(cfg, **over):
     return O.make_desc(**kw)
 
 
-def main():
+def main(only=None):
     o32, o64 = O.Oracle("f32"), O.Oracle("f64")
     for name, cfg in CONFIGS.items():
+        if only and name not in only:
+            continue
         ts, z0, theta, W, dz = inputs(cfg)
         d = desc(cfg)
         z, ret, info = o32.forward(d, z0, theta, ts, W=W)
@@ -120,6 +127,8 @@ def chain_main():
 
 if __name__ == "__main__":
     import sys
+    only = [a for a in sys.argv[1:] if not a.startswith("--")]   # fixture names: regenerate just those
     if "--chain-only" not in sys.argv:
-        main()
-    chain_main()
+        main(only)
+    if not only:
+        chain_main()

@@ -130,6 +130,17 @@ def test_reference_shaped_host_api_surface():
     assert w.numel() == 6 * 8 + 8 + 8 * 8 + 8 + 8 * 6 + 6
     lin = n.dudt[0]
     assert np.allclose(w[:48].detach().numpy().reshape(6, 8).T, lin.weight.detach().numpy())  # vec(W) column-major
+    # Flux's default Dense init (no `init=` in the reference's NODE [REF nODE.jl:12-14]): glorot_uniform weights, zero biases
+    ref = la.NODE(16)                                  # the reference default: 16 → 200 → 200 → 16
+    assert ref.layer_sizes == [16, 200, 200, 16] and ref.flat_weights().numel() == 46816
+    for m in ref.dudt:
+        if hasattr(m, "weight"):
+            out_f, in_f = m.weight.shape
+            bound = (6.0 / (in_f + out_f)) ** 0.5
+            wv = m.weight.detach().numpy()
+            assert np.abs(wv).max() <= bound and np.abs(wv).max() >= 0.97 * bound        # U(±bound): the extremes are reached
+            assert abs(wv.std() - bound / 3 ** 0.5) <= 0.05 * bound                     # std of U(±a) = a/√3
+            assert not m.bias.detach().numpy().any()
     assert issubclass(la.GOKU_basic, la.GOKU) and issubclass(la.GOKU, la.LatentDE) and issubclass(la.LatentODE, la.LatentDE)
     assert la.transform_after_diffeq("x", p) == "x"   # identity by default [REF GOKU.jl:136]
 

@@ -157,6 +157,74 @@ def test_coupled_solve_while_another_stream_keeps_the_gpu_busy(o32):
     assert np.array_equal(z_idle, z_busy) and np.array_equal(g_idle[0], g_busy[0]) and np.array_equal(g_idle[2], g_busy[2])
 
 
+def test_reference_default_latentode_b64(o32, o64):
+    """The reference's OWN LatentODE example [REF examples/pendulum_friction-less/model_train_LatentODE.jl:37, :42], [REF nODE.jl:11-16]:
+    NODE(16) = 16-200-200-16 relu, Tsit5 at the default tolerances, ONE coupled solve on the [16 × 64] state, T = 50 — forward and
+    adjoint at the full shape against the f32 oracle and float64 (gates: c4's, the other relu network under the adaptive coupled
+    controller), plus bitwise determinism."""
+    layers = (16, 200, 200, 16)
+    W = O.mlp_weights(layers, seed=3)
+    kw = dict(rhs_kind=O.RHS_MLP, state_dim=16, param_dim=0, layers=layers, batching=O.BATCH_COUPLED)
+    nat, od = _native(W, **kw)
+    B, T = 64, 50
+    z0, ts = _z0(B, 16), O.time_grid(T)
+    dz = O.cotangent(T, B, 16)
+    z, ret, st = nat.forward(z0, None, ts)
+    g0, _, gW, sb = nat.adjoint(z, None, ts, dz)
+    assert (ret == 0).all() and st["nfailed"] == 0 and sb["nfailed"] == 0
+    zr, _, info = o32.forward(od, z0, None, ts, W=W, nthreads=NT)
+    r0, _, rW, infob = o32.adjoint(od, z, None, ts, dz, W=W, nthreads=NT)
+    assert abs(st["naccept"] - info["naccept"]) <= 0.1 * info["naccept"] + 2
+    assert abs(sb["naccept"] - infob["naccept"]) <= 0.1 * infob["naccept"] + 2
+    d64 = O.make_desc(**{**kw, "abstol": 1e-11, "reltol": 1e-11})
+    W64 = W.astype(np.float64)
+    z64, _, _ = o64.forward(d64, z0, None, ts, W=W64, nthreads=NT)
+    t0, _, tW, _ = o64.adjoint(d64, z64, None, ts, dz, W=W64, nthreads=NT)
+    scale = max(1.0, np.abs(zr).max())
+    e_k, e_o = np.abs(z - z64).max(), np.abs(zr - z64).max()
+    assert np.abs(z - zr).max() <= 3e-4 * scale
+    assert e_k <= 1.5 * e_o + 1e-5 * scale, (e_k, e_o)
+    assert _rel(g0, r0) <= 5e-3 and _rel(gW, rW) <= 5e-3, (_rel(g0, r0), _rel(gW, rW))
+    for g, r, t, what in ((g0, r0, t0, "dz0"), (gW, rW, tW, "dW")):
+        assert _rel(g, t) <= 1.5 * _rel(r, t) + 5e-3, (what, _rel(g, t), _rel(r, t))
+    z2, _, _ = nat.forward(z0, None, ts)
+    h0, _, hW, _ = nat.adjoint(z2, None, ts, dz)
+    assert np.array_equal(z, z2) and np.array_equal(g0, h0) and np.array_equal(gW, hW)
+
+
+def test_c3_tanh_forced_rejections(o32, o64):
+    """k_mlp64_adj folds gW₂ over an ACCEPTED step's six (h₁, δ₂) pairs and drops the pending sums of a rejected attempt; c3's smooth tanh
+    twin never rejects under the default controller (nreject = 0 in every bench line), and with 49 save-time stops the backward steps are
+    clipped before the controller can overshoot. Here it is pushed into rejections in BOTH directions: eight save times (intervals of
+    0.35), an integral controller without safety factor (gamma = 1, beta1 = 0.2, beta2 = 0, qmax = 50) — the oracle rejects ≈ 6.6
+    attempts per trajectory backward (measured: 6768 of 26836 attempts at B = 1024). The f32 oracle itself sits 1.5e-5 (dẑ₀) / 9e-6 (dW)
+    from float64 under this controller; the gates are 5e-5: a fold that kept one rejected attempt's pairs, or lost one accepted step's,
+    is ≈ 1/20 of the gradient — three orders above."""
+    layers = (2, 64, 64, 2)
+    kw = dict(rhs_kind=O.RHS_PENDULUM_PLUS_MLP, layers=layers, activation=O.ACT_TANH)
+    ctl = dict(abstol=1e-6, reltol=1e-6, gamma=1.0, beta1=0.2, beta2=0.0, qmax=50.0)
+    W = O.mlp_weights(layers, seed=3)
+    nat, od = _native(W, **kw, **ctl)
+    B, T = 1024, 8
+    z0, L = O.pendulum_inputs(B)
+    ts = np.linspace(0.0, 2.45, T)
+    dz = O.cotangent(T, B, 2)
+    z, ret, st = nat.forward(z0, L, ts)
+    g0, gL, gW, sb = nat.adjoint(z, L, ts, dz)
+    assert (ret == 0).all() and st["nfailed"] == 0 and sb["nfailed"] == 0
+    assert sb["nreject"] > 2 * B and st["nreject"] > 2 * B, (st["nreject"], sb["nreject"])   # the path under test ran, in bulk
+    r0, rL, rW, infob = o32.adjoint(od, z, L, ts, dz, W=W, nthreads=NT)
+    assert infob["nreject"] > 2 * B
+    d64 = O.make_desc(**kw, abstol=1e-11, reltol=1e-11)
+    W64 = W.astype(np.float64)
+    z64, _, _ = o64.forward(d64, z0, L, ts, W=W64, nthreads=NT)
+    t0, tL, tW, _ = o64.adjoint(d64, z64, L, ts, dz, W=W64, nthreads=NT)
+    assert np.abs(z - z64).max() <= 5e-5 * max(1.0, np.abs(z64).max())
+    for g, r, t, what in ((g0, r0, t0, "dz0"), (gL, rL, tL, "dL"), (gW, rW, tW, "dW")):
+        assert _rel(g, r) <= 5e-5, (what, _rel(g, r))
+        assert _rel(g, t) <= 5e-5, (what, _rel(g, t))
+
+
 TIGHT = {
     # name: (desc kwargs, B, D, pendulum inputs?, gates (z vs oracle, z vs f64, grads vs oracle, grads vs f64) in units of the scale)
     # Measured (abl/c3_tight.py, MI355X): the tanh networks — smooth right-hand sides, the solver's order holds — agree to 3e-6 in ẑ and
@@ -170,6 +238,12 @@ TIGHT = {
                 (1e-5, 1e-4, 5e-3, 5e-3)),
     "c4_tanh": (dict(rhs_kind=O.RHS_MLP, state_dim=32, param_dim=0, layers=(32, 128, 128, 32), batching=O.BATCH_COUPLED,
                      activation=O.ACT_TANH), 512, 32, False, (1e-5, 1e-5, 1e-5, 1e-5)),
+    # the reference's default NODE shape [REF nODE.jl:11-16] at its example's batch [REF model_train_LatentODE.jl:42]: relu as in the
+    # reference (the gates of c4_relu), and the tanh twin that holds the code path to 1e-5
+    "ref_relu": (dict(rhs_kind=O.RHS_MLP, state_dim=16, param_dim=0, layers=(16, 200, 200, 16), batching=O.BATCH_COUPLED), 64, 16, False,
+                 (1e-5, 1e-4, 5e-3, 5e-3)),
+    "ref_tanh": (dict(rhs_kind=O.RHS_MLP, state_dim=16, param_dim=0, layers=(16, 200, 200, 16), batching=O.BATCH_COUPLED,
+                      activation=O.ACT_TANH), 64, 16, False, (1e-5, 1e-5, 1e-5, 1e-5)),
 }
 
 

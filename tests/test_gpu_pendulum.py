@@ -329,7 +329,7 @@ np.savez({path!r}, **out)
 """
 
 
-@pytest.mark.parametrize("variant", ["ws", "tl", "lb", "sh"])
+@pytest.mark.parametrize("variant", ["ws", "tl", "lb", "lb8", "lb32", "sh"])
 def test_small_batch_forward_kernels_match_the_single_wave_kernel(tmp_path, variant):
     """Five forward kernels share the step code and the dense-output formulas: k_pend_forward_sh (B ≤ 256: one trajectory per
     workgroup, a stepping wave + three dense-output waves; LDE_PEND_SH_MAX_B forces it for every batch here — the 200-point tight case
@@ -354,6 +354,12 @@ def test_small_batch_forward_kernels_match_the_single_wave_kernel(tmp_path, vari
                    env=dict(os.environ, **{"ws": dict(LDE_PEND_TL_MAX_B="0", LDE_PEND_SH_MAX_B="0"),
                                            "tl": dict(LDE_PEND_TL_MAX_B="1024", LDE_PEND_SH_MAX_B="0"),
                                            "lb": dict(LDE_PEND_TL_MAX_B="0", LDE_PEND_SH_MAX_B="0", LDE_PEND_WS="0", LDE_PEND_LB_MIN_B="0"),
+                                           # ring of 8 rows with a requested hold of 8 (≥ the ring: the host clamps it to 7 — unclamped, every
+                                           # lane would sit out every iteration and the solve would never end), and 32 rows with the default hold
+                                           "lb8": dict(LDE_PEND_TL_MAX_B="0", LDE_PEND_SH_MAX_B="0", LDE_PEND_WS="0", LDE_PEND_LB_MIN_B="0",
+                                                       LDE_PEND_LB="8", LDE_PEND_LB_HOLD="8"),
+                                           "lb32": dict(LDE_PEND_TL_MAX_B="0", LDE_PEND_SH_MAX_B="0", LDE_PEND_WS="0", LDE_PEND_LB_MIN_B="0",
+                                                        LDE_PEND_LB="32"),
                                            "sh": dict(LDE_PEND_SH_MAX_B="1000000")}[variant]),
                    timeout=600)
     a, b = np.load(here), np.load(path)

@@ -1344,6 +1344,7 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
 #include "lde_mlpv.h"
 #include "lde_mlp64.h"
 #include "lde_mlpw.h"
+#include "lde_mlpb.h"
 
 // ================================================ host side =================================================
 struct MlpPlan {
@@ -1354,6 +1355,9 @@ struct MlpPlan {
   WDims wd;                    // W-waves-per-trajectory register kernels (lde_mlpw.h)
   bool w_ok = false;
   float* wpack = nullptr;
+  BDims bd;                    // block-layout register kernels (lde_mlpb.h)
+  bool b_ok = false;
+  float* bpack = nullptr;
   unsigned epoch = 0;          // launch counter of k_mlpw's tagged grid-sum words
   float* wslots = nullptr;     // k_mlpw's own [2][nWG][4] words ({value, tag} pairs): never shared with the float partials of grid_sum4
   int wslots_cap = 0;
@@ -1402,6 +1406,7 @@ struct MlpPlan {
 void mlp_plan_destroy(MlpPlan* p);
 static bool mlp64_applicable(const MlpDims& dm, int B);
 static int mlp64_adj_waves(int B);
+static bool b_applicable(const MlpPlan* p, int B, int T, bool adj, bool coupled_adaptive);
 
 int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err) {
   MlpPlan* p = new MlpPlan();
@@ -1547,6 +1552,28 @@ int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err) 
       }
     }
   }
+  {   // four waves per trajectory, W₂ as 2-D register blocks, the weight gradient on the CU (lde_mlpb.h): three layers, H ≤ 200, D′ ≤ 16
+    const int hm = dm.nL == 3 ? std::max(dm.sizes[1], dm.sizes[2]) : 0;
+    p->b_ok = dm.nL == 3 && !dm.has_pend && dm.P == 0 && dm.Dp <= 16 && hm >= 1 && hm <= 200;
+    if (p->b_ok) {
+      BDims& bd = p->bd;
+      bd.DP = dm.Dp <= 8 ? 8 : 16;
+      bd.SEG = 64 / bd.DP;
+      bd.GS = (200 / bd.SEG + 3) / 4;   // = the kernel's compile-time GS
+      bd.o_wb = 0;
+      bd.o_w13 = bd.o_wb + mlpb::RB * mlpb::CB * mlpb::UT;
+      bd.o_b1 = bd.o_w13 + mlpb::HV * (2 * bd.DP + 4);
+      bd.o_b3 = bd.o_b1 + mlpb::UT;
+      bd.o_n3 = bd.o_b3 + 64;
+      bd.o_n1 = bd.o_n3 + bd.GS * 64 * 4;
+      bd.total = bd.o_n1 + bd.GS * 64 * 4;
+      if (hipMalloc(&p->bpack, (size_t)bd.total * sizeof(float)) != hipSuccess) {
+        err = "MLP plan: hipMalloc failed";
+        mlp_plan_destroy(p);
+        return LDE_ERR_ALLOC;
+      }
+    }
+  }
   if (hipMalloc(&p->frag, p->nfrag * sizeof(float)) != hipSuccess ||
       hipMalloc(&p->fragT, p->nfragT * sizeof(float)) != hipSuccess ||
       hipMalloc(&p->counter, 64) != hipSuccess || hipMalloc(&p->abort_flag, 64) != hipSuccess ||
@@ -1569,6 +1596,7 @@ void mlp_plan_destroy(MlpPlan* p) {
   if (p->fragT) (void)hipFree(p->fragT);
   if (p->vecw) (void)hipFree(p->vecw);
   if (p->wpack) (void)hipFree(p->wpack);
+  if (p->bpack) (void)hipFree(p->bpack);
   if (p->wslots) (void)hipFree(p->wslots);
   if (p->counter) (void)hipFree(p->counter);
   if (p->abort_flag) (void)hipFree(p->abort_flag);
@@ -1614,6 +1642,14 @@ int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::strin
   if (mlp64_applicable(dm, B)) {   // no staging area: a slab row per wave is the kernel's only workspace
     p->rows_stride = (dm.nW + 63) & ~63;
     if (!grow(&p->rows, &p->rows_cap, (size_t)mlp64_adj_waves(B) * p->rows_stride)) {
+      err = "MLP plan: hipMalloc of the weight-gradient rows failed";
+      return LDE_ERR_ALLOC;
+    }
+    return LDE_OK;
+  }
+  if (b_applicable(p, B, T, true, dm.coupled != 0)) {   // no staging area either: one slab row per workgroup (= trajectory)
+    p->rows_stride = (dm.nW + 63) & ~63;
+    if (!grow(&p->rows, &p->rows_cap, (size_t)B * p->rows_stride)) {
       err = "MLP plan: hipMalloc of the weight-gradient rows failed";
       return LDE_ERR_ALLOC;
     }
@@ -1672,6 +1708,7 @@ int mlp_set_weights(MlpPlan* p, const float* W_dev, hipStream_t stream, std::str
   hipLaunchKernelGGL(k_build_frags, dim3(64, p->dm.nL), dim3(256), 0, stream, W_dev, p->dm, p->frag, p->fragT, (float*)nullptr, (__bf16*)nullptr, (__bf16*)nullptr);
   if (p->vec_ok) hipLaunchKernelGGL(k_build_vec, dim3(64, p->dm.nL), dim3(256), 0, stream, W_dev, p->dm, p->vd, p->vecw);
   if (p->w_ok) hipLaunchKernelGGL(k_build_wpack, dim3(128), dim3(256), 0, stream, W_dev, p->dm, p->wd, p->wpack);
+  if (p->b_ok) hipLaunchKernelGGL(k_build_bpack, dim3(128), dim3(256), 0, stream, W_dev, p->dm, p->bd, p->bpack);
   if (hipGetLastError() != hipSuccess) {
     err = "k_build_frags launch failed";
     return LDE_ERR_HIP;
@@ -1879,6 +1916,33 @@ static bool w_applicable(const MlpPlan* p, int B, int T, bool adj, bool coupled_
   const int maxw = coupled_adaptive ? 1024 : (m ? atoi(m) : 2048);
   return (long long)B * p->wd.W <= maxw;
 }
+// tagged grid-sum words of w_grid_sum: an own buffer (zeroed: no tag is 0), a fresh epoch per launch, cleared when the epoch wraps
+static int grid_words_prepare(MlpPlan* p, int B, VArgs& a, hipStream_t stream, std::string& err) {
+  const size_t bytes = (size_t)2 * (B + 1) * 4 * sizeof(float);
+  if (B + 1 > p->wslots_cap) {
+    if (p->wslots) (void)hipFree(p->wslots);
+    p->wslots = nullptr;
+    p->wslots_cap = 0;
+    if (hipMalloc(&p->wslots, bytes) != hipSuccess || hipMemsetAsync(p->wslots, 0, bytes, stream) != hipSuccess) {
+      (void)hipGetLastError();
+      err = "MLP plan: hipMalloc of the grid-sum words failed";
+      return LDE_ERR_ALLOC;
+    }
+    p->wslots_cap = B + 1;
+    p->epoch = 0;
+  }
+  p->epoch = (p->epoch + 1) & 0xffffu;
+  if (p->epoch == 0) {
+    if (hipMemsetAsync(p->wslots, 0, (size_t)2 * p->wslots_cap * 4 * sizeof(float), stream) != hipSuccess) {
+      err = "hipMemsetAsync(grid-sum words) failed";
+      return LDE_ERR_HIP;
+    }
+    p->epoch = 1;
+  }
+  a.epoch = p->epoch;
+  a.gs.slots = p->wslots;
+  return LDE_OK;
+}
 template <int SOLVER, bool ADJ>
 static int launch_w(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t stream, std::string& err) {
   MlpDims dmv = p->dm;
@@ -1913,30 +1977,9 @@ static int launch_w(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t
   a.wpack = p->wpack;
   const bool relay = a.gs.host_req != nullptr;   // LDE_BATCH_COUPLED_GLOBAL: sums leave the device; a plain launch (two ranks' cooperative
                                                  // launches on one device could be serialised by the runtime — each would wait for the other's sums)
-  if (coop || relay) {   // tagged grid-sum words: an own buffer (zeroed: no tag is 0), a fresh epoch per launch, cleared when the epoch wraps
-    const size_t bytes = (size_t)2 * (o.B + 1) * 4 * sizeof(float);
-    if (o.B + 1 > p->wslots_cap) {
-      if (p->wslots) (void)hipFree(p->wslots);
-      p->wslots = nullptr;
-      p->wslots_cap = 0;
-      if (hipMalloc(&p->wslots, bytes) != hipSuccess || hipMemsetAsync(p->wslots, 0, bytes, stream) != hipSuccess) {
-        (void)hipGetLastError();
-        err = "MLP plan: hipMalloc of the grid-sum words failed";
-        return LDE_ERR_ALLOC;
-      }
-      p->wslots_cap = o.B + 1;
-      p->epoch = 0;
-    }
-    p->epoch = (p->epoch + 1) & 0xffffu;
-    if (p->epoch == 0) {
-      if (hipMemsetAsync(p->wslots, 0, (size_t)2 * p->wslots_cap * 4 * sizeof(float), stream) != hipSuccess) {
-        err = "hipMemsetAsync(grid-sum words) failed";
-        return LDE_ERR_HIP;
-      }
-      p->epoch = 1;
-    }
-    a.epoch = p->epoch;
-    a.gs.slots = p->wslots;
+  if (coop || relay) {
+    const int rcw = grid_words_prepare(p, o.B, a, stream, err);
+    if (rcw) return rcw;
   }
 #if LDE_PROF
   prof_reset();
@@ -1944,6 +1987,69 @@ static int launch_w(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t
   const int rcl = launch_maybe_coop(coop && !relay, fn, dim3(o.B), dim3(wdv.UT), lds, stream, err, "k_mlpw", dmv, wdv, ov, a);
 #if LDE_PROF
   prof_dump(ADJ ? "w adjoint" : "w forward", stream);
+#endif
+  return rcl;
+}
+
+// ---- four waves per trajectory, W₂ as register blocks, the weight gradient folded on the CU (lde_mlpb.h)
+static size_t b_lds_base(const BDims& bd, int T, bool adj, int nst) {   // save times, ring (+ partial sums), narrow slices
+  const int nsl = adj ? nst + 1 : 1;
+  return (((size_t)T * 8 + 15) & ~size_t(15)) + (size_t)(nsl * mlpb::SLOT + (adj ? 16 * mlpb::HV + (mlpb::NTL - mlpb::ntr(bd.DP)) * mlpb::UT * 4 : 0)) * 4 +
+         (size_t)bd.GS * 64 * 16 * (adj ? 2 : 1) + (size_t)mlpb::HV * (2 * bd.DP + 4) * 4 + 16;
+}
+static bool b_applicable(const MlpPlan* p, int B, int T, bool adj, bool coupled_adaptive) {
+  // LDE_MLPB (read per call: the tests switch kernels inside one process): 0 = off (k_mlpw: the parity reference of this kernel),
+  // 2 = also the networks of at most 128 units that k_mlpw's two-wave form serves by default
+  const char* e = getenv("LDE_MLPB");
+  const int mode = e ? atoi(e) : 1;
+  const char* ew = getenv("LDE_MLPW");   // (LDE_MLPW=0 switches BOTH register families off: the tests' "tiles" / "k_mlpv" legs)
+  if (!p->b_ok || mode == 0 || (ew && atoi(ew) == 0)) return false;
+  const int hm = std::max(p->dm.sizes[1], p->dm.sizes[2]);
+  if (hm <= 128 && mode != 2) return false;
+  if (b_lds_base(p->bd, T, adj, p->dm.solver == LDE_SOLVER_RK4 ? 4 : 6) > LDS_MAX) return false;
+  // one workgroup per CU (512 registers per lane): 256 trajectories are resident at once; an uncoupled solve may queue a second
+  // round, a coupled adaptive one needs every trajectory resident
+  return B <= (coupled_adaptive ? 256 : 512);
+}
+template <int SOLVER, bool ADJ>
+static int launch_b(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t stream, std::string& err) {
+  MlpDims dmv = p->dm;
+  BDims bdv = p->bd;
+  KOpts ov = o;
+  const bool d8 = bdv.DP == 8;
+  const bool tanh_ = dmv.act == LDE_ACT_TANH;
+  const void* fn = tanh_ ? (d8 ? (const void*)k_mlpb<SOLVER, 8, LDE_ACT_TANH, ADJ> : (const void*)k_mlpb<SOLVER, 16, LDE_ACT_TANH, ADJ>)
+                         : (d8 ? (const void*)k_mlpb<SOLVER, 8, LDE_ACT_RELU, ADJ> : (const void*)k_mlpb<SOLVER, 16, LDE_ACT_RELU, ADJ>);
+  size_t lds = b_lds_base(bdv, o.T, ADJ, SOLVER == LDE_SOLVER_RK4 ? 4 : 6);
+  const size_t cot = ADJ ? (size_t)o.T * dmv.Dp * 4 * (o.checkpoint ? 2 : 1) : 0;
+  a.cot_lds = ADJ && cot <= 40 * 1024 && lds + cot <= LDS_MAX;   // the trajectory's dẑ (and saved ẑ) by save time: no global load inside the solve
+  if (a.cot_lds) lds += cot;
+  {   // dynamic LDS beyond the default limit needs the attribute, once per instantiation
+    static bool attr_set[2][2] = {{false, false}, {false, false}};
+    if (!attr_set[d8][tanh_]) {
+      hipFuncAttributes fa{};
+      (void)hipFuncGetAttributes(&fa, fn);
+      const hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX - (int)fa.sharedSizeBytes);
+      if (ea != hipSuccess) {
+        (void)hipGetLastError();
+        err = std::string("hipFuncSetAttribute(k_mlpb) failed: ") + hipGetErrorString(ea);
+        return LDE_ERR_HIP;
+      }
+      attr_set[d8][tanh_] = true;
+    }
+  }
+  a.wpack = p->bpack;
+  const bool relay = a.gs.host_req != nullptr;   // LDE_BATCH_COUPLED_GLOBAL: sums leave the device; a plain launch (see launch_w)
+  if (coop || relay) {
+    const int rcw = grid_words_prepare(p, o.B, a, stream, err);
+    if (rcw) return rcw;
+  }
+#if LDE_PROF
+  prof_reset();
+#endif
+  const int rcl = launch_maybe_coop(coop && !relay, fn, dim3(o.B), dim3(mlpb::UT), lds, stream, err, "k_mlpb", dmv, bdv, ov, a);
+#if LDE_PROF
+  prof_dump(ADJ ? "b adjoint" : "b forward", stream);
 #endif
   return rcl;
 }
@@ -2092,7 +2198,8 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
   {   // small batches: one trajectory per workgroup, lanes = hidden units (lde_mlpv.h)
     size_t ldsv = 0;
     const bool ca = dm.coupled && o.adaptive && o.B > 1;
-    const bool use_w = w_applicable(p, o.B, o.T, false, ca);
+    const bool use_b = b_applicable(p, o.B, o.T, false, ca);
+    const bool use_w = use_b || w_applicable(p, o.B, o.T, false, ca);
     if (p->global_mode && !use_w) {
       err = "LDE_BATCH_COUPLED_GLOBAL: this shape / batch is not served by the register kernels (three Dense layers, 2·D' ≤ 64, H ≤ 200, B·W ≤ 1024 waves)";
       return LDE_ERR_UNSUPPORTED;
@@ -2109,8 +2216,10 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
       if (use_w) {
         const int rca = global_arm(p, va, stream, err);
         if (rca) return rca;
-        const int rcw = dm.solver == LDE_SOLVER_RK4 ? launch_w<LDE_SOLVER_RK4, false>(p, o, va, ca, stream, err)
-                                                    : launch_w<LDE_SOLVER_TSIT5, false>(p, o, va, ca, stream, err);
+        const int rcw = use_b ? (dm.solver == LDE_SOLVER_RK4 ? launch_b<LDE_SOLVER_RK4, false>(p, o, va, ca, stream, err)
+                                                             : launch_b<LDE_SOLVER_TSIT5, false>(p, o, va, ca, stream, err))
+                              : (dm.solver == LDE_SOLVER_RK4 ? launch_w<LDE_SOLVER_RK4, false>(p, o, va, ca, stream, err)
+                                                             : launch_w<LDE_SOLVER_TSIT5, false>(p, o, va, ca, stream, err));
         return rcw ? rcw : global_serve(p, stream, err);
       }
       return dm.solver == LDE_SOLVER_RK4 ? launch_vec<LDE_SOLVER_RK4, false>(p, o, va, ldsv, ca, stream, err)
@@ -2263,6 +2372,41 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
     }
     phase_mark(p, 2, stream);
     return LDE_OK;
+  }
+  {   // W₂ as register blocks, the weight gradient folded on the CU (lde_mlpb.h): two launches, no staging area
+    const bool ca = dm.coupled && o.adaptive && o.B > 1;
+    if (b_applicable(p, o.B, o.T, true, dm.coupled != 0)) {
+      if (!p->rows || p->rows_cap < (size_t)o.B * p->rows_stride || p->rows_stride < dm.nW) {
+        err = "MLP adjoint: workspace not reserved";
+        return LDE_ERR_INVALID_ARG;
+      }
+      VArgs va{};
+      va.theta = theta; va.ts = ts_dev; va.Wflat = W_dev; va.z_out = const_cast<float*>(z_out); va.dz_out = dz_out;
+      va.dz0 = dz0; va.dtheta = dtheta; va.stage = p->rows; va.cap = p->rows_stride;
+      va.st_nfe = nfe; va.st_nacc = nacc; va.st_nrej = nrej; va.st_ret = ret;
+      va.gs.counter = p->counter; va.gs.slots = p->slots; va.gs.abort_flag = p->abort_flag; va.gs.nwg = ca ? o.B : 1;
+      if (ca && !zero_regions(stream, {{p->counter, sizeof(unsigned)}, {p->abort_flag, sizeof(int)}})) {
+        err = "k_zero_regions(counter) failed";
+        return LDE_ERR_HIP;
+      }
+      const int rca = global_arm(p, va, stream, err);
+      if (rca) return rca;
+      phase_mark(p, 0, stream);
+      int rcb = dm.solver == LDE_SOLVER_RK4 ? launch_b<LDE_SOLVER_RK4, true>(p, o, va, ca, stream, err)
+                                            : launch_b<LDE_SOLVER_TSIT5, true>(p, o, va, ca, stream, err);
+      if (!rcb) rcb = global_serve(p, stream, err);
+      if (rcb) return rcb;
+      phase_mark(p, 1, stream);
+      if (dW) {
+        hipLaunchKernelGGL(k_sum_rows, dim3(cdiv(dm.nW, 64)), dim3(1024), 0, stream, p->rows, o.B, p->rows_stride, dm.nW, dW);
+        if (hipGetLastError() != hipSuccess) {
+          err = "k_sum_rows launch failed";
+          return LDE_ERR_HIP;
+        }
+      }
+      phase_mark(p, 2, stream);
+      return LDE_OK;
+    }
   }
   const int nwg = cdiv(o.B, NB);
   const bool sync = dm.coupled && o.adaptive && nwg > 1;

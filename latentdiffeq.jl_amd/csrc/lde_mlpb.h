@@ -1,0 +1,732 @@
+// lde_mlpb.h — three-layer networks wider than one wave at SMALL batches, second form (round 4): the hidden×hidden matrix as 2-D
+// register BLOCKS, one copy serving both W₂·h and W₂ᵀ·δ, and the weight gradient kept on the CU (included by lde_mlp.hip after
+// lde_mlpw.h).
+//
+// k_mlpw (lde_mlpw.h) gives every lane a ROW and a COLUMN of W₂: 2·H weight registers per lane (c2: 416, half of them AGPRs the
+// VALU reaches only through v_accvgpr_read), every lane needs the WHOLE input vector of each product (H/4 broadcast ds_read_b128
+// per lane and product: 800 LDS-array cycles per product and CU), and nothing is left for the weight gradient, whose (a_l, δ_l)
+// panels it stages through HBM for k_mlp_dw (c2: 203 MB per launch against 0.84 MB of algorithmic traffic). Here:
+//   * the 256 lanes of the workgroup (one trajectory, one wave per SIMD) form a 16 × 16 grid: lane (r, c) — r = tid >> 4 a DPP row,
+//     c = tid & 15 the lane in it — owns the BLOCK W₂[13r … 13r+12][14c … 14c+13] as 13 × 7 register pairs (182 VGPRs, all arch
+//     VGPRs). W₂·h₁: the lane needs only h₁[14c …] (7 ds_read_b64), 91 v_pk_fma_f32, and the row sums meet inside the DPP row
+//     (quad_perm ×2, row_half_mirror, row_mirror: 4 steps per row, every lane of the row ends with all 13 sums, bitwise equal).
+//     W₂ᵀ·δ₂ runs on the SAME registers — 91 v_pk_fma_f32 with δ₂[i] on both halves — and its 14 partial sums per lane cross the
+//     16 row groups through LDS (7 ds_write_b64, then lane u adds its unit's 16 partials). The bias b₂ rides as column H₁ of the
+//     block against a constant 1 in h₁[H₁] (the padding of the 16·14 = 224 columns), so it costs nothing — and the same 1 makes
+//     row H₁ of the weight-gradient tiles below the gradient of b₂;
+//   * the thin products stay as in k_mlpw: lane u owns unit u's row of W₁ and column of W₃ (a₁ and W₃ᵀλ: D′ FMAs each on the
+//     broadcast state), and H → D′ (f = W₃h₂, vz = W₁ᵀδ₁) with lanes = (K-segment, output) on slices kept in LDS;
+//   * THE WEIGHT GRADIENT NEVER LEAVES THE CU: the vectors an evaluation passes through LDS anyway (z|λ, h₁, δ₂, h₂, δ₁) are a RING
+//     indexed by the stage; at accept time the step's 4 (RK4) or 6 (Tsit5) evaluations are folded by v_mfma_f32_16x16x4_f32 — K =
+//     four evaluations per instruction, the δ-side operand scaled by its quadrature weight b_s·|h| — into accumulator-resident
+//     16 × 16 tiles: 13 × 13 of gW₂ᵀ, 13 of gW₁, 13 of gW₃ᵀ, dealt round-robin to the four waves (50 tiles = 200 AGPRs per lane); a
+//     rejected attempt folds nothing. Biases of the thin layers: one FMA per evaluation and lane at fold time. At the end every
+//     workgroup writes ONE row of a [workgroups × nW] slab in flat destructure order and k_sum_rows adds the rows in index order
+//     (bit-reproducible). No staging area, no k_mlp_dw, no k_reduce_tiles, no memsets: lde_adjoint is two launches.
+// Same algorithm and control arithmetic as k_mlpw (state in lanes 0 … 2·DP−1 of every wave, HNW initial step, PI controller
+// carried across the save times, one-round-trip grid sum for coupled control). Limits: exactly three Dense layers D′ → H₁ → H₂ →
+// D′ with D′ ≤ 16, 128 < max(H₁, H₂) ≤ 200 (narrower networks: k_mlpw's two-wave form), P = 0, no analytic part.
+
+struct BDims {
+  int DP;                 // lanes per state half: 8 or 16
+  int SEG, GS;            // narrow products: K-segments (64/DP), float4 groups per lane
+  // float offsets in the packed array
+  int o_wb, o_w13, o_b1, o_b3, o_n3, o_n1, total;
+};
+
+namespace mlpb {
+constexpr int W = 4, UT = 256;        // waves, lanes of a workgroup
+constexpr int RB = 13, CB = 13, CBP = 6; // block: 13 rows × 13 columns = 6 column pairs + a single column
+constexpr int HV = 224;               // floats of a hidden vector in LDS (16·13 = 208 block columns / rows, padded for the narrow products' float4 reads)
+constexpr int NT = 13;                // 16-wide tiles along a hidden index (unit H₁ = 200, the constant 1, included)
+constexpr int XS = 32;                // floats of the [z | λ] part of a ring slot
+constexpr int SLOT = XS + 4 * HV;     // ring slot: xs | h₁ | g₂ → δ₂ | h₂ | δ₁
+constexpr int NTL = 51;               // weight-gradient tile slots of a wave: 39 + 4 of gW₂ᵀ, 4 of gW₁, 4 of gW₃ᵀ
+constexpr int ntr(int dp) { return dp == 16 ? 40 : 36; }   // … of which this many are accumulator registers (the rest: LDS, 1 KB per slot and wave)
+}  // namespace mlpb
+
+// one-time packing (set_weights): everything in the order the kernel's lanes read it
+static __global__ void k_build_bpack(const float* __restrict__ Wflat, MlpDims dm, BDims bd, float* __restrict__ wp) {
+  using namespace mlpb;
+  const int H1 = dm.sizes[1], H2 = dm.sizes[2], Dp = dm.Dp;
+  const float *W1 = Wflat + dm.w_off[0], *W2 = Wflat + dm.w_off[1], *W3 = Wflat + dm.w_off[2];   // column-major [out×in]
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < bd.total; e += gridDim.x * blockDim.x) {
+    float v = 0.f;
+    if (e < bd.o_w13) {            // wb[i·CB + j][tid] = W₂(13r + i, 13c + j); column H₁ carries b₂
+      const int q = e / UT, tid = e % UT, j = q % CB, i = q / CB;
+      const int row = RB * (tid >> 4) + i, col = CB * (tid & 15) + j;
+      if (row < H2) {
+        if (col < H1) v = W2[row + H2 * col];
+        else if (col == H1) v = Wflat[dm.b_off[1] + row];
+      }
+    } else if (e < bd.o_b1) {      // w13[u][0 … DP) = W₁(u, ·), w13[u][DP … 2·DP) = W₃(·, u); rows of 2·DP + 4 floats (conflict-free ds_read_b128)
+      const int r = e - bd.o_w13, u = r / (2 * bd.DP + 4), k = r % (2 * bd.DP + 4);
+      if (k < bd.DP) { if (u < H1 && k < Dp) v = W1[u + H1 * k]; }
+      else if (k < 2 * bd.DP) { const int d = k - bd.DP; if (u < H2 && d < Dp) v = W3[d + Dp * u]; }
+    } else if (e < bd.o_b3) {
+      const int u = e - bd.o_b1;
+      if (u < H1) v = Wflat[dm.b_off[0] + u];
+    } else if (e < bd.o_n3) {
+      const int d = (e - bd.o_b3) % bd.DP;
+      if (d < Dp) v = Wflat[dm.b_off[2] + d];
+    } else {                       // narrow slices: [g][lane][4]; lane = seg·DP + d, k = (seg·GS + g)·4 + c
+      const bool n1 = e >= bd.o_n1;
+      const int r = e - (n1 ? bd.o_n1 : bd.o_n3);
+      const int c = r & 3, ln = (r >> 2) & 63, g = r >> 8;
+      const int seg = ln / bd.DP, d = ln % bd.DP, k = (seg * bd.GS + g) * 4 + c;
+      if (!n1) { if (d < Dp && k < H2) v = W3[d + Dp * k]; }      // f_d  = Σ_k W₃(d, k) h₂_k
+      else     { if (d < Dp && k < H1) v = W1[k + H1 * d]; }      // vz_d = Σ_k W₁(k, d) δ₁_k
+    }
+    wp[e] = v;
+  }
+}
+
+// v + (v of the lane 16 / 32 further, modulo 32 / 64): v_permlane16_swap / v_permlane32_swap (gfx950) exchange the odd rows of one
+// register with the even rows of the other; with both registers holding v, one ends up with the even rows repeated, the other with
+// the odd rows. (Inline asm: ROCm 7.2's __builtin_amdgcn_permlane*_swap returns its FIRST result in both elements — probed.)
+template <int W_>
+__device__ __forceinline__ float swap_sum(float v) {
+  float a = v, b = v;
+  if (W_ == 16) asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  else asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+template <int CTRL>
+__device__ __forceinline__ float dpp_xadd(float v) {   // v + (v of the lane CTRL maps this lane to): the butterfly steps inside a row of 16
+  return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// (quad_perm [1,0,3,2], quad_perm [2,3,0,1], row_half_mirror (lane i ↔ 7 − i), row_mirror (lane i ↔ 15 − i) = the sum over the 16
+//  lanes of a DPP row in every lane of the row; the two operands of every add are exchanged between the partner lanes and f32
+//  addition commutes, so all 16 results are bitwise equal)
+
+__device__ __forceinline__ float sgpr_f(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, v))); }
+__device__ __forceinline__ long long sgpr_ll(long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double sgpr_d(double v) { return __builtin_bit_cast(double, sgpr_ll(__builtin_bit_cast(long long, v))); }
+
+template <int SOLVER, int DP, int ACT, bool ADJ>
+__global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, VArgs a) {
+  using namespace mlpb;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  constexpr int SEG = 64 / DP, G1 = DP / 4, GS = (200 / SEG + 3) / 4;   // GS: host = bd.GS
+  constexpr int NST = SOLVER == LDE_SOLVER_TSIT5 ? 6 : 4;                // weighted stages of a step = ring slots the fold reads
+  constexpr int NSL = ADJ ? NST + 1 : 1;                                  // + one scratch slot (initial-step probes, the FSAL stage)
+  constexpr int W13S = 2 * DP + 4;
+  constexpr int NTR = ntr(DP);
+  static_assert(DP == 8 || DP == 16, "k_mlpb geometry");
+  const int T = o.T, B = o.B, D = dm.D, Dp = dm.Dp, tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int u = tid;                      // the hidden unit this lane owns in the thin products
+  const int br = tid >> 4, bc = tid & 15; // block coordinates
+  const int H1 = dm.sizes[1], H2 = dm.sizes[2];
+  // ---- LDS: save times | ring | partial sums of W₂ᵀδ₂ | narrow slices | cotangents
+  double* s_ts = reinterpret_cast<double*>(smem);
+  float* ring = reinterpret_cast<float*>(smem + (((size_t)T * 8 + 15) & ~size_t(15)));
+  float* part = ring + NSL * SLOT;
+  f32x4* ltile = reinterpret_cast<f32x4*>(part + (ADJ ? 16 * HV : 0));
+  f32x4* n3 = ltile + (ADJ ? (NTL - NTR) * UT : 0);
+  f32x4* n1 = n3 + GS * 64;
+  float* w13 = reinterpret_cast<float*>(n1 + (ADJ ? GS * 64 : 0));     // rows of W₁ | columns of W₃ by unit: [HV][2·DP + 4]
+  float* s_cot = w13 + HV * W13S;                                      // adjoint: the trajectory's cotangents (and saved states) by save time
+  for (int i = tid; i < T; i += UT) s_ts[i] = a.ts[i];
+  for (int i = tid; i < NSL * SLOT + (ADJ ? 16 * HV + (NTL - NTR) * UT * 4 : 0); i += UT) ring[i] = 0.f;
+  {
+    const f32x4* g3 = reinterpret_cast<const f32x4*>(a.wpack + bd.o_n3);
+    for (int i = tid; i < GS * 64; i += UT) n3[i] = g3[i];
+    if (ADJ) {
+      const f32x4* g1 = reinterpret_cast<const f32x4*>(a.wpack + bd.o_n1);
+      for (int i = tid; i < GS * 64; i += UT) n1[i] = g1[i];
+    }
+    const f32x4* g13 = reinterpret_cast<const f32x4*>(a.wpack + bd.o_w13);
+    for (int i = tid; i < HV * W13S / 4; i += UT) reinterpret_cast<f32x4*>(w13)[i] = g13[i];
+    if (ADJ && a.cot_lds) {   // [T][Dp] dẑ (+ [T][Dp] ẑ when the adjoint restarts from the saved states): no global load inside the solve
+      for (int i = tid; i < T * Dp; i += UT) {
+        const size_t g = (size_t)Dp * ((size_t)b + (size_t)B * (i / Dp)) + (i % Dp);
+        s_cot[i] = a.dz_out[g];
+        if (o.checkpoint) s_cot[T * Dp + i] = a.z_out[g];
+      }
+    }
+  }
+  // ---- registers: the lane's block of W₂ (pairs along the columns), its row of W₁ and column of W₃
+  f32x2 wb[RB][CBP];
+  float ws[RB];
+  {
+    const float* wp = a.wpack + bd.o_wb + tid;
+#pragma unroll
+    for (int i = 0; i < RB; i++) {
+#pragma unroll
+      for (int jp = 0; jp < CBP; jp++) wb[i][jp] = f32x2{wp[(i * CB + 2 * jp) * UT], wp[(i * CB + 2 * jp + 1) * UT]};
+      ws[i] = wp[(i * CB + CB - 1) * UT];
+    }
+  }
+  const f32x4* const my13 = reinterpret_cast<const f32x4*>(w13 + (u < HV ? u : 0) * W13S);   // this lane's row of W₁ | column of W₃ (LDS)
+  const float b1 = a.wpack[bd.o_b1 + u], b3 = a.wpack[bd.o_b3 + (lane % DP)];
+  constexpr int act = ACT;   // (compile-time: a run-time activation is a branch per call, and the block product applies it 13 times per lane)
+  // the weight gradient: accumulator-resident 16×16 tiles (C/D layout of v_mfma_f32_16x16x4_f32: column = lane & 15, row = 4·(lane >> 4) + reg)
+  // (of a wave's NTL tile slots the first NTR stay in registers; the others live in LDS, a 1 KB word array per slot and wave)
+  f32x4 gt[ADJ ? NTR : 1];
+  float gb1 = 0.f, gb3 = 0.f;
+  if (ADJ) {
+#pragma unroll
+    for (int n = 0; n < NTR; n++) gt[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4* const my_lt = ltile + tid;
+  float lt_a[NTL - NTR + 1], lt_b[NTL - NTR + 1];   // operands of the LDS-resident slots, collected while the register slots are multiplied
+  auto acc_tile = [&](int n, float av, float bv) {   // n: compile-time after unrolling
+    if (n < NTR) gt[n < NTR ? n : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, gt[n < NTR ? n : 0], 0, 0, 0);
+    else { lt_a[n < NTR ? 0 : n - NTR] = av; lt_b[n < NTR ? 0 : n - NTR] = bv; }
+  };
+  auto acc_lds_tiles = [&]() {   // read – multiply – write, five slots at a time (one round trip per batch, not per slot)
+    constexpr int NL = NTL - NTR, BT = 5;
+#pragma unroll
+    for (int n0 = 0; n0 < NL; n0 += BT) {
+      f32x4 tv[BT];
+#pragma unroll
+      for (int q = 0; q < BT; q++)
+        if (n0 + q < NL) tv[q] = my_lt[(n0 + q) * UT];
+#pragma unroll
+      for (int q = 0; q < BT; q++)
+        if (n0 + q < NL) tv[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(lt_a[n0 + q], lt_b[n0 + q], tv[q], 0, 0, 0);
+#pragma unroll
+      for (int q = 0; q < BT; q++)
+        if (n0 + q < NL) my_lt[(n0 + q) * UT] = tv[q];
+    }
+  };
+  auto get_tile = [&](int n) -> f32x4 { return n < NTR ? gt[n < NTR ? n : 0] : my_lt[(n - NTR) * UT]; };
+  __syncthreads();
+
+  const bool coupled = dm.coupled != 0;
+  const double t0 = s_ts[0], tend = s_ts[T - 1], dtmax = fabs(tend - t0);
+  unsigned gen = 0;
+
+  // ---- state: lane i < DP holds z_i, lane DP + i holds λ_i (adjoint); the other lanes stay 0
+  const bool is_z = lane < Dp, is_l = ADJ && lane >= DP && lane < DP + Dp;
+  const bool counted = is_z || is_l;
+  const int row = is_l ? lane - DP : lane;
+  float y = 0.f, yn = 0.f, tmp = 0.f, scr = 0.f, k[7];
+#pragma unroll
+  for (int s = 0; s < 7; s++) k[s] = 0.f;
+  if (!ADJ) {
+    if (lane < D) y = a.z0[(size_t)b * D + lane];
+  } else if (counted) {
+    const size_t srcg = (size_t)Dp * ((size_t)b + (size_t)B * (T - 1)) + row;
+    y = is_z ? a.z_out[srcg] : a.dz_out[srcg];
+  }
+  double t = ADJ ? tend : t0, dt = 0.0, tnew = 0.0;
+  float h = 0.f, qold = 1e-4f, wq = 0.f, d1n = 0.f;
+  int status, j = ADJ ? T - 2 : 1, last = 0, hit = 0, nfe = 0, nacc = 0, nrej = 0;
+  long long iters = 0;
+  {
+    // a failed forward trajectory is a constant NaN block ⇒ zero gradient  [REF GOKU.jl:114]
+    const bool bad = ADJ && __any(is_z && !isfinite(y));
+    status = bad ? 1 + LDE_RET_NONFINITE : (T > 1 ? 0 : 1);
+    if (ADJ && bad) y = 0.f;
+  }
+  if (!ADJ && wv == 0 && lane < Dp) a.z_out[(size_t)b * Dp + lane] = y;   // save time 0 = ẑ₀ itself (augmented rows 0)
+
+  enum { PH_K0 = 0, PH_INIT1 = 1, PH_STAGE = 2 };
+  constexpr int LAST_STAGE = SOLVER == LDE_SOLVER_TSIT5 ? 6 : (ADJ ? 3 : 4);
+  const float dirn = ADJ ? -1.f : 1.f;
+  const float nnorm = (float)(ADJ ? 2 * Dp : Dp) * (coupled ? (float)(a.Bnorm > 0 ? a.Bnorm : B) : 1.f);   // Bnorm: the batch over ALL ranks (LDE_BATCH_COUPLED_GLOBAL)
+
+  auto begin_step = [&]() -> bool {
+    if (status == 0 && iters++ >= o.maxiters) status = 1 + LDE_RET_MAXITERS;
+    if (status == 0) {
+      if (!ADJ) {
+        double d = dt;
+        last = 0;
+        if (t + d >= tend - 1e-12 * fabs(tend)) { d = tend - t; last = 1; }
+        tnew = last ? tend : t + d;
+        h = (float)d;
+        wq = (float)d;
+        dt = d;
+      } else {
+        const double dist = t - s_ts[j];
+        double hmag = dt;
+        hit = 0;
+        if (hmag >= dist * (1.0 - 1e-12)) { hmag = dist; hit = 1; }
+        tnew = hmag;
+        h = -(float)hmag;
+        wq = (float)hmag;
+      }
+    } else {
+      h = 0.f;
+      wq = 0.f;
+      hit = 0;
+    }
+    return status == 0;
+  };
+  // (coupled control: the status is a function of the shared sums, so every workgroup leaves the loop at the same step)
+  // Σ over the lanes that differ in the K-segment bits (lane bits ≥ log₂ DP), in every lane — on the VALU (a DPP rotate inside the
+  // row of 16, v_permlane16_swap / v_permlane32_swap across rows), not three dependent ds_bpermute round trips
+  auto xor_segs = [&](float p) -> float {
+    if (DP <= 8) p = dpp_xadd<0x128>(p);   // row_ror:8
+    return swap_sum<32>(swap_sum<16>(p));
+  };
+  // H → D′ with lanes = (K-segment, output): the slice `ns` against the LDS vector `vec`; every lane with lane % DP == d gets output d
+  auto narrow = [&](const f32x4* ns, const float* vec) -> float {
+    const f32x4* hv = reinterpret_cast<const f32x4*>(vec) + (lane / DP) * GS;
+    f32x2 p01 = {0.f, 0.f}, p23 = {0.f, 0.f};
+#pragma unroll
+    for (int g = 0; g < GS; g++) {
+      const f32x4 wq4 = ns[g * 64 + lane], xv = hv[g];
+      p01 += wq4.lo * xv.lo;
+      p23 += wq4.hi * xv.hi;
+    }
+    return xor_segs((p01.x + p01.y) + (p23.x + p23.y));
+  };
+
+  // one evaluation of the (augmented) right-hand side: src → dst; its vectors stay in ring slot `slot`
+  auto eval = [&](float src, int slot) -> float {
+    PROF_T(e0);
+    float* xs = ring + slot * SLOT;
+    float *h1v = xs + XS, *d2v = h1v + HV, *h2v = d2v + HV, *d1v = h2v + HV;
+    if (lane < XS) xs[lane] = src;   // (every wave stores the same values)
+    asm volatile("" ::: "memory");   // same wave, in-order LDS: the broadcast reads below see the write (no barrier needed)
+    const f32x4* x4 = reinterpret_cast<const f32x4*>(xs);
+    float h1;
+    {
+      f32x2 c01 = {0.f, 0.f}, c23 = {0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < G1; g++) {
+        const f32x4 xv = x4[g], wv4 = my13[g];
+        c01 += wv4.lo * xv.lo;
+        c23 += wv4.hi * xv.hi;
+      }
+      const float a1 = b1 + ((c01.x + c01.y) + (c23.x + c23.y));
+      h1 = u == H1 ? 1.f : act_fn(act, a1);   // unit H₁: the constant that carries b₂ (rows beyond: zero weights and bias ⇒ act(0) = 0)
+    }
+    if (u < HV) h1v[u] = h1;
+    if (ADJ) {
+      f32x2 c01 = {0.f, 0.f}, c23 = {0.f, 0.f};
+#pragma unroll
+      for (int g = 0; g < G1; g++) {
+        const f32x4 xv = x4[DP / 4 + g], wv4 = my13[DP / 4 + g];   // λ
+        c01 += wv4.lo * xv.lo;
+        c23 += wv4.hi * xv.hi;
+      }
+      if (u < HV) d2v[u] = (c01.x + c01.y) + (c23.x + c23.y);   // (W₃ᵀλ)_u; becomes δ₂ below
+    }
+    __syncthreads();
+    PROF_T(e1);
+    // ---- the block products (independent chains side by side: two groups of rows, each as 7 / 6 accumulator pairs + singles)
+    float h2[RB];
+    {
+      const float* hc = h1v + CB * bc;
+      f32x2 hp[CBP];
+#pragma unroll
+      for (int jp = 0; jp < CBP; jp++) hp[jp] = f32x2{hc[2 * jp], hc[2 * jp + 1]};
+      const float hs = hc[CB - 1];
+#pragma unroll
+      for (int i0 = 0; i0 < RB; i0 += 7) {
+        f32x2 acc[7];
+        float as[7];
+#pragma unroll
+        for (int ii = 0; ii < 7; ii++)
+          if (i0 + ii < RB) { acc[ii] = wb[i0 + ii][0] * hp[0]; as[ii] = ws[i0 + ii] * hs; }
+#pragma unroll
+        for (int jp = 1; jp < CBP; jp++)
+#pragma unroll
+          for (int ii = 0; ii < 7; ii++)
+            if (i0 + ii < RB) acc[ii] += wb[i0 + ii][jp] * hp[jp];
+#pragma unroll
+        for (int ii = 0; ii < 7; ii++)
+          if (i0 + ii < RB) h2[i0 + ii] = (acc[ii].x + acc[ii].y) + as[ii];
+      }
+      // the 16 lanes of a row add their 13 partial sums: four butterfly steps, all 13 values per step
+#pragma unroll
+      for (int i = 0; i < RB; i++) h2[i] = dpp_xadd<0xB1>(h2[i]);    // quad_perm [1,0,3,2]
+#pragma unroll
+      for (int i = 0; i < RB; i++) h2[i] = dpp_xadd<0x4E>(h2[i]);    // quad_perm [2,3,0,1]
+#pragma unroll
+      for (int i = 0; i < RB; i++) h2[i] = dpp_xadd<0x141>(h2[i]);   // row_half_mirror
+#pragma unroll
+      for (int i = 0; i < RB; i++) h2[i] = act_fn(act, dpp_xadd<0x140>(h2[i]));   // row_mirror; every lane of the row holds the 13 sums, bitwise equal
+    }
+    if (ADJ) {
+      float d2[RB];
+#pragma unroll
+      for (int i = 0; i < RB; i++) d2[i] = d2v[RB * br + i] * act_grad(act, h2[i]);
+      if (bc == 0) {   // one lane of the row leaves h₂ and δ₂ for the thin products and the fold
+#pragma unroll
+        for (int i = 0; i < RB; i++) {
+          h2v[RB * br + i] = h2[i];
+          d2v[RB * br + i] = d2[i];
+        }
+      }
+      f32x2 gp[CBP];
+      float gs = 0.f;
+#pragma unroll
+      for (int jp = 0; jp < CBP; jp++) gp[jp] = f32x2{0.f, 0.f};
+#pragma unroll
+      for (int i = 0; i < RB; i++) {
+        const f32x2 dd = {d2[i], d2[i]};
+#pragma unroll
+        for (int jp = 0; jp < CBP; jp++) gp[jp] += wb[i][jp] * dd;
+        gs += ws[i] * d2[i];
+      }
+      float* pp = part + br * HV + CB * bc;
+#pragma unroll
+      for (int jp = 0; jp < CBP; jp++) { pp[2 * jp] = gp[jp].x; pp[2 * jp + 1] = gp[jp].y; }
+      pp[CB - 1] = gs;
+    } else if (bc == 0) {
+#pragma unroll
+      for (int i = 0; i < RB; i++) h2v[RB * br + i] = h2[i];
+    }
+    __syncthreads();
+    PROF_T(e2);
+    const float f = narrow(n3, h2v) + b3;
+    float dst = is_z ? f : 0.f;
+    PROF_ADD(3, e0, e1);
+    PROF_ADD(4, e1, e2);
+    if (ADJ) {
+      float g1 = 0.f;
+      if (u < HV) {
+        float p[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) p[r] = part[r * HV + u];
+#pragma unroll
+        for (int r = 0; r < 16; r++) g1 += p[r];
+      }
+      const float d1 = u < H1 ? g1 * act_grad(act, h1) : 0.f;
+      if (u < HV) d1v[u] = d1;
+      __syncthreads();
+      const float vz = narrow(n1, d1v);     // every lane with lane % DP == d holds vz_d
+      if (is_l) dst = -vz;
+      PROF_T(e3);
+      PROF_ADD(5, e2, e3);
+    }
+    PROF_T(e5);
+    PROF_ADD(1, e0, e5);
+    PROF_ADD(20, e5 - 1, e5);
+    return dst;
+  };
+
+  // the accepted step's share of the quadrature gW = Σ_s |h| b_s (∂f/∂W)ᵀλ, from the vectors its evaluations left in the ring.
+  // Tile slots of wave w (every operand address = a per-lane base + a compile-time offset):
+  //   n = 3·ti + m, ti < 13, m < 3 : gW₂ᵀ tile (ti, tj = 4m + w)          n = 39 + q : gW₂ᵀ tile (ti = 4q + w, tj = 12)
+  //   n = 43 + q : gW₁ tile 4q + w (A = δ₁, B = z)                        n = 47 + q : gW₃ᵀ tile 4q + w (A = h₂, B = λ)
+  // (q = 3 is a real tile for wave 0 only; the other waves' slot accumulates finite junk that is never written out)
+  auto fold = [&]() {
+    PROF_T(f0);
+    const int l15 = lane & 15, e4 = lane >> 4;
+#pragma unroll
+    for (int g = 0; g < (NST + 3) / 4; g++) {
+      const int e = 4 * g + e4;
+      float bs;
+      if (SOLVER == LDE_SOLVER_TSIT5) bs = e == 0 ? ts5::A[6][0] : e == 1 ? ts5::A[6][1] : e == 2 ? ts5::A[6][2] : e == 3 ? ts5::A[6][3] : e == 4 ? ts5::A[6][4] : e == 5 ? ts5::A[6][5] : 0.f;
+      else bs = (e == 0 || e == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
+      const bool ev = e < NST;                 // (Tsit5's second group has two evaluations: the other two K slots are zeros)
+      const float wsc = ev ? wq * bs : 0.f, am = ev ? 1.f : 0.f;
+      const float* sl = ring + (ev ? e : 0) * SLOT + l15;
+      const float* pa = sl + XS + 16 * wv;     // A operands of the slots whose tile index is 4q + w
+      float bm[3];
+#pragma unroll
+      for (int m = 0; m < 3; m++) bm[m] = sl[XS + HV + 64 * m + 16 * wv] * wsc;
+#pragma unroll
+      for (int ti = 0; ti < NT; ti++) {        // gW₂ᵀ[i][o] += Σ_e h₁_e[i] · (w_e δ₂_e)[o]
+        const float av = sl[XS + 16 * ti] * am;
+#pragma unroll
+        for (int m = 0; m < 3; m++) acc_tile(3 * ti + m, av, bm[m]);
+      }
+      {
+        const float b12 = sl[XS + HV + 16 * 12] * wsc;
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc_tile(39 + q, pa[64 * q] * am, b12);
+      }
+      {                                        // gW₁[u][k] += Σ_e (w_e δ₁_e)[u] · z_e[k];  gW₃ᵀ[u][d] += Σ_e h₂_e[u] · (w_e λ_e)[d]
+        const float bz = l15 < Dp ? sl[0] * wsc : 0.f, bl = l15 < Dp ? sl[DP] * wsc : 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc_tile(43 + q, pa[3 * HV + 64 * q] * am, bz);
+#pragma unroll
+        for (int q = 0; q < 4; q++) acc_tile(47 + q, pa[2 * HV + 64 * q] * am, bl);
+      }
+      acc_lds_tiles();
+    }
+    // thin biases: gb₁[u] += Σ_e w_e δ₁_e[u] (lane u), gb₃[d] += Σ_e w_e λ_e[d] (the λ lanes); gb₂ is row H₁ of the gW₂ᵀ tiles
+#pragma unroll
+    for (int e = 0; e < NST; e++) {
+      const float bs = SOLVER == LDE_SOLVER_TSIT5 ? ts5::A[6][e] : ((e == 0 || e == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f));
+      const float* sl = ring + e * SLOT;
+      if (u < HV) gb1 += (wq * bs) * sl[XS + 3 * HV + u];
+      if (lane < XS) gb3 += (wq * bs) * sl[lane];
+    }
+    __syncthreads();   // the next attempt overwrites the ring: every wave has read it
+    PROF_T(f1);
+    PROF_ADD(6, f0, f1);
+  };
+
+  const bool auto_dt = o.adaptive && !(o.dt_fixed > 0);
+  int phase = (ADJ && !auto_dt) ? PH_STAGE : PH_K0, s = 0;
+  bool running = T > 1 && status == 0;
+  if (ADJ && running && !auto_dt) {
+    dt = o.adaptive ? fmin(o.dt_fixed, dtmax) : o.dt_fixed;
+    running = begin_step();
+  }
+  while (__builtin_amdgcn_readfirstlane((int)running)) {
+    // inner loop: the evaluations of one unit of work (the two probes of the initial step size, or the stages of one step attempt) — the
+    // weight-gradient tiles are touched only outside it, in the step-end block below
+    bool step_end = false;
+    do {
+      // the step control is wave-uniform (every lane computes the same values): keep it in scalar registers across the evaluation
+      s = __builtin_amdgcn_readfirstlane(s);
+      phase = __builtin_amdgcn_readfirstlane(phase);
+      status = __builtin_amdgcn_readfirstlane(status);
+      j = __builtin_amdgcn_readfirstlane(j); last = __builtin_amdgcn_readfirstlane(last); hit = __builtin_amdgcn_readfirstlane(hit);
+      nfe = __builtin_amdgcn_readfirstlane(nfe); nacc = __builtin_amdgcn_readfirstlane(nacc); nrej = __builtin_amdgcn_readfirstlane(nrej);
+      iters = sgpr_ll(iters);
+      t = sgpr_d(t); dt = sgpr_d(dt); tnew = sgpr_d(tnew);
+      h = sgpr_f(h); qold = sgpr_f(qold); wq = sgpr_f(wq); d1n = sgpr_f(d1n);
+      PROF_T(l0);
+  #if LDE_PROF
+      struct ProfEnd { long long t0; __device__ ~ProfEnd() { PROF_T(t1); PROF_ADD(11, t0, t1); } } prof_end{l0};
+  #endif
+      float src = phase == PH_INIT1 ? tmp : y;
+      if (phase == PH_STAGE) {
+        if (SOLVER == LDE_SOLVER_TSIT5) {
+          if (s > 0) {
+  #define BSTAGE(S_)                                                                 \
+    case S_: {                                                                       \
+      float accv = ts5::A[S_][0] * k[0];                                             \
+      _Pragma("unroll") for (int jj = 1; jj < S_; jj++) accv += ts5::A[S_][jj] * k[jj]; \
+      src = y + h * accv;                                                            \
+    } break;
+            switch (s) {
+              BSTAGE(1) BSTAGE(2) BSTAGE(3) BSTAGE(4) BSTAGE(5) BSTAGE(6)
+              default: break;
+            }
+  #undef BSTAGE
+            if (s == 6) yn = src;
+          }
+        } else if (ADJ || s < 4) {
+          if (s > 0) {
+            const float cs = (s == 3 ? 1.0f : 0.5f) * h;
+            src = y + cs * (s == 1 ? k[0] : (s == 2 ? k[1] : k[2]));
+          }
+        } else {
+          const float h6 = h * (1.0f / 6.0f);
+          yn = y + h6 * (k[0] + 2.0f * (k[1] + k[2]) + k[3]);
+          src = yn;
+        }
+      }
+      const float dst = eval(src, ADJ ? ((phase == PH_STAGE && s < NST) ? s : NST) : 0);
+      {
+        const int ks = phase == PH_K0 ? 0 : (phase == PH_INIT1 ? 1 : s);
+  #pragma unroll
+        for (int q = 0; q < 7; q++)
+          if (q == ks) k[q] = dst;
+      }
+      if (status == 0) nfe++;
+
+      if (phase == PH_K0 && !(ADJ || auto_dt)) {
+        dt = o.adaptive ? fmin(o.dt_fixed, dtmax) : o.dt_fixed;
+        phase = PH_STAGE;
+        s = 1;
+        running = begin_step();
+      } else if (phase == PH_K0) {
+        // Hairer–Nørsett–Wanner, part 1
+        const float sk = fast_rcp(o.abstol + fabsf(y) * o.reltol);
+        scr = sk;
+        const float a0 = y * sk, a1v = k[0] * sk;
+        float v0 = wave_sum64(counted ? a0 * a0 : 0.f), v1 = wave_sum64(counted ? a1v * a1v : 0.f);
+        if (coupled) {
+          if (status != 0) v0 = v1 = 0.f;
+          w_grid_sum<true>(a.gs, gen, a.epoch, v0, v1);
+        }
+        const float d0 = sqrtf(v0 / nnorm);
+        d1n = sqrtf(v1 / nnorm);
+        double dt0 = (d0 < 1e-5f || d1n < 1e-5f) ? 1e-6 : 0.01 * (double)(d0 * fast_rcp(d1n));
+        if (dt0 > dtmax) dt0 = dtmax;
+        dt = dt0;
+        h = status == 0 ? dirn * (float)dt0 : 0.f;
+        tmp = y + h * k[0];
+        phase = PH_INIT1;
+      } else if (phase == PH_INIT1) {
+        const float dd = (k[1] - k[0]) * scr;
+        float w0 = wave_sum64(counted ? dd * dd : 0.f), w1 = 0.f;
+        if (coupled) {
+          if (status != 0) w0 = 0.f;
+          w_grid_sum<false>(a.gs, gen, a.epoch, w0, w1);
+        }
+        const double dt0 = dt;
+        const float d2 = sqrtf(w0 / nnorm) * fast_rcp((float)dt0);
+        const float dm_ = fmaxf(d1n, d2);
+        const double dt1 = (dm_ <= 1e-15f) ? fmax(1e-6, dt0 * 1e-3) : (double)(0.39810717055349726f * fast_pow(dm_, -0.2f));
+        const double dn = fmin(100.0 * dt0, dt1);
+        dt = dn > dtmax ? dtmax : dn;
+        phase = PH_STAGE;
+        s = ADJ ? 0 : 1;
+        running = begin_step();
+      } else if (s < LAST_STAGE) {
+        s++;
+      } else
+        step_end = true;
+    } while (!__builtin_amdgcn_readfirstlane((int)step_end));
+    // ---- the end of a step attempt: error norm, controller, accept / reject
+    if (ADJ && SOLVER == LDE_SOLVER_RK4) {
+      const float h6 = h * (1.0f / 6.0f);
+      yn = y + h6 * (k[0] + 2.0f * (k[1] + k[2]) + k[3]);
+    }
+    float r2 = 0.f;
+    if (o.adaptive && counted) {
+      float er = ts5::BT[0] * k[0];
+#pragma unroll
+      for (int jj = 1; jj < 7; jj++) er += ts5::BT[jj] * k[jj];
+      er *= h;
+      const float sk = o.abstol + fmaxf(fabsf(y), fabsf(yn)) * o.reltol;
+      const float r = er * fast_rcp(sk);
+      r2 = r * r;
+    }
+    if (!isfinite(yn)) r2 = __int_as_float(0x7fc00000);   // a non-finite state poisons the sum
+    float s2 = wave_sum64(r2), s2b = 0.f;
+    if (coupled) {
+      if (status != 0) s2 = 0.f;
+      w_grid_sum<false>(a.gs, gen, a.epoch, s2, s2b);
+    }
+    bool accepted = false;
+    if (status == 0) {
+      const float EEst = o.adaptive ? sqrtf(s2 / nnorm) : (s2 == s2 ? 0.f : s2);
+      const double hmag = ADJ ? tnew : dt;
+      if (!(EEst == EEst)) {
+        if (o.adaptive && hmag > o.dtmin) { nrej++; dt = hmag * (double)o.qmin; }
+        else status = 1 + LDE_RET_NONFINITE;
+      } else if (o.adaptive) {
+        float q11;
+        const float q = pi_q(EEst, qold, o, q11);
+        if (EEst > 1.0f) {
+          nrej++;
+          const double nd = hmag * (double)fast_rcp(fminf(o.q_hi, q11 * o.inv_gamma));
+          dt = nd;
+          if (nd < o.dtmin) status = 1 + LDE_RET_DTMIN;
+        } else {
+          qold = fmaxf(EEst, 1e-4f);
+          double dtp = hmag * (double)fast_rcp(q);
+          if (dtp > dtmax) dtp = dtmax;
+          dt = dtp;
+          accepted = true;
+        }
+      } else {
+        dt = o.dt_fixed;
+        accepted = true;
+      }
+      if (accepted) nacc++;
+    }
+    if (!ADJ) {
+      while (accepted && j < T && s_ts[j] <= tnew) {   // dense output at every save time inside the accepted step
+        const double tj = s_ts[j];
+        const float th = (tj >= tnew || (j == T - 1 && last)) ? 2.0f : (float)(tj - t) * fast_rcp(wq);
+        float ov;
+        if (th > 1.5f) ov = yn;
+        else if (SOLVER == LDE_SOLVER_TSIT5) {
+          float bw[7];
+          tsit5_interp_weights(th, bw);
+          float acc = bw[0] * k[0];
+#pragma unroll
+          for (int q = 1; q < 7; q++) acc += bw[q] * k[q];
+          ov = y + wq * acc;
+        } else {
+          const float om = 1.0f - th;
+          const float h00 = (1.0f + 2.0f * th) * om * om, h10 = th * om * om;
+          const float h01 = th * th * (3.0f - 2.0f * th), h11 = th * th * (th - 1.0f);
+          ov = h00 * y + (h10 * wq) * k[0] + h01 * yn + (h11 * wq) * k[4];
+        }
+        if (wv == 0 && lane < Dp) a.z_out[(size_t)Dp * ((size_t)b + (size_t)B * j) + lane] = ov;
+        j++;
+      }
+      if (accepted) {
+        y = yn;
+        k[0] = k[LAST_STAGE];
+        t = tnew;
+        if (last) status = 1;
+      }
+      s = 1;
+      running = begin_step();
+    } else {
+      if (__builtin_amdgcn_readfirstlane((int)accepted)) {   // (workgroup-uniform: every wave takes bitwise the same decisions — say so to the compiler: a scalar branch)
+        fold();
+        y = yn;
+        if (hit) {
+          if (counted) {
+            if (a.cot_lds) {
+              if (is_l) y += s_cot[j * Dp + row];
+              else if (o.checkpoint) y = s_cot[(T + j) * Dp + row];
+            } else {
+              const size_t srcg = (size_t)Dp * ((size_t)b + (size_t)B * j) + row;
+              if (is_l) y += a.dz_out[srcg];
+              else if (o.checkpoint) y = a.z_out[srcg];
+            }
+          }
+          t = s_ts[j];
+          j--;
+          if (j < 0) status = 1;
+        } else
+          t -= tnew;
+      }
+      s = 0;
+      running = begin_step();
+    }
+  }
+
+  // ---- results
+  const int st = status;
+  if (!ADJ) {
+    if (st > 1) {
+      const float qn = __int_as_float(0x7fc00000);
+      for (int e = tid; e < Dp * T; e += UT) a.z_out[(size_t)Dp * ((size_t)b + (size_t)B * (e / Dp)) + (e % Dp)] = qn;
+    }
+    if (tid == 0) {
+      const int ret = st > 1 ? st - 1 : 0;
+      if (a.retcode) a.retcode[b] = ret;
+      a.st_ret[b] = ret;
+    }
+  } else {
+    if (wv == 0 && lane >= DP && lane < DP + D) a.dz0[(size_t)b * D + (lane - DP)] = st > 1 ? 0.f : y;
+    if (tid == 0) a.st_ret[b] = st > 1 ? st - 1 : 0;
+    // the workgroup's row of the [workgroups × row stride] slab, flat destructure order (vec(W) column-major [out×in], then b): every
+    // entry is owned by exactly one lane (a failed trajectory contributes zeros: nothing was folded after the failure … and what was
+    // folded before it is dropped, as its dẑ₀ is)
+    float* out = a.stage + (size_t)b * a.cap;
+    const bool keep = st <= 1;
+    const int l15 = lane & 15, e4 = lane >> 4;
+    auto put2 = [&](int n, int ti, int tj) {   // gW₂ᵀ tile (ti, tj): rows = h₁ index (row H₁: gb₂), columns = δ₂ index
+      const f32x4 tv = get_tile(n);
+      const int oo = 16 * tj + l15;
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int i = 16 * ti + 4 * e4 + r;
+        if (ti < NT && oo < H2) {
+          if (i < H1) out[dm.w_off[1] + oo + H2 * i] = keep ? tv[r] : 0.f;
+          else if (i == H1) out[dm.b_off[1] + oo] = keep ? tv[r] : 0.f;
+        }
+      }
+    };
+#pragma unroll
+    for (int ti = 0; ti < NT; ti++)
+#pragma unroll
+      for (int m = 0; m < 3; m++) put2(3 * ti + m, ti, 4 * m + wv);
+#pragma unroll
+    for (int q = 0; q < 4; q++) put2(39 + q, 4 * q + wv, 12);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const f32x4 t1 = get_tile(43 + q), t3 = get_tile(47 + q);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int uu = 16 * (4 * q + wv) + 4 * e4 + r;
+        if (l15 < Dp) {
+          if (uu < H1) out[dm.w_off[0] + uu + H1 * l15] = keep ? t1[r] : 0.f;
+          if (uu < H2) out[dm.w_off[2] + l15 + Dp * uu] = keep ? t3[r] : 0.f;
+        }
+      }
+    }
+    if (u < H1) out[dm.b_off[0] + u] = keep ? gb1 : 0.f;
+    if (wv == 0 && is_l) out[dm.b_off[2] + row] = keep ? gb3 : 0.f;
+  }
+  if (tid == 0) {
+    const bool rep = !coupled || b == 0;   // coupled: one step sequence for the whole batch, reported once
+    a.st_nfe[b] = rep ? nfe : 0;
+    a.st_nacc[b] = rep ? nacc : 0;
+    a.st_nrej[b] = rep ? nrej : 0;
+  }
+}

@@ -241,7 +241,7 @@ TIGHT = {
     # the reference's default NODE shape [REF nODE.jl:11-16] at its example's batch [REF model_train_LatentODE.jl:42]: relu as in the
     # reference (the gates of c4_relu), and the tanh twin that holds the code path to 1e-5
     "ref_relu": (dict(rhs_kind=O.RHS_MLP, state_dim=16, param_dim=0, layers=(16, 200, 200, 16), batching=O.BATCH_COUPLED), 64, 16, False,
-                 (1e-5, 1e-4, 5e-3, 5e-3)),
+                 (5e-5, 1e-4, 5e-3, 5e-3)),   # (measured, round 4: kernel and f32 oracle 1.3e-5·scale apart on this relu network at 1e-6)
     "ref_tanh": (dict(rhs_kind=O.RHS_MLP, state_dim=16, param_dim=0, layers=(16, 200, 200, 16), batching=O.BATCH_COUPLED,
                       activation=O.ACT_TANH), 64, 16, False, (1e-5, 1e-5, 1e-5, 1e-5)),
 }

@@ -563,8 +563,10 @@ def test_kernel_families_agree(case, monkeypatch, o64):
         z0, L = _z0(B, D, seed=4), None
     dz = O.cotangent(T, B, D + kw.get("augment_dim", 0))
     res = {}
-    for fam, env in (("new", {}), ("tiles", {"LDE_MLPV": "0", "LDE_MLP64": "0", "LDE_MLPW": "0"}), ("mlpv", {"LDE_MLP64": "0", "LDE_MLPW": "0"})):
-        for k_ in ("LDE_MLPV", "LDE_MLP64", "LDE_MLPW"):
+    # ("mlpw": k_mlpw where k_mlpb — W₂ as register blocks, the weight gradient folded on the CU; round 4 — is the default)
+    for fam, env in (("new", {}), ("mlpw", {"LDE_MLPB": "0"}), ("tiles", {"LDE_MLPV": "0", "LDE_MLP64": "0", "LDE_MLPW": "0"}),
+                     ("mlpv", {"LDE_MLP64": "0", "LDE_MLPW": "0"})):
+        for k_ in ("LDE_MLPV", "LDE_MLP64", "LDE_MLPW", "LDE_MLPB"):
             monkeypatch.delenv(k_, raising=False)
         for k_, v_ in env.items():
             monkeypatch.setenv(k_, v_)
@@ -574,7 +576,7 @@ def test_kernel_families_agree(case, monkeypatch, o64):
         assert (ret == 0).all() and sb["nfailed"] == 0
         res[fam] = (z, g0, gL, gW)
     rel = lambda a, b: np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
-    for fam in ("new", "mlpv"):
+    for fam in ("new", "mlpw", "mlpv"):
         z, g0, gL, gW = res[fam]
         zt, t0, tL, tW = res["tiles"]
         assert np.abs(z - zt).max() <= max(lim, 2e-5) * max(1.0, np.abs(zt).max()), (fam, "z")

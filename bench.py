@@ -523,7 +523,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def attach_traffic(roof, workload, B, mlp, full_batch, dom=None, rounds=("r3", "r2", "r1")):
+def attach_traffic(roof, workload, B, mlp, full_batch, dom=None, rounds=("r4", "r3", "r2", "r1")):
     """roofline.traffic (+ rocprof_avg_launch_ms, whole_step.traffic) of the solve workloads from the newest committed PMC summary
     (profiles/collect.sh + profiles/summarize.py; FETCH_SIZE ×2 only for kernels that load 16 bytes per lane, WRITE_SIZE as is —
     MI355X_MICROARCH.md §HBM). Also called by profiles/refresh.py on the bench line it copies next to a fresh summary, so the
@@ -544,8 +544,8 @@ def attach_traffic(roof, workload, B, mlp, full_batch, dom=None, rounds=("r3", "
                     roof["traffic"] = tb(kd)
                     roof["rocprof_avg_launch_ms"] = kd["avg_ns"] * 1e-6
         elif full_batch:   # MLP workloads: the dominant kernel's own traffic; the whole step's beside it
-            def is_adj_solve(name):   # the adjoint's solve kernels: k_mlp64_adj<…>, k_mlpw / k_mlpv<…, true…>, k_mlp_adjoint, k_mlp4_adjoint
-                return name.startswith(("k_mlp64_adj", "k_mlp_adjoint", "k_mlp4_adjoint")) or (name.startswith(("k_mlpw", "k_mlpv")) and "true" in name)
+            def is_adj_solve(name):   # the adjoint's solve kernels: k_mlp64_adj<…>, k_mlpb / k_mlpc / k_mlpw / k_mlpv<…, true…>, k_mlp_adjoint, k_mlp4_adjoint
+                return name.startswith(("k_mlp64_adj", "k_mlp_adjoint", "k_mlp4_adjoint")) or (name.startswith(("k_mlpb", "k_mlpc", "k_mlpw", "k_mlpv")) and "true" in name)
             adj = [(kd.get("avg_ns", 0), tb(kd)) for name, kd in kern.items() if is_adj_solve(name) and "write_bytes" in kd]
             tr = [tb(kd) for name, kd in kern.items() if name.startswith(("k_mlp", "k_reduce", "k_sum")) and "write_bytes" in kd]
             if adj:
@@ -872,7 +872,9 @@ def main():
         # (2·F_f each; the weight-gradient product, the third F_f, is counted where it runs — inside that kernel or in the tail)
         cols = B if w["batching"] == "coupled" else 1
         ph = m.get("phase_ms")
-        in_kernel_dw = ph is not None and ph[1] < 0.25 * ph[0] and args.workload == "c3"   # k_mlp64 folds gW in the wave
+        # k_mlp64 / k_mlpb / k_mlpc fold gW inside the solve kernel (what follows it is the fixed-order row sum: a few µs); the tile
+        # kernels and k_mlpw / k_mlpv stage (a_l, δ_l) for k_mlp_dw, whose product then is the tail's
+        in_kernel_dw = ph is not None and ph[1] < 0.05 * ph[0]
         dom_flops = bstat["nfe"] * (3 if in_kernel_dw else 2) * Ff * cols
         dom_ms_k = ph[0] if ph else bwd_stream
         ach = dom_flops / (dom_ms_k * 1e-3) / 1e12

@@ -1345,6 +1345,7 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
 #include "lde_mlp64.h"
 #include "lde_mlpw.h"
 #include "lde_mlpb.h"
+#include "lde_mlpc.h"
 
 // ================================================ host side =================================================
 struct MlpPlan {
@@ -1358,6 +1359,9 @@ struct MlpPlan {
   BDims bd;                    // block-layout register kernels (lde_mlpb.h)
   bool b_ok = false;
   float* bpack = nullptr;
+  CDims cd;                    // two trajectories per workgroup, networks up to 128 wide (lde_mlpc.h)
+  bool c_ok = false;
+  float* cpack = nullptr;
   unsigned epoch = 0;          // launch counter of k_mlpw's tagged grid-sum words
   float* wslots = nullptr;     // k_mlpw's own [2][nWG][4] words ({value, tag} pairs): never shared with the float partials of grid_sum4
   int wslots_cap = 0;
@@ -1407,6 +1411,7 @@ void mlp_plan_destroy(MlpPlan* p);
 static bool mlp64_applicable(const MlpDims& dm, int B);
 static int mlp64_adj_waves(int B);
 static bool b_applicable(const MlpPlan* p, int B, int T, bool adj, bool coupled_adaptive);
+static bool c_applicable(const MlpPlan* p, int B, int T, bool adj, bool coupled_adaptive);
 
 int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err) {
   MlpPlan* p = new MlpPlan();
@@ -1574,6 +1579,25 @@ int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err) 
       }
     }
   }
+  {   // two trajectories per workgroup on one register copy of the weights (lde_mlpc.h): three layers, H ≤ 128, D′ ≤ 32, coupled control
+    const int hm = dm.nL == 3 ? std::max(dm.sizes[1], dm.sizes[2]) : 0;
+    p->c_ok = dm.nL == 3 && !dm.has_pend && dm.P == 0 && dm.Dp <= 32 && hm >= 1 && hm <= 128 && dm.coupled;
+    if (p->c_ok) {
+      CDims& cd = p->cd;
+      cd.o_wb = 0;
+      cd.o_w3b = cd.o_wb + mlpc::RB * mlpc::CB * mlpc::UT;
+      cd.o_w13 = cd.o_w3b + mlpc::RB * 2 * mlpc::UT;
+      cd.o_b1 = cd.o_w13 + 128 * mlpc::W13S;
+      cd.o_b3 = cd.o_b1 + 128;
+      cd.o_n1 = cd.o_b3 + 64;
+      cd.total = cd.o_n1 + mlpc::GS * 64 * 4;
+      if (hipMalloc(&p->cpack, (size_t)cd.total * sizeof(float)) != hipSuccess) {
+        err = "MLP plan: hipMalloc failed";
+        mlp_plan_destroy(p);
+        return LDE_ERR_ALLOC;
+      }
+    }
+  }
   if (hipMalloc(&p->frag, p->nfrag * sizeof(float)) != hipSuccess ||
       hipMalloc(&p->fragT, p->nfragT * sizeof(float)) != hipSuccess ||
       hipMalloc(&p->counter, 64) != hipSuccess || hipMalloc(&p->abort_flag, 64) != hipSuccess ||
@@ -1597,6 +1621,7 @@ void mlp_plan_destroy(MlpPlan* p) {
   if (p->vecw) (void)hipFree(p->vecw);
   if (p->wpack) (void)hipFree(p->wpack);
   if (p->bpack) (void)hipFree(p->bpack);
+  if (p->cpack) (void)hipFree(p->cpack);
   if (p->wslots) (void)hipFree(p->wslots);
   if (p->counter) (void)hipFree(p->counter);
   if (p->abort_flag) (void)hipFree(p->abort_flag);
@@ -1647,7 +1672,7 @@ int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::strin
     }
     return LDE_OK;
   }
-  if (b_applicable(p, B, T, true, dm.coupled != 0)) {   // no staging area either: one slab row per workgroup (= trajectory)
+  if (b_applicable(p, B, T, true, dm.coupled != 0) || c_applicable(p, B, T, true, dm.coupled != 0)) {   // no staging area either: one slab row per workgroup
     p->rows_stride = (dm.nW + 63) & ~63;
     if (!grow(&p->rows, &p->rows_cap, (size_t)B * p->rows_stride)) {
       err = "MLP plan: hipMalloc of the weight-gradient rows failed";
@@ -1709,6 +1734,7 @@ int mlp_set_weights(MlpPlan* p, const float* W_dev, hipStream_t stream, std::str
   if (p->vec_ok) hipLaunchKernelGGL(k_build_vec, dim3(64, p->dm.nL), dim3(256), 0, stream, W_dev, p->dm, p->vd, p->vecw);
   if (p->w_ok) hipLaunchKernelGGL(k_build_wpack, dim3(128), dim3(256), 0, stream, W_dev, p->dm, p->wd, p->wpack);
   if (p->b_ok) hipLaunchKernelGGL(k_build_bpack, dim3(128), dim3(256), 0, stream, W_dev, p->dm, p->bd, p->bpack);
+  if (p->c_ok) hipLaunchKernelGGL(k_build_cpack, dim3(128), dim3(256), 0, stream, W_dev, p->dm, p->cd, p->cpack);
   if (hipGetLastError() != hipSuccess) {
     err = "k_build_frags launch failed";
     return LDE_ERR_HIP;
@@ -2054,6 +2080,63 @@ static int launch_b(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t
   return rcl;
 }
 
+// ---- two trajectories per workgroup, networks up to 128 wide (lde_mlpc.h)
+static size_t c_lds_base(int T, bool adj, int nst) {
+  const int nsl = adj ? nst + 1 : 1;
+  return (((size_t)T * 8 + 15) & ~size_t(15)) + (size_t)(nsl * mlpc::SLOT + (adj ? 16 * mlpc::HV : 0) + 16 * 16 * 4) * 4 +
+         (size_t)128 * mlpc::W13S * 4 + (adj ? (size_t)mlpc::GS * 64 * 16 : 0) + 16;
+}
+static bool c_applicable(const MlpPlan* p, int B, int T, bool adj, bool coupled_adaptive) {
+  const char* e = getenv("LDE_MLPB");    // (the switches of k_mlpb: 0 = k_mlpw instead — the parity reference)
+  const char* ew = getenv("LDE_MLPW");
+  if (!p->c_ok || (e && atoi(e) == 0) || (ew && atoi(ew) == 0)) return false;
+  if (c_lds_base(T, adj, p->dm.solver == LDE_SOLVER_RK4 ? 4 : 6) > LDS_MAX) return false;
+  // one workgroup (two trajectories) per CU: 512 trajectories are resident at once, which a coupled adaptive solve needs
+  return B <= (coupled_adaptive ? 512 : 1024);
+}
+template <int SOLVER, bool ADJ>
+static int launch_c(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t stream, std::string& err) {
+  MlpDims dmv = p->dm;
+  CDims cdv = p->cd;
+  KOpts ov = o;
+  const bool tanh_ = dmv.act == LDE_ACT_TANH;
+  const void* fn = tanh_ ? (const void*)k_mlpc<SOLVER, LDE_ACT_TANH, ADJ> : (const void*)k_mlpc<SOLVER, LDE_ACT_RELU, ADJ>;
+  size_t lds = c_lds_base(o.T, ADJ, SOLVER == LDE_SOLVER_RK4 ? 4 : 6);
+  const size_t cot = ADJ ? (size_t)2 * o.T * dmv.Dp * 4 * (o.checkpoint ? 2 : 1) : 0;
+  a.cot_lds = ADJ && lds + cot <= LDS_MAX;   // the two trajectories' dẑ (and saved ẑ) by save time: no global load inside the solve
+  if (a.cot_lds) lds += cot;
+  {   // dynamic LDS beyond the default limit needs the attribute, once per instantiation
+    static bool attr_set[2] = {false, false};
+    if (!attr_set[tanh_]) {
+      hipFuncAttributes fa{};
+      (void)hipFuncGetAttributes(&fa, fn);
+      const hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX - (int)fa.sharedSizeBytes);
+      if (ea != hipSuccess) {
+        (void)hipGetLastError();
+        err = std::string("hipFuncSetAttribute(k_mlpc) failed: ") + hipGetErrorString(ea);
+        return LDE_ERR_HIP;
+      }
+      attr_set[tanh_] = true;
+    }
+  }
+  a.wpack = p->cpack;
+  const int nwg = (o.B + 1) / 2;
+  a.gs.nwg = a.gs.nwg > 1 ? nwg : a.gs.nwg;   // (grid-wide sums: one word pair per workgroup)
+  const bool relay = a.gs.host_req != nullptr;   // LDE_BATCH_COUPLED_GLOBAL: sums leave the device; a plain launch (see launch_w)
+  if (coop || relay) {
+    const int rcw = grid_words_prepare(p, o.B, a, stream, err);
+    if (rcw) return rcw;
+  }
+#if LDE_PROF
+  prof_reset();
+#endif
+  const int rcl = launch_maybe_coop(coop && !relay, fn, dim3(nwg), dim3(mlpc::UT), lds, stream, err, "k_mlpc", dmv, cdv, ov, a);
+#if LDE_PROF
+  prof_dump(ADJ ? "c adjoint" : "c forward", stream);
+#endif
+  return rcl;
+}
+
 int mlp_set_phase_timing(MlpPlan* p, int on) {
   if (on && !p->ph_ev[0])
     for (int i = 0; i < 3; i++)
@@ -2199,7 +2282,8 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
     size_t ldsv = 0;
     const bool ca = dm.coupled && o.adaptive && o.B > 1;
     const bool use_b = b_applicable(p, o.B, o.T, false, ca);
-    const bool use_w = use_b || w_applicable(p, o.B, o.T, false, ca);
+    const bool use_c = !use_b && c_applicable(p, o.B, o.T, false, ca);
+    const bool use_w = use_b || use_c || w_applicable(p, o.B, o.T, false, ca);
     if (p->global_mode && !use_w) {
       err = "LDE_BATCH_COUPLED_GLOBAL: this shape / batch is not served by the register kernels (three Dense layers, 2·D' ≤ 64, H ≤ 200, B·W ≤ 1024 waves)";
       return LDE_ERR_UNSUPPORTED;
@@ -2218,6 +2302,8 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
         if (rca) return rca;
         const int rcw = use_b ? (dm.solver == LDE_SOLVER_RK4 ? launch_b<LDE_SOLVER_RK4, false>(p, o, va, ca, stream, err)
                                                              : launch_b<LDE_SOLVER_TSIT5, false>(p, o, va, ca, stream, err))
+                        : use_c ? (dm.solver == LDE_SOLVER_RK4 ? launch_c<LDE_SOLVER_RK4, false>(p, o, va, ca, stream, err)
+                                                               : launch_c<LDE_SOLVER_TSIT5, false>(p, o, va, ca, stream, err))
                               : (dm.solver == LDE_SOLVER_RK4 ? launch_w<LDE_SOLVER_RK4, false>(p, o, va, ca, stream, err)
                                                              : launch_w<LDE_SOLVER_TSIT5, false>(p, o, va, ca, stream, err));
         return rcw ? rcw : global_serve(p, stream, err);
@@ -2375,7 +2461,10 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
   }
   {   // W₂ as register blocks, the weight gradient folded on the CU (lde_mlpb.h): two launches, no staging area
     const bool ca = dm.coupled && o.adaptive && o.B > 1;
-    if (b_applicable(p, o.B, o.T, true, dm.coupled != 0)) {
+    const bool use_b = b_applicable(p, o.B, o.T, true, dm.coupled != 0);
+    const bool use_c = !use_b && c_applicable(p, o.B, o.T, true, dm.coupled != 0);
+    if (use_b || use_c) {
+      const int nrows = use_b ? o.B : (o.B + 1) / 2;
       if (!p->rows || p->rows_cap < (size_t)o.B * p->rows_stride || p->rows_stride < dm.nW) {
         err = "MLP adjoint: workspace not reserved";
         return LDE_ERR_INVALID_ARG;
@@ -2392,13 +2481,15 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
       const int rca = global_arm(p, va, stream, err);
       if (rca) return rca;
       phase_mark(p, 0, stream);
-      int rcb = dm.solver == LDE_SOLVER_RK4 ? launch_b<LDE_SOLVER_RK4, true>(p, o, va, ca, stream, err)
-                                            : launch_b<LDE_SOLVER_TSIT5, true>(p, o, va, ca, stream, err);
+      int rcb = use_b ? (dm.solver == LDE_SOLVER_RK4 ? launch_b<LDE_SOLVER_RK4, true>(p, o, va, ca, stream, err)
+                                                     : launch_b<LDE_SOLVER_TSIT5, true>(p, o, va, ca, stream, err))
+                      : (dm.solver == LDE_SOLVER_RK4 ? launch_c<LDE_SOLVER_RK4, true>(p, o, va, ca, stream, err)
+                                                     : launch_c<LDE_SOLVER_TSIT5, true>(p, o, va, ca, stream, err));
       if (!rcb) rcb = global_serve(p, stream, err);
       if (rcb) return rcb;
       phase_mark(p, 1, stream);
       if (dW) {
-        hipLaunchKernelGGL(k_sum_rows, dim3(cdiv(dm.nW, 64)), dim3(1024), 0, stream, p->rows, o.B, p->rows_stride, dm.nW, dW);
+        hipLaunchKernelGGL(k_sum_rows, dim3(cdiv(dm.nW, 64)), dim3(1024), 0, stream, p->rows, nrows, p->rows_stride, dm.nW, dW);
         if (hipGetLastError() != hipSuccess) {
           err = "k_sum_rows launch failed";
           return LDE_ERR_HIP;

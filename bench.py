@@ -303,6 +303,13 @@ def run_decoder(args, torch, dist, world, rank, local):
                          whole_step_TFLOPs=flops / (ms_per_step * 1e-3) / 1e12),
         "kernel_ms": parts,
     }
+    hv, tr, trk = chain_hbm_view("goku_decoder", args.dtype != "f32")
+    if hv:   # the bf16 chain kernels move 2.4–4 TB/s of counter bytes: HBM-bound, not MFMA-bound — both views side by side
+        out["roofline"]["traffic"] = tr
+        out["roofline"]["traffic_kernel"] = trk
+        out["roofline"]["hbm_view"] = hv
+        if args.dtype != "f32":
+            out["roofline"]["bound"] = "hbm (mixed: see hbm_view; the MFMA fraction is quoted beside it)"
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = decoder_cpu_baseline(specs, weights, d, ts, zt.cpu().numpy(), tt.cpu().numpy(), dxh.cpu().numpy(), B, T)
     else:
@@ -420,7 +427,7 @@ def run_goku_step(args, torch, dist, world, rank, local):
         mu, logvar = encode(enc, x)
         if fused_loss:   # sample and β·KL of the same (μ, logσ²) in one pass, the additions folded into the reductions (train.loss_batch)
             l_tilde, bkl = sample_with_kl(mu, logvar, 1e-3, Bg)
-            loss, (x_hat, z_hat, l_hat) = decode_loss(dec, l_tilde, ts, x, Bg, plus=bkl)   # Σ_pixels mean_{B,T} + β·KL  [REF model_train.jl:225-238]
+            loss, _ = decode_loss(dec, l_tilde, ts, x, Bg, plus=bkl, want_x_hat=False)   # Σ_pixels mean_{B,T} + β·KL  [REF model_train.jl:225-238]; the step keeps no x̂
         else:
             l_tilde = sample(mu, logvar)
             x_hat, z_hat, l_hat = decode(dec, l_tilde, ts)
@@ -442,7 +449,7 @@ def run_goku_step(args, torch, dist, world, rank, local):
         opt.zero_grad(set_to_none=True)
         mu, logvar = encode(enc, x)
         l_tilde, bkl = sample_with_kl(mu, logvar, 1e-3, Bg)
-        loss, _ = decode_loss(dec, l_tilde, ts, x, Bg, plus=bkl)
+        loss, _ = decode_loss(dec, l_tilde, ts, x, Bg, plus=bkl, want_x_hat=False)
         loss_backward(loss)
         return loss
 
@@ -502,13 +509,21 @@ def run_goku_step(args, torch, dist, world, rank, local):
                    "submission": ("two hipGraph replays per step around the eager gradient all-reduce (train.GraphedStep)" if split else
                                   "one hipGraph replay per step (train.GraphedStep)") if use_graph else "eager (≈ 50 launches per step)"},
         "roofline": dict(bound="mfma", kernel="whole step (dense chains dominate the flops)", achieved=3 * F_dense / (ms * 1e-3) / 1e12,
-                         peak=FP32_PEAK_TFLOPS, unit="TFLOP/s", frac=3 * F_dense / (ms * 1e-3) / 1e12 / FP32_PEAK_TFLOPS, traffic=None,
+                         peak=FP32_PEAK_TFLOPS if args.dtype == "f32" else BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                         frac=3 * F_dense / (ms * 1e-3) / 1e12 / (FP32_PEAK_TFLOPS if args.dtype == "f32" else BF16_PEAK_TFLOPS), traffic=None,
                          note=("one hipGraph replay of ≈ 30 kernels on one stream: the figure is the device's critical path (DESIGN.md §4.7)"
                                if use_graph else "eager: ≈ 50 launches per step, host enqueue time comparable to device time (DESIGN.md §4.7)")
-                         + ("; mixed: the dense chains run on the bf16 matrix cores, the fraction is still quoted against the f32 peak"
-                            if args.dtype != "f32" else "")),
+                         + ("; mixed: the dense chains run on the bf16 matrix cores — the fraction is against the dense bf16 peak (2.5 PF), and "
+                            "the chains' large kernels are HBM-bound (hbm_view)" if args.dtype != "f32" else "")),
         "loss": float(loss.detach()), "cpu_baseline": None,
     }
+    hv, tr, trk = chain_hbm_view("goku_step", args.dtype != "f32")
+    if hv:
+        out["roofline"]["traffic"] = tr
+        out["roofline"]["traffic_kernel"] = trk
+        out["roofline"]["hbm_view"] = hv
+        if args.dtype != "f32":
+            out["roofline"]["bound"] = "hbm (mixed: see hbm_view; the MFMA fraction is quoted beside it)"
     if world > 1 or (dist.is_available() and dist.is_initialized()):
         dist.barrier()
         dist.destroy_process_group()
@@ -558,6 +573,29 @@ def attach_traffic(roof, workload, B, mlp, full_batch, dom=None, rounds=("r4", "
             break
     return roof
 
+
+
+def chain_hbm_view(workload, mixed, rounds=("r4", "r3", "r2")):
+    """The dense chains' large kernels against the HBM roof: counter bytes (FETCH_SIZE + WRITE_SIZE of the committed PMC passes,
+    corrected as MI355X_MICROARCH.md §HBM prescribes) ÷ rocprofv3's average launch duration, per kernel, for the three kernels that
+    carry the step's bytes. Returns (view, traffic of the slowest of them, its name) or (None, None, None) without a committed summary."""
+    name = f"{workload}_mixed" if mixed else workload
+    for rnd in rounds:
+        prof = os.path.join(ROOT, "profiles", f"{rnd}_{name}_summary.json")
+        if not os.path.exists(prof):
+            continue
+        kern = json.load(open(prof))["kernels"]
+        rows = []
+        for kn, kd in kern.items():
+            if kn.startswith(("k_chain_forward", "k_chain_backward", "k_chain_dw")) and "_group" not in kn and "write_bytes" in kd:
+                by = kd.get("fetch_bytes", kd["fetch_bytes_x2_gfx950"]) + kd["write_bytes"]
+                gbs = by / (kd["avg_ns"] * 1e-9) / 1e9
+                rows.append(dict(kernel=kn, avg_launch_us=kd["avg_ns"] * 1e-3, traffic=by, achieved=gbs, peak=HBM_PEAK_GBS, unit="GB/s",
+                                 frac=gbs / HBM_PEAK_GBS))
+        if rows:
+            rows.sort(key=lambda r: -r["avg_launch_us"])
+            return dict(bound="hbm", source=os.path.relpath(prof, ROOT), kernels=rows[:3]), rows[0]["traffic"], rows[0]["kernel"]
+    return None, None, None
 
 
 def emit(out):
@@ -825,6 +863,19 @@ def main():
             res["fwd"] = kernel_ms(fwd, nprobe)
             res["bwd"] = kernel_ms(bwd, nprobe)
             res["step"] = kernel_ms(step, nprobe)
+            # SURVEY.md §8(d)'s definition of the time: wall clock of lde_forward + lde_adjoint, device-synchronised per call, median of
+            # ≥ 100 iterations after ≥ 10 warm-ups (the host's enqueue and the synchronisation's wake-up are inside every sample)
+            nsync = max(100, min(args.steps, 1000))
+            for _ in range(10):
+                step()
+            torch.cuda.synchronize()
+            samp = []
+            for _ in range(nsync):
+                t1 = time.perf_counter()
+                step()
+                torch.cuda.synchronize()
+                samp.append(time.perf_counter() - t1)
+            res["sync_call"] = (float(np.median(samp)) * 1e3, float(np.mean(samp)) * 1e3, nsync)
             if nW:   # the adjoint's two phases, from HIP events the library records on this stream (lde_set_phase_timing)
                 lib.lde_set_phase_timing(h, 1)
                 ph = []
@@ -912,6 +963,9 @@ def main():
         # per-step figures from HIP events (an event pair around every step): the wall-clock mean above is K steps / elapsed
         "ms_per_step_events": {"median": m["step"][1], "mean": m["step"][0], "back_to_back": m["step"][2], "samples": min(max(args.steps, 20), 200)},
         "solver_stats": {"forward": fstat, "adjoint": bstat},
+        # device-synchronised per call, median of ≥ 100 (host enqueue + wake-up included) — beside the pipelined figure above
+        "per_call_synchronised": {"median_ms": m["sync_call"][0], "mean_ms": m["sync_call"][1], "samples": m["sync_call"][2],
+                                  "value": B * world / (m["sync_call"][0] * 1e-3), "unit": "trajectories/s"},
     }
 
     if world > 1 and args.scaling == "weak" and args.workload == "goku_pendulum":

@@ -295,6 +295,17 @@ int  lde_chain_forward_save_mse(lde_chain* c, const float* x, int64_t N, float* 
  * Same values as the two calls, bit for bit. */
 int  lde_chain_backward_saved_mse(lde_chain* c, const float* x, const float* y, const float* target, const float* g_dev, float scale,
                                   const float* dy_more, const float* saved, int64_t N, float* dx, float* dW, void* stream);
+/* The same pair without the x̂ round trip (LDE_DTYPE_BF16 chains; LDE_ERR_UNSUPPORTED otherwise, or when the output width is not a
+ * multiple of 8): the forward launch's last epilogue — where x̂ and the target are in registers for the squares anyway — also leaves
+ * δ_L′ = 2·scale·(y − target)·act′(y) as the pullback's bf16 δ matrix and stores y only when asked (y may be NULL); the pullback starts
+ * from that matrix — it reads neither y nor the target: of a GOKU step's reconstructor [REF src/models/GOKU.jl:252-269] 40 MB written and
+ * 80 MB read less — and multiplies dx and dW by g = *g_dev at the end (δ is linear in g; with g = 1, the loss being the objective
+ * [REF model_train.jl:225-238], the results are those of lde_chain_backward_saved_mse bit for bit). The δ matrix lives in the chain's
+ * workspace: the pullback must follow the forward call of the same N with no other pullback of this chain in between. */
+int  lde_chain_forward_save_mse_delta(lde_chain* c, const float* x, int64_t N, float* y, float* saved, const float* target, float scale,
+                                      const float* base, float* out, float* scratch, void* stream);
+int  lde_chain_backward_saved_delta(lde_chain* c, const float* x, const float* g_dev, const float* saved, int64_t N, float* dx, float* dW,
+                                    void* stream);
 /* How the pullbacks deliver the weight gradient: on = 1 (default) dW += gradient, like lde_adjoint; on = 0: dW = gradient — every
  * entry of dW is written exactly once, so a caller that wants the plain gradient needs no zero fill (one launch less). */
 int  lde_chain_set_accumulate(lde_chain* c, int on);

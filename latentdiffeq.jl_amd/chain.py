@@ -143,7 +143,7 @@ class _ChainMseFn(torch.autograd.Function):
     test_reconstructor_under_mse_as_one_node). A cotangent of y itself (y used elsewhere too) is added in."""
 
     @staticmethod
-    def forward(ctx, chain: "Chain", x, W, target, scale: float, base):
+    def forward(ctx, chain: "Chain", x, W, target, scale: float, base, want_y: bool = True):
         if not x.is_cuda:
             raise L.LdeError("Chain needs CUDA/HIP tensors: it runs on the GPU only (no CPU fallback)")
         h = chain._native()
@@ -154,9 +154,23 @@ class _ChainMseFn(torch.autograd.Function):
             L.check(lib.lde_chain_set_weights_device(h, C.c_void_p(Wc.data_ptr()), Wc.numel(), stream), h, "lde_chain_set_weights_device", chain=True)
             chain._wkey = None
         N = x.shape[0]
-        y = torch.empty((N, chain.sizes[-1]), device=x.device, dtype=torch.float32)
         train = bool(ctx.needs_input_grad[1] or ctx.needs_input_grad[2])
         saved = torch.empty((int(lib.lde_chain_saved_floats(h, N)),), device=x.device, dtype=torch.float32) if train else None
+        ctx.delta = False
+        if _RECON_MSE_FWD and train and chain.dtype == "bf16" and chain.sizes[-1] % 8 == 0:
+            # bf16 chains: the forward launch leaves δ_L′ for the pullback (lde_chain_forward_save_mse_delta) — the pullback reads neither x̂
+            # nor the frames, and x̂ itself is stored only when the caller wants it
+            y = torch.empty((N, chain.sizes[-1]), device=x.device, dtype=torch.float32) if want_y else None
+            ws = torch.empty(int(lib.lde_chain_mse_scratch_floats(h, N)) + 1, device=x.device, dtype=torch.float32)
+            L.check(lib.lde_chain_forward_save_mse_delta(h, C.c_void_p(x.data_ptr()), N, C.c_void_p(y.data_ptr()) if want_y else C.c_void_p(),
+                                                         C.c_void_p(saved.data_ptr()), C.c_void_p(target.data_ptr()), scale,
+                                                         C.c_void_p(base.data_ptr()) if base is not None else C.c_void_p(), C.c_void_p(ws.data_ptr()),
+                                                         C.c_void_p(ws.data_ptr() + 4), stream), h, "lde_chain_forward_save_mse_delta", chain=True)
+            ctx.chain, ctx.scale, ctx.has_base, ctx.need_dx, ctx.has_saved, ctx.delta = chain, scale, base is not None, x.requires_grad, True, True
+            ctx.save_for_backward(x, y if want_y else x.new_empty(0), saved, target)
+            ctx.set_materialize_grads(False)
+            return ws[0], (y if want_y else x.new_empty(0))
+        y = torch.empty((N, chain.sizes[-1]), device=x.device, dtype=torch.float32)
         if _RECON_MSE_FWD:      # the loss value from the forward launch itself: squares summed in the last layer's epilogue
             ws = torch.empty(int(lib.lde_chain_mse_scratch_floats(h, N)) + 1, device=x.device, dtype=torch.float32)     # [0]: the result, then tile sums
             L.check(lib.lde_chain_forward_save_mse(h, C.c_void_p(x.data_ptr()), N, C.c_void_p(y.data_ptr()),
@@ -201,6 +215,8 @@ class _ChainMseFn(torch.autograd.Function):
         if dy is not None:
             dy = dy.contiguous().float()
         if g is None:          # only y was used downstream: the plain pullback
+            if y.numel() == 0:
+                raise L.LdeError("decode_loss(want_x_hat=False): x̂ was not kept, so it cannot carry a cotangent of its own")
             if dy is None:
                 dy = torch.zeros_like(y)
             fn = lib.lde_chain_backward_saved if ctx.has_saved else None
@@ -210,12 +226,18 @@ class _ChainMseFn(torch.autograd.Function):
             else:
                 L.check(lib.lde_chain_backward(h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(dy.data_ptr()), N, pdx,
                                                C.c_void_p(dW.data_ptr()), stream), h, "lde_chain_backward", chain=True)
-            return None, dx, dW, None, None, None
+            return None, dx, dW, None, None, None, None
         g = g.contiguous().float()
+        if ctx.delta and dy is None:   # δ_L′ is staged in the chain's workspace: no pass over x̂ / the frames; g multiplies dx and dW at the end
+            L.check(lib.lde_chain_backward_saved_delta(h, C.c_void_p(x.data_ptr()), C.c_void_p(g.data_ptr()), psv, N, pdx, C.c_void_p(dW.data_ptr()), stream),
+                    h, "lde_chain_backward_saved_delta", chain=True)
+            return None, dx, dW, None, None, (g if ctx.has_base else None), None
+        if y.numel() == 0:
+            raise L.LdeError("decode_loss(want_x_hat=False): x̂ was not kept, so it cannot carry a cotangent of its own")
         L.check(lib.lde_chain_backward_saved_mse(h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(target.data_ptr()),
                                                  C.c_void_p(g.data_ptr()), ctx.scale, C.c_void_p(dy.data_ptr()) if dy is not None else C.c_void_p(),
                                                  psv, N, pdx, C.c_void_p(dW.data_ptr()), stream), h, "lde_chain_backward_saved_mse", chain=True)
-        return None, dx, dW, None, None, (g if ctx.has_base else None)
+        return None, dx, dW, None, None, (g if ctx.has_base else None), None
 
 
 class _ChainGroupFn(torch.autograd.Function):
@@ -424,10 +446,12 @@ _RECON_MSE_FWD = os.environ.get("LDE_RECON_MSE_FWD", "1") != "0"   # _ChainMseFn
 _RECON_MSE = os.environ.get("LDE_RECON_MSE", "1") != "0"   # decode_loss: the reconstructor and reconstruction_loss as one autograd node (diagnostic switch)
 
 
-def decode_loss(decoder: Decoder, l_tilde, t, x, batch_size=None, plus=None):
+def decode_loss(decoder: Decoder, l_tilde, t, x, batch_size=None, plus=None, want_x_hat: bool = True):
     """(reconstruction_loss(x, x̂) [+ plus], (x̂, ẑ, l̂)) with (x̂, ẑ, l̂) = decoder(l̃, t)  [REF src/models/LatentDiffEqModel.jl:101-113],
     [REF examples/pendulum_friction-less/model_train.jl:225-238] — `decode` followed by `loss.reconstruction_loss`, with the
-    reconstructor and the loss as ONE autograd node when the reconstructor is a Chain on HIP frames x [pixels, B, T] (_ChainMseFn)."""
+    reconstructor and the loss as ONE autograd node when the reconstructor is a Chain on HIP frames x [pixels, B, T] (_ChainMseFn).
+    `want_x_hat=False` (a training step that only needs the loss): a bf16 reconstructor then never writes x̂ [pixels × B × T] — the largest
+    array of the step — to HBM, and x̂ in the returned tuple is None."""
     from .loss import reconstruction_loss
     l_hat = apply_latent_out(decoder, l_tilde)
     z_hat = diffeq_layer(decoder, l_hat, t)
@@ -441,8 +465,8 @@ def decode_loss(decoder: Decoder, l_tilde, t, x, batch_size=None, plus=None):
     zb = z_hat.permute(2, 1, 0).reshape(T * B, n_in).contiguous().float()          # (T·B, D): in place when ẑ came from diffeq_layer
     xt = x.permute(2, 1, 0).reshape(T * B, x.shape[0]).contiguous().float()       # the frames in the same (T·B, pixels) order
     n_mean = (batch_size or B) * T
-    loss, y = _ChainMseFn.apply(rec, zb, rec.flat_weights(), xt, 1.0 / n_mean, plus.float() if plus is not None else None)
-    return loss, (y.reshape(T, B, -1).permute(2, 1, 0), z_hat, l_hat)
+    loss, y = _ChainMseFn.apply(rec, zb, rec.flat_weights(), xt, 1.0 / n_mean, plus.float() if plus is not None else None, want_x_hat)
+    return loss, ((y.reshape(T, B, -1).permute(2, 1, 0) if y.numel() else None), z_hat, l_hat)
 
 
 def default_decoder_layers(model_type, input_dim: int, diffeq, hidden_dim_resnet: int = 200, latent_dim_z0: int = 16,

@@ -662,6 +662,7 @@ struct lde_chain {
   BfDims bd, bdx;           // bf16 layouts (bdx: the panel-free wide-input layout)
   int bcg_fwd = 0, bcg_bwd = 0, bcgx_fwd = 0, bcgx_bwd = 0;
   __bf16* dstage = nullptr; size_t dstage_cap = 0;       // δ_l matrices of the bf16 pullback
+  int64_t delta_N = -1;     // lde_chain_forward_save_mse_delta left δ_L′ of this many columns in dstage (−1: none)
   __bf16* svscratch = nullptr; size_t svscratch_cap = 0;  // lde_chain_backward (no saved buffer) in bf16 mode: its own forward pass saves here
   lde_chain_desc d;
   ChainDims cd;
@@ -1084,10 +1085,11 @@ struct GroupRec {
   RecDw dw[GROUP_MAX];
   RecRed red[GROUP_MAX];
 };
-struct FwdMse { const float* t; float* part; unsigned tiles; };
-static thread_local FwdMse t_fwd_mse = {nullptr, nullptr, 0};                // lde_chain_forward_save_mse (tiles: the forward launch's grid, set by the launch site)
+struct FwdMse { const float* t; float* part; unsigned tiles; bool delta; float scale; };   // delta: also leave δ_L′ for the pullback (bf16 mode)
+static thread_local FwdMse t_fwd_mse = {nullptr, nullptr, 0, false, 0.f};                // lde_chain_forward_save_mse (tiles: the forward launch's grid, set by the launch site)
 struct MseSrc { const float* t; const float* g; float scale; };
-static thread_local MseSrc t_mse = {nullptr, nullptr, 0.f};              // lde_chain_backward_saved_mse
+static thread_local MseSrc t_mse = {nullptr, nullptr, 0.f};
+static thread_local const float* t_delta_g = nullptr;   // lde_chain_backward_saved_delta: δ_L′ is staged; the cotangent g multiplies dx / dW at the end              // lde_chain_backward_saved_mse
 static thread_local const float* t_dy_more[2] = {nullptr, nullptr};   // lde_chain_backward_saved_sum: further sources of the output gradient
 static thread_local GroupRec* t_rec = nullptr;
 // (kernel arguments: 4 KB on this runtime)
@@ -1250,7 +1252,22 @@ static int chain_forward_b(lde_chain* c, const float* x, int64_t N, float* y, __
     c->err = "lde_chain_forward (bf16): no tile layout fits LDS for this input";
     return LDE_ERR_UNSUPPORTED;
   }
-  ChainFwdArgsB a{x, y, c->fragb, c->W_dev, (long long)N, saved, t_fwd_mse.t, t_fwd_mse.part};
+  ChainFwdArgsB a{x, y, c->fragb, c->W_dev, (long long)N, saved, t_fwd_mse.t, t_fwd_mse.part, nullptr, 0.f, 0};
+  if (t_fwd_mse.delta) {   // δ_L′ into the last layer's δ matrix of the pullback's workspace (the allocation the pullback would make: it finds it there)
+    const MlpDims& dmf = c->cd.dm;
+    if (!grow(&c->dstage, &c->dstage_cap, (size_t)N * c->bd.dl_total + (size_t)64 * c->bd.dl_w[dmf.nL - 1] + 64)) {
+      c->err = "chain: hipMalloc of the bf16 backward workspace failed";
+      return LDE_ERR_ALLOC;
+    }
+    ChainPickB pkb;   // (the δ matrices' layout is the pullback's choice)
+    if (!chain_pick_b(c, x, N, true, &pkb)) {
+      c->err = "lde_chain_forward_save_mse_delta: no pullback tile layout fits LDS for this input";
+      return LDE_ERR_UNSUPPORTED;
+    }
+    a.dL = c->dstage + (size_t)N * pkb.bd->dl_off[dmf.nL - 1];
+    a.dk2 = 2.0f * t_fwd_mse.scale;
+    a.dlw = pkb.bd->dl_w[dmf.nL - 1];
+  }
   const int NC = 16 * pk.cg;
   const dim3 grid((unsigned)((N + NC - 1) / NC));
   t_fwd_mse.tiles = grid.x;
@@ -1335,7 +1352,9 @@ static int chain_backward_b(lde_chain* c, const float* x, const float* y, const 
     c->err = "lde_chain_backward (bf16): no tile layout fits LDS for this input";
     return LDE_ERR_UNSUPPORTED;
   }
-  ChainBwdArgsB a{x, y, dy, dx, c->fragTb, c->W_dev, c->dstage, (long long)N, saved, t_dy_more[0], t_dy_more[1], t_mse.t, t_mse.g, t_mse.scale};
+  ChainBwdArgsB a{x, y, dy, dx, c->fragTb, c->W_dev, c->dstage, (long long)N, saved, t_dy_more[0], t_dy_more[1], t_mse.t, t_mse.g, t_mse.scale,
+                  t_delta_g ? 1 : 0, t_delta_g};
+  if (!t_delta_g) c->delta_N = -1;   // (this pullback writes its own δ_L over whatever the forward pass staged)
   const int NC = 16 * pk.cg;
   {
     const dim3 grid((unsigned)((N + NC - 1) / NC));
@@ -1386,7 +1405,7 @@ static int chain_backward_b(lde_chain* c, const float* x, const float* y, const 
       }
       attr_set = true;
     }
-    DwArgsB da{x, saved, c->dstage, c->slab, (long long)N};
+    DwArgsB da{x, saved, c->dstage, c->slab, (long long)N, t_delta_g};
     const dim3 grid(parts, jobs);
 #if LDE_PROF
     { (void)hipStreamSynchronize(wst); long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
@@ -1435,7 +1454,7 @@ static int chain_backward_b(lde_chain* c, const float* x, const float* y, const 
 
 static int chain_forward_impl(lde_chain* c, const float* x, int64_t N, float* y, float* saved, void* stream_) {
   if (!c || !c->W_dev) return LDE_ERR_INVALID_ARG;
-  if (!x || !y || N < 1) {
+  if (!x || (!y && !t_fwd_mse.delta) || N < 1) {   // (y may be NULL only where the forward pass leaves δ_L′ instead: lde_chain_forward_save_mse_delta)
     c->err = "lde_chain_forward: NULL pointer or empty batch";
     return LDE_ERR_INVALID_ARG;
   }
@@ -1696,6 +1715,46 @@ int lde_chain_backward_saved_mse(lde_chain* c, const float* x, const float* y, c
   const int rc = saved ? lde_chain_backward_saved(c, x, y, target, saved, N, dx, dW, stream) : lde_chain_backward(c, x, y, target, N, dx, dW, stream);
   t_mse = MseSrc{nullptr, nullptr, 0.f};
   t_dy_more[0] = nullptr;
+  return rc;
+}
+
+// The reconstructor under the loss, bf16 mode, without the x̂ round trip: the forward launch's last epilogue — where x̂ and the target are in
+// registers for the squares anyway — also leaves δ_L′ = 2·scale·(x̂ − target)·act′(x̂) as the pullback's bf16 δ matrix, and stores x̂ only when
+// the caller wants it (y may be NULL); the pullback then starts from that matrix (no pass over x̂ / target, 120 MB of a GOKU step's HBM traffic)
+// and multiplies dx and dW by the loss's cotangent g at the end (δ is linear in g; with g = 1 — the loss IS the objective — the bits are
+// those of lde_chain_backward_saved_mse). LDE_ERR_UNSUPPORTED outside the bf16 mode or for an output width that is not a multiple of 8.
+int lde_chain_forward_save_mse_delta(lde_chain* c, const float* x, int64_t N, float* y, float* saved, const float* target, float scale, const float* base,
+                                     float* out, float* scratch, void* stream) {
+  if (!c) return LDE_ERR_INVALID_ARG;
+  if (!target || !out || !scratch || !saved || (((uintptr_t)target) & 15) != 0) {
+    c->err = "lde_chain_forward_save_mse_delta: NULL pointer or unaligned target";
+    return LDE_ERR_INVALID_ARG;
+  }
+  if (!c->bf16 || (c->cd.dm.sizes[c->cd.dm.nL] & 7) != 0 || t_rec) {
+    c->err = "lde_chain_forward_save_mse_delta: bf16 mode, an output width that is a multiple of 8, not inside a grouped call";
+    return LDE_ERR_UNSUPPORTED;
+  }
+  t_fwd_mse = FwdMse{target, scratch, 0, true, scale};
+  const int rc = lde_chain_forward_save(c, x, N, y, saved, stream);
+  const unsigned tiles = t_fwd_mse.tiles;
+  t_fwd_mse = FwdMse{nullptr, nullptr, 0, false, 0.f};
+  if (rc) return rc;
+  c->delta_N = N;
+  return loss_finalize(scratch, (int)tiles, scale, base, out, (hipStream_t)stream);
+}
+int lde_chain_backward_saved_delta(lde_chain* c, const float* x, const float* g_dev, const float* saved, int64_t N, float* dx, float* dW, void* stream) {
+  if (!c) return LDE_ERR_INVALID_ARG;
+  if (!g_dev || !saved) {
+    c->err = "lde_chain_backward_saved_delta: NULL cotangent / saved activations";
+    return LDE_ERR_INVALID_ARG;
+  }
+  if (!c->bf16 || c->delta_N != N || !c->dstage) {
+    c->err = "lde_chain_backward_saved_delta: no staged δ_L of this size (call lde_chain_forward_save_mse_delta first)";
+    return LDE_ERR_INVALID_ARG;
+  }
+  t_delta_g = g_dev;
+  const int rc = lde_chain_backward_saved(c, x, x, x, saved, N, dx, dW, stream);   // (y and dy are not read: δ_L′ is staged)
+  t_delta_g = nullptr;
   return rc;
 }
 

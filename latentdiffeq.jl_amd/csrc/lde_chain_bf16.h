@@ -320,6 +320,12 @@ struct ChainFwdArgsB {
   __bf16* saved;       // training: hidden activations [n][h] bf16 (the regions of ChainDims::sv_pre, in elements)
   const float* mse_t;  // as in ChainFwdArgs: Σ (y − mse_t)² of the tile's own columns → mse_part[tile]
   float* mse_part;
+  // lde_chain_forward_save_mse_delta: the last epilogue also leaves δ_L′ = dk2·(y − mse_t)·act′(y), dk2 = 2·scale, as the last layer's bf16
+  // δ matrix [n][dl_w] for the pullback (which multiplies dx and dW by the loss's cotangent g at the end): the pullback then reads neither
+  // y nor the target, and y itself is only stored when the caller wants it (y == nullptr)
+  __bf16* dL;
+  float dk2;
+  int dlw;             // row width of that matrix (BfDims::dl_w of the last layer: the output width padded to whole K-groups; the pad is written as zeros)
 };
 
 // zero the panels, copy the biases, and (no gx) the tile's input columns rounded to bf16
@@ -440,7 +446,7 @@ __device__ __forceinline__ void chain_forward_b_body(const ChainDims& cd, const 
     ldx = ldh;
   }
   PROF_T(pz0);
-  if (a.y) {  // last layer: f32 straight to HBM (y == nullptr: the pullback's own forward pass, which only wants the saved matrices)
+  if (a.y || a.dL) {  // last layer: f32 straight to HBM (neither: the pullback's own forward pass, which only wants the saved matrices)
     const int l = nL - 1, in = dm.sizes[l], out = dm.sizes[l + 1], actk = cd.act[l];
     const float* bias = biasc + dm.bias_lin[l];
     const bool vec = (out & 3) == 0;
@@ -468,6 +474,18 @@ __device__ __forceinline__ void chain_forward_b_body(const ChainDims& cd, const 
             }
         }
       }
+      if (a.dL) {   // (out % 8 == 0 and a 16-byte-aligned target: checked by the host) — the same arithmetic, in the same order, as the pullback's own δ_L with g = 1
+        const f32x4 t4 = *reinterpret_cast<const f32x4*>(a.mse_t + (size_t)n * out + row0);
+        const f32x4 a4 = cact_grad_out4(actk, r);
+        f32x4 d;
+#pragma unroll
+        for (int q = 0; q < 4; q++) d[q] = __fmul_rn(a.dk2, r[q] - t4[q]) * a4[q];
+        __bf16* dp = a.dL + (size_t)n * a.dlw;
+        *reinterpret_cast<bf16x4*>(dp + row0) = to_bf4(d);
+        if (row0 + 4 >= out)   // the lane of the row's last four features also zeroes the pad up to the matrix's row width
+          for (int r = out; r < a.dlw; r += 4) *reinterpret_cast<bf16x4*>(dp + r) = to_bf4(f32x4{0.f, 0.f, 0.f, 0.f});
+      }
+      if (!a.y) return;
       float* yp = a.y + (size_t)n * out + row0;
       if (vec) *reinterpret_cast<f32x4*>(yp) = r;
       else {
@@ -516,6 +534,8 @@ struct ChainBwdArgsB {
   const float* mse_t;   // as in ChainBwdArgs: the first source is 2·(g·scale)·(y − mse_t) instead of dy
   const float* mse_g;
   float mse_scale;
+  int dl_ready;         // δ_L′ (without the loss's cotangent g) is already in dstage (ChainFwdArgsB::dL): no first pass over y / target / dy …
+  const float* gs;      // … and dx is multiplied by g = gs[0] here (dW: in k_chain_dw_b); nullptr: 1
 };
 
 struct PreH { f32x4 h; };
@@ -555,7 +575,8 @@ __device__ __forceinline__ void chain_backward_b_body(const ChainDims& cd, const
 
   // ---- δ_L = dy ⊙ act'(y) from the caller's arrays → the δ-stage matrix of the last layer (bf16) -----------------------
   const int L1 = nL - 1;
-  {
+  const float gsv = a.gs ? a.gs[0] : 1.0f;
+  if (!a.dl_ready) {
     const int out = dm.sizes[nL], w = bd.dl_w[L1], actk = cd.act[L1], chunks = w / 8;
     __bf16* dL = a.dstage + (size_t)a.N * bd.dl_off[L1];
     const bool vec = (out & 3) == 0;
@@ -676,7 +697,7 @@ __device__ __forceinline__ void chain_backward_b_body(const ChainDims& cd, const
         if (n < a.N) {
 #pragma unroll
           for (int q = 0; q < 4; q++)
-            if (row0 + q < in) a.dx[(size_t)n * in + row0 + q] = g[q];
+            if (row0 + q < in) a.dx[(size_t)n * in + row0 + q] = a.gs ? g[q] * gsv : g[q];
         }
       };
       if (l == L1) chain_gemm_b<CG, 2>(fragT, in, out, Bglb, bd.dl_w[l], 16L * bd.dl_w[l], pre, epi, stage_prev);
@@ -709,6 +730,7 @@ struct DwArgsB {
   const __bf16* dstage;    // δ_l [N][dl_w[l]]
   float* slab;             // [parts][slab_n]
   long long N;
+  const float* gs;         // the δ matrices lack the loss's cotangent g (ChainBwdArgsB::dl_ready): everything written is multiplied by gs[0]; nullptr: 1
 };
 
 __host__ __device__ inline int tr_stride_bytes(int feats) {   // row stride of an image of `feats` bf16 features: smallest ≥ 2·feats that is ≡ 64 (mod 128)
@@ -927,6 +949,7 @@ __device__ __forceinline__ void chain_dw_b_body(const ChainDims& cd, const BfDim
     PROF_ADD(56, d6 - 1, d6);
   }
   float* slab = a.slab + (size_t)part * dm.slab_n;
+  const float gsv = a.gs ? a.gs[0] : 1.0f;
 #pragma unroll
   for (int m = 0; m < DW_NDW; m++) {
     const int t = wave + 8 * m;
@@ -938,14 +961,14 @@ __device__ __forceinline__ void chain_dw_b_body(const ChainDims& cd, const BfDim
       for (int q = 0; q < 4; q++) {
         f32x4 v;
         v[0] = acc[m][4 * q + 0]; v[1] = acc[m][4 * q + 1]; v[2] = acc[m][4 * q + 2]; v[3] = acc[m][4 * q + 3];
-        g4[q] = v;
+        g4[q] = a.gs ? v * gsv : v;
       }
       if (do_bias_row && jb.i0 + itl == IT - 1) {   // row `in` of the last input tile = the bias gradient of this tile's 32 outputs
         const int r = in & 31, reg = (r & 3) + 4 * (r >> 3), o = (jb.o0 + otl) * 32 + (lane & 31);
         float bv = 0.f;
 #pragma unroll
         for (int rr = 0; rr < 16; rr++) bv = rr == reg ? acc[m][rr] : bv;
-        if ((lane >> 5) == ((r >> 2) & 1) && o < out) slab[(size_t)dm.tile_off[dm.nL] * 1024 + dm.bias_lin[l] + o] = bv;
+        if ((lane >> 5) == ((r >> 2) & 1) && o < out) slab[(size_t)dm.tile_off[dm.nL] * 1024 + dm.bias_lin[l] + o] = a.gs ? bv * gsv : bv;
       }
     }
   }
@@ -953,7 +976,7 @@ __device__ __forceinline__ void chain_dw_b_body(const ChainDims& cd, const BfDim
 #pragma unroll
     for (int q = 0; q < 2; q++) {
       const int row = tid + 512 * q;
-      if (row < nd && rd0 + row < out) slab[(size_t)dm.tile_off[dm.nL] * 1024 + dm.bias_lin[l] + rd0 + row] = bsum[q];
+      if (row < nd && rd0 + row < out) slab[(size_t)dm.tile_off[dm.nL] * 1024 + dm.bias_lin[l] + rd0 + row] = a.gs ? bsum[q] * gsv : bsum[q];
     }
   }
 }

@@ -88,7 +88,7 @@ def loss_batch(model, x, t, beta: float, variational: bool, batch_size: Optional
         # reductions (loss.sample_with_kl): encoder → (l̃, β·kl) → decoder → reconstruction_loss + β·kl
         mu, logvar = encode(model.encoder, x)
         l_tilde, bkl = sample_with_kl(mu, logvar, beta, batch_size)
-        loss, _ = decode_loss(model.decoder, l_tilde, t, x, batch_size, plus=bkl)     # (the reconstructor and the loss as one autograd node)
+        loss, _ = decode_loss(model.decoder, l_tilde, t, x, batch_size, plus=bkl, want_x_hat=False)   # (the reconstructor and the loss as one autograd node; x̂ is not kept)
         return loss
     (x_hat, _z, _l), mu, logvar = model(x, t, variational)
     return reconstruction_loss(x, x_hat, batch_size) + beta * vector_kl(mu, logvar, batch_size)

@@ -29,6 +29,17 @@ def test_gpus_2_spawns_two_ranks_and_emits_one_line():
 
 
 @pytest.mark.timeout(900)
+def test_gpus_8_dry_launch_is_one_node_of_eight_ranks():
+    """The shape of the driver's scaling run (N = 8 on one node): eight ranks rendezvous on 127.0.0.1, one collective, ONE line."""
+    r = _bench("--gpus", "8", "--dry-launch")
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["collective_ranks"] == 8
+
+
+@pytest.mark.timeout(900)
 def test_launcher_refuses_more_ranks_than_gpus_and_propagates_failure():
     # no GPU in this container: the non-dry launcher must refuse instead of printing an n_gpus: 1 line
     import torch

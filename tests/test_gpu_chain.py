@@ -339,7 +339,11 @@ def test_reconstructor_under_mse_as_one_node(dtype):
     params = [p for m in (*lo, rec) for p in m.parameters()]
     keep = CH._RECON_MSE
     try:
-        for B, T, second_use in ((24, 12, False), (64, 50, False), (33, 9, True)):
+        # (gfac: the loss's cotangent. The bf16 chain's one node leaves δ_L′ = 2·scale·(x̂ − x)·σ′ in the forward launch and multiplies by g
+        #  at the END of the pullback — lde_chain_backward_saved_delta, round 4 — so with g = 1 its bits are the two-call path's, and with
+        #  g ≠ 1 they differ by the bf16 rounding of δ (g·δ rounded against δ rounded): compared to that level. x̂ used a second time
+        #  carries its own cotangent: the staged δ is not used then.)
+        for B, T, second_use, gfac in ((24, 12, False, 1.7), (64, 50, False, 1.7), (64, 50, False, 1.0), (33, 9, True, 1.7)):
             ts = np.arange(T) * 0.05
             x = torch.rand(T, B, NI, device="cuda").permute(2, 1, 0)
             l0 = (torch.randn(16, B, device="cuda"), torch.randn(16, B, device="cuda"))
@@ -353,15 +357,19 @@ def test_reconstructor_under_mse_as_one_node(dtype):
                 lt = tuple(t_.clone().requires_grad_(True) for t_ in l0)
                 plus = plus0.clone().requires_grad_(True)
                 loss, (x_hat, z_hat, _) = CH.decode_loss(dec, lt, ts, x, 4 * B, plus=plus)
-                total = 1.7 * loss + ((x_hat * w2).sum() if second_use else 0.0)
+                total = gfac * loss + ((x_hat * w2).sum() if second_use else 0.0)
                 total.backward()
                 torch.cuda.synchronize()
                 res.append((loss.detach().clone(), x_hat.detach().clone(), [p.grad.clone() for p in params] + [t_.grad.clone() for t_ in lt] + [plus.grad.clone()]))
             # (the one node sums the squares per column tile in the reconstructor's last epilogue, lde_mse_forward per slice of the flat array:
             #  the loss value agrees to rounding — 2e-6 —, and bit for bit with LDE_RECON_MSE_FWD=0; x̂ and every gradient are the same bits)
             assert abs(float(res[0][0]) - float(res[1][0])) <= 2e-6 * abs(float(res[1][0])) and torch.equal(res[0][1], res[1][1]), (B, T)
+            rounded = dtype == "bf16" and gfac != 1.0 and not second_use
             for i, (a, b) in enumerate(zip(res[0][2], res[1][2])):
-                assert torch.equal(a, b), (B, T, second_use, i)
+                if rounded:
+                    assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()) and float((a - b).norm()) <= 5e-3 * float(b.norm()), (B, T, i)
+                else:
+                    assert torch.equal(a, b), (B, T, second_use, gfac, i)
     finally:
         CH._RECON_MSE = keep
 

@@ -132,3 +132,73 @@ def test_set_dtype_validates():
     from tests.gpu_util import NativeChain
     ch = NativeChain((4, 8, 2), (L.CACT_RELU, L.CACT_IDENTITY))
     assert ch.lib.lde_chain_set_dtype(ch.h, 7) == -1 and ch.lib.lde_chain_set_dtype(None, 0) == -1
+
+
+@pytest.mark.parametrize("N", [12800, 1000])
+def test_reconstructor_pullback_from_the_delta_the_forward_pass_left(N):
+    """lde_chain_forward_save_mse_delta / lde_chain_backward_saved_delta (bf16 chains): the forward launch's last epilogue leaves
+    δ_L′ = 2·scale·(x̂ − x)·σ′(x̂) as the pullback's bf16 δ matrix, the pullback starts there (no pass over x̂ and the frames) and multiplies
+    dx / dW by the loss's cotangent g at the end. Against lde_chain_forward_save_mse + lde_chain_backward_saved_mse on the same chain
+    [REF src/models/GOKU.jl:252-269], [REF examples/pendulum_friction-less/model_train.jl:225-238]: with g = 1 — the loss is the
+    objective — the SAME BITS (loss, dx, dW; and x̂ when it is asked for); with g ≠ 1 the results are g times those of g = 1 exactly
+    (δ is linear in g: the rounded-operand arithmetic is that of g = 1), which is the two-call path's to bf16 rounding of δ."""
+    import ctypes as C
+    import torch
+    from tests.gpu_util import NativeChain
+    from latentdiffeq_amd import synthetic as S
+    sizes, acts, skips = (2, 200, 200, 200, 784), (L.CACT_RELU, L.CACT_RELU, L.CACT_RELU, L.CACT_SIGMOID), (0, 1, 1, 0)
+    rng = np.random.default_rng(3)
+    W = S.mlp_weights(sizes, seed=11)
+    x = torch.from_numpy((0.7 * rng.standard_normal((N, 2))).astype(np.float32)).cuda()
+    tgt = torch.from_numpy(rng.uniform(0, 1, (N, 784)).astype(np.float32)).cuda()
+    base = torch.tensor([0.25], device="cuda")
+    ch = NativeChain(sizes, acts, skips)
+    ch.set_weights(W)
+    ch.set_dtype("bf16")
+    lib, h = ch.lib, ch.h
+    lib.lde_chain_saved_floats.restype = C.c_int64
+    lib.lde_chain_mse_scratch_floats.restype = C.c_int64
+    p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p()
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    scale = 1.0 / N
+    nsv, nws = int(lib.lde_chain_saved_floats(h, N)), int(lib.lde_chain_mse_scratch_floats(h, N)) + 1
+
+    def two_calls(g):
+        y, saved, ws = torch.empty((N, 784), device="cuda"), torch.empty((nsv,), device="cuda"), torch.empty((nws,), device="cuda")
+        L.check(lib.lde_chain_forward_save_mse(h, p(x), N, p(y), p(saved), p(tgt), scale, p(base), p(ws), C.c_void_p(ws.data_ptr() + 4), s), h, "fwd", chain=True)
+        dx, dW, gd = torch.empty_like(x), torch.zeros((ch.nW,), device="cuda"), torch.tensor([g], device="cuda")
+        L.check(lib.lde_chain_backward_saved_mse(h, p(x), p(y), p(tgt), p(gd), scale, C.c_void_p(), p(saved), N, p(dx), p(dW), s), h, "bwd", chain=True)
+        torch.cuda.synchronize()
+        return ws[0].item(), y.cpu().numpy(), dx.cpu().numpy(), dW.cpu().numpy()
+
+    def delta(g, want_y):
+        y = torch.full((N, 784), 7.0, device="cuda") if want_y else None
+        saved, ws = torch.empty((nsv,), device="cuda"), torch.empty((nws,), device="cuda")
+        L.check(lib.lde_chain_forward_save_mse_delta(h, p(x), N, p(y), p(saved), p(tgt), scale, p(base), p(ws), C.c_void_p(ws.data_ptr() + 4), s), h, "fwd", chain=True)
+        dx, dW, gd = torch.empty_like(x), torch.zeros((ch.nW,), device="cuda"), torch.tensor([g], device="cuda")
+        L.check(lib.lde_chain_backward_saved_delta(h, p(x), p(gd), p(saved), N, p(dx), p(dW), s), h, "bwd", chain=True)
+        torch.cuda.synchronize()
+        return ws[0].item(), (y.cpu().numpy() if want_y else None), dx.cpu().numpy(), dW.cpu().numpy()
+
+    l0, y0, dx0, dW0 = two_calls(1.0)
+    l1, y1, dx1, dW1 = delta(1.0, True)
+    l2, y2, dx2, dW2 = delta(1.0, False)
+    assert l0 == l1 == l2 and np.array_equal(y0, y1) and y2 is None
+    relm = lambda a, b: float(np.abs(a - b).max() / np.abs(b).max())
+    assert np.array_equal(dx0, dx1) and np.array_equal(dW0, dW1) and np.array_equal(dx0, dx2) and np.array_equal(dW0, dW2), \
+        (relm(dx1, dx0), relm(dW1, dW0), relm(dx2, dx0), relm(dW2, dW0))
+    g = 0.5                                                          # (a power of two: g·v is exact, so "g times the g = 1 result" is a bit statement)
+    _, _, dxg, dWg = delta(g, False)
+    assert np.array_equal(dxg, g * dx0) and np.array_equal(dWg, g * dW0)
+    _, _, dxr, dWr = two_calls(g)                                    # the two-call path rounds g·δ instead of δ: equal to bf16 rounding of δ
+    rel = lambda a, b: np.abs(a - b).max() / np.abs(b).max()
+    assert rel(dxg, dxr) <= 2e-2 and rel(dWg, dWr) <= 2e-2 and np.linalg.norm(dWg - dWr) <= 4e-3 * np.linalg.norm(dWr)
+    # a pullback without a staged δ of this size is refused, not guessed
+    gd = torch.tensor([1.0], device="cuda")
+    sv = torch.empty((nsv,), device="cuda")
+    dW = torch.zeros((ch.nW,), device="cuda")
+    assert lib.lde_chain_backward_saved_delta(h, p(x), p(gd), p(sv), N - 16, C.c_void_p(), p(dW), s) != 0
+    ch.set_dtype("f32")
+    y = torch.empty((N, 784), device="cuda")
+    ws = torch.empty((nws,), device="cuda")
+    assert lib.lde_chain_forward_save_mse_delta(h, p(x), N, p(y), p(sv), p(tgt), scale, p(base), p(ws), C.c_void_p(ws.data_ptr() + 4), s) == -2   # LDE_ERR_UNSUPPORTED

@@ -416,10 +416,6 @@ def run_goku_step(args, torch, dist, world, rank, local):
     Bg = B * world
 
     fused_loss = os.environ.get("LDE_FUSED_LOSS", "1") != "0"     # diagnostic: 0 = separate sample / vector_kl / reconstruction_loss and torch additions
-    if os.environ.get("LDE_ASYNC_DW", "0") != "0":               # opt-in: weight-gradient kernels of the chain / recurrent pullbacks on a stream of their
-                                                                   # own (measured at B = 256: 1.86 vs 1.66 ms median over 8 alternations — the wide dW grids
-                                                                   # slow the latency-bound small kernels they overlap with more than they save; off)
-        L.set_async_weight_gradients(True, dev)
     refresh = os.environ.get("LDE_BENCH_REFRESH", "1") != "0"   # diagnostic: 0 = every module re-uploads its weights at its next call
 
     def step():
@@ -462,22 +458,11 @@ def run_goku_step(args, torch, dist, world, rank, local):
         gs = GraphedStep(step_a, warmup=3, between=sync, fn2=step_b)
         run = gs.replay
     elif use_graph:
-        # several steps per captured graph: a replay has a fixed cost of its own on this runtime (≈ 13 µs at its head: a copy kernel and a
-        # gap) that a training loop feeding `unroll` minibatches per replay pays once per replay. Every step is a whole
-        # step (its own update, hand-over and noise); K steps = K / unroll replays (unroll falls back to 1 when it does not divide K).
-        unroll = int(os.environ.get("LDE_BENCH_UNROLL", "1"))
-        if unroll < 1 or args.steps % unroll or args.warmup % unroll:
-            unroll = 1
-
-        def steps_unrolled():
-            for _ in range(unroll):
-                l = step()
-            return l
-        gs = GraphedStep(steps_unrolled if unroll > 1 else step, warmup=3)
+        gs = GraphedStep(step, warmup=3)
         run = gs.replay
     else:
         run = step
-    n_rep = unroll if (use_graph and not split) else 1
+    n_rep = 1
     for _ in range(args.warmup // n_rep):
         run()
     fence()

@@ -417,11 +417,7 @@ def apply_latent_out(decoder: Decoder, l_tilde):
     if isinstance(decoder.model_type, GOKU):
         z0_t, th_t = l_tilde
         lo_z0, lo_th = decoder.latent_out
-        from .recurrent import _CHAIN_STREAMS, run_forked
-        if _CHAIN_STREAMS:                          # (opt-in, measured slower: parallel branches inside a captured step)
-            z0_hat, th_hat = run_forked([(lo_z0, z0_t), (lo_th, th_t)])
-        else:
-            z0_hat, th_hat = apply_chains_grouped([(lo_z0, z0_t), (lo_th, th_t)])
+        z0_hat, th_hat = apply_chains_grouped([(lo_z0, z0_t), (lo_th, th_t)])   # the two chains as one autograd node, one launch per stage
         return z0_hat, th_hat
     if isinstance(decoder.model_type, LatentODE):
         return decoder.latent_out(l_tilde)

@@ -335,9 +335,7 @@ __device__ __forceinline__ void chain_hidden_layer(const ChainDims& cd, int l, c
                         });
 }
 
-#ifndef LDE_F32_OCC
-#define LDE_F32_OCC 1
-#endif
+constexpr int F32_OCC = 1;   // waves per SIMD of the f32 chain kernels' launch bounds
 template <int CG, bool BF>
 __device__ __forceinline__ void chain_forward_body(const ChainDims& cd, const ChainFwdArgs& a, const unsigned bx) {
   extern __shared__ __attribute__((aligned(16))) float csm[];
@@ -423,11 +421,11 @@ __device__ __forceinline__ void chain_forward_body(const ChainDims& cd, const Ch
   PROF_ADD(40, pc0, pz1);
 }
 template <int CG, bool BF>
-__global__ void __launch_bounds__(512, (CG <= 2 ? LDE_F32_OCC : 1)) k_chain_forward(ChainDims cd, ChainFwdArgs a) {
+__global__ void __launch_bounds__(512, (CG <= 2 ? F32_OCC : 1)) k_chain_forward(ChainDims cd, ChainFwdArgs a) {
   chain_forward_body<CG, BF>(cd, a, blockIdx.x);
 }
 template <int CG, bool BF>
-__global__ void __launch_bounds__(512, (CG <= 2 ? LDE_F32_OCC : 1)) k_chain_forward_group(GroupTable<ChainDims, ChainFwdArgs> g) {
+__global__ void __launch_bounds__(512, (CG <= 2 ? F32_OCC : 1)) k_chain_forward_group(GroupTable<ChainDims, ChainFwdArgs> g) {
   const int j = group_find(g.start, g.n, blockIdx.x);
   chain_forward_body<CG, BF>(g.dims[j], g.args[j], blockIdx.x - g.start[j]);
 }
@@ -637,11 +635,11 @@ __device__ __forceinline__ void chain_backward_body(const ChainDims& cd, const C
   }
 }
 template <int CG, bool BF>
-__global__ void __launch_bounds__(512, (CG <= 2 ? LDE_F32_OCC : 1)) k_chain_backward(ChainDims cd, ChainBwdArgs a) {
+__global__ void __launch_bounds__(512, (CG <= 2 ? F32_OCC : 1)) k_chain_backward(ChainDims cd, ChainBwdArgs a) {
   chain_backward_body<CG, BF>(cd, a, blockIdx.x);
 }
 template <int CG, bool BF>
-__global__ void __launch_bounds__(512, (CG <= 2 ? LDE_F32_OCC : 1)) k_chain_backward_group(GroupTable<ChainDims, ChainBwdArgs> g) {
+__global__ void __launch_bounds__(512, (CG <= 2 ? F32_OCC : 1)) k_chain_backward_group(GroupTable<ChainDims, ChainBwdArgs> g) {
   const int j = group_find(g.start, g.n, blockIdx.x);
   chain_backward_body<CG, BF>(g.dims[j], g.args[j], blockIdx.x - g.start[j]);
 }
@@ -707,9 +705,9 @@ static size_t chain_lds(const ChainDims& cd, int cg, int npanels) {
 // skip-gradient panel) kernels
 static size_t chain_lds_b(const ChainDims& cd, const BfDims& bd, int cg, bool bwd) {
   const size_t NC = 16 * cg;
-  if (bwd) return NC * bd.ldb * 2 * 2 + NC * bd.ldg * 4 + ((LDE_BF_XSTAGE_BWD != 0) ? chain_xs_bytes(cg, XKC_BWD) : 0);
+  if (bwd) return NC * bd.ldb * 2 * 2 + NC * bd.ldg * 4;
   return (2 + (bd.fpanel ? 1 : 0)) * NC * bd.ldb * 2 + (size_t)((cd.dm.nbias + 3) & ~3) * 4   // the input panel shares the second panel's space
-         + ((cd.gx && (LDE_BF_XSTAGE != 0)) ? chain_xs_bytes(cg) : 0);                                 // wide input: the first layer's chunk buffers
+         + (cd.gx ? chain_xs_bytes(cg) : 0);                                 // wide input: the first layer's chunk buffers
 }
 
 // lde_loss.hip: out[0] = (base ? base[0] : 0) + scale·Σ scratch[0..g) in index order (k_loss_final)
@@ -798,15 +796,13 @@ int lde_chain_create(const lde_chain_desc* d, lde_chain** out) {
   // Column groups per workgroup: the widest tile that still lets TWO workgroups share a CU (≤ 80 KB of LDS each) — one
   // tile's barrier / prologue latencies are then covered by the other's MFMAs. Measured on the reconstructor
   // (N = 12800): forward 64 columns 110 µs, 32 columns 107 µs; backward 32 columns 331 µs, 16 columns 313 µs.
-  // Falls back to the widest tile that fits at all. LDE_CHAIN_CG_FWD / LDE_CHAIN_CG_BWD force a value (experiments).
-  const char* ef = getenv("LDE_CHAIN_CG_FWD");
-  const char* eb = getenv("LDE_CHAIN_CG_BWD");
+  // Falls back to the widest tile that fits at all.
   auto pick = [&](const ChainDims& q, int* cgf, size_t* ldf, int* cgb, size_t* ldb) {
     *cgf = *cgb = 0;
     for (size_t lim : {LDS_MAX / 2, LDS_MAX}) {
       for (int cg : {4, 2, 1}) {
-        if (!*cgf && (!ef || cg == atoi(ef)) && chain_lds(q, cg, 2) <= (ef ? LDS_MAX : lim)) { *cgf = cg; *ldf = chain_lds(q, cg, 2); }
-        if (cg <= 2 && !*cgb && (!eb || cg == atoi(eb)) && chain_lds(q, cg, 3) <= (eb ? LDS_MAX : lim)) { *cgb = cg; *ldb = chain_lds(q, cg, 3); }
+        if (!*cgf && chain_lds(q, cg, 2) <= lim) { *cgf = cg; *ldf = chain_lds(q, cg, 2); }
+        if (cg <= 2 && !*cgb && chain_lds(q, cg, 3) <= lim) { *cgb = cg; *ldb = chain_lds(q, cg, 3); }
       }
     }
   };
@@ -818,10 +814,6 @@ int lde_chain_create(const lde_chain_desc* d, lde_chain** out) {
     c->cdx.gx = 1;
     c->cdx.ld0 = 0;
     pick(c->cdx, &c->cgx_fwd, &c->ldsx_fwd, &c->cgx_bwd, &c->ldsx_bwd);
-    if (const char* ex = getenv("LDE_CHAIN_CGX_FWD")) {   // experiments: the panel-free layout's forward tile alone
-      const int g = atoi(ex);
-      if ((g == 1 || g == 2 || g == 4) && chain_lds(c->cdx, g, 2) <= LDS_MAX) { c->cgx_fwd = g; c->ldsx_fwd = chain_lds(c->cdx, g, 2); }
-    }
   }
   if (!c->cg_fwd || !c->cg_bwd) {
     if (c->cgx_fwd && c->cgx_bwd) {   // only the panel-free layout fits: it needs N ≥ one tile (checked per call)
@@ -848,8 +840,8 @@ int lde_chain_create(const lde_chain_desc* d, lde_chain** out) {
     c->bdx = bd;
     c->bdx.ldb = panel_stride_b(pad32(hmax));   // wide input read in place: the panels only hold hidden vectors
     c->bdx.ld0 = 0;
-    // 32-column tiles (CG = 2): ≤ 128 registers and ≤ 80 KB of LDS, so two workgroups share a CU (lde_chain_bf16.h: LDE_BF_PFA / LDE_BF_OCC);
-    // the 64-column forward instantiation exists for experiments (LDE_CHAIN_BCG_FWD=4)
+    // 32-column tiles (CG = 2): ≤ 128 registers and ≤ 80 KB of LDS, so two workgroups share a CU (lde_chain_bf16.h: BF_PFA / BF_OCC);
+    // (a 64-column forward instantiation exists; it is only picked when nothing narrower fits)
     auto pickb = [&](const ChainDims& q, const BfDims& b, int* cgf, int* cgb) {
       *cgf = *cgb = 0;
       for (size_t lim : {LDS_MAX / 2, LDS_MAX}) {
@@ -974,11 +966,10 @@ static bool chain_pick(const lde_chain* c, const float* x, int64_t N, bool bwd, 
   // Mid-size batches (a training step's N = B·T ≈ 3 200 columns): the widest tile leaves most CUs without a workgroup —
   // 50–100 tiles on 256 CUs — and a tile's time barely depends on its width (the weight fragments stream through the
   // workgroup either way). Narrow the tile until the grid has ≈ 200 workgroups (measured, GOKU training step at B = 64:
-  // 1.70 → 1.32 ms and 2.17 → 1.84 ms in two back-to-back pairs; at B = 256 the grids are full and nothing changes). LDE_CHAIN_FILL=0: off.
-  static const bool fill = [] { const char* e = getenv("LDE_CHAIN_FILL"); return !e || atoi(e) != 0; }();
+  // 1.70 → 1.32 ms and 2.17 → 1.84 ms in two back-to-back pairs; at B = 256 the grids are full and nothing changes).
   auto narrow = [&](const ChainDims& q, int cg0, size_t lds0) {
     int g = cg0;
-    while (fill && g > 1 && (N + 16 * g - 1) / (16 * g) < 192) g /= 2;
+    while (g > 1 && (N + 16 * g - 1) / (16 * g) < 192) g /= 2;
     return ChainPick{&q, g, g == cg0 ? lds0 : chain_lds(q, g, bwd ? 3 : 2)};
   };
   if (cgx && N >= 16 * cgx && (((uintptr_t)x) & 15) == 0) {
@@ -1028,14 +1019,9 @@ int lde_chain_reserve(lde_chain* c, int64_t N) {
 struct ChainPickB { const ChainDims* cd; const BfDims* bd; int cg; size_t lds; };
 static bool chain_pick_b(const lde_chain* c, const float* x, int64_t N, bool bwd, ChainPickB* p) {
   const int cgx = bwd ? c->bcgx_bwd : c->bcgx_fwd, cg = bwd ? c->bcg_bwd : c->bcg_fwd;
-  static const bool fill = [] { const char* e = getenv("LDE_CHAIN_FILL"); return !e || atoi(e) != 0; }();
   auto narrow = [&](const ChainDims& q, const BfDims& b, int cg0) {
     int g = cg0;
-    if (const char* e = getenv(bwd ? "LDE_CHAIN_BCG_BWD" : "LDE_CHAIN_BCG_FWD")) {   // experiments: force the tile width
-      const int v = atoi(e);
-      if ((v == 1 || v == 2 || v == 4) && chain_lds_b(q, b, v, bwd) <= LDS_MAX) return ChainPickB{&q, &b, v, chain_lds_b(q, b, v, bwd)};
-    }
-    while (fill && g > 1 && (N + 16 * g - 1) / (16 * g) < 192) g /= 2;
+    while (g > 1 && (N + 16 * g - 1) / (16 * g) < 192) g /= 2;
     return ChainPickB{&q, &b, g, chain_lds_b(q, b, g, bwd)};
   };
   if (c->cdx.gx && cgx && N >= 16 * cgx && (((uintptr_t)x) & 15) == 0) {
@@ -1321,7 +1307,6 @@ static int chain_backward_b(lde_chain* c, const float* x, const float* y, const 
   const int ndw = dw_pick_ndw(dm), jobs = dw_jobs(dm, ndw);
   const int64_t nchunks = (N + DWB_NK - 1) / DWB_NK;
   int parts = 256 / jobs;
-  if (const char* e = getenv("LDE_CHAIN_DW_PARTS")) parts = atoi(e);
   parts = parts < 1 ? 1 : parts;
   if (parts > nchunks) parts = (int)nchunks;
   // (+ one tile of rows of the last layer's matrix: its read-back as a B operand covers the ragged tile's columns beyond N — their

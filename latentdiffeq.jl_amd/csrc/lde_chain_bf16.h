@@ -25,20 +25,10 @@
 // take ≤ 128 registers, TWO workgroups share a CU (16 waves: one's barrier / L2 waits are the other's MFMAs) and all 400 tiles are
 // resident at once — forward 57 → 38 µs, pullback kernel 72 → 57 µs; eight K-groups deep (200+ registers, one workgroup per CU) the
 // 64-column forward took 45 µs, and four deep at 128 registers spills (pullback 118 → 134 µs).
-#ifndef LDE_BF_PFA
-#define LDE_BF_PFA 2
-#endif
-#ifndef LDE_BF_XSTAGE
-#define LDE_BF_XSTAGE 1   // the wide-input first layer's operand staged through LDS by all waves (chain_gemm_b_gx); 0: every wave loads it (BSRC 1)
-#endif
-#ifndef LDE_BF_XSTAGE_BWD
-#define LDE_BF_XSTAGE_BWD 0   // the same staging for the pullback's first product (W_Lᵀ·δ_L, K = the chain's output width). Measured slower: the
-                              // reconstructor's pullback kernel 58 → 69 µs with 64-wide chunks (13 barriers per tile, 31 spilled registers at the
-                              // 128-register budget), and with 128-wide chunks the tile no longer fits two workgroups per CU (73 µs at 16 columns)
-#endif
-#ifndef LDE_BF_OCC
-#define LDE_BF_OCC 4      // __launch_bounds__' second argument = waves per SIMD: 4 = two 512-thread workgroups per CU
-#endif
+constexpr int BF_PFA = 2;   // A-fragment ring depth of the 16- / 32-column kernels (K-groups in flight)
+constexpr int BF_OCC = 4;   // __launch_bounds__' second argument = waves per SIMD: 4 = two 512-thread workgroups per CU
+// (the wide-input first layer's operand is staged through LDS by all waves — chain_gemm_b_gx; the same staging for the pullback's first
+//  product was measured slower — 58 → 69 µs with 64-wide chunks, 73 µs with 128-wide ones — and is gone: abl/HISTORY.md §4.5)
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 typedef short s16x8 __attribute__((ext_vector_type(8)));
@@ -84,7 +74,7 @@ __device__ __forceinline__ f32x4 mfma32_b(bf16x8 a, bf16x8 b, f32x4 c) { return 
 template <int CG, int BSRC, class Pre, class Epi, class Hook>
 __device__ __forceinline__ void chain_gemm_b(const __bf16* __restrict__ gfrag, int R, int K, const void* Bp, int ldb, long cgstride,
                                              Pre pre, Epi epi, Hook hook) {
-  constexpr int NW = 8, PFA = CG >= 4 ? 8 : LDE_BF_PFA, PFB0 = BSRC == 0 ? 2 : 4, PFB = PFB0 < PFA ? PFB0 : PFA;
+  constexpr int NW = 8, PFA = CG >= 4 ? 8 : BF_PFA, PFB0 = BSRC == 0 ? 2 : 4, PFB = PFB0 < PFA ? PFB0 : PFA;
   static_assert(PFA % PFB == 0, "the B ring is indexed by i % PFB inside a PFA-unrolled block");
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -205,7 +195,7 @@ struct NoHook { __device__ __forceinline__ void operator()() const {} };
 // many bytes as this one reads, took 37.) Two chunk buffers; one barrier per chunk: the next chunk's global loads are issued before the
 // current chunk's MFMAs and written to the other buffer behind them. A chunk past the row's end reads the row's last floats instead
 // (finite values against zero weights, as in BSRC 1). Same products on the same rounded operands in the same order: the same bits.
-constexpr int XKC = 128, XKC_BWD = 64;        // chunk of the forward's first layer / of the pullback's first product (whose LDS is fuller); the LDS row
+constexpr int XKC = 128;        // chunk of the forward's first layer / of the pullback's first product (whose LDS is fuller); the LDS row
                                               // stride is the chunk + 16 elements (≡ 16 mod 64 like every bf16 panel)
 __host__ __device__ inline size_t chain_xs_bytes(int cg, int kc = XKC) { return (size_t)2 * 16 * cg * (kc + 16) * 2; }
 // SrcT float: the caller's f32 x[n][ldx] (rounded here); SrcT __bf16: a [n][ldx] bf16 matrix as it stands — the pullback's δ_L, which
@@ -409,7 +399,7 @@ __device__ __forceinline__ void chain_forward_b_body(const ChainDims& cd, const 
   __bf16* F = (a.saved && any_skip && bd.fpanel) ? H1 + NC * ldh : nullptr;
   float* biasc = reinterpret_cast<float*>(H1 + NC * ldh + (bd.fpanel ? NC * ldh : 0));
   // wide input: the chunk buffers of the first layer's staged operand (chain_gemm_b_gx) behind the biases; K ≥ 8 and 16-byte rows
-  __bf16* XS = (cd.gx && (LDE_BF_XSTAGE != 0) && dm.sizes[0] >= 8 && dm.sizes[0] % 4 == 0) ? reinterpret_cast<__bf16*>(biasc + ((dm.nbias + 3) & ~3)) : nullptr;
+  __bf16* XS = (cd.gx && dm.sizes[0] >= 8 && dm.sizes[0] % 4 == 0) ? reinterpret_cast<__bf16*>(biasc + ((dm.nbias + 3) & ~3)) : nullptr;
   int dup;
   const long long n0 = chain_tile_start(cd, NC, a.N, &dup, bx);
   PROF_T(pc0);
@@ -510,11 +500,11 @@ __device__ __forceinline__ void chain_forward_b_body(const ChainDims& cd, const 
 }
 struct ChainBDims { ChainDims cd; BfDims bd; };
 template <int CG>
-__global__ void __launch_bounds__(512, (CG <= 2 ? LDE_BF_OCC : 1)) k_chain_forward_b(ChainDims cd, BfDims bd, ChainFwdArgsB a) {
+__global__ void __launch_bounds__(512, (CG <= 2 ? BF_OCC : 1)) k_chain_forward_b(ChainDims cd, BfDims bd, ChainFwdArgsB a) {
   chain_forward_b_body<CG>(cd, bd, a, blockIdx.x);
 }
 template <int CG>
-__global__ void __launch_bounds__(512, (CG <= 2 ? LDE_BF_OCC : 1)) k_chain_forward_b_group(GroupTable<ChainBDims, ChainFwdArgsB> g) {
+__global__ void __launch_bounds__(512, (CG <= 2 ? BF_OCC : 1)) k_chain_forward_b_group(GroupTable<ChainBDims, ChainFwdArgsB> g) {
   const int j = group_find(g.start, g.n, blockIdx.x);
   chain_forward_b_body<CG>(g.dims[j].cd, g.dims[j].bd, g.args[j], blockIdx.x - g.start[j]);
 }
@@ -568,7 +558,6 @@ __device__ __forceinline__ void chain_backward_b_body(const ChainDims& cd, const
   __bf16* P0 = reinterpret_cast<__bf16*>(csm);
   __bf16* P1 = P0 + NC * ldh;
   float* G = reinterpret_cast<float*>(P1 + NC * ldh);
-  __bf16* XSB = (LDE_BF_XSTAGE_BWD != 0) ? reinterpret_cast<__bf16*>(G + NC * ldg) : nullptr;   // chunk buffers of the first product's staged operand (chain_gemm_b_gx)
   int dup;
   const long long n0 = chain_tile_start(cd, NC, a.N, &dup, bx);
   for (int i = tid; i < (2 * NC * ldh) / 8 + (NC * ldg) / 4; i += 512) reinterpret_cast<f32x4*>(csm)[i] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -681,8 +670,7 @@ __device__ __forceinline__ void chain_backward_b_body(const ChainDims& cd, const
         for (int q = 0; q < 4; q++) d[q] = row0 + q < in ? g[q] * d[q] : 0.f;
         *reinterpret_cast<bf16x4*>(Dn + c * ldh + row0) = to_bf4(d);
       };
-      if (l == L1 && XSB && out >= 2 * XKC_BWD) chain_gemm_b_gx<CG, XKC_BWD>(fragT, in, out, Bglb, bd.dl_w[l], XSB, pre, epi, stage_prev);
-      else if (l == L1) chain_gemm_b<CG, 2>(fragT, in, out, Bglb, bd.dl_w[l], 16L * bd.dl_w[l], pre, epi, stage_prev);
+      if (l == L1) chain_gemm_b<CG, 2>(fragT, in, out, Bglb, bd.dl_w[l], 16L * bd.dl_w[l], pre, epi, stage_prev);
       else chain_gemm_b<CG, 0>(fragT, in, out, Dcur, ldh, 16L * ldh, pre, epi, stage_prev);
       __syncthreads();
       Dcur = Dn;
@@ -707,11 +695,11 @@ __device__ __forceinline__ void chain_backward_b_body(const ChainDims& cd, const
   stage_prev();   // (no product followed the last δ: the input gradient was not asked for)
 }
 template <int CG>
-__global__ void __launch_bounds__(512, (CG <= 2 ? LDE_BF_OCC : 1)) k_chain_backward_b(ChainDims cd, BfDims bd, ChainBwdArgsB a) {
+__global__ void __launch_bounds__(512, (CG <= 2 ? BF_OCC : 1)) k_chain_backward_b(ChainDims cd, BfDims bd, ChainBwdArgsB a) {
   chain_backward_b_body<CG>(cd, bd, a, blockIdx.x);
 }
 template <int CG>
-__global__ void __launch_bounds__(512, (CG <= 2 ? LDE_BF_OCC : 1)) k_chain_backward_b_group(GroupTable<ChainBDims, ChainBwdArgsB> g) {
+__global__ void __launch_bounds__(512, (CG <= 2 ? BF_OCC : 1)) k_chain_backward_b_group(GroupTable<ChainBDims, ChainBwdArgsB> g) {
   const int j = group_find(g.start, g.n, blockIdx.x);
   chain_backward_b_body<CG>(g.dims[j].cd, g.dims[j].bd, g.args[j], blockIdx.x - g.start[j]);
 }

@@ -1458,18 +1458,13 @@ int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err) 
     if (p->vec_ok) {
       int nt = 64;
       while (nt < maxw) nt *= 2;
-      if (const char* e = getenv("LDE_MLPV_NT")) {   // diagnostic: more lanes than units = the contractions split over lane groups
-        const int v = atoi(e);
-        if ((v == 64 || v == 128 || v == 256) && v >= nt) nt = v;
-      }
       // Register-resident hidden layer (lde_mlpv.h: vec_matvec_reg): three Dense layers with a hidden×hidden product of at
-      // most 128×128 — the workgroup takes S·r lanes so that a lane's share of a row is VREG_K groups (LDE_MLPV_REG=0: off)
+      // most 128×128 — the workgroup takes S·r lanes so that a lane's share of a row is VREG_K groups
       vd.reg_l = -1;
       int reg_r = 0, reg_s = 0;
       {
-        const char* e = getenv("LDE_MLPV_REG");
         const int hm = dm.nL == 3 ? std::max(dm.sizes[1], dm.sizes[2]) : 0;
-        if (!(e && atoi(e) == 0) && dm.nL == 3 && hm <= 128 && hm > 16) {
+        if (dm.nL == 3 && hm <= 128 && hm > 16) {
           reg_r = hm <= 64 ? 64 : 128;
           reg_s = reg_r / 64;                 // 64 → one wave holds the rows whole; 128 → two lane groups split K
           const int want = reg_r * reg_s;     // 64 or 256 lanes
@@ -1660,7 +1655,7 @@ int mlp_reserve(MlpPlan* p, int B, int T, std::string& err) {
 // Workspace of the adjoint for batches up to B with T save points. `steps_hint` > 0: step attempts known in advance
 // (fixed step size). Staging slots per workgroup: stages × (3 step attempts per save interval + 32) — doubled whenever
 // the previous call reported an overflow — bounded by a memory budget
-// (LDE_MLP_STAGE_MB, default 24 GiB of the 288); a workgroup that needs more folds its slots into its private slab
+// (24 GiB of the 288); a workgroup that needs more folds its slots into its private slab
 // (slow but correct). LDE_MLP_STAGE_SLOTS forces the slot count (tests).
 int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::string& err) {
   const MlpDims& dm = p->dm;
@@ -1682,7 +1677,7 @@ int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::strin
   }
   const int nwg = cdiv(B, NB);
   const int nst = dm.solver == LDE_SOLVER_RK4 ? 4 : 6;
-  static const long budget_mb = [] { const char* e = getenv("LDE_MLP_STAGE_MB"); return e ? atol(e) : 24576L; }();
+  constexpr long budget_mb = 24576L;
   const char* sf = getenv("LDE_MLP_STAGE_SLOTS");   // read on every call: the tests switch it inside one process
   const int slots_force = sf ? atoi(sf) : 0;
   if (p->fb_pending) {
@@ -1786,12 +1781,11 @@ static size_t with_cache(size_t fixed, size_t want_floats) {
 
 // Kernels that run the grid-wide sum (coupled adaptive control) need every workgroup resident at once: they are launched
 // COOPERATIVELY — the runtime checks that the grid fits the device and keeps other streams' work from taking its CUs —
-// instead of assuming residency (the bounded spin of grid_sum4 stays as the last line of defence). LDE_COOP=0 (diagnostic)
-// restores the plain launch.
+// instead of assuming residency (the bounded spin of grid_sum4 stays as the last line of defence).
 template <class... A>
 static int launch_maybe_coop(bool coop, const void* fn, dim3 grid, dim3 block, size_t lds, hipStream_t stream, std::string& err,
                              const char* what, A&... args) {
-  static const bool coop_on = [] { const char* e = getenv("LDE_COOP"); return !e || atoi(e) != 0; }();
+  constexpr bool coop_on = true;
   void* argv[] = {(void*)&args...};
   hipError_t rc;
   if (coop && coop_on) {
@@ -1815,8 +1809,7 @@ static int launch_maybe_coop(bool coop, const void* fn, dim3 grid, dim3 block, s
 static bool mlp64_applicable(const MlpDims& dm, int B) {
   const char* e = getenv("LDE_MLP64");   // read per call: the tests switch kernels inside one process
   if (e && atoi(e) == 0) return false;
-  const char* m = getenv("LDE_MLP64_MAX_B");
-  const int maxb = m ? atoi(m) : 65536;   // measured (c3 shape): 0.28 + 3.9 ms vs 0.61 + 5.8 for the tile kernels at B = 4096, 0.77 + 10.4 vs 2.2 + 12.0 at 16384
+  const int maxb = 65536;   // measured (c3 shape): 0.28 + 3.9 ms vs 0.61 + 5.8 for the tile kernels at B = 4096, 0.77 + 10.4 vs 2.2 + 12.0 at 16384
   return dm.nL == 3 && dm.sizes[1] <= 64 && dm.sizes[2] <= 64 && dm.Dp <= 4 && dm.P <= 1 && !dm.coupled && B <= maxb;
 }
 // waves of the adjoint launch: one per SIMD (the kernel takes more than 256 registers); a wave walks trajectories b, b + waves, …
@@ -1826,7 +1819,7 @@ static bool mlp64_applicable(const MlpDims& dm, int B) {
 // sum reads has one row per workgroup whatever the batch
 constexpr int MLP64_NWV = 4;
 static int mlp64_adj_waves(int B) {   // = workgroups = slab rows
-  static const int maxw = [] { const char* e = getenv("LDE_MLP64_WGS"); const int v = e ? atoi(e) : 0; return v > 0 ? v : 256; }();
+  constexpr int maxw = 256;
   const int need = (B + MLP64_NWV - 1) / MLP64_NWV;
   return need < maxw ? need : maxw;
 }
@@ -1873,15 +1866,14 @@ static size_t vec_lds_fixed(const MlpDims& dm, const VecDims& vd, int T, bool ad
   b += (size_t)(11 * nsp + vd.htotal + MAXL * vd.maxw4 + vd.NT + ((dm.nbias + 3) & ~3) + 2 * MAXL * (sizeof(VLayer) / 4)) * sizeof(float);
   return (b + 15) & ~size_t(15);
 }
-// Which batches run there: see the measurement below. LDE_MLPV=0 switches the kernels off, LDE_MLPV_MAX_B moves the limit.
+// Which batches run there: see the measurement below. LDE_MLPV=0 switches the kernels off.
 static bool vec_applicable(const MlpPlan* p, int B, int T, bool adj, bool coupled_adaptive, size_t* lds, std::string& why) {
   const char* e = getenv("LDE_MLPV");   // read per call: the tests switch kernels inside one process
   if (!p->vec_ok || (e && atoi(e) == 0)) return false;
   // measured (MI355X, c2 / c3 / c4 shapes, abl/ + profiles/): the one-trajectory workgroups win while the chip has a SIMD per
   // wave (B·NT/64 ≤ 1024: c2 0.88 + 1.97 ms vs 1.77 + 3.44 at B = 256, c3 0.36 + 4.28 vs 0.63 + 5.0 at 1024, c4 0.46 + 3.77 vs
   // 0.45 + 4.3 at 512) and lose beyond (c2 at B = 1024: 1.94 + 4.5 vs 1.78 + 3.9) — the tiles then have enough columns
-  const char* m = getenv("LDE_MLPV_MAX_B");
-  const int maxb = m ? atoi(m) : (p->vd.reg_l >= 0 ? 2048 : 1024) * 64 / p->vd.NT;   // register-resident layer: two waves per SIMD still win
+  const int maxb = (p->vd.reg_l >= 0 ? 2048 : 1024) * 64 / p->vd.NT;   // register-resident layer: two waves per SIMD still win
   if (B > maxb) return false;
   const size_t fixed = vec_lds_fixed(p->dm, p->vd, T, adj);
   if (fixed > LDS_MAX / 2) return false;
@@ -1938,8 +1930,7 @@ static bool w_applicable(const MlpPlan* p, int B, int T, bool adj, bool coupled_
   if (w_lds_base(p->wd, T, adj) > LDS_MAX * p->wd.W / 4) return false;   // 4/W workgroups share a CU's LDS (one wave per SIMD)
   // one wave per SIMD (the weights take most of the 512 registers): 1024 waves are resident at once; an uncoupled solve may
   // queue a second round, a coupled one needs every trajectory resident
-  const char* m = getenv("LDE_MLPW_MAX_WAVES");
-  const int maxw = coupled_adaptive ? 1024 : (m ? atoi(m) : 2048);
+  const int maxw = coupled_adaptive ? 1024 : 2048;
   return (long long)B * p->wd.W <= maxw;
 }
 // tagged grid-sum words of w_grid_sum: an own buffer (zeroed: no tag is 0), a fresh epoch per launch, cleared when the epoch wraps

@@ -1639,7 +1639,7 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
   const size_t shm = o.T <= TS_LDS_MAX ? (size_t)o.T * sizeof(double) : 0;
   // small batches: stepping and dense output on different waves of a 64-trajectory workgroup (k_pend_forward_ws)
   static const bool ws_on = [] { const char* e = getenv("LDE_PEND_WS"); return !e || atoi(e) != 0; }();
-  static const int ws_max_b = [] { const char* e = getenv("LDE_PEND_WS_MAX_B"); return e ? atoi(e) : 16384; }();   // measured (abl/pend_B.py): 21.6 vs 31.2 µs at 16384, 36.8 vs 32.6 µs at 32768
+  constexpr int ws_max_b = 16384;   // measured (abl/pend_B.py): 21.6 vs 31.2 µs at 16384, 36.8 vs 32.6 µs at 32768
   // the smallest batches: lanes = save times, TPW trajectories per wave (k_pend_forward_tl)
   static const int tl_max_b = [] { const char* e = getenv("LDE_PEND_TL_MAX_B"); return e ? atoi(e) : 1024; }();
   // one trajectory per workgroup, a stepping wave + three dense-output waves (k_pend_forward_sh): while every workgroup has a CU to itself
@@ -1967,8 +1967,8 @@ __global__ void __launch_bounds__(256) k_pend_adjoint_stream(const float2* __res
 // readers with different caching could disagree after an environment change and send a NULL `ops` into the two-kernel form.
 enum { PEND_ADJ_FUSED = 0, PEND_ADJ_STREAM = 1, PEND_ADJ_TWO_KERNEL = 2 };
 static int pend_adjoint_form(int B, int T) {
-  static const int fused_max_b = [] { const char* e = getenv("LDE_FUSED_MAX_B"); return e ? atoi(e) : 24576; }();   // measured (abl/adj_B.py): fused 9.5 µs vs stream 39 µs at 4096, 48 vs 41 µs at 32768
-  static const bool stream_on = [] { const char* e = getenv("LDE_PEND_ADJ_STREAM"); return !e || atoi(e) != 0; }();
+  constexpr int fused_max_b = 24576;   // measured (abl/adj_B.py): fused 9.5 µs vs stream 39 µs at 4096, 48 vs 41 µs at 32768
+  constexpr bool stream_on = true;
   if (T > 1 && T - 1 <= 1024 && B <= fused_max_b) return PEND_ADJ_FUSED;
   return stream_on ? PEND_ADJ_STREAM : PEND_ADJ_TWO_KERNEL;
 }

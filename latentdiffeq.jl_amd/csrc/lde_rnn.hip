@@ -1107,10 +1107,8 @@ static int rnn_launch(lde_rnn* r, const RnnArgs& a, int B, hipStream_t stream) {
   // at every step, so a small batch is spread over as many CUs as it has waves (one wave per workgroup: the LDS of a CU then
   // serves one wave instead of sixteen); only a batch that would exceed ~4 workgroups per CU packs more trajectories
   // behind one LDS copy of the weights.
-  static const int tpw_env = std::getenv("LDE_RNN_TPW") ? std::atoi(std::getenv("LDE_RNN_TPW")) : 0;
   int tpw = std::max(1, 64 / r->rd.Hp);
   while (tpw < 16 && cdiv(B, tpw) > 1024) tpw *= 2;
-  if (tpw_env == 1 || tpw_env == 2 || tpw_env == 4 || tpw_env == 8 || tpw_env == 16) tpw = tpw_env;
   const char* erw = std::getenv("LDE_RNN_REGW");   // read per call: the tests compare the two instantiations inside one process
   const bool one_wave = tpw * r->rd.Hp == 64 && !(erw && std::atoi(erw) == 0);   // one wave per workgroup: the register-resident-weights instantiation
   // … and, for the default shape, one wave per CELL (rnn_body2): LDE_RNN_PIPE=0 keeps the single wave
@@ -1204,10 +1202,8 @@ int lde_rnn_forward_train(lde_rnn* r, const float* x, int T, int B, float* y, vo
     r->err = "lde_rnn_forward_train: weights not set";
     return LDE_ERR_NO_WEIGHTS;
   }
-  static const bool keep_on = [] { const char* e = std::getenv("LDE_RNN_KEEP"); return !e || std::atoi(e) != 0; }();
   r->kept_T = r->kept_B = 0;
   r->kept_x = nullptr;
-  if (!keep_on) return lde_rnn_forward(r, x, T, B, y, stream_);
   r->staged_T = r->staged_B = 0;
   int rc = lde_rnn_reserve(r, B, T);
   if (rc) return rc;
@@ -1294,10 +1290,6 @@ int lde_rnn_backward_dw(lde_rnn* r, float* dW, void* stream_) {
     da.stage = r->stage[l]; da.wts = r->wts; da.nslots = nullptr; da.slab = r->slab + (size_t)l * r->slab_layer; da.cap = T; da.total = (long long)ntile * T;   // every tile staged exactly T slots
     int ks = cdiv(512, ntile * dw_jobs(r->dmw[l], dw_pick_ndw(r->dmw[l])));
     ks = ks < 1 ? 1 : (ks > 8 ? 8 : ks);
-    if (const char* e = std::getenv("LDE_RNN_DW_KS")) {   // experiments: the K-split of the cells' weight-gradient products
-      const int v = std::atoi(e);
-      if (v >= 1 && v <= 8) ks = v;
-    }
     if (t_rrec && t_rrec->ndw < GROUP_MAX_DW) {
       RnnRecDw& q = t_rrec->dw[t_rrec->ndw++];
       q.ndw = dw_pick_ndw(r->dmw[l]); q.dm = r->dmw[l]; q.da = da; q.gx = ntile; q.gy = ks; q.gz = dw_jobs(r->dmw[l], q.ndw);
@@ -1378,8 +1370,7 @@ static int rnn_group_flush(RnnGroupRec& g, hipStream_t stream) {
       }
       void* argv[] = {(void*)&t};
       (void)hipLaunchKernel((const void*)k_mlp_dw_group<1, false>, dim3(t.start[g.ndw]), dim3(512), argv, lds, stream);
-      static const bool merge_s0 = [] { const char* e = std::getenv("LDE_RNN_MERGE_S0"); return !e || std::atoi(e) != 0; }();
-      if (merge_s0 && g.ns0 >= 2) {   // … and the initial-state sums ride on the slab sums' launch
+      if (g.ns0 >= 2) {   // … and the initial-state sums ride on the slab sums' launch
         ReduceState0Tables rs{};
         rs.u = u;
         rs.s.n = g.ns0;
@@ -1418,8 +1409,7 @@ static bool rnn_group_ok(int n) {
 #if LDE_PROF
   return false;
 #else
-  static const bool on = [] { const char* e = std::getenv("LDE_RNN_GROUP_LAUNCH"); return !e || std::atoi(e) != 0; }();
-  return on && n >= 2 && n <= RNN_GROUP_MAX && dw_stream_get() == nullptr;
+  return n >= 2 && n <= RNN_GROUP_MAX && dw_stream_get() == nullptr;
 #endif
 }
 static bool rnn_group_fits(int n, lde_rnn* const* rs) {   // every (stack, cell) weight-gradient job must fit one table; a handle's workspace serves one call at a time

@@ -526,35 +526,6 @@ def _run_concurrently(stacks, x):
     return outs
 
 
-_CHAIN_STREAMS = os.environ.get("LDE_CHAIN_STREAMS", "0") != "0"   # the independent small chains (latent_in's four heads, latent_out's two) on side
-                                                                     # streams, i.e. parallel branches of a captured step instead of a chain of ≈ 6 µs
-                                                                     # launches. Opt-in: measured SLOWER — goku_step replay 1.48 → 1.61 ms f32, 1.00 →
-                                                                     # 1.13 ms mixed (one box, back to back): a fork–join inside a hipGraph costs more in
-                                                                     # dependency resolution than the four launches it takes off the critical path.
-
-
-def run_forked(pairs):
-    """[(module, input), …] → [module(input), …] with every call on a side HIP stream of its own: a flat fork–join (the calls must be
-    independent of each other). Same arithmetic, same results; only the order in which the device may run them changes."""
-    if not _CHAIN_STREAMS or len(pairs) < 2 or not pairs[0][1].is_cuda:
-        return [m(x) for m, x in pairs]
-    dev = pairs[0][1].device
-    main = torch.cuda.current_stream(dev)
-    streams = _side_streams.setdefault((dev.index, "fork", len(pairs)), [torch.cuda.Stream(dev) for _ in pairs])
-    ready = main.record_event()
-    outs = []
-    for (m, x), st in zip(pairs, streams):
-        st.wait_event(ready)
-        with torch.cuda.stream(st):
-            y = m(x)
-        x.record_stream(st)
-        outs.append(y)
-    for st, y in zip(streams, outs):
-        main.wait_stream(st)
-        y.record_stream(main)
-    return outs
-
-
 def apply_pattern_extractor(encoder: Encoder, fe_out):
     """[REF src/models/GOKU.jl:32-51]: pe_z₀ on the reversed frames; pe_θ forward ⊕ pe_θ backward (reversed frames).
     [REF src/models/LatentODE.jl:24-33]: one stack on the reversed frames."""
@@ -578,11 +549,8 @@ def apply_latent_in(encoder: Encoder, pe_out):
         pe_z0, pe_th = pe_out
         li_mu_z0, li_ls_z0, li_mu_th, li_ls_th = encoder.latent_in
         heads = [(li_mu_z0, pe_z0), (li_mu_th, pe_th), (li_ls_z0, pe_z0), (li_ls_th, pe_th)]
-        if _CHAIN_STREAMS:
-            mu_z0, mu_th, ls_z0, ls_th = run_forked(heads)
-        else:
-            from .chain import apply_chains_grouped      # the four heads as one autograd node, one launch per stage
-            mu_z0, mu_th, ls_z0, ls_th = apply_chains_grouped(heads)
+        from .chain import apply_chains_grouped      # the four heads as one autograd node, one launch per stage
+        mu_z0, mu_th, ls_z0, ls_th = apply_chains_grouped(heads)
         return (mu_z0, mu_th), (ls_z0, ls_th)
     li_mu, li_ls = encoder.latent_in
     from .chain import apply_chains_grouped

@@ -93,6 +93,8 @@ def test_two_shards_under_the_global_norm_equal_the_unsharded_solve():
     W = O.mlp_weights(LAYERS, seed=3)
     B = 192
     z0, ts, dz = _inputs(B)
+    z0[80:] *= 3.0                           # the second shard's columns move faster: they set the global step size, so a shard-LOCAL norm
+                                             # on the first shard is a visibly different controller (the last assertion below)
     ref = _setup(O.BATCH_COUPLED, W)
     zf, _, sf = ref.forward(z0, None, ts)
     f0, _, fW, sbf = ref.adjoint(zf, None, ts, dz)
@@ -152,7 +154,7 @@ def test_two_shards_under_the_global_norm_equal_the_unsharded_solve():
     # (how different depends on the kernel's round-off: measured 8e-7·scale with k_mlpc against ≤ 1e-7 between the sharded-global and
     #  the unsharded solve — the gate is "more than the sharded-global solve's own distance", not a fixed 1e-6)
     d_glob = max(np.abs(out[r][0] - zf[:, lo:hi]).max() for r, (lo, hi) in enumerate(bounds))
-    assert np.abs(zl - zf[:, :80]).max() > max(1.5 * d_glob, 2e-7 * scale) or sl["naccept"] != sf["naccept"], (np.abs(zl - zf[:, :80]).max(), d_glob)
+    assert np.abs(zl - zf[:, :80]).max() > max(3.0 * d_glob, 1e-6 * scale) or sl["naccept"] != sf["naccept"], (np.abs(zl - zf[:, :80]).max(), d_glob)
 
 
 def test_a_failing_hook_fails_the_solve_without_hanging():

@@ -151,10 +151,10 @@ def test_two_shards_under_the_global_norm_equal_the_unsharded_solve():
     # the shard-LOCAL norm (option (i), the default for sharded runs) is a different — equally valid — step sequence
     loc = _setup(O.BATCH_COUPLED, W)
     zl, _, sl = loc.forward(z0[:80], None, ts)
-    # (how different depends on the kernel's round-off: measured 8e-7·scale with k_mlpc against ≤ 1e-7 between the sharded-global and
+    # (how different depends on the kernel's round-off: measured 1.3e-6 with k_mlpc against 0 — bit-equal — between the sharded-global and
     #  the unsharded solve — the gate is "more than the sharded-global solve's own distance", not a fixed 1e-6)
     d_glob = max(np.abs(out[r][0] - zf[:, lo:hi]).max() for r, (lo, hi) in enumerate(bounds))
-    assert np.abs(zl - zf[:, :80]).max() > max(3.0 * d_glob, 1e-6 * scale) or sl["naccept"] != sf["naccept"], (np.abs(zl - zf[:, :80]).max(), d_glob)
+    assert np.abs(zl - zf[:, :80]).max() > max(3.0 * d_glob, 5e-7) or sl["naccept"] != sf["naccept"], (np.abs(zl - zf[:, :80]).max(), d_glob)
 
 
 def test_a_failing_hook_fails_the_solve_without_hanging():

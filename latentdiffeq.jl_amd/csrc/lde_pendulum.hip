@@ -85,6 +85,14 @@ static __device__ long long g_pprof[32];
 // scalar coefficient (no per-component instructions, no operand shuffles) — the stepping wave's instruction count is the
 // metric kernel's duration. Same tableau, same order of operations per component as tsit5_attempt<2>; k[0] = f(y) on entry;
 // leaves k[1..6], yn; returns the mean square of the scaled error (EEst²; 0 when !ADAPT).
+// max(|a|, |b|) as the one instruction it is (fmaxf(fabsf(a), fabsf(b)) compiles to a canonicalising v_max |a|, |a| in front of it when a
+// is a loop-carried value; the result is the same number).
+__device__ __forceinline__ float max_abs(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 template <class F, bool ADAPT>
 __device__ __forceinline__ float tsit5_attempt_pair(F& f, float h, f32x2 y, f32x2 (&k)[7], f32x2& yn, const KOpts& o) {
   // Column-oriented: as soon as a slope exists it is added to the sums of ALL later stages — independent instructions that fill the
@@ -110,7 +118,7 @@ __device__ __forceinline__ float tsit5_attempt_pair(F& f, float h, f32x2 y, f32x
 #pragma unroll
   for (int j = 1; j < 7; j++) e += k[j] * ts5::BT[j];
   e *= h;
-  const f32x2 sk = f32x2{fmaxf(fabsf(y.x), fabsf(yn.x)), fmaxf(fabsf(y.y), fabsf(yn.y))} * o.reltol + o.abstol;
+  const f32x2 sk = f32x2{max_abs(y.x, yn.x), max_abs(y.y, yn.y)} * o.reltol + o.abstol;
   const f32x2 r = e * f32x2{fast_rcp(sk.x), fast_rcp(sk.y)};
   const f32x2 r2 = r * r;
   return (r2.x + r2.y) * 0.5f;
@@ -893,7 +901,7 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
       for (;;) {
         if (!__any(pen == 0.f)) break;
         const float rem = (float)(tend - t);
-        const bool last = dt >= rem * 0.99999988f;
+        const bool last = __any(dt >= rem * 0.99999988f);   // (every lane of this wave carries the same solve: a vote is the lane's own answer, as a scalar branch)
         const float h = last ? rem : dt;
         k[0] = kf;
         f.anchor(y.x);
@@ -910,28 +918,27 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
           yn = f32x2{yna[0], yna[1]};
         }
         const float mq = fmaf(0.f, fabsf(yn.x) + fabsf(yn.y), msq + pen);   // ∞·0 = NaN: a non-finite state never passes
-        const bool ok = mq <= 1.0f;
+        const bool ok = __any(mq <= 1.0f);
         float dtn = (float)o.dt_fixed, l = 0.f;
         if (ADAPT) {
           l = 0.5f * __builtin_amdgcn_logf(msq);
           const float q = fmaxf(o.q_lo, fminf(o.q_hi, __builtin_amdgcn_exp2f(o.beta1 * l - o.beta2 * lqold) * o.inv_gamma));
           dtn = fminf(h * fast_rcp(q), dtmax);
         }
-        if (__builtin_expect(__any(!ok && pen == 0.f), 0)) {   // rare: a rejected or non-finite attempt
-          if (!ok && pen == 0.f) {
-            const bool fin = (fabsf(yn.x) + fabsf(yn.y)) < __builtin_inff();
-            nrej++;
-            iters++;
-            if (!ADAPT) { ret = LDE_RET_NONFINITE; active = false; nrej--; }
-            else if (!fin) {
-              if (h > dtmin) dt = h * o.qmin;
-              else { ret = LDE_RET_NONFINITE; active = false; nrej--; }
-            } else {
-              dt = h * fast_rcp(fminf(o.q_hi, __builtin_amdgcn_exp2f(o.beta1 * l) * o.inv_gamma));
-              if (dt < dtmin) { ret = LDE_RET_DTMIN; active = false; }
-            }
-            if (!active || iters >= maxit) pen = __builtin_inff();
+        if (__builtin_expect(!ok && __any(pen == 0.f), 0)) {   // rare: a rejected or non-finite attempt (scalar branches throughout: the
+                                                               // loop's variables are updated in place, no exec-masked copies at the loop edge)
+          const bool fin = __any((fabsf(yn.x) + fabsf(yn.y)) < __builtin_inff());
+          nrej++;
+          iters++;
+          if (!ADAPT) { ret = LDE_RET_NONFINITE; active = false; nrej--; }
+          else if (!fin) {
+            if (__any(h > dtmin)) dt = h * o.qmin;
+            else { ret = LDE_RET_NONFINITE; active = false; nrej--; }
+          } else {
+            dt = h * fast_rcp(fminf(o.q_hi, __builtin_amdgcn_exp2f(o.beta1 * l) * o.inv_gamma));
+            if (__any(dt < dtmin)) { ret = LDE_RET_DTMIN; active = false; }
           }
+          if (!active || iters >= maxit) pen = __builtin_inff();
         }
         if (ok) {   // the accepted step: leave {h, yₙ₊₁} behind, publish, advance
           if (last) {   // once per solve: the last step's slopes travel too — its helper would otherwise start rebuilding them only now, a
@@ -951,7 +958,7 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
           iters++;
           y = yn;
           kf = k[FS];
-          t = last ? tend : t + (double)h;
+          t += (double)h;   // (the last step ends the loop: its t is not read again)
           dt = dtn;
           lqold = fmaxf(l, LQ_MIN);
           active = !last;

@@ -1,12 +1,12 @@
 #!/bin/bash
 # the round's evidence: rocprofv3 kernel trace + FETCH_SIZE / WRITE_SIZE passes and the plain bench line for every workload
-#   abl/collect_all.sh [round tag, default r3]      (run on the GPU box from the repo root; then profiles/refresh.py --round <tag> …)
-R=${1:-r3}
+#   abl/collect_all.sh [round tag, default r4]      (run on the GPU box from the repo root; then profiles/refresh.py --round <tag> …)
+R=${1:-r4}
 cd "$GRAFT_REPO_ROOT"
 python bench.py --workload goku_step --steps 30 --warmup 10 --no-cpu-baseline > /dev/null 2>&1   # a fresh box runs its first process ≈ 8 % slow
 bash profiles/collect.sh ${R}_goku_pendulum_b256 --steps 200 --warmup 20 --no-cpu-baseline > /dev/null 2>&1
 python bench.py --steps 200 --warmup 20 --sweep > gpurun_out/bench_metric.json 2> gpurun_out/bench_metric.err
-for w in c2 c3 c4; do
+for w in c2 c3 c4 latentode_ref; do
   bash profiles/collect.sh ${R}_$w --workload $w --steps 20 --warmup 5 --no-cpu-baseline > /dev/null 2>&1
   python bench.py --workload $w --steps 20 --warmup 5 > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err
 done

@@ -202,7 +202,10 @@ int lde_get_phase_ms(lde_handle* h, float* ms2);
  * is called on the thread that called lde_forward / lde_adjoint, while the solve's kernel waits for the answer — use a HOST
  * collective (MPI, gloo, a pipe): the device is occupied — and nothing in the hook may synchronise the device (hipFree, a null-stream
  * copy, a finaliser that releases device memory): it would wait for the kernel that waits for the hook. `global_batch` = Σ over ranks of
- * their B (the norm's divisor).
+ * their B (the norm's divisor). The values are float32 sums widened to f64 (the device forms and consumes them in f32). If the hook
+ * returns non-zero the solve is poisoned with NaN sums and ends with retcode != 0 / rc -1; requests that still arrive are passed to
+ * the hook with NaN payloads (its result ignored) so that peers still in the exchange fail too — but a failed solve issues few
+ * requests, so give the host collective a finite time-out: a peer then fails by it instead of waiting for ever.
  * hook == NULL clears it (the mode then equals LDE_BATCH_COUPLED on this rank's columns). */
 typedef int (*lde_sum_hook)(void* user, double* vals, int n);
 int lde_set_global_sum_hook(lde_handle* h, lde_sum_hook hook, void* user, int64_t global_batch);

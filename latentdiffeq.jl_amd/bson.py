@@ -71,7 +71,12 @@ def _parse_doc(b: memoryview, at: int, as_list: bool):
     out = [] if as_list else {}
     while at < end:
         t = b[at]
-        z = bytes(b[at + 1:end]).find(b"\x00")
+        z, w = -1, 64          # the key's terminator, looked for in growing windows: O(key length), not a copy of the document's remainder per element
+        while z < 0 and at + 1 < end:
+            z = bytes(b[at + 1:min(end, at + 1 + w)]).find(b"\x00")
+            if at + 1 + w >= end:
+                break
+            w *= 8
         if z < 0:
             raise ValueError("unterminated BSON key")
         key, at = bytes(b[at + 1:at + 1 + z]).decode("utf-8"), at + 2 + z

@@ -52,7 +52,7 @@ __device__ __forceinline__ float kl_term(float m, float lv) { return 0.5f * (__e
 template <int TERM>
 __device__ __forceinline__ void loss_partial_body(const float* __restrict__ a, const float* __restrict__ b, int64_t n,
                                                   float* __restrict__ scratch, const float* __restrict__ c, float* __restrict__ l, float fscale,
-                                                  float* __restrict__ fout, const float* __restrict__ fbase, const unsigned bx, const unsigned nblk) {
+                                                  float* fout, const float* fbase, const unsigned bx, const unsigned nblk) {   // (fout may BE fbase: k_sample_kl_pair's second part adds to the first's result)
   // workgroup w owns the slice [w·per, (w+1)·per) with per a multiple of 4 floats
   const int64_t nwg = nblk;
   int64_t per = (n + nwg - 1) / nwg;

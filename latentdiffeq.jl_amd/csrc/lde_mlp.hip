@@ -2205,7 +2205,11 @@ static int global_serve(MlpPlan* p, hipStream_t stream, std::string& err) {
       if ((unsigned)(w0 >> 32) == tag && (unsigned)(w1 >> 32) == tag) {
         auto f = [](unsigned long long w) { unsigned u = (unsigned)w; float v; std::memcpy(&v, &u, 4); return (double)v; };
         double vals[2] = {f(w0), f(w1)};
-        if (rc == LDE_OK && p->sum_hook(p->sum_user, vals, n) != 0) {
+        if (rc != LDE_OK) {   // after a failure the hook is still called, with NaN: peers that are still in the exchange receive NaN sums and
+                              // end their solves with retcode != 0 too, instead of waiting for a rank that has stopped answering
+          vals[0] = vals[1] = std::nan("");
+          (void)p->sum_hook(p->sum_user, vals, n);
+        } else if (p->sum_hook(p->sum_user, vals, n) != 0) {
           err = "LDE_BATCH_COUPLED_GLOBAL: the sum hook reported an error";
           rc = LDE_ERR_INVALID_ARG;
         }

@@ -697,12 +697,16 @@ __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict
     active = t < tend && maxit > 0;
     if (t < tend && !active) ret = LDE_RET_MAXITERS;
   }
-  // the stepping loop of k_pend_forward_ws (see there): one float decides acceptance, rare cases out of line
+  // the stepping loop of k_pend_forward_ws (see there): one float decides acceptance, rare cases out of line. With one trajectory per
+  // wave (TPW = 1) every lane carries the same solve, so each decision is taken as a vote — the lane's own answer, but a scalar branch:
+  // the loop's variables are then updated in place instead of through exec-masked copies (as in k_pend_forward_sh).
+  constexpr bool UNI = TPW == 1 && RING == 0;
+  auto vote = [](bool c) -> bool { return UNI ? (bool)__any(c) : c; };
   float pen = (active && iters < maxit) ? 0.f : __builtin_inff();
   for (;;) {
     if (!__any(pen == 0.f)) break;
     const float rem = (float)(tend - t);
-    const bool last = dt >= rem * 0.99999988f;
+    const bool last = vote(dt >= rem * 0.99999988f);
     // (RING) a trajectory that has run to within lb_hold rows of the ring's end sits this iteration out: its attempt is computed and
     // dropped like a stopped lane's, nothing of its state changes, and the rows it would have had to store piecemeal wait for the wave
     const float penh = (RING > 0 && j >= jc + RING - o.lb_hold && o.lb_hold > 0) ? __builtin_inff() : pen;
@@ -722,7 +726,7 @@ __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict
       yn = f32x2{yna[0], yna[1]};
     }
     const float mq = fmaf(0.f, fabsf(yn.x) + fabsf(yn.y), msq + penh);   // ∞·0 = NaN: a non-finite state never passes
-    const bool ok = mq <= 1.0f;
+    const bool ok = vote(mq <= 1.0f);
     float dtn = (float)o.dt_fixed, l = 0.f;
     if (ADAPT) {
       l = 0.5f * __builtin_amdgcn_logf(msq);
@@ -730,17 +734,17 @@ __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict
       dtn = fminf(h * fast_rcp(q), dtmax);
     }
     if (__builtin_expect(__any(!ok && penh == 0.f), 0)) {   // rare: a rejected or non-finite attempt
-      if (!ok && penh == 0.f) {
-        const bool fin = (fabsf(yn.x) + fabsf(yn.y)) < __builtin_inff();
+      if (vote(!ok && penh == 0.f)) {
+        const bool fin = vote((fabsf(yn.x) + fabsf(yn.y)) < __builtin_inff());
         nrej++;
         iters++;
         if (!ADAPT) { ret = LDE_RET_NONFINITE; active = false; nrej--; }
         else if (!fin) {
-          if (h > dtmin) dt = h * o.qmin;
+          if (vote(h > dtmin)) dt = h * o.qmin;
           else { ret = LDE_RET_NONFINITE; active = false; nrej--; }
         } else {
           dt = h * fast_rcp(fminf(o.q_hi, __builtin_amdgcn_exp2f(o.beta1 * l) * o.inv_gamma));
-          if (dt < dtmin) { ret = LDE_RET_DTMIN; active = false; }
+          if (vote(dt < dtmin)) { ret = LDE_RET_DTMIN; active = false; }
         }
         if (!active || iters >= maxit) pen = __builtin_inff();
       }

@@ -260,7 +260,11 @@ class LdeComm:
 def global_sum_hook(group=None):
     """The `fn` of `NODE.set_global_sum` (LDE_BATCH_COUPLED_GLOBAL, SURVEY.md §8e option (ii)): sums the step-control sums of ONE
     coupled solve over the ranks that share it. `group` must be a HOST group (gloo): the hook runs while the solve's kernel occupies the
-    device and waits for the answer — create one with `dist.new_group(backend="gloo")` next to the RCCL group of the gradients."""
+    device and waits for the answer — create one with `dist.new_group(backend="gloo", timeout=timedelta(seconds=…))` next to the RCCL
+    group of the gradients. Give it a FINITE timeout: a rank whose solve has failed stops entering the exchange (after a hook failure the
+    library keeps calling the hook with NaN payloads for the requests it still receives, but a failed solve issues few or none), and a
+    peer's all-reduce then ends by the group's timeout — the exception makes the hook fail and that peer's solve ends with retcode ≠ 0
+    instead of blocking for ever. The sums cross the boundary as doubles but are formed and consumed in float32 on the device."""
     def fn(vals):
         t = torch.from_numpy(vals)          # shares memory with the C array: the all-reduce is in place
         dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)

@@ -169,8 +169,34 @@ class FluxADAMW(torch.optim.Adam):
             raise ValueError("FluxADAMW(capturable=True) needs the native path")
         self._step_dev = torch.zeros((), dtype=torch.int64, device=params[0].device) if self.capturable else None
         if self.capturable:
+            if len(self.param_groups) != 1:     # one device counter, bumped by every lde_adamw_flux_step_dev launch: one launch per step
+                raise ValueError("FluxADAMW(capturable=True) takes ONE parameter group")
             from .loss import set_noise_epoch
             set_noise_epoch(self._step_dev)     # a captured step's ε is keyed by this counter: fresh noise at every replay (loss.randn)
+
+    def add_param_group(self, param_group):
+        if getattr(self, "capturable", False) and self.param_groups:
+            raise ValueError("FluxADAMW(capturable=True) takes ONE parameter group")
+        super().add_param_group(param_group)
+
+    def state_dict(self):
+        """The capturable form's step count lives on the device (`_step_dev`), not in `state`: a checkpoint carries it as every array's
+        `step` (what the non-capturable and torch forms keep), so that a resumed run's bias corrections continue at t, not at 0."""
+        sd = super().state_dict()
+        if self.capturable:
+            t = int(self._step_dev.item())
+            sd["state"] = {k: dict(v, step=t) for k, v in sd["state"].items()}
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict(state_dict)
+        if self.capturable:
+            steps = [int(st["step"]) for st in self.state.values() if "step" in st]
+            if steps and min(steps) != max(steps):
+                raise ValueError("FluxADAMW(capturable=True): the checkpoint's arrays have been updated unequally often")
+            self._step_dev.fill_(steps[0] if steps else 0)
+            for st in self.state.values():
+                st.pop("step", None)
 
     @torch.no_grad()
     def _native_step(self):

@@ -83,3 +83,44 @@ def test_native_update_skips_parameters_without_gradient_and_rejects_bad_argumen
     assert lib.lde_adamw_flux_step(0, None, 1e-3, 0.9, 0.999, 1e-8, 0.0, 1, None) == 0
     with pytest.raises(ValueError):
         FluxADAMW([torch.nn.Parameter(torch.ones(3))], native=True)                         # CPU parameters: no native path
+
+
+def test_capturable_step_count_survives_a_checkpoint():
+    """The capturable form keeps t in one device word: a state_dict carries it as every array's `step`, a loaded one restores it —
+    a resumed run continues the bias corrections at t (restarting at 0 scales m̂ by 10 and v̂ by 1000 on the first resumed step) —
+    and the checkpoint is the one the non-capturable form writes and reads. One parameter group only (one launch bumps the word)."""
+    import torch
+    from latentdiffeq_amd.train import FluxADAMW
+    rng = np.random.default_rng(11)
+    eta, b1, b2, eps, decay = 1e-3, 0.9, 0.999, 1e-8, 1e-3
+    x0 = rng.standard_normal(1000).astype(np.float32)
+    grads = [rng.standard_normal(1000).astype(np.float32) for _ in range(6)]
+
+    def run(opt, p, gs):
+        for g in gs:
+            p.grad = torch.from_numpy(g).cuda()
+            opt.step()
+
+    p1 = torch.nn.Parameter(torch.from_numpy(x0).cuda())
+    o1 = FluxADAMW([p1], lr=eta, betas=(b1, b2), decay=decay, eps=eps, capturable=True)
+    run(o1, p1, grads[:3])
+    sd = o1.state_dict()
+    assert all(st["step"] == 3 for st in sd["state"].values())
+    p2 = torch.nn.Parameter(p1.detach().clone())
+    o2 = FluxADAMW([p2], lr=eta, betas=(b1, b2), decay=decay, eps=eps, capturable=True)
+    o2.load_state_dict(sd)
+    assert int(o2._step_dev.item()) == 3
+    p3 = torch.nn.Parameter(p1.detach().clone())
+    o3 = FluxADAMW([p3], lr=eta, betas=(b1, b2), decay=decay, eps=eps)          # the non-capturable form resumes from the same file
+    o3.load_state_dict(sd)
+    run(o1, p1, grads[3:])
+    run(o2, p2, grads[3:])
+    run(o3, p3, grads[3:])
+    want = _flux_reference(x0, grads, eta, b1, b2, eps, decay)
+    for p in (p1, p2, p3):
+        assert np.abs(p.detach().cpu().numpy() - want).max() <= 2e-6 * np.abs(want).max()
+    assert torch.equal(p1, p2)
+    with pytest.raises(ValueError):
+        FluxADAMW([{"params": [p1]}, {"params": [p2]}], capturable=True)
+    with pytest.raises(ValueError):
+        o1.add_param_group({"params": [p3]})

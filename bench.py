@@ -416,7 +416,7 @@ def run_goku_step(args, torch, dist, world, rank, local):
     Bg = B * world
 
     fused_loss = os.environ.get("LDE_FUSED_LOSS", "1") != "0"     # diagnostic: 0 = separate sample / vector_kl / reconstruction_loss and torch additions
-    refresh = os.environ.get("LDE_BENCH_REFRESH", "1") != "0"   # diagnostic: 0 = every module re-uploads its weights at its next call
+    refresh = True   # one k_refresh_many launch re-packs every module's weights after the update (instead of an upload at each module's next call)
 
     def step():
         opt.zero_grad(set_to_none=True)

@@ -172,7 +172,7 @@ def _same_layout(a: torch.Tensor, b: torch.Tensor):
 # into the graph, so the draw is keyed by the state last seen outside, a per-draw call index, and a DEVICE counter read by the kernel:
 # the step count of the optimiser in the captured step (train.FluxADAMW(capturable=True) registers it) — fresh noise at every replay,
 # none of the three fill / copy launches torch's graph-safe generator puts in front of a replay. No counter registered: torch.randn.
-_NATIVE_RNG = os.environ.get("LDE_NATIVE_RNG", "1") != "0"
+_NATIVE_RNG = True
 _noise_epoch = {}          # device index → int64 device scalar that changes from replay to replay
 _noise_base = {}           # device index → (seed, offset) of torch's generator when last seen outside a capture
 _noise_call = [0]
@@ -250,7 +250,7 @@ class _SampleKlPairFn(torch.autograd.Function):
         return dmu_a, dlv_a, dmu_b, dlv_b, None, None, None
 
 
-_SAMPLE_PAIR = os.environ.get("LDE_SAMPLE_PAIR", "1") != "0"   # sample_with_kl of a two-part tuple: one launch each way (diagnostic switch)
+_SAMPLE_PAIR = True                                             # sample_with_kl of a two-part tuple: one launch each way
 _PAIR_MAX = 8192                                                # entries per part (one workgroup of the separate kernels)
 
 

@@ -389,7 +389,7 @@ class _GokuEncoderFn(torch.autograd.Function):
         return (None, dx, dW_fe, *dW_pe, *dW_li)
 
 
-_ENCODER_FUSED = os.environ.get("LDE_ENCODER_FUSED", "1") != "0"   # encode() without branch streams (what a captured step runs): the GOKU encoder as one autograd node
+_ENCODER_FUSED = True   # encode() without branch streams (what a captured step runs): the GOKU encoder as one autograd node
 
 
 def _encode_goku_fused(encoder: Encoder, x):
@@ -498,9 +498,9 @@ _RNN_GROUP = os.environ.get("LDE_RNN_GROUP", "0") != "0"             # encode():
                                                                        # alternations on one box) — the z₀ branch's latent_in chains then run after the join instead of
                                                                        # beside the θ branch's longer stacks, and the per-tensor record_stream calls cost the host more
                                                                        # than the two autograd nodes they save
-_RNN_LAUNCH_GROUP = os.environ.get("LDE_RNN_LAUNCH_GROUP", "1") != "0"   # apply_pattern_extractor (the path without branch streams — what a captured step
+_RNN_LAUNCH_GROUP = True   # apply_pattern_extractor (the path without branch streams — what a captured step
                                                                            # runs): the stacks through lde_rnn_group_* on one stream instead of three side streams
-_STACKS_FIRST = os.environ.get("LDE_STACKS_FIRST", "1") != "0"       # encode(): issue the three recurrent stacks before the latent_in chains (diagnostic switch)
+_STACKS_FIRST = True       # encode(): issue the three recurrent stacks before the latent_in chains
 _BRANCH_STREAMS = os.environ.get("LDE_BRANCH_STREAMS", "1") != "0"   # encode(): keep the z₀ / θ branches on their own streams (diagnostic switch)
 
 

@@ -150,11 +150,13 @@ class FluxADAMW(torch.optim.Adam):
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), decay: float = 0.0, eps: float = 1e-8, fused=None, native=None,
                  capturable: bool = False):
-        params = list(params)
+        groups = list(params)
+        params = [p for g in groups for p in (g["params"] if isinstance(g, dict) else [g])]     # (arrays, or torch's group dicts)
         on_gpu = bool(params) and all(p.is_cuda for p in params)
         if fused is None:
             fused = on_gpu
-        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=0.0, fused=fused or None)
+        self.capturable = False             # (add_param_group runs inside the base constructor)
+        super().__init__(groups, lr=lr, betas=betas, eps=eps, weight_decay=0.0, fused=fused or None)
         self.decay = float(decay)
         ok = on_gpu and all(p.dtype == torch.float32 and p.is_contiguous() for p in params)
         if native is None:

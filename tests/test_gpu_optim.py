@@ -104,7 +104,10 @@ def test_capturable_step_count_survives_a_checkpoint():
     p1 = torch.nn.Parameter(torch.from_numpy(x0).cuda())
     o1 = FluxADAMW([p1], lr=eta, betas=(b1, b2), decay=decay, eps=eps, capturable=True)
     run(o1, p1, grads[:3])
-    sd = o1.state_dict()
+    import io
+    buf = io.BytesIO()
+    torch.save(o1.state_dict(), buf)          # through a file image: load_state_dict does not copy tensors that are already on the device
+    sd = torch.load(io.BytesIO(buf.getvalue()))
     assert all(st["step"] == 3 for st in sd["state"].values())
     p2 = torch.nn.Parameter(p1.detach().clone())
     o2 = FluxADAMW([p2], lr=eta, betas=(b1, b2), decay=decay, eps=eps, capturable=True)
@@ -112,7 +115,7 @@ def test_capturable_step_count_survives_a_checkpoint():
     assert int(o2._step_dev.item()) == 3
     p3 = torch.nn.Parameter(p1.detach().clone())
     o3 = FluxADAMW([p3], lr=eta, betas=(b1, b2), decay=decay, eps=eps)          # the non-capturable form resumes from the same file
-    o3.load_state_dict(sd)
+    o3.load_state_dict(torch.load(io.BytesIO(buf.getvalue())))
     run(o1, p1, grads[3:])
     run(o2, p2, grads[3:])
     run(o3, p3, grads[3:])

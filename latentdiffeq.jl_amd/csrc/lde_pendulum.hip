@@ -93,6 +93,13 @@ __device__ __forceinline__ float max_abs(float a, float b) {
   return r;
 }
 
+// max(a, b) of two numbers that are not NaN as one instruction (fmaxf canonicalises a loop-carried operand first: v_max a, a)
+__device__ __forceinline__ float max_f(float a, float b) {
+  float r;
+  asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 template <class F, bool ADAPT>
 __device__ __forceinline__ float tsit5_attempt_pair(F& f, float h, f32x2 y, f32x2 (&k)[7], f32x2& yn, const KOpts& o) {
   // Column-oriented: as soon as a slope exists it is added to the sums of ALL later stages — independent instructions that fill the
@@ -896,14 +903,15 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
       }
     } else
       dt = (float)o.dt_fixed;
-    bool active = t < tend && maxit > 0;
-    if (t < tend && !active) ret = LDE_RET_MAXITERS;
+    bool active = __any(t < tend) && maxit > 0;   // (votes: scalar from here on)
+    if (__any(t < tend) && !active) ret = LDE_RET_MAXITERS;
     for (;;) {   // rounds
       int n = 0;
       float* rp = rec_at(0);
-      float pen = (active && iters < maxit) ? 0.f : __builtin_inff();
-      for (;;) {
-        if (!__any(pen == 0.f)) break;
+      // `go` (scalar): this round goes on. (k_pend_forward_tl carries it as a float penalty added to the error norm, because its lanes stop
+      // one by one; here the wave stops as one, and inside the loop the penalty would be the constant 0: msq + 0 is msq, bit for bit.)
+      bool go = active && iters < maxit;
+      while (go) {
         const float rem = (float)(tend - t);
         const bool last = __any(dt >= rem * 0.99999988f);   // (every lane of this wave carries the same solve: a vote is the lane's own answer, as a scalar branch)
         const float h = last ? rem : dt;
@@ -921,7 +929,7 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
           for (int s = 1; s <= 4; s++) k[s] = f32x2{ka[s][0], ka[s][1]};
           yn = f32x2{yna[0], yna[1]};
         }
-        const float mq = fmaf(0.f, fabsf(yn.x) + fabsf(yn.y), msq + pen);   // ∞·0 = NaN: a non-finite state never passes
+        const float mq = fmaf(0.f, fabsf(yn.x) + fabsf(yn.y), msq);   // ∞·0 = NaN: a non-finite state never passes
         const bool ok = __any(mq <= 1.0f);
         float dtn = (float)o.dt_fixed, l = 0.f;
         if (ADAPT) {
@@ -929,7 +937,7 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
           const float q = fmaxf(o.q_lo, fminf(o.q_hi, __builtin_amdgcn_exp2f(o.beta1 * l - o.beta2 * lqold) * o.inv_gamma));
           dtn = fminf(h * fast_rcp(q), dtmax);
         }
-        if (__builtin_expect(!ok && __any(pen == 0.f), 0)) {   // rare: a rejected or non-finite attempt (scalar branches throughout: the
+        if (__builtin_expect(!ok, 0)) {                        // rare: a rejected or non-finite attempt (scalar branches throughout: the
                                                                // loop's variables are updated in place, no exec-masked copies at the loop edge)
           const bool fin = __any((fabsf(yn.x) + fabsf(yn.y)) < __builtin_inff());
           nrej++;
@@ -942,9 +950,10 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
             dt = h * fast_rcp(fminf(o.q_hi, __builtin_amdgcn_exp2f(o.beta1 * l) * o.inv_gamma));
             if (__any(dt < dtmin)) { ret = LDE_RET_DTMIN; active = false; }
           }
-          if (!active || iters >= maxit) pen = __builtin_inff();
+          if (!active || iters >= maxit) go = false;
+          continue;
         }
-        if (ok) {   // the accepted step: leave {h, yₙ₊₁} behind, publish, advance
+        {   // the accepted step: leave {h, yₙ₊₁} behind, publish, advance
           if (last) {   // once per solve: the last step's slopes travel too — its helper would otherwise start rebuilding them only now, a
                         // whole step's worth of instructions behind the end of the solve (measured: 1.3 µs of the launch)
             float* kl = s_klast + lane * 4;   // [quarter][lane][4]: every 16-byte write conflict-free
@@ -964,9 +973,9 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
           kf = k[FS];
           t += (double)h;   // (the last step ends the loop: its t is not read again)
           dt = dtn;
-          lqold = fmaxf(l, LQ_MIN);
+          lqold = max_f(l, LQ_MIN);
           active = !last;
-          if (last || n >= SH_CAP || iters >= maxit) pen = __builtin_inff();
+          if (last || n >= SH_CAP || iters >= maxit) go = false;
         }
       }
       if (active && iters >= maxit) { ret = LDE_RET_MAXITERS; active = false; }

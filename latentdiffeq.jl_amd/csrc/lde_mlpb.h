@@ -113,6 +113,11 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
   constexpr int SEG = 64 / DP, G1 = DP / 4, GS = (200 / SEG + 3) / 4;   // GS: host = bd.GS
   constexpr int NST = SOLVER == LDE_SOLVER_TSIT5 ? 6 : 4;                // weighted stages of a step = ring slots the fold reads
   constexpr int NSL = ADJ ? NST + 1 : 1;                                  // + one scratch slot (initial-step probes, the FSAL stage)
+  // SPEC (adjoint, Tsit5): an attempt never evaluates its first stage. f(yₙ₊₁) — the step's seventh evaluation — IS the next attempt's k₁
+  // when the step is accepted inside a save interval, k₁ of a rejected attempt is still valid, and behind a save time (where λ jumps) the
+  // first evaluation at the jumped state runs BEFORE the decision is known, while the grid-wide error sum is under way (coupled control):
+  // its vectors sit in the spare ring slot and move to slot 0 at accept. Same evaluations on the same inputs — the same bits, fewer of them.
+  constexpr bool SPEC = ADJ && SOLVER == LDE_SOLVER_TSIT5;
   constexpr int W13S = 2 * DP + 4;
   constexpr int NTR = ntr(DP);
   static_assert(DP == 8 || DP == 16, "k_mlpb geometry");
@@ -458,6 +463,35 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
     PROF_ADD(6, f0, f1);
   };
 
+  // this wave's sum of the attempt's scaled squared errors (every wave holds the whole state: the same number in all of them)
+  auto err_sum = [&]() -> float {
+    float r2 = 0.f;
+    if (o.adaptive && counted) {
+      float er = ts5::BT[0] * k[0];
+#pragma unroll
+      for (int jj = 1; jj < 7; jj++) er += ts5::BT[jj] * k[jj];
+      er *= h;
+      const float sk = o.abstol + fmaxf(fabsf(y), fabsf(yn)) * o.reltol;
+      const float r = er * fast_rcp(sk);
+      r2 = r * r;
+    }
+    if (!isfinite(yn)) r2 = __int_as_float(0x7fc00000);   // a non-finite state poisons the sum
+    return wave_sum64(r2);
+  };
+  // the adjoint's state behind save time j: λ += Δ_j, z reset to the saved ẑ(t_j) (checkpointing)
+  auto jumped = [&](float v) -> float {
+    if (counted) {
+      if (a.cot_lds) {
+        if (is_l) v += s_cot[j * Dp + row];
+        else if (o.checkpoint) v = s_cot[(T + j) * Dp + row];
+      } else {
+        const size_t srcg = (size_t)Dp * ((size_t)b + (size_t)B * j) + row;
+        if (is_l) v += a.dz_out[srcg];
+        else if (o.checkpoint) v = a.z_out[srcg];
+      }
+    }
+    return v;
+  };
   const bool auto_dt = o.adaptive && !(o.dt_fixed > 0);
   int phase = (ADJ && !auto_dt) ? PH_STAGE : PH_K0, s = 0;
   bool running = T > 1 && status == 0;
@@ -469,6 +503,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
     // inner loop: the evaluations of one unit of work (the two probes of the initial step size, or the stages of one step attempt) — the
     // weight-gradient tiles are touched only outside it, in the step-end block below
     bool step_end = false;
+    float s2 = 0.f, s2b = 0.f;
     do {
       // the step control is wave-uniform (every lane computes the same values): keep it in scalar registers across the evaluation
       s = __builtin_amdgcn_readfirstlane(s);
@@ -510,6 +545,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
           yn = y + h6 * (k[0] + 2.0f * (k[1] + k[2]) + k[3]);
           src = yn;
         }
+        if (SPEC && s == 7) src = tmp;   // the speculative first evaluation of the next attempt: the state behind the jump
       }
       const float dst = eval(src, ADJ ? ((phase == PH_STAGE && s < NST) ? s : NST) : 0);
       {
@@ -517,6 +553,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
   #pragma unroll
         for (int q = 0; q < 7; q++)
           if (q == ks) k[q] = dst;
+        if (SPEC && ks == 7) scr = dst;
       }
       if (status == 0) nfe++;
 
@@ -561,6 +598,16 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
         running = begin_step();
       } else if (s < LAST_STAGE) {
         s++;
+      } else if (SPEC && s == LAST_STAGE) {   // the attempt's slopes are complete: its error sum leaves for the grid, and — behind a save time —
+                                              // the next attempt's first evaluation runs while the other workgroups' sums arrive
+        s2 = err_sum();
+        if (coupled) {
+          if (status != 0) s2 = 0.f;
+          w_grid_publish<false>(a.gs, gen, a.epoch, s2, 0.f);
+        }
+        if (hit) tmp = jumped(yn);
+        if (hit && j > 0 && status == 0) s = 7;
+        else step_end = true;
       } else
         step_end = true;
     } while (!__builtin_amdgcn_readfirstlane((int)step_end));
@@ -569,21 +616,14 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
       const float h6 = h * (1.0f / 6.0f);
       yn = y + h6 * (k[0] + 2.0f * (k[1] + k[2]) + k[3]);
     }
-    float r2 = 0.f;
-    if (o.adaptive && counted) {
-      float er = ts5::BT[0] * k[0];
-#pragma unroll
-      for (int jj = 1; jj < 7; jj++) er += ts5::BT[jj] * k[jj];
-      er *= h;
-      const float sk = o.abstol + fmaxf(fabsf(y), fabsf(yn)) * o.reltol;
-      const float r = er * fast_rcp(sk);
-      r2 = r * r;
-    }
-    if (!isfinite(yn)) r2 = __int_as_float(0x7fc00000);   // a non-finite state poisons the sum
-    float s2 = wave_sum64(r2), s2b = 0.f;
-    if (coupled) {
-      if (status != 0) s2 = 0.f;
-      w_grid_sum<false>(a.gs, gen, a.epoch, s2, s2b);
+    if (SPEC) {
+      if (coupled) w_grid_collect<false>(a.gs, gen, a.epoch, s2, s2b);
+    } else {
+      s2 = err_sum();
+      if (coupled) {
+        if (status != 0) s2 = 0.f;
+        w_grid_sum<false>(a.gs, gen, a.epoch, s2, s2b);
+      }
     }
     bool accepted = false;
     if (status == 0) {
@@ -646,25 +686,25 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
     } else {
       if (__builtin_amdgcn_readfirstlane((int)accepted)) {   // (workgroup-uniform: every wave takes bitwise the same decisions — say so to the compiler: a scalar branch)
         fold();
-        y = yn;
+        if (SPEC) {
+          y = hit ? tmp : yn;
+          k[0] = hit ? scr : k[6];
+          // that evaluation's vectors (the spare ring slot: the seventh stage's, or the speculative one's) are the coming attempt's first stage's
+          const f32x4* s4 = reinterpret_cast<const f32x4*>(ring + NST * SLOT);
+          f32x4* d4 = reinterpret_cast<f32x4*>(ring);
+          for (int i = tid; i < SLOT / 4; i += UT) d4[i] = s4[i];
+        } else {
+          y = yn;
+          if (hit) y = jumped(y);
+        }
         if (hit) {
-          if (counted) {
-            if (a.cot_lds) {
-              if (is_l) y += s_cot[j * Dp + row];
-              else if (o.checkpoint) y = s_cot[(T + j) * Dp + row];
-            } else {
-              const size_t srcg = (size_t)Dp * ((size_t)b + (size_t)B * j) + row;
-              if (is_l) y += a.dz_out[srcg];
-              else if (o.checkpoint) y = a.z_out[srcg];
-            }
-          }
           t = s_ts[j];
           j--;
           if (j < 0) status = 1;
         } else
           t -= tnew;
       }
-      s = 0;
+      s = SPEC ? 1 : 0;   // (SPEC: k₁ and its ring slot are in place — accepted: from above; rejected: the attempt's own)
       running = begin_step();
     }
   }

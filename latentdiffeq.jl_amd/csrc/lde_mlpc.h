@@ -78,6 +78,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NST = SOLVER == LDE_SOLVER_TSIT5 ? 6 : 4;                // weighted stages of a step = ring slots the fold reads
   constexpr int NSL = ADJ ? NST + 1 : 1;                                  // + one scratch slot (initial-step probes, the FSAL stage)
+  constexpr bool SPEC = ADJ && SOLVER == LDE_SOLVER_TSIT5;                // an attempt never evaluates its first stage (k_mlpb: see there)
   constexpr int act = ACT;
   const int T = o.T, B = o.B, D = dm.D, Dp = dm.Dp, tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -418,6 +419,40 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
     PROF_ADD(6, f0, f1);
   };
 
+  // this wave's sum of the attempt's scaled squared errors over both trajectories (every wave holds the whole state)
+  auto err_sum = [&]() -> float {
+    float r2 = 0.f;
+#pragma unroll
+    for (int tt = 0; tt < 2; tt++) {
+      if (o.adaptive && counted && (tt == 0 || two)) {
+        float er = ts5::BT[0] * k[0][tt];
+#pragma unroll
+        for (int jj = 1; jj < 7; jj++) er += ts5::BT[jj] * k[jj][tt];
+        er *= h;
+        const float sk = o.abstol + fmaxf(fabsf(y[tt]), fabsf(yn[tt])) * o.reltol;
+        const float r = er * fast_rcp(sk);
+        r2 += r * r;
+      }
+      if (!isfinite(yn[tt])) r2 = __int_as_float(0x7fc00000);   // a non-finite state poisons the sum
+    }
+    return wave_sum64(r2);
+  };
+  // the adjoint's state behind save time j: λ += Δ_j, z reset to the saved ẑ(t_j) (checkpointing)
+  auto jumped = [&](float (&v)[2]) {
+    if (counted) {
+#pragma unroll
+      for (int tt = 0; tt < 2; tt++) {
+        if (a.cot_lds) {
+          if (is_l) v[tt] += s_cot[(tt * T + j) * Dp + row];
+          else if (o.checkpoint) v[tt] = s_cot[((2 + tt) * T + j) * Dp + row];
+        } else if (bt0 + tt < B) {
+          const size_t srcg = (size_t)Dp * ((size_t)(bt0 + tt) + (size_t)B * j) + row;
+          if (is_l) v[tt] += a.dz_out[srcg];
+          else if (o.checkpoint) v[tt] = a.z_out[srcg];
+        }
+      }
+    }
+  };
   const bool auto_dt = o.adaptive && !(o.dt_fixed > 0);
   int phase = (ADJ && !auto_dt) ? PH_STAGE : PH_K0, s = 0;
   bool running = T > 1 && status == 0;
@@ -429,6 +464,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
     // inner loop: the evaluations of one unit of work (the two probes of the initial step size, or the stages of one step attempt) — the
     // weight-gradient tiles are touched only outside it, in the step-end block below
     bool step_end = false;
+    float s2 = 0.f, s2b = 0.f;
     do {
       // the step control is wave-uniform (every lane computes the same values): keep it in scalar registers across the evaluation
       s = __builtin_amdgcn_readfirstlane(s);
@@ -473,6 +509,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
             yn[tt] = y[tt] + h6 * (k[0][tt] + 2.0f * (k[1][tt] + k[2][tt]) + k[3][tt]);
             sv = yn[tt];
           }
+          if (SPEC && s == 7) sv = tmp[tt];   // the speculative first evaluation of the next attempt: the state behind the jump
         }
         src[tt] = sv;
       }
@@ -483,6 +520,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
 #pragma unroll
         for (int q = 0; q < 7; q++)
           if (q == ks) { k[q][0] = dst[0]; k[q][1] = dst[1]; }
+        if (SPEC && ks == 7) { scr[0] = dst[0]; scr[1] = dst[1]; }
       }
       if (status == 0) nfe++;
 
@@ -538,6 +576,20 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
         running = begin_step();
       } else if (s < LAST_STAGE) {
         s++;
+      } else if (SPEC && s == LAST_STAGE) {   // the attempt's slopes are complete: its error sum leaves for the grid, and — behind a save time —
+                                              // the next attempt's first evaluation runs while the other workgroups' sums arrive
+        s2 = err_sum();
+        if (coupled) {
+          if (status != 0) s2 = 0.f;
+          w_grid_publish<false>(a.gs, gen, a.epoch, s2, 0.f);
+        }
+        if (hit) {
+          tmp[0] = yn[0];
+          tmp[1] = yn[1];
+          jumped(tmp);
+        }
+        if (hit && j > 0 && status == 0) s = 7;
+        else step_end = true;
       } else
         step_end = true;
     } while (!__builtin_amdgcn_readfirstlane((int)step_end));
@@ -547,24 +599,14 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
 #pragma unroll
       for (int tt = 0; tt < 2; tt++) yn[tt] = y[tt] + h6 * (k[0][tt] + 2.0f * (k[1][tt] + k[2][tt]) + k[3][tt]);
     }
-    float r2 = 0.f;
-#pragma unroll
-    for (int tt = 0; tt < 2; tt++) {
-      if (o.adaptive && counted && (tt == 0 || two)) {
-        float er = ts5::BT[0] * k[0][tt];
-#pragma unroll
-        for (int jj = 1; jj < 7; jj++) er += ts5::BT[jj] * k[jj][tt];
-        er *= h;
-        const float sk = o.abstol + fmaxf(fabsf(y[tt]), fabsf(yn[tt])) * o.reltol;
-        const float r = er * fast_rcp(sk);
-        r2 += r * r;
+    if (SPEC) {
+      if (coupled) w_grid_collect<false>(a.gs, gen, a.epoch, s2, s2b);
+    } else {
+      s2 = err_sum();
+      if (coupled) {
+        if (status != 0) s2 = 0.f;
+        w_grid_sum<false>(a.gs, gen, a.epoch, s2, s2b);
       }
-      if (!isfinite(yn[tt])) r2 = __int_as_float(0x7fc00000);   // a non-finite state poisons the sum
-    }
-    float s2 = wave_sum64(r2), s2b = 0.f;
-    if (coupled) {
-      if (status != 0) s2 = 0.f;
-      w_grid_sum<false>(a.gs, gen, a.epoch, s2, s2b);
     }
     bool accepted = false;
     if (status == 0) {
@@ -637,29 +679,29 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
     } else {
       if (__builtin_amdgcn_readfirstlane((int)accepted)) {   // (workgroup-uniform: every wave takes bitwise the same decisions — a scalar branch)
         fold();
-        y[0] = yn[0];
-        y[1] = yn[1];
-        if (hit) {
-          if (counted) {
+        if (SPEC) {
 #pragma unroll
-            for (int tt = 0; tt < 2; tt++) {
-              if (a.cot_lds) {
-                if (is_l) y[tt] += s_cot[(tt * T + j) * Dp + row];
-                else if (o.checkpoint) y[tt] = s_cot[((2 + tt) * T + j) * Dp + row];
-              } else if (bt0 + tt < B) {
-                const size_t srcg = (size_t)Dp * ((size_t)(bt0 + tt) + (size_t)B * j) + row;
-                if (is_l) y[tt] += a.dz_out[srcg];
-                else if (o.checkpoint) y[tt] = a.z_out[srcg];
-              }
-            }
+          for (int tt = 0; tt < 2; tt++) {
+            y[tt] = hit ? tmp[tt] : yn[tt];
+            k[0][tt] = hit ? scr[tt] : k[6][tt];
           }
+          // that evaluation's vectors (the spare ring slot: the seventh stage's, or the speculative one's) are the coming attempt's first stage's
+          const f32x4* s4 = reinterpret_cast<const f32x4*>(ring + NST * SLOT);
+          f32x4* d4 = reinterpret_cast<f32x4*>(ring);
+          for (int i = tid; i < SLOT / 4; i += UT) d4[i] = s4[i];
+        } else {
+          y[0] = yn[0];
+          y[1] = yn[1];
+          if (hit) jumped(y);
+        }
+        if (hit) {
           t = s_ts[j];
           j--;
           if (j < 0) status = 1;
         } else
           t -= tnew;
       }
-      s = 0;
+      s = SPEC ? 1 : 0;   // (SPEC: k₁ and its ring slot are in place — accepted: from above; rejected: the attempt's own)
       running = begin_step();
     }
   }

@@ -126,10 +126,24 @@ __device__ __forceinline__ void w_host_sum(const GridSync& gs, unsigned tag, flo
   if (TWO) v1 = aborted ? __int_as_float(0x7fc00000) : __uint_as_float((unsigned)q1);
 }
 
+// The two halves of a sum, for a caller with work to do between them (k_mlpb / k_mlpc: the next attempt's first evaluation runs while
+// the other workgroups' words arrive): publish this workgroup's words — collect all of them. w_grid_sum = one behind the other.
 template <bool TWO>
-__device__ __forceinline__ void w_grid_sum(const GridSync& gs, unsigned& gen, unsigned epoch, float& v0, float& v1) {
+__device__ __forceinline__ void w_grid_publish(const GridSync& gs, unsigned& gen, unsigned epoch, float v0, float v1) {
   if (gs.nwg == 1 && !gs.host_req) return;
   gen++;
+  if (gs.nwg == 1) return;
+  const unsigned tag = (epoch << 16) + gen;
+  unsigned long long* slots = reinterpret_cast<unsigned long long*>(gs.slots) + (size_t)(gen & 1) * gs.nwg * 2;
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(slots + (size_t)blockIdx.x * 2, ((unsigned long long)tag << 32) | __float_as_uint(v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (TWO)
+      __hip_atomic_store(slots + (size_t)blockIdx.x * 2 + 1, ((unsigned long long)tag << 32) | __float_as_uint(v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+template <bool TWO>
+__device__ __forceinline__ void w_grid_collect(const GridSync& gs, unsigned gen, unsigned epoch, float& v0, float& v1) {   // `gen` as w_grid_publish left it
+  if (gs.nwg == 1 && !gs.host_req) return;
   PROF_T(g0);
   const unsigned tag = (epoch << 16) + gen;
   if (gs.nwg == 1) {
@@ -137,11 +151,6 @@ __device__ __forceinline__ void w_grid_sum(const GridSync& gs, unsigned& gen, un
     return;
   }
   unsigned long long* slots = reinterpret_cast<unsigned long long*>(gs.slots) + (size_t)(gen & 1) * gs.nwg * 2;
-  if (threadIdx.x == 0) {
-    __hip_atomic_store(slots + (size_t)blockIdx.x * 2, ((unsigned long long)tag << 32) | __float_as_uint(v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (TWO)
-      __hip_atomic_store(slots + (size_t)blockIdx.x * 2 + 1, ((unsigned long long)tag << 32) | __float_as_uint(v1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
   float p0 = 0.f, p1 = 0.f;
   bool aborted = false;
   for (int w = threadIdx.x & 63; w < gs.nwg; w += 64) {
@@ -170,6 +179,11 @@ __device__ __forceinline__ void w_grid_sum(const GridSync& gs, unsigned& gen, un
   PROF_T(g1);
   PROF_ADD(12, g0, g1);
   PROF_ADD(21, g1 - 1, g1);
+}
+template <bool TWO>
+__device__ __forceinline__ void w_grid_sum(const GridSync& gs, unsigned& gen, unsigned epoch, float& v0, float& v1) {
+  w_grid_publish<TWO>(gs, gen, epoch, v0, v1);
+  w_grid_collect<TWO>(gs, gen, epoch, v0, v1);
 }
 
 template <int SOLVER, int DP, int HP, int W, bool ADJ>

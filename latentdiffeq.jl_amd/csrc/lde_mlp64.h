@@ -277,6 +277,12 @@ __device__ __forceinline__ void mlp64_body(const MlpDims& dm, const KOpts& o, co
 
   // one evaluation of the (augmented) right-hand side at `src`; `slot`: the ring slot its h₁ / δ₂ vectors go through; `bs` ≠ 0: the
   // evaluation is a weighted stage of the attempt — its thin-layer gradient terms are added to the attempt's sums
+  // FSAL in the reverse solve (Tsit5): inside a save interval f(yₙ₊₁) — the accepted step's seventh evaluation — is the next attempt's k₁:
+  // its slope moves to k[0], its (h₁, δ₂) from ring slot 6 to slot 0, and its thin-layer terms (δ₁, h₂, δ₂ of the lane; z and λ are the
+  // state itself) open the next attempt's sums with the weight b₁ — the values a re-evaluation would produce. (Behind a save time the
+  // state jumps, and a rejected attempt re-evaluates as before: its pending sums are dropped with it.)
+  bool fsal = false;
+  float last_d1 = 0.f, last_h2 = 0.f, last_d2 = 0.f, f_d1 = 0.f, f_h2 = 0.f, f_d2 = 0.f;
   auto eval = [&](const float (&src)[NS], float (&dst)[NS], int slot, float bs) {
     float z[DP], f[DP];
     n.hx = s_hx + slot * 128;
@@ -293,6 +299,9 @@ __device__ __forceinline__ void mlp64_body(const MlpDims& dm, const KOpts& o, co
 #pragma unroll
       for (int r = 0; r < DP; r++) dst[DP + r] = -vz[r];
       dst[ADJ ? 2 * DP : 0] = -vth;
+      last_d1 = d1;
+      last_h2 = n.h2;
+      last_d2 = d2;
       if (bs != 0.f) {   // (a₀, δ₁) = (z, δ₁), (a₂, δ₃) = (h₂, λ) and the three bias terms; (a₁, δ₂) = (h₁, δ₂) waits in the ring
         const float bd1 = bs * d1, bh2 = bs * n.h2;
 #pragma unroll
@@ -323,6 +332,18 @@ __device__ __forceinline__ void mlp64_body(const MlpDims& dm, const KOpts& o, co
     if (phase == PH_STAGE) {
 #pragma unroll
       for (int s = ADJ ? 0 : 1; s <= LAST_STAGE; s++) {
+        if (ADJ && SOLVER == LDE_SOLVER_TSIT5 && s == 0 && fsal) {   // k₁ = the previous step's f(yₙ₊₁): nothing to evaluate
+          const float bs0 = bq(0), bd1 = bs0 * f_d1, bh2 = bs0 * f_h2;
+#pragma unroll
+          for (int r = 0; r < DP; r++) {
+            g.pw1[r] = bd1 * y[r];
+            g.pw3[r] = bh2 * y[DP + r];
+            g.pb3[r] = bs0 * y[DP + r];
+          }
+          g.pb1 = bd1;
+          g.pb2 = bs0 * f_d2;
+          continue;
+        }
         float src[NS];
         bool any_w = false;
 #pragma unroll
@@ -512,6 +533,17 @@ __device__ __forceinline__ void mlp64_body(const MlpDims& dm, const KOpts& o, co
             if (j < 0) status = 1;
           } else
             t -= tnew;
+        }
+        fsal = false;
+        if (SOLVER == LDE_SOLVER_TSIT5 && accepted && !hit && status == 0) {
+          fsal = true;
+#pragma unroll
+          for (int i = 0; i < NS; i++) k[0][i] = k[6][i];
+          s_hx[lane] = s_hx[6 * 128 + lane];             // (this wave's ring: LDS operations of one wave execute in order)
+          s_hx[64 + lane] = s_hx[6 * 128 + 64 + lane];
+          f_d1 = last_d1;
+          f_h2 = last_h2;
+          f_d2 = last_d2;
         }
         s = 0;
         running = begin_step();

@@ -885,7 +885,6 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
     float lqold = LQ_MIN;
     const int maxit = o.maxiters > 0x7fffffffLL ? 0x7fffffff : (int)o.maxiters;
     const float dtmin = (float)o.dtmin;
-    int iters = 0;
 #pragma unroll
     for (int s = 0; s < 7; s++) k[s] = f32x2{0.f, 0.f};
     if (valid && lane == 0) z_out[b] = zi;  // ts[0] is saved as ẑ₀ itself
@@ -910,7 +909,10 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
       float* rp = rec_at(0);
       // `go` (scalar): this round goes on. (k_pend_forward_tl carries it as a float penalty added to the error norm, because its lanes stop
       // one by one; here the wave stops as one, and inside the loop the penalty would be the constant 0: msq + 0 is msq, bit for bit.)
-      bool go = active && iters < maxit;
+      // (attempts so far = nacc + nrej; `lim` = accepted steps this round may still record: the ring's capacity or what maxiters leaves,
+      //  one less per rejected attempt — so an accepted step costs one scalar add and one compare)
+      int lim = min(SH_CAP, maxit - (nacc + nrej));
+      bool go = active && lim > 0;
       while (go) {
         const float rem = (float)(tend - t);
         const bool last = __any(dt >= rem * 0.99999988f);   // (every lane of this wave carries the same solve: a vote is the lane's own answer, as a scalar branch)
@@ -941,7 +943,7 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
                                                                // loop's variables are updated in place, no exec-masked copies at the loop edge)
           const bool fin = __any((fabsf(yn.x) + fabsf(yn.y)) < __builtin_inff());
           nrej++;
-          iters++;
+          lim--;
           if (!ADAPT) { ret = LDE_RET_NONFINITE; active = false; nrej--; }
           else if (!fin) {
             if (__any(h > dtmin)) dt = h * o.qmin;
@@ -950,7 +952,7 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
             dt = h * fast_rcp(fminf(o.q_hi, __builtin_amdgcn_exp2f(o.beta1 * l) * o.inv_gamma));
             if (__any(dt < dtmin)) { ret = LDE_RET_DTMIN; active = false; }
           }
-          if (!active || iters >= maxit) go = false;
+          if (!active || n >= lim) go = false;
           continue;
         }
         {   // the accepted step: leave {h, yₙ₊₁} behind, publish, advance
@@ -962,23 +964,23 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
             *reinterpret_cast<f32x4*>(kl + 512) = f32x4{k[4].x, k[4].y, k[5].x, k[5].y};
             *reinterpret_cast<f32x4*>(kl + 768) = f32x4{k[6].x, k[6].y, 0.f, 0.f};
           }
-          *reinterpret_cast<f32x4*>(rp) = f32x4{h, yn.x, yn.y, 0.f};
+          *reinterpret_cast<f32x2*>(rp) = yn;   // record = {yₙ₊₁ (the pair as it sits in its registers: one 8-byte write), h}
+          rp[2] = h;
           rp += 64 * 4;
           n++;
           asm volatile("" ::: "memory");                                      // the count is published AFTER the record
           __hip_atomic_store(&s_cnt[lane], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (a plain LDS store: ds_write_b32)
-          nacc++;
-          iters++;
           y = yn;
           kf = k[FS];
           t += (double)h;   // (the last step ends the loop: its t is not read again)
           dt = dtn;
           lqold = max_f(l, LQ_MIN);
           active = !last;
-          if (last || n >= SH_CAP || iters >= maxit) go = false;
+          if (last || n >= lim) go = false;
         }
       }
-      if (active && iters >= maxit) { ret = LDE_RET_MAXITERS; active = false; }
+      nacc += n;
+      if (active && nacc + nrej >= maxit) { ret = LDE_RET_MAXITERS; active = false; }
       if (ret != LDE_RET_SUCCESS && lane == 0) __hip_atomic_store(&s_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       asm volatile("" ::: "memory");
       if (lane == 0) __hip_atomic_store(&s_fin, active ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -1024,8 +1026,8 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
       asm volatile("" ::: "memory");
       while (n2 < cnt) {
         const f32x4 q = *reinterpret_cast<const f32x4*>(rec_at(n2));
-        const float h = q[0];
-        const f32x2 ye = {q[1], q[2]};
+        const float h = q[2];
+        const f32x2 ye = {q[0], q[1]};
         const double t1 = (h == (float)(tend - tn)) ? tend : tn + (double)h;   // exactly the stepper's arithmetic
         const bool mine = (nrec % SH_NH) == hid;
         if (__any(tj <= t1)) {

@@ -42,7 +42,11 @@ constexpr int NT = 13;                // 16-wide tiles along a hidden index (uni
 constexpr int XS = 32;                // floats of the [z | λ] part of a ring slot
 constexpr int SLOT = XS + 4 * HV;     // ring slot: xs | h₁ | g₂ → δ₂ | h₂ | δ₁
 constexpr int NTL = 51;               // weight-gradient tile slots of a wave: 39 + 4 of gW₂ᵀ, 4 of gW₁, 4 of gW₃ᵀ
-constexpr int ntr(int dp) { return dp == 16 ? 40 : 36; }   // … of which this many are accumulator registers (the rest: LDS, 1 KB per slot and wave)
+// … of which this many are accumulator registers (the rest: LDS, 1 KB per slot and wave). `low` (RK4's adjoint when the LDS has room for eight
+// more tiles — its ring is two slots shorter): the compiler keeps 36 tiles only by spilling 11 of them around the evaluation loop
+// (260 bytes of scratch per lane: a global round trip per step); with 28 it spills 15 words — c2: 0.975 -> 0.913 ms (24: no scratch, but
+// 12 KB more LDS than the CU has; 30 / 32: 0.918 / 0.930).
+constexpr int ntr(int dp, int nst, bool low) { return (nst == 4 && low) ? 28 : (dp == 16 ? 40 : 36); }
 }  // namespace mlpb
 
 // one-time packing (set_weights): everything in the order the kernel's lanes read it
@@ -106,7 +110,7 @@ __device__ __forceinline__ long long sgpr_ll(long long v) {
 }
 __device__ __forceinline__ double sgpr_d(double v) { return __builtin_bit_cast(double, sgpr_ll(__builtin_bit_cast(long long, v))); }
 
-template <int SOLVER, int DP, int ACT, bool ADJ>
+template <int SOLVER, int DP, int ACT, bool ADJ, bool LOW = false>
 __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, VArgs a) {
   using namespace mlpb;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -119,7 +123,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
   // its vectors sit in the spare ring slot and move to slot 0 at accept. Same evaluations on the same inputs — the same bits, fewer of them.
   constexpr bool SPEC = ADJ && SOLVER == LDE_SOLVER_TSIT5;
   constexpr int W13S = 2 * DP + 4;
-  constexpr int NTR = ntr(DP);
+  constexpr int NTR = ntr(DP, SOLVER == LDE_SOLVER_TSIT5 ? 6 : 4, LOW);
   static_assert(DP == 8 || DP == 16, "k_mlpb geometry");
   const int T = o.T, B = o.B, D = dm.D, Dp = dm.Dp, tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);

@@ -278,11 +278,29 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
   auto narrow = [&](const f32x4* ns, const float* vec) -> float {
     const f32x4* hv = reinterpret_cast<const f32x4*>(vec) + (lane / DP) * GS;
     f32x2 p01 = {0.f, 0.f}, p23 = {0.f, 0.f};
+    if (DP <= 8) {
+      // every read issued before the first product waits for one: left to itself under this kernel's register pressure the compiler reuses
+      // ONE pair of buffers — read, wait, multiply: GS dependent LDS round trips (c2: 0.918 -> 0.901 ms). Not at D′ = 16: twice the
+      // reads, and the 112 registers they need at once are spilled (latentode_ref: 3.43 -> 3.51 ms with it).
+      f32x4 wq4[GS], xv[GS];
 #pragma unroll
-    for (int g = 0; g < GS; g++) {
-      const f32x4 wq4 = ns[g * 64 + lane], xv = hv[g];
-      p01 += wq4.lo * xv.lo;
-      p23 += wq4.hi * xv.hi;
+      for (int g = 0; g < GS; g++) {
+        wq4[g] = ns[g * 64 + lane];
+        xv[g] = hv[g];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < GS; g++) {
+        p01 += wq4[g].lo * xv[g].lo;
+        p23 += wq4[g].hi * xv[g].hi;
+      }
+    } else {
+#pragma unroll
+      for (int g = 0; g < GS; g++) {
+        const f32x4 wq4 = ns[g * 64 + lane], xv = hv[g];
+        p01 += wq4.lo * xv.lo;
+        p23 += wq4.hi * xv.hi;
+      }
     }
     return xor_segs((p01.x + p01.y) + (p23.x + p23.y));
   };

@@ -115,27 +115,39 @@ __host__ __device__ inline size_t bf_frag_off(const MlpDims& dm, int l, bool T) 
   for (int m = 0; m < l; m++) o += bf_frag_elems(dm, m, T);
   return o;
 }
+// One WAVE per fragment (launches use 256 threads per block): the fragment's tile coordinates are wave-uniform — one scalar division per
+// 512 (256) elements instead of two vector divisions per element, which was what these launches spent their time on (k_refresh_many:
+// 15 µs per training step) — and a lane writes its 16 bytes of the fragment with one store.
 __device__ inline void build_frags_layer_bf(const float* __restrict__ Wflat, const MlpDims& dm, __bf16* __restrict__ fragb,
                                             __bf16* __restrict__ fragTb, int l, int bx, int nbx) {
+  typedef __bf16 bfx8 __attribute__((ext_vector_type(8)));
   const int in = dm.sizes[l], out = dm.sizes[l + 1];
-  const int stride = nbx * blockDim.x, first = bx * blockDim.x + threadIdx.x;
+  const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(bx * wpb + (int)(threadIdx.x >> 6)), nw = nbx * wpb;
+  const int r16 = lane & 15, k8 = 8 * (lane >> 4);
   const float* W = Wflat + dm.w_off[l];  // column-major [out×in]: W(o,i) at o + out*i
   {
-    const int KG = (in + 31) / 32, n = (int)bf_frag_elems(dm, l, false);
+    const int KG = (in + 31) / 32, nf = (int)(bf_frag_elems(dm, l, false) >> 9);
     __bf16* dst = fragb + bf_frag_off(dm, l, false);
-    for (int e = first; e < n; e += stride) {
-      const int j = e & 7, lane = (e >> 3) & 63, f = e >> 9, rt = f / KG, kg = f % KG;
-      const int o = rt * 16 + (lane & 15), i = kg * 32 + 8 * (lane >> 4) + j;
-      dst[e] = (__bf16)((o < out && i < in) ? W[o + (size_t)out * i] : 0.f);
+    for (int f = wave; f < nf; f += nw) {
+      const int rt = f / KG, kg = f - rt * KG;
+      const int o = rt * 16 + r16, i0 = kg * 32 + k8;
+      bfx8 v;
+#pragma unroll
+      for (int j = 0; j < 8; j++) v[j] = (__bf16)((o < out && i0 + j < in) ? W[o + (size_t)out * (i0 + j)] : 0.f);
+      *reinterpret_cast<bfx8*>(dst + ((size_t)f << 9) + 8 * lane) = v;
     }
   }
   {
-    const int KG = (out + 31) / 32, n = (int)bf_frag_elems(dm, l, true);   // Wᵀ[in×out]
+    const int KG = (out + 31) / 32, nf = (int)(bf_frag_elems(dm, l, true) >> 9);   // Wᵀ[in×out]
     __bf16* dst = fragTb + bf_frag_off(dm, l, true);
-    for (int e = first; e < n; e += stride) {
-      const int j = e & 7, lane = (e >> 3) & 63, f = e >> 9, rt = f / KG, kg = f % KG;
-      const int i = rt * 16 + (lane & 15), o = kg * 32 + 8 * (lane >> 4) + j;
-      dst[e] = (__bf16)((o < out && i < in) ? W[o + (size_t)out * i] : 0.f);
+    for (int f = wave; f < nf; f += nw) {
+      const int rt = f / KG, kg = f - rt * KG;
+      const int i = rt * 16 + r16, o0 = kg * 32 + k8;
+      bfx8 v;
+#pragma unroll
+      for (int j = 0; j < 8; j++) v[j] = (__bf16)((o0 + j < out && i < in) ? W[o0 + j + (size_t)out * i] : 0.f);
+      *reinterpret_cast<bfx8*>(dst + ((size_t)f << 9) + 8 * lane) = v;
     }
   }
 }
@@ -150,20 +162,31 @@ __device__ inline void build_frags_layer(const float* __restrict__ Wflat, const 
   }
   const float* W = Wflat + dm.w_off[l];  // column-major [out×in]: W(o,i) at o + out*i
   if (!frag) return;                     // (lde_refresh_weights for a chain in bf16 mode: its f32 fragments are not read)
+  const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(bx * wpb + (int)(threadIdx.x >> 6)), nw = nbx * wpb;
+  const int r16 = lane & 15, k4 = 4 * (lane >> 4);
   {
-    const int KG = cdiv(in, 16), n = dm.frag_n[l];
-    for (int e = first; e < n; e += stride) {
-      const int s4 = e & 3, lane = (e >> 2) & 63, f = e >> 8, rt = f / KG, kg = f % KG;
-      const int o = rt * 16 + (lane & 15), i = kg * 16 + 4 * (lane >> 4) + s4;
-      frag[dm.frag_off[l] + e] = (o < out && i < in) ? W[o + (size_t)out * i] : 0.f;
+    const int KG = cdiv(in, 16), nf = dm.frag_n[l] >> 8;
+    float* dst = frag + dm.frag_off[l];
+    for (int f = wave; f < nf; f += nw) {
+      const int rt = f / KG, kg = f - rt * KG;
+      const int o = rt * 16 + r16, i0 = kg * 16 + k4;
+      f32x4 v;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4++) v[s4] = (o < out && i0 + s4 < in) ? W[o + (size_t)out * (i0 + s4)] : 0.f;
+      *reinterpret_cast<f32x4*>(dst + ((size_t)f << 8) + 4 * lane) = v;
     }
   }
   {
-    const int KG = cdiv(out, 16), n = dm.fragT_n[l];  // Wᵀ[in×out]
-    for (int e = first; e < n; e += stride) {
-      const int s4 = e & 3, lane = (e >> 2) & 63, f = e >> 8, rt = f / KG, kg = f % KG;
-      const int i = rt * 16 + (lane & 15), o = kg * 16 + 4 * (lane >> 4) + s4;
-      fragT[dm.fragT_off[l] + e] = (o < out && i < in) ? W[o + (size_t)out * i] : 0.f;
+    const int KG = cdiv(out, 16), nf = dm.fragT_n[l] >> 8;  // Wᵀ[in×out]
+    float* dst = fragT + dm.fragT_off[l];
+    for (int f = wave; f < nf; f += nw) {
+      const int rt = f / KG, kg = f - rt * KG;
+      const int i = rt * 16 + r16, o0 = kg * 16 + k4;
+      f32x4 v;
+#pragma unroll
+      for (int s4 = 0; s4 < 4; s4++) v[s4] = (o0 + s4 < out && i < in) ? W[o0 + s4 + (size_t)out * i] : 0.f;
+      *reinterpret_cast<f32x4*>(dst + ((size_t)f << 8) + 4 * lane) = v;
     }
   }
 }

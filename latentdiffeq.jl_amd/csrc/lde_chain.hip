@@ -920,14 +920,24 @@ int lde_refresh_weights(int n, const int* kinds, void* const* handles, const flo
     if (kinds[m] == LDE_MODULE_CHAIN) {
       lde_chain* c = (lde_chain*)handles[m];
       if (!c->W_dev || !c->dm_dev) return LDE_ERR_INVALID_ARG;
-      for (int l = 0; l < c->cd.dm.nL; l++)
-        jobs.push_back(RefreshJob{flat_dev[m], flat_dev[m] == c->W_dev ? nullptr : c->W_dev, c->bf16 ? nullptr : c->frag, c->bf16 ? nullptr : c->fragT,
-                                  c->dm_dev, l, 0, c->fragb, c->fragTb});   // (a bf16 chain reads bf16 fragments only: half the hand-over's work)
+      for (int l = 0; l < c->cd.dm.nL; l++) {
+        RefreshJob q;
+        std::memset(&q, 0, sizeof(q));   // (the table is compared byte-wise with the previous call's: padding too)
+        q.src = flat_dev[m]; q.keep = flat_dev[m] == c->W_dev ? nullptr : c->W_dev;
+        q.frag = c->bf16 ? nullptr : c->frag; q.fragT = c->bf16 ? nullptr : c->fragT;   // (a bf16 chain reads bf16 fragments only: half the hand-over's work)
+        q.g = frag_geom(c->cd.dm, l); q.layer = l; q.n = 0; q.fragb = c->fragb; q.fragTb = c->fragTb;
+        jobs.push_back(q);
+      }
     } else if (kinds[m] == LDE_MODULE_RNN) {
       float* dst = nullptr;
       int64_t nw = 0;
       if (!rnn_refresh_target((lde_rnn*)handles[m], &dst, &nw)) return LDE_ERR_INVALID_ARG;
-      if (dst != flat_dev[m]) jobs.push_back(RefreshJob{flat_dev[m], dst, nullptr, nullptr, nullptr, -1, (int)nw, nullptr, nullptr});
+      if (dst != flat_dev[m]) {
+        RefreshJob q;
+        std::memset(&q, 0, sizeof(q));
+        q.src = flat_dev[m]; q.keep = dst; q.layer = -1; q.n = (int)nw;
+        jobs.push_back(q);
+      }
     } else
       return LDE_ERR_INVALID_ARG;
   }

@@ -115,20 +115,52 @@ __host__ __device__ inline size_t bf_frag_off(const MlpDims& dm, int l, bool T) 
   for (int m = 0; m < l; m++) o += bf_frag_elems(dm, m, T);
   return o;
 }
+// what the re-layout of ONE layer needs, as plain numbers: k_refresh_many reads them from its job table in one load (through a device
+// copy of MlpDims every workgroup walked a chain of dependent scalar loads before its first useful instruction)
+struct FragGeom {                       // (no padding bytes: lde_refresh_weights compares its job table byte-wise with the previous call's)
+  long long bf_off, bfT_off;
+  int in, out, w_off, lo, hi;           // the layer's W at Wflat + w_off; its slice [lo, hi) of the flat vector (weights and, behind them, biases)
+  int frag_off, frag_nf, fragT_off, fragT_nf;   // f32 fragments (256 floats each)
+  int bf_nf, bfT_nf;                    // bf16 fragments (512 elements each)
+  int pad_;
+};
+static_assert(sizeof(FragGeom) == 2 * 8 + 12 * 4, "FragGeom must not contain padding");
+__host__ __device__ inline FragGeom frag_geom(const MlpDims& dm, int l) {
+  FragGeom g;
+  g.pad_ = 0;
+  g.in = dm.sizes[l]; g.out = dm.sizes[l + 1]; g.w_off = dm.w_off[l];
+  g.lo = dm.w_off[l]; g.hi = l + 1 < dm.nL ? dm.w_off[l + 1] : dm.nW;
+  g.frag_off = dm.frag_off[l]; g.frag_nf = dm.frag_n[l] >> 8; g.fragT_off = dm.fragT_off[l]; g.fragT_nf = dm.fragT_n[l] >> 8;
+  g.bf_nf = (int)(bf_frag_elems(dm, l, false) >> 9); g.bfT_nf = (int)(bf_frag_elems(dm, l, true) >> 9);
+  g.bf_off = (long long)bf_frag_off(dm, l, false); g.bfT_off = (long long)bf_frag_off(dm, l, true);
+  return g;
+}
+
+// dst[e] = src[e] for e = first, first + stride, … < hi — four loads in flight per thread (as a plain loop every iteration is a dependent
+// global round trip: ten of them per thread for the encoder's 784 × 200 layer)
+__device__ inline void copy_strided(float* __restrict__ dst, const float* __restrict__ src, int first, int hi, int stride) {
+  int e = first;
+  for (; e + 3 * stride < hi; e += 4 * stride) {
+    const float v0 = src[e], v1 = src[e + stride], v2 = src[e + 2 * stride], v3 = src[e + 3 * stride];
+    dst[e] = v0; dst[e + stride] = v1; dst[e + 2 * stride] = v2; dst[e + 3 * stride] = v3;
+  }
+  for (; e < hi; e += stride) dst[e] = src[e];
+}
+
 // One WAVE per fragment (launches use 256 threads per block): the fragment's tile coordinates are wave-uniform — one scalar division per
 // 512 (256) elements instead of two vector divisions per element, which was what these launches spent their time on (k_refresh_many:
 // 15 µs per training step) — and a lane writes its 16 bytes of the fragment with one store.
-__device__ inline void build_frags_layer_bf(const float* __restrict__ Wflat, const MlpDims& dm, __bf16* __restrict__ fragb,
-                                            __bf16* __restrict__ fragTb, int l, int bx, int nbx) {
+__device__ inline void build_frags_layer_bf(const float* __restrict__ Wflat, const FragGeom& g, __bf16* __restrict__ fragb,
+                                            __bf16* __restrict__ fragTb, int bx, int nbx) {
   typedef __bf16 bfx8 __attribute__((ext_vector_type(8)));
-  const int in = dm.sizes[l], out = dm.sizes[l + 1];
+  const int in = g.in, out = g.out;
   const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(bx * wpb + (int)(threadIdx.x >> 6)), nw = nbx * wpb;
   const int r16 = lane & 15, k8 = 8 * (lane >> 4);
-  const float* W = Wflat + dm.w_off[l];  // column-major [out×in]: W(o,i) at o + out*i
+  const float* W = Wflat + g.w_off;  // column-major [out×in]: W(o,i) at o + out*i
   {
-    const int KG = (in + 31) / 32, nf = (int)(bf_frag_elems(dm, l, false) >> 9);
-    __bf16* dst = fragb + bf_frag_off(dm, l, false);
+    const int KG = (in + 31) / 32, nf = g.bf_nf;
+    __bf16* dst = fragb + g.bf_off;
     for (int f = wave; f < nf; f += nw) {
       const int rt = f / KG, kg = f - rt * KG;
       const int o = rt * 16 + r16, i0 = kg * 32 + k8;
@@ -139,8 +171,8 @@ __device__ inline void build_frags_layer_bf(const float* __restrict__ Wflat, con
     }
   }
   {
-    const int KG = (out + 31) / 32, nf = (int)(bf_frag_elems(dm, l, true) >> 9);   // Wᵀ[in×out]
-    __bf16* dst = fragTb + bf_frag_off(dm, l, true);
+    const int KG = (out + 31) / 32, nf = g.bfT_nf;   // Wᵀ[in×out]
+    __bf16* dst = fragTb + g.bfT_off;
     for (int f = wave; f < nf; f += nw) {
       const int rt = f / KG, kg = f - rt * KG;
       const int i = rt * 16 + r16, o0 = kg * 32 + k8;
@@ -152,22 +184,19 @@ __device__ inline void build_frags_layer_bf(const float* __restrict__ Wflat, con
   }
 }
 
-__device__ inline void build_frags_layer(const float* __restrict__ Wflat, const MlpDims& dm, float* __restrict__ frag,
-                                         float* __restrict__ fragT, float* __restrict__ keep, int l, int bx, int nbx) {
-  const int in = dm.sizes[l], out = dm.sizes[l + 1];
+__device__ inline void build_frags_layer(const float* __restrict__ Wflat, const FragGeom& g, float* __restrict__ frag,
+                                         float* __restrict__ fragT, float* __restrict__ keep, int bx, int nbx) {
+  const int in = g.in, out = g.out;
   const int stride = nbx * blockDim.x, first = bx * blockDim.x + threadIdx.x;
-  if (keep) {   // this layer's slice [w_off[l], w_off[l+1]) of the flat vector
-    const int lo = dm.w_off[l], hi = l + 1 < dm.nL ? dm.w_off[l + 1] : dm.nW;
-    for (int e = lo + first; e < hi; e += stride) keep[e] = Wflat[e];
-  }
-  const float* W = Wflat + dm.w_off[l];  // column-major [out×in]: W(o,i) at o + out*i
+  if (keep) copy_strided(keep, Wflat, g.lo + first, g.hi, stride);   // this layer's slice [w_off[l], w_off[l+1]) of the flat vector
+  const float* W = Wflat + g.w_off;  // column-major [out×in]: W(o,i) at o + out*i
   if (!frag) return;                     // (lde_refresh_weights for a chain in bf16 mode: its f32 fragments are not read)
   const int lane = threadIdx.x & 63, wpb = blockDim.x >> 6;
   const int wave = __builtin_amdgcn_readfirstlane(bx * wpb + (int)(threadIdx.x >> 6)), nw = nbx * wpb;
   const int r16 = lane & 15, k4 = 4 * (lane >> 4);
   {
-    const int KG = cdiv(in, 16), nf = dm.frag_n[l] >> 8;
-    float* dst = frag + dm.frag_off[l];
+    const int KG = cdiv(in, 16), nf = g.frag_nf;
+    float* dst = frag + g.frag_off;
     for (int f = wave; f < nf; f += nw) {
       const int rt = f / KG, kg = f - rt * KG;
       const int o = rt * 16 + r16, i0 = kg * 16 + k4;
@@ -178,8 +207,8 @@ __device__ inline void build_frags_layer(const float* __restrict__ Wflat, const 
     }
   }
   {
-    const int KG = cdiv(out, 16), nf = dm.fragT_n[l] >> 8;  // Wᵀ[in×out]
-    float* dst = fragT + dm.fragT_off[l];
+    const int KG = cdiv(out, 16), nf = g.fragT_nf;  // Wᵀ[in×out]
+    float* dst = fragT + g.fragT_off;
     for (int f = wave; f < nf; f += nw) {
       const int rt = f / KG, kg = f - rt * KG;
       const int i = rt * 16 + r16, o0 = kg * 16 + k4;
@@ -194,8 +223,9 @@ __device__ inline void build_frags_layer(const float* __restrict__ Wflat, const 
 static __global__ void k_build_frags(const float* __restrict__ Wflat, MlpDims dm, float* __restrict__ frag,
                               float* __restrict__ fragT, float* __restrict__ keep, __bf16* __restrict__ fragb = nullptr,
                               __bf16* __restrict__ fragTb = nullptr) {
-  if (fragb) build_frags_layer_bf(Wflat, dm, fragb, fragTb, blockIdx.y, blockIdx.x, gridDim.x);   // (reads Wflat: before `keep` could alias it)
-  build_frags_layer(Wflat, dm, frag, fragT, keep, blockIdx.y, blockIdx.x, gridDim.x);
+  const FragGeom g = frag_geom(dm, blockIdx.y);
+  if (fragb) build_frags_layer_bf(Wflat, g, fragb, fragTb, blockIdx.x, gridDim.x);   // (reads Wflat: before `keep` could alias it)
+  build_frags_layer(Wflat, g, frag, fragT, keep, blockIdx.x, gridDim.x);
 }
 
 // The same re-layout for MANY modules in one launch (lde_refresh_weights: once per optimiser step instead of once per
@@ -206,7 +236,7 @@ struct RefreshJob {
   float* keep;
   float* frag;
   float* fragT;
-  const MlpDims* dm;   // device copy of the chain's dimensions
+  FragGeom g;          // the layer's geometry (layer ≥ 0)
   int layer;
   int n;
   __bf16* fragb;       // bf16 K = 32 fragment copies (chains; nullptr: none)
@@ -215,11 +245,11 @@ struct RefreshJob {
 static __global__ void k_refresh_many(const RefreshJob* __restrict__ jobs) {
   const RefreshJob j = jobs[blockIdx.y];
   if (j.layer < 0) {
-    for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < j.n; e += gridDim.x * blockDim.x) j.keep[e] = j.src[e];
+    copy_strided(j.keep, j.src, blockIdx.x * blockDim.x + threadIdx.x, j.n, gridDim.x * blockDim.x);
     return;
   }
-  if (j.fragb) build_frags_layer_bf(j.src, *j.dm, j.fragb, j.fragTb, j.layer, blockIdx.x, gridDim.x);
-  build_frags_layer(j.src, *j.dm, j.frag, j.fragT, j.keep, j.layer, blockIdx.x, gridDim.x);
+  if (j.fragb) build_frags_layer_bf(j.src, j.g, j.fragb, j.fragTb, blockIdx.x, gridDim.x);
+  build_frags_layer(j.src, j.g, j.frag, j.fragT, j.keep, blockIdx.x, gridDim.x);
 }
 
 __host__ __device__ inline int pad32(int v) { return (v + 31) & ~31; }

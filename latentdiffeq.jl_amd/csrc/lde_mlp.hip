@@ -2037,7 +2037,7 @@ static int launch_b(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t
   const bool tanh_ = dmv.act == LDE_ACT_TANH;
   const size_t cot = ADJ ? (size_t)o.T * dmv.Dp * 4 * (o.checkpoint ? 2 : 1) : 0;
   // RK4's adjoint with fewer register tiles (mlpb::ntr) when the eight LDS tiles more — and the cotangents beside them — fit
-  constexpr bool CAN_LOW = ADJ && SOLVER == LDE_SOLVER_RK4;
+  constexpr bool CAN_LOW = false;   // (the tiles are hidden AGPRs now: no LDS tiles, one variant)
   const bool low = CAN_LOW && cot <= 40 * 1024 && b_lds_base(bdv, o.T, ADJ, 4, true) + cot <= LDS_MAX;
   const void* fn = tanh_ ? (d8 ? (const void*)k_mlpb<SOLVER, 8, LDE_ACT_TANH, ADJ> : (const void*)k_mlpb<SOLVER, 16, LDE_ACT_TANH, ADJ>)
                          : (d8 ? (const void*)k_mlpb<SOLVER, 8, LDE_ACT_RELU, ADJ> : (const void*)k_mlpb<SOLVER, 16, LDE_ACT_RELU, ADJ>);

@@ -42,11 +42,43 @@ constexpr int NT = 13;                // 16-wide tiles along a hidden index (uni
 constexpr int XS = 32;                // floats of the [z | λ] part of a ring slot
 constexpr int SLOT = XS + 4 * HV;     // ring slot: xs | h₁ | g₂ → δ₂ | h₂ | δ₁
 constexpr int NTL = 51;               // weight-gradient tile slots of a wave: 39 + 4 of gW₂ᵀ, 4 of gW₁, 4 of gW₃ᵀ
-// … of which this many are accumulator registers (the rest: LDS, 1 KB per slot and wave). `low` (RK4's adjoint when the LDS has room for eight
-// more tiles — its ring is two slots shorter): the compiler keeps 36 tiles only by spilling 11 of them around the evaluation loop
-// (260 bytes of scratch per lane: a global round trip per step); with 28 it spills 15 words — c2: 0.975 -> 0.913 ms (24: no scratch, but
-// 12 KB more LDS than the CU has; 30 / 32: 0.918 / 0.930).
-constexpr int ntr(int dp, int nst, bool low) { return (nst == 4 && low) ? 28 : (dp == 16 ? 40 : 36); }
+// The weight-gradient tiles live in AGPRs the COMPILER DOES NOT KNOW ABOUT (round 4): the kernel caps the compiler's own registers at
+// 256 VGPRs + A0 AGPRs (amdgpu_num_vgpr), an empty asm clobbering a255 makes the kernel allocate all 512, and tile n of a wave is
+// a[A0 + 4n : A0 + 4n + 3], touched only by inline asm with literal register numbers (v_accvgpr_write at the start, the fold's
+// v_mfma_f32_16x16x4_f32 with the tile as C and D, v_accvgpr_read at the end). As ordinary variables the loop-carried tiles were kept
+// in TWO places by the register allocator (8 AGPRs per tile, `v_accvgpr_mov` blocks at the loop edges), so that only 28–40 of the 51
+// fit and the rest lived in LDS — and 11 of those were spilled to scratch around the evaluation loop.
+constexpr int NTH = 51;               // tiles per wave in hidden AGPRs (all of them)
+constexpr int A0 = 256 - 4 * NTH;     // the compiler's AGPRs: a[0 : A0)
+// tile N += av ⊗ bv (K = the four lane groups). The two wait states in front of the MFMA are the VALU → MFMA-operand distance (the compiler
+// pads nothing inside an asm string); an MFMA that takes the previous one's D whole as its C needs none.
+template <int N>
+__device__ __forceinline__ void tile_mfma(float av, float bv) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 a[%2:%3], %0, %1, a[%2:%3]" :: "v"(av), "v"(bv), "n"(A0 + 4 * N), "n"(A0 + 4 * N + 3));
+}
+template <int N>
+__device__ __forceinline__ void tile_zero() {
+  asm volatile("v_accvgpr_write_b32 a[%0], 0\n\tv_accvgpr_write_b32 a[%1], 0\n\tv_accvgpr_write_b32 a[%2], 0\n\tv_accvgpr_write_b32 a[%3], 0"
+               :: "n"(A0 + 4 * N), "n"(A0 + 4 * N + 1), "n"(A0 + 4 * N + 2), "n"(A0 + 4 * N + 3));
+}
+template <int N>
+__device__ __forceinline__ f32x4 tile_read() {   // (the caller has put the MFMA → reader distance in front of the first read)
+  f32x4 r;
+  asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\tv_accvgpr_read_b32 %2, a[%6]\n\tv_accvgpr_read_b32 %3, a[%7]"
+               : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3])
+               : "n"(A0 + 4 * N), "n"(A0 + 4 * N + 1), "n"(A0 + 4 * N + 2), "n"(A0 + 4 * N + 3));
+  return r;
+}
+// f(integral_constant<int, I>) for I = B … E − 1: the tile number must be a constant EXPRESSION where the asm is written (an unrolled loop
+// variable is not one: the switch over 51 cases stayed a run-time branch tree)
+template <int B_, int E_, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (B_ < E_) {
+    f(std::integral_constant<int, B_>{});
+    static_for<B_ + 1, E_>(f);
+  }
+}
+constexpr int ntr(int, int, bool) { return NTH; }   // (tiles not in LDS; the LDS path below serves NTH < NTL)
 }  // namespace mlpb
 
 // one-time packing (set_weights): everything in the order the kernel's lanes read it
@@ -111,7 +143,7 @@ __device__ __forceinline__ long long sgpr_ll(long long v) {
 __device__ __forceinline__ double sgpr_d(double v) { return __builtin_bit_cast(double, sgpr_ll(__builtin_bit_cast(long long, v))); }
 
 template <int SOLVER, int DP, int ACT, bool ADJ, bool LOW = false>
-__global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, VArgs a) {
+__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(256 + mlpb::A0))) k_mlpb(MlpDims dm, BDims bd, KOpts o, VArgs a) {
   using namespace mlpb;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int SEG = 64 / DP, G1 = DP / 4, GS = (200 / SEG + 3) / 4;   // GS: host = bd.GS
@@ -175,35 +207,11 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
   constexpr int act = ACT;   // (compile-time: a run-time activation is a branch per call, and the block product applies it 13 times per lane)
   // the weight gradient: accumulator-resident 16×16 tiles (C/D layout of v_mfma_f32_16x16x4_f32: column = lane & 15, row = 4·(lane >> 4) + reg)
   // (of a wave's NTL tile slots the first NTR stay in registers; the others live in LDS, a 1 KB word array per slot and wave)
-  f32x4 gt[ADJ ? NTR : 1];
   float gb1 = 0.f, gb3 = 0.f;
   if (ADJ) {
-#pragma unroll
-    for (int n = 0; n < NTR; n++) gt[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("" ::: "a255");   // the kernel owns all 512 registers of a lane
+    static_for<0, NTL>([&](auto nc) { tile_zero<decltype(nc)::value>(); });
   }
-  f32x4* const my_lt = ltile + tid;
-  float lt_a[NTL - NTR + 1], lt_b[NTL - NTR + 1];   // operands of the LDS-resident slots, collected while the register slots are multiplied
-  auto acc_tile = [&](int n, float av, float bv) {   // n: compile-time after unrolling
-    if (n < NTR) gt[n < NTR ? n : 0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv, gt[n < NTR ? n : 0], 0, 0, 0);
-    else { lt_a[n < NTR ? 0 : n - NTR] = av; lt_b[n < NTR ? 0 : n - NTR] = bv; }
-  };
-  auto acc_lds_tiles = [&]() {   // read – multiply – write, five slots at a time (one round trip per batch, not per slot)
-    constexpr int NL = NTL - NTR, BT = 5;
-#pragma unroll
-    for (int n0 = 0; n0 < NL; n0 += BT) {
-      f32x4 tv[BT];
-#pragma unroll
-      for (int q = 0; q < BT; q++)
-        if (n0 + q < NL) tv[q] = my_lt[(n0 + q) * UT];
-#pragma unroll
-      for (int q = 0; q < BT; q++)
-        if (n0 + q < NL) tv[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(lt_a[n0 + q], lt_b[n0 + q], tv[q], 0, 0, 0);
-#pragma unroll
-      for (int q = 0; q < BT; q++)
-        if (n0 + q < NL) my_lt[(n0 + q) * UT] = tv[q];
-    }
-  };
-  auto get_tile = [&](int n) -> f32x4 { return n < NTR ? gt[n < NTR ? n : 0] : my_lt[(n - NTR) * UT]; };
   __syncthreads();
 
   const bool coupled = dm.coupled != 0;
@@ -452,25 +460,31 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
       float bm[3];
 #pragma unroll
       for (int m = 0; m < 3; m++) bm[m] = sl[XS + HV + 64 * m + 16 * wv] * wsc;
+      // every operand of the group is read before the first MFMA (one LDS round trip, not one per tile row: the asm statements keep their
+      // order, and a read placed between them would be waited for in front of the next one)
+      float av[NT], a39[4], a43[4], a47[4];
 #pragma unroll
-      for (int ti = 0; ti < NT; ti++) {        // gW₂ᵀ[i][o] += Σ_e h₁_e[i] · (w_e δ₂_e)[o]
-        const float av = sl[XS + 16 * ti] * am;
+      for (int ti = 0; ti < NT; ti++) av[ti] = sl[XS + 16 * ti] * am;
+      const float b12 = sl[XS + HV + 16 * 12] * wsc;
+      const float z0v = sl[0], l0v = sl[DP];   // (unconditional reads: a read under a lane condition is waited for where it stands)
+      const float bz = l15 < Dp ? z0v * wsc : 0.f, bl = l15 < Dp ? l0v * wsc : 0.f;
 #pragma unroll
-        for (int m = 0; m < 3; m++) acc_tile(3 * ti + m, av, bm[m]);
+      for (int q = 0; q < 4; q++) {
+        a39[q] = pa[64 * q] * am;
+        a43[q] = pa[3 * HV + 64 * q] * am;
+        a47[q] = pa[2 * HV + 64 * q] * am;
       }
-      {
-        const float b12 = sl[XS + HV + 16 * 12] * wsc;
-#pragma unroll
-        for (int q = 0; q < 4; q++) acc_tile(39 + q, pa[64 * q] * am, b12);
-      }
-      {                                        // gW₁[u][k] += Σ_e (w_e δ₁_e)[u] · z_e[k];  gW₃ᵀ[u][d] += Σ_e h₂_e[u] · (w_e λ_e)[d]
-        const float bz = l15 < Dp ? sl[0] * wsc : 0.f, bl = l15 < Dp ? sl[DP] * wsc : 0.f;
-#pragma unroll
-        for (int q = 0; q < 4; q++) acc_tile(43 + q, pa[3 * HV + 64 * q] * am, bz);
-#pragma unroll
-        for (int q = 0; q < 4; q++) acc_tile(47 + q, pa[2 * HV + 64 * q] * am, bl);
-      }
-      acc_lds_tiles();
+      __builtin_amdgcn_sched_barrier(0);
+      static_for<0, NT>([&](auto tic) {        // gW₂ᵀ[i][o] += Σ_e h₁_e[i] · (w_e δ₂_e)[o]
+        constexpr int ti = decltype(tic)::value;
+        tile_mfma<3 * ti + 0>(av[ti], bm[0]);
+        tile_mfma<3 * ti + 1>(av[ti], bm[1]);
+        tile_mfma<3 * ti + 2>(av[ti], bm[2]);
+      });
+      static_for<0, 4>([&](auto qc) { constexpr int q = decltype(qc)::value; tile_mfma<39 + q>(a39[q], b12); });
+      // gW₁[u][k] += Σ_e (w_e δ₁_e)[u] · z_e[k];  gW₃ᵀ[u][d] += Σ_e h₂_e[u] · (w_e λ_e)[d]
+      static_for<0, 4>([&](auto qc) { constexpr int q = decltype(qc)::value; tile_mfma<43 + q>(a43[q], bz); });
+      static_for<0, 4>([&](auto qc) { constexpr int q = decltype(qc)::value; tile_mfma<47 + q>(a47[q], bl); });
     }
     // thin biases: gb₁[u] += Σ_e w_e δ₁_e[u] (lane u), gb₃[d] += Σ_e w_e λ_e[d] (the λ lanes); gb₂ is row H₁ of the gW₂ᵀ tiles
 #pragma unroll
@@ -751,9 +765,9 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
     // folded before it is dropped, as its dẑ₀ is)
     float* out = a.stage + (size_t)b * a.cap;
     const bool keep = st <= 1;
+    asm volatile("s_nop 15\n\ts_nop 15");   // the last fold's MFMAs → the v_accvgpr_read of their tiles (nothing pads hidden registers)
     const int l15 = lane & 15, e4 = lane >> 4;
-    auto put2 = [&](int n, int ti, int tj) {   // gW₂ᵀ tile (ti, tj): rows = h₁ index (row H₁: gb₂), columns = δ₂ index
-      const f32x4 tv = get_tile(n);
+    auto put2 = [&](const f32x4 tv, int ti, int tj) {   // gW₂ᵀ tile (ti, tj): rows = h₁ index (row H₁: gb₂), columns = δ₂ index
       const int oo = 16 * tj + l15;
 #pragma unroll
       for (int r = 0; r < 4; r++) {
@@ -764,15 +778,16 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
         }
       }
     };
-#pragma unroll
-    for (int ti = 0; ti < NT; ti++)
-#pragma unroll
-      for (int m = 0; m < 3; m++) put2(3 * ti + m, ti, 4 * m + wv);
-#pragma unroll
-    for (int q = 0; q < 4; q++) put2(39 + q, 4 * q + wv, 12);
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const f32x4 t1 = get_tile(43 + q), t3 = get_tile(47 + q);
+    static_for<0, NT>([&](auto tic) {
+      constexpr int ti = decltype(tic)::value;
+      put2(tile_read<3 * ti + 0>(), ti, 0 + wv);
+      put2(tile_read<3 * ti + 1>(), ti, 4 + wv);
+      put2(tile_read<3 * ti + 2>(), ti, 8 + wv);
+    });
+    static_for<0, 4>([&](auto qc) { constexpr int q = decltype(qc)::value; put2(tile_read<39 + q>(), 4 * q + wv, 12); });
+    static_for<0, 4>([&](auto qc) {
+      constexpr int q = decltype(qc)::value;
+      const f32x4 t1 = tile_read<43 + q>(), t3 = tile_read<47 + q>();
 #pragma unroll
       for (int r = 0; r < 4; r++) {
         const int uu = 16 * (4 * q + wv) + 4 * e4 + r;
@@ -781,7 +796,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
           if (uu < H2) out[dm.w_off[2] + l15 + Dp * uu] = keep ? t3[r] : 0.f;
         }
       }
-    }
+    });
     if (u < H1) out[dm.b_off[0] + u] = keep ? gb1 : 0.f;
     if (wv == 0 && is_l) out[dm.b_off[2] + row] = keep ? gb3 : 0.f;
   }

@@ -50,25 +50,27 @@ constexpr int NTL = 51;               // weight-gradient tile slots of a wave: 3
 // fit and the rest lived in LDS — and 11 of those were spilled to scratch around the evaluation loop.
 constexpr int NTH = 51;               // tiles per wave in hidden AGPRs (all of them)
 constexpr int A0 = 256 - 4 * NTH;     // the compiler's AGPRs: a[0 : A0)
-// tile N += av ⊗ bv (K = the four lane groups). The two wait states in front of the MFMA are the VALU → MFMA-operand distance (the compiler
-// pads nothing inside an asm string); an MFMA that takes the previous one's D whole as its C needs none.
-template <int N>
-__device__ __forceinline__ void tile_mfma(float av, float bv) {
-  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 a[%2:%3], %0, %1, a[%2:%3]" :: "v"(av), "v"(bv), "n"(A0 + 4 * N), "n"(A0 + 4 * N + 3));
+// tile at a[R : R + 3] += av ⊗ bv (K = the four lane groups). The two wait states in front of the MFMA are the VALU → MFMA-operand distance
+// (the compiler pads nothing inside an asm string); an MFMA that takes the previous one's D whole as its C needs none.
+template <int R>
+__device__ __forceinline__ void areg_mfma(float av, float bv) {
+  asm volatile("s_nop 1\n\tv_mfma_f32_16x16x4_f32 a[%2:%3], %0, %1, a[%2:%3]" :: "v"(av), "v"(bv), "n"(R), "n"(R + 3));
 }
-template <int N>
-__device__ __forceinline__ void tile_zero() {
+template <int R>
+__device__ __forceinline__ void areg_zero() {
   asm volatile("v_accvgpr_write_b32 a[%0], 0\n\tv_accvgpr_write_b32 a[%1], 0\n\tv_accvgpr_write_b32 a[%2], 0\n\tv_accvgpr_write_b32 a[%3], 0"
-               :: "n"(A0 + 4 * N), "n"(A0 + 4 * N + 1), "n"(A0 + 4 * N + 2), "n"(A0 + 4 * N + 3));
+               :: "n"(R), "n"(R + 1), "n"(R + 2), "n"(R + 3));
 }
-template <int N>
-__device__ __forceinline__ f32x4 tile_read() {   // (the caller has put the MFMA → reader distance in front of the first read)
+template <int R>
+__device__ __forceinline__ f32x4 areg_read() {   // (the caller has put the MFMA → reader distance in front of the first read)
   f32x4 r;
   asm volatile("v_accvgpr_read_b32 %0, a[%4]\n\tv_accvgpr_read_b32 %1, a[%5]\n\tv_accvgpr_read_b32 %2, a[%6]\n\tv_accvgpr_read_b32 %3, a[%7]"
-               : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3])
-               : "n"(A0 + 4 * N), "n"(A0 + 4 * N + 1), "n"(A0 + 4 * N + 2), "n"(A0 + 4 * N + 3));
+               : "=v"(r[0]), "=v"(r[1]), "=v"(r[2]), "=v"(r[3]) : "n"(R), "n"(R + 1), "n"(R + 2), "n"(R + 3));
   return r;
 }
+template <int N> __device__ __forceinline__ void tile_mfma(float av, float bv) { areg_mfma<A0 + 4 * N>(av, bv); }
+template <int N> __device__ __forceinline__ void tile_zero() { areg_zero<A0 + 4 * N>(); }
+template <int N> __device__ __forceinline__ f32x4 tile_read() { return areg_read<A0 + 4 * N>(); }
 // f(integral_constant<int, I>) for I = B … E − 1: the tile number must be a constant EXPRESSION where the asm is written (an unrolled loop
 // variable is not one: the switch over 51 cases stayed a run-time branch tree)
 template <int B_, int E_, class F>

@@ -23,6 +23,8 @@ struct CDims {
 };
 
 namespace mlpc {
+constexpr int A0 = 256 - 4 * 26;     // the compiler's AGPRs: a[0 : A0); the 26 tiles of a wave sit behind them (hidden: lde_mlpb.h)
+
 constexpr int UT = 256;
 constexpr int DP = 32, G1 = DP / 4, SEG = 2, GS = 16;   // state lanes, float4 groups of a state half, narrow products: K-segments and float4 groups per lane
 constexpr int RB = 8, CB = 9;          // block: 8 rows × 9 columns
@@ -73,7 +75,7 @@ static __global__ void k_build_cpack(const float* __restrict__ Wflat, MlpDims dm
 }
 
 template <int SOLVER, int ACT, bool ADJ>
-__global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, VArgs a) {
+__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(256 + mlpc::A0))) k_mlpc(MlpDims dm, CDims cd, KOpts o, VArgs a) {
   using namespace mlpc;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NST = SOLVER == LDE_SOLVER_TSIT5 ? 6 : 4;                // weighted stages of a step = ring slots the fold reads
@@ -139,11 +141,11 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
   const f32x4* const my13 = reinterpret_cast<const f32x4*>(w13 + u * W13S);   // this lane's row of W₁ | column of W₃ (LDS)
   const float b1 = a.wpack[cd.o_b1 + u], b3 = a.wpack[cd.o_b3 + (lane % DP)];
   // the weight gradient: accumulator-resident 16×16 tiles (C/D layout of v_mfma_f32_16x16x4_f32: column = lane & 15, row = 4·(lane >> 4) + reg)
-  f32x4 gt[ADJ ? NTL : 1];
+  // — in AGPRs the compiler does not know about (a[A0 + 4n : A0 + 4n + 3], inline asm with literal numbers; see lde_mlpb.h)
   float gb1 = 0.f, gb3 = 0.f;
   if (ADJ) {
-#pragma unroll
-    for (int n = 0; n < NTL; n++) gt[n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    asm volatile("" ::: "a255");   // the kernel owns all 512 registers of a lane
+    mlpb::static_for<0, NTL>([&](auto nc) { mlpb::areg_zero<A0 + 4 * decltype(nc)::value>(); });
   }
   __syncthreads();
 
@@ -380,30 +382,45 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
       const float* pv = sl + XS + 2 * l15 + tt;           // + 32·tile: element (16·tile + l15) of trajectory tt of the slot's first vector
       const float* pw = pv + 32 * wv;                     // … of the tiles 4m + w
       float bm[2];
+      const float am = ev ? 1.f : 0.f, wm = ev ? wsc : 0.f;   // (reads unconditional — the slot index is clamped — and masked by a factor)
 #pragma unroll
-      for (int m = 0; m < 2; m++) bm[m] = ev ? pw[HV + 128 * m] * wsc : 0.f;                 // δ₂ tiles 4m + w, scaled
+      for (int m = 0; m < 2; m++) bm[m] = pw[HV + 128 * m] * wm;                 // δ₂ tiles 4m + w, scaled
+      // every operand of the group is read before the first MFMA (the asm statements keep their order: a read between them would be
+      // waited for in front of the next one)
+      float av[9], a1[2], a3[2], zv[2], lv[2];
 #pragma unroll
-      for (int ti = 0; ti < 9; ti++) {                    // gW₂ᵀ[i][o] += Σ h₁[i] · (w δ₂)[o]   (row H₁: gb₂)
-        const float av = ev ? pv[32 * ti] : 0.f;
+      for (int ti = 0; ti < 9; ti++) av[ti] = pv[32 * ti] * am;
 #pragma unroll
-        for (int m = 0; m < 2; m++) gt[2 * ti + m] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bm[m], gt[2 * ti + m], 0, 0, 0);
+      for (int m = 0; m < 2; m++) {
+        a1[m] = pw[3 * HV + 128 * m] * am;
+        a3[m] = pw[2 * HV + 128 * m] * am;
+      }
+#pragma unroll
+      for (int tk = 0; tk < 2; tk++) {   // (unconditional reads, clamped rows: a read under a lane condition is waited for where it stands)
+        const int rz = 16 * tk + l15 < Dp ? 16 * tk + l15 : 0;
+        zv[tk] = sl[64 * tt + rz];
+        lv[tk] = sl[64 * tt + DP + rz];
       }
       float bz[2], bl[2];
 #pragma unroll
       for (int tk = 0; tk < 2; tk++) {
         const bool in = ev && 16 * tk + l15 < Dp;
-        bz[tk] = in ? sl[64 * tt + 16 * tk + l15] * wsc : 0.f;         // z rows of the tile, scaled
-        bl[tk] = in ? sl[64 * tt + DP + 16 * tk + l15] * wsc : 0.f;    // λ rows, scaled
+        bz[tk] = in ? zv[tk] * wsc : 0.f;         // z rows of the tile, scaled
+        bl[tk] = in ? lv[tk] * wsc : 0.f;         // λ rows, scaled
       }
-#pragma unroll
-      for (int m = 0; m < 2; m++) {                       // gW₁[u][k] += Σ (w δ₁)[u] · z[k];  gW₃ᵀ[u][d] += Σ h₂[u] · (w λ)[d]
-        const float a1 = ev ? pw[3 * HV + 128 * m] : 0.f, a3 = ev ? pw[2 * HV + 128 * m] : 0.f;
-#pragma unroll
-        for (int tk = 0; tk < 2; tk++) {
-          gt[18 + 2 * m + tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a1, bz[tk], gt[18 + 2 * m + tk], 0, 0, 0);
-          gt[22 + 2 * m + tk] = __builtin_amdgcn_mfma_f32_16x16x4f32(a3, bl[tk], gt[22 + 2 * m + tk], 0, 0, 0);
-        }
-      }
+      __builtin_amdgcn_sched_barrier(0);
+      mlpb::static_for<0, 9>([&](auto tic) {   // gW₂ᵀ[i][o] += Σ h₁[i] · (w δ₂)[o]   (row H₁: gb₂)
+        constexpr int ti = decltype(tic)::value;
+        mlpb::areg_mfma<A0 + 4 * (2 * ti + 0)>(av[ti], bm[0]);
+        mlpb::areg_mfma<A0 + 4 * (2 * ti + 1)>(av[ti], bm[1]);
+      });
+      mlpb::static_for<0, 2>([&](auto mc) {    // gW₁[u][k] += Σ (w δ₁)[u] · z[k];  gW₃ᵀ[u][d] += Σ h₂[u] · (w λ)[d]
+        constexpr int m = decltype(mc)::value;
+        mlpb::areg_mfma<A0 + 4 * (18 + 2 * m + 0)>(a1[m], bz[0]);
+        mlpb::areg_mfma<A0 + 4 * (18 + 2 * m + 1)>(a1[m], bz[1]);
+        mlpb::areg_mfma<A0 + 4 * (22 + 2 * m + 0)>(a3[m], bl[0]);
+        mlpb::areg_mfma<A0 + 4 * (22 + 2 * m + 1)>(a3[m], bl[1]);
+      });
     }
     // thin biases: gb₁[u] += Σ w (δ₁_A + δ₁_B)[u] (lanes tid < 128), gb₃[d] += Σ w (λ_A + λ_B)[d] (the λ lanes); gb₂ is row H₁ of the gW₂ᵀ tiles
 #pragma unroll
@@ -730,36 +747,39 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
     float* out = a.stage + (size_t)blockIdx.x * a.cap;
     const bool keep = st <= 1;
     const int l15 = lane & 15, e4 = lane >> 4;
+    asm volatile("s_nop 15\n\ts_nop 15");   // the last fold's MFMAs → the v_accvgpr_read of their tiles (nothing pads hidden registers)
+    auto put2 = [&](const f32x4 tv, int ti, int m) {   // gW₂ᵀ tile (ti, 4m + w): rows = h₁ index (row H₁: gb₂), columns = δ₂ index
+      const int oo = 16 * (4 * m + wv) + l15;
 #pragma unroll
-    for (int ti = 0; ti < 9; ti++)
-#pragma unroll
-      for (int m = 0; m < 2; m++) {   // gW₂ᵀ tile (ti, 4m + w): rows = h₁ index (row H₁: gb₂), columns = δ₂ index
-        const f32x4 tv = gt[2 * ti + m];
-        const int oo = 16 * (4 * m + wv) + l15;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int i = 16 * ti + 4 * e4 + r;
-          if (oo < H2) {
-            if (i < H1) out[dm.w_off[1] + oo + H2 * i] = keep ? tv[r] : 0.f;
-            else if (i == H1) out[dm.b_off[1] + oo] = keep ? tv[r] : 0.f;
-          }
+      for (int r = 0; r < 4; r++) {
+        const int i = 16 * ti + 4 * e4 + r;
+        if (oo < H2) {
+          if (i < H1) out[dm.w_off[1] + oo + H2 * i] = keep ? tv[r] : 0.f;
+          else if (i == H1) out[dm.b_off[1] + oo] = keep ? tv[r] : 0.f;
         }
       }
+    };
+    mlpb::static_for<0, 9>([&](auto tic) {
+      constexpr int ti = decltype(tic)::value;
+      put2(mlpb::areg_read<A0 + 4 * (2 * ti + 0)>(), ti, 0);
+      put2(mlpb::areg_read<A0 + 4 * (2 * ti + 1)>(), ti, 1);
+    });
+    auto put13 = [&](const f32x4 t1, const f32x4 t3, int m, int tk) {
+      const int kk = 16 * tk + l15;
 #pragma unroll
-    for (int m = 0; m < 2; m++)
-#pragma unroll
-      for (int tk = 0; tk < 2; tk++) {
-        const f32x4 t1 = gt[18 + 2 * m + tk], t3 = gt[22 + 2 * m + tk];
-        const int kk = 16 * tk + l15;
-#pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int uu = 16 * (4 * m + wv) + 4 * e4 + r;
-          if (kk < Dp) {
-            if (uu < H1) out[dm.w_off[0] + uu + H1 * kk] = keep ? t1[r] : 0.f;
-            if (uu < H2) out[dm.w_off[2] + kk + Dp * uu] = keep ? t3[r] : 0.f;
-          }
+      for (int r = 0; r < 4; r++) {
+        const int uu = 16 * (4 * m + wv) + 4 * e4 + r;
+        if (kk < Dp) {
+          if (uu < H1) out[dm.w_off[0] + uu + H1 * kk] = keep ? t1[r] : 0.f;
+          if (uu < H2) out[dm.w_off[2] + kk + Dp * uu] = keep ? t3[r] : 0.f;
         }
       }
+    };
+    mlpb::static_for<0, 2>([&](auto mc) {
+      constexpr int m = decltype(mc)::value;
+      put13(mlpb::areg_read<A0 + 4 * (18 + 2 * m + 0)>(), mlpb::areg_read<A0 + 4 * (22 + 2 * m + 0)>(), m, 0);
+      put13(mlpb::areg_read<A0 + 4 * (18 + 2 * m + 1)>(), mlpb::areg_read<A0 + 4 * (22 + 2 * m + 1)>(), m, 1);
+    });
     if (tid < H1) out[dm.b_off[0] + tid] = keep ? gb1 : 0.f;
     if (wv == 0 && is_l) out[dm.b_off[2] + row] = keep ? gb3 : 0.f;
   }

@@ -63,6 +63,14 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out: s
                 if verbose:
                     sys.stderr.write(r.stderr)
     objs = [os.path.join(objdir, s.replace(".hip", ".o")) for s in SOURCES]
+    if any(c[-3].endswith("lde_mlp.hip") for c in jobs):
+        # k_mlpb / k_mlpc keep their weight-gradient tiles in AGPRs the compiler is not told about (csrc/lde_mlpb.h): every new object is
+        # checked — the compiler's own code must not touch that range. A violation is a build failure, never a shipped library.
+        from .check_agprs import check_object
+        bad = check_object(os.path.join(objdir, "lde_mlp.o"))
+        if bad:
+            os.remove(os.path.join(objdir, "lde_mlp.o"))
+            raise RuntimeError("lde_mlp.o: the compiler uses hidden accumulator registers of k_mlpb / k_mlpc:\n  " + "\n  ".join(bad[:12]))
     if jobs or _newer(out, objs):
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"], capture_output=True, text=True)
         if r.returncode != 0:

@@ -42,12 +42,16 @@ constexpr int NT = 13;                // 16-wide tiles along a hidden index (uni
 constexpr int XS = 32;                // floats of the [z | λ] part of a ring slot
 constexpr int SLOT = XS + 4 * HV;     // ring slot: xs | h₁ | g₂ → δ₂ | h₂ | δ₁
 constexpr int NTL = 51;               // weight-gradient tile slots of a wave: 39 + 4 of gW₂ᵀ, 4 of gW₁, 4 of gW₃ᵀ
-// The weight-gradient tiles live in AGPRs the COMPILER DOES NOT KNOW ABOUT (round 4): the kernel caps the compiler's own registers at
-// 256 VGPRs + A0 AGPRs (amdgpu_num_vgpr), an empty asm clobbering a255 makes the kernel allocate all 512, and tile n of a wave is
-// a[A0 + 4n : A0 + 4n + 3], touched only by inline asm with literal register numbers (v_accvgpr_write at the start, the fold's
-// v_mfma_f32_16x16x4_f32 with the tile as C and D, v_accvgpr_read at the end). As ordinary variables the loop-carried tiles were kept
-// in TWO places by the register allocator (8 AGPRs per tile, `v_accvgpr_mov` blocks at the loop edges), so that only 28–40 of the 51
-// fit and the rest lived in LDS — and 11 of those were spilled to scratch around the evaluation loop.
+// The weight-gradient tiles live in AGPRs the COMPILER DOES NOT KNOW ABOUT (round 4): an empty asm clobbering a255 makes the kernel
+// allocate all 512 registers of a lane, and tile n of a wave is a[A0 + 4n : A0 + 4n + 3], touched only by inline asm with literal register
+// numbers (v_accvgpr_write at the start, the fold's v_mfma_f32_16x16x4_f32 with the tile as C and D, v_accvgpr_read at the end). As
+// ordinary variables the loop-carried tiles were kept in TWO places by the register allocator (8 AGPRs per tile, `v_accvgpr_mov` blocks
+// at the loop edges), so that only 28–40 of the 51 fit, the rest lived in LDS — and 11 of those were spilled to scratch around the
+// evaluation loop. NOTHING IN LLVM RESERVES THESE REGISTERS (`amdgpu_num_vgpr` is a budget that is split evenly between VGPRs and AGPRs
+// once a kernel uses AGPRs, not a cap on one half: a variant of this kernel with more live values was seen to use a0–a91): what the
+// compiler needs for itself — copies of VGPR values, ≤ 40 AGPRs in every instantiation — happens to sit below A0 because it allocates
+// from a0 upwards. EVERY BUILD IS THEREFORE CHECKED (check_agprs.py, called by build.py and by tests/test_abi.py): no instruction of
+// these kernels may write an AGPR ≥ A0 except the asm's own three forms; a violation fails the build.
 constexpr int NTH = 51;               // tiles per wave in hidden AGPRs (all of them)
 constexpr int A0 = 256 - 4 * NTH;     // the compiler's AGPRs: a[0 : A0)
 // tile at a[R : R + 3] += av ⊗ bv (K = the four lane groups). The two wait states in front of the MFMA are the VALU → MFMA-operand distance
@@ -145,7 +149,7 @@ __device__ __forceinline__ long long sgpr_ll(long long v) {
 __device__ __forceinline__ double sgpr_d(double v) { return __builtin_bit_cast(double, sgpr_ll(__builtin_bit_cast(long long, v))); }
 
 template <int SOLVER, int DP, int ACT, bool ADJ, bool LOW = false>
-__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(256 + mlpb::A0))) k_mlpb(MlpDims dm, BDims bd, KOpts o, VArgs a) {
+__global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, VArgs a) {
   using namespace mlpb;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int SEG = 64 / DP, G1 = DP / 4, GS = (200 / SEG + 3) / 4;   // GS: host = bd.GS

@@ -75,7 +75,7 @@ static __global__ void k_build_cpack(const float* __restrict__ Wflat, MlpDims dm
 }
 
 template <int SOLVER, int ACT, bool ADJ>
-__global__ void __launch_bounds__(256, 1) __attribute__((amdgpu_num_vgpr(256 + mlpc::A0))) k_mlpc(MlpDims dm, CDims cd, KOpts o, VArgs a) {
+__global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, VArgs a) {
   using namespace mlpc;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NST = SOLVER == LDE_SOLVER_TSIT5 ? 6 : 4;                // weighted stages of a step = ring slots the fold reads

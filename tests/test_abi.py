@@ -215,3 +215,20 @@ def test_documented_julia_struct_layouts():
     # the stub must start from the library's defaults (sensealg = PARALLEL_CHECKPOINTED), not from zeros
     src = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     assert "lde_problem_desc_default" in src.split("mutable struct LdeHandle")[0]
+
+
+def test_hidden_accumulator_registers_are_not_touched_by_the_compiler():
+    """k_mlpb / k_mlpc keep their weight-gradient tiles in AGPRs a[A0 : 256) that only inline asm names (csrc/lde_mlpb.h); LLVM has no way
+    to reserve them, so the built object is checked: outside the asm's own three instruction forms nothing in those kernels writes or
+    reads that range (build.py runs the same check and fails the build). The checker itself is checked with a bound it must trip over."""
+    from latentdiffeq_amd import build, check_agprs
+    build.build_lib()
+    obj = os.path.join(build.OBJ, "lde_mlp.o")
+    assert os.path.exists(obj)
+    assert check_agprs.check_object(obj) == []
+    saved = dict(check_agprs.A0)
+    try:
+        check_agprs.A0.update({k: 8 for k in saved})          # the compiler's own copies live above a8: the check must see them
+        assert len(check_agprs.check_object(obj)) > 0
+    finally:
+        check_agprs.A0.update(saved)

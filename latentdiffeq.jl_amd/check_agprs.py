@@ -46,8 +46,10 @@ def check_object(obj: str) -> list:
             kern, lim = None, None
             for k, a0 in A0.items():
                 if f"6{k}I" in name:          # _ZN3lde6k_mlpbI…
-                    kern, lim = name, a0
                     seen.add(k)
+                    adj = re.search(r"Lb([01])E", name)          # the first bool template argument is ADJ: only the adjoint has tiles
+                    if adj and adj.group(1) == "1":
+                        kern, lim = name, a0
             continue
         if kern is None:
             continue

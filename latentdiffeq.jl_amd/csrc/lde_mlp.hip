@@ -2012,7 +2012,7 @@ static int launch_w(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t
 static size_t b_lds_base(const BDims& bd, int T, bool adj, int nst, bool low = false) {   // save times, ring (+ partial sums), narrow slices
   const int nsl = adj ? nst + 1 : 1;
   return (((size_t)T * 8 + 15) & ~size_t(15)) + (size_t)(nsl * mlpb::SLOT + (adj ? 16 * mlpb::HV + (mlpb::NTL - mlpb::ntr(bd.DP, nst, low)) * mlpb::UT * 4 : 0)) * 4 +
-         (size_t)bd.GS * 64 * 16 * (adj ? 2 : 1) + (size_t)mlpb::HV * (2 * bd.DP + 4) * 4 + 16;
+         (size_t)bd.GS * 64 * 16 * (adj ? 2 : 1) + (size_t)mlpb::HV * (2 * bd.DP + 4) * 4 + 16 + ((adj && bd.DP == 16) ? 2 * mlpb::W * 16 * 4 : 0);
 }
 static bool b_applicable(const MlpPlan* p, int B, int T, bool adj, bool coupled_adaptive) {
   // LDE_MLPB (read per call: the tests switch kernels inside one process): 0 = off (k_mlpw: the parity reference of this kernel),

@@ -176,7 +176,12 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
   f32x4* n3 = ltile + (ADJ ? (NTL - NTR) * UT : 0);
   f32x4* n1 = n3 + GS * 64;
   float* w13 = reinterpret_cast<float*>(n1 + (ADJ ? GS * 64 : 0));     // rows of W₁ | columns of W₃ by unit: [HV][2·DP + 4]
-  float* s_cot = w13 + HV * W13S;                                      // adjoint: the trajectory's cotangents (and saved states) by save time
+  // KSPLIT (adjoint, D′ = 16): the two H → D′ products are split over the four waves along K — a quarter of the 14 read groups each,
+  // which this kernel's register pressure serialises into dependent LDS round trips and which cannot be batched at this width (112
+  // registers) — and the partial results meet in s_np behind a barrier (the first product's behind the one that is there anyway)
+  constexpr bool KSPLIT = ADJ && DP == 16;
+  float* s_np = w13 + HV * W13S;                                       // [2 products][4 waves][D′] partial outputs (KSPLIT)
+  float* s_cot = s_np + (KSPLIT ? 2 * W * DP : 0);                     // adjoint: the trajectory's cotangents (and saved states) by save time
   for (int i = tid; i < T; i += UT) s_ts[i] = a.ts[i];
   for (int i = tid; i < NSL * SLOT + (ADJ ? 16 * HV + (NTL - NTR) * UT * 4 : 0); i += UT) ring[i] = 0.f;
   {
@@ -318,6 +323,27 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
     }
     return xor_segs((p01.x + p01.y) + (p23.x + p23.y));
   };
+  // this wave's quarter of the K range of the same product (KSPLIT): groups wv·GP … wv·GP + GP − 1, all reads in flight together
+  auto narrow_part = [&](const f32x4* ns, const float* vec) -> float {
+    constexpr int GP = (GS + W - 1) / W;
+    const f32x4* hv = reinterpret_cast<const f32x4*>(vec) + (lane / DP) * GS;
+    f32x4 wq4[GP], xv[GP];
+#pragma unroll
+    for (int q = 0; q < GP; q++) {
+      const int g = wv * GP + q, gc = g < GS ? g : GS - 1;
+      wq4[q] = ns[gc * 64 + lane];
+      xv[q] = hv[gc];
+      if (g >= GS) xv[q] = f32x4{0.f, 0.f, 0.f, 0.f};   // (wave-uniform: a group beyond the range contributes zeros)
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x2 p01 = {0.f, 0.f}, p23 = {0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < GP; q++) {
+      p01 += wq4[q].lo * xv[q].lo;
+      p23 += wq4[q].hi * xv[q].hi;
+    }
+    return xor_segs((p01.x + p01.y) + (p23.x + p23.y));
+  };
 
   // one evaluation of the (augmented) right-hand side: src → dst; its vectors stay in ring slot `slot`
   auto eval = [&](float src, int slot) -> float {
@@ -418,7 +444,12 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
     }
     __syncthreads();
     PROF_T(e2);
-    const float f = narrow(n3, h2v) + b3;
+    float f = 0.f;
+    if (KSPLIT) {
+      const float pf = narrow_part(n3, h2v);
+      if (lane < DP) s_np[wv * DP + lane] = pf;
+    } else
+      f = narrow(n3, h2v) + b3;
     float dst = is_z ? f : 0.f;
     PROF_ADD(3, e0, e1);
     PROF_ADD(4, e1, e2);
@@ -434,7 +465,17 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
       const float d1 = u < H1 ? g1 * act_grad(act, h1) : 0.f;
       if (u < HV) d1v[u] = d1;
       __syncthreads();
-      const float vz = narrow(n1, d1v);     // every lane with lane % DP == d holds vz_d
+      float vz;
+      if (KSPLIT) {
+        const int dd = lane % DP;
+        f = b3 + ((s_np[dd] + s_np[DP + dd]) + (s_np[2 * DP + dd] + s_np[3 * DP + dd]));   // the same order in every wave: the same bits
+        dst = is_z ? f : 0.f;
+        const float pv = narrow_part(n1, d1v);
+        if (lane < DP) s_np[(W + wv) * DP + lane] = pv;
+        __syncthreads();
+        vz = (s_np[W * DP + dd] + s_np[(W + 1) * DP + dd]) + (s_np[(W + 2) * DP + dd] + s_np[(W + 3) * DP + dd]);
+      } else
+        vz = narrow(n1, d1v);     // every lane with lane % DP == d holds vz_d
       if (is_l) dst = -vz;
       PROF_T(e3);
       PROF_ADD(5, e2, e3);

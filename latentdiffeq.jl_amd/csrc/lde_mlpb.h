@@ -582,21 +582,26 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
     dt = o.adaptive ? fmin(o.dt_fixed, dtmax) : o.dt_fixed;
     running = begin_step();
   }
+  // the step control is wave-uniform (every lane computes the same values): it is kept in scalar registers across the evaluations —
+  // made scalar wherever it has been through vector arithmetic (the step-end block, the two probes of the initial step size), not once
+  // per evaluation (21 v_readfirstlane)
+  auto scalarise = [&]() {
+    s = __builtin_amdgcn_readfirstlane(s);
+    phase = __builtin_amdgcn_readfirstlane(phase);
+    status = __builtin_amdgcn_readfirstlane(status);
+    j = __builtin_amdgcn_readfirstlane(j); last = __builtin_amdgcn_readfirstlane(last); hit = __builtin_amdgcn_readfirstlane(hit);
+    nfe = __builtin_amdgcn_readfirstlane(nfe); nacc = __builtin_amdgcn_readfirstlane(nacc); nrej = __builtin_amdgcn_readfirstlane(nrej);
+    iters = sgpr_ll(iters);
+    t = sgpr_d(t); dt = sgpr_d(dt); tnew = sgpr_d(tnew);
+    h = sgpr_f(h); qold = sgpr_f(qold); wq = sgpr_f(wq); d1n = sgpr_f(d1n);
+  };
   while (__builtin_amdgcn_readfirstlane((int)running)) {
     // inner loop: the evaluations of one unit of work (the two probes of the initial step size, or the stages of one step attempt) — the
     // weight-gradient tiles are touched only outside it, in the step-end block below
     bool step_end = false;
     float s2 = 0.f, s2b = 0.f;
+    scalarise();
     do {
-      // the step control is wave-uniform (every lane computes the same values): keep it in scalar registers across the evaluation
-      s = __builtin_amdgcn_readfirstlane(s);
-      phase = __builtin_amdgcn_readfirstlane(phase);
-      status = __builtin_amdgcn_readfirstlane(status);
-      j = __builtin_amdgcn_readfirstlane(j); last = __builtin_amdgcn_readfirstlane(last); hit = __builtin_amdgcn_readfirstlane(hit);
-      nfe = __builtin_amdgcn_readfirstlane(nfe); nacc = __builtin_amdgcn_readfirstlane(nacc); nrej = __builtin_amdgcn_readfirstlane(nrej);
-      iters = sgpr_ll(iters);
-      t = sgpr_d(t); dt = sgpr_d(dt); tnew = sgpr_d(tnew);
-      h = sgpr_f(h); qold = sgpr_f(qold); wq = sgpr_f(wq); d1n = sgpr_f(d1n);
       PROF_T(l0);
   #if LDE_PROF
       struct ProfEnd { long long t0; __device__ ~ProfEnd() { PROF_T(t1); PROF_ADD(11, t0, t1); } } prof_end{l0};
@@ -645,6 +650,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
         phase = PH_STAGE;
         s = 1;
         running = begin_step();
+        scalarise();
       } else if (phase == PH_K0) {
         // Hairer–Nørsett–Wanner, part 1
         const float sk = fast_rcp(o.abstol + fabsf(y) * o.reltol);
@@ -663,6 +669,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
         h = status == 0 ? dirn * (float)dt0 : 0.f;
         tmp = y + h * k[0];
         phase = PH_INIT1;
+        scalarise();
       } else if (phase == PH_INIT1) {
         const float dd = (k[1] - k[0]) * scr;
         float w0 = wave_sum64(counted ? dd * dd : 0.f), w1 = 0.f;
@@ -679,6 +686,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
         phase = PH_STAGE;
         s = ADJ ? 0 : 1;
         running = begin_step();
+        scalarise();
       } else if (s < LAST_STAGE) {
         s++;
       } else if (SPEC && s == LAST_STAGE) {   // the attempt's slopes are complete: its error sum leaves for the grid, and — behind a save time —

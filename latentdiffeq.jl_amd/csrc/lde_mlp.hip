@@ -2081,7 +2081,7 @@ static int launch_b(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t
 static size_t c_lds_base(int T, bool adj, int nst) {
   const int nsl = adj ? nst + 1 : 1;
   return (((size_t)T * 8 + 15) & ~size_t(15)) + (size_t)(nsl * mlpc::SLOT + (adj ? 16 * mlpc::HV : 0) + 16 * 16 * 4) * 4 +
-         (size_t)128 * mlpc::W13S * 4 + (adj ? (size_t)mlpc::GS * 64 * 16 : 0) + 16;
+         (size_t)128 * mlpc::W13S * 4 + (adj ? (size_t)mlpc::GS * 64 * 16 + 4 * mlpc::DP * 2 * 4 : 0) + 16;
 }
 static bool c_applicable(const MlpPlan* p, int B, int T, bool adj, bool coupled_adaptive) {
   const char* e = getenv("LDE_MLPB");    // (the switches of k_mlpb: 0 = k_mlpw instead — the parity reference)

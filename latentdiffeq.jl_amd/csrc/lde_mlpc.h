@@ -96,7 +96,8 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
   float* fpart = part + (ADJ ? 16 * HV : 0);   // f = W₃h₂: the 16 row groups' partial sums, [r][c][output 2c + h][trajectory]
   float* w13 = fpart + 16 * 16 * 4;
   f32x4* n1 = reinterpret_cast<f32x4*>(w13 + 128 * W13S);
-  float* s_cot = reinterpret_cast<float*>(n1 + (ADJ ? GS * 64 : 0));          // adjoint: the two trajectories' cotangents (and saved states) by save time: [t][T][Dp] (+ the same for ẑ)
+  float* s_np = reinterpret_cast<float*>(n1 + (ADJ ? GS * 64 : 0));           // adjoint: the waves' partial outputs of the K-split narrow product, [wave][D′][trajectory]
+  float* s_cot = s_np + (ADJ ? 4 * DP * 2 : 0);                               // adjoint: the two trajectories' cotangents (and saved states) by save time: [t][T][Dp] (+ the same for ẑ)
   for (int i = tid; i < T; i += UT) s_ts[i] = a.ts[i];
   for (int i = tid; i < NSL * SLOT + (ADJ ? 16 * HV : 0); i += UT) ring[i] = 0.f;
   {
@@ -235,6 +236,31 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
     const f32x2 p = p0 + p1;
     return f32x2{swap_sum<32>(p.x), swap_sum<32>(p.y)};
   };
+  // the same product split over the four waves along K (as k_mlpb's KSPLIT): this wave's four of the sixteen read groups — 12 LDS reads in
+  // flight together instead of 48 that the register pressure serialises — and the partial outputs meet in s_np behind a barrier
+  auto narrow_part = [&](const float* vec) -> f32x2 {
+    constexpr int GP = GS / 4;
+    const f32x4* hv = reinterpret_cast<const f32x4*>(vec) + (lane / DP) * GS * 2;
+    f32x4 wq4[GP], x01[GP], x23[GP];
+#pragma unroll
+    for (int q = 0; q < GP; q++) {
+      const int g = wv * GP + q;
+      wq4[q] = n1[g * 64 + lane];
+      x01[q] = hv[2 * g];
+      x23[q] = hv[2 * g + 1];
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    f32x2 p0 = {0.f, 0.f}, p1 = {0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < GP; q++) {
+      p0 += f32x2{wq4[q].x, wq4[q].x} * x01[q].lo;
+      p1 += f32x2{wq4[q].y, wq4[q].y} * x01[q].hi;
+      p0 += f32x2{wq4[q].z, wq4[q].z} * x23[q].lo;
+      p1 += f32x2{wq4[q].w, wq4[q].w} * x23[q].hi;
+    }
+    const f32x2 p = p0 + p1;
+    return f32x2{swap_sum<32>(p.x), swap_sum<32>(p.y)};
+  };
 
   // one evaluation of the (augmented) right-hand side for both trajectories: src → dst; its vectors stay in ring slot `slot`
   auto eval = [&](const float (&src)[2], int slot, float (&dst)[2]) {
@@ -354,7 +380,11 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
       const float d1 = u < H1 ? g1 * act_grad(act, h1) : 0.f;
       d1v[2 * u + ut] = d1;
       __syncthreads();
-      const f32x2 vz = narrow(d1v);     // every lane with lane % 32 == d holds vz_d of A and B
+      const f32x2 pvz = narrow_part(d1v);
+      if (lane < DP) reinterpret_cast<f32x2*>(s_np)[wv * DP + lane] = pvz;
+      __syncthreads();
+      const f32x2* qz = reinterpret_cast<const f32x2*>(s_np) + (lane % DP);
+      const f32x2 vz = (qz[0] + qz[DP]) + (qz[2 * DP] + qz[3 * DP]);   // every lane with lane % 32 == d holds vz_d of A and B (the same order in every wave)
       if (is_l) { dst[0] = -vz.x; dst[1] = -vz.y; }
       PROF_T(e3);
       PROF_ADD(5, e2, e3);

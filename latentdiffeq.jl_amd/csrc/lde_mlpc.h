@@ -273,24 +273,32 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
     const f32x4* x4 = reinterpret_cast<const f32x4*>(xs + 64 * ut);
     float h1;
     {
+      // (the sixteen reads of a thin product are issued before its first multiplication waits for one — the compiler's own order was eight,
+      //  then two at a time: five LDS round trips per product)
+      f32x4 xv[G1], wv4[G1];
+#pragma unroll
+      for (int g = 0; g < G1; g++) { xv[g] = x4[g]; wv4[g] = my13[g]; }
+      __builtin_amdgcn_sched_barrier(0);
       f32x2 c01 = {0.f, 0.f}, c23 = {0.f, 0.f};
 #pragma unroll
       for (int g = 0; g < G1; g++) {
-        const f32x4 xv = x4[g], wv4 = my13[g];
-        c01 += wv4.lo * xv.lo;
-        c23 += wv4.hi * xv.hi;
+        c01 += wv4[g].lo * xv[g].lo;
+        c23 += wv4[g].hi * xv[g].hi;
       }
       const float a1 = b1 + ((c01.x + c01.y) + (c23.x + c23.y));
       h1 = u == H1 ? 1.f : act_fn(act, a1);   // unit H₁ (when < 128): the constant that carries b₂ (rows beyond: zero weights and bias ⇒ act(0) = 0)
     }
     h1v[2 * u + ut] = h1;
     if (ADJ) {
+      f32x4 xv[G1], wv4[G1];
+#pragma unroll
+      for (int g = 0; g < G1; g++) { xv[g] = x4[G1 + g]; wv4[g] = my13[G1 + g]; }   // λ
+      __builtin_amdgcn_sched_barrier(0);
       f32x2 c01 = {0.f, 0.f}, c23 = {0.f, 0.f};
 #pragma unroll
       for (int g = 0; g < G1; g++) {
-        const f32x4 xv = x4[G1 + g], wv4 = my13[G1 + g];   // λ
-        c01 += wv4.lo * xv.lo;
-        c23 += wv4.hi * xv.hi;
+        c01 += wv4[g].lo * xv[g].lo;
+        c23 += wv4[g].hi * xv[g].hi;
       }
       d2v[2 * u + ut] = (c01.x + c01.y) + (c23.x + c23.y);   // (W₃ᵀλ)_u; becomes δ₂ below
     }

@@ -151,30 +151,39 @@ __device__ __forceinline__ void w_grid_collect(const GridSync& gs, unsigned gen,
     return;
   }
   unsigned long long* slots = reinterpret_cast<unsigned long long*>(gs.slots) + (size_t)(gen & 1) * gs.nwg * 2;
+  // ONE wave of the workgroup polls (and adds, in index order: the same bits in every workgroup); the others pick the sums up from LDS
+  // behind the barrier that makes the decision workgroup-uniform anyway. With every wave polling, 1 024 waves read all 256 words in
+  // every round of the spin: four times the L2 traffic in front of the words that are still on their way.
+  __shared__ float s_gsum[2][2];   // by generation parity: the sum after the next one rewrites a word, and this workgroup's barrier of the next sum lies between
   float p0 = 0.f, p1 = 0.f;
   bool aborted = false;
-  for (int w = threadIdx.x & 63; w < gs.nwg; w += 64) {
-    unsigned long long q0, q1 = 0;
-    long long spins = 0;
-    for (;;) {
-      q0 = __hip_atomic_load(slots + (size_t)w * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (TWO) q1 = __hip_atomic_load(slots + (size_t)w * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if ((unsigned)(q0 >> 32) == tag && (!TWO || (unsigned)(q1 >> 32) == tag)) break;
-      __builtin_amdgcn_s_sleep(1);
-      if ((++spins & 4095) == 0 &&
-          (spins > 20000000LL || __hip_atomic_load(gs.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-        // a peer is not resident (the launch is cooperative: cannot happen) — give up instead of hanging
-        __hip_atomic_store(gs.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        aborted = true;
-        break;
+  if (threadIdx.x < 64) {
+    for (int w = threadIdx.x; w < gs.nwg; w += 64) {
+      unsigned long long q0, q1 = 0;
+      long long spins = 0;
+      for (;;) {
+        q0 = __hip_atomic_load(slots + (size_t)w * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (TWO) q1 = __hip_atomic_load(slots + (size_t)w * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(q0 >> 32) == tag && (!TWO || (unsigned)(q1 >> 32) == tag)) break;
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 4095) == 0 &&
+            (spins > 20000000LL || __hip_atomic_load(gs.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          // a peer is not resident (the launch is cooperative: cannot happen) — give up instead of hanging
+          __hip_atomic_store(gs.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          aborted = true;
+          break;
+        }
       }
+      p0 += __uint_as_float((unsigned)q0);
+      p1 += __uint_as_float((unsigned)q1);
     }
-    p0 += __uint_as_float((unsigned)q0);
-    p1 += __uint_as_float((unsigned)q1);
+    p0 = wave_sum64(p0);
+    if (TWO) p1 = wave_sum64(p1);
+    if (threadIdx.x == 0) { s_gsum[gen & 1][0] = p0; s_gsum[gen & 1][1] = p1; }
   }
   aborted = __syncthreads_or(aborted ? 1 : 0) != 0;   // the waves of a workgroup must take the same decision
-  v0 = aborted ? __int_as_float(0x7fc00000) : wave_sum64(p0);   // a timed-out barrier poisons the sums: retcode != 0
-  if (TWO) v1 = aborted ? __int_as_float(0x7fc00000) : wave_sum64(p1);
+  v0 = aborted ? __int_as_float(0x7fc00000) : s_gsum[gen & 1][0];   // a timed-out barrier poisons the sums: retcode != 0
+  if (TWO) v1 = aborted ? __int_as_float(0x7fc00000) : s_gsum[gen & 1][1];
   w_host_sum<TWO>(gs, tag, v0, v1);
   PROF_T(g1);
   PROF_ADD(12, g0, g1);

@@ -2009,9 +2009,9 @@ static int launch_w(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t
 }
 
 // ---- four waves per trajectory, W₂ as register blocks, the weight gradient folded on the CU (lde_mlpb.h)
-static size_t b_lds_base(const BDims& bd, int T, bool adj, int nst, bool low = false) {   // save times, ring (+ partial sums), narrow slices
+static size_t b_lds_base(const BDims& bd, int T, bool adj, int nst) {   // save times, ring (+ partial sums), narrow slices
   const int nsl = adj ? nst + 1 : 1;
-  return (((size_t)T * 8 + 15) & ~size_t(15)) + (size_t)(nsl * mlpb::SLOT + (adj ? 16 * mlpb::HV + (mlpb::NTL - mlpb::ntr(bd.DP, nst, low)) * mlpb::UT * 4 : 0)) * 4 +
+  return (((size_t)T * 8 + 15) & ~size_t(15)) + (size_t)(nsl * mlpb::SLOT + (adj ? 16 * mlpb::HV : 0)) * 4 +
          (size_t)bd.GS * 64 * 16 * (adj ? 2 : 1) + (size_t)mlpb::HV * (2 * bd.DP + 4) * 4 + 16 + ((adj && bd.DP == 16) ? 2 * mlpb::W * 16 * 4 : 0);
 }
 static bool b_applicable(const MlpPlan* p, int B, int T, bool adj, bool coupled_adaptive) {
@@ -2036,20 +2036,14 @@ static int launch_b(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t
   const bool d8 = bdv.DP == 8;
   const bool tanh_ = dmv.act == LDE_ACT_TANH;
   const size_t cot = ADJ ? (size_t)o.T * dmv.Dp * 4 * (o.checkpoint ? 2 : 1) : 0;
-  // RK4's adjoint with fewer register tiles (mlpb::ntr) when the eight LDS tiles more — and the cotangents beside them — fit
-  constexpr bool CAN_LOW = false;   // (the tiles are hidden AGPRs now: no LDS tiles, one variant)
-  const bool low = CAN_LOW && cot <= 40 * 1024 && b_lds_base(bdv, o.T, ADJ, 4, true) + cot <= LDS_MAX;
   const void* fn = tanh_ ? (d8 ? (const void*)k_mlpb<SOLVER, 8, LDE_ACT_TANH, ADJ> : (const void*)k_mlpb<SOLVER, 16, LDE_ACT_TANH, ADJ>)
                          : (d8 ? (const void*)k_mlpb<SOLVER, 8, LDE_ACT_RELU, ADJ> : (const void*)k_mlpb<SOLVER, 16, LDE_ACT_RELU, ADJ>);
-  if (low)
-    fn = tanh_ ? (d8 ? (const void*)k_mlpb<SOLVER, 8, LDE_ACT_TANH, ADJ, CAN_LOW> : (const void*)k_mlpb<SOLVER, 16, LDE_ACT_TANH, ADJ, CAN_LOW>)
-               : (d8 ? (const void*)k_mlpb<SOLVER, 8, LDE_ACT_RELU, ADJ, CAN_LOW> : (const void*)k_mlpb<SOLVER, 16, LDE_ACT_RELU, ADJ, CAN_LOW>);
-  size_t lds = b_lds_base(bdv, o.T, ADJ, SOLVER == LDE_SOLVER_RK4 ? 4 : 6, low);
+  size_t lds = b_lds_base(bdv, o.T, ADJ, SOLVER == LDE_SOLVER_RK4 ? 4 : 6);
   a.cot_lds = ADJ && cot <= 40 * 1024 && lds + cot <= LDS_MAX;   // the trajectory's dẑ (and saved ẑ) by save time: no global load inside the solve
   if (a.cot_lds) lds += cot;
   {   // dynamic LDS beyond the default limit needs the attribute, once per instantiation
-    static bool attr_set[2][2][2] = {};
-    if (!attr_set[d8][tanh_][low]) {
+    static bool attr_set[2][2] = {};
+    if (!attr_set[d8][tanh_]) {
       hipFuncAttributes fa{};
       (void)hipFuncGetAttributes(&fa, fn);
       const hipError_t ea = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX - (int)fa.sharedSizeBytes);
@@ -2058,7 +2052,7 @@ static int launch_b(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t
         err = std::string("hipFuncSetAttribute(k_mlpb) failed: ") + hipGetErrorString(ea);
         return LDE_ERR_HIP;
       }
-      attr_set[d8][tanh_][low] = true;
+      attr_set[d8][tanh_] = true;
     }
   }
   a.wpack = p->bpack;

@@ -54,6 +54,7 @@ constexpr int NTL = 51;               // weight-gradient tile slots of a wave: 3
 // these kernels may write an AGPR ≥ A0 except the asm's own three forms; a violation fails the build.
 constexpr int NTH = 51;               // tiles per wave in hidden AGPRs (all of them)
 constexpr int A0 = 256 - 4 * NTH;     // the compiler's AGPRs: a[0 : A0)
+static_assert(NTH == NTL, "every tile slot of a wave is a hidden register tile (there is no LDS tile path any more)");
 // tile at a[R : R + 3] += av ⊗ bv (K = the four lane groups). The two wait states in front of the MFMA are the VALU → MFMA-operand distance
 // (the compiler pads nothing inside an asm string); an MFMA that takes the previous one's D whole as its C needs none.
 template <int R>
@@ -84,7 +85,6 @@ __device__ __forceinline__ void static_for(F&& f) {
     static_for<B_ + 1, E_>(f);
   }
 }
-constexpr int ntr(int, int, bool) { return NTH; }   // (tiles not in LDS; the LDS path below serves NTH < NTL)
 }  // namespace mlpb
 
 // one-time packing (set_weights): everything in the order the kernel's lanes read it
@@ -148,7 +148,7 @@ __device__ __forceinline__ long long sgpr_ll(long long v) {
 }
 __device__ __forceinline__ double sgpr_d(double v) { return __builtin_bit_cast(double, sgpr_ll(__builtin_bit_cast(long long, v))); }
 
-template <int SOLVER, int DP, int ACT, bool ADJ, bool LOW = false>
+template <int SOLVER, int DP, int ACT, bool ADJ>
 __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, VArgs a) {
   using namespace mlpb;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -161,19 +161,17 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
   // its vectors sit in the spare ring slot and move to slot 0 at accept. Same evaluations on the same inputs — the same bits, fewer of them.
   constexpr bool SPEC = ADJ && SOLVER == LDE_SOLVER_TSIT5;
   constexpr int W13S = 2 * DP + 4;
-  constexpr int NTR = ntr(DP, SOLVER == LDE_SOLVER_TSIT5 ? 6 : 4, LOW);
   static_assert(DP == 8 || DP == 16, "k_mlpb geometry");
   const int T = o.T, B = o.B, D = dm.D, Dp = dm.Dp, tid = threadIdx.x, lane = tid & 63, b = blockIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int u = tid;                      // the hidden unit this lane owns in the thin products
   const int br = tid >> 4, bc = tid & 15; // block coordinates
   const int H1 = dm.sizes[1], H2 = dm.sizes[2];
-  // ---- LDS: save times | ring | partial sums of W₂ᵀδ₂ | narrow slices | cotangents
+  // ---- LDS: save times | ring | partial sums of W₂ᵀδ₂ | narrow slices | thin-layer weights | K-split partials | cotangents
   double* s_ts = reinterpret_cast<double*>(smem);
   float* ring = reinterpret_cast<float*>(smem + (((size_t)T * 8 + 15) & ~size_t(15)));
   float* part = ring + NSL * SLOT;
-  f32x4* ltile = reinterpret_cast<f32x4*>(part + (ADJ ? 16 * HV : 0));
-  f32x4* n3 = ltile + (ADJ ? (NTL - NTR) * UT : 0);
+  f32x4* n3 = reinterpret_cast<f32x4*>(part + (ADJ ? 16 * HV : 0));
   f32x4* n1 = n3 + GS * 64;
   float* w13 = reinterpret_cast<float*>(n1 + (ADJ ? GS * 64 : 0));     // rows of W₁ | columns of W₃ by unit: [HV][2·DP + 4]
   // KSPLIT (adjoint, D′ = 16): the two H → D′ products are split over the four waves along K — a quarter of the 14 read groups each,
@@ -183,7 +181,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
   float* s_np = w13 + HV * W13S;                                       // [2 products][4 waves][D′] partial outputs (KSPLIT)
   float* s_cot = s_np + (KSPLIT ? 2 * W * DP : 0);                     // adjoint: the trajectory's cotangents (and saved states) by save time
   for (int i = tid; i < T; i += UT) s_ts[i] = a.ts[i];
-  for (int i = tid; i < NSL * SLOT + (ADJ ? 16 * HV + (NTL - NTR) * UT * 4 : 0); i += UT) ring[i] = 0.f;
+  for (int i = tid; i < NSL * SLOT + (ADJ ? 16 * HV : 0); i += UT) ring[i] = 0.f;
   {
     const f32x4* g3 = reinterpret_cast<const f32x4*>(a.wpack + bd.o_n3);
     for (int i = tid; i < GS * 64; i += UT) n3[i] = g3[i];
@@ -217,7 +215,6 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
   const float b1 = a.wpack[bd.o_b1 + u], b3 = a.wpack[bd.o_b3 + (lane % DP)];
   constexpr int act = ACT;   // (compile-time: a run-time activation is a branch per call, and the block product applies it 13 times per lane)
   // the weight gradient: accumulator-resident 16×16 tiles (C/D layout of v_mfma_f32_16x16x4_f32: column = lane & 15, row = 4·(lane >> 4) + reg)
-  // (of a wave's NTL tile slots the first NTR stay in registers; the others live in LDS, a 1 KB word array per slot and wave)
   float gb1 = 0.f, gb3 = 0.f;
   if (ADJ) {
     asm volatile("" ::: "a255");   // the kernel owns all 512 registers of a lane

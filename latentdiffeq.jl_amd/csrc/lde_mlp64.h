@@ -78,11 +78,19 @@ __device__ __forceinline__ void net64_rhs(Net64<DP>& n, const float (&z)[DP], fl
   {
     const f32x4* hv = reinterpret_cast<const f32x4*>(n.hx);
     f32x2 c01 = {0.f, 0.f}, c23 = {0.f, 0.f};
+    // (eight broadcast reads in flight per batch: left alone the compiler rotates three buffers — three reads in flight, sixteen times)
 #pragma unroll
-    for (int g = 0; g < 16; g++) {
-      const f32x4 xv = hv[g];
-      c01 += n.w2r[2 * g] * xv.lo;
-      c23 += n.w2r[2 * g + 1] * xv.hi;
+    for (int g0 = 0; g0 < 16; g0 += 8) {
+      f32x4 xv[8];
+#pragma unroll
+      for (int g = 0; g < 8; g++) xv[g] = hv[g0 + g];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < 8; g++) {
+        c01 += n.w2r[2 * (g0 + g)] * xv[g].lo;
+        c23 += n.w2r[2 * (g0 + g) + 1] * xv[g].hi;
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     a2 += (c01.x + c01.y) + (c23.x + c23.y);
   }
@@ -109,11 +117,19 @@ __device__ __forceinline__ void net64_vjp(const Net64<DP>& n, const float (&z)[D
   {
     const f32x4* hv = reinterpret_cast<const f32x4*>(n.hx + 64);
     f32x2 c01 = {0.f, 0.f}, c23 = {0.f, 0.f};
+    // (eight broadcast reads in flight per batch: left alone the compiler rotates three buffers — three reads in flight, sixteen times)
 #pragma unroll
-    for (int g = 0; g < 16; g++) {
-      const f32x4 xv = hv[g];
-      c01 += n.w2c[2 * g] * xv.lo;
-      c23 += n.w2c[2 * g + 1] * xv.hi;
+    for (int g0 = 0; g0 < 16; g0 += 8) {
+      f32x4 xv[8];
+#pragma unroll
+      for (int g = 0; g < 8; g++) xv[g] = hv[g0 + g];
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < 8; g++) {
+        c01 += n.w2c[2 * (g0 + g)] * xv[g].lo;
+        c23 += n.w2c[2 * (g0 + g) + 1] * xv[g].hi;
+      }
+      __builtin_amdgcn_sched_barrier(0);
     }
     s1 = (c01.x + c01.y) + (c23.x + c23.y);
   }

@@ -74,6 +74,16 @@ enum lde_batching {
 enum lde_sensealg {
   LDE_SENSE_BACKSOLVE_CHECKPOINTED = 0, /* reverse-time adjoint, z re-integrated backwards and reset to the saved ẑ(t_j) at every save time */
   LDE_SENSE_BACKSOLVE              = 1, /* same without the reset (BacksolveAdjoint, hinted at [REF nODE.jl:17]) */
+  LDE_SENSE_DISCRETE               = 3, /* discrete (exact) sensitivity: the derivative of the DISCRETE solve on its accepted step sequence, step sizes held
+                                           constant — what the reference's GOKU default ForwardDiffSensitivity() delivers
+                                           [REF examples/pendulum_friction-less/pendulum.jl:11], [REF src/models/GOKU.jl:107, :121] (there by dual numbers
+                                           through the stepper, here by reverse mode: same derivative). lde_forward records (t_n, dt_n, y_n) per accepted
+                                           step (lde_set_step_record / the handle's own buffer); lde_adjoint sweeps those steps in reverse: the stages are
+                                           rebuilt from y_n, the cotangent is pulled through the stage sums, through the dense-output weights b_i(Θ_j) of
+                                           every save time inside the step and through the FSAL slope; no controller, no forced stops, no error norm.
+                                           lde_adjoint must follow the lde_forward that made the record (same B, T, ts). One deviation from upstream, stated:
+                                           under dual numbers OrdinaryDiffEq's error norm also counts the partials, so the reference's accepted step
+                                           sequence under ForwardDiffSensitivity differs from its primal solve's; here the primal sequence is used. */
   LDE_SENSE_PARALLEL_CHECKPOINTED  = 2  /* checkpointed adjoint, parallel in time: with z reset at every save time the T-1 save
                                            intervals are independent and λ enters linearly, so each (trajectory, interval) pair
                                            integrates the interval's transition operator (λ_j = M_j λ_{j+1}, g += n_j·λ_{j+1}) on

@@ -445,9 +445,21 @@ static real pi_q(real EEst, real qold, const sopts* o, real* q11_out) {
   return q;
 }
 
+/* The accepted steps of ONE solve (one per trajectory, or one for a coupled solve): start time and step size of step n. Written by an
+ * adaptive solve (presc = 0) or READ by a solve that is to take exactly these steps (presc = 1: no error control, every step is
+ * accepted) — the latter is how the tests give the checker the step sequence a kernel recorded, so that the two are compared on the
+ * SAME discrete solve instead of through two step-size controllers that wander apart (tests/test_gpu_discrete.py). */
+typedef struct {
+  double* t;     /* [cap] (forward only; NULL in a reverse-time record) */
+  double* dt;    /* [cap] step size (forward) / magnitude (reverse) as f64; the state advances by (real)dt */
+  int32_t* n;    /* steps recorded / prescribed */
+  int cap;
+  int presc;
+} steprec;
+
 /* Forward solve with saveat: out[j*n + i] = y_i(ts[j]). dt_trace (optional): accepted dt's. */
 static void solve_forward(ode_fn fn, void* ctx, int64_t n, const real* y0, const double* ts, int T, const sopts* o,
-                          real* out, sstat* st, double* dt_trace, int* n_trace, int max_trace) {
+                          real* out, sstat* st, double* dt_trace, int* n_trace, int max_trace, steprec* rec) {
   rkwork w;
   rkwork_init(&w, n);
   real* y = (real*)malloc((size_t)n * sizeof(real));
@@ -467,18 +479,25 @@ static void solve_forward(ode_fn fn, void* ctx, int64_t n, const real* y0, const
       dt = o->dt_fixed;
     real qold = (real)1e-4;
     int64_t iters = 0;
+    const int presc = rec && rec->presc;
+    int adaptive = o->adaptive && !presc;
     while (t < tend) {
       if (iters++ >= o->maxiters) { st->retcode = LDE_RET_MAXITERS; break; }
       double dtp = dt; /* controller proposal */
       int last = 0;
-      if (t + dt >= tend - 1e-12 * fabs(tend)) { dt = tend - t; last = 1; }
+      if (presc) {   /* step ntr of the prescribed sequence: its recorded start time and size; the last one ends at tend */
+        if (ntr >= *rec->n) { st->retcode = LDE_RET_MAXITERS; break; }
+        t = rec->t[ntr];
+        dt = rec->dt[ntr];
+        last = ntr == *rec->n - 1;
+      } else if (t + dt >= tend - 1e-12 * fabs(tend)) { dt = tend - t; last = 1; }
       real EEst = 0;
       if (o->solver == LDE_SOLVER_TSIT5)
         EEst = tsit5_attempt(fn, ctx, &w, t, dt, y, 0, 0.0, o, st);
       else
         rk4_step(fn, ctx, &w, t, dt, y, 0, 0.0, 1, st);
       if (!all_finite(w.ynew, n) || !(EEst == EEst)) {
-        if (o->adaptive && dt > o->dtmin) { /* treat as a rejected step with maximal shrink */
+        if (adaptive && dt > o->dtmin) { /* treat as a rejected step with maximal shrink */
           st->nrej++;
           dt = dt * o->qmin;
           continue;
@@ -486,7 +505,7 @@ static void solve_forward(ode_fn fn, void* ctx, int64_t n, const real* y0, const
         st->retcode = LDE_RET_NONFINITE;
         break;
       }
-      if (o->adaptive) {
+      if (adaptive) {
         real q11, q = pi_q(EEst, qold, o, &q11);
         if (EEst > (real)1) {
           st->nrej++;
@@ -500,8 +519,9 @@ static void solve_forward(ode_fn fn, void* ctx, int64_t n, const real* y0, const
       }
       st->nacc++;
       if (dt_trace && ntr < max_trace) dt_trace[ntr] = dt;
+      if (rec && !presc && ntr < rec->cap) { rec->t[ntr] = t; rec->dt[ntr] = dt; }
       ntr++;
-      double tnew = last ? tend : t + dt;
+      double tnew = last ? tend : (presc ? rec->t[ntr] : t + dt);
       while (j < T && ts[j] <= tnew) {
         double th = (ts[j] - t) / dt;
         real* o_j = out + (int64_t)j * n;
@@ -531,6 +551,7 @@ static void solve_forward(ode_fn fn, void* ctx, int64_t n, const real* y0, const
       t = tnew;
       dt = o->adaptive ? dtp : o->dt_fixed;
     }
+    if (rec && !presc) *rec->n = ntr;   /* (> cap: the record is incomplete — the caller checks) */
   }
   if (st->retcode != LDE_RET_SUCCESS) {
     for (int64_t i = 0; i < (int64_t)T * n; i++) out[i] = (real)NAN;
@@ -545,7 +566,7 @@ static void solve_forward(ode_fn fn, void* ctx, int64_t n, const real* y0, const
  * begin/commit/discard bracket the dW quadrature of one step attempt. */
 typedef void (*jump_fn)(void* ctx, int j, real* y);
 static void solve_backward(ode_fn fn, void* ctx, int64_t n, real* y, const double* ts, int T, const sopts* o,
-                           jump_fn jump, hook_fn begin, hook_fn commit, sstat* st) {
+                           jump_fn jump, hook_fn begin, hook_fn commit, sstat* st, steprec* rec) {
   rkwork w;
   rkwork_init(&w, n);
   st->retcode = LDE_RET_SUCCESS;
@@ -564,10 +585,17 @@ static void solve_backward(ode_fn fn, void* ctx, int64_t n, real* y, const doubl
     real qold = (real)1e-4;
     int64_t iters = 0;
     int j = T - 2;
+    const int presc = rec && rec->presc;
+    const int adaptive = o->adaptive && !presc;
+    int ntr = 0;
     while (j >= 0) {
       if (iters++ >= o->maxiters) { st->retcode = LDE_RET_MAXITERS; break; }
       double tstop = ts[j];
       double dist = t - tstop;
+      if (presc) {   /* the recorded magnitude of accepted step ntr (already clipped to its save time where it hit one) */
+        if (ntr >= *rec->n) { st->retcode = LDE_RET_MAXITERS; break; }
+        dt = rec->dt[ntr];
+      }
       double h = dt;
       int hit = 0;
       if (h >= dist * (1.0 - 1e-12)) { h = dist; hit = 1; }
@@ -578,12 +606,12 @@ static void solve_backward(ode_fn fn, void* ctx, int64_t n, real* y, const doubl
       else
         rk4_step(fn, ctx, &w, t, -h, y, 1, h, 0, st);
       if (!all_finite(w.ynew, n) || !(EEst == EEst)) {
-        if (o->adaptive && h > o->dtmin) { st->nrej++; dt = h * o->qmin; continue; }
+        if (adaptive && h > o->dtmin) { st->nrej++; dt = h * o->qmin; continue; }
         st->retcode = LDE_RET_NONFINITE;
         break;
       }
       double dtp = dt;
-      if (o->adaptive) {
+      if (adaptive) {
         real q11, q = pi_q(EEst, qold, o, &q11);
         if (EEst > (real)1) {
           st->nrej++;
@@ -596,6 +624,8 @@ static void solve_backward(ode_fn fn, void* ctx, int64_t n, real* y, const doubl
         if (dtp > dtmax) dtp = dtmax;
       }
       st->nacc++;
+      if (rec && !presc && ntr < rec->cap) rec->dt[ntr] = h;
+      ntr++;
       if (commit) commit(ctx);
       memcpy(y, w.ynew, (size_t)n * sizeof(real));
       if (hit) {
@@ -606,6 +636,7 @@ static void solve_backward(ode_fn fn, void* ctx, int64_t n, real* y, const doubl
         t -= h;
       dt = o->adaptive ? dtp : o->dt_fixed;
     }
+    if (rec && !presc) *rec->n = ntr;
   }
   rkwork_free(&w);
 }
@@ -742,9 +773,9 @@ static int check_desc(const lde_problem_desc* d) {
 
 /* out layouts as in include/lde.h. stats: [nfe, naccept, nreject, nfailed, max_steps].
  * dt_trace/n_trace: accepted step sizes of trajectory 0 (or of the coupled solve). */
-int oracle_forward(const lde_problem_desc* d, const real* W, const real* z0, const real* theta, const double* ts, int T,
-                   int B, real* z_out, int32_t* retcode, int64_t* stats, double* dt_trace, int* n_trace, int max_trace,
-                   int nthreads) {
+static int forward_impl(const lde_problem_desc* d, const real* W, const real* z0, const real* theta, const double* ts, int T,
+                        int B, real* z_out, int32_t* retcode, int64_t* stats, double* dt_trace, int* n_trace, int max_trace,
+                        double* rec_t, double* rec_dt, int32_t* rec_n, int rec_cap, int presc, int nthreads) {
   int rc = check_desc(d);
   if (rc) return rc;
   if (T < 1 || B < 1) return LDE_ERR_INVALID_ARG;
@@ -766,7 +797,8 @@ int oracle_forward(const lde_problem_desc* d, const real* W, const real* z0, con
       for (int i = 0; i < D; i++) y0[(int64_t)c * Dp + i] = z0[(int64_t)c * D + i];
     sstat st = {0, 0, 0, 0};
     /* out as [T][Dp*B] is exactly the [Dp × B × T] column-major layout */
-    solve_forward(fwd_fn, &b, n, y0, ts, T, &o, z_out, &st, dt_trace, n_trace, max_trace);
+    steprec rec = {rec_t, rec_dt, rec_n, rec_cap, presc};
+    solve_forward(fwd_fn, &b, n, y0, ts, T, &o, z_out, &st, dt_trace, n_trace, max_trace, rec_dt ? &rec : NULL);
     for (int c = 0; c < B; c++)
       if (retcode) retcode[c] = st.retcode;
     nfe = st.nfe; nacc = st.nacc; nrej = st.nrej; nfail = st.retcode ? B : 0; maxsteps = st.nacc + st.nrej;
@@ -791,7 +823,10 @@ int oracle_forward(const lde_problem_desc* d, const real* W, const real* z0, con
         for (int i = 0; i < Dp; i++) y0[i] = i < D ? z0[(int64_t)c * D + i] : (real)0;
         b.theta = theta ? theta + (int64_t)c * P : NULL;
         sstat st = {0, 0, 0, 0};
-        solve_forward(fwd_fn, &b, Dp, y0, ts, T, &o, out, &st, c == 0 ? dt_trace : NULL, c == 0 ? n_trace : NULL, max_trace);
+        steprec rec = {rec_t ? rec_t + (int64_t)c * rec_cap : NULL, rec_dt ? rec_dt + (int64_t)c * rec_cap : NULL, rec_n ? rec_n + c : NULL,
+                       rec_cap, presc};
+        solve_forward(fwd_fn, &b, Dp, y0, ts, T, &o, out, &st, c == 0 ? dt_trace : NULL, c == 0 ? n_trace : NULL, max_trace,
+                      rec_dt ? &rec : NULL);
         for (int j = 0; j < T; j++)
           for (int i = 0; i < Dp; i++) z_out[i + (int64_t)Dp * (c + (int64_t)B * j)] = out[(int64_t)j * Dp + i];
         if (retcode) retcode[c] = st.retcode;
@@ -805,6 +840,20 @@ int oracle_forward(const lde_problem_desc* d, const real* W, const real* z0, con
   }
   if (stats) { stats[0] = nfe; stats[1] = nacc; stats[2] = nrej; stats[3] = nfail; stats[4] = maxsteps; }
   return LDE_OK;
+}
+
+int oracle_forward(const lde_problem_desc* d, const real* W, const real* z0, const real* theta, const double* ts, int T,
+                   int B, real* z_out, int32_t* retcode, int64_t* stats, double* dt_trace, int* n_trace, int max_trace,
+                   int nthreads) {
+  return forward_impl(d, W, z0, theta, ts, T, B, z_out, retcode, stats, dt_trace, n_trace, max_trace, NULL, NULL, NULL, 0, 0, nthreads);
+}
+/* The same solve with its accepted steps recorded (presc = 0) or prescribed (presc = 1): rec_t, rec_dt [nseq][rec_cap], rec_n [nseq],
+ * nseq = B (per-trajectory control) or 1 (coupled). */
+int oracle_forward_steps(const lde_problem_desc* d, const real* W, const real* z0, const real* theta, const double* ts, int T,
+                         int B, real* z_out, int32_t* retcode, int64_t* stats, double* rec_t, double* rec_dt, int32_t* rec_n,
+                         int rec_cap, int presc, int nthreads) {
+  if (!rec_t || !rec_dt || !rec_n || rec_cap < 1) return LDE_ERR_INVALID_ARG;
+  return forward_impl(d, W, z0, theta, ts, T, B, z_out, retcode, stats, NULL, NULL, 0, rec_t, rec_dt, rec_n, rec_cap, presc, nthreads);
 }
 
 /* ---- parallel-in-time checkpointed adjoint (LDE_SENSE_PARALLEL_CHECKPOINTED), analytic RHS ------------------ */
@@ -858,7 +907,7 @@ static int adjoint_parallel(const lde_problem_desc* d, const real* z_out, const 
         opts_from_desc(d, &o, ts[0], ts[T - 1]);
         if (o.adaptive) o.dt_fixed = ts[j + 1] - ts[j];   /* first attempt = the whole interval */
         sstat st = {0, 0, 0, 0};
-        solve_backward(basis_fn, &b, n, y, tsj, 2, &o, no_jump, NULL, NULL, &st);
+        solve_backward(basis_fn, &b, n, y, tsj, 2, &o, no_jump, NULL, NULL, &st, NULL);
         if (st.retcode) bad = 1;
         memcpy(M + (int64_t)j * (Dp * Dp + Dp * P), y + Dp, (size_t)(Dp * Dp + Dp * P) * sizeof(real));
         nfe += st.nfe; nacc += st.nacc; nrej += st.nrej; steps += st.nacc + st.nrej;
@@ -898,13 +947,19 @@ static int adjoint_parallel(const lde_problem_desc* d, const real* z_out, const 
   return LDE_OK;
 }
 
-/* dW is ACCUMULATED (+=), as in lde_adjoint. */
-int oracle_adjoint(const lde_problem_desc* d, const real* W, const real* z_out, const real* theta, const double* ts,
-                   int T, int B, const real* dz_out, real* dz0, real* dtheta, real* dW, int64_t* stats, int nthreads) {
+static int adjoint_discrete(const lde_problem_desc* d, const real* W, const real* z_out, const real* theta, const double* ts, int T, int B,
+                            const real* dz_out, const double* rec_t, const double* rec_dt, const int32_t* rec_n, int rec_cap, real* dz0,
+                            real* dtheta, real* dW, int64_t* stats, int nthreads);
+
+/* dW is ACCUMULATED (+=), as in lde_adjoint. rec_*: the reverse-time solve's accepted step magnitudes, recorded or prescribed. */
+static int adjoint_impl(const lde_problem_desc* d, const real* W, const real* z_out, const real* theta, const double* ts,
+                        int T, int B, const real* dz_out, real* dz0, real* dtheta, real* dW, int64_t* stats, double* rec_dt,
+                        int32_t* rec_n, int rec_cap, int presc, int nthreads) {
   int rc = check_desc(d);
   if (rc) return rc;
   if (T < 1 || B < 1) return LDE_ERR_INVALID_ARG;
-  if (d->sensealg == LDE_SENSE_PARALLEL_CHECKPOINTED && !has_mlp(d) && d->batching == LDE_BATCH_PER_TRAJECTORY)
+  if (d->sensealg == LDE_SENSE_DISCRETE) return LDE_ERR_INVALID_ARG;   /* needs the forward record: oracle_adjoint_discrete */
+  if (d->sensealg == LDE_SENSE_PARALLEL_CHECKPOINTED && !has_mlp(d) && d->batching == LDE_BATCH_PER_TRAJECTORY && !rec_dt)
     return adjoint_parallel(d, z_out, theta, ts, T, B, dz_out, dz0, dtheta, stats, nthreads);
   const int D = d->state_dim, Dp = D + d->augment_dim, P = d->param_dim;
   const int64_t nW = has_mlp(d) ? num_weights(d) : 0;
@@ -935,7 +990,8 @@ int oracle_adjoint(const lde_problem_desc* d, const real* W, const real* z_out, 
       bad = v != 0;
     }
     sstat st = {0, 0, 0, 0};
-    if (!bad) solve_backward(bwd_fn, &b, n, y, ts, T, &o, bwd_jump, bwd_begin, bwd_commit, &st);
+    steprec rec = {NULL, rec_dt, rec_n, rec_cap, presc};
+    if (!bad) solve_backward(bwd_fn, &b, n, y, ts, T, &o, bwd_jump, bwd_begin, bwd_commit, &st, rec_dt ? &rec : NULL);
     for (int c = 0; c < B; c++) {
       for (int i = 0; i < D; i++) dz0[(int64_t)c * D + i] = bad ? 0 : y[nz + (int64_t)c * Dp + i];
       for (int p = 0; p < P; p++) dtheta[(int64_t)c * P + p] = bad ? 0 : y[2 * nz + (int64_t)c * P + p];
@@ -972,7 +1028,9 @@ int oracle_adjoint(const lde_problem_desc* d, const real* W, const real* z_out, 
         }
         for (int p = 0; p < P; p++) y[2 * Dp + p] = 0;
         sstat st = {0, 0, 0, 0};
-        if (!bad) solve_backward(bwd_fn, &b, n, y, ts, T, &o, bwd_jump, bwd_begin, bwd_commit, &st);
+        steprec rec = {NULL, rec_dt ? rec_dt + (int64_t)c * rec_cap : NULL, rec_n ? rec_n + c : NULL, rec_cap, presc};
+        if (rec_n && !presc) rec_n[c] = 0;
+        if (!bad) solve_backward(bwd_fn, &b, n, y, ts, T, &o, bwd_jump, bwd_begin, bwd_commit, &st, rec_dt ? &rec : NULL);
         if (st.retcode) bad = 1;
         for (int i = 0; i < D; i++) dz0[(int64_t)c * D + i] = bad ? 0 : y[Dp + i];
         for (int p = 0; p < P; p++) dtheta[(int64_t)c * P + p] = bad ? 0 : y[2 * Dp + p];
@@ -993,6 +1051,267 @@ int oracle_adjoint(const lde_problem_desc* d, const real* W, const real* z_out, 
   free(dW_tot);
   if (stats) { stats[0] = nfe; stats[1] = nacc; stats[2] = nrej; stats[3] = nfail; stats[4] = maxsteps; }
   return LDE_OK;
+}
+
+int oracle_adjoint(const lde_problem_desc* d, const real* W, const real* z_out, const real* theta, const double* ts,
+                   int T, int B, const real* dz_out, real* dz0, real* dtheta, real* dW, int64_t* stats, int nthreads) {
+  return adjoint_impl(d, W, z_out, theta, ts, T, B, dz_out, dz0, dtheta, dW, stats, NULL, NULL, 0, 0, nthreads);
+}
+/* The continuous adjoint (sensealg 0 / 1) with the reverse-time solve's accepted step magnitudes recorded (presc = 0) or prescribed
+ * (presc = 1): rec_dt [nseq][rec_cap], rec_n [nseq], nseq = B or 1 as in oracle_forward_steps. */
+int oracle_adjoint_steps(const lde_problem_desc* d, const real* W, const real* z_out, const real* theta, const double* ts,
+                         int T, int B, const real* dz_out, real* dz0, real* dtheta, real* dW, int64_t* stats, double* rec_dt,
+                         int32_t* rec_n, int rec_cap, int presc, int nthreads) {
+  if (!rec_dt || !rec_n || rec_cap < 1) return LDE_ERR_INVALID_ARG;
+  return adjoint_impl(d, W, z_out, theta, ts, T, B, dz_out, dz0, dtheta, dW, stats, rec_dt, rec_n, rec_cap, presc, nthreads);
+}
+
+/* ---- discrete (exact) sensitivity: LDE_SENSE_DISCRETE ----------------------------------------------------------------------------
+ * What `ForwardDiffSensitivity()` — the GOKU default [REF examples/pendulum_friction-less/pendulum.jl:11], splatted into solve at
+ * [REF src/models/GOKU.jl:107, :121] — differentiates: the discrete solve itself, on its accepted step sequence, the step sizes being
+ * plain Float64 numbers (not duals), i.e. constants of the differentiation. SciMLSensitivity 7.10.0 [REF Manifest.toml:1200] gets it
+ * by pushing dual numbers through the stepper; the same derivative is restated here in reverse mode (one sweep instead of D + P):
+ *   step n:  g_i = y_n + h Σ_{j<i} a_ij k_j,  k_i = f(g_i)  (i = 1..S);  y_{n+1} = y_n + h Σ b_i k_i;  k_{S+1} = f(y_{n+1})  (FSAL: the next k_1)
+ *   saveat:  ẑ(t_j) = y_n + h Σ_{i≤S+1} w_i(Θ_j) k_i  (Tsit5's free interpolant; RK4: the cubic Hermite on (y_n, k_1, y_{n+1}, k_{S+1}))
+ *   reverse: k̄_{S+1} = (next step's k̄_1) + h w_{S+1}(Θ_j) Δ_j;  ȳ_{n+1} += J(y_{n+1})ᵀ k̄_{S+1};  k̄_i += h b_i ȳ_{n+1} + h w_i(Θ_j) Δ_j;
+ *            ȳ_n = ȳ_{n+1} + Σ_j Δ_j;  for i = S..2: ḡ = J(g_i)ᵀ k̄_i, ȳ_n += ḡ, k̄_j += h a_ij ḡ (j < i);  k̄_1 travels to step n − 1
+ *            (at n = 0: ȳ_0 += J(y_0)ᵀ k̄_1).  θ̄ and W̄ collect (∂f/∂θ)ᵀ k̄_i, (∂f/∂W)ᵀ k̄_i of every evaluation.
+ * One block of `ncol` columns sharing ONE step sequence (ncol = 1: a GOKU trajectory; ncol = B: the coupled NeuralODE solve). */
+typedef struct {
+  int S;                 /* stages before the FSAL evaluation: 6 (Tsit5) / 4 (RK4) */
+  double A[7][7];        /* a_ij, row S = the solution weights b */
+} dtab;
+static void dtab_init(dtab* tb, int solver) {
+  memset(tb, 0, sizeof(*tb));
+  if (solver == LDE_SOLVER_TSIT5) {
+    tb->S = 6;
+    for (int i = 0; i < 7; i++)
+      for (int j = 0; j < 6; j++) tb->A[i][j] = TS_A[i][j];
+  } else {
+    tb->S = 4;
+    tb->A[1][0] = 0.5; tb->A[2][1] = 0.5; tb->A[3][2] = 1.0;
+    tb->A[4][0] = 1.0 / 6.0; tb->A[4][1] = 1.0 / 3.0; tb->A[4][2] = 1.0 / 3.0; tb->A[4][3] = 1.0 / 6.0;
+  }
+}
+
+/* f for the block's columns */
+static void blk_f(blockctx* b, const real* y, real* dy) { fwd_fn(b, 0.0, y, dy, 0); }
+/* vz += J(y)ᵀ kb; gth += (∂f/∂θ)ᵀ kb; dW_acc += (∂f/∂W)ᵀ kb — skipped altogether when kb is identically zero */
+static void blk_vjp(blockctx* b, const real* y, const real* kb, real* vz_add, real* gth, sstat* st) {
+  int64_t n = (int64_t)b->Dp * b->ncol;
+  int any = 0;
+  for (int64_t i = 0; i < n && !any; i++) any = kb[i] != 0;
+  if (!any) return;
+  real f[1024], vz[1024], vth[16];
+  for (int c = 0; c < b->ncol; c++) {
+    if (b->c.dW_step) memset(b->c.dW_step, 0, (size_t)b->c.nW * sizeof(real));
+    rhs_vjp_col(&b->c, y + (int64_t)c * b->Dp, b->theta + (int64_t)c * b->P, kb + (int64_t)c * b->Dp, f, vz, vth, (real)1);
+    for (int i = 0; i < b->Dp; i++) vz_add[(int64_t)c * b->Dp + i] += vz[i];
+    for (int p = 0; p < b->P; p++) gth[(int64_t)c * b->P + p] += vth[p];
+    if (b->c.dW_step && b->dW_acc)
+      for (int64_t i = 0; i < b->c.nW; i++) b->dW_acc[i] += (double)b->c.dW_step[i];
+  }
+  st->nfe++;
+}
+
+/* returns 0, or a retcode when the record is unusable (then the caller reports zeros, as for a failed trajectory) */
+static int discrete_block(blockctx* b, const lde_problem_desc* d, const real* y0, const double* ts, int T, const double* rt,
+                          const double* rdt, int ns, real* ybar /* out: ∂L/∂y_0 [n] */, real* gth /* out [P·ncol] */, sstat* st) {
+  const int64_t n = (int64_t)b->Dp * b->ncol;
+  dtab tb;
+  dtab_init(&tb, d->solver);
+  const int S = tb.S;
+  const double tend = ts[T - 1];
+  real* Y = (real*)malloc((size_t)(ns + 1) * n * sizeof(real));
+  int* jlo = (int*)malloc((size_t)(ns + 1) * sizeof(int));   /* save times of step s: jlo[s] ≤ j < jlo[s+1] */
+  real *k[8], *g[8], *kb[8];
+  for (int i = 0; i < 8; i++) {
+    k[i] = (real*)calloc((size_t)n, sizeof(real));
+    g[i] = (real*)calloc((size_t)n, sizeof(real));
+    kb[i] = (real*)calloc((size_t)n, sizeof(real));
+  }
+  real* yb_n = (real*)calloc((size_t)n, sizeof(real));
+  real* gbar = (real*)calloc((size_t)n, sizeof(real));
+  memcpy(Y, y0, (size_t)n * sizeof(real));
+  /* pass 1: the states y_n of the recorded steps (the forward solve's own arithmetic) and which save times each step serves */
+  int j = 1, rcode = 0;
+  for (int s = 0; s < ns; s++) {
+    const real h = (real)rdt[s];
+    const real* y = Y + (int64_t)s * n;
+    real* yn = Y + (int64_t)(s + 1) * n;
+    blk_f(b, y, k[0]);
+    for (int i = 1; i < S; i++) {
+      for (int64_t e = 0; e < n; e++) {
+        real acc = (real)tb.A[i][0] * k[0][e];
+        for (int q = 1; q < i; q++) acc += (real)tb.A[i][q] * k[q][e];
+        g[i][e] = y[e] + h * acc;
+      }
+      blk_f(b, g[i], k[i]);
+    }
+    if (d->solver == LDE_SOLVER_TSIT5) {
+      for (int64_t e = 0; e < n; e++) {
+        real acc = (real)tb.A[S][0] * k[0][e];
+        for (int q = 1; q < S; q++) acc += (real)tb.A[S][q] * k[q][e];
+        yn[e] = y[e] + h * acc;
+      }
+    } else {
+      const real h6 = (real)(rdt[s] / 6.0);
+      for (int64_t e = 0; e < n; e++) yn[e] = y[e] + h6 * (k[0][e] + (real)2 * (k[1][e] + k[2][e]) + k[3][e]);
+    }
+    st->nfe += S;
+    if (!all_finite(yn, n)) { rcode = LDE_RET_NONFINITE; break; }
+    const double tnew = s == ns - 1 ? tend : rt[s + 1];
+    jlo[s] = j;
+    while (j < T && ts[j] <= tnew) j++;
+  }
+  jlo[ns] = j;
+  if (!rcode && j < T) rcode = LDE_RET_MAXITERS;   /* the record does not reach the last save time */
+  for (int64_t e = 0; e < n; e++) ybar[e] = 0;
+  for (int64_t e = 0; e < (int64_t)b->P * b->ncol; e++) gth[e] = 0;
+  real* carry = kb[7];   /* k̄_1 of the step behind (in time: ahead of) the current one */
+  /* pass 2 */
+  for (int s = ns - 1; s >= 0 && !rcode; s--) {
+    const double t = rt[s], dt = rdt[s];
+    const real h = (real)dt;
+    const int last = s == ns - 1;
+    const real* y = Y + (int64_t)s * n;
+    const real* yn = Y + (int64_t)(s + 1) * n;
+    /* the stage points again (k_i are needed only to form them) */
+    blk_f(b, y, k[0]);
+    for (int i = 1; i < S; i++) {
+      for (int64_t e = 0; e < n; e++) {
+        real acc = (real)tb.A[i][0] * k[0][e];
+        for (int q = 1; q < i; q++) acc += (real)tb.A[i][q] * k[q][e];
+        g[i][e] = y[e] + h * acc;
+      }
+      if (i < S - 1) blk_f(b, g[i], k[i]);   /* (k_S is not needed to form a stage point) */
+    }
+    st->nfe += S - 1;
+    for (int i = 0; i < S; i++) memset(kb[i], 0, (size_t)n * sizeof(real));
+    memcpy(kb[S], carry, (size_t)n * sizeof(real));
+    memset(yb_n, 0, (size_t)n * sizeof(real));
+    /* the save times inside the step */
+    for (int jj = jlo[s]; jj < jlo[s + 1]; jj++) {
+      const double th = (ts[jj] - t) / dt;
+      const int at_end = th >= 1.0 || (jj == T - 1 && last);
+      for (int c = 0; c < b->ncol; c++)
+        for (int i = 0; i < b->Dp; i++) {
+          const int64_t e = (int64_t)c * b->Dp + i;
+          const real D_ = b->dzout[i + (int64_t)b->Dp * (c + b->Bstride * jj)];
+          if (at_end) ybar[e] += D_;
+          else if (d->solver == LDE_SOLVER_TSIT5) {
+            double bw[7];
+            tsit5_interp_weights(th, bw);
+            yb_n[e] += D_;
+            for (int q = 0; q < 7; q++) kb[q][e] += (h * (real)bw[q]) * D_;
+          } else {
+            const double h00 = (1 + 2 * th) * (1 - th) * (1 - th), h10 = th * (1 - th) * (1 - th);
+            const double h01 = th * th * (3 - 2 * th), h11 = th * th * (th - 1);
+            yb_n[e] += (real)h00 * D_;
+            kb[0][e] += (real)(h10 * dt) * D_;
+            ybar[e] += (real)h01 * D_;
+            kb[4][e] += (real)(h11 * dt) * D_;
+          }
+        }
+    }
+    /* the FSAL evaluation at y_{n+1} */
+    blk_vjp(b, yn, kb[S], ybar, gth, st);
+    /* y_{n+1} = y_n + h Σ b_i k_i */
+    for (int i = 0; i < S; i++)
+      for (int64_t e = 0; e < n; e++) kb[i][e] += (h * (real)tb.A[S][i]) * ybar[e];
+    for (int64_t e = 0; e < n; e++) yb_n[e] += ybar[e];
+    /* stages S..2 */
+    for (int i = S - 1; i >= 1; i--) {
+      memset(gbar, 0, (size_t)n * sizeof(real));
+      blk_vjp(b, g[i], kb[i], gbar, gth, st);
+      for (int64_t e = 0; e < n; e++) yb_n[e] += gbar[e];
+      for (int q = 0; q < i; q++)
+        if (tb.A[i][q] != 0)
+          for (int64_t e = 0; e < n; e++) kb[q][e] += (h * (real)tb.A[i][q]) * gbar[e];
+    }
+    memcpy(carry, kb[0], (size_t)n * sizeof(real));
+    memcpy(ybar, yb_n, (size_t)n * sizeof(real));
+    st->nacc++;
+  }
+  if (!rcode) blk_vjp(b, Y, carry, ybar, gth, st);   /* k_1 of the first step = f(y_0) */
+  for (int i = 0; i < 8; i++) { free(k[i]); free(g[i]); free(kb[i]); }
+  free(yb_n); free(gbar); free(Y); free(jlo);
+  return rcode;
+}
+
+static int adjoint_discrete(const lde_problem_desc* d, const real* W, const real* z_out, const real* theta, const double* ts, int T, int B,
+                            const real* dz_out, const double* rec_t, const double* rec_dt, const int32_t* rec_n, int rec_cap, real* dz0,
+                            real* dtheta, real* dW, int64_t* stats, int nthreads) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (T < 1 || B < 1 || !rec_t || !rec_dt || !rec_n) return LDE_ERR_INVALID_ARG;
+  const int D = d->state_dim, Dp = D + d->augment_dim, P = d->param_dim;
+  const int64_t nW = has_mlp(d) ? num_weights(d) : 0;
+  int64_t nfe = 0, nacc = 0, nfail = 0, maxsteps = 0;
+  double* dW_tot = nW ? (double*)calloc((size_t)nW, sizeof(double)) : NULL;
+  const int coupled = d->batching != LDE_BATCH_PER_TRAJECTORY;
+  const int nblk = coupled ? 1 : B, ncol = coupled ? B : 1;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel reduction(+ : nfe, nacc, nfail) reduction(max : maxsteps)
+  {
+    blockctx b;
+    memset(&b, 0, sizeof(b));
+    colrhs_init(&b.c, d, W);
+    b.ncol = ncol; b.Dp = Dp; b.P = P; b.Bstride = B;
+    b.dW_acc = nW ? (double*)calloc((size_t)nW, sizeof(double)) : NULL;
+    const int64_t n = (int64_t)Dp * ncol;
+    real* y0 = (real*)calloc((size_t)n, sizeof(real));
+    real* ybar = (real*)calloc((size_t)n, sizeof(real));
+    real* gth = (real*)calloc((size_t)(P * ncol + 1), sizeof(real));
+#pragma omp for schedule(static)
+    for (int blk = 0; blk < nblk; blk++) {
+      const int c0 = coupled ? 0 : blk;
+      b.theta = theta ? theta + (int64_t)c0 * P : NULL;
+      b.dzout = dz_out + (int64_t)Dp * c0;
+      int bad = 0;
+      for (int c = 0; c < ncol; c++)
+        for (int i = 0; i < Dp; i++) {
+          y0[(int64_t)c * Dp + i] = z_out[i + (int64_t)Dp * (c0 + c)];   /* save time 0 is ẑ₀ itself (augmented rows 0) */
+          if (!isfinite((double)y0[(int64_t)c * Dp + i])) bad = 1;
+        }
+      const int ns = rec_n[blk];
+      if (ns > rec_cap || (T > 1 && ns < 1)) bad = 1;
+      sstat st = {0, 0, 0, 0};
+      if (!bad && T > 1) bad = discrete_block(&b, d, y0, ts, T, rec_t + (int64_t)blk * rec_cap, rec_dt + (int64_t)blk * rec_cap, ns, ybar, gth, &st) != 0;
+      else if (!bad) {   /* T == 1: the output is ẑ₀ */
+        for (int64_t e = 0; e < n; e++) ybar[e] = 0;
+        for (int e = 0; e < P * ncol; e++) gth[e] = 0;
+      }
+      if (!bad && T >= 1)   /* save time 0: ẑ(t_1) = ẑ₀ */
+        for (int c = 0; c < ncol; c++)
+          for (int i = 0; i < Dp; i++) ybar[(int64_t)c * Dp + i] += dz_out[i + (int64_t)Dp * (c0 + c)];
+      for (int c = 0; c < ncol; c++) {
+        for (int i = 0; i < D; i++) dz0[(int64_t)(c0 + c) * D + i] = bad ? 0 : ybar[(int64_t)c * Dp + i];
+        for (int p = 0; p < P; p++) dtheta[(int64_t)(c0 + c) * P + p] = bad ? 0 : gth[(int64_t)c * P + p];
+      }
+      nfe += st.nfe; nacc += st.nacc; nfail += bad ? ncol : 0;
+      if (st.nacc > maxsteps) maxsteps = st.nacc;
+    }
+    if (nW) {
+#pragma omp critical
+      for (int64_t i = 0; i < nW; i++) dW_tot[i] += b.dW_acc[i];
+      free(b.dW_acc);
+    }
+    free(y0); free(ybar); free(gth);
+    colrhs_free(&b.c);
+  }
+  if (nW && dW)
+    for (int64_t i = 0; i < nW; i++) dW[i] += (real)dW_tot[i];
+  free(dW_tot);
+  if (stats) { stats[0] = nfe; stats[1] = nacc; stats[2] = 0; stats[3] = nfail; stats[4] = maxsteps; }
+  return LDE_OK;
+}
+int oracle_adjoint_discrete(const lde_problem_desc* d, const real* W, const real* z_out, const real* theta, const double* ts, int T, int B,
+                            const real* dz_out, const double* rec_t, const double* rec_dt, const int32_t* rec_n, int rec_cap, real* dz0,
+                            real* dtheta, real* dW, int64_t* stats, int nthreads) {
+  return adjoint_discrete(d, W, z_out, theta, ts, T, B, dz_out, rec_t, rec_dt, rec_n, rec_cap, dz0, dtheta, dW, stats, nthreads);
 }
 
 /* RHS and VJP of a single column, exported for unit tests of the RHS menu. */

@@ -21,7 +21,7 @@ LDE_MAX_LAYERS = 6
 RHS_PENDULUM, RHS_PENDULUM_FRICTION, RHS_MLP, RHS_PENDULUM_PLUS_MLP = 0, 1, 2, 3
 SOLVER_TSIT5, SOLVER_RK4 = 0, 1
 BATCH_PER_TRAJECTORY, BATCH_COUPLED, BATCH_COUPLED_GLOBAL = 0, 1, 2
-SENSE_BACKSOLVE_CHECKPOINTED, SENSE_BACKSOLVE, SENSE_PARALLEL_CHECKPOINTED = 0, 1, 2
+SENSE_BACKSOLVE_CHECKPOINTED, SENSE_BACKSOLVE, SENSE_PARALLEL_CHECKPOINTED, SENSE_DISCRETE = 0, 1, 2, 3
 ACT_RELU, ACT_TANH = 0, 1
 
 
@@ -168,6 +168,101 @@ class Oracle:
             raise RuntimeError(f"oracle_adjoint failed: {rc}")
         info = dict(nfe=int(stats[0]), naccept=int(stats[1]), nreject=int(stats[2]), nfailed=int(stats[3]),
                     max_steps=int(stats[4]))
+        return dz0, (dth[:, :P] if P else None), (dW[:nW] if nW else None), info
+
+    # ---- the same solves with their accepted steps recorded or prescribed (lde_oracle.c: steprec) -----------------------------------
+    @staticmethod
+    def _nseq(d: Desc, B: int) -> int:
+        return B if d.batching == BATCH_PER_TRAJECTORY else 1
+
+    def forward_steps(self, d: Desc, z0, theta, ts, W=None, rec=None, cap=4096, nthreads=0):
+        """rec=None: an adaptive solve, its accepted steps returned as rec = dict(t [nseq,cap], dt [nseq,cap], n [nseq]).
+        rec given: exactly these steps are taken (no error control)."""
+        dt = self.dtype
+        z0 = np.ascontiguousarray(z0, dtype=dt)
+        B, D = z0.shape
+        Dp = D + d.augment_dim
+        theta = None if theta is None else np.ascontiguousarray(theta, dtype=dt)
+        ts = np.ascontiguousarray(ts, dtype=np.float64)
+        T = ts.shape[0]
+        W = None if W is None else np.ascontiguousarray(W, dtype=dt)
+        nseq = self._nseq(d, B)
+        presc = rec is not None
+        if presc:
+            rt = np.ascontiguousarray(rec["t"], np.float64).reshape(nseq, -1)
+            rdt = np.ascontiguousarray(rec["dt"], np.float64).reshape(nseq, -1)
+            rn = np.ascontiguousarray(rec["n"], np.int32).reshape(nseq)
+            cap = rt.shape[1]
+        else:
+            rt, rdt, rn = np.zeros((nseq, cap)), np.zeros((nseq, cap)), np.zeros(nseq, np.int32)
+        z_out = np.zeros((T, B, Dp), dtype=dt)
+        ret = np.zeros(B, dtype=np.int32)
+        stats = np.zeros(5, dtype=np.int64)
+        rc = self.lib.oracle_forward_steps(C.byref(d), self._p(W), self._p(z0), self._p(theta), self._p(ts), T, B, self._p(z_out),
+                                           self._p(ret), self._p(stats), self._p(rt), self._p(rdt), self._p(rn), cap, int(presc), nthreads)
+        if rc != 0:
+            raise RuntimeError(f"oracle_forward_steps failed: {rc}")
+        assert presc or int(rn.max()) <= cap, "step record overflow: raise cap"
+        info = dict(nfe=int(stats[0]), naccept=int(stats[1]), nreject=int(stats[2]), nfailed=int(stats[3]), max_steps=int(stats[4]))
+        return z_out, ret, dict(t=rt, dt=rdt, n=rn), info
+
+    def adjoint_steps(self, d: Desc, z_out, theta, ts, dz_out, W=None, rec=None, cap=8192, nthreads=0):
+        """The continuous adjoint with the reverse-time solve's accepted step magnitudes recorded (rec=None) or prescribed."""
+        dt = self.dtype
+        z_out = np.ascontiguousarray(z_out, dtype=dt)
+        dz_out = np.ascontiguousarray(dz_out, dtype=dt)
+        T, B, Dp = z_out.shape
+        D, P = d.state_dim, d.param_dim
+        theta = None if theta is None else np.ascontiguousarray(theta, dtype=dt)
+        ts = np.ascontiguousarray(ts, dtype=np.float64)
+        W = None if W is None else np.ascontiguousarray(W, dtype=dt)
+        nseq = self._nseq(d, B)
+        presc = rec is not None
+        if presc:
+            rdt = np.ascontiguousarray(rec["dt"], np.float64).reshape(nseq, -1)
+            rn = np.ascontiguousarray(rec["n"], np.int32).reshape(nseq)
+            cap = rdt.shape[1]
+        else:
+            rdt, rn = np.zeros((nseq, cap)), np.zeros(nseq, np.int32)
+        dz0 = np.zeros((B, D), dtype=dt)
+        dth = np.zeros((B, max(P, 1)), dtype=dt)
+        nW = self.num_weights(d) if d.rhs_kind in (RHS_MLP, RHS_PENDULUM_PLUS_MLP) else 0
+        dW = np.zeros(max(nW, 1), dtype=dt)
+        stats = np.zeros(5, dtype=np.int64)
+        rc = self.lib.oracle_adjoint_steps(C.byref(d), self._p(W), self._p(z_out), self._p(theta), self._p(ts), T, B, self._p(dz_out),
+                                           self._p(dz0), self._p(dth), self._p(dW), self._p(stats), self._p(rdt), self._p(rn), cap,
+                                           int(presc), nthreads)
+        if rc != 0:
+            raise RuntimeError(f"oracle_adjoint_steps failed: {rc}")
+        assert presc or int(rn.max()) <= cap, "step record overflow: raise cap"
+        info = dict(nfe=int(stats[0]), naccept=int(stats[1]), nreject=int(stats[2]), nfailed=int(stats[3]), max_steps=int(stats[4]))
+        return dz0, (dth[:, :P] if P else None), (dW[:nW] if nW else None), dict(dt=rdt, n=rn), info
+
+    def adjoint_discrete(self, d: Desc, z_out, theta, ts, dz_out, rec, W=None, nthreads=0):
+        """LDE_SENSE_DISCRETE: reverse-mode derivative of the discrete solve on the recorded steps `rec` (of forward_steps, or of a kernel)."""
+        dt = self.dtype
+        z_out = np.ascontiguousarray(z_out, dtype=dt)
+        dz_out = np.ascontiguousarray(dz_out, dtype=dt)
+        T, B, Dp = z_out.shape
+        D, P = d.state_dim, d.param_dim
+        theta = None if theta is None else np.ascontiguousarray(theta, dtype=dt)
+        ts = np.ascontiguousarray(ts, dtype=np.float64)
+        W = None if W is None else np.ascontiguousarray(W, dtype=dt)
+        nseq = self._nseq(d, B)
+        rt = np.ascontiguousarray(rec["t"], np.float64).reshape(nseq, -1)
+        rdt = np.ascontiguousarray(rec["dt"], np.float64).reshape(nseq, -1)
+        rn = np.ascontiguousarray(rec["n"], np.int32).reshape(nseq)
+        dz0 = np.zeros((B, D), dtype=dt)
+        dth = np.zeros((B, max(P, 1)), dtype=dt)
+        nW = self.num_weights(d) if d.rhs_kind in (RHS_MLP, RHS_PENDULUM_PLUS_MLP) else 0
+        dW = np.zeros(max(nW, 1), dtype=dt)
+        stats = np.zeros(5, dtype=np.int64)
+        rc = self.lib.oracle_adjoint_discrete(C.byref(d), self._p(W), self._p(z_out), self._p(theta), self._p(ts), T, B, self._p(dz_out),
+                                              self._p(rt), self._p(rdt), self._p(rn), rt.shape[1], self._p(dz0), self._p(dth), self._p(dW),
+                                              self._p(stats), nthreads)
+        if rc != 0:
+            raise RuntimeError(f"oracle_adjoint_discrete failed: {rc}")
+        info = dict(nfe=int(stats[0]), naccept=int(stats[1]), nreject=0, nfailed=int(stats[3]), max_steps=int(stats[4]))
         return dz0, (dth[:, :P] if P else None), (dW[:nW] if nW else None), info
 
     def rhs(self, d: Desc, z, theta, W=None):

@@ -220,6 +220,31 @@ int lde_get_phase_ms(lde_handle* h, float* ms2);
 typedef int (*lde_sum_hook)(void* user, double* vals, int n);
 int lde_set_global_sum_hook(lde_handle* h, lde_sum_hook hook, void* user, int64_t global_batch);
 
+/* ---- step records: LDE_SENSE_DISCRETE's hand-over between lde_forward and lde_adjoint, and the parity tests' view of a solve's steps ----
+ * A record holds, per step sequence (one per trajectory with LDE_BATCH_PER_TRAJECTORY, one for a coupled solve) and accepted step n,
+ * the step's start time and size (f64) and — forward records — the state y_n [D'×B] it started from. With sensealg = LDE_SENSE_DISCRETE
+ * lde_forward writes one and lde_adjoint reads it. By default it lives in the handle: ONE outstanding forward per handle. A caller with
+ * several forwards in flight before their pullbacks (an AD tape) owns the records instead: lde_step_record_bytes(h, B, T) device bytes
+ * each, handed over with lde_set_step_record before lde_forward AND before the matching lde_adjoint (NULL: back to the handle's own).
+ * Capacity = option "record_capacity" accepted steps per sequence (default max(64, 4·T)); a solve that needs more leaves the record
+ * incomplete and the discrete adjoint then returns NaN gradients with retcode LDE_RET_MAXITERS in its statistics — never a silently
+ * truncated sweep. The reference has no counterpart (dual numbers carry the derivative through the solve [REF src/models/GOKU.jl:121]). */
+int64_t lde_step_record_bytes(const lde_handle* h, int B, int T);
+int lde_set_step_record(lde_handle* h, void* rec_dev, int64_t bytes);
+/* Host copy of the step sequences of the last call: which = 0 the forward record (needs LDE_SENSE_DISCRETE or option "step_trace"),
+ * which = 1 the reverse-time solve of the continuous adjoint (option "step_trace"; t_host is not written: NULL). Arrays [nseq][cap]
+ * row-major, n_host[nseq] (a count > cap: truncated); nseq = B or 1. Synchronises `stream`. What tests/test_gpu_discrete.py hands to the
+ * checker so that kernel and oracle are compared on the SAME discrete solve. */
+int lde_get_step_record(lde_handle* h, int which, double* t_host, double* dt_host, int32_t* n_host, int nseq, int cap, void* stream);
+
+/* Options that are not part of the reference's `diffeq` struct (a library must not be steered by environment variables):
+ *   "record_capacity"  accepted steps a step record holds per sequence (0: automatic)
+ *   "step_trace"       1: lde_forward records its steps whatever the sensealg, lde_adjoint (continuous) records its reverse-time steps
+ *   "adjoint_overwrite" 1: lde_adjoint WRITES dW (every entry exactly once) instead of accumulating — the caller's zero fill disappears
+ * Unknown key: LDE_ERR_INVALID_ARG. */
+int lde_set_option(lde_handle* h, const char* key, double value);
+int lde_get_option(const lde_handle* h, const char* key, double* value);
+
 /* Human-readable text for the last error on this handle (never NULL). */
 const char* lde_last_error(const lde_handle* h);
 

@@ -18,7 +18,7 @@ LDE_MAX_LAYERS = 6
 RHS_PENDULUM, RHS_PENDULUM_FRICTION, RHS_MLP, RHS_PENDULUM_PLUS_MLP = 0, 1, 2, 3
 SOLVER_TSIT5, SOLVER_RK4 = 0, 1
 BATCH_PER_TRAJECTORY, BATCH_COUPLED, BATCH_COUPLED_GLOBAL = 0, 1, 2
-SENSE_BACKSOLVE_CHECKPOINTED, SENSE_BACKSOLVE, SENSE_PARALLEL_CHECKPOINTED = 0, 1, 2
+SENSE_BACKSOLVE_CHECKPOINTED, SENSE_BACKSOLVE, SENSE_PARALLEL_CHECKPOINTED, SENSE_DISCRETE = 0, 1, 2, 3
 ACT_RELU, ACT_TANH = 0, 1
 
 STATUS = {0: "LDE_OK", -1: "LDE_ERR_INVALID_ARG", -2: "LDE_ERR_UNSUPPORTED", -3: "LDE_ERR_NO_DEVICE",
@@ -28,6 +28,7 @@ STATUS = {0: "LDE_OK", -1: "LDE_ERR_INVALID_ARG", -2: "LDE_ERR_UNSUPPORTED", -3:
 EXPORTS = ["lde_abi_version", "lde_problem_desc_default", "lde_num_weights", "lde_create", "lde_destroy",
            "lde_set_weights", "lde_set_weights_device", "lde_reserve", "lde_forward", "lde_adjoint",
            "lde_get_stats", "lde_last_error", "lde_set_global_sum_hook", "lde_set_phase_timing", "lde_get_phase_ms",
+           "lde_step_record_bytes", "lde_set_step_record", "lde_get_step_record", "lde_set_option", "lde_get_option",
            "lde_chain_num_weights", "lde_chain_create", "lde_chain_destroy", "lde_chain_set_weights",
            "lde_chain_set_weights_device", "lde_chain_reserve", "lde_chain_forward", "lde_chain_backward",
            "lde_chain_last_error", "lde_chain_set_accumulate", "lde_chain_set_dtype", "lde_rnn_set_accumulate", "lde_chain_saved_floats", "lde_chain_forward_save", "lde_chain_backward_saved", "lde_chain_group_forward_save", "lde_chain_group_backward_saved", "lde_rnn_group_forward", "lde_rnn_group_backward", "lde_rnn_forward_train", "lde_rnn_group_forward_train", "lde_chain_backward_saved_sum", "lde_chain_backward_saved_mse", "lde_chain_forward_save_mse", "lde_chain_forward_save_mse_delta", "lde_chain_backward_saved_delta", "lde_chain_mse_scratch_floats", "lde_randn", "lde_sample_kl_pair_forward", "lde_sample_kl_pair_backward", "lde_rnn_group_forward_ld", "lde_rnn_group_backward_ld",
@@ -124,6 +125,12 @@ def load():
     lib.lde_set_global_sum_hook.restype = C.c_int
     lib.lde_last_error.argtypes = [vp]
     lib.lde_last_error.restype = C.c_char_p
+    lib.lde_step_record_bytes.argtypes = [vp, i32, i32]
+    lib.lde_step_record_bytes.restype = i64
+    lib.lde_set_step_record.argtypes = [vp, vp, i64]
+    lib.lde_get_step_record.argtypes = [vp, i32, vp, vp, vp, i32, i32, vp]
+    lib.lde_set_option.argtypes = [vp, C.c_char_p, C.c_double]
+    lib.lde_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_double)]
     lib.lde_chain_num_weights.argtypes = [C.POINTER(ChainDesc)]
     lib.lde_chain_num_weights.restype = i64
     lib.lde_chain_create.argtypes = [C.POINTER(ChainDesc), C.POINTER(vp)]

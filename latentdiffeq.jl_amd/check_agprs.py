@@ -11,7 +11,22 @@ import subprocess
 import sys
 import tempfile
 
-LLVM = "/opt/rocm/lib/llvm/bin"
+def llvm_bin() -> str:
+    """llvm-objdump of the SAME toolchain hipcc drives: <rocm>/lib/llvm/bin, derived from hipcc's location or ROCM_PATH."""
+    import shutil
+    cands = []
+    hipcc = shutil.which("hipcc")
+    if hipcc:
+        cands.append(os.path.join(os.path.dirname(os.path.dirname(os.path.realpath(hipcc))), "lib", "llvm", "bin"))
+    if os.environ.get("ROCM_PATH"):
+        cands.append(os.path.join(os.environ["ROCM_PATH"], "lib", "llvm", "bin"))
+    cands.append("/opt/rocm/lib/llvm/bin")
+    for c in cands:
+        if os.path.exists(os.path.join(c, "llvm-objdump")):
+            return c
+    raise FileNotFoundError("llvm-objdump not found next to hipcc, under ROCM_PATH or /opt/rocm: the hidden-AGPR check cannot run")
+
+
 A0 = {"k_mlpb": 256 - 4 * 51, "k_mlpc": 256 - 4 * 26}     # mlpb::A0, mlpc::A0
 
 
@@ -27,6 +42,7 @@ def _regs(tok):
 
 def check_object(obj: str) -> list:
     """Returns the list of violations ('kernel: instruction') in a host object with bundled gfx950 code."""
+    LLVM = llvm_bin()
     with tempfile.TemporaryDirectory() as td:
         import glob
         import shutil
@@ -38,7 +54,7 @@ def check_object(obj: str) -> list:
             return [f"{obj}: expected one gfx950 code object, found {len(devs)}"]
         dev = devs[0]
         dis = subprocess.run([f"{LLVM}/llvm-objdump", "-d", "--no-show-raw-insn", dev], check=True, capture_output=True, text=True).stdout
-    bad, kern, lim, seen = [], None, None, set()
+    bad, kern, lim, seen, scanned = [], None, None, set(), set()
     for line in dis.splitlines():
         m = re.match(r"^[0-9a-f]+ <(\S+)>:", line)
         if m:
@@ -47,9 +63,12 @@ def check_object(obj: str) -> list:
             for k, a0 in A0.items():
                 if f"6{k}I" in name:          # _ZN3lde6k_mlpbI…
                     seen.add(k)
-                    adj = re.search(r"Lb([01])E", name)          # the first bool template argument is ADJ: only the adjoint has tiles
-                    if adj and adj.group(1) == "1":
+                    # the kernels' template arguments end with <…, bool ADJ> (k_mlpb: SOLVER, DP, ACT, ADJ; k_mlpc: SOLVER, ACT, ADJ): the
+                    # LAST bool of the mangled argument list is ADJ; only the adjoint instantiations own tiles
+                    bools = re.findall(r"Lb([01])E", name)
+                    if bools and bools[-1] == "1":
                         kern, lim = name, a0
+                        scanned.add(k)
             continue
         if kern is None:
             continue
@@ -71,6 +90,8 @@ def check_object(obj: str) -> list:
     for k in A0:
         if k not in seen:
             bad.append(f"{k}: no such kernel in {obj} (the check looks for the mangled name)")
+        elif k not in scanned:   # (a changed template signature must not turn the check into a no-op)
+            bad.append(f"{k}: no ADJ = true instantiation was scanned in {obj} — the name heuristic no longer matches the kernel's template arguments")
     return bad
 
 

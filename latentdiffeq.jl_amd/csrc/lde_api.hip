@@ -7,6 +7,7 @@
 // hot path once lde_reserve() (or a first call of the same size) has run.
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <atomic>
 
 #include <cmath>
@@ -29,6 +30,9 @@ int launch_pend_adjoint_par(int kind, int solver, const float* z_out, const floa
                             const KOpts& o, const float* dz_out, float* dz0, float* dtheta, float* ops, int32_t* info,
                             int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret, hipStream_t stream);
 bool pend_adjoint_needs_ops(int B, int T);
+int launch_pend_adjoint_disc(int kind, int solver, const float* z_out, const float* theta, const double* ts_dev, const KOpts& o,
+                             const float* dz_out, float* dz0, float* dtheta, int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret,
+                             hipStream_t stream);
 struct MlpPlan;
 int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err);
 void mlp_plan_destroy(MlpPlan* p);
@@ -71,6 +75,17 @@ struct lde_handle {
   float* par_ops = nullptr;
   int32_t* par_info = nullptr;
   size_t par_cap = 0;
+  // step records (include/lde.h: lde_set_step_record): [0] the forward solve's (LDE_SENSE_DISCRETE / step tracing), [1] the continuous
+  // adjoint's reverse-time steps (step tracing). own: the handle's buffer; user: the caller's (forward record only)
+  void* rec_own[2] = {nullptr, nullptr};
+  size_t rec_own_bytes[2] = {0, 0};
+  void* rec_user = nullptr;
+  size_t rec_user_bytes = 0;
+  lde::StepRec rec_last[2] = {};     // the views the last forward / adjoint were given (lde_get_step_record reads them back)
+  int rec_B = 0, rec_T = 0;          // shape of the forward that wrote rec_last[0]
+  int opt_record_capacity = 0;       // 0: automatic
+  int opt_step_trace = 0;
+  int opt_adjoint_overwrite = 0;
   std::string err = "";
 };
 
@@ -112,7 +127,9 @@ static int validate(const lde_problem_desc* d, std::string* why) {
   if (d->batching != LDE_BATCH_PER_TRAJECTORY && d->batching != LDE_BATCH_COUPLED && d->batching != LDE_BATCH_COUPLED_GLOBAL)
     return bad("unknown batching");
   if (d->batching == LDE_BATCH_COUPLED_GLOBAL && !has_mlp(*d)) return bad("LDE_BATCH_COUPLED_GLOBAL needs an MLP right-hand side");
-  if (d->sensealg < LDE_SENSE_BACKSOLVE_CHECKPOINTED || d->sensealg > LDE_SENSE_PARALLEL_CHECKPOINTED) return bad("unknown sensealg");
+  if (d->sensealg < LDE_SENSE_BACKSOLVE_CHECKPOINTED || d->sensealg > LDE_SENSE_DISCRETE) return bad("unknown sensealg");
+  if (d->sensealg == LDE_SENSE_DISCRETE && d->batching == LDE_BATCH_COUPLED_GLOBAL)
+    return bad("LDE_SENSE_DISCRETE with LDE_BATCH_COUPLED_GLOBAL: not supported (the record would be sharded)");
 
   if (d->solver == LDE_SOLVER_RK4 && d->adaptive) {
     if (why) *why = "RK4 is fixed-step only here: pass adaptive=0, dt=h";
@@ -227,6 +244,8 @@ void lde_destroy(lde_handle* h) {
   if (h->ts_dev) (void)hipFree(h->ts_dev);
   if (h->par_ops) (void)hipFree(h->par_ops);
   if (h->par_info) (void)hipFree(h->par_info);
+  for (int i = 0; i < 2; i++)
+    if (h->rec_own[i]) (void)hipFree(h->rec_own[i]);
   for (int i = 0; i < TS_RING; i++) {
     if (h->ts_pinned[i]) (void)hipHostFree(h->ts_pinned[i]);
     if (h->ts_ev[i]) (void)hipEventDestroy(h->ts_ev[i]);
@@ -262,6 +281,57 @@ int lde_set_weights_device(lde_handle* h, const float* flat_dev, int64_t n, void
 }
 
 }  // extern "C"
+
+// ---- step records --------------------------------------------------------------------------------------------------------------
+static int rec_nseq(const lde_problem_desc& d, int B) { return d.batching == LDE_BATCH_PER_TRAJECTORY ? B : 1; }
+static int rec_capacity(const lde_handle* h, int T, int which) {
+  if (h->opt_record_capacity > 0) return h->opt_record_capacity;
+  const int64_t c = which == 0 ? std::max<int64_t>(64, 4 * (int64_t)T) : std::max<int64_t>(256, 16 * (int64_t)T);
+  return (int)std::min<int64_t>(c, std::max<int64_t>(1, h->d.maxiters));
+}
+static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
+// layout: n [nseq] | t [cap][nseq] | dt [cap][nseq] | y [cap][B][D'] (forward records only)
+static size_t rec_bytes(const lde_problem_desc& d, int B, int cap, bool with_y) {
+  const size_t nseq = (size_t)rec_nseq(d, B), Dp = (size_t)(d.state_dim + d.augment_dim);
+  return align256(nseq * 4) + 2 * align256((size_t)cap * nseq * 8) + (with_y ? align256((size_t)cap * B * Dp * 4) : 0);
+}
+static lde::StepRec rec_view(const lde_problem_desc& d, void* base, int B, int cap, bool with_y) {
+  lde::StepRec r{};
+  const size_t nseq = (size_t)rec_nseq(d, B);
+  unsigned char* p = (unsigned char*)base;
+  r.n = (int32_t*)p; p += align256(nseq * 4);
+  r.t = (double*)p; p += align256((size_t)cap * nseq * 8);
+  r.dt = (double*)p; p += align256((size_t)cap * nseq * 8);
+  r.y = with_y ? (float*)p : nullptr;
+  r.cap = cap;
+  r.nseq = (int)nseq;
+  return r;
+}
+// the record a call of shape (B, T) uses: the caller's buffer if one was handed over (forward records), else the handle's own, grown here
+static int rec_prepare(lde_handle* h, int which, int B, int T, lde::StepRec* out) {
+  const int cap = rec_capacity(h, T, which);
+  const bool with_y = which == 0;
+  const size_t need = rec_bytes(h->d, B, cap, with_y);
+  void* base = nullptr;
+  if (which == 0 && h->rec_user) {
+    if (h->rec_user_bytes < need) {
+      h->err = "step record: the caller's buffer is smaller than lde_step_record_bytes(h, B, T)";
+      return LDE_ERR_INVALID_ARG;
+    }
+    base = h->rec_user;
+  } else {
+    if (h->rec_own_bytes[which] < need) {
+      if (h->rec_own[which]) (void)hipFree(h->rec_own[which]);
+      h->rec_own[which] = nullptr;
+      h->rec_own_bytes[which] = 0;
+      HIP_TRY(h, hipMalloc(&h->rec_own[which], need));
+      h->rec_own_bytes[which] = need;
+    }
+    base = h->rec_own[which];
+  }
+  *out = rec_view(h->d, base, B, cap, with_y);
+  return LDE_OK;
+}
 
 // adjoint_ws: also size the workspace only lde_adjoint needs (the MLP adjoint's staging area is large)
 static int reserve_impl(lde_handle* h, int B, int T, bool adjoint_ws, int64_t steps_hint) {
@@ -301,6 +371,12 @@ static int reserve_impl(lde_handle* h, int B, int T, bool adjoint_ws, int64_t st
       HIP_TRY(h, hipMalloc(&h->par_info, need * sizeof(int32_t)));
       h->par_cap = need;
     }
+  }
+  if (!h->rec_user && (h->d.sensealg == LDE_SENSE_DISCRETE || h->opt_step_trace)) {   // (lde_reserve pre-sizes the handle's own records too)
+    lde::StepRec tmp;
+    int rc = rec_prepare(h, 0, B, T, &tmp);
+    if (!rc && h->opt_step_trace && adjoint_ws && h->d.sensealg != LDE_SENSE_DISCRETE) rc = rec_prepare(h, 1, B, T, &tmp);
+    if (rc) return rc;
   }
   if (h->mlp) {
     const int rc = lde::mlp_reserve(h->mlp, B, T, h->err);
@@ -349,8 +425,10 @@ static lde::KOpts make_opts(const lde_problem_desc& d, const double* ts, int T, 
   o.T = T;
   o.B = B;
   o.lb_hold = 0;
+  o.dw_overwrite = 0;
   o.t_first = ts[0];
   o.t_last = ts[T - 1];
+  o.rec = lde::StepRec{};
   return o;
 }
 
@@ -372,7 +450,15 @@ int lde_forward(lde_handle* h, const float* z0, const float* theta, const double
   if (rc) return rc;
   rc = stage_ts(h, ts, T, stream);
   if (rc) return rc;
-  const lde::KOpts o = make_opts(h->d, ts, T, B);
+  lde::KOpts o = make_opts(h->d, ts, T, B);
+  h->rec_last[0] = lde::StepRec{};
+  if (h->d.sensealg == LDE_SENSE_DISCRETE || h->opt_step_trace) {
+    rc = rec_prepare(h, 0, B, T, &o.rec);
+    if (rc) return rc;
+    h->rec_last[0] = o.rec;
+    h->rec_B = B;
+    h->rec_T = T;
+  }
   int32_t** st = h->st[0];
   h->last_B[0] = B;
   if (h->mlp)
@@ -408,9 +494,39 @@ int lde_adjoint(lde_handle* h, const float* z_out, const float* theta, const dou
   if (rc) return rc;
   rc = stage_ts(h, ts, T, stream);
   if (rc) return rc;
-  const lde::KOpts o = make_opts(h->d, ts, T, B);
+  lde::KOpts o = make_opts(h->d, ts, T, B);
+  o.dw_overwrite = h->opt_adjoint_overwrite;
   int32_t** st = h->st[1];
   h->last_B[1] = B;
+  h->rec_last[1] = lde::StepRec{};
+  if (h->d.sensealg == LDE_SENSE_DISCRETE) {
+    // the record of the forward solve this call differentiates: the caller's buffer (lde_set_step_record) or the handle's own
+    lde::StepRec r;
+    if (h->rec_user) {
+      rc = rec_prepare(h, 0, B, T, &r);
+      if (rc) return rc;
+    } else {
+      if (!h->rec_last[0].n || h->rec_B != B || h->rec_T != T) {
+        h->err = "lde_adjoint (LDE_SENSE_DISCRETE): no step record of an lde_forward with this (B, T) on this handle";
+        return LDE_ERR_INVALID_ARG;
+      }
+      r = h->rec_last[0];
+    }
+    o.rec = r;
+    if (h->mlp)
+      return lde::mlp_adjoint(h->mlp, h->W_dev, z_out, theta, h->ts_dev, o, dz_out, dz0, dtheta, dW, st[0], st[1], st[2], st[3], stream,
+                              h->err);
+    rc = lde::launch_pend_adjoint_disc(h->d.rhs_kind, h->d.solver, z_out, theta, h->ts_dev, o, dz_out, dz0, dtheta, st[0], st[1], st[2],
+                                       st[3], stream);
+    if (rc) h->err = "lde_adjoint: kernel launch failed";
+    return rc;
+  }
+  if (h->opt_step_trace) {
+    rc = rec_prepare(h, 1, B, T, &o.rec);
+    if (rc) return rc;
+    h->rec_last[1] = o.rec;
+    HIP_TRY(h, hipMemsetAsync(o.rec.n, 0, (size_t)o.rec.nseq * 4, stream));
+  }
   if (h->mlp)
     return lde::mlp_adjoint(h->mlp, h->W_dev, z_out, theta, h->ts_dev, o, dz_out, dz0, dtheta, dW, st[0], st[1], st[2],
                             st[3], stream, h->err);
@@ -464,6 +580,72 @@ int lde_set_global_sum_hook(lde_handle* h, lde_sum_hook hook, void* user, int64_
     return LDE_ERR_INVALID_ARG;
   }
   return lde::mlp_set_sum_hook(h->mlp, hook, user, hook ? global_batch : 0, h->err);
+}
+
+int64_t lde_step_record_bytes(const lde_handle* h, int B, int T) {
+  if (!h || B < 1 || T < 1) return 0;
+  return (int64_t)rec_bytes(h->d, B, rec_capacity(h, T, 0), true);
+}
+
+int lde_set_step_record(lde_handle* h, void* rec_dev, int64_t bytes) {
+  if (!h || (rec_dev && bytes < 1) || ((uintptr_t)rec_dev & 255)) {
+    if (h) h->err = "lde_set_step_record: the buffer must be 256-byte aligned device memory";
+    return LDE_ERR_INVALID_ARG;
+  }
+  h->rec_user = rec_dev;
+  h->rec_user_bytes = rec_dev ? (size_t)bytes : 0;
+  return LDE_OK;
+}
+
+int lde_get_step_record(lde_handle* h, int which, double* t_host, double* dt_host, int32_t* n_host, int nseq, int cap, void* stream_) {
+  if (!h || which < 0 || which > 1 || !dt_host || !n_host || nseq < 1 || cap < 1) return LDE_ERR_INVALID_ARG;
+  const lde::StepRec& r = h->rec_last[which];
+  if (!r.n) {
+    h->err = "lde_get_step_record: the last call made no record (LDE_SENSE_DISCRETE or option \"step_trace\")";
+    return LDE_ERR_INVALID_ARG;
+  }
+  if (nseq != r.nseq) {
+    h->err = "lde_get_step_record: nseq does not match the record";
+    return LDE_ERR_INVALID_ARG;
+  }
+  HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream_));
+  HIP_TRY(h, hipMemcpy(n_host, r.n, (size_t)nseq * 4, hipMemcpyDeviceToHost));
+  std::vector<double> buf((size_t)r.cap * nseq);
+  for (int a = 0; a < 2; a++) {
+    double* dst = a == 0 ? t_host : dt_host;
+    const double* src = a == 0 ? r.t : r.dt;
+    if (!dst || (a == 0 && which == 1)) continue;
+    HIP_TRY(h, hipMemcpy(buf.data(), src, buf.size() * 8, hipMemcpyDeviceToHost));
+    for (int q = 0; q < nseq; q++) {
+      const int n = std::min(std::min(n_host[q], r.cap), cap);
+      for (int i = 0; i < cap; i++) dst[(size_t)q * cap + i] = i < n ? buf[(size_t)i * nseq + q] : 0.0;
+    }
+  }
+  return LDE_OK;
+}
+
+static int* option_slot(lde_handle* h, const char* key) {
+  if (!std::strcmp(key, "record_capacity")) return &h->opt_record_capacity;
+  if (!std::strcmp(key, "step_trace")) return &h->opt_step_trace;
+  if (!std::strcmp(key, "adjoint_overwrite")) return &h->opt_adjoint_overwrite;
+  return nullptr;
+}
+int lde_set_option(lde_handle* h, const char* key, double value) {
+  if (!h || !key) return LDE_ERR_INVALID_ARG;
+  int* slot = option_slot(h, key);
+  if (!slot || !(value >= 0) || value > 2e9) {
+    h->err = std::string("lde_set_option: unknown key or value out of range: ") + key;
+    return LDE_ERR_INVALID_ARG;
+  }
+  *slot = (int)value;
+  return LDE_OK;
+}
+int lde_get_option(const lde_handle* h, const char* key, double* value) {
+  if (!h || !key || !value) return LDE_ERR_INVALID_ARG;
+  int* slot = option_slot(const_cast<lde_handle*>(h), key);
+  if (!slot) return LDE_ERR_INVALID_ARG;
+  *value = (double)*slot;
+  return LDE_OK;
 }
 
 const char* lde_last_error(const lde_handle* h) { return h ? h->err.c_str() : "NULL handle"; }

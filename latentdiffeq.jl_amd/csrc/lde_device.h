@@ -14,6 +14,18 @@
 
 namespace lde {
 
+// A step record in device memory (include/lde.h: lde_set_step_record): the accepted steps of each of `nseq` step sequences (one per
+// trajectory, or one for a coupled solve) — written by a forward solve (LDE_SENSE_DISCRETE: start time, step size and start state of
+// every accepted step, what the discrete adjoint sweeps in reverse), read by that adjoint; the continuous adjoint writes the magnitudes of
+// its reverse-time steps into one when step tracing is on (y == nullptr). n == nullptr: no record.
+struct StepRec {
+  int32_t* n;    // [nseq] accepted steps; a count > cap means the record is incomplete
+  double* t;     // [cap][nseq] start time of step n
+  double* dt;    // [cap][nseq] its size (the state advances by (float)dt)
+  float* y;      // [cap][B][D'] state at the start of step n
+  int cap, nseq;
+};
+
 // Options handed to every kernel by value (mirrors the `kwargs...` splat into solve()).
 struct KOpts {
   float abstol, reltol;
@@ -30,6 +42,8 @@ struct KOpts {
   int T, B;
   double t_first, t_last;   // ts[0], ts[T−1] (the host has the grid): a kernel need not load them before its first step
   int lb_hold;              // large-batch forward: a lane this close to the end of the row ring waits for its wave (0: never)
+  StepRec rec;              // forward: the record to write; discrete adjoint: the record to read; continuous adjoint: the trace to write
+  int dw_overwrite;         // adjoint: dW is written, not accumulated (option "adjoint_overwrite")
 };
 
 

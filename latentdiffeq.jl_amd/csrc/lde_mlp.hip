@@ -680,7 +680,14 @@ __global__ void __launch_bounds__(NT) k_mlp_forward(MlpDims dm, KOpts o, FwdArgs
           accepted = 1;
         }
         c->accepted[col] = accepted;
-        if (accepted) c->nacc[col]++;
+        if (accepted) {
+          if (o.rec.n && c->nacc[col] < o.rec.cap && (!coupled || b0 + col == 0)) {   // the step record: start time and size (a coupled solve has ONE sequence)
+            const size_t ri = (size_t)c->nacc[col] * o.rec.nseq + (coupled ? 0 : b0 + col);
+            o.rec.t[ri] = c->t[col];
+            o.rec.dt[ri] = dt;
+          }
+          c->nacc[col]++;
+        }
       } else if (tid < NB)
         c->accepted[tid] = 0;
       __syncthreads();
@@ -736,6 +743,8 @@ __global__ void __launch_bounds__(NT) k_mlp_forward(MlpDims dm, KOpts o, FwdArgs
       // ---- advance accepted columns (FSAL: the last slope becomes k1) --------------------------------------
       FOR_ELEMS(idx, ecol) {
         if (c->accepted[ecol]) {
+          if (o.rec.n && c->nacc[ecol] <= o.rec.cap && b0 + ecol < B)   // … and the state the step started from
+            o.rec.y[((size_t)(c->nacc[ecol] - 1) * B + (b0 + ecol)) * Dp + (idx - ecol * lds)] = P.y[idx];
           P.y[idx] = P.yn[idx];
           P.k(0)[idx] = P.k(LAST_STAGE)[idx];
         }
@@ -767,6 +776,7 @@ __global__ void __launch_bounds__(NT) k_mlp_forward(MlpDims dm, KOpts o, FwdArgs
     a.st_nfe[b] = rep ? c->nfe[col] : 0;
     a.st_nacc[b] = rep ? c->nacc[col] : 0;
     a.st_nrej[b] = rep ? c->nrej[col] : 0;
+    if (o.rec.n && rep) o.rec.n[coupled ? 0 : b] = ret == 0 ? c->nacc[col] : 0;
   }
 #undef FOR_ELEMS
 }
@@ -1340,6 +1350,7 @@ __global__ void __launch_bounds__(NT) k_mlp_adjoint(MlpDims dm, KOpts o, BwdArgs
 #undef FOR_ELEMS
 }
 
+#include "lde_mlpd.h"
 #include "lde_mlp4.h"
 #include "lde_mlpv.h"
 #include "lde_mlp64.h"
@@ -1405,6 +1416,7 @@ struct MlpPlan {
   // lde_set_phase_timing: HIP events around the adjoint's solve kernel and its weight-gradient tail (bench.py's per-kernel roofline)
   bool phase_on = false;
   hipEvent_t ph_ev[3] = {nullptr, nullptr, nullptr};
+  bool disc = false;           // LDE_SENSE_DISCRETE: lde_adjoint sweeps the forward solve's step record (lde_mlpd.h)
 };
 
 void mlp_plan_destroy(MlpPlan* p);
@@ -1426,6 +1438,7 @@ int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err) 
   dm.has_pend = d.rhs_kind == LDE_RHS_PENDULUM_PLUS_MLP;
   dm.coupled = d.batching == LDE_BATCH_COUPLED || d.batching == LDE_BATCH_COUPLED_GLOBAL;
   p->global_mode = d.batching == LDE_BATCH_COUPLED_GLOBAL;
+  p->disc = d.sensealg == LDE_SENSE_DISCRETE;
   dm.solver = d.solver;
   int hmax = 16;
   for (int l = 0; l + 1 < dm.nL; l++) hmax = std::max(hmax, dm.sizes[l + 1]);
@@ -1659,7 +1672,7 @@ int mlp_reserve(MlpPlan* p, int B, int T, std::string& err) {
 // (slow but correct). LDE_MLP_STAGE_SLOTS forces the slot count (tests).
 int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::string& err) {
   const MlpDims& dm = p->dm;
-  if (mlp64_applicable(dm, B)) {   // no staging area: a slab row per wave is the kernel's only workspace
+  if (!p->disc && mlp64_applicable(dm, B)) {   // no staging area: a slab row per wave is the kernel's only workspace
     p->rows_stride = (dm.nW + 63) & ~63;
     if (!grow(&p->rows, &p->rows_cap, (size_t)mlp64_adj_waves(B) * p->rows_stride)) {
       err = "MLP plan: hipMalloc of the weight-gradient rows failed";
@@ -1667,7 +1680,7 @@ int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::strin
     }
     return LDE_OK;
   }
-  if (b_applicable(p, B, T, true, dm.coupled != 0) || c_applicable(p, B, T, true, dm.coupled != 0)) {   // no staging area either: one slab row per workgroup
+  if (!p->disc && (b_applicable(p, B, T, true, dm.coupled != 0) || c_applicable(p, B, T, true, dm.coupled != 0))) {   // no staging area either: one slab row per workgroup
     p->rows_stride = (dm.nW + 63) & ~63;
     if (!grow(&p->rows, &p->rows_cap, (size_t)B * p->rows_stride)) {
       err = "MLP plan: hipMalloc of the weight-gradient rows failed";
@@ -2267,13 +2280,14 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
                 const KOpts& o, float* z_out, int32_t* retcode, int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret,
                 hipStream_t stream, std::string& err) {
   const MlpDims& dm = p->dm;
-  if (mlp64_applicable(dm, o.B)) {   // small network, small state: one wave per trajectory, registers only (lde_mlp64.h)
+  const bool recording = o.rec.n != nullptr;   // the step record is written by k_mlp_forward (the tiles)
+  if (!recording && mlp64_applicable(dm, o.B)) {   // small network, small state: one wave per trajectory, registers only (lde_mlp64.h)
     VArgs va{};
     va.z0 = z0; va.theta = theta; va.ts = ts_dev; va.Wflat = W_dev; va.z_out = z_out; va.retcode = retcode;
     va.st_nfe = nfe; va.st_nacc = nacc; va.st_nrej = nrej; va.st_ret = ret;
     return launch_mlp64<false>(dm, o, va, stream, err);
   }
-  {   // small batches: one trajectory per workgroup, lanes = hidden units (lde_mlpv.h)
+  if (!recording) {   // small batches: one trajectory per workgroup, lanes = hidden units (lde_mlpv.h)
     size_t ldsv = 0;
     const bool ca = dm.coupled && o.adaptive && o.B > 1;
     const bool use_b = b_applicable(p, o.B, o.T, false, ca);
@@ -2426,10 +2440,69 @@ static int launch_mlp4(const MlpDims& dm, const Mlp4Dims& md, const KOpts& o, co
                            "k_mlp4_adjoint", dmv, mdv, ov, av);
 }
 
+// LDE_SENSE_DISCRETE: the reverse sweep over the forward solve's step record (lde_mlpd.h), then the weight gradient from the staged panels
+static int mlp_adjoint_disc(MlpPlan* p, const float* W_dev, const float* z_out, const float* theta, const double* ts_dev,
+                            const KOpts& o, const float* dz_out, float* dz0, float* dtheta, float* dW, int32_t* nfe, int32_t* nacc,
+                            int32_t* nrej, int32_t* ret, hipStream_t stream, std::string& err) {
+  const MlpDims& dm = p->dm;
+  if (!o.rec.n || !o.rec.y) {
+    err = "MLP adjoint (LDE_SENSE_DISCRETE): no step record";
+    return LDE_ERR_INVALID_ARG;
+  }
+  const int nwg = cdiv(o.B, NB);
+  const size_t fixed = disc_lds_fixed(dm, o.T, 512);
+  if (fixed > LDS_MAX) {
+    err = "MLP adjoint (LDE_SENSE_DISCRETE): tile state does not fit the 160 KiB LDS";
+    return LDE_ERR_UNSUPPORTED;
+  }
+  if (!p->stage || p->adj_cap < 1) {
+    err = "MLP adjoint: workspace not reserved";
+    return LDE_ERR_INVALID_ARG;
+  }
+  BwdArgs a{};
+  a.z_out = z_out; a.dz_out = dz_out; a.theta = theta; a.ts = ts_dev; a.frag = p->frag; a.fragT = p->fragT; a.Wflat = W_dev;
+  a.dz0 = dz0; a.dtheta = dtheta; a.slab = p->slab;
+  a.stage = p->stage; a.wts = p->wts; a.nslots = p->nslots; a.nflush = p->nslots + (nwg + 1); a.cap = p->adj_cap;
+  a.ovf = p->fb_dev + 1; a.fallback = 0;
+  a.st_nfe = nfe; a.st_nacc = nacc; a.st_nrej = nrej; a.st_ret = ret;
+  a.gs.counter = p->counter; a.gs.slots = p->slots; a.gs.abort_flag = p->abort_flag; a.gs.nwg = 1;
+  const size_t lds = with_cache(fixed, p->nfrag + p->nfragT);
+  a.lds_bytes = (int)lds;
+  if (!zero_regions(stream, {{p->fb_dev, 2 * sizeof(int32_t)}, {p->nslots, (size_t)2 * (nwg + 1) * sizeof(int32_t)}})) {
+    err = "k_zero_regions failed";
+    return LDE_ERR_HIP;
+  }
+  const bool rk4 = dm.solver == LDE_SOLVER_RK4;
+  const void* fn = rk4 ? (const void*)k_mlp_adjoint_disc<LDE_SOLVER_RK4, 512> : (const void*)k_mlp_adjoint_disc<LDE_SOLVER_TSIT5, 512>;
+  static bool attr_set[2] = {false, false};
+  if (!attr_set[rk4]) {
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
+      err = "hipFuncSetAttribute(k_mlp_adjoint_disc) failed";
+      return LDE_ERR_HIP;
+    }
+    attr_set[rk4] = true;
+  }
+  MlpDims dmv = dm;
+  KOpts ov = o;
+  phase_mark(p, 0, stream);
+  int rc = launch_maybe_coop(false, fn, dim3(nwg), dim3(512), lds, stream, err, "k_mlp_adjoint_disc", dmv, ov, a);
+  if (rc) return rc;
+  phase_mark(p, 1, stream);
+  DwArgs da;
+  da.stage = p->stage; da.wts = p->wts; da.nslots = p->nslots; da.slab = p->slab + (size_t)(nwg + 1) * dm.slab_n; da.cap = p->adj_cap; da.total = 0;
+  if (dW) {
+    rc = launch_weight_gradient(dm, da, nwg, p->adj_ks, p->slab, p->nslots + (nwg + 1), nwg, dW, p->fb_dev, stream, err, o.dw_overwrite != 0);
+    if (rc) return rc;
+  }
+  phase_mark(p, 2, stream);
+  return LDE_OK;
+}
+
 int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float* theta, const double* ts_dev,
                 const KOpts& o, const float* dz_out, float* dz0, float* dtheta, float* dW, int32_t* nfe, int32_t* nacc,
                 int32_t* nrej, int32_t* ret, hipStream_t stream, std::string& err) {
   const MlpDims& dm = p->dm;
+  if (p->disc) return mlp_adjoint_disc(p, W_dev, z_out, theta, ts_dev, o, dz_out, dz0, dtheta, dW, nfe, nacc, nrej, ret, stream, err);
   if (mlp64_applicable(dm, o.B)) {   // one wave per trajectory, registers only, the weight gradient included (lde_mlp64.h): two launches
     const int waves = mlp64_adj_waves(o.B);
     if (!p->rows || p->rows_cap < (size_t)waves * p->rows_stride || p->rows_stride < dm.nW) {

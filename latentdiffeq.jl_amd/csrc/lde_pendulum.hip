@@ -210,6 +210,11 @@ __global__ void __launch_bounds__(256) k_pend_forward(const float2* __restrict__
         dtp = dt * (double)fast_rcp(q);
         if (dtp > dtmax) dtp = dtmax;
       }
+      if (o.rec.n && nacc < o.rec.cap) {   // LDE_SENSE_DISCRETE / step tracing: the accepted step's start time, size and start state
+        o.rec.t[(size_t)nacc * B + b] = t;
+        o.rec.dt[(size_t)nacc * B + b] = dt;
+        reinterpret_cast<float2*>(o.rec.y)[(size_t)nacc * B + b] = make_float2(y[0], y[1]);
+      }
       nacc++;
       const double tnew = last ? tend : t + dt;
       if (j < T && tj <= tnew) {  // at least one save time in (t, tnew]
@@ -257,6 +262,7 @@ __global__ void __launch_bounds__(256) k_pend_forward(const float2* __restrict__
   st_nfe[b] = nfe;
   st_nacc[b] = nacc;
   st_nrej[b] = nrej;
+  if (o.rec.n) o.rec.n[b] = ret == LDE_RET_SUCCESS ? nacc : 0;
 }
 
 // ---- forward, small batches: stepping and dense output on different waves, pipelined through LDS ------------------------
@@ -1003,6 +1009,7 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
       st_nfe[b] = nfe + NS * (nacc + nrej);
       st_nacc[b] = nacc;
       st_nrej[b] = nrej;
+      if (o.rec.n) o.rec.n[b] = ret == LDE_RET_SUCCESS ? nacc : 0;
     }
     return;
   }
@@ -1030,6 +1037,11 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
         const f32x2 ye = {q[0], q[1]};
         const double t1 = (h == (float)(tend - tn)) ? tend : tn + (double)h;   // exactly the stepper's arithmetic
         const bool mine = (nrec % SH_NH) == hid;
+        if (o.rec.n && hid == 0 && lane == 0 && valid && nrec < o.rec.cap) {   // the step record (LDE_SENSE_DISCRETE), off the stepper's chain
+          o.rec.t[(size_t)nrec * B + b] = tn;
+          o.rec.dt[(size_t)nrec * B + b] = (double)h;
+          reinterpret_cast<float2*>(o.rec.y)[(size_t)nrec * B + b] = make_float2(ys.x, ys.y);
+        }
         if (__any(tj <= t1)) {
           f32x2 k0 = {0.f, 0.f}, kE = {0.f, 0.f}, P2 = {0.f, 0.f}, P3 = {0.f, 0.f}, P4 = {0.f, 0.f};
           float rh = 0.f;
@@ -1682,7 +1694,8 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
 #undef LDE_LAUNCH_SH
     return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
   }
-  if (o.T > 1 && o.B <= tl_max_b) {
+  const bool recording = o.rec.n != nullptr;   // k_pend_forward_sh and k_pend_forward are the mappings that write step records
+  if (!recording && o.T > 1 && o.B <= tl_max_b) {
     const bool ad = o.adaptive != 0;
     const bool few = o.T - 1 <= 64;   // a lane serves exactly one save time: the variant without a load in the stepping loop
 #define LDE_LAUNCH_TL(K, S, A)                                                                                          \
@@ -1704,7 +1717,7 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
 #undef LDE_LAUNCH_TL
     return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
   }
-  if (ws_on && shm && o.T > 2 && o.B <= ws_max_b) {
+  if (!recording && ws_on && shm && o.T > 2 && o.B <= ws_max_b) {
     const size_t lds = (size_t)((o.T + 1) & ~1) * sizeof(double) + (size_t)WS_CAP * 64 * WS_RW * sizeof(float);
     const int g64 = (o.B + 63) / 64;
 #define LDE_LAUNCH_WS(K, S, A)                                                                                         \
@@ -1739,7 +1752,7 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
   // LDE_PEND_LB = rows of the ring (8 / 16 / 32; 0: off), LDE_PEND_LB_HOLD = the hold margin.
   static const int lb_ring = [] { const char* e = getenv("LDE_PEND_LB"); return e ? atoi(e) : 16; }();   // rows of the ring; 0: off
   static const int lb_min_b = [] { const char* e = getenv("LDE_PEND_LB_MIN_B"); return e ? atoi(e) : (1 << 17); }();
-  if (lb_ring > 0 && o.T > 1 && o.T <= 2048 && o.B >= lb_min_b) {   // (the save grid in LDS beside the ring: T ≤ 2048)
+  if (!recording && lb_ring > 0 && o.T > 1 && o.T <= 2048 && o.B >= lb_min_b) {   // (the save grid in LDS beside the ring: T ≤ 2048)
     // a lane sits out while j ≥ jc + RING − hold; the slowest lane has j = jc, so hold ≤ RING − 1 keeps it (and with it jc) moving —
     // hold ≥ RING would hold EVERY lane on every iteration and the solve loop would never end. Default: half the ring.
     static const int lb_hold_env = [] { const char* e = getenv("LDE_PEND_LB_HOLD"); return e ? atoi(e) : -1; }();
@@ -1802,6 +1815,217 @@ int launch_pend_adjoint(int kind, int solver, const float* z_out, const float* t
       hipLaunchKernelGGL((k_pend_adjoint<K, S, false>), dim3(grid), dim3(block), 0, stream, (const float2*)z_out,     \
                          theta, ts_dev, o, (const float2*)dz_out, (float2*)dz0, dtheta, nfe, nacc, nrej, ret);      \
   } while (0)
+  if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH(0, LDE_SOLVER_TSIT5);
+  else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_RK4) LDE_LAUNCH(0, LDE_SOLVER_RK4);
+  else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH(1, LDE_SOLVER_TSIT5);
+  else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_RK4) LDE_LAUNCH(1, LDE_SOLVER_RK4);
+  else return LDE_ERR_UNSUPPORTED;
+#undef LDE_LAUNCH
+  return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
+}
+
+// ---- discrete (exact) sensitivity: LDE_SENSE_DISCRETE ---------------------------------------------------------------------------
+// What the reference's GOKU default ForwardDiffSensitivity() [REF examples/pendulum_friction-less/pendulum.jl:11] differentiates
+// [REF src/models/GOKU.jl:107, :121]: the discrete solve on its accepted step sequence, step sizes constant. A lane owns a trajectory and
+// sweeps ITS recorded steps (t_n, dt_n, y_n) from the last to the first: the six (four) stage points and their sin / cos are rebuilt from
+// y_n — the forward kernel's arithmetic on the forward kernel's inputs — and the cotangent is pulled through the dense output of every save
+// time inside the step, the FSAL slope, the solution weights and the stage sums.
+// No controller, no error norm, no forced stops at the save times: (2S + 1) sine/cosine pairs per accepted step. Traffic = the record
+// (24 B per step) + Δẑ; every access coalesced over the batch index.
+template <int KIND, int SOLVER>
+__global__ void __launch_bounds__(256) k_pend_adjoint_disc(const float2* __restrict__ z_out, const float* __restrict__ theta,
+                                                           const double* __restrict__ ts_g, KOpts o,
+                                                           const float2* __restrict__ dz_out, float2* __restrict__ dz0,
+                                                           float* __restrict__ dtheta, int32_t* __restrict__ st_nfe,
+                                                           int32_t* __restrict__ st_nacc, int32_t* __restrict__ st_nrej,
+                                                           int32_t* __restrict__ st_ret) {
+  extern __shared__ __attribute__((aligned(16))) double s_lds[];
+  const int T = o.T, B = o.B;
+  const bool ts_lds = T <= TS_LDS_MAX;
+  if (ts_lds)
+    for (int i = threadIdx.x; i < T; i += blockDim.x) s_lds[i] = ts_g[i];
+  __syncthreads();
+  auto s_ts = [&](int i) -> double { return ts_lds ? s_lds[i] : ts_g[i]; };
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  constexpr int S = SOLVER == LDE_SOLVER_TSIT5 ? 6 : 4;
+  // a_ij of the stages and, in row S, the solution weights
+  constexpr float RK[5][4] = {{0.f, 0.f, 0.f, 0.f}, {0.5f, 0.f, 0.f, 0.f}, {0.f, 0.5f, 0.f, 0.f}, {0.f, 0.f, 1.f, 0.f},
+                              {1.0f / 6.0f, 1.0f / 3.0f, 1.0f / 3.0f, 1.0f / 6.0f}};
+  auto A = [&](int i, int q) -> float { return SOLVER == LDE_SOLVER_TSIT5 ? ts5::A[i][q] : RK[i][q]; };
+  const StepRec& R = o.rec;
+  const float L = theta[b];
+  const float ngl = -10.0f / L, gl2 = 10.0f / (L * L);
+  const float2 y0 = z_out[b];
+  const int ns = R.n[b];
+  int ret = LDE_RET_SUCCESS;
+  if (!isfinite(y0.x) || !isfinite(y0.y)) ret = LDE_RET_NONFINITE;      // a failed forward trajectory: zero gradient [REF GOKU.jl:114]
+  else if (T > 1 && (ns < 1 || ns > R.cap)) ret = LDE_RET_MAXITERS;      // no usable record: NaN gradient (never a truncated sweep)
+  float yb[2] = {0.f, 0.f}, carry[2] = {0.f, 0.f}, gth = 0.f;
+  float sn[S + 1], cs[S + 1];
+  sn[0] = cs[0] = 0.f;
+  if (ret == LDE_RET_SUCCESS && T > 1) {
+    const double tend = s_ts(T - 1);
+    int j = T - 1;
+    double tnext = tend;
+    for (int s = ns - 1; s >= 0; s--) {
+      const double t = R.t[(size_t)s * B + b], dt = R.dt[(size_t)s * B + b];
+      const float2 yv = reinterpret_cast<const float2*>(R.y)[(size_t)s * B + b];
+      const float h = (float)dt;
+      const bool last = s == ns - 1;
+      const double tnew = tnext;
+      tnext = t;
+      // ---- the stage points again: g_0 = y_n, g_i = y_n + h Σ a_iq k_q, g_S = y_{n+1}
+      const float noff = turn_anchor(yv.x);
+      float gx[S + 1], gy[S + 1], kx[S], ky[S];
+      gx[0] = yv.x;
+      gy[0] = yv.y;
+#pragma unroll
+      for (int i = 0; i <= S; i++) {
+        if (i > 0) {
+          if (SOLVER == LDE_SOLVER_RK4 && i == S) {   // the forward kernel's own form of the RK4 update
+            const float h6 = h * (1.0f / 6.0f);
+            gx[i] = yv.x + h6 * (kx[0] + 2.0f * (kx[1] + kx[2]) + kx[3]);
+            gy[i] = yv.y + h6 * (ky[0] + 2.0f * (ky[1] + ky[2]) + ky[3]);
+          } else {
+            float ax = A(i, 0) * kx[0], ay = A(i, 0) * ky[0];
+#pragma unroll
+            for (int q = 1; q < i; q++) {
+              ax += A(i, q) * kx[q];
+              ay += A(i, q) * ky[q];
+            }
+            gx[i] = yv.x + h * ax;
+            gy[i] = yv.y + h * ay;
+          }
+        }
+        hw_sincos(gx[i], sn[i], cs[i], noff);
+        if (i < S) {
+          kx[i] = gy[i];
+          float acc = ngl * sn[i];
+          if (KIND == 1) acc -= 0.7f * gy[i];
+          ky[i] = acc;
+        }
+      }
+      // ---- cotangents of the slopes: the FSAL slope carries the next step's k̄₁
+      float kbx[S + 1], kby[S + 1];
+#pragma unroll
+      for (int i = 0; i < S; i++) kbx[i] = kby[i] = 0.f;
+      kbx[S] = carry[0];
+      kby[S] = carry[1];
+      float ynx = 0.f, yny = 0.f;   // cotangent reaching y_n directly
+      // the save times inside the step (t, tnew]: moments of Θ for the interpolant's polynomial weights
+      float c1x = 0.f, c1y = 0.f, c2x = 0.f, c2y = 0.f, c3x = 0.f, c3y = 0.f, c4x = 0.f, c4y = 0.f;
+      const float rh = fast_rcp(h);
+      while (j >= 1) {
+        const double tj = s_ts(j);
+        if (!(tj > t)) break;
+        const float2 dj = dz_out[(size_t)j * B + b];
+        if (tj >= tnew || (j == T - 1 && last)) {
+          yb[0] += dj.x;
+          yb[1] += dj.y;
+        } else {
+          const float th = (float)(tj - t) * rh;
+          if (SOLVER == LDE_SOLVER_TSIT5) {
+            ynx += dj.x;
+            yny += dj.y;
+            const float t2 = th * th, t3 = t2 * th, t4 = t2 * t2;
+            c1x += th * dj.x; c1y += th * dj.y;
+            c2x += t2 * dj.x; c2y += t2 * dj.y;
+            c3x += t3 * dj.x; c3y += t3 * dj.y;
+            c4x += t4 * dj.x; c4y += t4 * dj.y;
+          } else {   // cubic Hermite on (y_n, k₁, y_{n+1}, f(y_{n+1}))
+            const float om = 1.0f - th;
+            const float h00 = (1.0f + 2.0f * th) * om * om, h10 = th * om * om;
+            const float h01 = th * th * (3.0f - 2.0f * th), h11 = th * th * (th - 1.0f);
+            ynx += h00 * dj.x; yny += h00 * dj.y;
+            kbx[0] += (h10 * h) * dj.x; kby[0] += (h10 * h) * dj.y;
+            yb[0] += h01 * dj.x; yb[1] += h01 * dj.y;
+            kbx[S] += (h11 * h) * dj.x; kby[S] += (h11 * h) * dj.y;
+          }
+        }
+        j--;
+      }
+      if (SOLVER == LDE_SOLVER_TSIT5) {   // k̄_i += h Σ_j b_i(Θ_j) Δ_j, b_1 = Θ + r₁₂Θ² + r₁₃Θ³ + r₁₄Θ⁴, b_i = r_i2Θ² + r_i3Θ³ + r_i4Θ⁴
+        kbx[0] += h * (c1x + ts5::R1[0] * c2x + ts5::R1[1] * c3x + ts5::R1[2] * c4x);
+        kby[0] += h * (c1y + ts5::R1[0] * c2y + ts5::R1[1] * c3y + ts5::R1[2] * c4y);
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          kbx[i + 1] += h * (ts5::R[i][0] * c2x + ts5::R[i][1] * c3x + ts5::R[i][2] * c4x);
+          kby[i + 1] += h * (ts5::R[i][0] * c2y + ts5::R[i][1] * c3y + ts5::R[i][2] * c4y);
+        }
+      }
+      // Jᵀk̄ at stage point i: J = [[0, 1], [ngl cos x, −b/m]], ∂f₂/∂L = gl2 sin x
+      auto vjp = [&](int i, float kx_, float ky_, float& vx, float& vy) {
+        vx = ngl * cs[i] * ky_;
+        vy = kx_;
+        if (KIND == 1) vy -= 0.7f * ky_;
+        gth += gl2 * sn[i] * ky_;
+      };
+      {   // the FSAL evaluation at y_{n+1}
+        float vx, vy;
+        vjp(S, kbx[S], kby[S], vx, vy);
+        yb[0] += vx;
+        yb[1] += vy;
+      }
+#pragma unroll
+      for (int i = 0; i < S; i++) {   // y_{n+1} = y_n + h Σ b_i k_i
+        kbx[i] += (h * A(S, i)) * yb[0];
+        kby[i] += (h * A(S, i)) * yb[1];
+      }
+      ynx += yb[0];
+      yny += yb[1];
+#pragma unroll
+      for (int i = S - 1; i >= 1; i--) {
+        float vx, vy;
+        vjp(i, kbx[i], kby[i], vx, vy);
+        ynx += vx;
+        yny += vy;
+#pragma unroll
+        for (int q = 0; q < i; q++) {
+          if (A(i, q) != 0.f) {
+            kbx[q] += (h * A(i, q)) * vx;
+            kby[q] += (h * A(i, q)) * vy;
+          }
+        }
+      }
+      carry[0] = kbx[0];
+      carry[1] = kby[0];
+      yb[0] = ynx;
+      yb[1] = yny;
+    }
+    {   // k₁ of the first step = f(y_0): sn[0], cs[0] of the last iteration are those of y_0
+      float vx = ngl * cs[0] * carry[1], vy = carry[0];
+      if (KIND == 1) vy -= 0.7f * carry[1];
+      gth += gl2 * sn[0] * carry[1];
+      yb[0] += vx;
+      yb[1] += vy;
+    }
+  }
+  if (ret == LDE_RET_SUCCESS) {   // save time 0 is ẑ₀ itself
+    const float2 d0 = dz_out[b];
+    yb[0] += d0.x;
+    yb[1] += d0.y;
+  }
+  const float qn = __int_as_float(0x7fc00000);
+  const bool nanout = ret == LDE_RET_MAXITERS;
+  dz0[b] = ret == LDE_RET_SUCCESS ? make_float2(yb[0], yb[1]) : (nanout ? make_float2(qn, qn) : make_float2(0.f, 0.f));
+  dtheta[b] = ret == LDE_RET_SUCCESS ? gth : (nanout ? qn : 0.f);
+  st_ret[b] = ret;
+  const int nst = ret == LDE_RET_SUCCESS && T > 1 ? ns : 0;
+  st_nfe[b] = nst * (2 * S + 1) + (nst ? 1 : 0);
+  st_nacc[b] = nst;
+  st_nrej[b] = 0;
+}
+
+int launch_pend_adjoint_disc(int kind, int solver, const float* z_out, const float* theta, const double* ts_dev, const KOpts& o,
+                             const float* dz_out, float* dz0, float* dtheta, int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret,
+                             hipStream_t stream) {
+  if (!o.rec.n || !o.rec.y) return LDE_ERR_INVALID_ARG;
+  const int block = pick_block(o.B), grid = (o.B + block - 1) / block;
+  const size_t shm = o.T <= TS_LDS_MAX ? (size_t)o.T * sizeof(double) : 0;
+#define LDE_LAUNCH(K, S)                                                                                                         \
+  hipLaunchKernelGGL((k_pend_adjoint_disc<K, S>), dim3(grid), dim3(block), shm, stream, (const float2*)z_out, theta, ts_dev, o, \
+                     (const float2*)dz_out, (float2*)dz0, dtheta, nfe, nacc, nrej, ret)
   if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH(0, LDE_SOLVER_TSIT5);
   else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_RK4) LDE_LAUNCH(0, LDE_SOLVER_RK4);
   else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH(1, LDE_SOLVER_TSIT5);

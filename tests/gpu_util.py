@@ -93,6 +93,22 @@ class Native:
         return (dz0.cpu().numpy(), None if dth is None else dth.cpu().numpy(),
                 None if dW is None else dW.cpu().numpy(), self.stats(1))
 
+    def set_option(self, key, value):
+        L.check(self.lib.lde_set_option(self.h, key.encode(), float(value)), self.h, "lde_set_option")
+
+    def step_record(self, which, B, cap=None):
+        """Host copy of the last call's step sequences as the oracle's `rec` dict: t, dt [nseq, cap], n [nseq]."""
+        nseq = B if self.d.batching == L.BATCH_PER_TRAJECTORY else 1
+        cap = cap or 4096
+        t, dt, n = np.zeros((nseq, cap)), np.zeros((nseq, cap)), np.zeros(nseq, np.int32)
+        s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        L.check(self.lib.lde_get_step_record(self.h, which, t.ctypes.data_as(C.c_void_p) if which == 0 else None,
+                                             dt.ctypes.data_as(C.c_void_p), n.ctypes.data_as(C.c_void_p), nseq, cap, s), self.h,
+                "lde_get_step_record")
+        m = max(int(n.max()), 1)
+        assert m <= cap, "record longer than the host copy"
+        return dict(t=t[:, :m].copy(), dt=dt[:, :m].copy(), n=n)
+
     def stats(self, which):
         st = L.Stats()
         L.check(self.lib.lde_get_stats(self.h, which, C.byref(st), C.c_void_p(torch.cuda.current_stream().cuda_stream)),

@@ -112,6 +112,9 @@ typedef struct {
   real* del[2];           /* backprop scratch */
   real* dW_step;          /* [nW] contributions of the current step attempt (NULL if none) */
   int64_t nW;
+  double* margin;         /* (optional) running minimum of |pre-activation| / (Σ|w·x| + |b|) over the hidden units evaluated: how close this
+                             column's solve came to a relu kink (tests: a gradient that differs between two f32 implementations by more than
+                             round-off must have passed within round-off of one) */
 } colrhs;
 
 static int64_t num_weights(const lde_problem_desc* d) {
@@ -173,6 +176,13 @@ static void mlp_forward(colrhs* c, const real* z) {
       const real* col = Wl + (int64_t)out * i;
       for (int o = 0; o < out; o++) y[o] += col[o] * xi;
     }
+    if (c->margin && l < c->nL - 1)
+      for (int o = 0; o < out; o++) {
+        double sa = fabs((double)bl[o]);
+        for (int i = 0; i < in; i++) sa += fabs((double)Wl[o + (int64_t)out * i] * (double)c->act[l][i]);
+        const double m = sa > 0 ? fabs((double)y[o]) / sa : 1.0;
+        if (m < *c->margin) *c->margin = m;
+      }
     if (l < c->nL - 1)
       for (int o = 0; o < out; o++) y[o] = act_fn(d->activation, y[o]);
   }
@@ -657,6 +667,7 @@ typedef struct {
   colrhs* cs;          /* coupled mode with nth > 1: one RHS scratch per OpenMP thread (columns of a stage evaluation are
                           independent — the reference gets the same from OpenBLAS threads under its per-stage sgemms) */
   int nth;
+  double* col_margin;  /* (optional) [ncol] relu-kink margins of the block's columns (discrete sweep) */
 } blockctx;
 
 static void block_threads_init(blockctx* b, const lde_problem_desc* d, const real* W, int nthreads) {
@@ -949,7 +960,7 @@ static int adjoint_parallel(const lde_problem_desc* d, const real* z_out, const 
 
 static int adjoint_discrete(const lde_problem_desc* d, const real* W, const real* z_out, const real* theta, const double* ts, int T, int B,
                             const real* dz_out, const double* rec_t, const double* rec_dt, const int32_t* rec_n, int rec_cap, real* dz0,
-                            real* dtheta, real* dW, int64_t* stats, int nthreads);
+                            real* dtheta, real* dW, int64_t* stats, double* margins, int nthreads);
 
 /* dW is ACCUMULATED (+=), as in lde_adjoint. rec_*: the reverse-time solve's accepted step magnitudes, recorded or prescribed. */
 static int adjoint_impl(const lde_problem_desc* d, const real* W, const real* z_out, const real* theta, const double* ts,
@@ -1095,7 +1106,14 @@ static void dtab_init(dtab* tb, int solver) {
 }
 
 /* f for the block's columns */
-static void blk_f(blockctx* b, const real* y, real* dy) { fwd_fn(b, 0.0, y, dy, 0); }
+static void blk_f(blockctx* b, const real* y, real* dy) {
+  if (!b->col_margin) { fwd_fn(b, 0.0, y, dy, 0); return; }
+  for (int c = 0; c < b->ncol; c++) {
+    b->c.margin = b->col_margin + c;
+    rhs_col(&b->c, y + (int64_t)c * b->Dp, b->theta + (int64_t)c * b->P, dy + (int64_t)c * b->Dp);
+  }
+  b->c.margin = NULL;
+}
 /* vz += J(y)ᵀ kb; gth += (∂f/∂θ)ᵀ kb; dW_acc += (∂f/∂W)ᵀ kb — skipped altogether when kb is identically zero */
 static void blk_vjp(blockctx* b, const real* y, const real* kb, real* vz_add, real* gth, sstat* st) {
   int64_t n = (int64_t)b->Dp * b->ncol;
@@ -1105,7 +1123,9 @@ static void blk_vjp(blockctx* b, const real* y, const real* kb, real* vz_add, re
   real f[1024], vz[1024], vth[16];
   for (int c = 0; c < b->ncol; c++) {
     if (b->c.dW_step) memset(b->c.dW_step, 0, (size_t)b->c.nW * sizeof(real));
+    b->c.margin = b->col_margin ? b->col_margin + c : NULL;
     rhs_vjp_col(&b->c, y + (int64_t)c * b->Dp, b->theta + (int64_t)c * b->P, kb + (int64_t)c * b->Dp, f, vz, vth, (real)1);
+    b->c.margin = NULL;
     for (int i = 0; i < b->Dp; i++) vz_add[(int64_t)c * b->Dp + i] += vz[i];
     for (int p = 0; p < b->P; p++) gth[(int64_t)c * b->P + p] += vth[p];
     if (b->c.dW_step && b->dW_acc)
@@ -1241,8 +1261,10 @@ static int discrete_block(blockctx* b, const lde_problem_desc* d, const real* y0
 
 static int adjoint_discrete(const lde_problem_desc* d, const real* W, const real* z_out, const real* theta, const double* ts, int T, int B,
                             const real* dz_out, const double* rec_t, const double* rec_dt, const int32_t* rec_n, int rec_cap, real* dz0,
-                            real* dtheta, real* dW, int64_t* stats, int nthreads) {
+                            real* dtheta, real* dW, int64_t* stats, double* margins, int nthreads) {
   int rc = check_desc(d);
+  if (margins)
+    for (int c = 0; c < B; c++) margins[c] = 1.0;
   if (rc) return rc;
   if (T < 1 || B < 1 || !rec_t || !rec_dt || !rec_n) return LDE_ERR_INVALID_ARG;
   const int D = d->state_dim, Dp = D + d->augment_dim, P = d->param_dim;
@@ -1270,6 +1292,7 @@ static int adjoint_discrete(const lde_problem_desc* d, const real* W, const real
       const int c0 = coupled ? 0 : blk;
       b.theta = theta ? theta + (int64_t)c0 * P : NULL;
       b.dzout = dz_out + (int64_t)Dp * c0;
+      b.col_margin = margins ? margins + c0 : NULL;
       int bad = 0;
       for (int c = 0; c < ncol; c++)
         for (int i = 0; i < Dp; i++) {
@@ -1311,7 +1334,14 @@ static int adjoint_discrete(const lde_problem_desc* d, const real* W, const real
 int oracle_adjoint_discrete(const lde_problem_desc* d, const real* W, const real* z_out, const real* theta, const double* ts, int T, int B,
                             const real* dz_out, const double* rec_t, const double* rec_dt, const int32_t* rec_n, int rec_cap, real* dz0,
                             real* dtheta, real* dW, int64_t* stats, int nthreads) {
-  return adjoint_discrete(d, W, z_out, theta, ts, T, B, dz_out, rec_t, rec_dt, rec_n, rec_cap, dz0, dtheta, dW, stats, nthreads);
+  return adjoint_discrete(d, W, z_out, theta, ts, T, B, dz_out, rec_t, rec_dt, rec_n, rec_cap, dz0, dtheta, dW, stats, NULL, nthreads);
+}
+/* … and how close each trajectory's discrete solve came to a relu kink: margins[B] = min over its hidden-unit evaluations of
+ * |pre-activation| / (Σ|w·x| + |b|) (1 for tanh networks' purposes too: the number is what it is, the tests use it for relu). */
+int oracle_adjoint_discrete_margins(const lde_problem_desc* d, const real* W, const real* z_out, const real* theta, const double* ts, int T,
+                                    int B, const real* dz_out, const double* rec_t, const double* rec_dt, const int32_t* rec_n, int rec_cap,
+                                    real* dz0, real* dtheta, real* dW, int64_t* stats, double* margins, int nthreads) {
+  return adjoint_discrete(d, W, z_out, theta, ts, T, B, dz_out, rec_t, rec_dt, rec_n, rec_cap, dz0, dtheta, dW, stats, margins, nthreads);
 }
 
 /* RHS and VJP of a single column, exported for unit tests of the RHS menu. */

@@ -238,8 +238,9 @@ class Oracle:
         info = dict(nfe=int(stats[0]), naccept=int(stats[1]), nreject=int(stats[2]), nfailed=int(stats[3]), max_steps=int(stats[4]))
         return dz0, (dth[:, :P] if P else None), (dW[:nW] if nW else None), dict(dt=rdt, n=rn), info
 
-    def adjoint_discrete(self, d: Desc, z_out, theta, ts, dz_out, rec, W=None, nthreads=0):
-        """LDE_SENSE_DISCRETE: reverse-mode derivative of the discrete solve on the recorded steps `rec` (of forward_steps, or of a kernel)."""
+    def adjoint_discrete(self, d: Desc, z_out, theta, ts, dz_out, rec, W=None, nthreads=0, margins=False):
+        """LDE_SENSE_DISCRETE: reverse-mode derivative of the discrete solve on the recorded steps `rec` (of forward_steps, or of a kernel).
+        margins=True: info["margins"][b] = how close trajectory b's solve came to a relu kink (min |pre-activation| / Σ|terms|)."""
         dt = self.dtype
         z_out = np.ascontiguousarray(z_out, dtype=dt)
         dz_out = np.ascontiguousarray(dz_out, dtype=dt)
@@ -257,12 +258,13 @@ class Oracle:
         nW = self.num_weights(d) if d.rhs_kind in (RHS_MLP, RHS_PENDULUM_PLUS_MLP) else 0
         dW = np.zeros(max(nW, 1), dtype=dt)
         stats = np.zeros(5, dtype=np.int64)
-        rc = self.lib.oracle_adjoint_discrete(C.byref(d), self._p(W), self._p(z_out), self._p(theta), self._p(ts), T, B, self._p(dz_out),
-                                              self._p(rt), self._p(rdt), self._p(rn), rt.shape[1], self._p(dz0), self._p(dth), self._p(dW),
-                                              self._p(stats), nthreads)
+        mg = np.ones(B) if margins else None
+        rc = self.lib.oracle_adjoint_discrete_margins(C.byref(d), self._p(W), self._p(z_out), self._p(theta), self._p(ts), T, B,
+                                                      self._p(dz_out), self._p(rt), self._p(rdt), self._p(rn), rt.shape[1], self._p(dz0),
+                                                      self._p(dth), self._p(dW), self._p(stats), self._p(mg), nthreads)
         if rc != 0:
             raise RuntimeError(f"oracle_adjoint_discrete failed: {rc}")
-        info = dict(nfe=int(stats[0]), naccept=int(stats[1]), nreject=0, nfailed=int(stats[3]), max_steps=int(stats[4]))
+        info = dict(nfe=int(stats[0]), naccept=int(stats[1]), nreject=0, nfailed=int(stats[3]), max_steps=int(stats[4]), margins=mg)
         return dz0, (dth[:, :P] if P else None), (dW[:nW] if nW else None), info
 
     def rhs(self, d: Desc, z, theta, W=None):

@@ -9,6 +9,13 @@ step) is handed to the oracle, which replays exactly those steps (`forward_steps
     |Δẑ| ≤ 2e-5 (f32 round-off through the stages),
     every gradient ≤ 1e-4 of its largest entry against the f32 oracle AND against the float64 oracle on the same steps —
 also for relu networks at the reference's default tolerances (reltol 1e-3), where the continuous-adjoint gates are 1e-2.
+
+The one thing arithmetic cannot pin: a relu unit whose pre-activation lies within f32 round-off of zero is switched on in one
+implementation and off in the other (different summation orders), and that trajectory's gradient then differs by a finite amount.
+At the BASELINE sizes this happens to about one unit evaluation in 10⁷ (measured, abl/disc_diag.py: c3 at B = 1024 — 21 M unit
+evaluations — 2 trajectories; the reference's NODE shape at B = 64 — 1; c4 at B = 512 — 0; the tanh twins of all three: 0, every
+gradient within 3e-6). The full-size relu tests therefore hold every trajectory to 1e-4 EXCEPT those the float64 oracle finds within
+1e-5 (relative) of a kink on the same steps — these are named by the oracle, must be few, and a mismatch anywhere else fails.
 """
 import os
 
@@ -36,7 +43,10 @@ def _rel(a, b):
     return np.abs(a - b).max() / max(np.abs(b).max(), 1e-30)
 
 
-def _check(nat, od, o32, o64, z0, theta, ts, dz, W, z_tol=Z_TOL, g_tol=G_TOL, check64=True):
+KINK = 1e-5     # a relu pre-activation this close to zero (relative to Σ|w·x| + |b|) may fall on either side in f32
+
+
+def _check(nat, od, o32, o64, z0, theta, ts, dz, W, z_tol=Z_TOL, g_tol=G_TOL, check64=True, kinks=False):
     B = z0.shape[0]
     z, ret, st = nat.forward(z0, theta, ts)
     assert (ret == 0).all() and st["nfailed"] == 0
@@ -48,7 +58,20 @@ def _check(nat, od, o32, o64, z0, theta, ts, dz, W, z_tol=Z_TOL, g_tol=G_TOL, ch
     assert np.abs(z - zr).max() <= z_tol, np.abs(z - zr).max()
     g0, gth, gW, sb = nat.adjoint(z, theta, ts, dz)
     assert sb["nfailed"] == 0 and sb["nreject"] == 0
-    r0, rth, rW, _ = o32.adjoint_discrete(od, z, theta, ts, dz, rec, W=W, nthreads=NT)
+    r0, rth, rW, ri = o32.adjoint_discrete(od, z, theta, ts, dz, rec, W=W, nthreads=NT, margins=kinks)
+    if kinks:
+        # per-trajectory errors; the trajectories the oracle finds at a relu kink are exempt from the 1e-4 gate (module docstring)
+        per = np.abs(g0 - r0).max(axis=1) / np.abs(r0).max()
+        if theta is not None:
+            per = np.maximum(per, np.abs(gth - rth).max(axis=1) / np.abs(rth).max())
+        near = ri["margins"] < KINK
+        off = per > g_tol
+        assert np.median(per) <= 2e-6, np.median(per)
+        assert not (off & ~near).any(), ("a gradient differs away from any relu kink", np.nonzero(off & ~near)[0][:8], per[off & ~near][:8])
+        assert off.sum() <= max(2, B // 50) and per.max() <= 0.1, (int(off.sum()), per.max())
+        if W is not None:
+            assert _rel(gW, rW) <= (g_tol if not off.any() else 1e-2), _rel(gW, rW)
+        return z, rec, (g0, gth, gW), st, sb
     errs = {"dz0": _rel(g0, r0)}
     if theta is not None:
         errs["dtheta"] = _rel(gth, rth)
@@ -194,11 +217,15 @@ def test_discrete_uses_far_fewer_evaluations_than_the_continuous_adjoint():
                                     ("c2_rk4_relu", 256)])
 def test_discrete_at_baseline_sizes(o32, o64, name, B):
     """BASELINE.json configs[2] (B = 1024), configs[3] at one GPU's share (B = 512), the reference's own LatentODE example (B = 64),
-    configs[1] (B = 256): relu networks at the reference's DEFAULT tolerances, gradients held to 1e-4."""
+    configs[1] (B = 256): relu networks at the reference's DEFAULT tolerances, every trajectory's gradient held to 1e-4 unless the oracle
+    finds it at a relu kink (module docstring) — and the tanh twin of each shape, where nothing is exempt: 1e-5."""
     kw, _ = MLP_CASES[name]
     W, z0, theta, ts, dz = _mlp_inputs(kw, B, seed=3)
     nat, od = _native(W, **kw)
-    _check(nat, od, o32, o64, z0, theta, ts, dz, W, check64=(B <= 256 or kw["rhs_kind"] == O.RHS_PENDULUM_PLUS_MLP))
+    _check(nat, od, o32, o64, z0, theta, ts, dz, W, kinks=True)
+    kwt = {**kw, "activation": O.ACT_TANH}
+    nat, od = _native(W, **kwt)
+    _check(nat, od, o32, o64, z0, theta, ts, dz, W, g_tol=1e-5, check64=False)
 
 
 # ---------------------------------------------------------------------------------------------------- through the reference's interface

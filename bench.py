@@ -50,7 +50,7 @@ WORKLOADS = {
 }
 
 
-def build_problem(w, B, seed_shift=0):
+def build_problem(w, B, seed_shift=0, sensealg="default"):
     from latentdiffeq_amd import _lib as L
     from latentdiffeq_amd import synthetic as O
     lib = L.load()
@@ -65,6 +65,8 @@ def build_problem(w, B, seed_shift=0):
     d.batching = L.BATCH_COUPLED if w["batching"] == "coupled" else L.BATCH_PER_TRAJECTORY
     if w["solver"] == "rk4":
         d.adaptive, d.dt = 0, w["dt"]
+    if sensealg == "discrete":   # LDE_SENSE_DISCRETE: what the reference's GOKU default ForwardDiffSensitivity() differentiates [REF pendulum.jl:11]
+        d.sensealg = L.SENSE_DISCRETE
     T, D = w["T"], w["D"]
     ts = O.time_grid(T)
     if w["rhs"] == "mlp":
@@ -109,6 +111,10 @@ def cpu_baseline(w, d_native, ts, z0, theta, W, dz, budget_s=12.0):
     z0s, ths, dzs = z0[:cap], (None if theta is None else theta[:cap]), dz[:, :cap]
 
     def one(nt):
+        if od.sensealg == O.SENSE_DISCRETE:   # the same definition of the gradient on the CPU: record the steps, sweep them in reverse
+            z, _, rec, _ = orc.forward_steps(od, z0s, ths, ts, W=W, cap=1024, nthreads=nt)
+            orc.adjoint_discrete(od, z, ths, ts, dzs, rec, W=W, nthreads=nt)
+            return
         z, _, _ = orc.forward(od, z0s, ths, ts, W=W, nthreads=nt)
         orc.adjoint(od, z, ths, ts, dzs, W=W, nthreads=nt)
 
@@ -672,6 +678,9 @@ def main():
                     help="weak: the workload's batch on EVERY GPU (default); strong: the workload's batch split over the GPUs")
     ap.add_argument("--dtype", default="f32", choices=["f32", "mixed"],
                     help="goku_step / goku_decoder: 'mixed' = bf16 dense chains (f32 accumulate, f32 master weights), f32 solve")
+    ap.add_argument("--sensealg", default="default", choices=["default", "discrete"],
+                    help="discrete: LDE_SENSE_DISCRETE (the exact derivative of the discrete solve — the reference's ForwardDiffSensitivity) "
+                         "instead of the workload's continuous adjoint")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--sweep", action="store_true", help="also report a large-batch sweep (extra keys, rank 0)")
     ap.add_argument("--dry-launch", action="store_true", help="exercise the N-rank launch path without GPUs (gloo)")
@@ -756,7 +765,7 @@ def main():
 
     def measure(B, seed_shift, detail):
         """W warm-up steps, then exactly K timed steps of lde_forward + lde_adjoint on B resident trajectories."""
-        d, ts, z0, theta, W, dz = build_problem(w, B, seed_shift=seed_shift)
+        d, ts, z0, theta, W, dz = build_problem(w, B, seed_shift=seed_shift, sensealg=args.sensealg)
         h = C.c_void_p()
         L.check(lib.lde_create(C.byref(d), C.byref(h)), None, "lde_create")
         nW = int(lib.lde_num_weights(C.byref(d)))
@@ -789,6 +798,21 @@ def main():
         def step():
             fwd()
             bwd()
+
+        # the same step as a training loop pays it (MLP right-hand sides): the weights are handed over before every forward solve
+        # (lde_set_weights_device + the re-layout launches behind it: the optimiser has just changed them) and the pullback WRITES dW
+        # (option "adjoint_overwrite": no zero fill by the caller)
+        Wd = torch.from_numpy(W).to(dev) if nW else None
+
+        def step_train():
+            L.check(lib.lde_set_weights_device(h, p(Wd), nW, sp), h, "lde_set_weights_device")
+            fwd()
+            L.check(lib.lde_adjoint(h, p(zout), p(thd), tsp, T, B, p(dzd), p(dz0), p(dth), p(dW), sp), h, "lde_adjoint")
+            if world > 1:
+                if comm is not None:
+                    comm.allreduce_(dW)
+                else:
+                    dist.all_reduce(dW)
 
         # The analytic-RHS step is two ≈ 5–11 µs kernels: a launch-bound inner loop, so the K timed steps are submitted as hipGraph
         # replays (chunks of ≤ 256 captured steps; every step still runs both kernels on the same buffers — abl/metric_graph.py:
@@ -861,6 +885,14 @@ def main():
                 torch.cuda.synchronize()
                 samp.append(time.perf_counter() - t1)
             res["sync_call"] = (float(np.median(samp)) * 1e3, float(np.mean(samp)) * 1e3, nsync)
+            if nW:
+                L.check(lib.lde_set_option(h, b"adjoint_overwrite", 1.0), h, "lde_set_option")
+                step_train()
+                res["step_train"] = kernel_ms(step_train, nprobe)
+                L.check(lib.lde_set_option(h, b"adjoint_overwrite", 0.0), h, "lde_set_option")
+                fam = C.c_double(-1.0)
+                lib.lde_get_option(h, b"adjoint_family", C.byref(fam))
+                res["adjoint_family"] = int(fam.value)
             if nW:   # the adjoint's two phases, from HIP events the library records on this stream (lde_set_phase_timing)
                 lib.lde_set_phase_timing(h, 1)
                 ph = []
@@ -899,10 +931,14 @@ def main():
     fb, bb = alg_bytes_per_traj(w)
     dom, dom_ms, dom_stream, dom_bytes = ("lde_adjoint", bwd_ms, bwd_stream, bb) if bwd_ms >= fwd_ms else ("lde_forward", fwd_ms, fwd_stream, fb)
     Ff = flops_per_eval(w)
+    # flops of the pullback per evaluation it reports: the continuous adjoint's evaluations are fused (forward + z-VJP + weight gradient:
+    # 3·F_f); the discrete sweep reports 2S per accepted step — S forward-only (F_f) and S fused (3·F_f): 2·F_f on average
+    disc = args.sensealg == "discrete"
+    adj_f = 2 if disc else 3
     if Ff and w["batching"] == "coupled":
-        flops = (fstat["nfe"] * Ff + bstat["nfe"] * 3 * Ff) * B
+        flops = (fstat["nfe"] * Ff + bstat["nfe"] * adj_f * Ff) * B
     else:
-        flops = fstat["nfe"] * Ff + bstat["nfe"] * 3 * Ff
+        flops = fstat["nfe"] * Ff + bstat["nfe"] * adj_f * Ff
     if Ff:  # MLP right-hand side: compute-bound on the f32 MFMA/VALU rate
         # the DOMINANT kernel = the adjoint's solve kernel: its flops are the recomputed forward pass and the z-VJP of every evaluation
         # (2·F_f each; the weight-gradient product, the third F_f, is counted where it runs — inside that kernel or in the tail)
@@ -910,8 +946,9 @@ def main():
         ph = m.get("phase_ms")
         # k_mlp64 / k_mlpb / k_mlpc fold gW inside the solve kernel (what follows it is the fixed-order row sum: a few µs); the tile
         # kernels and k_mlpw / k_mlpv stage (a_l, δ_l) for k_mlp_dw, whose product then is the tail's
-        in_kernel_dw = ph is not None and ph[1] < 0.05 * ph[0]
-        dom_flops = bstat["nfe"] * (3 if in_kernel_dw else 2) * Ff * cols
+        # which family ran: reported by the library (option "adjoint_family": 1 k_mlp64, 2 k_mlpb, 3 k_mlpc fold in the kernel), not guessed
+        in_kernel_dw = m.get("adjoint_family", -1) in (1, 2, 3)
+        dom_flops = bstat["nfe"] * ((2 if in_kernel_dw else 1.5) if disc else (3 if in_kernel_dw else 2)) * Ff * cols
         dom_ms_k = ph[0] if ph else bwd_stream
         ach = dom_flops / (dom_ms_k * 1e-3) / 1e12
         whole = flops / ((fwd_stream + bwd_stream) * 1e-3) / 1e12
@@ -948,11 +985,19 @@ def main():
         # per-step figures from HIP events (an event pair around every step): the wall-clock mean above is K steps / elapsed
         "ms_per_step_events": {"median": m["step"][1], "mean": m["step"][0], "back_to_back": m["step"][2], "samples": min(max(args.steps, 20), 200)},
         "solver_stats": {"forward": fstat, "adjoint": bstat},
+        "sensealg": "LDE_SENSE_DISCRETE (exact derivative of the discrete solve on its accepted steps)" if disc else "workload default (continuous adjoint)",
         # device-synchronised per call, median of ≥ 100 (host enqueue + wake-up included) — beside the pipelined figure above
         "per_call_synchronised": {"median_ms": m["sync_call"][0], "mean_ms": m["sync_call"][1], "samples": m["sync_call"][2],
                                   "value": B * world / (m["sync_call"][0] * 1e-3), "unit": "trajectories/s"},
     }
 
+    if "step_train" in m:
+        # the MLP lines' step as a training loop pays it: lde_set_weights_device (+ its re-layout launches) before every forward solve, dW
+        # written by the pullback (no zero fill) — beside the headline, whose weights are uploaded once
+        st_ = m["step_train"]
+        out["training_step"] = {"what": "lde_set_weights_device + lde_forward + lde_adjoint (option adjoint_overwrite: dW written, no fill launch)",
+                                "ms_per_step": st_[2], "ms_per_step_bracketed": st_[0], "value": global_batch / (st_[2] * 1e-3),
+                                "adjoint_family": m.get("adjoint_family")}
     if world > 1 and args.scaling == "weak" and args.workload == "goku_pendulum":
         # the same ranks on the GLOBAL batch of the metric (256 split over the GPUs): the strong-scaling figure beside the weak one
         lo, hi = shard_bounds(Bw, rank, world)

@@ -241,6 +241,8 @@ int lde_get_step_record(lde_handle* h, int which, double* t_host, double* dt_hos
  *   "record_capacity"  accepted steps a step record holds per sequence (0: automatic)
  *   "step_trace"       1: lde_forward records its steps whatever the sensealg, lde_adjoint (continuous) records its reverse-time steps
  *   "adjoint_overwrite" 1: lde_adjoint WRITES dW (every entry exactly once) instead of accumulating — the caller's zero fill disappears
+ * lde_get_option also answers the read-only "adjoint_family": the kernel family the last lde_adjoint ran on an MLP right-hand side
+ * (0 tiles, 1 k_mlp64, 2 k_mlpb, 3 k_mlpc, 4 k_mlpw, 5 k_mlpv, 6 k_mlp4; −1 none) — what bench.py prices its roofline with.
  * Unknown key: LDE_ERR_INVALID_ARG. */
 int lde_set_option(lde_handle* h, const char* key, double value);
 int lde_get_option(const lde_handle* h, const char* key, double* value);

@@ -39,6 +39,7 @@ void mlp_plan_destroy(MlpPlan* p);
 int mlp_reserve(MlpPlan* p, int B, int T, std::string& err);
 int mlp_set_sum_hook(MlpPlan* p, lde_sum_hook hook, void* user, int64_t global_batch, std::string& err);
 int mlp_set_phase_timing(MlpPlan* p, int on);
+int mlp_last_family(const MlpPlan* p);
 int mlp_get_phase_ms(MlpPlan* p, float* out);
 int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::string& err);
 int mlp_set_weights(MlpPlan* p, const float* W_dev, hipStream_t stream, std::string& err);
@@ -642,6 +643,10 @@ int lde_set_option(lde_handle* h, const char* key, double value) {
 }
 int lde_get_option(const lde_handle* h, const char* key, double* value) {
   if (!h || !key || !value) return LDE_ERR_INVALID_ARG;
+  if (!std::strcmp(key, "adjoint_family")) {   // read-only: the kernel family the last lde_adjoint ran (MLP right-hand sides; −1: none)
+    *value = h->mlp ? (double)lde::mlp_last_family(h->mlp) : -1.0;
+    return LDE_OK;
+  }
   int* slot = option_slot(const_cast<lde_handle*>(h), key);
   if (!slot) return LDE_ERR_INVALID_ARG;
   *value = (double)*slot;

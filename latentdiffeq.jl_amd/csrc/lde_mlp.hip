@@ -1417,6 +1417,8 @@ struct MlpPlan {
   bool phase_on = false;
   hipEvent_t ph_ev[3] = {nullptr, nullptr, nullptr};
   bool disc = false;           // LDE_SENSE_DISCRETE: lde_adjoint sweeps the forward solve's step record (lde_mlpd.h)
+  int last_family = -1;        // the kernel family of the last lde_adjoint: 0 tiles (gW in the tail: k_mlp_dw), 1 k_mlp64, 2 k_mlpb, 3 k_mlpc (gW folded
+                               // in the solve kernel), 4 k_mlpw, 5 k_mlpv, 6 k_mlp4 (staged, tail)
 };
 
 void mlp_plan_destroy(MlpPlan* p);
@@ -1424,6 +1426,8 @@ static bool mlp64_applicable(const MlpDims& dm, int B);
 static int mlp64_adj_waves(int B);
 static bool b_applicable(const MlpPlan* p, int B, int T, bool adj, bool coupled_adaptive);
 static bool c_applicable(const MlpPlan* p, int B, int T, bool adj, bool coupled_adaptive);
+enum { DISC_TILES = 0, DISC_64 = 1, DISC_B = 2, DISC_C = 3 };
+static int disc_family(const MlpPlan* p, int B, int T);
 
 int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err) {
   MlpPlan* p = new MlpPlan();
@@ -1672,7 +1676,7 @@ int mlp_reserve(MlpPlan* p, int B, int T, std::string& err) {
 // (slow but correct). LDE_MLP_STAGE_SLOTS forces the slot count (tests).
 int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::string& err) {
   const MlpDims& dm = p->dm;
-  if (!p->disc && mlp64_applicable(dm, B)) {   // no staging area: a slab row per wave is the kernel's only workspace
+  if (mlp64_applicable(dm, B)) {   // no staging area: a slab row per wave is the kernel's only workspace (continuous and discrete adjoint alike)
     p->rows_stride = (dm.nW + 63) & ~63;
     if (!grow(&p->rows, &p->rows_cap, (size_t)mlp64_adj_waves(B) * p->rows_stride)) {
       err = "MLP plan: hipMalloc of the weight-gradient rows failed";
@@ -1680,7 +1684,9 @@ int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::strin
     }
     return LDE_OK;
   }
-  if (!p->disc && (b_applicable(p, B, T, true, dm.coupled != 0) || c_applicable(p, B, T, true, dm.coupled != 0))) {   // no staging area either: one slab row per workgroup
+  const int dfam = p->disc ? disc_family(p, B, T) : -1;
+  if (p->disc ? (dfam == DISC_B || dfam == DISC_C)
+              : (b_applicable(p, B, T, true, dm.coupled != 0) || c_applicable(p, B, T, true, dm.coupled != 0))) {   // no staging area either: one slab row per workgroup
     p->rows_stride = (dm.nW + 63) & ~63;
     if (!grow(&p->rows, &p->rows_cap, (size_t)B * p->rows_stride)) {
       err = "MLP plan: hipMalloc of the weight-gradient rows failed";
@@ -1836,14 +1842,16 @@ static int mlp64_adj_waves(int B) {   // = workgroups = slab rows
   const int need = (B + MLP64_NWV - 1) / MLP64_NWV;
   return need < maxw ? need : maxw;
 }
-template <bool ADJ>
+template <bool ADJ, bool DISC = false>
 static int launch_mlp64(const MlpDims& dm, const KOpts& o, const VArgs& a, hipStream_t stream, std::string& err) {
   const bool rk4 = dm.solver == LDE_SOLVER_RK4, d2 = dm.Dp <= 2;
   if (ADJ) {
     const dim3 grid(mlp64_adj_waves(o.B));
     const size_t lds = (size_t)MLP64_NWV * a.cap * sizeof(float);   // the four waves' rows (c3: 4 × 17.9 KB)
-    const void* fn = rk4 ? (d2 ? (const void*)k_mlp64_adj<LDE_SOLVER_RK4, 2> : (const void*)k_mlp64_adj<LDE_SOLVER_RK4, 4>)
-                         : (d2 ? (const void*)k_mlp64_adj<LDE_SOLVER_TSIT5, 2> : (const void*)k_mlp64_adj<LDE_SOLVER_TSIT5, 4>);
+    const void* fn = DISC ? (rk4 ? (d2 ? (const void*)k_mlp64_disc<LDE_SOLVER_RK4, 2> : (const void*)k_mlp64_disc<LDE_SOLVER_RK4, 4>)
+                                 : (d2 ? (const void*)k_mlp64_disc<LDE_SOLVER_TSIT5, 2> : (const void*)k_mlp64_disc<LDE_SOLVER_TSIT5, 4>))
+                          : (rk4 ? (d2 ? (const void*)k_mlp64_adj<LDE_SOLVER_RK4, 2> : (const void*)k_mlp64_adj<LDE_SOLVER_RK4, 4>)
+                                 : (d2 ? (const void*)k_mlp64_adj<LDE_SOLVER_TSIT5, 2> : (const void*)k_mlp64_adj<LDE_SOLVER_TSIT5, 4>));
     static bool attr_set[2][2] = {{false, false}, {false, false}};
     if (!attr_set[rk4][d2]) {
       hipFuncAttributes fa{};
@@ -2041,7 +2049,7 @@ static bool b_applicable(const MlpPlan* p, int B, int T, bool adj, bool coupled_
   // round, a coupled adaptive one needs every trajectory resident
   return B <= (coupled_adaptive ? 256 : 512);
 }
-template <int SOLVER, bool ADJ>
+template <int SOLVER, bool ADJ, bool DISC = false>
 static int launch_b(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t stream, std::string& err) {
   MlpDims dmv = p->dm;
   BDims bdv = p->bd;
@@ -2049,8 +2057,8 @@ static int launch_b(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t
   const bool d8 = bdv.DP == 8;
   const bool tanh_ = dmv.act == LDE_ACT_TANH;
   const size_t cot = ADJ ? (size_t)o.T * dmv.Dp * 4 * (o.checkpoint ? 2 : 1) : 0;
-  const void* fn = tanh_ ? (d8 ? (const void*)k_mlpb<SOLVER, 8, LDE_ACT_TANH, ADJ> : (const void*)k_mlpb<SOLVER, 16, LDE_ACT_TANH, ADJ>)
-                         : (d8 ? (const void*)k_mlpb<SOLVER, 8, LDE_ACT_RELU, ADJ> : (const void*)k_mlpb<SOLVER, 16, LDE_ACT_RELU, ADJ>);
+  const void* fn = tanh_ ? (d8 ? (const void*)k_mlpb<SOLVER, 8, LDE_ACT_TANH, DISC, ADJ> : (const void*)k_mlpb<SOLVER, 16, LDE_ACT_TANH, DISC, ADJ>)
+                         : (d8 ? (const void*)k_mlpb<SOLVER, 8, LDE_ACT_RELU, DISC, ADJ> : (const void*)k_mlpb<SOLVER, 16, LDE_ACT_RELU, DISC, ADJ>);
   size_t lds = b_lds_base(bdv, o.T, ADJ, SOLVER == LDE_SOLVER_RK4 ? 4 : 6);
   a.cot_lds = ADJ && cot <= 40 * 1024 && lds + cot <= LDS_MAX;   // the trajectory's dẑ (and saved ẑ) by save time: no global load inside the solve
   if (a.cot_lds) lds += cot;
@@ -2098,13 +2106,25 @@ static bool c_applicable(const MlpPlan* p, int B, int T, bool adj, bool coupled_
   // one workgroup (two trajectories) per CU: 512 trajectories are resident at once, which a coupled adaptive solve needs
   return B <= (coupled_adaptive ? 512 : 1024);
 }
-template <int SOLVER, bool ADJ>
+// LDE_SENSE_DISCRETE: the kernel family that sweeps the step record. The register kernels take the shapes they serve in the continuous
+// adjoint — without that path's residency limit (no grid-wide sum here: workgroups may queue) — up to what one slab row per workgroup
+// costs in memory; everything else runs on the tiles (lde_mlpd.h).
+static int disc_family(const MlpPlan* p, int B, int T) {
+  const MlpDims& dm = p->dm;
+  if (mlp64_applicable(dm, B)) return DISC_64;
+  const int nst = dm.solver == LDE_SOLVER_RK4 ? 4 : 6;
+  if (b_applicable(p, std::min(B, 256), T, true, false) && B <= 1024 && b_lds_base(p->bd, T, true, nst) + (size_t)T * dm.Dp * 4 <= LDS_MAX) return DISC_B;
+  if (c_applicable(p, std::min(B, 512), T, true, false) && B <= 2048) return DISC_C;
+  return DISC_TILES;
+}
+
+template <int SOLVER, bool ADJ, bool DISC = false>
 static int launch_c(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t stream, std::string& err) {
   MlpDims dmv = p->dm;
   CDims cdv = p->cd;
   KOpts ov = o;
   const bool tanh_ = dmv.act == LDE_ACT_TANH;
-  const void* fn = tanh_ ? (const void*)k_mlpc<SOLVER, LDE_ACT_TANH, ADJ> : (const void*)k_mlpc<SOLVER, LDE_ACT_RELU, ADJ>;
+  const void* fn = tanh_ ? (const void*)k_mlpc<SOLVER, LDE_ACT_TANH, DISC, ADJ> : (const void*)k_mlpc<SOLVER, LDE_ACT_RELU, DISC, ADJ>;
   size_t lds = c_lds_base(o.T, ADJ, SOLVER == LDE_SOLVER_RK4 ? 4 : 6);
   const size_t cot = ADJ ? (size_t)2 * o.T * dmv.Dp * 4 * (o.checkpoint ? 2 : 1) : 0;
   a.cot_lds = ADJ && lds + cot <= LDS_MAX;   // the two trajectories' dẑ (and saved ẑ) by save time: no global load inside the solve
@@ -2140,6 +2160,8 @@ static int launch_c(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t
 #endif
   return rcl;
 }
+
+int mlp_last_family(const MlpPlan* p) { return p->last_family; }
 
 int mlp_set_phase_timing(MlpPlan* p, int on) {
   if (on && !p->ph_ev[0])
@@ -2280,24 +2302,24 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
                 const KOpts& o, float* z_out, int32_t* retcode, int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret,
                 hipStream_t stream, std::string& err) {
   const MlpDims& dm = p->dm;
-  const bool recording = o.rec.n != nullptr;   // the step record is written by k_mlp_forward (the tiles)
-  if (!recording && mlp64_applicable(dm, o.B)) {   // small network, small state: one wave per trajectory, registers only (lde_mlp64.h)
+  const bool recording = o.rec.n != nullptr;   // the step record is written by k_mlp64 and by k_mlp_forward (the tiles)
+  if (mlp64_applicable(dm, o.B)) {   // small network, small state: one wave per trajectory, registers only (lde_mlp64.h)
     VArgs va{};
     va.z0 = z0; va.theta = theta; va.ts = ts_dev; va.Wflat = W_dev; va.z_out = z_out; va.retcode = retcode;
     va.st_nfe = nfe; va.st_nacc = nacc; va.st_nrej = nrej; va.st_ret = ret;
     return launch_mlp64<false>(dm, o, va, stream, err);
   }
-  if (!recording) {   // small batches: one trajectory per workgroup, lanes = hidden units (lde_mlpv.h)
+  {   // small batches: one trajectory per workgroup, lanes = hidden units (lde_mlpv.h)
     size_t ldsv = 0;
     const bool ca = dm.coupled && o.adaptive && o.B > 1;
     const bool use_b = b_applicable(p, o.B, o.T, false, ca);
     const bool use_c = !use_b && c_applicable(p, o.B, o.T, false, ca);
-    const bool use_w = use_b || use_c || w_applicable(p, o.B, o.T, false, ca);
+    const bool use_w = use_b || use_c || (!recording && w_applicable(p, o.B, o.T, false, ca));   // (k_mlpw / k_mlpv write no step record)
     if (p->global_mode && !use_w) {
       err = "LDE_BATCH_COUPLED_GLOBAL: this shape / batch is not served by the register kernels (three Dense layers, 2·D' ≤ 64, H ≤ 200, B·W ≤ 1024 waves)";
       return LDE_ERR_UNSUPPORTED;
     }
-    if (use_w || vec_applicable(p, o.B, o.T, false, ca, &ldsv, err)) {
+    if (use_w || (!recording && vec_applicable(p, o.B, o.T, false, ca, &ldsv, err))) {
       VArgs va{};
       va.z0 = z0; va.theta = theta; va.ts = ts_dev; va.vecw = p->vecw; va.Wflat = W_dev; va.z_out = z_out; va.retcode = retcode;
       va.st_nfe = nfe; va.st_nacc = nacc; va.st_nrej = nrej; va.st_ret = ret;
@@ -2449,6 +2471,38 @@ static int mlp_adjoint_disc(MlpPlan* p, const float* W_dev, const float* z_out, 
     err = "MLP adjoint (LDE_SENSE_DISCRETE): no step record";
     return LDE_ERR_INVALID_ARG;
   }
+  const int fam = disc_family(p, o.B, o.T);
+  p->last_family = fam == DISC_B ? 2 : (fam == DISC_C ? 3 : 0);
+  if (fam == DISC_B || fam == DISC_C) {   // W₂ as register blocks, the weight gradient folded on the CU: two launches, no staging area, no grid-wide sum
+    const int nrows = fam == DISC_B ? o.B : (o.B + 1) / 2;
+    if (!p->rows || p->rows_cap < (size_t)o.B * p->rows_stride || p->rows_stride < dm.nW) {
+      err = "MLP adjoint: workspace not reserved";
+      return LDE_ERR_INVALID_ARG;
+    }
+    VArgs va{};
+    va.theta = theta; va.ts = ts_dev; va.Wflat = W_dev; va.z_out = const_cast<float*>(z_out); va.dz_out = dz_out;
+    va.dz0 = dz0; va.dtheta = dtheta; va.stage = p->rows; va.cap = p->rows_stride;
+    va.st_nfe = nfe; va.st_nacc = nacc; va.st_nrej = nrej; va.st_ret = ret;
+    va.gs.counter = p->counter; va.gs.slots = p->slots; va.gs.abort_flag = p->abort_flag; va.gs.nwg = 1;
+    va.gs.host_req = nullptr; va.gs.host_rep = nullptr; va.gs.dev_rep = nullptr; va.Bnorm = 0;
+    phase_mark(p, 0, stream);
+    const bool rk4 = dm.solver == LDE_SOLVER_RK4;
+    const int rcb = fam == DISC_B ? (rk4 ? launch_b<LDE_SOLVER_RK4, true, true>(p, o, va, false, stream, err)
+                                         : launch_b<LDE_SOLVER_TSIT5, true, true>(p, o, va, false, stream, err))
+                                  : (rk4 ? launch_c<LDE_SOLVER_RK4, true, true>(p, o, va, false, stream, err)
+                                         : launch_c<LDE_SOLVER_TSIT5, true, true>(p, o, va, false, stream, err));
+    if (rcb) return rcb;
+    phase_mark(p, 1, stream);
+    if (dW) {
+      hipLaunchKernelGGL(k_sum_rows, dim3(cdiv(dm.nW, 64)), dim3(1024), 0, stream, p->rows, nrows, p->rows_stride, dm.nW, dW, o.dw_overwrite);
+      if (hipGetLastError() != hipSuccess) {
+        err = "k_sum_rows launch failed";
+        return LDE_ERR_HIP;
+      }
+    }
+    phase_mark(p, 2, stream);
+    return LDE_OK;
+  }
   const int nwg = cdiv(o.B, NB);
   const size_t fixed = disc_lds_fixed(dm, o.T, 512);
   if (fixed > LDS_MAX) {
@@ -2502,8 +2556,10 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
                 const KOpts& o, const float* dz_out, float* dz0, float* dtheta, float* dW, int32_t* nfe, int32_t* nacc,
                 int32_t* nrej, int32_t* ret, hipStream_t stream, std::string& err) {
   const MlpDims& dm = p->dm;
-  if (p->disc) return mlp_adjoint_disc(p, W_dev, z_out, theta, ts_dev, o, dz_out, dz0, dtheta, dW, nfe, nacc, nrej, ret, stream, err);
+  if (p->disc && !mlp64_applicable(dm, o.B))
+    return mlp_adjoint_disc(p, W_dev, z_out, theta, ts_dev, o, dz_out, dz0, dtheta, dW, nfe, nacc, nrej, ret, stream, err);
   if (mlp64_applicable(dm, o.B)) {   // one wave per trajectory, registers only, the weight gradient included (lde_mlp64.h): two launches
+    p->last_family = 1;
     const int waves = mlp64_adj_waves(o.B);
     if (!p->rows || p->rows_cap < (size_t)waves * p->rows_stride || p->rows_stride < dm.nW) {
       err = "MLP adjoint: workspace not reserved";
@@ -2514,11 +2570,15 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
     va.dz0 = dz0; va.dtheta = dtheta; va.stage = p->rows; va.cap = p->rows_stride;
     va.st_nfe = nfe; va.st_nacc = nacc; va.st_nrej = nrej; va.st_ret = ret;
     phase_mark(p, 0, stream);
-    const int rc6 = launch_mlp64<true>(dm, o, va, stream, err);
+    if (p->disc && (!o.rec.n || !o.rec.y)) {
+      err = "MLP adjoint (LDE_SENSE_DISCRETE): no step record";
+      return LDE_ERR_INVALID_ARG;
+    }
+    const int rc6 = p->disc ? launch_mlp64<true, true>(dm, o, va, stream, err) : launch_mlp64<true>(dm, o, va, stream, err);
     if (rc6) return rc6;
     phase_mark(p, 1, stream);
     if (dW) {
-      hipLaunchKernelGGL(k_sum_rows, dim3(cdiv(dm.nW, 64)), dim3(1024), 0, stream, p->rows, waves, p->rows_stride, dm.nW, dW);
+      hipLaunchKernelGGL(k_sum_rows, dim3(cdiv(dm.nW, 64)), dim3(1024), 0, stream, p->rows, waves, p->rows_stride, dm.nW, dW, o.dw_overwrite);
       if (hipGetLastError() != hipSuccess) {
         err = "k_sum_rows launch failed";
         return LDE_ERR_HIP;
@@ -2532,6 +2592,7 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
     const bool use_b = b_applicable(p, o.B, o.T, true, dm.coupled != 0);
     const bool use_c = !use_b && c_applicable(p, o.B, o.T, true, dm.coupled != 0);
     if (use_b || use_c) {
+      p->last_family = use_b ? 2 : 3;
       const int nrows = use_b ? o.B : (o.B + 1) / 2;
       if (!p->rows || p->rows_cap < (size_t)o.B * p->rows_stride || p->rows_stride < dm.nW) {
         err = "MLP adjoint: workspace not reserved";
@@ -2557,7 +2618,7 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
       if (rcb) return rcb;
       phase_mark(p, 1, stream);
       if (dW) {
-        hipLaunchKernelGGL(k_sum_rows, dim3(cdiv(dm.nW, 64)), dim3(1024), 0, stream, p->rows, nrows, p->rows_stride, dm.nW, dW);
+        hipLaunchKernelGGL(k_sum_rows, dim3(cdiv(dm.nW, 64)), dim3(1024), 0, stream, p->rows, nrows, p->rows_stride, dm.nW, dW, o.dw_overwrite);
         if (hipGetLastError() != hipSuccess) {
           err = "k_sum_rows launch failed";
           return LDE_ERR_HIP;
@@ -2598,6 +2659,7 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
 #endif
   int ntile_dw = nwg;
   bool vec_done = false;
+  p->last_family = 0;
   if (!vec_done) {   // small batches: one trajectory per workgroup, lanes = hidden units (lde_mlpv.h)
     size_t ldsv = 0;
     const bool ca = dm.coupled && o.adaptive && o.B > 1;
@@ -2607,6 +2669,7 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
       return LDE_ERR_UNSUPPORTED;
     }
     if (use_w || vec_applicable(p, o.B, o.T, true, ca, &ldsv, err)) {
+      p->last_family = use_w ? 4 : 5;
       if (!zero_regions(stream, {{p->fb_dev, 2 * sizeof(int32_t)}, {p->nslots, (size_t)2 * (nwg + 1) * sizeof(int32_t)},
                                  {p->wts, (size_t)nwg * p->adj_cap * NB * sizeof(float)},
                                  {(ca || sync) ? p->counter : nullptr, sizeof(unsigned)}, {(ca || sync) ? p->abort_flag : nullptr, sizeof(int)}})) {
@@ -2649,6 +2712,7 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
     int nblocks = 0;
     if (mlp4_layout(dm, o.T, o.B, dm.coupled && o.adaptive, &md, &lds4, &nblocks)) {
       const bool sync4 = dm.coupled && o.adaptive && nblocks > 1;
+      p->last_family = 6;
       const int ntile4 = cdiv(nblocks * md.wpb, 4);   // ≤ nwg + 1: the workspace is sized for that
       if (!zero_regions(stream, {{p->fb_dev, 2 * sizeof(int32_t)}, {p->nslots, (size_t)2 * (nwg + 1) * sizeof(int32_t)},
                                  {p->wts, (size_t)ntile4 * p->adj_cap * NB * sizeof(float)},
@@ -2692,7 +2756,7 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
   DwArgs da;
   da.stage = p->stage; da.wts = p->wts; da.nslots = p->nslots; da.slab = p->slab + (size_t)(nwg + 1) * dm.slab_n; da.cap = p->adj_cap; da.total = 0;
   if (!vec_done) phase_mark(p, 1, stream);   // (the tile kernels: the solve is the launch above; the small-batch kernels marked theirs already)
-  rc = launch_weight_gradient(dm, da, ntile_dw, ks, p->slab, p->nslots + (nwg + 1), nwg, dW, p->fb_dev, stream, err);
+  rc = launch_weight_gradient(dm, da, ntile_dw, ks, p->slab, p->nslots + (nwg + 1), nwg, dW, p->fb_dev, stream, err, o.dw_overwrite != 0);
   if (rc) return rc;
   phase_mark(p, 2, stream);
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;

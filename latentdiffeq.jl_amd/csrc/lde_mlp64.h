@@ -146,6 +146,37 @@ __device__ __forceinline__ void net64_vjp(const Net64<DP>& n, const float (&z)[D
   }
 }
 
+// weights into registers (flat destructure order: vec(W) column-major [out×in], then b)
+template <int DP, bool ADJ>
+__device__ __forceinline__ void net64_load(Net64<DP>& n, const MlpDims& dm, const VArgs& a, int lane, float* s_hx) {
+  const int Dp = dm.Dp, H1 = dm.sizes[1], H2 = dm.sizes[2];
+  const float* W = a.Wflat;
+  const float *W1 = W + dm.w_off[0], *W2 = W + dm.w_off[1], *W3 = W + dm.w_off[2];
+  // Every load UNCONDITIONAL, from a clamped (always valid) index, and the zero padding applied as a MULTIPLICATION by a 0/1 mask:
+  // written as `cond ? W[i] : 0` the compiler predicates each load on its lane condition — ≈ 270 exec-masked blocks, each with
+  // `s_waitcnt vmcnt(0)` before the next: 270 dependent L2 round trips before the first step (≈ half of the forward kernel's time
+  // at B = 1024); a select after an unconditional load is folded back into the same thing. (w is a finite weight, so w·0 = ±0.)
+  const int l1 = min(lane, H1 - 1), l2 = min(lane, H2 - 1);
+  const float m1 = lane < H1 ? 1.f : 0.f, m2 = lane < H2 ? 1.f : 0.f;
+#pragma unroll
+  for (int k = 0; k < DP; k++) n.w1[k] = W1[l1 + H1 * min(k, Dp - 1)] * (k < Dp ? m1 : 0.f);
+  n.b1 = W[dm.b_off[0] + l1] * m1;
+#pragma unroll
+  for (int k = 0; k < 64; k++) n.w2r[k >> 1][k & 1] = W2[l2 + H2 * min(k, H1 - 1)] * (k < H1 ? m2 : 0.f);
+  n.b2 = W[dm.b_off[1] + l2] * m2;
+#pragma unroll
+  for (int i = 0; i < 64; i++) n.w2c[i >> 1][i & 1] = ADJ ? W2[min(i, H2 - 1) + H2 * l1] * (i < H2 ? m1 : 0.f) : 0.f;
+  n.hx = s_hx + 6 * 128;
+#pragma unroll
+  for (int d = 0; d < DP; d++) {
+    n.w3c[d] = W3[min(d, Dp - 1) + Dp * l2] * (d < Dp ? m2 : 0.f);
+    n.b3[d] = W[dm.b_off[2] + min(d, Dp - 1)] * (d < Dp ? 1.f : 0.f);
+  }
+  n.act = dm.act;
+  n.has_pend = dm.has_pend;
+  n.h1 = n.h2 = 0.f;
+}
+
 // the weight gradient of one wave: accepted sums, and the sums of the attempt in flight (weights b_s, not yet scaled by |h|)
 template <int DP>
 struct Grad64 {
@@ -153,6 +184,42 @@ struct Grad64 {
   float w1[DP], b1, b2, w3[DP], b3[DP];              // lane j: gW₁[j][k], gb₁[j], gb₂[j], gW₃[d][j]; gb₃[d] (uniform)
   float pw1[DP], pb1, pb2, pw3[DP], pb3[DP];         // the attempt's
 };
+
+// the workgroup's row of the [workgroups × row stride] slab, flat destructure order (vec(W) column-major [out×in], then b):
+// every wave lays its sums out in LDS, the four copies are added in wave order (fixed: bit-reproducible) and ONE row leaves the CU —
+// a quarter of the slab bytes of a row per wave (c3: 18.6 → 4.6 MB written, and as much less read back by k_sum_rows)
+template <int DP>
+__device__ __forceinline__ void grad64_store_row(const Grad64<DP>& g, const MlpDims& dm, const VArgs& a, int wv, int nwv) {
+  extern __shared__ __attribute__((aligned(16))) float s_red[];
+  const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31, H1 = dm.sizes[1], H2 = dm.sizes[2];
+  float* row = s_red + (size_t)wv * a.cap;
+  const int Dpv = dm.Dp;
+  for (int e = lane; e < a.cap; e += 64) row[e] = 0.f;   // (entries no lane owns: the padding of the row stride)
+#pragma unroll
+  for (int ti = 0; ti < 2; ti++)
+#pragma unroll
+    for (int tj = 0; tj < 2; tj++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int i = 32 * ti + ((r & 3) | (half << 2) | ((r >> 2) << 3)), oo = 32 * tj + l31;
+        if (i < H1 && oo < H2) row[dm.w_off[1] + oo + H2 * i] = g.w2[ti][tj][r];
+      }
+#pragma unroll
+  for (int d = 0; d < DP; d++) {
+    if (d < Dpv && lane < H1) row[dm.w_off[0] + lane + H1 * d] = g.w1[d];
+    if (d < Dpv && lane < H2) row[dm.w_off[2] + d + Dpv * lane] = g.w3[d];
+    if (lane == d && d < Dpv) row[dm.b_off[2] + d] = g.b3[d];
+  }
+  if (lane < H1) row[dm.b_off[0] + lane] = g.b1;
+  if (lane < H2) row[dm.b_off[1] + lane] = g.b2;
+  __syncthreads();
+  float* out = a.stage + (size_t)blockIdx.x * a.cap;
+  for (int e = threadIdx.x; e < a.cap; e += blockDim.x) {
+    float t = s_red[e];
+    for (int w = 1; w < nwv; w++) t += s_red[(size_t)w * a.cap + e];
+    out[e] = t;
+  }
+}
 
 template <int SOLVER, int DP, bool ADJ>
 __device__ __forceinline__ void mlp64_body(const MlpDims& dm, const KOpts& o, const VArgs& a) {
@@ -163,33 +230,7 @@ __device__ __forceinline__ void mlp64_body(const MlpDims& dm, const KOpts& o, co
   __shared__ __attribute__((aligned(16))) float s_hx_all[(ADJ ? 4 : 1) * 7 * 128];   // per wave a ring: stage s → h₁ at [128 s, +64), δ₂ at [128 s + 64, +64)
   float* const s_hx = s_hx_all + wv * 7 * 128;
   Net64<DP> n;
-  {   // weights into registers (flat destructure order: vec(W) column-major [out×in], then b)
-    const float* W = a.Wflat;
-    const float *W1 = W + dm.w_off[0], *W2 = W + dm.w_off[1], *W3 = W + dm.w_off[2];
-    // Every load UNCONDITIONAL, from a clamped (always valid) index, and the zero padding applied as a MULTIPLICATION by a 0/1 mask:
-    // written as `cond ? W[i] : 0` the compiler predicates each load on its lane condition — ≈ 270 exec-masked blocks, each with
-    // `s_waitcnt vmcnt(0)` before the next: 270 dependent L2 round trips before the first step (≈ half of the forward kernel's time
-    // at B = 1024); a select after an unconditional load is folded back into the same thing. (w is a finite weight, so w·0 = ±0.)
-    const int l1 = min(lane, H1 - 1), l2 = min(lane, H2 - 1);
-    const float m1 = lane < H1 ? 1.f : 0.f, m2 = lane < H2 ? 1.f : 0.f;
-#pragma unroll
-    for (int k = 0; k < DP; k++) n.w1[k] = W1[l1 + H1 * min(k, Dp - 1)] * (k < Dp ? m1 : 0.f);
-    n.b1 = W[dm.b_off[0] + l1] * m1;
-#pragma unroll
-    for (int k = 0; k < 64; k++) n.w2r[k >> 1][k & 1] = W2[l2 + H2 * min(k, H1 - 1)] * (k < H1 ? m2 : 0.f);
-    n.b2 = W[dm.b_off[1] + l2] * m2;
-#pragma unroll
-    for (int i = 0; i < 64; i++) n.w2c[i >> 1][i & 1] = ADJ ? W2[min(i, H2 - 1) + H2 * l1] * (i < H2 ? m1 : 0.f) : 0.f;
-    n.hx = s_hx + 6 * 128;
-#pragma unroll
-    for (int d = 0; d < DP; d++) {
-      n.w3c[d] = W3[min(d, Dp - 1) + Dp * l2] * (d < Dp ? m2 : 0.f);
-      n.b3[d] = W[dm.b_off[2] + min(d, Dp - 1)] * (d < Dp ? 1.f : 0.f);
-    }
-    n.act = dm.act;
-    n.has_pend = dm.has_pend;
-    n.h1 = n.h2 = 0.f;
-  }
+  net64_load<DP, ADJ>(n, dm, a, lane, s_hx);
   const double* ts = a.ts;
   const double t0 = ts[0], tend = ts[T - 1], dtmax = fabs(tend - t0);
   constexpr int NST = SOLVER == LDE_SOLVER_TSIT5 ? 6 : 4;   // weighted evaluations of a step (Tsit5: b₇ = 0)
@@ -445,9 +486,11 @@ __device__ __forceinline__ void mlp64_body(const MlpDims& dm, const KOpts& o, co
       }
       if (!fin) s2 = __int_as_float(0x7fc00000);
       bool accepted = false;
+      double hrec = 0.0;   // the attempted step as f64 (the controller overwrites dt below)
       if (status == 0) {
         const float EEst = o.adaptive ? sqrtf(s2 / nnorm) : (s2 == s2 ? 0.f : s2);
         const double hmag = ADJ ? tnew : dt;
+        hrec = hmag;
         if (!(EEst == EEst)) {
           if (o.adaptive && hmag > o.dtmin) { nrej++; dt = hmag * (double)o.qmin; }
           else status = 1 + LDE_RET_NONFINITE;
@@ -471,6 +514,19 @@ __device__ __forceinline__ void mlp64_body(const MlpDims& dm, const KOpts& o, co
           accepted = true;
         }
         if (accepted) nacc++;
+      }
+      if (accepted && o.rec.n && nacc <= o.rec.cap) {   // the step record (forward: start time, size, start state) / the reverse-time trace (size)
+        const size_t ri = (size_t)(nacc - 1) * B + b;
+        if (lane == 0) {
+          if (!ADJ) o.rec.t[ri] = t;
+          o.rec.dt[ri] = hrec;
+        }
+        if (!ADJ) {
+          float yv = 0.f;
+#pragma unroll
+          for (int r = 0; r < DP; r++) yv = lane == r ? y[r] : yv;
+          if (lane < Dp) o.rec.y[ri * Dp + lane] = yv;
+        }
       }
       if (!ADJ) {
         while (accepted && j < T && ts[j] <= tnew) {   // dense output at every save time inside the accepted step
@@ -649,41 +705,231 @@ __device__ __forceinline__ void mlp64_body(const MlpDims& dm, const KOpts& o, co
     a.st_nfe[b] = nfe;
     a.st_nacc[b] = nacc;
     a.st_nrej[b] = nrej;
+    if (o.rec.n) o.rec.n[b] = st > 1 ? 0 : nacc;
   }
   }   // trajectories of this wave
 
-  if (ADJ) {   // the workgroup's row of the [workgroups × row stride] slab, flat destructure order (vec(W) column-major [out×in], then b):
-    // every wave lays its sums out in LDS, the four copies are added in wave order (fixed: bit-reproducible) and ONE row leaves the CU —
-    // a quarter of the slab bytes of a row per wave (c3: 18.6 → 4.6 MB written, and as much less read back by k_sum_rows)
-    extern __shared__ __attribute__((aligned(16))) float s_red[];
-    float* row = s_red + (size_t)wv * a.cap;
-    const int Dpv = Dp;
-    for (int e = lane; e < a.cap; e += 64) row[e] = 0.f;   // (entries no lane owns: the padding of the row stride)
+  if (ADJ) grad64_store_row<DP>(g, dm, a, wv, nwv);
+}
+
+// LDE_SENSE_DISCRETE on the same register layout (lde_mlpd.h has the algorithm; [REF examples/pendulum_friction-less/pendulum.jl:11],
+// [REF src/models/GOKU.jl:107, :121]): a wave sweeps its trajectory's recorded steps (t_n, dt_n, y_n) from the last to the first — pass 1
+// rebuilds the slopes k_1 … k_S with forward evaluations, the save times inside the step put their cotangents on y_n / the slopes /
+// y_{n+1}, pass 2 pulls k̄ through f at y_{n+1} and at g_S … g_2 (one fused forward + vector-Jacobian evaluation each, its (h₁, δ₂)
+// through ring slot S − i). The weight gradient is folded per step exactly as in the continuous adjoint, at weight 1 (the scale h·b_i is
+// inside k̄). 2S evaluations per accepted FORWARD step — c3: ≈ 160 per trajectory against ≈ 480 of the reverse-time solve.
+template <int SOLVER, int DP>
+__device__ __forceinline__ void mlp64_disc_body(const MlpDims& dm, const KOpts& o, const VArgs& a) {
+  const int T = o.T, B = o.B, D = dm.D, Dp = dm.Dp, NP = dm.P, lane = threadIdx.x & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nwv = (int)(blockDim.x >> 6);
+  __shared__ __attribute__((aligned(16))) float s_hx_all[4 * 7 * 128];
+  float* const s_hx = s_hx_all + wv * 7 * 128;
+  Net64<DP> n;
+  net64_load<DP, true>(n, dm, a, lane, s_hx);
+  constexpr int S = SOLVER == LDE_SOLVER_TSIT5 ? 6 : 4;
+  constexpr float RK[5][4] = {{0.f, 0.f, 0.f, 0.f}, {0.5f, 0.f, 0.f, 0.f}, {0.f, 0.5f, 0.f, 0.f}, {0.f, 0.f, 1.f, 0.f},
+                              {1.0f / 6.0f, 1.0f / 3.0f, 1.0f / 3.0f, 1.0f / 6.0f}};
+  auto A = [&](int i, int q) -> float { return SOLVER == LDE_SOLVER_TSIT5 ? ts5::A[i][q] : RK[i][q]; };
+  const double* ts = a.ts;
+  const double tend = ts[T - 1];
+  const StepRec R = o.rec;
+  Grad64<DP> g;
+  const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
-    for (int ti = 0; ti < 2; ti++)
+  for (int ti = 0; ti < 2; ti++)
 #pragma unroll
-      for (int tj = 0; tj < 2; tj++)
+    for (int tj = 0; tj < 2; tj++)
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-          const int i = 32 * ti + ((r & 3) | (half << 2) | ((r >> 2) << 3)), oo = 32 * tj + l31;
-          if (i < H1 && oo < H2) row[dm.w_off[1] + oo + H2 * i] = g.w2[ti][tj][r];
-        }
+      for (int r = 0; r < 16; r++) g.w2[ti][tj][r] = 0.f;
 #pragma unroll
-    for (int d = 0; d < DP; d++) {
-      if (d < Dpv && lane < H1) row[dm.w_off[0] + lane + H1 * d] = g.w1[d];
-      if (d < Dpv && lane < H2) row[dm.w_off[2] + d + Dpv * lane] = g.w3[d];
-      if (lane == d && d < Dpv) row[dm.b_off[2] + d] = g.b3[d];
+  for (int d = 0; d < DP; d++) g.w1[d] = g.w3[d] = g.b3[d] = g.pw1[d] = g.pw3[d] = g.pb3[d] = 0.f;
+  g.b1 = g.b2 = g.pb1 = g.pb2 = 0.f;
+
+  // one fused evaluation at (z, k̄): vz = Jᵀk̄, the thin layers' gradient terms at weight 1, (h₁, δ₂) left in ring slot `slot`
+  auto vjp_at = [&](const float (&z)[DP], const float (&kb)[DP], int slot, float (&vz)[DP], float& gth) {
+    float f[DP], vth, d1, d2;
+    n.hx = s_hx + slot * 128;
+    net64_rhs<DP>(n, z, f);
+    net64_vjp<DP>(n, z, kb, vz, vth, d1, d2);
+    gth += vth;
+#pragma unroll
+    for (int r = 0; r < DP; r++) {
+      g.w1[r] += d1 * z[r];
+      g.w3[r] += n.h2 * kb[r];
+      g.b3[r] += kb[r];
     }
-    if (lane < H1) row[dm.b_off[0] + lane] = g.b1;
-    if (lane < H2) row[dm.b_off[1] + lane] = g.b2;
-    __syncthreads();
-    float* out = a.stage + (size_t)blockIdx.x * a.cap;
-    for (int e = threadIdx.x; e < a.cap; e += blockDim.x) {
-      float t = s_red[e];
-      for (int w = 1; w < nwv; w++) t += s_red[(size_t)w * a.cap + e];
-      out[e] = t;
+    g.b1 += d1;
+    g.b2 += d2;
+  };
+  // gW₂ᵀ += Σ over ring slots [0, nslots) of h₁ ⊗ δ₂ (one MFMA takes two slots)
+  auto fold = [&](int nslots) {
+#pragma unroll
+    for (int m = 0; m < S / 2; m++) {
+      const float* rs = s_hx + (2 * m + half) * 128 + l31;
+      const float wsc = 2 * m + half < nslots ? 1.f : 0.f;
+      const float a0 = rs[0], a1 = rs[32], b0 = rs[64] * wsc, b1 = rs[96] * wsc;
+      g.w2[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, g.w2[0][0], 0, 0, 0);
+      g.w2[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, g.w2[0][1], 0, 0, 0);
+      g.w2[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, g.w2[1][0], 0, 0, 0);
+      g.w2[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, g.w2[1][1], 0, 0, 0);
+    }
+  };
+  for (int e = lane; e < 7 * 128; e += 64) s_hx[e] = 0.f;   // (slots a fold reads at weight 0 must hold finite numbers)
+
+  for (int b = blockIdx.x * nwv + wv; b < B; b += gridDim.x * nwv) {
+    {
+      float L = 1.f;
+      if (dm.has_pend) L = a.theta[(size_t)b * NP];
+      n.ngl = -10.0f / L;
+      n.gl2 = 10.0f / (L * L);
+    }
+    float y0[DP], yb[DP], carry[DP], gth = 0.f;
+    bool bad = false;
+#pragma unroll
+    for (int r = 0; r < DP; r++) {
+      y0[r] = r < Dp ? a.z_out[(size_t)b * Dp + r] : 0.f;   // save time 0 is ẑ₀ itself
+      bad = bad || !isfinite(y0[r]);
+      yb[r] = carry[r] = 0.f;
+    }
+    const int ns = R.n[b];
+    int status = bad ? 1 + LDE_RET_NONFINITE : ((T > 1 && (ns < 1 || ns > R.cap)) ? 1 + LDE_RET_MAXITERS : 1);
+    int nfe = 0;
+    if (status == 1 && T > 1) {
+      int j = T - 1;
+      double tnext = tend;
+#pragma unroll 1
+      for (int s = ns - 1; s >= 0; s--) {
+        const double t = R.t[(size_t)s * B + b], dt = R.dt[(size_t)s * B + b];
+        const float h = (float)dt;
+        const bool last = s == ns - 1;
+        const double tnew = tnext;
+        tnext = t;
+        float yN[DP], K[S][DP];
+#pragma unroll
+        for (int r = 0; r < DP; r++) yN[r] = r < Dp ? R.y[((size_t)s * B + b) * Dp + r] : 0.f;
+        auto point = [&](int i, float (&zp)[DP]) {   // g_i (i < S) or y_{n+1} (i == S) from y_n and the slopes
+#pragma unroll
+          for (int r = 0; r < DP; r++) {
+            float zv = yN[r];
+            if (i > 0) {
+              if (SOLVER == LDE_SOLVER_RK4 && i == S) zv = yN[r] + (h * (1.0f / 6.0f)) * (K[0][r] + 2.0f * (K[1][r] + K[2][r]) + K[3][r]);
+              else {
+                float acc = A(i, 0) * K[0][r];
+#pragma unroll
+                for (int q = 1; q < i; q++) acc += A(i, q) * K[q][r];
+                zv = yN[r] + h * acc;
+              }
+            }
+            zp[r] = zv;
+          }
+        };
+        // ---- pass 1: the slopes (forward evaluations through the scratch slot)
+        n.hx = s_hx + 6 * 128;
+#pragma unroll
+        for (int i = 0; i < S; i++) {
+          float zp[DP];
+          point(i, zp);
+          net64_rhs<DP>(n, zp, K[i]);
+        }
+        // ---- the save times inside the step
+        float KB[S + 1][DP], ybn[DP];
+#pragma unroll
+        for (int r = 0; r < DP; r++) {
+#pragma unroll
+          for (int i = 0; i < S; i++) KB[i][r] = 0.f;
+          KB[S][r] = carry[r];
+          ybn[r] = 0.f;
+        }
+        const float rh = fast_rcp(h);
+        while (j >= 1 && ts[j] > t) {
+          const double tj = ts[j];
+          float dj[DP];
+#pragma unroll
+          for (int r = 0; r < DP; r++) dj[r] = r < Dp ? a.dz_out[(size_t)Dp * ((size_t)b + (size_t)B * j) + r] : 0.f;
+          if (tj >= tnew || (j == T - 1 && last)) {
+#pragma unroll
+            for (int r = 0; r < DP; r++) yb[r] += dj[r];
+          } else {
+            const float th = (float)(tj - t) * rh;
+            if (SOLVER == LDE_SOLVER_TSIT5) {
+              float bw[7];
+              tsit5_interp_weights(th, bw);
+#pragma unroll
+              for (int r = 0; r < DP; r++) {
+                ybn[r] += dj[r];
+#pragma unroll
+                for (int q = 0; q < 7; q++) KB[q][r] += (h * bw[q]) * dj[r];
+              }
+            } else {
+              const float om = 1.0f - th;
+              const float h00 = (1.0f + 2.0f * th) * om * om, h10 = th * om * om;
+              const float h01 = th * th * (3.0f - 2.0f * th), h11 = th * th * (th - 1.0f);
+#pragma unroll
+              for (int r = 0; r < DP; r++) {
+                ybn[r] += h00 * dj[r];
+                KB[0][r] += (h10 * h) * dj[r];
+                yb[r] += h01 * dj[r];
+                KB[S][r] += (h11 * h) * dj[r];
+              }
+            }
+          }
+          j--;
+        }
+        // ---- pass 2: Jᵀk̄ at y_{n+1}, then at g_S … g_2
+#pragma unroll
+        for (int i = S; i >= 1; i--) {
+          float zp[DP], vz[DP];
+          point(i, zp);
+          vjp_at(zp, KB[i], S - i, vz, gth);
+          if (i == S) {
+#pragma unroll
+            for (int r = 0; r < DP; r++) {
+              yb[r] += vz[r];
+#pragma unroll
+              for (int q = 0; q < S; q++) KB[q][r] += (h * A(S, q)) * yb[r];
+              ybn[r] += yb[r];
+            }
+          } else {
+#pragma unroll
+            for (int r = 0; r < DP; r++) {
+              ybn[r] += vz[r];
+#pragma unroll
+              for (int q = 0; q < i; q++)
+                if (A(i, q) != 0.f) KB[q][r] += (h * A(i, q)) * vz[r];
+            }
+          }
+        }
+        fold(S);
+#pragma unroll
+        for (int r = 0; r < DP; r++) {
+          carry[r] = KB[0][r];
+          yb[r] = ybn[r];
+        }
+        nfe += 2 * S;
+      }
+      {   // k_1 of the first step = f(y_0)
+        float vz[DP];
+        vjp_at(y0, carry, 0, vz, gth);
+        fold(1);
+#pragma unroll
+        for (int r = 0; r < DP; r++) yb[r] += vz[r];
+        nfe++;
+      }
+    }
+    const float qn = __int_as_float(0x7fc00000);
+    float g0 = 0.f;
+#pragma unroll
+    for (int r = 0; r < DP; r++) g0 = lane == r ? yb[r] : g0;
+    if (lane < D) a.dz0[(size_t)b * D + lane] = status == 1 ? g0 + a.dz_out[(size_t)b * Dp + lane] : (status == 1 + LDE_RET_MAXITERS ? qn : 0.f);
+    if (lane == 0 && NP > 0) a.dtheta[(size_t)b * NP] = status == 1 ? gth : (status == 1 + LDE_RET_MAXITERS ? qn : 0.f);
+    if (lane == 0) {
+      a.st_ret[b] = status > 1 ? status - 1 : 0;
+      a.st_nfe[b] = nfe;
+      a.st_nacc[b] = status == 1 && T > 1 ? ns : 0;
+      a.st_nrej[b] = 0;
     }
   }
+  grad64_store_row<DP>(g, dm, a, wv, nwv);
 }
 
 template <int SOLVER, int DP>
@@ -697,10 +943,17 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))
   mlp64_body<SOLVER, DP, true>(dm, o, a);
 }
 
+template <int SOLVER, int DP>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) k_mlp64_disc(MlpDims dm, KOpts o, VArgs a) {
+  mlp64_disc_body<SOLVER, DP>(dm, o, a);
+}
+
 // dW[e] += Σ_s rows[s][e], s in index order (bit-reproducible): the rows the adjoint's waves left. A workgroup owns 64 consecutive
 // entries; its sixteen waves each add a contiguous block of rows (eight loads in flight), the sixteen partial sums meet in LDS and
 // are added in wave order.
-static __global__ void __launch_bounds__(1024) k_sum_rows(const float* __restrict__ rows, int nrows, int stride, int n, float* __restrict__ dW) {
+// assign != 0: dW[e] = the sum (option "adjoint_overwrite": the caller's zero fill disappears).
+static __global__ void __launch_bounds__(1024) k_sum_rows(const float* __restrict__ rows, int nrows, int stride, int n, float* __restrict__ dW,
+                                                          int assign = 0) {
   __shared__ float part[16][64];
   const int c = threadIdx.x & 63, rg = threadIdx.x >> 6, e = blockIdx.x * 64 + c;
   const int per = (nrows + 15) / 16, r0 = rg * per, r1 = min(nrows, r0 + per);
@@ -723,6 +976,6 @@ static __global__ void __launch_bounds__(1024) k_sum_rows(const float* __restric
     float t = part[0][c];
 #pragma unroll
     for (int u = 1; u < 16; u++) t += part[u][c];
-    dW[e] += t;
+    dW[e] = assign ? t : dW[e] + t;
   }
 }

@@ -148,9 +148,12 @@ __device__ __forceinline__ long long sgpr_ll(long long v) {
 }
 __device__ __forceinline__ double sgpr_d(double v) { return __builtin_bit_cast(double, sgpr_ll(__builtin_bit_cast(long long, v))); }
 
-template <int SOLVER, int DP, int ACT, bool ADJ>
+// DISC (with ADJ): LDE_SENSE_DISCRETE — the reverse sweep over the forward solve's step record instead of a reverse-time solve (the block
+// behind the evaluation lambdas; lde_mlpd.h has the algorithm). The template's LAST bool stays ADJ (check_agprs.py reads it).
+template <int SOLVER, int DP, int ACT, bool DISC, bool ADJ>
 __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, VArgs a) {
   using namespace mlpb;
+  static_assert(ADJ || !DISC, "the discrete sweep is an adjoint");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int SEG = 64 / DP, G1 = DP / 4, GS = (200 / SEG + 3) / 4;   // GS: host = bd.GS
   constexpr int NST = SOLVER == LDE_SOLVER_TSIT5 ? 6 : 4;                // weighted stages of a step = ring slots the fold reads
@@ -235,6 +238,8 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
   for (int s = 0; s < 7; s++) k[s] = 0.f;
   if (!ADJ) {
     if (lane < D) y = a.z0[(size_t)b * D + lane];
+  } else if (DISC) {
+    if (is_z) y = a.z_out[(size_t)b * Dp + row];   // ẑ₀ (save time 0): only the failure check reads it here
   } else if (counted) {
     const size_t srcg = (size_t)Dp * ((size_t)b + (size_t)B * (T - 1)) + row;
     y = is_z ? a.z_out[srcg] : a.dz_out[srcg];
@@ -294,7 +299,8 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
   auto narrow = [&](const f32x4* ns, const float* vec) -> float {
     const f32x4* hv = reinterpret_cast<const f32x4*>(vec) + (lane / DP) * GS;
     f32x2 p01 = {0.f, 0.f}, p23 = {0.f, 0.f};
-    if (DP <= 8) {
+    if (DP <= 8 && !DISC) {   // (not in the discrete sweep: its three inlined evaluations leave the allocator no room for 56 registers of reads —
+                              //  the compiler's copies then climb into the hidden tiles and check_agprs.py fails the build)
       // every read issued before the first product waits for one: left to itself under this kernel's register pressure the compiler reuses
       // ONE pair of buffers — read, wait, multiply: GS dependent LDS round trips (c2: 0.918 -> 0.901 ms). Not at D′ = 16: twice the
       // reads, and the 112 registers they need at once are spilled (latentode_ref: 3.43 -> 3.51 ms with it).
@@ -343,7 +349,8 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
   };
 
   // one evaluation of the (augmented) right-hand side: src → dst; its vectors stay in ring slot `slot`
-  auto eval = [&](float src, int slot) -> float {
+  // vj (wave-uniform; only the discrete sweep passes false): false = the forward half alone — f, h₁, h₂ — for the evaluations that rebuild slopes
+  auto eval = [&](float src, int slot, bool vj = true) -> float {
     PROF_T(e0);
     float* xs = ring + slot * SLOT;
     float *h1v = xs + XS, *d2v = h1v + HV, *h2v = d2v + HV, *d1v = h2v + HV;
@@ -363,7 +370,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
       h1 = u == H1 ? 1.f : act_fn(act, a1);   // unit H₁: the constant that carries b₂ (rows beyond: zero weights and bias ⇒ act(0) = 0)
     }
     if (u < HV) h1v[u] = h1;
-    if (ADJ) {
+    if (ADJ && vj) {
       f32x2 c01 = {0.f, 0.f}, c23 = {0.f, 0.f};
 #pragma unroll
       for (int g = 0; g < G1; g++) {
@@ -409,7 +416,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
 #pragma unroll
       for (int i = 0; i < RB; i++) h2[i] = act_fn(act, dpp_xadd<0x140>(h2[i]));   // row_mirror; every lane of the row holds the 13 sums, bitwise equal
     }
-    if (ADJ) {
+    if (ADJ && vj) {
       float d2[RB];
 #pragma unroll
       for (int i = 0; i < RB; i++) d2[i] = d2v[RB * br + i] * act_grad(act, h2[i]);
@@ -450,7 +457,13 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
     float dst = is_z ? f : 0.f;
     PROF_ADD(3, e0, e1);
     PROF_ADD(4, e1, e2);
-    if (ADJ) {
+    if (ADJ && !vj && KSPLIT) {   // the forward half alone, K split over the waves: the partial outputs meet behind a barrier of their own
+      __syncthreads();
+      const int dd = lane % DP;
+      f = b3 + ((s_np[dd] + s_np[DP + dd]) + (s_np[2 * DP + dd] + s_np[3 * DP + dd]));
+      dst = is_z ? f : 0.f;
+    }
+    if (ADJ && vj) {
       float g1 = 0.f;
       if (u < HV) {
         float p[16];
@@ -488,17 +501,18 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
   //   n = 3·ti + m, ti < 13, m < 3 : gW₂ᵀ tile (ti, tj = 4m + w)          n = 39 + q : gW₂ᵀ tile (ti = 4q + w, tj = 12)
   //   n = 43 + q : gW₁ tile 4q + w (A = δ₁, B = z)                        n = 47 + q : gW₃ᵀ tile 4q + w (A = h₂, B = λ)
   // (q = 3 is a real tile for wave 0 only; the other waves' slot accumulates finite junk that is never written out)
-  auto fold = [&]() {
+  auto fold = [&](int nvalid) {   // nvalid (wave-uniform): ring slots [0, nvalid) count
     PROF_T(f0);
     const int l15 = lane & 15, e4 = lane >> 4;
 #pragma unroll
     for (int g = 0; g < (NST + 3) / 4; g++) {
       const int e = 4 * g + e4;
       float bs;
-      if (SOLVER == LDE_SOLVER_TSIT5) bs = e == 0 ? ts5::A[6][0] : e == 1 ? ts5::A[6][1] : e == 2 ? ts5::A[6][2] : e == 3 ? ts5::A[6][3] : e == 4 ? ts5::A[6][4] : e == 5 ? ts5::A[6][5] : 0.f;
+      if (DISC) bs = 1.f;   // (the scale h·b_i is inside k̄)
+      else if (SOLVER == LDE_SOLVER_TSIT5) bs = e == 0 ? ts5::A[6][0] : e == 1 ? ts5::A[6][1] : e == 2 ? ts5::A[6][2] : e == 3 ? ts5::A[6][3] : e == 4 ? ts5::A[6][4] : e == 5 ? ts5::A[6][5] : 0.f;
       else bs = (e == 0 || e == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
-      const bool ev = e < NST;                 // (Tsit5's second group has two evaluations: the other two K slots are zeros)
-      const float wsc = ev ? wq * bs : 0.f, am = ev ? 1.f : 0.f;
+      const bool ev = e < nvalid;              // (Tsit5's second group has two evaluations: the other two K slots are zeros)
+      const float wsc = ev ? (DISC ? 1.f : wq * bs) : 0.f, am = ev ? 1.f : 0.f;
       const float* sl = ring + (ev ? e : 0) * SLOT + l15;
       const float* pa = sl + XS + 16 * wv;     // A operands of the slots whose tile index is 4q + w
       float bm[3];
@@ -534,9 +548,10 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
 #pragma unroll
     for (int e = 0; e < NST; e++) {
       const float bs = SOLVER == LDE_SOLVER_TSIT5 ? ts5::A[6][e] : ((e == 0 || e == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f));
+      const float wb_ = DISC ? (e < nvalid ? 1.f : 0.f) : wq * bs;
       const float* sl = ring + e * SLOT;
-      if (u < HV) gb1 += (wq * bs) * sl[XS + 3 * HV + u];
-      if (lane < XS) gb3 += (wq * bs) * sl[lane];
+      if (u < HV) gb1 += wb_ * sl[XS + 3 * HV + u];
+      if (lane < XS) gb3 += wb_ * sl[lane];
     }
     __syncthreads();   // the next attempt overwrites the ring: every wave has read it
     PROF_T(f1);
@@ -572,9 +587,142 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
     }
     return v;
   };
+  if constexpr (DISC) {
+    // ---- LDE_SENSE_DISCRETE: the recorded steps (t_n, dt_n, y_n), last to first. z lanes carry the stage points and slopes (y = y_n,
+    //      yn = y_{n+1}, k[i] = k_{i+1}); λ lanes carry the cotangents (y = ȳ_{n+1}, yn = ȳ_n, k[i] = k̄_{i+1}, scr = the k̄₁ that travels on)
+    constexpr int S = NST;
+    constexpr float RK[5][4] = {{0.f, 0.f, 0.f, 0.f}, {0.5f, 0.f, 0.f, 0.f}, {0.f, 0.5f, 0.f, 0.f}, {0.f, 0.f, 1.f, 0.f},
+                                {1.0f / 6.0f, 1.0f / 3.0f, 1.0f / 3.0f, 1.0f / 6.0f}};
+    auto A = [&](int i, int q) -> float { return SOLVER == LDE_SOLVER_TSIT5 ? ts5::A[i][q] : RK[i][q]; };
+    const StepRec R = o.rec;
+    const int seq = coupled ? 0 : b;
+    const int ns = R.n[seq];
+    if (status == 0 && (ns < 1 || ns > R.cap)) status = 1 + LDE_RET_MAXITERS;   // no usable record: NaN gradient, never a truncated sweep
+    y = 0.f;                            // (ẑ₀ has served the failure check; the last evaluation reloads it)
+    // stage point i of the step from y_n and the slopes (z lanes; i == S: y_{n+1})
+    auto point = [&](int i, float hh) -> float {
+      float zv = y;
+      if (SOLVER == LDE_SOLVER_RK4 && i == S) zv = y + (hh * (1.0f / 6.0f)) * (k[0] + 2.0f * (k[1] + k[2]) + k[3]);
+      else {
+#define DSTAGE(S_)                                                               \
+  case S_: {                                                                     \
+    float accv = A(S_, 0) * k[0];                                                \
+    _Pragma("unroll") for (int jj = 1; jj < S_; jj++) accv += A(S_, jj) * k[jj]; \
+    zv = y + hh * accv;                                                          \
+  } break;
+        switch (i) {
+          DSTAGE(1) DSTAGE(2) DSTAGE(3) DSTAGE(4)
+          default: break;
+        }
+        if constexpr (S == 6) {
+          switch (i) {
+            DSTAGE(5) DSTAGE(6)
+            default: break;
+          }
+        }
+#undef DSTAGE
+      }
+      return zv;
+    };
+    if (status == 0) {
+      j = T - 1;
+      double tnext = tend;
+#pragma unroll 1
+      for (int sidx = ns - 1; sidx >= 0; sidx--) {
+        const double ts_n = R.t[(size_t)sidx * R.nseq + seq], dts = R.dt[(size_t)sidx * R.nseq + seq];
+        const float hh = (float)dts;
+        const bool lastst = sidx == ns - 1;
+        const double tnw = tnext;
+        tnext = ts_n;
+        if (is_z) y = R.y[((size_t)sidx * B + b) * Dp + row];
+        else {
+          yn = 0.f;
+#pragma unroll
+          for (int q = 0; q < S; q++) k[q] = 0.f;
+          k[S] = is_l ? scr : 0.f;
+        }
+        // pass 1: the slopes k_1 … k_S (forward halves, through the scratch slot)
+#pragma unroll 1
+        for (int i = 0; i < S; i++) {
+          const float dstv = eval(is_z ? point(i, hh) : 0.f, NST, false);
+#pragma unroll
+          for (int q = 0; q < S; q++)
+            if (q == i && is_z) k[q] = dstv;
+        }
+        if (is_z) yn = point(S, hh);
+        // the save times inside the step (t_n, t_{n+1}]
+        while (j >= 1 && sgpr_d(s_ts[j]) > ts_n) {   // (wave-uniform: kept scalar)
+          const double tj = sgpr_d(s_ts[j]);
+          const bool at_end = tj >= tnw || (j == T - 1 && lastst);
+          const float th = at_end ? 2.0f : (float)(tj - ts_n) * fast_rcp(hh);
+          if (is_l) {
+            const float dj = a.cot_lds ? s_cot[j * Dp + row] : a.dz_out[(size_t)Dp * ((size_t)b + (size_t)B * j) + row];
+            if (at_end) y += dj;
+            else if (SOLVER == LDE_SOLVER_TSIT5) {
+              float bw[7];
+              tsit5_interp_weights(th, bw);
+              yn += dj;
+#pragma unroll
+              for (int q = 0; q < 7; q++) k[q] += (hh * bw[q]) * dj;
+            } else {
+              const float om = 1.0f - th;
+              const float h00 = (1.0f + 2.0f * th) * om * om, h10 = th * om * om;
+              const float h01 = th * th * (3.0f - 2.0f * th), h11 = th * th * (th - 1.0f);
+              yn += h00 * dj;
+              k[0] += (h10 * hh) * dj;
+              y += h01 * dj;
+              k[S] += (h11 * hh) * dj;
+            }
+          }
+          j--;
+        }
+        // pass 2: Jᵀk̄ at y_{n+1}, then at g_S … g_2 (fused evaluations; their vectors stay in ring slots 0 … S − 1 for the fold)
+#pragma unroll 1
+        for (int i = S; i >= 1; i--) {
+          float kb = 0.f;
+#pragma unroll
+          for (int q = 0; q <= S; q++) kb = q == i ? k[q] : kb;
+          const float dstv = eval(is_z ? (i == S ? yn : point(i, hh)) : kb, S - i, true);
+          if (is_l) {
+            const float v = -dstv;
+            if (i == S) {
+              y += v;
+#pragma unroll
+              for (int q = 0; q < S; q++) k[q] += (hh * A(S, q)) * y;
+              yn += y;
+            } else {
+              yn += v;
+#pragma unroll
+              for (int q = 0; q < S - 1; q++) {
+                float aq = 0.f;
+#pragma unroll
+                for (int ii = 1; ii < S; ii++) aq = ii == i ? A(ii, q) : aq;
+                if (q < i) k[q] += (hh * aq) * v;
+              }
+            }
+          }
+        }
+        fold(S);
+        if (is_l) {
+          scr = k[0];
+          y = yn;
+        }
+        nfe += 2 * S;
+        nacc++;
+      }
+      {   // k_1 of the first step = f(y_0)
+        const float dstv = eval(is_z ? a.z_out[(size_t)b * Dp + row] : (is_l ? scr : 0.f), 0, true);
+        fold(1);
+        if (is_l) y -= dstv;
+        nfe++;
+      }
+      status = 1;
+    }
+    if (is_l) y += a.dz_out[(size_t)b * Dp + row];   // save time 0 is ẑ₀ itself
+  }
   const bool auto_dt = o.adaptive && !(o.dt_fixed > 0);
   int phase = (ADJ && !auto_dt) ? PH_STAGE : PH_K0, s = 0;
-  bool running = T > 1 && status == 0;
+  bool running = !DISC && T > 1 && status == 0;
   if (ADJ && running && !auto_dt) {
     dt = o.adaptive ? fmin(o.dt_fixed, dtmax) : o.dt_fixed;
     running = begin_step();
@@ -714,9 +862,11 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
       }
     }
     bool accepted = false;
+    double hrec = 0.0;   // the attempted step as f64 (the controller overwrites dt below)
     if (status == 0) {
       const float EEst = o.adaptive ? sqrtf(s2 / nnorm) : (s2 == s2 ? 0.f : s2);
       const double hmag = ADJ ? tnew : dt;
+      hrec = hmag;
       if (!(EEst == EEst)) {
         if (o.adaptive && hmag > o.dtmin) { nrej++; dt = hmag * (double)o.qmin; }
         else status = 1 + LDE_RET_NONFINITE;
@@ -740,6 +890,14 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
         accepted = true;
       }
       if (accepted) nacc++;
+    }
+    if (accepted && o.rec.n && nacc <= o.rec.cap) {   // the step record (forward: start time, size, start state) / the reverse-time trace (size)
+      if (tid == 0 && (!coupled || b == 0)) {
+        const size_t ri = (size_t)(nacc - 1) * o.rec.nseq + (coupled ? 0 : b);
+        if (!ADJ) o.rec.t[ri] = t;
+        o.rec.dt[ri] = hrec;
+      }
+      if (!ADJ && wv == 0 && lane < Dp) o.rec.y[((size_t)(nacc - 1) * B + b) * Dp + lane] = y;
     }
     if (!ADJ) {
       while (accepted && j < T && s_ts[j] <= tnew) {   // dense output at every save time inside the accepted step
@@ -773,7 +931,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
       running = begin_step();
     } else {
       if (__builtin_amdgcn_readfirstlane((int)accepted)) {   // (workgroup-uniform: every wave takes bitwise the same decisions — say so to the compiler: a scalar branch)
-        fold();
+        fold(NST);
         if (SPEC) {
           y = hit ? tmp : yn;
           k[0] = hit ? scr : k[6];
@@ -810,7 +968,8 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
       a.st_ret[b] = ret;
     }
   } else {
-    if (wv == 0 && lane >= DP && lane < DP + D) a.dz0[(size_t)b * D + (lane - DP)] = st > 1 ? 0.f : y;
+    if (wv == 0 && lane >= DP && lane < DP + D)   // (no usable step record: NaN, not zeros)
+      a.dz0[(size_t)b * D + (lane - DP)] = st > 1 ? ((DISC && st == 1 + LDE_RET_MAXITERS) ? __int_as_float(0x7fc00000) : 0.f) : y;
     if (tid == 0) a.st_ret[b] = st > 1 ? st - 1 : 0;
     // the workgroup's row of the [workgroups × row stride] slab, flat destructure order (vec(W) column-major [out×in], then b): every
     // entry is owned by exactly one lane (a failed trajectory contributes zeros: nothing was folded after the failure … and what was
@@ -857,5 +1016,6 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
     a.st_nfe[b] = rep ? nfe : 0;
     a.st_nacc[b] = rep ? nacc : 0;
     a.st_nrej[b] = rep ? nrej : 0;
+    if (!DISC && o.rec.n && rep) o.rec.n[coupled ? 0 : b] = st > 1 ? 0 : nacc;
   }
 }

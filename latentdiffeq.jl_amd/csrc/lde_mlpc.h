@@ -74,9 +74,12 @@ static __global__ void k_build_cpack(const float* __restrict__ Wflat, MlpDims dm
   }
 }
 
-template <int SOLVER, int ACT, bool ADJ>
+// DISC (with ADJ): LDE_SENSE_DISCRETE — the reverse sweep over the forward solve's step record instead of a reverse-time solve (the block
+// behind the evaluation lambdas; lde_mlpd.h has the algorithm). The template's LAST bool stays ADJ (check_agprs.py reads it).
+template <int SOLVER, int ACT, bool DISC, bool ADJ>
 __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, VArgs a) {
   using namespace mlpc;
+  static_assert(ADJ || !DISC, "the discrete sweep is an adjoint");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NST = SOLVER == LDE_SOLVER_TSIT5 ? 6 : 4;                // weighted stages of a step = ring slots the fold reads
   constexpr int NSL = ADJ ? NST + 1 : 1;                                  // + one scratch slot (initial-step probes, the FSAL stage)
@@ -166,6 +169,8 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
     if (bt0 + t < B) {
       if (!ADJ) {
         if (lane < D) y[t] = a.z0[(size_t)(bt0 + t) * D + lane];
+      } else if (DISC) {
+        if (is_z) y[t] = a.z_out[(size_t)(bt0 + t) * Dp + row];   // ẑ₀ (save time 0): only the failure check reads it here
       } else if (counted) {
         const size_t srcg = (size_t)Dp * ((size_t)(bt0 + t) + (size_t)B * (T - 1)) + row;
         y[t] = is_z ? a.z_out[srcg] : a.dz_out[srcg];
@@ -263,7 +268,8 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
   };
 
   // one evaluation of the (augmented) right-hand side for both trajectories: src → dst; its vectors stay in ring slot `slot`
-  auto eval = [&](const float (&src)[2], int slot, float (&dst)[2]) {
+  // vj (wave-uniform; only the discrete sweep passes false): false = the forward half alone — f, h₁, h₂ — for the evaluations that rebuild slopes
+  auto eval = [&](const float (&src)[2], int slot, float (&dst)[2], bool vj = true) {
     PROF_T(e0);
     float* xs = ring + slot * SLOT;
     float *h1v = xs + XS, *d2v = h1v + HV, *h2v = d2v + HV, *d1v = h2v + HV;
@@ -289,7 +295,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
       h1 = u == H1 ? 1.f : act_fn(act, a1);   // unit H₁ (when < 128): the constant that carries b₂ (rows beyond: zero weights and bias ⇒ act(0) = 0)
     }
     h1v[2 * u + ut] = h1;
-    if (ADJ) {
+    if (ADJ && vj) {
       f32x4 xv[G1], wv4[G1];
 #pragma unroll
       for (int g = 0; g < G1; g++) { xv[g] = x4[G1 + g]; wv4[g] = my13[G1 + g]; }   // λ
@@ -339,7 +345,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
       }
       reinterpret_cast<f32x4*>(fpart)[br * 16 + bc] = f32x4{f0.x, f0.y, f1.x, f1.y};
     }
-    if (ADJ) {
+    if (ADJ && vj) {
       f32x2 d2[RB];
       const f32x2* dv = reinterpret_cast<const f32x2*>(d2v) + RB * br;
 #pragma unroll
@@ -376,7 +382,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
     }
     PROF_ADD(3, e0, e1);
     PROF_ADD(4, e1, e2);
-    if (ADJ) {
+    if (ADJ && vj) {
       float g1 = 0.f;
       {
         float p[16];
@@ -405,17 +411,18 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
   // the accepted step's share of the quadrature gW = Σ_s |h| b_s (∂f/∂W)ᵀλ of BOTH trajectories, from the ring. K slot q = 4g + (lane >> 4)
   // ↔ (stage e, trajectory) = (q >> 1, q & 1). Tiles of wave w (operand addresses = a per-lane base + compile-time offsets):
   //   n = 2·ti + m, ti < 9, m < 2 : gW₂ᵀ tile (ti, tj = 4m + w)     n = 18 + 2m + tk : gW₁ tile (4m + w, tk)     n = 22 + 2m + tk : gW₃ᵀ tile (4m + w, tk)
-  auto fold = [&]() {
+  auto fold = [&](int nvalid) {   // nvalid (wave-uniform): ring slots [0, nvalid) count
     PROF_T(f0);
     const int l15 = lane & 15, e4 = lane >> 4;
 #pragma unroll
     for (int g = 0; g < (2 * NST + 3) / 4; g++) {
       const int q = 4 * g + e4, e = q >> 1, tt = q & 1;
       float bs;
-      if (SOLVER == LDE_SOLVER_TSIT5) bs = e == 0 ? ts5::A[6][0] : e == 1 ? ts5::A[6][1] : e == 2 ? ts5::A[6][2] : e == 3 ? ts5::A[6][3] : e == 4 ? ts5::A[6][4] : ts5::A[6][5];
+      if (DISC) bs = 1.f;   // (the scale h·b_i is inside k̄)
+      else if (SOLVER == LDE_SOLVER_TSIT5) bs = e == 0 ? ts5::A[6][0] : e == 1 ? ts5::A[6][1] : e == 2 ? ts5::A[6][2] : e == 3 ? ts5::A[6][3] : e == 4 ? ts5::A[6][4] : ts5::A[6][5];
       else bs = (e == 0 || e == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
-      const bool ev = e < NST;
-      const float wsc = wq * bs;
+      const bool ev = e < nvalid;
+      const float wsc = DISC ? 1.f : wq * bs;
       const float* sl = ring + (ev ? e : 0) * SLOT;
       const float* pv = sl + XS + 2 * l15 + tt;           // + 32·tile: element (16·tile + l15) of trajectory tt of the slot's first vector
       const float* pw = pv + 32 * wv;                     // … of the tiles 4m + w
@@ -464,10 +471,11 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
 #pragma unroll
     for (int e = 0; e < NST; e++) {
       const float bs = SOLVER == LDE_SOLVER_TSIT5 ? ts5::A[6][e] : ((e == 0 || e == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f));
+      const float wb_ = DISC ? (e < nvalid ? 1.f : 0.f) : wq * bs;
       const float* sl = ring + e * SLOT;
       const f32x2 dd = reinterpret_cast<const f32x2*>(sl + XS + 3 * HV)[u];
-      gb1 += (wq * bs) * (dd.x + dd.y);
-      gb3 += (wq * bs) * (sl[lane] + sl[64 + lane]);
+      gb1 += wb_ * (dd.x + dd.y);
+      gb3 += wb_ * (sl[lane] + sl[64 + lane]);
     }
     __syncthreads();   // the next attempt overwrites the ring: every wave has read it
     PROF_T(f1);
@@ -508,9 +516,171 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
       }
     }
   };
+  if constexpr (DISC) {
+    // ---- LDE_SENSE_DISCRETE: the recorded steps (t_n, dt_n, y_n), last to first. z lanes carry the stage points and slopes (y = y_n,
+    //      yn = y_{n+1}, k[i] = k_{i+1}); λ lanes carry the cotangents (y = ȳ_{n+1}, yn = ȳ_n, k[i] = k̄_{i+1}, scr = the k̄₁ that travels on)
+    constexpr int S = NST;
+    constexpr float RK[5][4] = {{0.f, 0.f, 0.f, 0.f}, {0.5f, 0.f, 0.f, 0.f}, {0.f, 0.5f, 0.f, 0.f}, {0.f, 0.f, 1.f, 0.f},
+                                {1.0f / 6.0f, 1.0f / 3.0f, 1.0f / 3.0f, 1.0f / 6.0f}};
+    auto A = [&](int i, int q) -> float { return SOLVER == LDE_SOLVER_TSIT5 ? ts5::A[i][q] : RK[i][q]; };
+    const StepRec R = o.rec;
+    const int seq = coupled ? 0 : bt0;   // (both trajectories walk ONE sequence: a coupled solve's, or the same fixed steps)
+    const int ns = R.n[seq];
+    if (status == 0 && (ns < 1 || ns > R.cap)) status = 1 + LDE_RET_MAXITERS;   // no usable record: NaN gradient, never a truncated sweep
+    y[0] = y[1] = 0.f;                  // (ẑ₀ has served the failure check; the last evaluation reloads it)
+    // stage point i of the step from y_n and the slopes (z lanes; i == S: y_{n+1})
+    auto point = [&](int i, float hh, int tt) -> float {
+      float zv = y[tt];
+      if (SOLVER == LDE_SOLVER_RK4 && i == S) zv = y[tt] + (hh * (1.0f / 6.0f)) * (k[0][tt] + 2.0f * (k[1][tt] + k[2][tt]) + k[3][tt]);
+      else {
+#define DSTAGE(S_)                                                                   \
+  case S_: {                                                                         \
+    float accv = A(S_, 0) * k[0][tt];                                                \
+    _Pragma("unroll") for (int jj = 1; jj < S_; jj++) accv += A(S_, jj) * k[jj][tt]; \
+    zv = y[tt] + hh * accv;                                                          \
+  } break;
+        switch (i) {
+          DSTAGE(1) DSTAGE(2) DSTAGE(3) DSTAGE(4)
+          default: break;
+        }
+        if constexpr (S == 6) {
+          switch (i) {
+            DSTAGE(5) DSTAGE(6)
+            default: break;
+          }
+        }
+#undef DSTAGE
+      }
+      return zv;
+    };
+    if (status == 0) {
+      j = T - 1;
+      double tnext = tend;
+#pragma unroll 1
+      for (int sidx = ns - 1; sidx >= 0; sidx--) {
+        const double ts_n = R.t[(size_t)sidx * R.nseq + seq], dts = R.dt[(size_t)sidx * R.nseq + seq];
+        const float hh = (float)dts;
+        const bool lastst = sidx == ns - 1;
+        const double tnw = tnext;
+        tnext = ts_n;
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++) {
+          if (is_z) y[tt] = (tt == 0 || two) ? R.y[((size_t)sidx * B + (bt0 + tt)) * Dp + row] : 0.f;
+          else {
+            yn[tt] = 0.f;
+#pragma unroll
+            for (int q = 0; q < S; q++) k[q][tt] = 0.f;
+            k[S][tt] = is_l ? scr[tt] : 0.f;
+          }
+        }
+        // pass 1: the slopes k_1 … k_S (forward halves, through the scratch slot)
+#pragma unroll 1
+        for (int i = 0; i < S; i++) {
+          float src[2], dst[2];
+#pragma unroll
+          for (int tt = 0; tt < 2; tt++) src[tt] = is_z ? point(i, hh, tt) : 0.f;
+          eval(src, NST, dst, false);
+#pragma unroll
+          for (int q = 0; q < S; q++)
+            if (q == i && is_z) { k[q][0] = dst[0]; k[q][1] = dst[1]; }
+        }
+        if (is_z) { yn[0] = point(S, hh, 0); yn[1] = point(S, hh, 1); }
+        // the save times inside the step (t_n, t_{n+1}]
+        while (j >= 1 && sgpr_d(s_ts[j]) > ts_n) {   // (wave-uniform: kept scalar)
+          const double tj = sgpr_d(s_ts[j]);
+          const bool at_end = tj >= tnw || (j == T - 1 && lastst);
+          const float th = at_end ? 2.0f : (float)(tj - ts_n) * fast_rcp(hh);
+          if (is_l) {
+            float bw[7];
+            if (SOLVER == LDE_SOLVER_TSIT5) tsit5_interp_weights(th, bw);
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++) {
+              float dj = 0.f;
+              if (a.cot_lds) dj = s_cot[(tt * T + j) * Dp + row];
+              else if (bt0 + tt < B) dj = a.dz_out[(size_t)Dp * ((size_t)(bt0 + tt) + (size_t)B * j) + row];
+              if (at_end) y[tt] += dj;
+              else if (SOLVER == LDE_SOLVER_TSIT5) {
+                yn[tt] += dj;
+#pragma unroll
+                for (int q = 0; q < 7; q++) k[q][tt] += (hh * bw[q]) * dj;
+              } else {
+                const float om = 1.0f - th;
+                const float h00 = (1.0f + 2.0f * th) * om * om, h10 = th * om * om;
+                const float h01 = th * th * (3.0f - 2.0f * th), h11 = th * th * (th - 1.0f);
+                yn[tt] += h00 * dj;
+                k[0][tt] += (h10 * hh) * dj;
+                y[tt] += h01 * dj;
+                k[S][tt] += (h11 * hh) * dj;
+              }
+            }
+          }
+          j--;
+        }
+        // pass 2: Jᵀk̄ at y_{n+1}, then at g_S … g_2 (fused evaluations; their vectors stay in ring slots 0 … S − 1 for the fold)
+#pragma unroll 1
+        for (int i = S; i >= 1; i--) {
+          float src[2], dst[2];
+#pragma unroll
+          for (int tt = 0; tt < 2; tt++) {
+            float kb = 0.f;
+#pragma unroll
+            for (int q = 0; q <= S; q++) kb = q == i ? k[q][tt] : kb;
+            src[tt] = is_z ? (i == S ? yn[tt] : point(i, hh, tt)) : kb;
+          }
+          eval(src, S - i, dst, true);
+          if (is_l) {
+#pragma unroll
+            for (int tt = 0; tt < 2; tt++) {
+              const float v = -dst[tt];
+              if (i == S) {
+                y[tt] += v;
+#pragma unroll
+                for (int q = 0; q < S; q++) k[q][tt] += (hh * A(S, q)) * y[tt];
+                yn[tt] += y[tt];
+              } else {
+                yn[tt] += v;
+#pragma unroll
+                for (int q = 0; q < S - 1; q++) {
+                  float aq = 0.f;
+#pragma unroll
+                  for (int ii = 1; ii < S; ii++) aq = ii == i ? A(ii, q) : aq;
+                  if (q < i) k[q][tt] += (hh * aq) * v;
+                }
+              }
+            }
+          }
+        }
+        fold(S);
+        if (is_l) {
+#pragma unroll
+          for (int tt = 0; tt < 2; tt++) {
+            scr[tt] = k[0][tt];
+            y[tt] = yn[tt];
+          }
+        }
+        nfe += 2 * S;
+        nacc++;
+      }
+      {   // k_1 of the first step = f(y_0)
+        float src[2], dst[2];
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++) src[tt] = is_z ? ((tt == 0 || two) ? a.z_out[(size_t)(bt0 + tt) * Dp + row] : 0.f) : (is_l ? scr[tt] : 0.f);
+        eval(src, 0, dst, true);
+        fold(1);
+        if (is_l) { y[0] -= dst[0]; y[1] -= dst[1]; }
+        nfe++;
+      }
+      status = 1;
+    }
+    if (is_l) {   // save time 0 is ẑ₀ itself
+#pragma unroll
+      for (int tt = 0; tt < 2; tt++)
+        if (bt0 + tt < B) y[tt] += a.dz_out[(size_t)(bt0 + tt) * Dp + row];
+    }
+  }
   const bool auto_dt = o.adaptive && !(o.dt_fixed > 0);
   int phase = (ADJ && !auto_dt) ? PH_STAGE : PH_K0, s = 0;
-  bool running = T > 1 && status == 0;
+  bool running = !DISC && T > 1 && status == 0;
   if (ADJ && running && !auto_dt) {
     dt = o.adaptive ? fmin(o.dt_fixed, dtmax) : o.dt_fixed;
     running = begin_step();
@@ -672,9 +842,11 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
       }
     }
     bool accepted = false;
+    double hrec = 0.0;   // the attempted step as f64 (the controller overwrites dt below)
     if (status == 0) {
       const float EEst = o.adaptive ? sqrtf(s2 / nnorm) : (s2 == s2 ? 0.f : s2);
       const double hmag = ADJ ? tnew : dt;
+      hrec = hmag;
       if (!(EEst == EEst)) {
         if (o.adaptive && hmag > o.dtmin) { nrej++; dt = hmag * (double)o.qmin; }
         else status = 1 + LDE_RET_NONFINITE;
@@ -698,6 +870,17 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
         accepted = true;
       }
       if (accepted) nacc++;
+    }
+    if (accepted && o.rec.n && nacc <= o.rec.cap) {   // the step record (forward: start time, size, start state) / the reverse-time trace (size)
+      if (tid < 2 && (coupled ? (blockIdx.x == 0 && tid == 0) : bt0 + tid < B)) {
+        const size_t ri = (size_t)(nacc - 1) * o.rec.nseq + (coupled ? 0 : bt0 + tid);
+        if (!ADJ) o.rec.t[ri] = t;
+        o.rec.dt[ri] = hrec;
+      }
+      if (!ADJ && wv == 0 && lane < Dp) {
+        o.rec.y[((size_t)(nacc - 1) * B + bt0) * Dp + lane] = y[0];
+        if (two) o.rec.y[((size_t)(nacc - 1) * B + bt0 + 1) * Dp + lane] = y[1];
+      }
     }
     if (!ADJ) {
       while (accepted && j < T && s_ts[j] <= tnew) {   // dense output at every save time inside the accepted step
@@ -741,7 +924,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
       running = begin_step();
     } else {
       if (__builtin_amdgcn_readfirstlane((int)accepted)) {   // (workgroup-uniform: every wave takes bitwise the same decisions — a scalar branch)
-        fold();
+        fold(NST);
         if (SPEC) {
 #pragma unroll
           for (int tt = 0; tt < 2; tt++) {
@@ -784,8 +967,9 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
     }
   } else {
     if (wv == 0 && lane >= DP && lane < DP + D) {
-      a.dz0[(size_t)bt0 * D + (lane - DP)] = st > 1 ? 0.f : y[0];
-      if (two) a.dz0[(size_t)(bt0 + 1) * D + (lane - DP)] = st > 1 ? 0.f : y[1];
+      const float fv = (DISC && st == 1 + LDE_RET_MAXITERS) ? __int_as_float(0x7fc00000) : 0.f;   // (no usable step record: NaN, not zeros)
+      a.dz0[(size_t)bt0 * D + (lane - DP)] = st > 1 ? fv : y[0];
+      if (two) a.dz0[(size_t)(bt0 + 1) * D + (lane - DP)] = st > 1 ? fv : y[1];
     }
     if (tid < (two ? 2 : 1)) a.st_ret[bt0 + tid] = st > 1 ? st - 1 : 0;
     // the workgroup's row of the [workgroups × row stride] slab, flat destructure order (vec(W) column-major [out×in], then b): every
@@ -834,5 +1018,6 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
     a.st_nfe[bt0 + tid] = rep ? nfe : 0;
     a.st_nacc[bt0 + tid] = rep ? nacc : 0;
     a.st_nrej[bt0 + tid] = rep ? nrej : 0;
+    if (!DISC && o.rec.n && rep) o.rec.n[coupled ? 0 : bt0 + tid] = st > 1 ? 0 : nacc;
   }
 }

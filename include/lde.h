@@ -346,6 +346,11 @@ int  lde_chain_forward_save_mse_delta(lde_chain* c, const float* x, int64_t N, f
                                       const float* base, float* out, float* scratch, void* stream);
 int  lde_chain_backward_saved_delta(lde_chain* c, const float* x, const float* g_dev, const float* saved, int64_t N, float* dx, float* dW,
                                     void* stream);
+/* 1 when the δ matrix in the chain's workspace is the one lde_chain_forward_save_mse_delta staged for THIS forward call — identified by
+ * its `saved` buffer and N — and no later forward / pullback of the chain has overwritten or consumed it; 0 otherwise. A caller that may
+ * have several forwards of one chain in flight (an AD tape) asks before lde_chain_backward_saved_delta — which refuses with
+ * LDE_ERR_INVALID_ARG rather than use another call's δ — and takes lde_chain_backward_saved_mse instead (same values; needs y). */
+int  lde_chain_delta_is_staged(const lde_chain* c, const float* saved, int64_t N);
 /* How the pullbacks deliver the weight gradient: on = 1 (default) dW += gradient, like lde_adjoint; on = 0: dW = gradient — every
  * entry of dW is written exactly once, so a caller that wants the plain gradient needs no zero fill (one launch less). */
 int  lde_chain_set_accumulate(lde_chain* c, int on);

@@ -228,12 +228,16 @@ class _ChainMseFn(torch.autograd.Function):
                                                C.c_void_p(dW.data_ptr()), stream), h, "lde_chain_backward", chain=True)
             return None, dx, dW, None, None, None, None
         g = g.contiguous().float()
-        if ctx.delta and dy is None:   # δ_L′ is staged in the chain's workspace: no pass over x̂ / the frames; g multiplies dx and dW at the end
+        # δ_L′ staged in the chain's workspace by THIS node's forward (lde_chain_delta_is_staged: another forward of the same decoder before this
+        # pullback re-stages it — then the two-pass pullback below runs from x̂ and the frames instead): no pass over x̂ / the frames; g
+        # multiplies dx and dW at the end
+        if ctx.delta and dy is None and lib.lde_chain_delta_is_staged(h, psv, N):
             L.check(lib.lde_chain_backward_saved_delta(h, C.c_void_p(x.data_ptr()), C.c_void_p(g.data_ptr()), psv, N, pdx, C.c_void_p(dW.data_ptr()), stream),
                     h, "lde_chain_backward_saved_delta", chain=True)
             return None, dx, dW, None, None, (g if ctx.has_base else None), None
         if y.numel() == 0:
-            raise L.LdeError("decode_loss(want_x_hat=False): x̂ was not kept, so it cannot carry a cotangent of its own")
+            raise L.LdeError("decode_loss(want_x_hat=False): x̂ was not kept — it cannot carry a cotangent of its own, and another forward of this "
+                             "decoder has re-staged the loss's δ since (keep x̂, or run each forward's backward before the next forward)")
         L.check(lib.lde_chain_backward_saved_mse(h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(target.data_ptr()),
                                                  C.c_void_p(g.data_ptr()), ctx.scale, C.c_void_p(dy.data_ptr()) if dy is not None else C.c_void_p(),
                                                  psv, N, pdx, C.c_void_p(dW.data_ptr()), stream), h, "lde_chain_backward_saved_mse", chain=True)

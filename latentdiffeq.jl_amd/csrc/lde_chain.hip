@@ -661,6 +661,7 @@ struct lde_chain {
   int bcg_fwd = 0, bcg_bwd = 0, bcgx_fwd = 0, bcgx_bwd = 0;
   __bf16* dstage = nullptr; size_t dstage_cap = 0;       // δ_l matrices of the bf16 pullback
   int64_t delta_N = -1;     // lde_chain_forward_save_mse_delta left δ_L′ of this many columns in dstage (−1: none)
+  const float* delta_saved = nullptr;   // … for the forward call whose saved-activation buffer this is: the token the pullback must present
   __bf16* svscratch = nullptr; size_t svscratch_cap = 0;  // lde_chain_backward (no saved buffer) in bf16 mode: its own forward pass saves here
   lde_chain_desc d;
   ChainDims cd;
@@ -1349,7 +1350,7 @@ static int chain_backward_b(lde_chain* c, const float* x, const float* y, const 
   }
   ChainBwdArgsB a{x, y, dy, dx, c->fragTb, c->W_dev, c->dstage, (long long)N, saved, t_dy_more[0], t_dy_more[1], t_mse.t, t_mse.g, t_mse.scale,
                   t_delta_g ? 1 : 0, t_delta_g};
-  if (!t_delta_g) c->delta_N = -1;   // (this pullback writes its own δ_L over whatever the forward pass staged)
+  if (!t_delta_g) { c->delta_N = -1; c->delta_saved = nullptr; }   // (this pullback writes its own δ_L over whatever the forward pass staged)
   const int NC = 16 * pk.cg;
   {
     const dim3 grid((unsigned)((N + NC - 1) / NC));
@@ -1735,7 +1736,11 @@ int lde_chain_forward_save_mse_delta(lde_chain* c, const float* x, int64_t N, fl
   t_fwd_mse = FwdMse{nullptr, nullptr, 0, false, 0.f};
   if (rc) return rc;
   c->delta_N = N;
+  c->delta_saved = saved;
   return loss_finalize(scratch, (int)tiles, scale, base, out, (hipStream_t)stream);
+}
+int lde_chain_delta_is_staged(const lde_chain* c, const float* saved, int64_t N) {
+  return c && c->bf16 && c->dstage && c->delta_N == N && N >= 0 && c->delta_saved == saved && saved != nullptr;
 }
 int lde_chain_backward_saved_delta(lde_chain* c, const float* x, const float* g_dev, const float* saved, int64_t N, float* dx, float* dW, void* stream) {
   if (!c) return LDE_ERR_INVALID_ARG;
@@ -1743,13 +1748,18 @@ int lde_chain_backward_saved_delta(lde_chain* c, const float* x, const float* g_
     c->err = "lde_chain_backward_saved_delta: NULL cotangent / saved activations";
     return LDE_ERR_INVALID_ARG;
   }
-  if (!c->bf16 || c->delta_N != N || !c->dstage) {
-    c->err = "lde_chain_backward_saved_delta: no staged δ_L of this size (call lde_chain_forward_save_mse_delta first)";
+  if (!lde_chain_delta_is_staged(c, saved, N)) {
+    // (another forward of this chain has re-staged δ_L′ since — or none ran: the δ in the workspace is not this call's; using it would give
+    //  silently wrong gradients)
+    c->err = "lde_chain_backward_saved_delta: the staged δ_L is not the one of the forward call these saved activations belong to "
+             "(lde_chain_forward_save_mse_delta must be the chain's last such call; lde_chain_delta_is_staged tells)";
     return LDE_ERR_INVALID_ARG;
   }
   t_delta_g = g_dev;
   const int rc = lde_chain_backward_saved(c, x, x, x, saved, N, dx, dW, stream);   // (y and dy are not read: δ_L′ is staged)
   t_delta_g = nullptr;
+  c->delta_N = -1;          // consumed: a second pullback from the same staging must not pass silently either
+  c->delta_saved = nullptr;
   return rc;
 }
 

@@ -719,7 +719,10 @@ static void bwd_fn(void* vctx, double t, const real* y, real* dy, real wq) {
       real* fz = dy + (int64_t)c * b->Dp;
       real* dl = dy + nz + (int64_t)c * b->Dp;
       real* dg = dy + 2 * nz + (int64_t)c * b->P;
-      rhs_vjp_col(&b->cs[omp_get_thread_num()], z, b->theta + (int64_t)c * b->P, lam, fz, vz, vth, wq);
+      colrhs* cc = &b->cs[omp_get_thread_num()];
+      cc->margin = b->col_margin ? b->col_margin + c : NULL;
+      rhs_vjp_col(cc, z, b->theta + (int64_t)c * b->P, lam, fz, vz, vth, wq);
+      cc->margin = NULL;
       for (int i = 0; i < b->Dp; i++) dl[i] = -vz[i];
       for (int p = 0; p < b->P; p++) dg[p] = -vth[p];
     }
@@ -734,7 +737,9 @@ static void bwd_fn(void* vctx, double t, const real* y, real* dy, real wq) {
     real* fz = dy + (int64_t)c * b->Dp;
     real* dl = dy + nz + (int64_t)c * b->Dp;
     real* dg = dy + 2 * nz + (int64_t)c * b->P;
+    b->c.margin = b->col_margin ? b->col_margin + c : NULL;
     rhs_vjp_col(&b->c, z, b->theta + (int64_t)c * b->P, lam, fz, vz, vth, wq);
+    b->c.margin = NULL;
     for (int i = 0; i < b->Dp; i++) dl[i] = -vz[i];
     for (int p = 0; p < b->P; p++) dg[p] = -vth[p];
   }
@@ -965,10 +970,12 @@ static int adjoint_discrete(const lde_problem_desc* d, const real* W, const real
 /* dW is ACCUMULATED (+=), as in lde_adjoint. rec_*: the reverse-time solve's accepted step magnitudes, recorded or prescribed. */
 static int adjoint_impl(const lde_problem_desc* d, const real* W, const real* z_out, const real* theta, const double* ts,
                         int T, int B, const real* dz_out, real* dz0, real* dtheta, real* dW, int64_t* stats, double* rec_dt,
-                        int32_t* rec_n, int rec_cap, int presc, int nthreads) {
+                        int32_t* rec_n, int rec_cap, int presc, double* margins, int nthreads) {
   int rc = check_desc(d);
   if (rc) return rc;
   if (T < 1 || B < 1) return LDE_ERR_INVALID_ARG;
+  if (margins)
+    for (int c = 0; c < B; c++) margins[c] = 1.0;
   if (d->sensealg == LDE_SENSE_DISCRETE) return LDE_ERR_INVALID_ARG;   /* needs the forward record: oracle_adjoint_discrete */
   if (d->sensealg == LDE_SENSE_PARALLEL_CHECKPOINTED && !has_mlp(d) && d->batching == LDE_BATCH_PER_TRAJECTORY && !rec_dt)
     return adjoint_parallel(d, z_out, theta, ts, T, B, dz_out, dz0, dtheta, stats, nthreads);
@@ -986,6 +993,7 @@ static int adjoint_impl(const lde_problem_desc* d, const real* W, const real* z_
     colrhs_init(&b.c, d, W);
     b.ncol = B; b.Dp = Dp; b.P = P; b.theta = theta;
     b.zsave = z_out; b.dzout = dz_out; b.Bstride = B; b.checkpoint = ckpt; b.dW_acc = dW_tot;
+    b.col_margin = margins;
     block_threads_init(&b, d, W, nthreads);
     int64_t nz = (int64_t)Dp * B, n = 2 * nz + (int64_t)P * B;
     real* y = (real*)calloc((size_t)n, sizeof(real));
@@ -1030,6 +1038,7 @@ static int adjoint_impl(const lde_problem_desc* d, const real* W, const real* z_
         b.theta = theta ? theta + (int64_t)c * P : NULL;
         b.zsave = z_out + (int64_t)Dp * c;
         b.dzout = dz_out + (int64_t)Dp * c;
+        b.col_margin = margins ? margins + c : NULL;
         int bad = 0;
         for (int i = 0; i < Dp; i++) {
           int64_t src = i + (int64_t)Dp * ((int64_t)B * (T - 1));
@@ -1066,7 +1075,7 @@ static int adjoint_impl(const lde_problem_desc* d, const real* W, const real* z_
 
 int oracle_adjoint(const lde_problem_desc* d, const real* W, const real* z_out, const real* theta, const double* ts,
                    int T, int B, const real* dz_out, real* dz0, real* dtheta, real* dW, int64_t* stats, int nthreads) {
-  return adjoint_impl(d, W, z_out, theta, ts, T, B, dz_out, dz0, dtheta, dW, stats, NULL, NULL, 0, 0, nthreads);
+  return adjoint_impl(d, W, z_out, theta, ts, T, B, dz_out, dz0, dtheta, dW, stats, NULL, NULL, 0, 0, NULL, nthreads);
 }
 /* The continuous adjoint (sensealg 0 / 1) with the reverse-time solve's accepted step magnitudes recorded (presc = 0) or prescribed
  * (presc = 1): rec_dt [nseq][rec_cap], rec_n [nseq], nseq = B or 1 as in oracle_forward_steps. */
@@ -1074,7 +1083,14 @@ int oracle_adjoint_steps(const lde_problem_desc* d, const real* W, const real* z
                          int T, int B, const real* dz_out, real* dz0, real* dtheta, real* dW, int64_t* stats, double* rec_dt,
                          int32_t* rec_n, int rec_cap, int presc, int nthreads) {
   if (!rec_dt || !rec_n || rec_cap < 1) return LDE_ERR_INVALID_ARG;
-  return adjoint_impl(d, W, z_out, theta, ts, T, B, dz_out, dz0, dtheta, dW, stats, rec_dt, rec_n, rec_cap, presc, nthreads);
+  return adjoint_impl(d, W, z_out, theta, ts, T, B, dz_out, dz0, dtheta, dW, stats, rec_dt, rec_n, rec_cap, presc, NULL, nthreads);
+}
+/* … with the relu-kink margins of the reverse-time solve (see oracle_adjoint_discrete_margins): margins[B]. */
+int oracle_adjoint_steps_margins(const lde_problem_desc* d, const real* W, const real* z_out, const real* theta, const double* ts,
+                                 int T, int B, const real* dz_out, real* dz0, real* dtheta, real* dW, int64_t* stats, double* rec_dt,
+                                 int32_t* rec_n, int rec_cap, int presc, double* margins, int nthreads) {
+  if (!rec_dt || !rec_n || rec_cap < 1) return LDE_ERR_INVALID_ARG;
+  return adjoint_impl(d, W, z_out, theta, ts, T, B, dz_out, dz0, dtheta, dW, stats, rec_dt, rec_n, rec_cap, presc, margins, nthreads);
 }
 
 /* ---- discrete (exact) sensitivity: LDE_SENSE_DISCRETE ----------------------------------------------------------------------------

@@ -206,8 +206,9 @@ class Oracle:
         info = dict(nfe=int(stats[0]), naccept=int(stats[1]), nreject=int(stats[2]), nfailed=int(stats[3]), max_steps=int(stats[4]))
         return z_out, ret, dict(t=rt, dt=rdt, n=rn), info
 
-    def adjoint_steps(self, d: Desc, z_out, theta, ts, dz_out, W=None, rec=None, cap=8192, nthreads=0):
-        """The continuous adjoint with the reverse-time solve's accepted step magnitudes recorded (rec=None) or prescribed."""
+    def adjoint_steps(self, d: Desc, z_out, theta, ts, dz_out, W=None, rec=None, cap=8192, nthreads=0, margins=False):
+        """The continuous adjoint with the reverse-time solve's accepted step magnitudes recorded (rec=None) or prescribed.
+        margins=True: info["margins"][b] = how close trajectory b's reverse-time solve came to a relu kink."""
         dt = self.dtype
         z_out = np.ascontiguousarray(z_out, dtype=dt)
         dz_out = np.ascontiguousarray(dz_out, dtype=dt)
@@ -229,13 +230,15 @@ class Oracle:
         nW = self.num_weights(d) if d.rhs_kind in (RHS_MLP, RHS_PENDULUM_PLUS_MLP) else 0
         dW = np.zeros(max(nW, 1), dtype=dt)
         stats = np.zeros(5, dtype=np.int64)
-        rc = self.lib.oracle_adjoint_steps(C.byref(d), self._p(W), self._p(z_out), self._p(theta), self._p(ts), T, B, self._p(dz_out),
-                                           self._p(dz0), self._p(dth), self._p(dW), self._p(stats), self._p(rdt), self._p(rn), cap,
-                                           int(presc), nthreads)
+        mg = np.ones(B) if margins else None
+        rc = self.lib.oracle_adjoint_steps_margins(C.byref(d), self._p(W), self._p(z_out), self._p(theta), self._p(ts), T, B,
+                                                   self._p(dz_out), self._p(dz0), self._p(dth), self._p(dW), self._p(stats), self._p(rdt),
+                                                   self._p(rn), cap, int(presc), self._p(mg), nthreads)
         if rc != 0:
             raise RuntimeError(f"oracle_adjoint_steps failed: {rc}")
         assert presc or int(rn.max()) <= cap, "step record overflow: raise cap"
-        info = dict(nfe=int(stats[0]), naccept=int(stats[1]), nreject=int(stats[2]), nfailed=int(stats[3]), max_steps=int(stats[4]))
+        info = dict(nfe=int(stats[0]), naccept=int(stats[1]), nreject=int(stats[2]), nfailed=int(stats[3]), max_steps=int(stats[4]),
+                    margins=mg)
         return dz0, (dth[:, :P] if P else None), (dW[:nW] if nW else None), dict(dt=rdt, n=rn), info
 
     def adjoint_discrete(self, d: Desc, z_out, theta, ts, dz_out, rec, W=None, nthreads=0, margins=False):

@@ -187,7 +187,7 @@ def test_dense_chain_and_recurrent_mirrors_fail_loudly_on_cpu():
 
 def _julia_struct_fields(name):
     """(field, julia type) list of `mutable struct <name>` in INTEGRATION.md, in declaration order."""
-    src = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    src = open(os.path.join(ROOT, "julia", "LdeNative.jl")).read()      # the loadable stub (INTEGRATION.md §2 walks through it)
     m = re.search(r"mutable struct " + name + r"\b(.*?)\nend\b", src, flags=re.S)
     assert m, name
     body = re.sub(r"#.*", "", m.group(1))
@@ -195,7 +195,7 @@ def _julia_struct_fields(name):
 
 
 def test_documented_julia_struct_layouts():
-    """The Julia stub of INTEGRATION.md cannot run here; its struct mirrors must at least be field-for-field right:
+    """The Julia stub (julia/LdeNative.jl) cannot run here; its struct mirrors must at least be field-for-field right:
     same order, sizes and C offsets (natural alignment — what Julia uses for an isbits-field struct passed by Ref)."""
     from latentdiffeq_amd import _lib
     for jname, cstruct in (("LdeDesc", _lib.ProblemDesc), ("LdeChainDesc", _lib.ChainDesc), ("LdeRnnDesc", _lib.RnnDesc)):
@@ -213,8 +213,12 @@ def test_documented_julia_struct_layouts():
             off += size
         assert (off + 7) // 8 * 8 == C.sizeof(cstruct) or off == C.sizeof(cstruct), jname
     # the stub must start from the library's defaults (sensealg = PARALLEL_CHECKPOINTED), not from zeros
-    src = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    src = open(os.path.join(ROOT, "julia", "LdeNative.jl")).read()
     assert "lde_problem_desc_default" in src.split("mutable struct LdeHandle")[0]
+    # every entry point the stub ccalls is an export of the library
+    from latentdiffeq_amd import _lib as _l
+    called = set(re.findall(r"ccall\(\(:(\w+), liblde\)", src))
+    assert called and called <= set(_l.EXPORTS), called - set(_l.EXPORTS)
 
 
 def test_hidden_accumulator_registers_are_not_touched_by_the_compiler():

@@ -202,3 +202,58 @@ def test_reconstructor_pullback_from_the_delta_the_forward_pass_left(N):
     y = torch.empty((N, 784), device="cuda")
     ws = torch.empty((nws,), device="cuda")
     assert lib.lde_chain_forward_save_mse_delta(h, p(x), N, p(y), p(sv), p(tgt), scale, p(base), p(ws), C.c_void_p(ws.data_ptr() + 4), s) == -2   # LDE_ERR_UNSUPPORTED
+
+
+def test_two_forwards_of_one_decoder_before_their_backwards():
+    """the bf16 δ-staging lives in the chain's single workspace. Two `decode_loss`-style forwards of the SAME chain (same N)
+    before their pullbacks: the first graph must not run its pullback from the second forward's δ_L′. The staging is tokenised by the
+    forward call's saved-activation buffer (lde_chain_delta_is_staged): the second forward's pullback takes the staged δ, the first one's
+    falls back to the two-pass pullback from x̂ and the frames — both give the gradients of their OWN forward; the C entry point refuses a
+    stale token instead of guessing. [REF src/models/GOKU.jl:252-269], [REF examples/pendulum_friction-less/model_train.jl:225-238]"""
+    import ctypes as C
+    import torch
+    from latentdiffeq_amd import chain as CH
+    from latentdiffeq_amd import synthetic as S
+    sizes = (2, 200, 200, 200, 784)
+    N = 1024
+    rng = np.random.default_rng(5)
+    dec = CH.Chain(CH.Dense(2, 200, "relu"), CH.SkipConnection(CH.Dense(200, 200, "relu")), CH.SkipConnection(CH.Dense(200, 200, "relu")),
+                   CH.Dense(200, 784, "sigmoid")).cuda().set_dtype("bf16")
+    assert tuple(dec.sizes) == sizes
+    xs = [torch.from_numpy((0.7 * rng.standard_normal((N, 2))).astype(np.float32)).cuda().requires_grad_() for _ in range(2)]
+    tg = [torch.from_numpy(rng.uniform(0, 1, (N, 784)).astype(np.float32)).cuda() for _ in range(2)]
+
+    def grads(order):
+        for x in xs:
+            x.grad = None
+        dec.theta.grad = None
+        losses = [CH._ChainMseFn.apply(dec, xs[i], dec.theta, tg[i], 1.0 / N, None, True)[0] for i in range(2)]
+        out = {}
+        for i in order:
+            dec.theta.grad = None
+            losses[i].backward()
+            out[i] = (xs[i].grad.clone(), dec.theta.grad.clone())
+        return out
+
+    # reference: each forward followed at once by its own backward
+    ref = {}
+    for i in range(2):
+        xs[i].grad = None
+        dec.theta.grad = None
+        CH._ChainMseFn.apply(dec, xs[i], dec.theta, tg[i], 1.0 / N, None, True)[0].backward()
+        ref[i] = (xs[i].grad.clone(), dec.theta.grad.clone())
+    for order in ((0, 1), (1, 0)):
+        got = grads(order)
+        for i in range(2):
+            for a, b in zip(got[i], ref[i]):
+                rel = float((a - b).abs().max() / b.abs().max())
+                assert rel <= 2e-2, (order, i, rel)           # (the fall-back rounds g·δ instead of δ: equal to bf16 rounding; a stale δ would be O(1) off)
+    # and the C entry point: a stale token is refused
+    h, lib = dec._native(), dec._lib
+    sv = torch.empty((int(lib.lde_chain_saved_floats(h, N)),), device="cuda")
+    gd = torch.tensor([1.0], device="cuda")
+    dW = torch.zeros((dec.num_weights,), device="cuda")
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    assert lib.lde_chain_delta_is_staged(h, C.c_void_p(sv.data_ptr()), N) == 0
+    assert lib.lde_chain_backward_saved_delta(h, C.c_void_p(xs[0].data_ptr()), C.c_void_p(gd.data_ptr()), C.c_void_p(sv.data_ptr()), N, C.c_void_p(),
+                                              C.c_void_p(dW.data_ptr()), s) != 0

@@ -529,7 +529,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def attach_traffic(roof, workload, B, mlp, full_batch, dom=None, rounds=("r4", "r3", "r2", "r1")):
+def attach_traffic(roof, workload, B, mlp, full_batch, dom=None, rounds=("r5", "r4", "r3", "r2", "r1")):
     """roofline.traffic (+ rocprof_avg_launch_ms, whole_step.traffic) of the solve workloads from the newest committed PMC summary
     (profiles/collect.sh + profiles/summarize.py; FETCH_SIZE ×2 only for kernels that load 16 bytes per lane, WRITE_SIZE as is —
     MI355X_MICROARCH.md §HBM). Also called by profiles/refresh.py on the bench line it copies next to a fresh summary, so the
@@ -550,8 +550,8 @@ def attach_traffic(roof, workload, B, mlp, full_batch, dom=None, rounds=("r4", "
                     roof["traffic"] = tb(kd)
                     roof["rocprof_avg_launch_ms"] = kd["avg_ns"] * 1e-6
         elif full_batch:   # MLP workloads: the dominant kernel's own traffic; the whole step's beside it
-            def is_adj_solve(name):   # the adjoint's solve kernels: k_mlp64_adj<…>, k_mlpb / k_mlpc / k_mlpw / k_mlpv<…, true…>, k_mlp_adjoint, k_mlp4_adjoint
-                return name.startswith(("k_mlp64_adj", "k_mlp_adjoint", "k_mlp4_adjoint")) or (name.startswith(("k_mlpb", "k_mlpc", "k_mlpw", "k_mlpv")) and "true" in name)
+            def is_adj_solve(name):   # the adjoint's solve kernels: k_mlp64_adj / k_mlp64_disc<…>, k_mlpb / k_mlpc / k_mlpw / k_mlpv<…, true…>, k_mlp_adjoint[_disc], k_mlp4_adjoint
+                return name.startswith(("k_mlp64_adj", "k_mlp64_disc", "k_mlp_adjoint", "k_mlp4_adjoint")) or (name.startswith(("k_mlpb", "k_mlpc", "k_mlpw", "k_mlpv")) and "true" in name)
             adj = [(kd.get("avg_ns", 0), tb(kd)) for name, kd in kern.items() if is_adj_solve(name) and "write_bytes" in kd]
             tr = [tb(kd) for name, kd in kern.items() if name.startswith(("k_mlp", "k_reduce", "k_sum")) and "write_bytes" in kd]
             if adj:
@@ -966,7 +966,7 @@ def main():
                     traffic=None, alg_bytes_per_launch=dom_bytes * B, avg_launch_ms=dom_stream, avg_launch_ms_bracketed=dom_ms)
 
     # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    attach_traffic(roof, args.workload, B, mlp=bool(Ff), full_batch=(B == w["B"]), dom=None if Ff else dom)
+    attach_traffic(roof, args.workload + ("_discrete" if disc else ""), B, mlp=bool(Ff), full_batch=(B == w["B"]), dom=None if Ff else dom)
 
     out = {
         "metric": "trajectories/sec (fwd+adjoint) GOKU pendulum, batch=256, 1/2/4/8 GPU"

@@ -47,7 +47,7 @@ for w in args:
         roof = d.get("roofline") or {}
         if roof.get("bound") == "hbm" and w.startswith("goku_pendulum"):
             bench.attach_traffic(roof, "goku_pendulum", d["config"]["batch_per_gpu"], mlp=False, full_batch=True, rounds=(RND,))
-        elif w in ("c2", "c3", "c4", "latentode_ref"):
+        elif w.replace("_discrete", "") in ("c2", "c3", "c4", "latentode_ref"):
             bench.attach_traffic(roof, w, d["config"]["batch_per_gpu"], mlp=True, full_batch=True, rounds=(RND,))
         open(dst, "w").write(json.dumps(d) + "\n")
     s = json.load(open(f"{ROOT}/profiles/{RND}_{w}_summary.json"))

@@ -382,9 +382,10 @@ def decoder_cpu_baseline(specs, weights, d_native, ts, zt, tt, dxh, B, T, budget
 
 # ---- whole GOKU training step (BASELINE.json configs[4] shape, one GPU's share): encoder → sample → decoder → loss → pullback → AdamW
 def run_goku_step(args, torch, dist, world, rank, local):
-    if os.environ.get("LDE_BENCH_GRAPH", "1") != "0":
-        os.environ.setdefault("LDE_BRANCH_STREAMS", "0")   # the captured step runs on one stream (read when the package is imported)
     import latentdiffeq_amd as M
+    from latentdiffeq_amd import recurrent as _rec
+    if os.environ.get("LDE_BENCH_GRAPH", "1") != "0":
+        _rec._BRANCH_STREAMS = False   # the captured step runs on one stream (a module attribute of the host code: nothing reads the environment)
     from latentdiffeq_amd.chain import decode, decode_loss, default_decoder_layers
     from latentdiffeq_amd.dist import FlatGradAllReduce
     from latentdiffeq_amd.loss import reconstruction_loss, sample, sample_with_kl, vector_kl
@@ -410,9 +411,12 @@ def run_goku_step(args, torch, dist, world, rank, local):
     from latentdiffeq_amd.train import FluxADAMW, GraphedStep
     # one GPU: the whole step is captured in a hipGraph and replayed (train.GraphedStep; needs the encoder's branch streams off — read when
     # the package was imported); LDE_BENCH_GRAPH=0 or a process group: eager
-    use_graph = os.environ.get("LDE_BENCH_GRAPH", "1") != "0" and os.environ.get("LDE_BRANCH_STREAMS") == "0"
+    use_graph = os.environ.get("LDE_BENCH_GRAPH", "1") != "0" and not _rec._BRANCH_STREAMS
     unroll = 1
-    split = use_graph and (world > 1 or os.environ.get("LDE_BENCH_FORCE_PG") == "1")   # several GPUs: graph · all-reduce (eager) · graph
+    split = use_graph and (world > 1 or os.environ.get("LDE_BENCH_FORCE_PG") == "1")
+    if os.environ.get("LDE_BENCH_FORCE_PG") == "1":
+        from latentdiffeq_amd import dist as _ldist
+        _ldist.FORCE_ALLREDUCE = True   # (a one-rank RCCL group on a one-GPU box still runs the collective)   # several GPUs: graph · all-reduce (eager) · graph
     opt = FluxADAMW(params, lr=1e-3, decay=1e-10, capturable=use_graph)   # ADAMW(η, β, decay), Flux flavour [REF model_train.jl:138, :150]; one fused update kernel
     sync = FlatGradAllReduce(params)
     torch.manual_seed(1000 + rank)
@@ -421,7 +425,7 @@ def run_goku_step(args, torch, dist, world, rank, local):
     ts = np.arange(T) * 0.05
     Bg = B * world
 
-    fused_loss = os.environ.get("LDE_FUSED_LOSS", "1") != "0"     # diagnostic: 0 = separate sample / vector_kl / reconstruction_loss and torch additions
+    fused_loss = True     # (False: separate sample / vector_kl / reconstruction_loss and torch additions — tests/test_gpu_loss.py compares the two)
     refresh = True   # one k_refresh_many launch re-packs every module's weights after the update (instead of an upload at each module's next call)
 
     def step():

@@ -241,6 +241,10 @@ int lde_get_step_record(lde_handle* h, int which, double* t_host, double* dt_hos
  *   "record_capacity"  accepted steps a step record holds per sequence (0: automatic)
  *   "step_trace"       1: lde_forward records its steps whatever the sensealg, lde_adjoint (continuous) records its reverse-time steps
  *   "adjoint_overwrite" 1: lde_adjoint WRITES dW (every entry exactly once) instead of accumulating — the caller's zero fill disappears
+ * and the kernel-choice knobs the parity tests force a kernel family / a threshold with (defaults = the measured choices; a production
+ * host never sets them): "pend_ws", "pend_tl_max_b", "pend_sh_max_b", "pend_lb", "pend_lb_min_b", "pend_lb_hold" (analytic right-hand
+ * sides: which of the five forward mappings serves a batch), "mlp64", "mlpv", "mlpw", "mlpb" (0 off, 2 also ≤ 128-wide networks), "mlp4",
+ * "mlp4_maxw", "mlp_stage_slots" (MLP right-hand sides). The library reads NO environment variable for any of this.
  * lde_get_option also answers the read-only "adjoint_family": the kernel family the last lde_adjoint ran on an MLP right-hand side
  * (0 tiles, 1 k_mlp64, 2 k_mlpb, 3 k_mlpc, 4 k_mlpw, 5 k_mlpv, 6 k_mlp4; −1 none) — what bench.py prices its roofline with.
  * Unknown key: LDE_ERR_INVALID_ARG. */
@@ -361,6 +365,10 @@ int  lde_chain_set_accumulate(lde_chain* c, int on);
  * without re-uploading anything. The solve (lde_forward / lde_adjoint) is f32 in either mode. */
 enum lde_dtype { LDE_DTYPE_F32 = 0, LDE_DTYPE_BF16 = 1 };
 int  lde_chain_set_dtype(lde_chain* c, int dtype);
+/* Kernel-choice knobs of the parity tests (a production host never sets them; the library reads no environment variable):
+ * "gx" = 0: never the panel-free layout of a wide first layer (LDE_ERR_UNSUPPORTED when it is the only one that fits);
+ * "group" = 0: this chain does not take part in merged grouped calls (its stages then run as launches of their own). */
+int  lde_chain_set_option(lde_chain* c, const char* key, double value);
 const char* lde_chain_last_error(const lde_chain* c);
 
 /* ======================================================================================================
@@ -433,6 +441,9 @@ int  lde_rnn_group_forward_ld(int n, lde_rnn* const* stacks, const float* const*
 int  lde_rnn_group_backward_ld(int n, lde_rnn* const* stacks, const float* const* xs, const float* const* dys, const float* const* dys2,
                                const int* lddys, int T, int B, float* const* dxs, float* const* dWs, void* stream);
 int  lde_rnn_set_accumulate(lde_rnn* r, int on);   /* as lde_chain_set_accumulate */
+/* Kernel-choice knobs of the parity tests: "generic" = 1 the run-time-shaped kernel for every stack, "regw" = 0 weights in LDS instead
+ * of registers, "pipe" = 0 one wave per stack instead of one per cell. Same results to round-off; the library reads no environment variable. */
+int  lde_rnn_set_option(lde_rnn* r, const char* key, double value);
 const char* lde_rnn_last_error(const lde_rnn* r);
 
 /* After an optimiser step: hand the new flat weights of MANY modules to their handles in ONE launch — what n calls of

@@ -31,7 +31,7 @@ EXPORTS = ["lde_abi_version", "lde_problem_desc_default", "lde_num_weights", "ld
            "lde_step_record_bytes", "lde_set_step_record", "lde_get_step_record", "lde_set_option", "lde_get_option",
            "lde_chain_num_weights", "lde_chain_create", "lde_chain_destroy", "lde_chain_set_weights",
            "lde_chain_set_weights_device", "lde_chain_reserve", "lde_chain_forward", "lde_chain_backward",
-           "lde_chain_last_error", "lde_chain_set_accumulate", "lde_chain_set_dtype", "lde_rnn_set_accumulate", "lde_chain_saved_floats", "lde_chain_forward_save", "lde_chain_backward_saved", "lde_chain_group_forward_save", "lde_chain_group_backward_saved", "lde_rnn_group_forward", "lde_rnn_group_backward", "lde_rnn_forward_train", "lde_rnn_group_forward_train", "lde_chain_backward_saved_sum", "lde_chain_backward_saved_mse", "lde_chain_forward_save_mse", "lde_chain_forward_save_mse_delta", "lde_chain_backward_saved_delta", "lde_chain_delta_is_staged", "lde_chain_mse_scratch_floats", "lde_randn", "lde_sample_kl_pair_forward", "lde_sample_kl_pair_backward", "lde_rnn_group_forward_ld", "lde_rnn_group_backward_ld",
+           "lde_chain_last_error", "lde_chain_set_option", "lde_rnn_set_option", "lde_chain_set_accumulate", "lde_chain_set_dtype", "lde_rnn_set_accumulate", "lde_chain_saved_floats", "lde_chain_forward_save", "lde_chain_backward_saved", "lde_chain_group_forward_save", "lde_chain_group_backward_saved", "lde_rnn_group_forward", "lde_rnn_group_backward", "lde_rnn_forward_train", "lde_rnn_group_forward_train", "lde_chain_backward_saved_sum", "lde_chain_backward_saved_mse", "lde_chain_forward_save_mse", "lde_chain_forward_save_mse_delta", "lde_chain_backward_saved_delta", "lde_chain_delta_is_staged", "lde_chain_mse_scratch_floats", "lde_randn", "lde_sample_kl_pair_forward", "lde_sample_kl_pair_backward", "lde_rnn_group_forward_ld", "lde_rnn_group_backward_ld",
            "lde_rnn_num_weights", "lde_rnn_create", "lde_rnn_destroy", "lde_rnn_set_weights", "lde_rnn_set_weights_device",
            "lde_rnn_reserve", "lde_rnn_forward", "lde_rnn_backward", "lde_rnn_last_error", "lde_rnn_backward_dx", "lde_rnn_backward_dw", "lde_refresh_weights",
            "lde_sample_forward", "lde_sample_backward", "lde_kl_forward", "lde_kl_backward", "lde_mse_forward",
@@ -144,6 +144,8 @@ def load():
     lib.lde_chain_last_error.argtypes = [vp]
     lib.lde_chain_last_error.restype = C.c_char_p
     lib.lde_chain_set_accumulate.argtypes = [vp, i32]
+    lib.lde_chain_set_option.argtypes = [vp, C.c_char_p, C.c_double]
+    lib.lde_rnn_set_option.argtypes = [vp, C.c_char_p, C.c_double]
     lib.lde_chain_set_dtype.argtypes = [vp, i32]
     lib.lde_rnn_set_accumulate.argtypes = [vp, i32]
     lib.lde_chain_saved_floats.argtypes = [vp, i64]

@@ -307,7 +307,7 @@ class _ChainGroupFn(torch.autograd.Function):
         return (None, *dxs, *dWs)
 
 
-_CHAIN_GROUP = os.environ.get("LDE_CHAIN_GROUP", "1") != "0"   # apply_latent_in / apply_latent_out: independent chains as one node (diagnostic switch)
+_CHAIN_GROUP = True   # apply_latent_in / apply_latent_out: independent chains as one node (diagnostic switch)
 
 
 def apply_chains_grouped(pairs):
@@ -441,9 +441,9 @@ def decode(decoder: Decoder, l_tilde, t):
     return x_hat, z_hat, l_hat
 
 
-_RECON_MSE_FWD = os.environ.get("LDE_RECON_MSE_FWD", "1") != "0"   # _ChainMseFn: the loss value from the reconstructor's forward launch (its squares summed
+_RECON_MSE_FWD = True   # _ChainMseFn: the loss value from the reconstructor's forward launch (its squares summed
                                                                      # per column tile in the last layer's epilogue) instead of lde_mse_forward's pass over x and x̂
-_RECON_MSE = os.environ.get("LDE_RECON_MSE", "1") != "0"   # decode_loss: the reconstructor and reconstruction_loss as one autograd node (diagnostic switch)
+_RECON_MSE = True   # decode_loss: the reconstructor and reconstruction_loss as one autograd node (diagnostic switch)
 
 
 def decode_loss(decoder: Decoder, l_tilde, t, x, batch_size=None, plus=None, want_x_hat: bool = True):

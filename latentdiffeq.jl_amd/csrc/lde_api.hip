@@ -22,7 +22,7 @@
 namespace lde {
 int launch_pend_forward(int kind, int solver, const float* z0, const float* theta, const double* ts_dev, const KOpts& o,
                         float* z_out, int32_t* retcode, int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret,
-                        hipStream_t stream);
+                        hipStream_t stream, const PendTune& tn);
 int launch_pend_adjoint(int kind, int solver, const float* z_out, const float* theta, const double* ts_dev,
                         const KOpts& o, const float* dz_out, float* dz0, float* dtheta, int32_t* nfe, int32_t* nacc,
                         int32_t* nrej, int32_t* ret, hipStream_t stream);
@@ -40,6 +40,7 @@ int mlp_reserve(MlpPlan* p, int B, int T, std::string& err);
 int mlp_set_sum_hook(MlpPlan* p, lde_sum_hook hook, void* user, int64_t global_batch, std::string& err);
 int mlp_set_phase_timing(MlpPlan* p, int on);
 int mlp_last_family(const MlpPlan* p);
+MlpTune* mlp_tune(MlpPlan* p);
 int mlp_get_phase_ms(MlpPlan* p, float* out);
 int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::string& err);
 int mlp_set_weights(MlpPlan* p, const float* W_dev, hipStream_t stream, std::string& err);
@@ -87,6 +88,7 @@ struct lde_handle {
   int opt_record_capacity = 0;       // 0: automatic
   int opt_step_trace = 0;
   int opt_adjoint_overwrite = 0;
+  lde::PendTune pend_tune;           // kernel-choice knobs of the analytic right-hand sides (MLP ones live in the plan)
   std::string err = "";
 };
 
@@ -465,7 +467,7 @@ int lde_forward(lde_handle* h, const float* z0, const float* theta, const double
   if (h->mlp)
     return lde::mlp_forward(h->mlp, h->W_dev, z0, theta, h->ts_dev, o, z_out, retcode, st[0], st[1], st[2], st[3], stream, h->err);
   rc = lde::launch_pend_forward(h->d.rhs_kind, h->d.solver, z0, theta, h->ts_dev, o, z_out, retcode, st[0], st[1], st[2],
-                                st[3], stream);
+                                st[3], stream, h->pend_tune);
   if (rc) h->err = "lde_forward: kernel launch failed";
   return rc;
 }
@@ -629,12 +631,30 @@ static int* option_slot(lde_handle* h, const char* key) {
   if (!std::strcmp(key, "record_capacity")) return &h->opt_record_capacity;
   if (!std::strcmp(key, "step_trace")) return &h->opt_step_trace;
   if (!std::strcmp(key, "adjoint_overwrite")) return &h->opt_adjoint_overwrite;
+  // kernel-choice knobs (include/lde.h): what the tests force a family / a threshold with
+  lde::PendTune& pt = h->pend_tune;
+  if (!std::strcmp(key, "pend_ws")) return &pt.ws;
+  if (!std::strcmp(key, "pend_tl_max_b")) return &pt.tl_max_b;
+  if (!std::strcmp(key, "pend_sh_max_b")) return &pt.sh_max_b;
+  if (!std::strcmp(key, "pend_lb")) return &pt.lb_ring;
+  if (!std::strcmp(key, "pend_lb_min_b")) return &pt.lb_min_b;
+  if (!std::strcmp(key, "pend_lb_hold")) return &pt.lb_hold;
+  if (h->mlp) {
+    lde::MlpTune& mt = *lde::mlp_tune(h->mlp);
+    if (!std::strcmp(key, "mlp64")) return &mt.mlp64;
+    if (!std::strcmp(key, "mlpv")) return &mt.mlpv;
+    if (!std::strcmp(key, "mlpw")) return &mt.mlpw;
+    if (!std::strcmp(key, "mlpb")) return &mt.mlpb;
+    if (!std::strcmp(key, "mlp4")) return &mt.mlp4;
+    if (!std::strcmp(key, "mlp4_maxw")) return &mt.mlp4_maxw;
+    if (!std::strcmp(key, "mlp_stage_slots")) return &mt.stage_slots;
+  }
   return nullptr;
 }
 int lde_set_option(lde_handle* h, const char* key, double value) {
   if (!h || !key) return LDE_ERR_INVALID_ARG;
   int* slot = option_slot(h, key);
-  if (!slot || !(value >= 0) || value > 2e9) {
+  if (!slot || !(value >= (std::strcmp(key, "pend_lb_hold") ? 0 : -1)) || value > 2e9) {
     h->err = std::string("lde_set_option: unknown key or value out of range: ") + key;
     return LDE_ERR_INVALID_ARG;
   }

@@ -676,6 +676,7 @@ struct lde_chain {
   size_t lds_fwd = 0, lds_bwd = 0;
   ChainDims cdx;               // the panel-free layout for wide inputs (gx), when applicable
   int cgx_fwd = 0, cgx_bwd = 0;
+  int opt_group = 1;        // lde_chain_set_option "group": this chain may take part in a merged (one launch per stage) grouped call
   size_t ldsx_fwd = 0, ldsx_bwd = 0;
   // backward workspace
   float* stage = nullptr; size_t stage_cap = 0;
@@ -810,8 +811,7 @@ int lde_chain_create(const lde_chain_desc* d, lde_chain** out) {
   pick(cd, &c->cg_fwd, &c->lds_fwd, &c->cg_bwd, &c->lds_bwd);
   // wide inputs (an image encoder's first layer): x itself is the B operand of layer 0, no input panel
   c->cdx = cd;
-  const char* eg = getenv("LDE_CHAIN_GX");
-  if (dm.sizes[0] % 16 == 0 && dm.sizes[0] >= 128 && !cd.skip[0] && !(eg && atoi(eg) == 0)) {
+  if (dm.sizes[0] % 16 == 0 && dm.sizes[0] >= 128 && !cd.skip[0]) {   // (lde_chain_set_option "gx" = 0 takes the layout away again: tests)
     c->cdx.gx = 1;
     c->cdx.ld0 = 0;
     pick(c->cdx, &c->cgx_fwd, &c->ldsx_fwd, &c->cgx_bwd, &c->ldsx_bwd);
@@ -1764,12 +1764,13 @@ int lde_chain_backward_saved_delta(lde_chain* c, const float* x, const float* g_
 }
 
 // ---- grouped calls: n independent chains, each stage of the call ONE launch when the chains ask for the same small-tile kernel ----------
-static bool group_ok(int n) {
+static bool group_ok(int n, lde_chain* const* cs) {
 #if LDE_PROF
   return false;
 #else
-  static const bool on = [] { const char* e = getenv("LDE_CHAIN_GROUP"); return !e || atoi(e) != 0; }();
-  return on && n >= 2 && n <= GROUP_MAX && dw_stream_get() == nullptr;
+  for (int i = 0; i < n; i++)
+    if (!cs[i] || !cs[i]->opt_group) return false;   // (lde_chain_set_option "group" = 0: the chains of the call run one after the other)
+  return n >= 2 && n <= GROUP_MAX && dw_stream_get() == nullptr;
 #endif
 }
 static bool group_distinct(int n, lde_chain* const* cs) {   // a handle's workspace serves one call at a time: the same chain twice runs one after the other
@@ -1783,7 +1784,7 @@ int lde_chain_group_forward_save(int n, lde_chain* const* cs, const float* const
   if (n < 1 || !cs || !xs || !Ns || !ys) return LDE_ERR_INVALID_ARG;
   for (int i = 0; i < n; i++)
     if (!cs[i]) return LDE_ERR_INVALID_ARG;
-  if (!group_ok(n) || !group_distinct(n, cs)) {
+  if (!group_ok(n, cs) || !group_distinct(n, cs)) {
     for (int i = 0; i < n; i++) {
       const int rc = chain_forward_impl(cs[i], xs[i], Ns[i], ys[i], saveds ? saveds[i] : nullptr, stream);
       if (rc) return rc;
@@ -1806,7 +1807,7 @@ int lde_chain_group_forward_save(int n, lde_chain* const* cs, const float* const
 int lde_chain_group_backward_saved(int n, lde_chain* const* cs, const float* const* xs, const float* const* ys, const float* const* dys,
                                    const float* const* saveds, const int64_t* Ns, float* const* dxs, float* const* dWs, void* stream) {
   if (n < 1 || !cs || !xs || !ys || !dys || !Ns || !dWs) return LDE_ERR_INVALID_ARG;
-  bool grp = group_ok(n);
+  bool grp = group_ok(n, cs);
   for (int i = 0; i < n; i++) {
     if (!cs[i]) return LDE_ERR_INVALID_ARG;
     if (cs[i]->bf16 && !(saveds && saveds[i])) grp = false;   // (a bf16 pullback without saved activations starts with a forward launch of its own)
@@ -1837,6 +1838,26 @@ int lde_chain_set_accumulate(lde_chain* c, int on) {
   if (!c) return LDE_ERR_INVALID_ARG;
   c->accumulate = on != 0;
   return LDE_OK;
+}
+
+int lde_chain_set_option(lde_chain* c, const char* key, double value) {
+  if (!c || !key) return LDE_ERR_INVALID_ARG;
+  if (!std::strcmp(key, "group")) {
+    c->opt_group = value != 0;
+    return LDE_OK;
+  }
+  if (!std::strcmp(key, "gx")) {   // 0: never the panel-free layout of a wide first layer (the two layouts are each other's parity reference)
+    if (value != 0) return LDE_OK;
+    if (!c->cg_fwd || !c->cg_bwd) {
+      c->err = "lde_chain_set_option(gx = 0): only the panel-free layout fits this chain";
+      return LDE_ERR_UNSUPPORTED;
+    }
+    c->cdx.gx = 0;
+    c->cgx_fwd = c->cgx_bwd = c->bcgx_fwd = c->bcgx_bwd = 0;
+    return LDE_OK;
+  }
+  c->err = std::string("lde_chain_set_option: unknown key: ") + key;
+  return LDE_ERR_INVALID_ARG;
 }
 
 const char* lde_chain_last_error(const lde_chain* c) { return c ? c->err.c_str() : "null handle"; }

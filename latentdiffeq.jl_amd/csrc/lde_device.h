@@ -26,6 +26,23 @@ struct StepRec {
   int cap, nseq;
 };
 
+// Kernel-choice knobs of a handle (lde_set_option; tests force a family / a threshold through them — formerly LDE_* environment variables,
+// which a library behind a `ccall` host must not read). Defaults = the measured choices.
+struct PendTune {
+  int ws = 1;                 // "pend_ws": k_pend_forward_ws for B ≤ 16384
+  int tl_max_b = 1024;        // "pend_tl_max_b": k_pend_forward_tl up to this batch
+  int sh_max_b = 256;         // "pend_sh_max_b": k_pend_forward_sh up to this batch
+  int lb_ring = 16;           // "pend_lb": rows of the large-batch row ring (8 / 16 / 32; 0: off)
+  int lb_min_b = 1 << 17;     // "pend_lb_min_b": the large-batch form from this batch on
+  int lb_hold = -1;           // "pend_lb_hold": its hold margin (−1: half the ring)
+};
+struct MlpTune {
+  int mlp64 = 1, mlpv = 1, mlpw = 1, mlp4 = 1;   // "mlp64", "mlpv", "mlpw", "mlp4": 0 switches the family off
+  int mlpb = 1;               // "mlpb": 0 off (k_mlpw instead: the parity reference), 2 also the networks of ≤ 128 units
+  int mlp4_maxw = 64;         // "mlp4_maxw": widest layer k_mlp4_adjoint takes
+  int stage_slots = 0;        // "mlp_stage_slots": staging slots per workgroup (0: automatic)
+};
+
 // Options handed to every kernel by value (mirrors the `kwargs...` splat into solve()).
 struct KOpts {
   float abstol, reltol;

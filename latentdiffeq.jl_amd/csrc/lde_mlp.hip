@@ -1417,12 +1417,13 @@ struct MlpPlan {
   bool phase_on = false;
   hipEvent_t ph_ev[3] = {nullptr, nullptr, nullptr};
   bool disc = false;           // LDE_SENSE_DISCRETE: lde_adjoint sweeps the forward solve's step record (lde_mlpd.h)
+  MlpTune tune;                // kernel-family switches and thresholds (lde_set_option)
   int last_family = -1;        // the kernel family of the last lde_adjoint: 0 tiles (gW in the tail: k_mlp_dw), 1 k_mlp64, 2 k_mlpb, 3 k_mlpc (gW folded
                                // in the solve kernel), 4 k_mlpw, 5 k_mlpv, 6 k_mlp4 (staged, tail)
 };
 
 void mlp_plan_destroy(MlpPlan* p);
-static bool mlp64_applicable(const MlpDims& dm, int B);
+static bool mlp64_applicable(const MlpPlan* p, int B);
 static int mlp64_adj_waves(int B);
 static bool b_applicable(const MlpPlan* p, int B, int T, bool adj, bool coupled_adaptive);
 static bool c_applicable(const MlpPlan* p, int B, int T, bool adj, bool coupled_adaptive);
@@ -1673,10 +1674,10 @@ int mlp_reserve(MlpPlan* p, int B, int T, std::string& err) {
 // (fixed step size). Staging slots per workgroup: stages × (3 step attempts per save interval + 32) — doubled whenever
 // the previous call reported an overflow — bounded by a memory budget
 // (24 GiB of the 288); a workgroup that needs more folds its slots into its private slab
-// (slow but correct). LDE_MLP_STAGE_SLOTS forces the slot count (tests).
+// (slow but correct). option "mlp_stage_slots" forces the slot count (tests).
 int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::string& err) {
   const MlpDims& dm = p->dm;
-  if (mlp64_applicable(dm, B)) {   // no staging area: a slab row per wave is the kernel's only workspace (continuous and discrete adjoint alike)
+  if (mlp64_applicable(p, B)) {   // no staging area: a slab row per wave is the kernel's only workspace (continuous and discrete adjoint alike)
     p->rows_stride = (dm.nW + 63) & ~63;
     if (!grow(&p->rows, &p->rows_cap, (size_t)mlp64_adj_waves(B) * p->rows_stride)) {
       err = "MLP plan: hipMalloc of the weight-gradient rows failed";
@@ -1697,8 +1698,7 @@ int mlp_reserve_adjoint(MlpPlan* p, int B, int T, int64_t steps_hint, std::strin
   const int nwg = cdiv(B, NB);
   const int nst = dm.solver == LDE_SOLVER_RK4 ? 4 : 6;
   constexpr long budget_mb = 24576L;
-  const char* sf = getenv("LDE_MLP_STAGE_SLOTS");   // read on every call: the tests switch it inside one process
-  const int slots_force = sf ? atoi(sf) : 0;
+  const int slots_force = p->tune.stage_slots;
   if (p->fb_pending) {
     if (hipEventQuery(p->fb_ev) == hipSuccess) {
       p->fb_pending = false;
@@ -1825,9 +1825,9 @@ static int launch_maybe_coop(bool coop, const void* fn, dim3 grid, dim3 block, s
 }
 
 // ---- one wave per trajectory, everything in registers (lde_mlp64.h): small networks on small states, per-trajectory control
-static bool mlp64_applicable(const MlpDims& dm, int B) {
-  const char* e = getenv("LDE_MLP64");   // read per call: the tests switch kernels inside one process
-  if (e && atoi(e) == 0) return false;
+static bool mlp64_applicable(const MlpPlan* p, int B) {
+  const MlpDims& dm = p->dm;
+  if (!p->tune.mlp64) return false;
   const int maxb = 65536;   // measured (c3 shape): 0.28 + 3.9 ms vs 0.61 + 5.8 for the tile kernels at B = 4096, 0.77 + 10.4 vs 2.2 + 12.0 at 16384
   return dm.nL == 3 && dm.sizes[1] <= 64 && dm.sizes[2] <= 64 && dm.Dp <= 4 && dm.P <= 1 && !dm.coupled && B <= maxb;
 }
@@ -1887,10 +1887,9 @@ static size_t vec_lds_fixed(const MlpDims& dm, const VecDims& vd, int T, bool ad
   b += (size_t)(11 * nsp + vd.htotal + MAXL * vd.maxw4 + vd.NT + ((dm.nbias + 3) & ~3) + 2 * MAXL * (sizeof(VLayer) / 4)) * sizeof(float);
   return (b + 15) & ~size_t(15);
 }
-// Which batches run there: see the measurement below. LDE_MLPV=0 switches the kernels off.
+// Which batches run there: see the measurement below. Option "mlpv" = 0 switches the kernels off.
 static bool vec_applicable(const MlpPlan* p, int B, int T, bool adj, bool coupled_adaptive, size_t* lds, std::string& why) {
-  const char* e = getenv("LDE_MLPV");   // read per call: the tests switch kernels inside one process
-  if (!p->vec_ok || (e && atoi(e) == 0)) return false;
+  if (!p->vec_ok || !p->tune.mlpv) return false;
   // measured (MI355X, c2 / c3 / c4 shapes, abl/ + profiles/): the one-trajectory workgroups win while the chip has a SIMD per
   // wave (B·NT/64 ≤ 1024: c2 0.88 + 1.97 ms vs 1.77 + 3.44 at B = 256, c3 0.36 + 4.28 vs 0.63 + 5.0 at 1024, c4 0.46 + 3.77 vs
   // 0.45 + 4.3 at 512) and lose beyond (c2 at B = 1024: 1.94 + 4.5 vs 1.78 + 3.9) — the tiles then have enough columns
@@ -1946,8 +1945,7 @@ static size_t w_lds_base(const WDims& wd, int T, bool adj) {   // save times, st
   return (((size_t)T * 8 + 15) & ~size_t(15)) + (size_t)(wd.W * 64 + 2 * wd.HX) * 4 + (size_t)wd.GS * 64 * 16 * (adj ? 2 : 1) + 16;
 }
 static bool w_applicable(const MlpPlan* p, int B, int T, bool adj, bool coupled_adaptive) {
-  const char* e = getenv("LDE_MLPW");   // read per call: the tests switch kernels inside one process
-  if (!p->w_ok || (e && atoi(e) == 0)) return false;
+  if (!p->w_ok || !p->tune.mlpw) return false;
   if (w_lds_base(p->wd, T, adj) > LDS_MAX * p->wd.W / 4) return false;   // 4/W workgroups share a CU's LDS (one wave per SIMD)
   // one wave per SIMD (the weights take most of the 512 registers): 1024 waves are resident at once; an uncoupled solve may
   // queue a second round, a coupled one needs every trajectory resident
@@ -2036,12 +2034,10 @@ static size_t b_lds_base(const BDims& bd, int T, bool adj, int nst) {   // save 
          (size_t)bd.GS * 64 * 16 * (adj ? 2 : 1) + (size_t)mlpb::HV * (2 * bd.DP + 4) * 4 + 16 + ((adj && bd.DP == 16) ? 2 * mlpb::W * 16 * 4 : 0);
 }
 static bool b_applicable(const MlpPlan* p, int B, int T, bool adj, bool coupled_adaptive) {
-  // LDE_MLPB (read per call: the tests switch kernels inside one process): 0 = off (k_mlpw: the parity reference of this kernel),
-  // 2 = also the networks of at most 128 units that k_mlpw's two-wave form serves by default
-  const char* e = getenv("LDE_MLPB");
-  const int mode = e ? atoi(e) : 1;
-  const char* ew = getenv("LDE_MLPW");   // (LDE_MLPW=0 switches BOTH register families off: the tests' "tiles" / "k_mlpv" legs)
-  if (!p->b_ok || mode == 0 || (ew && atoi(ew) == 0)) return false;
+  // option "mlpb": 0 = off (k_mlpw: the parity reference of this kernel), 2 = also the networks of at most 128 units that k_mlpw's
+  // two-wave form serves by default; "mlpw" = 0 switches BOTH register families off (the tests' "tiles" / "k_mlpv" legs)
+  const int mode = p->tune.mlpb;
+  if (!p->b_ok || mode == 0 || !p->tune.mlpw) return false;
   const int hm = std::max(p->dm.sizes[1], p->dm.sizes[2]);
   if (hm <= 128 && mode != 2) return false;
   if (b_lds_base(p->bd, T, adj, p->dm.solver == LDE_SOLVER_RK4 ? 4 : 6) > LDS_MAX) return false;
@@ -2099,9 +2095,7 @@ static size_t c_lds_base(int T, bool adj, int nst) {
          (size_t)128 * mlpc::W13S * 4 + (adj ? (size_t)mlpc::GS * 64 * 16 + 4 * mlpc::DP * 2 * 4 : 0) + 16;
 }
 static bool c_applicable(const MlpPlan* p, int B, int T, bool adj, bool coupled_adaptive) {
-  const char* e = getenv("LDE_MLPB");    // (the switches of k_mlpb: 0 = k_mlpw instead — the parity reference)
-  const char* ew = getenv("LDE_MLPW");
-  if (!p->c_ok || (e && atoi(e) == 0) || (ew && atoi(ew) == 0)) return false;
+  if (!p->c_ok || p->tune.mlpb == 0 || !p->tune.mlpw) return false;   // (the switches of k_mlpb: 0 = k_mlpw instead — the parity reference)
   if (c_lds_base(T, adj, p->dm.solver == LDE_SOLVER_RK4 ? 4 : 6) > LDS_MAX) return false;
   // one workgroup (two trajectories) per CU: 512 trajectories are resident at once, which a coupled adaptive solve needs
   return B <= (coupled_adaptive ? 512 : 1024);
@@ -2111,7 +2105,7 @@ static bool c_applicable(const MlpPlan* p, int B, int T, bool adj, bool coupled_
 // costs in memory; everything else runs on the tiles (lde_mlpd.h).
 static int disc_family(const MlpPlan* p, int B, int T) {
   const MlpDims& dm = p->dm;
-  if (mlp64_applicable(dm, B)) return DISC_64;
+  if (mlp64_applicable(p, B)) return DISC_64;
   const int nst = dm.solver == LDE_SOLVER_RK4 ? 4 : 6;
   if (b_applicable(p, std::min(B, 256), T, true, false) && B <= 1024 && b_lds_base(p->bd, T, true, nst) + (size_t)T * dm.Dp * 4 <= LDS_MAX) return DISC_B;
   if (c_applicable(p, std::min(B, 512), T, true, false) && B <= 2048) return DISC_C;
@@ -2162,6 +2156,7 @@ static int launch_c(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t
 }
 
 int mlp_last_family(const MlpPlan* p) { return p->last_family; }
+MlpTune* mlp_tune(MlpPlan* p) { return &p->tune; }
 
 int mlp_set_phase_timing(MlpPlan* p, int on) {
   if (on && !p->ph_ev[0])
@@ -2303,7 +2298,7 @@ int mlp_forward(MlpPlan* p, const float* W_dev, const float* z0, const float* th
                 hipStream_t stream, std::string& err) {
   const MlpDims& dm = p->dm;
   const bool recording = o.rec.n != nullptr;   // the step record is written by k_mlp64 and by k_mlp_forward (the tiles)
-  if (mlp64_applicable(dm, o.B)) {   // small network, small state: one wave per trajectory, registers only (lde_mlp64.h)
+  if (mlp64_applicable(p, o.B)) {   // small network, small state: one wave per trajectory, registers only (lde_mlp64.h)
     VArgs va{};
     va.z0 = z0; va.theta = theta; va.ts = ts_dev; va.Wflat = W_dev; va.z_out = z_out; va.retcode = retcode;
     va.st_nfe = nfe; va.st_nacc = nacc; va.st_nrej = nrej; va.st_ret = ret;
@@ -2407,16 +2402,14 @@ static int launch_adjoint(MlpPlan* p, const KOpts& o, const BwdArgs& a, int nwg,
 }
 
 // ---- the 4-columns-per-wave adjoint (lde_mlp4.h): applicability, LDS layout, launch --------------------------------
-static bool mlp4_layout(const MlpDims& dm, int T, int B, bool coupled_adaptive, Mlp4Dims* md, size_t* lds, int* nblocks) {
-  const char* e4 = getenv("LDE_MLP4");   // read per call: the tests switch kernels inside one process
-  if ((e4 && atoi(e4) == 0) || dm.Dp > 64 || dm.P > 1) return false;
+static bool mlp4_layout(const MlpTune& tune, const MlpDims& dm, int T, int B, bool coupled_adaptive, Mlp4Dims* md, size_t* lds, int* nblocks) {
+  if (!tune.mlp4 || dm.Dp > 64 || dm.P > 1) return false;
   int maxw = 0;
   for (int l = 0; l <= dm.nL; l++) maxw = std::max(maxw, dm.sizes[l]);
   // measured (MI355X): one wave has ONE SIMD's matrix pipe and v_mfma_f32_4x4x1 costs 11 cycles per 256 MACs (the
   // 16x16x4 form: 8), so the 4-column kernel only wins while the layers are small enough for the 16-column kernel's
   // fixed ≈ 2 000 cycles per layer to dominate: config 3 (64 wide) 7.3 → 5.3 ms, config 4 (128 wide) 4.4 → 5.5 ms.
-  const char* ew = getenv("LDE_MLP4_MAXW");
-  const int maxw_lim = ew ? atoi(ew) : 64;
+  const int maxw_lim = tune.mlp4_maxw;
   if (maxw > maxw_lim || maxw > 256) return false;
   int off = 0;
   for (int l = 0; l < dm.nL; l++) {
@@ -2556,9 +2549,9 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
                 const KOpts& o, const float* dz_out, float* dz0, float* dtheta, float* dW, int32_t* nfe, int32_t* nacc,
                 int32_t* nrej, int32_t* ret, hipStream_t stream, std::string& err) {
   const MlpDims& dm = p->dm;
-  if (p->disc && !mlp64_applicable(dm, o.B))
+  if (p->disc && !mlp64_applicable(p, o.B))
     return mlp_adjoint_disc(p, W_dev, z_out, theta, ts_dev, o, dz_out, dz0, dtheta, dW, nfe, nacc, nrej, ret, stream, err);
-  if (mlp64_applicable(dm, o.B)) {   // one wave per trajectory, registers only, the weight gradient included (lde_mlp64.h): two launches
+  if (mlp64_applicable(p, o.B)) {   // one wave per trajectory, registers only, the weight gradient included (lde_mlp64.h): two launches
     p->last_family = 1;
     const int waves = mlp64_adj_waves(o.B);
     if (!p->rows || p->rows_cap < (size_t)waves * p->rows_stride || p->rows_stride < dm.nW) {
@@ -2710,7 +2703,7 @@ int mlp_adjoint(MlpPlan* p, const float* W_dev, const float* z_out, const float*
     Mlp4Dims md;
     size_t lds4 = 0;
     int nblocks = 0;
-    if (mlp4_layout(dm, o.T, o.B, dm.coupled && o.adaptive, &md, &lds4, &nblocks)) {
+    if (mlp4_layout(p->tune, dm, o.T, o.B, dm.coupled && o.adaptive, &md, &lds4, &nblocks)) {
       const bool sync4 = dm.coupled && o.adaptive && nblocks > 1;
       p->last_family = 6;
       const int ntile4 = cdiv(nblocks * md.wpb, 4);   // ≤ nwg + 1: the workspace is sized for that

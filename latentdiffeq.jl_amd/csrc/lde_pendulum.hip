@@ -1668,16 +1668,16 @@ static inline int pick_block(int B) { return B <= 4096 ? 64 : 256; }
 
 int launch_pend_forward(int kind, int solver, const float* z0, const float* theta, const double* ts_dev, const KOpts& o,
                         float* z_out, int32_t* retcode, int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret,
-                        hipStream_t stream) {
+                        hipStream_t stream, const PendTune& tn) {
   const int block = pick_block(o.B), grid = (o.B + block - 1) / block;
   const size_t shm = o.T <= TS_LDS_MAX ? (size_t)o.T * sizeof(double) : 0;
   // small batches: stepping and dense output on different waves of a 64-trajectory workgroup (k_pend_forward_ws)
-  static const bool ws_on = [] { const char* e = getenv("LDE_PEND_WS"); return !e || atoi(e) != 0; }();
+  const bool ws_on = tn.ws != 0;
   constexpr int ws_max_b = 16384;   // measured (abl/pend_B.py): 21.6 vs 31.2 µs at 16384, 36.8 vs 32.6 µs at 32768
   // the smallest batches: lanes = save times, TPW trajectories per wave (k_pend_forward_tl)
-  static const int tl_max_b = [] { const char* e = getenv("LDE_PEND_TL_MAX_B"); return e ? atoi(e) : 1024; }();
+  const int tl_max_b = tn.tl_max_b;
   // one trajectory per workgroup, a stepping wave + three dense-output waves (k_pend_forward_sh): while every workgroup has a CU to itself
-  static const int sh_max_b = [] { const char* e = getenv("LDE_PEND_SH_MAX_B"); return e ? atoi(e) : 256; }();
+  const int sh_max_b = tn.sh_max_b;
   if (o.T > 1 && o.B <= sh_max_b) {
     const bool ad = o.adaptive != 0;
     const int g8 = ((o.B + 7) / 8) * 8;
@@ -1743,19 +1743,19 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
 #undef LDE_LAUNCH_WS
     return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
   }
-  // large batches (B ≥ 2¹⁷ — LDE_PEND_LB_MIN_B; T ≤ 2048): the lanes-as-save-times kernel with 64 trajectories per wave, the row ring
+  // large batches (B ≥ 2¹⁷ — option "pend_lb_min_b"; T ≤ 2048): the lanes-as-save-times kernel with 64 trajectories per wave, the row ring
   // and the save grid in LDS (k_pend_forward_tl<…, 64, false, RING>). k_pend_forward's per-lane stores reach HBM as partial lines —
   // 1128 MB written for 419 MB of ẑ at B = 2²⁰ — and the launch is bound by that traffic: 303 µs. With 16 ring rows and an 8-row hold
   // 444 … 574 MB are written and the launch takes 206 µs (2.1 TB/s of ẑ; abl/pend_LB.py, abl/pend_LB_pmc.sh); 8 rows / 3 the same within the
   // run-to-run spread, 32 rows leave 2.5 waves per SIMD (16 KB of LDS per wave) and take 258 µs. What remains is instruction issue:
   // ≈ 8.2 k instructions per wave (5.1 k VALU), of which the wave-sequential dense-output loop is ≈ 75 × 45 and the row flush 49 × 28.
-  // LDE_PEND_LB = rows of the ring (8 / 16 / 32; 0: off), LDE_PEND_LB_HOLD = the hold margin.
-  static const int lb_ring = [] { const char* e = getenv("LDE_PEND_LB"); return e ? atoi(e) : 16; }();   // rows of the ring; 0: off
-  static const int lb_min_b = [] { const char* e = getenv("LDE_PEND_LB_MIN_B"); return e ? atoi(e) : (1 << 17); }();
+  // options "pend_lb" = rows of the ring (8 / 16 / 32; 0: off), "pend_lb_hold" = the hold margin.
+  const int lb_ring = tn.lb_ring;   // rows of the ring; 0: off
+  const int lb_min_b = tn.lb_min_b;
   if (!recording && lb_ring > 0 && o.T > 1 && o.T <= 2048 && o.B >= lb_min_b) {   // (the save grid in LDS beside the ring: T ≤ 2048)
     // a lane sits out while j ≥ jc + RING − hold; the slowest lane has j = jc, so hold ≤ RING − 1 keeps it (and with it jc) moving —
     // hold ≥ RING would hold EVERY lane on every iteration and the solve loop would never end. Default: half the ring.
-    static const int lb_hold_env = [] { const char* e = getenv("LDE_PEND_LB_HOLD"); return e ? atoi(e) : -1; }();
+    const int lb_hold_env = tn.lb_hold;
     const int ring_rows = lb_ring >= 32 ? 32 : (lb_ring >= 16 ? 16 : 8);
     KOpts oh = o;
     oh.lb_hold = std::max(0, std::min(lb_hold_env >= 0 ? lb_hold_env : ring_rows / 2, ring_rows - 1));

@@ -861,6 +861,7 @@ struct lde_rnn {
   float* slab = nullptr; size_t slab_cap = 0; size_t slab_layer = 0;
   int32_t* ints = nullptr; size_t ints_cap = 0;
   bool accumulate = true;   // pullback: dW += gradient (default) or dW = gradient
+  int opt_generic = 0, opt_regw = 1, opt_pipe = 1;   // lde_rnn_set_option: "generic", "regw", "pipe" (kernel-choice knobs of the parity tests)
   void (*kernel[4][3])(lde::RnnDims, lde::RnnArgs) = {};   // the k_rnn instantiations for this stack: [mode][any workgroup size, one wave per workgroup, one wave per cell]
   int io_ldy = 0, io_lddy = 0;       // set around a call by the *_ld group entry points (0: rows are hL apart)
   const float* io_dy2 = nullptr;
@@ -1068,8 +1069,7 @@ int lde_rnn_reserve(lde_rnn* r, int B, int T) {
 
 // the instantiation for this stack: the reference's default pattern extractors (32 → 16 → 16) have their own, any other shape
 // runs the run-time-shaped kernel
-static rnn_kernel_t rnn_pick(const RnnDims& rd, int mode, bool one_wave = false) {
-  static const bool generic_only = std::getenv("LDE_RNN_GENERIC") && std::atoi(std::getenv("LDE_RNN_GENERIC")) != 0;
+static rnn_kernel_t rnn_pick(const RnnDims& rd, int mode, bool one_wave = false, bool generic_only = false) {
   if (!generic_only && rd.wt && rd.nL == 2 && rd.sizes[0] == 32 && rd.sizes[1] == 16 && rd.sizes[2] == 16) {
     if (one_wave) {
       if (rd.cell == LDE_CELL_LSTM) return rnn_pick_mode<LDE_CELL_LSTM, true>(mode);
@@ -1109,21 +1109,19 @@ static int rnn_launch(lde_rnn* r, const RnnArgs& a, int B, hipStream_t stream) {
   // behind one LDS copy of the weights.
   int tpw = std::max(1, 64 / r->rd.Hp);
   while (tpw < 16 && cdiv(B, tpw) > 1024) tpw *= 2;
-  const char* erw = std::getenv("LDE_RNN_REGW");   // read per call: the tests compare the two instantiations inside one process
-  const bool one_wave = tpw * r->rd.Hp == 64 && !(erw && std::atoi(erw) == 0);   // one wave per workgroup: the register-resident-weights instantiation
-  // … and, for the default shape, one wave per CELL (rnn_body2): LDE_RNN_PIPE=0 keeps the single wave
-  const char* epipe = std::getenv("LDE_RNN_PIPE");
+  const bool one_wave = tpw * r->rd.Hp == 64 && r->opt_regw != 0;   // one wave per workgroup: the register-resident-weights instantiation (option "regw")
+  // … and, for the default shape, one wave per CELL (rnn_body2): option "pipe" = 0 keeps the single wave
   const RnnDims& rd0 = r->rd;
   const bool def_shape = rd0.wt && rd0.nL == 2 && rd0.sizes[0] == 32 && rd0.sizes[1] == 16 && rd0.sizes[2] == 16;
-  static const bool generic_only = std::getenv("LDE_RNN_GENERIC") && std::atoi(std::getenv("LDE_RNN_GENERIC")) != 0;
-  const bool pipe = one_wave && def_shape && !generic_only && !LDE_PROF && !(epipe && std::atoi(epipe) == 0);
+  const bool generic_only = r->opt_generic != 0;
+  const bool pipe = one_wave && def_shape && !generic_only && !LDE_PROF && r->opt_pipe != 0;
   const int one = pipe ? 2 : (one_wave ? 1 : 0);
   if (!r->kernel[m][one]) {
     if (pipe)
       r->kernel[m][one] = rd0.cell == LDE_CELL_LSTM ? rnn_pick_pipe<LDE_CELL_LSTM>(m)
                           : rd0.cell == LDE_CELL_RNN_RELU ? rnn_pick_pipe<LDE_CELL_RNN_RELU>(m) : rnn_pick_pipe<LDE_CELL_RNN_TANH>(m);
     else
-      r->kernel[m][one] = rnn_pick(r->rd, m, one != 0);
+      r->kernel[m][one] = rnn_pick(r->rd, m, one != 0, generic_only);
     if (hipFuncSetAttribute((const void*)r->kernel[m][one], hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS_MAX) != hipSuccess) {
       r->kernel[m][one] = nullptr;
       r->err = "hipFuncSetAttribute(k_rnn) failed";
@@ -1539,6 +1537,19 @@ int lde_rnn_group_backward_ld(int n, lde_rnn* const* rs, const float* const* xs,
 int lde_rnn_set_accumulate(lde_rnn* r, int on) {
   if (!r) return LDE_ERR_INVALID_ARG;
   r->accumulate = on != 0;
+  return LDE_OK;
+}
+
+int lde_rnn_set_option(lde_rnn* r, const char* key, double value) {
+  if (!r || !key) return LDE_ERR_INVALID_ARG;
+  int* slot = !std::strcmp(key, "generic") ? &r->opt_generic : !std::strcmp(key, "regw") ? &r->opt_regw : !std::strcmp(key, "pipe") ? &r->opt_pipe : nullptr;
+  if (!slot || !(value >= 0)) {
+    r->err = std::string("lde_rnn_set_option: unknown key or negative value: ") + key;
+    return LDE_ERR_INVALID_ARG;
+  }
+  *slot = (int)value;
+  for (auto& km : r->kernel)      // the instantiations are cached per (mode, form): picked afresh under the new options
+    for (auto& k : km) k = nullptr;
   return LDE_OK;
 }
 

@@ -55,6 +55,8 @@ def shard_columns(x: Optional[torch.Tensor], rank: int, world: int, dim: int = -
     return x.narrow(dim, lo, hi - lo)
 
 
+FORCE_ALLREDUCE = False   # diagnostic: run the collective on a one-rank group too (tests set the attribute; nothing here reads the environment)
+
 class FlatGradAllReduce:
     """Data-parallel gradient sum over the parameters of a model: ONE persistent flat f32 buffer, the parameters' `.grad`
     fields are VIEWS into it (`attach()`), so a step packs and unpacks nothing — the collective runs on the buffer the
@@ -86,8 +88,8 @@ class FlatGradAllReduce:
 
     # ---- layout -------------------------------------------------------------------------------------------------------
     def _active(self) -> bool:
-        # (LDE_FORCE_ALLREDUCE=1: also with ONE rank — a one-GPU box then exercises the pack / all-reduce / unpack path over RCCL)
-        return dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or os.environ.get("LDE_FORCE_ALLREDUCE") == "1")
+        # (dist.FORCE_ALLREDUCE: also with ONE rank — a one-GPU box then exercises the pack / all-reduce / unpack path over RCCL)
+        return dist.is_available() and dist.is_initialized() and (dist.get_world_size(self.group) > 1 or FORCE_ALLREDUCE)
 
     def _build(self, device) -> None:
         n = sum(p.numel() for p in self.params)

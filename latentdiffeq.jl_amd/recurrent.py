@@ -493,7 +493,7 @@ def apply_feature_extractor(encoder: Encoder, x):
 
 
 _side_streams = {}
-_RNN_GROUP = os.environ.get("LDE_RNN_GROUP", "0") != "0"             # encode(): the three stacks as ONE autograd node on raw side streams, sweeps issued before
+_RNN_GROUP = False           # encode(): the three stacks as ONE autograd node on raw side streams, sweeps issued before
                                                                        # the weight-gradient tails. Opt-in: measured 1.80 vs 1.64 ms per goku_step at B = 256 (six
                                                                        # alternations on one box) — the z₀ branch's latent_in chains then run after the join instead of
                                                                        # beside the θ branch's longer stacks, and the per-tensor record_stream calls cost the host more
@@ -501,7 +501,7 @@ _RNN_GROUP = os.environ.get("LDE_RNN_GROUP", "0") != "0"             # encode():
 _RNN_LAUNCH_GROUP = True   # apply_pattern_extractor (the path without branch streams — what a captured step
                                                                            # runs): the stacks through lde_rnn_group_* on one stream instead of three side streams
 _STACKS_FIRST = True       # encode(): issue the three recurrent stacks before the latent_in chains
-_BRANCH_STREAMS = os.environ.get("LDE_BRANCH_STREAMS", "1") != "0"   # encode(): keep the z₀ / θ branches on their own streams (diagnostic switch)
+_BRANCH_STREAMS = True   # encode(): keep the z₀ / θ branches on their own streams (diagnostic switch)
 
 
 def _run_concurrently(stacks, x):

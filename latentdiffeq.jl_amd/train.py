@@ -32,7 +32,8 @@ from .loss import backward as _loss_backward
 from .recurrent import Encoder, default_encoder_layers, encode
 
 
-_FUSED_LOSS = os.environ.get("LDE_FUSED_LOSS", "1") != "0"   # loss_batch: sample + KL in one pass (diagnostic switch)
+_FUSED_LOSS = True    # module-level switches (diagnostic: set the attribute before the call; nothing here reads the environment)
+_NATIVE_ADAM = True   # FluxADAMW: the one-launch lde_adamw_flux_step   # loss_batch: sample + KL in one pass (diagnostic switch)
 
 
 class LatentDiffEqModel:
@@ -160,7 +161,7 @@ class FluxADAMW(torch.optim.Adam):
         self.decay = float(decay)
         ok = on_gpu and all(p.dtype == torch.float32 and p.is_contiguous() for p in params)
         if native is None:
-            native = ok and os.environ.get("LDE_NATIVE_ADAM", "1") != "0"
+            native = ok and _NATIVE_ADAM
         if native and not ok:
             raise ValueError("FluxADAMW(native=True) needs contiguous float32 HIP parameters")
         self.native = bool(native)
@@ -282,7 +283,7 @@ class GraphedStep:
     What the capture needs, and gets: every workspace sized before it (`warmup` eager steps on a side stream), the optimiser's step count
     in device memory (lde_adamw_flux_step_dev), gradients at fixed addresses (allocated from the graph's pool during capture), inputs
     copied INTO the captured tensors (`static_inputs`: tensors `fn` reads; `replay(*new)` copies into them), and a single stream — call
-    with the encoder's branch streams off (`LDE_BRANCH_STREAMS=0`: cross-stream capture of the recurrent stacks' side streams aborts
+    with the encoder's branch streams off (`recurrent._BRANCH_STREAMS = False`: cross-stream capture of the recurrent stacks' side streams aborts
     inside the HIP runtime on ROCm 7.2). ε of `sample` comes from torch's generator, which is graph-safe (its offsets advance per replay).
     Several GPUs: the collective stays OUTSIDE the graphs — pass the step in two halves: `fn` = zero_grad, forward, loss, backward;
     `between` = the gradient all-reduce (dist.FlatGradAllReduce: eager, on the gradients' fixed addresses); `fn2` = the optimiser step and

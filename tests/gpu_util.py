@@ -119,6 +119,9 @@ class Native:
 class NativeChain:
     """The dense-chain entry points of the C ABI (lde_chain_*), numpy in / numpy out."""
 
+    def set_option(self, key, value):
+        L.check(self.lib.lde_chain_set_option(self.h, key.encode(), float(value)), self.h, "lde_chain_set_option", chain=True)
+
     def __init__(self, sizes, acts, skips=None):
         self.lib = L.load()
         d = L.ChainDesc()
@@ -216,6 +219,9 @@ class NativeChain:
 
 class NativeRnn:
     """The recurrent-stack entry points of the C ABI (lde_rnn_*), numpy in / numpy out."""
+
+    def set_option(self, key, value):
+        L.check(self.lib.lde_rnn_set_option(self.h, key.encode(), float(value)), self.h, "lde_rnn_set_option", rnn=True)
 
     def __init__(self, cell, sizes, reverse=False):
         self.lib = L.load()

@@ -22,7 +22,7 @@ FE = ((784, 200, 200, 200, 32), (O.CACT_RELU,) * 4, (0, 1, 1, 0))   # feature ex
 ONE_WIDE = ((256, 24), (O.CACT_TANH,), (0,))                         # single layer, wide input: in place too
 
 
-def _run(spec, N, o32, o64, seed=5, need_dx=True):
+def _run(spec, N, o32, o64, seed=5, need_dx=True, options=()):
     from tests.gpu_util import NativeChain
     sizes, acts, skips = spec
     d = O.make_chain_desc(sizes, acts, skips)
@@ -32,6 +32,8 @@ def _run(spec, N, o32, o64, seed=5, need_dx=True):
     dy = (rng.standard_normal((N, sizes[-1])) / N).astype(np.float32)
     nat = NativeChain(sizes, acts, skips)
     assert nat.nW == W.size
+    for k_, v_ in options:
+        nat.set_option(k_, v_)
     nat.set_weights(W)
     y = nat.forward(x)
     yr = o32.chain_forward(d, W, x)
@@ -64,13 +66,12 @@ def test_reconstructor_at_the_metric_shape(o32, o64):
     _run(RECON, 256 * 50 - 1, o32, o64, seed=9)
 
 
-def test_wide_input_layouts_agree(o32, o64, monkeypatch):
+def test_wide_input_layouts_agree(o32, o64):
     """Wide inputs are read in place from x (no LDS input panel, ragged last tile shifted back with zero-weight repeats);
-    LDE_CHAIN_GX=0 forces the panel layout. Both must give the same numbers to round-off, on a ragged N."""
+    lde_chain_set_option("gx", 0) forces the panel layout. Both must give the same numbers to round-off, on a ragged N."""
     outs = []
-    for flag in ("1", "0"):
-        monkeypatch.setenv("LDE_CHAIN_GX", flag)
-        _, (x, y, dy, dx, dW) = _run(FE, 16 * 7 + 5, o32, o64, seed=13)
+    for flag in (1, 0):
+        _, (x, y, dy, dx, dW) = _run(FE, 16 * 7 + 5, o32, o64, seed=13, options=(("gx", flag),))
         outs.append((y, dx, dW))
     (ya, dxa, dWa), (yb, dxb, dWb) = outs
     assert np.abs(ya - yb).max() <= 1e-6 * max(1.0, np.abs(ya).max())

@@ -2,7 +2,7 @@
 Flux-flavour ADAMW with its step count in device memory → weight hand-over) replays to the SAME numbers as the eager step: with ε
 drawn once and shared, the loss of every step and every parameter after k steps are equal bit for bit
 [REF examples/pendulum_friction-less/model_train.jl:186-204: the loop body]. Runs in a subprocess: the encoder's side streams must be
-off (LDE_BRANCH_STREAMS=0, read at import) for the capture."""
+off (recurrent._BRANCH_STREAMS = False) for the capture."""
 import os
 import subprocess
 import sys
@@ -18,14 +18,18 @@ sys.path.insert(0, os.environ["LDE_ROOT"])
 import numpy as np, torch
 import latentdiffeq_amd as M
 from latentdiffeq_amd import _lib as L
+from latentdiffeq_amd import recurrent as _rec
+_rec._BRANCH_STREAMS = False          # the captured step runs on one stream (module attribute: the package reads no environment variable)
 from latentdiffeq_amd.chain import decode, default_decoder_layers
 from latentdiffeq_amd.loss import reconstruction_loss, sample_with_kl
 from latentdiffeq_amd.recurrent import Encoder, default_encoder_layers, encode
 from latentdiffeq_amd.train import FluxADAMW, GraphedStep
 dtype = sys.argv[1]
 split = len(sys.argv) > 2 and sys.argv[2] == "split"
-if split:   # several GPUs in miniature: a ONE-rank RCCL group, the gradient all-reduce forced on (LDE_FORCE_ALLREDUCE=1)
+if split:   # several GPUs in miniature: a ONE-rank RCCL group, the gradient all-reduce forced on (dist.FORCE_ALLREDUCE)
     import torch.distributed as dist
+    from latentdiffeq_amd import dist as _ldist
+    _ldist.FORCE_ALLREDUCE = True
     from latentdiffeq_amd.dist import FlatGradAllReduce
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29641", RANK="0", WORLD_SIZE="1")
     dist.init_process_group("nccl", device_id=torch.device("cuda", 0))
@@ -96,7 +100,7 @@ print("ok", dtype, le[-1])
 def test_graph_replay_equals_eager_step(tmp_path, dtype):
     f = tmp_path / "graph_step.py"
     f.write_text(SCRIPT)
-    env = dict(os.environ, LDE_ROOT=ROOT, LDE_BRANCH_STREAMS="0")
+    env = dict(os.environ, LDE_ROOT=ROOT)
     r = subprocess.run([sys.executable, str(f), dtype], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
@@ -107,7 +111,7 @@ def test_split_graph_step_with_a_process_group_equals_eager(tmp_path):
     all-reduce, bit for bit."""
     f = tmp_path / "graph_step_split.py"
     f.write_text(SCRIPT)
-    env = dict(os.environ, LDE_ROOT=ROOT, LDE_BRANCH_STREAMS="0", LDE_FORCE_ALLREDUCE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, LDE_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, str(f), "mixed", "split"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 

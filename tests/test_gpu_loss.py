@@ -97,7 +97,7 @@ def test_sample_with_kl_in_one_pass(nat, o64, n, offset):
 
 def test_loss_batch_fused_equals_the_separate_terms():
     """train.loss_batch with the sample and β·KL in one pass (default) vs the reference's composition of sample / vector_kl /
-    reconstruction_loss and torch additions (LDE_FUSED_LOSS=0): same ε (same generator state), same loss to f32 rounding of the
+    reconstruction_loss and torch additions (train._FUSED_LOSS = False): same ε (same generator state), same loss to f32 rounding of the
     scalar additions, same gradients to 1e-6 of their largest entry."""
     import torch
     import latentdiffeq_amd as la

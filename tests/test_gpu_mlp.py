@@ -11,10 +11,12 @@ from oracle import oracle as O
 pytestmark = pytest.mark.gpu
 
 
-def _native(W, **kw):
+def _native(W, options=(), **kw):
     from tests.gpu_util import Native, make_desc, copy_desc_to_oracle
     d = make_desc(**kw)
     nat = Native(d)
+    for k_, v_ in dict(options).items():        # kernel-choice knobs (lde_set_option): which family serves the call
+        nat.set_option(k_, v_)
     if W is not None:
         nat.set_weights(W)
     return nat, copy_desc_to_oracle(d)
@@ -260,7 +262,7 @@ def test_per_trajectory_rejections_partial_acceptance(o32, o64):
 
 
 @pytest.mark.parametrize("case", ["rk4_coupled", "tsit5_per_traj", "c3"])
-def test_staging_overflow_path_gives_the_same_gradient(case, monkeypatch):
+def test_staging_overflow_path_gives_the_same_gradient(case):
     """The adjoint stages (a_l, δ_l) panels in HBM and a second kernel forms dW. When a workgroup runs out of staging
     slots it folds them into a private slab inside the solve kernel. Forcing a tiny staging area (2 step attempts) must
     reproduce the gradient of the roomy run: dz0 bit-for-bit (the solve is untouched), dW up to summation order."""
@@ -287,11 +289,7 @@ def test_staging_overflow_path_gives_the_same_gradient(case, monkeypatch):
     dz = O.cotangent(T, B, D)
     res = []
     for slots in (None, 2 * nst):
-        if slots is None:
-            monkeypatch.delenv("LDE_MLP_STAGE_SLOTS", raising=False)
-        else:
-            monkeypatch.setenv("LDE_MLP_STAGE_SLOTS", str(slots))
-        nat, _ = _native(W, **kw)
+        nat, _ = _native(W, options={} if slots is None else {"mlp_stage_slots": slots}, **kw)
         z, _, _ = nat.forward(z0, L, ts)
         g0, gL, gW, st = nat.adjoint(z, L, ts, dz)
         assert st["nfailed"] == 0 and st["naccept"] >= T - 1
@@ -310,11 +308,12 @@ def test_staging_overflow_path_gives_the_same_gradient(case, monkeypatch):
 
 
 @pytest.mark.parametrize("case", ["c3", "tanh_per_traj", "tanh_coupled", "rk4_fixed", "wide_128", "aug_odd"])
-def test_four_column_kernel_matches_sixteen_column_kernel(case, monkeypatch, o64):
-    """Networks ≤ 64 wide run the adjoint with four trajectories per wave (lde_mlp4.h); LDE_MLP4=0 forces the 16-column
+def test_four_column_kernel_matches_sixteen_column_kernel(case, o64):
+    """Networks ≤ 64 wide run the adjoint with four trajectories per wave (lde_mlp4.h); option "mlp4" = 0 forces the 16-column
     workgroup kernel. Same algorithm, other summation order: at tight tolerance both must sit within 1e-4 of the float64
-    adjoint and within 5e-5 of each other (LDE_MLP4_MAXW=256 lets the 128-wide case through the four-column kernel)."""
+    adjoint and within 5e-5 of each other (option "mlp4_maxw" = 256 lets the 128-wide case through the four-column kernel)."""
     tight = dict(abstol=1e-7, reltol=1e-7)
+    opts4 = {}
     if case == "c3":
         layers, kw, B, D, T = (2, 64, 64, 2), dict(rhs_kind=O.RHS_PENDULUM_PLUS_MLP, activation=O.ACT_TANH, **tight), 70, 2, 12
     elif case == "tanh_per_traj":
@@ -328,7 +327,7 @@ def test_four_column_kernel_matches_sixteen_column_kernel(case, monkeypatch, o64
     elif case == "wide_128":
         layers, kw, B, D, T = (32, 128, 128, 32), dict(rhs_kind=O.RHS_MLP, state_dim=32, param_dim=0, activation=O.ACT_TANH,
                                                        batching=O.BATCH_COUPLED, **tight), 24, 32, 8
-        monkeypatch.setenv("LDE_MLP4_MAXW", "256")
+        opts4 = {"mlp4_maxw": 256}
     else:
         layers, kw, B, D, T = (7, 33, 50, 21, 7), dict(rhs_kind=O.RHS_MLP, state_dim=5, param_dim=0, augment_dim=2,
                                                        activation=O.ACT_TANH, **tight), 21, 5, 9
@@ -343,8 +342,7 @@ def test_four_column_kernel_matches_sixteen_column_kernel(case, monkeypatch, o64
     dz = O.cotangent(T, B, Dp)
     out = {}
     for flag in ("1", "0"):
-        monkeypatch.setenv("LDE_MLP4", flag)
-        nat, od = _native(W, **kw)
+        nat, od = _native(W, options={**opts4, "mlp4": int(flag)}, **kw)
         z, _, _ = nat.forward(z0, L, ts)
         out[flag] = nat.adjoint(z, L, ts, dz)
     d64 = O.make_desc(**{**kw, **({"abstol": 1e-11, "reltol": 1e-11} if kw.get("adaptive", 1) else {"dt": kw["dt"] / 8, "adaptive": False})})
@@ -529,9 +527,9 @@ def test_one_mlp_handle_changing_shapes(o32, layers, batching, solver):
 @pytest.mark.parametrize("case", ["c2_rk4_coupled", "c3_per_traj", "c4_coupled", "tanh_per_traj_4d", "rk4_per_traj_small", "deep_4_layers",
                                   "tsit5_d12_h150_coupled", "rk4_d20_h96_per_traj", "tanh_d8_h70_aug", "tanh_d8_h70_backsolve",
                                   "relu_d32_h128_long_grid"])
-def test_kernel_families_agree(case, monkeypatch, o64):
-    """Four kernel families serve the MLP right-hand sides: 16-column MFMA tiles (large batches; LDE_MLPV=0 LDE_MLP64=0 LDE_MLPW=0
-    forces them), one trajectory per workgroup with lanes = hidden units (k_mlpv; LDE_MLP64=0 LDE_MLPW=0), one wave per trajectory
+def test_kernel_families_agree(case, o64):
+    """Four kernel families serve the MLP right-hand sides: 16-column MFMA tiles (large batches; options "mlpv" = "mlp64" = "mlpw" = 0
+    force them), one trajectory per workgroup with lanes = hidden units (k_mlpv; "mlp64" = "mlpw" = 0), one wave per trajectory
     with everything in registers (k_mlp64: three layers ≤ 64 wide, D' ≤ 4, per-trajectory control) and W waves per trajectory with
     weights and state in registers (k_mlpw: three layers ≤ 200 wide, D' ≤ 32). Same algorithm, same control arithmetic: they
     agree like two correct f32 solves — round-off for fixed steps and smooth networks at tight tolerance, the solver's own error
@@ -564,13 +562,8 @@ def test_kernel_families_agree(case, monkeypatch, o64):
     dz = O.cotangent(T, B, D + kw.get("augment_dim", 0))
     res = {}
     # ("mlpw": k_mlpw where k_mlpb — W₂ as register blocks, the weight gradient folded on the CU; round 4 — is the default)
-    for fam, env in (("new", {}), ("mlpw", {"LDE_MLPB": "0"}), ("tiles", {"LDE_MLPV": "0", "LDE_MLP64": "0", "LDE_MLPW": "0"}),
-                     ("mlpv", {"LDE_MLP64": "0", "LDE_MLPW": "0"})):
-        for k_ in ("LDE_MLPV", "LDE_MLP64", "LDE_MLPW", "LDE_MLPB"):
-            monkeypatch.delenv(k_, raising=False)
-        for k_, v_ in env.items():
-            monkeypatch.setenv(k_, v_)
-        nat, _ = _native(W, **kw)
+    for fam, opts in (("new", {}), ("mlpw", {"mlpb": 0}), ("tiles", {"mlpv": 0, "mlp64": 0, "mlpw": 0}), ("mlpv", {"mlp64": 0, "mlpw": 0})):
+        nat, _ = _native(W, options=opts, **kw)
         z, ret, st = nat.forward(z0, L, ts)
         g0, gL, gW, sb = nat.adjoint(z, L, ts, dz)
         assert (ret == 0).all() and sb["nfailed"] == 0

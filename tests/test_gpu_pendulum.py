@@ -310,59 +310,51 @@ def test_save_grid_at_the_lds_limit_of_the_small_batch_kernel(o32):
     assert (ret == 0).all() and np.abs(z - zr).max() <= 1e-5
 
 
-_WS_SCRIPT = r"""
-import sys, numpy as np
-sys.path.insert(0, {root!r})
-from oracle import oracle as O
-from tests.gpu_util import Native, make_desc
-out = {{}}
-cases = [("default", dict(), 256, 50), ("tight", dict(abstol=1e-6, reltol=1e-6), 70, 50), ("friction", dict(rhs_kind=O.RHS_PENDULUM_FRICTION), 64, 23),
-         ("rk4", dict(solver=O.SOLVER_RK4, adaptive=0, dt=0.013), 65, 50), ("one", dict(), 1, 3), ("long", dict(abstol=1e-8, reltol=1e-8), 130, 200),
-         ("fail", dict(maxiters=9), 256, 50), ("mid", dict(), 3000, 50), ("dense", dict(), 130, 600)]
-for name, kw, B, T in cases:
-    z0, L = O.pendulum_inputs(B, seed=3)
-    ts = np.sort(np.random.default_rng(1).uniform(0.0, 3.0, T)) if name == "friction" else O.time_grid(T, 0.004) if name == "dense" else O.time_grid(T)
-    z, ret, st = Native(make_desc(**kw)).forward(z0, L, ts)
-    out[name + "_z"], out[name + "_ret"] = z, ret
-    out[name + "_st"] = np.array([st["nfe"], st["naccept"], st["nreject"], st["nfailed"]])
-np.savez({path!r}, **out)
-"""
+def _variant_run(options):
+    """The forward solve of every case below with the given kernel-choice options (lde_set_option) on the handle."""
+    from tests.gpu_util import Native, make_desc
+    out = {}
+    cases = [("default", dict(), 256, 50), ("tight", dict(abstol=1e-6, reltol=1e-6), 70, 50), ("friction", dict(rhs_kind=O.RHS_PENDULUM_FRICTION), 64, 23),
+             ("rk4", dict(solver=O.SOLVER_RK4, adaptive=0, dt=0.013), 65, 50), ("one", dict(), 1, 3), ("long", dict(abstol=1e-8, reltol=1e-8), 130, 200),
+             ("fail", dict(maxiters=9), 256, 50), ("mid", dict(), 3000, 50), ("dense", dict(), 130, 600)]
+    for name, kw, B, T in cases:
+        z0, L = O.pendulum_inputs(B, seed=3)
+        ts = np.sort(np.random.default_rng(1).uniform(0.0, 3.0, T)) if name == "friction" else O.time_grid(T, 0.004) if name == "dense" else O.time_grid(T)
+        nat = Native(make_desc(**kw))
+        for k_, v_ in options.items():
+            nat.set_option(k_, v_)
+        z, ret, st = nat.forward(z0, L, ts)
+        out[name + "_z"], out[name + "_ret"] = z, ret
+        out[name + "_st"] = np.array([st["nfe"], st["naccept"], st["nreject"], st["nfailed"]])
+    return out
+
+
+_SINGLE = {}
 
 
 @pytest.mark.parametrize("variant", ["ws", "tl", "lb", "lb8", "lb32", "sh"])
-def test_small_batch_forward_kernels_match_the_single_wave_kernel(tmp_path, variant):
+def test_small_batch_forward_kernels_match_the_single_wave_kernel(variant):
     """Five forward kernels share the step code and the dense-output formulas: k_pend_forward_sh (B ≤ 256: one trajectory per
-    workgroup, a stepping wave + three dense-output waves; LDE_PEND_SH_MAX_B forces it for every batch here — the 200-point tight case
+    workgroup, a stepping wave + three dense-output waves; option "pend_sh_max_b" forces it for every batch here — the 200-point tight case
     needs several rounds of its 48-step record ring, the maxiters case takes its failure barrier), k_pend_forward_tl (B ≤ 1024: lanes = save
     times), k_pend_forward_ws (B ≤ 16384: a stepping wave + helper waves pipelined through LDS), k_pend_forward (one lane
-    per trajectory; LDE_PEND_TL_MAX_B=0 LDE_PEND_WS=0 forces it) and the large-batch form of the first (B ≥ 2¹⁷: a lane per
-    trajectory, ẑ rows leave through an LDS ring as whole 512-byte stores; LDE_PEND_LB_MIN_B=0 forces it, and the 200-point
+    per trajectory; "pend_tl_max_b" = "pend_sh_max_b" = "pend_ws" = 0 forces it) and the large-batch form of the first (B ≥ 2¹⁷: a lane per
+    trajectory, ẑ rows leave through an LDS ring as whole 512-byte stores; "pend_lb_min_b" = 0 forces it, and the 200-point
     grid with its 16-row ring exercises both the hold and the direct-store overflow). They agree like two correct f32 solves — default and tight
     tolerance, friction with off-grid save times, fixed-step RK4, a single trajectory, 200 save points (several save times
-    per lane in the tl kernel), and trajectories that fail (NaN blocks)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    if os.environ.get("LDE_PEND_WS", "1") == "0" or "LDE_PEND_TL_MAX_B" in os.environ or "LDE_PEND_LB_MIN_B" in os.environ or "LDE_PEND_SH_MAX_B" in os.environ:
-        pytest.skip("this process already runs with a forced kernel choice")
-    path = str(tmp_path / "single.npz")
-    subprocess.run([sys.executable, "-c", _WS_SCRIPT.format(root=root, path=path)], check=True,
-                   env=dict(os.environ, LDE_PEND_WS="0", LDE_PEND_TL_MAX_B="0", LDE_PEND_SH_MAX_B="0"), timeout=600)
-    here = str(tmp_path / "split.npz")
-    subprocess.run([sys.executable, "-c", _WS_SCRIPT.format(root=root, path=here)], check=True,
-                   env=dict(os.environ, **{"ws": dict(LDE_PEND_TL_MAX_B="0", LDE_PEND_SH_MAX_B="0"),
-                                           "tl": dict(LDE_PEND_TL_MAX_B="1024", LDE_PEND_SH_MAX_B="0"),
-                                           "lb": dict(LDE_PEND_TL_MAX_B="0", LDE_PEND_SH_MAX_B="0", LDE_PEND_WS="0", LDE_PEND_LB_MIN_B="0"),
-                                           # ring of 8 rows with a requested hold of 8 (≥ the ring: the host clamps it to 7 — unclamped, every
-                                           # lane would sit out every iteration and the solve would never end), and 32 rows with the default hold
-                                           "lb8": dict(LDE_PEND_TL_MAX_B="0", LDE_PEND_SH_MAX_B="0", LDE_PEND_WS="0", LDE_PEND_LB_MIN_B="0",
-                                                       LDE_PEND_LB="8", LDE_PEND_LB_HOLD="8"),
-                                           "lb32": dict(LDE_PEND_TL_MAX_B="0", LDE_PEND_SH_MAX_B="0", LDE_PEND_WS="0", LDE_PEND_LB_MIN_B="0",
-                                                        LDE_PEND_LB="32"),
-                                           "sh": dict(LDE_PEND_SH_MAX_B="1000000")}[variant]),
-                   timeout=600)
-    a, b = np.load(here), np.load(path)
+    per lane in the tl kernel), and trajectories that fail (NaN blocks). The kernel choice is a per-handle option (lde_set_option):
+    the library reads no environment variable."""
+    if "ref" not in _SINGLE:
+        _SINGLE["ref"] = _variant_run(dict(pend_ws=0, pend_tl_max_b=0, pend_sh_max_b=0))
+    b = _SINGLE["ref"]
+    a = _variant_run({"ws": dict(pend_tl_max_b=0, pend_sh_max_b=0),
+                      "tl": dict(pend_tl_max_b=1024, pend_sh_max_b=0),
+                      "lb": dict(pend_tl_max_b=0, pend_sh_max_b=0, pend_ws=0, pend_lb_min_b=0),
+                      # ring of 8 rows with a requested hold of 8 (≥ the ring: the host clamps it to 7 — unclamped, every
+                      # lane would sit out every iteration and the solve would never end), and 32 rows with the default hold
+                      "lb8": dict(pend_tl_max_b=0, pend_sh_max_b=0, pend_ws=0, pend_lb_min_b=0, pend_lb=8, pend_lb_hold=8),
+                      "lb32": dict(pend_tl_max_b=0, pend_sh_max_b=0, pend_ws=0, pend_lb_min_b=0, pend_lb=32),
+                      "sh": dict(pend_sh_max_b=1000000)}[variant])
     # different compilations of the same step code: multiply-adds contract differently, so the adaptive step sequences part at
     # round-off level — the kernels agree like two correct f32 solves do (tests above: ≤ 3e-4 at the default tolerance,
     # ≤ 2e-5 at 1e-6), exactly where there is no controller (fixed-step RK4 ≤ 2e-6)

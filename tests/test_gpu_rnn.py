@@ -152,51 +152,33 @@ def test_one_rnn_handle_changing_shapes(o32):
             assert np.abs(dx - rx).max() <= 1e-4 * np.abs(rx).max() and np.abs(dW - rW).max() <= 1e-4 * np.abs(rW).max(), (T, B)
 
 
-_GENERIC = r"""
-import sys, numpy as np
-sys.path.insert(0, {root!r})
-from oracle import oracle as O
-from tests.gpu_util import NativeRnn
-out = {{}}
-for name, cell in (("lstm", O.CELL_LSTM), ("relu", O.CELL_RNN_RELU), ("tanh", O.CELL_RNN_TANH)):
-    sizes, T, B = (32, 16, 16), 23, 70
-    W = O.rnn_weights(cell, sizes, seed=6)
-    rng = np.random.default_rng(7)
-    x = rng.standard_normal((T, B, 32)).astype(np.float32)
-    dy = (rng.standard_normal((B, 16)) / B).astype(np.float32)
-    nat = NativeRnn(cell, sizes, True)
-    nat.set_weights(W)
-    out[name + "_y"] = nat.forward(x)
-    out[name + "_dx"], out[name + "_dW"] = nat.backward(x, dy)
-np.savez({path!r}, **out)
-"""
-
-
-def test_instantiated_and_run_time_shaped_kernels_agree(tmp_path):
-    """The reference's default stacks (32 → 16 → 16) run compile-time instantiations of k_rnn; LDE_RNN_GENERIC=1 forces the
-    run-time-shaped kernel every other shape uses. Same source, same order of operations: the two must agree to round-off
+def test_instantiated_and_run_time_shaped_kernels_agree():
+    """The reference's default stacks (32 → 16 → 16) run compile-time instantiations of k_rnn; lde_rnn_set_option("generic", 1) forces
+    the run-time-shaped kernel every other shape uses. Same source, same order of operations: the two must agree to round-off
     (the compiler may contract multiply-adds differently, nothing more)."""
-    import os
-    import subprocess
-    import sys
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    if os.environ.get("LDE_RNN_GENERIC", "0") not in ("", "0"):
-        pytest.skip("this process already runs the run-time-shaped kernel")
-    path = str(tmp_path / "rnn_generic.npz")
-    subprocess.run([sys.executable, "-c", _GENERIC.format(root=root, path=path)], check=True,
-                   env=dict(os.environ, LDE_RNN_GENERIC="1"), timeout=600)
-    here = str(tmp_path / "rnn_here.npz")
-    exec(compile(_GENERIC.format(root=root, path=here), "<rnn instantiated>", "exec"), {})      # the same script, in this process
-    res = {"0": np.load(here), "1": np.load(path)}
-    for k in res["0"].files:
-        a, b = res["0"][k], res["1"][k]
-        assert np.abs(a - b).max() <= 2e-6 * max(np.abs(b).max(), 1e-30), k
+    from tests.gpu_util import NativeRnn
+    for cell in (O.CELL_LSTM, O.CELL_RNN_RELU, O.CELL_RNN_TANH):
+        sizes, T, B = (32, 16, 16), 23, 70
+        W = O.rnn_weights(cell, sizes, seed=6)
+        rng = np.random.default_rng(7)
+        x = rng.standard_normal((T, B, 32)).astype(np.float32)
+        dy = (rng.standard_normal((B, 16)) / B).astype(np.float32)
+        res = []
+        for generic in (0, 1):
+            nat = NativeRnn(cell, sizes, True)
+            nat.set_option("generic", generic)
+            nat.set_weights(W)
+            y = nat.forward(x)
+            dx, dW = nat.backward(x, dy)
+            res.append((y, dx, dW))
+        for a, b, what in zip(res[0], res[1], ("y", "dx", "dW")):
+            assert np.abs(a - b).max() <= 2e-6 * max(np.abs(b).max(), 1e-30), (cell, what)
 
 
 @pytest.mark.parametrize("cell", [O.CELL_LSTM, O.CELL_RNN_RELU, O.CELL_RNN_TANH])
-def test_register_and_lds_weight_rows_agree(cell, monkeypatch):
+def test_register_and_lds_weight_rows_agree(cell):
     """Small batches of the default stacks run one wave per workgroup with the weight rows in registers (packed FMAs);
-    LDE_RNN_REGW=0 keeps them in LDS (the instantiation larger batches use). Same sums in a different association: round-off."""
+    lde_rnn_set_option("regw", 0) keeps them in LDS (the instantiation larger batches use). Same sums in a different association: round-off."""
     from tests.gpu_util import NativeRnn
     sizes, T, B = (32, 16, 16), 23, 37
     W = O.rnn_weights(cell, sizes, seed=9)
@@ -204,9 +186,9 @@ def test_register_and_lds_weight_rows_agree(cell, monkeypatch):
     x = rng.standard_normal((T, B, sizes[0])).astype(np.float32)
     dy = (rng.standard_normal((B, sizes[-1])) / B).astype(np.float32)
     res = []
-    for flag in ("1", "0"):
-        monkeypatch.setenv("LDE_RNN_REGW", flag)
+    for flag in (1, 0):
         nat = NativeRnn(cell, sizes, True)
+        nat.set_option("regw", flag)
         nat.set_weights(W)
         y = nat.forward(x)
         dx, dW = nat.backward(x, dy)
@@ -217,9 +199,9 @@ def test_register_and_lds_weight_rows_agree(cell, monkeypatch):
 
 @pytest.mark.parametrize("cell", [O.CELL_LSTM, O.CELL_RNN_RELU, O.CELL_RNN_TANH])
 @pytest.mark.parametrize("T,B,rev", [(23, 37, True), (1, 5, False), (8, 16, True), (9, 64, False), (50, 256, True)])
-def test_one_wave_per_cell_equals_one_wave_per_stack(cell, T, B, rev, monkeypatch):
+def test_one_wave_per_cell_equals_one_wave_per_stack(cell, T, B, rev):
     """The default stacks run a workgroup of two waves, one per cell, handing h¹ₛ forward and ∂L/∂h¹ₛ backward through an LDS ring
-    (rnn_body2); LDE_RNN_PIPE=0 keeps the single wave that walks both cells (rnn_body). Same arithmetic per cell, in the same
+    (rnn_body2); lde_rnn_set_option("pipe", 0) keeps the single wave that walks both cells (rnn_body). Same arithmetic per cell, in the same
     order ⇒ the same bits — outputs, input gradients and weight gradients, on sweeps shorter than, equal to and longer than the
     ring, with ragged batches, both directions of time; the training forward + pullback from kept records as well."""
     from tests.gpu_util import NativeRnn
@@ -229,9 +211,9 @@ def test_one_wave_per_cell_equals_one_wave_per_stack(cell, T, B, rev, monkeypatc
     x = rng.standard_normal((T, B, sizes[0])).astype(np.float32)
     dy = (rng.standard_normal((B, sizes[-1])) / B).astype(np.float32)
     res = []
-    for flag in ("1", "0"):
-        monkeypatch.setenv("LDE_RNN_PIPE", flag)
+    for flag in (1, 0):
         nat = NativeRnn(cell, sizes, rev)
+        nat.set_option("pipe", flag)
         nat.set_weights(W)
         y = nat.forward(x)
         dx, dW = nat.backward(x, dy)

@@ -883,6 +883,7 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
 
   if (w == 0) {
     // ================= the stepper: k_pend_forward_tl's loop without the dense output =================
+    PPROF(8);
     f32x2 y = {zi.x, zi.y}, k[7], yn = {0.f, 0.f}, kf = {0.f, 0.f};
     int ret = LDE_RET_SUCCESS, nfe = 0, nacc = 0, nrej = 0;
     double t = t_first;
@@ -910,6 +911,7 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
       dt = (float)o.dt_fixed;
     bool active = __any(t < tend) && maxit > 0;   // (votes: scalar from here on)
     if (__any(t < tend) && !active) ret = LDE_RET_MAXITERS;
+    PPROF(9);
     for (;;) {   // rounds
       int n = 0;
       float* rp = rec_at(0);
@@ -986,6 +988,8 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
         }
       }
       nacc += n;
+      PPROF(10);
+      PPROF_VAL(30, nacc + nrej);
       if (active && nacc + nrej >= maxit) { ret = LDE_RET_MAXITERS; active = false; }
       if (ret != LDE_RET_SUCCESS && lane == 0) __hip_atomic_store(&s_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       asm volatile("" ::: "memory");
@@ -1011,6 +1015,7 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
       st_nrej[b] = nrej;
       if (o.rec.n) o.rec.n[b] = ret == LDE_RET_SUCCESS ? nacc : 0;
     }
+    PPROF(11);
     return;
   }
 
@@ -1113,6 +1118,9 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
     __syncthreads();   // A
     __syncthreads();   // B
   }
+#if LDE_PEND_PROF
+  if (blockIdx.x == 0 && lane == 0) { g_pprof[2 * (12 + hid)] = wall_clock64(); g_pprof[2 * (12 + hid) + 1] = __builtin_readcyclecounter(); }   // helper hid has stored its last save
+#endif
   if (__hip_atomic_load(&s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();   // F: every helper store has been issued and waited for

@@ -1130,12 +1130,33 @@ static void blk_f(blockctx* b, const real* y, real* dy) {
   }
   b->c.margin = NULL;
 }
-/* vz += J(y)ᵀ kb; gth += (∂f/∂θ)ᵀ kb; dW_acc += (∂f/∂W)ᵀ kb — skipped altogether when kb is identically zero */
+/* vz += J(y)ᵀ kb; gth += (∂f/∂θ)ᵀ kb; dW_acc += (∂f/∂W)ᵀ kb — skipped altogether when kb is identically zero.
+ * A coupled block with nth > 1 spreads its columns over OpenMP threads (as the continuous adjoint's bwd_fn does — the role OpenBLAS
+ * threads play under the reference's per-stage sgemms): per-thread scratch, the threads' weight-gradient sums added in thread order. */
 static void blk_vjp(blockctx* b, const real* y, const real* kb, real* vz_add, real* gth, sstat* st) {
   int64_t n = (int64_t)b->Dp * b->ncol;
   int any = 0;
   for (int64_t i = 0; i < n && !any; i++) any = kb[i] != 0;
   if (!any) return;
+#ifdef _OPENMP
+  if (b->nth > 1 && !b->col_margin) {
+    for (int t = 0; t < b->nth; t++)
+      if (b->cs[t].dW_step) memset(b->cs[t].dW_step, 0, (size_t)b->cs[t].nW * sizeof(real));
+#pragma omp parallel for num_threads(b->nth) schedule(static)
+    for (int c = 0; c < b->ncol; c++) {
+      real f[1024], vz[1024], vth[16];
+      rhs_vjp_col(&b->cs[omp_get_thread_num()], y + (int64_t)c * b->Dp, b->theta + (int64_t)c * b->P, kb + (int64_t)c * b->Dp, f, vz, vth, (real)1);
+      for (int i = 0; i < b->Dp; i++) vz_add[(int64_t)c * b->Dp + i] += vz[i];
+      for (int p = 0; p < b->P; p++) gth[(int64_t)c * b->P + p] += vth[p];
+    }
+    if (b->dW_acc)
+      for (int t = 0; t < b->nth; t++)
+        if (b->cs[t].dW_step)
+          for (int64_t i = 0; i < b->cs[t].nW; i++) b->dW_acc[i] += (double)b->cs[t].dW_step[i];
+    st->nfe++;
+    return;
+  }
+#endif
   real f[1024], vz[1024], vth[16];
   for (int c = 0; c < b->ncol; c++) {
     if (b->c.dW_step) memset(b->c.dW_step, 0, (size_t)b->c.nW * sizeof(real));
@@ -1292,13 +1313,14 @@ static int adjoint_discrete(const lde_problem_desc* d, const real* W, const real
 #ifdef _OPENMP
   if (nthreads > 0) omp_set_num_threads(nthreads);
 #endif
-#pragma omp parallel reduction(+ : nfe, nacc, nfail) reduction(max : maxsteps)
+#pragma omp parallel if (!coupled) reduction(+ : nfe, nacc, nfail) reduction(max : maxsteps)   /* a coupled solve is ONE block: its columns are threaded instead */
   {
     blockctx b;
     memset(&b, 0, sizeof(b));
     colrhs_init(&b.c, d, W);
     b.ncol = ncol; b.Dp = Dp; b.P = P; b.Bstride = B;
     b.dW_acc = nW ? (double*)calloc((size_t)nW, sizeof(double)) : NULL;
+    if (coupled) block_threads_init(&b, d, W, nthreads);   /* (one block: the parallel region above has one thread at work; the columns get the rest) */
     const int64_t n = (int64_t)Dp * ncol;
     real* y0 = (real*)calloc((size_t)n, sizeof(real));
     real* ybar = (real*)calloc((size_t)n, sizeof(real));
@@ -1339,6 +1361,7 @@ static int adjoint_discrete(const lde_problem_desc* d, const real* W, const real
       free(b.dW_acc);
     }
     free(y0); free(ybar); free(gth);
+    block_threads_free(&b);
     colrhs_free(&b.c);
   }
   if (nW && dW)

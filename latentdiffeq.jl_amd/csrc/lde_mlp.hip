@@ -2089,8 +2089,8 @@ static int launch_b(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t
 }
 
 // ---- two trajectories per workgroup, networks up to 128 wide (lde_mlpc.h)
-static size_t c_lds_base(int T, bool adj, int nst) {
-  const int nsl = adj ? nst + 1 : 1;
+static size_t c_lds_base(int T, bool adj, int nst, bool disc = false) {
+  const int nsl = disc ? 2 * nst + 1 : (adj ? nst + 1 : 1);   // (the discrete sweep: three rotating first-stage slots + two banks of nst − 1)
   return (((size_t)T * 8 + 15) & ~size_t(15)) + (size_t)(nsl * mlpc::SLOT + (adj ? 16 * mlpc::HV : 0) + 16 * 16 * 4) * 4 +
          (size_t)128 * mlpc::W13S * 4 + (adj ? (size_t)mlpc::GS * 64 * 16 + 4 * mlpc::DP * 2 * 4 : 0) + 16;
 }
@@ -2108,7 +2108,7 @@ static int disc_family(const MlpPlan* p, int B, int T) {
   if (mlp64_applicable(p, B)) return DISC_64;
   const int nst = dm.solver == LDE_SOLVER_RK4 ? 4 : 6;
   if (b_applicable(p, std::min(B, 256), T, true, false) && B <= 1024 && b_lds_base(p->bd, T, true, nst) + (size_t)T * dm.Dp * 4 <= LDS_MAX) return DISC_B;
-  if (c_applicable(p, std::min(B, 512), T, true, false) && B <= 2048) return DISC_C;
+  if (c_applicable(p, std::min(B, 512), T, true, false) && B <= 2048 && c_lds_base(T, true, nst, true) <= LDS_MAX) return DISC_C;
   return DISC_TILES;
 }
 
@@ -2119,8 +2119,12 @@ static int launch_c(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t
   KOpts ov = o;
   const bool tanh_ = dmv.act == LDE_ACT_TANH;
   const void* fn = tanh_ ? (const void*)k_mlpc<SOLVER, LDE_ACT_TANH, DISC, ADJ> : (const void*)k_mlpc<SOLVER, LDE_ACT_RELU, DISC, ADJ>;
-  size_t lds = c_lds_base(o.T, ADJ, SOLVER == LDE_SOLVER_RK4 ? 4 : 6);
-  const size_t cot = ADJ ? (size_t)2 * o.T * dmv.Dp * 4 * (o.checkpoint ? 2 : 1) : 0;
+  size_t lds = c_lds_base(o.T, ADJ, SOLVER == LDE_SOLVER_RK4 ? 4 : 6, DISC);
+  if (lds > LDS_MAX) {
+    err = "k_mlpc: the save-time grid does not fit LDS";
+    return LDE_ERR_UNSUPPORTED;
+  }
+  const size_t cot = ADJ ? (size_t)2 * o.T * dmv.Dp * 4 * ((o.checkpoint && !DISC) ? 2 : 1) : 0;
   a.cot_lds = ADJ && lds + cot <= LDS_MAX;   // the two trajectories' dẑ (and saved ẑ) by save time: no global load inside the solve
   if (a.cot_lds) lds += cot;
   {   // dynamic LDS beyond the default limit needs the attribute, once per instantiation

@@ -82,7 +82,10 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
   static_assert(ADJ || !DISC, "the discrete sweep is an adjoint");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   constexpr int NST = SOLVER == LDE_SOLVER_TSIT5 ? 6 : 4;                // weighted stages of a step = ring slots the fold reads
-  constexpr int NSL = ADJ ? NST + 1 : 1;                                  // + one scratch slot (initial-step probes, the FSAL stage)
+  // ring slots. Continuous adjoint: the NST weighted stages + one scratch slot (initial-step probes, the FSAL stage). Discrete sweep: three
+  // rotating slots for first stage points (= FSAL points of the step before) and two banks of NST − 1 stage slots — the step being reversed
+  // and the step whose slopes are being rebuilt beside it (paired evaluations: see the sweep)
+  constexpr int NSL = DISC ? 2 * NST + 1 : (ADJ ? NST + 1 : 1);
   constexpr bool SPEC = ADJ && SOLVER == LDE_SOLVER_TSIT5;                // an attempt never evaluates its first stage (k_mlpb: see there)
   constexpr int act = ACT;
   const int T = o.T, B = o.B, D = dm.D, Dp = dm.Dp, tid = threadIdx.x, lane = tid & 63;
@@ -117,7 +120,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
         const int bb = bt0 + t < B ? bt0 + t : bt0;
         const size_t g = (size_t)Dp * ((size_t)bb + (size_t)B * (q / Dp)) + (q % Dp);
         s_cot[i] = bt0 + t < B ? a.dz_out[g] : 0.f;
-        if (o.checkpoint) s_cot[2 * per + i] = a.z_out[g];
+        if (!DISC && o.checkpoint) s_cot[2 * per + i] = a.z_out[g];   // (the discrete sweep takes its states from the step record)
       }
     }
   }
@@ -268,15 +271,27 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
   };
 
   // one evaluation of the (augmented) right-hand side for both trajectories: src → dst; its vectors stay in ring slot `slot`
-  // vj (wave-uniform; only the discrete sweep passes false): false = the forward half alone — f, h₁, h₂ — for the evaluations that rebuild slopes
-  auto eval = [&](const float (&src)[2], int slot, float (&dst)[2], bool vj = true) {
+  // vj (wave-uniform; only the discrete sweep passes false): false = the forward half alone — f, h₁, h₂ — for the evaluations that rebuild slopes.
+  // vslot ≥ 0 (the discrete sweep's PAIRED evaluation): the vector-Jacobian half belongs to ANOTHER point — the one whose forward half left
+  // z, h₁, h₂ in ring slot `vslot` earlier — while the forward half evaluates `src`'s z lanes into `slot`: two independent evaluations in one
+  // evaluation's phases. (vslot < 0: both halves at the same point, the activations taken from registers — the continuous adjoint's form.)
+  auto eval = [&](const float (&src)[2], int slot, float (&dst)[2], bool vj = true, int vslot = -1) {
     PROF_T(e0);
+    const bool paired = DISC && vslot >= 0;
     float* xs = ring + slot * SLOT;
-    float *h1v = xs + XS, *d2v = h1v + HV, *h2v = d2v + HV, *d1v = h2v + HV;
-    xs[lane] = src[0];          // (every wave stores the same values)
-    xs[64 + lane] = src[1];
+    float* xv = paired ? ring + vslot * SLOT : xs;   // the slot of the vector-Jacobian half: its λ, W₃ᵀλ → δ₂, δ₁ (and, paired, its saved h₁, h₂)
+    float *h1v = xs + XS, *h2v = h1v + 2 * HV;
+    float *d2v = xv + XS + HV, *d1v = xv + XS + 3 * HV;
+    if (paired) {   // z lanes feed the forward half's slot, λ lanes the other one's
+      (lane < DP ? xs : xv)[lane] = src[0];
+      (lane < DP ? xs : xv)[64 + lane] = src[1];
+    } else {
+      xs[lane] = src[0];          // (every wave stores the same values)
+      xs[64 + lane] = src[1];
+    }
     asm volatile("" ::: "memory");   // same wave, in-order LDS: the broadcast reads below see the write (no barrier needed)
     const f32x4* x4 = reinterpret_cast<const f32x4*>(xs + 64 * ut);
+    const f32x4* x4v = reinterpret_cast<const f32x4*>(xv + 64 * ut);
     float h1;
     {
       // (the sixteen reads of a thin product are issued before its first multiplication waits for one — the compiler's own order was eight,
@@ -294,11 +309,12 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
       const float a1 = b1 + ((c01.x + c01.y) + (c23.x + c23.y));
       h1 = u == H1 ? 1.f : act_fn(act, a1);   // unit H₁ (when < 128): the constant that carries b₂ (rows beyond: zero weights and bias ⇒ act(0) = 0)
     }
+    const float h1b = paired ? xv[XS + 2 * u + ut] : h1;   // h₁ of the vector-Jacobian half's point (read before this lane's own word is rewritten: X and Y may be one slot)
     h1v[2 * u + ut] = h1;
     if (ADJ && vj) {
       f32x4 xv[G1], wv4[G1];
 #pragma unroll
-      for (int g = 0; g < G1; g++) { xv[g] = x4[G1 + g]; wv4[g] = my13[G1 + g]; }   // λ
+      for (int g = 0; g < G1; g++) { xv[g] = x4v[G1 + g]; wv4[g] = my13[G1 + g]; }   // λ
       __builtin_amdgcn_sched_barrier(0);
       f32x2 c01 = {0.f, 0.f}, c23 = {0.f, 0.f};
 #pragma unroll
@@ -348,10 +364,12 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
     if (ADJ && vj) {
       f32x2 d2[RB];
       const f32x2* dv = reinterpret_cast<const f32x2*>(d2v) + RB * br;
+      const f32x2* hb = reinterpret_cast<const f32x2*>(xv + XS + 2 * HV) + RB * br;   // (paired) h₂ of the other point, as its forward half left it
 #pragma unroll
       for (int i = 0; i < RB; i++) {
         const f32x2 g2 = dv[i];
-        d2[i] = f32x2{g2.x * act_grad(act, h2[i].x), g2.y * act_grad(act, h2[i].y)};
+        const f32x2 hh = paired ? hb[i] : h2[i];
+        d2[i] = f32x2{g2.x * act_grad(act, hh.x), g2.y * act_grad(act, hh.y)};
       }
       if (bc == 0) {   // one lane of the row leaves h₂ and δ₂ for the thin products and the fold
         f32x2* hw = reinterpret_cast<f32x2*>(h2v) + RB * br;
@@ -369,6 +387,10 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
       f32x2* pp = reinterpret_cast<f32x2*>(part) + br * HU + CB * bc;
 #pragma unroll
       for (int jj = 0; jj < CB; jj++) pp[jj] = gp[jj];
+    } else if (DISC && bc == 0) {   // the forward half alone (the sweep's prologue): h₂ stays in the slot for the paired evaluation that follows
+      f32x2* hw = reinterpret_cast<f32x2*>(h2v) + RB * br;
+#pragma unroll
+      for (int i = 0; i < RB; i++) hw[i] = h2[i];
     }
     __syncthreads();
     PROF_T(e2);
@@ -391,7 +413,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
 #pragma unroll
         for (int r = 0; r < 16; r++) g1 += p[r];
       }
-      const float d1 = u < H1 ? g1 * act_grad(act, h1) : 0.f;
+      const float d1 = u < H1 ? g1 * act_grad(act, h1b) : 0.f;
       d1v[2 * u + ut] = d1;
       __syncthreads();
       const f32x2 pvz = narrow_part(d1v);
@@ -411,6 +433,8 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
   // the accepted step's share of the quadrature gW = Σ_s |h| b_s (∂f/∂W)ᵀλ of BOTH trajectories, from the ring. K slot q = 4g + (lane >> 4)
   // ↔ (stage e, trajectory) = (q >> 1, q & 1). Tiles of wave w (operand addresses = a per-lane base + compile-time offsets):
   //   n = 2·ti + m, ti < 9, m < 2 : gW₂ᵀ tile (ti, tj = 4m + w)     n = 18 + 2m + tk : gW₁ tile (4m + w, tk)     n = 22 + 2m + tk : gW₃ᵀ tile (4m + w, tk)
+  int vbank = 3, fsx = 0;   // (discrete sweep) first slot of the bank of the step being reversed (stage point i ≥ 1 at vbank + i − 1), and the FSAL point's slot
+  auto fslot = [&](int e) -> int { return DISC ? (e == 0 ? fsx : vbank + (NST - e) - 1) : e; };   // ring slot of the fold's evaluation e
   auto fold = [&](int nvalid) {   // nvalid (wave-uniform): ring slots [0, nvalid) count
     PROF_T(f0);
     const int l15 = lane & 15, e4 = lane >> 4;
@@ -423,7 +447,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
       else bs = (e == 0 || e == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f);
       const bool ev = e < nvalid;
       const float wsc = DISC ? 1.f : wq * bs;
-      const float* sl = ring + (ev ? e : 0) * SLOT;
+      const float* sl = ring + fslot(ev ? e : 0) * SLOT;
       const float* pv = sl + XS + 2 * l15 + tt;           // + 32·tile: element (16·tile + l15) of trajectory tt of the slot's first vector
       const float* pw = pv + 32 * wv;                     // … of the tiles 4m + w
       float bm[2];
@@ -472,7 +496,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
     for (int e = 0; e < NST; e++) {
       const float bs = SOLVER == LDE_SOLVER_TSIT5 ? ts5::A[6][e] : ((e == 0 || e == 3) ? (1.0f / 6.0f) : (1.0f / 3.0f));
       const float wb_ = DISC ? (e < nvalid ? 1.f : 0.f) : wq * bs;
-      const float* sl = ring + e * SLOT;
+      const float* sl = ring + fslot(e) * SLOT;
       const f32x2 dd = reinterpret_cast<const f32x2*>(sl + XS + 3 * HV)[u];
       gb1 += wb_ * (dd.x + dd.y);
       gb3 += wb_ * (sl[lane] + sl[64 + lane]);
@@ -554,37 +578,53 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
       return zv;
     };
     if (status == 0) {
+      // PAIRED evaluations: while step m is reversed, the slopes of step m − 1 are rebuilt — the two chains are independent, so the forward
+      // half of one evaluation's phases rebuilds a slope of step m − 1 and its vector-Jacobian half pulls a k̄ of step m through a stage point
+      // whose z, h₁, h₂ the forward half of an EARLIER evaluation left in the ring: S evaluation-times per step instead of 2S.
+      // Ring slots: three rotating ones — sx: the FSAL point y_{m+1} of the step being reversed (= the first stage point of step m + 1),
+      // sy: the first stage point of step m (the next sx), sz: where the forward halves put the first stage point of step m − 1 — and two
+      // banks of S − 1 slots (stage i ≥ 2 at bank + i − 2): vbank of step m, fbank of step m − 1.
+      int sx = 0, sy = 1, sz = 2, fbank = 3;
+      vbank = S + 2;
       j = T - 1;
       double tnext = tend;
+      {   // prologue: the slopes of the last step (forward halves alone: first stage point → sy, the others → vbank), then f at its end
+          // state y_ns — the FSAL point of that step — into sx
+        const float hz = (float)R.dt[(size_t)(ns - 1) * R.nseq + seq];
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++)
+          if (is_z) y[tt] = (tt == 0 || two) ? R.y[((size_t)(ns - 1) * B + (bt0 + tt)) * Dp + row] : 0.f;
+#pragma unroll 1
+        for (int i = 0; i <= S; i++) {
+          float src[2], dst[2];
+#pragma unroll
+          for (int tt = 0; tt < 2; tt++) src[tt] = is_z ? point(i, hz, tt) : 0.f;
+          eval(src, i == 0 ? sy : (i == S ? sx : vbank + i - 1), dst, false);
+#pragma unroll
+          for (int q = 0; q < S; q++)
+            if (q == i && is_z) { k[q][0] = dst[0]; k[q][1] = dst[1]; }
+        }
+        nfe += S + 1;
+      }
 #pragma unroll 1
       for (int sidx = ns - 1; sidx >= 0; sidx--) {
         const double ts_n = R.t[(size_t)sidx * R.nseq + seq], dts = R.dt[(size_t)sidx * R.nseq + seq];
-        const float hh = (float)dts;
+        const float hh = (float)dts;                                                                   // the step being reversed (λ lanes)
+        const float hz = sidx > 0 ? (float)R.dt[(size_t)(sidx - 1) * R.nseq + seq] : 0.f;             // the step being rebuilt (z lanes)
         const bool lastst = sidx == ns - 1;
         const double tnw = tnext;
         tnext = ts_n;
 #pragma unroll
         for (int tt = 0; tt < 2; tt++) {
-          if (is_z) y[tt] = (tt == 0 || two) ? R.y[((size_t)sidx * B + (bt0 + tt)) * Dp + row] : 0.f;
-          else {
+          if (is_z) {
+            if (sidx > 0) y[tt] = (tt == 0 || two) ? R.y[((size_t)(sidx - 1) * B + (bt0 + tt)) * Dp + row] : 0.f;   // (the first step rebuilds nothing: a dummy forward half)
+          } else {
             yn[tt] = 0.f;
 #pragma unroll
             for (int q = 0; q < S; q++) k[q][tt] = 0.f;
             k[S][tt] = is_l ? scr[tt] : 0.f;
           }
         }
-        // pass 1: the slopes k_1 … k_S (forward halves, through the scratch slot)
-#pragma unroll 1
-        for (int i = 0; i < S; i++) {
-          float src[2], dst[2];
-#pragma unroll
-          for (int tt = 0; tt < 2; tt++) src[tt] = is_z ? point(i, hh, tt) : 0.f;
-          eval(src, NST, dst, false);
-#pragma unroll
-          for (int q = 0; q < S; q++)
-            if (q == i && is_z) { k[q][0] = dst[0]; k[q][1] = dst[1]; }
-        }
-        if (is_z) { yn[0] = point(S, hh, 0); yn[1] = point(S, hh, 1); }
         // the save times inside the step (t_n, t_{n+1}]
         while (j >= 1 && sgpr_d(s_ts[j]) > ts_n) {   // (wave-uniform: kept scalar)
           const double tj = sgpr_d(s_ts[j]);
@@ -616,18 +656,25 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
           }
           j--;
         }
-        // pass 2: Jᵀk̄ at y_{n+1}, then at g_S … g_2 (fused evaluations; their vectors stay in ring slots 0 … S − 1 for the fold)
+        // S paired evaluations: vector-Jacobian half at y_{n+1} (slot sx), then at g_S … g_2 (vbank); forward half at the stage points 1 … S
+        // of step n − 1 (→ sz, fbank)
 #pragma unroll 1
-        for (int i = S; i >= 1; i--) {
+        for (int kk = 0; kk < S; kk++) {
+          const int i = S - kk;   // the stage whose k̄ is pulled back (i == S: the FSAL slope at y_{n+1})
           float src[2], dst[2];
 #pragma unroll
           for (int tt = 0; tt < 2; tt++) {
             float kb = 0.f;
 #pragma unroll
             for (int q = 0; q <= S; q++) kb = q == i ? k[q][tt] : kb;
-            src[tt] = is_z ? (i == S ? yn[tt] : point(i, hh, tt)) : kb;
+            src[tt] = is_z ? point(kk, hz, tt) : kb;
           }
-          eval(src, S - i, dst, true);
+          eval(src, kk == 0 ? sz : fbank + kk - 1, dst, true, kk == 0 ? sx : vbank + i - 1);
+          if (is_z) {
+#pragma unroll
+            for (int q = 0; q < S; q++)
+              if (q == kk) { k[q][0] = dst[0]; k[q][1] = dst[1]; }
+          }
           if (is_l) {
 #pragma unroll
             for (int tt = 0; tt < 2; tt++) {
@@ -650,6 +697,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
             }
           }
         }
+        fsx = sx;
         fold(S);
         if (is_l) {
 #pragma unroll
@@ -658,14 +706,21 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
             y[tt] = yn[tt];
           }
         }
-        nfe += 2 * S;
+        {   // the rebuilt step becomes the one to reverse: its first stage point is the next FSAL point
+          const int t3 = sx;
+          sx = sy; sy = sz; sz = t3;
+          const int tb = vbank;
+          vbank = fbank; fbank = tb;
+        }
+        nfe += S;
         nacc++;
       }
-      {   // k_1 of the first step = f(y_0)
+      {   // k_1 of the first step = f(y_0): its forward half ran as the first stage point of step 0 (slot sx by now)
         float src[2], dst[2];
 #pragma unroll
-        for (int tt = 0; tt < 2; tt++) src[tt] = is_z ? ((tt == 0 || two) ? a.z_out[(size_t)(bt0 + tt) * Dp + row] : 0.f) : (is_l ? scr[tt] : 0.f);
-        eval(src, 0, dst, true);
+        for (int tt = 0; tt < 2; tt++) src[tt] = is_z ? y[tt] : (is_l ? scr[tt] : 0.f);
+        eval(src, sz, dst, true, sx);
+        fsx = sx;
         fold(1);
         if (is_l) { y[0] -= dst[0]; y[1] -= dst[1]; }
         nfe++;

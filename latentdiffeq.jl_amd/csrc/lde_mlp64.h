@@ -715,9 +715,10 @@ __device__ __forceinline__ void mlp64_body(const MlpDims& dm, const KOpts& o, co
 // LDE_SENSE_DISCRETE on the same register layout (lde_mlpd.h has the algorithm; [REF examples/pendulum_friction-less/pendulum.jl:11],
 // [REF src/models/GOKU.jl:107, :121]): a wave sweeps its trajectory's recorded steps (t_n, dt_n, y_n) from the last to the first — pass 1
 // rebuilds the slopes k_1 … k_S with forward evaluations, the save times inside the step put their cotangents on y_n / the slopes /
-// y_{n+1}, pass 2 pulls k̄ through f at y_{n+1} and at g_S … g_2 (one fused forward + vector-Jacobian evaluation each, its (h₁, δ₂)
-// through ring slot S − i). The weight gradient is folded per step exactly as in the continuous adjoint, at weight 1 (the scale h·b_i is
-// inside k̄). 2S evaluations per accepted FORWARD step — c3: ≈ 160 per trajectory against ≈ 480 of the reverse-time solve.
+// y_{n+1}, pass 2 pulls k̄ through f at y_{n+1} and at g_S … g_2 (the vector-Jacobian half alone: the hidden units of every stage point
+// are lane-owned registers that pass 1 keeps, so no point is evaluated twice; (h₁, δ₂) through ring slot S − i). The weight gradient is folded per step exactly as in the continuous adjoint, at weight 1 (the scale h·b_i is
+// inside k̄). S forward + S vector-Jacobian halves per accepted FORWARD step — c3: ≈ 160 half-evaluations per trajectory against ≈ 480
+// fused ones of the reverse-time solve.
 template <int SOLVER, int DP>
 __device__ __forceinline__ void mlp64_disc_body(const MlpDims& dm, const KOpts& o, const VArgs& a) {
   const int T = o.T, B = o.B, D = dm.D, Dp = dm.Dp, NP = dm.P, lane = threadIdx.x & 63;
@@ -745,11 +746,15 @@ __device__ __forceinline__ void mlp64_disc_body(const MlpDims& dm, const KOpts& 
   for (int d = 0; d < DP; d++) g.w1[d] = g.w3[d] = g.b3[d] = g.pw1[d] = g.pw3[d] = g.pb3[d] = 0.f;
   g.b1 = g.b2 = g.pb1 = g.pb2 = 0.f;
 
-  // one fused evaluation at (z, k̄): vz = Jᵀk̄, the thin layers' gradient terms at weight 1, (h₁, δ₂) left in ring slot `slot`
-  auto vjp_at = [&](const float (&z)[DP], const float (&kb)[DP], int slot, float (&vz)[DP], float& gth) {
-    float f[DP], vth, d1, d2;
+  // the vector-Jacobian half at (z, k̄) with the hidden units (h1, h2) its forward evaluation produced (lane-owned registers: pass 1 keeps
+  // them per stage, so nothing is evaluated twice): vz = Jᵀk̄, the thin layers' gradient terms at weight 1, δ₂ into ring slot `slot` — whose h₁
+  // half pass 1 filled (put_h1: the FSAL point's, which belongs to the step before, is written here)
+  auto vjp_at = [&](const float (&z)[DP], const float (&kb)[DP], int slot, float h1, float h2, bool put_h1, float (&vz)[DP], float& gth) {
+    float vth, d1, d2;
     n.hx = s_hx + slot * 128;
-    net64_rhs<DP>(n, z, f);
+    n.h1 = h1;
+    n.h2 = h2;
+    if (put_h1) n.hx[lane] = h1;
     net64_vjp<DP>(n, z, kb, vz, vth, d1, d2);
     gth += vth;
 #pragma unroll
@@ -797,6 +802,7 @@ __device__ __forceinline__ void mlp64_disc_body(const MlpDims& dm, const KOpts& 
     if (status == 1 && T > 1) {
       int j = T - 1;
       double tnext = tend;
+      float h1f = 0.f, h2f = 0.f;   // hidden units at the FSAL point y_{n+1} of the step being reversed (= the first stage point of step n + 1)
 #pragma unroll 1
       for (int s = ns - 1; s >= 0; s--) {
         const double t = R.t[(size_t)s * B + b], dt = R.dt[(size_t)s * B + b];
@@ -823,13 +829,26 @@ __device__ __forceinline__ void mlp64_disc_body(const MlpDims& dm, const KOpts& 
             zp[r] = zv;
           }
         };
-        // ---- pass 1: the slopes (forward evaluations through the scratch slot)
-        n.hx = s_hx + 6 * 128;
+        // ---- pass 1: the slopes — forward evaluations; stage point i ≥ 1 leaves its h₁ in the ring slot its pullback will use (S − i) and
+        //      its hidden units in this lane's registers; the first one's (needed when step n − 1 is reversed) go through the scratch slot
+        float h1s[S], h2s[S];
 #pragma unroll
         for (int i = 0; i < S; i++) {
           float zp[DP];
           point(i, zp);
+          n.hx = s_hx + (i == 0 ? 6 : S - i) * 128;
           net64_rhs<DP>(n, zp, K[i]);
+          h1s[i] = n.h1;
+          h2s[i] = n.h2;
+        }
+        if (last) {   // the end state of the solve: the FSAL point of the last step
+          float zp[DP], fe[DP];
+          point(S, zp);
+          n.hx = s_hx + 6 * 128;
+          net64_rhs<DP>(n, zp, fe);
+          h1f = n.h1;
+          h2f = n.h2;
+          nfe++;
         }
         // ---- the save times inside the step
         float KB[S + 1][DP], ybn[DP];
@@ -880,7 +899,7 @@ __device__ __forceinline__ void mlp64_disc_body(const MlpDims& dm, const KOpts& 
         for (int i = S; i >= 1; i--) {
           float zp[DP], vz[DP];
           point(i, zp);
-          vjp_at(zp, KB[i], S - i, vz, gth);
+          vjp_at(zp, KB[i], S - i, i == S ? h1f : h1s[i < S ? i : 0], i == S ? h2f : h2s[i < S ? i : 0], i == S, vz, gth);
           if (i == S) {
 #pragma unroll
             for (int r = 0; r < DP; r++) {
@@ -905,11 +924,13 @@ __device__ __forceinline__ void mlp64_disc_body(const MlpDims& dm, const KOpts& 
           carry[r] = KB[0][r];
           yb[r] = ybn[r];
         }
+        h1f = h1s[0];   // this step's first stage point is the FSAL point of the step before it
+        h2f = h2s[0];
         nfe += 2 * S;
       }
-      {   // k_1 of the first step = f(y_0)
+      {   // k_1 of the first step = f(y_0): the first stage point of step 0, evaluated in the last iteration's pass 1
         float vz[DP];
-        vjp_at(y0, carry, 0, vz, gth);
+        vjp_at(y0, carry, 0, h1f, h2f, true, vz, gth);
         fold(1);
 #pragma unroll
         for (int r = 0; r < DP; r++) yb[r] += vz[r];

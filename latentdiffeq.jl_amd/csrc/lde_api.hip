@@ -32,7 +32,7 @@ int launch_pend_adjoint_par(int kind, int solver, const float* z_out, const floa
 bool pend_adjoint_needs_ops(int B, int T);
 int launch_pend_adjoint_disc(int kind, int solver, const float* z_out, const float* theta, const double* ts_dev, const KOpts& o,
                              const float* dz_out, float* dz0, float* dtheta, int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret,
-                             hipStream_t stream);
+                             hipStream_t stream, const PendTune& tn);
 struct MlpPlan;
 int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err);
 void mlp_plan_destroy(MlpPlan* p);
@@ -520,7 +520,7 @@ int lde_adjoint(lde_handle* h, const float* z_out, const float* theta, const dou
       return lde::mlp_adjoint(h->mlp, h->W_dev, z_out, theta, h->ts_dev, o, dz_out, dz0, dtheta, dW, st[0], st[1], st[2], st[3], stream,
                               h->err);
     rc = lde::launch_pend_adjoint_disc(h->d.rhs_kind, h->d.solver, z_out, theta, h->ts_dev, o, dz_out, dz0, dtheta, st[0], st[1], st[2],
-                                       st[3], stream);
+                                       st[3], stream, h->pend_tune);
     if (rc) h->err = "lde_adjoint: kernel launch failed";
     return rc;
   }
@@ -639,6 +639,7 @@ static int* option_slot(lde_handle* h, const char* key) {
   if (!std::strcmp(key, "pend_lb")) return &pt.lb_ring;
   if (!std::strcmp(key, "pend_lb_min_b")) return &pt.lb_min_b;
   if (!std::strcmp(key, "pend_lb_hold")) return &pt.lb_hold;
+  if (!std::strcmp(key, "pend_disc_tp_max_b")) return &pt.disc_tp_max_b;
   if (h->mlp) {
     lde::MlpTune& mt = *lde::mlp_tune(h->mlp);
     if (!std::strcmp(key, "mlp64")) return &mt.mlp64;

@@ -35,6 +35,7 @@ struct PendTune {
   int lb_ring = 16;           // "pend_lb": rows of the large-batch row ring (8 / 16 / 32; 0: off)
   int lb_min_b = 1 << 17;     // "pend_lb_min_b": the large-batch form from this batch on
   int lb_hold = -1;           // "pend_lb_hold": its hold margin (−1: half the ring)
+  int disc_tp_max_b = 16384;  // "pend_disc_tp_max_b": LDE_SENSE_DISCRETE pullback with a wave per trajectory (k_pend_adjoint_disc_tp) up to this batch
 };
 struct MlpTune {
   int mlp64 = 1, mlpv = 1, mlpw = 1, mlp4 = 1;   // "mlp64", "mlpv", "mlpw", "mlp4": 0 switches the family off

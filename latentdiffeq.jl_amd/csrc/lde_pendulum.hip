@@ -289,7 +289,7 @@ constexpr int WS_HELPERS = WS_WAVES - 1;
 constexpr int WS_THREADS = 64 * WS_WAVES;
 constexpr int WS_RW = 4;         // floats per record: {h, y₀, y₁ after the step, –}: 16 B per lane, conflict-free b128 / b64 accesses
 
-template <int KIND, int SOLVER, bool ADAPT>
+template <int KIND, int SOLVER, bool ADAPT, bool REC>   // REC: the instantiation that writes step records (LDE_SENSE_DISCRETE, "step_trace")
 __global__ void __launch_bounds__(WS_THREADS) k_pend_forward_ws(const float2* __restrict__ z0, const float* __restrict__ theta,
                                                          const double* __restrict__ ts_g, KOpts o,
                                                          float2* __restrict__ z_out, int32_t* __restrict__ retcode,
@@ -379,6 +379,8 @@ __global__ void __launch_bounds__(WS_THREADS) k_pend_forward_ws(const float2* __
         __syncthreads();   // B: the counts are reset, the base is in place
       }
       first_round = false;
+      const double t_round = t;   // (REC) where this round's first record starts
+      const f32x2 y_round = y;
       int wave_iters = 0;
       PPROF(2);
       // The stepping loop is the launch's critical path. What one wave pays for on gfx950 (abl/valu_rate.hip): 4 cycles per
@@ -464,6 +466,25 @@ __global__ void __launch_bounds__(WS_THREADS) k_pend_forward_ws(const float2* __
       if (__any(ret != LDE_RET_SUCCESS) && lane == 0) __hip_atomic_store(&s_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       asm volatile("" ::: "memory");
       if (lane == 0) __hip_atomic_store(&s_fin, more ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (REC) {
+        // The step records of this round (LDE_SENSE_DISCRETE / "step_trace"), written by the stepping wave while the helpers finish their
+        // dense output: every lane walks ITS records in the ring — start state = the step before's end, start time = the stepper's own
+        // f64 sum replayed — and the stores of a step are coalesced over the 64 trajectories.
+        const int i0 = nacc - n;
+        double tr = t_round;
+        f32x2 yr = y_round;
+        const float* rq = rec_at(0);
+        for (int i = 0; __any(i < n); i++, rq += 64 * WS_RW) {
+          const f32x4 q = *reinterpret_cast<const f32x4*>(rq);
+          if (valid && i < n && i0 + i < o.rec.cap) {
+            o.rec.t[(size_t)(i0 + i) * B + b] = tr;
+            o.rec.dt[(size_t)(i0 + i) * B + b] = (double)q[0];
+            reinterpret_cast<float2*>(o.rec.y)[(size_t)(i0 + i) * B + b] = make_float2(yr.x, yr.y);
+          }
+          tr += (double)q[0];
+          yr = f32x2{q[1], q[2]};
+        }
+      }
       if (!more) break;
       __syncthreads();   // A: the helpers have consumed this round's records
       s_cnt[lane] = 0;
@@ -481,6 +502,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_pend_forward_ws(const float2* __
       st_nfe[b] = nfe + NS * (nacc + nrej);
       st_nacc[b] = nacc;
       st_nrej[b] = nrej;
+      if (REC) o.rec.n[b] = ret == LDE_RET_SUCCESS ? nacc : 0;
     }
     PPROF(7);
     return;
@@ -855,7 +877,7 @@ constexpr int SH_NH = 3;         // helper waves
 #define LDE_PEND_SH_SLEEP 0
 #endif
 
-template <int KIND, int SOLVER, bool ADAPT>
+template <int KIND, int SOLVER, bool ADAPT, bool REC>   // REC: the instantiation that writes step records (LDE_SENSE_DISCRETE, "step_trace")
 __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restrict__ z0, const float* __restrict__ theta,
                                                          const double* __restrict__ ts_g, KOpts o,
                                                          float2* __restrict__ z_out, int32_t* __restrict__ retcode,
@@ -915,6 +937,8 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
     for (;;) {   // rounds
       int n = 0;
       float* rp = rec_at(0);
+      const double t_round = t;   // (REC) where this round's first record starts
+      const f32x2 y_round = y;
       // `go` (scalar): this round goes on. (k_pend_forward_tl carries it as a float penalty added to the error norm, because its lanes stop
       // one by one; here the wave stops as one, and inside the loop the penalty would be the constant 0: msq + 0 is msq, bit for bit.)
       // (attempts so far = nacc + nrej; `lim` = accepted steps this round may still record: the ring's capacity or what maxiters leaves,
@@ -994,6 +1018,27 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
       if (ret != LDE_RET_SUCCESS && lane == 0) __hip_atomic_store(&s_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       asm volatile("" ::: "memory");
       if (lane == 0) __hip_atomic_store(&s_fin, active ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (REC) {
+        // The step records (LDE_SENSE_DISCRETE / "step_trace") of this round, written by the stepping wave while the helpers finish their
+        // dense output (the stepper is done ≈ 2 µs before them): lane i = the round's step i, read back from the ring — start state = the
+        // step before's end, start time = the stepper's own running sum (replayed in its order: the same doubles).
+        const int i0 = nacc - n;
+        const bool mine = lane < n;
+        const f32x4 q = *reinterpret_cast<const f32x4*>(s_rec + (size_t)((mine ? lane : 0) * 64 + lane) * 4);
+        const f32x4 qp = *reinterpret_cast<const f32x4*>(s_rec + (size_t)((mine && lane > 0 ? lane - 1 : 0) * 64 + lane) * 4);
+        const f32x2 ys = lane == 0 ? y_round : f32x2{qp[0], qp[1]};
+        double tacc = t_round, ti = t_round;
+        const int hbits = __float_as_int(q[2]);
+        for (int i = 0; i < n; i++) {
+          if (lane == i) ti = tacc;
+          tacc += (double)__int_as_float(__builtin_amdgcn_readlane(hbits, i));
+        }
+        if (valid && mine && i0 + lane < o.rec.cap) {
+          o.rec.t[(size_t)(i0 + lane) * B + b] = ti;
+          o.rec.dt[(size_t)(i0 + lane) * B + b] = (double)q[2];
+          reinterpret_cast<float2*>(o.rec.y)[(size_t)(i0 + lane) * B + b] = make_float2(ys.x, ys.y);
+        }
+      }
       if (!active) break;
       __syncthreads();   // A: the helpers have consumed this round's records
       s_cnt[lane] = 0;
@@ -1013,7 +1058,7 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
       st_nfe[b] = nfe + NS * (nacc + nrej);
       st_nacc[b] = nacc;
       st_nrej[b] = nrej;
-      if (o.rec.n) o.rec.n[b] = ret == LDE_RET_SUCCESS ? nacc : 0;
+      if (REC) o.rec.n[b] = ret == LDE_RET_SUCCESS ? nacc : 0;
     }
     PPROF(11);
     return;
@@ -1042,11 +1087,6 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
         const f32x2 ye = {q[0], q[1]};
         const double t1 = (h == (float)(tend - tn)) ? tend : tn + (double)h;   // exactly the stepper's arithmetic
         const bool mine = (nrec % SH_NH) == hid;
-        if (o.rec.n && hid == 0 && lane == 0 && valid && nrec < o.rec.cap) {   // the step record (LDE_SENSE_DISCRETE), off the stepper's chain
-          o.rec.t[(size_t)nrec * B + b] = tn;
-          o.rec.dt[(size_t)nrec * B + b] = (double)h;
-          reinterpret_cast<float2*>(o.rec.y)[(size_t)nrec * B + b] = make_float2(ys.x, ys.y);
-        }
         if (__any(tj <= t1)) {
           f32x2 k0 = {0.f, 0.f}, kE = {0.f, 0.f}, P2 = {0.f, 0.f}, P3 = {0.f, 0.f}, P4 = {0.f, 0.f};
           float rh = 0.f;
@@ -1690,8 +1730,14 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
     const bool ad = o.adaptive != 0;
     const int g8 = ((o.B + 7) / 8) * 8;
 #define LDE_LAUNCH_SH(K, S, A)                                                                                          \
-  hipLaunchKernelGGL((k_pend_forward_sh<K, S, A>), dim3(g8), dim3(256), 0, stream, (const float2*)z0, theta, ts_dev, o,  \
-                     (float2*)z_out, retcode, nfe, nacc, nrej, ret)
+  do {                                                                                                                  \
+    if (o.rec.n)                                                                                                        \
+      hipLaunchKernelGGL((k_pend_forward_sh<K, S, A, true>), dim3(g8), dim3(256), 0, stream, (const float2*)z0, theta, ts_dev, o,  \
+                         (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                                \
+    else                                                                                                                \
+      hipLaunchKernelGGL((k_pend_forward_sh<K, S, A, false>), dim3(g8), dim3(256), 0, stream, (const float2*)z0, theta, ts_dev, o, \
+                         (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                                \
+  } while (0)
     if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5 && ad) LDE_LAUNCH_SH(0, LDE_SOLVER_TSIT5, true);
     else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH_SH(0, LDE_SOLVER_TSIT5, false);
     else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_RK4) LDE_LAUNCH_SH(0, LDE_SOLVER_RK4, false);
@@ -1702,7 +1748,7 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
 #undef LDE_LAUNCH_SH
     return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
   }
-  const bool recording = o.rec.n != nullptr;   // k_pend_forward_sh and k_pend_forward are the mappings that write step records
+  const bool recording = o.rec.n != nullptr;   // k_pend_forward_sh, k_pend_forward_ws and k_pend_forward are the mappings that write step records
   if (!recording && o.T > 1 && o.B <= tl_max_b) {
     const bool ad = o.adaptive != 0;
     const bool few = o.T - 1 <= 64;   // a lane serves exactly one save time: the variant without a load in the stepping loop
@@ -1725,20 +1771,26 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
 #undef LDE_LAUNCH_TL
     return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
   }
-  if (!recording && ws_on && shm && o.T > 2 && o.B <= ws_max_b) {
+  if (ws_on && shm && o.T > 2 && o.B <= ws_max_b) {   // (writes step records too)
     const size_t lds = (size_t)((o.T + 1) & ~1) * sizeof(double) + (size_t)WS_CAP * 64 * WS_RW * sizeof(float);
     const int g64 = (o.B + 63) / 64;
 #define LDE_LAUNCH_WS(K, S, A)                                                                                         \
   do {                                                                                                                 \
     static bool attr = false;                                                                                          \
     if (!attr) {                                                                                                       \
-      if (hipFuncSetAttribute((const void*)k_pend_forward_ws<K, S, A>, hipFuncAttributeMaxDynamicSharedMemorySize,     \
+      if (hipFuncSetAttribute((const void*)k_pend_forward_ws<K, S, A, false>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              160 * 1024 - 2048) != hipSuccess ||                                                       \
+          hipFuncSetAttribute((const void*)k_pend_forward_ws<K, S, A, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                               160 * 1024 - 2048) != hipSuccess)                                                         \
         return LDE_ERR_HIP;                                                                                            \
       attr = true;                                                                                                     \
     }                                                                                                                  \
-    hipLaunchKernelGGL((k_pend_forward_ws<K, S, A>), dim3(g64), dim3(WS_THREADS), lds, stream, (const float2*)z0, theta, ts_dev, \
-                       o, (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                              \
+    if (recording)                                                                                                     \
+      hipLaunchKernelGGL((k_pend_forward_ws<K, S, A, true>), dim3(g64), dim3(WS_THREADS), lds, stream, (const float2*)z0, theta, ts_dev, \
+                         o, (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                            \
+    else                                                                                                               \
+      hipLaunchKernelGGL((k_pend_forward_ws<K, S, A, false>), dim3(g64), dim3(WS_THREADS), lds, stream, (const float2*)z0, theta, ts_dev, \
+                         o, (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                            \
   } while (0)
     const bool ad = o.adaptive != 0;
     if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5 && ad) LDE_LAUNCH_WS(0, LDE_SOLVER_TSIT5, true);
@@ -2025,15 +2077,237 @@ __global__ void __launch_bounds__(256) k_pend_adjoint_disc(const float2* __restr
   st_nrej[b] = 0;
 }
 
+// LDE_SENSE_DISCRETE at small batches: the steps of a trajectory side by side. With the record every accepted step is a known map
+// y_n → y_{n+1} (and → the saves inside it), so its Jacobian needs nothing from its neighbours: a wave owns a trajectory, lanes (s, τ)
+// carry the tangent τ ∈ {∂/∂y_x, ∂/∂y_y, ∂/∂L} through step s — the forward kernel's stage points rebuilt from y_n, then
+//   G'_i = e_τ + h Σ a_iq K'_q,   K'_i = J_f(g_i) G'_i + ∂f/∂L(g_i)        (i = 0 … S; K'_S: the FSAL slope at y_{n+1})
+// — and contract it with the cotangents of the save times inside the step (the moment sums of the sequential kernel above):
+//   c_τ = Σ_j Δ_j · ∂ẑ_j/∂τ,   Y'_τ = ∂y_{n+1}/∂τ.
+// What is sequential is then three fused multiply-adds per step: (ȳ, dθ) ← ((ȳ + e_s)·Y'_x + c_x, (ȳ + e_s)·Y'_y + c_y, dθ + (ȳ + e_s)·Y'_θ + c_θ),
+// e_s = the cotangents of the saves ON the step's end, from the last step to the first — results pass between lanes by v_readlane.
+// 21 steps per round (63 lanes); longer records take further rounds from the top. Same derivative as k_pend_adjoint_disc (forward
+// instead of reverse accumulation inside a step: rounding differs, tests/test_gpu_discrete.py compares both with the oracle);
+// same failure semantics and statistics.
+constexpr int DTP_STEPS = 21;
+template <int KIND, int SOLVER>
+__global__ void __launch_bounds__(64) k_pend_adjoint_disc_tp(const float2* __restrict__ z_out, const float* __restrict__ theta,
+                                                             const double* __restrict__ ts_g, KOpts o,
+                                                             const float2* __restrict__ dz_out, float2* __restrict__ dz0,
+                                                             float* __restrict__ dtheta, int32_t* __restrict__ st_nfe,
+                                                             int32_t* __restrict__ st_nacc, int32_t* __restrict__ st_nrej,
+                                                             int32_t* __restrict__ st_ret) {
+  extern __shared__ __attribute__((aligned(16))) double s_lds[];   // the save grid [T] | this trajectory's Δẑ [T]
+  const int T = o.T, B = o.B, b = blockIdx.x, lane = threadIdx.x;
+  double* s_t = s_lds;
+  float2* s_d = reinterpret_cast<float2*>(s_lds + T);
+  constexpr int S = SOLVER == LDE_SOLVER_TSIT5 ? 6 : 4;
+  constexpr float RK[5][4] = {{0.f, 0.f, 0.f, 0.f}, {0.5f, 0.f, 0.f, 0.f}, {0.f, 0.5f, 0.f, 0.f}, {0.f, 0.f, 1.f, 0.f},
+                              {1.0f / 6.0f, 1.0f / 3.0f, 1.0f / 3.0f, 1.0f / 6.0f}};
+  auto A = [&](int i, int q) -> float { return SOLVER == LDE_SOLVER_TSIT5 ? ts5::A[i][q] : RK[i][q]; };
+  const StepRec& R = o.rec;
+  const int sl = (lane * 43) >> 7, tau = lane - 3 * sl;   // lane = 3·(step of the round) + tangent
+  PPROF(0);
+  // ---- everything whose address is known now: the save grid, Δẑ, the record's first round, the step count
+  const bool j0ok = lane < T;
+  const double tsv = j0ok ? ts_g[lane] : 0.0;
+  const float2 dv = j0ok ? dz_out[(size_t)lane * B + b] : make_float2(0.f, 0.f);
+  const int spec_ok = sl < DTP_STEPS && sl < R.cap;
+  double t0r = 0.0, dt0r = 0.0, tn0r = 0.0;
+  float2 y0r = make_float2(0.f, 0.f);
+  if (spec_ok) {
+    t0r = R.t[(size_t)sl * B + b];
+    dt0r = R.dt[(size_t)sl * B + b];
+    y0r = reinterpret_cast<const float2*>(R.y)[(size_t)sl * B + b];
+    if (sl + 1 < R.cap) tn0r = R.t[(size_t)(sl + 1) * B + b];
+  }
+  const int ns = __builtin_amdgcn_readfirstlane(R.n[b]);
+  const float L = theta[b];
+  const float2 y0 = z_out[b];
+  if (j0ok) {
+    s_t[lane] = tsv;
+    s_d[lane] = dv;
+  }
+  for (int j = lane + 64; j < T; j += 64) {
+    s_t[j] = ts_g[j];
+    s_d[j] = dz_out[(size_t)j * B + b];
+  }
+  __syncthreads();
+  PPROF(1);
+  const float ngl = -10.0f / L, gl2 = 10.0f / (L * L);
+  int ret = LDE_RET_SUCCESS;
+  if (!isfinite(y0.x) || !isfinite(y0.y)) ret = LDE_RET_NONFINITE;      // a failed forward trajectory: zero gradient [REF GOKU.jl:114]
+  else if (T > 1 && (ns < 1 || ns > R.cap)) ret = LDE_RET_MAXITERS;      // no usable record: NaN gradient (never a truncated sweep)
+  float ax = 0.f, ay = 0.f, gth = 0.f;   // wave-uniform: the cotangent below the steps done so far, dθ
+  if (ret == LDE_RET_SUCCESS && T > 1) {
+    const double tbeg = s_t[0], tend = s_t[T - 1];
+    const float jscale = (float)(T - 1) / (float)(tend - tbeg);   // where a uniform grid would have a save time (a first guess only)
+    const float e0x = tau == 0 ? 1.f : 0.f, e0y = tau == 1 ? 1.f : 0.f, pth = tau == 2 ? gl2 : 0.f;
+    for (int r = (ns - 1) / DTP_STEPS; r >= 0; r--) {
+      const int s = r * DTP_STEPS + sl;
+      const bool act = sl < DTP_STEPS && s < ns;
+      double t = t0r, dt = dt0r, tnew = tn0r;
+      float2 yv = y0r;
+      if (r > 0 && act) {
+        t = R.t[(size_t)s * B + b];
+        dt = R.dt[(size_t)s * B + b];
+        yv = reinterpret_cast<const float2*>(R.y)[(size_t)s * B + b];
+        if (s + 1 < ns) tnew = R.t[(size_t)(s + 1) * B + b];
+      }
+      const bool last = s == ns - 1;
+      if (last) tnew = tend;
+      if (!act) {
+        yv = make_float2(0.f, 0.f);
+        dt = 0.0;
+      }
+      const float h = (float)dt;
+      // ---- the stage points again (the forward kernel's arithmetic on its inputs) and tangent τ through them
+      const float noff = turn_anchor(yv.x);
+      float gx[S + 1], gy[S + 1], kx[S], ky[S], sn, cs;
+      float Kx[S + 1], Ky[S + 1], Yx = 0.f, Yy = 0.f;
+      gx[0] = yv.x;
+      gy[0] = yv.y;
+#pragma unroll
+      for (int i = 0; i <= S; i++) {
+        float Gx = e0x, Gy = e0y;
+        if (i > 0) {
+          if (SOLVER == LDE_SOLVER_RK4 && i == S) {   // the forward kernel's own form of the RK4 update
+            const float h6 = h * (1.0f / 6.0f);
+            gx[i] = yv.x + h6 * (kx[0] + 2.0f * (kx[1] + kx[2]) + kx[3]);
+            gy[i] = yv.y + h6 * (ky[0] + 2.0f * (ky[1] + ky[2]) + ky[3]);
+            Gx = e0x + h6 * (Kx[0] + 2.0f * (Kx[1] + Kx[2]) + Kx[3]);
+            Gy = e0y + h6 * (Ky[0] + 2.0f * (Ky[1] + Ky[2]) + Ky[3]);
+          } else {
+            float ax_ = A(i, 0) * kx[0], ay_ = A(i, 0) * ky[0], tx = A(i, 0) * Kx[0], ty = A(i, 0) * Ky[0];
+#pragma unroll
+            for (int q = 1; q < i; q++) {
+              ax_ += A(i, q) * kx[q];
+              ay_ += A(i, q) * ky[q];
+              if (A(i, q) != 0.f) {
+                tx += A(i, q) * Kx[q];
+                ty += A(i, q) * Ky[q];
+              }
+            }
+            gx[i] = yv.x + h * ax_;
+            gy[i] = yv.y + h * ay_;
+            Gx = e0x + h * tx;
+            Gy = e0y + h * ty;
+          }
+        }
+        hw_sincos(gx[i], sn, cs, noff);
+        if (i < S) {
+          kx[i] = gy[i];
+          float acc = ngl * sn;
+          if (KIND == 1) acc -= 0.7f * gy[i];
+          ky[i] = acc;
+        }
+        Kx[i] = Gy;                              // J = [[0, 1], [ngl cos x, −b/m]], ∂f₂/∂L = gl2 sin x
+        float kt = (ngl * cs) * Gx + pth * sn;
+        if (KIND == 1) kt -= 0.7f * Gy;
+        Ky[i] = kt;
+        if (i == S) {
+          Yx = Gx;
+          Yy = Gy;
+        }
+      }
+      PPROF(2);
+      // ---- the save times in (t, tnew]: on the step's end → e_s; inside → the interpolant's weights
+      float ex = 0.f, ey = 0.f, ynx = 0.f, yny = 0.f;
+      float c1x = 0.f, c1y = 0.f, c2x = 0.f, c2y = 0.f, c3x = 0.f, c3y = 0.f, c4x = 0.f, c4y = 0.f;   // Tsit5: moments of Θ; RK4: the four Hermite sums
+      if (act) {
+        int j = (int)((float)(tnew - tbeg) * jscale);
+        j = j < 0 ? 0 : (j > T - 1 ? T - 1 : j);
+        while (j < T - 1 && s_t[j + 1] <= tnew) j++;
+        while (j > 0 && s_t[j] > tnew) j--;
+        const float rh = fast_rcp(h);
+        for (; j >= 1; j--) {
+          const double tj = s_t[j];
+          if (!(tj > t)) break;
+          const float2 dj = s_d[j];
+          if (tj >= tnew || (j == T - 1 && last)) {
+            ex += dj.x;
+            ey += dj.y;
+          } else {
+            const float th = (float)(tj - t) * rh;
+            if (SOLVER == LDE_SOLVER_TSIT5) {
+              ynx += dj.x;
+              yny += dj.y;
+              const float t2 = th * th, t3 = t2 * th, t4 = t2 * t2;
+              c1x += th * dj.x; c1y += th * dj.y;
+              c2x += t2 * dj.x; c2y += t2 * dj.y;
+              c3x += t3 * dj.x; c3y += t3 * dj.y;
+              c4x += t4 * dj.x; c4y += t4 * dj.y;
+            } else {   // cubic Hermite on (y_n, k₁, y_{n+1}, f(y_{n+1}))
+              const float om = 1.0f - th;
+              const float h00 = (1.0f + 2.0f * th) * om * om, h10 = th * om * om;
+              const float h01 = th * th * (3.0f - 2.0f * th), h11 = th * th * (th - 1.0f);
+              ynx += h00 * dj.x; yny += h00 * dj.y;
+              c1x += (h10 * h) * dj.x; c1y += (h10 * h) * dj.y;
+              c2x += h01 * dj.x; c2y += h01 * dj.y;
+              c3x += (h11 * h) * dj.x; c3y += (h11 * h) * dj.y;
+            }
+          }
+        }
+      }
+      PPROF(3);
+      float c = ynx * e0x + yny * e0y;
+      if (SOLVER == LDE_SOLVER_TSIT5) {   // k̄_i = h Σ_j b_i(Θ_j) Δ_j, b_1 = Θ + r₁₂Θ² + r₁₃Θ³ + r₁₄Θ⁴, b_i = r_i2Θ² + r_i3Θ³ + r_i4Θ⁴
+        const float b0x = h * (c1x + ts5::R1[0] * c2x + ts5::R1[1] * c3x + ts5::R1[2] * c4x);
+        const float b0y = h * (c1y + ts5::R1[0] * c2y + ts5::R1[1] * c3y + ts5::R1[2] * c4y);
+        c += b0x * Kx[0] + b0y * Ky[0];
+#pragma unroll
+        for (int i = 0; i < 6; i++) {
+          const float bx = h * (ts5::R[i][0] * c2x + ts5::R[i][1] * c3x + ts5::R[i][2] * c4x);
+          const float by = h * (ts5::R[i][0] * c2y + ts5::R[i][1] * c3y + ts5::R[i][2] * c4y);
+          c += bx * Kx[i + 1] + by * Ky[i + 1];
+        }
+      } else {
+        c += c1x * Kx[0] + c1y * Ky[0] + c2x * Yx + c2y * Yy + c3x * Kx[S] + c3y * Ky[S];
+      }
+      PPROF(4);
+      // ---- the sweep: three multiply-adds per step, results handed on by v_readlane
+      const int cnt = min(DTP_STEPS, ns - r * DTP_STEPS);
+      for (int it = cnt - 1; it >= 0; it--) {
+        const float rr = __builtin_fmaf(ax + ex, Yx, __builtin_fmaf(ay + ey, Yy, c));
+        const float nx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rr), 3 * it));
+        const float ny = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rr), 3 * it + 1));
+        gth += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rr), 3 * it + 2));
+        ax = nx;
+        ay = ny;
+      }
+    }
+  }
+  PPROF(5);
+  if (lane == 0) {
+    const float2 d0 = s_d[0];   // save time 0 is ẑ₀ itself
+    const float qn = __int_as_float(0x7fc00000);
+    const bool ok = ret == LDE_RET_SUCCESS, nanout = ret == LDE_RET_MAXITERS;
+    dz0[b] = ok ? make_float2(ax + d0.x, ay + d0.y) : (nanout ? make_float2(qn, qn) : make_float2(0.f, 0.f));
+    dtheta[b] = ok ? gth : (nanout ? qn : 0.f);
+    st_ret[b] = ret;
+    const int nst = ok && T > 1 ? ns : 0;
+    st_nfe[b] = nst * (2 * S + 1) + (nst ? 1 : 0);
+    st_nacc[b] = nst;
+    st_nrej[b] = 0;
+  }
+}
+
 int launch_pend_adjoint_disc(int kind, int solver, const float* z_out, const float* theta, const double* ts_dev, const KOpts& o,
                              const float* dz_out, float* dz0, float* dtheta, int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret,
-                             hipStream_t stream) {
+                             hipStream_t stream, const PendTune& tn) {
   if (!o.rec.n || !o.rec.y) return LDE_ERR_INVALID_ARG;
   const int block = pick_block(o.B), grid = (o.B + block - 1) / block;
   const size_t shm = o.T <= TS_LDS_MAX ? (size_t)o.T * sizeof(double) : 0;
+  // the steps side by side (a wave per trajectory) while the chip has waves to spare: option "pend_disc_tp_max_b"
+  const bool tp = o.T > 1 && o.T <= 4096 && o.B <= tn.disc_tp_max_b;
 #define LDE_LAUNCH(K, S)                                                                                                         \
-  hipLaunchKernelGGL((k_pend_adjoint_disc<K, S>), dim3(grid), dim3(block), shm, stream, (const float2*)z_out, theta, ts_dev, o, \
-                     (const float2*)dz_out, (float2*)dz0, dtheta, nfe, nacc, nrej, ret)
+  do {                                                                                                                           \
+    if (tp)                                                                                                                      \
+      hipLaunchKernelGGL((k_pend_adjoint_disc_tp<K, S>), dim3(o.B), dim3(64), (size_t)o.T * 16, stream, (const float2*)z_out, theta, ts_dev, o, \
+                         (const float2*)dz_out, (float2*)dz0, dtheta, nfe, nacc, nrej, ret);                                     \
+    else                                                                                                                         \
+      hipLaunchKernelGGL((k_pend_adjoint_disc<K, S>), dim3(grid), dim3(block), shm, stream, (const float2*)z_out, theta, ts_dev, o, \
+                         (const float2*)dz_out, (float2*)dz0, dtheta, nfe, nacc, nrej, ret);                                     \
+  } while (0)
   if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH(0, LDE_SOLVER_TSIT5);
   else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_RK4) LDE_LAUNCH(0, LDE_SOLVER_RK4);
   else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH(1, LDE_SOLVER_TSIT5);

@@ -100,15 +100,70 @@ def _check(nat, od, o32, o64, z0, theta, ts, dz, W, z_tol=Z_TOL, g_tol=G_TOL, ch
     (O.RHS_PENDULUM, O.SOLVER_RK4, 80),              # fixed steps that do not hit the save times: the Hermite interpolant's pullback
     (O.RHS_PENDULUM_FRICTION, O.SOLVER_RK4, 300),
 ])
-def test_goku_discrete_matches_oracle_on_the_same_steps(o32, o64, kind, solver, B):
+@pytest.mark.parametrize("mapping", ["steps_side_by_side", "lane_per_trajectory"])
+def test_goku_discrete_matches_oracle_on_the_same_steps(o32, o64, kind, solver, B, mapping):
+    """Both mappings of the pullback: k_pend_adjoint_disc_tp (a wave per trajectory, lanes = steps × tangents: the default up to
+    option "pend_disc_tp_max_b") and k_pend_adjoint_disc (a lane per trajectory, reverse accumulation)."""
     kw = dict(rhs_kind=kind, solver=solver)
     if solver == O.SOLVER_RK4:
         kw.update(adaptive=0, dt=0.13)
     nat, od = _native(None, **kw)
+    if mapping == "lane_per_trajectory":
+        nat.set_option("pend_disc_tp_max_b", 0)
     z0, L = O.pendulum_inputs(B, seed=3)
     ts = O.time_grid(50)
     dz = O.cotangent(50, B, 2)
     _check(nat, od, o32, o64, z0, L, ts, dz, None)
+
+
+@pytest.mark.parametrize("B,options,tol", [
+    (200, {}, 1e-6),                                       # k_pend_forward_sh: a trajectory per workgroup, the stepping wave writes the round's records
+    (200, {"pend_sh_max_b": 0}, 1e-6),                     # k_pend_forward_ws: 64 trajectories per workgroup, each stepper lane its own records
+    (1000, {}, 1e-6),                                      # (the default at this batch)
+    (1000, {"pend_ws": 0}, 1e-6),                          # k_pend_forward: a lane per trajectory, records at accept
+    (200, {"record_capacity": 64}, 1e-8),                  # ≈ 150 steps: records from several rounds of the ring (48 per round), then overflow → see below
+    (200, {"pend_sh_max_b": 0, "record_capacity": 512}, 1e-8),   # several rounds of k_pend_forward_ws's ring (96 per round)
+])
+def test_goku_discrete_every_recording_forward_mapping(o32, o64, B, options, tol):
+    """Every forward mapping that writes step records: the record reproduces the kernel's own solve in the oracle (|Δẑ| ≤ 2e-5 on the
+    recorded steps — a wrong start time or start state of a single step would show) and the pullback on it matches."""
+    nat, od = _native(None, abstol=tol, reltol=tol)
+    for k, v in options.items():
+        nat.set_option(k, v)
+    z0, L = O.pendulum_inputs(B, seed=9)
+    ts = O.time_grid(50)
+    dz = O.cotangent(50, B, 2)
+    if options.get("record_capacity") == 64:               # too small for this solve: NaN gradients, never a truncated sweep
+        z, ret, st = nat.forward(z0, L, ts)
+        g0, gth, _, sb = nat.adjoint(z, L, ts, dz)
+        assert st["max_steps"] > 64 and np.isnan(g0).any()
+        nat.set_option("record_capacity", 512)
+    _, rec, _, st, _ = _check(nat, od, o32, o64, z0, L, ts, dz, None)
+    if tol < 1e-7:
+        assert int(rec["n"].max()) > 96
+
+
+@pytest.mark.parametrize("kind,solver", [(O.RHS_PENDULUM, O.SOLVER_TSIT5), (O.RHS_PENDULUM_FRICTION, O.SOLVER_TSIT5), (O.RHS_PENDULUM, O.SOLVER_RK4)])
+def test_goku_discrete_long_records_and_ragged_save_grids(o32, o64, kind, solver):
+    """Records longer than one round of the steps-side-by-side kernel (21 steps per round; here 60 … 200), 150 save times on a ragged
+    grid (several per step, some steps with none, more save times than lanes), both mappings against the oracle and each other."""
+    B, T = 70, 150
+    rng = np.random.default_rng(11)
+    ts = np.concatenate([[0.0], np.cumsum(rng.uniform(0.002, 0.05, T - 1) * rng.choice([1.0, 1.0, 4.0], T - 1))])
+    kw = dict(rhs_kind=kind, solver=solver, abstol=1e-8, reltol=1e-8)
+    if solver == O.SOLVER_RK4:
+        kw.update(adaptive=0, dt=0.031)
+    z0, L = O.pendulum_inputs(B, seed=4)
+    dz = O.cotangent(T, B, 2)
+    out = []
+    for tp in (1 << 20, 0):
+        nat, od = _native(None, **kw)
+        nat.set_option("pend_disc_tp_max_b", tp)
+        nat.set_option("record_capacity", 512)
+        _, rec, g, st, sb = _check(nat, od, o32, o64, z0, L, ts, dz, None)
+        assert int(rec["n"].max()) > 42
+        out.append(g)
+    assert _rel(out[0][0], out[1][0]) <= 1e-5 and _rel(out[0][1], out[1][1]) <= 1e-5
 
 
 def test_goku_discrete_agrees_with_the_continuous_adjoint_to_solver_tolerance(o64):

@@ -4,7 +4,16 @@ cycle stamps of workgroup 0 from a -DLDE_PEND_PROF=1 build.
     python abl/disc_tp_prof.py            (on the GPU box; uses / builds abl/liblde_pprof.so)
 
 Stamps: 0 entry, 1 loads landed (save grid and Δẑ in LDS, the record's first round in registers), 2 stage points and the tangent through
-them done, 3 save times contracted, 4 c_τ formed, 5 sweep done. With several rounds (records longer than 21 steps) 2–4 are the last round's."""
+them done, 3 save times contracted (the three lanes' shares added up), 4 c_τ formed, 6 the step maps gathered (lane p = step p), 7 the four
+scan levels done, 5 sweep done. The compiler moves arithmetic across the stamps (most of c_τ lands behind stamp 4), so the split between
+neighbouring phases is approximate; the sum is not. With several rounds (records longer than 21 steps) 2–7 are the last round's.
+
+Round 5, B = 256 (µs, shader clock 2.3 GHz): loads 0.62, tangent 0.49, save times 0.85, c_τ + gather 0.6, scan 0.23, rest 0.17: 2.96 from entry
+to the sweep's end, 4.5 per launch back to back. What was tried on the way (each measured with this script):
+  the sweep as a chain of 21 map applications — value passed by v_readlane → scalar → VALU: 92 cycles per step; by DPP wave_shl:1: 100; by DPP
+  row_shl:1 within rows: 110 (one wave per SIMD: every dependent instruction's latency is exposed) — as a suffix scan of the maps: 530 cycles;
+  the save times of a step walked by every one of its three lanes: 2700 cycles (the longest step of the trajectory decides: 3 round trips
+  of 4) — shared between the three lanes and added up in LDS: 2000."""
 import ctypes as C
 import os
 import subprocess
@@ -54,10 +63,11 @@ v = np.array(rows[10:]).astype(np.float64)
 wall = lambda i: v[:, 2 * i]
 cyc = lambda i: v[:, 2 * i + 1]
 names = ["loads (grid, cotangents, record) + LDS fill", "stage points + tangent through the step", "save times of the step contracted",
-         "c_tau from the slopes' tangents", "sweep over the steps (v_readlane chain)"]
+         "c_tau from the slopes' tangents", "sweep over the steps (gather, suffix scan, dθ)"]
 print(f"k_pend_adjoint_disc_tp, B = {B}, workgroup 0")
 for i, nm in enumerate(names):
     print(f"  {nm:48s} {(cyc(i + 1) - cyc(i)).mean():8.0f} cycles {(wall(i + 1) - wall(i)).mean() * 10 / 1e3:6.2f} us")
+print(f"    of the sweep: gather {(cyc(6) - cyc(4)).mean():.0f}, four scan levels {(cyc(7) - cyc(6)).mean():.0f}, rest {(cyc(5) - cyc(7)).mean():.0f} cycles")
 print(f"  entry → sweep done                               {(cyc(5) - cyc(0)).mean():8.0f} cycles {(wall(5) - wall(0)).mean() * 10 / 1e3:6.2f} us")
 for name, fn in (("lde_adjoint", lambda: lib.lde_adjoint(h, p(zo), p(thd), tsp, T, B, p(dz), p(g0), p(gth), None, C.c_void_p())),
                  ("lde_forward (recording)", lambda: lib.lde_forward(h, p(z0d), p(thd), tsp, T, B, p(zo), p(ret), C.c_void_p()))):

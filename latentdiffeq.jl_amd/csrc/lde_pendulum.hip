@@ -2089,6 +2089,17 @@ __global__ void __launch_bounds__(256) k_pend_adjoint_disc(const float2* __restr
 // instead of reverse accumulation inside a step: rounding differs, tests/test_gpu_discrete.py compares both with the oracle);
 // same failure semantics and statistics.
 constexpr int DTP_STEPS = 21;
+__device__ __forceinline__ float dtp_from_lane(float v, int src) {   // lane ℓ ← v of lane src(ℓ) (ds_bpermute_b32: through the LDS crossbar, no LDS memory)
+  return __int_as_float(__builtin_amdgcn_ds_bpermute(src << 2, __float_as_int(v)));
+}
+template <int CTRL>
+__device__ __forceinline__ float dtp_row_dpp(float v, float edge) {   // DPP row_shl:n (CTRL = 0x100 + n): lane ℓ ← v of lane ℓ + n of its row of 16, `edge` beyond the row
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(edge), __float_as_int(v), CTRL, 0xf, 0xf, false));
+}
+template <int CTRL>
+__device__ __forceinline__ float dtp_dpp_add(float v) {
+  return v + __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
 template <int KIND, int SOLVER>
 __global__ void __launch_bounds__(64) k_pend_adjoint_disc_tp(const float2* __restrict__ z_out, const float* __restrict__ theta,
                                                              const double* __restrict__ ts_g, KOpts o,
@@ -2096,10 +2107,15 @@ __global__ void __launch_bounds__(64) k_pend_adjoint_disc_tp(const float2* __res
                                                              float* __restrict__ dtheta, int32_t* __restrict__ st_nfe,
                                                              int32_t* __restrict__ st_nacc, int32_t* __restrict__ st_nrej,
                                                              int32_t* __restrict__ st_ret) {
-  extern __shared__ __attribute__((aligned(16))) double s_lds[];   // the save grid [T] | this trajectory's Δẑ [T]
-  const int T = o.T, B = o.B, b = blockIdx.x, lane = threadIdx.x;
+  extern __shared__ __attribute__((aligned(16))) double s_lds[];   // the save grid [T] | this trajectory's Δẑ [T] | partial sums [66][12]
+  const int T = o.T, B = o.B, lane = threadIdx.x;
+  // trajectory ↔ workgroup as in k_pend_forward_sh (the grid is a multiple of 8): the workgroup lands on the XCD whose L2 holds the
+  // record and the ẑ the forward launch wrote for this trajectory
+  const int b = (blockIdx.x & 7) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+  if (b >= B) return;
   double* s_t = s_lds;
   float2* s_d = reinterpret_cast<float2*>(s_lds + T);
+  float* s_red = reinterpret_cast<float*>(s_lds + 2 * T);   // [66][12]: where the three lanes of a step add up their shares of its save times (lane 63 reads rows 63 … 65)
   constexpr int S = SOLVER == LDE_SOLVER_TSIT5 ? 6 : 4;
   constexpr float RK[5][4] = {{0.f, 0.f, 0.f, 0.f}, {0.5f, 0.f, 0.f, 0.f}, {0.f, 0.5f, 0.f, 0.f}, {0.f, 0.f, 1.f, 0.f},
                               {1.0f / 6.0f, 1.0f / 3.0f, 1.0f / 3.0f, 1.0f / 6.0f}};
@@ -2140,7 +2156,7 @@ __global__ void __launch_bounds__(64) k_pend_adjoint_disc_tp(const float2* __res
   float ax = 0.f, ay = 0.f, gth = 0.f;   // wave-uniform: the cotangent below the steps done so far, dθ
   if (ret == LDE_RET_SUCCESS && T > 1) {
     const double tbeg = s_t[0], tend = s_t[T - 1];
-    const float jscale = (float)(T - 1) / (float)(tend - tbeg);   // where a uniform grid would have a save time (a first guess only)
+    const double jscale = (double)(T - 1) / (tend - tbeg);   // where a uniform grid would have a save time (a first guess, checked)
     const float e0x = tau == 0 ? 1.f : 0.f, e0y = tau == 1 ? 1.f : 0.f, pth = tau == 2 ? gl2 : 0.f;
     for (int r = (ns - 1) / DTP_STEPS; r >= 0; r--) {
       const int s = r * DTP_STEPS + sl;
@@ -2211,43 +2227,93 @@ __global__ void __launch_bounds__(64) k_pend_adjoint_disc_tp(const float2* __res
       }
       PPROF(2);
       // ---- the save times in (t, tnew]: on the step's end → e_s; inside → the interpolant's weights
-      float ex = 0.f, ey = 0.f, ynx = 0.f, yny = 0.f;
-      float c1x = 0.f, c1y = 0.f, c2x = 0.f, c2y = 0.f, c3x = 0.f, c3y = 0.f, c4x = 0.f, c4y = 0.f;   // Tsit5: moments of Θ; RK4: the four Hermite sums
+      // (One wave per SIMD: nothing hides a dependent instruction's latency but the wave's own independent instructions. So the four save
+      //  times of a round trip are four independent, branch-free bodies — a save time outside the step enters with weight zero — on
+      //  register pairs (x, y); only the ten running sums chain from body to body.)
+      f32x2 ev = {0.f, 0.f}, ynv = {0.f, 0.f}, c1 = {0.f, 0.f}, c2 = {0.f, 0.f}, c3 = {0.f, 0.f}, c4 = {0.f, 0.f};   // Tsit5: moments of Θ; RK4: the four Hermite sums
       if (act) {
-        int j = (int)((float)(tnew - tbeg) * jscale);
+        // the last save time ≤ tnew: where a uniform grid has it (exact there: the index in f64 with a margin far below a grid spacing),
+        // checked against the grid itself in the round trip that also fetches the first four save times below it
+        int j = (int)((tnew - tbeg) * jscale + 1e-6);
         j = j < 0 ? 0 : (j > T - 1 ? T - 1 : j);
-        while (j < T - 1 && s_t[j + 1] <= tnew) j++;
-        while (j > 0 && s_t[j] > tnew) j--;
         const float rh = fast_rcp(h);
-        for (; j >= 1; j--) {
-          const double tj = s_t[j];
-          if (!(tj > t)) break;
-          const float2 dj = s_d[j];
-          if (tj >= tnew || (j == T - 1 && last)) {
-            ex += dj.x;
-            ey += dj.y;
-          } else {
+        double tq[4];
+        f32x2 dq[4];
+        auto fetch = [&]() {
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int jj = j - 3 * u > 0 ? j - 3 * u : 0;
+            tq[u] = s_t[jj];
+            dq[u] = *reinterpret_cast<const f32x2*>(&s_d[jj]);
+          }
+        };
+        {
+          const double ttop = s_t[j], tup = s_t[j < T - 1 ? j + 1 : j];
+          const bool ragged = !(ttop <= tnew && (j == T - 1 || tup > tnew));
+          j -= tau;   // the step's three lanes share its save times: lane τ takes the τ-th, (τ + 3)-th, … from the last one down
+          fetch();
+          if (__builtin_expect(ragged, 0)) {   // (a ragged grid: walk to it)
+            j += tau;
+            while (j < T - 1 && s_t[j + 1] <= tnew) j++;
+            while (j > 0 && s_t[j] > tnew) j--;
+            j -= tau;
+            fetch();
+          }
+        }
+        for (;;) {
+          bool in = false;
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const double tj = tq[u];
+            in = j - 3 * u >= 1 && tj > t;                   // (the grid ascends: once false, false for every save time below)
+            const bool end = tj >= tnew || (j - 3 * u == T - 1 && last);
+            const f32x2 zero = {0.f, 0.f};
+            const f32x2 de = in && end ? dq[u] : zero, di = in && !end ? dq[u] : zero;
             const float th = (float)(tj - t) * rh;
+            ev += de;
             if (SOLVER == LDE_SOLVER_TSIT5) {
-              ynx += dj.x;
-              yny += dj.y;
               const float t2 = th * th, t3 = t2 * th, t4 = t2 * t2;
-              c1x += th * dj.x; c1y += th * dj.y;
-              c2x += t2 * dj.x; c2y += t2 * dj.y;
-              c3x += t3 * dj.x; c3y += t3 * dj.y;
-              c4x += t4 * dj.x; c4y += t4 * dj.y;
+              ynv += di;
+              c1 += th * di;
+              c2 += t2 * di;
+              c3 += t3 * di;
+              c4 += t4 * di;
             } else {   // cubic Hermite on (y_n, k₁, y_{n+1}, f(y_{n+1}))
               const float om = 1.0f - th;
               const float h00 = (1.0f + 2.0f * th) * om * om, h10 = th * om * om;
               const float h01 = th * th * (3.0f - 2.0f * th), h11 = th * th * (th - 1.0f);
-              ynx += h00 * dj.x; yny += h00 * dj.y;
-              c1x += (h10 * h) * dj.x; c1y += (h10 * h) * dj.y;
-              c2x += h01 * dj.x; c2y += h01 * dj.y;
-              c3x += (h11 * h) * dj.x; c3y += (h11 * h) * dj.y;
+              ynv += h00 * di;
+              c1 += (h10 * h) * di;
+              c2 += h01 * di;
+              c3 += (h11 * h) * di;
             }
           }
+          if (!in) break;
+          j -= 12;
+          fetch();
         }
       }
+      {   // the three lanes' partial sums meet in LDS (a wave's LDS operations execute in order) and are added in the order τ = 0, 1, 2
+        float* rw = s_red + lane * 12;
+        *reinterpret_cast<f32x4*>(rw) = f32x4{ev.x, ev.y, ynv.x, ynv.y};
+        *reinterpret_cast<f32x4*>(rw + 4) = f32x4{c1.x, c1.y, c2.x, c2.y};
+        *reinterpret_cast<f32x4*>(rw + 8) = f32x4{c3.x, c3.y, c4.x, c4.y};
+        __syncthreads();
+        const float* rr = s_red + (lane - tau) * 12;
+        f32x4 q0 = *reinterpret_cast<const f32x4*>(rr), q1 = *reinterpret_cast<const f32x4*>(rr + 4), q2 = *reinterpret_cast<const f32x4*>(rr + 8);
+#pragma unroll
+        for (int g = 1; g < 3; g++) {
+          q0 += *reinterpret_cast<const f32x4*>(rr + 12 * g);
+          q1 += *reinterpret_cast<const f32x4*>(rr + 12 * g + 4);
+          q2 += *reinterpret_cast<const f32x4*>(rr + 12 * g + 8);
+        }
+        __syncthreads();
+        ev = f32x2{q0[0], q0[1]}; ynv = f32x2{q0[2], q0[3]};
+        c1 = f32x2{q1[0], q1[1]}; c2 = f32x2{q1[2], q1[3]};
+        c3 = f32x2{q2[0], q2[1]}; c4 = f32x2{q2[2], q2[3]};
+      }
+      const float ex = ev.x, ey = ev.y, ynx = ynv.x, yny = ynv.y;
+      const float c1x = c1.x, c1y = c1.y, c2x = c2.x, c2y = c2.y, c3x = c3.x, c3y = c3.y, c4x = c4.x, c4y = c4.y;
       PPROF(3);
       float c = ynx * e0x + yny * e0y;
       if (SOLVER == LDE_SOLVER_TSIT5) {   // k̄_i = h Σ_j b_i(Θ_j) Δ_j, b_1 = Θ + r₁₂Θ² + r₁₃Θ³ + r₁₄Θ⁴, b_i = r_i2Θ² + r_i3Θ³ + r_i4Θ⁴
@@ -2264,15 +2330,55 @@ __global__ void __launch_bounds__(64) k_pend_adjoint_disc_tp(const float2* __res
         c += c1x * Kx[0] + c1y * Ky[0] + c2x * Yx + c2y * Yy + c3x * Kx[S] + c3y * Ky[S];
       }
       PPROF(4);
-      // ---- the sweep: three multiply-adds per step, results handed on by v_readlane
-      const int cnt = min(DTP_STEPS, ns - r * DTP_STEPS);
-      for (int it = cnt - 1; it >= 0; it--) {
-        const float rr = __builtin_fmaf(ax + ex, Yx, __builtin_fmaf(ay + ey, Yy, c));
-        const float nx = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rr), 3 * it));
-        const float ny = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rr), 3 * it + 1));
-        gth += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, rr), 3 * it + 2));
-        ax = nx;
-        ay = ny;
+      // ---- the sweep. Lane p ≤ 20 gathers step p's affine map ȳ → ȳ·A_p + d_p (from lanes 3p + τ); lanes ≥ 21 are sources (A = 0, d = the
+      // cotangent that enters the round). A chain of 21 dependent map applications costs ≈ 90 cycles per step here whichever way the value
+      // travels (v_readlane → scalar → VALU, DPP wave_shl, DPP row_shl: measured), so the maps are composed instead: a suffix scan
+      // within each row of 16 lanes — four levels, partner = lane + 1, 2, 4, 8 by DPP row_shl, eighteen independent multiply-adds per level,
+      // a partner outside the row = the identity — leaves in lane p the composite of steps p … 15 (first row) and of steps p … 20 on the
+      // source (second row, a constant). Lane 16's constant enters the first row's composites; what entered step p (for dθ) is what
+      // left step p + 1. Steps beyond the record's end carry h = 0 and no save times: the identity map.
+      const float dfl = __builtin_fmaf(ex, Yx, __builtin_fmaf(ey, Yy, c));   // (ȳ + e)·Y' + c = ȳ·Y' + (e·Y' + c)
+      const int src = lane < DTP_STEPS ? 3 * lane : 63;
+      float a00 = dtp_from_lane(Yx, src), a10 = dtp_from_lane(Yy, src), d0 = dtp_from_lane(dfl, src);               // new ȳ_x = ȳ_x a00 + ȳ_y a10 + d0
+      float a01 = dtp_from_lane(Yx, src + 1), a11 = dtp_from_lane(Yy, src + 1), d1 = dtp_from_lane(dfl, src + 1);   // new ȳ_y = ȳ_x a01 + ȳ_y a11 + d1
+      const float mtx = dtp_from_lane(Yx, src + 2), mty = dtp_from_lane(Yy, src + 2), mtd = dtp_from_lane(dfl, src + 2);   // dθ += ȳ_x mtx + ȳ_y mty + mtd
+      if (lane >= DTP_STEPS) {
+        a00 = a01 = a10 = a11 = 0.f;
+        d0 = ax;
+        d1 = ay;
+      }
+      PPROF(6);
+#define LDE_DTP_LEVEL(CTRL)                                                                                     \
+  {                                                                                                             \
+    const float h00 = dtp_row_dpp<CTRL>(a00, 1.f), h01 = dtp_row_dpp<CTRL>(a01, 0.f);                           \
+    const float h10 = dtp_row_dpp<CTRL>(a10, 0.f), h11 = dtp_row_dpp<CTRL>(a11, 1.f);                           \
+    const float g0 = dtp_row_dpp<CTRL>(d0, 0.f), g1 = dtp_row_dpp<CTRL>(d1, 0.f);                               \
+    const float n00 = __builtin_fmaf(h00, a00, h01 * a10), n01 = __builtin_fmaf(h00, a01, h01 * a11);           \
+    const float n10 = __builtin_fmaf(h10, a00, h11 * a10), n11 = __builtin_fmaf(h10, a01, h11 * a11);           \
+    d0 = __builtin_fmaf(g0, a00, __builtin_fmaf(g1, a10, d0));                                                  \
+    d1 = __builtin_fmaf(g0, a01, __builtin_fmaf(g1, a11, d1));                                                  \
+    a00 = n00; a01 = n01; a10 = n10; a11 = n11;                                                                 \
+  }
+      LDE_DTP_LEVEL(0x101)
+      LDE_DTP_LEVEL(0x102)
+      LDE_DTP_LEVEL(0x104)
+      LDE_DTP_LEVEL(0x108)
+#undef LDE_DTP_LEVEL
+      PPROF(7);
+      {
+        const float hx = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d0), 16));   // what leaves step 16 = what enters step 15
+        const float hy = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(d1), 16));
+        const float ox = __builtin_fmaf(hx, a00, __builtin_fmaf(hy, a10, d0));                 // what leaves step p (second row: A = 0, the constant itself)
+        const float oy = __builtin_fmaf(hx, a01, __builtin_fmaf(hy, a11, d1));
+        const float qx = dtp_row_dpp<0x101>(ox, hx), qy = dtp_row_dpp<0x101>(oy, hy);           // what entered step p
+        float gp = lane < DTP_STEPS ? __builtin_fmaf(qx, mtx, __builtin_fmaf(qy, mty, mtd)) : 0.f;
+        gp = dtp_dpp_add<0x111>(gp);   // row_shr:1, 2, 4, 8: inclusive sums within the rows of 16 lanes
+        gp = dtp_dpp_add<0x112>(gp);
+        gp = dtp_dpp_add<0x114>(gp);
+        gp = dtp_dpp_add<0x118>(gp);
+        gth += __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gp), 15)) + __int_as_float(__builtin_amdgcn_readlane(__float_as_int(gp), 31));
+        ax = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(ox), 0));
+        ay = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(oy), 0));
       }
     }
   }
@@ -2302,7 +2408,7 @@ int launch_pend_adjoint_disc(int kind, int solver, const float* z_out, const flo
 #define LDE_LAUNCH(K, S)                                                                                                         \
   do {                                                                                                                           \
     if (tp)                                                                                                                      \
-      hipLaunchKernelGGL((k_pend_adjoint_disc_tp<K, S>), dim3(o.B), dim3(64), (size_t)o.T * 16, stream, (const float2*)z_out, theta, ts_dev, o, \
+      hipLaunchKernelGGL((k_pend_adjoint_disc_tp<K, S>), dim3(((o.B + 7) / 8) * 8), dim3(64), (size_t)o.T * 16 + 66 * 12 * sizeof(float), stream, (const float2*)z_out, theta, ts_dev, o, \
                          (const float2*)dz_out, (float2*)dz0, dtheta, nfe, nacc, nrej, ret);                                     \
     else                                                                                                                         \
       hipLaunchKernelGGL((k_pend_adjoint_disc<K, S>), dim3(grid), dim3(block), shm, stream, (const float2*)z_out, theta, ts_dev, o, \

@@ -767,9 +767,9 @@ def main():
         torch.cuda.synchronize()
         return float(np.mean(br)), float(np.median(br)), a.elapsed_time(b) / n
 
-    def measure(B, seed_shift, detail):
+    def measure(B, seed_shift, detail, sensealg=None):
         """W warm-up steps, then exactly K timed steps of lde_forward + lde_adjoint on B resident trajectories."""
-        d, ts, z0, theta, W, dz = build_problem(w, B, seed_shift=seed_shift, sensealg=args.sensealg)
+        d, ts, z0, theta, W, dz = build_problem(w, B, seed_shift=seed_shift, sensealg=sensealg or args.sensealg)
         h = C.c_void_p()
         L.check(lib.lde_create(C.byref(d), C.byref(h)), None, "lde_create")
         nW = int(lib.lde_num_weights(C.byref(d)))
@@ -994,6 +994,13 @@ def main():
         "per_call_synchronised": {"median_ms": m["sync_call"][0], "mean_ms": m["sync_call"][1], "samples": m["sync_call"][2],
                                   "value": B * world / (m["sync_call"][0] * 1e-3), "unit": "trajectories/s"},
     }
+
+    # the same K steps with the other definition of the gradient, beside the headline (every rank takes part: the timing's barriers are collective)
+    other = "default" if disc else "discrete"
+    mo = measure(B, rank, False, sensealg=other)
+    out["other_sensealg"] = {"sensealg": other, "value": global_batch * args.steps / mo["el"], "unit": "trajectories/s",
+                             "ms_per_step": mo["el"] / args.steps * 1e3}
+    lib.lde_destroy(mo["handle"])
 
     if "step_train" in m:
         # the MLP lines' step as a training loop pays it: lde_set_weights_device (+ its re-layout launches) before every forward solve, dW

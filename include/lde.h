@@ -153,6 +153,11 @@ typedef struct lde_handle lde_handle;
 /* library ABI version (= LDE_ABI_VERSION it was built with). */
 int lde_abi_version(void);
 
+/* What this binary was built and validated with: the hipcc version line and the verdict of the build's register check (the weight-gradient
+ * tiles of k_mlpb / k_mlpc live in accumulator registers the compiler is not told about; every build disassembles the object and refuses to
+ * link if the compiler's own code touches them — latentdiffeq.jl_amd/check_agprs.py). A static string; never NULL. */
+const char* lde_build_info(void);
+
 /* Fill `desc` with the defaults `Pendulum()` would carry: Tsit5, per-trajectory, abstol 1e-6,
  * reltol 1e-3, maxiters 1e5, PI controller constants  [REF pendulum.jl:11]; sensealg = PARALLEL_CHECKPOINTED. */
 int lde_problem_desc_default(lde_problem_desc* desc);

@@ -26,7 +26,7 @@ STATUS = {0: "LDE_OK", -1: "LDE_ERR_INVALID_ARG", -2: "LDE_ERR_UNSUPPORTED", -3:
 
 # every symbol include/lde.h declares
 EXPORTS = ["lde_abi_version", "lde_problem_desc_default", "lde_num_weights", "lde_create", "lde_destroy",
-           "lde_set_weights", "lde_set_weights_device", "lde_reserve", "lde_forward", "lde_adjoint",
+           "lde_build_info", "lde_set_weights", "lde_set_weights_device", "lde_reserve", "lde_forward", "lde_adjoint",
            "lde_get_stats", "lde_last_error", "lde_set_global_sum_hook", "lde_set_phase_timing", "lde_get_phase_ms",
            "lde_step_record_bytes", "lde_set_step_record", "lde_get_step_record", "lde_set_option", "lde_get_option",
            "lde_chain_num_weights", "lde_chain_create", "lde_chain_destroy", "lde_chain_set_weights",
@@ -107,6 +107,8 @@ def load():
     lib = C.CDLL(LIB_PATH)
     vp, i32, i64 = C.c_void_p, C.c_int, C.c_int64
     lib.lde_abi_version.restype = i32
+    lib.lde_build_info.restype = C.c_char_p
+    lib.lde_build_info.argtypes = []
     lib.lde_problem_desc_default.argtypes = [C.POINTER(ProblemDesc)]
     lib.lde_num_weights.argtypes = [C.POINTER(ProblemDesc)]
     lib.lde_num_weights.restype = i64

@@ -86,6 +86,18 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), out: s
         ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.strip().splitlines()
         with open(stamp, "w") as f:
             f.write("hidden AGPR ranges respected\n" + "\n".join(ver[:2]) + "\n")
+    # what was validated travels in the library itself: lde_build_info() returns the stamp's text (compiler version + the check's verdict)
+    info_src, info_obj = os.path.join(objdir, "lde_buildinfo.cpp"), os.path.join(objdir, "lde_buildinfo.o")
+    text = open(stamp).read().strip().replace("\\", "/").replace('"', "'").replace("\n", "; ")
+    body = f'extern "C" __attribute__((visibility("default"))) const char* lde_build_info(void) {{ return "{text}"; }}\n'
+    if not os.path.exists(info_src) or open(info_src).read() != body or not os.path.exists(info_obj):
+        with open(info_src, "w") as f:
+            f.write(body)
+        r = subprocess.run([shutil.which("g++") or hipcc, "-O1", "-fPIC", "-c", info_src, "-o", info_obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            sys.stderr.write(r.stdout + r.stderr)
+            raise RuntimeError("compiling lde_buildinfo.cpp failed")
+    objs.append(info_obj)
     if jobs or _newer(out, objs):
         r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", out] + objs + ["-ldl"], capture_output=True, text=True)
         if r.returncode != 0:

@@ -7,13 +7,14 @@
 // per lane and product: 800 LDS-array cycles per product and CU), and nothing is left for the weight gradient, whose (a_l, δ_l)
 // panels it stages through HBM for k_mlp_dw (c2: 203 MB per launch against 0.84 MB of algorithmic traffic). Here:
 //   * the 256 lanes of the workgroup (one trajectory, one wave per SIMD) form a 16 × 16 grid: lane (r, c) — r = tid >> 4 a DPP row,
-//     c = tid & 15 the lane in it — owns the BLOCK W₂[13r … 13r+12][14c … 14c+13] as 13 × 7 register pairs (182 VGPRs, all arch
-//     VGPRs). W₂·h₁: the lane needs only h₁[14c …] (7 ds_read_b64), 91 v_pk_fma_f32, and the row sums meet inside the DPP row
-//     (quad_perm ×2, row_half_mirror, row_mirror: 4 steps per row, every lane of the row ends with all 13 sums, bitwise equal).
-//     W₂ᵀ·δ₂ runs on the SAME registers — 91 v_pk_fma_f32 with δ₂[i] on both halves — and its 14 partial sums per lane cross the
-//     16 row groups through LDS (7 ds_write_b64, then lane u adds its unit's 16 partials). The bias b₂ rides as column H₁ of the
-//     block against a constant 1 in h₁[H₁] (the padding of the 16·14 = 224 columns), so it costs nothing — and the same 1 makes
-//     row H₁ of the weight-gradient tiles below the gradient of b₂;
+//     c = tid & 15 the lane in it — owns the BLOCK W₂[13r … 13r+12][13c … 13c+12] as 13 rows × (6 register pairs + a single
+//     register) (RB = CB = 13, CBP = 6: 169 VGPRs, all arch VGPRs). W₂·h₁: the lane needs only h₁[13c … 13c+12] (13 floats from
+//     LDS), 78 v_pk_fma_f32 + 13 v_fma_f32, and the row sums meet inside the DPP row (quad_perm ×2, row_half_mirror, row_mirror:
+//     4 steps per row, every lane of the row ends with all 13 sums, bitwise equal). W₂ᵀ·δ₂ runs on the SAME registers — 78
+//     v_pk_fma_f32 + 13 v_fma_f32 with δ₂[i] on both halves — and its 13 partial sums per lane cross the 16 row groups through LDS
+//     (then lane u adds its unit's 16 partials). The bias b₂ rides as column H₁ of the block against a constant 1 in h₁[H₁]
+//     (16·13 = 208 block columns for H₁ ≤ 200 units: the padding), so it costs nothing — and the same 1 makes row H₁ of the
+//     weight-gradient tiles below the gradient of b₂;
 //   * the thin products stay as in k_mlpw: lane u owns unit u's row of W₁ and column of W₃ (a₁ and W₃ᵀλ: D′ FMAs each on the
 //     broadcast state), and H → D′ (f = W₃h₂, vz = W₁ᵀδ₁) with lanes = (K-segment, output) on slices kept in LDS;
 //   * THE WEIGHT GRADIENT NEVER LEAVES THE CU: the vectors an evaluation passes through LDS anyway (z|λ, h₁, δ₂, h₂, δ₁) are a RING

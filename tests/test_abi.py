@@ -28,6 +28,8 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
         assert hasattr(lib, name), f"{name} declared in include/lde.h but not exported by liblde.so"
     assert sorted(_lib.EXPORTS) == decl, "the ctypes binding must bind exactly the declared entry points"
     assert lib.lde_abi_version() == 1
+    info = lib.lde_build_info().decode()          # the compiler that built it and the register check's verdict travel in the binary
+    assert "hidden AGPR ranges respected" in info and ("clang" in info.lower() or "hip" in info.lower()), info
 
 
 def test_desc_defaults_match_ordinarydiffeq_defaults_and_bindings_agree():

@@ -686,6 +686,7 @@ def main():
                     help="discrete: LDE_SENSE_DISCRETE (the exact derivative of the discrete solve — the reference's ForwardDiffSensitivity) "
                          "instead of the workload's continuous adjoint")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-sensealg", action="store_true", help="skip the second measurement with the other definition of the gradient (profiling runs: one set of kernels per trace)")
     ap.add_argument("--sweep", action="store_true", help="also report a large-batch sweep (extra keys, rank 0)")
     ap.add_argument("--dry-launch", action="store_true", help="exercise the N-rank launch path without GPUs (gloo)")
     args = ap.parse_args()
@@ -996,11 +997,12 @@ def main():
     }
 
     # the same K steps with the other definition of the gradient, beside the headline (every rank takes part: the timing's barriers are collective)
-    other = "default" if disc else "discrete"
-    mo = measure(B, rank, False, sensealg=other)
-    out["other_sensealg"] = {"sensealg": other, "value": global_batch * args.steps / mo["el"], "unit": "trajectories/s",
-                             "ms_per_step": mo["el"] / args.steps * 1e3}
-    lib.lde_destroy(mo["handle"])
+    if not args.no_other_sensealg:
+        other = "default" if disc else "discrete"
+        mo = measure(B, rank, False, sensealg=other)
+        out["other_sensealg"] = {"sensealg": other, "value": global_batch * args.steps / mo["el"], "unit": "trajectories/s",
+                                 "ms_per_step": mo["el"] / args.steps * 1e3}
+        lib.lde_destroy(mo["handle"])
 
     if "step_train" in m:
         # the MLP lines' step as a training loop pays it: lde_set_weights_device (+ its re-layout launches) before every forward solve, dW

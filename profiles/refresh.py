@@ -35,7 +35,7 @@ for w in args:
                    stdout=subprocess.DEVNULL, check=True)
     ks = sorted(glob.glob(f"{d}/trace/*/*kernel_stats.csv"), key=os.path.getmtime)[-1]
     shutil.copy(ks, f"{ROOT}/profiles/{RND}_{w}_kernel_stats.csv")
-    b = f"{OUT}/bench_{w}.json" if not w.startswith("goku_pendulum") else f"{OUT}/bench_metric.json"
+    b = f"{OUT}/bench_{w}.json" if not w.startswith("goku_pendulum") else (f"{OUT}/bench_metric_discrete.json" if "discrete" in w else f"{OUT}/bench_metric.json")
     if os.path.exists(b):
         dst = f"{ROOT}/profiles/{RND}_{w}_bench.json"
         shutil.copy(b, dst)
@@ -46,7 +46,7 @@ for w in args:
         d = json.loads(lines[-1])
         roof = d.get("roofline") or {}
         if roof.get("bound") == "hbm" and w.startswith("goku_pendulum"):
-            bench.attach_traffic(roof, "goku_pendulum", d["config"]["batch_per_gpu"], mlp=False, full_batch=True, rounds=(RND,))
+            bench.attach_traffic(roof, "goku_pendulum_discrete" if "discrete" in w else "goku_pendulum", d["config"]["batch_per_gpu"], mlp=False, full_batch=True, rounds=(RND,))
         elif w.replace("_discrete", "") in ("c2", "c3", "c4", "latentode_ref"):
             bench.attach_traffic(roof, w, d["config"]["batch_per_gpu"], mlp=True, full_batch=True, rounds=(RND,))
         open(dst, "w").write(json.dumps(d) + "\n")

@@ -9,7 +9,7 @@ bash profiles/collect.sh ${R}_goku_pendulum_b256 --steps 200 --warmup 20 --no-cp
 bash profiles/collect.sh ${R}_goku_pendulum_discrete_b256 --sensealg discrete --steps 200 --warmup 20 --no-cpu-baseline --no-other-sensealg > /dev/null 2>&1
 python bench.py --steps 200 --warmup 20 --sweep > gpurun_out/bench_metric.json 2> gpurun_out/bench_metric.err
 python bench.py --steps 20 --warmup 5 > gpurun_out/bench_metric_steps20.json 2>> gpurun_out/bench_metric.err
-python bench.py --steps 200 --warmup 20 --sensealg discrete > gpurun_out/bench_metric_discrete.json 2>> gpurun_out/bench_metric.err
+python bench.py --steps 200 --warmup 20 --sensealg discrete --sweep > gpurun_out/bench_metric_discrete.json 2>> gpurun_out/bench_metric.err
 for w in c2 c3 c4 latentode_ref; do
   bash profiles/collect.sh ${R}_$w --workload $w --steps 20 --warmup 5 --no-cpu-baseline --no-other-sensealg > /dev/null 2>&1
   python bench.py --workload $w --steps 20 --warmup 5 > gpurun_out/bench_$w.json 2> gpurun_out/bench_$w.err

@@ -712,7 +712,8 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
           const int tb = vbank;
           vbank = fbank; fbank = tb;
         }
-        nfe += S;
+        nfe += sidx > 0 ? 2 * S : S;   // evaluations as the other discrete kernels count them: a paired evaluation = the vector-Jacobian half of this
+                                       // step's stage + the forward half of a stage of step sidx − 1
         nacc++;
       }
       {   // k_1 of the first step = f(y_0): its forward half ran as the first stage point of step 0 (slot sx by now)

@@ -882,6 +882,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
       } else
         step_end = true;
     } while (!__builtin_amdgcn_readfirstlane((int)step_end));
+    PROF_T(g0);
     // ---- the end of a step attempt: error norm, controller, accept / reject
     if (ADJ && SOLVER == LDE_SOLVER_RK4) {
       const float h6 = h * (1.0f / 6.0f);
@@ -897,6 +898,8 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
         w_grid_sum<false>(a.gs, gen, a.epoch, s2, s2b);
       }
     }
+    PROF_T(g1);
+    PROF_ADD(12, g0, g1);   // (diagnostic builds) error sum + the grid-wide round trip
     bool accepted = false;
     double hrec = 0.0;   // the attempted step as f64 (the controller overwrites dt below)
     if (status == 0) {
@@ -1006,6 +1009,9 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
       s = SPEC ? 1 : 0;   // (SPEC: k₁ and its ring slot are in place — accepted: from above; rejected: the attempt's own)
       running = begin_step();
     }
+    PROF_T(g2);
+    PROF_ADD(13, g1, g2);   // controller, record, dense output / fold, begin_step
+    PROF_ADD(21, g2 - 1, g2);   // attempts
   }
 
   // ---- results

@@ -310,3 +310,31 @@ def test_diffeq_layer_with_exact_forwarddiff_sensitivity_two_graphs_in_flight(o3
         r0, rth, _, _ = o32.adjoint_discrete(d, z, L, ts, dz, rec)
         # (the oracle on its OWN steps here: two adaptive f32 solves — the gate is the solver's tolerance, the point is which record was used)
         assert _rel(zt.grad.T.cpu().numpy(), r0) < 5e-3 and _rel(Lt.grad.T.cpu().numpy(), rth) < 5e-3
+
+
+def test_latentode_diffeq_layer_with_discrete_sensitivity_reaches_the_network_parameters(o64):
+    """`NODE(…, sensealg=DiscreteSensitivity())` through diffeq_layer + autograd [REF src/models/LatentODE.jl:61-78]: the gradient of the
+    network parameters (every Linear's weight and bias) and of ẑ₀ against the float64 oracle's discrete sweep on its own steps, at a
+    tolerance where the two adaptive solves' step sequences no longer matter (tanh: no kinks)."""
+    import torch
+    from latentdiffeq_amd import api
+    B, T, D, H = 24, 30, 4, 48
+    torch.manual_seed(3)
+    dq = api.NODE(D, hidden_dim=H, device="cuda", sensealg=api.DiscreteSensitivity(), activation="tanh", abstol=1e-7, reltol=1e-7)
+    dec = api.Decoder(api.LatentODE(), (None, dq, None))
+    rng = np.random.default_rng(5)
+    z0 = rng.standard_normal((B, D)).astype(np.float32)
+    ts = O.time_grid(T)
+    dz = O.cotangent(T, B, D)
+    zt = torch.tensor(z0.T.copy(), device="cuda", requires_grad=True)
+    zhat = api.diffeq_layer(dec, zt, ts)                                            # [D, B, T]
+    (zhat * torch.tensor(dz, device="cuda").permute(2, 1, 0)).sum().backward()
+    W = dq.flat_weights().detach().cpu().numpy().astype(np.float64)
+    d = O.make_desc(rhs_kind=O.RHS_MLP, state_dim=D, param_dim=0, layers=(D, H, H, D), activation=O.ACT_TANH, batching=O.BATCH_COUPLED,
+                    sensealg=O.SENSE_DISCRETE, abstol=1e-7, reltol=1e-7)
+    z, ret, rec, _ = o64.forward_steps(d, z0, None, ts, W=W)
+    r0, _, rW, _ = o64.adjoint_discrete(d, z, None, ts, dz, rec, W=W)
+    assert np.abs(zhat.detach().permute(2, 1, 0).cpu().numpy() - z).max() <= 2e-5
+    assert _rel(zt.grad.T.cpu().numpy(), r0) <= 1e-3
+    gW = torch.cat([torch.cat([m.weight.grad.t().reshape(-1), m.bias.grad]) for m in dq.dudt if isinstance(m, torch.nn.Linear)]).cpu().numpy()
+    assert gW.shape == rW.shape and _rel(gW, rW) <= 1e-3, _rel(gW, rW)

@@ -351,7 +351,9 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
 
   // one evaluation of the (augmented) right-hand side: src → dst; its vectors stay in ring slot `slot`
   // vj (wave-uniform; only the discrete sweep passes false): false = the forward half alone — f, h₁, h₂ — for the evaluations that rebuild slopes
-  auto eval = [&](float src, int slot, bool vj = true) -> float {
+  // fwd (wave-uniform; only the discrete sweep passes false): false = the vector-Jacobian half alone, at the point whose forward half left
+  // z, h₁, h₂ in ring slot `slot` earlier (the sweep's pass 1): no W₁z, no W₂h₁, no f
+  auto eval = [&](float src, int slot, bool vj = true, bool fwd = true) -> float {
     PROF_T(e0);
     float* xs = ring + slot * SLOT;
     float *h1v = xs + XS, *d2v = h1v + HV, *h2v = d2v + HV, *d1v = h2v + HV;
@@ -359,7 +361,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
     asm volatile("" ::: "memory");   // same wave, in-order LDS: the broadcast reads below see the write (no barrier needed)
     const f32x4* x4 = reinterpret_cast<const f32x4*>(xs);
     float h1;
-    {
+    if (!DISC || fwd) {
       f32x2 c01 = {0.f, 0.f}, c23 = {0.f, 0.f};
 #pragma unroll
       for (int g = 0; g < G1; g++) {
@@ -369,8 +371,9 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
       }
       const float a1 = b1 + ((c01.x + c01.y) + (c23.x + c23.y));
       h1 = u == H1 ? 1.f : act_fn(act, a1);   // unit H₁: the constant that carries b₂ (rows beyond: zero weights and bias ⇒ act(0) = 0)
-    }
-    if (u < HV) h1v[u] = h1;
+      if (u < HV) h1v[u] = h1;
+    } else
+      h1 = u < HV ? h1v[u] : 0.f;
     if (ADJ && vj) {
       f32x2 c01 = {0.f, 0.f}, c23 = {0.f, 0.f};
 #pragma unroll
@@ -385,7 +388,10 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
     PROF_T(e1);
     // ---- the block products (independent chains side by side: two groups of rows, each as 7 / 6 accumulator pairs + singles)
     float h2[RB];
-    {
+    if (DISC && !fwd) {   // h₂ as pass 1 left it (a row's 16 lanes read the same 13 words)
+#pragma unroll
+      for (int i = 0; i < RB; i++) h2[i] = h2v[RB * br + i];
+    } else {
       const float* hc = h1v + CB * bc;
       f32x2 hp[CBP];
 #pragma unroll
@@ -424,7 +430,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
       if (bc == 0) {   // one lane of the row leaves h₂ and δ₂ for the thin products and the fold
 #pragma unroll
         for (int i = 0; i < RB; i++) {
-          h2v[RB * br + i] = h2[i];
+          if (!DISC || fwd) h2v[RB * br + i] = h2[i];
           d2v[RB * br + i] = d2[i];
         }
       }
@@ -450,11 +456,13 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
     __syncthreads();
     PROF_T(e2);
     float f = 0.f;
-    if (KSPLIT) {
-      const float pf = narrow_part(n3, h2v);
-      if (lane < DP) s_np[wv * DP + lane] = pf;
-    } else
-      f = narrow(n3, h2v) + b3;
+    if (!DISC || fwd) {
+      if (KSPLIT) {
+        const float pf = narrow_part(n3, h2v);
+        if (lane < DP) s_np[wv * DP + lane] = pf;
+      } else
+        f = narrow(n3, h2v) + b3;
+    }
     float dst = is_z ? f : 0.f;
     PROF_ADD(3, e0, e1);
     PROF_ADD(4, e1, e2);
@@ -480,7 +488,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
       if (KSPLIT) {
         const int dd = lane % DP;
         f = b3 + ((s_np[dd] + s_np[DP + dd]) + (s_np[2 * DP + dd] + s_np[3 * DP + dd]));   // the same order in every wave: the same bits
-        dst = is_z ? f : 0.f;
+        dst = is_z && (!DISC || fwd) ? f : 0.f;   // (the vector-Jacobian half alone: no f)
         const float pv = narrow_part(n1, d1v);
         if (lane < DP) s_np[(W + wv) * DP + lane] = pv;
         __syncthreads();
@@ -642,10 +650,11 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
           for (int q = 0; q < S; q++) k[q] = 0.f;
           k[S] = is_l ? scr : 0.f;
         }
-        // pass 1: the slopes k_1 … k_S (forward halves, through the scratch slot)
+        // pass 1: the slopes k_1 … k_S — forward halves; stage i ≥ 1 leaves z, h₁, h₂ in ITS ring slot (S − i) for pass 2's
+        // vector-Jacobian half, the first stage point goes through the scratch slot (its pullback is the next step's FSAL point)
 #pragma unroll 1
         for (int i = 0; i < S; i++) {
-          const float dstv = eval(is_z ? point(i, hh) : 0.f, NST, false);
+          const float dstv = eval(is_z ? point(i, hh) : 0.f, i == 0 ? NST : S - i, false);
 #pragma unroll
           for (int q = 0; q < S; q++)
             if (q == i && is_z) k[q] = dstv;
@@ -677,13 +686,14 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
           }
           j--;
         }
-        // pass 2: Jᵀk̄ at y_{n+1}, then at g_S … g_2 (fused evaluations; their vectors stay in ring slots 0 … S − 1 for the fold)
+        // pass 2: Jᵀk̄ at y_{n+1} (a fused evaluation: nothing has been evaluated there), then at g_S … g_2 (the vector-Jacobian half
+        // alone, on the activations pass 1 left); their vectors stay in ring slots 0 … S − 1 for the fold
 #pragma unroll 1
         for (int i = S; i >= 1; i--) {
           float kb = 0.f;
 #pragma unroll
           for (int q = 0; q <= S; q++) kb = q == i ? k[q] : kb;
-          const float dstv = eval(is_z ? (i == S ? yn : point(i, hh)) : kb, S - i, true);
+          const float dstv = eval(is_z ? (i == S ? yn : point(i, hh)) : kb, S - i, true, i == S);
           if (is_l) {
             const float v = -dstv;
             if (i == S) {

@@ -58,6 +58,15 @@ static __device__ long long g_prof[64];
 #define PROF_T(var) do {} while (0)
 #define PROF_ADD(slot, t0, t1) do {} while (0)
 #endif
+// -DLDE_PROF=2: also the stamps inside an evaluation (every stamp waits for the wave's outstanding LDS / scalar loads, so the phases of an
+// evaluation are priced at the cost of stretching it; level 1 keeps to a handful of stamps per step attempt)
+#if LDE_PROF >= 2
+#define PROF_T2(var) PROF_T(var)
+#define PROF_ADD2(slot, t0, t1) PROF_ADD(slot, t0, t1)
+#else
+#define PROF_T2(var) do {} while (0)
+#define PROF_ADD2(slot, t0, t1) do {} while (0)
+#endif
 
 // Static description of the RHS handed to the kernels by value.
 struct MlpDims {

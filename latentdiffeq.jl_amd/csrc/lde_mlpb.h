@@ -354,7 +354,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
   // fwd (wave-uniform; only the discrete sweep passes false): false = the vector-Jacobian half alone, at the point whose forward half left
   // z, h₁, h₂ in ring slot `slot` earlier (the sweep's pass 1): no W₁z, no W₂h₁, no f
   auto eval = [&](float src, int slot, bool vj = true, bool fwd = true) -> float {
-    PROF_T(e0);
+    PROF_T2(e0);
     float* xs = ring + slot * SLOT;
     float *h1v = xs + XS, *d2v = h1v + HV, *h2v = d2v + HV, *d1v = h2v + HV;
     if (lane < XS) xs[lane] = src;   // (every wave stores the same values)
@@ -385,7 +385,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
       if (u < HV) d2v[u] = (c01.x + c01.y) + (c23.x + c23.y);   // (W₃ᵀλ)_u; becomes δ₂ below
     }
     __syncthreads();
-    PROF_T(e1);
+    PROF_T2(e1);
     // ---- the block products (independent chains side by side: two groups of rows, each as 7 / 6 accumulator pairs + singles)
     float h2[RB];
     if (DISC && !fwd) {   // h₂ as pass 1 left it (a row's 16 lanes read the same 13 words)
@@ -454,7 +454,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
       for (int i = 0; i < RB; i++) h2v[RB * br + i] = h2[i];
     }
     __syncthreads();
-    PROF_T(e2);
+    PROF_T2(e2);
     float f = 0.f;
     if (!DISC || fwd) {
       if (KSPLIT) {
@@ -464,8 +464,8 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
         f = narrow(n3, h2v) + b3;
     }
     float dst = is_z ? f : 0.f;
-    PROF_ADD(3, e0, e1);
-    PROF_ADD(4, e1, e2);
+    PROF_ADD2(3, e0, e1);
+    PROF_ADD2(4, e1, e2);
     if (ADJ && !vj && KSPLIT) {   // the forward half alone, K split over the waves: the partial outputs meet behind a barrier of their own
       __syncthreads();
       const int dd = lane % DP;
@@ -496,12 +496,12 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
       } else
         vz = narrow(n1, d1v);     // every lane with lane % DP == d holds vz_d
       if (is_l) dst = -vz;
-      PROF_T(e3);
-      PROF_ADD(5, e2, e3);
+      PROF_T2(e3);
+      PROF_ADD2(5, e2, e3);
     }
-    PROF_T(e5);
-    PROF_ADD(1, e0, e5);
-    PROF_ADD(20, e5 - 1, e5);
+    PROF_T2(e5);
+    PROF_ADD2(1, e0, e5);
+    PROF_ADD2(20, e5 - 1, e5);
     return dst;
   };
 
@@ -511,7 +511,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
   //   n = 43 + q : gW₁ tile 4q + w (A = δ₁, B = z)                        n = 47 + q : gW₃ᵀ tile 4q + w (A = h₂, B = λ)
   // (q = 3 is a real tile for wave 0 only; the other waves' slot accumulates finite junk that is never written out)
   auto fold = [&](int nvalid) {   // nvalid (wave-uniform): ring slots [0, nvalid) count
-    PROF_T(f0);
+    PROF_T2(f0);
     const int l15 = lane & 15, e4 = lane >> 4;
 #pragma unroll
     for (int g = 0; g < (NST + 3) / 4; g++) {
@@ -563,8 +563,8 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
       if (lane < XS) gb3 += wb_ * sl[lane];
     }
     __syncthreads();   // the next attempt overwrites the ring: every wave has read it
-    PROF_T(f1);
-    PROF_ADD(6, f0, f1);
+    PROF_T2(f1);
+    PROF_ADD2(6, f0, f1);
   };
 
   // this wave's sum of the attempt's scaled squared errors (every wave holds the whole state: the same number in all of them)
@@ -757,9 +757,10 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
     bool step_end = false;
     float s2 = 0.f, s2b = 0.f;
     scalarise();
+    PROF_T(a0);
     do {
-      PROF_T(l0);
-  #if LDE_PROF
+      PROF_T2(l0);
+  #if LDE_PROF >= 2
       struct ProfEnd { long long t0; __device__ ~ProfEnd() { PROF_T(t1); PROF_ADD(11, t0, t1); } } prof_end{l0};
   #endif
       float src = phase == PH_INIT1 ? tmp : y;
@@ -858,6 +859,8 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
       } else
         step_end = true;
     } while (!__builtin_amdgcn_readfirstlane((int)step_end));
+    PROF_T(g0);
+    PROF_ADD(10, a0, g0);   // (diagnostic builds) the attempt's evaluations with their stage arithmetic
     // ---- the end of a step attempt: error norm, controller, accept / reject
     if (ADJ && SOLVER == LDE_SOLVER_RK4) {
       const float h6 = h * (1.0f / 6.0f);
@@ -872,6 +875,8 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
         w_grid_sum<false>(a.gs, gen, a.epoch, s2, s2b);
       }
     }
+    PROF_T(g1);
+    PROF_ADD(12, g0, g1);   // error sum + the grid-wide round trip
     bool accepted = false;
     double hrec = 0.0;   // the attempted step as f64 (the controller overwrites dt below)
     if (status == 0) {
@@ -964,6 +969,9 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
       s = SPEC ? 1 : 0;   // (SPEC: k₁ and its ring slot are in place — accepted: from above; rejected: the attempt's own)
       running = begin_step();
     }
+    PROF_T(g2);
+    PROF_ADD(13, g1, g2);   // controller, record, dense output / fold, begin_step
+    PROF_ADD(21, g2 - 1, g2);   // attempts
   }
 
   // ---- results

@@ -276,7 +276,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
   // z, h₁, h₂ in ring slot `vslot` earlier — while the forward half evaluates `src`'s z lanes into `slot`: two independent evaluations in one
   // evaluation's phases. (vslot < 0: both halves at the same point, the activations taken from registers — the continuous adjoint's form.)
   auto eval = [&](const float (&src)[2], int slot, float (&dst)[2], bool vj = true, int vslot = -1) {
-    PROF_T(e0);
+    PROF_T2(e0);
     const bool paired = DISC && vslot >= 0;
     float* xs = ring + slot * SLOT;
     float* xv = paired ? ring + vslot * SLOT : xs;   // the slot of the vector-Jacobian half: its λ, W₃ᵀλ → δ₂, δ₁ (and, paired, its saved h₁, h₂)
@@ -325,7 +325,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
       d2v[2 * u + ut] = (c01.x + c01.y) + (c23.x + c23.y);   // (W₃ᵀλ)_u; becomes δ₂ below
     }
     __syncthreads();
-    PROF_T(e1);
+    PROF_T2(e1);
     // ---- the block products: every v_pk_fma_f32 is (trajectory A, trajectory B) against the weight on both halves
     f32x2 h2[RB];
     {
@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
       for (int i = 0; i < RB; i++) hw[i] = h2[i];
     }
     __syncthreads();
-    PROF_T(e2);
+    PROF_T2(e2);
     {
       f32x2 f = {b3, b3};
       const f32x2* fq = reinterpret_cast<const f32x2*>(fpart) + (lane & 31);   // output d = lane: [r][d >> 1][d & 1] pairs
@@ -402,8 +402,8 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
       dst[0] = is_z ? f.x : 0.f;
       dst[1] = is_z ? f.y : 0.f;
     }
-    PROF_ADD(3, e0, e1);
-    PROF_ADD(4, e1, e2);
+    PROF_ADD2(3, e0, e1);
+    PROF_ADD2(4, e1, e2);
     if (ADJ && vj) {
       float g1 = 0.f;
       {
@@ -422,12 +422,12 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
       const f32x2* qz = reinterpret_cast<const f32x2*>(s_np) + (lane % DP);
       const f32x2 vz = (qz[0] + qz[DP]) + (qz[2 * DP] + qz[3 * DP]);   // every lane with lane % 32 == d holds vz_d of A and B (the same order in every wave)
       if (is_l) { dst[0] = -vz.x; dst[1] = -vz.y; }
-      PROF_T(e3);
-      PROF_ADD(5, e2, e3);
+      PROF_T2(e3);
+      PROF_ADD2(5, e2, e3);
     }
-    PROF_T(e5);
-    PROF_ADD(1, e0, e5);
-    PROF_ADD(20, e5 - 1, e5);
+    PROF_T2(e5);
+    PROF_ADD2(1, e0, e5);
+    PROF_ADD2(20, e5 - 1, e5);
   };
 
   // the accepted step's share of the quadrature gW = Σ_s |h| b_s (∂f/∂W)ᵀλ of BOTH trajectories, from the ring. K slot q = 4g + (lane >> 4)
@@ -436,7 +436,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
   int vbank = 3, fsx = 0;   // (discrete sweep) first slot of the bank of the step being reversed (stage point i ≥ 1 at vbank + i − 1), and the FSAL point's slot
   auto fslot = [&](int e) -> int { return DISC ? (e == 0 ? fsx : vbank + (NST - e) - 1) : e; };   // ring slot of the fold's evaluation e
   auto fold = [&](int nvalid) {   // nvalid (wave-uniform): ring slots [0, nvalid) count
-    PROF_T(f0);
+    PROF_T2(f0);
     const int l15 = lane & 15, e4 = lane >> 4;
 #pragma unroll
     for (int g = 0; g < (2 * NST + 3) / 4; g++) {
@@ -502,8 +502,8 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
       gb3 += wb_ * (sl[lane] + sl[64 + lane]);
     }
     __syncthreads();   // the next attempt overwrites the ring: every wave has read it
-    PROF_T(f1);
-    PROF_ADD(6, f0, f1);
+    PROF_T2(f1);
+    PROF_ADD2(6, f0, f1);
   };
 
   // this wave's sum of the attempt's scaled squared errors over both trajectories (every wave holds the whole state)
@@ -760,9 +760,10 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
     bool step_end = false;
     float s2 = 0.f, s2b = 0.f;
     scalarise();
+    PROF_T(a0);
     do {
-      PROF_T(l0);
-#if LDE_PROF
+      PROF_T2(l0);
+#if LDE_PROF >= 2
       struct ProfEnd { long long t0; __device__ ~ProfEnd() { PROF_T(t1); PROF_ADD(11, t0, t1); } } prof_end{l0};
 #endif
       float src[2];
@@ -883,6 +884,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
         step_end = true;
     } while (!__builtin_amdgcn_readfirstlane((int)step_end));
     PROF_T(g0);
+    PROF_ADD(10, a0, g0);   // (diagnostic builds) the attempt's evaluations with their stage arithmetic
     // ---- the end of a step attempt: error norm, controller, accept / reject
     if (ADJ && SOLVER == LDE_SOLVER_RK4) {
       const float h6 = h * (1.0f / 6.0f);
@@ -899,7 +901,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
       }
     }
     PROF_T(g1);
-    PROF_ADD(12, g0, g1);   // (diagnostic builds) error sum + the grid-wide round trip
+    PROF_ADD(12, g0, g1);   // error sum + the grid-wide round trip
     bool accepted = false;
     double hrec = 0.0;   // the attempted step as f64 (the controller overwrites dt below)
     if (status == 0) {

@@ -151,39 +151,42 @@ __device__ __forceinline__ void w_grid_collect(const GridSync& gs, unsigned gen,
     return;
   }
   unsigned long long* slots = reinterpret_cast<unsigned long long*>(gs.slots) + (size_t)(gen & 1) * gs.nwg * 2;
-  // ONE wave of the workgroup polls (and adds, in index order: the same bits in every workgroup); the others pick the sums up from LDS
-  // behind the barrier that makes the decision workgroup-uniform anyway. With every wave polling, 1 024 waves read all 256 words in
-  // every round of the spin: four times the L2 traffic in front of the words that are still on their way.
-  __shared__ float s_gsum[2][2];   // by generation parity: the sum after the next one rewrites a word, and this workgroup's barrier of the next sum lies between
+  // Every wave of the workgroup polls ITS share of the words — word w belongs to thread w mod blockDim — so that a lane has one word and the
+  // sum is ONE round trip to the memory side (agent-scope loads do not stop at this XCD's L2). (Round 4 had one wave poll all words, a lane's
+  // four one after the other: 3.2 µs per sum with 256 workgroups against 1.8 µs with 64 — abl: -DLDE_PROF=1, slot 12; every wave polling ALL
+  // words, before that, was four times the traffic in front of the words still on their way.) Added up in a fixed order — a wave's words by
+  // its fixed tree, then the waves' sums in wave order: the same bits in every workgroup.
+  __shared__ float s_gpart[2][8][2];   // by generation parity: the sum after the next one rewrites a word, and this workgroup's barrier of the next sum lies between
   float p0 = 0.f, p1 = 0.f;
   bool aborted = false;
-  if (threadIdx.x < 64) {
-    for (int w = threadIdx.x; w < gs.nwg; w += 64) {
-      unsigned long long q0, q1 = 0;
-      long long spins = 0;
-      for (;;) {
-        q0 = __hip_atomic_load(slots + (size_t)w * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (TWO) q1 = __hip_atomic_load(slots + (size_t)w * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned)(q0 >> 32) == tag && (!TWO || (unsigned)(q1 >> 32) == tag)) break;
-        __builtin_amdgcn_s_sleep(1);
-        if ((++spins & 4095) == 0 &&
-            (spins > 20000000LL || __hip_atomic_load(gs.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
-          // a peer is not resident (the launch is cooperative: cannot happen) — give up instead of hanging
-          __hip_atomic_store(gs.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          aborted = true;
-          break;
-        }
+  const int gwv = threadIdx.x >> 6, gnw = (blockDim.x + 63) >> 6;
+  for (int w = threadIdx.x; w < gs.nwg; w += blockDim.x) {
+    unsigned long long q0, q1 = 0;
+    long long spins = 0;
+    for (;;) {
+      q0 = __hip_atomic_load(slots + (size_t)w * 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (TWO) q1 = __hip_atomic_load(slots + (size_t)w * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if ((unsigned)(q0 >> 32) == tag && (!TWO || (unsigned)(q1 >> 32) == tag)) break;
+      __builtin_amdgcn_s_sleep(1);
+      if ((++spins & 4095) == 0 &&
+          (spins > 20000000LL || __hip_atomic_load(gs.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+        // a peer is not resident (the launch is cooperative: cannot happen) — give up instead of hanging
+        __hip_atomic_store(gs.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        aborted = true;
+        break;
       }
-      p0 += __uint_as_float((unsigned)q0);
-      p1 += __uint_as_float((unsigned)q1);
     }
-    p0 = wave_sum64(p0);
-    if (TWO) p1 = wave_sum64(p1);
-    if (threadIdx.x == 0) { s_gsum[gen & 1][0] = p0; s_gsum[gen & 1][1] = p1; }
+    p0 += __uint_as_float((unsigned)q0);
+    p1 += __uint_as_float((unsigned)q1);
   }
+  p0 = wave_sum64(p0);
+  if (TWO) p1 = wave_sum64(p1);
+  if ((threadIdx.x & 63) == 0) { s_gpart[gen & 1][gwv][0] = p0; s_gpart[gen & 1][gwv][1] = p1; }
   aborted = __syncthreads_or(aborted ? 1 : 0) != 0;   // the waves of a workgroup must take the same decision
-  v0 = aborted ? __int_as_float(0x7fc00000) : s_gsum[gen & 1][0];   // a timed-out barrier poisons the sums: retcode != 0
-  if (TWO) v1 = aborted ? __int_as_float(0x7fc00000) : s_gsum[gen & 1][1];
+  float t0 = s_gpart[gen & 1][0][0], t1 = s_gpart[gen & 1][0][1];
+  for (int i = 1; i < gnw; i++) { t0 += s_gpart[gen & 1][i][0]; t1 += s_gpart[gen & 1][i][1]; }
+  v0 = aborted ? __int_as_float(0x7fc00000) : t0;   // a timed-out barrier poisons the sums: retcode != 0
+  if (TWO) v1 = aborted ? __int_as_float(0x7fc00000) : t1;
   w_host_sum<TWO>(gs, tag, v0, v1);
   PROF_T(g1);
   PROF_ADD(12, g0, g1);

@@ -751,11 +751,39 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
     t = sgpr_d(t); dt = sgpr_d(dt); tnew = sgpr_d(tnew);
     h = sgpr_f(h); qold = sgpr_f(qold); wq = sgpr_f(wq); d1n = sgpr_f(d1n);
   };
+  // Dense output of the attempted step at the save times it covers, written BEFORE the step is known to be accepted — between the error
+  // sum's publication and its collection, where the workgroup would wait for the grid anyway. A rejected attempt's values are overwritten:
+  // every save time is covered again by a later accepted step (j advances only on acceptance), or the solve fails and the NaN block follows.
+  auto dense_output = [&](int jj) -> int {   // returns the index of the first save time behind the step
+    while (jj < T && s_ts[jj] <= tnew) {
+      const double tj = s_ts[jj];
+      const float th = (tj >= tnew || (jj == T - 1 && last)) ? 2.0f : (float)(tj - t) * fast_rcp(wq);
+      float ov;
+      if (th > 1.5f) ov = yn;
+      else if (SOLVER == LDE_SOLVER_TSIT5) {
+        float bw[7];
+        tsit5_interp_weights(th, bw);
+        float acc = bw[0] * k[0];
+#pragma unroll
+        for (int q = 1; q < 7; q++) acc += bw[q] * k[q];
+        ov = y + wq * acc;
+      } else {
+        const float om = 1.0f - th;
+        const float h00 = (1.0f + 2.0f * th) * om * om, h10 = th * om * om;
+        const float h01 = th * th * (3.0f - 2.0f * th), h11 = th * th * (th - 1.0f);
+        ov = h00 * y + (h10 * wq) * k[0] + h01 * yn + (h11 * wq) * k[4];
+      }
+      if (wv == 0 && lane < Dp) a.z_out[(size_t)Dp * ((size_t)b + (size_t)B * jj) + lane] = ov;
+      jj++;
+    }
+    return jj;
+  };
   while (__builtin_amdgcn_readfirstlane((int)running)) {
     // inner loop: the evaluations of one unit of work (the two probes of the initial step size, or the stages of one step attempt) — the
     // weight-gradient tiles are touched only outside it, in the step-end block below
     bool step_end = false;
     float s2 = 0.f, s2b = 0.f;
+    int jd = j;
     scalarise();
     PROF_T(a0);
     do {
@@ -872,8 +900,10 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
       s2 = err_sum();
       if (coupled) {
         if (status != 0) s2 = 0.f;
-        w_grid_sum<false>(a.gs, gen, a.epoch, s2, s2b);
+        w_grid_publish<false>(a.gs, gen, a.epoch, s2, s2b);
       }
+      if (!ADJ && status == 0) jd = dense_output(j);
+      if (coupled) w_grid_collect<false>(a.gs, gen, a.epoch, s2, s2b);
     }
     PROF_T(g1);
     PROF_ADD(12, g0, g1);   // error sum + the grid-wide round trip
@@ -916,27 +946,7 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
       if (!ADJ && wv == 0 && lane < Dp) o.rec.y[((size_t)(nacc - 1) * B + b) * Dp + lane] = y;
     }
     if (!ADJ) {
-      while (accepted && j < T && s_ts[j] <= tnew) {   // dense output at every save time inside the accepted step
-        const double tj = s_ts[j];
-        const float th = (tj >= tnew || (j == T - 1 && last)) ? 2.0f : (float)(tj - t) * fast_rcp(wq);
-        float ov;
-        if (th > 1.5f) ov = yn;
-        else if (SOLVER == LDE_SOLVER_TSIT5) {
-          float bw[7];
-          tsit5_interp_weights(th, bw);
-          float acc = bw[0] * k[0];
-#pragma unroll
-          for (int q = 1; q < 7; q++) acc += bw[q] * k[q];
-          ov = y + wq * acc;
-        } else {
-          const float om = 1.0f - th;
-          const float h00 = (1.0f + 2.0f * th) * om * om, h10 = th * om * om;
-          const float h01 = th * th * (3.0f - 2.0f * th), h11 = th * th * (th - 1.0f);
-          ov = h00 * y + (h10 * wq) * k[0] + h01 * yn + (h11 * wq) * k[4];
-        }
-        if (wv == 0 && lane < Dp) a.z_out[(size_t)Dp * ((size_t)b + (size_t)B * j) + lane] = ov;
-        j++;
-      }
+      if (accepted) j = jd;   // (the step's dense output was written ahead: dense_output)
       if (accepted) {
         y = yn;
         k[0] = k[LAST_STAGE];

@@ -159,8 +159,10 @@ __device__ __forceinline__ void w_grid_collect(const GridSync& gs, unsigned gen,
   __shared__ float s_gpart[2][8][2];   // by generation parity: the sum after the next one rewrites a word, and this workgroup's barrier of the next sum lies between
   float p0 = 0.f, p1 = 0.f;
   bool aborted = false;
-  const int gwv = threadIdx.x >> 6, gnw = (blockDim.x + 63) >> 6;
-  for (int w = threadIdx.x; w < gs.nwg; w += blockDim.x) {
+  // (up to 64 workgroups one wave has a word per lane already: the other waves go straight to the barrier, as in round 4)
+  const int gpoll = gs.nwg <= 64 ? 64 : (int)blockDim.x;
+  const int gwv = threadIdx.x >> 6, gnw = (gpoll + 63) >> 6;
+  for (int w = threadIdx.x < gpoll ? (int)threadIdx.x : gs.nwg; w < gs.nwg; w += gpoll) {
     unsigned long long q0, q1 = 0;
     long long spins = 0;
     for (;;) {
@@ -181,7 +183,7 @@ __device__ __forceinline__ void w_grid_collect(const GridSync& gs, unsigned gen,
   }
   p0 = wave_sum64(p0);
   if (TWO) p1 = wave_sum64(p1);
-  if ((threadIdx.x & 63) == 0) { s_gpart[gen & 1][gwv][0] = p0; s_gpart[gen & 1][gwv][1] = p1; }
+  if ((threadIdx.x & 63) == 0 && gwv < gnw) { s_gpart[gen & 1][gwv][0] = p0; s_gpart[gen & 1][gwv][1] = p1; }
   aborted = __syncthreads_or(aborted ? 1 : 0) != 0;   // the waves of a workgroup must take the same decision
   float t0 = s_gpart[gen & 1][0][0], t1 = s_gpart[gen & 1][0][1];
   for (int i = 1; i < gnw; i++) { t0 += s_gpart[gen & 1][i][0]; t1 += s_gpart[gen & 1][i][1]; }

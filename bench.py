@@ -425,6 +425,14 @@ def run_goku_step(args, torch, dist, world, rank, local):
     ts = np.arange(T) * 0.05
     Bg = B * world
 
+    # default: on for the f32 step (1.036 → 0.998 ms), off for the mixed one (its bf16 weight-gradient kernel is HBM-bound and slows what it runs beside: 0.491 → 0.502 ms)
+    async_dw = args.async_dw == 1 or (args.async_dw == -1 and args.dtype == "f32" and use_graph and world == 1)
+    if async_dw:
+        # only the reconstructor's weight gradient has something to run beside (the solve's adjoint, the small chains, the recurrent stacks'
+        # pullback); the feature extractor's is the last kernel of the pullback
+        L.set_async_weight_gradients(True, dev)
+        for m in (enc.feature_extractor, *enc.latent_in, lo_z0, lo_th):
+            L.check(L.load().lde_chain_set_option(m._native(), b"async_dw", 0.0), m._native(), "lde_chain_set_option", chain=True)
     fused_loss = True     # (False: separate sample / vector_kl / reconstruction_loss and torch additions — tests/test_gpu_loss.py compares the two)
     refresh = True   # one k_refresh_many launch re-packs every module's weights after the update (instead of an upload at each module's next call)
 
@@ -502,7 +510,9 @@ def run_goku_step(args, torch, dist, world, rank, local):
                    "batch_per_gpu": B, "global_batch": Bg, "save_points": T,
                    "parallelism": f"dp{world} (batch sharded by trajectory; one flat all-reduce of all parameter gradients per step)",
                    "submission": ("two hipGraph replays per step around the eager gradient all-reduce (train.GraphedStep)" if split else
-                                  "one hipGraph replay per step (train.GraphedStep)") if use_graph else "eager (≈ 50 launches per step)"},
+                                  "one hipGraph replay per step (train.GraphedStep)") if use_graph else "eager (≈ 50 launches per step)",
+                   "weight_gradient_branch": "the reconstructor's weight-gradient kernels run as a parallel branch of the captured step (lde_set_dw_stream)" if async_dw
+                   else "off: every kernel on one stream"},
         "roofline": dict(bound="mfma", kernel="whole step (dense chains dominate the flops)", achieved=3 * F_dense / (ms * 1e-3) / 1e12,
                          peak=FP32_PEAK_TFLOPS if args.dtype == "f32" else BF16_PEAK_TFLOPS, unit="TFLOP/s",
                          frac=3 * F_dense / (ms * 1e-3) / 1e12 / (FP32_PEAK_TFLOPS if args.dtype == "f32" else BF16_PEAK_TFLOPS), traffic=None,
@@ -685,6 +695,8 @@ def main():
     ap.add_argument("--sensealg", default="default", choices=["default", "discrete"],
                     help="discrete: LDE_SENSE_DISCRETE (the exact derivative of the discrete solve — the reference's ForwardDiffSensitivity) "
                          "instead of the workload's continuous adjoint")
+    ap.add_argument("--async-dw", type=int, default=-1, choices=[-1, 0, 1],
+                    help="goku_step: the large chains' weight-gradient kernels on a stream of their own — a parallel branch of the captured step (-1: the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-sensealg", action="store_true", help="skip the second measurement with the other definition of the gradient (profiling runs: one set of kernels per trace)")
     ap.add_argument("--sweep", action="store_true", help="also report a large-batch sweep (extra keys, rank 0)")

@@ -372,7 +372,10 @@ enum lde_dtype { LDE_DTYPE_F32 = 0, LDE_DTYPE_BF16 = 1 };
 int  lde_chain_set_dtype(lde_chain* c, int dtype);
 /* Kernel-choice knobs of the parity tests (a production host never sets them; the library reads no environment variable):
  * "gx" = 0: never the panel-free layout of a wide first layer (LDE_ERR_UNSUPPORTED when it is the only one that fits);
- * "group" = 0: this chain does not take part in merged grouped calls (its stages then run as launches of their own). */
+ * "group" = 0: this chain does not take part in merged grouped calls (its stages then run as launches of their own).
+ * A scheduling choice, not a parity knob: "async_dw" = 0: with a weight-gradient stream set (lde_set_dw_stream) this chain's weight-gradient
+ * kernels stay on the caller's stream all the same — the stream pays where something runs beside them (the reconstructor's, beside the
+ * rest of the pullback) and costs a fork and a join where nothing does (the feature extractor's: the last kernel of the pullback). */
 int  lde_chain_set_option(lde_chain* c, const char* key, double value);
 const char* lde_chain_last_error(const lde_chain* c);
 

@@ -163,6 +163,14 @@ int lde_set_dw_stream(void* stream) {
 
 int lde_join_dw(void* stream) {
   hipStream_t dws = g_dw_stream.load(std::memory_order_acquire);
+#if LDE_DW_DEBUG
+  {
+    hipStreamCaptureStatus ca = hipStreamCaptureStatusNone, cb = hipStreamCaptureStatusNone;
+    if (stream) (void)hipStreamIsCapturing((hipStream_t)stream, &ca);
+    if (dws) (void)hipStreamIsCapturing(dws, &cb);
+    fprintf(stderr, "[dw join] stream=%p(cap %d) dws=%p(cap %d)\n", stream, (int)ca, (void*)dws, (int)cb);
+  }
+#endif
   if (!dws || dws == (hipStream_t)stream) return LDE_OK;
   if (!g_dw_join && hipEventCreateWithFlags(&g_dw_join, hipEventDisableTiming) != hipSuccess) return LDE_ERR_HIP;
   if (hipEventRecord(g_dw_join, dws) != hipSuccess || hipStreamWaitEvent((hipStream_t)stream, g_dw_join, 0) != hipSuccess) return LDE_ERR_HIP;

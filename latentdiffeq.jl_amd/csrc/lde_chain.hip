@@ -677,6 +677,7 @@ struct lde_chain {
   ChainDims cdx;               // the panel-free layout for wide inputs (gx), when applicable
   int cgx_fwd = 0, cgx_bwd = 0;
   int opt_group = 1;        // lde_chain_set_option "group": this chain may take part in a merged (one launch per stage) grouped call
+  int opt_async_dw = 1;     // lde_chain_set_option "async_dw": this chain's weight-gradient kernels go to the dw stream when one is set (lde_set_dw_stream)
   size_t ldsx_fwd = 0, ldsx_bwd = 0;
   // backward workspace
   float* stage = nullptr; size_t stage_cap = 0;
@@ -1380,7 +1381,7 @@ static int chain_backward_b(lde_chain* c, const float* x, const float* y, const 
   }
   // weight gradient: [n][feature] matrices through the transposing LDS reads, then the fixed-order slab reduction
   bool sw_ok = true;
-  hipStream_t wst = dw_sync_switch(c->dws, stream, &sw_ok);
+  hipStream_t wst = (t_rec || !c->opt_async_dw) ? stream : dw_sync_switch(c->dws, stream, &sw_ok);   // (recorded for a grouped launch: on the caller's stream)
   if (!sw_ok) {
     c->err = "lde_chain_backward: switching to the weight-gradient stream failed";
     return LDE_ERR_HIP;
@@ -1586,7 +1587,7 @@ static int chain_backward_impl(lde_chain* c, const float* x, const float* y, con
   { (void)hipStreamSynchronize(stream); long long z[64] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof(z)); }
 #endif
   bool sw_ok = true;
-  hipStream_t wst = dw_sync_switch(c->dws, stream, &sw_ok);
+  hipStream_t wst = (t_rec || !c->opt_async_dw) ? stream : dw_sync_switch(c->dws, stream, &sw_ok);   // (recorded for a grouped launch: on the caller's stream)
   if (!sw_ok) {
     c->err = "lde_chain_backward: switching to the weight-gradient stream failed";
     return LDE_ERR_HIP;
@@ -1770,7 +1771,7 @@ static bool group_ok(int n, lde_chain* const* cs) {
 #else
   for (int i = 0; i < n; i++)
     if (!cs[i] || !cs[i]->opt_group) return false;   // (lde_chain_set_option "group" = 0: the chains of the call run one after the other)
-  return n >= 2 && n <= GROUP_MAX && dw_stream_get() == nullptr;
+  return n >= 2 && n <= GROUP_MAX;   // (with a weight-gradient stream set, a group's jobs stay on the caller's stream: they are small; the stream is for the large single chains)
 #endif
 }
 static bool group_distinct(int n, lde_chain* const* cs) {   // a handle's workspace serves one call at a time: the same chain twice runs one after the other
@@ -1844,6 +1845,10 @@ int lde_chain_set_option(lde_chain* c, const char* key, double value) {
   if (!c || !key) return LDE_ERR_INVALID_ARG;
   if (!std::strcmp(key, "group")) {
     c->opt_group = value != 0;
+    return LDE_OK;
+  }
+  if (!std::strcmp(key, "async_dw")) {   // 0: this chain's weight-gradient kernels stay on the caller's stream even when a dw stream is set
+    c->opt_async_dw = value != 0;
     return LDE_OK;
   }
   if (!std::strcmp(key, "gx")) {   // 0: never the panel-free layout of a wide first layer (the two layouts are each other's parity reference)

@@ -650,21 +650,43 @@ struct DwSync {
   hipEvent_t staged = nullptr;   // the pullback kernel's panels are complete (recorded on the caller's stream)
   hipEvent_t done = nullptr;     // this handle's weight-gradient kernels are complete (recorded on the dw stream)
   bool pending = false;
+  bool done_captured = false;    // `done` was recorded while the dw stream was part of a stream capture (a graph node, not a live event)
 };
+inline bool dw_is_capturing(hipStream_t s) {
+  hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+  return s && hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
 inline void dw_sync_destroy(DwSync& s) {
   if (s.staged) (void)hipEventDestroy(s.staged);
   if (s.done) (void)hipEventDestroy(s.done);
   s.staged = s.done = nullptr;
 }
 // before the pullback kernel overwrites the handle's workspace: wait for the handle's previous weight-gradient kernels
+#if LDE_DW_DEBUG
+inline void dw_dbg(const char* what, const DwSync* s, hipStream_t a, hipStream_t b) {
+  hipStreamCaptureStatus ca = hipStreamCaptureStatusNone, cb = hipStreamCaptureStatusNone;
+  if (a) (void)hipStreamIsCapturing(a, &ca);
+  if (b) (void)hipStreamIsCapturing(b, &cb);
+  fprintf(stderr, "[dw %s] sync=%p stream=%p(cap %d) dws=%p(cap %d) pending=%d\n", what, (const void*)s, (void*)a, (int)ca, (void*)b, (int)cb, s ? (int)s->pending : -1);
+}
+#else
+#define dw_dbg(...) do {} while (0)
+#endif
 inline bool dw_sync_begin(DwSync& s, hipStream_t stream) {
+  dw_dbg("begin", &s, stream, dw_stream_get());
   if (!s.pending) return true;
   s.pending = false;
+  // The wait is an edge between two pieces of work of the same kind: live stream ↔ live event, or both inside ONE capture. Across the
+  // boundary there is nothing to wait for — a capture starts behind a device synchronisation (the eager weight-gradient kernels are long
+  // done; waiting on their event from a capturing stream while the dw stream itself is being captured is refused by the runtime), and a
+  // captured graph joins the dw stream back into its origin before it ends (lde_join_dw), so whatever follows a replay is ordered behind it.
+  if (dw_is_capturing(stream) != s.done_captured) return true;
   return hipStreamWaitEvent(stream, s.done, 0) == hipSuccess;
 }
 inline hipStream_t dw_sync_switch(DwSync& s, hipStream_t stream, bool* ok) {
   *ok = true;
   hipStream_t dws = dw_stream_get();
+  dw_dbg("switch", &s, stream, dws);
   if (!dws || dws == stream) return stream;
   if (!s.staged && (hipEventCreateWithFlags(&s.staged, hipEventDisableTiming) != hipSuccess ||
                     hipEventCreateWithFlags(&s.done, hipEventDisableTiming) != hipSuccess)) {
@@ -678,8 +700,10 @@ inline hipStream_t dw_sync_switch(DwSync& s, hipStream_t stream, bool* ok) {
   return dws;
 }
 inline bool dw_sync_end(DwSync& s, hipStream_t used, hipStream_t stream) {
+  dw_dbg("end", &s, stream, used);
   if (used == stream) return true;
   s.pending = true;
+  s.done_captured = dw_is_capturing(used);
   return hipEventRecord(s.done, used) == hipSuccess;
 }
 

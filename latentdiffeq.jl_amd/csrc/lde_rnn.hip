@@ -1278,7 +1278,7 @@ int lde_rnn_backward_dw(lde_rnn* r, float* dW, void* stream_) {
   const RnnDims& rd = r->rd;
   const int ntile = cdiv(B, 16);
   bool sw_ok = true;
-  hipStream_t wst = dw_sync_switch(r->dws, stream, &sw_ok);   // the weight-gradient kernels: on the dw stream when one is set
+  hipStream_t wst = t_rrec ? stream : dw_sync_switch(r->dws, stream, &sw_ok);   // the weight-gradient kernels: on the dw stream when one is set (a grouped call's stay on the caller's)
   if (!sw_ok) {
     r->err = "lde_rnn_backward: switching to the weight-gradient stream failed";
     return LDE_ERR_HIP;
@@ -1407,7 +1407,7 @@ static bool rnn_group_ok(int n) {
 #if LDE_PROF
   return false;
 #else
-  return n >= 2 && n <= RNN_GROUP_MAX && dw_stream_get() == nullptr;
+  return n >= 2 && n <= RNN_GROUP_MAX;   // (with a weight-gradient stream set, a group's jobs stay on the caller's stream)
 #endif
 }
 static bool rnn_group_fits(int n, lde_rnn* const* rs) {   // every (stack, cell) weight-gradient job must fit one table; a handle's workspace serves one call at a time

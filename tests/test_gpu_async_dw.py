@@ -69,3 +69,53 @@ def test_join_without_a_stream_is_a_no_op():
     lib = L.load()
     assert lib.lde_set_dw_stream(None) == 0 and lib.lde_join_dw(None) == 0
     L.join_weight_gradients()
+
+
+def test_the_weight_gradient_stream_is_a_branch_of_a_captured_step():
+    """Stream capture with the weight-gradient stream set: the capture forks into it and joins back (lde_join_dw); the events the eager
+    warm-up steps left behind are not waited for across the capture boundary (the runtime refuses such a wait once the dw stream itself is
+    being captured — found in round 5), and grouped calls stay available. Replayed gradients equal the eager, synchronous ones bit for bit
+    (the non-variational loss: no ε to keep in step)."""
+    import torch
+    from latentdiffeq_amd import _lib as L
+    from latentdiffeq_amd import recurrent as R
+    from latentdiffeq_amd import train as TR
+    B, T = 32, 20
+    ts = np.arange(T) * 0.05
+    x = torch.rand(T, B, 784, device="cuda").permute(2, 1, 0)
+    m = _model(7)
+    old = R._BRANCH_STREAMS
+    R._BRANCH_STREAMS = False           # (a captured step runs the encoder on one stream)
+
+    def grads():
+        for p in m.parameters():
+            p.grad = None
+        loss = TR.loss_batch(m, x, ts, 1e-3, False)
+        loss.backward()
+        L.join_weight_gradients()
+        torch.cuda.synchronize()
+        return [p.grad.detach().clone() for p in m.parameters()]
+    try:
+        L.set_async_weight_gradients(False)
+        g0 = grads()
+        L.set_async_weight_gradients(True)
+        for _ in range(2):
+            g1 = grads()                # eager, asynchronous: leaves pending events behind
+        assert all(torch.equal(u, v) for u, v in zip(g0, g1))
+        for p in m.parameters():
+            p.grad = None
+        graph = torch.cuda.CUDAGraph()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.graph(graph, stream=side):
+            loss = TR.loss_batch(m, x, ts, 1e-3, False)
+            loss.backward()
+            L.join_weight_gradients()
+        for _ in range(3):
+            graph.replay()
+        torch.cuda.synchronize()
+        g2 = [p.grad.detach().clone() for p in m.parameters()]
+        assert all(torch.equal(u, v) for u, v in zip(g0, g2))
+    finally:
+        L.set_async_weight_gradients(False)
+        R._BRANCH_STREAMS = old

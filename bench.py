@@ -426,13 +426,18 @@ def run_goku_step(args, torch, dist, world, rank, local):
     Bg = B * world
 
     # default: on for the f32 step (1.036 → 0.998 ms), off for the mixed one (its bf16 weight-gradient kernel is HBM-bound and slows what it runs beside: 0.491 → 0.502 ms)
-    async_dw = args.async_dw == 1 or (args.async_dw == -1 and args.dtype == "f32" and use_graph and world == 1)
+    async_dw = args.async_dw >= 1 or (args.async_dw == -1 and args.dtype == "f32" and use_graph and world == 1)
     if async_dw:
-        # only the reconstructor's weight gradient has something to run beside (the solve's adjoint, the small chains, the recurrent stacks'
-        # pullback); the feature extractor's is the last kernel of the pullback
+        # what has something to run beside: the reconstructor's weight gradient (the solve's adjoint, the small chains, the recurrent stacks'
+        # pullback follow it) and the stacks' (the feature extractor's pullback follows); the feature extractor's own is the last kernel of the
+        # pullback. (--async-dw 2: the stacks' only, 3: the reconstructor's only)
         L.set_async_weight_gradients(True, dev)
-        for m in (enc.feature_extractor, *enc.latent_in, lo_z0, lo_th):
+        off = [enc.feature_extractor, *enc.latent_in, lo_z0, lo_th] + ([dec.reconstructor] if args.async_dw == 2 else [])
+        for m in off:
             L.check(L.load().lde_chain_set_option(m._native(), b"async_dw", 0.0), m._native(), "lde_chain_set_option", chain=True)
+        if args.async_dw == 3:
+            for m in enc.pattern_extractor:
+                L.check(L.load().lde_rnn_set_option(m._native(), b"async_dw", 0.0), m._native(), "lde_rnn_set_option", rnn=True)
     fused_loss = True     # (False: separate sample / vector_kl / reconstruction_loss and torch additions — tests/test_gpu_loss.py compares the two)
     refresh = True   # one k_refresh_many launch re-packs every module's weights after the update (instead of an upload at each module's next call)
 
@@ -695,7 +700,7 @@ def main():
     ap.add_argument("--sensealg", default="default", choices=["default", "discrete"],
                     help="discrete: LDE_SENSE_DISCRETE (the exact derivative of the discrete solve — the reference's ForwardDiffSensitivity) "
                          "instead of the workload's continuous adjoint")
-    ap.add_argument("--async-dw", type=int, default=-1, choices=[-1, 0, 1],
+    ap.add_argument("--async-dw", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
                     help="goku_step: the large chains' weight-gradient kernels on a stream of their own — a parallel branch of the captured step (-1: the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-other-sensealg", action="store_true", help="skip the second measurement with the other definition of the gradient (profiling runs: one set of kernels per trace)")

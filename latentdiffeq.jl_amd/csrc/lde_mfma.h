@@ -699,6 +699,10 @@ inline hipStream_t dw_sync_switch(DwSync& s, hipStream_t stream, bool* ok) {
   }
   return dws;
 }
+inline bool dw_sync_ensure(DwSync& s) {   // the two events exist (dw_sync_switch creates them for the handle it is called with)
+  if (s.staged) return true;
+  return hipEventCreateWithFlags(&s.staged, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&s.done, hipEventDisableTiming) == hipSuccess;
+}
 inline bool dw_sync_end(DwSync& s, hipStream_t used, hipStream_t stream) {
   dw_dbg("end", &s, stream, used);
   if (used == stream) return true;

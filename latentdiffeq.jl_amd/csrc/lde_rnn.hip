@@ -862,6 +862,7 @@ struct lde_rnn {
   int32_t* ints = nullptr; size_t ints_cap = 0;
   bool accumulate = true;   // pullback: dW += gradient (default) or dW = gradient
   int opt_generic = 0, opt_regw = 1, opt_pipe = 1;   // lde_rnn_set_option: "generic", "regw", "pipe" (kernel-choice knobs of the parity tests)
+  int opt_async_dw = 1;                              // "async_dw": with a dw stream set, a grouped pullback's weight-gradient products go there (0: stay on the caller's stream)
   void (*kernel[4][3])(lde::RnnDims, lde::RnnArgs) = {};   // the k_rnn instantiations for this stack: [mode][any workgroup size, one wave per workgroup, one wave per cell]
   int io_ldy = 0, io_lddy = 0;       // set around a call by the *_ld group entry points (0: rows are hL apart)
   const float* io_dy2 = nullptr;
@@ -1097,6 +1098,8 @@ struct RnnGroupRec {
   RnnRecDw dw[GROUP_MAX_DW];
   int ns0 = 0;
   RnnRecS0 s0[RNN_GROUP_MAX];
+  lde_rnn* hs[RNN_GROUP_MAX] = {};   // the stacks of the call (their weight-gradient events, when the group's products go to the dw stream)
+  int nhs = 0;
 };
 static thread_local RnnGroupRec* t_rrec = nullptr;
 static_assert(sizeof(GroupTable<RnnDims, RnnArgs, RNN_GROUP_MAX>) <= 4096, "a group's argument table must fit the kernel-argument segment");
@@ -1348,6 +1351,18 @@ static int rnn_group_flush(RnnGroupRec& g, hipStream_t stream) {
         if (g.main_set[j]) hipLaunchKernelGGL(g.main[j].fn, dim3(g.main[j].grid), dim3(g.main[j].block), g.main[j].lds, stream, g.main[j].rd, g.main[j].a);
     }
   }
+  // With a weight-gradient stream set (lde_set_dw_stream) the products, their slab sums and the initial-state sums of the whole group go
+  // there — a branch beside whatever the caller enqueues next (the feature extractor's pullback needs only the sweeps' input gradients);
+  // every stack's event is recorded behind them (its next call waits for it before its workspace is rewritten).
+  hipStream_t origin = stream;
+  bool forked = false;
+  if ((g.ndw > 0 || g.ns0 > 0) && g.nhs > 0 && g.hs[0]->opt_async_dw) {
+    bool ok = true;
+    hipStream_t wst = dw_sync_switch(g.hs[0]->dws, stream, &ok);
+    if (!ok) return LDE_ERR_HIP;
+    forked = wst != stream;
+    stream = wst;
+  }
   if (g.ndw > 0) {   // the weight-gradient products of every (stack, cell), then their slab sums
     bool same = g.ndw >= 2;
     for (int j = 0; j < g.ndw; j++) same = same && g.dw[j].ndw == 1;
@@ -1401,6 +1416,17 @@ static int rnn_group_flush(RnnGroupRec& g, hipStream_t stream) {
       hipLaunchKernelGGL(k_rnn_state0, dim3(q.grid), dim3(64), 0, stream, q.a.g0, q.a.B, q.a.g0w, q.rd, q.a.dW, q.a.assign);
     }
   }
+#if LDE_DW_DEBUG
+  { hipError_t e = hipPeekAtLastError(); if (e != hipSuccess) fprintf(stderr, "[dw rnn flush] before the events: %s\n", hipGetErrorString(e)); }
+#endif
+  if (forked)
+    for (int j = 0; j < g.nhs; j++)
+      if (!dw_sync_ensure(g.hs[j]->dws) || !dw_sync_end(g.hs[j]->dws, stream, origin)) {
+#if LDE_DW_DEBUG
+        fprintf(stderr, "[dw rnn flush] dw_sync_end %d failed: %s\n", j, hipGetErrorString(hipPeekAtLastError()));
+#endif
+        return LDE_ERR_HIP;
+      }
   return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
 }
 static bool rnn_group_ok(int n) {
@@ -1481,6 +1507,8 @@ int lde_rnn_group_backward(int n, lde_rnn* const* rs, const float* const* xs, co
   }
   RnnGroupRec g;
   t_rrec = &g;
+  g.nhs = n;
+  for (int i = 0; i < n; i++) g.hs[i] = rs[i];
   for (int i = 0; i < n; i++) {
     g.n = i;
     int rc = lde_rnn_backward_dx(rs[i], xs[i], dys[i], T, B, dxs ? dxs[i] : nullptr, stream);
@@ -1542,7 +1570,8 @@ int lde_rnn_set_accumulate(lde_rnn* r, int on) {
 
 int lde_rnn_set_option(lde_rnn* r, const char* key, double value) {
   if (!r || !key) return LDE_ERR_INVALID_ARG;
-  int* slot = !std::strcmp(key, "generic") ? &r->opt_generic : !std::strcmp(key, "regw") ? &r->opt_regw : !std::strcmp(key, "pipe") ? &r->opt_pipe : nullptr;
+  int* slot = !std::strcmp(key, "generic") ? &r->opt_generic : !std::strcmp(key, "regw") ? &r->opt_regw : !std::strcmp(key, "pipe") ? &r->opt_pipe
+              : !std::strcmp(key, "async_dw") ? &r->opt_async_dw : nullptr;
   if (!slot || !(value >= 0)) {
     r->err = std::string("lde_rnn_set_option: unknown key or negative value: ") + key;
     return LDE_ERR_INVALID_ARG;

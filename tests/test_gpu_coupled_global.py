@@ -134,11 +134,21 @@ def test_two_shards_under_the_global_norm_equal_the_unsharded_solve():
             err.append(e)
             bar.abort()
 
-    th = [threading.Thread(target=rank, args=(r,)) for r in range(2)]
-    for t in th:
-        t.start()
-    for t in th:
-        t.join(timeout=300)
+    # (the same construction artefact from another side: a handle of an EARLIER test collected by Python's garbage collector in the middle of
+    #  the two solves — lde_destroy → hipFree synchronises the device — stalls one thread behind the other's waiting kernel until the barrier
+    #  times out; seen once in a full-suite run of round 5. Collected now, and not again until both shards are done.)
+    import gc
+    gc.collect()
+    torch.cuda.synchronize()
+    gc.disable()
+    try:
+        th = [threading.Thread(target=rank, args=(r,)) for r in range(2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join(timeout=300)
+    finally:
+        gc.enable()
     assert not err, err
     scale = max(1.0, np.abs(zf).max())
     gW = out[0][4] + out[1][4]               # the path's one data collective: Σ over ranks of the shared weight gradient

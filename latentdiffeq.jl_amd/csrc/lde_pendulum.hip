@@ -872,13 +872,17 @@ __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict
 // waits; what follows the last step is one helper's last evaluation. Records live in a ring of SH_CAP steps (a solve that needs
 // more goes through another round: one barrier pair); a failed solve's NaN block is written after the helpers' stores have landed.
 constexpr int SH_CAP = 48;       // accepted steps recorded per round (48 KB of LDS: 16 B × 64 lane copies per step)
-constexpr int SH_NH = 3;         // helper waves
+#ifndef LDE_SH_NH
+#define LDE_SH_NH 3
+#endif
+constexpr int SH_NH = LDE_SH_NH;   // helper waves (measured at B = 256 with 3 / 5 / 7: 20.2 / 20.0 / 20.0–20.2 M trajectories/s — the tail behind the
+                                  // stepper's last step is not the helpers' throughput)
 #ifndef LDE_PEND_SH_SLEEP
 #define LDE_PEND_SH_SLEEP 0
 #endif
 
 template <int KIND, int SOLVER, bool ADAPT, bool REC>   // REC: the instantiation that writes step records (LDE_SENSE_DISCRETE, "step_trace")
-__global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restrict__ z0, const float* __restrict__ theta,
+__global__ void __launch_bounds__(64 * (1 + SH_NH)) k_pend_forward_sh(const float2* __restrict__ z0, const float* __restrict__ theta,
                                                          const double* __restrict__ ts_g, KOpts o,
                                                          float2* __restrict__ z_out, int32_t* __restrict__ retcode,
                                                          int32_t* __restrict__ st_nfe, int32_t* __restrict__ st_nacc,
@@ -1159,7 +1163,7 @@ __global__ void __launch_bounds__(256) k_pend_forward_sh(const float2* __restric
     __syncthreads();   // B
   }
 #if LDE_PEND_PROF
-  if (blockIdx.x == 0 && lane == 0) { g_pprof[2 * (12 + hid)] = wall_clock64(); g_pprof[2 * (12 + hid) + 1] = __builtin_readcyclecounter(); }   // helper hid has stored its last save
+  if (blockIdx.x == 0 && lane == 0 && hid < 3) { g_pprof[2 * (12 + hid)] = wall_clock64(); g_pprof[2 * (12 + hid) + 1] = __builtin_readcyclecounter(); }   // helper hid has stored its last save
 #endif
   if (__hip_atomic_load(&s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1732,10 +1736,10 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
 #define LDE_LAUNCH_SH(K, S, A)                                                                                          \
   do {                                                                                                                  \
     if (o.rec.n)                                                                                                        \
-      hipLaunchKernelGGL((k_pend_forward_sh<K, S, A, true>), dim3(g8), dim3(256), 0, stream, (const float2*)z0, theta, ts_dev, o,  \
+      hipLaunchKernelGGL((k_pend_forward_sh<K, S, A, true>), dim3(g8), dim3(64 * (1 + SH_NH)), 0, stream, (const float2*)z0, theta, ts_dev, o,  \
                          (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                                \
     else                                                                                                                \
-      hipLaunchKernelGGL((k_pend_forward_sh<K, S, A, false>), dim3(g8), dim3(256), 0, stream, (const float2*)z0, theta, ts_dev, o, \
+      hipLaunchKernelGGL((k_pend_forward_sh<K, S, A, false>), dim3(g8), dim3(64 * (1 + SH_NH)), 0, stream, (const float2*)z0, theta, ts_dev, o, \
                          (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                                \
   } while (0)
     if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5 && ad) LDE_LAUNCH_SH(0, LDE_SOLVER_TSIT5, true);

@@ -143,6 +143,33 @@ def test_goku_discrete_every_recording_forward_mapping(o32, o64, B, options, tol
         assert int(rec["n"].max()) > 96
 
 
+@pytest.mark.parametrize("T", [1, 2, 3])
+@pytest.mark.parametrize("solver", [O.SOLVER_TSIT5, O.SOLVER_RK4])
+def test_goku_discrete_smallest_grids_and_batches(o32, o64, T, solver):
+    """One, two and three save times (T = 1: no step at all — the pullback is the cotangent of ẑ₀ itself), five trajectories (less than a
+    workgroup row of the XCD-aware map), both pullback mappings."""
+    B = 5
+    kw = dict(solver=solver)
+    if solver == O.SOLVER_RK4:
+        kw.update(adaptive=0, dt=0.02)
+    z0, L = O.pendulum_inputs(B, seed=12)
+    ts = O.time_grid(T)
+    dz = O.cotangent(T, B, 2)
+    res = []
+    for tp in (1 << 20, 0):
+        nat, od = _native(None, **kw)
+        nat.set_option("pend_disc_tp_max_b", tp)
+        if T == 1:
+            z, ret, st = nat.forward(z0, L, ts)
+            g0, gth, _, sb = nat.adjoint(z, L, ts, dz)
+            assert np.array_equal(z[0], z0) and np.array_equal(g0, dz[0]) and (gth == 0).all() and sb["nfailed"] == 0
+        else:
+            _, _, (g0, gth, _), _, _ = _check(nat, od, o32, o64, z0, L, ts, dz, None)
+        res.append((g0, gth))
+    assert np.allclose(res[0][0], res[1][0], rtol=0, atol=1e-6 * max(1e-30, np.abs(res[1][0]).max()))
+    assert np.allclose(res[0][1], res[1][1], rtol=0, atol=1e-6 * max(1e-30, np.abs(res[1][1]).max()) + 1e-12)
+
+
 @pytest.mark.parametrize("kind,solver", [(O.RHS_PENDULUM, O.SOLVER_TSIT5), (O.RHS_PENDULUM_FRICTION, O.SOLVER_TSIT5), (O.RHS_PENDULUM, O.SOLVER_RK4)])
 def test_goku_discrete_long_records_and_ragged_save_grids(o32, o64, kind, solver):
     """Records longer than one round of the steps-side-by-side kernel (21 steps per round; here 60 … 200), 150 save times on a ragged

@@ -225,6 +225,20 @@ int lde_get_phase_ms(lde_handle* h, float* ms2);
 typedef int (*lde_sum_hook)(void* user, double* vals, int n);
 int lde_set_global_sum_hook(lde_handle* h, lde_sum_hook hook, void* user, int64_t global_batch);
 
+/* The same exchange WITHOUT the host (round 5): every rank owns a mailbox of lde_global_sum_mailbox_bytes(nranks) bytes of device memory,
+ * zero-initialised once, that every other rank's device can write (one process per GPU: fine-grained memory — hipExtMallocWithFlags(…,
+ * hipDeviceMallocFinegrained) — shared by hipIpcGetMemHandle / hipIpcOpenMemHandle with peer access enabled; ranks that share a device
+ * pass plain device pointers). `mailboxes[r]` = rank r's mailbox AS MAPPED ON THIS DEVICE, the same order on every rank, `rank` = this
+ * handle's index in it. Workgroup 0 of the solve's kernel writes this rank's (float32) sums into slot `rank` of every mailbox, waits for the
+ * nranks words of its own and adds them in rank order — the same bits on every rank — so lde_forward / lde_adjoint stay asynchronous and
+ * a sum costs one xGMI round trip instead of a host collective. Every rank must make the same sequence of calls on its handle (the words are
+ * tagged with the handle's launch count and the launch's sum count, and those are compared across ranks); a rank that stops answering
+ * poisons the others' sums after a bounded spin (retcode != 0, never a hang). nranks ≤ 8 (one node); nranks == 0 switches the path off;
+ * setting peers clears a hook. [REF src/models/LatentODE.jl:70-72] as above. Exercised in this repository by two handles on ONE device
+ * (tests/test_gpu_coupled_global.py) — the cross-device mapping itself has not run on hardware here (one-GPU boxes). */
+int64_t lde_global_sum_mailbox_bytes(int nranks);
+int lde_set_global_sum_peers(lde_handle* h, int rank, int nranks, void* const* mailboxes, int64_t global_batch);
+
 /* ---- step records: LDE_SENSE_DISCRETE's hand-over between lde_forward and lde_adjoint, and the parity tests' view of a solve's steps ----
  * A record holds, per step sequence (one per trajectory with LDE_BATCH_PER_TRAJECTORY, one for a coupled solve) and accepted step n,
  * the step's start time and size (f64) and — forward records — the state y_n [D'×B] it started from. With sensealg = LDE_SENSE_DISCRETE

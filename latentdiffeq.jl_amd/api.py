@@ -291,6 +291,21 @@ class NODE:
         L.check(lib.lde_set_global_sum_hook(h.ptr, cb, None, int(global_batch)), h.ptr, "lde_set_global_sum_hook")
         self._sum_cb = cb              # keep the trampoline alive as long as the handle uses it
 
+    def set_global_sum_peers(self, rank: int, nranks: int, mailboxes, global_batch: int):
+        """lde_set_global_sum_peers: the same exchange device to device — `mailboxes` = every rank's mailbox as mapped on this device, in rank
+        order (`dist.GlobalSumMailboxes(group).pointers()`; integers or tensors). The calls stay asynchronous. nranks = 0 switches it off."""
+        import ctypes as C
+        lib = L.load()
+        h = self._native()
+        if nranks == 0:
+            L.check(lib.lde_set_global_sum_peers(h.ptr, 0, 0, None, 0), h.ptr, "lde_set_global_sum_peers")
+            self._mailboxes = None
+            return
+        ptrs = [m.data_ptr() if hasattr(m, "data_ptr") else int(m) for m in mailboxes]
+        arr = (C.c_void_p * len(ptrs))(*ptrs)
+        L.check(lib.lde_set_global_sum_peers(h.ptr, int(rank), int(nranks), arr, int(global_batch)), h.ptr, "lde_set_global_sum_peers")
+        self._mailboxes = mailboxes       # kept alive as long as the handle uses them
+
     def flat_weights(self) -> torch.Tensor:
         """Flux.destructure order: per Dense layer vec(W) column-major [out×in], then b."""
         parts = []

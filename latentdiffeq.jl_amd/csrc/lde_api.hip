@@ -38,6 +38,8 @@ int mlp_plan_create(const lde_problem_desc& d, MlpPlan** out, std::string& err);
 void mlp_plan_destroy(MlpPlan* p);
 int mlp_reserve(MlpPlan* p, int B, int T, std::string& err);
 int mlp_set_sum_hook(MlpPlan* p, lde_sum_hook hook, void* user, int64_t global_batch, std::string& err);
+size_t mlp_sum_mailbox_bytes(int nranks);
+int mlp_set_sum_peers(MlpPlan* p, int rank, int nranks, void* const* boxes, int64_t global_batch, std::string& err);
 int mlp_set_phase_timing(MlpPlan* p, int on);
 int mlp_last_family(const MlpPlan* p);
 MlpTune* mlp_tune(MlpPlan* p);
@@ -591,6 +593,16 @@ int lde_set_global_sum_hook(lde_handle* h, lde_sum_hook hook, void* user, int64_
     return LDE_ERR_INVALID_ARG;
   }
   return lde::mlp_set_sum_hook(h->mlp, hook, user, hook ? global_batch : 0, h->err);
+}
+
+int64_t lde_global_sum_mailbox_bytes(int nranks) { return nranks < 1 || nranks > 8 ? 0 : (int64_t)lde::mlp_sum_mailbox_bytes(nranks); }
+int lde_set_global_sum_peers(lde_handle* h, int rank, int nranks, void* const* mailboxes, int64_t global_batch) {
+  if (!h) return LDE_ERR_INVALID_ARG;
+  if (h->d.batching != LDE_BATCH_COUPLED_GLOBAL || !h->mlp) {
+    h->err = "lde_set_global_sum_peers: the handle was not created with LDE_BATCH_COUPLED_GLOBAL";
+    return LDE_ERR_INVALID_ARG;
+  }
+  return lde::mlp_set_sum_peers(h->mlp, rank, nranks, mailboxes, global_batch, h->err);
 }
 
 int64_t lde_step_record_bytes(const lde_handle* h, int B, int T) {

@@ -188,6 +188,7 @@ __device__ __forceinline__ void layer_gemm(const float* lds_base, int ofs, const
 }
 
 // ---- grid-wide deterministic sum (coupled mode) ----------------------------------------------------
+constexpr int LDE_MAX_PEERS = 8;   // ranks of a device-side cross-rank sum: one node
 struct GridSync {
   unsigned* counter;   // monotonic arrival counter, zeroed before the launch
   float* slots;        // [2][nWG][4] partials (ping-pong by generation parity)
@@ -200,6 +201,12 @@ struct GridSync {
   unsigned long long* host_req;
   unsigned long long* host_rep;
   unsigned long long* dev_rep;
+  // … or, without the host (lde_set_global_sum_peers): every rank's mailbox is mapped on every device — peer[r] = rank r's, [2 parities][ranks][2
+  // words] — and workgroup 0 writes this rank's words into slot `rank` of all of them, then adds the `nranks` words of its own in rank order
+  // (the same bits on every rank). nranks = 0: off.
+  unsigned long long* peer[LDE_MAX_PEERS];
+  int rank, nranks;
+  __host__ __device__ bool cross() const { return host_req != nullptr || nranks > 0; }   // the sums leave the device
 };
 
 // every thread of the workgroup calls this; v[0..3] of thread 0 are the workgroup's partials; returns the totals.
@@ -1413,6 +1420,9 @@ struct MlpPlan {
   unsigned long long* mbox = nullptr;       // pinned, coherent host memory: [0..2] request words, [8..9] reply words
   unsigned long long* mbox_dev = nullptr;   // device memory: the reply republished for the other workgroups
   hipEvent_t mbox_ev = nullptr;
+  // … or device to device (lde_set_global_sum_peers): every rank's mailbox as mapped on THIS device
+  int peer_n = 0, peer_rank = 0;
+  unsigned long long* peer_box[LDE_MAX_PEERS] = {};
   // lde_set_phase_timing: HIP events around the adjoint's solve kernel and its weight-gradient tail (bench.py's per-kernel roofline)
   bool phase_on = false;
   hipEvent_t ph_ev[3] = {nullptr, nullptr, nullptr};
@@ -2011,7 +2021,7 @@ static int launch_w(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t
     }
   }
   a.wpack = p->wpack;
-  const bool relay = a.gs.host_req != nullptr;   // LDE_BATCH_COUPLED_GLOBAL: sums leave the device; a plain launch (two ranks' cooperative
+  const bool relay = a.gs.cross();   // LDE_BATCH_COUPLED_GLOBAL: sums leave the device; a plain launch (two ranks' cooperative
                                                  // launches on one device could be serialised by the runtime — each would wait for the other's sums)
   if (coop || relay) {
     const int rcw = grid_words_prepare(p, o.B, a, stream, err);
@@ -2073,7 +2083,7 @@ static int launch_b(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t
     }
   }
   a.wpack = p->bpack;
-  const bool relay = a.gs.host_req != nullptr;   // LDE_BATCH_COUPLED_GLOBAL: sums leave the device; a plain launch (see launch_w)
+  const bool relay = a.gs.cross();   // LDE_BATCH_COUPLED_GLOBAL: sums leave the device; a plain launch (see launch_w)
   if (coop || relay) {
     const int rcw = grid_words_prepare(p, o.B, a, stream, err);
     if (rcw) return rcw;
@@ -2144,7 +2154,7 @@ static int launch_c(MlpPlan* p, const KOpts& o, VArgs& a, bool coop, hipStream_t
   a.wpack = p->cpack;
   const int nwg = (o.B + 1) / 2;
   a.gs.nwg = a.gs.nwg > 1 ? nwg : a.gs.nwg;   // (grid-wide sums: one word pair per workgroup)
-  const bool relay = a.gs.host_req != nullptr;   // LDE_BATCH_COUPLED_GLOBAL: sums leave the device; a plain launch (see launch_w)
+  const bool relay = a.gs.cross();   // LDE_BATCH_COUPLED_GLOBAL: sums leave the device; a plain launch (see launch_w)
   if (coop || relay) {
     const int rcw = grid_words_prepare(p, o.B, a, stream, err);
     if (rcw) return rcw;
@@ -2197,12 +2207,54 @@ int mlp_set_sum_hook(MlpPlan* p, lde_sum_hook hook, void* user, int64_t global_b
   return LDE_OK;
 }
 
+size_t mlp_sum_mailbox_bytes(int nranks) { return (size_t)4 * (size_t)std::max(nranks, 1) * 2 * sizeof(unsigned long long); }   // (launch parity, sum parity) × ranks × 2 words
+int mlp_set_sum_peers(MlpPlan* p, int rank, int nranks, void* const* boxes, int64_t global_batch, std::string& err) {
+  if (nranks == 0) {   // off
+    p->peer_n = 0;
+    return LDE_OK;
+  }
+  if (nranks < 1 || nranks > LDE_MAX_PEERS || rank < 0 || rank >= nranks || !boxes || global_batch < 1) {
+    err = "lde_set_global_sum_peers: 1 … 8 ranks, 0 ≤ rank < nranks, a mailbox pointer per rank, global_batch ≥ 1";
+    return LDE_ERR_INVALID_ARG;
+  }
+  for (int r = 0; r < nranks; r++)
+    if (!boxes[r] || (((uintptr_t)boxes[r]) & 7) != 0) {
+      err = "lde_set_global_sum_peers: NULL or unaligned mailbox pointer";
+      return LDE_ERR_INVALID_ARG;
+    }
+  if (!p->mbox_dev && hipMalloc(&p->mbox_dev, 16 * sizeof(unsigned long long)) != hipSuccess) {
+    (void)hipGetLastError();
+    err = "lde_set_global_sum_peers: allocating the republish words failed";
+    return LDE_ERR_ALLOC;
+  }
+  p->sum_hook = nullptr;   // one exchange path at a time
+  p->peer_n = nranks;
+  p->peer_rank = rank;
+  for (int r = 0; r < nranks; r++) p->peer_box[r] = (unsigned long long*)boxes[r];
+  p->global_batch = global_batch;
+  return LDE_OK;
+}
+
 // LDE_BATCH_COUPLED_GLOBAL with a hook: arm the mailbox before the launch …
 static int global_arm(MlpPlan* p, VArgs& a, hipStream_t stream, std::string& err) {
   a.gs.host_req = nullptr;
   a.gs.host_rep = nullptr;
   a.gs.dev_rep = nullptr;
+  a.gs.nranks = 0;
+  a.gs.rank = 0;
   a.Bnorm = 0;
+  if (p->global_mode && p->peer_n > 0) {   // device to device: nothing for the host to serve, the call stays asynchronous
+    if (hipMemsetAsync(p->mbox_dev, 0, 16 * sizeof(unsigned long long), stream) != hipSuccess) {
+      err = "hipMemsetAsync(mailbox) failed";
+      return LDE_ERR_HIP;
+    }
+    a.gs.nranks = p->peer_n;
+    a.gs.rank = p->peer_rank;
+    for (int r = 0; r < p->peer_n; r++) a.gs.peer[r] = p->peer_box[r];
+    a.gs.dev_rep = p->mbox_dev;
+    a.Bnorm = p->global_batch;
+    return LDE_OK;
+  }
   if (!p->global_mode || !p->sum_hook) return LDE_OK;
   for (int i = 0; i < 16; i++) p->mbox[i] = 0;
   if (hipMemsetAsync(p->mbox_dev, 0, 16 * sizeof(unsigned long long), stream) != hipSuccess) {
@@ -2481,7 +2533,7 @@ static int mlp_adjoint_disc(MlpPlan* p, const float* W_dev, const float* z_out, 
     va.dz0 = dz0; va.dtheta = dtheta; va.stage = p->rows; va.cap = p->rows_stride;
     va.st_nfe = nfe; va.st_nacc = nacc; va.st_nrej = nrej; va.st_ret = ret;
     va.gs.counter = p->counter; va.gs.slots = p->slots; va.gs.abort_flag = p->abort_flag; va.gs.nwg = 1;
-    va.gs.host_req = nullptr; va.gs.host_rep = nullptr; va.gs.dev_rep = nullptr; va.Bnorm = 0;
+    va.gs.host_req = nullptr; va.gs.host_rep = nullptr; va.gs.dev_rep = nullptr; va.gs.nranks = 0; va.gs.rank = 0; va.Bnorm = 0;
     phase_mark(p, 0, stream);
     const bool rk4 = dm.solver == LDE_SOLVER_RK4;
     const int rcb = fam == DISC_B ? (rk4 ? launch_b<LDE_SOLVER_RK4, true, true>(p, o, va, false, stream, err)

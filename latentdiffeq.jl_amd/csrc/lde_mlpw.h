@@ -84,9 +84,47 @@ static __global__ void k_build_wpack(const float* __restrict__ Wflat, MlpDims dm
 // the host, which adds the other ranks' values through the caller's hook, and republishes the answer in device memory
 template <bool TWO>
 __device__ __forceinline__ void w_host_sum(const GridSync& gs, unsigned tag, float& v0, float& v1) {
-  if (!gs.host_req) return;
+  if (!gs.cross()) return;
   bool aborted = false;
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
+  if (gs.nranks > 0) {
+    // device to device: this rank's words go into slot `rank` of EVERY rank's mailbox (its own included), then the nranks words of its own
+    // mailbox are awaited and added in rank order. Word sets by (launch parity, sum parity): a rank writes sum g + 2 only after it has read all
+    // of g + 1, which every rank wrote after reading g; the first sums of the NEXT launch use the other launch parity. Every rank must make
+    // the same sequence of calls on its handle (the tag = (launch count, sum count) is compared across ranks). System scope: the words cross xGMI
+    // (fine-grained, peer-mapped memory).
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      const size_t par = (size_t)((((tag >> 16) & 1u) << 1) | (tag & 1u)) * gs.nranks * 2;   // four word sets: (launch parity, sum parity)
+      const unsigned long long w0 = ((unsigned long long)tag << 32) | __float_as_uint(v0), w1 = ((unsigned long long)tag << 32) | __float_as_uint(TWO ? v1 : 0.f);
+      for (int r = 0; r < gs.nranks; r++) {
+        unsigned long long* box = gs.peer[r] + par + (size_t)gs.rank * 2;
+        __hip_atomic_store(box + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(box + 0, w0, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      float t0 = 0.f, t1 = 0.f;
+      bool bad = false;
+      const unsigned long long* mine = gs.peer[gs.rank] + par;
+      for (int r = 0; r < gs.nranks && !bad; r++) {
+        unsigned long long q0 = 0, q1 = 0;
+        long long spins = 0;
+        for (;;) {
+          q0 = __hip_atomic_load(mine + (size_t)r * 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
+          q1 = __hip_atomic_load(mine + (size_t)r * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          if ((unsigned)(q0 >> 32) == tag && (unsigned)(q1 >> 32) == tag) break;
+          __builtin_amdgcn_s_sleep(2);
+          if ((++spins & 1023) == 0 && (spins > 8000000LL || __hip_atomic_load(gs.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+            __hip_atomic_store(gs.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // a peer rank is gone: poison the sums instead of hanging
+            bad = true;
+            break;
+          }
+        }
+        t0 += __uint_as_float((unsigned)q0);
+        t1 += __uint_as_float((unsigned)q1);
+      }
+      const unsigned nanb = 0x7fc00000u;
+      __hip_atomic_store(gs.dev_rep + 1, ((unsigned long long)tag << 32) | (bad ? nanb : __float_as_uint(t1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(gs.dev_rep + 0, ((unsigned long long)tag << 32) | (bad ? nanb : __float_as_uint(t0)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  } else if (blockIdx.x == 0 && threadIdx.x == 0) {
     __hip_atomic_store(gs.host_req + 0, ((unsigned long long)tag << 32) | __float_as_uint(v0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(gs.host_req + 1, ((unsigned long long)tag << 32) | __float_as_uint(TWO ? v1 : 0.f), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     __hip_atomic_store(gs.host_req + 2, ((unsigned long long)tag << 32) | (TWO ? 2u : 1u), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -130,7 +168,7 @@ __device__ __forceinline__ void w_host_sum(const GridSync& gs, unsigned tag, flo
 // the other workgroups' words arrive): publish this workgroup's words — collect all of them. w_grid_sum = one behind the other.
 template <bool TWO>
 __device__ __forceinline__ void w_grid_publish(const GridSync& gs, unsigned& gen, unsigned epoch, float v0, float v1) {
-  if (gs.nwg == 1 && !gs.host_req) return;
+  if (gs.nwg == 1 && !gs.cross()) return;
   gen++;
   if (gs.nwg == 1) return;
   const unsigned tag = (epoch << 16) + gen;
@@ -143,7 +181,7 @@ __device__ __forceinline__ void w_grid_publish(const GridSync& gs, unsigned& gen
 }
 template <bool TWO>
 __device__ __forceinline__ void w_grid_collect(const GridSync& gs, unsigned gen, unsigned epoch, float& v0, float& v1) {   // `gen` as w_grid_publish left it
-  if (gs.nwg == 1 && !gs.host_req) return;
+  if (gs.nwg == 1 && !gs.cross()) return;
   PROF_T(g0);
   const unsigned tag = (epoch << 16) + gen;
   if (gs.nwg == 1) {

@@ -273,6 +273,82 @@ def global_sum_hook(group=None):
     return fn
 
 
+class GlobalSumMailboxes:
+    """The device-to-device exchange of LDE_BATCH_COUPLED_GLOBAL's step-control sums (`NODE.set_global_sum_peers`, lde_set_global_sum_peers):
+    one mailbox per rank in FINE-GRAINED device memory (hipExtMallocWithFlags — a kernel on another GPU sees the words while both kernels run),
+    shared between the processes of one node by hipIpcGetMemHandle / hipIpcOpenMemHandle, the handles gathered over `group` (any backend:
+    64 bytes per rank, once). `.pointers()` is the list every rank passes, in rank order; keep the object alive as long as the handles use it.
+
+    One process per GPU, one node (≤ 8 ranks). With a single rank — all a one-GPU box can run, and what tests/test_gpu_coupled_global.py
+    runs — the allocation, the hand-over and the kernel's exchange with itself are exercised; the cross-process mapping is written to the
+    HIP IPC contract and has NOT run on multi-GPU hardware in this repository."""
+
+    _FINEGRAINED = 0x1   # hipDeviceMallocFinegrained
+    _LAZY_PEER = 0x1     # hipIpcMemLazyEnablePeerAccess
+
+    def __init__(self, group=None, device=None):
+        import ctypes as C
+        from . import _lib as L
+        self._C = C
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        if self.world > 8:
+            raise ValueError("GlobalSumMailboxes: at most 8 ranks (one node)")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self._hip = C.CDLL("libamdhip64.so")
+        self.nbytes = int(L.load().lde_global_sum_mailbox_bytes(self.world))
+        with torch.cuda.device(self.device):
+            own = C.c_void_p()
+            rc = self._hip.hipExtMallocWithFlags(C.byref(own), C.c_size_t(self.nbytes), C.c_uint(self._FINEGRAINED))
+            if rc != 0 or not own.value:
+                raise RuntimeError(f"hipExtMallocWithFlags(fine-grained mailbox) failed: {rc}")
+            if self._hip.hipMemset(own, 0, C.c_size_t(self.nbytes)) != 0:
+                raise RuntimeError("hipMemset(mailbox) failed")
+            torch.cuda.synchronize()
+            self._own = own
+            self._ptrs = [None] * self.world
+            self._ptrs[self.rank] = own.value
+            self._opened = []
+            if self.world > 1:
+                handle = (C.c_ubyte * 64)()
+                if self._hip.hipIpcGetMemHandle(C.byref(handle), own) != 0:
+                    raise RuntimeError("hipIpcGetMemHandle(mailbox) failed")
+                mine = torch.tensor(list(handle), dtype=torch.uint8)
+                backend = dist.get_backend(group)
+                if backend == "nccl":
+                    mine = mine.to(self.device)
+                gathered = [torch.empty_like(mine) for _ in range(self.world)]
+                dist.all_gather(gathered, mine, group=group)
+                for r, hb in enumerate(gathered):
+                    if r == self.rank:
+                        continue
+                    hr = (C.c_ubyte * 64)(*hb.cpu().tolist())
+                    p = C.c_void_p()
+                    if self._hip.hipIpcOpenMemHandle(C.byref(p), hr, C.c_uint(self._LAZY_PEER)) != 0 or not p.value:
+                        raise RuntimeError(f"hipIpcOpenMemHandle(rank {r}'s mailbox) failed")
+                    self._ptrs[r] = p.value
+                    self._opened.append(p)
+                dist.barrier(group=group)      # every rank has mapped every mailbox before anyone's kernel writes
+
+    def pointers(self):
+        return list(self._ptrs)
+
+    def close(self):
+        C = self._C
+        for p in getattr(self, "_opened", []):
+            self._hip.hipIpcCloseMemHandle(p)
+        self._opened = []
+        if getattr(self, "_own", None) is not None:
+            self._hip.hipFree(self._own)
+            self._own = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:      # noqa: BLE001
+            pass
+
+
 def diffeq_layer_sharded(decoder, l_hat, t, rank: Optional[int] = None, world: Optional[int] = None):
     """diffeq_layer on this rank's block of columns: returns the LOCAL shard ẑ[:, lo:hi, :] (it feeds the local shard of
     the reconstructor). No communication."""

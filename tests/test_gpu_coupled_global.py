@@ -6,7 +6,9 @@ One GPU per box here, so the two "ranks" are two handles driven by two host thre
 meeting at a thread barrier (the exchange a gloo all-reduce performs between processes: tests/test_dist_gloo.py has that side with the
 oracle as the solver). What is checked: with a hook that adds nothing (one rank) the mode IS the plain coupled solve, bit for bit; two
 shards under the global norm reproduce the unsharded solve's step sequence and results to f32 summation order, forward and adjoint
-(ẑ ≤ 1e-6·scale, gradients ≤ 1e-5); the shard-LOCAL norm does not; a failing hook ends the solve with retcode ≠ 0, no hang."""
+(ẑ ≤ 1e-6·scale, gradients ≤ 1e-5); the shard-LOCAL norm does not; a failing hook ends the solve with retcode ≠ 0, no hang. Round 5: the same exchange device to device
+(lde_set_global_sum_peers: every rank's kernel writes its sums into every rank's mailbox; no host in the loop, the calls stay asynchronous) —
+the same two shards, the same assertions."""
 import threading
 
 import numpy as np
@@ -134,21 +136,11 @@ def test_two_shards_under_the_global_norm_equal_the_unsharded_solve():
             err.append(e)
             bar.abort()
 
-    # (the same construction artefact from another side: a handle of an EARLIER test collected by Python's garbage collector in the middle of
-    #  the two solves — lde_destroy → hipFree synchronises the device — stalls one thread behind the other's waiting kernel until the barrier
-    #  times out; seen once in a full-suite run of round 5. Collected now, and not again until both shards are done.)
-    import gc
-    gc.collect()
-    torch.cuda.synchronize()
-    gc.disable()
-    try:
-        th = [threading.Thread(target=rank, args=(r,)) for r in range(2)]
-        for t in th:
-            t.start()
-        for t in th:
-            t.join(timeout=300)
-    finally:
-        gc.enable()
+    th = [threading.Thread(target=rank, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
     assert not err, err
     scale = max(1.0, np.abs(zf).max())
     gW = out[0][4] + out[1][4]               # the path's one data collective: Σ over ranks of the shared weight gradient
@@ -189,3 +181,108 @@ def test_a_failing_hook_fails_the_solve_without_hanging():
     torch.cuda.synchronize()
     assert rc == -1 and b"hook" in nat.lib.lde_last_error(nat.h)
     assert (ret.cpu().numpy() != 0).all() and bool(torch.isnan(out[1:]).all())       # NaN blocks, as every failed solve
+
+
+def test_two_shards_exchange_their_sums_device_to_device():
+    """lde_set_global_sum_peers: the two shards' kernels write their sums into each other's mailbox (here: two allocations of ONE device;
+    across devices the mailboxes are peer-mapped fine-grained memory) — no hook, no host thread in the loop, asynchronous calls. Same
+    step sequence and results as the unsharded solve, forward and adjoint; the two ranks' dẑ₀ / ẑ are bit-identical to the host-relayed
+    exchange of the test above would be (same sums in the same order)."""
+    import ctypes as C
+    import torch
+    from latentdiffeq_amd import _lib as L
+    W = O.mlp_weights(LAYERS, seed=3)
+    B = 192
+    z0, ts, dz = _inputs(B)
+    z0[80:] *= 3.0
+    ref = _setup(O.BATCH_COUPLED, W)
+    zf, _, sf = ref.forward(z0, None, ts)
+    f0, _, fW, sbf = ref.adjoint(zf, None, ts, dz)
+    bounds = [(0, 80), (80, 192)]
+    lib = L.load()
+    nbytes = int(lib.lde_global_sum_mailbox_bytes(2))
+    assert nbytes == 4 * 2 * 2 * 8 and lib.lde_global_sum_mailbox_bytes(9) == 0
+    boxes = [torch.zeros(nbytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
+    ptrs = (C.c_void_p * 2)(*[b_.data_ptr() for b_ in boxes])
+    nats = []
+    for r, (lo, hi) in enumerate(bounds):
+        nat = _setup(O.BATCH_COUPLED_GLOBAL, W)
+        L.check(lib.lde_set_global_sum_peers(nat.h, r, 2, ptrs, B), nat.h, "lde_set_global_sum_peers")
+        assert lib.lde_reserve(nat.h, hi - lo, len(ts)) == 0
+        nats.append(nat)
+    torch.cuda.synchronize()
+    bar = threading.Barrier(2)
+    out, err = [None, None], []
+
+    def rank(r):
+        try:
+            lo, hi = bounds[r]
+            bar.wait(timeout=60)
+            with torch.cuda.stream(torch.cuda.Stream()):      # a stream of its own: both solves must be in flight at once
+                z, ret, st = nats[r].forward(z0[lo:hi], None, ts)
+                g0, _, gW, sb = nats[r].adjoint(z, None, ts, dz[:, lo:hi])
+            out[r] = (z, ret, st, g0, gW, sb)
+        except Exception as e:               # noqa: BLE001
+            err.append(e)
+            bar.abort()
+    th = [threading.Thread(target=rank, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    assert not err, err
+    scale = max(1.0, np.abs(zf).max())
+    gW = out[0][4] + out[1][4]
+    for r, (lo, hi) in enumerate(bounds):
+        z, ret, st, g0, _, sb = out[r]
+        assert (ret == 0).all() and st["naccept"] == sf["naccept"] and sb["naccept"] == sbf["naccept"], (st, sf, sb, sbf)
+        assert np.abs(z - zf[:, lo:hi]).max() <= 1e-6 * scale
+        assert np.abs(g0 - f0[lo:hi]).max() <= 1e-5 * np.abs(f0).max()
+    assert np.abs(gW - fW).max() <= 1e-5 * np.abs(fW).max()
+    # a second pair of calls on the same handles (the word sets alternate by launch parity), and a rank on its own times out cleanly
+    outs2 = [None, None]
+
+    def again(r):
+        lo, hi = bounds[r]
+        bar2.wait(timeout=60)
+        with torch.cuda.stream(torch.cuda.Stream()):
+            outs2[r] = nats[r].forward(z0[lo:hi], None, ts)
+    bar2 = threading.Barrier(2)
+    th = [threading.Thread(target=again, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(timeout=300)
+    for r in range(2):
+        assert np.array_equal(outs2[r][0], out[r][0])
+    L.check(lib.lde_set_global_sum_peers(nats[0].h, 0, 0, None, 0), nats[0].h, "lde_set_global_sum_peers")   # off: the shard-local solve again
+    zl, retl, _ = nats[0].forward(z0[:80], None, ts)
+    assert (retl == 0).all()
+
+
+def test_node_api_with_fine_grained_mailboxes_one_rank():
+    """`dist.GlobalSumMailboxes` + `NODE.set_global_sum_peers` through diffeq_layer: the mailbox is fine-grained device memory
+    (hipExtMallocWithFlags), the one rank exchanges its sums with itself inside the kernel — and the result is the plain coupled solve,
+    bit for bit, forward and gradients."""
+    import torch
+    from latentdiffeq_amd import api, dist as D
+    torch.manual_seed(2)
+    B, T, Dm = 64, 20, 8
+    ts = O.time_grid(T)
+    z0 = torch.randn(Dm, B, device="cuda") * 0.5
+    outs = []
+    for mode in ("coupled", "coupled_global"):
+        torch.manual_seed(5)
+        dq = api.NODE(Dm, hidden_dim=64, device="cuda", batching=mode)
+        if mode == "coupled_global":
+            boxes = D.GlobalSumMailboxes()
+            assert boxes.world == 1 and boxes.nbytes == 64
+            dq.set_global_sum_peers(0, 1, boxes.pointers(), B)
+        dec = api.Decoder(api.LatentODE(), (None, dq, None))
+        zt = z0.clone().requires_grad_(True)
+        zh = api.diffeq_layer(dec, zt, ts)
+        zh.square().sum().backward()
+        outs.append((zh.detach().clone(), zt.grad.clone(), [p.grad.clone() for p in dq.dudt.parameters()]))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for a, b in zip(outs[0][2], outs[1][2]):
+        assert torch.equal(a, b)

@@ -2408,7 +2408,7 @@ int launch_pend_adjoint_disc(int kind, int solver, const float* z_out, const flo
   const int block = pick_block(o.B), grid = (o.B + block - 1) / block;
   const size_t shm = o.T <= TS_LDS_MAX ? (size_t)o.T * sizeof(double) : 0;
   // the steps side by side (a wave per trajectory) while the chip has waves to spare: option "pend_disc_tp_max_b"
-  const bool tp = o.T > 1 && o.T <= 4096 && o.B <= tn.disc_tp_max_b;
+  const bool tp = o.T > 1 && o.T <= 3840 && o.B <= tn.disc_tp_max_b;   // (16·T + 3 168 bytes of LDS: within the 64 KB a launch gets without asking)
 #define LDE_LAUNCH(K, S)                                                                                                         \
   do {                                                                                                                           \
     if (tp)                                                                                                                      \

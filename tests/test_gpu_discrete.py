@@ -170,6 +170,23 @@ def test_goku_discrete_smallest_grids_and_batches(o32, o64, T, solver):
     assert np.allclose(res[0][1], res[1][1], rtol=0, atol=1e-6 * max(1e-30, np.abs(res[1][1]).max()) + 1e-12)
 
 
+@pytest.mark.parametrize("T", [3000, 4000])
+def test_goku_discrete_thousands_of_save_times(o32, o64, T):
+    """T = 3000: the steps-side-by-side kernel with 51 KB of LDS (many save times per step, chunks of twelve per round trip);
+    T = 4000: beyond what a launch gets of LDS without asking — the lane-per-trajectory kernel serves it whatever the option says."""
+    B = 6
+    z0, L = O.pendulum_inputs(B, seed=13)
+    ts = np.arange(T) * (2.45 / (T - 1))
+    dz = O.cotangent(T, B, 2)
+    out = []
+    for tp in (1 << 20, 0):
+        nat, od = _native(None)
+        nat.set_option("pend_disc_tp_max_b", tp)
+        _, _, g, _, _ = _check(nat, od, o32, o64, z0, L, ts, dz, None)
+        out.append(g)
+    assert _rel(out[0][0], out[1][0]) <= 1e-5 and _rel(out[0][1], out[1][1]) <= 1e-5
+
+
 @pytest.mark.parametrize("kind,solver", [(O.RHS_PENDULUM, O.SOLVER_TSIT5), (O.RHS_PENDULUM_FRICTION, O.SOLVER_TSIT5), (O.RHS_PENDULUM, O.SOLVER_RK4)])
 def test_goku_discrete_long_records_and_ragged_save_grids(o32, o64, kind, solver):
     """Records longer than one round of the steps-side-by-side kernel (21 steps per round; here 60 … 200), 150 save times on a ragged

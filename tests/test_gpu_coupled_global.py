@@ -28,6 +28,8 @@ def _no_device_synchronising_garbage_collection():
     import gc
     import torch
     gc.collect()
+    torch.cuda.empty_cache()     # … and torch's caching allocator: with a full cache (a whole suite behind it) an allocation on one thread may RELEASE
+                                 # cached blocks first — hipFree again; with an empty one it can only hipMalloc (round 5: two full-suite failures)
     torch.cuda.synchronize()
     gc.disable()
     try:

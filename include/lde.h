@@ -234,7 +234,9 @@ int lde_set_global_sum_hook(lde_handle* h, lde_sum_hook hook, void* user, int64_
  * a sum costs one xGMI round trip instead of a host collective. Every rank must make the same sequence of calls on its handle (the words are
  * tagged with the handle's launch count and the launch's sum count, and those are compared across ranks); a rank that stops answering
  * poisons the others' sums after a bounded spin (retcode != 0, never a hang). nranks ≤ 8 (one node); nranks == 0 switches the path off;
- * setting peers clears a hook. [REF src/models/LatentODE.jl:70-72] as above. Exercised in this repository by two handles on ONE device
+ * setting peers clears a hook. (Ranks that SHARE a device — the tests' construction — must issue their calls on streams that cannot share a
+ * hardware queue, e.g. streams of different priority: the kernels wait for each other, so they have to be in flight at once.)
+ * [REF src/models/LatentODE.jl:70-72] as above. Exercised in this repository by two handles on ONE device
  * (tests/test_gpu_coupled_global.py) — the cross-device mapping itself has not run on hardware here (one-GPU boxes). */
 int64_t lde_global_sum_mailbox_bytes(int nranks);
 int lde_set_global_sum_peers(lde_handle* h, int rank, int nranks, void* const* mailboxes, int64_t global_batch);

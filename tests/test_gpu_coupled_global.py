@@ -42,6 +42,15 @@ LAYERS = (32, 128, 128, 32)
 KW = dict(rhs_kind=O.RHS_MLP, state_dim=32, param_dim=0, layers=LAYERS, activation=O.ACT_TANH)
 
 
+def _rank_stream(r):
+    """A stream for in-process "rank" r whose kernels run BESIDE the other rank's: the two shards' kernels wait for each other's sums, so
+    they must be in flight at once — and two HIP streams may share a hardware queue (then the second kernel sits behind the first, which
+    waits for it: both time out; seen after an earlier test of the same process had captured a graph with a parallel branch, whose internal
+    streams shift the stream → queue map). Streams of different priority never share a queue."""
+    import torch
+    return torch.cuda.Stream(priority=-1 if r == 0 else 0)
+
+
 def _setup(batching, W):
     from tests.gpu_util import Native, make_desc
     nat = Native(make_desc(batching=batching, **KW))
@@ -130,7 +139,7 @@ def test_two_shards_under_the_global_norm_equal_the_unsharded_solve():
             assert nat.lib.lde_reserve(nat.h, hi - lo, len(ts)) == 0
             torch.cuda.synchronize()
             bar.wait(timeout=60)
-            with torch.cuda.stream(torch.cuda.Stream()):      # a stream of its own: both solves must be in flight at once
+            with torch.cuda.stream(_rank_stream(r)):      # a stream of its own: both solves must be in flight at once
                 z, ret, st = nat.forward(z0[lo:hi], None, ts)
                 g0, _, gW, sb = nat.adjoint(z, None, ts, dz[:, lo:hi])
             out[r] = (z, ret, st, g0, gW, sb)
@@ -220,7 +229,7 @@ def test_two_shards_exchange_their_sums_device_to_device():
         try:
             lo, hi = bounds[r]
             bar.wait(timeout=60)
-            with torch.cuda.stream(torch.cuda.Stream()):      # a stream of its own: both solves must be in flight at once
+            with torch.cuda.stream(_rank_stream(r)):      # a stream of its own: both solves must be in flight at once
                 z, ret, st = nats[r].forward(z0[lo:hi], None, ts)
                 g0, _, gW, sb = nats[r].adjoint(z, None, ts, dz[:, lo:hi])
             out[r] = (z, ret, st, g0, gW, sb)
@@ -247,7 +256,7 @@ def test_two_shards_exchange_their_sums_device_to_device():
     def again(r):
         lo, hi = bounds[r]
         bar2.wait(timeout=60)
-        with torch.cuda.stream(torch.cuda.Stream()):
+        with torch.cuda.stream(_rank_stream(r)):
             outs2[r] = nats[r].forward(z0[lo:hi], None, ts)
     bar2 = threading.Barrier(2)
     th = [threading.Thread(target=again, args=(r,)) for r in range(2)]

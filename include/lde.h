@@ -83,7 +83,9 @@ enum lde_sensealg {
                                            every save time inside the step and through the FSAL slope; no controller, no forced stops, no error norm.
                                            lde_adjoint must follow the lde_forward that made the record (same B, T, ts). One deviation from upstream, stated:
                                            under dual numbers OrdinaryDiffEq's error norm also counts the partials, so the reference's accepted step
-                                           sequence under ForwardDiffSensitivity differs from its primal solve's; here the primal sequence is used. */
+                                           sequence under ForwardDiffSensitivity differs from its primal solve's; here the primal sequence is used.
+                                           With LDE_BATCH_COUPLED_GLOBAL every rank records the common step sequence and its own columns' states; the
+                                           sweep has no step control, so the sharded pullback exchanges nothing. */
   LDE_SENSE_PARALLEL_CHECKPOINTED  = 2  /* checkpointed adjoint, parallel in time: with z reset at every save time the T-1 save
                                            intervals are independent and λ enters linearly, so each (trajectory, interval) pair
                                            integrates the interval's transition operator (λ_j = M_j λ_{j+1}, g += n_j·λ_{j+1}) on

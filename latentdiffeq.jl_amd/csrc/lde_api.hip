@@ -133,8 +133,8 @@ static int validate(const lde_problem_desc* d, std::string* why) {
     return bad("unknown batching");
   if (d->batching == LDE_BATCH_COUPLED_GLOBAL && !has_mlp(*d)) return bad("LDE_BATCH_COUPLED_GLOBAL needs an MLP right-hand side");
   if (d->sensealg < LDE_SENSE_BACKSOLVE_CHECKPOINTED || d->sensealg > LDE_SENSE_DISCRETE) return bad("unknown sensealg");
-  if (d->sensealg == LDE_SENSE_DISCRETE && d->batching == LDE_BATCH_COUPLED_GLOBAL)
-    return bad("LDE_SENSE_DISCRETE with LDE_BATCH_COUPLED_GLOBAL: not supported (the record would be sharded)");
+  // (LDE_SENSE_DISCRETE with LDE_BATCH_COUPLED_GLOBAL: every rank records the common step sequence and ITS columns' states; the sweep
+  //  has no step control, hence no sum to exchange)
 
   if (d->solver == LDE_SOLVER_RK4 && d->adaptive) {
     if (why) *why = "RK4 is fixed-step only here: pass adaptive=0, dt=h";

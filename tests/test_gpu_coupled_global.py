@@ -51,9 +51,9 @@ def _rank_stream(r):
     return torch.cuda.Stream(priority=-1 if r == 0 else 0)
 
 
-def _setup(batching, W):
+def _setup(batching, W, **more):
     from tests.gpu_util import Native, make_desc
-    nat = Native(make_desc(batching=batching, **KW))
+    nat = Native(make_desc(batching=batching, **KW, **more))
     nat.set_weights(W)
     return nat
 
@@ -194,8 +194,11 @@ def test_a_failing_hook_fails_the_solve_without_hanging():
     assert (ret.cpu().numpy() != 0).all() and bool(torch.isnan(out[1:]).all())       # NaN blocks, as every failed solve
 
 
-def test_two_shards_exchange_their_sums_device_to_device():
-    """lde_set_global_sum_peers: the two shards' kernels write their sums into each other's mailbox (here: two allocations of ONE device;
+@pytest.mark.parametrize("sense", ["continuous", "discrete"])
+def test_two_shards_exchange_their_sums_device_to_device(sense):
+    """(sense = discrete: LDE_SENSE_DISCRETE on the sharded solve — every rank records the common step sequence and its own columns' states;
+    the pullback sweeps them without any exchange.)
+    lde_set_global_sum_peers: the two shards' kernels write their sums into each other's mailbox (here: two allocations of ONE device;
     across devices the mailboxes are peer-mapped fine-grained memory) — no hook, no host thread in the loop, asynchronous calls. Same
     step sequence and results as the unsharded solve, forward and adjoint; the two ranks' dẑ₀ / ẑ are bit-identical to the host-relayed
     exchange of the test above would be (same sums in the same order)."""
@@ -206,7 +209,8 @@ def test_two_shards_exchange_their_sums_device_to_device():
     B = 192
     z0, ts, dz = _inputs(B)
     z0[80:] *= 3.0
-    ref = _setup(O.BATCH_COUPLED, W)
+    more = dict(sensealg=O.SENSE_DISCRETE) if sense == "discrete" else {}
+    ref = _setup(O.BATCH_COUPLED, W, **more)
     zf, _, sf = ref.forward(z0, None, ts)
     f0, _, fW, sbf = ref.adjoint(zf, None, ts, dz)
     bounds = [(0, 80), (80, 192)]
@@ -217,7 +221,7 @@ def test_two_shards_exchange_their_sums_device_to_device():
     ptrs = (C.c_void_p * 2)(*[b_.data_ptr() for b_ in boxes])
     nats = []
     for r, (lo, hi) in enumerate(bounds):
-        nat = _setup(O.BATCH_COUPLED_GLOBAL, W)
+        nat = _setup(O.BATCH_COUPLED_GLOBAL, W, **more)
         L.check(lib.lde_set_global_sum_peers(nat.h, r, 2, ptrs, B), nat.h, "lde_set_global_sum_peers")
         assert lib.lde_reserve(nat.h, hi - lo, len(ts)) == 0
         nats.append(nat)

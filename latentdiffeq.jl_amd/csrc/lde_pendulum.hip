@@ -2087,9 +2087,11 @@ __global__ void __launch_bounds__(256) k_pend_adjoint_disc(const float2* __restr
 //   G'_i = e_τ + h Σ a_iq K'_q,   K'_i = J_f(g_i) G'_i + ∂f/∂L(g_i)        (i = 0 … S; K'_S: the FSAL slope at y_{n+1})
 // — and contract it with the cotangents of the save times inside the step (the moment sums of the sequential kernel above):
 //   c_τ = Σ_j Δ_j · ∂ẑ_j/∂τ,   Y'_τ = ∂y_{n+1}/∂τ.
-// What is sequential is then three fused multiply-adds per step: (ȳ, dθ) ← ((ȳ + e_s)·Y'_x + c_x, (ȳ + e_s)·Y'_y + c_y, dθ + (ȳ + e_s)·Y'_θ + c_θ),
-// e_s = the cotangents of the saves ON the step's end, from the last step to the first — results pass between lanes by v_readlane.
-// 21 steps per round (63 lanes); longer records take further rounds from the top. Same derivative as k_pend_adjoint_disc (forward
+// (each of the step's three lanes takes a third of the save times; the partial sums meet in LDS).
+// What is sequential is then an affine map per step: (ȳ, dθ) ← ((ȳ + e_s)·Y'_x + c_x, (ȳ + e_s)·Y'_y + c_y, dθ + (ȳ + e_s)·Y'_θ + c_θ),
+// e_s = the cotangents of the saves ON the step's end, from the last step to the first — and the maps are COMPOSED (a suffix scan over the
+// steps, see "the sweep" below) rather than applied one after the other: a chain of 21 dependent applications costs ≈ 90 cycles per step on a
+// lone wave however the value travels between lanes. 21 steps per round (63 lanes); longer records take further rounds from the top. Same derivative as k_pend_adjoint_disc (forward
 // instead of reverse accumulation inside a step: rounding differs, tests/test_gpu_discrete.py compares both with the oracle);
 // same failure semantics and statistics.
 constexpr int DTP_STEPS = 21;

@@ -313,7 +313,7 @@ def test_discrete_uses_far_fewer_evaluations_than_the_continuous_adjoint():
 
 
 @pytest.mark.parametrize("name,B", [("c3_pend_plus_mlp_relu", 1024), ("c4_relu_coupled", 512), ("latentode_ref_relu_coupled", 64),
-                                    ("c2_rk4_relu", 256)])
+                                    ("c2_rk4_relu", 256), ("c4_relu_coupled", 4096)])   # (4096: configs[3]'s whole batch on one GPU — the tile kernels)
 def test_discrete_at_baseline_sizes(o32, o64, name, B):
     """BASELINE.json configs[2] (B = 1024), configs[3] at one GPU's share (B = 512), the reference's own LatentODE example (B = 64),
     configs[1] (B = 256): relu networks at the reference's DEFAULT tolerances, every trajectory's gradient held to 1e-4 unless the oracle

@@ -656,7 +656,7 @@ __global__ void __launch_bounds__(WS_THREADS) k_pend_forward_ws(const float2* __
 // predicated block and the stepping loop contains no load at all. With the next save time's load in it the compiler must put
 // `s_waitcnt vmcnt(0)` in front of the block, and vmcnt counts the previous step's ẑ STORES too — the stepping chain then waits
 // for write acknowledgements it has no use for.
-template <int KIND, int SOLVER, bool ADAPT, int TPW, bool ONE = false, int RING = 0>
+template <int KIND, int SOLVER, bool ADAPT, int TPW, bool ONE = false, int RING = 0, bool REC = false>   // REC (with RING: a lane per trajectory): step records at accept
 __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict__ z0, const float* __restrict__ theta,
                                                         const double* __restrict__ ts_g, KOpts o,
                                                         float2* __restrict__ z_out, int32_t* __restrict__ retcode,
@@ -664,6 +664,7 @@ __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict
                                                         int32_t* __restrict__ st_nrej, int32_t* __restrict__ st_ret) {
   constexpr int LPT = 64 / TPW;   // lanes per trajectory
   static_assert(RING == 0 || (TPW == 64 && !ONE && RING <= 32 && (RING & (RING - 1)) == 0), "the row ring is for one trajectory per lane");
+  static_assert(!REC || RING > 0, "step records: the lane-per-trajectory form only");
   // RING > 0 (large batches, a lane owns a trajectory): the lanes of a wave pass a given save time at different iterations, so a
   // direct store is 64 lanes × 8 bytes into up to 64 different rows of ẑ, and the 512 contiguous bytes a wave owns in row j arrive
   // piecemeal over many iterations — with ≈ 25 KB of such half-written rows per resident wave and thousands of waves the L2s
@@ -786,6 +787,11 @@ __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict
     }
     if (ok) {
       const double tn = last ? tend : t + (double)h;
+      if (REC && valid && nacc < o.rec.cap) {   // LDE_SENSE_DISCRETE / step tracing: the accepted step's start time, size and start state
+        o.rec.t[(size_t)nacc * B + b] = t;
+        o.rec.dt[(size_t)nacc * B + b] = (double)h;
+        reinterpret_cast<float2*>(o.rec.y)[(size_t)nacc * B + b] = make_float2(y.x, y.y);
+      }
       if (__any(tj <= tn)) {   // dense output: some lane's save time lies in (t, tn]
         f32x2 P2, P3, P4;
         if (SOLVER == LDE_SOLVER_TSIT5) {
@@ -858,6 +864,7 @@ __global__ void __launch_bounds__(64) k_pend_forward_tl(const float2* __restrict
     st_nfe[b] = nfe + NS * (nacc + nrej);
     st_nacc[b] = nacc;
     st_nrej[b] = nrej;
+    if (REC) o.rec.n[b] = ret == LDE_RET_SUCCESS ? nacc : 0;
   }
 }
 
@@ -1816,18 +1823,21 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
   // options "pend_lb" = rows of the ring (8 / 16 / 32; 0: off), "pend_lb_hold" = the hold margin.
   const int lb_ring = tn.lb_ring;   // rows of the ring; 0: off
   const int lb_min_b = tn.lb_min_b;
-  if (!recording && lb_ring > 0 && o.T > 1 && o.T <= 2048 && o.B >= lb_min_b) {   // (the save grid in LDS beside the ring: T ≤ 2048)
+  if (lb_ring > 0 && o.T > 1 && o.T <= 2048 && o.B >= lb_min_b) {   // (the save grid in LDS beside the ring: T ≤ 2048; a recording forward: the 16-row ring)
     // a lane sits out while j ≥ jc + RING − hold; the slowest lane has j = jc, so hold ≤ RING − 1 keeps it (and with it jc) moving —
     // hold ≥ RING would hold EVERY lane on every iteration and the solve loop would never end. Default: half the ring.
     const int lb_hold_env = tn.lb_hold;
-    const int ring_rows = lb_ring >= 32 ? 32 : (lb_ring >= 16 ? 16 : 8);
+    const int ring_rows = recording ? 16 : (lb_ring >= 32 ? 32 : (lb_ring >= 16 ? 16 : 8));
     KOpts oh = o;
     oh.lb_hold = std::max(0, std::min(lb_hold_env >= 0 ? lb_hold_env : ring_rows / 2, ring_rows - 1));
     const bool ad = o.adaptive != 0;
     const int g8 = (((o.B + 63) / 64 + 7) / 8) * 8;
 #define LDE_LAUNCH_LB(K, S, A)                                                                                          \
   do {                                                                                                                  \
-    if (lb_ring >= 32)                                                                                                  \
+    if (recording)                                                                                                      \
+      hipLaunchKernelGGL((k_pend_forward_tl<K, S, A, 64, false, 16, true>), dim3(g8), dim3(64), (size_t)o.T * sizeof(double), stream, (const float2*)z0, theta, ts_dev, oh, \
+                         (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                                \
+    else if (lb_ring >= 32)                                                                                             \
       hipLaunchKernelGGL((k_pend_forward_tl<K, S, A, 64, false, 32>), dim3(g8), dim3(64), (size_t)o.T * sizeof(double), stream, (const float2*)z0, theta, ts_dev, oh, \
                          (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                                \
     else if (lb_ring >= 16)                                                                                             \

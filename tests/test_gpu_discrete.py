@@ -123,6 +123,7 @@ def test_goku_discrete_matches_oracle_on_the_same_steps(o32, o64, kind, solver, 
     (1000, {"pend_ws": 0}, 1e-6),                          # k_pend_forward: a lane per trajectory, records at accept
     (200, {"record_capacity": 64}, 1e-8),                  # ≈ 150 steps: records from several rounds of the ring (48 per round), then overflow → see below
     (200, {"pend_sh_max_b": 0, "record_capacity": 512}, 1e-8),   # several rounds of k_pend_forward_ws's ring (96 per round)
+    (1000, {"pend_tl_max_b": 0, "pend_sh_max_b": 0, "pend_ws": 0, "pend_lb_min_b": 0}, 1e-6),   # the large-batch form (rows of ẑ through the LDS ring), forced at a test-sized batch
 ])
 def test_goku_discrete_every_recording_forward_mapping(o32, o64, B, options, tol):
     """Every forward mapping that writes step records: the record reproduces the kernel's own solve in the oracle (|Δẑ| ≤ 2e-5 on the

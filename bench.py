@@ -397,7 +397,8 @@ def run_goku_step(args, torch, dist, world, rank, local):
     dev = torch.device("cuda", local)
     torch.manual_seed(100)                  # the same initial weights on every rank (data parallel); the data differs per rank
     mt = M.GOKU_basic()
-    diffeq = M.Pendulum()
+    # (--sensealg discrete: the solve's pullback as the reference's GOKU default defines it — ForwardDiffSensitivity, exactly [REF pendulum.jl:11])
+    diffeq = M.Pendulum(sensealg=M.DiscreteSensitivity()) if args.sensealg == "discrete" else M.Pendulum()
     enc = Encoder(mt, default_encoder_layers(mt, NI, device=dev))
     dec = M.Decoder(mt, default_decoder_layers(mt, NI, diffeq, device=dev))
     lo_z0, lo_th = dec.latent_out

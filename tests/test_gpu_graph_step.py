@@ -26,6 +26,7 @@ from latentdiffeq_amd.recurrent import Encoder, default_encoder_layers, encode
 from latentdiffeq_amd.train import FluxADAMW, GraphedStep
 dtype = sys.argv[1]
 split = len(sys.argv) > 2 and sys.argv[2] == "split"
+discrete = len(sys.argv) > 2 and sys.argv[2] == "discrete"      # the solve's pullback as LDE_SENSE_DISCRETE: a step record per autograd node
 if split:   # several GPUs in miniature: a ONE-rank RCCL group, the gradient all-reduce forced on (dist.FORCE_ALLREDUCE)
     import torch.distributed as dist
     from latentdiffeq_amd import dist as _ldist
@@ -37,7 +38,7 @@ B, T, NI = 64, 20, 784
 dev = torch.device("cuda", 0)
 def build():
     torch.manual_seed(100)
-    mt, diffeq = M.GOKU_basic(), M.Pendulum()
+    mt, diffeq = M.GOKU_basic(), (M.Pendulum(sensealg=M.DiscreteSensitivity()) if discrete else M.Pendulum())
     enc = Encoder(mt, default_encoder_layers(mt, NI, device=dev))
     dec = M.Decoder(mt, default_decoder_layers(mt, NI, diffeq, device=dev))
     with torch.no_grad():
@@ -102,6 +103,16 @@ def test_graph_replay_equals_eager_step(tmp_path, dtype):
     f.write_text(SCRIPT)
     env = dict(os.environ, LDE_ROOT=ROOT)
     r = subprocess.run([sys.executable, str(f), dtype], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
+
+
+def test_graph_replay_with_the_discrete_sensitivity_equals_eager(tmp_path):
+    """The same with `Pendulum(sensealg=DiscreteSensitivity())` — the reference's GOKU default gradient definition: the step record of the
+    captured solve lives in the graph's memory pool, forward writes it and the pullback sweeps it on every replay."""
+    f = tmp_path / "graph_step_discrete.py"
+    f.write_text(SCRIPT)
+    env = dict(os.environ, LDE_ROOT=ROOT)
+    r = subprocess.run([sys.executable, str(f), "f32", "discrete"], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "ok" in r.stdout, r.stdout[-1500:] + r.stderr[-3000:]
 
 

@@ -23,6 +23,10 @@ for w in c2 c3 c4 latentode_ref; do
   echo "## $w --sensealg discrete" >> gpurun_out/r5_sq_counters.txt
   bash profiles/pmc_sq.sh $w mlp --sensealg discrete >> gpurun_out/r5_sq_counters.txt 2>&1
 done
+echo "## goku_pendulum (metric, continuous adjoint)" >> gpurun_out/r5_sq_counters.txt
+bash profiles/pmc_sq.sh goku_pendulum k_pend >> gpurun_out/r5_sq_counters.txt 2>&1
+echo "## goku_pendulum --sensealg discrete" >> gpurun_out/r5_sq_counters.txt
+bash profiles/pmc_sq.sh goku_pendulum k_pend --sensealg discrete >> gpurun_out/r5_sq_counters.txt 2>&1
 for d in f32 mixed; do
   python bench.py --workload goku_step --dtype $d > gpurun_out/bench_goku_step_$d.json 2> gpurun_out/bench_goku_step_$d.err
   python bench.py --workload goku_decoder --dtype $d > gpurun_out/bench_goku_decoder_$d.json 2> gpurun_out/bench_goku_decoder_$d.err

@@ -185,4 +185,17 @@ set_option!(h::LdeHandle, key::AbstractString, value::Real) =
 # set_option!(h, "adjoint_overwrite", 1)   # lde_adjoint WRITES dW: the `AMDGPU.zeros` in the LatentODE pullback becomes `similar`
 
 
+# What the loaded binary was built and validated with (compiler version, the register check's verdict)
+build_info() = unsafe_string(ccall((:lde_build_info, liblde), Cstring, ()))
+
+# LDE_BATCH_COUPLED_GLOBAL without the host in the loop (include/lde.h: lde_set_global_sum_peers): one mailbox per rank in fine-grained device
+# memory, mapped on every peer (HIP IPC handles exchanged once, e.g. over MPI); `mailboxes[r]` = rank r's as mapped on THIS device.
+global_sum_mailbox_bytes(nranks::Integer) = Int(ccall((:lde_global_sum_mailbox_bytes, liblde), Int64, (Cint,), nranks))
+function set_global_sum_peers!(h::LdeHandle, rank::Integer, mailboxes::Vector{Ptr{Cvoid}}, global_batch::Integer)
+    rc = ccall((:lde_set_global_sum_peers, liblde), Cint, (Ptr{Cvoid}, Cint, Cint, Ptr{Ptr{Cvoid}}, Int64),
+               h.ptr, rank, length(mailboxes), mailboxes, global_batch)
+    rc == 0 || error("lde_set_global_sum_peers: " * unsafe_string(ccall((:lde_last_error, liblde), Cstring, (Ptr{Cvoid},), h.ptr)))
+    return h
+end
+
 end # module LdeNative

@@ -50,7 +50,18 @@ WORKLOADS = {
 }
 
 
-def build_problem(w, B, seed_shift=0, sensealg="default"):
+# The reference's default definition of the gradient, per workload: the GOKU path carries ForwardDiffSensitivity() — the exact derivative of
+# the discrete solve [REF examples/pendulum_friction-less/pendulum.jl:8-11], [REF src/models/GOKU.jl:107, :121] = LDE_SENSE_DISCRETE; a
+# NeuralODE carries DiffEqFlux's InterpolatingAdjoint [REF src/models/LatentODE.jl:67-70] = the continuous adjoint.
+REF_SENSEALG = {"goku_pendulum": "discrete", "c3": "discrete", "goku_decoder": "discrete", "goku_step": "discrete",
+                "c2": "continuous", "c4": "continuous", "latentode_ref": "continuous"}
+
+
+def resolve_sensealg(workload, arg):
+    return REF_SENSEALG[workload] if arg == "default" else arg
+
+
+def build_problem(w, B, seed_shift=0, sensealg="discrete"):
     from latentdiffeq_amd import _lib as L
     from latentdiffeq_amd import synthetic as O
     lib = L.load()
@@ -65,8 +76,10 @@ def build_problem(w, B, seed_shift=0, sensealg="default"):
     d.batching = L.BATCH_COUPLED if w["batching"] == "coupled" else L.BATCH_PER_TRAJECTORY
     if w["solver"] == "rk4":
         d.adaptive, d.dt = 0, w["dt"]
-    if sensealg == "discrete":   # LDE_SENSE_DISCRETE: what the reference's GOKU default ForwardDiffSensitivity() differentiates [REF pendulum.jl:11]
-        d.sensealg = L.SENSE_DISCRETE
+    # LDE_SENSE_DISCRETE: what the reference's GOKU default ForwardDiffSensitivity() differentiates [REF pendulum.jl:11]; continuous: the
+    # time-parallel checkpointed adjoint on the GOKU path, the sequential checkpointed one for MLP right-hand sides (lde_create's mapping)
+    assert sensealg in ("discrete", "continuous"), sensealg
+    d.sensealg = L.SENSE_DISCRETE if sensealg == "discrete" else L.SENSE_PARALLEL_CHECKPOINTED
     T, D = w["T"], w["D"]
     ts = O.time_grid(T)
     if w["rhs"] == "mlp":
@@ -167,7 +180,7 @@ def run_decoder(args, torch, dist, world, rank, local):
     T, D, P, NI, NL = DECODER["T"], 2, 1, DECODER["input_dim"], DECODER["latent"]
     N = B * T
     dev = torch.device("cuda", local)
-    d, ts, _, _, _, _ = build_problem(w, B, seed_shift=rank)
+    d, ts, _, _, _, _ = build_problem(w, B, seed_shift=rank, sensealg=resolve_sensealg("goku_decoder", args.sensealg))
     h = C.c_void_p()
     L.check(lib.lde_create(C.byref(d), C.byref(h)), None, "lde_create")
     L.check(lib.lde_reserve(h, B, T), h, "lde_reserve")
@@ -350,11 +363,18 @@ def decoder_cpu_baseline(specs, weights, d_native, ts, zt, tt, dxh, B, T, budget
     def one(nt):
         z0 = orc.chain_forward(cd["lo_z0"], weights["lo_z0"], zs, nthreads=nt)
         th = orc.chain_forward(cd["lo_th"], weights["lo_th"], tsm, nthreads=nt)
-        z, _, _ = orc.forward(od, z0, th, ts, nthreads=nt)
+        disc = od.sensealg == O.SENSE_DISCRETE
+        if disc:
+            z, _, rec, _ = orc.forward_steps(od, z0, th, ts, cap=1024, nthreads=nt)
+        else:
+            z, _, _ = orc.forward(od, z0, th, ts, nthreads=nt)
         zc = z.reshape(T * cap, -1)
         orc.chain_forward(cd["rec"], weights["rec"], zc, nthreads=nt)
         dz, _ = orc.chain_backward(cd["rec"], weights["rec"], zc, dxs, nthreads=nt)
-        g0, gth, _, _ = orc.adjoint(od, z, th, ts, dz.reshape(T, cap, -1), nthreads=nt)
+        if disc:
+            g0, gth, _, _ = orc.adjoint_discrete(od, z, th, ts, dz.reshape(T, cap, -1), rec, nthreads=nt)
+        else:
+            g0, gth, _, _ = orc.adjoint(od, z, th, ts, dz.reshape(T, cap, -1), nthreads=nt)
         orc.chain_backward(cd["lo_z0"], weights["lo_z0"], zs, g0, nthreads=nt)
         orc.chain_backward(cd["lo_th"], weights["lo_th"], tsm, gth, nthreads=nt)
 
@@ -397,8 +417,9 @@ def run_goku_step(args, torch, dist, world, rank, local):
     dev = torch.device("cuda", local)
     torch.manual_seed(100)                  # the same initial weights on every rank (data parallel); the data differs per rank
     mt = M.GOKU_basic()
-    # (--sensealg discrete: the solve's pullback as the reference's GOKU default defines it — ForwardDiffSensitivity, exactly [REF pendulum.jl:11])
-    diffeq = M.Pendulum(sensealg=M.DiscreteSensitivity()) if args.sensealg == "discrete" else M.Pendulum()
+    # Pendulum() carries the reference's GOKU default, ForwardDiffSensitivity = LDE_SENSE_DISCRETE [REF pendulum.jl:8-11]; --sensealg continuous:
+    # the time-parallel continuous adjoint instead
+    diffeq = M.Pendulum() if resolve_sensealg("goku_step", args.sensealg) == "discrete" else M.Pendulum(sensealg=M.ParallelAdjoint())
     enc = Encoder(mt, default_encoder_layers(mt, NI, device=dev))
     dec = M.Decoder(mt, default_decoder_layers(mt, NI, diffeq, device=dev))
     lo_z0, lo_th = dec.latent_out
@@ -549,7 +570,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def attach_traffic(roof, workload, B, mlp, full_batch, dom=None, rounds=("r5", "r4", "r3", "r2", "r1")):
+def attach_traffic(roof, workload, B, mlp, full_batch, dom=None, rounds=("r6", "r5", "r4", "r3", "r2", "r1")):
     """roofline.traffic (+ rocprof_avg_launch_ms, whole_step.traffic) of the solve workloads from the newest committed PMC summary
     (profiles/collect.sh + profiles/summarize.py; FETCH_SIZE ×2 only for kernels that load 16 bytes per lane, WRITE_SIZE as is —
     MI355X_MICROARCH.md §HBM). Also called by profiles/refresh.py on the bench line it copies next to a fresh summary, so the
@@ -698,9 +719,10 @@ def main():
                     help="weak: the workload's batch on EVERY GPU (default); strong: the workload's batch split over the GPUs")
     ap.add_argument("--dtype", default="f32", choices=["f32", "mixed"],
                     help="goku_step / goku_decoder: 'mixed' = bf16 dense chains (f32 accumulate, f32 master weights), f32 solve")
-    ap.add_argument("--sensealg", default="default", choices=["default", "discrete"],
-                    help="discrete: LDE_SENSE_DISCRETE (the exact derivative of the discrete solve — the reference's ForwardDiffSensitivity) "
-                         "instead of the workload's continuous adjoint")
+    ap.add_argument("--sensealg", default="default", choices=["default", "discrete", "continuous"],
+                    help="default: the reference's own default for the workload — discrete (LDE_SENSE_DISCRETE: the exact derivative of the discrete "
+                         "solve, the GOKU path's ForwardDiffSensitivity) for goku_pendulum / c3 / goku_decoder / goku_step, continuous (the reverse-time "
+                         "adjoint: a NeuralODE's InterpolatingAdjoint) for c2 / c4 / latentode_ref; or force one of the two")
     ap.add_argument("--async-dw", type=int, default=-1, choices=[-1, 0, 1, 2, 3],
                     help="goku_step: the large chains' weight-gradient kernels on a stream of their own — a parallel branch of the captured step (-1: the workload's default)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -788,7 +810,7 @@ def main():
 
     def measure(B, seed_shift, detail, sensealg=None):
         """W warm-up steps, then exactly K timed steps of lde_forward + lde_adjoint on B resident trajectories."""
-        d, ts, z0, theta, W, dz = build_problem(w, B, seed_shift=seed_shift, sensealg=sensealg or args.sensealg)
+        d, ts, z0, theta, W, dz = build_problem(w, B, seed_shift=seed_shift, sensealg=sensealg or sense)
         h = C.c_void_p()
         L.check(lib.lde_create(C.byref(d), C.byref(h)), None, "lde_create")
         nW = int(lib.lde_num_weights(C.byref(d)))
@@ -935,6 +957,7 @@ def main():
         res["handle"] = h
         return res
 
+    sense = resolve_sensealg(args.workload, args.sensealg)
     Bw = args.batch or w["B"]
     if args.scaling == "strong":
         lo, hi = shard_bounds(Bw, rank, world)
@@ -956,7 +979,7 @@ def main():
     Ff = flops_per_eval(w)
     # flops of the pullback per evaluation it reports: the continuous adjoint's evaluations are fused (forward + z-VJP + weight gradient:
     # 3·F_f); the discrete sweep reports 2S per accepted step — S forward-only (F_f) and S fused (3·F_f): 2·F_f on average
-    disc = args.sensealg == "discrete"
+    disc = sense == "discrete"
     adj_f = 2 if disc else 3
     if Ff and w["batching"] == "coupled":
         flops = (fstat["nfe"] * Ff + bstat["nfe"] * adj_f * Ff) * B
@@ -1008,7 +1031,9 @@ def main():
         # per-step figures from HIP events (an event pair around every step): the wall-clock mean above is K steps / elapsed
         "ms_per_step_events": {"median": m["step"][1], "mean": m["step"][0], "back_to_back": m["step"][2], "samples": min(max(args.steps, 20), 200)},
         "solver_stats": {"forward": fstat, "adjoint": bstat},
-        "sensealg": "LDE_SENSE_DISCRETE (exact derivative of the discrete solve on its accepted steps)" if disc else "workload default (continuous adjoint)",
+        "sensealg": ("LDE_SENSE_DISCRETE (the exact derivative of the discrete solve on its accepted steps: the reference's ForwardDiffSensitivity)" if disc
+                     else "continuous adjoint (reverse-time solve; time-parallel on the analytic GOKU path)")
+        + (" — the reference's default for this workload" if sense == REF_SENSEALG[args.workload] else " — forced by --sensealg"),
         # device-synchronised per call, median of ≥ 100 (host enqueue + wake-up included) — beside the pipelined figure above
         "per_call_synchronised": {"median_ms": m["sync_call"][0], "mean_ms": m["sync_call"][1], "samples": m["sync_call"][2],
                                   "value": B * world / (m["sync_call"][0] * 1e-3), "unit": "trajectories/s"},
@@ -1016,7 +1041,7 @@ def main():
 
     # the same K steps with the other definition of the gradient, beside the headline (every rank takes part: the timing's barriers are collective)
     if not args.no_other_sensealg:
-        other = "default" if disc else "discrete"
+        other = "continuous" if disc else "discrete"
         mo = measure(B, rank, False, sensealg=other)
         out["other_sensealg"] = {"sensealg": other, "value": global_batch * args.steps / mo["el"], "unit": "trajectories/s",
                                  "ms_per_step": mo["el"] / args.steps * 1e3}

@@ -161,7 +161,10 @@ int lde_abi_version(void);
 const char* lde_build_info(void);
 
 /* Fill `desc` with the defaults `Pendulum()` would carry: Tsit5, per-trajectory, abstol 1e-6,
- * reltol 1e-3, maxiters 1e5, PI controller constants  [REF pendulum.jl:11]; sensealg = PARALLEL_CHECKPOINTED. */
+ * reltol 1e-3, maxiters 1e5, PI controller constants, and sensealg = LDE_SENSE_DISCRETE — `Pendulum()`'s ForwardDiffSensitivity()
+ * [REF examples/pendulum_friction-less/pendulum.jl:8-11], splatted into solve() at [REF src/models/GOKU.jl:107, :121]: the exact derivative
+ * of the discrete solve. A binding of `NODE` sets LDE_SENSE_BACKSOLVE_CHECKPOINTED itself (DiffEqFlux's InterpolatingAdjoint
+ * [REF src/models/LatentODE.jl:67-70]); the time-parallel continuous adjoint (LDE_SENSE_PARALLEL_CHECKPOINTED) stays selectable. */
 int lde_problem_desc_default(lde_problem_desc* desc);
 
 /* Number of floats in the flat weight vector implied by desc (0 for analytic RHS). */
@@ -254,6 +257,15 @@ int lde_set_global_sum_peers(lde_handle* h, int rank, int nranks, void* const* m
  * truncated sweep. The reference has no counterpart (dual numbers carry the derivative through the solve [REF src/models/GOKU.jl:121]). */
 int64_t lde_step_record_bytes(const lde_handle* h, int B, int T);
 int lde_set_step_record(lde_handle* h, void* rec_dev, int64_t bytes);
+/* Did the record hold the solve? lde_step_record_capacity(h, T) = the accepted steps per sequence a record made now would hold;
+ * lde_step_record_status waits for `stream` and returns, for the record of a finished lde_forward of shape (B, T) — `rec_dev`, the caller's
+ * buffer, or NULL = the handle's last one — the largest accepted-step count of its sequences (*max_steps; counts run on past the capacity)
+ * and the capacity the record was made with (*capacity, may be NULL). max_steps > capacity ⇒ the pullback would return NaN gradients: raise
+ * "record_capacity" (to ≥ max_steps), repeat lde_forward (deterministic: the same steps), then lde_adjoint — what a host's pullback does
+ * before it hands NaNs to an optimiser (latentdiffeq.jl_amd/api.py: _SolveFn.backward; julia/LdeNative.jl: the rrule). The reference has no
+ * counterpart: ForwardDiffSensitivity differentiates any solve up to maxiters [REF src/models/GOKU.jl:121]. */
+int lde_step_record_capacity(const lde_handle* h, int T);
+int lde_step_record_status(lde_handle* h, const void* rec_dev, int B, int T, int32_t* max_steps, int32_t* capacity, void* stream);
 /* Host copy of the step sequences of the last call: which = 0 the forward record (needs LDE_SENSE_DISCRETE or option "step_trace"),
  * which = 1 the reverse-time solve of the continuous adjoint (option "step_trace"; t_host is not written: NULL). Arrays [nseq][cap]
  * row-major, n_host[nseq] (a count > cap: truncated); nseq = B or 1. Synchronises `stream`. What tests/test_gpu_discrete.py hands to the

@@ -78,13 +78,15 @@ class DiscreteSensitivity(BacksolveAdjoint):
         self.code = L.SENSE_DISCRETE
 
 
-class ForwardDiffSensitivity(ParallelAdjoint):
-    """The reference's GOKU default [REF pendulum.jl:11]: a discrete-exact gradient. `ForwardDiffSensitivity(exact=True)` runs
-    exactly that (LDE_SENSE_DISCRETE, see DiscreteSensitivity). The default `exact=False` keeps the time-parallel continuous
-    adjoint on the GOKU path — the two agree to solver tolerance, and at the metric's batch size the time-parallel kernel is the
-    faster pullback."""
+class ForwardDiffSensitivity(DiscreteSensitivity):
+    """The reference's GOKU default [REF examples/pendulum_friction-less/pendulum.jl:8-11], splatted into `solve` at
+    [REF src/models/GOKU.jl:107, :121]: the exact derivative of the discrete solve on its accepted steps = LDE_SENSE_DISCRETE
+    (see DiscreteSensitivity; upstream pushes dual numbers through the stepper, here the same derivative is taken in reverse mode).
+    `Pendulum()` carries it, as in the reference. The continuous adjoints stay selectable: `ParallelAdjoint()` (time-parallel,
+    checkpointed), `BacksolveAdjoint()`, `InterpolatingAdjoint()`. (`exact=False`, rounds 1–5's meaning of this tag — the time-parallel
+    continuous adjoint — is still accepted and equals `ParallelAdjoint()`.)"""
 
-    def __init__(self, exact: bool = False):
+    def __init__(self, exact: bool = True):
         self.code = L.SENSE_DISCRETE if exact else L.SENSE_PARALLEL_CHECKPOINTED
 
 
@@ -121,6 +123,7 @@ class _Handle:
         self.ptr = C.c_void_p()
         L.check(self.lib.lde_create(C.byref(desc), C.byref(self.ptr)), None, "lde_create")
         self.nW = int(self.lib.lde_num_weights(C.byref(desc)))
+        self.check_record = True          # _SolveFn.backward: look at the step record's counts before the discrete pullback
 
     def __del__(self):
         try:
@@ -396,8 +399,12 @@ class _SolveFn(torch.autograd.Function):
             nbytes = int(lib.lde_step_record_bytes(handle.ptr, B, T))
             ctx.rec = torch.empty((nbytes,), device=z0.device, dtype=torch.uint8)
             L.check(lib.lde_set_step_record(handle.ptr, _ptr(ctx.rec), nbytes), handle.ptr, "lde_set_step_record")
-        L.check(lib.lde_forward(handle.ptr, _ptr(z0), _ptr(theta), tsp, T, B, _ptr(z_out), _ptr(retcode), stream),
-                handle.ptr, "lde_forward")
+        try:
+            L.check(lib.lde_forward(handle.ptr, _ptr(z0), _ptr(theta), tsp, T, B, _ptr(z_out), _ptr(retcode), stream),
+                    handle.ptr, "lde_forward")
+        finally:
+            if ctx.rec is not None:       # the handle must not keep a pointer into a block this graph node owns (and torch recycles)
+                lib.lde_set_step_record(handle.ptr, C.c_void_p(), 0)
         ctx.handle, ctx.ts = handle, ts
         ctx.has_theta, ctx.has_W = theta is not None, W is not None
         ctx.save_for_backward(z_out, theta if theta is not None else z0.new_empty(0))
@@ -422,16 +429,61 @@ class _SolveFn(torch.autograd.Function):
         dth = torch.empty_like(theta) if theta is not None else None
         dW = torch.zeros((handle.nW,), device=z_out.device, dtype=torch.float32) if ctx.has_W else None
         tsp = ts.ctypes.data_as(C.POINTER(C.c_double))
-        if ctx.rec is not None:
-            L.check(lib.lde_set_step_record(handle.ptr, _ptr(ctx.rec), ctx.rec.numel()), handle.ptr, "lde_set_step_record")
-        L.check(lib.lde_adjoint(handle.ptr, _ptr(z_out), _ptr(theta), tsp, T, B, _ptr(dz_out), _ptr(dz0), _ptr(dth),
-                                _ptr(dW), stream), handle.ptr, "lde_adjoint")
+        rec = ctx.rec
+        if rec is not None and handle.check_record and not torch.cuda.is_current_stream_capturing():
+            rec = _SolveFn._record_that_holds(handle, rec, z_out, theta, ts, stream)
+        if rec is not None:
+            L.check(lib.lde_set_step_record(handle.ptr, _ptr(rec), rec.numel()), handle.ptr, "lde_set_step_record")
+        try:
+            L.check(lib.lde_adjoint(handle.ptr, _ptr(z_out), _ptr(theta), tsp, T, B, _ptr(dz_out), _ptr(dz0), _ptr(dth),
+                                    _ptr(dW), stream), handle.ptr, "lde_adjoint")
+        finally:
+            if rec is not None:
+                lib.lde_set_step_record(handle.ptr, C.c_void_p(), 0)
         return None, None, dz0, dth, dW
+
+    @staticmethod
+    def _record_that_holds(handle: _Handle, rec: torch.Tensor, z_out: torch.Tensor, theta, ts: np.ndarray, stream) -> torch.Tensor:
+        """A solve that accepted more steps than its record holds would come back from lde_adjoint as NaN gradients (never a truncated
+        sweep) — and NaNs in an optimiser are for ever. The reference's ForwardDiffSensitivity differentiates any solve up to maxiters
+        [REF src/models/GOKU.jl:121], so: look at the record's step counts (one device synchronisation — `diffeq.check_record = False`
+        switches it off; a captured step cannot do it: GraphedStep's eager warm-up steps do), and when it overflowed raise the handle's
+        "record_capacity" and repeat the forward solve — deterministic: the same steps, the same ẑ — into a record that holds it."""
+        lib = handle.lib
+        T, B, Dp = z_out.shape
+        nmax, cap = C.c_int32(0), C.c_int32(0)
+        L.check(lib.lde_step_record_status(handle.ptr, _ptr(rec), B, T, C.byref(nmax), C.byref(cap), stream), handle.ptr,
+                "lde_step_record_status")
+        have = (rec.numel(), int(lib.lde_step_record_bytes(handle.ptr, B, T)))
+        if nmax.value <= cap.value and have[0] >= have[1]:
+            return rec
+        if have[0] < have[1] and nmax.value <= cap.value:
+            # the capacity option was RAISED since this node's forward (another node's overflow): the record is complete but laid out for
+            # the old capacity — the adjoint's view would be wrong. Re-solve into a record of today's layout.
+            pass
+        else:
+            want = min(int(handle.desc.maxiters), max(nmax.value + 8, 2 * cap.value))
+            if want <= cap.value:
+                raise L.LdeError(f"the solve accepted {nmax.value} steps, more than maxiters = {handle.desc.maxiters} lets a step record hold")
+            L.check(lib.lde_set_option(handle.ptr, b"record_capacity", float(want)), handle.ptr, "lde_set_option")
+        nbytes = int(lib.lde_step_record_bytes(handle.ptr, B, T))
+        rec2 = torch.empty((nbytes,), device=z_out.device, dtype=torch.uint8)
+        z0 = z_out[0, :, :handle.desc.state_dim].contiguous()    # ẑ(t₁) is ẑ₀ itself (SURVEY A.4); the augmented rows start at zero
+        z_tmp = torch.empty_like(z_out)
+        tsp = ts.ctypes.data_as(C.POINTER(C.c_double))
+        L.check(lib.lde_set_step_record(handle.ptr, _ptr(rec2), nbytes), handle.ptr, "lde_set_step_record")
+        try:
+            L.check(lib.lde_forward(handle.ptr, _ptr(z0), _ptr(theta), tsp, T, B, _ptr(z_tmp), C.c_void_p(), stream), handle.ptr,
+                    "lde_forward")
+        finally:
+            lib.lde_set_step_record(handle.ptr, C.c_void_p(), 0)
+        return rec2
 
 
 def solve_batch(diffeq, z0_BD: torch.Tensor, theta_BP: Optional[torch.Tensor], t) -> Tuple[torch.Tensor, torch.Tensor]:
     """Batch-major entry point: z0 (B, D), θ (B, P) → ẑ (T, B, D'), retcode (B,). Differentiable."""
     handle = diffeq._native()
+    handle.check_record = bool(getattr(diffeq, "check_record", True))     # (see _SolveFn._record_that_holds)
     W = diffeq.flat_weights()
     return _SolveFn.apply(handle, _ts_array(t), z0_BD.contiguous().float(),
                           None if theta_BP is None else theta_BP.contiguous().float(), W)

@@ -188,7 +188,10 @@ int lde_problem_desc_default(lde_problem_desc* d) {
   d->param_dim = 1;
   d->solver = LDE_SOLVER_TSIT5;
   d->batching = LDE_BATCH_PER_TRAJECTORY;
-  d->sensealg = LDE_SENSE_PARALLEL_CHECKPOINTED;
+  // `Pendulum()` carries ForwardDiffSensitivity() [REF examples/pendulum_friction-less/pendulum.jl:8-11], splatted into solve() at
+  // [REF src/models/GOKU.jl:107, :121]: the exact derivative of the discrete solve — LDE_SENSE_DISCRETE. (A NODE binding sets
+  // LDE_SENSE_BACKSOLVE_CHECKPOINTED itself: DiffEqFlux's InterpolatingAdjoint [REF src/models/LatentODE.jl:67-70].)
+  d->sensealg = LDE_SENSE_DISCRETE;
   d->activation = LDE_ACT_RELU;
   d->adaptive = 1;
   d->maxiters = 100000;
@@ -337,6 +340,9 @@ static int rec_prepare(lde_handle* h, int which, int B, int T, lde::StepRec* out
       if (h->rec_own[which]) (void)hipFree(h->rec_own[which]);
       h->rec_own[which] = nullptr;
       h->rec_own_bytes[which] = 0;
+      // whatever the last call left in the old buffer is gone: a pullback (or lde_get_step_record) that would still read it through
+      // rec_last must be refused, not handed freed memory (e.g. "record_capacity" raised between lde_forward and lde_adjoint)
+      if (!(which == 0 && h->rec_user && h->rec_last[0].n && (void*)h->rec_last[0].n == h->rec_user)) h->rec_last[which] = lde::StepRec{};
       HIP_TRY(h, hipMalloc(&h->rec_own[which], need));
       h->rec_own_bytes[which] = need;
     }
@@ -617,6 +623,30 @@ int lde_set_step_record(lde_handle* h, void* rec_dev, int64_t bytes) {
   }
   h->rec_user = rec_dev;
   h->rec_user_bytes = rec_dev ? (size_t)bytes : 0;
+  return LDE_OK;
+}
+
+int lde_step_record_capacity(const lde_handle* h, int T) { return (!h || T < 1) ? 0 : rec_capacity(h, T, 0); }
+
+int lde_step_record_status(lde_handle* h, const void* rec_dev, int B, int T, int32_t* max_steps, int32_t* capacity, void* stream_) {
+  if (!h || !max_steps || B < 1 || T < 1) return LDE_ERR_INVALID_ARG;
+  lde::StepRec r;
+  if (rec_dev) {
+    r = rec_view(h->d, const_cast<void*>(rec_dev), B, rec_capacity(h, T, 0), true);
+  } else {
+    r = h->rec_last[0];
+    if (!r.n || h->rec_B != B || h->rec_T != T) {
+      h->err = "lde_step_record_status: no step record of an lde_forward with this (B, T) on this handle";
+      return LDE_ERR_INVALID_ARG;
+    }
+  }
+  HIP_TRY(h, hipStreamSynchronize((hipStream_t)stream_));
+  std::vector<int32_t> n((size_t)r.nseq);
+  HIP_TRY(h, hipMemcpy(n.data(), r.n, n.size() * 4, hipMemcpyDeviceToHost));
+  int32_t m = 0;
+  for (int32_t v : n) m = std::max(m, v);
+  *max_steps = m;
+  if (capacity) *capacity = r.cap;
   return LDE_OK;
 }
 

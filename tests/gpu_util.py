@@ -11,6 +11,10 @@ def make_desc(**kw):
     lib = L.load()
     d = L.ProblemDesc()
     lib.lde_problem_desc_default(C.byref(d))
+    # the library's default is LDE_SENSE_DISCRETE (the reference's ForwardDiffSensitivity; tests/test_gpu_discrete.py, test_gpu_default_sensealg.py);
+    # a parity test that says nothing about the sensealg checks the CONTINUOUS adjoint against the oracle's reverse-time solve
+    # (time-parallel on the GOKU path, the sequential checkpointed one elsewhere: lde_create's mapping)
+    kw.setdefault("sensealg", L.SENSE_PARALLEL_CHECKPOINTED)
     layers = kw.pop("layers", ())
     d.n_layers = max(len(layers) - 1, 0)
     for i, s in enumerate(layers):

@@ -42,8 +42,10 @@ def test_desc_defaults_match_ordinarydiffeq_defaults_and_bindings_agree():
     assert (d.abstol, d.reltol, d.maxiters, d.adaptive) == (1e-6, 1e-3, 100000, 1)
     assert (d.qmin, d.qmax, d.gamma) == (0.2, 10.0, 0.9) and abs(d.beta1 - 0.14) < 1e-15 and abs(d.beta2 - 0.08) < 1e-15
     assert (d.rhs_kind, d.state_dim, d.param_dim, d.solver, d.batching) == (0, 2, 1, 0, 0)
-    assert d.sensealg == _lib.SENSE_PARALLEL_CHECKPOINTED   # the GOKU path defaults to the time-parallel adjoint
-    od = O.make_desc(sensealg=O.SENSE_PARALLEL_CHECKPOINTED)
+    # Pendulum() carries ForwardDiffSensitivity() [REF pendulum.jl:8-11], splatted into solve() [REF src/models/GOKU.jl:107, :121]:
+    # the exact derivative of the discrete solve = LDE_SENSE_DISCRETE
+    assert d.sensealg == _lib.SENSE_DISCRETE == 3
+    od = O.make_desc(sensealg=O.SENSE_DISCRETE)
     assert C.sizeof(od) == C.sizeof(d)
     assert bytes(od) == bytes(d), "oracle and product describe the default problem with identical bytes"
     # header struct size: 18 int32 (incl. layer_sizes[7]) + pad, 1 int64, 9 doubles
@@ -123,6 +125,12 @@ def test_reference_shaped_host_api_surface():
     assert hasattr(p, "prob") and hasattr(p, "solver") and hasattr(p, "sensealg") and hasattr(p, "kwargs")
     assert len(p.prob.u0) == 2 and len(p.prob.p) == 1
     assert isinstance(la.Pendulum(sensalg=la.BacksolveAdjoint()).sensealg, la.BacksolveAdjoint)  # `sensalg` spelling [REF pendulum.jl:11]
+    # the default IS the reference's: ForwardDiffSensitivity() [REF pendulum.jl:8-11] = the exact derivative of the discrete solve
+    from latentdiffeq_amd import _lib as _l
+    assert isinstance(p.sensealg, la.ForwardDiffSensitivity) and p.sensealg.code == _l.SENSE_DISCRETE
+    assert la.Pendulum_friction().sensealg.code == _l.SENSE_DISCRETE and la.DiscreteSensitivity().code == _l.SENSE_DISCRETE
+    assert la.ParallelAdjoint().code == _l.SENSE_PARALLEL_CHECKPOINTED == la.ForwardDiffSensitivity(exact=False).code   # still selectable
+    assert la.NODE(4, hidden_dim=8).sensealg.code == _l.SENSE_BACKSOLVE_CHECKPOINTED      # InterpolatingAdjoint [REF LatentODE.jl:67-70]
     n = la.NODE(4, hidden_dim=8, augment_dim=2)
     # [REF nODE.jl:3-32], [REF src/models/LatentODE.jl:62-66, :105-106]
     for f in ("dudt", "solver", "neural_model", "latent_dim_in", "latent_dim_out", "augment_dim", "kwargs"):
@@ -214,7 +222,7 @@ def test_documented_julia_struct_layouts():
             assert (cf.offset, cf.size) == (off, size), (jname, fname, cf.offset, off)
             off += size
         assert (off + 7) // 8 * 8 == C.sizeof(cstruct) or off == C.sizeof(cstruct), jname
-    # the stub must start from the library's defaults (sensealg = PARALLEL_CHECKPOINTED), not from zeros
+    # the stub must start from the library's defaults (sensealg = LDE_SENSE_DISCRETE, the reference's ForwardDiffSensitivity), not from zeros
     src = open(os.path.join(ROOT, "julia", "LdeNative.jl")).read()
     assert "lde_problem_desc_default" in src.split("mutable struct LdeHandle")[0]
     # every entry point the stub ccalls is an export of the library

@@ -218,13 +218,15 @@ def test_large_batch_adjoint_streams_per_trajectory(o32, o64, kind, tol):
 
 
 def test_torch_api_diffeq_layer(o32):
-    """The reference-shaped host API: ẑ = diffeq_layer(decoder, (ẑ₀, θ̂), t), differentiable."""
+    """The reference-shaped host API: ẑ = diffeq_layer(decoder, (ẑ₀, θ̂), t), differentiable — here with the continuous (time-parallel)
+    adjoint against the oracle's reverse-time solve; the struct's default, ForwardDiffSensitivity = LDE_SENSE_DISCRETE, is held to the
+    oracle's discrete sweep in tests/test_gpu_default_sensealg.py and tests/test_gpu_discrete.py."""
     import torch
     import latentdiffeq_amd as la
     B, T = 64, 50
     z0, L = O.pendulum_inputs(B)
     ts = O.time_grid(T)
-    dec = la.Decoder(la.GOKU_basic(), (None, la.Pendulum(), None))
+    dec = la.Decoder(la.GOKU_basic(), (None, la.Pendulum(sensealg=la.ParallelAdjoint()), None))
     z0t = torch.tensor(z0.T.copy(), device="cuda", requires_grad=True)      # [D, B]
     tht = torch.tensor(L.T.copy(), device="cuda", requires_grad=True)        # [P, B]
     zhat = la.diffeq_layer(dec, (z0t, tht), ts)

@@ -237,12 +237,14 @@ int lde_set_global_sum_hook(lde_handle* h, lde_sum_hook hook, void* user, int64_
  * handle's index in it. Workgroup 0 of the solve's kernel writes this rank's (float32) sums into slot `rank` of every mailbox, waits for the
  * nranks words of its own and adds them in rank order — the same bits on every rank — so lde_forward / lde_adjoint stay asynchronous and
  * a sum costs one xGMI round trip instead of a host collective. Every rank must make the same sequence of calls on its handle (the words are
- * tagged with the handle's launch count and the launch's sum count, and those are compared across ranks); a rank that stops answering
- * poisons the others' sums after a bounded spin (retcode != 0, never a hang). nranks ≤ 8 (one node); nranks == 0 switches the path off;
+ * tagged with the count of exchanging launches since lde_set_global_sum_peers — a counter of its own that never skips or restarts — and the
+ * launch's sum count, and those are compared across ranks); a rank that stops answering poisons the others' sums after a bounded spin
+ * (option "peer_spin_k"; retcode != 0, never a hang). nranks ≤ 8 (one node); nranks == 0 switches the path off;
  * setting peers clears a hook. (Ranks that SHARE a device — the tests' construction — must issue their calls on streams that cannot share a
  * hardware queue, e.g. streams of different priority: the kernels wait for each other, so they have to be in flight at once.)
- * [REF src/models/LatentODE.jl:70-72] as above. Exercised in this repository by two handles on ONE device
- * (tests/test_gpu_coupled_global.py) — the cross-device mapping itself has not run on hardware here (one-GPU boxes). */
+ * [REF src/models/LatentODE.jl:70-72] as above. Exercised in this repository by two handles on ONE device and by two PROCESSES sharing
+ * one device through HIP IPC handles (tests/test_gpu_coupled_global.py, tests/test_gpu_ipc_mailboxes.py) — the mapping across DEVICES has
+ * not run on hardware here (one-GPU boxes). */
 int64_t lde_global_sum_mailbox_bytes(int nranks);
 int lde_set_global_sum_peers(lde_handle* h, int rank, int nranks, void* const* mailboxes, int64_t global_batch);
 
@@ -279,7 +281,9 @@ int lde_get_step_record(lde_handle* h, int which, double* t_host, double* dt_hos
  * and the kernel-choice knobs the parity tests force a kernel family / a threshold with (defaults = the measured choices; a production
  * host never sets them): "pend_ws", "pend_tl_max_b", "pend_sh_max_b", "pend_lb", "pend_lb_min_b", "pend_lb_hold" (analytic right-hand
  * sides: which of the five forward mappings serves a batch), "mlp64", "mlpv", "mlpw", "mlpb" (0 off, 2 also ≤ 128-wide networks), "mlp4",
- * "mlp4_maxw", "mlp_stage_slots" (MLP right-hand sides). The library reads NO environment variable for any of this.
+ * "mlp4_maxw", "mlp_stage_slots" (MLP right-hand sides), "peer_spin_k" (lde_set_global_sum_peers: the cross-rank wait poisons the sums after
+ * this many × 1024 polls of ≈ 1 µs; 0 = 8192 ≈ 10 s — raise it when ranks may enter a solve seconds apart, e.g. a first call's module load;
+ * all ranks should be warmed up before the first exchanging call). The library reads NO environment variable for any of this.
  * lde_get_option also answers the read-only "adjoint_family": the kernel family the last lde_adjoint ran on an MLP right-hand side
  * (0 tiles, 1 k_mlp64, 2 k_mlpb, 3 k_mlpc, 4 k_mlpw, 5 k_mlpv, 6 k_mlp4; −1 none) — what bench.py prices its roofline with.
  * Unknown key: LDE_ERR_INVALID_ARG. */

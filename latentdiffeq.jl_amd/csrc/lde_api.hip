@@ -699,6 +699,7 @@ static int* option_slot(lde_handle* h, const char* key) {
     if (!std::strcmp(key, "mlp4")) return &mt.mlp4;
     if (!std::strcmp(key, "mlp4_maxw")) return &mt.mlp4_maxw;
     if (!std::strcmp(key, "mlp_stage_slots")) return &mt.stage_slots;
+    if (!std::strcmp(key, "peer_spin_k")) return &mt.peer_spin_k;
   }
   return nullptr;
 }

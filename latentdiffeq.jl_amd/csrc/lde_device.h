@@ -42,6 +42,7 @@ struct MlpTune {
   int mlpb = 1;               // "mlpb": 0 off (k_mlpw instead: the parity reference), 2 also the networks of ≤ 128 units
   int mlp4_maxw = 64;         // "mlp4_maxw": widest layer k_mlp4_adjoint takes
   int stage_slots = 0;        // "mlp_stage_slots": staging slots per workgroup (0: automatic)
+  int peer_spin_k = 0;        // "peer_spin_k": lde_set_global_sum_peers' cross-rank wait gives up after this many × 1024 polls (0: 8192 ≈ 10 s)
 };
 
 // Options handed to every kernel by value (mirrors the `kwargs...` splat into solve()).

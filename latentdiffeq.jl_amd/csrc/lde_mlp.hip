@@ -206,6 +206,10 @@ struct GridSync {
   // (the same bits on every rank). nranks = 0: off.
   unsigned long long* peer[LDE_MAX_PEERS];
   int rank, nranks;
+  unsigned xlaunch;    // the peer exchange's OWN launch counter (16 bits): +1 per launch that exchanges, never skipped, never reset — the mailbox
+                       // words' tag and parity come from it, not from the grid words' epoch (which skips 0 at its wrap and restarts when the
+                       // words are reallocated: ranks whose local batch grows at different calls would fall out of step)
+  int xspin_k;         // cross-rank wait: give up (poison the sums) after xspin_k·1024 polls of ≈ 1 µs (option "peer_spin_k", default 8192 ≈ 10 s)
   __host__ __device__ bool cross() const { return host_req != nullptr || nranks > 0; }   // the sums leave the device
 };
 
@@ -1422,6 +1426,7 @@ struct MlpPlan {
   hipEvent_t mbox_ev = nullptr;
   // … or device to device (lde_set_global_sum_peers): every rank's mailbox as mapped on THIS device
   int peer_n = 0, peer_rank = 0;
+  unsigned peer_launch = 0;    // launches that exchanged through the peer mailboxes (GridSync::xlaunch)
   unsigned long long* peer_box[LDE_MAX_PEERS] = {};
   // lde_set_phase_timing: HIP events around the adjoint's solve kernel and its weight-gradient tail (bench.py's per-kernel roofline)
   bool phase_on = false;
@@ -2228,6 +2233,7 @@ int mlp_set_sum_peers(MlpPlan* p, int rank, int nranks, void* const* boxes, int6
     return LDE_ERR_ALLOC;
   }
   p->sum_hook = nullptr;   // one exchange path at a time
+  p->peer_launch = 0;      // a fresh set of (zeroed) mailboxes: every rank starts its count with them
   p->peer_n = nranks;
   p->peer_rank = rank;
   for (int r = 0; r < nranks; r++) p->peer_box[r] = (unsigned long long*)boxes[r];
@@ -2242,6 +2248,8 @@ static int global_arm(MlpPlan* p, VArgs& a, hipStream_t stream, std::string& err
   a.gs.dev_rep = nullptr;
   a.gs.nranks = 0;
   a.gs.rank = 0;
+  a.gs.xlaunch = 0;
+  a.gs.xspin_k = p->tune.peer_spin_k > 0 ? p->tune.peer_spin_k : 8192;
   a.Bnorm = 0;
   if (p->global_mode && p->peer_n > 0) {   // device to device: nothing for the host to serve, the call stays asynchronous
     if (hipMemsetAsync(p->mbox_dev, 0, 16 * sizeof(unsigned long long), stream) != hipSuccess) {
@@ -2250,6 +2258,8 @@ static int global_arm(MlpPlan* p, VArgs& a, hipStream_t stream, std::string& err
     }
     a.gs.nranks = p->peer_n;
     a.gs.rank = p->peer_rank;
+    p->peer_launch = (p->peer_launch + 1) & 0xffffu;
+    a.gs.xlaunch = p->peer_launch;
     for (int r = 0; r < p->peer_n; r++) a.gs.peer[r] = p->peer_box[r];
     a.gs.dev_rep = p->mbox_dev;
     a.Bnorm = p->global_batch;
@@ -2533,7 +2543,7 @@ static int mlp_adjoint_disc(MlpPlan* p, const float* W_dev, const float* z_out, 
     va.dz0 = dz0; va.dtheta = dtheta; va.stage = p->rows; va.cap = p->rows_stride;
     va.st_nfe = nfe; va.st_nacc = nacc; va.st_nrej = nrej; va.st_ret = ret;
     va.gs.counter = p->counter; va.gs.slots = p->slots; va.gs.abort_flag = p->abort_flag; va.gs.nwg = 1;
-    va.gs.host_req = nullptr; va.gs.host_rep = nullptr; va.gs.dev_rep = nullptr; va.gs.nranks = 0; va.gs.rank = 0; va.Bnorm = 0;
+    va.gs.host_req = nullptr; va.gs.host_rep = nullptr; va.gs.dev_rep = nullptr; va.gs.nranks = 0; va.gs.rank = 0; va.gs.xlaunch = 0; va.gs.xspin_k = 8192; va.Bnorm = 0;
     phase_mark(p, 0, stream);
     const bool rk4 = dm.solver == LDE_SOLVER_RK4;
     const int rcb = fam == DISC_B ? (rk4 ? launch_b<LDE_SOLVER_RK4, true, true>(p, o, va, false, stream, err)

@@ -89,12 +89,16 @@ __device__ __forceinline__ void w_host_sum(const GridSync& gs, unsigned tag, flo
   if (gs.nranks > 0) {
     // device to device: this rank's words go into slot `rank` of EVERY rank's mailbox (its own included), then the nranks words of its own
     // mailbox are awaited and added in rank order. Word sets by (launch parity, sum parity): a rank writes sum g + 2 only after it has read all
-    // of g + 1, which every rank wrote after reading g; the first sums of the NEXT launch use the other launch parity. Every rank must make
-    // the same sequence of calls on its handle (the tag = (launch count, sum count) is compared across ranks). System scope: the words cross xGMI
+    // of g + 1, which every rank wrote after reading g; the first sums of the NEXT launch use the other launch parity — the parity of
+    // gs.xlaunch, the exchange's own launch counter, which advances by exactly one per exchanging launch on every rank (the grid words'
+    // epoch skips 0 when it wraps and restarts when the words are reallocated). Every rank must make the same sequence of calls on its
+    // handle (the tag = (exchange launch count, sum count) is compared across ranks). System scope: the words cross xGMI
     // (fine-grained, peer-mapped memory).
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-      const size_t par = (size_t)((((tag >> 16) & 1u) << 1) | (tag & 1u)) * gs.nranks * 2;   // four word sets: (launch parity, sum parity)
-      const unsigned long long w0 = ((unsigned long long)tag << 32) | __float_as_uint(v0), w1 = ((unsigned long long)tag << 32) | __float_as_uint(TWO ? v1 : 0.f);
+      // the words' tag: (the exchange's own launch count, this launch's sum count) — the same on every rank by the contract above
+      const unsigned xt = (gs.xlaunch << 16) | (tag & 0xffffu);
+      const size_t par = (size_t)(((gs.xlaunch & 1u) << 1) | (xt & 1u)) * gs.nranks * 2;   // four word sets: (launch parity, sum parity)
+      const unsigned long long w0 = ((unsigned long long)xt << 32) | __float_as_uint(v0), w1 = ((unsigned long long)xt << 32) | __float_as_uint(TWO ? v1 : 0.f);
       for (int r = 0; r < gs.nranks; r++) {
         unsigned long long* box = gs.peer[r] + par + (size_t)gs.rank * 2;
         __hip_atomic_store(box + 1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -103,15 +107,16 @@ __device__ __forceinline__ void w_host_sum(const GridSync& gs, unsigned tag, flo
       float t0 = 0.f, t1 = 0.f;
       bool bad = false;
       const unsigned long long* mine = gs.peer[gs.rank] + par;
+      const long long spin_max = (long long)gs.xspin_k * 1024;
       for (int r = 0; r < gs.nranks && !bad; r++) {
         unsigned long long q0 = 0, q1 = 0;
         long long spins = 0;
         for (;;) {
           q0 = __hip_atomic_load(mine + (size_t)r * 2, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM);
           q1 = __hip_atomic_load(mine + (size_t)r * 2 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-          if ((unsigned)(q0 >> 32) == tag && (unsigned)(q1 >> 32) == tag) break;
+          if ((unsigned)(q0 >> 32) == xt && (unsigned)(q1 >> 32) == xt) break;
           __builtin_amdgcn_s_sleep(2);
-          if ((++spins & 1023) == 0 && (spins > 8000000LL || __hip_atomic_load(gs.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
+          if ((++spins & 1023) == 0 && (spins >= spin_max || __hip_atomic_load(gs.abort_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0)) {
             __hip_atomic_store(gs.abort_flag, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // a peer rank is gone: poison the sums instead of hanging
             bad = true;
             break;

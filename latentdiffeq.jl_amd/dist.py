@@ -279,9 +279,9 @@ class GlobalSumMailboxes:
     shared between the processes of one node by hipIpcGetMemHandle / hipIpcOpenMemHandle, the handles gathered over `group` (any backend:
     64 bytes per rank, once). `.pointers()` is the list every rank passes, in rank order; keep the object alive as long as the handles use it.
 
-    One process per GPU, one node (≤ 8 ranks). With a single rank — all a one-GPU box can run, and what tests/test_gpu_coupled_global.py
-    runs — the allocation, the hand-over and the kernel's exchange with itself are exercised; the cross-process mapping is written to the
-    HIP IPC contract and has NOT run on multi-GPU hardware in this repository."""
+    One process per GPU, one node (≤ 8 ranks). tests/test_gpu_ipc_mailboxes.py runs the cross-PROCESS half on a one-GPU box: two processes
+    on GPU 0 exchange their IPC handles over a gloo group, map each other's mailbox and run the two shards of one coupled solve; across
+    DEVICES (peer access over xGMI) it has not run on hardware in this repository."""
 
     _FINEGRAINED = 0x1   # hipDeviceMallocFinegrained
     _LAZY_PEER = 0x1     # hipIpcMemLazyEnablePeerAccess
@@ -310,10 +310,22 @@ class GlobalSumMailboxes:
             self._ptrs[self.rank] = own.value
             self._opened = []
             if self.world > 1:
-                handle = (C.c_ubyte * 64)()
-                if self._hip.hipIpcGetMemHandle(C.byref(handle), own) != 0:
-                    raise RuntimeError("hipIpcGetMemHandle(mailbox) failed")
-                mine = torch.tensor(list(handle), dtype=torch.uint8)
+                # hipIpcMemHandle_t is a 64-byte struct and hipIpcOpenMemHandle takes it BY VALUE (ctypes would pass an array as a pointer:
+                # the callee would read a garbage handle — ADVICE r5)
+                class hipIpcMemHandle_t(C.Structure):
+                    _fields_ = [("reserved", C.c_char * 64)]
+                hip = self._hip
+                hip.hipIpcGetMemHandle.argtypes = [C.POINTER(hipIpcMemHandle_t), C.c_void_p]
+                hip.hipIpcGetMemHandle.restype = C.c_int
+                hip.hipIpcOpenMemHandle.argtypes = [C.POINTER(C.c_void_p), hipIpcMemHandle_t, C.c_uint]
+                hip.hipIpcOpenMemHandle.restype = C.c_int
+                hip.hipIpcCloseMemHandle.argtypes = [C.c_void_p]
+                hip.hipIpcCloseMemHandle.restype = C.c_int
+                handle = hipIpcMemHandle_t()
+                rc = hip.hipIpcGetMemHandle(C.byref(handle), own)
+                if rc != 0:
+                    raise RuntimeError(f"hipIpcGetMemHandle(mailbox) failed: {rc}")
+                mine = torch.frombuffer(bytearray(bytes(handle)), dtype=torch.uint8).clone()
                 backend = dist.get_backend(group)
                 if backend == "nccl":
                     mine = mine.to(self.device)
@@ -322,10 +334,11 @@ class GlobalSumMailboxes:
                 for r, hb in enumerate(gathered):
                     if r == self.rank:
                         continue
-                    hr = (C.c_ubyte * 64)(*hb.cpu().tolist())
+                    hr = hipIpcMemHandle_t.from_buffer_copy(bytes(hb.cpu().tolist()))
                     p = C.c_void_p()
-                    if self._hip.hipIpcOpenMemHandle(C.byref(p), hr, C.c_uint(self._LAZY_PEER)) != 0 or not p.value:
-                        raise RuntimeError(f"hipIpcOpenMemHandle(rank {r}'s mailbox) failed")
+                    rc = hip.hipIpcOpenMemHandle(C.byref(p), hr, C.c_uint(self._LAZY_PEER))
+                    if rc != 0 or not p.value:
+                        raise RuntimeError(f"hipIpcOpenMemHandle(rank {r}'s mailbox) failed: {rc}")
                     self._ptrs[r] = p.value
                     self._opened.append(p)
                 dist.barrier(group=group)      # every rank has mapped every mailbox before anyone's kernel writes

@@ -686,6 +686,7 @@ static int* option_slot(lde_handle* h, const char* key) {
   if (!std::strcmp(key, "pend_ws")) return &pt.ws;
   if (!std::strcmp(key, "pend_tl_max_b")) return &pt.tl_max_b;
   if (!std::strcmp(key, "pend_sh_max_b")) return &pt.sh_max_b;
+  if (!std::strcmp(key, "pend_lp")) return &pt.lp;
   if (!std::strcmp(key, "pend_lb")) return &pt.lb_ring;
   if (!std::strcmp(key, "pend_lb_min_b")) return &pt.lb_min_b;
   if (!std::strcmp(key, "pend_lb_hold")) return &pt.lb_hold;

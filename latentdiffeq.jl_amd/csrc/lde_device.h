@@ -31,7 +31,8 @@ struct StepRec {
 struct PendTune {
   int ws = 1;                 // "pend_ws": k_pend_forward_ws for B ≤ 16384
   int tl_max_b = 1024;        // "pend_tl_max_b": k_pend_forward_tl up to this batch
-  int sh_max_b = 256;         // "pend_sh_max_b": k_pend_forward_sh up to this batch
+  int sh_max_b = 256;         // "pend_sh_max_b": k_pend_forward_sh / k_pend_forward_lp (a trajectory per workgroup) up to this batch
+  int lp = 1;                 // "pend_lp": frictionless Tsit5 adaptive solves of that shape run k_pend_forward_lp (lane pairs, Nyström form); 0: k_pend_forward_sh
   int lb_ring = 16;           // "pend_lb": rows of the large-batch row ring (8 / 16 / 32; 0: off)
   int lb_min_b = 1 << 17;     // "pend_lb_min_b": the large-batch form from this batch on
   int lb_hold = -1;           // "pend_lb_hold": its hold margin (−1: half the ring)

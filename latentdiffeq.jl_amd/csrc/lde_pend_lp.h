@@ -1,0 +1,390 @@
+// lde_pend_lp.h — k_pend_forward_lp: the metric's forward solve (frictionless pendulum, Tsit5, adaptive, B ≤ one workgroup per CU) with the
+// stepping wave's 64 redundant lanes put to work (round 6; included by lde_pendulum.hip behind k_pend_forward_sh, whose protocol it keeps).
+//
+// k_pend_forward_sh's stepping wave carries the SAME solve in all 64 lanes and its duration is one dependent-instruction chain: six stage
+// evaluations one behind the other, each (stage sum → angle in turns → v_sin_f32 → ·(−g/L) → into the later stages' sums), ≈ 757 cycles per
+// accepted step. Two observations remove half of that chain:
+//
+//  1. For f = (v, s(x)), s = −(g/L)·sin x, Tsit5 is a Nyström scheme: the stage ANGLES need no stage velocities,
+//         x_i = x + c_i·h·v + h²·Σ_{l ≤ i−2} Ā_il s_l,   Ā = A·A,
+//     so s_i depends on s_1 … s_{i−2} only: the six evaluations of a step are two interleaved chains (2 → 4 → 6) and (3 → 5 → 7) of depth
+//     THREE. (The register-pair form hides this: a v_pk_fma_f32 on (x, v) waits for s_{i−1} although only its v half needs it.)
+//  2. The two chains run in the two lanes of a lane pair under ONE instruction stream: even lanes evaluate stages 3, 5 and the new state's
+//     slope 7 (= the next step's first: FSAL), odd lanes 2, 4, 6, with lane-dependent tableau coefficients in registers; a level is
+//     (sum → v_sin_f32 → quad_perm swap), three levels per step. Even lanes also carry x, odd lanes v: y_new, the error estimate's two
+//     components and their scaled squares are one instruction each for both components, and the two squares meet by one DPP add.
+//
+// Per accepted step ≈ 85 instructions with 7 quarter-rate ones on a chain of ≈ 30 (k_pend_forward_sh: 128 / 9 / ≈ 56). The arithmetic is the
+// same method with the same coefficients — derived here in double precision from the tableau (lp::TB; abl/rkn_coeffs.py checks the
+// identities in float64) — in another order of operations: results agree with k_pend_forward_sh like two correct f32 solves
+// (tests/test_gpu_pendulum.py: both held to the oracle by the same gates; option "pend_lp" = 0 selects the older kernel).
+//
+// The record a step leaves for the dense-output waves is {σ₂ … σ₇, y_new, h} (σ_i = sin x_i): the helpers no longer re-run the stages —
+// the interpolant's polynomials follow from the sines directly, P_m = (h·(−g/L)·Σ_l RA_ml σ_l, (−g/L)·Σ_j r_jm σ_j), RA = rᵀA — so the
+// last step's slopes need no second hand-over (k_pend_forward_sh's s_klast) and a helper's work per step is ≈ 60 shallow instructions.
+// [REF src/models/GOKU.jl:98-130: the solve this replaces; examples/pendulum_friction-less/pendulum.jl:19-26: the right-hand side]
+#pragma once
+
+namespace lp {
+// Tsit5 in double precision, 1-based (the f32 tables of lde_device.h are these constants rounded)
+struct Tab {
+  double C[8];        // c_i = Σ_j a_ij
+  double Ab[8][8];    // Ā = A·A; row 7 = B̄ (x_new)
+  double Et[8];       // Ẽ_l = Σ_j b̃_j a_jl (a_7l = b_l): err_x = h² Σ_l Ẽ_l s_l
+  double RA[3][8];    // RA_ml = Σ_j r_jm a_jl: the dense output's Θ², Θ³, Θ⁴ polynomials, x component
+  double RR[8][3];    // r_jm
+  double A[8][8], BT[8];
+};
+constexpr Tab make_tab() {
+  Tab t{};
+  constexpr double a[8][8] = {
+      {0, 0, 0, 0, 0, 0, 0, 0},
+      {0, 0, 0, 0, 0, 0, 0, 0},
+      {0, 0.161, 0, 0, 0, 0, 0, 0},
+      {0, -0.008480655492356989, 0.335480655492357, 0, 0, 0, 0, 0},
+      {0, 2.8971530571054935, -6.359448489975075, 4.3622954328695815, 0, 0, 0, 0},
+      {0, 5.325864828439257, -11.748883564062828, 7.4955393428898365, -0.09249506636175525, 0, 0, 0},
+      {0, 5.86145544294642, -12.92096931784711, 8.159367898576159, -0.071584973281401, -0.028269050394068383, 0, 0},
+      {0, 0.09646076681806523, 0.01, 0.4798896504144996, 1.379008574103742, -3.290069515436081, 2.324710524099774, 0}};
+  constexpr double bt[8] = {0, -0.00178001105222577714, -0.0008164344596567469, 0.007880878010261995, -0.1447110071732629,
+                            0.5823571654525552, -0.45808210592918697, 0.015151515151515152};
+  constexpr double rr[8][3] = {{0, 0, 0},
+                               {-2.763706197274826, 2.9132554618219126, -1.0530884977290216},
+                               {0.13169999999999998, -0.2234, 0.1017},
+                               {3.9302962368947516, -5.941033872131505, 2.490627285651253},
+                               {-12.411077166933676, 30.33818863028232, -16.548102889244902},
+                               {37.50931341651104, -88.1789048947664, 47.37952196281928},
+                               {-27.896526289197286, 65.09189467479366, -34.87065786149661},
+                               {1.5, -4.0, 2.5}};
+  for (int i = 0; i < 8; i++) {
+    t.BT[i] = bt[i];
+    double c = 0;
+    for (int j = 0; j < 8; j++) { t.A[i][j] = a[i][j]; c += a[i][j]; }
+    t.C[i] = c;
+    for (int m = 0; m < 3; m++) t.RR[i][m] = rr[i][m];
+  }
+  for (int i = 0; i < 8; i++)
+    for (int l = 0; l < 8; l++) {
+      double s = 0;
+      for (int j = 0; j < 8; j++) s += a[i][j] * a[j][l];
+      t.Ab[i][l] = s;
+    }
+  for (int l = 0; l < 8; l++) {
+    double s = 0;
+    for (int j = 0; j < 8; j++) s += bt[j] * a[j][l];
+    t.Et[l] = s;
+    for (int m = 0; m < 3; m++) {
+      double q = 0;
+      for (int j = 0; j < 8; j++) q += rr[j][m] * a[j][l];
+      t.RA[m][l] = q;
+    }
+  }
+  return t;
+}
+constexpr Tab TB = make_tab();
+// the structure the kernel relies on: x_i needs s_1 … s_{i−2} only
+static_assert(TB.Ab[2][1] == 0 && TB.Ab[3][2] == 0 && TB.Ab[4][3] == 0 && TB.Ab[5][4] == 0 && TB.Ab[6][5] == 0 && TB.Ab[7][6] == 0, "Nyström structure");
+static_assert(TB.C[6] > 0.999999999 && TB.C[6] < 1.000000001 && TB.C[7] > 0.999999999 && TB.C[7] < 1.000000001, "c₆ = c₇ = 1");
+
+constexpr int COPIES = 16;         // copies of a step's record (lane ℓ uses copy ℓ >> 2: every access a 16-byte chunk of its own)
+constexpr int RECF = 12;           // floats per copy: {σ₃, σ₅, σ₇, x_new | σ₂, σ₄, σ₆, v_new | h, h, ·, ·}
+constexpr int STEPF = COPIES * RECF;
+
+template <int CTRL>
+__device__ __forceinline__ float dpp(float v) {   // the value of the lane CTRL maps this lane to (quad_perm patterns: every lane has a source)
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+constexpr int SWAP = 0xB1;   // quad_perm [1,0,3,2]: the partner lane
+constexpr int EVEN = 0xA0;   // quad_perm [0,0,2,2]: the pair's even lane
+constexpr int ODD = 0xF5;    // quad_perm [1,1,3,3]: the pair's odd lane
+}  // namespace lp
+
+template <bool REC>   // REC: the instantiation that writes step records (LDE_SENSE_DISCRETE, "step_trace")
+__global__ void __launch_bounds__(64 * (1 + SH_NH)) k_pend_forward_lp(const float2* __restrict__ z0, const float* __restrict__ theta,
+                                                         const double* __restrict__ ts_g, KOpts o,
+                                                         float2* __restrict__ z_out, int32_t* __restrict__ retcode,
+                                                         int32_t* __restrict__ st_nfe, int32_t* __restrict__ st_nacc,
+                                                         int32_t* __restrict__ st_nrej, int32_t* __restrict__ st_ret) {
+  using namespace lp;
+  __shared__ __attribute__((aligned(16))) float s_rec[SH_CAP * STEPF];
+  __shared__ int s_cnt[64];
+  __shared__ int s_fin;    // 0: stepping; 1: the round is over, another follows; 2: done
+  __shared__ int s_fail;
+  const int T = o.T, B = o.B, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int chunk = gridDim.x >> 3;   // XCD-aware trajectory ↔ workgroup map (as k_pend_forward_sh); the grid is a multiple of 8
+  const int b = (blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  const bool valid = b < B;
+  const int bc = valid ? b : B - 1;
+  const double t_first = o.t_first, tend = o.t_last;
+  const float2 zi = z0[bc];
+  PendFwd<0> f(theta[bc]);
+  const float ngl = f.ngl;
+  if (tid < 64) s_cnt[tid] = 0;
+  if (tid == 0) { s_fin = 0; s_fail = 0; }
+  __syncthreads();
+  constexpr int NS = 6;  // RHS evaluations per attempt
+  float* const myrec = s_rec + (lane >> 2) * RECF;   // this lane's copy of record 0
+
+  if (w == 0) {
+    // ================= the stepper =================
+    PPROF(8);
+    const bool ev = (lane & 1) == 0;
+    auto sel = [&](double a, double c) -> float { return ev ? (float)a : (float)c; };
+    // lane-dependent coefficients: even lanes stages 3, 5, new (7); odd lanes stages 2, 4, 6. "own" = this lane's sine of the level
+    // before, "par" = the partner lane's.
+    const float C1 = sel(TB.C[3], TB.C[2]), K11 = sel(TB.Ab[3][1], 0.0);
+    const float C2 = sel(TB.C[5], TB.C[4]), K21 = sel(TB.Ab[5][1], TB.Ab[4][1]), K2o = sel(TB.Ab[5][3], TB.Ab[4][2]), K2p = sel(TB.Ab[5][2], 0.0);
+    const float K31 = sel(TB.Ab[7][1], TB.Ab[6][1]), K3o1 = sel(TB.Ab[7][3], TB.Ab[6][2]), K3p1 = sel(TB.Ab[7][2], TB.Ab[6][3]);
+    const float K3o2 = sel(TB.Ab[7][5], TB.Ab[6][4]), K3p2 = sel(TB.Ab[7][4], 0.0);
+    // first sum: even lanes the error estimate's x component (Ẽ), odd lanes the new velocity (b)
+    const float D11 = sel(TB.Et[1], TB.A[7][1]), D1o1 = sel(TB.Et[3], TB.A[7][2]), D1p1 = sel(TB.Et[2], TB.A[7][3]);
+    const float D1o2 = sel(TB.Et[5], TB.A[7][4]), D1p2 = sel(TB.Et[4], TB.A[7][5]), D1o3 = sel(0.0, TB.A[7][6]), D1p3 = sel(TB.Et[6], 0.0);
+    // second sum: the error estimate's v component (b̃), every lane its own sines' terms; the two halves meet by one DPP add
+    const float D21 = sel(TB.BT[1], 0.0), D2o1 = sel(TB.BT[3], TB.BT[2]), D2o2 = sel(TB.BT[5], TB.BT[4]), D2o3 = sel(TB.BT[7], TB.BT[6]);
+    const float evm = ev ? 1.f : 0.f;
+    const float glt = ngl * INV_2PI;   // −g/L per turn: scales h² into the angle's unit (turns)
+
+    int ret = LDE_RET_SUCCESS, nfe = 0, nacc = 0, nrej = 0;
+    double t = t_first;
+    float dt = 0.f;
+    constexpr float LQ_MIN = -13.287712379549449f;   // log₂ of qoldinit = 1e-4
+    float lqold = LQ_MIN;
+    const int maxit = o.maxiters > 0x7fffffffLL ? 0x7fffffff : (int)o.maxiters;
+    const float dtmin = (float)o.dtmin;
+    if (valid && lane == 0) z_out[b] = zi;  // ts[0] is saved as ẑ₀ itself
+    const double dtmax_d = tend - t;
+    const float dtmax = (float)dtmax_d;
+    float s1 = hw_sin(zi.x, turn_anchor(zi.x));   // σ₁ = sin x₀ (uniform)
+    nfe = 1;
+    if (o.dt_fixed > 0) dt = (float)fmin(o.dt_fixed, dtmax_d);
+    else {
+      f.anchor(zi.x);
+      const float ya[2] = {zi.x, zi.y}, fa[2] = {zi.y, ngl * s1};
+      dt = (float)init_dt<2>(f, ya, fa, 1.0f, dtmax_d, o);
+      nfe++;
+    }
+    float yc = ev ? zi.x : zi.y;   // even lanes x, odd lanes v
+    bool active = __any(t < tend) && maxit > 0;   // (votes: scalar from here on)
+    if (__any(t < tend) && !active) ret = LDE_RET_MAXITERS;
+    PPROF(9);
+    for (;;) {   // rounds
+      int n = 0;
+      float* rp = myrec + (lane & 1) * 4;
+      const double t_round = t;   // (REC) where this round's first record starts
+      const float xr = dpp<EVEN>(yc), vr = dpp<ODD>(yc);
+      int lim = min(SH_CAP, maxit - (nacc + nrej));
+      bool go = active && lim > 0;
+      while (go) {
+        const float rem = (float)(tend - t);
+        const bool last = __any(dt >= rem * 0.99999988f);
+        const float h = last ? rem : dt;
+        const float xa = dpp<EVEN>(yc), va = dpp<ODD>(yc);
+        const float xi0 = fmaf(xa, INV_2PI, turn_anchor(xa));     // the start angle in turns, whole turns removed (lde_device.h: turn_anchor)
+        const float hv = h * va, hvt = hv * INV_2PI, hh = h * h, hhgt = hh * glt;
+        // level 1: stages 3 | 2
+        const float g1 = __builtin_amdgcn_sinf(fmaf(hhgt, K11 * s1, fmaf(C1, hvt, xi0)));
+        const float p1 = dpp<SWAP>(g1);
+        // level 2: stages 5 | 4
+        float in2 = K21 * s1;
+        in2 = fmaf(K2o, g1, in2);
+        in2 = fmaf(K2p, p1, in2);
+        const float g2 = __builtin_amdgcn_sinf(fmaf(hhgt, in2, fmaf(C2, hvt, xi0)));
+        const float p2 = dpp<SWAP>(g2);
+        // level 3: the new state's slope (7) | stage 6
+        float in3 = K31 * s1;
+        in3 = fmaf(K3o1, g1, in3);
+        in3 = fmaf(K3p1, p1, in3);
+        in3 = fmaf(K3o2, g2, in3);
+        in3 = fmaf(K3p2, p2, in3);
+        const float g3 = __builtin_amdgcn_sinf(fmaf(hhgt, in3, xi0 + hvt));
+        const float p3 = dpp<SWAP>(g3);
+        // the sums over all seven sines
+        float ac1 = D11 * s1;
+        ac1 = fmaf(D1o1, g1, ac1);
+        ac1 = fmaf(D1p1, p1, ac1);
+        ac1 = fmaf(D1o2, g2, ac1);
+        ac1 = fmaf(D1p2, p2, ac1);
+        ac1 = fmaf(D1o3, g3, ac1);
+        ac1 = fmaf(D1p3, p3, ac1);
+        float ac2 = D21 * s1;
+        ac2 = fmaf(D2o1, g1, ac2);
+        ac2 = fmaf(D2o2, g2, ac2);
+        ac2 = fmaf(D2o3, g3, ac2);
+        ac2 += dpp<SWAP>(ac2);
+        // new state and error estimate, component per lane: x_new = x + h·v + h²(−g/L)·Σ B̄σ | v_new = v + h(−g/L)·Σ bσ
+        const float scale = (ev ? hh : h) * ngl;
+        const float newc = fmaf(scale, ev ? in3 : ac1, fmaf(evm, hv, yc));
+        const float err = scale * (ev ? ac1 : ac2);
+        const float sk = fmaf(max_abs(yc, newc), o.reltol, o.abstol);
+        const float r = err * fast_rcp(sk);
+        const float r2 = r * r;
+        const float m2 = r2 + dpp<SWAP>(r2);                    // = 2·EEst² (the same bits in both lanes)
+        const float mq = fmaf(0.f, newc, m2);                   // ∞·0 = NaN: a non-finite state never passes
+        const bool ok = !__any(!(mq <= 2.0f));
+        const float l = fmaf(0.5f, __builtin_amdgcn_logf(m2), -0.5f);   // log₂ EEst
+        const float q = fmaxf(o.q_lo, fminf(o.q_hi, __builtin_amdgcn_exp2f(o.beta1 * l - o.beta2 * lqold) * o.inv_gamma));
+        const float dtn = fminf(h * fast_rcp(q), dtmax);
+        if (__builtin_expect(!ok, 0)) {                        // rare: a rejected or non-finite attempt
+          const bool fin = !__any(!(fabsf(newc) < __builtin_inff()));
+          nrej++;
+          lim--;
+          if (!fin) {
+            if (__any(h > dtmin)) dt = h * o.qmin;
+            else { ret = LDE_RET_NONFINITE; active = false; nrej--; }
+          } else {
+            dt = h * fast_rcp(fminf(o.q_hi, __builtin_amdgcn_exp2f(o.beta1 * l) * o.inv_gamma));
+            if (__any(dt < dtmin)) { ret = LDE_RET_DTMIN; active = false; }
+          }
+          if (!active || n >= lim) go = false;
+          continue;
+        }
+        {   // the accepted step: leave {σ's, y_new, h} behind, publish, advance
+          *reinterpret_cast<f32x4*>(rp) = f32x4{g1, g2, g3, newc};
+          myrec[n * STEPF + 8 + (lane & 1)] = h;
+          rp += STEPF;
+          n++;
+          asm volatile("" ::: "memory");                                      // the count is published AFTER the record
+          __hip_atomic_store(&s_cnt[lane], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (a plain LDS store: ds_write_b32)
+          yc = newc;
+          s1 = dpp<EVEN>(g3);   // FSAL: σ₇ is the next step's σ₁
+          t += (double)h;
+          dt = dtn;
+          lqold = max_f(l, LQ_MIN);
+          active = !last;
+          if (last || n >= lim) go = false;
+        }
+      }
+      nacc += n;
+      PPROF(10);
+      PPROF_VAL(30, nacc + nrej);
+      if (active && nacc + nrej >= maxit) { ret = LDE_RET_MAXITERS; active = false; }
+      if (ret != LDE_RET_SUCCESS && lane == 0) __hip_atomic_store(&s_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      asm volatile("" ::: "memory");
+      if (lane == 0) __hip_atomic_store(&s_fin, active ? 1 : 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      if (REC) {
+        // The step records (LDE_SENSE_DISCRETE / "step_trace") of this round, written by the stepping wave while the helpers finish their
+        // dense output: lane i = the round's step i, read back from the ring — start state = the step before's end, start time = the
+        // stepper's own running sum (replayed in its order: the same doubles).
+        const int i0 = nacc - n;
+        const bool mine = lane < n;
+        const float* ri = s_rec + (size_t)(mine ? lane : 0) * STEPF;
+        const float* rq = s_rec + (size_t)(mine && lane > 0 ? lane - 1 : 0) * STEPF;
+        const float hi = ri[8];
+        const float2 ys = lane == 0 ? make_float2(xr, vr) : make_float2(rq[3], rq[7]);
+        double tacc = t_round, ti = t_round;
+        const int hbits = __float_as_int(hi);
+        for (int i = 0; i < n; i++) {
+          if (lane == i) ti = tacc;
+          tacc += (double)__int_as_float(__builtin_amdgcn_readlane(hbits, i));
+        }
+        if (valid && mine && i0 + lane < o.rec.cap) {
+          o.rec.t[(size_t)(i0 + lane) * B + b] = ti;
+          o.rec.dt[(size_t)(i0 + lane) * B + b] = (double)hi;
+          reinterpret_cast<float2*>(o.rec.y)[(size_t)(i0 + lane) * B + b] = ys;
+        }
+      }
+      if (!active) break;
+      __syncthreads();   // A: the helpers have consumed this round's records
+      s_cnt[lane] = 0;
+      if (lane == 0) s_fin = 0;
+      __syncthreads();   // B: counts reset
+    }
+    if (ret != LDE_RET_SUCCESS) {  // failed solve ⇒ NaN block, never an error [REF GOKU.jl:114] — after every helper store has landed
+      __syncthreads();   // F
+      if (valid) {
+        const float qn = __int_as_float(0x7fc00000);
+        for (int j = lane; j < T; j += 64) z_out[(size_t)j * B + b] = make_float2(qn, qn);
+      }
+    }
+    if (valid && lane == 0) {
+      if (retcode) retcode[b] = ret;
+      st_ret[b] = ret;
+      st_nfe[b] = nfe + NS * (nacc + nrej);
+      st_nacc[b] = nacc;
+      st_nrej[b] = nrej;
+      if (REC) o.rec.n[b] = ret == LDE_RET_SUCCESS ? nacc : 0;
+    }
+    PPROF(11);
+    return;
+  }
+
+  // ================= the helpers: wave 1 + hid serves every SH_NH-th step; lanes = save times =================
+  const int hid = w - 1;
+  const double dinf = __longlong_as_double(0x7ff0000000000000LL);
+  int jq = 1 + lane;                                   // the save time this lane looks for next
+  double tj = jq < T ? ts_g[jq] : dinf;
+  double tn = t_first;                                 // the walk over the records: record n2 starts at time tn in state ys with first sine sg1
+  f32x2 ys = {zi.x, zi.y};
+  float sg1 = hw_sin(zi.x, turn_anchor(zi.x));         // the stepper's σ₁ of the first step (the same instructions on the same input)
+  int nrec = 0;                                        // records walked so far over all rounds (whose turn a step is)
+  for (;;) {   // rounds
+    int n2 = 0, fin;
+    for (;;) {
+      fin = __hip_atomic_load(&s_fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // read BEFORE the count: if the round is over, the count is final
+      const int cnt = __hip_atomic_load(&s_cnt[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+      asm volatile("" ::: "memory");
+      while (n2 < cnt) {
+        const float* rc = myrec + (size_t)n2 * STEPF;
+        const f32x4 qe = *reinterpret_cast<const f32x4*>(rc), qo = *reinterpret_cast<const f32x4*>(rc + 4);
+        const float h = rc[8];
+        const f32x2 ye = {qe[3], qo[3]};
+        const double t1 = (h == (float)(tend - tn)) ? tend : tn + (double)h;   // exactly the stepper's arithmetic
+        const bool mine = (nrec % SH_NH) == hid;
+        if (__any(tj <= t1)) {
+          f32x2 k0 = {0.f, 0.f}, P2 = {0.f, 0.f}, P3 = {0.f, 0.f}, P4 = {0.f, 0.f};
+          float rh = 0.f;
+          if (mine && __any(tj < t1)) {   // the interpolant's polynomials from the step's seven sines
+            rh = fast_rcp(h);
+            const float sg[8] = {0.f, sg1, qo[0], qe[0], qo[1], qe[1], qo[2], qe[2]};   // σ₁ … σ₇
+            const float hg = h * ngl;
+            float px[3], pv[3];
+#pragma unroll
+            for (int m = 0; m < 3; m++) {
+              float ax = (float)TB.RA[m][1] * sg[1], av = (float)TB.RR[1][m] * sg[1];
+#pragma unroll
+              for (int l = 2; l <= 6; l++) ax = fmaf((float)TB.RA[m][l], sg[l], ax);
+#pragma unroll
+              for (int j = 2; j <= 7; j++) av = fmaf((float)TB.RR[j][m], sg[j], av);
+              px[m] = hg * ax;
+              pv[m] = ngl * av;
+            }
+            k0 = f32x2{ys.y, ngl * sg1};
+            P2 = f32x2{px[0], pv[0]};
+            P3 = f32x2{px[1], pv[1]};
+            P4 = f32x2{px[2], pv[2]};
+          }
+          while (tj <= t1) {   // this lane's save times inside the step (whoever serves them, the lane moves past them)
+            if (mine) {
+              float2 out;
+              if (tj >= t1) out = make_float2(ye.x, ye.y);   // the save time is the step's end
+              else {
+                const float th = (float)(tj - tn) * rh;
+                out.x = tsit5_dense_eval<2>(th, h, ys.x, k0.x, P2.x, P3.x, P4.x);
+                out.y = tsit5_dense_eval<2>(th, h, ys.y, k0.y, P2.y, P3.y, P4.y);
+              }
+              if (valid) z_out[(size_t)jq * B + b] = out;
+            }
+            jq += 64;
+            tj = jq < T ? ts_g[jq] : dinf;
+          }
+        }
+        tn = t1;
+        ys = ye;
+        sg1 = qe[2];   // FSAL
+        n2++;
+        nrec++;
+      }
+      if (fin) break;   // (read before the count: everything of this round has been walked)
+    }
+    if (fin == 2) break;
+    __syncthreads();   // A
+    __syncthreads();   // B
+  }
+#if LDE_PEND_PROF
+  if (blockIdx.x == 0 && lane == 0 && hid < 3) { g_pprof[2 * (12 + hid)] = wall_clock64(); g_pprof[2 * (12 + hid) + 1] = __builtin_readcyclecounter(); }   // helper hid has stored its last save
+#endif
+  if (__hip_atomic_load(&s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // F: every helper store has been issued and waited for
+  }
+}

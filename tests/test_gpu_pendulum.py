@@ -336,7 +336,7 @@ def _variant_run(options):
 _SINGLE = {}
 
 
-@pytest.mark.parametrize("variant", ["ws", "tl", "lb", "lb8", "lb32", "sh"])
+@pytest.mark.parametrize("variant", ["ws", "tl", "lb", "lb8", "lb32", "sh", "lp"])
 def test_small_batch_forward_kernels_match_the_single_wave_kernel(variant):
     """Five forward kernels share the step code and the dense-output formulas: k_pend_forward_sh (B ≤ 256: one trajectory per
     workgroup, a stepping wave + three dense-output waves; option "pend_sh_max_b" forces it for every batch here — the 200-point tight case
@@ -358,7 +358,10 @@ def test_small_batch_forward_kernels_match_the_single_wave_kernel(variant):
                       # lane would sit out every iteration and the solve would never end), and 32 rows with the default hold
                       "lb8": dict(pend_tl_max_b=0, pend_sh_max_b=0, pend_ws=0, pend_lb_min_b=0, pend_lb=8, pend_lb_hold=8),
                       "lb32": dict(pend_tl_max_b=0, pend_sh_max_b=0, pend_ws=0, pend_lb_min_b=0, pend_lb=32),
-                      "sh": dict(pend_sh_max_b=1000000)}[variant])
+                      "sh": dict(pend_sh_max_b=1000000, pend_lp=0),
+                      # k_pend_forward_lp (round 6; frictionless Tsit5 adaptive solves — the other cases of this variant run k_pend_forward_sh):
+                      # the stepping wave in lane pairs on the Nyström form of the step, the helpers interpolating from the stage sines
+                      "lp": dict(pend_sh_max_b=1000000)}[variant])
     # different compilations of the same step code: multiply-adds contract differently, so the adaptive step sequences part at
     # round-off level — the kernels agree like two correct f32 solves do (tests above: ≤ 3e-4 at the default tolerance,
     # ≤ 2e-5 at 1e-6), exactly where there is no controller (fixed-step RK4 ≤ 2e-6)
@@ -366,12 +369,15 @@ def test_small_batch_forward_kernels_match_the_single_wave_kernel(variant):
     for name, lim in tol.items():
         za, zb, ra, rb = a[name + "_z"], b[name + "_z"], a[name + "_ret"], b[name + "_ret"]
         flips = ra != rb
-        assert flips.sum() <= (3 if name == "fail" else 0), name     # a trajectory sitting exactly at maxiters may flip
+        # a trajectory sitting exactly at maxiters may flip (another order of operations — k_pend_forward_lp — moves a few more: ≤ 3 %)
+        assert flips.sum() <= ((8 if variant == "lp" else 3) if name == "fail" else 0), (name, int(flips.sum()))
         ok = ~flips
         assert np.array_equal(np.isnan(za[:, ok]), np.isnan(zb[:, ok])), name
         assert np.nanmax(np.abs(za[:, ok] - zb[:, ok]), initial=0.0) <= lim, name
         sa, sb = a[name + "_st"], b[name + "_st"]
-        assert np.all(np.abs(sa - sb) <= 0.02 * sb[1] + 3), (name, sa, sb)     # nfe, naccept, nreject, nfailed: within 2 % of the steps
+        # nfe, naccept, nreject, nfailed: within 2 % of the steps (k_pend_forward_lp's controller — 1/q from one exp2, no reciprocal — takes ≈ 3 %
+        # fewer steps at 1e-8 for the same accuracy: abl/lp_accuracy.py; 5 % there)
+        assert np.all(np.abs(sa - sb) <= (0.05 if variant == "lp" else 0.02) * sb[1] + 3), (name, sa, sb)
 
 
 @pytest.mark.parametrize("sense", [O.SENSE_PARALLEL_CHECKPOINTED, O.SENSE_BACKSOLVE_CHECKPOINTED])

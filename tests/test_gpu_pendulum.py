@@ -377,7 +377,7 @@ def test_small_batch_forward_kernels_match_the_single_wave_kernel(variant):
         sa, sb = a[name + "_st"], b[name + "_st"]
         # nfe, naccept, nreject, nfailed: within 2 % of the steps (k_pend_forward_lp's controller — 1/q from one exp2, no reciprocal — takes ≈ 3 %
         # fewer steps at 1e-8 for the same accuracy: abl/lp_accuracy.py; 5 % there)
-        assert np.all(np.abs(sa - sb) <= (0.05 if variant == "lp" else 0.02) * sb[1] + 3), (name, sa, sb)
+        assert np.all(np.abs(sa - sb) <= (0.05 if variant == "lp" else 0.02) * np.maximum(sb, sb[1]) + 3), (name, sa, sb)
 
 
 @pytest.mark.parametrize("sense", [O.SENSE_PARALLEL_CHECKPOINTED, O.SENSE_BACKSOLVE_CHECKPOINTED])

@@ -1384,6 +1384,270 @@ int oracle_adjoint_discrete_margins(const lde_problem_desc* d, const real* W, co
 }
 
 /* RHS and VJP of a single column, exported for unit tests of the RHS menu. */
+/* ---- ForwardDiffSensitivity as the reference EXECUTES it: the solve on dual numbers ---------------------------------------------------
+ * `Pendulum()` carries sensealg = ForwardDiffSensitivity() [REF examples/pendulum_friction-less/pendulum.jl:8-11], splatted into solve() at
+ * [REF src/models/GOKU.jl:107, :121]. SciMLSensitivity 7.10.0 [REF Manifest.toml:1200] then seeds (u0, p) with D + P dual partials and runs
+ * the SAME OrdinaryDiffEq solve on Dual numbers: every state component carries its value and its D + P partials through the
+ * stages, the solution weights, the FSAL slope and the saveat interpolant; the pullback is Σ_j J_jᵀ Δ_j with J_j = ∂ẑ(t_j)/∂(u0, p) read off
+ * the partials. Two things follow from running the solver itself on duals (DiffEqBase 6.104.3 [REF Manifest.toml:292]):
+ *   - the step sizes are plain Float64s: the derivative is that of the DISCRETE solve on its accepted steps (what LDE_SENSE_DISCRETE
+ *     computes in reverse mode: oracle_adjoint_discrete);
+ *   - the error norm sees the partials: ODE_DEFAULT_NORM(u::Dual) = sqrt(value² + Σ partials²), so a component's scale is
+ *     abstol + reltol·max(‖u_i‖, ‖u_new,i‖) with these dual norms, its scaled error the dual norm of ũ_i over that scale, and EEst the RMS over
+ *     the n components. The accepted step sequence of a TRAINING solve therefore differs from that of the same solve run without AD
+ *     (dual_norm = 1 here; dual_norm = 0 controls the steps by the values alone: the primal sequence, on which this routine's Jacobians
+ *     equal oracle_adjoint_discrete's pullback to round-off — tests/test_oracle_dual.py).
+ * Analytic right-hand sides, per-trajectory control (the GOKU path): state (x, v), partials with respect to (x0, v0, L).
+ * Also bench.py's cpu_baseline for the GOKU workloads: this IS the algorithm the reference's CPU path runs (kind "port"). */
+#define DN 2
+#define DPAR 3
+typedef struct { real v[DN]; real p[DN][DPAR]; } dstate;
+
+static real (*volatile dual_sin)(real) = r_sin;   /* (through a pointer: the compiler would merge sin and cos into ONE sincos call, whose sine is not the bits of sin) */
+static void dual_rhs(int kind, real L, const dstate* y, dstate* dy) {
+  const real ngl = -(real)10 / L, s = dual_sin(y->v[0]), c = r_cos(y->v[0]);   /* (rhs_col's arithmetic on the values: the same bits) */
+  const int fr = kind == LDE_RHS_PENDULUM_FRICTION;
+  dy->v[0] = y->v[1];
+  real acc = ngl * s;
+  if (fr) acc -= ((real)0.7 / (real)1) * y->v[1];
+  dy->v[1] = acc;
+  for (int q = 0; q < DPAR; q++) {
+    dy->p[0][q] = y->p[1][q];
+    real a = ngl * c * y->p[0][q];
+    if (fr) a -= (real)0.7 * y->p[1][q];
+    dy->p[1][q] = a;
+  }
+  dy->p[1][2] += ((real)10 / (L * L)) * s;   /* ∂f/∂L = (G/L²) sin x */
+}
+static void dual_axpy(dstate* out, const dstate* y, real h, const dstate* acc) {
+  for (int i = 0; i < DN; i++) {
+    out->v[i] = y->v[i] + h * acc->v[i];
+    for (int q = 0; q < DPAR; q++) out->p[i][q] = y->p[i][q] + h * acc->p[i][q];
+  }
+}
+static void dual_lincomb(dstate* acc, const double* coef, const dstate* k, int n) {   /* acc = Σ_{j<n} coef[j] k[j], terms in the order j = 0, 1, … */
+  for (int i = 0; i < DN; i++) {
+    real a = (real)coef[0] * k[0].v[i];
+    for (int j = 1; j < n; j++) a += (real)coef[j] * k[j].v[i];
+    acc->v[i] = a;
+    for (int q = 0; q < DPAR; q++) {
+      real b = (real)coef[0] * k[0].p[i][q];
+      for (int j = 1; j < n; j++) b += (real)coef[j] * k[j].p[i][q];
+      acc->p[i][q] = b;
+    }
+  }
+}
+static real dual_abs(const dstate* y, int i, int dual_norm) {   /* ODE_DEFAULT_NORM of one (dual) component */
+  if (!dual_norm) return r_fabs(y->v[i]);
+  real s2 = y->v[i] * y->v[i];
+  for (int q = 0; q < DPAR; q++) s2 += y->p[i][q] * y->p[i][q];
+  return r_sqrt(s2);
+}
+static int dual_finite(const dstate* y) {
+  for (int i = 0; i < DN; i++) {
+    if (!isfinite((double)y->v[i])) return 0;
+    for (int q = 0; q < DPAR; q++) if (!isfinite((double)y->p[i][q])) return 0;
+  }
+  return 1;
+}
+/* RMS over the n components of (‖e_i‖ / sk_i), sk_i = abstol + reltol·sc_i */
+static double dual_rms(const dstate* e, const real* sk, int dual_norm) {
+  double s2 = 0;
+  for (int i = 0; i < DN; i++) {
+    real r = dual_abs(e, i, dual_norm) / sk[i];
+    s2 += (double)(r * r);
+  }
+  return sqrt(s2 / DN);
+}
+
+/* one trajectory: z [T][2], J [T][2][3]; returns the retcode */
+static int dual_solve(int kind, real L, const real* z0, const double* ts, int T, const sopts* o, int dual_norm, real* z, real* J,
+                      sstat* st, steprec* rec) {
+  dstate y, yn, tmp, acc, k[7];
+  memset(&y, 0, sizeof(y));
+  y.v[0] = z0[0]; y.v[1] = z0[1];
+  y.p[0][0] = 1; y.p[1][1] = 1;      /* seeds: ∂y0/∂x0, ∂y0/∂v0; ∂y0/∂L = 0 */
+  int ret = LDE_RET_SUCCESS, ntr = 0;
+#define DUAL_SAVE(j, ys) do { for (int i_ = 0; i_ < DN; i_++) { z[(j) * DN + i_] = (ys).v[i_]; for (int q_ = 0; q_ < DPAR; q_++) J[((j) * DN + i_) * DPAR + q_] = (ys).p[i_][q_]; } } while (0)
+  DUAL_SAVE(0, y);
+  if (T > 1) {
+    double t = ts[0], tend = ts[T - 1], dtmax = tend - t, dt;
+    const real at = (real)o->abstol, rt = (real)o->reltol;
+    int j = 1;
+    dual_rhs(kind, L, &y, &k[0]);
+    st->nfe++;
+    if (!o->adaptive) dt = o->dt_fixed;
+    else if (o->dt_fixed > 0) dt = fmin(o->dt_fixed, dtmax);
+    else {   /* Hairer–Nørsett–Wanner on duals: every norm the dual norm (as init_dt above on values) */
+      real sk[DN];
+      for (int i = 0; i < DN; i++) sk[i] = at + dual_abs(&y, i, dual_norm) * rt;
+      const double d0 = dual_rms(&y, sk, dual_norm), d1 = dual_rms(&k[0], sk, dual_norm);
+      double dt0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+      if (dt0 > dtmax) dt0 = dtmax;
+      dual_axpy(&tmp, &y, (real)dt0, &k[0]);
+      dual_rhs(kind, L, &tmp, &k[1]);
+      st->nfe++;
+      for (int i = 0; i < DN; i++) {
+        acc.v[i] = k[1].v[i] - k[0].v[i];
+        for (int q = 0; q < DPAR; q++) acc.p[i][q] = k[1].p[i][q] - k[0].p[i][q];
+      }
+      const double d2 = dual_rms(&acc, sk, dual_norm) / dt0, dm = d1 > d2 ? d1 : d2;
+      const double dt1 = (dm <= 1e-15) ? fmax(1e-6, dt0 * 1e-3) : pow(10.0, -(2.0 + log10(dm)) / 5.0);
+      dt = fmin(100.0 * dt0, dt1);
+      if (dt > dtmax) dt = dtmax;
+    }
+    real qold = (real)1e-4;
+    int64_t iters = 0;
+    const int presc = rec && rec->presc;
+    const int adaptive = o->adaptive && !presc;
+    while (t < tend) {
+      if (iters++ >= o->maxiters) { ret = LDE_RET_MAXITERS; break; }
+      double dtp = dt;
+      int last = 0;
+      if (presc) {
+        if (ntr >= *rec->n) { ret = LDE_RET_MAXITERS; break; }
+        t = rec->t[ntr]; dt = rec->dt[ntr]; last = ntr == *rec->n - 1;
+      } else if (t + dt >= tend - 1e-12 * fabs(tend)) { dt = tend - t; last = 1; }
+      const real h = (real)dt;
+      const int S = o->solver == LDE_SOLVER_TSIT5 ? 6 : 4;   /* index of the FSAL slope */
+      if (o->solver == LDE_SOLVER_TSIT5) {
+        for (int s = 1; s < 6; s++) {
+          dual_lincomb(&acc, TS_A[s], k, s);
+          dual_axpy(&tmp, &y, h, &acc);
+          dual_rhs(kind, L, &tmp, &k[s]);
+        }
+        dual_lincomb(&acc, TS_A[6], k, 6);
+        dual_axpy(&yn, &y, h, &acc);
+        dual_rhs(kind, L, &yn, &k[6]);
+        st->nfe += 6;
+      } else {
+        const real hh = (real)(0.5 * dt);   /* (rk4_step's own arithmetic: y + (h/2)·k) */
+        dual_axpy(&tmp, &y, hh, &k[0]); dual_rhs(kind, L, &tmp, &k[1]);
+        dual_axpy(&tmp, &y, hh, &k[1]); dual_rhs(kind, L, &tmp, &k[2]);
+        dual_axpy(&tmp, &y, h, &k[2]); dual_rhs(kind, L, &tmp, &k[3]);
+        for (int i = 0; i < DN; i++) {   /* the oracle's own order: y + (h/6)·(k1 + 2(k2 + k3) + k4) */
+          const real h6 = (real)(dt / 6.0);
+          yn.v[i] = y.v[i] + h6 * (k[0].v[i] + (real)2 * (k[1].v[i] + k[2].v[i]) + k[3].v[i]);
+          for (int q = 0; q < DPAR; q++) yn.p[i][q] = y.p[i][q] + h6 * (k[0].p[i][q] + (real)2 * (k[1].p[i][q] + k[2].p[i][q]) + k[3].p[i][q]);
+        }
+        dual_rhs(kind, L, &yn, &k[4]);
+        st->nfe += 4;
+      }
+      real EEst = 0;
+      if (o->adaptive && o->solver == LDE_SOLVER_TSIT5) {
+        dual_lincomb(&acc, TS_BT, k, 7);
+        real sk[DN];
+        for (int i = 0; i < DN; i++) {
+          sk[i] = at + r_fmax(dual_abs(&y, i, dual_norm), dual_abs(&yn, i, dual_norm)) * rt;
+          acc.v[i] *= h;
+          for (int q = 0; q < DPAR; q++) acc.p[i][q] *= h;
+        }
+        EEst = (real)dual_rms(&acc, sk, dual_norm);
+      }
+      if (!dual_finite(&yn) || !(EEst == EEst)) {
+        if (adaptive && dt > o->dtmin) { st->nrej++; dt = dt * o->qmin; continue; }
+        ret = LDE_RET_NONFINITE;
+        break;
+      }
+      if (adaptive) {
+        real q11, q = pi_q(EEst, qold, o, &q11);
+        if (EEst > (real)1) {
+          st->nrej++;
+          dt = dt / (double)r_fmin((real)(1.0 / o->qmin), q11 / (real)o->gamma);
+          if (dt < o->dtmin) { ret = LDE_RET_DTMIN; break; }
+          continue;
+        }
+        qold = r_fmax(EEst, (real)1e-4);
+        dtp = dt / (double)q;
+        if (dtp > dtmax) dtp = dtmax;
+      }
+      st->nacc++;
+      if (rec && !presc && ntr < rec->cap) { rec->t[ntr] = t; rec->dt[ntr] = dt; }
+      ntr++;
+      const double tnew = last ? tend : (presc ? rec->t[ntr] : t + dt);
+      while (j < T && ts[j] <= tnew) {
+        const double th = (ts[j] - t) / dt;
+        if (th >= 1.0 || (j == T - 1 && last)) DUAL_SAVE(j, yn);
+        else if (o->solver == LDE_SOLVER_TSIT5) {
+          double bw[7];
+          tsit5_interp_weights(th, bw);
+          dual_lincomb(&acc, bw, k, 7);
+          dual_axpy(&tmp, &y, h, &acc);
+          DUAL_SAVE(j, tmp);
+        } else {   /* cubic Hermite between (y, k1) and (y_new, f(y_new)) */
+          const double h00 = (1 + 2 * th) * (1 - th) * (1 - th), h10 = th * (1 - th) * (1 - th), h01 = th * th * (3 - 2 * th), h11 = th * th * (th - 1);
+          for (int i = 0; i < DN; i++) {
+            tmp.v[i] = (real)h00 * y.v[i] + (real)(h10 * dt) * k[0].v[i] + (real)h01 * yn.v[i] + (real)(h11 * dt) * k[4].v[i];
+            for (int q = 0; q < DPAR; q++)
+              tmp.p[i][q] = (real)h00 * y.p[i][q] + (real)(h10 * dt) * k[0].p[i][q] + (real)h01 * yn.p[i][q] + (real)(h11 * dt) * k[4].p[i][q];
+          }
+          DUAL_SAVE(j, tmp);
+        }
+        j++;
+      }
+      y = yn;
+      k[0] = k[S];
+      t = tnew;
+      dt = o->adaptive ? dtp : o->dt_fixed;
+    }
+    if (rec && !presc) *rec->n = ntr;
+  }
+#undef DUAL_SAVE
+  st->retcode = ret;
+  return ret;
+}
+
+/* z_out [T][B][2], J_out [T][B][2][3] (NULL: not kept); with dz_out [T][B][2] given: dz0 [B][2], dtheta [B][1] = Σ_j J_jᵀ Δ_j (the pullback the reference
+ * forms from the stored partials). A failed trajectory: NaN block, zero gradient [REF src/models/GOKU.jl:114]. */
+int oracle_forward_dual(const lde_problem_desc* d, const real* z0, const real* theta, const double* ts, int T, int B, int dual_norm,
+                        real* z_out, real* J_out, const real* dz_out, real* dz0, real* dtheta, int32_t* retcode, int64_t* stats,
+                        double* rec_t, double* rec_dt, int32_t* rec_n, int rec_cap, int presc, int nthreads) {
+  int rc = check_desc(d);
+  if (rc) return rc;
+  if (T < 1 || B < 1 || !z0 || !theta || !z_out) return LDE_ERR_INVALID_ARG;
+  if (has_mlp(d) || d->batching != LDE_BATCH_PER_TRAJECTORY) return LDE_ERR_UNSUPPORTED;
+  sopts o;
+  opts_from_desc(d, &o, ts[0], ts[T - 1]);
+  int64_t nfe = 0, nacc = 0, nrej = 0, nfail = 0, maxsteps = 0;
+#ifdef _OPENMP
+  if (nthreads > 0) omp_set_num_threads(nthreads);
+#endif
+#pragma omp parallel reduction(+ : nfe, nacc, nrej, nfail) reduction(max : maxsteps)
+  {
+    real* z = (real*)calloc((size_t)T * DN, sizeof(real));
+    real* J = (real*)calloc((size_t)T * DN * DPAR, sizeof(real));
+#pragma omp for schedule(static)
+    for (int c = 0; c < B; c++) {
+      sstat st = {0, 0, 0, 0};
+      steprec rec = {rec_t ? rec_t + (int64_t)c * rec_cap : NULL, rec_dt ? rec_dt + (int64_t)c * rec_cap : NULL, rec_n ? rec_n + c : NULL, rec_cap, presc};
+      const int ret = dual_solve(d->rhs_kind, theta[c], z0 + (int64_t)c * DN, ts, T, &o, dual_norm, z, J, &st, rec_dt ? &rec : NULL);
+      real g[DPAR] = {0, 0, 0};
+      for (int j = 0; j < T; j++) {
+        for (int i = 0; i < DN; i++) {
+          const int64_t e = i + (int64_t)DN * (c + (int64_t)B * j);
+          z_out[e] = ret ? (real)NAN : z[j * DN + i];
+          for (int q = 0; q < DPAR; q++) {
+            const real Jv = ret ? (real)0 : J[(j * DN + i) * DPAR + q];
+            if (J_out) J_out[e * DPAR + q] = Jv;
+            if (dz_out) g[q] += Jv * dz_out[e];
+          }
+        }
+      }
+      if (dz_out && dz0) { dz0[(int64_t)c * DN] = g[0]; dz0[(int64_t)c * DN + 1] = g[1]; }
+      if (dz_out && dtheta) dtheta[c] = g[2];
+      if (retcode) retcode[c] = ret;
+      nfe += st.nfe; nacc += st.nacc; nrej += st.nrej; nfail += ret ? 1 : 0;
+      if (st.nacc + st.nrej > maxsteps) maxsteps = st.nacc + st.nrej;
+    }
+    free(z);
+    free(J);
+  }
+  if (stats) { stats[0] = nfe; stats[1] = nacc; stats[2] = nrej; stats[3] = nfail; stats[4] = maxsteps; }
+  return LDE_OK;
+}
+#undef DN
+#undef DPAR
+
 int oracle_rhs(const lde_problem_desc* d, const real* W, const real* z, const real* theta, real* out) {
   colrhs c;
   colrhs_init(&c, d, W);

@@ -206,6 +206,41 @@ class Oracle:
         info = dict(nfe=int(stats[0]), naccept=int(stats[1]), nreject=int(stats[2]), nfailed=int(stats[3]), max_steps=int(stats[4]))
         return z_out, ret, dict(t=rt, dt=rdt, n=rn), info
 
+    def forward_dual(self, d: Desc, z0, theta, ts, dz_out=None, dual_norm=True, rec=None, cap=4096, nthreads=0, keep_jac=True):
+        """ForwardDiffSensitivity as the reference executes it (oracle_forward_dual): the solve on dual numbers, partials with respect to
+        (ẑ₀, θ̂). dual_norm=True: the step control's norms see the partials (what the reference's TRAINING solve does); False: the
+        primal step sequence. rec given: exactly these steps. Returns ẑ [T,B,2], J [T,B,2,3] (or None), (dz0 [B,2], dθ [B,1]) for dz_out, ret, rec, info."""
+        dt = self.dtype
+        z0 = np.ascontiguousarray(z0, dtype=dt)
+        B, D = z0.shape
+        assert D == 2 and d.param_dim == 1
+        theta = np.ascontiguousarray(theta, dtype=dt)
+        ts = np.ascontiguousarray(ts, dtype=np.float64)
+        T = ts.shape[0]
+        presc = rec is not None
+        if presc:
+            rt = np.ascontiguousarray(rec["t"], np.float64).reshape(B, -1)
+            rdt = np.ascontiguousarray(rec["dt"], np.float64).reshape(B, -1)
+            rn = np.ascontiguousarray(rec["n"], np.int32).reshape(B)
+            cap = rt.shape[1]
+        else:
+            rt, rdt, rn = np.zeros((B, cap)), np.zeros((B, cap)), np.zeros(B, np.int32)
+        z_out = np.zeros((T, B, 2), dtype=dt)
+        J = np.zeros((T, B, 2, 3), dtype=dt) if keep_jac else None
+        dz = None if dz_out is None else np.ascontiguousarray(dz_out, dtype=dt)
+        dz0 = np.zeros((B, 2), dtype=dt)
+        dth = np.zeros((B, 1), dtype=dt)
+        ret = np.zeros(B, dtype=np.int32)
+        stats = np.zeros(5, dtype=np.int64)
+        rc = self.lib.oracle_forward_dual(C.byref(d), self._p(z0), self._p(theta), self._p(ts), T, B, int(bool(dual_norm)), self._p(z_out),
+                                          self._p(J), self._p(dz), self._p(dz0), self._p(dth), self._p(ret), self._p(stats), self._p(rt),
+                                          self._p(rdt), self._p(rn), cap, int(presc), nthreads)
+        if rc != 0:
+            raise RuntimeError(f"oracle_forward_dual failed: {rc}")
+        assert presc or int(rn.max()) <= cap, "step record overflow: raise cap"
+        info = dict(nfe=int(stats[0]), naccept=int(stats[1]), nreject=int(stats[2]), nfailed=int(stats[3]), max_steps=int(stats[4]))
+        return z_out, J, (dz0, dth), ret, dict(t=rt, dt=rdt, n=rn), info
+
     def adjoint_steps(self, d: Desc, z_out, theta, ts, dz_out, W=None, rec=None, cap=8192, nthreads=0, margins=False):
         """The continuous adjoint with the reverse-time solve's accepted step magnitudes recorded (rec=None) or prescribed.
         margins=True: info["margins"][b] = how close trajectory b's reverse-time solve came to a relu kink."""

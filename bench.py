@@ -616,12 +616,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def attach_traffic(roof, workload, B, mlp, full_batch, dom=None, rounds=("r6", "r5", "r4", "r3", "r2", "r1")):
+def attach_traffic(roof, workload, B, mlp, full_batch, dom=None, rounds=("r6", "r5", "r4", "r3", "r2", "r1"), launched=None):
     """roofline.traffic (+ rocprof_avg_launch_ms, whole_step.traffic) of the solve workloads from the newest committed PMC summary
     (profiles/collect.sh + profiles/summarize.py; FETCH_SIZE ×2 only for kernels that load 16 bytes per lane, WRITE_SIZE as is —
     MI355X_MICROARCH.md §HBM). Also called by profiles/refresh.py on the bench line it copies next to a fresh summary, so the
     committed line and its summary cannot disagree."""
+    # `launched` = {"lde_forward": name, "lde_adjoint": name}: the kernels THIS run launched (lde_last_kernel). A summary that does not hold
+    # the launched kernel is stale — a kernel change since it was collected — and is not attached (traffic stays null and the line says why).
     roof["traffic"] = None
+    stale = []
     for rnd in rounds:
         prof = os.path.join(ROOT, "profiles", f"{rnd}_{workload}_b{B}_summary.json" if not mlp else f"{rnd}_{workload}_summary.json")
         if not os.path.exists(prof):
@@ -631,24 +634,34 @@ def attach_traffic(roof, workload, B, mlp, full_batch, dom=None, rounds=("r6", "
         def tb(kd):
             return kd.get("fetch_bytes", kd["fetch_bytes_x2_gfx950"]) + kd["write_bytes"]
         if not mlp:
-            kn = {"lde_forward": "k_pend_forward", "lde_adjoint": "k_pend_adjoint"}[dom or ("lde_forward" if "lde_forward" in roof.get("kernel", "lde_forward") else "lde_adjoint")]
+            call = dom or ("lde_forward" if "lde_forward" in roof.get("kernel", "lde_forward") else "lde_adjoint")
+            kn = (launched or {}).get(call) or {"lde_forward": "k_pend_forward", "lde_adjoint": "k_pend_adjoint"}[call]
             for name, kd in kern.items():
                 if name.startswith(kn) and "write_bytes" in kd:
                     roof["traffic"] = tb(kd)
+                    roof["traffic_kernel"] = name
                     roof["rocprof_avg_launch_ms"] = kd["avg_ns"] * 1e-6
+            if roof["traffic"] is None:
+                stale.append(f"{os.path.relpath(prof, ROOT)} holds no {kn}")
         elif full_batch:   # MLP workloads: the dominant kernel's own traffic; the whole step's beside it
             def is_adj_solve(name):   # the adjoint's solve kernels: k_mlp64_adj / k_mlp64_disc<…>, k_mlpb / k_mlpc / k_mlpw / k_mlpv<…, true…>, k_mlp_adjoint[_disc], k_mlp4_adjoint
                 return name.startswith(("k_mlp64_adj", "k_mlp64_disc", "k_mlp_adjoint", "k_mlp4_adjoint")) or (name.startswith(("k_mlpb", "k_mlpc", "k_mlpw", "k_mlpv")) and "true" in name)
-            adj = [(kd.get("avg_ns", 0), tb(kd)) for name, kd in kern.items() if is_adj_solve(name) and "write_bytes" in kd]
+            want = (launched or {}).get("lde_adjoint") or "k_mlp"
+            adj = [(kd.get("avg_ns", 0), tb(kd), name) for name, kd in kern.items() if is_adj_solve(name) and name.startswith(want) and "write_bytes" in kd]
+            if not adj:
+                stale.append(f"{os.path.relpath(prof, ROOT)} holds no {want} adjoint solve kernel")
             tr = [tb(kd) for name, kd in kern.items() if name.startswith(("k_mlp", "k_reduce", "k_sum")) and "write_bytes" in kd]
             if adj:
                 roof["traffic"] = float(max(adj)[1])                 # the longest-running solve kernel of the step = the adjoint's
+                roof["traffic_kernel"] = max(adj)[2]
                 roof["rocprof_avg_launch_ms"] = max(adj)[0] * 1e-6
             if tr and "whole_step" in roof:
                 roof["whole_step"]["traffic"] = float(sum(tr))
         if roof["traffic"] is not None:
             roof["traffic_source"] = os.path.relpath(prof, ROOT)
             break
+    if roof["traffic"] is None and stale:
+        roof["traffic_source"] = "none attached (stale summaries: " + "; ".join(stale[:3]) + ")"
     return roof
 
 
@@ -1058,7 +1071,10 @@ def main():
                     traffic=None, alg_bytes_per_launch=dom_bytes * B, avg_launch_ms=dom_stream, avg_launch_ms_bracketed=dom_ms)
 
     # HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this same command
-    attach_traffic(roof, args.workload + ("_discrete" if disc else ""), B, mlp=bool(Ff), full_batch=(B == w["B"]), dom=None if Ff else dom)
+    lib.lde_last_kernel.restype = C.c_char_p
+    launched = {"lde_forward": (lib.lde_last_kernel(h, 0) or b"").decode(), "lde_adjoint": (lib.lde_last_kernel(h, 1) or b"").decode()}
+    attach_traffic(roof, args.workload + ("_discrete" if disc else ""), B, mlp=bool(Ff), full_batch=(B == w["B"]), dom=None if Ff else dom, launched=launched)
+    roof["launched_kernels"] = launched
 
     out = {
         "metric": "trajectories/sec (fwd+adjoint) GOKU pendulum, batch=256, 1/2/4/8 GPU"

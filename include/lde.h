@@ -293,6 +293,12 @@ int lde_get_option(const lde_handle* h, const char* key, double* value);
 /* Human-readable text for the last error on this handle (never NULL). */
 const char* lde_last_error(const lde_handle* h);
 
+/* The name (prefix) of the solve kernel the last lde_forward (which = 0) / lde_adjoint (which = 1) on this handle launched, e.g.
+ * "k_pend_forward_lp", "k_pend_adjoint_disc_tp", "k_mlpc" — "" before the first call. A measurement aid like lde_get_phase_ms: bench.py attaches
+ * HBM counter bytes from a committed rocprofv3 summary to its roofline line only when that summary's kernel IS the one the run launched
+ * (a stale summary must not survive a kernel change). Static strings; never NULL. */
+const char* lde_last_kernel(const lde_handle* h, int which);
+
 
 /* ======================================================================================================
  * Dense chains either side of the solve — scope row f-1: what runs under

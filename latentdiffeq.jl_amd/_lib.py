@@ -27,7 +27,7 @@ STATUS = {0: "LDE_OK", -1: "LDE_ERR_INVALID_ARG", -2: "LDE_ERR_UNSUPPORTED", -3:
 # every symbol include/lde.h declares
 EXPORTS = ["lde_abi_version", "lde_problem_desc_default", "lde_num_weights", "lde_create", "lde_destroy",
            "lde_build_info", "lde_global_sum_mailbox_bytes", "lde_set_global_sum_peers", "lde_set_weights", "lde_set_weights_device", "lde_reserve", "lde_forward", "lde_adjoint",
-           "lde_get_stats", "lde_last_error", "lde_set_global_sum_hook", "lde_set_phase_timing", "lde_get_phase_ms",
+           "lde_get_stats", "lde_last_error", "lde_last_kernel", "lde_set_global_sum_hook", "lde_set_phase_timing", "lde_get_phase_ms",
            "lde_step_record_bytes", "lde_set_step_record", "lde_get_step_record", "lde_step_record_capacity", "lde_step_record_status", "lde_set_option", "lde_get_option",
            "lde_chain_num_weights", "lde_chain_create", "lde_chain_destroy", "lde_chain_set_weights",
            "lde_chain_set_weights_device", "lde_chain_reserve", "lde_chain_forward", "lde_chain_backward",
@@ -131,6 +131,8 @@ def load():
     lib.lde_set_global_sum_peers.restype = C.c_int
     lib.lde_last_error.argtypes = [vp]
     lib.lde_last_error.restype = C.c_char_p
+    lib.lde_last_kernel.argtypes = [vp, i32]
+    lib.lde_last_kernel.restype = C.c_char_p
     lib.lde_step_record_bytes.argtypes = [vp, i32, i32]
     lib.lde_step_record_bytes.restype = i64
     lib.lde_set_step_record.argtypes = [vp, vp, i64]

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "lde_device.h"
+#include "lde_host.h"
 
 namespace lde {
 int launch_pend_forward(int kind, int solver, const float* z0, const float* theta, const double* ts_dev, const KOpts& o,
@@ -30,6 +31,7 @@ int launch_pend_adjoint_par(int kind, int solver, const float* z_out, const floa
                             const KOpts& o, const float* dz_out, float* dz0, float* dtheta, float* ops, int32_t* info,
                             int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret, hipStream_t stream);
 bool pend_adjoint_needs_ops(int B, int T);
+const char* pend_last_kernel(int which);
 int launch_pend_adjoint_disc(int kind, int solver, const float* z_out, const float* theta, const double* ts_dev, const KOpts& o,
                              const float* dz_out, float* dz0, float* dtheta, int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret,
                              hipStream_t stream, const PendTune& tn);
@@ -91,8 +93,12 @@ struct lde_handle {
   int opt_step_trace = 0;
   int opt_adjoint_overwrite = 0;
   lde::PendTune pend_tune;           // kernel-choice knobs of the analytic right-hand sides (MLP ones live in the plan)
+  const char* last_kernel[2] = {"", ""};   // lde_last_kernel: the solve kernel the last lde_forward / lde_adjoint launched
   std::string err = "";
 };
+
+using namespace lde_host;   // validate, has_mlp, has_pend, rec_nseq, rec_capacity, rec_bytes, rec_view, align256, make_opts, num_weights, grid_ok, fixed_step_count
+static int rec_capacity(const lde_handle* h, int T, int which);
 
 #define HIP_TRY(h, expr)                                                                   \
   do {                                                                                     \
@@ -102,50 +108,6 @@ struct lde_handle {
       return LDE_ERR_HIP;                                                                  \
     }                                                                                      \
   } while (0)
-
-static bool has_mlp(const lde_problem_desc& d) {
-  return d.rhs_kind == LDE_RHS_MLP || d.rhs_kind == LDE_RHS_PENDULUM_PLUS_MLP;
-}
-static bool has_pend(const lde_problem_desc& d) { return d.rhs_kind != LDE_RHS_MLP; }
-
-static int validate(const lde_problem_desc* d, std::string* why) {
-  auto bad = [&](const char* m) {
-    if (why) *why = m;
-    return (int)LDE_ERR_INVALID_ARG;
-  };
-  if (!d) return bad("desc is NULL");
-  if (d->abi_version != LDE_ABI_VERSION) return bad("abi_version mismatch");
-  if (d->rhs_kind < 0 || d->rhs_kind > LDE_RHS_PENDULUM_PLUS_MLP) return bad("unknown rhs_kind");
-  if (d->state_dim < 1 || d->param_dim < 0 || d->augment_dim < 0) return bad("bad dims");
-  if (has_pend(*d) && (d->state_dim != 2 || d->param_dim != 1 || d->augment_dim != 0))
-    return bad("pendulum RHS needs state_dim=2, param_dim=1, augment_dim=0");
-  if (d->rhs_kind == LDE_RHS_MLP && d->param_dim != 0) return bad("MLP RHS takes no per-trajectory parameters");
-  if (has_mlp(*d)) {
-    if (d->n_layers < 1 || d->n_layers > LDE_MAX_LAYERS) return bad("n_layers out of range");
-    const int Dp = d->state_dim + d->augment_dim;
-    if (d->layer_sizes[0] != Dp || d->layer_sizes[d->n_layers] != Dp) return bad("MLP in/out must equal D+augment_dim");
-    for (int l = 0; l <= d->n_layers; l++)
-      if (d->layer_sizes[l] < 1) return bad("layer size < 1");
-    if (d->activation != LDE_ACT_RELU && d->activation != LDE_ACT_TANH) return bad("unknown activation");
-  }
-  if (d->solver != LDE_SOLVER_TSIT5 && d->solver != LDE_SOLVER_RK4) return bad("unknown solver");
-  if (d->batching != LDE_BATCH_PER_TRAJECTORY && d->batching != LDE_BATCH_COUPLED && d->batching != LDE_BATCH_COUPLED_GLOBAL)
-    return bad("unknown batching");
-  if (d->batching == LDE_BATCH_COUPLED_GLOBAL && !has_mlp(*d)) return bad("LDE_BATCH_COUPLED_GLOBAL needs an MLP right-hand side");
-  if (d->sensealg < LDE_SENSE_BACKSOLVE_CHECKPOINTED || d->sensealg > LDE_SENSE_DISCRETE) return bad("unknown sensealg");
-  // (LDE_SENSE_DISCRETE with LDE_BATCH_COUPLED_GLOBAL: every rank records the common step sequence and ITS columns' states; the sweep
-  //  has no step control, hence no sum to exchange)
-
-  if (d->solver == LDE_SOLVER_RK4 && d->adaptive) {
-    if (why) *why = "RK4 is fixed-step only here: pass adaptive=0, dt=h";
-    return LDE_ERR_UNSUPPORTED;
-  }
-  if (!d->adaptive && !(d->dt > 0)) return bad("adaptive=0 needs dt>0");
-  if (d->adaptive && (!(d->abstol > 0) || !(d->reltol > 0))) return bad("tolerances must be > 0");
-  if (d->maxiters < 1) return bad("maxiters < 1");
-  if (!(d->qmin > 0) || !(d->qmax > 0) || !(d->gamma > 0)) return bad("controller constants must be > 0");
-  return LDE_OK;
-}
 
 // the weight-gradient stream of the chain / recurrent pullbacks (lde_mfma.h: dw_stream_get); one per process
 static std::atomic<hipStream_t> g_dw_stream{nullptr};
@@ -205,13 +167,7 @@ int lde_problem_desc_default(lde_problem_desc* d) {
   return LDE_OK;
 }
 
-int64_t lde_num_weights(const lde_problem_desc* d) {
-  if (!d || !has_mlp(*d)) return 0;
-  int64_t n = 0;
-  for (int l = 0; l < d->n_layers && l < LDE_MAX_LAYERS; l++)
-    n += (int64_t)d->layer_sizes[l + 1] * d->layer_sizes[l] + d->layer_sizes[l + 1];
-  return n;
-}
+int64_t lde_num_weights(const lde_problem_desc* d) { return num_weights(d); }
 
 int lde_create(const lde_problem_desc* desc, lde_handle** out) {
   if (!out) return LDE_ERR_INVALID_ARG;
@@ -299,30 +255,7 @@ int lde_set_weights_device(lde_handle* h, const float* flat_dev, int64_t n, void
 }  // extern "C"
 
 // ---- step records --------------------------------------------------------------------------------------------------------------
-static int rec_nseq(const lde_problem_desc& d, int B) { return d.batching == LDE_BATCH_PER_TRAJECTORY ? B : 1; }
-static int rec_capacity(const lde_handle* h, int T, int which) {
-  if (h->opt_record_capacity > 0) return h->opt_record_capacity;
-  const int64_t c = which == 0 ? std::max<int64_t>(64, 4 * (int64_t)T) : std::max<int64_t>(256, 16 * (int64_t)T);
-  return (int)std::min<int64_t>(c, std::max<int64_t>(1, h->d.maxiters));
-}
-static size_t align256(size_t x) { return (x + 255) & ~size_t(255); }
-// layout: n [nseq] | t [cap][nseq] | dt [cap][nseq] | y [cap][B][D'] (forward records only)
-static size_t rec_bytes(const lde_problem_desc& d, int B, int cap, bool with_y) {
-  const size_t nseq = (size_t)rec_nseq(d, B), Dp = (size_t)(d.state_dim + d.augment_dim);
-  return align256(nseq * 4) + 2 * align256((size_t)cap * nseq * 8) + (with_y ? align256((size_t)cap * B * Dp * 4) : 0);
-}
-static lde::StepRec rec_view(const lde_problem_desc& d, void* base, int B, int cap, bool with_y) {
-  lde::StepRec r{};
-  const size_t nseq = (size_t)rec_nseq(d, B);
-  unsigned char* p = (unsigned char*)base;
-  r.n = (int32_t*)p; p += align256(nseq * 4);
-  r.t = (double*)p; p += align256((size_t)cap * nseq * 8);
-  r.dt = (double*)p; p += align256((size_t)cap * nseq * 8);
-  r.y = with_y ? (float*)p : nullptr;
-  r.cap = cap;
-  r.nseq = (int)nseq;
-  return r;
-}
+static int rec_capacity(const lde_handle* h, int T, int which) { return lde_host::rec_capacity(h->d, h->opt_record_capacity, T, which); }
 // the record a call of shape (B, T) uses: the caller's buffer if one was handed over (forward records), else the handle's own, grown here
 static int rec_prepare(lde_handle* h, int which, int B, int T, lde::StepRec* out) {
   const int cap = rec_capacity(h, T, which);
@@ -409,11 +342,9 @@ extern "C" int lde_reserve(lde_handle* h, int B, int T) { return reserve_impl(h,
 
 // Make the device copy of the save-time grid current (no-op when `ts` is unchanged since the last call).
 static int stage_ts(lde_handle* h, const double* ts, int T, hipStream_t stream) {
-  for (int j = 0; j < T; j++) {
-    if (!std::isfinite(ts[j]) || (j && !(ts[j] > ts[j - 1]))) {
-      h->err = "ts must be finite and strictly increasing";
-      return LDE_ERR_INVALID_ARG;
-    }
+  if (!grid_ok(ts, T)) {
+    h->err = "ts must be finite and strictly increasing";
+    return LDE_ERR_INVALID_ARG;
   }
   if ((int)h->ts_host.size() == T && std::memcmp(h->ts_host.data(), ts, (size_t)T * sizeof(double)) == 0) return LDE_OK;
   const int slot = h->ring;
@@ -424,31 +355,6 @@ static int stage_ts(lde_handle* h, const double* ts, int T, hipStream_t stream) 
   HIP_TRY(h, hipEventRecord(h->ts_ev[slot], stream));
   h->ts_host.assign(ts, ts + T);
   return LDE_OK;
-}
-
-static lde::KOpts make_opts(const lde_problem_desc& d, const double* ts, int T, int B) {
-  lde::KOpts o;
-  o.abstol = (float)d.abstol;
-  o.reltol = (float)d.reltol;
-  o.beta1 = (float)d.beta1;
-  o.beta2 = (float)d.beta2;
-  o.inv_gamma = (float)(1.0 / d.gamma);
-  o.q_lo = (float)(1.0 / d.qmax);
-  o.q_hi = (float)(1.0 / d.qmin);
-  o.qmin = (float)d.qmin;
-  o.dtmin = d.dtmin > 0 ? d.dtmin : 1e-12 * std::fabs(ts[T - 1] - ts[0]);
-  o.dt_fixed = d.dt;
-  o.maxiters = d.maxiters;
-  o.adaptive = d.adaptive;
-  o.checkpoint = d.sensealg != LDE_SENSE_BACKSOLVE;
-  o.T = T;
-  o.B = B;
-  o.lb_hold = 0;
-  o.dw_overwrite = 0;
-  o.t_first = ts[0];
-  o.t_last = ts[T - 1];
-  o.rec = lde::StepRec{};
-  return o;
 }
 
 extern "C" {
@@ -484,6 +390,7 @@ int lde_forward(lde_handle* h, const float* z0, const float* theta, const double
     return lde::mlp_forward(h->mlp, h->W_dev, z0, theta, h->ts_dev, o, z_out, retcode, st[0], st[1], st[2], st[3], stream, h->err);
   rc = lde::launch_pend_forward(h->d.rhs_kind, h->d.solver, z0, theta, h->ts_dev, o, z_out, retcode, st[0], st[1], st[2],
                                 st[3], stream, h->pend_tune);
+  h->last_kernel[0] = lde::pend_last_kernel(0);
   if (rc) h->err = "lde_forward: kernel launch failed";
   return rc;
 }
@@ -501,14 +408,7 @@ int lde_adjoint(lde_handle* h, const float* z_out, const float* theta, const dou
     h->err = "lde_adjoint: weights not set";
     return LDE_ERR_NO_WEIGHTS;
   }
-  int64_t steps_hint = 0;   // fixed step size: the number of step attempts is known here
-  if (h->mlp && !h->d.adaptive && h->d.dt > 0) {
-    for (int j = 0; j + 1 < T; j++) {
-      const double n = std::ceil((ts[j + 1] - ts[j]) / h->d.dt * (1.0 - 1e-12));
-      steps_hint += n < 1 ? 1 : (n > 1e9 ? (int64_t)1e9 : (int64_t)n);
-    }
-    if (steps_hint > h->d.maxiters) steps_hint = h->d.maxiters;
-  }
+  const int64_t steps_hint = h->mlp ? fixed_step_count(h->d, ts, T) : 0;   // fixed step size: the number of step attempts is known here
   int rc = reserve_impl(h, B, T, true, steps_hint);
   if (rc) return rc;
   rc = stage_ts(h, ts, T, stream);
@@ -537,6 +437,7 @@ int lde_adjoint(lde_handle* h, const float* z_out, const float* theta, const dou
                               h->err);
     rc = lde::launch_pend_adjoint_disc(h->d.rhs_kind, h->d.solver, z_out, theta, h->ts_dev, o, dz_out, dz0, dtheta, st[0], st[1], st[2],
                                        st[3], stream, h->pend_tune);
+    h->last_kernel[1] = lde::pend_last_kernel(1);
     if (rc) h->err = "lde_adjoint: kernel launch failed";
     return rc;
   }
@@ -555,6 +456,7 @@ int lde_adjoint(lde_handle* h, const float* z_out, const float* theta, const dou
   else
     rc = lde::launch_pend_adjoint(h->d.rhs_kind, h->d.solver, z_out, theta, h->ts_dev, o, dz_out, dz0, dtheta, st[0], st[1],
                                   st[2], st[3], stream);
+  h->last_kernel[1] = lde::pend_last_kernel(1);
   if (rc) h->err = "lde_adjoint: kernel launch failed";
   return rc;
 }
@@ -727,5 +629,15 @@ int lde_get_option(const lde_handle* h, const char* key, double* value) {
 }
 
 const char* lde_last_error(const lde_handle* h) { return h ? h->err.c_str() : "NULL handle"; }
+
+const char* lde_last_kernel(const lde_handle* h, int which) {
+  if (!h || which < 0 || which > 1) return "";
+  if (h->mlp) {   // the MLP families by the adjoint's last choice ("adjoint_family"); the forward solve runs the same family's forward instantiation
+    static const char* fam[] = {"k_mlp_", "k_mlp64", "k_mlpb", "k_mlpc", "k_mlpw", "k_mlpv", "k_mlp4"};
+    const int f = lde::mlp_last_family(h->mlp);
+    return f >= 0 && f < 7 ? fam[f] : "";
+  }
+  return h->last_kernel[which];
+}
 
 }  // extern "C"

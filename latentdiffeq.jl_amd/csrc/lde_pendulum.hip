@@ -131,6 +131,10 @@ __device__ __forceinline__ float tsit5_attempt_pair(F& f, float h, f32x2 y, f32x
   return (r2.x + r2.y) * 0.5f;
 }
 
+// which kernel the last launch_pend_* call of this thread ran (lde_last_kernel: bench.py checks its committed profile summaries against it)
+static thread_local const char* g_pend_last[2] = {"", ""};
+const char* pend_last_kernel(int which) { return g_pend_last[which & 1]; }
+
 constexpr int TS_LDS_MAX = 6000;   // doubles of the save-time grid kept in LDS (48 KB)
 
 // ---- forward ------------------------------------------------------------------------------------
@@ -1751,6 +1755,7 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
       hipLaunchKernelGGL((k_pend_forward_sh<K, S, A, false>), dim3(g8), dim3(64 * (1 + SH_NH)), 0, stream, (const float2*)z0, theta, ts_dev, o, \
                          (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                                \
   } while (0)
+    g_pend_last[0] = (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5 && ad && tn.lp) ? "k_pend_forward_lp" : "k_pend_forward_sh";
     if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5 && ad && tn.lp) {
       // the metric's shape: the stepping wave's lanes in pairs, the step as a Nyström scheme (lde_pend_lp.h; option "pend_lp" = 0: k_pend_forward_sh)
       if (o.rec.n)
@@ -1771,6 +1776,7 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
   }
   const bool recording = o.rec.n != nullptr;   // k_pend_forward_sh, k_pend_forward_ws and k_pend_forward are the mappings that write step records
   if (!recording && o.T > 1 && o.B <= tl_max_b) {
+    g_pend_last[0] = "k_pend_forward_tl";
     const bool ad = o.adaptive != 0;
     const bool few = o.T - 1 <= 64;   // a lane serves exactly one save time: the variant without a load in the stepping loop
 #define LDE_LAUNCH_TL(K, S, A)                                                                                          \
@@ -1793,6 +1799,7 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
     return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
   }
   if (ws_on && shm && o.T > 2 && o.B <= ws_max_b) {   // (writes step records too)
+    g_pend_last[0] = "k_pend_forward_ws";
     const size_t lds = (size_t)((o.T + 1) & ~1) * sizeof(double) + (size_t)WS_CAP * 64 * WS_RW * sizeof(float);
     const int g64 = (o.B + 63) / 64;
 #define LDE_LAUNCH_WS(K, S, A)                                                                                         \
@@ -1834,6 +1841,7 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
   const int lb_ring = tn.lb_ring;   // rows of the ring; 0: off
   const int lb_min_b = tn.lb_min_b;
   if (lb_ring > 0 && o.T > 1 && o.T <= 2048 && o.B >= lb_min_b) {   // (the save grid in LDS beside the ring: T ≤ 2048; a recording forward: the 16-row ring)
+    g_pend_last[0] = "k_pend_forward_tl";
     // a lane sits out while j ≥ jc + RING − hold; the slowest lane has j = jc, so hold ≤ RING − 1 keeps it (and with it jc) moving —
     // hold ≥ RING would hold EVERY lane on every iteration and the solve loop would never end. Default: half the ring.
     const int lb_hold_env = tn.lb_hold;
@@ -1867,6 +1875,7 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
 #undef LDE_LAUNCH_LB
     return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
   }
+  g_pend_last[0] = "k_pend_forward<";
 #define LDE_LAUNCH(K, S)                                                                                              \
   do {                                                                                                                \
     if (shm)                                                                                                          \
@@ -1890,6 +1899,7 @@ int launch_pend_adjoint(int kind, int solver, const float* z_out, const float* t
                         int32_t* nrej, int32_t* ret, hipStream_t stream) {
   const int block = pick_block(o.B), grid = (o.B + block - 1) / block;
   const size_t shm = o.T <= TS_LDS_MAX ? (size_t)o.T * sizeof(double) : 0;
+  g_pend_last[1] = "k_pend_adjoint<";
 #define LDE_LAUNCH(K, S)                                                                                          \
   do {                                                                                                              \
     if (shm)                                                                                                        \
@@ -2431,6 +2441,7 @@ int launch_pend_adjoint_disc(int kind, int solver, const float* z_out, const flo
   const size_t shm = o.T <= TS_LDS_MAX ? (size_t)o.T * sizeof(double) : 0;
   // the steps side by side (a wave per trajectory) while the chip has waves to spare: option "pend_disc_tp_max_b"
   const bool tp = o.T > 1 && o.T <= 3840 && o.B <= tn.disc_tp_max_b;   // (16·T + 3 168 bytes of LDS: within the 64 KB a launch gets without asking)
+  g_pend_last[1] = tp ? "k_pend_adjoint_disc_tp" : "k_pend_adjoint_disc<";
 #define LDE_LAUNCH(K, S)                                                                                                         \
   do {                                                                                                                           \
     if (tp)                                                                                                                      \
@@ -2638,6 +2649,7 @@ int launch_pend_adjoint_par(int kind, int solver, const float* z_out, const floa
                             const KOpts& o, const float* dz_out, float* dz0, float* dtheta, float* ops, int32_t* info,
                             int32_t* nfe, int32_t* nacc, int32_t* nrej, int32_t* ret, hipStream_t stream) {
   const int form = pend_adjoint_form(o.B, o.T);
+  g_pend_last[1] = form == PEND_ADJ_FUSED ? "k_pend_adjoint_fused" : (form == PEND_ADJ_STREAM ? "k_pend_adjoint_stream" : "k_pend_adjoint_par");
   if (form == PEND_ADJ_FUSED) {   // fused: one workgroup per trajectory, one lane per interval
     const int block = ((o.T - 1 + 63) / 64) * 64;
 #define LDE_LAUNCH(K, S)                                                                                                  \

@@ -46,9 +46,10 @@ for w in args:
         d = json.loads(lines[-1])
         roof = d.get("roofline") or {}
         if roof.get("bound") == "hbm" and w.startswith("goku_pendulum"):
-            bench.attach_traffic(roof, "goku_pendulum_discrete" if "discrete" in w else "goku_pendulum", d["config"]["batch_per_gpu"], mlp=False, full_batch=True, rounds=(RND,))
+            bench.attach_traffic(roof, "goku_pendulum_discrete" if "discrete" in w else "goku_pendulum", d["config"]["batch_per_gpu"], mlp=False, full_batch=True, rounds=(RND,),
+                                 launched=roof.get("launched_kernels"))
         elif w.replace("_discrete", "") in ("c2", "c3", "c4", "latentode_ref"):
-            bench.attach_traffic(roof, w, d["config"]["batch_per_gpu"], mlp=True, full_batch=True, rounds=(RND,))
+            bench.attach_traffic(roof, w, d["config"]["batch_per_gpu"], mlp=True, full_batch=True, rounds=(RND,), launched=roof.get("launched_kernels"))
         open(dst, "w").write(json.dumps(d) + "\n")
     s = json.load(open(f"{ROOT}/profiles/{RND}_{w}_summary.json"))
     print(w, {k.split("<")[0]: round(v.get("avg_ns", 0) / 1e3, 1) for k, v in s["kernels"].items() if k.startswith("k_")})

@@ -35,6 +35,21 @@ def test_metric_line():
     assert {"value", "unit", "cores", "kind", "sample"} <= set(c) and c["kind"] == "port" and c["value"] > 0 and c["cores"] >= 1
     assert d["value"] > c["value"]
     assert d["solver_stats"]["forward"]["nfailed"] == 0 and d["solver_stats"]["adjoint"]["nfailed"] == 0
+    # the headline runs the reference's own default gradient: ForwardDiffSensitivity = LDE_SENSE_DISCRETE [REF pendulum.jl:8-11]
+    assert d["sensealg"].startswith("LDE_SENSE_DISCRETE") and "reference's default" in d["sensealg"]
+    assert d["other_sensealg"]["sensealg"] == "continuous" and d["other_sensealg"]["value"] > 0
+    # counter bytes are attached from a committed summary ONLY when it holds the kernel this run launched (lde_last_kernel): a stale summary
+    # must not survive a kernel change
+    lk = r["launched_kernels"]
+    assert lk["lde_forward"].startswith("k_pend_forward") and lk["lde_adjoint"].startswith("k_pend_adjoint")
+    if r["traffic"] is not None:
+        dom = "lde_forward" if r["kernel"] == "lde_forward" else "lde_adjoint"
+        assert r["traffic_kernel"].startswith(lk[dom]) and r["traffic_source"].startswith("profiles/"), (r["traffic_kernel"], lk)
+    else:
+        assert "stale" in r.get("traffic_source", "stale") or "traffic_source" not in r
+    # the CPU side runs the same definition of the gradient, by the algorithm the reference executes (the solve on dual numbers)
+    assert "dual numbers" in c["algorithm"] and c["reverse_sweep"]["value"] > 0 and c["continuous_adjoint"]["value"] > 0
+    assert abs(d["vs_cpu_baseline"]["ratio"] - d["value"] / c["value"]) <= 1e-9 * d["vs_cpu_baseline"]["ratio"]
 
 
 @pytest.mark.parametrize("workload,bound", [("c2", "mfma"), ("goku_decoder", "mfma"), ("goku_step", "mfma")])

@@ -14,13 +14,18 @@ Gradients: a per-fixture relative gate against the fixture (GRAD_LIM), set at â‰
     goku_pendulum_friction_b32           2.3e-5    2.8e-7    6.0e-7    â€“         4.6e-7 / 1.8e-5 / â€“
     c2_latentode_rk4_d8_h200_b16         1.2e-7    1.4e-7    â€“         1.2e-7    3.4e-4 / â€“ / 4.0e-4   (own: RK4 dt=0.05 truncation)
     latentode_aug_tanh_d6a2_b16          3.8e-7    2.3e-7    â€“         2.2e-7    2.5e-7 / â€“ / 1.4e-7
-    c4_latentode_tsit5_d32_h128_b16      3.2e-5    8.3e-4    â€“         4.2e-3    5.9e-4 / â€“ / 3.5e-3   (relu + reltol 1e-3)
-    c3_pendulum_plus_mlp_b32             1.3e-3    2.6e-3    3.9e-3    8.4e-3    2.4e-3 / 2.0e-3 / 1.0e-2 (relu + reltol 1e-3)
+    c4_latentode_tsit5_d32_h128_b16      3.2e-5    (gradients: tests/test_gpu_same_steps.py, 1e-4 on the same steps)
+    c3_pendulum_plus_mlp_b32             1.3e-3    (   "   )
+    latentode_ref_tsit5_d16_h200_b16     â€¦         (   "   )
 
 The analytic right-hand sides and the smooth / fixed-step networks reproduce the fixture's gradients to ~1e-6 (the
-time-parallel adjoint takes the same single step per save interval as the oracle); where a relu network meets the adaptive
-controller at reltol = 1e-3, two correct f32 solves differ by about the solver's own error â€” those two fixtures keep a
-gate of the size of their own float64 distance. Against the float64 adjoint: â‰¤ 3.5Ã— the fixture's own distance + 1e-3."""
+time-parallel adjoint takes the same single step per save interval as the oracle). Where a relu network meets the adaptive
+controller at reltol = 1e-3, two correct f32 solves â€” two free-running controllers â€” differ by about the solver's own error
+(rounds 1â€“4 gated those three fixtures' gradients at 3e-3 â€¦ 2.5e-2 here: a number that says nothing about arithmetic). Since
+round 5 their gradients are held where they can be held tightly: kernel and oracle on the SAME recorded steps, every gradient
+â‰¤ 1e-4 (tests/test_gpu_same_steps.py, continuous adjoint; tests/test_gpu_discrete.py, LDE_SENSE_DISCRETE) â€” so this file keeps
+their forward gate and a bound against the FLOAT64 adjoint of the size of the fixture's own float64 distance, and no loose
+fixture-relative gate. Against the float64 adjoint: â‰¤ 3.5Ã— the fixture's own distance + 1e-3."""
 import glob
 import os
 
@@ -34,9 +39,10 @@ pytestmark = pytest.mark.gpu
 GRAD_LIM = {
     "c1_goku_pendulum_b64": (1e-5, None), "metric_goku_pendulum_b256": (1e-5, None), "metric_goku_pendulum_b256_tight": (5e-6, None),
     "goku_pendulum_friction_b32": (1e-5, None), "c2_latentode_rk4_d8_h200_b16": (5e-6, 5e-6), "latentode_aug_tanh_d6a2_b16": (5e-6, 5e-6),
-    "c4_latentode_tsit5_d32_h128_b16": (3e-3, 1e-2), "c3_pendulum_plus_mlp_b32": (1e-2, 2.5e-2),
-    "latentode_ref_tsit5_d16_h200_b16": (3e-3, 1e-2),   # relu + reltol 1e-3, as c4 (the reference's default NODE shape)
 }
+# relu network + adaptive control at reltol 1e-3: no fixture-relative gradient gate here (two free-running controllers) â€” their gradients are
+# held to 1e-4 on the same steps in tests/test_gpu_same_steps.py / tests/test_gpu_discrete.py
+SAME_STEPS_ONLY = {"c4_latentode_tsit5_d32_h128_b16", "c3_pendulum_plus_mlp_b32", "latentode_ref_tsit5_d16_h200_b16"}
 FIX = sorted(f for f in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
              if not os.path.basename(f).startswith("chain_"))   # chain fixtures: tests/test_oracle_chain.py
 
@@ -76,7 +82,7 @@ def test_hip_matches_golden_fixture(path):
     s0 = np.abs(fx["dz0"]).max()
 
     def close(g, ref, ref64, lim=lim):   # within the fixture's measured-margin gate (module docstring)
-        return np.abs(g - ref).max() <= lim * np.abs(ref).max()
+        return name in SAME_STEPS_ONLY or np.abs(g - ref).max() <= lim * np.abs(ref).max()
     assert close(g0[:k], fx["dz0"], fx["dz0_64"])
     assert np.abs(g0[:k] - fx["dz0_64"]).max() <= 3.5 * np.abs(fx["dz0"] - fx["dz0_64"]).max() + 1e-3 * s0
     if theta is not None:
@@ -84,5 +90,5 @@ def test_hip_matches_golden_fixture(path):
     if W is not None:
         sw = np.abs(fx["dW"]).max()
         assert close(gW[fx["dW_idx"]], fx["dW"], fx["dW_64"], limW)
-        assert abs(np.linalg.norm(gW.astype(np.float64)) - fx["dW_norm"][0]) <= 4 * limW * fx["dW_norm"][0]
+        assert name in SAME_STEPS_ONLY or abs(np.linalg.norm(gW.astype(np.float64)) - fx["dW_norm"][0]) <= 4 * limW * fx["dW_norm"][0]
         assert np.abs(gW[fx["dW_idx"]] - fx["dW_64"]).max() <= 3.5 * np.abs(fx["dW"] - fx["dW_64"]).max() + 1e-3 * sw

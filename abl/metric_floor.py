@@ -62,6 +62,8 @@ for i in range(3):
           f"({((wall(12 + i) - wall(10)).mean()) / 100:5.2f} us after the loop's end)")
 if v[:, 1].mean() > 0:   # k_pend_forward_lp's helper statistics (slots 0..6)
     print(f"  helper 0: own records {v[:, 0].mean() / v[:, 1].mean():6.0f} cycles each ({v[:, 1].mean():.1f}), idle polls {v[:, 4].mean():.0f}, entry to done {v[:, 6].mean():.0f} cycles")
+    n_ = v[:, 1].mean()
+    print(f"            per own record: walk to it {v[:, 7].mean() / n_:.0f}, read + times + skip {v[:, 8].mean() / n_:.0f}, polynomials {v[:, 9].mean() / n_:.0f}, evaluate + store {v[:, 10].mean() / n_:.0f} cycles")
 print(f"  shader clock during the loop: {((cyc(10) - cyc(9)) / ((wall(10) - wall(9)) * 10e-9)).mean() / 1e9:.2f} GHz")
 # the kernel as the host sees it (HIP events, back to back) and an empty kernel's launch floor
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]

@@ -340,7 +340,7 @@ __global__ void __launch_bounds__(64 * (1 + SH_NH)) k_pend_forward_lp(const floa
   // a faster stepper they fell behind, and what they were behind by was the launch's tail.)
   const int hid = w - 1;
 #if LDE_PEND_PROF
-  long long pq[5] = {0, 0, 0, 0, 0};
+  long long pq[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const long long pq_in = __builtin_readcyclecounter();
 #endif
   const double dinf = __longlong_as_double(0x7ff0000000000000LL);
@@ -373,6 +373,10 @@ __global__ void __launch_bounds__(64 * (1 + SH_NH)) k_pend_forward_lp(const floa
         const long long pc0 = __builtin_readcyclecounter();
 #endif
         advance(n2, m);
+#if LDE_PEND_PROF
+        asm volatile("" : "+v"(ys), "+v"(sg1));
+        const long long pc1 = __builtin_readcyclecounter();
+#endif
         const float* rc = myrec + (size_t)m * STEPF;
         const f32x4 qe = *reinterpret_cast<const f32x4*>(rc), qo = *reinterpret_cast<const f32x4*>(rc + 4);
         const float h = rc[8];
@@ -382,6 +386,10 @@ __global__ void __launch_bounds__(64 * (1 + SH_NH)) k_pend_forward_lp(const floa
           jq += 64;
           tj = jq < T ? ts_g[jq] : dinf;
         }
+#if LDE_PEND_PROF
+        const long long pc2 = __builtin_readcyclecounter();
+        long long pc3 = pc2;
+#endif
         if (__any(tj <= t1)) {
           f32x2 k0 = {0.f, 0.f}, P2 = {0.f, 0.f}, P3 = {0.f, 0.f}, P4 = {0.f, 0.f};
           float rh = 0.f;
@@ -405,6 +413,10 @@ __global__ void __launch_bounds__(64 * (1 + SH_NH)) k_pend_forward_lp(const floa
             P3 = f32x2{px[1], pv[1]};
             P4 = f32x2{px[2], pv[2]};
           }
+#if LDE_PEND_PROF
+          asm volatile("" : "+v"(P2), "+v"(P3), "+v"(P4));
+          pc3 = __builtin_readcyclecounter();
+#endif
           while (tj <= t1) {   // this lane's save times inside the step
             float2 out;
             if (tj >= t1) out = make_float2(ye.x, ye.y);   // the save time is the step's end
@@ -423,8 +435,7 @@ __global__ void __launch_bounds__(64 * (1 + SH_NH)) k_pend_forward_lp(const floa
         sg1 = qe[2];   // FSAL
         n2 = m + 1;
 #if LDE_PEND_PROF
-        pq[0] += __builtin_readcyclecounter() - pc0;
-        pq[1] += 1;
+        { const long long pc4 = __builtin_readcyclecounter(); pq[0] += pc4 - pc0; pq[1] += 1; pq[7] += pc1 - pc0; pq[8] += pc2 - pc1; pq[9] += pc3 - pc2; pq[10] += pc4 - pc3; }
 #endif
         continue;
       }
@@ -445,6 +456,7 @@ __global__ void __launch_bounds__(64 * (1 + SH_NH)) k_pend_forward_lp(const floa
 #if LDE_PEND_PROF
   if (blockIdx.x == 0 && hid == 0 && lane == 0) {   // helper 0: entry → done
     for (int i = 0; i < 5; i++) g_pprof[i] = pq[i];
+    for (int i = 7; i < 11; i++) g_pprof[i] = pq[i];
     g_pprof[6] = __builtin_readcyclecounter() - pq_in;
   }
   if (blockIdx.x == 0 && lane == 0 && hid < 3) { g_pprof[2 * (12 + hid)] = wall_clock64(); g_pprof[2 * (12 + hid) + 1] = __builtin_readcyclecounter(); }   // helper hid has stored its last save

@@ -52,7 +52,8 @@ wall = lambda i: v[:, 2 * i]
 cyc = lambda i: v[:, 2 * i + 1]
 steps = v[:, 30].mean()
 seg = [("stepper: loads, k1 = f(y0), Hairer initial step", 8, 9), ("stepper: the stepping loop", 9, 10), ("stepper: publish, statistics, exit", 10, 11)]
-print(f"k_pend_forward_sh, B = {B}, workgroup 0: {steps:.1f} step attempts")
+lib.lde_last_kernel.restype = C.c_char_p
+print(f"{lib.lde_last_kernel(h, 0).decode()}, B = {B}, workgroup 0: {steps:.1f} step attempts")
 for name, a, b_ in seg:
     dc, dw = (cyc(b_) - cyc(a)).mean(), (wall(b_) - wall(a)).mean() * 10.0
     extra = f"   = {dc / steps:.0f} cycles = {dw / steps:.0f} ns per step" if a == 9 else ""

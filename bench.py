@@ -729,7 +729,7 @@ def launch_ranks(args, argv):
     — a process that has initialised HIP must never be replaced by another program —, relay rank 0's single JSON line and
     exit with the children's code."""
     import subprocess
-    if not args.dry_launch:
+    if not args.dry_launch and os.environ.get("LDE_BENCH_SHARE_GPU") != "1":
         have = count_gpus_sysfs()                 # from the KFD topology in sysfs: this process never opens the GPU driver
         if have is not None and have < args.gpus:
             raise SystemExit(f"bench.py --gpus {args.gpus}: only {have} GPU(s) visible on this node")
@@ -805,6 +805,12 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the product has no CPU path")
+    # LDE_BENCH_SHARE_GPU=1 — a TEST switch (tests/test_gpu_bench_contract.py), never a measurement: the N ranks share the box's GPUs
+    # (rank r on device r mod device_count) and meet over gloo, because RCCL refuses two ranks on one device. It runs every line of the
+    # N > 1 path except RCCL itself on the one-GPU boxes the round's tests get; the line says so (`config.shared_gpu_test`).
+    args.share_gpu = world > 1 and os.environ.get("LDE_BENCH_SHARE_GPU") == "1"
+    if args.share_gpu:
+        local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     args.rccl_ranks = 1
@@ -814,7 +820,10 @@ def main():
         if world == 1:
             os.environ.setdefault("RANK", "0")
             os.environ.setdefault("WORLD_SIZE", "1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.share_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         one = torch.ones(1, device=dev)
         dist.all_reduce(one)                    # RCCL is up and spans every rank
         args.rccl_ranks = int(one.item())
@@ -837,13 +846,15 @@ def main():
 
     # the one collective of the path (shared RHS-MLP gradient): through the C ABI (lde_comm_*) when RCCL binds, else torch's
     comm, comm_kind = None, "none"
-    if world > 1 and args.workload != "goku_pendulum":   # (the metric's right-hand side has no weights: no collective, no communicator)
+    if world > 1 and args.workload != "goku_pendulum" and not args.share_gpu:   # (the metric's right-hand side has no weights: no collective, no communicator)
         try:
             from latentdiffeq_amd.dist import LdeComm
             comm, comm_kind = LdeComm(rank, world), "lde_comm_allreduce_f32 (C ABI over RCCL)"
         except Exception as e:                                                   # noqa: BLE001
             comm_kind = f"torch.distributed all_reduce (lde_comm unavailable: {e})"
         C.CDLL(None).fflush(None)
+    elif world > 1 and args.share_gpu:
+        comm_kind = "torch.distributed all_reduce over gloo (LDE_BENCH_SHARE_GPU test)"
 
     def fence():
         if world > 1:
@@ -1083,7 +1094,7 @@ def main():
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {w['desc']}", "batch_per_gpu": B, "global_batch": global_batch,
-                   "save_points": T, "rccl_ranks": args.rccl_ranks,
+                   "save_points": T, "rccl_ranks": args.rccl_ranks, **({"shared_gpu_test": "ranks share a GPU and meet over gloo: plumbing test, not a measurement"} if args.share_gpu else {}),
                    "parallelism": f"dp{world} (batch sharded by trajectory, no data-path collective)"
                    if not nW else f"dp{world} (batch sharded; one all-reduce of dW per step: {comm_kind})",
                    "submission": "hipGraph replays of ≤ 256 captured steps (each step = lde_forward + lde_adjoint)" if m.get("graphed")

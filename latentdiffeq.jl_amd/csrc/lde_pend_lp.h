@@ -104,8 +104,30 @@ constexpr int EVEN = 0xA0;   // quad_perm [0,0,2,2]: the pair's even lane
 constexpr int ODD = 0xF5;    // quad_perm [1,1,3,3]: the pair's odd lane
 }  // namespace lp
 
+#ifndef LDE_LP_NH
+#define LDE_LP_NH 4
+#endif
+#ifndef LDE_LP_SW
+#define LDE_LP_SW 2
+#endif
+#if LDE_PEND_PROF   // stamps by the stepping wave's first lane, whichever wave of the workgroup that is
+#define LPPROF(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { g_pprof[2 * (i)] = wall_clock64(); g_pprof[2 * (i) + 1] = __builtin_readcyclecounter(); } } while (0)
+#define LPPROF_VAL(i, v) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_pprof[i] = (v); } while (0)
+#else
+#define LPPROF(i) do { } while (0)
+#define LPPROF_VAL(i, v) do { } while (0)
+#endif
+// Measured at B = 256 on one box (abl/ab_libs.sh, three alternations; M trajectories/s at K = 200 | K = 20): 3 helpers 22.85 | 20.75 (round 6's
+// first form); 4: 23.61 | 21.52; 5: 23.57 | 21.44; 6: 23.5 | 21.4; 7: 23.1 | 21.0; 9: 22.5 | 20.6; 11: 22.0; 15: 21.6 — a helper's own record costs
+// ≈ 1 350 cycles and three of them had ≈ 1 750 per record between them: they ran behind, and what they were behind by was the launch's tail
+// (1.3–1.6 → 0.6–1.1 µs behind the stepper's last step). With five waves on four SIMDs one SIMD holds two: the stepping wave as wave 2
+// measured +0.4 % over wave 0 (23.72 | 21.64) and as the LAST wave −7 % (it starts last). Also measured, slower, not kept: the helper
+// walking up to its next record before that is published (−1.4 %), the helpers writing the step records instead of the stepper's
+// replay (−3 %: three more global stores on the last record's path).
+constexpr int LP_NH = LDE_LP_NH;   // dense-output waves
+constexpr int LP_SW = LDE_LP_SW;   // which wave of the workgroup steps
 template <bool REC>   // REC: the instantiation that writes step records (LDE_SENSE_DISCRETE, "step_trace")
-__global__ void __launch_bounds__(64 * (1 + SH_NH)) k_pend_forward_lp(const float2* __restrict__ z0, const float* __restrict__ theta,
+__global__ void __launch_bounds__(64 * (1 + LP_NH)) k_pend_forward_lp(const float2* __restrict__ z0, const float* __restrict__ theta,
                                                          const double* __restrict__ ts_g, KOpts o,
                                                          float2* __restrict__ z_out, int32_t* __restrict__ retcode,
                                                          int32_t* __restrict__ st_nfe, int32_t* __restrict__ st_nacc,
@@ -130,9 +152,9 @@ __global__ void __launch_bounds__(64 * (1 + SH_NH)) k_pend_forward_lp(const floa
   constexpr int NS = 6;  // RHS evaluations per attempt
   float* const myrec = s_rec + (lane >> 2) * RECF;   // this lane's copy of record 0
 
-  if (w == 0) {
+  if (w == LP_SW) {
     // ================= the stepper =================
-    PPROF(8);
+    LPPROF(8);
     const bool ev = (lane & 1) == 0;
     auto sel = [&](double a, double c) -> float { return ev ? (float)a : (float)c; };
     // lane-dependent coefficients: even lanes stages 3, 5, new (7); odd lanes stages 2, 4, 6. "own" = this lane's sine of the level
@@ -183,7 +205,7 @@ __global__ void __launch_bounds__(64 * (1 + SH_NH)) k_pend_forward_lp(const floa
     float yc = (ev ? zi.x : zi.y) * INV_2PI;   // even lanes ξ = x/2π, odd lanes ω = v/2π
     bool active = __any(t < tend) && maxit > 0;   // (votes: scalar from here on)
     if (__any(t < tend) && !active) ret = LDE_RET_MAXITERS;
-    PPROF(9);
+    LPPROF(9);
     // the step about to be attempted: its size h and whether it reaches the end (decided when the step BEFORE it was accepted — with the
     // f64 time arithmetic done while that step's stages were in flight — so that neither sits between two steps' dependent chains)
     float rem = (float)(tend - t);
@@ -280,8 +302,8 @@ __global__ void __launch_bounds__(64 * (1 + SH_NH)) k_pend_forward_lp(const floa
         }
       }
       nacc += n;
-      PPROF(10);
-      PPROF_VAL(30, nacc + nrej);
+      LPPROF(10);
+      LPPROF_VAL(30, nacc + nrej);
       if (active && nacc + nrej >= maxit) { ret = LDE_RET_MAXITERS; active = false; }
       if (ret != LDE_RET_SUCCESS && lane == 0) __hip_atomic_store(&s_fail, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       asm volatile("" ::: "memory");
@@ -329,16 +351,16 @@ __global__ void __launch_bounds__(64 * (1 + SH_NH)) k_pend_forward_lp(const floa
       st_nrej[b] = nrej;
       if (REC) o.rec.n[b] = ret == LDE_RET_SUCCESS ? nacc : 0;
     }
-    PPROF(11);
+    LPPROF(11);
     return;
   }
 
-  // ================= the helpers: wave 1 + hid serves every SH_NH-th step; lanes = save times =================
+  // ================= the helpers: wave 1 + hid serves every LP_NH-th step; lanes = save times =================
   // A helper touches ONLY its own records: of the records between two of its own it reads the step sizes (the time) and, from the one
   // before its own, the end state and the last sine (its record's start state and first sine). (k_pend_forward_sh's helpers walk every
   // record — two LDS round trips and the f64 time arithmetic per record and helper, ≈ 550 cycles against a stepper's ≈ 600 per step: with
   // a faster stepper they fell behind, and what they were behind by was the launch's tail.)
-  const int hid = w - 1;
+  const int hid = w < LP_SW ? w : w - 1;
 #if LDE_PEND_PROF
   long long pq[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
   const long long pq_in = __builtin_readcyclecounter();
@@ -364,7 +386,7 @@ __global__ void __launch_bounds__(64 * (1 + SH_NH)) k_pend_forward_lp(const floa
   for (;;) {   // rounds
     int n2 = 0, fin;
     for (;;) {
-      const int m = n2 + (hid + SH_NH - (nrec0 + n2) % SH_NH) % SH_NH;   // my next record of this round
+      const int m = n2 + (hid + LP_NH - (nrec0 + n2) % LP_NH) % LP_NH;   // my next record of this round
       fin = __hip_atomic_load(&s_fin, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // read BEFORE the count: if the round is over, the count is final
       const int cnt = __hip_atomic_load(&s_cnt[lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
       asm volatile("" ::: "memory");

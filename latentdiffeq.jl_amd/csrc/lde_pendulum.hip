@@ -1759,10 +1759,10 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
     if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5 && ad && tn.lp) {
       // the metric's shape: the stepping wave's lanes in pairs, the step as a Nyström scheme (lde_pend_lp.h; option "pend_lp" = 0: k_pend_forward_sh)
       if (o.rec.n)
-        hipLaunchKernelGGL((k_pend_forward_lp<true>), dim3(g8), dim3(64 * (1 + SH_NH)), 0, stream, (const float2*)z0, theta, ts_dev, o,
+        hipLaunchKernelGGL((k_pend_forward_lp<true>), dim3(g8), dim3(64 * (1 + LP_NH)), 0, stream, (const float2*)z0, theta, ts_dev, o,
                            (float2*)z_out, retcode, nfe, nacc, nrej, ret);
       else
-        hipLaunchKernelGGL((k_pend_forward_lp<false>), dim3(g8), dim3(64 * (1 + SH_NH)), 0, stream, (const float2*)z0, theta, ts_dev, o,
+        hipLaunchKernelGGL((k_pend_forward_lp<false>), dim3(g8), dim3(64 * (1 + LP_NH)), 0, stream, (const float2*)z0, theta, ts_dev, o,
                            (float2*)z_out, retcode, nfe, nacc, nrej, ret);
     } else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5 && ad) LDE_LAUNCH_SH(0, LDE_SOLVER_TSIT5, true);
     else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH_SH(0, LDE_SOLVER_TSIT5, false);

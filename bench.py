@@ -141,8 +141,15 @@ def cpu_baseline(w, d_native, ts, z0, theta, W, dz, budget_s=12.0):
         elif disc:    # the same definition of the gradient on the CPU: record the steps, sweep them in reverse
             reverse(nt)
         else:
-            z, _, _ = orc.forward(od, z0s, ths, ts, W=W, nthreads=nt)
-            orc.adjoint(od, z, ths, ts, dzs, W=W, nthreads=nt)
+            z, _, _ = orc.forward(oc_seq, z0s, ths, ts, W=W, nthreads=nt)
+            orc.adjoint(oc_seq, z, ths, ts, dzs, W=W, nthreads=nt)
+
+    # the continuous adjoint on the CPU: the sequential checkpointed form whatever form the GPU runs (the time-parallel one restarts the solver
+    # in each of the T − 1 intervals — what pays on a GPU costs a CPU a factor two: 0.47 M against 0.88 M trajectories/s at the metric shape)
+    oc_seq = O.Desc()
+    C.memmove(C.byref(oc_seq), C.byref(od), C.sizeof(oc_seq))
+    if not disc and od.sensealg == O.SENSE_PARALLEL_CHECKPOINTED:
+        oc_seq.sensealg = O.SENSE_BACKSOLVE_CHECKPOINTED
 
     def rate(fn, nt, budget):
         fn(nt)  # warm-up (thread pool, page faults)
@@ -177,7 +184,7 @@ def cpu_baseline(w, d_native, ts, z0, theta, W, dz, budget_s=12.0):
                algorithm=("the solve on dual numbers (D + P = 3 partials per state component, dual-aware error norm) + the pullback's contraction: "
                           "ForwardDiffSensitivity as the reference's CPU path executes it" if dual else
                           "forward solve recording its steps + reverse sweep over them (LDE_SENSE_DISCRETE on the CPU)" if disc else
-                          "forward solve + reverse-time continuous adjoint"))
+                          "forward solve + reverse-time continuous adjoint (sequential, checkpointed at the save times: the faster form on a CPU)"))
     if dual:
         def best_of(fn):   # (its own fastest thread count: the three algorithms parallelise differently)
             r = []

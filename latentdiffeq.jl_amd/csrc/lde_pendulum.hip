@@ -1926,6 +1926,9 @@ int launch_pend_adjoint(int kind, int solver, const float* z_out, const float* t
 // time inside the step, the FSAL slope, the solution weights and the stage sums.
 // No controller, no error norm, no forced stops at the save times: (2S + 1) sine/cosine pairs per accepted step. Traffic = the record
 // (24 B per step) + Δẑ; every access coalesced over the batch index.
+#ifndef LDE_DISC_PF
+#define LDE_DISC_PF 4   // B = 2²⁰: 0.43 → 0.37–0.39 ms (2: 0.40; 6, 8 and workgroups of 64 / 128 lanes: the same within the run-to-run spread; abl/lb_ab.sh)
+#endif
 template <int KIND, int SOLVER>
 __global__ void __launch_bounds__(256) k_pend_adjoint_disc(const float2* __restrict__ z_out, const float* __restrict__ theta,
                                                            const double* __restrict__ ts_g, KOpts o,
@@ -1962,9 +1965,29 @@ __global__ void __launch_bounds__(256) k_pend_adjoint_disc(const float2* __restr
     const double tend = s_ts(T - 1);
     int j = T - 1;
     double tnext = tend;
+#if LDE_DISC_PF
+    // Every load of the sweep is requested a step (the record) resp. LDE_DISC_PF save times (Δẑ) before its use: the walk is one dependent
+    // chain per lane, and a load at the head of each link leaves only the other waves of the SIMD to cover its latency.
+    float2 dq[LDE_DISC_PF];
+#pragma unroll
+    for (int u = 0; u < LDE_DISC_PF; u++) dq[u] = dz_out[(size_t)(j - u > 0 ? j - u : 0) * B + b];
+    double t_pf = R.t[(size_t)(ns - 1) * B + b], dt_pf = R.dt[(size_t)(ns - 1) * B + b];
+    float2 y_pf = reinterpret_cast<const float2*>(R.y)[(size_t)(ns - 1) * B + b];
+#endif
     for (int s = ns - 1; s >= 0; s--) {
+#if LDE_DISC_PF
+      const double t = t_pf, dt = dt_pf;
+      const float2 yv = y_pf;
+      {
+        const int sp = s > 0 ? s - 1 : 0;
+        t_pf = R.t[(size_t)sp * B + b];
+        dt_pf = R.dt[(size_t)sp * B + b];
+        y_pf = reinterpret_cast<const float2*>(R.y)[(size_t)sp * B + b];
+      }
+#else
       const double t = R.t[(size_t)s * B + b], dt = R.dt[(size_t)s * B + b];
       const float2 yv = reinterpret_cast<const float2*>(R.y)[(size_t)s * B + b];
+#endif
       const float h = (float)dt;
       const bool last = s == ns - 1;
       const double tnew = tnext;
@@ -2013,7 +2036,14 @@ __global__ void __launch_bounds__(256) k_pend_adjoint_disc(const float2* __restr
       while (j >= 1) {
         const double tj = s_ts(j);
         if (!(tj > t)) break;
+#if LDE_DISC_PF
+        const float2 dj = dq[0];
+#pragma unroll
+        for (int u = 0; u + 1 < LDE_DISC_PF; u++) dq[u] = dq[u + 1];
+        dq[LDE_DISC_PF - 1] = dz_out[(size_t)(j - LDE_DISC_PF > 0 ? j - LDE_DISC_PF : 0) * B + b];
+#else
         const float2 dj = dz_out[(size_t)j * B + b];
+#endif
         if (tj >= tnew || (j == T - 1 && last)) {
           yb[0] += dj.x;
           yb[1] += dj.y;

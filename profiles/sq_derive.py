@@ -25,7 +25,8 @@ hdr = f"""# SQ counter passes (profiles/pmc_sq.sh via abl/collect_{rnd}.sh; per-
 # Template arguments: k_mlpb<SOLVER, D', ACT, DISC, ADJ>, k_mlpc<SOLVER, ACT, DISC, ADJ>: <…, false, false> the forward solve, <…, false, true> the
 # continuous adjoint's reverse-time solve, <…, true, true> the discrete sweep (LDE_SENSE_DISCRETE); k_mlp64 / k_mlp64_adj / k_mlp64_disc likewise.
 # (rocprofv3 7.2 crashes at process exit behind cooperative launches — the coupled workloads — after it has written its CSVs.)
-# The last two sections: the metric's pullback kernels (continuous, time-parallel: k_pend_adjoint_fused; discrete, steps side by side: k_pend_adjoint_disc_tp)."""
+# The last two sections: the metric's kernels — forward k_pend_forward_lp<REC> (round 6: lane pairs, Nyström form, four dense-output waves), pullbacks
+# k_pend_adjoint_disc_tp (discrete, the default: steps side by side) and k_pend_adjoint_fused (continuous, time-parallel)."""
 der = ["#", "# Derived (per launch): issue fraction = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES; LDS wait = SQ_WAIT_INST_LDS / SQ_WAVE_CYCLES; "
        "MFMA busy = SQ_VALU_MFMA_BUSY_CYCLES / (4·SQ_BUSY_CYCLES)"]
 for name, d in rows.items():

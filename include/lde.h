@@ -279,8 +279,9 @@ int lde_get_step_record(lde_handle* h, int which, double* t_host, double* dt_hos
  *   "step_trace"       1: lde_forward records its steps whatever the sensealg, lde_adjoint (continuous) records its reverse-time steps
  *   "adjoint_overwrite" 1: lde_adjoint WRITES dW (every entry exactly once) instead of accumulating — the caller's zero fill disappears
  * and the kernel-choice knobs the parity tests force a kernel family / a threshold with (defaults = the measured choices; a production
- * host never sets them): "pend_ws", "pend_tl_max_b", "pend_sh_max_b", "pend_lb", "pend_lb_min_b", "pend_lb_hold" (analytic right-hand
- * sides: which of the five forward mappings serves a batch), "mlp64", "mlpv", "mlpw", "mlpb" (0 off, 2 also ≤ 128-wide networks), "mlp4",
+ * host never sets them): "pend_ws", "pend_tl_max_b", "pend_sh_max_b" (−1, the default: the measured thresholds of the two mappings with a
+ * trajectory per workgroup; ≥ 0: one threshold for both), "pend_lp", "pend_lb", "pend_lb_min_b", "pend_lb_hold", "pend_disc_tp_max_b" (analytic
+ * right-hand sides: which of the forward / pullback mappings serves a batch), "mlp64", "mlpv", "mlpw", "mlpb" (0 off, 2 also ≤ 128-wide networks), "mlp4",
  * "mlp4_maxw", "mlp_stage_slots" (MLP right-hand sides), "peer_spin_k" (lde_set_global_sum_peers: the cross-rank wait poisons the sums after
  * this many × 1024 polls of ≈ 1 µs; 0 = 8192 ≈ 10 s — raise it when ranks may enter a solve seconds apart, e.g. a first call's module load;
  * all ranks should be warmed up before the first exchanging call). The library reads NO environment variable for any of this.

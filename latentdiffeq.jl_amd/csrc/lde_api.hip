@@ -609,7 +609,7 @@ static int* option_slot(lde_handle* h, const char* key) {
 int lde_set_option(lde_handle* h, const char* key, double value) {
   if (!h || !key) return LDE_ERR_INVALID_ARG;
   int* slot = option_slot(h, key);
-  if (!slot || !(value >= (std::strcmp(key, "pend_lb_hold") ? 0 : -1)) || value > 2e9) {
+  if (!slot || !(value >= ((std::strcmp(key, "pend_lb_hold") && std::strcmp(key, "pend_sh_max_b")) ? 0 : -1)) || value > 2e9) {
     h->err = std::string("lde_set_option: unknown key or value out of range: ") + key;
     return LDE_ERR_INVALID_ARG;
   }

@@ -30,6 +30,9 @@
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
+#ifndef LDE_M64_PF
+#define LDE_M64_PF 4   // c3 discrete: 0.2306 → 0.2263 ms per step (abl/ab_mlp.sh, three alternations)
+#endif
 template <int CTRL>
 __device__ __forceinline__ float dpp_add(float v) {   // v + (v of the lane CTRL points at, 0 outside the row)
   return v + __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
@@ -803,16 +806,47 @@ __device__ __forceinline__ void mlp64_disc_body(const MlpDims& dm, const KOpts& 
       int j = T - 1;
       double tnext = tend;
       float h1f = 0.f, h2f = 0.f;   // hidden units at the FSAL point y_{n+1} of the step being reversed (= the first stage point of step n + 1)
+#if LDE_M64_PF
+      // every load of the sweep is requested a link ahead of its use — the next step's record while this step's evaluations run, the Δẑ of
+      // the next LDE_M64_PF save times while this one is applied: with one wave per SIMD nothing else covers a load at the head of a link
+      double t_pf = R.t[(size_t)(ns - 1) * B + b], dt_pf = R.dt[(size_t)(ns - 1) * B + b];
+      float yN_pf[DP], dq[LDE_M64_PF][DP];
+#pragma unroll
+      for (int r = 0; r < DP; r++) yN_pf[r] = r < Dp ? R.y[((size_t)(ns - 1) * B + b) * Dp + r] : 0.f;
+#pragma unroll
+      for (int u = 0; u < LDE_M64_PF; u++)
+#pragma unroll
+        for (int r = 0; r < DP; r++) dq[u][r] = r < Dp ? a.dz_out[(size_t)Dp * ((size_t)b + (size_t)B * (j - u > 0 ? j - u : 0)) + r] : 0.f;
+      double tq[LDE_M64_PF];   // … and the save times themselves (the grid is in global memory)
+#pragma unroll
+      for (int u = 0; u < LDE_M64_PF; u++) tq[u] = ts[j - u > 0 ? j - u : 0];
+#endif
 #pragma unroll 1
       for (int s = ns - 1; s >= 0; s--) {
+#if LDE_M64_PF
+        const double t = t_pf, dt = dt_pf;
+#else
         const double t = R.t[(size_t)s * B + b], dt = R.dt[(size_t)s * B + b];
+#endif
         const float h = (float)dt;
         const bool last = s == ns - 1;
         const double tnew = tnext;
         tnext = t;
         float yN[DP], K[S][DP];
+#if LDE_M64_PF
+        {
+          const size_t sp = s > 0 ? s - 1 : 0;
+#pragma unroll
+          for (int r = 0; r < DP; r++) yN[r] = yN_pf[r];
+          t_pf = R.t[sp * B + b];
+          dt_pf = R.dt[sp * B + b];
+#pragma unroll
+          for (int r = 0; r < DP; r++) yN_pf[r] = r < Dp ? R.y[(sp * B + b) * Dp + r] : 0.f;
+        }
+#else
 #pragma unroll
         for (int r = 0; r < DP; r++) yN[r] = r < Dp ? R.y[((size_t)s * B + b) * Dp + r] : 0.f;
+#endif
         auto point = [&](int i, float (&zp)[DP]) {   // g_i (i < S) or y_{n+1} (i == S) from y_n and the slopes
 #pragma unroll
           for (int r = 0; r < DP; r++) {
@@ -860,11 +894,29 @@ __device__ __forceinline__ void mlp64_disc_body(const MlpDims& dm, const KOpts& 
           ybn[r] = 0.f;
         }
         const float rh = fast_rcp(h);
+#if LDE_M64_PF
+        while (j >= 1 && tq[0] > t) {
+          const double tj = tq[0];
+#pragma unroll
+          for (int u = 0; u + 1 < LDE_M64_PF; u++) tq[u] = tq[u + 1];
+          tq[LDE_M64_PF - 1] = ts[j - LDE_M64_PF > 0 ? j - LDE_M64_PF : 0];
+#else
         while (j >= 1 && ts[j] > t) {
           const double tj = ts[j];
+#endif
           float dj[DP];
+#if LDE_M64_PF
+#pragma unroll
+          for (int r = 0; r < DP; r++) {
+            dj[r] = dq[0][r];
+#pragma unroll
+            for (int u = 0; u + 1 < LDE_M64_PF; u++) dq[u][r] = dq[u + 1][r];
+            dq[LDE_M64_PF - 1][r] = r < Dp ? a.dz_out[(size_t)Dp * ((size_t)b + (size_t)B * (j - LDE_M64_PF > 0 ? j - LDE_M64_PF : 0)) + r] : 0.f;
+          }
+#else
 #pragma unroll
           for (int r = 0; r < DP; r++) dj[r] = r < Dp ? a.dz_out[(size_t)Dp * ((size_t)b + (size_t)B * j) + r] : 0.f;
+#endif
           if (tj >= tnew || (j == T - 1 && last)) {
 #pragma unroll
             for (int r = 0; r < DP; r++) yb[r] += dj[r];

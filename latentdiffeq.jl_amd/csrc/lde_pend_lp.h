@@ -104,12 +104,6 @@ constexpr int EVEN = 0xA0;   // quad_perm [0,0,2,2]: the pair's even lane
 constexpr int ODD = 0xF5;    // quad_perm [1,1,3,3]: the pair's odd lane
 }  // namespace lp
 
-#ifndef LDE_LP_NH
-#define LDE_LP_NH 4
-#endif
-#ifndef LDE_LP_SW
-#define LDE_LP_SW 2
-#endif
 #if LDE_PEND_PROF   // stamps by the stepping wave's first lane, whichever wave of the workgroup that is
 #define LPPROF(i) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) { g_pprof[2 * (i)] = wall_clock64(); g_pprof[2 * (i) + 1] = __builtin_readcyclecounter(); } } while (0)
 #define LPPROF_VAL(i, v) do { if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_pprof[i] = (v); } while (0)
@@ -124,15 +118,22 @@ constexpr int ODD = 0xF5;    // quad_perm [1,1,3,3]: the pair's odd lane
 // measured +0.4 % over wave 0 (23.72 | 21.64) and as the LAST wave −7 % (it starts last). Also measured, slower, not kept: the helper
 // walking up to its next record before that is published (−1.4 %), the helpers writing the step records instead of the stepper's
 // replay (−3 %: three more global stores on the last record's path).
-constexpr int LP_NH = LDE_LP_NH;   // dense-output waves
-constexpr int LP_SW = LDE_LP_SW;   // which wave of the workgroup steps
-template <bool REC>   // REC: the instantiation that writes step records (LDE_SENSE_DISCRETE, "step_trace")
-__global__ void __launch_bounds__(64 * (1 + LP_NH)) k_pend_forward_lp(const float2* __restrict__ z0, const float* __restrict__ theta,
+// Beyond one workgroup per CU (B > 256; the launch code's thresholds, abl/lp_midB.py): the same kernel serves B ≤ 1 024 — up to four
+// workgroups share a CU, their stepping waves still mostly a SIMD apart — with THREE dense-output waves from B > 512 on (forward µs per
+// launch with 4 | 3 helpers: B = 512 7.7 | 8.2, 768 9.6 | 9.5, 1 024 13.2 | 10.5, 2 048 23.0 | 18.2; k_pend_forward_ws: 15.4–16.1 throughout).
+template <int NH>
+struct LpShape {
+  static constexpr int LP_NH = NH;              // dense-output waves
+  static constexpr int LP_SW = NH >= 4 ? 2 : 0;   // which wave of the workgroup steps
+};
+template <bool REC, int NH = 4>   // REC: the instantiation that writes step records (LDE_SENSE_DISCRETE, "step_trace"); NH: dense-output waves
+__global__ void __launch_bounds__(64 * (1 + NH)) k_pend_forward_lp(const float2* __restrict__ z0, const float* __restrict__ theta,
                                                          const double* __restrict__ ts_g, KOpts o,
                                                          float2* __restrict__ z_out, int32_t* __restrict__ retcode,
                                                          int32_t* __restrict__ st_nfe, int32_t* __restrict__ st_nacc,
                                                          int32_t* __restrict__ st_nrej, int32_t* __restrict__ st_ret) {
   using namespace lp;
+  constexpr int LP_NH = LpShape<NH>::LP_NH, LP_SW = LpShape<NH>::LP_SW;
   __shared__ __attribute__((aligned(16))) float s_rec[SH_CAP * STEPF];
   __shared__ int s_cnt[64];
   __shared__ int s_fin;    // 0: stepping; 1: the round is over, another follows; 2: done

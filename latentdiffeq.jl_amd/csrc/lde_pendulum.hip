@@ -1741,8 +1741,13 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
   constexpr int ws_max_b = 16384;   // measured (abl/pend_B.py): 21.6 vs 31.2 µs at 16384, 36.8 vs 32.6 µs at 32768
   // the smallest batches: lanes = save times, TPW trajectories per wave (k_pend_forward_tl)
   const int tl_max_b = tn.tl_max_b;
-  // one trajectory per workgroup, a stepping wave + three dense-output waves (k_pend_forward_sh): while every workgroup has a CU to itself
-  const int sh_max_b = tn.sh_max_b;
+  // one trajectory per workgroup, a stepping wave + dense-output waves (k_pend_forward_lp for the frictionless adaptive Tsit5 solve,
+  // k_pend_forward_sh for every other): option "pend_sh_max_b" ≥ 0 is ONE threshold for both (what the tests force a mapping with); −1, the
+  // default, the measured ones (abl/lp_midB.py, forward µs per launch at B = 384 | 512 | 768 | 1 024 | 1 536): k_pend_forward_lp 7.8 | 7.9 |
+  // 9.5 | 10.5 | 15.5 against k_pend_forward_tl 11.2 | 11.0 | 11.0 | 11.5 | 13.8 and k_pend_forward_ws (the next mapping that writes step
+  // records) 15.7 | 15.4 | 15.6 | 15.9 | 16.1; k_pend_forward_sh 10.9 | 10.7 | 12.4 | 17.3 — level with tl, ahead of ws up to 768.
+  const bool lp_shape = kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5 && o.adaptive != 0 && tn.lp;
+  const int sh_max_b = tn.sh_max_b >= 0 ? tn.sh_max_b : lp_shape ? 1024 : o.rec.n ? 768 : 256;
   if (o.T > 1 && o.B <= sh_max_b) {
     const bool ad = o.adaptive != 0;
     const int g8 = ((o.B + 7) / 8) * 8;
@@ -1755,15 +1760,21 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
       hipLaunchKernelGGL((k_pend_forward_sh<K, S, A, false>), dim3(g8), dim3(64 * (1 + SH_NH)), 0, stream, (const float2*)z0, theta, ts_dev, o, \
                          (float2*)z_out, retcode, nfe, nacc, nrej, ret);                                                \
   } while (0)
-    g_pend_last[0] = (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5 && ad && tn.lp) ? "k_pend_forward_lp" : "k_pend_forward_sh";
-    if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5 && ad && tn.lp) {
-      // the metric's shape: the stepping wave's lanes in pairs, the step as a Nyström scheme (lde_pend_lp.h; option "pend_lp" = 0: k_pend_forward_sh)
-      if (o.rec.n)
-        hipLaunchKernelGGL((k_pend_forward_lp<true>), dim3(g8), dim3(64 * (1 + LP_NH)), 0, stream, (const float2*)z0, theta, ts_dev, o,
-                           (float2*)z_out, retcode, nfe, nacc, nrej, ret);
-      else
-        hipLaunchKernelGGL((k_pend_forward_lp<false>), dim3(g8), dim3(64 * (1 + LP_NH)), 0, stream, (const float2*)z0, theta, ts_dev, o,
-                           (float2*)z_out, retcode, nfe, nacc, nrej, ret);
+    g_pend_last[0] = lp_shape ? "k_pend_forward_lp" : "k_pend_forward_sh";
+    if (lp_shape) {
+      // the metric's shape: the stepping wave's lanes in pairs, the step as a Nyström scheme (lde_pend_lp.h; option "pend_lp" = 0: k_pend_forward_sh);
+      // four dense-output waves while at most two workgroups share a CU, three beyond
+#define LDE_LAUNCH_LP(R, NH)                                                                                                              \
+  hipLaunchKernelGGL((k_pend_forward_lp<R, NH>), dim3(g8), dim3(64 * (1 + NH)), 0, stream, (const float2*)z0, theta, ts_dev, o, (float2*)z_out, \
+                     retcode, nfe, nacc, nrej, ret)
+      if (o.B <= 512) {
+        if (o.rec.n) LDE_LAUNCH_LP(true, 4);
+        else LDE_LAUNCH_LP(false, 4);
+      } else {
+        if (o.rec.n) LDE_LAUNCH_LP(true, 3);
+        else LDE_LAUNCH_LP(false, 3);
+      }
+#undef LDE_LAUNCH_LP
     } else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5 && ad) LDE_LAUNCH_SH(0, LDE_SOLVER_TSIT5, true);
     else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5) LDE_LAUNCH_SH(0, LDE_SOLVER_TSIT5, false);
     else if (kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_RK4) LDE_LAUNCH_SH(0, LDE_SOLVER_RK4, false);

@@ -24,8 +24,8 @@ struct StepRec {
 // which a library behind a `ccall` host must not read). Defaults = the measured choices.
 struct PendTune {
   int ws = 1;                 // "pend_ws": k_pend_forward_ws for B ≤ 16384
-  int tl_max_b = 1024;        // "pend_tl_max_b": k_pend_forward_tl up to this batch
-  int sh_max_b = 256;         // "pend_sh_max_b": k_pend_forward_sh / k_pend_forward_lp (a trajectory per workgroup) up to this batch
+  int tl_max_b = 2048;        // "pend_tl_max_b": k_pend_forward_tl up to this batch (solves that write no step record; 13.5 against k_pend_forward_ws's 15.9 µs at 2 048, 20.9 against 15.8 at 4 096)
+  int sh_max_b = -1;          // "pend_sh_max_b": k_pend_forward_sh / k_pend_forward_lp (a trajectory per workgroup) up to this batch; −1: the measured thresholds (lp 1 024; sh 768 with a step record, 256 without)
   int lp = 1;                 // "pend_lp": frictionless Tsit5 adaptive solves of that shape run k_pend_forward_lp (lane pairs, Nyström form); 0: k_pend_forward_sh
   int lb_ring = 16;           // "pend_lb": rows of the large-batch row ring (8 / 16 / 32; 0: off)
   int lb_min_b = 1 << 17;     // "pend_lb_min_b": the large-batch form from this batch on

@@ -636,14 +636,38 @@ __global__ void __launch_bounds__(256, 1) k_mlpb(MlpDims dm, BDims bd, KOpts o, 
     if (status == 0) {
       j = T - 1;
       double tnext = tend;
+      // The next step's record is requested while this step's evaluations run (a load at the head of a step is covered by nothing): Tsit5
+      // −1.6 % on the reference NODE's sweep; the RK4 instantiation measured +1 % with it (abl/ab_mlp.sh) and loads at the head.
+      constexpr bool PFR = SOLVER == LDE_SOLVER_TSIT5;
+      double t_pf = 0.0, dt_pf = 0.0;
+      float y_pf = 0.f;
+      if (PFR) {
+        t_pf = R.t[(size_t)(ns - 1) * R.nseq + seq];
+        dt_pf = R.dt[(size_t)(ns - 1) * R.nseq + seq];
+        if (is_z) y_pf = R.y[((size_t)(ns - 1) * B + b) * Dp + row];
+      }
 #pragma unroll 1
       for (int sidx = ns - 1; sidx >= 0; sidx--) {
-        const double ts_n = R.t[(size_t)sidx * R.nseq + seq], dts = R.dt[(size_t)sidx * R.nseq + seq];
+        double ts_n, dts;
+        float y_rec = 0.f;
+        if (PFR) {
+          ts_n = t_pf;
+          dts = dt_pf;
+          y_rec = y_pf;
+          const size_t sp = sidx > 0 ? sidx - 1 : 0;
+          t_pf = R.t[sp * R.nseq + seq];
+          dt_pf = R.dt[sp * R.nseq + seq];
+          if (is_z) y_pf = R.y[(sp * B + b) * Dp + row];
+        } else {
+          ts_n = R.t[(size_t)sidx * R.nseq + seq];
+          dts = R.dt[(size_t)sidx * R.nseq + seq];
+          if (is_z) y_rec = R.y[((size_t)sidx * B + b) * Dp + row];
+        }
         const float hh = (float)dts;
         const bool lastst = sidx == ns - 1;
         const double tnw = tnext;
         tnext = ts_n;
-        if (is_z) y = R.y[((size_t)sidx * B + b) * Dp + row];
+        if (is_z) y = y_rec;
         else {
           yn = 0.f;
 #pragma unroll

@@ -22,6 +22,9 @@ struct CDims {
   int o_wb, o_w3b, o_w13, o_b1, o_b3, o_n1, total;   // float offsets in the packed array
 };
 
+#ifndef LDE_MLPC_PF
+#define LDE_MLPC_PF 1   // c4 discrete: 0.4272 → 0.4230 ms per step (abl/ab_mlp.sh)
+#endif
 namespace mlpc {
 constexpr int A0 = 256 - 4 * 26;     // the compiler's AGPRs: a[0 : A0); the 26 tiles of a wave sit behind them (hidden: lde_mlpb.h)
 
@@ -606,18 +609,45 @@ __global__ void __launch_bounds__(256, 1) k_mlpc(MlpDims dm, CDims cd, KOpts o, 
         }
         nfe += S + 1;
       }
+#if LDE_MLPC_PF   // the record of the step after next is requested while this step's evaluations run (a load at the head of a step is covered by nothing)
+      double t_pf = R.t[(size_t)(ns - 1) * R.nseq + seq], dt_pf = R.dt[(size_t)(ns - 1) * R.nseq + seq];
+      double dtz_pf = ns > 1 ? R.dt[(size_t)(ns - 2) * R.nseq + seq] : 0.0;
+      float y_pf[2];
+#pragma unroll
+      for (int tt = 0; tt < 2; tt++) y_pf[tt] = (is_z && ns > 1 && (tt == 0 || two)) ? R.y[((size_t)(ns - 2) * B + (bt0 + tt)) * Dp + row] : 0.f;
+#endif
 #pragma unroll 1
       for (int sidx = ns - 1; sidx >= 0; sidx--) {
+#if LDE_MLPC_PF
+        const double ts_n = t_pf, dts = dt_pf;
+        const float hh = (float)dts;                                                                   // the step being reversed (λ lanes)
+        const float hz = sidx > 0 ? (float)dtz_pf : 0.f;                                               // the step being rebuilt (z lanes)
+        const float y_rec[2] = {y_pf[0], y_pf[1]};
+        {
+          const size_t sp = sidx > 0 ? sidx - 1 : 0, sq = sidx > 1 ? sidx - 2 : 0;
+          t_pf = R.t[sp * R.nseq + seq];
+          dt_pf = dtz_pf;
+          dtz_pf = R.dt[sq * R.nseq + seq];
+#pragma unroll
+          for (int tt = 0; tt < 2; tt++)
+            if (is_z && (tt == 0 || two)) y_pf[tt] = R.y[(sq * B + (bt0 + tt)) * Dp + row];
+        }
+#else
         const double ts_n = R.t[(size_t)sidx * R.nseq + seq], dts = R.dt[(size_t)sidx * R.nseq + seq];
         const float hh = (float)dts;                                                                   // the step being reversed (λ lanes)
         const float hz = sidx > 0 ? (float)R.dt[(size_t)(sidx - 1) * R.nseq + seq] : 0.f;             // the step being rebuilt (z lanes)
+#endif
         const bool lastst = sidx == ns - 1;
         const double tnw = tnext;
         tnext = ts_n;
 #pragma unroll
         for (int tt = 0; tt < 2; tt++) {
           if (is_z) {
+#if LDE_MLPC_PF
+            if (sidx > 0) y[tt] = y_rec[tt];
+#else
             if (sidx > 0) y[tt] = (tt == 0 || two) ? R.y[((size_t)(sidx - 1) * B + (bt0 + tt)) * Dp + row] : 0.f;   // (the first step rebuilds nothing: a dummy forward half)
+#endif
           } else {
             yn[tt] = 0.f;
 #pragma unroll

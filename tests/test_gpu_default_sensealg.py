@@ -153,3 +153,43 @@ def test_step_record_status_entry_point():
     assert lib.lde_step_record_status(nat.h, C.c_void_p(buf.data_ptr()), B, T, C.byref(nmax), C.byref(cap), s) == 0
     assert cap.value == 4 and nmax.value == int(rec["n"].max()) > 4   # counts run on past the capacity
     lib.lde_set_step_record(nat.h, None, 0)
+
+
+@pytest.mark.parametrize("B,kind,sense,kernel", [
+    (384, "pendulum", "discrete", "k_pend_forward_lp"),       # four dense-output waves (B ≤ 512)
+    (640, "pendulum", "discrete", "k_pend_forward_lp"),       # three (B > 512): the other instantiation, recording
+    (1000, "pendulum", "continuous", "k_pend_forward_lp"),    # … and not recording
+    (1100, "pendulum", "discrete", "k_pend_forward_ws"),      # beyond the threshold: the next mapping that writes step records
+    (1500, "pendulum", "continuous", "k_pend_forward_tl"),    # … resp. lanes = save times (B ≤ 2 048 without a record)
+    (640, "friction", "discrete", "k_pend_forward_sh"),       # every other solve of a trajectory per workgroup: B ≤ 768 when it records
+    (640, "friction", "continuous", "k_pend_forward_tl"),     # … B ≤ 256 when it does not
+])
+def test_default_mapping_of_the_batches_between_the_metric_and_the_large_ones(o32, B, kind, sense, kernel):
+    """The forward mapping the library picks BY ITSELF (option "pend_sh_max_b" = −1: the measured thresholds, abl/lp_midB.py) at batches between
+    the metric's 256 and the large ones, named by lde_last_kernel — and held to the oracle like every other mapping: ẑ on the kernel's own recorded
+    steps to 2e-5, the gradient of those steps to 1e-4 (discrete); free-running against the oracle's own solve to 3e-4 (continuous)."""
+    from latentdiffeq_amd import _lib as L
+    from tests.gpu_util import Native, make_desc, copy_desc_to_oracle
+    rhs = L.RHS_PENDULUM if kind == "pendulum" else L.RHS_PENDULUM_FRICTION
+    d = make_desc(rhs_kind=rhs, sensealg=L.SENSE_DISCRETE if sense == "discrete" else L.SENSE_PARALLEL_CHECKPOINTED)
+    nat = Native(d)
+    od = copy_desc_to_oracle(d)
+    T = 50
+    z0, Lp = O.pendulum_inputs(B, seed=11)
+    ts = O.time_grid(T)
+    dz = O.cotangent(T, B, 2)
+    z, ret, st = nat.forward(z0, Lp, ts)
+    assert (ret == 0).all()
+    assert nat.lib.lde_last_kernel(nat.h, 0).decode() == kernel
+    if sense == "discrete":
+        rec = nat.step_record(0, B)
+        assert int(rec["n"].sum()) == st["naccept"]
+        zr, _, _, _ = o32.forward_steps(od, z0, Lp, ts, rec=rec, nthreads=NT)
+        assert np.abs(z - zr).max() <= 2e-5
+        g0, gL, _, sb = nat.adjoint(z, Lp, ts, dz)
+        assert sb["nfailed"] == 0
+        r0, rL, _, _ = o32.adjoint_discrete(od, z, Lp, ts, dz, rec, nthreads=NT)
+        assert _rel(g0, r0) <= 1e-4 and _rel(gL, rL) <= 1e-4
+    else:
+        zo, _, _ = o32.forward(od, z0, Lp, ts, nthreads=NT)
+        assert np.abs(z - zo).max() <= 3e-4

@@ -904,13 +904,16 @@ def main():
         dW = torch.zeros((nW,), device=dev) if nW else None
         tsp = ts.ctypes.data_as(C.POINTER(C.c_double))
 
+        # the device pointers as ctypes objects, made once (a `ccall` host pays nothing per argument; ctypes re-wraps every int it is handed)
+        pz0, pth, pzo, pret, pdz, pdz0, pdth, pdW = p(z0d), p(thd), p(zout), p(ret), p(dzd), p(dz0), p(dth), p(dW)
+
         def fwd(s=sp):
-            L.check(lib.lde_forward(h, p(z0d), p(thd), tsp, T, B, p(zout), p(ret), s), h, "lde_forward")
+            L.check(lib.lde_forward(h, pz0, pth, tsp, T, B, pzo, pret, s), h, "lde_forward")
 
         def bwd(s=sp):
             if dW is not None:
                 dW.zero_()
-            L.check(lib.lde_adjoint(h, p(zout), p(thd), tsp, T, B, p(dzd), p(dz0), p(dth), p(dW), s), h, "lde_adjoint")
+            L.check(lib.lde_adjoint(h, pzo, pth, tsp, T, B, pdz, pdz0, pdth, pdW, s), h, "lde_adjoint")
             if dW is not None and world > 1:  # the one collective of the path: shared RHS-MLP gradient
                 if comm is not None:
                     comm.allreduce_(dW)

@@ -33,3 +33,4 @@ for d in f32 mixed; do
   python bench.py --workload goku_decoder --dtype $d > gpurun_out/bench_goku_decoder_$d.json 2> gpurun_out/bench_goku_decoder_$d.err
 done
 ls gpurun_out/bench_*.json | wc -l
+python abl/metric_floor.py > gpurun_out/${R}_metric_floor.txt 2>&1   # (abl/liblde_pprof.so: built beforehand by abl/variant_lib.sh pprof "-DLDE_PEND_PROF=1")

@@ -1,5 +1,5 @@
-// lde_pend_lp.h — k_pend_forward_lp: the metric's forward solve (frictionless pendulum, Tsit5, adaptive, B ≤ one workgroup per CU) with the
-// stepping wave's 64 redundant lanes put to work (round 6; included by lde_pendulum.hip behind k_pend_forward_sh, whose protocol it keeps).
+// lde_pend_lp.h — k_pend_forward_lp: the metric's forward solve (frictionless pendulum, Tsit5, adaptive; a trajectory per workgroup, B ≤ 1 024:
+// the launch code's thresholds) with the stepping wave's 64 redundant lanes put to work (round 6; included by lde_pendulum.hip behind k_pend_forward_sh, whose protocol it keeps).
 //
 // k_pend_forward_sh's stepping wave carries the SAME solve in all 64 lanes and its duration is one dependent-instruction chain: six stage
 // evaluations one behind the other, each (stage sum → angle in turns → v_sin_f32 → ·(−g/L) → into the later stages' sums), ≈ 757 cycles per

@@ -115,6 +115,28 @@ static int64_t fixed_step_count(const lde_problem_desc& d, const double* ts, int
   return steps > d.maxiters ? d.maxiters : steps;
 }
 
+// Which forward mapping of the analytic right-hand sides serves a solve (csrc/lde_pendulum.hip's launch code switches on this; DESIGN.md §4.1;
+// the thresholds are measurements: abl/lp_midB.py, abl/pend_B.py, abl/pend_LB.py). `ts_lds_max`: the longest save grid the kernels stage in LDS.
+enum PendFwdMap {
+  PEND_FWD_LP4 = 0,   // k_pend_forward_lp<REC, 4>: a trajectory per workgroup, lane pairs / Nyström form, four dense-output waves
+  PEND_FWD_LP3,       // … three (more than two workgroups per CU)
+  PEND_FWD_SH,        // k_pend_forward_sh: a trajectory per workgroup, every other solve (friction, RK4, fixed steps; option "pend_lp" = 0)
+  PEND_FWD_TL,        // k_pend_forward_tl<…, 1>: lanes = save times (writes no step record)
+  PEND_FWD_WS,        // k_pend_forward_ws: a stepping wave + dense-output waves per 64 trajectories
+  PEND_FWD_RING,      // k_pend_forward_tl<…, 64, RING>: a lane per trajectory, ẑ rows through an LDS ring (large batches)
+  PEND_FWD_LANE       // k_pend_forward: a lane per trajectory, direct stores
+};
+static PendFwdMap pend_forward_mapping(int kind, int solver, bool adaptive, bool recording, int B, int T, const lde::PendTune& tn, int ts_lds_max) {
+  const bool lp_shape = kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5 && adaptive && tn.lp;
+  // option "pend_sh_max_b" ≥ 0: ONE threshold for both mappings with a trajectory per workgroup (what the tests force a mapping with); −1: the measured ones
+  const int sh_max_b = tn.sh_max_b >= 0 ? tn.sh_max_b : lp_shape ? 1024 : recording ? 768 : 256;
+  if (T > 1 && B <= sh_max_b) return lp_shape ? (B <= 512 ? PEND_FWD_LP4 : PEND_FWD_LP3) : PEND_FWD_SH;
+  if (!recording && T > 1 && B <= tn.tl_max_b) return PEND_FWD_TL;
+  if (tn.ws != 0 && T <= ts_lds_max && T > 2 && B <= 16384) return PEND_FWD_WS;   // (21.6 against 31.2 µs at 16 384, 36.8 against 32.6 at 32 768)
+  if (tn.lb_ring > 0 && T > 1 && T <= 2048 && B >= tn.lb_min_b) return PEND_FWD_RING;
+  return PEND_FWD_LANE;
+}
+
 static KOpts make_opts(const lde_problem_desc& d, const double* ts, int T, int B) {
   KOpts o;
   o.abstol = (float)d.abstol;

@@ -14,6 +14,7 @@
 #include <cstdlib>
 
 #include "lde_device.h"
+#include "lde_host.h"
 
 namespace lde {
 
@@ -1736,19 +1737,11 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
                         hipStream_t stream, const PendTune& tn) {
   const int block = pick_block(o.B), grid = (o.B + block - 1) / block;
   const size_t shm = o.T <= TS_LDS_MAX ? (size_t)o.T * sizeof(double) : 0;
-  // small batches: stepping and dense output on different waves of a 64-trajectory workgroup (k_pend_forward_ws)
-  const bool ws_on = tn.ws != 0;
-  constexpr int ws_max_b = 16384;   // measured (abl/pend_B.py): 21.6 vs 31.2 µs at 16384, 36.8 vs 32.6 µs at 32768
-  // the smallest batches: lanes = save times, TPW trajectories per wave (k_pend_forward_tl)
-  const int tl_max_b = tn.tl_max_b;
-  // one trajectory per workgroup, a stepping wave + dense-output waves (k_pend_forward_lp for the frictionless adaptive Tsit5 solve,
-  // k_pend_forward_sh for every other): option "pend_sh_max_b" ≥ 0 is ONE threshold for both (what the tests force a mapping with); −1, the
-  // default, the measured ones (abl/lp_midB.py, forward µs per launch at B = 384 | 512 | 768 | 1 024 | 1 536): k_pend_forward_lp 7.8 | 7.9 |
-  // 9.5 | 10.5 | 15.5 against k_pend_forward_tl 11.2 | 11.0 | 11.0 | 11.5 | 13.8 and k_pend_forward_ws (the next mapping that writes step
-  // records) 15.7 | 15.4 | 15.6 | 15.9 | 16.1; k_pend_forward_sh 10.9 | 10.7 | 12.4 | 17.3 — level with tl, ahead of ws up to 768.
-  const bool lp_shape = kind == LDE_RHS_PENDULUM && solver == LDE_SOLVER_TSIT5 && o.adaptive != 0 && tn.lp;
-  const int sh_max_b = tn.sh_max_b >= 0 ? tn.sh_max_b : lp_shape ? 1024 : o.rec.n ? 768 : 256;
-  if (o.T > 1 && o.B <= sh_max_b) {
+  // which mapping serves this solve: csrc/lde_host.h (pend_forward_mapping — pure host logic, tested on the CPU: tests/test_sanitizers.py)
+  const bool recording = o.rec.n != nullptr;   // k_pend_forward_lp / _sh, k_pend_forward_ws, k_pend_forward and the 16-row ring form write step records
+  const lde_host::PendFwdMap map = lde_host::pend_forward_mapping(kind, solver, o.adaptive != 0, recording, o.B, o.T, tn, TS_LDS_MAX);
+  const bool lp_shape = map == lde_host::PEND_FWD_LP4 || map == lde_host::PEND_FWD_LP3;
+  if (lp_shape || map == lde_host::PEND_FWD_SH) {
     const bool ad = o.adaptive != 0;
     const int g8 = ((o.B + 7) / 8) * 8;
 #define LDE_LAUNCH_SH(K, S, A)                                                                                          \
@@ -1767,7 +1760,7 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
 #define LDE_LAUNCH_LP(R, NH)                                                                                                              \
   hipLaunchKernelGGL((k_pend_forward_lp<R, NH>), dim3(g8), dim3(64 * (1 + NH)), 0, stream, (const float2*)z0, theta, ts_dev, o, (float2*)z_out, \
                      retcode, nfe, nacc, nrej, ret)
-      if (o.B <= 512) {
+      if (map == lde_host::PEND_FWD_LP4) {
         if (o.rec.n) LDE_LAUNCH_LP(true, 4);
         else LDE_LAUNCH_LP(false, 4);
       } else {
@@ -1785,8 +1778,7 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
 #undef LDE_LAUNCH_SH
     return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
   }
-  const bool recording = o.rec.n != nullptr;   // k_pend_forward_sh, k_pend_forward_ws and k_pend_forward are the mappings that write step records
-  if (!recording && o.T > 1 && o.B <= tl_max_b) {
+  if (map == lde_host::PEND_FWD_TL) {
     g_pend_last[0] = "k_pend_forward_tl";
     const bool ad = o.adaptive != 0;
     const bool few = o.T - 1 <= 64;   // a lane serves exactly one save time: the variant without a load in the stepping loop
@@ -1809,7 +1801,7 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
 #undef LDE_LAUNCH_TL
     return hipGetLastError() == hipSuccess ? LDE_OK : LDE_ERR_HIP;
   }
-  if (ws_on && shm && o.T > 2 && o.B <= ws_max_b) {   // (writes step records too)
+  if (map == lde_host::PEND_FWD_WS) {   // (writes step records too)
     g_pend_last[0] = "k_pend_forward_ws";
     const size_t lds = (size_t)((o.T + 1) & ~1) * sizeof(double) + (size_t)WS_CAP * 64 * WS_RW * sizeof(float);
     const int g64 = (o.B + 63) / 64;
@@ -1850,8 +1842,7 @@ int launch_pend_forward(int kind, int solver, const float* z0, const float* thet
   // ≈ 8.2 k instructions per wave (5.1 k VALU), of which the wave-sequential dense-output loop is ≈ 75 × 45 and the row flush 49 × 28.
   // options "pend_lb" = rows of the ring (8 / 16 / 32; 0: off), "pend_lb_hold" = the hold margin.
   const int lb_ring = tn.lb_ring;   // rows of the ring; 0: off
-  const int lb_min_b = tn.lb_min_b;
-  if (lb_ring > 0 && o.T > 1 && o.T <= 2048 && o.B >= lb_min_b) {   // (the save grid in LDS beside the ring: T ≤ 2048; a recording forward: the 16-row ring)
+  if (map == lde_host::PEND_FWD_RING) {   // (the save grid in LDS beside the ring: T ≤ 2048; a recording forward: the 16-row ring)
     g_pend_last[0] = "k_pend_forward_tl";
     // a lane sits out while j ≥ jc + RING − hold; the slowest lane has j = jc, so hold ≤ RING − 1 keeps it (and with it jc) moving —
     // hold ≥ RING would hold EVERY lane on every iteration and the solve loop would never end. Default: half the ring.

@@ -131,6 +131,48 @@ int main() {
     const double a[3] = {0, 1, 1}, b[3] = {0, nan, 2}, c[2] = {0, inf}, e[1] = {5};
     assert(!grid_ok(a, 3) && !grid_ok(b, 3) && !grid_ok(c, 2) && grid_ok(e, 1));
   }
-  std::printf("host logic under ASan + UBSan: %d accepted, %d refused hostile descriptions\n", n_ok, n_bad);
+  // 4. which forward mapping serves a solve of the analytic right-hand sides (csrc/lde_pendulum.hip's launch code switches on this)
+  {
+    const lde::PendTune def;   // the measured thresholds
+    const int P = LDE_RHS_PENDULUM, F = LDE_RHS_PENDULUM_FRICTION, TS = LDE_SOLVER_TSIT5, RK = LDE_SOLVER_RK4, LMAX = 6000;
+    auto m = [&](int kind, int solver, bool ad, bool rec, int B, int T, const lde::PendTune& tn) { return pend_forward_mapping(kind, solver, ad, rec, B, T, tn, LMAX); };
+    // the metric's shape (frictionless, Tsit5, adaptive): lane pairs up to 1 024, four dense-output waves up to 512 — recording or not
+    for (int rec = 0; rec < 2; rec++) {
+      assert(m(P, TS, true, rec, 1, 50, def) == PEND_FWD_LP4 && m(P, TS, true, rec, 256, 50, def) == PEND_FWD_LP4 && m(P, TS, true, rec, 512, 50, def) == PEND_FWD_LP4);
+      assert(m(P, TS, true, rec, 513, 50, def) == PEND_FWD_LP3 && m(P, TS, true, rec, 1024, 50, def) == PEND_FWD_LP3);
+    }
+    assert(m(P, TS, true, false, 1025, 50, def) == PEND_FWD_TL && m(P, TS, true, false, 2048, 50, def) == PEND_FWD_TL && m(P, TS, true, false, 2049, 50, def) == PEND_FWD_WS);
+    assert(m(P, TS, true, true, 1025, 50, def) == PEND_FWD_WS && m(P, TS, true, true, 16384, 50, def) == PEND_FWD_WS);
+    // every other solve of a trajectory per workgroup: B ≤ 768 when it writes step records, ≤ 256 when it does not
+    assert(m(F, TS, true, true, 768, 50, def) == PEND_FWD_SH && m(F, TS, true, true, 769, 50, def) == PEND_FWD_WS);
+    assert(m(F, TS, true, false, 256, 50, def) == PEND_FWD_SH && m(F, TS, true, false, 257, 50, def) == PEND_FWD_TL);
+    assert(m(P, RK, false, false, 256, 50, def) == PEND_FWD_SH && m(P, TS, false, true, 700, 50, def) == PEND_FWD_SH);
+    // beyond: a lane per trajectory, through the row ring from 2^17 on (save grids that fit beside it)
+    assert(m(P, TS, true, false, 16385, 50, def) == PEND_FWD_LANE && m(P, TS, true, true, (1 << 17) - 1, 50, def) == PEND_FWD_LANE);
+    assert(m(P, TS, true, false, 1 << 17, 50, def) == PEND_FWD_RING && m(P, TS, true, true, 1 << 20, 50, def) == PEND_FWD_RING && m(P, TS, true, false, 1 << 20, 2049, def) == PEND_FWD_LANE);
+    // degenerate grids: T = 1 solves nothing (a lane per trajectory writes ẑ₀); T = 2 has no interior for k_pend_forward_ws
+    assert(m(P, TS, true, false, 256, 1, def) == PEND_FWD_LANE && m(P, TS, true, true, 5000, 2, def) == PEND_FWD_LANE && m(P, TS, true, true, 5000, 6001, def) == PEND_FWD_LANE);
+    // the options the tests force a mapping with: "pend_sh_max_b" ≥ 0 is ONE threshold for lp and sh; "pend_lp" = 0 sends the metric's shape to sh
+    lde::PendTune t = def;
+    t.sh_max_b = 0;
+    assert(m(P, TS, true, false, 1, 50, t) == PEND_FWD_TL && m(P, TS, true, true, 1, 50, t) == PEND_FWD_WS);
+    t.sh_max_b = 1 << 20;
+    assert(m(P, TS, true, true, 5000, 50, t) == PEND_FWD_LP3 && m(F, TS, true, false, 5000, 50, t) == PEND_FWD_SH);
+    t.lp = 0;
+    assert(m(P, TS, true, true, 100, 50, t) == PEND_FWD_SH);
+    t = def; t.ws = 0; t.tl_max_b = 0; t.sh_max_b = 0; t.lb_min_b = 0;
+    assert(m(P, TS, true, false, 1000, 50, t) == PEND_FWD_RING);
+    t.lb_ring = 0;
+    assert(m(P, TS, true, false, 1000, 50, t) == PEND_FWD_LANE);
+    // … and for ANY arguments one of the seven
+    for (int it = 0; it < 20000; it++) {
+      lde::PendTune h;
+      h.ws = (int)(rnd() % 3); h.tl_max_b = (int)(rnd() % 5000); h.sh_max_b = (int)(rnd() % 3000) - 1; h.lp = (int)(rnd() & 1);
+      h.lb_ring = (int)(rnd() % 40); h.lb_min_b = (int)(rnd() % 300000);
+      const PendFwdMap r = m((int)(rnd() % 2), (int)(rnd() % 2), rnd() & 1, rnd() & 1, 1 + (int)(rnd() % (1 << 21)), 1 + (int)(rnd() % 7000), h);
+      assert(r >= PEND_FWD_LP4 && r <= PEND_FWD_LANE);
+    }
+  }
+  std::printf("host logic under ASan + UBSan: %d accepted, %d refused hostile descriptions; forward mappings as measured\n", n_ok, n_bad);
   return 0;
 }

@@ -35,12 +35,14 @@ def test_c_abi_host_logic_under_asan_ubsan(tmp_path):
                     "-Wall", "-Wextra", "-Wno-unused-function", "-o", exe, os.path.join(ROOT, "tests", "host_logic_driver.cpp")], check=True)
     r = subprocess.run([exe], capture_output=True, text=True, env=ENV, timeout=600)
     _clean(r)
-    assert "accepted" in r.stdout
+    assert "accepted" in r.stdout and "forward mappings as measured" in r.stdout
 
 
 def test_lde_api_is_built_from_the_checked_logic():
     """lde_api.hip must USE lde_host.h's functions (not keep private copies that the sanitizers never see)."""
     src = open(os.path.join(ROOT, "latentdiffeq.jl_amd", "csrc", "lde_api.hip")).read()
     assert '#include "lde_host.h"' in src and "using namespace lde_host" in src
+    pend = open(os.path.join(ROOT, "latentdiffeq.jl_amd", "csrc", "lde_pendulum.hip")).read()
+    assert "lde_host::pend_forward_mapping(" in pend and "tn.sh_max_b" not in pend and "tn.tl_max_b" not in pend   # the launch code follows the checked function, no thresholds of its own
     for fn in ("static int validate(", "static size_t rec_bytes(", "static lde::StepRec rec_view(", "static lde::KOpts make_opts("):
         assert fn not in src, fn

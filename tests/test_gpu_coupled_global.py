@@ -42,6 +42,18 @@ LAYERS = (32, 128, 128, 32)
 KW = dict(rhs_kind=O.RHS_MLP, state_dim=32, param_dim=0, layers=LAYERS, activation=O.ACT_TANH)
 
 
+def _warm_stream_pool(stream):
+    """torch's caching allocator keeps a pool PER STREAM: on a stream made a moment ago every tensor the helpers create (inputs, outputs,
+    gradients) is a fresh hipMalloc — and a hipMalloc may wait for the device, i.e. for the other in-process rank's kernel, which waits for
+    this thread's launch: both sit out the mailbox time-out and poison their sums (seen once in ≈ six full-suite runs). So the stream's small
+    pool and a few larger blocks are made before the start line and handed back to the pool."""
+    import torch
+    with torch.cuda.stream(stream):
+        blocks = [torch.empty(n, dtype=torch.float32, device="cuda") for n in (64, 4096, 65536, 262144, 1 << 20, 1 << 20)]
+        del blocks
+    torch.cuda.synchronize()
+
+
 def _rank_stream(r):
     """A stream for in-process "rank" r whose kernels run BESIDE the other rank's: the two shards' kernels wait for each other's sums, so
     they must be in flight at once — and two HIP streams may share a hardware queue (then the second kernel sits behind the first, which
@@ -137,9 +149,11 @@ def test_two_shards_under_the_global_norm_equal_the_unsharded_solve():
             # null-stream memset inside lde_adjoint would wait for that kernel, which waits for this thread: both then sit out the
             # mailbox time-out and poison their sums (seen once in a full-suite run). So every workspace is reserved before the start line.
             assert nat.lib.lde_reserve(nat.h, hi - lo, len(ts)) == 0
+            rs = _rank_stream(r)
+            _warm_stream_pool(rs)
             torch.cuda.synchronize()
             bar.wait(timeout=60)
-            with torch.cuda.stream(_rank_stream(r)):      # a stream of its own: both solves must be in flight at once
+            with torch.cuda.stream(rs):      # a stream of its own: both solves must be in flight at once
                 z, ret, st = nat.forward(z0[lo:hi], None, ts)
                 g0, _, gW, sb = nat.adjoint(z, None, ts, dz[:, lo:hi])
             out[r] = (z, ret, st, g0, gW, sb)
@@ -225,6 +239,9 @@ def test_two_shards_exchange_their_sums_device_to_device(sense):
         L.check(lib.lde_set_global_sum_peers(nat.h, r, 2, ptrs, B), nat.h, "lde_set_global_sum_peers")
         assert lib.lde_reserve(nat.h, hi - lo, len(ts)) == 0
         nats.append(nat)
+    streams = [_rank_stream(r) for r in range(2)]
+    for st_ in streams:
+        _warm_stream_pool(st_)
     torch.cuda.synchronize()
     bar = threading.Barrier(2)
     out, err = [None, None], []
@@ -233,7 +250,7 @@ def test_two_shards_exchange_their_sums_device_to_device(sense):
         try:
             lo, hi = bounds[r]
             bar.wait(timeout=60)
-            with torch.cuda.stream(_rank_stream(r)):      # a stream of its own: both solves must be in flight at once
+            with torch.cuda.stream(streams[r]):      # a stream of its own: both solves must be in flight at once
                 z, ret, st = nats[r].forward(z0[lo:hi], None, ts)
                 g0, _, gW, sb = nats[r].adjoint(z, None, ts, dz[:, lo:hi])
             out[r] = (z, ret, st, g0, gW, sb)
@@ -260,7 +277,7 @@ def test_two_shards_exchange_their_sums_device_to_device(sense):
     def again(r):
         lo, hi = bounds[r]
         bar2.wait(timeout=60)
-        with torch.cuda.stream(_rank_stream(r)):
+        with torch.cuda.stream(streams[r]):
             outs2[r] = nats[r].forward(z0[lo:hi], None, ts)
     bar2 = threading.Barrier(2)
     th = [threading.Thread(target=again, args=(r,)) for r in range(2)]

@@ -120,7 +120,8 @@ def test_goku_discrete_matches_oracle_on_the_same_steps(o32, o64, kind, solver, 
     (200, {}, 1e-6),                                       # k_pend_forward_lp (round 6): a trajectory per workgroup, the stepping wave — lane pairs — writes the round's records
     (200, {"pend_lp": 0}, 1e-6),                           # k_pend_forward_sh: the same mapping with every lane carrying the whole solve
     (200, {"pend_sh_max_b": 0}, 1e-6),                     # k_pend_forward_ws: 64 trajectories per workgroup, each stepper lane its own records
-    (1000, {}, 1e-6),                                      # (the default at this batch)
+    (1000, {}, 1e-6),                                      # (the default at this batch: k_pend_forward_lp with three dense-output waves, B > 512)
+    (600, {"record_capacity": 512}, 3e-9),                 # … and several rounds of ITS ring
     (1000, {"pend_ws": 0}, 1e-6),                          # k_pend_forward: a lane per trajectory, records at accept
     (200, {"record_capacity": 64}, 3e-9),                  # ≈ 100 steps: records from several rounds of the ring (48 per round), then overflow → see below
     (200, {"pend_lp": 0, "record_capacity": 64}, 3e-9),    # the same through k_pend_forward_sh (the default at this shape is k_pend_forward_lp)
